@@ -1,0 +1,105 @@
+/*
+ * pinn_hip.h — C ABI of the MI355X-native PINN residual/loss engine (libpinn_hip.so).
+ *
+ * Drop-in boundary for NeuralPDE.jl's PhysicsInformedNN/discretize hot path.  The Julia glue
+ *  `ccall`s these from the per-term loss closures that
+ * `merge_strategy_with_loss_function` returns (reference: src/training_strategies.jl:131-160,
+ * 247-269, 336-363) and from the `grad` of the OptimizationFunction built in
+ * src/discretize.jl:776-780.  Plain pointers and sizes only; all matrices use the reference's
+ * own memory layout (Julia column-major):
+ *     points of a term      : d x N Float32, point-major (each point's d coordinates contiguous)
+ *                             == the `cord` matrix of the generated loss function, src/discretize.jl:126-131
+ *     theta / gradient      : flat vector in ComponentArrays order
+ *                             [net(depvar 1): W1 (out x in, col-major) | b1 | W2 | b2 ... | net(depvar 2) ... | p]
+ *                             == pinnrep.flat_init_params, src/discretize.jl:451-465
+ * Every function returns 0 on success, non-zero on error; pinn_last_error() gives the message
+ * (thread-local).  The engine computes in fp32 on the device with exact (Taylor-mode) derivatives;
+ * it reproduces the reference's Float64 finite-difference semantics to ~1e-7 relative
+ * (SURVEY.md §8c).  There is NO CPU fallback: without a gfx950 device pinn_create fails.
+ *
+ * One handle = one caller thread at a time (the reference's loss closures are not re-entrant
+ * either: `iteration[] += 1`, src/discretize.jl:574-576).
+ */
+#ifndef PINN_HIP_H
+#define PINN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pinn_engine* pinn_handle;
+
+/* ABI / build identification ("hip" for the product library). */
+const char* pinn_backend(void);
+int pinn_abi_version(void);
+const char* pinn_last_error(void);
+
+/*
+ * Build an engine from a problem descriptor (text, format "pinnir 1").
+ * The descriptor carries what symbolic_discretize extracts from the PDESystem:
+ * chains (sizes, activation, offset in theta)   <- pinnrep.phi / flat_init_params   (src/discretize.jl:432-465)
+ * per term: dimension, jet slots, residual tape <- symbolic_pde/bc_loss_functions   (src/discretize.jl:505-525)
+ * Replaces: build_loss_function + RuntimeGeneratedFunction (src/discretize.jl:163-175).
+ * Unsupported expressions / network shapes fail HERE (never a silent fallback).
+ */
+int pinn_create(const char* descriptor, pinn_handle* out);
+int pinn_destroy(pinn_handle h);
+
+/* Number of loss terms K (pde terms first, then bcs: the order of src/discretize.jl:569-570) and length of theta. */
+int pinn_num_terms(pinn_handle h);
+int64_t pinn_num_theta(pinn_handle h);
+
+/*
+ * Install the collocation set of one term (host pointer; copied to HBM and kept resident).
+ * Replaces the `train_set` captured by get_loss_function (src/training_strategies.jl:215-221) or the
+ * per-call sample of StochasticTraining / QuasiRandomTraining (:271-282, :365-389).
+ * n_norm: the N of mean(abs2, .) — the GLOBAL point count when the set is one shard of a
+ * multi-GPU partition; pass 0 for n_norm == n.
+ */
+int pinn_set_points(pinn_handle h, int term, const float* pts, int64_t n, int64_t n_norm);
+/* Same, `pts` already in device memory (adopted by copy). */
+int pinn_set_points_device(pinn_handle h, int term, const float* d_pts, int64_t n, int64_t n_norm);
+
+/*
+ * One evaluation of full_loss_function and its reverse-mode gradient (src/discretize.jl:567-598, :778):
+ *   term_losses[k] = mean(abs2, residual_k(set_k, theta))            (K doubles, unweighted)
+ *   grad           = d/dtheta sum_k term_w[k] * term_losses[k]       (P floats, nullable)
+ * theta: P floats (host).  term_w: K floats (adaptive-loss weights, src/adaptive_losses.jl; NULL = ones).
+ * Deterministic: identical inputs give bit-identical outputs.
+ */
+int pinn_loss_grad(pinn_handle h, const float* theta, int64_t p, const float* term_w,
+                   double* term_losses, float* grad);
+/* Float64 convenience for the reference's default eltype (src/discretize.jl:432-449): converts at the boundary. */
+int pinn_loss_grad_f64(pinn_handle h, const double* theta, int64_t p, const double* term_w,
+                       double* term_losses, double* grad);
+/*
+ * Per-term gradients for GradientScaleAdaptiveLoss (src/adaptive_losses.jl:112-123):
+ * term_grads is K x P (row k = d term_losses[k] / d theta), row-major.
+ */
+int pinn_term_grads(pinn_handle h, const float* theta, int64_t p, double* term_losses, float* term_grads);
+
+/*
+ * Device-resident variant for multi-GPU data parallelism (one process per GPU; the caller
+ * all-reduces d_out with RCCL): d_theta = P floats in HBM; d_out = P + K floats in HBM:
+ *   d_out[0..P)   = this shard's gradient contribution (already scaled by term_w[k]/n_norm_k)
+ *   d_out[P..P+K) = this shard's sum of squared residuals per term (divide by n_norm_k after the all-reduce)
+ * Asynchronous on `stream` (a hipStream_t, may be NULL).
+ */
+int pinn_loss_grad_device(pinn_handle h, const float* d_theta, const float* term_w, float* d_out, void* stream);
+
+/* residual_k(set_k, theta): the datafree loss function of src/discretize.jl:174 on the installed set; r has n_k floats. */
+int pinn_residual(pinn_handle h, int term, const float* theta, int64_t p, float* r);
+/* Trial function phi(x, theta) of one net (src/pinn_types.jl:88-90): pts = d x n point-major, out = n floats. */
+int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float* pts, int64_t n, float* out);
+
+/* Timing of the last pinn_loss_grad*: HIP-event milliseconds of the fused residual kernels / of the whole device section. */
+int pinn_last_timing(pinn_handle h, float* kernel_ms, float* total_ms);
+/* Introspection used by tests and bench: writes a short human-readable description of the kernel plan. */
+int pinn_describe(pinn_handle h, char* buf, int64_t buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PINN_HIP_H */

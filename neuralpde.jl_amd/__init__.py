@@ -1,0 +1,21 @@
+"""neuralpde.jl_amd — MI355X-native engine for NeuralPDE.jl's PhysicsInformedNN/discretize hot path.
+
+Python host mirror of the reference's discretizer API over the C ABI of libpinn_hip.so
+(include/pinn_hip.h).  The directory name contains a dot, so import it through the repo-root shim:
+
+    import pinn_import; npde = pinn_import.load()
+
+See DESIGN.md for the kernel design and INTEGRATION.md for the Julia `ccall` binding.
+"""
+from . import _lib
+from ._lib import Engine, EngineError, Library
+from .ir import Instr, NetIR, ProblemIR, Slot, TermIR
+from .pinn import (Chain, Dense, LogOptions, NonAdaptiveLoss, OptimizationFunction, OptimizationProblem, Phi,
+                   PhysicsInformedNN, PINNLossFunctions, PINNRepresentation, discretize, initialparameters, remake,
+                   symbolic_discretize)
+from .strategies import (AbstractTrainingStrategy, GridTraining, LatinHypercubeSample, QuasiRandomTraining,
+                         SobolSample, StochasticTraining, generate_random_points, generate_training_sets, get_bounds)
+from .symbolic import (Differential, Eq, Equation, In, Interval, LoweringError, PDESystem, get_argument, get_variables,
+                       get_vars, lower_equation, parameters, variables)
+
+__all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,188 @@
+"""ctypes binding of the C ABI in include/pinn_hip.h (libpinn_hip.so).
+
+This is the Python mirror of the `ccall` layer the Julia glue uses.  There is no
+CPU fallback: if the HIP library is missing this module raises, and if no gfx950 device is
+present `pinn_create` fails with the library's own error message.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_PATH = os.path.join(_HERE, "csrc", "libpinn_hip.so")
+
+# every symbol declared in include/pinn_hip.h
+SYMBOLS = [
+    "pinn_backend", "pinn_abi_version", "pinn_last_error", "pinn_create", "pinn_destroy", "pinn_num_terms",
+    "pinn_num_theta", "pinn_set_points", "pinn_set_points_device", "pinn_loss_grad", "pinn_loss_grad_f64",
+    "pinn_term_grads", "pinn_loss_grad_device", "pinn_residual", "pinn_phi", "pinn_last_timing", "pinn_describe",
+]
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Library:
+    """A loaded build of the engine ABI."""
+
+    def __init__(self, path: str = DEFAULT_PATH):
+        if not os.path.exists(path):
+            raise EngineError(
+                f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+                "The PINN engine has no CPU fallback.")
+        self.path = path
+        self.lib = C.CDLL(path)
+        L = self.lib
+        fp, dp, vp = C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_void_p
+        L.pinn_backend.restype = C.c_char_p
+        L.pinn_abi_version.restype = C.c_int
+        L.pinn_last_error.restype = C.c_char_p
+        L.pinn_create.argtypes = [C.c_char_p, C.POINTER(vp)]
+        L.pinn_destroy.argtypes = [vp]
+        L.pinn_num_terms.argtypes = [vp]
+        L.pinn_num_theta.argtypes = [vp]
+        L.pinn_num_theta.restype = C.c_int64
+        L.pinn_set_points.argtypes = [vp, C.c_int, fp, C.c_int64, C.c_int64]
+        L.pinn_set_points_device.argtypes = [vp, C.c_int, vp, C.c_int64, C.c_int64]
+        L.pinn_loss_grad.argtypes = [vp, fp, C.c_int64, fp, dp, fp]
+        L.pinn_loss_grad_f64.argtypes = [vp, dp, C.c_int64, dp, dp, dp]
+        L.pinn_term_grads.argtypes = [vp, fp, C.c_int64, dp, fp]
+        L.pinn_loss_grad_device.argtypes = [vp, vp, fp, vp, vp]
+        L.pinn_residual.argtypes = [vp, C.c_int, fp, C.c_int64, fp]
+        L.pinn_phi.argtypes = [vp, C.c_int, fp, C.c_int64, fp, C.c_int64, fp]
+        L.pinn_last_timing.argtypes = [vp, fp, fp]
+        L.pinn_describe.argtypes = [vp, C.c_char_p, C.c_int64]
+
+    @property
+    def backend(self) -> str:
+        return self.lib.pinn_backend().decode()
+
+    def last_error(self) -> str:
+        return self.lib.pinn_last_error().decode()
+
+    def check(self, rc: int, what: str):
+        if rc != 0:
+            raise EngineError(f"{what}: {self.last_error()}")
+
+
+_default: Optional[Library] = None
+
+
+def default_library() -> Library:
+    global _default
+    if _default is None:
+        _default = Library(DEFAULT_PATH)
+    return _default
+
+
+def set_library(lib: Optional[Library]):
+    """Replace the process-wide library object.  Used by the CPU test-suite to drive the host logic
+    through tests/emu/libpinn_emu.so (same sources, wave emulation); never called by the package."""
+    global _default
+    _default = lib
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+class Engine:
+    """One `pinn_handle`."""
+
+    def __init__(self, descriptor: str, lib: Optional[Library] = None):
+        self.L = lib or default_library()
+        self.h = C.c_void_p()
+        self.L.check(self.L.lib.pinn_create(descriptor.encode(), C.byref(self.h)), "pinn_create")
+        self.K = self.L.lib.pinn_num_terms(self.h)
+        self.P = int(self.L.lib.pinn_num_theta(self.h))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.lib.pinn_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_points(self, term: int, pts, n_norm: int = 0):
+        """pts: (d x N) array as the reference holds it; stored point-major (Julia column-major)."""
+        pts = np.asarray(pts)
+        flat = _f32(pts.T).reshape(-1)     # (N x d) C-order == (d x N) Fortran order
+        self.L.check(self.L.lib.pinn_set_points(self.h, term, flat.ctypes.data_as(C.POINTER(C.c_float)), pts.shape[1], n_norm),
+                     "pinn_set_points")
+
+    def set_points_device(self, term: int, dptr: int, n: int, n_norm: int = 0):
+        self.L.check(self.L.lib.pinn_set_points_device(self.h, term, C.c_void_p(dptr), n, n_norm), "pinn_set_points_device")
+
+    def loss_grad(self, theta, weights: Optional[Sequence[float]] = None, want_grad: bool = True):
+        th = _f32(theta)
+        losses = np.zeros(self.K, dtype=np.float64)
+        grad = np.zeros(self.P, dtype=np.float32) if want_grad else None
+        w = _f32(weights) if weights is not None else None
+        self.L.check(self.L.lib.pinn_loss_grad(
+            self.h, th.ctypes.data_as(C.POINTER(C.c_float)), th.size,
+            w.ctypes.data_as(C.POINTER(C.c_float)) if w is not None else None,
+            losses.ctypes.data_as(C.POINTER(C.c_double)),
+            grad.ctypes.data_as(C.POINTER(C.c_float)) if grad is not None else None), "pinn_loss_grad")
+        return losses, grad
+
+    def loss_grad_f64(self, theta, weights=None):
+        th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64))
+        losses = np.zeros(self.K, dtype=np.float64)
+        grad = np.zeros(self.P, dtype=np.float64)
+        w = np.ascontiguousarray(np.asarray(weights, dtype=np.float64)) if weights is not None else None
+        self.L.check(self.L.lib.pinn_loss_grad_f64(
+            self.h, th.ctypes.data_as(C.POINTER(C.c_double)), th.size,
+            w.ctypes.data_as(C.POINTER(C.c_double)) if w is not None else None,
+            losses.ctypes.data_as(C.POINTER(C.c_double)), grad.ctypes.data_as(C.POINTER(C.c_double))), "pinn_loss_grad_f64")
+        return losses, grad
+
+    def term_grads(self, theta):
+        th = _f32(theta)
+        losses = np.zeros(self.K, dtype=np.float64)
+        tg = np.zeros((self.K, self.P), dtype=np.float32)
+        self.L.check(self.L.lib.pinn_term_grads(self.h, th.ctypes.data_as(C.POINTER(C.c_float)), th.size,
+                                                losses.ctypes.data_as(C.POINTER(C.c_double)),
+                                                tg.ctypes.data_as(C.POINTER(C.c_float))), "pinn_term_grads")
+        return losses, tg
+
+    def loss_grad_device(self, d_theta: int, d_out: int, weights=None, stream: int = 0):
+        w = _f32(weights) if weights is not None else None
+        self.L.check(self.L.lib.pinn_loss_grad_device(
+            self.h, C.c_void_p(d_theta), w.ctypes.data_as(C.POINTER(C.c_float)) if w is not None else None,
+            C.c_void_p(d_out), C.c_void_p(stream)), "pinn_loss_grad_device")
+
+    def residual(self, term: int, theta, n: int) -> np.ndarray:
+        th = _f32(theta)
+        r = np.zeros(n, dtype=np.float32)
+        self.L.check(self.L.lib.pinn_residual(self.h, term, th.ctypes.data_as(C.POINTER(C.c_float)), th.size,
+                                              r.ctypes.data_as(C.POINTER(C.c_float))), "pinn_residual")
+        return r
+
+    def phi(self, net: int, theta, pts) -> np.ndarray:
+        th = _f32(theta)
+        pts = np.asarray(pts)
+        flat = _f32(pts.T).reshape(-1)
+        out = np.zeros(pts.shape[1], dtype=np.float32)
+        self.L.check(self.L.lib.pinn_phi(self.h, net, th.ctypes.data_as(C.POINTER(C.c_float)), th.size,
+                                         flat.ctypes.data_as(C.POINTER(C.c_float)), pts.shape[1],
+                                         out.ctypes.data_as(C.POINTER(C.c_float))), "pinn_phi")
+        return out
+
+    def last_timing(self):
+        k, t = C.c_float(), C.c_float()
+        self.L.check(self.L.lib.pinn_last_timing(self.h, C.byref(k), C.byref(t)), "pinn_last_timing")
+        return k.value, t.value
+
+    def describe(self) -> str:
+        buf = C.create_string_buffer(4096)
+        self.L.check(self.L.lib.pinn_describe(self.h, buf, 4096), "pinn_describe")
+        return buf.value.decode()

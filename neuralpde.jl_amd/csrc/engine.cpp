@@ -1,0 +1,793 @@
+// engine.cpp — host side of the C ABI: descriptor parsing, kernel-plan construction, launches.
+//
+// Mirrors what the reference does once per `discretize` call on the host
+// (src/discretize.jl:413-767: build loss functions, merge with the strategy, build full_loss_function)
+// and what it does per optimiser iteration (src/discretize.jl:567-598).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/pinn_hip.h"
+#include "aux_kernels.hpp"
+#include "plat.hpp"
+#include "spec_registry.hpp"
+
+namespace pk {
+std::vector<SpecInfo>& registry() {
+    static std::vector<SpecInfo> r;
+    return r;
+}
+}  // namespace pk
+
+namespace {
+
+thread_local std::string g_err;
+int fail(const std::string& m) {
+    g_err = m;
+    return 1;
+}
+
+struct Slot {
+    int net;
+    int order;
+    int axes[4];
+};
+struct Net {
+    int act;
+    int theta_off;
+    std::vector<int> sizes;          // n0 .. nL (nL == 1)
+    int nparams() const {
+        int n = 0;
+        for (size_t i = 0; i + 1 < sizes.size(); ++i) n += sizes[i + 1] * sizes[i] + sizes[i + 1];
+        return n;
+    }
+    int maxhidden() const {
+        int m = 0;
+        for (size_t i = 1; i + 1 < sizes.size(); ++i) m = std::max(m, sizes[i]);
+        return m;
+    }
+};
+struct Term {
+    int d = 0;
+    std::vector<Slot> slots;
+    std::vector<rp::Instr> ops;      // descriptor row numbering
+    int out_row = 0;
+    // plan
+    int net = -1;
+    int group = -1;
+    int slot_in_group = -1;
+    std::vector<int> chan_of_slot;
+    // data
+    float* d_pts = nullptr;
+    int64_t n = 0, n_norm = 0;
+    float* d_resid = nullptr;
+    int64_t resid_cap = 0;
+};
+struct Group {
+    int net = -1;
+    const pk::SpecInfo* spec = nullptr;
+    std::vector<int> terms;
+    pk::GroupArgs ga;
+    rp::Instr* d_prog = nullptr;
+    std::vector<int> prog_off, prog_n, out_row;
+    float* d_slabs = nullptr;
+    double* d_losspart = nullptr;
+    float* d_scratch = nullptr;
+    int* d_map_theta = nullptr;      // reduce map: theta index
+    int* d_map_slab = nullptr;       // reduce map: slab offset
+    int nmap = 0;
+    int blocks = 0;
+    int max_blocks = 0;
+};
+struct NetPlan {
+    const pk::SpecInfo* spec = nullptr;   // any spec with the right (HP,NHH,D): packed layout is shared
+    float* d_packed = nullptr;
+    int* d_pack_idx = nullptr;
+    int npacked = 0;
+};
+
+}  // namespace
+
+struct pinn_engine {
+    int64_t ntheta = 0;
+    int np = 0, ne = 0, p_theta_off = 0;
+    std::vector<float> p_defaults;
+    std::vector<Net> nets;
+    std::vector<Term> terms;
+    std::vector<Group> groups;
+    std::vector<NetPlan> netplans;
+    int ncu = 0;
+    plat_stream stream = nullptr;
+    bool own_stream = true;
+    float* d_theta = nullptr;
+    float* d_params = nullptr;
+    float* d_defaults = nullptr;
+    double* d_gradd = nullptr;
+    double* d_lossraw = nullptr;
+    float* d_out = nullptr;          // [P grad | K raw sums]
+    std::vector<float> h_out;
+    plat_event ev0, ev1, ev2, ev3;
+    float last_kernel_ms = 0.f, last_total_ms = 0.f;
+    bool timing_valid = false;
+    // phi scratch
+    float* d_phi_pts = nullptr;
+    float* d_phi_out = nullptr;
+    int64_t phi_cap = 0;
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// descriptor parsing
+// ---------------------------------------------------------------------------------------------
+const char* OPNAMES[rp::OP_COUNT] = {"CONST", "ADD", "SUB", "MUL", "DIV", "NEG", "ADDC", "MULC", "POWI", "POW", "POWC",
+                                     "SIN", "COS", "TAN", "EXP", "LOG", "SQRT", "ABS", "TANH", "SINH", "COSH", "SECH",
+                                     "SINPI", "COSPI", "MAX", "MIN"};
+
+int parse_descriptor(const char* text, pinn_engine& E) {
+    std::istringstream in(text);
+    std::string tok;
+    auto expect = [&](const char* w) -> bool {
+        in >> tok;
+        return (bool)in && tok == w;
+    };
+    int ver = 0;
+    if (!expect("pinnir") || !(in >> ver) || ver != 1) return fail("descriptor: expected 'pinnir 1'");
+    if (!expect("ntheta") || !(in >> E.ntheta)) return fail("descriptor: ntheta");
+    if (!expect("params") || !(in >> E.np >> E.ne >> E.p_theta_off)) return fail("descriptor: params");
+    if (E.np < 0 || E.np > pk::MAX_PARAMS || E.ne > E.np) return fail("descriptor: at most 4 PDE parameters are supported");
+    if (!expect("defaults")) return fail("descriptor: defaults");
+    E.p_defaults.assign(pk::MAX_PARAMS, 0.f);
+    for (int i = 0; i < E.np; ++i)
+        if (!(in >> E.p_defaults[i])) return fail("descriptor: defaults values");
+    int nn = 0;
+    if (!expect("nets") || !(in >> nn) || nn < 1) return fail("descriptor: nets");
+    E.nets.resize(nn);
+    for (int i = 0; i < nn; ++i) {
+        int id, ns;
+        std::string act;
+        if (!expect("net") || !(in >> id >> act >> E.nets[i].theta_off >> ns) || id != i) return fail("descriptor: net line");
+        if (act == "tanh") E.nets[i].act = pk::ACT_TANH;
+        else if (act == "sigmoid") E.nets[i].act = pk::ACT_SIGMOID;
+        else return fail("descriptor: unsupported activation '" + act + "' (supported: tanh, sigmoid)");
+        E.nets[i].sizes.resize(ns);
+        for (int j = 0; j < ns; ++j)
+            if (!(in >> E.nets[i].sizes[j])) return fail("descriptor: net sizes");
+        if (ns < 3) return fail("descriptor: a chain needs at least one hidden layer");
+        if (E.nets[i].sizes.back() != 1) return fail("descriptor: only single-output chains (one per dependent variable) are supported, as in the reference (pinn_types.jl:106-108)");
+    }
+    int nt = 0;
+    if (!expect("terms") || !(in >> nt) || nt < 1) return fail("descriptor: terms");
+    E.terms.resize(nt);
+    for (int i = 0; i < nt; ++i) {
+        Term& T = E.terms[i];
+        int id, ns, no;
+        if (!expect("term") || !(in >> id >> T.d >> ns >> no >> T.out_row) || id != i) return fail("descriptor: term line");
+        T.slots.resize(ns);
+        for (int s = 0; s < ns; ++s) {
+            Slot& S = T.slots[s];
+            if (!expect("slot") || !(in >> S.net >> S.order)) return fail("descriptor: slot line");
+            if (S.order < 0 || S.order > 2) return fail("derivative order > 2 is not supported yet by the HIP engine");
+            if (S.net < 0 || S.net >= nn) return fail("descriptor: slot net id");
+            for (int a = 0; a < S.order; ++a)
+                if (!(in >> S.axes[a])) return fail("descriptor: slot axes");
+            if (S.order == 2 && S.axes[0] > S.axes[1]) std::swap(S.axes[0], S.axes[1]);
+        }
+        T.ops.resize(no);
+        for (int q = 0; q < no; ++q) {
+            std::string name;
+            rp::Instr& I = T.ops[q];
+            if (!expect("op") || !(in >> name >> I.a >> I.b >> I.imm)) return fail("descriptor: op line");
+            I.code = -1;
+            for (int c = 0; c < rp::OP_COUNT; ++c)
+                if (name == OPNAMES[c]) I.code = c;
+            if (I.code < 0) return fail("descriptor: unknown op '" + name + "'");
+        }
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// plan: pick a compiled kernel for every term, build pack / reduce index maps
+// ---------------------------------------------------------------------------------------------
+int round_hp(int h) {
+    if (h <= 16) return 16;
+    if (h <= 32) return 32;
+    if (h <= 64) return 64;
+    return ((h + 15) / 16) * 16;
+}
+
+const pk::SpecInfo* find_spec(int HP, int NHH, int D, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs,
+                              std::vector<int>* pair_index) {
+    const pk::SpecInfo* best = nullptr;
+    for (const pk::SpecInfo& s : pk::registry()) {
+        if (s.HP != HP || s.NHH != NHH || s.D != D) continue;
+        if ((s.D1MASK & need_first) != need_first) continue;
+        bool ok = true;
+        for (auto& pr : need_pairs) {
+            bool f = false;
+            for (int p = 0; p < s.NPAIR; ++p) {
+                int a = (int)((s.PAIRS >> (8 * p)) & 0xF), b = (int)((s.PAIRS >> (8 * p + 4)) & 0xF);
+                if (a == pr.first && b == pr.second) f = true;
+            }
+            ok = ok && f;
+        }
+        if (!ok) continue;
+        if (!best || s.C < best->C || (s.C == best->C && s.PG > best->PG)) best = &s;
+    }
+    (void)pair_index;
+    return best;
+}
+
+int first_rank(const pk::SpecInfo& s, int axis) {
+    int c = 0;
+    for (int a = 0; a < axis; ++a)
+        if (s.D1MASK & (1u << a)) ++c;
+    return c;
+}
+
+int chan_of(const pk::SpecInfo& s, const Slot& sl) {
+    if (sl.order == 0) return 0;
+    if (sl.order == 1) return 1 + first_rank(s, sl.axes[0]);
+    for (int p = 0; p < s.NPAIR; ++p) {
+        int a = (int)((s.PAIRS >> (8 * p)) & 0xF), b = (int)((s.PAIRS >> (8 * p + 4)) & 0xF);
+        if (a == sl.axes[0] && b == sl.axes[1]) return 1 + s.NFIRST + p;
+    }
+    return -1;
+}
+
+std::string spec_name(const pk::SpecInfo& s) {
+    char b[160];
+    std::snprintf(b, sizeof b, "HP%d_NHH%d_D%d_F%x_P%llx_PG%d(C=%d)", s.HP, s.NHH, s.D, s.D1MASK, s.PAIRS, s.PG, s.C);
+    return b;
+}
+
+int build_plan(pinn_engine& E) {
+    // ---- nets ----
+    E.netplans.resize(E.nets.size());
+    for (size_t n = 0; n < E.nets.size(); ++n) {
+        const Net& N = E.nets[n];
+        if (N.theta_off < 0 || N.theta_off + N.nparams() > E.ntheta) return fail("descriptor: net parameters exceed ntheta");
+    }
+    if (E.ne > 0 && (E.p_theta_off < 0 || E.p_theta_off + E.ne > E.ntheta)) return fail("descriptor: theta.p exceeds ntheta");
+
+    // ---- terms -> groups ----
+    for (size_t t = 0; t < E.terms.size(); ++t) {
+        Term& T = E.terms[t];
+        int net = -1;
+        for (auto& s : T.slots) {
+            if (net >= 0 && s.net != net)
+                return fail("term " + std::to_string(t) + ": equations coupling several networks are not supported by this build of the HIP engine yet");
+            net = s.net;
+        }
+        if (net < 0) return fail("term " + std::to_string(t) + " does not reference any dependent variable");
+        T.net = net;
+        const Net& N = E.nets[net];
+        if (N.sizes[0] != T.d)
+            return fail("term " + std::to_string(t) + ": network input dimension differs from the term's coordinate count (heterogeneous inputs are not supported yet)");
+        const int LH = (int)N.sizes.size() - 2;
+        const int HP = round_hp(N.maxhidden());
+        unsigned need_first = 0;
+        std::vector<std::pair<int, int>> need_pairs;
+        for (auto& s : T.slots) {
+            for (int a = 0; a < s.order; ++a) {
+                if (s.axes[a] < 0 || s.axes[a] >= T.d) return fail("descriptor: slot axis out of range");
+                need_first |= 1u << s.axes[a];
+            }
+            if (s.order == 2) {
+                auto pr = std::make_pair(s.axes[0], s.axes[1]);
+                if (std::find(need_pairs.begin(), need_pairs.end(), pr) == need_pairs.end()) need_pairs.push_back(pr);
+            }
+        }
+        const pk::SpecInfo* sp = find_spec(HP, LH - 1, T.d, need_first, need_pairs, nullptr);
+        if (!sp) {
+            char b[256];
+            std::snprintf(b, sizeof b,
+                          "term %zu: no compiled kernel for hidden width %d (padded %d), %d hidden layers, d=%d, first-derivative axes mask 0x%x, %zu second derivatives; add a PINN_INSTANTIATE line in csrc/inst_*.hip",
+                          t, N.maxhidden(), HP, LH, T.d, need_first, need_pairs.size());
+            return fail(b);
+        }
+        T.chan_of_slot.clear();
+        for (auto& s : T.slots) {
+            int c = chan_of(*sp, s);
+            if (c < 0) return fail("internal: slot has no channel");
+            T.chan_of_slot.push_back(c);
+        }
+        const int rows = T.d + E.np + sp->C + (int)T.ops.size();
+        if (rows > rp::MAX_ROWS_FUSED)
+            return fail("term " + std::to_string(t) + ": residual expression too long for the fused kernel tape (" + std::to_string(rows) + " rows > 32)");
+        if (!E.netplans[net].spec) E.netplans[net].spec = sp;
+        // find / make group
+        int gi = -1;
+        for (size_t g = 0; g < E.groups.size(); ++g)
+            if (E.groups[g].net == net && E.groups[g].spec == sp && (int)E.groups[g].terms.size() < pk::MAX_GROUP_TERMS) gi = (int)g;
+        if (gi < 0) {
+            E.groups.emplace_back();
+            gi = (int)E.groups.size() - 1;
+            E.groups[gi].net = net;
+            E.groups[gi].spec = sp;
+        }
+        T.group = gi;
+        T.slot_in_group = (int)E.groups[gi].terms.size();
+        E.groups[gi].terms.push_back((int)t);
+    }
+
+    // ---- per-net pack index map ----
+    for (size_t n = 0; n < E.nets.size(); ++n) {
+        NetPlan& NP = E.netplans[n];
+        if (!NP.spec) continue;   // net unused by any term
+        const pk::SpecInfo& s = *NP.spec;
+        const Net& N = E.nets[n];
+        const int LH = s.LH, HP = s.HP, MT = s.MT, D = s.D;
+        std::vector<int> loff(LH + 1);
+        int o = N.theta_off;
+        for (int j = 0; j <= LH; ++j) {
+            loff[j] = o;
+            o += N.sizes[j + 1] * N.sizes[j] + N.sizes[j + 1];
+        }
+        auto Widx = [&](int j, int out, int in) -> int {
+            if (out >= N.sizes[j + 1] || in >= N.sizes[j]) return -1;
+            return loff[j] + out + in * N.sizes[j + 1];
+        };
+        auto bidx = [&](int j, int out) -> int {
+            if (out >= N.sizes[j + 1]) return -1;
+            return loff[j] + N.sizes[j + 1] * N.sizes[j] + out;
+        };
+        std::vector<int> idx(s.PACKED, -1);
+        for (int i = 0; i < D; ++i)
+            for (int nn = 0; nn < HP; ++nn) idx[s.OFF_W1 + i * HP + nn] = Widx(0, nn, i);
+        for (int l = 0; l < LH; ++l)
+            for (int nn = 0; nn < HP; ++nn) idx[s.OFF_B + l * HP + nn] = bidx(l, nn);
+        for (int nn = 0; nn < HP; ++nn) idx[s.OFF_WL + nn] = Widx(LH, 0, nn);
+        idx[s.OFF_BL] = bidx(LH, 0);
+        for (int hl = 0; hl < s.NHH; ++hl)
+            for (int m1 = 0; m1 < MT; ++m1)
+                for (int rr = 0; rr < 4; ++rr)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int m2 = 0; m2 < MT; ++m2) {
+                            const int g = lane >> 4, c = lane & 15;
+                            // forward fragments: [mi=m1][rr][lane][mo=m2] = W[out=16mo+c][in=16mi+4g+rr]
+                            idx[s.OFF_WPK + hl * HP * HP + ((m1 * 4 + rr) * 64 + lane) * MT + m2] = Widx(hl + 1, 16 * m2 + c, 16 * m1 + 4 * g + rr);
+                            // transposed fragments: [mo=m1][rr][lane][mi=m2] = W[out=16mo+4g+rr][in=16mi+c]
+                            idx[s.OFF_WTPK + hl * HP * HP + ((m1 * 4 + rr) * 64 + lane) * MT + m2] = Widx(hl + 1, 16 * m1 + 4 * g + rr, 16 * m2 + c);
+                        }
+        NP.npacked = s.PACKED;
+        NP.d_packed = (float*)plat_malloc(sizeof(float) * s.PACKED);
+        NP.d_pack_idx = (int*)plat_malloc(sizeof(int) * s.PACKED);
+        if (!NP.d_packed || !NP.d_pack_idx) return fail("device allocation failed (packed weights)");
+        plat_h2d(NP.d_pack_idx, idx.data(), sizeof(int) * s.PACKED, E.stream);
+        plat_sync(E.stream);
+    }
+
+    // ---- per-group buffers and reduce maps ----
+    int total_terms = (int)E.terms.size();
+    for (auto& G : E.groups) {
+        const pk::SpecInfo& s = *G.spec;
+        const Net& N = E.nets[G.net];
+        const int LH = s.LH, HP = s.HP, MT = s.MT, D = s.D;
+        (void)HP;
+        G.max_blocks = E.ncu;
+        const size_t nw = (size_t)G.max_blocks * 4;
+        G.d_slabs = (float*)plat_malloc(sizeof(float) * nw * s.SLAB);
+        G.d_losspart = (double*)plat_malloc(sizeof(double) * nw * total_terms);
+        G.d_scratch = (float*)plat_malloc(sizeof(float) * nw * s.SCR);
+        if (!G.d_slabs || !G.d_losspart || !G.d_scratch) return fail("device allocation failed (group buffers)");
+        // programs (rows remapped to the kernel's channel numbering)
+        std::vector<rp::Instr> prog;
+        for (int ti : G.terms) {
+            Term& T = E.terms[ti];
+            const int S = (int)T.slots.size();
+            const int rslot0 = T.d + E.np, rop0 = rslot0 + S;
+            auto remap = [&](int row) -> int {
+                if (row < rslot0) return row;
+                if (row < rop0) return T.d + E.np + T.chan_of_slot[row - rslot0];
+                return T.d + E.np + s.C + (row - rop0);
+            };
+            G.prog_off.push_back((int)prog.size());
+            G.prog_n.push_back((int)T.ops.size());
+            for (size_t q = 0; q < T.ops.size(); ++q) {
+                rp::Instr I = T.ops[q];
+                const int lim = rop0 + (int)q;
+                if (!rp::is_nullary(I.code)) {
+                    if (I.a < 0 || I.a >= lim) return fail("descriptor: op operand row out of range");
+                    I.a = remap(I.a);
+                } else I.a = 0;
+                if (rp::is_binary(I.code)) {
+                    if (I.b < 0 || I.b >= lim) return fail("descriptor: op operand row out of range");
+                    I.b = remap(I.b);
+                } else I.b = 0;
+                prog.push_back(I);
+            }
+            if (T.out_row < 0 || T.out_row >= rop0 + (int)T.ops.size()) return fail("descriptor: out row out of range");
+            G.out_row.push_back(remap(T.out_row));
+        }
+        G.d_prog = (rp::Instr*)plat_malloc(sizeof(rp::Instr) * std::max<size_t>(prog.size(), 1));
+        if (!G.d_prog) return fail("device allocation failed (programs)");
+        if (!prog.empty()) plat_h2d(G.d_prog, prog.data(), sizeof(rp::Instr) * prog.size(), E.stream);
+        // reduce map
+        std::vector<int> mt, ms;
+        std::vector<int> loff(LH + 1);
+        int o = N.theta_off;
+        for (int j = 0; j <= LH; ++j) {
+            loff[j] = o;
+            o += N.sizes[j + 1] * N.sizes[j] + N.sizes[j + 1];
+        }
+        // layer 0: W (n1 x d), b
+        for (int in = 0; in < D; ++in)
+            for (int out = 0; out < N.sizes[1]; ++out) {
+                mt.push_back(loff[0] + out + in * N.sizes[1]);
+                ms.push_back(s.G_W1 + (in * MT + out % MT) * 16 + out / MT);
+            }
+        for (int l = 0; l < LH; ++l) {
+            const int nb = N.sizes[l + 1];
+            for (int out = 0; out < nb; ++out) {
+                mt.push_back(loff[l] + nb * N.sizes[l] + out);
+                ms.push_back(s.G_BFR + (l * MT + out % MT) * 16 + out / MT);
+            }
+        }
+        for (int hl = 0; hl < s.NHH; ++hl) {
+            const int j = hl + 1;
+            for (int in = 0; in < N.sizes[j]; ++in)
+                for (int out = 0; out < N.sizes[j + 1]; ++out) {
+                    const int to = out % MT, i = out / MT, g = i / 4, r = i % 4;
+                    const int ti = in % MT, c = in / MT;
+                    mt.push_back(loff[j] + out + in * N.sizes[j + 1]);
+                    ms.push_back(s.G_WBAR + hl * s.HP * s.HP + ((to * MT + ti) * 64 + g * 16 + c) * 4 + r);
+                }
+        }
+        for (int in = 0; in < N.sizes[LH]; ++in) {
+            mt.push_back(loff[LH] + in);     // W_out (1 x nLH): out=0, index = 0 + in*1
+            ms.push_back(s.G_WL + ((in / 16) * 4 + (in % 16) / 4) * 4 + in % 4);
+        }
+        mt.push_back(loff[LH] + N.sizes[LH]);
+        ms.push_back(s.G_BL);
+        for (int j = 0; j < E.ne; ++j) {
+            mt.push_back(E.p_theta_off + j);
+            ms.push_back(s.G_P + j);
+        }
+        G.nmap = (int)mt.size();
+        G.d_map_theta = (int*)plat_malloc(sizeof(int) * G.nmap);
+        G.d_map_slab = (int*)plat_malloc(sizeof(int) * G.nmap);
+        if (!G.d_map_theta || !G.d_map_slab) return fail("device allocation failed (reduce map)");
+        plat_h2d(G.d_map_theta, mt.data(), sizeof(int) * G.nmap, E.stream);
+        plat_h2d(G.d_map_slab, ms.data(), sizeof(int) * G.nmap, E.stream);
+        plat_sync(E.stream);
+        // static part of the launch arguments
+        pk::GroupArgs& ga = G.ga;
+        std::memset(&ga, 0, sizeof ga);
+        ga.packed = E.netplans[G.net].d_packed;
+        ga.params = E.d_params;
+        ga.prog = G.d_prog;
+        ga.slabs = G.d_slabs;
+        ga.losspart = G.d_losspart;
+        ga.scratch = G.d_scratch;
+        ga.nterms_total = total_terms;
+        ga.nterms = (int)G.terms.size();
+        ga.nparams = E.np;
+        ga.nparams_estim = E.ne;
+        ga.act = N.act;
+    }
+    return 0;
+}
+
+// refresh tile tables after a point set changed
+void retile(pinn_engine& E, Group& G) {
+    const pk::SpecInfo& s = *G.spec;
+    int tile = 0;
+    for (size_t j = 0; j < G.terms.size(); ++j) {
+        Term& T = E.terms[G.terms[j]];
+        pk::TermDev& td = G.ga.terms[j];
+        td.pts = T.d_pts;
+        td.N = (int)T.n;
+        td.tile0 = tile;
+        td.ntiles = (int)((T.n + s.TP - 1) / s.TP);
+        td.prog_off = G.prog_off[j];
+        td.nops = G.prog_n[j];
+        td.out_row = G.out_row[j];
+        td.term_id = G.terms[j];
+        td.scale = 0.f;
+        td.out = nullptr;
+        tile += td.ntiles;
+    }
+    G.ga.ntiles = tile;
+    G.blocks = std::max(1, std::min(G.max_blocks, (tile + 3) / 4));
+}
+
+int ensure_points(pinn_engine& E) {
+    for (size_t t = 0; t < E.terms.size(); ++t)
+        if (!E.terms[t].d_pts || E.terms[t].n <= 0)
+            return fail("term " + std::to_string(t) + " has no collocation points (call pinn_set_points first)");
+    return 0;
+}
+
+void pack_all(pinn_engine& E) {
+    for (size_t n = 0; n < E.nets.size(); ++n) {
+        NetPlan& NP = E.netplans[n];
+        if (!NP.spec) continue;
+        aux::launch_pack(NP.d_packed, NP.d_pack_idx, E.d_theta, NP.npacked, E.stream);
+    }
+    aux::launch_params(E.d_params, E.d_theta, E.d_defaults, E.np, E.ne, E.p_theta_off, E.stream);
+}
+
+// the device section shared by all loss/grad entry points; theta must already be in E.d_theta
+int run_loss_grad(pinn_engine& E, const float* term_w, int only_term /* -1 = all */, bool timing) {
+    if (ensure_points(E)) return 1;
+    const int K = (int)E.terms.size();
+    if (timing) plat_event_record(E.ev0, E.stream);
+    pack_all(E);
+    plat_memset(E.d_gradd, 0, sizeof(double) * E.ntheta, E.stream);
+    plat_memset(E.d_lossraw, 0, sizeof(double) * K, E.stream);
+    if (timing) plat_event_record(E.ev1, E.stream);
+    for (auto& G : E.groups) {
+        bool any = false;
+        for (size_t j = 0; j < G.terms.size(); ++j) {
+            const int ti = G.terms[j];
+            Term& T = E.terms[ti];
+            const float w = term_w ? term_w[ti] : 1.0f;
+            const bool on = (only_term < 0 || only_term == ti);
+            G.ga.terms[j].scale = on ? (float)(2.0 * (double)w / (double)T.n_norm) : 0.f;
+            any = any || on;
+        }
+        if (!any) continue;
+        plat_memset(G.d_losspart, 0, sizeof(double) * (size_t)G.blocks * 4 * K, E.stream);
+        G.spec->launch(G.ga, pk::MODE_FUSED, G.blocks, E.stream);
+    }
+    if (timing) plat_event_record(E.ev2, E.stream);
+    for (auto& G : E.groups)
+        aux::launch_reduce(E.d_gradd, E.d_lossraw, G.d_slabs, G.spec->SLAB, G.blocks * 4, G.d_map_theta, G.d_map_slab, G.nmap,
+                           G.d_losspart, K, E.stream);
+    aux::launch_finish(E.d_out, E.d_gradd, E.d_lossraw, (int)E.ntheta, K, E.stream);
+    if (timing) plat_event_record(E.ev3, E.stream);
+    return 0;
+}
+
+int upload_theta(pinn_engine& E, const float* theta, int64_t p) {
+    if (p != E.ntheta) return fail("theta length " + std::to_string(p) + " != ntheta " + std::to_string(E.ntheta));
+    if (plat_h2d(E.d_theta, theta, sizeof(float) * p, E.stream)) return fail(std::string("H2D copy of theta failed: ") + plat_last_error());
+    return 0;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+const char* pinn_backend(void) { return plat_name(); }
+int pinn_abi_version(void) { return 1; }
+const char* pinn_last_error(void) { return g_err.c_str(); }
+
+int pinn_create(const char* descriptor, pinn_handle* out) {
+    if (!descriptor || !out) return fail("pinn_create: null argument");
+    *out = nullptr;
+    std::string err;
+    if (plat_init(err)) return fail(err);
+    std::unique_ptr<pinn_engine> E(new pinn_engine());
+    if (parse_descriptor(descriptor, *E)) return 1;
+    E->ncu = plat_num_cus();
+    E->stream = plat_stream_create();
+    const int K = (int)E->terms.size();
+    E->d_theta = (float*)plat_malloc(sizeof(float) * E->ntheta);
+    E->d_params = (float*)plat_malloc(sizeof(float) * pk::MAX_PARAMS);
+    E->d_defaults = (float*)plat_malloc(sizeof(float) * pk::MAX_PARAMS);
+    E->d_gradd = (double*)plat_malloc(sizeof(double) * E->ntheta);
+    E->d_lossraw = (double*)plat_malloc(sizeof(double) * K);
+    E->d_out = (float*)plat_malloc(sizeof(float) * (E->ntheta + K));
+    if (!E->d_theta || !E->d_params || !E->d_defaults || !E->d_gradd || !E->d_lossraw || !E->d_out) return fail("device allocation failed");
+    plat_h2d(E->d_defaults, E->p_defaults.data(), sizeof(float) * pk::MAX_PARAMS, E->stream);
+    E->h_out.resize(E->ntheta + K);
+    plat_event_create(E->ev0); plat_event_create(E->ev1); plat_event_create(E->ev2); plat_event_create(E->ev3);
+    if (build_plan(*E)) { pinn_destroy(E.release()); return 1; }
+    *out = E.release();
+    return 0;
+}
+
+int pinn_destroy(pinn_handle h) {
+    if (!h) return 0;
+    pinn_engine& E = *h;
+    plat_sync(E.stream);
+    for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_resid); }
+    for (auto& G : E.groups) {
+        plat_free(G.d_prog); plat_free(G.d_slabs); plat_free(G.d_losspart); plat_free(G.d_scratch);
+        plat_free(G.d_map_theta); plat_free(G.d_map_slab);
+    }
+    for (auto& N : E.netplans) { plat_free(N.d_packed); plat_free(N.d_pack_idx); }
+    plat_free(E.d_theta); plat_free(E.d_params); plat_free(E.d_defaults); plat_free(E.d_gradd); plat_free(E.d_lossraw);
+    plat_free(E.d_out); plat_free(E.d_phi_pts); plat_free(E.d_phi_out);
+    plat_event_destroy(E.ev0); plat_event_destroy(E.ev1); plat_event_destroy(E.ev2); plat_event_destroy(E.ev3);
+    if (E.own_stream) plat_stream_destroy(E.stream);
+    delete h;
+    return 0;
+}
+
+int pinn_num_terms(pinn_handle h) { return h ? (int)h->terms.size() : -1; }
+int64_t pinn_num_theta(pinn_handle h) { return h ? h->ntheta : -1; }
+
+static int set_points_impl(pinn_handle h, int term, const float* pts, int64_t n, int64_t n_norm, bool device) {
+    if (!h) return fail("null handle");
+    pinn_engine& E = *h;
+    if (term < 0 || term >= (int)E.terms.size()) return fail("pinn_set_points: term index out of range");
+    if (!pts || n <= 0) return fail("pinn_set_points: empty point set (the reference's mean(abs2, .) over an empty set is NaN; refusing)");
+    Term& T = E.terms[term];
+    if (n * T.d >= (int64_t)1 << 31) return fail("pinn_set_points: point set too large for 32-bit indexing; shard it");
+    plat_sync(E.stream);
+    if (T.n != n || !T.d_pts) {
+        plat_free(T.d_pts);
+        T.d_pts = (float*)plat_malloc(sizeof(float) * n * T.d);
+        if (!T.d_pts) return fail("device allocation failed (points)");
+    }
+    int rc = device ? plat_d2d(T.d_pts, pts, sizeof(float) * n * T.d, E.stream) : plat_h2d(T.d_pts, pts, sizeof(float) * n * T.d, E.stream);
+    if (rc) return fail(std::string("copy of points failed: ") + plat_last_error());
+    plat_sync(E.stream);
+    T.n = n;
+    T.n_norm = n_norm > 0 ? n_norm : n;
+    retile(E, E.groups[T.group]);
+    return 0;
+}
+int pinn_set_points(pinn_handle h, int term, const float* pts, int64_t n, int64_t n_norm) { return set_points_impl(h, term, pts, n, n_norm, false); }
+int pinn_set_points_device(pinn_handle h, int term, const float* d_pts, int64_t n, int64_t n_norm) { return set_points_impl(h, term, d_pts, n, n_norm, true); }
+
+int pinn_loss_grad(pinn_handle h, const float* theta, int64_t p, const float* term_w, double* term_losses, float* grad) {
+    if (!h || !theta) return fail("pinn_loss_grad: null argument");
+    pinn_engine& E = *h;
+    const int K = (int)E.terms.size();
+    if (upload_theta(E, theta, p)) return 1;
+    if (run_loss_grad(E, term_w, -1, true)) return 1;
+    if (plat_d2h(E.h_out.data(), E.d_out, sizeof(float) * (E.ntheta + K), E.stream)) return fail("D2H copy failed");
+    // exact double sums for the host path
+    std::vector<double> raw(K);
+    if (plat_d2h(raw.data(), E.d_lossraw, sizeof(double) * K, E.stream)) return fail("D2H copy failed");
+    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    E.last_kernel_ms = plat_event_ms(E.ev1, E.ev2);
+    E.last_total_ms = plat_event_ms(E.ev0, E.ev3);
+    E.timing_valid = true;
+    if (term_losses)
+        for (int k = 0; k < K; ++k) term_losses[k] = raw[k] / (double)E.terms[k].n_norm;
+    if (grad) std::memcpy(grad, E.h_out.data(), sizeof(float) * E.ntheta);
+    return 0;
+}
+
+int pinn_loss_grad_f64(pinn_handle h, const double* theta, int64_t p, const double* term_w, double* term_losses, double* grad) {
+    if (!h || !theta) return fail("pinn_loss_grad_f64: null argument");
+    const int K = (int)h->terms.size();
+    std::vector<float> th(p), w(K, 1.0f), g(grad ? p : 0);
+    for (int64_t i = 0; i < p; ++i) th[i] = (float)theta[i];
+    if (term_w)
+        for (int k = 0; k < K; ++k) w[k] = (float)term_w[k];
+    int rc = pinn_loss_grad(h, th.data(), p, w.data(), term_losses, grad ? g.data() : nullptr);
+    if (rc) return rc;
+    if (grad)
+        for (int64_t i = 0; i < p; ++i) grad[i] = (double)g[i];
+    return 0;
+}
+
+int pinn_term_grads(pinn_handle h, const float* theta, int64_t p, double* term_losses, float* term_grads) {
+    if (!h || !theta || !term_grads) return fail("pinn_term_grads: null argument");
+    pinn_engine& E = *h;
+    const int K = (int)E.terms.size();
+    if (upload_theta(E, theta, p)) return 1;
+    for (int k = 0; k < K; ++k) {
+        if (run_loss_grad(E, nullptr, k, false)) return 1;
+        if (plat_d2h(term_grads + (size_t)k * p, E.d_out, sizeof(float) * p, E.stream)) return fail("D2H copy failed");
+        double raw = 0;
+        if (plat_d2h(&raw, E.d_lossraw + k, sizeof(double), E.stream)) return fail("D2H copy failed");
+        if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+        if (term_losses) term_losses[k] = raw / (double)E.terms[k].n_norm;
+    }
+    return 0;
+}
+
+int pinn_loss_grad_device(pinn_handle h, const float* d_theta, const float* term_w, float* d_out, void* stream) {
+    if (!h || !d_theta || !d_out) return fail("pinn_loss_grad_device: null argument");
+    pinn_engine& E = *h;
+    const int K = (int)E.terms.size();
+    plat_stream user = (plat_stream)stream;
+    plat_stream saved = E.stream;
+    E.stream = user ? user : saved;
+    int rc = plat_d2d(E.d_theta, d_theta, sizeof(float) * E.ntheta, E.stream);
+    if (!rc) rc = run_loss_grad(E, term_w, -1, true);
+    if (!rc) rc = plat_d2d(d_out, E.d_out, sizeof(float) * (E.ntheta + K), E.stream);
+    E.stream = saved;
+    if (rc && g_err.empty()) return fail("pinn_loss_grad_device failed");
+    E.timing_valid = false;
+    return rc;
+}
+
+int pinn_residual(pinn_handle h, int term, const float* theta, int64_t p, float* r) {
+    if (!h || !theta || !r) return fail("pinn_residual: null argument");
+    pinn_engine& E = *h;
+    if (term < 0 || term >= (int)E.terms.size()) return fail("pinn_residual: term index out of range");
+    Term& T = E.terms[term];
+    if (!T.d_pts) return fail("pinn_residual: term has no points");
+    if (upload_theta(E, theta, p)) return 1;
+    pack_all(E);
+    if (T.resid_cap < T.n) {
+        plat_free(T.d_resid);
+        T.d_resid = (float*)plat_malloc(sizeof(float) * T.n);
+        T.resid_cap = T.n;
+        if (!T.d_resid) return fail("device allocation failed (residual)");
+    }
+    Group& G = E.groups[T.group];
+    pk::GroupArgs ga = G.ga;
+    ga.nterms = 1;
+    ga.terms[0] = G.ga.terms[T.slot_in_group];
+    ga.terms[0].tile0 = 0;
+    ga.terms[0].out = T.d_resid;
+    ga.ntiles = ga.terms[0].ntiles;
+    const int blocks = std::max(1, std::min(G.max_blocks, (ga.ntiles + 3) / 4));
+    G.spec->launch(ga, pk::MODE_RESID, blocks, E.stream);
+    if (plat_d2h(r, T.d_resid, sizeof(float) * T.n, E.stream)) return fail("D2H copy failed");
+    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    return 0;
+}
+
+int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float* pts, int64_t n, float* out) {
+    if (!h || !theta || !pts || !out) return fail("pinn_phi: null argument");
+    pinn_engine& E = *h;
+    if (net < 0 || net >= (int)E.nets.size()) return fail("pinn_phi: net index out of range");
+    if (n <= 0) return fail("pinn_phi: n must be positive");
+    const Net& N = E.nets[net];
+    const int LH = (int)N.sizes.size() - 2;
+    const pk::SpecInfo* sp = find_spec(round_hp(N.maxhidden()), LH - 1, N.sizes[0], 0, {}, nullptr);
+    if (!sp) return fail("pinn_phi: no compiled value-only kernel for this network shape");
+    if (!E.netplans[net].spec) return fail("pinn_phi: network is not used by any term");
+    if (upload_theta(E, theta, p)) return 1;
+    pack_all(E);
+    if (E.phi_cap < n) {
+        plat_free(E.d_phi_pts); plat_free(E.d_phi_out);
+        E.d_phi_pts = (float*)plat_malloc(sizeof(float) * n * N.sizes[0]);
+        E.d_phi_out = (float*)plat_malloc(sizeof(float) * n * sp->C);
+        E.phi_cap = n;
+        if (!E.d_phi_pts || !E.d_phi_out) return fail("device allocation failed (phi)");
+    }
+    plat_h2d(E.d_phi_pts, pts, sizeof(float) * n * N.sizes[0], E.stream);
+    pk::GroupArgs ga;
+    std::memset(&ga, 0, sizeof ga);
+    ga.packed = E.netplans[net].d_packed;
+    ga.params = E.d_params;
+    ga.nterms = 1;
+    ga.nterms_total = 1;
+    ga.act = N.act;
+    ga.terms[0].pts = E.d_phi_pts;
+    ga.terms[0].N = (int)n;
+    ga.terms[0].tile0 = 0;
+    ga.terms[0].ntiles = (int)((n + sp->TP - 1) / sp->TP);
+    ga.terms[0].out = E.d_phi_out;
+    ga.ntiles = ga.terms[0].ntiles;
+    const int blocks = std::max(1, std::min(E.ncu, (ga.ntiles + 3) / 4));
+    sp->launch(ga, pk::MODE_FWD, blocks, E.stream);
+    if (plat_d2h(out, E.d_phi_out, sizeof(float) * n, E.stream)) return fail("D2H copy failed");
+    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    return 0;
+}
+
+int pinn_last_timing(pinn_handle h, float* kernel_ms, float* total_ms) {
+    if (!h) return fail("null handle");
+    if (!h->timing_valid) return fail("no timing available (call pinn_loss_grad first)");
+    if (kernel_ms) *kernel_ms = h->last_kernel_ms;
+    if (total_ms) *total_ms = h->last_total_ms;
+    return 0;
+}
+
+int pinn_describe(pinn_handle h, char* buf, int64_t buflen) {
+    if (!h || !buf || buflen <= 0) return fail("pinn_describe: bad argument");
+    std::ostringstream os;
+    os << "backend=" << plat_name() << " cus=" << h->ncu << " ntheta=" << h->ntheta << " terms=" << h->terms.size() << "\n";
+    for (size_t g = 0; g < h->groups.size(); ++g) {
+        const Group& G = h->groups[g];
+        os << "group " << g << " net=" << G.net << " kernel=" << spec_name(*G.spec) << " tiles=" << G.ga.ntiles << " blocks=" << G.blocks << " terms=";
+        for (int t : G.terms) os << t << ",";
+        os << "\n";
+    }
+    std::string s = os.str();
+    std::snprintf(buf, (size_t)buflen, "%s", s.c_str());
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,595 @@
+// pinn_kernels.hpp — the PINN residual/loss hot path for gfx950 (CDNA4), one wavefront per point tile.
+//
+// Replaces, per collocation point (reference file:line):
+//   Phi / Lux Dense forward                      src/pinn_types.jl:79-90
+//   numeric_derivative (FD stencils)             src/pinn_types.jl:445-482   -> exact forward-mode Taylor jets
+//   generated residual function                  src/discretize.jl:163-175   -> rprog.hpp tape
+//   mean(abs2, residual)                         src/training_strategies.jl:220,280,380
+//   weighted sum of terms                        src/discretize.jl:582-588
+//   Zygote reverse mode of all of the above      src/discretize.jl:778       -> hand-derived reverse sweep
+//
+// Data flow of one wave-tile (TP = 16*PG points, C jet channels => NG = C*PG column groups of 16):
+//   * every activation tensor of a layer lives in registers in the MFMA C/D layout:
+//       A[q][m][r]  (vfloat4 per (column group q, 16-neuron tile m)):  neuron 16m + 4*(lane>>4) + r,
+//       column (point) lane&15 of group q.   q = pg*C + channel.
+//   * hidden GEMMs use v_mfma_f32_16x16x4_f32 with the layer weights as the A operand, pre-packed on
+//     the device in fragment order, and the previous layer's D registers fed straight back in as the B
+//     operand (the contraction index is permuted, k-step (mi,r') <-> neurons 16mi+4g+r', so no LDS
+//     round trip between layers).
+//   * the tanh/sigmoid Taylor-jet rules run lane-local on the VALU (all channels of a (neuron, point)
+//     are in the same lane).
+//   * (a, z_i, z_ij) of every hidden layer is parked in a per-wave scratch slab (lane-native, 16 B per
+//     lane per store) for the reverse sweep; it is re-read by the same wave a few microseconds later
+//     (L2 / Infinity-Cache resident).
+//   * reverse sweep: activation adjoints lane-local; dA = W^T dZ by the same register-chained MFMA
+//     scheme with the transposed packed weights; dW += dZ A^T needs both operands with the point index
+//     on the contraction axis, i.e. transposed — done through a per-wave XOR-swizzled LDS buffer
+//     (conflict-free ds_write_b128 / ds_read_b128), accumulating into persistent MFMA accumulators
+//     that live in registers across all tiles of the wave (deterministic, no float atomics).
+//   * quadrature sum of r^2 and the per-wave gradient slab are reduced in a fixed order by
+//     k_reduce (pinn_aux_kernels.hpp) => bit-identical results run to run (BFGS callers need that,
+//     test/NNPDE1/nnpde__pde_vi_pde_with_mixed_derivative.jl:77-80).
+#pragma once
+#include "rprog.hpp"
+#include "vec.hpp"
+
+namespace pk {
+using namespace wv;
+
+enum Act : int { ACT_TANH = 0, ACT_SIGMOID = 1 };
+enum Mode : int { MODE_FUSED = 0, MODE_RESID = 1, MODE_FWD = 2 };
+
+constexpr int MAX_GROUP_TERMS = 12;
+constexpr int MAX_PARAMS = 4;
+
+// ------------------------------------------------------------------------------------------------
+// compile-time description of one kernel family member
+// ------------------------------------------------------------------------------------------------
+template <int HP_, int NHH_, int D_, unsigned D1MASK_, unsigned long long PAIRS_, int NPAIR_, int PG_>
+struct Spec {
+    static constexpr int HP = HP_;            // padded hidden width (multiple of 16)
+    static constexpr int MT = HP_ / 16;       // 16-neuron tiles per layer
+    static constexpr int NHH = NHH_;          // hidden->hidden layers
+    static constexpr int LH = NHH_ + 1;       // hidden layers
+    static constexpr int D = D_;              // input dimension
+    static constexpr unsigned D1MASK = D1MASK_;
+    static constexpr unsigned long long PAIRS = PAIRS_;
+    static constexpr int NPAIR = NPAIR_;
+    static constexpr int PG = PG_;            // 16-point groups per tile
+    static constexpr int popc(unsigned x) { int n = 0; while (x) { n += x & 1; x >>= 1; } return n; }
+    static constexpr int NFIRST = popc(D1MASK_);
+    static constexpr int C = 1 + NFIRST + NPAIR_;
+    static constexpr int NG = C * PG_;
+    static constexpr int TP = 16 * PG_;       // points per tile
+    // k-th first-order axis
+    static constexpr int first_axis(int k) {
+        int cnt = 0;
+        for (int a = 0; a < 8; ++a)
+            if (D1MASK_ & (1u << a)) { if (cnt == k) return a; ++cnt; }
+        return -1;
+    }
+    // rank of axis among first-order channels
+    static constexpr int first_rank(int axis) {
+        int cnt = 0;
+        for (int a = 0; a < axis; ++a) if (D1MASK_ & (1u << a)) ++cnt;
+        return cnt;
+    }
+    static constexpr int pair_a(int p) { return (int)((PAIRS_ >> (8 * p)) & 0xF); }
+    static constexpr int pair_b(int p) { return (int)((PAIRS_ >> (8 * p + 4)) & 0xF); }
+    // packed parameter buffer (floats)
+    static constexpr int OFF_W1 = 0;                       // [D][HP]
+    static constexpr int OFF_B = OFF_W1 + D_ * HP_;        // [LH][HP]
+    static constexpr int OFF_WL = OFF_B + LH * HP_;        // [HP]
+    static constexpr int OFF_BL = OFF_WL + HP_;            // [4] (1 used)
+    static constexpr int OFF_WPK = OFF_BL + 4;             // [NHH][HP*HP]  forward fragments
+    static constexpr int OFF_WTPK = OFF_WPK + NHH_ * HP_ * HP_;   // [NHH][HP*HP] transposed fragments
+    static constexpr int PACKED = OFF_WTPK + NHH_ * HP_ * HP_;
+    // per-wave gradient slab (floats)
+    static constexpr int G_WBAR = 0;                       // [NHH][MT][MT][64][4]
+    static constexpr int G_BFR = G_WBAR + NHH_ * HP_ * HP_;    // [LH][MT][16]
+    static constexpr int G_W1 = G_BFR + LH * HP_;          // [D][MT][16]
+    static constexpr int G_WL = G_W1 + D_ * HP_;           // [MT][4][4]
+    static constexpr int G_BL = G_WL + HP_;                // [1]
+    static constexpr int G_P = G_BL + 1;                   // [MAX_PARAMS]
+    static constexpr int SLAB = ((G_P + MAX_PARAMS + 63) / 64) * 64;
+    // per-wave activation scratch (floats): [LH][NG][MT][64][4]
+    static constexpr int SCR = LH * NG * MT * 256;
+    // per-wave LDS (floats): 2 x (ZT,AT) transpose buffers of 16 columns (also the residual tape) + coords
+    static constexpr int LDS_T = (16 * HP_ > 1024) ? 16 * HP_ : 1024;
+    static constexpr int LDS_X = 16 * PG_ * D_;
+    static constexpr int LDS_WAVE = 4 * LDS_T + ((LDS_X + 63) / 64) * 64;
+};
+
+struct TermDev {
+    const float* pts;        // d x N, point-major (Julia d×N column-major matrix)
+    int N;                   // points of this term on this device
+    int tile0;               // first tile of this term inside the group
+    int ntiles;
+    int prog_off;            // into GroupArgs::prog
+    int nops;
+    int out_row;
+    int term_id;             // global term index (loss partial column)
+    float scale;             // 2 * w_k / N_k(global)   — reverse-sweep seed of mean(abs2, r)
+    float* out;              // MODE_RESID: residual r[N];  MODE_FWD: jets [C][N]
+};
+
+struct GroupArgs {
+    const float* packed;         // Spec::PACKED floats (this net, this call's theta)
+    const float* params;         // MAX_PARAMS floats (theta.p / default_p)
+    const rp::Instr* prog;
+    float* slabs;                // [nwaves][SLAB]
+    double* losspart;            // [nwaves][nterms_total]
+    float* scratch;              // [nwaves][SCR]
+    int nterms_total;
+    int nterms;                  // terms in this group
+    int ntiles;
+    int nparams;                 // NP rows in the tape
+    int nparams_estim;           // first NE params get adjoints
+    int act;
+    TermDev terms[MAX_GROUP_TERMS];
+};
+
+template <int ACTK>
+DEV void act_derivs(vfloat a, vfloat& d1, vfloat& d2, vfloat& d3) {
+    if (ACTK == ACT_TANH) {
+        vfloat a2 = a * a;
+        d1 = vfloat(1.0f) - a2;
+        d2 = vfloat(-2.0f) * a * d1;
+        d3 = d1 * (vfloat(6.0f) * a2 - vfloat(2.0f));
+    } else {
+        d1 = a * (vfloat(1.0f) - a);
+        d2 = d1 * (vfloat(1.0f) - vfloat(2.0f) * a);
+        d3 = d1 * (vfloat(1.0f) - vfloat(6.0f) * d1);
+    }
+}
+DEV vfloat act_value(int act, vfloat z) {
+    if (act == ACT_TANH) return vtanh(z);
+    return vrcp(vfloat(1.0f) + vexp(vfloat(0.0f) - z));
+}
+DEV void act_derivs_rt(int act, vfloat a, vfloat& d1, vfloat& d2, vfloat& d3) {
+    if (act == ACT_TANH) act_derivs<ACT_TANH>(a, d1, d2, d3);
+    else act_derivs<ACT_SIGMOID>(a, d1, d2, d3);
+}
+
+// XOR-swizzled address inside a [16 columns][HP] transpose buffer: neuron n of column `col`
+template <class S>
+DEV vint tr_addr(vint col, vint slot) {
+    // slots of 4 floats; 4*MT slots per row
+    return col * S::HP + (((slot ^ col) & (4 * S::MT - 1)) << 2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The wave program.  `wave`/`nwaves`: this wave's index in the persistent grid.
+// ------------------------------------------------------------------------------------------------
+template <class S, int MODE>
+DEV void wave_main(const GroupArgs& ga, int wave, int nwaves, float* lds) {
+    constexpr int HP = S::HP, MT = S::MT, NHH = S::NHH, LH = S::LH, D = S::D, C = S::C, PG = S::PG, NG = S::NG;
+    constexpr int NFIRST = S::NFIRST, NPAIR = S::NPAIR;
+    const vint lane = lane_id();
+    const vint g = lane >> 4;
+    const vint c = lane & vint(15);
+    const vbool g0 = veq(g, 0);
+    const float* P = ga.packed;
+    const int act = ga.act;
+
+    // ---- persistent per-wave gradient accumulators (registers / AGPRs across all tiles) ----
+    vfloat4 wbar[NHH > 0 ? NHH : 1][MT][MT];
+    vfloat bfr[LH][MT];
+    vfloat w1fr[D][MT];
+    vfloat4 wLbar[MT];
+    vfloat bLbar = vfloat(0.f);
+    vfloat pbar[MAX_PARAMS];
+    PINN_UNROLL for (int l = 0; l < (NHH > 0 ? NHH : 1); ++l)
+        PINN_UNROLL for (int a = 0; a < MT; ++a)
+            PINN_UNROLL for (int b = 0; b < MT; ++b) wbar[l][a][b] = vzero4();
+    PINN_UNROLL for (int l = 0; l < LH; ++l)
+        PINN_UNROLL for (int a = 0; a < MT; ++a) bfr[l][a] = vfloat(0.f);
+    PINN_UNROLL for (int i = 0; i < D; ++i)
+        PINN_UNROLL for (int a = 0; a < MT; ++a) w1fr[i][a] = vfloat(0.f);
+    PINN_UNROLL for (int a = 0; a < MT; ++a) wLbar[a] = vzero4();
+    PINN_UNROLL for (int i = 0; i < MAX_PARAMS; ++i) pbar[i] = vfloat(0.f);
+
+    vfloat lsum = vfloat(0.f);
+    int cur_term = -1;      // index into ga.terms of the term whose loss is being accumulated
+
+    float* scr = ga.scratch + (size_t)wave * S::SCR;
+    float* xs = lds + 4 * S::LDS_T;           // coords of the tile: [pg][pt][i]
+
+    // output layer weights in D layout
+    vfloat4 wL[MT];
+    PINN_UNROLL for (int m = 0; m < MT; ++m) wL[m] = gload4(P + S::OFF_WL, vint(16 * m) + (g << 2));
+    const float bL = P[S::OFF_BL];
+
+    for (int t = wave; t < ga.ntiles; t += nwaves) {
+        // ---- locate the term of this tile (terms are tile-contiguous) ----
+        int k = 0;
+        for (int j = 1; j < ga.nterms; ++j)
+            if (t >= ga.terms[j].tile0) k = j;
+        if (k != cur_term) {
+            if (cur_term >= 0) {
+                double s = wave_sum_d(lsum, g0);
+                if (MODE == MODE_FUSED) ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[cur_term].term_id] = s;
+            }
+            lsum = vfloat(0.f);
+            cur_term = k;
+        }
+        const TermDev& T = ga.terms[k];
+        const int pbase = (t - T.tile0) * S::TP;
+
+        // ---- coordinates ----
+        vfloat x[PG][D];
+        vbool valid[PG];
+        PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+            vint p = vint(pbase + 16 * pg) + c;
+            valid[pg] = vlt(p, T.N);
+            PINN_UNROLL for (int i = 0; i < D; ++i) {
+                x[pg][i] = gload_masked(T.pts, p * D + vint(i), valid[pg]);
+                if (MODE == MODE_FUSED) lds_store(xs, (vint(16 * pg) + c) * D + vint(i), x[pg][i]);
+            }
+        }
+
+        // =========================== forward Taylor-jet sweep ===========================
+        vfloat4 A[NG][MT];
+        // ---- layer 1: d -> HP on the VALU (K = d is tiny) ----
+        PINN_UNROLL for (int m = 0; m < MT; ++m) {
+            const vint nidx = vint(16 * m) + (g << 2);
+            vfloat4 b1 = gload4(P + S::OFF_B, nidx);
+            vfloat4 w1[D];
+            PINN_UNROLL for (int i = 0; i < D; ++i) w1[i] = gload4(P + S::OFF_W1 + i * HP, nidx);
+            PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                vfloat4 z = b1;
+                PINN_UNROLL for (int i = 0; i < D; ++i)
+                    PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = vfma(w1[i][r], x[pg][i], z[r]);
+                A[pg * C][m] = z;
+                PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) A[pg * C + 1 + kf][m] = w1[S::first_axis(kf)];
+                PINN_UNROLL for (int p = 0; p < NPAIR; ++p) A[pg * C + 1 + NFIRST + p][m] = vzero4();
+            }
+        }
+
+        // activation jets in place + park (a, z_i, z_ij) in the scratch slab
+        auto act_forward = [&](vfloat4 (&Z)[NG][MT], int layer /*0-based hidden layer*/) {
+            PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
+                PINN_UNROLL for (int m = 0; m < MT; ++m) {
+                    vfloat4 d1v, d2v;
+                    vfloat4 av;
+                    PINN_UNROLL for (int r = 0; r < 4; ++r) {
+                        vfloat a = act_value(act, Z[pg * C][m][r]);
+                        vfloat d1, d2, d3;
+                        act_derivs_rt(act, a, d1, d2, d3);
+                        av[r] = a; d1v[r] = d1; d2v[r] = d2;
+                    }
+                    Z[pg * C][m] = av;
+                    if (MODE == MODE_FUSED) {
+                        PINN_UNROLL for (int ch = 0; ch < C; ++ch)
+                            gstore4(scr, vint((((layer * NG) + pg * C + ch) * MT + m) * 256) + (lane << 2), Z[pg * C + ch][m]);
+                    }
+                    PINN_UNROLL for (int p = 0; p < NPAIR; ++p) {
+                        const int cp = pg * C + 1 + NFIRST + p;
+                        const int ca = pg * C + 1 + S::first_rank(S::pair_a(p));
+                        const int cb = pg * C + 1 + S::first_rank(S::pair_b(p));
+                        PINN_UNROLL for (int r = 0; r < 4; ++r)
+                            Z[cp][m][r] = vfma(d2v[r] * Z[ca][m][r], Z[cb][m][r], d1v[r] * Z[cp][m][r]);
+                    }
+                    PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf)
+                        PINN_UNROLL for (int r = 0; r < 4; ++r) Z[pg * C + 1 + kf][m][r] = d1v[r] * Z[pg * C + 1 + kf][m][r];
+                }
+        };
+        act_forward(A, 0);
+
+        // ---- hidden -> hidden layers on the matrix cores ----
+        PINN_UNROLL for (int hl = 0; hl < NHH; ++hl) {
+            vfloat4 Zn[NG][MT];
+            PINN_UNROLL for (int m = 0; m < MT; ++m) {
+                vfloat4 bv = gload4(P + S::OFF_B + (hl + 1) * HP, vint(16 * m) + (g << 2));
+                PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                    Zn[pg * C][m] = bv;
+                    PINN_UNROLL for (int ch = 1; ch < C; ++ch) Zn[pg * C + ch][m] = vzero4();
+                }
+            }
+            const float* Wf = P + S::OFF_WPK + hl * HP * HP;
+            PINN_UNROLL for (int mi = 0; mi < MT; ++mi)
+                PINN_UNROLL for (int rr = 0; rr < 4; ++rr) {
+                    vfloat wf[MT];
+                    if (MT == 4) {
+                        vfloat4 w4 = gload4(Wf, vint((mi * 4 + rr) * 64 * MT) + (lane << 2));
+                        PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wf[mo] = w4[mo & 3];
+                    } else {
+                        PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wf[mo] = gload(Wf, vint((mi * 4 + rr) * 64 * MT + mo) + lane * MT);
+                    }
+                    PINN_UNROLL for (int q = 0; q < NG; ++q)
+                        PINN_UNROLL for (int mo = 0; mo < MT; ++mo) Zn[q][mo] = mfma16(wf[mo], A[q][mi][rr], Zn[q][mo]);
+                }
+            act_forward(Zn, hl + 1);
+            PINN_UNROLL for (int q = 0; q < NG; ++q)
+                PINN_UNROLL for (int m = 0; m < MT; ++m) A[q][m] = Zn[q][m];
+        }
+
+        // ---- output layer HP -> 1 (identity): per-lane partial dot + reduction over the 4 row groups ----
+        vfloat U[PG][C];
+        PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
+            PINN_UNROLL for (int ch = 0; ch < C; ++ch) {
+                vfloat s = vfloat(0.f);
+                PINN_UNROLL for (int m = 0; m < MT; ++m)
+                    PINN_UNROLL for (int r = 0; r < 4; ++r) s = vfma(wL[m][r], A[pg * C + ch][m][r], s);
+                s = s + shfl_xor(s, 16);
+                s = s + shfl_xor(s, 32);
+                U[pg][ch] = (ch == 0) ? s + vfloat(bL) : s;
+            }
+
+        if (MODE == MODE_FWD) {
+            PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                vint p = vint(pbase + 16 * pg) + c;
+                PINN_UNROLL for (int ch = 0; ch < C; ++ch)
+                    gstore_masked(T.out, vint(ch * T.N) + p, U[pg][ch], vand(valid[pg], g0));
+            }
+            continue;
+        }
+
+        // =========================== residual tape (values, then adjoints) ===========================
+        vfloat ubar[PG][C];
+        {
+            wave_fence();
+            float* tv = lds;                    // value rows  [row][64]
+            float* ta = lds + 2 * S::LDS_T;     // adjoint rows
+            const int NP = ga.nparams;
+            const int R0 = D + NP + C;
+            const rp::Instr* prog = ga.prog + T.prog_off;
+            const int nrows = R0 + T.nops;
+            PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                PINN_UNROLL for (int i = 0; i < D; ++i) lds_store(tv, vint(i * 64) + lane, x[pg][i]);
+                for (int j = 0; j < NP; ++j) lds_store(tv, vint((D + j) * 64) + lane, vfloat(ga.params[j]));
+                PINN_UNROLL for (int ch = 0; ch < C; ++ch) lds_store(tv, vint((D + NP + ch) * 64) + lane, U[pg][ch]);
+                for (int q = 0; q < T.nops; ++q) {
+                    const rp::Instr ins = prog[q];
+                    vfloat va = rp::is_nullary(ins.code) ? vfloat(0.f) : lds_load(tv, vint(ins.a * 64) + lane);
+                    vfloat vb = rp::is_binary(ins.code) ? lds_load(tv, vint(ins.b * 64) + lane) : vfloat(0.f);
+                    lds_store(tv, vint((R0 + q) * 64) + lane, rp::apply<vfloat>(ins.code, va, vb, ins.imm));
+                }
+                vfloat r = lds_load(tv, vint(T.out_row * 64) + lane);
+                if (MODE == MODE_RESID) {
+                    vint p = vint(pbase + 16 * pg) + c;
+                    gstore_masked(T.out, p, r, vand(valid[pg], g0));
+                    continue;
+                }
+                vfloat rm = vselect(valid[pg], r, vfloat(0.f));
+                lsum = vfma(rm, vselect(g0, rm, vfloat(0.f)), lsum);
+                vfloat rbar = rm * vfloat(T.scale);
+                for (int q = 0; q < nrows; ++q) lds_store(ta, vint(q * 64) + lane, vfloat(0.f));
+                lds_store(ta, vint(T.out_row * 64) + lane, vfloat(1.0f));
+                for (int q = T.nops - 1; q >= 0; --q) {
+                    const rp::Instr ins = prog[q];
+                    if (rp::is_nullary(ins.code)) continue;
+                    vfloat gq = lds_load(ta, vint((R0 + q) * 64) + lane);
+                    vfloat vo = lds_load(tv, vint((R0 + q) * 64) + lane);
+                    vfloat va = lds_load(tv, vint(ins.a * 64) + lane);
+                    const bool bin = rp::is_binary(ins.code);
+                    vfloat vb = bin ? lds_load(tv, vint(ins.b * 64) + lane) : vfloat(0.f);
+                    vfloat da, db;
+                    rp::adjoint<vfloat>(ins.code, va, vb, vo, ins.imm, gq, da, db);
+                    lds_store(ta, vint(ins.a * 64) + lane, lds_load(ta, vint(ins.a * 64) + lane) + da);
+                    if (bin) lds_store(ta, vint(ins.b * 64) + lane, lds_load(ta, vint(ins.b * 64) + lane) + db);
+                }
+                PINN_UNROLL for (int ch = 0; ch < C; ++ch) ubar[pg][ch] = rbar * lds_load(ta, vint((D + NP + ch) * 64) + lane);
+                for (int j = 0; j < ga.nparams_estim; ++j) {
+                    vfloat pj = vselect(g0, rbar * lds_load(ta, vint((D + j) * 64) + lane), vfloat(0.f));
+                    PINN_UNROLL for (int jj = 0; jj < MAX_PARAMS; ++jj) if (jj == j) pbar[jj] += pj;
+                }
+            }
+            wave_fence();
+        }
+        if (MODE == MODE_RESID) continue;
+
+        // =========================== reverse sweep ===========================
+        auto load_raw = [&](vfloat4 (&Sr)[NG][MT], int layer) {
+            PINN_UNROLL for (int q = 0; q < NG; ++q)
+                PINN_UNROLL for (int m = 0; m < MT; ++m)
+                    Sr[q][m] = gload4(scr, vint((((layer * NG) + q) * MT + m) * 256) + (lane << 2));
+        };
+        // post-activation jet of channel ch from the raw (a, z_i, z_ij) record
+        auto ajet = [&](const vfloat4 (&Sr)[NG][MT], int pg, int ch, int m) -> vfloat4 {
+            vfloat4 out;
+            PINN_UNROLL for (int r = 0; r < 4; ++r) {
+                vfloat a = Sr[pg * C][m][r];
+                if (ch == 0) { out[r] = a; continue; }
+                vfloat d1, d2, d3;
+                act_derivs_rt(act, a, d1, d2, d3);
+                if (ch <= NFIRST) out[r] = d1 * Sr[pg * C + ch][m][r];
+                else {
+                    const int p = ch - 1 - NFIRST;
+                    const int ca = pg * C + 1 + S::first_rank(S::pair_a(p));
+                    const int cb = pg * C + 1 + S::first_rank(S::pair_b(p));
+                    out[r] = vfma(d2 * Sr[ca][m][r], Sr[cb][m][r], d1 * Sr[pg * C + ch][m][r]);
+                }
+            }
+            return out;
+        };
+        // activation adjoint in place: G (dA jets) -> dZ jets
+        auto act_adjoint = [&](vfloat4 (&G)[NG][MT], const vfloat4 (&Sr)[NG][MT]) {
+            PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
+                PINN_UNROLL for (int m = 0; m < MT; ++m)
+                    PINN_UNROLL for (int r = 0; r < 4; ++r) {
+                        vfloat a = Sr[pg * C][m][r];
+                        vfloat d1, d2, d3;
+                        act_derivs_rt(act, a, d1, d2, d3);
+                        vfloat zv = d1 * G[pg * C][m][r];
+                        vfloat zf[NFIRST > 0 ? NFIRST : 1];
+                        PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) {
+                            vfloat gk = G[pg * C + 1 + kf][m][r];
+                            zv = vfma(d2 * Sr[pg * C + 1 + kf][m][r], gk, zv);
+                            zf[kf] = d1 * gk;
+                        }
+                        PINN_UNROLL for (int p = 0; p < NPAIR; ++p) {
+                            const int cp = pg * C + 1 + NFIRST + p;
+                            const int ka = S::first_rank(S::pair_a(p)), kb = S::first_rank(S::pair_b(p));
+                            vfloat za = Sr[pg * C + 1 + ka][m][r], zb = Sr[pg * C + 1 + kb][m][r];
+                            vfloat gp = G[cp][m][r];
+                            zv = vfma(vfma(d3 * za, zb, d2 * Sr[cp][m][r]), gp, zv);
+                            zf[ka] = vfma(d2 * zb, gp, zf[ka]);
+                            zf[kb] = vfma(d2 * za, gp, zf[kb]);
+                            G[cp][m][r] = d1 * gp;
+                        }
+                        G[pg * C][m][r] = zv;
+                        PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) G[pg * C + 1 + kf][m][r] = zf[kf];
+                    }
+        };
+
+        vfloat4 G[NG][MT];     // adjoint chain (dA, then dZ in place)
+        {
+            vfloat4 Sr[NG][MT];
+            load_raw(Sr, LH - 1);
+            // output layer: dW_out += sum ubar * a_jets ; dA = w_out * ubar
+            PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                bLbar += vselect(g0, ubar[pg][0], vfloat(0.f));
+                PINN_UNROLL for (int ch = 0; ch < C; ++ch)
+                    PINN_UNROLL for (int m = 0; m < MT; ++m) {
+                        vfloat4 aj = ajet(Sr, pg, ch, m);
+                        PINN_UNROLL for (int r = 0; r < 4; ++r) {
+                            wLbar[m][r] = vfma(ubar[pg][ch], aj[r], wLbar[m][r]);
+                            G[pg * C + ch][m][r] = wL[m][r] * ubar[pg][ch];
+                        }
+                    }
+            }
+            act_adjoint(G, Sr);
+        }
+
+        PINN_UNROLL for (int hl = NHH - 1; hl >= 0; --hl) {
+            // layer (hl+1) -> (hl+2) weights; inputs are hidden layer hl's a-jets
+            vfloat4 Sr[NG][MT];
+            load_raw(Sr, hl);
+            // ---- dW += dZ A^T through the swizzled LDS transpose, 16 columns at a time ----
+            PINN_UNROLL for (int q = 0; q < NG; ++q) {
+                float* zt = lds + (q & 1) * 2 * S::LDS_T;
+                float* at = zt + S::LDS_T;
+                const int pg = q / C, ch = q % C;
+                PINN_UNROLL for (int m = 0; m < MT; ++m) {
+                    const vint ad = tr_addr<S>(c, vint(4 * m) + g);
+                    lds_store4(zt, ad, G[q][m]);
+                    lds_store4(at, ad, ajet(Sr, pg, ch, m));
+                }
+                wave_fence();
+                PINN_UNROLL for (int kk = 0; kk < 4; ++kk) {
+                    const vint row = vint(4 * kk) + g;
+                    vfloat zf[MT], af[MT];
+                    if (MT == 4) {
+                        const vint ad = tr_addr<S>(row, c);
+                        vfloat4 z4 = lds_load4(zt, ad), a4 = lds_load4(at, ad);
+                        PINN_UNROLL for (int to = 0; to < MT; ++to) { zf[to] = z4[to & 3]; af[to] = a4[to & 3]; }
+                    } else {
+                        PINN_UNROLL for (int to = 0; to < MT; ++to) {
+                            const vint n = c * MT + vint(to);
+                            const vint ad = tr_addr<S>(row, n >> 2) + (n & vint(3));
+                            zf[to] = lds_load(zt, ad);
+                            af[to] = lds_load(at, ad);
+                        }
+                    }
+                    PINN_UNROLL for (int to = 0; to < MT; ++to)
+                        PINN_UNROLL for (int ti = 0; ti < MT; ++ti) wbar[hl][to][ti] = mfma16(zf[to], af[ti], wbar[hl][to][ti]);
+                    if (ch == 0) PINN_UNROLL for (int to = 0; to < MT; ++to) bfr[hl + 1][to] += zf[to];
+                }
+                wave_fence();
+            }
+            // ---- dA_prev = W^T dZ on the matrix cores (register-chained) ----
+            vfloat4 Gn[NG][MT];
+            PINN_UNROLL for (int q = 0; q < NG; ++q)
+                PINN_UNROLL for (int m = 0; m < MT; ++m) Gn[q][m] = vzero4();
+            const float* Wt = P + S::OFF_WTPK + hl * HP * HP;
+            PINN_UNROLL for (int mo = 0; mo < MT; ++mo)
+                PINN_UNROLL for (int rr = 0; rr < 4; ++rr) {
+                    vfloat wf[MT];
+                    if (MT == 4) {
+                        vfloat4 w4 = gload4(Wt, vint((mo * 4 + rr) * 64 * MT) + (lane << 2));
+                        PINN_UNROLL for (int mi = 0; mi < MT; ++mi) wf[mi] = w4[mi & 3];
+                    } else {
+                        PINN_UNROLL for (int mi = 0; mi < MT; ++mi) wf[mi] = gload(Wt, vint((mo * 4 + rr) * 64 * MT + mi) + lane * MT);
+                    }
+                    PINN_UNROLL for (int q = 0; q < NG; ++q)
+                        PINN_UNROLL for (int mi = 0; mi < MT; ++mi) Gn[q][mi] = mfma16(wf[mi], G[q][mo][rr], Gn[q][mi]);
+                }
+            PINN_UNROLL for (int q = 0; q < NG; ++q)
+                PINN_UNROLL for (int m = 0; m < MT; ++m) G[q][m] = Gn[q][m];
+            act_adjoint(G, Sr);
+        }
+
+        // ---- layer 1 (d -> HP): dW1, db1 from the transposed dZ fragments ----
+        PINN_UNROLL for (int q = 0; q < NG; ++q) {
+            const int pg = q / C, ch = q % C;
+            if (ch > NFIRST) continue;     // second-order channels of layer 1 do not depend on W1 (z_ij = 0)
+            float* zt = lds + (q & 1) * 2 * S::LDS_T;
+            PINN_UNROLL for (int m = 0; m < MT; ++m) lds_store4(zt, tr_addr<S>(c, vint(4 * m) + g), G[q][m]);
+            wave_fence();
+            PINN_UNROLL for (int kk = 0; kk < 4; ++kk) {
+                const vint row = vint(4 * kk) + g;
+                vfloat zf[MT];
+                if (MT == 4) {
+                    vfloat4 z4 = lds_load4(zt, tr_addr<S>(row, c));
+                    PINN_UNROLL for (int to = 0; to < MT; ++to) zf[to] = z4[to & 3];
+                } else {
+                    PINN_UNROLL for (int to = 0; to < MT; ++to) {
+                        const vint n = c * MT + vint(to);
+                        zf[to] = lds_load(zt, tr_addr<S>(row, n >> 2) + (n & vint(3)));
+                    }
+                }
+                if (ch == 0) {
+                    PINN_UNROLL for (int to = 0; to < MT; ++to) bfr[0][to] += zf[to];
+                    PINN_UNROLL for (int i = 0; i < D; ++i) {
+                        vfloat xc = lds_load(xs, (vint(16 * pg) + row) * D + vint(i));
+                        PINN_UNROLL for (int to = 0; to < MT; ++to) w1fr[i][to] = vfma(zf[to], xc, w1fr[i][to]);
+                    }
+                } else {
+                    const int axis = S::first_axis(ch - 1);
+                    PINN_UNROLL for (int i = 0; i < D; ++i)
+                        if (i == axis) PINN_UNROLL for (int to = 0; to < MT; ++to) w1fr[i][to] += zf[to];
+                }
+            }
+            wave_fence();
+        }
+    }  // tiles
+
+    if (MODE != MODE_FUSED) return;
+
+    // =========================== epilogue: per-wave slab ===========================
+    if (cur_term >= 0) {
+        double s = wave_sum_d(lsum, g0);
+        ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[cur_term].term_id] = s;
+    }
+    float* slab = ga.slabs + (size_t)wave * S::SLAB;
+    PINN_UNROLL for (int hl = 0; hl < NHH; ++hl)
+        PINN_UNROLL for (int to = 0; to < MT; ++to)
+            PINN_UNROLL for (int ti = 0; ti < MT; ++ti)
+                gstore4(slab + S::G_WBAR + hl * HP * HP, vint((to * MT + ti) * 256) + (lane << 2), wbar[hl][to][ti]);
+    PINN_UNROLL for (int l = 0; l < LH; ++l)
+        PINN_UNROLL for (int to = 0; to < MT; ++to) {
+            vfloat v = bfr[l][to];
+            v = v + shfl_xor(v, 16);
+            v = v + shfl_xor(v, 32);
+            gstore_masked(slab + S::G_BFR, vint((l * MT + to) * 16) + c, v, g0);
+        }
+    PINN_UNROLL for (int i = 0; i < D; ++i)
+        PINN_UNROLL for (int to = 0; to < MT; ++to) {
+            vfloat v = w1fr[i][to];
+            v = v + shfl_xor(v, 16);
+            v = v + shfl_xor(v, 32);
+            gstore_masked(slab + S::G_W1, vint((i * MT + to) * 16) + c, v, g0);
+        }
+    const vbool c0 = veq(c, 0);
+    PINN_UNROLL for (int m = 0; m < MT; ++m)
+        PINN_UNROLL for (int r = 0; r < 4; ++r) {
+            vfloat v = wLbar[m][r];
+            v = v + shfl_xor(v, 1);
+            v = v + shfl_xor(v, 2);
+            v = v + shfl_xor(v, 4);
+            v = v + shfl_xor(v, 8);
+            gstore_masked(slab + S::G_WL, ((vint(m * 4) + g) << 2) + vint(r), v, c0);
+        }
+    {
+        vbool all = vlt(lane, 64);
+        float s = (float)wave_sum_d(bLbar, all);
+        gstore_masked(slab + S::G_BL, vint(0), vfloat(s), veq(lane, 0));
+        PINN_UNROLL for (int j = 0; j < MAX_PARAMS; ++j) {
+            float sp = (float)wave_sum_d(pbar[j], all);
+            gstore_masked(slab + S::G_P, vint(j), vfloat(sp), veq(lane, 0));
+        }
+    }
+}
+
+}  // namespace pk

@@ -1,0 +1,69 @@
+// plat.hpp — the few runtime calls the engine needs, for the two builds of the SAME host code:
+//   default   : HIP runtime on a gfx950 device (the product, libpinn_hip.so)
+//   PINN_EMU  : host memory + lock-step wave emulation (tests/emu only; never shipped)
+#pragma once
+#include <cstddef>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#ifdef PINN_EMU
+typedef void* plat_stream;
+struct plat_event { double t; };
+inline const char* plat_name() { return "emu"; }
+inline int plat_init(std::string&) { return 0; }
+inline void* plat_malloc(size_t n) { return std::calloc(n ? n : 1, 1); }
+inline void plat_free(void* p) { std::free(p); }
+inline int plat_h2d(void* d, const void* s, size_t n, plat_stream) { std::memcpy(d, s, n); return 0; }
+inline int plat_d2h(void* d, const void* s, size_t n, plat_stream) { std::memcpy(d, s, n); return 0; }
+inline int plat_d2d(void* d, const void* s, size_t n, plat_stream) { std::memcpy(d, s, n); return 0; }
+inline int plat_memset(void* d, int v, size_t n, plat_stream) { std::memset(d, v, n); return 0; }
+inline int plat_sync(plat_stream) { return 0; }
+inline int plat_num_cus() { return 2; }
+inline plat_stream plat_stream_create() { return nullptr; }
+inline void plat_stream_destroy(plat_stream) {}
+inline void plat_event_create(plat_event&) {}
+inline void plat_event_destroy(plat_event&) {}
+inline void plat_event_record(plat_event&, plat_stream) {}
+inline float plat_event_ms(plat_event&, plat_event&) { return 0.f; }
+inline const char* plat_last_error() { return ""; }
+#else
+#include <hip/hip_runtime.h>
+typedef hipStream_t plat_stream;
+struct plat_event { hipEvent_t e; };
+inline const char* plat_name() { return "hip"; }
+inline const char* plat_last_error() { return hipGetErrorString(hipGetLastError()); }
+inline int plat_init(std::string& err) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        err = std::string("no HIP device available (") + hipGetErrorString(e) + "): the PINN engine has no CPU fallback";
+        return 1;
+    }
+    return 0;
+}
+inline void* plat_malloc(size_t n) {
+    void* p = nullptr;
+    if (hipMalloc(&p, n ? n : 4) != hipSuccess) return nullptr;
+    return p;
+}
+inline void plat_free(void* p) { if (p) (void)hipFree(p); }
+inline int plat_h2d(void* d, const void* s, size_t n, plat_stream st) { return hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, st) != hipSuccess; }
+inline int plat_d2h(void* d, const void* s, size_t n, plat_stream st) { return hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, st) != hipSuccess; }
+inline int plat_d2d(void* d, const void* s, size_t n, plat_stream st) { return hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, st) != hipSuccess; }
+inline int plat_memset(void* d, int v, size_t n, plat_stream st) { return hipMemsetAsync(d, v, n, st) != hipSuccess; }
+inline int plat_sync(plat_stream st) { return hipStreamSynchronize(st) != hipSuccess; }
+inline int plat_num_cus() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
+    return p.multiProcessorCount;
+}
+inline plat_stream plat_stream_create() { hipStream_t s = nullptr; (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking); return s; }
+inline void plat_stream_destroy(plat_stream s) { if (s) (void)hipStreamDestroy(s); }
+inline void plat_event_create(plat_event& e) { (void)hipEventCreate(&e.e); }
+inline void plat_event_destroy(plat_event& e) { (void)hipEventDestroy(e.e); }
+inline void plat_event_record(plat_event& e, plat_stream s) { (void)hipEventRecord(e.e, s); }
+inline float plat_event_ms(plat_event& a, plat_event& b) { float ms = 0.f; (void)hipEventElapsedTime(&ms, a.e, b.e); return ms; }
+#endif

@@ -1,0 +1,83 @@
+// spec_registry.hpp — table of compiled kernel-family members (one per translation unit inst_*.hip).
+#pragma once
+#include <vector>
+
+#include "pinn_kernels.hpp"
+#include "plat.hpp"
+
+namespace pk {
+
+struct SpecInfo {
+    int HP, NHH, D;
+    unsigned D1MASK;
+    unsigned long long PAIRS;
+    int NPAIR, PG, C, NG, TP, MT, LH, NFIRST;
+    int PACKED, SLAB, SCR, LDS_WAVE;
+    int OFF_W1, OFF_B, OFF_WL, OFF_BL, OFF_WPK, OFF_WTPK;
+    int G_WBAR, G_BFR, G_W1, G_WL, G_BL, G_P;
+    void (*launch)(const GroupArgs&, int mode, int blocks, plat_stream);
+};
+
+std::vector<SpecInfo>& registry();
+
+template <class S>
+SpecInfo make_info(void (*launch)(const GroupArgs&, int, int, plat_stream)) {
+    SpecInfo s;
+    s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR;
+    s.PG = S::PG; s.C = S::C; s.NG = S::NG; s.TP = S::TP; s.MT = S::MT; s.LH = S::LH; s.NFIRST = S::NFIRST;
+    s.PACKED = S::PACKED; s.SLAB = S::SLAB; s.SCR = S::SCR; s.LDS_WAVE = S::LDS_WAVE;
+    s.OFF_W1 = S::OFF_W1; s.OFF_B = S::OFF_B; s.OFF_WL = S::OFF_WL; s.OFF_BL = S::OFF_BL;
+    s.OFF_WPK = S::OFF_WPK; s.OFF_WTPK = S::OFF_WTPK;
+    s.G_WBAR = S::G_WBAR; s.G_BFR = S::G_BFR; s.G_W1 = S::G_W1; s.G_WL = S::G_WL; s.G_BL = S::G_BL; s.G_P = S::G_P;
+    s.launch = launch;
+    return s;
+}
+
+#ifdef PINN_EMU
+template <class S, int MODE>
+void run_emu(const GroupArgs& ga, int blocks) {
+    std::vector<float> lds((size_t)S::LDS_WAVE);
+    for (int b = 0; b < blocks; ++b)
+        for (int w = 0; w < 4; ++w) {
+            std::fill(lds.begin(), lds.end(), 0.f);
+            wave_main<S, MODE>(ga, b * 4 + w, blocks * 4, lds.data());
+        }
+}
+template <class S>
+void launch_spec(const GroupArgs& ga, int mode, int blocks, plat_stream) {
+    if (mode == MODE_FUSED) run_emu<S, MODE_FUSED>(ga, blocks);
+    else if (mode == MODE_RESID) run_emu<S, MODE_RESID>(ga, blocks);
+    else run_emu<S, MODE_FWD>(ga, blocks);
+}
+#else
+// One workgroup = 4 independent waves (one per SIMD); persistent grid of <= #CU workgroups.
+// __launch_bounds__(256, 1): one wave per SIMD => the full 512-entry unified VGPR/AGPR file per lane
+// is available for the persistent dW accumulators (MI355X_MICROARCH.md "Register files").
+template <class S, int MODE>
+__global__ void __launch_bounds__(256, 1) k_wave(const GroupArgs ga) {
+    __shared__ __attribute__((aligned(16))) float lds_all[4 * S::LDS_WAVE];
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    wave_main<S, MODE>(ga, (int)blockIdx.x * 4 + w, (int)gridDim.x * 4, lds_all + w * S::LDS_WAVE);
+}
+template <class S>
+void launch_spec(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
+    if (mode == MODE_FUSED) hipLaunchKernelGGL((k_wave<S, MODE_FUSED>), dim3(blocks), dim3(256), 0, st, ga);
+    else if (mode == MODE_RESID) hipLaunchKernelGGL((k_wave<S, MODE_RESID>), dim3(blocks), dim3(256), 0, st, ga);
+    else hipLaunchKernelGGL((k_wave<S, MODE_FWD>), dim3(blocks), dim3(256), 0, st, ga);
+}
+#endif
+
+struct Registrar {
+    explicit Registrar(const SpecInfo& s) { registry().push_back(s); }
+};
+
+// PAIRS encoding: pair p occupies byte p: low nibble = axis a, high nibble = axis b (a <= b)
+#define PINN_PAIR(p, a, b) (((unsigned long long)((a) | ((b) << 4))) << (8 * (p)))
+
+#define PINN_INSTANTIATE(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG)                         \
+    namespace {                                                                              \
+    using NAME##_spec = pk::Spec<HP, NHH, D, D1MASK, PAIRS, NPAIR, PG>;                      \
+    pk::Registrar NAME##_reg(pk::make_info<NAME##_spec>(&pk::launch_spec<NAME##_spec>));     \
+    }
+
+}  // namespace pk

@@ -1,0 +1,169 @@
+// vec.hpp — lane-vector vocabulary for the wave-level kernels.
+//
+// Device build (hipcc, gfx950): vfloat/vint/vbool are plain per-lane scalars, every helper is a
+// one-instruction inline wrapper (MFMA builtin, ds_*/global_* accesses, DPP/bpermute shuffles).
+//
+// PINN_EMU build (g++, tests only): the same names are 64-wide value arrays executed in lock-step
+// on the host, with v_mfma_f32_16x16x4_f32 lane semantics restated from
+// /opt/skills/guides/cdna_hip_programming.md §3.  The emulation exists so that tests/ can run the
+// *actual kernel source* on a GPU-less box against the oracle; it is never linked into
+// libpinn_hip.so and is not a product fallback.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#ifdef PINN_EMU
+// ------------------------------------------------------------------------------------------
+// host lock-step emulation of one 64-lane wavefront
+// ------------------------------------------------------------------------------------------
+#define DEV inline
+#define HD inline
+#define PINN_UNROLL
+namespace wv {
+constexpr int W = 64;
+struct vbool { bool v[W]; };
+struct vint {
+    int v[W];
+    vint() {}
+    vint(int s) { for (int l = 0; l < W; ++l) v[l] = s; }
+};
+struct vfloat {
+    float v[W];
+    vfloat() {}
+    vfloat(float s) { for (int l = 0; l < W; ++l) v[l] = s; }
+};
+#define VOP2(T, op) \
+    inline T operator op(const T& a, const T& b) { T r; for (int l = 0; l < W; ++l) r.v[l] = a.v[l] op b.v[l]; return r; }
+VOP2(vfloat, +) VOP2(vfloat, -) VOP2(vfloat, *) VOP2(vfloat, /)
+VOP2(vint, +) VOP2(vint, -) VOP2(vint, *) VOP2(vint, &) VOP2(vint, ^) VOP2(vint, |)
+#undef VOP2
+inline vint operator>>(const vint& a, int s) { vint r; for (int l = 0; l < W; ++l) r.v[l] = a.v[l] >> s; return r; }
+inline vint operator<<(const vint& a, int s) { vint r; for (int l = 0; l < W; ++l) r.v[l] = a.v[l] << s; return r; }
+inline vfloat operator-(const vfloat& a) { vfloat r; for (int l = 0; l < W; ++l) r.v[l] = -a.v[l]; return r; }
+inline vfloat& operator+=(vfloat& a, const vfloat& b) { for (int l = 0; l < W; ++l) a.v[l] += b.v[l]; return a; }
+inline vfloat& operator*=(vfloat& a, const vfloat& b) { for (int l = 0; l < W; ++l) a.v[l] *= b.v[l]; return a; }
+struct vfloat4 {
+    vfloat x[4];
+    vfloat& operator[](int i) { return x[i]; }
+    const vfloat& operator[](int i) const { return x[i]; }
+};
+inline vint lane_id() { vint r; for (int l = 0; l < W; ++l) r.v[l] = l; return r; }
+inline vfloat vfma(const vfloat& a, const vfloat& b, const vfloat& c) {
+    vfloat r; for (int l = 0; l < W; ++l) r.v[l] = std::fmaf(a.v[l], b.v[l], c.v[l]); return r;
+}
+#define VFN1(name, expr) \
+    inline vfloat name(const vfloat& a) { vfloat r; for (int l = 0; l < W; ++l) { float x = a.v[l]; r.v[l] = (expr); } return r; }
+VFN1(vtanh, std::tanh(x)) VFN1(vsin, std::sin(x)) VFN1(vcos, std::cos(x)) VFN1(vexp, std::exp(x))
+VFN1(vlog, std::log(x)) VFN1(vsqrt, std::sqrt(x)) VFN1(vabs, std::fabs(x)) VFN1(vsinh, std::sinh(x))
+VFN1(vcosh, std::cosh(x)) VFN1(vtan, std::tan(x)) VFN1(vrcp, 1.0f / x)
+VFN1(vsign, (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f))
+VFN1(vsinpi, std::sin(3.14159265358979323846f * x)) VFN1(vcospi, std::cos(3.14159265358979323846f * x))
+#undef VFN1
+inline vfloat vpow(const vfloat& a, const vfloat& b) { vfloat r; for (int l = 0; l < W; ++l) r.v[l] = std::pow(a.v[l], b.v[l]); return r; }
+inline vfloat vmax(const vfloat& a, const vfloat& b) { vfloat r; for (int l = 0; l < W; ++l) r.v[l] = a.v[l] > b.v[l] ? a.v[l] : b.v[l]; return r; }
+inline vfloat vmin(const vfloat& a, const vfloat& b) { vfloat r; for (int l = 0; l < W; ++l) r.v[l] = a.v[l] < b.v[l] ? a.v[l] : b.v[l]; return r; }
+inline vbool vlt(const vint& a, int b) { vbool r; for (int l = 0; l < W; ++l) r.v[l] = a.v[l] < b; return r; }
+inline vbool veq(const vint& a, int b) { vbool r; for (int l = 0; l < W; ++l) r.v[l] = a.v[l] == b; return r; }
+inline vbool vgt(const vfloat& a, const vfloat& b) { vbool r; for (int l = 0; l < W; ++l) r.v[l] = a.v[l] > b.v[l]; return r; }
+inline vbool vand(const vbool& a, const vbool& b) { vbool r; for (int l = 0; l < W; ++l) r.v[l] = a.v[l] && b.v[l]; return r; }
+inline vfloat vselect(const vbool& m, const vfloat& a, const vfloat& b) { vfloat r; for (int l = 0; l < W; ++l) r.v[l] = m.v[l] ? a.v[l] : b.v[l]; return r; }
+inline vint vselect(const vbool& m, const vint& a, const vint& b) { vint r; for (int l = 0; l < W; ++l) r.v[l] = m.v[l] ? a.v[l] : b.v[l]; return r; }
+// global memory
+inline vfloat gload(const float* p, const vint& i) { vfloat r; for (int l = 0; l < W; ++l) r.v[l] = p[i.v[l]]; return r; }
+inline vfloat gload_masked(const float* p, const vint& i, const vbool& m) { vfloat r; for (int l = 0; l < W; ++l) r.v[l] = m.v[l] ? p[i.v[l]] : 0.f; return r; }
+inline void gstore(float* p, const vint& i, const vfloat& x) { for (int l = 0; l < W; ++l) p[i.v[l]] = x.v[l]; }
+inline void gstore_masked(float* p, const vint& i, const vfloat& x, const vbool& m) { for (int l = 0; l < W; ++l) if (m.v[l]) p[i.v[l]] = x.v[l]; }
+inline vfloat4 gload4(const float* p, const vint& i) { vfloat4 r; for (int k = 0; k < 4; ++k) for (int l = 0; l < W; ++l) r.x[k].v[l] = p[i.v[l] + k]; return r; }
+inline void gstore4(float* p, const vint& i, const vfloat4& x) { for (int k = 0; k < 4; ++k) for (int l = 0; l < W; ++l) p[i.v[l] + k] = x.x[k].v[l]; }
+// LDS (per-wave private region in the emulation == a plain array)
+inline vfloat lds_load(const float* p, const vint& i) { return gload(p, i); }
+inline void lds_store(float* p, const vint& i, const vfloat& x) { gstore(p, i, x); }
+inline vfloat4 lds_load4(const float* p, const vint& i) { return gload4(p, i); }
+inline void lds_store4(float* p, const vint& i, const vfloat4& x) { gstore4(p, i, x); }
+inline void wave_fence() {}
+// cross-lane
+inline vfloat shfl_xor(const vfloat& a, int m) { vfloat r; for (int l = 0; l < W; ++l) r.v[l] = a.v[l ^ m]; return r; }
+inline float lane0(const vfloat& a) { return a.v[0]; }
+inline double wave_sum_d(const vfloat& a, const vbool& m) { double s = 0; for (int l = 0; l < W; ++l) if (m.v[l]) s += (double)a.v[l]; return s; }
+// v_mfma_f32_16x16x4_f32: D[i][j] += sum_k A[i][k] B[k][j]; lane l supplies A[i=l&15][k=l>>4] and
+// B[k=l>>4][j=l&15]; lane l holds D[row=(l>>4)*4+r][col=l&15], r=0..3. k-ordered fmaf chain.
+inline vfloat4 mfma16(const vfloat& a, const vfloat& b, const vfloat4& c) {
+    vfloat4 d;
+    for (int l = 0; l < W; ++l)
+        for (int r = 0; r < 4; ++r) {
+            int row = (l >> 4) * 4 + r, col = l & 15;
+            float acc = c.x[r].v[l];
+            for (int k = 0; k < 4; ++k) acc = std::fmaf(a.v[k * 16 + row], b.v[k * 16 + col], acc);
+            d.x[r].v[l] = acc;
+        }
+    return d;
+}
+inline vfloat4 vzero4() { vfloat4 z; for (int k = 0; k < 4; ++k) z.x[k] = vfloat(0.f); return z; }
+}  // namespace wv
+#else
+// ------------------------------------------------------------------------------------------
+// gfx950 device build
+// ------------------------------------------------------------------------------------------
+#include <hip/hip_runtime.h>
+#define DEV __device__ __forceinline__
+#define HD __host__ __device__ __forceinline__
+#define PINN_UNROLL _Pragma("unroll")
+namespace wv {
+using vfloat = float;
+using vint = int;
+using vbool = bool;
+typedef float vfloat4 __attribute__((ext_vector_type(4)));
+DEV vint lane_id() { return (int)(threadIdx.x & 63); }
+DEV vfloat vfma(vfloat a, vfloat b, vfloat c) { return __builtin_fmaf(a, b, c); }
+DEV vfloat vtanh(vfloat x) { return tanhf(x); }
+DEV vfloat vsin(vfloat x) { return sinf(x); }
+DEV vfloat vcos(vfloat x) { return cosf(x); }
+DEV vfloat vtan(vfloat x) { return tanf(x); }
+DEV vfloat vexp(vfloat x) { return expf(x); }
+DEV vfloat vlog(vfloat x) { return logf(x); }
+DEV vfloat vsqrt(vfloat x) { return sqrtf(x); }
+DEV vfloat vabs(vfloat x) { return fabsf(x); }
+DEV vfloat vsinh(vfloat x) { return sinhf(x); }
+DEV vfloat vcosh(vfloat x) { return coshf(x); }
+DEV vfloat vrcp(vfloat x) { return 1.0f / x; }
+DEV vfloat vsign(vfloat x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
+DEV vfloat vsinpi(vfloat x) { return sinpif(x); }
+DEV vfloat vcospi(vfloat x) { return cospif(x); }
+DEV vfloat vpow(vfloat a, vfloat b) { return powf(a, b); }
+DEV vfloat vmax(vfloat a, vfloat b) { return fmaxf(a, b); }
+DEV vfloat vmin(vfloat a, vfloat b) { return fminf(a, b); }
+DEV vbool vlt(vint a, int b) { return a < b; }
+DEV vbool veq(vint a, int b) { return a == b; }
+DEV vbool vgt(vfloat a, vfloat b) { return a > b; }
+DEV vbool vand(vbool a, vbool b) { return a && b; }
+DEV vfloat vselect(vbool m, vfloat a, vfloat b) { return m ? a : b; }
+DEV vint vselect(vbool m, vint a, vint b) { return m ? a : b; }
+DEV vfloat gload(const float* p, vint i) { return p[i]; }
+DEV vfloat gload_masked(const float* p, vint i, vbool m) { return m ? p[i] : 0.f; }
+DEV void gstore(float* p, vint i, vfloat x) { p[i] = x; }
+DEV void gstore_masked(float* p, vint i, vfloat x, vbool m) { if (m) p[i] = x; }
+DEV vfloat4 gload4(const float* p, vint i) { return *reinterpret_cast<const vfloat4*>(p + i); }
+DEV void gstore4(float* p, vint i, vfloat4 x) { *reinterpret_cast<vfloat4*>(p + i) = x; }
+DEV vfloat lds_load(const float* p, vint i) { return p[i]; }
+DEV void lds_store(float* p, vint i, vfloat x) { p[i] = x; }
+DEV vfloat4 lds_load4(const float* p, vint i) { return *reinterpret_cast<const vfloat4*>(p + i); }
+DEV void lds_store4(float* p, vint i, vfloat4 x) { *reinterpret_cast<vfloat4*>(p + i) = x; }
+// Orders this wave's LDS traffic as seen by its OTHER lanes: DS ops of one wave execute in issue
+// order, so only the compiler must be stopped from reordering a lane's read above another lane's
+// write (it cannot see the cross-lane dependence).
+DEV void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+DEV vfloat shfl_xor(vfloat a, int m) { return __shfl_xor(a, m, 64); }
+DEV float lane0(vfloat a) { return __builtin_amdgcn_readfirstlane(a); }
+DEV double wave_sum_d(vfloat a, vbool m) {
+    double s = m ? (double)a : 0.0;
+    PINN_UNROLL for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    return s;
+}
+DEV vfloat4 mfma16(vfloat a, vfloat b, vfloat4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+DEV vfloat4 vzero4() { return vfloat4{0.f, 0.f, 0.f, 0.f}; }
+}  // namespace wv
+#endif

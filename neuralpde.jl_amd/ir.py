@@ -1,0 +1,85 @@
+"""Residual IR ("pinnir 1"): the serialisable problem description handed to `pinn_create`.
+
+It carries exactly the information `symbolic_discretize` extracts from a PDESystem in the reference
+(src/discretize.jl:413-545): the chains, the flat-theta layout, and per equation / boundary
+condition the residual expression with its `u(...)` / `derivative(...)` call sites — here as jet
+slots plus a straight-line SSA tape instead of a Julia Expr (src/symbolic_utilities.jl:132-331).
+
+Row numbering inside a term (descriptor side):
+    [0, d)                 coordinates, in the positional order of `this_eq_indvars` (discretize.jl:126-131)
+    [d, d+NP)              PDE parameters (theta.p when param_estim, else default_p; discretize.jl:83-109)
+    [d+NP, d+NP+S)         jet slots
+    [d+NP+S, ...)          ops
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Sequence, Tuple
+
+OPS = ["CONST", "ADD", "SUB", "MUL", "DIV", "NEG", "ADDC", "MULC", "POWI", "POW", "POWC", "SIN", "COS", "TAN", "EXP",
+       "LOG", "SQRT", "ABS", "TANH", "SINH", "COSH", "SECH", "SINPI", "COSPI", "MAX", "MIN"]
+BINARY = {"ADD", "SUB", "MUL", "DIV", "POW", "MAX", "MIN"}
+NULLARY = {"CONST"}
+
+
+@dataclass(frozen=True)
+class Slot:
+    net: int
+    axes: Tuple[int, ...]        # () = value; (i,) = d/dx_i; (i, j) = d2/dx_i dx_j  (net-input axis numbers, sorted)
+
+    @property
+    def order(self) -> int:
+        return len(self.axes)
+
+
+@dataclass
+class Instr:
+    op: str
+    a: int = 0
+    b: int = 0
+    imm: float = 0.0
+
+
+@dataclass
+class TermIR:
+    dim: int
+    slots: List[Slot]
+    ops: List[Instr]
+    out_row: int
+    indvars: Tuple[str, ...] = ()       # names bound to the rows of `cord`
+    kind: str = "pde"                   # "pde" | "bc"
+    source: str = ""                    # printable form of lhs - rhs
+
+
+@dataclass
+class NetIR:
+    sizes: Tuple[int, ...]
+    act: str
+    theta_off: int
+
+
+@dataclass
+class ProblemIR:
+    ntheta: int
+    nets: List[NetIR]
+    terms: List[TermIR]
+    nparams: int = 0
+    nparams_estim: int = 0
+    p_theta_off: int = 0
+    p_defaults: Sequence[float] = ()
+
+    def to_descriptor(self) -> str:
+        out = ["pinnir 1", f"ntheta {self.ntheta}",
+               f"params {self.nparams} {self.nparams_estim} {self.p_theta_off}",
+               "defaults " + " ".join(repr(float(v)) for v in list(self.p_defaults)[: self.nparams]),
+               f"nets {len(self.nets)}"]
+        for i, n in enumerate(self.nets):
+            out.append(f"net {i} {n.act} {n.theta_off} {len(n.sizes)} " + " ".join(str(s) for s in n.sizes))
+        out.append(f"terms {len(self.terms)}")
+        for i, t in enumerate(self.terms):
+            out.append(f"term {i} {t.dim} {len(t.slots)} {len(t.ops)} {t.out_row}")
+            for s in t.slots:
+                out.append(f"slot {s.net} {s.order} " + " ".join(str(a) for a in s.axes))
+            for q in t.ops:
+                out.append(f"op {q.op} {q.a} {q.b} {float(q.imm)!r}")
+        return "\n".join(out) + "\n"

@@ -1,0 +1,400 @@
+"""PhysicsInformedNN / discretize / symbolic_discretize — host-side mirror of the reference's discretizer
+API for the PINN hot path, on top of the HIP engine.
+
+Reference surface mirrored (same names, argument meaning, error behaviour):
+  Chain / Dense                       [3P] Lux (only Dense chains; DGM etc. are out of scope)
+  Phi                                 src/pinn_types.jl:79-90
+  PhysicsInformedNN(chain, strategy; init_params, param_estim, additional_loss, adaptive_loss, logger,
+                    log_options, iteration)                                 src/pinn_types.jl:147-211
+  NonAdaptiveLoss                     src/adaptive_losses.jl:22-42
+  symbolic_discretize -> PINNRepresentation   src/discretize.jl:413-767, src/pinn_types.jl:257-440
+  discretize -> OptimizationProblem   src/discretize.jl:776-780
+What the reference does with RuntimeGeneratedFunctions + Zygote per iteration is one `pinn_loss_grad`
+call into libpinn_hip.so here.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .ir import NetIR, ProblemIR, TermIR
+from .strategies import AbstractTrainingStrategy
+from .symbolic import Equation, PDESystem, VarInfo, get_vars, lower_equation
+
+
+# ------------------------------------------------------------------------------------------------
+# chains
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class Dense:
+    """Lux.Dense(in => out, activation)."""
+    n_in: int
+    n_out: int
+    activation: str = "identity"
+
+
+class Chain:
+    """Lux.Chain of Dense layers.  The engine supports the shape every PINN chain in the reference's PDE tests
+    has: one activation on all hidden layers, identity on the last, single output."""
+
+    def __init__(self, *layers: Dense):
+        if not layers:
+            raise ValueError("Chain needs at least one layer")
+        for a, b in zip(layers[:-1], layers[1:]):
+            if a.n_out != b.n_in:
+                raise ValueError("DimensionMismatch: consecutive Dense layers do not chain")
+        self.layers = list(layers)
+        self.sizes = tuple([layers[0].n_in] + [l.n_out for l in layers])
+        acts = {l.activation for l in layers[:-1]}
+        if len(layers) < 2:
+            raise ValueError("the HIP engine needs at least one hidden layer")
+        if len(acts) != 1:
+            raise ValueError("the HIP engine needs the same activation on every hidden layer")
+        if layers[-1].activation != "identity":
+            raise ValueError("the last layer must have identity activation")
+        self.act = acts.pop()
+        if self.act in ("σ", "sigmoid_fast"):
+            self.act = "sigmoid"
+        if self.act == "tanh_fast":
+            self.act = "tanh"
+
+    @property
+    def nparams(self) -> int:
+        return sum(l.n_in * l.n_out + l.n_out for l in self.layers)
+
+
+def initialparameters(rng: np.random.Generator, chain: Chain, dtype=np.float64) -> np.ndarray:
+    """[3P] Lux.initialparameters for Dense: glorot_uniform weights, zero bias; flattened in ComponentArrays
+    order [W1 (out x in, column-major) | b1 | ...]."""
+    parts = []
+    for l in chain.layers:
+        lim = math.sqrt(6.0 / (l.n_in + l.n_out))
+        W = rng.uniform(-lim, lim, size=(l.n_out, l.n_in))
+        parts += [W.T.reshape(-1), np.zeros(l.n_out)]
+    return np.concatenate(parts).astype(dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# discretizer types
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class LogOptions:
+    """src/pinn_types.jl:7-17."""
+    log_frequency: int = 50
+
+
+@dataclass
+class NonAdaptiveLoss:
+    """NonAdaptiveLoss(; pde_loss_weights = 1, bc_loss_weights = 1, additional_loss_weights = 1) —
+    src/adaptive_losses.jl:22-42; scalars are broadcast to the number of terms (src/discretize.jl:553-559)."""
+    pde_loss_weights: object = 1.0
+    bc_loss_weights: object = 1.0
+    additional_loss_weights: object = 1.0
+
+
+class PhysicsInformedNN:
+    """PhysicsInformedNN(chain, strategy; ...) — src/pinn_types.jl:165-211.
+    `chain` is one Chain or a list with one single-output Chain per dependent variable (:106-108)."""
+
+    def __init__(self, chain, strategy: AbstractTrainingStrategy, *, init_params=None, phi=None, derivative=None,
+                 param_estim: bool = False, additional_loss: Optional[Callable] = None, adaptive_loss=None,
+                 logger=None, log_options: LogOptions = LogOptions(), iteration=None, **kwargs):
+        if phi is not None or derivative is not None:
+            raise ValueError("custom `phi` / `derivative` closures are per-call Julia hooks (src/pinn_types.jl:166-167) "
+                             "and cannot be fused into the HIP kernels; they are not supported by this backend")
+        self.chain = list(chain) if isinstance(chain, (list, tuple)) else [chain]
+        self.multioutput = isinstance(chain, (list, tuple))
+        self.strategy = strategy
+        self.init_params = init_params
+        self.param_estim = param_estim
+        self.additional_loss = additional_loss
+        self.adaptive_loss = adaptive_loss
+        self.logger = logger
+        self.log_options = log_options
+        if iteration is None:                      # src/pinn_types.jl:195-204
+            self.iteration, self.self_increment = [1], True
+        else:
+            self.iteration, self.self_increment = iteration, False
+        self.kwargs = kwargs                       # stored, never used — as in the reference (:162, :209)
+        self.phi = None                            # filled by symbolic_discretize
+
+
+class Phi:
+    """Trial function handle: `phi(x, theta)` evaluates the network (src/pinn_types.jl:88-90).  x: (d,) or (d x N)."""
+
+    def __init__(self, engine: "_lib.Engine", net: int, theta_slice: slice, d: int):
+        self.engine, self.net, self.d = engine, net, d
+
+    def __call__(self, x, theta):
+        x = np.asarray(x, dtype=np.float64)
+        single = x.ndim == 1
+        pts = x.reshape(self.d, -1) if not single else x.reshape(self.d, 1)
+        out = self.engine.phi(self.net, theta, pts).astype(np.float64).reshape(1, -1)
+        return out[:, 0] if single else out
+
+
+@dataclass
+class PINNLossFunctions:
+    """src/pinn_types.jl:414-440."""
+    bc_loss_functions: List[Callable]
+    pde_loss_functions: List[Callable]
+    full_loss_function: Callable
+    additional_loss_function: Optional[Callable]
+    datafree_pde_loss_functions: List[Callable]
+    datafree_bc_loss_functions: List[Callable]
+
+
+@dataclass
+class PINNRepresentation:
+    """src/pinn_types.jl:257-403 (the fields the hot path uses)."""
+    eqs: list
+    bcs: list
+    domains: list
+    eq_params: tuple
+    defaults: Optional[dict]
+    default_p: Optional[np.ndarray]
+    param_estim: bool
+    additional_loss: Optional[Callable]
+    adaloss: NonAdaptiveLoss
+    depvars: list
+    indvars: list
+    dict_indvars: dict
+    dict_depvars: dict
+    dict_depvar_input: dict
+    logger: object
+    multioutput: bool
+    iteration: list
+    init_params: np.ndarray
+    flat_init_params: np.ndarray
+    phi: object
+    strategy: object
+    pde_indvars: list
+    bc_indvars: list
+    symbolic_pde_loss_functions: List[TermIR]
+    symbolic_bc_loss_functions: List[TermIR]
+    loss_functions: Optional[PINNLossFunctions] = None
+    ir: Optional[ProblemIR] = None
+    engine: Optional[object] = None
+    pde_train_sets: Optional[list] = None
+    bcs_train_sets: Optional[list] = None
+
+
+class OptimizationFunction:
+    """[3P] SciMLBase.OptimizationFunction(f, AutoZygote()) stand-in with an explicit gradient."""
+
+    def __init__(self, f: Callable, value_and_grad: Callable):
+        self.f, self.value_and_grad = f, value_and_grad
+
+    def __call__(self, theta, p=None):
+        return self.f(theta, p)
+
+    def grad(self, theta, p=None):
+        return self.value_and_grad(theta)[1]
+
+
+@dataclass
+class OptimizationProblem:
+    """[3P] SciMLBase.OptimizationProblem(f, u0)."""
+    f: OptimizationFunction
+    u0: np.ndarray
+    p: object = None
+
+
+def remake(prob: OptimizationProblem, u0=None) -> OptimizationProblem:
+    """`remake(prob, u0 = res.u)` — the reference's resume idiom (test/NNPDE1/nnpde__pde_ii_2d_poisson.jl:84-85)."""
+    return OptimizationProblem(prob.f, prob.u0 if u0 is None else np.asarray(u0), prob.p)
+
+
+# ------------------------------------------------------------------------------------------------
+# symbolic_discretize / discretize
+# ------------------------------------------------------------------------------------------------
+def _broadcast_weights(w, n: int) -> np.ndarray:
+    a = np.ones(n) * np.asarray(w, dtype=np.float64)      # errors like the reference if lengths mismatch
+    return a
+
+
+def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN) -> PINNRepresentation:
+    """src/discretize.jl:413-767."""
+    eqs, bcs = list(pde_system.eqs), list(pde_system.bcs)
+    if not bcs:
+        raise TypeError("MethodError: PDESystem without boundary conditions (the reference fails at solve time, "
+                        "test/direct_function__empty_boundary_condition_fails_in_solve_phase.jl:24)")
+    vi = get_vars(pde_system.ivs, pde_system.dvs)
+    chains = discretization.chain
+    if len(chains) != len(vi.depvars):
+        raise ValueError(f"{len(vi.depvars)} dependent variables need {len(vi.depvars)} single-output chains "
+                         f"(src/pinn_types.jl:106-108); got {len(chains)}")
+    for ch in chains:
+        if ch.sizes[-1] != 1:
+            raise ValueError("each chain must have a single output (one chain per dependent variable)")
+    eq_params = tuple(pde_system.ps)
+    defaults = pde_system.defaults
+    param_estim = discretization.param_estim
+    default_p = None
+    if eq_params:
+        if defaults is None:
+            raise ValueError("PDESystem with parameters needs `defaults`")
+        default_p = np.array([float(defaults[p]) for p in eq_params], dtype=np.float64)
+
+    # ---- flat init params (src/discretize.jl:432-465): Float64 unless the user passed Float32 ----
+    net_offs, o = [], 0
+    for ch in chains:
+        net_offs.append(o)
+        o += ch.nparams
+    nnet = o
+    if discretization.init_params is None:
+        rng = np.random.default_rng()
+        flat = np.concatenate([initialparameters(rng, ch, np.float64) for ch in chains])
+    else:
+        ip = discretization.init_params
+        flat = np.concatenate([np.asarray(a).reshape(-1) for a in ip]) if isinstance(ip, (list, tuple)) else np.asarray(ip).reshape(-1)
+        if flat.size != nnet:
+            raise ValueError(f"init_params has {flat.size} entries, the chains need {nnet}")
+    if param_estim and eq_params:
+        flat = np.concatenate([flat, default_p.astype(flat.dtype)])      # theta.p block (:457-462)
+    dtype = flat.dtype if flat.dtype in (np.float32, np.float64) else np.float64
+
+    # ---- residual IR per equation / bc (src/discretize.jl:505-525) ----
+    sym_pde = [lower_equation(eq, vi, eq_params, "pde") for eq in eqs]
+    sym_bc = []
+    for bc in bcs:
+        if bc.lhs.is_Number and bc.rhs.is_Number:
+            raise ValueError("ArgumentError: boundary condition without a dependent variable "
+                             "(test/direct_function__trivial_bc_0_0_*.jl:44)")
+        sym_bc.append(lower_equation(bc, vi, eq_params, "bc"))
+    terms = sym_pde + sym_bc
+    for t in terms:
+        for s in t.slots:
+            name = vi.depvars[s.net]
+            if vi.dict_depvar_input[name] != list(t.indvars):
+                raise NotImplementedError(
+                    f"heterogeneous inputs: {name} takes {vi.dict_depvar_input[name]} but the term binds {list(t.indvars)}; "
+                    "per-network input subsets (test/NNPDE1/nnpde__pde_i_heterogeneous_system.jl) are not supported yet")
+
+    NP = len(eq_params)
+    NE = NP if (param_estim and NP) else 0
+    ir = ProblemIR(
+        ntheta=int(flat.size),
+        nets=[NetIR(tuple(ch.sizes), ch.act, off) for ch, off in zip(chains, net_offs)],
+        terms=terms, nparams=NP, nparams_estim=NE, p_theta_off=nnet,
+        p_defaults=list(default_p) if default_p is not None else [])
+    engine = _lib.Engine(ir.to_descriptor())
+
+    # ---- strategy: point sets (src/discretize.jl:541-545) ----
+    strategy = discretization.strategy
+    pde_sets, bc_sets, resample = strategy.point_sets(pde_system, vi, dtype)
+    n_pde, n_bc = len(eqs), len(bcs)
+
+    def install(pde_sets, bc_sets):
+        for k, s in enumerate(list(pde_sets) + list(bc_sets)):
+            if s.shape[0] != terms[k].dim:
+                raise ValueError(f"point set of term {k} has {s.shape[0]} rows, the term binds {terms[k].dim} variables")
+            engine.set_points(k, s)
+
+    install(pde_sets, bc_sets)
+    state = {"pde_sets": pde_sets, "bc_sets": bc_sets, "cache_theta": None, "cache": None}
+
+    adaloss = discretization.adaptive_loss or NonAdaptiveLoss()
+    if not isinstance(adaloss, NonAdaptiveLoss):
+        raise NotImplementedError("only NonAdaptiveLoss weights are wired up in this round; adaptive reweighting "
+                                  "(src/adaptive_losses.jl) consumes pinn_term_grads / per-term losses and stays on the host")
+    w_pde = _broadcast_weights(adaloss.pde_loss_weights, n_pde)
+    w_bc = _broadcast_weights(adaloss.bc_loss_weights, n_bc)
+    weights = np.concatenate([w_pde, w_bc])
+    iteration = discretization.iteration
+
+    def evaluate(theta, want_grad=True):
+        """one fused engine call; memoised on theta so the per-term closures and the full loss share it"""
+        th = np.asarray(theta)
+        key = th.tobytes()
+        if resample is None and state["cache_theta"] == key and (state["cache"][1] is not None or not want_grad):
+            return state["cache"]
+        if resample is not None:
+            ps, bs = resample()
+            state["pde_sets"], state["bc_sets"] = ps, bs
+            install(ps, bs)
+        losses, grad = engine.loss_grad(th, weights, want_grad=want_grad)
+        state["cache_theta"], state["cache"] = key, (losses, grad)
+        return losses, grad
+
+    def term_loss(k):
+        def f(theta):
+            return float(evaluate(theta, want_grad=False)[0][k])
+        return f
+
+    def datafree(k):
+        def f(cord, theta):
+            """(cord, theta) -> 1 x N residual (src/discretize.jl:174)."""
+            cord = np.asarray(cord)
+            engine.set_points(k, cord)
+            r = engine.residual(k, np.asarray(theta), cord.shape[1]).astype(np.float64).reshape(1, -1)
+            engine.set_points(k, (state["pde_sets"] + state["bc_sets"])[k])
+            state["cache_theta"] = None
+            return r
+        return f
+
+    additional_loss = discretization.additional_loss
+
+    def value_and_grad(theta):
+        losses, grad = evaluate(theta, want_grad=True)
+        total = float(np.dot(weights, losses))
+        g = grad.astype(np.asarray(theta).dtype if np.asarray(theta).dtype in (np.float32, np.float64) else np.float64)
+        if additional_loss is not None:
+            add = additional_loss(phi, np.asarray(theta)[:nnet] if param_estim else theta,
+                                  np.asarray(theta)[nnet:] if param_estim else None)
+            if isinstance(add, tuple):
+                total += float(_broadcast_weights(adaloss.additional_loss_weights, 1)[0]) * float(add[0])
+                g = g + float(_broadcast_weights(adaloss.additional_loss_weights, 1)[0]) * np.asarray(add[1])
+            else:
+                total += float(_broadcast_weights(adaloss.additional_loss_weights, 1)[0]) * float(add)
+        return total, g
+
+    def full_loss_function(theta, p=None):
+        """src/discretize.jl:567-598."""
+        losses, _ = evaluate(theta, want_grad=False)
+        if discretization.self_increment:
+            iteration[0] += 1
+        total = float(np.dot(weights, losses))
+        if additional_loss is not None:
+            add = additional_loss(phi, np.asarray(theta)[:nnet] if param_estim else theta,
+                                  np.asarray(theta)[nnet:] if param_estim else None)
+            total += float(_broadcast_weights(adaloss.additional_loss_weights, 1)[0]) * float(add[0] if isinstance(add, tuple) else add)
+        return total
+
+    phis = [Phi(engine, i, slice(net_offs[i], net_offs[i] + chains[i].nparams), chains[i].sizes[0]) for i in range(len(chains))]
+    phi = phis if discretization.multioutput else phis[0]
+    discretization.phi = phi
+
+    rep = PINNRepresentation(
+        eqs=eqs, bcs=bcs, domains=list(pde_system.domain), eq_params=eq_params, defaults=defaults, default_p=default_p,
+        param_estim=param_estim, additional_loss=additional_loss, adaloss=adaloss, depvars=vi.depvars, indvars=vi.indvars,
+        dict_indvars=vi.dict_indvars, dict_depvars=vi.dict_depvars, dict_depvar_input=vi.dict_depvar_input,
+        logger=discretization.logger, multioutput=discretization.multioutput, iteration=iteration,
+        init_params=flat[:nnet], flat_init_params=flat, phi=phi, strategy=strategy,
+        pde_indvars=[list(t.indvars) for t in sym_pde], bc_indvars=[list(t.indvars) for t in sym_bc],
+        symbolic_pde_loss_functions=sym_pde, symbolic_bc_loss_functions=sym_bc, ir=ir, engine=engine,
+        pde_train_sets=pde_sets, bcs_train_sets=bc_sets)
+    rep.loss_functions = PINNLossFunctions(
+        bc_loss_functions=[term_loss(n_pde + j) for j in range(n_bc)],
+        pde_loss_functions=[term_loss(i) for i in range(n_pde)],
+        full_loss_function=full_loss_function, additional_loss_function=additional_loss,
+        datafree_pde_loss_functions=[datafree(i) for i in range(n_pde)],
+        datafree_bc_loss_functions=[datafree(n_pde + j) for j in range(n_bc)])
+    rep._value_and_grad = value_and_grad
+    rep._weights = weights
+    rep._state = state
+    return rep
+
+
+def discretize(pde_system: PDESystem, discretization: PhysicsInformedNN) -> OptimizationProblem:
+    """src/discretize.jl:776-780: OptimizationProblem(OptimizationFunction(full_loss_function, AutoZygote()),
+    flat_init_params) — with the engine's reverse-mode gradient in place of Zygote."""
+    rep = symbolic_discretize(pde_system, discretization)
+    f = OptimizationFunction(rep.loss_functions.full_loss_function, rep._value_and_grad)
+    prob = OptimizationProblem(f, rep.flat_init_params)
+    prob.pinnrep = rep
+    return prob

@@ -1,0 +1,188 @@
+"""Training strategies = collocation point sets (host side).
+
+Mirror of src/training_strategies.jl (GridTraining :13, StochasticTraining :235, QuasiRandomTraining :311)
+and of the set / bound builders in src/discretize.jl (generate_training_sets :185-241, get_bounds :299-324).
+The reduction `theta -> mean(abs2, residual(set, theta))` (training_strategies.jl:220, 280, 380) itself is
+done by the HIP engine; these classes only decide WHICH points it runs on and when they are redrawn.
+QuadratureTraining (adaptive CPU cubature, "not GPU compatible", docs/src/manual/training_strategies.md:10-11)
+and WeightedIntervalTraining (NNODE only) are out of scope.
+"""
+from __future__ import annotations
+
+import itertools
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .symbolic import PDESystem, VarInfo, get_argument, get_variables
+
+
+class AbstractTrainingStrategy:
+    """Extension point, as `AbstractTrainingStrategy` in src/NeuralPDE.jl:92-134: a strategy provides
+    `point_sets(pinnrep) -> (pde_sets, bc_sets, resample)`."""
+
+    def point_sets(self, pde_system: PDESystem, vi: VarInfo, dtype):
+        raise NotImplementedError
+
+
+def _julia_range(lo: float, step: float, hi: float) -> np.ndarray:
+    """`lo:step:hi` with Julia's length rule floor((hi-lo)/step + eps) + 1."""
+    n = int(np.floor((hi - lo) / step + 1e-10)) + 1
+    return lo + step * np.arange(n)
+
+
+def generate_training_sets(domains, dx, eqs, bcs, dtype, vi: VarInfo):
+    """src/discretize.jl:185-241.  Returns [pde_train_sets, bcs_train_sets]; each set is (d_k x N_k),
+    columns enumerate Iterators.product with the first variable fastest."""
+    dxs = list(dx) if isinstance(dx, (list, tuple, np.ndarray)) else [dx] * len(domains)
+    dict_var_span = {str(d.variable): _julia_range(d.domain.lo, s, d.domain.hi) for d, s in zip(domains, dxs)}
+    bound_args = get_argument(bcs, vi)
+    # Reference quirk, restated faithfully (:202-214): `dif` is filled from `bound_vars = get_variables(bcs)`,
+    # which holds only Symbols, so `x isa Number && push!(dif[i], x)` never fires, `dif` stays empty and
+    # `setdiff(c, d)` is the identity: in v6.2.2 the pde sets are the FULL grids, boundary values included
+    # (the removal shown in docs/src/developer/debugging.md:160-192 is from an older version; that page is
+    # marked "not current").
+    dict_var_span_ = dict(dict_var_span)
+
+    def product(spans):
+        # Iterators.product: first iterator fastest
+        cols = list(itertools.product(*[list(s) for s in reversed(spans)]))
+        arr = np.array([c[::-1] for c in cols], dtype=dtype).T
+        return arr.reshape(len(spans), -1)
+
+    bcs_train_sets = []
+    for bt in bound_args:
+        spans = [dict_var_span[str(a)] if not isinstance(a, float) else np.array([a]) for a in bt]
+        bcs_train_sets.append(product(spans))
+    pde_args = get_argument(eqs, vi)
+    pde_train_sets = []
+    for bt in pde_args:
+        spans = [dict_var_span_[str(a)] if not isinstance(a, float) else np.array([a]) for a in bt]
+        pde_train_sets.append(product(spans))
+    return [pde_train_sets, bcs_train_sets]
+
+
+def get_bounds(domains, eqs, bcs, dtype, vi: VarInfo, points: int):
+    """Non-quadrature bounds, src/discretize.jl:299-324: variables -> [inf + 1/points, sup - 1/points]
+    (absolute shrink regardless of domain length), numeric bc arguments -> [c, c]."""
+    dx = 1.0 / points
+    span = {str(d.variable): (d.domain.lo + dx, d.domain.hi - dx) for d in domains}
+
+    def bounds(args_list):
+        res = []
+        for args in args_list:
+            lb = np.array([span[str(a)][0] if not isinstance(a, float) else a for a in args], dtype=dtype)
+            ub = np.array([span[str(a)][1] if not isinstance(a, float) else a for a in args], dtype=dtype)
+            res.append((lb, ub))
+        return res
+
+    return bounds(get_argument(eqs, vi)), bounds(get_argument(bcs, vi))
+
+
+@dataclass
+class GridTraining(AbstractTrainingStrategy):
+    """GridTraining(dx) — src/training_strategies.jl:13; fixed sets built once (:131-160, :215-221)."""
+    dx: object
+
+    def point_sets(self, pde_system, vi, dtype):
+        pde, bc = generate_training_sets(pde_system.domain, self.dx, pde_system.eqs, pde_system.bcs, dtype, vi)
+        return pde, bc, None
+
+
+def generate_random_points(points: int, bound, dtype, rng: np.random.Generator) -> np.ndarray:
+    """src/training_strategies.jl:242-245: rand(T, d, N) .* (ub .- lb) .+ lb."""
+    lb, ub = bound
+    return (rng.random((len(lb), points)).astype(dtype) * (ub - lb)[:, None] + lb[:, None]).astype(dtype)
+
+
+@dataclass
+class StochasticTraining(AbstractTrainingStrategy):
+    """StochasticTraining(points; bcs_points = points) — src/training_strategies.jl:235-240.  A fresh uniform
+    sample per loss call (:277-281)."""
+    points: int
+    bcs_points: Optional[int] = None
+    rng: np.random.Generator = field(default_factory=lambda: np.random.default_rng())
+
+    def __post_init__(self):
+        if self.bcs_points is None:
+            self.bcs_points = self.points
+
+    def point_sets(self, pde_system, vi, dtype):
+        pb, bb = get_bounds(pde_system.domain, pde_system.eqs, pde_system.bcs, dtype, vi, self.points)
+
+        def draw():
+            return ([generate_random_points(self.points, b, dtype, self.rng) for b in pb],
+                    [generate_random_points(self.bcs_points, b, dtype, self.rng) for b in bb])
+
+        pde, bc = draw()
+        return pde, bc, draw
+
+
+class SobolSample:
+    """[3P] QuasiMonteCarlo.SobolSample stand-in (scipy.stats.qmc.Sobol, scrambled, seeded)."""
+
+    def __init__(self, seed: int = 0, scramble: bool = True):
+        self.seed, self.scramble = seed, scramble
+        self._calls = 0
+
+    def sample(self, n, lb, ub, dtype):
+        from scipy.stats import qmc
+        eng = qmc.Sobol(len(lb), scramble=self.scramble, seed=self.seed + self._calls)
+        self._calls += 1
+        m = int(np.ceil(np.log2(max(n, 1))))
+        u = eng.random_base2(m)[:n] if (1 << m) >= n else eng.random(n)
+        return (lb[:, None] + (ub - lb)[:, None] * u.T).astype(dtype)
+
+
+class LatinHypercubeSample:
+    """[3P] QuasiMonteCarlo.LatinHypercubeSample stand-in — the reference's default sampling_alg
+    (src/training_strategies.jl:321)."""
+
+    def __init__(self, seed: Optional[int] = None):
+        self.rng = np.random.default_rng(seed)
+
+    def sample(self, n, lb, ub, dtype):
+        d = len(lb)
+        u = np.empty((d, n))
+        for i in range(d):
+            u[i] = (self.rng.permutation(n) + self.rng.random(n)) / n
+        return (lb[:, None] + (ub - lb)[:, None] * u).astype(dtype)
+
+
+@dataclass
+class QuasiRandomTraining(AbstractTrainingStrategy):
+    """QuasiRandomTraining(points; bcs_points, sampling_alg, resampling = true, minibatch = 0) —
+    src/training_strategies.jl:311-334.  resampling: new design every call (:375-381); otherwise `minibatch`
+    designs generated up front and one picked at random per call (:383-387)."""
+    points: int
+    bcs_points: Optional[int] = None
+    sampling_alg: object = field(default_factory=LatinHypercubeSample)
+    resampling: bool = True
+    minibatch: int = 0
+    rng: np.random.Generator = field(default_factory=lambda: np.random.default_rng())
+
+    def __post_init__(self):
+        if self.bcs_points is None:
+            self.bcs_points = self.points
+
+    def point_sets(self, pde_system, vi, dtype):
+        pb, bb = get_bounds(pde_system.domain, pde_system.eqs, pde_system.bcs, dtype, vi, self.points)
+        alg = self.sampling_alg
+
+        def design():
+            return ([alg.sample(self.points, lb, ub, dtype) for lb, ub in pb],
+                    [alg.sample(self.bcs_points, lb, ub, dtype) for lb, ub in bb])
+
+        if self.resampling:
+            pde, bc = design()
+            return pde, bc, design
+        nb = max(int(self.minibatch), 1)
+        batches = [design() for _ in range(nb)]
+        if nb == 1:
+            return batches[0][0], batches[0][1], None
+
+        def pick():
+            return batches[int(self.rng.integers(nb))]
+
+        return batches[0][0], batches[0][1], pick
