@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py — collocation-point residual+grad evals/sec on the BASELINE.json workload.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+One "step" = one evaluation of the PINN loss (all K term losses) AND its gradient w.r.t. all network
+weights for fixed theta and fixed collocation sets, delivered to the host (the reference's optimiser lives on
+the host, src/discretize.jl:776-780), i.e. exactly what NeuralPDE.jl computes once per optimiser iteration
+(src/discretize.jl:567-598 + Zygote, :778).
+
+Workload at every N (config.workload): BASELINE.json configs[1] — 2-D Poisson on the unit square, 4x64 tanh MLP,
+QuasiRandomTraining: 65,536 interior points + 4 boundary terms x 65,536 points, all resident in HBM before
+the timed region.  N > 1 is STRONG scaling (the same 65,536+4x65,536 points are sharded over the ranks in contiguous
+blocks; one RCCL all-reduce of [gradient | per-term squared-residual sums] per step).
+value = interior collocation points x steps / time  (the metric's unit: interior-point residual+grad evals/s;
+the 4x65,536 boundary-term points ride along in every step and are counted in `point_terms_per_s`).
+
+JSON extras: "roofline" (fp32 MFMA roofline of the dominant kernel = the fused interior residual kernel,
+algorithmic flops per SURVEY.md §8d / DESIGN.md ÷ its HIP-event duration) and "cpu_baseline" (the float64 oracle =
+CPU restatement of the reference algorithm, timed on this box's host cores on a bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md:41
+
+
+def algorithmic_flops_per_point(sizes, C):
+    """flops(net, C) per point = 6*C*S - 2*C*n0*n1, S = sum_l n_{l-1} n_l."""
+    S = sum(sizes[i] * sizes[i + 1] for i in range(len(sizes) - 1))
+    return 6 * C * S - 2 * C * sizes[0] * sizes[1]
+
+
+def cpu_baseline(npde, wl_small, sets_small, budget_s=12.0):
+    """Time the float64 oracle (stencil mode = the reference's algorithm: 6 batched forward passes per Poisson
+    residual + reverse mode) on a bounded sample of the same workload, all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import pinn_oracle as po
+    import helpers
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    prob = helpers.oracle_problem(npde, wl_small.pde_system, wl_small.chains)
+    n_int = sets_small[0].shape[1]
+    po.loss_and_grad(prob, wl_small.theta, sets_small, mode="stencil")       # warm-up
+    t0, reps = time.perf_counter(), 0
+    while True:
+        po.loss_and_grad(prob, wl_small.theta, sets_small, mode="stencil")
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or reps >= 50:
+            break
+    return {"value": n_int * reps / el, "unit": "interior-point residual+grad evals/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} evals of the float64 stencil-mode oracle (torch CPU, {cores} threads) on {n_int} interior + "
+                      f"4x{sets_small[1].shape[1]} boundary points of the same workload; Julia/NeuralPDE.jl is not installable here"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--points", type=int, default=65536)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import pinn_import
+    npde = pinn_import.load()
+    from neuralpde_jl_amd import workloads
+
+    wl = workloads.cfg2_poisson2d(points=args.points)
+    disc = wl.discretization()
+    rep = npde.symbolic_discretize(wl.pde_system, disc)
+    eng = rep.engine
+    assert eng.L.backend == "hip"
+    sets = rep.pde_train_sets + rep.bcs_train_sets
+    K, P = eng.K, eng.P
+    n_glob = [s.shape[1] for s in sets]
+    # shard every term's set into contiguous column blocks (strong scaling)
+    if world > 1:
+        for k, s in enumerate(sets):
+            n = s.shape[1]
+            lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+            eng.set_points(k, s[:, lo:hi], n_norm=n)
+    theta_d = torch.tensor(wl.theta, dtype=torch.float32, device="cuda")
+    out_d = torch.zeros(P + K, dtype=torch.float32, device="cuda")
+    out_h = torch.zeros(P + K, dtype=torch.float32).pin_memory()
+    stream = torch.cuda.current_stream()
+
+    def step():
+        eng.loss_grad_device(theta_d.data_ptr(), out_d.data_ptr(), None, stream.cuda_stream)
+        if world > 1:
+            dist.all_reduce(out_d)
+        out_h.copy_(out_d, non_blocking=True)
+        stream.synchronize()                 # the optimiser needs loss + gradient on the host every iteration
+
+    for _ in range(args.warmup):
+        step()
+    kern_ms = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kern_ms.append([g["ms"] for g in eng.group_timings()])
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    if rank == 0:
+        res = out_h.numpy()
+        losses = res[P:] / np.array(n_glob)
+        groups = eng.group_timings()
+        kern_ms = np.array(kern_ms)
+        # dominant kernel = the interior (C=5) fused residual kernel
+        dom = int(np.argmax([g["channels"] for g in groups]))
+        sizes = wl.chains[0].sizes
+        dom_ms = float(np.mean(kern_ms[:, dom]))
+        flops_dom = algorithmic_flops_per_point(sizes, groups[dom]["channels"]) * groups[dom]["points"]
+        achieved = flops_dom / (dom_ms * 1e-3) / 1e12
+        all_ms = float(np.mean(kern_ms.sum(axis=1)))
+        flops_all = sum(algorithmic_flops_per_point(sizes, g["channels"]) * g["points"] for g in groups)
+        n_int = n_glob[0]
+        line = {
+            "metric": "collocation-point residual+grad evals/sec, 2D Poisson 4x64 MLP",
+            "value": n_int * args.steps / el,
+            "unit": "interior-point residual+grad evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": el / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": wl.name, "interior_points": n_int, "boundary_terms": K - 1,
+                       "boundary_points_per_term": n_glob[1], "theta": P,
+                       "parallelism": f"point-shard x{world}" if world > 1 else "single"},
+            "point_terms_per_s": sum(n_glob) * args.steps / el,
+            "loss_terms": [float(v) for v in losses],
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "k_wave<Spec<64,3,2,...C=5>,FUSED> (interior residual+grad)",
+                         "kernel_ms": dom_ms, "points_per_launch": groups[dom]["points"],
+                         "flops_per_point": algorithmic_flops_per_point(sizes, groups[dom]["channels"]),
+                         "all_fused_kernels_ms": all_ms,
+                         "all_fused_kernels_tflops": flops_all / (all_ms * 1e-3) / 1e12},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            wls = workloads.cfg2_poisson2d(points=8192)
+            reps = npde.symbolic_discretize(wls.pde_system, wls.discretization())
+            line["cpu_baseline"] = cpu_baseline(npde, wls, reps.pde_train_sets + reps.bcs_train_sets)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

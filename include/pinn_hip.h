@@ -85,7 +85,7 @@ int pinn_term_grads(pinn_handle h, const float* theta, int64_t p, double* term_l
  * all-reduces d_out with RCCL): d_theta = P floats in HBM; d_out = P + K floats in HBM:
  *   d_out[0..P)   = this shard's gradient contribution (already scaled by term_w[k]/n_norm_k)
  *   d_out[P..P+K) = this shard's sum of squared residuals per term (divide by n_norm_k after the all-reduce)
- * Asynchronous on `stream` (a hipStream_t, may be NULL).
+ * Asynchronous on `stream` (a hipStream_t; NULL = the default stream, e.g. torch's current stream).
  */
 int pinn_loss_grad_device(pinn_handle h, const float* d_theta, const float* term_w, float* d_out, void* stream);
 
@@ -96,6 +96,10 @@ int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float*
 
 /* Timing of the last pinn_loss_grad*: HIP-event milliseconds of the fused residual kernels / of the whole device section. */
 int pinn_last_timing(pinn_handle h, float* kernel_ms, float* total_ms);
+/* Kernel plan: number of launch groups (terms that share one fused kernel) and the HIP-event duration of group g's
+ * fused residual kernel in the last evaluation, with the points / jet channels / wave tiles it processed. */
+int pinn_num_groups(pinn_handle h);
+int pinn_group_timing(pinn_handle h, int group, float* ms, int64_t* points, int* channels, int* tiles);
 /* Introspection used by tests and bench: writes a short human-readable description of the kernel plan. */
 int pinn_describe(pinn_handle h, char* buf, int64_t buflen);
 

@@ -19,7 +19,7 @@ DEFAULT_PATH = os.path.join(_HERE, "csrc", "libpinn_hip.so")
 SYMBOLS = [
     "pinn_backend", "pinn_abi_version", "pinn_last_error", "pinn_create", "pinn_destroy", "pinn_num_terms",
     "pinn_num_theta", "pinn_set_points", "pinn_set_points_device", "pinn_loss_grad", "pinn_loss_grad_f64",
-    "pinn_term_grads", "pinn_loss_grad_device", "pinn_residual", "pinn_phi", "pinn_last_timing", "pinn_describe",
+    "pinn_term_grads", "pinn_loss_grad_device", "pinn_residual", "pinn_phi", "pinn_last_timing", "pinn_describe", "pinn_num_groups", "pinn_group_timing",
 ]
 
 
@@ -57,6 +57,8 @@ class Library:
         L.pinn_phi.argtypes = [vp, C.c_int, fp, C.c_int64, fp, C.c_int64, fp]
         L.pinn_last_timing.argtypes = [vp, fp, fp]
         L.pinn_describe.argtypes = [vp, C.c_char_p, C.c_int64]
+        L.pinn_num_groups.argtypes = [vp]
+        L.pinn_group_timing.argtypes = [vp, C.c_int, fp, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
 
     @property
     def backend(self) -> str:
@@ -181,6 +183,15 @@ class Engine:
         k, t = C.c_float(), C.c_float()
         self.L.check(self.L.lib.pinn_last_timing(self.h, C.byref(k), C.byref(t)), "pinn_last_timing")
         return k.value, t.value
+
+    def group_timings(self):
+        out = []
+        for g in range(self.L.lib.pinn_num_groups(self.h)):
+            ms, pts, ch, tiles = C.c_float(), C.c_int64(), C.c_int(), C.c_int()
+            self.L.check(self.L.lib.pinn_group_timing(self.h, g, C.byref(ms), C.byref(pts), C.byref(ch), C.byref(tiles)),
+                         "pinn_group_timing")
+            out.append(dict(group=g, ms=ms.value, points=pts.value, channels=ch.value, tiles=tiles.value))
+        return out
 
     def describe(self) -> str:
         buf = C.create_string_buffer(4096)

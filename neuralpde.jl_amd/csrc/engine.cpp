@@ -17,6 +17,13 @@
 #include "plat.hpp"
 #include "spec_registry.hpp"
 
+#ifdef PINN_EMU
+namespace wv {
+thread_local void (*emu_barrier_hook)(void*) = nullptr;
+thread_local void* emu_barrier_ctx = nullptr;
+}  // namespace wv
+#endif
+
 namespace pk {
 std::vector<SpecInfo>& registry() {
     static std::vector<SpecInfo> r;
@@ -25,6 +32,8 @@ std::vector<SpecInfo>& registry() {
 }  // namespace pk
 
 namespace {
+
+constexpr int REDUCE_SPLIT = 32;      // stage-1 chunks of the fixed-order slab reduction
 
 thread_local std::string g_err;
 int fail(const std::string& m) {
@@ -78,11 +87,16 @@ struct Group {
     float* d_slabs = nullptr;
     double* d_losspart = nullptr;
     float* d_scratch = nullptr;
-    int* d_map_theta = nullptr;      // reduce map: theta index
-    int* d_map_slab = nullptr;       // reduce map: slab offset
-    int nmap = 0;
+    int* d_ent_off = nullptr;        // reduce map: slab offset of every entry
+    int* d_row_ptr = nullptr;        // reduce map: CSR rows (one per theta element touched by this group)
+    int* d_row_theta = nullptr;
+    double* d_tmp = nullptr;         // stage-1 partial sums [nsplit][nent + K]
+    int nent = 0, nrows = 0;
     int blocks = 0;
     int max_blocks = 0;
+    bool active = false;
+    plat_event ev_a, ev_b;
+    bool timed = false;
 };
 struct NetPlan {
     const pk::SpecInfo* spec = nullptr;   // any spec with the right (HP,NHH,D): packed layout is shared
@@ -372,8 +386,10 @@ int build_plan(pinn_engine& E) {
         const int LH = s.LH, HP = s.HP, MT = s.MT, D = s.D;
         (void)HP;
         G.max_blocks = E.ncu;
+        plat_event_create(G.ev_a);
+        plat_event_create(G.ev_b);
         const size_t nw = (size_t)G.max_blocks * 4;
-        G.d_slabs = (float*)plat_malloc(sizeof(float) * nw * s.SLAB);
+        G.d_slabs = (float*)plat_malloc(sizeof(float) * (size_t)G.max_blocks * s.SLAB);
         G.d_losspart = (double*)plat_malloc(sizeof(double) * nw * total_terms);
         G.d_scratch = (float*)plat_malloc(sizeof(float) * nw * s.SCR);
         if (!G.d_slabs || !G.d_losspart || !G.d_scratch) return fail("device allocation failed (group buffers)");
@@ -409,53 +425,53 @@ int build_plan(pinn_engine& E) {
         G.d_prog = (rp::Instr*)plat_malloc(sizeof(rp::Instr) * std::max<size_t>(prog.size(), 1));
         if (!G.d_prog) return fail("device allocation failed (programs)");
         if (!prog.empty()) plat_h2d(G.d_prog, prog.data(), sizeof(rp::Instr) * prog.size(), E.stream);
-        // reduce map
-        std::vector<int> mt, ms;
+        // reduce map (CSR): theta element -> slab offsets that must be summed (1 for workgroup-shared sections,
+        // 4 for per-wave sections), see Spec in pinn_kernels.hpp
+        std::vector<int> row_theta, row_ptr{0}, ent;
+        auto add_row = [&](int theta_idx, int off, bool shared) {
+            row_theta.push_back(theta_idx);
+            if (shared) ent.push_back(off);
+            else
+                for (int w = 0; w < 4; ++w) ent.push_back(s.SH + w * s.PW + off);
+            row_ptr.push_back((int)ent.size());
+        };
+        const bool coop = s.COOP != 0;
         std::vector<int> loff(LH + 1);
         int o = N.theta_off;
         for (int j = 0; j <= LH; ++j) {
             loff[j] = o;
             o += N.sizes[j + 1] * N.sizes[j] + N.sizes[j + 1];
         }
-        // layer 0: W (n1 x d), b
-        for (int in = 0; in < D; ++in)
-            for (int out = 0; out < N.sizes[1]; ++out) {
-                mt.push_back(loff[0] + out + in * N.sizes[1]);
-                ms.push_back(s.G_W1 + (in * MT + out % MT) * 16 + out / MT);
-            }
-        for (int l = 0; l < LH; ++l) {
-            const int nb = N.sizes[l + 1];
-            for (int out = 0; out < nb; ++out) {
-                mt.push_back(loff[l] + nb * N.sizes[l] + out);
-                ms.push_back(s.G_BFR + (l * MT + out % MT) * 16 + out / MT);
-            }
-        }
+        for (int in = 0; in < D; ++in)                          // layer 0: W (n1 x d)
+            for (int out = 0; out < N.sizes[1]; ++out)
+                add_row(loff[0] + out + in * N.sizes[1], s.O_W1 + (in * MT + out % MT) * 16 + out / MT, false);
+        for (int out = 0; out < N.sizes[1]; ++out)              // bias of hidden layer 0
+            add_row(loff[0] + N.sizes[1] * N.sizes[0] + out, s.O_BFR0 + (out % MT) * 16 + out / MT, false);
         for (int hl = 0; hl < s.NHH; ++hl) {
             const int j = hl + 1;
             for (int in = 0; in < N.sizes[j]; ++in)
                 for (int out = 0; out < N.sizes[j + 1]; ++out) {
                     const int to = out % MT, i = out / MT, g = i / 4, r = i % 4;
                     const int ti = in % MT, c = in / MT;
-                    mt.push_back(loff[j] + out + in * N.sizes[j + 1]);
-                    ms.push_back(s.G_WBAR + hl * s.HP * s.HP + ((to * MT + ti) * 64 + g * 16 + c) * 4 + r);
+                    add_row(loff[j] + out + in * N.sizes[j + 1], s.O_WBAR + hl * s.HP * s.HP + ((to * MT + ti) * 64 + g * 16 + c) * 4 + r, coop);
                 }
+            for (int out = 0; out < N.sizes[j + 1]; ++out)
+                add_row(loff[j] + N.sizes[j + 1] * N.sizes[j] + out, s.O_BFRH + (hl * MT + out % MT) * 16 + out / MT, coop);
         }
-        for (int in = 0; in < N.sizes[LH]; ++in) {
-            mt.push_back(loff[LH] + in);     // W_out (1 x nLH): out=0, index = 0 + in*1
-            ms.push_back(s.G_WL + ((in / 16) * 4 + (in % 16) / 4) * 4 + in % 4);
-        }
-        mt.push_back(loff[LH] + N.sizes[LH]);
-        ms.push_back(s.G_BL);
-        for (int j = 0; j < E.ne; ++j) {
-            mt.push_back(E.p_theta_off + j);
-            ms.push_back(s.G_P + j);
-        }
-        G.nmap = (int)mt.size();
-        G.d_map_theta = (int*)plat_malloc(sizeof(int) * G.nmap);
-        G.d_map_slab = (int*)plat_malloc(sizeof(int) * G.nmap);
-        if (!G.d_map_theta || !G.d_map_slab) return fail("device allocation failed (reduce map)");
-        plat_h2d(G.d_map_theta, mt.data(), sizeof(int) * G.nmap, E.stream);
-        plat_h2d(G.d_map_slab, ms.data(), sizeof(int) * G.nmap, E.stream);
+        for (int in = 0; in < N.sizes[LH]; ++in)                // W_out (1 x nLH)
+            add_row(loff[LH] + in, s.O_WL + ((in / 16) * 4 + (in % 16) / 4) * 4 + in % 4, false);
+        add_row(loff[LH] + N.sizes[LH], s.O_BL, false);
+        for (int j = 0; j < E.ne; ++j) add_row(E.p_theta_off + j, s.O_P + j, false);
+        G.nent = (int)ent.size();
+        G.nrows = (int)row_theta.size();
+        G.d_ent_off = (int*)plat_malloc(sizeof(int) * G.nent);
+        G.d_row_ptr = (int*)plat_malloc(sizeof(int) * (G.nrows + 1));
+        G.d_row_theta = (int*)plat_malloc(sizeof(int) * G.nrows);
+        G.d_tmp = (double*)plat_malloc(sizeof(double) * (size_t)REDUCE_SPLIT * (G.nent + total_terms));
+        if (!G.d_ent_off || !G.d_row_ptr || !G.d_row_theta || !G.d_tmp) return fail("device allocation failed (reduce map)");
+        plat_h2d(G.d_ent_off, ent.data(), sizeof(int) * G.nent, E.stream);
+        plat_h2d(G.d_row_ptr, row_ptr.data(), sizeof(int) * (G.nrows + 1), E.stream);
+        plat_h2d(G.d_row_theta, row_theta.data(), sizeof(int) * G.nrows, E.stream);
         plat_sync(E.stream);
         // static part of the launch arguments
         pk::GroupArgs& ga = G.ga;
@@ -533,14 +549,23 @@ int run_loss_grad(pinn_engine& E, const float* term_w, int only_term /* -1 = all
             G.ga.terms[j].scale = on ? (float)(2.0 * (double)w / (double)T.n_norm) : 0.f;
             any = any || on;
         }
+        G.active = any;
         if (!any) continue;
         plat_memset(G.d_losspart, 0, sizeof(double) * (size_t)G.blocks * 4 * K, E.stream);
+        if (timing) plat_event_record(G.ev_a, E.stream);
         G.spec->launch(G.ga, pk::MODE_FUSED, G.blocks, E.stream);
+        if (timing) plat_event_record(G.ev_b, E.stream);
+        G.timed = timing;
     }
     if (timing) plat_event_record(E.ev2, E.stream);
-    for (auto& G : E.groups)
-        aux::launch_reduce(E.d_gradd, E.d_lossraw, G.d_slabs, G.spec->SLAB, G.blocks * 4, G.d_map_theta, G.d_map_slab, G.nmap,
-                           G.d_losspart, K, E.stream);
+    for (auto& G : E.groups) {
+        if (!G.active) continue;
+        aux::ReduceArgs ra;
+        ra.gradd = E.d_gradd; ra.lossraw = E.d_lossraw; ra.tmp = G.d_tmp; ra.slabs = G.d_slabs; ra.slab = G.spec->SLAB;
+        ra.nblocks = G.blocks; ra.nsplit = std::min(REDUCE_SPLIT, G.blocks); ra.ent_off = G.d_ent_off; ra.nent = G.nent;
+        ra.row_ptr = G.d_row_ptr; ra.row_theta = G.d_row_theta; ra.nrows = G.nrows; ra.losspart = G.d_losspart; ra.K = K;
+        aux::launch_reduce(ra, E.stream);
+    }
     aux::launch_finish(E.d_out, E.d_gradd, E.d_lossraw, (int)E.ntheta, K, E.stream);
     if (timing) plat_event_record(E.ev3, E.stream);
     return 0;
@@ -595,7 +620,8 @@ int pinn_destroy(pinn_handle h) {
     for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_resid); }
     for (auto& G : E.groups) {
         plat_free(G.d_prog); plat_free(G.d_slabs); plat_free(G.d_losspart); plat_free(G.d_scratch);
-        plat_free(G.d_map_theta); plat_free(G.d_map_slab);
+        plat_free(G.d_ent_off); plat_free(G.d_row_ptr); plat_free(G.d_row_theta); plat_free(G.d_tmp);
+        plat_event_destroy(G.ev_a); plat_event_destroy(G.ev_b);
     }
     for (auto& N : E.netplans) { plat_free(N.d_packed); plat_free(N.d_pack_idx); }
     plat_free(E.d_theta); plat_free(E.d_params); plat_free(E.d_defaults); plat_free(E.d_gradd); plat_free(E.d_lossraw);
@@ -644,8 +670,6 @@ int pinn_loss_grad(pinn_handle h, const float* theta, int64_t p, const float* te
     std::vector<double> raw(K);
     if (plat_d2h(raw.data(), E.d_lossraw, sizeof(double) * K, E.stream)) return fail("D2H copy failed");
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
-    E.last_kernel_ms = plat_event_ms(E.ev1, E.ev2);
-    E.last_total_ms = plat_event_ms(E.ev0, E.ev3);
     E.timing_valid = true;
     if (term_losses)
         for (int k = 0; k < K; ++k) term_losses[k] = raw[k] / (double)E.terms[k].n_norm;
@@ -689,13 +713,13 @@ int pinn_loss_grad_device(pinn_handle h, const float* d_theta, const float* term
     const int K = (int)E.terms.size();
     plat_stream user = (plat_stream)stream;
     plat_stream saved = E.stream;
-    E.stream = user ? user : saved;
+    E.stream = user;     // NULL is the (legacy) default stream — e.g. torch's current stream
     int rc = plat_d2d(E.d_theta, d_theta, sizeof(float) * E.ntheta, E.stream);
     if (!rc) rc = run_loss_grad(E, term_w, -1, true);
     if (!rc) rc = plat_d2d(d_out, E.d_out, sizeof(float) * (E.ntheta + K), E.stream);
     E.stream = saved;
     if (rc && g_err.empty()) return fail("pinn_loss_grad_device failed");
-    E.timing_valid = false;
+    E.timing_valid = (rc == 0);
     return rc;
 }
 
@@ -770,8 +794,26 @@ int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float*
 int pinn_last_timing(pinn_handle h, float* kernel_ms, float* total_ms) {
     if (!h) return fail("null handle");
     if (!h->timing_valid) return fail("no timing available (call pinn_loss_grad first)");
-    if (kernel_ms) *kernel_ms = h->last_kernel_ms;
-    if (total_ms) *total_ms = h->last_total_ms;
+    plat_event_sync(h->ev3);
+    if (kernel_ms) *kernel_ms = plat_event_ms(h->ev1, h->ev2);
+    if (total_ms) *total_ms = plat_event_ms(h->ev0, h->ev3);
+    return 0;
+}
+
+int pinn_num_groups(pinn_handle h) { return h ? (int)h->groups.size() : -1; }
+
+int pinn_group_timing(pinn_handle h, int group, float* ms, int64_t* points, int* channels, int* tiles) {
+    if (!h) return fail("null handle");
+    if (group < 0 || group >= (int)h->groups.size()) return fail("pinn_group_timing: group index out of range");
+    Group& G = h->groups[group];
+    if (!G.timed) return fail("no timing available for this group");
+    plat_event_sync(G.ev_b);
+    if (ms) *ms = plat_event_ms(G.ev_a, G.ev_b);
+    int64_t n = 0;
+    for (int t : G.terms) n += h->terms[t].n;
+    if (points) *points = n;
+    if (channels) *channels = G.spec->C;
+    if (tiles) *tiles = G.ga.ntiles;
     return 0;
 }
 

@@ -84,20 +84,32 @@ struct Spec {
     static constexpr int OFF_WPK = OFF_BL + 4;             // [NHH][HP*HP]  forward fragments
     static constexpr int OFF_WTPK = OFF_WPK + NHH_ * HP_ * HP_;   // [NHH][HP*HP] transposed fragments
     static constexpr int PACKED = OFF_WTPK + NHH_ * HP_ * HP_;
-    // per-wave gradient slab (floats)
-    static constexpr int G_WBAR = 0;                       // [NHH][MT][MT][64][4]
-    static constexpr int G_BFR = G_WBAR + NHH_ * HP_ * HP_;    // [LH][MT][16]
-    static constexpr int G_W1 = G_BFR + LH * HP_;          // [D][MT][16]
-    static constexpr int G_WL = G_W1 + D_ * HP_;           // [MT][4][4]
-    static constexpr int G_BL = G_WL + HP_;                // [1]
-    static constexpr int G_P = G_BL + 1;                   // [MAX_PARAMS]
-    static constexpr int SLAB = ((G_P + MAX_PARAMS + 63) / 64) * 64;
+    // dW ownership: with 4 neuron tiles (HP = 64) the four waves of a workgroup each own one 16-row block of every
+    // layer's dW (COOP); smaller nets keep all of dW per wave.
+    static constexpr bool COOP = (MT == 4);
+    static constexpr int WT = COOP ? 1 : MT;                     // dW row tiles held by one wave
+    // per-WORKGROUP gradient slab (floats) = [shared section SH][4 x per-wave section PW]
+    static constexpr int O_WBAR = 0;                                         // [NHH][MT(to)][MT(ti)][64][4]
+    static constexpr int O_BFRH = NHH_ * HP_ * HP_;                          // [NHH][MT][16]  biases of hidden layers >= 1
+    static constexpr int SH = COOP ? (NHH_ * HP_ * HP_ + NHH_ * HP_) : 0;
+    static constexpr int PB = COOP ? 0 : (NHH_ * HP_ * HP_ + NHH_ * HP_);
+    static constexpr int O_BFR0 = PB;                                        // [MT][16]     bias of hidden layer 0
+    static constexpr int O_W1 = O_BFR0 + HP_;                                // [D][MT][16]
+    static constexpr int O_WL = O_W1 + D_ * HP_;                             // [MT][4][4]
+    static constexpr int O_BL = O_WL + HP_;                                  // [1]
+    static constexpr int O_P = O_BL + 1;                                     // [MAX_PARAMS]
+    static constexpr int PW = ((O_P + MAX_PARAMS + 63) / 64) * 64;
+    static constexpr int SLAB = SH + 4 * PW;
     // per-wave activation scratch (floats): [LH][NG][MT][64][4]
     static constexpr int SCR = LH * NG * MT * 256;
-    // per-wave LDS (floats): 2 x (ZT,AT) transpose buffers of 16 columns (also the residual tape) + coords
+    // LDS (floats).  Per wave private: residual tape (32 value rows + 32 adjoint rows), aliased by the wave-private
+    // transpose buffers of the reverse sweep, + the tile's coordinates.  COOP adds a workgroup-shared double buffer of
+    // the four waves' (dZ^T, A^T) 16-column chunks.
     static constexpr int LDS_T = (16 * HP_ > 1024) ? 16 * HP_ : 1024;
-    static constexpr int LDS_X = 16 * PG_ * D_;
-    static constexpr int LDS_WAVE = 4 * LDS_T + ((LDS_X + 63) / 64) * 64;
+    static constexpr int LDS_X = ((16 * PG_ * D_ + 63) / 64) * 64;
+    static constexpr int LDS_PRIV = 4 * LDS_T + LDS_X;
+    static constexpr int LDS_SHARED = COOP ? 2 * 4 * 2 * LDS_T : 0;
+    static constexpr int LDS_WG = LDS_SHARED + 4 * LDS_PRIV;
 };
 
 struct TermDev {
@@ -117,7 +129,7 @@ struct GroupArgs {
     const float* packed;         // Spec::PACKED floats (this net, this call's theta)
     const float* params;         // MAX_PARAMS floats (theta.p / default_p)
     const rp::Instr* prog;
-    float* slabs;                // [nwaves][SLAB]
+    float* slabs;                // [nblocks][SLAB]
     double* losspart;            // [nwaves][nterms_total]
     float* scratch;              // [nwaves][SCR]
     int nterms_total;
@@ -143,8 +155,8 @@ DEV void act_derivs(vfloat a, vfloat& d1, vfloat& d2, vfloat& d3) {
     }
 }
 DEV vfloat act_value(int act, vfloat z) {
-    if (act == ACT_TANH) return vtanh(z);
-    return vrcp(vfloat(1.0f) + vexp(vfloat(0.0f) - z));
+    if (act == ACT_TANH) return vtanh_fast(z);
+    return vsigmoid_fast(z);
 }
 DEV void act_derivs_rt(int act, vfloat a, vfloat& d1, vfloat& d2, vfloat& d3) {
     if (act == ACT_TANH) act_derivs<ACT_TANH>(a, d1, d2, d3);
@@ -159,10 +171,17 @@ DEV vint tr_addr(vint col, vint slot) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// The wave program.  `wave`/`nwaves`: this wave's index in the persistent grid.
+// The wave program.  Workgroup `blk` of `nblocks` (persistent grid), wave `w` (0..3) of the workgroup.
+// All four waves of a workgroup run the same number of tile iterations (tiles past the end are fully masked
+// dummies) because the COOP dW phase synchronises them with workgroup barriers.
 // ------------------------------------------------------------------------------------------------
 template <class S, int MODE>
-DEV void wave_main(const GroupArgs& ga, int wave, int nwaves, float* lds) {
+DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_wg) {
+    const int wave = blk * 4 + w;
+    float* lds = lds_wg + S::LDS_SHARED + w * S::LDS_PRIV;     // wave-private LDS
+    float* lds_sh = lds_wg;                                    // workgroup-shared chunk buffers (COOP)
+    constexpr bool COOP = S::COOP && (MODE == MODE_FUSED);
+    constexpr int WT = S::WT;
     constexpr int HP = S::HP, MT = S::MT, NHH = S::NHH, LH = S::LH, D = S::D, C = S::C, PG = S::PG, NG = S::NG;
     constexpr int NFIRST = S::NFIRST, NPAIR = S::NPAIR;
     const vint lane = lane_id();
@@ -173,17 +192,19 @@ DEV void wave_main(const GroupArgs& ga, int wave, int nwaves, float* lds) {
     const int act = ga.act;
 
     // ---- persistent per-wave gradient accumulators (registers / AGPRs across all tiles) ----
-    vfloat4 wbar[NHH > 0 ? NHH : 1][MT][MT];
-    vfloat bfr[LH][MT];
+    vfloat4 wbar[NHH > 0 ? NHH : 1][WT][MT];      // COOP: this wave's row block (to == w) only
+    vfloat bfrh[NHH > 0 ? NHH : 1][WT];           // bias grads of hidden layers >= 1 (fragment form)
+    vfloat bfr0[MT];                              // bias grad of hidden layer 0
     vfloat w1fr[D][MT];
     vfloat4 wLbar[MT];
     vfloat bLbar = vfloat(0.f);
     vfloat pbar[MAX_PARAMS];
     PINN_UNROLL for (int l = 0; l < (NHH > 0 ? NHH : 1); ++l)
-        PINN_UNROLL for (int a = 0; a < MT; ++a)
+        PINN_UNROLL for (int a = 0; a < WT; ++a) {
+            bfrh[l][a] = vfloat(0.f);
             PINN_UNROLL for (int b = 0; b < MT; ++b) wbar[l][a][b] = vzero4();
-    PINN_UNROLL for (int l = 0; l < LH; ++l)
-        PINN_UNROLL for (int a = 0; a < MT; ++a) bfr[l][a] = vfloat(0.f);
+        }
+    PINN_UNROLL for (int a = 0; a < MT; ++a) bfr0[a] = vfloat(0.f);
     PINN_UNROLL for (int i = 0; i < D; ++i)
         PINN_UNROLL for (int a = 0; a < MT; ++a) w1fr[i][a] = vfloat(0.f);
     PINN_UNROLL for (int a = 0; a < MT; ++a) wLbar[a] = vzero4();
@@ -191,16 +212,20 @@ DEV void wave_main(const GroupArgs& ga, int wave, int nwaves, float* lds) {
 
     vfloat lsum = vfloat(0.f);
     int cur_term = -1;      // index into ga.terms of the term whose loss is being accumulated
+    int cq = 0;             // running chunk counter: parity selects the shared LDS chunk buffer (COOP)
 
-    float* scr = ga.scratch + (size_t)wave * S::SCR;
+    const ubuf SB = ub_make(ga.scratch + (size_t)wave * S::SCR, S::SCR);      // this wave's activation scratch
+    const ubuf PB = ub_make(P, S::PACKED);                                         // packed weights of this net
     float* xs = lds + 4 * S::LDS_T;           // coords of the tile: [pg][pt][i]
 
     // output layer weights in D layout
     vfloat4 wL[MT];
-    PINN_UNROLL for (int m = 0; m < MT; ++m) wL[m] = gload4(P + S::OFF_WL, vint(16 * m) + (g << 2));
+    PINN_UNROLL for (int m = 0; m < MT; ++m) wL[m] = ub_load4(PB, S::OFF_WL + 16 * m, g << 2);
     const float bL = P[S::OFF_BL];
 
-    for (int t = wave; t < ga.ntiles; t += nwaves) {
+    const int niter = (ga.ntiles + 4 * nblocks - 1) / (4 * nblocks);
+    for (int it = 0; it < niter; ++it) {
+        const int t = (it * nblocks + blk) * 4 + w;          // >= ntiles: dummy tile of the last term, all points masked
         // ---- locate the term of this tile (terms are tile-contiguous) ----
         int k = 0;
         for (int j = 1; j < ga.nterms; ++j)
@@ -232,10 +257,9 @@ DEV void wave_main(const GroupArgs& ga, int wave, int nwaves, float* lds) {
         vfloat4 A[NG][MT];
         // ---- layer 1: d -> HP on the VALU (K = d is tiny) ----
         PINN_UNROLL for (int m = 0; m < MT; ++m) {
-            const vint nidx = vint(16 * m) + (g << 2);
-            vfloat4 b1 = gload4(P + S::OFF_B, nidx);
+            vfloat4 b1 = ub_load4(PB, S::OFF_B + 16 * m, g << 2);
             vfloat4 w1[D];
-            PINN_UNROLL for (int i = 0; i < D; ++i) w1[i] = gload4(P + S::OFF_W1 + i * HP, nidx);
+            PINN_UNROLL for (int i = 0; i < D; ++i) w1[i] = ub_load4(PB, S::OFF_W1 + i * HP + 16 * m, g << 2);
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
                 vfloat4 z = b1;
                 PINN_UNROLL for (int i = 0; i < D; ++i)
@@ -261,7 +285,7 @@ DEV void wave_main(const GroupArgs& ga, int wave, int nwaves, float* lds) {
                     Z[pg * C][m] = av;
                     if (MODE == MODE_FUSED) {
                         PINN_UNROLL for (int ch = 0; ch < C; ++ch)
-                            gstore4(scr, vint((((layer * NG) + pg * C + ch) * MT + m) * 256) + (lane << 2), Z[pg * C + ch][m]);
+                            ub_store4(SB, (((layer * NG) + pg * C + ch) * MT + m) * 256, lane << 2, Z[pg * C + ch][m]);
                     }
                     PINN_UNROLL for (int p = 0; p < NPAIR; ++p) {
                         const int cp = pg * C + 1 + NFIRST + p;
@@ -280,21 +304,21 @@ DEV void wave_main(const GroupArgs& ga, int wave, int nwaves, float* lds) {
         PINN_UNROLL for (int hl = 0; hl < NHH; ++hl) {
             vfloat4 Zn[NG][MT];
             PINN_UNROLL for (int m = 0; m < MT; ++m) {
-                vfloat4 bv = gload4(P + S::OFF_B + (hl + 1) * HP, vint(16 * m) + (g << 2));
+                vfloat4 bv = ub_load4(PB, S::OFF_B + (hl + 1) * HP + 16 * m, g << 2);
                 PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
                     Zn[pg * C][m] = bv;
                     PINN_UNROLL for (int ch = 1; ch < C; ++ch) Zn[pg * C + ch][m] = vzero4();
                 }
             }
-            const float* Wf = P + S::OFF_WPK + hl * HP * HP;
+            const int Wf = S::OFF_WPK + hl * HP * HP;
             PINN_UNROLL for (int mi = 0; mi < MT; ++mi)
                 PINN_UNROLL for (int rr = 0; rr < 4; ++rr) {
                     vfloat wf[MT];
                     if (MT == 4) {
-                        vfloat4 w4 = gload4(Wf, vint((mi * 4 + rr) * 64 * MT) + (lane << 2));
+                        vfloat4 w4 = ub_load4(PB, Wf + (mi * 4 + rr) * 64 * MT, lane << 2);
                         PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wf[mo] = w4[mo & 3];
                     } else {
-                        PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wf[mo] = gload(Wf, vint((mi * 4 + rr) * 64 * MT + mo) + lane * MT);
+                        PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wf[mo] = ub_load(PB, Wf + (mi * 4 + rr) * 64 * MT + mo, lane * MT);
                     }
                     PINN_UNROLL for (int q = 0; q < NG; ++q)
                         PINN_UNROLL for (int mo = 0; mo < MT; ++mo) Zn[q][mo] = mfma16(wf[mo], A[q][mi][rr], Zn[q][mo]);
@@ -383,7 +407,7 @@ DEV void wave_main(const GroupArgs& ga, int wave, int nwaves, float* lds) {
         auto load_raw = [&](vfloat4 (&Sr)[NG][MT], int layer) {
             PINN_UNROLL for (int q = 0; q < NG; ++q)
                 PINN_UNROLL for (int m = 0; m < MT; ++m)
-                    Sr[q][m] = gload4(scr, vint((((layer * NG) + q) * MT + m) * 256) + (lane << 2));
+                    Sr[q][m] = ub_load4(SB, (((layer * NG) + q) * MT + m) * 256, lane << 2);
         };
         // post-activation jet of channel ch from the raw (a, z_i, z_ij) record
         auto ajet = [&](const vfloat4 (&Sr)[NG][MT], int pg, int ch, int m) -> vfloat4 {
@@ -457,50 +481,81 @@ DEV void wave_main(const GroupArgs& ga, int wave, int nwaves, float* lds) {
             vfloat4 Sr[NG][MT];
             load_raw(Sr, hl);
             // ---- dW += dZ A^T through the swizzled LDS transpose, 16 columns at a time ----
-            PINN_UNROLL for (int q = 0; q < NG; ++q) {
-                float* zt = lds + (q & 1) * 2 * S::LDS_T;
-                float* at = zt + S::LDS_T;
-                const int pg = q / C, ch = q % C;
-                PINN_UNROLL for (int m = 0; m < MT; ++m) {
-                    const vint ad = tr_addr<S>(c, vint(4 * m) + g);
-                    lds_store4(zt, ad, G[q][m]);
-                    lds_store4(at, ad, ajet(Sr, pg, ch, m));
-                }
-                wave_fence();
-                PINN_UNROLL for (int kk = 0; kk < 4; ++kk) {
-                    const vint row = vint(4 * kk) + g;
-                    vfloat zf[MT], af[MT];
-                    if (MT == 4) {
-                        const vint ad = tr_addr<S>(row, c);
-                        vfloat4 z4 = lds_load4(zt, ad), a4 = lds_load4(at, ad);
-                        PINN_UNROLL for (int to = 0; to < MT; ++to) { zf[to] = z4[to & 3]; af[to] = a4[to & 3]; }
-                    } else {
-                        PINN_UNROLL for (int to = 0; to < MT; ++to) {
-                            const vint n = c * MT + vint(to);
-                            const vint ad = tr_addr<S>(row, n >> 2) + (n & vint(3));
-                            zf[to] = lds_load(zt, ad);
-                            af[to] = lds_load(at, ad);
+            if (COOP) {
+                // Every wave publishes its (dZ^T, A^T) chunk in the workgroup-shared double buffer; after one barrier
+                // each wave accumulates ITS 16-row block of dW (out neurons 4i+w) over the chunks of all four waves,
+                // in the fixed order ws = 0..3 => deterministic, and only MT accumulator tiles per layer stay resident.
+                PINN_UNROLL for (int q = 0; q < NG; ++q) {
+                    float* cb = lds_sh + (cq & 1) * (4 * 2 * S::LDS_T);
+                    ++cq;
+                    float* myzt = cb + w * 2 * S::LDS_T;
+                    float* myat = myzt + S::LDS_T;
+                    const int pg = q / C, ch = q % C;
+                    PINN_UNROLL for (int m = 0; m < MT; ++m) {
+                        const vint ad = tr_addr<S>(c, vint(4 * m) + g);
+                        lds_store4(myzt, ad, G[q][m]);
+                        lds_store4(myat, ad, ajet(Sr, pg, ch, m));
+                    }
+                    wg_barrier();
+                    for (int ws = 0; ws < 4; ++ws) {
+                        const float* zt = cb + ws * 2 * S::LDS_T;
+                        const float* at = zt + S::LDS_T;
+                        PINN_UNROLL for (int kk = 0; kk < 4; ++kk) {
+                            const vint row = vint(4 * kk) + g;
+                            const vint ad = tr_addr<S>(row, c);
+                            vfloat zf1 = lds_load(zt, ad + vint(w));          // dZ[out neuron 4c + w][column row]
+                            vfloat4 a4 = lds_load4(at, ad);                   // A[in neurons 4c .. 4c+3][column row]
+                            PINN_UNROLL for (int ti = 0; ti < MT; ++ti) wbar[hl][0][ti] = mfma16(zf1, a4[ti & 3], wbar[hl][0][ti]);
+                            if (ch == 0) bfrh[hl][0] += zf1;
                         }
                     }
-                    PINN_UNROLL for (int to = 0; to < MT; ++to)
-                        PINN_UNROLL for (int ti = 0; ti < MT; ++ti) wbar[hl][to][ti] = mfma16(zf[to], af[ti], wbar[hl][to][ti]);
-                    if (ch == 0) PINN_UNROLL for (int to = 0; to < MT; ++to) bfr[hl + 1][to] += zf[to];
                 }
-                wave_fence();
+            } else {
+                PINN_UNROLL for (int q = 0; q < NG; ++q) {
+                    float* zt = lds + (q & 1) * 2 * S::LDS_T;
+                    float* at = zt + S::LDS_T;
+                    const int pg = q / C, ch = q % C;
+                    PINN_UNROLL for (int m = 0; m < MT; ++m) {
+                        const vint ad = tr_addr<S>(c, vint(4 * m) + g);
+                        lds_store4(zt, ad, G[q][m]);
+                        lds_store4(at, ad, ajet(Sr, pg, ch, m));
+                    }
+                    wave_fence();
+                    PINN_UNROLL for (int kk = 0; kk < 4; ++kk) {
+                        const vint row = vint(4 * kk) + g;
+                        vfloat zf[MT], af[MT];
+                        if (MT == 4) {
+                            const vint ad = tr_addr<S>(row, c);
+                            vfloat4 z4 = lds_load4(zt, ad), a4 = lds_load4(at, ad);
+                            PINN_UNROLL for (int to = 0; to < MT; ++to) { zf[to] = z4[to & 3]; af[to] = a4[to & 3]; }
+                        } else {
+                            PINN_UNROLL for (int to = 0; to < MT; ++to) {
+                                const vint n = c * MT + vint(to);
+                                const vint ad = tr_addr<S>(row, n >> 2) + (n & vint(3));
+                                zf[to] = lds_load(zt, ad);
+                                af[to] = lds_load(at, ad);
+                            }
+                        }
+                        PINN_UNROLL for (int to = 0; to < WT; ++to)
+                            PINN_UNROLL for (int ti = 0; ti < MT; ++ti) wbar[hl][to][ti] = mfma16(zf[to], af[ti], wbar[hl][to][ti]);
+                        if (ch == 0) PINN_UNROLL for (int to = 0; to < WT; ++to) bfrh[hl][to] += zf[to];
+                    }
+                    wave_fence();
+                }
             }
             // ---- dA_prev = W^T dZ on the matrix cores (register-chained) ----
             vfloat4 Gn[NG][MT];
             PINN_UNROLL for (int q = 0; q < NG; ++q)
                 PINN_UNROLL for (int m = 0; m < MT; ++m) Gn[q][m] = vzero4();
-            const float* Wt = P + S::OFF_WTPK + hl * HP * HP;
+            const int Wt = S::OFF_WTPK + hl * HP * HP;
             PINN_UNROLL for (int mo = 0; mo < MT; ++mo)
                 PINN_UNROLL for (int rr = 0; rr < 4; ++rr) {
                     vfloat wf[MT];
                     if (MT == 4) {
-                        vfloat4 w4 = gload4(Wt, vint((mo * 4 + rr) * 64 * MT) + (lane << 2));
+                        vfloat4 w4 = ub_load4(PB, Wt + (mo * 4 + rr) * 64 * MT, lane << 2);
                         PINN_UNROLL for (int mi = 0; mi < MT; ++mi) wf[mi] = w4[mi & 3];
                     } else {
-                        PINN_UNROLL for (int mi = 0; mi < MT; ++mi) wf[mi] = gload(Wt, vint((mo * 4 + rr) * 64 * MT + mi) + lane * MT);
+                        PINN_UNROLL for (int mi = 0; mi < MT; ++mi) wf[mi] = ub_load(PB, Wt + (mo * 4 + rr) * 64 * MT + mi, lane * MT);
                     }
                     PINN_UNROLL for (int q = 0; q < NG; ++q)
                         PINN_UNROLL for (int mi = 0; mi < MT; ++mi) Gn[q][mi] = mfma16(wf[mi], G[q][mo][rr], Gn[q][mi]);
@@ -530,7 +585,7 @@ DEV void wave_main(const GroupArgs& ga, int wave, int nwaves, float* lds) {
                     }
                 }
                 if (ch == 0) {
-                    PINN_UNROLL for (int to = 0; to < MT; ++to) bfr[0][to] += zf[to];
+                    PINN_UNROLL for (int to = 0; to < MT; ++to) bfr0[to] += zf[to];
                     PINN_UNROLL for (int i = 0; i < D; ++i) {
                         vfloat xc = lds_load(xs, (vint(16 * pg) + row) * D + vint(i));
                         PINN_UNROLL for (int to = 0; to < MT; ++to) w1fr[i][to] = vfma(zf[to], xc, w1fr[i][to]);
@@ -547,29 +602,38 @@ DEV void wave_main(const GroupArgs& ga, int wave, int nwaves, float* lds) {
 
     if (MODE != MODE_FUSED) return;
 
-    // =========================== epilogue: per-wave slab ===========================
+    // =========================== epilogue: gradient slab ===========================
     if (cur_term >= 0) {
         double s = wave_sum_d(lsum, g0);
         ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[cur_term].term_id] = s;
     }
-    float* slab = ga.slabs + (size_t)wave * S::SLAB;
+    // per-workgroup slab: [shared section | 4 x per-wave section]; COOP: dW / hidden-bias rows are written by their
+    // owner wave into the shared section, everything else (and everything for small nets) is per wave.
+    float* slab_wg = ga.slabs + (size_t)blk * S::SLAB;
+    float* mine = slab_wg + S::SH + w * S::PW;
+    float* big = S::COOP ? slab_wg : mine;
     PINN_UNROLL for (int hl = 0; hl < NHH; ++hl)
-        PINN_UNROLL for (int to = 0; to < MT; ++to)
+        PINN_UNROLL for (int to = 0; to < WT; ++to) {
+            const int trow = S::COOP ? w : to;
             PINN_UNROLL for (int ti = 0; ti < MT; ++ti)
-                gstore4(slab + S::G_WBAR + hl * HP * HP, vint((to * MT + ti) * 256) + (lane << 2), wbar[hl][to][ti]);
-    PINN_UNROLL for (int l = 0; l < LH; ++l)
-        PINN_UNROLL for (int to = 0; to < MT; ++to) {
-            vfloat v = bfr[l][to];
+                gstore4(big + S::O_WBAR + hl * HP * HP, vint((trow * MT + ti) * 256) + (lane << 2), wbar[hl][to][ti]);
+            vfloat v = bfrh[hl][to];
             v = v + shfl_xor(v, 16);
             v = v + shfl_xor(v, 32);
-            gstore_masked(slab + S::G_BFR, vint((l * MT + to) * 16) + c, v, g0);
+            gstore_masked(big + S::O_BFRH, vint((hl * MT + trow) * 16) + c, v, g0);
         }
+    PINN_UNROLL for (int to = 0; to < MT; ++to) {
+        vfloat v = bfr0[to];
+        v = v + shfl_xor(v, 16);
+        v = v + shfl_xor(v, 32);
+        gstore_masked(mine + S::O_BFR0, vint(to * 16) + c, v, g0);
+    }
     PINN_UNROLL for (int i = 0; i < D; ++i)
         PINN_UNROLL for (int to = 0; to < MT; ++to) {
             vfloat v = w1fr[i][to];
             v = v + shfl_xor(v, 16);
             v = v + shfl_xor(v, 32);
-            gstore_masked(slab + S::G_W1, vint((i * MT + to) * 16) + c, v, g0);
+            gstore_masked(mine + S::O_W1, vint((i * MT + to) * 16) + c, v, g0);
         }
     const vbool c0 = veq(c, 0);
     PINN_UNROLL for (int m = 0; m < MT; ++m)
@@ -579,15 +643,15 @@ DEV void wave_main(const GroupArgs& ga, int wave, int nwaves, float* lds) {
             v = v + shfl_xor(v, 2);
             v = v + shfl_xor(v, 4);
             v = v + shfl_xor(v, 8);
-            gstore_masked(slab + S::G_WL, ((vint(m * 4) + g) << 2) + vint(r), v, c0);
+            gstore_masked(mine + S::O_WL, ((vint(m * 4) + g) << 2) + vint(r), v, c0);
         }
     {
         vbool all = vlt(lane, 64);
         float s = (float)wave_sum_d(bLbar, all);
-        gstore_masked(slab + S::G_BL, vint(0), vfloat(s), veq(lane, 0));
+        gstore_masked(mine + S::O_BL, vint(0), vfloat(s), veq(lane, 0));
         PINN_UNROLL for (int j = 0; j < MAX_PARAMS; ++j) {
             float sp = (float)wave_sum_d(pbar[j], all);
-            gstore_masked(slab + S::G_P, vint(j), vfloat(sp), veq(lane, 0));
+            gstore_masked(mine + S::O_P, vint(j), vfloat(sp), veq(lane, 0));
         }
     }
 }

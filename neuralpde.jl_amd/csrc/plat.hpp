@@ -26,6 +26,7 @@ inline void plat_event_create(plat_event&) {}
 inline void plat_event_destroy(plat_event&) {}
 inline void plat_event_record(plat_event&, plat_stream) {}
 inline float plat_event_ms(plat_event&, plat_event&) { return 0.f; }
+inline void plat_event_sync(plat_event&) {}
 inline const char* plat_last_error() { return ""; }
 #else
 #include <hip/hip_runtime.h>
@@ -65,5 +66,6 @@ inline void plat_stream_destroy(plat_stream s) { if (s) (void)hipStreamDestroy(s
 inline void plat_event_create(plat_event& e) { (void)hipEventCreate(&e.e); }
 inline void plat_event_destroy(plat_event& e) { (void)hipEventDestroy(e.e); }
 inline void plat_event_record(plat_event& e, plat_stream s) { (void)hipEventRecord(e.e, s); }
+inline void plat_event_sync(plat_event& e) { (void)hipEventSynchronize(e.e); }
 inline float plat_event_ms(plat_event& a, plat_event& b) { float ms = 0.f; (void)hipEventElapsedTime(&ms, a.e, b.e); return ms; }
 #endif

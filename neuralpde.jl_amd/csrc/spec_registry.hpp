@@ -1,5 +1,8 @@
 // spec_registry.hpp — table of compiled kernel-family members (one per translation unit inst_*.hip).
 #pragma once
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "pinn_kernels.hpp"
@@ -12,9 +15,9 @@ struct SpecInfo {
     unsigned D1MASK;
     unsigned long long PAIRS;
     int NPAIR, PG, C, NG, TP, MT, LH, NFIRST;
-    int PACKED, SLAB, SCR, LDS_WAVE;
+    int PACKED, SLAB, SCR, LDS_WG, COOP, SH, PW;
     int OFF_W1, OFF_B, OFF_WL, OFF_BL, OFF_WPK, OFF_WTPK;
-    int G_WBAR, G_BFR, G_W1, G_WL, G_BL, G_P;
+    int O_WBAR, O_BFRH, O_BFR0, O_W1, O_WL, O_BL, O_P;
     void (*launch)(const GroupArgs&, int mode, int blocks, plat_stream);
 };
 
@@ -25,23 +28,44 @@ SpecInfo make_info(void (*launch)(const GroupArgs&, int, int, plat_stream)) {
     SpecInfo s;
     s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR;
     s.PG = S::PG; s.C = S::C; s.NG = S::NG; s.TP = S::TP; s.MT = S::MT; s.LH = S::LH; s.NFIRST = S::NFIRST;
-    s.PACKED = S::PACKED; s.SLAB = S::SLAB; s.SCR = S::SCR; s.LDS_WAVE = S::LDS_WAVE;
+    s.PACKED = S::PACKED; s.SLAB = S::SLAB; s.SCR = S::SCR; s.LDS_WG = S::LDS_WG; s.COOP = S::COOP ? 1 : 0; s.SH = S::SH; s.PW = S::PW;
     s.OFF_W1 = S::OFF_W1; s.OFF_B = S::OFF_B; s.OFF_WL = S::OFF_WL; s.OFF_BL = S::OFF_BL;
     s.OFF_WPK = S::OFF_WPK; s.OFF_WTPK = S::OFF_WTPK;
-    s.G_WBAR = S::G_WBAR; s.G_BFR = S::G_BFR; s.G_W1 = S::G_W1; s.G_WL = S::G_WL; s.G_BL = S::G_BL; s.G_P = S::G_P;
+    s.O_WBAR = S::O_WBAR; s.O_BFRH = S::O_BFRH; s.O_BFR0 = S::O_BFR0; s.O_W1 = S::O_W1; s.O_WL = S::O_WL; s.O_BL = S::O_BL; s.O_P = S::O_P;
     s.launch = launch;
     return s;
 }
 
 #ifdef PINN_EMU
+// The emulation runs the four waves of a workgroup as four host threads joined by a barrier, so that the COOP dW phase
+// (workgroup barriers + shared LDS) executes with real concurrency.
+struct EmuBarrier {
+    std::mutex m;
+    std::condition_variable cv;
+    int count = 0, gen = 0;
+    static void wait(void* p) {
+        EmuBarrier* b = (EmuBarrier*)p;
+        std::unique_lock<std::mutex> lk(b->m);
+        const int g = b->gen;
+        if (++b->count == 4) { b->count = 0; ++b->gen; b->cv.notify_all(); }
+        else b->cv.wait(lk, [&] { return b->gen != g; });
+    }
+};
 template <class S, int MODE>
 void run_emu(const GroupArgs& ga, int blocks) {
-    std::vector<float> lds((size_t)S::LDS_WAVE);
-    for (int b = 0; b < blocks; ++b)
-        for (int w = 0; w < 4; ++w) {
-            std::fill(lds.begin(), lds.end(), 0.f);
-            wave_main<S, MODE>(ga, b * 4 + w, blocks * 4, lds.data());
-        }
+    std::vector<float> lds((size_t)S::LDS_WG);
+    for (int b = 0; b < blocks; ++b) {
+        std::fill(lds.begin(), lds.end(), 0.f);
+        EmuBarrier bar;
+        std::thread th[4];
+        for (int w = 0; w < 4; ++w)
+            th[w] = std::thread([&, w] {
+                wv::emu_barrier_hook = &EmuBarrier::wait;
+                wv::emu_barrier_ctx = &bar;
+                wave_main<S, MODE>(ga, b, blocks, w, lds.data());
+            });
+        for (int w = 0; w < 4; ++w) th[w].join();
+    }
 }
 template <class S>
 void launch_spec(const GroupArgs& ga, int mode, int blocks, plat_stream) {
@@ -55,9 +79,9 @@ void launch_spec(const GroupArgs& ga, int mode, int blocks, plat_stream) {
 // is available for the persistent dW accumulators (MI355X_MICROARCH.md "Register files").
 template <class S, int MODE>
 __global__ void __launch_bounds__(256, 1) k_wave(const GroupArgs ga) {
-    __shared__ __attribute__((aligned(16))) float lds_all[4 * S::LDS_WAVE];
+    __shared__ __attribute__((aligned(16))) float lds_all[S::LDS_WG];
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    wave_main<S, MODE>(ga, (int)blockIdx.x * 4 + w, (int)gridDim.x * 4, lds_all + w * S::LDS_WAVE);
+    wave_main<S, MODE>(ga, (int)blockIdx.x, (int)gridDim.x, w, lds_all);
 }
 template <class S>
 void launch_spec(const GroupArgs& ga, int mode, int blocks, plat_stream st) {

@@ -56,6 +56,7 @@ inline vfloat vfma(const vfloat& a, const vfloat& b, const vfloat& c) {
 VFN1(vtanh, std::tanh(x)) VFN1(vsin, std::sin(x)) VFN1(vcos, std::cos(x)) VFN1(vexp, std::exp(x))
 VFN1(vlog, std::log(x)) VFN1(vsqrt, std::sqrt(x)) VFN1(vabs, std::fabs(x)) VFN1(vsinh, std::sinh(x))
 VFN1(vcosh, std::cosh(x)) VFN1(vtan, std::tan(x)) VFN1(vrcp, 1.0f / x)
+VFN1(vtanh_fast, std::tanh(x)) VFN1(vsigmoid_fast, 1.0f / (1.0f + std::exp(-x)))
 VFN1(vsign, (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f))
 VFN1(vsinpi, std::sin(3.14159265358979323846f * x)) VFN1(vcospi, std::cos(3.14159265358979323846f * x))
 #undef VFN1
@@ -75,12 +76,22 @@ inline void gstore(float* p, const vint& i, const vfloat& x) { for (int l = 0; l
 inline void gstore_masked(float* p, const vint& i, const vfloat& x, const vbool& m) { for (int l = 0; l < W; ++l) if (m.v[l]) p[i.v[l]] = x.v[l]; }
 inline vfloat4 gload4(const float* p, const vint& i) { vfloat4 r; for (int k = 0; k < 4; ++k) for (int l = 0; l < W; ++l) r.x[k].v[l] = p[i.v[l] + k]; return r; }
 inline void gstore4(float* p, const vint& i, const vfloat4& x) { for (int k = 0; k < 4; ++k) for (int l = 0; l < W; ++l) p[i.v[l] + k] = x.x[k].v[l]; }
+// uniform-base buffer view (device: buffer descriptor in SGPRs + scalar offset + per-lane voffset)
+struct ubuf { float* p; };
+inline ubuf ub_make(const float* p, size_t) { return ubuf{const_cast<float*>(p)}; }
+inline vfloat4 ub_load4(const ubuf& b, int soff, const vint& voff) { vfloat4 r; for (int k = 0; k < 4; ++k) for (int l = 0; l < W; ++l) r.x[k].v[l] = b.p[soff + voff.v[l] + k]; return r; }
+inline void ub_store4(const ubuf& b, int soff, const vint& voff, const vfloat4& x) { for (int k = 0; k < 4; ++k) for (int l = 0; l < W; ++l) b.p[soff + voff.v[l] + k] = x.x[k].v[l]; }
+inline vfloat ub_load(const ubuf& b, int soff, const vint& voff) { vfloat r; for (int l = 0; l < W; ++l) r.v[l] = b.p[soff + voff.v[l]]; return r; }
 // LDS (per-wave private region in the emulation == a plain array)
 inline vfloat lds_load(const float* p, const vint& i) { return gload(p, i); }
 inline void lds_store(float* p, const vint& i, const vfloat& x) { gstore(p, i, x); }
 inline vfloat4 lds_load4(const float* p, const vint& i) { return gload4(p, i); }
 inline void lds_store4(float* p, const vint& i, const vfloat4& x) { gstore4(p, i, x); }
 inline void wave_fence() {}
+// workgroup barrier: the emulation runs the 4 waves of a workgroup as host threads (spec_registry.hpp)
+extern thread_local void (*emu_barrier_hook)(void*);
+extern thread_local void* emu_barrier_ctx;
+inline void wg_barrier() { if (emu_barrier_hook) emu_barrier_hook(emu_barrier_ctx); }
 // cross-lane
 inline vfloat shfl_xor(const vfloat& a, int m) { vfloat r; for (int l = 0; l < W; ++l) r.v[l] = a.v[l ^ m]; return r; }
 inline float lane0(const vfloat& a) { return a.v[0]; }
@@ -125,7 +136,11 @@ DEV vfloat vsqrt(vfloat x) { return sqrtf(x); }
 DEV vfloat vabs(vfloat x) { return fabsf(x); }
 DEV vfloat vsinh(vfloat x) { return sinhf(x); }
 DEV vfloat vcosh(vfloat x) { return coshf(x); }
-DEV vfloat vrcp(vfloat x) { return 1.0f / x; }
+DEV vfloat vrcp(vfloat x) { return __builtin_amdgcn_rcpf(x); }
+// tanh(x) = 1 - 2/(exp(2x)+1) on v_exp_f32 / v_rcp_f32: absolute error ~1e-7 (the quantity that matters for a
+// bounded activation feeding a linear layer); saturates correctly to +-1 for |x| large.
+DEV vfloat vtanh_fast(vfloat x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
+DEV vfloat vsigmoid_fast(vfloat x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 DEV vfloat vsign(vfloat x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
 DEV vfloat vsinpi(vfloat x) { return sinpif(x); }
 DEV vfloat vcospi(vfloat x) { return cospif(x); }
@@ -144,6 +159,24 @@ DEV void gstore(float* p, vint i, vfloat x) { p[i] = x; }
 DEV void gstore_masked(float* p, vint i, vfloat x, vbool m) { if (m) p[i] = x; }
 DEV vfloat4 gload4(const float* p, vint i) { return *reinterpret_cast<const vfloat4*>(p + i); }
 DEV void gstore4(float* p, vint i, vfloat4 x) { *reinterpret_cast<vfloat4*>(p + i) = x; }
+// Uniform-base buffer view: descriptor in SGPRs + scalar byte offset + ONE per-lane voffset VGPR.  Used for every access
+// of the form base[const + f(lane)] inside the tile loop: with flat `global_*` the compiler materialises one 64-bit VGPR
+// address per distinct constant (>4 KB apart), hoists hundreds of them out of the loop and spills them
+// (cdna_hip_programming.md T8/T20).  `p` must be wave-uniform.
+struct ubuf { __amdgpu_buffer_rsrc_t r; };
+typedef unsigned vuint4 __attribute__((ext_vector_type(4)));
+DEV ubuf ub_make(const float* p, size_t nfloats) {
+    return ubuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)(nfloats * 4), 0x00020000)};
+}
+DEV vfloat4 ub_load4(ubuf b, int soff, vint voff) {
+    return __builtin_bit_cast(vfloat4, __builtin_amdgcn_raw_buffer_load_b128(b.r, voff * 4, soff * 4, 0));
+}
+DEV void ub_store4(ubuf b, int soff, vint voff, vfloat4 x) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vuint4, x), b.r, voff * 4, soff * 4, 0);
+}
+DEV vfloat ub_load(ubuf b, int soff, vint voff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, voff * 4, soff * 4, 0));
+}
 DEV vfloat lds_load(const float* p, vint i) { return p[i]; }
 DEV void lds_store(float* p, vint i, vfloat x) { p[i] = x; }
 DEV vfloat4 lds_load4(const float* p, vint i) { return *reinterpret_cast<const vfloat4*>(p + i); }
@@ -156,6 +189,7 @@ DEV void wave_fence() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+DEV void wg_barrier() { __syncthreads(); }
 DEV vfloat shfl_xor(vfloat a, int m) { return __shfl_xor(a, m, 64); }
 DEV float lane0(vfloat a) { return __builtin_amdgcn_readfirstlane(a); }
 DEV double wave_sum_d(vfloat a, vbool m) {

@@ -1,0 +1,106 @@
+"""The BASELINE.json configurations as concrete problem statements + synthetic inputs.
+
+Used by bench.py (config 2 is the bench workload) and by the parity tests (all configs, possibly at
+reduced point counts).  Synthetic data only: theta ~ glorot-uniform weights / U(+-0.1) biases from
+numpy.random.default_rng(1000 + cfg), Sobol / grid / uniform collocation sets as listed below.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+import sympy as sp
+
+from .pinn import Chain, Dense, NonAdaptiveLoss, PhysicsInformedNN
+from .strategies import GridTraining, QuasiRandomTraining, SobolSample, StochasticTraining
+from .symbolic import Differential, Eq, In, Interval, PDESystem, parameters, variables
+
+
+@dataclass
+class Workload:
+    name: str
+    pde_system: PDESystem
+    chains: List[Chain]
+    strategy: object
+    theta: np.ndarray
+    adaptive_loss: Optional[NonAdaptiveLoss] = None
+    param_estim: bool = False
+    n_interior: int = 0
+
+    def discretization(self) -> PhysicsInformedNN:
+        chain = self.chains if len(self.chains) > 1 else self.chains[0]
+        return PhysicsInformedNN(chain, self.strategy, init_params=self.theta, adaptive_loss=self.adaptive_loss,
+                                 param_estim=self.param_estim)
+
+
+def mlp(n_in: int, width: int, hidden_layers: int, act: str = "tanh") -> Chain:
+    layers = [Dense(n_in, width, act)] + [Dense(width, width, act) for _ in range(hidden_layers - 1)] + [Dense(width, 1)]
+    return Chain(*layers)
+
+
+def synthetic_theta(chains: List[Chain], seed: int, extra: int = 0, dtype=np.float64) -> np.ndarray:
+    """weights ~ U(+-sqrt(6/(fan_in+fan_out))), biases ~ U(+-0.1)  (SURVEY.md §8d)."""
+    rng = np.random.default_rng(seed)
+    parts = []
+    for ch in chains:
+        for l in ch.layers:
+            lim = math.sqrt(6.0 / (l.n_in + l.n_out))
+            W = rng.uniform(-lim, lim, size=(l.n_out, l.n_in))
+            b = rng.uniform(-0.1, 0.1, size=(l.n_out,))
+            parts += [W.T.reshape(-1), b]
+    if extra:
+        parts.append(np.ones(extra))
+    return np.concatenate(parts).astype(dtype)
+
+
+def cfg1_poisson1d(points: int = 1024, dtype=np.float64) -> Workload:
+    """1-D Poisson u'' = -pi^2 sin(pi x), u(0)=u(1)=0, 3x32 tanh MLP, GridTraining with `points` grid nodes
+    (dx = 1/(points-1): the reference's grid includes both end points, discretize.jl:202-214)."""
+    (x,) = parameters("x")
+    (u,) = variables("u")
+    Dxx = Differential(x) ** 2
+    eq = Eq(Dxx(u(x)), -sp.pi ** 2 * sp.sin(sp.pi * x))
+    bcs = [Eq(u(0.0), 0.0), Eq(u(1.0), 0.0)]
+    sysm = PDESystem([eq], bcs, [In(x, Interval(0.0, 1.0))], [x], [u(x)])
+    chain = mlp(1, 32, 3)
+    return Workload("cfg1_poisson1d_3x32_grid", sysm, [chain], GridTraining(1.0 / (points - 1)),
+                    synthetic_theta([chain], 1001, dtype=dtype), n_interior=points)
+
+
+def cfg2_poisson2d(points: int = 65536, bcs_points: Optional[int] = None, width: int = 64, hidden: int = 4,
+                   dtype=np.float64) -> Workload:
+    """2-D Poisson on the unit square exactly as test/NNPDE1/nnpde__pde_ii_2d_poisson.jl:65-76, 4x64 tanh MLP,
+    QuasiRandomTraining(points) with a fixed scrambled-Sobol design (resampling = false, as the reference's own
+    deterministic tests do, test/NNPDE1/nnpde__pde_vi_pde_with_mixed_derivative.jl:78-80)."""
+    x, y = parameters("x y")
+    (u,) = variables("u")
+    Dxx, Dyy = Differential(x) ** 2, Differential(y) ** 2
+    eq = Eq(Dxx(u(x, y)) + Dyy(u(x, y)), -sp.sin(sp.pi * x) * sp.sin(sp.pi * y))
+    bcs = [Eq(u(0, y), 0.0), Eq(u(1, y), 0.0), Eq(u(x, 0), 0.0), Eq(u(x, 1), 0.0)]
+    dom = [In(x, Interval(0.0, 1.0)), In(y, Interval(0.0, 1.0))]
+    sysm = PDESystem([eq], bcs, dom, [x, y], [u(x, y)])
+    chain = mlp(2, width, hidden)
+    strat = QuasiRandomTraining(points, bcs_points=bcs_points, sampling_alg=SobolSample(seed=1002), resampling=False, minibatch=1)
+    return Workload("cfg2_poisson2d_4x64_quasirandom", sysm, [chain], strat, synthetic_theta([chain], 1002, dtype=dtype),
+                    n_interior=points)
+
+
+def cfg3_burgers(points: int = 262144, bcs_points: Optional[int] = None, dtype=np.float64) -> Workload:
+    """Burgers u_t + u u_x - (0.01/pi) u_xx = 0 (docs/src/tutorials/low_level.md:27-32), (t,x) in [0,1]x[-1,1],
+    u(0,x) = -sin(pi x), u(t,-1) = u(t,1) = 0; 4x64 tanh MLP."""
+    t, x = parameters("t x")
+    (u,) = variables("u")
+    Dt, Dx, Dxx = Differential(t), Differential(x), Differential(x) ** 2
+    eq = Eq(Dt(u(t, x)) + u(t, x) * Dx(u(t, x)) - (0.01 / sp.pi) * Dxx(u(t, x)), 0)
+    bcs = [Eq(u(0, x), -sp.sin(sp.pi * x)), Eq(u(t, -1), 0.0), Eq(u(t, 1), 0.0)]
+    dom = [In(t, Interval(0.0, 1.0)), In(x, Interval(-1.0, 1.0))]
+    sysm = PDESystem([eq], bcs, dom, [t, x], [u(t, x)])
+    chain = mlp(2, 64, 4)
+    strat = QuasiRandomTraining(points, bcs_points=bcs_points, sampling_alg=SobolSample(seed=1003), resampling=False, minibatch=1)
+    return Workload("cfg3_burgers_4x64_quasirandom", sysm, [chain], strat, synthetic_theta([chain], 1003, dtype=dtype),
+                    n_interior=points)
+
+
+CONFIGS = {"cfg1": cfg1_poisson1d, "cfg2": cfg2_poisson2d, "cfg3": cfg3_burgers}
