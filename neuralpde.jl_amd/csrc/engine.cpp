@@ -88,10 +88,9 @@ struct Group {
     double* d_losspart = nullptr;
     float* d_scratch = nullptr;
     int* d_ent_off = nullptr;        // reduce map: slab offset of every entry
-    int* d_row_ptr = nullptr;        // reduce map: CSR rows (one per theta element touched by this group)
-    int* d_row_theta = nullptr;
     double* d_tmp = nullptr;         // stage-1 partial sums [nsplit][nent + K]
-    int nent = 0, nrows = 0;
+    std::vector<int> row_theta, row_ptr;   // host CSR: theta element -> entries of this group
+    int nent = 0;
     int blocks = 0;
     int max_blocks = 0;
     bool active = false;
@@ -121,8 +120,10 @@ struct pinn_engine {
     float* d_theta = nullptr;
     float* d_params = nullptr;
     float* d_defaults = nullptr;
-    double* d_gradd = nullptr;
     double* d_lossraw = nullptr;
+    int* d_gr_ptr = nullptr;         // global reduce CSR over theta: contributions (group, entry)
+    int* d_gr_grp = nullptr;
+    int* d_gr_ent = nullptr;
     float* d_out = nullptr;          // [P grad | K raw sums]
     std::vector<float> h_out;
     plat_event ev0, ev1, ev2, ev3;
@@ -393,6 +394,8 @@ int build_plan(pinn_engine& E) {
         G.d_losspart = (double*)plat_malloc(sizeof(double) * nw * total_terms);
         G.d_scratch = (float*)plat_malloc(sizeof(float) * nw * s.SCR);
         if (!G.d_slabs || !G.d_losspart || !G.d_scratch) return fail("device allocation failed (group buffers)");
+        // columns of terms this group does not own are never written by its kernel but are summed by the reduction
+        plat_memset(G.d_losspart, 0, sizeof(double) * nw * total_terms, E.stream);
         // programs (rows remapped to the kernel's channel numbering)
         std::vector<rp::Instr> prog;
         for (int ti : G.terms) {
@@ -463,15 +466,12 @@ int build_plan(pinn_engine& E) {
         add_row(loff[LH] + N.sizes[LH], s.O_BL, false);
         for (int j = 0; j < E.ne; ++j) add_row(E.p_theta_off + j, s.O_P + j, false);
         G.nent = (int)ent.size();
-        G.nrows = (int)row_theta.size();
+        G.row_theta = row_theta;
+        G.row_ptr = row_ptr;
         G.d_ent_off = (int*)plat_malloc(sizeof(int) * G.nent);
-        G.d_row_ptr = (int*)plat_malloc(sizeof(int) * (G.nrows + 1));
-        G.d_row_theta = (int*)plat_malloc(sizeof(int) * G.nrows);
         G.d_tmp = (double*)plat_malloc(sizeof(double) * (size_t)REDUCE_SPLIT * (G.nent + total_terms));
-        if (!G.d_ent_off || !G.d_row_ptr || !G.d_row_theta || !G.d_tmp) return fail("device allocation failed (reduce map)");
+        if (!G.d_ent_off || !G.d_tmp) return fail("device allocation failed (reduce map)");
         plat_h2d(G.d_ent_off, ent.data(), sizeof(int) * G.nent, E.stream);
-        plat_h2d(G.d_row_ptr, row_ptr.data(), sizeof(int) * (G.nrows + 1), E.stream);
-        plat_h2d(G.d_row_theta, row_theta.data(), sizeof(int) * G.nrows, E.stream);
         plat_sync(E.stream);
         // static part of the launch arguments
         pk::GroupArgs& ga = G.ga;
@@ -487,6 +487,31 @@ int build_plan(pinn_engine& E) {
         ga.nparams = E.np;
         ga.nparams_estim = E.ne;
         ga.act = N.act;
+    }
+    // ---- global reduce map: theta element -> (group, slab entry) contributions, group order fixed ----
+    if ((int)E.groups.size() > aux::MAX_GROUPS) return fail("too many kernel launch groups for one engine");
+    {
+        std::vector<std::vector<std::pair<int, int>>> contrib((size_t)E.ntheta);
+        for (size_t g = 0; g < E.groups.size(); ++g) {
+            const Group& G = E.groups[g];
+            for (size_t r = 0; r < G.row_theta.size(); ++r)
+                for (int e = G.row_ptr[r]; e < G.row_ptr[r + 1]; ++e) contrib[G.row_theta[r]].push_back({(int)g, e});
+        }
+        std::vector<int> ptr{0}, grp, ent;
+        for (auto& c : contrib) {
+            for (auto& pr : c) { grp.push_back(pr.first); ent.push_back(pr.second); }
+            ptr.push_back((int)grp.size());
+        }
+        E.d_gr_ptr = (int*)plat_malloc(sizeof(int) * ptr.size());
+        E.d_gr_grp = (int*)plat_malloc(sizeof(int) * std::max<size_t>(grp.size(), 1));
+        E.d_gr_ent = (int*)plat_malloc(sizeof(int) * std::max<size_t>(ent.size(), 1));
+        if (!E.d_gr_ptr || !E.d_gr_grp || !E.d_gr_ent) return fail("device allocation failed (global reduce map)");
+        plat_h2d(E.d_gr_ptr, ptr.data(), sizeof(int) * ptr.size(), E.stream);
+        if (!grp.empty()) {
+            plat_h2d(E.d_gr_grp, grp.data(), sizeof(int) * grp.size(), E.stream);
+            plat_h2d(E.d_gr_ent, ent.data(), sizeof(int) * ent.size(), E.stream);
+        }
+        plat_sync(E.stream);
     }
     return 0;
 }
@@ -521,25 +546,32 @@ int ensure_points(pinn_engine& E) {
     return 0;
 }
 
-void pack_all(pinn_engine& E) {
+void pack_all(pinn_engine& E, const float* d_theta = nullptr) {
+    const float* th = d_theta ? d_theta : E.d_theta;
     for (size_t n = 0; n < E.nets.size(); ++n) {
         NetPlan& NP = E.netplans[n];
         if (!NP.spec) continue;
-        aux::launch_pack(NP.d_packed, NP.d_pack_idx, E.d_theta, NP.npacked, E.stream);
+        aux::launch_pack(NP.d_packed, NP.d_pack_idx, th, NP.npacked, E.stream);
     }
-    aux::launch_params(E.d_params, E.d_theta, E.d_defaults, E.np, E.ne, E.p_theta_off, E.stream);
+    aux::launch_params(E.d_params, th, E.d_defaults, E.np, E.ne, E.p_theta_off, E.stream);
 }
 
 // the device section shared by all loss/grad entry points; theta must already be in E.d_theta
-int run_loss_grad(pinn_engine& E, const float* term_w, int only_term /* -1 = all */, bool timing) {
+// the device section shared by all loss/grad entry points.  d_theta: theta in device memory; d_out: [P + K] floats in
+// device memory.  Launches per evaluation: pack (1 per net) -> fused residual kernel (1 per group) -> reduce1 -> reduce2.
+int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const float* term_w, int only_term /* -1 = all */, bool timing) {
     if (ensure_points(E)) return 1;
     const int K = (int)E.terms.size();
     if (timing) plat_event_record(E.ev0, E.stream);
-    pack_all(E);
-    plat_memset(E.d_gradd, 0, sizeof(double) * E.ntheta, E.stream);
-    plat_memset(E.d_lossraw, 0, sizeof(double) * K, E.stream);
+    pack_all(E, d_theta);
     if (timing) plat_event_record(E.ev1, E.stream);
-    for (auto& G : E.groups) {
+    aux::Reduce1Args a1;
+    aux::Reduce2Args a2;
+    std::memset(&a1, 0, sizeof a1);
+    std::memset(&a2, 0, sizeof a2);
+    int max_n1 = 1, max_split = 1;
+    for (size_t g = 0; g < E.groups.size(); ++g) {
+        Group& G = E.groups[g];
         bool any = false;
         for (size_t j = 0; j < G.terms.size(); ++j) {
             const int ti = G.terms[j];
@@ -550,23 +582,23 @@ int run_loss_grad(pinn_engine& E, const float* term_w, int only_term /* -1 = all
             any = any || on;
         }
         G.active = any;
+        const int nsplit = std::min(REDUCE_SPLIT, G.blocks);
+        a1.tmp[g] = G.d_tmp; a1.slabs[g] = G.d_slabs; a1.losspart[g] = G.d_losspart; a1.ent_off[g] = G.d_ent_off;
+        a1.slab[g] = G.spec->SLAB; a1.nblocks[g] = G.blocks; a1.nsplit[g] = nsplit; a1.nent[g] = G.nent; a1.active[g] = any;
+        a2.tmp[g] = G.d_tmp; a2.stride[g] = G.nent + K; a2.nsplit[g] = nsplit; a2.nent[g] = G.nent; a2.active[g] = any;
         if (!any) continue;
-        plat_memset(G.d_losspart, 0, sizeof(double) * (size_t)G.blocks * 4 * K, E.stream);
+        max_n1 = std::max(max_n1, G.nent + K);
+        max_split = std::max(max_split, nsplit);
         if (timing) plat_event_record(G.ev_a, E.stream);
         G.spec->launch(G.ga, pk::MODE_FUSED, G.blocks, E.stream);
         if (timing) plat_event_record(G.ev_b, E.stream);
         G.timed = timing;
     }
     if (timing) plat_event_record(E.ev2, E.stream);
-    for (auto& G : E.groups) {
-        if (!G.active) continue;
-        aux::ReduceArgs ra;
-        ra.gradd = E.d_gradd; ra.lossraw = E.d_lossraw; ra.tmp = G.d_tmp; ra.slabs = G.d_slabs; ra.slab = G.spec->SLAB;
-        ra.nblocks = G.blocks; ra.nsplit = std::min(REDUCE_SPLIT, G.blocks); ra.ent_off = G.d_ent_off; ra.nent = G.nent;
-        ra.row_ptr = G.d_row_ptr; ra.row_theta = G.d_row_theta; ra.nrows = G.nrows; ra.losspart = G.d_losspart; ra.K = K;
-        aux::launch_reduce(ra, E.stream);
-    }
-    aux::launch_finish(E.d_out, E.d_gradd, E.d_lossraw, (int)E.ntheta, K, E.stream);
+    a1.K = K;
+    a2.out = d_out; a2.lossraw = E.d_lossraw; a2.row_ptr = E.d_gr_ptr; a2.row_grp = E.d_gr_grp; a2.row_ent = E.d_gr_ent;
+    a2.ngroups = (int)E.groups.size(); a2.P = (int)E.ntheta; a2.K = K;
+    aux::launch_reduce(a1, a2, max_n1, max_split, E.stream);
     if (timing) plat_event_record(E.ev3, E.stream);
     return 0;
 }
@@ -601,10 +633,9 @@ int pinn_create(const char* descriptor, pinn_handle* out) {
     E->d_theta = (float*)plat_malloc(sizeof(float) * E->ntheta);
     E->d_params = (float*)plat_malloc(sizeof(float) * pk::MAX_PARAMS);
     E->d_defaults = (float*)plat_malloc(sizeof(float) * pk::MAX_PARAMS);
-    E->d_gradd = (double*)plat_malloc(sizeof(double) * E->ntheta);
     E->d_lossraw = (double*)plat_malloc(sizeof(double) * K);
     E->d_out = (float*)plat_malloc(sizeof(float) * (E->ntheta + K));
-    if (!E->d_theta || !E->d_params || !E->d_defaults || !E->d_gradd || !E->d_lossraw || !E->d_out) return fail("device allocation failed");
+    if (!E->d_theta || !E->d_params || !E->d_defaults || !E->d_lossraw || !E->d_out) return fail("device allocation failed");
     plat_h2d(E->d_defaults, E->p_defaults.data(), sizeof(float) * pk::MAX_PARAMS, E->stream);
     E->h_out.resize(E->ntheta + K);
     plat_event_create(E->ev0); plat_event_create(E->ev1); plat_event_create(E->ev2); plat_event_create(E->ev3);
@@ -620,11 +651,11 @@ int pinn_destroy(pinn_handle h) {
     for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_resid); }
     for (auto& G : E.groups) {
         plat_free(G.d_prog); plat_free(G.d_slabs); plat_free(G.d_losspart); plat_free(G.d_scratch);
-        plat_free(G.d_ent_off); plat_free(G.d_row_ptr); plat_free(G.d_row_theta); plat_free(G.d_tmp);
+        plat_free(G.d_ent_off); plat_free(G.d_tmp);
         plat_event_destroy(G.ev_a); plat_event_destroy(G.ev_b);
     }
     for (auto& N : E.netplans) { plat_free(N.d_packed); plat_free(N.d_pack_idx); }
-    plat_free(E.d_theta); plat_free(E.d_params); plat_free(E.d_defaults); plat_free(E.d_gradd); plat_free(E.d_lossraw);
+    plat_free(E.d_theta); plat_free(E.d_params); plat_free(E.d_defaults); plat_free(E.d_lossraw); plat_free(E.d_gr_ptr); plat_free(E.d_gr_grp); plat_free(E.d_gr_ent);
     plat_free(E.d_out); plat_free(E.d_phi_pts); plat_free(E.d_phi_out);
     plat_event_destroy(E.ev0); plat_event_destroy(E.ev1); plat_event_destroy(E.ev2); plat_event_destroy(E.ev3);
     if (E.own_stream) plat_stream_destroy(E.stream);
@@ -664,7 +695,7 @@ int pinn_loss_grad(pinn_handle h, const float* theta, int64_t p, const float* te
     pinn_engine& E = *h;
     const int K = (int)E.terms.size();
     if (upload_theta(E, theta, p)) return 1;
-    if (run_loss_grad(E, term_w, -1, true)) return 1;
+    if (run_loss_grad(E, E.d_theta, E.d_out, term_w, -1, true)) return 1;
     if (plat_d2h(E.h_out.data(), E.d_out, sizeof(float) * (E.ntheta + K), E.stream)) return fail("D2H copy failed");
     // exact double sums for the host path
     std::vector<double> raw(K);
@@ -697,7 +728,7 @@ int pinn_term_grads(pinn_handle h, const float* theta, int64_t p, double* term_l
     const int K = (int)E.terms.size();
     if (upload_theta(E, theta, p)) return 1;
     for (int k = 0; k < K; ++k) {
-        if (run_loss_grad(E, nullptr, k, false)) return 1;
+        if (run_loss_grad(E, E.d_theta, E.d_out, nullptr, k, false)) return 1;
         if (plat_d2h(term_grads + (size_t)k * p, E.d_out, sizeof(float) * p, E.stream)) return fail("D2H copy failed");
         double raw = 0;
         if (plat_d2h(&raw, E.d_lossraw + k, sizeof(double), E.stream)) return fail("D2H copy failed");
@@ -714,9 +745,7 @@ int pinn_loss_grad_device(pinn_handle h, const float* d_theta, const float* term
     plat_stream user = (plat_stream)stream;
     plat_stream saved = E.stream;
     E.stream = user;     // NULL is the (legacy) default stream — e.g. torch's current stream
-    int rc = plat_d2d(E.d_theta, d_theta, sizeof(float) * E.ntheta, E.stream);
-    if (!rc) rc = run_loss_grad(E, term_w, -1, true);
-    if (!rc) rc = plat_d2d(d_out, E.d_out, sizeof(float) * (E.ntheta + K), E.stream);
+    int rc = run_loss_grad(E, d_theta, d_out, term_w, -1, true);
     E.stream = saved;
     if (rc && g_err.empty()) return fail("pinn_loss_grad_device failed");
     E.timing_valid = (rc == 0);

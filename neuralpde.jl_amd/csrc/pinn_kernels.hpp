@@ -155,6 +155,9 @@ DEV void act_derivs(vfloat a, vfloat& d1, vfloat& d2, vfloat& d3) {
     }
 }
 DEV vfloat act_value(int act, vfloat z) {
+#ifdef PINN_ABL_NOACT
+    return z * vfloat(0.25f);
+#endif
     if (act == ACT_TANH) return vtanh_fast(z);
     return vsigmoid_fast(z);
 }
@@ -223,6 +226,8 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
     PINN_UNROLL for (int m = 0; m < MT; ++m) wL[m] = ub_load4(PB, S::OFF_WL + 16 * m, g << 2);
     const float bL = P[S::OFF_BL];
 
+    if (MODE == MODE_FUSED)      // this wave's loss columns start at zero (no host-side memset per evaluation)
+        for (int j = 0; j < ga.nterms; ++j) ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[j].term_id] = 0.0;
     const int niter = (ga.ntiles + 4 * nblocks - 1) / (4 * nblocks);
     for (int it = 0; it < niter; ++it) {
         const int t = (it * nblocks + blk) * 4 + w;          // >= ntiles: dummy tile of the last term, all points masked
@@ -270,7 +275,9 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
             }
         }
 
-        // activation jets in place + park (a, z_i, z_ij) in the scratch slab
+        // raw (a, z_i, z_ij) record of the LAST hidden layer stays in registers for the reverse sweep
+        vfloat4 Rlast[NG][MT];
+        // activation jets in place + park (a, z_i, z_ij) of the other layers in the scratch slab
         auto act_forward = [&](vfloat4 (&Z)[NG][MT], int layer /*0-based hidden layer*/) {
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                 PINN_UNROLL for (int m = 0; m < MT; ++m) {
@@ -283,10 +290,16 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                         av[r] = a; d1v[r] = d1; d2v[r] = d2;
                     }
                     Z[pg * C][m] = av;
+#ifndef PINN_ABL_NOSCR
                     if (MODE == MODE_FUSED) {
-                        PINN_UNROLL for (int ch = 0; ch < C; ++ch)
-                            ub_store4(SB, (((layer * NG) + pg * C + ch) * MT + m) * 256, lane << 2, Z[pg * C + ch][m]);
+                        if (layer == LH - 1) {
+                            PINN_UNROLL for (int ch = 0; ch < C; ++ch) Rlast[pg * C + ch][m] = Z[pg * C + ch][m];
+                        } else {
+                            PINN_UNROLL for (int ch = 0; ch < C; ++ch)
+                                ub_store4(SB, (((layer * NG) + pg * C + ch) * MT + m) * 256, lane << 2, Z[pg * C + ch][m]);
+                        }
                     }
+#endif
                     PINN_UNROLL for (int p = 0; p < NPAIR; ++p) {
                         const int cp = pg * C + 1 + NFIRST + p;
                         const int ca = pg * C + 1 + S::first_rank(S::pair_a(p));
@@ -311,18 +324,30 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                 }
             }
             const int Wf = S::OFF_WPK + hl * HP * HP;
-            PINN_UNROLL for (int mi = 0; mi < MT; ++mi)
-                PINN_UNROLL for (int rr = 0; rr < 4; ++rr) {
-                    vfloat wf[MT];
-                    if (MT == 4) {
-                        vfloat4 w4 = ub_load4(PB, Wf + (mi * 4 + rr) * 64 * MT, lane << 2);
-                        PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wf[mo] = w4[mo & 3];
-                    } else {
-                        PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wf[mo] = ub_load(PB, Wf + (mi * 4 + rr) * 64 * MT + mo, lane * MT);
-                    }
-                    PINN_UNROLL for (int q = 0; q < NG; ++q)
-                        PINN_UNROLL for (int mo = 0; mo < MT; ++mo) Zn[q][mo] = mfma16(wf[mo], A[q][mi][rr], Zn[q][mo]);
+            // k-steps (mi, rr); the fragment of step ks+1 is requested before the MFMAs of step ks (software pipeline:
+            // with one wave per SIMD nothing else hides the L2 latency of a just-in-time load)
+            auto load_wf = [&](int ks, vfloat (&wf)[MT]) {
+                if (MT == 4) {
+                    vfloat4 w4 = ub_load4(PB, Wf + ks * 64 * MT, lane << 2);
+                    PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wf[mo] = w4[mo & 3];
+                } else {
+                    PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wf[mo] = ub_load(PB, Wf + ks * 64 * MT + mo, lane * MT);
                 }
+            };
+            vfloat wcur[MT], wnxt[MT];
+            load_wf(0, wcur);
+            PINN_UNROLL for (int ks = 0; ks < 4 * MT; ++ks) {
+                const int mi = ks >> 2, rr = ks & 3;
+                if (ks + 1 < 4 * MT) load_wf(ks + 1, wnxt);
+#ifdef PINN_ABL_NOFWD
+                PINN_UNROLL for (int q = 0; q < NG; ++q)
+                    PINN_UNROLL for (int mo = 0; mo < MT; ++mo) if (mi == mo) Zn[q][mo][rr] += wcur[mo] * A[q][mi][rr];
+#else
+                PINN_UNROLL for (int q = 0; q < NG; ++q)
+                    PINN_UNROLL for (int mo = 0; mo < MT; ++mo) Zn[q][mo] = mfma16(wcur[mo], A[q][mi][rr], Zn[q][mo]);
+#endif
+                PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wcur[mo] = wnxt[mo];
+            }
             act_forward(Zn, hl + 1);
             PINN_UNROLL for (int q = 0; q < NG; ++q)
                 PINN_UNROLL for (int m = 0; m < MT; ++m) A[q][m] = Zn[q][m];
@@ -348,6 +373,19 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
             }
             continue;
         }
+
+        auto load_raw = [&](vfloat4 (&Sr)[NG][MT], int layer) {
+            PINN_UNROLL for (int q = 0; q < NG; ++q)
+                PINN_UNROLL for (int m = 0; m < MT; ++m)
+                    #ifdef PINN_ABL_NOSCR
+                    Sr[q][m] = vfloat4{0.3f, 0.2f, 0.1f, 0.4f};
+#else
+Sr[q][m] = ub_load4(SB, (((layer * NG) + q) * MT + m) * 256, lane << 2);
+#endif
+        };
+        // prefetch the raw record of the layer feeding the last hidden->hidden GEMM: it lands while the tape runs
+        vfloat4 SrN[NG][MT];
+        if (MODE == MODE_FUSED && NHH > 0) load_raw(SrN, NHH - 1);
 
         // =========================== residual tape (values, then adjoints) ===========================
         vfloat ubar[PG][C];
@@ -404,11 +442,6 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
         if (MODE == MODE_RESID) continue;
 
         // =========================== reverse sweep ===========================
-        auto load_raw = [&](vfloat4 (&Sr)[NG][MT], int layer) {
-            PINN_UNROLL for (int q = 0; q < NG; ++q)
-                PINN_UNROLL for (int m = 0; m < MT; ++m)
-                    Sr[q][m] = ub_load4(SB, (((layer * NG) + q) * MT + m) * 256, lane << 2);
-        };
         // post-activation jet of channel ch from the raw (a, z_i, z_ij) record
         auto ajet = [&](const vfloat4 (&Sr)[NG][MT], int pg, int ch, int m) -> vfloat4 {
             vfloat4 out;
@@ -459,27 +492,26 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
 
         vfloat4 G[NG][MT];     // adjoint chain (dA, then dZ in place)
         {
-            vfloat4 Sr[NG][MT];
-            load_raw(Sr, LH - 1);
-            // output layer: dW_out += sum ubar * a_jets ; dA = w_out * ubar
+            // output layer: dW_out += sum ubar * a_jets (A still holds the last hidden layer's jets); dA = w_out * ubar
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
                 bLbar += vselect(g0, ubar[pg][0], vfloat(0.f));
                 PINN_UNROLL for (int ch = 0; ch < C; ++ch)
                     PINN_UNROLL for (int m = 0; m < MT; ++m) {
-                        vfloat4 aj = ajet(Sr, pg, ch, m);
                         PINN_UNROLL for (int r = 0; r < 4; ++r) {
-                            wLbar[m][r] = vfma(ubar[pg][ch], aj[r], wLbar[m][r]);
+                            wLbar[m][r] = vfma(ubar[pg][ch], A[pg * C + ch][m][r], wLbar[m][r]);
                             G[pg * C + ch][m][r] = wL[m][r] * ubar[pg][ch];
                         }
                     }
             }
-            act_adjoint(G, Sr);
+            act_adjoint(G, Rlast);
         }
 
         PINN_UNROLL for (int hl = NHH - 1; hl >= 0; --hl) {
-            // layer (hl+1) -> (hl+2) weights; inputs are hidden layer hl's a-jets
+            // layer (hl+1) -> (hl+2) weights; inputs are hidden layer hl's a-jets (record prefetched into SrN)
             vfloat4 Sr[NG][MT];
-            load_raw(Sr, hl);
+            PINN_UNROLL for (int q = 0; q < NG; ++q)
+                PINN_UNROLL for (int m = 0; m < MT; ++m) Sr[q][m] = SrN[q][m];
+#ifndef PINN_ABL_NODW
             // ---- dW += dZ A^T through the swizzled LDS transpose, 16 columns at a time ----
             if (COOP) {
                 // Every wave publishes its (dZ^T, A^T) chunk in the workgroup-shared double buffer; after one barrier
@@ -497,17 +529,26 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                         lds_store4(myat, ad, ajet(Sr, pg, ch, m));
                     }
                     wg_barrier();
-                    for (int ws = 0; ws < 4; ++ws) {
+                    // operands of source wave ws+1 are requested before the 16 MFMAs of source wave ws
+                    vfloat zc[4], zn[4];
+                    vfloat4 ac[4], an[4];
+                    auto load_ops = [&](int ws, vfloat (&zf)[4], vfloat4 (&af)[4]) {
                         const float* zt = cb + ws * 2 * S::LDS_T;
                         const float* at = zt + S::LDS_T;
                         PINN_UNROLL for (int kk = 0; kk < 4; ++kk) {
-                            const vint row = vint(4 * kk) + g;
-                            const vint ad = tr_addr<S>(row, c);
-                            vfloat zf1 = lds_load(zt, ad + vint(w));          // dZ[out neuron 4c + w][column row]
-                            vfloat4 a4 = lds_load4(at, ad);                   // A[in neurons 4c .. 4c+3][column row]
-                            PINN_UNROLL for (int ti = 0; ti < MT; ++ti) wbar[hl][0][ti] = mfma16(zf1, a4[ti & 3], wbar[hl][0][ti]);
-                            if (ch == 0) bfrh[hl][0] += zf1;
+                            const vint ad = tr_addr<S>(vint(4 * kk) + g, c);
+                            zf[kk] = lds_load(zt, ad + vint(w));              // dZ[out neuron 4c + w][column 4kk + g]
+                            af[kk] = lds_load4(at, ad);                       // A[in neurons 4c .. 4c+3][column 4kk + g]
                         }
+                    };
+                    load_ops(0, zc, ac);
+                    PINN_UNROLL for (int ws = 0; ws < 4; ++ws) {
+                        if (ws + 1 < 4) load_ops(ws + 1, zn, an);
+                        PINN_UNROLL for (int kk = 0; kk < 4; ++kk) {
+                            PINN_UNROLL for (int ti = 0; ti < MT; ++ti) wbar[hl][0][ti] = mfma16(zc[kk], ac[kk][ti & 3], wbar[hl][0][ti]);
+                            if (ch == 0) bfrh[hl][0] += zc[kk];
+                        }
+                        PINN_UNROLL for (int kk = 0; kk < 4; ++kk) { zc[kk] = zn[kk]; ac[kk] = an[kk]; }
                     }
                 }
             } else {
@@ -543,23 +584,36 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                     wave_fence();
                 }
             }
+#endif
+            // prefetch the next layer's record: its latency hides under the dA GEMM below
+            if (hl > 0) load_raw(SrN, hl - 1);
             // ---- dA_prev = W^T dZ on the matrix cores (register-chained) ----
             vfloat4 Gn[NG][MT];
             PINN_UNROLL for (int q = 0; q < NG; ++q)
                 PINN_UNROLL for (int m = 0; m < MT; ++m) Gn[q][m] = vzero4();
             const int Wt = S::OFF_WTPK + hl * HP * HP;
-            PINN_UNROLL for (int mo = 0; mo < MT; ++mo)
-                PINN_UNROLL for (int rr = 0; rr < 4; ++rr) {
-                    vfloat wf[MT];
-                    if (MT == 4) {
-                        vfloat4 w4 = ub_load4(PB, Wt + (mo * 4 + rr) * 64 * MT, lane << 2);
-                        PINN_UNROLL for (int mi = 0; mi < MT; ++mi) wf[mi] = w4[mi & 3];
-                    } else {
-                        PINN_UNROLL for (int mi = 0; mi < MT; ++mi) wf[mi] = ub_load(PB, Wt + (mo * 4 + rr) * 64 * MT + mi, lane * MT);
-                    }
-                    PINN_UNROLL for (int q = 0; q < NG; ++q)
-                        PINN_UNROLL for (int mi = 0; mi < MT; ++mi) Gn[q][mi] = mfma16(wf[mi], G[q][mo][rr], Gn[q][mi]);
+            auto load_wt = [&](int ks, vfloat (&wf)[MT]) {
+                if (MT == 4) {
+                    vfloat4 w4 = ub_load4(PB, Wt + ks * 64 * MT, lane << 2);
+                    PINN_UNROLL for (int mi = 0; mi < MT; ++mi) wf[mi] = w4[mi & 3];
+                } else {
+                    PINN_UNROLL for (int mi = 0; mi < MT; ++mi) wf[mi] = ub_load(PB, Wt + ks * 64 * MT + mi, lane * MT);
                 }
+            };
+            vfloat tcur[MT], tnxt[MT];
+            load_wt(0, tcur);
+            PINN_UNROLL for (int ks = 0; ks < 4 * MT; ++ks) {
+                const int mo = ks >> 2, rr = ks & 3;
+                if (ks + 1 < 4 * MT) load_wt(ks + 1, tnxt);
+#ifdef PINN_ABL_NODA
+                PINN_UNROLL for (int q = 0; q < NG; ++q)
+                    PINN_UNROLL for (int mi = 0; mi < MT; ++mi) if (mi == mo) Gn[q][mi][rr] += tcur[mi] * G[q][mo][rr];
+#else
+                PINN_UNROLL for (int q = 0; q < NG; ++q)
+                    PINN_UNROLL for (int mi = 0; mi < MT; ++mi) Gn[q][mi] = mfma16(tcur[mi], G[q][mo][rr], Gn[q][mi]);
+#endif
+                PINN_UNROLL for (int mi = 0; mi < MT; ++mi) tcur[mi] = tnxt[mi];
+            }
             PINN_UNROLL for (int q = 0; q < NG; ++q)
                 PINN_UNROLL for (int m = 0; m < MT; ++m) G[q][m] = Gn[q][m];
             act_adjoint(G, Sr);

@@ -12,7 +12,8 @@ typedef void* plat_stream;
 struct plat_event { double t; };
 inline const char* plat_name() { return "emu"; }
 inline int plat_init(std::string&) { return 0; }
-inline void* plat_malloc(size_t n) { return std::calloc(n ? n : 1, 1); }
+// poison fresh allocations (0xFF.. = NaN) so that reads of never-written device memory fail the CPU tests
+inline void* plat_malloc(size_t n) { void* p = std::malloc(n ? n : 1); if (p) std::memset(p, 0xFF, n ? n : 1); return p; }
 inline void plat_free(void* p) { std::free(p); }
 inline int plat_h2d(void* d, const void* s, size_t n, plat_stream) { std::memcpy(d, s, n); return 0; }
 inline int plat_d2h(void* d, const void* s, size_t n, plat_stream) { std::memcpy(d, s, n); return 0; }
