@@ -1,8 +1,8 @@
 // aux_kernels.hpp — small HBM-side kernels around the fused residual kernel.
 //   k_pack    : theta (ComponentArrays order, src/discretize.jl:451-465) -> padded MFMA-fragment order
 //   k_params  : theta.p / default_p -> parameter rows of the residual tape (src/discretize.jl:83-109)
-//   k_reduce1 : stage 1 of the fixed-order reduction: every gradient-slab entry (and loss column) of every launch
-//               group summed over one contiguous chunk of workgroups
+//   k_reduce1 : stage 1 of the fixed-order reduction: every gradient-slab offset (dense, coalesced) and loss column of
+//               every launch group summed over one contiguous chunk of workgroups
 //   k_reduce2 : stage 2: theta element p = sum over the groups / slab entries / chunks that feed it, written straight
 //               into the output vector [P floats grad | K floats raw sums of squares] (+ K doubles for the host path)
 // Every sum has a fixed order => bit-identical results run to run.
@@ -23,7 +23,6 @@ struct Reduce1Args {
     double* tmp[MAX_GROUPS];            // [nsplit][nent + K]
     const float* slabs[MAX_GROUPS];     // [nblocks][slab]
     const double* losspart[MAX_GROUPS]; // [nblocks*4][K]
-    const int* ent_off[MAX_GROUPS];
     int slab[MAX_GROUPS], nblocks[MAX_GROUPS], nsplit[MAX_GROUPS], nent[MAX_GROUPS], active[MAX_GROUPS];
     int K;
 };
@@ -51,8 +50,8 @@ AUX_DEV void reduce1_body(int e, int chunk, int g, const Reduce1Args& a) {
     const int per = (nb + ns - 1) / ns;
     const int b0 = chunk * per, b1 = (b0 + per < nb) ? b0 + per : nb;
     double s = 0.0;
-    if (e < a.nent[g]) {
-        const float* p = a.slabs[g] + a.ent_off[g][e];
+    if (e < a.nent[g]) {      // dense over slab offsets: consecutive threads read consecutive floats of every slab
+        const float* p = a.slabs[g] + e;
         for (int b = b0; b < b1; ++b) s += (double)p[(size_t)b * a.slab[g]];
     } else {
         const double* p = a.losspart[g] + (e - a.nent[g]);

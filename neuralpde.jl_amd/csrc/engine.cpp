@@ -33,7 +33,7 @@ std::vector<SpecInfo>& registry() {
 
 namespace {
 
-constexpr int REDUCE_SPLIT = 32;      // stage-1 chunks of the fixed-order slab reduction
+constexpr int REDUCE_SPLIT = 8;      // stage-1 chunks of the fixed-order slab reduction
 
 thread_local std::string g_err;
 int fail(const std::string& m) {
@@ -87,9 +87,8 @@ struct Group {
     float* d_slabs = nullptr;
     double* d_losspart = nullptr;
     float* d_scratch = nullptr;
-    int* d_ent_off = nullptr;        // reduce map: slab offset of every entry
     double* d_tmp = nullptr;         // stage-1 partial sums [nsplit][nent + K]
-    std::vector<int> row_theta, row_ptr;   // host CSR: theta element -> entries of this group
+    std::vector<int> row_theta, row_ptr, row_off;   // host CSR: theta element -> slab offsets of this group
     int nent = 0;
     int blocks = 0;
     int max_blocks = 0;
@@ -465,14 +464,12 @@ int build_plan(pinn_engine& E) {
             add_row(loff[LH] + in, s.O_WL + ((in / 16) * 4 + (in % 16) / 4) * 4 + in % 4, false);
         add_row(loff[LH] + N.sizes[LH], s.O_BL, false);
         for (int j = 0; j < E.ne; ++j) add_row(E.p_theta_off + j, s.O_P + j, false);
-        G.nent = (int)ent.size();
+        G.nent = s.SLAB;                 // stage 1 is dense over slab offsets
         G.row_theta = row_theta;
         G.row_ptr = row_ptr;
-        G.d_ent_off = (int*)plat_malloc(sizeof(int) * G.nent);
+        G.row_off = ent;                 // slab offsets of the contributions
         G.d_tmp = (double*)plat_malloc(sizeof(double) * (size_t)REDUCE_SPLIT * (G.nent + total_terms));
-        if (!G.d_ent_off || !G.d_tmp) return fail("device allocation failed (reduce map)");
-        plat_h2d(G.d_ent_off, ent.data(), sizeof(int) * G.nent, E.stream);
-        plat_sync(E.stream);
+        if (!G.d_tmp) return fail("device allocation failed (reduce map)");
         // static part of the launch arguments
         pk::GroupArgs& ga = G.ga;
         std::memset(&ga, 0, sizeof ga);
@@ -495,7 +492,7 @@ int build_plan(pinn_engine& E) {
         for (size_t g = 0; g < E.groups.size(); ++g) {
             const Group& G = E.groups[g];
             for (size_t r = 0; r < G.row_theta.size(); ++r)
-                for (int e = G.row_ptr[r]; e < G.row_ptr[r + 1]; ++e) contrib[G.row_theta[r]].push_back({(int)g, e});
+                for (int e = G.row_ptr[r]; e < G.row_ptr[r + 1]; ++e) contrib[G.row_theta[r]].push_back({(int)g, G.row_off[e]});
         }
         std::vector<int> ptr{0}, grp, ent;
         for (auto& c : contrib) {
@@ -583,7 +580,7 @@ int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const floa
         }
         G.active = any;
         const int nsplit = std::min(REDUCE_SPLIT, G.blocks);
-        a1.tmp[g] = G.d_tmp; a1.slabs[g] = G.d_slabs; a1.losspart[g] = G.d_losspart; a1.ent_off[g] = G.d_ent_off;
+        a1.tmp[g] = G.d_tmp; a1.slabs[g] = G.d_slabs; a1.losspart[g] = G.d_losspart;
         a1.slab[g] = G.spec->SLAB; a1.nblocks[g] = G.blocks; a1.nsplit[g] = nsplit; a1.nent[g] = G.nent; a1.active[g] = any;
         a2.tmp[g] = G.d_tmp; a2.stride[g] = G.nent + K; a2.nsplit[g] = nsplit; a2.nent[g] = G.nent; a2.active[g] = any;
         if (!any) continue;
@@ -651,7 +648,7 @@ int pinn_destroy(pinn_handle h) {
     for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_resid); }
     for (auto& G : E.groups) {
         plat_free(G.d_prog); plat_free(G.d_slabs); plat_free(G.d_losspart); plat_free(G.d_scratch);
-        plat_free(G.d_ent_off); plat_free(G.d_tmp);
+        plat_free(G.d_tmp);
         plat_event_destroy(G.ev_a); plat_event_destroy(G.ev_b);
     }
     for (auto& N : E.netplans) { plat_free(N.d_packed); plat_free(N.d_pack_idx); }

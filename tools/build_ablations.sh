@@ -22,4 +22,6 @@ build_one NOFWD -DPINN_ABL_NOFWD
 build_one NODA -DPINN_ABL_NODA
 build_one NODW -DPINN_ABL_NODW
 build_one NOMFMA -DPINN_ABL_NOFWD -DPINN_ABL_NODA -DPINN_ABL_NODW
+build_one NOTAPE -DPINN_ABL_NOTAPE
+build_one NOMEM -DPINN_ABL_NOSCR -DPINN_ABL_NOTAPE
 ls -la abl/
