@@ -1,0 +1,56 @@
+"""Multi-GPU path on CPU: world_size-2 gloo processes, each with its own engine handle on one contiguous shard of every
+collocation set (n_norm = global count), one all-reduce of [gradient | per-term squared-residual sums] — exactly what
+bench.py does over RCCL.  The per-rank compute runs through the emulation build of the kernels."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pinn_import
+    m = pinn_import.load()
+    from neuralpde_jl_amd import workloads
+    m._lib.set_library(m.Library(os.path.join(ROOT, "tests", "emu", "libpinn_emu.so")))
+    wl = workloads.cfg2_poisson2d(points=100, bcs_points=37, width=16, hidden=2)
+    rep = m.symbolic_discretize(wl.pde_system, wl.discretization())
+    eng = rep.engine
+    sets = rep.pde_train_sets + rep.bcs_train_sets
+    w = np.array([1.0, 2.0, 0.5, 1.5, 3.0], dtype=np.float32)
+    full_losses, full_grad = eng.loss_grad(wl.theta, w)
+    for k, s in enumerate(sets):
+        n = s.shape[1]
+        lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+        eng.set_points(k, s[:, lo:hi], n_norm=n)
+    theta = torch.tensor(wl.theta, dtype=torch.float32)
+    out = torch.zeros(eng.P + eng.K, dtype=torch.float32)
+    eng.loss_grad_device(theta.data_ptr(), out.data_ptr(), w, 0)       # "device" pointers are host pointers in the emulation
+    dist.all_reduce(out)
+    grad = out[: eng.P].numpy()
+    losses = out[eng.P:].numpy() / np.array([s.shape[1] for s in sets])
+    if rank == 0:
+        q.put((np.max(np.abs(losses - full_losses) / full_losses), np.linalg.norm(grad - full_grad) / np.linalg.norm(full_grad)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_equals_single(emu_lib):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    le, ge = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert le < 1e-6 and ge < 1e-6, (le, ge)

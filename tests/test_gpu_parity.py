@@ -61,3 +61,88 @@ def test_residual_and_phi(npde, hip_lib):
     u = rep.phi(pts, wl.theta)[0]
     u_ref = po.phi_values(prob.chains[0], wl.theta, pts)[0]
     assert np.max(np.abs(u - u_ref)) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["cfg1_poisson1d_1024", "cfg2_poisson2d_512", "cfg3_burgers_512"])
+def test_golden_fixtures(npde, hip_lib, name):
+    """Committed golden vectors (oracle/make_golden.py): inputs AND expected outputs come from the fixture file."""
+    import os
+    from neuralpde_jl_amd import workloads
+    makers = {"cfg1_poisson1d_1024": lambda: workloads.cfg1_poisson1d(1024),
+              "cfg2_poisson2d_512": lambda: workloads.cfg2_poisson2d(points=512, bcs_points=128),
+              "cfg3_burgers_512": lambda: workloads.cfg3_burgers(points=512, bcs_points=128)}
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    wl = makers[name]()
+    rep = npde.symbolic_discretize(wl.pde_system, wl.discretization())
+    for k in range(int(g["nsets"])):
+        rep.engine.set_points(k, g[f"set{k}"])
+    losses, grad = rep.engine.loss_grad(g["theta"], g["weights"])
+    assert np.max(np.abs(losses - g["losses_stencil"]) / g["losses_stencil"]) < TOL
+    assert np.linalg.norm(grad - g["grad_stencil"]) / np.linalg.norm(g["grad_stencil"]) < TOL
+    assert np.max(np.abs(grad - g["grad_stencil"])) / np.max(np.abs(g["grad_stencil"])) < TOL
+    l64, g64 = rep.engine.loss_grad_f64(g["theta"], g["weights"])          # Float64 boundary (the reference's default eltype)
+    assert np.array_equal(l64, losses) and np.array_equal(g64.astype(np.float32), grad)
+
+
+def test_full_size_cfg2_properties(npde, hip_lib):
+    """BASELINE.json config 2 at full size (65,536 interior + 4 x 65,536 boundary points): size-independent properties.
+    (a) additivity over point shards with n_norm = global count (what the multi-GPU path relies on),
+    (b) linearity of the gradient in the term weights / per-term gradients,
+    (c) residual spot check of 512 random points against the oracle, (d) bit-determinism."""
+    from neuralpde_jl_amd import workloads
+    wl = workloads.cfg2_poisson2d(points=65536)
+    rep = npde.symbolic_discretize(wl.pde_system, wl.discretization())
+    eng = rep.engine
+    sets = rep.pde_train_sets + rep.bcs_train_sets
+    w = np.array([1.0, 2.0, 0.5, 4.0, 3.0], dtype=np.float32)
+    L, G = eng.loss_grad(wl.theta, w)
+    L2, G2 = eng.loss_grad(wl.theta, w)
+    assert np.array_equal(L, L2) and np.array_equal(G, G2)                                      # (d)
+    Lt, TG = eng.term_grads(wl.theta)                                                            # (b)
+    np.testing.assert_allclose(Lt, L, rtol=1e-12)
+    Gw = (w[:, None].astype(np.float64) * TG.astype(np.float64)).sum(axis=0)
+    assert np.linalg.norm(Gw - G) / np.linalg.norm(G) < 1e-6
+    acc_l, acc_g = np.zeros(5), np.zeros(eng.P)                                                  # (a)
+    for part in range(2):
+        for k, s in enumerate(sets):
+            n = s.shape[1]
+            eng.set_points(k, s[:, part * n // 2:(part + 1) * n // 2], n_norm=n)
+        l_, g_ = eng.loss_grad(wl.theta, w)
+        acc_l += l_
+        acc_g += g_
+    for k, s in enumerate(sets):
+        eng.set_points(k, s)
+    np.testing.assert_allclose(acc_l, L, rtol=1e-6)
+    assert np.linalg.norm(acc_g - G) / np.linalg.norm(G) < 1e-6
+    rng = np.random.default_rng(0)                                                                # (c)
+    prob = helpers.oracle_problem(npde, wl.pde_system, wl.chains)
+    for k in (0, 2):
+        idx = rng.choice(sets[k].shape[1], 512, replace=False)
+        r = eng.residual(k, wl.theta, sets[k].shape[1])[idx]
+        r_ref = po.residual_values(prob, wl.theta, k, sets[k][:, idx])[0]
+        assert np.max(np.abs(r - r_ref)) < 2e-5 * max(1.0, np.max(np.abs(r_ref)))
+    assert abs(L[0] - np.mean(eng.residual(0, wl.theta, 65536).astype(np.float64) ** 2)) < 1e-6 * L[0]
+
+
+def test_param_estim_4x64(npde, hip_lib):
+    import sympy as sp
+    t, x = npde.parameters("t x")
+    (u,) = npde.variables("u")
+    (k,) = npde.parameters("k")
+    Dt, Dxx = npde.Differential(t), npde.Differential(x) ** 2
+    eq = npde.Eq(Dt(u(t, x)), k * Dxx(u(t, x)))
+    bcs = [npde.Eq(u(0, x), sp.sin(sp.pi * x)), npde.Eq(u(t, 0), 0.0), npde.Eq(u(t, 1), 0.0)]
+    dom = [npde.In(t, npde.Interval(0.0, 1.0)), npde.In(x, npde.Interval(0.0, 1.0))]
+    sysm = npde.PDESystem([eq], bcs, dom, [t, x], [u(t, x)], ps=[k], defaults={k: 0.7})
+    from neuralpde_jl_amd import workloads
+    chain = workloads.mlp(2, 64, 4)
+    theta = workloads.synthetic_theta([chain], 77)
+    strat = npde.QuasiRandomTraining(3000, bcs_points=500, sampling_alg=npde.SobolSample(seed=9), resampling=False, minibatch=1)
+    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=theta, param_estim=True))
+    th = rep.flat_init_params
+    sets = rep.pde_train_sets + rep.bcs_train_sets
+    losses, grad = rep.engine.loss_grad(th)
+    ref = po.loss_and_grad(helpers.oracle_problem(npde, sysm, [chain], param_estim=True), th, sets, mode="stencil")
+    le, g2, gi = helpers.rel_errors(losses, grad, ref)
+    assert le.max() < TOL and g2 < TOL and gi < TOL
+    assert abs(grad[-1] - ref.grad[-1]) < TOL * abs(ref.grad[-1])          # dL/dk itself

@@ -1,0 +1,120 @@
+"""Host-side mirror of the reference API: symbolic lowering, point sets, descriptor, error behaviour (CPU only)."""
+import numpy as np
+import pytest
+import sympy as sp
+
+
+def _poisson(npde):
+    x, y = npde.parameters("x y")
+    (u,) = npde.variables("u")
+    Dxx, Dyy = npde.Differential(x) ** 2, npde.Differential(y) ** 2
+    eq = npde.Eq(Dxx(u(x, y)) + Dyy(u(x, y)), -sp.sin(sp.pi * x) * sp.sin(sp.pi * y))
+    bcs = [npde.Eq(u(0, y), 0.0), npde.Eq(u(1, y), 0.0), npde.Eq(u(x, 0), 0.0), npde.Eq(u(x, 1), 0.0)]
+    dom = [npde.In(x, npde.Interval(0.0, 1.0)), npde.In(y, npde.Interval(0.0, 1.0))]
+    return npde.PDESystem([eq], bcs, dom, [x, y], [u(x, y)]), (x, y, u)
+
+
+def test_lowering_poisson_slots_and_ops(npde):
+    sysm, (x, y, u) = _poisson(npde)
+    vi = npde.get_vars(sysm.ivs, sysm.dvs)
+    t = npde.lower_equation(sysm.eqs[0], vi, (), "pde")
+    assert t.dim == 2 and t.indvars == ("x", "y")
+    assert sorted(s.axes for s in t.slots) == [(0, 0), (1, 1)]          # u_xx, u_yy; the value u itself is not needed
+    assert [q.op for q in t.ops].count("SINPI") == 2                     # sin(pi x) sin(pi y) -> sinpi
+    # boundary condition: call arguments are dropped (symbolic_utilities.jl:145-160) -> plain value slot
+    b = npde.lower_equation(sysm.bcs[0], vi, (), "bc")
+    assert [s.axes for s in b.slots] == [()] and b.indvars == ("x", "y")
+
+
+def test_get_argument_variables_and_bounds(npde):
+    sysm, _ = _poisson(npde)
+    vi = npde.get_vars(sysm.ivs, sysm.dvs)
+    args = npde.get_argument(sysm.bcs, vi)
+    assert args[0][0] == 0.0 and str(args[0][1]) == "y" and str(args[2][0]) == "x" and args[2][1] == 0.0
+    assert [[str(a) for a in v] for v in npde.get_variables(sysm.bcs, vi)] == [["y"], ["y"], ["x"], ["x"]]
+    # docs/src/developer/debugging.md: 100 stochastic points on [0,1] -> bounds [0.01, 0.99]; numeric bc args -> [c, c]
+    pb, bb = npde.get_bounds(sysm.domain, sysm.eqs, sysm.bcs, np.float64, vi, 100)
+    np.testing.assert_allclose(pb[0][0], [0.01, 0.01]); np.testing.assert_allclose(pb[0][1], [0.99, 0.99])
+    np.testing.assert_allclose(bb[1][0], [1.0, 0.01]); np.testing.assert_allclose(bb[1][1], [1.0, 0.99])
+
+
+def test_grid_training_sets(npde):
+    sysm, _ = _poisson(npde)
+    vi = npde.get_vars(sysm.ivs, sysm.dvs)
+    pde, bcs = npde.generate_training_sets(sysm.domain, 0.25, sysm.eqs, sysm.bcs, np.float64, vi)
+    # full 5x5 grid (reference v6.2.2: `dif` stays empty, discretize.jl:202-214), first variable fastest
+    assert pde[0].shape == (2, 25)
+    np.testing.assert_allclose(pde[0][:, :6].T, [[0, 0], [0.25, 0], [0.5, 0], [0.75, 0], [1, 0], [0, 0.25]])
+    assert bcs[0].shape == (2, 5) and np.all(bcs[0][0] == 0.0) and np.all(bcs[3][1] == 1.0)
+
+
+def test_stochastic_and_quasirandom_sets_inside_bounds(npde):
+    sysm, _ = _poisson(npde)
+    vi = npde.get_vars(sysm.ivs, sysm.dvs)
+    for strat in (npde.StochasticTraining(64, bcs_points=16, rng=np.random.default_rng(0)),
+                  npde.QuasiRandomTraining(64, bcs_points=16, sampling_alg=npde.SobolSample(seed=1)),
+                  npde.QuasiRandomTraining(64, bcs_points=16, sampling_alg=npde.LatinHypercubeSample(seed=1), resampling=False, minibatch=3)):
+        pde, bc, resample = strat.point_sets(sysm, vi, np.float64)
+        assert pde[0].shape == (2, 64) and bc[0].shape == (2, 16)
+        d = 1.0 / 64
+        assert pde[0].min() >= d - 1e-12 and pde[0].max() <= 1 - d + 1e-12
+        assert np.all(bc[0][0] == 0.0) and np.all(bc[1][0] == 1.0)
+        if resample is not None:
+            p2, _ = resample()
+            assert p2[0].shape == (2, 64)
+
+
+def test_burgers_and_params_lowering(npde):
+    t, x = npde.parameters("t x")
+    (u,) = npde.variables("u")
+    (nu,) = npde.parameters("nu")
+    Dt, Dx, Dxx = npde.Differential(t), npde.Differential(x), npde.Differential(x) ** 2
+    eq = npde.Eq(Dt(u(t, x)) + u(t, x) * Dx(u(t, x)) - nu * Dxx(u(t, x)), 0)
+    vi = npde.get_vars([t, x], [u(t, x)])
+    term = npde.lower_equation(eq, vi, (nu,), "pde")
+    assert sorted(s.axes for s in term.slots) == [(), (0,), (1,), (1, 1)]
+    d, NP = 2, 1
+    assert any(q.op == "MUL" and (q.a == d or q.b == d) for q in term.ops)        # the parameter row d is used
+    desc = npde.ProblemIR(ntheta=10, nets=[npde.NetIR((2, 4, 1), "tanh", 0)], terms=[term], nparams=1, nparams_estim=1,
+                          p_theta_off=9, p_defaults=[0.5]).to_descriptor()
+    assert desc.startswith("pinnir 1\n") and "params 1 1 9" in desc and "slot 0 2 1 1" in desc
+
+
+def test_lowering_errors(npde):
+    x, y = npde.parameters("x y")
+    (u,) = npde.variables("u")
+    vi = npde.get_vars([x, y], [u(x, y)])
+    with pytest.raises(npde.LoweringError):
+        npde.lower_equation(npde.Eq((npde.Differential(x) ** 3)(u(x, y)), 0), vi, (), "pde")      # order 3: not yet
+    with pytest.raises(npde.LoweringError):
+        npde.lower_equation(npde.Eq(sp.gamma(u(x, y)), 0), vi, (), "pde")                        # outside the op set
+    with pytest.raises(npde.LoweringError):
+        npde.lower_equation(npde.Eq(x + y, 0), vi, (), "pde")                                     # no dependent variable
+
+
+def test_discretizer_errors(npde, use_emu):
+    sysm, (x, y, u) = _poisson(npde)
+    chain = npde.Chain(npde.Dense(2, 16, "tanh"), npde.Dense(16, 16, "tanh"), npde.Dense(16, 1))
+    with pytest.raises(TypeError):                # no boundary conditions (reference: MethodError in the solve phase)
+        npde.symbolic_discretize(npde.PDESystem(sysm.eqs, [], sysm.domain, sysm.ivs, sysm.dvs),
+                                 npde.PhysicsInformedNN(chain, npde.GridTraining(0.5)))
+    with pytest.raises(ValueError):               # trivial bc 0 ~ 0 (reference: ArgumentError at discretize)
+        npde.symbolic_discretize(npde.PDESystem(sysm.eqs, [npde.Eq(0.0, 0.0)], sysm.domain, sysm.ivs, sysm.dvs),
+                                 npde.PhysicsInformedNN(chain, npde.GridTraining(0.5)))
+    with pytest.raises(ValueError):               # chain count != dependent variable count
+        npde.symbolic_discretize(sysm, npde.PhysicsInformedNN([chain, chain], npde.GridTraining(0.5)))
+    # unsupported shapes fail loudly at create time, never silently fall back
+    odd = npde.Chain(npde.Dense(2, 200, "tanh"), npde.Dense(200, 200, "tanh"), npde.Dense(200, 1))
+    with pytest.raises(npde.EngineError, match="no compiled kernel"):
+        npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(odd, npde.GridTraining(0.5)))
+    with pytest.raises(npde.EngineError):
+        npde.Engine("pinnir 2\n")
+
+
+def test_chain_and_init_params(npde):
+    chain = npde.Chain(npde.Dense(2, 12, "σ"), npde.Dense(12, 12, "σ"), npde.Dense(12, 1))
+    assert chain.act == "sigmoid" and chain.sizes == (2, 12, 12, 1) and chain.nparams == 2 * 12 + 12 + 144 + 12 + 12 + 1
+    th = npde.initialparameters(np.random.default_rng(0), chain)
+    assert th.dtype == np.float64 and th.size == chain.nparams          # Float64 default (src/discretize.jl:432-449)
+    with pytest.raises(ValueError):
+        npde.Chain(npde.Dense(2, 8, "tanh"), npde.Dense(9, 1))
