@@ -1,0 +1,17 @@
+#!/bin/bash
+# PMC passes for the bench workload (each counter set in its own run, --kernel-trace only; see MI355X_MICROARCH.md
+# "rocprofv3 PMC slots"): HBM read bytes, HBM write bytes, MFMA busy / issue counters, wave-state counters.
+# Usage (on the GPU box): tools/pmc_profile.sh <outdir>
+set -e
+OUT=${1:-gpurun_out/pmc}
+mkdir -p $OUT
+export TMPDIR=/tmp
+REPO=$(pwd)
+cd /tmp
+run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" -d $REPO/$OUT/$name -o p -- python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $REPO/$OUT/$name.json 2> $REPO/$OUT/$name.err || echo "pass $name failed"; }
+run fetch FETCH_SIZE
+run write WRITE_SIZE
+run mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+run waves SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA
+run lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS
+ls -R $REPO/$OUT | head -30
