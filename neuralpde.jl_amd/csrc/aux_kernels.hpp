@@ -8,6 +8,7 @@
 // Every sum has a fixed order => bit-identical results run to run.
 #pragma once
 #include "plat.hpp"
+#include "rprog.hpp"
 
 namespace aux {
 
@@ -17,7 +18,9 @@ namespace aux {
 #define AUX_DEV __device__ __forceinline__
 #endif
 
-constexpr int MAX_GROUPS = 8;
+constexpr int MAX_GROUPS = 24;
+constexpr int EXPR_MAX_SLOTS = 24;
+constexpr int EXPR_MAX_ROWS = 96;
 
 struct Reduce1Args {
     double* tmp[MAX_GROUPS];            // [nsplit][nent + K]
@@ -36,6 +39,60 @@ struct Reduce2Args {
     int stride[MAX_GROUPS], nsplit[MAX_GROUPS], nent[MAX_GROUPS], active[MAX_GROUPS];
     int ngroups, P, K;
 };
+
+// k_expr: the residual tape of an equation that couples several networks, one thread per collocation point.
+// Inputs: the jet channels every network's FWD launch wrote ([channel][N]); outputs: d(loss)/d(jet) per slot for the
+// GRADIN launches, per-wave loss / dL/dp partial sums (fixed order), optionally the residual itself.
+struct ExprArgs {
+    const float* pts;                     // d x N point-major
+    int N, d, nparams, nparams_estim;
+    const float* params;
+    int nslots;
+    const float* jets[EXPR_MAX_SLOTS];    // slot s -> its channel array [N]
+    float* ubar[EXPR_MAX_SLOTS];          // slot s -> d(loss)/d(jet) channel array [N] (distinct slots = distinct arrays)
+    int nzero;
+    float* zero[EXPR_MAX_SLOTS];          // channel arrays of the kernels' jet sets that this equation does not use
+    const rp::Instr* prog;
+    int nops, out_row;
+    float scale;                          // 2 w / N_norm
+    double* losspart;                     // [nblocks*4][K]
+    float* pslab;                         // [nblocks][4 waves][4 params]
+    int K, term_id;
+    float* resid;                         // nullable: write r[N] and skip the adjoint
+};
+// one point; returns r (masked by `valid`), writes ubar, returns dL/dp contributions in pb[]
+AUX_DEV float expr_point(int p, const ExprArgs& a, float (&pb)[4]) {
+    float v[EXPR_MAX_ROWS], g[EXPR_MAX_ROWS];
+    const int R0 = a.d + a.nparams + a.nslots;
+    for (int i = 0; i < a.d; ++i) v[i] = a.pts[(size_t)p * a.d + i];
+    for (int j = 0; j < a.nparams; ++j) v[a.d + j] = a.params[j];
+    for (int s = 0; s < a.nslots; ++s) v[a.d + a.nparams + s] = a.jets[s][p];
+    for (int q = 0; q < a.nops; ++q) {
+        const rp::Instr ins = a.prog[q];
+        const float va = rp::is_nullary(ins.code) ? 0.f : v[ins.a];
+        const float vb = rp::is_binary(ins.code) ? v[ins.b] : 0.f;
+        v[R0 + q] = rp::apply<float>(ins.code, va, vb, ins.imm);
+    }
+    const float r = v[a.out_row];
+    for (int j = 0; j < 4; ++j) pb[j] = 0.f;
+    if (a.resid) { a.resid[p] = r; return r; }
+    for (int q = 0; q < R0 + a.nops; ++q) g[q] = 0.f;
+    g[a.out_row] = 1.0f;
+    for (int q = a.nops - 1; q >= 0; --q) {
+        const rp::Instr ins = a.prog[q];
+        if (rp::is_nullary(ins.code)) continue;
+        const float vb = rp::is_binary(ins.code) ? v[ins.b] : 0.f;
+        float da, db;
+        rp::adjoint<float>(ins.code, v[ins.a], vb, v[R0 + q], ins.imm, g[R0 + q], da, db);
+        g[ins.a] += da;
+        if (rp::is_binary(ins.code)) g[ins.b] += db;
+    }
+    const float rbar = r * a.scale;
+    for (int s = 0; s < a.nslots; ++s) a.ubar[s][p] = rbar * g[a.d + a.nparams + s];
+    for (int z = 0; z < a.nzero; ++z) a.zero[z][p] = 0.f;
+    for (int j = 0; j < a.nparams_estim; ++j) pb[j] = rbar * g[a.d + j];
+    return r;
+}
 
 AUX_DEV void pack_body(int i, float* packed, const int* idx, const float* theta) {
     const int j = idx[i];
@@ -89,6 +146,25 @@ inline void launch_pack(float* packed, const int* idx, const float* theta, int n
 inline void launch_params(float* params, const float* theta, const float* defaults, int np, int ne, int p_off, plat_stream) {
     for (int j = 0; j < np; ++j) params_body(j, params, theta, defaults, ne, p_off);
 }
+inline void launch_expr(const ExprArgs& a, int nblocks, plat_stream) {
+    for (int b = 0; b < nblocks; ++b)
+        for (int w = 0; w < 4; ++w) {
+            double ls = 0.0;
+            double ps[4] = {0, 0, 0, 0};
+            for (int l = 0; l < 64; ++l) {
+                const int p = (b * 4 + w) * 64 + l;
+                if (p >= a.N) continue;
+                float pb[4];
+                const float r = expr_point(p, a, pb);
+                ls += (double)r * (double)r;
+                for (int j = 0; j < 4; ++j) ps[j] += (double)pb[j];
+            }
+            if (!a.resid) {
+                a.losspart[(size_t)(b * 4 + w) * a.K + a.term_id] = ls;
+                for (int j = 0; j < 4; ++j) a.pslab[(size_t)(b * 4 + w) * 4 + j] = (float)ps[j];
+            }
+        }
+}
 inline void launch_reduce(const Reduce1Args& a1, const Reduce2Args& a2, int max_n1, int max_split, plat_stream) {
     for (int g = 0; g < a2.ngroups; ++g)
         for (int ch = 0; ch < max_split; ++ch)
@@ -104,6 +180,24 @@ __global__ void k_params(float* params, const float* theta, const float* default
     const int j = threadIdx.x;
     if (j < np) params_body(j, params, theta, defaults, ne, p_off);
 }
+__global__ void __launch_bounds__(256) k_expr(const ExprArgs a) {
+    __shared__ double sh[5][256];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    float pb[4] = {0.f, 0.f, 0.f, 0.f};
+    float r = 0.f;
+    if (p < a.N) r = expr_point(p, a, pb);
+    if (a.resid) return;
+    sh[0][threadIdx.x] = (double)r * (double)r;
+    for (int j = 0; j < 4; ++j) sh[1 + j][threadIdx.x] = (double)pb[j];
+    __syncthreads();
+    if (threadIdx.x < 20) {            // 4 waves x (loss + 4 params): serial fixed-order sums of 64 values each
+        const int w = threadIdx.x & 3, q = threadIdx.x >> 2;
+        double s = 0.0;
+        for (int l = 0; l < 64; ++l) s += sh[q][w * 64 + l];
+        if (q == 0) a.losspart[(size_t)(blockIdx.x * 4 + w) * a.K + a.term_id] = s;
+        else a.pslab[(size_t)(blockIdx.x * 4 + w) * 4 + (q - 1)] = (float)s;
+    }
+}
 __global__ void k_reduce1(const Reduce1Args a) {
     reduce1_body((int)(blockIdx.x * blockDim.x + threadIdx.x), (int)blockIdx.y, (int)blockIdx.z, a);
 }
@@ -115,6 +209,9 @@ inline void launch_pack(float* packed, const int* idx, const float* theta, int n
 }
 inline void launch_params(float* params, const float* theta, const float* defaults, int np, int ne, int p_off, plat_stream st) {
     if (np > 0) hipLaunchKernelGGL(k_params, dim3(1), dim3(64), 0, st, params, theta, defaults, np, ne, p_off);
+}
+inline void launch_expr(const ExprArgs& a, int nblocks, plat_stream st) {
+    hipLaunchKernelGGL(k_expr, dim3(nblocks), dim3(256), 0, st, a);
 }
 inline void launch_reduce(const Reduce1Args& a1, const Reduce2Args& a2, int max_n1, int max_split, plat_stream st) {
     hipLaunchKernelGGL(k_reduce1, dim3((max_n1 + 255) / 256, max_split, a2.ngroups), dim3(256), 0, st, a1);

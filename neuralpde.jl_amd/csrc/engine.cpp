@@ -70,6 +70,7 @@ struct Term {
     int net = -1;
     int group = -1;
     int slot_in_group = -1;
+    int coupled = -1;                // >= 0: index into pinn_engine::coupled (equation couples several networks)
     std::vector<int> chan_of_slot;
     // data
     float* d_pts = nullptr;
@@ -78,6 +79,7 @@ struct Term {
     int64_t resid_cap = 0;
 };
 struct Group {
+    int kind = 0;                    // 0: fused (single-network terms); 1: per-network FWD/GRADIN launches of coupled terms
     int net = -1;
     const pk::SpecInfo* spec = nullptr;
     std::vector<int> terms;
@@ -96,6 +98,22 @@ struct Group {
     plat_event ev_a, ev_b;
     bool timed = false;
 };
+// an equation that couples several networks (systems of PDEs, src/discretize.jl:58-80): forward launch per network ->
+// k_expr (tape over all networks' jets) -> reverse launch per network
+struct Coupled {
+    int term = -1;
+    std::vector<int> nets;           // networks referenced, increasing
+    std::vector<int> groups;         // per network: the kind-1 group that runs it
+    std::vector<int> slot_net;       // per slot: index into `nets`
+    std::vector<float*> d_jets, d_ubar;   // per network: [C_n][N]
+    int64_t cap = 0;
+    rp::Instr* d_prog = nullptr;
+    double* d_losspart = nullptr;    // pseudo-group for the reduction: [blocks*4][K]
+    float* d_pslab = nullptr;        // [blocks][16]
+    double* d_tmp = nullptr;
+    int blocks = 0, cap_blocks = 0;
+    std::vector<int> row_theta, row_ptr, row_off;
+};
 struct NetPlan {
     const pk::SpecInfo* spec = nullptr;   // any spec with the right (HP,NHH,D): packed layout is shared
     float* d_packed = nullptr;
@@ -112,6 +130,7 @@ struct pinn_engine {
     std::vector<Net> nets;
     std::vector<Term> terms;
     std::vector<Group> groups;
+    std::vector<Coupled> coupled;
     std::vector<NetPlan> netplans;
     int ncu = 0;
     plat_stream stream = nullptr;
@@ -271,24 +290,9 @@ int build_plan(pinn_engine& E) {
     if (E.ne > 0 && (E.p_theta_off < 0 || E.p_theta_off + E.ne > E.ntheta)) return fail("descriptor: theta.p exceeds ntheta");
 
     // ---- terms -> groups ----
-    for (size_t t = 0; t < E.terms.size(); ++t) {
-        Term& T = E.terms[t];
-        int net = -1;
+    auto needs_of = [&](const Term& T, int net, unsigned& need_first, std::vector<std::pair<int, int>>& need_pairs) -> int {
         for (auto& s : T.slots) {
-            if (net >= 0 && s.net != net)
-                return fail("term " + std::to_string(t) + ": equations coupling several networks are not supported by this build of the HIP engine yet");
-            net = s.net;
-        }
-        if (net < 0) return fail("term " + std::to_string(t) + " does not reference any dependent variable");
-        T.net = net;
-        const Net& N = E.nets[net];
-        if (N.sizes[0] != T.d)
-            return fail("term " + std::to_string(t) + ": network input dimension differs from the term's coordinate count (heterogeneous inputs are not supported yet)");
-        const int LH = (int)N.sizes.size() - 2;
-        const int HP = round_hp(N.maxhidden());
-        unsigned need_first = 0;
-        std::vector<std::pair<int, int>> need_pairs;
-        for (auto& s : T.slots) {
+            if (s.net != net) continue;
             for (int a = 0; a < s.order; ++a) {
                 if (s.axes[a] < 0 || s.axes[a] >= T.d) return fail("descriptor: slot axis out of range");
                 need_first |= 1u << s.axes[a];
@@ -298,37 +302,112 @@ int build_plan(pinn_engine& E) {
                 if (std::find(need_pairs.begin(), need_pairs.end(), pr) == need_pairs.end()) need_pairs.push_back(pr);
             }
         }
-        const pk::SpecInfo* sp = find_spec(HP, LH - 1, T.d, need_first, need_pairs, nullptr);
+        return 0;
+    };
+    auto spec_for = [&](size_t t, int net, int d, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs,
+                        const pk::SpecInfo*& sp) -> int {
+        const Net& N = E.nets[net];
+        if (N.sizes[0] != d)
+            return fail("term " + std::to_string(t) + ": network input dimension differs from the term's coordinate count (heterogeneous inputs are not supported yet)");
+        const int LH = (int)N.sizes.size() - 2;
+        const int HP = round_hp(N.maxhidden());
+        sp = find_spec(HP, LH - 1, d, need_first, need_pairs, nullptr);
         if (!sp) {
             char b[256];
             std::snprintf(b, sizeof b,
                           "term %zu: no compiled kernel for hidden width %d (padded %d), %d hidden layers, d=%d, first-derivative axes mask 0x%x, %zu second derivatives; add a PINN_INSTANTIATE line in csrc/inst_*.hip",
-                          t, N.maxhidden(), HP, LH, T.d, need_first, need_pairs.size());
+                          t, N.maxhidden(), HP, LH, d, need_first, need_pairs.size());
             return fail(b);
         }
-        T.chan_of_slot.clear();
-        for (auto& s : T.slots) {
-            int c = chan_of(*sp, s);
-            if (c < 0) return fail("internal: slot has no channel");
-            T.chan_of_slot.push_back(c);
+        return 0;
+    };
+    // pass 1: which terms couple several networks; union of the jet needs per network over all coupled terms
+    std::vector<std::vector<int>> term_nets(E.terms.size());
+    std::map<int, std::pair<unsigned, std::vector<std::pair<int, int>>>> coupled_needs;   // net -> needs
+    std::map<int, int> coupled_dim;
+    for (size_t t = 0; t < E.terms.size(); ++t) {
+        Term& T = E.terms[t];
+        for (auto& s : T.slots)
+            if (std::find(term_nets[t].begin(), term_nets[t].end(), s.net) == term_nets[t].end()) term_nets[t].push_back(s.net);
+        std::sort(term_nets[t].begin(), term_nets[t].end());
+        if (term_nets[t].empty()) return fail("term " + std::to_string(t) + " does not reference any dependent variable");
+        if (term_nets[t].size() > 1)
+            for (int net : term_nets[t]) {
+                auto& nd = coupled_needs[net];
+                if (needs_of(T, net, nd.first, nd.second)) return 1;
+                if (coupled_dim.count(net) && coupled_dim[net] != T.d) return fail("coupled terms of one network must bind the same variables");
+                coupled_dim[net] = T.d;
+            }
+    }
+    std::map<int, int> coupled_group;        // net -> kind-1 group
+    for (size_t t = 0; t < E.terms.size(); ++t) {
+        Term& T = E.terms[t];
+        if (term_nets[t].size() == 1) {
+            const int net = term_nets[t][0];
+            T.net = net;
+            unsigned need_first = 0;
+            std::vector<std::pair<int, int>> need_pairs;
+            if (needs_of(T, net, need_first, need_pairs)) return 1;
+            const pk::SpecInfo* sp = nullptr;
+            if (spec_for(t, net, T.d, need_first, need_pairs, sp)) return 1;
+            T.chan_of_slot.clear();
+            for (auto& s : T.slots) {
+                int c = chan_of(*sp, s);
+                if (c < 0) return fail("internal: slot has no channel");
+                T.chan_of_slot.push_back(c);
+            }
+            const int rows = T.d + E.np + sp->C + (int)T.ops.size();
+            if (rows > rp::MAX_ROWS_FUSED)
+                return fail("term " + std::to_string(t) + ": residual expression too long for the fused kernel tape (" + std::to_string(rows) + " rows > 32)");
+            if (!E.netplans[net].spec) E.netplans[net].spec = sp;
+            int gi = -1;
+            for (size_t g = 0; g < E.groups.size(); ++g)
+                if (E.groups[g].kind == 0 && E.groups[g].net == net && E.groups[g].spec == sp && (int)E.groups[g].terms.size() < pk::MAX_GROUP_TERMS) gi = (int)g;
+            if (gi < 0) {
+                E.groups.emplace_back();
+                gi = (int)E.groups.size() - 1;
+                E.groups[gi].net = net;
+                E.groups[gi].spec = sp;
+            }
+            T.group = gi;
+            T.slot_in_group = (int)E.groups[gi].terms.size();
+            E.groups[gi].terms.push_back((int)t);
+            continue;
         }
-        const int rows = T.d + E.np + sp->C + (int)T.ops.size();
-        if (rows > rp::MAX_ROWS_FUSED)
-            return fail("term " + std::to_string(t) + ": residual expression too long for the fused kernel tape (" + std::to_string(rows) + " rows > 32)");
-        if (!E.netplans[net].spec) E.netplans[net].spec = sp;
-        // find / make group
-        int gi = -1;
-        for (size_t g = 0; g < E.groups.size(); ++g)
-            if (E.groups[g].net == net && E.groups[g].spec == sp && (int)E.groups[g].terms.size() < pk::MAX_GROUP_TERMS) gi = (int)g;
-        if (gi < 0) {
-            E.groups.emplace_back();
-            gi = (int)E.groups.size() - 1;
-            E.groups[gi].net = net;
-            E.groups[gi].spec = sp;
+        // ---- coupled term ----
+        if ((int)T.slots.size() > aux::EXPR_MAX_SLOTS || T.d + E.np + (int)T.slots.size() + (int)T.ops.size() > aux::EXPR_MAX_ROWS)
+            return fail("term " + std::to_string(t) + ": coupled residual expression too long");
+        E.coupled.emplace_back();
+        Coupled& Cp = E.coupled.back();
+        T.coupled = (int)E.coupled.size() - 1;
+        Cp.term = (int)t;
+        Cp.nets = term_nets[t];
+        T.chan_of_slot.assign(T.slots.size(), -1);
+        Cp.slot_net.assign(T.slots.size(), -1);
+        for (size_t i = 0; i < Cp.nets.size(); ++i) {
+            const int net = Cp.nets[i];
+            if (!coupled_group.count(net)) {
+                const pk::SpecInfo* sp = nullptr;
+                if (spec_for(t, net, T.d, coupled_needs[net].first, coupled_needs[net].second, sp)) return 1;
+                E.groups.emplace_back();
+                Group& G = E.groups.back();
+                G.kind = 1;
+                G.net = net;
+                G.spec = sp;
+                coupled_group[net] = (int)E.groups.size() - 1;
+                if (!E.netplans[net].spec) E.netplans[net].spec = sp;
+            }
+            Group& G = E.groups[coupled_group[net]];
+            if ((int)G.terms.size() >= pk::MAX_GROUP_TERMS) return fail("too many coupled equations for one network");
+            Cp.groups.push_back(coupled_group[net]);
+            G.terms.push_back((int)t);
+            for (size_t si = 0; si < T.slots.size(); ++si)
+                if (T.slots[si].net == net) {
+                    T.chan_of_slot[si] = chan_of(*G.spec, T.slots[si]);
+                    Cp.slot_net[si] = (int)i;
+                    if (T.chan_of_slot[si] < 0) return fail("internal: slot has no channel");
+                }
         }
-        T.group = gi;
-        T.slot_in_group = (int)E.groups[gi].terms.size();
-        E.groups[gi].terms.push_back((int)t);
     }
 
     // ---- per-net pack index map ----
@@ -399,6 +478,10 @@ int build_plan(pinn_engine& E) {
         std::vector<rp::Instr> prog;
         for (int ti : G.terms) {
             Term& T = E.terms[ti];
+            if (G.kind == 1) {           // coupled terms: the tape runs in k_expr, not in the wave kernel
+                G.prog_off.push_back(0); G.prog_n.push_back(0); G.out_row.push_back(0);
+                continue;
+            }
             const int S = (int)T.slots.size();
             const int rslot0 = T.d + E.np, rop0 = rslot0 + S;
             auto remap = [&](int row) -> int {
@@ -485,14 +568,46 @@ int build_plan(pinn_engine& E) {
         ga.nparams_estim = E.ne;
         ga.act = N.act;
     }
+    // ---- coupled equations: tape in descriptor row numbering (slots are direct inputs of k_expr) ----
+    for (auto& Cp : E.coupled) {
+        Term& T = E.terms[Cp.term];
+        const int lim0 = T.d + E.np + (int)T.slots.size();
+        std::vector<rp::Instr> prog = T.ops;
+        for (size_t q = 0; q < prog.size(); ++q) {
+            rp::Instr& I = prog[q];
+            const int lim = lim0 + (int)q;
+            if (!rp::is_nullary(I.code) && (I.a < 0 || I.a >= lim)) return fail("descriptor: op operand row out of range");
+            if (rp::is_binary(I.code) && (I.b < 0 || I.b >= lim)) return fail("descriptor: op operand row out of range");
+            if (rp::is_nullary(I.code)) I.a = 0;
+            if (!rp::is_binary(I.code)) I.b = 0;
+        }
+        if (T.out_row < 0 || T.out_row >= lim0 + (int)prog.size()) return fail("descriptor: out row out of range");
+        Cp.d_prog = (rp::Instr*)plat_malloc(sizeof(rp::Instr) * std::max<size_t>(prog.size(), 1));
+        Cp.d_tmp = (double*)plat_malloc(sizeof(double) * (size_t)REDUCE_SPLIT * (16 + total_terms));
+        if (!Cp.d_prog || !Cp.d_tmp) return fail("device allocation failed (coupled term)");
+        if (!prog.empty()) plat_h2d(Cp.d_prog, prog.data(), sizeof(rp::Instr) * prog.size(), E.stream);
+        Cp.row_ptr = {0};
+        for (int j = 0; j < E.ne; ++j) {                 // dL/dp partials: 4 per-wave entries per parameter
+            Cp.row_theta.push_back(E.p_theta_off + j);
+            for (int w = 0; w < 4; ++w) Cp.row_off.push_back(w * 4 + j);
+            Cp.row_ptr.push_back((int)Cp.row_off.size());
+        }
+        plat_sync(E.stream);
+    }
     // ---- global reduce map: theta element -> (group, slab entry) contributions, group order fixed ----
-    if ((int)E.groups.size() > aux::MAX_GROUPS) return fail("too many kernel launch groups for one engine");
+    if ((int)(E.groups.size() + E.coupled.size()) > aux::MAX_GROUPS) return fail("too many kernel launch groups for one engine");
     {
         std::vector<std::vector<std::pair<int, int>>> contrib((size_t)E.ntheta);
         for (size_t g = 0; g < E.groups.size(); ++g) {
             const Group& G = E.groups[g];
             for (size_t r = 0; r < G.row_theta.size(); ++r)
                 for (int e = G.row_ptr[r]; e < G.row_ptr[r + 1]; ++e) contrib[G.row_theta[r]].push_back({(int)g, G.row_off[e]});
+        }
+        for (size_t c = 0; c < E.coupled.size(); ++c) {          // pseudo-groups after the kernel groups
+            const Coupled& Cp = E.coupled[c];
+            for (size_t r = 0; r < Cp.row_theta.size(); ++r)
+                for (int e = Cp.row_ptr[r]; e < Cp.row_ptr[r + 1]; ++e)
+                    contrib[Cp.row_theta[r]].push_back({(int)(E.groups.size() + c), Cp.row_off[e]});
         }
         std::vector<int> ptr{0}, grp, ent;
         for (auto& c : contrib) {
@@ -514,7 +629,8 @@ int build_plan(pinn_engine& E) {
 }
 
 // refresh tile tables after a point set changed
-void retile(pinn_engine& E, Group& G) {
+void retile(pinn_engine& E, int gi) {
+    Group& G = E.groups[gi];
     const pk::SpecInfo& s = *G.spec;
     int tile = 0;
     for (size_t j = 0; j < G.terms.size(); ++j) {
@@ -530,6 +646,12 @@ void retile(pinn_engine& E, Group& G) {
         td.term_id = G.terms[j];
         td.scale = 0.f;
         td.out = nullptr;
+        td.in = nullptr;
+        if (G.kind == 1) {               // coupled term: this network's jet / seed buffers
+            const Coupled& Cp = E.coupled[T.coupled];
+            for (size_t i = 0; i < Cp.groups.size(); ++i)
+                if (Cp.groups[i] == gi && i < Cp.d_jets.size()) { td.out = Cp.d_jets[i]; td.in = Cp.d_ubar[i]; }
+        }
         tile += td.ntiles;
     }
     G.ga.ntiles = tile;
@@ -554,6 +676,29 @@ void pack_all(pinn_engine& E, const float* d_theta = nullptr) {
 }
 
 // the device section shared by all loss/grad entry points; theta must already be in E.d_theta
+// launch arguments of k_expr for one coupled equation
+aux::ExprArgs expr_args(pinn_engine& E, Coupled& Cp, float scale, float* resid) {
+    Term& T = E.terms[Cp.term];
+    aux::ExprArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.pts = T.d_pts; a.N = (int)T.n; a.d = T.d; a.nparams = E.np; a.nparams_estim = E.ne; a.params = E.d_params;
+    a.nslots = (int)T.slots.size();
+    std::vector<std::vector<char>> used(Cp.nets.size());
+    for (size_t i = 0; i < Cp.nets.size(); ++i) used[i].assign(E.groups[Cp.groups[i]].spec->C, 0);
+    for (int si = 0; si < a.nslots; ++si) {
+        const int i = Cp.slot_net[si], ch = T.chan_of_slot[si];
+        a.jets[si] = Cp.d_jets[i] + (size_t)ch * T.n;
+        a.ubar[si] = Cp.d_ubar[i] + (size_t)ch * T.n;
+        used[i][ch] = 1;
+    }
+    for (size_t i = 0; i < Cp.nets.size(); ++i)
+        for (size_t ch = 0; ch < used[i].size(); ++ch)
+            if (!used[i][ch] && a.nzero < aux::EXPR_MAX_SLOTS) a.zero[a.nzero++] = Cp.d_ubar[i] + ch * T.n;
+    a.prog = Cp.d_prog; a.nops = (int)T.ops.size(); a.out_row = T.out_row; a.scale = scale;
+    a.losspart = Cp.d_losspart; a.pslab = Cp.d_pslab; a.K = (int)E.terms.size(); a.term_id = Cp.term; a.resid = resid;
+    return a;
+}
+
 // the device section shared by all loss/grad entry points.  d_theta: theta in device memory; d_out: [P + K] floats in
 // device memory.  Launches per evaluation: pack (1 per net) -> fused residual kernel (1 per group) -> reduce1 -> reduce2.
 int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const float* term_w, int only_term /* -1 = all */, bool timing) {
@@ -567,16 +712,17 @@ int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const floa
     std::memset(&a1, 0, sizeof a1);
     std::memset(&a2, 0, sizeof a2);
     int max_n1 = 1, max_split = 1;
+    auto scale_of = [&](int ti) -> float {
+        const float w = term_w ? term_w[ti] : 1.0f;
+        const bool on = (only_term < 0 || only_term == ti);
+        return on ? (float)(2.0 * (double)w / (double)E.terms[ti].n_norm) : 0.f;
+    };
     for (size_t g = 0; g < E.groups.size(); ++g) {
         Group& G = E.groups[g];
         bool any = false;
         for (size_t j = 0; j < G.terms.size(); ++j) {
-            const int ti = G.terms[j];
-            Term& T = E.terms[ti];
-            const float w = term_w ? term_w[ti] : 1.0f;
-            const bool on = (only_term < 0 || only_term == ti);
-            G.ga.terms[j].scale = on ? (float)(2.0 * (double)w / (double)T.n_norm) : 0.f;
-            any = any || on;
+            G.ga.terms[j].scale = scale_of(G.terms[j]);
+            any = any || (only_term < 0 || only_term == G.terms[j]);
         }
         G.active = any;
         const int nsplit = std::min(REDUCE_SPLIT, G.blocks);
@@ -586,15 +732,42 @@ int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const floa
         if (!any) continue;
         max_n1 = std::max(max_n1, G.nent + K);
         max_split = std::max(max_split, nsplit);
+        if (G.kind == 1) {               // coupled: forward launch now, reverse launch after k_expr
+            G.spec->launch(G.ga, pk::MODE_FWD, G.blocks, E.stream);
+            continue;
+        }
         if (timing) plat_event_record(G.ev_a, E.stream);
         G.spec->launch(G.ga, pk::MODE_FUSED, G.blocks, E.stream);
+        if (timing) plat_event_record(G.ev_b, E.stream);
+        G.timed = timing;
+    }
+    for (size_t c = 0; c < E.coupled.size(); ++c) {
+        Coupled& Cp = E.coupled[c];
+        const int g = (int)(E.groups.size() + c);
+        const bool on = (only_term < 0 || only_term == Cp.term);
+        const int nsplit = std::min(REDUCE_SPLIT, Cp.blocks);
+        a1.tmp[g] = Cp.d_tmp; a1.slabs[g] = Cp.d_pslab; a1.losspart[g] = Cp.d_losspart;
+        a1.slab[g] = 16; a1.nblocks[g] = Cp.blocks; a1.nsplit[g] = nsplit; a1.nent[g] = 16; a1.active[g] = on;
+        a2.tmp[g] = Cp.d_tmp; a2.stride[g] = 16 + K; a2.nsplit[g] = nsplit; a2.nent[g] = 16; a2.active[g] = on;
+        bool groups_active = false;
+        for (int gi : Cp.groups) groups_active = groups_active || E.groups[gi].active;
+        if (!groups_active) continue;
+        max_n1 = std::max(max_n1, 16 + K);
+        max_split = std::max(max_split, nsplit);
+        aux::launch_expr(expr_args(E, Cp, scale_of(Cp.term), nullptr), Cp.blocks, E.stream);    // scale 0 => zero seeds
+    }
+    for (size_t g = 0; g < E.groups.size(); ++g) {
+        Group& G = E.groups[g];
+        if (G.kind != 1 || !G.active) continue;
+        if (timing) plat_event_record(G.ev_a, E.stream);
+        G.spec->launch(G.ga, pk::MODE_GRADIN, G.blocks, E.stream);
         if (timing) plat_event_record(G.ev_b, E.stream);
         G.timed = timing;
     }
     if (timing) plat_event_record(E.ev2, E.stream);
     a1.K = K;
     a2.out = d_out; a2.lossraw = E.d_lossraw; a2.row_ptr = E.d_gr_ptr; a2.row_grp = E.d_gr_grp; a2.row_ent = E.d_gr_ent;
-    a2.ngroups = (int)E.groups.size(); a2.P = (int)E.ntheta; a2.K = K;
+    a2.ngroups = (int)(E.groups.size() + E.coupled.size()); a2.P = (int)E.ntheta; a2.K = K;
     aux::launch_reduce(a1, a2, max_n1, max_split, E.stream);
     if (timing) plat_event_record(E.ev3, E.stream);
     return 0;
@@ -651,6 +824,11 @@ int pinn_destroy(pinn_handle h) {
         plat_free(G.d_tmp);
         plat_event_destroy(G.ev_a); plat_event_destroy(G.ev_b);
     }
+    for (auto& Cp : E.coupled) {
+        for (float* q : Cp.d_jets) plat_free(q);
+        for (float* q : Cp.d_ubar) plat_free(q);
+        plat_free(Cp.d_prog); plat_free(Cp.d_losspart); plat_free(Cp.d_pslab); plat_free(Cp.d_tmp);
+    }
     for (auto& N : E.netplans) { plat_free(N.d_packed); plat_free(N.d_pack_idx); }
     plat_free(E.d_theta); plat_free(E.d_params); plat_free(E.d_defaults); plat_free(E.d_lossraw); plat_free(E.d_gr_ptr); plat_free(E.d_gr_grp); plat_free(E.d_gr_ent);
     plat_free(E.d_out); plat_free(E.d_phi_pts); plat_free(E.d_phi_out);
@@ -681,7 +859,37 @@ static int set_points_impl(pinn_handle h, int term, const float* pts, int64_t n,
     plat_sync(E.stream);
     T.n = n;
     T.n_norm = n_norm > 0 ? n_norm : n;
-    retile(E, E.groups[T.group]);
+    if (T.coupled < 0) {
+        retile(E, T.group);
+        return 0;
+    }
+    Coupled& Cp = E.coupled[T.coupled];
+    const int K = (int)E.terms.size();
+    if (Cp.cap < n) {
+        for (float* q : Cp.d_jets) plat_free(q);
+        for (float* q : Cp.d_ubar) plat_free(q);
+        Cp.d_jets.assign(Cp.nets.size(), nullptr);
+        Cp.d_ubar.assign(Cp.nets.size(), nullptr);
+        for (size_t i = 0; i < Cp.nets.size(); ++i) {
+            const int C = E.groups[Cp.groups[i]].spec->C;
+            Cp.d_jets[i] = (float*)plat_malloc(sizeof(float) * (size_t)C * n);
+            Cp.d_ubar[i] = (float*)plat_malloc(sizeof(float) * (size_t)C * n);
+            if (!Cp.d_jets[i] || !Cp.d_ubar[i]) return fail("device allocation failed (coupled jets)");
+        }
+        Cp.cap = n;
+    }
+    Cp.blocks = (int)((n + 255) / 256);
+    if (Cp.cap_blocks < Cp.blocks) {
+        plat_free(Cp.d_losspart); plat_free(Cp.d_pslab);
+        Cp.d_losspart = (double*)plat_malloc(sizeof(double) * (size_t)Cp.blocks * 4 * K);
+        Cp.d_pslab = (float*)plat_malloc(sizeof(float) * (size_t)Cp.blocks * 16);
+        if (!Cp.d_losspart || !Cp.d_pslab) return fail("device allocation failed (coupled partials)");
+        plat_memset(Cp.d_losspart, 0, sizeof(double) * (size_t)Cp.blocks * 4 * K, E.stream);
+        plat_memset(Cp.d_pslab, 0, sizeof(float) * (size_t)Cp.blocks * 16, E.stream);
+        plat_sync(E.stream);
+        Cp.cap_blocks = Cp.blocks;
+    }
+    for (int gi : Cp.groups) retile(E, gi);
     return 0;
 }
 int pinn_set_points(pinn_handle h, int term, const float* pts, int64_t n, int64_t n_norm) { return set_points_impl(h, term, pts, n, n_norm, false); }
@@ -762,6 +970,24 @@ int pinn_residual(pinn_handle h, int term, const float* theta, int64_t p, float*
         T.d_resid = (float*)plat_malloc(sizeof(float) * T.n);
         T.resid_cap = T.n;
         if (!T.d_resid) return fail("device allocation failed (residual)");
+    }
+    if (T.coupled >= 0) {
+        Coupled& Cp = E.coupled[T.coupled];
+        for (int gi : Cp.groups) {
+            Group& G = E.groups[gi];
+            pk::GroupArgs ga = G.ga;
+            int j = 0;
+            for (size_t q = 0; q < G.terms.size(); ++q) if (G.terms[q] == term) j = (int)q;
+            ga.nterms = 1;
+            ga.terms[0] = G.ga.terms[j];
+            ga.terms[0].tile0 = 0;
+            ga.ntiles = ga.terms[0].ntiles;
+            G.spec->launch(ga, pk::MODE_FWD, std::max(1, std::min(G.max_blocks, (ga.ntiles + 3) / 4)), E.stream);
+        }
+        aux::launch_expr(expr_args(E, Cp, 0.f, T.d_resid), Cp.blocks, E.stream);
+        if (plat_d2h(r, T.d_resid, sizeof(float) * T.n, E.stream)) return fail("D2H copy failed");
+        if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+        return 0;
     }
     Group& G = E.groups[T.group];
     pk::GroupArgs ga = G.ga;
@@ -849,7 +1075,7 @@ int pinn_describe(pinn_handle h, char* buf, int64_t buflen) {
     os << "backend=" << plat_name() << " cus=" << h->ncu << " ntheta=" << h->ntheta << " terms=" << h->terms.size() << "\n";
     for (size_t g = 0; g < h->groups.size(); ++g) {
         const Group& G = h->groups[g];
-        os << "group " << g << " net=" << G.net << " kernel=" << spec_name(*G.spec) << " tiles=" << G.ga.ntiles << " blocks=" << G.blocks << " terms=";
+        os << "group " << g << (G.kind == 1 ? " [coupled fwd/gradin]" : "") << " net=" << G.net << " kernel=" << spec_name(*G.spec) << " tiles=" << G.ga.ntiles << " blocks=" << G.blocks << " terms=";
         for (int t : G.terms) os << t << ",";
         os << "\n";
     }

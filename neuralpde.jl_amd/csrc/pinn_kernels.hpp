@@ -37,7 +37,10 @@ namespace pk {
 using namespace wv;
 
 enum Act : int { ACT_TANH = 0, ACT_SIGMOID = 1 };
-enum Mode : int { MODE_FUSED = 0, MODE_RESID = 1, MODE_FWD = 2 };
+// FUSED: forward + residual tape + reverse sweep.  RESID: forward + tape, writes r.  FWD: forward only, writes the jet
+// channels per point.  GRADIN: forward + reverse sweep seeded with per-point d(loss)/d(jet) read from memory (equations that
+// couple several networks: the tape runs in k_expr between the FWD and GRADIN launches of every network involved).
+enum Mode : int { MODE_FUSED = 0, MODE_RESID = 1, MODE_FWD = 2, MODE_GRADIN = 3 };
 
 constexpr int MAX_GROUP_TERMS = 12;
 constexpr int MAX_PARAMS = 4;
@@ -123,6 +126,7 @@ struct TermDev {
     int term_id;             // global term index (loss partial column)
     float scale;             // 2 * w_k / N_k(global)   — reverse-sweep seed of mean(abs2, r)
     float* out;              // MODE_RESID: residual r[N];  MODE_FWD: jets [C][N]
+    const float* in;         // MODE_GRADIN: d(loss)/d(jet) [C][N]
 };
 
 struct GroupArgs {
@@ -183,7 +187,8 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
     const int wave = blk * 4 + w;
     float* lds = lds_wg + S::LDS_SHARED + w * S::LDS_PRIV;     // wave-private LDS
     float* lds_sh = lds_wg;                                    // workgroup-shared chunk buffers (COOP)
-    constexpr bool COOP = S::COOP && (MODE == MODE_FUSED);
+    constexpr bool BWD = (MODE == MODE_FUSED || MODE == MODE_GRADIN);       // modes that run the reverse sweep
+    constexpr bool COOP = S::COOP && BWD;
     constexpr int WT = S::WT;
     constexpr int HP = S::HP, MT = S::MT, NHH = S::NHH, LH = S::LH, D = S::D, C = S::C, PG = S::PG, NG = S::NG;
     constexpr int NFIRST = S::NFIRST, NPAIR = S::NPAIR;
@@ -254,7 +259,7 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
             valid[pg] = vlt(p, T.N);
             PINN_UNROLL for (int i = 0; i < D; ++i) {
                 x[pg][i] = gload_masked(T.pts, p * D + vint(i), valid[pg]);
-                if (MODE == MODE_FUSED) lds_store(xs, (vint(16 * pg) + c) * D + vint(i), x[pg][i]);
+                if (BWD) lds_store(xs, (vint(16 * pg) + c) * D + vint(i), x[pg][i]);
             }
         }
 
@@ -291,7 +296,7 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                     }
                     Z[pg * C][m] = av;
 #ifndef PINN_ABL_NOSCR
-                    if (MODE == MODE_FUSED) {
+                    if (BWD) {
                         if (layer == LH - 1) {
                             PINN_UNROLL for (int ch = 0; ch < C; ++ch) Rlast[pg * C + ch][m] = Z[pg * C + ch][m];
                         } else {
@@ -385,11 +390,16 @@ Sr[q][m] = ub_load4(SB, (((layer * NG) + q) * MT + m) * 256, lane << 2);
         };
         // prefetch the raw record of the layer feeding the last hidden->hidden GEMM: it lands while the tape runs
         vfloat4 SrN[NG][MT];
-        if (MODE == MODE_FUSED && NHH > 0) load_raw(SrN, NHH - 1);
+        if (BWD && NHH > 0) load_raw(SrN, NHH - 1);
 
         // =========================== residual tape (values, then adjoints) ===========================
         vfloat ubar[PG][C];
-        {
+        if (MODE == MODE_GRADIN) {
+            PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                vint p = vint(pbase + 16 * pg) + c;
+                PINN_UNROLL for (int ch = 0; ch < C; ++ch) ubar[pg][ch] = gload_masked(T.in, vint(ch * T.N) + p, valid[pg]);
+            }
+        } else {
             wave_fence();
             float* tv = lds;                    // value rows  [row][64]
             float* ta = lds + 2 * S::LDS_T;     // adjoint rows
@@ -654,7 +664,7 @@ Sr[q][m] = ub_load4(SB, (((layer * NG) + q) * MT + m) * 256, lane << 2);
         }
     }  // tiles
 
-    if (MODE != MODE_FUSED) return;
+    if (!BWD) return;
 
     // =========================== epilogue: gradient slab ===========================
     if (cur_term >= 0) {

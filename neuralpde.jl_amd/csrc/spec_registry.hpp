@@ -71,6 +71,7 @@ template <class S>
 void launch_spec(const GroupArgs& ga, int mode, int blocks, plat_stream) {
     if (mode == MODE_FUSED) run_emu<S, MODE_FUSED>(ga, blocks);
     else if (mode == MODE_RESID) run_emu<S, MODE_RESID>(ga, blocks);
+    else if (mode == MODE_GRADIN) run_emu<S, MODE_GRADIN>(ga, blocks);
     else run_emu<S, MODE_FWD>(ga, blocks);
 }
 #else
@@ -87,6 +88,7 @@ template <class S>
 void launch_spec(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
     if (mode == MODE_FUSED) hipLaunchKernelGGL((k_wave<S, MODE_FUSED>), dim3(blocks), dim3(256), 0, st, ga);
     else if (mode == MODE_RESID) hipLaunchKernelGGL((k_wave<S, MODE_RESID>), dim3(blocks), dim3(256), 0, st, ga);
+    else if (mode == MODE_GRADIN) hipLaunchKernelGGL((k_wave<S, MODE_GRADIN>), dim3(blocks), dim3(256), 0, st, ga);
     else hipLaunchKernelGGL((k_wave<S, MODE_FWD>), dim3(blocks), dim3(256), 0, st, ga);
 }
 #endif

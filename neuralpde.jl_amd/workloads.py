@@ -103,4 +103,27 @@ def cfg3_burgers(points: int = 262144, bcs_points: Optional[int] = None, dtype=n
                     n_interior=points)
 
 
-CONFIGS = {"cfg1": cfg1_poisson1d, "cfg2": cfg2_poisson2d, "cfg3": cfg3_burgers}
+def cfg4_cavity(points: int = 262144, bcs_points: int = 32768, width: int = 128, hidden: int = 5, dtype=np.float64) -> Workload:
+    """Steady lid-driven cavity, Re = 100 (nu = 0.01): u u_x + v u_y + p_x - nu (u_xx + u_yy) = 0, same for v with p_y,
+    u_x + v_y = 0; 8 Dirichlet terms (u, v on four walls, lid u(x,1) = 1); three single-output nets (u, v, p) — the only
+    way the reference expresses several dependent variables; bc weights 10 (NonAdaptiveLoss)."""
+    x, y = parameters("x y")
+    u, v, p = variables("u v p")
+    Dx, Dy = Differential(x), Differential(y)
+    Dxx, Dyy = Dx ** 2, Dy ** 2
+    nu = 0.01
+    U, V, Pp = u(x, y), v(x, y), p(x, y)
+    eqs = [Eq(U * Dx(U) + V * Dy(U) + Dx(Pp) - nu * (Dxx(U) + Dyy(U)), 0),
+           Eq(U * Dx(V) + V * Dy(V) + Dy(Pp) - nu * (Dxx(V) + Dyy(V)), 0),
+           Eq(Dx(U) + Dy(V), 0)]
+    bcs = [Eq(u(0, y), 0.0), Eq(u(1, y), 0.0), Eq(u(x, 0), 0.0), Eq(u(x, 1), 1.0),
+           Eq(v(0, y), 0.0), Eq(v(1, y), 0.0), Eq(v(x, 0), 0.0), Eq(v(x, 1), 0.0)]
+    dom = [In(x, Interval(0.0, 1.0)), In(y, Interval(0.0, 1.0))]
+    sysm = PDESystem(eqs, bcs, dom, [x, y], [U, V, Pp])
+    chains = [mlp(2, width, hidden) for _ in range(3)]
+    strat = QuasiRandomTraining(points, bcs_points=bcs_points, sampling_alg=SobolSample(seed=1004), resampling=False, minibatch=1)
+    return Workload(f"cfg4_cavity_3x({hidden}x{width})_quasirandom", sysm, chains, strat, synthetic_theta(chains, 1004, dtype=dtype),
+                    adaptive_loss=NonAdaptiveLoss(pde_loss_weights=1.0, bc_loss_weights=10.0), n_interior=points)
+
+
+CONFIGS = {"cfg1": cfg1_poisson1d, "cfg2": cfg2_poisson2d, "cfg3": cfg3_burgers, "cfg4": cfg4_cavity}

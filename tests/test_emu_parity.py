@@ -148,3 +148,36 @@ def test_golden_fixture_cfg1_through_engine(npde, use_emu):
     losses, grad = rep.engine.loss_grad(g["theta"], g["weights"])
     assert np.max(np.abs(losses - g["losses_stencil"]) / g["losses_stencil"]) < TOL
     assert np.linalg.norm(grad - g["grad_stencil"]) / np.linalg.norm(g["grad_stencil"]) < TOL
+
+
+def test_coupled_system_of_pdes(npde, use_emu):
+    """Equations coupling several networks (src/discretize.jl:58-80): the reference's own system test
+    (test/NNPDE1/nnpde__pde_iv_system_of_pdes.jl:55-86: two chains Dense(2,15,tanh) -> Dense(15,1)), plus a nonlinear
+    coupling with second derivatives on deeper nets.  Forward launch per network -> k_expr -> reverse launch per network."""
+    x, y = npde.parameters("x y")
+    u1, u2 = npde.variables("u1 u2")
+    Dx, Dy = npde.Differential(x), npde.Differential(y)
+    eqs = [npde.Eq(Dx(u1(x, y)) + 4 * Dy(u2(x, y)), 0), npde.Eq(Dx(u2(x, y)) + 9 * Dy(u1(x, y)), 0)]
+    bcs = [npde.Eq(u1(x, 0), 2 * x), npde.Eq(u2(x, 0), 3 * x)]
+    dom = [npde.In(x, npde.Interval(0.0, 1.0)), npde.In(y, npde.Interval(0.0, 1.0))]
+    sysm = npde.PDESystem(eqs, bcs, dom, [x, y], [u1(x, y), u2(x, y)])
+    chains = [npde.Chain(npde.Dense(2, 15, "tanh"), npde.Dense(15, 1)) for _ in range(2)]
+    theta = np.concatenate([theta_for(c, 31 + i) for i, c in enumerate(chains)])
+    strat = npde.QuasiRandomTraining(70, bcs_points=20, sampling_alg=npde.SobolSample(seed=5), resampling=False, minibatch=1)
+    rep, prob, sets, th = check(npde, sysm, chains, strat, theta, weights=[1.0, 2.0, 3.0, 0.5])
+    assert "coupled" in rep.engine.describe()
+    r = rep.loss_functions.datafree_pde_loss_functions[1](sets[1], th)
+    np.testing.assert_allclose(r, po.residual_values(prob, th, 1, sets[1]), atol=3e-5)
+    losses, tg = rep.engine.term_grads(th)
+    ref = po.loss_and_grad(prob, th, sets, mode="stencil", per_term_grads=True)
+    assert np.max(np.abs(tg - ref.term_grads)) / np.max(np.abs(ref.term_grads)) < TOL
+    # nonlinear coupling, second derivatives, deeper nets, a PDE parameter estimated through the coupled path
+    (nu,) = npde.parameters("nu")
+    Dxx, Dyy = Dx ** 2, Dy ** 2
+    eqs = [npde.Eq(u1(x, y) * Dx(u1(x, y)) + u2(x, y) * Dy(u1(x, y)), nu * (Dxx(u1(x, y)) + Dyy(u1(x, y)))),
+           npde.Eq(Dx(u1(x, y)) + Dy(u2(x, y)), sp.sin(sp.pi * x) * u2(x, y))]
+    bcs = [npde.Eq(u1(x, 1), 1.0), npde.Eq(u2(0, y), 0.0), npde.Eq(u1(0, y), 0.0)]
+    sysm = npde.PDESystem(eqs, bcs, dom, [x, y], [u1(x, y), u2(x, y)], ps=[nu], defaults={nu: 0.05})
+    chains = [npde.Chain(npde.Dense(2, 16, "tanh"), npde.Dense(16, 16, "tanh"), npde.Dense(16, 1)) for _ in range(2)]
+    theta = np.concatenate([theta_for(c, 41 + i) for i, c in enumerate(chains)])
+    check(npde, sysm, chains, strat, theta, param_estim=True)

@@ -146,3 +146,22 @@ def test_param_estim_4x64(npde, hip_lib):
     le, g2, gi = helpers.rel_errors(losses, grad, ref)
     assert le.max() < TOL and g2 < TOL and gi < TOL
     assert abs(grad[-1] - ref.grad[-1]) < TOL * abs(ref.grad[-1])          # dL/dk itself
+
+
+def test_cfg4_cavity_coupled_three_nets_reduced_width(npde, hip_lib):
+    """BASELINE config 4 (lid-driven cavity, three coupled networks, bc weights 10) at the widths this round's kernels
+    cover: 3 x (4x64) instead of 3 x (5x128) — 128-wide layers are a next-round kernel."""
+    from neuralpde_jl_amd import workloads
+    wl = workloads.cfg4_cavity(points=3000, bcs_points=400, width=64, hidden=4)
+    rep = npde.symbolic_discretize(wl.pde_system, wl.discretization())
+    assert "coupled" in rep.engine.describe()
+    sets = rep.pde_train_sets + rep.bcs_train_sets
+    w = rep._weights
+    assert list(w) == [1.0] * 3 + [10.0] * 8
+    losses, grad = rep.engine.loss_grad(wl.theta, w)
+    prob = helpers.oracle_problem(npde, wl.pde_system, wl.chains)
+    ref = po.loss_and_grad(prob, wl.theta, sets, weights=w, mode="stencil")
+    le, g2, gi = helpers.rel_errors(losses, grad, ref)
+    assert le.max() < TOL and g2 < TOL and gi < TOL, (le, g2, gi)
+    l2, gr2 = rep.engine.loss_grad(wl.theta, w)
+    assert np.array_equal(l2, losses) and np.array_equal(gr2, grad)
