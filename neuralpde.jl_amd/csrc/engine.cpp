@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <sstream>
@@ -251,7 +252,11 @@ const pk::SpecInfo* find_spec(int HP, int NHH, int D, unsigned need_first, const
             ok = ok && f;
         }
         if (!ok) continue;
-        if (!best || s.C < best->C || (s.C == best->C && s.PG > best->PG)) best = &s;
+        // PINN_KERNEL_FAMILY=1|2 restricts the choice (tests / A-B measurements); default: family 2 where compiled
+        static const int want_family = [] { const char* e = std::getenv("PINN_KERNEL_FAMILY"); return e ? std::atoi(e) : 0; }();
+        if (want_family && s.family != want_family) continue;
+        if (!best || s.C < best->C || (s.C == best->C && s.family > best->family) ||
+            (s.C == best->C && s.family == best->family && s.PG > best->PG)) best = &s;
     }
     (void)pair_index;
     return best;
@@ -276,7 +281,7 @@ int chan_of(const pk::SpecInfo& s, const Slot& sl) {
 
 std::string spec_name(const pk::SpecInfo& s) {
     char b[160];
-    std::snprintf(b, sizeof b, "HP%d_NHH%d_D%d_F%x_P%llx_PG%d(C=%d)", s.HP, s.NHH, s.D, s.D1MASK, s.PAIRS, s.PG, s.C);
+    std::snprintf(b, sizeof b, "F%d_HP%d_NHH%d_D%d_F%x_P%llx_PG%d(C=%d)", s.family, s.HP, s.NHH, s.D, s.D1MASK, s.PAIRS, s.PG, s.C);
     return b;
 }
 
@@ -438,7 +443,17 @@ int build_plan(pinn_engine& E) {
             for (int nn = 0; nn < HP; ++nn) idx[s.OFF_B + l * HP + nn] = bidx(l, nn);
         for (int nn = 0; nn < HP; ++nn) idx[s.OFF_WL + nn] = Widx(LH, 0, nn);
         idx[s.OFF_BL] = bidx(LH, 0);
-        for (int hl = 0; hl < s.NHH; ++hl)
+        for (int hl = 0; hl < s.NHH && s.family == 2; ++hl)
+            for (int ta = 0; ta < MT; ++ta)
+                for (int tb = 0; tb < MT; ++tb)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const int g = lane >> 4, c = lane & 15;
+                            // forward [mo=ta][mi=tb][lane][rr] = W[16mo+c][16mi+4g+rr]; transposed [mi=ta][mo=tb][lane][rr] = W[16mo+4g+rr][16mi+c]
+                            idx[s.OFF_WPK + ((hl * MT + ta) * MT + tb) * 256 + lane * 4 + rr] = Widx(hl + 1, 16 * ta + c, 16 * tb + 4 * g + rr);
+                            idx[s.OFF_WTPK + ((hl * MT + ta) * MT + tb) * 256 + lane * 4 + rr] = Widx(hl + 1, 16 * tb + 4 * g + rr, 16 * ta + c);
+                        }
+        for (int hl = 0; hl < s.NHH && s.family == 1; ++hl)
             for (int m1 = 0; m1 < MT; ++m1)
                 for (int rr = 0; rr < 4; ++rr)
                     for (int lane = 0; lane < 64; ++lane)
@@ -464,13 +479,13 @@ int build_plan(pinn_engine& E) {
         const Net& N = E.nets[G.net];
         const int LH = s.LH, HP = s.HP, MT = s.MT, D = s.D;
         (void)HP;
-        G.max_blocks = E.ncu;
+        G.max_blocks = E.ncu * s.WG_PER_CU;
         plat_event_create(G.ev_a);
         plat_event_create(G.ev_b);
         const size_t nw = (size_t)G.max_blocks * 4;
         G.d_slabs = (float*)plat_malloc(sizeof(float) * (size_t)G.max_blocks * s.SLAB);
         G.d_losspart = (double*)plat_malloc(sizeof(double) * nw * total_terms);
-        G.d_scratch = (float*)plat_malloc(sizeof(float) * nw * s.SCR);
+        G.d_scratch = (float*)plat_malloc(sizeof(float) * (s.family == 2 ? (size_t)G.max_blocks : nw) * s.SCR);
         if (!G.d_slabs || !G.d_losspart || !G.d_scratch) return fail("device allocation failed (group buffers)");
         // columns of terms this group does not own are never written by its kernel but are summed by the reduction
         plat_memset(G.d_losspart, 0, sizeof(double) * nw * total_terms, E.stream);
@@ -527,12 +542,31 @@ int build_plan(pinn_engine& E) {
             loff[j] = o;
             o += N.sizes[j + 1] * N.sizes[j] + N.sizes[j + 1];
         }
-        for (int in = 0; in < D; ++in)                          // layer 0: W (n1 x d)
+        if (s.family == 2) {                                    // every slab entry has exactly one writer wave
+            for (int in = 0; in < D; ++in)
+                for (int out = 0; out < N.sizes[1]; ++out) add_row(loff[0] + out + in * N.sizes[1], s.O_W1 + in * s.HP + out, true);
+            for (int l = 0; l < LH; ++l)
+                for (int out = 0; out < N.sizes[l + 1]; ++out)
+                    add_row(loff[l] + N.sizes[l + 1] * N.sizes[l] + out, s.O_BFRH + l * s.HP + out, true);
+            for (int hl = 0; hl < s.NHH; ++hl) {
+                const int j = hl + 1;
+                for (int in = 0; in < N.sizes[j]; ++in)
+                    for (int out = 0; out < N.sizes[j + 1]; ++out) {
+                        const int to = out / 16, i = out % 16, g = i / 4, r = i % 4;
+                        const int ti = (in / 64) * 4 + (in % 4), c = (in % 64) / 4;
+                        add_row(loff[j] + out + in * N.sizes[j + 1], s.O_WBAR + (((hl * MT + to) * MT + ti) * 64 + g * 16 + c) * 4 + r, true);
+                    }
+            }
+            for (int in = 0; in < N.sizes[LH]; ++in) add_row(loff[LH] + in, s.O_WL + in, true);
+            add_row(loff[LH] + N.sizes[LH], s.O_BL, true);
+            for (int j = 0; j < E.ne; ++j) add_row(E.p_theta_off + j, s.O_P + j, true);
+        }
+        for (int in = 0; in < D && s.family == 1; ++in)          // layer 0: W (n1 x d)
             for (int out = 0; out < N.sizes[1]; ++out)
                 add_row(loff[0] + out + in * N.sizes[1], s.O_W1 + (in * MT + out % MT) * 16 + out / MT, false);
-        for (int out = 0; out < N.sizes[1]; ++out)              // bias of hidden layer 0
+        for (int out = 0; out < N.sizes[1] && s.family == 1; ++out)              // bias of hidden layer 0
             add_row(loff[0] + N.sizes[1] * N.sizes[0] + out, s.O_BFR0 + (out % MT) * 16 + out / MT, false);
-        for (int hl = 0; hl < s.NHH; ++hl) {
+        for (int hl = 0; hl < s.NHH && s.family == 1; ++hl) {
             const int j = hl + 1;
             for (int in = 0; in < N.sizes[j]; ++in)
                 for (int out = 0; out < N.sizes[j + 1]; ++out) {
@@ -543,10 +577,12 @@ int build_plan(pinn_engine& E) {
             for (int out = 0; out < N.sizes[j + 1]; ++out)
                 add_row(loff[j] + N.sizes[j + 1] * N.sizes[j] + out, s.O_BFRH + (hl * MT + out % MT) * 16 + out / MT, coop);
         }
-        for (int in = 0; in < N.sizes[LH]; ++in)                // W_out (1 x nLH)
+        for (int in = 0; in < N.sizes[LH] && s.family == 1; ++in)                // W_out (1 x nLH)
             add_row(loff[LH] + in, s.O_WL + ((in / 16) * 4 + (in % 16) / 4) * 4 + in % 4, false);
-        add_row(loff[LH] + N.sizes[LH], s.O_BL, false);
-        for (int j = 0; j < E.ne; ++j) add_row(E.p_theta_off + j, s.O_P + j, false);
+        if (s.family == 1) {
+            add_row(loff[LH] + N.sizes[LH], s.O_BL, false);
+            for (int j = 0; j < E.ne; ++j) add_row(E.p_theta_off + j, s.O_P + j, false);
+        }
         G.nent = s.SLAB;                 // stage 1 is dense over slab offsets
         G.row_theta = row_theta;
         G.row_ptr = row_ptr;
@@ -655,7 +691,7 @@ void retile(pinn_engine& E, int gi) {
         tile += td.ntiles;
     }
     G.ga.ntiles = tile;
-    G.blocks = std::max(1, std::min(G.max_blocks, (tile + 3) / 4));
+    G.blocks = std::max(1, std::min(G.max_blocks, s.family == 2 ? tile : (tile + 3) / 4));
 }
 
 int ensure_points(pinn_engine& E) {

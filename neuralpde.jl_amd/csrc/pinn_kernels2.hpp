@@ -1,0 +1,476 @@
+// pinn_kernels2.hpp — "family 2" of the PINN residual/loss kernel: neuron-split workgroups.
+//
+// Same mathematics, same replaced reference code (see pinn_kernels.hpp header) — different mapping onto the CU:
+//   * one workgroup (4 waves) owns one tile of TP = 16*PG points; wave w owns the 16-neuron tiles
+//     {w*MTW .. w*MTW+MTW-1} of EVERY layer (MTW = HP/64), for all NG = C*PG column groups of the tile;
+//   * between layers the activation jets are exchanged through LDS in MFMA-B-fragment order
+//     X[column group][neuron tile][lane][4] (ping-pong buffers, one s_barrier per layer); a wave's accumulators are
+//     only NG*MTW vfloat4 (20 registers for the 2-D Poisson interior term) instead of 2 x 80, so the kernel stays under
+//     256 VGPR+AGPR and TWO workgroups (8 waves = 2 per SIMD) are resident per CU: one wave's VALU/LDS/HBM latency
+//     hides under the other's MFMA issue (family 1 runs a single 512-register wave per SIMD and overlaps nothing);
+//   * dW rows are naturally wave-owned (its neuron tiles x all inputs): MTW*MT accumulator tiles per layer stay resident
+//     across all tiles of the workgroup; the transposed operands go through LDS: dZ^T wave-private, A^T cooperatively;
+//   * the residual tape runs in vector registers (vtape, VGPR-index mode), redundantly in the four waves.
+#pragma once
+#include "pinn_kernels.hpp"
+
+namespace pk {
+
+template <int HP_, int NHH_, int D_, unsigned D1MASK_, unsigned long long PAIRS_, int NPAIR_, int PG_>
+struct Spec2 {
+    static constexpr int FAMILY = 2;
+    static constexpr int HP = HP_, MT = HP_ / 16, NHH = NHH_, LH = NHH_ + 1, D = D_, NPAIR = NPAIR_, PG = PG_;
+    static constexpr unsigned D1MASK = D1MASK_;
+    static constexpr unsigned long long PAIRS = PAIRS_;
+    static constexpr int MTW = MT / 4;                 // neuron tiles per wave
+    static_assert(MT % 4 == 0, "family 2 needs a hidden width that is a multiple of 64");
+    static constexpr int popc(unsigned x) { int n = 0; while (x) { n += x & 1; x >>= 1; } return n; }
+    static constexpr int NFIRST = popc(D1MASK_);
+    static constexpr int C = 1 + NFIRST + NPAIR_;
+    static constexpr int NG = C * PG_;
+    static constexpr int TP = 16 * PG_;
+    static constexpr int first_axis(int k) {
+        int cnt = 0;
+        for (int a = 0; a < 8; ++a)
+            if (D1MASK_ & (1u << a)) { if (cnt == k) return a; ++cnt; }
+        return -1;
+    }
+    static constexpr int first_rank(int axis) {
+        int cnt = 0;
+        for (int a = 0; a < axis; ++a) if (D1MASK_ & (1u << a)) ++cnt;
+        return cnt;
+    }
+    static constexpr int pair_a(int p) { return (int)((PAIRS_ >> (8 * p)) & 0xF); }
+    static constexpr int pair_b(int p) { return (int)((PAIRS_ >> (8 * p + 4)) & 0xF); }
+    // packed parameter buffer (floats); fragment images are [layer][tile a][tile b][lane][4 k-steps]
+    static constexpr int OFF_W1 = 0;
+    static constexpr int OFF_B = OFF_W1 + D_ * HP_;
+    static constexpr int OFF_WL = OFF_B + LH * HP_;
+    static constexpr int OFF_BL = OFF_WL + HP_;
+    static constexpr int OFF_WPK = OFF_BL + 4;                       // [NHH][mo][mi][64][4]: W[16mo+(l&15)][16mi+4(l>>4)+rr]
+    static constexpr int OFF_WTPK = OFF_WPK + NHH_ * HP_ * HP_;      // [NHH][mi][mo][64][4]: W[16mo+4(l>>4)+rr][16mi+(l&15)]
+    static constexpr int PACKED = OFF_WTPK + NHH_ * HP_ * HP_;
+    // per-workgroup gradient slab: every entry is written by exactly one wave
+    static constexpr int O_WBAR = 0;                                 // [NHH][to][ti][64][4]
+    static constexpr int O_BH = NHH_ * HP_ * HP_;                    // [LH][HP]  natural neuron order
+    static constexpr int O_W1 = O_BH + LH * HP_;                     // [D][HP]
+    static constexpr int O_WL = O_W1 + D_ * HP_;                     // [HP]
+    static constexpr int O_BL = O_WL + HP_;
+    static constexpr int O_P = O_BL + 1;
+    static constexpr int SLAB = ((O_P + MAX_PARAMS + 63) / 64) * 64;
+    // per-workgroup record scratch, [layer][q][tile][lane][4]; layer LH-1 stays in registers, layer 0 is recomputed
+    static constexpr int SCR = (LH > 2 ? LH - 2 : 1) * NG * MT * 256;      // hidden layers 1 .. LH-2
+    // LDS (floats): X0 | X1 (activation / dZ exchange, A^T) | ZT (4 x private dZ^T) | output partials | coords
+    static constexpr int XSZ = NG * MT * 256;
+    static constexpr int LDS_UP = ((4 * NG * 16 + 63) / 64) * 64;
+    static constexpr int LDS_WG = 3 * XSZ + LDS_UP;
+    static constexpr int WG_PER_CU = (LDS_WG * 4 <= 80 * 1024) ? 2 : 1;
+};
+
+template <class S, int MODE>
+DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds) {
+    constexpr int HP = S::HP, MT = S::MT, MTW = S::MTW, NHH = S::NHH, LH = S::LH, D = S::D, C = S::C, PG = S::PG, NG = S::NG;
+    constexpr int NFIRST = S::NFIRST, NPAIR = S::NPAIR;
+    constexpr bool BWD = (MODE == MODE_FUSED || MODE == MODE_GRADIN);
+    const int wave = blk * 4 + w;
+    const vint lane = lane_id();
+    const vint g = lane >> 4;
+    const vint c = lane & vint(15);
+    const vbool g0 = veq(g, 0);
+    const float* P = ga.packed;
+    const int act = ga.act;
+    const ubuf PB = ub_make(P, S::PACKED);
+    const ubuf SB = ub_make(ga.scratch + (size_t)blk * S::SCR, S::SCR);
+    float* X0 = lds;
+    float* X1 = lds + S::XSZ;
+    float* ZT = lds + 2 * S::XSZ + w * (NG * MTW * 256);      // wave-private dZ^T: [q][t][16 columns][16 neurons]
+    float* UP = lds + 3 * S::XSZ;                             // output-layer partial sums [wave][q][16]
+
+    // ---- persistent gradient accumulators of this wave's neuron tiles ----
+    vfloat4 wbar[NHH > 0 ? NHH : 1][MTW][MT];
+    vfloat4 bbar[LH][MTW];
+    vfloat4 w1bar[D][MTW];
+    vfloat4 wLbar[MTW];
+    vfloat bLbar = vfloat(0.f);
+    vfloat pbar[MAX_PARAMS];
+    PINN_UNROLL for (int l = 0; l < (NHH > 0 ? NHH : 1); ++l)
+        PINN_UNROLL for (int t = 0; t < MTW; ++t)
+            PINN_UNROLL for (int ti = 0; ti < MT; ++ti) wbar[l][t][ti] = vzero4();
+    PINN_UNROLL for (int l = 0; l < LH; ++l)
+        PINN_UNROLL for (int t = 0; t < MTW; ++t) bbar[l][t] = vzero4();
+    PINN_UNROLL for (int i = 0; i < D; ++i)
+        PINN_UNROLL for (int t = 0; t < MTW; ++t) w1bar[i][t] = vzero4();
+    PINN_UNROLL for (int t = 0; t < MTW; ++t) wLbar[t] = vzero4();
+    PINN_UNROLL for (int i = 0; i < MAX_PARAMS; ++i) pbar[i] = vfloat(0.f);
+    vfloat lsum = vfloat(0.f);
+    int cur_term = -1;
+
+    vfloat4 wL[MTW];
+    PINN_UNROLL for (int t = 0; t < MTW; ++t) wL[t] = ub_load4(PB, S::OFF_WL + 16 * (w * MTW + t), g << 2);
+    const float bL = P[S::OFF_BL];
+
+    if (MODE == MODE_FUSED)
+        for (int j = 0; j < ga.nterms; ++j) ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[j].term_id] = 0.0;
+
+    const int niter = (ga.ntiles + nblocks - 1) / nblocks;
+    for (int it = 0; it < niter; ++it) {
+        const int tix = it * nblocks + blk;                  // >= ntiles: dummy tile (all points masked)
+        int k = 0;
+        for (int j = 1; j < ga.nterms; ++j)
+            if (tix >= ga.terms[j].tile0) k = j;
+        if (k != cur_term) {
+            if (cur_term >= 0 && MODE == MODE_FUSED && w == 0)
+                ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[cur_term].term_id] = wave_sum_d(lsum, g0);
+            lsum = vfloat(0.f);
+            cur_term = k;
+        }
+        const TermDev& T = ga.terms[k];
+        const int pbase = (tix - T.tile0) * S::TP;
+
+        vfloat x[PG][D];
+        vbool valid[PG];
+        PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+            vint p = vint(pbase + 16 * pg) + c;
+            valid[pg] = vlt(p, T.N);
+            PINN_UNROLL for (int i = 0; i < D; ++i) x[pg][i] = gload_masked(T.pts, p * D + vint(i), valid[pg]);
+        }
+
+        // jet activation in place + record: layer LH-1 stays in registers (Rlast), the others go to the scratch slab
+        vfloat4 Rlast[NG][MTW];
+        auto act_forward = [&](vfloat4 (&Z)[NG][MTW], int layer) {
+            PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
+                PINN_UNROLL for (int t = 0; t < MTW; ++t) {
+                    vfloat4 d1v, d2v, av;
+                    PINN_UNROLL for (int r = 0; r < 4; ++r) {
+                        vfloat a = act_value(act, Z[pg * C][t][r]);
+                        vfloat d1, d2, d3;
+                        act_derivs_rt(act, a, d1, d2, d3);
+                        av[r] = a; d1v[r] = d1; d2v[r] = d2;
+                    }
+                    Z[pg * C][t] = av;
+                    if (BWD) {
+                        if (layer == LH - 1) {
+                            PINN_UNROLL for (int ch = 0; ch < C; ++ch) Rlast[pg * C + ch][t] = Z[pg * C + ch][t];
+                        } else if (layer > 0) {          // layer 0's record is recomputed from the coordinates (no storage)
+                            PINN_UNROLL for (int ch = 0; ch < C; ++ch)
+                                ub_store4(SB, (((layer - 1) * NG + pg * C + ch) * MT + w * MTW + t) * 256, lane << 2, Z[pg * C + ch][t]);
+                        }
+                    }
+                    PINN_UNROLL for (int p = 0; p < NPAIR; ++p) {
+                        const int cp = pg * C + 1 + NFIRST + p;
+                        const int ca = pg * C + 1 + S::first_rank(S::pair_a(p));
+                        const int cb = pg * C + 1 + S::first_rank(S::pair_b(p));
+                        PINN_UNROLL for (int r = 0; r < 4; ++r)
+                            Z[cp][t][r] = vfma(d2v[r] * Z[ca][t][r], Z[cb][t][r], d1v[r] * Z[cp][t][r]);
+                    }
+                    PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf)
+                        PINN_UNROLL for (int r = 0; r < 4; ++r) Z[pg * C + 1 + kf][t][r] = d1v[r] * Z[pg * C + 1 + kf][t][r];
+                }
+        };
+        // publish this wave's tiles of a [NG][MT] tensor in B-fragment order: X[q][tile][lane][4]
+        auto publish = [&](float* X, const vfloat4 (&A)[NG][MTW]) {
+            PINN_UNROLL for (int q = 0; q < NG; ++q)
+                PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                    lds_store4(X, vint(((q * MT + w * MTW + t) * 64) * 4) + (lane << 2), A[q][t]);
+        };
+
+        // =========================== forward ===========================
+        vfloat4 A[NG][MTW];
+        PINN_UNROLL for (int t = 0; t < MTW; ++t) {                          // hidden layer 0: d -> HP on the VALU
+            const int n0 = 16 * (w * MTW + t);
+            vfloat4 b1 = ub_load4(PB, S::OFF_B + n0, g << 2);
+            vfloat4 w1[D];
+            PINN_UNROLL for (int i = 0; i < D; ++i) w1[i] = ub_load4(PB, S::OFF_W1 + i * HP + n0, g << 2);
+            PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                vfloat4 z = b1;
+                PINN_UNROLL for (int i = 0; i < D; ++i)
+                    PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = vfma(w1[i][r], x[pg][i], z[r]);
+                A[pg * C][t] = z;
+                PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) A[pg * C + 1 + kf][t] = w1[S::first_axis(kf)];
+                PINN_UNROLL for (int p = 0; p < NPAIR; ++p) A[pg * C + 1 + NFIRST + p][t] = vzero4();
+            }
+        }
+        act_forward(A, 0);
+        PINN_UNROLL for (int hl = 0; hl < NHH; ++hl) {
+            float* Xin = (hl & 1) ? X1 : X0;
+            publish(Xin, A);
+            wg_barrier();                                                   // layer hl activations complete in Xin
+            PINN_UNROLL for (int t = 0; t < MTW; ++t) {
+                vfloat4 bv = ub_load4(PB, S::OFF_B + (hl + 1) * HP + 16 * (w * MTW + t), g << 2);
+                PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                    A[pg * C][t] = bv;
+                    PINN_UNROLL for (int ch = 1; ch < C; ++ch) A[pg * C + ch][t] = vzero4();
+                }
+            }
+            PINN_UNROLL for (int mi = 0; mi < MT; ++mi) {
+                vfloat4 wf[MTW];
+                PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                    wf[t] = ub_load4(PB, S::OFF_WPK + ((hl * MT + w * MTW + t) * MT + mi) * 256, lane << 2);
+                PINN_UNROLL for (int q = 0; q < NG; ++q) {
+                    vfloat4 b4 = lds_load4(Xin, vint(((q * MT + mi) * 64) * 4) + (lane << 2));
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                        PINN_UNROLL for (int rr = 0; rr < 4; ++rr) A[q][t] = mfma16(wf[t][rr], b4[rr], A[q][t]);
+                }
+            }
+            act_forward(A, hl + 1);
+        }
+        // output layer HP -> 1: per-wave partial dot over its neurons, summed across the 4 waves through LDS
+        {
+            PINN_UNROLL for (int q = 0; q < NG; ++q) {
+                vfloat s = vfloat(0.f);
+                PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                    PINN_UNROLL for (int r = 0; r < 4; ++r) s = vfma(wL[t][r], A[q][t][r], s);
+                s = s + shfl_xor(s, 16);
+                s = s + shfl_xor(s, 32);
+                lds_store(UP, vint((w * NG + q) * 16) + c, s);             // all four row groups hold the same value
+            }
+            wg_barrier();
+        }
+        vfloat U[PG][C];
+        PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
+            PINN_UNROLL for (int ch = 0; ch < C; ++ch) {
+                vfloat s = vfloat(0.f);
+                PINN_UNROLL for (int ws = 0; ws < 4; ++ws) s = s + lds_load(UP, vint((ws * NG + pg * C + ch) * 16) + c);
+                U[pg][ch] = (ch == 0) ? s + vfloat(bL) : s;
+            }
+        if (MODE == MODE_FWD) {
+            if (w == 0)
+                PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                    vint p = vint(pbase + 16 * pg) + c;
+                    PINN_UNROLL for (int ch = 0; ch < C; ++ch)
+                        gstore_masked(T.out, vint(ch * T.N) + p, U[pg][ch], vand(valid[pg], g0));
+                }
+            wg_barrier();                                                   // UP is rewritten by the next tile
+            continue;
+        }
+
+        // =========================== residual tape (vector registers, redundantly in the 4 waves) ===========================
+        vfloat ubar[PG][C];
+        if (MODE == MODE_GRADIN) {
+            PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                vint p = vint(pbase + 16 * pg) + c;
+                PINN_UNROLL for (int ch = 0; ch < C; ++ch) ubar[pg][ch] = gload_masked(T.in, vint(ch * T.N) + p, valid[pg]);
+            }
+        } else {
+            const int NP = ga.nparams;
+            const int R0 = D + NP + C;
+            const rp::Instr* prog = ga.prog + T.prog_off;
+            PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                vtape tv;
+                tape_zero(tv);
+                PINN_UNROLL for (int i = 0; i < D; ++i) tape_set(tv, i, x[pg][i]);
+                for (int j = 0; j < NP; ++j) tape_set(tv, D + j, vfloat(ga.params[j]));
+                PINN_UNROLL for (int ch = 0; ch < C; ++ch) tape_set(tv, D + NP + ch, U[pg][ch]);
+                for (int q = 0; q < T.nops; ++q) {
+                    const rp::Instr ins = prog[q];
+                    tape_set(tv, R0 + q, rp::apply<vfloat>(ins.code, tape_get(tv, ins.a), tape_get(tv, ins.b), ins.imm));
+                }
+                vfloat r = tape_get(tv, T.out_row);
+                if (MODE == MODE_RESID) {
+                    vint p = vint(pbase + 16 * pg) + c;
+                    if (w == 0) gstore_masked(T.out, p, r, vand(valid[pg], g0));
+                    continue;
+                }
+                vfloat rm = vselect(valid[pg], r, vfloat(0.f));
+                lsum = vfma(rm, vselect(g0, rm, vfloat(0.f)), lsum);       // only wave 0's copy is written out
+                vfloat rbar = rm * vfloat(T.scale);
+                vtape ta;
+                tape_zero(ta);
+                tape_set(ta, T.out_row, vfloat(1.0f));
+                for (int q = T.nops - 1; q >= 0; --q) {
+                    const rp::Instr ins = prog[q];
+                    if (rp::is_nullary(ins.code)) continue;
+                    vfloat da, db;
+                    rp::adjoint<vfloat>(ins.code, tape_get(tv, ins.a), tape_get(tv, ins.b), tape_get(tv, R0 + q), ins.imm,
+                                        tape_get(ta, R0 + q), da, db);
+                    tape_set(ta, ins.a, tape_get(ta, ins.a) + da);
+                    if (rp::is_binary(ins.code)) tape_set(ta, ins.b, tape_get(ta, ins.b) + db);
+                }
+                PINN_UNROLL for (int ch = 0; ch < C; ++ch) ubar[pg][ch] = rbar * tape_get(ta, D + NP + ch);
+                for (int j = 0; j < ga.nparams_estim; ++j) {
+                    vfloat pj = vselect(g0, rbar * tape_get(ta, D + j), vfloat(0.f));
+                    PINN_UNROLL for (int jj = 0; jj < MAX_PARAMS; ++jj) if (jj == j) pbar[jj] += pj;
+                }
+            }
+        }
+        if (MODE == MODE_RESID) { wg_barrier(); continue; }
+
+        // =========================== reverse sweep ===========================
+        auto ajet = [&](const vfloat4 (&Sr)[NG][MTW], int pg, int ch, int t) -> vfloat4 {
+            vfloat4 out;
+            PINN_UNROLL for (int r = 0; r < 4; ++r) {
+                vfloat a = Sr[pg * C][t][r];
+                if (ch == 0) { out[r] = a; continue; }
+                vfloat d1, d2, d3;
+                act_derivs_rt(act, a, d1, d2, d3);
+                if (ch <= NFIRST) out[r] = d1 * Sr[pg * C + ch][t][r];
+                else {
+                    const int p = ch - 1 - NFIRST;
+                    const int ca = pg * C + 1 + S::first_rank(S::pair_a(p));
+                    const int cb = pg * C + 1 + S::first_rank(S::pair_b(p));
+                    out[r] = vfma(d2 * Sr[ca][t][r], Sr[cb][t][r], d1 * Sr[pg * C + ch][t][r]);
+                }
+            }
+            return out;
+        };
+        auto act_adjoint = [&](vfloat4 (&G)[NG][MTW], const vfloat4 (&Sr)[NG][MTW]) {
+            PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
+                PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                    PINN_UNROLL for (int r = 0; r < 4; ++r) {
+                        vfloat a = Sr[pg * C][t][r];
+                        vfloat d1, d2, d3;
+                        act_derivs_rt(act, a, d1, d2, d3);
+                        vfloat zv = d1 * G[pg * C][t][r];
+                        vfloat zf[NFIRST > 0 ? NFIRST : 1];
+                        PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) {
+                            vfloat gk = G[pg * C + 1 + kf][t][r];
+                            zv = vfma(d2 * Sr[pg * C + 1 + kf][t][r], gk, zv);
+                            zf[kf] = d1 * gk;
+                        }
+                        PINN_UNROLL for (int p = 0; p < NPAIR; ++p) {
+                            const int cp = pg * C + 1 + NFIRST + p;
+                            const int ka = S::first_rank(S::pair_a(p)), kb = S::first_rank(S::pair_b(p));
+                            vfloat za = Sr[pg * C + 1 + ka][t][r], zb = Sr[pg * C + 1 + kb][t][r];
+                            vfloat gp = G[cp][t][r];
+                            zv = vfma(vfma(d3 * za, zb, d2 * Sr[cp][t][r]), gp, zv);
+                            zf[ka] = vfma(d2 * zb, gp, zf[ka]);
+                            zf[kb] = vfma(d2 * za, gp, zf[kb]);
+                            G[cp][t][r] = d1 * gp;
+                        }
+                        G[pg * C][t][r] = zv;
+                        PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) G[pg * C + 1 + kf][t][r] = zf[kf];
+                    }
+        };
+
+        vfloat4 G[NG][MTW];
+        PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {                        // output layer
+            if (w == 0) bLbar += vselect(g0, ubar[pg][0], vfloat(0.f));
+            PINN_UNROLL for (int ch = 0; ch < C; ++ch)
+                PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                    PINN_UNROLL for (int r = 0; r < 4; ++r) {
+                        wLbar[t][r] = vfma(ubar[pg][ch], A[pg * C + ch][t][r], wLbar[t][r]);
+                        G[pg * C + ch][t][r] = wL[t][r] * ubar[pg][ch];
+                    }
+        }
+        act_adjoint(G, Rlast);
+
+        PINN_UNROLL for (int hl = NHH - 1; hl >= 0; --hl) {
+            // G = dZ of hidden layer hl+1 (own tiles).  Inputs of that layer = a-jets of hidden layer hl.
+            vfloat4 Sr[NG][MTW];
+            if (hl == 0) {              // record of hidden layer 0: K = d, recomputed on the VALU
+                PINN_UNROLL for (int t = 0; t < MTW; ++t) {
+                    const int n0 = 16 * (w * MTW + t);
+                    vfloat4 b1 = ub_load4(PB, S::OFF_B + n0, g << 2);
+                    vfloat4 w1[D];
+                    PINN_UNROLL for (int i = 0; i < D; ++i) w1[i] = ub_load4(PB, S::OFF_W1 + i * HP + n0, g << 2);
+                    PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                        vfloat4 z = b1;
+                        PINN_UNROLL for (int i = 0; i < D; ++i)
+                            PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = vfma(w1[i][r], x[pg][i], z[r]);
+                        PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = act_value(act, z[r]);
+                        Sr[pg * C][t] = z;
+                        PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) Sr[pg * C + 1 + kf][t] = w1[S::first_axis(kf)];
+                        PINN_UNROLL for (int p = 0; p < NPAIR; ++p) Sr[pg * C + 1 + NFIRST + p][t] = vzero4();
+                    }
+                }
+            } else {
+                PINN_UNROLL for (int q = 0; q < NG; ++q)
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                        Sr[q][t] = ub_load4(SB, (((hl - 1) * NG + q) * MT + w * MTW + t) * 256, lane << 2);
+            }
+            PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
+                PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                    PINN_UNROLL for (int r = 0; r < 4; ++r) bbar[hl + 1][t][r] += G[pg * C][t][r];
+            publish(X0, G);                                                  // dZ in B-fragment order for dA = W^T dZ
+            PINN_UNROLL for (int q = 0; q < NG; ++q)
+                PINN_UNROLL for (int t = 0; t < MTW; ++t) {
+                    // dZ^T, wave private: [q][t][column][16 neurons], slot-swizzled
+                    lds_store4(ZT, vint(((q * MTW + t) * 16) * 16) + c * 16 + ((g ^ (c & vint(3))) << 2), G[q][t]);
+                    // A^T, cooperative: X1[q][column][HP], slot-swizzled (tr_addr of family 1)
+                    const vint slot = vint(4 * (w * MTW + t)) + g;
+                    lds_store4(X1, vint(q * 16 * HP) + c * HP + (((slot ^ c) & vint(4 * MT - 1)) << 2), ajet(Sr, q / C, q % C, t));
+                }
+            wg_barrier();
+            // ---- dW[own rows][all inputs] += dZ A^T ----
+            PINN_UNROLL for (int q = 0; q < NG; ++q)
+                PINN_UNROLL for (int kk = 0; kk < 4; ++kk) {
+                    const vint row = vint(4 * kk) + g;
+                    vfloat zf[MTW];
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                        zf[t] = lds_load(ZT, vint(((q * MTW + t) * 16) * 16) + row * 16 + (((c >> 2) ^ (row & vint(3))) << 2) + (c & vint(3)));
+                    PINN_UNROLL for (int hb = 0; hb < MT / 4; ++hb) {
+                        const vint slot = vint(16 * hb) + c;
+                        vfloat4 a4 = lds_load4(X1, vint(q * 16 * HP) + row * HP + (((slot ^ row) & vint(4 * MT - 1)) << 2));
+                        PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                            PINN_UNROLL for (int e = 0; e < 4; ++e) wbar[hl][t][hb * 4 + e] = mfma16(zf[t], a4[e], wbar[hl][t][hb * 4 + e]);
+                    }
+                }
+            // ---- dA (own input tiles) = W^T dZ ----
+            vfloat4 Gn[NG][MTW];
+            PINN_UNROLL for (int q = 0; q < NG; ++q)
+                PINN_UNROLL for (int t = 0; t < MTW; ++t) Gn[q][t] = vzero4();
+            PINN_UNROLL for (int mo = 0; mo < MT; ++mo) {
+                vfloat4 wt[MTW];
+                PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                    wt[t] = ub_load4(PB, S::OFF_WTPK + ((hl * MT + w * MTW + t) * MT + mo) * 256, lane << 2);
+                PINN_UNROLL for (int q = 0; q < NG; ++q) {
+                    vfloat4 b4 = lds_load4(X0, vint(((q * MT + mo) * 64) * 4) + (lane << 2));
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                        PINN_UNROLL for (int rr = 0; rr < 4; ++rr) Gn[q][t] = mfma16(wt[t][rr], b4[rr], Gn[q][t]);
+                }
+            }
+            wg_barrier();                                                   // X0 / X1 free again
+            PINN_UNROLL for (int q = 0; q < NG; ++q)
+                PINN_UNROLL for (int t = 0; t < MTW; ++t) G[q][t] = Gn[q][t];
+            act_adjoint(G, Sr);
+        }
+        // hidden layer 0: db0, dW1 in the D layout (per-lane partial sums over this lane's column)
+        PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
+            PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                PINN_UNROLL for (int r = 0; r < 4; ++r) {
+                    const vfloat gz = G[pg * C][t][r];
+                    bbar[0][t][r] += gz;
+                    PINN_UNROLL for (int i = 0; i < D; ++i) w1bar[i][t][r] = vfma(gz, x[pg][i], w1bar[i][t][r]);
+                    PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf)
+                        PINN_UNROLL for (int i = 0; i < D; ++i)
+                            if (i == S::first_axis(kf)) w1bar[i][t][r] += G[pg * C + 1 + kf][t][r];
+                }
+        if (NHH == 0) wg_barrier();                                         // UP reuse across tiles when there is no layer barrier
+    }  // tiles
+
+    if (!BWD) return;
+    // =========================== epilogue ===========================
+    if (cur_term >= 0 && MODE == MODE_FUSED && w == 0)
+        ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[cur_term].term_id] = wave_sum_d(lsum, g0);
+    float* slab = ga.slabs + (size_t)blk * S::SLAB;
+    PINN_UNROLL for (int hl = 0; hl < NHH; ++hl)
+        PINN_UNROLL for (int t = 0; t < MTW; ++t)
+            PINN_UNROLL for (int ti = 0; ti < MT; ++ti)
+                gstore4(slab + S::O_WBAR, vint((((hl * MT + w * MTW + t) * MT + ti) * 64) * 4) + (lane << 2), wbar[hl][t][ti]);
+    const vbool c0 = veq(c, 0);
+    auto reduce_cols = [&](vfloat v) -> vfloat {       // sum over the 16 column lanes of a row group
+        v = v + shfl_xor(v, 1);
+        v = v + shfl_xor(v, 2);
+        v = v + shfl_xor(v, 4);
+        v = v + shfl_xor(v, 8);
+        return v;
+    };
+    PINN_UNROLL for (int t = 0; t < MTW; ++t)
+        PINN_UNROLL for (int r = 0; r < 4; ++r) {
+            const vint n = vint(16 * (w * MTW + t) + r) + (g << 2);          // natural neuron index
+            PINN_UNROLL for (int l = 0; l < LH; ++l) gstore_masked(slab + S::O_BH + l * HP, n, reduce_cols(bbar[l][t][r]), c0);
+            PINN_UNROLL for (int i = 0; i < D; ++i) gstore_masked(slab + S::O_W1 + i * HP, n, reduce_cols(w1bar[i][t][r]), c0);
+            gstore_masked(slab + S::O_WL, n, reduce_cols(wLbar[t][r]), c0);
+        }
+    if (w == 0) {
+        vbool all = vlt(lane, 64);
+        float s = (float)wave_sum_d(bLbar, all);
+        gstore_masked(slab + S::O_BL, vint(0), vfloat(s), veq(lane, 0));
+        PINN_UNROLL for (int j = 0; j < MAX_PARAMS; ++j) {
+            float sp = (float)wave_sum_d(pbar[j], all);
+            gstore_masked(slab + S::O_P, vint(j), vfloat(sp), veq(lane, 0));
+        }
+    }
+}
+
+}  // namespace pk

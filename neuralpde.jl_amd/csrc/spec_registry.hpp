@@ -6,11 +6,14 @@
 #include <vector>
 
 #include "pinn_kernels.hpp"
+#include "pinn_kernels2.hpp"
 #include "plat.hpp"
 
 namespace pk {
 
 struct SpecInfo {
+    int family;                      // 1: one wave per tile (pinn_kernels.hpp); 2: neuron-split workgroups (pinn_kernels2.hpp)
+    int WG_PER_CU;
     int HP, NHH, D;
     unsigned D1MASK;
     unsigned long long PAIRS;
@@ -26,12 +29,27 @@ std::vector<SpecInfo>& registry();
 template <class S>
 SpecInfo make_info(void (*launch)(const GroupArgs&, int, int, plat_stream)) {
     SpecInfo s;
+    s.family = 1; s.WG_PER_CU = 1;
     s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR;
     s.PG = S::PG; s.C = S::C; s.NG = S::NG; s.TP = S::TP; s.MT = S::MT; s.LH = S::LH; s.NFIRST = S::NFIRST;
     s.PACKED = S::PACKED; s.SLAB = S::SLAB; s.SCR = S::SCR; s.LDS_WG = S::LDS_WG; s.COOP = S::COOP ? 1 : 0; s.SH = S::SH; s.PW = S::PW;
     s.OFF_W1 = S::OFF_W1; s.OFF_B = S::OFF_B; s.OFF_WL = S::OFF_WL; s.OFF_BL = S::OFF_BL;
     s.OFF_WPK = S::OFF_WPK; s.OFF_WTPK = S::OFF_WTPK;
     s.O_WBAR = S::O_WBAR; s.O_BFRH = S::O_BFRH; s.O_BFR0 = S::O_BFR0; s.O_W1 = S::O_W1; s.O_WL = S::O_WL; s.O_BL = S::O_BL; s.O_P = S::O_P;
+    s.launch = launch;
+    return s;
+}
+
+template <class S>
+SpecInfo make_info2(void (*launch)(const GroupArgs&, int, int, plat_stream)) {
+    SpecInfo s;
+    s.family = 2; s.WG_PER_CU = S::WG_PER_CU;
+    s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR;
+    s.PG = S::PG; s.C = S::C; s.NG = S::NG; s.TP = S::TP; s.MT = S::MT; s.LH = S::LH; s.NFIRST = S::NFIRST;
+    s.PACKED = S::PACKED; s.SLAB = S::SLAB; s.SCR = S::SCR; s.LDS_WG = S::LDS_WG; s.COOP = 1; s.SH = S::SLAB; s.PW = 0;
+    s.OFF_W1 = S::OFF_W1; s.OFF_B = S::OFF_B; s.OFF_WL = S::OFF_WL; s.OFF_BL = S::OFF_BL;
+    s.OFF_WPK = S::OFF_WPK; s.OFF_WTPK = S::OFF_WTPK;
+    s.O_WBAR = S::O_WBAR; s.O_BFRH = S::O_BH; s.O_BFR0 = S::O_BH; s.O_W1 = S::O_W1; s.O_WL = S::O_WL; s.O_BL = S::O_BL; s.O_P = S::O_P;
     s.launch = launch;
     return s;
 }
@@ -67,6 +85,29 @@ void run_emu(const GroupArgs& ga, int blocks) {
         for (int w = 0; w < 4; ++w) th[w].join();
     }
 }
+template <class S, int MODE>
+void run_emu2(const GroupArgs& ga, int blocks) {
+    std::vector<float> lds((size_t)S::LDS_WG);
+    for (int b = 0; b < blocks; ++b) {
+        for (auto& v : lds) v = std::nanf("");       // poison: nothing may be read before it is written
+        EmuBarrier bar;
+        std::thread th[4];
+        for (int w = 0; w < 4; ++w)
+            th[w] = std::thread([&, w] {
+                wv::emu_barrier_hook = &EmuBarrier::wait;
+                wv::emu_barrier_ctx = &bar;
+                wave_main2<S, MODE>(ga, b, blocks, w, lds.data());
+            });
+        for (int w = 0; w < 4; ++w) th[w].join();
+    }
+}
+template <class S>
+void launch_spec2(const GroupArgs& ga, int mode, int blocks, plat_stream) {
+    if (mode == MODE_FUSED) run_emu2<S, MODE_FUSED>(ga, blocks);
+    else if (mode == MODE_RESID) run_emu2<S, MODE_RESID>(ga, blocks);
+    else if (mode == MODE_GRADIN) run_emu2<S, MODE_GRADIN>(ga, blocks);
+    else run_emu2<S, MODE_FWD>(ga, blocks);
+}
 template <class S>
 void launch_spec(const GroupArgs& ga, int mode, int blocks, plat_stream) {
     if (mode == MODE_FUSED) run_emu<S, MODE_FUSED>(ga, blocks);
@@ -84,6 +125,20 @@ __global__ void __launch_bounds__(256, 1) k_wave(const GroupArgs ga) {
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     wave_main<S, MODE>(ga, (int)blockIdx.x, (int)gridDim.x, w, lds_all);
 }
+// family 2: __launch_bounds__(256, 2) => at most 256 VGPR+AGPR per lane, two workgroups (8 waves) resident per CU
+template <class S, int MODE>
+__global__ void __launch_bounds__(256, 2) k_wave2(const GroupArgs ga) {
+    __shared__ __attribute__((aligned(16))) float lds_all[S::LDS_WG];
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    wave_main2<S, MODE>(ga, (int)blockIdx.x, (int)gridDim.x, w, lds_all);
+}
+template <class S>
+void launch_spec2(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
+    if (mode == MODE_FUSED) hipLaunchKernelGGL((k_wave2<S, MODE_FUSED>), dim3(blocks), dim3(256), 0, st, ga);
+    else if (mode == MODE_RESID) hipLaunchKernelGGL((k_wave2<S, MODE_RESID>), dim3(blocks), dim3(256), 0, st, ga);
+    else if (mode == MODE_GRADIN) hipLaunchKernelGGL((k_wave2<S, MODE_GRADIN>), dim3(blocks), dim3(256), 0, st, ga);
+    else hipLaunchKernelGGL((k_wave2<S, MODE_FWD>), dim3(blocks), dim3(256), 0, st, ga);
+}
 template <class S>
 void launch_spec(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
     if (mode == MODE_FUSED) hipLaunchKernelGGL((k_wave<S, MODE_FUSED>), dim3(blocks), dim3(256), 0, st, ga);
@@ -99,6 +154,12 @@ struct Registrar {
 
 // PAIRS encoding: pair p occupies byte p: low nibble = axis a, high nibble = axis b (a <= b)
 #define PINN_PAIR(p, a, b) (((unsigned long long)((a) | ((b) << 4))) << (8 * (p)))
+
+#define PINN_INSTANTIATE2(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG)                        \
+    namespace {                                                                              \
+    using NAME##_spec2 = pk::Spec2<HP, NHH, D, D1MASK, PAIRS, NPAIR, PG>;                    \
+    pk::Registrar NAME##_reg2(pk::make_info2<NAME##_spec2>(&pk::launch_spec2<NAME##_spec2>)); \
+    }
 
 #define PINN_INSTANTIATE(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG)                         \
     namespace {                                                                              \

@@ -76,10 +76,16 @@ inline void gstore(float* p, const vint& i, const vfloat& x) { for (int l = 0; l
 inline void gstore_masked(float* p, const vint& i, const vfloat& x, const vbool& m) { for (int l = 0; l < W; ++l) if (m.v[l]) p[i.v[l]] = x.v[l]; }
 inline vfloat4 gload4(const float* p, const vint& i) { vfloat4 r; for (int k = 0; k < 4; ++k) for (int l = 0; l < W; ++l) r.x[k].v[l] = p[i.v[l] + k]; return r; }
 inline void gstore4(float* p, const vint& i, const vfloat4& x) { for (int k = 0; k < 4; ++k) for (int l = 0; l < W; ++l) p[i.v[l] + k] = x.x[k].v[l]; }
+// 32-row register tape with a wave-uniform dynamic row index (device: VGPR-index mode, s_set_gpr_idx_on)
+struct vtape { vfloat r[32]; };
+inline vfloat tape_get(const vtape& t, int i) { return t.r[i]; }
+inline void tape_set(vtape& t, int i, const vfloat& x) { t.r[i] = x; }
+inline void tape_zero(vtape& t) { for (int i = 0; i < 32; ++i) t.r[i] = vfloat(0.f); }
 // uniform-base buffer view (device: buffer descriptor in SGPRs + scalar offset + per-lane voffset)
 struct ubuf { float* p; };
 inline ubuf ub_make(const float* p, size_t) { return ubuf{const_cast<float*>(p)}; }
 inline vfloat4 ub_load4(const ubuf& b, int soff, const vint& voff) { vfloat4 r; for (int k = 0; k < 4; ++k) for (int l = 0; l < W; ++l) r.x[k].v[l] = b.p[soff + voff.v[l] + k]; return r; }
+inline vfloat4 ub_load4_sc1(const ubuf& b, int soff, const vint& voff) { return ub_load4(b, soff, voff); }
 inline void ub_store4(const ubuf& b, int soff, const vint& voff, const vfloat4& x) { for (int k = 0; k < 4; ++k) for (int l = 0; l < W; ++l) b.p[soff + voff.v[l] + k] = x.x[k].v[l]; }
 inline vfloat ub_load(const ubuf& b, int soff, const vint& voff) { vfloat r; for (int l = 0; l < W; ++l) r.v[l] = b.p[soff + voff.v[l]]; return r; }
 // LDS (per-wave private region in the emulation == a plain array)
@@ -163,6 +169,12 @@ DEV void gstore4(float* p, vint i, vfloat4 x) { *reinterpret_cast<vfloat4*>(p + 
 // of the form base[const + f(lane)] inside the tile loop: with flat `global_*` the compiler materialises one 64-bit VGPR
 // address per distinct constant (>4 KB apart), hoists hundreds of them out of the loop and spills them
 // (cdna_hip_programming.md T8/T20).  `p` must be wave-uniform.
+// 32-row tape in vector registers; a wave-uniform runtime row index compiles to VGPR-index mode
+// (s_set_gpr_idx_on), not to scratch or LDS.
+typedef float vtape __attribute__((ext_vector_type(32)));
+DEV vfloat tape_get(const vtape& t, int i) { return t[i]; }
+DEV void tape_set(vtape& t, int i, vfloat x) { t[i] = x; }
+DEV void tape_zero(vtape& t) { PINN_UNROLL for (int i = 0; i < 32; ++i) t[i] = 0.f; }
 struct ubuf { __amdgpu_buffer_rsrc_t r; };
 typedef unsigned vuint4 __attribute__((ext_vector_type(4)));
 DEV ubuf ub_make(const float* p, size_t nfloats) {
@@ -170,6 +182,10 @@ DEV ubuf ub_make(const float* p, size_t nfloats) {
 }
 DEV vfloat4 ub_load4(ubuf b, int soff, vint voff) {
     return __builtin_bit_cast(vfloat4, __builtin_amdgcn_raw_buffer_load_b128(b.r, voff * 4, soff * 4, 0));
+}
+// L1-bypassing (sc1) variant for data another wave / an earlier phase may have rewritten
+DEV vfloat4 ub_load4_sc1(ubuf b, int soff, vint voff) {
+    return __builtin_bit_cast(vfloat4, __builtin_amdgcn_raw_buffer_load_b128(b.r, voff * 4, soff * 4, 16));
 }
 DEV void ub_store4(ubuf b, int soff, vint voff, vfloat4 x) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vuint4, x), b.r, voff * 4, soff * 4, 0);
