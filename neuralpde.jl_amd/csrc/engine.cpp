@@ -233,6 +233,7 @@ int round_hp(int h) {
     if (h <= 16) return 16;
     if (h <= 32) return 32;
     if (h <= 64) return 64;
+    if (h <= 128) return 128;
     return ((h + 15) / 16) * 16;
 }
 

@@ -1,0 +1,7 @@
+// family 2, 128-wide nets (BASELINE config 4: 2-D, 5x128): two neuron tiles per wave, dW accumulated in the slab
+#include "spec_registry.hpp"
+PINN_INSTANTIATE2(f2_h128n4d2_lap, 128, 4, 2, 0x3, (PINN_PAIR(0, 0, 0) | PINN_PAIR(1, 1, 1)), 2, 1)
+PINN_INSTANTIATE2(f2_h128n4d2_val, 128, 4, 2, 0x0, 0ull, 0, 4)
+// 2 hidden layers of 128: unit tests
+PINN_INSTANTIATE2(f2_h128n1d2_lap, 128, 1, 2, 0x3, (PINN_PAIR(0, 0, 0) | PINN_PAIR(1, 1, 1)), 2, 1)
+PINN_INSTANTIATE2(f2_h128n1d2_val, 128, 1, 2, 0x0, 0ull, 0, 4)

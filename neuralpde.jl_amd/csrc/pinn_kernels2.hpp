@@ -65,6 +65,9 @@ struct Spec2 {
     static constexpr int LDS_UP = ((4 * NG * 16 + 63) / 64) * 64;
     static constexpr int LDS_WG = 3 * XSZ + LDS_UP;
     static constexpr int WG_PER_CU = (LDS_WG * 4 <= 80 * 1024) ? 2 : 1;
+    // dW accumulators: resident in registers across tiles when they fit (4x64: 48 registers); for wide/deep nets they
+    // are accumulated per tile into this workgroup's slab instead (read-modify-write, L2; same wave owns the same tiles)
+    static constexpr bool WBAR_REG = (NHH_ * MTW * MT * 4 <= 96);
 };
 
 template <class S, int MODE>
@@ -87,15 +90,21 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
     float* UP = lds + 3 * S::XSZ;                             // output-layer partial sums [wave][q][16]
 
     // ---- persistent gradient accumulators of this wave's neuron tiles ----
-    vfloat4 wbar[NHH > 0 ? NHH : 1][MTW][MT];
+    vfloat4 wbar[(S::WBAR_REG && NHH > 0) ? NHH : 1][MTW][MT];
+    float* slab = ga.slabs + (size_t)blk * S::SLAB;
     vfloat4 bbar[LH][MTW];
     vfloat4 w1bar[D][MTW];
     vfloat4 wLbar[MTW];
     vfloat bLbar = vfloat(0.f);
     vfloat pbar[MAX_PARAMS];
-    PINN_UNROLL for (int l = 0; l < (NHH > 0 ? NHH : 1); ++l)
+    PINN_UNROLL for (int l = 0; l < ((S::WBAR_REG && NHH > 0) ? NHH : 1); ++l)
         PINN_UNROLL for (int t = 0; t < MTW; ++t)
             PINN_UNROLL for (int ti = 0; ti < MT; ++ti) wbar[l][t][ti] = vzero4();
+    if (!S::WBAR_REG && BWD)                 // slab-resident dW: this wave's tiles start at zero
+        for (int hl = 0; hl < NHH; ++hl)
+            PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                PINN_UNROLL for (int ti = 0; ti < MT; ++ti)
+                    gstore4(slab + S::O_WBAR, vint((((hl * MT + w * MTW + t) * MT + ti) * 64) * 4) + (lane << 2), vzero4());
     PINN_UNROLL for (int l = 0; l < LH; ++l)
         PINN_UNROLL for (int t = 0; t < MTW; ++t) bbar[l][t] = vzero4();
     PINN_UNROLL for (int i = 0; i < D; ++i)
@@ -392,6 +401,10 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                 }
             wg_barrier();
             // ---- dW[own rows][all inputs] += dZ A^T ----
+            vfloat4 wacc[S::WBAR_REG ? 1 : MTW][S::WBAR_REG ? 1 : MT];
+            if (!S::WBAR_REG)
+                PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                    PINN_UNROLL for (int ti = 0; ti < MT; ++ti) wacc[t][ti] = vzero4();
             PINN_UNROLL for (int q = 0; q < NG; ++q)
                 PINN_UNROLL for (int kk = 0; kk < 4; ++kk) {
                     const vint row = vint(4 * kk) + g;
@@ -402,9 +415,20 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         const vint slot = vint(16 * hb) + c;
                         vfloat4 a4 = lds_load4(X1, vint(q * 16 * HP) + row * HP + (((slot ^ row) & vint(4 * MT - 1)) << 2));
                         PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                            PINN_UNROLL for (int e = 0; e < 4; ++e) wbar[hl][t][hb * 4 + e] = mfma16(zf[t], a4[e], wbar[hl][t][hb * 4 + e]);
+                            PINN_UNROLL for (int e = 0; e < 4; ++e) {
+                                if (S::WBAR_REG) wbar[hl][t][hb * 4 + e] = mfma16(zf[t], a4[e], wbar[hl][t][hb * 4 + e]);
+                                else wacc[t][hb * 4 + e] = mfma16(zf[t], a4[e], wacc[t][hb * 4 + e]);
+                            }
                     }
                 }
+            if (!S::WBAR_REG)
+                PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                    PINN_UNROLL for (int ti = 0; ti < MT; ++ti) {
+                        const vint off = vint((((hl * MT + w * MTW + t) * MT + ti) * 64) * 4) + (lane << 2);
+                        vfloat4 cur = gload4(slab + S::O_WBAR, off);
+                        PINN_UNROLL for (int e = 0; e < 4; ++e) cur[e] += wacc[t][ti][e];
+                        gstore4(slab + S::O_WBAR, off, cur);
+                    }
             // ---- dA (own input tiles) = W^T dZ ----
             vfloat4 Gn[NG][MTW];
             PINN_UNROLL for (int q = 0; q < NG; ++q)
@@ -442,11 +466,11 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
     // =========================== epilogue ===========================
     if (cur_term >= 0 && MODE == MODE_FUSED && w == 0)
         ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[cur_term].term_id] = wave_sum_d(lsum, g0);
-    float* slab = ga.slabs + (size_t)blk * S::SLAB;
-    PINN_UNROLL for (int hl = 0; hl < NHH; ++hl)
-        PINN_UNROLL for (int t = 0; t < MTW; ++t)
-            PINN_UNROLL for (int ti = 0; ti < MT; ++ti)
-                gstore4(slab + S::O_WBAR, vint((((hl * MT + w * MTW + t) * MT + ti) * 64) * 4) + (lane << 2), wbar[hl][t][ti]);
+    if (S::WBAR_REG)
+        PINN_UNROLL for (int hl = 0; hl < NHH; ++hl)
+            PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                PINN_UNROLL for (int ti = 0; ti < MT; ++ti)
+                    gstore4(slab + S::O_WBAR, vint((((hl * MT + w * MTW + t) * MT + ti) * 64) * 4) + (lane << 2), wbar[hl][t][ti]);
     const vbool c0 = veq(c, 0);
     auto reduce_cols = [&](vfloat v) -> vfloat {       // sum over the 16 column lanes of a row group
         v = v + shfl_xor(v, 1);

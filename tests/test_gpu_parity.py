@@ -148,11 +148,12 @@ def test_param_estim_4x64(npde, hip_lib):
     assert abs(grad[-1] - ref.grad[-1]) < TOL * abs(ref.grad[-1])          # dL/dk itself
 
 
-def test_cfg4_cavity_coupled_three_nets_reduced_width(npde, hip_lib):
-    """BASELINE config 4 (lid-driven cavity, three coupled networks, bc weights 10) at the widths this round's kernels
-    cover: 3 x (4x64) instead of 3 x (5x128) — 128-wide layers are a next-round kernel."""
+@pytest.mark.parametrize("width,hidden", [(64, 4), (128, 5)])
+def test_cfg4_cavity_coupled_three_nets(npde, hip_lib, width, hidden):
+    """BASELINE config 4 (lid-driven cavity, three coupled networks u, v, p, bc weights 10): 3 x (5x128) as stated in
+    BASELINE.json, and 3 x (4x64); reduced point counts so the float64 oracle finishes in seconds."""
     from neuralpde_jl_amd import workloads
-    wl = workloads.cfg4_cavity(points=3000, bcs_points=400, width=64, hidden=4)
+    wl = workloads.cfg4_cavity(points=3000, bcs_points=400, width=width, hidden=hidden)
     rep = npde.symbolic_discretize(wl.pde_system, wl.discretization())
     assert "coupled" in rep.engine.describe()
     sets = rep.pde_train_sets + rep.bcs_train_sets
