@@ -63,7 +63,14 @@ struct Spec2 {
     // LDS (floats): X0 | X1 (activation / dZ exchange, A^T) | ZT (4 x private dZ^T) | output partials | coords
     static constexpr int XSZ = NG * MT * 256;
     static constexpr int LDS_UP = ((4 * NG * 16 + 63) / 64) * 64;
-    static constexpr int LDS_WG = 3 * XSZ + LDS_UP;
+    // when X0 | X1 | ZT would not fit in 160 KiB (H = 128 with 8 jet channels) the dW operands are staged one column group
+    // at a time in a double buffer carved out of X1: [A^T chunk 16 x HP | 4 x dZ^T chunk]
+    static constexpr bool CHUNKED = (3 * XSZ + LDS_UP) * 4 > 160 * 1024;
+    static constexpr int CH_AT = 16 * HP_;
+    static constexpr int CH_ZT = MTW * 256;
+    static constexpr int CHSZ = CH_AT + 4 * CH_ZT;
+    static_assert(!CHUNKED || 2 * CHSZ <= XSZ, "chunk double buffer must fit inside X1");
+    static constexpr int LDS_WG = (CHUNKED ? 2 : 3) * XSZ + LDS_UP;
     static constexpr int WG_PER_CU = (LDS_WG * 4 <= 80 * 1024) ? 2 : 1;
     // dW accumulators: resident in registers across tiles when they fit (4x64: 48 registers); for wide/deep nets they
     // are accumulated per tile into this workgroup's slab instead (read-modify-write, L2; same wave owns the same tiles)
@@ -87,7 +94,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
     float* X0 = lds;
     float* X1 = lds + S::XSZ;
     float* ZT = lds + 2 * S::XSZ + w * (NG * MTW * 256);      // wave-private dZ^T: [q][t][16 columns][16 neurons]
-    float* UP = lds + 3 * S::XSZ;                             // output-layer partial sums [wave][q][16]
+    float* UP = lds + (S::CHUNKED ? 2 : 3) * S::XSZ;          // output-layer partial sums [wave][q][16]
 
     // ---- persistent gradient accumulators of this wave's neuron tiles ----
     vfloat4 wbar[(S::WBAR_REG && NHH > 0) ? NHH : 1][MTW][MT];
@@ -391,29 +398,28 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                 PINN_UNROLL for (int t = 0; t < MTW; ++t)
                     PINN_UNROLL for (int r = 0; r < 4; ++r) bbar[hl + 1][t][r] += G[pg * C][t][r];
             publish(X0, G);                                                  // dZ in B-fragment order for dA = W^T dZ
-            PINN_UNROLL for (int q = 0; q < NG; ++q)
+            // stage column group q: dZ^T (wave private, [t][column][16 neurons]) and A^T (cooperative, [column][HP]), slot-swizzled
+            auto stage_q = [&](int q, float* zt, float* at) {
                 PINN_UNROLL for (int t = 0; t < MTW; ++t) {
-                    // dZ^T, wave private: [q][t][column][16 neurons], slot-swizzled
-                    lds_store4(ZT, vint(((q * MTW + t) * 16) * 16) + c * 16 + ((g ^ (c & vint(3))) << 2), G[q][t]);
-                    // A^T, cooperative: X1[q][column][HP], slot-swizzled (tr_addr of family 1)
+                    lds_store4(zt, vint((t * 16) * 16) + c * 16 + ((g ^ (c & vint(3))) << 2), G[q][t]);
                     const vint slot = vint(4 * (w * MTW + t)) + g;
-                    lds_store4(X1, vint(q * 16 * HP) + c * HP + (((slot ^ c) & vint(4 * MT - 1)) << 2), ajet(Sr, q / C, q % C, t));
+                    lds_store4(at, c * HP + (((slot ^ c) & vint(4 * MT - 1)) << 2), ajet(Sr, q / C, q % C, t));
                 }
-            wg_barrier();
-            // ---- dW[own rows][all inputs] += dZ A^T ----
+            };
             vfloat4 wacc[S::WBAR_REG ? 1 : MTW][S::WBAR_REG ? 1 : MT];
             if (!S::WBAR_REG)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t)
                     PINN_UNROLL for (int ti = 0; ti < MT; ++ti) wacc[t][ti] = vzero4();
-            PINN_UNROLL for (int q = 0; q < NG; ++q)
+            // dW[own rows][all inputs] += dZ A^T for one column group
+            auto dw_q = [&](const float* zt, const float* at) {
                 PINN_UNROLL for (int kk = 0; kk < 4; ++kk) {
                     const vint row = vint(4 * kk) + g;
                     vfloat zf[MTW];
                     PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                        zf[t] = lds_load(ZT, vint(((q * MTW + t) * 16) * 16) + row * 16 + (((c >> 2) ^ (row & vint(3))) << 2) + (c & vint(3)));
+                        zf[t] = lds_load(zt, vint((t * 16) * 16) + row * 16 + (((c >> 2) ^ (row & vint(3))) << 2) + (c & vint(3)));
                     PINN_UNROLL for (int hb = 0; hb < MT / 4; ++hb) {
                         const vint slot = vint(16 * hb) + c;
-                        vfloat4 a4 = lds_load4(X1, vint(q * 16 * HP) + row * HP + (((slot ^ row) & vint(4 * MT - 1)) << 2));
+                        vfloat4 a4 = lds_load4(at, row * HP + (((slot ^ row) & vint(4 * MT - 1)) << 2));
                         PINN_UNROLL for (int t = 0; t < MTW; ++t)
                             PINN_UNROLL for (int e = 0; e < 4; ++e) {
                                 if (S::WBAR_REG) wbar[hl][t][hb * 4 + e] = mfma16(zf[t], a4[e], wbar[hl][t][hb * 4 + e]);
@@ -421,6 +427,19 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                             }
                     }
                 }
+            };
+            if (S::CHUNKED) {
+                PINN_UNROLL for (int q = 0; q < NG; ++q) {
+                    float* cb = X1 + (q & 1) * S::CHSZ;
+                    stage_q(q, cb + S::CH_AT + w * S::CH_ZT, cb);
+                    wg_barrier();                                           // chunk q complete; chunk q-1's buffer is free again
+                    dw_q(cb + S::CH_AT + w * S::CH_ZT, cb);
+                }
+            } else {
+                PINN_UNROLL for (int q = 0; q < NG; ++q) stage_q(q, ZT + q * (MTW * 256), X1 + q * 16 * HP);
+                wg_barrier();
+                PINN_UNROLL for (int q = 0; q < NG; ++q) dw_q(ZT + q * (MTW * 256), X1 + q * 16 * HP);
+            }
             if (!S::WBAR_REG)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t)
                     PINN_UNROLL for (int ti = 0; ti < MT; ++ti) {

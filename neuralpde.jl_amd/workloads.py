@@ -126,4 +126,29 @@ def cfg4_cavity(points: int = 262144, bcs_points: int = 32768, width: int = 128,
                     adaptive_loss=NonAdaptiveLoss(pde_loss_weights=1.0, bc_loss_weights=10.0), n_interior=points)
 
 
-CONFIGS = {"cfg1": cfg1_poisson1d, "cfg2": cfg2_poisson2d, "cfg3": cfg3_burgers, "cfg4": cfg4_cavity}
+def cfg5_heat_inverse(points: int = 1000000, bcs_points: int = 65536, width: int = 128, hidden: int = 6, seed: int = 1005,
+                      dtype=np.float64) -> Workload:
+    """3-D heat equation inverse problem u_t = kappa (u_xx + u_yy + u_zz) on (t,x,y,z) in [0,1]^4 with kappa estimated
+    (param_estim = true, initial 1.0; SURVEY.md N2: the reference expresses it as PhysicsInformedNN(...; param_estim) +
+    StochasticTraining, docs/src/tutorials/param_estim.md:97-102), IC u(0,x,y,z) = sin(pi x) sin(pi y) sin(pi z), six
+    homogeneous wall conditions; 6x128 tanh MLP; StochasticTraining(points; bcs_points) redrawn on every call.
+    The data-misfit term of the reference set-up is a host-side `additional_loss` and is not part of this workload."""
+    t, x, y, z = parameters("t x y z")
+    (u,) = variables("u")
+    (kappa,) = parameters("kappa")
+    Dt = Differential(t)
+    Dxx, Dyy, Dzz = Differential(x) ** 2, Differential(y) ** 2, Differential(z) ** 2
+    U = u(t, x, y, z)
+    eq = Eq(Dt(U), kappa * (Dxx(U) + Dyy(U) + Dzz(U)))
+    bcs = [Eq(u(0, x, y, z), sp.sin(sp.pi * x) * sp.sin(sp.pi * y) * sp.sin(sp.pi * z)),
+           Eq(u(t, 0, y, z), 0.0), Eq(u(t, 1, y, z), 0.0), Eq(u(t, x, 0, z), 0.0), Eq(u(t, x, 1, z), 0.0),
+           Eq(u(t, x, y, 0), 0.0), Eq(u(t, x, y, 1), 0.0)]
+    dom = [In(v, Interval(0.0, 1.0)) for v in (t, x, y, z)]
+    sysm = PDESystem([eq], bcs, dom, [t, x, y, z], [U], ps=[kappa], defaults={kappa: 1.0})
+    chain = mlp(4, width, hidden)
+    strat = StochasticTraining(points, bcs_points=bcs_points, rng=np.random.default_rng(seed))
+    return Workload(f"cfg5_heat_inverse_{hidden}x{width}_stochastic", sysm, [chain], strat, synthetic_theta([chain], seed, dtype=dtype),
+                    param_estim=True, n_interior=points)
+
+
+CONFIGS = {"cfg1": cfg1_poisson1d, "cfg2": cfg2_poisson2d, "cfg3": cfg3_burgers, "cfg4": cfg4_cavity, "cfg5": cfg5_heat_inverse}

@@ -181,3 +181,23 @@ def test_coupled_system_of_pdes(npde, use_emu):
     chains = [npde.Chain(npde.Dense(2, 16, "tanh"), npde.Dense(16, 16, "tanh"), npde.Dense(16, 1)) for _ in range(2)]
     theta = np.concatenate([theta_for(c, 41 + i) for i, c in enumerate(chains)])
     check(npde, sysm, chains, strat, theta, param_estim=True)
+
+
+def test_wide_nets_family2(npde, use_emu):
+    """Neuron-split kernel family: 4x64 (register-resident dW), 2x128 with 5 jet channels, 5x128 (slab-resident dW) and the
+    4-D config-5 shape (8 jet channels, chunked dW staging, estimated PDE parameter) at 2x128."""
+    from neuralpde_jl_amd import workloads
+    for wl in (workloads.cfg2_poisson2d(points=40, bcs_points=70, width=128, hidden=2),
+               workloads.cfg2_poisson2d(points=20, bcs_points=70, width=100, hidden=5),
+               workloads.cfg5_heat_inverse(points=40, bcs_points=70, width=128, hidden=2)):
+        rep = npde.symbolic_discretize(wl.pde_system, wl.discretization())
+        assert "F2_HP128" in rep.engine.describe()
+        th = rep.flat_init_params
+        sets = rep._state["pde_sets"] + rep._state["bc_sets"]
+        for k, sset in enumerate(sets):
+            rep.engine.set_points(k, sset)
+        losses, grad = rep.engine.loss_grad(th)
+        prob = helpers.oracle_problem(npde, wl.pde_system, wl.chains, param_estim=wl.param_estim)
+        ref = po.loss_and_grad(prob, th, sets, mode="stencil")
+        le, g2, gi = helpers.rel_errors(losses, grad, ref)
+        assert le.max() < TOL and g2 < TOL and gi < TOL, (wl.name, le, g2, gi)

@@ -166,3 +166,25 @@ def test_cfg4_cavity_coupled_three_nets(npde, hip_lib, width, hidden):
     assert le.max() < TOL and g2 < TOL and gi < TOL, (le, g2, gi)
     l2, gr2 = rep.engine.loss_grad(wl.theta, w)
     assert np.array_equal(l2, losses) and np.array_equal(gr2, grad)
+
+
+def test_cfg5_heat_inverse_6x128(npde, hip_lib):
+    """BASELINE config 5 (3-D heat inverse problem, 6x128 MLP, 4 inputs, 8 jet channels, kappa estimated, stochastic points)
+    at a reduced point count; the stochastic sets drawn by the strategy are the ones handed to the oracle."""
+    from neuralpde_jl_amd import workloads
+    wl = workloads.cfg5_heat_inverse(points=4000, bcs_points=500)
+    rep = npde.symbolic_discretize(wl.pde_system, wl.discretization())
+    th = rep.flat_init_params
+    assert th.size == wl.chains[0].nparams + 1
+    sets = rep._state["pde_sets"] + rep._state["bc_sets"]
+    for k, sset in enumerate(sets):
+        rep.engine.set_points(k, sset)
+    losses, grad = rep.engine.loss_grad(th)
+    ref = po.loss_and_grad(helpers.oracle_problem(npde, wl.pde_system, wl.chains, param_estim=True), th, sets, mode="stencil")
+    le, g2, gi = helpers.rel_errors(losses, grad, ref)
+    assert le.max() < TOL and g2 < TOL and gi < TOL, (le, g2, gi)
+    assert abs(grad[-1] - ref.grad[-1]) < TOL * abs(ref.grad[-1])
+    # the strategy redraws on every full_loss_function call (training_strategies.jl:277-281)
+    f1 = rep.loss_functions.full_loss_function(th)
+    f2 = rep.loss_functions.full_loss_function(th)
+    assert np.isfinite(f1) and f1 != f2
