@@ -94,6 +94,22 @@ int pinn_residual(pinn_handle h, int term, const float* theta, int64_t p, float*
 /* Trial function phi(x, theta) of one net (src/pinn_types.jl:88-90): pts = d x n point-major, out = n floats. */
 int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float* pts, int64_t n, float* out);
 
+/*
+ * Resident-theta training loop: theta, the Adam moments and the collocation sets stay in HBM; no
+ * per-iteration PCIe traffic.  Mirrors `solve(prob, Adam(lr); maxiters)` ([3P] OptimizationOptimisers, used by every
+ * reference test, e.g. test/NNPDE1/nnpde__pde_ii_2d_poisson.jl:83) on the objective of pinn_loss_grad.
+ *   pinn_set_sampler : kind 1 = redraw the term's points uniformly in [lb, ub] on the device before every step
+ *                      (StochasticTraining, src/training_strategies.jl:242-245, 277-281); kind 0 = keep the installed set.
+ *   pinn_adam_init   : upload theta (P floats), zero the moments.
+ *   pinn_adam_steps  : nsteps updates m = b1 m + (1-b1) g, v = b2 v + (1-b2) g^2, theta -= lr m^/(sqrt(v^) + eps);
+ *                      loss_history (nullable) receives the weighted total loss of every step.
+ *   pinn_adam_get    : download theta.
+ */
+int pinn_set_sampler(pinn_handle h, int term, int kind, const float* lb, const float* ub, int64_t n, uint64_t seed);
+int pinn_adam_init(pinn_handle h, const float* theta, int64_t p);
+int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta2, float eps, const float* term_w, double* loss_history);
+int pinn_adam_get(pinn_handle h, float* theta, int64_t p);
+
 /* Timing of the last pinn_loss_grad*: HIP-event milliseconds of the fused residual kernels / of the whole device section. */
 int pinn_last_timing(pinn_handle h, float* kernel_ms, float* total_ms);
 /* Kernel plan: number of launch groups (terms that share one fused kernel) and the HIP-event duration of group g's

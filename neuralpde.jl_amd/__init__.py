@@ -10,7 +10,7 @@ See DESIGN.md for the kernel design and INTEGRATION.md for the Julia `ccall` bin
 from . import _lib
 from ._lib import Engine, EngineError, Library
 from .ir import Instr, NetIR, ProblemIR, Slot, TermIR
-from .pinn import (Chain, Dense, LogOptions, NonAdaptiveLoss, OptimizationFunction, OptimizationProblem, Phi,
+from .pinn import (Adam, OptimizationSolution, solve, Chain, Dense, LogOptions, NonAdaptiveLoss, OptimizationFunction, OptimizationProblem, Phi,
                    PhysicsInformedNN, PINNLossFunctions, PINNRepresentation, discretize, initialparameters, remake,
                    symbolic_discretize)
 from .strategies import (AbstractTrainingStrategy, GridTraining, LatinHypercubeSample, QuasiRandomTraining,

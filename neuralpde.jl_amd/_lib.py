@@ -20,6 +20,7 @@ SYMBOLS = [
     "pinn_backend", "pinn_abi_version", "pinn_last_error", "pinn_create", "pinn_destroy", "pinn_num_terms",
     "pinn_num_theta", "pinn_set_points", "pinn_set_points_device", "pinn_loss_grad", "pinn_loss_grad_f64",
     "pinn_term_grads", "pinn_loss_grad_device", "pinn_residual", "pinn_phi", "pinn_last_timing", "pinn_describe", "pinn_num_groups", "pinn_group_timing",
+    "pinn_set_sampler", "pinn_adam_init", "pinn_adam_steps", "pinn_adam_get",
 ]
 
 
@@ -58,6 +59,10 @@ class Library:
         L.pinn_last_timing.argtypes = [vp, fp, fp]
         L.pinn_describe.argtypes = [vp, C.c_char_p, C.c_int64]
         L.pinn_num_groups.argtypes = [vp]
+        L.pinn_set_sampler.argtypes = [vp, C.c_int, C.c_int, fp, fp, C.c_int64, C.c_uint64]
+        L.pinn_adam_init.argtypes = [vp, fp, C.c_int64]
+        L.pinn_adam_steps.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, fp, dp]
+        L.pinn_adam_get.argtypes = [vp, fp, C.c_int64]
         L.pinn_group_timing.argtypes = [vp, C.c_int, fp, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
 
     @property
@@ -183,6 +188,25 @@ class Engine:
         k, t = C.c_float(), C.c_float()
         self.L.check(self.L.lib.pinn_last_timing(self.h, C.byref(k), C.byref(t)), "pinn_last_timing")
         return k.value, t.value
+
+    def set_sampler(self, term: int, lb, ub, n: int, seed: int = 0, kind: int = 1):
+        lb, ub = _f32(lb), _f32(ub)
+        self.L.check(self.L.lib.pinn_set_sampler(self.h, term, kind, lb.ctypes.data_as(C.POINTER(C.c_float)),
+                                                 ub.ctypes.data_as(C.POINTER(C.c_float)), n, seed), "pinn_set_sampler")
+
+    def adam(self, theta, nsteps: int, lr: float, weights=None, beta1=0.9, beta2=0.999, eps=1e-8, init=True):
+        """`nsteps` Adam iterations with theta resident on the device; returns (theta, loss history)."""
+        th = _f32(theta)
+        if init:
+            self.L.check(self.L.lib.pinn_adam_init(self.h, th.ctypes.data_as(C.POINTER(C.c_float)), th.size), "pinn_adam_init")
+        hist = np.zeros(nsteps, dtype=np.float64)
+        w = _f32(weights) if weights is not None else None
+        self.L.check(self.L.lib.pinn_adam_steps(self.h, nsteps, lr, beta1, beta2, eps,
+                                                w.ctypes.data_as(C.POINTER(C.c_float)) if w is not None else None,
+                                                hist.ctypes.data_as(C.POINTER(C.c_double))), "pinn_adam_steps")
+        out = np.zeros(self.P, dtype=np.float32)
+        self.L.check(self.L.lib.pinn_adam_get(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), out.size), "pinn_adam_get")
+        return out, hist
 
     def group_timings(self):
         out = []

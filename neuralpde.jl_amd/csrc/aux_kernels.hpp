@@ -94,6 +94,36 @@ AUX_DEV float expr_point(int p, const ExprArgs& a, float (&pb)[4]) {
     return r;
 }
 
+// ---- resident-theta training loop ----
+// Adam exactly as [3P] Optimisers.Adam: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; theta -= lr * (m/(1-b1^t)) / (sqrt(v/(1-b2^t)) + eps)
+AUX_DEV void adam_body(int i, float* theta, float* m, float* v, const float* grad, float lr, float b1, float b2, float eps, float c1, float c2) {
+    const float g = grad[i];
+    const float mi = b1 * m[i] + (1.0f - b1) * g;
+    const float vi = b2 * v[i] + (1.0f - b2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    theta[i] -= lr * (mi * c1) / (sqrtf(vi * c2) + eps);      // c1 = 1/(1-b1^t), c2 = 1/(1-b2^t)
+}
+// total weighted loss of one evaluation from the raw per-term sums in out[P..P+K)
+AUX_DEV void total_loss_body(double* hist, int step, const float* out, int P, int K, const float* w_over_n) {
+    double s = 0.0;
+    for (int k = 0; k < K; ++k) s += (double)out[P + k] * (double)w_over_n[k];
+    hist[step] = s;
+}
+// counter-based uniform sampler (StochasticTraining's rand(T, d, N) .* (ub .- lb) .+ lb, src/training_strategies.jl:242-245):
+// value = hash(seed, draw counter, element index) -> [0, 1)
+AUX_DEV unsigned mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+AUX_DEV void sample_body(int e, float* pts, int d, const float* lb, const float* ub, unsigned seed, unsigned draw) {
+    const int i = e % d;
+    unsigned h = mix32((unsigned)e * 0x9E3779B9U + seed);
+    h = mix32(h ^ (draw * 0x85EBCA6BU + 0xC2B2AE35U));
+    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+    pts[e] = lb[i] + (ub[i] - lb[i]) * u;
+}
+
 AUX_DEV void pack_body(int i, float* packed, const int* idx, const float* theta) {
     const int j = idx[i];
     packed[i] = (j >= 0) ? theta[j] : 0.f;
@@ -146,6 +176,15 @@ inline void launch_pack(float* packed, const int* idx, const float* theta, int n
 inline void launch_params(float* params, const float* theta, const float* defaults, int np, int ne, int p_off, plat_stream) {
     for (int j = 0; j < np; ++j) params_body(j, params, theta, defaults, ne, p_off);
 }
+inline void launch_adam(float* theta, float* m, float* v, const float* grad, int P, float lr, float b1, float b2, float eps, float c1, float c2, plat_stream) {
+    for (int i = 0; i < P; ++i) adam_body(i, theta, m, v, grad, lr, b1, b2, eps, c1, c2);
+}
+inline void launch_total_loss(double* hist, int step, const float* out, int P, int K, const float* w_over_n, plat_stream) {
+    total_loss_body(hist, step, out, P, K, w_over_n);
+}
+inline void launch_sample(float* pts, int n_elems, int d, const float* lb, const float* ub, unsigned seed, unsigned draw, plat_stream) {
+    for (int e = 0; e < n_elems; ++e) sample_body(e, pts, d, lb, ub, seed, draw);
+}
 inline void launch_expr(const ExprArgs& a, int nblocks, plat_stream) {
     for (int b = 0; b < nblocks; ++b)
         for (int w = 0; w < 4; ++w) {
@@ -179,6 +218,26 @@ __global__ void k_pack(float* packed, const int* idx, const float* theta, int n)
 __global__ void k_params(float* params, const float* theta, const float* defaults, int np, int ne, int p_off) {
     const int j = threadIdx.x;
     if (j < np) params_body(j, params, theta, defaults, ne, p_off);
+}
+__global__ void k_adam(float* theta, float* m, float* v, const float* grad, int P, float lr, float b1, float b2, float eps, float c1, float c2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P) adam_body(i, theta, m, v, grad, lr, b1, b2, eps, c1, c2);
+}
+__global__ void k_total_loss(double* hist, int step, const float* out, int P, int K, const float* w_over_n) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) total_loss_body(hist, step, out, P, K, w_over_n);
+}
+__global__ void k_sample(float* pts, int n_elems, int d, const float* lb, const float* ub, unsigned seed, unsigned draw) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_elems) sample_body(e, pts, d, lb, ub, seed, draw);
+}
+inline void launch_adam(float* theta, float* m, float* v, const float* grad, int P, float lr, float b1, float b2, float eps, float c1, float c2, plat_stream st) {
+    hipLaunchKernelGGL(k_adam, dim3((P + 255) / 256), dim3(256), 0, st, theta, m, v, grad, P, lr, b1, b2, eps, c1, c2);
+}
+inline void launch_total_loss(double* hist, int step, const float* out, int P, int K, const float* w_over_n, plat_stream st) {
+    hipLaunchKernelGGL(k_total_loss, dim3(1), dim3(64), 0, st, hist, step, out, P, K, w_over_n);
+}
+inline void launch_sample(float* pts, int n_elems, int d, const float* lb, const float* ub, unsigned seed, unsigned draw, plat_stream st) {
+    hipLaunchKernelGGL(k_sample, dim3((n_elems + 255) / 256), dim3(256), 0, st, pts, n_elems, d, lb, ub, seed, draw);
 }
 __global__ void __launch_bounds__(256) k_expr(const ExprArgs a) {
     __shared__ double sh[5][256];

@@ -34,7 +34,7 @@ std::vector<SpecInfo>& registry() {
 
 namespace {
 
-constexpr int REDUCE_SPLIT = 8;      // stage-1 chunks of the fixed-order slab reduction
+constexpr int REDUCE_SPLIT = 32;     // stage-1 chunks of the fixed-order slab reduction
 
 thread_local std::string g_err;
 int fail(const std::string& m) {
@@ -78,6 +78,11 @@ struct Term {
     int64_t n = 0, n_norm = 0;
     float* d_resid = nullptr;
     int64_t resid_cap = 0;
+    // on-device sampler (StochasticTraining): kind 0 = fixed set, 1 = uniform redraw before every training step
+    int sampler = 0;
+    float* d_lb = nullptr;
+    float* d_ub = nullptr;
+    unsigned seed = 0, draws = 0;
 };
 struct Group {
     int kind = 0;                    // 0: fused (single-network terms); 1: per-network FWD/GRADIN launches of coupled terms
@@ -148,6 +153,15 @@ struct pinn_engine {
     plat_event ev0, ev1, ev2, ev3;
     float last_kernel_ms = 0.f, last_total_ms = 0.f;
     bool timing_valid = false;
+    // resident-theta Adam state
+    float* d_opt_theta = nullptr;
+    float* d_opt_m = nullptr;
+    float* d_opt_v = nullptr;
+    float* d_opt_out = nullptr;      // [P + K]
+    float* d_w_over_n = nullptr;     // [K]
+    double* d_hist = nullptr;
+    int hist_cap = 0;
+    long long opt_t = 0;
     // phi scratch
     float* d_phi_pts = nullptr;
     float* d_phi_out = nullptr;
@@ -855,7 +869,8 @@ int pinn_destroy(pinn_handle h) {
     if (!h) return 0;
     pinn_engine& E = *h;
     plat_sync(E.stream);
-    for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_resid); }
+    for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_resid); plat_free(T.d_lb); plat_free(T.d_ub); }
+    plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist);
     for (auto& G : E.groups) {
         plat_free(G.d_prog); plat_free(G.d_slabs); plat_free(G.d_losspart); plat_free(G.d_scratch);
         plat_free(G.d_tmp);
@@ -1076,6 +1091,92 @@ int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float*
     const int blocks = std::max(1, std::min(E.ncu, (ga.ntiles + 3) / 4));
     sp->launch(ga, pk::MODE_FWD, blocks, E.stream);
     if (plat_d2h(out, E.d_phi_out, sizeof(float) * n, E.stream)) return fail("D2H copy failed");
+    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    return 0;
+}
+
+int pinn_set_sampler(pinn_handle h, int term, int kind, const float* lb, const float* ub, int64_t n, uint64_t seed) {
+    if (!h) return fail("null handle");
+    pinn_engine& E = *h;
+    if (term < 0 || term >= (int)E.terms.size()) return fail("pinn_set_sampler: term index out of range");
+    Term& T = E.terms[term];
+    if (kind != 0 && kind != 1) return fail("pinn_set_sampler: kind must be 0 (fixed set) or 1 (uniform)");
+    T.sampler = kind;
+    if (kind == 0) return 0;
+    if (!lb || !ub || n <= 0) return fail("pinn_set_sampler: bounds and a positive point count are required");
+    if (!T.d_lb) { T.d_lb = (float*)plat_malloc(sizeof(float) * 8); T.d_ub = (float*)plat_malloc(sizeof(float) * 8); }
+    if (!T.d_lb || !T.d_ub) return fail("device allocation failed (sampler)");
+    plat_h2d(T.d_lb, lb, sizeof(float) * T.d, E.stream);
+    plat_h2d(T.d_ub, ub, sizeof(float) * T.d, E.stream);
+    T.seed = (unsigned)(seed ^ (seed >> 32)) + 0x9E3779B9U * (unsigned)(term + 1);
+    T.draws = 0;
+    // allocate / size the term's point buffer through the normal path with a first draw
+    std::vector<float> tmp((size_t)n * T.d, 0.f);
+    if (set_points_impl(h, term, tmp.data(), n, 0, false)) return 1;
+    aux::launch_sample(T.d_pts, (int)(n * T.d), T.d, T.d_lb, T.d_ub, T.seed, T.draws++, E.stream);
+    plat_sync(E.stream);
+    return 0;
+}
+
+int pinn_adam_init(pinn_handle h, const float* theta, int64_t p) {
+    if (!h || !theta) return fail("pinn_adam_init: null argument");
+    pinn_engine& E = *h;
+    if (p != E.ntheta) return fail("pinn_adam_init: theta length mismatch");
+    const int K = (int)E.terms.size();
+    if (!E.d_opt_theta) {
+        E.d_opt_theta = (float*)plat_malloc(sizeof(float) * p);
+        E.d_opt_m = (float*)plat_malloc(sizeof(float) * p);
+        E.d_opt_v = (float*)plat_malloc(sizeof(float) * p);
+        E.d_opt_out = (float*)plat_malloc(sizeof(float) * (p + K));
+        E.d_w_over_n = (float*)plat_malloc(sizeof(float) * K);
+        if (!E.d_opt_theta || !E.d_opt_m || !E.d_opt_v || !E.d_opt_out || !E.d_w_over_n) return fail("device allocation failed (optimiser state)");
+    }
+    plat_h2d(E.d_opt_theta, theta, sizeof(float) * p, E.stream);
+    plat_memset(E.d_opt_m, 0, sizeof(float) * p, E.stream);
+    plat_memset(E.d_opt_v, 0, sizeof(float) * p, E.stream);
+    plat_sync(E.stream);
+    E.opt_t = 0;
+    return 0;
+}
+
+int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta2, float eps, const float* term_w, double* loss_history) {
+    if (!h) return fail("null handle");
+    pinn_engine& E = *h;
+    if (!E.d_opt_theta) return fail("pinn_adam_steps: call pinn_adam_init first");
+    if (nsteps <= 0) return fail("pinn_adam_steps: nsteps must be positive");
+    if (ensure_points(E)) return 1;
+    const int K = (int)E.terms.size(), P = (int)E.ntheta;
+    if (E.hist_cap < nsteps) {
+        plat_free(E.d_hist);
+        E.d_hist = (double*)plat_malloc(sizeof(double) * nsteps);
+        E.hist_cap = nsteps;
+        if (!E.d_hist) return fail("device allocation failed (loss history)");
+    }
+    std::vector<float> wn(K);
+    for (int k = 0; k < K; ++k) wn[k] = (term_w ? term_w[k] : 1.0f) / (float)E.terms[k].n_norm;
+    plat_h2d(E.d_w_over_n, wn.data(), sizeof(float) * K, E.stream);
+    for (int s = 0; s < nsteps; ++s) {
+        for (size_t t = 0; t < E.terms.size(); ++t) {            // resampling strategies: fresh points every evaluation, on device
+            Term& T = E.terms[t];
+            if (T.sampler == 1) aux::launch_sample(T.d_pts, (int)(T.n * T.d), T.d, T.d_lb, T.d_ub, T.seed, T.draws++, E.stream);
+        }
+        if (run_loss_grad(E, E.d_opt_theta, E.d_opt_out, term_w, -1, false)) return 1;
+        aux::launch_total_loss(E.d_hist, s, E.d_opt_out, P, K, E.d_w_over_n, E.stream);
+        ++E.opt_t;
+        const float c1 = (float)(1.0 / (1.0 - std::pow((double)beta1, (double)E.opt_t)));
+        const float c2 = (float)(1.0 / (1.0 - std::pow((double)beta2, (double)E.opt_t)));
+        aux::launch_adam(E.d_opt_theta, E.d_opt_m, E.d_opt_v, E.d_opt_out, P, lr, beta1, beta2, eps, c1, c2, E.stream);
+    }
+    if (loss_history && plat_d2h(loss_history, E.d_hist, sizeof(double) * nsteps, E.stream)) return fail("D2H copy failed");
+    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    return 0;
+}
+
+int pinn_adam_get(pinn_handle h, float* theta, int64_t p) {
+    if (!h || !theta) return fail("pinn_adam_get: null argument");
+    pinn_engine& E = *h;
+    if (!E.d_opt_theta || p != E.ntheta) return fail("pinn_adam_get: no optimiser state / length mismatch");
+    if (plat_d2h(theta, E.d_opt_theta, sizeof(float) * p, E.stream)) return fail("D2H copy failed");
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
     return 0;
 }

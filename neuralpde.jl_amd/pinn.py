@@ -204,6 +204,53 @@ class OptimizationProblem:
     p: object = None
 
 
+@dataclass
+class Adam:
+    """[3P] Optimisers.Adam(eta, (beta1, beta2), eps)."""
+    eta: float = 0.001
+    beta: tuple = (0.9, 0.999)
+    epsilon: float = 1e-8
+
+
+@dataclass
+class OptimizationSolution:
+    u: np.ndarray
+    objective: float
+    losses: np.ndarray
+
+
+def solve(prob: OptimizationProblem, alg: Adam, maxiters: int = 1000, callback: Optional[Callable] = None) -> OptimizationSolution:
+    """`solve(prob, Adam(eta); maxiters, callback)` ([3P] Optimization.jl, test/NNPDE1/nnpde__pde_ii_2d_poisson.jl:83-85) on
+    the engine's resident-theta Adam loop (pinn_adam_steps).  StochasticTraining redraws its points on the device before
+    every step; fixed sets stay installed.  Without a callback the whole loop runs without host synchronisation; with a
+    callback `(state, loss) -> stop::Bool` it runs in chunks of 50 steps."""
+    rep = prob.pinnrep
+    if rep.additional_loss is not None:
+        raise NotImplementedError("solve(): additional_loss is a host-side term; use prob.f.value_and_grad in a host loop")
+    eng = rep.engine
+    eng_resample = getattr(rep, "_device_samplers", None)
+    if eng_resample:
+        for k, (lb, ub, n, seed) in eng_resample.items():
+            eng.set_sampler(k, lb, ub, n, seed)
+    elif rep._state.get("resample") is not None:
+        raise NotImplementedError("solve(): only StochasticTraining has an on-device sampler; use resampling=False designs "
+                                  "or a host loop over prob.f.value_and_grad")
+    theta, losses, done, init = np.asarray(prob.u0, dtype=np.float64), [], 0, True
+    chunk = maxiters if callback is None else 50
+    th32 = theta.astype(np.float32)
+    while done < maxiters:
+        n = min(chunk, maxiters - done)
+        th32, hist = eng.adam(th32, n, alg.eta, rep._weights, alg.beta[0], alg.beta[1], alg.epsilon, init=init)
+        init = False
+        losses.append(hist)
+        done += n
+        if callback is not None and callback({"iter": done, "u": th32.astype(np.float64)}, float(hist[-1])):
+            break
+    losses = np.concatenate(losses)
+    rep.iteration[0] += done
+    return OptimizationSolution(th32.astype(prob.u0.dtype), float(losses[-1]), losses)
+
+
 def remake(prob: OptimizationProblem, u0=None) -> OptimizationProblem:
     """`remake(prob, u0 = res.u)` — the reference's resume idiom (test/NNPDE1/nnpde__pde_ii_2d_poisson.jl:84-85)."""
     return OptimizationProblem(prob.f, prob.u0 if u0 is None else np.asarray(u0), prob.p)
@@ -296,7 +343,7 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
             engine.set_points(k, s)
 
     install(pde_sets, bc_sets)
-    state = {"pde_sets": pde_sets, "bc_sets": bc_sets, "cache_theta": None, "cache": None}
+    state = {"pde_sets": pde_sets, "bc_sets": bc_sets, "cache_theta": None, "cache": None, "resample": resample}
 
     adaloss = discretization.adaptive_loss or NonAdaptiveLoss()
     if not isinstance(adaloss, NonAdaptiveLoss):
@@ -386,6 +433,14 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
         datafree_bc_loss_functions=[datafree(n_pde + j) for j in range(n_bc)])
     rep._value_and_grad = value_and_grad
     rep._weights = weights
+    # StochasticTraining has an on-device counterpart (uniform redraw in the same bounds) for the resident-theta loop
+    from .strategies import StochasticTraining, get_bounds
+    rep._device_samplers = None
+    if isinstance(strategy, StochasticTraining):
+        pb, bb = get_bounds(pde_system.domain, eqs, bcs, np.float64, vi, strategy.points)
+        rep._device_samplers = {}
+        for k, (lb, ub) in enumerate(list(pb) + list(bb)):
+            rep._device_samplers[k] = (lb, ub, strategy.points if k < n_pde else strategy.bcs_points, int(strategy.rng.integers(1 << 31)))
     rep._state = state
     return rep
 

@@ -201,3 +201,39 @@ def test_wide_nets_family2(npde, use_emu):
         ref = po.loss_and_grad(prob, th, sets, mode="stencil")
         le, g2, gi = helpers.rel_errors(losses, grad, ref)
         assert le.max() < TOL and g2 < TOL and gi < TOL, (wl.name, le, g2, gi)
+
+
+def test_resident_adam_matches_host_adam_and_sampler(npde, use_emu):
+    """Resident-theta Adam (pinn_adam_steps) == a host Adam loop over the engine's own gradients ([3P] Optimisers.Adam
+    update rule); the on-device uniform sampler stays inside the StochasticTraining bounds and changes every step."""
+    sysm, chain = poisson2d(npde)
+    th0 = theta_for(chain, 51)
+    disc = npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=th0,
+                                  adaptive_loss=npde.NonAdaptiveLoss(pde_loss_weights=1.0, bc_loss_weights=[2.0, 1.0, 3.0, 1.0]))
+    prob = npde.discretize(sysm, disc)
+    res = npde.solve(prob, npde.Adam(0.01), maxiters=25)
+    th, m_, v_, hist = prob.u0.astype(np.float32).copy(), 0.0, 0.0, []
+    for it in range(1, 26):
+        val, g = prob.f.value_and_grad(th)
+        hist.append(val)
+        g = g.astype(np.float32)
+        m_ = np.float32(0.9) * m_ + np.float32(0.1) * g
+        v_ = np.float32(0.999) * v_ + np.float32(0.001) * g * g
+        th = (th - np.float32(0.01) * (m_ / np.float32(1 - 0.9 ** it)) / (np.sqrt(v_ / np.float32(1 - 0.999 ** it)) + np.float32(1e-8))).astype(np.float32)
+    np.testing.assert_allclose(res.losses, hist, rtol=2e-5)
+    assert np.max(np.abs(res.u - th)) < 5e-5
+    assert res.losses[-1] < res.losses[0]
+    # callback protocol: stop after the first chunk
+    calls = []
+    res2 = npde.solve(prob, npde.Adam(0.01), maxiters=200, callback=lambda st, l: calls.append(st["iter"]) or True)
+    assert calls == [50] and len(res2.losses) == 50
+    # StochasticTraining -> on-device sampler
+    disc = npde.PhysicsInformedNN(chain, npde.StochasticTraining(64, bcs_points=32, rng=np.random.default_rng(3)), init_params=th0)
+    prob = npde.discretize(sysm, disc)
+    res = npde.solve(prob, npde.Adam(0.01), maxiters=6)
+    assert np.all(np.isfinite(res.losses)) and len(set(np.round(res.losses, 12))) == 6
+    rep = prob.pinnrep
+    lb, ub, n, seed = rep._device_samplers[1]
+    assert lb[0] == ub[0] == 0.0 and n == 32          # bc u(0, y): x pinned to 0, y in [1/64, 1 - 1/64]
+    r = rep.engine.residual(1, res.u, 32)              # runs on the device-sampled set
+    assert r.shape == (32,) and np.all(np.isfinite(r))

@@ -188,3 +188,29 @@ def test_cfg5_heat_inverse_6x128(npde, hip_lib):
     f1 = rep.loss_functions.full_loss_function(th)
     f2 = rep.loss_functions.full_loss_function(th)
     assert np.isfinite(f1) and f1 != f2
+
+
+def test_training_converges_resident_adam(npde, hip_lib):
+    """End-to-end check in the style of the reference's NNPDE1 integration tests (test/NNPDE1/nnpde__pde_ii_2d_poisson.jl:
+    59-101: train, then compare phi with the analytic solution sin(pi x) sin(pi y) / (2 pi^2)) on the resident-theta Adam
+    loop: loss and solution error must drop."""
+    import sympy as sp
+    x, y = npde.parameters("x y")
+    (u,) = npde.variables("u")
+    Dxx, Dyy = npde.Differential(x) ** 2, npde.Differential(y) ** 2
+    eq = npde.Eq(Dxx(u(x, y)) + Dyy(u(x, y)), -sp.sin(sp.pi * x) * sp.sin(sp.pi * y))
+    bcs = [npde.Eq(u(0, y), 0.0), npde.Eq(u(1, y), 0.0), npde.Eq(u(x, 0), 0.0), npde.Eq(u(x, 1), 0.0)]
+    dom = [npde.In(x, npde.Interval(0.0, 1.0)), npde.In(y, npde.Interval(0.0, 1.0))]
+    sysm = npde.PDESystem([eq], bcs, dom, [x, y], [u(x, y)])
+    chain = npde.Chain(npde.Dense(2, 16, "tanh"), npde.Dense(16, 16, "tanh"), npde.Dense(16, 1))
+    th0 = npde.initialparameters(np.random.default_rng(0), chain)
+    strat = npde.QuasiRandomTraining(2048, bcs_points=256, sampling_alg=npde.SobolSample(seed=1), resampling=False, minibatch=1)
+    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th0))
+    res = npde.solve(prob, npde.Adam(0.01), maxiters=3000)
+    xs = np.linspace(0, 1, 21)
+    grid = np.array([[a, b] for a in xs for b in xs]).T
+    analytic = np.sin(np.pi * grid[0]) * np.sin(np.pi * grid[1]) / (2 * np.pi ** 2)
+    err0 = np.max(np.abs(prob.pinnrep.phi(grid, prob.u0)[0] - analytic))
+    err1 = np.max(np.abs(prob.pinnrep.phi(grid, res.u)[0] - analytic))
+    print("loss", res.losses[0], "->", res.losses[-1], "max error", err0, "->", err1)
+    assert res.losses[-1] < res.losses[0] / 50 and err1 < 0.02 and err1 < err0 / 3
