@@ -87,13 +87,8 @@ class LogOptions:
     log_frequency: int = 50
 
 
-@dataclass
-class NonAdaptiveLoss:
-    """NonAdaptiveLoss(; pde_loss_weights = 1, bc_loss_weights = 1, additional_loss_weights = 1) —
-    src/adaptive_losses.jl:22-42; scalars are broadcast to the number of terms (src/discretize.jl:553-559)."""
-    pde_loss_weights: object = 1.0
-    bc_loss_weights: object = 1.0
-    additional_loss_weights: object = 1.0
+from .adaptive import (AbstractAdaptiveLoss, GradientScaleAdaptiveLoss, MiniMaxAdaptiveLoss, NonAdaptiveLoss,  # noqa: E402
+                       ReLoBRaLoAdaptiveLoss, SoftAdaptAdaptiveLoss)
 
 
 class PhysicsInformedNN:
@@ -236,14 +231,24 @@ def solve(prob: OptimizationProblem, alg: Adam, maxiters: int = 1000, callback: 
         raise NotImplementedError("solve(): only StochasticTraining has an on-device sampler; use resampling=False designs "
                                   "or a host loop over prob.f.value_and_grad")
     theta, losses, done, init = np.asarray(prob.u0, dtype=np.float64), [], 0, True
+    ada = rep.adaloss
+    n_pde = len(rep.eqs)
     chunk = maxiters if callback is None else 50
+    if ada.reweight_every > 0:                     # adaptive weights: reweight on the host between chunks of device steps
+        chunk = min(chunk, ada.reweight_every)
     th32 = theta.astype(np.float32)
     while done < maxiters:
         n = min(chunk, maxiters - done)
-        th32, hist = eng.adam(th32, n, alg.eta, rep._weights, alg.beta[0], alg.beta[1], alg.epsilon, init=init)
+        if ada.reweight_every > 0:                 # end the chunk where the iteration counter hits a multiple of reweight_every
+            it = rep.iteration[0] + done
+            n = min(n, ada.reweight_every - (it % ada.reweight_every))
+        th32, hist = eng.adam(th32, n, alg.eta, rep._weights_now(), alg.beta[0], alg.beta[1], alg.epsilon, init=init)
         init = False
         losses.append(hist)
         done += n
+        if ada.reweight_every > 0:
+            tl, _ = eng.loss_grad(th32, None, want_grad=False)
+            ada.reweight(th32, tl[:n_pde], tl[n_pde:], rep.iteration[0] + done, term_grads=lambda: eng.term_grads(th32)[1])
         if callback is not None and callback({"iter": done, "u": th32.astype(np.float64)}, float(hist[-1])):
             break
     losses = np.concatenate(losses)
@@ -346,25 +351,26 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
     state = {"pde_sets": pde_sets, "bc_sets": bc_sets, "cache_theta": None, "cache": None, "resample": resample}
 
     adaloss = discretization.adaptive_loss or NonAdaptiveLoss()
-    if not isinstance(adaloss, NonAdaptiveLoss):
-        raise NotImplementedError("only NonAdaptiveLoss weights are wired up in this round; adaptive reweighting "
-                                  "(src/adaptive_losses.jl) consumes pinn_term_grads / per-term losses and stays on the host")
-    w_pde = _broadcast_weights(adaloss.pde_loss_weights, n_pde)
-    w_bc = _broadcast_weights(adaloss.bc_loss_weights, n_bc)
-    weights = np.concatenate([w_pde, w_bc])
+    if not isinstance(adaloss, AbstractAdaptiveLoss):
+        raise TypeError("adaptive_loss must be an AbstractAdaptiveLoss (src/adaptive_losses.jl)")
+    adaloss.broadcast(n_pde, n_bc)                      # scalars -> one weight per term (src/discretize.jl:553-559)
     iteration = discretization.iteration
 
-    def evaluate(theta, want_grad=True):
-        """one fused engine call; memoised on theta so the per-term closures and the full loss share it"""
+    def weights_now():
+        return np.concatenate([adaloss.pde_loss_weights, adaloss.bc_loss_weights]).astype(np.float64)
+
+    def evaluate(theta, want_grad=True, weights=None, redraw=True):
+        """one fused engine call; memoised on (theta, weights) so the per-term closures and the full loss share it"""
         th = np.asarray(theta)
-        key = th.tobytes()
+        w = weights_now() if weights is None else np.asarray(weights, dtype=np.float64)
+        key = (th.tobytes(), w.tobytes())
         if resample is None and state["cache_theta"] == key and (state["cache"][1] is not None or not want_grad):
             return state["cache"]
-        if resample is not None:
+        if resample is not None and redraw:
             ps, bs = resample()
             state["pde_sets"], state["bc_sets"] = ps, bs
             install(ps, bs)
-        losses, grad = engine.loss_grad(th, weights, want_grad=want_grad)
+        losses, grad = engine.loss_grad(th, w, want_grad=want_grad)
         state["cache_theta"], state["cache"] = key, (losses, grad)
         return losses, grad
 
@@ -386,31 +392,42 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
 
     additional_loss = discretization.additional_loss
 
-    def value_and_grad(theta):
-        losses, grad = evaluate(theta, want_grad=True)
-        total = float(np.dot(weights, losses))
-        g = grad.astype(np.asarray(theta).dtype if np.asarray(theta).dtype in (np.float32, np.float64) else np.float64)
-        if additional_loss is not None:
-            add = additional_loss(phi, np.asarray(theta)[:nnet] if param_estim else theta,
-                                  np.asarray(theta)[nnet:] if param_estim else None)
-            if isinstance(add, tuple):
-                total += float(_broadcast_weights(adaloss.additional_loss_weights, 1)[0]) * float(add[0])
-                g = g + float(_broadcast_weights(adaloss.additional_loss_weights, 1)[0]) * np.asarray(add[1])
-            else:
-                total += float(_broadcast_weights(adaloss.additional_loss_weights, 1)[0]) * float(add)
-        return total, g
-
-    def full_loss_function(theta, p=None):
-        """src/discretize.jl:567-598."""
+    def losses_and_reweight(theta):
+        """the part of full_loss_function that runs outside AD (src/discretize.jl:569-580): term losses, iteration
+        counter, adaptive reweighting (which may ask the engine for per-term gradients)"""
         losses, _ = evaluate(theta, want_grad=False)
         if discretization.self_increment:
             iteration[0] += 1
-        total = float(np.dot(weights, losses))
-        if additional_loss is not None:
-            add = additional_loss(phi, np.asarray(theta)[:nnet] if param_estim else theta,
-                                  np.asarray(theta)[nnet:] if param_estim else None)
-            total += float(_broadcast_weights(adaloss.additional_loss_weights, 1)[0]) * float(add[0] if isinstance(add, tuple) else add)
-        return total
+        adaloss.reweight(theta, losses[:n_pde], losses[n_pde:], iteration[0],
+                         term_grads=lambda: engine.term_grads(np.asarray(theta))[1])
+        return losses
+
+    def add_term(theta):
+        if additional_loss is None:
+            return 0.0, None
+        th = np.asarray(theta)
+        add = additional_loss(phi, th[:nnet] if param_estim else theta, th[nnet:] if param_estim else None)
+        wa = float(np.ones(1) * adaloss.additional_loss_weights[0])
+        if isinstance(add, tuple):
+            return wa * float(add[0]), wa * np.asarray(add[1])
+        return wa * float(add), None
+
+    def value_and_grad(theta):
+        losses = losses_and_reweight(theta)
+        w = weights_now()
+        _, grad = evaluate(theta, want_grad=True, weights=w, redraw=False)      # gradient under the (possibly new) weights
+        total = float(np.dot(w, losses))
+        dt = np.asarray(theta).dtype
+        g = grad.astype(dt if dt in (np.float32, np.float64) else np.float64)
+        av, ag = add_term(theta)
+        if ag is not None:
+            g = g + ag
+        return total + av, g
+
+    def full_loss_function(theta, p=None):
+        """src/discretize.jl:567-598."""
+        losses = losses_and_reweight(theta)
+        return float(np.dot(weights_now(), losses)) + add_term(theta)[0]
 
     phis = [Phi(engine, i, slice(net_offs[i], net_offs[i] + chains[i].nparams), chains[i].sizes[0]) for i in range(len(chains))]
     phi = phis if discretization.multioutput else phis[0]
@@ -432,7 +449,8 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
         datafree_pde_loss_functions=[datafree(i) for i in range(n_pde)],
         datafree_bc_loss_functions=[datafree(n_pde + j) for j in range(n_bc)])
     rep._value_and_grad = value_and_grad
-    rep._weights = weights
+    rep._weights_now = weights_now
+    rep._weights = weights_now()
     # StochasticTraining has an on-device counterpart (uniform redraw in the same bounds) for the resident-theta loop
     from .strategies import StochasticTraining, get_bounds
     rep._device_samplers = None

@@ -13,7 +13,8 @@ from typing import List, Optional
 import numpy as np
 import sympy as sp
 
-from .pinn import Chain, Dense, NonAdaptiveLoss, PhysicsInformedNN
+from .adaptive import NonAdaptiveLoss
+from .pinn import Chain, Dense, PhysicsInformedNN
 from .strategies import GridTraining, QuasiRandomTraining, SobolSample, StochasticTraining
 from .symbolic import Differential, Eq, In, Interval, PDESystem, parameters, variables
 

@@ -1,0 +1,71 @@
+"""Adaptive loss weighting (src/adaptive_losses.jl) on top of the engine's per-term losses / gradients (emulation build)."""
+import numpy as np
+
+import helpers
+import pinn_oracle as po
+from test_emu_parity import poisson2d, theta_for
+
+
+def _setup(npde, ada, seed=61):
+    sysm, chain = poisson2d(npde)
+    th0 = theta_for(chain, seed)
+    strat = npde.QuasiRandomTraining(48, bcs_points=20, sampling_alg=npde.SobolSample(seed=2), resampling=False, minibatch=1)
+    disc = npde.PhysicsInformedNN(chain, strat, init_params=th0, adaptive_loss=ada)
+    prob = npde.discretize(sysm, disc)
+    return sysm, chain, prob, th0
+
+
+def test_gradient_scale_matches_reference_rule(npde, use_emu):
+    # src/adaptive_losses.jl:112-131 evaluated with the ORACLE's per-term gradients
+    ada = npde.GradientScaleAdaptiveLoss(1, weight_change_inertia=0.9)
+    sysm, chain, prob, th0 = _setup(npde, ada)
+    rep = prob.pinnrep
+    sets = rep.pde_train_sets + rep.bcs_train_sets
+    ref = po.loss_and_grad(helpers.oracle_problem(npde, sysm, [chain]), th0, sets, mode="stencil", per_term_grads=True)
+    pde_max = np.max(np.abs(ref.term_grads[0]))
+    bc_mean = np.array([np.mean(np.abs(ref.term_grads[1 + j])) for j in range(4)])
+    expected = 0.9 * np.ones(4) + 0.1 * pde_max / (bc_mean + 1e-11)
+    val, g = prob.f.value_and_grad(th0)                      # iteration 1 -> 2, 2 % 1 == 0: reweight fires
+    np.testing.assert_allclose(ada.bc_loss_weights, expected, rtol=1e-5)
+    # objective and gradient use the NEW weights (src/discretize.jl:582-588)
+    w = np.concatenate([[1.0], expected])
+    assert abs(val - np.dot(w, ref.term_losses)) < 1e-5 * abs(val)
+    gref = (w[:, None] * ref.term_grads).sum(axis=0)
+    assert np.linalg.norm(g - gref) / np.linalg.norm(gref) < 1e-5
+
+
+def test_minimax_softadapt_relobralo_rules(npde, use_emu):
+    ada = npde.MiniMaxAdaptiveLoss(1, pde_max_eta=1e-4, bc_max_eta=0.5)
+    sysm, chain, prob, th0 = _setup(npde, ada)
+    losses, _ = prob.pinnrep.engine.loss_grad(th0, None, want_grad=False)
+    prob.f(th0)
+    # first Adam step on the weights with gradient -losses moves every weight up by eta (m^/sqrt(v^) = -1)
+    np.testing.assert_allclose(ada.pde_loss_weights, [1.0 + 1e-4], rtol=1e-9)
+    np.testing.assert_allclose(ada.bc_loss_weights, np.ones(4) + 0.5, rtol=1e-6)
+
+    ada = npde.SoftAdaptAdaptiveLoss(1, alpha=0.1)
+    sysm, chain, prob, th0 = _setup(npde, ada)
+    prob.f(th0)                                               # first call seeds prev = current -> rates 0 -> uniform weights
+    np.testing.assert_allclose(np.concatenate([ada.pde_loss_weights, ada.bc_loss_weights]), np.ones(5), rtol=1e-12)
+    th1 = th0 * 1.05
+    l1, _ = prob.pinnrep.engine.loss_grad(th1, None, want_grad=False)
+    prob.f(th1)
+    rates = (l1 - losses) / (losses + 1e-8)
+    e = np.exp(0.1 * rates - np.max(0.1 * rates))
+    np.testing.assert_allclose(np.concatenate([ada.pde_loss_weights, ada.bc_loss_weights]), e / e.sum() * 5, rtol=1e-6)
+
+    ada = npde.ReLoBRaLoAdaptiveLoss(1, alpha=1.0, beta=0.0)   # beta = 0: always compare with the initial losses
+    sysm, chain, prob, th0 = _setup(npde, ada)
+    prob.f(th0)
+    prob.f(th1)
+    ratios = l1 / (losses + 1e-8)
+    e = np.exp(ratios - np.max(ratios))
+    np.testing.assert_allclose(np.concatenate([ada.pde_loss_weights, ada.bc_loss_weights]), e / e.sum() * 5, rtol=1e-6)
+
+
+def test_adaptive_training_runs_on_device_loop(npde, use_emu):
+    ada = npde.GradientScaleAdaptiveLoss(5)
+    sysm, chain, prob, th0 = _setup(npde, ada)
+    res = npde.solve(prob, npde.Adam(0.01), maxiters=12)
+    assert len(res.losses) == 12 and np.all(np.isfinite(res.losses))
+    assert not np.allclose(ada.bc_loss_weights, 1.0)          # reweighted between the device chunks

@@ -119,7 +119,7 @@ def test_high_level_api_and_resampling(npde, use_emu):
     assert np.isfinite(f1) and f1 != f2                 # StochasticTraining redraws on every call (training_strategies.jl:277-281)
     val, g = prob.f.value_and_grad(prob.u0)
     assert np.isfinite(val) and g.shape == prob.u0.shape and g.dtype == np.float64
-    assert disc.iteration[0] == 3                       # self-incremented by full_loss_function (discretize.jl:574-576)
+    assert disc.iteration[0] == 4                       # self-incremented by every evaluation (discretize.jl:574-576)
     # a few Adam steps on a fixed grid lower the loss (the reference's own convergence-style check, loosely)
     disc = npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=th0)
     prob = npde.discretize(sysm, disc)
