@@ -112,8 +112,13 @@ int pinn_adam_get(pinn_handle h, float* theta, int64_t p);
 
 /* Timing of the last pinn_loss_grad*: HIP-event milliseconds of the fused residual kernels / of the whole device section. */
 int pinn_last_timing(pinn_handle h, float* kernel_ms, float* total_ms);
+/* How many HIP events an evaluation records: level 0 none, 1 a start/stop pair around launch group `group` (-1: every
+ * group), 2 (default) additionally the phase events behind pinn_last_timing.  Every recorded event costs a few us of
+ * dispatch gap between kernels, so latency-critical callers (small per-rank shares) use 0 or 1. */
+int pinn_set_timing(pinn_handle h, int level, int group);
 /* Kernel plan: number of launch groups (terms that share one fused kernel) and the HIP-event duration of group g's
- * fused residual kernel in the last evaluation, with the points / jet channels / wave tiles it processed. */
+ * fused residual kernel in the last evaluation (-1 if that group was not timed, see pinn_set_timing), with the
+ * points / jet channels / wave tiles it processed. */
 int pinn_num_groups(pinn_handle h);
 int pinn_group_timing(pinn_handle h, int group, float* ms, int64_t* points, int* channels, int* tiles);
 /* Introspection used by tests and bench: writes a short human-readable description of the kernel plan. */

@@ -19,7 +19,7 @@ DEFAULT_PATH = os.path.join(_HERE, "csrc", "libpinn_hip.so")
 SYMBOLS = [
     "pinn_backend", "pinn_abi_version", "pinn_last_error", "pinn_create", "pinn_destroy", "pinn_num_terms",
     "pinn_num_theta", "pinn_set_points", "pinn_set_points_device", "pinn_loss_grad", "pinn_loss_grad_f64",
-    "pinn_term_grads", "pinn_loss_grad_device", "pinn_residual", "pinn_phi", "pinn_last_timing", "pinn_describe", "pinn_num_groups", "pinn_group_timing",
+    "pinn_term_grads", "pinn_loss_grad_device", "pinn_residual", "pinn_phi", "pinn_last_timing", "pinn_set_timing", "pinn_describe", "pinn_num_groups", "pinn_group_timing",
     "pinn_set_sampler", "pinn_adam_init", "pinn_adam_steps", "pinn_adam_get",
 ]
 
@@ -57,6 +57,7 @@ class Library:
         L.pinn_residual.argtypes = [vp, C.c_int, fp, C.c_int64, fp]
         L.pinn_phi.argtypes = [vp, C.c_int, fp, C.c_int64, fp, C.c_int64, fp]
         L.pinn_last_timing.argtypes = [vp, fp, fp]
+        L.pinn_set_timing.argtypes = [vp, C.c_int, C.c_int]
         L.pinn_describe.argtypes = [vp, C.c_char_p, C.c_int64]
         L.pinn_num_groups.argtypes = [vp]
         L.pinn_set_sampler.argtypes = [vp, C.c_int, C.c_int, fp, fp, C.c_int64, C.c_uint64]
@@ -183,6 +184,9 @@ class Engine:
                                          flat.ctypes.data_as(C.POINTER(C.c_float)), pts.shape[1],
                                          out.ctypes.data_as(C.POINTER(C.c_float))), "pinn_phi")
         return out
+
+    def set_timing(self, level: int, group: int = -1):
+        self.L.check(self.L.lib.pinn_set_timing(self.h, level, group), "pinn_set_timing")
 
     def last_timing(self):
         k, t = C.c_float(), C.c_float()

@@ -151,8 +151,12 @@ struct pinn_engine {
     float* d_out = nullptr;          // [P grad | K raw sums]
     std::vector<float> h_out;
     plat_event ev0, ev1, ev2, ev3;
+    plat_stream aux_stream[2] = {nullptr, nullptr};     // under-filled launch groups run concurrently (fork/join by events)
+    plat_event ev_fork, ev_join[aux::MAX_GROUPS];
     float last_kernel_ms = 0.f, last_total_ms = 0.f;
     bool timing_valid = false;
+    int timing_level = 2;        // 0: no events, 1: per-launch-group kernel events, 2: + phase events (pinn_last_timing)
+    int timing_group = -1;       // level >= 1: which launch group gets events (-1: all)
     // resident-theta Adam state
     float* d_opt_theta = nullptr;
     float* d_opt_m = nullptr;
@@ -755,9 +759,11 @@ aux::ExprArgs expr_args(pinn_engine& E, Coupled& Cp, float scale, float* resid) 
 int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const float* term_w, int only_term /* -1 = all */, bool timing) {
     if (ensure_points(E)) return 1;
     const int K = (int)E.terms.size();
-    if (timing) plat_event_record(E.ev0, E.stream);
+    const bool phase_ev = timing && E.timing_level >= 2;
+    auto group_ev = [&](size_t g) { return timing && E.timing_level >= 1 && (E.timing_group < 0 || E.timing_group == (int)g); };
+    if (phase_ev) plat_event_record(E.ev0, E.stream);
     pack_all(E, d_theta);
-    if (timing) plat_event_record(E.ev1, E.stream);
+    if (phase_ev) plat_event_record(E.ev1, E.stream);
     aux::Reduce1Args a1;
     aux::Reduce2Args a2;
     std::memset(&a1, 0, sizeof a1);
@@ -768,6 +774,24 @@ int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const floa
         const bool on = (only_term < 0 || only_term == ti);
         return on ? (float)(2.0 * (double)w / (double)E.terms[ti].n_norm) : 0.f;
     };
+    // Fused groups that cannot fill the chip on their own (at most ~1.5 rounds of workgroups, e.g. one rank's share in an
+    // 8-GPU strong-scaling run) are launched concurrently on auxiliary streams; big groups run back to back.
+    int nfused_active = 0;
+    bool all_small = true;
+    for (auto& G : E.groups) {
+        bool on = false;
+        for (int ti : G.terms) on = on || (only_term < 0 || only_term == ti);
+        if (G.kind == 0 && on) {
+            ++nfused_active;
+            const int per_round = G.max_blocks * (G.spec->family == 2 ? 1 : 4);
+            if (2 * G.ga.ntiles > 3 * per_round) all_small = false;
+        }
+    }
+    // opt-in: on this stack a cross-stream event wait costs 15-20 us, more than the overlap buys (profiles/r01 timeline)
+    static const bool want_concurrent = std::getenv("PINN_CONCURRENT_GROUPS") != nullptr;
+    const bool concurrent = want_concurrent && nfused_active >= 2 && all_small;
+    int nforked = 0;
+    if (concurrent) plat_event_record(E.ev_fork, E.stream);
     for (size_t g = 0; g < E.groups.size(); ++g) {
         Group& G = E.groups[g];
         bool any = false;
@@ -781,16 +805,26 @@ int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const floa
         a1.slab[g] = G.spec->SLAB; a1.nblocks[g] = G.blocks; a1.nsplit[g] = nsplit; a1.nent[g] = G.nent; a1.active[g] = any;
         a2.tmp[g] = G.d_tmp; a2.stride[g] = G.nent + K; a2.nsplit[g] = nsplit; a2.nent[g] = G.nent; a2.active[g] = any;
         if (!any) continue;
-        max_n1 = std::max(max_n1, G.nent + K);
+        max_n1 = std::max(max_n1, G.nent / 4 + K);
         max_split = std::max(max_split, nsplit);
         if (G.kind == 1) {               // coupled: forward launch now, reverse launch after k_expr
             G.spec->launch(G.ga, pk::MODE_FWD, G.blocks, E.stream);
             continue;
         }
-        if (timing) plat_event_record(G.ev_a, E.stream);
-        G.spec->launch(G.ga, pk::MODE_FUSED, G.blocks, E.stream);
-        if (timing) plat_event_record(G.ev_b, E.stream);
-        G.timed = timing;
+        plat_stream st = E.stream;
+        const bool forked = concurrent && nforked++ > 0;       // the first fused group stays on the caller's stream
+        if (forked) {
+            st = E.aux_stream[nforked % 2];
+            plat_stream_wait_event(st, E.ev_fork);
+        }
+        if (group_ev(g)) plat_event_record(G.ev_a, st);
+        G.spec->launch(G.ga, pk::MODE_FUSED, G.blocks, st);
+        if (group_ev(g)) plat_event_record(G.ev_b, st);
+        G.timed = group_ev(g);
+        if (forked) {
+            plat_event_record(E.ev_join[g], st);
+            plat_stream_wait_event(E.stream, E.ev_join[g]);
+        }
     }
     for (size_t c = 0; c < E.coupled.size(); ++c) {
         Coupled& Cp = E.coupled[c];
@@ -803,24 +837,24 @@ int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const floa
         bool groups_active = false;
         for (int gi : Cp.groups) groups_active = groups_active || E.groups[gi].active;
         if (!groups_active) continue;
-        max_n1 = std::max(max_n1, 16 + K);
+        max_n1 = std::max(max_n1, 4 + K);
         max_split = std::max(max_split, nsplit);
         aux::launch_expr(expr_args(E, Cp, scale_of(Cp.term), nullptr), Cp.blocks, E.stream);    // scale 0 => zero seeds
     }
     for (size_t g = 0; g < E.groups.size(); ++g) {
         Group& G = E.groups[g];
         if (G.kind != 1 || !G.active) continue;
-        if (timing) plat_event_record(G.ev_a, E.stream);
+        if (group_ev(g)) plat_event_record(G.ev_a, E.stream);
         G.spec->launch(G.ga, pk::MODE_GRADIN, G.blocks, E.stream);
-        if (timing) plat_event_record(G.ev_b, E.stream);
-        G.timed = timing;
+        if (group_ev(g)) plat_event_record(G.ev_b, E.stream);
+        G.timed = group_ev(g);
     }
-    if (timing) plat_event_record(E.ev2, E.stream);
+    if (phase_ev) plat_event_record(E.ev2, E.stream);
     a1.K = K;
     a2.out = d_out; a2.lossraw = E.d_lossraw; a2.row_ptr = E.d_gr_ptr; a2.row_grp = E.d_gr_grp; a2.row_ent = E.d_gr_ent;
     a2.ngroups = (int)(E.groups.size() + E.coupled.size()); a2.P = (int)E.ntheta; a2.K = K;
     aux::launch_reduce(a1, a2, max_n1, max_split, E.stream);
-    if (timing) plat_event_record(E.ev3, E.stream);
+    if (phase_ev) plat_event_record(E.ev3, E.stream);
     return 0;
 }
 
@@ -860,6 +894,9 @@ int pinn_create(const char* descriptor, pinn_handle* out) {
     plat_h2d(E->d_defaults, E->p_defaults.data(), sizeof(float) * pk::MAX_PARAMS, E->stream);
     E->h_out.resize(E->ntheta + K);
     plat_event_create(E->ev0); plat_event_create(E->ev1); plat_event_create(E->ev2); plat_event_create(E->ev3);
+    plat_event_create(E->ev_fork);
+    for (auto& e : E->ev_join) plat_event_create(e);
+    for (auto& st : E->aux_stream) st = plat_stream_create();
     if (build_plan(*E)) { pinn_destroy(E.release()); return 1; }
     *out = E.release();
     return 0;
@@ -885,6 +922,9 @@ int pinn_destroy(pinn_handle h) {
     plat_free(E.d_theta); plat_free(E.d_params); plat_free(E.d_defaults); plat_free(E.d_lossraw); plat_free(E.d_gr_ptr); plat_free(E.d_gr_grp); plat_free(E.d_gr_ent);
     plat_free(E.d_out); plat_free(E.d_phi_pts); plat_free(E.d_phi_out);
     plat_event_destroy(E.ev0); plat_event_destroy(E.ev1); plat_event_destroy(E.ev2); plat_event_destroy(E.ev3);
+    plat_event_destroy(E.ev_fork);
+    for (auto& e : E.ev_join) plat_event_destroy(e);
+    for (auto& st : E.aux_stream) plat_stream_destroy(st);
     if (E.own_stream) plat_stream_destroy(E.stream);
     delete h;
     return 0;
@@ -958,7 +998,7 @@ int pinn_loss_grad(pinn_handle h, const float* theta, int64_t p, const float* te
     std::vector<double> raw(K);
     if (plat_d2h(raw.data(), E.d_lossraw, sizeof(double) * K, E.stream)) return fail("D2H copy failed");
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
-    E.timing_valid = true;
+    E.timing_valid = E.timing_level >= 2;
     if (term_losses)
         for (int k = 0; k < K; ++k) term_losses[k] = raw[k] / (double)E.terms[k].n_norm;
     if (grad) std::memcpy(grad, E.h_out.data(), sizeof(float) * E.ntheta);
@@ -1005,7 +1045,7 @@ int pinn_loss_grad_device(pinn_handle h, const float* d_theta, const float* term
     int rc = run_loss_grad(E, d_theta, d_out, term_w, -1, true);
     E.stream = saved;
     if (rc && g_err.empty()) return fail("pinn_loss_grad_device failed");
-    E.timing_valid = (rc == 0);
+    E.timing_valid = (rc == 0) && E.timing_level >= 2;
     return rc;
 }
 
@@ -1181,6 +1221,16 @@ int pinn_adam_get(pinn_handle h, float* theta, int64_t p) {
     return 0;
 }
 
+int pinn_set_timing(pinn_handle h, int level, int group) {
+    if (!h) return fail("pinn_set_timing: null handle");
+    if (level < 0 || level > 2) return fail("pinn_set_timing: level must be 0, 1 or 2");
+    if (group < -1 || group >= (int)h->groups.size()) return fail("pinn_set_timing: group index out of range");
+    h->timing_level = level; h->timing_group = group;
+    h->timing_valid = false;
+    for (auto& G : h->groups) G.timed = false;
+    return 0;
+}
+
 int pinn_last_timing(pinn_handle h, float* kernel_ms, float* total_ms) {
     if (!h) return fail("null handle");
     if (!h->timing_valid) return fail("no timing available (call pinn_loss_grad first)");
@@ -1196,9 +1246,11 @@ int pinn_group_timing(pinn_handle h, int group, float* ms, int64_t* points, int*
     if (!h) return fail("null handle");
     if (group < 0 || group >= (int)h->groups.size()) return fail("pinn_group_timing: group index out of range");
     Group& G = h->groups[group];
-    if (!G.timed) return fail("no timing available for this group");
-    plat_event_sync(G.ev_b);
-    if (ms) *ms = plat_event_ms(G.ev_a, G.ev_b);
+    if (ms) *ms = -1.f;                   // not timed in the last evaluation (pinn_set_timing)
+    if (G.timed) {
+        plat_event_sync(G.ev_b);
+        if (ms) *ms = plat_event_ms(G.ev_a, G.ev_b);
+    }
     int64_t n = 0;
     for (int t : G.terms) n += h->terms[t].n;
     if (points) *points = n;

@@ -28,6 +28,7 @@ inline void plat_event_destroy(plat_event&) {}
 inline void plat_event_record(plat_event&, plat_stream) {}
 inline float plat_event_ms(plat_event&, plat_event&) { return 0.f; }
 inline void plat_event_sync(plat_event&) {}
+inline void plat_stream_wait_event(plat_stream, plat_event&) {}
 inline const char* plat_last_error() { return ""; }
 #else
 #include <hip/hip_runtime.h>
@@ -68,5 +69,6 @@ inline void plat_event_create(plat_event& e) { (void)hipEventCreate(&e.e); }
 inline void plat_event_destroy(plat_event& e) { (void)hipEventDestroy(e.e); }
 inline void plat_event_record(plat_event& e, plat_stream s) { (void)hipEventRecord(e.e, s); }
 inline void plat_event_sync(plat_event& e) { (void)hipEventSynchronize(e.e); }
+inline void plat_stream_wait_event(plat_stream s, plat_event& e) { (void)hipStreamWaitEvent(s, e.e, 0); }
 inline float plat_event_ms(plat_event& a, plat_event& b) { float ms = 0.f; (void)hipEventElapsedTime(&ms, a.e, b.e); return ms; }
 #endif
