@@ -1242,6 +1242,21 @@ int pinn_last_timing(pinn_handle h, float* kernel_ms, float* total_ms) {
 
 int pinn_num_groups(pinn_handle h) { return h ? (int)h->groups.size() : -1; }
 
+#ifdef PINN_STAMP
+// profiling build only (tools/stamp_profile.sh): raw read-back of one workgroup's gradient slab incl. the stamp tail
+int pinn_debug_slab(pinn_handle h, int group, int blk, float* dst, int64_t n) {
+    if (!h || group < 0 || group >= (int)h->groups.size()) return -1;
+    Group& G = h->groups[group];
+    if (blk < 0) return G.blocks;
+    if (blk == (1 << 30)) return G.spec->SLAB;
+    if (blk >= G.blocks || n > G.spec->SLAB) return -1;
+    plat_sync(h->stream);
+    plat_d2h(dst, G.d_slabs + (size_t)blk * G.spec->SLAB + (G.spec->SLAB - n), sizeof(float) * n, h->stream);
+    plat_sync(h->stream);
+    return 0;
+}
+#endif
+
 int pinn_group_timing(pinn_handle h, int group, float* ms, int64_t* points, int* channels, int* tiles) {
     if (!h) return fail("null handle");
     if (group < 0 || group >= (int)h->groups.size()) return fail("pinn_group_timing: group index out of range");

@@ -412,7 +412,7 @@ Sr[q][m] = ub_load4(SB, (((layer * NG) + q) * MT + m) * 256, lane << 2);
                 for (int j = 0; j < NP; ++j) lds_store(tv, vint((D + j) * 64) + lane, vfloat(ga.params[j]));
                 PINN_UNROLL for (int ch = 0; ch < C; ++ch) lds_store(tv, vint((D + NP + ch) * 64) + lane, U[pg][ch]);
                 for (int q = 0; q < T.nops; ++q) {
-                    const rp::Instr ins = prog[q];
+                    const rp::Instr ins = rp::fetch_uniform(prog, q);
                     vfloat va = rp::is_nullary(ins.code) ? vfloat(0.f) : lds_load(tv, vint(ins.a * 64) + lane);
                     vfloat vb = rp::is_binary(ins.code) ? lds_load(tv, vint(ins.b * 64) + lane) : vfloat(0.f);
                     lds_store(tv, vint((R0 + q) * 64) + lane, rp::apply<vfloat>(ins.code, va, vb, ins.imm));
@@ -429,7 +429,7 @@ Sr[q][m] = ub_load4(SB, (((layer * NG) + q) * MT + m) * 256, lane << 2);
                 for (int q = 0; q < nrows; ++q) lds_store(ta, vint(q * 64) + lane, vfloat(0.f));
                 lds_store(ta, vint(T.out_row * 64) + lane, vfloat(1.0f));
                 for (int q = T.nops - 1; q >= 0; --q) {
-                    const rp::Instr ins = prog[q];
+                    const rp::Instr ins = rp::fetch_uniform(prog, q);
                     if (rp::is_nullary(ins.code)) continue;
                     vfloat gq = lds_load(ta, vint((R0 + q) * 64) + lane);
                     vfloat vo = lds_load(tv, vint((R0 + q) * 64) + lane);

@@ -14,6 +14,18 @@
 #pragma once
 #include "pinn_kernels.hpp"
 
+// Profiling build only (tools/stamp_profile.sh): per-wave cycle counters per phase of a tile, written to the tail of the
+// workgroup's gradient slab (beyond the reduced entries).  Never defined for the product or the emulation library.
+#if defined(PINN_STAMP) && !defined(PINN_EMU)
+#define STAMP_DECL unsigned st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#define STAMP(i) { const unsigned long long st_now = __builtin_amdgcn_s_memtime(); st_acc[i] += (unsigned)(st_now - st_last); st_last = st_now; }
+#define STAMP_EXTRA 64
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_EXTRA 0
+#endif
+
 namespace pk {
 
 template <int HP_, int NHH_, int D_, unsigned D1MASK_, unsigned long long PAIRS_, int NPAIR_, int PG_>
@@ -57,12 +69,13 @@ struct Spec2 {
     static constexpr int O_WL = O_W1 + D_ * HP_;                     // [HP]
     static constexpr int O_BL = O_WL + HP_;
     static constexpr int O_P = O_BL + 1;
-    static constexpr int SLAB = ((O_P + MAX_PARAMS + 63) / 64) * 64;
+    static constexpr int SLAB = ((O_P + MAX_PARAMS + 63) / 64) * 64 + STAMP_EXTRA;
     // per-workgroup record scratch, [layer][q][tile][lane][4]; layer LH-1 stays in registers, layer 0 is recomputed
     static constexpr int SCR = (LH > 2 ? LH - 2 : 1) * NG * MT * 256;      // hidden layers 1 .. LH-2
     // LDS (floats): X0 | X1 (activation / dZ exchange, A^T) | ZT (4 x private dZ^T) | output partials | coords
     static constexpr int XSZ = NG * MT * 256;
-    static constexpr int LDS_UP = ((4 * NG * 16 + 63) / 64) * 64;
+    static constexpr int LDS_UP = ((5 * NG * 16 + 63) / 64) * 64;    // 4 x output partials + seed broadcast (UB)
+    static_assert(PG_ >= 1 && PG_ <= 4, "one tape wave per point group");
     // when X0 | X1 | ZT would not fit in 160 KiB (H = 128 with 8 jet channels) the dW operands are staged one column group
     // at a time in a double buffer carved out of X1: [A^T chunk 16 x HP | 4 x dZ^T chunk]
     static constexpr bool CHUNKED = (3 * XSZ + LDS_UP) * 4 > 160 * 1024;
@@ -129,13 +142,15 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
         for (int j = 0; j < ga.nterms; ++j) ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[j].term_id] = 0.0;
 
     const int niter = (ga.ntiles + nblocks - 1) / nblocks;
+    STAMP_DECL
     for (int it = 0; it < niter; ++it) {
+        STAMP(15)
         const int tix = it * nblocks + blk;                  // >= ntiles: dummy tile (all points masked)
         int k = 0;
         for (int j = 1; j < ga.nterms; ++j)
             if (tix >= ga.terms[j].tile0) k = j;
         if (k != cur_term) {
-            if (cur_term >= 0 && MODE == MODE_FUSED && w == 0)
+            if (cur_term >= 0 && MODE == MODE_FUSED)
                 ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[cur_term].term_id] = wave_sum_d(lsum, g0);
             lsum = vfloat(0.f);
             cur_term = k;
@@ -207,10 +222,12 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
             }
         }
         act_forward(A, 0);
+        STAMP(0)
         PINN_UNROLL for (int hl = 0; hl < NHH; ++hl) {
             float* Xin = (hl & 1) ? X1 : X0;
             publish(Xin, A);
             wg_barrier();                                                   // layer hl activations complete in Xin
+            STAMP(1)
             PINN_UNROLL for (int t = 0; t < MTW; ++t) {
                 vfloat4 bv = ub_load4(PB, S::OFF_B + (hl + 1) * HP + 16 * (w * MTW + t), g << 2);
                 PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
@@ -228,7 +245,9 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         PINN_UNROLL for (int rr = 0; rr < 4; ++rr) A[q][t] = mfma16(wf[t][rr], b4[rr], A[q][t]);
                 }
             }
+            STAMP(2)
             act_forward(A, hl + 1);
+            STAMP(3)
         }
         // output layer HP -> 1: per-wave partial dot over its neurons, summed across the 4 waves through LDS
         {
@@ -249,6 +268,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                 PINN_UNROLL for (int ws = 0; ws < 4; ++ws) s = s + lds_load(UP, vint((ws * NG + pg * C + ch) * 16) + c);
                 U[pg][ch] = (ch == 0) ? s + vfloat(bL) : s;
             }
+        STAMP(4)
         if (MODE == MODE_FWD) {
             if (w == 0)
                 PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
@@ -260,7 +280,9 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
             continue;
         }
 
-        // =========================== residual tape (vector registers, redundantly in the 4 waves) ===========================
+        // =========================== residual tape (vector registers) ===========================
+        // Wave pg interprets the program for point group pg (ONE copy of the interpreter in the instruction stream) and
+        // broadcasts the seeds ubar = dL/d(jet channel) to the other waves through LDS.
         vfloat ubar[PG][C];
         if (MODE == MODE_GRADIN) {
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
@@ -268,48 +290,66 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                 PINN_UNROLL for (int ch = 0; ch < C; ++ch) ubar[pg][ch] = gload_masked(T.in, vint(ch * T.N) + p, valid[pg]);
             }
         } else {
-            const int NP = ga.nparams;
-            const int R0 = D + NP + C;
-            const rp::Instr* prog = ga.prog + T.prog_off;
-            PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+            float* UB = UP + 4 * NG * 16;
+            if (w < PG) {
+                vfloat xin[D], Uin[C];
+                vbool vin = valid[0];
+                PINN_UNROLL for (int i = 0; i < D; ++i) xin[i] = x[0][i];
+                PINN_UNROLL for (int ch = 0; ch < C; ++ch) Uin[ch] = U[0][ch];
+                PINN_UNROLL for (int pg = 1; pg < PG; ++pg)
+                    if (w == pg) {
+                        vin = valid[pg];
+                        PINN_UNROLL for (int i = 0; i < D; ++i) xin[i] = x[pg][i];
+                        PINN_UNROLL for (int ch = 0; ch < C; ++ch) Uin[ch] = U[pg][ch];
+                    }
+                const int NP = ga.nparams;
+                const int R0 = D + NP + C;
+                const rp::Instr* prog = ga.prog + T.prog_off;
                 vtape tv;
                 tape_zero(tv);
-                PINN_UNROLL for (int i = 0; i < D; ++i) tape_set(tv, i, x[pg][i]);
+                PINN_UNROLL for (int i = 0; i < D; ++i) tape_set(tv, i, xin[i]);
                 for (int j = 0; j < NP; ++j) tape_set(tv, D + j, vfloat(ga.params[j]));
-                PINN_UNROLL for (int ch = 0; ch < C; ++ch) tape_set(tv, D + NP + ch, U[pg][ch]);
+                PINN_UNROLL for (int ch = 0; ch < C; ++ch) tape_set(tv, D + NP + ch, Uin[ch]);
                 for (int q = 0; q < T.nops; ++q) {
-                    const rp::Instr ins = prog[q];
+                    const rp::Instr ins = rp::fetch_uniform(prog, q);
                     tape_set(tv, R0 + q, rp::apply<vfloat>(ins.code, tape_get(tv, ins.a), tape_get(tv, ins.b), ins.imm));
                 }
                 vfloat r = tape_get(tv, T.out_row);
                 if (MODE == MODE_RESID) {
-                    vint p = vint(pbase + 16 * pg) + c;
-                    if (w == 0) gstore_masked(T.out, p, r, vand(valid[pg], g0));
-                    continue;
+                    vint p = vint(pbase + 16 * w) + c;
+                    gstore_masked(T.out, p, r, vand(vin, g0));
+                } else {
+                    vfloat rm = vselect(vin, r, vfloat(0.f));
+                    lsum = vfma(rm, vselect(g0, rm, vfloat(0.f)), lsum);   // this wave's share of the term's sum of squares
+                    vfloat rbar = rm * vfloat(T.scale);
+                    vtape ta;
+                    tape_zero(ta);
+                    tape_set(ta, T.out_row, vfloat(1.0f));
+                    for (int q = T.nops - 1; q >= 0; --q) {
+                        const rp::Instr ins = rp::fetch_uniform(prog, q);
+                        if (rp::is_nullary(ins.code)) continue;
+                        vfloat da, db;
+                        rp::adjoint<vfloat>(ins.code, tape_get(tv, ins.a), tape_get(tv, ins.b), tape_get(tv, R0 + q), ins.imm,
+                                            tape_get(ta, R0 + q), da, db);
+                        tape_set(ta, ins.a, tape_get(ta, ins.a) + da);
+                        if (rp::is_binary(ins.code)) tape_set(ta, ins.b, tape_get(ta, ins.b) + db);
+                    }
+                    PINN_UNROLL for (int ch = 0; ch < C; ++ch)
+                        lds_store(UB, vint((w * C + ch) * 16) + c, rbar * tape_get(ta, D + NP + ch));   // 4 row groups: same value
+                    for (int j = 0; j < ga.nparams_estim; ++j) {
+                        vfloat pj = vselect(g0, rbar * tape_get(ta, D + j), vfloat(0.f));
+                        PINN_UNROLL for (int jj = 0; jj < MAX_PARAMS; ++jj) if (jj == j) pbar[jj] += pj;
+                    }
                 }
-                vfloat rm = vselect(valid[pg], r, vfloat(0.f));
-                lsum = vfma(rm, vselect(g0, rm, vfloat(0.f)), lsum);       // only wave 0's copy is written out
-                vfloat rbar = rm * vfloat(T.scale);
-                vtape ta;
-                tape_zero(ta);
-                tape_set(ta, T.out_row, vfloat(1.0f));
-                for (int q = T.nops - 1; q >= 0; --q) {
-                    const rp::Instr ins = prog[q];
-                    if (rp::is_nullary(ins.code)) continue;
-                    vfloat da, db;
-                    rp::adjoint<vfloat>(ins.code, tape_get(tv, ins.a), tape_get(tv, ins.b), tape_get(tv, R0 + q), ins.imm,
-                                        tape_get(ta, R0 + q), da, db);
-                    tape_set(ta, ins.a, tape_get(ta, ins.a) + da);
-                    if (rp::is_binary(ins.code)) tape_set(ta, ins.b, tape_get(ta, ins.b) + db);
-                }
-                PINN_UNROLL for (int ch = 0; ch < C; ++ch) ubar[pg][ch] = rbar * tape_get(ta, D + NP + ch);
-                for (int j = 0; j < ga.nparams_estim; ++j) {
-                    vfloat pj = vselect(g0, rbar * tape_get(ta, D + j), vfloat(0.f));
-                    PINN_UNROLL for (int jj = 0; jj < MAX_PARAMS; ++jj) if (jj == j) pbar[jj] += pj;
-                }
+            }
+            if (MODE != MODE_RESID) {
+                wg_barrier();                                                   // seeds of every point group are in UB
+                PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
+                    PINN_UNROLL for (int ch = 0; ch < C; ++ch) ubar[pg][ch] = lds_load(UB, vint((pg * C + ch) * 16) + c);
             }
         }
         if (MODE == MODE_RESID) { wg_barrier(); continue; }
+        STAMP(5)
 
         // =========================== reverse sweep ===========================
         auto ajet = [&](const vfloat4 (&Sr)[NG][MTW], int pg, int ch, int t) -> vfloat4 {
@@ -369,6 +409,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                     }
         }
         act_adjoint(G, Rlast);
+        STAMP(6)
 
         PINN_UNROLL for (int hl = NHH - 1; hl >= 0; --hl) {
             // G = dZ of hidden layer hl+1 (own tiles).  Inputs of that layer = a-jets of hidden layer hl.
@@ -437,8 +478,11 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                 }
             } else {
                 PINN_UNROLL for (int q = 0; q < NG; ++q) stage_q(q, ZT + q * (MTW * 256), X1 + q * 16 * HP);
+                STAMP(7)
                 wg_barrier();
+                STAMP(8)
                 PINN_UNROLL for (int q = 0; q < NG; ++q) dw_q(ZT + q * (MTW * 256), X1 + q * 16 * HP);
+                STAMP(9)
             }
             if (!S::WBAR_REG)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t)
@@ -462,10 +506,13 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         PINN_UNROLL for (int rr = 0; rr < 4; ++rr) Gn[q][t] = mfma16(wt[t][rr], b4[rr], Gn[q][t]);
                 }
             }
+            STAMP(10)
             wg_barrier();                                                   // X0 / X1 free again
+            STAMP(11)
             PINN_UNROLL for (int q = 0; q < NG; ++q)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t) G[q][t] = Gn[q][t];
             act_adjoint(G, Sr);
+            STAMP(12)
         }
         // hidden layer 0: db0, dW1 in the D layout (per-lane partial sums over this lane's column)
         PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
@@ -479,11 +526,12 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                             if (i == S::first_axis(kf)) w1bar[i][t][r] += G[pg * C + 1 + kf][t][r];
                 }
         if (NHH == 0) wg_barrier();                                         // UP reuse across tiles when there is no layer barrier
+        STAMP(13)
     }  // tiles
 
     if (!BWD) return;
     // =========================== epilogue ===========================
-    if (cur_term >= 0 && MODE == MODE_FUSED && w == 0)
+    if (cur_term >= 0 && MODE == MODE_FUSED)
         ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[cur_term].term_id] = wave_sum_d(lsum, g0);
     if (S::WBAR_REG)
         PINN_UNROLL for (int hl = 0; hl < NHH; ++hl)
@@ -505,15 +553,28 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
             PINN_UNROLL for (int i = 0; i < D; ++i) gstore_masked(slab + S::O_W1 + i * HP, n, reduce_cols(w1bar[i][t][r]), c0);
             gstore_masked(slab + S::O_WL, n, reduce_cols(wLbar[t][r]), c0);
         }
+    // PDE-parameter gradients: the tape waves' partial sums meet in wave 0 (fixed order)
+    static_assert(4 * MAX_PARAMS <= 16, "UB holds the per-wave parameter partials");
+    const vbool all = vlt(lane, 64);
+    float* UBp = UP + 4 * NG * 16;
+    if (w > 0 && w < PG)
+        PINN_UNROLL for (int j = 0; j < MAX_PARAMS; ++j)
+            lds_store(UBp, vint(w * MAX_PARAMS + j) + (lane & vint(0)), vfloat((float)wave_sum_d(pbar[j], all)));
+    if (PG > 1) wg_barrier();
     if (w == 0) {
-        vbool all = vlt(lane, 64);
         float s = (float)wave_sum_d(bLbar, all);
         gstore_masked(slab + S::O_BL, vint(0), vfloat(s), veq(lane, 0));
         PINN_UNROLL for (int j = 0; j < MAX_PARAMS; ++j) {
-            float sp = (float)wave_sum_d(pbar[j], all);
-            gstore_masked(slab + S::O_P, vint(j), vfloat(sp), veq(lane, 0));
+            vfloat sp = vfloat((float)wave_sum_d(pbar[j], all));
+            PINN_UNROLL for (int ws = 1; ws < PG; ++ws) sp = sp + lds_load(UBp, vint(ws * MAX_PARAMS + j) + (lane & vint(0)));
+            gstore_masked(slab + S::O_P, vint(j), sp, veq(lane, 0));
         }
     }
+#if defined(PINN_STAMP) && !defined(PINN_EMU)
+    STAMP(14)
+    if ((threadIdx.x & 63) == 0)
+        for (int i = 0; i < 16; ++i) reinterpret_cast<unsigned*>(slab + S::SLAB - 64)[w * 16 + i] = st_acc[i];
+#endif
 }
 
 }  // namespace pk

@@ -28,6 +28,15 @@ struct Instr {
     float imm;
 };
 
+// instruction q of a program whose address is uniform across the wave (fused kernels): scalar fetch
+DEV Instr fetch_uniform(const Instr* prog, int q) {
+    const wv::urec16 r = wv::uload16(prog + q);
+    Instr ins;
+    ins.code = r.x; ins.a = r.y; ins.b = r.z;
+    __builtin_memcpy(&ins.imm, &r.w, 4);
+    return ins;
+}
+
 constexpr int MAX_ROWS_FUSED = 32;   // LDS tape rows available to the fused kernel (values + adjoints)
 constexpr int MAX_ROWS = 256;        // hard limit of the IR
 

@@ -11,6 +11,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 
 #ifdef PINN_EMU
 // ------------------------------------------------------------------------------------------
@@ -81,6 +82,9 @@ struct vtape { vfloat r[32]; };
 inline vfloat tape_get(const vtape& t, int i) { return t.r[i]; }
 inline void tape_set(vtape& t, int i, const vfloat& x) { t.r[i] = x; }
 inline void tape_zero(vtape& t) { for (int i = 0; i < 32; ++i) t.r[i] = vfloat(0.f); }
+// 16-byte record at a wave-uniform address (device: scalar-cache load)
+struct urec16 { int x, y, z, w; };
+inline urec16 uload16(const void* p) { urec16 r; std::memcpy(&r, p, 16); return r; }
 // uniform-base buffer view (device: buffer descriptor in SGPRs + scalar offset + per-lane voffset)
 struct ubuf { float* p; };
 inline ubuf ub_make(const float* p, size_t) { return ubuf{const_cast<float*>(p)}; }
@@ -175,6 +179,19 @@ typedef float vtape __attribute__((ext_vector_type(32)));
 DEV vfloat tape_get(const vtape& t, int i) { return t[i]; }
 DEV void tape_set(vtape& t, int i, vfloat x) { t[i] = x; }
 DEV void tape_zero(vtape& t) { PINN_UNROLL for (int i = 0; i < 32; ++i) t[i] = 0.f; }
+// 16-byte record at a wave-uniform, read-only address, fetched through the scalar cache (s_load_dwordx4) into SGPRs.
+// A plain load is not scalarised because the kernel also stores to global memory: it becomes global_load + vmcnt(0)
+// (which also drains every outstanding record store) and its fields need waterfall loops to be used as register indices.
+struct urec16 { int x, y, z, w; };
+DEV urec16 uload16(const void* p) {
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);          // (the builtin returns int: no sign extension)
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    const unsigned long long u = (unsigned long long)lo | ((unsigned long long)hi << 32);
+    const i4 v = *(const __attribute__((address_space(4))) i4*)u;
+    return {v.x, v.y, v.z, v.w};
+}
 struct ubuf { __amdgpu_buffer_rsrc_t r; };
 typedef unsigned vuint4 __attribute__((ext_vector_type(4)));
 DEV ubuf ub_make(const float* p, size_t nfloats) {
