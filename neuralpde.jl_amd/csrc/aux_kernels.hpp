@@ -95,6 +95,29 @@ AUX_DEV float expr_point(int p, const ExprArgs& a, float (&pb)[4]) {
     return r;
 }
 
+// k_src: coordinate-only subexpressions of a residual (source terms f(x), boundary data g(x), variable coefficients ...),
+// evaluated once per installed / redrawn point set, one thread per point, into channel arrays src[j][N] that the fused
+// kernel's tape reads as input rows.  The reference re-evaluates them inside the generated loss function on every call
+// (they are part of the broadcast expression, src/symbolic_utilities.jl:360-370); values are identical.
+constexpr int SRC_MAX = 8;
+struct SrcArgs {
+    const float* pts;                     // d x N point-major
+    int N, d;
+    const rp::Instr* prog;                // compact numbering: rows [0,d) coordinates, row d+q = op q
+    int nops, nsrc;
+    int root[SRC_MAX];                    // compact row of source j
+    float* out;                           // [nsrc][N]
+};
+AUX_DEV void src_point(int p, const SrcArgs& a) {
+    float v[EXPR_MAX_ROWS];
+    for (int i = 0; i < a.d; ++i) v[i] = a.pts[(size_t)p * a.d + i];
+    for (int q = 0; q < a.nops; ++q) {
+        const rp::Instr ins = a.prog[q];
+        v[a.d + q] = rp::apply<float>(ins.code, v[ins.a], v[ins.b], ins.imm);
+    }
+    for (int j = 0; j < a.nsrc; ++j) a.out[(size_t)j * a.N + p] = v[a.root[j]];
+}
+
 // ---- resident-theta training loop ----
 // Adam exactly as [3P] Optimisers.Adam: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; theta -= lr * (m/(1-b1^t)) / (sqrt(v/(1-b2^t)) + eps)
 AUX_DEV void adam_body(int i, float* theta, float* m, float* v, const float* grad, float lr, float b1, float b2, float eps, float c1, float c2) {
@@ -207,6 +230,9 @@ inline void launch_total_loss(double* hist, int step, const float* out, int P, i
 inline void launch_sample(float* pts, int n_elems, int d, const float* lb, const float* ub, unsigned seed, unsigned draw, plat_stream) {
     for (int e = 0; e < n_elems; ++e) sample_body(e, pts, d, lb, ub, seed, draw);
 }
+inline void launch_src(const SrcArgs& a, plat_stream) {
+    for (int p = 0; p < a.N; ++p) src_point(p, a);
+}
 inline void launch_expr(const ExprArgs& a, int nblocks, plat_stream) {
     for (int b = 0; b < nblocks; ++b)
         for (int w = 0; w < 4; ++w) {
@@ -290,6 +316,13 @@ inline void launch_pack(float* packed, const int* idx, const float* theta, int n
 }
 inline void launch_params(float* params, const float* theta, const float* defaults, int np, int ne, int p_off, plat_stream st) {
     if (np > 0) hipLaunchKernelGGL(k_params, dim3(1), dim3(64), 0, st, params, theta, defaults, np, ne, p_off);
+}
+__global__ void __launch_bounds__(256) k_src(const SrcArgs a) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < a.N) src_point(p, a);
+}
+inline void launch_src(const SrcArgs& a, plat_stream st) {
+    hipLaunchKernelGGL(k_src, dim3((a.N + 255) / 256), dim3(256), 0, st, a);
 }
 inline void launch_expr(const ExprArgs& a, int nblocks, plat_stream st) {
     hipLaunchKernelGGL(k_expr, dim3(nblocks), dim3(256), 0, st, a);

@@ -73,6 +73,14 @@ struct Term {
     int slot_in_group = -1;
     int coupled = -1;                // >= 0: index into pinn_engine::coupled (equation couples several networks)
     std::vector<int> chan_of_slot;
+    // coordinate-only subexpressions hoisted out of the fused tape (analyse_static): evaluated by k_src per point set
+    std::vector<rp::Instr> src_prog;     // compact numbering: rows [0,d) coordinates, row d+i = static op i
+    std::vector<int> src_root;           // compact row of source j
+    std::vector<int> src_of_op;          // per descriptor op: source index, or -1
+    std::vector<int> tape_ops;           // descriptor ops that stay in the fused tape, in order
+    rp::Instr* d_src_prog = nullptr;
+    float* d_src = nullptr;              // [nsrc][n]
+    int64_t src_cap = 0;
     // data
     float* d_pts = nullptr;
     int64_t n = 0, n_norm = 0;
@@ -239,7 +247,12 @@ int parse_descriptor(const char* text, pinn_engine& E) {
             for (int c = 0; c < rp::OP_COUNT; ++c)
                 if (name == OPNAMES[c]) I.code = c;
             if (I.code < 0) return fail("descriptor: unknown op '" + name + "'");
+            const int lim = T.d + E.np + ns + q;          // operands may only reference earlier rows
+            if (!rp::is_nullary(I.code) && (I.a < 0 || I.a >= lim)) return fail("descriptor: op operand row out of range");
+            if (rp::is_binary(I.code) && (I.b < 0 || I.b >= lim)) return fail("descriptor: op operand row out of range");
+            rp::finalize(I);
         }
+        if (T.out_row < 0 || T.out_row >= T.d + E.np + ns + no) return fail("descriptor: out row out of range");
     }
     return 0;
 }
@@ -247,6 +260,56 @@ int parse_descriptor(const char* text, pinn_engine& E) {
 // ---------------------------------------------------------------------------------------------
 // plan: pick a compiled kernel for every term, build pack / reduce index maps
 // ---------------------------------------------------------------------------------------------
+// Split a single-network term's program into the coordinate-only part (no dependence on the trial function or on PDE
+// parameters) and the rest.  Coordinate-only ops that feed the rest become "sources": per-point input channels of the
+// fused kernel's tape, evaluated once per point set instead of once per loss evaluation.
+void analyse_static(Term& T, int np) {
+    const int S = (int)T.slots.size(), nops = (int)T.ops.size();
+    const int rslot0 = T.d + np, rop0 = rslot0 + S;
+    std::vector<char> dyn(nops, 0), keep(nops, 0), used(nops, 0);
+    auto row_dyn = [&](int row) { return row >= T.d && (row < rop0 || dyn[row - rop0]); };
+    for (int q = 0; q < nops; ++q) {
+        const rp::Instr& I = T.ops[q];
+        dyn[q] = (!rp::is_nullary(I.code) && row_dyn(I.a)) || (rp::is_binary(I.code) && row_dyn(I.b));
+    }
+    T.src_prog.clear(); T.src_root.clear(); T.tape_ops.clear();
+    T.src_of_op.assign(nops, -1);
+    auto mark = [&](int row) {                 // operand of a tape op: a static op row must be provided to the tape
+        if (row < rop0) return;
+        const int q = row - rop0;
+        if (dyn[q]) return;
+        if (T.ops[q].code == rp::OP_CONST) keep[q] = 1;      // constants stay in the tape (no dispatch cost)
+        else used[q] = 1;
+    };
+    for (int q = 0; q < nops; ++q)
+        if (dyn[q]) {
+            keep[q] = 1;
+            if (!rp::is_nullary(T.ops[q].code)) mark(T.ops[q].a);
+            if (rp::is_binary(T.ops[q].code)) mark(T.ops[q].b);
+        }
+    mark(T.out_row);
+    int nsrc = 0, nstatic = 0;
+    for (int q = 0; q < nops; ++q) { nsrc += used[q]; nstatic += !dyn[q]; }
+    if (nsrc == 0 || nsrc > aux::SRC_MAX || T.d + nstatic > aux::EXPR_MAX_ROWS) {       // nothing to hoist / too many: keep everything
+        for (int q = 0; q < nops; ++q) T.tape_ops.push_back(q);
+        return;
+    }
+    std::vector<int> compact(nops, -1);
+    for (int q = 0; q < nops; ++q) {
+        if (dyn[q]) continue;
+        rp::Instr I = T.ops[q];
+        auto cmap = [&](int row) { return row < T.d ? row : T.d + compact[row - rop0]; };
+        I.a = rp::is_nullary(I.code) ? 0 : cmap(I.a);
+        I.b = rp::is_binary(I.code) ? cmap(I.b) : 0;
+        rp::finalize(I);
+        compact[q] = (int)T.src_prog.size();
+        T.src_prog.push_back(I);
+        if (used[q]) { T.src_of_op[q] = (int)T.src_root.size(); T.src_root.push_back(T.d + compact[q]); }
+    }
+    for (int q = 0; q < nops; ++q)
+        if (keep[q]) T.tape_ops.push_back(q);
+}
+
 int round_hp(int h) {
     if (h <= 16) return 16;
     if (h <= 32) return 32;
@@ -380,7 +443,8 @@ int build_plan(pinn_engine& E) {
                 if (c < 0) return fail("internal: slot has no channel");
                 T.chan_of_slot.push_back(c);
             }
-            const int rows = T.d + E.np + sp->C + (int)T.ops.size();
+            analyse_static(T, E.np);
+            const int rows = T.d + E.np + sp->C + (int)T.src_root.size() + (int)T.tape_ops.size();
             if (rows > rp::MAX_ROWS_FUSED)
                 return fail("term " + std::to_string(t) + ": residual expression too long for the fused kernel tape (" + std::to_string(rows) + " rows > 32)");
             if (!E.netplans[net].spec) E.netplans[net].spec = sp;
@@ -518,25 +582,30 @@ int build_plan(pinn_engine& E) {
             }
             const int S = (int)T.slots.size();
             const int rslot0 = T.d + E.np, rop0 = rslot0 + S;
+            const int nsrc = (int)T.src_root.size();
+            std::vector<int> tape_pos(T.ops.size(), -1);
+            for (size_t i = 0; i < T.tape_ops.size(); ++i) tape_pos[T.tape_ops[i]] = (int)i;
+            // fused tape rows: [coordinates d | params np | jet channels C | sources nsrc | tape ops]
             auto remap = [&](int row) -> int {
                 if (row < rslot0) return row;
                 if (row < rop0) return T.d + E.np + T.chan_of_slot[row - rslot0];
-                return T.d + E.np + s.C + (row - rop0);
+                const int q = row - rop0;
+                if (T.src_of_op[q] >= 0) return T.d + E.np + s.C + T.src_of_op[q];
+                return T.d + E.np + s.C + nsrc + tape_pos[q];
             };
             G.prog_off.push_back((int)prog.size());
-            G.prog_n.push_back((int)T.ops.size());
-            for (size_t q = 0; q < T.ops.size(); ++q) {
+            G.prog_n.push_back((int)T.tape_ops.size());
+            for (int q : T.tape_ops) {
                 rp::Instr I = T.ops[q];
-                const int lim = rop0 + (int)q;
-                if (!rp::is_nullary(I.code)) {
-                    if (I.a < 0 || I.a >= lim) return fail("descriptor: op operand row out of range");
-                    I.a = remap(I.a);
-                } else I.a = 0;
-                if (rp::is_binary(I.code)) {
-                    if (I.b < 0 || I.b >= lim) return fail("descriptor: op operand row out of range");
-                    I.b = remap(I.b);
-                } else I.b = 0;
+                I.a = rp::is_nullary(I.code) ? 0 : remap(I.a);
+                I.b = rp::is_binary(I.code) ? remap(I.b) : 0;
+                rp::finalize(I);
                 prog.push_back(I);
+            }
+            if (nsrc > 0) {
+                T.d_src_prog = (rp::Instr*)plat_malloc(sizeof(rp::Instr) * T.src_prog.size());
+                if (!T.d_src_prog) return fail("device allocation failed (source programs)");
+                plat_h2d(T.d_src_prog, T.src_prog.data(), sizeof(rp::Instr) * T.src_prog.size(), E.stream);
             }
             if (T.out_row < 0 || T.out_row >= rop0 + (int)T.ops.size()) return fail("descriptor: out row out of range");
             G.out_row.push_back(remap(T.out_row));
@@ -635,6 +704,7 @@ int build_plan(pinn_engine& E) {
             if (rp::is_binary(I.code) && (I.b < 0 || I.b >= lim)) return fail("descriptor: op operand row out of range");
             if (rp::is_nullary(I.code)) I.a = 0;
             if (!rp::is_binary(I.code)) I.b = 0;
+            rp::finalize(I);
         }
         if (T.out_row < 0 || T.out_row >= lim0 + (int)prog.size()) return fail("descriptor: out row out of range");
         Cp.d_prog = (rp::Instr*)plat_malloc(sizeof(rp::Instr) * std::max<size_t>(prog.size(), 1));
@@ -702,6 +772,8 @@ void retile(pinn_engine& E, int gi) {
         td.scale = 0.f;
         td.out = nullptr;
         td.in = nullptr;
+        td.src = (G.kind == 0) ? T.d_src : nullptr;
+        td.nsrc = (G.kind == 0) ? (int)T.src_root.size() : 0;
         if (G.kind == 1) {               // coupled term: this network's jet / seed buffers
             const Coupled& Cp = E.coupled[T.coupled];
             for (size_t i = 0; i < Cp.groups.size(); ++i)
@@ -711,6 +783,18 @@ void retile(pinn_engine& E, int gi) {
     }
     G.ga.ntiles = tile;
     G.blocks = std::max(1, std::min(G.max_blocks, s.family == 2 ? tile : (tile + 3) / 4));
+}
+
+// (re-)evaluate a term's coordinate-only source channels for its current point set
+void eval_sources(pinn_engine& E, Term& T) {
+    if (T.src_root.empty() || T.coupled >= 0) return;
+    aux::SrcArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.pts = T.d_pts; a.N = (int)T.n; a.d = T.d; a.prog = T.d_src_prog; a.nops = (int)T.src_prog.size();
+    a.nsrc = (int)T.src_root.size();
+    for (int j = 0; j < a.nsrc; ++j) a.root[j] = T.src_root[j];
+    a.out = T.d_src;
+    aux::launch_src(a, E.stream);
 }
 
 int ensure_points(pinn_engine& E) {
@@ -906,7 +990,7 @@ int pinn_destroy(pinn_handle h) {
     if (!h) return 0;
     pinn_engine& E = *h;
     plat_sync(E.stream);
-    for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_resid); plat_free(T.d_lb); plat_free(T.d_ub); }
+    for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_resid); plat_free(T.d_lb); plat_free(T.d_ub); plat_free(T.d_src_prog); plat_free(T.d_src); }
     plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist);
     for (auto& G : E.groups) {
         plat_free(G.d_prog); plat_free(G.d_slabs); plat_free(G.d_losspart); plat_free(G.d_scratch);
@@ -952,6 +1036,16 @@ static int set_points_impl(pinn_handle h, int term, const float* pts, int64_t n,
     T.n = n;
     T.n_norm = n_norm > 0 ? n_norm : n;
     if (T.coupled < 0) {
+        if (!T.src_root.empty()) {
+            if (T.src_cap < n) {
+                plat_free(T.d_src);
+                T.d_src = (float*)plat_malloc(sizeof(float) * T.src_root.size() * (size_t)n);
+                if (!T.d_src) return fail("device allocation failed (source channels)");
+                T.src_cap = n;
+            }
+            eval_sources(E, T);
+            plat_sync(E.stream);
+        }
         retile(E, T.group);
         return 0;
     }
@@ -1154,6 +1248,7 @@ int pinn_set_sampler(pinn_handle h, int term, int kind, const float* lb, const f
     std::vector<float> tmp((size_t)n * T.d, 0.f);
     if (set_points_impl(h, term, tmp.data(), n, 0, false)) return 1;
     aux::launch_sample(T.d_pts, (int)(n * T.d), T.d, T.d_lb, T.d_ub, T.seed, T.draws++, E.stream);
+    eval_sources(E, T);
     plat_sync(E.stream);
     return 0;
 }
@@ -1198,7 +1293,10 @@ int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta
     for (int s = 0; s < nsteps; ++s) {
         for (size_t t = 0; t < E.terms.size(); ++t) {            // resampling strategies: fresh points every evaluation, on device
             Term& T = E.terms[t];
-            if (T.sampler == 1) aux::launch_sample(T.d_pts, (int)(T.n * T.d), T.d, T.d_lb, T.d_ub, T.seed, T.draws++, E.stream);
+            if (T.sampler == 1) {
+                aux::launch_sample(T.d_pts, (int)(T.n * T.d), T.d, T.d_lb, T.d_ub, T.seed, T.draws++, E.stream);
+                eval_sources(E, T);
+            }
         }
         if (run_loss_grad(E, E.d_opt_theta, E.d_opt_out, term_w, -1, false)) return 1;
         aux::launch_total_loss(E.d_hist, s, E.d_opt_out, P, K, E.d_w_over_n, E.stream);

@@ -127,6 +127,8 @@ struct TermDev {
     float scale;             // 2 * w_k / N_k(global)   — reverse-sweep seed of mean(abs2, r)
     float* out;              // MODE_RESID: residual r[N];  MODE_FWD: jets [C][N]
     const float* in;         // MODE_GRADIN: d(loss)/d(jet) [C][N]
+    const float* src;        // [nsrc][N]: coordinate-only subexpressions of the residual, evaluated when the point set was installed
+    int nsrc;                // tape rows D+NP+C .. D+NP+C+nsrc-1
 };
 
 struct GroupArgs {
@@ -404,18 +406,23 @@ Sr[q][m] = ub_load4(SB, (((layer * NG) + q) * MT + m) * 256, lane << 2);
             float* tv = lds;                    // value rows  [row][64]
             float* ta = lds + 2 * S::LDS_T;     // adjoint rows
             const int NP = ga.nparams;
-            const int R0 = D + NP + C;
+            const int R0 = D + NP + C + T.nsrc;
             const rp::Instr* prog = ga.prog + T.prog_off;
             const int nrows = R0 + T.nops;
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
                 PINN_UNROLL for (int i = 0; i < D; ++i) lds_store(tv, vint(i * 64) + lane, x[pg][i]);
                 for (int j = 0; j < NP; ++j) lds_store(tv, vint((D + j) * 64) + lane, vfloat(ga.params[j]));
                 PINN_UNROLL for (int ch = 0; ch < C; ++ch) lds_store(tv, vint((D + NP + ch) * 64) + lane, U[pg][ch]);
+                for (int j = 0; j < T.nsrc; ++j)
+                    lds_store(tv, vint((D + NP + C + j) * 64) + lane, gload_masked(T.src, vint(j * T.N + pbase + 16 * pg) + c, valid[pg]));
                 for (int q = 0; q < T.nops; ++q) {
                     const rp::Instr ins = rp::fetch_uniform(prog, q);
-                    vfloat va = rp::is_nullary(ins.code) ? vfloat(0.f) : lds_load(tv, vint(ins.a * 64) + lane);
-                    vfloat vb = rp::is_binary(ins.code) ? lds_load(tv, vint(ins.b * 64) + lane) : vfloat(0.f);
-                    lds_store(tv, vint((R0 + q) * 64) + lane, rp::apply<vfloat>(ins.code, va, vb, ins.imm));
+                    vfloat va = lds_load(tv, vint(ins.a * 64) + lane);            // unused operands point at row 0
+                    vfloat vb = lds_load(tv, vint(ins.b * 64) + lane);
+                    vfloat vo;
+                    if (rp::is_bilinear(ins.code)) vo = rp::apply_bilinear<vfloat>(ins, va, vb);
+                    else vo = rp::apply<vfloat>(ins.code, va, vb, ins.imm);
+                    lds_store(tv, vint((R0 + q) * 64) + lane, vo);
                 }
                 vfloat r = lds_load(tv, vint(T.out_row * 64) + lane);
                 if (MODE == MODE_RESID) {
@@ -430,16 +437,17 @@ Sr[q][m] = ub_load4(SB, (((layer * NG) + q) * MT + m) * 256, lane << 2);
                 lds_store(ta, vint(T.out_row * 64) + lane, vfloat(1.0f));
                 for (int q = T.nops - 1; q >= 0; --q) {
                     const rp::Instr ins = rp::fetch_uniform(prog, q);
-                    if (rp::is_nullary(ins.code)) continue;
                     vfloat gq = lds_load(ta, vint((R0 + q) * 64) + lane);
-                    vfloat vo = lds_load(tv, vint((R0 + q) * 64) + lane);
                     vfloat va = lds_load(tv, vint(ins.a * 64) + lane);
-                    const bool bin = rp::is_binary(ins.code);
-                    vfloat vb = bin ? lds_load(tv, vint(ins.b * 64) + lane) : vfloat(0.f);
+                    vfloat vb = lds_load(tv, vint(ins.b * 64) + lane);
                     vfloat da, db;
-                    rp::adjoint<vfloat>(ins.code, va, vb, vo, ins.imm, gq, da, db);
+                    if (rp::is_bilinear(ins.code)) rp::adjoint_bilinear<vfloat>(ins, va, vb, gq, da, db);      // unused operands: zero adjoint into row 0
+                    else {
+                        vfloat vo = lds_load(tv, vint((R0 + q) * 64) + lane);
+                        rp::adjoint<vfloat>(ins.code, va, vb, vo, ins.imm, gq, da, db);
+                    }
                     lds_store(ta, vint(ins.a * 64) + lane, lds_load(ta, vint(ins.a * 64) + lane) + da);
-                    if (bin) lds_store(ta, vint(ins.b * 64) + lane, lds_load(ta, vint(ins.b * 64) + lane) + db);
+                    lds_store(ta, vint(ins.b * 64) + lane, lds_load(ta, vint(ins.b * 64) + lane) + db);
                 }
                 PINN_UNROLL for (int ch = 0; ch < C; ++ch) ubar[pg][ch] = rbar * lds_load(ta, vint((D + NP + ch) * 64) + lane);
                 for (int j = 0; j < ga.nparams_estim; ++j) {

@@ -95,6 +95,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
     constexpr int HP = S::HP, MT = S::MT, MTW = S::MTW, NHH = S::NHH, LH = S::LH, D = S::D, C = S::C, PG = S::PG, NG = S::NG;
     constexpr int NFIRST = S::NFIRST, NPAIR = S::NPAIR;
     constexpr bool BWD = (MODE == MODE_FUSED || MODE == MODE_GRADIN);
+    constexpr bool WPRE = (MT * MTW * 4 <= 16);        // prefetch a layer's weight fragments when they take <= 16 registers (H = 64)
     const int wave = blk * 4 + w;
     const vint lane = lane_id();
     const vint g = lane >> 4;
@@ -225,24 +226,34 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
         STAMP(0)
         PINN_UNROLL for (int hl = 0; hl < NHH; ++hl) {
             float* Xin = (hl & 1) ? X1 : X0;
+            // this wave's weight fragments + bias of the layer: issued before the exchange so that their L2 latency hides
+            // under publish + barrier instead of stalling the first MFMA of every k-block
+            vfloat4 wf[WPRE ? MT : 1][MTW], bv[MTW];
+            if (WPRE) {
+                PINN_UNROLL for (int mi = 0; mi < MT; ++mi)
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                        wf[mi][t] = ub_load4(PB, S::OFF_WPK + ((hl * MT + w * MTW + t) * MT + mi) * 256, lane << 2);
+                PINN_UNROLL for (int t = 0; t < MTW; ++t) bv[t] = ub_load4(PB, S::OFF_B + (hl + 1) * HP + 16 * (w * MTW + t), g << 2);
+                sched_fence();
+            }
             publish(Xin, A);
             wg_barrier();                                                   // layer hl activations complete in Xin
             STAMP(1)
             PINN_UNROLL for (int t = 0; t < MTW; ++t) {
-                vfloat4 bv = ub_load4(PB, S::OFF_B + (hl + 1) * HP + 16 * (w * MTW + t), g << 2);
+                if (!WPRE) bv[t] = ub_load4(PB, S::OFF_B + (hl + 1) * HP + 16 * (w * MTW + t), g << 2);
                 PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
-                    A[pg * C][t] = bv;
+                    A[pg * C][t] = bv[t];
                     PINN_UNROLL for (int ch = 1; ch < C; ++ch) A[pg * C + ch][t] = vzero4();
                 }
             }
             PINN_UNROLL for (int mi = 0; mi < MT; ++mi) {
-                vfloat4 wf[MTW];
-                PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                    wf[t] = ub_load4(PB, S::OFF_WPK + ((hl * MT + w * MTW + t) * MT + mi) * 256, lane << 2);
+                if (!WPRE)
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                        wf[0][t] = ub_load4(PB, S::OFF_WPK + ((hl * MT + w * MTW + t) * MT + mi) * 256, lane << 2);
                 PINN_UNROLL for (int q = 0; q < NG; ++q) {
                     vfloat4 b4 = lds_load4(Xin, vint(((q * MT + mi) * 64) * 4) + (lane << 2));
                     PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                        PINN_UNROLL for (int rr = 0; rr < 4; ++rr) A[q][t] = mfma16(wf[t][rr], b4[rr], A[q][t]);
+                        PINN_UNROLL for (int rr = 0; rr < 4; ++rr) A[q][t] = mfma16(wf[WPRE ? mi : 0][t][rr], b4[rr], A[q][t]);
                 }
             }
             STAMP(2)
@@ -303,16 +314,22 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         PINN_UNROLL for (int ch = 0; ch < C; ++ch) Uin[ch] = U[pg][ch];
                     }
                 const int NP = ga.nparams;
-                const int R0 = D + NP + C;
+                const int R0 = D + NP + C + T.nsrc;
                 const rp::Instr* prog = ga.prog + T.prog_off;
                 vtape tv;
                 tape_zero(tv);
                 PINN_UNROLL for (int i = 0; i < D; ++i) tape_set(tv, i, xin[i]);
                 for (int j = 0; j < NP; ++j) tape_set(tv, D + j, vfloat(ga.params[j]));
                 PINN_UNROLL for (int ch = 0; ch < C; ++ch) tape_set(tv, D + NP + ch, Uin[ch]);
+                for (int j = 0; j < T.nsrc; ++j)
+                    tape_set(tv, D + NP + C + j, gload_masked(T.src, vint(j * T.N + pbase + 16 * w) + c, vin));
                 for (int q = 0; q < T.nops; ++q) {
                     const rp::Instr ins = rp::fetch_uniform(prog, q);
-                    tape_set(tv, R0 + q, rp::apply<vfloat>(ins.code, tape_get(tv, ins.a), tape_get(tv, ins.b), ins.imm));
+                    const vfloat va = tape_get(tv, ins.a), vb = tape_get(tv, ins.b);      // unused operands point at row 0
+                    vfloat vo;
+                    if (rp::is_bilinear(ins.code)) vo = rp::apply_bilinear<vfloat>(ins, va, vb);
+                    else vo = rp::apply<vfloat>(ins.code, va, vb, ins.imm);
+                    tape_set(tv, R0 + q, vo);
                 }
                 vfloat r = tape_get(tv, T.out_row);
                 if (MODE == MODE_RESID) {
@@ -327,12 +344,12 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                     tape_set(ta, T.out_row, vfloat(1.0f));
                     for (int q = T.nops - 1; q >= 0; --q) {
                         const rp::Instr ins = rp::fetch_uniform(prog, q);
-                        if (rp::is_nullary(ins.code)) continue;
+                        const vfloat va = tape_get(tv, ins.a), vb = tape_get(tv, ins.b), gq = tape_get(ta, R0 + q);
                         vfloat da, db;
-                        rp::adjoint<vfloat>(ins.code, tape_get(tv, ins.a), tape_get(tv, ins.b), tape_get(tv, R0 + q), ins.imm,
-                                            tape_get(ta, R0 + q), da, db);
+                        if (rp::is_bilinear(ins.code)) rp::adjoint_bilinear<vfloat>(ins, va, vb, gq, da, db);   // unused operands: zero adjoint into row 0
+                        else rp::adjoint<vfloat>(ins.code, va, vb, tape_get(tv, R0 + q), ins.imm, gq, da, db);
                         tape_set(ta, ins.a, tape_get(ta, ins.a) + da);
-                        if (rp::is_binary(ins.code)) tape_set(ta, ins.b, tape_get(ta, ins.b) + db);
+                        tape_set(ta, ins.b, tape_get(ta, ins.b) + db);
                     }
                     PINN_UNROLL for (int ch = 0; ch < C; ++ch)
                         lds_store(UB, vint((w * C + ch) * 16) + c, rbar * tape_get(ta, D + NP + ch));   // 4 row groups: same value
@@ -469,6 +486,14 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                     }
                 }
             };
+            // W^T fragments for dA: issued ahead of the dW GEMM, which hides their latency
+            vfloat4 wt[WPRE ? MT : 1][MTW];
+            if (WPRE) {
+                PINN_UNROLL for (int mo = 0; mo < MT; ++mo)
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                        wt[mo][t] = ub_load4(PB, S::OFF_WTPK + ((hl * MT + w * MTW + t) * MT + mo) * 256, lane << 2);
+                sched_fence();
+            }
             if (S::CHUNKED) {
                 PINN_UNROLL for (int q = 0; q < NG; ++q) {
                     float* cb = X1 + (q & 1) * S::CHSZ;
@@ -497,13 +522,13 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
             PINN_UNROLL for (int q = 0; q < NG; ++q)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t) Gn[q][t] = vzero4();
             PINN_UNROLL for (int mo = 0; mo < MT; ++mo) {
-                vfloat4 wt[MTW];
-                PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                    wt[t] = ub_load4(PB, S::OFF_WTPK + ((hl * MT + w * MTW + t) * MT + mo) * 256, lane << 2);
+                if (!WPRE)
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                        wt[0][t] = ub_load4(PB, S::OFF_WTPK + ((hl * MT + w * MTW + t) * MT + mo) * 256, lane << 2);
                 PINN_UNROLL for (int q = 0; q < NG; ++q) {
                     vfloat4 b4 = lds_load4(X0, vint(((q * MT + mo) * 64) * 4) + (lane << 2));
                     PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                        PINN_UNROLL for (int rr = 0; rr < 4; ++rr) Gn[q][t] = mfma16(wt[t][rr], b4[rr], Gn[q][t]);
+                        PINN_UNROLL for (int rr = 0; rr < 4; ++rr) Gn[q][t] = mfma16(wt[WPRE ? mo : 0][t][rr], b4[rr], Gn[q][t]);
                 }
             }
             STAMP(10)

@@ -21,19 +21,23 @@ enum Op : int {
     OP_SINPI, OP_COSPI, OP_MAX, OP_MIN, OP_COUNT
 };
 
+// 32 bytes, pre-decoded by the engine (finalize): the arithmetic ops CONST/ADD/SUB/MUL/NEG/ADDC/MULC are all instances of
+//     out = a * (k3 * b + k1) + (k2 * b + k0),     d out/da = k3 * b + k1,     d out/db = k3 * a + k2
+// so the fused kernels evaluate them and their adjoints without any dispatch on the op code.
 struct Instr {
     int code;
     int a;
     int b;
     float imm;
+    float k0, k1, k2, k3;
 };
+static_assert(sizeof(Instr) == 32, "Instr is fetched as one 32-byte scalar load");
 
 // instruction q of a program whose address is uniform across the wave (fused kernels): scalar fetch
 DEV Instr fetch_uniform(const Instr* prog, int q) {
-    const wv::urec16 r = wv::uload16(prog + q);
+    const wv::urec32 r = wv::uload32(prog + q);
     Instr ins;
-    ins.code = r.x; ins.a = r.y; ins.b = r.z;
-    __builtin_memcpy(&ins.imm, &r.w, 4);
+    __builtin_memcpy(&ins, &r, 32);
     return ins;
 }
 
@@ -161,5 +165,27 @@ HD bool is_binary(int code) {
            code == OP_MAX || code == OP_MIN;
 }
 HD bool is_nullary(int code) { return code == OP_CONST; }
+HD bool is_bilinear(int code) { return code <= OP_MULC && code != OP_DIV; }
+// fill the pre-decoded coefficients (host side, once per program)
+inline void finalize(Instr& I) {
+    I.k0 = I.k1 = I.k2 = I.k3 = 0.f;
+    switch (I.code) {
+        case OP_CONST: I.k0 = I.imm; break;
+        case OP_ADD: I.k1 = 1.f; I.k2 = 1.f; break;
+        case OP_SUB: I.k1 = 1.f; I.k2 = -1.f; break;
+        case OP_MUL: I.k3 = 1.f; break;
+        case OP_NEG: I.k1 = -1.f; break;
+        case OP_ADDC: I.k1 = 1.f; I.k0 = I.imm; break;
+        case OP_MULC: I.k1 = I.imm; break;
+        default: break;
+    }
+}
+template <class T>
+DEV T apply_bilinear(const Instr& I, T va, T vb) { return vfma(va, vfma(vb, T(I.k3), T(I.k1)), vfma(vb, T(I.k2), T(I.k0))); }
+template <class T>
+DEV void adjoint_bilinear(const Instr& I, T va, T vb, T g, T& da, T& db) {
+    da = g * vfma(vb, T(I.k3), T(I.k1));
+    db = g * vfma(va, T(I.k3), T(I.k2));
+}
 
 }  // namespace rp

@@ -84,7 +84,10 @@ inline void tape_set(vtape& t, int i, const vfloat& x) { t.r[i] = x; }
 inline void tape_zero(vtape& t) { for (int i = 0; i < 32; ++i) t.r[i] = vfloat(0.f); }
 // 16-byte record at a wave-uniform address (device: scalar-cache load)
 struct urec16 { int x, y, z, w; };
+inline void sched_fence() {}
 inline urec16 uload16(const void* p) { urec16 r; std::memcpy(&r, p, 16); return r; }
+struct urec32 { int v[8]; };
+inline urec32 uload32(const void* p) { urec32 r; std::memcpy(&r, p, 32); return r; }
 // uniform-base buffer view (device: buffer descriptor in SGPRs + scalar offset + per-lane voffset)
 struct ubuf { float* p; };
 inline ubuf ub_make(const float* p, size_t) { return ubuf{const_cast<float*>(p)}; }
@@ -182,6 +185,8 @@ DEV void tape_zero(vtape& t) { PINN_UNROLL for (int i = 0; i < 32; ++i) t[i] = 0
 // 16-byte record at a wave-uniform, read-only address, fetched through the scalar cache (s_load_dwordx4) into SGPRs.
 // A plain load is not scalarised because the kernel also stores to global memory: it becomes global_load + vmcnt(0)
 // (which also drains every outstanding record store) and its fields need waterfall loops to be used as register indices.
+// the instruction scheduler may not move anything across this point (keeps a block of prefetch loads where it was written)
+DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 struct urec16 { int x, y, z, w; };
 DEV urec16 uload16(const void* p) {
     typedef int i4 __attribute__((ext_vector_type(4)));
@@ -191,6 +196,16 @@ DEV urec16 uload16(const void* p) {
     const unsigned long long u = (unsigned long long)lo | ((unsigned long long)hi << 32);
     const i4 v = *(const __attribute__((address_space(4))) i4*)u;
     return {v.x, v.y, v.z, v.w};
+}
+struct urec32 { int v[8]; };
+DEV urec32 uload32(const void* p) {                          // s_load_dwordx8
+    typedef int i8 __attribute__((ext_vector_type(8)));
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    const unsigned long long u = (unsigned long long)lo | ((unsigned long long)hi << 32);
+    const i8 v = *(const __attribute__((address_space(4))) i8*)u;
+    return {{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]}};
 }
 struct ubuf { __amdgpu_buffer_rsrc_t r; };
 typedef unsigned vuint4 __attribute__((ext_vector_type(4)));
