@@ -1382,6 +1382,12 @@ int pinn_describe(pinn_handle h, char* buf, int64_t buflen) {
         for (int t : G.terms) os << t << ",";
         os << "\n";
     }
+    for (size_t t = 0; t < h->terms.size(); ++t) {
+        const Term& T = h->terms[t];
+        if (T.coupled >= 0) continue;
+        os << "term " << t << ": tape ops=" << T.tape_ops.size() << " of " << T.ops.size() << ", sources=" << T.src_root.size()
+           << " (" << T.src_prog.size() << " coordinate-only ops evaluated per point set)\n";
+    }
     std::string s = os.str();
     std::snprintf(buf, (size_t)buflen, "%s", s.c_str());
     return 0;

@@ -449,9 +449,10 @@ Sr[q][m] = ub_load4(SB, (((layer * NG) + q) * MT + m) * 256, lane << 2);
                     lds_store(ta, vint(ins.a * 64) + lane, lds_load(ta, vint(ins.a * 64) + lane) + da);
                     lds_store(ta, vint(ins.b * 64) + lane, lds_load(ta, vint(ins.b * 64) + lane) + db);
                 }
-                PINN_UNROLL for (int ch = 0; ch < C; ++ch) ubar[pg][ch] = rbar * lds_load(ta, vint((D + NP + ch) * 64) + lane);
+                PINN_UNROLL for (int ch = 0; ch < C; ++ch)       // masked points may hold inf/NaN (their sources read as 0)
+                    ubar[pg][ch] = vselect(valid[pg], rbar * lds_load(ta, vint((D + NP + ch) * 64) + lane), vfloat(0.f));
                 for (int j = 0; j < ga.nparams_estim; ++j) {
-                    vfloat pj = vselect(g0, rbar * lds_load(ta, vint((D + j) * 64) + lane), vfloat(0.f));
+                    vfloat pj = vselect(vand(g0, valid[pg]), rbar * lds_load(ta, vint((D + j) * 64) + lane), vfloat(0.f));
                     PINN_UNROLL for (int jj = 0; jj < MAX_PARAMS; ++jj) if (jj == j) pbar[jj] += pj;
                 }
             }

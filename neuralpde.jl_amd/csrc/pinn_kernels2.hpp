@@ -352,9 +352,9 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         tape_set(ta, ins.b, tape_get(ta, ins.b) + db);
                     }
                     PINN_UNROLL for (int ch = 0; ch < C; ++ch)
-                        lds_store(UB, vint((w * C + ch) * 16) + c, rbar * tape_get(ta, D + NP + ch));   // 4 row groups: same value
+                        lds_store(UB, vint((w * C + ch) * 16) + c, vselect(vin, rbar * tape_get(ta, D + NP + ch), vfloat(0.f)));   // 4 row groups: same value; masked points may hold inf/NaN
                     for (int j = 0; j < ga.nparams_estim; ++j) {
-                        vfloat pj = vselect(g0, rbar * tape_get(ta, D + j), vfloat(0.f));
+                        vfloat pj = vselect(vand(g0, vin), rbar * tape_get(ta, D + j), vfloat(0.f));
                         PINN_UNROLL for (int jj = 0; jj < MAX_PARAMS; ++jj) if (jj == j) pbar[jj] += pj;
                     }
                 }

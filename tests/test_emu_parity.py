@@ -237,3 +237,36 @@ def test_resident_adam_matches_host_adam_and_sampler(npde, use_emu):
     assert lb[0] == ub[0] == 0.0 and n == 32          # bc u(0, y): x pinned to 0, y in [1/64, 1 - 1/64]
     r = rep.engine.residual(1, res.u, 32)              # runs on the device-sampled set
     assert r.shape == (32,) and np.all(np.isfinite(r))
+
+
+def test_hoisted_sources_and_mixed_ops(npde, use_emu):
+    """coordinate-only subexpressions (variable coefficients, source terms, boundary data) are evaluated by k_src once per
+    point set; what stays in the fused tape mixes dispatch-free arithmetic with transcendental ops of u."""
+    x, y = npde.parameters("x y")
+    (u,) = npde.variables("u")
+    Dx, Dy = npde.Differential(x), npde.Differential(y)
+    Dxx, Dyy = Dx ** 2, Dy ** 2
+    U = u(x, y)
+    a = sp.exp(-x) * sp.cos(y)                          # used twice: as a coefficient and inside the source
+    eq = npde.Eq(a * Dxx(U) + (1 + x * y) * Dyy(U) + sp.sin(U) * Dx(U) - U ** 2 / (2 + sp.cos(x)),
+                 a * sp.sin(sp.pi * x) + sp.sqrt(1 + y) - 3.0)
+    bcs = [npde.Eq(u(0, y), sp.cos(sp.pi * y) * sp.exp(y)), npde.Eq(u(x, 1), x ** 3 - x), npde.Eq(Dx(u(1, y)), 0.5)]
+    dom = [npde.In(x, npde.Interval(0.0, 1.0)), npde.In(y, npde.Interval(0.0, 1.0))]
+    sysm = npde.PDESystem([eq], bcs, dom, [x, y], [U])
+    for width, seed in ((16, 21), (64, 22)):            # family 1 (LDS tape) and family 2 (register tape, one tape wave per point group)
+        hidden = 2 if width == 16 else 4                # compiled kernels: 2 x 16 (family 1), 4 x 64 (family 2)
+        chain = npde.Chain(npde.Dense(2, width, "tanh"), *[npde.Dense(width, width, "tanh") for _ in range(hidden - 1)], npde.Dense(width, 1))
+        strat = npde.QuasiRandomTraining(50, bcs_points=37, sampling_alg=npde.SobolSample(seed=8), resampling=False, minibatch=1)
+        rep, prob, sets, th = check(npde, sysm, [chain], strat, theta_for(chain, seed), weights=[1.0, 2.0, 0.5, 3.0])
+        assert "sources" in rep.engine.describe()
+        r = rep.loss_functions.datafree_pde_loss_functions[0](sets[0], th)
+        np.testing.assert_allclose(r, po.residual_values(prob, th, 0, sets[0]), rtol=2e-5, atol=2e-5)
+        # a new point set re-evaluates the sources
+        new = [s[:, ::-1].copy() * 0.9 + 0.05 for s in sets]
+        new[1][0, :] = 0.0; new[2][1, :] = 1.0; new[3][0, :] = 1.0
+        for k, s in enumerate(new):
+            rep.engine.set_points(k, s)
+        losses, grad = rep.engine.loss_grad(th, [1.0, 2.0, 0.5, 3.0])
+        ref = po.loss_and_grad(prob, th, new, weights=[1.0, 2.0, 0.5, 3.0], mode="stencil")
+        le, g2, gi = helpers.rel_errors(losses, grad, ref)
+        assert le.max() < TOL and g2 < TOL and gi < TOL, (le, g2, gi)
