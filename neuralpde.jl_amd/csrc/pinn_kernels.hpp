@@ -367,8 +367,7 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                 vfloat s = vfloat(0.f);
                 PINN_UNROLL for (int m = 0; m < MT; ++m)
                     PINN_UNROLL for (int r = 0; r < 4; ++r) s = vfma(wL[m][r], A[pg * C + ch][m][r], s);
-                s = s + shfl_xor(s, 16);
-                s = s + shfl_xor(s, 32);
+                s = xrow_allsum(s);
                 U[pg][ch] = (ch == 0) ? s + vfloat(bL) : s;
             }
 
@@ -691,31 +690,25 @@ Sr[q][m] = ub_load4(SB, (((layer * NG) + q) * MT + m) * 256, lane << 2);
             PINN_UNROLL for (int ti = 0; ti < MT; ++ti)
                 gstore4(big + S::O_WBAR + hl * HP * HP, vint((trow * MT + ti) * 256) + (lane << 2), wbar[hl][to][ti]);
             vfloat v = bfrh[hl][to];
-            v = v + shfl_xor(v, 16);
-            v = v + shfl_xor(v, 32);
+            v = xrow_allsum(v);
             gstore_masked(big + S::O_BFRH, vint((hl * MT + trow) * 16) + c, v, g0);
         }
     PINN_UNROLL for (int to = 0; to < MT; ++to) {
         vfloat v = bfr0[to];
-        v = v + shfl_xor(v, 16);
-        v = v + shfl_xor(v, 32);
+        v = xrow_allsum(v);
         gstore_masked(mine + S::O_BFR0, vint(to * 16) + c, v, g0);
     }
     PINN_UNROLL for (int i = 0; i < D; ++i)
         PINN_UNROLL for (int to = 0; to < MT; ++to) {
             vfloat v = w1fr[i][to];
-            v = v + shfl_xor(v, 16);
-            v = v + shfl_xor(v, 32);
+            v = xrow_allsum(v);
             gstore_masked(mine + S::O_W1, vint((i * MT + to) * 16) + c, v, g0);
         }
     const vbool c0 = veq(c, 0);
     PINN_UNROLL for (int m = 0; m < MT; ++m)
         PINN_UNROLL for (int r = 0; r < 4; ++r) {
             vfloat v = wLbar[m][r];
-            v = v + shfl_xor(v, 1);
-            v = v + shfl_xor(v, 2);
-            v = v + shfl_xor(v, 4);
-            v = v + shfl_xor(v, 8);
+            v = row_allsum16(v);
             gstore_masked(mine + S::O_WL, ((vint(m * 4) + g) << 2) + vint(r), v, c0);
         }
     {

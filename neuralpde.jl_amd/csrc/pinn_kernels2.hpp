@@ -17,9 +17,9 @@
 // Profiling build only (tools/stamp_profile.sh): per-wave cycle counters per phase of a tile, written to the tail of the
 // workgroup's gradient slab (beyond the reduced entries).  Never defined for the product or the emulation library.
 #if defined(PINN_STAMP) && !defined(PINN_EMU)
-#define STAMP_DECL unsigned st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#define STAMP_DECL unsigned st_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_last = __builtin_amdgcn_s_memtime();
 #define STAMP(i) { const unsigned long long st_now = __builtin_amdgcn_s_memtime(); st_acc[i] += (unsigned)(st_now - st_last); st_last = st_now; }
-#define STAMP_EXTRA 64
+#define STAMP_EXTRA 128
 #else
 #define STAMP_DECL
 #define STAMP(i)
@@ -266,8 +266,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                 vfloat s = vfloat(0.f);
                 PINN_UNROLL for (int t = 0; t < MTW; ++t)
                     PINN_UNROLL for (int r = 0; r < 4; ++r) s = vfma(wL[t][r], A[q][t][r], s);
-                s = s + shfl_xor(s, 16);
-                s = s + shfl_xor(s, 32);
+                s = xrow_allsum(s);
                 lds_store(UP, vint((w * NG + q) * 16) + c, s);             // all four row groups hold the same value
             }
             wg_barrier();
@@ -565,10 +564,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                     gstore4(slab + S::O_WBAR, vint((((hl * MT + w * MTW + t) * MT + ti) * 64) * 4) + (lane << 2), wbar[hl][t][ti]);
     const vbool c0 = veq(c, 0);
     auto reduce_cols = [&](vfloat v) -> vfloat {       // sum over the 16 column lanes of a row group
-        v = v + shfl_xor(v, 1);
-        v = v + shfl_xor(v, 2);
-        v = v + shfl_xor(v, 4);
-        v = v + shfl_xor(v, 8);
+        v = row_allsum16(v);
         return v;
     };
     PINN_UNROLL for (int t = 0; t < MTW; ++t)
@@ -598,7 +594,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
 #if defined(PINN_STAMP) && !defined(PINN_EMU)
     STAMP(14)
     if ((threadIdx.x & 63) == 0)
-        for (int i = 0; i < 16; ++i) reinterpret_cast<unsigned*>(slab + S::SLAB - 64)[w * 16 + i] = st_acc[i];
+        for (int i = 0; i < 24; ++i) reinterpret_cast<unsigned*>(slab + S::SLAB - 128)[w * 24 + i] = st_acc[i];
 #endif
 }
 

@@ -107,6 +107,18 @@ extern thread_local void* emu_barrier_ctx;
 inline void wg_barrier() { if (emu_barrier_hook) emu_barrier_hook(emu_barrier_ctx); }
 // cross-lane
 inline vfloat shfl_xor(const vfloat& a, int m) { vfloat r; for (int l = 0; l < W; ++l) r.v[l] = a.v[l ^ m]; return r; }
+// all-reduce sums without LDS traffic (device: DPP row rotations / gfx950 permlane swaps)
+inline vfloat row_allsum16(const vfloat& a) {            // over the 16 lanes of each row (lanes sharing l >> 4)
+    vfloat v = a;
+    for (int n : {8, 4, 2, 1}) { vfloat r; for (int l = 0; l < W; ++l) r.v[l] = v.v[l] + v.v[(l & ~15) | ((l - n) & 15)]; v = r; }
+    return v;
+}
+inline vfloat xrow_allsum(const vfloat& a) {             // over the 4 rows (lanes sharing l & 15)
+    vfloat s, t;
+    for (int l = 0; l < W; ++l) s.v[l] = a.v[l & ~16] + a.v[l | 16];
+    for (int l = 0; l < W; ++l) t.v[l] = s.v[l & ~32] + s.v[l | 32];
+    return t;
+}
 inline float lane0(const vfloat& a) { return a.v[0]; }
 inline double wave_sum_d(const vfloat& a, const vbool& m) { double s = 0; for (int l = 0; l < W; ++l) if (m.v[l]) s += (double)a.v[l]; return s; }
 // v_mfma_f32_16x16x4_f32: D[i][j] += sum_k A[i][k] B[k][j]; lane l supplies A[i=l&15][k=l>>4] and
@@ -239,6 +251,23 @@ DEV void wave_fence() {
 }
 DEV void wg_barrier() { __syncthreads(); }
 DEV vfloat shfl_xor(vfloat a, int m) { return __shfl_xor(a, m, 64); }
+// all-reduce sums without LDS traffic: v_add_f32_dpp row_ror within the 16-lane rows, v_permlane16/32_swap (gfx950) across rows
+template <int CTRL> DEV float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+DEV vfloat row_allsum16(vfloat v) {
+    v += dpp_mov<0x128>(v); v += dpp_mov<0x124>(v); v += dpp_mov<0x122>(v); v += dpp_mov<0x121>(v);
+    return v;
+}
+DEV vfloat xrow_allsum(vfloat v) {
+    // inline asm: with this compiler the second result of __builtin_amdgcn_permlane{16,32}_swap is mis-selected (the sum
+    // came out as r[0] + r[0]).  swap16: odd rows of a <-> even rows of b; swap32: rows 2,3 of a <-> rows 0,1 of b.
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    float s = a + b, t = s;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(s), "+v"(t));
+    return s + t;
+}
 DEV float lane0(vfloat a) { return __builtin_amdgcn_readfirstlane(a); }
 DEV double wave_sum_d(vfloat a, vbool m) {
     double s = m ? (double)a : 0.0;

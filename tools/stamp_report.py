@@ -9,7 +9,7 @@ m = pinn_import.load()
 from neuralpde_jl_amd import workloads
 PH = ["0 coords+layer0+act0", "1 publish+barrier (fwd)", "2 fwd GEMM (+W/b loads)", "3 act_forward (+record st)", "4 out layer+barrier+U",
       "5 tape", "6 out adjoint+act_adj(last)", "7 record ld+publish+stage", "8 barrier (staged)", "9 dW GEMM", "10 dA GEMM",
-      "11 barrier (X free)", "12 act_adjoint", "13 layer-0 grads", "14 epilogue", "15 loop top"]
+      "11 barrier (X free)", "12 act_adjoint", "13 layer-0 grads", "14 epilogue", "15 loop top", "16 tape: setup (zero, inputs, sources)", "17 tape: forward ops", "18 tape: adjoint ops", "19 tape: seeds -> LDS", "20", "21", "22", "23"]
 tag = sys.argv[1] if len(sys.argv) > 1 else ""
 path = os.path.join(ROOT, "neuralpde.jl_amd", "csrc", "abl", f"libpinn_stamp{tag}.so")
 lib = m.Library(path)
@@ -25,12 +25,12 @@ dbg = lib.lib.pinn_debug_slab
 dbg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int64]
 for g, info in enumerate(gt):
     nb = dbg(eng.h, g, -1, None, 0)
-    acc = np.zeros((4, 16))
-    buf = np.zeros(64, dtype=np.float32)
+    acc = np.zeros((4, 24))
+    buf = np.zeros(128, dtype=np.float32)
     nsample = min(nb, 64)
     for b in np.linspace(0, nb - 1, nsample).astype(int):
-        assert dbg(eng.h, g, int(b), buf.ctypes.data_as(C.POINTER(C.c_float)), 64) == 0
-        acc += buf.view(np.uint32).reshape(4, 16)
+        assert dbg(eng.h, g, int(b), buf.ctypes.data_as(C.POINTER(C.c_float)), 128) == 0
+        acc += buf.view(np.uint32)[:96].reshape(4, 24)
     acc /= nsample
     tiles_per_wg = info["tiles"] / nb
     tot = acc.sum(axis=1)
