@@ -38,4 +38,6 @@ for g, info in enumerate(gt):
           + " ".join(f"{t:.0f}" for t in tot) + f"  = {tot[0]/info['ms']/1e3:.0f} MHz counter")
     print(f"  {'phase':32s} " + " ".join(f"{'w'+str(w):>9s}" for w in range(4)) + "   share(w0)   cyc/tile(w0)")
     for i, name in enumerate(PH):
+        if not acc[:, i].any():
+            continue
         print(f"  {name:32s} " + " ".join(f"{acc[w, i]:9.0f}" for w in range(4)) + f"   {100*acc[0,i]/tot[0]:6.1f} %   {acc[0,i]/tiles_per_wg:9.0f}")
