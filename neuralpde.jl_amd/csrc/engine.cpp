@@ -232,11 +232,14 @@ int parse_descriptor(const char* text, pinn_engine& E) {
         for (int s = 0; s < ns; ++s) {
             Slot& S = T.slots[s];
             if (!expect("slot") || !(in >> S.net >> S.order)) return fail("descriptor: slot line");
-            if (S.order < 0 || S.order > 2) return fail("derivative order > 2 is not supported yet by the HIP engine");
+            if (S.order < 0 || S.order > 4) return fail("derivative order > 4 is not supported by the HIP engine");
             if (S.net < 0 || S.net >= nn) return fail("descriptor: slot net id");
             for (int a = 0; a < S.order; ++a)
                 if (!(in >> S.axes[a])) return fail("descriptor: slot axes");
             if (S.order == 2 && S.axes[0] > S.axes[1]) std::swap(S.axes[0], S.axes[1]);
+            if (S.order >= 3)
+                for (int a = 1; a < S.order; ++a)
+                    if (S.axes[a] != S.axes[0]) return fail("mixed derivatives of order > 2 are not supported by the HIP engine (pure d^3/dx^3, d^4/dx^4 are)");
         }
         T.ops.resize(no);
         for (int q = 0; q < no; ++q) {
@@ -319,12 +322,14 @@ int round_hp(int h) {
 }
 
 const pk::SpecInfo* find_spec(int HP, int NHH, int D, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs,
-                              std::vector<int>* pair_index) {
+                              unsigned need_hi, std::vector<int>* pair_index) {
     const pk::SpecInfo* best = nullptr;
     for (const pk::SpecInfo& s : pk::registry()) {
         if (s.HP != HP || s.NHH != NHH || s.D != D) continue;
         if ((s.D1MASK & need_first) != need_first) continue;
         bool ok = true;
+        for (int a = 0; a < 8; ++a)
+            if (((need_hi >> (4 * a)) & 0xF) > ((s.HI >> (4 * a)) & 0xF)) ok = false;
         for (auto& pr : need_pairs) {
             bool f = false;
             for (int p = 0; p < s.NPAIR; ++p) {
@@ -354,6 +359,16 @@ int first_rank(const pk::SpecInfo& s, int axis) {
 int chan_of(const pk::SpecInfo& s, const Slot& sl) {
     if (sl.order == 0) return 0;
     if (sl.order == 1) return 1 + first_rank(s, sl.axes[0]);
+    if (sl.order >= 3) {             // pure third / fourth derivative: channels after the pairs, thirds first
+        int n3 = 0, n3_before = 0, n4_before = 0;
+        for (int a = 0; a < 8; ++a) {
+            const int h = (int)((s.HI >> (4 * a)) & 0xF);
+            if (h >= 3) { ++n3; if (a < sl.axes[0]) ++n3_before; }
+            if (h >= 4 && a < sl.axes[0]) ++n4_before;
+        }
+        if ((int)((s.HI >> (4 * sl.axes[0])) & 0xF) < sl.order) return -1;
+        return sl.order == 3 ? 1 + s.NFIRST + s.NPAIR + n3_before : 1 + s.NFIRST + s.NPAIR + n3 + n4_before;
+    }
     for (int p = 0; p < s.NPAIR; ++p) {
         int a = (int)((s.PAIRS >> (8 * p)) & 0xF), b = (int)((s.PAIRS >> (8 * p + 4)) & 0xF);
         if (a == sl.axes[0] && b == sl.axes[1]) return 1 + s.NFIRST + p;
@@ -363,7 +378,7 @@ int chan_of(const pk::SpecInfo& s, const Slot& sl) {
 
 std::string spec_name(const pk::SpecInfo& s) {
     char b[160];
-    std::snprintf(b, sizeof b, "F%d_HP%d_NHH%d_D%d_F%x_P%llx_PG%d(C=%d)", s.family, s.HP, s.NHH, s.D, s.D1MASK, s.PAIRS, s.PG, s.C);
+    std::snprintf(b, sizeof b, "F%d_HP%d_NHH%d_D%d_F%x_P%llx_H%x_PG%d(C=%d)", s.family, s.HP, s.NHH, s.D, s.D1MASK, s.PAIRS, s.HI, s.PG, s.C);
     return b;
 }
 
@@ -377,33 +392,37 @@ int build_plan(pinn_engine& E) {
     if (E.ne > 0 && (E.p_theta_off < 0 || E.p_theta_off + E.ne > E.ntheta)) return fail("descriptor: theta.p exceeds ntheta");
 
     // ---- terms -> groups ----
-    auto needs_of = [&](const Term& T, int net, unsigned& need_first, std::vector<std::pair<int, int>>& need_pairs) -> int {
+    auto needs_of = [&](const Term& T, int net, unsigned& need_first, std::vector<std::pair<int, int>>& need_pairs, unsigned& need_hi) -> int {
         for (auto& s : T.slots) {
             if (s.net != net) continue;
             for (int a = 0; a < s.order; ++a) {
                 if (s.axes[a] < 0 || s.axes[a] >= T.d) return fail("descriptor: slot axis out of range");
                 need_first |= 1u << s.axes[a];
             }
-            if (s.order == 2) {
+            if (s.order >= 2) {        // (orders 3, 4 are pure: they also need the pure second derivative of their axis)
                 auto pr = std::make_pair(s.axes[0], s.axes[1]);
                 if (std::find(need_pairs.begin(), need_pairs.end(), pr) == need_pairs.end()) need_pairs.push_back(pr);
+            }
+            if (s.order >= 3) {
+                const unsigned cur = (need_hi >> (4 * s.axes[0])) & 0xF;
+                if ((unsigned)s.order > cur) need_hi = (need_hi & ~(0xFu << (4 * s.axes[0]))) | ((unsigned)s.order << (4 * s.axes[0]));
             }
         }
         return 0;
     };
-    auto spec_for = [&](size_t t, int net, int d, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs,
+    auto spec_for = [&](size_t t, int net, int d, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs, unsigned need_hi,
                         const pk::SpecInfo*& sp) -> int {
         const Net& N = E.nets[net];
         if (N.sizes[0] != d)
             return fail("term " + std::to_string(t) + ": network input dimension differs from the term's coordinate count (heterogeneous inputs are not supported yet)");
         const int LH = (int)N.sizes.size() - 2;
         const int HP = round_hp(N.maxhidden());
-        sp = find_spec(HP, LH - 1, d, need_first, need_pairs, nullptr);
+        sp = find_spec(HP, LH - 1, d, need_first, need_pairs, need_hi, nullptr);
         if (!sp) {
             char b[256];
             std::snprintf(b, sizeof b,
-                          "term %zu: no compiled kernel for hidden width %d (padded %d), %d hidden layers, d=%d, first-derivative axes mask 0x%x, %zu second derivatives; add a PINN_INSTANTIATE line in csrc/inst_*.hip",
-                          t, N.maxhidden(), HP, LH, d, need_first, need_pairs.size());
+                          "term %zu: no compiled kernel for hidden width %d (padded %d), %d hidden layers, d=%d, first-derivative axes mask 0x%x, %zu second derivatives, higher-order mask 0x%x; add a PINN_INSTANTIATE line in csrc/inst_*.hip",
+                          t, N.maxhidden(), HP, LH, d, need_first, need_pairs.size(), need_hi);
             return fail(b);
         }
         return 0;
@@ -412,6 +431,7 @@ int build_plan(pinn_engine& E) {
     std::vector<std::vector<int>> term_nets(E.terms.size());
     std::map<int, std::pair<unsigned, std::vector<std::pair<int, int>>>> coupled_needs;   // net -> needs
     std::map<int, int> coupled_dim;
+    std::map<int, unsigned> coupled_hi;
     for (size_t t = 0; t < E.terms.size(); ++t) {
         Term& T = E.terms[t];
         for (auto& s : T.slots)
@@ -421,7 +441,7 @@ int build_plan(pinn_engine& E) {
         if (term_nets[t].size() > 1)
             for (int net : term_nets[t]) {
                 auto& nd = coupled_needs[net];
-                if (needs_of(T, net, nd.first, nd.second)) return 1;
+                if (needs_of(T, net, nd.first, nd.second, coupled_hi[net])) return 1;
                 if (coupled_dim.count(net) && coupled_dim[net] != T.d) return fail("coupled terms of one network must bind the same variables");
                 coupled_dim[net] = T.d;
             }
@@ -434,9 +454,10 @@ int build_plan(pinn_engine& E) {
             T.net = net;
             unsigned need_first = 0;
             std::vector<std::pair<int, int>> need_pairs;
-            if (needs_of(T, net, need_first, need_pairs)) return 1;
+            unsigned need_hi = 0;
+            if (needs_of(T, net, need_first, need_pairs, need_hi)) return 1;
             const pk::SpecInfo* sp = nullptr;
-            if (spec_for(t, net, T.d, need_first, need_pairs, sp)) return 1;
+            if (spec_for(t, net, T.d, need_first, need_pairs, need_hi, sp)) return 1;
             T.chan_of_slot.clear();
             for (auto& s : T.slots) {
                 int c = chan_of(*sp, s);
@@ -476,7 +497,7 @@ int build_plan(pinn_engine& E) {
             const int net = Cp.nets[i];
             if (!coupled_group.count(net)) {
                 const pk::SpecInfo* sp = nullptr;
-                if (spec_for(t, net, T.d, coupled_needs[net].first, coupled_needs[net].second, sp)) return 1;
+                if (spec_for(t, net, T.d, coupled_needs[net].first, coupled_needs[net].second, coupled_hi[net], sp)) return 1;
                 E.groups.emplace_back();
                 Group& G = E.groups.back();
                 G.kind = 1;
@@ -1196,7 +1217,7 @@ int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float*
     if (n <= 0) return fail("pinn_phi: n must be positive");
     const Net& N = E.nets[net];
     const int LH = (int)N.sizes.size() - 2;
-    const pk::SpecInfo* sp = find_spec(round_hp(N.maxhidden()), LH - 1, N.sizes[0], 0, {}, nullptr);
+    const pk::SpecInfo* sp = find_spec(round_hp(N.maxhidden()), LH - 1, N.sizes[0], 0, {}, 0u, nullptr);
     if (!sp) return fail("pinn_phi: no compiled value-only kernel for this network shape");
     if (!E.netplans[net].spec) return fail("pinn_phi: network is not used by any term");
     if (upload_theta(E, theta, p)) return 1;

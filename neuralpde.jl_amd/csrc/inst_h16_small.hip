@@ -7,3 +7,9 @@ PINN_INSTANTIATE(h16n1d1_val, 16, 1, 1, 0x0, 0ull, 0, 2)
 // single-hidden-layer nets (e.g. the reference's system-of-PDEs test chains Dense(2,15,tanh) -> Dense(15,1))
 PINN_INSTANTIATE(h16n0d2_hess, 16, 0, 2, 0x3, (PINN_PAIR(0, 0, 0) | PINN_PAIR(1, 0, 1) | PINN_PAIR(2, 1, 1)), 3, 1)
 PINN_INSTANTIATE(h16n0d2_val, 16, 0, 2, 0x0, 0ull, 0, 2)
+// pure third / fourth derivatives: 1-D nets (the reference's 3rd-order ODE test, test/NNPDE1/nnpde__pde_iii_3rd_order_ode.jl)
+// and the 2-D Kuramoto-Sivashinsky set u, u_t, u_x, u_xx, u_xxx, u_xxxx (docs/src/examples/ks.md:45-46)
+PINN_INSTANTIATE_HI(h16n1d1_o4, 16, 1, 1, 0x1, PINN_PAIR(0, 0, 0), 1, 1, PINN_HI(0, 4))
+PINN_INSTANTIATE_HI(h16n0d1_o4, 16, 0, 1, 0x1, PINN_PAIR(0, 0, 0), 1, 1, PINN_HI(0, 4))
+PINN_INSTANTIATE_HI(h16n1d2_ks, 16, 1, 2, 0x3, PINN_PAIR(0, 1, 1), 1, 1, PINN_HI(1, 4))      // u(t, x)
+PINN_INSTANTIATE_HI(h16n1d2_ks0, 16, 1, 2, 0x3, PINN_PAIR(0, 0, 0), 1, 1, PINN_HI(0, 4))     // u(x, t) as in docs/src/examples/ks.md

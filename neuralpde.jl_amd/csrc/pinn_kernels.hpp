@@ -46,10 +46,68 @@ constexpr int MAX_GROUP_TERMS = 12;
 constexpr int MAX_PARAMS = 4;
 
 // ------------------------------------------------------------------------------------------------
+// The jet-channel set of a kernel: which derivatives of the trial function travel through the layers.
+//   channel 0                        u
+//   1 .. NFIRST                      du/dx_a            for the axes a in D1MASK
+//   then NPAIR                       d2u/dx_a dx_b      pairs (a <= b) packed one per byte in PAIRS
+//   then N3                          d3u/dx_a^3         axes whose nibble in HI is >= 3
+//   then N4                          d4u/dx_a^4         axes whose nibble in HI is 4
+// (pure third / fourth derivatives need the lower pure derivatives of the same axis: first(a), pair(a,a), third(a).)
+// ------------------------------------------------------------------------------------------------
+template <unsigned D1MASK_, unsigned long long PAIRS_, int NPAIR_, unsigned HI_>
+struct JetSet {
+    static constexpr int popc(unsigned x) { int n = 0; while (x) { n += x & 1; x >>= 1; } return n; }
+    static constexpr int NFIRST = popc(D1MASK_);
+    static constexpr int NPAIR = NPAIR_;
+    static constexpr int first_axis(int k) {
+        int cnt = 0;
+        for (int a = 0; a < 8; ++a)
+            if (D1MASK_ & (1u << a)) { if (cnt == k) return a; ++cnt; }
+        return -1;
+    }
+    static constexpr int first_rank(int axis) {
+        int cnt = 0;
+        for (int a = 0; a < axis; ++a) if (D1MASK_ & (1u << a)) ++cnt;
+        return cnt;
+    }
+    static constexpr int pair_a(int p) { return (int)((PAIRS_ >> (8 * p)) & 0xF); }
+    static constexpr int pair_b(int p) { return (int)((PAIRS_ >> (8 * p + 4)) & 0xF); }
+    static constexpr int pair_index(int a, int b) {
+        for (int p = 0; p < NPAIR_; ++p) if (pair_a(p) == a && pair_b(p) == b) return p;
+        return -1;
+    }
+    static constexpr int hi_order(int axis) { return (int)((HI_ >> (4 * axis)) & 0xF); }
+    static constexpr int hi_count(int k) { int n = 0; for (int a = 0; a < 8; ++a) if (hi_order(a) >= k) ++n; return n; }
+    static constexpr int hi_axis(int k, int idx) {
+        int cnt = 0;
+        for (int a = 0; a < 8; ++a)
+            if (hi_order(a) >= k) { if (cnt == idx) return a; ++cnt; }
+        return -1;
+    }
+    static constexpr int hi_rank(int k, int axis) { int n = 0; for (int a = 0; a < axis; ++a) if (hi_order(a) >= k) ++n; return n; }
+    static constexpr int N3 = hi_count(3), N4 = hi_count(4);
+    static constexpr int C = 1 + NFIRST + NPAIR_ + N3 + N4;
+    static constexpr int CH_FIRST = 1, CH_PAIR = 1 + NFIRST, CH_3 = CH_PAIR + NPAIR_, CH_4 = CH_3 + N3;
+    static constexpr bool valid() {
+        for (int a = 0; a < 8; ++a) {
+            const int h = hi_order(a);
+            if (h != 0 && h != 3 && h != 4) return false;
+            if (h && (!(D1MASK_ & (1u << a)) || pair_index(a, a) < 0)) return false;
+        }
+        return true;
+    }
+    static_assert(valid(), "third/fourth derivative channels need first(a) and pair(a,a) of the same axis");
+    // derivatives of the activation needed by the reverse sweep (one more than the highest jet order)
+    static constexpr int NORD = N4 > 0 ? 5 : (N3 > 0 ? 4 : 3);
+};
+
+// ------------------------------------------------------------------------------------------------
 // compile-time description of one kernel family member
 // ------------------------------------------------------------------------------------------------
-template <int HP_, int NHH_, int D_, unsigned D1MASK_, unsigned long long PAIRS_, int NPAIR_, int PG_>
+template <int HP_, int NHH_, int D_, unsigned D1MASK_, unsigned long long PAIRS_, int NPAIR_, int PG_, unsigned HI_ = 0>
 struct Spec {
+    using J = JetSet<D1MASK_, PAIRS_, NPAIR_, HI_>;
+    static constexpr unsigned HI = HI_;
     static constexpr int HP = HP_;            // padded hidden width (multiple of 16)
     static constexpr int MT = HP_ / 16;       // 16-neuron tiles per layer
     static constexpr int NHH = NHH_;          // hidden->hidden layers
@@ -59,26 +117,14 @@ struct Spec {
     static constexpr unsigned long long PAIRS = PAIRS_;
     static constexpr int NPAIR = NPAIR_;
     static constexpr int PG = PG_;            // 16-point groups per tile
-    static constexpr int popc(unsigned x) { int n = 0; while (x) { n += x & 1; x >>= 1; } return n; }
-    static constexpr int NFIRST = popc(D1MASK_);
-    static constexpr int C = 1 + NFIRST + NPAIR_;
+    static constexpr int NFIRST = J::NFIRST;
+    static constexpr int C = J::C;
     static constexpr int NG = C * PG_;
     static constexpr int TP = 16 * PG_;       // points per tile
-    // k-th first-order axis
-    static constexpr int first_axis(int k) {
-        int cnt = 0;
-        for (int a = 0; a < 8; ++a)
-            if (D1MASK_ & (1u << a)) { if (cnt == k) return a; ++cnt; }
-        return -1;
-    }
-    // rank of axis among first-order channels
-    static constexpr int first_rank(int axis) {
-        int cnt = 0;
-        for (int a = 0; a < axis; ++a) if (D1MASK_ & (1u << a)) ++cnt;
-        return cnt;
-    }
-    static constexpr int pair_a(int p) { return (int)((PAIRS_ >> (8 * p)) & 0xF); }
-    static constexpr int pair_b(int p) { return (int)((PAIRS_ >> (8 * p + 4)) & 0xF); }
+    static constexpr int first_axis(int k) { return J::first_axis(k); }       // k-th first-order axis
+    static constexpr int first_rank(int axis) { return J::first_rank(axis); } // rank of axis among first-order channels
+    static constexpr int pair_a(int p) { return J::pair_a(p); }
+    static constexpr int pair_b(int p) { return J::pair_b(p); }
     // packed parameter buffer (floats)
     static constexpr int OFF_W1 = 0;                       // [D][HP]
     static constexpr int OFF_B = OFF_W1 + D_ * HP_;        // [LH][HP]
@@ -160,6 +206,101 @@ DEV void act_derivs(vfloat a, vfloat& d1, vfloat& d2, vfloat& d3) {
         d3 = d1 * (vfloat(1.0f) - vfloat(6.0f) * d1);
     }
 }
+// derivatives phi', ..., phi^(NORD) of the activation from a = phi(z)   (d[0] unused)
+template <int NORD>
+DEV void act_derivs_n(int act, vfloat a, vfloat (&d)[6]) {
+    if (act == ACT_TANH) {
+        const vfloat a2 = a * a;
+        d[1] = vfloat(1.0f) - a2;
+        d[2] = vfloat(-2.0f) * a * d[1];
+        d[3] = d[1] * (vfloat(6.0f) * a2 - vfloat(2.0f));
+        if (NORD >= 4) d[4] = d[1] * a * (vfloat(16.0f) - vfloat(24.0f) * a2);
+        if (NORD >= 5) d[5] = d[1] * (vfma(vfma(vfloat(120.0f), a2, vfloat(-120.0f)), a2, vfloat(16.0f)));
+    } else {
+        d[1] = a * (vfloat(1.0f) - a);
+        d[2] = d[1] * (vfloat(1.0f) - vfloat(2.0f) * a);
+        d[3] = d[1] * (vfloat(1.0f) - vfloat(6.0f) * d[1]);
+        if (NORD >= 4) d[4] = d[2] * (vfloat(1.0f) - vfloat(12.0f) * d[1]);
+        if (NORD >= 5) d[5] = d[3] * (vfloat(1.0f) - vfloat(12.0f) * d[1]) - vfloat(12.0f) * d[2] * d[2];
+    }
+}
+// One element's jet through the activation (Faa di Bruno), in place: z[0] = a = phi(z0) on entry, z[k>0] = pre-activation
+// channels; on exit z[k] = post-activation channels.  Higher channels first: they read the lower pre-activation values.
+template <class J>
+DEV void jet_forward(vfloat (&z)[J::C], const vfloat (&d)[6]) {
+    PINN_UNROLL for (int k = 0; k < J::N4; ++k) {
+        const int ax = J::hi_axis(4, k);
+        const vfloat z1 = z[J::CH_FIRST + J::first_rank(ax)], z2 = z[J::CH_PAIR + J::pair_index(ax, ax)], z3 = z[J::CH_3 + J::hi_rank(3, ax)];
+        const vfloat z11 = z1 * z1;
+        vfloat r = d[1] * z[J::CH_4 + k];
+        r = vfma(vfloat(4.0f) * d[2] * z1, z3, r);
+        r = vfma(vfloat(3.0f) * d[2] * z2, z2, r);
+        r = vfma(vfloat(6.0f) * d[3] * z11, z2, r);
+        r = vfma(d[4] * z11, z11, r);
+        z[J::CH_4 + k] = r;
+    }
+    PINN_UNROLL for (int k = 0; k < J::N3; ++k) {
+        const int ax = J::hi_axis(3, k);
+        const vfloat z1 = z[J::CH_FIRST + J::first_rank(ax)], z2 = z[J::CH_PAIR + J::pair_index(ax, ax)];
+        vfloat r = d[1] * z[J::CH_3 + k];
+        r = vfma(vfloat(3.0f) * d[2] * z1, z2, r);
+        r = vfma(d[3] * z1 * z1, z1, r);
+        z[J::CH_3 + k] = r;
+    }
+    PINN_UNROLL for (int p = 0; p < J::NPAIR; ++p) {
+        const int ca = J::CH_FIRST + J::first_rank(J::pair_a(p)), cb = J::CH_FIRST + J::first_rank(J::pair_b(p));
+        z[J::CH_PAIR + p] = vfma(d[2] * z[ca], z[cb], d[1] * z[J::CH_PAIR + p]);
+    }
+    PINN_UNROLL for (int kf = 0; kf < J::NFIRST; ++kf) z[J::CH_FIRST + kf] = d[1] * z[J::CH_FIRST + kf];
+}
+// Adjoint of jet_forward for one element: g[k] = adjoint of post-activation channel k on entry, of pre-activation channel k
+// on exit; s = the record (s[0] = a, s[k>0] = pre-activation channels).
+template <class J>
+DEV void jet_adjoint(vfloat (&g)[J::C], const vfloat (&s)[J::C], const vfloat (&d)[6]) {
+    vfloat zv = d[1] * g[0];
+    vfloat zf[J::NFIRST > 0 ? J::NFIRST : 1], zp[J::NPAIR > 0 ? J::NPAIR : 1], z3b[J::N3 > 0 ? J::N3 : 1];
+    PINN_UNROLL for (int kf = 0; kf < J::NFIRST; ++kf) {
+        const vfloat gk = g[J::CH_FIRST + kf];
+        zv = vfma(d[2] * s[J::CH_FIRST + kf], gk, zv);
+        zf[kf] = d[1] * gk;
+    }
+    PINN_UNROLL for (int p = 0; p < J::NPAIR; ++p) {
+        const int ka = J::first_rank(J::pair_a(p)), kb = J::first_rank(J::pair_b(p));
+        const vfloat za = s[J::CH_FIRST + ka], zb = s[J::CH_FIRST + kb], gp = g[J::CH_PAIR + p];
+        zv = vfma(vfma(d[3] * za, zb, d[2] * s[J::CH_PAIR + p]), gp, zv);
+        zf[ka] = vfma(d[2] * zb, gp, zf[ka]);
+        zf[kb] = vfma(d[2] * za, gp, zf[kb]);
+        zp[p] = d[1] * gp;
+    }
+    PINN_UNROLL for (int k = 0; k < J::N3; ++k) {
+        const int ax = J::hi_axis(3, k), k1 = J::first_rank(ax), p2 = J::pair_index(ax, ax);
+        const vfloat z1 = s[J::CH_FIRST + k1], z2 = s[J::CH_PAIR + p2], z3 = s[J::CH_3 + k], g3 = g[J::CH_3 + k];
+        z3b[k] = d[1] * g3;
+        zp[p2] = vfma(vfloat(3.0f) * d[2] * z1, g3, zp[p2]);
+        zf[k1] = vfma(vfloat(3.0f) * vfma(d[3] * z1, z1, d[2] * z2), g3, zf[k1]);
+        zv = vfma(vfma(d[4] * z1 * z1, z1, vfma(vfloat(3.0f) * d[3] * z1, z2, d[2] * z3)), g3, zv);
+    }
+    PINN_UNROLL for (int k = 0; k < J::N4; ++k) {
+        const int ax = J::hi_axis(4, k), k1 = J::first_rank(ax), p2 = J::pair_index(ax, ax), k3 = J::hi_rank(3, ax);
+        const vfloat z1 = s[J::CH_FIRST + k1], z2 = s[J::CH_PAIR + p2], z3 = s[J::CH_3 + k3], z4 = s[J::CH_4 + k], g4 = g[J::CH_4 + k];
+        const vfloat z11 = z1 * z1;
+        g[J::CH_4 + k] = d[1] * g4;
+        z3b[k3] = vfma(vfloat(4.0f) * d[2] * z1, g4, z3b[k3]);
+        zp[p2] = vfma(vfloat(6.0f) * vfma(d[3], z11, d[2] * z2), g4, zp[p2]);
+        zf[k1] = vfma(vfloat(4.0f) * vfma(d[4] * z11, z1, vfma(vfloat(3.0f) * d[3] * z1, z2, d[2] * z3)), g4, zf[k1]);
+        vfloat t = d[2] * z4;
+        t = vfma(vfloat(4.0f) * d[3] * z1, z3, t);
+        t = vfma(vfloat(3.0f) * d[3] * z2, z2, t);
+        t = vfma(vfloat(6.0f) * d[4] * z11, z2, t);
+        t = vfma(d[5] * z11, z11, t);
+        zv = vfma(t, g4, zv);
+    }
+    g[0] = zv;
+    PINN_UNROLL for (int kf = 0; kf < J::NFIRST; ++kf) g[J::CH_FIRST + kf] = zf[kf];
+    PINN_UNROLL for (int p = 0; p < J::NPAIR; ++p) g[J::CH_PAIR + p] = zp[p];
+    PINN_UNROLL for (int k = 0; k < J::N3; ++k) g[J::CH_3 + k] = z3b[k];
+}
+
 DEV vfloat act_value(int act, vfloat z) {
 #ifdef PINN_ABL_NOACT
     return z * vfloat(0.25f);
@@ -193,7 +334,8 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
     constexpr bool COOP = S::COOP && BWD;
     constexpr int WT = S::WT;
     constexpr int HP = S::HP, MT = S::MT, NHH = S::NHH, LH = S::LH, D = S::D, C = S::C, PG = S::PG, NG = S::NG;
-    constexpr int NFIRST = S::NFIRST, NPAIR = S::NPAIR;
+    constexpr int NFIRST = S::NFIRST;
+    using J = typename S::J;
     const vint lane = lane_id();
     const vint g = lane >> 4;
     const vint c = lane & vint(15);
@@ -278,7 +420,7 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                     PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = vfma(w1[i][r], x[pg][i], z[r]);
                 A[pg * C][m] = z;
                 PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) A[pg * C + 1 + kf][m] = w1[S::first_axis(kf)];
-                PINN_UNROLL for (int p = 0; p < NPAIR; ++p) A[pg * C + 1 + NFIRST + p][m] = vzero4();
+                PINN_UNROLL for (int ch = 1 + NFIRST; ch < C; ++ch) A[pg * C + ch][m] = vzero4();       // second and higher derivatives of an affine map
             }
         }
 
@@ -288,15 +430,7 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
         auto act_forward = [&](vfloat4 (&Z)[NG][MT], int layer /*0-based hidden layer*/) {
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                 PINN_UNROLL for (int m = 0; m < MT; ++m) {
-                    vfloat4 d1v, d2v;
-                    vfloat4 av;
-                    PINN_UNROLL for (int r = 0; r < 4; ++r) {
-                        vfloat a = act_value(act, Z[pg * C][m][r]);
-                        vfloat d1, d2, d3;
-                        act_derivs_rt(act, a, d1, d2, d3);
-                        av[r] = a; d1v[r] = d1; d2v[r] = d2;
-                    }
-                    Z[pg * C][m] = av;
+                    PINN_UNROLL for (int r = 0; r < 4; ++r) Z[pg * C][m][r] = act_value(act, Z[pg * C][m][r]);
 #ifndef PINN_ABL_NOSCR
                     if (BWD) {
                         if (layer == LH - 1) {
@@ -307,15 +441,13 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                         }
                     }
 #endif
-                    PINN_UNROLL for (int p = 0; p < NPAIR; ++p) {
-                        const int cp = pg * C + 1 + NFIRST + p;
-                        const int ca = pg * C + 1 + S::first_rank(S::pair_a(p));
-                        const int cb = pg * C + 1 + S::first_rank(S::pair_b(p));
-                        PINN_UNROLL for (int r = 0; r < 4; ++r)
-                            Z[cp][m][r] = vfma(d2v[r] * Z[ca][m][r], Z[cb][m][r], d1v[r] * Z[cp][m][r]);
+                    PINN_UNROLL for (int r = 0; r < 4; ++r) {
+                        vfloat zz[C], dd[6];
+                        PINN_UNROLL for (int ch = 0; ch < C; ++ch) zz[ch] = Z[pg * C + ch][m][r];
+                        act_derivs_n<J::NORD - 1>(act, zz[0], dd);
+                        jet_forward<J>(zz, dd);
+                        PINN_UNROLL for (int ch = 1; ch < C; ++ch) Z[pg * C + ch][m][r] = zz[ch];
                     }
-                    PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf)
-                        PINN_UNROLL for (int r = 0; r < 4; ++r) Z[pg * C + 1 + kf][m][r] = d1v[r] * Z[pg * C + 1 + kf][m][r];
                 }
         };
         act_forward(A, 0);
@@ -464,17 +596,13 @@ Sr[q][m] = ub_load4(SB, (((layer * NG) + q) * MT + m) * 256, lane << 2);
         auto ajet = [&](const vfloat4 (&Sr)[NG][MT], int pg, int ch, int m) -> vfloat4 {
             vfloat4 out;
             PINN_UNROLL for (int r = 0; r < 4; ++r) {
-                vfloat a = Sr[pg * C][m][r];
-                if (ch == 0) { out[r] = a; continue; }
-                vfloat d1, d2, d3;
-                act_derivs_rt(act, a, d1, d2, d3);
-                if (ch <= NFIRST) out[r] = d1 * Sr[pg * C + ch][m][r];
-                else {
-                    const int p = ch - 1 - NFIRST;
-                    const int ca = pg * C + 1 + S::first_rank(S::pair_a(p));
-                    const int cb = pg * C + 1 + S::first_rank(S::pair_b(p));
-                    out[r] = vfma(d2 * Sr[ca][m][r], Sr[cb][m][r], d1 * Sr[pg * C + ch][m][r]);
+                vfloat zz[C], dd[6];
+                PINN_UNROLL for (int k = 0; k < C; ++k) zz[k] = Sr[pg * C + k][m][r];
+                if (ch > 0) {
+                    act_derivs_n<J::NORD - 1>(act, zz[0], dd);
+                    jet_forward<J>(zz, dd);                 // (ch is a constant after unrolling: the other channels are dead code)
                 }
+                out[r] = zz[ch];
             }
             return out;
         };
@@ -483,28 +611,11 @@ Sr[q][m] = ub_load4(SB, (((layer * NG) + q) * MT + m) * 256, lane << 2);
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                 PINN_UNROLL for (int m = 0; m < MT; ++m)
                     PINN_UNROLL for (int r = 0; r < 4; ++r) {
-                        vfloat a = Sr[pg * C][m][r];
-                        vfloat d1, d2, d3;
-                        act_derivs_rt(act, a, d1, d2, d3);
-                        vfloat zv = d1 * G[pg * C][m][r];
-                        vfloat zf[NFIRST > 0 ? NFIRST : 1];
-                        PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) {
-                            vfloat gk = G[pg * C + 1 + kf][m][r];
-                            zv = vfma(d2 * Sr[pg * C + 1 + kf][m][r], gk, zv);
-                            zf[kf] = d1 * gk;
-                        }
-                        PINN_UNROLL for (int p = 0; p < NPAIR; ++p) {
-                            const int cp = pg * C + 1 + NFIRST + p;
-                            const int ka = S::first_rank(S::pair_a(p)), kb = S::first_rank(S::pair_b(p));
-                            vfloat za = Sr[pg * C + 1 + ka][m][r], zb = Sr[pg * C + 1 + kb][m][r];
-                            vfloat gp = G[cp][m][r];
-                            zv = vfma(vfma(d3 * za, zb, d2 * Sr[cp][m][r]), gp, zv);
-                            zf[ka] = vfma(d2 * zb, gp, zf[ka]);
-                            zf[kb] = vfma(d2 * za, gp, zf[kb]);
-                            G[cp][m][r] = d1 * gp;
-                        }
-                        G[pg * C][m][r] = zv;
-                        PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) G[pg * C + 1 + kf][m][r] = zf[kf];
+                        vfloat gg[C], ss[C], dd[6];
+                        PINN_UNROLL for (int k = 0; k < C; ++k) { gg[k] = G[pg * C + k][m][r]; ss[k] = Sr[pg * C + k][m][r]; }
+                        act_derivs_n<J::NORD>(act, ss[0], dd);
+                        jet_adjoint<J>(gg, ss, dd);
+                        PINN_UNROLL for (int k = 0; k < C; ++k) G[pg * C + k][m][r] = gg[k];
                     }
         };
 

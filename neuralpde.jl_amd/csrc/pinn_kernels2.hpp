@@ -28,32 +28,24 @@
 
 namespace pk {
 
-template <int HP_, int NHH_, int D_, unsigned D1MASK_, unsigned long long PAIRS_, int NPAIR_, int PG_>
+template <int HP_, int NHH_, int D_, unsigned D1MASK_, unsigned long long PAIRS_, int NPAIR_, int PG_, unsigned HI_ = 0>
 struct Spec2 {
+    using J = JetSet<D1MASK_, PAIRS_, NPAIR_, HI_>;
+    static constexpr unsigned HI = HI_;
     static constexpr int FAMILY = 2;
     static constexpr int HP = HP_, MT = HP_ / 16, NHH = NHH_, LH = NHH_ + 1, D = D_, NPAIR = NPAIR_, PG = PG_;
     static constexpr unsigned D1MASK = D1MASK_;
     static constexpr unsigned long long PAIRS = PAIRS_;
     static constexpr int MTW = MT / 4;                 // neuron tiles per wave
     static_assert(MT % 4 == 0, "family 2 needs a hidden width that is a multiple of 64");
-    static constexpr int popc(unsigned x) { int n = 0; while (x) { n += x & 1; x >>= 1; } return n; }
-    static constexpr int NFIRST = popc(D1MASK_);
-    static constexpr int C = 1 + NFIRST + NPAIR_;
+    static constexpr int NFIRST = J::NFIRST;
+    static constexpr int C = J::C;
     static constexpr int NG = C * PG_;
     static constexpr int TP = 16 * PG_;
-    static constexpr int first_axis(int k) {
-        int cnt = 0;
-        for (int a = 0; a < 8; ++a)
-            if (D1MASK_ & (1u << a)) { if (cnt == k) return a; ++cnt; }
-        return -1;
-    }
-    static constexpr int first_rank(int axis) {
-        int cnt = 0;
-        for (int a = 0; a < axis; ++a) if (D1MASK_ & (1u << a)) ++cnt;
-        return cnt;
-    }
-    static constexpr int pair_a(int p) { return (int)((PAIRS_ >> (8 * p)) & 0xF); }
-    static constexpr int pair_b(int p) { return (int)((PAIRS_ >> (8 * p + 4)) & 0xF); }
+    static constexpr int first_axis(int k) { return J::first_axis(k); }
+    static constexpr int first_rank(int axis) { return J::first_rank(axis); }
+    static constexpr int pair_a(int p) { return J::pair_a(p); }
+    static constexpr int pair_b(int p) { return J::pair_b(p); }
     // packed parameter buffer (floats); fragment images are [layer][tile a][tile b][lane][4 k-steps]
     static constexpr int OFF_W1 = 0;
     static constexpr int OFF_B = OFF_W1 + D_ * HP_;
@@ -93,7 +85,8 @@ struct Spec2 {
 template <class S, int MODE>
 DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds) {
     constexpr int HP = S::HP, MT = S::MT, MTW = S::MTW, NHH = S::NHH, LH = S::LH, D = S::D, C = S::C, PG = S::PG, NG = S::NG;
-    constexpr int NFIRST = S::NFIRST, NPAIR = S::NPAIR;
+    constexpr int NFIRST = S::NFIRST;
+    using J = typename S::J;
     constexpr bool BWD = (MODE == MODE_FUSED || MODE == MODE_GRADIN);
     constexpr bool WPRE = (MT * MTW * 4 <= 16);        // prefetch a layer's weight fragments when they take <= 16 registers (H = 64)
     const int wave = blk * 4 + w;
@@ -172,14 +165,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
         auto act_forward = [&](vfloat4 (&Z)[NG][MTW], int layer) {
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t) {
-                    vfloat4 d1v, d2v, av;
-                    PINN_UNROLL for (int r = 0; r < 4; ++r) {
-                        vfloat a = act_value(act, Z[pg * C][t][r]);
-                        vfloat d1, d2, d3;
-                        act_derivs_rt(act, a, d1, d2, d3);
-                        av[r] = a; d1v[r] = d1; d2v[r] = d2;
-                    }
-                    Z[pg * C][t] = av;
+                    PINN_UNROLL for (int r = 0; r < 4; ++r) Z[pg * C][t][r] = act_value(act, Z[pg * C][t][r]);
                     if (BWD) {
                         if (layer == LH - 1) {
                             PINN_UNROLL for (int ch = 0; ch < C; ++ch) Rlast[pg * C + ch][t] = Z[pg * C + ch][t];
@@ -188,15 +174,13 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                                 ub_store4(SB, (((layer - 1) * NG + pg * C + ch) * MT + w * MTW + t) * 256, lane << 2, Z[pg * C + ch][t]);
                         }
                     }
-                    PINN_UNROLL for (int p = 0; p < NPAIR; ++p) {
-                        const int cp = pg * C + 1 + NFIRST + p;
-                        const int ca = pg * C + 1 + S::first_rank(S::pair_a(p));
-                        const int cb = pg * C + 1 + S::first_rank(S::pair_b(p));
-                        PINN_UNROLL for (int r = 0; r < 4; ++r)
-                            Z[cp][t][r] = vfma(d2v[r] * Z[ca][t][r], Z[cb][t][r], d1v[r] * Z[cp][t][r]);
+                    PINN_UNROLL for (int r = 0; r < 4; ++r) {
+                        vfloat zz[C], dd[6];
+                        PINN_UNROLL for (int ch = 0; ch < C; ++ch) zz[ch] = Z[pg * C + ch][t][r];
+                        act_derivs_n<J::NORD - 1>(act, zz[0], dd);
+                        jet_forward<J>(zz, dd);
+                        PINN_UNROLL for (int ch = 1; ch < C; ++ch) Z[pg * C + ch][t][r] = zz[ch];
                     }
-                    PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf)
-                        PINN_UNROLL for (int r = 0; r < 4; ++r) Z[pg * C + 1 + kf][t][r] = d1v[r] * Z[pg * C + 1 + kf][t][r];
                 }
         };
         // publish this wave's tiles of a [NG][MT] tensor in B-fragment order: X[q][tile][lane][4]
@@ -219,7 +203,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                     PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = vfma(w1[i][r], x[pg][i], z[r]);
                 A[pg * C][t] = z;
                 PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) A[pg * C + 1 + kf][t] = w1[S::first_axis(kf)];
-                PINN_UNROLL for (int p = 0; p < NPAIR; ++p) A[pg * C + 1 + NFIRST + p][t] = vzero4();
+                PINN_UNROLL for (int ch = 1 + NFIRST; ch < C; ++ch) A[pg * C + ch][t] = vzero4();      // second and higher derivatives of an affine map
             }
         }
         act_forward(A, 0);
@@ -371,17 +355,13 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
         auto ajet = [&](const vfloat4 (&Sr)[NG][MTW], int pg, int ch, int t) -> vfloat4 {
             vfloat4 out;
             PINN_UNROLL for (int r = 0; r < 4; ++r) {
-                vfloat a = Sr[pg * C][t][r];
-                if (ch == 0) { out[r] = a; continue; }
-                vfloat d1, d2, d3;
-                act_derivs_rt(act, a, d1, d2, d3);
-                if (ch <= NFIRST) out[r] = d1 * Sr[pg * C + ch][t][r];
-                else {
-                    const int p = ch - 1 - NFIRST;
-                    const int ca = pg * C + 1 + S::first_rank(S::pair_a(p));
-                    const int cb = pg * C + 1 + S::first_rank(S::pair_b(p));
-                    out[r] = vfma(d2 * Sr[ca][t][r], Sr[cb][t][r], d1 * Sr[pg * C + ch][t][r]);
+                vfloat zz[C], dd[6];
+                PINN_UNROLL for (int k = 0; k < C; ++k) zz[k] = Sr[pg * C + k][t][r];
+                if (ch > 0) {
+                    act_derivs_n<J::NORD - 1>(act, zz[0], dd);
+                    jet_forward<J>(zz, dd);                 // (ch is a constant after unrolling: the other channels are dead code)
                 }
+                out[r] = zz[ch];
             }
             return out;
         };
@@ -389,28 +369,11 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t)
                     PINN_UNROLL for (int r = 0; r < 4; ++r) {
-                        vfloat a = Sr[pg * C][t][r];
-                        vfloat d1, d2, d3;
-                        act_derivs_rt(act, a, d1, d2, d3);
-                        vfloat zv = d1 * G[pg * C][t][r];
-                        vfloat zf[NFIRST > 0 ? NFIRST : 1];
-                        PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) {
-                            vfloat gk = G[pg * C + 1 + kf][t][r];
-                            zv = vfma(d2 * Sr[pg * C + 1 + kf][t][r], gk, zv);
-                            zf[kf] = d1 * gk;
-                        }
-                        PINN_UNROLL for (int p = 0; p < NPAIR; ++p) {
-                            const int cp = pg * C + 1 + NFIRST + p;
-                            const int ka = S::first_rank(S::pair_a(p)), kb = S::first_rank(S::pair_b(p));
-                            vfloat za = Sr[pg * C + 1 + ka][t][r], zb = Sr[pg * C + 1 + kb][t][r];
-                            vfloat gp = G[cp][t][r];
-                            zv = vfma(vfma(d3 * za, zb, d2 * Sr[cp][t][r]), gp, zv);
-                            zf[ka] = vfma(d2 * zb, gp, zf[ka]);
-                            zf[kb] = vfma(d2 * za, gp, zf[kb]);
-                            G[cp][t][r] = d1 * gp;
-                        }
-                        G[pg * C][t][r] = zv;
-                        PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) G[pg * C + 1 + kf][t][r] = zf[kf];
+                        vfloat gg[C], ss[C], dd[6];
+                        PINN_UNROLL for (int k = 0; k < C; ++k) { gg[k] = G[pg * C + k][t][r]; ss[k] = Sr[pg * C + k][t][r]; }
+                        act_derivs_n<J::NORD>(act, ss[0], dd);
+                        jet_adjoint<J>(gg, ss, dd);
+                        PINN_UNROLL for (int k = 0; k < C; ++k) G[pg * C + k][t][r] = gg[k];
                     }
         };
 
@@ -443,7 +406,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = act_value(act, z[r]);
                         Sr[pg * C][t] = z;
                         PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) Sr[pg * C + 1 + kf][t] = w1[S::first_axis(kf)];
-                        PINN_UNROLL for (int p = 0; p < NPAIR; ++p) Sr[pg * C + 1 + NFIRST + p][t] = vzero4();
+                        PINN_UNROLL for (int ch = 1 + NFIRST; ch < C; ++ch) Sr[pg * C + ch][t] = vzero4();
                     }
                 }
             } else {

@@ -25,7 +25,7 @@ NULLARY = {"CONST"}
 @dataclass(frozen=True)
 class Slot:
     net: int
-    axes: Tuple[int, ...]        # () = value; (i,) = d/dx_i; (i, j) = d2/dx_i dx_j  (net-input axis numbers, sorted)
+    axes: Tuple[int, ...]        # () = value; (i,) = d/dx_i; (i, j) = d2/dx_i dx_j; (i,i,i), (i,i,i,i) pure 3rd/4th  (net-input axes, sorted)
 
     @property
     def order(self) -> int:

@@ -239,8 +239,11 @@ class _Builder:
             if str(v) not in inputs:
                 raise LoweringError(f"derivative of {name} w.r.t. {v}, which is not one of its inputs {inputs}")
             axes += [inputs.index(str(v))] * int(n)
-        if len(axes) > 2:
-            raise LoweringError(f"derivative order {len(axes)} > 2 of {name} is not supported by the HIP engine yet")
+        if len(axes) > 4:
+            raise LoweringError(f"derivative order {len(axes)} > 4 of {name} is not supported by the HIP engine")
+        if len(axes) > 2 and len(set(axes)) > 1:
+            raise LoweringError(f"mixed derivative of order {len(axes)} of {name} is not supported by the HIP engine "
+                                f"(pure third / fourth derivatives along one axis are)")
         return self.slot(Slot(net, tuple(sorted(axes))))
 
     def _lower(self, e):

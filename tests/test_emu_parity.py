@@ -11,7 +11,7 @@ import pinn_oracle as po
 TOL = 1e-5
 
 
-def check(npde, sysm, chains, strat, theta, weights=None, param_estim=False, tol=TOL):
+def check(npde, sysm, chains, strat, theta, weights=None, param_estim=False, tol=TOL, mode="stencil"):
     disc = npde.PhysicsInformedNN(chains if len(chains) > 1 else chains[0], strat, init_params=theta,
                                   param_estim=param_estim)
     rep = npde.symbolic_discretize(sysm, disc)
@@ -20,7 +20,7 @@ def check(npde, sysm, chains, strat, theta, weights=None, param_estim=False, tol
     th = rep.flat_init_params
     losses, grad = rep.engine.loss_grad(th, weights)
     prob = helpers.oracle_problem(npde, sysm, chains, param_estim=param_estim)
-    ref = po.loss_and_grad(prob, th, sets, weights=weights, mode="stencil")
+    ref = po.loss_and_grad(prob, th, sets, weights=weights, mode=mode)
     le, g2, gi = helpers.rel_errors(losses, grad, ref)
     assert le.max() < tol and g2 < tol and gi < tol, (le, g2, gi)
     l2, g2_ = rep.engine.loss_grad(th, weights)
@@ -270,3 +270,64 @@ def test_hoisted_sources_and_mixed_ops(npde, use_emu):
         ref = po.loss_and_grad(prob, th, new, weights=[1.0, 2.0, 0.5, 3.0], mode="stencil")
         le, g2, gi = helpers.rel_errors(losses, grad, ref)
         assert le.max() < TOL and g2 < TOL and gi < TOL, (le, g2, gi)
+
+
+def _third_order_ode(npde):
+    # test/NNPDE1/nnpde__pde_iii_3rd_order_ode.jl:66-80
+    (x,) = npde.parameters("x")
+    (u,) = npde.variables("u")
+    Dx, Dxxx = npde.Differential(x), npde.Differential(x) ** 3
+    eq = npde.Eq(Dxxx(u(x)), sp.cos(sp.pi * x))
+    bcs = [npde.Eq(u(0.0), 0.0), npde.Eq(u(1.0), sp.cos(sp.pi)), npde.Eq(Dx(u(1.0)), 1.0)]
+    return npde.PDESystem([eq], bcs, [npde.In(x, npde.Interval(0.0, 1.0))], [x], [u(x)])
+
+
+def _ks(npde):
+    # docs/src/examples/ks.md:33-62 (alpha = 1, beta = 4, gamma = 1), Dirichlet + Neumann data from the analytic solution
+    x, t = npde.parameters("x t")
+    (u,) = npde.variables("u")
+    Dt, Dx = npde.Differential(t), npde.Differential(x)
+    Dx2, Dx3, Dx4 = Dx ** 2, Dx ** 3, Dx ** 4
+    U = u(x, t)
+    th = lambda xx, tt: xx / 2 - 1.2 * tt                  # (scaled so that tanh stays away from saturation on the test box)
+    ua = lambda xx, tt: 11 + 15 * sp.tanh(th(xx, tt)) - 15 * sp.tanh(th(xx, tt)) ** 2 - 15 * sp.tanh(th(xx, tt)) ** 3
+    eq = npde.Eq(Dt(U) + U * Dx(U) + 1 * Dx2(U) + 4 * Dx3(U) + 1 * Dx4(U), 0)
+    bcs = [npde.Eq(u(x, 0), ua(x, 0)), npde.Eq(u(-1.0, t), ua(-1.0, t)), npde.Eq(u(1.0, t), ua(1.0, t)),
+           npde.Eq(Dx(u(-1.0, t)), sp.diff(ua(x, t), x).subs(x, -1.0)), npde.Eq(Dx(u(1.0, t)), sp.diff(ua(x, t), x).subs(x, 1.0))]
+    dom = [npde.In(x, npde.Interval(-1.0, 1.0)), npde.In(t, npde.Interval(0.0, 1.0))]
+    return npde.PDESystem([eq], bcs, dom, [x, t], [U])
+
+
+def test_third_and_fourth_order_derivatives(npde, use_emu):
+    """pure d3/dx3, d4/dx4 jets (Faa di Bruno through the activation, hand-derived adjoints) against the float64 oracle's exact
+    derivatives; the reference's own order-3/4 stencils (eps^(1/5), eps^(1/6)) agree with them to ~1e-5 only, checked loosely."""
+    # the reference's 3rd-order ODE set-up: Dense(1, 8, sigma) -> Dense(8, 1)
+    sysm = _third_order_ode(npde)
+    chain = npde.Chain(npde.Dense(1, 8, "sigmoid"), npde.Dense(8, 1))
+    rep, prob, sets, th = check(npde, sysm, [chain], npde.GridTraining(0.05), theta_for(chain, 31), mode="exact")
+    ref_fd = po.loss_and_grad(prob, th, sets, mode="stencil")
+    losses, grad = rep.engine.loss_grad(th)
+    le, g2, gi = helpers.rel_errors(losses, grad, ref_fd)
+    assert le.max() < 2e-4 and g2 < 2e-4, (le, g2)
+    # fourth order, 1-D, two hidden layers, both activations
+    (x,) = npde.parameters("x")
+    (u,) = npde.variables("u")
+    D4, D3, D2 = npde.Differential(x) ** 4, npde.Differential(x) ** 3, npde.Differential(x) ** 2
+    eq = npde.Eq(D4(u(x)) + 0.5 * u(x) * D3(u(x)) - D2(u(x)) ** 2, sp.sin(2 * x))
+    sys4 = npde.PDESystem([eq], [npde.Eq(u(0.0), 0.0), npde.Eq(D2(u(1.0)), 0.3)], [npde.In(x, npde.Interval(0.0, 1.0))], [x], [u(x)])
+    for act, seed in (("tanh", 32), ("sigmoid", 33)):
+        chain = npde.Chain(npde.Dense(1, 16, act), npde.Dense(16, 16, act), npde.Dense(16, 1))
+        check(npde, sys4, [chain], npde.GridTraining(0.04), theta_for(chain, seed), weights=[1.0, 2.0, 0.5], mode="exact")
+
+
+def test_kuramoto_sivashinsky_jets(npde, use_emu):
+    sysm = _ks(npde)
+    strat = npde.QuasiRandomTraining(40, bcs_points=20, sampling_alg=npde.SobolSample(seed=12), resampling=False, minibatch=1)
+    # the reference's KS net (Dense(2,12,sigma) x2, padded to 16; family 1) and a 4x64 tanh net (family 2)
+    small = npde.Chain(npde.Dense(2, 12, "sigmoid"), npde.Dense(12, 12, "sigmoid"), npde.Dense(12, 1))
+    rep, prob, sets, th = check(npde, sysm, [small], strat, theta_for(small, 41), mode="exact")
+    assert "_H4_" in rep.engine.describe()                      # the kernel carrying d3/dx3, d4/dx4 along axis 0
+    r = rep.loss_functions.datafree_pde_loss_functions[0](sets[0], th)
+    np.testing.assert_allclose(r, po.residual_values(prob, th, 0, sets[0], mode="exact"), rtol=3e-5, atol=3e-5)
+    big = npde.Chain(npde.Dense(2, 64, "tanh"), *[npde.Dense(64, 64, "tanh") for _ in range(3)], npde.Dense(64, 1))
+    check(npde, sysm, [big], strat, theta_for(big, 42), weights=[1.0, 1.0, 2.0, 2.0, 0.5, 0.5], mode="exact")

@@ -214,3 +214,36 @@ def test_training_converges_resident_adam(npde, hip_lib):
     err1 = np.max(np.abs(prob.pinnrep.phi(grid, res.u)[0] - analytic))
     print("loss", res.losses[0], "->", res.losses[-1], "max error", err0, "->", err1)
     assert res.losses[-1] < res.losses[0] / 50 and err1 < 0.02 and err1 < err0 / 3
+
+
+def test_higher_order_derivatives_gpu(npde, hip_lib):
+    """pure third / fourth derivative jets on the hardware: the reference's 3rd-order ODE set-up, a 4th-order 1-D problem and the
+    Kuramoto-Sivashinsky jet set (family 1 sigmoid 2x12 and family 2 tanh 4x64), against the oracle's exact derivatives
+    (the reference's order-3/4 stencils themselves carry ~1e-5 of finite-difference error)."""
+    import test_emu_parity as tp
+    import sympy as sp
+
+    def run(sysm, chain, strat, seed, weights=None):
+        th = tp.theta_for(chain, seed)
+        rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th))
+        assert rep.engine.L.backend == "hip"
+        sets = rep.pde_train_sets + rep.bcs_train_sets
+        losses, grad = rep.engine.loss_grad(th, weights)
+        prob = helpers.oracle_problem(npde, sysm, [chain])
+        ref = po.loss_and_grad(prob, th, sets, weights=weights, mode="exact")
+        le, g2, gi = helpers.rel_errors(losses, grad, ref)
+        assert le.max() < TOL and g2 < TOL and gi < TOL, (le, g2, gi)
+
+    run(tp._third_order_ode(npde), npde.Chain(npde.Dense(1, 8, "sigmoid"), npde.Dense(8, 1)), npde.GridTraining(0.01), 31)
+    (x,) = npde.parameters("x")
+    (u,) = npde.variables("u")
+    D4, D3, D2 = npde.Differential(x) ** 4, npde.Differential(x) ** 3, npde.Differential(x) ** 2
+    sys4 = npde.PDESystem([npde.Eq(D4(u(x)) + 0.5 * u(x) * D3(u(x)) - D2(u(x)) ** 2, sp.sin(2 * x))],
+                          [npde.Eq(u(0.0), 0.0), npde.Eq(D2(u(1.0)), 0.3)], [npde.In(x, npde.Interval(0.0, 1.0))], [x], [u(x)])
+    run(sys4, npde.Chain(npde.Dense(1, 16, "tanh"), npde.Dense(16, 16, "tanh"), npde.Dense(16, 1)), npde.GridTraining(0.002), 32,
+        weights=[1.0, 2.0, 0.5])
+    ks = tp._ks(npde)
+    strat = npde.QuasiRandomTraining(3000, bcs_points=500, sampling_alg=npde.SobolSample(seed=12), resampling=False, minibatch=1)
+    run(ks, npde.Chain(npde.Dense(2, 12, "sigmoid"), npde.Dense(12, 12, "sigmoid"), npde.Dense(12, 1)), strat, 41)
+    run(ks, npde.Chain(npde.Dense(2, 64, "tanh"), *[npde.Dense(64, 64, "tanh") for _ in range(3)], npde.Dense(64, 1)), strat, 42,
+        weights=[1.0, 1.0, 2.0, 2.0, 0.5, 0.5])

@@ -85,7 +85,11 @@ def test_lowering_errors(npde):
     (u,) = npde.variables("u")
     vi = npde.get_vars([x, y], [u(x, y)])
     with pytest.raises(npde.LoweringError):
-        npde.lower_equation(npde.Eq((npde.Differential(x) ** 3)(u(x, y)), 0), vi, (), "pde")      # order 3: not yet
+        npde.lower_equation(npde.Eq((npde.Differential(x) ** 5)(u(x, y)), 0), vi, (), "pde")      # order 5
+    with pytest.raises(npde.LoweringError):
+        npde.lower_equation(npde.Eq((npde.Differential(x) ** 2)(npde.Differential(y)(u(x, y))), 0), vi, (), "pde")   # mixed order 3
+    t3 = npde.lower_equation(npde.Eq((npde.Differential(x) ** 3)(u(x, y)), 0), vi, (), "pde")     # pure third derivative: supported
+    assert [s.axes for s in t3.slots] == [(0, 0, 0)]
     with pytest.raises(npde.LoweringError):
         npde.lower_equation(npde.Eq(sp.gamma(u(x, y)), 0), vi, (), "pde")                        # outside the op set
     with pytest.raises(npde.LoweringError):
