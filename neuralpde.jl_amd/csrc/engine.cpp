@@ -73,6 +73,9 @@ struct Term {
     int slot_in_group = -1;
     int coupled = -1;                // >= 0: index into pinn_engine::coupled (equation couples several networks)
     std::vector<int> chan_of_slot;
+    // per referenced network: which of the term's coordinates feed the network's inputs (descriptor `inmap` lines; default
+    // identity) — dependent variables of one system may take different arguments (src/discretize.jl:111-131)
+    std::map<int, std::vector<int>> inmap;
     // coordinate-only subexpressions hoisted out of the fused tape (analyse_static): evaluated by k_src per point set
     std::vector<rp::Instr> src_prog;     // compact numbering: rows [0,d) coordinates, row d+i = static op i
     std::vector<int> src_root;           // compact row of source j
@@ -256,6 +259,20 @@ int parse_descriptor(const char* text, pinn_engine& E) {
             rp::finalize(I);
         }
         if (T.out_row < 0 || T.out_row >= T.d + E.np + ns + no) return fail("descriptor: out row out of range");
+        // optional: inmap <net> <n> <coordinate index of input 0> ... (one line per network whose inputs are not simply the
+        // term's coordinates in order)
+        for (;;) {
+            const std::streampos pos = in.tellg();
+            std::string tok;
+            if (!(in >> tok)) { in.clear(); break; }
+            if (tok != "inmap") { in.seekg(pos); break; }
+            int net, n;
+            if (!(in >> net >> n) || net < 0 || net >= nn || n < 1 || n > 4) return fail("descriptor: inmap line");
+            std::vector<int> m(n);
+            for (int i = 0; i < n; ++i)
+                if (!(in >> m[i]) || m[i] < 0 || m[i] >= T.d) return fail("descriptor: inmap coordinate index out of range");
+            T.inmap[net] = m;
+        }
     }
     return 0;
 }
@@ -413,8 +430,8 @@ int build_plan(pinn_engine& E) {
     auto spec_for = [&](size_t t, int net, int d, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs, unsigned need_hi,
                         const pk::SpecInfo*& sp) -> int {
         const Net& N = E.nets[net];
-        if (N.sizes[0] != d)
-            return fail("term " + std::to_string(t) + ": network input dimension differs from the term's coordinate count (heterogeneous inputs are not supported yet)");
+        (void)t;
+        d = N.sizes[0];                                 // kernels are compiled per network input dimension
         const int LH = (int)N.sizes.size() - 2;
         const int HP = round_hp(N.maxhidden());
         sp = find_spec(HP, LH - 1, d, need_first, need_pairs, need_hi, nullptr);
@@ -438,11 +455,24 @@ int build_plan(pinn_engine& E) {
             if (std::find(term_nets[t].begin(), term_nets[t].end(), s.net) == term_nets[t].end()) term_nets[t].push_back(s.net);
         std::sort(term_nets[t].begin(), term_nets[t].end());
         if (term_nets[t].empty()) return fail("term " + std::to_string(t) + " does not reference any dependent variable");
+        if (T.d > 4) return fail("term " + std::to_string(t) + ": more than 4 coordinates");
+        for (int net : term_nets[t]) {                  // input maps: default = the term's coordinates in order
+            const Net& N = E.nets[net];
+            if (!T.inmap.count(net)) {
+                if (N.sizes[0] != T.d)
+                    return fail("term " + std::to_string(t) + ": network " + std::to_string(net) + " takes " + std::to_string(N.sizes[0]) +
+                                " inputs but the term binds " + std::to_string(T.d) + " coordinates and the descriptor has no inmap line for it");
+                std::vector<int> id(T.d);
+                for (int i = 0; i < T.d; ++i) id[i] = i;
+                T.inmap[net] = id;
+            }
+            if ((int)T.inmap[net].size() != N.sizes[0])
+                return fail("term " + std::to_string(t) + ": inmap length differs from the input count of network " + std::to_string(net));
+        }
         if (term_nets[t].size() > 1)
             for (int net : term_nets[t]) {
                 auto& nd = coupled_needs[net];
                 if (needs_of(T, net, nd.first, nd.second, coupled_hi[net])) return 1;
-                if (coupled_dim.count(net) && coupled_dim[net] != T.d) return fail("coupled terms of one network must bind the same variables");
                 coupled_dim[net] = T.d;
             }
     }
@@ -795,6 +825,15 @@ void retile(pinn_engine& E, int gi) {
         td.in = nullptr;
         td.src = (G.kind == 0) ? T.d_src : nullptr;
         td.nsrc = (G.kind == 0) ? (int)T.src_root.size() : 0;
+        {
+            const std::vector<int>& m = T.inmap.at(G.net);
+            td.dt = T.d;
+            td.hetero = ((int)m.size() != T.d);
+            for (int i = 0; i < 4; ++i) {
+                td.imap[i] = i < (int)m.size() ? m[i] : 0;
+                if (i < (int)m.size() && m[i] != i) td.hetero = 1;
+            }
+        }
         if (G.kind == 1) {               // coupled term: this network's jet / seed buffers
             const Coupled& Cp = E.coupled[T.coupled];
             for (size_t i = 0; i < Cp.groups.size(); ++i)
@@ -1238,6 +1277,8 @@ int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float*
     ga.nterms_total = 1;
     ga.act = N.act;
     ga.terms[0].pts = E.d_phi_pts;
+    ga.terms[0].dt = N.sizes[0];
+    for (int i = 0; i < 4; ++i) ga.terms[0].imap[i] = i;
     ga.terms[0].N = (int)n;
     ga.terms[0].tile0 = 0;
     ga.terms[0].ntiles = (int)((n + sp->TP - 1) / sp->TP);

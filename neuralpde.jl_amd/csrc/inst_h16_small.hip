@@ -13,3 +13,6 @@ PINN_INSTANTIATE_HI(h16n1d1_o4, 16, 1, 1, 0x1, PINN_PAIR(0, 0, 0), 1, 1, PINN_HI
 PINN_INSTANTIATE_HI(h16n0d1_o4, 16, 0, 1, 0x1, PINN_PAIR(0, 0, 0), 1, 1, PINN_HI(0, 4))
 PINN_INSTANTIATE_HI(h16n1d2_ks, 16, 1, 2, 0x3, PINN_PAIR(0, 1, 1), 1, 1, PINN_HI(1, 4))      // u(t, x)
 PINN_INSTANTIATE_HI(h16n1d2_ks0, 16, 1, 2, 0x3, PINN_PAIR(0, 0, 0), 1, 1, PINN_HI(0, 4))     // u(x, t) as in docs/src/examples/ks.md
+// 3-D value-only / gradient nets (the reference's heterogeneous-system test: u(x,y,z), v(y,x), h(z), p(x,z))
+PINN_INSTANTIATE(h16n1d3_val, 16, 1, 3, 0x0, 0ull, 0, 2)
+PINN_INSTANTIATE(h16n1d3_grad, 16, 1, 3, 0x7, 0ull, 0, 1)

@@ -174,7 +174,13 @@ struct TermDev {
     float* out;              // MODE_RESID: residual r[N];  MODE_FWD: jets [C][N]
     const float* in;         // MODE_GRADIN: d(loss)/d(jet) [C][N]
     const float* src;        // [nsrc][N]: coordinate-only subexpressions of the residual, evaluated when the point set was installed
-    int nsrc;                // tape rows D+NP+C .. D+NP+C+nsrc-1
+    int nsrc;                // tape rows dt+NP+C .. dt+NP+C+nsrc-1
+    // The term binds dt coordinates (rows of its point matrix, tape rows 0..dt-1); input i of the group's network is
+    // coordinate imap[i] of the term (src/discretize.jl:111-131: every depvar gets its own `cord` rows).  hetero = the map is
+    // not the identity over dt == D coordinates (systems whose dependent variables take different arguments).
+    int dt;
+    int hetero;
+    int imap[4];
 };
 
 struct GroupArgs {
@@ -402,7 +408,7 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
             vint p = vint(pbase + 16 * pg) + c;
             valid[pg] = vlt(p, T.N);
             PINN_UNROLL for (int i = 0; i < D; ++i) {
-                x[pg][i] = gload_masked(T.pts, p * D + vint(i), valid[pg]);
+                x[pg][i] = gload_masked(T.pts, p * T.dt + vint(T.imap[i]), valid[pg]);
                 if (BWD) lds_store(xs, (vint(16 * pg) + c) * D + vint(i), x[pg][i]);
             }
         }
@@ -537,15 +543,21 @@ Sr[q][m] = ub_load4(SB, (((layer * NG) + q) * MT + m) * 256, lane << 2);
             float* tv = lds;                    // value rows  [row][64]
             float* ta = lds + 2 * S::LDS_T;     // adjoint rows
             const int NP = ga.nparams;
-            const int R0 = D + NP + C + T.nsrc;
+            const int DT = T.dt;                // tape rows: [coordinates DT | params NP | jet channels C | sources | ops]
+            const int R0 = DT + NP + C + T.nsrc;
             const rp::Instr* prog = ga.prog + T.prog_off;
             const int nrows = R0 + T.nops;
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
-                PINN_UNROLL for (int i = 0; i < D; ++i) lds_store(tv, vint(i * 64) + lane, x[pg][i]);
-                for (int j = 0; j < NP; ++j) lds_store(tv, vint((D + j) * 64) + lane, vfloat(ga.params[j]));
-                PINN_UNROLL for (int ch = 0; ch < C; ++ch) lds_store(tv, vint((D + NP + ch) * 64) + lane, U[pg][ch]);
+                if (!T.hetero) {
+                    PINN_UNROLL for (int i = 0; i < D; ++i) lds_store(tv, vint(i * 64) + lane, x[pg][i]);
+                } else {
+                    for (int j = 0; j < DT; ++j)
+                        lds_store(tv, vint(j * 64) + lane, gload_masked(T.pts, (vint(pbase + 16 * pg) + c) * DT + vint(j), valid[pg]));
+                }
+                for (int j = 0; j < NP; ++j) lds_store(tv, vint((DT + j) * 64) + lane, vfloat(ga.params[j]));
+                PINN_UNROLL for (int ch = 0; ch < C; ++ch) lds_store(tv, vint((DT + NP + ch) * 64) + lane, U[pg][ch]);
                 for (int j = 0; j < T.nsrc; ++j)
-                    lds_store(tv, vint((D + NP + C + j) * 64) + lane, gload_masked(T.src, vint(j * T.N + pbase + 16 * pg) + c, valid[pg]));
+                    lds_store(tv, vint((DT + NP + C + j) * 64) + lane, gload_masked(T.src, vint(j * T.N + pbase + 16 * pg) + c, valid[pg]));
                 for (int q = 0; q < T.nops; ++q) {
                     const rp::Instr ins = rp::fetch_uniform(prog, q);
                     vfloat va = lds_load(tv, vint(ins.a * 64) + lane);            // unused operands point at row 0
@@ -581,9 +593,9 @@ Sr[q][m] = ub_load4(SB, (((layer * NG) + q) * MT + m) * 256, lane << 2);
                     lds_store(ta, vint(ins.b * 64) + lane, lds_load(ta, vint(ins.b * 64) + lane) + db);
                 }
                 PINN_UNROLL for (int ch = 0; ch < C; ++ch)       // masked points may hold inf/NaN (their sources read as 0)
-                    ubar[pg][ch] = vselect(valid[pg], rbar * lds_load(ta, vint((D + NP + ch) * 64) + lane), vfloat(0.f));
+                    ubar[pg][ch] = vselect(valid[pg], rbar * lds_load(ta, vint((DT + NP + ch) * 64) + lane), vfloat(0.f));
                 for (int j = 0; j < ga.nparams_estim; ++j) {
-                    vfloat pj = vselect(vand(g0, valid[pg]), rbar * lds_load(ta, vint((D + j) * 64) + lane), vfloat(0.f));
+                    vfloat pj = vselect(vand(g0, valid[pg]), rbar * lds_load(ta, vint((DT + j) * 64) + lane), vfloat(0.f));
                     PINN_UNROLL for (int jj = 0; jj < MAX_PARAMS; ++jj) if (jj == j) pbar[jj] += pj;
                 }
             }

@@ -157,7 +157,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
         PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
             vint p = vint(pbase + 16 * pg) + c;
             valid[pg] = vlt(p, T.N);
-            PINN_UNROLL for (int i = 0; i < D; ++i) x[pg][i] = gload_masked(T.pts, p * D + vint(i), valid[pg]);
+            PINN_UNROLL for (int i = 0; i < D; ++i) x[pg][i] = gload_masked(T.pts, p * T.dt + vint(T.imap[i]), valid[pg]);
         }
 
         // jet activation in place + record: layer LH-1 stays in registers (Rlast), the others go to the scratch slab
@@ -297,15 +297,20 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         PINN_UNROLL for (int ch = 0; ch < C; ++ch) Uin[ch] = U[pg][ch];
                     }
                 const int NP = ga.nparams;
-                const int R0 = D + NP + C + T.nsrc;
+                const int DT = T.dt;            // tape rows: [coordinates DT | params NP | jet channels C | sources | ops]
+                const int R0 = DT + NP + C + T.nsrc;
                 const rp::Instr* prog = ga.prog + T.prog_off;
                 vtape tv;
                 tape_zero(tv);
-                PINN_UNROLL for (int i = 0; i < D; ++i) tape_set(tv, i, xin[i]);
-                for (int j = 0; j < NP; ++j) tape_set(tv, D + j, vfloat(ga.params[j]));
-                PINN_UNROLL for (int ch = 0; ch < C; ++ch) tape_set(tv, D + NP + ch, Uin[ch]);
+                if (!T.hetero) {
+                    PINN_UNROLL for (int i = 0; i < D; ++i) tape_set(tv, i, xin[i]);
+                } else {
+                    for (int j = 0; j < DT; ++j) tape_set(tv, j, gload_masked(T.pts, (vint(pbase + 16 * w) + c) * DT + vint(j), vin));
+                }
+                for (int j = 0; j < NP; ++j) tape_set(tv, DT + j, vfloat(ga.params[j]));
+                PINN_UNROLL for (int ch = 0; ch < C; ++ch) tape_set(tv, DT + NP + ch, Uin[ch]);
                 for (int j = 0; j < T.nsrc; ++j)
-                    tape_set(tv, D + NP + C + j, gload_masked(T.src, vint(j * T.N + pbase + 16 * w) + c, vin));
+                    tape_set(tv, DT + NP + C + j, gload_masked(T.src, vint(j * T.N + pbase + 16 * w) + c, vin));
                 for (int q = 0; q < T.nops; ++q) {
                     const rp::Instr ins = rp::fetch_uniform(prog, q);
                     const vfloat va = tape_get(tv, ins.a), vb = tape_get(tv, ins.b);      // unused operands point at row 0
@@ -335,9 +340,9 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         tape_set(ta, ins.b, tape_get(ta, ins.b) + db);
                     }
                     PINN_UNROLL for (int ch = 0; ch < C; ++ch)
-                        lds_store(UB, vint((w * C + ch) * 16) + c, vselect(vin, rbar * tape_get(ta, D + NP + ch), vfloat(0.f)));   // 4 row groups: same value; masked points may hold inf/NaN
+                        lds_store(UB, vint((w * C + ch) * 16) + c, vselect(vin, rbar * tape_get(ta, DT + NP + ch), vfloat(0.f)));   // 4 row groups: same value; masked points may hold inf/NaN
                     for (int j = 0; j < ga.nparams_estim; ++j) {
-                        vfloat pj = vselect(vand(g0, vin), rbar * tape_get(ta, D + j), vfloat(0.f));
+                        vfloat pj = vselect(vand(g0, vin), rbar * tape_get(ta, DT + j), vfloat(0.f));
                         PINN_UNROLL for (int jj = 0; jj < MAX_PARAMS; ++jj) if (jj == j) pbar[jj] += pj;
                     }
                 }

@@ -14,7 +14,7 @@ Row numbering inside a term (descriptor side):
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import List, Sequence, Tuple
+from typing import Dict, List, Sequence, Tuple
 
 OPS = ["CONST", "ADD", "SUB", "MUL", "DIV", "NEG", "ADDC", "MULC", "POWI", "POW", "POWC", "SIN", "COS", "TAN", "EXP",
        "LOG", "SQRT", "ABS", "TANH", "SINH", "COSH", "SECH", "SINPI", "COSPI", "MAX", "MIN"]
@@ -49,6 +49,9 @@ class TermIR:
     indvars: Tuple[str, ...] = ()       # names bound to the rows of `cord`
     kind: str = "pde"                   # "pde" | "bc"
     source: str = ""                    # printable form of lhs - rhs
+    # net -> for each network input the index of the term coordinate that feeds it, only for networks whose inputs are
+    # not simply the term's coordinates in order (dependent variables with different arguments, src/discretize.jl:111-131)
+    inmaps: Dict[int, Tuple[int, ...]] = field(default_factory=dict)
 
 
 @dataclass
@@ -82,4 +85,6 @@ class ProblemIR:
                 out.append(f"slot {s.net} {s.order} " + " ".join(str(a) for a in s.axes))
             for q in t.ops:
                 out.append(f"op {q.op} {q.a} {q.b} {float(q.imm)!r}")
+            for net, m in sorted(t.inmaps.items()):
+                out.append(f"inmap {net} {len(m)} " + " ".join(str(i) for i in m))
         return "\n".join(out) + "\n"

@@ -319,13 +319,6 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
                              "(test/direct_function__trivial_bc_0_0_*.jl:44)")
         sym_bc.append(lower_equation(bc, vi, eq_params, "bc"))
     terms = sym_pde + sym_bc
-    for t in terms:
-        for s in t.slots:
-            name = vi.depvars[s.net]
-            if vi.dict_depvar_input[name] != list(t.indvars):
-                raise NotImplementedError(
-                    f"heterogeneous inputs: {name} takes {vi.dict_depvar_input[name]} but the term binds {list(t.indvars)}; "
-                    "per-network input subsets (test/NNPDE1/nnpde__pde_i_heterogeneous_system.jl) are not supported yet")
 
     NP = len(eq_params)
     NE = NP if (param_estim and NP) else 0

@@ -369,5 +369,15 @@ def lower_equation(eq: Equation, vi: VarInfo, params: Sequence, kind: str) -> Te
     ops = []
     for (op, a, b, imm) in B.ops:
         ops.append(Instr(op, row(a) if a is not None else 0, row(b) if (b is not None and op in BINARY) else 0, imm))
+    # every dependent variable gets its own rows of `cord` (src/discretize.jl:111-131): inputs of net k = the term's
+    # coordinates named by dict_depvar_input[depvar k]
+    inmaps = {}
+    for sl in B.slots:
+        if sl.net in inmaps:
+            continue
+        name = vi.depvars[sl.net]
+        m = tuple(indvars.index(v) for v in vi.dict_depvar_input[name])
+        if m != tuple(range(d)):
+            inmaps[sl.net] = m
     return TermIR(dim=d, slots=list(B.slots), ops=ops, out_row=row(out), indvars=tuple(indvars), kind=kind,
-                  source=str(expr))
+                  source=str(expr), inmaps=inmaps)

@@ -331,3 +331,27 @@ def test_kuramoto_sivashinsky_jets(npde, use_emu):
     np.testing.assert_allclose(r, po.residual_values(prob, th, 0, sets[0], mode="exact"), rtol=3e-5, atol=3e-5)
     big = npde.Chain(npde.Dense(2, 64, "tanh"), *[npde.Dense(64, 64, "tanh") for _ in range(3)], npde.Dense(64, 1))
     check(npde, sysm, [big], strat, theta_for(big, 42), weights=[1.0, 1.0, 2.0, 2.0, 0.5, 0.5], mode="exact")
+
+
+def test_heterogeneous_system(npde, use_emu):
+    """dependent variables with different argument lists in one system (test/NNPDE1/nnpde__pde_i_heterogeneous_system.jl:58-80):
+    u(x,y,z), v(y,x), h(z), p(x,z) — every network reads its own rows of the term's coordinate matrix (permuted for v)."""
+    x, y, z = npde.parameters("x y z")
+    u, v, h, p = npde.variables("u v h p")
+    Dz = npde.Differential(z)
+    eqs = [npde.Eq(u(x, y, z), x + y + z),
+           npde.Eq(v(y, x), x ** 2 + y ** 2),
+           npde.Eq(h(z), sp.cos(z)),
+           npde.Eq(p(x, z), sp.exp(x) * sp.exp(z)),
+           npde.Eq(u(x, y, z) + v(y, x) * Dz(h(z)) - p(x, z), x + y + z - (x ** 2 + y ** 2) * sp.sin(z) - sp.exp(x) * sp.exp(z))]
+    bcs = [npde.Eq(u(0.0, 0.0, 0.0), 0.0)]
+    dom = [npde.In(s, npde.Interval(0.0, 1.0)) for s in (x, y, z)]
+    sysm = npde.PDESystem(eqs, bcs, dom, [x, y, z], [u(x, y, z), v(y, x), h(z), p(x, z)])
+    chains = [npde.Chain(npde.Dense(n, 12, "tanh"), npde.Dense(12, 12, "tanh"), npde.Dense(12, 1)) for n in (3, 2, 1, 2)]
+    theta = np.concatenate([theta_for(c, 50 + i) for i, c in enumerate(chains)])
+    rep, prob, sets, th = check(npde, sysm, chains, npde.GridTraining(0.25), theta, weights=[1.0, 2.0, 0.5, 1.5, 3.0, 1.0])
+    d = rep.engine.describe()
+    assert "coupled" in d
+    # the permuted-input network alone: residual of v(y, x) ~ x^2 + y^2 on its own (y, x) point matrix
+    r = rep.loss_functions.datafree_pde_loss_functions[1](sets[1], th)
+    np.testing.assert_allclose(r, po.residual_values(prob, th, 1, sets[1]), rtol=2e-5, atol=2e-5)

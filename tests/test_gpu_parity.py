@@ -247,3 +247,27 @@ def test_higher_order_derivatives_gpu(npde, hip_lib):
     run(ks, npde.Chain(npde.Dense(2, 12, "sigmoid"), npde.Dense(12, 12, "sigmoid"), npde.Dense(12, 1)), strat, 41)
     run(ks, npde.Chain(npde.Dense(2, 64, "tanh"), *[npde.Dense(64, 64, "tanh") for _ in range(3)], npde.Dense(64, 1)), strat, 42,
         weights=[1.0, 1.0, 2.0, 2.0, 0.5, 0.5])
+
+
+def test_heterogeneous_system_gpu(npde, hip_lib):
+    """u(x,y,z), v(y,x), h(z), p(x,z) in one system (test/NNPDE1/nnpde__pde_i_heterogeneous_system.jl): per-network input maps."""
+    import test_emu_parity as tp
+    import sympy as sp
+    x, y, z = npde.parameters("x y z")
+    u, v, h, p = npde.variables("u v h p")
+    Dz = npde.Differential(z)
+    eqs = [npde.Eq(u(x, y, z), x + y + z), npde.Eq(v(y, x), x ** 2 + y ** 2), npde.Eq(h(z), sp.cos(z)),
+           npde.Eq(p(x, z), sp.exp(x) * sp.exp(z)),
+           npde.Eq(u(x, y, z) + v(y, x) * Dz(h(z)) - p(x, z), x + y + z - (x ** 2 + y ** 2) * sp.sin(z) - sp.exp(x) * sp.exp(z))]
+    sysm = npde.PDESystem(eqs, [npde.Eq(u(0.0, 0.0, 0.0), 0.0)], [npde.In(s, npde.Interval(0.0, 1.0)) for s in (x, y, z)], [x, y, z],
+                          [u(x, y, z), v(y, x), h(z), p(x, z)])
+    chains = [npde.Chain(npde.Dense(n, 12, "tanh"), npde.Dense(12, 12, "tanh"), npde.Dense(12, 1)) for n in (3, 2, 1, 2)]
+    theta = np.concatenate([tp.theta_for(c, 50 + i) for i, c in enumerate(chains)])
+    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chains, npde.GridTraining(0.1), init_params=theta))
+    assert rep.engine.L.backend == "hip"
+    sets = rep.pde_train_sets + rep.bcs_train_sets
+    w = [1.0, 2.0, 0.5, 1.5, 3.0, 1.0]
+    losses, grad = rep.engine.loss_grad(theta, w)
+    ref = po.loss_and_grad(helpers.oracle_problem(npde, sysm, chains), theta, sets, weights=w, mode="stencil")
+    le, g2, gi = helpers.rel_errors(losses, grad, ref)
+    assert le.max() < TOL and g2 < TOL and gi < TOL, (le, g2, gi)
