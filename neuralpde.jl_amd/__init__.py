@@ -10,6 +10,7 @@ See DESIGN.md for the kernel design and INTEGRATION.md for the Julia `ccall` bin
 from . import _lib
 from ._lib import Engine, EngineError, Library
 from .ir import Instr, NetIR, ProblemIR, Slot, TermIR
+from .bpinn import physics_loglikelihood
 from .adaptive import (AbstractAdaptiveLoss, GradientScaleAdaptiveLoss, MiniMaxAdaptiveLoss, ReLoBRaLoAdaptiveLoss,
                        SoftAdaptAdaptiveLoss)
 from .pinn import (Adam, OptimizationSolution, solve, Chain, Dense, LogOptions, NonAdaptiveLoss, OptimizationFunction, OptimizationProblem, Phi,

@@ -355,3 +355,26 @@ def test_heterogeneous_system(npde, use_emu):
     # the permuted-input network alone: residual of v(y, x) ~ x^2 + y^2 on its own (y, x) point matrix
     r = rep.loss_functions.datafree_pde_loss_functions[1](sets[1], th)
     np.testing.assert_allclose(r, po.residual_values(prob, th, 1, sets[1]), rtol=2e-5, atol=2e-5)
+
+
+def test_bpinn_physics_loglikelihood(npde, use_emu):
+    """l(theta) = sum_k logpdf(MvNormal(r_k, sigma_k^2 I), 0) (src/training_strategies.jl:113-127, ext/bpinn/PDE_BPINN.jl:425)
+    and its gradient from the engine's per-term sums, against the oracle's residuals."""
+    sysm, chain = poisson2d(npde, "tanh")
+    th = theta_for(chain, 61)
+    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.125), init_params=th))
+    sets = rep.pde_train_sets + rep.bcs_train_sets
+    stds = [0.7, 0.05, 0.08, 0.11, 0.2]
+    sizes = [s.shape[1] for s in sets]
+    ll, g = npde.physics_loglikelihood(rep.engine, th, stds, sizes)
+    prob = helpers.oracle_problem(npde, sysm, [chain])
+    ll_ref = 0.0
+    for k, (s, sd) in enumerate(zip(sets, stds)):
+        r = po.residual_values(prob, th, k, s).reshape(-1)
+        ll_ref += -0.5 * r.size * np.log(2 * np.pi) - r.size * np.log(sd) - np.sum(r * r) / (2 * sd * sd)
+    assert abs(ll - ll_ref) < 1e-5 * abs(ll_ref)
+    w = [n / (2 * sd * sd) for n, sd in zip(sizes, stds)]
+    ref = po.loss_and_grad(prob, th, sets, weights=w, mode="stencil")
+    assert np.linalg.norm(g + ref.grad) < 1e-5 * np.linalg.norm(ref.grad)
+    with pytest.raises(ValueError):
+        npde.physics_loglikelihood(rep.engine, th, stds[:-1], sizes[:-1])
