@@ -382,6 +382,16 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                     }
         };
 
+        // records parked in the scratch slab are requested one phase before they are needed (SPRE: when they take <= 24 registers)
+        constexpr bool SPRE = (NG * MTW * 4 <= 24);
+        vfloat4 Snext[SPRE ? NG : 1][SPRE ? MTW : 1];
+        auto load_record = [&](int hl) {                                     // record of hidden layer hl (1 <= hl <= LH-2)
+            PINN_UNROLL for (int q = 0; q < NG; ++q)
+                PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                    Snext[q][t] = ub_load4(SB, (((hl - 1) * NG + q) * MT + w * MTW + t) * 256, lane << 2);
+            sched_fence();
+        };
+        if (SPRE && NHH - 1 >= 1) load_record(NHH - 1);
         vfloat4 G[NG][MTW];
         PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {                        // output layer
             if (w == 0) bLbar += vselect(g0, ubar[pg][0], vfloat(0.f));
@@ -414,6 +424,9 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         PINN_UNROLL for (int ch = 1 + NFIRST; ch < C; ++ch) Sr[pg * C + ch][t] = vzero4();
                     }
                 }
+            } else if (SPRE) {
+                PINN_UNROLL for (int q = 0; q < NG; ++q)
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t) Sr[q][t] = Snext[q][t];
             } else {
                 PINN_UNROLL for (int q = 0; q < NG; ++q)
                     PINN_UNROLL for (int t = 0; t < MTW; ++t)
@@ -484,6 +497,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         PINN_UNROLL for (int e = 0; e < 4; ++e) cur[e] += wacc[t][ti][e];
                         gstore4(slab + S::O_WBAR, off, cur);
                     }
+            if (SPRE && hl - 1 >= 1) load_record(hl - 1);                    // next iteration's record: latency hides under the dA GEMM
             // ---- dA (own input tiles) = W^T dZ ----
             vfloat4 Gn[NG][MTW];
             PINN_UNROLL for (int q = 0; q < NG; ++q)
