@@ -295,6 +295,173 @@ DEV void jet_adjoint(vfloat (&g)[J::C], const vfloat (&s)[J::C], const vfloat (&
 }
 
 DEV vfloat act_value(int act, vfloat z) {
+    if (act == ACT_TANH) return vtanh_fast(z);
+    return vsigmoid_fast(z);
+}
+
+// XOR-swizzled address inside a [16 columns][HP] transpose buffer: neuron n of column `col`
+template <class S>
+DEV vint tr_addr(vint col, vint slot) {
+    // slots of 4 floats; 4*MT slots per row
+    return col * S::HP + (((slot ^ col) & (4 * S::MT - 1)) << 2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The wave program.  Workgroup `blk` of `nblocks` (persistent grid), wave `w` (0..3) of the workgroup.
+// All four waves of a workgroup run the same number of tile iterations (tiles past the end are fully masked
+// dummies) because the COOP dW phase synchronises them with workgroup barriers.
+// ------------------------------------------------------------------------------------------------
+template <class S, int MODE>
+DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_wg) {
+    const int wave = blk * 4 + w;
+    float* lds = lds_wg + S::LDS_SHARED + w * S::LDS_PRIV;     // wave-private LDS
+    float* lds_sh = lds_wg;                                    // workgroup-shared chunk buffers (COOP)
+    constexpr bool BWD = (MODE == MODE_FUSED || MODE == MODE_GRADIN);       // modes that run the reverse sweep
+    constexpr bool COOP = S::COOP && BWD;
+    constexpr int WT = S::WT;
+    constexpr int HP = S::HP, MT = S::MT, NHH = S::NHH, LH = S::LH, D = S::D, C = S::C, PG = S::PG, NG = S::NG;
+    constexpr int NFIRST = S::NFIRST;
+    using J = typename S::J;
+    const vint lane = lane_id();
+    const vint g = lane >> 4;
+    const vint c = lane & vint(15);
+    const vbool g0 = veq(g, 0);
+    const float* P = ga.packed;
+    const int act = ga.act;
+
+    // ---- persistent per-wave gradient accumulators (registers / AGPRs across all tiles) ----
+    vfloat4 wbar[NHH > 0 ? NHH : 1][WT][MT];      // COOP: this wave's row block (to == w) only
+    vfloat bfrh[NHH > 0 ? NHH : 1][WT];           // bias grads of hidden layers >= 1 (fragment form)
+    vfloat bfr0[MT];                              // bias grad of hidden layer 0
+    vfloat w1fr[D][MT];
+    vfloat4 wLbar[MT];
+    vfloat bLbar = vfloat(0.f);
+    vfloat pbar[MAX_PARAMS];
+    PINN_UNROLL for (int l = 0; l < (NHH > 0 ? NHH : 1); ++l)
+        PINN_UNROLL for (int a = 0; a < WT; ++a) {
+            bfrh[l][a] = vfloat(0.f);
+            PINN_UNROLL for (int b = 0; b < MT; ++b) wbar[l][a][b] = vzero4();
+        }
+    PINN_UNROLL for (int a = 0; a < MT; ++a) bfr0[a] = vfloat(0.f);
+    PINN_UNROLL for (int i = 0; i < D; ++i)
+        PINN_UNROLL for (int a = 0; a < MT; ++a) w1fr[i][a] = vfloat(0.f);
+    PINN_UNROLL for (int a = 0; a < MT; ++a) wLbar[a] = vzero4();
+    PINN_UNROLL for (int i = 0; i < MAX_PARAMS; ++i) pbar[i] = vfloat(0.f);
+
+    vfloat lsum = vfloat(0.f);
+    int cur_term = -1;      // index into ga.terms of the term whose loss is being accumulated
+    int cq = 0;             // running chunk counter: parity selects the shared LDS chunk buffer (COOP)
+
+    const ubuf SB = ub_make(ga.scratch + (size_t)wave * S::SCR, S::SCR);      // this wave's activation scratch
+    const ubuf PB = ub_make(P, S::PACKED);                                         // packed weights of this net
+    float* xs = lds + 4 * S::LDS_T;           // coords of the tile: [pg][pt][i]
+
+    // output layer weights in D layout
+    vfloat4 wL[MT];
+    PINN_UNROLL for (int m = 0; m < MT; ++m) wL[m] = ub_load4(PB, S::OFF_WL + 16 * m, g << 2);
+    const float bL = P[S::OFF_BL];
+
+    if (MODE == MODE_FUSED)      // this wave's loss columns start at zero (no host-side memset per evaluation)
+        for (int j = 0; j < ga.nterms; ++j) ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[j].term_id] = 0.0;
+    const int niter = (ga.ntiles + 4 * nblocks - 1) / (4 * nblocks);
+    for (int it = 0; it < niter; ++it) {
+        const int t = (it * nblocks + blk) * 4 + w;          // >= ntiles: dummy tile of the last term, all points masked
+        // ---- locate the term of this tile (terms are tile-contiguous) ----
+        int k = 0;
+        for (int j = 1; j < ga.nterms; ++j)
+            if (t >= ga.terms[j].tile0) k = j;
+        if (k != cur_term) {
+            if (cur_term >= 0) {
+                double s = wave_sum_d(lsum, g0);
+                if (MODE == MODE_FUSED) ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[cur_term].term_id] = s;
+            }
+            lsum = vfloat(0.f);
+            cur_term = k;
+        }
+        const TermDev& T = ga.terms[k];
+        const int pbase = (t - T.tile0) * S::TP;
+
+        // ---- coordinates ----
+        vfloat x[PG][D];
+        vbool valid[PG];
+        PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+            vint p = vint(pbase + 16 * pg) + c;
+            valid[pg] = vlt(p, T.N);
+            PINN_UNROLL for (int i = 0; i < D; ++i) {
+                x[pg][i] = gload_masked(T.pts, p * T.dt + vint(T.imap[i]), valid[pg]);
+                if (BWD) lds_store(xs, (vint(16 * pg) + c) * D + vint(i), x[pg][i]);
+            }
+        }
+
+        // =========================== forward Taylor-jet sweep ===========================
+        vfloat4 A[NG][MT];
+        // ---- layer 1: d -> HP on the VALU (K = d is tiny) ----
+        PINN_UNROLL for (int m = 0; m < MT; ++m) {
+            vfloat4 b1 = ub_load4(PB, S::OFF_B + 16 * m, g << 2);
+            vfloat4 w1[D];
+            PINN_UNROLL for (int i = 0; i < D; ++i) w1[i] = ub_load4(PB, S::OFF_W1 + i * HP + 16 * m, g << 2);
+            PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                vfloat4 z = b1;
+                PINN_UNROLL for (int i = 0; i < D; ++i)
+                    PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = vfma(w1[i][r], x[pg][i], z[r]);
+                A[pg * C][m] = z;
+                PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) A[pg * C + 1 + kf][m] = w1[S::first_axis(kf)];
+                PINN_UNROLL for (int ch = 1 + NFIRST; ch < C; ++ch) A[pg * C + ch][m] = vzero4();       // second and higher derivatives of an affine map
+            }
+        }
+
+        // raw (a, z_i, z_ij) record of the LAST hidden layer stays in registers for the reverse sweep
+        vfloat4 Rlast[NG][MT];
+        // activation jets in place + park (a, z_i, z_ij) of the other layers in the scratch slab
+        auto act_forward = [&](vfloat4 (&Z)[NG][MT], int layer /*0-based hidden layer*/) {
+            PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
+                PINN_UNROLL for (int m = 0; m < MT; ++m) {
+                    PINN_UNROLL for (int r = 0; r < 4; ++r) Z[pg * C][m][r] = act_value(act, Z[pg * C][m][r]);
+                    if (BWD) {
+                        if (layer == LH - 1) {
+                            PINN_UNROLL for (int ch = 0; ch < C; ++ch) Rlast[pg * C + ch][m] = Z[pg * C + ch][m];
+                        } else {
+                            PINN_UNROLL for (int ch = 0; ch < C; ++ch)
+                                ub_store4(SB, (((layer * NG) + pg * C + ch) * MT + m) * 256, lane << 2, Z[pg * C + ch][m]);
+                        }
+                    }
+                    PINN_UNROLL for (int r = 0; r < 4; ++r) {
+                        vfloat zz[C], dd[6];
+                        PINN_UNROLL for (int ch = 0; ch < C; ++ch) zz[ch] = Z[pg * C + ch][m][r];
+                        act_derivs_n<J::NORD - 1>(act, zz[0], dd);
+                        jet_forward<J>(zz, dd);
+                        PINN_UNROLL for (int ch = 1; ch < C; ++ch) Z[pg * C + ch][m][r] = zz[ch];
+                    }
+                }
+        };
+        act_forward(A, 0);
+
+        // ---- hidden -> hidden layers on the matrix cores ----
+        PINN_UNROLL for (int hl = 0; hl < NHH; ++hl) {
+            vfloat4 Zn[NG][MT];
+            PINN_UNROLL for (int m = 0; m < MT; ++m) {
+                vfloat4 bv = ub_load4(PB, S::OFF_B + (hl + 1) * HP + 16 * m, g << 2);
+                PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                    Zn[pg * C][m] = bv;
+                    PINN_UNROLL for (int ch = 1; ch < C; ++ch) Zn[pg * C + ch][m] = vzero4();
+                }
+            }
+            const int Wf = S::OFF_WPK + hl * HP * HP;
+            // k-steps (mi, rr); the fragment of step ks+1 is requested before the MFMAs of step ks (software pipeline:
+            // with one wave per SIMD nothing else hides the L2 latency of a just-in-time load)
+            auto load_wf = [&](int ks, vfloat (&wf)[MT]) {
+                if (MT == 4) {
+                    vfloat4 w4 = ub_load4(PB, Wf + ks * 64 * MT, lane << 2);
+                    PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wf[mo] = w4[mo & 3];
+                } else {
+                    PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wf[mo] = ub_load(PB, Wf + ks * 64 * MT + mo, lane * MT);
+                }
+            };
+            vfloat wcur[MT], wnxt[MT];
+            load_wf(0, wcur);
+            PINN_UNROLL for (int ks = 0; ks < 4 * MT; ++ks) {
+                const int mi = ks >> 2, rr = ks & 3;
+                if (ks + 1 < 4 * MT) load_wf(ks + 1, wnxt);
                 PINN_UNROLL for (int q = 0; q < NG; ++q)
                     PINN_UNROLL for (int mo = 0; mo < MT; ++mo) Zn[q][mo] = mfma16(wcur[mo], A[q][mi][rr], Zn[q][mo]);
                 PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wcur[mo] = wnxt[mo];
