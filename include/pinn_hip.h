@@ -99,13 +99,17 @@ int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float*
  * per-iteration PCIe traffic.  Mirrors `solve(prob, Adam(lr); maxiters)` ([3P] OptimizationOptimisers, used by every
  * reference test, e.g. test/NNPDE1/nnpde__pde_ii_2d_poisson.jl:83) on the objective of pinn_loss_grad.
  *   pinn_set_sampler : kind 1 = redraw the term's points uniformly in [lb, ub] on the device before every step
- *                      (StochasticTraining, src/training_strategies.jl:242-245, 277-281); kind 0 = keep the installed set.
+ *                      (StochasticTraining, src/training_strategies.jl:242-245, 277-281); kind 2 = Latin-hypercube redraw
+ *                      (QuasiRandomTraining with its default LatinHypercubeSample and resampling = true, :321, 375-381);
+ *                      kind 0 = keep the installed set.
  *   pinn_adam_init   : upload theta (P floats), zero the moments.
  *   pinn_adam_steps  : nsteps updates m = b1 m + (1-b1) g, v = b2 v + (1-b2) g^2, theta -= lr m^/(sqrt(v^) + eps);
  *                      loss_history (nullable) receives the weighted total loss of every step.
  *   pinn_adam_get    : download theta.
  */
 int pinn_set_sampler(pinn_handle h, int term, int kind, const float* lb, const float* ub, int64_t n, uint64_t seed);
+/* Copy the term's current collocation set (d x N, point-major, as installed or as last drawn by the device sampler) to the host. */
+int pinn_get_points(pinn_handle h, int term, float* pts, int64_t n);
 int pinn_adam_init(pinn_handle h, const float* theta, int64_t p);
 int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta2, float eps, const float* term_w, double* loss_history);
 int pinn_adam_get(pinn_handle h, float* theta, int64_t p);

@@ -148,6 +148,37 @@ AUX_DEV void sample_body(int e, float* pts, int d, const float* lb, const float*
     pts[e] = lb[i] + (ub[i] - lb[i]) * u;
 }
 
+// Latin-hypercube redraw (the reference's default QuasiRandomTraining sampler, LatinHypercubeSample, src/training_strategies.jl:321,
+// 375-381): along every axis the n points occupy the n strata [k/n, (k+1)/n) exactly once, at a random position inside the
+// stratum.  The per-axis random permutation of the strata is a keyed 4-round Feistel network on ceil(log2 n) bits with
+// cycle walking (a bijection of [0, n) that needs no sort and no memory), keyed by (seed, draw counter, axis).
+AUX_DEV unsigned lhs_perm(unsigned k, unsigned n, unsigned key) {
+    unsigned bits = 1;
+    while ((1u << bits) < n) ++bits;
+    if (bits & 1) ++bits;                               // even split into two halves
+    const unsigned half = bits >> 1, mask = (1u << half) - 1u;
+    unsigned x = k;
+    do {
+        unsigned l = x >> half, r = x & mask;
+        for (unsigned round = 0; round < 4; ++round) {
+            const unsigned f = mix32(r ^ (key + round * 0x9E3779B9U)) & mask;
+            const unsigned nl = r, nr = l ^ f;
+            l = nl; r = nr;
+        }
+        x = (l << half) | r;
+    } while (x >= n);                                   // cycle walking: stay inside [0, n)
+    return x;
+}
+AUX_DEV void sample_lhs_body(int e, float* pts, int d, int n, const float* lb, const float* ub, unsigned seed, unsigned draw) {
+    const int i = e % d, p = e / d;
+    const unsigned key = mix32(seed ^ (draw * 0x85EBCA6BU + 0xC2B2AE35U) ^ ((unsigned)i * 0x27D4EB2FU));
+    const unsigned stratum = lhs_perm((unsigned)p, (unsigned)n, key);
+    unsigned h = mix32((unsigned)e * 0x9E3779B9U + seed);
+    h = mix32(h ^ (draw * 0xC2B2AE3DU + 0x165667B1U));
+    const float u = ((float)stratum + (float)(h >> 8) * (1.0f / 16777216.0f)) / (float)n;
+    pts[e] = lb[i] + (ub[i] - lb[i]) * u;
+}
+
 AUX_DEV void pack_body(int i, float* packed, const int* idx, const float* theta) {
     const int j = idx[i];
     packed[i] = (j >= 0) ? theta[j] : 0.f;
@@ -227,8 +258,11 @@ inline void launch_adam(float* theta, float* m, float* v, const float* grad, int
 inline void launch_total_loss(double* hist, int step, const float* out, int P, int K, const float* w_over_n, plat_stream) {
     total_loss_body(hist, step, out, P, K, w_over_n);
 }
-inline void launch_sample(float* pts, int n_elems, int d, const float* lb, const float* ub, unsigned seed, unsigned draw, plat_stream) {
-    for (int e = 0; e < n_elems; ++e) sample_body(e, pts, d, lb, ub, seed, draw);
+inline void launch_sample(int kind, float* pts, int n_elems, int d, const float* lb, const float* ub, unsigned seed, unsigned draw, plat_stream) {
+    for (int e = 0; e < n_elems; ++e) {
+        if (kind == 2) sample_lhs_body(e, pts, d, n_elems / d, lb, ub, seed, draw);
+        else sample_body(e, pts, d, lb, ub, seed, draw);
+    }
 }
 inline void launch_src(const SrcArgs& a, plat_stream) {
     for (int p = 0; p < a.N; ++p) src_point(p, a);
@@ -278,14 +312,19 @@ __global__ void k_sample(float* pts, int n_elems, int d, const float* lb, const 
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < n_elems) sample_body(e, pts, d, lb, ub, seed, draw);
 }
+__global__ void k_sample_lhs(float* pts, int n_elems, int d, const float* lb, const float* ub, unsigned seed, unsigned draw) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_elems) sample_lhs_body(e, pts, d, n_elems / d, lb, ub, seed, draw);
+}
 inline void launch_adam(float* theta, float* m, float* v, const float* grad, int P, float lr, float b1, float b2, float eps, float c1, float c2, plat_stream st) {
     hipLaunchKernelGGL(k_adam, dim3((P + 255) / 256), dim3(256), 0, st, theta, m, v, grad, P, lr, b1, b2, eps, c1, c2);
 }
 inline void launch_total_loss(double* hist, int step, const float* out, int P, int K, const float* w_over_n, plat_stream st) {
     hipLaunchKernelGGL(k_total_loss, dim3(1), dim3(64), 0, st, hist, step, out, P, K, w_over_n);
 }
-inline void launch_sample(float* pts, int n_elems, int d, const float* lb, const float* ub, unsigned seed, unsigned draw, plat_stream st) {
-    hipLaunchKernelGGL(k_sample, dim3((n_elems + 255) / 256), dim3(256), 0, st, pts, n_elems, d, lb, ub, seed, draw);
+inline void launch_sample(int kind, float* pts, int n_elems, int d, const float* lb, const float* ub, unsigned seed, unsigned draw, plat_stream st) {
+    if (kind == 2) hipLaunchKernelGGL(k_sample_lhs, dim3((n_elems + 255) / 256), dim3(256), 0, st, pts, n_elems, d, lb, ub, seed, draw);
+    else hipLaunchKernelGGL(k_sample, dim3((n_elems + 255) / 256), dim3(256), 0, st, pts, n_elems, d, lb, ub, seed, draw);
 }
 __global__ void __launch_bounds__(256) k_expr(const ExprArgs a) {
     __shared__ double sh[5][256];

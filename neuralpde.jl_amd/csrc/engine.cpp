@@ -89,7 +89,8 @@ struct Term {
     int64_t n = 0, n_norm = 0;
     float* d_resid = nullptr;
     int64_t resid_cap = 0;
-    // on-device sampler (StochasticTraining): kind 0 = fixed set, 1 = uniform redraw before every training step
+    // on-device sampler: kind 0 = fixed set, 1 = uniform (StochasticTraining), 2 = Latin hypercube (QuasiRandomTraining default),
+    // redrawn before every training step
     int sampler = 0;
     float* d_lb = nullptr;
     float* d_ub = nullptr;
@@ -1296,7 +1297,7 @@ int pinn_set_sampler(pinn_handle h, int term, int kind, const float* lb, const f
     pinn_engine& E = *h;
     if (term < 0 || term >= (int)E.terms.size()) return fail("pinn_set_sampler: term index out of range");
     Term& T = E.terms[term];
-    if (kind != 0 && kind != 1) return fail("pinn_set_sampler: kind must be 0 (fixed set) or 1 (uniform)");
+    if (kind < 0 || kind > 2) return fail("pinn_set_sampler: kind must be 0 (fixed set), 1 (uniform) or 2 (Latin hypercube)");
     T.sampler = kind;
     if (kind == 0) return 0;
     if (!lb || !ub || n <= 0) return fail("pinn_set_sampler: bounds and a positive point count are required");
@@ -1309,9 +1310,20 @@ int pinn_set_sampler(pinn_handle h, int term, int kind, const float* lb, const f
     // allocate / size the term's point buffer through the normal path with a first draw
     std::vector<float> tmp((size_t)n * T.d, 0.f);
     if (set_points_impl(h, term, tmp.data(), n, 0, false)) return 1;
-    aux::launch_sample(T.d_pts, (int)(n * T.d), T.d, T.d_lb, T.d_ub, T.seed, T.draws++, E.stream);
+    aux::launch_sample(kind, T.d_pts, (int)(n * T.d), T.d, T.d_lb, T.d_ub, T.seed, T.draws++, E.stream);
     eval_sources(E, T);
     plat_sync(E.stream);
+    return 0;
+}
+
+int pinn_get_points(pinn_handle h, int term, float* pts, int64_t n) {
+    if (!h || !pts) return fail("pinn_get_points: null argument");
+    pinn_engine& E = *h;
+    if (term < 0 || term >= (int)E.terms.size()) return fail("pinn_get_points: term index out of range");
+    Term& T = E.terms[term];
+    if (!T.d_pts || n != T.n) return fail("pinn_get_points: the term holds " + std::to_string(T.n) + " points");
+    if (plat_d2h(pts, T.d_pts, sizeof(float) * (size_t)n * T.d, E.stream)) return fail("D2H copy failed");
+    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
     return 0;
 }
 
@@ -1355,8 +1367,8 @@ int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta
     for (int s = 0; s < nsteps; ++s) {
         for (size_t t = 0; t < E.terms.size(); ++t) {            // resampling strategies: fresh points every evaluation, on device
             Term& T = E.terms[t];
-            if (T.sampler == 1) {
-                aux::launch_sample(T.d_pts, (int)(T.n * T.d), T.d, T.d_lb, T.d_ub, T.seed, T.draws++, E.stream);
+            if (T.sampler != 0) {
+                aux::launch_sample(T.sampler, T.d_pts, (int)(T.n * T.d), T.d, T.d_lb, T.d_ub, T.seed, T.draws++, E.stream);
                 eval_sources(E, T);
             }
         }

@@ -225,10 +225,10 @@ def solve(prob: OptimizationProblem, alg: Adam, maxiters: int = 1000, callback: 
     eng = rep.engine
     eng_resample = getattr(rep, "_device_samplers", None)
     if eng_resample:
-        for k, (lb, ub, n, seed) in eng_resample.items():
-            eng.set_sampler(k, lb, ub, n, seed)
+        for k, (lb, ub, n, seed, kind) in eng_resample.items():
+            eng.set_sampler(k, lb, ub, n, seed, kind)
     elif rep._state.get("resample") is not None:
-        raise NotImplementedError("solve(): only StochasticTraining has an on-device sampler; use resampling=False designs "
+        raise NotImplementedError("solve(): only StochasticTraining and Latin-hypercube QuasiRandomTraining have on-device samplers; use resampling=False designs "
                                   "or a host loop over prob.f.value_and_grad")
     theta, losses, done, init = np.asarray(prob.u0, dtype=np.float64), [], 0, True
     ada = rep.adaloss
@@ -444,14 +444,18 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
     rep._value_and_grad = value_and_grad
     rep._weights_now = weights_now
     rep._weights = weights_now()
-    # StochasticTraining has an on-device counterpart (uniform redraw in the same bounds) for the resident-theta loop
-    from .strategies import StochasticTraining, get_bounds
+    # resampling strategies with an on-device counterpart for the resident-theta loop: StochasticTraining (uniform redraw in the
+    # same bounds) and QuasiRandomTraining(resampling = true) with its default LatinHypercubeSample
+    from .strategies import LatinHypercubeSample, QuasiRandomTraining, StochasticTraining, get_bounds
     rep._device_samplers = None
-    if isinstance(strategy, StochasticTraining):
+    kind = 1 if isinstance(strategy, StochasticTraining) else (
+        2 if (isinstance(strategy, QuasiRandomTraining) and strategy.resampling and isinstance(strategy.sampling_alg, LatinHypercubeSample)) else 0)
+    if kind:
         pb, bb = get_bounds(pde_system.domain, eqs, bcs, np.float64, vi, strategy.points)
+        rng = getattr(strategy, "rng", None) or np.random.default_rng()
         rep._device_samplers = {}
         for k, (lb, ub) in enumerate(list(pb) + list(bb)):
-            rep._device_samplers[k] = (lb, ub, strategy.points if k < n_pde else strategy.bcs_points, int(strategy.rng.integers(1 << 31)))
+            rep._device_samplers[k] = (lb, ub, strategy.points if k < n_pde else strategy.bcs_points, int(rng.integers(1 << 31)), kind)
     rep._state = state
     return rep
 

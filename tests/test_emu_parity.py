@@ -233,10 +233,32 @@ def test_resident_adam_matches_host_adam_and_sampler(npde, use_emu):
     res = npde.solve(prob, npde.Adam(0.01), maxiters=6)
     assert np.all(np.isfinite(res.losses)) and len(set(np.round(res.losses, 12))) == 6
     rep = prob.pinnrep
-    lb, ub, n, seed = rep._device_samplers[1]
-    assert lb[0] == ub[0] == 0.0 and n == 32          # bc u(0, y): x pinned to 0, y in [1/64, 1 - 1/64]
+    lb, ub, n, seed, kind = rep._device_samplers[1]
+    assert lb[0] == ub[0] == 0.0 and n == 32 and kind == 1        # bc u(0, y): x pinned to 0, y in [1/64, 1 - 1/64]
     r = rep.engine.residual(1, res.u, 32)              # runs on the device-sampled set
     assert r.shape == (32,) and np.all(np.isfinite(r))
+    pts = rep.engine.get_points(1, 2, 32)
+    assert np.all(pts[0] == 0.0) and pts[1].min() >= 1 / 64 - 1e-6 and pts[1].max() <= 1 - 1 / 64 + 1e-6
+    # QuasiRandomTraining(resampling = true) with its default LatinHypercubeSample -> on-device Latin-hypercube redraw
+    disc = npde.PhysicsInformedNN(chain, npde.QuasiRandomTraining(100, bcs_points=37, sampling_alg=npde.LatinHypercubeSample(seed=5)),
+                                  init_params=th0)
+    prob = npde.discretize(sysm, disc)
+    res = npde.solve(prob, npde.Adam(0.01), maxiters=4)
+    assert np.all(np.isfinite(res.losses)) and len(set(np.round(res.losses, 12))) == 4
+    rep = prob.pinnrep
+    assert rep._device_samplers[0][4] == 2
+    draws = []
+    for n_, k, d_ in ((100, 0, 2), (37, 3, 2)):
+        p = rep.engine.get_points(k, d_, n_).astype(np.float64)
+        lb, ub = rep._device_samplers[k][0], rep._device_samplers[k][1]
+        for i in range(d_):
+            if ub[i] == lb[i]:
+                assert np.all(p[i] == np.float32(lb[i]))
+                continue
+            strata = np.floor((p[i] - lb[i]) / (ub[i] - lb[i]) * n_ - 1e-9).astype(int).clip(0, n_ - 1)
+            assert sorted(strata) == list(range(n_))            # every stratum exactly once along every free axis
+        draws.append(p)
+    assert not np.array_equal(np.argsort(draws[0][0]), np.argsort(draws[0][1]))      # axes are permuted independently
 
 
 def test_hoisted_sources_and_mixed_ops(npde, use_emu):
