@@ -474,6 +474,36 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         wt[mo][t] = ub_load4(PB, S::OFF_WTPK + ((hl * MT + w * MTW + t) * MT + mo) * 256, lane << 2);
                 sched_fence();
             }
+            vfloat4 Gn[NG][MTW];
+            PINN_UNROLL for (int q = 0; q < NG; ++q)
+                PINN_UNROLL for (int t = 0; t < MTW; ++t) Gn[q][t] = vzero4();
+            // OVL (H = 64): the staging of the dW operands (VALU + LDS stores) is issued between the MFMAs of the dA GEMM, and
+            // the activation adjoint between those of the dW GEMM, instead of in phases of their own:
+            //   publish dZ | barrier | dA(q) + stage(q) ... | barrier | dW(q) ... + act_adjoint | next layer
+            constexpr bool OVL = WPRE && !S::CHUNKED && S::WBAR_REG;
+            if (OVL) {
+                STAMP(7)
+                wg_barrier();                                               // dZ of every wave is in X0; the previous layer's dW reads are done
+                STAMP(8)
+                if (SPRE && hl - 1 >= 1) load_record(hl - 1);
+                PINN_UNROLL for (int q = 0; q < NG; ++q) {
+                    PINN_UNROLL for (int mo = 0; mo < MT; ++mo) {
+                        vfloat4 b4 = lds_load4(X0, vint(((q * MT + mo) * 64) * 4) + (lane << 2));
+                        PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                            PINN_UNROLL for (int rr = 0; rr < 4; ++rr) Gn[q][t] = mfma16(wt[mo][t][rr], b4[rr], Gn[q][t]);
+                    }
+                    stage_q(q, ZT + q * (MTW * 256), X1 + q * 16 * HP);
+                }
+                STAMP(10)
+                wg_barrier();                                               // staged operands complete; X0 free again
+                STAMP(11)
+                PINN_UNROLL for (int q = 0; q < NG; ++q) dw_q(ZT + q * (MTW * 256), X1 + q * 16 * HP);
+                PINN_UNROLL for (int q = 0; q < NG; ++q)
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t) G[q][t] = Gn[q][t];
+                act_adjoint(G, Sr);
+                STAMP(9)
+                continue;
+            }
             if (S::CHUNKED) {
                 PINN_UNROLL for (int q = 0; q < NG; ++q) {
                     float* cb = X1 + (q & 1) * S::CHSZ;
@@ -499,9 +529,6 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                     }
             if (SPRE && hl - 1 >= 1) load_record(hl - 1);                    // next iteration's record: latency hides under the dA GEMM
             // ---- dA (own input tiles) = W^T dZ ----
-            vfloat4 Gn[NG][MTW];
-            PINN_UNROLL for (int q = 0; q < NG; ++q)
-                PINN_UNROLL for (int t = 0; t < MTW; ++t) Gn[q][t] = vzero4();
             PINN_UNROLL for (int mo = 0; mo < MT; ++mo) {
                 if (!WPRE)
                     PINN_UNROLL for (int t = 0; t < MTW; ++t)
