@@ -46,6 +46,7 @@ struct Slot {
     int net;
     int order;
     int axes[4];
+    unsigned lap = 0;        // != 0: the sum of the pure second derivatives over these axes (one "forward Laplacian" jet channel)
 };
 struct Net {
     int act;
@@ -235,9 +236,23 @@ int parse_descriptor(const char* text, pinn_engine& E) {
         T.slots.resize(ns);
         for (int s = 0; s < ns; ++s) {
             Slot& S = T.slots[s];
-            if (!expect("slot") || !(in >> S.net >> S.order)) return fail("descriptor: slot line");
-            if (S.order < 0 || S.order > 4) return fail("derivative order > 4 is not supported by the HIP engine");
+            std::string ord;
+            if (!expect("slot") || !(in >> S.net >> ord)) return fail("descriptor: slot line");
             if (S.net < 0 || S.net >= nn) return fail("descriptor: slot net id");
+            if (ord == "lap") {                      // slot <net> lap <n> a0 a1 ... : sum of d2/dx_a^2 over the listed axes
+                int n = 0;
+                if (!(in >> n) || n < 1 || n > 8) return fail("descriptor: lap slot");
+                S.order = 2; S.axes[0] = S.axes[1] = S.axes[2] = S.axes[3] = 0;
+                for (int a = 0; a < n; ++a) {
+                    int ax;
+                    if (!(in >> ax) || ax < 0 || ax > 7) return fail("descriptor: lap slot axes");
+                    S.lap |= 1u << ax;
+                }
+                continue;
+            }
+            S.order = std::atoi(ord.c_str());
+            if (ord.empty() || ord.find_first_not_of("0123456789") != std::string::npos) return fail("descriptor: slot order");
+            if (S.order < 0 || S.order > 4) return fail("derivative order > 4 is not supported by the HIP engine");
             for (int a = 0; a < S.order; ++a)
                 if (!(in >> S.axes[a])) return fail("descriptor: slot axes");
             if (S.order == 2 && S.axes[0] > S.axes[1]) std::swap(S.axes[0], S.axes[1]);
@@ -331,6 +346,153 @@ void analyse_static(Term& T, int np) {
         if (keep[q]) T.tape_ops.push_back(q);
 }
 
+
+// "Forward Laplacian": when pure second derivatives u_aa, u_bb, ... of one network occur in a residual only as terms of one sum
+// (each used once, as leaves of the same tree of ADD ops), they are replaced by ONE jet channel carrying sum_a u_aa through the
+// layers (JetSet::LAP) — the 2-D Poisson interior term then needs 4 channels (u, u_x, u_y, lap u) instead of 5, the 3-D heat
+// equation 6 instead of 8.  Works on the descriptor numbering (rows [coords | params | slots | ops]); returns false (term
+// untouched) when nothing can be fused.
+bool fuse_laplacian(Term& T, int np) {
+    const int S = (int)T.slots.size(), nops = (int)T.ops.size();
+    const int rslot0 = T.d + np, rop0 = rslot0 + S;
+    std::vector<int> uses(rop0 + nops, 0);
+    for (int q = 0; q < nops; ++q) {
+        const rp::Instr& I = T.ops[q];
+        if (!rp::is_nullary(I.code)) ++uses[I.a];
+        if (rp::is_binary(I.code)) ++uses[I.b];
+    }
+    ++uses[T.out_row];
+    auto is_add = [&](int row) { return row >= rop0 && T.ops[row - rop0].code == rp::OP_ADD; };
+    auto inner = [&](int row) { return is_add(row) && uses[row] == 1; };         // ADD node that only feeds its parent ADD
+    auto cand = [&](int row) {                                                     // pure second derivative, used exactly once
+        if (row < rslot0 || row >= rop0 || uses[row] != 1) return false;
+        const Slot& s = T.slots[row - rslot0];
+        return s.lap == 0 && s.order == 2 && s.axes[0] == s.axes[1];
+    };
+    // roots: ADD ops that are not themselves inner nodes of a larger ADD tree
+    std::vector<char> is_inner_child(nops, 0);
+    for (int q = 0; q < nops; ++q)
+        if (T.ops[q].code == rp::OP_ADD) {
+            if (inner(T.ops[q].a)) is_inner_child[T.ops[q].a - rop0] = 1;
+            if (inner(T.ops[q].b)) is_inner_child[T.ops[q].b - rop0] = 1;
+        }
+    // a leaf c * u_aa: the bare slot (c = 1), MULC(slot, c) or NEG(slot) — numeric factors are distributed over sums by the host's
+    // algebra system, so nu * (u_xx + u_yy) usually arrives as nu * u_xx + nu * u_yy
+    struct Leaf { int slot_row; float coef; int via_op; };
+    auto leaf_of = [&](int row) -> Leaf {
+        if (cand(row)) return Leaf{row, 1.0f, -1};
+        if (row >= rop0 && uses[row] == 1) {
+            const rp::Instr& I = T.ops[row - rop0];
+            if (I.code == rp::OP_MULC && cand(I.a)) return Leaf{I.a, I.imm, row - rop0};
+            if (I.code == rp::OP_NEG && cand(I.a)) return Leaf{I.a, -1.0f, row - rop0};
+        }
+        return Leaf{-1, 0.f, -1};
+    };
+    struct Tree { int root; std::vector<int> leaves, nodes; std::vector<int> fused; std::vector<int> fused_ops; unsigned mask; int net; float coef; };
+    std::vector<Tree> trees;
+    for (int q = 0; q < nops; ++q) {
+        if (T.ops[q].code != rp::OP_ADD || is_inner_child[q]) continue;
+        Tree tr; tr.root = q; tr.mask = 0; tr.net = -1;
+        std::vector<int> stack{rop0 + q};
+        while (!stack.empty()) {
+            const int row = stack.back(); stack.pop_back();
+            tr.nodes.push_back(row - rop0);
+            for (int child : {T.ops[row - rop0].b, T.ops[row - rop0].a}) {
+                if (inner(child)) stack.push_back(child);
+                else tr.leaves.push_back(child);
+            }
+        }
+        // candidate leaves of one network with one common coefficient and distinct axes
+        std::map<std::pair<int, float>, std::vector<int>> by_key;
+        for (int leaf : tr.leaves) {
+            const Leaf lf = leaf_of(leaf);
+            if (lf.slot_row >= 0) by_key[{T.slots[lf.slot_row - rslot0].net, lf.coef}].push_back(leaf);
+        }
+        for (auto& kv : by_key) {
+            unsigned mask = 0; bool dup = false;
+            for (int leaf : kv.second) { const unsigned b = 1u << T.slots[leaf_of(leaf).slot_row - rslot0].axes[0]; dup = dup || (mask & b); mask |= b; }
+            if (kv.second.size() >= 2 && !dup && tr.fused.empty()) {
+                tr.fused = kv.second; tr.mask = mask; tr.net = kv.first.first; tr.coef = kv.first.second;
+                for (int leaf : kv.second) if (leaf_of(leaf).via_op >= 0) tr.fused_ops.push_back(leaf_of(leaf).via_op);
+            }
+        }
+        if (!tr.fused.empty()) trees.push_back(tr);
+    }
+    if (trees.empty()) return false;
+    // at most one Laplacian channel per network in the compiled kernels: all fused groups of a network must agree on the axes
+    std::map<int, unsigned> net_mask;
+    for (auto& tr : trees) {
+        if (net_mask.count(tr.net) && net_mask[tr.net] != tr.mask) return false;
+        net_mask[tr.net] = tr.mask;
+    }
+    // ---- rebuild: slots (drop fused ones, append one lap slot per fused tree), ops (fused trees become ADD chains over the
+    // remaining leaves + the lap slot) ----
+    std::vector<char> slot_dead(S, 0);
+    for (auto& tr : trees) for (int leaf : tr.fused) slot_dead[leaf_of(leaf).slot_row - rslot0] = 1;
+    std::vector<Slot> nslots;
+    std::vector<int> slot_new(S, -1);
+    for (int s = 0; s < S; ++s) if (!slot_dead[s]) { slot_new[s] = (int)nslots.size(); nslots.push_back(T.slots[s]); }
+    std::vector<int> tree_slot(trees.size());
+    for (size_t i = 0; i < trees.size(); ++i) {
+        Slot L; L.net = trees[i].net; L.order = 2; L.axes[0] = L.axes[1] = L.axes[2] = L.axes[3] = 0; L.lap = trees[i].mask;
+        tree_slot[i] = (int)nslots.size();
+        nslots.push_back(L);
+    }
+    const int S2 = (int)nslots.size(), rop0n = rslot0 + S2;
+    std::vector<int> op_new(nops, -1);                    // old op -> new ROW (may be a non-op row when a tree collapses to one leaf)
+    std::vector<char> op_dropped(nops, 0);
+    std::map<int, size_t> root_tree;
+    for (size_t i = 0; i < trees.size(); ++i) {
+        root_tree[trees[i].root] = i;
+        for (int n : trees[i].nodes) if (n != trees[i].root) op_dropped[n] = 1;
+        for (int n : trees[i].fused_ops) op_dropped[n] = 1;
+    }
+    std::vector<rp::Instr> nops_v;
+    auto map_row = [&](int row) -> int {
+        if (row < rslot0) return row;
+        if (row < rop0) return rslot0 + slot_new[row - rslot0];
+        return op_new[row - rop0];
+    };
+    for (int q = 0; q < nops; ++q) {
+        if (op_dropped[q]) continue;
+        auto it = root_tree.find(q);
+        if (it == root_tree.end()) {
+            rp::Instr I = T.ops[q];
+            if (!rp::is_nullary(I.code)) I.a = map_row(I.a);
+            if (rp::is_binary(I.code)) I.b = map_row(I.b);
+            op_new[q] = rop0n + (int)nops_v.size();
+            nops_v.push_back(I);
+            continue;
+        }
+        const Tree& tr = trees[it->second];
+        int lap_row = rslot0 + tree_slot[it->second];
+        if (tr.coef != 1.0f) {                          // c * (sum of second derivatives)
+            rp::Instr I{};
+            I.code = rp::OP_MULC; I.a = lap_row; I.b = 0; I.imm = tr.coef;
+            rp::finalize(I);
+            lap_row = rop0n + (int)nops_v.size();
+            nops_v.push_back(I);
+        }
+        std::vector<int> leaves{lap_row};
+        for (int leaf : tr.leaves)
+            if (std::find(tr.fused.begin(), tr.fused.end(), leaf) == tr.fused.end()) leaves.push_back(map_row(leaf));
+        int acc = leaves[0];
+        for (size_t i = 1; i < leaves.size(); ++i) {
+            rp::Instr I{};
+            I.code = rp::OP_ADD; I.a = acc; I.b = leaves[i]; I.imm = 0.f;
+            rp::finalize(I);
+            acc = rop0n + (int)nops_v.size();
+            nops_v.push_back(I);
+        }
+        op_new[q] = acc;
+    }
+    const int out_new = map_row(T.out_row);
+    T.slots = nslots;
+    T.ops = nops_v;
+    T.out_row = out_new;
+    return true;
+}
+
 int round_hp(int h) {
     if (h <= 16) return 16;
     if (h <= 32) return 32;
@@ -346,8 +508,9 @@ const pk::SpecInfo* find_spec(int HP, int NHH, int D, unsigned need_first, const
         if (s.HP != HP || s.NHH != NHH || s.D != D) continue;
         if ((s.D1MASK & need_first) != need_first) continue;
         bool ok = true;
-        for (int a = 0; a < 8; ++a)
+        for (int a = 0; a < 6; ++a)
             if (((need_hi >> (4 * a)) & 0xF) > ((s.HI >> (4 * a)) & 0xF)) ok = false;
+        if ((need_hi >> 24) && (need_hi >> 24) != s.LAP) ok = false;          // a Laplacian channel must cover exactly the requested axes
         for (auto& pr : need_pairs) {
             bool f = false;
             for (int p = 0; p < s.NPAIR; ++p) {
@@ -375,17 +538,19 @@ int first_rank(const pk::SpecInfo& s, int axis) {
 }
 
 int chan_of(const pk::SpecInfo& s, const Slot& sl) {
+    if (sl.lap) return sl.lap == s.LAP ? 1 + s.NFIRST + s.NPAIR : -1;
+    const int nlap = s.LAP ? 1 : 0;
     if (sl.order == 0) return 0;
     if (sl.order == 1) return 1 + first_rank(s, sl.axes[0]);
     if (sl.order >= 3) {             // pure third / fourth derivative: channels after the pairs, thirds first
         int n3 = 0, n3_before = 0, n4_before = 0;
-        for (int a = 0; a < 8; ++a) {
+        for (int a = 0; a < 6; ++a) {
             const int h = (int)((s.HI >> (4 * a)) & 0xF);
             if (h >= 3) { ++n3; if (a < sl.axes[0]) ++n3_before; }
             if (h >= 4 && a < sl.axes[0]) ++n4_before;
         }
-        if ((int)((s.HI >> (4 * sl.axes[0])) & 0xF) < sl.order) return -1;
-        return sl.order == 3 ? 1 + s.NFIRST + s.NPAIR + n3_before : 1 + s.NFIRST + s.NPAIR + n3 + n4_before;
+        if (sl.axes[0] >= 6 || (int)((s.HI >> (4 * sl.axes[0])) & 0xF) < sl.order) return -1;
+        return sl.order == 3 ? 1 + s.NFIRST + s.NPAIR + nlap + n3_before : 1 + s.NFIRST + s.NPAIR + nlap + n3 + n4_before;
     }
     for (int p = 0; p < s.NPAIR; ++p) {
         int a = (int)((s.PAIRS >> (8 * p)) & 0xF), b = (int)((s.PAIRS >> (8 * p + 4)) & 0xF);
@@ -396,7 +561,7 @@ int chan_of(const pk::SpecInfo& s, const Slot& sl) {
 
 std::string spec_name(const pk::SpecInfo& s) {
     char b[160];
-    std::snprintf(b, sizeof b, "F%d_HP%d_NHH%d_D%d_F%x_P%llx_H%x_PG%d(C=%d)", s.family, s.HP, s.NHH, s.D, s.D1MASK, s.PAIRS, s.HI, s.PG, s.C);
+    std::snprintf(b, sizeof b, "F%d_HP%d_NHH%d_D%d_F%x_P%llx_H%x_L%x_PG%d(C=%d)", s.family, s.HP, s.NHH, s.D, s.D1MASK, s.PAIRS, s.HI, s.LAP, s.PG, s.C);
     return b;
 }
 
@@ -413,8 +578,15 @@ int build_plan(pinn_engine& E) {
     auto needs_of = [&](const Term& T, int net, unsigned& need_first, std::vector<std::pair<int, int>>& need_pairs, unsigned& need_hi) -> int {
         for (auto& s : T.slots) {
             if (s.net != net) continue;
+            if (s.lap) {
+                if (s.lap >> E.nets[net].sizes[0]) return fail("descriptor: lap slot axis out of range");
+                need_first |= s.lap;
+                if ((need_hi >> 24) && (need_hi >> 24) != s.lap) return fail("two different Laplacian channels of one network in one kernel are not supported");
+                need_hi |= s.lap << 24;
+                continue;
+            }
             for (int a = 0; a < s.order; ++a) {
-                if (s.axes[a] < 0 || s.axes[a] >= T.d) return fail("descriptor: slot axis out of range");
+                if (s.axes[a] < 0 || s.axes[a] >= E.nets[net].sizes[0]) return fail("descriptor: slot axis out of range");
                 need_first |= 1u << s.axes[a];
             }
             if (s.order >= 2) {        // (orders 3, 4 are pure: they also need the pure second derivative of their axis)
@@ -445,6 +617,46 @@ int build_plan(pinn_engine& E) {
         }
         return 0;
     };
+    // pass 0: forward-Laplacian fusion (fuse_laplacian) wherever a compiled kernel carries the resulting channel set
+    static const bool no_lap = std::getenv("PINN_NO_LAPLACIAN") != nullptr;
+    auto spec_exists = [&](int net, unsigned nf, const std::vector<std::pair<int, int>>& npairs, unsigned nh) {
+        const Net& N = E.nets[net];
+        return find_spec(round_hp(N.maxhidden()), (int)N.sizes.size() - 3, N.sizes[0], nf, npairs, nh, nullptr) != nullptr;
+    };
+    if (!no_lap) {
+        std::vector<Term> fused(E.terms.size());
+        std::vector<char> did(E.terms.size(), 0);
+        std::map<int, std::pair<unsigned, std::vector<std::pair<int, int>>>> cn;      // coupled networks: union needs with fusion
+        std::map<int, unsigned> ch;
+        bool coupled_ok = true, any_coupled = false;
+        for (size_t t = 0; t < E.terms.size(); ++t) {
+            fused[t] = E.terms[t];
+            did[t] = fuse_laplacian(fused[t], E.np);
+            std::vector<int> nets;
+            for (auto& s : fused[t].slots) if (std::find(nets.begin(), nets.end(), s.net) == nets.end()) nets.push_back(s.net);
+            if (nets.size() == 1) {
+                if (!did[t]) continue;
+                unsigned nf = 0, nh = 0;
+                std::vector<std::pair<int, int>> npairs;
+                g_err.clear();
+                if (needs_of(fused[t], nets[0], nf, npairs, nh) == 0 && spec_exists(nets[0], nf, npairs, nh)) E.terms[t] = fused[t];
+                g_err.clear();
+            } else if (nets.size() > 1) {
+                any_coupled = any_coupled || did[t];
+                for (int net : nets)
+                    if (needs_of(fused[t], net, cn[net].first, cn[net].second, ch[net])) { coupled_ok = false; g_err.clear(); }
+            }
+        }
+        if (any_coupled && coupled_ok) {
+            for (auto& kv : cn) coupled_ok = coupled_ok && spec_exists(kv.first, kv.second.first, kv.second.second, ch[kv.first]);
+            if (coupled_ok)
+                for (size_t t = 0; t < E.terms.size(); ++t) {
+                    std::vector<int> nets;
+                    for (auto& s : fused[t].slots) if (std::find(nets.begin(), nets.end(), s.net) == nets.end()) nets.push_back(s.net);
+                    if (nets.size() > 1 && did[t]) E.terms[t] = fused[t];
+                }
+        }
+    }
     // pass 1: which terms couple several networks; union of the jet needs per network over all coupled terms
     std::vector<std::vector<int>> term_nets(E.terms.size());
     std::map<int, std::pair<unsigned, std::vector<std::pair<int, int>>>> coupled_needs;   // net -> needs

@@ -5,3 +5,6 @@ PINN_INSTANTIATE2(f2_h128n4d2_val, 128, 4, 2, 0x0, 0ull, 0, 4)
 // 2 hidden layers of 128: unit tests
 PINN_INSTANTIATE2(f2_h128n1d2_lap, 128, 1, 2, 0x3, (PINN_PAIR(0, 0, 0) | PINN_PAIR(1, 1, 1)), 2, 1)
 PINN_INSTANTIATE2(f2_h128n1d2_val, 128, 1, 2, 0x0, 0ull, 0, 4)
+// first derivatives only {u, u_x, u_y} (the pressure network of the cavity problem)
+PINN_INSTANTIATE2(f2_h128n4d2_grad, 128, 4, 2, 0x3, 0ull, 0, 1)
+PINN_INSTANTIATE2(f2_h128n1d2_grad, 128, 1, 2, 0x3, 0ull, 0, 1)

@@ -16,3 +16,6 @@ PINN_INSTANTIATE_HI(h16n1d2_ks0, 16, 1, 2, 0x3, PINN_PAIR(0, 0, 0), 1, 1, PINN_H
 // 3-D value-only / gradient nets (the reference's heterogeneous-system test: u(x,y,z), v(y,x), h(z), p(x,z))
 PINN_INSTANTIATE(h16n1d3_val, 16, 1, 3, 0x0, 0ull, 0, 2)
 PINN_INSTANTIATE(h16n1d3_grad, 16, 1, 3, 0x7, 0ull, 0, 1)
+// forward-Laplacian channel sets {u, u_x, u_y, u_xx + u_yy} for the small test nets
+PINN_INSTANTIATE_HI(h16n1d2_lapc, 16, 1, 2, 0x3, 0ull, 0, 1, PINN_LAP(0x3))
+PINN_INSTANTIATE_HI(h16n0d2_lapc, 16, 0, 2, 0x3, 0ull, 0, 1, PINN_LAP(0x3))

@@ -50,7 +50,10 @@ constexpr int MAX_PARAMS = 4;
 //   channel 0                        u
 //   1 .. NFIRST                      du/dx_a            for the axes a in D1MASK
 //   then NPAIR                       d2u/dx_a dx_b      pairs (a <= b) packed one per byte in PAIRS
-//   then N3                          d3u/dx_a^3         axes whose nibble in HI is >= 3
+//   then NLAP (0 or 1)               sum_a d2u/dx_a^2   over the axes in LAP = bits 24..31 of HI ("forward Laplacian": one channel
+//                                                        carries the whole sum, a_L = phi'' sum_a z_a^2 + phi' z_L, instead of one
+//                                                        channel per pure second derivative — used when a residual needs them only summed)
+//   then N3                          d3u/dx_a^3         axes whose nibble in HI (bits 0..23) is >= 3
 //   then N4                          d4u/dx_a^4         axes whose nibble in HI is 4
 // (pure third / fourth derivatives need the lower pure derivatives of the same axis: first(a), pair(a,a), third(a).)
 // ------------------------------------------------------------------------------------------------
@@ -76,7 +79,9 @@ struct JetSet {
         for (int p = 0; p < NPAIR_; ++p) if (pair_a(p) == a && pair_b(p) == b) return p;
         return -1;
     }
-    static constexpr int hi_order(int axis) { return (int)((HI_ >> (4 * axis)) & 0xF); }
+    static constexpr unsigned LAP = (HI_ >> 24) & 0xFFu;
+    static constexpr int NLAP = LAP ? 1 : 0;
+    static constexpr int hi_order(int axis) { return axis < 6 ? (int)((HI_ >> (4 * axis)) & 0xF) : 0; }
     static constexpr int hi_count(int k) { int n = 0; for (int a = 0; a < 8; ++a) if (hi_order(a) >= k) ++n; return n; }
     static constexpr int hi_axis(int k, int idx) {
         int cnt = 0;
@@ -86,17 +91,18 @@ struct JetSet {
     }
     static constexpr int hi_rank(int k, int axis) { int n = 0; for (int a = 0; a < axis; ++a) if (hi_order(a) >= k) ++n; return n; }
     static constexpr int N3 = hi_count(3), N4 = hi_count(4);
-    static constexpr int C = 1 + NFIRST + NPAIR_ + N3 + N4;
-    static constexpr int CH_FIRST = 1, CH_PAIR = 1 + NFIRST, CH_3 = CH_PAIR + NPAIR_, CH_4 = CH_3 + N3;
+    static constexpr int C = 1 + NFIRST + NPAIR_ + NLAP + N3 + N4;
+    static constexpr int CH_FIRST = 1, CH_PAIR = 1 + NFIRST, CH_LAP = CH_PAIR + NPAIR_, CH_3 = CH_LAP + NLAP, CH_4 = CH_3 + N3;
     static constexpr bool valid() {
         for (int a = 0; a < 8; ++a) {
             const int h = hi_order(a);
             if (h != 0 && h != 3 && h != 4) return false;
             if (h && (!(D1MASK_ & (1u << a)) || pair_index(a, a) < 0)) return false;
         }
+        if ((LAP & D1MASK_) != LAP) return false;        // the Laplacian recurrence reads the first-derivative channels of its axes
         return true;
     }
-    static_assert(valid(), "third/fourth derivative channels need first(a) and pair(a,a) of the same axis");
+    static_assert(valid(), "third/fourth derivative channels need first(a) and pair(a,a) of the same axis; Laplacian axes need first(a)");
     // derivatives of the activation needed by the reverse sweep (one more than the highest jet order)
     static constexpr int NORD = N4 > 0 ? 5 : (N3 > 0 ? 4 : 3);
 };
@@ -244,6 +250,12 @@ DEV void jet_forward(vfloat (&z)[J::C], const vfloat (&d)[6]) {
         const int ca = J::CH_FIRST + J::first_rank(J::pair_a(p)), cb = J::CH_FIRST + J::first_rank(J::pair_b(p));
         z[J::CH_PAIR + p] = vfma(d[2] * z[ca], z[cb], d[1] * z[J::CH_PAIR + p]);
     }
+    if (J::NLAP) {
+        vfloat sq = vfloat(0.f);
+        PINN_UNROLL for (int a = 0; a < 8; ++a)
+            if (J::LAP & (1u << a)) sq = vfma(z[J::CH_FIRST + J::first_rank(a)], z[J::CH_FIRST + J::first_rank(a)], sq);
+        z[J::CH_LAP] = vfma(d[2], sq, d[1] * z[J::CH_LAP]);
+    }
     PINN_UNROLL for (int kf = 0; kf < J::NFIRST; ++kf) z[J::CH_FIRST + kf] = d[1] * z[J::CH_FIRST + kf];
 }
 // Adjoint of jet_forward for one element: g[k] = adjoint of post-activation channel k on entry, of pre-activation channel k
@@ -264,6 +276,18 @@ DEV void jet_adjoint(vfloat (&g)[J::C], const vfloat (&s)[J::C], const vfloat (&
         zf[ka] = vfma(d[2] * zb, gp, zf[ka]);
         zf[kb] = vfma(d[2] * za, gp, zf[kb]);
         zp[p] = d[1] * gp;
+    }
+    if (J::NLAP) {
+        const vfloat gl = g[J::CH_LAP];
+        vfloat sq = vfloat(0.f);
+        PINN_UNROLL for (int a = 0; a < 8; ++a)
+            if (J::LAP & (1u << a)) {
+                const vfloat za = s[J::CH_FIRST + J::first_rank(a)];
+                sq = vfma(za, za, sq);
+                zf[J::first_rank(a)] = vfma(vfloat(2.0f) * d[2] * za, gl, zf[J::first_rank(a)]);
+            }
+        zv = vfma(vfma(d[3], sq, d[2] * s[J::CH_LAP]), gl, zv);
+        g[J::CH_LAP] = d[1] * gl;
     }
     PINN_UNROLL for (int k = 0; k < J::N3; ++k) {
         const int ax = J::hi_axis(3, k), k1 = J::first_rank(ax), p2 = J::pair_index(ax, ax);

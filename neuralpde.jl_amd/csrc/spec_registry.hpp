@@ -17,7 +17,8 @@ struct SpecInfo {
     int HP, NHH, D;
     unsigned D1MASK;
     unsigned long long PAIRS;
-    unsigned HI;                     // nibble per axis: highest pure derivative order carried (0, 3 or 4)
+    unsigned HI;                     // bits 0..23: nibble per axis = highest pure derivative order carried (0, 3 or 4); bits 24..31: LAP
+    unsigned LAP;                    // axis mask of the forward-Laplacian channel (0: none)
     int NPAIR, PG, C, NG, TP, MT, LH, NFIRST;
     int PACKED, SLAB, SCR, LDS_WG, COOP, SH, PW;
     int OFF_W1, OFF_B, OFF_WL, OFF_BL, OFF_WPK, OFF_WTPK;
@@ -31,7 +32,7 @@ template <class S>
 SpecInfo make_info(void (*launch)(const GroupArgs&, int, int, plat_stream)) {
     SpecInfo s;
     s.family = 1; s.WG_PER_CU = 1;
-    s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR; s.HI = S::HI;
+    s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR; s.HI = S::HI & 0xFFFFFFu; s.LAP = S::J::LAP;
     s.PG = S::PG; s.C = S::C; s.NG = S::NG; s.TP = S::TP; s.MT = S::MT; s.LH = S::LH; s.NFIRST = S::NFIRST;
     s.PACKED = S::PACKED; s.SLAB = S::SLAB; s.SCR = S::SCR; s.LDS_WG = S::LDS_WG; s.COOP = S::COOP ? 1 : 0; s.SH = S::SH; s.PW = S::PW;
     s.OFF_W1 = S::OFF_W1; s.OFF_B = S::OFF_B; s.OFF_WL = S::OFF_WL; s.OFF_BL = S::OFF_BL;
@@ -45,7 +46,7 @@ template <class S>
 SpecInfo make_info2(void (*launch)(const GroupArgs&, int, int, plat_stream)) {
     SpecInfo s;
     s.family = 2; s.WG_PER_CU = S::WG_PER_CU;
-    s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR; s.HI = S::HI;
+    s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR; s.HI = S::HI & 0xFFFFFFu; s.LAP = S::J::LAP;
     s.PG = S::PG; s.C = S::C; s.NG = S::NG; s.TP = S::TP; s.MT = S::MT; s.LH = S::LH; s.NFIRST = S::NFIRST;
     s.PACKED = S::PACKED; s.SLAB = S::SLAB; s.SCR = S::SCR; s.LDS_WG = S::LDS_WG; s.COOP = 1; s.SH = S::SLAB; s.PW = 0;
     s.OFF_W1 = S::OFF_W1; s.OFF_B = S::OFF_B; s.OFF_WL = S::OFF_WL; s.OFF_BL = S::OFF_BL;
@@ -158,6 +159,8 @@ struct Registrar {
 
 // HI: nibble per axis = highest pure derivative order carried along that axis (0, 3 or 4), e.g. PINN_HI(1, 4) for d4/dx_1^4
 #define PINN_HI(axis, order) ((unsigned)(order) << (4 * (axis)))
+// forward-Laplacian channel over the axes in `mask` (ORed into the HI argument)
+#define PINN_LAP(mask) ((unsigned)(mask) << 24)
 #define PINN_INSTANTIATE2_HI(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI)                 \
     namespace {                                                                              \
     using NAME##_spec2 = pk::Spec2<HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI>;                \

@@ -400,3 +400,28 @@ def test_bpinn_physics_loglikelihood(npde, use_emu):
     assert np.linalg.norm(g + ref.grad) < 1e-5 * np.linalg.norm(ref.grad)
     with pytest.raises(ValueError):
         npde.physics_loglikelihood(rep.engine, th, stds[:-1], sizes[:-1])
+
+
+def test_forward_laplacian_fusion(npde, use_emu):
+    """pure second derivatives that occur only summed (with one common coefficient) travel as ONE jet channel (engine.cpp:
+    fuse_laplacian, JetSet::LAP); sums with unequal coefficients, or second derivatives used elsewhere too, keep their own channels."""
+    x, y = npde.parameters("x y")
+    (u,) = npde.variables("u")
+    Dx, Dy = npde.Differential(x), npde.Differential(y)
+    Dxx, Dyy = Dx ** 2, Dy ** 2
+    U = u(x, y)
+    dom = [npde.In(x, npde.Interval(0.0, 1.0)), npde.In(y, npde.Interval(0.0, 1.0))]
+    bcs = [npde.Eq(u(0, y), 0.0), npde.Eq(Dx(u(1, y)), 0.2)]
+    chain = npde.Chain(npde.Dense(2, 16, "tanh"), npde.Dense(16, 16, "tanh"), npde.Dense(16, 1))
+    strat = npde.QuasiRandomTraining(45, bcs_points=20, sampling_alg=npde.SobolSample(seed=4), resampling=False, minibatch=1)
+    cases = [(npde.Eq(-0.3 * (Dxx(U) + Dyy(U)) + U * Dx(U) + sp.exp(x) * Dy(U), sp.cos(x * y)), "_L3_"),     # c * lap + other leaves
+             (npde.Eq(Dxx(U) + Dyy(U), 0), "_L3_"),                                                          # residual == lap
+             (npde.Eq(Dxx(U) + 2 * Dyy(U), sp.sin(x)), "_L0_"),                                               # unequal coefficients: not fused
+             (npde.Eq(Dxx(U) + Dyy(U) + Dxx(U) * U, 0), "_L0_")]                                              # u_xx used twice: not fused
+    for k, (eq, tag) in enumerate(cases):
+        sysm = npde.PDESystem([eq], bcs, dom, [x, y], [U])
+        rep, prob, sets, th = check(npde, sysm, [chain], strat, theta_for(chain, 70 + k), weights=[1.0, 2.0, 0.5])
+        kern = [l for l in rep.engine.describe().split("\n") if l.startswith("group 0")][0]
+        assert tag in kern, kern
+        r = rep.loss_functions.datafree_pde_loss_functions[0](sets[0], th)
+        np.testing.assert_allclose(r, po.residual_values(prob, th, 0, sets[0]), rtol=3e-5, atol=3e-5)

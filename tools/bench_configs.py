@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Single-GPU timing of all five BASELINE.json configurations at their full sizes (parity for them: tests/test_gpu_parity.py).
-Reports ms per loss+gradient evaluation, interior-point evals/s and algorithmic TFLOP/s (SURVEY.md §8d flop model)."""
+Reports ms per loss+gradient evaluation, interior-point evals/s and EXECUTED TFLOP/s (SURVEY.md §8d flop model applied to the jet channels the kernels actually carry)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
