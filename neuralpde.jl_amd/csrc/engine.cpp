@@ -108,6 +108,9 @@ struct Group {
     float* d_slabs = nullptr;
     double* d_losspart = nullptr;
     float* d_scratch = nullptr;
+    float* d_rec = nullptr;          // kind 1, family 2: per-tile records of the forward launch, read back by the reverse launch
+    size_t rec_slots = 0;            // (instead of running the forward pass twice; falls back to recomputation above REC_BUDGET)
+    bool use_rec = false;
     double* d_tmp = nullptr;         // stage-1 partial sums [nsplit][nent + K]
     std::vector<int> row_theta, row_ptr, row_off;   // host CSR: theta element -> slab offsets of this group
     int nent = 0;
@@ -1056,6 +1059,26 @@ void retile(pinn_engine& E, int gi) {
     }
     G.ga.ntiles = tile;
     G.blocks = std::max(1, std::min(G.max_blocks, s.family == 2 ? tile : (tile + 3) / 4));
+    // coupled groups: keep the forward launch's records in HBM when they fit the budget (default 96 GB per handle, PINN_REC_GB)
+    G.use_rec = false;
+    if (G.kind == 1 && s.family == 2 && s.REC > 0) {
+        static const double budget_gb = [] { const char* e = std::getenv("PINN_REC_GB"); return e ? std::atof(e) : 96.0; }();
+        const size_t niter = ((size_t)tile + G.blocks - 1) / G.blocks;
+        const size_t slots = niter * (size_t)G.blocks;              // dummy tiles of the last round get slots of their own
+        const double gb = (double)slots * s.REC * 4.0 / 1e9;
+        double others = 0.0;
+        for (auto& H : E.groups) if (&H != &G && H.d_rec) others += (double)H.rec_slots * H.spec->REC * 4.0 / 1e9;
+        if (gb + others <= budget_gb) {
+            if (slots > G.rec_slots) {
+                plat_sync(E.stream);
+                plat_free(G.d_rec);
+                G.d_rec = (float*)plat_malloc(sizeof(float) * slots * (size_t)s.REC);
+                G.rec_slots = G.d_rec ? slots : 0;
+            }
+            G.use_rec = G.d_rec != nullptr;
+        }
+    }
+    G.ga.rec = G.d_rec;
 }
 
 // (re-)evaluate a term's coordinate-only source channels for its current point set
@@ -1165,7 +1188,7 @@ int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const floa
         max_n1 = std::max(max_n1, G.nent / 4 + K);
         max_split = std::max(max_split, nsplit);
         if (G.kind == 1) {               // coupled: forward launch now, reverse launch after k_expr
-            G.spec->launch(G.ga, pk::MODE_FWD, G.blocks, E.stream);
+            G.spec->launch(G.ga, G.use_rec ? pk::MODE_FWDREC : pk::MODE_FWD, G.blocks, E.stream);
             continue;
         }
         plat_stream st = E.stream;
@@ -1202,7 +1225,7 @@ int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const floa
         Group& G = E.groups[g];
         if (G.kind != 1 || !G.active) continue;
         if (group_ev(g)) plat_event_record(G.ev_a, E.stream);
-        G.spec->launch(G.ga, pk::MODE_GRADIN, G.blocks, E.stream);
+        G.spec->launch(G.ga, G.use_rec ? pk::MODE_GRADREC : pk::MODE_GRADIN, G.blocks, E.stream);
         if (group_ev(g)) plat_event_record(G.ev_b, E.stream);
         G.timed = group_ev(g);
     }
@@ -1266,7 +1289,7 @@ int pinn_destroy(pinn_handle h) {
     for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_resid); plat_free(T.d_lb); plat_free(T.d_ub); plat_free(T.d_src_prog); plat_free(T.d_src); }
     plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist);
     for (auto& G : E.groups) {
-        plat_free(G.d_prog); plat_free(G.d_slabs); plat_free(G.d_losspart); plat_free(G.d_scratch);
+        plat_free(G.d_prog); plat_free(G.d_slabs); plat_free(G.d_losspart); plat_free(G.d_scratch); plat_free(G.d_rec);
         plat_free(G.d_tmp);
         plat_event_destroy(G.ev_a); plat_event_destroy(G.ev_b);
     }
@@ -1664,7 +1687,7 @@ int pinn_describe(pinn_handle h, char* buf, int64_t buflen) {
     os << "backend=" << plat_name() << " cus=" << h->ncu << " ntheta=" << h->ntheta << " terms=" << h->terms.size() << "\n";
     for (size_t g = 0; g < h->groups.size(); ++g) {
         const Group& G = h->groups[g];
-        os << "group " << g << (G.kind == 1 ? " [coupled fwd/gradin]" : "") << " net=" << G.net << " kernel=" << spec_name(*G.spec) << " tiles=" << G.ga.ntiles << " blocks=" << G.blocks << " terms=";
+        os << "group " << g << (G.kind == 1 ? (G.use_rec ? " [coupled fwd/gradin, records in HBM]" : " [coupled fwd/gradin]") : "") << " net=" << G.net << " kernel=" << spec_name(*G.spec) << " tiles=" << G.ga.ntiles << " blocks=" << G.blocks << " terms=";
         for (int t : G.terms) os << t << ",";
         os << "\n";
     }

@@ -40,7 +40,9 @@ enum Act : int { ACT_TANH = 0, ACT_SIGMOID = 1 };
 // FUSED: forward + residual tape + reverse sweep.  RESID: forward + tape, writes r.  FWD: forward only, writes the jet
 // channels per point.  GRADIN: forward + reverse sweep seeded with per-point d(loss)/d(jet) read from memory (equations that
 // couple several networks: the tape runs in k_expr between the FWD and GRADIN launches of every network involved).
-enum Mode : int { MODE_FUSED = 0, MODE_RESID = 1, MODE_FWD = 2, MODE_GRADIN = 3 };
+// FWDREC / GRADREC (family 2): as FWD / GRADIN, but the forward launch keeps every hidden layer's record in HBM (per tile) and
+// the reverse launch reads them back instead of running the forward pass a second time — 288 GB of HBM make the 8 KB/point affordable.
+enum Mode : int { MODE_FUSED = 0, MODE_RESID = 1, MODE_FWD = 2, MODE_GRADIN = 3, MODE_FWDREC = 4, MODE_GRADREC = 5 };
 
 constexpr int MAX_GROUP_TERMS = 12;
 constexpr int MAX_PARAMS = 4;
@@ -196,6 +198,7 @@ struct GroupArgs {
     float* slabs;                // [nblocks][SLAB]
     double* losspart;            // [nwaves][nterms_total]
     float* scratch;              // [nwaves][SCR]
+    float* rec;                  // MODE_FWDREC / MODE_GRADREC: [tile slots][Spec2::REC] records of hidden layers 1 .. LH-1
     int nterms_total;
     int nterms;                  // terms in this group
     int ntiles;

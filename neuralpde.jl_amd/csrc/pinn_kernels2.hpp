@@ -64,6 +64,8 @@ struct Spec2 {
     static constexpr int SLAB = ((O_P + MAX_PARAMS + 63) / 64) * 64 + STAMP_EXTRA;
     // per-workgroup record scratch, [layer][q][tile][lane][4]; layer LH-1 stays in registers, layer 0 is recomputed
     static constexpr int SCR = (LH > 2 ? LH - 2 : 1) * NG * MT * 256;      // hidden layers 1 .. LH-2
+    // per-TILE record store of the two-launch path for coupled equations (MODE_FWDREC -> MODE_GRADREC): hidden layers 1 .. LH-1
+    static constexpr int REC = (LH - 1) * NG * MT * 256;
     // LDS (floats): X0 | X1 (activation / dZ exchange, A^T) | ZT (4 x private dZ^T) | output partials | coords
     static constexpr int XSZ = NG * MT * 256;
     static constexpr int LDS_UP = ((5 * NG * 16 + 63) / 64) * 64;    // 4 x output partials + seed broadcast (UB)
@@ -87,7 +89,9 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
     constexpr int HP = S::HP, MT = S::MT, MTW = S::MTW, NHH = S::NHH, LH = S::LH, D = S::D, C = S::C, PG = S::PG, NG = S::NG;
     constexpr int NFIRST = S::NFIRST;
     using J = typename S::J;
-    constexpr bool BWD = (MODE == MODE_FUSED || MODE == MODE_GRADIN);
+    constexpr bool BWD = (MODE == MODE_FUSED || MODE == MODE_GRADIN || MODE == MODE_GRADREC);
+    constexpr bool RECOUT = (MODE == MODE_FWDREC), RECIN = (MODE == MODE_GRADREC);
+    constexpr bool IS_FWD = (MODE == MODE_FWD || MODE == MODE_FWDREC), IS_GRADIN = (MODE == MODE_GRADIN || MODE == MODE_GRADREC);
     constexpr bool WPRE = (MT * MTW * 4 <= 16);        // prefetch a layer's weight fragments when they take <= 16 registers (H = 64)
     const int wave = blk * 4 + w;
     const vint lane = lane_id();
@@ -151,6 +155,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
         }
         const TermDev& T = ga.terms[k];
         const int pbase = (tix - T.tile0) * S::TP;
+        const ubuf RB = ub_make((RECOUT || RECIN) ? ga.rec + (size_t)tix * S::REC : ga.scratch, S::REC);    // this tile's record slot
 
         vfloat x[PG][D];
         vbool valid[PG];
@@ -166,6 +171,9 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t) {
                     PINN_UNROLL for (int r = 0; r < 4; ++r) Z[pg * C][t][r] = act_value(act, Z[pg * C][t][r]);
+                    if (RECOUT && layer > 0)
+                        PINN_UNROLL for (int ch = 0; ch < C; ++ch)
+                            ub_store4(RB, (((layer - 1) * NG + pg * C + ch) * MT + w * MTW + t) * 256, lane << 2, Z[pg * C + ch][t]);
                     if (BWD) {
                         if (layer == LH - 1) {
                             PINN_UNROLL for (int ch = 0; ch < C; ++ch) Rlast[pg * C + ch][t] = Z[pg * C + ch][t];
@@ -192,78 +200,115 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
 
         // =========================== forward ===========================
         vfloat4 A[NG][MTW];
-        PINN_UNROLL for (int t = 0; t < MTW; ++t) {                          // hidden layer 0: d -> HP on the VALU
-            const int n0 = 16 * (w * MTW + t);
-            vfloat4 b1 = ub_load4(PB, S::OFF_B + n0, g << 2);
-            vfloat4 w1[D];
-            PINN_UNROLL for (int i = 0; i < D; ++i) w1[i] = ub_load4(PB, S::OFF_W1 + i * HP + n0, g << 2);
-            PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
-                vfloat4 z = b1;
-                PINN_UNROLL for (int i = 0; i < D; ++i)
-                    PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = vfma(w1[i][r], x[pg][i], z[r]);
-                A[pg * C][t] = z;
-                PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) A[pg * C + 1 + kf][t] = w1[S::first_axis(kf)];
-                PINN_UNROLL for (int ch = 1 + NFIRST; ch < C; ++ch) A[pg * C + ch][t] = vzero4();      // second and higher derivatives of an affine map
-            }
-        }
-        act_forward(A, 0);
-        STAMP(0)
-        PINN_UNROLL for (int hl = 0; hl < NHH; ++hl) {
-            float* Xin = (hl & 1) ? X1 : X0;
-            // this wave's weight fragments + bias of the layer: issued before the exchange so that their L2 latency hides
-            // under publish + barrier instead of stalling the first MFMA of every k-block
-            vfloat4 wf[WPRE ? MT : 1][MTW], bv[MTW];
-            if (WPRE) {
-                PINN_UNROLL for (int mi = 0; mi < MT; ++mi)
-                    PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                        wf[mi][t] = ub_load4(PB, S::OFF_WPK + ((hl * MT + w * MTW + t) * MT + mi) * 256, lane << 2);
-                PINN_UNROLL for (int t = 0; t < MTW; ++t) bv[t] = ub_load4(PB, S::OFF_B + (hl + 1) * HP + 16 * (w * MTW + t), g << 2);
-                sched_fence();
-            }
-            publish(Xin, A);
-            wg_barrier();                                                   // layer hl activations complete in Xin
-            STAMP(1)
-            PINN_UNROLL for (int t = 0; t < MTW; ++t) {
-                if (!WPRE) bv[t] = ub_load4(PB, S::OFF_B + (hl + 1) * HP + 16 * (w * MTW + t), g << 2);
-                PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
-                    A[pg * C][t] = bv[t];
-                    PINN_UNROLL for (int ch = 1; ch < C; ++ch) A[pg * C + ch][t] = vzero4();
-                }
-            }
-            PINN_UNROLL for (int mi = 0; mi < MT; ++mi) {
-                if (!WPRE)
-                    PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                        wf[0][t] = ub_load4(PB, S::OFF_WPK + ((hl * MT + w * MTW + t) * MT + mi) * 256, lane << 2);
-                PINN_UNROLL for (int q = 0; q < NG; ++q) {
-                    vfloat4 b4 = lds_load4(Xin, vint(((q * MT + mi) * 64) * 4) + (lane << 2));
-                    PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                        PINN_UNROLL for (int rr = 0; rr < 4; ++rr) A[q][t] = mfma16(wf[WPRE ? mi : 0][t][rr], b4[rr], A[q][t]);
-                }
-            }
-            STAMP(2)
-            act_forward(A, hl + 1);
-            STAMP(3)
-        }
-        // output layer HP -> 1: per-wave partial dot over its neurons, summed across the 4 waves through LDS
-        {
-            PINN_UNROLL for (int q = 0; q < NG; ++q) {
-                vfloat s = vfloat(0.f);
-                PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                    PINN_UNROLL for (int r = 0; r < 4; ++r) s = vfma(wL[t][r], A[q][t][r], s);
-                s = xrow_allsum(s);
-                lds_store(UP, vint((w * NG + q) * 16) + c, s);             // all four row groups hold the same value
-            }
-            wg_barrier();
-        }
         vfloat U[PG][C];
-        PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
-            PINN_UNROLL for (int ch = 0; ch < C; ++ch) {
-                vfloat s = vfloat(0.f);
-                PINN_UNROLL for (int ws = 0; ws < 4; ++ws) s = s + lds_load(UP, vint((ws * NG + pg * C + ch) * 16) + c);
-                U[pg][ch] = (ch == 0) ? s + vfloat(bL) : s;
+        if (!RECIN) {
+            PINN_UNROLL for (int t = 0; t < MTW; ++t) {                          // hidden layer 0: d -> HP on the VALU
+                const int n0 = 16 * (w * MTW + t);
+                vfloat4 b1 = ub_load4(PB, S::OFF_B + n0, g << 2);
+                vfloat4 w1[D];
+                PINN_UNROLL for (int i = 0; i < D; ++i) w1[i] = ub_load4(PB, S::OFF_W1 + i * HP + n0, g << 2);
+                PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                    vfloat4 z = b1;
+                    PINN_UNROLL for (int i = 0; i < D; ++i)
+                        PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = vfma(w1[i][r], x[pg][i], z[r]);
+                    A[pg * C][t] = z;
+                    PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) A[pg * C + 1 + kf][t] = w1[S::first_axis(kf)];
+                    PINN_UNROLL for (int ch = 1 + NFIRST; ch < C; ++ch) A[pg * C + ch][t] = vzero4();      // second and higher derivatives of an affine map
+                }
             }
+            act_forward(A, 0);
+            STAMP(0)
+            PINN_UNROLL for (int hl = 0; hl < NHH; ++hl) {
+                float* Xin = (hl & 1) ? X1 : X0;
+                // this wave's weight fragments + bias of the layer: issued before the exchange so that their L2 latency hides
+                // under publish + barrier instead of stalling the first MFMA of every k-block
+                vfloat4 wf[WPRE ? MT : 1][MTW], bv[MTW];
+                if (WPRE) {
+                    PINN_UNROLL for (int mi = 0; mi < MT; ++mi)
+                        PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                            wf[mi][t] = ub_load4(PB, S::OFF_WPK + ((hl * MT + w * MTW + t) * MT + mi) * 256, lane << 2);
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t) bv[t] = ub_load4(PB, S::OFF_B + (hl + 1) * HP + 16 * (w * MTW + t), g << 2);
+                    sched_fence();
+                }
+                publish(Xin, A);
+                wg_barrier();                                                   // layer hl activations complete in Xin
+                STAMP(1)
+                PINN_UNROLL for (int t = 0; t < MTW; ++t) {
+                    if (!WPRE) bv[t] = ub_load4(PB, S::OFF_B + (hl + 1) * HP + 16 * (w * MTW + t), g << 2);
+                    PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                        A[pg * C][t] = bv[t];
+                        PINN_UNROLL for (int ch = 1; ch < C; ++ch) A[pg * C + ch][t] = vzero4();
+                    }
+                }
+                PINN_UNROLL for (int mi = 0; mi < MT; ++mi) {
+                    if (!WPRE)
+                        PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                            wf[0][t] = ub_load4(PB, S::OFF_WPK + ((hl * MT + w * MTW + t) * MT + mi) * 256, lane << 2);
+                    PINN_UNROLL for (int q = 0; q < NG; ++q) {
+                        vfloat4 b4 = lds_load4(Xin, vint(((q * MT + mi) * 64) * 4) + (lane << 2));
+                        PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                            PINN_UNROLL for (int rr = 0; rr < 4; ++rr) A[q][t] = mfma16(wf[WPRE ? mi : 0][t][rr], b4[rr], A[q][t]);
+                    }
+                }
+                STAMP(2)
+                act_forward(A, hl + 1);
+                STAMP(3)
+            }
+            // output layer HP -> 1: per-wave partial dot over its neurons, summed across the 4 waves through LDS
+            {
+                PINN_UNROLL for (int q = 0; q < NG; ++q) {
+                    vfloat s = vfloat(0.f);
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                        PINN_UNROLL for (int r = 0; r < 4; ++r) s = vfma(wL[t][r], A[q][t][r], s);
+                    s = xrow_allsum(s);
+                    lds_store(UP, vint((w * NG + q) * 16) + c, s);             // all four row groups hold the same value
+                }
+                wg_barrier();
+            }
+            PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
+                PINN_UNROLL for (int ch = 0; ch < C; ++ch) {
+                    vfloat s = vfloat(0.f);
+                    PINN_UNROLL for (int ws = 0; ws < 4; ++ws) s = s + lds_load(UP, vint((ws * NG + pg * C + ch) * 16) + c);
+                    U[pg][ch] = (ch == 0) ? s + vfloat(bL) : s;
+                }
+        } else {
+            // reverse launch of the two-launch path: no forward pass.  The last hidden layer's record comes from this tile's slot in
+            // HBM; its post-activation jets (needed for the output layer's weight gradient) are recomputed lane-locally.
+            PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
+                PINN_UNROLL for (int ch = 0; ch < C; ++ch) U[pg][ch] = vfloat(0.f);
+            if (LH == 1) {
+                PINN_UNROLL for (int t = 0; t < MTW; ++t) {
+                    const int n0 = 16 * (w * MTW + t);
+                    vfloat4 b1 = ub_load4(PB, S::OFF_B + n0, g << 2);
+                    vfloat4 w1[D];
+                    PINN_UNROLL for (int i = 0; i < D; ++i) w1[i] = ub_load4(PB, S::OFF_W1 + i * HP + n0, g << 2);
+                    PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                        vfloat4 z = b1;
+                        PINN_UNROLL for (int i = 0; i < D; ++i)
+                            PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = vfma(w1[i][r], x[pg][i], z[r]);
+                        PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = act_value(act, z[r]);
+                        Rlast[pg * C][t] = z;
+                        PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) Rlast[pg * C + 1 + kf][t] = w1[S::first_axis(kf)];
+                        PINN_UNROLL for (int ch = 1 + NFIRST; ch < C; ++ch) Rlast[pg * C + ch][t] = vzero4();
+                    }
+                }
+            } else {
+                PINN_UNROLL for (int q = 0; q < NG; ++q)
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                        Rlast[q][t] = ub_load4(RB, (((LH - 2) * NG + q) * MT + w * MTW + t) * 256, lane << 2);
+            }
+            PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
+                PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                    PINN_UNROLL for (int r = 0; r < 4; ++r) {
+                        vfloat zz[C], dd[6];
+                        PINN_UNROLL for (int k2 = 0; k2 < C; ++k2) zz[k2] = Rlast[pg * C + k2][t][r];
+                        act_derivs_n<J::NORD - 1>(act, zz[0], dd);
+                        jet_forward<J>(zz, dd);
+                        PINN_UNROLL for (int k2 = 0; k2 < C; ++k2) A[pg * C + k2][t][r] = zz[k2];
+                    }
+        }
         STAMP(4)
-        if (MODE == MODE_FWD) {
+        if (IS_FWD) {
             if (w == 0)
                 PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
                     vint p = vint(pbase + 16 * pg) + c;
@@ -278,7 +323,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
         // Wave pg interprets the program for point group pg (ONE copy of the interpreter in the instruction stream) and
         // broadcasts the seeds ubar = dL/d(jet channel) to the other waves through LDS.
         vfloat ubar[PG][C];
-        if (MODE == MODE_GRADIN) {
+        if (IS_GRADIN) {
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
                 vint p = vint(pbase + 16 * pg) + c;
                 PINN_UNROLL for (int ch = 0; ch < C; ++ch) ubar[pg][ch] = gload_masked(T.in, vint(ch * T.N) + p, valid[pg]);
@@ -388,7 +433,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
         auto load_record = [&](int hl) {                                     // record of hidden layer hl (1 <= hl <= LH-2)
             PINN_UNROLL for (int q = 0; q < NG; ++q)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                    Snext[q][t] = ub_load4(SB, (((hl - 1) * NG + q) * MT + w * MTW + t) * 256, lane << 2);
+                    Snext[q][t] = ub_load4(RECIN ? RB : SB, (((hl - 1) * NG + q) * MT + w * MTW + t) * 256, lane << 2);
             sched_fence();
         };
         if (SPRE && NHH - 1 >= 1) load_record(NHH - 1);
@@ -430,7 +475,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
             } else {
                 PINN_UNROLL for (int q = 0; q < NG; ++q)
                     PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                        Sr[q][t] = ub_load4(SB, (((hl - 1) * NG + q) * MT + w * MTW + t) * 256, lane << 2);
+                        Sr[q][t] = ub_load4(RECIN ? RB : SB, (((hl - 1) * NG + q) * MT + w * MTW + t) * 256, lane << 2);
             }
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t)

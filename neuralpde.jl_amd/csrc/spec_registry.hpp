@@ -21,6 +21,7 @@ struct SpecInfo {
     unsigned LAP;                    // axis mask of the forward-Laplacian channel (0: none)
     int NPAIR, PG, C, NG, TP, MT, LH, NFIRST;
     int PACKED, SLAB, SCR, LDS_WG, COOP, SH, PW;
+    int REC;                         // floats per tile of the HBM record store (MODE_FWDREC / MODE_GRADREC); 0: not supported
     int OFF_W1, OFF_B, OFF_WL, OFF_BL, OFF_WPK, OFF_WTPK;
     int O_WBAR, O_BFRH, O_BFR0, O_W1, O_WL, O_BL, O_P;
     void (*launch)(const GroupArgs&, int mode, int blocks, plat_stream);
@@ -35,6 +36,7 @@ SpecInfo make_info(void (*launch)(const GroupArgs&, int, int, plat_stream)) {
     s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR; s.HI = S::HI & 0xFFFFFFu; s.LAP = S::J::LAP;
     s.PG = S::PG; s.C = S::C; s.NG = S::NG; s.TP = S::TP; s.MT = S::MT; s.LH = S::LH; s.NFIRST = S::NFIRST;
     s.PACKED = S::PACKED; s.SLAB = S::SLAB; s.SCR = S::SCR; s.LDS_WG = S::LDS_WG; s.COOP = S::COOP ? 1 : 0; s.SH = S::SH; s.PW = S::PW;
+    s.REC = 0;
     s.OFF_W1 = S::OFF_W1; s.OFF_B = S::OFF_B; s.OFF_WL = S::OFF_WL; s.OFF_BL = S::OFF_BL;
     s.OFF_WPK = S::OFF_WPK; s.OFF_WTPK = S::OFF_WTPK;
     s.O_WBAR = S::O_WBAR; s.O_BFRH = S::O_BFRH; s.O_BFR0 = S::O_BFR0; s.O_W1 = S::O_W1; s.O_WL = S::O_WL; s.O_BL = S::O_BL; s.O_P = S::O_P;
@@ -49,6 +51,7 @@ SpecInfo make_info2(void (*launch)(const GroupArgs&, int, int, plat_stream)) {
     s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR; s.HI = S::HI & 0xFFFFFFu; s.LAP = S::J::LAP;
     s.PG = S::PG; s.C = S::C; s.NG = S::NG; s.TP = S::TP; s.MT = S::MT; s.LH = S::LH; s.NFIRST = S::NFIRST;
     s.PACKED = S::PACKED; s.SLAB = S::SLAB; s.SCR = S::SCR; s.LDS_WG = S::LDS_WG; s.COOP = 1; s.SH = S::SLAB; s.PW = 0;
+    s.REC = S::REC;
     s.OFF_W1 = S::OFF_W1; s.OFF_B = S::OFF_B; s.OFF_WL = S::OFF_WL; s.OFF_BL = S::OFF_BL;
     s.OFF_WPK = S::OFF_WPK; s.OFF_WTPK = S::OFF_WTPK;
     s.O_WBAR = S::O_WBAR; s.O_BFRH = S::O_BH; s.O_BFR0 = S::O_BH; s.O_W1 = S::O_W1; s.O_WL = S::O_WL; s.O_BL = S::O_BL; s.O_P = S::O_P;
@@ -108,6 +111,8 @@ void launch_spec2(const GroupArgs& ga, int mode, int blocks, plat_stream) {
     if (mode == MODE_FUSED) run_emu2<S, MODE_FUSED>(ga, blocks);
     else if (mode == MODE_RESID) run_emu2<S, MODE_RESID>(ga, blocks);
     else if (mode == MODE_GRADIN) run_emu2<S, MODE_GRADIN>(ga, blocks);
+    else if (mode == MODE_FWDREC) run_emu2<S, MODE_FWDREC>(ga, blocks);
+    else if (mode == MODE_GRADREC) run_emu2<S, MODE_GRADREC>(ga, blocks);
     else run_emu2<S, MODE_FWD>(ga, blocks);
 }
 template <class S>
@@ -139,6 +144,8 @@ void launch_spec2(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
     if (mode == MODE_FUSED) hipLaunchKernelGGL((k_wave2<S, MODE_FUSED>), dim3(blocks), dim3(256), 0, st, ga);
     else if (mode == MODE_RESID) hipLaunchKernelGGL((k_wave2<S, MODE_RESID>), dim3(blocks), dim3(256), 0, st, ga);
     else if (mode == MODE_GRADIN) hipLaunchKernelGGL((k_wave2<S, MODE_GRADIN>), dim3(blocks), dim3(256), 0, st, ga);
+    else if (mode == MODE_FWDREC) hipLaunchKernelGGL((k_wave2<S, MODE_FWDREC>), dim3(blocks), dim3(256), 0, st, ga);
+    else if (mode == MODE_GRADREC) hipLaunchKernelGGL((k_wave2<S, MODE_GRADREC>), dim3(blocks), dim3(256), 0, st, ga);
     else hipLaunchKernelGGL((k_wave2<S, MODE_FWD>), dim3(blocks), dim3(256), 0, st, ga);
 }
 template <class S>
