@@ -222,7 +222,8 @@ int parse_descriptor(const char* text, pinn_engine& E) {
         if (!expect("net") || !(in >> id >> act >> E.nets[i].theta_off >> ns) || id != i) return fail("descriptor: net line");
         if (act == "tanh") E.nets[i].act = pk::ACT_TANH;
         else if (act == "sigmoid") E.nets[i].act = pk::ACT_SIGMOID;
-        else return fail("descriptor: unsupported activation '" + act + "' (supported: tanh, sigmoid)");
+        else if (act == "sin") E.nets[i].act = pk::ACT_SIN;
+        else return fail("descriptor: unsupported activation '" + act + "' (supported: tanh, sigmoid, sin)");
         E.nets[i].sizes.resize(ns);
         for (int j = 0; j < ns; ++j)
             if (!(in >> E.nets[i].sizes[j])) return fail("descriptor: net sizes");
@@ -505,10 +506,11 @@ int round_hp(int h) {
 }
 
 const pk::SpecInfo* find_spec(int HP, int NHH, int D, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs,
-                              unsigned need_hi, std::vector<int>* pair_index) {
+                              unsigned need_hi, std::vector<int>* pair_index, bool need_sin = false) {
     const pk::SpecInfo* best = nullptr;
     for (const pk::SpecInfo& s : pk::registry()) {
         if (s.HP != HP || s.NHH != NHH || s.D != D) continue;
+        if (need_sin && !s.has_sin) continue;
         if ((s.D1MASK & need_first) != need_first) continue;
         bool ok = true;
         for (int a = 0; a < 6; ++a)
@@ -610,12 +612,12 @@ int build_plan(pinn_engine& E) {
         d = N.sizes[0];                                 // kernels are compiled per network input dimension
         const int LH = (int)N.sizes.size() - 2;
         const int HP = round_hp(N.maxhidden());
-        sp = find_spec(HP, LH - 1, d, need_first, need_pairs, need_hi, nullptr);
+        sp = find_spec(HP, LH - 1, d, need_first, need_pairs, need_hi, nullptr, N.act == pk::ACT_SIN);
         if (!sp) {
             char b[256];
             std::snprintf(b, sizeof b,
-                          "term %zu: no compiled kernel for hidden width %d (padded %d), %d hidden layers, d=%d, first-derivative axes mask 0x%x, %zu second derivatives, higher-order mask 0x%x; add a PINN_INSTANTIATE line in csrc/inst_*.hip",
-                          t, N.maxhidden(), HP, LH, d, need_first, need_pairs.size(), need_hi);
+                          "term %zu: no compiled kernel for hidden width %d (padded %d), %d hidden layers, d=%d, first-derivative axes mask 0x%x, %zu second derivatives, higher-order mask 0x%x%s; add a PINN_INSTANTIATE line in csrc/inst_*.hip",
+                          t, N.maxhidden(), HP, LH, d, need_first, need_pairs.size(), need_hi, N.act == pk::ACT_SIN ? ", sin activation (PINN_INSTANTIATE*_SIN)" : "");
             return fail(b);
         }
         return 0;
@@ -624,7 +626,7 @@ int build_plan(pinn_engine& E) {
     static const bool no_lap = std::getenv("PINN_NO_LAPLACIAN") != nullptr;
     auto spec_exists = [&](int net, unsigned nf, const std::vector<std::pair<int, int>>& npairs, unsigned nh) {
         const Net& N = E.nets[net];
-        return find_spec(round_hp(N.maxhidden()), (int)N.sizes.size() - 3, N.sizes[0], nf, npairs, nh, nullptr) != nullptr;
+        return find_spec(round_hp(N.maxhidden()), (int)N.sizes.size() - 3, N.sizes[0], nf, npairs, nh, nullptr, N.act == pk::ACT_SIN) != nullptr;
     };
     if (!no_lap) {
         std::vector<Term> fused(E.terms.size());
@@ -1492,7 +1494,7 @@ int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float*
     if (n <= 0) return fail("pinn_phi: n must be positive");
     const Net& N = E.nets[net];
     const int LH = (int)N.sizes.size() - 2;
-    const pk::SpecInfo* sp = find_spec(round_hp(N.maxhidden()), LH - 1, N.sizes[0], 0, {}, 0u, nullptr);
+    const pk::SpecInfo* sp = find_spec(round_hp(N.maxhidden()), LH - 1, N.sizes[0], 0, {}, 0u, nullptr, N.act == pk::ACT_SIN);
     if (!sp) return fail("pinn_phi: no compiled value-only kernel for this network shape");
     if (!E.netplans[net].spec) return fail("pinn_phi: network is not used by any term");
     if (upload_theta(E, theta, p)) return 1;

@@ -36,7 +36,9 @@
 namespace pk {
 using namespace wv;
 
-enum Act : int { ACT_TANH = 0, ACT_SIGMOID = 1 };
+// The record of a layer keeps r0 = phi(z) for tanh / sigmoid (their derivatives are polynomials in phi) and r0 = z for sin
+// (cos z cannot be recovered from sin z); act_derivs_n / act_from_record take that r0.
+enum Act : int { ACT_TANH = 0, ACT_SIGMOID = 1, ACT_SIN = 2 };
 // FUSED: forward + residual tape + reverse sweep.  RESID: forward + tape, writes r.  FWD: forward only, writes the jet
 // channels per point.  GRADIN: forward + reverse sweep seeded with per-point d(loss)/d(jet) read from memory (equations that
 // couple several networks: the tape runs in k_expr between the FWD and GRADIN launches of every network involved).
@@ -208,10 +210,18 @@ struct GroupArgs {
     TermDev terms[MAX_GROUP_TERMS];
 };
 
-// derivatives phi', ..., phi^(NORD) of the activation from a = phi(z)   (d[0] unused)
+// derivatives phi', ..., phi^(NORD) of the activation from the record value r0 (see Act)   (d[0] unused)
 template <int NORD>
 DEV void act_derivs_n(int act, vfloat a, vfloat (&d)[6]) {
-    if (act == ACT_TANH) {
+    if (act == ACT_SIN) {
+        vfloat sn, cs;
+        vsincos(a, sn, cs);
+        d[1] = cs;
+        d[2] = vfloat(0.f) - sn;
+        d[3] = vfloat(0.f) - cs;
+        if (NORD >= 4) d[4] = sn;
+        if (NORD >= 5) d[5] = cs;
+    } else if (act == ACT_TANH) {
         const vfloat a2 = a * a;
         d[1] = vfloat(1.0f) - a2;
         d[2] = vfloat(-2.0f) * a * d[1];
@@ -323,7 +333,16 @@ DEV void jet_adjoint(vfloat (&g)[J::C], const vfloat (&s)[J::C], const vfloat (&
 
 DEV vfloat act_value(int act, vfloat z) {
     if (act == ACT_TANH) return vtanh_fast(z);
+    if (act == ACT_SIN) { vfloat sn, cs; vsincos(z, sn, cs); return sn; }
     return vsigmoid_fast(z);
+}
+// record value r0 of an element with pre-activation z and activation a, and the activation back from r0
+DEV vfloat act_record(int act, vfloat z, vfloat a) { return act == ACT_SIN ? z : a; }
+DEV vfloat act_from_record(int act, vfloat r0) {
+    if (act != ACT_SIN) return r0;
+    vfloat sn, cs;
+    vsincos(r0, sn, cs);
+    return sn;
 }
 
 // XOR-swizzled address inside a [16 columns][HP] transpose buffer: neuron n of column `col`
@@ -338,7 +357,7 @@ DEV vint tr_addr(vint col, vint slot) {
 // All four waves of a workgroup run the same number of tile iterations (tiles past the end are fully masked
 // dummies) because the COOP dW phase synchronises them with workgroup barriers.
 // ------------------------------------------------------------------------------------------------
-template <class S, int MODE>
+template <class S, int MODE, bool SINACT>
 DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_wg) {
     const int wave = blk * 4 + w;
     float* lds = lds_wg + S::LDS_SHARED + w * S::LDS_PRIV;     // wave-private LDS
@@ -354,7 +373,7 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
     const vint c = lane & vint(15);
     const vbool g0 = veq(g, 0);
     const float* P = ga.packed;
-    const int act = ga.act;
+    const int act = SINACT ? (int)ACT_SIN : (ga.act == ACT_SIGMOID ? (int)ACT_SIGMOID : (int)ACT_TANH);    // never ACT_SIN unless SINACT: the sin rules fold away
 
     // ---- persistent per-wave gradient accumulators (registers / AGPRs across all tiles) ----
     vfloat4 wbar[NHH > 0 ? NHH : 1][WT][MT];      // COOP: this wave's row block (to == w) only
@@ -443,7 +462,12 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
         auto act_forward = [&](vfloat4 (&Z)[NG][MT], int layer /*0-based hidden layer*/) {
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                 PINN_UNROLL for (int m = 0; m < MT; ++m) {
-                    PINN_UNROLL for (int r = 0; r < 4; ++r) Z[pg * C][m][r] = act_value(act, Z[pg * C][m][r]);
+                    vfloat4 av;                                       // activation values; Z[pg*C] holds the RECORD value r0 meanwhile
+                    PINN_UNROLL for (int r = 0; r < 4; ++r) {
+                        const vfloat z0 = Z[pg * C][m][r];
+                        av[r] = act_value(act, z0);
+                        Z[pg * C][m][r] = act_record(act, z0, av[r]);
+                    }
                     if (BWD) {
                         if (layer == LH - 1) {
                             PINN_UNROLL for (int ch = 0; ch < C; ++ch) Rlast[pg * C + ch][m] = Z[pg * C + ch][m];
@@ -459,6 +483,7 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                         jet_forward<J>(zz, dd);
                         PINN_UNROLL for (int ch = 1; ch < C; ++ch) Z[pg * C + ch][m][r] = zz[ch];
                     }
+                    Z[pg * C][m] = av;
                 }
         };
         act_forward(A, 0);
@@ -610,7 +635,7 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                     act_derivs_n<J::NORD - 1>(act, zz[0], dd);
                     jet_forward<J>(zz, dd);                 // (ch is a constant after unrolling: the other channels are dead code)
                 }
-                out[r] = zz[ch];
+                out[r] = (ch == 0) ? act_from_record(act, zz[0]) : zz[ch];
             }
             return out;
         };

@@ -84,7 +84,7 @@ struct Spec2 {
     static constexpr bool WBAR_REG = (NHH_ * MTW * MT * 4 <= 96);
 };
 
-template <class S, int MODE>
+template <class S, int MODE, bool SINACT>
 DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds) {
     constexpr int HP = S::HP, MT = S::MT, MTW = S::MTW, NHH = S::NHH, LH = S::LH, D = S::D, C = S::C, PG = S::PG, NG = S::NG;
     constexpr int NFIRST = S::NFIRST;
@@ -99,7 +99,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
     const vint c = lane & vint(15);
     const vbool g0 = veq(g, 0);
     const float* P = ga.packed;
-    const int act = ga.act;
+    const int act = SINACT ? (int)ACT_SIN : (ga.act == ACT_SIGMOID ? (int)ACT_SIGMOID : (int)ACT_TANH);    // never ACT_SIN unless SINACT: the sin rules fold away
     const ubuf PB = ub_make(P, S::PACKED);
     const ubuf SB = ub_make(ga.scratch + (size_t)blk * S::SCR, S::SCR);
     float* X0 = lds;
@@ -170,7 +170,12 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
         auto act_forward = [&](vfloat4 (&Z)[NG][MTW], int layer) {
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t) {
-                    PINN_UNROLL for (int r = 0; r < 4; ++r) Z[pg * C][t][r] = act_value(act, Z[pg * C][t][r]);
+                    vfloat4 av;                                       // activation values; Z[pg*C] holds the RECORD value r0 meanwhile
+                    PINN_UNROLL for (int r = 0; r < 4; ++r) {
+                        const vfloat z0 = Z[pg * C][t][r];
+                        av[r] = act_value(act, z0);
+                        Z[pg * C][t][r] = act_record(act, z0, av[r]);
+                    }
                     if (RECOUT && layer > 0)
                         PINN_UNROLL for (int ch = 0; ch < C; ++ch)
                             ub_store4(RB, (((layer - 1) * NG + pg * C + ch) * MT + w * MTW + t) * 256, lane << 2, Z[pg * C + ch][t]);
@@ -189,6 +194,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         jet_forward<J>(zz, dd);
                         PINN_UNROLL for (int ch = 1; ch < C; ++ch) Z[pg * C + ch][t][r] = zz[ch];
                     }
+                    Z[pg * C][t] = av;
                 }
         };
         // publish this wave's tiles of a [NG][MT] tensor in B-fragment order: X[q][tile][lane][4]
@@ -286,7 +292,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         vfloat4 z = b1;
                         PINN_UNROLL for (int i = 0; i < D; ++i)
                             PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = vfma(w1[i][r], x[pg][i], z[r]);
-                        PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = act_value(act, z[r]);
+                        PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = act_record(act, z[r], act_value(act, z[r]));
                         Rlast[pg * C][t] = z;
                         PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) Rlast[pg * C + 1 + kf][t] = w1[S::first_axis(kf)];
                         PINN_UNROLL for (int ch = 1 + NFIRST; ch < C; ++ch) Rlast[pg * C + ch][t] = vzero4();
@@ -304,7 +310,8 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         PINN_UNROLL for (int k2 = 0; k2 < C; ++k2) zz[k2] = Rlast[pg * C + k2][t][r];
                         act_derivs_n<J::NORD - 1>(act, zz[0], dd);
                         jet_forward<J>(zz, dd);
-                        PINN_UNROLL for (int k2 = 0; k2 < C; ++k2) A[pg * C + k2][t][r] = zz[k2];
+                        A[pg * C][t][r] = act_from_record(act, Rlast[pg * C][t][r]);
+                        PINN_UNROLL for (int k2 = 1; k2 < C; ++k2) A[pg * C + k2][t][r] = zz[k2];
                     }
         }
         STAMP(4)
@@ -411,7 +418,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                     act_derivs_n<J::NORD - 1>(act, zz[0], dd);
                     jet_forward<J>(zz, dd);                 // (ch is a constant after unrolling: the other channels are dead code)
                 }
-                out[r] = zz[ch];
+                out[r] = (ch == 0) ? act_from_record(act, zz[0]) : zz[ch];
             }
             return out;
         };
@@ -463,7 +470,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         vfloat4 z = b1;
                         PINN_UNROLL for (int i = 0; i < D; ++i)
                             PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = vfma(w1[i][r], x[pg][i], z[r]);
-                        PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = act_value(act, z[r]);
+                        PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = act_record(act, z[r], act_value(act, z[r]));
                         Sr[pg * C][t] = z;
                         PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) Sr[pg * C + 1 + kf][t] = w1[S::first_axis(kf)];
                         PINN_UNROLL for (int ch = 1 + NFIRST; ch < C; ++ch) Sr[pg * C + ch][t] = vzero4();

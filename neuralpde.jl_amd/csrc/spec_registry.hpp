@@ -21,6 +21,7 @@ struct SpecInfo {
     unsigned LAP;                    // axis mask of the forward-Laplacian channel (0: none)
     int NPAIR, PG, C, NG, TP, MT, LH, NFIRST;
     int PACKED, SLAB, SCR, LDS_WG, COOP, SH, PW;
+    int has_sin;                     // kernels for the sin activation are compiled for this spec
     int REC;                         // floats per tile of the HBM record store (MODE_FWDREC / MODE_GRADREC); 0: not supported
     int OFF_W1, OFF_B, OFF_WL, OFF_BL, OFF_WPK, OFF_WTPK;
     int O_WBAR, O_BFRH, O_BFR0, O_W1, O_WL, O_BL, O_P;
@@ -30,8 +31,9 @@ struct SpecInfo {
 std::vector<SpecInfo>& registry();
 
 template <class S>
-SpecInfo make_info(void (*launch)(const GroupArgs&, int, int, plat_stream)) {
+SpecInfo make_info(void (*launch)(const GroupArgs&, int, int, plat_stream), int has_sin = 0) {
     SpecInfo s;
+    s.has_sin = has_sin;
     s.family = 1; s.WG_PER_CU = 1;
     s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR; s.HI = S::HI & 0xFFFFFFu; s.LAP = S::J::LAP;
     s.PG = S::PG; s.C = S::C; s.NG = S::NG; s.TP = S::TP; s.MT = S::MT; s.LH = S::LH; s.NFIRST = S::NFIRST;
@@ -45,8 +47,9 @@ SpecInfo make_info(void (*launch)(const GroupArgs&, int, int, plat_stream)) {
 }
 
 template <class S>
-SpecInfo make_info2(void (*launch)(const GroupArgs&, int, int, plat_stream)) {
+SpecInfo make_info2(void (*launch)(const GroupArgs&, int, int, plat_stream), int has_sin = 0) {
     SpecInfo s;
+    s.has_sin = has_sin;
     s.family = 2; s.WG_PER_CU = S::WG_PER_CU;
     s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR; s.HI = S::HI & 0xFFFFFFu; s.LAP = S::J::LAP;
     s.PG = S::PG; s.C = S::C; s.NG = S::NG; s.TP = S::TP; s.MT = S::MT; s.LH = S::LH; s.NFIRST = S::NFIRST;
@@ -74,7 +77,7 @@ struct EmuBarrier {
         else b->cv.wait(lk, [&] { return b->gen != g; });
     }
 };
-template <class S, int MODE>
+template <class S, int MODE, bool SINACT>
 void run_emu(const GroupArgs& ga, int blocks) {
     std::vector<float> lds((size_t)S::LDS_WG);
     for (int b = 0; b < blocks; ++b) {
@@ -85,12 +88,12 @@ void run_emu(const GroupArgs& ga, int blocks) {
             th[w] = std::thread([&, w] {
                 wv::emu_barrier_hook = &EmuBarrier::wait;
                 wv::emu_barrier_ctx = &bar;
-                wave_main<S, MODE>(ga, b, blocks, w, lds.data());
+                wave_main<S, MODE, SINACT>(ga, b, blocks, w, lds.data());
             });
         for (int w = 0; w < 4; ++w) th[w].join();
     }
 }
-template <class S, int MODE>
+template <class S, int MODE, bool SINACT>
 void run_emu2(const GroupArgs& ga, int blocks) {
     std::vector<float> lds((size_t)S::LDS_WG);
     for (int b = 0; b < blocks; ++b) {
@@ -101,61 +104,63 @@ void run_emu2(const GroupArgs& ga, int blocks) {
             th[w] = std::thread([&, w] {
                 wv::emu_barrier_hook = &EmuBarrier::wait;
                 wv::emu_barrier_ctx = &bar;
-                wave_main2<S, MODE>(ga, b, blocks, w, lds.data());
+                wave_main2<S, MODE, SINACT>(ga, b, blocks, w, lds.data());
             });
         for (int w = 0; w < 4; ++w) th[w].join();
     }
 }
-template <class S>
-void launch_spec2(const GroupArgs& ga, int mode, int blocks, plat_stream) {
-    if (mode == MODE_FUSED) run_emu2<S, MODE_FUSED>(ga, blocks);
-    else if (mode == MODE_RESID) run_emu2<S, MODE_RESID>(ga, blocks);
-    else if (mode == MODE_GRADIN) run_emu2<S, MODE_GRADIN>(ga, blocks);
-    else if (mode == MODE_FWDREC) run_emu2<S, MODE_FWDREC>(ga, blocks);
-    else if (mode == MODE_GRADREC) run_emu2<S, MODE_GRADREC>(ga, blocks);
-    else run_emu2<S, MODE_FWD>(ga, blocks);
-}
-template <class S>
-void launch_spec(const GroupArgs& ga, int mode, int blocks, plat_stream) {
-    if (mode == MODE_FUSED) run_emu<S, MODE_FUSED>(ga, blocks);
-    else if (mode == MODE_RESID) run_emu<S, MODE_RESID>(ga, blocks);
-    else if (mode == MODE_GRADIN) run_emu<S, MODE_GRADIN>(ga, blocks);
-    else run_emu<S, MODE_FWD>(ga, blocks);
-}
+#define PINN_LAUNCH2(S, MODE, SINACT, ga, blocks, st) run_emu2<S, MODE, SINACT>(ga, blocks)
+#define PINN_LAUNCH1(S, MODE, SINACT, ga, blocks, st) run_emu<S, MODE, SINACT>(ga, blocks)
 #else
 // One workgroup = 4 independent waves (one per SIMD); persistent grid of <= #CU workgroups.
 // __launch_bounds__(256, 1): one wave per SIMD => the full 512-entry unified VGPR/AGPR file per lane
 // is available for the persistent dW accumulators (MI355X_MICROARCH.md "Register files").
-template <class S, int MODE>
+template <class S, int MODE, bool SINACT>
 __global__ void __launch_bounds__(256, 1) k_wave(const GroupArgs ga) {
     __shared__ __attribute__((aligned(16))) float lds_all[S::LDS_WG];
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    wave_main<S, MODE>(ga, (int)blockIdx.x, (int)gridDim.x, w, lds_all);
+    wave_main<S, MODE, SINACT>(ga, (int)blockIdx.x, (int)gridDim.x, w, lds_all);
 }
 // family 2: __launch_bounds__(256, 2) => at most 256 VGPR+AGPR per lane, two workgroups (8 waves) resident per CU
-template <class S, int MODE>
+template <class S, int MODE, bool SINACT>
 __global__ void __launch_bounds__(256, 2) k_wave2(const GroupArgs ga) {
     __shared__ __attribute__((aligned(16))) float lds_all[S::LDS_WG];
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    wave_main2<S, MODE>(ga, (int)blockIdx.x, (int)gridDim.x, w, lds_all);
+    wave_main2<S, MODE, SINACT>(ga, (int)blockIdx.x, (int)gridDim.x, w, lds_all);
 }
-template <class S>
-void launch_spec2(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
-    if (mode == MODE_FUSED) hipLaunchKernelGGL((k_wave2<S, MODE_FUSED>), dim3(blocks), dim3(256), 0, st, ga);
-    else if (mode == MODE_RESID) hipLaunchKernelGGL((k_wave2<S, MODE_RESID>), dim3(blocks), dim3(256), 0, st, ga);
-    else if (mode == MODE_GRADIN) hipLaunchKernelGGL((k_wave2<S, MODE_GRADIN>), dim3(blocks), dim3(256), 0, st, ga);
-    else if (mode == MODE_FWDREC) hipLaunchKernelGGL((k_wave2<S, MODE_FWDREC>), dim3(blocks), dim3(256), 0, st, ga);
-    else if (mode == MODE_GRADREC) hipLaunchKernelGGL((k_wave2<S, MODE_GRADREC>), dim3(blocks), dim3(256), 0, st, ga);
-    else hipLaunchKernelGGL((k_wave2<S, MODE_FWD>), dim3(blocks), dim3(256), 0, st, ga);
-}
-template <class S>
-void launch_spec(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
-    if (mode == MODE_FUSED) hipLaunchKernelGGL((k_wave<S, MODE_FUSED>), dim3(blocks), dim3(256), 0, st, ga);
-    else if (mode == MODE_RESID) hipLaunchKernelGGL((k_wave<S, MODE_RESID>), dim3(blocks), dim3(256), 0, st, ga);
-    else if (mode == MODE_GRADIN) hipLaunchKernelGGL((k_wave<S, MODE_GRADIN>), dim3(blocks), dim3(256), 0, st, ga);
-    else hipLaunchKernelGGL((k_wave<S, MODE_FWD>), dim3(blocks), dim3(256), 0, st, ga);
-}
+#define PINN_LAUNCH2(S, MODE, SINACT, ga, blocks, st) hipLaunchKernelGGL((k_wave2<S, MODE, SINACT>), dim3(blocks), dim3(256), 0, st, ga)
+#define PINN_LAUNCH1(S, MODE, SINACT, ga, blocks, st) hipLaunchKernelGGL((k_wave<S, MODE, SINACT>), dim3(blocks), dim3(256), 0, st, ga)
 #endif
+
+// The activation kind is a runtime field of the launch (tanh / sigmoid share one kernel); sin gets kernels of its own
+// (SINACT = true: sincos in every jet rule would bloat the common kernels past the instruction cache), compiled only for the
+// specs registered with PINN_INSTANTIATE*_SIN.
+template <class S, bool SINACT>
+void launch_modes2(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
+    (void)st;
+    if (mode == MODE_FUSED) PINN_LAUNCH2(S, MODE_FUSED, SINACT, ga, blocks, st);
+    else if (mode == MODE_RESID) PINN_LAUNCH2(S, MODE_RESID, SINACT, ga, blocks, st);
+    else if (mode == MODE_GRADIN) PINN_LAUNCH2(S, MODE_GRADIN, SINACT, ga, blocks, st);
+    else if (mode == MODE_FWDREC) PINN_LAUNCH2(S, MODE_FWDREC, SINACT, ga, blocks, st);
+    else if (mode == MODE_GRADREC) PINN_LAUNCH2(S, MODE_GRADREC, SINACT, ga, blocks, st);
+    else PINN_LAUNCH2(S, MODE_FWD, SINACT, ga, blocks, st);
+}
+template <class S, bool SINACT>
+void launch_modes1(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
+    (void)st;
+    if (mode == MODE_FUSED) PINN_LAUNCH1(S, MODE_FUSED, SINACT, ga, blocks, st);
+    else if (mode == MODE_RESID) PINN_LAUNCH1(S, MODE_RESID, SINACT, ga, blocks, st);
+    else if (mode == MODE_GRADIN) PINN_LAUNCH1(S, MODE_GRADIN, SINACT, ga, blocks, st);
+    else PINN_LAUNCH1(S, MODE_FWD, SINACT, ga, blocks, st);
+}
+template <class S> void launch_spec2(const GroupArgs& ga, int mode, int blocks, plat_stream st) { launch_modes2<S, false>(ga, mode, blocks, st); }
+template <class S> void launch_spec(const GroupArgs& ga, int mode, int blocks, plat_stream st) { launch_modes1<S, false>(ga, mode, blocks, st); }
+template <class S> void launch_spec2_sin(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
+    if (ga.act == ACT_SIN) launch_modes2<S, true>(ga, mode, blocks, st); else launch_modes2<S, false>(ga, mode, blocks, st);
+}
+template <class S> void launch_spec_sin(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
+    if (ga.act == ACT_SIN) launch_modes1<S, true>(ga, mode, blocks, st); else launch_modes1<S, false>(ga, mode, blocks, st);
+}
 
 struct Registrar {
     explicit Registrar(const SpecInfo& s) { registry().push_back(s); }
@@ -177,6 +182,17 @@ struct Registrar {
     namespace {                                                                              \
     using NAME##_spec = pk::Spec<HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI>;                  \
     pk::Registrar NAME##_reg(pk::make_info<NAME##_spec>(&pk::launch_spec<NAME##_spec>));     \
+    }
+// the same with the sin-activation kernels compiled in as well
+#define PINN_INSTANTIATE2_HI_SIN(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI)             \
+    namespace {                                                                              \
+    using NAME##_spec2 = pk::Spec2<HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI>;                \
+    pk::Registrar NAME##_reg2(pk::make_info2<NAME##_spec2>(&pk::launch_spec2_sin<NAME##_spec2>, 1)); \
+    }
+#define PINN_INSTANTIATE_HI_SIN(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI)              \
+    namespace {                                                                              \
+    using NAME##_spec = pk::Spec<HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI>;                  \
+    pk::Registrar NAME##_reg(pk::make_info<NAME##_spec>(&pk::launch_spec_sin<NAME##_spec>, 1)); \
     }
 #define PINN_INSTANTIATE2(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG) PINN_INSTANTIATE2_HI(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, 0u)
 #define PINN_INSTANTIATE(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG) PINN_INSTANTIATE_HI(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, 0u)

@@ -85,6 +85,7 @@ inline void tape_zero(vtape& t) { for (int i = 0; i < 32; ++i) t.r[i] = vfloat(0
 // 16-byte record at a wave-uniform address (device: scalar-cache load)
 struct urec16 { int x, y, z, w; };
 inline void sched_fence() {}
+inline void vsincos(const vfloat& x, vfloat& s, vfloat& c) { for (int l = 0; l < W; ++l) { s.v[l] = std::sin(x.v[l]); c.v[l] = std::cos(x.v[l]); } }
 inline urec16 uload16(const void* p) { urec16 r; std::memcpy(&r, p, 16); return r; }
 struct urec32 { int v[8]; };
 inline urec32 uload32(const void* p) { urec32 r; std::memcpy(&r, p, 32); return r; }
@@ -164,6 +165,20 @@ DEV vfloat vcosh(vfloat x) { return coshf(x); }
 DEV vfloat vrcp(vfloat x) { return __builtin_amdgcn_rcpf(x); }
 // tanh(x) = 1 - 2/(exp(2x)+1) on v_exp_f32 / v_rcp_f32: absolute error ~1e-7 (the quantity that matters for a
 // bounded activation feeding a linear layer); saturates correctly to +-1 for |x| large.
+// sin and cos together in ~25 instructions (the library sinf/cosf inline a Payne-Hanek reduction each): two-constant Cody-Waite
+// reduction to [-pi/4, pi/4] (exact enough for |x| < ~1e4; network pre-activations are O(1..10)) + the cephes minimax polynomials.
+DEV void vsincos(vfloat x, vfloat& s, vfloat& c) {
+    const float k = __builtin_rintf(x * 0.63661977236758134f);
+    float r = __builtin_fmaf(k, -1.5707963109016418f, x);
+    r = __builtin_fmaf(k, -1.5893254712295857e-8f, r);
+    const float r2 = r * r;
+    const float sp = r + r * r2 * (-1.6666654611e-1f + r2 * (8.3321608736e-3f + r2 * -1.9515295891e-4f));
+    const float cp = 1.0f + r2 * (-0.5f + r2 * (4.166664568298827e-2f + r2 * (-1.388731625493765e-3f + r2 * 2.443315711809948e-5f)));
+    const int q = (int)k & 3;
+    const float sv = (q & 1) ? cp : sp, cv = (q & 1) ? sp : cp;
+    s = (q & 2) ? -sv : sv;
+    c = ((q + 1) & 2) ? -cv : cv;
+}
 DEV vfloat vtanh_fast(vfloat x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
 DEV vfloat vsigmoid_fast(vfloat x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 DEV vfloat vsign(vfloat x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }

@@ -425,3 +425,15 @@ def test_forward_laplacian_fusion(npde, use_emu):
         assert tag in kern, kern
         r = rep.loss_functions.datafree_pde_loss_functions[0](sets[0], th)
         np.testing.assert_allclose(r, po.residual_values(prob, th, 0, sets[0]), rtol=3e-5, atol=3e-5)
+
+
+def test_sin_activation(npde, use_emu):
+    """sin hidden activations (test/NNPDE2/direct_function__approximation_of_function_1d_2.jl:23-26): the layer records keep the
+    pre-activation z (cos z is not a function of sin z); second derivatives and, on the KS set, phi''''' = cos."""
+    sysm, _ = poisson2d(npde, "tanh")
+    chain = npde.Chain(npde.Dense(2, 16, "sin"), npde.Dense(16, 16, "sin"), npde.Dense(16, 1))
+    strat = npde.QuasiRandomTraining(50, bcs_points=21, sampling_alg=npde.SobolSample(seed=6), resampling=False, minibatch=1)
+    check(npde, sysm, [chain], strat, theta_for(chain, 81), weights=[1.0, 2.0, 0.5, 1.5, 1.0])
+    big = npde.Chain(npde.Dense(2, 64, "sin"), *[npde.Dense(64, 64, "sin") for _ in range(3)], npde.Dense(64, 1))
+    check(npde, sysm, [big], strat, theta_for(big, 82))
+    check(npde, _ks(npde), [chain], strat, theta_for(chain, 83), mode="exact")

@@ -271,3 +271,19 @@ def test_heterogeneous_system_gpu(npde, hip_lib):
     ref = po.loss_and_grad(helpers.oracle_problem(npde, sysm, chains), theta, sets, weights=w, mode="stencil")
     le, g2, gi = helpers.rel_errors(losses, grad, ref)
     assert le.max() < TOL and g2 < TOL and gi < TOL, (le, g2, gi)
+
+
+def test_sin_activation_gpu(npde, hip_lib):
+    """sin hidden activations (records keep z): 2-D Poisson on a 4x64 sin net and the small KS set."""
+    import test_emu_parity as tp
+    sysm, _ = tp.poisson2d(npde, "tanh")
+    strat = npde.QuasiRandomTraining(3000, bcs_points=700, sampling_alg=npde.SobolSample(seed=6), resampling=False, minibatch=1)
+    for chain, seed, s, mode in ((npde.Chain(npde.Dense(2, 64, "sin"), *[npde.Dense(64, 64, "sin") for _ in range(3)], npde.Dense(64, 1)), 82, sysm, "stencil"),
+                                 (npde.Chain(npde.Dense(2, 16, "sin"), npde.Dense(16, 16, "sin"), npde.Dense(16, 1)), 83, tp._ks(npde), "exact")):
+        th = tp.theta_for(chain, seed)
+        rep = npde.symbolic_discretize(s, npde.PhysicsInformedNN(chain, strat, init_params=th))
+        sets = rep.pde_train_sets + rep.bcs_train_sets
+        losses, grad = rep.engine.loss_grad(th)
+        ref = po.loss_and_grad(helpers.oracle_problem(npde, s, [chain]), th, sets, mode=mode)
+        le, g2, gi = helpers.rel_errors(losses, grad, ref)
+        assert le.max() < TOL and g2 < TOL and gi < TOL, (le, g2, gi)
