@@ -211,9 +211,9 @@ struct GroupArgs {
 };
 
 // derivatives phi', ..., phi^(NORD) of the activation from the record value r0 (see Act)   (d[0] unused)
-template <int NORD>
+template <int NORD, bool SINACT>
 DEV void act_derivs_n(int act, vfloat a, vfloat (&d)[6]) {
-    if (act == ACT_SIN) {
+    if (SINACT) {
         vfloat sn, cs;
         vsincos(a, sn, cs);
         d[1] = cs;
@@ -331,15 +331,17 @@ DEV void jet_adjoint(vfloat (&g)[J::C], const vfloat (&s)[J::C], const vfloat (&
     PINN_UNROLL for (int k = 0; k < J::N3; ++k) g[J::CH_3 + k] = z3b[k];
 }
 
+template <bool SINACT>
 DEV vfloat act_value(int act, vfloat z) {
+    if (SINACT) { vfloat sn, cs; vsincos(z, sn, cs); return sn; }
     if (act == ACT_TANH) return vtanh_fast(z);
-    if (act == ACT_SIN) { vfloat sn, cs; vsincos(z, sn, cs); return sn; }
     return vsigmoid_fast(z);
 }
 // record value r0 of an element with pre-activation z and activation a, and the activation back from r0
-DEV vfloat act_record(int act, vfloat z, vfloat a) { return act == ACT_SIN ? z : a; }
-DEV vfloat act_from_record(int act, vfloat r0) {
-    if (act != ACT_SIN) return r0;
+template <bool SINACT> DEV vfloat act_record(vfloat z, vfloat a) { return SINACT ? z : a; }
+template <bool SINACT>
+DEV vfloat act_from_record(vfloat r0) {
+    if (!SINACT) return r0;
     vfloat sn, cs;
     vsincos(r0, sn, cs);
     return sn;
@@ -373,7 +375,7 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
     const vint c = lane & vint(15);
     const vbool g0 = veq(g, 0);
     const float* P = ga.packed;
-    const int act = SINACT ? (int)ACT_SIN : (ga.act == ACT_SIGMOID ? (int)ACT_SIGMOID : (int)ACT_TANH);    // never ACT_SIN unless SINACT: the sin rules fold away
+    const int act = ga.act;                 // tanh / sigmoid at run time; sin is the compile-time SINACT variant
 
     // ---- persistent per-wave gradient accumulators (registers / AGPRs across all tiles) ----
     vfloat4 wbar[NHH > 0 ? NHH : 1][WT][MT];      // COOP: this wave's row block (to == w) only
@@ -462,11 +464,11 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
         auto act_forward = [&](vfloat4 (&Z)[NG][MT], int layer /*0-based hidden layer*/) {
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                 PINN_UNROLL for (int m = 0; m < MT; ++m) {
-                    vfloat4 av;                                       // activation values; Z[pg*C] holds the RECORD value r0 meanwhile
+                    vfloat4 av;                                       // sin: activation values; Z[pg*C] holds the RECORD value z meanwhile
                     PINN_UNROLL for (int r = 0; r < 4; ++r) {
                         const vfloat z0 = Z[pg * C][m][r];
-                        av[r] = act_value(act, z0);
-                        Z[pg * C][m][r] = act_record(act, z0, av[r]);
+                        av[r] = act_value<SINACT>(act, z0);
+                        Z[pg * C][m][r] = SINACT ? z0 : av[r];
                     }
                     if (BWD) {
                         if (layer == LH - 1) {
@@ -479,11 +481,11 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                     PINN_UNROLL for (int r = 0; r < 4; ++r) {
                         vfloat zz[C], dd[6];
                         PINN_UNROLL for (int ch = 0; ch < C; ++ch) zz[ch] = Z[pg * C + ch][m][r];
-                        act_derivs_n<J::NORD - 1>(act, zz[0], dd);
+                        act_derivs_n<J::NORD - 1, SINACT>(act, zz[0], dd);
                         jet_forward<J>(zz, dd);
                         PINN_UNROLL for (int ch = 1; ch < C; ++ch) Z[pg * C + ch][m][r] = zz[ch];
                     }
-                    Z[pg * C][m] = av;
+                    if (SINACT) Z[pg * C][m] = av;
                 }
         };
         act_forward(A, 0);
@@ -632,10 +634,10 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                 vfloat zz[C], dd[6];
                 PINN_UNROLL for (int k = 0; k < C; ++k) zz[k] = Sr[pg * C + k][m][r];
                 if (ch > 0) {
-                    act_derivs_n<J::NORD - 1>(act, zz[0], dd);
+                    act_derivs_n<J::NORD - 1, SINACT>(act, zz[0], dd);
                     jet_forward<J>(zz, dd);                 // (ch is a constant after unrolling: the other channels are dead code)
                 }
-                out[r] = (ch == 0) ? act_from_record(act, zz[0]) : zz[ch];
+                out[r] = (ch == 0) ? act_from_record<SINACT>(zz[0]) : zz[ch];
             }
             return out;
         };
@@ -646,7 +648,7 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                     PINN_UNROLL for (int r = 0; r < 4; ++r) {
                         vfloat gg[C], ss[C], dd[6];
                         PINN_UNROLL for (int k = 0; k < C; ++k) { gg[k] = G[pg * C + k][m][r]; ss[k] = Sr[pg * C + k][m][r]; }
-                        act_derivs_n<J::NORD>(act, ss[0], dd);
+                        act_derivs_n<J::NORD, SINACT>(act, ss[0], dd);
                         jet_adjoint<J>(gg, ss, dd);
                         PINN_UNROLL for (int k = 0; k < C; ++k) G[pg * C + k][m][r] = gg[k];
                     }

@@ -99,7 +99,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
     const vint c = lane & vint(15);
     const vbool g0 = veq(g, 0);
     const float* P = ga.packed;
-    const int act = SINACT ? (int)ACT_SIN : (ga.act == ACT_SIGMOID ? (int)ACT_SIGMOID : (int)ACT_TANH);    // never ACT_SIN unless SINACT: the sin rules fold away
+    const int act = ga.act;                 // tanh / sigmoid at run time; sin is the compile-time SINACT variant
     const ubuf PB = ub_make(P, S::PACKED);
     const ubuf SB = ub_make(ga.scratch + (size_t)blk * S::SCR, S::SCR);
     float* X0 = lds;
@@ -170,11 +170,11 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
         auto act_forward = [&](vfloat4 (&Z)[NG][MTW], int layer) {
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t) {
-                    vfloat4 av;                                       // activation values; Z[pg*C] holds the RECORD value r0 meanwhile
+                    vfloat4 av;                                       // sin: activation values; Z[pg*C] holds the RECORD value z meanwhile
                     PINN_UNROLL for (int r = 0; r < 4; ++r) {
                         const vfloat z0 = Z[pg * C][t][r];
-                        av[r] = act_value(act, z0);
-                        Z[pg * C][t][r] = act_record(act, z0, av[r]);
+                        av[r] = act_value<SINACT>(act, z0);
+                        Z[pg * C][t][r] = SINACT ? z0 : av[r];
                     }
                     if (RECOUT && layer > 0)
                         PINN_UNROLL for (int ch = 0; ch < C; ++ch)
@@ -190,11 +190,11 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                     PINN_UNROLL for (int r = 0; r < 4; ++r) {
                         vfloat zz[C], dd[6];
                         PINN_UNROLL for (int ch = 0; ch < C; ++ch) zz[ch] = Z[pg * C + ch][t][r];
-                        act_derivs_n<J::NORD - 1>(act, zz[0], dd);
+                        act_derivs_n<J::NORD - 1, SINACT>(act, zz[0], dd);
                         jet_forward<J>(zz, dd);
                         PINN_UNROLL for (int ch = 1; ch < C; ++ch) Z[pg * C + ch][t][r] = zz[ch];
                     }
-                    Z[pg * C][t] = av;
+                    if (SINACT) Z[pg * C][t] = av;
                 }
         };
         // publish this wave's tiles of a [NG][MT] tensor in B-fragment order: X[q][tile][lane][4]
@@ -292,7 +292,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         vfloat4 z = b1;
                         PINN_UNROLL for (int i = 0; i < D; ++i)
                             PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = vfma(w1[i][r], x[pg][i], z[r]);
-                        PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = act_record(act, z[r], act_value(act, z[r]));
+                        PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = act_record<SINACT>(z[r], act_value<SINACT>(act, z[r]));
                         Rlast[pg * C][t] = z;
                         PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) Rlast[pg * C + 1 + kf][t] = w1[S::first_axis(kf)];
                         PINN_UNROLL for (int ch = 1 + NFIRST; ch < C; ++ch) Rlast[pg * C + ch][t] = vzero4();
@@ -308,9 +308,9 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                     PINN_UNROLL for (int r = 0; r < 4; ++r) {
                         vfloat zz[C], dd[6];
                         PINN_UNROLL for (int k2 = 0; k2 < C; ++k2) zz[k2] = Rlast[pg * C + k2][t][r];
-                        act_derivs_n<J::NORD - 1>(act, zz[0], dd);
+                        act_derivs_n<J::NORD - 1, SINACT>(act, zz[0], dd);
                         jet_forward<J>(zz, dd);
-                        A[pg * C][t][r] = act_from_record(act, Rlast[pg * C][t][r]);
+                        A[pg * C][t][r] = act_from_record<SINACT>(Rlast[pg * C][t][r]);
                         PINN_UNROLL for (int k2 = 1; k2 < C; ++k2) A[pg * C + k2][t][r] = zz[k2];
                     }
         }
@@ -415,10 +415,10 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                 vfloat zz[C], dd[6];
                 PINN_UNROLL for (int k = 0; k < C; ++k) zz[k] = Sr[pg * C + k][t][r];
                 if (ch > 0) {
-                    act_derivs_n<J::NORD - 1>(act, zz[0], dd);
+                    act_derivs_n<J::NORD - 1, SINACT>(act, zz[0], dd);
                     jet_forward<J>(zz, dd);                 // (ch is a constant after unrolling: the other channels are dead code)
                 }
-                out[r] = (ch == 0) ? act_from_record(act, zz[0]) : zz[ch];
+                out[r] = (ch == 0) ? act_from_record<SINACT>(zz[0]) : zz[ch];
             }
             return out;
         };
@@ -428,7 +428,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                     PINN_UNROLL for (int r = 0; r < 4; ++r) {
                         vfloat gg[C], ss[C], dd[6];
                         PINN_UNROLL for (int k = 0; k < C; ++k) { gg[k] = G[pg * C + k][t][r]; ss[k] = Sr[pg * C + k][t][r]; }
-                        act_derivs_n<J::NORD>(act, ss[0], dd);
+                        act_derivs_n<J::NORD, SINACT>(act, ss[0], dd);
                         jet_adjoint<J>(gg, ss, dd);
                         PINN_UNROLL for (int k = 0; k < C; ++k) G[pg * C + k][t][r] = gg[k];
                     }
@@ -470,7 +470,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         vfloat4 z = b1;
                         PINN_UNROLL for (int i = 0; i < D; ++i)
                             PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = vfma(w1[i][r], x[pg][i], z[r]);
-                        PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = act_record(act, z[r], act_value(act, z[r]));
+                        PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = act_record<SINACT>(z[r], act_value<SINACT>(act, z[r]));
                         Sr[pg * C][t] = z;
                         PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) Sr[pg * C + 1 + kf][t] = w1[S::first_axis(kf)];
                         PINN_UNROLL for (int ch = 1 + NFIRST; ch < C; ++ch) Sr[pg * C + ch][t] = vzero4();
