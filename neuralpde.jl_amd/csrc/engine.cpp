@@ -1272,14 +1272,22 @@ int pinn_create(const char* descriptor, pinn_handle* out) {
     E->d_defaults = (float*)plat_malloc(sizeof(float) * pk::MAX_PARAMS);
     E->d_lossraw = (double*)plat_malloc(sizeof(double) * K);
     E->d_out = (float*)plat_malloc(sizeof(float) * (E->ntheta + K));
-    if (!E->d_theta || !E->d_params || !E->d_defaults || !E->d_lossraw || !E->d_out) return fail("device allocation failed");
-    plat_h2d(E->d_defaults, E->p_defaults.data(), sizeof(float) * pk::MAX_PARAMS, E->stream);
-    E->h_out.resize(E->ntheta + K);
     plat_event_create(E->ev0); plat_event_create(E->ev1); plat_event_create(E->ev2); plat_event_create(E->ev3);
     plat_event_create(E->ev_fork);
     for (auto& e : E->ev_join) plat_event_create(e);
     for (auto& st : E->aux_stream) st = plat_stream_create();
-    if (build_plan(*E)) { pinn_destroy(E.release()); return 1; }
+    if (!E->d_theta || !E->d_params || !E->d_defaults || !E->d_lossraw || !E->d_out) {
+        pinn_destroy(E.release());                   // releases whatever was allocated
+        return fail("device allocation failed");
+    }
+    plat_h2d(E->d_defaults, E->p_defaults.data(), sizeof(float) * pk::MAX_PARAMS, E->stream);
+    E->h_out.resize(E->ntheta + K);
+    if (build_plan(*E)) {
+        const std::string msg = g_err;               // pinn_destroy must not lose the reason
+        pinn_destroy(E.release());
+        g_err = msg;
+        return 1;
+    }
     *out = E.release();
     return 0;
 }
