@@ -831,7 +831,9 @@ int build_plan(pinn_engine& E) {
         const Net& N = E.nets[G.net];
         const int LH = s.LH, HP = s.HP, MT = s.MT, D = s.D;
         (void)HP;
-        G.max_blocks = E.ncu * s.WG_PER_CU;
+        // (PINN_WG_PER_CU=1 limits the grid to one workgroup per CU: occupancy experiments)
+        static const int wg_cap = [] { const char* e = std::getenv("PINN_WG_PER_CU"); return e ? std::atoi(e) : 0; }();
+        G.max_blocks = E.ncu * ((wg_cap > 0 && wg_cap < s.WG_PER_CU) ? wg_cap : s.WG_PER_CU);
         plat_event_create(G.ev_a);
         plat_event_create(G.ev_b);
         const size_t nw = (size_t)G.max_blocks * 4;
