@@ -26,6 +26,10 @@
 #define STAMP_EXTRA 0
 #endif
 
+#ifndef PINN_F2_OCC
+#define PINN_F2_OCC 2
+#endif
+
 namespace pk {
 
 template <int HP_, int NHH_, int D_, unsigned D1MASK_, unsigned long long PAIRS_, int NPAIR_, int PG_, unsigned HI_ = 0>
@@ -78,7 +82,9 @@ struct Spec2 {
     static constexpr int CHSZ = CH_AT + 4 * CH_ZT;
     static_assert(!CHUNKED || 2 * CHSZ <= XSZ, "chunk double buffer must fit inside X1");
     static constexpr int LDS_WG = (CHUNKED ? 2 : 3) * XSZ + LDS_UP;
-    static constexpr int WG_PER_CU = (LDS_WG * 4 <= 80 * 1024) ? 2 : 1;
+    // PINN_F2_OCC=3 (experiment): three workgroups per CU where the LDS allows it — the kernel is then compiled for <= 168 VGPRs
+    static constexpr int WG_PER_CU = (PINN_F2_OCC >= 3 && LDS_WG * 4 <= 53 * 1024) ? 3 : ((LDS_WG * 4 <= 80 * 1024) ? 2 : 1);
+    static constexpr int OCC = WG_PER_CU > 2 ? WG_PER_CU : 2;            // waves per SIMD the kernel is compiled for
     // dW accumulators: resident in registers across tiles when they fit (4x64: 48 registers); for wide/deep nets they
     // are accumulated per tile into this workgroup's slab instead (read-modify-write, L2; same wave owns the same tiles)
     static constexpr bool WBAR_REG = (NHH_ * MTW * MT * 4 <= 96);

@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256, 1) k_wave(const GroupArgs ga) {
 }
 // family 2: __launch_bounds__(256, 2) => at most 256 VGPR+AGPR per lane, two workgroups (8 waves) resident per CU
 template <class S, int MODE, bool SINACT>
-__global__ void __launch_bounds__(256, 2) k_wave2(const GroupArgs ga) {
+__global__ void __launch_bounds__(256, S::OCC) k_wave2(const GroupArgs ga) {
     __shared__ __attribute__((aligned(16))) float lds_all[S::LDS_WG];
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     wave_main2<S, MODE, SINACT>(ga, (int)blockIdx.x, (int)gridDim.x, w, lds_all);
