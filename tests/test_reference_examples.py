@@ -1,0 +1,154 @@
+"""The reference's documented PDE examples / PDE tests, stated through the mirror API and checked against the float64 oracle
+(CPU: real kernel sources in the lock-step emulation; small point sets).  Each case cites the reference file it restates.
+Networks are the documented shapes or the nearest compiled shape (hidden widths are zero-padded to 16)."""
+import numpy as np
+import pytest
+import sympy as sp
+
+import helpers
+import pinn_oracle as po
+from test_emu_parity import check, theta_for
+
+
+def chains_for(npde, n_in_list, width, act):
+    return [npde.Chain(npde.Dense(n, width, act), npde.Dense(width, width, act), npde.Dense(width, 1)) for n in n_in_list]
+
+
+def thetas(chains, seed):
+    return np.concatenate([theta_for(c, seed + i) for i, c in enumerate(chains)])
+
+
+def test_wave_equation(npde, use_emu):
+    # docs/src/examples/wave.md:27-37: u_tt = c^2 u_xx, Dirichlet walls, u(0,x) = x(1-x), u_t(0,x) = 0; Dense(2,16,sigma) x2
+    t, x = npde.parameters("t x")
+    (u,) = npde.variables("u")
+    Dtt, Dxx, Dt = npde.Differential(t) ** 2, npde.Differential(x) ** 2, npde.Differential(t)
+    eq = npde.Eq(Dtt(u(t, x)), 1 ** 2 * Dxx(u(t, x)))
+    bcs = [npde.Eq(u(t, 0), 0.0), npde.Eq(u(t, 1), 0.0), npde.Eq(u(0, x), x * (1.0 - x)), npde.Eq(Dt(u(0, x)), 0.0)]
+    dom = [npde.In(t, npde.Interval(0.0, 1.0)), npde.In(x, npde.Interval(0.0, 1.0))]
+    sysm = npde.PDESystem([eq], bcs, dom, [t, x], [u(t, x)])
+    (chain,) = chains_for(npde, [2], 16, "sigmoid")
+    check(npde, sysm, [chain], npde.GridTraining(0.1), theta_for(chain, 101))
+
+
+def test_mixed_derivative_pde(npde, use_emu):
+    # test/NNPDE1/nnpde__pde_vi_pde_with_mixed_derivative.jl:58-72: u_xx + u_xy - 2 u_yy = -1; bcs mix values and derivatives
+    x, y = npde.parameters("x y")
+    (u,) = npde.variables("u")
+    Dx, Dy = npde.Differential(x), npde.Differential(y)
+    Dxx, Dyy = Dx ** 2, Dy ** 2
+    eq = npde.Eq(Dxx(u(x, y)) + Dx(Dy(u(x, y))) - 2 * Dyy(u(x, y)), -1.0)
+    bcs = [npde.Eq(u(x, 0), x), npde.Eq(Dy(u(x, 0)), x), npde.Eq(u(x, 0), Dy(u(x, 0)))]
+    dom = [npde.In(x, npde.Interval(0.0, 1.0)), npde.In(y, npde.Interval(0.0, 1.0))]
+    sysm = npde.PDESystem([eq], bcs, dom, [x, y], [u(x, y)])
+    (chain,) = chains_for(npde, [2], 12, "sigmoid")
+    strat = npde.QuasiRandomTraining(64, sampling_alg=npde.SobolSample(seed=2), resampling=False, minibatch=1)
+    check(npde, sysm, [chain], strat, theta_for(chain, 102))
+
+
+def test_system_of_three_pdes(npde, use_emu):
+    # docs/src/tutorials/systems.md:44-66: two wave equations coupled through an algebraic constraint, three networks
+    t, x = npde.parameters("t x")
+    u1, u2, u3 = npde.variables("u1 u2 u3")
+    Dt, Dtt, Dxx = npde.Differential(t), npde.Differential(t) ** 2, npde.Differential(x) ** 2
+    sinpi, cospi = (lambda z: sp.sin(sp.pi * z)), (lambda z: sp.cos(sp.pi * z))
+    eqs = [npde.Eq(Dtt(u1(t, x)), Dxx(u1(t, x)) + u3(t, x) * sinpi(x)),
+           npde.Eq(Dtt(u2(t, x)), Dxx(u2(t, x)) + u3(t, x) * cospi(x)),
+           npde.Eq(0.0, u1(t, x) * sinpi(x) + u2(t, x) * cospi(x) - sp.exp(-t))]
+    bcs = [npde.Eq(u1(0, x), sinpi(x)), npde.Eq(u2(0, x), cospi(x)), npde.Eq(Dt(u1(0, x)), -sinpi(x)), npde.Eq(Dt(u2(0, x)), -cospi(x)),
+           npde.Eq(u1(t, 0), 0.0), npde.Eq(u2(t, 0), sp.exp(-t)), npde.Eq(u1(t, 1), 0.0), npde.Eq(u2(t, 1), -sp.exp(-t))]
+    dom = [npde.In(t, npde.Interval(0.0, 1.0)), npde.In(x, npde.Interval(0.0, 1.0))]
+    sysm = npde.PDESystem(eqs, bcs, dom, [t, x], [u1(t, x), u2(t, x), u3(t, x)])
+    chains = chains_for(npde, [2, 2, 2], 15, "sigmoid")
+    strat = npde.QuasiRandomTraining(40, bcs_points=16, sampling_alg=npde.SobolSample(seed=3), resampling=False, minibatch=1)
+    check(npde, sysm, chains, strat, thetas(chains, 110))
+
+
+def test_linear_parabolic_system(npde, use_emu):
+    # docs/src/examples/linear_parabolic.md:34-66: u_t = a u_xx + b1 u + c1 w, w_t = a w_xx + b2 u + c2 w with analytic boundary data
+    t, x = npde.parameters("t x")
+    u, w = npde.variables("u w")
+    Dt, Dxx = npde.Differential(t), npde.Differential(x) ** 2
+    a, b1, b2, c1, c2 = 1, 4, 2, 3, 1
+    l1 = (b1 + c2 + sp.sqrt((b1 + c2) ** 2 + 4 * (b1 * c2 - b2 * c1))) / 2
+    l2 = (b1 + c2 - sp.sqrt((b1 + c2) ** 2 + 4 * (b1 * c2 - b2 * c1))) / 2
+    th = lambda tt, xx: sp.exp(-tt) * sp.cos(xx / a)
+    ua = lambda tt, xx: (b1 - l2) / (b2 * (l1 - l2)) * sp.exp(l1 * tt) * th(tt, xx) - (b1 - l1) / (b2 * (l1 - l2)) * sp.exp(l2 * tt) * th(tt, xx)
+    wa = lambda tt, xx: 1 / (l1 - l2) * (sp.exp(l1 * tt) * th(tt, xx) - sp.exp(l2 * tt) * th(tt, xx))
+    eqs = [npde.Eq(Dt(u(t, x)), a * Dxx(u(t, x)) + b1 * u(t, x) + c1 * w(t, x)),
+           npde.Eq(Dt(w(t, x)), a * Dxx(w(t, x)) + b2 * u(t, x) + c2 * w(t, x))]
+    bcs = [npde.Eq(u(0, x), ua(0, x)), npde.Eq(w(0, x), wa(0, x)), npde.Eq(u(t, 0), ua(t, 0)), npde.Eq(w(t, 0), wa(t, 0)),
+           npde.Eq(u(t, 1), ua(t, 1)), npde.Eq(w(t, 1), wa(t, 1))]
+    dom = [npde.In(t, npde.Interval(0.0, 1.0)), npde.In(x, npde.Interval(0.0, 1.0))]
+    sysm = npde.PDESystem(eqs, bcs, dom, [t, x], [u(t, x), w(t, x)])
+    chains = chains_for(npde, [2, 2], 15, "sigmoid")
+    strat = npde.QuasiRandomTraining(40, bcs_points=16, sampling_alg=npde.SobolSample(seed=4), resampling=False, minibatch=1)
+    check(npde, sysm, chains, strat, thetas(chains, 120))
+
+
+def test_nonlinear_elliptic_first_order_system(npde, use_emu):
+    # docs/src/examples/nonlinear_elliptic.md:36-71: reaction-diffusion pair written as a first-order system in SIX dependent variables
+    # (u, w and their gradients as networks of their own); every equation couples two or three networks
+    x, y = npde.parameters("x y")
+    Dx, Dy = npde.Differential(x), npde.Differential(y)
+    u, w, Dxu, Dyu, Dxw, Dyw = npde.variables("u w Dxu Dyu Dxw Dyw")
+    f, g, h = sp.sin, sp.cos, (lambda z: z)
+    U, Wv = u(x, y), w(x, y)
+    eqs = [npde.Eq(Dx(Dxu(x, y)) + Dy(Dyu(x, y)), U * f(U / Wv) + U / Wv * h(U / Wv)),
+           npde.Eq(Dx(Dxw(x, y)) + Dy(Dyw(x, y)), Wv * g(U / Wv) + h(U / Wv))]
+    k = 0.7853981633974483                                  # root of sin = cos on (0, 1)
+    theta_a = lambda xx, yy: (sp.cosh(sp.sqrt(sp.sin(k)) * xx) + sp.sinh(sp.sqrt(sp.sin(k)) * xx)) * (yy + 1)
+    wa = lambda xx, yy: theta_a(xx, yy) - k / sp.sin(k)
+    ua = lambda xx, yy: k * wa(xx, yy)
+    bcs = [npde.Eq(u(0, y), ua(0, y)), npde.Eq(u(1, y), ua(1, y)), npde.Eq(u(x, 0), ua(x, 0)),
+           npde.Eq(w(0, y), wa(0, y)), npde.Eq(w(1, y), wa(1, y)), npde.Eq(w(x, 0), wa(x, 0)),
+           npde.Eq(Dy(u(x, y)), Dyu(x, y)), npde.Eq(Dy(w(x, y)), Dyw(x, y)), npde.Eq(Dx(u(x, y)), Dxu(x, y)), npde.Eq(Dx(w(x, y)), Dxw(x, y))]
+    dom = [npde.In(x, npde.Interval(0.0, 1.0)), npde.In(y, npde.Interval(0.0, 1.0))]
+    dvs = [u(x, y), w(x, y), Dxu(x, y), Dyu(x, y), Dxw(x, y), Dyw(x, y)]
+    sysm = npde.PDESystem(eqs, bcs, dom, [x, y], dvs)
+    chains = chains_for(npde, [2] * 6, 15, "tanh")
+    # shift the w network's output bias so that u / w stays away from a zero denominator at the random initialisation
+    th = thetas(chains, 130)
+    off = chains[0].nparams
+    th[off + chains[1].nparams - 1] += 3.0
+    strat = npde.QuasiRandomTraining(32, bcs_points=12, sampling_alg=npde.SobolSample(seed=5), resampling=False, minibatch=1)
+    rep, prob, sets, th = check(npde, sysm, chains, strat, th)
+    assert rep.engine.describe().count("coupled") >= 6
+
+
+def test_lorenz_parameter_estimation_terms(npde, use_emu):
+    # docs/src/tutorials/param_estim.md (Lorenz system, three networks of t, sigma / rho / beta estimated): the physics terms and
+    # their gradient w.r.t. the network weights AND the three parameters (the data misfit is a host-side additional_loss)
+    (t,) = npde.parameters("t")
+    sg, rho, beta = npde.parameters("sigma_ rho beta")
+    xv, yv, zv = npde.variables("x y z")
+    Dt = npde.Differential(t)
+    eqs = [npde.Eq(Dt(xv(t)), sg * (yv(t) - xv(t))), npde.Eq(Dt(yv(t)), xv(t) * (rho - zv(t)) - yv(t)), npde.Eq(Dt(zv(t)), xv(t) * yv(t) - beta * zv(t))]
+    bcs = [npde.Eq(xv(0), 1.0), npde.Eq(yv(0), 0.0), npde.Eq(zv(0), 0.0)]
+    sysm = npde.PDESystem(eqs, bcs, [npde.In(t, npde.Interval(0.0, 1.0))], [t], [xv(t), yv(t), zv(t)], ps=[sg, rho, beta],
+                          defaults={sg: 9.0, rho: 25.0, beta: 2.5})
+    chains = chains_for(npde, [1, 1, 1], 8, "sigmoid")
+    rep, prob, sets, th = check(npde, sysm, chains, npde.GridTraining(0.05), thetas(chains, 140), param_estim=True)
+    assert th.size == sum(c.nparams for c in chains) + 3 and list(th[-3:]) == [9.0, 25.0, 2.5]      # theta.p appended (src/discretize.jl:451-465)
+
+
+def test_nonlinear_hyperbolic_system(npde, use_emu):
+    # docs/src/examples/nonlinear_hyperbolic.md:66-68 (with n = 1 so that the nested derivative Dx(x^n Dx(u)) has to be expanded):
+    # u_tt = a/x^n (x^n u_x)_x + u f(u/w), w_tt = b/x^n (x^n w_x)_x + w g(u/w), f(z) = z^2, g(z) = 4 cos(pi z).
+    # (the documented boundary data are Bessel functions, outside the engine's op set: smooth stand-ins here)
+    t, x = npde.parameters("t x")
+    u, w = npde.variables("u w")
+    Dx, Dtt = npde.Differential(x), npde.Differential(t) ** 2
+    a, b, n = 16, 16, 1
+    f, g = (lambda z: z ** 2), (lambda z: 4 * sp.cos(sp.pi * z))
+    U, Wv = u(t, x), w(t, x)
+    eqs = [npde.Eq(Dtt(U), a / (x ** n) * Dx(x ** n * Dx(U)) + U * f(U / Wv)),
+           npde.Eq(Dtt(Wv), b / (x ** n) * Dx(x ** n * Dx(Wv)) + Wv * g(U / Wv))]
+    bcs = [npde.Eq(u(0, x), sp.cos(x)), npde.Eq(w(0, x), 2 + sp.sin(x)), npde.Eq(u(t, 1), sp.exp(-t)), npde.Eq(w(t, 1), 2.0 + t)]
+    dom = [npde.In(t, npde.Interval(0.0, 1.0)), npde.In(x, npde.Interval(0.5, 1.5))]
+    sysm = npde.PDESystem(eqs, bcs, dom, [t, x], [U, Wv])
+    chains = chains_for(npde, [2, 2], 15, "sigmoid")
+    th = thetas(chains, 150)
+    th[-1] += 3.0                                           # keep u / w away from a zero denominator
+    strat = npde.QuasiRandomTraining(40, bcs_points=16, sampling_alg=npde.SobolSample(seed=7), resampling=False, minibatch=1)
+    check(npde, sysm, chains, strat, th)
