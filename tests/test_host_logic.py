@@ -122,3 +122,34 @@ def test_chain_and_init_params(npde):
     assert th.dtype == np.float64 and th.size == chain.nparams          # Float64 default (src/discretize.jl:432-449)
     with pytest.raises(ValueError):
         npde.Chain(npde.Dense(2, 8, "tanh"), npde.Dense(9, 1))
+
+
+def test_engine_error_paths(npde, use_emu):
+    """C-ABI error behaviour: every misuse returns a status + message (rethrown as EngineError), never a crash or a silent default."""
+    x, y = npde.parameters("x y")
+    (u,) = npde.variables("u")
+    vi = npde.get_vars([x, y], [u(x, y)])
+    term = npde.lower_equation(npde.Eq((npde.Differential(x) ** 2)(u(x, y)), 0), vi, (), "pde")
+    ir = npde.ProblemIR(ntheta=16 * 2 + 16 + 16 * 16 + 16 + 16 + 1, nets=[npde.NetIR((2, 16, 16, 1), "tanh", 0)], terms=[term])
+    eng = npde.Engine(ir.to_descriptor())
+    th = np.zeros(eng.P)
+    with pytest.raises(npde.EngineError, match="no collocation points"):
+        eng.loss_grad(th)
+    with pytest.raises(npde.EngineError, match="out of range"):
+        eng.set_points(3, np.zeros((2, 4)))
+    with pytest.raises(npde.EngineError, match="empty point set"):
+        eng.set_points(0, np.zeros((2, 0)))
+    eng.set_points(0, np.random.default_rng(0).uniform(size=(2, 7)))
+    with pytest.raises(npde.EngineError, match="theta length"):
+        eng.loss_grad(np.zeros(eng.P + 1))
+    losses, grad = eng.loss_grad(th)
+    assert losses.shape == (1,) and grad.shape == (eng.P,) and np.all(np.isfinite(grad))
+    with pytest.raises(npde.EngineError, match="holds 7 points"):
+        eng.get_points(0, 2, 8)
+    # descriptor errors name the problem
+    for bad, msg in (("pinnir 1\nntheta 5\nparams 0 0 5\ndefaults \nnets 1\nnet 0 relu 0 3 2 16 1\nterms 0\n", "unsupported activation"),
+                     (ir.to_descriptor().replace("op ADDC", "op FOO"), "unknown op"),
+                     (ir.to_descriptor().replace("slot 0 2 0 0", "slot 0 2 0 5"), "axis out of range"),
+                     (ir.to_descriptor().replace("slot 0 2 0 0", "slot 0 5 0 0 0 0 0"), "order > 4")):
+        with pytest.raises(npde.EngineError, match=msg):
+            npde.Engine(bad)
