@@ -87,7 +87,11 @@ struct Spec2 {
     static constexpr int OCC = WG_PER_CU > 2 ? WG_PER_CU : 2;            // waves per SIMD the kernel is compiled for
     // dW accumulators: resident in registers across tiles when they fit (4x64: 48 registers); for wide/deep nets they
     // are accumulated per tile into this workgroup's slab instead (read-modify-write, L2; same wave owns the same tiles)
+#ifdef PINN_F2_WBAR_SLAB
+    static constexpr bool WBAR_REG = false;      // experiment: dW always accumulated in the slab (frees 48 registers at H = 64)
+#else
     static constexpr bool WBAR_REG = (NHH_ * MTW * MT * 4 <= 96);
+#endif
 };
 
 template <class S, int MODE, bool SINACT>
@@ -538,7 +542,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
             // OVL (H = 64): the staging of the dW operands (VALU + LDS stores) is issued between the MFMAs of the dA GEMM, and
             // the activation adjoint between those of the dW GEMM, instead of in phases of their own:
             //   publish dZ | barrier | dA(q) + stage(q) ... | barrier | dW(q) ... + act_adjoint | next layer
-            constexpr bool OVL = WPRE && !S::CHUNKED && S::WBAR_REG;
+            constexpr bool OVL = WPRE && !S::CHUNKED;
             if (OVL) {
                 STAMP(7)
                 wg_barrier();                                               // dZ of every wave is in X0; the previous layer's dW reads are done
@@ -559,6 +563,14 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                 PINN_UNROLL for (int q = 0; q < NG; ++q)
                     PINN_UNROLL for (int t = 0; t < MTW; ++t) G[q][t] = Gn[q][t];
                 act_adjoint(G, Sr);
+                if (!S::WBAR_REG)
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                        PINN_UNROLL for (int ti = 0; ti < MT; ++ti) {
+                            const vint off = vint((((hl * MT + w * MTW + t) * MT + ti) * 64) * 4) + (lane << 2);
+                            vfloat4 cur = gload4(slab + S::O_WBAR, off);
+                            PINN_UNROLL for (int e = 0; e < 4; ++e) cur[e] += wacc[t][ti][e];
+                            gstore4(slab + S::O_WBAR, off, cur);
+                        }
                 STAMP(9)
                 continue;
             }

@@ -41,7 +41,11 @@ DEV Instr fetch_uniform(const Instr* prog, int q) {
     return ins;
 }
 
-constexpr int MAX_ROWS_FUSED = 32;   // LDS tape rows available to the fused kernel (values + adjoints)
+#ifdef PINN_TAPE_ROWS
+constexpr int MAX_ROWS_FUSED = PINN_TAPE_ROWS;
+#else
+constexpr int MAX_ROWS_FUSED = 32;
+#endif   // LDS tape rows available to the fused kernel (values + adjoints)
 constexpr int MAX_ROWS = 256;        // hard limit of the IR
 
 #ifdef PINN_EMU

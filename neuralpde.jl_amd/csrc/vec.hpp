@@ -205,10 +205,13 @@ DEV void gstore4(float* p, vint i, vfloat4 x) { *reinterpret_cast<vfloat4*>(p + 
 // (cdna_hip_programming.md T8/T20).  `p` must be wave-uniform.
 // 32-row tape in vector registers; a wave-uniform runtime row index compiles to VGPR-index mode
 // (s_set_gpr_idx_on), not to scratch or LDS.
-typedef float vtape __attribute__((ext_vector_type(32)));
+#ifndef PINN_TAPE_ROWS
+#define PINN_TAPE_ROWS 32
+#endif
+typedef float vtape __attribute__((ext_vector_type(PINN_TAPE_ROWS)));
 DEV vfloat tape_get(const vtape& t, int i) { return t[i]; }
 DEV void tape_set(vtape& t, int i, vfloat x) { t[i] = x; }
-DEV void tape_zero(vtape& t) { PINN_UNROLL for (int i = 0; i < 32; ++i) t[i] = 0.f; }
+DEV void tape_zero(vtape& t) { PINN_UNROLL for (int i = 0; i < PINN_TAPE_ROWS; ++i) t[i] = 0.f; }
 // 16-byte record at a wave-uniform, read-only address, fetched through the scalar cache (s_load_dwordx4) into SGPRs.
 // A plain load is not scalarised because the kernel also stores to global memory: it becomes global_load + vmcnt(0)
 // (which also drains every outstanding record store) and its fields need waterfall loops to be used as register indices.
