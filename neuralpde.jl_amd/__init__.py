@@ -17,7 +17,8 @@ from .pinn import (Adam, OptimizationSolution, solve, Chain, Dense, LogOptions, 
                    PhysicsInformedNN, PINNLossFunctions, PINNRepresentation, discretize, initialparameters, remake,
                    symbolic_discretize)
 from .strategies import (AbstractTrainingStrategy, GridTraining, LatinHypercubeSample, QuasiRandomTraining,
-                         SobolSample, StochasticTraining, generate_random_points, generate_training_sets, get_bounds)
+                         SobolSample, StochasticTraining, generate_random_points, generate_training_sets, get_bounds,
+                         get_loss_function, merge_strategy_with_loss_function)
 from .symbolic import (Differential, Eq, Equation, In, Interval, LoweringError, PDESystem, get_argument, get_variables,
                        get_vars, lower_equation, parameters, variables)
 

@@ -457,6 +457,7 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
         for k, (lb, ub) in enumerate(list(pb) + list(bb)):
             rep._device_samplers[k] = (lb, ub, strategy.points if k < n_pde else strategy.bcs_points, int(rng.integers(1 << 31)), kind)
     rep._state = state
+    rep._pde_system, rep._vi = pde_system, vi
     return rep
 
 

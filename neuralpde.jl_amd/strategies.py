@@ -186,3 +186,40 @@ class QuasiRandomTraining(AbstractTrainingStrategy):
             return batches[int(self.rng.integers(nb))]
 
         return batches[0][0], batches[0][1], pick
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's strategy plug-in points, by name
+# ------------------------------------------------------------------------------------------------
+def get_loss_function(init_params_or_pinnrep, loss_function, train_set, eltype=np.float64, strategy=None):
+    """`get_loss_function(init_params, loss_function, train_set, eltypeθ, strategy)` (src/training_strategies.jl:213-221):
+    the per-term closure `θ -> mean(abs2, loss_function(train_set, θ))` of a datafree residual function `(cord, θ) -> 1 x N`
+    (contract: test/Interface/interface__abstract_contracts.jl:53-64)."""
+    train_set = np.asarray(train_set, dtype=eltype)
+
+    def loss(theta):
+        r = np.asarray(loss_function(train_set, theta), dtype=np.float64)
+        return float(np.mean(np.abs(r) ** 2))
+    return loss
+
+
+def merge_strategy_with_loss_function(pinnrep, strategy: AbstractTrainingStrategy, datafree_pde_loss_function, datafree_bc_loss_function):
+    """`merge_strategy_with_loss_function(pinnrep, strategy, datafree_pde, datafree_bc)` (src/training_strategies.jl:131-160 Grid,
+    247-269 Stochastic, 336-363 QuasiRandom; called at src/discretize.jl:541-545): zips every datafree residual function with the
+    point set the strategy provides for it and returns `(pde_loss_functions, bc_loss_functions)`, lists of `θ -> scalar`.
+    A custom strategy only has to subclass AbstractTrainingStrategy and implement `point_sets`.  (`symbolic_discretize` itself
+    evaluates all terms and the gradient in one fused engine call; these closures are the per-term, value-only view of it.)"""
+    pde_sets, bc_sets, resample = strategy.point_sets(pinnrep._pde_system, pinnrep._vi, np.float64)
+    if len(pde_sets) != len(datafree_pde_loss_function) or len(bc_sets) != len(datafree_bc_loss_function):
+        raise ValueError("the strategy must provide one point set per equation and per boundary condition")
+
+    def wrap(fns, which):
+        out = []
+        for k, fn in enumerate(fns):
+            def loss(theta, fn=fn, k=k):
+                sets = resample()[which] if resample is not None else (pde_sets, bc_sets)[which]    # fresh sets every call (:277-281, :375-381)
+                r = np.asarray(fn(sets[k], theta), dtype=np.float64)
+                return float(np.mean(np.abs(r) ** 2))
+            out.append(loss)
+        return out
+    return wrap(datafree_pde_loss_function, 0), wrap(datafree_bc_loss_function, 1)

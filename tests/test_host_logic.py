@@ -153,3 +153,32 @@ def test_engine_error_paths(npde, use_emu):
                      (ir.to_descriptor().replace("slot 0 2 0 0", "slot 0 5 0 0 0 0 0"), "order > 4")):
         with pytest.raises(npde.EngineError, match=msg):
             npde.Engine(bad)
+
+
+def test_strategy_plugin_contract(npde, use_emu):
+    """the reference's strategy plug-in points by name (test/Interface/interface__abstract_contracts.jl:15-22, 53-64): a custom
+    AbstractTrainingStrategy subtype works through discretize, and merge_strategy_with_loss_function / get_loss_function give the
+    per-term closures  theta -> mean(abs2, residual(set, theta))."""
+    sysm, (x, y, u) = _poisson(npde)
+
+    class TwoRowsOfPoints(npde.AbstractTrainingStrategy):
+        def point_sets(self, pde_system, vi, dtype):
+            g = np.linspace(0.1, 0.9, 9)
+            pde = [np.stack([np.tile(g, 2), np.repeat([0.3, 0.7], 9)]).astype(dtype)]
+            bc = [np.stack([np.zeros(5), np.linspace(0, 1, 5)]), np.stack([np.ones(5), np.linspace(0, 1, 5)]),
+                  np.stack([np.linspace(0, 1, 5), np.zeros(5)]), np.stack([np.linspace(0, 1, 5), np.ones(5)])]
+            return pde, [b.astype(dtype) for b in bc], None
+
+    chain = npde.Chain(npde.Dense(2, 16, "tanh"), npde.Dense(16, 16, "tanh"), npde.Dense(16, 1))
+    th = npde.initialparameters(np.random.default_rng(5), chain)
+    strat = TwoRowsOfPoints()
+    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th))
+    rep = prob.pinnrep
+    assert rep.pde_train_sets[0].shape == (2, 18)
+    lf = rep.loss_functions
+    pde_l, bc_l = npde.merge_strategy_with_loss_function(rep, strat, lf.datafree_pde_loss_functions, lf.datafree_bc_loss_functions)
+    assert len(pde_l) == 1 and len(bc_l) == 4
+    np.testing.assert_allclose([f(th) for f in pde_l + bc_l], [f(th) for f in lf.pde_loss_functions + lf.bc_loss_functions], rtol=2e-5)
+    one = npde.get_loss_function(th, lf.datafree_bc_loss_functions[2], rep.bcs_train_sets[2], np.float64, strat)
+    assert abs(one(th) - lf.bc_loss_functions[2](th)) < 2e-5 * max(1.0, abs(one(th)))
+    assert abs(prob.f(th) - sum(f(th) for f in pde_l + bc_l)) < 1e-4 * abs(prob.f(th))       # low_level.md:52-67: sum of the term closures
