@@ -149,6 +149,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
     if (MODE == MODE_FUSED)
         for (int j = 0; j < ga.nterms; ++j) ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[j].term_id] = 0.0;
 
+    wave_prio(1);
     const int niter = (ga.ntiles + nblocks - 1) / nblocks;
     STAMP_DECL
     for (int it = 0; it < niter; ++it) {
@@ -256,6 +257,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         PINN_UNROLL for (int ch = 1; ch < C; ++ch) A[pg * C + ch][t] = vzero4();
                     }
                 }
+                wave_prio(0);
                 PINN_UNROLL for (int mi = 0; mi < MT; ++mi) {
                     if (!WPRE)
                         PINN_UNROLL for (int t = 0; t < MTW; ++t)
@@ -266,6 +268,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                             PINN_UNROLL for (int rr = 0; rr < 4; ++rr) A[q][t] = mfma16(wf[WPRE ? mi : 0][t][rr], b4[rr], A[q][t]);
                     }
                 }
+                wave_prio(1);
                 STAMP(2)
                 act_forward(A, hl + 1);
                 STAMP(3)
@@ -548,6 +551,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                 wg_barrier();                                               // dZ of every wave is in X0; the previous layer's dW reads are done
                 STAMP(8)
                 if (SPRE && hl - 1 >= 1) load_record(hl - 1);
+                wave_prio(0);
                 PINN_UNROLL for (int q = 0; q < NG; ++q) {
                     PINN_UNROLL for (int mo = 0; mo < MT; ++mo) {
                         vfloat4 b4 = lds_load4(X0, vint(((q * MT + mo) * 64) * 4) + (lane << 2));
@@ -556,10 +560,13 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                     }
                     stage_q(q, ZT + q * (MTW * 256), X1 + q * 16 * HP);
                 }
+                wave_prio(1);
                 STAMP(10)
                 wg_barrier();                                               // staged operands complete; X0 free again
                 STAMP(11)
+                wave_prio(0);
                 PINN_UNROLL for (int q = 0; q < NG; ++q) dw_q(ZT + q * (MTW * 256), X1 + q * 16 * HP);
+                wave_prio(1);
                 PINN_UNROLL for (int q = 0; q < NG; ++q)
                     PINN_UNROLL for (int t = 0; t < MTW; ++t) G[q][t] = Gn[q][t];
                 act_adjoint(G, Sr);

@@ -85,6 +85,7 @@ inline void tape_zero(vtape& t) { for (int i = 0; i < 32; ++i) t.r[i] = vfloat(0
 // 16-byte record at a wave-uniform address (device: scalar-cache load)
 struct urec16 { int x, y, z, w; };
 inline void sched_fence() {}
+inline void wave_prio(int) {}
 inline void vsincos(const vfloat& x, vfloat& s, vfloat& c) { for (int l = 0; l < W; ++l) { s.v[l] = std::sin(x.v[l]); c.v[l] = std::cos(x.v[l]); } }
 inline urec16 uload16(const void* p) { urec16 r; std::memcpy(&r, p, 16); return r; }
 struct urec32 { int v[8]; };
@@ -217,6 +218,9 @@ DEV void tape_zero(vtape& t) { PINN_UNROLL for (int i = 0; i < PINN_TAPE_ROWS; +
 // (which also drains every outstanding record store) and its fields need waterfall loops to be used as register indices.
 // the instruction scheduler may not move anything across this point (keeps a block of prefetch loads where it was written)
 DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// issue priority of this wave against the other wave resident on its SIMD (s_setprio): raised around MFMA clusters
+template <int P> DEV void wave_prio_t() { __builtin_amdgcn_s_setprio(P); }
+#define wave_prio(P) wave_prio_t<P>()
 struct urec16 { int x, y, z, w; };
 DEV urec16 uload16(const void* p) {
     typedef int i4 __attribute__((ext_vector_type(4)));
