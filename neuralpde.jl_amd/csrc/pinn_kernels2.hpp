@@ -351,6 +351,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
         } else {
             float* UB = UP + 4 * NG * 16;
             if (w < PG) {
+                wave_prio(3);                       // the other waves of the workgroup wait for this one
                 vfloat xin[D], Uin[C];
                 vbool vin = valid[0];
                 PINN_UNROLL for (int i = 0; i < D; ++i) xin[i] = x[0][i];
@@ -412,6 +413,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                     }
                 }
             }
+            wave_prio(1);
             if (MODE != MODE_RESID) {
                 wg_barrier();                                                   // seeds of every point group are in UB
                 PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
