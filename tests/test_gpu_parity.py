@@ -310,3 +310,20 @@ def test_reference_examples_gpu(npde, hip_lib, monkeypatch):
     for name in ("test_wave_equation", "test_mixed_derivative_pde", "test_system_of_three_pdes", "test_linear_parabolic_system",
                  "test_nonlinear_elliptic_first_order_system", "test_lorenz_parameter_estimation_terms", "test_nonlinear_hyperbolic_system"):
         getattr(ex, name)(npde, None)
+
+
+def test_bench_two_ranks_share_the_gpu(hip_lib):
+    """bench.py's N > 1 path (point sharding with n_norm = global N, all-reduce of [gradient | sums]) with two ranks folded onto
+    the one visible GPU and the gloo backend: per-term losses must equal the single-rank run's (RCCL itself needs a multi-GPU node)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    one = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--points", "8192"],
+                         cwd=root, capture_output=True, text=True, timeout=300)
+    env = dict(os.environ, PINN_BENCH_BACKEND="gloo")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29517", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--points", "8192"],
+                         cwd=root, capture_output=True, text=True, timeout=300, env=env)
+    l1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    l2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert l2["n_gpus"] == 2 and l2["config"]["parallelism"] == "point-shard x2"
+    np.testing.assert_allclose(l2["loss_terms"], l1["loss_terms"], rtol=1e-6)
