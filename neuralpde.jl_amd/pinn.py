@@ -258,7 +258,10 @@ def solve(prob: OptimizationProblem, alg: Adam, maxiters: int = 1000, callback: 
 
 def remake(prob: OptimizationProblem, u0=None) -> OptimizationProblem:
     """`remake(prob, u0 = res.u)` — the reference's resume idiom (test/NNPDE1/nnpde__pde_ii_2d_poisson.jl:84-85)."""
-    return OptimizationProblem(prob.f, prob.u0 if u0 is None else np.asarray(u0), prob.p)
+    new = OptimizationProblem(prob.f, prob.u0 if u0 is None else np.asarray(u0), prob.p)
+    if hasattr(prob, "pinnrep"):
+        new.pinnrep = prob.pinnrep          # the discretisation (engine, point sets, weights) is shared
+    return new
 
 
 # ------------------------------------------------------------------------------------------------

@@ -223,6 +223,9 @@ def test_resident_adam_matches_host_adam_and_sampler(npde, use_emu):
     np.testing.assert_allclose(res.losses, hist, rtol=2e-5)
     assert np.max(np.abs(res.u - th)) < 5e-5
     assert res.losses[-1] < res.losses[0]
+    # resume idiom of the reference: prob = remake(prob, u0 = res.u); solve again (nnpde__pde_ii_2d_poisson.jl:84-85)
+    res_b = npde.solve(npde.remake(prob, u0=res.u), npde.Adam(0.01), maxiters=5)
+    assert len(res_b.losses) == 5 and res_b.losses[-1] < res.losses[0]
     # callback protocol: stop after the first chunk
     calls = []
     res2 = npde.solve(prob, npde.Adam(0.01), maxiters=200, callback=lambda st, l: calls.append(st["iter"]) or True)
