@@ -122,14 +122,28 @@ class Phi:
     """Trial function handle: `phi(x, theta)` evaluates the network (src/pinn_types.jl:88-90).  x: (d,) or (d x N)."""
 
     def __init__(self, engine: "_lib.Engine", net: int, theta_slice: slice, d: int):
-        self.engine, self.net, self.d = engine, net, d
+        self.engine, self.net, self.d, self.theta_slice = engine, net, d, theta_slice
 
     def __call__(self, x, theta):
+        """theta: the whole flat vector, or only this network's own parameters — the reference's `phi[i](x, res.u.depvar.u_i)`
+        (docs/src/tutorials/systems.md:112-121)."""
         x = np.asarray(x, dtype=np.float64)
         single = x.ndim == 1
         pts = x.reshape(self.d, -1) if not single else x.reshape(self.d, 1)
-        out = self.engine.phi(self.net, theta, pts).astype(np.float64).reshape(1, -1)
+        th = np.asarray(theta).reshape(-1)
+        n_own = self.theta_slice.stop - self.theta_slice.start
+        if th.size == n_own and th.size != self.engine.P:
+            full = np.zeros(self.engine.P, dtype=th.dtype)
+            full[self.theta_slice] = th
+            th = full
+        out = self.engine.phi(self.net, th, pts).astype(np.float64).reshape(1, -1)
         return out[:, 0] if single else out
+
+
+def depvar_params(rep, theta, name):
+    """`theta.depvar.<name>` of the reference's ComponentArray (src/discretize.jl:451-465): the parameters of one dependent variable's
+    network out of the flat vector."""
+    return np.asarray(theta)[rep.net_slices[rep.depvars.index(str(name))]]
 
 
 @dataclass
@@ -173,6 +187,7 @@ class PINNRepresentation:
     symbolic_bc_loss_functions: List[TermIR]
     loss_functions: Optional[PINNLossFunctions] = None
     ir: Optional[ProblemIR] = None
+    net_slices: Optional[list] = None               # per dependent variable: its slice of the flat theta (theta.depvar.<name>)
     engine: Optional[object] = None
     pde_train_sets: Optional[list] = None
     bcs_train_sets: Optional[list] = None
@@ -437,7 +452,8 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
         init_params=flat[:nnet], flat_init_params=flat, phi=phi, strategy=strategy,
         pde_indvars=[list(t.indvars) for t in sym_pde], bc_indvars=[list(t.indvars) for t in sym_bc],
         symbolic_pde_loss_functions=sym_pde, symbolic_bc_loss_functions=sym_bc, ir=ir, engine=engine,
-        pde_train_sets=pde_sets, bcs_train_sets=bc_sets)
+        pde_train_sets=pde_sets, bcs_train_sets=bc_sets,
+        net_slices=[slice(net_offs[i], net_offs[i] + chains[i].nparams) for i in range(len(chains))])
     rep.loss_functions = PINNLossFunctions(
         bc_loss_functions=[term_loss(n_pde + j) for j in range(n_bc)],
         pde_loss_functions=[term_loss(i) for i in range(n_pde)],

@@ -152,3 +152,37 @@ def test_nonlinear_hyperbolic_system(npde, use_emu):
     th[-1] += 3.0                                           # keep u / w away from a zero denominator
     strat = npde.QuasiRandomTraining(40, bcs_points=16, sampling_alg=npde.SobolSample(seed=7), resampling=False, minibatch=1)
     check(npde, sysm, chains, strat, th)
+
+
+def test_system_tutorial_idioms(npde, use_emu):
+    """the post-processing idioms of docs/src/tutorials/systems.md:82-121: per-term closures in a callback, `phi[i]` evaluated with the
+    network's own parameters `res.u.depvar.u_i`, the resume idiom, `prob.f(theta, nothing)`."""
+    t, x = npde.parameters("t x")
+    u1, u2 = npde.variables("u1 u2")
+    Dt, Dxx = npde.Differential(t), npde.Differential(x) ** 2
+    eqs = [npde.Eq(Dt(u1(t, x)), Dxx(u1(t, x)) + u2(t, x)), npde.Eq(Dt(u2(t, x)), Dxx(u2(t, x)) - u1(t, x))]
+    bcs = [npde.Eq(u1(0, x), sp.sin(sp.pi * x)), npde.Eq(u2(0, x), sp.cos(sp.pi * x)), npde.Eq(u1(t, 0), 0.0), npde.Eq(u2(t, 1), -sp.exp(-t))]
+    dom = [npde.In(t, npde.Interval(0.0, 1.0)), npde.In(x, npde.Interval(0.0, 1.0))]
+    sysm = npde.PDESystem(eqs, bcs, dom, [t, x], [u1(t, x), u2(t, x)])
+    chains = chains_for(npde, [2, 2], 15, "sigmoid")
+    disc = npde.PhysicsInformedNN(chains, npde.GridTraining(0.25), init_params=thetas(chains, 160))
+    sym_prob = npde.symbolic_discretize(sysm, disc)
+    prob = npde.discretize(sysm, disc)
+    pde_inner, bcs_inner = sym_prob.loss_functions.pde_loss_functions, sym_prob.loss_functions.bc_loss_functions
+    log = []
+    res = npde.solve(prob, npde.Adam(0.01), maxiters=100,
+                     callback=lambda st, l: log.append(([f(st["u"]) for f in pde_inner], [f(st["u"]) for f in bcs_inner], l)) or False)
+    assert len(log) == 2 and len(log[0][0]) == 2 and len(log[0][1]) == 4 and res.losses[-1] < res.losses[0]
+    assert abs(prob.f(res.u, None) - (sum(log[-1][0]) + sum(log[-1][1]))) < 1e-4 * abs(prob.f(res.u, None))
+    phi = disc.phi
+    rep = prob.pinnrep
+    minimizers = [npde.depvar_params(rep, res.u, name) for name in ("u1", "u2")]
+    assert [m.size for m in minimizers] == [c.nparams for c in chains]
+    for i in range(2):
+        a = phi[i](np.array([0.3, 0.6]), minimizers[i])                 # own parameters
+        b = phi[i](np.array([0.3, 0.6]), res.u)                         # whole vector
+        assert a.shape == (1,) and abs(a[0] - b[0]) < 1e-7
+        oracle_u = po.phi_values(po.Chain(tuple(chains[i].sizes), chains[i].act), minimizers[i], np.array([[0.3], [0.6]]))[0, 0]
+        assert abs(a[0] - oracle_u) < 2e-6
+    res2 = npde.solve(npde.remake(prob, u0=res.u), npde.Adam(0.001), maxiters=20)
+    assert res2.losses[-1] <= res.losses[-1] * 1.05
