@@ -182,3 +182,22 @@ def test_strategy_plugin_contract(npde, use_emu):
     one = npde.get_loss_function(th, lf.datafree_bc_loss_functions[2], rep.bcs_train_sets[2], np.float64, strat)
     assert abs(one(th) - lf.bc_loss_functions[2](th)) < 2e-5 * max(1.0, abs(one(th)))
     assert abs(prob.f(th) - sum(f(th) for f in pde_l + bc_l)) < 1e-4 * abs(prob.f(th))       # low_level.md:52-67: sum of the term closures
+
+
+def test_dropped_call_arguments_quirk(npde, use_emu):
+    """The generated loss drops the actual arguments of dependent-variable calls (src/symbolic_utilities.jl:145-160): the `periodic` bc
+    `u(t,-1) ~ u(t,1)` of docs/src/tutorials/low_level.md:33 evaluates both sides on the SAME point set (the first call's arguments,
+    get_argument) and is identically zero.  Reproduced, not fixed."""
+    t, x = npde.parameters("t x")
+    (u,) = npde.variables("u")
+    Dt, Dx, Dxx = npde.Differential(t), npde.Differential(x), npde.Differential(x) ** 2
+    eq = npde.Eq(Dt(u(t, x)) + u(t, x) * Dx(u(t, x)) - (0.01 / sp.pi) * Dxx(u(t, x)), 0)
+    bcs = [npde.Eq(u(0, x), -sp.sin(sp.pi * x)), npde.Eq(u(t, -1), 0.0), npde.Eq(u(t, 1), 0.0), npde.Eq(u(t, -1), u(t, 1))]
+    dom = [npde.In(t, npde.Interval(0.0, 1.0)), npde.In(x, npde.Interval(-1.0, 1.0))]
+    sysm = npde.PDESystem([eq], bcs, dom, [t, x], [u(t, x)])
+    chain = npde.Chain(npde.Dense(2, 16, "sigmoid"), npde.Dense(16, 16, "sigmoid"), npde.Dense(16, 1))
+    th = npde.initialparameters(np.random.default_rng(2), chain)
+    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=th))
+    assert np.all(rep.bcs_train_sets[3][1] == -1.0)                      # the first call's arguments define the set
+    assert rep.loss_functions.bc_loss_functions[3](th) == 0.0
+    assert rep.loss_functions.bc_loss_functions[1](th) > 0.0
