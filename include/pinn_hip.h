@@ -108,6 +108,12 @@ int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float*
  *   pinn_adam_get    : download theta.
  */
 int pinn_set_sampler(pinn_handle h, int term, int kind, const float* lb, const float* ub, int64_t n, uint64_t seed);
+/*
+ * Per-point data of a term whose residual contains DATA channels (descriptor op `DATA j`): ndata x N floats, channel-major, for the
+ * point set installed last (observations d_i of a data-misfit term  u(x_i) - d_i, the usual content of the reference's
+ * `additional_loss`, e.g. docs/src/tutorials/param_estim.md:79-95, evaluated inside the fused loss + gradient instead of on the host).
+ */
+int pinn_set_point_data(pinn_handle h, int term, const float* data, int ndata, int64_t n);
 /* Copy the term's current collocation set (d x N, point-major, as installed or as last drawn by the device sampler) to the host. */
 int pinn_get_points(pinn_handle h, int term, float* pts, int64_t n);
 int pinn_adam_init(pinn_handle h, const float* theta, int64_t p);

@@ -13,7 +13,7 @@ from .ir import Instr, NetIR, ProblemIR, Slot, TermIR
 from .bpinn import physics_loglikelihood
 from .adaptive import (AbstractAdaptiveLoss, GradientScaleAdaptiveLoss, MiniMaxAdaptiveLoss, ReLoBRaLoAdaptiveLoss,
                        SoftAdaptAdaptiveLoss)
-from .pinn import (depvar_params, Adam, OptimizationSolution, solve, Chain, Dense, LogOptions, NonAdaptiveLoss, OptimizationFunction, OptimizationProblem, Phi,
+from .pinn import (DataLoss, depvar_params, Adam, OptimizationSolution, solve, Chain, Dense, LogOptions, NonAdaptiveLoss, OptimizationFunction, OptimizationProblem, Phi,
                    PhysicsInformedNN, PINNLossFunctions, PINNRepresentation, discretize, initialparameters, remake,
                    symbolic_discretize)
 from .strategies import (AbstractTrainingStrategy, GridTraining, LatinHypercubeSample, QuasiRandomTraining,

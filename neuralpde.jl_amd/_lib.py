@@ -20,7 +20,7 @@ SYMBOLS = [
     "pinn_backend", "pinn_abi_version", "pinn_last_error", "pinn_create", "pinn_destroy", "pinn_num_terms",
     "pinn_num_theta", "pinn_set_points", "pinn_set_points_device", "pinn_loss_grad", "pinn_loss_grad_f64",
     "pinn_term_grads", "pinn_loss_grad_device", "pinn_residual", "pinn_phi", "pinn_last_timing", "pinn_set_timing", "pinn_describe", "pinn_num_groups", "pinn_group_timing",
-    "pinn_set_sampler", "pinn_get_points", "pinn_adam_init", "pinn_adam_steps", "pinn_adam_get",
+    "pinn_set_sampler", "pinn_set_point_data", "pinn_get_points", "pinn_adam_init", "pinn_adam_steps", "pinn_adam_get",
 ]
 
 
@@ -62,6 +62,7 @@ class Library:
         L.pinn_num_groups.argtypes = [vp]
         L.pinn_set_sampler.argtypes = [vp, C.c_int, C.c_int, fp, fp, C.c_int64, C.c_uint64]
         L.pinn_get_points.argtypes = [vp, C.c_int, fp, C.c_int64]
+        L.pinn_set_point_data.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int64]
         L.pinn_adam_init.argtypes = [vp, fp, C.c_int64]
         L.pinn_adam_steps.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, fp, dp]
         L.pinn_adam_get.argtypes = [vp, fp, C.c_int64]
@@ -193,6 +194,12 @@ class Engine:
         k, t = C.c_float(), C.c_float()
         self.L.check(self.L.lib.pinn_last_timing(self.h, C.byref(k), C.byref(t)), "pinn_last_timing")
         return k.value, t.value
+
+    def set_point_data(self, term: int, data):
+        """data: (ndata x N) per-point channels of the term's current point set (descriptor op DATA j)"""
+        data = _f32(np.atleast_2d(np.asarray(data)))
+        self.L.check(self.L.lib.pinn_set_point_data(self.h, term, data.ctypes.data_as(C.POINTER(C.c_float)), data.shape[0], data.shape[1]),
+                     "pinn_set_point_data")
 
     def get_points(self, term: int, d: int, n: int) -> np.ndarray:
         """the term's current set as a (d x N) array (e.g. what the device sampler drew last)"""

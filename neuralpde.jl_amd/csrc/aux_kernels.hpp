@@ -60,6 +60,7 @@ struct ExprArgs {
     float* pslab;                         // [nblocks][4 waves][4 params]
     int K, term_id;
     float* resid;                         // nullable: write r[N] and skip the adjoint
+    const float* data;                    // [ndata][N] user-supplied per-point channels (OP_DATA), nullable
 };
 // one point; returns r (masked by `valid`), writes ubar, returns dL/dp contributions in pb[]
 AUX_DEV float expr_point(int p, const ExprArgs& a, float (&pb)[4]) {
@@ -72,7 +73,7 @@ AUX_DEV float expr_point(int p, const ExprArgs& a, float (&pb)[4]) {
         const rp::Instr ins = a.prog[q];
         const float va = rp::is_nullary(ins.code) ? 0.f : v[ins.a];
         const float vb = rp::is_binary(ins.code) ? v[ins.b] : 0.f;
-        v[R0 + q] = rp::apply<float>(ins.code, va, vb, ins.imm);
+        v[R0 + q] = (ins.code == rp::OP_DATA) ? a.data[(size_t)(int)ins.imm * a.N + p] : rp::apply<float>(ins.code, va, vb, ins.imm);
     }
     const float r = v[a.out_row];
     for (int j = 0; j < 4; ++j) pb[j] = 0.f;
@@ -107,13 +108,14 @@ struct SrcArgs {
     int nops, nsrc;
     int root[SRC_MAX];                    // compact row of source j
     float* out;                           // [nsrc][N]
+    const float* data;                    // [ndata][N] user-supplied per-point channels (OP_DATA), nullable
 };
 AUX_DEV void src_point(int p, const SrcArgs& a) {
     float v[EXPR_MAX_ROWS];
     for (int i = 0; i < a.d; ++i) v[i] = a.pts[(size_t)p * a.d + i];
     for (int q = 0; q < a.nops; ++q) {
         const rp::Instr ins = a.prog[q];
-        v[a.d + q] = rp::apply<float>(ins.code, v[ins.a], v[ins.b], ins.imm);
+        v[a.d + q] = (ins.code == rp::OP_DATA) ? a.data[(size_t)(int)ins.imm * a.N + p] : rp::apply<float>(ins.code, v[ins.a], v[ins.b], ins.imm);
     }
     for (int j = 0; j < a.nsrc; ++j) a.out[(size_t)j * a.N + p] = v[a.root[j]];
 }

@@ -85,6 +85,10 @@ struct Term {
     rp::Instr* d_src_prog = nullptr;
     float* d_src = nullptr;              // [nsrc][n]
     int64_t src_cap = 0;
+    // user-supplied per-point data channels (OP_DATA; pinn_set_point_data), valid for the current point set only
+    int ndata = 0;
+    float* d_data = nullptr;
+    int64_t data_n = 0, data_cap = 0;
     // data
     float* d_pts = nullptr;
     int64_t n = 0, n_norm = 0;
@@ -195,7 +199,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 const char* OPNAMES[rp::OP_COUNT] = {"CONST", "ADD", "SUB", "MUL", "DIV", "NEG", "ADDC", "MULC", "POWI", "POW", "POWC",
                                      "SIN", "COS", "TAN", "EXP", "LOG", "SQRT", "ABS", "TANH", "SINH", "COSH", "SECH",
-                                     "SINPI", "COSPI", "MAX", "MIN"};
+                                     "SINPI", "COSPI", "MAX", "MIN", "DATA"};
 
 int parse_descriptor(const char* text, pinn_engine& E) {
     std::istringstream in(text);
@@ -277,6 +281,10 @@ int parse_descriptor(const char* text, pinn_engine& E) {
             if (!rp::is_nullary(I.code) && (I.a < 0 || I.a >= lim)) return fail("descriptor: op operand row out of range");
             if (rp::is_binary(I.code) && (I.b < 0 || I.b >= lim)) return fail("descriptor: op operand row out of range");
             rp::finalize(I);
+            if (I.code == rp::OP_DATA) {
+                if (I.imm < 0.f || I.imm > 15.f || I.imm != (float)(int)I.imm) return fail("descriptor: DATA channel index");
+                T.ndata = std::max(T.ndata, (int)I.imm + 1);
+            }
         }
         if (T.out_row < 0 || T.out_row >= T.d + E.np + ns + no) return fail("descriptor: out row out of range");
         // optional: inmap <net> <n> <coordinate index of input 0> ... (one line per network whose inputs are not simply the
@@ -713,6 +721,9 @@ int build_plan(pinn_engine& E) {
                 T.chan_of_slot.push_back(c);
             }
             analyse_static(T, E.np);
+            for (int q : T.tape_ops)
+                if (T.ops[q].code == rp::OP_DATA)
+                    return fail("term " + std::to_string(t) + ": per-point data channels must be inputs of the residual (they are evaluated in the source pass), not its output");
             const int rows = T.d + E.np + sp->C + (int)T.src_root.size() + (int)T.tape_ops.size();
             if (rows > rp::MAX_ROWS_FUSED)
                 return fail("term " + std::to_string(t) + ": residual expression too long for the fused kernel tape (" + std::to_string(rows) + " rows > 32)");
@@ -1094,13 +1105,18 @@ void eval_sources(pinn_engine& E, Term& T) {
     a.nsrc = (int)T.src_root.size();
     for (int j = 0; j < a.nsrc; ++j) a.root[j] = T.src_root[j];
     a.out = T.d_src;
+    a.data = T.d_data;
+    if (T.ndata > 0 && T.data_n != T.n) return;          // data not installed yet for this point set (ensure_points reports it)
     aux::launch_src(a, E.stream);
 }
 
 int ensure_points(pinn_engine& E) {
-    for (size_t t = 0; t < E.terms.size(); ++t)
+    for (size_t t = 0; t < E.terms.size(); ++t) {
         if (!E.terms[t].d_pts || E.terms[t].n <= 0)
             return fail("term " + std::to_string(t) + " has no collocation points (call pinn_set_points first)");
+        if (E.terms[t].ndata > 0 && E.terms[t].data_n != E.terms[t].n)
+            return fail("term " + std::to_string(t) + " uses per-point data channels but none are installed for its current point set (call pinn_set_point_data after pinn_set_points)");
+    }
     return 0;
 }
 
@@ -1135,6 +1151,7 @@ aux::ExprArgs expr_args(pinn_engine& E, Coupled& Cp, float scale, float* resid) 
             if (!used[i][ch] && a.nzero < aux::EXPR_MAX_SLOTS) a.zero[a.nzero++] = Cp.d_ubar[i] + ch * T.n;
     a.prog = Cp.d_prog; a.nops = (int)T.ops.size(); a.out_row = T.out_row; a.scale = scale;
     a.losspart = Cp.d_losspart; a.pslab = Cp.d_pslab; a.K = (int)E.terms.size(); a.term_id = Cp.term; a.resid = resid;
+    a.data = T.d_data;
     return a;
 }
 
@@ -1298,7 +1315,7 @@ int pinn_destroy(pinn_handle h) {
     if (!h) return 0;
     pinn_engine& E = *h;
     plat_sync(E.stream);
-    for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_resid); plat_free(T.d_lb); plat_free(T.d_ub); plat_free(T.d_src_prog); plat_free(T.d_src); }
+    for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_resid); plat_free(T.d_lb); plat_free(T.d_ub); plat_free(T.d_src_prog); plat_free(T.d_src); plat_free(T.d_data); }
     plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist);
     for (auto& G : E.groups) {
         plat_free(G.d_prog); plat_free(G.d_slabs); plat_free(G.d_losspart); plat_free(G.d_scratch); plat_free(G.d_rec);
@@ -1343,6 +1360,7 @@ static int set_points_impl(pinn_handle h, int term, const float* pts, int64_t n,
     plat_sync(E.stream);
     T.n = n;
     T.n_norm = n_norm > 0 ? n_norm : n;
+    T.data_n = 0;                                        // per-point data belong to the previous set
     if (T.coupled < 0) {
         if (!T.src_root.empty()) {
             if (T.src_cap < n) {
@@ -1560,6 +1578,29 @@ int pinn_set_sampler(pinn_handle h, int term, int kind, const float* lb, const f
     aux::launch_sample(kind, T.d_pts, (int)(n * T.d), T.d, T.d_lb, T.d_ub, T.seed, T.draws++, E.stream);
     eval_sources(E, T);
     plat_sync(E.stream);
+    return 0;
+}
+
+int pinn_set_point_data(pinn_handle h, int term, const float* data, int ndata, int64_t n) {
+    if (!h || !data) return fail("pinn_set_point_data: null argument");
+    pinn_engine& E = *h;
+    if (term < 0 || term >= (int)E.terms.size()) return fail("pinn_set_point_data: term index out of range");
+    Term& T = E.terms[term];
+    if (T.ndata == 0) return fail("pinn_set_point_data: the term's residual has no DATA channels");
+    if (ndata != T.ndata) return fail("pinn_set_point_data: the term's residual uses " + std::to_string(T.ndata) + " data channel(s)");
+    if (!T.d_pts || n != T.n) return fail("pinn_set_point_data: the term holds " + std::to_string(T.n) + " points (install the point set first)");
+    if (T.sampler != 0) return fail("pinn_set_point_data: per-point data cannot follow a resampled point set");
+    plat_sync(E.stream);
+    if (T.data_cap < n) {
+        plat_free(T.d_data);
+        T.d_data = (float*)plat_malloc(sizeof(float) * (size_t)T.ndata * n);
+        if (!T.d_data) return fail("device allocation failed (point data)");
+        T.data_cap = n;
+    }
+    if (plat_h2d(T.d_data, data, sizeof(float) * (size_t)T.ndata * n, E.stream)) return fail("H2D copy of point data failed");
+    T.data_n = n;
+    eval_sources(E, T);
+    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
     return 0;
 }
 

@@ -18,7 +18,10 @@ namespace rp {
 enum Op : int {
     OP_CONST = 0, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_ADDC, OP_MULC, OP_POWI, OP_POW, OP_POWC,
     OP_SIN, OP_COS, OP_TAN, OP_EXP, OP_LOG, OP_SQRT, OP_ABS, OP_TANH, OP_SINH, OP_COSH, OP_SECH,
-    OP_SINPI, OP_COSPI, OP_MAX, OP_MIN, OP_COUNT
+    OP_SINPI, OP_COSPI, OP_MAX, OP_MIN,
+    OP_DATA,        // nullary: channel (int)imm of the term's user-supplied per-point data (pinn_set_point_data): observations for data-misfit
+                    // terms.  Coordinate-only by construction, so it only ever runs in the per-point-set source pass (k_src) or in k_expr.
+    OP_COUNT
 };
 
 // 32 bytes, pre-decoded by the engine (finalize): the arithmetic ops CONST/ADD/SUB/MUL/NEG/ADDC/MULC are all instances of
@@ -168,7 +171,7 @@ HD bool is_binary(int code) {
     return code == OP_ADD || code == OP_SUB || code == OP_MUL || code == OP_DIV || code == OP_POW ||
            code == OP_MAX || code == OP_MIN;
 }
-HD bool is_nullary(int code) { return code == OP_CONST; }
+HD bool is_nullary(int code) { return code == OP_CONST || code == OP_DATA; }
 HD bool is_bilinear(int code) { return code <= OP_MULC && code != OP_DIV; }
 // fill the pre-decoded coefficients (host side, once per program)
 inline void finalize(Instr& I) {

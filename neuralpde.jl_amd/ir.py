@@ -17,9 +17,9 @@ from dataclasses import dataclass, field
 from typing import Dict, List, Sequence, Tuple
 
 OPS = ["CONST", "ADD", "SUB", "MUL", "DIV", "NEG", "ADDC", "MULC", "POWI", "POW", "POWC", "SIN", "COS", "TAN", "EXP",
-       "LOG", "SQRT", "ABS", "TANH", "SINH", "COSH", "SECH", "SINPI", "COSPI", "MAX", "MIN"]
+       "LOG", "SQRT", "ABS", "TANH", "SINH", "COSH", "SECH", "SINPI", "COSPI", "MAX", "MIN", "DATA"]
 BINARY = {"ADD", "SUB", "MUL", "DIV", "POW", "MAX", "MIN"}
-NULLARY = {"CONST"}
+NULLARY = {"CONST", "DATA"}
 
 
 @dataclass(frozen=True)

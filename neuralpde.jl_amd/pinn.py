@@ -91,13 +91,26 @@ from .adaptive import (AbstractAdaptiveLoss, GradientScaleAdaptiveLoss, MiniMaxA
                        ReLoBRaLoAdaptiveLoss, SoftAdaptAdaptiveLoss)
 
 
+@dataclass
+class DataLoss:
+    """EXTENSION (not in the reference's API): a data-misfit term  weight * mean(abs2, u(points) - values)  evaluated ON THE DEVICE
+    with the physics terms, gradient included.  It is what the reference's users write as `additional_loss(phi, theta, p)` for
+    inverse problems (docs/src/tutorials/param_estim.md:79-95, test/NNPDE2/additional_loss__lorenz_system.jl:66-77); keeping it
+    in the fused evaluation lets `solve(prob, Adam)` run the whole inverse problem without leaving HBM.
+    depvar: the dependent variable (e.g. `u` or `u(t, x)`); points: (d x N) in the order of that variable's arguments; values: N."""
+    depvar: object
+    points: np.ndarray
+    values: np.ndarray
+    weight: float = 1.0
+
+
 class PhysicsInformedNN:
     """PhysicsInformedNN(chain, strategy; ...) — src/pinn_types.jl:165-211.
     `chain` is one Chain or a list with one single-output Chain per dependent variable (:106-108)."""
 
     def __init__(self, chain, strategy: AbstractTrainingStrategy, *, init_params=None, phi=None, derivative=None,
                  param_estim: bool = False, additional_loss: Optional[Callable] = None, adaptive_loss=None,
-                 logger=None, log_options: LogOptions = LogOptions(), iteration=None, **kwargs):
+                 logger=None, log_options: LogOptions = LogOptions(), iteration=None, data_loss: Sequence[DataLoss] = (), **kwargs):
         if phi is not None or derivative is not None:
             raise ValueError("custom `phi` / `derivative` closures are per-call Julia hooks (src/pinn_types.jl:166-167) "
                              "and cannot be fused into the HIP kernels; they are not supported by this backend")
@@ -107,6 +120,7 @@ class PhysicsInformedNN:
         self.init_params = init_params
         self.param_estim = param_estim
         self.additional_loss = additional_loss
+        self.data_loss = list(data_loss)
         self.adaptive_loss = adaptive_loss
         self.logger = logger
         self.log_options = log_options
@@ -155,6 +169,7 @@ class PINNLossFunctions:
     additional_loss_function: Optional[Callable]
     datafree_pde_loss_functions: List[Callable]
     datafree_bc_loss_functions: List[Callable]
+    data_loss_functions: List[Callable] = field(default_factory=list)      # DataLoss extension
 
 
 @dataclass
@@ -263,7 +278,7 @@ def solve(prob: OptimizationProblem, alg: Adam, maxiters: int = 1000, callback: 
         done += n
         if ada.reweight_every > 0:
             tl, _ = eng.loss_grad(th32, None, want_grad=False)
-            ada.reweight(th32, tl[:n_pde], tl[n_pde:], rep.iteration[0] + done, term_grads=lambda: eng.term_grads(th32)[1])
+            ada.reweight(th32, tl[:n_pde], tl[n_pde:n_pde + len(rep.bcs)], rep.iteration[0] + done, term_grads=lambda: eng.term_grads(th32)[1])
         if callback is not None and callback({"iter": done, "u": th32.astype(np.float64)}, float(hist[-1])):
             break
     losses = np.concatenate(losses)
@@ -336,10 +351,25 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
             raise ValueError("ArgumentError: boundary condition without a dependent variable "
                              "(test/direct_function__trivial_bc_0_0_*.jl:44)")
         sym_bc.append(lower_equation(bc, vi, eq_params, "bc"))
-    terms = sym_pde + sym_bc
-
     NP = len(eq_params)
     NE = NP if (param_estim and NP) else 0
+    # data-misfit terms (DataLoss extension): residual u(x_i) - d_i with d a per-point data channel (descriptor op DATA)
+    from .ir import Instr, Slot
+    sym_data = []
+    for dl in discretization.data_loss:
+        name = str(getattr(dl.depvar, "func", dl.depvar))
+        if name not in vi.dict_depvars:
+            raise ValueError(f"DataLoss: {name} is not a dependent variable of the system")
+        inputs = vi.dict_depvar_input[name]
+        d_net = len(inputs)
+        pts, vals = np.asarray(dl.points, dtype=np.float64), np.asarray(dl.values, dtype=np.float64).reshape(-1)
+        if pts.ndim != 2 or pts.shape[0] != d_net or pts.shape[1] != vals.size or vals.size == 0:
+            raise ValueError(f"DataLoss for {name}: points must be ({d_net} x N) and values N (N > 0)")
+        slot_row = d_net + NP
+        sym_data.append(TermIR(dim=d_net, slots=[Slot(vi.dict_depvars[name] - 1, ())],
+                               ops=[Instr("DATA", 0, 0, 0.0), Instr("SUB", slot_row, slot_row + 1, 0.0)], out_row=slot_row + 2,
+                               indvars=tuple(inputs), kind="data", source=f"{name}(points) - values"))
+    terms = sym_pde + sym_bc + sym_data
     ir = ProblemIR(
         ntheta=int(flat.size),
         nets=[NetIR(tuple(ch.sizes), ch.act, off) for ch, off in zip(chains, net_offs)],
@@ -359,6 +389,11 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
             engine.set_points(k, s)
 
     install(pde_sets, bc_sets)
+    n_data = len(sym_data)
+    data_sets = [np.asarray(dl.points, dtype=np.float64) for dl in discretization.data_loss]
+    for j, dl in enumerate(discretization.data_loss):                    # fixed sets + their observations, installed once
+        engine.set_points(n_pde + n_bc + j, data_sets[j])
+        engine.set_point_data(n_pde + n_bc + j, np.asarray(dl.values, dtype=np.float64).reshape(1, -1))
     state = {"pde_sets": pde_sets, "bc_sets": bc_sets, "cache_theta": None, "cache": None, "resample": resample}
 
     adaloss = discretization.adaptive_loss or NonAdaptiveLoss()
@@ -368,7 +403,8 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
     iteration = discretization.iteration
 
     def weights_now():
-        return np.concatenate([adaloss.pde_loss_weights, adaloss.bc_loss_weights]).astype(np.float64)
+        wd = np.array([float(adaloss.additional_loss_weights[0]) * float(dl.weight) for dl in discretization.data_loss])
+        return np.concatenate([adaloss.pde_loss_weights, adaloss.bc_loss_weights, wd]).astype(np.float64)
 
     def evaluate(theta, want_grad=True, weights=None, redraw=True):
         """one fused engine call; memoised on (theta, weights) so the per-term closures and the full loss share it"""
@@ -409,7 +445,7 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
         losses, _ = evaluate(theta, want_grad=False)
         if discretization.self_increment:
             iteration[0] += 1
-        adaloss.reweight(theta, losses[:n_pde], losses[n_pde:], iteration[0],
+        adaloss.reweight(theta, losses[:n_pde], losses[n_pde:n_pde + n_bc], iteration[0],
                          term_grads=lambda: engine.term_grads(np.asarray(theta))[1])
         return losses
 
@@ -418,7 +454,7 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
             return 0.0, None
         th = np.asarray(theta)
         add = additional_loss(phi, th[:nnet] if param_estim else theta, th[nnet:] if param_estim else None)
-        wa = float(np.ones(1) * adaloss.additional_loss_weights[0])
+        wa = float(np.asarray(adaloss.additional_loss_weights).reshape(-1)[0])
         if isinstance(add, tuple):
             return wa * float(add[0]), wa * np.asarray(add[1])
         return wa * float(add), None
@@ -459,7 +495,8 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
         pde_loss_functions=[term_loss(i) for i in range(n_pde)],
         full_loss_function=full_loss_function, additional_loss_function=additional_loss,
         datafree_pde_loss_functions=[datafree(i) for i in range(n_pde)],
-        datafree_bc_loss_functions=[datafree(n_pde + j) for j in range(n_bc)])
+        datafree_bc_loss_functions=[datafree(n_pde + j) for j in range(n_bc)],
+        data_loss_functions=[term_loss(n_pde + n_bc + j) for j in range(n_data)])
     rep._value_and_grad = value_and_grad
     rep._weights_now = weights_now
     rep._weights = weights_now()

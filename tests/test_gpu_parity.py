@@ -310,6 +310,7 @@ def test_reference_examples_gpu(npde, hip_lib, monkeypatch):
     for name in ("test_wave_equation", "test_mixed_derivative_pde", "test_system_of_three_pdes", "test_linear_parabolic_system",
                  "test_nonlinear_elliptic_first_order_system", "test_lorenz_parameter_estimation_terms", "test_nonlinear_hyperbolic_system"):
         getattr(ex, name)(npde, None)
+    ex.test_data_misfit_terms_on_device(npde, None)          # DataLoss extension: device objective == physics + host additional_loss
 
 
 def test_bench_two_ranks_share_the_gpu(hip_lib):

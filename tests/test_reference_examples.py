@@ -186,3 +186,62 @@ def test_system_tutorial_idioms(npde, use_emu):
         assert abs(a[0] - oracle_u) < 2e-6
     res2 = npde.solve(npde.remake(prob, u0=res.u), npde.Adam(0.001), maxiters=20)
     assert res2.losses[-1] <= res.losses[-1] * 1.05
+
+
+def test_data_misfit_terms_on_device(npde, use_emu):
+    """DataLoss extension: the data-misfit part of an inverse problem (what the reference's tutorials put into `additional_loss`,
+    docs/src/tutorials/param_estim.md:79-95) inside the fused device evaluation.  Checked against (a) the same observations stated
+    as an analytic boundary-like equation, whose residual the oracle knows, and (b) a host-side additional_loss doing the same sum."""
+    t, x = npde.parameters("t x")
+    (u,) = npde.variables("u")
+    (k,) = npde.parameters("k")
+    Dt, Dxx = npde.Differential(t), npde.Differential(x) ** 2
+    eq = npde.Eq(Dt(u(t, x)), k * Dxx(u(t, x)))
+    bcs = [npde.Eq(u(0, x), sp.sin(sp.pi * x)), npde.Eq(u(t, 0), 0.0)]
+    dom = [npde.In(t, npde.Interval(0.0, 1.0)), npde.In(x, npde.Interval(0.0, 1.0))]
+    chain = npde.Chain(npde.Dense(2, 16, "tanh"), npde.Dense(16, 16, "tanh"), npde.Dense(16, 1))
+    th = theta_for(chain, 171)
+    mk = lambda: npde.QuasiRandomTraining(40, bcs_points=16, sampling_alg=npde.SobolSample(seed=8), resampling=False, minibatch=1)
+    strat = mk()
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(size=(2, 37))
+    g = lambda tt, xx: np.exp(-0.3 * np.pi ** 2 * tt) * np.sin(np.pi * xx)
+    vals = g(pts[0], pts[1])
+    sysm = npde.PDESystem([eq], bcs, dom, [t, x], [u(t, x)], ps=[k], defaults={k: 0.7})
+    disc = npde.PhysicsInformedNN(chain, strat, init_params=th, param_estim=True,
+                                  data_loss=[npde.DataLoss(u(t, x), pts, vals, weight=3.0)],
+                                  adaptive_loss=npde.NonAdaptiveLoss(pde_loss_weights=1.0, bc_loss_weights=2.0, additional_loss_weights=0.5))
+    prob = npde.discretize(sysm, disc)
+    rep = prob.pinnrep
+    theta = rep.flat_init_params
+    assert rep.engine.K == 4 and len(rep.loss_functions.data_loss_functions) == 1
+    # (a) value of the data term = mean((phi - d)^2), weights 0.5 * 3
+    u_at = po.phi_values(po.Chain(tuple(chain.sizes), chain.act), theta[:chain.nparams], pts).reshape(-1)
+    dl = rep.loss_functions.data_loss_functions[0](theta)
+    assert abs(dl - np.mean((u_at - vals) ** 2)) < 1e-5 * dl
+    # (b) whole objective and gradient == the same physics + a host-side additional_loss computing the identical data term with autograd
+    import torch
+    oc = po.Chain(tuple(chain.sizes), chain.act)
+
+    def additional(phi, th_net, p):
+        tt = torch.tensor(np.asarray(th_net), dtype=torch.float64, requires_grad=True)
+        out = oc(torch.tensor(pts, dtype=torch.float64), tt).reshape(-1)
+        val = 3.0 * torch.mean((out - torch.tensor(vals, dtype=torch.float64)) ** 2)
+        (gr,) = torch.autograd.grad(val, tt)
+        return float(val.detach()), np.concatenate([gr.numpy(), np.zeros(1)])
+    disc_h = npde.PhysicsInformedNN(chain, mk(), init_params=th, param_estim=True, additional_loss=additional,          # (a sampler object continues its sequence)
+                                    adaptive_loss=npde.NonAdaptiveLoss(pde_loss_weights=1.0, bc_loss_weights=2.0, additional_loss_weights=0.5))
+    prob_h = npde.discretize(sysm, disc_h)
+    v_d, g_d = prob.f.value_and_grad(theta)
+    v_h, g_h = prob_h.f.value_and_grad(theta)
+    assert abs(v_d - v_h) < 1e-5 * abs(v_h)
+    assert np.linalg.norm(g_d - g_h) < 2e-5 * np.linalg.norm(g_h)
+    # the whole inverse problem runs in the resident loop (no host term left)
+    res = npde.solve(prob, npde.Adam(0.01), maxiters=30)
+    assert res.losses[-1] < res.losses[0]
+    with pytest.raises(NotImplementedError):
+        npde.solve(prob_h, npde.Adam(0.01), maxiters=2)
+    # misuse
+    with pytest.raises(ValueError):
+        npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, mk(), init_params=th, param_estim=True,
+                                                             data_loss=[npde.DataLoss(u(t, x), pts[:1], vals)]))
