@@ -262,11 +262,11 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                     if (!WPRE)
                         PINN_UNROLL for (int t = 0; t < MTW; ++t)
                             wf[0][t] = ub_load4(PB, S::OFF_WPK + ((hl * MT + w * MTW + t) * MT + mi) * 256, lane << 2);
-                    PINN_UNROLL for (int q = 0; q < NG; ++q) {
-                        vfloat4 b4 = lds_load4(Xin, vint(((q * MT + mi) * 64) * 4) + (lane << 2));
+                    vfloat4 b4[NG];                                          // all B fragments of this k-block first: their LDS latency overlaps
+                    PINN_UNROLL for (int q = 0; q < NG; ++q) b4[q] = lds_load4(Xin, vint(((q * MT + mi) * 64) * 4) + (lane << 2));
+                    PINN_UNROLL for (int q = 0; q < NG; ++q)
                         PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                            PINN_UNROLL for (int rr = 0; rr < 4; ++rr) A[q][t] = mfma16(wf[WPRE ? mi : 0][t][rr], b4[rr], A[q][t]);
-                    }
+                            PINN_UNROLL for (int rr = 0; rr < 4; ++rr) A[q][t] = mfma16(wf[WPRE ? mi : 0][t][rr], b4[q][rr], A[q][t]);
                 }
                 wave_prio(1);
                 STAMP(2)
