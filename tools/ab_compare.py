@@ -1,10 +1,12 @@
+"""A/B timing of two builds of libpinn_hip.so on the same GPU box: the fused kernels of the bench workload, alternating between
+neuralpde.jl_amd/csrc/abl/libpinn_other.so (copy the reference build there) and the current library.  Usage: python tools/ab_compare.py"""
 import sys, os, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 import pinn_import
 m = pinn_import.load()
 from neuralpde_jl_amd import workloads
-for tag, path in (("presin", "neuralpde.jl_amd/csrc/abl/libpinn_presin.so"), ("head", None), ("presin", "neuralpde.jl_amd/csrc/abl/libpinn_presin.so"), ("head", None)):
+for tag, path in (("other", "neuralpde.jl_amd/csrc/abl/libpinn_other.so"), ("head", None), ("other", "neuralpde.jl_amd/csrc/abl/libpinn_other.so"), ("head", None)):
     m._lib.set_library(m.Library(path) if path else None)
     wl = workloads.cfg2_poisson2d(points=65536)
     rep = m.symbolic_discretize(wl.pde_system, wl.discretization())
