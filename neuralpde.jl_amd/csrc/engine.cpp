@@ -675,6 +675,7 @@ int build_plan(pinn_engine& E) {
     std::map<int, std::pair<unsigned, std::vector<std::pair<int, int>>>> coupled_needs;   // net -> needs
     std::map<int, int> coupled_dim;
     std::map<int, unsigned> coupled_hi;
+    std::vector<char> two_launch(E.terms.size(), 0);
     for (size_t t = 0; t < E.terms.size(); ++t) {
         Term& T = E.terms[t];
         for (auto& s : T.slots)
@@ -695,7 +696,19 @@ int build_plan(pinn_engine& E) {
             if ((int)T.inmap[net].size() != N.sizes[0])
                 return fail("term " + std::to_string(t) + ": inmap length differs from the input count of network " + std::to_string(net));
         }
-        if (term_nets[t].size() > 1)
+        // a single-network residual too long for the fused kernel's 32-row tape takes the two-launch path (k_expr has 96 rows)
+        two_launch[t] = term_nets[t].size() > 1;
+        if (!two_launch[t]) {
+            Term probe = T;
+            analyse_static(probe, E.np);
+            unsigned nf = 0, nh = 0;
+            std::vector<std::pair<int, int>> npairs;
+            if (needs_of(T, term_nets[t][0], nf, npairs, nh)) return 1;
+            int cmin = 1 + (int)npairs.size() + ((nh >> 24) ? 1 : 0);
+            for (int a = 0; a < 8; ++a) cmin += ((nf >> a) & 1) + (a < 6 && ((nh >> (4 * a)) & 0xF) >= 3) + (a < 6 && ((nh >> (4 * a)) & 0xF) >= 4);
+            two_launch[t] = T.d + E.np + cmin + (int)probe.src_root.size() + (int)probe.tape_ops.size() > rp::MAX_ROWS_FUSED;
+        }
+        if (two_launch[t])
             for (int net : term_nets[t]) {
                 auto& nd = coupled_needs[net];
                 if (needs_of(T, net, nd.first, nd.second, coupled_hi[net])) return 1;
@@ -705,7 +718,7 @@ int build_plan(pinn_engine& E) {
     std::map<int, int> coupled_group;        // net -> kind-1 group
     for (size_t t = 0; t < E.terms.size(); ++t) {
         Term& T = E.terms[t];
-        if (term_nets[t].size() == 1) {
+        if (!two_launch[t]) {
             const int net = term_nets[t][0];
             T.net = net;
             unsigned need_first = 0;

@@ -440,3 +440,24 @@ def test_sin_activation(npde, use_emu):
     big = npde.Chain(npde.Dense(2, 64, "sin"), *[npde.Dense(64, 64, "sin") for _ in range(3)], npde.Dense(64, 1))
     check(npde, sysm, [big], strat, theta_for(big, 82))
     check(npde, _ks(npde), [chain], strat, theta_for(chain, 83), mode="exact")
+
+
+def test_long_residual_takes_the_two_launch_path(npde, use_emu):
+    """a single-network residual with more rows than the fused kernel's 32-row tape is not an error: it is evaluated by the
+    forward launch -> k_expr (96 rows) -> reverse launch path that systems of equations use."""
+    x, y = npde.parameters("x y")
+    (u,) = npde.variables("u")
+    Dx, Dy = npde.Differential(x), npde.Differential(y)
+    Dxx, Dyy = Dx ** 2, Dy ** 2
+    U = u(x, y)
+    expr = Dxx(U) * sp.exp(U) + Dyy(U) * sp.cos(U) + U ** 3 * Dx(U) + sp.tanh(U) * Dy(U) + sp.sin(U) * sp.cos(U) / (1 + U ** 2) \
+        + sp.exp(-U ** 2) * Dx(U) ** 2 + sp.log(1 + U ** 2) * Dy(U) ** 2 + sp.sqrt(1 + U ** 2) + sp.sinh(U) * sp.cosh(U) * 1e-2 \
+        + Dx(Dy(U)) * U + sp.Abs(U) * 0.1 + (U + 0.5) ** 4 * 0.01
+    eq = npde.Eq(expr, sp.sin(x) * sp.cos(y))
+    bcs = [npde.Eq(u(0, y), 0.0), npde.Eq(u(x, 1), x)]
+    dom = [npde.In(x, npde.Interval(0.0, 1.0)), npde.In(y, npde.Interval(0.0, 1.0))]
+    sysm = npde.PDESystem([eq], bcs, dom, [x, y], [U])
+    chain = npde.Chain(npde.Dense(2, 16, "tanh"), npde.Dense(16, 16, "tanh"), npde.Dense(16, 1))
+    strat = npde.QuasiRandomTraining(45, bcs_points=20, sampling_alg=npde.SobolSample(seed=4), resampling=False, minibatch=1)
+    rep, prob, sets, th = check(npde, sysm, [chain], strat, theta_for(chain, 91), weights=[1.0, 2.0, 0.5])
+    assert len(rep.ir.terms[0].ops) > 32 and "coupled" in rep.engine.describe()
