@@ -114,6 +114,13 @@ int pinn_set_sampler(pinn_handle h, int term, int kind, const float* lb, const f
  * `additional_loss`, e.g. docs/src/tutorials/param_estim.md:79-95, evaluated inside the fused loss + gradient instead of on the host).
  */
 int pinn_set_point_data(pinn_handle h, int term, const float* data, int ndata, int64_t n);
+/*
+ * Quadrature weights for the term's current point set: the term's loss becomes  sum_i w[i] * r_i^2  (with sum_i w[i] = 1: a weighted mean,
+ * e.g. a tensor Gauss-Legendre rule — (1/area) * integral of r^2, the objective of the reference's QuadratureTraining,
+ * src/training_strategies.jl:451-481) instead of mean(abs2, r).  NULL restores the plain mean.  Sharded sets: pass the shard's
+ * weights of the GLOBAL rule (n_norm of pinn_set_points is then only a scale that cancels).
+ */
+int pinn_set_point_weights(pinn_handle h, int term, const float* w, int64_t n);
 /* Copy the term's current collocation set (d x N, point-major, as installed or as last drawn by the device sampler) to the host. */
 int pinn_get_points(pinn_handle h, int term, float* pts, int64_t n);
 int pinn_adam_init(pinn_handle h, const float* theta, int64_t p);

@@ -16,7 +16,7 @@ from .adaptive import (AbstractAdaptiveLoss, GradientScaleAdaptiveLoss, MiniMaxA
 from .pinn import (DataLoss, depvar_params, Adam, OptimizationSolution, solve, Chain, Dense, LogOptions, NonAdaptiveLoss, OptimizationFunction, OptimizationProblem, Phi,
                    PhysicsInformedNN, PINNLossFunctions, PINNRepresentation, discretize, initialparameters, remake,
                    symbolic_discretize)
-from .strategies import (AbstractTrainingStrategy, GridTraining, LatinHypercubeSample, QuasiRandomTraining,
+from .strategies import (AbstractTrainingStrategy, QuadratureTraining, GridTraining, LatinHypercubeSample, QuasiRandomTraining,
                          SobolSample, StochasticTraining, generate_random_points, generate_training_sets, get_bounds,
                          get_loss_function, merge_strategy_with_loss_function)
 from .symbolic import (Differential, Eq, Equation, In, Interval, LoweringError, PDESystem, get_argument, get_variables,

@@ -20,7 +20,7 @@ SYMBOLS = [
     "pinn_backend", "pinn_abi_version", "pinn_last_error", "pinn_create", "pinn_destroy", "pinn_num_terms",
     "pinn_num_theta", "pinn_set_points", "pinn_set_points_device", "pinn_loss_grad", "pinn_loss_grad_f64",
     "pinn_term_grads", "pinn_loss_grad_device", "pinn_residual", "pinn_phi", "pinn_last_timing", "pinn_set_timing", "pinn_describe", "pinn_num_groups", "pinn_group_timing",
-    "pinn_set_sampler", "pinn_set_point_data", "pinn_get_points", "pinn_adam_init", "pinn_adam_steps", "pinn_adam_get",
+    "pinn_set_sampler", "pinn_set_point_data", "pinn_set_point_weights", "pinn_get_points", "pinn_adam_init", "pinn_adam_steps", "pinn_adam_get",
 ]
 
 
@@ -63,6 +63,7 @@ class Library:
         L.pinn_set_sampler.argtypes = [vp, C.c_int, C.c_int, fp, fp, C.c_int64, C.c_uint64]
         L.pinn_get_points.argtypes = [vp, C.c_int, fp, C.c_int64]
         L.pinn_set_point_data.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int64]
+        L.pinn_set_point_weights.argtypes = [vp, C.c_int, fp, C.c_int64]
         L.pinn_adam_init.argtypes = [vp, fp, C.c_int64]
         L.pinn_adam_steps.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, fp, dp]
         L.pinn_adam_get.argtypes = [vp, fp, C.c_int64]
@@ -200,6 +201,14 @@ class Engine:
         data = _f32(np.atleast_2d(np.asarray(data)))
         self.L.check(self.L.lib.pinn_set_point_data(self.h, term, data.ctypes.data_as(C.POINTER(C.c_float)), data.shape[0], data.shape[1]),
                      "pinn_set_point_data")
+
+    def set_point_weights(self, term: int, w):
+        """quadrature weights of the term's current point set: loss_k = sum_i w_i r_i^2 (None: back to mean(abs2, r))"""
+        if w is None:
+            self.L.check(self.L.lib.pinn_set_point_weights(self.h, term, None, 0), "pinn_set_point_weights")
+            return
+        w = _f32(np.asarray(w).reshape(-1))
+        self.L.check(self.L.lib.pinn_set_point_weights(self.h, term, w.ctypes.data_as(C.POINTER(C.c_float)), w.size), "pinn_set_point_weights")
 
     def get_points(self, term: int, d: int, n: int) -> np.ndarray:
         """the term's current set as a (d x N) array (e.g. what the device sampler drew last)"""

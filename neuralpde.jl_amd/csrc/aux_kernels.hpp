@@ -61,6 +61,7 @@ struct ExprArgs {
     int K, term_id;
     float* resid;                         // nullable: write r[N] and skip the adjoint
     const float* data;                    // [ndata][N] user-supplied per-point channels (OP_DATA), nullable
+    const float* pw;                      // per-point factors sqrt(N w_i) of a quadrature-weighted term, nullable
 };
 // one point; returns r (masked by `valid`), writes ubar, returns dL/dp contributions in pb[]
 AUX_DEV float expr_point(int p, const ExprArgs& a, float (&pb)[4]) {
@@ -89,11 +90,13 @@ AUX_DEV float expr_point(int p, const ExprArgs& a, float (&pb)[4]) {
         g[ins.a] += da;
         if (rp::is_binary(ins.code)) g[ins.b] += db;
     }
-    const float rbar = r * a.scale;
+    const float sw = a.pw ? a.pw[p] : 1.0f;
+    const float rs = r * sw;
+    const float rbar = rs * a.scale * sw;
     for (int s = 0; s < a.nslots; ++s) a.ubar[s][p] = rbar * g[a.d + a.nparams + s];
     for (int z = 0; z < a.nzero; ++z) a.zero[z][p] = 0.f;
     for (int j = 0; j < a.nparams_estim; ++j) pb[j] = rbar * g[a.d + j];
-    return r;
+    return rs;
 }
 
 // k_src: coordinate-only subexpressions of a residual (source terms f(x), boundary data g(x), variable coefficients ...),

@@ -89,6 +89,9 @@ struct Term {
     int ndata = 0;
     float* d_data = nullptr;
     int64_t data_n = 0, data_cap = 0;
+    // optional quadrature weights of the current point set, stored as sqrt(n_norm * w_i) (pinn_set_point_weights)
+    float* d_pw = nullptr;
+    int64_t pw_n = 0, pw_cap = 0;
     // data
     float* d_pts = nullptr;
     int64_t n = 0, n_norm = 0;
@@ -1067,6 +1070,7 @@ void retile(pinn_engine& E, int gi) {
         td.scale = 0.f;
         td.out = nullptr;
         td.in = nullptr;
+        td.pw = (T.pw_n == T.n && T.pw_n > 0) ? T.d_pw : nullptr;
         td.src = (G.kind == 0) ? T.d_src : nullptr;
         td.nsrc = (G.kind == 0) ? (int)T.src_root.size() : 0;
         {
@@ -1165,6 +1169,7 @@ aux::ExprArgs expr_args(pinn_engine& E, Coupled& Cp, float scale, float* resid) 
     a.prog = Cp.d_prog; a.nops = (int)T.ops.size(); a.out_row = T.out_row; a.scale = scale;
     a.losspart = Cp.d_losspart; a.pslab = Cp.d_pslab; a.K = (int)E.terms.size(); a.term_id = Cp.term; a.resid = resid;
     a.data = T.d_data;
+    a.pw = (T.pw_n == T.n && T.pw_n > 0) ? T.d_pw : nullptr;
     return a;
 }
 
@@ -1328,7 +1333,7 @@ int pinn_destroy(pinn_handle h) {
     if (!h) return 0;
     pinn_engine& E = *h;
     plat_sync(E.stream);
-    for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_resid); plat_free(T.d_lb); plat_free(T.d_ub); plat_free(T.d_src_prog); plat_free(T.d_src); plat_free(T.d_data); }
+    for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_resid); plat_free(T.d_lb); plat_free(T.d_ub); plat_free(T.d_src_prog); plat_free(T.d_src); plat_free(T.d_data); plat_free(T.d_pw); }
     plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist);
     for (auto& G : E.groups) {
         plat_free(G.d_prog); plat_free(G.d_slabs); plat_free(G.d_losspart); plat_free(G.d_scratch); plat_free(G.d_rec);
@@ -1373,7 +1378,8 @@ static int set_points_impl(pinn_handle h, int term, const float* pts, int64_t n,
     plat_sync(E.stream);
     T.n = n;
     T.n_norm = n_norm > 0 ? n_norm : n;
-    T.data_n = 0;                                        // per-point data belong to the previous set
+    T.data_n = 0;                                        // per-point data and weights belong to the previous set
+    T.pw_n = 0;
     if (T.coupled < 0) {
         if (!T.src_root.empty()) {
             if (T.src_cap < n) {
@@ -1614,6 +1620,37 @@ int pinn_set_point_data(pinn_handle h, int term, const float* data, int ndata, i
     T.data_n = n;
     eval_sources(E, T);
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    return 0;
+}
+
+int pinn_set_point_weights(pinn_handle h, int term, const float* w, int64_t n) {
+    if (!h) return fail("pinn_set_point_weights: null handle");
+    pinn_engine& E = *h;
+    if (term < 0 || term >= (int)E.terms.size()) return fail("pinn_set_point_weights: term index out of range");
+    Term& T = E.terms[term];
+    plat_sync(E.stream);
+    if (!w) {                                            // back to the plain mean
+        T.pw_n = 0;
+    } else {
+        if (!T.d_pts || n != T.n) return fail("pinn_set_point_weights: the term holds " + std::to_string(T.n) + " points (install the point set first)");
+        if (T.sampler != 0) return fail("pinn_set_point_weights: weights cannot follow a resampled point set");
+        std::vector<float> s((size_t)n);
+        for (int64_t i = 0; i < n; ++i) {
+            if (!(w[i] >= 0.f)) return fail("pinn_set_point_weights: weights must be non-negative");
+            s[i] = (float)std::sqrt((double)w[i] * (double)T.n_norm);
+        }
+        if (T.pw_cap < n) {
+            plat_free(T.d_pw);
+            T.d_pw = (float*)plat_malloc(sizeof(float) * (size_t)n);
+            if (!T.d_pw) return fail("device allocation failed (point weights)");
+            T.pw_cap = n;
+        }
+        if (plat_h2d(T.d_pw, s.data(), sizeof(float) * (size_t)n, E.stream)) return fail("H2D copy of point weights failed");
+        if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+        T.pw_n = n;
+    }
+    if (T.coupled < 0) retile(E, T.group);
+    else for (int gi : E.coupled[T.coupled].groups) retile(E, gi);
     return 0;
 }
 

@@ -191,6 +191,9 @@ struct TermDev {
     int dt;
     int hetero;
     int imap[4];
+    // optional per-point factors s_i = sqrt(N w_i) (pinn_set_point_weights): the term's loss becomes sum_i w_i r_i^2 — a quadrature
+    // rule — instead of the plain mean; nullptr: mean(abs2, r)
+    const float* pw;
 };
 
 struct GroupArgs {
@@ -596,9 +599,11 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                     gstore_masked(T.out, p, r, vand(valid[pg], g0));
                     continue;
                 }
-                vfloat rm = vselect(valid[pg], r, vfloat(0.f));
+                vfloat sw = vfloat(1.0f);
+                if (T.pw) sw = gload_masked(T.pw, vint(pbase + 16 * pg) + c, valid[pg]);
+                vfloat rm = vselect(valid[pg], r * sw, vfloat(0.f));
                 lsum = vfma(rm, vselect(g0, rm, vfloat(0.f)), lsum);
-                vfloat rbar = rm * vfloat(T.scale);
+                vfloat rbar = rm * vfloat(T.scale) * sw;
                 for (int q = 0; q < nrows; ++q) lds_store(ta, vint(q * 64) + lane, vfloat(0.f));
                 lds_store(ta, vint(T.out_row * 64) + lane, vfloat(1.0f));
                 for (int q = T.nops - 1; q >= 0; --q) {

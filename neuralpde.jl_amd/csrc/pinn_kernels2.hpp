@@ -390,9 +390,11 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                     vint p = vint(pbase + 16 * w) + c;
                     gstore_masked(T.out, p, r, vand(vin, g0));
                 } else {
-                    vfloat rm = vselect(vin, r, vfloat(0.f));
-                    lsum = vfma(rm, vselect(g0, rm, vfloat(0.f)), lsum);   // this wave's share of the term's sum of squares
-                    vfloat rbar = rm * vfloat(T.scale);
+                    vfloat sw = vfloat(1.0f);
+                    if (T.pw) sw = gload_masked(T.pw, vint(pbase + 16 * w) + c, vin);
+                    vfloat rm = vselect(vin, r * sw, vfloat(0.f));
+                    lsum = vfma(rm, vselect(g0, rm, vfloat(0.f)), lsum);   // this wave's share of the term's (weighted) sum of squares
+                    vfloat rbar = rm * vfloat(T.scale) * sw;
                     vtape ta;
                     tape_zero(ta);
                     tape_set(ta, T.out_row, vfloat(1.0f));

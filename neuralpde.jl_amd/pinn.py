@@ -389,6 +389,9 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
             engine.set_points(k, s)
 
     install(pde_sets, bc_sets)
+    if getattr(strategy, "point_weights", None) is not None and strategy.point_weights() is not None:
+        for k, w in enumerate(strategy.point_weights()):           # quadrature strategies: loss_k = sum_i w_i r_i^2
+            engine.set_point_weights(k, w)
     n_data = len(sym_data)
     data_sets = [np.asarray(dl.points, dtype=np.float64) for dl in discretization.data_loss]
     for j, dl in enumerate(discretization.data_loss):                    # fixed sets + their observations, installed once
@@ -433,6 +436,8 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
             engine.set_points(k, cord)
             r = engine.residual(k, np.asarray(theta), cord.shape[1]).astype(np.float64).reshape(1, -1)
             engine.set_points(k, (state["pde_sets"] + state["bc_sets"])[k])
+            if getattr(strategy, "point_weights", None) is not None and strategy.point_weights() is not None:
+                engine.set_point_weights(k, strategy.point_weights()[k])
             state["cache_theta"] = None
             return r
         return f

@@ -188,6 +188,56 @@ class QuasiRandomTraining(AbstractTrainingStrategy):
         return batches[0][0], batches[0][1], pick
 
 
+class QuadratureTraining(AbstractTrainingStrategy):
+    """`QuadratureTraining(; quadrature_alg, reltol, abstol, maxiters, batch)` (src/training_strategies.jl:396-481): every term's loss is
+    (1/area) * integral of residual^2 over the term's domain.  STAND-IN: the reference integrates adaptively (Integrals.jl cubature,
+    HCubatureJL by default) to `reltol`/`abstol`; here the integral is a FIXED tensor Gauss-Legendre rule with `nodes` points per free
+    axis (default: 32 in 1-D, 24 in 2-D, 12 in 3-D, 8 in 4-D), evaluated with the other terms in one fused device call
+    (`pinn_set_point_weights`).  Same objective, different (non-adaptive) quadrature error; `quadrature_alg`, `reltol`, `abstol`,
+    `maxiters`, `batch` are accepted for source compatibility and ignored."""
+
+    def __init__(self, quadrature_alg=None, reltol=1e-6, abstol=1e-3, maxiters=1000, batch=100, nodes: int = None):
+        self.quadrature_alg, self.reltol, self.abstol, self.maxiters, self.batch = quadrature_alg, reltol, abstol, maxiters, batch
+        self.nodes = nodes
+        self._weights = None
+
+    def _rule(self, lb, ub, dtype):
+        free = [i for i in range(len(lb)) if ub[i] > lb[i]]
+        n = self.nodes or {0: 1, 1: 32, 2: 24, 3: 12}.get(len(free), 8)
+        xs, ws = np.polynomial.legendre.leggauss(n)
+        grids, wts = [], []
+        for i in range(len(lb)):
+            if i in free:
+                grids.append(0.5 * (ub[i] - lb[i]) * xs + 0.5 * (ub[i] + lb[i]))
+                wts.append(0.5 * ws)                                   # weights of the MEAN over the axis (sum to 1)
+            else:
+                grids.append(np.array([lb[i]]))
+                wts.append(np.array([1.0]))
+        mesh = np.meshgrid(*grids, indexing="ij")
+        wmesh = np.meshgrid(*wts, indexing="ij")
+        pts = np.stack([m.reshape(-1, order="F") for m in mesh]).astype(dtype)          # first variable fastest, like the grids
+        w = np.prod(np.stack([m.reshape(-1, order="F") for m in wmesh]), axis=0)
+        return pts, w / w.sum()
+
+    def point_sets(self, pde_system: PDESystem, vi: VarInfo, dtype):
+        # integration domains = the full variable ranges (no 1/points inset: src/discretize.jl get_bounds for QuadratureTraining)
+        dom = {str(d.variable): (float(d.domain.lo), float(d.domain.hi)) for d in pde_system.domain}
+        args = get_argument(list(pde_system.eqs) + list(pde_system.bcs), vi)
+        sets, weights = [], []
+        for a in args:
+            lb = np.array([float(v) if isinstance(v, (int, float)) else dom[str(v)][0] for v in a])
+            ub = np.array([float(v) if isinstance(v, (int, float)) else dom[str(v)][1] for v in a])
+            p, w = self._rule(lb, ub, dtype)
+            sets.append(p); weights.append(w)
+        n_pde = len(pde_system.eqs)
+        self._weights = weights
+        return sets[:n_pde], sets[n_pde:], None
+
+    def point_weights(self):
+        """per term: quadrature weights (sum to 1) of the sets returned by the last point_sets call"""
+        return self._weights
+
+
 # ------------------------------------------------------------------------------------------------
 # the reference's strategy plug-in points, by name (SURVEY.md §8b)
 # ------------------------------------------------------------------------------------------------

@@ -311,6 +311,7 @@ def test_reference_examples_gpu(npde, hip_lib, monkeypatch):
                  "test_nonlinear_elliptic_first_order_system", "test_lorenz_parameter_estimation_terms", "test_nonlinear_hyperbolic_system"):
         getattr(ex, name)(npde, None)
     ex.test_data_misfit_terms_on_device(npde, None)          # DataLoss extension: device objective == physics + host additional_loss
+    ex.test_quadrature_training_stand_in(npde, None)         # per-point quadrature weights
 
 
 def test_bench_two_ranks_share_the_gpu(hip_lib):

@@ -245,3 +245,41 @@ def test_data_misfit_terms_on_device(npde, use_emu):
     with pytest.raises(ValueError):
         npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, mk(), init_params=th, param_estim=True,
                                                              data_loss=[npde.DataLoss(u(t, x), pts[:1], vals)]))
+
+
+def test_quadrature_training_stand_in(npde, use_emu):
+    """QuadratureTraining stand-in (fixed tensor Gauss-Legendre rule through pinn_set_point_weights): per-term loss = sum_i w_i r_i^2
+    = (1/area) * integral of r^2 (the reference's objective, src/training_strategies.jl:451-481) and its gradient, against the oracle's
+    residual function differentiated by torch; the residual closure stays unweighted."""
+    import torch
+    from test_emu_parity import poisson2d
+    sysm, chain = poisson2d(npde, "tanh")
+    th = theta_for(chain, 181)
+    strat = npde.QuadratureTraining(nodes=6)
+    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th))
+    sets = rep.pde_train_sets + rep.bcs_train_sets
+    ws = strat.point_weights()
+    assert sets[0].shape == (2, 36) and sets[1].shape == (2, 6) and abs(ws[0].sum() - 1) < 1e-12 and np.all(sets[1][0] == 0.0)
+    wterm = [1.0, 2.0, 0.5, 1.5, 3.0]
+    losses, grad = rep.engine.loss_grad(th, wterm)
+    prob = helpers.oracle_problem(npde, sysm, [chain])
+    tt = torch.tensor(th, dtype=torch.float64, requires_grad=True)
+    total, ref_losses = 0.0, []
+    for k, (s, w) in enumerate(zip(sets, ws)):
+        term = (list(prob.pde_terms) + list(prob.bc_terms))[k]
+        r = po.build_residual(prob, term, mode="stencil")(torch.tensor(s, dtype=torch.float64), tt).reshape(-1)
+        lk = torch.sum(torch.tensor(w, dtype=torch.float64) * r * r)
+        ref_losses.append(float(lk.detach()))
+        total = total + wterm[k] * lk
+    (g_ref,) = torch.autograd.grad(total, tt)
+    np.testing.assert_allclose(losses, ref_losses, rtol=1e-5)
+    assert np.linalg.norm(grad - g_ref.numpy()) < 1e-5 * np.linalg.norm(g_ref.numpy())
+    # the datafree residual function is the plain residual, and evaluating it does not disturb the weighted loss
+    r0 = rep.loss_functions.datafree_pde_loss_functions[0](sets[0], th)
+    np.testing.assert_allclose(r0, po.residual_values(prob, th, 0, sets[0]), rtol=2e-5, atol=2e-5)
+    l2, _ = rep.engine.loss_grad(th, wterm)
+    np.testing.assert_allclose(l2, losses, rtol=1e-12)
+    # more nodes -> the integral converges (the rule is exact for polynomials of degree 2n - 1)
+    fine = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, npde.QuadratureTraining(nodes=14), init_params=th))
+    lf, _ = fine.engine.loss_grad(th)
+    assert abs(lf[0] - losses[0]) < 2e-3 * abs(lf[0])
