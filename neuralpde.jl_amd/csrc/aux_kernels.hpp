@@ -7,6 +7,7 @@
 //               into the output vector [P floats grad | K floats raw sums of squares] (+ K doubles for the host path)
 // Every sum has a fixed order => bit-identical results run to run.
 #pragma once
+#include "aux_limits.hpp"
 #include "plat.hpp"
 #include "rprog.hpp"
 
@@ -19,9 +20,6 @@ namespace aux {
 #endif
 
 struct alignas(16) F4 { float x, y, z, w; };
-constexpr int MAX_GROUPS = 24;
-constexpr int EXPR_MAX_SLOTS = 24;
-constexpr int EXPR_MAX_ROWS = 96;
 
 struct Reduce1Args {
     double* tmp[MAX_GROUPS];            // [nsplit][nent + K]
@@ -103,7 +101,6 @@ AUX_DEV float expr_point(int p, const ExprArgs& a, float (&pb)[4]) {
 // evaluated once per installed / redrawn point set, one thread per point, into channel arrays src[j][N] that the fused
 // kernel's tape reads as input rows.  The reference re-evaluates them inside the generated loss function on every call
 // (they are part of the broadcast expression, src/symbolic_utilities.jl:360-370); values are identical.
-constexpr int SRC_MAX = 8;
 struct SrcArgs {
     const float* pts;                     // d x N point-major
     int N, d;

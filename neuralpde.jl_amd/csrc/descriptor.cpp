@@ -1,0 +1,117 @@
+// descriptor.cpp — parser of the "pinnir 1" problem descriptor (grammar: DESIGN.md §2).
+#include "engine_types.hpp"
+
+namespace pe {
+
+// ---------------------------------------------------------------------------------------------
+// descriptor parsing
+// ---------------------------------------------------------------------------------------------
+const char* OPNAMES[rp::OP_COUNT] = {"CONST", "ADD", "SUB", "MUL", "DIV", "NEG", "ADDC", "MULC", "POWI", "POW", "POWC",
+                                     "SIN", "COS", "TAN", "EXP", "LOG", "SQRT", "ABS", "TANH", "SINH", "COSH", "SECH",
+                                     "SINPI", "COSPI", "MAX", "MIN", "DATA"};
+
+int parse_descriptor(const char* text, pinn_engine& E) {
+    std::istringstream in(text);
+    std::string tok;
+    auto expect = [&](const char* w) -> bool {
+        in >> tok;
+        return (bool)in && tok == w;
+    };
+    int ver = 0;
+    if (!expect("pinnir") || !(in >> ver) || ver != 1) return fail("descriptor: expected 'pinnir 1'");
+    if (!expect("ntheta") || !(in >> E.ntheta)) return fail("descriptor: ntheta");
+    if (!expect("params") || !(in >> E.np >> E.ne >> E.p_theta_off)) return fail("descriptor: params");
+    if (E.np < 0 || E.np > pk::MAX_PARAMS || E.ne > E.np) return fail("descriptor: at most 4 PDE parameters are supported");
+    if (!expect("defaults")) return fail("descriptor: defaults");
+    E.p_defaults.assign(pk::MAX_PARAMS, 0.f);
+    for (int i = 0; i < E.np; ++i)
+        if (!(in >> E.p_defaults[i])) return fail("descriptor: defaults values");
+    int nn = 0;
+    if (!expect("nets") || !(in >> nn) || nn < 1) return fail("descriptor: nets");
+    E.nets.resize(nn);
+    for (int i = 0; i < nn; ++i) {
+        int id, ns;
+        std::string act;
+        if (!expect("net") || !(in >> id >> act >> E.nets[i].theta_off >> ns) || id != i) return fail("descriptor: net line");
+        if (act == "tanh") E.nets[i].act = pk::ACT_TANH;
+        else if (act == "sigmoid") E.nets[i].act = pk::ACT_SIGMOID;
+        else if (act == "sin") E.nets[i].act = pk::ACT_SIN;
+        else return fail("descriptor: unsupported activation '" + act + "' (supported: tanh, sigmoid, sin)");
+        E.nets[i].sizes.resize(ns);
+        for (int j = 0; j < ns; ++j)
+            if (!(in >> E.nets[i].sizes[j])) return fail("descriptor: net sizes");
+        if (ns < 3) return fail("descriptor: a chain needs at least one hidden layer");
+        if (E.nets[i].sizes.back() != 1) return fail("descriptor: only single-output chains (one per dependent variable) are supported, as in the reference (pinn_types.jl:106-108)");
+    }
+    int nt = 0;
+    if (!expect("terms") || !(in >> nt) || nt < 1) return fail("descriptor: terms");
+    E.terms.resize(nt);
+    for (int i = 0; i < nt; ++i) {
+        Term& T = E.terms[i];
+        int id, ns, no;
+        if (!expect("term") || !(in >> id >> T.d >> ns >> no >> T.out_row) || id != i) return fail("descriptor: term line");
+        T.slots.resize(ns);
+        for (int s = 0; s < ns; ++s) {
+            Slot& S = T.slots[s];
+            std::string ord;
+            if (!expect("slot") || !(in >> S.net >> ord)) return fail("descriptor: slot line");
+            if (S.net < 0 || S.net >= nn) return fail("descriptor: slot net id");
+            if (ord == "lap") {                      // slot <net> lap <n> a0 a1 ... : sum of d2/dx_a^2 over the listed axes
+                int n = 0;
+                if (!(in >> n) || n < 1 || n > 8) return fail("descriptor: lap slot");
+                S.order = 2; S.axes[0] = S.axes[1] = S.axes[2] = S.axes[3] = 0;
+                for (int a = 0; a < n; ++a) {
+                    int ax;
+                    if (!(in >> ax) || ax < 0 || ax > 7) return fail("descriptor: lap slot axes");
+                    S.lap |= 1u << ax;
+                }
+                continue;
+            }
+            S.order = std::atoi(ord.c_str());
+            if (ord.empty() || ord.find_first_not_of("0123456789") != std::string::npos) return fail("descriptor: slot order");
+            if (S.order < 0 || S.order > 4) return fail("derivative order > 4 is not supported by the HIP engine");
+            for (int a = 0; a < S.order; ++a)
+                if (!(in >> S.axes[a])) return fail("descriptor: slot axes");
+            if (S.order == 2 && S.axes[0] > S.axes[1]) std::swap(S.axes[0], S.axes[1]);
+            if (S.order >= 3)
+                for (int a = 1; a < S.order; ++a)
+                    if (S.axes[a] != S.axes[0]) return fail("mixed derivatives of order > 2 are not supported by the HIP engine (pure d^3/dx^3, d^4/dx^4 are)");
+        }
+        T.ops.resize(no);
+        for (int q = 0; q < no; ++q) {
+            std::string name;
+            rp::Instr& I = T.ops[q];
+            if (!expect("op") || !(in >> name >> I.a >> I.b >> I.imm)) return fail("descriptor: op line");
+            I.code = -1;
+            for (int c = 0; c < rp::OP_COUNT; ++c)
+                if (name == OPNAMES[c]) I.code = c;
+            if (I.code < 0) return fail("descriptor: unknown op '" + name + "'");
+            const int lim = T.d + E.np + ns + q;          // operands may only reference earlier rows
+            if (!rp::is_nullary(I.code) && (I.a < 0 || I.a >= lim)) return fail("descriptor: op operand row out of range");
+            if (rp::is_binary(I.code) && (I.b < 0 || I.b >= lim)) return fail("descriptor: op operand row out of range");
+            rp::finalize(I);
+            if (I.code == rp::OP_DATA) {
+                if (I.imm < 0.f || I.imm > 15.f || I.imm != (float)(int)I.imm) return fail("descriptor: DATA channel index");
+                T.ndata = std::max(T.ndata, (int)I.imm + 1);
+            }
+        }
+        if (T.out_row < 0 || T.out_row >= T.d + E.np + ns + no) return fail("descriptor: out row out of range");
+        // optional: inmap <net> <n> <coordinate index of input 0> ... (one line per network whose inputs are not simply the
+        // term's coordinates in order)
+        for (;;) {
+            const std::streampos pos = in.tellg();
+            std::string tok;
+            if (!(in >> tok)) { in.clear(); break; }
+            if (tok != "inmap") { in.seekg(pos); break; }
+            int net, n;
+            if (!(in >> net >> n) || net < 0 || net >= nn || n < 1 || n > 4) return fail("descriptor: inmap line");
+            std::vector<int> m(n);
+            for (int i = 0; i < n; ++i)
+                if (!(in >> m[i]) || m[i] < 0 || m[i] >= T.d) return fail("descriptor: inmap coordinate index out of range");
+            T.inmap[net] = m;
+        }
+    }
+    return 0;
+}
+
+}  // namespace pe

@@ -1,0 +1,194 @@
+// engine_types.hpp — data model of the host side of the C ABI, shared by descriptor.cpp (parsing), program.cpp (residual-program
+// passes), plan.cpp (kernel selection, buffers, reduction maps) and engine.cpp (evaluation + the extern "C" entry points).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/pinn_hip.h"
+#include "aux_limits.hpp"
+#include "plat.hpp"
+#include "spec_registry.hpp"
+
+namespace pe {
+
+constexpr int REDUCE_SPLIT = 32;     // stage-1 chunks of the fixed-order slab reduction
+
+extern thread_local std::string g_err;      // message of the last failed call on this thread (pinn_last_error)
+int fail(const std::string& m);             // records the message, returns 1
+
+struct Slot {
+    int net;
+    int order;
+    int axes[4];
+    unsigned lap = 0;        // != 0: the sum of the pure second derivatives over these axes (one "forward Laplacian" jet channel)
+};
+struct Net {
+    int act;
+    int theta_off;
+    std::vector<int> sizes;          // n0 .. nL (nL == 1)
+    int nparams() const {
+        int n = 0;
+        for (size_t i = 0; i + 1 < sizes.size(); ++i) n += sizes[i + 1] * sizes[i] + sizes[i + 1];
+        return n;
+    }
+    int maxhidden() const {
+        int m = 0;
+        for (size_t i = 1; i + 1 < sizes.size(); ++i) m = std::max(m, sizes[i]);
+        return m;
+    }
+};
+struct Term {
+    int d = 0;
+    std::vector<Slot> slots;
+    std::vector<rp::Instr> ops;      // descriptor row numbering
+    int out_row = 0;
+    // plan
+    int net = -1;
+    int group = -1;
+    int slot_in_group = -1;
+    int coupled = -1;                // >= 0: index into pinn_engine::coupled (equation couples several networks)
+    std::vector<int> chan_of_slot;
+    // per referenced network: which of the term's coordinates feed the network's inputs (descriptor `inmap` lines; default
+    // identity) — dependent variables of one system may take different arguments (src/discretize.jl:111-131)
+    std::map<int, std::vector<int>> inmap;
+    // coordinate-only subexpressions hoisted out of the fused tape (analyse_static): evaluated by k_src per point set
+    std::vector<rp::Instr> src_prog;     // compact numbering: rows [0,d) coordinates, row d+i = static op i
+    std::vector<int> src_root;           // compact row of source j
+    std::vector<int> src_of_op;          // per descriptor op: source index, or -1
+    std::vector<int> tape_ops;           // descriptor ops that stay in the fused tape, in order
+    rp::Instr* d_src_prog = nullptr;
+    float* d_src = nullptr;              // [nsrc][n]
+    int64_t src_cap = 0;
+    // user-supplied per-point data channels (OP_DATA; pinn_set_point_data), valid for the current point set only
+    int ndata = 0;
+    float* d_data = nullptr;
+    int64_t data_n = 0, data_cap = 0;
+    // optional quadrature weights of the current point set, stored as sqrt(n_norm * w_i) (pinn_set_point_weights)
+    float* d_pw = nullptr;
+    int64_t pw_n = 0, pw_cap = 0;
+    // data
+    float* d_pts = nullptr;
+    int64_t n = 0, n_norm = 0;
+    float* d_resid = nullptr;
+    int64_t resid_cap = 0;
+    // on-device sampler: kind 0 = fixed set, 1 = uniform (StochasticTraining), 2 = Latin hypercube (QuasiRandomTraining default),
+    // redrawn before every training step
+    int sampler = 0;
+    float* d_lb = nullptr;
+    float* d_ub = nullptr;
+    unsigned seed = 0, draws = 0;
+};
+struct Group {
+    int kind = 0;                    // 0: fused (single-network terms); 1: per-network FWD/GRADIN launches of coupled terms
+    int net = -1;
+    const pk::SpecInfo* spec = nullptr;
+    std::vector<int> terms;
+    pk::GroupArgs ga;
+    rp::Instr* d_prog = nullptr;
+    std::vector<int> prog_off, prog_n, out_row;
+    float* d_slabs = nullptr;
+    double* d_losspart = nullptr;
+    float* d_scratch = nullptr;
+    float* d_rec = nullptr;          // kind 1, family 2: per-tile records of the forward launch, read back by the reverse launch
+    size_t rec_slots = 0;            // (instead of running the forward pass twice; falls back to recomputation above REC_BUDGET)
+    bool use_rec = false;
+    double* d_tmp = nullptr;         // stage-1 partial sums [nsplit][nent + K]
+    std::vector<int> row_theta, row_ptr, row_off;   // host CSR: theta element -> slab offsets of this group
+    int nent = 0;
+    int blocks = 0;
+    int max_blocks = 0;
+    bool active = false;
+    plat_event ev_a, ev_b;
+    bool timed = false;
+};
+// an equation that couples several networks (systems of PDEs, src/discretize.jl:58-80): forward launch per network ->
+// k_expr (tape over all networks' jets) -> reverse launch per network
+struct Coupled {
+    int term = -1;
+    std::vector<int> nets;           // networks referenced, increasing
+    std::vector<int> groups;         // per network: the kind-1 group that runs it
+    std::vector<int> slot_net;       // per slot: index into `nets`
+    std::vector<float*> d_jets, d_ubar;   // per network: [C_n][N]
+    int64_t cap = 0;
+    rp::Instr* d_prog = nullptr;
+    double* d_losspart = nullptr;    // pseudo-group for the reduction: [blocks*4][K]
+    float* d_pslab = nullptr;        // [blocks][16]
+    double* d_tmp = nullptr;
+    int blocks = 0, cap_blocks = 0;
+    std::vector<int> row_theta, row_ptr, row_off;
+};
+struct NetPlan {
+    const pk::SpecInfo* spec = nullptr;   // any spec with the right (HP,NHH,D): packed layout is shared
+    float* d_packed = nullptr;
+    int* d_pack_idx = nullptr;
+    int npacked = 0;
+};
+
+}  // namespace pe
+
+using pe::Coupled; using pe::Group; using pe::Net; using pe::NetPlan; using pe::Slot; using pe::Term;
+
+struct pinn_engine {
+    int64_t ntheta = 0;
+    int np = 0, ne = 0, p_theta_off = 0;
+    std::vector<float> p_defaults;
+    std::vector<Net> nets;
+    std::vector<Term> terms;
+    std::vector<Group> groups;
+    std::vector<Coupled> coupled;
+    std::vector<NetPlan> netplans;
+    int ncu = 0;
+    plat_stream stream = nullptr;
+    bool own_stream = true;
+    float* d_theta = nullptr;
+    float* d_params = nullptr;
+    float* d_defaults = nullptr;
+    double* d_lossraw = nullptr;
+    int* d_gr_ptr = nullptr;         // global reduce CSR over theta: contributions (group, entry)
+    int* d_gr_grp = nullptr;
+    int* d_gr_ent = nullptr;
+    float* d_out = nullptr;          // [P grad | K raw sums]
+    std::vector<float> h_out;
+    plat_event ev0, ev1, ev2, ev3;
+    plat_stream aux_stream[2] = {nullptr, nullptr};     // under-filled launch groups run concurrently (fork/join by events)
+    plat_event ev_fork, ev_join[aux::MAX_GROUPS];
+    float last_kernel_ms = 0.f, last_total_ms = 0.f;
+    bool timing_valid = false;
+    int timing_level = 2;        // 0: no events, 1: per-launch-group kernel events, 2: + phase events (pinn_last_timing)
+    int timing_group = -1;       // level >= 1: which launch group gets events (-1: all)
+    // resident-theta Adam state
+    float* d_opt_theta = nullptr;
+    float* d_opt_m = nullptr;
+    float* d_opt_v = nullptr;
+    float* d_opt_out = nullptr;      // [P + K]
+    float* d_w_over_n = nullptr;     // [K]
+    double* d_hist = nullptr;
+    int hist_cap = 0;
+    long long opt_t = 0;
+    // phi scratch
+    float* d_phi_pts = nullptr;
+    float* d_phi_out = nullptr;
+    int64_t phi_cap = 0;
+};
+
+namespace pe {
+// descriptor.cpp
+int parse_descriptor(const char* text, pinn_engine& E);
+// program.cpp
+void analyse_static(Term& T, int np);
+bool fuse_laplacian(Term& T, int np);
+// plan.cpp
+int round_hp(int h);
+const pk::SpecInfo* find_spec(int HP, int NHH, int D, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs,
+                              unsigned need_hi, std::vector<int>* pair_index, bool need_sin = false);
+std::string spec_name(const pk::SpecInfo& s);
+int build_plan(pinn_engine& E);
+void retile(pinn_engine& E, int gi);
+}  // namespace pe

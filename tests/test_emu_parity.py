@@ -406,7 +406,7 @@ def test_bpinn_physics_loglikelihood(npde, use_emu):
 
 
 def test_forward_laplacian_fusion(npde, use_emu):
-    """pure second derivatives that occur only summed (with one common coefficient) travel as ONE jet channel (engine.cpp:
+    """pure second derivatives that occur only summed (with one common coefficient) travel as ONE jet channel (program.cpp:
     fuse_laplacian, JetSet::LAP); sums with unequal coefficients, or second derivatives used elsewhere too, keep their own channels."""
     x, y = npde.parameters("x y")
     (u,) = npde.variables("u")

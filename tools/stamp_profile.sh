@@ -6,8 +6,8 @@ cd "$(dirname "$0")/../neuralpde.jl_amd/csrc"
 mkdir -p abl build/abl
 HIPCC=/opt/rocm/bin/hipcc
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable -DPINN_STAMP $EXTRA"
-for f in engine.cpp ${INST:-inst2_h64_d2.hip inst2_lapc.hip}; do
-  x=""; [ "$f" = engine.cpp ] && x="-x hip"
+for f in engine.cpp descriptor.cpp program.cpp plan.cpp ${INST:-inst2_h64_d2.hip inst2_lapc.hip}; do
+  x=""; [ "${f##*.}" = cpp ] && x="-x hip"
   $HIPCC $FLAGS $x -c $f -o build/abl/stamp_$(basename $f).o &
 done
 wait
