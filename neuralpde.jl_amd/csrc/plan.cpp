@@ -77,7 +77,8 @@ std::string spec_name(const pk::SpecInfo& s) {
     return b;
 }
 
-int build_plan(pinn_engine& E) {
+// theta offsets of the networks and of theta.p lie inside theta
+static int plan_check_nets(pinn_engine& E) {
     // ---- nets ----
     E.netplans.resize(E.nets.size());
     for (size_t n = 0; n < E.nets.size(); ++n) {
@@ -85,7 +86,12 @@ int build_plan(pinn_engine& E) {
         if (N.theta_off < 0 || N.theta_off + N.nparams() > E.ntheta) return fail("descriptor: net parameters exceed ntheta");
     }
     if (E.ne > 0 && (E.p_theta_off < 0 || E.p_theta_off + E.ne > E.ntheta)) return fail("descriptor: theta.p exceeds ntheta");
+    return 0;
+}
 
+// which compiled kernel evaluates which term: single-network terms join fused launch groups, equations that couple several
+// networks (or are too long for the fused tape) get forward / k_expr / reverse launches per network
+static int plan_assign_terms(pinn_engine& E) {
     // ---- terms -> groups ----
     auto needs_of = [&](const Term& T, int net, unsigned& need_first, std::vector<std::pair<int, int>>& need_pairs, unsigned& need_hi) -> int {
         for (auto& s : T.slots) {
@@ -289,7 +295,11 @@ int build_plan(pinn_engine& E) {
                 }
         }
     }
+    return 0;
+}
 
+// per network: index map theta -> packed weight image (fragment order of the kernels)
+static int plan_pack_maps(pinn_engine& E) {
     // ---- per-net pack index map ----
     for (size_t n = 0; n < E.nets.size(); ++n) {
         NetPlan& NP = E.netplans[n];
@@ -346,7 +356,11 @@ int build_plan(pinn_engine& E) {
         plat_h2d(NP.d_pack_idx, idx.data(), sizeof(int) * s.PACKED, E.stream);
         plat_sync(E.stream);
     }
+    return 0;
+}
 
+// per launch group: slabs, scratch, loss partials, programs, slab -> theta reduce rows, kernel arguments
+static int plan_group_buffers(pinn_engine& E) {
     // ---- per-group buffers and reduce maps ----
     int total_terms = (int)E.terms.size();
     for (auto& G : E.groups) {
@@ -486,6 +500,12 @@ int build_plan(pinn_engine& E) {
         ga.nparams_estim = E.ne;
         ga.act = N.act;
     }
+    return 0;
+}
+
+// coupled equations: tape in descriptor row numbering (slots are direct inputs of k_expr), pseudo-group reduce rows
+static int plan_coupled_programs(pinn_engine& E) {
+    const int total_terms = (int)E.terms.size();
     // ---- coupled equations: tape in descriptor row numbering (slots are direct inputs of k_expr) ----
     for (auto& Cp : E.coupled) {
         Term& T = E.terms[Cp.term];
@@ -513,6 +533,11 @@ int build_plan(pinn_engine& E) {
         }
         plat_sync(E.stream);
     }
+    return 0;
+}
+
+// theta element -> (group, slab entry) contributions, group order fixed: the deterministic stage-2 gather
+static int plan_global_reduce_map(pinn_engine& E) {
     // ---- global reduce map: theta element -> (group, slab entry) contributions, group order fixed ----
     if ((int)(E.groups.size() + E.coupled.size()) > aux::MAX_GROUPS) return fail("too many kernel launch groups for one engine");
     {
@@ -544,6 +569,13 @@ int build_plan(pinn_engine& E) {
         }
         plat_sync(E.stream);
     }
+    return 0;
+}
+
+int build_plan(pinn_engine& E) {
+    if (plan_check_nets(E) || plan_assign_terms(E) || plan_pack_maps(E) || plan_group_buffers(E) || plan_coupled_programs(E) ||
+        plan_global_reduce_map(E))
+        return 1;
     return 0;
 }
 
