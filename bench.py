@@ -140,11 +140,15 @@ def main():
     out_h = torch.zeros(P + K, dtype=torch.float32).pin_memory()
     stream = torch.cuda.current_stream()
 
+    # N = 1: the reduction kernel writes [grad | sums] straight into the pinned (device-mapped, coherent) host buffer — no
+    # copy command; N > 1: the all-reduce needs the vector in HBM first, then one D2H copy.
     def step():
-        eng.loss_grad_device(theta_d.data_ptr(), out_d.data_ptr(), None, stream.cuda_stream)
         if world > 1:
+            eng.loss_grad_device(theta_d.data_ptr(), out_d.data_ptr(), None, stream.cuda_stream)
             dist.all_reduce(out_d)
-        out_h.copy_(out_d, non_blocking=True)
+            out_h.copy_(out_d, non_blocking=True)
+        else:
+            eng.loss_grad_device(theta_d.data_ptr(), out_h.data_ptr(), None, stream.cuda_stream)
         stream.synchronize()                 # the optimiser needs loss + gradient on the host every iteration
 
     for _ in range(args.warmup):
@@ -176,6 +180,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
+    host_path_ms = None
+    if world == 1:
+        # cross-check of the zero-copy delivery against a plain device-buffer evaluation + copy
+        eng.set_timing(0, -1)
+        eng.loss_grad_device(theta_d.data_ptr(), out_d.data_ptr(), None, stream.cuda_stream)
+        stream.synchronize()
+        assert np.array_equal(out_d.cpu().numpy(), out_h.numpy()), "zero-copy host delivery differs from the device buffer"
+        # the C-ABI host entry point (theta from host memory, loss + gradient back to host memory: PCIe both ways)
+        th = np.ascontiguousarray(wl.theta, dtype=np.float32)
+        for _ in range(5):
+            eng.loss_grad(th)
+        nh = max(10, args.steps // 4)
+        t1 = time.perf_counter()
+        for _ in range(nh):
+            eng.loss_grad(th)
+        host_path_ms = (time.perf_counter() - t1) / nh * 1e3
     if rank == 0:
         res = out_h.numpy()
         losses = res[P:] / np.array(n_glob)
@@ -208,6 +228,7 @@ def main():
                        "boundary_points_per_term": n_glob[1], "theta": P,
                        "parallelism": f"point-shard x{world}" if world > 1 else "single"},
             "point_terms_per_s": sum(n_glob) * args.steps / el,
+            "host_entry_ms_per_step": host_path_ms,     # pinn_loss_grad: theta host -> device, results device -> host (PCIe-inclusive)
             "loss_terms": [float(v) for v in losses],
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS,

@@ -86,6 +86,8 @@ int pinn_term_grads(pinn_handle h, const float* theta, int64_t p, double* term_l
  *   d_out[0..P)   = this shard's gradient contribution (already scaled by term_w[k]/n_norm_k)
  *   d_out[P..P+K) = this shard's sum of squared residuals per term (divide by n_norm_k after the all-reduce)
  * Asynchronous on `stream` (a hipStream_t; NULL = the default stream, e.g. torch's current stream).
+ * d_out may be any device-accessible address, including pinned device-mapped host memory (hipHostMalloc): the last
+ * reduction kernel then delivers the result to the host without a copy command (what pinn_loss_grad does internally).
  */
 int pinn_loss_grad_device(pinn_handle h, const float* d_theta, const float* term_w, float* d_out, void* stream);
 

@@ -94,7 +94,8 @@ aux::ExprArgs expr_args(pinn_engine& E, Coupled& Cp, float scale, float* resid) 
 
 // the device section shared by all loss/grad entry points.  d_theta: theta in device memory; d_out: [P + K] floats in
 // device memory.  Launches per evaluation: pack (1 per net) -> fused residual kernel (1 per group) -> reduce1 -> reduce2.
-int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const float* term_w, int only_term /* -1 = all */, bool timing) {
+int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const float* term_w, int only_term /* -1 = all */, bool timing,
+                  double* lossraw = nullptr /* K exact double sums; default: E.d_lossraw */) {
     if (ensure_points(E)) return 1;
     const int K = (int)E.terms.size();
     const bool phase_ev = timing && E.timing_level >= 2;
@@ -189,7 +190,7 @@ int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const floa
     }
     if (phase_ev) plat_event_record(E.ev2, E.stream);
     a1.K = K;
-    a2.out = d_out; a2.lossraw = E.d_lossraw; a2.row_ptr = E.d_gr_ptr; a2.row_grp = E.d_gr_grp; a2.row_ent = E.d_gr_ent;
+    a2.out = d_out; a2.lossraw = lossraw ? lossraw : E.d_lossraw; a2.row_ptr = E.d_gr_ptr; a2.row_grp = E.d_gr_grp; a2.row_ent = E.d_gr_ent;
     a2.ngroups = (int)(E.groups.size() + E.coupled.size()); a2.P = (int)E.ntheta; a2.K = K;
     aux::launch_reduce(a1, a2, max_n1, max_split, E.stream);
     if (phase_ev) plat_event_record(E.ev3, E.stream);
@@ -198,7 +199,8 @@ int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const floa
 
 int upload_theta(pinn_engine& E, const float* theta, int64_t p) {
     if (p != E.ntheta) return fail("theta length " + std::to_string(p) + " != ntheta " + std::to_string(E.ntheta));
-    if (plat_h2d(E.d_theta, theta, sizeof(float) * p, E.stream)) return fail(std::string("H2D copy of theta failed: ") + plat_last_error());
+    std::memcpy(E.hp_theta, theta, sizeof(float) * p);          // pinned staging: the copy below is a plain DMA, no pageable bounce
+    if (plat_h2d(E.d_theta, E.hp_theta, sizeof(float) * p, E.stream)) return fail(std::string("H2D copy of theta failed: ") + plat_last_error());
     return 0;
 }
 
@@ -237,7 +239,14 @@ int pinn_create(const char* descriptor, pinn_handle* out) {
         return fail("device allocation failed");
     }
     plat_h2d(E->d_defaults, E->p_defaults.data(), sizeof(float) * pk::MAX_PARAMS, E->stream);
-    E->h_out.resize(E->ntheta + K);
+    // one pinned block for the host entry points; the reduction writes its results straight into it
+    E->hp_theta = (float*)plat_host_alloc(sizeof(float) * (2 * E->ntheta + K + 2) + sizeof(double) * K);
+    if (!E->hp_theta) {
+        pinn_destroy(E.release());
+        return fail("pinned host allocation failed");
+    }
+    E->hp_out = E->hp_theta + E->ntheta;
+    E->hp_raw = (double*)(E->hp_theta + ((2 * E->ntheta + K + 1) / 2) * 2);
     if (build_plan(*E)) {
         const std::string msg = g_err;               // pinn_destroy must not lose the reason
         pinn_destroy(E.release());
@@ -267,6 +276,7 @@ int pinn_destroy(pinn_handle h) {
     for (auto& N : E.netplans) { plat_free(N.d_packed); plat_free(N.d_pack_idx); }
     plat_free(E.d_theta); plat_free(E.d_params); plat_free(E.d_defaults); plat_free(E.d_lossraw); plat_free(E.d_gr_ptr); plat_free(E.d_gr_grp); plat_free(E.d_gr_ent);
     plat_free(E.d_out); plat_free(E.d_phi_pts); plat_free(E.d_phi_out);
+    plat_host_free(E.hp_theta);
     plat_event_destroy(E.ev0); plat_event_destroy(E.ev1); plat_event_destroy(E.ev2); plat_event_destroy(E.ev3);
     plat_event_destroy(E.ev_fork);
     for (auto& e : E.ev_join) plat_event_destroy(e);
@@ -350,16 +360,12 @@ int pinn_loss_grad(pinn_handle h, const float* theta, int64_t p, const float* te
     pinn_engine& E = *h;
     const int K = (int)E.terms.size();
     if (upload_theta(E, theta, p)) return 1;
-    if (run_loss_grad(E, E.d_theta, E.d_out, term_w, -1, true)) return 1;
-    if (plat_d2h(E.h_out.data(), E.d_out, sizeof(float) * (E.ntheta + K), E.stream)) return fail("D2H copy failed");
-    // exact double sums for the host path
-    std::vector<double> raw(K);
-    if (plat_d2h(raw.data(), E.d_lossraw, sizeof(double) * K, E.stream)) return fail("D2H copy failed");
+    if (run_loss_grad(E, E.d_theta, E.hp_out, term_w, -1, true, E.hp_raw)) return 1;     // results land in pinned host memory
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
     E.timing_valid = E.timing_level >= 2;
     if (term_losses)
-        for (int k = 0; k < K; ++k) term_losses[k] = raw[k] / (double)E.terms[k].n_norm;
-    if (grad) std::memcpy(grad, E.h_out.data(), sizeof(float) * E.ntheta);
+        for (int k = 0; k < K; ++k) term_losses[k] = E.hp_raw[k] / (double)E.terms[k].n_norm;   // exact double sums
+    if (grad) std::memcpy(grad, E.hp_out, sizeof(float) * E.ntheta);
     return 0;
 }
 
@@ -383,12 +389,10 @@ int pinn_term_grads(pinn_handle h, const float* theta, int64_t p, double* term_l
     const int K = (int)E.terms.size();
     if (upload_theta(E, theta, p)) return 1;
     for (int k = 0; k < K; ++k) {
-        if (run_loss_grad(E, E.d_theta, E.d_out, nullptr, k, false)) return 1;
-        if (plat_d2h(term_grads + (size_t)k * p, E.d_out, sizeof(float) * p, E.stream)) return fail("D2H copy failed");
-        double raw = 0;
-        if (plat_d2h(&raw, E.d_lossraw + k, sizeof(double), E.stream)) return fail("D2H copy failed");
+        if (run_loss_grad(E, E.d_theta, E.hp_out, nullptr, k, false, E.hp_raw)) return 1;
         if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
-        if (term_losses) term_losses[k] = raw / (double)E.terms[k].n_norm;
+        std::memcpy(term_grads + (size_t)k * p, E.hp_out, sizeof(float) * p);
+        if (term_losses) term_losses[k] = E.hp_raw[k] / (double)E.terms[k].n_norm;
     }
     return 0;
 }

@@ -155,7 +155,10 @@ struct pinn_engine {
     int* d_gr_grp = nullptr;
     int* d_gr_ent = nullptr;
     float* d_out = nullptr;          // [P grad | K raw sums]
-    std::vector<float> h_out;
+    // pinned host block of the host entry points: [P floats theta | P + K floats out | K doubles raw sums]
+    float* hp_theta = nullptr;
+    float* hp_out = nullptr;
+    double* hp_raw = nullptr;
     plat_event ev0, ev1, ev2, ev3;
     plat_stream aux_stream[2] = {nullptr, nullptr};     // under-filled launch groups run concurrently (fork/join by events)
     plat_event ev_fork, ev_join[aux::MAX_GROUPS];

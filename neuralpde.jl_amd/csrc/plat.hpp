@@ -15,6 +15,8 @@ inline int plat_init(std::string&) { return 0; }
 // poison fresh allocations (0xFF.. = NaN) so that reads of never-written device memory fail the CPU tests
 inline void* plat_malloc(size_t n) { void* p = std::malloc(n ? n : 1); if (p) std::memset(p, 0xFF, n ? n : 1); return p; }
 inline void plat_free(void* p) { std::free(p); }
+inline void* plat_host_alloc(size_t n) { return plat_malloc(n); }
+inline void plat_host_free(void* p) { std::free(p); }
 inline int plat_h2d(void* d, const void* s, size_t n, plat_stream) { std::memcpy(d, s, n); return 0; }
 inline int plat_d2h(void* d, const void* s, size_t n, plat_stream) { std::memcpy(d, s, n); return 0; }
 inline int plat_d2d(void* d, const void* s, size_t n, plat_stream) { std::memcpy(d, s, n); return 0; }
@@ -51,6 +53,13 @@ inline void* plat_malloc(size_t n) {
     return p;
 }
 inline void plat_free(void* p) { if (p) (void)hipFree(p); }
+// pinned, device-mapped, coherent host memory: kernels write results straight into it (no copy command on the host path)
+inline void* plat_host_alloc(size_t n) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, n ? n : 4, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return nullptr;
+    return p;
+}
+inline void plat_host_free(void* p) { if (p) (void)hipHostFree(p); }
 inline int plat_h2d(void* d, const void* s, size_t n, plat_stream st) { return hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, st) != hipSuccess; }
 inline int plat_d2h(void* d, const void* s, size_t n, plat_stream st) { return hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, st) != hipSuccess; }
 inline int plat_d2d(void* d, const void* s, size_t n, plat_stream st) { return hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, st) != hipSuccess; }
