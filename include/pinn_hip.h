@@ -103,6 +103,8 @@ int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float*
  *   pinn_set_sampler : kind 1 = redraw the term's points uniformly in [lb, ub] on the device before every step
  *                      (StochasticTraining, src/training_strategies.jl:242-245, 277-281); kind 2 = Latin-hypercube redraw
  *                      (QuasiRandomTraining with its default LatinHypercubeSample and resampling = true, :321, 375-381);
+ *                      kind 3 = Sobol' design (QuasiRandomTraining with SobolSample: Gray-code sequence, Joe-Kuo direction numbers,
+ *                      first element skipped as in Sobol.jl; seed 0 = the plain sequence on every draw, otherwise a fresh digital shift per draw);
  *                      kind 0 = keep the installed set.
  *   pinn_adam_init   : upload theta (P floats), zero the moments.
  *   pinn_adam_steps  : nsteps updates m = b1 m + (1-b1) g, v = b2 v + (1-b2) g^2, theta -= lr m^/(sqrt(v^) + eps);

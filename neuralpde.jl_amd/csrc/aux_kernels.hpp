@@ -181,6 +181,45 @@ AUX_DEV void sample_lhs_body(int e, float* pts, int d, int n, const float* lb, c
     pts[e] = lb[i] + (ub[i] - lb[i]) * u;
 }
 
+// Sobol' redraw (QuasiRandomTraining(points; sampling_alg = SobolSample()), [3P] QuasiMonteCarlo.jl / Sobol.jl, used by the reference's
+// deterministic tests, e.g. test/NNPDE1/nnpde__pde_vi_pde_with_mixed_derivative.jl:78-80).  Point p of the design is element p + 1
+// of the Gray-code (Antonov-Saleev) Sobol' sequence — the all-zero first element is skipped as Sobol.jl does — with the
+// Joe-Kuo direction numbers ("new-joe-kuo-6", the table Sobol.jl and scipy.stats.qmc share) of axes 1..8, regenerated from the
+// primitive polynomial (degree s, coefficients a) and initial values m by the standard recurrence, so no table lives in memory.
+// seed = 0: the plain sequence on every draw = what the reference's un-randomised SobolSample returns on every call; seed != 0:
+// every draw applies a fresh per-axis digital shift keyed by (seed, draw counter) — a randomisation that keeps the net property.
+AUX_DEV unsigned sobol_bits(unsigned index, int axis) {
+    // degree | coefficient bits | up to five initial m values, 4 bits each (values 1..17 need 5 bits for the last one: kept apart)
+    const int S[8] = {0, 1, 2, 3, 3, 4, 4, 5};
+    const int A[8] = {0, 0, 1, 1, 2, 1, 4, 2};
+    const int M[8][5] = {{0, 0, 0, 0, 0}, {1, 0, 0, 0, 0}, {1, 3, 0, 0, 0}, {1, 3, 1, 0, 0}, {1, 1, 1, 0, 0}, {1, 1, 3, 3, 0}, {1, 3, 5, 13, 0}, {1, 1, 5, 5, 17}};
+    const unsigned gray = index ^ (index >> 1);
+    const int s = S[axis], a = A[axis];
+    unsigned m[5] = {0, 0, 0, 0, 0};                    // sliding window m[j-1] .. m[j-s] (newest first)
+    unsigned x = 0;
+    for (int j = 1; j <= 32 && (gray >> (j - 1)) != 0u; ++j) {
+        unsigned mj;
+        if (axis == 0) mj = 1u;
+        else if (j <= s) mj = (unsigned)M[axis][j - 1];
+        else {
+            mj = m[s - 1] ^ (m[s - 1] << s);
+            for (int k = 1; k < s; ++k)
+                if ((a >> (s - 1 - k)) & 1) mj ^= m[k - 1] << k;
+        }
+        for (int k = 4; k > 0; --k) m[k] = m[k - 1];
+        m[0] = mj;
+        if ((gray >> (j - 1)) & 1u) x ^= mj << (32 - j);
+    }
+    return x;
+}
+AUX_DEV void sample_sobol_body(int e, float* pts, int d, const float* lb, const float* ub, unsigned seed, unsigned draw) {
+    const int i = e % d, p = e / d;
+    unsigned x = sobol_bits((unsigned)p + 1u, i);
+    if (seed != 0u) x ^= mix32(seed ^ (draw * 0x85EBCA6BU + 0xC2B2AE35U) ^ ((unsigned)i * 0x27D4EB2FU));
+    const float u = (float)(x >> 8) * (1.0f / 16777216.0f);        // exact for the plain sequence while n < 2^24
+    pts[e] = lb[i] + (ub[i] - lb[i]) * u;
+}
+
 AUX_DEV void pack_body(int i, float* packed, const int* idx, const float* theta) {
     const int j = idx[i];
     packed[i] = (j >= 0) ? theta[j] : 0.f;
@@ -262,7 +301,8 @@ inline void launch_total_loss(double* hist, int step, const float* out, int P, i
 }
 inline void launch_sample(int kind, float* pts, int n_elems, int d, const float* lb, const float* ub, unsigned seed, unsigned draw, plat_stream) {
     for (int e = 0; e < n_elems; ++e) {
-        if (kind == 2) sample_lhs_body(e, pts, d, n_elems / d, lb, ub, seed, draw);
+        if (kind == 3) sample_sobol_body(e, pts, d, lb, ub, seed, draw);
+        else if (kind == 2) sample_lhs_body(e, pts, d, n_elems / d, lb, ub, seed, draw);
         else sample_body(e, pts, d, lb, ub, seed, draw);
     }
 }
@@ -318,6 +358,10 @@ __global__ void k_sample_lhs(float* pts, int n_elems, int d, const float* lb, co
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < n_elems) sample_lhs_body(e, pts, d, n_elems / d, lb, ub, seed, draw);
 }
+__global__ void k_sample_sobol(float* pts, int n_elems, int d, const float* lb, const float* ub, unsigned seed, unsigned draw) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_elems) sample_sobol_body(e, pts, d, lb, ub, seed, draw);
+}
 inline void launch_adam(float* theta, float* m, float* v, const float* grad, int P, float lr, float b1, float b2, float eps, float c1, float c2, plat_stream st) {
     hipLaunchKernelGGL(k_adam, dim3((P + 255) / 256), dim3(256), 0, st, theta, m, v, grad, P, lr, b1, b2, eps, c1, c2);
 }
@@ -325,7 +369,8 @@ inline void launch_total_loss(double* hist, int step, const float* out, int P, i
     hipLaunchKernelGGL(k_total_loss, dim3(1), dim3(64), 0, st, hist, step, out, P, K, w_over_n);
 }
 inline void launch_sample(int kind, float* pts, int n_elems, int d, const float* lb, const float* ub, unsigned seed, unsigned draw, plat_stream st) {
-    if (kind == 2) hipLaunchKernelGGL(k_sample_lhs, dim3((n_elems + 255) / 256), dim3(256), 0, st, pts, n_elems, d, lb, ub, seed, draw);
+    if (kind == 3) hipLaunchKernelGGL(k_sample_sobol, dim3((n_elems + 255) / 256), dim3(256), 0, st, pts, n_elems, d, lb, ub, seed, draw);
+    else if (kind == 2) hipLaunchKernelGGL(k_sample_lhs, dim3((n_elems + 255) / 256), dim3(256), 0, st, pts, n_elems, d, lb, ub, seed, draw);
     else hipLaunchKernelGGL(k_sample, dim3((n_elems + 255) / 256), dim3(256), 0, st, pts, n_elems, d, lb, ub, seed, draw);
 }
 __global__ void __launch_bounds__(256) k_expr(const ExprArgs a) {

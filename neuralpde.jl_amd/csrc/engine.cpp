@@ -504,7 +504,8 @@ int pinn_set_sampler(pinn_handle h, int term, int kind, const float* lb, const f
     pinn_engine& E = *h;
     if (term < 0 || term >= (int)E.terms.size()) return fail("pinn_set_sampler: term index out of range");
     Term& T = E.terms[term];
-    if (kind < 0 || kind > 2) return fail("pinn_set_sampler: kind must be 0 (fixed set), 1 (uniform) or 2 (Latin hypercube)");
+    if (kind < 0 || kind > 3) return fail("pinn_set_sampler: kind must be 0 (fixed set), 1 (uniform), 2 (Latin hypercube) or 3 (Sobol)");
+    if (kind == 3 && T.d > 8) return fail("pinn_set_sampler: the Sobol sampler covers up to 8 axes");
     T.sampler = kind;
     if (kind == 0) return 0;
     if (!lb || !ub || n <= 0) return fail("pinn_set_sampler: bounds and a positive point count are required");
@@ -513,6 +514,7 @@ int pinn_set_sampler(pinn_handle h, int term, int kind, const float* lb, const f
     plat_h2d(T.d_lb, lb, sizeof(float) * T.d, E.stream);
     plat_h2d(T.d_ub, ub, sizeof(float) * T.d, E.stream);
     T.seed = (unsigned)(seed ^ (seed >> 32)) + 0x9E3779B9U * (unsigned)(term + 1);
+    if (kind == 3 && seed == 0) T.seed = 0;              // un-randomised Sobol: the same design on every draw
     T.draws = 0;
     // allocate / size the term's point buffer through the normal path with a first draw
     std::vector<float> tmp((size_t)n * T.d, 0.f);
@@ -729,3 +731,8 @@ int pinn_describe(pinn_handle h, char* buf, int64_t buflen) {
 }
 
 }  // extern "C"
+
+#ifdef PINN_EMU
+// test hook of the emulation build only (never part of libpinn_hip.so): the device Sobol' bit generator
+extern "C" unsigned pinn_emu_sobol_bits(unsigned index, int axis) { return aux::sobol_bits(index, axis); }
+#endif

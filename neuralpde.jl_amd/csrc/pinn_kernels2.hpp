@@ -84,7 +84,7 @@ struct Spec2 {
     static constexpr int LDS_WG = (CHUNKED ? 2 : 3) * XSZ + LDS_UP;
     // PINN_F2_OCC=3 (experiment): three workgroups per CU where the LDS allows it — the kernel is then compiled for <= 168 VGPRs
     static constexpr int WG_PER_CU = (PINN_F2_OCC >= 3 && LDS_WG * 4 <= 53 * 1024) ? 3 : ((LDS_WG * 4 <= 80 * 1024) ? 2 : 1);
-    static constexpr int OCC = WG_PER_CU > 2 ? WG_PER_CU : 2;            // waves per SIMD the kernel is compiled for
+    static constexpr int OCC = WG_PER_CU;                                // waves per SIMD the kernel is compiled for
     // dW accumulators: resident in registers across tiles when they fit (4x64: 48 registers); for wide/deep nets they
     // are accumulated per tile into this workgroup's slab instead (read-modify-write, L2; same wave owns the same tiles)
 #ifdef PINN_F2_WBAR_SLAB

@@ -506,17 +506,24 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
     rep._weights_now = weights_now
     rep._weights = weights_now()
     # resampling strategies with an on-device counterpart for the resident-theta loop: StochasticTraining (uniform redraw in the
-    # same bounds) and QuasiRandomTraining(resampling = true) with its default LatinHypercubeSample
+    # same bounds) and QuasiRandomTraining(resampling = true) with LatinHypercubeSample (its default) or SobolSample
     from .strategies import LatinHypercubeSample, QuasiRandomTraining, StochasticTraining, get_bounds
     rep._device_samplers = None
-    kind = 1 if isinstance(strategy, StochasticTraining) else (
-        2 if (isinstance(strategy, QuasiRandomTraining) and strategy.resampling and isinstance(strategy.sampling_alg, LatinHypercubeSample)) else 0)
+    from .strategies import SobolSample
+    kind = 0
+    if isinstance(strategy, StochasticTraining):
+        kind = 1
+    elif isinstance(strategy, QuasiRandomTraining) and strategy.resampling:
+        kind = 2 if isinstance(strategy.sampling_alg, LatinHypercubeSample) else (3 if isinstance(strategy.sampling_alg, SobolSample) else 0)
     if kind:
         pb, bb = get_bounds(pde_system.domain, eqs, bcs, np.float64, vi, strategy.points)
         rng = getattr(strategy, "rng", None) or np.random.default_rng()
         rep._device_samplers = {}
         for k, (lb, ub) in enumerate(list(pb) + list(bb)):
-            rep._device_samplers[k] = (lb, ub, strategy.points if k < n_pde else strategy.bcs_points, int(rng.integers(1 << 31)), kind)
+            seed = int(rng.integers(1, 1 << 31))
+            if kind == 3 and not strategy.sampling_alg.scramble:
+                seed = 0                                    # un-randomised Sobol: the same design on every draw, as in the reference
+            rep._device_samplers[k] = (lb, ub, strategy.points if k < n_pde else strategy.bcs_points, seed, kind)
     rep._state = state
     rep._pde_system, rep._vi = pde_system, vi
     return rep

@@ -264,6 +264,76 @@ def test_resident_adam_matches_host_adam_and_sampler(npde, use_emu):
     assert not np.array_equal(np.argsort(draws[0][0]), np.argsort(draws[0][1]))      # axes are permuted independently
 
 
+def test_device_sobol_sampler_matches_reference_sequence(npde, use_emu):
+    """kind-3 device sampler == elements 1..n of the un-randomised Sobol' sequence (Joe-Kuo direction numbers, Gray-code order,
+    first element skipped as Sobol.jl does): bit-exact against scipy.stats.qmc.Sobol(scramble=False), which shares the table;
+    with a seed every draw is a fresh digital shift of the same net."""
+    from scipy.stats import qmc
+    sysm, chain = poisson2d(npde)
+    th0 = theta_for(chain, 52)
+    strat = npde.QuasiRandomTraining(256, bcs_points=64, sampling_alg=npde.SobolSample(scramble=False))
+    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th0))
+    res = npde.solve(prob, npde.Adam(0.01), maxiters=3)
+    rep = prob.pinnrep
+    assert np.all(np.isfinite(res.losses)) and rep._device_samplers[0][4] == 3 and rep._device_samplers[0][3] == 0
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = qmc.Sobol(2, scramble=False).random(257)[1:].T
+    lb, ub = rep._device_samplers[0][0], rep._device_samplers[0][1]
+    want = (np.float32(lb)[:, None] + (np.float32(ub) - np.float32(lb))[:, None] * ref.astype(np.float32)).astype(np.float32)
+    got = rep.engine.get_points(0, 2, 256)
+    assert np.array_equal(got, want)                      # same design on every draw (3 Adam steps = 3 draws)
+    # boundary term u(0, y): the pinned axis stays at its constant, the free one follows its own axis of the sequence
+    pb = rep.engine.get_points(1, 2, 64)
+    assert np.all(pb[0] == 0.0) and len(np.unique(pb[1])) == 64
+    # engine level, d = 4 .. 8 axes (a term of a d-input net is needed only for the buffer shape: use the raw entry point on term 0)
+    eng = rep.engine
+    eng.set_sampler(0, [0.0, 0.0], [1.0, 1.0], 1024, seed=0, kind=3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = qmc.Sobol(2, scramble=False).random(1025)[1:].T.astype(np.float32)
+    assert np.array_equal(eng.get_points(0, 2, 1024), ref)
+    # seeded: digitally shifted nets — elements 1..1023 still occupy distinct elementary intervals of length 1/1024 along every
+    # axis (element 1024 stands in for the skipped element 0, so at most one interval is hit twice)
+    eng.set_sampler(0, [0.0, 0.0], [1.0, 1.0], 1024, seed=77, kind=3)
+    a = eng.get_points(0, 2, 1024)
+    assert not np.array_equal(a, ref)
+    for i in range(2):
+        assert len(set(np.floor(a[i].astype(np.float64) * 1024).astype(int))) >= 1023
+
+
+def test_sobol_direction_numbers_up_to_8_axes(npde, use_emu):
+    """all eight supported axes of the device Sobol' sampler against scipy: a 3-input problem through the sampler entry point
+    (axes 1-3), and the bit generator itself for axes 1-8 through the emulation build's test hook."""
+    from scipy.stats import qmc
+    import ctypes, warnings
+    t, x, y = npde.parameters("t x y")
+    (u,) = npde.variables("u")
+    U = u(t, x, y)
+    eq = npde.Eq(npde.Differential(t)(U) + npde.Differential(x)(U) + npde.Differential(y)(U), 0)
+    bcs = [npde.Eq(u(0, x, y), 0)]
+    dom = [npde.In(v, npde.Interval(0.0, 1.0)) for v in (t, x, y)]
+    sysm = npde.PDESystem([eq], bcs, dom, [t, x, y], [U])
+    chain = npde.Chain(npde.Dense(3, 16, "tanh"), npde.Dense(16, 16, "tanh"), npde.Dense(16, 1))
+    th0 = theta_for(chain, 53)
+    strat = npde.QuasiRandomTraining(512, bcs_points=32, sampling_alg=npde.SobolSample(scramble=False))
+    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th0))
+    eng = prob.pinnrep.engine
+    eng.set_sampler(0, [0.0] * 3, [1.0] * 3, 512, seed=0, kind=3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = qmc.Sobol(3, scramble=False).random(513)[1:].T.astype(np.float32)
+        ref8 = qmc.Sobol(8, scramble=False, bits=32).random(4097)[1:]
+    assert np.array_equal(eng.get_points(0, 3, 512), ref)
+    hook = getattr(eng.L.lib, "pinn_emu_sobol_bits", None)
+    if hook is not None:                                  # emulation build only
+        hook.restype, hook.argtypes = ctypes.c_uint, [ctypes.c_uint, ctypes.c_int]
+        for axis in range(8):
+            got = np.array([hook(i + 1, axis) for i in range(4096)], dtype=np.float64) / 2.0 ** 32
+            assert np.array_equal(got, ref8[:, axis]), axis
+
+
 def test_hoisted_sources_and_mixed_ops(npde, use_emu):
     """coordinate-only subexpressions (variable coefficients, source terms, boundary data) are evaluated by k_src once per
     point set; what stays in the fused tape mixes dispatch-free arithmetic with transcendental ops of u."""
