@@ -36,6 +36,7 @@ struct Reduce2Args {
     const int* row_ent;                 // slab-entry index (within its group) of every contribution
     const double* tmp[MAX_GROUPS];
     int stride[MAX_GROUPS], nsplit[MAX_GROUPS], nent[MAX_GROUPS], active[MAX_GROUPS];
+    int ent_active[MAX_GROUPS];         // 0: this group's gradient went into another group's slabs (chained launch groups)
     int ngroups, P, K;
 };
 
@@ -177,7 +178,13 @@ AUX_DEV void sample_lhs_body(int e, float* pts, int d, int n, const float* lb, c
     const unsigned stratum = lhs_perm((unsigned)p, (unsigned)n, key);
     unsigned h = mix32((unsigned)e * 0x9E3779B9U + seed);
     h = mix32(h ^ (draw * 0xC2B2AE3DU + 0x165667B1U));
-    const float u = ((float)stratum + (float)(h >> 8) * (1.0f / 16777216.0f)) / (float)n;
+    // stratum and in-stratum position are combined as integers (24 significant bits in total) so that the float sum can never
+    // round up into the next stratum
+    unsigned bits = 1;
+    while ((1u << bits) < (unsigned)n) ++bits;
+    const unsigned k = bits < 24u ? 24u - bits : 0u;
+    const unsigned fixed = (stratum << k) | (k ? (h >> (32u - k)) : 0u);
+    const float u = (float)fixed / ((float)n * (float)(1u << k));
     pts[e] = lb[i] + (ub[i] - lb[i]) * u;
 }
 
@@ -266,7 +273,7 @@ AUX_DEV void reduce2_body(int r, const Reduce2Args& a) {
         double s = 0.0;
         for (int i = a.row_ptr[r]; i < a.row_ptr[r + 1]; ++i) {
             const int g = a.row_grp[i];
-            if (!a.active[g]) continue;
+            if (!a.ent_active[g]) continue;
             const double* t = a.tmp[g] + (size_t)a.row_ent[i] * a.nsplit[g];
             AUX_UNROLL8
             for (int ch = 0; ch < a.nsplit[g]; ++ch) s += t[ch];

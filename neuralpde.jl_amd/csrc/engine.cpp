@@ -129,6 +129,7 @@ int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const floa
     // opt-in: on this stack a cross-stream event wait costs 15-20 us, more than the overlap buys (profiles/r01 timeline)
     static const bool want_concurrent = std::getenv("PINN_CONCURRENT_GROUPS") != nullptr;
     const bool concurrent = want_concurrent && nfused_active >= 2 && all_small;
+    static const bool no_chain = std::getenv("PINN_NO_CHAIN") != nullptr;      // A/B switch
     int nforked = 0;
     if (concurrent) plat_event_record(E.ev_fork, E.stream);
     for (size_t g = 0; g < E.groups.size(); ++g) {
@@ -140,9 +141,17 @@ int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const floa
         }
         G.active = any;
         const int nsplit = std::min(REDUCE_SPLIT, G.blocks);
+        // chained launch groups: this group's workgroups add their sums onto the slabs the head group (same network, launched
+        // earlier on the same stream in this evaluation) has just written, so the reduction reads one slab set, not two
+        const bool chained = any && !no_chain && !concurrent && G.kind == 0 && G.chain_to >= 0 && E.groups[G.chain_to].active &&
+                             G.blocks <= E.groups[G.chain_to].blocks;
+        const int nent = chained ? 0 : G.nent;
+        G.ga.slabs = chained ? E.groups[G.chain_to].d_slabs : G.d_slabs;
+        G.ga.chain = chained ? 1 : 0;
         a1.tmp[g] = G.d_tmp; a1.slabs[g] = G.d_slabs; a1.losspart[g] = G.d_losspart;
-        a1.slab[g] = G.spec->SLAB; a1.nblocks[g] = G.blocks; a1.nsplit[g] = nsplit; a1.nent[g] = G.nent; a1.active[g] = any;
-        a2.tmp[g] = G.d_tmp; a2.stride[g] = G.nent + K; a2.nsplit[g] = nsplit; a2.nent[g] = G.nent; a2.active[g] = any;
+        a1.slab[g] = G.spec->SLAB; a1.nblocks[g] = G.blocks; a1.nsplit[g] = nsplit; a1.nent[g] = nent; a1.active[g] = any;
+        a2.tmp[g] = G.d_tmp; a2.stride[g] = nent + K; a2.nsplit[g] = nsplit; a2.nent[g] = nent; a2.active[g] = any;
+        a2.ent_active[g] = any && !chained;
         if (!any) continue;
         max_n1 = std::max(max_n1, G.nent / 4 + K);
         max_split = std::max(max_split, nsplit);
@@ -172,7 +181,7 @@ int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const floa
         const int nsplit = std::min(REDUCE_SPLIT, Cp.blocks);
         a1.tmp[g] = Cp.d_tmp; a1.slabs[g] = Cp.d_pslab; a1.losspart[g] = Cp.d_losspart;
         a1.slab[g] = 16; a1.nblocks[g] = Cp.blocks; a1.nsplit[g] = nsplit; a1.nent[g] = 16; a1.active[g] = on;
-        a2.tmp[g] = Cp.d_tmp; a2.stride[g] = 16 + K; a2.nsplit[g] = nsplit; a2.nent[g] = 16; a2.active[g] = on;
+        a2.tmp[g] = Cp.d_tmp; a2.stride[g] = 16 + K; a2.nsplit[g] = nsplit; a2.nent[g] = 16; a2.active[g] = on; a2.ent_active[g] = on;
         bool groups_active = false;
         for (int gi : Cp.groups) groups_active = groups_active || E.groups[gi].active;
         if (!groups_active) continue;
@@ -717,6 +726,7 @@ int pinn_describe(pinn_handle h, char* buf, int64_t buflen) {
         const Group& G = h->groups[g];
         os << "group " << g << (G.kind == 1 ? (G.use_rec ? " [coupled fwd/gradin, records in HBM]" : " [coupled fwd/gradin]") : "") << " net=" << G.net << " kernel=" << spec_name(*G.spec) << " tiles=" << G.ga.ntiles << " blocks=" << G.blocks << " terms=";
         for (int t : G.terms) os << t << ",";
+        if (G.chain_to >= 0) os << " slabs=" << (G.blocks <= h->groups[G.chain_to].blocks ? "chained onto group " : "own (more workgroups than group ") << G.chain_to << (G.blocks <= h->groups[G.chain_to].blocks ? "" : ")");
         os << "\n";
     }
     for (size_t t = 0; t < h->terms.size(); ++t) {

@@ -105,6 +105,7 @@ struct Group {
     int blocks = 0;
     int max_blocks = 0;
     bool active = false;
+    int chain_to = -1;               // earlier launch group of the same network whose slab set this group may accumulate into
     plat_event ev_a, ev_b;
     bool timed = false;
 };

@@ -210,6 +210,8 @@ struct GroupArgs {
     int nparams;                 // NP rows in the tape
     int nparams_estim;           // first NE params get adjoints
     int act;
+    int chain;                   // family 2: add this launch's gradient onto the slab contents an earlier launch group of the same
+                                 // network left behind (one slab set and one reduction input for several launch groups)
     TermDev terms[MAX_GROUP_TERMS];
 };
 

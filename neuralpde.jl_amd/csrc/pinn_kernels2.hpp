@@ -128,7 +128,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
     PINN_UNROLL for (int l = 0; l < ((S::WBAR_REG && NHH > 0) ? NHH : 1); ++l)
         PINN_UNROLL for (int t = 0; t < MTW; ++t)
             PINN_UNROLL for (int ti = 0; ti < MT; ++ti) wbar[l][t][ti] = vzero4();
-    if (!S::WBAR_REG && BWD)                 // slab-resident dW: this wave's tiles start at zero
+    if (!S::WBAR_REG && BWD && !ga.chain)    // slab-resident dW: this wave's tiles start at zero (or on top of the chained group's sums)
         for (int hl = 0; hl < NHH; ++hl)
             PINN_UNROLL for (int t = 0; t < MTW; ++t)
                 PINN_UNROLL for (int ti = 0; ti < MT; ++ti)
@@ -139,6 +139,29 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
         PINN_UNROLL for (int t = 0; t < MTW; ++t) w1bar[i][t] = vzero4();
     PINN_UNROLL for (int t = 0; t < MTW; ++t) wLbar[t] = vzero4();
     PINN_UNROLL for (int i = 0; i < MAX_PARAMS; ++i) pbar[i] = vfloat(0.f);
+    if (BWD && ga.chain) {
+        // chained launch group: the accumulators continue from the sums an earlier launch group of this network stored in this slab
+        // (same wave, same entries), so one slab set — one reduction input — carries both groups.  Lane c = 0 of a row group holds the
+        // stored value, the other column lanes start at zero: the row sums of the epilogue then include it exactly once.
+        if (S::WBAR_REG)
+            PINN_UNROLL for (int hl = 0; hl < NHH; ++hl)
+                PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                    PINN_UNROLL for (int ti = 0; ti < MT; ++ti)
+                        wbar[hl][t][ti] = gload4(slab + S::O_WBAR, vint((((hl * MT + w * MTW + t) * MT + ti) * 64) * 4) + (lane << 2));
+        const vbool c0i = veq(c, 0);
+        PINN_UNROLL for (int t = 0; t < MTW; ++t)
+            PINN_UNROLL for (int r = 0; r < 4; ++r) {
+                const vint n = vint(16 * (w * MTW + t) + r) + (g << 2);
+                PINN_UNROLL for (int l = 0; l < LH; ++l) bbar[l][t][r] = gload_masked(slab + S::O_BH + l * HP, n, c0i);
+                PINN_UNROLL for (int i = 0; i < D; ++i) w1bar[i][t][r] = gload_masked(slab + S::O_W1 + i * HP, n, c0i);
+                wLbar[t][r] = gload_masked(slab + S::O_WL, n, c0i);
+            }
+        if (w == 0) {
+            const vbool l0 = veq(lane, 0);
+            bLbar = gload_masked(slab + S::O_BL, lane & vint(0), l0);
+            PINN_UNROLL for (int j = 0; j < MAX_PARAMS; ++j) pbar[j] = gload_masked(slab + S::O_P, vint(j) + (lane & vint(0)), l0);
+        }
+    }
     vfloat lsum = vfloat(0.f);
     int cur_term = -1;
 

@@ -572,9 +572,30 @@ static int plan_global_reduce_map(pinn_engine& E) {
     return 0;
 }
 
+// fused launch groups of the same network with the same slab layout (e.g. the interior group and the boundary group of one PINN)
+// can share one slab set: the later group's workgroups add their sums onto what the earlier group stored (GroupArgs::chain), and the
+// reduction reads one set instead of two.  Decided per evaluation in run_loss_grad (the head must have been launched, and must
+// have at least as many workgroups); here: which earlier group is a compatible head.
+static int plan_chain_groups(pinn_engine& E) {
+    for (size_t g = 0; g < E.groups.size(); ++g) {
+        Group& G = E.groups[g];
+        G.chain_to = -1;
+        if (G.kind != 0 || G.spec->family != 2) continue;
+        for (size_t h = 0; h < g; ++h) {
+            const Group& H = E.groups[h];
+            if (H.kind != 0 || H.spec->family != 2 || H.chain_to >= 0 || H.net != G.net) continue;
+            if (H.spec->SLAB != G.spec->SLAB || H.nent != G.nent || H.max_blocks < G.max_blocks) continue;
+            if (H.row_theta != G.row_theta || H.row_ptr != G.row_ptr || H.row_off != G.row_off) continue;
+            G.chain_to = (int)h;
+            break;
+        }
+    }
+    return 0;
+}
+
 int build_plan(pinn_engine& E) {
     if (plan_check_nets(E) || plan_assign_terms(E) || plan_pack_maps(E) || plan_group_buffers(E) || plan_coupled_programs(E) ||
-        plan_global_reduce_map(E))
+        plan_chain_groups(E) || plan_global_reduce_map(E))
         return 1;
     return 0;
 }

@@ -74,6 +74,24 @@ def test_cfg2_4x64_small_ragged(npde, use_emu):
     check(npde, wl.pde_system, wl.chains, wl.strategy, wl.theta)
 
 
+def test_chained_launch_groups_share_one_slab_set(npde, use_emu):
+    """interior + boundary launch groups of one 4x64 network: the boundary group's workgroups add onto the interior group's slabs
+    (one reduction input); per-term gradients (head group not launched) fall back to the group's own slabs; both vs the oracle."""
+    from neuralpde_jl_amd import workloads
+    wl = workloads.cfg2_poisson2d(points=70, bcs_points=30)      # 5 interior tiles / 4 boundary tiles on 4 emulated workgroup slots
+    w = np.array([1.0, 2.0, 0.5, 3.0, 1.5])
+    rep, _, _, th = check(npde, wl.pde_system, wl.chains, wl.strategy, wl.theta, weights=list(w))
+    assert "chained onto group 0" in rep.engine.describe()
+    losses, grad = rep.engine.loss_grad(th, list(w))
+    tl, tg = rep.engine.term_grads(th)                    # one evaluation per term: groups run alone
+    np.testing.assert_allclose((w[:, None] * tg).sum(axis=0), grad, rtol=0, atol=2e-6 * np.abs(grad).max())
+    np.testing.assert_allclose(tl, losses, rtol=1e-6)
+    # more boundary workgroups than interior ones: not chained, same answers
+    wl2 = workloads.cfg2_poisson2d(points=20, bcs_points=70)
+    rep2, *_ = check(npde, wl2.pde_system, wl2.chains, wl2.strategy, wl2.theta)
+    assert "own (more workgroups than group 0)" in rep2.engine.describe()
+
+
 def test_cfg3_burgers_4x64_small(npde, use_emu):
     from neuralpde_jl_amd import workloads
     wl = workloads.cfg3_burgers(points=40, bcs_points=30)

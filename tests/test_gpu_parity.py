@@ -216,6 +216,43 @@ def test_training_converges_resident_adam(npde, hip_lib):
     assert res.losses[-1] < res.losses[0] / 50 and err1 < 0.02 and err1 < err0 / 3
 
 
+def test_device_samplers_gpu(npde, hip_lib):
+    """k_sample_sobol on the GPU == elements 1..n of scipy's un-randomised Sobol' sequence, bit for bit (axes 1-2 through the
+    Poisson problem, n = 65,536); Latin-hypercube and uniform redraws stay inside their bounds and stratify."""
+    import sympy as sp
+    import warnings
+    from scipy.stats import qmc
+    x, y = npde.parameters("x y")
+    (u,) = npde.variables("u")
+    Dxx, Dyy = npde.Differential(x) ** 2, npde.Differential(y) ** 2
+    eq = npde.Eq(Dxx(u(x, y)) + Dyy(u(x, y)), -sp.sin(sp.pi * x) * sp.sin(sp.pi * y))
+    bcs = [npde.Eq(u(0, y), 0.0), npde.Eq(u(1, y), 0.0), npde.Eq(u(x, 0), 0.0), npde.Eq(u(x, 1), 0.0)]
+    dom = [npde.In(x, npde.Interval(0.0, 1.0)), npde.In(y, npde.Interval(0.0, 1.0))]
+    sysm = npde.PDESystem([eq], bcs, dom, [x, y], [u(x, y)])
+    chain = npde.Chain(npde.Dense(2, 16, "tanh"), npde.Dense(16, 16, "tanh"), npde.Dense(16, 1))
+    th0 = npde.initialparameters(np.random.default_rng(0), chain)
+    strat = npde.QuasiRandomTraining(65536, bcs_points=1024, sampling_alg=npde.SobolSample(scramble=False))
+    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th0))
+    eng = prob.pinnrep.engine
+    assert eng.L.backend == "hip"
+    n = 65536
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = qmc.Sobol(2, scramble=False).random(n + 1)[1:].T.astype(np.float32)
+    eng.set_sampler(0, [0.0, 0.0], [1.0, 1.0], n, seed=0, kind=3)
+    assert np.array_equal(eng.get_points(0, 2, n), ref)
+    eng.set_sampler(0, [0.0, 0.0], [1.0, 1.0], n, seed=9, kind=2)          # Latin hypercube
+    p = eng.get_points(0, 2, n).astype(np.float64)
+    for i in range(2):
+        assert sorted(np.floor(p[i] * n).astype(int).clip(0, n - 1)) == list(range(n))
+    eng.set_sampler(0, [0.25, -1.0], [0.5, 3.0], n, seed=9, kind=1)         # uniform
+    p = eng.get_points(0, 2, n)
+    assert p[0].min() >= 0.25 and p[0].max() <= 0.5 and p[1].min() >= -1.0 and p[1].max() <= 3.0
+    assert abs(p[1].mean() - 1.0) < 0.05
+    res = npde.solve(prob, npde.Adam(0.01), maxiters=20)                     # Sobol design drawn on the device every iteration
+    assert np.all(np.isfinite(res.losses)) and res.losses[-1] < res.losses[0]
+
+
 def test_higher_order_derivatives_gpu(npde, hip_lib):
     """pure third / fourth derivative jets on the hardware: the reference's 3rd-order ODE set-up, a 4th-order 1-D problem and the
     Kuramoto-Sivashinsky jet set (family 1 sigmoid 2x12 and family 2 tanh 4x64), against the oracle's exact derivatives
