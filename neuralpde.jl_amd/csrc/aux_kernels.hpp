@@ -26,6 +26,7 @@ struct Reduce1Args {
     const float* slabs[MAX_GROUPS];     // [nblocks][slab]
     const double* losspart[MAX_GROUPS]; // [nblocks*4][K]
     int slab[MAX_GROUPS], nblocks[MAX_GROUPS], nsplit[MAX_GROUPS], nent[MAX_GROUPS], active[MAX_GROUPS];
+    int nwpb[MAX_GROUPS];               // waves per workgroup (rows of losspart per block)
     int K;
 };
 struct Reduce2Args {
@@ -264,7 +265,7 @@ AUX_DEV void reduce1_body(int e4, int chunk, int g, const Reduce1Args& a) {
         const double* p = a.losspart[g] + k;
         double s = 0.0;
         AUX_UNROLL8
-        for (int wv = b0 * 4; wv < b1 * 4; ++wv) s += p[(size_t)wv * a.K];
+        for (int wv = b0 * a.nwpb[g]; wv < b1 * a.nwpb[g]; ++wv) s += p[(size_t)wv * a.K];
         out[(size_t)(a.nent[g] + k) * ns] = s;
     }
 }

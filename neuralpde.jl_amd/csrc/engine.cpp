@@ -149,7 +149,7 @@ int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const floa
         G.ga.slabs = chained ? E.groups[G.chain_to].d_slabs : G.d_slabs;
         G.ga.chain = chained ? 1 : 0;
         a1.tmp[g] = G.d_tmp; a1.slabs[g] = G.d_slabs; a1.losspart[g] = G.d_losspart;
-        a1.slab[g] = G.spec->SLAB; a1.nblocks[g] = G.blocks; a1.nsplit[g] = nsplit; a1.nent[g] = nent; a1.active[g] = any;
+        a1.slab[g] = G.spec->SLAB; a1.nblocks[g] = G.blocks; a1.nsplit[g] = nsplit; a1.nent[g] = nent; a1.active[g] = any; a1.nwpb[g] = G.spec->NW;
         a2.tmp[g] = G.d_tmp; a2.stride[g] = nent + K; a2.nsplit[g] = nsplit; a2.nent[g] = nent; a2.active[g] = any;
         a2.ent_active[g] = any && !chained;
         if (!any) continue;
@@ -180,7 +180,7 @@ int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const floa
         const bool on = (only_term < 0 || only_term == Cp.term);
         const int nsplit = std::min(REDUCE_SPLIT, Cp.blocks);
         a1.tmp[g] = Cp.d_tmp; a1.slabs[g] = Cp.d_pslab; a1.losspart[g] = Cp.d_losspart;
-        a1.slab[g] = 16; a1.nblocks[g] = Cp.blocks; a1.nsplit[g] = nsplit; a1.nent[g] = 16; a1.active[g] = on;
+        a1.slab[g] = 16; a1.nblocks[g] = Cp.blocks; a1.nsplit[g] = nsplit; a1.nent[g] = 16; a1.active[g] = on; a1.nwpb[g] = 4;
         a2.tmp[g] = Cp.d_tmp; a2.stride[g] = 16 + K; a2.nsplit[g] = nsplit; a2.nent[g] = 16; a2.active[g] = on; a2.ent_active[g] = on;
         bool groups_active = false;
         for (int gi : Cp.groups) groups_active = groups_active || E.groups[gi].active;

@@ -26,6 +26,11 @@
 #define STAMP_EXTRA 0
 #endif
 
+// waves per workgroup of the H = 128 kernels: 8 => two waves per SIMD share one workgroup's LDS tiles (each owns HALF the neuron
+// tiles a wave of a 4-wave workgroup would own, so its register state fits 256 VGPRs); 4 => one wave per SIMD with 512 registers
+#ifndef PINN_F2_WAVES128
+#define PINN_F2_WAVES128 8
+#endif
 #ifndef PINN_F2_OCC
 #define PINN_F2_OCC 2
 #endif
@@ -40,8 +45,12 @@ struct Spec2 {
     static constexpr int HP = HP_, MT = HP_ / 16, NHH = NHH_, LH = NHH_ + 1, D = D_, NPAIR = NPAIR_, PG = PG_;
     static constexpr unsigned D1MASK = D1MASK_;
     static constexpr unsigned long long PAIRS = PAIRS_;
-    static constexpr int MTW = MT / 4;                 // neuron tiles per wave
-    static_assert(MT % 4 == 0, "family 2 needs a hidden width that is a multiple of 64");
+    // waves per workgroup: 8 where the workgroup's LDS tiles (3 x NG x MT KB) leave room for only one workgroup per CU anyway and
+    // a wave's state for NG <= 4 column groups fits 256 registers (measured: cfg4 44.5 -> 39.0 ms; with NG = 6 the 8-wave
+    // build of the cfg5 kernel spills 800 B/lane and is 4 % slower than the 4-wave, 512-register build)
+    static constexpr int NW = (HP_ >= 128 && 3 * (J::C * PG_) * (HP_ / 16) * 1024 > 76 * 1024 && J::C * PG_ <= 4) ? PINN_F2_WAVES128 : 4;
+    static constexpr int MTW = MT / NW;                // neuron tiles per wave
+    static_assert(MT % NW == 0 && MT % 4 == 0, "family 2 needs a hidden width that is a multiple of 64 (16 x waves per workgroup)");
     static constexpr int NFIRST = J::NFIRST;
     static constexpr int C = J::C;
     static constexpr int NG = C * PG_;
@@ -72,19 +81,19 @@ struct Spec2 {
     static constexpr int REC = (LH - 1) * NG * MT * 256;
     // LDS (floats): X0 | X1 (activation / dZ exchange, A^T) | ZT (4 x private dZ^T) | output partials | coords
     static constexpr int XSZ = NG * MT * 256;
-    static constexpr int LDS_UP = ((5 * NG * 16 + 63) / 64) * 64;    // 4 x output partials + seed broadcast (UB)
+    static constexpr int LDS_UP = (((NW + 1) * NG * 16 + 63) / 64) * 64;    // NW x output partials + seed broadcast (UB)
     static_assert(PG_ >= 1 && PG_ <= 4, "one tape wave per point group");
     // when X0 | X1 | ZT would not fit in 160 KiB (H = 128 with 8 jet channels) the dW operands are staged one column group
     // at a time in a double buffer carved out of X1: [A^T chunk 16 x HP | 4 x dZ^T chunk]
     static constexpr bool CHUNKED = (3 * XSZ + LDS_UP) * 4 > 160 * 1024;
     static constexpr int CH_AT = 16 * HP_;
     static constexpr int CH_ZT = MTW * 256;
-    static constexpr int CHSZ = CH_AT + 4 * CH_ZT;
+    static constexpr int CHSZ = CH_AT + NW * CH_ZT;
     static_assert(!CHUNKED || 2 * CHSZ <= XSZ, "chunk double buffer must fit inside X1");
     static constexpr int LDS_WG = (CHUNKED ? 2 : 3) * XSZ + LDS_UP;
     // PINN_F2_OCC=3 (experiment): three workgroups per CU where the LDS allows it — the kernel is then compiled for <= 168 VGPRs
     static constexpr int WG_PER_CU = (PINN_F2_OCC >= 3 && LDS_WG * 4 <= 53 * 1024) ? 3 : ((LDS_WG * 4 <= 80 * 1024) ? 2 : 1);
-    static constexpr int OCC = WG_PER_CU;                                // waves per SIMD the kernel is compiled for
+    static constexpr int OCC = WG_PER_CU * NW / 4;                       // waves per SIMD the kernel is compiled for
     // dW accumulators: resident in registers across tiles when they fit (4x64: 48 registers); for wide/deep nets they
     // are accumulated per tile into this workgroup's slab instead (read-modify-write, L2; same wave owns the same tiles)
 #ifdef PINN_F2_WBAR_SLAB
@@ -103,7 +112,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
     constexpr bool RECOUT = (MODE == MODE_FWDREC), RECIN = (MODE == MODE_GRADREC);
     constexpr bool IS_FWD = (MODE == MODE_FWD || MODE == MODE_FWDREC), IS_GRADIN = (MODE == MODE_GRADIN || MODE == MODE_GRADREC);
     constexpr bool WPRE = (MT * MTW * 4 <= 16);        // prefetch a layer's weight fragments when they take <= 16 registers (H = 64)
-    const int wave = blk * 4 + w;
+    const int wave = blk * S::NW + w;
     const vint lane = lane_id();
     const vint g = lane >> 4;
     const vint c = lane & vint(15);
@@ -310,7 +319,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                 PINN_UNROLL for (int ch = 0; ch < C; ++ch) {
                     vfloat s = vfloat(0.f);
-                    PINN_UNROLL for (int ws = 0; ws < 4; ++ws) s = s + lds_load(UP, vint((ws * NG + pg * C + ch) * 16) + c);
+                    PINN_UNROLL for (int ws = 0; ws < S::NW; ++ws) s = s + lds_load(UP, vint((ws * NG + pg * C + ch) * 16) + c);
                     U[pg][ch] = (ch == 0) ? s + vfloat(bL) : s;
                 }
         } else {
@@ -372,7 +381,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                 PINN_UNROLL for (int ch = 0; ch < C; ++ch) ubar[pg][ch] = gload_masked(T.in, vint(ch * T.N) + p, valid[pg]);
             }
         } else {
-            float* UB = UP + 4 * NG * 16;
+            float* UB = UP + S::NW * NG * 16;
             if (w < PG) {
                 wave_prio(3);                       // the other waves of the workgroup wait for this one
                 vfloat xin[D], Uin[C];
@@ -690,7 +699,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
     // PDE-parameter gradients: the tape waves' partial sums meet in wave 0 (fixed order)
     static_assert(4 * MAX_PARAMS <= 16, "UB holds the per-wave parameter partials");
     const vbool all = vlt(lane, 64);
-    float* UBp = UP + 4 * NG * 16;
+    float* UBp = UP + S::NW * NG * 16;
     if (w > 0 && w < PG)
         PINN_UNROLL for (int j = 0; j < MAX_PARAMS; ++j)
             lds_store(UBp, vint(w * MAX_PARAMS + j) + (lane & vint(0)), vfloat((float)wave_sum_d(pbar[j], all)));

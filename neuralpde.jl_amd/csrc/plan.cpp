@@ -373,7 +373,7 @@ static int plan_group_buffers(pinn_engine& E) {
         G.max_blocks = E.ncu * ((wg_cap > 0 && wg_cap < s.WG_PER_CU) ? wg_cap : s.WG_PER_CU);
         plat_event_create(G.ev_a);
         plat_event_create(G.ev_b);
-        const size_t nw = (size_t)G.max_blocks * 4;
+        const size_t nw = (size_t)G.max_blocks * s.NW;
         G.d_slabs = (float*)plat_malloc(sizeof(float) * (size_t)G.max_blocks * s.SLAB);
         G.d_losspart = (double*)plat_malloc(sizeof(double) * nw * total_terms);
         G.d_scratch = (float*)plat_malloc(sizeof(float) * (s.family == 2 ? (size_t)G.max_blocks : nw) * s.SCR);

@@ -14,6 +14,7 @@ namespace pk {
 struct SpecInfo {
     int family;                      // 1: one wave per tile (pinn_kernels.hpp); 2: neuron-split workgroups (pinn_kernels2.hpp)
     int WG_PER_CU;
+    int NW;                          // waves per workgroup (family 1: 4 independent waves; family 2: 4, or 8 at H = 128)
     int HP, NHH, D;
     unsigned D1MASK;
     unsigned long long PAIRS;
@@ -34,7 +35,7 @@ template <class S>
 SpecInfo make_info(void (*launch)(const GroupArgs&, int, int, plat_stream), int has_sin = 0) {
     SpecInfo s;
     s.has_sin = has_sin;
-    s.family = 1; s.WG_PER_CU = 1;
+    s.family = 1; s.WG_PER_CU = 1; s.NW = 4;
     s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR; s.HI = S::HI & 0xFFFFFFu; s.LAP = S::J::LAP;
     s.PG = S::PG; s.C = S::C; s.NG = S::NG; s.TP = S::TP; s.MT = S::MT; s.LH = S::LH; s.NFIRST = S::NFIRST;
     s.PACKED = S::PACKED; s.SLAB = S::SLAB; s.SCR = S::SCR; s.LDS_WG = S::LDS_WG; s.COOP = S::COOP ? 1 : 0; s.SH = S::SH; s.PW = S::PW;
@@ -50,7 +51,7 @@ template <class S>
 SpecInfo make_info2(void (*launch)(const GroupArgs&, int, int, plat_stream), int has_sin = 0) {
     SpecInfo s;
     s.has_sin = has_sin;
-    s.family = 2; s.WG_PER_CU = S::WG_PER_CU;
+    s.family = 2; s.WG_PER_CU = S::WG_PER_CU; s.NW = S::NW;
     s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR; s.HI = S::HI & 0xFFFFFFu; s.LAP = S::J::LAP;
     s.PG = S::PG; s.C = S::C; s.NG = S::NG; s.TP = S::TP; s.MT = S::MT; s.LH = S::LH; s.NFIRST = S::NFIRST;
     s.PACKED = S::PACKED; s.SLAB = S::SLAB; s.SCR = S::SCR; s.LDS_WG = S::LDS_WG; s.COOP = 1; s.SH = S::SLAB; s.PW = 0;
@@ -68,12 +69,12 @@ SpecInfo make_info2(void (*launch)(const GroupArgs&, int, int, plat_stream), int
 struct EmuBarrier {
     std::mutex m;
     std::condition_variable cv;
-    int count = 0, gen = 0;
+    int count = 0, gen = 0, nwaves = 4;
     static void wait(void* p) {
         EmuBarrier* b = (EmuBarrier*)p;
         std::unique_lock<std::mutex> lk(b->m);
         const int g = b->gen;
-        if (++b->count == 4) { b->count = 0; ++b->gen; b->cv.notify_all(); }
+        if (++b->count == b->nwaves) { b->count = 0; ++b->gen; b->cv.notify_all(); }
         else b->cv.wait(lk, [&] { return b->gen != g; });
     }
 };
@@ -99,14 +100,15 @@ void run_emu2(const GroupArgs& ga, int blocks) {
     for (int b = 0; b < blocks; ++b) {
         for (auto& v : lds) v = std::nanf("");       // poison: nothing may be read before it is written
         EmuBarrier bar;
-        std::thread th[4];
-        for (int w = 0; w < 4; ++w)
+        bar.nwaves = S::NW;
+        std::thread th[S::NW];
+        for (int w = 0; w < S::NW; ++w)
             th[w] = std::thread([&, w] {
                 wv::emu_barrier_hook = &EmuBarrier::wait;
                 wv::emu_barrier_ctx = &bar;
                 wave_main2<S, MODE, SINACT>(ga, b, blocks, w, lds.data());
             });
-        for (int w = 0; w < 4; ++w) th[w].join();
+        for (int w = 0; w < S::NW; ++w) th[w].join();
     }
 }
 #define PINN_LAUNCH2(S, MODE, SINACT, ga, blocks, st) run_emu2<S, MODE, SINACT>(ga, blocks)
@@ -121,14 +123,15 @@ __global__ void __launch_bounds__(256, 1) k_wave(const GroupArgs ga) {
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     wave_main<S, MODE, SINACT>(ga, (int)blockIdx.x, (int)gridDim.x, w, lds_all);
 }
-// family 2: __launch_bounds__(256, 2) => at most 256 VGPR+AGPR per lane, two workgroups (8 waves) resident per CU
+// family 2: two waves per SIMD => at most 256 VGPR+AGPR per lane: two 4-wave workgroups per CU (H = 64), or one 8-wave workgroup
+// (H = 128: LDS 100-150 KB per workgroup)
 template <class S, int MODE, bool SINACT>
-__global__ void __launch_bounds__(256, S::OCC) k_wave2(const GroupArgs ga) {
+__global__ void __launch_bounds__(64 * S::NW, S::OCC) k_wave2(const GroupArgs ga) {
     __shared__ __attribute__((aligned(16))) float lds_all[S::LDS_WG];
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     wave_main2<S, MODE, SINACT>(ga, (int)blockIdx.x, (int)gridDim.x, w, lds_all);
 }
-#define PINN_LAUNCH2(S, MODE, SINACT, ga, blocks, st) hipLaunchKernelGGL((k_wave2<S, MODE, SINACT>), dim3(blocks), dim3(256), 0, st, ga)
+#define PINN_LAUNCH2(S, MODE, SINACT, ga, blocks, st) hipLaunchKernelGGL((k_wave2<S, MODE, SINACT>), dim3(blocks), dim3(64 * S::NW), 0, st, ga)
 #define PINN_LAUNCH1(S, MODE, SINACT, ga, blocks, st) hipLaunchKernelGGL((k_wave<S, MODE, SINACT>), dim3(blocks), dim3(256), 0, st, ga)
 #endif
 

@@ -11,6 +11,8 @@ npde = pinn_import.load()
 from neuralpde_jl_amd import workloads
 from bench import algorithmic_flops_per_point, PEAK_FP32_MFMA_TFLOPS
 
+if os.environ.get("PINN_AB_LIB"):            # A/B runs: time another build of the library (tools/ab_compare.py convention)
+    npde._lib.set_library(npde.Library(os.environ["PINN_AB_LIB"]))
 scale = float(os.environ.get("SCALE", "1.0"))
 cfgs = [("cfg1", workloads.cfg1_poisson1d, dict(points=1024)),
         ("cfg2", workloads.cfg2_poisson2d, dict(points=65536)),
