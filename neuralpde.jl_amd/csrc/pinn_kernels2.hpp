@@ -31,6 +31,12 @@
 #ifndef PINN_F2_WAVES128
 #define PINN_F2_WAVES128 8
 #endif
+#ifndef PINN_F2_NW8_MAXNG
+#define PINN_F2_NW8_MAXNG 4
+#endif
+#ifndef PINN_F2_SPRE_MAX
+#define PINN_F2_SPRE_MAX 24
+#endif
 #ifndef PINN_F2_OCC
 #define PINN_F2_OCC 2
 #endif
@@ -48,7 +54,7 @@ struct Spec2 {
     // waves per workgroup: 8 where the workgroup's LDS tiles (3 x NG x MT KB) leave room for only one workgroup per CU anyway and
     // a wave's state for NG <= 4 column groups fits 256 registers (measured: cfg4 44.5 -> 39.0 ms; with NG = 6 the 8-wave
     // build of the cfg5 kernel spills 800 B/lane and is 4 % slower than the 4-wave, 512-register build)
-    static constexpr int NW = (HP_ >= 128 && 3 * (J::C * PG_) * (HP_ / 16) * 1024 > 76 * 1024 && J::C * PG_ <= 4) ? PINN_F2_WAVES128 : 4;
+    static constexpr int NW = (HP_ >= 128 && 3 * (J::C * PG_) * (HP_ / 16) * 1024 > 76 * 1024 && J::C * PG_ <= PINN_F2_NW8_MAXNG) ? PINN_F2_WAVES128 : 4;
     static constexpr int MTW = MT / NW;                // neuron tiles per wave
     static_assert(MT % NW == 0 && MT % 4 == 0, "family 2 needs a hidden width that is a multiple of 64 (16 x waves per workgroup)");
     static constexpr int NFIRST = J::NFIRST;
@@ -484,7 +490,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
         };
 
         // records parked in the scratch slab are requested one phase before they are needed (SPRE: when they take <= 24 registers)
-        constexpr bool SPRE = (NG * MTW * 4 <= 24);
+        constexpr bool SPRE = (NG * MTW * 4 <= PINN_F2_SPRE_MAX);
         vfloat4 Snext[SPRE ? NG : 1][SPRE ? MTW : 1];
         auto load_record = [&](int hl) {                                     // record of hidden layer hl (1 <= hl <= LH-2)
             PINN_UNROLL for (int q = 0; q < NG; ++q)
