@@ -30,3 +30,37 @@ def rel_errors(losses, grad, ref):
     g2 = np.linalg.norm(g - ref.grad) / np.linalg.norm(ref.grad)
     gi = np.max(np.abs(g - ref.grad)) / np.max(np.abs(ref.grad))
     return le, g2, gi
+
+
+def shape_problem(npde, width, hidden, d):
+    """A PDE with mixed second derivatives on a d-input net of `hidden` hidden layers of `width` (shape-grid parity tests)."""
+    import sympy as sp
+    act = "tanh" if (width + hidden) % 2 else "sigmoid"
+    if d == 1:
+        (x,) = npde.parameters("x")
+        (u,) = npde.variables("u")
+        U = u(x)
+        eqs = [npde.Eq((npde.Differential(x) ** 2)(U) + 0.5 * npde.Differential(x)(U), -sp.pi ** 2 * sp.sin(sp.pi * x))]
+        bcs = [npde.Eq(u(0), 0.0), npde.Eq(u(1), 0.0)]
+        iv = [x]
+    elif d == 2:
+        x, y = npde.parameters("x y")
+        (u,) = npde.variables("u")
+        U = u(x, y)
+        Dx, Dy = npde.Differential(x), npde.Differential(y)
+        eqs = [npde.Eq((Dx ** 2)(U) + (Dy ** 2)(U) + 0.5 * Dx(Dy(U)) - U * Dx(U), -sp.sin(sp.pi * x) * sp.sin(sp.pi * y))]
+        bcs = [npde.Eq(u(0, y), 0.0), npde.Eq(u(x, 1), sp.sin(x))]
+        iv = [x, y]
+    else:
+        t, x, y = npde.parameters("t x y")
+        (u,) = npde.variables("u")
+        U = u(t, x, y)
+        Dt, Dx, Dy = npde.Differential(t), npde.Differential(x), npde.Differential(y)
+        eqs = [npde.Eq(Dt(U), (Dx ** 2)(U) + (Dy ** 2)(U) + 0.3 * Dx(Dy(U)) + 0.1 * Dt(Dx(U)))]
+        bcs = [npde.Eq(u(0, x, y), sp.sin(sp.pi * x) * sp.sin(sp.pi * y)), npde.Eq(u(t, 0, y), 0.0)]
+        iv = [t, x, y]
+    dom = [npde.In(v, npde.Interval(0.0, 1.0)) for v in iv]
+    sysm = npde.PDESystem(eqs, bcs, dom, iv, [U])
+    layers = [npde.Dense(d, width, act)] + [npde.Dense(width, width, act) for _ in range(hidden - 1)] + [npde.Dense(width, 1)]
+    chain = npde.Chain(*layers)
+    return sysm, chain

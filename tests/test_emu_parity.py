@@ -92,6 +92,20 @@ def test_chained_launch_groups_share_one_slab_set(npde, use_emu):
     assert "own (more workgroups than group 0)" in rep2.engine.describe()
 
 
+@pytest.mark.parametrize("width,hidden,d", [(10, 3, 1), (7, 1, 1), (16, 3, 2), (25, 2, 2), (32, 1, 2), (20, 3, 2), (8, 1, 3), (12, 3, 3),
+                                            (25, 3, 3), (18, 2, 3), (30, 1, 3), (25, 1, 1), (18, 2, 1),
+                                            (40, 2, 2), (50, 3, 2), (40, 2, 1), (64, 4, 1), (48, 3, 3), (33, 2, 3), (40, 4, 3)])
+def test_small_net_shape_grid(npde, use_emu, width, hidden, d):
+    """the widths / depths / input counts of the reference's own test nets (4..32 wide, 1-3 hidden layers, 1-3 inputs): value-only and
+    full-Hessian kernels exist for every such shape (inst_h16_*.hip, inst_h32_*.hip), and for widths 33..64 with 2-4 hidden layers on
+    the neuron-split kernels (inst2_h64_*.hip); residuals with mixed second derivatives."""
+    sysm, chain = helpers.shape_problem(npde, width, hidden, d)
+    strat = npde.QuasiRandomTraining(40, bcs_points=20, sampling_alg=npde.SobolSample(seed=width + hidden), resampling=False, minibatch=1)
+    # exact-derivative oracle mode: with mixed third-order-total stencils (D_t D_x) the FD oracle's own truncation error reaches 5e-5
+    # on some of these random nets, the engine's derivatives are exact
+    check(npde, sysm, [chain], strat, theta_for(chain, 100 + width + 10 * hidden + d), mode="exact")
+
+
 def test_cfg3_burgers_4x64_small(npde, use_emu):
     from neuralpde_jl_amd import workloads
     wl = workloads.cfg3_burgers(points=40, bcs_points=30)

@@ -253,6 +253,24 @@ def test_device_samplers_gpu(npde, hip_lib):
     assert np.all(np.isfinite(res.losses)) and res.losses[-1] < res.losses[0]
 
 
+@pytest.mark.parametrize("width,hidden,d", [(10, 3, 1), (16, 3, 2), (25, 2, 2), (12, 3, 3), (25, 3, 3), (30, 1, 3),
+                                            (40, 2, 2), (50, 3, 2), (64, 4, 1), (48, 3, 3), (40, 4, 3)])
+def test_small_net_shape_grid_gpu(npde, hip_lib, width, hidden, d):
+    """the reference's test-suite net shapes (4..64 wide, 1-4 hidden layers, 1-3 inputs) on the HIP kernels, incl. the full-Hessian jet
+    sets of 3-input nets (10 channels): loss and gradient vs the float64 oracle (exact-derivative mode) at 1e-5."""
+    sysm, chain = helpers.shape_problem(npde, width, hidden, d)
+    strat = npde.QuasiRandomTraining(700, bcs_points=300, sampling_alg=npde.SobolSample(seed=width + hidden), resampling=False, minibatch=1)
+    th = po.glorot_theta(po.Chain(tuple(chain.sizes), chain.act), np.random.default_rng(100 + width + 10 * hidden + d))
+    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th))
+    assert rep.engine.L.backend == "hip"
+    sets = rep.pde_train_sets + rep.bcs_train_sets
+    losses, grad = rep.engine.loss_grad(rep.flat_init_params)
+    prob = helpers.oracle_problem(npde, sysm, [chain])
+    ref = po.loss_and_grad(prob, rep.flat_init_params, sets, mode="exact")
+    le, g2, gi = helpers.rel_errors(losses, grad, ref)
+    assert le.max() < TOL and g2 < TOL and gi < TOL, (le, g2, gi)
+
+
 def test_higher_order_derivatives_gpu(npde, hip_lib):
     """pure third / fourth derivative jets on the hardware: the reference's 3rd-order ODE set-up, a 4th-order 1-D problem and the
     Kuramoto-Sivashinsky jet set (family 1 sigmoid 2x12 and family 2 tanh 4x64), against the oracle's exact derivatives
