@@ -271,6 +271,26 @@ def test_small_net_shape_grid_gpu(npde, hip_lib, width, hidden, d):
     assert le.max() < TOL and g2 < TOL and gi < TOL, (le, g2, gi)
 
 
+@pytest.mark.parametrize("which", ["cfg2", "cfg3", "cfg4_64", "cfg4_128", "cfg5"])
+def test_bit_reproducibility(npde, hip_lib, which):
+    """fixed theta + fixed points => bit-identical losses and gradient on every call (SURVEY 8b "Determinism": BFGS/LBFGS callers need a
+    fixed objective): six repeated evaluations per configuration, every kernel family / launch mode (fused, chained slab sets, coupled
+    forward-with-records + reverse launches, 4- and 8-wave workgroups)."""
+    from neuralpde_jl_amd import workloads
+    wl = {"cfg2": lambda: workloads.cfg2_poisson2d(points=8192),
+          "cfg3": lambda: workloads.cfg3_burgers(points=6000, bcs_points=3000),
+          "cfg4_64": lambda: workloads.cfg4_cavity(points=3000, bcs_points=400, width=64, hidden=4),
+          "cfg4_128": lambda: workloads.cfg4_cavity(points=3000, bcs_points=400, width=128, hidden=5),
+          "cfg5": lambda: workloads.cfg5_heat_inverse(points=4000, bcs_points=500)}[which]()
+    rep = npde.symbolic_discretize(wl.pde_system, wl.discretization())
+    th = rep.flat_init_params
+    l0, g0 = rep.engine.loss_grad(th)
+    assert np.all(np.isfinite(g0))
+    for _ in range(6):
+        l, g = rep.engine.loss_grad(th)
+        assert np.array_equal(l, l0) and np.array_equal(g, g0), int(np.sum(g != g0))
+
+
 def test_higher_order_derivatives_gpu(npde, hip_lib):
     """pure third / fourth derivative jets on the hardware: the reference's 3rd-order ODE set-up, a 4th-order 1-D problem and the
     Kuramoto-Sivashinsky jet set (family 1 sigmoid 2x12 and family 2 tanh 4x64), against the oracle's exact derivatives
