@@ -269,6 +269,9 @@ def test_small_net_shape_grid_gpu(npde, hip_lib, width, hidden, d):
     ref = po.loss_and_grad(prob, rep.flat_init_params, sets, mode="exact")
     le, g2, gi = helpers.rel_errors(losses, grad, ref)
     assert le.max() < TOL and g2 < TOL and gi < TOL, (le, g2, gi)
+    for _ in range(3):                                   # bit-reproducible
+        l2, gr2 = rep.engine.loss_grad(rep.flat_init_params)
+        assert np.array_equal(l2, losses) and np.array_equal(gr2, grad)
 
 
 @pytest.mark.parametrize("which", ["cfg2", "cfg3", "cfg4_64", "cfg4_128", "cfg5"])
