@@ -54,7 +54,7 @@ struct Spec2 {
     // waves per workgroup: 8 where the workgroup's LDS tiles (3 x NG x MT KB) leave room for only one workgroup per CU anyway and
     // a wave's state for NG <= 4 column groups fits 256 registers (measured: cfg4 44.5 -> 39.0 ms; with NG = 6 the 8-wave
     // build of the cfg5 kernel spills 800 B/lane and is 4 % slower than the 4-wave, 512-register build)
-    static constexpr int NW = (HP_ >= 128 && 3 * (J::C * PG_) * (HP_ / 16) * 1024 > 76 * 1024 && J::C * PG_ <= PINN_F2_NW8_MAXNG) ? PINN_F2_WAVES128 : 4;
+    static constexpr int NW = (HP_ >= 128 && J::C * PG_ <= PINN_F2_NW8_MAXNG) ? PINN_F2_WAVES128 : 4;
     static constexpr int MTW = MT / NW;                // neuron tiles per wave
     static_assert(MT % NW == 0 && MT % 4 == 0, "family 2 needs a hidden width that is a multiple of 64 (16 x waves per workgroup)");
     static constexpr int NFIRST = J::NFIRST;
@@ -98,7 +98,7 @@ struct Spec2 {
     static_assert(!CHUNKED || 2 * CHSZ <= XSZ, "chunk double buffer must fit inside X1");
     static constexpr int LDS_WG = (CHUNKED ? 2 : 3) * XSZ + LDS_UP;
     // PINN_F2_OCC=3 (experiment): three workgroups per CU where the LDS allows it — the kernel is then compiled for <= 168 VGPRs
-    static constexpr int WG_PER_CU = (PINN_F2_OCC >= 3 && LDS_WG * 4 <= 53 * 1024) ? 3 : ((LDS_WG * 4 <= 80 * 1024) ? 2 : 1);
+    static constexpr int WG_PER_CU = (NW == 8) ? 1 : ((PINN_F2_OCC >= 3 && LDS_WG * 4 <= 53 * 1024) ? 3 : ((LDS_WG * 4 <= 80 * 1024) ? 2 : 1));
     static constexpr int OCC = WG_PER_CU * NW / 4;                       // waves per SIMD the kernel is compiled for
     // dW accumulators: resident in registers across tiles when they fit (4x64: 48 registers); for wide/deep nets they
     // are accumulated per tile into this workgroup's slab instead (read-modify-write, L2; same wave owns the same tiles)
