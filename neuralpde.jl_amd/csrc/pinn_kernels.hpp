@@ -364,7 +364,7 @@ DEV vint tr_addr(vint col, vint slot) {
 // All four waves of a workgroup run the same number of tile iterations (tiles past the end are fully masked
 // dummies) because the COOP dW phase synchronises them with workgroup barriers.
 // ------------------------------------------------------------------------------------------------
-template <class S, int MODE, bool SINACT>
+template <class S, int MODE, int ACTK>
 DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_wg) {
     const int wave = blk * 4 + w;
     float* lds = lds_wg + S::LDS_SHARED + w * S::LDS_PRIV;     // wave-private LDS
@@ -380,7 +380,10 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
     const vint c = lane & vint(15);
     const vbool g0 = veq(g, 0);
     const float* P = ga.packed;
-    const int act = ga.act;                 // tanh / sigmoid at run time; sin is the compile-time SINACT variant
+    // the activation kind is a template parameter: every kernel is straight-line code behind its GEMMs (no activation branches for the
+    // optimiser to hoist); sin variants are compiled only for the specs registered with PINN_INSTANTIATE*_SIN
+    constexpr int act = ACTK;
+    constexpr bool SINACT = (ACTK == ACT_SIN);
 
     // ---- persistent per-wave gradient accumulators (registers / AGPRs across all tiles) ----
     vfloat4 wbar[NHH > 0 ? NHH : 1][WT][MT];      // COOP: this wave's row block (to == w) only

@@ -109,7 +109,7 @@ struct Spec2 {
 #endif
 };
 
-template <class S, int MODE, bool SINACT>
+template <class S, int MODE, int ACTK>
 DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds) {
     constexpr int HP = S::HP, MT = S::MT, MTW = S::MTW, NHH = S::NHH, LH = S::LH, D = S::D, C = S::C, PG = S::PG, NG = S::NG;
     constexpr int NFIRST = S::NFIRST;
@@ -124,7 +124,10 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
     const vint c = lane & vint(15);
     const vbool g0 = veq(g, 0);
     const float* P = ga.packed;
-    const int act = ga.act;                 // tanh / sigmoid at run time; sin is the compile-time SINACT variant
+    // the activation kind is a template parameter: every kernel is straight-line code behind its GEMMs (no activation branches for the
+    // optimiser to hoist); sin variants are compiled only for the specs registered with PINN_INSTANTIATE*_SIN
+    constexpr int act = ACTK;
+    constexpr bool SINACT = (ACTK == ACT_SIN);
     const ubuf PB = ub_make(P, S::PACKED);
     const ubuf SB = ub_make(ga.scratch + (size_t)blk * S::SCR, S::SCR);
     float* X0 = lds;

@@ -78,7 +78,7 @@ struct EmuBarrier {
         else b->cv.wait(lk, [&] { return b->gen != g; });
     }
 };
-template <class S, int MODE, bool SINACT>
+template <class S, int MODE, int ACTK>
 void run_emu(const GroupArgs& ga, int blocks) {
     std::vector<float> lds((size_t)S::LDS_WG);
     for (int b = 0; b < blocks; ++b) {
@@ -89,12 +89,12 @@ void run_emu(const GroupArgs& ga, int blocks) {
             th[w] = std::thread([&, w] {
                 wv::emu_barrier_hook = &EmuBarrier::wait;
                 wv::emu_barrier_ctx = &bar;
-                wave_main<S, MODE, SINACT>(ga, b, blocks, w, lds.data());
+                wave_main<S, MODE, ACTK>(ga, b, blocks, w, lds.data());
             });
         for (int w = 0; w < 4; ++w) th[w].join();
     }
 }
-template <class S, int MODE, bool SINACT>
+template <class S, int MODE, int ACTK>
 void run_emu2(const GroupArgs& ga, int blocks) {
     std::vector<float> lds((size_t)S::LDS_WG);
     for (int b = 0; b < blocks; ++b) {
@@ -106,63 +106,66 @@ void run_emu2(const GroupArgs& ga, int blocks) {
             th[w] = std::thread([&, w] {
                 wv::emu_barrier_hook = &EmuBarrier::wait;
                 wv::emu_barrier_ctx = &bar;
-                wave_main2<S, MODE, SINACT>(ga, b, blocks, w, lds.data());
+                wave_main2<S, MODE, ACTK>(ga, b, blocks, w, lds.data());
             });
         for (int w = 0; w < S::NW; ++w) th[w].join();
     }
 }
-#define PINN_LAUNCH2(S, MODE, SINACT, ga, blocks, st) run_emu2<S, MODE, SINACT>(ga, blocks)
-#define PINN_LAUNCH1(S, MODE, SINACT, ga, blocks, st) run_emu<S, MODE, SINACT>(ga, blocks)
+#define PINN_LAUNCH2(S, MODE, ACTK, ga, blocks, st) run_emu2<S, MODE, ACTK>(ga, blocks)
+#define PINN_LAUNCH1(S, MODE, ACTK, ga, blocks, st) run_emu<S, MODE, ACTK>(ga, blocks)
 #else
 // One workgroup = 4 independent waves (one per SIMD); persistent grid of <= #CU workgroups.
 // __launch_bounds__(256, 1): one wave per SIMD => the full 512-entry unified VGPR/AGPR file per lane
 // is available for the persistent dW accumulators (MI355X_MICROARCH.md "Register files").
-template <class S, int MODE, bool SINACT>
+template <class S, int MODE, int ACTK>
 __global__ void __launch_bounds__(256, 1) k_wave(const GroupArgs ga) {
     __shared__ __attribute__((aligned(16))) float lds_all[S::LDS_WG];
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    wave_main<S, MODE, SINACT>(ga, (int)blockIdx.x, (int)gridDim.x, w, lds_all);
+    wave_main<S, MODE, ACTK>(ga, (int)blockIdx.x, (int)gridDim.x, w, lds_all);
 }
 // family 2: two waves per SIMD => at most 256 VGPR+AGPR per lane: two 4-wave workgroups per CU (H = 64), or one 8-wave workgroup
 // (H = 128: LDS 100-150 KB per workgroup)
-template <class S, int MODE, bool SINACT>
+template <class S, int MODE, int ACTK>
 __global__ void __launch_bounds__(64 * S::NW, S::OCC) k_wave2(const GroupArgs ga) {
     __shared__ __attribute__((aligned(16))) float lds_all[S::LDS_WG];
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    wave_main2<S, MODE, SINACT>(ga, (int)blockIdx.x, (int)gridDim.x, w, lds_all);
+    wave_main2<S, MODE, ACTK>(ga, (int)blockIdx.x, (int)gridDim.x, w, lds_all);
 }
-#define PINN_LAUNCH2(S, MODE, SINACT, ga, blocks, st) hipLaunchKernelGGL((k_wave2<S, MODE, SINACT>), dim3(blocks), dim3(64 * S::NW), 0, st, ga)
-#define PINN_LAUNCH1(S, MODE, SINACT, ga, blocks, st) hipLaunchKernelGGL((k_wave<S, MODE, SINACT>), dim3(blocks), dim3(256), 0, st, ga)
+#define PINN_LAUNCH2(S, MODE, ACTK, ga, blocks, st) hipLaunchKernelGGL((k_wave2<S, MODE, ACTK>), dim3(blocks), dim3(64 * S::NW), 0, st, ga)
+#define PINN_LAUNCH1(S, MODE, ACTK, ga, blocks, st) hipLaunchKernelGGL((k_wave<S, MODE, ACTK>), dim3(blocks), dim3(256), 0, st, ga)
 #endif
 
-// The activation kind is a runtime field of the launch (tanh / sigmoid share one kernel); sin gets kernels of its own
-// (SINACT = true: sincos in every jet rule would bloat the common kernels past the instruction cache), compiled only for the
-// specs registered with PINN_INSTANTIATE*_SIN.
-template <class S, bool SINACT>
+// The activation kind is a template parameter of the kernels (ACTK): tanh and sigmoid variants for every spec; sin variants (sincos in
+// every jet rule) only for the specs registered with PINN_INSTANTIATE*_SIN.  The launch picks the variant from GroupArgs::act.
+template <class S, int ACTK>
 void launch_modes2(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
     (void)st;
-    if (mode == MODE_FUSED) PINN_LAUNCH2(S, MODE_FUSED, SINACT, ga, blocks, st);
-    else if (mode == MODE_RESID) PINN_LAUNCH2(S, MODE_RESID, SINACT, ga, blocks, st);
-    else if (mode == MODE_GRADIN) PINN_LAUNCH2(S, MODE_GRADIN, SINACT, ga, blocks, st);
-    else if (mode == MODE_FWDREC) PINN_LAUNCH2(S, MODE_FWDREC, SINACT, ga, blocks, st);
-    else if (mode == MODE_GRADREC) PINN_LAUNCH2(S, MODE_GRADREC, SINACT, ga, blocks, st);
-    else PINN_LAUNCH2(S, MODE_FWD, SINACT, ga, blocks, st);
+    if (mode == MODE_FUSED) PINN_LAUNCH2(S, MODE_FUSED, ACTK, ga, blocks, st);
+    else if (mode == MODE_RESID) PINN_LAUNCH2(S, MODE_RESID, ACTK, ga, blocks, st);
+    else if (mode == MODE_GRADIN) PINN_LAUNCH2(S, MODE_GRADIN, ACTK, ga, blocks, st);
+    else if (mode == MODE_FWDREC) PINN_LAUNCH2(S, MODE_FWDREC, ACTK, ga, blocks, st);
+    else if (mode == MODE_GRADREC) PINN_LAUNCH2(S, MODE_GRADREC, ACTK, ga, blocks, st);
+    else PINN_LAUNCH2(S, MODE_FWD, ACTK, ga, blocks, st);
 }
-template <class S, bool SINACT>
+template <class S, int ACTK>
 void launch_modes1(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
     (void)st;
-    if (mode == MODE_FUSED) PINN_LAUNCH1(S, MODE_FUSED, SINACT, ga, blocks, st);
-    else if (mode == MODE_RESID) PINN_LAUNCH1(S, MODE_RESID, SINACT, ga, blocks, st);
-    else if (mode == MODE_GRADIN) PINN_LAUNCH1(S, MODE_GRADIN, SINACT, ga, blocks, st);
-    else PINN_LAUNCH1(S, MODE_FWD, SINACT, ga, blocks, st);
+    if (mode == MODE_FUSED) PINN_LAUNCH1(S, MODE_FUSED, ACTK, ga, blocks, st);
+    else if (mode == MODE_RESID) PINN_LAUNCH1(S, MODE_RESID, ACTK, ga, blocks, st);
+    else if (mode == MODE_GRADIN) PINN_LAUNCH1(S, MODE_GRADIN, ACTK, ga, blocks, st);
+    else PINN_LAUNCH1(S, MODE_FWD, ACTK, ga, blocks, st);
 }
-template <class S> void launch_spec2(const GroupArgs& ga, int mode, int blocks, plat_stream st) { launch_modes2<S, false>(ga, mode, blocks, st); }
-template <class S> void launch_spec(const GroupArgs& ga, int mode, int blocks, plat_stream st) { launch_modes1<S, false>(ga, mode, blocks, st); }
+template <class S> void launch_spec2(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
+    if (ga.act == ACT_TANH) launch_modes2<S, ACT_TANH>(ga, mode, blocks, st); else launch_modes2<S, ACT_SIGMOID>(ga, mode, blocks, st);
+}
+template <class S> void launch_spec(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
+    if (ga.act == ACT_TANH) launch_modes1<S, ACT_TANH>(ga, mode, blocks, st); else launch_modes1<S, ACT_SIGMOID>(ga, mode, blocks, st);
+}
 template <class S> void launch_spec2_sin(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
-    if (ga.act == ACT_SIN) launch_modes2<S, true>(ga, mode, blocks, st); else launch_modes2<S, false>(ga, mode, blocks, st);
+    if (ga.act == ACT_SIN) launch_modes2<S, ACT_SIN>(ga, mode, blocks, st); else launch_spec2<S>(ga, mode, blocks, st);
 }
 template <class S> void launch_spec_sin(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
-    if (ga.act == ACT_SIN) launch_modes1<S, true>(ga, mode, blocks, st); else launch_modes1<S, false>(ga, mode, blocks, st);
+    if (ga.act == ACT_SIN) launch_modes1<S, ACT_SIN>(ga, mode, blocks, st); else launch_spec<S>(ga, mode, blocks, st);
 }
 
 struct Registrar {
