@@ -259,6 +259,11 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
         // =========================== forward ===========================
         vfloat4 A[NG][MTW];
         vfloat U[PG][C];
+        constexpr int SRC_PRE = 2;                     // source channels requested one phase ahead of the tape (the rest at tape time)
+        vfloat srcv[SRC_PRE];
+        PINN_UNROLL for (int j = 0; j < SRC_PRE; ++j) srcv[j] = vfloat(0.f);
+        vbool valid_w = valid[0];
+        PINN_UNROLL for (int pg = 1; pg < PG; ++pg) if (w == pg) valid_w = valid[pg];
         if (!RECIN) {
             PINN_UNROLL for (int t = 0; t < MTW; ++t) {                          // hidden layer 0: d -> HP on the VALU
                 const int n0 = 16 * (w * MTW + t);
@@ -314,6 +319,12 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                 act_forward(A, hl + 1);
                 STAMP(3)
             }
+            // the tape waves request their hoisted source channels now: the latency hides under the output layer + its barrier
+            // instead of sitting in the serialised tape phase (registers are held for one short phase only)
+            if (MODE == MODE_FUSED || MODE == MODE_RESID)
+                if (w < PG)
+                    PINN_UNROLL for (int j = 0; j < SRC_PRE; ++j)
+                        if (j < T.nsrc) srcv[j] = gload_masked(T.src, vint(j * T.N + pbase + 16 * w) + c, valid_w);
             // output layer HP -> 1: per-wave partial dot over its neurons, summed across the 4 waves through LDS
             {
                 PINN_UNROLL for (int q = 0; q < NG; ++q) {
@@ -416,8 +427,12 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                 }
                 for (int j = 0; j < NP; ++j) tape_set(tv, DT + j, vfloat(ga.params[j]));
                 PINN_UNROLL for (int ch = 0; ch < C; ++ch) tape_set(tv, DT + NP + ch, Uin[ch]);
-                for (int j = 0; j < T.nsrc; ++j)
-                    tape_set(tv, DT + NP + C + j, gload_masked(T.src, vint(j * T.N + pbase + 16 * w) + c, vin));
+                for (int j = 0; j < T.nsrc; ++j) {
+                    vfloat sv;
+                    if (j < SRC_PRE) { PINN_UNROLL for (int jj = 0; jj < SRC_PRE; ++jj) if (jj == j) sv = srcv[jj]; }
+                    else sv = gload_masked(T.src, vint(j * T.N + pbase + 16 * w) + c, vin);
+                    tape_set(tv, DT + NP + C + j, sv);
+                }
                 for (int q = 0; q < T.nops; ++q) {
                     const rp::Instr ins = rp::fetch_uniform(prog, q);
                     const vfloat va = tape_get(tv, ins.a), vb = tape_get(tv, ins.b);      // unused operands point at row 0
