@@ -78,9 +78,9 @@ def cpu_baseline(npde, wl_small, sets_small, budget_s=14.0):
                       f"workload; Julia/NeuralPDE.jl itself is not installable here (no network)"}
 
 
-# HBM-side bytes per launch of the dominant kernel from the PMC passes in profiles/r01_pmc_summary_v10.txt
+# HBM-side bytes per launch of the dominant kernel from the PMC passes in profiles/r01_pmc_summary_v11.txt
 # (2 x FETCH_SIZE [gfx950 wide-read correction] + WRITE_SIZE, KB -> bytes); only valid for the default workload size.
-PMC_TRAFFIC_BYTES = {65536: (2 * 10880.1 + 78593.5) * 1024}    # profiles/r01_pmc_summary_v10.txt
+PMC_TRAFFIC_BYTES = {65536: (2 * 10862.5 + 77600.1) * 1024}    # profiles/r01_pmc_summary_v11.txt
 
 
 def main():
@@ -233,7 +233,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": PMC_TRAFFIC_BYTES.get(n_int) if world == 1 else None,
-                         "traffic_note": "HBM bytes/launch from separate rocprofv3 --pmc passes (profiles/r01_pmc_summary_v10.txt); "
+                         "traffic_note": "HBM bytes/launch from separate rocprofv3 --pmc passes (profiles/r01_pmc_summary_v11.txt); "
                                          "algorithmic bytes are 8 B/point = 0.5 MB/launch, the rest is the workgroup-private activation-record scratch (L2/Infinity-Cache resident, 16 MB footprint) and the gradient slabs",
                          "kernel": "k_wave2<Spec2<64,3,2,F=xy,LAP=xy>,FUSED> (interior residual+grad, neuron-split workgroups, C=4 executed jet channels)",
                          "kernel_ms": dom_ms, "points_per_launch": groups[dom]["points"],

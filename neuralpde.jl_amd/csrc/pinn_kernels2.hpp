@@ -394,12 +394,23 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
         // =========================== residual tape (vector registers) ===========================
         // Wave pg interprets the program for point group pg (ONE copy of the interpreter in the instruction stream) and
         // broadcasts the seeds ubar = dL/d(jet channel) to the other waves through LDS.
+        // records parked in the scratch slab are requested one phase before they are needed (SPRE: when they take <= 24 registers);
+        // the first request (last stored layer) goes out before the wait for the tape waves' seeds
+        constexpr bool SPRE = (NG * MTW * 4 <= PINN_F2_SPRE_MAX);
+        vfloat4 Snext[SPRE ? NG : 1][SPRE ? MTW : 1];
+        auto load_record = [&](int hl) {                                     // record of hidden layer hl (1 <= hl <= LH-2)
+            PINN_UNROLL for (int q = 0; q < NG; ++q)
+                PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                    Snext[q][t] = ub_load4(RECIN ? RB : SB, (((hl - 1) * NG + q) * MT + w * MTW + t) * 256, lane << 2);
+            sched_fence();
+        };
         vfloat ubar[PG][C];
         if (IS_GRADIN) {
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
                 vint p = vint(pbase + 16 * pg) + c;
                 PINN_UNROLL for (int ch = 0; ch < C; ++ch) ubar[pg][ch] = gload_masked(T.in, vint(ch * T.N) + p, valid[pg]);
             }
+            if (SPRE && NHH - 1 >= 1) load_record(NHH - 1);
         } else {
             float* UB = UP + S::NW * NG * 16;
             if (w < PG) {
@@ -473,6 +484,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
             }
             wave_prio(1);
             if (MODE != MODE_RESID) {
+                if (SPRE && NHH - 1 >= 1) load_record(NHH - 1);
                 wg_barrier();                                                   // seeds of every point group are in UB
                 PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                     PINN_UNROLL for (int ch = 0; ch < C; ++ch) ubar[pg][ch] = lds_load(UB, vint((pg * C + ch) * 16) + c);
@@ -507,16 +519,6 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                     }
         };
 
-        // records parked in the scratch slab are requested one phase before they are needed (SPRE: when they take <= 24 registers)
-        constexpr bool SPRE = (NG * MTW * 4 <= PINN_F2_SPRE_MAX);
-        vfloat4 Snext[SPRE ? NG : 1][SPRE ? MTW : 1];
-        auto load_record = [&](int hl) {                                     // record of hidden layer hl (1 <= hl <= LH-2)
-            PINN_UNROLL for (int q = 0; q < NG; ++q)
-                PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                    Snext[q][t] = ub_load4(RECIN ? RB : SB, (((hl - 1) * NG + q) * MT + w * MTW + t) * 256, lane << 2);
-            sched_fence();
-        };
-        if (SPRE && NHH - 1 >= 1) load_record(NHH - 1);
         vfloat4 G[NG][MTW];
         PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {                        // output layer
             if (w == 0) bLbar += vselect(g0, ubar[pg][0], vfloat(0.f));
