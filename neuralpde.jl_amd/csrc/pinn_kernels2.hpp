@@ -1,8 +1,9 @@
 // pinn_kernels2.hpp — "family 2" of the PINN residual/loss kernel: neuron-split workgroups.
 //
 // Same mathematics, same replaced reference code (see pinn_kernels.hpp header) — different mapping onto the CU:
-//   * one workgroup (4 waves) owns one tile of TP = 16*PG points; wave w owns the 16-neuron tiles
-//     {w*MTW .. w*MTW+MTW-1} of EVERY layer (MTW = HP/64), for all NG = C*PG column groups of the tile;
+//   * one workgroup (NW = 4 waves; 8 at H = 128 when a wave's state for NG <= 4 column groups fits 256 registers) owns one tile of
+//     TP = 16*PG points; wave w owns the 16-neuron tiles {w*MTW .. w*MTW+MTW-1} of EVERY layer (MTW = HP/(16 NW)), for all
+//     NG = C*PG column groups of the tile;
 //   * between layers the activation jets are exchanged through LDS in MFMA-B-fragment order
 //     X[column group][neuron tile][lane][4] (ping-pong buffers, one s_barrier per layer); a wave's accumulators are
 //     only NG*MTW vfloat4 (20 registers for the 2-D Poisson interior term) instead of 2 x 80, so the kernel stays under
@@ -10,7 +11,9 @@
 //     hides under the other's MFMA issue (family 1 runs a single 512-register wave per SIMD and overlaps nothing);
 //   * dW rows are naturally wave-owned (its neuron tiles x all inputs): MTW*MT accumulator tiles per layer stay resident
 //     across all tiles of the workgroup; the transposed operands go through LDS: dZ^T wave-private, A^T cooperatively;
-//   * the residual tape runs in vector registers (vtape, VGPR-index mode), redundantly in the four waves.
+//   * the residual tape runs in vector registers (vtape, VGPR-index mode): wave pg interprets it for point group pg and broadcasts the
+//     seeds through LDS;
+//   * the activation kind (tanh / sigmoid / sin) is a template parameter: straight-line code behind every GEMM.
 #pragma once
 #include "pinn_kernels.hpp"
 
