@@ -1,5 +1,6 @@
 // descriptor.cpp — parser of the "pinnir 1" problem descriptor (grammar: DESIGN.md §2).
 #include "engine_types.hpp"
+#include <sstream>
 
 namespace pe {
 
@@ -33,15 +34,39 @@ int parse_descriptor(const char* text, pinn_engine& E) {
         int id, ns;
         std::string act;
         if (!expect("net") || !(in >> id >> act >> E.nets[i].theta_off >> ns) || id != i) return fail("descriptor: net line");
-        if (act == "tanh") E.nets[i].act = pk::ACT_TANH;
-        else if (act == "sigmoid") E.nets[i].act = pk::ACT_SIGMOID;
-        else if (act == "sin") E.nets[i].act = pk::ACT_SIN;
-        else return fail("descriptor: unsupported activation '" + act + "' (supported: tanh, sigmoid, sin)");
+        // one activation for all hidden layers, or a comma-separated list with one entry per hidden layer: tanh and sigmoid may be mixed
+        // (e.g. the reference's Dense(1, n, tanh), Dense(n, n, sigma), Dense(n, 1)); sin only on all layers
+        std::vector<int> kinds;
+        {
+            std::stringstream as(act);
+            std::string tok;
+            while (std::getline(as, tok, ',')) {
+                if (tok == "tanh") kinds.push_back(pk::ACT_TANH);
+                else if (tok == "sigmoid") kinds.push_back(pk::ACT_SIGMOID);
+                else if (tok == "sin") kinds.push_back(pk::ACT_SIN);
+                else return fail("descriptor: unsupported activation '" + tok + "' (supported: tanh, sigmoid, sin)");
+            }
+        }
         E.nets[i].sizes.resize(ns);
         for (int j = 0; j < ns; ++j)
             if (!(in >> E.nets[i].sizes[j])) return fail("descriptor: net sizes");
         if (ns < 3) return fail("descriptor: a chain needs at least one hidden layer");
         if (E.nets[i].sizes.back() != 1) return fail("descriptor: only single-output chains (one per dependent variable) are supported, as in the reference (pinn_types.jl:106-108)");
+        const int nhidden = ns - 2;
+        if (kinds.size() == 1) kinds.assign((size_t)nhidden, kinds[0]);
+        if ((int)kinds.size() != nhidden) return fail("descriptor: the activation list of net " + std::to_string(i) + " needs one entry per hidden layer");
+        bool uniform = true;
+        for (int l = 1; l < nhidden; ++l) uniform = uniform && kinds[l] == kinds[0];
+        E.nets[i].act = kinds[0];
+        E.nets[i].act_layers = 0;
+        if (!uniform) {
+            if (nhidden > 8) return fail("descriptor: per-layer activations cover at most 8 hidden layers");
+            for (int l = 0; l < nhidden; ++l) {
+                if (kinds[l] == pk::ACT_SIN) return fail("descriptor: sin cannot be mixed with other activations inside one chain");
+                E.nets[i].act_layers |= kinds[l] << (4 * l);
+            }
+            E.nets[i].act = pk::ACT_MIXED;
+        }
     }
     int nt = 0;
     if (!expect("terms") || !(in >> nt) || nt < 1) return fail("descriptor: terms");

@@ -473,7 +473,7 @@ int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float*
     if (n <= 0) return fail("pinn_phi: n must be positive");
     const Net& N = E.nets[net];
     const int LH = (int)N.sizes.size() - 2;
-    const pk::SpecInfo* sp = find_spec(round_hp(N.maxhidden()), LH - 1, N.sizes[0], 0, {}, 0u, nullptr, N.act == pk::ACT_SIN);
+    const pk::SpecInfo* sp = find_spec(round_hp(N.maxhidden()), LH - 1, N.sizes[0], 0, {}, 0u, nullptr, variant_of(N.act));
     if (!sp) return fail("pinn_phi: no compiled value-only kernel for this network shape");
     if (!E.netplans[net].spec) return fail("pinn_phi: network is not used by any term");
     if (upload_theta(E, theta, p)) return 1;
@@ -493,6 +493,7 @@ int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float*
     ga.nterms = 1;
     ga.nterms_total = 1;
     ga.act = N.act;
+    ga.act_layers = N.act_layers;
     ga.terms[0].pts = E.d_phi_pts;
     ga.terms[0].dt = N.sizes[0];
     for (int i = 0; i < 4; ++i) ga.terms[0].imap[i] = i;

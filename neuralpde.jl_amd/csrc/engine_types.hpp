@@ -30,7 +30,8 @@ struct Slot {
     unsigned lap = 0;        // != 0: the sum of the pure second derivatives over these axes (one "forward Laplacian" jet channel)
 };
 struct Net {
-    int act;
+    int act;                         // ACT_TANH / ACT_SIGMOID / ACT_SIN on every hidden layer, or ACT_MIXED with
+    int act_layers = 0;              //   the kind of hidden layer l (tanh / sigmoid) in bits 4l .. 4l+3
     int theta_off;
     std::vector<int> sizes;          // n0 .. nL (nL == 1)
     int nparams() const {
@@ -191,7 +192,9 @@ bool fuse_laplacian(Term& T, int np);
 // plan.cpp
 int round_hp(int h);
 const pk::SpecInfo* find_spec(int HP, int NHH, int D, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs,
-                              unsigned need_hi, std::vector<int>* pair_index, bool need_sin = false);
+                              unsigned need_hi, std::vector<int>* pair_index, int need_variant = 0);
+// kernel-variant bit a network's activation needs beyond the tanh / sigmoid kernels every spec has (SpecInfo::has_sin)
+inline int variant_of(int act) { return act == pk::ACT_SIN ? 1 : (act == pk::ACT_MIXED ? 2 : 0); }
 std::string spec_name(const pk::SpecInfo& s);
 int build_plan(pinn_engine& E);
 void retile(pinn_engine& E, int gi);

@@ -2,8 +2,9 @@
 #include "spec_registry.hpp"
 PINN_INSTANTIATE_HI_SIN(h16n1d2_hess, 16, 1, 2, 0x3, (PINN_PAIR(0, 0, 0) | PINN_PAIR(1, 0, 1) | PINN_PAIR(2, 1, 1)), 3, 1, 0u)
 PINN_INSTANTIATE_HI_SIN(h16n1d2_val, 16, 1, 2, 0x0, 0ull, 0, 2, 0u)
-PINN_INSTANTIATE(h16n1d1_lap, 16, 1, 1, 0x1, PINN_PAIR(0, 0, 0), 1, 1)
-PINN_INSTANTIATE(h16n1d1_val, 16, 1, 1, 0x0, 0ull, 0, 2)
+// (+ the per-layer tanh / sigmoid variant: the reference's Lorenz parameter-estimation chains Dense(1, 8, tanh), Dense(8, 8, sigma), Dense(8, 1))
+PINN_INSTANTIATE_HI_MIX(h16n1d1_lap, 16, 1, 1, 0x1, PINN_PAIR(0, 0, 0), 1, 1, 0u)
+PINN_INSTANTIATE_HI_MIX(h16n1d1_val, 16, 1, 1, 0x0, 0ull, 0, 2, 0u)
 // single-hidden-layer nets (e.g. the reference's system-of-PDEs test chains Dense(2,15,tanh) -> Dense(15,1))
 PINN_INSTANTIATE(h16n0d2_hess, 16, 0, 2, 0x3, (PINN_PAIR(0, 0, 0) | PINN_PAIR(1, 0, 1) | PINN_PAIR(2, 1, 1)), 3, 1)
 PINN_INSTANTIATE(h16n0d2_val, 16, 0, 2, 0x0, 0ull, 0, 2)

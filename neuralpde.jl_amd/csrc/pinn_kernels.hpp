@@ -38,7 +38,8 @@ using namespace wv;
 
 // The record of a layer keeps r0 = phi(z) for tanh / sigmoid (their derivatives are polynomials in phi) and r0 = z for sin
 // (cos z cannot be recovered from sin z); act_derivs_n / act_from_record take that r0.
-enum Act : int { ACT_TANH = 0, ACT_SIGMOID = 1, ACT_SIN = 2 };
+enum Act : int { ACT_TANH = 0, ACT_SIGMOID = 1, ACT_SIN = 2,
+                 ACT_MIXED = 3 /* kernel variant only: tanh / sigmoid chosen per hidden layer at run time, branch-free */ };
 // FUSED: forward + residual tape + reverse sweep.  RESID: forward + tape, writes r.  FWD: forward only, writes the jet
 // channels per point.  GRADIN: forward + reverse sweep seeded with per-point d(loss)/d(jet) read from memory (equations that
 // couple several networks: the tape runs in k_expr between the FWD and GRADIN launches of every network involved).
@@ -209,15 +210,32 @@ struct GroupArgs {
     int ntiles;
     int nparams;                 // NP rows in the tape
     int nparams_estim;           // first NE params get adjoints
-    int act;
+    int act;                     // ACT_TANH / ACT_SIGMOID / ACT_SIN for all hidden layers, or ACT_MIXED:
+    int act_layers;              //   kind of hidden layer l (tanh / sigmoid) in bits 4l .. 4l+3
     int chain;                   // family 2: add this launch's gradient onto the slab contents an earlier launch group of the same
                                  // network left behind (one slab set and one reduction input for several launch groups)
     TermDev terms[MAX_GROUP_TERMS];
 };
 
 // derivatives phi', ..., phi^(NORD) of the activation from the record value r0 (see Act)   (d[0] unused)
-template <int NORD, bool SINACT>
+// MIXED (ACT_MIXED kernels): `act` is the run-time kind of THIS layer (tanh or sigmoid).  Both are one function family,
+// f(z) = m s(m z) + 1 - m with s = logistic and m = 2 (tanh) or 1 (sigmoid), so the layer kind enters only through the scalar m:
+// no branch behind the GEMMs (a run-time branch there is what the unmixed kernels avoid by taking the kind as a template parameter).
+template <int NORD, bool SINACT, bool MIXED = false>
 DEV void act_derivs_n(int act, vfloat a, vfloat (&d)[6]) {
+    if (MIXED) {
+        const float m = 2.0f - (float)act, im = 0.5f + 0.5f * (float)act, m2 = m * m;      // act in {ACT_TANH = 0, ACT_SIGMOID = 1}
+        const vfloat s = (a + vfloat(m - 1.0f)) * vfloat(im);                              // logistic value behind the record
+        const vfloat s1 = s * (vfloat(1.0f) - s);
+        const vfloat s2 = s1 * (vfloat(1.0f) - vfloat(2.0f) * s);
+        const vfloat s3 = s1 * (vfloat(1.0f) - vfloat(6.0f) * s1);
+        d[1] = vfloat(m2) * s1;
+        d[2] = vfloat(m2 * m) * s2;
+        d[3] = vfloat(m2 * m2) * s3;
+        if (NORD >= 4) d[4] = vfloat(m2 * m2 * m) * (s2 * (vfloat(1.0f) - vfloat(12.0f) * s1));
+        if (NORD >= 5) d[5] = vfloat(m2 * m2 * m2) * (s3 * (vfloat(1.0f) - vfloat(12.0f) * s1) - vfloat(12.0f) * s2 * s2);
+        return;
+    }
     if (SINACT) {
         vfloat sn, cs;
         vsincos(a, sn, cs);
@@ -336,8 +354,12 @@ DEV void jet_adjoint(vfloat (&g)[J::C], const vfloat (&s)[J::C], const vfloat (&
     PINN_UNROLL for (int k = 0; k < J::N3; ++k) g[J::CH_3 + k] = z3b[k];
 }
 
-template <bool SINACT>
+template <bool SINACT, bool MIXED = false>
 DEV vfloat act_value(int act, vfloat z) {
+    if (MIXED) {
+        const float m = 2.0f - (float)act;
+        return vfma(vsigmoid_fast(vfloat(m) * z), vfloat(m), vfloat(1.0f - m));
+    }
     if (SINACT) { vfloat sn, cs; vsincos(z, sn, cs); return sn; }
     if (act == ACT_TANH) return vtanh_fast(z);
     return vsigmoid_fast(z);
@@ -382,8 +404,9 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
     const float* P = ga.packed;
     // the activation kind is a template parameter: every kernel is straight-line code behind its GEMMs (no activation branches for the
     // optimiser to hoist); sin variants are compiled only for the specs registered with PINN_INSTANTIATE*_SIN
-    constexpr int act = ACTK;
     constexpr bool SINACT = (ACTK == ACT_SIN);
+    constexpr bool MIXED = (ACTK == ACT_MIXED);             // tanh / sigmoid per hidden layer (GroupArgs::act: one nibble per layer), branch-free
+    auto act_of = [&](int layer) -> int { return MIXED ? ((ga.act_layers >> (4 * layer)) & 15) : ACTK; };
 
     // ---- persistent per-wave gradient accumulators (registers / AGPRs across all tiles) ----
     vfloat4 wbar[NHH > 0 ? NHH : 1][WT][MT];      // COOP: this wave's row block (to == w) only
@@ -470,12 +493,13 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
         vfloat4 Rlast[NG][MT];
         // activation jets in place + park (a, z_i, z_ij) of the other layers in the scratch slab
         auto act_forward = [&](vfloat4 (&Z)[NG][MT], int layer /*0-based hidden layer*/) {
+            const int act = act_of(layer);
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                 PINN_UNROLL for (int m = 0; m < MT; ++m) {
                     vfloat4 av;                                       // sin: activation values; Z[pg*C] holds the RECORD value z meanwhile
                     PINN_UNROLL for (int r = 0; r < 4; ++r) {
                         const vfloat z0 = Z[pg * C][m][r];
-                        av[r] = act_value<SINACT>(act, z0);
+                        av[r] = act_value<SINACT, MIXED>(act, z0);
                         Z[pg * C][m][r] = SINACT ? z0 : av[r];
                     }
                     if (BWD) {
@@ -489,7 +513,7 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                     PINN_UNROLL for (int r = 0; r < 4; ++r) {
                         vfloat zz[C], dd[6];
                         PINN_UNROLL for (int ch = 0; ch < C; ++ch) zz[ch] = Z[pg * C + ch][m][r];
-                        act_derivs_n<J::NORD - 1, SINACT>(act, zz[0], dd);
+                        act_derivs_n<J::NORD - 1, SINACT, MIXED>(act, zz[0], dd);
                         jet_forward<J>(zz, dd);
                         PINN_UNROLL for (int ch = 1; ch < C; ++ch) Z[pg * C + ch][m][r] = zz[ch];
                     }
@@ -638,13 +662,13 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
 
         // =========================== reverse sweep ===========================
         // post-activation jet of channel ch from the raw (a, z_i, z_ij) record
-        auto ajet = [&](const vfloat4 (&Sr)[NG][MT], int pg, int ch, int m) -> vfloat4 {
+        auto ajet = [&](const vfloat4 (&Sr)[NG][MT], int pg, int ch, int m, int act) -> vfloat4 {
             vfloat4 out;
             PINN_UNROLL for (int r = 0; r < 4; ++r) {
                 vfloat zz[C], dd[6];
                 PINN_UNROLL for (int k = 0; k < C; ++k) zz[k] = Sr[pg * C + k][m][r];
                 if (ch > 0) {
-                    act_derivs_n<J::NORD - 1, SINACT>(act, zz[0], dd);
+                    act_derivs_n<J::NORD - 1, SINACT, MIXED>(act, zz[0], dd);
                     jet_forward<J>(zz, dd);                 // (ch is a constant after unrolling: the other channels are dead code)
                 }
                 out[r] = (ch == 0) ? act_from_record<SINACT>(zz[0]) : zz[ch];
@@ -652,13 +676,13 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
             return out;
         };
         // activation adjoint in place: G (dA jets) -> dZ jets
-        auto act_adjoint = [&](vfloat4 (&G)[NG][MT], const vfloat4 (&Sr)[NG][MT]) {
+        auto act_adjoint = [&](vfloat4 (&G)[NG][MT], const vfloat4 (&Sr)[NG][MT], int act) {
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                 PINN_UNROLL for (int m = 0; m < MT; ++m)
                     PINN_UNROLL for (int r = 0; r < 4; ++r) {
                         vfloat gg[C], ss[C], dd[6];
                         PINN_UNROLL for (int k = 0; k < C; ++k) { gg[k] = G[pg * C + k][m][r]; ss[k] = Sr[pg * C + k][m][r]; }
-                        act_derivs_n<J::NORD, SINACT>(act, ss[0], dd);
+                        act_derivs_n<J::NORD, SINACT, MIXED>(act, ss[0], dd);
                         jet_adjoint<J>(gg, ss, dd);
                         PINN_UNROLL for (int k = 0; k < C; ++k) G[pg * C + k][m][r] = gg[k];
                     }
@@ -677,11 +701,12 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                         }
                     }
             }
-            act_adjoint(G, Rlast);
+            act_adjoint(G, Rlast, act_of(LH - 1));
         }
 
         PINN_UNROLL for (int hl = NHH - 1; hl >= 0; --hl) {
             // layer (hl+1) -> (hl+2) weights; inputs are hidden layer hl's a-jets (record prefetched into SrN)
+            const int act = act_of(hl);
             vfloat4 Sr[NG][MT];
             PINN_UNROLL for (int q = 0; q < NG; ++q)
                 PINN_UNROLL for (int m = 0; m < MT; ++m) Sr[q][m] = SrN[q][m];
@@ -699,7 +724,7 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                     PINN_UNROLL for (int m = 0; m < MT; ++m) {
                         const vint ad = tr_addr<S>(c, vint(4 * m) + g);
                         lds_store4(myzt, ad, G[q][m]);
-                        lds_store4(myat, ad, ajet(Sr, pg, ch, m));
+                        lds_store4(myat, ad, ajet(Sr, pg, ch, m, act));
                     }
                     wg_barrier();
                     // operands of source wave ws+1 are requested before the 16 MFMAs of source wave ws
@@ -732,7 +757,7 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                     PINN_UNROLL for (int m = 0; m < MT; ++m) {
                         const vint ad = tr_addr<S>(c, vint(4 * m) + g);
                         lds_store4(zt, ad, G[q][m]);
-                        lds_store4(at, ad, ajet(Sr, pg, ch, m));
+                        lds_store4(at, ad, ajet(Sr, pg, ch, m, act));
                     }
                     wave_fence();
                     PINN_UNROLL for (int kk = 0; kk < 4; ++kk) {
@@ -783,7 +808,7 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
             }
             PINN_UNROLL for (int q = 0; q < NG; ++q)
                 PINN_UNROLL for (int m = 0; m < MT; ++m) G[q][m] = Gn[q][m];
-            act_adjoint(G, Sr);
+            act_adjoint(G, Sr, act);
         }
 
         // ---- layer 1 (d -> HP): dW1, db1 from the transposed dZ fragments ----

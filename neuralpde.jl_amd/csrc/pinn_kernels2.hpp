@@ -130,6 +130,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
     // the activation kind is a template parameter: every kernel is straight-line code behind its GEMMs (no activation branches for the
     // optimiser to hoist); sin variants are compiled only for the specs registered with PINN_INSTANTIATE*_SIN
     constexpr int act = ACTK;
+    static_assert(ACTK != ACT_MIXED, "per-layer activation kinds are compiled for family 1 (small nets) only");
     constexpr bool SINACT = (ACTK == ACT_SIN);
     const ubuf PB = ub_make(P, S::PACKED);
     const ubuf SB = ub_make(ga.scratch + (size_t)blk * S::SCR, S::SCR);

@@ -13,11 +13,11 @@ int round_hp(int h) {
 }
 
 const pk::SpecInfo* find_spec(int HP, int NHH, int D, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs,
-                              unsigned need_hi, std::vector<int>* pair_index, bool need_sin) {
+                              unsigned need_hi, std::vector<int>* pair_index, int need_variant) {
     const pk::SpecInfo* best = nullptr;
     for (const pk::SpecInfo& s : pk::registry()) {
         if (s.HP != HP || s.NHH != NHH || s.D != D) continue;
-        if (need_sin && !s.has_sin) continue;
+        if (need_variant && !(s.has_sin & need_variant)) continue;
         if ((s.D1MASK & need_first) != need_first) continue;
         bool ok = true;
         for (int a = 0; a < 6; ++a)
@@ -125,12 +125,12 @@ static int plan_assign_terms(pinn_engine& E) {
         d = N.sizes[0];                                 // kernels are compiled per network input dimension
         const int LH = (int)N.sizes.size() - 2;
         const int HP = round_hp(N.maxhidden());
-        sp = find_spec(HP, LH - 1, d, need_first, need_pairs, need_hi, nullptr, N.act == pk::ACT_SIN);
+        sp = find_spec(HP, LH - 1, d, need_first, need_pairs, need_hi, nullptr, variant_of(N.act));
         if (!sp) {
             char b[256];
             std::snprintf(b, sizeof b,
                           "term %zu: no compiled kernel for hidden width %d (padded %d), %d hidden layers, d=%d, first-derivative axes mask 0x%x, %zu second derivatives, higher-order mask 0x%x%s; add a PINN_INSTANTIATE line in csrc/inst_*.hip",
-                          t, N.maxhidden(), HP, LH, d, need_first, need_pairs.size(), need_hi, N.act == pk::ACT_SIN ? ", sin activation (PINN_INSTANTIATE*_SIN)" : "");
+                          t, N.maxhidden(), HP, LH, d, need_first, need_pairs.size(), need_hi, N.act == pk::ACT_SIN ? ", sin activation (PINN_INSTANTIATE*_SIN)" : (N.act == pk::ACT_MIXED ? ", per-layer tanh/sigmoid (PINN_INSTANTIATE_HI_MIX, family 1 only)" : ""));
             return fail(b);
         }
         return 0;
@@ -139,7 +139,7 @@ static int plan_assign_terms(pinn_engine& E) {
     static const bool no_lap = std::getenv("PINN_NO_LAPLACIAN") != nullptr;
     auto spec_exists = [&](int net, unsigned nf, const std::vector<std::pair<int, int>>& npairs, unsigned nh) {
         const Net& N = E.nets[net];
-        return find_spec(round_hp(N.maxhidden()), (int)N.sizes.size() - 3, N.sizes[0], nf, npairs, nh, nullptr, N.act == pk::ACT_SIN) != nullptr;
+        return find_spec(round_hp(N.maxhidden()), (int)N.sizes.size() - 3, N.sizes[0], nf, npairs, nh, nullptr, variant_of(N.act)) != nullptr;
     };
     if (!no_lap) {
         std::vector<Term> fused(E.terms.size());
@@ -499,6 +499,7 @@ static int plan_group_buffers(pinn_engine& E) {
         ga.nparams = E.np;
         ga.nparams_estim = E.ne;
         ga.act = N.act;
+        ga.act_layers = N.act_layers;
     }
     return 0;
 }

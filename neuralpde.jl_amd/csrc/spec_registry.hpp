@@ -22,7 +22,7 @@ struct SpecInfo {
     unsigned LAP;                    // axis mask of the forward-Laplacian channel (0: none)
     int NPAIR, PG, C, NG, TP, MT, LH, NFIRST;
     int PACKED, SLAB, SCR, LDS_WG, COOP, SH, PW;
-    int has_sin;                     // kernels for the sin activation are compiled for this spec
+    int has_sin;                     // extra kernel variants compiled for this spec: bit 0 = sin activation, bit 1 = per-layer tanh / sigmoid (ACT_MIXED)
     int REC;                         // floats per tile of the HBM record store (MODE_FWDREC / MODE_GRADREC); 0: not supported
     int OFF_W1, OFF_B, OFF_WL, OFF_BL, OFF_WPK, OFF_WTPK;
     int O_WBAR, O_BFRH, O_BFR0, O_W1, O_WL, O_BL, O_P;
@@ -167,6 +167,9 @@ template <class S> void launch_spec2_sin(const GroupArgs& ga, int mode, int bloc
 template <class S> void launch_spec_sin(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
     if (ga.act == ACT_SIN) launch_modes1<S, ACT_SIN>(ga, mode, blocks, st); else launch_spec<S>(ga, mode, blocks, st);
 }
+template <class S> void launch_spec_mix(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
+    if (ga.act == ACT_MIXED) launch_modes1<S, ACT_MIXED>(ga, mode, blocks, st); else launch_spec<S>(ga, mode, blocks, st);
+}
 
 struct Registrar {
     explicit Registrar(const SpecInfo& s) { registry().push_back(s); }
@@ -199,6 +202,12 @@ struct Registrar {
     namespace {                                                                              \
     using NAME##_spec = pk::Spec<HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI>;                  \
     pk::Registrar NAME##_reg(pk::make_info<NAME##_spec>(&pk::launch_spec_sin<NAME##_spec>, 1)); \
+    }
+// family 1 spec that also carries the per-layer tanh / sigmoid variant (small nets such as the reference's Dense(1, 8, tanh), Dense(8, 8, sigma))
+#define PINN_INSTANTIATE_HI_MIX(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI)                  \
+    namespace {                                                                              \
+    using NAME##_spec = pk::Spec<HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI>;                  \
+    pk::Registrar NAME##_reg(pk::make_info<NAME##_spec>(&pk::launch_spec_mix<NAME##_spec>, 2)); \
     }
 #define PINN_INSTANTIATE2(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG) PINN_INSTANTIATE2_HI(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, 0u)
 #define PINN_INSTANTIATE(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG) PINN_INSTANTIATE_HI(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, 0u)

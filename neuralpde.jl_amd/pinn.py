@@ -39,7 +39,7 @@ class Dense:
 
 class Chain:
     """Lux.Chain of Dense layers.  The engine supports the shape every PINN chain in the reference's PDE tests
-    has: one activation on all hidden layers, identity on the last, single output."""
+    has: tanh / sigmoid (per layer) or sin (all layers) on the hidden layers, identity on the last, single output."""
 
     def __init__(self, *layers: Dense):
         if not layers:
@@ -49,18 +49,20 @@ class Chain:
                 raise ValueError("DimensionMismatch: consecutive Dense layers do not chain")
         self.layers = list(layers)
         self.sizes = tuple([layers[0].n_in] + [l.n_out for l in layers])
-        acts = {l.activation for l in layers[:-1]}
         if len(layers) < 2:
             raise ValueError("the HIP engine needs at least one hidden layer")
-        if len(acts) != 1:
-            raise ValueError("the HIP engine needs the same activation on every hidden layer")
         if layers[-1].activation != "identity":
             raise ValueError("the last layer must have identity activation")
-        self.act = acts.pop()
-        if self.act in ("σ", "sigmoid_fast"):
-            self.act = "sigmoid"
-        if self.act == "tanh_fast":
-            self.act = "tanh"
+        alias = {"σ": "sigmoid", "sigmoid_fast": "sigmoid", "tanh_fast": "tanh"}
+        acts = [alias.get(l.activation, l.activation) for l in layers[:-1]]
+        if len(set(acts)) == 1:
+            self.act = acts[0]
+        else:
+            # per-layer activations (e.g. the reference's Dense(1, n, tanh), Dense(n, n, σ), Dense(n, 1)): tanh and sigmoid may be
+            # mixed (kernel variant ACT_MIXED, compiled for the small-net shapes); sin has kernels of its own and cannot be mixed
+            if not set(acts) <= {"tanh", "sigmoid"}:
+                raise ValueError("the HIP engine mixes only tanh and sigmoid inside one chain (got " + ", ".join(acts) + ")")
+            self.act = ",".join(acts)
 
     @property
     def nparams(self) -> int:

@@ -484,6 +484,28 @@ def test_heterogeneous_system(npde, use_emu):
     np.testing.assert_allclose(r, po.residual_values(prob, th, 1, sets[1]), rtol=2e-5, atol=2e-5)
 
 
+def test_per_layer_activations(npde, use_emu):
+    """tanh and sigmoid mixed inside one chain (the reference's Lorenz chains: Dense(1, n, tanh), Dense(n, n, σ), Dense(n, 1)): kernel
+    variant ACT_MIXED of the small-net specs — the layer kind enters the activation rules as a scalar (tanh(z) = 2 s(2z) - 1), no branch."""
+    for d, width, acts, seed in ((2, 12, ("tanh", "sigmoid"), 71), (2, 16, ("sigmoid", "tanh", "sigmoid"), 72), (1, 8, ("tanh", "sigmoid"), 73),
+                                 (1, 10, ("sigmoid", "sigmoid", "tanh"), 74)):
+        sysm, _ = helpers.shape_problem(npde, width, len(acts), d)
+        layers = [npde.Dense(d, width, acts[0])] + [npde.Dense(width, width, a) for a in acts[1:]] + [npde.Dense(width, 1)]
+        chain = npde.Chain(*layers)
+        assert chain.act == ",".join(acts)
+        strat = npde.QuasiRandomTraining(50, bcs_points=30, sampling_alg=npde.SobolSample(seed=seed), resampling=False, minibatch=1)
+        rep, prob, sets, th = check(npde, sysm, [chain], strat, theta_for(chain, seed), mode="exact")
+        pts = np.array([[0.3, 0.7], [0.6, 0.2]])[:d]
+        np.testing.assert_allclose(rep.phi(pts, th)[0], po.phi_values(prob.chains[0], th, pts)[0], rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError, match="mixes only tanh and sigmoid"):
+        npde.Chain(npde.Dense(2, 8, "sin"), npde.Dense(8, 8, "tanh"), npde.Dense(8, 1))
+    # shapes without the mixed variant fail loudly at discretize time
+    sysm, _ = helpers.shape_problem(npde, 64, 4, 2)
+    big = npde.Chain(npde.Dense(2, 64, "tanh"), npde.Dense(64, 64, "sigmoid"), npde.Dense(64, 64, "tanh"), npde.Dense(64, 64, "tanh"), npde.Dense(64, 1))
+    with pytest.raises(Exception, match="per-layer tanh/sigmoid"):
+        npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(big, npde.GridTraining(0.25), init_params=theta_for(big, 75)))
+
+
 def test_bpinn_physics_loglikelihood(npde, use_emu):
     """l(theta) = sum_k logpdf(MvNormal(r_k, sigma_k^2 I), 0) (src/training_strategies.jl:113-127, ext/bpinn/PDE_BPINN.jl:425)
     and its gradient from the engine's per-term sums, against the oracle's residuals."""

@@ -294,6 +294,27 @@ def test_bit_reproducibility(npde, hip_lib, which):
         assert np.array_equal(l, l0) and np.array_equal(g, g0), int(np.sum(g != g0))
 
 
+@pytest.mark.parametrize("d,width,acts", [(1, 8, ("tanh", "sigmoid")), (2, 12, ("tanh", "sigmoid")), (2, 16, ("sigmoid", "tanh", "sigmoid"))])
+def test_per_layer_activations_gpu(npde, hip_lib, d, width, acts):
+    """tanh / sigmoid mixed per hidden layer (the reference's Lorenz chains: Dense(1, n, tanh), Dense(n, n, σ), Dense(n, 1)) on the HIP
+    kernels' branch-free ACT_MIXED variant, against the oracle; bit-reproducible."""
+    sysm, _ = helpers.shape_problem(npde, width, len(acts), d)
+    layers = [npde.Dense(d, width, acts[0])] + [npde.Dense(width, width, a) for a in acts[1:]] + [npde.Dense(width, 1)]
+    chain = npde.Chain(*layers)
+    strat = npde.QuasiRandomTraining(900, bcs_points=300, sampling_alg=npde.SobolSample(seed=width), resampling=False, minibatch=1)
+    th = po.glorot_theta(po.Chain(tuple(chain.sizes), chain.act), np.random.default_rng(width))
+    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th))
+    assert rep.engine.L.backend == "hip"
+    sets = rep.pde_train_sets + rep.bcs_train_sets
+    losses, grad = rep.engine.loss_grad(rep.flat_init_params)
+    ref = po.loss_and_grad(helpers.oracle_problem(npde, sysm, [chain]), rep.flat_init_params, sets, mode="exact")
+    le, g2, gi = helpers.rel_errors(losses, grad, ref)
+    assert le.max() < TOL and g2 < TOL and gi < TOL, (le, g2, gi)
+    for _ in range(4):
+        l2, gr2 = rep.engine.loss_grad(rep.flat_init_params)
+        assert np.array_equal(l2, losses) and np.array_equal(gr2, grad)
+
+
 def test_higher_order_derivatives_gpu(npde, hip_lib):
     """pure third / fourth derivative jets on the hardware: the reference's 3rd-order ODE set-up, a 4th-order 1-D problem and the
     Kuramoto-Sivashinsky jet set (family 1 sigmoid 2x12 and family 2 tanh 4x64), against the oracle's exact derivatives

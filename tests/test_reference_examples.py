@@ -127,7 +127,10 @@ def test_lorenz_parameter_estimation_terms(npde, use_emu):
     bcs = [npde.Eq(xv(0), 1.0), npde.Eq(yv(0), 0.0), npde.Eq(zv(0), 0.0)]
     sysm = npde.PDESystem(eqs, bcs, [npde.In(t, npde.Interval(0.0, 1.0))], [t], [xv(t), yv(t), zv(t)], ps=[sg, rho, beta],
                           defaults={sg: 9.0, rho: 25.0, beta: 2.5})
-    chains = chains_for(npde, [1, 1, 1], 8, "sigmoid")
+    # the reference's own chains for this system mix activations: Dense(1, n, tanh), Dense(n, n, σ), Dense(n, 1), n = 8
+    # (test/NNPDE2/additional_loss__lorenz_system.jl:26-27)
+    chains = [npde.Chain(npde.Dense(1, 8, "tanh"), npde.Dense(8, 8, "σ"), npde.Dense(8, 1)) for _ in range(3)]
+    assert chains[0].act == "tanh,sigmoid"
     rep, prob, sets, th = check(npde, sysm, chains, npde.GridTraining(0.05), thetas(chains, 140), param_estim=True)
     assert th.size == sum(c.nparams for c in chains) + 3 and list(th[-3:]) == [9.0, 25.0, 2.5]      # theta.p appended (src/discretize.jl:451-465)
 
