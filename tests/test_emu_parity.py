@@ -106,6 +106,14 @@ def test_small_net_shape_grid(npde, use_emu, width, hidden, d):
     check(npde, sysm, [chain], strat, theta_for(chain, 100 + width + 10 * hidden + d), mode="exact")
 
 
+@pytest.mark.parametrize("width,hidden,act", [(100, 3, "tanh"), (128, 4, "sigmoid")])
+def test_wide_nets_3_and_4_hidden_layers(npde, use_emu, width, hidden, act):
+    """65..128-wide nets with 3 / 4 hidden layers (inst2_h128_mid_d2.hip): 2-D Poisson, 8-wave workgroups, slab-resident dW."""
+    sysm, chain = poisson2d(npde, act, width=width, hidden=hidden)
+    strat = npde.QuasiRandomTraining(40, bcs_points=70, sampling_alg=npde.SobolSample(seed=hidden), resampling=False, minibatch=1)
+    check(npde, sysm, [chain], strat, theta_for(chain, 200 + hidden))
+
+
 def test_cfg3_burgers_4x64_small(npde, use_emu):
     from neuralpde_jl_amd import workloads
     wl = workloads.cfg3_burgers(points=40, bcs_points=30)

@@ -315,6 +315,32 @@ def test_per_layer_activations_gpu(npde, hip_lib, d, width, acts):
         assert np.array_equal(l2, losses) and np.array_equal(gr2, grad)
 
 
+@pytest.mark.parametrize("width,hidden,act", [(100, 3, "tanh"), (128, 4, "sigmoid")])
+def test_wide_nets_3_and_4_hidden_layers_gpu(npde, hip_lib, width, hidden, act):
+    """65..128-wide nets with 3 / 4 hidden layers on the HIP kernels (8-wave workgroups): 2-D Poisson vs the oracle, bit-reproducible."""
+    import sympy as sp
+    x, y = npde.parameters("x y")
+    (u,) = npde.variables("u")
+    Dxx, Dyy = npde.Differential(x) ** 2, npde.Differential(y) ** 2
+    eq = npde.Eq(Dxx(u(x, y)) + Dyy(u(x, y)), -sp.sin(sp.pi * x) * sp.sin(sp.pi * y))
+    bcs = [npde.Eq(u(0, y), 0.0), npde.Eq(u(1, y), 0.0), npde.Eq(u(x, 0), 0.0), npde.Eq(u(x, 1), 0.0)]
+    dom = [npde.In(x, npde.Interval(0.0, 1.0)), npde.In(y, npde.Interval(0.0, 1.0))]
+    sysm = npde.PDESystem([eq], bcs, dom, [x, y], [u(x, y)])
+    layers = [npde.Dense(2, width, act)] + [npde.Dense(width, width, act) for _ in range(hidden - 1)] + [npde.Dense(width, 1)]
+    chain = npde.Chain(*layers)
+    strat = npde.QuasiRandomTraining(2000, bcs_points=500, sampling_alg=npde.SobolSample(seed=hidden), resampling=False, minibatch=1)
+    th = po.glorot_theta(po.Chain(tuple(chain.sizes), chain.act), np.random.default_rng(300 + hidden))
+    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th))
+    sets = rep.pde_train_sets + rep.bcs_train_sets
+    losses, grad = rep.engine.loss_grad(rep.flat_init_params)
+    ref = po.loss_and_grad(helpers.oracle_problem(npde, sysm, [chain]), rep.flat_init_params, sets, mode="stencil")
+    le, g2, gi = helpers.rel_errors(losses, grad, ref)
+    assert le.max() < TOL and g2 < TOL and gi < TOL, (le, g2, gi)
+    for _ in range(4):
+        l2, gr2 = rep.engine.loss_grad(rep.flat_init_params)
+        assert np.array_equal(l2, losses) and np.array_equal(gr2, grad)
+
+
 def test_higher_order_derivatives_gpu(npde, hip_lib):
     """pure third / fourth derivative jets on the hardware: the reference's 3rd-order ODE set-up, a 4th-order 1-D problem and the
     Kuramoto-Sivashinsky jet set (family 1 sigmoid 2x12 and family 2 tanh 4x64), against the oracle's exact derivatives
