@@ -16,6 +16,9 @@ from typing import Callable, Optional
 import numpy as np
 
 
+NONZERO_DIVISOR_EPS = 1.0e-7          # src/adaptive_losses.jl:125 (effective value, see GradientScaleAdaptiveLoss.reweight)
+
+
 def _vectorify(w, n: Optional[int] = None) -> np.ndarray:
     a = np.atleast_1d(np.asarray(w, dtype=np.float64)).copy()
     return a
@@ -67,7 +70,9 @@ class GradientScaleAdaptiveLoss(AbstractAdaptiveLoss):
         n_pde = len(pde_losses)
         pde_grads_max = max(np.max(np.abs(tg[k])) for k in range(n_pde))
         bc_grads_mean = np.array([np.mean(np.abs(tg[n_pde + j])) for j in range(len(bc_losses))])
-        proposed = pde_grads_max / (bc_grads_mean + 1.0e-11)      # Float64 weights: nonzero_divisor_eps = 1e-11 (:124)
+        # nonzero_divisor_eps (:125): `adaloss_T isa Float64 ? 1e-11 : convert(adaloss_T, 1e-7)` — `adaloss_T` is a TYPE, and a type is
+        # never an instance of Float64, so the reference always takes the second branch: 1e-7, also for Float64 weights (restated as is)
+        proposed = pde_grads_max / (bc_grads_mean + NONZERO_DIVISOR_EPS)
         a = self.weight_change_inertia
         self.bc_loss_weights = a * self.bc_loss_weights + (1 - a) * proposed
 

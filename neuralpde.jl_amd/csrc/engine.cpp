@@ -516,8 +516,7 @@ int pinn_set_sampler(pinn_handle h, int term, int kind, const float* lb, const f
     Term& T = E.terms[term];
     if (kind < 0 || kind > 3) return fail("pinn_set_sampler: kind must be 0 (fixed set), 1 (uniform), 2 (Latin hypercube) or 3 (Sobol)");
     if (kind == 3 && T.d > 8) return fail("pinn_set_sampler: the Sobol sampler covers up to 8 axes");
-    T.sampler = kind;
-    if (kind == 0) return 0;
+    if (kind == 0) { T.sampler = 0; return 0; }
     if (!lb || !ub || n <= 0) return fail("pinn_set_sampler: bounds and a positive point count are required");
     if (!T.d_lb) { T.d_lb = (float*)plat_malloc(sizeof(float) * 8); T.d_ub = (float*)plat_malloc(sizeof(float) * 8); }
     if (!T.d_lb || !T.d_ub) return fail("device allocation failed (sampler)");
@@ -529,6 +528,7 @@ int pinn_set_sampler(pinn_handle h, int term, int kind, const float* lb, const f
     // allocate / size the term's point buffer through the normal path with a first draw
     std::vector<float> tmp((size_t)n * T.d, 0.f);
     if (set_points_impl(h, term, tmp.data(), n, 0, false)) return 1;
+    T.sampler = kind;                                    // only now: every check and allocation above has succeeded
     aux::launch_sample(kind, T.d_pts, (int)(n * T.d), T.d, T.d_lb, T.d_ub, T.seed, T.draws++, E.stream);
     eval_sources(E, T);
     plat_sync(E.stream);

@@ -69,14 +69,25 @@ class Chain:
         return sum(l.n_in * l.n_out + l.n_out for l in self.layers)
 
 
-def initialparameters(rng: np.random.Generator, chain: Chain, dtype=np.float64) -> np.ndarray:
-    """[3P] Lux.initialparameters for Dense: glorot_uniform weights, zero bias; flattened in ComponentArrays
-    order [W1 (out x in, column-major) | b1 | ...]."""
+def initialparameters(rng: np.random.Generator, chain: Chain, dtype=np.float64, init: str = "lux1") -> np.ndarray:
+    """[3P] Lux.initialparameters for a Chain of Dense layers, flattened in ComponentArrays order [W1 (out x in, column-major) | b1 | ...].
+    init = "lux1" (default): the Dense defaults of the Lux 1.x line the reference pins (Project.toml: Lux 1.31) —
+    `init_weight = kaiming_uniform(gain = 1/sqrt(3))` and `init_bias = U(-1/sqrt(fan_in), 1/sqrt(fan_in))`, i.e. both drawn from
+    U(+-1/sqrt(fan_in)) (the PyTorch convention Lux adopted in 1.0; the Lux sources are not part of the reference tree, so this
+    is restated from its documentation);
+    init = "glorot": glorot_uniform weights and zero bias (Lux < 1.0, and what `dgm.jl:12` still passes explicitly).
+    Only the distribution of the random start matters here: a user-supplied `init_params` bypasses this function."""
     parts = []
     for l in chain.layers:
-        lim = math.sqrt(6.0 / (l.n_in + l.n_out))
-        W = rng.uniform(-lim, lim, size=(l.n_out, l.n_in))
-        parts += [W.T.reshape(-1), np.zeros(l.n_out)]
+        if init == "glorot":
+            lim = math.sqrt(6.0 / (l.n_in + l.n_out))
+            W, b = rng.uniform(-lim, lim, size=(l.n_out, l.n_in)), np.zeros(l.n_out)
+        elif init == "lux1":
+            lim = 1.0 / math.sqrt(l.n_in)
+            W, b = rng.uniform(-lim, lim, size=(l.n_out, l.n_in)), rng.uniform(-lim, lim, size=l.n_out)
+        else:
+            raise ValueError("init must be 'lux1' or 'glorot'")
+        parts += [W.T.reshape(-1), b]
     return np.concatenate(parts).astype(dtype)
 
 
@@ -256,9 +267,12 @@ def solve(prob: OptimizationProblem, alg: Adam, maxiters: int = 1000, callback: 
         raise NotImplementedError("solve(): additional_loss is a host-side term; use prob.f.value_and_grad in a host loop")
     eng = rep.engine
     eng_resample = getattr(rep, "_device_samplers", None)
-    if eng_resample:
+    if eng_resample and not rep._state.get("samplers_installed"):
+        # installed ONCE per discretisation: a second solve (the resume idiom solve(remake(prob, u0 = res.u))) continues the
+        # device draw counters instead of replaying the first run's point sequence
         for k, (lb, ub, n, seed, kind) in eng_resample.items():
             eng.set_sampler(k, lb, ub, n, seed, kind)
+        rep._state["samplers_installed"] = True
     elif rep._state.get("resample") is not None:
         raise NotImplementedError("solve(): only StochasticTraining and Latin-hypercube QuasiRandomTraining have on-device samplers; use resampling=False designs "
                                   "or a host loop over prob.f.value_and_grad")
@@ -416,7 +430,8 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
         th = np.asarray(theta)
         w = weights_now() if weights is None else np.asarray(weights, dtype=np.float64)
         key = (th.tobytes(), w.tobytes())
-        if resample is None and state["cache_theta"] == key and (state["cache"][1] is not None or not want_grad):
+        # memo: valid for fixed sets, and for resampling strategies when the caller asks for the SAME draw again (redraw = False)
+        if (resample is None or not redraw) and state["cache_theta"] == key and (state["cache"][1] is not None or not want_grad):
             return state["cache"]
         if resample is not None and redraw:
             ps, bs = resample()
@@ -446,10 +461,10 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
 
     additional_loss = discretization.additional_loss
 
-    def losses_and_reweight(theta):
+    def losses_and_reweight(theta, want_grad=False):
         """the part of full_loss_function that runs outside AD (src/discretize.jl:569-580): term losses, iteration
         counter, adaptive reweighting (which may ask the engine for per-term gradients)"""
-        losses, _ = evaluate(theta, want_grad=False)
+        losses, _ = evaluate(theta, want_grad=want_grad)
         if discretization.self_increment:
             iteration[0] += 1
         adaloss.reweight(theta, losses[:n_pde], losses[n_pde:n_pde + n_bc], iteration[0],
@@ -467,9 +482,11 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
         return wa * float(add), None
 
     def value_and_grad(theta):
-        losses = losses_and_reweight(theta)
+        # ONE device evaluation per optimiser step: losses and gradient together (the engine always runs the reverse sweep); the
+        # memo in `evaluate` serves the gradient below unless the adaptive rule has just changed the weights
+        losses = losses_and_reweight(theta, want_grad=True)
         w = weights_now()
-        _, grad = evaluate(theta, want_grad=True, weights=w, redraw=False)      # gradient under the (possibly new) weights
+        _, grad = evaluate(theta, want_grad=True, weights=w, redraw=False)      # cached, or recomputed under the new weights
         total = float(np.dot(w, losses))
         dt = np.asarray(theta).dtype
         g = grad.astype(dt if dt in (np.float32, np.float64) else np.float64)

@@ -130,8 +130,14 @@ class SobolSample:
         from scipy.stats import qmc
         eng = qmc.Sobol(len(lb), scramble=self.scramble, seed=self.seed + self._calls)
         self._calls += 1
-        m = int(np.ceil(np.log2(max(n, 1))))
-        u = eng.random_base2(m)[:n] if (1 << m) >= n else eng.random(n)
+        if not self.scramble:
+            # un-randomised sequence: elements 1..n — Sobol.jl (behind QuasiMonteCarlo.SobolSample) never returns the all-zero
+            # element 0, and neither does the device sampler (pinn_set_sampler kind 3)
+            eng.fast_forward(1)
+            u = eng.random(n)
+        else:
+            m = int(np.ceil(np.log2(max(n, 1))))
+            u = eng.random_base2(m)[:n] if (1 << m) >= n else eng.random(n)
         return (lb[:, None] + (ub - lb)[:, None] * u.T).astype(dtype)
 
 

@@ -24,7 +24,7 @@ def test_gradient_scale_matches_reference_rule(npde, use_emu):
     ref = po.loss_and_grad(helpers.oracle_problem(npde, sysm, [chain]), th0, sets, mode="stencil", per_term_grads=True)
     pde_max = np.max(np.abs(ref.term_grads[0]))
     bc_mean = np.array([np.mean(np.abs(ref.term_grads[1 + j])) for j in range(4)])
-    expected = 0.9 * np.ones(4) + 0.1 * pde_max / (bc_mean + 1e-11)
+    expected = 0.9 * np.ones(4) + 0.1 * pde_max / (bc_mean + 1e-7)     # effective eps of the reference (adaptive_losses.jl:125: `adaloss_T isa Float64` is always false)
     val, g = prob.f.value_and_grad(th0)                      # iteration 1 -> 2, 2 % 1 == 0: reweight fires
     np.testing.assert_allclose(ada.bc_loss_weights, expected, rtol=1e-5)
     # objective and gradient use the NEW weights (src/discretize.jl:582-588)
