@@ -16,9 +16,10 @@ blocks; one RCCL all-reduce of [gradient | per-term squared-residual sums] per s
 value = interior collocation points x steps / time  (the metric's unit: interior-point residual+grad evals/s;
 the 4x65,536 boundary-term points ride along in every step and are counted in `point_terms_per_s`).
 
-JSON extras: "roofline" (fp32 MFMA roofline of the dominant kernel = the fused interior residual kernel,
-algorithmic flops per SURVEY.md §8d / DESIGN.md ÷ its HIP-event duration) and "cpu_baseline" (the float64 oracle =
-CPU restatement of the reference algorithm, timed on this box's host cores on a bounded sample; rank 0, N=1 only).
+JSON extras: "roofline" (fp32 MFMA roofline of the dominant kernel = the fused residual kernel with the most device time, flops the
+kernel executes per SURVEY.md §8d's formula ÷ its mean HIP-event duration over >= 12 launches sampled inside the timed region),
+"roofline_kernels" (the same for every fused kernel of the step) and "cpu_baseline" (the float64 oracle = CPU restatement of the
+reference algorithm, timed on this box's host cores on the same full-size workload with a fixed thread count; rank 0, N=1 only).
 """
 import argparse
 import json
@@ -38,49 +39,64 @@ def algorithmic_flops_per_point(sizes, C):
     return 6 * C * S - 2 * C * sizes[0] * sizes[1]
 
 
-def cpu_baseline(npde, wl_small, sets_small, budget_s=14.0):
-    """Time the float64 oracle (stencil mode = the reference's algorithm: 6 batched forward passes per Poisson
-    residual + reverse mode) on a bounded sample of the same workload on this box's host cores.  torch's intra-op
-    thread count is chosen from a short probe (more threads than ~32 slow these small float64 GEMMs down)."""
+CPU_THREADS = 32          # fixed intra-op thread count of the CPU baseline (capped by the box's hardware threads)
+
+
+def cpu_baseline(npde, wl, sets, nevals=20, budget_s=90.0, chunk=16384):
+    """Time the float64 oracle (stencil mode = the reference's algorithm: 6 batched forward passes per Poisson residual + reverse
+    mode) on this box's host cores on the SAME workload as the GPU leg — all 65,536 interior + 4 x 65,536 boundary points, evaluated
+    in chunks of `chunk` points per term to bound memory — with a FIXED thread count; value = interior points / median eval time."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
     import torch
     import pinn_oracle as po
     import helpers
     ncpu = os.cpu_count() or 1
-    prob = helpers.oracle_problem(npde, wl_small.pde_system, wl_small.chains)
-    n_int = sets_small[0].shape[1]
+    nt = min(CPU_THREADS, ncpu)
+    torch.set_num_threads(nt)
+    prob = helpers.oracle_problem(npde, wl.pde_system, wl.chains)
+    N = [s.shape[1] for s in sets]
+    nchunks = max((n + chunk - 1) // chunk for n in N)
 
     def one():
         t = time.perf_counter()
-        po.loss_and_grad(prob, wl_small.theta, sets_small, mode="stencil")
+        for c in range(nchunks):
+            part, w = [], []
+            for k, s_ in enumerate(sets):
+                lo, hi = c * chunk, min((c + 1) * chunk, N[k])
+                part.append(s_[:, lo:hi] if lo < hi else s_[:, :1])
+                w.append((hi - lo) / N[k] if lo < hi else 0.0)
+            po.loss_and_grad(prob, wl.theta, part, weights=w, mode="stencil")
         return time.perf_counter() - t
 
-    best_t, best_n = None, 1
-    for nt in sorted({min(ncpu, n) for n in (8, 16, 32, 64)}):
-        torch.set_num_threads(nt)
-        one()
-        dt = min(one(), one())
-        if best_t is None or dt < best_t:
-            best_t, best_n = dt, nt
-    torch.set_num_threads(best_n)
-    t0, reps = time.perf_counter(), 0
-    while True:
-        one()
-        reps += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or reps >= 200:
-            break
-    return {"value": n_int * reps / el, "unit": "interior-point residual+grad evals/s", "cores": best_n, "kind": "port",
-            "host_cpus": ncpu,
-            "sample": f"{reps} evals of the float64 stencil-mode oracle (torch CPU, {best_n} of {ncpu} hardware threads, best of a "
-                      f"8/16/32/64-thread probe) on {n_int} interior + 4x{sets_small[1].shape[1]} boundary points of the same "
-                      f"workload; Julia/NeuralPDE.jl itself is not installable here (no network)"}
+    one()                                   # warm-up (thread pool, allocator)
+    times, t0 = [], time.perf_counter()
+    while len(times) < nevals and (time.perf_counter() - t0 < budget_s or len(times) < 3):
+        times.append(one())
+    med = float(np.median(times))
+    return {"value": N[0] / med, "unit": "interior-point residual+grad evals/s", "cores": nt, "kind": "port",
+            "host_cpus": ncpu, "evals": len(times), "median_s": med, "min_s": float(min(times)), "max_s": float(max(times)),
+            "sample": f"median of {len(times)} evals of the float64 stencil-mode oracle (torch CPU, fixed {nt} of {ncpu} hardware threads) on the full "
+                      f"workload: {N[0]} interior + {len(N) - 1}x{N[1]} boundary points in chunks of {chunk}; Julia/NeuralPDE.jl itself is not "
+                      f"installable here (no network)"}
 
 
-# HBM-side bytes per launch of the dominant kernel from the PMC passes in profiles/r01_pmc_summary_v11.txt
-# (2 x FETCH_SIZE [gfx950 wide-read correction] + WRITE_SIZE, KB -> bytes); only valid for the default workload size.
-PMC_TRAFFIC_BYTES = {65536: (2 * 10862.5 + 77600.1) * 1024}    # profiles/r01_pmc_summary_v11.txt
+def pmc_traffic(kernel_key, points):
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc passes (tools/pmc_profile.sh writes
+    profiles/pmc_traffic.json: 2 x FETCH_SIZE [gfx950 wide-read correction] + WRITE_SIZE, KB -> bytes, per kernel and workload size).
+    Counters cannot be collected inside this process, so the line carries the profile's figure together with its source file, or
+    null when no profile matches this kernel / point count."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            tab = json.load(f)
+    except (OSError, ValueError):
+        return None, None
+    for e in tab.get("kernels", []):
+        if e.get("key") == kernel_key and e.get("points_per_launch") == points:
+            return e.get("bytes_per_launch"), e.get("source")
+    return None, None
 
 
 def main():
@@ -90,11 +106,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--events", choices=["dominant", "all", "none"], default="dominant",
-                    help="HIP events recorded inside the timed region: around the dominant kernel only (default; each extra "
-                         "event pair costs a few us of dispatch gap per step), around every fused kernel, or none")
-    ap.add_argument("--event-every", type=int, default=8, help="record the HIP events on every M-th timed step (a start/stop pair plus "
-                    "its read-back costs ~20 us of host+dispatch time, 3-10%% of a step; the sampled launches are inside the timed region)")
+    ap.add_argument("--events", choices=["all", "none"], default="all",
+                    help="HIP events recorded inside the timed region around every fused residual kernel (sampled steps only), or none")
+    ap.add_argument("--event-every", type=int, default=0, help="record the HIP events on every M-th timed step (a start/stop pair plus "
+                    "its read-back costs ~10 us of host+dispatch time per kernel; the sampled launches are inside the timed region). "
+                    "0 (default): steps // 12, i.e. at least 12 sampled launches of every kernel")
     args = ap.parse_args()
 
     import numpy as np
@@ -153,13 +169,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    groups = eng.group_timings()
-    dom = int(np.argmax([g["channels"] for g in groups]))      # dominant kernel = the interior (C=5) fused residual kernel
-    ev_level, ev_group = {"dominant": 1, "all": 1, "none": 0}[args.events], dom if args.events == "dominant" else -1
+    ev_level, ev_group = {"all": 1, "none": 0}[args.events], -1
     eng.set_timing(ev_level, ev_group)
     step()
     kern_ms = []
-    every = max(1, args.event_every)
+    every = max(1, args.event_every if args.event_every > 0 else args.steps // 12)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -197,22 +211,49 @@ def main():
             eng.loss_grad(th)
         host_path_ms = (time.perf_counter() - t1) / nh * 1e3
     if rank == 0:
+        import re
         res = out_h.numpy()
         losses = res[P:] / np.array(n_glob)
         groups = eng.group_timings()
+        names = dict((int(m.group(1)), m.group(2)) for m in re.finditer(r"group (\d+).*?kernel=(\S+)", eng.describe()))
         kern_ms = np.array(kern_ms) if kern_ms else np.full((1, len(groups)), np.nan)
         sizes = wl.chains[0].sizes
-        dom_ms = float(np.mean(kern_ms[:, dom]))
-        # algorithmic flops: the interior residual as written needs C = 5 jet channels (u, u_x, u_y, u_xx, u_yy)
-        # = 373,120 flop/point.  The kernel carries u_xx + u_yy as ONE forward-Laplacian channel (C = 4 executed channels,
-        # DESIGN.md §2), so it executes fewer flops than the model counts; both figures are reported.
-        C_ALG = 5
-        flops_dom = algorithmic_flops_per_point(sizes, C_ALG) * groups[dom]["points"]
-        flops_exec = algorithmic_flops_per_point(sizes, groups[dom]["channels"]) * groups[dom]["points"]
-        achieved = flops_dom / (dom_ms * 1e-3) / 1e12
-        all_ms = float(np.mean(kern_ms.sum(axis=1))) if args.events == "all" else None
-        flops_all = sum(algorithmic_flops_per_point(sizes, g["channels"]) * g["points"] for g in groups)
         n_int = n_glob[0]
+        # One roofline entry per fused residual kernel.  `achieved` / `frac` count the flops the kernel EXECUTES
+        # (SURVEY.md §8d formula 6 C S - 2 C n0 n1 with C = the jet channels the kernel carries) / its mean HIP-event duration over
+        # the sampled launches of the timed region.  The interior residual as written needs C = 5 channels (u, u_x, u_y, u_xx, u_yy:
+        # 373,120 flop/point, the §8d figure); the kernel carries u_xx + u_yy as ONE forward-Laplacian channel (C = 4),
+        # so the §8d "useful work" rate is reported separately as achieved_algorithmic / frac_algorithmic.
+        C_ALG = {True: 5, False: 1}
+        per_kernel = []
+        for gi, g in enumerate(groups):
+            ms = float(np.mean(kern_ms[:, gi]))
+            interior = g["channels"] > 1
+            f_exec = algorithmic_flops_per_point(sizes, g["channels"])
+            f_alg = algorithmic_flops_per_point(sizes, C_ALG[interior])
+            tf_exec = f_exec * g["points"] / (ms * 1e-3) / 1e12
+            tf_alg = f_alg * g["points"] / (ms * 1e-3) / 1e12
+            key = names.get(gi, f"group{gi}")
+            traffic, tsrc = pmc_traffic(key, g["points"]) if world == 1 else (None, None)
+            per_kernel.append({
+                "bound": "mfma", "achieved": tf_exec, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf_exec / PEAK_FP32_MFMA_TFLOPS,
+                "traffic": traffic, "traffic_source": tsrc,
+                "kernel": f"k_wave2<{key}, FUSED> ({'interior residual+grad' if interior else 'boundary residual+grad'}, neuron-split workgroups)",
+                "kernel_ms": ms, "kernel_ms_min": float(np.min(kern_ms[:, gi])), "kernel_ms_max": float(np.max(kern_ms[:, gi])),
+                "launches_sampled": int(kern_ms.shape[0]), "points_per_launch": g["points"], "executed_channels": g["channels"],
+                "executed_flops_per_point": f_exec, "algorithmic_flops_per_point": f_alg,
+                "achieved_algorithmic": tf_alg, "frac_algorithmic": tf_alg / PEAK_FP32_MFMA_TFLOPS,
+                "algorithmic_bytes_per_launch": 4 * sizes[0] * g["points"]})
+        dom = int(np.argmax([k["kernel_ms"] for k in per_kernel]))          # dominant = the kernel with the most device time
+        all_ms = float(np.mean(kern_ms.sum(axis=1)))
+        flops_all = sum(k["executed_flops_per_point"] * k["points_per_launch"] for k in per_kernel)
+        roof = dict(per_kernel[dom])
+        roof.update({"all_fused_kernels_ms": all_ms, "all_fused_kernels_tflops": flops_all / (all_ms * 1e-3) / 1e12,
+                     "all_fused_kernels_frac": flops_all / (all_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                     "events": f"HIP events around every fused kernel on every {every}. step of the timed region: {kern_ms.shape[0]} launches averaged",
+                     "note": "frac = executed flops / kernel time / fp32 MFMA peak (157.3 TF/s at the 2.4 GHz peak clock; the shader clock under this "
+                             "load is ~1.9 GHz); traffic = HBM-side bytes per launch from the committed rocprofv3 --pmc passes named in traffic_source "
+                             "(null: no profile for this kernel and size)"})
         line = {
             "metric": "collocation-point residual+grad evals/sec, 2D Poisson 4x64 MLP",
             "value": n_int * args.steps / el,
@@ -230,25 +271,11 @@ def main():
             "point_terms_per_s": sum(n_glob) * args.steps / el,
             "host_entry_ms_per_step": host_path_ms,     # pinn_loss_grad: theta host -> device, results device -> host (PCIe-inclusive)
             "loss_terms": [float(v) for v in losses],
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "traffic": PMC_TRAFFIC_BYTES.get(n_int) if world == 1 else None,
-                         "traffic_note": "HBM bytes/launch from separate rocprofv3 --pmc passes (profiles/r01_pmc_summary_v11.txt); "
-                                         "algorithmic bytes are 8 B/point = 0.5 MB/launch, the rest is the workgroup-private activation-record scratch (L2/Infinity-Cache resident, 16 MB footprint) and the gradient slabs",
-                         "kernel": "k_wave2<Spec2<64,3,2,F=xy,LAP=xy>,FUSED> (interior residual+grad, neuron-split workgroups, C=4 executed jet channels)",
-                         "kernel_ms": dom_ms, "points_per_launch": groups[dom]["points"],
-                         "flops_per_point": algorithmic_flops_per_point(sizes, C_ALG),
-                         "executed_channels": groups[dom]["channels"],
-                         "executed_flops_per_point": algorithmic_flops_per_point(sizes, groups[dom]["channels"]),
-                         "frac_executed": flops_exec / (dom_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                         "all_fused_kernels_ms": all_ms,
-                         "all_fused_kernels_tflops": flops_all / (all_ms * 1e-3) / 1e12 if all_ms else None,
-                         "events": f"{args.events} kernel(s), every {every} step(s) of the timed region: {len(kern_ms)} launches averaged"},
+            "roofline": roof,
+            "roofline_kernels": per_kernel,
         }
         if world == 1 and not args.no_cpu_baseline:
-            wls = workloads.cfg2_poisson2d(points=4096)
-            reps = npde.symbolic_discretize(wls.pde_system, wls.discretization())
-            line["cpu_baseline"] = cpu_baseline(npde, wls, reps.pde_train_sets + reps.bcs_train_sets)
+            line["cpu_baseline"] = cpu_baseline(npde, wl, sets)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -95,6 +95,13 @@ int pinn_loss_grad_device(pinn_handle h, const float* d_theta, const float* term
 int pinn_residual(pinn_handle h, int term, const float* theta, int64_t p, float* r);
 /* Trial function phi(x, theta) of one net (src/pinn_types.jl:88-90): pts = d x n point-major, out = n floats. */
 int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float* pts, int64_t n, float* out);
+/*
+ * derivative(phi, u, x, eps, order, theta) of one net at n points (numeric_derivative, src/pinn_types.jl:445-482; its epsilons come from
+ * get_eps, src/symbolic_utilities.jl:98-103): the derivative of the trial function of order `order` (0..4) along `axes[0..order)`
+ * (network-input axes, 0-based; order 2 may be mixed, orders 3-4 are along one axis).  The engine returns the EXACT derivative the
+ * Taylor-jet kernels carry (the value the reference's central differences approximate to ~1e-8, test/Forward/forward__derivatives.jl:22-44).
+ */
+int pinn_derivative(pinn_handle h, int net, const float* theta, int64_t p, const float* pts, int64_t n, int order, const int* axes, float* out);
 
 /*
  * Resident-theta training loop: theta, the Adam moments and the collocation sets stay in HBM; no

@@ -19,7 +19,7 @@ DEFAULT_PATH = os.path.join(_HERE, "csrc", "libpinn_hip.so")
 SYMBOLS = [
     "pinn_backend", "pinn_abi_version", "pinn_last_error", "pinn_create", "pinn_destroy", "pinn_num_terms",
     "pinn_num_theta", "pinn_set_points", "pinn_set_points_device", "pinn_loss_grad", "pinn_loss_grad_f64",
-    "pinn_term_grads", "pinn_loss_grad_device", "pinn_residual", "pinn_phi", "pinn_last_timing", "pinn_set_timing", "pinn_describe", "pinn_num_groups", "pinn_group_timing",
+    "pinn_term_grads", "pinn_loss_grad_device", "pinn_residual", "pinn_phi", "pinn_derivative", "pinn_last_timing", "pinn_set_timing", "pinn_describe", "pinn_num_groups", "pinn_group_timing",
     "pinn_set_sampler", "pinn_set_point_data", "pinn_set_point_weights", "pinn_get_points", "pinn_adam_init", "pinn_adam_steps", "pinn_adam_get",
 ]
 
@@ -56,6 +56,7 @@ class Library:
         L.pinn_loss_grad_device.argtypes = [vp, vp, fp, vp, vp]
         L.pinn_residual.argtypes = [vp, C.c_int, fp, C.c_int64, fp]
         L.pinn_phi.argtypes = [vp, C.c_int, fp, C.c_int64, fp, C.c_int64, fp]
+        L.pinn_derivative.argtypes = [vp, C.c_int, fp, C.c_int64, fp, C.c_int64, C.c_int, C.POINTER(C.c_int), fp]
         L.pinn_last_timing.argtypes = [vp, fp, fp]
         L.pinn_set_timing.argtypes = [vp, C.c_int, C.c_int]
         L.pinn_describe.argtypes = [vp, C.c_char_p, C.c_int64]
@@ -186,6 +187,18 @@ class Engine:
         self.L.check(self.L.lib.pinn_phi(self.h, net, th.ctypes.data_as(C.POINTER(C.c_float)), th.size,
                                          flat.ctypes.data_as(C.POINTER(C.c_float)), pts.shape[1],
                                          out.ctypes.data_as(C.POINTER(C.c_float))), "pinn_phi")
+        return out
+
+    def derivative(self, net: int, theta, pts, axes: Sequence[int]) -> np.ndarray:
+        """d^k phi_net / dx_axes at the columns of pts (d x N): the engine's counterpart of numeric_derivative (src/pinn_types.jl:445-482)"""
+        th = _f32(theta)
+        pts = np.asarray(pts)
+        flat = _f32(pts.T).reshape(-1)
+        out = np.zeros(pts.shape[1], dtype=np.float32)
+        ax = (C.c_int * max(len(axes), 1))(*[int(a) for a in axes])
+        self.L.check(self.L.lib.pinn_derivative(self.h, net, th.ctypes.data_as(C.POINTER(C.c_float)), th.size,
+                                                flat.ctypes.data_as(C.POINTER(C.c_float)), pts.shape[1], len(axes), ax,
+                                                out.ctypes.data_as(C.POINTER(C.c_float))), "pinn_derivative")
         return out
 
     def set_timing(self, level: int, group: int = -1):

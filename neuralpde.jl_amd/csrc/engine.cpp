@@ -466,24 +466,22 @@ int pinn_residual(pinn_handle h, int term, const float* theta, int64_t p, float*
     return 0;
 }
 
-int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float* pts, int64_t n, float* out) {
-    if (!h || !theta || !pts || !out) return fail("pinn_phi: null argument");
-    pinn_engine& E = *h;
-    if (net < 0 || net >= (int)E.nets.size()) return fail("pinn_phi: net index out of range");
-    if (n <= 0) return fail("pinn_phi: n must be positive");
+// forward-only launch of one network on caller-supplied points with kernel `sp`: the jet channels land in E.d_phi_out as [C][n]
+static int forward_jets(pinn_engine& E, int net, const pk::SpecInfo* sp, const float* theta, int64_t p, const float* pts, int64_t n) {
     const Net& N = E.nets[net];
-    const int LH = (int)N.sizes.size() - 2;
-    const pk::SpecInfo* sp = find_spec(round_hp(N.maxhidden()), LH - 1, N.sizes[0], 0, {}, 0u, nullptr, variant_of(N.act));
-    if (!sp) return fail("pinn_phi: no compiled value-only kernel for this network shape");
-    if (!E.netplans[net].spec) return fail("pinn_phi: network is not used by any term");
+    if (!E.netplans[net].spec) return fail("network is not used by any term");
+    if (sp->family != E.netplans[net].spec->family || sp->PACKED != E.netplans[net].spec->PACKED)
+        return fail("internal: forward kernel and the network's packed weight image disagree");
     if (upload_theta(E, theta, p)) return 1;
     pack_all(E);
-    if (E.phi_cap < n) {
+    if (E.phi_cap < n || E.phi_chan < sp->C) {
+        plat_sync(E.stream);
         plat_free(E.d_phi_pts); plat_free(E.d_phi_out);
-        E.d_phi_pts = (float*)plat_malloc(sizeof(float) * n * N.sizes[0]);
-        E.d_phi_out = (float*)plat_malloc(sizeof(float) * n * sp->C);
-        E.phi_cap = n;
-        if (!E.d_phi_pts || !E.d_phi_out) return fail("device allocation failed (phi)");
+        E.phi_cap = std::max(E.phi_cap, n);
+        E.phi_chan = std::max(E.phi_chan, sp->C);
+        E.d_phi_pts = (float*)plat_malloc(sizeof(float) * E.phi_cap * 8);
+        E.d_phi_out = (float*)plat_malloc(sizeof(float) * E.phi_cap * E.phi_chan);
+        if (!E.d_phi_pts || !E.d_phi_out) { E.phi_cap = 0; E.phi_chan = 0; return fail("device allocation failed (phi)"); }
     }
     plat_h2d(E.d_phi_pts, pts, sizeof(float) * n * N.sizes[0], E.stream);
     pk::GroupArgs ga;
@@ -502,9 +500,54 @@ int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float*
     ga.terms[0].ntiles = (int)((n + sp->TP - 1) / sp->TP);
     ga.terms[0].out = E.d_phi_out;
     ga.ntiles = ga.terms[0].ntiles;
-    const int blocks = std::max(1, std::min(E.ncu, (ga.ntiles + 3) / 4));
+    const int blocks = std::max(1, std::min(E.ncu * sp->WG_PER_CU, sp->family == 2 ? ga.ntiles : (ga.ntiles + 3) / 4));
     sp->launch(ga, pk::MODE_FWD, blocks, E.stream);
+    return 0;
+}
+
+int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float* pts, int64_t n, float* out) {
+    if (!h || !theta || !pts || !out) return fail("pinn_phi: null argument");
+    pinn_engine& E = *h;
+    if (net < 0 || net >= (int)E.nets.size()) return fail("pinn_phi: net index out of range");
+    if (n <= 0) return fail("pinn_phi: n must be positive");
+    const Net& N = E.nets[net];
+    if (!E.netplans[net].spec) return fail("pinn_phi: network is not used by any term");
+    const int LH = (int)N.sizes.size() - 2;
+    const pk::SpecInfo* sp = find_spec(round_hp(N.maxhidden()), LH - 1, N.sizes[0], 0, {}, 0u, nullptr, variant_of(N.act), E.netplans[net].spec->family);
+    if (!sp) return fail("pinn_phi: no compiled value-only kernel for this network shape");
+    if (forward_jets(E, net, sp, theta, p, pts, n)) return 1;
     if (plat_d2h(out, E.d_phi_out, sizeof(float) * n, E.stream)) return fail("D2H copy failed");
+    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    return 0;
+}
+
+int pinn_derivative(pinn_handle h, int net, const float* theta, int64_t p, const float* pts, int64_t n, int order, const int* axes, float* out) {
+    if (!h || !theta || !pts || !out) return fail("pinn_derivative: null argument");
+    pinn_engine& E = *h;
+    if (net < 0 || net >= (int)E.nets.size()) return fail("pinn_derivative: net index out of range");
+    if (n <= 0) return fail("pinn_derivative: n must be positive");
+    if (order < 0 || order > 4 || (order > 0 && !axes)) return fail("pinn_derivative: order must be 0..4 (with `order` axes)");
+    const Net& N = E.nets[net];
+    if (!E.netplans[net].spec) return fail("pinn_derivative: network is not used by any term");
+    Slot sl;
+    sl.net = net; sl.order = order; sl.lap = 0;
+    for (int a = 0; a < 4; ++a) sl.axes[a] = a < order ? axes[a] : 0;
+    std::sort(sl.axes, sl.axes + order);
+    for (int a = 0; a < order; ++a)
+        if (sl.axes[a] < 0 || sl.axes[a] >= N.sizes[0]) return fail("pinn_derivative: axis out of range");
+    if (order >= 3 && sl.axes[0] != sl.axes[order - 1]) return fail("pinn_derivative: mixed derivatives of order > 2 are not carried by the jet kernels");
+    unsigned need_first = 0, need_hi = 0;
+    std::vector<std::pair<int, int>> need_pairs;
+    for (int a = 0; a < order; ++a) need_first |= 1u << sl.axes[a];
+    if (order >= 2) need_pairs.push_back({sl.axes[0], sl.axes[1]});
+    if (order >= 3) need_hi = (unsigned)order << (4 * sl.axes[0]);
+    const int LH = (int)N.sizes.size() - 2;
+    const pk::SpecInfo* sp = find_spec(round_hp(N.maxhidden()), LH - 1, N.sizes[0], need_first, need_pairs, need_hi, nullptr, variant_of(N.act), E.netplans[net].spec->family);
+    if (!sp) return fail("pinn_derivative: no compiled kernel carries this derivative for this network shape");
+    const int ch = chan_of(*sp, sl);
+    if (ch < 0) return fail("internal: derivative has no channel");
+    if (forward_jets(E, net, sp, theta, p, pts, n)) return 1;
+    if (plat_d2h(out, E.d_phi_out + (size_t)ch * n, sizeof(float) * n, E.stream)) return fail("D2H copy failed");
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
     return 0;
 }

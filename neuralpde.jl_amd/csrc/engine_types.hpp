@@ -181,6 +181,7 @@ struct pinn_engine {
     float* d_phi_pts = nullptr;
     float* d_phi_out = nullptr;
     int64_t phi_cap = 0;
+    int phi_chan = 0;                // jet channels d_phi_out holds per point
 };
 
 namespace pe {
@@ -192,7 +193,8 @@ bool fuse_laplacian(Term& T, int np);
 // plan.cpp
 int round_hp(int h);
 const pk::SpecInfo* find_spec(int HP, int NHH, int D, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs,
-                              unsigned need_hi, std::vector<int>* pair_index, int need_variant = 0);
+                              unsigned need_hi, std::vector<int>* pair_index, int need_variant = 0, int need_family = 0);
+int chan_of(const pk::SpecInfo& s, const Slot& sl);      // jet channel of a slot in a kernel's channel set (-1: not carried)
 // kernel-variant bit a network's activation needs beyond the tanh / sigmoid kernels every spec has (SpecInfo::has_sin)
 inline int variant_of(int act) { return act == pk::ACT_SIN ? 1 : (act == pk::ACT_MIXED ? 2 : 0); }
 std::string spec_name(const pk::SpecInfo& s);

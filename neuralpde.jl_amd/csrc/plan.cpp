@@ -13,7 +13,7 @@ int round_hp(int h) {
 }
 
 const pk::SpecInfo* find_spec(int HP, int NHH, int D, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs,
-                              unsigned need_hi, std::vector<int>* pair_index, int need_variant) {
+                              unsigned need_hi, std::vector<int>* pair_index, int need_variant, int need_family) {
     const pk::SpecInfo* best = nullptr;
     for (const pk::SpecInfo& s : pk::registry()) {
         if (s.HP != HP || s.NHH != NHH || s.D != D) continue;
@@ -35,6 +35,7 @@ const pk::SpecInfo* find_spec(int HP, int NHH, int D, unsigned need_first, const
         // PINN_KERNEL_FAMILY=1|2 restricts the choice (tests / A-B measurements); default: family 2 where compiled
         static const int want_family = [] { const char* e = std::getenv("PINN_KERNEL_FAMILY"); return e ? std::atoi(e) : 0; }();
         if (want_family && s.family != want_family) continue;
+        if (need_family && s.family != need_family) continue;
         if (!best || s.C < best->C || (s.C == best->C && s.family > best->family) ||
             (s.C == best->C && s.family == best->family && s.PG > best->PG)) best = &s;
     }

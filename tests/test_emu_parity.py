@@ -9,13 +9,14 @@ import helpers
 import pinn_oracle as po
 
 TOL = 1e-5
+EXPECTED_BACKEND = "emu"      # tests/test_gpu_mirror.py re-runs this module's tests on the hardware with "hip" here
 
 
 def check(npde, sysm, chains, strat, theta, weights=None, param_estim=False, tol=TOL, mode="stencil"):
     disc = npde.PhysicsInformedNN(chains if len(chains) > 1 else chains[0], strat, init_params=theta,
                                   param_estim=param_estim)
     rep = npde.symbolic_discretize(sysm, disc)
-    assert rep.engine.L.backend == "emu"
+    assert rep.engine.L.backend == EXPECTED_BACKEND
     sets = rep.pde_train_sets + rep.bcs_train_sets
     th = rep.flat_init_params
     losses, grad = rep.engine.loss_grad(th, weights)
@@ -593,3 +594,45 @@ def test_long_residual_takes_the_two_launch_path(npde, use_emu):
     strat = npde.QuasiRandomTraining(45, bcs_points=20, sampling_alg=npde.SobolSample(seed=4), resampling=False, minibatch=1)
     rep, prob, sets, th = check(npde, sysm, [chain], strat, theta_for(chain, 91), weights=[1.0, 2.0, 0.5])
     assert len(rep.ir.terms[0].ops) > 32 and "coupled" in rep.engine.describe()
+
+
+def test_forward_derivatives_mirror(npde, use_emu):
+    """Mirror of test/Forward/forward__derivatives.jl:7-44 at the C ABI: a 2 -> 16 -> 16 -> 1 sigmoid chain at the point [1, 2];
+    `pinn_derivative` (the engine's numeric_derivative, exact Taylor jets carried by the forward kernel) against (a) the exact
+    derivatives (the reference compares with Zygote.gradient / Zygote.hessian) and (b) the reference's central-difference stencils with
+    its get_eps steps, at the reference's tolerances: first order atol 1e-8 in Float64 — here bounded by fp32 arithmetic, so 2e-6 —
+    and second order (xx, xy, yy) atol 4e-5."""
+    import torch
+    sysm, _ = helpers.shape_problem(npde, 16, 2, 2)                # any residual with u_x, u_y, u_xx, u_xy, u_yy: binds the network to the Hessian kernel
+    chain = npde.Chain(npde.Dense(2, 16, "sigmoid"), npde.Dense(16, 16, "sigmoid"), npde.Dense(16, 1))
+    ochain = po.Chain((2, 16, 16, 1), "sigmoid")
+    u = lambda cord, th, phi: phi(cord, th).sum(dim=0, keepdim=True)      # u_ of the reference test
+    x = np.array([[1.0], [2.0]])
+    xt = torch.tensor(x, dtype=po.DT)
+    for seed in range(3):
+        theta = po.glorot_theta(ochain, np.random.default_rng(seed), bias_amp=0.0)
+        rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=theta))
+        eng = rep.engine
+        tht = torch.tensor(theta, dtype=po.DT)
+        assert abs(eng.derivative(0, theta, x, [])[0] - float(ochain(xt, tht))) < 2e-6             # phi([1, 2], theta)
+        for ax in (0, 1):
+            got = float(eng.derivative(0, theta, x, [ax])[0])
+            fd = float(po.numeric_derivative(ochain, u, xt, [po.get_eps(2, ax + 1, np.float64, 1)], 1, tht))
+            ex = float(po.exact_derivative(ochain, u, xt, [ax], tht))
+            assert abs(got - ex) < 2e-6 and abs(got - fd) < 2e-6, (ax, got, ex, fd)
+        ex_, ey_ = po.get_eps(2, 1, np.float64, 2), po.get_eps(2, 2, np.float64, 2)
+        for epss, axes in [([ex_, ex_], [0, 0]), ([ex_, ey_], [0, 1]), ([ey_, ey_], [1, 1])]:
+            got = float(eng.derivative(0, theta, x, axes)[0])
+            fd = float(po.numeric_derivative(ochain, u, xt, epss, 2, tht))
+            ex = float(po.exact_derivative(ochain, u, xt, axes, tht))
+            assert abs(got - ex) < 4e-5 and abs(got - fd) < 4e-5, (axes, got, ex, fd)
+        assert abs(float(eng.derivative(0, theta, x, [1, 0])[0]) - float(eng.derivative(0, theta, x, [0, 1])[0])) == 0.0    # axes are sorted
+    # a batch of points, and the loud failures
+    pts = np.random.default_rng(5).uniform(0, 1, size=(2, 100))
+    got = eng.derivative(0, theta, pts, [0, 0])
+    ex = po.exact_derivative(ochain, u, torch.tensor(pts, dtype=po.DT), [0, 0], tht).detach().numpy().reshape(-1)
+    assert np.max(np.abs(got - ex)) < 1e-5
+    with pytest.raises(Exception, match="mixed derivatives of order > 2|no compiled kernel"):
+        eng.derivative(0, theta, pts, [0, 0, 1])
+    with pytest.raises(Exception, match="axis out of range"):
+        eng.derivative(0, theta, pts, [2])

@@ -414,31 +414,6 @@ def test_sin_activation_gpu(npde, hip_lib):
         assert le.max() < TOL and g2 < TOL and gi < TOL, (le, g2, gi)
 
 
-def test_reference_examples_gpu(npde, hip_lib, monkeypatch):
-    """the documented reference examples of tests/test_reference_examples.py, on the hardware (same statements, same oracle)."""
-    import test_reference_examples as ex
-
-    def gpu_check(npde_, sysm, chains, strat, theta, weights=None, param_estim=False, tol=TOL, mode="stencil"):
-        disc = npde_.PhysicsInformedNN(chains if len(chains) > 1 else chains[0], strat, init_params=theta, param_estim=param_estim)
-        rep = npde_.symbolic_discretize(sysm, disc)
-        assert rep.engine.L.backend == "hip"
-        sets = rep.pde_train_sets + rep.bcs_train_sets
-        th = rep.flat_init_params
-        losses, grad = rep.engine.loss_grad(th, weights)
-        prob = helpers.oracle_problem(npde_, sysm, chains, param_estim=param_estim)
-        ref = po.loss_and_grad(prob, th, sets, weights=weights, mode=mode)
-        le, g2, gi = helpers.rel_errors(losses, grad, ref)
-        assert le.max() < tol and g2 < tol and gi < tol, (le, g2, gi)
-        return rep, prob, sets, th
-
-    monkeypatch.setattr(ex, "check", gpu_check)
-    for name in ("test_wave_equation", "test_mixed_derivative_pde", "test_system_of_three_pdes", "test_linear_parabolic_system",
-                 "test_nonlinear_elliptic_first_order_system", "test_lorenz_parameter_estimation_terms", "test_nonlinear_hyperbolic_system"):
-        getattr(ex, name)(npde, None)
-    ex.test_data_misfit_terms_on_device(npde, None)          # DataLoss extension: device objective == physics + host additional_loss
-    ex.test_quadrature_training_stand_in(npde, None)         # per-point quadrature weights
-
-
 def test_bench_two_ranks_share_the_gpu(hip_lib):
     """bench.py's N > 1 path (point sharding with n_norm = global N, all-reduce of [gradient | sums]) with two ranks folded onto
     the one visible GPU and the gloo backend: per-term losses must equal the single-rank run's (RCCL itself needs a multi-GPU node)."""

@@ -95,8 +95,7 @@ def test_golden_fixtures_reproduce(npde):
     makers = {"cfg1_poisson1d_1024": lambda: workloads.cfg1_poisson1d(1024),
               "cfg2_poisson2d_512": lambda: workloads.cfg2_poisson2d(points=512, bcs_points=128),
               "cfg3_burgers_512": lambda: workloads.cfg3_burgers(points=512, bcs_points=128)}
-    files = sorted(glob.glob(os.path.join(root, "*.npz")))
-    assert len(files) >= 3
+    files = [os.path.join(root, n + ".npz") for n in sorted(makers)]
     for f in files:
         g = np.load(f)
         wl = makers[os.path.basename(f)[:-4]]()
@@ -108,3 +107,24 @@ def test_golden_fixtures_reproduce(npde):
         # the two oracle modes (reference FD semantics vs exact derivatives) agree far inside the 1e-5 parity bar
         assert np.linalg.norm(g["grad_stencil"] - g["grad_exact"]) / np.linalg.norm(g["grad_exact"]) < 1e-6
         assert np.max(np.abs(g["losses_stencil"] - g["losses_exact"]) / g["losses_exact"]) < 1e-6
+
+
+def test_full_size_fixtures_reproduce(npde):
+    """The full-size fixtures (`python oracle/make_golden.py full`): the regenerated point sets have the pinned SHA-256 digests, and
+    the benchmarked configuration's fixture (cfg2_full: 65,536 + 4 x 65,536 points) is what the oracle computes today."""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "oracle"))
+    import helpers
+    import make_golden as mg
+    for name in ("cfg2_full", "cfg3_full"):
+        g = np.load(os.path.join(root, "tests", "golden", name + ".npz"))
+        wl = mg.FULL_CASES[name][0]()
+        sets = mg.point_sets(wl)
+        assert [mg.set_digest(s) for s in sets] == list(g["set_sha256"])
+        if name != "cfg2_full":
+            continue
+        prob = helpers.oracle_problem(npde, wl.pde_system, wl.chains)
+        losses, grad = mg.chunked_loss_and_grad(prob, g["theta"], sets, g["weights"], chunk=int(g["chunk"]))
+        np.testing.assert_allclose(losses, g["losses_stencil"], rtol=1e-12)
+        np.testing.assert_allclose(grad, g["grad_stencil"], rtol=1e-9, atol=1e-13)

@@ -15,3 +15,5 @@ run mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRB
 run waves SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA
 run lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS
 ls -R $REPO/$OUT | head -30
+# text summary per pass + profiles/pmc_traffic.json (HBM-side bytes per launch of the fused kernels; read by bench.py's roofline.traffic)
+python $REPO/tools/pmc_summarize.py $REPO/$OUT $REPO/$OUT/pmc_summary.txt $REPO/$OUT/pmc_traffic.json
