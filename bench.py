@@ -17,7 +17,7 @@ value = interior collocation points x steps / time  (the metric's unit: interior
 the 4x65,536 boundary-term points ride along in every step and are counted in `point_terms_per_s`).
 
 JSON extras: "roofline" (fp32 MFMA roofline of the dominant kernel = the fused residual kernel with the most device time, flops the
-kernel executes per SURVEY.md §8d's formula ÷ its mean HIP-event duration over >= 12 launches sampled inside the timed region),
+kernel executes per SURVEY.md §8d's formula ÷ its mean HIP-event duration over >= 10 launches sampled inside the timed region),
 "roofline_kernels" (the same for every fused kernel of the step) and "cpu_baseline" (the float64 oracle = CPU restatement of the
 reference algorithm, timed on this box's host cores on the same full-size workload with a fixed thread count; rank 0, N=1 only).
 """
@@ -110,7 +110,7 @@ def main():
                     help="HIP events recorded inside the timed region around every fused residual kernel (sampled steps only), or none")
     ap.add_argument("--event-every", type=int, default=0, help="record the HIP events on every M-th timed step (a start/stop pair plus "
                     "its read-back costs ~10 us of host+dispatch time per kernel; the sampled launches are inside the timed region). "
-                    "0 (default): steps // 12, i.e. at least 12 sampled launches of every kernel")
+                    "0 (default): steps // 10, i.e. at least 10 sampled launches of every kernel")
     args = ap.parse_args()
 
     import numpy as np
@@ -173,7 +173,7 @@ def main():
     eng.set_timing(ev_level, ev_group)
     step()
     kern_ms = []
-    every = max(1, args.event_every if args.event_every > 0 else args.steps // 12)
+    every = max(1, args.event_every if args.event_every > 0 else args.steps // 10)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
