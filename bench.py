@@ -122,16 +122,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    # PINN_BENCH_BACKEND=gloo (+ ranks folded onto the visible devices): functional check of the N > 1 path on a 1-GPU box
+    # Control plane (rendezvous, barrier, max-over-ranks of the elapsed time): a gloo process group over TCP.  Data plane (the ONE
+    # all-reduce per step of [gradient | per-term sums]): the ENGINE's own RCCL communicator (pinn_comm_init_rank +
+    # pinn_loss_grad_sharded_device, issued on the evaluation's stream) — torch.distributed carries no tensor of the timed region.
+    # PINN_BENCH_COMM=torch falls back to a torch.distributed all-reduce (nccl = RCCL, or gloo with PINN_BENCH_BACKEND=gloo and the
+    # ranks folded onto the visible devices: functional check of the N > 1 path on a 1-GPU box).
     backend = os.environ.get("PINN_BENCH_BACKEND", "nccl")
-    local_dev = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    comm_mode = os.environ.get("PINN_BENCH_COMM", "engine" if backend == "nccl" else "torch")
+    local_dev = local_rank % torch.cuda.device_count()        # (== local_rank whenever the node has one GPU per rank)
     torch.cuda.set_device(local_dev)
+    data_group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_dev))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if comm_mode == "torch" and backend == "nccl":
+            data_group = dist.new_group(backend="nccl", device_id=torch.device("cuda", local_dev))
 
     import pinn_import
     npde = pinn_import.load()
@@ -158,10 +163,34 @@ def main():
 
     # N = 1: the reduction kernel writes [grad | sums] straight into the pinned (device-mapped, coherent) host buffer — no
     # copy command; N > 1: the all-reduce needs the vector in HBM first, then one D2H copy.
+    if world > 1 and comm_mode == "engine":
+        uid = [npde.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        try:
+            eng.comm_init_rank(world, rank, uid[0])
+        except Exception as e:                                    # keep the run alive: report which path carried the all-reduce
+            print(f"[bench rank {rank}] engine communicator failed ({e}); falling back to torch.distributed", file=sys.stderr)
+            comm_mode = "torch-fallback"
+        modes = [None] * world
+        dist.all_gather_object(modes, comm_mode)
+        if any(m != "engine" for m in modes):
+            if comm_mode == "engine":
+                eng.comm_destroy()
+            comm_mode = "torch-fallback"
+            data_group = dist.new_group(backend="nccl", device_id=torch.device("cuda", local_dev))
+
     def step():
-        if world > 1:
+        if world > 1 and comm_mode == "engine":
+            eng.loss_grad_sharded_device(theta_d.data_ptr(), out_d.data_ptr(), None, stream.cuda_stream)
+            out_h.copy_(out_d, non_blocking=True)
+        elif world > 1:
             eng.loss_grad_device(theta_d.data_ptr(), out_d.data_ptr(), None, stream.cuda_stream)
-            dist.all_reduce(out_d)
+            if data_group is not None:
+                dist.all_reduce(out_d, group=data_group)
+            else:                                                  # gloo functional check: reduce on the host
+                tmp = out_d.cpu()
+                dist.all_reduce(tmp)
+                out_d.copy_(tmp)
             out_h.copy_(out_d, non_blocking=True)
         else:
             eng.loss_grad_device(theta_d.data_ptr(), out_h.data_ptr(), None, stream.cuda_stream)
@@ -190,7 +219,7 @@ def main():
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
@@ -267,7 +296,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl.name, "interior_points": n_int, "boundary_terms": K - 1,
                        "boundary_points_per_term": n_glob[1], "theta": P,
-                       "parallelism": f"point-shard x{world}" if world > 1 else "single"},
+                       "parallelism": f"point-shard x{world}" if world > 1 else "single",
+                       "all_reduce": ({"engine": "engine-owned RCCL communicator (pinn_loss_grad_sharded_device)", "torch": f"torch.distributed ({backend})",
+                                       "torch-fallback": "torch.distributed (nccl) after the engine communicator failed"}[comm_mode] if world > 1 else None)},
             "point_terms_per_s": sum(n_glob) * args.steps / el,
             "host_entry_ms_per_step": host_path_ms,     # pinn_loss_grad: theta host -> device, results device -> host (PCIe-inclusive)
             "loss_terms": [float(v) for v in losses],

@@ -44,7 +44,8 @@ const char* pinn_last_error(void);
  * Replaces: build_loss_function + RuntimeGeneratedFunction (src/discretize.jl:163-175).
  * Unsupported expressions / network shapes fail HERE (never a silent fallback).
  */
-int pinn_create(const char* descriptor, pinn_handle* out);
+int pinn_create(const char* descriptor, pinn_handle* out);          /* on the caller's current HIP device */
+int pinn_create_on(const char* descriptor, int device, pinn_handle* out);   /* on HIP device `device` (single process, several GPUs) */
 int pinn_destroy(pinn_handle h);
 
 /* Number of loss terms K (pde terms first, then bcs: the order of src/discretize.jl:569-570) and length of theta. */
@@ -90,6 +91,29 @@ int pinn_term_grads(pinn_handle h, const float* theta, int64_t p, double* term_l
  * reduction kernel then delivers the result to the host without a copy command (what pinn_loss_grad does internally).
  */
 int pinn_loss_grad_device(pinn_handle h, const float* d_theta, const float* term_w, float* d_out, void* stream);
+
+/*
+ * Engine-owned data parallelism over the GPUs of one node: every term's point set is split into contiguous column
+ * blocks (install each block with pinn_set_points(..., n_norm = GLOBAL N)), theta is replicated, and ONE RCCL all-reduce (sum, fp32) of
+ * the packed vector [gradient (P) | per-term sums of squares (K)] — 51 KB for 4x64 — completes the evaluation on the evaluation's own
+ * stream.  The reference aggregates the K term losses on the host (src/discretize.jl:568-588); this is that aggregation across devices.
+ *   one process per GPU : rank 0: pinn_comm_unique_id(id); distribute the PINN_COMM_ID_BYTES bytes; all ranks: pinn_comm_init_rank;
+ *                         per evaluation pinn_loss_grad_sharded_device (as pinn_loss_grad_device, d_out all-reduced in place; d_out
+ *                         must be device memory; divide the K sums by n_norm_k afterwards).
+ *   one process, G GPUs : pinn_create_on(desc, g) for g = 0..G-1; pinn_comm_init_all(handles, G) (ncclCommInitAll); per evaluation
+ *                         pinn_loss_grad_sharded(handles, G, theta, ...) = pinn_loss_grad over all shards (host pointers in and out).
+ * RCCL is loaded on first use; single-GPU work never needs it.
+ */
+#define PINN_COMM_ID_BYTES 128
+int pinn_comm_unique_id(void* id, int64_t nbytes);
+int pinn_comm_init_rank(pinn_handle h, int nranks, int rank, const void* id, int64_t nbytes);
+int pinn_comm_init_all(pinn_handle* hs, int ndev);
+int pinn_comm_size(pinn_handle h);
+int pinn_comm_rank(pinn_handle h);
+int pinn_comm_destroy(pinn_handle h);
+int pinn_loss_grad_sharded_device(pinn_handle h, const float* d_theta, const float* term_w, float* d_out, void* stream);
+int pinn_loss_grad_sharded(pinn_handle* hs, int ndev, const float* theta, int64_t p, const float* term_w,
+                           double* term_losses, float* grad);
 
 /* residual_k(set_k, theta): the datafree loss function of src/discretize.jl:174 on the installed set; r has n_k floats. */
 int pinn_residual(pinn_handle h, int term, const float* theta, int64_t p, float* r);

@@ -8,7 +8,7 @@ Python host mirror of the reference's discretizer API over the C ABI of libpinn_
 See DESIGN.md for the kernel design and INTEGRATION.md for the Julia `ccall` binding.
 """
 from . import _lib
-from ._lib import Engine, EngineError, Library
+from ._lib import Engine, EngineError, Library, comm_init_all, comm_unique_id, loss_grad_sharded
 from .ir import Instr, NetIR, ProblemIR, Slot, TermIR
 from .bpinn import physics_loglikelihood
 from .adaptive import (AbstractAdaptiveLoss, GradientScaleAdaptiveLoss, MiniMaxAdaptiveLoss, ReLoBRaLoAdaptiveLoss,

@@ -20,6 +20,8 @@ SYMBOLS = [
     "pinn_backend", "pinn_abi_version", "pinn_last_error", "pinn_create", "pinn_destroy", "pinn_num_terms",
     "pinn_num_theta", "pinn_set_points", "pinn_set_points_device", "pinn_loss_grad", "pinn_loss_grad_f64",
     "pinn_term_grads", "pinn_loss_grad_device", "pinn_residual", "pinn_phi", "pinn_derivative", "pinn_last_timing", "pinn_set_timing", "pinn_describe", "pinn_num_groups", "pinn_group_timing",
+    "pinn_create_on", "pinn_comm_unique_id", "pinn_comm_init_rank", "pinn_comm_init_all", "pinn_comm_size", "pinn_comm_rank", "pinn_comm_destroy",
+    "pinn_loss_grad_sharded_device", "pinn_loss_grad_sharded",
     "pinn_set_sampler", "pinn_set_point_data", "pinn_set_point_weights", "pinn_get_points", "pinn_adam_init", "pinn_adam_steps", "pinn_adam_get",
 ]
 
@@ -44,6 +46,15 @@ class Library:
         L.pinn_abi_version.restype = C.c_int
         L.pinn_last_error.restype = C.c_char_p
         L.pinn_create.argtypes = [C.c_char_p, C.POINTER(vp)]
+        L.pinn_create_on.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+        L.pinn_comm_unique_id.argtypes = [vp, C.c_int64]
+        L.pinn_comm_init_rank.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int64]
+        L.pinn_comm_init_all.argtypes = [C.POINTER(vp), C.c_int]
+        L.pinn_comm_size.argtypes = [vp]
+        L.pinn_comm_rank.argtypes = [vp]
+        L.pinn_comm_destroy.argtypes = [vp]
+        L.pinn_loss_grad_sharded_device.argtypes = [vp, vp, fp, vp, vp]
+        L.pinn_loss_grad_sharded.argtypes = [C.POINTER(vp), C.c_int, fp, C.c_int64, fp, dp, fp]
         L.pinn_destroy.argtypes = [vp]
         L.pinn_num_terms.argtypes = [vp]
         L.pinn_num_theta.argtypes = [vp]
@@ -103,13 +114,50 @@ def _f32(a) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
 
 
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id(lib: Optional[Library] = None) -> bytes:
+    """rank 0 of a one-process-per-GPU job: the 128-byte id every rank passes to Engine.comm_init_rank"""
+    L = lib or default_library()
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    L.check(L.lib.pinn_comm_unique_id(buf, COMM_ID_BYTES), "pinn_comm_unique_id")
+    return buf.raw
+
+
+def comm_init_all(engines: Sequence["Engine"]):
+    """single process, one engine per device (Engine(descriptor, device=g)): form their communicator (ncclCommInitAll)"""
+    L = engines[0].L
+    hs = (C.c_void_p * len(engines))(*[e.h for e in engines])
+    L.check(L.lib.pinn_comm_init_all(hs, len(engines)), "pinn_comm_init_all")
+
+
+def loss_grad_sharded(engines: Sequence["Engine"], theta, weights=None, want_grad: bool = True):
+    """one evaluation over all devices of a comm_init_all communicator: every engine holds its shard of every term's point set
+    (set_points(..., n_norm = global N)); returns the GLOBAL per-term losses and gradient (pinn_loss_grad_sharded)"""
+    e0 = engines[0]
+    L = e0.L
+    hs = (C.c_void_p * len(engines))(*[e.h for e in engines])
+    th = _f32(theta)
+    losses = np.zeros(e0.K, dtype=np.float64)
+    grad = np.zeros(e0.P, dtype=np.float32) if want_grad else None
+    w = _f32(weights) if weights is not None else None
+    L.check(L.lib.pinn_loss_grad_sharded(hs, len(engines), th.ctypes.data_as(C.POINTER(C.c_float)), th.size,
+                                         w.ctypes.data_as(C.POINTER(C.c_float)) if w is not None else None,
+                                         losses.ctypes.data_as(C.POINTER(C.c_double)),
+                                         grad.ctypes.data_as(C.POINTER(C.c_float)) if grad is not None else None), "pinn_loss_grad_sharded")
+    return losses, grad
+
+
 class Engine:
     """One `pinn_handle`."""
 
-    def __init__(self, descriptor: str, lib: Optional[Library] = None):
+    def __init__(self, descriptor: str, lib: Optional[Library] = None, device: int = -1):
+        """device: HIP device index for single-process multi-GPU use (pinn_create_on); -1 = the caller's current device"""
         self.L = lib or default_library()
         self.h = C.c_void_p()
-        self.L.check(self.L.lib.pinn_create(descriptor.encode(), C.byref(self.h)), "pinn_create")
+        self.descriptor = descriptor
+        self.L.check(self.L.lib.pinn_create_on(descriptor.encode(), device, C.byref(self.h)), "pinn_create")
         self.K = self.L.lib.pinn_num_terms(self.h)
         self.P = int(self.L.lib.pinn_num_theta(self.h))
 
@@ -171,6 +219,25 @@ class Engine:
         self.L.check(self.L.lib.pinn_loss_grad_device(
             self.h, C.c_void_p(d_theta), w.ctypes.data_as(C.POINTER(C.c_float)) if w is not None else None,
             C.c_void_p(d_out), C.c_void_p(stream)), "pinn_loss_grad_device")
+
+    # ---- engine-owned data parallelism (include/pinn_hip.h: pinn_comm_*) ----
+    def comm_init_rank(self, nranks: int, rank: int, uid: bytes):
+        """one process per GPU: join the communicator identified by `uid` (comm_unique_id() of rank 0, distributed by the host side)"""
+        buf = C.create_string_buffer(bytes(uid), COMM_ID_BYTES)
+        self.L.check(self.L.lib.pinn_comm_init_rank(self.h, nranks, rank, buf, COMM_ID_BYTES), "pinn_comm_init_rank")
+
+    def comm_size(self) -> int:
+        return self.L.lib.pinn_comm_size(self.h)
+
+    def comm_destroy(self):
+        self.L.check(self.L.lib.pinn_comm_destroy(self.h), "pinn_comm_destroy")
+
+    def loss_grad_sharded_device(self, d_theta: int, d_out: int, weights=None, stream: int = 0):
+        """pinn_loss_grad_device on this rank's shards + the engine's all-reduce of d_out ([P + K] floats, device memory) on `stream`"""
+        w = _f32(weights) if weights is not None else None
+        self.L.check(self.L.lib.pinn_loss_grad_sharded_device(
+            self.h, C.c_void_p(d_theta), w.ctypes.data_as(C.POINTER(C.c_float)) if w is not None else None,
+            C.c_void_p(d_out), C.c_void_p(stream)), "pinn_loss_grad_sharded_device")
 
     def residual(self, term: int, theta, n: int) -> np.ndarray:
         th = _f32(theta)

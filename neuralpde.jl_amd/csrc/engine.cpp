@@ -92,10 +92,12 @@ aux::ExprArgs expr_args(pinn_engine& E, Coupled& Cp, float scale, float* resid) 
     return a;
 }
 
+}  // namespace
+
 // the device section shared by all loss/grad entry points.  d_theta: theta in device memory; d_out: [P + K] floats in
 // device memory.  Launches per evaluation: pack (1 per net) -> fused residual kernel (1 per group) -> reduce1 -> reduce2.
-int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const float* term_w, int only_term /* -1 = all */, bool timing,
-                  double* lossraw = nullptr /* K exact double sums; default: E.d_lossraw */) {
+int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const float* term_w, int only_term /* -1 = all */, bool timing,
+                  double* lossraw /* K exact double sums; default: E.d_lossraw */) {
     if (ensure_points(E)) return 1;
     const int K = (int)E.terms.size();
     const bool phase_ev = timing && E.timing_level >= 2;
@@ -206,14 +208,12 @@ int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const floa
     return 0;
 }
 
-int upload_theta(pinn_engine& E, const float* theta, int64_t p) {
+int pe::upload_theta(pinn_engine& E, const float* theta, int64_t p) {
     if (p != E.ntheta) return fail("theta length " + std::to_string(p) + " != ntheta " + std::to_string(E.ntheta));
     std::memcpy(E.hp_theta, theta, sizeof(float) * p);          // pinned staging: the copy below is a plain DMA, no pageable bounce
     if (plat_h2d(E.d_theta, E.hp_theta, sizeof(float) * p, E.stream)) return fail(std::string("H2D copy of theta failed: ") + plat_last_error());
     return 0;
 }
-
-}  // namespace
 
 // =================================================================================================
 // C ABI
@@ -224,12 +224,18 @@ const char* pinn_backend(void) { return plat_name(); }
 int pinn_abi_version(void) { return 1; }
 const char* pinn_last_error(void) { return g_err.c_str(); }
 
-int pinn_create(const char* descriptor, pinn_handle* out) {
+int pinn_create(const char* descriptor, pinn_handle* out) { return pinn_create_on(descriptor, -1, out); }
+
+int pinn_create_on(const char* descriptor, int device, pinn_handle* out) {
     if (!descriptor || !out) return fail("pinn_create: null argument");
     *out = nullptr;
     std::string err;
     if (plat_init(err)) return fail(err);
+    if (device >= plat_device_count()) return fail("pinn_create_on: device " + std::to_string(device) + " does not exist (" + std::to_string(plat_device_count()) + " visible)");
+    const int dev = device < 0 ? plat_get_device() : device;
+    DeviceScope scope(dev);
     std::unique_ptr<pinn_engine> E(new pinn_engine());
+    E->device = dev;
     if (parse_descriptor(descriptor, *E)) return 1;
     E->ncu = plat_num_cus();
     E->stream = plat_stream_create();
@@ -269,6 +275,8 @@ int pinn_create(const char* descriptor, pinn_handle* out) {
 int pinn_destroy(pinn_handle h) {
     if (!h) return 0;
     pinn_engine& E = *h;
+    DeviceScope scope(E.device);
+    pinn_comm_destroy(h);
     plat_sync(E.stream);
     for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_resid); plat_free(T.d_lb); plat_free(T.d_ub); plat_free(T.d_src_prog); plat_free(T.d_src); plat_free(T.d_data); plat_free(T.d_pw); }
     plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist);
@@ -301,6 +309,7 @@ int64_t pinn_num_theta(pinn_handle h) { return h ? h->ntheta : -1; }
 static int set_points_impl(pinn_handle h, int term, const float* pts, int64_t n, int64_t n_norm, bool device) {
     if (!h) return fail("null handle");
     pinn_engine& E = *h;
+    DeviceScope scope(E.device);
     if (term < 0 || term >= (int)E.terms.size()) return fail("pinn_set_points: term index out of range");
     if (!pts || n <= 0) return fail("pinn_set_points: empty point set (the reference's mean(abs2, .) over an empty set is NaN; refusing)");
     Term& T = E.terms[term];
@@ -367,6 +376,7 @@ int pinn_set_points_device(pinn_handle h, int term, const float* d_pts, int64_t 
 int pinn_loss_grad(pinn_handle h, const float* theta, int64_t p, const float* term_w, double* term_losses, float* grad) {
     if (!h || !theta) return fail("pinn_loss_grad: null argument");
     pinn_engine& E = *h;
+    DeviceScope scope(E.device);
     const int K = (int)E.terms.size();
     if (upload_theta(E, theta, p)) return 1;
     if (run_loss_grad(E, E.d_theta, E.hp_out, term_w, -1, true, E.hp_raw)) return 1;     // results land in pinned host memory
@@ -395,6 +405,7 @@ int pinn_loss_grad_f64(pinn_handle h, const double* theta, int64_t p, const doub
 int pinn_term_grads(pinn_handle h, const float* theta, int64_t p, double* term_losses, float* term_grads) {
     if (!h || !theta || !term_grads) return fail("pinn_term_grads: null argument");
     pinn_engine& E = *h;
+    DeviceScope scope(E.device);
     const int K = (int)E.terms.size();
     if (upload_theta(E, theta, p)) return 1;
     for (int k = 0; k < K; ++k) {
@@ -409,6 +420,7 @@ int pinn_term_grads(pinn_handle h, const float* theta, int64_t p, double* term_l
 int pinn_loss_grad_device(pinn_handle h, const float* d_theta, const float* term_w, float* d_out, void* stream) {
     if (!h || !d_theta || !d_out) return fail("pinn_loss_grad_device: null argument");
     pinn_engine& E = *h;
+    DeviceScope scope(E.device);
     const int K = (int)E.terms.size();
     plat_stream user = (plat_stream)stream;
     plat_stream saved = E.stream;
@@ -423,6 +435,7 @@ int pinn_loss_grad_device(pinn_handle h, const float* d_theta, const float* term
 int pinn_residual(pinn_handle h, int term, const float* theta, int64_t p, float* r) {
     if (!h || !theta || !r) return fail("pinn_residual: null argument");
     pinn_engine& E = *h;
+    DeviceScope scope(E.device);
     if (term < 0 || term >= (int)E.terms.size()) return fail("pinn_residual: term index out of range");
     Term& T = E.terms[term];
     if (!T.d_pts) return fail("pinn_residual: term has no points");
@@ -508,6 +521,7 @@ static int forward_jets(pinn_engine& E, int net, const pk::SpecInfo* sp, const f
 int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float* pts, int64_t n, float* out) {
     if (!h || !theta || !pts || !out) return fail("pinn_phi: null argument");
     pinn_engine& E = *h;
+    DeviceScope scope(E.device);
     if (net < 0 || net >= (int)E.nets.size()) return fail("pinn_phi: net index out of range");
     if (n <= 0) return fail("pinn_phi: n must be positive");
     const Net& N = E.nets[net];
@@ -524,6 +538,7 @@ int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float*
 int pinn_derivative(pinn_handle h, int net, const float* theta, int64_t p, const float* pts, int64_t n, int order, const int* axes, float* out) {
     if (!h || !theta || !pts || !out) return fail("pinn_derivative: null argument");
     pinn_engine& E = *h;
+    DeviceScope scope(E.device);
     if (net < 0 || net >= (int)E.nets.size()) return fail("pinn_derivative: net index out of range");
     if (n <= 0) return fail("pinn_derivative: n must be positive");
     if (order < 0 || order > 4 || (order > 0 && !axes)) return fail("pinn_derivative: order must be 0..4 (with `order` axes)");
@@ -555,6 +570,7 @@ int pinn_derivative(pinn_handle h, int net, const float* theta, int64_t p, const
 int pinn_set_sampler(pinn_handle h, int term, int kind, const float* lb, const float* ub, int64_t n, uint64_t seed) {
     if (!h) return fail("null handle");
     pinn_engine& E = *h;
+    DeviceScope scope(E.device);
     if (term < 0 || term >= (int)E.terms.size()) return fail("pinn_set_sampler: term index out of range");
     Term& T = E.terms[term];
     if (kind < 0 || kind > 3) return fail("pinn_set_sampler: kind must be 0 (fixed set), 1 (uniform), 2 (Latin hypercube) or 3 (Sobol)");
@@ -581,6 +597,7 @@ int pinn_set_sampler(pinn_handle h, int term, int kind, const float* lb, const f
 int pinn_set_point_data(pinn_handle h, int term, const float* data, int ndata, int64_t n) {
     if (!h || !data) return fail("pinn_set_point_data: null argument");
     pinn_engine& E = *h;
+    DeviceScope scope(E.device);
     if (term < 0 || term >= (int)E.terms.size()) return fail("pinn_set_point_data: term index out of range");
     Term& T = E.terms[term];
     if (T.ndata == 0) return fail("pinn_set_point_data: the term's residual has no DATA channels");
@@ -604,6 +621,7 @@ int pinn_set_point_data(pinn_handle h, int term, const float* data, int ndata, i
 int pinn_set_point_weights(pinn_handle h, int term, const float* w, int64_t n) {
     if (!h) return fail("pinn_set_point_weights: null handle");
     pinn_engine& E = *h;
+    DeviceScope scope(E.device);
     if (term < 0 || term >= (int)E.terms.size()) return fail("pinn_set_point_weights: term index out of range");
     Term& T = E.terms[term];
     plat_sync(E.stream);
@@ -635,6 +653,7 @@ int pinn_set_point_weights(pinn_handle h, int term, const float* w, int64_t n) {
 int pinn_get_points(pinn_handle h, int term, float* pts, int64_t n) {
     if (!h || !pts) return fail("pinn_get_points: null argument");
     pinn_engine& E = *h;
+    DeviceScope scope(E.device);
     if (term < 0 || term >= (int)E.terms.size()) return fail("pinn_get_points: term index out of range");
     Term& T = E.terms[term];
     if (!T.d_pts || n != T.n) return fail("pinn_get_points: the term holds " + std::to_string(T.n) + " points");
@@ -646,6 +665,7 @@ int pinn_get_points(pinn_handle h, int term, float* pts, int64_t n) {
 int pinn_adam_init(pinn_handle h, const float* theta, int64_t p) {
     if (!h || !theta) return fail("pinn_adam_init: null argument");
     pinn_engine& E = *h;
+    DeviceScope scope(E.device);
     if (p != E.ntheta) return fail("pinn_adam_init: theta length mismatch");
     const int K = (int)E.terms.size();
     if (!E.d_opt_theta) {
@@ -667,6 +687,7 @@ int pinn_adam_init(pinn_handle h, const float* theta, int64_t p) {
 int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta2, float eps, const float* term_w, double* loss_history) {
     if (!h) return fail("null handle");
     pinn_engine& E = *h;
+    DeviceScope scope(E.device);
     if (!E.d_opt_theta) return fail("pinn_adam_steps: call pinn_adam_init first");
     if (nsteps <= 0) return fail("pinn_adam_steps: nsteps must be positive");
     if (ensure_points(E)) return 1;
@@ -703,6 +724,7 @@ int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta
 int pinn_adam_get(pinn_handle h, float* theta, int64_t p) {
     if (!h || !theta) return fail("pinn_adam_get: null argument");
     pinn_engine& E = *h;
+    DeviceScope scope(E.device);
     if (!E.d_opt_theta || p != E.ntheta) return fail("pinn_adam_get: no optimiser state / length mismatch");
     if (plat_d2h(theta, E.d_opt_theta, sizeof(float) * p, E.stream)) return fail("D2H copy failed");
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());

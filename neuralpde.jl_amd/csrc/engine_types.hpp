@@ -147,6 +147,10 @@ struct pinn_engine {
     std::vector<Coupled> coupled;
     std::vector<NetPlan> netplans;
     int ncu = 0;
+    int device = 0;                  // the HIP device this handle lives on (pinn_create: the caller's current device; pinn_create_on)
+    // engine-owned data-parallel collective (comm.cpp): communicator of this handle's rank, nullptr = single device
+    void* comm = nullptr;
+    int comm_size = 1, comm_rank = 0;
     plat_stream stream = nullptr;
     bool own_stream = true;
     float* d_theta = nullptr;
@@ -190,6 +194,15 @@ int parse_descriptor(const char* text, pinn_engine& E);
 // program.cpp
 void analyse_static(Term& T, int np);
 bool fuse_laplacian(Term& T, int np);
+// engine.cpp (shared with comm.cpp)
+int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const float* term_w, int only_term, bool timing, double* lossraw = nullptr);
+int upload_theta(pinn_engine& E, const float* theta, int64_t p);
+// every entry point that touches the device first makes the handle's device current (single-process multi-GPU callers)
+struct DeviceScope {
+    int prev;
+    explicit DeviceScope(int dev) : prev(plat_get_device()) { if (prev != dev) plat_set_device(dev); else prev = -1; }
+    ~DeviceScope() { if (prev >= 0) plat_set_device(prev); }
+};
 // plan.cpp
 int round_hp(int h);
 const pk::SpecInfo* find_spec(int HP, int NHH, int D, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs,

@@ -23,6 +23,9 @@ inline int plat_d2d(void* d, const void* s, size_t n, plat_stream) { std::memcpy
 inline int plat_memset(void* d, int v, size_t n, plat_stream) { std::memset(d, v, n); return 0; }
 inline int plat_sync(plat_stream) { return 0; }
 inline int plat_num_cus() { return 2; }
+inline int plat_device_count() { return 8; }            // the emulation pretends to be an 8-device node (host memory: "devices" are labels)
+inline int plat_get_device() { return 0; }
+inline int plat_set_device(int) { return 0; }
 inline plat_stream plat_stream_create() { return nullptr; }
 inline void plat_stream_destroy(plat_stream) {}
 inline void plat_event_create(plat_event&) {}
@@ -47,6 +50,9 @@ inline int plat_init(std::string& err) {
     }
     return 0;
 }
+inline int plat_device_count() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+inline int plat_get_device() { int d = 0; (void)hipGetDevice(&d); return d; }
+inline int plat_set_device(int d) { return hipSetDevice(d) != hipSuccess; }
 inline void* plat_malloc(size_t n) {
     void* p = nullptr;
     if (hipMalloc(&p, n ? n : 4) != hipSuccess) return nullptr;
