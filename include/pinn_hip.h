@@ -82,6 +82,17 @@ int pinn_loss_grad_f64(pinn_handle h, const double* theta, int64_t p, const doub
 int pinn_term_grads(pinn_handle h, const float* theta, int64_t p, double* term_losses, float* term_grads);
 
 /*
+ * BPINN physics (+ data) log-likelihood and its gradients in one evaluation:
+ *   loglik = sum_k logpdf(MvNormal(residual_k(set_k, theta), stds[k]^2 I), 0)
+ *          = sum_k [ -N_k/2 log(2 pi) - N_k log stds[k] - SSE_k / (2 stds[k]^2) ]                     (SSE, not MSE)
+ * i.e. the sum the reference's BayesianPINN builds from get_points_loss_functions (src/training_strategies.jl:113-127,
+ * src/discretize.jl:678-754, ext/bpinn/PDE_BPINN.jl:16-26) over the pde and bc terms; a data-misfit term (descriptor op DATA) with
+ * its own std is the L2LossData term (ext/bpinn/PDE_BPINN.jl:148-183).  grad_theta (P floats, nullable) = d loglik / d theta by the
+ * engine's reverse sweep (the reference differentiates with ForwardDiff over all P parameters, ext/bpinn/PDE_BPINN.jl:519);
+ * grad_std (K doubles, nullable) = d loglik / d stds[k] = -N_k / s + SSE_k / s^3 for samplers that treat the stds as parameters.
+ */
+int pinn_loglik_grad(pinn_handle h, const float* theta, int64_t p, const double* stds, double* loglik, float* grad_theta, double* grad_std);
+/*
  * Device-resident variant for multi-GPU data parallelism (one process per GPU; the caller
  * all-reduces d_out with RCCL): d_theta = P floats in HBM; d_out = P + K floats in HBM:
  *   d_out[0..P)   = this shard's gradient contribution (already scaled by term_w[k]/n_norm_k)

@@ -1,0 +1,498 @@
+# NeuralPDEHIP.jl — the Julia side of the drop-in boundary: NeuralPDE.jl's `PhysicsInformedNN` / `discretize` hot path on the MI355X
+# engine (libpinn_hip.so, C ABI in include/pinn_hip.h).
+#
+# Everything symbolic stays where it is (ModelingToolkit / Symbolics / `symbolic_discretize`); this module
+#   1. PRINTS the expression trees the reference itself walks — `toexpr(expand_derivatives(eq.lhs))`, `toexpr(...rhs)`
+#      (src/symbolic_utilities.jl:360-370) — as prefix s-expressions (`sexpr`).  The lowering (`_transform_expression`,
+#      src/symbolic_utilities.jl:132-331: dependent-variable calls -> `u(cord, θ, phi)`, nested Differentials -> one
+#      `derivative(...)` call, everything else broadcast arithmetic) is done INSIDE the library (csrc/sexpr.cpp), the same code the
+#      Python mirror drives, so this file contains no lowering logic that could drift;
+#   2. writes the problem descriptor "pinnir 2" (`descriptor(pinnrep)`): chains, the flat-θ (ComponentArrays) layout, per equation the
+#      coordinate row order `this_eq_indvars` exactly as `build_symbolic_loss_function` computes it (src/discretize.jl:41-43);
+#   3. plugs into the reference at its two existing plug-in points (SURVEY.md §8b):
+#        * `HIPStrategy(inner)  <: NeuralPDE.AbstractTrainingStrategy` + `merge_strategy_with_loss_function` (called at
+#          src/discretize.jl:541-545): per-term closures `θ -> mean(abs2, residual)` with `ChainRulesCore.rrule`s, so `discretize`,
+#          adaptive losses, logging, `additional_loss`, `AutoZygote` and user callbacks keep working unchanged;
+#        * `hip_discretize(pde_system, discretization)`: the fast path — `OptimizationFunction(f; grad = ...)` whose gradient is ONE
+#          fused `pinn_loss_grad` call (all terms, current adaptive weights), bypassing Zygote for the physics terms;
+#   4. checks the θ layout once per engine (`verify_layout`: `pinn_phi` against the Lux chain at random points) and rethrows every
+#      non-zero status of the C ABI as a Julia exception (`HIPEngineError`).
+#
+# Status: written against NeuralPDE v6.2.2 / Lux 1.x / ComponentArrays 0.15 / Symbolics 7 from their sources and docs; Julia is not
+# installed in the build container, so this file has NOT been executed there.  What can be pinned without Julia is pinned:
+# tests/golden/descriptors/*.pinnir2 hold the descriptors of the five BASELINE configurations in exactly the format `descriptor`
+# emits, tests/test_sexpr_frontend.py feeds them (and Julia-style spellings of the same equations) through the library against the
+# float64 oracle, and `NeuralPDEHIP.selftest()` below re-checks every descriptor against the reference's own generated loss functions
+# on the first machine that has both Julia and the library.
+
+module NeuralPDEHIP
+
+using Libdl
+using Random
+using Statistics
+using ComponentArrays
+using ChainRulesCore
+using SciMLBase
+using Symbolics
+using Symbolics: toexpr, expand_derivatives, Differential
+using SymbolicUtils
+import Lux
+import NeuralPDE
+import NeuralPDE: AbstractTrainingStrategy, PINNRepresentation, GridTraining, StochasticTraining, QuasiRandomTraining,
+                  PhysicsInformedNN, merge_strategy_with_loss_function
+import QuasiMonteCarlo
+import Optimization
+
+export HIPStrategy, hip_discretize, descriptor, sexpr, HIPEngine, HIPEngineError
+
+# ------------------------------------------------------------------------------------------------
+# library + error convention (include/pinn_hip.h: every function returns 0 or sets pinn_last_error)
+# ------------------------------------------------------------------------------------------------
+const LIBPATH = Ref{String}(get(ENV, "PINN_HIP_LIB", joinpath(@__DIR__, "..", "neuralpde.jl_amd", "csrc", "libpinn_hip.so")))
+const LIB = Ref{Ptr{Cvoid}}(C_NULL)
+
+struct HIPEngineError <: Exception
+    msg::String
+end
+Base.showerror(io::IO, e::HIPEngineError) = print(io, "HIPEngineError: ", e.msg)
+
+function lib()
+    if LIB[] == C_NULL
+        isfile(LIBPATH[]) || throw(HIPEngineError("$(LIBPATH[]) not found: build it (python -c 'import __graft_entry__ as g; g.build()') " *
+                                                  "or set ENV[\"PINN_HIP_LIB\"]; the engine has no CPU fallback"))
+        LIB[] = Libdl.dlopen(LIBPATH[])
+    end
+    return LIB[]
+end
+sym(name::Symbol) = Libdl.dlsym(lib(), name)
+last_error() = unsafe_string(ccall(sym(:pinn_last_error), Cstring, ()))
+check(rc::Integer, what::AbstractString) = rc == 0 ? nothing : throw(HIPEngineError("$what: $(last_error())"))
+
+# ------------------------------------------------------------------------------------------------
+# one pinn_handle
+# ------------------------------------------------------------------------------------------------
+mutable struct HIPEngine
+    h::Ptr{Cvoid}
+    K::Int          # number of loss terms (pde terms first, then bcs: src/discretize.jl:569-570)
+    P::Int          # length(θ)
+    function HIPEngine(desc::AbstractString; device::Integer = -1)
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall(sym(:pinn_create_on), Cint, (Cstring, Cint, Ref{Ptr{Cvoid}}), desc, device, out), "pinn_create")
+        e = new(out[], 0, 0)
+        e.K = ccall(sym(:pinn_num_terms), Cint, (Ptr{Cvoid},), e.h)
+        e.P = ccall(sym(:pinn_num_theta), Int64, (Ptr{Cvoid},), e.h)
+        finalizer(x -> (x.h != C_NULL && ccall(sym(:pinn_destroy), Cint, (Ptr{Cvoid},), x.h); x.h = C_NULL), e)
+        return e
+    end
+end
+
+"Install the collocation set of term `k` (1-based): `pts` is the reference's `d × N` matrix (column-major == point-major, no transpose)."
+function set_points!(e::HIPEngine, k::Integer, pts::AbstractMatrix; n_norm::Integer = 0)
+    p32 = Matrix{Float32}(pts)                       # EltypeAdaptor of the reference (src/eltype_matching.jl:8-10): device dtype is fp32
+    GC.@preserve p32 check(ccall(sym(:pinn_set_points), Cint, (Ptr{Cvoid}, Cint, Ptr{Float32}, Int64, Int64),
+                                 e.h, k - 1, p32, size(p32, 2), n_norm), "pinn_set_points")
+    return nothing
+end
+
+"`(term_losses::Vector{Float64}, grad::Vector{Float64})` of `Σ_k w[k] * mean(abs2, residual_k)` — one fused device evaluation."
+function loss_grad(e::HIPEngine, θ::AbstractVector{<:Real}, w::AbstractVector{<:Real}; want_grad::Bool = true)
+    θ64 = Vector{Float64}(θ); w64 = Vector{Float64}(w)
+    length(θ64) == e.P || throw(DimensionMismatch("θ has $(length(θ64)) entries, the engine expects $(e.P)"))
+    length(w64) == e.K || throw(DimensionMismatch("need one weight per loss term ($(e.K))"))
+    losses = zeros(Float64, e.K)
+    grad = zeros(Float64, e.P)
+    GC.@preserve θ64 w64 losses grad check(ccall(sym(:pinn_loss_grad_f64), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        e.h, θ64, e.P, w64, losses, want_grad ? pointer(grad) : Ptr{Float64}(C_NULL)), "pinn_loss_grad_f64")
+    return losses, grad
+end
+
+"Per-term gradients `K × P` (row k = ∂ term_losses[k] / ∂θ): what GradientScaleAdaptiveLoss and the per-term rrules consume."
+function term_grads(e::HIPEngine, θ::AbstractVector{<:Real})
+    θ32 = Vector{Float32}(θ)
+    losses = zeros(Float64, e.K)
+    tg = zeros(Float32, e.P, e.K)                    # C row-major K × P == Julia column-major P × K
+    GC.@preserve θ32 losses tg check(ccall(sym(:pinn_term_grads), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64, Ptr{Float64}, Ptr{Float32}),
+                                           e.h, θ32, e.P, losses, tg), "pinn_term_grads")
+    return losses, tg
+end
+
+"`residual_k(set_k, θ)`: the datafree loss function of src/discretize.jl:174 on the installed set (1 × N like the reference)."
+function residual(e::HIPEngine, k::Integer, θ::AbstractVector{<:Real}, n::Integer)
+    θ32 = Vector{Float32}(θ); r = zeros(Float32, n)
+    GC.@preserve θ32 r check(ccall(sym(:pinn_residual), Cint, (Ptr{Cvoid}, Cint, Ptr{Float32}, Int64, Ptr{Float32}), e.h, k - 1, θ32, e.P, r),
+                             "pinn_residual")
+    return reshape(Float64.(r), 1, :)
+end
+
+"`phi(x, θ)` of network `net` (1-based) through the engine (src/pinn_types.jl:88-90)."
+function phi(e::HIPEngine, net::Integer, θ::AbstractVector{<:Real}, x::AbstractMatrix)
+    θ32 = Vector{Float32}(θ); x32 = Matrix{Float32}(x); out = zeros(Float32, size(x32, 2))
+    GC.@preserve θ32 x32 out check(ccall(sym(:pinn_phi), Cint, (Ptr{Cvoid}, Cint, Ptr{Float32}, Int64, Ptr{Float32}, Int64, Ptr{Float32}),
+                                         e.h, net - 1, θ32, e.P, x32, size(x32, 2), out), "pinn_phi")
+    return reshape(Float64.(out), 1, :)
+end
+
+# ------------------------------------------------------------------------------------------------
+# 1. s-expression printer of the Julia Expr trees `toexpr` returns
+# ------------------------------------------------------------------------------------------------
+"""
+    sexpr(ex) -> String
+
+Prefix form of a `toexpr` tree: `Expr(:call, f, args...)` -> `(name args...)` with `name` the function's name (`+ - * / ^ sin …`), a
+dependent-variable Symbol (`(u x y)`, `(u 0 y)`), or `D` for a `Differential` head: `(D x 2 (u x y))` (variable, `order` field,
+operand; nested Differentials nest).  Numbers print as literals (`π` as `pi`, rationals as `a//b`), Symbols by name.
+
+Shapes of the five BASELINE configurations (up to Symbolics' own term order, which the library does not depend on) — the same
+strings are committed under tests/golden/descriptors/ and exercised by tests/test_sexpr_frontend.py:
+
+    cfg2 (2-D Poisson)  lhs (+ (D x 2 (u x y)) (D y 2 (u x y)))            rhs (* -1 (sin (* pi x)) (sin (* pi y)))
+    cfg3 (Burgers)      lhs (+ (D t 1 (u t x)) (* (u t x) (D x 1 (u t x))) (* -0.01 (/ 1 pi) (D x 2 (u t x))))   rhs 0
+    cfg5 (heat, κ est.) lhs (D t 1 (u t x y z))     rhs (* kappa (+ (D x 2 (u t x y z)) (D y 2 (u t x y z)) (D z 2 (u t x y z))))
+    boundary terms      lhs (u 0 y)   rhs 0          (call arguments are dropped by the lowering, symbolic_utilities.jl:145-160)
+"""
+sexpr(x::Irrational{:π}) = "pi"
+sexpr(x::Irrational{:ℯ}) = string(Float64(x))
+sexpr(x::Rational) = string(numerator(x), "//", denominator(x))
+sexpr(x::Integer) = string(x)
+sexpr(x::AbstractFloat) = repr(Float64(x))
+sexpr(x::Real) = repr(Float64(x))
+sexpr(x::Symbol) = string(x)
+function sexpr(ex::Expr)
+    ex.head === :call || throw(HIPEngineError("cannot print expression head $(ex.head) (only calls occur in toexpr output): $ex"))
+    f = ex.args[1]
+    args = ex.args[2:end]
+    if f isa Differential
+        length(args) == 1 || throw(HIPEngineError("Differential with $(length(args)) operands"))
+        order = hasproperty(f, :order) ? Int(f.order) : 1
+        return string("(D ", sexpr(toexpr(f.x)), " ", order, " ", sexpr(args[1]), ")")
+    end
+    name = f isa Symbol ? string(f) : string(nameof(f))
+    name == "σ" && (name = "sigmoid")
+    return string("(", name, isempty(args) ? "" : " ", join((sexpr(a) for a in args), " "), ")")
+end
+sexpr(x) = sexpr(toexpr(x))          # Symbolics objects (Num, BasicSymbolic)
+
+"lhs / rhs of an equation as the reference's `parse_equation` sees them (src/symbolic_utilities.jl:360-364)."
+function equation_sexprs(eq)
+    l = SymbolicUtils._iszero(expand_derivatives(eq.lhs)) ? eq.lhs : expand_derivatives(eq.lhs)
+    r = SymbolicUtils._iszero(expand_derivatives(eq.rhs)) ? eq.rhs : expand_derivatives(eq.rhs)
+    return sexpr(toexpr(l)), sexpr(toexpr(r))
+end
+
+# ------------------------------------------------------------------------------------------------
+# 2. descriptor ("pinnir 2")
+# ------------------------------------------------------------------------------------------------
+const ACT_NAMES = Dict{Any, String}(tanh => "tanh", Lux.tanh_fast => "tanh", Lux.sigmoid => "sigmoid", Lux.sigmoid_fast => "sigmoid",
+                                    sin => "sin", identity => "identity")
+
+chains_of(pinnrep::PINNRepresentation) = pinnrep.phi isa AbstractVector ? [p.smodel.model for p in pinnrep.phi] : [pinnrep.phi.smodel.model]
+
+function chain_lines(i::Int, chain, θoff::Int, depvar::Symbol, inputs)
+    layers = collect(values(chain.layers))
+    all(l -> l isa Lux.Dense, layers) || throw(HIPEngineError("the HIP engine runs Chains of Dense layers (got $(typeof.(layers)))"))
+    length(layers) >= 2 || throw(HIPEngineError("the HIP engine needs at least one hidden layer"))
+    acts = [get(ACT_NAMES, l.activation, nothing) for l in layers]
+    any(isnothing, acts) && throw(HIPEngineError("unsupported activation in chain $i: $([l.activation for l in layers]) (supported: tanh, sigmoid, sin)"))
+    acts[end] == "identity" || throw(HIPEngineError("the last layer must have identity activation"))
+    layers[end].out_dims == 1 || throw(HIPEngineError("each chain must have a single output (one chain per dependent variable, src/pinn_types.jl:106-108)"))
+    all(l -> l.use_bias isa Lux.True || l.use_bias === true, layers) || throw(HIPEngineError("Dense layers without bias are not supported"))
+    hidden = acts[1:(end - 1)]
+    act = all(==(hidden[1]), hidden) ? hidden[1] : join(hidden, ",")
+    sizes = vcat(layers[1].in_dims, [l.out_dims for l in layers])
+    nparams = sum(l.in_dims * l.out_dims + l.out_dims for l in layers)
+    lines = ["net $(i - 1) $act $θoff $(length(sizes)) " * join(sizes, " "),
+             "netvar $(i - 1) $depvar $(length(inputs)) " * join(inputs, " ")]
+    return lines, nparams
+end
+
+"""
+    descriptor(pinnrep) -> String
+
+The "pinnir 2" text handed to `pinn_create` (grammar: DESIGN.md §2).  θ layout = `pinnrep.flat_init_params` (src/discretize.jl:451-465):
+`[depvar 1: W1 (out×in, column-major) | b1 | W2 | b2 … | depvar 2 … | p]` — the order ComponentArrays flattens Lux's
+`(layer_1 = (weight, bias), …)` NamedTuples in; `verify_layout` checks it numerically.  Coordinate rows of term k =
+`this_eq_indvars` of `build_symbolic_loss_function` (src/discretize.jl:41-43), computed with the reference's own `pair`.
+"""
+function descriptor(pinnrep::PINNRepresentation)
+    (; eqs, bcs, eq_params, default_p, param_estim, depvars, dict_depvars, dict_depvar_input, flat_init_params) = pinnrep
+    chains = chains_of(pinnrep)
+    length(chains) == length(depvars) || throw(HIPEngineError("$(length(depvars)) dependent variables need $(length(depvars)) single-output chains"))
+    has_p = !(eq_params isa SciMLBase.NullParameters)
+    np = has_p ? length(eq_params) : 0
+    ne = (param_estim && has_p) ? np : 0
+    lines = String[]
+    netlines = String[]
+    off = 0
+    for (i, ch) in enumerate(chains)
+        l, n = chain_lines(i, ch, off, depvars[i], dict_depvar_input[depvars[i]])
+        append!(netlines, l)
+        off += n
+    end
+    ntheta = length(flat_init_params)
+    ntheta == off + ne || throw(HIPEngineError("flat_init_params has $ntheta entries, the chains (+ θ.p) need $(off + ne)"))
+    push!(lines, "pinnir 2", "ntheta $ntheta", "params $np $ne $off",
+          "defaults " * join((repr(Float64(v)) for v in (has_p ? default_p : Float64[])), " "),
+          "pnames " * join((string(Symbol(toexpr(p))) for p in (has_p ? eq_params : [])), " "),
+          "nets $(length(chains))")
+    append!(lines, netlines)
+    terms = vcat(collect(eqs isa AbstractArray ? eqs : [eqs]), collect(bcs))
+    push!(lines, "terms $(length(terms))")
+    for (k, eq) in enumerate(terms)
+        this_eq_pair = NeuralPDE.pair(eq, depvars, dict_depvars, dict_depvar_input)
+        this_eq_indvars = unique(vcat(values(this_eq_pair)...))
+        isempty(this_eq_indvars) && throw(ArgumentError("equation $k does not contain a dependent variable"))
+        l, r = equation_sexprs(eq)
+        push!(lines, "sterm $(k - 1) $(length(this_eq_indvars)) " * join(this_eq_indvars, " "), "lhs " * l, "rhs " * r)
+    end
+    return join(lines, "\n") * "\n"
+end
+
+"θ-layout check: the engine's trial functions must equal the Lux chains on random points (throws otherwise)."
+function verify_layout(e::HIPEngine, pinnrep::PINNRepresentation; n::Int = 16, rtol = 1.0e-4)
+    θ = pinnrep.flat_init_params
+    flat = collect(Float64, ComponentArrays.getdata(θ))
+    phis = pinnrep.phi isa AbstractVector ? pinnrep.phi : [pinnrep.phi]
+    for (i, ph) in enumerate(phis)
+        d = first(values(ph.smodel.model.layers)).in_dims
+        x = rand(Float64, d, n)
+        # src/discretize.jl:451-465: multioutput => θ.depvar.<name>; single chain => θ itself, or θ.depvar when param_estim adds θ.p
+        θi = pinnrep.multioutput ? getproperty(θ.depvar, pinnrep.depvars[i]) : (pinnrep.param_estim ? θ.depvar : θ)
+        ref = ph(x, θi)
+        got = phi(e, i, flat, x)
+        err = maximum(abs.(got .- ref)) / max(maximum(abs.(ref)), 1.0e-12)
+        err <= rtol || throw(HIPEngineError("θ layout mismatch for dependent variable $(pinnrep.depvars[i]): engine and Lux chain differ by $err"))
+    end
+    return true
+end
+
+# ------------------------------------------------------------------------------------------------
+# 3a. plug-in point (1): training strategy
+# ------------------------------------------------------------------------------------------------
+"""
+    HIPStrategy(inner)
+
+`inner` is the reference strategy whose POINT SETS are used (`GridTraining`, `StochasticTraining`, `QuasiRandomTraining`); the residual,
+`mean(abs2, ·)` and the gradient run on the engine.  Use it wherever a strategy goes:
+`PhysicsInformedNN(chain, HIPStrategy(QuasiRandomTraining(65_536)))`.
+"""
+struct HIPStrategy{S} <: AbstractTrainingStrategy
+    inner::S
+end
+
+# shared state of all closures of one discretisation: one fused evaluation per θ serves every term
+mutable struct HIPState
+    engine::HIPEngine
+    pinnrep::PINNRepresentation
+    n_pde::Int
+    sets::Vector{Matrix{Float64}}                # current set of every term (fixed strategies), pde terms first
+    resample::Union{Nothing, Function}           # () -> Vector{Matrix}: fresh sets (resampling strategies), called once per new θ
+    key::UInt64
+    losses::Vector{Float64}
+    grad::Vector{Float64}                        # of Σ w_k L_k under `weights`
+    weights::Vector{Float64}
+    tgrads::Union{Nothing, Matrix{Float32}}      # P × K per-term gradients (filled on the first per-term pullback at this θ)
+end
+
+function current_weights(st::HIPState)
+    a = st.pinnrep.adaloss
+    wp = Float64.(a.pde_loss_weights); wb = Float64.(a.bc_loss_weights)
+    K = st.engine.K
+    # before src/discretize.jl:553-559 has broadcast them, the weights may still be scalars / length-1 vectors
+    w = vcat(length(wp) == st.n_pde ? wp : fill(first(wp), st.n_pde), length(wb) == K - st.n_pde ? wb : fill(first(wb), K - st.n_pde))
+    return w
+end
+
+function evaluate!(st::HIPState, θ)
+    flat = collect(Float64, ComponentArrays.getdata(θ))
+    w = current_weights(st)
+    key = hash(flat, hash(w))
+    if key != st.key
+        if st.resample !== nothing                              # fresh sets on every new θ (src/training_strategies.jl:277-281, 375-381)
+            st.sets = st.resample()
+            for (k, s) in enumerate(st.sets)
+                set_points!(st.engine, k, s)
+            end
+        end
+        st.losses, st.grad = loss_grad(st.engine, flat, w)
+        st.weights, st.key, st.tgrads = w, key, nothing
+    end
+    return st
+end
+
+"`θ -> mean(abs2, residual_k(set_k, θ))` (src/training_strategies.jl:220, 280, 380) served by the engine."
+struct HIPTermLoss <: Function
+    st::HIPState
+    k::Int
+end
+(f::HIPTermLoss)(θ) = evaluate!(f.st, θ).losses[f.k]
+
+function ChainRulesCore.rrule(f::HIPTermLoss, θ)
+    st = evaluate!(f.st, θ)
+    y = st.losses[f.k]
+    function term_pullback(ȳ)
+        if st.tgrads === nothing
+            _, st.tgrads = term_grads(st.engine, collect(Float64, ComponentArrays.getdata(θ)))
+        end
+        g = Float64.(view(st.tgrads, :, f.k)) .* ChainRulesCore.unthunk(ȳ)
+        return NoTangent(), θ isa ComponentArray ? ComponentArray(g, ComponentArrays.getaxes(θ)) : g
+    end
+    return y, term_pullback
+end
+
+point_sets(pinnrep, s::GridTraining) = begin
+    (; domains, eqs, bcs, dict_indvars, dict_depvars) = pinnrep
+    pde, bc = NeuralPDE.generate_training_sets(domains, s.dx, eqs, bcs, Float64, dict_indvars, dict_depvars)
+    (Matrix{Float64}[Matrix{Float64}(m) for m in vcat(pde, bc)], nothing)
+end
+function point_sets(pinnrep, s::StochasticTraining)
+    (; domains, eqs, bcs, dict_indvars, dict_depvars) = pinnrep
+    pde_b, bc_b = NeuralPDE.get_bounds(domains, eqs, bcs, Float64, dict_indvars, dict_depvars, s)
+    draw() = vcat(Matrix{Float64}[NeuralPDE.generate_random_points(s.points, b, Float64) for b in pde_b],
+                  Matrix{Float64}[NeuralPDE.generate_random_points(s.bcs_points, b, Float64) for b in bc_b])
+    return draw(), draw
+end
+function point_sets(pinnrep, s::QuasiRandomTraining)
+    (; domains, eqs, bcs, dict_indvars, dict_depvars) = pinnrep
+    pde_b, bc_b = NeuralPDE.get_bounds(domains, eqs, bcs, Float64, dict_indvars, dict_depvars, s)
+    design() = vcat(Matrix{Float64}[QuasiMonteCarlo.sample(s.points, b[1], b[2], s.sampling_alg) for b in pde_b],
+                    Matrix{Float64}[QuasiMonteCarlo.sample(s.bcs_points, b[1], b[2], s.sampling_alg) for b in bc_b])
+    s.resampling && return design(), design
+    nb = max(s.minibatch, 1)
+    batches = [design() for _ in 1:nb]
+    return batches[1], (nb == 1 ? nothing : () -> batches[rand(1:nb)])      # src/training_strategies.jl:383-387
+end
+point_sets(pinnrep, s) = throw(HIPEngineError("HIPStrategy wraps GridTraining, StochasticTraining or QuasiRandomTraining (got $(typeof(s))); " *
+                                              "QuadratureTraining's adaptive cubature is a host algorithm"))
+
+function build_state(pinnrep::PINNRepresentation, inner)
+    engine = HIPEngine(descriptor(pinnrep))
+    verify_layout(engine, pinnrep)
+    sets, resample = point_sets(pinnrep, inner)
+    for (k, s) in enumerate(sets)
+        set_points!(engine, k, s)
+    end
+    n_pde = pinnrep.eqs isa AbstractArray ? length(pinnrep.eqs) : 1
+    return HIPState(engine, pinnrep, n_pde, sets, resample, UInt64(0), Float64[], Float64[], Float64[], nothing)
+end
+
+const STATES = IdDict{Any, HIPState}()            # pinnrep -> state, so hip_discretize can reach the engine behind the closures
+
+function NeuralPDE.merge_strategy_with_loss_function(pinnrep::PINNRepresentation, strategy::HIPStrategy,
+                                                    datafree_pde_loss_function, datafree_bc_loss_function)
+    st = build_state(pinnrep, strategy.inner)
+    STATES[pinnrep] = st
+    n_pde, n_bc = length(datafree_pde_loss_function), length(datafree_bc_loss_function)
+    n_pde + n_bc == st.engine.K || throw(HIPEngineError("engine has $(st.engine.K) terms, the discretisation $(n_pde + n_bc)"))
+    return [HIPTermLoss(st, k) for k in 1:n_pde], [HIPTermLoss(st, n_pde + j) for j in 1:n_bc]
+end
+
+# ------------------------------------------------------------------------------------------------
+# 3b. plug-in point (2): the fast path — explicit gradient, one fused device call per optimiser iteration
+# ------------------------------------------------------------------------------------------------
+"""
+    prob = hip_discretize(pde_system, discretization::PhysicsInformedNN)
+
+Same `OptimizationProblem` as `discretize` (src/discretize.jl:776-780: objective `full_loss_function`, `u0 = flat_init_params`), but the
+`OptimizationFunction` carries an explicit `grad`: the engine's fused `∇θ Σ_k w_k L_k` (+ the Zygote gradient of `additional_loss`, which
+stays a Julia function).  The objective itself is the reference's own `full_loss_function`, so the iteration counter, adaptive
+reweighting and logging behave as always; value and gradient of one iterate share ONE device evaluation (memoised on θ and weights).
+"""
+function hip_discretize(pde_system, discretization::PhysicsInformedNN)
+    strat = discretization.strategy isa HIPStrategy ? discretization.strategy : HIPStrategy(discretization.strategy)
+    disc = discretization.strategy isa HIPStrategy ? discretization : rebuild(discretization, strat)
+    pinnrep = SciMLBase.symbolic_discretize(pde_system, disc)
+    st = STATES[pinnrep]
+    full = pinnrep.loss_functions.full_loss_function
+    function grad!(G, θ, p)
+        evaluate!(st, θ)
+        w = current_weights(st)
+        g = w == st.weights ? st.grad : last(loss_grad(st.engine, collect(Float64, ComponentArrays.getdata(θ)), w))
+        G .= g
+        if pinnrep.additional_loss !== nothing
+            wa = pinnrep.adaloss.additional_loss_weights[1]
+            ga = first(Optimization.Zygote.gradient(θ) do t
+                (t_, p_) = pinnrep.param_estim ? (t.depvar, t.p) : (t, nothing)
+                pinnrep.additional_loss(pinnrep.phi, t_, p_)
+            end)
+            ga === nothing || (G .+= wa .* ComponentArrays.getdata(ga))
+        end
+        return G
+    end
+    f = Optimization.OptimizationFunction(full; grad = grad!)
+    return Optimization.OptimizationProblem(f, pinnrep.flat_init_params)
+end
+
+# PhysicsInformedNN is an immutable struct of the reference (src/pinn_types.jl:147-163): the same discretisation with another strategy,
+# through its positional constructor so that phi, the iteration counter and every other field are shared, not rebuilt
+function rebuild(d::PhysicsInformedNN, strategy)
+    return PhysicsInformedNN(d.chain, strategy, d.init_params, d.init_states, d.phi, d.derivative, d.param_estim, d.additional_loss,
+                             d.adaptive_loss, d.logger, d.log_options, d.iteration, d.self_increment, d.multioutput, d.kwargs)
+end
+
+# ------------------------------------------------------------------------------------------------
+# 4. multi-GPU (single Julia process, G devices): point shards + the engine's RCCL all-reduce
+# ------------------------------------------------------------------------------------------------
+"""
+    ShardedEngine(desc, sets; devices = 0:G-1)
+
+One engine per device (`pinn_create_on`), every term's set split into contiguous column blocks (`n_norm` = global N), one
+communicator (`pinn_comm_init_all`); `loss_grad(se, θ, w)` = `pinn_loss_grad_sharded`: the global losses and gradient (SURVEY.md §8e).
+"""
+struct ShardedEngine
+    engines::Vector{HIPEngine}
+end
+function ShardedEngine(desc::AbstractString, sets::Vector{<:AbstractMatrix}; devices = 0:0)
+    engines = [HIPEngine(desc; device = d) for d in devices]
+    G = length(engines)
+    for (g, e) in enumerate(engines), (k, s) in enumerate(sets)
+        n = size(s, 2)
+        lo, hi = (n * (g - 1)) ÷ G + 1, (n * g) ÷ G
+        set_points!(e, k, s[:, lo:hi]; n_norm = n)
+    end
+    hs = [e.h for e in engines]
+    GC.@preserve hs check(ccall(sym(:pinn_comm_init_all), Cint, (Ptr{Ptr{Cvoid}}, Cint), hs, G), "pinn_comm_init_all")
+    return ShardedEngine(engines)
+end
+function loss_grad(se::ShardedEngine, θ::AbstractVector{<:Real}, w::AbstractVector{<:Real})
+    e = se.engines[1]
+    θ32 = Vector{Float32}(θ); w32 = Vector{Float32}(w)
+    losses = zeros(Float64, e.K); grad = zeros(Float32, e.P)
+    hs = [x.h for x in se.engines]
+    GC.@preserve hs θ32 w32 losses grad check(ccall(sym(:pinn_loss_grad_sharded), Cint,
+        (Ptr{Ptr{Cvoid}}, Cint, Ptr{Float32}, Int64, Ptr{Float32}, Ptr{Float64}, Ptr{Float32}),
+        hs, length(hs), θ32, e.P, w32, losses, grad), "pinn_loss_grad_sharded")
+    return losses, Float64.(grad)
+end
+
+# ------------------------------------------------------------------------------------------------
+# 5. self test (run once where Julia, NeuralPDE and the library are all present)
+# ------------------------------------------------------------------------------------------------
+"""
+    selftest(pde_system, discretization; npoints = 64, rtol = 1e-4)
+
+Builds the problem twice — with the reference's own strategy (generated Julia loss functions, finite-difference `numeric_derivative`)
+and with the engine — and compares, on the SAME point sets and θ, every datafree residual (`pinn_residual` against
+`pinnrep.loss_functions.datafree_*`, the reference's generated functions with their finite-difference `numeric_derivative`).
+This is the check that pins `descriptor` / `sexpr` / the θ layout against the real reference objects; returns the worst relative
+difference (expected ~1e-7 for Float64 θ: the central-difference error of the reference itself).
+"""
+function selftest(pde_system, discretization::PhysicsInformedNN; rtol = 1.0e-4)
+    ref = SciMLBase.symbolic_discretize(pde_system, discretization)
+    st = build_state(ref, GridTraining(0.1))                  # engine built from the REFERENCE's pinnrep, on its GridTraining(0.1) sets
+    θ = ref.flat_init_params
+    flat = collect(Float64, ComponentArrays.getdata(θ))
+    dfs = vcat(ref.loss_functions.datafree_pde_loss_functions, ref.loss_functions.datafree_bc_loss_functions)
+    worst = 0.0
+    for (k, df) in enumerate(dfs)
+        cord = st.sets[k]
+        set_points!(st.engine, k, cord)
+        r_ref = df(cord, θ)
+        r_hip = residual(st.engine, k, flat, size(cord, 2))
+        worst = max(worst, maximum(abs.(r_hip .- r_ref)) / max(maximum(abs.(r_ref)), 1.0))
+    end
+    worst <= rtol || throw(HIPEngineError("residuals differ from the reference's generated functions by $worst"))
+    return worst
+end
+
+end # module

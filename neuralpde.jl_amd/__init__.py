@@ -10,7 +10,7 @@ See DESIGN.md for the kernel design and INTEGRATION.md for the Julia `ccall` bin
 from . import _lib
 from ._lib import Engine, EngineError, Library, comm_init_all, comm_unique_id, loss_grad_sharded
 from .ir import Instr, NetIR, ProblemIR, Slot, TermIR
-from .bpinn import physics_loglikelihood
+from .bpinn import loglikelihood, physics_loglikelihood
 from .adaptive import (AbstractAdaptiveLoss, GradientScaleAdaptiveLoss, MiniMaxAdaptiveLoss, ReLoBRaLoAdaptiveLoss,
                        SoftAdaptAdaptiveLoss)
 from .pinn import (DataLoss, depvar_params, Adam, OptimizationSolution, solve, Chain, Dense, LogOptions, NonAdaptiveLoss, OptimizationFunction, OptimizationProblem, Phi,

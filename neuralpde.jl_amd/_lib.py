@@ -19,7 +19,7 @@ DEFAULT_PATH = os.path.join(_HERE, "csrc", "libpinn_hip.so")
 SYMBOLS = [
     "pinn_backend", "pinn_abi_version", "pinn_last_error", "pinn_create", "pinn_destroy", "pinn_num_terms",
     "pinn_num_theta", "pinn_set_points", "pinn_set_points_device", "pinn_loss_grad", "pinn_loss_grad_f64",
-    "pinn_term_grads", "pinn_loss_grad_device", "pinn_residual", "pinn_phi", "pinn_derivative", "pinn_last_timing", "pinn_set_timing", "pinn_describe", "pinn_num_groups", "pinn_group_timing",
+    "pinn_term_grads", "pinn_loglik_grad", "pinn_loss_grad_device", "pinn_residual", "pinn_phi", "pinn_derivative", "pinn_last_timing", "pinn_set_timing", "pinn_describe", "pinn_num_groups", "pinn_group_timing",
     "pinn_create_on", "pinn_comm_unique_id", "pinn_comm_init_rank", "pinn_comm_init_all", "pinn_comm_size", "pinn_comm_rank", "pinn_comm_destroy",
     "pinn_loss_grad_sharded_device", "pinn_loss_grad_sharded",
     "pinn_set_sampler", "pinn_set_point_data", "pinn_set_point_weights", "pinn_get_points", "pinn_adam_init", "pinn_adam_steps", "pinn_adam_get",
@@ -64,6 +64,7 @@ class Library:
         L.pinn_loss_grad.argtypes = [vp, fp, C.c_int64, fp, dp, fp]
         L.pinn_loss_grad_f64.argtypes = [vp, dp, C.c_int64, dp, dp, dp]
         L.pinn_term_grads.argtypes = [vp, fp, C.c_int64, dp, fp]
+        L.pinn_loglik_grad.argtypes = [vp, fp, C.c_int64, dp, dp, fp, dp]
         L.pinn_loss_grad_device.argtypes = [vp, vp, fp, vp, vp]
         L.pinn_residual.argtypes = [vp, C.c_int, fp, C.c_int64, fp]
         L.pinn_phi.argtypes = [vp, C.c_int, fp, C.c_int64, fp, C.c_int64, fp]
@@ -213,6 +214,20 @@ class Engine:
                                                 losses.ctypes.data_as(C.POINTER(C.c_double)),
                                                 tg.ctypes.data_as(C.POINTER(C.c_float))), "pinn_term_grads")
         return losses, tg
+
+    def loglik_grad(self, theta, stds, want_grad: bool = True):
+        """BPINN log-likelihood sum_k logpdf(MvNormal(r_k, std_k^2 I), 0), d/dtheta and d/dstd (pinn_loglik_grad)"""
+        th = _f32(theta)
+        sd = np.ascontiguousarray(np.asarray(stds, dtype=np.float64))
+        if sd.shape != (self.K,):
+            raise ValueError(f"need one std per loss term ({self.K})")
+        ll = C.c_double()
+        g = np.zeros(self.P, dtype=np.float32) if want_grad else None
+        gs = np.zeros(self.K, dtype=np.float64)
+        self.L.check(self.L.lib.pinn_loglik_grad(self.h, th.ctypes.data_as(C.POINTER(C.c_float)), th.size, sd.ctypes.data_as(C.POINTER(C.c_double)),
+                                                 C.byref(ll), g.ctypes.data_as(C.POINTER(C.c_float)) if g is not None else None,
+                                                 gs.ctypes.data_as(C.POINTER(C.c_double))), "pinn_loglik_grad")
+        return ll.value, g, gs
 
     def loss_grad_device(self, d_theta: int, d_out: int, weights=None, stream: int = 0):
         w = _f32(weights) if weights is not None else None

@@ -37,3 +37,11 @@ def physics_loglikelihood(engine, theta, stds: Sequence[float], term_sizes: Sequ
     losses, grad = engine.loss_grad_f64(theta, w) if want_grad else (engine.loss_grad(theta, w, want_grad=False)[0], None)
     ll = float(np.sum(-0.5 * n * math.log(2.0 * math.pi) - n * np.log(sig) - w * np.asarray(losses, dtype=np.float64)))
     return ll, (None if grad is None else -np.asarray(grad, dtype=np.float64))
+
+
+def loglikelihood(engine, theta, stds: Sequence[float], want_grad: bool = True):
+    """The same log-likelihood through the engine's own entry point `pinn_loglik_grad`: returns (loglik, d/dtheta, d/dstds) — the stds
+    as trailing sampler parameters (`allstd` of ext/bpinn/PDE_BPINN.jl:16-26 when they are not fixed).  Terms may include DataLoss
+    terms: with their own std they are the L2LossData term (ext/bpinn/PDE_BPINN.jl:148-183), evaluated in the same fused call."""
+    ll, g, gs = engine.loglik_grad(theta, stds, want_grad=want_grad)
+    return ll, (None if g is None else g.astype(np.float64)), gs

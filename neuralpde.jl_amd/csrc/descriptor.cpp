@@ -19,7 +19,8 @@ int parse_descriptor(const char* text, pinn_engine& E) {
         return (bool)in && tok == w;
     };
     int ver = 0;
-    if (!expect("pinnir") || !(in >> ver) || ver != 1) return fail("descriptor: expected 'pinnir 1'");
+    if (!expect("pinnir") || !(in >> ver) || (ver != 1 && ver != 2)) return fail("descriptor: expected 'pinnir 1' or 'pinnir 2'");
+    SexprContext ctx;                          // pinnir 2: names of the parameters / dependent variables and their inputs
     if (!expect("ntheta") || !(in >> E.ntheta)) return fail("descriptor: ntheta");
     if (!expect("params") || !(in >> E.np >> E.ne >> E.p_theta_off)) return fail("descriptor: params");
     if (E.np < 0 || E.np > pk::MAX_PARAMS || E.ne > E.np) return fail("descriptor: at most 4 PDE parameters are supported");
@@ -27,8 +28,16 @@ int parse_descriptor(const char* text, pinn_engine& E) {
     E.p_defaults.assign(pk::MAX_PARAMS, 0.f);
     for (int i = 0; i < E.np; ++i)
         if (!(in >> E.p_defaults[i])) return fail("descriptor: defaults values");
+    if (ver == 2) {                            // pnames <np names>
+        if (!expect("pnames")) return fail("descriptor: pnames");
+        ctx.params.resize(E.np);
+        for (int i = 0; i < E.np; ++i)
+            if (!(in >> ctx.params[i])) return fail("descriptor: pnames values");
+    }
     int nn = 0;
     if (!expect("nets") || !(in >> nn) || nn < 1) return fail("descriptor: nets");
+    ctx.depvars.resize(ver == 2 ? nn : 0);
+    ctx.depvar_inputs.resize(ver == 2 ? nn : 0);
     E.nets.resize(nn);
     for (int i = 0; i < nn; ++i) {
         int id, ns;
@@ -50,6 +59,14 @@ int parse_descriptor(const char* text, pinn_engine& E) {
         E.nets[i].sizes.resize(ns);
         for (int j = 0; j < ns; ++j)
             if (!(in >> E.nets[i].sizes[j])) return fail("descriptor: net sizes");
+        if (ver == 2) {                        // netvar <i> <depvar name> <#inputs> <input names...>  (dict_depvar_input, symbolic_utilities.jl:401-426)
+            int vid, nin;
+            if (!expect("netvar") || !(in >> vid >> ctx.depvars[i] >> nin) || vid != i || nin != E.nets[i].sizes[0])
+                return fail("descriptor: netvar line (one per net: name and as many input names as the chain has inputs)");
+            ctx.depvar_inputs[i].resize(nin);
+            for (int j = 0; j < nin; ++j)
+                if (!(in >> ctx.depvar_inputs[i][j])) return fail("descriptor: netvar input names");
+        }
         if (ns < 3) return fail("descriptor: a chain needs at least one hidden layer");
         if (E.nets[i].sizes.back() != 1) return fail("descriptor: only single-output chains (one per dependent variable) are supported, as in the reference (pinn_types.jl:106-108)");
         const int nhidden = ns - 2;
@@ -74,7 +91,24 @@ int parse_descriptor(const char* text, pinn_engine& E) {
     for (int i = 0; i < nt; ++i) {
         Term& T = E.terms[i];
         int id, ns, no;
-        if (!expect("term") || !(in >> id >> T.d >> ns >> no >> T.out_row) || id != i) return fail("descriptor: term line");
+        if (!(in >> tok)) return fail("descriptor: term line");
+        if (ver == 2 && tok == "sterm") {
+            // sterm <k> <d> <coordinate names>  /  lhs <s-expression>  /  rhs <s-expression>: lowered by sexpr.cpp
+            int d;
+            if (!(in >> id >> d) || id != i || d < 1 || d > 4) return fail("descriptor: sterm line");
+            std::vector<std::string> iv(d);
+            for (int j = 0; j < d; ++j)
+                if (!(in >> iv[j])) return fail("descriptor: sterm coordinate names");
+            std::string lhs, rhs;
+            if (!expect("lhs") || !std::getline(in, lhs)) return fail("descriptor: lhs line");
+            if (!expect("rhs") || !std::getline(in, rhs)) return fail("descriptor: rhs line");
+            if (lower_sexpr_term(ctx, iv, lhs, rhs, E.np, T)) return fail("term " + std::to_string(i) + ": " + g_err);
+            for (auto& S : T.slots) {
+                if (S.order == 2 && S.axes[0] > S.axes[1]) std::swap(S.axes[0], S.axes[1]);
+            }
+            continue;
+        }
+        if (tok != "term" || !(in >> id >> T.d >> ns >> no >> T.out_row) || id != i) return fail("descriptor: term line");
         T.slots.resize(ns);
         for (int s = 0; s < ns; ++s) {
             Slot& S = T.slots[s];

@@ -402,6 +402,34 @@ int pinn_loss_grad_f64(pinn_handle h, const double* theta, int64_t p, const doub
     return 0;
 }
 
+int pinn_loglik_grad(pinn_handle h, const float* theta, int64_t p, const double* stds, double* loglik, float* grad_theta, double* grad_std) {
+    if (!h || !theta || !stds || !loglik) return fail("pinn_loglik_grad: null argument");
+    pinn_engine& E = *h;
+    DeviceScope scope(E.device);
+    const int K = (int)E.terms.size();
+    // l = sum_k logpdf(MvNormal(r_k, sigma_k^2 I), 0) = sum_k [ -N_k/2 log(2 pi) - N_k log sigma_k - SSE_k / (2 sigma_k^2) ]
+    // (src/training_strategies.jl:113-127; "SSE not MSE", src/discretize.jl:681): an affine function of the per-term sums of squares,
+    // so grad_theta l = - grad_theta sum_k w_k L_k with w_k = N_k / (2 sigma_k^2): ONE weighted evaluation
+    std::vector<float> w(K);
+    for (int k = 0; k < K; ++k) {
+        if (!(stds[k] > 0.0)) return fail("pinn_loglik_grad: standard deviations must be positive");
+        w[k] = (float)((double)E.terms[k].n_norm / (2.0 * stds[k] * stds[k]));
+    }
+    if (upload_theta(E, theta, p)) return 1;
+    if (run_loss_grad(E, E.d_theta, E.hp_out, w.data(), -1, false, E.hp_raw)) return 1;
+    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    double ll = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const double N = (double)E.terms[k].n_norm, sse = E.hp_raw[k], sd = stds[k];          // (sharded sets: sse is this shard's part)
+        ll += -0.5 * N * std::log(2.0 * 3.14159265358979323846) - N * std::log(sd) - sse / (2.0 * sd * sd);
+        if (grad_std) grad_std[k] = -N / sd + sse / (sd * sd * sd);
+    }
+    *loglik = ll;
+    if (grad_theta)
+        for (int64_t i = 0; i < E.ntheta; ++i) grad_theta[i] = -E.hp_out[i];
+    return 0;
+}
+
 int pinn_term_grads(pinn_handle h, const float* theta, int64_t p, double* term_losses, float* term_grads) {
     if (!h || !theta || !term_grads) return fail("pinn_term_grads: null argument");
     pinn_engine& E = *h;

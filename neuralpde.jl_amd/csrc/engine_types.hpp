@@ -191,6 +191,14 @@ struct pinn_engine {
 namespace pe {
 // descriptor.cpp
 int parse_descriptor(const char* text, pinn_engine& E);
+// sexpr.cpp: the symbolic front end ("pinnir 2"): lhs / rhs of an equation as prefix s-expressions -> jet slots + tape
+struct SexprContext {
+    std::vector<std::string> params;                         // PDE parameter names, in theta.p order
+    std::vector<std::string> depvars;                        // dependent-variable name of net i
+    std::vector<std::vector<std::string>> depvar_inputs;     // its argument names (dict_depvar_input)
+};
+int lower_sexpr_term(const SexprContext& C, const std::vector<std::string>& indvars, const std::string& lhs, const std::string& rhs,
+                     int np, Term& T);
 // program.cpp
 void analyse_static(Term& T, int np);
 bool fuse_laplacian(Term& T, int np);

@@ -52,6 +52,10 @@ class TermIR:
     # net -> for each network input the index of the term coordinate that feeds it, only for networks whose inputs are
     # not simply the term's coordinates in order (dependent variables with different arguments, src/discretize.jl:111-131)
     inmaps: Dict[int, Tuple[int, ...]] = field(default_factory=dict)
+    # the equation as the pair of prefix s-expressions the symbolic front end lowers ("pinnir 2", csrc/sexpr.cpp); None for terms that
+    # exist only as tapes (DataLoss)
+    lhs_sexpr: str = None
+    rhs_sexpr: str = None
 
 
 @dataclass
@@ -70,6 +74,41 @@ class ProblemIR:
     nparams_estim: int = 0
     p_theta_off: int = 0
     p_defaults: Sequence[float] = ()
+    # names for the symbolic front end ("pinnir 2"): PDE parameters, dependent variable of every net and its arguments
+    param_names: Sequence[str] = ()
+    depvar_names: Sequence[str] = ()
+    depvar_inputs: Sequence[Sequence[str]] = ()
+
+    def to_descriptor2(self) -> str:
+        """"pinnir 2": the equations travel as s-expressions and are lowered inside the library (csrc/sexpr.cpp) — the form the Julia glue
+        emits (julia/NeuralPDEHIP.jl).  Terms without a symbolic form (DataLoss tapes) keep their pinnir-1 lines."""
+        out = ["pinnir 2", f"ntheta {self.ntheta}",
+               f"params {self.nparams} {self.nparams_estim} {self.p_theta_off}",
+               "defaults " + " ".join(repr(float(v)) for v in list(self.p_defaults)[: self.nparams]),
+               "pnames " + " ".join(self.param_names),
+               f"nets {len(self.nets)}"]
+        for i, n in enumerate(self.nets):
+            out.append(f"net {i} {n.act} {n.theta_off} {len(n.sizes)} " + " ".join(str(s) for s in n.sizes))
+            out.append(f"netvar {i} {self.depvar_names[i]} {len(self.depvar_inputs[i])} " + " ".join(self.depvar_inputs[i]))
+        out.append(f"terms {len(self.terms)}")
+        for i, t in enumerate(self.terms):
+            if t.lhs_sexpr is None:
+                out += self._term_lines(i, t)
+                continue
+            out.append(f"sterm {i} {t.dim} " + " ".join(t.indvars))
+            out.append("lhs " + t.lhs_sexpr)
+            out.append("rhs " + t.rhs_sexpr)
+        return "\n".join(out) + "\n"
+
+    def _term_lines(self, i, t):
+        out = [f"term {i} {t.dim} {len(t.slots)} {len(t.ops)} {t.out_row}"]
+        for s in t.slots:
+            out.append(f"slot {s.net} {s.order} " + " ".join(str(a) for a in s.axes))
+        for q in t.ops:
+            out.append(f"op {q.op} {q.a} {q.b} {float(q.imm)!r}")
+        for net, m in sorted(t.inmaps.items()):
+            out.append(f"inmap {net} {len(m)} " + " ".join(str(i) for i in m))
+        return out
 
     def to_descriptor(self) -> str:
         out = ["pinnir 1", f"ntheta {self.ntheta}",
@@ -80,11 +119,5 @@ class ProblemIR:
             out.append(f"net {i} {n.act} {n.theta_off} {len(n.sizes)} " + " ".join(str(s) for s in n.sizes))
         out.append(f"terms {len(self.terms)}")
         for i, t in enumerate(self.terms):
-            out.append(f"term {i} {t.dim} {len(t.slots)} {len(t.ops)} {t.out_row}")
-            for s in t.slots:
-                out.append(f"slot {s.net} {s.order} " + " ".join(str(a) for a in s.axes))
-            for q in t.ops:
-                out.append(f"op {q.op} {q.a} {q.b} {float(q.imm)!r}")
-            for net, m in sorted(t.inmaps.items()):
-                out.append(f"inmap {net} {len(m)} " + " ".join(str(i) for i in m))
+            out += self._term_lines(i, t)
         return "\n".join(out) + "\n"

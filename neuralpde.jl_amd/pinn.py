@@ -390,8 +390,13 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
         ntheta=int(flat.size),
         nets=[NetIR(tuple(ch.sizes), ch.act, off) for ch, off in zip(chains, net_offs)],
         terms=terms, nparams=NP, nparams_estim=NE, p_theta_off=nnet,
-        p_defaults=list(default_p) if default_p is not None else [])
-    engine = _lib.Engine(ir.to_descriptor())
+        p_defaults=list(default_p) if default_p is not None else [],
+        param_names=[str(p) for p in eq_params], depvar_names=list(vi.depvars),
+        depvar_inputs=[list(vi.dict_depvar_input[n]) for n in vi.depvars])
+    # PINN_DESCRIPTOR=2: hand the equations to the library as s-expressions (the form the Julia glue emits; lowered by csrc/sexpr.cpp)
+    # instead of the tapes lowered by symbolic.py — both front ends must give the same engine (tests/test_sexpr_frontend.py)
+    import os as _os
+    engine = _lib.Engine(ir.to_descriptor2() if _os.environ.get("PINN_DESCRIPTOR") == "2" else ir.to_descriptor())
 
     # ---- strategy: point sets (src/discretize.jl:541-545) ----
     strategy = discretization.strategy

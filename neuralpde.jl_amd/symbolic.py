@@ -379,5 +379,10 @@ def lower_equation(eq: Equation, vi: VarInfo, params: Sequence, kind: str) -> Te
         m = tuple(indvars.index(v) for v in vi.dict_depvar_input[name])
         if m != tuple(range(d)):
             inmaps[sl.net] = m
+    from .sexpr import SexprError, sexpr
+    try:                                                   # the same equation for the symbolic front end ("pinnir 2")
+        ls, rs = sexpr(eq.lhs), sexpr(eq.rhs)
+    except SexprError:
+        ls = rs = None
     return TermIR(dim=d, slots=list(B.slots), ops=ops, out_row=row(out), indvars=tuple(indvars), kind=kind,
-                  source=str(expr), inmaps=inmaps)
+                  source=str(expr), inmaps=inmaps, lhs_sexpr=ls, rhs_sexpr=rs)

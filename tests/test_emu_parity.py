@@ -636,3 +636,47 @@ def test_forward_derivatives_mirror(npde, use_emu):
         eng.derivative(0, theta, pts, [0, 0, 1])
     with pytest.raises(Exception, match="axis out of range"):
         eng.derivative(0, theta, pts, [2])
+
+
+def test_bpinn_loglikelihood_with_std_gradients_and_data_term(npde, use_emu):
+    """pinn_loglik_grad: l(theta, sigma) = sum_k logpdf(MvNormal(r_k, sigma_k^2 I), 0) over the pde, bc AND an L2 data term (a DataLoss
+    term = L2LossData of ext/bpinn/PDE_BPINN.jl:148-183), with d l / d theta (against the oracle's weighted gradient) and d l / d sigma_k
+    (against central differences of the oracle's l) in one call."""
+    sysm, chain = poisson2d(npde, "tanh")
+    th = theta_for(chain, 62)
+    rng = np.random.default_rng(9)
+    xd = rng.uniform(0.1, 0.9, size=(2, 24))
+    yd = np.sin(np.pi * xd[0]) * np.sin(np.pi * xd[1]) / (2 * np.pi ** 2) + 0.01 * rng.standard_normal(24)
+    disc = npde.PhysicsInformedNN(chain, npde.GridTraining(0.125), init_params=th, data_loss=[npde.DataLoss(sysm.dvs[0], xd, yd)])
+    rep = npde.symbolic_discretize(sysm, disc)
+    eng = rep.engine
+    sets = rep.pde_train_sets + rep.bcs_train_sets
+    stds = np.array([0.7, 0.05, 0.08, 0.11, 0.2, 0.03])
+    ll, g, gs = npde.loglikelihood(eng, th, stds)
+    prob = helpers.oracle_problem(npde, sysm, [chain])
+    ochain = po.Chain(tuple(chain.sizes), chain.act)
+
+    def sse():
+        out = [float(np.sum(po.residual_values(prob, th, k, s) ** 2)) for k, s in enumerate(sets)]
+        out.append(float(np.sum((po.phi_values(ochain, th, xd)[0] - yd) ** 2)))
+        return np.array(out)
+
+    S = sse()
+    N = np.array([s.shape[1] for s in sets] + [24], dtype=np.float64)
+    ll_of = lambda sd: float(np.sum(-0.5 * N * np.log(2 * np.pi) - N * np.log(sd) - S / (2 * sd ** 2)))
+    assert abs(ll - ll_of(stds)) < 1e-5 * abs(ll_of(stds))
+    for k in range(6):                                        # d l / d sigma_k
+        e = np.zeros(6); e[k] = 1e-6 * stds[k]
+        fd = (ll_of(stds + e) - ll_of(stds - e)) / (2 * e[k])
+        assert abs(gs[k] - fd) < 1e-5 * max(1.0, abs(fd)), (k, gs[k], fd)
+    # d l / d theta = - grad sum_k w_k L_k, w_k = N_k / (2 sigma_k^2): physics terms from the oracle, data term by autograd of its SSE
+    import torch
+    w = N / (2 * stds ** 2)
+    ref = po.loss_and_grad(prob, th, sets, weights=w[:5], mode="stencil")
+    tht = torch.tensor(th, dtype=po.DT, requires_grad=True)
+    sse_d = torch.sum((ochain(torch.tensor(xd, dtype=po.DT), tht)[0] - torch.tensor(yd, dtype=po.DT)) ** 2)
+    (gd,) = torch.autograd.grad(sse_d / (2 * stds[5] ** 2), tht)
+    gref = -(ref.grad + gd.numpy())
+    assert np.linalg.norm(g - gref) < 1e-5 * np.linalg.norm(gref)
+    with pytest.raises(Exception, match="positive"):
+        eng.loglik_grad(th, [0.1, 0.1, 0.0, 0.1, 0.1, 0.1])
