@@ -263,8 +263,6 @@ def solve(prob: OptimizationProblem, alg: Adam, maxiters: int = 1000, callback: 
     every step; fixed sets stay installed.  Without a callback the whole loop runs without host synchronisation; with a
     callback `(state, loss) -> stop::Bool` it runs in chunks of 50 steps."""
     rep = prob.pinnrep
-    if rep.additional_loss is not None:
-        raise NotImplementedError("solve(): additional_loss is a host-side term; use prob.f.value_and_grad in a host loop")
     eng = rep.engine
     eng_resample = getattr(rep, "_device_samplers", None)
     if eng_resample and not rep._state.get("samplers_installed"):
@@ -273,9 +271,11 @@ def solve(prob: OptimizationProblem, alg: Adam, maxiters: int = 1000, callback: 
         for k, (lb, ub, n, seed, kind) in eng_resample.items():
             eng.set_sampler(k, lb, ub, n, seed, kind)
         rep._state["samplers_installed"] = True
-    elif rep._state.get("resample") is not None:
-        raise NotImplementedError("solve(): only StochasticTraining and Latin-hypercube QuasiRandomTraining have on-device samplers; use resampling=False designs "
-                                  "or a host loop over prob.f.value_and_grad")
+    if rep.additional_loss is not None or (not eng_resample and rep._state.get("resample") is not None):
+        # host-side pieces per iteration — a Python `additional_loss(phi, theta, p)` (src/discretize.jl:590-598) or pre-generated
+        # designs picked at random per call (`resampling = false, minibatch > 1`, src/training_strategies.jl:383-387): the optimiser
+        # loop runs on the host, every iteration is still ONE fused device evaluation (value_and_grad)
+        return _host_adam(prob, alg, maxiters, callback)
     theta, losses, done, init = np.asarray(prob.u0, dtype=np.float64), [], 0, True
     ada = rep.adaloss
     n_pde = len(rep.eqs)
@@ -300,6 +300,27 @@ def solve(prob: OptimizationProblem, alg: Adam, maxiters: int = 1000, callback: 
     losses = np.concatenate(losses)
     rep.iteration[0] += done
     return OptimizationSolution(th32.astype(prob.u0.dtype), float(losses[-1]), losses)
+
+
+def _host_adam(prob: OptimizationProblem, alg: Adam, maxiters: int, callback) -> OptimizationSolution:
+    """[3P] Optimisers.Adam on the host over `prob.f.value_and_grad` (the objective of src/discretize.jl:567-598 incl. a host-side
+    `additional_loss`, which must return `(value, gradient)` here: the Python mirror has no AD to differentiate a bare value)."""
+    rep = prob.pinnrep
+    theta = np.asarray(prob.u0, dtype=np.float64).copy()
+    m, v, losses = np.zeros_like(theta), np.zeros_like(theta), []
+    b1, b2 = alg.beta
+    for it in range(1, maxiters + 1):
+        val, g = prob.f.value_and_grad(theta)
+        if rep.additional_loss is not None and rep._state.get("add_grad_missing"):
+            raise TypeError("solve(): additional_loss must return (value, gradient w.r.t. the flat theta) for training on this backend")
+        losses.append(val)
+        g = np.asarray(g, dtype=np.float64)
+        m = b1 * m + (1 - b1) * g
+        v = b2 * v + (1 - b2) * g * g
+        theta = theta - alg.eta * (m / (1 - b1 ** it)) / (np.sqrt(v / (1 - b2 ** it)) + alg.epsilon)
+        if callback is not None and callback({"iter": it, "u": theta.copy()}, float(val)):
+            break
+    return OptimizationSolution(theta.astype(prob.u0.dtype), float(losses[-1]), np.array(losses))
 
 
 def remake(prob: OptimizationProblem, u0=None) -> OptimizationProblem:
@@ -484,6 +505,7 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
         wa = float(np.asarray(adaloss.additional_loss_weights).reshape(-1)[0])
         if isinstance(add, tuple):
             return wa * float(add[0]), wa * np.asarray(add[1])
+        state["add_grad_missing"] = True
         return wa * float(add), None
 
     def value_and_grad(theta):

@@ -242,8 +242,21 @@ def test_data_misfit_terms_on_device(npde, use_emu):
     # the whole inverse problem runs in the resident loop (no host term left)
     res = npde.solve(prob, npde.Adam(0.01), maxiters=30)
     assert res.losses[-1] < res.losses[0]
-    with pytest.raises(NotImplementedError):
-        npde.solve(prob_h, npde.Adam(0.01), maxiters=2)
+    # the same problem with the data term as a HOST-side additional_loss (src/discretize.jl:590-598): solve() runs its Adam loop on the
+    # host, one fused device evaluation per iteration, and follows the device-resident run of the equivalent DataLoss problem
+    res_h = npde.solve(prob_h, npde.Adam(0.01), maxiters=30)
+    assert len(res_h.losses) == 30 and res_h.losses[-1] < res_h.losses[0]
+    np.testing.assert_allclose(res_h.losses, res.losses, rtol=2e-3)
+    assert np.max(np.abs(res_h.u - res.u)) < 2e-3
+    # pre-generated designs picked at random per call (resampling = false, minibatch > 1, src/training_strategies.jl:383-387)
+    strat_mb = npde.QuasiRandomTraining(40, bcs_points=16, sampling_alg=npde.SobolSample(seed=8), resampling=False, minibatch=3,
+                                        rng=np.random.default_rng(1))
+    prob_mb = npde.discretize(sysm, npde.PhysicsInformedNN(chain, strat_mb, init_params=th, param_estim=True))
+    res_mb = npde.solve(prob_mb, npde.Adam(0.01), maxiters=12)
+    assert len(res_mb.losses) == 12 and np.all(np.isfinite(res_mb.losses)) and len(set(np.round(res_mb.losses, 10))) == 12
+    with pytest.raises(TypeError, match="must return"):          # a bare value cannot be differentiated by this host
+        npde.solve(npde.discretize(sysm, npde.PhysicsInformedNN(chain, mk(), init_params=th, param_estim=True,
+                                                               additional_loss=lambda phi, t_, p_: 1.0)), npde.Adam(0.01), maxiters=2)
     # misuse
     with pytest.raises(ValueError):
         npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, mk(), init_params=th, param_estim=True,
