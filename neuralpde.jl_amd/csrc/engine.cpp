@@ -14,8 +14,8 @@ thread_local void* emu_barrier_ctx = nullptr;
 #endif
 
 namespace pk {
-std::vector<SpecInfo>& registry() {
-    static std::vector<SpecInfo> r;
+std::deque<SpecInfo>& registry() {
+    static std::deque<SpecInfo> r;
     return r;
 }
 }  // namespace pk
@@ -555,8 +555,9 @@ int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float*
     const Net& N = E.nets[net];
     if (!E.netplans[net].spec) return fail("pinn_phi: network is not used by any term");
     const int LH = (int)N.sizes.size() - 2;
-    const pk::SpecInfo* sp = find_spec(round_hp(N.maxhidden()), LH - 1, N.sizes[0], 0, {}, 0u, nullptr, variant_of(N.act), E.netplans[net].spec->family);
-    if (!sp) return fail("pinn_phi: no compiled value-only kernel for this network shape");
+    (void)LH;
+    const pk::SpecInfo* sp = ensure_spec(N, 0, {}, 0u, E.netplans[net].spec->family);
+    if (!sp) return fail("pinn_phi: no value-only kernel for this network shape (" + g_err + ")");
     if (forward_jets(E, net, sp, theta, p, pts, n)) return 1;
     if (plat_d2h(out, E.d_phi_out, sizeof(float) * n, E.stream)) return fail("D2H copy failed");
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
@@ -585,8 +586,9 @@ int pinn_derivative(pinn_handle h, int net, const float* theta, int64_t p, const
     if (order >= 2) need_pairs.push_back({sl.axes[0], sl.axes[1]});
     if (order >= 3) need_hi = (unsigned)order << (4 * sl.axes[0]);
     const int LH = (int)N.sizes.size() - 2;
-    const pk::SpecInfo* sp = find_spec(round_hp(N.maxhidden()), LH - 1, N.sizes[0], need_first, need_pairs, need_hi, nullptr, variant_of(N.act), E.netplans[net].spec->family);
-    if (!sp) return fail("pinn_derivative: no compiled kernel carries this derivative for this network shape");
+    (void)LH;
+    const pk::SpecInfo* sp = ensure_spec(N, need_first, need_pairs, need_hi, E.netplans[net].spec->family);
+    if (!sp) return fail("pinn_derivative: no kernel carries this derivative for this network shape (" + g_err + ")");
     const int ch = chan_of(*sp, sl);
     if (ch < 0) return fail("internal: derivative has no channel");
     if (forward_jets(E, net, sp, theta, p, pts, n)) return 1;

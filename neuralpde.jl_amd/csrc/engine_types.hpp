@@ -215,7 +215,13 @@ struct DeviceScope {
 int round_hp(int h);
 const pk::SpecInfo* find_spec(int HP, int NHH, int D, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs,
                               unsigned need_hi, std::vector<int>* pair_index, int need_variant = 0, int need_family = 0);
-int chan_of(const pk::SpecInfo& s, const Slot& sl);      // jet channel of a slot in a kernel's channel set (-1: not carried)
+int chan_of(const pk::SpecInfo& s, const Slot& sl);
+// find_spec, or — for shapes / jet sets outside the ahead-of-time table — compile, cache and load the kernel (jit.cpp) and look again
+const pk::SpecInfo* ensure_spec(const Net& N, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs, unsigned need_hi,
+                                int need_family = 0);
+// jit.cpp
+int jit_round_hp(int h);
+int jit_spec(int HP, int NHH, int D, unsigned D1MASK, unsigned long long PAIRS, int NPAIR, unsigned HI, int variant);      // jet channel of a slot in a kernel's channel set (-1: not carried)
 // kernel-variant bit a network's activation needs beyond the tanh / sigmoid kernels every spec has (SpecInfo::has_sin)
 inline int variant_of(int act) { return act == pk::ACT_SIN ? 1 : (act == pk::ACT_MIXED ? 2 : 0); }
 std::string spec_name(const pk::SpecInfo& s);

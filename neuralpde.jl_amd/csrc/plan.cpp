@@ -9,7 +9,34 @@ int round_hp(int h) {
     if (h <= 32) return 32;
     if (h <= 64) return 64;
     if (h <= 128) return 128;
-    return ((h + 15) / 16) * 16;
+    return jit_round_hp(h);          // wider nets: multiples of 64, kernels specialised at run time (jit.cpp)
+}
+
+const pk::SpecInfo* ensure_spec(const Net& N, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs, unsigned need_hi, int need_family) {
+    const int HP = round_hp(N.maxhidden()), NHH = (int)N.sizes.size() - 3, D = N.sizes[0], variant = variant_of(N.act);
+    const pk::SpecInfo* sp = find_spec(HP, NHH, D, need_first, need_pairs, need_hi, nullptr, variant, need_family);
+    int cneed = 1 + (int)need_pairs.size() + ((need_hi >> 24) ? 1 : 0);
+    for (int a = 0; a < 8; ++a) cneed += ((need_first >> a) & 1) + (a < 6 && ((need_hi >> (4 * a)) & 0xF) >= 3) + (a < 6 && ((need_hi >> (4 * a)) & 0xF) >= 4);
+    // a shape served only by run-time specialised kernels gets one per channel set (a boundary term does not ride on the interior
+    // term's 4-5 channel kernel); inside the ahead-of-time table a wider set may serve (e.g. the full-Hessian kernels of the small nets)
+    if (sp && !(sp->jit && sp->C > cneed)) return sp;
+    // exactly the requested channel set: first-derivative axes, pairs (a pure 3rd / 4th derivative also needs pair (a, a)), HI nibbles, LAP
+    unsigned long long PAIRS = 0;
+    std::vector<std::pair<int, int>> pairs = need_pairs;
+    for (int a = 0; a < 6; ++a)
+        if (((need_hi >> (4 * a)) & 0xF) >= 3 && std::find(pairs.begin(), pairs.end(), std::make_pair(a, a)) == pairs.end()) pairs.push_back({a, a});
+    if (pairs.size() > 8) { fail("more than 8 second-derivative channels in one kernel"); return nullptr; }
+    std::sort(pairs.begin(), pairs.end());
+    for (size_t p = 0; p < pairs.size(); ++p) PAIRS |= ((unsigned long long)(pairs[p].first | (pairs[p].second << 4))) << (8 * p);
+    unsigned first = need_first;
+    for (auto& pr : pairs) first |= (1u << pr.first) | (1u << pr.second);
+    const std::string before = g_err;
+    if (jit_spec(HP, NHH, D, first, PAIRS, (int)pairs.size(), need_hi, variant)) {
+        if (sp) { g_err = before; return sp; }                     // the wider kernel still serves
+        return nullptr;
+    }
+    g_err = before;
+    return find_spec(HP, NHH, D, need_first, need_pairs, need_hi, nullptr, variant, need_family);
 }
 
 const pk::SpecInfo* find_spec(int HP, int NHH, int D, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs,
@@ -126,8 +153,13 @@ static int plan_assign_terms(pinn_engine& E) {
         d = N.sizes[0];                                 // kernels are compiled per network input dimension
         const int LH = (int)N.sizes.size() - 2;
         const int HP = round_hp(N.maxhidden());
-        sp = find_spec(HP, LH - 1, d, need_first, need_pairs, need_hi, nullptr, variant_of(N.act));
+        const std::string prev = g_err;
+        g_err.clear();
+        sp = ensure_spec(N, need_first, need_pairs, need_hi);
+        const std::string why = g_err;
+        g_err = prev;
         if (!sp) {
+            if (!why.empty() && why.find("PINN_NO_JIT") == std::string::npos) return fail("term " + std::to_string(t) + ": " + why);
             char b[256];
             std::snprintf(b, sizeof b,
                           "term %zu: no compiled kernel for hidden width %d (padded %d), %d hidden layers, d=%d, first-derivative axes mask 0x%x, %zu second derivatives, higher-order mask 0x%x%s; add a PINN_INSTANTIATE line in csrc/inst_*.hip",
@@ -140,7 +172,16 @@ static int plan_assign_terms(pinn_engine& E) {
     static const bool no_lap = std::getenv("PINN_NO_LAPLACIAN") != nullptr;
     auto spec_exists = [&](int net, unsigned nf, const std::vector<std::pair<int, int>>& npairs, unsigned nh) {
         const Net& N = E.nets[net];
-        return find_spec(round_hp(N.maxhidden()), (int)N.sizes.size() - 3, N.sizes[0], nf, npairs, nh, nullptr, variant_of(N.act)) != nullptr;
+        if (find_spec(round_hp(N.maxhidden()), (int)N.sizes.size() - 3, N.sizes[0], nf, npairs, nh, nullptr, variant_of(N.act)) != nullptr) return true;
+        // shapes without ANY compiled kernel get the fused (fewer channels) form specialised at run time
+        bool any_aot = false;
+        for (const pk::SpecInfo& s : pk::registry())
+            any_aot = any_aot || (s.HP == round_hp(N.maxhidden()) && s.NHH == (int)N.sizes.size() - 3 && s.D == N.sizes[0] && s.C > 1);
+        if (any_aot) return false;
+        const std::string prev = g_err;
+        const bool ok = ensure_spec(N, nf, npairs, nh) != nullptr;
+        g_err = prev;
+        return ok;
     };
     if (!no_lap) {
         std::vector<Term> fused(E.terms.size());

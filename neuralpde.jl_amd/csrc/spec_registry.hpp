@@ -1,6 +1,7 @@
 // spec_registry.hpp — table of compiled kernel-family members (one per translation unit inst_*.hip).
 #pragma once
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -24,17 +25,19 @@ struct SpecInfo {
     int PACKED, SLAB, SCR, LDS_WG, COOP, SH, PW;
     int has_sin;                     // extra kernel variants compiled for this spec: bit 0 = sin activation, bit 1 = per-layer tanh / sigmoid (ACT_MIXED)
     int REC;                         // floats per tile of the HBM record store (MODE_FWDREC / MODE_GRADREC); 0: not supported
+    int jit;                         // 1: specialised at run time (jit.cpp), 0: from the ahead-of-time table
     int OFF_W1, OFF_B, OFF_WL, OFF_BL, OFF_WPK, OFF_WTPK;
     int O_WBAR, O_BFRH, O_BFR0, O_W1, O_WL, O_BL, O_P;
     void (*launch)(const GroupArgs&, int mode, int blocks, plat_stream);
 };
 
-std::vector<SpecInfo>& registry();
+std::deque<SpecInfo>& registry();      // a deque: runtime-specialised kernels (jit.cpp) are appended while engines hold SpecInfo pointers
 
 template <class S>
 SpecInfo make_info(void (*launch)(const GroupArgs&, int, int, plat_stream), int has_sin = 0) {
     SpecInfo s;
     s.has_sin = has_sin;
+    s.jit = 0;
     s.family = 1; s.WG_PER_CU = 1; s.NW = 4;
     s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR; s.HI = S::HI & 0xFFFFFFu; s.LAP = S::J::LAP;
     s.PG = S::PG; s.C = S::C; s.NG = S::NG; s.TP = S::TP; s.MT = S::MT; s.LH = S::LH; s.NFIRST = S::NFIRST;
@@ -51,6 +54,7 @@ template <class S>
 SpecInfo make_info2(void (*launch)(const GroupArgs&, int, int, plat_stream), int has_sin = 0) {
     SpecInfo s;
     s.has_sin = has_sin;
+    s.jit = 0;
     s.family = 2; s.WG_PER_CU = S::WG_PER_CU; s.NW = S::NW;
     s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR; s.HI = S::HI & 0xFFFFFFu; s.LAP = S::J::LAP;
     s.PG = S::PG; s.C = S::C; s.NG = S::NG; s.TP = S::TP; s.MT = S::MT; s.LH = S::LH; s.NFIRST = S::NFIRST;

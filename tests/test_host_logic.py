@@ -107,9 +107,9 @@ def test_discretizer_errors(npde, use_emu):
                                  npde.PhysicsInformedNN(chain, npde.GridTraining(0.5)))
     with pytest.raises(ValueError):               # chain count != dependent variable count
         npde.symbolic_discretize(sysm, npde.PhysicsInformedNN([chain, chain], npde.GridTraining(0.5)))
-    # unsupported shapes fail loudly at create time, never silently fall back
-    odd = npde.Chain(npde.Dense(2, 200, "tanh"), npde.Dense(200, 200, "tanh"), npde.Dense(200, 1))
-    with pytest.raises(npde.EngineError, match="no compiled kernel"):
+    # shapes outside the kernel table are specialised at create time (tests/test_jit.py); what cannot be built fails loudly, never a fallback
+    odd = npde.Chain(npde.Dense(2, 200, "relu"), npde.Dense(200, 200, "relu"), npde.Dense(200, 1))
+    with pytest.raises(npde.EngineError, match="unsupported activation"):
         npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(odd, npde.GridTraining(0.5)))
     with pytest.raises(npde.EngineError):
         npde.Engine("pinnir 2\n")

@@ -1,0 +1,71 @@
+"""Runtime specialisation (csrc/jit.cpp): network shapes / jet sets outside the ahead-of-time kernel table are compiled at
+`pinn_create` from the same kernel templates, cached and loaded — the reference accepts any Lux chain per dependent variable
+(src/pinn_types.jl:79-108).  CPU: through the emulation build (g++); GPU: hipcc on the box (tests/test_gpu_mirror.py re-runs these)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import sympy as sp
+
+import helpers
+import pinn_oracle as po
+import test_emu_parity as tp
+
+
+def test_wide_net_200(npde, use_emu):
+    """2 -> 200 -> 200 -> 1 (padded to 256): the shape test_discretizer_errors used to reject."""
+    sysm, _ = tp.poisson2d(npde)
+    odd = npde.Chain(npde.Dense(2, 200, "tanh"), npde.Dense(200, 200, "tanh"), npde.Dense(200, 1))
+    strat = npde.QuasiRandomTraining(24, bcs_points=10, sampling_alg=npde.SobolSample(seed=4), resampling=False, minibatch=1)
+    rep, prob, sets, th = tp.check(npde, sysm, [odd], strat, tp.theta_for(odd, 3))
+    kernels = [l.split("kernel=")[1].split()[0] for l in rep.engine.describe().splitlines() if "kernel=" in l]
+    assert any("HP256" in k and "L3" in k for k in kernels) and any("HP256" in k and "(C=1)" in k for k in kernels)   # interior (forward Laplacian) + value-only
+    u = rep.phi(sets[0], th)[0]
+    assert np.max(np.abs(u - po.phi_values(prob.chains[0], th, sets[0])[0])) < 1e-5
+
+
+def test_deep_net_and_unlisted_jet_sets(npde, use_emu):
+    # five hidden layers of 40 (table: up to four at this width), residual with mixed second derivatives
+    sysm, chain = helpers.shape_problem(npde, 40, 5, 2)
+    strat = npde.QuasiRandomTraining(20, bcs_points=8, sampling_alg=npde.SobolSample(seed=5), resampling=False, minibatch=1)
+    tp.check(npde, sysm, [chain], strat, tp.theta_for(chain, 31))
+    # a 4-input net of width 16 (table: 1-3 inputs for small nets), first + pure second derivatives
+    t, x, y, z = npde.parameters("t x y z")
+    (u,) = npde.variables("u")
+    U = u(t, x, y, z)
+    D = npde.Differential
+    eq = npde.Eq(D(t)(U), 0.3 * ((D(x) ** 2)(U) + (D(y) ** 2)(U) + (D(z) ** 2)(U)) + U * D(x)(U))
+    bcs = [npde.Eq(u(0, x, y, z), sp.sin(sp.pi * x) * sp.sin(sp.pi * y) * sp.sin(sp.pi * z)), npde.Eq(u(t, 0, y, z), 0.0)]
+    dom = [npde.In(v, npde.Interval(0.0, 1.0)) for v in (t, x, y, z)]
+    sysm = npde.PDESystem([eq], bcs, dom, [t, x, y, z], [U])
+    chain = npde.Chain(npde.Dense(4, 16, "sigmoid"), npde.Dense(16, 16, "sigmoid"), npde.Dense(16, 1))
+    strat = npde.QuasiRandomTraining(30, bcs_points=12, sampling_alg=npde.SobolSample(seed=6), resampling=False, minibatch=1)
+    tp.check(npde, sysm, [chain], strat, tp.theta_for(chain, 32))
+    # third derivative on a 32-wide net (table: pure orders 3-4 up to 16 wide)
+    (x,) = npde.parameters("x")
+    (u,) = npde.variables("u")
+    eq = npde.Eq((npde.Differential(x) ** 3)(u(x)) + u(x) * npde.Differential(x)(u(x)), sp.cos(sp.pi * x))
+    sysm = npde.PDESystem([eq], [npde.Eq(u(0.0), 0.0), npde.Eq(u(1.0), 1.0)], [npde.In(x, npde.Interval(0.0, 1.0))], [x], [u(x)])
+    chain = npde.Chain(npde.Dense(1, 24, "tanh"), npde.Dense(24, 24, "tanh"), npde.Dense(24, 1))
+    tp.check(npde, sysm, [chain], npde.GridTraining(0.05), tp.theta_for(chain, 33), mode="exact")
+
+
+def test_jit_failures_are_loud(npde, use_emu):
+    # per-layer tanh / sigmoid on a 64-wide net: the mixed variant exists for the one-wave-per-tile kernels (<= 32 wide) only
+    sysm, _ = helpers.shape_problem(npde, 64, 4, 2)
+    big = npde.Chain(npde.Dense(2, 64, "tanh"), npde.Dense(64, 64, "sigmoid"), npde.Dense(64, 64, "tanh"), npde.Dense(64, 64, "tanh"), npde.Dense(64, 1))
+    with pytest.raises(Exception, match="per-layer tanh/sigmoid"):
+        npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(big, npde.GridTraining(0.25), init_params=tp.theta_for(big, 75)))
+    # PINN_NO_JIT: the old behaviour — fail at create time with the line to add to the table
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import pinn_import; m = pinn_import.load(); m._lib.set_library(m.Library(%r))\n"
+            "import test_emu_parity as tp\n"
+            "sysm, _ = tp.poisson2d(m)\n"
+            "odd = m.Chain(m.Dense(2, 200, 'tanh'), m.Dense(200, 200, 'tanh'), m.Dense(200, 1))\n"
+            "try:\n    m.symbolic_discretize(sysm, m.PhysicsInformedNN(odd, m.GridTraining(0.5)))\nexcept m.EngineError as e:\n    print('ENGINEERROR', e)\n"
+            % (root, os.path.join(root, "tests"), os.path.join(root, "oracle"), os.path.join(root, "tests", "emu", "libpinn_emu.so")))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PINN_NO_JIT="1"), capture_output=True, text=True, timeout=300)
+    assert "ENGINEERROR" in r.stdout and "no compiled kernel" in r.stdout, r.stdout + r.stderr
