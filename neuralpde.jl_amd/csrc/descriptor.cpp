@@ -118,7 +118,7 @@ int parse_descriptor(const char* text, pinn_engine& E) {
             if (ord == "lap") {                      // slot <net> lap <n> a0 a1 ... : sum of d2/dx_a^2 over the listed axes
                 int n = 0;
                 if (!(in >> n) || n < 1 || n > 8) return fail("descriptor: lap slot");
-                S.order = 2; S.axes[0] = S.axes[1] = S.axes[2] = S.axes[3] = 0;
+                S.order = 2; for (int a = 0; a < MAX_DERIV_ORDER; ++a) S.axes[a] = 0;
                 for (int a = 0; a < n; ++a) {
                     int ax;
                     if (!(in >> ax) || ax < 0 || ax > 7) return fail("descriptor: lap slot axes");
@@ -128,13 +128,10 @@ int parse_descriptor(const char* text, pinn_engine& E) {
             }
             S.order = std::atoi(ord.c_str());
             if (ord.empty() || ord.find_first_not_of("0123456789") != std::string::npos) return fail("descriptor: slot order");
-            if (S.order < 0 || S.order > 4) return fail("derivative order > 4 is not supported by the HIP engine");
+            if (S.order < 0 || S.order > MAX_DERIV_ORDER) return fail("derivative order > 6 is not supported by the HIP engine");
             for (int a = 0; a < S.order; ++a)
                 if (!(in >> S.axes[a])) return fail("descriptor: slot axes");
-            if (S.order == 2 && S.axes[0] > S.axes[1]) std::swap(S.axes[0], S.axes[1]);
-            if (S.order >= 3)
-                for (int a = 1; a < S.order; ++a)
-                    if (S.axes[a] != S.axes[0]) return fail("mixed derivatives of order > 2 are not supported by the HIP engine (pure d^3/dx^3, d^4/dx^4 are)");
+            std::sort(S.axes, S.axes + S.order);
         }
         T.ops.resize(no);
         for (int q = 0; q < no; ++q) {

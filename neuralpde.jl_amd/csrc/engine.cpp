@@ -570,21 +570,23 @@ int pinn_derivative(pinn_handle h, int net, const float* theta, int64_t p, const
     DeviceScope scope(E.device);
     if (net < 0 || net >= (int)E.nets.size()) return fail("pinn_derivative: net index out of range");
     if (n <= 0) return fail("pinn_derivative: n must be positive");
-    if (order < 0 || order > 4 || (order > 0 && !axes)) return fail("pinn_derivative: order must be 0..4 (with `order` axes)");
+    if (order < 0 || order > MAX_DERIV_ORDER || (order > 0 && !axes)) return fail("pinn_derivative: order must be 0..6 (with `order` axes)");
     const Net& N = E.nets[net];
     if (!E.netplans[net].spec) return fail("pinn_derivative: network is not used by any term");
     Slot sl;
     sl.net = net; sl.order = order; sl.lap = 0;
-    for (int a = 0; a < 4; ++a) sl.axes[a] = a < order ? axes[a] : 0;
+    for (int a = 0; a < MAX_DERIV_ORDER; ++a) sl.axes[a] = a < order ? axes[a] : 0;
     std::sort(sl.axes, sl.axes + order);
     for (int a = 0; a < order; ++a)
         if (sl.axes[a] < 0 || sl.axes[a] >= N.sizes[0]) return fail("pinn_derivative: axis out of range");
-    if (order >= 3 && sl.axes[0] != sl.axes[order - 1]) return fail("pinn_derivative: mixed derivatives of order > 2 are not carried by the jet kernels");
     unsigned need_first = 0, need_hi = 0;
     std::vector<std::pair<int, int>> need_pairs;
-    for (int a = 0; a < order; ++a) need_first |= 1u << sl.axes[a];
-    if (order >= 2) need_pairs.push_back({sl.axes[0], sl.axes[1]});
-    if (order >= 3) need_hi = (unsigned)order << (4 * sl.axes[0]);
+    if (slot_is_general(sl)) need_hi = GEN_FLAG | (unsigned)gen_set_id({slot_mi(sl)});      // mixed of order >= 3, orders 5-6: generated jet set
+    else {
+        for (int a = 0; a < order; ++a) need_first |= 1u << sl.axes[a];
+        if (order >= 2) need_pairs.push_back({sl.axes[0], sl.axes[1]});
+        if (order >= 3) need_hi = (unsigned)order << (4 * sl.axes[0]);
+    }
     const int LH = (int)N.sizes.size() - 2;
     (void)LH;
     const pk::SpecInfo* sp = ensure_spec(N, need_first, need_pairs, need_hi, E.netplans[net].spec->family);

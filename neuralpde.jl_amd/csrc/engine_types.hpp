@@ -23,10 +23,11 @@ constexpr int REDUCE_SPLIT = 32;     // stage-1 chunks of the fixed-order slab r
 extern thread_local std::string g_err;      // message of the last failed call on this thread (pinn_last_error)
 int fail(const std::string& m);             // records the message, returns 1
 
+constexpr int MAX_DERIV_ORDER = 6;
 struct Slot {
     int net;
     int order;
-    int axes[4];
+    int axes[MAX_DERIV_ORDER];       // sorted; order <= 2 may be mixed in the fixed channel categories, anything else rides a general set
     unsigned lap = 0;        // != 0: the sum of the pure second derivatives over these axes (one "forward Laplacian" jet channel)
 };
 struct Net {
@@ -221,7 +222,17 @@ const pk::SpecInfo* ensure_spec(const Net& N, unsigned need_first, const std::ve
                                 int need_family = 0);
 // jit.cpp
 int jit_round_hp(int h);
-int jit_spec(int HP, int NHH, int D, unsigned D1MASK, unsigned long long PAIRS, int NPAIR, unsigned HI, int variant);      // jet channel of a slot in a kernel's channel set (-1: not carried)
+int jit_spec(int HP, int NHH, int D, unsigned D1MASK, unsigned long long PAIRS, int NPAIR, unsigned HI, int variant);
+// general multi-index jet sets (mixed derivatives of order >= 3, orders 5-6): closed, ordered channel list of a set of requested
+// multi-indices (nibble 0 = order, nibbles 1.. = sorted axes) and the kernel generated for it
+std::vector<unsigned> gen_close(const std::vector<unsigned>& want);
+int jit_spec_gen(int HP, int NHH, int D, const std::vector<unsigned>& channels, int variant);
+// plan.cpp: process-wide table of requested general sets; a request travels through the (first, pairs, hi) needs as hi = GEN_FLAG | id
+constexpr unsigned GEN_FLAG = 0x80000000u;
+int gen_set_id(const std::vector<unsigned>& want);             // id of the (closed) set containing `want`
+const std::vector<unsigned>& gen_set(int id);
+unsigned slot_mi(const Slot& s);                               // multi-index of a slot
+bool slot_is_general(const Slot& s);                           // not representable by the fixed channel categories      // jet channel of a slot in a kernel's channel set (-1: not carried)
 // kernel-variant bit a network's activation needs beyond the tanh / sigmoid kernels every spec has (SpecInfo::has_sin)
 inline int variant_of(int act) { return act == pk::ACT_SIN ? 1 : (act == pk::ACT_MIXED ? 2 : 0); }
 std::string spec_name(const pk::SpecInfo& s);

@@ -48,6 +48,7 @@ enum Act : int { ACT_TANH = 0, ACT_SIGMOID = 1, ACT_SIN = 2,
 enum Mode : int { MODE_FUSED = 0, MODE_RESID = 1, MODE_FWD = 2, MODE_GRADIN = 3, MODE_FWDREC = 4, MODE_GRADREC = 5 };
 
 constexpr int MAX_GROUP_TERMS = 12;
+constexpr int ND = 8;            // activation-derivative array: d[1] .. d[7] (jets up to order 6 need phi^(7) in the reverse sweep)
 constexpr int MAX_PARAMS = 4;
 
 // ------------------------------------------------------------------------------------------------
@@ -110,6 +111,10 @@ struct JetSet {
     static_assert(valid(), "third/fourth derivative channels need first(a) and pair(a,a) of the same axis; Laplacian axes need first(a)");
     // derivatives of the activation needed by the reverse sweep (one more than the highest jet order)
     static constexpr int NORD = N4 > 0 ? 5 : (N3 > 0 ? 4 : 3);
+    // general multi-index channel sets (mixed derivatives of order >= 3, orders 5-6) are SPECIALISATIONS of this template generated at
+    // run time (jit.cpp: bit 31 of HI + a set id); gen_channel(i) = the multi-index of channel i, 0 for the fixed categories above
+    static constexpr bool GEN = false;
+    static constexpr unsigned gen_channel(int) { return 0u; }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -221,8 +226,15 @@ struct GroupArgs {
 // MIXED (ACT_MIXED kernels): `act` is the run-time kind of THIS layer (tanh or sigmoid).  Both are one function family,
 // f(z) = m s(m z) + 1 - m with s = logistic and m = 2 (tanh) or 1 (sigmoid), so the layer kind enters only through the scalar m:
 // no branch behind the GEMMs (a run-time branch there is what the unmixed kernels avoid by taking the kind as a template parameter).
+// s^(6) / (s (1 - s)) and s^(7) / (s (1 - s)) of the logistic function as polynomials in s (Horner form)
+DEV vfloat sig_poly6(vfloat s) {
+    return vfma(vfma(vfma(vfma(vfma(vfloat(-720.0f), s, vfloat(1800.0f)), s, vfloat(-1560.0f)), s, vfloat(540.0f)), s, vfloat(-62.0f)), s, vfloat(1.0f));
+}
+DEV vfloat sig_poly7(vfloat s) {
+    return vfma(vfma(vfma(vfma(vfma(vfma(vfloat(5040.0f), s, vfloat(-15120.0f)), s, vfloat(16800.0f)), s, vfloat(-8400.0f)), s, vfloat(1806.0f)), s, vfloat(-126.0f)), s, vfloat(1.0f));
+}
 template <int NORD, bool SINACT, bool MIXED = false>
-DEV void act_derivs_n(int act, vfloat a, vfloat (&d)[6]) {
+DEV void act_derivs_n(int act, vfloat a, vfloat (&d)[ND]) {
     if (MIXED) {
         const float m = 2.0f - (float)act, im = 0.5f + 0.5f * (float)act, m2 = m * m;      // act in {ACT_TANH = 0, ACT_SIGMOID = 1}
         const vfloat s = (a + vfloat(m - 1.0f)) * vfloat(im);                              // logistic value behind the record
@@ -234,6 +246,8 @@ DEV void act_derivs_n(int act, vfloat a, vfloat (&d)[6]) {
         d[3] = vfloat(m2 * m2) * s3;
         if (NORD >= 4) d[4] = vfloat(m2 * m2 * m) * (s2 * (vfloat(1.0f) - vfloat(12.0f) * s1));
         if (NORD >= 5) d[5] = vfloat(m2 * m2 * m2) * (s3 * (vfloat(1.0f) - vfloat(12.0f) * s1) - vfloat(12.0f) * s2 * s2);
+        if (NORD >= 6) d[6] = vfloat(m2 * m2 * m2 * m) * s1 * sig_poly6(s);
+        if (NORD >= 7) d[7] = vfloat(m2 * m2 * m2 * m2) * s1 * sig_poly7(s);
         return;
     }
     if (SINACT) {
@@ -244,6 +258,8 @@ DEV void act_derivs_n(int act, vfloat a, vfloat (&d)[6]) {
         d[3] = vfloat(0.f) - cs;
         if (NORD >= 4) d[4] = sn;
         if (NORD >= 5) d[5] = cs;
+        if (NORD >= 6) d[6] = vfloat(0.f) - sn;
+        if (NORD >= 7) d[7] = vfloat(0.f) - cs;
     } else if (act == ACT_TANH) {
         const vfloat a2 = a * a;
         d[1] = vfloat(1.0f) - a2;
@@ -251,18 +267,22 @@ DEV void act_derivs_n(int act, vfloat a, vfloat (&d)[6]) {
         d[3] = d[1] * (vfloat(6.0f) * a2 - vfloat(2.0f));
         if (NORD >= 4) d[4] = d[1] * a * (vfloat(16.0f) - vfloat(24.0f) * a2);
         if (NORD >= 5) d[5] = d[1] * (vfma(vfma(vfloat(120.0f), a2, vfloat(-120.0f)), a2, vfloat(16.0f)));
+        if (NORD >= 6) d[6] = d[1] * a * vfma(vfma(vfloat(-720.0f), a2, vfloat(960.0f)), a2, vfloat(-272.0f));
+        if (NORD >= 7) d[7] = d[1] * vfma(vfma(vfma(vfloat(5040.0f), a2, vfloat(-8400.0f)), a2, vfloat(3696.0f)), a2, vfloat(-272.0f));
     } else {
         d[1] = a * (vfloat(1.0f) - a);
         d[2] = d[1] * (vfloat(1.0f) - vfloat(2.0f) * a);
         d[3] = d[1] * (vfloat(1.0f) - vfloat(6.0f) * d[1]);
         if (NORD >= 4) d[4] = d[2] * (vfloat(1.0f) - vfloat(12.0f) * d[1]);
         if (NORD >= 5) d[5] = d[3] * (vfloat(1.0f) - vfloat(12.0f) * d[1]) - vfloat(12.0f) * d[2] * d[2];
+        if (NORD >= 6) d[6] = d[1] * sig_poly6(a);
+        if (NORD >= 7) d[7] = d[1] * sig_poly7(a);
     }
 }
 // One element's jet through the activation (Faa di Bruno), in place: z[0] = a = phi(z0) on entry, z[k>0] = pre-activation
 // channels; on exit z[k] = post-activation channels.  Higher channels first: they read the lower pre-activation values.
 template <class J>
-DEV void jet_forward(vfloat (&z)[J::C], const vfloat (&d)[6]) {
+DEV void jet_forward(vfloat (&z)[J::C], const vfloat (&d)[ND]) {
     PINN_UNROLL for (int k = 0; k < J::N4; ++k) {
         const int ax = J::hi_axis(4, k);
         const vfloat z1 = z[J::CH_FIRST + J::first_rank(ax)], z2 = z[J::CH_PAIR + J::pair_index(ax, ax)], z3 = z[J::CH_3 + J::hi_rank(3, ax)];
@@ -297,7 +317,7 @@ DEV void jet_forward(vfloat (&z)[J::C], const vfloat (&d)[6]) {
 // Adjoint of jet_forward for one element: g[k] = adjoint of post-activation channel k on entry, of pre-activation channel k
 // on exit; s = the record (s[0] = a, s[k>0] = pre-activation channels).
 template <class J>
-DEV void jet_adjoint(vfloat (&g)[J::C], const vfloat (&s)[J::C], const vfloat (&d)[6]) {
+DEV void jet_adjoint(vfloat (&g)[J::C], const vfloat (&s)[J::C], const vfloat (&d)[ND]) {
     vfloat zv = d[1] * g[0];
     vfloat zf[J::NFIRST > 0 ? J::NFIRST : 1], zp[J::NPAIR > 0 ? J::NPAIR : 1], z3b[J::N3 > 0 ? J::N3 : 1];
     PINN_UNROLL for (int kf = 0; kf < J::NFIRST; ++kf) {
@@ -511,7 +531,7 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                         }
                     }
                     PINN_UNROLL for (int r = 0; r < 4; ++r) {
-                        vfloat zz[C], dd[6];
+                        vfloat zz[C], dd[ND];
                         PINN_UNROLL for (int ch = 0; ch < C; ++ch) zz[ch] = Z[pg * C + ch][m][r];
                         act_derivs_n<J::NORD - 1, SINACT, MIXED>(act, zz[0], dd);
                         jet_forward<J>(zz, dd);
@@ -665,7 +685,7 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
         auto ajet = [&](const vfloat4 (&Sr)[NG][MT], int pg, int ch, int m, int act) -> vfloat4 {
             vfloat4 out;
             PINN_UNROLL for (int r = 0; r < 4; ++r) {
-                vfloat zz[C], dd[6];
+                vfloat zz[C], dd[ND];
                 PINN_UNROLL for (int k = 0; k < C; ++k) zz[k] = Sr[pg * C + k][m][r];
                 if (ch > 0) {
                     act_derivs_n<J::NORD - 1, SINACT, MIXED>(act, zz[0], dd);
@@ -680,7 +700,7 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                 PINN_UNROLL for (int m = 0; m < MT; ++m)
                     PINN_UNROLL for (int r = 0; r < 4; ++r) {
-                        vfloat gg[C], ss[C], dd[6];
+                        vfloat gg[C], ss[C], dd[ND];
                         PINN_UNROLL for (int k = 0; k < C; ++k) { gg[k] = G[pg * C + k][m][r]; ss[k] = Sr[pg * C + k][m][r]; }
                         act_derivs_n<J::NORD, SINACT, MIXED>(act, ss[0], dd);
                         jet_adjoint<J>(gg, ss, dd);

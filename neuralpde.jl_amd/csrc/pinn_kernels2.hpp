@@ -244,7 +244,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         }
                     }
                     PINN_UNROLL for (int r = 0; r < 4; ++r) {
-                        vfloat zz[C], dd[6];
+                        vfloat zz[C], dd[ND];
                         PINN_UNROLL for (int ch = 0; ch < C; ++ch) zz[ch] = Z[pg * C + ch][t][r];
                         act_derivs_n<J::NORD - 1, SINACT>(act, zz[0], dd);
                         jet_forward<J>(zz, dd);
@@ -375,7 +375,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t)
                     PINN_UNROLL for (int r = 0; r < 4; ++r) {
-                        vfloat zz[C], dd[6];
+                        vfloat zz[C], dd[ND];
                         PINN_UNROLL for (int k2 = 0; k2 < C; ++k2) zz[k2] = Rlast[pg * C + k2][t][r];
                         act_derivs_n<J::NORD - 1, SINACT>(act, zz[0], dd);
                         jet_forward<J>(zz, dd);
@@ -501,7 +501,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
         auto ajet = [&](const vfloat4 (&Sr)[NG][MTW], int pg, int ch, int t) -> vfloat4 {
             vfloat4 out;
             PINN_UNROLL for (int r = 0; r < 4; ++r) {
-                vfloat zz[C], dd[6];
+                vfloat zz[C], dd[ND];
                 PINN_UNROLL for (int k = 0; k < C; ++k) zz[k] = Sr[pg * C + k][t][r];
                 if (ch > 0) {
                     act_derivs_n<J::NORD - 1, SINACT>(act, zz[0], dd);
@@ -515,7 +515,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t)
                     PINN_UNROLL for (int r = 0; r < 4; ++r) {
-                        vfloat gg[C], ss[C], dd[6];
+                        vfloat gg[C], ss[C], dd[ND];
                         PINN_UNROLL for (int k = 0; k < C; ++k) { gg[k] = G[pg * C + k][t][r]; ss[k] = Sr[pg * C + k][t][r]; }
                         act_derivs_n<J::NORD, SINACT>(act, ss[0], dd);
                         jet_adjoint<J>(gg, ss, dd);

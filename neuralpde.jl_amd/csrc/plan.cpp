@@ -14,6 +14,12 @@ int round_hp(int h) {
 
 const pk::SpecInfo* ensure_spec(const Net& N, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs, unsigned need_hi, int need_family) {
     const int HP = round_hp(N.maxhidden()), NHH = (int)N.sizes.size() - 3, D = N.sizes[0], variant = variant_of(N.act);
+    if (need_hi & GEN_FLAG) {                    // general multi-index channel set: always generated (jit.cpp: jit_spec_gen)
+        const pk::SpecInfo* g = find_spec(HP, NHH, D, 0, {}, need_hi, nullptr, variant, need_family);
+        if (g) return g;
+        if (jit_spec_gen(HP, NHH, D, gen_set((int)(need_hi & ~GEN_FLAG)), variant)) return nullptr;
+        return find_spec(HP, NHH, D, 0, {}, need_hi, nullptr, variant, need_family);
+    }
     const pk::SpecInfo* sp = find_spec(HP, NHH, D, need_first, need_pairs, need_hi, nullptr, variant, need_family);
     int cneed = 1 + (int)need_pairs.size() + ((need_hi >> 24) ? 1 : 0);
     for (int a = 0; a < 8; ++a) cneed += ((need_first >> a) & 1) + (a < 6 && ((need_hi >> (4 * a)) & 0xF) >= 3) + (a < 6 && ((need_hi >> (4 * a)) & 0xF) >= 4);
@@ -42,9 +48,23 @@ const pk::SpecInfo* ensure_spec(const Net& N, unsigned need_first, const std::ve
 const pk::SpecInfo* find_spec(int HP, int NHH, int D, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs,
                               unsigned need_hi, std::vector<int>* pair_index, int need_variant, int need_family) {
     const pk::SpecInfo* best = nullptr;
+    const bool want_gen = (need_hi & GEN_FLAG) != 0;
     for (const pk::SpecInfo& s : pk::registry()) {
         if (s.HP != HP || s.NHH != NHH || s.D != D) continue;
         if (need_variant && !(s.has_sin & need_variant)) continue;
+        if (want_gen != (s.ngen > 0)) continue;
+        if (want_gen) {                          // general multi-index set: every requested channel must be carried
+            bool all = true;
+            for (unsigned m : gen_set((int)(need_hi & ~GEN_FLAG))) {
+                bool f = false;
+                for (int c = 0; c < s.ngen; ++c) f = f || s.gen[c] == m;
+                all = all && f;
+            }
+            if (!all) continue;
+            if (need_family && s.family != need_family) continue;
+            if (!best || s.C < best->C) best = &s;
+            continue;
+        }
         if ((s.D1MASK & need_first) != need_first) continue;
         bool ok = true;
         for (int a = 0; a < 6; ++a)
@@ -77,7 +97,37 @@ int first_rank(const pk::SpecInfo& s, int axis) {
     return c;
 }
 
+unsigned slot_mi(const Slot& s) {
+    unsigned v = (unsigned)s.order;
+    for (int a = 0; a < s.order; ++a) v |= (unsigned)s.axes[a] << (4 * (a + 1));
+    return v;
+}
+bool slot_is_general(const Slot& s) {
+    if (s.lap) return false;
+    if (s.order >= 5) return true;
+    for (int a = 1; a < s.order && s.order >= 3; ++a)
+        if (s.axes[a] != s.axes[0]) return true;
+    return false;
+}
+static std::vector<std::vector<unsigned>>& gen_sets() { static std::vector<std::vector<unsigned>> v; return v; }
+int gen_set_id(const std::vector<unsigned>& want) {
+    const std::vector<unsigned> closed = gen_close(want);
+    auto& v = gen_sets();
+    for (size_t i = 0; i < v.size(); ++i)
+        if (v[i] == closed) return (int)i;
+    v.push_back(closed);
+    return (int)v.size() - 1;
+}
+const std::vector<unsigned>& gen_set(int id) { return gen_sets().at((size_t)id); }
+
 int chan_of(const pk::SpecInfo& s, const Slot& sl) {
+    if (s.ngen > 0) {
+        if (sl.lap) return -1;
+        const unsigned m = slot_mi(sl);
+        for (int c = 0; c < s.ngen; ++c)
+            if (s.gen[c] == m) return c;
+        return -1;
+    }
     if (sl.lap) return sl.lap == s.LAP ? 1 + s.NFIRST + s.NPAIR : -1;
     const int nlap = s.LAP ? 1 : 0;
     if (sl.order == 0) return 0;
@@ -122,6 +172,34 @@ static int plan_check_nets(pinn_engine& E) {
 static int plan_assign_terms(pinn_engine& E) {
     // ---- terms -> groups ----
     auto needs_of = [&](const Term& T, int net, unsigned& need_first, std::vector<std::pair<int, int>>& need_pairs, unsigned& need_hi) -> int {
+        bool general = (need_hi & GEN_FLAG) != 0;
+        for (auto& s : T.slots) general = general || (s.net == net && slot_is_general(s));
+        if (general) {
+            // a derivative outside the fixed channel categories (mixed of order >= 3, order 5-6): ALL channels this network needs — the
+            // ones accumulated so far and this term's — travel as one general multi-index set (closed under sub-multi-indices)
+            std::vector<unsigned> want;
+            if (need_hi & GEN_FLAG) want = gen_set((int)(need_hi & ~GEN_FLAG));
+            else {
+                if (need_hi >> 24) return fail("a forward-Laplacian channel cannot be combined with a general derivative set (internal)");
+                for (int a = 0; a < 8; ++a) if (need_first & (1u << a)) want.push_back(1u | ((unsigned)a << 4));
+                for (auto& pr : need_pairs) want.push_back(2u | ((unsigned)pr.first << 4) | ((unsigned)pr.second << 8));
+                for (int a = 0; a < 6; ++a) {
+                    const unsigned h = (need_hi >> (4 * a)) & 0xF;
+                    if (h >= 3) { unsigned m = h; for (unsigned i = 0; i < h; ++i) m |= (unsigned)a << (4 * (i + 1)); want.push_back(m); }
+                }
+            }
+            for (auto& s : T.slots) {
+                if (s.net != net || s.order == 0) continue;
+                if (s.lap) return fail("a forward-Laplacian channel cannot be combined with a general derivative set (internal)");
+                for (int a = 0; a < s.order; ++a)
+                    if (s.axes[a] < 0 || s.axes[a] >= E.nets[net].sizes[0]) return fail("descriptor: slot axis out of range");
+                want.push_back(slot_mi(s));
+            }
+            need_first = 0;
+            need_pairs.clear();
+            need_hi = GEN_FLAG | (unsigned)gen_set_id(want);
+            return 0;
+        }
         for (auto& s : T.slots) {
             if (s.net != net) continue;
             if (s.lap) {
@@ -183,7 +261,9 @@ static int plan_assign_terms(pinn_engine& E) {
         g_err = prev;
         return ok;
     };
-    if (!no_lap) {
+    bool any_general = false;
+    for (auto& T : E.terms) for (auto& sl : T.slots) any_general = any_general || slot_is_general(sl);
+    if (!no_lap && !any_general) {
         std::vector<Term> fused(E.terms.size());
         std::vector<char> did(E.terms.size(), 0);
         std::map<int, std::pair<unsigned, std::vector<std::pair<int, int>>>> cn;      // coupled networks: union needs with fusion
@@ -253,6 +333,7 @@ static int plan_assign_terms(pinn_engine& E) {
             if (needs_of(T, term_nets[t][0], nf, npairs, nh)) return 1;
             int cmin = 1 + (int)npairs.size() + ((nh >> 24) ? 1 : 0);
             for (int a = 0; a < 8; ++a) cmin += ((nf >> a) & 1) + (a < 6 && ((nh >> (4 * a)) & 0xF) >= 3) + (a < 6 && ((nh >> (4 * a)) & 0xF) >= 4);
+            if (nh & GEN_FLAG) cmin = (int)gen_set((int)(nh & ~GEN_FLAG)).size();
             two_launch[t] = T.d + E.np + cmin + (int)probe.src_root.size() + (int)probe.tape_ops.size() > rp::MAX_ROWS_FUSED;
         }
         if (two_launch[t])

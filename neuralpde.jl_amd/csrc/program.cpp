@@ -145,7 +145,7 @@ bool fuse_laplacian(Term& T, int np) {
     for (int s = 0; s < S; ++s) if (!slot_dead[s]) { slot_new[s] = (int)nslots.size(); nslots.push_back(T.slots[s]); }
     std::vector<int> tree_slot(trees.size());
     for (size_t i = 0; i < trees.size(); ++i) {
-        Slot L; L.net = trees[i].net; L.order = 2; L.axes[0] = L.axes[1] = L.axes[2] = L.axes[3] = 0; L.lap = trees[i].mask;
+        Slot L; L.net = trees[i].net; L.order = 2; for (int a = 0; a < MAX_DERIV_ORDER; ++a) L.axes[a] = 0; L.lap = trees[i].mask;
         tree_slot[i] = (int)nslots.size();
         nslots.push_back(L);
     }

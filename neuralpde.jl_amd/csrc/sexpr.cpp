@@ -125,11 +125,7 @@ struct Lowering {
 
     bool slot_ref(int net, std::vector<int> axes, Ref& out) {
         std::sort(axes.begin(), axes.end());
-        if (axes.size() > 4) return fail_("derivative order " + std::to_string(axes.size()) + " > 4 of " + C.depvars[net] + " is not supported by the HIP engine");
-        if (axes.size() > 2)
-            for (int a : axes)
-                if (a != axes[0]) return fail_("mixed derivative of order " + std::to_string(axes.size()) + " of " + C.depvars[net] +
-                                               " is not supported by the HIP engine (pure third / fourth derivatives along one axis are)");
+        if ((int)axes.size() > MAX_DERIV_ORDER) return fail_("derivative order " + std::to_string(axes.size()) + " > 6 of " + C.depvars[net] + " is not supported by the HIP engine");
         for (size_t i = 0; i < slots.size(); ++i) {
             bool same = slots[i].net == net && slots[i].order == (int)axes.size();
             for (size_t a = 0; same && a < axes.size(); ++a) same = slots[i].axes[a] == axes[a];
@@ -137,7 +133,7 @@ struct Lowering {
         }
         Slot s;
         s.net = net; s.order = (int)axes.size(); s.lap = 0;
-        for (int a = 0; a < 4; ++a) s.axes[a] = a < (int)axes.size() ? axes[a] : 0;
+        for (int a = 0; a < MAX_DERIV_ORDER; ++a) s.axes[a] = a < (int)axes.size() ? axes[a] : 0;
         slots.push_back(s);
         out = Ref{'s', (int)slots.size() - 1};
         return true;

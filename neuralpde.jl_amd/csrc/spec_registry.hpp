@@ -12,6 +12,8 @@
 
 namespace pk {
 
+constexpr int MAX_GEN_CHANNELS = 24;
+
 struct SpecInfo {
     int family;                      // 1: one wave per tile (pinn_kernels.hpp); 2: neuron-split workgroups (pinn_kernels2.hpp)
     int WG_PER_CU;
@@ -26,6 +28,8 @@ struct SpecInfo {
     int has_sin;                     // extra kernel variants compiled for this spec: bit 0 = sin activation, bit 1 = per-layer tanh / sigmoid (ACT_MIXED)
     int REC;                         // floats per tile of the HBM record store (MODE_FWDREC / MODE_GRADREC); 0: not supported
     int jit;                         // 1: specialised at run time (jit.cpp), 0: from the ahead-of-time table
+    int ngen;                        // > 0: general multi-index channel set (jit.cpp gen_*): gen[i] = multi-index of channel i (nibble 0 = order, nibbles 1.. = axes)
+    unsigned gen[MAX_GEN_CHANNELS];
     int OFF_W1, OFF_B, OFF_WL, OFF_BL, OFF_WPK, OFF_WTPK;
     int O_WBAR, O_BFRH, O_BFR0, O_W1, O_WL, O_BL, O_P;
     void (*launch)(const GroupArgs&, int mode, int blocks, plat_stream);
@@ -38,6 +42,8 @@ SpecInfo make_info(void (*launch)(const GroupArgs&, int, int, plat_stream), int 
     SpecInfo s;
     s.has_sin = has_sin;
     s.jit = 0;
+    s.ngen = S::J::GEN ? S::C : 0;
+    for (int i = 0; i < MAX_GEN_CHANNELS; ++i) s.gen[i] = (S::J::GEN && i < S::C) ? S::J::gen_channel(i) : 0u;
     s.family = 1; s.WG_PER_CU = 1; s.NW = 4;
     s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR; s.HI = S::HI & 0xFFFFFFu; s.LAP = S::J::LAP;
     s.PG = S::PG; s.C = S::C; s.NG = S::NG; s.TP = S::TP; s.MT = S::MT; s.LH = S::LH; s.NFIRST = S::NFIRST;
@@ -55,6 +61,8 @@ SpecInfo make_info2(void (*launch)(const GroupArgs&, int, int, plat_stream), int
     SpecInfo s;
     s.has_sin = has_sin;
     s.jit = 0;
+    s.ngen = S::J::GEN ? S::C : 0;
+    for (int i = 0; i < MAX_GEN_CHANNELS; ++i) s.gen[i] = (S::J::GEN && i < S::C) ? S::J::gen_channel(i) : 0u;
     s.family = 2; s.WG_PER_CU = S::WG_PER_CU; s.NW = S::NW;
     s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR; s.HI = S::HI & 0xFFFFFFu; s.LAP = S::J::LAP;
     s.PG = S::PG; s.C = S::C; s.NG = S::NG; s.TP = S::TP; s.MT = S::MT; s.LH = S::LH; s.NFIRST = S::NFIRST;

@@ -25,7 +25,7 @@ NULLARY = {"CONST", "DATA"}
 @dataclass(frozen=True)
 class Slot:
     net: int
-    axes: Tuple[int, ...]        # () = value; (i,) = d/dx_i; (i, j) = d2/dx_i dx_j; (i,i,i), (i,i,i,i) pure 3rd/4th  (net-input axes, sorted)
+    axes: Tuple[int, ...]        # () = value; (i,) = d/dx_i; (i, j) = d2/dx_i dx_j; ... any multi-index up to order 6 (net-input axes, sorted)
 
     @property
     def order(self) -> int:

