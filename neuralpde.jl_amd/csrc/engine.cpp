@@ -831,7 +831,7 @@ int pinn_describe(pinn_handle h, char* buf, int64_t buflen) {
         const Term& T = h->terms[t];
         if (T.coupled >= 0) continue;
         os << "term " << t << ": tape ops=" << T.tape_ops.size() << " of " << T.ops.size() << ", sources=" << T.src_root.size()
-           << " (" << T.src_prog.size() << " coordinate-only ops evaluated per point set)\n";
+           << " (" << T.src_prog.size() << " coordinate-only ops evaluated per point set)" << (T.linear ? ", affine residual: no tape interpreter" : "") << "\n";
     }
     std::string s = os.str();
     std::snprintf(buf, (size_t)buflen, "%s", s.c_str());

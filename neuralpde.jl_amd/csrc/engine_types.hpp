@@ -46,8 +46,11 @@ struct Net {
         return m;
     }
 };
+struct LinearForm { float k = 0.f; float a[pk::LIN_MAX_C] = {}; float b[pk::LIN_MAX_SRC] = {}; };
 struct Term {
     int d = 0;
+    bool linear = false;             // the fused tape is affine in the jet channels / sources (plan.cpp: detect_linear)
+    LinearForm lin;
     std::vector<Slot> slots;
     std::vector<rp::Instr> ops;      // descriptor row numbering
     int out_row = 0;

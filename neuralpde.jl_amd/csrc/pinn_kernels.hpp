@@ -50,6 +50,7 @@ enum Mode : int { MODE_FUSED = 0, MODE_RESID = 1, MODE_FWD = 2, MODE_GRADIN = 3,
 constexpr int MAX_GROUP_TERMS = 12;
 constexpr int ND = 8;            // activation-derivative array: d[1] .. d[7] (jets up to order 6 need phi^(7) in the reverse sweep)
 constexpr int MAX_PARAMS = 4;
+constexpr int LIN_MAX_C = 8, LIN_MAX_SRC = 4;      // TermDev::linear covers up to 8 jet channels and 4 sources
 
 // ------------------------------------------------------------------------------------------------
 // The jet-channel set of a kernel: which derivatives of the trial function travel through the layers.
@@ -200,6 +201,13 @@ struct TermDev {
     // optional per-point factors s_i = sqrt(N w_i) (pinn_set_point_weights): the term's loss becomes sum_i w_i r_i^2 — a quadrature
     // rule — instead of the plain mean; nullptr: mean(abs2, r)
     const float* pw;
+    // residuals that are AFFINE in the jet channels and the hoisted sources with constant coefficients — every Dirichlet boundary term
+    // (u - g), the Poisson interior term (lap u - f), linear PDEs with fixed coefficients — skip the tape interpreter in the neuron-split
+    // kernels: r = lin_k + sum_c lin_a[c] U_c + sum_j lin_b[j] src_j, seeds dr/dU_c = lin_a[c]   (plan.cpp: detect_linear)
+    int linear;
+    float lin_k;
+    float lin_a[LIN_MAX_C];
+    float lin_b[LIN_MAX_SRC];
 };
 
 struct GroupArgs {

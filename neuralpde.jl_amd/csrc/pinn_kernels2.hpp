@@ -429,63 +429,88 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         PINN_UNROLL for (int i = 0; i < D; ++i) xin[i] = x[pg][i];
                         PINN_UNROLL for (int ch = 0; ch < C; ++ch) Uin[ch] = U[pg][ch];
                     }
-                const int NP = ga.nparams;
-                const int DT = T.dt;            // tape rows: [coordinates DT | params NP | jet channels C | sources | ops]
-                const int R0 = DT + NP + C + T.nsrc;
-                const rp::Instr* prog = ga.prog + T.prog_off;
-                vtape tv;
-                tape_zero(tv);
-                if (!T.hetero) {
-                    PINN_UNROLL for (int i = 0; i < D; ++i) tape_set(tv, i, xin[i]);
+                if (T.linear && C <= LIN_MAX_C) {
+                    // affine residual: no interpreter, no tape registers — a handful of FMAs and the seeds are the constant coefficients
+                    vfloat r = vfloat(T.lin_k);
+                    PINN_UNROLL for (int ch = 0; ch < C; ++ch) r = vfma(vfloat(T.lin_a[ch < LIN_MAX_C ? ch : 0]), Uin[ch], r);
+                    PINN_UNROLL for (int j = 0; j < LIN_MAX_SRC; ++j)
+                        if (j < T.nsrc) {
+                            vfloat sv;
+                            if (j < SRC_PRE) { PINN_UNROLL for (int jj = 0; jj < SRC_PRE; ++jj) if (jj == j) sv = srcv[jj]; }
+                            else sv = gload_masked(T.src, vint(j * T.N + pbase + 16 * w) + c, vin);
+                            r = vfma(vfloat(T.lin_b[j]), sv, r);
+                        }
+                    if (MODE == MODE_RESID) {
+                        vint p = vint(pbase + 16 * w) + c;
+                        gstore_masked(T.out, p, r, vand(vin, g0));
+                    } else {
+                        vfloat sw = vfloat(1.0f);
+                        if (T.pw) sw = gload_masked(T.pw, vint(pbase + 16 * w) + c, vin);
+                        vfloat rm = vselect(vin, r * sw, vfloat(0.f));
+                        lsum = vfma(rm, vselect(g0, rm, vfloat(0.f)), lsum);
+                        vfloat rbar = rm * vfloat(T.scale) * sw;
+                        PINN_UNROLL for (int ch = 0; ch < C; ++ch)
+                            lds_store(UB, vint((w * C + ch) * 16) + c, vselect(vin, rbar * vfloat(T.lin_a[ch < LIN_MAX_C ? ch : 0]), vfloat(0.f)));
+                    }
                 } else {
-                    for (int j = 0; j < DT; ++j) tape_set(tv, j, gload_masked(T.pts, (vint(pbase + 16 * w) + c) * DT + vint(j), vin));
-                }
-                for (int j = 0; j < NP; ++j) tape_set(tv, DT + j, vfloat(ga.params[j]));
-                PINN_UNROLL for (int ch = 0; ch < C; ++ch) tape_set(tv, DT + NP + ch, Uin[ch]);
-                for (int j = 0; j < T.nsrc; ++j) {
-                    vfloat sv;
-                    if (j < SRC_PRE) { PINN_UNROLL for (int jj = 0; jj < SRC_PRE; ++jj) if (jj == j) sv = srcv[jj]; }
-                    else sv = gload_masked(T.src, vint(j * T.N + pbase + 16 * w) + c, vin);
-                    tape_set(tv, DT + NP + C + j, sv);
-                }
-                for (int q = 0; q < T.nops; ++q) {
-                    const rp::Instr ins = rp::fetch_uniform(prog, q);
-                    const vfloat va = tape_get(tv, ins.a), vb = tape_get(tv, ins.b);      // unused operands point at row 0
-                    vfloat vo;
-                    if (rp::is_bilinear(ins.code)) vo = rp::apply_bilinear<vfloat>(ins, va, vb);
-                    else vo = rp::apply<vfloat>(ins.code, va, vb, ins.imm);
-                    tape_set(tv, R0 + q, vo);
-                }
-                vfloat r = tape_get(tv, T.out_row);
-                if (MODE == MODE_RESID) {
-                    vint p = vint(pbase + 16 * w) + c;
-                    gstore_masked(T.out, p, r, vand(vin, g0));
-                } else {
-                    vfloat sw = vfloat(1.0f);
-                    if (T.pw) sw = gload_masked(T.pw, vint(pbase + 16 * w) + c, vin);
-                    vfloat rm = vselect(vin, r * sw, vfloat(0.f));
-                    lsum = vfma(rm, vselect(g0, rm, vfloat(0.f)), lsum);   // this wave's share of the term's (weighted) sum of squares
-                    vfloat rbar = rm * vfloat(T.scale) * sw;
-                    vtape ta;
-                    tape_zero(ta);
-                    tape_set(ta, T.out_row, vfloat(1.0f));
-                    for (int q = T.nops - 1; q >= 0; --q) {
+                    const int NP = ga.nparams;
+                    const int DT = T.dt;            // tape rows: [coordinates DT | params NP | jet channels C | sources | ops]
+                    const int R0 = DT + NP + C + T.nsrc;
+                    const rp::Instr* prog = ga.prog + T.prog_off;
+                    vtape tv;
+                    tape_zero(tv);
+                    if (!T.hetero) {
+                        PINN_UNROLL for (int i = 0; i < D; ++i) tape_set(tv, i, xin[i]);
+                    } else {
+                        for (int j = 0; j < DT; ++j) tape_set(tv, j, gload_masked(T.pts, (vint(pbase + 16 * w) + c) * DT + vint(j), vin));
+                    }
+                    for (int j = 0; j < NP; ++j) tape_set(tv, DT + j, vfloat(ga.params[j]));
+                    PINN_UNROLL for (int ch = 0; ch < C; ++ch) tape_set(tv, DT + NP + ch, Uin[ch]);
+                    for (int j = 0; j < T.nsrc; ++j) {
+                        vfloat sv;
+                        if (j < SRC_PRE) { PINN_UNROLL for (int jj = 0; jj < SRC_PRE; ++jj) if (jj == j) sv = srcv[jj]; }
+                        else sv = gload_masked(T.src, vint(j * T.N + pbase + 16 * w) + c, vin);
+                        tape_set(tv, DT + NP + C + j, sv);
+                    }
+                    for (int q = 0; q < T.nops; ++q) {
                         const rp::Instr ins = rp::fetch_uniform(prog, q);
-                        const vfloat va = tape_get(tv, ins.a), vb = tape_get(tv, ins.b), gq = tape_get(ta, R0 + q);
-                        vfloat da, db;
-                        if (rp::is_bilinear(ins.code)) rp::adjoint_bilinear<vfloat>(ins, va, vb, gq, da, db);   // unused operands: zero adjoint into row 0
-                        else rp::adjoint<vfloat>(ins.code, va, vb, tape_get(tv, R0 + q), ins.imm, gq, da, db);
-                        tape_set(ta, ins.a, tape_get(ta, ins.a) + da);
-                        tape_set(ta, ins.b, tape_get(ta, ins.b) + db);
+                        const vfloat va = tape_get(tv, ins.a), vb = tape_get(tv, ins.b);      // unused operands point at row 0
+                        vfloat vo;
+                        if (rp::is_bilinear(ins.code)) vo = rp::apply_bilinear<vfloat>(ins, va, vb);
+                        else vo = rp::apply<vfloat>(ins.code, va, vb, ins.imm);
+                        tape_set(tv, R0 + q, vo);
                     }
-                    PINN_UNROLL for (int ch = 0; ch < C; ++ch)
-                        lds_store(UB, vint((w * C + ch) * 16) + c, vselect(vin, rbar * tape_get(ta, DT + NP + ch), vfloat(0.f)));   // 4 row groups: same value; masked points may hold inf/NaN
-                    for (int j = 0; j < ga.nparams_estim; ++j) {
-                        vfloat pj = vselect(vand(g0, vin), rbar * tape_get(ta, DT + j), vfloat(0.f));
-                        PINN_UNROLL for (int jj = 0; jj < MAX_PARAMS; ++jj) if (jj == j) pbar[jj] += pj;
+                    vfloat r = tape_get(tv, T.out_row);
+                    if (MODE == MODE_RESID) {
+                        vint p = vint(pbase + 16 * w) + c;
+                        gstore_masked(T.out, p, r, vand(vin, g0));
+                    } else {
+                        vfloat sw = vfloat(1.0f);
+                        if (T.pw) sw = gload_masked(T.pw, vint(pbase + 16 * w) + c, vin);
+                        vfloat rm = vselect(vin, r * sw, vfloat(0.f));
+                        lsum = vfma(rm, vselect(g0, rm, vfloat(0.f)), lsum);   // this wave's share of the term's (weighted) sum of squares
+                        vfloat rbar = rm * vfloat(T.scale) * sw;
+                        vtape ta;
+                        tape_zero(ta);
+                        tape_set(ta, T.out_row, vfloat(1.0f));
+                        for (int q = T.nops - 1; q >= 0; --q) {
+                            const rp::Instr ins = rp::fetch_uniform(prog, q);
+                            const vfloat va = tape_get(tv, ins.a), vb = tape_get(tv, ins.b), gq = tape_get(ta, R0 + q);
+                            vfloat da, db;
+                            if (rp::is_bilinear(ins.code)) rp::adjoint_bilinear<vfloat>(ins, va, vb, gq, da, db);   // unused operands: zero adjoint into row 0
+                            else rp::adjoint<vfloat>(ins.code, va, vb, tape_get(tv, R0 + q), ins.imm, gq, da, db);
+                            tape_set(ta, ins.a, tape_get(ta, ins.a) + da);
+                            tape_set(ta, ins.b, tape_get(ta, ins.b) + db);
+                        }
+                        PINN_UNROLL for (int ch = 0; ch < C; ++ch)
+                            lds_store(UB, vint((w * C + ch) * 16) + c, vselect(vin, rbar * tape_get(ta, DT + NP + ch), vfloat(0.f)));   // 4 row groups: same value; masked points may hold inf/NaN
+                        for (int j = 0; j < ga.nparams_estim; ++j) {
+                            vfloat pj = vselect(vand(g0, vin), rbar * tape_get(ta, DT + j), vfloat(0.f));
+                            PINN_UNROLL for (int jj = 0; jj < MAX_PARAMS; ++jj) if (jj == j) pbar[jj] += pj;
+                        }
                     }
                 }
-            }
+                }
             wave_prio(1);
             if (MODE != MODE_RESID) {
                 if (SPRE && NHH - 1 >= 1) load_record(NHH - 1);

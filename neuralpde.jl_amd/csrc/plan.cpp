@@ -482,6 +482,52 @@ static int plan_pack_maps(pinn_engine& E) {
     return 0;
 }
 
+// A fused-tape program (rows [coordinates dt | params np | jet channels C | sources nsrc | ops]) whose output is an AFFINE function of
+// the jet channels and sources with constant coefficients needs no interpreter: the kernel evaluates it with C + nsrc FMAs and seeds
+// the reverse sweep with the coefficients (TermDev::linear).  True for every Dirichlet term u - g(x), for lap u - f(x), for linear
+// PDEs with fixed coefficients.  Anything that touches a coordinate or parameter row directly, or multiplies two non-constant rows,
+// keeps the tape.  PINN_NO_LINEAR=1 disables the shortcut (A/B measurements).
+static bool detect_linear(const std::vector<rp::Instr>& prog, int dt, int np, int C, int nsrc, int out_row, LinearForm& L) {
+    static const bool off = std::getenv("PINN_NO_LINEAR") != nullptr;
+    if (off || C > pk::LIN_MAX_C || nsrc > pk::LIN_MAX_SRC) return false;
+    const int r0 = dt + np + C + nsrc, nb = C + nsrc;
+    struct Aff { bool ok; std::vector<double> c; double k; };
+    auto row_form = [&](int row, const std::vector<Aff>& ops) -> Aff {
+        Aff a{true, std::vector<double>((size_t)nb, 0.0), 0.0};
+        if (row < dt + np) { a.ok = false; return a; }                 // coordinates / parameters: not covered
+        if (row < r0) { a.c[(size_t)(row - dt - np)] = 1.0; return a; }
+        return ops[(size_t)(row - r0)];
+    };
+    std::vector<Aff> ops;
+    for (const rp::Instr& I : prog) {
+        Aff o{true, std::vector<double>((size_t)nb, 0.0), 0.0};
+        const Aff a = rp::is_nullary(I.code) ? o : row_form(I.a, ops);
+        const Aff b = rp::is_binary(I.code) ? row_form(I.b, ops) : o;
+        auto is_const = [&](const Aff& f) { if (!f.ok) return false; for (double v : f.c) if (v != 0.0) return false; return true; };
+        switch (I.code) {
+            case rp::OP_CONST: o.k = I.imm; break;
+            case rp::OP_ADD: o.ok = a.ok && b.ok; for (int i = 0; i < nb; ++i) o.c[i] = a.c[i] + b.c[i]; o.k = a.k + b.k; break;
+            case rp::OP_SUB: o.ok = a.ok && b.ok; for (int i = 0; i < nb; ++i) o.c[i] = a.c[i] - b.c[i]; o.k = a.k - b.k; break;
+            case rp::OP_NEG: o.ok = a.ok; for (int i = 0; i < nb; ++i) o.c[i] = -a.c[i]; o.k = -a.k; break;
+            case rp::OP_ADDC: o = a; o.k += I.imm; break;
+            case rp::OP_MULC: o.ok = a.ok; for (int i = 0; i < nb; ++i) o.c[i] = a.c[i] * I.imm; o.k = a.k * I.imm; break;
+            case rp::OP_MUL:
+                if (is_const(a) && b.ok) { o = b; for (double& v : o.c) v *= a.k; o.k *= a.k; }
+                else if (is_const(b) && a.ok) { o = a; for (double& v : o.c) v *= b.k; o.k *= b.k; }
+                else o.ok = false;
+                break;
+            default: o.ok = false;
+        }
+        ops.push_back(o);
+    }
+    const Aff f = row_form(out_row, ops);
+    if (!f.ok) return false;
+    L.k = (float)f.k;
+    for (int c = 0; c < pk::LIN_MAX_C; ++c) L.a[c] = c < C ? (float)f.c[(size_t)c] : 0.f;
+    for (int j = 0; j < pk::LIN_MAX_SRC; ++j) L.b[j] = j < nsrc ? (float)f.c[(size_t)(C + j)] : 0.f;
+    return true;
+}
+
 // per launch group: slabs, scratch, loss partials, programs, slab -> theta reduce rows, kernel arguments
 static int plan_group_buffers(pinn_engine& E) {
     // ---- per-group buffers and reduce maps ----
@@ -526,13 +572,17 @@ static int plan_group_buffers(pinn_engine& E) {
             };
             G.prog_off.push_back((int)prog.size());
             G.prog_n.push_back((int)T.tape_ops.size());
+            std::vector<rp::Instr> mine;
             for (int q : T.tape_ops) {
                 rp::Instr I = T.ops[q];
                 I.a = rp::is_nullary(I.code) ? 0 : remap(I.a);
                 I.b = rp::is_binary(I.code) ? remap(I.b) : 0;
                 rp::finalize(I);
                 prog.push_back(I);
+                mine.push_back(I);
             }
+            T.lin = LinearForm();
+            T.linear = s.family == 2 && detect_linear(mine, T.d, E.np, s.C, nsrc, remap(T.out_row), T.lin);
             if (nsrc > 0) {
                 T.d_src_prog = (rp::Instr*)plat_malloc(sizeof(rp::Instr) * T.src_prog.size());
                 if (!T.d_src_prog) return fail("device allocation failed (source programs)");
@@ -746,6 +796,10 @@ void retile(pinn_engine& E, int gi) {
         td.pw = (T.pw_n == T.n && T.pw_n > 0) ? T.d_pw : nullptr;
         td.src = (G.kind == 0) ? T.d_src : nullptr;
         td.nsrc = (G.kind == 0) ? (int)T.src_root.size() : 0;
+        td.linear = (G.kind == 0 && T.linear) ? 1 : 0;
+        td.lin_k = T.lin.k;
+        for (int c = 0; c < pk::LIN_MAX_C; ++c) td.lin_a[c] = T.lin.a[c];
+        for (int j = 0; j < pk::LIN_MAX_SRC; ++j) td.lin_b[j] = T.lin.b[j];
         {
             const std::vector<int>& m = T.inmap.at(G.net);
             td.dt = T.d;
