@@ -43,6 +43,17 @@
 #ifndef PINN_F2_OCC
 #define PINN_F2_OCC 2
 #endif
+// forward GEMM: B-fragment LDS reads issued this many MFMA groups ahead of their use (0: leave the order to the compiler)
+#ifndef PINN_F2_GEMM_AHEAD
+#define PINN_F2_GEMM_AHEAD 2
+#endif
+// asymmetric MFMA-phase issue priority between the two waves of a SIMD (vec.hpp: wave_prio_gemm)
+#ifndef PINN_F2_ASYM_PRIO
+#define PINN_F2_ASYM_PRIO 0
+#endif
+#ifndef PINN_F2_GEMM_SITES
+#define PINN_F2_GEMM_SITES 7            // bit mask: 1 forward GEMM, 2 dA GEMM, 4 dW GEMM
+#endif
 
 namespace pk {
 
@@ -195,6 +206,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
         for (int j = 0; j < ga.nterms; ++j) ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[j].term_id] = 0.0;
 
     wave_prio(1);
+    const bool gemm_hi = PINN_F2_ASYM_PRIO ? ((hw_wave_slot() & 1) == 0) : false;        // see wave_prio_gemm
     const int niter = (ga.ntiles + nblocks - 1) / nblocks;
     STAMP_DECL
     for (int it = 0; it < niter; ++it) {
@@ -307,7 +319,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         PINN_UNROLL for (int ch = 1; ch < C; ++ch) A[pg * C + ch][t] = vzero4();
                     }
                 }
-                wave_prio(0);
+                wave_prio_gemm(gemm_hi);
                 PINN_UNROLL for (int mi = 0; mi < MT; ++mi) {
                     if (!WPRE)
                         PINN_UNROLL for (int t = 0; t < MTW; ++t)
@@ -318,6 +330,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         PINN_UNROLL for (int t = 0; t < MTW; ++t)
                             PINN_UNROLL for (int rr = 0; rr < 4; ++rr) A[q][t] = mfma16(wf[WPRE ? mi : 0][t][rr], b4[q][rr], A[q][t]);
                 }
+                if (WPRE && PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 1)) sched_gemm_prefetch<MT * NG, MTW * 4, PINN_F2_GEMM_AHEAD>();
                 wave_prio(1);
                 STAMP(2)
                 act_forward(A, hl + 1);
@@ -642,7 +655,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                 wg_barrier();                                               // dZ of every wave is in X0; the previous layer's dW reads are done
                 STAMP(8)
                 if (SPRE && hl - 1 >= 1) load_record(hl - 1);
-                wave_prio(0);
+                wave_prio_gemm(gemm_hi);
                 PINN_UNROLL for (int q = 0; q < NG; ++q) {
                     PINN_UNROLL for (int mo = 0; mo < MT; ++mo) {
                         vfloat4 b4 = lds_load4(X0, vint(((q * MT + mo) * 64) * 4) + (lane << 2));
@@ -651,12 +664,15 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                     }
                     stage_q(q, ZT + q * (MTW * 256), X1 + q * 16 * HP);
                 }
+                if (PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 2)) sched_gemm_prefetch<MT * NG, MTW * 4, PINN_F2_GEMM_AHEAD>();
                 wave_prio(1);
                 STAMP(10)
                 wg_barrier();                                               // staged operands complete; X0 free again
                 STAMP(11)
-                wave_prio(0);
+                wave_prio_gemm(gemm_hi);
                 PINN_UNROLL for (int q = 0; q < NG; ++q) dw_q(ZT + q * (MTW * 256), X1 + q * 16 * HP);
+                if (PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 4) && MTW == 1 && MT == 4)
+                    sched_gemm_prefetch<4 * NG, 4, PINN_F2_GEMM_AHEAD, 2>();
                 wave_prio(1);
                 PINN_UNROLL for (int q = 0; q < NG; ++q)
                     PINN_UNROLL for (int t = 0; t < MTW; ++t) G[q][t] = Gn[q][t];

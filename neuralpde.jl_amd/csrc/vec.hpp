@@ -86,6 +86,9 @@ inline void tape_zero(vtape& t) { for (int i = 0; i < 32; ++i) t.r[i] = vfloat(0
 struct urec16 { int x, y, z, w; };
 inline void sched_fence() {}
 inline void wave_prio(int) {}
+template <int NGROUPS, int MFMA_PER, int AHEAD, int DS_PER = 1> inline void sched_gemm_prefetch() {}
+inline int hw_wave_slot() { return 0; }
+inline void wave_prio_gemm(bool) {}
 inline void vsincos(const vfloat& x, vfloat& s, vfloat& c) { for (int l = 0; l < W; ++l) { s.v[l] = std::sin(x.v[l]); c.v[l] = std::cos(x.v[l]); } }
 inline urec16 uload16(const void* p) { urec16 r; std::memcpy(&r, p, 16); return r; }
 struct urec32 { int v[8]; };
@@ -218,8 +221,26 @@ DEV void tape_zero(vtape& t) { PINN_UNROLL for (int i = 0; i < PINN_TAPE_ROWS; +
 // (which also drains every outstanding record store) and its fields need waterfall loops to be used as register indices.
 // the instruction scheduler may not move anything across this point (keeps a block of prefetch loads where it was written)
 DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// Instruction-order request for a GEMM region of NGROUPS x [1 LDS fragment read -> MFMA_PER MFMAs]: the reads run AHEAD groups in front of
+// the MFMAs that consume them, so a wave's MFMAs issue back to back instead of waiting one LDS round trip per group (left alone, the
+// compiler sinks every ds_read next to its first use to save registers: ds_read, s_waitcnt, 4 x v_mfma, ds_read, s_waitcnt, ...).
+template <int NGROUPS, int MFMA_PER, int AHEAD, int DS_PER = 1> DEV void sched_gemm_prefetch() {
+    __builtin_amdgcn_sched_group_barrier(0x100, AHEAD * DS_PER, 0);
+    PINN_UNROLL for (int i = 0; i < NGROUPS - AHEAD; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, MFMA_PER, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, DS_PER, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, MFMA_PER * AHEAD, 0);
+}
 // issue priority of this wave against the other wave resident on its SIMD (s_setprio): raised around MFMA clusters
 template <int P> DEV void wave_prio_t() { __builtin_amdgcn_s_setprio(P); }
+// slot of this wave on its SIMD (HW_REG_HW_ID bits 3:0): distinguishes the two workgroups resident on a CU
+DEV int hw_wave_slot() { return (int)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 15u); }
+// issue priority inside the MFMA clusters: ASYMMETRIC between the two waves of a SIMD.  With equal priorities two workgroups that
+// enter their GEMM phases together share the matrix pipe half-half, leave them together and then sit in their non-MFMA phases
+// together (pipe idle): a convoy.  When one of them wins the pipe outright it finishes its GEMM early and runs its element-wise /
+// barrier phases while the other one has the pipe to itself: the phases fall into anti-phase.
+DEV void wave_prio_gemm(bool hi) { if (hi) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
 #define wave_prio(P) wave_prio_t<P>()
 struct urec16 { int x, y, z, w; };
 DEV urec16 uload16(const void* p) {
