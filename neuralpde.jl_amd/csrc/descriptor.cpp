@@ -46,10 +46,17 @@ int parse_descriptor(const char* text, pinn_engine& E) {
         // one activation for all hidden layers, or a comma-separated list with one entry per hidden layer: tanh and sigmoid may be mixed
         // (e.g. the reference's Dense(1, n, tanh), Dense(n, n, sigma), Dense(n, 1)); sin only on all layers
         std::vector<int> kinds;
+        bool dgm = false;
         {
             std::stringstream as(act);
             std::string tok;
             while (std::getline(as, tok, ',')) {
+                if (tok == "dgm" && kinds.empty() && !dgm) { dgm = true; continue; }      // dgm,<activation1>,<activation2>,<layers>
+                if (dgm && kinds.size() == 2) {
+                    E.nets[i].dgm_layers = std::atoi(tok.c_str());
+                    if (E.nets[i].dgm_layers < 1 || E.nets[i].dgm_layers > 8) return fail("descriptor: a DGM network has 1..8 gated layers");
+                    continue;
+                }
                 if (tok == "tanh") kinds.push_back(pk::ACT_TANH);
                 else if (tok == "sigmoid") kinds.push_back(pk::ACT_SIGMOID);
                 else if (tok == "sin") kinds.push_back(pk::ACT_SIN);
@@ -66,6 +73,17 @@ int parse_descriptor(const char* text, pinn_engine& E) {
             ctx.depvar_inputs[i].resize(nin);
             for (int j = 0; j < nin; ++j)
                 if (!(in >> ctx.depvar_inputs[i][j])) return fail("descriptor: netvar input names");
+        }
+        if (dgm) {
+            // the reference's DGM(in_dims, 1, modes, layers, activation1, activation2, identity) (src/dgm.jl:97-115): sizes = d modes 1
+            if (kinds.size() != 2 || E.nets[i].dgm_layers < 1 || ns != 3 || E.nets[i].sizes[2] != 1)
+                return fail("descriptor: a DGM net line reads `net <i> dgm,<activation1>,<activation2>,<layers> <theta_off> 3 <d> <modes> 1`");
+            if (E.nets[i].sizes[1] > 64) return fail("descriptor: DGM networks are supported up to 64 modes");
+            E.nets[i].kind = 1;
+            E.nets[i].act = kinds[0];
+            E.nets[i].act2 = kinds[1];
+            E.nets[i].act_layers = 0;
+            continue;
         }
         if (ns < 3) return fail("descriptor: a chain needs at least one hidden layer");
         if (E.nets[i].sizes.back() != 1) return fail("descriptor: only single-output chains (one per dependent variable) are supported, as in the reference (pinn_types.jl:106-108)");

@@ -60,7 +60,7 @@ void pack_all(pinn_engine& E, const float* d_theta = nullptr) {
     const float* th = d_theta ? d_theta : E.d_theta;
     for (size_t n = 0; n < E.nets.size(); ++n) {
         NetPlan& NP = E.netplans[n];
-        if (!NP.spec) continue;
+        if (!NP.spec || NP.spec->family == 3) continue;          // DGM kernels read theta unpacked
         aux::launch_pack(NP.d_packed, NP.d_pack_idx, th, NP.npacked, E.stream);
     }
     aux::launch_params(E.d_params, th, E.d_defaults, E.np, E.ne, E.p_theta_off, E.stream);
@@ -151,7 +151,8 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
         G.ga.slabs = chained ? E.groups[G.chain_to].d_slabs : G.d_slabs;
         G.ga.chain = chained ? 1 : 0;
         a1.tmp[g] = G.d_tmp; a1.slabs[g] = G.d_slabs; a1.losspart[g] = G.d_losspart;
-        a1.slab[g] = G.spec->SLAB; a1.nblocks[g] = G.blocks; a1.nsplit[g] = nsplit; a1.nent[g] = nent; a1.active[g] = any; a1.nwpb[g] = G.spec->NW;
+        if (G.spec->family == 3) G.ga.packed = d_theta + E.nets[G.net].theta_off;      // DGM: weights straight from theta
+        a1.slab[g] = G.slab_floats; a1.nblocks[g] = G.blocks; a1.nsplit[g] = nsplit; a1.nent[g] = nent; a1.active[g] = any; a1.nwpb[g] = G.spec->NW;
         a2.tmp[g] = G.d_tmp; a2.stride[g] = nent + K; a2.nsplit[g] = nsplit; a2.nent[g] = nent; a2.active[g] = any;
         a2.ent_active[g] = any && !chained;
         if (!any) continue;
@@ -292,7 +293,7 @@ int pinn_destroy(pinn_handle h) {
     }
     for (auto& N : E.netplans) { plat_free(N.d_packed); plat_free(N.d_pack_idx); }
     plat_free(E.d_theta); plat_free(E.d_params); plat_free(E.d_defaults); plat_free(E.d_lossraw); plat_free(E.d_gr_ptr); plat_free(E.d_gr_grp); plat_free(E.d_gr_ent);
-    plat_free(E.d_out); plat_free(E.d_phi_pts); plat_free(E.d_phi_out);
+    plat_free(E.d_out); plat_free(E.d_phi_pts); plat_free(E.d_phi_out); plat_free(E.d_phi_scr);
     plat_host_free(E.hp_theta);
     plat_event_destroy(E.ev0); plat_event_destroy(E.ev1); plat_event_destroy(E.ev2); plat_event_destroy(E.ev3);
     plat_event_destroy(E.ev_fork);
@@ -495,6 +496,7 @@ int pinn_residual(pinn_handle h, int term, const float* theta, int64_t p, float*
     }
     Group& G = E.groups[T.group];
     pk::GroupArgs ga = G.ga;
+    if (G.spec->family == 3) ga.packed = E.d_theta + E.nets[G.net].theta_off;      // DGM: weights straight from theta
     ga.nterms = 1;
     ga.terms[0] = G.ga.terms[T.slot_in_group];
     ga.terms[0].tile0 = 0;
@@ -541,7 +543,22 @@ static int forward_jets(pinn_engine& E, int net, const pk::SpecInfo* sp, const f
     ga.terms[0].ntiles = (int)((n + sp->TP - 1) / sp->TP);
     ga.terms[0].out = E.d_phi_out;
     ga.ntiles = ga.terms[0].ntiles;
-    const int blocks = std::max(1, std::min(E.ncu * sp->WG_PER_CU, sp->family == 2 ? ga.ntiles : (ga.ntiles + 3) / 4));
+    if (sp->family == 3) {               // DGM: unpacked weights + point-major scratch rows for these points
+        const size_t need = (size_t)sp->dgm_rows * (size_t)ga.ntiles * 64;
+        if (need > E.phi_scr_cap) {
+            plat_sync(E.stream);
+            plat_free(E.d_phi_scr);
+            E.d_phi_scr = (float*)plat_malloc(sizeof(float) * need);
+            E.phi_scr_cap = E.d_phi_scr ? need : 0;
+            if (!E.d_phi_scr) return fail("device allocation failed (phi scratch)");
+        }
+        ga.packed = E.d_theta + N.theta_off;
+        ga.scratch = E.d_phi_scr;
+        ga.dgm_modes = N.sizes[1];
+        ga.dgm_npad = ga.ntiles * 64;
+        ga.dgm_nparams = N.nparams();
+    }
+    const int blocks = std::max(1, std::min(E.ncu * sp->WG_PER_CU, sp->family == 1 ? (ga.ntiles + 3) / 4 : ga.ntiles));
     sp->launch(ga, pk::MODE_FWD, blocks, E.stream);
     return 0;
 }

@@ -34,8 +34,12 @@ struct Net {
     int act;                         // ACT_TANH / ACT_SIGMOID / ACT_SIN on every hidden layer, or ACT_MIXED with
     int act_layers = 0;              //   the kind of hidden layer l (tanh / sigmoid) in bits 4l .. 4l+3
     int theta_off;
-    std::vector<int> sizes;          // n0 .. nL (nL == 1)
+    std::vector<int> sizes;          // n0 .. nL (nL == 1); DGM: {d, modes, 1}
+    int kind = 0;                    // 0: Chain of Dense layers; 1: the reference's DGM architecture (src/dgm.jl:97-115)
+    int dgm_layers = 0;              // DGM: number of gated (LSTM-type) layers
+    int act2 = 0;                    // DGM: activation of the H gate (activation2); `act` is activation1
     int nparams() const {
+        if (kind == 1) { const int d = sizes[0], M = sizes[1]; return M * d + M + dgm_layers * (4 * M * d + 4 * M * M + 4 * M) + M + 1; }
         int n = 0;
         for (size_t i = 0; i + 1 < sizes.size(); ++i) n += sizes[i + 1] * sizes[i] + sizes[i + 1];
         return n;
@@ -101,12 +105,14 @@ struct Group {
     float* d_slabs = nullptr;
     double* d_losspart = nullptr;
     float* d_scratch = nullptr;
+    size_t scratch_cap = 0;          // family 3: floats allocated (rows x padded points; grows with the point sets)
     float* d_rec = nullptr;          // kind 1, family 2: per-tile records of the forward launch, read back by the reverse launch
     size_t rec_slots = 0;            // (instead of running the forward pass twice; falls back to recomputation above REC_BUDGET)
     bool use_rec = false;
     double* d_tmp = nullptr;         // stage-1 partial sums [nsplit][nent + K]
     std::vector<int> row_theta, row_ptr, row_off;   // host CSR: theta element -> slab offsets of this group
     int nent = 0;
+    int slab_floats = 0;             // floats per block of d_slabs
     int blocks = 0;
     int max_blocks = 0;
     bool active = false;
@@ -188,6 +194,8 @@ struct pinn_engine {
     // phi scratch
     float* d_phi_pts = nullptr;
     float* d_phi_out = nullptr;
+    float* d_phi_scr = nullptr;      // family 3: scratch rows of a pinn_phi / pinn_derivative call
+    size_t phi_scr_cap = 0;
     int64_t phi_cap = 0;
     int phi_chan = 0;                // jet channels d_phi_out holds per point
 };
@@ -230,6 +238,7 @@ int jit_spec(int HP, int NHH, int D, unsigned D1MASK, unsigned long long PAIRS, 
 // multi-indices (nibble 0 = order, nibbles 1.. = sorted axes) and the kernel generated for it
 std::vector<unsigned> gen_close(const std::vector<unsigned>& want);
 int jit_spec_gen(int HP, int NHH, int D, const std::vector<unsigned>& channels, int variant);
+int jit_spec_dgm(int MP, int L, int D, unsigned D1MASK, unsigned long long PAIRS, int NPAIR, unsigned HI, const std::vector<unsigned>* gen_channels, int act1, int act2);
 // plan.cpp: process-wide table of requested general sets; a request travels through the (first, pairs, hi) needs as hi = GEN_FLAG | id
 constexpr unsigned GEN_FLAG = 0x80000000u;
 int gen_set_id(const std::vector<unsigned>& want);             // id of the (closed) set containing `want`

@@ -74,7 +74,7 @@ int jit_round_hp(int h) {
 // Compile (or load from the cache) the kernel family member with the given compile-time parameters and add it to the registry.
 // variant: 0 tanh / sigmoid, 1 + sin, 2 + per-layer tanh / sigmoid (family 1 only).
 static int jit_build(int HP, int NHH, int D, unsigned D1MASK, unsigned long long PAIRS, int NPAIR, unsigned HI, int variant, int C,
-                     const std::string& preamble, const std::string& keytail);
+                     const std::string& preamble, const std::string& keytail, const std::string& instantiate = "");
 
 int jit_spec(int HP, int NHH, int D, unsigned D1MASK, unsigned long long PAIRS, int NPAIR, unsigned HI, int variant) {
     int C = 1 + NPAIR + ((HI >> 24) ? 1 : 0);
@@ -83,10 +83,10 @@ int jit_spec(int HP, int NHH, int D, unsigned D1MASK, unsigned long long PAIRS, 
 }
 
 static int jit_build(int HP, int NHH, int D, unsigned D1MASK, unsigned long long PAIRS, int NPAIR, unsigned HI, int variant, int C,
-                     const std::string& preamble, const std::string& keytail) {
+                     const std::string& preamble, const std::string& keytail, const std::string& instantiate) {
     static const bool off = std::getenv("PINN_NO_JIT") != nullptr;
     if (off) return fail("runtime specialisation is disabled (PINN_NO_JIT)");
-    const int family = HP >= 64 ? 2 : 1;
+    const int family = !instantiate.empty() ? 3 : (HP >= 64 ? 2 : 1);
     if (family == 2 && variant == 2) return fail("per-layer tanh/sigmoid chains are compiled for nets up to 32 wide (one-wave-per-tile kernels) only");
     if (family == 2 && NHH < 1) return fail("the neuron-split kernels need at least two hidden layers");
     // point groups per tile: about 4-5 column groups of 16 (jet channels x point groups), as in the ahead-of-time table
@@ -121,10 +121,11 @@ static int jit_build(int HP, int NHH, int D, unsigned D1MASK, unsigned long long
             f << "// generated by jit.cpp: " << key << "\n#include \"spec_registry.hpp\"\n"
               << "#ifdef PINN_EMU\nnamespace wv { thread_local void (*emu_barrier_hook)(void*) = nullptr; thread_local void* emu_barrier_ctx = nullptr; }\n#endif\n"
               << "namespace pk { std::deque<SpecInfo>& registry() { static std::deque<SpecInfo> r; return r; } }\n"
-              << preamble
-              << macro << "(jit, " << HP << ", " << NHH << ", " << D << ", 0x" << std::hex << D1MASK << "u, 0x" << PAIRS << "ull, " << std::dec << NPAIR
-              << ", " << PG << ", 0x" << std::hex << HI << std::dec << "u)\n"
-              << "extern \"C\" __attribute__((visibility(\"default\"))) const pk::SpecInfo* pinn_jit_specs(int* n) { static std::vector<pk::SpecInfo> v(pk::registry().begin(), pk::registry().end()); *n = (int)v.size(); return v.data(); }\n";
+              << preamble;
+            if (!instantiate.empty()) f << instantiate;
+            else f << macro << "(jit, " << HP << ", " << NHH << ", " << D << ", 0x" << std::hex << D1MASK << "u, 0x" << PAIRS << "ull, " << std::dec << NPAIR
+              << ", " << PG << ", 0x" << std::hex << HI << std::dec << "u)\n";
+            f << "extern \"C\" __attribute__((visibility(\"default\"))) const pk::SpecInfo* pinn_jit_specs(int* n) { static std::vector<pk::SpecInfo> v(pk::registry().begin(), pk::registry().end()); *n = (int)v.size(); return v.data(); }\n";
         }
 #ifdef PINN_EMU
         const char* cxx = std::getenv("CXX") ? std::getenv("CXX") : "g++";
@@ -244,7 +245,8 @@ std::string prod(const char* arr, const std::vector<int>& chs, int skip_one = -1
 }
 }  // namespace
 
-int jit_spec_gen(int HP, int NHH, int D, const std::vector<unsigned>& channels, int variant) {
+// the generated JetSet specialisation for a closed channel list; outputs its template arguments and a cache-key suffix
+static int gen_preamble(int D, const std::vector<unsigned>& channels, std::string& text, unsigned& d1mask_out, unsigned& HI_out, std::string& keytail_out) {
     const int C = (int)channels.size();
     if (C > pk::MAX_GEN_CHANNELS) return fail("derivative set needs " + std::to_string(C) + " jet channels (limit " + std::to_string(pk::MAX_GEN_CHANNELS) + ")");
     std::map<MI, int> chan;
@@ -282,7 +284,7 @@ int jit_spec_gen(int HP, int NHH, int D, const std::vector<unsigned>& channels, 
       << "    static constexpr int pair_a(int) { return -1; }\n    static constexpr int pair_b(int) { return -1; }\n    static constexpr int pair_index(int, int) { return -1; }\n"
       << "    static constexpr unsigned gen_channel(int i) { constexpr unsigned t[] = {";
     for (int c = 0; c < C; ++c) o << "0x" << std::hex << channels[c] << std::dec << "u, ";
-    o << "0u}; return t[i]; }\n};\nusing JG = " << jt << ";\n";
+    o << "0u}; return t[i]; }\n    static constexpr unsigned channel_mi(int i) { return gen_channel(i); }\n};\nusing JG = " << jt << ";\n";
     // forward rule
     std::vector<std::vector<Mono>> mons(C);
     for (int c = 1; c < C; ++c) mons[c] = monomials(mi_decode(channels[c]), chan);
@@ -313,7 +315,34 @@ int jit_spec_gen(int HP, int NHH, int D, const std::vector<unsigned>& channels, 
     o << "    g[0] = zv;\n";
     for (int b = 1; b < C; ++b) o << "    g[" << b << "] = n" << b << ";\n";
     o << "}\n}  // namespace pk\n";
-    return jit_build(HP, NHH, D, d1mask, 0ull, 0, HI, variant, C, o.str(), keytail);
+    text = o.str();
+    d1mask_out = d1mask;
+    HI_out = HI;
+    keytail_out = keytail;
+    return 0;
 }
+
+int jit_spec_gen(int HP, int NHH, int D, const std::vector<unsigned>& channels, int variant) {
+    std::string text, keytail;
+    unsigned d1mask = 0, HI = 0;
+    if (gen_preamble(D, channels, text, d1mask, HI, keytail)) return 1;
+    return jit_build(HP, NHH, D, d1mask, 0ull, 0, HI, variant, (int)channels.size(), text, keytail);
+}
+
+// DGM network (family 3, pinn_kernels3.hpp): always specialised at run time
+int jit_spec_dgm(int MP, int L, int D, unsigned D1MASK, unsigned long long PAIRS, int NPAIR, unsigned HI, const std::vector<unsigned>* gen_channels,
+                 int act1, int act2) {
+    std::string text, keytail;
+    if (gen_channels) {
+        if (gen_preamble(D, *gen_channels, text, D1MASK, HI, keytail)) return 1;
+        PAIRS = 0ull; NPAIR = 0;
+    }
+    char tail[64];
+    std::snprintf(tail, sizeof tail, "%s_dgm_a%d_%d", keytail.c_str(), act1, act2);
+    char line[256];
+    std::snprintf(line, sizeof line, "PINN_INSTANTIATE_DGM(jit, %d, %d, %d, 0x%xu, 0x%llxull, %d, 0x%xu, %d, %d)\n", MP, L, D, D1MASK, PAIRS, NPAIR, HI, act1, act2);
+    return jit_build(MP, L, D, D1MASK, PAIRS, NPAIR, HI, 0, 0, text, tail, line);
+}
+
 
 }  // namespace pe

@@ -116,6 +116,16 @@ struct JetSet {
     // run time (jit.cpp: bit 31 of HI + a set id); gen_channel(i) = the multi-index of channel i, 0 for the fixed categories above
     static constexpr bool GEN = false;
     static constexpr unsigned gen_channel(int) { return 0u; }
+    // multi-index of channel ch (nibble 0 = order, nibbles 1.. = sorted axes); the Laplacian channel is a sum, not a multi-index
+    static constexpr unsigned channel_mi(int ch) {
+        if (ch == 0) return 0u;
+        if (ch < CH_PAIR) return 1u | ((unsigned)first_axis(ch - CH_FIRST) << 4);
+        if (ch < CH_LAP) return 2u | ((unsigned)pair_a(ch - CH_PAIR) << 4) | ((unsigned)pair_b(ch - CH_PAIR) << 8);
+        if (ch < CH_3) return 0xFFFFFFFFu;
+        if (ch < CH_4) { const unsigned ax = (unsigned)hi_axis(3, ch - CH_3); return 3u | (ax << 4) | (ax << 8) | (ax << 12); }
+        const unsigned ax = (unsigned)hi_axis(4, ch - CH_4);
+        return 4u | (ax << 4) | (ax << 8) | (ax << 12) | (ax << 16);
+    }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -225,6 +235,12 @@ struct GroupArgs {
     int nparams_estim;           // first NE params get adjoints
     int act;                     // ACT_TANH / ACT_SIGMOID / ACT_SIN for all hidden layers, or ACT_MIXED:
     int act_layers;              //   kind of hidden layer l (tanh / sigmoid) in bits 4l .. 4l+3
+    // family 3 (DGM, pinn_kernels3.hpp): `packed` points at the network's parameters inside theta (unpacked), `scratch` at the
+    // point-major scratch rows [Spec3::ROWS][dgm_npad]
+    int dgm_modes;               // real number of modes M (<= the padded MP of the kernel)
+    int dgm_npad;                // points per scratch row (tiles x 64)
+    int dgm_slab;                // floats per block of the gradient slab
+    int dgm_nparams;             // parameters of the network (slab entries [0, nparams) = theta order; then MAX_PARAMS PDE-parameter sums)
     int chain;                   // family 2: add this launch's gradient onto the slab contents an earlier launch group of the same
                                  // network left behind (one slab set and one reduction input for several launch groups)
     TermDev terms[MAX_GROUP_TERMS];

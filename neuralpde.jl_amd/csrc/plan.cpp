@@ -12,7 +12,62 @@ int round_hp(int h) {
     return jit_round_hp(h);          // wider nets: multiples of 64, kernels specialised at run time (jit.cpp)
 }
 
+// DGM networks (family 3): one specialised kernel per (padded modes, layers, inputs, channel set, activations)
+static const pk::SpecInfo* find_spec_dgm(int MP, int L, int D, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs, unsigned need_hi,
+                                         int act1, int act2) {
+    const pk::SpecInfo* best = nullptr;
+    for (const pk::SpecInfo& s : pk::registry()) {
+        if (s.family != 3 || s.HP != MP || s.NHH != L || s.D != D || s.act1 != act1 || s.act2 != act2) continue;
+        bool ok = true;
+        if (need_hi & GEN_FLAG) {
+            if (s.ngen <= 0) continue;
+            for (unsigned m : gen_set((int)(need_hi & ~GEN_FLAG))) {
+                bool f = false;
+                for (int c = 0; c < s.ngen; ++c) f = f || s.gen[c] == m;
+                ok = ok && f;
+            }
+        } else {
+            if (s.ngen > 0 || (s.D1MASK & need_first) != need_first) continue;
+            for (int a = 0; a < 6; ++a)
+                if (((need_hi >> (4 * a)) & 0xF) > ((s.HI >> (4 * a)) & 0xF)) ok = false;
+            for (auto& pr : need_pairs) {
+                bool f = false;
+                for (int p = 0; p < s.NPAIR; ++p)
+                    f = f || ((int)((s.PAIRS >> (8 * p)) & 0xF) == pr.first && (int)((s.PAIRS >> (8 * p + 4)) & 0xF) == pr.second);
+                ok = ok && f;
+            }
+        }
+        if (ok && (!best || s.C < best->C)) best = &s;
+    }
+    return best;
+}
+static const pk::SpecInfo* ensure_spec_dgm(const Net& N, unsigned need_first, std::vector<std::pair<int, int>> need_pairs, unsigned need_hi) {
+    const int M = N.sizes[1], MP = M <= 16 ? 16 : (M <= 32 ? 32 : 64), L = N.dgm_layers, D = N.sizes[0];
+    if ((need_hi >> 24) && !(need_hi & GEN_FLAG)) { fail("DGM networks carry no forward-Laplacian channel (internal)"); return nullptr; }
+    const pk::SpecInfo* sp = find_spec_dgm(MP, L, D, need_first, need_pairs, need_hi, N.act, N.act2);
+    int cneed = 1 + (int)need_pairs.size();
+    for (int a = 0; a < 8; ++a) cneed += ((need_first >> a) & 1) + (a < 6 && ((need_hi >> (4 * a)) & 0xF) >= 3) + (a < 6 && ((need_hi >> (4 * a)) & 0xF) >= 4);
+    if (need_hi & GEN_FLAG) cneed = (int)gen_set((int)(need_hi & ~GEN_FLAG)).size();
+    if (sp && sp->C <= cneed) return sp;              // one kernel per channel set: a boundary term does not ride on the interior term's kernel
+    if (need_hi & GEN_FLAG) {
+        if (jit_spec_dgm(MP, L, D, 0, 0ull, 0, 0, &gen_set((int)(need_hi & ~GEN_FLAG)), N.act, N.act2)) return sp;
+    } else {
+        for (int a = 0; a < 6; ++a)
+            if (((need_hi >> (4 * a)) & 0xF) >= 3 && std::find(need_pairs.begin(), need_pairs.end(), std::make_pair(a, a)) == need_pairs.end()) need_pairs.push_back({a, a});
+        std::sort(need_pairs.begin(), need_pairs.end());
+        unsigned long long PAIRS = 0;
+        unsigned first = need_first;
+        for (size_t p = 0; p < need_pairs.size(); ++p) {
+            PAIRS |= ((unsigned long long)(need_pairs[p].first | (need_pairs[p].second << 4))) << (8 * p);
+            first |= (1u << need_pairs[p].first) | (1u << need_pairs[p].second);
+        }
+        if (jit_spec_dgm(MP, L, D, first, PAIRS, (int)need_pairs.size(), need_hi, nullptr, N.act, N.act2)) return sp;     // (sp: a wider kernel, if any, still serves)
+    }
+    return find_spec_dgm(MP, L, D, need_first, need_pairs, need_hi, N.act, N.act2);
+}
+
 const pk::SpecInfo* ensure_spec(const Net& N, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs, unsigned need_hi, int need_family) {
+    if (N.kind == 1) return ensure_spec_dgm(N, need_first, need_pairs, need_hi);
     const int HP = round_hp(N.maxhidden()), NHH = (int)N.sizes.size() - 3, D = N.sizes[0], variant = variant_of(N.act);
     if (need_hi & GEN_FLAG) {                    // general multi-index channel set: always generated (jit.cpp: jit_spec_gen)
         const pk::SpecInfo* g = find_spec(HP, NHH, D, 0, {}, need_hi, nullptr, variant, need_family);
@@ -263,6 +318,7 @@ static int plan_assign_terms(pinn_engine& E) {
     };
     bool any_general = false;
     for (auto& T : E.terms) for (auto& sl : T.slots) any_general = any_general || slot_is_general(sl);
+    for (auto& N : E.nets) any_general = any_general || N.kind == 1;        // DGM kernels carry multi-index channels only
     if (!no_lap && !any_general) {
         std::vector<Term> fused(E.terms.size());
         std::vector<char> did(E.terms.size(), 0);
@@ -384,6 +440,10 @@ static int plan_assign_terms(pinn_engine& E) {
             continue;
         }
         // ---- coupled term ----
+        for (int net : term_nets[t])
+            if (E.nets[net].kind == 1)
+                return fail("term " + std::to_string(t) + ": DGM networks are supported in single-network equations (one dependent variable per equation, "
+                            "residual within the fused tape)");
         if ((int)T.slots.size() > aux::EXPR_MAX_SLOTS || T.d + E.np + (int)T.slots.size() + (int)T.ops.size() > aux::EXPR_MAX_ROWS)
             return fail("term " + std::to_string(t) + ": coupled residual expression too long");
         E.coupled.emplace_back();
@@ -427,6 +487,7 @@ static int plan_pack_maps(pinn_engine& E) {
     for (size_t n = 0; n < E.nets.size(); ++n) {
         NetPlan& NP = E.netplans[n];
         if (!NP.spec) continue;   // net unused by any term
+        if (NP.spec->family == 3) continue;          // DGM kernels read theta directly
         const pk::SpecInfo& s = *NP.spec;
         const Net& N = E.nets[n];
         const int LH = s.LH, HP = s.HP, MT = s.MT, D = s.D;
@@ -543,9 +604,12 @@ static int plan_group_buffers(pinn_engine& E) {
         plat_event_create(G.ev_a);
         plat_event_create(G.ev_b);
         const size_t nw = (size_t)G.max_blocks * s.NW;
-        G.d_slabs = (float*)plat_malloc(sizeof(float) * (size_t)G.max_blocks * s.SLAB);
+        const int slab_floats = s.family == 3 ? ((N.nparams() + pk::MAX_PARAMS + 63) / 64) * 64 : s.SLAB;
+        G.slab_floats = slab_floats;
+        G.d_slabs = (float*)plat_malloc(sizeof(float) * (size_t)G.max_blocks * slab_floats);
         G.d_losspart = (double*)plat_malloc(sizeof(double) * nw * total_terms);
-        G.d_scratch = (float*)plat_malloc(sizeof(float) * (s.family == 2 ? (size_t)G.max_blocks : nw) * s.SCR);
+        // family 3: the scratch rows are sized by the point sets (retile)
+        G.d_scratch = s.family == 3 ? (float*)plat_malloc(4) : (float*)plat_malloc(sizeof(float) * (s.family == 2 ? (size_t)G.max_blocks : nw) * s.SCR);
         if (!G.d_slabs || !G.d_losspart || !G.d_scratch) return fail("device allocation failed (group buffers)");
         // columns of terms this group does not own are never written by its kernel but are summed by the reduction
         plat_memset(G.d_losspart, 0, sizeof(double) * nw * total_terms, E.stream);
@@ -611,6 +675,10 @@ static int plan_group_buffers(pinn_engine& E) {
             loff[j] = o;
             o += N.sizes[j + 1] * N.sizes[j] + N.sizes[j + 1];
         }
+        if (s.family == 3) {                                    // slab = the network's parameters in theta order, then the PDE-parameter sums
+            for (int e = 0; e < N.nparams(); ++e) add_row(N.theta_off + e, e, true);
+            for (int j = 0; j < E.ne; ++j) add_row(E.p_theta_off + j, N.nparams() + j, true);
+        }
         if (s.family == 2) {                                    // every slab entry has exactly one writer wave
             for (int in = 0; in < D; ++in)
                 for (int out = 0; out < N.sizes[1]; ++out) add_row(loff[0] + out + in * N.sizes[1], s.O_W1 + in * s.HP + out, true);
@@ -652,7 +720,7 @@ static int plan_group_buffers(pinn_engine& E) {
             add_row(loff[LH] + N.sizes[LH], s.O_BL, false);
             for (int j = 0; j < E.ne; ++j) add_row(E.p_theta_off + j, s.O_P + j, false);
         }
-        G.nent = s.SLAB;                 // stage 1 is dense over slab offsets
+        G.nent = slab_floats;            // stage 1 is dense over slab offsets
         G.row_theta = row_theta;
         G.row_ptr = row_ptr;
         G.row_off = ent;                 // slab offsets of the contributions
@@ -673,6 +741,11 @@ static int plan_group_buffers(pinn_engine& E) {
         ga.nparams_estim = E.ne;
         ga.act = N.act;
         ga.act_layers = N.act_layers;
+        if (s.family == 3) {
+            ga.dgm_modes = N.sizes[1];
+            ga.dgm_slab = slab_floats;
+            ga.dgm_nparams = N.nparams();
+        }
     }
     return 0;
 }
@@ -817,7 +890,18 @@ void retile(pinn_engine& E, int gi) {
         tile += td.ntiles;
     }
     G.ga.ntiles = tile;
-    G.blocks = std::max(1, std::min(G.max_blocks, s.family == 2 ? tile : (tile + 3) / 4));
+    G.blocks = std::max(1, std::min(G.max_blocks, s.family == 1 ? (tile + 3) / 4 : tile));
+    if (s.family == 3) {                 // point-major scratch rows [ROWS][tiles x 64]
+        const size_t need = (size_t)s.dgm_rows * (size_t)tile * 64;
+        if (need > G.scratch_cap) {
+            plat_sync(E.stream);
+            plat_free(G.d_scratch);
+            G.d_scratch = (float*)plat_malloc(sizeof(float) * need);
+            G.scratch_cap = G.d_scratch ? need : 0;
+        }
+        G.ga.scratch = G.d_scratch;
+        G.ga.dgm_npad = tile * 64;
+    }
     // coupled groups: keep the forward launch's records in HBM when they fit the budget (default 96 GB per handle, PINN_REC_GB)
     G.use_rec = false;
     if (G.kind == 1 && s.family == 2 && s.REC > 0) {

@@ -1,6 +1,7 @@
 // spec_registry.hpp — table of compiled kernel-family members (one per translation unit inst_*.hip).
 #pragma once
 #include <condition_variable>
+#include <cstring>
 #include <deque>
 #include <mutex>
 #include <thread>
@@ -8,6 +9,7 @@
 
 #include "pinn_kernels.hpp"
 #include "pinn_kernels2.hpp"
+#include "pinn_kernels3.hpp"
 #include "plat.hpp"
 
 namespace pk {
@@ -28,6 +30,8 @@ struct SpecInfo {
     int has_sin;                     // extra kernel variants compiled for this spec: bit 0 = sin activation, bit 1 = per-layer tanh / sigmoid (ACT_MIXED)
     int REC;                         // floats per tile of the HBM record store (MODE_FWDREC / MODE_GRADREC); 0: not supported
     int jit;                         // 1: specialised at run time (jit.cpp), 0: from the ahead-of-time table
+    int act1, act2, dgm_rows;        // family 3 (DGM): gate / output-gate activation kinds, scratch rows per point
+    int r_s, r_rec1, r_sr, r_dp1, r_dp, r_dpo, first_ch[8];      // family 3: scratch row bases and first-derivative channels for k_dgm_dw
     int ngen;                        // > 0: general multi-index channel set (jit.cpp gen_*): gen[i] = multi-index of channel i (nibble 0 = order, nibbles 1.. = axes)
     unsigned gen[MAX_GEN_CHANNELS];
     int OFF_W1, OFF_B, OFF_WL, OFF_BL, OFF_WPK, OFF_WTPK;
@@ -42,6 +46,7 @@ SpecInfo make_info(void (*launch)(const GroupArgs&, int, int, plat_stream), int 
     SpecInfo s;
     s.has_sin = has_sin;
     s.jit = 0;
+    s.act1 = s.act2 = s.dgm_rows = 0;
     s.ngen = S::J::GEN ? S::C : 0;
     for (int i = 0; i < MAX_GEN_CHANNELS; ++i) s.gen[i] = (S::J::GEN && i < S::C) ? S::J::gen_channel(i) : 0u;
     s.family = 1; s.WG_PER_CU = 1; s.NW = 4;
@@ -61,6 +66,7 @@ SpecInfo make_info2(void (*launch)(const GroupArgs&, int, int, plat_stream), int
     SpecInfo s;
     s.has_sin = has_sin;
     s.jit = 0;
+    s.act1 = s.act2 = s.dgm_rows = 0;
     s.ngen = S::J::GEN ? S::C : 0;
     for (int i = 0; i < MAX_GEN_CHANNELS; ++i) s.gen[i] = (S::J::GEN && i < S::C) ? S::J::gen_channel(i) : 0u;
     s.family = 2; s.WG_PER_CU = S::WG_PER_CU; s.NW = S::NW;
@@ -183,6 +189,69 @@ template <class S> void launch_spec_mix(const GroupArgs& ga, int mode, int block
     if (ga.act == ACT_MIXED) launch_modes1<S, ACT_MIXED>(ga, mode, blocks, st); else launch_spec<S>(ga, mode, blocks, st);
 }
 
+
+// ---- family 3 (DGM): one 64-lane wave per block, a lane per point; the weight-gradient contraction as a second kernel ----
+template <class S>
+SpecInfo make_info3(void (*launch)(const GroupArgs&, int, int, plat_stream)) {
+    SpecInfo s;
+    std::memset(&s, 0, sizeof s);
+    s.family = 3; s.WG_PER_CU = 8; s.NW = 1;
+    s.HP = S::MP; s.NHH = S::L; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR; s.HI = S::HI & 0xFFFFFFu; s.LAP = 0;
+    s.PG = 4; s.C = S::C; s.NG = S::C; s.TP = 64; s.MT = 0; s.LH = S::L; s.NFIRST = S::NFIRST;
+    s.COOP = 1;
+    s.act1 = S::ACT1; s.act2 = S::ACT2; s.dgm_rows = S::ROWS;
+    s.r_s = S::R_S; s.r_rec1 = S::R_REC1; s.r_sr = S::R_SR; s.r_dp1 = S::R_DP1; s.r_dp = S::R_DP; s.r_dpo = S::R_DPO;
+    for (int i = 0; i < 8; ++i) {
+        s.first_ch[i] = -1;
+        for (int k = 0; k < S::NFIRST; ++k) if (S::J::first_axis(k) == i) s.first_ch[i] = S::J::CH_FIRST + k;
+    }
+    s.ngen = S::J::GEN ? S::C : 0;
+    for (int i = 0; i < MAX_GEN_CHANNELS; ++i) s.gen[i] = (S::J::GEN && i < S::C) ? S::J::gen_channel(i) : 0u;
+    s.launch = launch;
+    return s;
+}
+inline DgmDwArgs dgm_dw_args(const GroupArgs& ga, const SpecInfo& s, int blocks) {
+    DgmDwArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.scratch = ga.scratch; a.slabs = ga.slabs; a.npad = ga.dgm_npad; a.slab = ga.dgm_slab; a.nblocks = blocks; a.ntiles = ga.ntiles;
+    a.M = ga.dgm_modes; a.MPad = s.HP; a.d = s.D; a.L = s.NHH; a.C = s.C; a.nparams = ga.dgm_nparams;
+    a.r_s = s.r_s; a.r_rec1 = s.r_rec1; a.r_sr = s.r_sr; a.r_dp1 = s.r_dp1; a.r_dp = s.r_dp; a.r_dpo = s.r_dpo;
+    for (int i = 0; i < 8; ++i) a.first_ch[i] = s.first_ch[i];
+    a.nterms = ga.nterms;
+    for (int j = 0; j < MAX_GROUP_TERMS; ++j) a.terms[j] = ga.terms[j];
+    return a;
+}
+#ifdef PINN_EMU
+template <class S, int MODE> void run_emu3(const GroupArgs& ga, int blocks) {
+    for (int b = 0; b < blocks; ++b) wave_dgm<S, MODE>(ga, b, blocks);
+}
+inline void run_dgm_dw(const DgmDwArgs& a, plat_stream) {
+    for (int b = 0; b < a.nblocks; ++b)
+        for (int e = 0; e < a.nparams; ++e) dgm_dw_entry(e, b, a);
+}
+#define PINN_LAUNCH3(S, MODE, ga, blocks, st) run_emu3<S, MODE>(ga, blocks)
+#else
+template <class S, int MODE>
+__global__ void __launch_bounds__(64) k_dgm(const GroupArgs ga) { wave_dgm<S, MODE>(ga, (int)blockIdx.x, (int)gridDim.x); }
+__global__ void __launch_bounds__(256) k_dgm_dw(const DgmDwArgs a) {
+    const int e = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (e < a.nparams) dgm_dw_entry(e, (int)blockIdx.y, a);
+}
+inline void run_dgm_dw(const DgmDwArgs& a, plat_stream st) {
+    hipLaunchKernelGGL(k_dgm_dw, dim3((a.nparams + 255) / 256, a.nblocks), dim3(256), 0, st, a);
+}
+#define PINN_LAUNCH3(S, MODE, ga, blocks, st) hipLaunchKernelGGL((k_dgm<S, MODE>), dim3(blocks), dim3(64), 0, st, ga)
+#endif
+template <class S> SpecInfo& info3_of();          // the registered SpecInfo of S (defined by PINN_INSTANTIATE_DGM)
+template <class S> void launch_spec3(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
+    (void)st;
+    if (mode == MODE_FUSED) {
+        PINN_LAUNCH3(S, MODE_FUSED, ga, blocks, st);
+        run_dgm_dw(dgm_dw_args(ga, info3_of<S>(), blocks), st);
+    } else if (mode == MODE_RESID) PINN_LAUNCH3(S, MODE_RESID, ga, blocks, st);
+    else PINN_LAUNCH3(S, MODE_FWD, ga, blocks, st);
+}
+
 struct Registrar {
     explicit Registrar(const SpecInfo& s) { registry().push_back(s); }
 };
@@ -220,6 +289,15 @@ struct Registrar {
     namespace {                                                                              \
     using NAME##_spec = pk::Spec<HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI>;                  \
     pk::Registrar NAME##_reg(pk::make_info<NAME##_spec>(&pk::launch_spec_mix<NAME##_spec>, 2)); \
+    }
+// DGM network (family 3): modes padded to MP, L gated layers, D inputs, jet set, gate activation ACT1, output-gate activation ACT2
+#define PINN_INSTANTIATE_DGM(NAME, MP, L, D, D1MASK, PAIRS, NPAIR, HI, ACT1, ACT2)           \
+    namespace pk {                                                                           \
+    using NAME##_spec3 = Spec3<MP, L, D, D1MASK, PAIRS, NPAIR, HI, ACT1, ACT2>;              \
+    template <> SpecInfo& info3_of<NAME##_spec3>() { static SpecInfo s = make_info3<NAME##_spec3>(&launch_spec3<NAME##_spec3>); return s; } \
+    }                                                                                        \
+    namespace {                                                                              \
+    pk::Registrar NAME##_reg3(pk::info3_of<pk::NAME##_spec3>());                             \
     }
 #define PINN_INSTANTIATE2(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG) PINN_INSTANTIATE2_HI(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, 0u)
 #define PINN_INSTANTIATE(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG) PINN_INSTANTIATE_HI(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, 0u)

@@ -69,6 +69,40 @@ class Chain:
         return sum(l.n_in * l.n_out + l.n_out for l in self.layers)
 
 
+class DGM:
+    """DGM(in_dims, out_dims, modes, layers, activation1, activation2, out_activation) — the Deep Galerkin architecture of the reference
+    (src/dgm.jl:97-115): S1 = a1(W1 x + b1); `layers` gated layers Z, G, R = a1(U x + W S + b), H = a2(Uh x + Wh (S .* R) + bh),
+    S' = (1 - G) .* H + Z .* S (DGMLSTMLayer, :40-48); f = W S + b.  The engine runs it with its own kernel family (csrc/pinn_kernels3.hpp):
+    single output, identity output activation, activations tanh / sigmoid / sin, up to 64 modes."""
+
+    def __init__(self, in_dims: int, out_dims: int, modes: int, layers: int, activation1="tanh", activation2="tanh", out_activation="identity"):
+        alias = {"σ": "sigmoid", "sigmoid_fast": "sigmoid", "tanh_fast": "tanh"}
+        a1, a2 = alias.get(activation1, activation1), alias.get(activation2, activation2)
+        if out_dims != 1:
+            raise ValueError("each network must have a single output (one network per dependent variable, src/pinn_types.jl:106-108)")
+        if out_activation != "identity":
+            raise ValueError("the HIP engine runs DGM networks with the identity output activation (the reference's examples use it)")
+        if not {a1, a2} <= {"tanh", "sigmoid", "sin"}:
+            raise ValueError(f"unsupported DGM activations ({a1}, {a2}); supported: tanh, sigmoid, sin")
+        if not (1 <= modes <= 64 and 1 <= layers <= 8):
+            raise ValueError("DGM networks are supported with 1..64 modes and 1..8 gated layers")
+        self.in_dims, self.modes, self.dgm_layers = in_dims, modes, layers
+        self.sizes = (in_dims, modes, 1)
+        self.act = f"dgm,{a1},{a2},{layers}"
+        self.layers = None
+
+    @property
+    def nparams(self) -> int:
+        d, M = self.in_dims, self.modes
+        return M * d + M + self.dgm_layers * (4 * M * d + 4 * M * M + 4 * M) + M + 1
+
+
+def DeepGalerkin(in_dims: int, out_dims: int, modes: int, L: int, activation1, activation2, out_activation, strategy, **kwargs):
+    """DeepGalerkin(in_dims, out_dims, modes, L, activation1, activation2, out_activation, strategy; kwargs...) — src/dgm.jl:143-152:
+    a PhysicsInformedNN over the DGM architecture."""
+    return PhysicsInformedNN(DGM(in_dims, out_dims, modes, L, activation1, activation2, out_activation), strategy, **kwargs)
+
+
 def initialparameters(rng: np.random.Generator, chain: Chain, dtype=np.float64, init: str = "lux1") -> np.ndarray:
     """[3P] Lux.initialparameters for a Chain of Dense layers, flattened in ComponentArrays order [W1 (out x in, column-major) | b1 | ...].
     init = "lux1" (default): the Dense defaults of the Lux 1.x line the reference pins (Project.toml: Lux 1.31) —
@@ -78,6 +112,19 @@ def initialparameters(rng: np.random.Generator, chain: Chain, dtype=np.float64, 
     init = "glorot": glorot_uniform weights and zero bias (Lux < 1.0, and what `dgm.jl:12` still passes explicitly).
     Only the distribution of the random start matters here: a user-supplied `init_params` bypasses this function."""
     parts = []
+    if isinstance(chain, DGM):
+        # Dense layers: the Lux Dense defaults; gated layers: glorot_uniform weights, zero biases (src/dgm.jl:10-13)
+        d, M = chain.in_dims, chain.modes
+        lim = 1.0 / math.sqrt(d)
+        parts += [rng.uniform(-lim, lim, size=(M, d)).T.reshape(-1), rng.uniform(-lim, lim, size=M)]
+        for _ in range(chain.dgm_layers):
+            for nin in (d, d, d, d, M, M, M, M):
+                g = math.sqrt(6.0 / (nin + M))
+                parts.append(rng.uniform(-g, g, size=(M, nin)).T.reshape(-1))
+            parts.append(np.zeros(4 * M))
+        lim = 1.0 / math.sqrt(M)
+        parts += [rng.uniform(-lim, lim, size=(1, M)).reshape(-1), rng.uniform(-lim, lim, size=1)]
+        return np.concatenate(parts).astype(dtype)
     for l in chain.layers:
         if init == "glorot":
             lim = math.sqrt(6.0 / (l.n_in + l.n_out))
