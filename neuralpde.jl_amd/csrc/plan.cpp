@@ -105,7 +105,7 @@ const pk::SpecInfo* find_spec(int HP, int NHH, int D, unsigned need_first, const
     const pk::SpecInfo* best = nullptr;
     const bool want_gen = (need_hi & GEN_FLAG) != 0;
     for (const pk::SpecInfo& s : pk::registry()) {
-        if (s.HP != HP || s.NHH != NHH || s.D != D) continue;
+        if (s.family == 3 || s.HP != HP || s.NHH != NHH || s.D != D) continue;       // (family 3 = DGM networks: find_spec_dgm)
         if (need_variant && !(s.has_sin & need_variant)) continue;
         if (want_gen != (s.ngen > 0)) continue;
         if (want_gen) {                          // general multi-index set: every requested channel must be carried
@@ -309,7 +309,7 @@ static int plan_assign_terms(pinn_engine& E) {
         // shapes without ANY compiled kernel get the fused (fewer channels) form specialised at run time
         bool any_aot = false;
         for (const pk::SpecInfo& s : pk::registry())
-            any_aot = any_aot || (s.HP == round_hp(N.maxhidden()) && s.NHH == (int)N.sizes.size() - 3 && s.D == N.sizes[0] && s.C > 1);
+            any_aot = any_aot || (s.family != 3 && s.HP == round_hp(N.maxhidden()) && s.NHH == (int)N.sizes.size() - 3 && s.D == N.sizes[0] && s.C > 1);
         if (any_aot) return false;
         const std::string prev = g_err;
         const bool ok = ensure_spec(N, nf, npairs, nh) != nullptr;

@@ -233,12 +233,13 @@ inline void run_dgm_dw(const DgmDwArgs& a, plat_stream) {
 #else
 template <class S, int MODE>
 __global__ void __launch_bounds__(64) k_dgm(const GroupArgs ga) { wave_dgm<S, MODE>(ga, (int)blockIdx.x, (int)gridDim.x); }
+template <int UNUSED>       // (a template only for its linkage: this header is included by every kernel translation unit)
 __global__ void __launch_bounds__(256) k_dgm_dw(const DgmDwArgs a) {
     const int e = (int)(blockIdx.x * 256 + threadIdx.x);
     if (e < a.nparams) dgm_dw_entry(e, (int)blockIdx.y, a);
 }
 inline void run_dgm_dw(const DgmDwArgs& a, plat_stream st) {
-    hipLaunchKernelGGL(k_dgm_dw, dim3((a.nparams + 255) / 256, a.nblocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_dgm_dw<0>), dim3((a.nparams + 255) / 256, a.nblocks), dim3(256), 0, st, a);
 }
 #define PINN_LAUNCH3(S, MODE, ga, blocks, st) hipLaunchKernelGGL((k_dgm<S, MODE>), dim3(blocks), dim3(64), 0, st, ga)
 #endif
