@@ -124,3 +124,16 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def reference_tables():
+    """Extract golden data the reference's own tests hold (needs /root/reference; the .npz is committed)."""
+    import re
+    src = open("/root/reference/test/DGM/dgm__burger_s_equation.jl").read()
+    body = re.search(r"const BURGER_REF_U = \[(.*?)\n\]", src, re.S).group(1)
+    rows = [r.strip().rstrip(";") for r in body.strip().split("\n")]
+    U = np.array([[float(v) for v in r.split()] for r in rows])
+    assert U.shape == (11, 21)
+    out = os.path.join(ROOT, "tests", "golden", "reference")
+    os.makedirs(out, exist_ok=True)
+    np.savez(os.path.join(out, "dgm_burgers_mol_table.npz"), ts=np.linspace(0, 1, 11), xs=np.linspace(-1, 1, 21), u=U)
