@@ -51,6 +51,12 @@
 #ifndef PINN_F2_ASYM_PRIO
 #define PINN_F2_ASYM_PRIO 0
 #endif
+#ifndef PINN_F2_OCC3_C1
+#define PINN_F2_OCC3_C1 0              // experiment: PINN_F2_OCC=3 only for the value-only (C = 1) kernels
+#endif
+#ifndef PINN_F2_LINEAR_ONLY
+#define PINN_F2_LINEAR_ONLY 0           // experiment: compile the tape interpreter out (kernels for groups whose terms are all affine)
+#endif
 #ifndef PINN_F2_GEMM_SITES
 #define PINN_F2_GEMM_SITES 7            // bit mask: 1 forward GEMM, 2 dA GEMM, 4 dW GEMM
 #endif
@@ -112,7 +118,7 @@ struct Spec2 {
     static_assert(!CHUNKED || 2 * CHSZ <= XSZ, "chunk double buffer must fit inside X1");
     static constexpr int LDS_WG = (CHUNKED ? 2 : 3) * XSZ + LDS_UP;
     // PINN_F2_OCC=3 (experiment): three workgroups per CU where the LDS allows it — the kernel is then compiled for <= 168 VGPRs
-    static constexpr int WG_PER_CU = (NW == 8) ? 1 : ((PINN_F2_OCC >= 3 && LDS_WG * 4 <= 53 * 1024) ? 3 : ((LDS_WG * 4 <= 80 * 1024) ? 2 : 1));
+    static constexpr int WG_PER_CU = (NW == 8) ? 1 : ((PINN_F2_OCC >= 3 && (!PINN_F2_OCC3_C1 || J::C == 1) && LDS_WG * 4 <= 53 * 1024) ? 3 : ((LDS_WG * 4 <= 80 * 1024) ? 2 : 1));
     static constexpr int OCC = WG_PER_CU * NW / 4;                       // waves per SIMD the kernel is compiled for
     // dW accumulators: resident in registers across tiles when they fit (4x64: 48 registers); for wide/deep nets they
     // are accumulated per tile into this workgroup's slab instead (read-modify-write, L2; same wave owns the same tiles)
@@ -442,7 +448,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         PINN_UNROLL for (int i = 0; i < D; ++i) xin[i] = x[pg][i];
                         PINN_UNROLL for (int ch = 0; ch < C; ++ch) Uin[ch] = U[pg][ch];
                     }
-                if (T.linear && C <= LIN_MAX_C) {
+                if ((PINN_F2_LINEAR_ONLY || T.linear) && C <= LIN_MAX_C) {
                     // affine residual: no interpreter, no tape registers — a handful of FMAs and the seeds are the constant coefficients
                     vfloat r = vfloat(T.lin_k);
                     PINN_UNROLL for (int ch = 0; ch < C; ++ch) r = vfma(vfloat(T.lin_a[ch < LIN_MAX_C ? ch : 0]), Uin[ch], r);
@@ -465,7 +471,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         PINN_UNROLL for (int ch = 0; ch < C; ++ch)
                             lds_store(UB, vint((w * C + ch) * 16) + c, vselect(vin, rbar * vfloat(T.lin_a[ch < LIN_MAX_C ? ch : 0]), vfloat(0.f)));
                     }
-                } else {
+                } else if (!PINN_F2_LINEAR_ONLY) {
                     const int NP = ga.nparams;
                     const int DT = T.dt;            // tape rows: [coordinates DT | params NP | jet channels C | sources | ops]
                     const int R0 = DT + NP + C + T.nsrc;
