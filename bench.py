@@ -196,6 +196,24 @@ def main():
             eng.loss_grad_device(theta_d.data_ptr(), out_h.data_ptr(), None, stream.cuda_stream)
         stream.synchronize()                 # the optimiser needs loss + gradient on the host every iteration
 
+    host_path_ms = None
+    if world == 1:
+        # (measured BEFORE the warm-up and the timed region: it doubles as the clock / cache warm-up of the device)
+        # cross-check of the zero-copy delivery against a plain device-buffer evaluation + copy
+        eng.set_timing(0, -1)
+        step()
+        eng.loss_grad_device(theta_d.data_ptr(), out_d.data_ptr(), None, stream.cuda_stream)
+        stream.synchronize()
+        assert np.array_equal(out_d.cpu().numpy(), out_h.numpy()), "zero-copy host delivery differs from the device buffer"
+        # the C-ABI host entry point (theta from host memory, loss + gradient back to host memory: PCIe both ways)
+        th = np.ascontiguousarray(wl.theta, dtype=np.float32)
+        for _ in range(5):
+            eng.loss_grad(th)
+        nh = 25
+        t1 = time.perf_counter()
+        for _ in range(nh):
+            eng.loss_grad(th)
+        host_path_ms = (time.perf_counter() - t1) / nh * 1e3
     for _ in range(args.warmup):
         step()
     ev_level, ev_group = {"all": 1, "none": 0}[args.events], -1
@@ -223,22 +241,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
-    host_path_ms = None
-    if world == 1:
-        # cross-check of the zero-copy delivery against a plain device-buffer evaluation + copy
-        eng.set_timing(0, -1)
-        eng.loss_grad_device(theta_d.data_ptr(), out_d.data_ptr(), None, stream.cuda_stream)
-        stream.synchronize()
-        assert np.array_equal(out_d.cpu().numpy(), out_h.numpy()), "zero-copy host delivery differs from the device buffer"
-        # the C-ABI host entry point (theta from host memory, loss + gradient back to host memory: PCIe both ways)
-        th = np.ascontiguousarray(wl.theta, dtype=np.float32)
-        for _ in range(5):
-            eng.loss_grad(th)
-        nh = max(10, args.steps // 4)
-        t1 = time.perf_counter()
-        for _ in range(nh):
-            eng.loss_grad(th)
-        host_path_ms = (time.perf_counter() - t1) / nh * 1e3
     if rank == 0:
         import re
         res = out_h.numpy()
