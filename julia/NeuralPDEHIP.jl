@@ -188,15 +188,39 @@ const ACT_NAMES = Dict{Any, String}(tanh => "tanh", Lux.tanh_fast => "tanh", Lux
 
 chains_of(pinnrep::PINNRepresentation) = pinnrep.phi isa AbstractVector ? [p.smodel.model for p in pinnrep.phi] : [pinnrep.phi.smodel.model]
 
+act_name(f) = get(ACT_NAMES, f, nothing)
+
+# the reference's DGM(in, 1, modes, L, activation1, activation2, identity) (src/dgm.jl:97-115): Chain(SkipConnection(Dense, DGMLSTMBlock), Dense)
+function dgm_lines(i::Int, dgm, θoff::Int, depvar::Symbol, inputs)
+    outer = collect(values(dgm.model.layers))
+    first_dense, block, last_dense = outer[1].layers, outer[1].connection, outer[2]
+    gated = collect(values(block.layers))
+    lstm = gated[1] isa Lux.SkipConnection ? gated[1].layers : gated[1]
+    a1, a2 = act_name(lstm.activation1), act_name(lstm.activation2)
+    (a1 === nothing || a2 === nothing || a1 == "identity" || a2 == "identity") &&
+        throw(HIPEngineError("unsupported DGM activations ($(lstm.activation1), $(lstm.activation2)); supported: tanh, sigmoid, sin"))
+    act_name(first_dense.activation) == a1 || throw(HIPEngineError("DGM: the first Dense layer must use activation1"))
+    act_name(last_dense.activation) == "identity" || throw(HIPEngineError("the HIP engine runs DGM networks with the identity output activation"))
+    last_dense.out_dims == 1 || throw(HIPEngineError("each network must have a single output (one per dependent variable)"))
+    d, M, L = first_dense.in_dims, first_dense.out_dims, length(gated)
+    nparams = M * d + M + L * (4 * M * d + 4 * M * M + 4 * M) + M + 1
+    nparams == Lux.LuxCore.parameterlength(dgm) || throw(HIPEngineError("DGM parameter count differs from the engine's layout"))
+    return ["net $(i - 1) dgm,$a1,$a2,$L $θoff 3 $d $M 1", "netvar $(i - 1) $depvar $(length(inputs)) " * join(inputs, " ")], nparams
+end
+
+input_dim(model) = model isa NeuralPDE.DGM ? first(values(model.model.layers)).layers.in_dims : first(values(model.layers)).in_dims
+
 function chain_lines(i::Int, chain, θoff::Int, depvar::Symbol, inputs)
+    chain isa NeuralPDE.DGM && return dgm_lines(i, chain, θoff, depvar, inputs)
     layers = collect(values(chain.layers))
     all(l -> l isa Lux.Dense, layers) || throw(HIPEngineError("the HIP engine runs Chains of Dense layers (got $(typeof.(layers)))"))
     length(layers) >= 2 || throw(HIPEngineError("the HIP engine needs at least one hidden layer"))
-    acts = [get(ACT_NAMES, l.activation, nothing) for l in layers]
+    acts = [act_name(l.activation) for l in layers]
     any(isnothing, acts) && throw(HIPEngineError("unsupported activation in chain $i: $([l.activation for l in layers]) (supported: tanh, sigmoid, sin)"))
     acts[end] == "identity" || throw(HIPEngineError("the last layer must have identity activation"))
     layers[end].out_dims == 1 || throw(HIPEngineError("each chain must have a single output (one chain per dependent variable, src/pinn_types.jl:106-108)"))
-    all(l -> l.use_bias isa Lux.True || l.use_bias === true, layers) || throw(HIPEngineError("Dense layers without bias are not supported"))
+    all(l -> Lux.LuxCore.parameterlength(l) == l.in_dims * l.out_dims + l.out_dims, layers) ||
+        throw(HIPEngineError("Dense layers without bias are not supported"))
     hidden = acts[1:(end - 1)]
     act = all(==(hidden[1]), hidden) ? hidden[1] : join(hidden, ",")
     sizes = vcat(layers[1].in_dims, [l.out_dims for l in layers])
@@ -254,7 +278,7 @@ function verify_layout(e::HIPEngine, pinnrep::PINNRepresentation; n::Int = 16, r
     flat = collect(Float64, ComponentArrays.getdata(θ))
     phis = pinnrep.phi isa AbstractVector ? pinnrep.phi : [pinnrep.phi]
     for (i, ph) in enumerate(phis)
-        d = first(values(ph.smodel.model.layers)).in_dims
+        d = input_dim(ph.smodel.model)
         x = rand(Float64, d, n)
         # src/discretize.jl:451-465: multioutput => θ.depvar.<name>; single chain => θ itself, or θ.depvar when param_estim adds θ.p
         θi = pinnrep.multioutput ? getproperty(θ.depvar, pinnrep.depvars[i]) : (pinnrep.param_estim ? θ.depvar : θ)
