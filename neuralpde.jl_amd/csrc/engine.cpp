@@ -142,7 +142,6 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
             any = any || (only_term < 0 || only_term == G.terms[j]);
         }
         G.active = any;
-        const int nsplit = std::min(REDUCE_SPLIT, G.blocks);
         // chained launch groups: this group's workgroups add their sums onto the slabs the head group (same network, launched
         // earlier on the same stream in this evaluation) has just written, so the reduction reads one slab set, not two
         const bool chained = any && !no_chain && !concurrent && G.kind == 0 && G.chain_to >= 0 && E.groups[G.chain_to].active &&
@@ -152,12 +151,28 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
         G.ga.chain = chained ? 1 : 0;
         a1.tmp[g] = G.d_tmp; a1.slabs[g] = G.d_slabs; a1.losspart[g] = G.d_losspart;
         if (G.spec->family == 3) G.ga.packed = d_theta + E.nets[G.net].theta_off;      // DGM: weights straight from theta
-        a1.slab[g] = G.slab_floats; a1.nblocks[g] = G.blocks; a1.nsplit[g] = nsplit; a1.nent[g] = nent; a1.active[g] = any; a1.nwpb[g] = G.spec->NW;
-        a2.tmp[g] = G.d_tmp; a2.stride[g] = nent + K; a2.nsplit[g] = nsplit; a2.nent[g] = nent; a2.active[g] = any;
+        // a single-term evaluation (pinn_term_grads) of a fused group launches ONLY that term's tiles: the K per-term gradients then cost
+        // about one full evaluation in total instead of K
+        pk::GroupArgs ga_one;
+        const pk::GroupArgs* ga_launch = &G.ga;
+        int blocks = G.blocks;
+        if (any && only_term >= 0 && G.kind == 0 && G.terms.size() > 1) {
+            ga_one = G.ga;
+            for (size_t j = 0; j < G.terms.size(); ++j)
+                if (G.terms[j] == only_term) ga_one.terms[0] = G.ga.terms[j];
+            ga_one.nterms = 1;
+            ga_one.terms[0].tile0 = 0;
+            ga_one.ntiles = ga_one.terms[0].ntiles;
+            blocks = std::max(1, std::min(G.max_blocks, G.spec->family == 1 ? (ga_one.ntiles + 3) / 4 : ga_one.ntiles));
+            ga_launch = &ga_one;
+        }
+        const int nsplit_g = std::min(REDUCE_SPLIT, blocks);
+        a1.slab[g] = G.slab_floats; a1.nblocks[g] = blocks; a1.nsplit[g] = nsplit_g; a1.nent[g] = nent; a1.active[g] = any; a1.nwpb[g] = G.spec->NW;
+        a2.tmp[g] = G.d_tmp; a2.stride[g] = nent + K; a2.nsplit[g] = nsplit_g; a2.nent[g] = nent; a2.active[g] = any;
         a2.ent_active[g] = any && !chained;
         if (!any) continue;
         max_n1 = std::max(max_n1, G.nent / 4 + K);
-        max_split = std::max(max_split, nsplit);
+        max_split = std::max(max_split, nsplit_g);
         if (G.kind == 1) {               // coupled: forward launch now, reverse launch after k_expr
             G.spec->launch(G.ga, G.use_rec ? pk::MODE_FWDREC : pk::MODE_FWD, G.blocks, E.stream);
             continue;
@@ -169,7 +184,7 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
             plat_stream_wait_event(st, E.ev_fork);
         }
         if (group_ev(g)) plat_event_record(G.ev_a, st);
-        G.spec->launch(G.ga, pk::MODE_FUSED, G.blocks, st);
+        G.spec->launch(*ga_launch, pk::MODE_FUSED, blocks, st);
         if (group_ev(g)) plat_event_record(G.ev_b, st);
         G.timed = group_ev(g);
         if (forked) {
