@@ -552,6 +552,9 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                         } else {
                             PINN_UNROLL for (int ch = 0; ch < C; ++ch)
                                 ub_store4(SB, (((layer * NG) + pg * C + ch) * MT + m) * 256, lane << 2, Z[pg * C + ch][m]);
+                            store_pad();                      // the stored channels are updated in place below (vec.hpp: store_pad)
+                            PINN_UNROLL for (int ch = 0; ch < C; ++ch) keep_alive(Z[pg * C + ch][m]);
+                            sched_fence();
                         }
                     }
                     PINN_UNROLL for (int r = 0; r < 4; ++r) {

@@ -261,6 +261,11 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                                 ub_store4(SB, (((layer - 1) * NG + pg * C + ch) * MT + w * MTW + t) * 256, lane << 2, Z[pg * C + ch][t]);
                         }
                     }
+                    if ((RECOUT && layer > 0) || (BWD && layer > 0 && layer != LH - 1)) {    // the stored channels are updated in place below
+                        store_pad();
+                        PINN_UNROLL for (int ch = 0; ch < C; ++ch) keep_alive(Z[pg * C + ch][t]);
+                        sched_fence();
+                    }
                     PINN_UNROLL for (int r = 0; r < 4; ++r) {
                         vfloat zz[C], dd[ND];
                         PINN_UNROLL for (int ch = 0; ch < C; ++ch) zz[ch] = Z[pg * C + ch][t][r];

@@ -303,6 +303,10 @@ static int plan_assign_terms(pinn_engine& E) {
     };
     // pass 0: forward-Laplacian fusion (fuse_laplacian) wherever a compiled kernel carries the resulting channel set
     static const bool no_lap = std::getenv("PINN_NO_LAPLACIAN") != nullptr;
+    // coupled equations: every (equation, network) pair runs the kernel of the channels THAT equation reads from the network (a network
+    // entering an equation only by its value costs one channel there, not the union over all equations); PINN_COUPLED_UNION=1 restores
+    // one kernel per network carrying the union (A/B measurements)
+    static const bool coupled_union = std::getenv("PINN_COUPLED_UNION") != nullptr;
     auto spec_exists = [&](int net, unsigned nf, const std::vector<std::pair<int, int>>& npairs, unsigned nh) {
         const Net& N = E.nets[net];
         if (find_spec(round_hp(N.maxhidden()), (int)N.sizes.size() - 3, N.sizes[0], nf, npairs, nh, nullptr, variant_of(N.act)) != nullptr) return true;
@@ -339,12 +343,19 @@ static int plan_assign_terms(pinn_engine& E) {
                 g_err.clear();
             } else if (nets.size() > 1) {
                 any_coupled = any_coupled || did[t];
-                for (int net : nets)
+                for (int net : nets) {
                     if (needs_of(fused[t], net, cn[net].first, cn[net].second, ch[net])) { coupled_ok = false; g_err.clear(); }
+                    if (!coupled_union && coupled_ok) {          // one kernel per (equation, network): check this equation's own channel set
+                        unsigned nf = 0, nh = 0;
+                        std::vector<std::pair<int, int>> npairs;
+                        coupled_ok = needs_of(fused[t], net, nf, npairs, nh) == 0 && spec_exists(net, nf, npairs, nh);
+                        g_err.clear();
+                    }
+                }
             }
         }
         if (any_coupled && coupled_ok) {
-            for (auto& kv : cn) coupled_ok = coupled_ok && spec_exists(kv.first, kv.second.first, kv.second.second, ch[kv.first]);
+            for (auto& kv : cn) coupled_ok = coupled_ok && (!coupled_union || spec_exists(kv.first, kv.second.first, kv.second.second, ch[kv.first]));
             if (coupled_ok)
                 for (size_t t = 0; t < E.terms.size(); ++t) {
                     std::vector<int> nets;
@@ -356,7 +367,6 @@ static int plan_assign_terms(pinn_engine& E) {
     // pass 1: which terms couple several networks; union of the jet needs per network over all coupled terms
     std::vector<std::vector<int>> term_nets(E.terms.size());
     std::map<int, std::pair<unsigned, std::vector<std::pair<int, int>>>> coupled_needs;   // net -> needs
-    std::map<int, int> coupled_dim;
     std::map<int, unsigned> coupled_hi;
     std::vector<char> two_launch(E.terms.size(), 0);
     for (size_t t = 0; t < E.terms.size(); ++t) {
@@ -396,10 +406,9 @@ static int plan_assign_terms(pinn_engine& E) {
             for (int net : term_nets[t]) {
                 auto& nd = coupled_needs[net];
                 if (needs_of(T, net, nd.first, nd.second, coupled_hi[net])) return 1;
-                coupled_dim[net] = T.d;
             }
     }
-    std::map<int, int> coupled_group;        // net -> kind-1 group
+    std::map<std::pair<int, const pk::SpecInfo*>, int> coupled_group;        // (net, kernel) -> kind-1 group
     for (size_t t = 0; t < E.terms.size(); ++t) {
         Term& T = E.terms[t];
         if (!two_launch[t]) {
@@ -455,20 +464,27 @@ static int plan_assign_terms(pinn_engine& E) {
         Cp.slot_net.assign(T.slots.size(), -1);
         for (size_t i = 0; i < Cp.nets.size(); ++i) {
             const int net = Cp.nets[i];
-            if (!coupled_group.count(net)) {
-                const pk::SpecInfo* sp = nullptr;
+            const pk::SpecInfo* sp = nullptr;
+            if (coupled_union) {
                 if (spec_for(t, net, T.d, coupled_needs[net].first, coupled_needs[net].second, coupled_hi[net], sp)) return 1;
+            } else {
+                unsigned nf = 0, nh = 0;
+                std::vector<std::pair<int, int>> npairs;
+                if (needs_of(T, net, nf, npairs, nh) || spec_for(t, net, T.d, nf, npairs, nh, sp)) return 1;
+            }
+            const auto key = std::make_pair(net, sp);
+            if (coupled_group.count(key) && (int)E.groups[coupled_group[key]].terms.size() >= pk::MAX_GROUP_TERMS) coupled_group.erase(key);
+            if (!coupled_group.count(key)) {
                 E.groups.emplace_back();
                 Group& G = E.groups.back();
                 G.kind = 1;
                 G.net = net;
                 G.spec = sp;
-                coupled_group[net] = (int)E.groups.size() - 1;
+                coupled_group[key] = (int)E.groups.size() - 1;
                 if (!E.netplans[net].spec) E.netplans[net].spec = sp;
             }
-            Group& G = E.groups[coupled_group[net]];
-            if ((int)G.terms.size() >= pk::MAX_GROUP_TERMS) return fail("too many coupled equations for one network");
-            Cp.groups.push_back(coupled_group[net]);
+            Group& G = E.groups[coupled_group[key]];
+            Cp.groups.push_back(coupled_group[key]);
             G.terms.push_back((int)t);
             for (size_t si = 0; si < T.slots.size(); ++si)
                 if (T.slots[si].net == net) {

@@ -85,6 +85,8 @@ inline void tape_zero(vtape& t) { for (int i = 0; i < 32; ++i) t.r[i] = vfloat(0
 // 16-byte record at a wave-uniform address (device: scalar-cache load)
 struct urec16 { int x, y, z, w; };
 inline void sched_fence() {}
+inline void store_pad() {}
+inline void keep_alive(const vfloat4&) {}
 inline void wave_prio(int) {}
 template <int NGROUPS, int MFMA_PER, int AHEAD, int DS_PER = 1> inline void sched_gemm_prefetch() {}
 inline int hw_wave_slot() { return 0; }
@@ -221,6 +223,25 @@ DEV void tape_zero(vtape& t) { PINN_UNROLL for (int i = 0; i < PINN_TAPE_ROWS; +
 // (which also drains every outstanding record store) and its fields need waterfall loops to be used as register indices.
 // the instruction scheduler may not move anything across this point (keeps a block of prefetch loads where it was written)
 DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// The data registers of a 128-bit buffer store must not be rewritten while the memory pipeline is still reading them.  The compiler
+// pads that hazard only for stores WITHOUT an SGPR offset; measured on gfx950 with an SGPR offset (8-wave workgroups, two back-to-back
+// record stores, v_pk_mul_f32 rewriting the stored registers 0-2 instructions later) the record in memory came out partly overwritten
+// (gradient errors of 1e-3, varying from run to run; -fno-slp-vectorize, -amdgpu-waitcnt-forcezero or a scheduling barrier after the
+// stores each made it exact).  store_pad + keep_alive: nothing is scheduled across, and the stored registers stay live, for
+// PINN_STORE_PAD wait states after a group of stores.
+#ifndef PINN_STORE_PAD
+#define PINN_STORE_PAD 8
+#endif
+DEV void store_pad() {
+    if (PINN_STORE_PAD > 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (PINN_STORE_PAD >= 16) asm volatile("s_nop 15");
+        else asm volatile("s_nop %0" ::"n"(PINN_STORE_PAD - 1));
+    }
+}
+DEV void keep_alive(const vfloat4& x) {
+    if (PINN_STORE_PAD > 0) asm volatile("" ::"v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
+}
 // Instruction-order request for a GEMM region of NGROUPS x [1 LDS fragment read -> MFMA_PER MFMAs]: the reads run AHEAD groups in front of
 // the MFMAs that consume them, so a wave's MFMAs issue back to back instead of waiting one LDS round trip per group (left alone, the
 // compiler sinks every ds_read next to its first use to save registers: ds_read, s_waitcnt, 4 x v_mfma, ds_read, s_waitcnt, ...).

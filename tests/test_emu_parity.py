@@ -224,6 +224,40 @@ def test_coupled_system_of_pdes(npde, use_emu):
     check(npde, sysm, chains, strat, theta, param_estim=True)
 
 
+def test_one_first_derivative_kernels_5x128(npde, use_emu):
+    """{u, u_x} / {u, u_y} kernels of the 5 x 128 nets (8-wave workgroups, two point groups per tile): alone (fused launch) and as what a
+    coupled system reads from its networks — every (equation, network) pair of a coupled system runs the kernel of ITS OWN channel
+    set, so the cavity problem's continuity equation reads {u, u_x} and {v, v_y}, its momentum equations {p, p_x} / {p, p_y} and a bare
+    value of the other velocity.  (On the hardware this shape once stored a hidden layer's record from registers the next instruction
+    rewrote: gradient off by 1e-3 with all losses right.  vec.hpp: store_pad.)"""
+    from neuralpde_jl_amd import workloads
+    x, y = npde.parameters("x y")
+    (u,) = npde.variables("u")
+    dom = [npde.In(x, npde.Interval(0.0, 1.0)), npde.In(y, npde.Interval(0.0, 1.0))]
+    chain = workloads.mlp(2, 128, 5)
+    strat = npde.QuasiRandomTraining(100, bcs_points=20, sampling_alg=npde.SobolSample(seed=9), resampling=False, minibatch=1)
+    for D, kern in ((npde.Differential(x), "D2_F1_"), (npde.Differential(y), "D2_F2_")):
+        sysm = npde.PDESystem([npde.Eq(D(u(x, y)), 0.5 * x - y)], [npde.Eq(u(0, y), 0.0)], dom, [x, y], [u(x, y)])
+        rep, *_ = check(npde, sysm, [chain], strat, theta_for(chain, 77))
+        assert kern in rep.engine.describe() and "(C=2)" in rep.engine.describe()
+    wl = workloads.cfg4_cavity(points=100, bcs_points=20)
+    rep = npde.symbolic_discretize(wl.pde_system, wl.discretization())
+    desc = rep.engine.describe()
+    assert desc.count("coupled") == 8 and desc.count("(C=2)") == 4 and desc.count("(C=4)") == 2, desc
+    th = rep.flat_init_params
+    sets = rep.pde_train_sets + rep.bcs_train_sets
+    w = [1.0] * 3 + [10.0] * 8
+    losses, tg = rep.engine.term_grads(th)
+    prob = helpers.oracle_problem(npde, wl.pde_system, wl.chains)
+    ref = po.loss_and_grad(prob, th, sets, mode="stencil", per_term_grads=True)
+    assert np.max(np.abs(losses - ref.term_losses) / np.abs(ref.term_losses)) < TOL
+    for k in range(len(sets)):
+        assert np.max(np.abs(tg[k] - ref.term_grads[k])) / np.max(np.abs(ref.term_grads[k])) < TOL, k
+    l2, grad = rep.engine.loss_grad(th, w)
+    gref = (np.asarray(w)[:, None] * ref.term_grads).sum(0)
+    assert np.linalg.norm(grad - gref) / np.linalg.norm(gref) < TOL
+
+
 def test_wide_nets_family2(npde, use_emu):
     """Neuron-split kernel family: 4x64 (register-resident dW), 2x128 with 5 jet channels, 5x128 (slab-resident dW) and the
     4-D config-5 shape (8 jet channels, chunked dW staging, estimated PDE parameter) at 2x128."""
