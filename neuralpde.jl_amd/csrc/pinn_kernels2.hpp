@@ -1,7 +1,7 @@
 // pinn_kernels2.hpp — "family 2" of the PINN residual/loss kernel: neuron-split workgroups.
 //
 // Same mathematics, same replaced reference code (see pinn_kernels.hpp header) — different mapping onto the CU:
-//   * one workgroup (NW = 4 waves; 8 at H = 128 when a wave's state for NG <= 4 column groups fits 256 registers) owns one tile of
+//   * one workgroup (NW = 4 waves; 8 at H = 128 for NG <= 6 column groups: one workgroup per CU either way, so 8 waves = 2 per SIMD) owns one tile of
 //     TP = 16*PG points; wave w owns the 16-neuron tiles {w*MTW .. w*MTW+MTW-1} of EVERY layer (MTW = HP/(16 NW)), for all
 //     NG = C*PG column groups of the tile;
 //   * between layers the activation jets are exchanged through LDS in MFMA-B-fragment order
@@ -35,7 +35,7 @@
 #define PINN_F2_WAVES128 8
 #endif
 #ifndef PINN_F2_NW8_MAXNG
-#define PINN_F2_NW8_MAXNG 4
+#define PINN_F2_NW8_MAXNG 6
 #endif
 #ifndef PINN_F2_SPRE_MAX
 #define PINN_F2_SPRE_MAX 24
@@ -72,8 +72,8 @@ struct Spec2 {
     static constexpr unsigned D1MASK = D1MASK_;
     static constexpr unsigned long long PAIRS = PAIRS_;
     // waves per workgroup: 8 where the workgroup's LDS tiles (3 x NG x MT KB) leave room for only one workgroup per CU anyway and
-    // a wave's state for NG <= 4 column groups fits 256 registers (measured: cfg4 44.5 -> 39.0 ms; with NG = 6 the 8-wave
-    // build of the cfg5 kernel spills 800 B/lane and is 4 % slower than the 4-wave, 512-register build)
+    // a wave's state fits 256 registers tolerably (measured: NG <= 4, cfg4 44.5 -> 39.0 ms; NG = 6, the forward-Laplacian kernel of
+    // cfg5: 114 spilled registers, yet 38.8 -> 34.6 ms against the 4-wave, 512-register build — the second wave per SIMD wins)
     static constexpr int NW = (HP_ >= 128 && J::C * PG_ <= PINN_F2_NW8_MAXNG) ? PINN_F2_WAVES128 : 4;
     static constexpr int MTW = MT / NW;                // neuron tiles per wave
     static_assert(MT % NW == 0 && MT % 4 == 0, "family 2 needs a hidden width that is a multiple of 64 (16 x waves per workgroup)");
