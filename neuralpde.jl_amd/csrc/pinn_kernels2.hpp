@@ -37,6 +37,9 @@
 #ifndef PINN_F2_NW8_MAXNG
 #define PINN_F2_NW8_MAXNG 6
 #endif
+#ifndef PINN_F2_REC_LDS
+#define PINN_F2_REC_LDS 1               // keep the records of the stored hidden layers in LDS as far as they fit (Spec2::NRQ)
+#endif
 #ifndef PINN_F2_SPRE_MAX
 #define PINN_F2_SPRE_MAX 24
 #endif
@@ -116,9 +119,18 @@ struct Spec2 {
     static constexpr int CH_ZT = MTW * 256;
     static constexpr int CHSZ = CH_AT + NW * CH_ZT;
     static_assert(!CHUNKED || 2 * CHSZ <= XSZ, "chunk double buffer must fit inside X1");
-    static constexpr int LDS_WG = (CHUNKED ? 2 : 3) * XSZ + LDS_UP;
+    static constexpr int LDS_BASE = (CHUNKED ? 2 : 3) * XSZ + LDS_UP;
     // PINN_F2_OCC=3 (experiment): three workgroups per CU where the LDS allows it — the kernel is then compiled for <= 168 VGPRs
-    static constexpr int WG_PER_CU = (NW == 8) ? 1 : ((PINN_F2_OCC >= 3 && (!PINN_F2_OCC3_C1 || J::C == 1) && LDS_WG * 4 <= 53 * 1024) ? 3 : ((LDS_WG * 4 <= 80 * 1024) ? 2 : 1));
+    static constexpr int WG_PER_CU = (NW == 8) ? 1 : ((PINN_F2_OCC >= 3 && (!PINN_F2_OCC3_C1 || J::C == 1) && LDS_BASE * 4 <= 53 * 1024) ? 3 : ((LDS_BASE * 4 <= 80 * 1024) ? 2 : 1));
+    // the records of the stored hidden layers stay in LDS instead of the per-workgroup scratch slab in global memory — as many
+    // (layer, column group) slices as fit without lowering the number of resident workgroups, from layer LH-2 (needed first by the
+    // reverse sweep) downwards.  Each wave writes and reads its own part of a slice only.  4x64, NG = 4: 7 of the 8 slices.
+    static constexpr int RECQ = MT * 256;                            // one column group of one layer's record of a tile (floats)
+    static constexpr int LDS_CAP = (WG_PER_CU == 3 ? 53 : (WG_PER_CU == 2 ? 80 : 160)) * 256 - 64;    // floats per workgroup
+    static constexpr int NRQ_ALL = (LH > 2 ? LH - 2 : 0) * NG;
+    static constexpr int NRQ_FIT = (LDS_CAP - LDS_BASE) / RECQ;
+    static constexpr int NRQ = PINN_F2_REC_LDS ? (NRQ_FIT < NRQ_ALL ? (NRQ_FIT > 0 ? NRQ_FIT : 0) : NRQ_ALL) : 0;
+    static constexpr int LDS_WG = LDS_BASE + NRQ * RECQ;
     static constexpr int OCC = WG_PER_CU * NW / 4;                       // waves per SIMD the kernel is compiled for
     // dW accumulators: resident in registers across tiles when they fit (4x64: 48 registers); for wide/deep nets they
     // are accumulated per tile into this workgroup's slab instead (read-modify-write, L2; same wave owns the same tiles)
@@ -155,6 +167,9 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
     float* X1 = lds + S::XSZ;
     float* ZT = lds + 2 * S::XSZ + w * (NG * MTW * 256);      // wave-private dZ^T: [q][t][16 columns][16 neurons]
     float* UP = lds + (S::CHUNKED ? 2 : 3) * S::XSZ;          // output-layer partial sums [wave][q][16]
+    float* RL = lds + S::LDS_BASE;                            // LDS-resident record slices [(LH-2-layer)*NG + q][tile][lane][4]
+    auto rec_in_lds = [](int layer, int q) { return layer >= 1 && layer <= LH - 2 && (LH - 2 - layer) * NG + q < S::NRQ; };   // (same-kernel records only)
+    auto rl_off = [&](int layer, int q, int t) { return vint((((LH - 2 - layer) * NG + q) * MT + w * MTW + t) * 256) + (lane << 2); };
 
     // ---- persistent gradient accumulators of this wave's neuron tiles ----
     vfloat4 wbar[(S::WBAR_REG && NHH > 0) ? NHH : 1][MTW][MT];
@@ -257,11 +272,13 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         if (layer == LH - 1) {
                             PINN_UNROLL for (int ch = 0; ch < C; ++ch) Rlast[pg * C + ch][t] = Z[pg * C + ch][t];
                         } else if (layer > 0) {          // layer 0's record is recomputed from the coordinates (no storage)
-                            PINN_UNROLL for (int ch = 0; ch < C; ++ch)
-                                ub_store4(SB, (((layer - 1) * NG + pg * C + ch) * MT + w * MTW + t) * 256, lane << 2, Z[pg * C + ch][t]);
+                            PINN_UNROLL for (int ch = 0; ch < C; ++ch) {
+                                if (rec_in_lds(layer, pg * C + ch)) lds_store4(RL, rl_off(layer, pg * C + ch, t), Z[pg * C + ch][t]);
+                                else ub_store4(SB, (((layer - 1) * NG + pg * C + ch) * MT + w * MTW + t) * 256, lane << 2, Z[pg * C + ch][t]);
+                            }
                         }
                     }
-                    if ((RECOUT && layer > 0) || (BWD && layer > 0 && layer != LH - 1)) {    // the stored channels are updated in place below
+                    if ((RECOUT && layer > 0) || (BWD && layer > 0 && layer != LH - 1 && !rec_in_lds(layer, pg * C + C - 1))) {    // the stored channels are updated in place below
                         store_pad();
                         PINN_UNROLL for (int ch = 0; ch < C; ++ch) keep_alive(Z[pg * C + ch][t]);
                         sched_fence();
@@ -429,7 +446,8 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
         auto load_record = [&](int hl) {                                     // record of hidden layer hl (1 <= hl <= LH-2)
             PINN_UNROLL for (int q = 0; q < NG; ++q)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                    Snext[q][t] = ub_load4(RECIN ? RB : SB, (((hl - 1) * NG + q) * MT + w * MTW + t) * 256, lane << 2);
+                    Snext[q][t] = (!RECIN && rec_in_lds(hl, q)) ? lds_load4(RL, rl_off(hl, q, t))
+                                                             : ub_load4(RECIN ? RB : SB, (((hl - 1) * NG + q) * MT + w * MTW + t) * 256, lane << 2);
             sched_fence();
         };
         vfloat ubar[PG][C];
@@ -610,7 +628,8 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
             } else {
                 PINN_UNROLL for (int q = 0; q < NG; ++q)
                     PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                        Sr[q][t] = ub_load4(RECIN ? RB : SB, (((hl - 1) * NG + q) * MT + w * MTW + t) * 256, lane << 2);
+                        Sr[q][t] = (!RECIN && rec_in_lds(hl, q)) ? lds_load4(RL, rl_off(hl, q, t))
+                                                              : ub_load4(RECIN ? RB : SB, (((hl - 1) * NG + q) * MT + w * MTW + t) * 256, lane << 2);
             }
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t)
