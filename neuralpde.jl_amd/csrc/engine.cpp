@@ -330,11 +330,13 @@ static int set_points_impl(pinn_handle h, int term, const float* pts, int64_t n,
     if (!pts || n <= 0) return fail("pinn_set_points: empty point set (the reference's mean(abs2, .) over an empty set is NaN; refusing)");
     Term& T = E.terms[term];
     if (n * T.d >= (int64_t)1 << 31) return fail("pinn_set_points: point set too large for 32-bit indexing; shard it");
-    plat_sync(E.stream);
-    if (T.n != n || !T.d_pts) {
+    if (n > T.pts_cap || !T.d_pts) {                     // grow only: a resampled set of another size reuses the buffer
+        plat_sync(E.stream);                             // (an evaluation in flight may still read the old buffer)
         plat_free(T.d_pts);
+        T.pts_cap = 0;
         T.d_pts = (float*)plat_malloc(sizeof(float) * n * T.d);
         if (!T.d_pts) return fail("device allocation failed (points)");
+        T.pts_cap = n;
     }
     int rc = device ? plat_d2d(T.d_pts, pts, sizeof(float) * n * T.d, E.stream) : plat_h2d(T.d_pts, pts, sizeof(float) * n * T.d, E.stream);
     if (rc) return fail(std::string("copy of points failed: ") + plat_last_error());
