@@ -314,6 +314,21 @@ inline void launch_sample(int kind, float* pts, int n_elems, int d, const float*
         else sample_body(e, pts, d, lb, ub, seed, draw);
     }
 }
+// device-counter variants for the resident optimiser loop: the step index and the samplers' draw counters live in device memory, so one
+// step's launch sequence is the same every step and can be replayed as a graph (engine.cpp: pinn_adam_steps)
+inline void launch_adam_dev(float* theta, float* m, float* v, const float* grad, int P, float lr, float b1, float b2, float eps, const float* c12, const int* step, plat_stream st) {
+    launch_adam(theta, m, v, grad, P, lr, b1, b2, eps, c12[2 * step[0]], c12[2 * step[0] + 1], st);
+}
+inline void launch_total_loss_dev(double* hist, const int* step, const float* out, int P, int K, const float* w_over_n, plat_stream st) {
+    launch_total_loss(hist, step[0], out, P, K, w_over_n, st);
+}
+inline void launch_sample_dev(int kind, float* pts, int n_elems, int d, const float* lb, const float* ub, unsigned seed, const unsigned* draw, plat_stream st) {
+    launch_sample(kind, pts, n_elems, d, lb, ub, seed, draw[0], st);
+}
+inline void launch_advance(int* step, unsigned* draws, const int* sampled, int K, plat_stream) {
+    for (int t = 0; t < K; ++t) if (sampled[t]) ++draws[t];
+    ++step[0];
+}
 inline void launch_src(const SrcArgs& a, plat_stream) {
     for (int p = 0; p < a.N; ++p) src_point(p, a);
 }
@@ -380,6 +395,40 @@ inline void launch_sample(int kind, float* pts, int n_elems, int d, const float*
     if (kind == 3) hipLaunchKernelGGL(k_sample_sobol, dim3((n_elems + 255) / 256), dim3(256), 0, st, pts, n_elems, d, lb, ub, seed, draw);
     else if (kind == 2) hipLaunchKernelGGL(k_sample_lhs, dim3((n_elems + 255) / 256), dim3(256), 0, st, pts, n_elems, d, lb, ub, seed, draw);
     else hipLaunchKernelGGL(k_sample, dim3((n_elems + 255) / 256), dim3(256), 0, st, pts, n_elems, d, lb, ub, seed, draw);
+}
+// device-counter variants for the resident optimiser loop (see the emulation section above)
+__global__ void k_adam_dev(float* theta, float* m, float* v, const float* grad, int P, float lr, float b1, float b2, float eps, const float* c12, const int* step) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = step[0];
+    if (i < P) adam_body(i, theta, m, v, grad, lr, b1, b2, eps, c12[2 * s], c12[2 * s + 1]);
+}
+__global__ void k_total_loss_dev(double* hist, const int* step, const float* out, int P, int K, const float* w_over_n) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) total_loss_body(hist, step[0], out, P, K, w_over_n);
+}
+__global__ void k_sample_dev(int kind, float* pts, int n_elems, int d, const float* lb, const float* ub, unsigned seed, const unsigned* draw) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_elems) return;
+    const unsigned dr = draw[0];
+    if (kind == 3) sample_sobol_body(e, pts, d, lb, ub, seed, dr);
+    else if (kind == 2) sample_lhs_body(e, pts, d, n_elems / d, lb, ub, seed, dr);
+    else sample_body(e, pts, d, lb, ub, seed, dr);
+}
+__global__ void k_advance(int* step, unsigned* draws, const int* sampled, int K) {
+    const int t = threadIdx.x;
+    if (t < K && sampled[t]) ++draws[t];
+    if (t == 0) ++step[0];
+}
+inline void launch_adam_dev(float* theta, float* m, float* v, const float* grad, int P, float lr, float b1, float b2, float eps, const float* c12, const int* step, plat_stream st) {
+    hipLaunchKernelGGL(k_adam_dev, dim3((P + 255) / 256), dim3(256), 0, st, theta, m, v, grad, P, lr, b1, b2, eps, c12, step);
+}
+inline void launch_total_loss_dev(double* hist, const int* step, const float* out, int P, int K, const float* w_over_n, plat_stream st) {
+    hipLaunchKernelGGL(k_total_loss_dev, dim3(1), dim3(64), 0, st, hist, step, out, P, K, w_over_n);
+}
+inline void launch_sample_dev(int kind, float* pts, int n_elems, int d, const float* lb, const float* ub, unsigned seed, const unsigned* draw, plat_stream st) {
+    hipLaunchKernelGGL(k_sample_dev, dim3((n_elems + 255) / 256), dim3(256), 0, st, kind, pts, n_elems, d, lb, ub, seed, draw);
+}
+inline void launch_advance(int* step, unsigned* draws, const int* sampled, int K, plat_stream st) {
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(256), 0, st, step, draws, sampled, K);
 }
 __global__ void __launch_bounds__(256) k_expr(const ExprArgs a) {
     __shared__ double sh[5][256];

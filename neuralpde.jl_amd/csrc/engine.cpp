@@ -295,7 +295,7 @@ int pinn_destroy(pinn_handle h) {
     pinn_comm_destroy(h);
     plat_sync(E.stream);
     for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_resid); plat_free(T.d_lb); plat_free(T.d_ub); plat_free(T.d_src_prog); plat_free(T.d_src); plat_free(T.d_data); plat_free(T.d_pw); }
-    plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist);
+    plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist); plat_free(E.d_step); plat_free(E.d_draws); plat_free(E.d_sampled); plat_free(E.d_c12);
     for (auto& G : E.groups) {
         plat_free(G.d_prog); plat_free(G.d_slabs); plat_free(G.d_losspart); plat_free(G.d_scratch); plat_free(G.d_rec);
         plat_free(G.d_tmp);
@@ -750,6 +750,68 @@ int pinn_adam_init(pinn_handle h, const float* theta, int64_t p) {
     return 0;
 }
 
+// pinn_adam_steps through a hipGraph (PINN_GRAPH=1; see the note there).  Returns 0 when all nsteps ran, 1 when the graph could not be
+// built (nothing has run then; the caller takes the plain loop) — a failure INSIDE a step is reported through g_err as usual.
+static int adam_steps_graph(pinn_engine& E, int nsteps, float lr, float beta1, float beta2, float eps, const float* term_w) {
+    const int K = (int)E.terms.size(), P = (int)E.ntheta;
+    if (!E.d_step) {
+        E.d_step = (int*)plat_malloc(sizeof(int));
+        E.d_draws = (unsigned*)plat_malloc(sizeof(unsigned) * K);
+        E.d_sampled = (int*)plat_malloc(sizeof(int) * K);
+        if (!E.d_step || !E.d_draws || !E.d_sampled) return 1;
+    }
+    if (E.c12_cap < nsteps) {
+        plat_sync(E.stream);
+        plat_free(E.d_c12);
+        E.d_c12 = (float*)plat_malloc(sizeof(float) * 2 * (size_t)nsteps);
+        E.c12_cap = E.d_c12 ? nsteps : 0;
+        if (!E.d_c12) return 1;
+    }
+    std::vector<float> c12(2 * (size_t)nsteps);
+    for (int s = 0; s < nsteps; ++s) {
+        c12[2 * s] = (float)(1.0 / (1.0 - std::pow((double)beta1, (double)(E.opt_t + s + 1))));
+        c12[2 * s + 1] = (float)(1.0 / (1.0 - std::pow((double)beta2, (double)(E.opt_t + s + 1))));
+    }
+    std::vector<unsigned> draws(K);
+    std::vector<int> sampled(K);
+    const int zero = 0;
+    for (int t = 0; t < K; ++t) { draws[t] = E.terms[t].draws; sampled[t] = E.terms[t].sampler != 0; }
+    plat_h2d(E.d_c12, c12.data(), sizeof(float) * c12.size(), E.stream);
+    plat_h2d(E.d_draws, draws.data(), sizeof(unsigned) * K, E.stream);
+    plat_h2d(E.d_sampled, sampled.data(), sizeof(int) * K, E.stream);
+    plat_h2d(E.d_step, &zero, sizeof(int), E.stream);
+    if (plat_sync(E.stream)) return 1;                           // (the host vectors above are pageable)
+    auto one_step = [&]() -> int {
+        for (size_t t = 0; t < E.terms.size(); ++t) {
+            Term& T = E.terms[t];
+            if (T.sampler != 0) {
+                aux::launch_sample_dev(T.sampler, T.d_pts, (int)(T.n * T.d), T.d, T.d_lb, T.d_ub, T.seed, E.d_draws + t, E.stream);
+                eval_sources(E, T);
+            }
+        }
+        if (run_loss_grad(E, E.d_opt_theta, E.d_opt_out, term_w, -1, false)) return 1;
+        aux::launch_total_loss_dev(E.d_hist, E.d_step, E.d_opt_out, P, K, E.d_w_over_n, E.stream);
+        aux::launch_adam_dev(E.d_opt_theta, E.d_opt_m, E.d_opt_v, E.d_opt_out, P, lr, beta1, beta2, eps, E.d_c12, E.d_step, E.stream);
+        aux::launch_advance(E.d_step, E.d_draws, E.d_sampled, K, E.stream);
+        return 0;
+    };
+    int done = 0;
+    if (one_step()) return 1;                                    // first step outside the capture: lazy allocations and module loads happen here
+    done = 1;
+    plat_graph graph;
+    bool ok = plat_graph_capture_begin(E.stream);
+    if (ok) {
+        const int rc = one_step();
+        ok = plat_graph_capture_end(E.stream, graph) && rc == 0;
+    }
+    for (; ok && done < nsteps; ++done)
+        if (!plat_graph_launch(graph, E.stream)) ok = false;
+    plat_graph_destroy(graph);
+    for (; done < nsteps; ++done)                                // no graph (emulation, or the capture failed): same kernels, launched one by one
+        if (one_step()) return 1;
+    return 0;
+}
+
 int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta2, float eps, const float* term_w, double* loss_history) {
     if (!h) return fail("null handle");
     pinn_engine& E = *h;
@@ -767,20 +829,32 @@ int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta
     std::vector<float> wn(K);
     for (int k = 0; k < K; ++k) wn[k] = (term_w ? term_w[k] : 1.0f) / (float)E.terms[k].n_norm;
     plat_h2d(E.d_w_over_n, wn.data(), sizeof(float) * K, E.stream);
-    for (int s = 0; s < nsteps; ++s) {
-        for (size_t t = 0; t < E.terms.size(); ++t) {            // resampling strategies: fresh points every evaluation, on device
-            Term& T = E.terms[t];
-            if (T.sampler != 0) {
-                aux::launch_sample(T.sampler, T.d_pts, (int)(T.n * T.d), T.d, T.d_lb, T.d_ub, T.seed, T.draws++, E.stream);
-                eval_sources(E, T);
+    // Default: plain launches, the step index / bias corrections / draw counters as kernel arguments.
+    // PINN_GRAPH=1 (experiment, kept for reproduction): everything that changes from step to step lives in device memory and is advanced
+    // by a kernel, so every step issues the SAME launch sequence, which is recorded once from the stream and replayed as a hipGraph.
+    // Measured on MI355X / ROCm 7.2 (tools/time_adam_loop.py): the replay is SLOWER than the plain launches — cfg1 (1,026 points, 8 small
+    // kernels per step) 69 vs 62 us per iteration, cfg2 401 vs 390 us: the loop is bound by the dependent kernels' own latencies, not by
+    // host launch cost, and the graph's kernel nodes do not start any closer together than stream launches do.
+    const bool want_graph = std::getenv("PINN_GRAPH") != nullptr;       // (read per call: the tests switch it)
+    if (want_graph && nsteps >= 8 && K <= 256 && adam_steps_graph(E, nsteps, lr, beta1, beta2, eps, term_w) == 0) {
+        E.opt_t += nsteps;
+        for (auto& T : E.terms) if (T.sampler != 0) T.draws += (unsigned)nsteps;
+    } else {
+        for (int s = 0; s < nsteps; ++s) {
+            for (size_t t = 0; t < E.terms.size(); ++t) {            // resampling strategies: fresh points every evaluation, on device
+                Term& T = E.terms[t];
+                if (T.sampler != 0) {
+                    aux::launch_sample(T.sampler, T.d_pts, (int)(T.n * T.d), T.d, T.d_lb, T.d_ub, T.seed, T.draws++, E.stream);
+                    eval_sources(E, T);
+                }
             }
+            if (run_loss_grad(E, E.d_opt_theta, E.d_opt_out, term_w, -1, false)) return 1;
+            aux::launch_total_loss(E.d_hist, s, E.d_opt_out, P, K, E.d_w_over_n, E.stream);
+            ++E.opt_t;
+            const float c1 = (float)(1.0 / (1.0 - std::pow((double)beta1, (double)E.opt_t)));
+            const float c2 = (float)(1.0 / (1.0 - std::pow((double)beta2, (double)E.opt_t)));
+            aux::launch_adam(E.d_opt_theta, E.d_opt_m, E.d_opt_v, E.d_opt_out, P, lr, beta1, beta2, eps, c1, c2, E.stream);
         }
-        if (run_loss_grad(E, E.d_opt_theta, E.d_opt_out, term_w, -1, false)) return 1;
-        aux::launch_total_loss(E.d_hist, s, E.d_opt_out, P, K, E.d_w_over_n, E.stream);
-        ++E.opt_t;
-        const float c1 = (float)(1.0 / (1.0 - std::pow((double)beta1, (double)E.opt_t)));
-        const float c2 = (float)(1.0 / (1.0 - std::pow((double)beta2, (double)E.opt_t)));
-        aux::launch_adam(E.d_opt_theta, E.d_opt_m, E.d_opt_v, E.d_opt_out, P, lr, beta1, beta2, eps, c1, c2, E.stream);
     }
     if (loss_history && plat_d2h(loss_history, E.d_hist, sizeof(double) * nsteps, E.stream)) return fail("D2H copy failed");
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());

@@ -192,6 +192,13 @@ struct pinn_engine {
     double* d_hist = nullptr;
     int hist_cap = 0;
     long long opt_t = 0;
+    // device-side step state of the resident loop (pinn_adam_steps): [0] = step index of the current call; draw counters and the
+    // sampled-term mask per term; bias-correction table [2 x steps]
+    int* d_step = nullptr;
+    unsigned* d_draws = nullptr;
+    int* d_sampled = nullptr;
+    float* d_c12 = nullptr;
+    int c12_cap = 0;
     // phi scratch
     float* d_phi_pts = nullptr;
     float* d_phi_out = nullptr;

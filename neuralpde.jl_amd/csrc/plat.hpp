@@ -22,6 +22,11 @@ inline int plat_d2h(void* d, const void* s, size_t n, plat_stream) { std::memcpy
 inline int plat_d2d(void* d, const void* s, size_t n, plat_stream) { std::memcpy(d, s, n); return 0; }
 inline int plat_memset(void* d, int v, size_t n, plat_stream) { std::memset(d, v, n); return 0; }
 inline int plat_sync(plat_stream) { return 0; }
+struct plat_graph { int unused = 0; };
+inline bool plat_graph_capture_begin(plat_stream) { return false; }        // the emulation has no graphs: callers run the plain loop
+inline bool plat_graph_capture_end(plat_stream, plat_graph&) { return false; }
+inline bool plat_graph_launch(plat_graph&, plat_stream) { return false; }
+inline void plat_graph_destroy(plat_graph&) {}
 inline int plat_num_cus() { return 2; }
 inline int plat_device_count() { return 8; }            // the emulation pretends to be an 8-device node (host memory: "devices" are labels)
 inline int plat_get_device() { return 0; }
@@ -86,4 +91,18 @@ inline void plat_event_record(plat_event& e, plat_stream s) { (void)hipEventReco
 inline void plat_event_sync(plat_event& e) { (void)hipEventSynchronize(e.e); }
 inline void plat_stream_wait_event(plat_stream s, plat_event& e) { (void)hipStreamWaitEvent(s, e.e, 0); }
 inline float plat_event_ms(plat_event& a, plat_event& b) { float ms = 0.f; (void)hipEventElapsedTime(&ms, a.e, b.e); return ms; }
+// hipGraph of a launch sequence recorded from a stream (the resident optimiser loop replays one step's graph)
+struct plat_graph { hipGraph_t g = nullptr; hipGraphExec_t x = nullptr; };
+inline bool plat_graph_capture_begin(plat_stream s) { return hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess; }
+inline bool plat_graph_capture_end(plat_stream s, plat_graph& G) {
+    if (hipStreamEndCapture(s, &G.g) != hipSuccess || !G.g) { G.g = nullptr; (void)hipGetLastError(); return false; }
+    if (hipGraphInstantiate(&G.x, G.g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(G.g); G.g = nullptr; G.x = nullptr; (void)hipGetLastError(); return false; }
+    return true;
+}
+inline bool plat_graph_launch(plat_graph& G, plat_stream s) { return hipGraphLaunch(G.x, s) == hipSuccess; }
+inline void plat_graph_destroy(plat_graph& G) {
+    if (G.x) (void)hipGraphExecDestroy(G.x);
+    if (G.g) (void)hipGraphDestroy(G.g);
+    G.x = nullptr; G.g = nullptr;
+}
 #endif

@@ -339,6 +339,28 @@ def test_resident_adam_matches_host_adam_and_sampler(npde, use_emu):
     assert not np.array_equal(np.argsort(draws[0][0]), np.argsort(draws[0][1]))      # axes are permuted independently
 
 
+def test_adam_loop_graph_replay_matches_plain_launches(npde, use_emu, monkeypatch):
+    """PINN_GRAPH=1 (step index, bias corrections and draw counters in device memory, one step recorded and replayed as a hipGraph; on
+    the emulation: the same device-counter kernels launched one by one) reproduces the default loop bit for bit, with fixed point sets
+    and with on-device resampling, across a resume."""
+    sysm, chain = poisson2d(npde)
+    th0 = theta_for(chain, 53)
+    for strat in (lambda: npde.GridTraining(0.25), lambda: npde.StochasticTraining(64, bcs_points=32, rng=np.random.default_rng(3))):
+        out = []
+        for graph in (False, True):
+            if graph:
+                monkeypatch.setenv("PINN_GRAPH", "1")
+            else:
+                monkeypatch.delenv("PINN_GRAPH", raising=False)
+            prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, strat(), init_params=th0))
+            res = npde.solve(prob, npde.Adam(0.01), maxiters=20)
+            res_b = npde.solve(npde.remake(prob, u0=res.u), npde.Adam(0.01), maxiters=12)
+            out.append((np.asarray(res.losses), res.u, np.asarray(res_b.losses), res_b.u))
+        for a, b in zip(out[0], out[1]):
+            assert np.array_equal(a, b)
+    monkeypatch.delenv("PINN_GRAPH", raising=False)
+
+
 def test_device_sobol_sampler_matches_reference_sequence(npde, use_emu):
     """kind-3 device sampler == elements 1..n of the un-randomised Sobol' sequence (Joe-Kuo direction numbers, Gray-code order,
     first element skipped as Sobol.jl does): bit-exact against scipy.stats.qmc.Sobol(scramble=False), which shares the table;
