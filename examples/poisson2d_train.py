@@ -13,6 +13,7 @@ from neuralpde_jl_amd import workloads
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 6000
 lr = float(sys.argv[2]) if len(sys.argv) > 2 else 3e-3
+decay = float(sys.argv[3]) if len(sys.argv) > 3 else 0.6          # step-size factor per 1000 iterations
 wl = workloads.cfg2_poisson2d(points=65536)
 rng = np.random.default_rng(0)
 theta0 = np.concatenate([npde.initialparameters(rng, ch) for ch in wl.chains])          # glorot weights, zero biases (Lux default)
@@ -29,7 +30,7 @@ while done < iters:
     n = min(1000, iters - done)
     p = npde.remake(prob, u0=theta)
     t0 = time.perf_counter()
-    res = npde.solve(p, npde.Adam(lr * (0.5 ** (done // 2000))), maxiters=n)       # halve the step every 2000 iterations
+    res = npde.solve(p, npde.Adam(lr * (decay ** (done // 1000))), maxiters=n)      # (every solve starts Adam afresh, as solve(remake(prob, u0 = res.u)) does in the reference)
     t_total += time.perf_counter() - t0
     theta, done = res.u, done + n
     u = prob.pinnrep.phi(grid, theta)[0]

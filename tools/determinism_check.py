@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Bit-reproducibility probe on a GPU box: repeated loss+gradient evaluations of a workload must be bit-identical (fixed-order
-reductions, no float atomics).  Usage: python tools/determinism_check.py [cfg4|cfg5|cfg2] [reps]; PINN_AB_LIB selects another build."""
+reductions, no float atomics).  Usage: [FULL=1] python tools/determinism_check.py [cfg2|cfg3|cfg4|cfg5] [reps]; PINN_AB_LIB selects another build."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,9 +12,11 @@ if os.environ.get("PINN_AB_LIB"):
     npde._lib.set_library(npde.Library(os.environ["PINN_AB_LIB"]))
 which = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-wl = {"cfg4": lambda: workloads.cfg4_cavity(points=3000, bcs_points=400, width=128, hidden=5),
-      "cfg5": lambda: workloads.cfg5_heat_inverse(points=4000, bcs_points=500),
-      "cfg2": lambda: workloads.cfg2_poisson2d(points=8192)}[which]()
+full = os.environ.get("FULL") is not None             # FULL=1: the BASELINE sizes (every workgroup runs many tiles)
+wl = {"cfg4": lambda: workloads.cfg4_cavity(points=262144, bcs_points=32768) if full else workloads.cfg4_cavity(points=3000, bcs_points=400, width=128, hidden=5),
+      "cfg5": lambda: workloads.cfg5_heat_inverse(points=1000000 if full else 4000, bcs_points=65536 if full else 500),
+      "cfg3": lambda: workloads.cfg3_burgers(points=262144 if full else 8192),
+      "cfg2": lambda: workloads.cfg2_poisson2d(points=65536 if full else 8192)}[which]()
 rep = npde.symbolic_discretize(wl.pde_system, wl.discretization())
 eng = rep.engine
 print(eng.describe().split("term")[0])
