@@ -271,13 +271,24 @@ AUX_DEV void reduce1_body(int e4, int chunk, int g, const Reduce1Args& a) {
 }
 AUX_DEV void reduce2_body(int r, const Reduce2Args& a) {
     if (r < a.P) {
+        // contributions in batches of 4: their index loads (map -> group -> chunk row) are issued together, then the values are added
+        // in the fixed map order — one contribution at a time the three dependent loads of each were serialised (12 us for a 2,209-
+        // parameter net with 8 contributions per element)
         double s = 0.0;
-        for (int i = a.row_ptr[r]; i < a.row_ptr[r + 1]; ++i) {
-            const int g = a.row_grp[i];
-            if (!a.ent_active[g]) continue;
-            const double* t = a.tmp[g] + (size_t)a.row_ent[i] * a.nsplit[g];
-            AUX_UNROLL8
-            for (int ch = 0; ch < a.nsplit[g]; ++ch) s += t[ch];
+        const int i0 = a.row_ptr[r], i1 = a.row_ptr[r + 1];
+        for (int i = i0; i < i1; i += 4) {
+            const double* t[4];
+            int ns[4];
+            for (int j = 0; j < 4; ++j) {
+                const int ii = (i + j < i1) ? i + j : i;
+                const int g = a.row_grp[ii];
+                ns[j] = (i + j < i1 && a.ent_active[g]) ? a.nsplit[g] : 0;
+                t[j] = a.tmp[g] + (size_t)a.row_ent[ii] * a.nsplit[g];
+            }
+            for (int j = 0; j < 4; ++j) {
+                AUX_UNROLL8
+                for (int ch = 0; ch < ns[j]; ++ch) s += t[j][ch];
+            }
         }
         a.out[r] = (float)s;
     } else if (r < a.P + a.K) {

@@ -166,7 +166,10 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
             blocks = std::max(1, std::min(G.max_blocks, G.spec->family == 1 ? (ga_one.ntiles + 3) / 4 : ga_one.ntiles));
             ga_launch = &ga_one;
         }
-        const int nsplit_g = std::min(REDUCE_SPLIT, blocks);
+        // stage-1 chunks: the serial part of the two-stage sum is (blocks / chunks) loads in stage 1 plus (chunks x slab entries per theta
+        // element: 4 per-wave copies in family 1, 1 in the others) in stage 2 — shortest for chunks ~ sqrt(blocks / entries)
+        const int epe = G.spec->family == 1 ? 4 : 1;
+        const int nsplit_g = std::max(1, std::min(REDUCE_SPLIT, (int)std::ceil(std::sqrt((double)blocks / epe))));
         a1.slab[g] = G.slab_floats; a1.nblocks[g] = blocks; a1.nsplit[g] = nsplit_g; a1.nent[g] = nent; a1.active[g] = any; a1.nwpb[g] = G.spec->NW;
         a2.tmp[g] = G.d_tmp; a2.stride[g] = nent + K; a2.nsplit[g] = nsplit_g; a2.nent[g] = nent; a2.active[g] = any;
         a2.ent_active[g] = any && !chained;
