@@ -610,7 +610,12 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
         kind = 2 if isinstance(strategy.sampling_alg, LatinHypercubeSample) else (3 if isinstance(strategy.sampling_alg, SobolSample) else 0)
     if kind:
         pb, bb = get_bounds(pde_system.domain, eqs, bcs, np.float64, vi, strategy.points)
-        rng = getattr(strategy, "rng", None) or np.random.default_rng()
+        # the device samplers' seeds come from the strategy's own generator (StochasticTraining.rng, LatinHypercubeSample.rng) or seed
+        # (SobolSample.seed), so a seeded strategy gives a reproducible run; an unseeded one draws fresh seeds
+        alg = getattr(strategy, "sampling_alg", None)
+        rng = getattr(strategy, "rng", None) or getattr(alg, "rng", None)
+        if rng is None:
+            rng = np.random.default_rng(getattr(alg, "seed", None))
         rep._device_samplers = {}
         for k, (lb, ub) in enumerate(list(pb) + list(bb)):
             seed = int(rng.integers(1, 1 << 31))
