@@ -13,7 +13,7 @@ from .ir import Instr, NetIR, ProblemIR, Slot, TermIR
 from .bpinn import loglikelihood, physics_loglikelihood
 from .adaptive import (AbstractAdaptiveLoss, GradientScaleAdaptiveLoss, MiniMaxAdaptiveLoss, ReLoBRaLoAdaptiveLoss,
                        SoftAdaptAdaptiveLoss)
-from .pinn import (DGM, DeepGalerkin, DataLoss, depvar_params, Adam, OptimizationSolution, solve, Chain, Dense, LogOptions, NonAdaptiveLoss, OptimizationFunction, OptimizationProblem, Phi,
+from .pinn import (DGM, DeepGalerkin, DataLoss, depvar_params, Adam, BFGS, LBFGS, OptimizationSolution, solve, Chain, Dense, LogOptions, NonAdaptiveLoss, OptimizationFunction, OptimizationProblem, Phi,
                    PhysicsInformedNN, PINNLossFunctions, PINNRepresentation, discretize, initialparameters, remake,
                    symbolic_discretize)
 from .strategies import (AbstractTrainingStrategy, QuadratureTraining, GridTraining, LatinHypercubeSample, QuasiRandomTraining,

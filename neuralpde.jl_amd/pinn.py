@@ -298,6 +298,21 @@ class Adam:
 
 
 @dataclass
+class BFGS:
+    """[3P] OptimizationOptimJL.BFGS() — the quasi-Newton finisher of the reference's tests (e.g. test/NNPDE1/nnpde__pde_ii_2d_poisson.jl:86).
+    Mirror: scipy's BFGS on the HOST over the engine's fused `value_and_grad` (one device evaluation per objective call, float64 iterates,
+    fp32 evaluation); needs a fixed objective, i.e. fixed point sets — as the reference's own comments require (`resampling = false`)."""
+    gtol: float = 1e-8
+
+
+@dataclass
+class LBFGS:
+    """[3P] OptimizationOptimJL.LBFGS(): scipy's L-BFGS-B on the host, see BFGS."""
+    m: int = 10
+    gtol: float = 1e-8
+
+
+@dataclass
 class OptimizationSolution:
     u: np.ndarray
     objective: float
@@ -312,6 +327,8 @@ def solve(prob: OptimizationProblem, alg: Adam, maxiters: int = 1000, callback: 
     rep = prob.pinnrep
     eng = rep.engine
     eng_resample = getattr(rep, "_device_samplers", None)
+    if isinstance(alg, (BFGS, LBFGS)):
+        return _host_quasi_newton(prob, alg, maxiters, callback)
     if eng_resample and not rep._state.get("samplers_installed"):
         # installed ONCE per discretisation: a second solve (the resume idiom solve(remake(prob, u0 = res.u))) continues the
         # device draw counters instead of replaying the first run's point sequence
@@ -368,6 +385,46 @@ def _host_adam(prob: OptimizationProblem, alg: Adam, maxiters: int, callback) ->
         if callback is not None and callback({"iter": it, "u": theta.copy()}, float(val)):
             break
     return OptimizationSolution(theta.astype(prob.u0.dtype), float(losses[-1]), np.array(losses))
+
+
+def _host_quasi_newton(prob: OptimizationProblem, alg, maxiters: int, callback) -> OptimizationSolution:
+    """BFGS / LBFGS of the reference's test scripts: scipy.optimize.minimize on the host, every objective call = ONE fused device
+    evaluation through `prob.f.value_and_grad`.  The objective must not change between calls (fixed point sets)."""
+    from scipy.optimize import minimize
+    rep = prob.pinnrep
+    if getattr(rep, "_device_samplers", None) or rep._state.get("resample") is not None:
+        raise ValueError("BFGS / LBFGS need a fixed objective: use GridTraining, QuadratureTraining or QuasiRandomTraining(...; resampling = false, "
+                         "minibatch = 1) (the reference's tests say the same, e.g. test/NNPDE1/nnpde__pde_vi_pde_with_mixed_derivative.jl:76)")
+    losses, it, last = [], [0], [None]
+
+    def fun(th):
+        val, g = prob.f.value_and_grad(th)
+        return float(val), np.asarray(g, dtype=np.float64)
+
+    class _Stop(Exception):
+        pass
+
+    def cb(th):
+        it[0] += 1
+        last[0] = np.asarray(th, dtype=np.float64).copy()
+        val, _ = fun(th) if callback is not None else (np.nan, None)
+        losses.append(val)
+        if callback is not None and callback({"iter": it[0], "u": np.asarray(th).copy()}, float(val)):
+            raise _Stop
+    x0 = np.asarray(prob.u0, dtype=np.float64).copy()
+    method, opts = ("BFGS", {"maxiter": int(maxiters), "gtol": alg.gtol}) if isinstance(alg, BFGS) else \
+        ("L-BFGS-B", {"maxiter": int(maxiters), "maxcor": alg.m, "gtol": alg.gtol, "ftol": 0.0})
+    try:
+        out = minimize(fun, x0, jac=True, method=method, callback=cb, options=opts)
+        theta, final = out.x, float(out.fun)
+    except _Stop:
+        theta, final = None, None
+    if theta is None:                                   # stopped by the callback: the last iterate it saw
+        theta = last[0] if last[0] is not None else x0
+    if final is None:
+        final = fun(theta)[0]
+    rep.iteration[0] += it[0]
+    return OptimizationSolution(np.asarray(theta).astype(prob.u0.dtype), final, np.array(losses if callback is not None else [final]))
 
 
 def remake(prob: OptimizationProblem, u0=None) -> OptimizationProblem:
