@@ -231,14 +231,14 @@ function chain_lines(i::Int, chain, θoff::Int, depvar::Symbol, inputs)
 end
 
 """
-    descriptor(pinnrep) -> String
+    descriptor(pinnrep; hints = Int[]) -> String
 
 The "pinnir 2" text handed to `pinn_create` (grammar: DESIGN.md §2).  θ layout = `pinnrep.flat_init_params` (src/discretize.jl:451-465):
 `[depvar 1: W1 (out×in, column-major) | b1 | W2 | b2 … | depvar 2 … | p]` — the order ComponentArrays flattens Lux's
 `(layer_1 = (weight, bias), …)` NamedTuples in; `verify_layout` checks it numerically.  Coordinate rows of term k =
 `this_eq_indvars` of `build_symbolic_loss_function` (src/discretize.jl:41-43), computed with the reference's own `pair`.
 """
-function descriptor(pinnrep::PINNRepresentation)
+function descriptor(pinnrep::PINNRepresentation; hints::AbstractVector{<:Integer} = Int[])
     (; eqs, bcs, eq_params, default_p, param_estim, depvars, dict_depvars, dict_depvar_input, flat_init_params) = pinnrep
     chains = chains_of(pinnrep)
     length(chains) == length(depvars) || throw(HIPEngineError("$(length(depvars)) dependent variables need $(length(depvars)) single-output chains"))
@@ -268,6 +268,11 @@ function descriptor(pinnrep::PINNRepresentation)
         isempty(this_eq_indvars) && throw(ArgumentError("equation $k does not contain a dependent variable"))
         l, r = equation_sexprs(eq)
         push!(lines, "sterm $(k - 1) $(length(this_eq_indvars)) " * join(this_eq_indvars, " "), "lhs " * l, "rhs " * r)
+    end
+    # optional tail: `hint <term> <points>` — the sizes of the sets about to be installed; lets the planner put a boundary condition of a
+    # few points onto a launch its network already has instead of giving it a launch of its own (csrc/plan.cpp)
+    for (k, n) in enumerate(hints)
+        n > 0 && push!(lines, "hint $(k - 1) $n")
     end
     return join(lines, "\n") * "\n"
 end
@@ -390,9 +395,9 @@ point_sets(pinnrep, s) = throw(HIPEngineError("HIPStrategy wraps GridTraining, S
                                               "QuadratureTraining's adaptive cubature is a host algorithm"))
 
 function build_state(pinnrep::PINNRepresentation, inner)
-    engine = HIPEngine(descriptor(pinnrep))
-    verify_layout(engine, pinnrep)
     sets, resample = point_sets(pinnrep, inner)
+    engine = HIPEngine(descriptor(pinnrep; hints = [size(s, 2) for s in sets]))
+    verify_layout(engine, pinnrep)
     for (k, s) in enumerate(sets)
         set_points!(engine, k, s)
     end

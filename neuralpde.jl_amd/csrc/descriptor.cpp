@@ -185,6 +185,16 @@ int parse_descriptor(const char* text, pinn_engine& E) {
             T.inmap[net] = m;
         }
     }
+    // optional, after the terms: `hint <term> <points>` — how many points the caller is going to install for the term.  The planner uses it
+    // to let SMALL value-only terms (a boundary condition at one or two points) ride on a launch the network already has instead of paying a
+    // launch of their own (plan.cpp: plan_assign_terms); without hints every channel set gets its own launch group.
+    for (;;) {
+        std::string t2;
+        if (!(in >> t2)) break;
+        long long id = -1, n = 0;
+        if (t2 != "hint" || !(in >> id >> n) || id < 0 || id >= nt || n < 0) return fail("descriptor: trailing text after the last term (expected `hint <term> <points>`)");
+        E.terms[id].hint_n = n;
+    }
     return 0;
 }
 

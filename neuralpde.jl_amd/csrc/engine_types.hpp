@@ -84,6 +84,7 @@ struct Term {
     int64_t pw_n = 0, pw_cap = 0;
     // data
     float* d_pts = nullptr;
+    long long hint_n = 0;            // descriptor `hint`: points the caller expects to install (0: unknown)
     int64_t pts_cap = 0;             // points d_pts has room for (grows, never shrinks: resampled sets of varying size reuse it)
     int64_t n = 0, n_norm = 0;
     float* d_resid = nullptr;

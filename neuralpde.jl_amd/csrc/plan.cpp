@@ -145,6 +145,22 @@ const pk::SpecInfo* find_spec(int HP, int NHH, int D, unsigned need_first, const
     return best;
 }
 
+// does kernel `s` (fixed channel categories) carry every channel of the needs?  (the superset test of find_spec for ONE kernel)
+static bool spec_covers(const pk::SpecInfo& s, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs, unsigned need_hi) {
+    if (s.family == 3 || s.ngen > 0 || (need_hi & GEN_FLAG)) return false;
+    if ((s.D1MASK & need_first) != need_first) return false;
+    for (int a = 0; a < 6; ++a)
+        if (((need_hi >> (4 * a)) & 0xF) > ((s.HI >> (4 * a)) & 0xF)) return false;
+    if ((need_hi >> 24) && (need_hi >> 24) != s.LAP) return false;
+    for (auto& pr : need_pairs) {
+        bool f = false;
+        for (int p = 0; p < s.NPAIR; ++p)
+            f = f || ((int)((s.PAIRS >> (8 * p)) & 0xF) == pr.first && (int)((s.PAIRS >> (8 * p + 4)) & 0xF) == pr.second);
+        if (!f) return false;
+    }
+    return true;
+}
+
 int first_rank(const pk::SpecInfo& s, int axis) {
     int c = 0;
     for (int a = 0; a < axis; ++a)
@@ -419,7 +435,19 @@ static int plan_assign_terms(pinn_engine& E) {
             unsigned need_hi = 0;
             if (needs_of(T, net, need_first, need_pairs, need_hi)) return 1;
             const pk::SpecInfo* sp = nullptr;
-            if (spec_for(t, net, T.d, need_first, need_pairs, need_hi, sp)) return 1;
+            // A SMALL term (descriptor `hint`: a boundary condition at a handful of points) rides on a launch group this network already
+            // has when that group's kernel carries its channels: a few extra tiles there cost less than a launch of its own (family 1,
+            // one tile per wave: ~20 us per launch whatever the point count; measured on cfg1: 58 -> 37 us per evaluation).  Decided
+            // before the term's own kernel is looked up, so a run-time specialised shape does not compile a kernel it will not use.
+            static const bool no_ride = std::getenv("PINN_NO_RIDE") != nullptr;
+            if (!no_ride && T.hint_n > 0 && !(need_hi & GEN_FLAG))
+                for (size_t g = 0; g < E.groups.size() && !sp; ++g) {
+                    const Group& H = E.groups[g];
+                    if (H.kind != 0 || H.net != net || H.spec->family == 3 || (int)H.terms.size() >= pk::MAX_GROUP_TERMS) continue;
+                    if (T.hint_n > (H.spec->family == 1 ? 256 : 64)) continue;
+                    if (spec_covers(*H.spec, need_first, need_pairs, need_hi)) sp = H.spec;
+                }
+            if (!sp && spec_for(t, net, T.d, need_first, need_pairs, need_hi, sp)) return 1;
             T.chan_of_slot.clear();
             for (auto& s : T.slots) {
                 int c = chan_of(*sp, s);

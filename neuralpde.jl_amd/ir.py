@@ -79,7 +79,13 @@ class ProblemIR:
     depvar_names: Sequence[str] = ()
     depvar_inputs: Sequence[Sequence[str]] = ()
 
-    def to_descriptor2(self) -> str:
+    @staticmethod
+    def _hint_lines(hints) -> list:
+        """`hint <term> <points>` lines (optional tail of a descriptor): the point counts the caller is about to install; lets the planner
+        put a boundary condition of a few points onto a launch the network already has (csrc/plan.cpp)."""
+        return [f"hint {k} {int(n)}" for k, n in enumerate(hints or []) if n and n > 0]
+
+    def to_descriptor2(self, hints=None) -> str:
         """"pinnir 2": the equations travel as s-expressions and are lowered inside the library (csrc/sexpr.cpp) — the form the Julia glue
         emits (julia/NeuralPDEHIP.jl).  Terms without a symbolic form (DataLoss tapes) keep their pinnir-1 lines."""
         out = ["pinnir 2", f"ntheta {self.ntheta}",
@@ -98,7 +104,7 @@ class ProblemIR:
             out.append(f"sterm {i} {t.dim} " + " ".join(t.indvars))
             out.append("lhs " + t.lhs_sexpr)
             out.append("rhs " + t.rhs_sexpr)
-        return "\n".join(out) + "\n"
+        return "\n".join(out + self._hint_lines(hints)) + "\n"
 
     def _term_lines(self, i, t):
         out = [f"term {i} {t.dim} {len(t.slots)} {len(t.ops)} {t.out_row}"]
@@ -110,7 +116,7 @@ class ProblemIR:
             out.append(f"inmap {net} {len(m)} " + " ".join(str(i) for i in m))
         return out
 
-    def to_descriptor(self) -> str:
+    def to_descriptor(self, hints=None) -> str:
         out = ["pinnir 1", f"ntheta {self.ntheta}",
                f"params {self.nparams} {self.nparams_estim} {self.p_theta_off}",
                "defaults " + " ".join(repr(float(v)) for v in list(self.p_defaults)[: self.nparams]),
@@ -120,4 +126,4 @@ class ProblemIR:
         out.append(f"terms {len(self.terms)}")
         for i, t in enumerate(self.terms):
             out += self._term_lines(i, t)
-        return "\n".join(out) + "\n"
+        return "\n".join(out + self._hint_lines(hints)) + "\n"

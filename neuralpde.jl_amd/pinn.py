@@ -521,12 +521,12 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
     # PINN_DESCRIPTOR=2: hand the equations to the library as s-expressions (the form the Julia glue emits; lowered by csrc/sexpr.cpp)
     # instead of the tapes lowered by symbolic.py — both front ends must give the same engine (tests/test_sexpr_frontend.py)
     import os as _os
-    engine = _lib.Engine(ir.to_descriptor2() if _os.environ.get("PINN_DESCRIPTOR") == "2" else ir.to_descriptor())
-
-    # ---- strategy: point sets (src/discretize.jl:541-545) ----
+    # ---- strategy: point sets (src/discretize.jl:541-545); their sizes go into the descriptor as planner hints ----
     strategy = discretization.strategy
     pde_sets, bc_sets, resample = strategy.point_sets(pde_system, vi, dtype)
     n_pde, n_bc = len(eqs), len(bcs)
+    hints = [s.shape[1] for s in list(pde_sets) + list(bc_sets)] + [np.asarray(dl.values).size for dl in discretization.data_loss]
+    engine = _lib.Engine(ir.to_descriptor2(hints) if _os.environ.get("PINN_DESCRIPTOR") == "2" else ir.to_descriptor(hints))
 
     def install(pde_sets, bc_sets):
         for k, s in enumerate(list(pde_sets) + list(bc_sets)):

@@ -67,6 +67,23 @@ def test_cfg1_grid_3x32(npde, use_emu):
     u = rep.phi(sets[0], th)
     np.testing.assert_allclose(u, po.phi_values(prob.chains[0], th, sets[0]), atol=1e-6)
     assert abs(rep.phi(np.array([0.3]), th)[0] - po.phi_values(prob.chains[0], th, np.array([[0.3]]))[0, 0]) < 1e-6
+    # the two one-point boundary terms ride on the interior term's launch (descriptor `hint` lines: sizes of the sets about to be installed)
+    groups = [l for l in rep.engine.describe().splitlines() if l.startswith("group")]
+    assert len(groups) == 1 and "terms=0,1,2," in groups[0], groups
+    losses, tg = rep.engine.term_grads(th)
+    ref = po.loss_and_grad(prob, th, sets, mode="stencil", per_term_grads=True)
+    assert np.max(np.abs(tg - ref.term_grads)) / np.max(np.abs(ref.term_grads)) < TOL
+    # the same problem without hints (a caller that does not send them): one launch group per channel set, same numbers
+    import os
+    eng2 = npde._lib.Engine(rep.ir.to_descriptor2() if os.environ.get("PINN_DESCRIPTOR") == "2" else rep.ir.to_descriptor()) if hasattr(rep, "ir") else None
+    if eng2 is not None:
+        assert len([l for l in eng2.describe().splitlines() if l.startswith("group")]) == 2
+        for k, sset in enumerate(sets):
+            eng2.set_points(k, sset)
+        l2, g2 = eng2.loss_grad(th)
+        l1, g1 = rep.engine.loss_grad(th)
+        np.testing.assert_allclose(l2, l1, rtol=1e-6)
+        np.testing.assert_allclose(g2, g1, rtol=0, atol=2e-6 * np.abs(g1).max())
 
 
 def test_cfg2_4x64_small_ragged(npde, use_emu):
@@ -79,7 +96,8 @@ def test_chained_launch_groups_share_one_slab_set(npde, use_emu):
     """interior + boundary launch groups of one 4x64 network: the boundary group's workgroups add onto the interior group's slabs
     (one reduction input); per-term gradients (head group not launched) fall back to the group's own slabs; both vs the oracle."""
     from neuralpde_jl_amd import workloads
-    wl = workloads.cfg2_poisson2d(points=70, bcs_points=30)      # 5 interior tiles / 4 boundary tiles on 4 emulated workgroup slots
+    wl = workloads.cfg2_poisson2d(points=70, bcs_points=70)      # 5 interior tiles / 8 boundary tiles on 4 emulated workgroup slots (more than 64
+                                                                 # points per boundary term: small hinted terms would ride on the interior launch)
     w = np.array([1.0, 2.0, 0.5, 3.0, 1.5])
     rep, _, _, th = check(npde, wl.pde_system, wl.chains, wl.strategy, wl.theta, weights=list(w))
     assert "chained onto group 0" in rep.engine.describe()

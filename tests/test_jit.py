@@ -18,7 +18,7 @@ def test_wide_net_200(npde, use_emu):
     """2 -> 200 -> 200 -> 1 (padded to 256): the shape test_discretizer_errors used to reject."""
     sysm, _ = tp.poisson2d(npde)
     odd = npde.Chain(npde.Dense(2, 200, "tanh"), npde.Dense(200, 200, "tanh"), npde.Dense(200, 1))
-    strat = npde.QuasiRandomTraining(24, bcs_points=10, sampling_alg=npde.SobolSample(seed=4), resampling=False, minibatch=1)
+    strat = npde.QuasiRandomTraining(24, bcs_points=70, sampling_alg=npde.SobolSample(seed=4), resampling=False, minibatch=1)   # (> 64 boundary points: their own launch)
     rep, prob, sets, th = tp.check(npde, sysm, [odd], strat, tp.theta_for(odd, 3))
     kernels = [l.split("kernel=")[1].split()[0] for l in rep.engine.describe().splitlines() if "kernel=" in l]
     assert any("HP256" in k and "L3" in k for k in kernels) and any("HP256" in k and "(C=1)" in k for k in kernels)   # interior (forward Laplacian) + value-only
