@@ -96,7 +96,7 @@ def test_chained_launch_groups_share_one_slab_set(npde, use_emu):
     """interior + boundary launch groups of one 4x64 network: the boundary group's workgroups add onto the interior group's slabs
     (one reduction input); per-term gradients (head group not launched) fall back to the group's own slabs; both vs the oracle."""
     from neuralpde_jl_amd import workloads
-    wl = workloads.cfg2_poisson2d(points=70, bcs_points=70)      # 5 interior tiles / 8 boundary tiles on 4 emulated workgroup slots (more than 64
+    wl = workloads.cfg2_poisson2d(points=200, bcs_points=70)     # 13 interior tiles / 8 boundary tiles (4 emulated workgroup slots; more than 64
                                                                  # points per boundary term: small hinted terms would ride on the interior launch)
     w = np.array([1.0, 2.0, 0.5, 3.0, 1.5])
     rep, _, _, th = check(npde, wl.pde_system, wl.chains, wl.strategy, wl.theta, weights=list(w))
