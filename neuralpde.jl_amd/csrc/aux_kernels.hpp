@@ -7,6 +7,7 @@
 //               into the output vector [P floats grad | K floats raw sums of squares] (+ K doubles for the host path)
 // Every sum has a fixed order => bit-identical results run to run.
 #pragma once
+#include <cstdlib>
 #include "aux_limits.hpp"
 #include "plat.hpp"
 #include "rprog.hpp"
@@ -305,6 +306,44 @@ AUX_DEV void reduce2_body(int r, const Reduce2Args& a) {
     }
 }
 
+// one-stage variant for SMALL launches (every group at most REDUCE_DIRECT_MAX workgroups): theta element r sums its slab entries over the
+// workgroups directly, in the fixed order (map entry, workgroup); two kernels of ~6 us each for a 17-workgroup problem were a third of
+// its evaluation time
+constexpr int REDUCE_DIRECT_MAX = 32;
+AUX_DEV void reduce_direct_body(int r, const Reduce1Args& a1, const Reduce2Args& a) {
+    if (r < a.P) {
+        double s = 0.0;
+        for (int i = a.row_ptr[r]; i < a.row_ptr[r + 1]; ++i) {
+            const int g = a.row_grp[i];
+            if (!a.ent_active[g]) continue;
+            const float* p = a1.slabs[g] + a.row_ent[i];
+            const int nb = a1.nblocks[g], st = a1.slab[g];
+            AUX_UNROLL8
+            for (int b = 0; b < nb; ++b) s += (double)p[(size_t)b * st];
+        }
+        a.out[r] = (float)s;
+    } else if (r < a.P + a.K) {
+        const int k = r - a.P;
+        double s = 0.0;
+        for (int g = 0; g < a.ngroups; ++g) {
+            if (!a.active[g]) continue;
+            const double* p = a1.losspart[g] + k;
+            const int nw = a1.nblocks[g] * a1.nwpb[g];
+            AUX_UNROLL8
+            for (int wv = 0; wv < nw; ++wv) s += p[(size_t)wv * a.K];
+        }
+        a.out[r] = (float)s;
+        if (a.lossraw) a.lossraw[k] = s;
+    }
+}
+
+inline bool reduce_is_small(const Reduce1Args& a1, const Reduce2Args& a2) {
+    const char* e = std::getenv("PINN_REDUCE_DIRECT_MAX");       // (read per call: tests switch between the two paths; 0 = always two stages)
+    const int lim = e ? std::atoi(e) : REDUCE_DIRECT_MAX;
+    for (int g = 0; g < a2.ngroups; ++g)
+        if (a1.active[g] && a1.nblocks[g] > lim) return false;
+    return true;
+}
 #ifdef PINN_EMU
 inline void launch_pack(float* packed, const int* idx, const float* theta, int n, plat_stream) {
     for (int i = 0; i < n; ++i) pack_body(i, packed, idx, theta);
@@ -363,6 +402,10 @@ inline void launch_expr(const ExprArgs& a, int nblocks, plat_stream) {
         }
 }
 inline void launch_reduce(const Reduce1Args& a1, const Reduce2Args& a2, int max_n1, int max_split, plat_stream) {
+    if (reduce_is_small(a1, a2)) {
+        for (int r = 0; r < a2.P + a2.K; ++r) reduce_direct_body(r, a1, a2);
+        return;
+    }
     for (int g = 0; g < a2.ngroups; ++g)
         for (int ch = 0; ch < max_split; ++ch)
             for (int e = 0; e < max_n1; ++e) reduce1_body(e, ch, g, a1);
@@ -481,7 +524,14 @@ inline void launch_src(const SrcArgs& a, plat_stream st) {
 inline void launch_expr(const ExprArgs& a, int nblocks, plat_stream st) {
     hipLaunchKernelGGL(k_expr, dim3(nblocks), dim3(256), 0, st, a);
 }
+__global__ void k_reduce_direct(const Reduce1Args a1, const Reduce2Args a2) {
+    reduce_direct_body((int)(blockIdx.x * blockDim.x + threadIdx.x), a1, a2);
+}
 inline void launch_reduce(const Reduce1Args& a1, const Reduce2Args& a2, int max_n1, int max_split, plat_stream st) {
+    if (reduce_is_small(a1, a2)) {
+        hipLaunchKernelGGL(k_reduce_direct, dim3((a2.P + a2.K + 63) / 64), dim3(64), 0, st, a1, a2);
+        return;
+    }
     hipLaunchKernelGGL(k_reduce1, dim3((max_n1 + 255) / 256, max_split, a2.ngroups), dim3(256), 0, st, a1);
     hipLaunchKernelGGL(k_reduce2, dim3((a2.P + a2.K + 255) / 256), dim3(256), 0, st, a2);
 }

@@ -51,6 +51,20 @@ def test_small_poisson_tanh_and_sigmoid(npde, use_emu):
         check(npde, sysm, [chain], strat, theta_for(chain, seed), weights=[1.0, 3.0, 0.5, 2.0, 1.5])
 
 
+def test_two_stage_and_one_stage_reductions_agree(npde, use_emu, monkeypatch):
+    """small launches (every group <= 32 workgroups) sum the slabs in one kernel, large ones in two stages: same numbers from both."""
+    sysm, chain = poisson2d(npde, "tanh")
+    strat = npde.QuasiRandomTraining(70, bcs_points=300, sampling_alg=npde.SobolSample(seed=3), resampling=False, minibatch=1)
+    rep, prob, sets, th = check(npde, sysm, [chain], strat, theta_for(chain, 1), weights=[1.0, 3.0, 0.5, 2.0, 1.5])
+    out = []
+    for lim in ("0", "1000"):                      # (the limit is read at every evaluation)
+        monkeypatch.setenv("PINN_REDUCE_DIRECT_MAX", lim)
+        out.append(rep.engine.loss_grad(th, [1.0, 3.0, 0.5, 2.0, 1.5]))
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-12)
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=0, atol=1e-6 * np.abs(out[1][1]).max())
+    monkeypatch.delenv("PINN_REDUCE_DIRECT_MAX", raising=False)
+
+
 def test_padded_width_12(npde, use_emu):
     # the reference's own test net (test/NNPDE1/nnpde__pde_ii_2d_poisson.jl:97): 2 -> 12 -> 12 -> 1 sigmoid; padded to 16
     sysm, chain = poisson2d(npde, "sigmoid", width=12)
