@@ -133,6 +133,35 @@ AUX_DEV void adam_body(int i, float* theta, float* m, float* v, const float* gra
     v[i] = vi;
     theta[i] -= lr * (mi * c1) / (sqrtf(vi * c2) + eps);      // c1 = 1/(1-b1^t), c2 = 1/(1-b2^t)
 }
+// the resident loop's update kernel: Adam step of element i, its new value scattered into the packed weight images (inverse pack
+// map), and — one thread — the evaluation's total weighted loss into the history: one launch instead of total_loss + adam + pack
+struct AdamFusedArgs {
+    float* theta; float* m; float* v; const float* out;      // out = [P gradient | K raw per-term sums]
+    int P, K;
+    float lr, b1, b2, eps, c1, c2;
+    const int* inv_ptr; const int* inv_pos;
+    float* packed[MAX_PACK_NETS];
+    double* hist; int step; const float* w_over_n;
+};
+AUX_DEV void adam_fused_body(int i, const AdamFusedArgs& a) {
+    if (i == 0) {
+        double s = 0.0;
+        for (int k = 0; k < a.K; ++k) s += (double)a.out[a.P + k] * (double)a.w_over_n[k];
+        a.hist[a.step] = s;
+    }
+    if (i >= a.P) return;
+    const float g = a.out[i];
+    const float mi = a.b1 * a.m[i] + (1.0f - a.b1) * g;
+    const float vi = a.b2 * a.v[i] + (1.0f - a.b2) * g * g;
+    a.m[i] = mi;
+    a.v[i] = vi;
+    const float t = a.theta[i] - a.lr * (mi * a.c1) / (sqrtf(vi * a.c2) + a.eps);
+    a.theta[i] = t;
+    for (int q = a.inv_ptr[i]; q < a.inv_ptr[i + 1]; ++q) {
+        const int pos = a.inv_pos[q];
+        a.packed[pos >> 24][pos & 0xFFFFFF] = t;
+    }
+}
 // total weighted loss of one evaluation from the raw per-term sums in out[P..P+K)
 AUX_DEV void total_loss_body(double* hist, int step, const float* out, int P, int K, const float* w_over_n) {
     double s = 0.0;
@@ -364,6 +393,9 @@ inline void launch_sample(int kind, float* pts, int n_elems, int d, const float*
         else sample_body(e, pts, d, lb, ub, seed, draw);
     }
 }
+inline void launch_adam_fused(const AdamFusedArgs& a, plat_stream) {
+    for (int i = 0; i < (a.P > 1 ? a.P : 1); ++i) adam_fused_body(i, a);
+}
 // device-counter variants for the resident optimiser loop: the step index and the samplers' draw counters live in device memory, so one
 // step's launch sequence is the same every step and can be replayed as a graph (engine.cpp: pinn_adam_steps)
 inline void launch_adam_dev(float* theta, float* m, float* v, const float* grad, int P, float lr, float b1, float b2, float eps, const float* c12, const int* step, plat_stream st) {
@@ -449,6 +481,10 @@ inline void launch_sample(int kind, float* pts, int n_elems, int d, const float*
     if (kind == 3) hipLaunchKernelGGL(k_sample_sobol, dim3((n_elems + 255) / 256), dim3(256), 0, st, pts, n_elems, d, lb, ub, seed, draw);
     else if (kind == 2) hipLaunchKernelGGL(k_sample_lhs, dim3((n_elems + 255) / 256), dim3(256), 0, st, pts, n_elems, d, lb, ub, seed, draw);
     else hipLaunchKernelGGL(k_sample, dim3((n_elems + 255) / 256), dim3(256), 0, st, pts, n_elems, d, lb, ub, seed, draw);
+}
+__global__ void k_adam_fused(const AdamFusedArgs a) { adam_fused_body((int)(blockIdx.x * blockDim.x + threadIdx.x), a); }
+inline void launch_adam_fused(const AdamFusedArgs& a, plat_stream st) {
+    hipLaunchKernelGGL(k_adam_fused, dim3((a.P + 255) / 256), dim3(256), 0, st, a);
 }
 // device-counter variants for the resident optimiser loop (see the emulation section above)
 __global__ void k_adam_dev(float* theta, float* m, float* v, const float* grad, int P, float lr, float b1, float b2, float eps, const float* c12, const int* step) {

@@ -56,9 +56,9 @@ int ensure_points(pinn_engine& E) {
     return 0;
 }
 
-void pack_all(pinn_engine& E, const float* d_theta = nullptr) {
+void pack_all(pinn_engine& E, const float* d_theta = nullptr, bool packed_fresh = false) {
     const float* th = d_theta ? d_theta : E.d_theta;
-    for (size_t n = 0; n < E.nets.size(); ++n) {
+    for (size_t n = 0; n < E.nets.size() && !packed_fresh; ++n) {      // (fresh: the optimiser's update kernel already wrote the images)
         NetPlan& NP = E.netplans[n];
         if (!NP.spec || NP.spec->family == 3) continue;          // DGM kernels read theta unpacked
         aux::launch_pack(NP.d_packed, NP.d_pack_idx, th, NP.npacked, E.stream);
@@ -97,13 +97,13 @@ aux::ExprArgs expr_args(pinn_engine& E, Coupled& Cp, float scale, float* resid) 
 // the device section shared by all loss/grad entry points.  d_theta: theta in device memory; d_out: [P + K] floats in
 // device memory.  Launches per evaluation: pack (1 per net) -> fused residual kernel (1 per group) -> reduce1 -> reduce2.
 int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const float* term_w, int only_term /* -1 = all */, bool timing,
-                  double* lossraw /* K exact double sums; default: E.d_lossraw */) {
+                  double* lossraw /* K exact double sums; default: E.d_lossraw */, bool packed_fresh) {
     if (ensure_points(E)) return 1;
     const int K = (int)E.terms.size();
     const bool phase_ev = timing && E.timing_level >= 2;
     auto group_ev = [&](size_t g) { return timing && E.timing_level >= 1 && (E.timing_group < 0 || E.timing_group == (int)g); };
     if (phase_ev) plat_event_record(E.ev0, E.stream);
-    pack_all(E, d_theta);
+    pack_all(E, d_theta, packed_fresh);
     if (phase_ev) plat_event_record(E.ev1, E.stream);
     aux::Reduce1Args a1;
     aux::Reduce2Args a2;
@@ -298,7 +298,7 @@ int pinn_destroy(pinn_handle h) {
     pinn_comm_destroy(h);
     plat_sync(E.stream);
     for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_resid); plat_free(T.d_lb); plat_free(T.d_ub); plat_free(T.d_src_prog); plat_free(T.d_src); plat_free(T.d_data); plat_free(T.d_pw); }
-    plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist); plat_free(E.d_step); plat_free(E.d_draws); plat_free(E.d_sampled); plat_free(E.d_c12);
+    plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist); plat_free(E.d_inv_ptr); plat_free(E.d_inv_pos); plat_free(E.d_step); plat_free(E.d_draws); plat_free(E.d_sampled); plat_free(E.d_c12);
     for (auto& G : E.groups) {
         plat_free(G.d_prog); plat_free(G.d_slabs); plat_free(G.d_losspart); plat_free(G.d_scratch); plat_free(G.d_rec);
         plat_free(G.d_tmp);
@@ -843,6 +843,9 @@ int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta
         E.opt_t += nsteps;
         for (auto& T : E.terms) if (T.sampler != 0) T.draws += (unsigned)nsteps;
     } else {
+        // one update kernel per step: Adam + the evaluation's total loss + the new parameters scattered into the packed weight images
+        // (PINN_NO_FUSED_ADAM=1: total_loss, adam and next step's pack as three launches)
+        const bool fused = E.inv_ok && E.d_inv_ptr && std::getenv("PINN_NO_FUSED_ADAM") == nullptr;
         for (int s = 0; s < nsteps; ++s) {
             for (size_t t = 0; t < E.terms.size(); ++t) {            // resampling strategies: fresh points every evaluation, on device
                 Term& T = E.terms[t];
@@ -851,12 +854,24 @@ int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta
                     eval_sources(E, T);
                 }
             }
-            if (run_loss_grad(E, E.d_opt_theta, E.d_opt_out, term_w, -1, false)) return 1;
-            aux::launch_total_loss(E.d_hist, s, E.d_opt_out, P, K, E.d_w_over_n, E.stream);
+            // from the second step on the packed weight images are already those of the current theta: the update kernel below wrote them
+            if (run_loss_grad(E, E.d_opt_theta, E.d_opt_out, term_w, -1, false, nullptr, fused && s > 0)) return 1;
             ++E.opt_t;
             const float c1 = (float)(1.0 / (1.0 - std::pow((double)beta1, (double)E.opt_t)));
             const float c2 = (float)(1.0 / (1.0 - std::pow((double)beta2, (double)E.opt_t)));
-            aux::launch_adam(E.d_opt_theta, E.d_opt_m, E.d_opt_v, E.d_opt_out, P, lr, beta1, beta2, eps, c1, c2, E.stream);
+            if (fused) {
+                aux::AdamFusedArgs fa;
+                std::memset(&fa, 0, sizeof fa);
+                fa.theta = E.d_opt_theta; fa.m = E.d_opt_m; fa.v = E.d_opt_v; fa.out = E.d_opt_out; fa.P = P; fa.K = K;
+                fa.lr = lr; fa.b1 = beta1; fa.b2 = beta2; fa.eps = eps; fa.c1 = c1; fa.c2 = c2;
+                fa.inv_ptr = E.d_inv_ptr; fa.inv_pos = E.d_inv_pos;
+                for (size_t n = 0; n < E.nets.size(); ++n) fa.packed[n] = E.netplans[n].d_packed;
+                fa.hist = E.d_hist; fa.step = s; fa.w_over_n = E.d_w_over_n;
+                aux::launch_adam_fused(fa, E.stream);
+            } else {
+                aux::launch_total_loss(E.d_hist, s, E.d_opt_out, P, K, E.d_w_over_n, E.stream);
+                aux::launch_adam(E.d_opt_theta, E.d_opt_m, E.d_opt_v, E.d_opt_out, P, lr, beta1, beta2, eps, c1, c2, E.stream);
+            }
         }
     }
     if (loss_history && plat_d2h(loss_history, E.d_hist, sizeof(double) * nsteps, E.stream)) return fail("D2H copy failed");

@@ -142,6 +142,7 @@ struct NetPlan {
     const pk::SpecInfo* spec = nullptr;   // any spec with the right (HP,NHH,D): packed layout is shared
     float* d_packed = nullptr;
     int* d_pack_idx = nullptr;
+    std::vector<int> h_pack_idx;     // host copy (inverse map construction)
     int npacked = 0;
 };
 
@@ -195,6 +196,9 @@ struct pinn_engine {
     long long opt_t = 0;
     // device-side step state of the resident loop (pinn_adam_steps): [0] = step index of the current call; draw counters and the
     // sampled-term mask per term; bias-correction table [2 x steps]
+    int* d_inv_ptr = nullptr;        // theta element -> positions (net << 24 | offset) in the packed weight images
+    int* d_inv_pos = nullptr;
+    bool inv_ok = false;
     int* d_step = nullptr;
     unsigned* d_draws = nullptr;
     int* d_sampled = nullptr;
@@ -224,7 +228,8 @@ int lower_sexpr_term(const SexprContext& C, const std::vector<std::string>& indv
 void analyse_static(Term& T, int np);
 bool fuse_laplacian(Term& T, int np);
 // engine.cpp (shared with comm.cpp)
-int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const float* term_w, int only_term, bool timing, double* lossraw = nullptr);
+int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const float* term_w, int only_term, bool timing, double* lossraw = nullptr,
+                  bool packed_fresh = false);
 int upload_theta(pinn_engine& E, const float* theta, int64_t p);
 // every entry point that touches the device first makes the handle's device current (single-process multi-GPU callers)
 struct DeviceScope {

@@ -583,6 +583,30 @@ static int plan_pack_maps(pinn_engine& E) {
         if (!NP.d_packed || !NP.d_pack_idx) return fail("device allocation failed (packed weights)");
         plat_h2d(NP.d_pack_idx, idx.data(), sizeof(int) * s.PACKED, E.stream);
         plat_sync(E.stream);
+        NP.h_pack_idx = idx;
+    }
+    // inverse map (theta element -> its positions in the packed images): the resident optimiser's update kernel writes the new value
+    // of every parameter straight into the images, so the next evaluation needs no pack launch (engine.cpp: pinn_adam_steps)
+    E.inv_ok = E.nets.size() <= (size_t)aux::MAX_PACK_NETS;
+    if (E.inv_ok) {
+        std::vector<std::vector<int>> inv((size_t)E.ntheta);
+        for (size_t n = 0; n < E.nets.size(); ++n) {
+            const NetPlan& NP = E.netplans[n];
+            if (!NP.spec || NP.spec->family == 3) continue;
+            if (NP.npacked >= (1 << 24)) { E.inv_ok = false; break; }
+            for (int q = 0; q < NP.npacked; ++q)
+                if (NP.h_pack_idx[q] >= 0) inv[(size_t)NP.h_pack_idx[q]].push_back((int)((n << 24) | (unsigned)q));
+        }
+        if (E.inv_ok) {
+            std::vector<int> ptr{0}, pos;
+            for (auto& v : inv) { pos.insert(pos.end(), v.begin(), v.end()); ptr.push_back((int)pos.size()); }
+            E.d_inv_ptr = (int*)plat_malloc(sizeof(int) * ptr.size());
+            E.d_inv_pos = (int*)plat_malloc(sizeof(int) * std::max<size_t>(pos.size(), 1));
+            if (!E.d_inv_ptr || !E.d_inv_pos) return fail("device allocation failed (inverse pack map)");
+            plat_h2d(E.d_inv_ptr, ptr.data(), sizeof(int) * ptr.size(), E.stream);
+            if (!pos.empty()) plat_h2d(E.d_inv_pos, pos.data(), sizeof(int) * pos.size(), E.stream);
+            plat_sync(E.stream);
+        }
     }
     return 0;
 }
