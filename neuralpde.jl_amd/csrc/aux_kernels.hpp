@@ -125,13 +125,20 @@ AUX_DEV void src_point(int p, const SrcArgs& a) {
 
 // ---- resident-theta training loop ----
 // Adam exactly as [3P] Optimisers.Adam: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; theta -= lr * (m/(1-b1^t)) / (sqrt(v/(1-b2^t)) + eps)
+// one Adam update ([3P] Optimisers.Adam): the multiply-adds are spelled out as fused operations, so that every kernel that performs the
+// update (plain, fused with the pack, device-counter variant) and the CPU emulation round identically — left to the compiler, two kernels
+// with the same source expression contracted it differently (1-ulp differences from the second step on)
+AUX_DEV float adam_update(float th, float& m, float& v, float g, float lr, float b1, float b2, float eps, float c1, float c2) {
+    m = __builtin_fmaf(b1, m, (1.0f - b1) * g);
+    v = __builtin_fmaf(b2, v, ((1.0f - b2) * g) * g);
+    return th - (lr * (m * c1)) / (sqrtf(v * c2) + eps);      // c1 = 1/(1-b1^t), c2 = 1/(1-b2^t)
+}
 AUX_DEV void adam_body(int i, float* theta, float* m, float* v, const float* grad, float lr, float b1, float b2, float eps, float c1, float c2) {
-    const float g = grad[i];
-    const float mi = b1 * m[i] + (1.0f - b1) * g;
-    const float vi = b2 * v[i] + (1.0f - b2) * g * g;
+    float mi = m[i], vi = v[i];
+    const float t = adam_update(theta[i], mi, vi, grad[i], lr, b1, b2, eps, c1, c2);
     m[i] = mi;
     v[i] = vi;
-    theta[i] -= lr * (mi * c1) / (sqrtf(vi * c2) + eps);      // c1 = 1/(1-b1^t), c2 = 1/(1-b2^t)
+    theta[i] = t;
 }
 // the resident loop's update kernel: Adam step of element i, its new value scattered into the packed weight images (inverse pack
 // map), and — one thread — the evaluation's total weighted loss into the history: one launch instead of total_loss + adam + pack
@@ -150,12 +157,10 @@ AUX_DEV void adam_fused_body(int i, const AdamFusedArgs& a) {
         a.hist[a.step] = s;
     }
     if (i >= a.P) return;
-    const float g = a.out[i];
-    const float mi = a.b1 * a.m[i] + (1.0f - a.b1) * g;
-    const float vi = a.b2 * a.v[i] + (1.0f - a.b2) * g * g;
+    float mi = a.m[i], vi = a.v[i];
+    const float t = adam_update(a.theta[i], mi, vi, a.out[i], a.lr, a.b1, a.b2, a.eps, a.c1, a.c2);
     a.m[i] = mi;
     a.v[i] = vi;
-    const float t = a.theta[i] - a.lr * (mi * a.c1) / (sqrtf(vi * a.c2) + a.eps);
     a.theta[i] = t;
     for (int q = a.inv_ptr[i]; q < a.inv_ptr[i + 1]; ++q) {
         const int pos = a.inv_pos[q];
