@@ -37,7 +37,9 @@ int pinn_abi_version(void);
 const char* pinn_last_error(void);
 
 /*
- * Build an engine from a problem descriptor (text, format "pinnir 1").
+ * Build an engine from a problem descriptor (text; "pinnir 1": residual tapes, or "pinnir 2": the equations as s-expressions, lowered
+ * inside the library — grammar of both in DESIGN.md §2; optional trailing `hint <term> <points>` lines announce the sizes of the point
+ * sets the caller is going to install, so that the planner can put small terms onto a launch their network already has).
  * The descriptor carries what symbolic_discretize extracts from the PDESystem:
  * chains (sizes, activation, offset in theta)   <- pinnrep.phi / flat_init_params   (src/discretize.jl:432-465)
  * per term: dimension, jet slots, residual tape <- symbolic_pde/bc_loss_functions   (src/discretize.jl:505-525)
