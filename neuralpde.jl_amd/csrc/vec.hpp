@@ -185,8 +185,18 @@ DEV void vsincos(vfloat x, vfloat& s, vfloat& c) {
     s = (q & 2) ? -sv : sv;
     c = ((q + 1) & 2) ? -cv : cv;
 }
-DEV vfloat vtanh_fast(vfloat x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
-DEV vfloat vsigmoid_fast(vfloat x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// exp(2x) and exp(-x) as ONE multiply + v_exp_f32 (2^(x * 2 log2 e)); __expf(2.0f * x) compiled to add, multiply, v_exp
+#ifndef PINN_ACT_EXP2
+#define PINN_ACT_EXP2 1
+#endif
+DEV vfloat vtanh_fast(vfloat x) {
+    const float e = PINN_ACT_EXP2 ? __builtin_amdgcn_exp2f(x * 2.8853900817779268f) : __expf(2.0f * x);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+DEV vfloat vsigmoid_fast(vfloat x) {
+    const float e = PINN_ACT_EXP2 ? __builtin_amdgcn_exp2f(x * -1.4426950408889634f) : __expf(-x);
+    return __builtin_amdgcn_rcpf(1.0f + e);
+}
 DEV vfloat vsign(vfloat x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
 DEV vfloat vsinpi(vfloat x) { return sinpif(x); }
 DEV vfloat vcospi(vfloat x) { return cospif(x); }
