@@ -150,7 +150,9 @@ def test_engine_error_paths(npde, use_emu):
     for bad, msg in (("pinnir 1\nntheta 5\nparams 0 0 5\ndefaults \nnets 1\nnet 0 relu 0 3 2 16 1\nterms 0\n", "unsupported activation"),
                      (ir.to_descriptor().replace("op ADDC", "op FOO"), "unknown op"),
                      (ir.to_descriptor().replace("slot 0 2 0 0", "slot 0 2 0 5"), "axis out of range"),
-                     (ir.to_descriptor().replace("slot 0 2 0 0", "slot 0 7 0 0 0 0 0 0 0"), "order > 6")):
+                     (ir.to_descriptor().replace("slot 0 2 0 0", "slot 0 7 0 0 0 0 0 0 0"), "order > 6"),
+                     (ir.to_descriptor() + "garbage 1 2\n", "trailing text after the last term"),
+                     (ir.to_descriptor() + "hint 9 4\n", "trailing text after the last term")):          # (no term 9)
         with pytest.raises(npde.EngineError, match=msg):
             npde.Engine(bad)
 
