@@ -10,7 +10,14 @@ See DESIGN.md for the kernel design and INTEGRATION.md for the Julia `ccall` bin
 from . import _lib
 from ._lib import Engine, EngineError, Library, comm_init_all, comm_unique_id, loss_grad_sharded
 from .ir import Instr, NetIR, ProblemIR, Slot, TermIR
-from .bpinn import loglikelihood, physics_loglikelihood
+from .bpinn import BPINNsolution, loglikelihood, physics_loglikelihood
+from . import bpinn as _bpinn
+
+
+def ahmc_bayesian_pinn_pde(pde_system, discretization, **kw):
+    """ext/bpinn/PDE_BPINN.jl:371 — see bpinn.ahmc_bayesian_pinn_pde."""
+    import sys as _sys
+    return _bpinn.ahmc_bayesian_pinn_pde(_sys.modules[__name__], pde_system, discretization, **kw)
 from .adaptive import (AbstractAdaptiveLoss, GradientScaleAdaptiveLoss, MiniMaxAdaptiveLoss, ReLoBRaLoAdaptiveLoss,
                        SoftAdaptAdaptiveLoss)
 from .pinn import (DGM, DeepGalerkin, DataLoss, depvar_params, Adam, BFGS, LBFGS, OptimizationSolution, solve, Chain, Dense, LogOptions, NonAdaptiveLoss, OptimizationFunction, OptimizationProblem, Phi,

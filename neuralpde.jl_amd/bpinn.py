@@ -45,3 +45,128 @@ def loglikelihood(engine, theta, stds: Sequence[float], want_grad: bool = True):
     terms: with their own std they are the L2LossData term (ext/bpinn/PDE_BPINN.jl:148-183), evaluated in the same fused call."""
     ll, g, gs = engine.loglik_grad(theta, stds, want_grad=want_grad)
     return ll, (None if g is None else g.astype(np.float64)), gs
+
+
+# ------------------------------------------------------------------------------------------------
+# host-side sampler: the mirror of `ahmc_bayesian_pinn_pde` (ext/bpinn/PDE_BPINN.jl:371-640)
+# ------------------------------------------------------------------------------------------------
+class BPINNsolution:
+    """ext/bpinn/PDE_BPINN.jl `BPINNsolution`: samples, per-dependent-variable ensemble prediction (mean, std over the last `numensemble`
+    draws) on the `saveats` grid, and that grid."""
+
+    def __init__(self, samples, ensemblesol, ensemblestd, timepoints, stats):
+        self.samples, self.ensemblesol, self.ensemblestd, self.timepoints, self.stats = samples, ensemblesol, ensemblestd, timepoints, stats
+
+
+def _hmc(logp_grad, theta0, draw_samples, n_leapfrog, eps0, target, rng, n_adapts=None):
+    """HMC with `n_leapfrog` leapfrog steps per draw ([3P] AdvancedHMC.HMC(eps, n_leapfrog)), Stan-style adaptation during the first
+    n_adapts = min(draw_samples / 10, 1000) draws (AdvancedHMC's default): dual averaging of the step size towards `target` acceptance
+    and a diagonal metric from the windowed sample variance (StanHMCAdaptor + DiagEuclideanMetric)."""
+    n = theta0.size
+    n_adapts = min(draw_samples // 10, 1000) if n_adapts is None else n_adapts
+    th = theta0.astype(np.float64).copy()
+    lp, g = logp_grad(th)
+    minv = np.ones(n)                                # inverse mass (diagonal metric)
+
+    def leap(th, r, g, eps, steps):
+        r = r + 0.5 * eps * g
+        for s in range(steps):
+            th = th + eps * minv * r
+            lp, g = logp_grad(th)
+            r = r + (eps if s < steps - 1 else 0.5 * eps) * g
+        return th, r, lp, g
+
+    # find_good_stepsize: double / halve until the one-step acceptance crosses 0.8 (AdvancedHMC.find_good_stepsize)
+    eps = eps0
+    r0 = rng.standard_normal(n) / np.sqrt(minv)
+    h0 = -lp + 0.5 * np.sum(minv * r0 * r0)
+    t1, r1, lp1, _ = leap(th, r0, g, eps, 1)
+    d = h0 - (-lp1 + 0.5 * np.sum(minv * r1 * r1))
+    direction = 1.0 if (np.isfinite(d) and d > np.log(0.8)) else -1.0
+    for _ in range(40):
+        eps *= 2.0 ** direction
+        t1, r1, lp1, _ = leap(th, r0, g, eps, 1)
+        d = h0 - (-lp1 + 0.5 * np.sum(minv * r1 * r1))
+        if not np.isfinite(d):
+            d = -np.inf
+        if (direction > 0) == (d <= np.log(0.8)):
+            break
+    mu, hbar, log_eps_bar, t0, gamma, kappa = np.log(10 * eps), 0.0, 0.0, 10.0, 0.05, 0.75
+    w0, w1 = int(0.15 * n_adapts), int(0.9 * n_adapts)            # variance window of the metric adaptation
+    win = []
+    samples, accs = [], []
+    m_count = 0
+    for it in range(draw_samples):
+        r = rng.standard_normal(n) / np.sqrt(minv)
+        h_old = -lp + 0.5 * np.sum(minv * r * r)
+        tn, rn, lpn, gn = leap(th, r, g, eps, n_leapfrog)
+        h_new = -lpn + 0.5 * np.sum(minv * rn * rn)
+        a = float(np.exp(min(0.0, h_old - h_new))) if np.isfinite(h_new) else 0.0
+        if rng.random() < a:
+            th, lp, g = tn, lpn, gn
+        samples.append(th.copy())
+        accs.append(a)
+        if it < n_adapts:
+            m_count += 1
+            hbar = (1 - 1 / (m_count + t0)) * hbar + (target - a) / (m_count + t0)
+            log_eps = mu - np.sqrt(m_count) / gamma * hbar
+            eta = m_count ** (-kappa)
+            log_eps_bar = eta * log_eps + (1 - eta) * log_eps_bar
+            eps = float(np.exp(log_eps))
+            if w0 <= it < w1:
+                win.append(th.copy())
+            if it == w1 - 1 and len(win) >= 8 and n_adapts >= 100:       # (a metric from fewer draws is noise; short runs keep the unit metric)
+                var = np.var(np.asarray(win), axis=0)
+                k = len(win)
+                minv = (k / (k + 5.0)) * var + 1e-3 * (5.0 / (k + 5.0))
+                mu, hbar, log_eps_bar, m_count = np.log(10 * eps), 0.0, 0.0, 0          # restart the step-size search on the new metric
+            if it == n_adapts - 1:
+                eps = float(np.exp(log_eps_bar)) if m_count > 0 else eps
+    return np.asarray(samples), {"acceptance": np.asarray(accs), "step_size": eps, "inv_metric": minv, "n_adapts": n_adapts}
+
+
+def ahmc_bayesian_pinn_pde(npde, pde_system, discretization, draw_samples=1000, bcstd=(0.01,), phystd=(0.05,), priorsNNw=(0.0, 2.0),
+                           n_leapfrog=30, step_size=0.1, targetacceptancerate=0.8, saveats=(0.1,), numensemble=None, rng=None):
+    """`ahmc_bayesian_pinn_pde(pde_system, discretization; draw_samples, bcstd, phystd, priorsNNw, Kernel = HMC(0.1, 30), saveats,
+    numensemble)` — the forward-problem form of ext/bpinn/PDE_BPINN.jl:371-640: the posterior over the network parameters is
+    prior N(priorsNNw[1], priorsNNw[2]^2 I) x physics likelihood (`pinn_loglik_grad`: every leapfrog step is ONE fused device evaluation,
+    reverse mode over all parameters where the reference differentiates forward over each of them); the HMC sampler, its adaptation and
+    the ensemble statistics run on the host, as in the reference.  `discretization`: a PhysicsInformedNN with fixed point sets (the
+    reference's BayesianPINN takes GridTraining).  Inverse problems (`param`, `dataset`) are not part of this mirror."""
+    rng = np.random.default_rng() if rng is None else rng
+    rep = npde.symbolic_discretize(pde_system, discretization)
+    eng = rep.engine
+    n_pde, n_bc = len(rep.eqs), len(rep.bcs)
+    bro = lambda s, n: list(np.broadcast_to(np.asarray(s, dtype=np.float64).reshape(-1), (n,))) if np.size(s) in (1, n) else None
+    ps, bs = bro(phystd, n_pde), bro(bcstd, n_bc)
+    if ps is None or bs is None:
+        raise ValueError("phystd / bcstd: one standard deviation per equation / boundary condition (or one for all)")
+    stds = np.asarray(ps + bs, dtype=np.float64)
+    mu0, sd0 = float(priorsNNw[0]), float(priorsNNw[1])
+
+    def logp_grad(th):
+        ll, g, _ = eng.loglik_grad(th, stds)
+        lp = ll - 0.5 * np.sum(((th - mu0) / sd0) ** 2) - th.size * (np.log(sd0) + 0.5 * np.log(2 * np.pi))
+        return lp, g.astype(np.float64) - (th - mu0) / sd0 ** 2
+    theta0 = np.asarray(rep.flat_init_params, dtype=np.float64)
+    samples, stats = _hmc(logp_grad, theta0, int(draw_samples), int(n_leapfrog), float(step_size), float(targetacceptancerate), rng)
+    numensemble = int(draw_samples // 3) if numensemble is None else int(numensemble)
+    # inference: the last `numensemble` draws on the saveats grid (one spacing per independent variable), per dependent variable
+    doms = {str(d.variable): (float(d.domain.lo), float(d.domain.hi)) for d in pde_system.domain}
+    ens, ens_std, tps = [], [], []
+    for i, name in enumerate(rep.depvars):
+        ins = list(rep.dict_depvar_input[name])
+        if len(saveats) not in (1, len(pde_system.ivs)):
+            raise ValueError("saveats: one grid spacing per independent variable")
+        axes = []
+        for v in ins:
+            k = [str(q) for q in pde_system.ivs].index(str(v))
+            lo, hi = doms[str(v)]
+            step = float(saveats[k if len(saveats) > 1 else 0])
+            axes.append(np.arange(lo, hi + 0.5 * step, step))
+        mesh = np.meshgrid(*axes, indexing="ij")
+        pts = np.stack([m.ravel() for m in mesh])
+        preds = np.stack([rep.phi[i](pts, npde.depvar_params(rep, th, name))[0] if isinstance(rep.phi, (list, tuple)) else rep.phi(pts, th)[0]
+                          for th in samples[-numensemble:]])
+        ens.append(preds.mean(axis=0)); ens_std.append(preds.std(axis=0)); tps.append(pts)
+    return BPINNsolution(samples, ens, ens_std, tps, stats)
