@@ -203,3 +203,16 @@ def test_dropped_call_arguments_quirk(npde, use_emu):
     assert np.all(rep.bcs_train_sets[3][1] == -1.0)                      # the first call's arguments define the set
     assert rep.loss_functions.bc_loss_functions[3](th) == 0.0
     assert rep.loss_functions.bc_loss_functions[1](th) > 0.0
+
+
+def test_hmc_sampler_on_a_gaussian(npde):
+    """the host-side HMC of the BPINN mirror (bpinn._hmc: dual-averaging step size, windowed diagonal metric) on a known target:
+    N(mu, diag(s^2)) in 5 dimensions — sample mean and standard deviation within Monte-Carlo error, acceptance near the target."""
+    from neuralpde_jl_amd import bpinn
+    mu, sd = np.array([1.0, -2.0, 0.5, 3.0, 0.0]), np.array([0.5, 2.0, 1.0, 0.1, 5.0])
+    logp = lambda th: (float(-0.5 * np.sum(((th - mu) / sd) ** 2)), -(th - mu) / sd ** 2)
+    samples, stats = bpinn._hmc(logp, np.zeros(5), 4000, 10, 0.1, 0.8, np.random.default_rng(0))
+    s = samples[1000:]
+    assert np.all(np.abs(s.mean(axis=0) - mu) < 0.25 * sd + 0.02)
+    assert np.all(np.abs(s.std(axis=0) / sd - 1.0) < 0.25)
+    assert 0.6 < stats["acceptance"][400:].mean() <= 1.0 and stats["n_adapts"] == 400
