@@ -125,14 +125,46 @@ def _hmc(logp_grad, theta0, draw_samples, n_leapfrog, eps0, target, rng, n_adapt
     return np.asarray(samples), {"acceptance": np.asarray(accs), "step_size": eps, "inv_metric": minv, "n_adapts": n_adapts}
 
 
-def ahmc_bayesian_pinn_pde(npde, pde_system, discretization, draw_samples=1000, bcstd=(0.01,), phystd=(0.05,), priorsNNw=(0.0, 2.0),
-                           n_leapfrog=30, step_size=0.1, targetacceptancerate=0.8, saveats=(0.1,), numensemble=None, rng=None):
+class LogNormal:
+    """[3P] Distributions.LogNormal(mu, sigma) as a parameter prior (`param = [LogNormal(6.0, 0.5)]`, test/PDEBPINN/bpinn_pde__bpinn_pde_inv_i_*.jl:58)."""
+
+    def __init__(self, mu, sigma):
+        self.mu, self.sigma = float(mu), float(sigma)
+
+    def params(self):
+        return (self.mu, self.sigma)
+
+    def logpdf_grad(self, x):
+        if not x > 0.0:
+            return -np.inf, 0.0
+        z = (np.log(x) - self.mu) / self.sigma
+        return float(-np.log(x * self.sigma * np.sqrt(2 * np.pi)) - 0.5 * z * z), float(-1.0 / x - z / (self.sigma * x))
+
+
+class Normal:
+    """[3P] Distributions.Normal(mu, sigma) as a parameter prior."""
+
+    def __init__(self, mu, sigma):
+        self.mu, self.sigma = float(mu), float(sigma)
+
+    def params(self):
+        return (self.mu, self.sigma)
+
+    def logpdf_grad(self, x):
+        z = (x - self.mu) / self.sigma
+        return float(-np.log(self.sigma * np.sqrt(2 * np.pi)) - 0.5 * z * z), float(-z / self.sigma)
+
+
+def ahmc_bayesian_pinn_pde(npde, pde_system, discretization, draw_samples=1000, bcstd=(0.01,), l2std=(0.05,), phystd=(0.05,), priorsNNw=(0.0, 2.0),
+                           param=(), n_leapfrog=30, step_size=0.1, targetacceptancerate=0.8, saveats=(0.1,), numensemble=None, rng=None):
     """`ahmc_bayesian_pinn_pde(pde_system, discretization; draw_samples, bcstd, phystd, priorsNNw, Kernel = HMC(0.1, 30), saveats,
     numensemble)` — the forward-problem form of ext/bpinn/PDE_BPINN.jl:371-640: the posterior over the network parameters is
     prior N(priorsNNw[1], priorsNNw[2]^2 I) x physics likelihood (`pinn_loglik_grad`: every leapfrog step is ONE fused device evaluation,
     reverse mode over all parameters where the reference differentiates forward over each of them); the HMC sampler, its adaptation and
     the ensemble statistics run on the host, as in the reference.  `discretization`: a PhysicsInformedNN with fixed point sets (the
-    reference's BayesianPINN takes GridTraining).  Inverse problems (`param`, `dataset`) are not part of this mirror."""
+    reference's BayesianPINN takes GridTraining).  Inverse problems: `param = [prior of every PDE parameter]` (the chain starts at the
+    priors' first parameter, as in the reference), the discretization built with `param_estim = True` and the observations as `data_loss`
+    terms (the reference's `dataset`), whose standard deviations are `l2std` — the L2 data term then sits in the same fused device call."""
     rng = np.random.default_rng() if rng is None else rng
     rep = npde.symbolic_discretize(pde_system, discretization)
     eng = rep.engine
@@ -141,14 +173,31 @@ def ahmc_bayesian_pinn_pde(npde, pde_system, discretization, draw_samples=1000, 
     ps, bs = bro(phystd, n_pde), bro(bcstd, n_bc)
     if ps is None or bs is None:
         raise ValueError("phystd / bcstd: one standard deviation per equation / boundary condition (or one for all)")
-    stds = np.asarray(ps + bs, dtype=np.float64)
+    n_data = eng.K - n_pde - n_bc
+    ls = bro(l2std, n_data) if n_data else []
+    if ls is None:
+        raise ValueError("l2std: one standard deviation per data term (or one for all)")
+    stds = np.asarray(ps + bs + ls, dtype=np.float64)
     mu0, sd0 = float(priorsNNw[0]), float(priorsNNw[1])
+    ninv = len(param)
+    if ninv and (not discretization.param_estim or ninv != int(eng.P - sum(c.nparams for c in discretization.chain))):
+        raise ValueError("param: one prior per estimated PDE parameter, and the discretization needs param_estim = True")
+    nn = eng.P - ninv
 
     def logp_grad(th):
         ll, g, _ = eng.loglik_grad(th, stds)
-        lp = ll - 0.5 * np.sum(((th - mu0) / sd0) ** 2) - th.size * (np.log(sd0) + 0.5 * np.log(2 * np.pi))
-        return lp, g.astype(np.float64) - (th - mu0) / sd0 ** 2
-    theta0 = np.asarray(rep.flat_init_params, dtype=np.float64)
+        g = g.astype(np.float64)
+        w = th[:nn]
+        lp = ll - 0.5 * np.sum(((w - mu0) / sd0) ** 2) - nn * (np.log(sd0) + 0.5 * np.log(2 * np.pi))
+        g[:nn] -= (w - mu0) / sd0 ** 2
+        for j, pr in enumerate(param):
+            l, d = pr.logpdf_grad(float(th[nn + j]))
+            lp += l
+            g[nn + j] += d
+        return lp, g
+    theta0 = np.asarray(rep.flat_init_params, dtype=np.float64).copy()
+    for j, pr in enumerate(param):
+        theta0[nn + j] = pr.params()[0]
     samples, stats = _hmc(logp_grad, theta0, int(draw_samples), int(n_leapfrog), float(step_size), float(targetacceptancerate), rng)
     numensemble = int(draw_samples // 3) if numensemble is None else int(numensemble)
     # inference: the last `numensemble` draws on the saveats grid (one spacing per independent variable), per dependent variable
@@ -169,4 +218,6 @@ def ahmc_bayesian_pinn_pde(npde, pde_system, discretization, draw_samples=1000, 
         preds = np.stack([rep.phi[i](pts, npde.depvar_params(rep, th, name))[0] if isinstance(rep.phi, (list, tuple)) else rep.phi(pts, th)[0]
                           for th in samples[-numensemble:]])
         ens.append(preds.mean(axis=0)); ens_std.append(preds.std(axis=0)); tps.append(pts)
-    return BPINNsolution(samples, ens, ens_std, tps, stats)
+    sol = BPINNsolution(samples, ens, ens_std, tps, stats)
+    sol.estimated_de_params = [float(samples[-numensemble:, nn + j].mean()) for j in range(ninv)]
+    return sol

@@ -414,3 +414,30 @@ def test_bpinn_pde_ii_1d_ode(npde, lib):
     err = float(np.median(errs))
     print(f"bpinn pde ii: ||u_predict - u_real||_2 = {', '.join('%.3f' % e for e in errs)} -> median {err:.3f} over {ts.size} points (reference tolerance 0.8)")
     assert err <= 0.8
+
+
+def test_bpinn_pde_inv_i_1d_periodic_system(npde, lib):
+    """test/PDEBPINN/bpinn_pde__bpinn_pde_inv_i_1d_periodic_system.jl:12-74: u' = cos(p t), p estimated (truth 2 pi; start and prior
+    LogNormal(6, 0.5) as written there), 201 observations of the solution with 20 % multiplicative noise as the L2 data term,
+    Chain(Dense(1,6,tanh), Dense(6,6,tanh), Dense(6,1)), GridTraining(0.02), draw_samples = 1500, all stds 0.02, priors N(0, 1);
+    criteria: mean |u_predict - u_real| < 8e-2 and the estimated parameter within 10 % of 2 pi."""
+    from neuralpde_jl_amd import bpinn
+    (t,) = npde.parameters("t")
+    (p,) = npde.parameters("p")
+    (u,) = npde.variables("u")
+    eq = npde.Eq(npde.Differential(t)(u(t)) - sp.cos(p * t), 0)
+    sysm = npde.PDESystem([eq], [npde.Eq(u(0), 0.0)], [npde.In(t, npde.Interval(0.0, 2.0))], [t], [u(t)], ps=[p], defaults={p: 4.0})
+    chain = chain_of(npde, 1, 6, 2, "tanh")
+    rng = np.random.default_rng(100)
+    tp = np.arange(0.0, 2.0 + 0.005, 0.01)
+    clean = np.sin(2 * np.pi * tp) / (2 * np.pi)
+    obs = clean + clean * 0.2 * rng.standard_normal(tp.size)
+    theta0 = npde.initialparameters(rng, chain)                       # (theta.p is appended by the discretizer from `defaults`)
+    disc = npde.PhysicsInformedNN(chain, npde.GridTraining(0.02), init_params=theta0, param_estim=True, data_loss=[npde.DataLoss(u(t), tp[None, :], obs)])
+    sol = npde.ahmc_bayesian_pinn_pde(sysm, disc, draw_samples=1500, bcstd=[0.02], phystd=[0.02], l2std=[0.02], priorsNNw=(0.0, 1.0),
+                                      saveats=[1 / 50.0], param=[bpinn.LogNormal(6.0, 0.5)], rng=np.random.default_rng(104))
+    ts = sol.timepoints[0][0]
+    err = float(np.mean(np.abs(sol.ensemblesol[0] - np.sin(2 * np.pi * ts) / (2 * np.pi))))
+    pe = sol.estimated_de_params[0]
+    print(f"bpinn pde inv i: mean |u_predict - u_real| = {err:.4f} (reference criterion < 0.08), p = {pe:.3f} (truth {2 * np.pi:.3f}, rtol 0.1)")
+    assert err < 8.0e-2 and abs(pe - 2 * np.pi) <= 0.1 * max(abs(pe), 2 * np.pi)
