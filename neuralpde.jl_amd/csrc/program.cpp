@@ -73,8 +73,9 @@ bool fuse_laplacian(Term& T, int np) {
         if (rp::is_binary(I.code)) ++uses[I.b];
     }
     ++uses[T.out_row];
-    auto is_add = [&](int row) { return row >= rop0 && T.ops[row - rop0].code == rp::OP_ADD; };
-    auto inner = [&](int row) { return is_add(row) && uses[row] == 1; };         // ADD node that only feeds its parent ADD
+    // sums are trees of ADD and SUB ops (u_t - u_xx - u_yy arrives as SUB(SUB(u_t, u_xx), u_yy)): every leaf carries the sign it enters with
+    auto is_add = [&](int row) { return row >= rop0 && (T.ops[row - rop0].code == rp::OP_ADD || T.ops[row - rop0].code == rp::OP_SUB); };
+    auto inner = [&](int row) { return is_add(row) && uses[row] == 1; };         // ADD / SUB node that only feeds its parent node
     auto cand = [&](int row) {                                                     // pure second derivative, used exactly once
         if (row < rslot0 || row >= rop0 || uses[row] != 1) return false;
         const Slot& s = T.slots[row - rslot0];
@@ -83,7 +84,7 @@ bool fuse_laplacian(Term& T, int np) {
     // roots: ADD ops that are not themselves inner nodes of a larger ADD tree
     std::vector<char> is_inner_child(nops, 0);
     for (int q = 0; q < nops; ++q)
-        if (T.ops[q].code == rp::OP_ADD) {
+        if (is_add(rop0 + q)) {
             if (inner(T.ops[q].a)) is_inner_child[T.ops[q].a - rop0] = 1;
             if (inner(T.ops[q].b)) is_inner_child[T.ops[q].b - rop0] = 1;
         }
@@ -99,25 +100,29 @@ bool fuse_laplacian(Term& T, int np) {
         }
         return Leaf{-1, 0.f, -1};
     };
-    struct Tree { int root; std::vector<int> leaves, nodes; std::vector<int> fused; std::vector<int> fused_ops; unsigned mask; int net; float coef; };
+    struct Tree { int root; std::vector<int> leaves, nodes; std::vector<float> sign; std::vector<int> fused; std::vector<int> fused_ops; unsigned mask; int net; float coef; };
     std::vector<Tree> trees;
     for (int q = 0; q < nops; ++q) {
-        if (T.ops[q].code != rp::OP_ADD || is_inner_child[q]) continue;
+        if (!is_add(rop0 + q) || is_inner_child[q]) continue;
         Tree tr; tr.root = q; tr.mask = 0; tr.net = -1;
-        std::vector<int> stack{rop0 + q};
+        std::vector<std::pair<int, float>> stack{{rop0 + q, 1.0f}};
         while (!stack.empty()) {
-            const int row = stack.back(); stack.pop_back();
+            const int row = stack.back().first;
+            const float sg = stack.back().second;
+            stack.pop_back();
             tr.nodes.push_back(row - rop0);
-            for (int child : {T.ops[row - rop0].b, T.ops[row - rop0].a}) {
-                if (inner(child)) stack.push_back(child);
-                else tr.leaves.push_back(child);
+            const rp::Instr& N = T.ops[row - rop0];
+            const float sb = N.code == rp::OP_SUB ? -sg : sg;
+            for (auto ch : {std::make_pair(N.b, sb), std::make_pair(N.a, sg)}) {
+                if (inner(ch.first)) stack.push_back(ch);
+                else { tr.leaves.push_back(ch.first); tr.sign.push_back(ch.second); }
             }
         }
         // candidate leaves of one network with one common coefficient and distinct axes
         std::map<std::pair<int, float>, std::vector<int>> by_key;
-        for (int leaf : tr.leaves) {
-            const Leaf lf = leaf_of(leaf);
-            if (lf.slot_row >= 0) by_key[{T.slots[lf.slot_row - rslot0].net, lf.coef}].push_back(leaf);
+        for (size_t li = 0; li < tr.leaves.size(); ++li) {
+            const Leaf lf = leaf_of(tr.leaves[li]);
+            if (lf.slot_row >= 0) by_key[{T.slots[lf.slot_row - rslot0].net, lf.coef * tr.sign[li]}].push_back(tr.leaves[li]);
         }
         for (auto& kv : by_key) {
             unsigned mask = 0; bool dup = false;
@@ -184,13 +189,12 @@ bool fuse_laplacian(Term& T, int np) {
             lap_row = rop0n + (int)nops_v.size();
             nops_v.push_back(I);
         }
-        std::vector<int> leaves{lap_row};
-        for (int leaf : tr.leaves)
-            if (std::find(tr.fused.begin(), tr.fused.end(), leaf) == tr.fused.end()) leaves.push_back(map_row(leaf));
-        int acc = leaves[0];
-        for (size_t i = 1; i < leaves.size(); ++i) {
+        int acc = lap_row;
+        for (size_t li = 0; li < tr.leaves.size(); ++li) {
+            const int leaf = tr.leaves[li];
+            if (std::find(tr.fused.begin(), tr.fused.end(), leaf) != tr.fused.end()) continue;
             rp::Instr I{};
-            I.code = rp::OP_ADD; I.a = acc; I.b = leaves[i]; I.imm = 0.f;
+            I.code = tr.sign[li] < 0.f ? rp::OP_SUB : rp::OP_ADD; I.a = acc; I.b = map_row(leaf); I.imm = 0.f;      // the leaf keeps its sign
             rp::finalize(I);
             acc = rop0n + (int)nops_v.size();
             nops_v.push_back(I);
