@@ -538,3 +538,51 @@ def test_cuda_2d_pde(npde, lib):
     rel = np.linalg.norm(pred - real) / max(np.linalg.norm(pred), np.linalg.norm(real))
     print(f"cuda 2d pde: relative 2-norm error {rel:.3f} over {pts.shape[1]} points (reference tolerance 0.2), loss {losses[0]:.3e} -> {losses[-1]:.3e}")
     assert _ON_EMU or rel <= 0.2
+
+
+def test_dgm_poisson(npde, lib):
+    """test/DGM/dgm__poisson_s_equation.jl:8-47: 2-D Poisson with DeepGalerkin(2, 1, 20, 3, tanh, tanh, identity, QuasiRandomTraining(256; minibatch = 32)),
+    Adam(0.01) x 500 then Adam(0.001) x 200; `u_real ≈ u_predict atol = 0.4` on the 101 x 101 grid."""
+    x, y = npde.parameters("x y")
+    (u,) = npde.variables("u")
+    Dxx, Dyy = npde.Differential(x) ** 2, npde.Differential(y) ** 2
+    eq = npde.Eq(Dxx(u(x, y)) + Dyy(u(x, y)), -sp.sin(sp.pi * x) * sp.sin(sp.pi * y))
+    bcs = [npde.Eq(u(0, y), 0.0), npde.Eq(u(1, y), -math.sin(math.pi * 1) * sp.sin(sp.pi * y)),
+           npde.Eq(u(x, 0), 0.0), npde.Eq(u(x, 1), -sp.sin(sp.pi * x) * math.sin(math.pi * 1))]
+    dom = [npde.In(x, npde.Interval(0.0, 1.0)), npde.In(y, npde.Interval(0.0, 1.0))]
+    strat = npde.QuasiRandomTraining(256, sampling_alg=npde.LatinHypercubeSample(seed=7), minibatch=32)
+    disc = npde.DeepGalerkin(2, 1, 20, 3, "tanh", "tanh", "identity", strat)
+    prob = npde.discretize(npde.PDESystem([eq], bcs, dom, [x, y], [u(x, y)]), disc)
+    theta, losses = train(npde, prob, [(0.01, 500), (0.001, 200)])
+    pts = grid2((0.0, 1.0), (0.0, 1.0), 0.01)
+    real = np.sin(np.pi * pts[0]) * np.sin(np.pi * pts[1]) / (2 * np.pi ** 2)
+    err = np.linalg.norm(prob.pinnrep.phi(pts, theta)[0] - real)
+    print(f"dgm poisson: ||u_real - u_predict||_2 = {err:.3f} over {pts.shape[1]} points (reference tolerance 0.4), loss {losses[0]:.3e} -> {losses[-1]:.3e}")
+    assert err <= 0.4
+
+
+def test_dgm_black_scholes(npde, lib):
+    """test/DGM/dgm__black_scholes_pde_european_call_option.jl:8-56: g_t + r x g_x + sigma^2/2 g_xx = r g with the terminal pay-off max(x - K, 0),
+    DeepGalerkin(2, 1, 40, 3, tanh, tanh, identity, QuasiRandomTraining(128; minibatch = 32)), Adam(0.1) x 100 then Adam(0.01) x 500;
+    `mean(abs, u_predict - u_real) < 5.0` against the Black-Scholes formula on t in 0:0.01:0.999, x in 0:1:130."""
+    from scipy.stats import norm
+    K, T, r, sig, S, mult = 50.0, 1.0, 0.05, 0.25, 130.0, 1.3
+    xx, tt = npde.parameters("x t")
+    (g,) = npde.variables("g")
+    Dt, Dx = npde.Differential(tt), npde.Differential(xx)
+    eq = npde.Eq(Dt(g(tt, xx)) + r * xx * Dx(g(tt, xx)) + 0.5 * sig ** 2 * (Dx ** 2)(g(tt, xx)), r * g(tt, xx))
+    bcs = [npde.Eq(g(T, xx), sp.Max(xx - K, 0.0))]
+    dom = [npde.In(tt, npde.Interval(0.0, T)), npde.In(xx, npde.Interval(0.0, S * mult))]
+    strat = npde.QuasiRandomTraining(128, sampling_alg=npde.LatinHypercubeSample(seed=8), minibatch=32)
+    disc = npde.DeepGalerkin(2, 1, 40, 3, "tanh", "tanh", "identity", strat)
+    prob = npde.discretize(npde.PDESystem([eq], bcs, dom, [tt, xx], [g(tt, xx)]), disc)
+    theta, losses = train(npde, prob, [(0.1, 100), (0.01, 500)])
+    ts, xs = np.arange(0.0, T - 0.001 + 1e-9, 0.01), np.arange(0.0, S + 0.5, 1.0)
+    Tm, Xm = np.meshgrid(ts, xs, indexing="ij")
+    with np.errstate(divide="ignore"):
+        dp = (np.log(Xm / K) + (r + 0.5 * sig ** 2) * (T - Tm)) / (sig * np.sqrt(T - Tm))
+    real = Xm * norm.cdf(dp) - K * np.exp(-r * (T - Tm)) * norm.cdf(dp - sig * np.sqrt(T - Tm))
+    pred = prob.pinnrep.phi(np.stack([Tm.ravel(), Xm.ravel()]), theta)[0].reshape(Tm.shape)
+    err = float(np.mean(np.abs(pred - real)))
+    print(f"dgm black-scholes: mean |u_predict - u_real| = {err:.3f} over {real.size} points (reference criterion < 5.0)")
+    assert err < 5.0
