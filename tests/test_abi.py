@@ -4,6 +4,8 @@ import os
 import re
 import subprocess
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "neuralpde.jl_amd", "csrc", "libpinn_hip.so")
 HDR = os.path.join(ROOT, "include", "pinn_hip.h")
@@ -46,3 +48,27 @@ def test_hip_objects_contain_gfx950_mfma_code():
     data = open(LIB, "rb").read()
     assert b"amdgcn-amd-amdhsa--gfx950" in data          # offload bundle entry for gfx950
     assert b"k_wave" in data                             # the fused residual kernel symbols
+
+
+def _build_c_client(libdir, libname, out):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "c_abi_client.c"), "-o", out,
+                        "-L" + libdir, "-l:" + libname, "-lm", "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return subprocess.run([out], capture_output=True, text=True, timeout=600)
+
+
+def test_plain_c_client_of_the_abi(emu_lib, tmp_path):
+    """include/pinn_hip.h is a C header (gcc -std=c99 -Werror) and the ABI is usable without any host framework: examples/c_abi_client.c
+    (descriptor text in, point sets in, resident Adam, trial function out) compiled by gcc and run against the emulation build."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = _build_c_client(os.path.join(root, "tests", "emu"), "libpinn_emu.so", str(tmp_path / "c_abi_client"))
+    assert r.returncode == 0 and "backend: emu" in r.stdout and "u(0.5) = +1.00" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_plain_c_client_of_the_abi_gpu(hip_lib, tmp_path):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = _build_c_client(os.path.join(root, "neuralpde.jl_amd", "csrc"), "libpinn_hip.so", str(tmp_path / "c_abi_client"))
+    assert r.returncode == 0 and "backend: hip" in r.stdout and "u(0.5) = +1.00" in r.stdout, r.stdout + r.stderr
