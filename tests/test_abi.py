@@ -59,16 +59,21 @@ def _build_c_client(libdir, libname, out):
     return subprocess.run([out], capture_output=True, text=True, timeout=600)
 
 
+def _u_mid_ok(out):
+    m = re.search(r"u\(0\.5\) = ([+-][0-9.]+)", out)              # the trained trial function at the midpoint: sin(pi / 2) = 1
+    return m is not None and abs(float(m.group(1)) - 1.0) < 0.02
+
+
 def test_plain_c_client_of_the_abi(emu_lib, tmp_path):
     """include/pinn_hip.h is a C header (gcc -std=c99 -Werror) and the ABI is usable without any host framework: examples/c_abi_client.c
     (descriptor text in, point sets in, resident Adam, trial function out) compiled by gcc and run against the emulation build."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = _build_c_client(os.path.join(root, "tests", "emu"), "libpinn_emu.so", str(tmp_path / "c_abi_client"))
-    assert r.returncode == 0 and "backend: emu" in r.stdout and "u(0.5) = +1.00" in r.stdout, r.stdout + r.stderr
+    assert r.returncode == 0 and "backend: emu" in r.stdout and _u_mid_ok(r.stdout), r.stdout + r.stderr
 
 
 @pytest.mark.gpu
 def test_plain_c_client_of_the_abi_gpu(hip_lib, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = _build_c_client(os.path.join(root, "neuralpde.jl_amd", "csrc"), "libpinn_hip.so", str(tmp_path / "c_abi_client"))
-    assert r.returncode == 0 and "backend: hip" in r.stdout and "u(0.5) = +1.00" in r.stdout, r.stdout + r.stderr
+    assert r.returncode == 0 and "backend: hip" in r.stdout and _u_mid_ok(r.stdout), r.stdout + r.stderr
