@@ -72,3 +72,36 @@ def test_block_structure_balances():
             ends += tok == "end"
             opens += tok != "end"
     assert opens == ends, (opens, ends)
+
+
+def test_ccall_argument_types_match_the_header():
+    """argument TYPE classes (32/64-bit integers, floats, pointers, C strings) of every ccall against the C declarations: a Cint where the
+    header says int64_t would be a silent stack/register mismatch on the first real run."""
+    txt = re.sub(r"/\*.*?\*/", "", open(HDR).read(), flags=re.S)
+
+    def cclass(t):
+        t = t.strip()
+        if "*" in t:
+            return "str" if re.match(r"const\s+char\s*\*", t) else "ptr"
+        t = re.sub(r"\b[a-z_0-9]+$", "", t).strip() if re.search(r"\s", t) else t
+        return {"int": "i32", "int64_t": "i64", "float": "f32", "double": "f64", "uint64_t": "u64", "pinn_handle": "ptr", "unsigned": "u32"}.get(t, t)
+
+    def jclass(t):
+        t = t.strip()
+        if t == "Cstring":
+            return "str"
+        if t.startswith("Ptr{") or t.startswith("Ref{"):
+            return "ptr"
+        return {"Cint": "i32", "Int32": "i32", "Int64": "i64", "Clonglong": "i64", "Cfloat": "f32", "Float32": "f32", "Cdouble": "f64",
+                "Float64": "f64", "UInt64": "u64", "Culonglong": "u64", "Cuint": "u32"}.get(t, t)
+    decl = {}
+    for m in re.finditer(r"\b(pinn_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", txt):
+        args = m.group(2).strip()
+        decl[m.group(1)] = [] if args in ("", "void") else [cclass(a) for a in args.split(",")]
+    src = _strip(open(JL).read())
+    n = 0
+    for m in re.finditer(r"ccall\(sym\(:(pinn_[a-z0-9_]+)\),\s*[A-Za-z0-9_{}]+,\s*\(([^()]*(?:\([^()]*\)[^()]*)*)\)", src):
+        ja = [jclass(a) for a in re.split(r",(?![^{]*})", m.group(2).strip()) if a.strip()]
+        assert ja == decl[m.group(1)], (m.group(1), ja, decl[m.group(1)])
+        n += 1
+    assert n >= 10
