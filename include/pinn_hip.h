@@ -174,6 +174,17 @@ int pinn_get_points(pinn_handle h, int term, float* pts, int64_t n);
 int pinn_adam_init(pinn_handle h, const float* theta, int64_t p);
 int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta2, float eps, const float* term_w, double* loss_history);
 int pinn_adam_get(pinn_handle h, float* theta, int64_t p);
+/*
+ * L-BFGS on the weighted objective sum_k w_k L_k over FIXED point sets (the quasi-Newton finisher of the reference's scripts,
+ * `solve(prob, BFGS() / LBFGS(); maxiters)`, e.g. test/NNPDE1/nnpde__pde_ii_2d_poisson.jl:86 — there [3P] OptimizationOptimJL on the
+ * host; here inside the library so that C / Julia / Python callers share it).  theta (double, in/out) is iterated in double precision
+ * on the host; every objective / gradient evaluation is one fused device evaluation in fp32.  Two-loop recursion with `history` pairs,
+ * backtracking line search (Armijo), stops after `maxiters` iterations, when the gradient's max-norm falls below `gtol`, or when the line
+ * search cannot decrease the objective any more (the fp32 noise floor).  loss_history (nullable): objective after every iteration,
+ * `maxiters` entries; *iters_done: iterations performed.  Terms with device samplers are refused (the objective must not change).
+ */
+int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int history, double gtol, const float* term_w, double* loss_history,
+               int* iters_done);
 
 /* Timing of the last pinn_loss_grad*: HIP-event milliseconds of the fused residual kernels / of the whole device section. */
 int pinn_last_timing(pinn_handle h, float* kernel_ms, float* total_ms);

@@ -22,7 +22,7 @@ SYMBOLS = [
     "pinn_term_grads", "pinn_loglik_grad", "pinn_loss_grad_device", "pinn_residual", "pinn_phi", "pinn_derivative", "pinn_last_timing", "pinn_set_timing", "pinn_describe", "pinn_num_groups", "pinn_group_timing",
     "pinn_create_on", "pinn_comm_unique_id", "pinn_comm_init_rank", "pinn_comm_init_all", "pinn_comm_size", "pinn_comm_rank", "pinn_comm_destroy",
     "pinn_loss_grad_sharded_device", "pinn_loss_grad_sharded",
-    "pinn_set_sampler", "pinn_set_point_data", "pinn_set_point_weights", "pinn_get_points", "pinn_adam_init", "pinn_adam_steps", "pinn_adam_get",
+    "pinn_set_sampler", "pinn_set_point_data", "pinn_set_point_weights", "pinn_get_points", "pinn_adam_init", "pinn_adam_steps", "pinn_adam_get", "pinn_lbfgs",
 ]
 
 
@@ -80,6 +80,7 @@ class Library:
         L.pinn_adam_init.argtypes = [vp, fp, C.c_int64]
         L.pinn_adam_steps.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, fp, dp]
         L.pinn_adam_get.argtypes = [vp, fp, C.c_int64]
+        L.pinn_lbfgs.argtypes = [vp, C.POINTER(C.c_double), C.c_int64, C.c_int, C.c_int, C.c_double, fp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.pinn_group_timing.argtypes = [vp, C.c_int, fp, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
 
     @property
@@ -329,6 +330,18 @@ class Engine:
         out = np.zeros(self.P, dtype=np.float32)
         self.L.check(self.L.lib.pinn_adam_get(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), out.size), "pinn_adam_get")
         return out, hist
+
+    def lbfgs(self, theta, maxiters: int, weights=None, history: int = 10, gtol: float = 1e-8):
+        """`pinn_lbfgs`: L-BFGS on the weighted objective over the installed (fixed) point sets; returns (theta float64, objective after
+        every performed iteration)."""
+        th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64)).copy()
+        hist = np.zeros(int(maxiters), dtype=np.float64)
+        done = C.c_int(0)
+        w = _f32(weights) if weights is not None else None
+        self.L.check(self.L.lib.pinn_lbfgs(self.h, th.ctypes.data_as(C.POINTER(C.c_double)), th.size, int(maxiters), int(history), float(gtol),
+                                           w.ctypes.data_as(C.POINTER(C.c_float)) if w is not None else None,
+                                           hist.ctypes.data_as(C.POINTER(C.c_double)), C.byref(done)), "pinn_lbfgs")
+        return th, hist[:done.value]
 
     def group_timings(self):
         out = []

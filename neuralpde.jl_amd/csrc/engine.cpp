@@ -879,6 +879,88 @@ int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta
     return 0;
 }
 
+int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int history, double gtol, const float* term_w, double* loss_history,
+               int* iters_done) {
+    if (!h || !theta) return fail("pinn_lbfgs: null argument");
+    pinn_engine& E = *h;
+    DeviceScope scope(E.device);
+    if (p != E.ntheta) return fail("pinn_lbfgs: theta length " + std::to_string(p) + " != ntheta " + std::to_string(E.ntheta));
+    if (maxiters <= 0 || history <= 0 || history > 64) return fail("pinn_lbfgs: maxiters must be positive and history in 1..64");
+    for (auto& T : E.terms)
+        if (T.sampler != 0) return fail("pinn_lbfgs: a term redraws its points on the device; L-BFGS needs a fixed objective (fixed point sets)");
+    if (ensure_points(E)) return 1;
+    const int K = (int)E.terms.size();
+    const size_t P = (size_t)p;
+    std::vector<float> th32(P);
+    std::vector<double> g(P), x(theta, theta + P), xn(P), gn(P), d(P), q(P);
+    auto eval = [&](const std::vector<double>& at, std::vector<double>& grad, double& f) -> int {      // one fused device evaluation
+        for (size_t i = 0; i < P; ++i) th32[i] = (float)at[i];
+        if (upload_theta(E, th32.data(), p)) return 1;
+        if (run_loss_grad(E, E.d_theta, E.hp_out, term_w, -1, false, E.hp_raw)) return 1;
+        if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+        f = 0.0;
+        for (int k = 0; k < K; ++k) f += (double)(term_w ? term_w[k] : 1.0f) * E.hp_raw[k] / (double)E.terms[k].n_norm;
+        for (size_t i = 0; i < P; ++i) grad[i] = (double)E.hp_out[i];
+        return 0;
+    };
+    auto dot = [&](const std::vector<double>& a, const std::vector<double>& b) { double s = 0.0; for (size_t i = 0; i < P; ++i) s += a[i] * b[i]; return s; };
+    double f = 0.0;
+    if (eval(x, g, f)) return 1;
+    std::deque<std::vector<double>> S, Y;
+    std::deque<double> RHO;
+    int it = 0;
+    for (; it < maxiters; ++it) {
+        double gmax = 0.0;
+        for (size_t i = 0; i < P; ++i) gmax = std::max(gmax, std::fabs(g[i]));
+        if (!(gmax > gtol)) break;
+        // two-loop recursion: d = -H g
+        q = g;
+        std::vector<double> alpha(S.size());
+        for (int i = (int)S.size() - 1; i >= 0; --i) {
+            alpha[i] = RHO[i] * dot(S[i], q);
+            for (size_t j = 0; j < P; ++j) q[j] -= alpha[i] * Y[i][j];
+        }
+        double gamma = 1.0;
+        if (!S.empty()) gamma = dot(S.back(), Y.back()) / dot(Y.back(), Y.back());
+        for (size_t j = 0; j < P; ++j) q[j] *= gamma;
+        for (size_t i = 0; i < S.size(); ++i) {
+            const double beta = RHO[i] * dot(Y[i], q);
+            for (size_t j = 0; j < P; ++j) q[j] += (alpha[i] - beta) * S[i][j];
+        }
+        for (size_t j = 0; j < P; ++j) d[j] = -q[j];
+        double gd = dot(g, d);
+        if (!(gd < 0.0)) {                               // not a descent direction (stale curvature): restart from steepest descent
+            S.clear(); Y.clear(); RHO.clear();
+            for (size_t j = 0; j < P; ++j) d[j] = -g[j];
+            gd = dot(g, d);
+        }
+        // backtracking line search (Armijo, c1 = 1e-4); first iteration: step 1 / |g|_1-ish scale
+        double t = S.empty() ? std::min(1.0, 1.0 / std::sqrt(dot(g, g))) : 1.0;
+        double fn = f;
+        bool ok = false;
+        for (int ls = 0; ls < 30; ++ls) {
+            for (size_t j = 0; j < P; ++j) xn[j] = x[j] + t * d[j];
+            if (eval(xn, gn, fn)) return 1;
+            if (std::isfinite(fn) && fn <= f + 1e-4 * t * gd) { ok = true; break; }
+            t *= 0.5;
+        }
+        if (!ok) break;                                  // no decrease along a descent direction: the evaluation's noise floor
+        std::vector<double> sv(P), yv(P);
+        for (size_t j = 0; j < P; ++j) { sv[j] = xn[j] - x[j]; yv[j] = gn[j] - g[j]; }
+        const double sy = dot(sv, yv);
+        if (sy > 1e-10 * std::sqrt(dot(sv, sv) * dot(yv, yv))) {
+            S.push_back(std::move(sv)); Y.push_back(std::move(yv)); RHO.push_back(1.0 / sy);
+            if ((int)S.size() > history) { S.pop_front(); Y.pop_front(); RHO.pop_front(); }
+        }
+        x.swap(xn); g.swap(gn); f = fn;
+        if (loss_history) loss_history[it] = f;
+    }
+    if (loss_history) for (int i = it; i < maxiters; ++i) loss_history[i] = f;
+    if (iters_done) *iters_done = it;
+    for (size_t i = 0; i < P; ++i) theta[i] = x[i];
+    return 0;
+}
+
 int pinn_adam_get(pinn_handle h, float* theta, int64_t p) {
     if (!h || !theta) return fail("pinn_adam_get: null argument");
     pinn_engine& E = *h;

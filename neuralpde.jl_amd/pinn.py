@@ -395,6 +395,12 @@ def _host_quasi_newton(prob: OptimizationProblem, alg, maxiters: int, callback) 
     if getattr(rep, "_device_samplers", None) or rep._state.get("resample") is not None:
         raise ValueError("BFGS / LBFGS need a fixed objective: use GridTraining, QuadratureTraining or QuasiRandomTraining(...; resampling = false, "
                          "minibatch = 1) (the reference's tests say the same, e.g. test/NNPDE1/nnpde__pde_vi_pde_with_mixed_derivative.jl:76)")
+    if isinstance(alg, LBFGS) and callback is None and rep.additional_loss is None and rep.adaloss.reweight_every <= 0:
+        # the library's own L-BFGS (pinn_lbfgs): same recursion, no Python in the loop
+        theta, hist = rep.engine.lbfgs(prob.u0, int(maxiters), rep._weights_now(), history=alg.m, gtol=alg.gtol)
+        rep.iteration[0] += len(hist)
+        final = float(hist[-1]) if len(hist) else float(prob.f.value_and_grad(np.asarray(prob.u0, dtype=np.float64))[0])
+        return OptimizationSolution(theta.astype(prob.u0.dtype), final, hist if len(hist) else np.array([final]))
     losses, it, last = [], [0], [None]
 
     def fun(th):

@@ -1,8 +1,8 @@
 """The reference's own END-TO-END acceptance tests, run through the engine on the hardware: same PDE systems, same networks, same point
 designs, the reference's own known answers (analytic solutions) and its own tolerances (`isapprox` semantics: 2-norm of the whole
 prediction vector unless the test names another norm).  Adam stages run in the resident-theta loop (`pinn_adam_steps`); where the
-reference finishes with BFGS the mirror either runs more Adam iterations or the mirror API's host-side BFGS (scipy over the engine's
-fused value_and_grad — the optimiser stays on the host in the reference too).  These are the
+reference finishes with BFGS the mirror runs more Adam iterations, the mirror API's host-side BFGS (scipy over the engine's fused
+value_and_grad — the optimiser stays on the host in the reference too) or the library's own L-BFGS (`pinn_lbfgs`).  These are the
 known-answer tests the reference holds for the PhysicsInformedNN path; every case cites its file and line.
 `PINN_ACCEPT_ON_EMU=1` runs the same statements on the CPU emulation (development aid)."""
 import math
@@ -137,7 +137,7 @@ def test_pde_vi_mixed_derivative(npde, lib):
     theta0 = npde.initialparameters(np.random.default_rng(100), chain)
     strat = npde.QuasiRandomTraining(2048, sampling_alg=npde.SobolSample(seed=1), resampling=False, minibatch=1)
     prob = npde.discretize(npde.PDESystem([eq], bcs, dom, [x, y], [u(x, y)]), npde.PhysicsInformedNN(chain, strat, init_params=theta0))
-    theta, losses = train(npde, prob, [("bfgs", 500)])                        # the reference's schedule
+    theta, losses = train(npde, prob, [("lbfgs", 500)])                       # the reference's schedule (BFGS there; L-BFGS of the library here)
     pts = grid2((0.0, 1.0), (0.0, 1.0), 0.01)
     real = pts[0] + pts[0] * pts[1] + pts[1] ** 2 / 2
     pred = prob.pinnrep.phi(pts, theta)[0]
@@ -310,7 +310,7 @@ def test_pde_i_heterogeneous_system(npde, lib):
     theta0 = np.concatenate([npde.initialparameters(rng, c) for c in chains])
     disc = npde.PhysicsInformedNN(chains, npde.GridTraining(0.1), init_params=theta0)
     prob = npde.discretize(npde.PDESystem(eqs, bcs, dom, [x, y, z], [u(x, y, z), v(y, x), h(z), p(x, z)]), disc)
-    theta, losses = train(npde, prob, [("bfgs", 2000)])
+    theta, losses = train(npde, prob, [("lbfgs", 2000)])
     g = np.arange(0.0, 1.0 + 0.05, 0.1)
     X3 = np.stack([a.ravel() for a in np.meshgrid(g, g, g, indexing="ij")])
     X2 = np.stack([a.ravel() for a in np.meshgrid(g, g, indexing="ij")])
