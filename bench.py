@@ -9,7 +9,9 @@ weights for fixed theta and fixed collocation sets, delivered to the host (the r
 the host, src/discretize.jl:776-780), i.e. exactly what NeuralPDE.jl computes once per optimiser iteration
 (src/discretize.jl:567-598 + Zygote, :778).
 
-Workload at every N (config.workload): BASELINE.json configs[1] — 2-D Poisson on the unit square, 4x64 tanh MLP,
+Workload at every N (config.workload; `--workload cfg3|cfg4|cfg5` selects another BASELINE config for profiling / scaling proxies, and
+`--emulate-world N` times rank 0's share of an N-rank job on one GPU incl. the engine's RCCL call — tools/scaling_proxy.py):
+BASELINE.json configs[1] — 2-D Poisson on the unit square, 4x64 tanh MLP,
 QuasiRandomTraining: 65,536 interior points + 4 boundary terms x 65,536 points, all resident in HBM before
 the timed region.  N > 1 is STRONG scaling (the same 65,536+4x65,536 points are sharded over the ranks in contiguous
 blocks; one RCCL all-reduce of [gradient | per-term squared-residual sums] per step).
@@ -99,12 +101,63 @@ def pmc_traffic(kernel_key, points):
     return None, None
 
 
+def roofline_entries(eng, kern_ms, sizes, world):
+    """One roofline entry per fused residual LAUNCH of the step.  A MERGED launch (the interior jet set and the value-only boundary set
+    of one network walked by one persistent kernel, pinn_group_launched_by) is one entry covering both groups' points and flops.
+    `achieved` / `frac` count the flops the kernel EXECUTES (SURVEY.md §8d formula 6 C S - 2 C n0 n1 with C = the jet channels each
+    member carries) / its mean HIP-event duration over the sampled launches of the timed region.  The 2-D Poisson interior residual as
+    written needs C = 5 channels (u, u_x, u_y, u_xx, u_yy: 373,120 flop/point, the §8d figure); the kernel carries u_xx + u_yy as ONE
+    forward-Laplacian channel (C = 4), so the §8d "useful work" rate is reported separately as frac_algorithmic."""
+    import re
+    import numpy as np
+    groups = eng.group_timings()
+    desc = eng.describe()
+    names = dict((int(m.group(1)), m.group(2)) for m in re.finditer(r"group (\d+).*?kernel=(\S+)", desc))
+    coupled = set(int(m.group(1)) for m in re.finditer(r"group (\d+) \[coupled", desc))
+    per_kernel = []
+    for gi, g in enumerate(groups):
+        if g["launched_by"] != gi:
+            continue                                    # rode on another group's launch
+        members = [h for h in groups if h["launched_by"] == gi]
+        ms = float(np.mean(kern_ms[:, gi]))
+        if not (ms > 0):
+            continue
+        f_exec = sum(algorithmic_flops_per_point(sizes, h["channels"]) * h["points"] for h in members)
+        # §8d algorithmic channel count: the forward-Laplacian channel stands for the pure second derivatives it sums (2-D: +1, 3-D: +2)
+        def lap_extra(key):                              # kernel names carry the Laplacian axis mask as _L<mask>_
+            m = re.search(r"_L(\d+)_", key)
+            return max(0, bin(int(m.group(1))).count("1") - 1) if m else 0
+        f_alg = sum(algorithmic_flops_per_point(sizes, h["channels"] + lap_extra(names.get(h["group"], ""))) * h["points"] for h in members)
+        pts = sum(h["points"] for h in members)
+        key = "+".join(names.get(h["group"], f"group{h['group']}") for h in members)
+        traffic, tsrc = pmc_traffic(key, pts) if world == 1 else (None, None)
+        kind = "coupled reverse launch (forward launches not timed)" if gi in coupled else ("merged interior+boundary residual+grad" if len(members) > 1 else
+               ("interior residual+grad" if g["channels"] > 1 else "boundary residual+grad"))
+        tf_exec, tf_alg = f_exec / (ms * 1e-3) / 1e12, f_alg / (ms * 1e-3) / 1e12
+        per_kernel.append({
+            "bound": "mfma", "achieved": tf_exec, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf_exec / PEAK_FP32_MFMA_TFLOPS,
+            "traffic": traffic, "traffic_source": tsrc,
+            "kernel": f"{'k_wave2m' if len(members) > 1 else 'k_wave2'}<{key}, FUSED> ({kind}, neuron-split workgroups)",
+            "kernel_ms": ms, "kernel_ms_min": float(np.min(kern_ms[:, gi])), "kernel_ms_max": float(np.max(kern_ms[:, gi])),
+            "launches_sampled": int(kern_ms.shape[0]), "points_per_launch": pts,
+            "executed_channels": [h["channels"] for h in members], "executed_flops_per_launch": f_exec, "algorithmic_flops_per_launch": f_alg,
+            "achieved_algorithmic": tf_alg, "frac_algorithmic": tf_alg / PEAK_FP32_MFMA_TFLOPS,
+            "algorithmic_bytes_per_launch": 4 * sizes[0] * pts})
+    return per_kernel
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=65536)
+    ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2",
+                    help="BASELINE.json config; cfg2 (default) is the one the metric is quoted on — the others are scaling-proxy / profiling runs")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="scaling PROXY on one GPU: this process evaluates rank 0's contiguous 1/N share of every term's point set (n_norm = "
+                         "the global N) and runs the engine's RCCL all-reduce on a 1-rank communicator, so the collective's launch cost is "
+                         "inside the step; value = what N such ranks would deliver together (tools/scaling_proxy.py, profiles/r03_scaling_proxy.json)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--events", choices=["all", "none"], default="all",
                     help="HIP events recorded inside the timed region around every fused residual kernel (sampled steps only), or none")
@@ -121,6 +174,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert not (args.emulate_world and world > 1), "--emulate-world is a single-GPU proxy"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     # Control plane (rendezvous, barrier, max-over-ranks of the elapsed time): a gloo process group over TCP.  Data plane (the ONE
     # all-reduce per step of [gradient | per-term sums]): the ENGINE's own RCCL communicator (pinn_comm_init_rank +
@@ -142,7 +196,7 @@ def main():
     npde = pinn_import.load()
     from neuralpde_jl_amd import workloads
 
-    wl = workloads.cfg2_poisson2d(points=args.points)
+    wl = workloads.cfg2_poisson2d(points=args.points) if args.workload == "cfg2" else workloads.CONFIGS[args.workload]()
     disc = wl.discretization()
     rep = npde.symbolic_discretize(wl.pde_system, disc)
     eng = rep.engine
@@ -150,13 +204,18 @@ def main():
     sets = rep.pde_train_sets + rep.bcs_train_sets
     K, P = eng.K, eng.P
     n_glob = [s.shape[1] for s in sets]
-    # shard every term's set into contiguous column blocks (strong scaling)
-    if world > 1:
+    theta0 = np.asarray(rep.flat_init_params, dtype=np.float32)
+    tw = rep._weights_now() if hasattr(rep, "_weights_now") else None        # cfg4: bc weights 10 (NonAdaptiveLoss)
+    tw = None if tw is None or np.all(np.asarray(tw) == 1.0) else list(np.asarray(tw, dtype=np.float32))
+    # shard every term's set into contiguous column blocks (strong scaling); --emulate-world: rank 0's share of an N-rank job
+    eworld = args.emulate_world if args.emulate_world > 0 else world
+    erank = 0 if args.emulate_world > 0 else rank
+    if eworld > 1:
         for k, s in enumerate(sets):
             n = s.shape[1]
-            lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+            lo, hi = (n * erank) // eworld, (n * (erank + 1)) // eworld
             eng.set_points(k, s[:, lo:hi], n_norm=n)
-    theta_d = torch.tensor(wl.theta, dtype=torch.float32, device="cuda")
+    theta_d = torch.tensor(theta0, dtype=torch.float32, device="cuda")
     out_d = torch.zeros(P + K, dtype=torch.float32, device="cuda")
     out_h = torch.zeros(P + K, dtype=torch.float32).pin_memory()
     stream = torch.cuda.current_stream()
@@ -178,13 +237,16 @@ def main():
                 eng.comm_destroy()
             comm_mode = "torch-fallback"
             data_group = dist.new_group(backend="nccl", device_id=torch.device("cuda", local_dev))
+    if args.emulate_world > 0:
+        eng.comm_init_rank(1, 0, npde.comm_unique_id())           # the real RCCL entry points on a 1-rank communicator
+    sharded = world > 1 or args.emulate_world > 0
 
     def step():
-        if world > 1 and comm_mode == "engine":
-            eng.loss_grad_sharded_device(theta_d.data_ptr(), out_d.data_ptr(), None, stream.cuda_stream)
+        if sharded and (comm_mode == "engine" or args.emulate_world > 0):
+            eng.loss_grad_sharded_device(theta_d.data_ptr(), out_d.data_ptr(), tw, stream.cuda_stream)
             out_h.copy_(out_d, non_blocking=True)
         elif world > 1:
-            eng.loss_grad_device(theta_d.data_ptr(), out_d.data_ptr(), None, stream.cuda_stream)
+            eng.loss_grad_device(theta_d.data_ptr(), out_d.data_ptr(), tw, stream.cuda_stream)
             if data_group is not None:
                 dist.all_reduce(out_d, group=data_group)
             else:                                                  # gloo functional check: reduce on the host
@@ -193,27 +255,36 @@ def main():
                 out_d.copy_(tmp)
             out_h.copy_(out_d, non_blocking=True)
         else:
-            eng.loss_grad_device(theta_d.data_ptr(), out_h.data_ptr(), None, stream.cuda_stream)
+            eng.loss_grad_device(theta_d.data_ptr(), out_h.data_ptr(), tw, stream.cuda_stream)
         stream.synchronize()                 # the optimiser needs loss + gradient on the host every iteration
 
     host_path_ms = None
-    if world == 1:
+    loss_only_ms = None
+    if world == 1 and not sharded:
         # (measured BEFORE the warm-up and the timed region: it doubles as the clock / cache warm-up of the device)
         # cross-check of the zero-copy delivery against a plain device-buffer evaluation + copy
         eng.set_timing(0, -1)
         step()
-        eng.loss_grad_device(theta_d.data_ptr(), out_d.data_ptr(), None, stream.cuda_stream)
+        eng.loss_grad_device(theta_d.data_ptr(), out_d.data_ptr(), tw, stream.cuda_stream)
         stream.synchronize()
         assert np.array_equal(out_d.cpu().numpy(), out_h.numpy()), "zero-copy host delivery differs from the device buffer"
         # the C-ABI host entry point (theta from host memory, loss + gradient back to host memory: PCIe both ways)
-        th = np.ascontiguousarray(wl.theta, dtype=np.float32)
+        th = np.ascontiguousarray(theta0, dtype=np.float32)
         for _ in range(5):
-            eng.loss_grad(th)
+            eng.loss_grad(th, tw)
         nh = 25
         t1 = time.perf_counter()
         for _ in range(nh):
-            eng.loss_grad(th)
+            eng.loss_grad(th, tw)
         host_path_ms = (time.perf_counter() - t1) / nh * 1e3
+        # the loss-only evaluation through the same entry point (grad = NULL: no reverse sweep), same numbers for the losses
+        l_full, _ = eng.loss_grad(th, tw)
+        l_only, _ = eng.loss_grad(th, tw, want_grad=False)
+        assert np.array_equal(l_full, l_only), "loss-only evaluation differs from the fused evaluation's losses"
+        t1 = time.perf_counter()
+        for _ in range(nh):
+            eng.loss_grad(th, tw, want_grad=False)
+        loss_only_ms = (time.perf_counter() - t1) / nh * 1e3
     else:
         for _ in range(30):                  # N > 1: the same device clock / cache settling the N = 1 leg gets from the checks above
             step()
@@ -245,51 +316,16 @@ def main():
         el = float(t.item())
 
     if rank == 0:
-        import re
         res = out_h.numpy()
         losses = res[P:] / np.array(n_glob)
-        groups = eng.group_timings()
-        names = dict((int(m.group(1)), m.group(2)) for m in re.finditer(r"group (\d+).*?kernel=(\S+)", eng.describe()))
-        kern_ms = np.array(kern_ms) if kern_ms else np.full((1, len(groups)), np.nan)
+        ngroups = len(eng.group_timings())
+        kern_ms = np.array(kern_ms) if kern_ms else np.full((1, ngroups), np.nan)
         sizes = wl.chains[0].sizes
         n_int = n_glob[0]
-        # One roofline entry per fused residual kernel.  `achieved` / `frac` count the flops the kernel EXECUTES
-        # (SURVEY.md §8d formula 6 C S - 2 C n0 n1 with C = the jet channels the kernel carries) / its mean HIP-event duration over
-        # the sampled launches of the timed region.  The interior residual as written needs C = 5 channels (u, u_x, u_y, u_xx, u_yy:
-        # 373,120 flop/point, the §8d figure); the kernel carries u_xx + u_yy as ONE forward-Laplacian channel (C = 4),
-        # so the §8d "useful work" rate is reported separately as achieved_algorithmic / frac_algorithmic.
-        C_ALG = {True: 5, False: 1}
-        per_kernel = []
-        for gi, g in enumerate(groups):
-            ms = float(np.mean(kern_ms[:, gi]))
-            interior = g["channels"] > 1
-            f_exec = algorithmic_flops_per_point(sizes, g["channels"])
-            f_alg = algorithmic_flops_per_point(sizes, C_ALG[interior])
-            tf_exec = f_exec * g["points"] / (ms * 1e-3) / 1e12
-            tf_alg = f_alg * g["points"] / (ms * 1e-3) / 1e12
-            key = names.get(gi, f"group{gi}")
-            traffic, tsrc = pmc_traffic(key, g["points"]) if world == 1 else (None, None)
-            per_kernel.append({
-                "bound": "mfma", "achieved": tf_exec, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf_exec / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": traffic, "traffic_source": tsrc,
-                "kernel": f"k_wave2<{key}, FUSED> ({'interior residual+grad' if interior else 'boundary residual+grad'}, neuron-split workgroups)",
-                "kernel_ms": ms, "kernel_ms_min": float(np.min(kern_ms[:, gi])), "kernel_ms_max": float(np.max(kern_ms[:, gi])),
-                "launches_sampled": int(kern_ms.shape[0]), "points_per_launch": g["points"], "executed_channels": g["channels"],
-                "executed_flops_per_point": f_exec, "algorithmic_flops_per_point": f_alg,
-                "achieved_algorithmic": tf_alg, "frac_algorithmic": tf_alg / PEAK_FP32_MFMA_TFLOPS,
-                "algorithmic_bytes_per_launch": 4 * sizes[0] * g["points"]})
-        dom = int(np.argmax([k["kernel_ms"] for k in per_kernel]))          # dominant = the kernel with the most device time
-        all_ms = float(np.mean(kern_ms.sum(axis=1)))
-        flops_all = sum(k["executed_flops_per_point"] * k["points_per_launch"] for k in per_kernel)
-        roof = dict(per_kernel[dom])
-        roof.update({"all_fused_kernels_ms": all_ms, "all_fused_kernels_tflops": flops_all / (all_ms * 1e-3) / 1e12,
-                     "all_fused_kernels_frac": flops_all / (all_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                     "events": f"HIP events around every fused kernel on every {every}. step of the timed region: {kern_ms.shape[0]} launches averaged",
-                     "note": "frac = executed flops / kernel time / fp32 MFMA peak (157.3 TF/s at the 2.4 GHz peak clock; the shader clock under this "
-                             "load is ~1.9 GHz); traffic = HBM-side bytes per launch from the committed rocprofv3 --pmc passes named in traffic_source "
-                             "(null: no profile for this kernel and size)"})
+        per_kernel = roofline_entries(eng, kern_ms, sizes, world if not args.emulate_world else 2)
         line = {
-            "metric": "collocation-point residual+grad evals/sec, 2D Poisson 4x64 MLP",
+            "metric": "collocation-point residual+grad evals/sec, 2D Poisson 4x64 MLP" if args.workload == "cfg2" else
+                      f"collocation-point residual+grad evals/sec, {wl.name}",
             "value": n_int * args.steps / el,
             "unit": "interior-point residual+grad evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -299,18 +335,36 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl.name, "interior_points": n_int, "boundary_terms": K - 1,
-                       "boundary_points_per_term": n_glob[1], "theta": P,
+            "config": {"workload": wl.name, "interior_points": n_int, "boundary_terms": K - len(rep.pde_train_sets),
+                       "boundary_points_per_term": n_glob[-1], "theta": P,
                        "parallelism": f"point-shard x{world}" if world > 1 else "single",
                        "all_reduce": ({"engine": "engine-owned RCCL communicator (pinn_loss_grad_sharded_device)", "torch": f"torch.distributed ({backend})",
                                        "torch-fallback": "torch.distributed (nccl) after the engine communicator failed"}[comm_mode] if world > 1 else None)},
             "point_terms_per_s": sum(n_glob) * args.steps / el,
             "host_entry_ms_per_step": host_path_ms,     # pinn_loss_grad: theta host -> device, results device -> host (PCIe-inclusive)
+            "loss_only_host_entry_ms": loss_only_ms,    # pinn_loss_grad(grad = NULL): the loss-only evaluation through the same entry point
             "loss_terms": [float(v) for v in losses],
-            "roofline": roof,
-            "roofline_kernels": per_kernel,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.emulate_world > 0:
+            line["config"].update({"emulate_world": args.emulate_world, "parallelism": f"PROXY: rank 0's 1/{args.emulate_world} share on one GPU",
+                                   "all_reduce": "engine-owned RCCL all-reduce on a 1-rank communicator (launch cost inside the step)"})
+            line["proxy"] = True
+            line["value_note"] = ("projected whole-job rate if all N ranks take as long as this share (no xGMI hop measured): "
+                                  "global interior points x steps / time of rank 0's share")
+        if per_kernel:
+            dom = int(np.argmax([k["kernel_ms"] for k in per_kernel]))          # dominant = the launch with the most device time
+            all_ms = float(sum(k["kernel_ms"] for k in per_kernel))
+            flops_all = sum(k["executed_flops_per_launch"] for k in per_kernel)
+            roof = dict(per_kernel[dom])
+            roof.update({"all_fused_kernels_ms": all_ms, "all_fused_kernels_tflops": flops_all / (all_ms * 1e-3) / 1e12,
+                         "all_fused_kernels_frac": flops_all / (all_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                         "events": f"HIP events around every fused kernel on every {every}. step of the timed region: {kern_ms.shape[0]} launches averaged",
+                         "note": "frac = executed flops / kernel time / fp32 MFMA peak (157.3 TF/s at the 2.4 GHz peak clock; the shader clock under this "
+                                 "load is ~1.9 GHz); traffic = HBM-side bytes per launch from the committed rocprofv3 --pmc passes named in traffic_source "
+                                 "(null: no profile for this kernel and size)"})
+            line["roofline"] = roof
+            line["roofline_kernels"] = per_kernel
+        if world == 1 and not sharded and not args.no_cpu_baseline and args.workload == "cfg2":
             line["cpu_baseline"] = cpu_baseline(npde, wl, sets)
         print(json.dumps(line))
     if world > 1:

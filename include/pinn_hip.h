@@ -71,6 +71,10 @@ int pinn_set_points_device(pinn_handle h, int term, const float* d_pts, int64_t 
  *   grad           = d/dtheta sum_k term_w[k] * term_losses[k]       (P floats, nullable)
  * theta: P floats (host).  term_w: K floats (adaptive-loss weights, src/adaptive_losses.jl; NULL = ones).
  * Deterministic: identical inputs give bit-identical outputs.
+ * grad == NULL selects the LOSS-ONLY evaluation: forward pass + residual + sums of squares, no records, no reverse sweep, no
+ * gradient reduction (about a third of the full evaluation) — the cost class of the reference's per-term closures when they are only
+ * evaluated, not differentiated (src/training_strategies.jl:215-221: callbacks, MiniMax / SoftAdapt reweighting, rejected line-search
+ * trials).  The term losses are the same numbers the full evaluation returns.
  */
 int pinn_loss_grad(pinn_handle h, const float* theta, int64_t p, const float* term_w,
                    double* term_losses, float* grad);
@@ -104,6 +108,9 @@ int pinn_loglik_grad(pinn_handle h, const float* theta, int64_t p, const double*
  * reduction kernel then delivers the result to the host without a copy command (what pinn_loss_grad does internally).
  */
 int pinn_loss_grad_device(pinn_handle h, const float* d_theta, const float* term_w, float* d_out, void* stream);
+/* Loss-only counterpart: d_sums = K floats in device-accessible memory = this shard's sum of squared residuals per term
+ * (divide by n_norm_k; the same numbers pinn_loss_grad_device writes to d_out[P..P+K)).  Asynchronous on `stream`. */
+int pinn_loss_device(pinn_handle h, const float* d_theta, float* d_sums, void* stream);
 
 /*
  * Engine-owned data parallelism over the GPUs of one node: every term's point set is split into contiguous column
@@ -197,6 +204,10 @@ int pinn_set_timing(pinn_handle h, int level, int group);
  * points / jet channels / wave tiles it processed. */
 int pinn_num_groups(pinn_handle h);
 int pinn_group_timing(pinn_handle h, int group, float* ms, int64_t* points, int* channels, int* tiles);
+/* Launch group whose launch carried group g's tiles in the last evaluation: g itself, or the head group of a MERGED launch (two
+ * kernel-family members of one network — e.g. the interior jet set and the value-only boundary set — walked by one persistent
+ * kernel; the head's pinn_group_timing then covers both).  -1: not launched yet / bad index. */
+int pinn_group_launched_by(pinn_handle h, int group);
 /* Introspection used by tests and bench: writes a short human-readable description of the kernel plan. */
 int pinn_describe(pinn_handle h, char* buf, int64_t buflen);
 

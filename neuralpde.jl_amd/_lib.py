@@ -23,6 +23,7 @@ SYMBOLS = [
     "pinn_create_on", "pinn_comm_unique_id", "pinn_comm_init_rank", "pinn_comm_init_all", "pinn_comm_size", "pinn_comm_rank", "pinn_comm_destroy",
     "pinn_loss_grad_sharded_device", "pinn_loss_grad_sharded",
     "pinn_set_sampler", "pinn_set_point_data", "pinn_set_point_weights", "pinn_get_points", "pinn_adam_init", "pinn_adam_steps", "pinn_adam_get", "pinn_lbfgs",
+    "pinn_loss_device", "pinn_group_launched_by",
 ]
 
 
@@ -66,6 +67,8 @@ class Library:
         L.pinn_term_grads.argtypes = [vp, fp, C.c_int64, dp, fp]
         L.pinn_loglik_grad.argtypes = [vp, fp, C.c_int64, dp, dp, fp, dp]
         L.pinn_loss_grad_device.argtypes = [vp, vp, fp, vp, vp]
+        L.pinn_loss_device.argtypes = [vp, vp, vp, vp]
+        L.pinn_group_launched_by.argtypes = [vp, C.c_int]
         L.pinn_residual.argtypes = [vp, C.c_int, fp, C.c_int64, fp]
         L.pinn_phi.argtypes = [vp, C.c_int, fp, C.c_int64, fp, C.c_int64, fp]
         L.pinn_derivative.argtypes = [vp, C.c_int, fp, C.c_int64, fp, C.c_int64, C.c_int, C.POINTER(C.c_int), fp]
@@ -185,6 +188,8 @@ class Engine:
         self.L.check(self.L.lib.pinn_set_points_device(self.h, term, C.c_void_p(dptr), n, n_norm), "pinn_set_points_device")
 
     def loss_grad(self, theta, weights: Optional[Sequence[float]] = None, want_grad: bool = True):
+        """K term losses (+ gradient).  want_grad=False is the LOSS-ONLY evaluation (grad = NULL at the ABI): forward pass + residuals +
+        sums of squares, no reverse sweep — the same loss values at about a third of the cost."""
         th = _f32(theta)
         losses = np.zeros(self.K, dtype=np.float64)
         grad = np.zeros(self.P, dtype=np.float32) if want_grad else None
@@ -235,6 +240,10 @@ class Engine:
         self.L.check(self.L.lib.pinn_loss_grad_device(
             self.h, C.c_void_p(d_theta), w.ctypes.data_as(C.POINTER(C.c_float)) if w is not None else None,
             C.c_void_p(d_out), C.c_void_p(stream)), "pinn_loss_grad_device")
+
+    def loss_device(self, d_theta: int, d_sums: int, stream: int = 0):
+        """loss-only evaluation on device pointers: d_sums = K floats (this shard's sums of squared residuals per term)"""
+        self.L.check(self.L.lib.pinn_loss_device(self.h, C.c_void_p(d_theta), C.c_void_p(d_sums), C.c_void_p(stream)), "pinn_loss_device")
 
     # ---- engine-owned data parallelism (include/pinn_hip.h: pinn_comm_*) ----
     def comm_init_rank(self, nranks: int, rank: int, uid: bytes):
@@ -349,7 +358,8 @@ class Engine:
             ms, pts, ch, tiles = C.c_float(), C.c_int64(), C.c_int(), C.c_int()
             self.L.check(self.L.lib.pinn_group_timing(self.h, g, C.byref(ms), C.byref(pts), C.byref(ch), C.byref(tiles)),
                          "pinn_group_timing")
-            out.append(dict(group=g, ms=ms.value, points=pts.value, channels=ch.value, tiles=tiles.value))
+            out.append(dict(group=g, ms=ms.value, points=pts.value, channels=ch.value, tiles=tiles.value,
+                            launched_by=self.L.lib.pinn_group_launched_by(self.h, g)))
         return out
 
     def describe(self) -> str:

@@ -40,7 +40,26 @@ struct Reduce2Args {
     int stride[MAX_GROUPS], nsplit[MAX_GROUPS], nent[MAX_GROUPS], active[MAX_GROUPS];
     int ent_active[MAX_GROUPS];         // 0: this group's gradient went into another group's slabs (chained launch groups)
     int ngroups, P, K;
+    int skip_grad;                      // loss-only evaluation: only the K sums are produced, out[0, P) is left alone
 };
+// ONE-kernel reduction for the common case that a single slab set carries the whole gradient (one network whose launch groups are
+// merged / chained, family 2 or 3: every theta element has exactly one slab entry): a block sums 32 consecutive slab entries over all
+// workgroups — 32 chunks of consecutive slabs in parallel, one 16-byte load per slab and lane, then the chunk sums in order — and
+// scatters them through the entry -> theta map; one more block per term sums that term's per-wave loss partials.  Fixed association =>
+// bit-identical run to run.  (k_reduce1 + k_reduce2 read the same 26 MB with 300 blocks and pay a second dependent launch:
+// 13 + 6 us on the bench workload; this kernel: see profiles/r03_*.)
+struct ReduceOneArgs {
+    const float* slabs;                 // [nblocks][slab]
+    int slab, nblocks, nent;            // nent: floats per slab that take part (multiple of 4)
+    const int* ent_theta;               // [nent]: theta element fed by slab entry e, -1: none
+    float* out;                         // [P + K]
+    double* lossraw;                    // [K] (nullable)
+    int P, K;
+    int nloss;                          // launches whose per-wave loss partials are summed, in this order
+    const double* losspart[MAX_GROUPS];
+    int nrows[MAX_GROUPS];              // rows (waves) of losspart[i]
+};
+constexpr int RONE_CHUNKS = 32, RONE_ENT = 32;
 
 // k_expr: the residual tape of an equation that couples several networks, one thread per collocation point.
 // Inputs: the jet channels every network's FWD launch wrote ([channel][N]); outputs: d(loss)/d(jet) per slot for the
@@ -61,6 +80,7 @@ struct ExprArgs {
     float* pslab;                         // [nblocks][4 waves][4 params]
     int K, term_id;
     float* resid;                         // nullable: write r[N] and skip the adjoint
+    int loss_only;                        // 1: the sums of squares only (no adjoint, ubar untouched)
     const float* data;                    // [ndata][N] user-supplied per-point channels (OP_DATA), nullable
     const float* pw;                      // per-point factors sqrt(N w_i) of a quadrature-weighted term, nullable
 };
@@ -80,6 +100,7 @@ AUX_DEV float expr_point(int p, const ExprArgs& a, float (&pb)[4]) {
     const float r = v[a.out_row];
     for (int j = 0; j < 4; ++j) pb[j] = 0.f;
     if (a.resid) { a.resid[p] = r; return r; }
+    if (a.loss_only) return r * (a.pw ? a.pw[p] : 1.0f);
     for (int q = 0; q < R0 + a.nops; ++q) g[q] = 0.f;
     g[a.out_row] = 1.0f;
     for (int q = a.nops - 1; q >= 0; --q) {
@@ -263,6 +284,9 @@ AUX_DEV void sample_sobol_body(int e, float* pts, int d, const float* lb, const 
     pts[e] = lb[i] + (ub[i] - lb[i]) * u;
 }
 
+// sharded evaluations: the K per-term sums of squares cross the ranks as DOUBLES (their own all-reduce, grouped with the gradient's), so
+// that N > 1 delivers the same losses as N = 1 to double rounding; this writes them back into the float out vector [P .. P + K)
+AUX_DEV void sums_from_double_body(int k, float* out_sums, const double* raw) { out_sums[k] = (float)raw[k]; }
 AUX_DEV void pack_body(int i, float* packed, const int* idx, const float* theta) {
     const int j = idx[i];
     packed[i] = (j >= 0) ? theta[j] : 0.f;
@@ -304,8 +328,28 @@ AUX_DEV void reduce1_body(int e4, int chunk, int g, const Reduce1Args& a) {
         out[(size_t)(a.nent[g] + k) * ns] = s;
     }
 }
+// chunk `ch` of the one-kernel reduction: slab entries 4*e4 .. 4*e4+3 summed over the chunk's consecutive workgroups
+AUX_DEV void reduce_one_chunk(int e4, int ch, const ReduceOneArgs& a, double (&s)[4]) {
+    const int per = (a.nblocks + RONE_CHUNKS - 1) / RONE_CHUNKS;
+    const int b0 = ch * per, b1 = (b0 + per < a.nblocks) ? b0 + per : a.nblocks;
+    s[0] = s[1] = s[2] = s[3] = 0.0;
+    const float* p = a.slabs + 4 * e4;
+    AUX_UNROLL8
+    for (int b = b0; b < b1; ++b) {
+        const F4 q = *reinterpret_cast<const F4*>(p + (size_t)b * a.slab);
+        s[0] += (double)q.x; s[1] += (double)q.y; s[2] += (double)q.z; s[3] += (double)q.w;
+    }
+}
+// loss column k: rows strided over `nthreads` partial sums (thread t takes rows t, t + nthreads, ... of every launch in turn)
+AUX_DEV double reduce_one_loss_part(int k, int t, int nthreads, const ReduceOneArgs& a) {
+    double s = 0.0;
+    for (int i = 0; i < a.nloss; ++i)
+        for (int r = t; r < a.nrows[i]; r += nthreads) s += a.losspart[i][(size_t)r * a.K + k];
+    return s;
+}
 AUX_DEV void reduce2_body(int r, const Reduce2Args& a) {
     if (r < a.P) {
+        if (a.skip_grad) return;
         // contributions in batches of 4: their index loads (map -> group -> chunk row) are issued together, then the values are added
         // in the fixed map order — one contribution at a time the three dependent loads of each were serialised (12 us for a 2,209-
         // parameter net with 8 contributions per element)
@@ -346,6 +390,7 @@ AUX_DEV void reduce2_body(int r, const Reduce2Args& a) {
 constexpr int REDUCE_DIRECT_MAX = 32;
 AUX_DEV void reduce_direct_body(int r, const Reduce1Args& a1, const Reduce2Args& a) {
     if (r < a.P) {
+        if (a.skip_grad) return;
         double s = 0.0;
         for (int i = a.row_ptr[r]; i < a.row_ptr[r + 1]; ++i) {
             const int g = a.row_grp[i];
@@ -384,6 +429,9 @@ inline void launch_pack(float* packed, const int* idx, const float* theta, int n
 }
 inline void launch_params(float* params, const float* theta, const float* defaults, int np, int ne, int p_off, plat_stream) {
     for (int j = 0; j < np; ++j) params_body(j, params, theta, defaults, ne, p_off);
+}
+inline void launch_sums_from_double(float* out_sums, const double* raw, int K, plat_stream) {
+    for (int k = 0; k < K; ++k) sums_from_double_body(k, out_sums, raw);
 }
 inline void launch_adam(float* theta, float* m, float* v, const float* grad, int P, float lr, float b1, float b2, float eps, float c1, float c2, plat_stream) {
     for (int i = 0; i < P; ++i) adam_body(i, theta, m, v, grad, lr, b1, b2, eps, c1, c2);
@@ -437,6 +485,26 @@ inline void launch_expr(const ExprArgs& a, int nblocks, plat_stream) {
                 for (int j = 0; j < 4; ++j) a.pslab[(size_t)(b * 4 + w) * 4 + j] = (float)ps[j];
             }
         }
+}
+inline void launch_reduce_one(const ReduceOneArgs& a, plat_stream) {
+    for (int e4 = 0; e4 < a.nent / 4; ++e4) {
+        double tot[4] = {0, 0, 0, 0}, s[4];
+        for (int ch = 0; ch < RONE_CHUNKS; ++ch) {
+            reduce_one_chunk(e4, ch, a, s);
+            for (int e = 0; e < 4; ++e) tot[e] += s[e];
+        }
+        for (int e = 0; e < 4; ++e)
+            if (a.ent_theta[4 * e4 + e] >= 0) a.out[a.ent_theta[4 * e4 + e]] = (float)tot[e];
+    }
+    for (int k = 0; k < a.K; ++k) {
+        double part[256], s = 0.0;
+        for (int t = 0; t < 256; ++t) part[t] = reduce_one_loss_part(k, t, 256, a);
+        for (int st = 128; st >= 1; st >>= 1)
+            for (int t = 0; t < st; ++t) part[t] += part[t + st];
+        s = part[0];
+        a.out[a.P + k] = (float)s;
+        if (a.lossraw) a.lossraw[k] = s;
+    }
 }
 inline void launch_reduce(const Reduce1Args& a1, const Reduce2Args& a2, int max_n1, int max_split, plat_stream) {
     if (reduce_is_small(a1, a2)) {
@@ -555,6 +623,13 @@ inline void launch_pack(float* packed, const int* idx, const float* theta, int n
 inline void launch_params(float* params, const float* theta, const float* defaults, int np, int ne, int p_off, plat_stream st) {
     if (np > 0) hipLaunchKernelGGL(k_params, dim3(1), dim3(64), 0, st, params, theta, defaults, np, ne, p_off);
 }
+__global__ void k_sums_from_double(float* out_sums, const double* raw, int K) {
+    const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (k < K) sums_from_double_body(k, out_sums, raw);
+}
+inline void launch_sums_from_double(float* out_sums, const double* raw, int K, plat_stream st) {
+    hipLaunchKernelGGL(k_sums_from_double, dim3((K + 63) / 64), dim3(64), 0, st, out_sums, raw, K);
+}
 __global__ void __launch_bounds__(256) k_src(const SrcArgs a) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p < a.N) src_point(p, a);
@@ -564,6 +639,44 @@ inline void launch_src(const SrcArgs& a, plat_stream st) {
 }
 inline void launch_expr(const ExprArgs& a, int nblocks, plat_stream st) {
     hipLaunchKernelGGL(k_expr, dim3(nblocks), dim3(256), 0, st, a);
+}
+__global__ void __launch_bounds__(256) k_reduce_one(const ReduceOneArgs a) {
+    __shared__ double sh[RONE_CHUNKS][RONE_ENT + 1];
+    const int tid = (int)threadIdx.x;
+    const int nentblocks = (a.nent + RONE_ENT - 1) / RONE_ENT;
+    if ((int)blockIdx.x < nentblocks) {
+        const int j = tid & 7, ch = tid >> 3;
+        const int e4 = (int)blockIdx.x * (RONE_ENT / 4) + j;
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        if (4 * e4 < a.nent) reduce_one_chunk(e4, ch, a, s);
+        for (int e = 0; e < 4; ++e) sh[ch][4 * j + e] = s[e];
+        __syncthreads();
+        if (tid < RONE_ENT) {
+            const int ent = (int)blockIdx.x * RONE_ENT + tid;
+            if (ent < a.nent) {
+                double tot = 0.0;
+                for (int c2 = 0; c2 < RONE_CHUNKS; ++c2) tot += sh[c2][tid];
+                const int th = a.ent_theta[ent];
+                if (th >= 0) a.out[th] = (float)tot;
+            }
+        }
+    } else {
+        const int k = (int)blockIdx.x - nentblocks;
+        double* part = &sh[0][0];
+        part[tid] = reduce_one_loss_part(k, tid, 256, a);
+        __syncthreads();
+        for (int st = 128; st >= 1; st >>= 1) {
+            if (tid < st) part[tid] += part[tid + st];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            a.out[a.P + k] = (float)part[0];
+            if (a.lossraw) a.lossraw[k] = part[0];
+        }
+    }
+}
+inline void launch_reduce_one(const ReduceOneArgs& a, plat_stream st) {
+    hipLaunchKernelGGL(k_reduce_one, dim3((a.nent + RONE_ENT - 1) / RONE_ENT + a.K), dim3(256), 0, st, a);
 }
 __global__ void k_reduce_direct(const Reduce1Args a1, const Reduce2Args a2) {
     reduce_direct_body((int)(blockIdx.x * blockDim.x + threadIdx.x), a1, a2);

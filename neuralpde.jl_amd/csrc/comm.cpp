@@ -3,6 +3,8 @@
 // evaluation.  The reference has no collective: it aggregates the K per-term losses on the host (src/discretize.jl:568-588) — this is
 // the multi-GPU form of that aggregation, issued by the engine on the evaluation's own stream (RCCL over xGMI; the message is
 // 51 KB - 0.8 MB, i.e. latency-bound, so it is ONE collective per evaluation and never split into buckets).
+// The K sums of squares additionally travel as DOUBLES (K x 8 bytes, grouped into the same RCCL launch): every rank's sums are exact
+// doubles (fixed-order device reduction), so the N-rank losses equal the single-device ones to double rounding.
 //
 // RCCL is bound lazily (dlopen of librccl.so.1 on first use): libpinn_hip.so loads and runs single-GPU work without it, and in a
 // process that already carries an RCCL (e.g. PyTorch's bundled copy) the same instance is shared instead of a second one being mapped.
@@ -13,6 +15,7 @@
 //   * one process, several devices (what a Julia caller does): pinn_create_on(desc, device_i) for every device, pinn_comm_init_all
 //     over the handles (ncclCommInitAll), then pinn_loss_grad_sharded(handles, ...) per evaluation (host theta in, loss + gradient out).
 #include "engine_types.hpp"
+#include "aux_kernels.hpp"
 
 using namespace pe;
 
@@ -176,10 +179,16 @@ int pinn_loss_grad_sharded_device(pinn_handle h, const float* d_theta, const flo
     if (rc) return rc;
     E.timing_valid = E.timing_level >= 2;
 #ifndef PINN_EMU
-    NCCL_TRY(rccl().AllReduce(d_out, d_out, (size_t)(E.ntheta + (int64_t)E.terms.size()), ncclFloat, ncclSum, (ncclComm_t)E.comm, st), "ncclAllReduce");
+    NCCL_TRY(rccl().GroupStart(), "ncclGroupStart");
+    ncclResult_t r1 = rccl().AllReduce(d_out, d_out, (size_t)(E.ntheta + (int64_t)E.terms.size()), ncclFloat, ncclSum, (ncclComm_t)E.comm, st);
+    ncclResult_t r2 = rccl().AllReduce(E.d_lossraw, E.d_lossraw, E.terms.size(), ncclDouble, ncclSum, (ncclComm_t)E.comm, st);
+    NCCL_TRY(rccl().GroupEnd(), "ncclGroupEnd");
+    if (r1 != ncclSuccess) return nccl_fail("ncclAllReduce", r1);
+    if (r2 != ncclSuccess) return nccl_fail("ncclAllReduce", r2);
 #else
     if (E.comm_size != 1) return fail("pinn_loss_grad_sharded_device: the emulation build reduces only inside pinn_loss_grad_sharded (single process)");
 #endif
+    aux::launch_sums_from_double(d_out + E.ntheta, E.d_lossraw, (int)E.terms.size(), st);      // the exact (double) sums replace the float-summed ones
     return 0;
 }
 
@@ -210,15 +219,22 @@ int pinn_loss_grad_sharded(pinn_handle* hs, int ndev, const float* theta, int64_
         pinn_engine& E = *hs[i];
         DeviceScope scope(E.device);
         ncclResult_t rc = rccl().AllReduce(E.d_out, E.d_out, (size_t)(P + K), ncclFloat, ncclSum, (ncclComm_t)E.comm, E.stream);
+        if (rc == ncclSuccess) rc = rccl().AllReduce(E.d_lossraw, E.d_lossraw, (size_t)K, ncclDouble, ncclSum, (ncclComm_t)E.comm, E.stream);
         if (rc != ncclSuccess) { (void)rccl().GroupEnd(); return nccl_fail("ncclAllReduce", rc); }
     }
     NCCL_TRY(rccl().GroupEnd(), "ncclGroupEnd");
 #else
     {
         std::vector<float> sum((size_t)(P + K), 0.f);
-        for (int i = 0; i < ndev; ++i)
+        std::vector<double> raw((size_t)K, 0.0);
+        for (int i = 0; i < ndev; ++i) {
             for (int64_t j = 0; j < P + K; ++j) sum[j] += hs[i]->d_out[j];          // rank order: deterministic
-        for (int i = 0; i < ndev; ++i) std::memcpy(hs[i]->d_out, sum.data(), sizeof(float) * (P + K));
+            for (int k = 0; k < K; ++k) raw[k] += hs[i]->d_lossraw[k];
+        }
+        for (int i = 0; i < ndev; ++i) {
+            std::memcpy(hs[i]->d_out, sum.data(), sizeof(float) * (P + K));
+            std::memcpy(hs[i]->d_lossraw, raw.data(), sizeof(double) * K);
+        }
     }
 #endif
     // the result is identical on every device; rank 0 delivers it
@@ -226,13 +242,14 @@ int pinn_loss_grad_sharded(pinn_handle* hs, int ndev, const float* theta, int64_
     {
         DeviceScope scope(E0.device);
         if (plat_d2h(E0.hp_out, E0.d_out, sizeof(float) * (P + K), E0.stream)) return fail("D2H copy failed");
+        if (plat_d2h(E0.hp_raw, E0.d_lossraw, sizeof(double) * K, E0.stream)) return fail("D2H copy failed");
     }
     for (int i = 0; i < ndev; ++i) {
         DeviceScope scope(hs[i]->device);
         if (plat_sync(hs[i]->stream)) return fail(std::string("device error: ") + plat_last_error());
     }
     if (term_losses)
-        for (int k = 0; k < K; ++k) term_losses[k] = (double)E0.hp_out[P + k] / (double)E0.terms[k].n_norm;
+        for (int k = 0; k < K; ++k) term_losses[k] = E0.hp_raw[k] / (double)E0.terms[k].n_norm;      // exact double sums, as on one device
     if (grad) std::memcpy(grad, E0.hp_out, sizeof(float) * P);
     return 0;
 }

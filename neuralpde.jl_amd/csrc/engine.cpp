@@ -18,6 +18,10 @@ std::deque<SpecInfo>& registry() {
     static std::deque<SpecInfo> r;
     return r;
 }
+std::deque<PairInfo>& pair_registry() {
+    static std::deque<PairInfo> r;
+    return r;
+}
 }  // namespace pk
 
 namespace pe {
@@ -95,9 +99,12 @@ aux::ExprArgs expr_args(pinn_engine& E, Coupled& Cp, float scale, float* resid) 
 }  // namespace
 
 // the device section shared by all loss/grad entry points.  d_theta: theta in device memory; d_out: [P + K] floats in
-// device memory.  Launches per evaluation: pack (1 per net) -> fused residual kernel (1 per group) -> reduce1 -> reduce2.
+// device memory.  Launches per evaluation: pack (1 per net) -> fused residual kernel (1 per group, or 1 per MERGED pair of groups)
+// -> reduction (one kernel when a single slab set carries the gradient, else reduce1 -> reduce2).
+// loss_only: MODE_LOSS launches (forward + tape + sums of squares; coupled equations: forward launches + k_expr without adjoints), only
+// the K sums are reduced and d_out[0, P) is left untouched.
 int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const float* term_w, int only_term /* -1 = all */, bool timing,
-                  double* lossraw /* K exact double sums; default: E.d_lossraw */, bool packed_fresh) {
+                  double* lossraw /* K exact double sums; default: E.d_lossraw */, bool packed_fresh, bool loss_only) {
     if (ensure_points(E)) return 1;
     const int K = (int)E.terms.size();
     const bool phase_ev = timing && E.timing_level >= 2;
@@ -131,8 +138,11 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
     // opt-in: on this stack a cross-stream event wait costs 15-20 us, more than the overlap buys (profiles/r01 timeline)
     static const bool want_concurrent = std::getenv("PINN_CONCURRENT_GROUPS") != nullptr;
     const bool concurrent = want_concurrent && nfused_active >= 2 && all_small;
-    static const bool no_chain = std::getenv("PINN_NO_CHAIN") != nullptr;      // A/B switch
+    static const bool no_chain = std::getenv("PINN_NO_CHAIN") != nullptr;      // A/B switches
+    const bool no_merge = std::getenv("PINN_NO_MERGE") != nullptr;            // (read per call: the tests switch them)
+    const bool may_merge = !no_merge && !no_chain && !concurrent && !loss_only && only_term < 0;
     int nforked = 0;
+    int nslabsets = 0, slabset_group = -1;          // launch groups whose own slab set carries gradient sums in this evaluation
     if (concurrent) plat_event_record(E.ev_fork, E.stream);
     for (size_t g = 0; g < E.groups.size(); ++g) {
         Group& G = E.groups[g];
@@ -142,14 +152,26 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
             any = any || (only_term < 0 || only_term == G.terms[j]);
         }
         G.active = any;
+        G.timed = false;
+        const MergedUnit* mu = (may_merge && G.kind == 0 && G.merged >= 0) ? &E.merged[G.merged] : nullptr;
+        a1.tmp[g] = G.d_tmp; a1.slabs[g] = G.d_slabs; a1.losspart[g] = G.d_losspart;
+        a2.tmp[g] = G.d_tmp;
+        if (mu && (int)g == mu->tail) {
+            // this group's tiles ran in the head's merged launch: its gradient and its loss partials are in the head's buffers
+            G.launched_by = mu->head;
+            G.launched_blocks = E.groups[mu->head].launched_blocks;
+            a1.active[g] = 0; a2.active[g] = 0; a2.ent_active[g] = 0;
+            a1.slab[g] = G.slab_floats; a1.nblocks[g] = 0; a1.nsplit[g] = 1; a1.nent[g] = 0; a1.nwpb[g] = G.spec->NW;
+            a2.stride[g] = K; a2.nsplit[g] = 1; a2.nent[g] = 0;
+            continue;
+        }
         // chained launch groups: this group's workgroups add their sums onto the slabs the head group (same network, launched
         // earlier on the same stream in this evaluation) has just written, so the reduction reads one slab set, not two
-        const bool chained = any && !no_chain && !concurrent && G.kind == 0 && G.chain_to >= 0 && E.groups[G.chain_to].active &&
-                             G.blocks <= E.groups[G.chain_to].blocks;
-        const int nent = chained ? 0 : G.nent;
+        const bool chained = any && !loss_only && !no_chain && !concurrent && G.kind == 0 && G.chain_to >= 0 && E.groups[G.chain_to].active &&
+                             G.blocks <= E.groups[G.chain_to].launched_blocks;
+        const int nent = (chained || loss_only) ? 0 : G.nent;
         G.ga.slabs = chained ? E.groups[G.chain_to].d_slabs : G.d_slabs;
         G.ga.chain = chained ? 1 : 0;
-        a1.tmp[g] = G.d_tmp; a1.slabs[g] = G.d_slabs; a1.losspart[g] = G.d_losspart;
         if (G.spec->family == 3) G.ga.packed = d_theta + E.nets[G.net].theta_off;      // DGM: weights straight from theta
         // a single-term evaluation (pinn_term_grads) of a fused group launches ONLY that term's tiles: the K per-term gradients then cost
         // about one full evaluation in total instead of K
@@ -166,18 +188,43 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
             blocks = std::max(1, std::min(G.max_blocks, G.spec->family == 1 ? (ga_one.ntiles + 3) / 4 : ga_one.ntiles));
             ga_launch = &ga_one;
         }
+        const bool merged_head = mu && (int)g == mu->head;
+        if (merged_head) {
+            // ONE launch for this group's tiles and the tail group's: terms and tiles concatenated, the tail's after the head's
+            const Group& T2 = E.groups[mu->tail];
+            ga_one = G.ga;
+            for (size_t j = 0; j < T2.terms.size(); ++j) {
+                pk::TermDev td = T2.ga.terms[j];
+                td.tile0 += G.ga.ntiles;
+                td.scale = scale_of(T2.terms[j]);
+                ga_one.terms[G.terms.size() + j] = td;
+            }
+            ga_one.nterms = (int)(G.terms.size() + T2.terms.size());
+            ga_one.sub_terms0 = (int)G.terms.size();
+            ga_one.sub_tiles0 = G.ga.ntiles;
+            ga_one.ntiles = G.ga.ntiles + T2.ga.ntiles;
+            ga_one.scratch = mu->d_scratch;
+            ga_one.losspart = mu->d_losspart;
+            a1.losspart[g] = mu->d_losspart;
+            ga_one.chain = 0;
+            blocks = std::max(1, std::min(mu->max_blocks, ga_one.ntiles));
+            ga_launch = &ga_one;
+        }
+        G.launched_blocks = blocks;
+        G.launched_by = (int)g;
         // stage-1 chunks: the serial part of the two-stage sum is (blocks / chunks) loads in stage 1 plus (chunks x slab entries per theta
         // element: 4 per-wave copies in family 1, 1 in the others) in stage 2 — shortest for chunks ~ sqrt(blocks / entries)
         const int epe = G.spec->family == 1 ? 4 : 1;
         const int nsplit_g = std::max(1, std::min(REDUCE_SPLIT, (int)std::ceil(std::sqrt((double)blocks / epe))));
         a1.slab[g] = G.slab_floats; a1.nblocks[g] = blocks; a1.nsplit[g] = nsplit_g; a1.nent[g] = nent; a1.active[g] = any; a1.nwpb[g] = G.spec->NW;
-        a2.tmp[g] = G.d_tmp; a2.stride[g] = nent + K; a2.nsplit[g] = nsplit_g; a2.nent[g] = nent; a2.active[g] = any;
-        a2.ent_active[g] = any && !chained;
+        a2.stride[g] = nent + K; a2.nsplit[g] = nsplit_g; a2.nent[g] = nent; a2.active[g] = any;
+        a2.ent_active[g] = any && !chained && !loss_only;
         if (!any) continue;
-        max_n1 = std::max(max_n1, G.nent / 4 + K);
+        if (a2.ent_active[g]) { ++nslabsets; slabset_group = (int)g; }
+        max_n1 = std::max(max_n1, nent / 4 + K);
         max_split = std::max(max_split, nsplit_g);
         if (G.kind == 1) {               // coupled: forward launch now, reverse launch after k_expr
-            G.spec->launch(G.ga, G.use_rec ? pk::MODE_FWDREC : pk::MODE_FWD, G.blocks, E.stream);
+            G.spec->launch(G.ga, (G.use_rec && !loss_only) ? pk::MODE_FWDREC : pk::MODE_FWD, G.blocks, E.stream);
             continue;
         }
         plat_stream st = E.stream;
@@ -187,7 +234,8 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
             plat_stream_wait_event(st, E.ev_fork);
         }
         if (group_ev(g)) plat_event_record(G.ev_a, st);
-        G.spec->launch(*ga_launch, pk::MODE_FUSED, blocks, st);
+        if (merged_head) mu->pair->launch(*ga_launch, blocks, st);
+        else G.spec->launch(*ga_launch, loss_only ? pk::MODE_LOSS : pk::MODE_FUSED, blocks, st);
         if (group_ev(g)) plat_event_record(G.ev_b, st);
         G.timed = group_ev(g);
         if (forked) {
@@ -195,22 +243,27 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
             plat_stream_wait_event(E.stream, E.ev_join[g]);
         }
     }
+    bool coupled_active = false;
     for (size_t c = 0; c < E.coupled.size(); ++c) {
         Coupled& Cp = E.coupled[c];
         const int g = (int)(E.groups.size() + c);
         const bool on = (only_term < 0 || only_term == Cp.term);
         const int nsplit = std::min(REDUCE_SPLIT, Cp.blocks);
+        const int nent = loss_only ? 0 : 16;
         a1.tmp[g] = Cp.d_tmp; a1.slabs[g] = Cp.d_pslab; a1.losspart[g] = Cp.d_losspart;
-        a1.slab[g] = 16; a1.nblocks[g] = Cp.blocks; a1.nsplit[g] = nsplit; a1.nent[g] = 16; a1.active[g] = on; a1.nwpb[g] = 4;
-        a2.tmp[g] = Cp.d_tmp; a2.stride[g] = 16 + K; a2.nsplit[g] = nsplit; a2.nent[g] = 16; a2.active[g] = on; a2.ent_active[g] = on;
+        a1.slab[g] = 16; a1.nblocks[g] = Cp.blocks; a1.nsplit[g] = nsplit; a1.nent[g] = nent; a1.active[g] = on; a1.nwpb[g] = 4;
+        a2.tmp[g] = Cp.d_tmp; a2.stride[g] = nent + K; a2.nsplit[g] = nsplit; a2.nent[g] = nent; a2.active[g] = on; a2.ent_active[g] = on && !loss_only;
         bool groups_active = false;
         for (int gi : Cp.groups) groups_active = groups_active || E.groups[gi].active;
         if (!groups_active) continue;
-        max_n1 = std::max(max_n1, 4 + K);
+        coupled_active = true;
+        max_n1 = std::max(max_n1, nent / 4 + K);
         max_split = std::max(max_split, nsplit);
-        aux::launch_expr(expr_args(E, Cp, scale_of(Cp.term), nullptr), Cp.blocks, E.stream);    // scale 0 => zero seeds
+        aux::ExprArgs ea = expr_args(E, Cp, scale_of(Cp.term), nullptr);    // scale 0 => zero seeds
+        ea.loss_only = loss_only ? 1 : 0;
+        aux::launch_expr(ea, Cp.blocks, E.stream);
     }
-    for (size_t g = 0; g < E.groups.size(); ++g) {
+    for (size_t g = 0; g < E.groups.size() && !loss_only; ++g) {
         Group& G = E.groups[g];
         if (G.kind != 1 || !G.active) continue;
         if (group_ev(g)) plat_event_record(G.ev_a, E.stream);
@@ -222,7 +275,21 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
     a1.K = K;
     a2.out = d_out; a2.lossraw = lossraw ? lossraw : E.d_lossraw; a2.row_ptr = E.d_gr_ptr; a2.row_grp = E.d_gr_grp; a2.row_ent = E.d_gr_ent;
     a2.ngroups = (int)(E.groups.size() + E.coupled.size()); a2.P = (int)E.ntheta; a2.K = K;
-    aux::launch_reduce(a1, a2, max_n1, max_split, E.stream);
+    a2.skip_grad = loss_only ? 1 : 0;
+    // one slab set carries the whole gradient (a single network whose launch groups are merged / chained): one reduction kernel
+    const bool no_reduce_one = std::getenv("PINN_NO_REDUCE_ONE") != nullptr;
+    const Group* RG = (nslabsets == 1 && !coupled_active && !loss_only && !no_reduce_one) ? &E.groups[slabset_group] : nullptr;
+    if (RG && RG->d_ent_theta && RG->ent_covers_theta && !aux::reduce_is_small(a1, a2)) {
+        aux::ReduceOneArgs ro;
+        std::memset(&ro, 0, sizeof ro);
+        ro.slabs = RG->d_slabs; ro.slab = RG->slab_floats; ro.nblocks = a1.nblocks[slabset_group]; ro.nent = RG->nent;
+        ro.ent_theta = RG->d_ent_theta; ro.out = d_out; ro.lossraw = a2.lossraw; ro.P = (int)E.ntheta; ro.K = K;
+        for (size_t g = 0; g < E.groups.size(); ++g)
+            if (a1.active[g]) { ro.losspart[ro.nloss] = a1.losspart[g]; ro.nrows[ro.nloss] = a1.nblocks[g] * a1.nwpb[g]; ++ro.nloss; }
+        aux::launch_reduce_one(ro, E.stream);
+    } else {
+        aux::launch_reduce(a1, a2, max_n1, max_split, E.stream);
+    }
     if (phase_ev) plat_event_record(E.ev3, E.stream);
     return 0;
 }
@@ -301,9 +368,10 @@ int pinn_destroy(pinn_handle h) {
     plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist); plat_free(E.d_inv_ptr); plat_free(E.d_inv_pos); plat_free(E.d_step); plat_free(E.d_draws); plat_free(E.d_sampled); plat_free(E.d_c12);
     for (auto& G : E.groups) {
         plat_free(G.d_prog); plat_free(G.d_slabs); plat_free(G.d_losspart); plat_free(G.d_scratch); plat_free(G.d_rec);
-        plat_free(G.d_tmp);
+        plat_free(G.d_tmp); plat_free(G.d_ent_theta);
         plat_event_destroy(G.ev_a); plat_event_destroy(G.ev_b);
     }
+    for (auto& M : E.merged) { plat_free(M.d_scratch); plat_free(M.d_losspart); }
     for (auto& Cp : E.coupled) {
         for (float* q : Cp.d_jets) plat_free(q);
         for (float* q : Cp.d_ubar) plat_free(q);
@@ -400,7 +468,10 @@ int pinn_loss_grad(pinn_handle h, const float* theta, int64_t p, const float* te
     DeviceScope scope(E.device);
     const int K = (int)E.terms.size();
     if (upload_theta(E, theta, p)) return 1;
-    if (run_loss_grad(E, E.d_theta, E.hp_out, term_w, -1, true, E.hp_raw)) return 1;     // results land in pinned host memory
+    // grad == NULL: loss-only evaluation (no records, no reverse sweep, no gradient reduction) — what a callback, an adaptive-weight
+    // rule or a rejected line-search trial needs (the reference's per-term closures are value-only unless differentiated,
+    // src/training_strategies.jl:215-221)
+    if (run_loss_grad(E, E.d_theta, E.hp_out, term_w, -1, true, E.hp_raw, false, grad == nullptr)) return 1;     // results land in pinned host memory
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
     E.timing_valid = E.timing_level >= 2;
     if (term_losses)
@@ -479,6 +550,23 @@ int pinn_loss_grad_device(pinn_handle h, const float* d_theta, const float* term
     if (rc && g_err.empty()) return fail("pinn_loss_grad_device failed");
     E.timing_valid = (rc == 0) && E.timing_level >= 2;
     return rc;
+}
+
+int pinn_loss_device(pinn_handle h, const float* d_theta, float* d_sums, void* stream) {
+    if (!h || !d_theta || !d_sums) return fail("pinn_loss_device: null argument");
+    pinn_engine& E = *h;
+    DeviceScope scope(E.device);
+    plat_stream saved = E.stream;
+    E.stream = (plat_stream)stream;
+    int rc = run_loss_grad(E, d_theta, d_sums - E.ntheta, nullptr, -1, false, nullptr, false, true);     // only [P, P + K) of the out vector is written
+    E.stream = saved;
+    if (rc && g_err.empty()) return fail("pinn_loss_device failed");
+    return rc;
+}
+
+int pinn_group_launched_by(pinn_handle h, int group) {
+    if (!h || group < 0 || group >= (int)h->groups.size()) return -1;
+    return h->groups[group].launched_by;
 }
 
 int pinn_residual(pinn_handle h, int term, const float* theta, int64_t p, float* r) {
@@ -893,19 +981,22 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
     const size_t P = (size_t)p;
     std::vector<float> th32(P);
     std::vector<double> g(P), x(theta, theta + P), xn(P), gn(P), d(P), q(P);
-    auto eval = [&](const std::vector<double>& at, std::vector<double>& grad, double& f) -> int {      // one fused device evaluation
+    // one device evaluation: fused loss + gradient, or (grad == nullptr) the loss-only launch — a rejected line-search trial needs the
+    // objective only, at about a third of the cost
+    auto eval = [&](const std::vector<double>& at, std::vector<double>* grad, double& f) -> int {
         for (size_t i = 0; i < P; ++i) th32[i] = (float)at[i];
         if (upload_theta(E, th32.data(), p)) return 1;
-        if (run_loss_grad(E, E.d_theta, E.hp_out, term_w, -1, false, E.hp_raw)) return 1;
+        if (run_loss_grad(E, E.d_theta, E.hp_out, term_w, -1, false, E.hp_raw, false, grad == nullptr)) return 1;
         if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
         f = 0.0;
         for (int k = 0; k < K; ++k) f += (double)(term_w ? term_w[k] : 1.0f) * E.hp_raw[k] / (double)E.terms[k].n_norm;
-        for (size_t i = 0; i < P; ++i) grad[i] = (double)E.hp_out[i];
+        if (grad)
+            for (size_t i = 0; i < P; ++i) (*grad)[i] = (double)E.hp_out[i];
         return 0;
     };
     auto dot = [&](const std::vector<double>& a, const std::vector<double>& b) { double s = 0.0; for (size_t i = 0; i < P; ++i) s += a[i] * b[i]; return s; };
     double f = 0.0;
-    if (eval(x, g, f)) return 1;
+    if (eval(x, &g, f)) return 1;
     std::deque<std::vector<double>> S, Y;
     std::deque<double> RHO;
     int it = 0;
@@ -938,10 +1029,16 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
         double t = S.empty() ? std::min(1.0, 1.0 / std::sqrt(dot(g, g))) : 1.0;
         double fn = f;
         bool ok = false;
+        // the first trial (accepted most of the time) is a full evaluation: its gradient is the next iterate's; after a rejection the
+        // trials are loss-only evaluations and the accepted point gets its gradient from one more full evaluation
         for (int ls = 0; ls < 30; ++ls) {
             for (size_t j = 0; j < P; ++j) xn[j] = x[j] + t * d[j];
-            if (eval(xn, gn, fn)) return 1;
-            if (std::isfinite(fn) && fn <= f + 1e-4 * t * gd) { ok = true; break; }
+            if (eval(xn, ls == 0 ? &gn : nullptr, fn)) return 1;
+            if (std::isfinite(fn) && fn <= f + 1e-4 * t * gd) {
+                if (ls > 0 && eval(xn, &gn, fn)) return 1;
+                ok = true;
+                break;
+            }
             t *= 0.5;
         }
         if (!ok) break;                                  // no decrease along a descent direction: the evaluation's noise floor
@@ -1033,6 +1130,7 @@ int pinn_describe(pinn_handle h, char* buf, int64_t buflen) {
         os << "group " << g << (G.kind == 1 ? (G.use_rec ? " [coupled fwd/gradin, records in HBM]" : " [coupled fwd/gradin]") : "") << " net=" << G.net << " kernel=" << spec_name(*G.spec) << " tiles=" << G.ga.ntiles << " blocks=" << G.blocks << " terms=";
         for (int t : G.terms) os << t << ",";
         if (G.chain_to >= 0) os << " slabs=" << (G.blocks <= h->groups[G.chain_to].blocks ? "chained onto group " : "own (more workgroups than group ") << G.chain_to << (G.blocks <= h->groups[G.chain_to].blocks ? "" : ")");
+        if (G.merged >= 0 && h->merged[G.merged].tail == (int)g) os << " launch=merged into group " << h->merged[G.merged].head << "'s (one persistent kernel walks both tile lists)";
         os << "\n";
     }
     for (size_t t = 0; t < h->terms.size(); ++t) {

@@ -113,12 +113,18 @@ struct Group {
     bool use_rec = false;
     double* d_tmp = nullptr;         // stage-1 partial sums [nsplit][nent + K]
     std::vector<int> row_theta, row_ptr, row_off;   // host CSR: theta element -> slab offsets of this group
+    int* d_ent_theta = nullptr;      // inverse map slab entry -> theta element (-1: none) when every theta element this group feeds has exactly
+                                     // one slab entry (families 2, 3): input of the one-kernel reduction (aux::k_reduce_one)
+    bool ent_covers_theta = false;   // ... and the group feeds EVERY theta element (single-network problems)
     int nent = 0;
     int slab_floats = 0;             // floats per block of d_slabs
     int blocks = 0;
     int max_blocks = 0;
     bool active = false;
     int chain_to = -1;               // earlier launch group of the same network whose slab set this group may accumulate into
+    int merged = -1;                 // >= 0: index into pinn_engine::merged — this group's tiles can ride in ONE launch with another group's
+    int launched_blocks = 0;         // workgroups of the launch that carried this group's tiles in the current evaluation
+    int launched_by = -1;            // launch group whose launch carried them (itself, or the head of a merged launch)
     plat_event ev_a, ev_b;
     bool timed = false;
 };
@@ -138,6 +144,16 @@ struct Coupled {
     int blocks = 0, cap_blocks = 0;
     std::vector<int> row_theta, row_ptr, row_off;
 };
+// two fused launch groups of one network (same shape, slab layout and reduce rows; e.g. interior jet set + value-only boundary set) for
+// which a merged kernel exists (pk::PairInfo): one persistent launch walks the head's tiles, then the tail's, with the weight-gradient
+// accumulators in registers across both (plan.cpp: plan_merge_groups; engine.cpp: run_loss_grad)
+struct MergedUnit {
+    int head = -1, tail = -1;
+    const pk::PairInfo* pair = nullptr;
+    float* d_scratch = nullptr;      // record scratch of the merged launch: max_blocks x pair->SCR
+    double* d_losspart = nullptr;    // per-wave loss partials of the merged launch [max_blocks * NW][K] (both groups' terms)
+    int max_blocks = 0;
+};
 struct NetPlan {
     const pk::SpecInfo* spec = nullptr;   // any spec with the right (HP,NHH,D): packed layout is shared
     float* d_packed = nullptr;
@@ -148,7 +164,7 @@ struct NetPlan {
 
 }  // namespace pe
 
-using pe::Coupled; using pe::Group; using pe::Net; using pe::NetPlan; using pe::Slot; using pe::Term;
+using pe::Coupled; using pe::Group; using pe::MergedUnit; using pe::Net; using pe::NetPlan; using pe::Slot; using pe::Term;
 
 struct pinn_engine {
     int64_t ntheta = 0;
@@ -158,6 +174,7 @@ struct pinn_engine {
     std::vector<Term> terms;
     std::vector<Group> groups;
     std::vector<Coupled> coupled;
+    std::vector<MergedUnit> merged;
     std::vector<NetPlan> netplans;
     int ncu = 0;
     int device = 0;                  // the HIP device this handle lives on (pinn_create: the caller's current device; pinn_create_on)
@@ -229,7 +246,7 @@ void analyse_static(Term& T, int np);
 bool fuse_laplacian(Term& T, int np);
 // engine.cpp (shared with comm.cpp)
 int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const float* term_w, int only_term, bool timing, double* lossraw = nullptr,
-                  bool packed_fresh = false);
+                  bool packed_fresh = false, bool loss_only = false);
 int upload_theta(pinn_engine& E, const float* theta, int64_t p);
 // every entry point that touches the device first makes the handle's device current (single-process multi-GPU callers)
 struct DeviceScope {

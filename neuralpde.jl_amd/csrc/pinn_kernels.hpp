@@ -45,7 +45,10 @@ enum Act : int { ACT_TANH = 0, ACT_SIGMOID = 1, ACT_SIN = 2,
 // couple several networks: the tape runs in k_expr between the FWD and GRADIN launches of every network involved).
 // FWDREC / GRADREC (family 2): as FWD / GRADIN, but the forward launch keeps every hidden layer's record in HBM (per tile) and
 // the reverse launch reads them back instead of running the forward pass a second time — 288 GB of HBM make the 8 KB/point affordable.
-enum Mode : int { MODE_FUSED = 0, MODE_RESID = 1, MODE_FWD = 2, MODE_GRADIN = 3, MODE_FWDREC = 4, MODE_GRADREC = 5 };
+// LOSS: forward + tape + the per-term sums of squares, nothing else (no records, no reverse sweep, no gradient slabs): what the
+// reference's per-term closures cost when they are only evaluated — callbacks, adaptive-weight rules, rejected line-search trials
+// (src/training_strategies.jl:215-221).  The forward arithmetic is the FUSED kernel's, so the sums are the same numbers.
+enum Mode : int { MODE_FUSED = 0, MODE_RESID = 1, MODE_FWD = 2, MODE_GRADIN = 3, MODE_FWDREC = 4, MODE_GRADREC = 5, MODE_LOSS = 6 };
 
 constexpr int MAX_GROUP_TERMS = 12;
 constexpr int ND = 8;            // activation-derivative array: d[1] .. d[7] (jets up to order 6 need phi^(7) in the reverse sweep)
@@ -243,6 +246,8 @@ struct GroupArgs {
     int dgm_nparams;             // parameters of the network (slab entries [0, nparams) = theta order; then MAX_PARAMS PDE-parameter sums)
     int chain;                   // family 2: add this launch's gradient onto the slab contents an earlier launch group of the same
                                  // network left behind (one slab set and one reduction input for several launch groups)
+    int sub_terms0, sub_tiles0;  // merged launch (family 2, wave_main2m): terms [0, sub_terms0) / tiles [0, sub_tiles0) run the first
+                                 // kernel-family member, the rest the second
     TermDev terms[MAX_GROUP_TERMS];
 };
 
@@ -471,7 +476,7 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
     PINN_UNROLL for (int a = 0; a < MT; ++a) wLbar[a] = vzero4();
     PINN_UNROLL for (int i = 0; i < MAX_PARAMS; ++i) pbar[i] = vfloat(0.f);
 
-    vfloat lsum = vfloat(0.f);
+    vdacc lsum = vdacc_zero();     // per-lane double sums of squared residuals
     int cur_term = -1;      // index into ga.terms of the term whose loss is being accumulated
     int cq = 0;             // running chunk counter: parity selects the shared LDS chunk buffer (COOP)
 
@@ -484,7 +489,8 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
     PINN_UNROLL for (int m = 0; m < MT; ++m) wL[m] = ub_load4(PB, S::OFF_WL + 16 * m, g << 2);
     const float bL = P[S::OFF_BL];
 
-    if (MODE == MODE_FUSED)      // this wave's loss columns start at zero (no host-side memset per evaluation)
+    constexpr bool SUMS = (MODE == MODE_FUSED || MODE == MODE_LOSS);      // modes that deliver the per-term sums of squares
+    if (SUMS)                    // this wave's loss columns start at zero (no host-side memset per evaluation)
         for (int j = 0; j < ga.nterms; ++j) ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[j].term_id] = 0.0;
     const int niter = (ga.ntiles + 4 * nblocks - 1) / (4 * nblocks);
     for (int it = 0; it < niter; ++it) {
@@ -495,10 +501,10 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
             if (t >= ga.terms[j].tile0) k = j;
         if (k != cur_term) {
             if (cur_term >= 0) {
-                double s = wave_sum_d(lsum, g0);
-                if (MODE == MODE_FUSED) ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[cur_term].term_id] = s;
+                double s = wave_sum_dd(lsum, g0);
+                if (SUMS) ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[cur_term].term_id] = s;
             }
-            lsum = vfloat(0.f);
+            lsum = vdacc_zero();
             cur_term = k;
         }
         const TermDev& T = ga.terms[k];
@@ -678,7 +684,8 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                 vfloat sw = vfloat(1.0f);
                 if (T.pw) sw = gload_masked(T.pw, vint(pbase + 16 * pg) + c, valid[pg]);
                 vfloat rm = vselect(valid[pg], r * sw, vfloat(0.f));
-                lsum = vfma(rm, vselect(g0, rm, vfloat(0.f)), lsum);
+                lsum = vdacc_fma(rm, vselect(g0, rm, vfloat(0.f)), lsum);
+                if (MODE == MODE_LOSS) continue;
                 vfloat rbar = rm * vfloat(T.scale) * sw;
                 for (int q = 0; q < nrows; ++q) lds_store(ta, vint(q * 64) + lane, vfloat(0.f));
                 lds_store(ta, vint(T.out_row * 64) + lane, vfloat(1.0f));
@@ -705,7 +712,7 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
             }
             wave_fence();
         }
-        if (MODE == MODE_RESID) continue;
+        if (MODE == MODE_RESID || MODE == MODE_LOSS) continue;
 
         // =========================== reverse sweep ===========================
         // post-activation jet of channel ch from the raw (a, z_i, z_ij) record
@@ -893,11 +900,12 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
         }
     }  // tiles
 
+    if (MODE == MODE_LOSS && cur_term >= 0) ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[cur_term].term_id] = wave_sum_dd(lsum, g0);
     if (!BWD) return;
 
     // =========================== epilogue: gradient slab ===========================
     if (cur_term >= 0) {
-        double s = wave_sum_d(lsum, g0);
+        double s = wave_sum_dd(lsum, g0);
         ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[cur_term].term_id] = s;
     }
     // per-workgroup slab: [shared section | 4 x per-wave section]; COOP: dW / hidden-bias rows are written by their

@@ -20,11 +20,13 @@
 // Profiling build only (tools/stamp_profile.sh): per-wave cycle counters per phase of a tile, written to the tail of the
 // workgroup's gradient slab (beyond the reduced entries).  Never defined for the product or the emulation library.
 #if defined(PINN_STAMP) && !defined(PINN_EMU)
-#define STAMP_DECL unsigned st_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_last = __builtin_amdgcn_s_memtime();
-#define STAMP(i) { const unsigned long long st_now = __builtin_amdgcn_s_memtime(); st_acc[i] += (unsigned)(st_now - st_last); st_last = st_now; }
+#define STAMP_MEMBERS unsigned st_acc[24]; unsigned long long st_last;
+#define STAMP_INIT(ac) { for (int i_ = 0; i_ < 24; ++i_) (ac).st_acc[i_] = 0; (ac).st_last = __builtin_amdgcn_s_memtime(); }
+#define STAMP(i) { const unsigned long long st_now = __builtin_amdgcn_s_memtime(); ac.st_acc[i] += (unsigned)(st_now - ac.st_last); ac.st_last = st_now; }
 #define STAMP_EXTRA 128
 #else
-#define STAMP_DECL
+#define STAMP_MEMBERS
+#define STAMP_INIT(ac)
 #define STAMP(i)
 #define STAMP_EXTRA 0
 #endif
@@ -65,6 +67,28 @@
 #endif
 
 namespace pk {
+
+// What a wave's persistent gradient accumulators depend on: the network shape and the neuron split — NOT the jet-channel set or the
+// points per tile.  Kernels of one network with different channel sets (the interior and the boundary terms of one PINN) therefore
+// share the accumulators, the gradient-slab layout and the packed weight image, which is what lets ONE launch walk both tile lists
+// (wave_main2m below).
+template <int HP_, int NHH_, int D_, int NW_, bool WBAR_REG_>
+struct Shape2 {
+    static constexpr int HP = HP_, MT = HP_ / 16, NHH = NHH_, LH = NHH_ + 1, D = D_, NW = NW_, MTW = MT / NW_;
+    static constexpr bool WBAR_REG = WBAR_REG_;
+};
+template <class SH>
+struct Acc2 {
+    vfloat4 wbar[(SH::WBAR_REG && SH::NHH > 0) ? SH::NHH : 1][SH::MTW][SH::MT];
+    vfloat4 bbar[SH::LH][SH::MTW];
+    vfloat4 w1bar[SH::D][SH::MTW];
+    vfloat4 wLbar[SH::MTW];
+    vfloat bLbar;
+    vfloat pbar[MAX_PARAMS];
+    vdacc lsum;                  // running sum of squares of the term being processed (tape waves), double per lane
+    int cur_term;                // index into GroupArgs::terms of that term, -1: none yet
+    STAMP_MEMBERS
+};
 
 template <int HP_, int NHH_, int D_, unsigned D1MASK_, unsigned long long PAIRS_, int NPAIR_, int PG_, unsigned HI_ = 0>
 struct Spec2 {
@@ -139,14 +163,72 @@ struct Spec2 {
 #else
     static constexpr bool WBAR_REG = (NHH_ * MTW * MT * 4 <= 96);
 #endif
+    using Shape = Shape2<HP_, NHH_, D_, NW, WBAR_REG>;
 };
 
+// ---- persistent gradient accumulators of this wave's neuron tiles: zero, or (chained launch group) the sums an earlier launch group of
+// this network stored in this workgroup's slab ----
+template <class S>
+DEV void acc2_init(Acc2<typename S::Shape>& ac, const GroupArgs& ga, int blk, int w, bool bwd) {
+    constexpr int HP = S::HP, MT = S::MT, MTW = S::MTW, NHH = S::NHH, LH = S::LH, D = S::D;
+    const vint lane = lane_id();
+    const vint g = lane >> 4;
+    const vint c = lane & vint(15);
+    float* slab = ga.slabs + (size_t)blk * S::SLAB;
+    PINN_UNROLL for (int l = 0; l < ((S::WBAR_REG && NHH > 0) ? NHH : 1); ++l)
+        PINN_UNROLL for (int t = 0; t < MTW; ++t)
+            PINN_UNROLL for (int ti = 0; ti < MT; ++ti) ac.wbar[l][t][ti] = vzero4();
+    if (!S::WBAR_REG && bwd && !ga.chain)    // slab-resident dW: this wave's tiles start at zero (or on top of the chained group's sums)
+        for (int hl = 0; hl < NHH; ++hl)
+            PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                PINN_UNROLL for (int ti = 0; ti < MT; ++ti)
+                    gstore4(slab + S::O_WBAR, vint((((hl * MT + w * MTW + t) * MT + ti) * 64) * 4) + (lane << 2), vzero4());
+    PINN_UNROLL for (int l = 0; l < LH; ++l)
+        PINN_UNROLL for (int t = 0; t < MTW; ++t) ac.bbar[l][t] = vzero4();
+    PINN_UNROLL for (int i = 0; i < D; ++i)
+        PINN_UNROLL for (int t = 0; t < MTW; ++t) ac.w1bar[i][t] = vzero4();
+    PINN_UNROLL for (int t = 0; t < MTW; ++t) ac.wLbar[t] = vzero4();
+    ac.bLbar = vfloat(0.f);
+    PINN_UNROLL for (int i = 0; i < MAX_PARAMS; ++i) ac.pbar[i] = vfloat(0.f);
+    ac.lsum = vdacc_zero();
+    ac.cur_term = -1;
+    STAMP_INIT(ac)
+    if (bwd && ga.chain) {
+        // chained launch group: the accumulators continue from the sums an earlier launch group of this network stored in this slab
+        // (same wave, same entries), so one slab set — one reduction input — carries both groups.  Lane c = 0 of a row group holds the
+        // stored value, the other column lanes start at zero: the row sums of the epilogue then include it exactly once.
+        if (S::WBAR_REG)
+            PINN_UNROLL for (int hl = 0; hl < NHH; ++hl)
+                PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                    PINN_UNROLL for (int ti = 0; ti < MT; ++ti)
+                        ac.wbar[hl][t][ti] = gload4(slab + S::O_WBAR, vint((((hl * MT + w * MTW + t) * MT + ti) * 64) * 4) + (lane << 2));
+        const vbool c0i = veq(c, 0);
+        PINN_UNROLL for (int t = 0; t < MTW; ++t)
+            PINN_UNROLL for (int r = 0; r < 4; ++r) {
+                const vint n = vint(16 * (w * MTW + t) + r) + (g << 2);
+                PINN_UNROLL for (int l = 0; l < LH; ++l) ac.bbar[l][t][r] = gload_masked(slab + S::O_BH + l * HP, n, c0i);
+                PINN_UNROLL for (int i = 0; i < D; ++i) ac.w1bar[i][t][r] = gload_masked(slab + S::O_W1 + i * HP, n, c0i);
+                ac.wLbar[t][r] = gload_masked(slab + S::O_WL, n, c0i);
+            }
+        if (w == 0) {
+            const vbool l0 = veq(lane, 0);
+            ac.bLbar = gload_masked(slab + S::O_BL, lane & vint(0), l0);
+            PINN_UNROLL for (int j = 0; j < MAX_PARAMS; ++j) ac.pbar[j] = gload_masked(slab + S::O_P, vint(j) + (lane & vint(0)), l0);
+        }
+    }
+}
+
+// ---- the tile loop: workgroup `blk` of `nblocks` takes the tiles tix = blk (mod nblocks) of [tile_lo, tile_hi), which belong to the terms
+// [term_lo, term_hi) of the launch (one launch group: everything; a merged launch: one call per kernel family member) ----
 template <class S, int MODE, int ACTK>
-DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds) {
+DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds, Acc2<typename S::Shape>& ac,
+                     int term_lo, int term_hi, int tile_lo, int tile_hi) {
     constexpr int HP = S::HP, MT = S::MT, MTW = S::MTW, NHH = S::NHH, LH = S::LH, D = S::D, C = S::C, PG = S::PG, NG = S::NG;
     constexpr int NFIRST = S::NFIRST;
     using J = typename S::J;
     constexpr bool BWD = (MODE == MODE_FUSED || MODE == MODE_GRADIN || MODE == MODE_GRADREC);
+    constexpr bool SUMS = (MODE == MODE_FUSED || MODE == MODE_LOSS);       // modes that deliver the per-term sums of squares
+    constexpr bool TAPE_ONLY = (MODE == MODE_RESID || MODE == MODE_LOSS);  // forward + tape, no reverse sweep
     constexpr bool RECOUT = (MODE == MODE_FWDREC), RECIN = (MODE == MODE_GRADREC);
     constexpr bool IS_FWD = (MODE == MODE_FWD || MODE == MODE_FWDREC), IS_GRADIN = (MODE == MODE_GRADIN || MODE == MODE_GRADREC);
     constexpr bool WPRE = (MT * MTW * 4 <= 16);        // prefetch a layer's weight fragments when they take <= 16 registers (H = 64)
@@ -171,75 +253,33 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
     auto rec_in_lds = [](int layer, int q) { return layer >= 1 && layer <= LH - 2 && (LH - 2 - layer) * NG + q < S::NRQ; };   // (same-kernel records only)
     auto rl_off = [&](int layer, int q, int t) { return vint((((LH - 2 - layer) * NG + q) * MT + w * MTW + t) * 256) + (lane << 2); };
 
-    // ---- persistent gradient accumulators of this wave's neuron tiles ----
-    vfloat4 wbar[(S::WBAR_REG && NHH > 0) ? NHH : 1][MTW][MT];
     float* slab = ga.slabs + (size_t)blk * S::SLAB;
-    vfloat4 bbar[LH][MTW];
-    vfloat4 w1bar[D][MTW];
-    vfloat4 wLbar[MTW];
-    vfloat bLbar = vfloat(0.f);
-    vfloat pbar[MAX_PARAMS];
-    PINN_UNROLL for (int l = 0; l < ((S::WBAR_REG && NHH > 0) ? NHH : 1); ++l)
-        PINN_UNROLL for (int t = 0; t < MTW; ++t)
-            PINN_UNROLL for (int ti = 0; ti < MT; ++ti) wbar[l][t][ti] = vzero4();
-    if (!S::WBAR_REG && BWD && !ga.chain)    // slab-resident dW: this wave's tiles start at zero (or on top of the chained group's sums)
-        for (int hl = 0; hl < NHH; ++hl)
-            PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                PINN_UNROLL for (int ti = 0; ti < MT; ++ti)
-                    gstore4(slab + S::O_WBAR, vint((((hl * MT + w * MTW + t) * MT + ti) * 64) * 4) + (lane << 2), vzero4());
-    PINN_UNROLL for (int l = 0; l < LH; ++l)
-        PINN_UNROLL for (int t = 0; t < MTW; ++t) bbar[l][t] = vzero4();
-    PINN_UNROLL for (int i = 0; i < D; ++i)
-        PINN_UNROLL for (int t = 0; t < MTW; ++t) w1bar[i][t] = vzero4();
-    PINN_UNROLL for (int t = 0; t < MTW; ++t) wLbar[t] = vzero4();
-    PINN_UNROLL for (int i = 0; i < MAX_PARAMS; ++i) pbar[i] = vfloat(0.f);
-    if (BWD && ga.chain) {
-        // chained launch group: the accumulators continue from the sums an earlier launch group of this network stored in this slab
-        // (same wave, same entries), so one slab set — one reduction input — carries both groups.  Lane c = 0 of a row group holds the
-        // stored value, the other column lanes start at zero: the row sums of the epilogue then include it exactly once.
-        if (S::WBAR_REG)
-            PINN_UNROLL for (int hl = 0; hl < NHH; ++hl)
-                PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                    PINN_UNROLL for (int ti = 0; ti < MT; ++ti)
-                        wbar[hl][t][ti] = gload4(slab + S::O_WBAR, vint((((hl * MT + w * MTW + t) * MT + ti) * 64) * 4) + (lane << 2));
-        const vbool c0i = veq(c, 0);
-        PINN_UNROLL for (int t = 0; t < MTW; ++t)
-            PINN_UNROLL for (int r = 0; r < 4; ++r) {
-                const vint n = vint(16 * (w * MTW + t) + r) + (g << 2);
-                PINN_UNROLL for (int l = 0; l < LH; ++l) bbar[l][t][r] = gload_masked(slab + S::O_BH + l * HP, n, c0i);
-                PINN_UNROLL for (int i = 0; i < D; ++i) w1bar[i][t][r] = gload_masked(slab + S::O_W1 + i * HP, n, c0i);
-                wLbar[t][r] = gload_masked(slab + S::O_WL, n, c0i);
-            }
-        if (w == 0) {
-            const vbool l0 = veq(lane, 0);
-            bLbar = gload_masked(slab + S::O_BL, lane & vint(0), l0);
-            PINN_UNROLL for (int j = 0; j < MAX_PARAMS; ++j) pbar[j] = gload_masked(slab + S::O_P, vint(j) + (lane & vint(0)), l0);
-        }
-    }
-    vfloat lsum = vfloat(0.f);
-    int cur_term = -1;
+    auto& wbar = ac.wbar;
+    auto& bbar = ac.bbar;
+    auto& w1bar = ac.w1bar;
+    auto& wLbar = ac.wLbar;
+    vfloat& bLbar = ac.bLbar;
+    auto& pbar = ac.pbar;
+    vdacc& lsum = ac.lsum;
+    int& cur_term = ac.cur_term;
 
     vfloat4 wL[MTW];
     PINN_UNROLL for (int t = 0; t < MTW; ++t) wL[t] = ub_load4(PB, S::OFF_WL + 16 * (w * MTW + t), g << 2);
     const float bL = P[S::OFF_BL];
 
-    if (MODE == MODE_FUSED)
-        for (int j = 0; j < ga.nterms; ++j) ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[j].term_id] = 0.0;
-
     wave_prio(1);
     const bool gemm_hi = PINN_F2_ASYM_PRIO ? ((hw_wave_slot() & 1) == 0) : false;        // see wave_prio_gemm
-    const int niter = (ga.ntiles + nblocks - 1) / nblocks;
-    STAMP_DECL
-    for (int it = 0; it < niter; ++it) {
+    // (no dummy tiles: every wave of a workgroup works on the same tile, so a workgroup simply stops after its last one)
+    const int first = tile_lo + (((blk - tile_lo) % nblocks) + nblocks) % nblocks;
+    for (int tix = first; tix < tile_hi; tix += nblocks) {
         STAMP(15)
-        const int tix = it * nblocks + blk;                  // >= ntiles: dummy tile (all points masked)
-        int k = 0;
-        for (int j = 1; j < ga.nterms; ++j)
+        int k = term_lo;
+        for (int j = term_lo + 1; j < term_hi; ++j)
             if (tix >= ga.terms[j].tile0) k = j;
         if (k != cur_term) {
-            if (cur_term >= 0 && MODE == MODE_FUSED)
-                ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[cur_term].term_id] = wave_sum_d(lsum, g0);
-            lsum = vfloat(0.f);
+            if (cur_term >= 0 && SUMS)
+                ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[cur_term].term_id] = wave_sum_dd(lsum, g0);
+            lsum = vdacc_zero();
             cur_term = k;
         }
         const TermDev& T = ga.terms[k];
@@ -366,7 +406,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
             }
             // the tape waves request their hoisted source channels now: the latency hides under the output layer + its barrier
             // instead of sitting in the serialised tape phase (registers are held for one short phase only)
-            if (MODE == MODE_FUSED || MODE == MODE_RESID)
+            if (MODE == MODE_FUSED || TAPE_ONLY)
                 if (w < PG)
                     PINN_UNROLL for (int j = 0; j < SRC_PRE; ++j)
                         if (j < T.nsrc) srcv[j] = gload_masked(T.src, vint(j * T.N + pbase + 16 * w) + c, valid_w);
@@ -489,10 +529,12 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         vfloat sw = vfloat(1.0f);
                         if (T.pw) sw = gload_masked(T.pw, vint(pbase + 16 * w) + c, vin);
                         vfloat rm = vselect(vin, r * sw, vfloat(0.f));
-                        lsum = vfma(rm, vselect(g0, rm, vfloat(0.f)), lsum);
-                        vfloat rbar = rm * vfloat(T.scale) * sw;
-                        PINN_UNROLL for (int ch = 0; ch < C; ++ch)
-                            lds_store(UB, vint((w * C + ch) * 16) + c, vselect(vin, rbar * vfloat(T.lin_a[ch < LIN_MAX_C ? ch : 0]), vfloat(0.f)));
+                        lsum = vdacc_fma(rm, vselect(g0, rm, vfloat(0.f)), lsum);
+                        if (MODE != MODE_LOSS) {
+                            vfloat rbar = rm * vfloat(T.scale) * sw;
+                            PINN_UNROLL for (int ch = 0; ch < C; ++ch)
+                                lds_store(UB, vint((w * C + ch) * 16) + c, vselect(vin, rbar * vfloat(T.lin_a[ch < LIN_MAX_C ? ch : 0]), vfloat(0.f)));
+                        }
                     }
                 } else if (!PINN_F2_LINEAR_ONLY) {
                     const int NP = ga.nparams;
@@ -530,7 +572,8 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                         vfloat sw = vfloat(1.0f);
                         if (T.pw) sw = gload_masked(T.pw, vint(pbase + 16 * w) + c, vin);
                         vfloat rm = vselect(vin, r * sw, vfloat(0.f));
-                        lsum = vfma(rm, vselect(g0, rm, vfloat(0.f)), lsum);   // this wave's share of the term's (weighted) sum of squares
+                        lsum = vdacc_fma(rm, vselect(g0, rm, vfloat(0.f)), lsum);   // this wave's share of the term's (weighted) sum of squares
+                        if (MODE != MODE_LOSS) {
                         vfloat rbar = rm * vfloat(T.scale) * sw;
                         vtape ta;
                         tape_zero(ta);
@@ -550,18 +593,19 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
                             vfloat pj = vselect(vand(g0, vin), rbar * tape_get(ta, DT + j), vfloat(0.f));
                             PINN_UNROLL for (int jj = 0; jj < MAX_PARAMS; ++jj) if (jj == j) pbar[jj] += pj;
                         }
+                        }
                     }
                 }
                 }
             wave_prio(1);
-            if (MODE != MODE_RESID) {
+            if (!TAPE_ONLY) {
                 if (SPRE && NHH - 1 >= 1) load_record(NHH - 1);
                 wg_barrier();                                                   // seeds of every point group are in UB
                 PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                     PINN_UNROLL for (int ch = 0; ch < C; ++ch) ubar[pg][ch] = lds_load(UB, vint((pg * C + ch) * 16) + c);
             }
         }
-        if (MODE == MODE_RESID) { wg_barrier(); continue; }
+        if (TAPE_ONLY) { wg_barrier(); continue; }
         STAMP(5)
 
         // =========================== reverse sweep ===========================
@@ -775,16 +819,22 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
         if (NHH == 0) wg_barrier();                                         // UP reuse across tiles when there is no layer barrier
         STAMP(13)
     }  // tiles
+}
 
-    if (!BWD) return;
-    // =========================== epilogue ===========================
-    if (cur_term >= 0 && MODE == MODE_FUSED)
-        ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[cur_term].term_id] = wave_sum_d(lsum, g0);
+// ---- epilogue: the wave's accumulators into this workgroup's gradient slab (every entry has exactly one writer) ----
+template <class S, int PG = S::PG /* tape waves that hold PDE-parameter partials: the largest PG of the launch's members */>
+DEV void acc2_store(Acc2<typename S::Shape>& ac, const GroupArgs& ga, int blk, int w, float* lds) {
+    constexpr int HP = S::HP, MT = S::MT, MTW = S::MTW, NHH = S::NHH, LH = S::LH, D = S::D, NG = S::NG;
+    const vint lane = lane_id();
+    const vint g = lane >> 4;
+    const vint c = lane & vint(15);
+    float* slab = ga.slabs + (size_t)blk * S::SLAB;
+    float* UP = lds + (S::CHUNKED ? 2 : 3) * S::XSZ;
     if (S::WBAR_REG)
         PINN_UNROLL for (int hl = 0; hl < NHH; ++hl)
             PINN_UNROLL for (int t = 0; t < MTW; ++t)
                 PINN_UNROLL for (int ti = 0; ti < MT; ++ti)
-                    gstore4(slab + S::O_WBAR, vint((((hl * MT + w * MTW + t) * MT + ti) * 64) * 4) + (lane << 2), wbar[hl][t][ti]);
+                    gstore4(slab + S::O_WBAR, vint((((hl * MT + w * MTW + t) * MT + ti) * 64) * 4) + (lane << 2), ac.wbar[hl][t][ti]);
     const vbool c0 = veq(c, 0);
     auto reduce_cols = [&](vfloat v) -> vfloat {       // sum over the 16 column lanes of a row group
         v = row_allsum16(v);
@@ -793,9 +843,9 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
     PINN_UNROLL for (int t = 0; t < MTW; ++t)
         PINN_UNROLL for (int r = 0; r < 4; ++r) {
             const vint n = vint(16 * (w * MTW + t) + r) + (g << 2);          // natural neuron index
-            PINN_UNROLL for (int l = 0; l < LH; ++l) gstore_masked(slab + S::O_BH + l * HP, n, reduce_cols(bbar[l][t][r]), c0);
-            PINN_UNROLL for (int i = 0; i < D; ++i) gstore_masked(slab + S::O_W1 + i * HP, n, reduce_cols(w1bar[i][t][r]), c0);
-            gstore_masked(slab + S::O_WL, n, reduce_cols(wLbar[t][r]), c0);
+            PINN_UNROLL for (int l = 0; l < LH; ++l) gstore_masked(slab + S::O_BH + l * HP, n, reduce_cols(ac.bbar[l][t][r]), c0);
+            PINN_UNROLL for (int i = 0; i < D; ++i) gstore_masked(slab + S::O_W1 + i * HP, n, reduce_cols(ac.w1bar[i][t][r]), c0);
+            gstore_masked(slab + S::O_WL, n, reduce_cols(ac.wLbar[t][r]), c0);
         }
     // PDE-parameter gradients: the tape waves' partial sums meet in wave 0 (fixed order)
     static_assert(4 * MAX_PARAMS <= 16, "UB holds the per-wave parameter partials");
@@ -803,13 +853,13 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
     float* UBp = UP + S::NW * NG * 16;
     if (w > 0 && w < PG)
         PINN_UNROLL for (int j = 0; j < MAX_PARAMS; ++j)
-            lds_store(UBp, vint(w * MAX_PARAMS + j) + (lane & vint(0)), vfloat((float)wave_sum_d(pbar[j], all)));
+            lds_store(UBp, vint(w * MAX_PARAMS + j) + (lane & vint(0)), vfloat((float)wave_sum_d(ac.pbar[j], all)));
     if (PG > 1) wg_barrier();
     if (w == 0) {
-        float s = (float)wave_sum_d(bLbar, all);
+        float s = (float)wave_sum_d(ac.bLbar, all);
         gstore_masked(slab + S::O_BL, vint(0), vfloat(s), veq(lane, 0));
         PINN_UNROLL for (int j = 0; j < MAX_PARAMS; ++j) {
-            vfloat sp = vfloat((float)wave_sum_d(pbar[j], all));
+            vfloat sp = vfloat((float)wave_sum_d(ac.pbar[j], all));
             PINN_UNROLL for (int ws = 1; ws < PG; ++ws) sp = sp + lds_load(UBp, vint(ws * MAX_PARAMS + j) + (lane & vint(0)));
             gstore_masked(slab + S::O_P, vint(j), sp, veq(lane, 0));
         }
@@ -817,8 +867,47 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
 #if defined(PINN_STAMP) && !defined(PINN_EMU)
     STAMP(14)
     if ((threadIdx.x & 63) == 0)
-        for (int i = 0; i < 24; ++i) reinterpret_cast<unsigned*>(slab + S::SLAB - 128)[w * 24 + i] = st_acc[i];
+        for (int i = 0; i < 24; ++i) reinterpret_cast<unsigned*>(slab + S::SLAB - 128)[w * 24 + i] = ac.st_acc[i];
 #endif
+}
+
+// ---- one launch group: accumulators, every tile of every term of the group, epilogue ----
+template <class S, int MODE, int ACTK>
+DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds) {
+    constexpr bool BWD = (MODE == MODE_FUSED || MODE == MODE_GRADIN || MODE == MODE_GRADREC);
+    constexpr bool SUMS = (MODE == MODE_FUSED || MODE == MODE_LOSS);
+    const int wave = blk * S::NW + w;
+    Acc2<typename S::Shape> ac;
+    acc2_init<S>(ac, ga, blk, w, BWD);
+    if (SUMS)
+        for (int j = 0; j < ga.nterms; ++j) ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[j].term_id] = 0.0;
+    wave_tiles2<S, MODE, ACTK>(ga, blk, nblocks, w, lds, ac, 0, ga.nterms, 0, ga.ntiles);
+    if (SUMS && ac.cur_term >= 0)
+        ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[ac.cur_term].term_id] = wave_sum_dd(ac.lsum, veq(lane_id() >> 4, 0));
+    if (!BWD) return;
+    acc2_store<S>(ac, ga, blk, w, lds);
+}
+
+// ---- MERGED launch: the tiles of TWO kernel-family members of one network (e.g. the interior term's jet set and the value-only set
+// of the boundary terms) in one persistent launch.  Both members share Shape2, hence the accumulators: a wave's dW / db sums stay in
+// registers across both tile lists and are written once — no slab round trip between two chained launches, one ramp, one epilogue.
+// Terms [0, sub_terms0) / tiles [0, sub_tiles0) belong to S0, the rest to S1; a workgroup walks its S0 tiles, then its S1 tiles
+// (round-robin over the concatenated list, so the members' tile counts need not divide the grid). ----
+template <class S0, class S1, int ACTK>
+DEV void wave_main2m(const GroupArgs& ga, int blk, int nblocks, int w, float* lds) {
+    static_assert(std::is_same<typename S0::Shape, typename S1::Shape>::value, "merged launches need members of one network shape and neuron split");
+    static_assert(S0::SLAB == S1::SLAB && S0::PACKED == S1::PACKED, "merged launches share the slab and the packed weight image");
+    const int wave = blk * S0::NW + w;
+    Acc2<typename S0::Shape> ac;
+    acc2_init<S0>(ac, ga, blk, w, true);
+    for (int j = 0; j < ga.nterms; ++j) ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[j].term_id] = 0.0;
+    wave_tiles2<S0, MODE_FUSED, ACTK>(ga, blk, nblocks, w, lds, ac, 0, ga.sub_terms0, 0, ga.sub_tiles0);
+    wg_barrier();                                                           // the members lay out the workgroup's LDS differently
+    wave_tiles2<S1, MODE_FUSED, ACTK>(ga, blk, nblocks, w, lds, ac, ga.sub_terms0, ga.nterms, ga.sub_tiles0, ga.ntiles);
+    if (ac.cur_term >= 0)
+        ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[ac.cur_term].term_id] = wave_sum_dd(ac.lsum, veq(lane_id() >> 4, 0));
+    wg_barrier();
+    acc2_store<S0, (S0::PG > S1::PG ? S0::PG : S1::PG)>(ac, ga, blk, w, lds);
 }
 
 }  // namespace pk

@@ -151,9 +151,10 @@ DEV void wave_dgm(const GroupArgs& ga, int blk, int nblocks) {
 
     vfloat pbar[MAX_PARAMS];
     PINN_UNROLL for (int j = 0; j < MAX_PARAMS; ++j) pbar[j] = vfloat(0.f);
-    vfloat lsum = vfloat(0.f);
+    vdacc lsum = vdacc_zero();
     int cur_term = -1;
-    if (MODE == MODE_FUSED)
+    constexpr bool SUMS = (MODE == MODE_FUSED || MODE == MODE_LOSS);      // modes that deliver the per-term sums of squares
+    if (SUMS)
         for (int j = 0; j < ga.nterms; ++j) ga.losspart[(size_t)blk * ga.nterms_total + ga.terms[j].term_id] = 0.0;
 
     const int niter = (ga.ntiles + nblocks - 1) / nblocks;
@@ -164,9 +165,9 @@ DEV void wave_dgm(const GroupArgs& ga, int blk, int nblocks) {
         for (int j = 1; j < ga.nterms; ++j)
             if (tix >= ga.terms[j].tile0) kt = j;
         if (kt != cur_term) {
-            if (cur_term >= 0 && MODE == MODE_FUSED)
-                ga.losspart[(size_t)blk * ga.nterms_total + ga.terms[cur_term].term_id] = wave_sum_d(lsum, vlt(lane, 64));
-            lsum = vfloat(0.f);
+            if (cur_term >= 0 && SUMS)
+                ga.losspart[(size_t)blk * ga.nterms_total + ga.terms[cur_term].term_id] = wave_sum_dd(lsum, vlt(lane, 64));
+            lsum = vdacc_zero();
             cur_term = kt;
         }
         const TermDev& T = ga.terms[kt];
@@ -294,7 +295,8 @@ DEV void wave_dgm(const GroupArgs& ga, int blk, int nblocks) {
         vfloat sw = vfloat(1.0f);
         if (T.pw) sw = gload_masked(T.pw, p, valid);
         const vfloat rm = vselect(valid, r * sw, vfloat(0.f));
-        lsum = vfma(rm, rm, lsum);
+        lsum = vdacc_fma(rm, rm, lsum);
+        if (MODE == MODE_LOSS) continue;
         const vfloat rbar = rm * vfloat(T.scale) * sw;
         vtape ta;
         tape_zero(ta);
@@ -404,8 +406,9 @@ DEV void wave_dgm(const GroupArgs& ga, int blk, int nblocks) {
             PINN_UNROLL for (int c = 0; c < C; ++c) ST(S::R_DP1 + m * C + c, m < M ? ds[c] : vfloat(0.f));
         }
     }
+    if (!SUMS) return;
+    if (cur_term >= 0) ga.losspart[(size_t)blk * ga.nterms_total + ga.terms[cur_term].term_id] = wave_sum_dd(lsum, vlt(lane, 64));
     if (MODE != MODE_FUSED) return;
-    if (cur_term >= 0) ga.losspart[(size_t)blk * ga.nterms_total + ga.terms[cur_term].term_id] = wave_sum_d(lsum, vlt(lane, 64));
     // PDE-parameter gradients of this block (the weight gradients come from k_dgm_dw)
     float* slab = ga.slabs + (size_t)blk * ga.dgm_slab;
     PINN_UNROLL for (int j = 0; j < MAX_PARAMS; ++j)

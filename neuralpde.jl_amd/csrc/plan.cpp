@@ -792,6 +792,19 @@ static int plan_group_buffers(pinn_engine& E) {
         G.row_theta = row_theta;
         G.row_ptr = row_ptr;
         G.row_off = ent;                 // slab offsets of the contributions
+        if (s.family != 1 && ent.size() == row_theta.size()) {          // one slab entry per theta element: inverse map for aux::k_reduce_one
+            std::vector<int> inv((size_t)slab_floats, -1);
+            std::vector<char> seen((size_t)E.ntheta, 0);
+            size_t covered = 0;
+            for (size_t r = 0; r < row_theta.size(); ++r) {
+                inv[(size_t)ent[r]] = row_theta[r];
+                if (!seen[(size_t)row_theta[r]]) { seen[(size_t)row_theta[r]] = 1; ++covered; }
+            }
+            G.d_ent_theta = (int*)plat_malloc(sizeof(int) * inv.size());
+            if (!G.d_ent_theta) return fail("device allocation failed (reduce map)");
+            plat_h2d(G.d_ent_theta, inv.data(), sizeof(int) * inv.size(), E.stream);
+            G.ent_covers_theta = covered == (size_t)E.ntheta && covered == row_theta.size();
+        }
         G.d_tmp = (double*)plat_malloc(sizeof(double) * (size_t)REDUCE_SPLIT * (G.nent + total_terms));
         if (!G.d_tmp) return fail("device allocation failed (reduce map)");
         // static part of the launch arguments
@@ -908,9 +921,41 @@ static int plan_chain_groups(pinn_engine& E) {
     return 0;
 }
 
+// A chained pair (head, tail) for which a MERGED kernel is compiled (pk::pair_registry: both members' bodies in one persistent kernel)
+// runs as ONE launch: the wave's weight-gradient accumulators stay in registers from the head's tiles into the tail's — no slab store
+// + reload between two chained launches, one ramp, one epilogue.  PINN_NO_MERGE=1 keeps the two chained launches (A/B measurements).
+static bool same_member(const pk::SpecInfo& x, const pk::SpecInfo& y) {
+    return x.family == 2 && y.family == 2 && x.HP == y.HP && x.NHH == y.NHH && x.D == y.D && x.D1MASK == y.D1MASK && x.PAIRS == y.PAIRS &&
+           x.NPAIR == y.NPAIR && x.PG == y.PG && x.HI == y.HI && x.LAP == y.LAP && x.ngen == 0 && y.ngen == 0 && x.NW == y.NW && x.SLAB == y.SLAB;
+}
+static int plan_merge_groups(pinn_engine& E) {
+    for (size_t g = 0; g < E.groups.size(); ++g) {
+        Group& G = E.groups[g];
+        if (G.chain_to < 0 || G.merged >= 0) continue;
+        Group& H = E.groups[G.chain_to];
+        if (H.merged >= 0 || H.terms.size() + G.terms.size() > (size_t)pk::MAX_GROUP_TERMS) continue;
+        if (E.nets[H.net].act != pk::ACT_TANH && E.nets[H.net].act != pk::ACT_SIGMOID) continue;
+        for (const pk::PairInfo& p : pk::pair_registry()) {
+            if (!same_member(p.a, *H.spec) || !same_member(p.b, *G.spec)) continue;
+            MergedUnit M;
+            M.head = G.chain_to; M.tail = (int)g; M.pair = &p;
+            M.max_blocks = std::min(E.ncu * p.WG_PER_CU, std::min(H.max_blocks, G.max_blocks));
+            M.d_scratch = (float*)plat_malloc(sizeof(float) * (size_t)M.max_blocks * std::max(p.SCR, 1));
+            const size_t lp = sizeof(double) * (size_t)M.max_blocks * p.NW * E.terms.size();
+            M.d_losspart = (double*)plat_malloc(lp);
+            if (!M.d_scratch || !M.d_losspart) return fail("device allocation failed (merged launch buffers)");
+            plat_memset(M.d_losspart, 0, lp, E.stream);
+            H.merged = G.merged = (int)E.merged.size();
+            E.merged.push_back(M);
+            break;
+        }
+    }
+    return 0;
+}
+
 int build_plan(pinn_engine& E) {
     if (plan_check_nets(E) || plan_assign_terms(E) || plan_pack_maps(E) || plan_group_buffers(E) || plan_coupled_programs(E) ||
-        plan_chain_groups(E) || plan_global_reduce_map(E))
+        plan_chain_groups(E) || plan_merge_groups(E) || plan_global_reduce_map(E))
         return 1;
     return 0;
 }

@@ -41,6 +41,16 @@ struct SpecInfo {
 
 std::deque<SpecInfo>& registry();      // a deque: runtime-specialised kernels (jit.cpp) are appended while engines hold SpecInfo pointers
 
+// A MERGED launch (family 2, wave_main2m): two members of the kernel family with the same network shape — `a` for the first tile list,
+// `b` for the second — compiled into one persistent kernel.  `a` / `b` identify the members (compared field by field with the
+// launch groups' SpecInfo); `launch` runs MODE_FUSED only.
+struct PairInfo {
+    SpecInfo a, b;
+    int WG_PER_CU, NW, LDS_WG, SCR;      // of the merged kernel: min / common / max / max of the members
+    void (*launch)(const GroupArgs&, int blocks, plat_stream);
+};
+std::deque<PairInfo>& pair_registry();
+
 template <class S>
 SpecInfo make_info(void (*launch)(const GroupArgs&, int, int, plat_stream), int has_sin = 0) {
     SpecInfo s;
@@ -129,7 +139,25 @@ void run_emu2(const GroupArgs& ga, int blocks) {
         for (int w = 0; w < S::NW; ++w) th[w].join();
     }
 }
+template <class S0, class S1, int ACTK>
+void run_emu2m(const GroupArgs& ga, int blocks) {
+    std::vector<float> lds((size_t)(S0::LDS_WG > S1::LDS_WG ? S0::LDS_WG : S1::LDS_WG));
+    for (int b = 0; b < blocks; ++b) {
+        for (auto& v : lds) v = std::nanf("");
+        EmuBarrier bar;
+        bar.nwaves = S0::NW;
+        std::thread th[S0::NW];
+        for (int w = 0; w < S0::NW; ++w)
+            th[w] = std::thread([&, w] {
+                wv::emu_barrier_hook = &EmuBarrier::wait;
+                wv::emu_barrier_ctx = &bar;
+                wave_main2m<S0, S1, ACTK>(ga, b, blocks, w, lds.data());
+            });
+        for (int w = 0; w < S0::NW; ++w) th[w].join();
+    }
+}
 #define PINN_LAUNCH2(S, MODE, ACTK, ga, blocks, st) run_emu2<S, MODE, ACTK>(ga, blocks)
+#define PINN_LAUNCH2M(S0, S1, ACTK, ga, blocks, st) run_emu2m<S0, S1, ACTK>(ga, blocks)
 #define PINN_LAUNCH1(S, MODE, ACTK, ga, blocks, st) run_emu<S, MODE, ACTK>(ga, blocks)
 #else
 // One workgroup = 4 independent waves (one per SIMD); persistent grid of <= #CU workgroups.
@@ -149,7 +177,21 @@ __global__ void __launch_bounds__(64 * S::NW, S::OCC) k_wave2(const GroupArgs ga
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     wave_main2<S, MODE, ACTK>(ga, (int)blockIdx.x, (int)gridDim.x, w, lds_all);
 }
+// merged launch of two family members (wave_main2m): LDS = the larger tile, resident workgroups = the smaller count
+template <class S0, class S1> struct Pair2 {
+    static constexpr int WG_PER_CU = S0::WG_PER_CU < S1::WG_PER_CU ? S0::WG_PER_CU : S1::WG_PER_CU;
+    static constexpr int LDS_WG = S0::LDS_WG > S1::LDS_WG ? S0::LDS_WG : S1::LDS_WG;
+    static constexpr int SCR = S0::SCR > S1::SCR ? S0::SCR : S1::SCR;
+    static constexpr int OCC = WG_PER_CU * S0::NW / 4;
+};
+template <class S0, class S1, int ACTK>
+__global__ void __launch_bounds__(64 * S0::NW, (Pair2<S0, S1>::OCC)) k_wave2m(const GroupArgs ga) {
+    __shared__ __attribute__((aligned(16))) float lds_all[Pair2<S0, S1>::LDS_WG];
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    wave_main2m<S0, S1, ACTK>(ga, (int)blockIdx.x, (int)gridDim.x, w, lds_all);
+}
 #define PINN_LAUNCH2(S, MODE, ACTK, ga, blocks, st) hipLaunchKernelGGL((k_wave2<S, MODE, ACTK>), dim3(blocks), dim3(64 * S::NW), 0, st, ga)
+#define PINN_LAUNCH2M(S0, S1, ACTK, ga, blocks, st) hipLaunchKernelGGL((k_wave2m<S0, S1, ACTK>), dim3(blocks), dim3(64 * S0::NW), 0, st, ga)
 #define PINN_LAUNCH1(S, MODE, ACTK, ga, blocks, st) hipLaunchKernelGGL((k_wave<S, MODE, ACTK>), dim3(blocks), dim3(256), 0, st, ga)
 #endif
 
@@ -163,6 +205,7 @@ void launch_modes2(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
     else if (mode == MODE_GRADIN) PINN_LAUNCH2(S, MODE_GRADIN, ACTK, ga, blocks, st);
     else if (mode == MODE_FWDREC) PINN_LAUNCH2(S, MODE_FWDREC, ACTK, ga, blocks, st);
     else if (mode == MODE_GRADREC) PINN_LAUNCH2(S, MODE_GRADREC, ACTK, ga, blocks, st);
+    else if (mode == MODE_LOSS) PINN_LAUNCH2(S, MODE_LOSS, ACTK, ga, blocks, st);
     else PINN_LAUNCH2(S, MODE_FWD, ACTK, ga, blocks, st);
 }
 template <class S, int ACTK>
@@ -171,6 +214,7 @@ void launch_modes1(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
     if (mode == MODE_FUSED) PINN_LAUNCH1(S, MODE_FUSED, ACTK, ga, blocks, st);
     else if (mode == MODE_RESID) PINN_LAUNCH1(S, MODE_RESID, ACTK, ga, blocks, st);
     else if (mode == MODE_GRADIN) PINN_LAUNCH1(S, MODE_GRADIN, ACTK, ga, blocks, st);
+    else if (mode == MODE_LOSS) PINN_LAUNCH1(S, MODE_LOSS, ACTK, ga, blocks, st);
     else PINN_LAUNCH1(S, MODE_FWD, ACTK, ga, blocks, st);
 }
 template <class S> void launch_spec2(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
@@ -178,6 +222,10 @@ template <class S> void launch_spec2(const GroupArgs& ga, int mode, int blocks, 
 }
 template <class S> void launch_spec(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
     if (ga.act == ACT_TANH) launch_modes1<S, ACT_TANH>(ga, mode, blocks, st); else launch_modes1<S, ACT_SIGMOID>(ga, mode, blocks, st);
+}
+template <class S0, class S1> void launch_pair2(const GroupArgs& ga, int blocks, plat_stream st) {
+    (void)st;
+    if (ga.act == ACT_TANH) PINN_LAUNCH2M(S0, S1, ACT_TANH, ga, blocks, st); else PINN_LAUNCH2M(S0, S1, ACT_SIGMOID, ga, blocks, st);
 }
 template <class S> void launch_spec2_sin(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
     if (ga.act == ACT_SIN) launch_modes2<S, ACT_SIN>(ga, mode, blocks, st); else launch_spec2<S>(ga, mode, blocks, st);
@@ -250,11 +298,27 @@ template <class S> void launch_spec3(const GroupArgs& ga, int mode, int blocks, 
         PINN_LAUNCH3(S, MODE_FUSED, ga, blocks, st);
         run_dgm_dw(dgm_dw_args(ga, info3_of<S>(), blocks), st);
     } else if (mode == MODE_RESID) PINN_LAUNCH3(S, MODE_RESID, ga, blocks, st);
+    else if (mode == MODE_LOSS) PINN_LAUNCH3(S, MODE_LOSS, ga, blocks, st);
     else PINN_LAUNCH3(S, MODE_FWD, ga, blocks, st);
 }
 
 struct Registrar {
     explicit Registrar(const SpecInfo& s) { registry().push_back(s); }
+};
+template <class S0, class S1>
+PairInfo make_pair_info() {
+    PairInfo p;
+    p.a = make_info2<S0>(nullptr);
+    p.b = make_info2<S1>(nullptr);
+    p.WG_PER_CU = S0::WG_PER_CU < S1::WG_PER_CU ? S0::WG_PER_CU : S1::WG_PER_CU;
+    p.NW = S0::NW;
+    p.LDS_WG = S0::LDS_WG > S1::LDS_WG ? S0::LDS_WG : S1::LDS_WG;
+    p.SCR = S0::SCR > S1::SCR ? S0::SCR : S1::SCR;
+    p.launch = &launch_pair2<S0, S1>;
+    return p;
+}
+struct PairRegistrar {
+    explicit PairRegistrar(const PairInfo& p) { pair_registry().push_back(p); }
 };
 
 // PAIRS encoding: pair p occupies byte p: low nibble = axis a, high nibble = axis b (a <= b)
@@ -299,6 +363,14 @@ struct Registrar {
     }                                                                                        \
     namespace {                                                                              \
     pk::Registrar NAME##_reg3(pk::info3_of<pk::NAME##_spec3>());                             \
+    }
+// merged launch of two family-2 members of one network shape (tanh / sigmoid): member A = (D1MASK, PAIRS, NPAIR, PG, HI) of the first
+// tile list (normally the interior term's jet set), member B of the second (normally the value-only set of the boundary terms)
+#define PINN_INSTANTIATE2_PAIR(NAME, HP, NHH, D, D1MASK_A, PAIRS_A, NPAIR_A, PG_A, HI_A, D1MASK_B, PAIRS_B, NPAIR_B, PG_B, HI_B) \
+    namespace {                                                                              \
+    using NAME##_pa = pk::Spec2<HP, NHH, D, D1MASK_A, PAIRS_A, NPAIR_A, PG_A, HI_A>;         \
+    using NAME##_pb = pk::Spec2<HP, NHH, D, D1MASK_B, PAIRS_B, NPAIR_B, PG_B, HI_B>;         \
+    pk::PairRegistrar NAME##_regp(pk::make_pair_info<NAME##_pa, NAME##_pb>());               \
     }
 #define PINN_INSTANTIATE2(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG) PINN_INSTANTIATE2_HI(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, 0u)
 #define PINN_INSTANTIATE(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG) PINN_INSTANTIATE_HI(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, 0u)

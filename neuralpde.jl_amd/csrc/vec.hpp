@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <type_traits>
 
 #ifdef PINN_EMU
 // ------------------------------------------------------------------------------------------
@@ -128,6 +129,12 @@ inline vfloat xrow_allsum(const vfloat& a) {             // over the 4 rows (lan
 }
 inline float lane0(const vfloat& a) { return a.v[0]; }
 inline double wave_sum_d(const vfloat& a, const vbool& m) { double s = 0; for (int l = 0; l < W; ++l) if (m.v[l]) s += (double)a.v[l]; return s; }
+// per-lane DOUBLE accumulator of products of floats (the sums of squared residuals): exact products, so a lane's sum does not depend on
+// how many tiles it saw — the per-term sums of a sharded evaluation equal the single-device ones to double rounding
+struct vdacc { double v[W]; };
+inline vdacc vdacc_zero() { vdacc r; for (int l = 0; l < W; ++l) r.v[l] = 0.0; return r; }
+inline vdacc vdacc_fma(const vfloat& a, const vfloat& b, const vdacc& c) { vdacc r; for (int l = 0; l < W; ++l) r.v[l] = std::fma((double)a.v[l], (double)b.v[l], c.v[l]); return r; }
+inline double wave_sum_dd(const vdacc& a, const vbool& m) { double s = 0; for (int l = 0; l < W; ++l) if (m.v[l]) s += a.v[l]; return s; }
 // v_mfma_f32_16x16x4_f32: D[i][j] += sum_k A[i][k] B[k][j]; lane l supplies A[i=l&15][k=l>>4] and
 // B[k=l>>4][j=l&15]; lane l holds D[row=(l>>4)*4+r][col=l&15], r=0..3. k-ordered fmaf chain.
 inline vfloat4 mfma16(const vfloat& a, const vfloat& b, const vfloat4& c) {
@@ -345,6 +352,15 @@ DEV vfloat xrow_allsum(vfloat v) {
 DEV float lane0(vfloat a) { return __builtin_amdgcn_readfirstlane(a); }
 DEV double wave_sum_d(vfloat a, vbool m) {
     double s = m ? (double)a : 0.0;
+    PINN_UNROLL for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    return s;
+}
+// per-lane DOUBLE accumulator of products of floats (see the emulation section)
+using vdacc = double;
+DEV vdacc vdacc_zero() { return 0.0; }
+DEV vdacc vdacc_fma(vfloat a, vfloat b, vdacc c) { return __builtin_fma((double)a, (double)b, c); }
+DEV double wave_sum_dd(vdacc a, vbool m) {
+    double s = m ? a : 0.0;
     PINN_UNROLL for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
     return s;
 }

@@ -799,3 +799,89 @@ def test_bpinn_loglikelihood_with_std_gradients_and_data_term(npde, use_emu):
     assert np.linalg.norm(g - gref) < 1e-5 * np.linalg.norm(gref)
     with pytest.raises(Exception, match="positive"):
         eng.loglik_grad(th, [0.1, 0.1, 0.0, 0.1, 0.1, 0.1])
+
+
+def _merge_cfg2(npde, points=200, bcs_points=70):
+    from neuralpde_jl_amd import workloads
+    wl = workloads.cfg2_poisson2d(points=points, bcs_points=bcs_points)
+    return wl
+
+
+def test_merged_launch_matches_chained_launches_and_oracle(npde, use_emu, monkeypatch):
+    """interior (forward-Laplacian jet set) + boundary (value-only) launch groups of one 4x64 network run as ONE persistent launch
+    (wave_main2m: both kernel-family members in one kernel, weight-gradient accumulators in registers across both tile lists);
+    PINN_NO_MERGE=1 restores the two chained launches.  Both against the oracle, and against each other."""
+    wl = _merge_cfg2(npde)
+    w = [1.0, 2.0, 0.5, 3.0, 1.5]
+    rep, _, _, th = check(npde, wl.pde_system, wl.chains, wl.strategy, wl.theta, weights=w)
+    assert "launch=merged into group 0" in rep.engine.describe()
+    l_m, g_m = rep.engine.loss_grad(th, w)
+    assert [g["launched_by"] for g in rep.engine.group_timings()] == [0, 0]
+    monkeypatch.setenv("PINN_NO_MERGE", "1")
+    l_c, g_c = rep.engine.loss_grad(th, w)
+    assert [g["launched_by"] for g in rep.engine.group_timings()] == [0, 1]
+    monkeypatch.delenv("PINN_NO_MERGE")
+    np.testing.assert_allclose(l_m, l_c, rtol=1e-12)                # same forward arithmetic, same per-wave partials
+    np.testing.assert_allclose(g_m, g_c, rtol=0, atol=2e-6 * np.abs(g_c).max())
+    # a merged evaluation must not leave anything behind that a later un-merged one picks up (per-term launches, loss-only launches)
+    tl, tg = rep.engine.term_grads(th)
+    np.testing.assert_allclose((np.array(w)[:, None] * tg).sum(axis=0), g_m, rtol=0, atol=2e-6 * np.abs(g_m).max())
+    np.testing.assert_allclose(tl, l_m, rtol=1e-12)
+    l_again, g_again = rep.engine.loss_grad(th, w)
+    assert np.array_equal(l_again, l_m) and np.array_equal(g_again, g_m)
+
+
+def test_merged_launch_uneven_tile_counts(npde, use_emu):
+    """tile counts that do not divide the grid: the tail group's tiles continue the round-robin where the head's stopped"""
+    for pts, bpts in ((17, 300), (333, 65), (64, 96)):
+        wl = _merge_cfg2(npde, pts, bpts)
+        rep, _, _, th = check(npde, wl.pde_system, wl.chains, wl.strategy, wl.theta)
+        assert "launch=merged" in rep.engine.describe()
+
+
+def test_one_kernel_reduction_matches_two_stage(npde, use_emu, monkeypatch):
+    """a single slab set (merged / chained groups of one network): aux::k_reduce_one; PINN_NO_REDUCE_ONE=1: reduce1 + reduce2"""
+    wl = _merge_cfg2(npde, 300, 130)
+    w = [1.0, 2.0, 0.5, 3.0, 1.5]
+    rep, _, _, th = check(npde, wl.pde_system, wl.chains, wl.strategy, wl.theta, weights=w)
+    monkeypatch.setenv("PINN_REDUCE_DIRECT_MAX", "0")             # (the emulated device has 4 workgroup slots: "small" otherwise)
+    l1, g1 = rep.engine.loss_grad(th, w)
+    monkeypatch.setenv("PINN_NO_REDUCE_ONE", "1")
+    l2, g2 = rep.engine.loss_grad(th, w)
+    monkeypatch.setenv("PINN_NO_MERGE", "1")                       # chained launches: still one slab set
+    monkeypatch.delenv("PINN_NO_REDUCE_ONE")
+    l3, g3 = rep.engine.loss_grad(th, w)
+    for l, g in ((l2, g2), (l3, g3)):
+        np.testing.assert_allclose(l, l1, rtol=1e-12)
+        np.testing.assert_allclose(g, g1, rtol=0, atol=2e-6 * np.abs(g1).max())
+    prob = helpers.oracle_problem(npde, wl.pde_system, wl.chains)
+    ref = po.loss_and_grad(prob, th, rep.pde_train_sets + rep.bcs_train_sets, weights=w, mode="stencil")
+    le, e2, ei = helpers.rel_errors(l1, g1, ref)
+    assert le.max() < TOL and e2 < TOL and ei < TOL
+
+
+def _loss_only_cases(npde):
+    from neuralpde_jl_amd import workloads
+    yield workloads.cfg1_poisson1d(64)                           # family 1 (3 x 32), boundary terms riding on the interior launch
+    yield workloads.cfg2_poisson2d(points=200, bcs_points=70)    # family 2, merged launch in the full evaluation
+    yield workloads.cfg4_cavity(points=70, bcs_points=40, width=16, hidden=2)      # coupled equations: forward launches + k_expr
+    yield workloads.cfg5_heat_inverse(points=150, bcs_points=70, width=128, hidden=2)   # 8-wave workgroups, PDE parameter
+
+
+def test_loss_only_evaluation_returns_the_fused_losses(npde, use_emu):
+    """pinn_loss_grad(grad = NULL): MODE_LOSS kernels (forward + tape + sums of squares, no reverse sweep) — the term losses are the
+    numbers of the full evaluation, bit for bit (same forward arithmetic), with and without term weights"""
+    for wl in _loss_only_cases(npde):
+        disc = wl.discretization()
+        rep = npde.symbolic_discretize(wl.pde_system, disc)
+        assert rep.engine.L.backend == EXPECTED_BACKEND
+        th = rep.flat_init_params
+        K = rep.engine.K
+        w = list(np.linspace(0.5, 2.0, K))
+        for weights in (None, w):
+            l_full, g_full = rep.engine.loss_grad(th, weights)
+            l_only, g_only = rep.engine.loss_grad(th, weights, want_grad=False)
+            assert g_only is None
+            assert np.array_equal(l_full, l_only), (wl.name, l_full, l_only)
+        l_again, g_again = rep.engine.loss_grad(th, w)            # a loss-only evaluation leaves nothing behind
+        assert np.array_equal(l_again, l_full) and np.array_equal(g_again, g_full)
