@@ -15,7 +15,6 @@
 //   * one process, several devices (what a Julia caller does): pinn_create_on(desc, device_i) for every device, pinn_comm_init_all
 //     over the handles (ncclCommInitAll), then pinn_loss_grad_sharded(handles, ...) per evaluation (host theta in, loss + gradient out).
 #include "engine_types.hpp"
-#include "aux_kernels.hpp"
 
 using namespace pe;
 
@@ -188,7 +187,7 @@ int pinn_loss_grad_sharded_device(pinn_handle h, const float* d_theta, const flo
 #else
     if (E.comm_size != 1) return fail("pinn_loss_grad_sharded_device: the emulation build reduces only inside pinn_loss_grad_sharded (single process)");
 #endif
-    aux::launch_sums_from_double(d_out + E.ntheta, E.d_lossraw, (int)E.terms.size(), st);      // the exact (double) sums replace the float-summed ones
+    sums_from_double(d_out + E.ntheta, E.d_lossraw, (int)E.terms.size(), st);      // the exact (double) sums replace the float-summed ones
     return 0;
 }
 

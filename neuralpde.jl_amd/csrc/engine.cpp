@@ -294,6 +294,8 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
     return 0;
 }
 
+void pe::sums_from_double(float* d_out_sums, const double* d_raw, int K, plat_stream st) { aux::launch_sums_from_double(d_out_sums, d_raw, K, st); }
+
 int pe::upload_theta(pinn_engine& E, const float* theta, int64_t p) {
     if (p != E.ntheta) return fail("theta length " + std::to_string(p) + " != ntheta " + std::to_string(E.ntheta));
     std::memcpy(E.hp_theta, theta, sizeof(float) * p);          // pinned staging: the copy below is a plain DMA, no pageable bounce

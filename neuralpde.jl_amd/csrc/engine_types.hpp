@@ -248,6 +248,7 @@ bool fuse_laplacian(Term& T, int np);
 int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const float* term_w, int only_term, bool timing, double* lossraw = nullptr,
                   bool packed_fresh = false, bool loss_only = false);
 int upload_theta(pinn_engine& E, const float* theta, int64_t p);
+void sums_from_double(float* d_out_sums, const double* d_raw, int K, plat_stream st);      // (float)raw[k] -> out_sums[k], on the stream
 // every entry point that touches the device first makes the handle's device current (single-process multi-GPU callers)
 struct DeviceScope {
     int prev;
