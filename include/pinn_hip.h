@@ -74,7 +74,8 @@ int pinn_set_points_device(pinn_handle h, int term, const float* d_pts, int64_t 
  * grad == NULL selects the LOSS-ONLY evaluation: forward pass + residual + sums of squares, no records, no reverse sweep, no
  * gradient reduction (about a third of the full evaluation) — the cost class of the reference's per-term closures when they are only
  * evaluated, not differentiated (src/training_strategies.jl:215-221: callbacks, MiniMax / SoftAdapt reweighting, rejected line-search
- * trials).  The term losses are the same numbers the full evaluation returns.
+ * trials).  The per-point residuals are those of the full evaluation bit for bit and their squares are summed in double precision, so
+ * the term losses agree with the full evaluation's to the order of those sums (1e-13 relative; identical as floats).
  */
 int pinn_loss_grad(pinn_handle h, const float* theta, int64_t p, const float* term_w,
                    double* term_losses, float* grad);

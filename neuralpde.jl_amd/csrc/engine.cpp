@@ -204,6 +204,7 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
             ga_one.sub_tiles0 = G.ga.ntiles;
             ga_one.ntiles = G.ga.ntiles + T2.ga.ntiles;
             ga_one.scratch = mu->d_scratch;
+            ga_one.scr_stride = mu->pair->SCR;
             ga_one.losspart = mu->d_losspart;
             a1.losspart[g] = mu->d_losspart;
             ga_one.chain = 0;
@@ -224,7 +225,8 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
         max_n1 = std::max(max_n1, nent / 4 + K);
         max_split = std::max(max_split, nsplit_g);
         if (G.kind == 1) {               // coupled: forward launch now, reverse launch after k_expr
-            G.spec->launch(G.ga, (G.use_rec && !loss_only) ? pk::MODE_FWDREC : pk::MODE_FWD, G.blocks, E.stream);
+            G.spec->launch(G.ga, (G.use_rec && !loss_only) ? pk::MODE_FWDREC : pk::MODE_FWD,
+                           std::max(1, std::min(E.ncu * G.spec->WG_FWD, G.spec->family == 1 ? (G.ga.ntiles + 3) / 4 : G.ga.ntiles)), E.stream);
             continue;
         }
         plat_stream st = E.stream;
@@ -235,7 +237,13 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
         }
         if (group_ev(g)) plat_event_record(G.ev_a, st);
         if (merged_head) mu->pair->launch(*ga_launch, blocks, st);
-        else G.spec->launch(*ga_launch, loss_only ? pk::MODE_LOSS : pk::MODE_FUSED, blocks, st);
+        else if (loss_only) {
+            const int tiles = ga_launch->ntiles;
+            const int fb = std::max(1, std::min(E.ncu * G.spec->WG_FWD, G.spec->family == 1 ? (tiles + 3) / 4 : tiles));
+            a1.nblocks[g] = fb;                            // rows of loss partials this launch writes
+            G.launched_blocks = fb;
+            G.spec->launch(*ga_launch, pk::MODE_LOSS, fb, st);
+        } else G.spec->launch(*ga_launch, pk::MODE_FUSED, blocks, st);
         if (group_ev(g)) plat_event_record(G.ev_b, st);
         G.timed = group_ev(g);
         if (forked) {
@@ -597,7 +605,7 @@ int pinn_residual(pinn_handle h, int term, const float* theta, int64_t p, float*
             ga.terms[0] = G.ga.terms[j];
             ga.terms[0].tile0 = 0;
             ga.ntiles = ga.terms[0].ntiles;
-            G.spec->launch(ga, pk::MODE_FWD, std::max(1, std::min(G.max_blocks, (ga.ntiles + 3) / 4)), E.stream);
+            G.spec->launch(ga, pk::MODE_FWD, std::max(1, std::min(E.ncu * G.spec->WG_FWD, G.spec->family == 1 ? (ga.ntiles + 3) / 4 : ga.ntiles)), E.stream);
         }
         aux::launch_expr(expr_args(E, Cp, 0.f, T.d_resid), Cp.blocks, E.stream);
         if (plat_d2h(r, T.d_resid, sizeof(float) * T.n, E.stream)) return fail("D2H copy failed");
@@ -612,7 +620,7 @@ int pinn_residual(pinn_handle h, int term, const float* theta, int64_t p, float*
     ga.terms[0].tile0 = 0;
     ga.terms[0].out = T.d_resid;
     ga.ntiles = ga.terms[0].ntiles;
-    const int blocks = std::max(1, std::min(G.max_blocks, (ga.ntiles + 3) / 4));
+    const int blocks = std::max(1, std::min(E.ncu * G.spec->WG_FWD, G.spec->family == 1 ? (ga.ntiles + 3) / 4 : ga.ntiles));
     G.spec->launch(ga, pk::MODE_RESID, blocks, E.stream);
     if (plat_d2h(r, T.d_resid, sizeof(float) * T.n, E.stream)) return fail("D2H copy failed");
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
@@ -668,7 +676,7 @@ static int forward_jets(pinn_engine& E, int net, const pk::SpecInfo* sp, const f
         ga.dgm_npad = ga.ntiles * 64;
         ga.dgm_nparams = N.nparams();
     }
-    const int blocks = std::max(1, std::min(E.ncu * sp->WG_PER_CU, sp->family == 1 ? (ga.ntiles + 3) / 4 : ga.ntiles));
+    const int blocks = std::max(1, std::min(E.ncu * sp->WG_FWD, sp->family == 1 ? (ga.ntiles + 3) / 4 : ga.ntiles));
     sp->launch(ga, pk::MODE_FWD, blocks, E.stream);
     return 0;
 }

@@ -49,6 +49,7 @@ enum Act : int { ACT_TANH = 0, ACT_SIGMOID = 1, ACT_SIN = 2,
 // reference's per-term closures cost when they are only evaluated — callbacks, adaptive-weight rules, rejected line-search trials
 // (src/training_strategies.jl:215-221).  The forward arithmetic is the FUSED kernel's, so the sums are the same numbers.
 enum Mode : int { MODE_FUSED = 0, MODE_RESID = 1, MODE_FWD = 2, MODE_GRADIN = 3, MODE_FWDREC = 4, MODE_GRADREC = 5, MODE_LOSS = 6 };
+constexpr bool mode_is_forward_only(int mode) { return mode == MODE_RESID || mode == MODE_FWD || mode == MODE_FWDREC || mode == MODE_LOSS; }
 
 constexpr int MAX_GROUP_TERMS = 12;
 constexpr int ND = 8;            // activation-derivative array: d[1] .. d[7] (jets up to order 6 need phi^(7) in the reverse sweep)
@@ -248,6 +249,9 @@ struct GroupArgs {
                                  // network left behind (one slab set and one reduction input for several launch groups)
     int sub_terms0, sub_tiles0;  // merged launch (family 2, wave_main2m): terms [0, sub_terms0) / tiles [0, sub_tiles0) run the first
                                  // kernel-family member, the rest the second
+    int scr_stride;              // floats between two workgroups' record scratch (0: the kernel's own Spec2::SCR).  A merged launch sets
+                                 // the larger of its members' sizes: workgroups are in different members' tile lists at the same time, so
+                                 // both members must address the scratch with ONE stride or their slots overlap
     TermDev terms[MAX_GROUP_TERMS];
 };
 

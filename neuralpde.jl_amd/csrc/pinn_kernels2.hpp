@@ -156,6 +156,13 @@ struct Spec2 {
     static constexpr int NRQ = PINN_F2_REC_LDS ? (NRQ_FIT < NRQ_ALL ? (NRQ_FIT > 0 ? NRQ_FIT : 0) : NRQ_ALL) : 0;
     static constexpr int LDS_WG = LDS_BASE + NRQ * RECQ;
     static constexpr int OCC = WG_PER_CU * NW / 4;                       // waves per SIMD the kernel is compiled for
+    // FORWARD-ONLY launches (MODE_FWD / FWDREC / RESID / LOSS: no reverse sweep) use the two exchange buffers and the output partials
+    // only and a fraction of the registers: they are compiled for up to four waves per SIMD (the loss-only evaluation, pinn_phi,
+    // pinn_residual, the forward launches of coupled equations)
+    static constexpr int LDS_FWD = 2 * XSZ + LDS_UP;
+    static constexpr int WG_FWD_LDS = (160 * 1024 - 1024) / (LDS_FWD * 4);
+    static constexpr int WG_FWD = (WG_FWD_LDS * NW >= 16) ? 16 / NW : (WG_FWD_LDS < 1 ? 1 : WG_FWD_LDS);
+    static constexpr int OCC_FWD = WG_FWD * NW / 4;
     // dW accumulators: resident in registers across tiles when they fit (4x64: 48 registers); for wide/deep nets they
     // are accumulated per tile into this workgroup's slab instead (read-modify-write, L2; same wave owns the same tiles)
 #ifdef PINN_F2_WBAR_SLAB
@@ -244,11 +251,11 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
     static_assert(ACTK != ACT_MIXED, "per-layer activation kinds are compiled for family 1 (small nets) only");
     constexpr bool SINACT = (ACTK == ACT_SIN);
     const ubuf PB = ub_make(P, S::PACKED);
-    const ubuf SB = ub_make(ga.scratch + (size_t)blk * S::SCR, S::SCR);
+    const ubuf SB = ub_make(ga.scratch + (size_t)blk * (ga.scr_stride ? ga.scr_stride : S::SCR), S::SCR);
     float* X0 = lds;
     float* X1 = lds + S::XSZ;
     float* ZT = lds + 2 * S::XSZ + w * (NG * MTW * 256);      // wave-private dZ^T: [q][t][16 columns][16 neurons]
-    float* UP = lds + (S::CHUNKED ? 2 : 3) * S::XSZ;          // output-layer partial sums [wave][q][16]
+    float* UP = lds + (BWD ? (S::CHUNKED ? 2 : 3) : 2) * S::XSZ;      // output-layer partial sums [wave][q][16] (forward-only launches: LDS_FWD)
     float* RL = lds + S::LDS_BASE;                            // LDS-resident record slices [(LH-2-layer)*NG + q][tile][lane][4]
     auto rec_in_lds = [](int layer, int q) { return layer >= 1 && layer <= LH - 2 && (LH - 2 - layer) * NG + q < S::NRQ; };   // (same-kernel records only)
     auto rl_off = [&](int layer, int q, int t) { return vint((((LH - 2 - layer) * NG + q) * MT + w * MTW + t) * 256) + (lane << 2); };

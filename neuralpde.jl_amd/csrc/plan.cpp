@@ -671,7 +671,7 @@ static int plan_group_buffers(pinn_engine& E) {
         G.max_blocks = E.ncu * ((wg_cap > 0 && wg_cap < s.WG_PER_CU) ? wg_cap : s.WG_PER_CU);
         plat_event_create(G.ev_a);
         plat_event_create(G.ev_b);
-        const size_t nw = (size_t)G.max_blocks * s.NW;
+        const size_t nw = (size_t)E.ncu * std::max(s.WG_PER_CU, s.WG_FWD) * s.NW;      // (loss-only launches run more workgroups per CU)
         const int slab_floats = s.family == 3 ? ((N.nparams() + pk::MAX_PARAMS + 63) / 64) * 64 : s.SLAB;
         G.slab_floats = slab_floats;
         G.d_slabs = (float*)plat_malloc(sizeof(float) * (size_t)G.max_blocks * slab_floats);

@@ -19,6 +19,7 @@ constexpr int MAX_GEN_CHANNELS = 24;
 struct SpecInfo {
     int family;                      // 1: one wave per tile (pinn_kernels.hpp); 2: neuron-split workgroups (pinn_kernels2.hpp)
     int WG_PER_CU;
+    int WG_FWD;                      // resident workgroups per CU of the forward-only launches (family 2: up to four waves per SIMD)
     int NW;                          // waves per workgroup (family 1: 4 independent waves; family 2: 4, or 8 at H = 128)
     int HP, NHH, D;
     unsigned D1MASK;
@@ -59,7 +60,7 @@ SpecInfo make_info(void (*launch)(const GroupArgs&, int, int, plat_stream), int 
     s.act1 = s.act2 = s.dgm_rows = 0;
     s.ngen = S::J::GEN ? S::C : 0;
     for (int i = 0; i < MAX_GEN_CHANNELS; ++i) s.gen[i] = (S::J::GEN && i < S::C) ? S::J::gen_channel(i) : 0u;
-    s.family = 1; s.WG_PER_CU = 1; s.NW = 4;
+    s.family = 1; s.WG_PER_CU = 1; s.WG_FWD = 1; s.NW = 4;
     s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR; s.HI = S::HI & 0xFFFFFFu; s.LAP = S::J::LAP;
     s.PG = S::PG; s.C = S::C; s.NG = S::NG; s.TP = S::TP; s.MT = S::MT; s.LH = S::LH; s.NFIRST = S::NFIRST;
     s.PACKED = S::PACKED; s.SLAB = S::SLAB; s.SCR = S::SCR; s.LDS_WG = S::LDS_WG; s.COOP = S::COOP ? 1 : 0; s.SH = S::SH; s.PW = S::PW;
@@ -79,7 +80,7 @@ SpecInfo make_info2(void (*launch)(const GroupArgs&, int, int, plat_stream), int
     s.act1 = s.act2 = s.dgm_rows = 0;
     s.ngen = S::J::GEN ? S::C : 0;
     for (int i = 0; i < MAX_GEN_CHANNELS; ++i) s.gen[i] = (S::J::GEN && i < S::C) ? S::J::gen_channel(i) : 0u;
-    s.family = 2; s.WG_PER_CU = S::WG_PER_CU; s.NW = S::NW;
+    s.family = 2; s.WG_PER_CU = S::WG_PER_CU; s.WG_FWD = S::WG_FWD; s.NW = S::NW;
     s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR; s.HI = S::HI & 0xFFFFFFu; s.LAP = S::J::LAP;
     s.PG = S::PG; s.C = S::C; s.NG = S::NG; s.TP = S::TP; s.MT = S::MT; s.LH = S::LH; s.NFIRST = S::NFIRST;
     s.PACKED = S::PACKED; s.SLAB = S::SLAB; s.SCR = S::SCR; s.LDS_WG = S::LDS_WG; s.COOP = 1; s.SH = S::SLAB; s.PW = 0;
@@ -172,8 +173,8 @@ __global__ void __launch_bounds__(256, 1) k_wave(const GroupArgs ga) {
 // family 2: two waves per SIMD => at most 256 VGPR+AGPR per lane: two 4-wave workgroups per CU (H = 64), or one 8-wave workgroup
 // (H = 128: LDS 100-150 KB per workgroup)
 template <class S, int MODE, int ACTK>
-__global__ void __launch_bounds__(64 * S::NW, S::OCC) k_wave2(const GroupArgs ga) {
-    __shared__ __attribute__((aligned(16))) float lds_all[S::LDS_WG];
+__global__ void __launch_bounds__(64 * S::NW, (mode_is_forward_only(MODE) ? S::OCC_FWD : S::OCC)) k_wave2(const GroupArgs ga) {
+    __shared__ __attribute__((aligned(16))) float lds_all[mode_is_forward_only(MODE) ? S::LDS_FWD : S::LDS_WG];
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     wave_main2<S, MODE, ACTK>(ga, (int)blockIdx.x, (int)gridDim.x, w, lds_all);
 }
@@ -243,7 +244,7 @@ template <class S>
 SpecInfo make_info3(void (*launch)(const GroupArgs&, int, int, plat_stream)) {
     SpecInfo s;
     std::memset(&s, 0, sizeof s);
-    s.family = 3; s.WG_PER_CU = 8; s.NW = 1;
+    s.family = 3; s.WG_PER_CU = 8; s.WG_FWD = 8; s.NW = 1;
     s.HP = S::MP; s.NHH = S::L; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR; s.HI = S::HI & 0xFFFFFFu; s.LAP = 0;
     s.PG = 4; s.C = S::C; s.NG = S::C; s.TP = 64; s.MT = 0; s.LH = S::L; s.NFIRST = S::NFIRST;
     s.COOP = 1;

@@ -869,8 +869,10 @@ def _loss_only_cases(npde):
 
 
 def test_loss_only_evaluation_returns_the_fused_losses(npde, use_emu):
-    """pinn_loss_grad(grad = NULL): MODE_LOSS kernels (forward + tape + sums of squares, no reverse sweep) — the term losses are the
-    numbers of the full evaluation, bit for bit (same forward arithmetic), with and without term weights"""
+    """pinn_loss_grad(grad = NULL): MODE_LOSS kernels (forward + tape + sums of squares, no reverse sweep) — the per-point residuals are
+    the fused kernel's bit for bit (same forward arithmetic) and their squares are summed in double, so the term losses agree to the
+    order of the double-precision sums (the launches partition the points differently): 1e-13 relative, identical once rounded to
+    float; with and without term weights"""
     for wl in _loss_only_cases(npde):
         disc = wl.discretization()
         rep = npde.symbolic_discretize(wl.pde_system, disc)
@@ -882,6 +884,7 @@ def test_loss_only_evaluation_returns_the_fused_losses(npde, use_emu):
             l_full, g_full = rep.engine.loss_grad(th, weights)
             l_only, g_only = rep.engine.loss_grad(th, weights, want_grad=False)
             assert g_only is None
-            assert np.array_equal(l_full, l_only), (wl.name, l_full, l_only)
+            np.testing.assert_allclose(l_only, l_full, rtol=1e-13, atol=0, err_msg=wl.name)
+            assert np.array_equal(l_only.astype(np.float32), l_full.astype(np.float32)), (wl.name, l_full, l_only)
         l_again, g_again = rep.engine.loss_grad(th, w)            # a loss-only evaluation leaves nothing behind
         assert np.array_equal(l_again, l_full) and np.array_equal(g_again, g_full)
