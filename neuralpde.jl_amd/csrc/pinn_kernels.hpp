@@ -272,13 +272,13 @@ DEV void act_derivs_n(int act, vfloat a, vfloat (&d)[ND]) {
         const float m = 2.0f - (float)act, im = 0.5f + 0.5f * (float)act, m2 = m * m;      // act in {ACT_TANH = 0, ACT_SIGMOID = 1}
         const vfloat s = (a + vfloat(m - 1.0f)) * vfloat(im);                              // logistic value behind the record
         const vfloat s1 = s * (vfloat(1.0f) - s);
-        const vfloat s2 = s1 * (vfloat(1.0f) - vfloat(2.0f) * s);
-        const vfloat s3 = s1 * (vfloat(1.0f) - vfloat(6.0f) * s1);
+        const vfloat s2 = s1 * vfma(vfloat(-2.0f), s, vfloat(1.0f));
+        const vfloat s3 = s1 * vfma(vfloat(-6.0f), s1, vfloat(1.0f));
         d[1] = vfloat(m2) * s1;
         d[2] = vfloat(m2 * m) * s2;
         d[3] = vfloat(m2 * m2) * s3;
-        if (NORD >= 4) d[4] = vfloat(m2 * m2 * m) * (s2 * (vfloat(1.0f) - vfloat(12.0f) * s1));
-        if (NORD >= 5) d[5] = vfloat(m2 * m2 * m2) * (s3 * (vfloat(1.0f) - vfloat(12.0f) * s1) - vfloat(12.0f) * s2 * s2);
+        if (NORD >= 4) d[4] = vfloat(m2 * m2 * m) * (s2 * vfma(vfloat(-12.0f), s1, vfloat(1.0f)));
+        if (NORD >= 5) d[5] = vfloat(m2 * m2 * m2) * vfma(s3, vfma(vfloat(-12.0f), s1, vfloat(1.0f)), vfloat(-12.0f) * s2 * s2);
         if (NORD >= 6) d[6] = vfloat(m2 * m2 * m2 * m) * s1 * sig_poly6(s);
         if (NORD >= 7) d[7] = vfloat(m2 * m2 * m2 * m2) * s1 * sig_poly7(s);
         return;
@@ -297,17 +297,17 @@ DEV void act_derivs_n(int act, vfloat a, vfloat (&d)[ND]) {
         const vfloat a2 = a * a;
         d[1] = vfloat(1.0f) - a2;
         d[2] = vfloat(-2.0f) * a * d[1];
-        d[3] = d[1] * (vfloat(6.0f) * a2 - vfloat(2.0f));
-        if (NORD >= 4) d[4] = d[1] * a * (vfloat(16.0f) - vfloat(24.0f) * a2);
+        d[3] = d[1] * vfma(vfloat(6.0f), a2, vfloat(-2.0f));
+        if (NORD >= 4) d[4] = d[1] * a * vfma(vfloat(-24.0f), a2, vfloat(16.0f));
         if (NORD >= 5) d[5] = d[1] * (vfma(vfma(vfloat(120.0f), a2, vfloat(-120.0f)), a2, vfloat(16.0f)));
         if (NORD >= 6) d[6] = d[1] * a * vfma(vfma(vfloat(-720.0f), a2, vfloat(960.0f)), a2, vfloat(-272.0f));
         if (NORD >= 7) d[7] = d[1] * vfma(vfma(vfma(vfloat(5040.0f), a2, vfloat(-8400.0f)), a2, vfloat(3696.0f)), a2, vfloat(-272.0f));
     } else {
         d[1] = a * (vfloat(1.0f) - a);
-        d[2] = d[1] * (vfloat(1.0f) - vfloat(2.0f) * a);
-        d[3] = d[1] * (vfloat(1.0f) - vfloat(6.0f) * d[1]);
-        if (NORD >= 4) d[4] = d[2] * (vfloat(1.0f) - vfloat(12.0f) * d[1]);
-        if (NORD >= 5) d[5] = d[3] * (vfloat(1.0f) - vfloat(12.0f) * d[1]) - vfloat(12.0f) * d[2] * d[2];
+        d[2] = d[1] * vfma(vfloat(-2.0f), a, vfloat(1.0f));
+        d[3] = d[1] * vfma(vfloat(-6.0f), d[1], vfloat(1.0f));
+        if (NORD >= 4) d[4] = d[2] * vfma(vfloat(-12.0f), d[1], vfloat(1.0f));
+        if (NORD >= 5) d[5] = vfma(d[3], vfma(vfloat(-12.0f), d[1], vfloat(1.0f)), vfloat(-12.0f) * d[2] * d[2]);
         if (NORD >= 6) d[6] = d[1] * sig_poly6(a);
         if (NORD >= 7) d[7] = d[1] * sig_poly7(a);
     }

@@ -14,6 +14,7 @@ run write WRITE_SIZE
 run mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 run waves SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA
 run lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS
+run l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum        # is the weight stream (packed image re-read by every workgroup) served by the L2?
 ls -R $REPO/$OUT | head -30
 # text summary per pass + profiles/pmc_traffic.json (HBM-side bytes per launch of the fused kernels; read by bench.py's roofline.traffic)
 python $REPO/tools/pmc_summarize.py $REPO/$OUT $REPO/$OUT/pmc_summary.txt $REPO/$OUT/pmc_traffic.json

@@ -18,20 +18,31 @@ import sys
 from collections import defaultdict
 
 
-def spec_key(kernel_name):
-    """k_wave2<Spec2<HP,NHH,D,D1MASK,PAIRS,NPAIR,PG,HI>,MODE,ACT> -> the name pinn_describe prints (plan.cpp: spec_name)"""
-    m = re.search(r"k_wave(2?)<pk::Spec2?<(\d+), (\d+), (\d+), (\d+)u?, (\d+)(?:ull|ul|u)?, (\d+), (\d+), (\d+)u?>, (\d+), (\d+)>", kernel_name)
-    if not m:
-        return None, None
-    fam = 2 if m.group(1) else 1
-    HP, NHH, D, F, PAIRS, NPAIR, PG, HI, MODE, ACT = [int(m.group(i)) for i in range(2, 12)]
+def _one_key(fam, HP, NHH, D, F, PAIRS, NPAIR, PG, HI):
     nfirst = bin(F).count("1")
     lap = (HI >> 24) & 0xFF
     n3 = sum(1 for a in range(6) if ((HI >> (4 * a)) & 0xF) >= 3)
     n4 = sum(1 for a in range(6) if ((HI >> (4 * a)) & 0xF) >= 4)
     C = 1 + nfirst + NPAIR + (1 if lap else 0) + n3 + n4
-    key = "F%d_HP%d_NHH%d_D%d_F%x_P%x_H%x_L%x_PG%d(C=%d)" % (fam, HP, NHH, D, F, PAIRS, HI & 0xFFFFFF, lap, PG, C)
-    return key, MODE
+    return "F%d_HP%d_NHH%d_D%d_F%x_P%x_H%x_L%x_PG%d(C=%d)" % (fam, HP, NHH, D, F, PAIRS, HI & 0xFFFFFF, lap, PG, C)
+
+
+SPEC_RE = r"pk::Spec2?<(\d+), (\d+), (\d+), (\d+)u?, (\d+)(?:ull|ul|u)?, (\d+), (\d+), (\d+)u?>"
+
+
+def spec_key(kernel_name):
+    """k_wave2<Spec2<HP,NHH,D,D1MASK,PAIRS,NPAIR,PG,HI>,MODE,ACT> -> the name pinn_describe prints (plan.cpp: spec_name);
+    k_wave2m<Spec2<..>,Spec2<..>,ACT> (merged launch, MODE_FUSED) -> "keyA+keyB" as bench.py builds it"""
+    m = re.search(r"k_wave2m<" + SPEC_RE + ", " + SPEC_RE + r", (\d+)>", kernel_name)
+    if m:
+        v = [int(m.group(i)) for i in range(1, 18)]
+        return _one_key(2, *v[0:8]) + "+" + _one_key(2, *v[8:16]), 0
+    m = re.search(r"k_wave(2?)<" + SPEC_RE + r", (\d+), (\d+)>", kernel_name)
+    if not m:
+        return None, None
+    fam = 2 if m.group(1) else 1
+    v = [int(m.group(i)) for i in range(2, 12)]
+    return _one_key(fam, *v[0:8]), v[8]
 
 
 def main():
@@ -69,9 +80,10 @@ def main():
             key, mode = spec_key(kn)
             if key is None or mode != 0 or "FETCH_SIZE" not in cs or "WRITE_SIZE" not in cs:
                 continue
-            # points per launch: the interior kernel (C > 1) runs the `points` interior points, the boundary kernel 4 x `points`
-            C = int(re.search(r"C=(\d+)", key).group(1))
-            ks.append({"key": key, "kernel": kn, "points_per_launch": points if C > 1 else 4 * points,
+            # points per launch: the interior kernel (C > 1) runs the `points` interior points, the boundary kernel 4 x `points`, the
+            # merged launch all five terms' points
+            ppl = sum(points if int(c) > 1 else 4 * points for c in re.findall(r"C=(\d+)", key))
+            ks.append({"key": key, "kernel": kn, "points_per_launch": ppl,
                        "fetch_kb": cs["FETCH_SIZE"], "write_kb": cs["WRITE_SIZE"],
                        "bytes_per_launch": (2.0 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024.0,
                        "source": os.path.relpath(out_txt, os.path.dirname(os.path.dirname(os.path.abspath(out_json))))})
