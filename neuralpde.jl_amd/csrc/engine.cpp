@@ -189,6 +189,8 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
             ga_launch = &ga_one;
         }
         const bool merged_head = mu && (int)g == mu->head;
+        bool pp_launch = false;
+        int pp_blocks = 0;
         if (merged_head) {
             // ONE launch for this group's tiles and the tail group's: terms and tiles concatenated, the tail's after the head's
             const Group& T2 = E.groups[mu->tail];
@@ -210,6 +212,12 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
             ga_one.chain = 0;
             blocks = std::max(1, std::min(mu->max_blocks, ga_one.ntiles));
             ga_launch = &ga_one;
+            // ping-pong scheduling (one 8-wave workgroup per CU = two wave quartets half a tile apart): PINN_PP=1
+            pp_launch = mu->pair->launch_pp != nullptr && std::getenv("PINN_PP") != nullptr && mu->max_blocks >= 2;
+            if (pp_launch) {
+                pp_blocks = std::max(1, std::min(mu->max_blocks / 2, (ga_one.ntiles + 1) / 2));
+                blocks = 2 * pp_blocks;                    // virtual workgroups (= gradient slabs, rows of loss partials / 4)
+            }
         }
         G.launched_blocks = blocks;
         G.launched_by = (int)g;
@@ -236,7 +244,8 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
             plat_stream_wait_event(st, E.ev_fork);
         }
         if (group_ev(g)) plat_event_record(G.ev_a, st);
-        if (merged_head) mu->pair->launch(*ga_launch, blocks, st);
+        if (merged_head && pp_launch) mu->pair->launch_pp(*ga_launch, pp_blocks, st);
+        else if (merged_head) mu->pair->launch(*ga_launch, blocks, st);
         else if (loss_only) {
             const int tiles = ga_launch->ntiles;
             const int fb = std::max(1, std::min(E.ncu * G.spec->WG_FWD, G.spec->family == 1 ? (tiles + 3) / 4 : tiles));

@@ -295,7 +295,7 @@ DEV void act_derivs_n(int act, vfloat a, vfloat (&d)[ND]) {
         if (NORD >= 7) d[7] = vfloat(0.f) - cs;
     } else if (act == ACT_TANH) {
         const vfloat a2 = a * a;
-        d[1] = vfloat(1.0f) - a2;
+        d[1] = vfma(-a, a, vfloat(1.0f));                           // 1 - a^2 with one rounding (the negation is an operand modifier)
         d[2] = vfloat(-2.0f) * a * d[1];
         d[3] = d[1] * vfma(vfloat(6.0f), a2, vfloat(-2.0f));
         if (NORD >= 4) d[4] = d[1] * a * vfma(vfloat(-24.0f), a2, vfloat(16.0f));
@@ -351,6 +351,9 @@ DEV void jet_forward(vfloat (&z)[J::C], const vfloat (&d)[ND]) {
 // on exit; s = the record (s[0] = a, s[k>0] = pre-activation channels).
 template <class J>
 DEV void jet_adjoint(vfloat (&g)[J::C], const vfloat (&s)[J::C], const vfloat (&d)[ND]) {
+#if !defined(PINN_EMU)
+#pragma clang fp contract(fast)      // reverse-sweep only: nothing here feeds a residual, so the compiler may fuse what it finds (vec.hpp)
+#endif
     vfloat zv = d[1] * g[0];
     vfloat zf[J::NFIRST > 0 ? J::NFIRST : 1], zp[J::NPAIR > 0 ? J::NPAIR : 1], z3b[J::N3 > 0 ? J::N3 : 1];
     PINN_UNROLL for (int kf = 0; kf < J::NFIRST; ++kf) {

@@ -62,6 +62,13 @@
 #ifndef PINN_F2_LINEAR_ONLY
 #define PINN_F2_LINEAR_ONLY 0           // experiment: compile the tape interpreter out (kernels for groups whose terms are all affine)
 #endif
+// ping-pong scheduling of the merged launch (wave_main2pp; PINN_PP=1 at run time selects it).  Measured in round 3 and NOT compiled into
+// the product: 560 vs 382 us per evaluation on the bench workload (profiles/r03_experiments.txt) — a workgroup-wide barrier after every
+// GEMM / element-wise phase makes each of the 20 supersteps of a tile as long as the slowest wave's worst latency (coordinate, weight and
+// record loads), which two free-running workgroups per CU hide from each other.  The emulation build keeps it compiled (tests).
+#ifndef PINN_F2_PP
+#define PINN_F2_PP 0
+#endif
 #ifndef PINN_F2_GEMM_SITES
 #define PINN_F2_GEMM_SITES 7            // bit mask: 1 forward GEMM, 2 dA GEMM, 4 dW GEMM
 #endif
@@ -171,6 +178,12 @@ struct Spec2 {
     static constexpr bool WBAR_REG = (NHH_ * MTW * MT * 4 <= 96);
 #endif
     using Shape = Shape2<HP_, NHH_, D_, NW, WBAR_REG>;
+    // ping-pong scheduling (wave_tiles2<.., PP = true>): supersteps (= workgroup barriers) per tile, GEMM phases at the odd positions;
+    // the second wave quartet of a workgroup starts PP_LAG supersteps (an odd number, about half a tile) behind the first
+    static constexpr int PP_STEPS = 6 * NHH_ + 2;
+    static constexpr int PP_LAG = ((PP_STEPS / 2) & 1) ? PP_STEPS / 2 : PP_STEPS / 2 - 1;
+    static constexpr bool PP_OK = (NW == 4) && (MT * MTW * 4 <= 16) && WBAR_REG && NHH_ >= 1 && ((3 * NG * MT * 256 + LDS_UP) * 4 <= 160 * 1024) &&
+                                  (2 * LDS_WG * 4 <= 160 * 1024);
 };
 
 // ---- persistent gradient accumulators of this wave's neuron tiles: zero, or (chained launch group) the sums an earlier launch group of
@@ -227,9 +240,15 @@ DEV void acc2_init(Acc2<typename S::Shape>& ac, const GroupArgs& ga, int blk, in
 
 // ---- the tile loop: workgroup `blk` of `nblocks` takes the tiles tix = blk (mod nblocks) of [tile_lo, tile_hi), which belong to the terms
 // [term_lo, term_hi) of the launch (one launch group: everything; a merged launch: one call per kernel family member) ----
-template <class S, int MODE, int ACTK>
+// PP ("ping-pong", wave_main2pp): the tile body as a fixed sequence of S::PP_STEPS supersteps, every one closed by a workgroup barrier and
+// every one either a GEMM phase (MFMA + fragment reads only) or an element-wise phase (VALU, LDS stores, global loads) — GEMM phases at the
+// odd positions.  Two wave quartets of ONE 8-wave workgroup run this body an odd number of supersteps apart, so that on every SIMD one
+// wave is in a GEMM phase while its partner does element-wise work: the matrix pipe never serves two GEMMs at once and is never left idle
+// by two waves that sit in element-wise phases together (what two independent workgroups per CU drift into).
+template <class S, int MODE, int ACTK, bool PP = false>
 DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds, Acc2<typename S::Shape>& ac,
                      int term_lo, int term_hi, int tile_lo, int tile_hi) {
+    static_assert(!PP || MODE == MODE_FUSED, "ping-pong scheduling is compiled for the fused evaluation only");
     constexpr int HP = S::HP, MT = S::MT, MTW = S::MTW, NHH = S::NHH, LH = S::LH, D = S::D, C = S::C, PG = S::PG, NG = S::NG;
     constexpr int NFIRST = S::NFIRST;
     using J = typename S::J;
@@ -408,6 +427,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 if (WPRE && PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 1)) sched_gemm_prefetch<MT * NG, MTW * 4, PINN_F2_GEMM_AHEAD>();
                 wave_prio(1);
                 STAMP(2)
+                if (PP) wg_barrier();                                           // superstep boundary: GEMM | element-wise
                 act_forward(A, hl + 1);
                 STAMP(3)
             }
@@ -685,7 +705,8 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t)
                     PINN_UNROLL for (int r = 0; r < 4; ++r) bbar[hl + 1][t][r] += G[pg * C][t][r];
-            publish(X0, G);                                                  // dZ in B-fragment order for dA = W^T dZ
+            if (!PP || hl == NHH - 1) publish(X0, G);                        // dZ in B-fragment order for dA = W^T dZ (PP: the later layers' dZ is
+                                                                             // published by the activation-adjoint superstep of the layer above)
             // stage column group q: dZ^T (wave private, [t][column][16 neurons]) and A^T (cooperative, [column][HP]), slot-swizzled
             auto stage_q = [&](int q, float* zt, float* at) {
                 PINN_UNROLL for (int t = 0; t < MTW; ++t) {
@@ -731,6 +752,44 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
             // the activation adjoint between those of the dW GEMM, instead of in phases of their own:
             //   publish dZ | barrier | dA(q) + stage(q) ... | barrier | dW(q) ... + act_adjoint | next layer
             constexpr bool OVL = WPRE && !S::CHUNKED;
+            if (PP) {
+                // supersteps of this layer:  [stage (+ publish of the first layer's dZ)] | dA GEMM | [activation adjoint + publish of the
+                // next layer's dZ] | dW GEMM |   — GEMM phases carry no VALU work of their own, element-wise phases no MFMA
+                static_assert(!PP || (OVL && S::WBAR_REG), "ping-pong scheduling: H = 64 kernels (weight fragments prefetched, dW in registers)");
+                PINN_UNROLL for (int q = 0; q < NG; ++q) stage_q(q, ZT + q * (MTW * 256), X1 + q * 16 * HP);
+                STAMP(7)
+                wg_barrier();                                               // staged operands + dZ of every wave visible
+                STAMP(8)
+                wave_prio_gemm(gemm_hi);
+                PINN_UNROLL for (int q = 0; q < NG; ++q)
+                    PINN_UNROLL for (int mo = 0; mo < MT; ++mo) {
+                        vfloat4 b4 = lds_load4(X0, vint(((q * MT + mo) * 64) * 4) + (lane << 2));
+                        PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                            PINN_UNROLL for (int rr = 0; rr < 4; ++rr) Gn[q][t] = mfma16(wt[mo][t][rr], b4[rr], Gn[q][t]);
+                    }
+                if (PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 2)) sched_gemm_prefetch<MT * NG, MTW * 4, PINN_F2_GEMM_AHEAD>();
+                wave_prio(1);
+                STAMP(10)
+                wg_barrier();                                               // dA done: X0 free
+                STAMP(11)
+                PINN_UNROLL for (int q = 0; q < NG; ++q)
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t) G[q][t] = Gn[q][t];
+                act_adjoint(G, Sr);
+                if (hl > 0) {
+                    publish(X0, G);                                         // next layer's dZ (its dW operands are staged after this layer's dW)
+                    if (SPRE && hl - 1 >= 1) load_record(hl - 1);
+                }
+                STAMP(12)
+                wg_barrier();                                               // element-wise | dW GEMM
+                wave_prio_gemm(gemm_hi);
+                PINN_UNROLL for (int q = 0; q < NG; ++q) dw_q(ZT + q * (MTW * 256), X1 + q * 16 * HP);
+                if (PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 4) && MTW == 1 && MT == 4)
+                    sched_gemm_prefetch<4 * NG, 4, PINN_F2_GEMM_AHEAD, 2>();
+                wave_prio(1);
+                STAMP(9)
+                wg_barrier();                                               // dW done: ZT / X1 free (the tile's last superstep for hl == 0)
+                continue;
+            }
             if (OVL) {
                 STAMP(7)
                 wg_barrier();                                               // dZ of every wave is in X0; the previous layer's dW reads are done
@@ -915,6 +974,42 @@ DEV void wave_main2m(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
         ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[ac.cur_term].term_id] = wave_sum_dd(ac.lsum, veq(lane_id() >> 4, 0));
     wg_barrier();
     acc2_store<S0, (S0::PG > S1::PG ? S0::PG : S1::PG)>(ac, ga, blk, w, lds);
+}
+
+// ---- MERGED launch with PING-PONG scheduling: one 8-wave workgroup per CU = two wave quartets, each a "virtual workgroup" of the merged
+// launch (own tile stream, own LDS half, own gradient slab: vb = 2 blk + quartet of 2 nblocks), run PP_LAG supersteps apart (see
+// wave_tiles2<.., PP>).  Every quartet passes the same number of workgroup barriers: PP_STEPS per tile slot (idle slots included), the lag
+// at the start (second quartet) or at the end (first), and the epilogue's.  Correctness never depends on how the two quartets' supersteps
+// pair up (they share no LDS) — only the overlap does. ----
+template <class S0, class S1, int ACTK>
+DEV void wave_main2pp(const GroupArgs& ga, int blk, int nblocks, int w8, float* lds) {
+    static_assert(std::is_same<typename S0::Shape, typename S1::Shape>::value, "merged launches need members of one network shape and neuron split");
+    static_assert(S0::SLAB == S1::SLAB && S0::PACKED == S1::PACKED && S0::PP_OK && S1::PP_OK, "ping-pong launches: H = 64 members of one network");
+    constexpr int LDSQ = S0::LDS_WG > S1::LDS_WG ? S0::LDS_WG : S1::LDS_WG;       // LDS floats of one quartet
+    constexpr int NB = S0::PP_STEPS, LAG = S0::PP_LAG;
+    const int quartet = w8 >> 2, w = w8 & 3;
+    const int vb = 2 * blk + quartet, nvb = 2 * nblocks;
+    float* ldsq = lds + quartet * LDSQ;
+    const int wave = vb * 4 + w;
+    Acc2<typename S0::Shape> ac;
+    acc2_init<S0>(ac, ga, vb, w, true);
+    for (int j = 0; j < ga.nterms; ++j) ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[j].term_id] = 0.0;
+    if (quartet == 1)
+        for (int i = 0; i < LAG; ++i) wg_barrier();
+    const int niter = (ga.ntiles + nvb - 1) / nvb;
+    for (int it = 0; it < niter; ++it) {
+        const int gt = it * nvb + vb;
+        if (gt < ga.sub_tiles0) wave_tiles2<S0, MODE_FUSED, ACTK, true>(ga, vb, nvb, w, ldsq, ac, 0, ga.sub_terms0, gt, gt + 1);
+        else if (gt < ga.ntiles) wave_tiles2<S1, MODE_FUSED, ACTK, true>(ga, vb, nvb, w, ldsq, ac, ga.sub_terms0, ga.nterms, gt, gt + 1);
+        else
+            for (int i = 0; i < NB; ++i) wg_barrier();                      // idle tile slot: keep in step with the other quartet
+    }
+    if (quartet == 0)
+        for (int i = 0; i < LAG; ++i) wg_barrier();
+    if (ac.cur_term >= 0)
+        ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[ac.cur_term].term_id] = wave_sum_dd(ac.lsum, veq(lane_id() >> 4, 0));
+    wg_barrier();
+    acc2_store<S0, (S0::PG > S1::PG ? S0::PG : S1::PG)>(ac, ga, vb, w, ldsq);
 }
 
 }  // namespace pk

@@ -49,6 +49,8 @@ struct PairInfo {
     SpecInfo a, b;
     int WG_PER_CU, NW, LDS_WG, SCR;      // of the merged kernel: min / common / max / max of the members
     void (*launch)(const GroupArgs&, int blocks, plat_stream);
+    // ping-pong variant (wave_main2pp): 8-wave workgroups of two quartets, `blocks` = workgroups = half the virtual workgroups; nullptr: none
+    void (*launch_pp)(const GroupArgs&, int blocks, plat_stream);
 };
 std::deque<PairInfo>& pair_registry();
 
@@ -157,8 +159,27 @@ void run_emu2m(const GroupArgs& ga, int blocks) {
         for (int w = 0; w < S0::NW; ++w) th[w].join();
     }
 }
+template <class S0, class S1, int ACTK>
+void run_emu2pp(const GroupArgs& ga, int blocks) {
+    constexpr int LDSQ = S0::LDS_WG > S1::LDS_WG ? S0::LDS_WG : S1::LDS_WG;
+    std::vector<float> lds((size_t)2 * LDSQ);
+    for (int b = 0; b < blocks; ++b) {
+        for (auto& v : lds) v = std::nanf("");
+        EmuBarrier bar;
+        bar.nwaves = 8;
+        std::thread th[8];
+        for (int w = 0; w < 8; ++w)
+            th[w] = std::thread([&, w] {
+                wv::emu_barrier_hook = &EmuBarrier::wait;
+                wv::emu_barrier_ctx = &bar;
+                wave_main2pp<S0, S1, ACTK>(ga, b, blocks, w, lds.data());
+            });
+        for (int w = 0; w < 8; ++w) th[w].join();
+    }
+}
 #define PINN_LAUNCH2(S, MODE, ACTK, ga, blocks, st) run_emu2<S, MODE, ACTK>(ga, blocks)
 #define PINN_LAUNCH2M(S0, S1, ACTK, ga, blocks, st) run_emu2m<S0, S1, ACTK>(ga, blocks)
+#define PINN_LAUNCH2PP(S0, S1, ACTK, ga, blocks, st) run_emu2pp<S0, S1, ACTK>(ga, blocks)
 #define PINN_LAUNCH1(S, MODE, ACTK, ga, blocks, st) run_emu<S, MODE, ACTK>(ga, blocks)
 #else
 // One workgroup = 4 independent waves (one per SIMD); persistent grid of <= #CU workgroups.
@@ -191,6 +212,14 @@ __global__ void __launch_bounds__(64 * S0::NW, (Pair2<S0, S1>::OCC)) k_wave2m(co
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     wave_main2m<S0, S1, ACTK>(ga, (int)blockIdx.x, (int)gridDim.x, w, lds_all);
 }
+// ping-pong variant: one 8-wave workgroup per CU (two wave quartets = two virtual workgroups of the merged launch), 2 waves per SIMD
+template <class S0, class S1, int ACTK>
+__global__ void __launch_bounds__(512, 2) k_wave2pp(const GroupArgs ga) {
+    __shared__ __attribute__((aligned(16))) float lds_all[2 * Pair2<S0, S1>::LDS_WG];
+    const int w8 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    wave_main2pp<S0, S1, ACTK>(ga, (int)blockIdx.x, (int)gridDim.x, w8, lds_all);
+}
+#define PINN_LAUNCH2PP(S0, S1, ACTK, ga, blocks, st) hipLaunchKernelGGL((k_wave2pp<S0, S1, ACTK>), dim3(blocks), dim3(512), 0, st, ga)
 #define PINN_LAUNCH2(S, MODE, ACTK, ga, blocks, st) hipLaunchKernelGGL((k_wave2<S, MODE, ACTK>), dim3(blocks), dim3(64 * S::NW), 0, st, ga)
 #define PINN_LAUNCH2M(S0, S1, ACTK, ga, blocks, st) hipLaunchKernelGGL((k_wave2m<S0, S1, ACTK>), dim3(blocks), dim3(64 * S0::NW), 0, st, ga)
 #define PINN_LAUNCH1(S, MODE, ACTK, ga, blocks, st) hipLaunchKernelGGL((k_wave<S, MODE, ACTK>), dim3(blocks), dim3(256), 0, st, ga)
@@ -228,6 +257,12 @@ template <class S0, class S1> void launch_pair2(const GroupArgs& ga, int blocks,
     (void)st;
     if (ga.act == ACT_TANH) PINN_LAUNCH2M(S0, S1, ACT_TANH, ga, blocks, st); else PINN_LAUNCH2M(S0, S1, ACT_SIGMOID, ga, blocks, st);
 }
+template <class S0, class S1> void launch_pair2pp(const GroupArgs& ga, int blocks, plat_stream st) {
+    (void)st;
+    if (ga.act == ACT_TANH) PINN_LAUNCH2PP(S0, S1, ACT_TANH, ga, blocks, st); else PINN_LAUNCH2PP(S0, S1, ACT_SIGMOID, ga, blocks, st);
+}
+template <class S, bool OK> struct PairPP { template <class S0, class S1> static void (*get())(const GroupArgs&, int, plat_stream) { return nullptr; } };
+template <class S> struct PairPP<S, true> { template <class S0, class S1> static void (*get())(const GroupArgs&, int, plat_stream) { return &launch_pair2pp<S0, S1>; } };
 template <class S> void launch_spec2_sin(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
     if (ga.act == ACT_SIN) launch_modes2<S, ACT_SIN>(ga, mode, blocks, st); else launch_spec2<S>(ga, mode, blocks, st);
 }
@@ -316,6 +351,7 @@ PairInfo make_pair_info() {
     p.LDS_WG = S0::LDS_WG > S1::LDS_WG ? S0::LDS_WG : S1::LDS_WG;
     p.SCR = S0::SCR > S1::SCR ? S0::SCR : S1::SCR;
     p.launch = &launch_pair2<S0, S1>;
+    p.launch_pp = PairPP<S0, (PINN_F2_PP && S0::PP_OK && S1::PP_OK)>::template get<S0, S1>();
     return p;
 }
 struct PairRegistrar {

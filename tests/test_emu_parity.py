@@ -831,6 +831,23 @@ def test_merged_launch_matches_chained_launches_and_oracle(npde, use_emu, monkey
     assert np.array_equal(l_again, l_m) and np.array_equal(g_again, g_m)
 
 
+def test_ping_pong_merged_launch(npde, use_emu, monkeypatch):
+    """PINN_PP=1: the merged launch as 8-wave workgroups of two wave quartets that run the tile body half a tile apart (GEMM supersteps of
+    one beside element-wise supersteps of the other); odd / even tile counts, idle tile slots; against the oracle and the plain merged launch"""
+    monkeypatch.setenv("PINN_PP", "1")
+    for pts, bpts in ((200, 70), (17, 300), (16, 65), (333, 129)):
+        wl = _merge_cfg2(npde, pts, bpts)
+        w = [1.0, 2.0, 0.5, 3.0, 1.5]
+        rep, _, _, th = check(npde, wl.pde_system, wl.chains, wl.strategy, wl.theta, weights=w)
+        assert "launch=merged" in rep.engine.describe()
+        l_pp, g_pp = rep.engine.loss_grad(th, w)
+        monkeypatch.delenv("PINN_PP")
+        l_m, g_m = rep.engine.loss_grad(th, w)
+        monkeypatch.setenv("PINN_PP", "1")
+        np.testing.assert_allclose(l_pp, l_m, rtol=1e-12)
+        np.testing.assert_allclose(g_pp, g_m, rtol=0, atol=2e-6 * np.abs(g_m).max())
+
+
 def test_merged_launch_uneven_tile_counts(npde, use_emu):
     """tile counts that do not divide the grid: the tail group's tiles continue the round-robin where the head's stopped"""
     for pts, bpts in ((17, 300), (333, 65), (64, 96)):
