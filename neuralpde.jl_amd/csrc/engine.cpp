@@ -140,7 +140,7 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
     const bool concurrent = want_concurrent && nfused_active >= 2 && all_small;
     static const bool no_chain = std::getenv("PINN_NO_CHAIN") != nullptr;      // A/B switches
     const bool no_merge = std::getenv("PINN_NO_MERGE") != nullptr;            // (read per call: the tests switch them)
-    const bool may_merge = !no_merge && !no_chain && !concurrent && !loss_only && only_term < 0;
+    const bool may_merge = !no_merge && !no_chain && !concurrent && only_term < 0;
     int nforked = 0;
     int nslabsets = 0, slabset_group = -1;          // launch groups whose own slab set carries gradient sums in this evaluation
     if (concurrent) plat_event_record(E.ev_fork, E.stream);
@@ -210,10 +210,10 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
             ga_one.losspart = mu->d_losspart;
             a1.losspart[g] = mu->d_losspart;
             ga_one.chain = 0;
-            blocks = std::max(1, std::min(mu->max_blocks, ga_one.ntiles));
+            blocks = std::max(1, std::min(loss_only ? E.ncu * mu->pair->WG_FWD : mu->max_blocks, ga_one.ntiles));
             ga_launch = &ga_one;
             // ping-pong scheduling (one 8-wave workgroup per CU = two wave quartets half a tile apart): PINN_PP=1
-            pp_launch = mu->pair->launch_pp != nullptr && std::getenv("PINN_PP") != nullptr && mu->max_blocks >= 2;
+            pp_launch = !loss_only && mu->pair->launch_pp != nullptr && std::getenv("PINN_PP") != nullptr && mu->max_blocks >= 2;
             if (pp_launch) {
                 pp_blocks = std::max(1, std::min(mu->max_blocks / 2, (ga_one.ntiles + 1) / 2));
                 blocks = 2 * pp_blocks;                    // virtual workgroups (= gradient slabs, rows of loss partials / 4)
@@ -245,7 +245,7 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
         }
         if (group_ev(g)) plat_event_record(G.ev_a, st);
         if (merged_head && pp_launch) mu->pair->launch_pp(*ga_launch, pp_blocks, st);
-        else if (merged_head) mu->pair->launch(*ga_launch, blocks, st);
+        else if (merged_head) mu->pair->launch(*ga_launch, loss_only ? pk::MODE_LOSS : pk::MODE_FUSED, blocks, st);
         else if (loss_only) {
             const int tiles = ga_launch->ntiles;
             const int fb = std::max(1, std::min(E.ncu * G.spec->WG_FWD, G.spec->family == 1 ? (tiles + 3) / 4 : tiles));
@@ -296,12 +296,13 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
     // one slab set carries the whole gradient (a single network whose launch groups are merged / chained): one reduction kernel
     const bool no_reduce_one = std::getenv("PINN_NO_REDUCE_ONE") != nullptr;
     const Group* RG = (nslabsets == 1 && !coupled_active && !loss_only && !no_reduce_one) ? &E.groups[slabset_group] : nullptr;
-    if (RG && RG->d_ent_theta && RG->ent_covers_theta && !aux::reduce_is_small(a1, a2)) {
+    const bool one_kernel = ((RG && RG->d_ent_theta && RG->ent_covers_theta) || (loss_only && !no_reduce_one)) && !aux::reduce_is_small(a1, a2);
+    if (one_kernel) {
         aux::ReduceOneArgs ro;
         std::memset(&ro, 0, sizeof ro);
-        ro.slabs = RG->d_slabs; ro.slab = RG->slab_floats; ro.nblocks = a1.nblocks[slabset_group]; ro.nent = RG->nent;
-        ro.ent_theta = RG->d_ent_theta; ro.out = d_out; ro.lossraw = a2.lossraw; ro.P = (int)E.ntheta; ro.K = K;
-        for (size_t g = 0; g < E.groups.size(); ++g)
+        if (RG) { ro.slabs = RG->d_slabs; ro.slab = RG->slab_floats; ro.nblocks = a1.nblocks[slabset_group]; ro.nent = RG->nent; ro.ent_theta = RG->d_ent_theta; }
+        ro.out = d_out; ro.lossraw = a2.lossraw; ro.P = (int)E.ntheta; ro.K = K;       // (loss-only: nent = 0, only the K loss blocks run)
+        for (int g = 0; g < a2.ngroups; ++g)
             if (a1.active[g]) { ro.losspart[ro.nloss] = a1.losspart[g]; ro.nrows[ro.nloss] = a1.nblocks[g] * a1.nwpb[g]; ++ro.nloss; }
         aux::launch_reduce_one(ro, E.stream);
     } else {

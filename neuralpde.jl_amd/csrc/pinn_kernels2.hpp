@@ -959,19 +959,21 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
 // registers across both tile lists and are written once — no slab round trip between two chained launches, one ramp, one epilogue.
 // Terms [0, sub_terms0) / tiles [0, sub_tiles0) belong to S0, the rest to S1; a workgroup walks its S0 tiles, then its S1 tiles
 // (round-robin over the concatenated list, so the members' tile counts need not divide the grid). ----
-template <class S0, class S1, int ACTK>
+template <class S0, class S1, int ACTK, int MODE = MODE_FUSED>
 DEV void wave_main2m(const GroupArgs& ga, int blk, int nblocks, int w, float* lds) {
     static_assert(std::is_same<typename S0::Shape, typename S1::Shape>::value, "merged launches need members of one network shape and neuron split");
     static_assert(S0::SLAB == S1::SLAB && S0::PACKED == S1::PACKED, "merged launches share the slab and the packed weight image");
+    static_assert(MODE == MODE_FUSED || MODE == MODE_LOSS, "merged launches: the fused evaluation and the loss-only evaluation");
     const int wave = blk * S0::NW + w;
     Acc2<typename S0::Shape> ac;
-    acc2_init<S0>(ac, ga, blk, w, true);
+    acc2_init<S0>(ac, ga, blk, w, MODE == MODE_FUSED);
     for (int j = 0; j < ga.nterms; ++j) ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[j].term_id] = 0.0;
-    wave_tiles2<S0, MODE_FUSED, ACTK>(ga, blk, nblocks, w, lds, ac, 0, ga.sub_terms0, 0, ga.sub_tiles0);
+    wave_tiles2<S0, MODE, ACTK>(ga, blk, nblocks, w, lds, ac, 0, ga.sub_terms0, 0, ga.sub_tiles0);
     wg_barrier();                                                           // the members lay out the workgroup's LDS differently
-    wave_tiles2<S1, MODE_FUSED, ACTK>(ga, blk, nblocks, w, lds, ac, ga.sub_terms0, ga.nterms, ga.sub_tiles0, ga.ntiles);
+    wave_tiles2<S1, MODE, ACTK>(ga, blk, nblocks, w, lds, ac, ga.sub_terms0, ga.nterms, ga.sub_tiles0, ga.ntiles);
     if (ac.cur_term >= 0)
         ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[ac.cur_term].term_id] = wave_sum_dd(ac.lsum, veq(lane_id() >> 4, 0));
+    if (MODE != MODE_FUSED) return;
     wg_barrier();
     acc2_store<S0, (S0::PG > S1::PG ? S0::PG : S1::PG)>(ac, ga, blk, w, lds);
 }

@@ -941,7 +941,7 @@ static int plan_merge_groups(pinn_engine& E) {
             M.head = G.chain_to; M.tail = (int)g; M.pair = &p;
             M.max_blocks = std::min(E.ncu * p.WG_PER_CU, std::min(H.max_blocks, G.max_blocks));
             M.d_scratch = (float*)plat_malloc(sizeof(float) * (size_t)M.max_blocks * std::max(p.SCR, 1));
-            const size_t lp = sizeof(double) * (size_t)M.max_blocks * p.NW * E.terms.size();
+            const size_t lp = sizeof(double) * (size_t)E.ncu * std::max(p.WG_PER_CU, p.WG_FWD) * p.NW * E.terms.size();
             M.d_losspart = (double*)plat_malloc(lp);
             if (!M.d_scratch || !M.d_losspart) return fail("device allocation failed (merged launch buffers)");
             plat_memset(M.d_losspart, 0, lp, E.stream);

@@ -48,7 +48,8 @@ std::deque<SpecInfo>& registry();      // a deque: runtime-specialised kernels (
 struct PairInfo {
     SpecInfo a, b;
     int WG_PER_CU, NW, LDS_WG, SCR;      // of the merged kernel: min / common / max / max of the members
-    void (*launch)(const GroupArgs&, int blocks, plat_stream);
+    int WG_FWD;                          // resident workgroups per CU of the loss-only variant (min of the members)
+    void (*launch)(const GroupArgs&, int mode /* MODE_FUSED | MODE_LOSS */, int blocks, plat_stream);
     // ping-pong variant (wave_main2pp): 8-wave workgroups of two quartets, `blocks` = workgroups = half the virtual workgroups; nullptr: none
     void (*launch_pp)(const GroupArgs&, int blocks, plat_stream);
 };
@@ -142,7 +143,7 @@ void run_emu2(const GroupArgs& ga, int blocks) {
         for (int w = 0; w < S::NW; ++w) th[w].join();
     }
 }
-template <class S0, class S1, int ACTK>
+template <class S0, class S1, int ACTK, int MODE>
 void run_emu2m(const GroupArgs& ga, int blocks) {
     std::vector<float> lds((size_t)(S0::LDS_WG > S1::LDS_WG ? S0::LDS_WG : S1::LDS_WG));
     for (int b = 0; b < blocks; ++b) {
@@ -154,7 +155,7 @@ void run_emu2m(const GroupArgs& ga, int blocks) {
             th[w] = std::thread([&, w] {
                 wv::emu_barrier_hook = &EmuBarrier::wait;
                 wv::emu_barrier_ctx = &bar;
-                wave_main2m<S0, S1, ACTK>(ga, b, blocks, w, lds.data());
+                wave_main2m<S0, S1, ACTK, MODE>(ga, b, blocks, w, lds.data());
             });
         for (int w = 0; w < S0::NW; ++w) th[w].join();
     }
@@ -178,7 +179,7 @@ void run_emu2pp(const GroupArgs& ga, int blocks) {
     }
 }
 #define PINN_LAUNCH2(S, MODE, ACTK, ga, blocks, st) run_emu2<S, MODE, ACTK>(ga, blocks)
-#define PINN_LAUNCH2M(S0, S1, ACTK, ga, blocks, st) run_emu2m<S0, S1, ACTK>(ga, blocks)
+#define PINN_LAUNCH2M(S0, S1, ACTK, MODE, ga, blocks, st) run_emu2m<S0, S1, ACTK, MODE>(ga, blocks)
 #define PINN_LAUNCH2PP(S0, S1, ACTK, ga, blocks, st) run_emu2pp<S0, S1, ACTK>(ga, blocks)
 #define PINN_LAUNCH1(S, MODE, ACTK, ga, blocks, st) run_emu<S, MODE, ACTK>(ga, blocks)
 #else
@@ -205,12 +206,15 @@ template <class S0, class S1> struct Pair2 {
     static constexpr int LDS_WG = S0::LDS_WG > S1::LDS_WG ? S0::LDS_WG : S1::LDS_WG;
     static constexpr int SCR = S0::SCR > S1::SCR ? S0::SCR : S1::SCR;
     static constexpr int OCC = WG_PER_CU * S0::NW / 4;
+    static constexpr int WG_FWD = S0::WG_FWD < S1::WG_FWD ? S0::WG_FWD : S1::WG_FWD;
+    static constexpr int LDS_FWD = S0::LDS_FWD > S1::LDS_FWD ? S0::LDS_FWD : S1::LDS_FWD;
+    static constexpr int OCC_FWD = WG_FWD * S0::NW / 4;
 };
-template <class S0, class S1, int ACTK>
-__global__ void __launch_bounds__(64 * S0::NW, (Pair2<S0, S1>::OCC)) k_wave2m(const GroupArgs ga) {
-    __shared__ __attribute__((aligned(16))) float lds_all[Pair2<S0, S1>::LDS_WG];
+template <class S0, class S1, int ACTK, int MODE>
+__global__ void __launch_bounds__(64 * S0::NW, (mode_is_forward_only(MODE) ? Pair2<S0, S1>::OCC_FWD : Pair2<S0, S1>::OCC)) k_wave2m(const GroupArgs ga) {
+    __shared__ __attribute__((aligned(16))) float lds_all[mode_is_forward_only(MODE) ? Pair2<S0, S1>::LDS_FWD : Pair2<S0, S1>::LDS_WG];
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    wave_main2m<S0, S1, ACTK>(ga, (int)blockIdx.x, (int)gridDim.x, w, lds_all);
+    wave_main2m<S0, S1, ACTK, MODE>(ga, (int)blockIdx.x, (int)gridDim.x, w, lds_all);
 }
 // ping-pong variant: one 8-wave workgroup per CU (two wave quartets = two virtual workgroups of the merged launch), 2 waves per SIMD
 template <class S0, class S1, int ACTK>
@@ -221,7 +225,7 @@ __global__ void __launch_bounds__(512, 2) k_wave2pp(const GroupArgs ga) {
 }
 #define PINN_LAUNCH2PP(S0, S1, ACTK, ga, blocks, st) hipLaunchKernelGGL((k_wave2pp<S0, S1, ACTK>), dim3(blocks), dim3(512), 0, st, ga)
 #define PINN_LAUNCH2(S, MODE, ACTK, ga, blocks, st) hipLaunchKernelGGL((k_wave2<S, MODE, ACTK>), dim3(blocks), dim3(64 * S::NW), 0, st, ga)
-#define PINN_LAUNCH2M(S0, S1, ACTK, ga, blocks, st) hipLaunchKernelGGL((k_wave2m<S0, S1, ACTK>), dim3(blocks), dim3(64 * S0::NW), 0, st, ga)
+#define PINN_LAUNCH2M(S0, S1, ACTK, MODE, ga, blocks, st) hipLaunchKernelGGL((k_wave2m<S0, S1, ACTK, MODE>), dim3(blocks), dim3(64 * S0::NW), 0, st, ga)
 #define PINN_LAUNCH1(S, MODE, ACTK, ga, blocks, st) hipLaunchKernelGGL((k_wave<S, MODE, ACTK>), dim3(blocks), dim3(256), 0, st, ga)
 #endif
 
@@ -253,9 +257,13 @@ template <class S> void launch_spec2(const GroupArgs& ga, int mode, int blocks, 
 template <class S> void launch_spec(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
     if (ga.act == ACT_TANH) launch_modes1<S, ACT_TANH>(ga, mode, blocks, st); else launch_modes1<S, ACT_SIGMOID>(ga, mode, blocks, st);
 }
-template <class S0, class S1> void launch_pair2(const GroupArgs& ga, int blocks, plat_stream st) {
+template <class S0, class S1> void launch_pair2(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
     (void)st;
-    if (ga.act == ACT_TANH) PINN_LAUNCH2M(S0, S1, ACT_TANH, ga, blocks, st); else PINN_LAUNCH2M(S0, S1, ACT_SIGMOID, ga, blocks, st);
+    if (mode == MODE_LOSS) {
+        if (ga.act == ACT_TANH) PINN_LAUNCH2M(S0, S1, ACT_TANH, MODE_LOSS, ga, blocks, st); else PINN_LAUNCH2M(S0, S1, ACT_SIGMOID, MODE_LOSS, ga, blocks, st);
+    } else {
+        if (ga.act == ACT_TANH) PINN_LAUNCH2M(S0, S1, ACT_TANH, MODE_FUSED, ga, blocks, st); else PINN_LAUNCH2M(S0, S1, ACT_SIGMOID, MODE_FUSED, ga, blocks, st);
+    }
 }
 template <class S0, class S1> void launch_pair2pp(const GroupArgs& ga, int blocks, plat_stream st) {
     (void)st;
@@ -350,6 +358,7 @@ PairInfo make_pair_info() {
     p.NW = S0::NW;
     p.LDS_WG = S0::LDS_WG > S1::LDS_WG ? S0::LDS_WG : S1::LDS_WG;
     p.SCR = S0::SCR > S1::SCR ? S0::SCR : S1::SCR;
+    p.WG_FWD = S0::WG_FWD < S1::WG_FWD ? S0::WG_FWD : S1::WG_FWD;
     p.launch = &launch_pair2<S0, S1>;
     p.launch_pp = PairPP<S0, (PINN_F2_PP && S0::PP_OK && S1::PP_OK)>::template get<S0, S1>();
     return p;

@@ -885,7 +885,7 @@ def _loss_only_cases(npde):
     yield workloads.cfg5_heat_inverse(points=150, bcs_points=70, width=128, hidden=2)   # 8-wave workgroups, PDE parameter
 
 
-def test_loss_only_evaluation_returns_the_fused_losses(npde, use_emu):
+def test_loss_only_evaluation_returns_the_fused_losses(npde, use_emu, monkeypatch):
     """pinn_loss_grad(grad = NULL): MODE_LOSS kernels (forward + tape + sums of squares, no reverse sweep) — the per-point residuals are
     the fused kernel's bit for bit (same forward arithmetic) and their squares are summed in double, so the term losses agree to the
     order of the double-precision sums (the launches partition the points differently): 1e-13 relative, identical once rounded to
@@ -905,3 +905,11 @@ def test_loss_only_evaluation_returns_the_fused_losses(npde, use_emu):
             assert np.array_equal(l_only.astype(np.float32), l_full.astype(np.float32)), (wl.name, l_full, l_only)
         l_again, g_again = rep.engine.loss_grad(th, w)            # a loss-only evaluation leaves nothing behind
         assert np.array_equal(l_again, l_full) and np.array_equal(g_again, g_full)
+        monkeypatch.setenv("PINN_REDUCE_DIRECT_MAX", "0")         # the large-launch reductions (one kernel; PINN_NO_REDUCE_ONE: two stages)
+        for no_one in (False, True):
+            if no_one:
+                monkeypatch.setenv("PINN_NO_REDUCE_ONE", "1")
+            l_big, _ = rep.engine.loss_grad(th, w, want_grad=False)
+            np.testing.assert_allclose(l_big, l_full, rtol=1e-13, atol=0, err_msg=wl.name)
+        monkeypatch.delenv("PINN_NO_REDUCE_ONE")
+        monkeypatch.delenv("PINN_REDUCE_DIRECT_MAX")
