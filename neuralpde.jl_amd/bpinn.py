@@ -202,6 +202,9 @@ def ahmc_bayesian_pinn_pde(npde, pde_system, discretization, draw_samples=1000, 
     numensemble = int(draw_samples // 3) if numensemble is None else int(numensemble)
     # inference: the last `numensemble` draws on the saveats grid (one spacing per independent variable), per dependent variable
     doms = {str(d.variable): (float(d.domain.lo), float(d.domain.hi)) for d in pde_system.domain}
+    # the reference slices samples[(end - numensemble):end] — numensemble + 1 draws (ext/bpinn/PDE_BPINN.jl:254) — estimates the PDE
+    # parameters over all of them (:264-269) and builds the ensemble curves from the first numensemble of the slice (:302); restated as is
+    ens_samples = samples[-(numensemble + 1):]
     ens, ens_std, tps = [], [], []
     for i, name in enumerate(rep.depvars):
         ins = list(rep.dict_depvar_input[name])
@@ -216,8 +219,8 @@ def ahmc_bayesian_pinn_pde(npde, pde_system, discretization, draw_samples=1000, 
         mesh = np.meshgrid(*axes, indexing="ij")
         pts = np.stack([m.ravel() for m in mesh])
         preds = np.stack([rep.phi[i](pts, npde.depvar_params(rep, th, name))[0] if isinstance(rep.phi, (list, tuple)) else rep.phi(pts, th)[0]
-                          for th in samples[-numensemble:]])
+                          for th in ens_samples[:numensemble]])     # the reference predicts with the FIRST numensemble of its slice (:302)
         ens.append(preds.mean(axis=0)); ens_std.append(preds.std(axis=0)); tps.append(pts)
     sol = BPINNsolution(samples, ens, ens_std, tps, stats)
-    sol.estimated_de_params = [float(samples[-numensemble:, nn + j].mean()) for j in range(ninv)]
+    sol.estimated_de_params = [float(ens_samples[:, nn + j].mean()) for j in range(ninv)]
     return sol

@@ -532,7 +532,9 @@ int pinn_loglik_grad(pinn_handle h, const float* theta, int64_t p, const double*
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
     double ll = 0.0;
     for (int k = 0; k < K; ++k) {
-        const double N = (double)E.terms[k].n_norm, sse = E.hp_raw[k], sd = stds[k];          // (sharded sets: sse is this shard's part)
+        // sharded point sets (n < n_norm): every quantity returned here is THIS SHARD'S additive part — the constants count the shard's
+        // own points — so that loglik, grad_theta and grad_std summed over the ranks are the global values
+        const double N = (double)E.terms[k].n, sse = E.hp_raw[k], sd = stds[k];
         ll += -0.5 * N * std::log(2.0 * 3.14159265358979323846) - N * std::log(sd) - sse / (2.0 * sd * sd);
         if (grad_std) grad_std[k] = -N / sd + sse / (sd * sd * sd);
     }
@@ -861,22 +863,23 @@ int pinn_adam_init(pinn_handle h, const float* theta, int64_t p) {
     return 0;
 }
 
-// pinn_adam_steps through a hipGraph (PINN_GRAPH=1; see the note there).  Returns 0 when all nsteps ran, 1 when the graph could not be
-// built (nothing has run then; the caller takes the plain loop) — a failure INSIDE a step is reported through g_err as usual.
+// pinn_adam_steps through a hipGraph (PINN_GRAPH=1; see the note there).  Returns 0 when all nsteps ran; -1 when the device-side step
+// state could not be set up (NOTHING has run: the caller takes the plain loop); 1 when a step failed after the optimiser state may
+// already have advanced (g_err holds the reason: the caller reports the failure and does NOT run the steps again).
 static int adam_steps_graph(pinn_engine& E, int nsteps, float lr, float beta1, float beta2, float eps, const float* term_w) {
     const int K = (int)E.terms.size(), P = (int)E.ntheta;
     if (!E.d_step) {
         E.d_step = (int*)plat_malloc(sizeof(int));
         E.d_draws = (unsigned*)plat_malloc(sizeof(unsigned) * K);
         E.d_sampled = (int*)plat_malloc(sizeof(int) * K);
-        if (!E.d_step || !E.d_draws || !E.d_sampled) return 1;
+        if (!E.d_step || !E.d_draws || !E.d_sampled) return -1;
     }
     if (E.c12_cap < nsteps) {
         plat_sync(E.stream);
         plat_free(E.d_c12);
         E.d_c12 = (float*)plat_malloc(sizeof(float) * 2 * (size_t)nsteps);
         E.c12_cap = E.d_c12 ? nsteps : 0;
-        if (!E.d_c12) return 1;
+        if (!E.d_c12) return -1;
     }
     std::vector<float> c12(2 * (size_t)nsteps);
     for (int s = 0; s < nsteps; ++s) {
@@ -891,7 +894,7 @@ static int adam_steps_graph(pinn_engine& E, int nsteps, float lr, float beta1, f
     plat_h2d(E.d_draws, draws.data(), sizeof(unsigned) * K, E.stream);
     plat_h2d(E.d_sampled, sampled.data(), sizeof(int) * K, E.stream);
     plat_h2d(E.d_step, &zero, sizeof(int), E.stream);
-    if (plat_sync(E.stream)) return 1;                           // (the host vectors above are pageable)
+    if (plat_sync(E.stream)) return -1;                          // (the host vectors above are pageable)
     auto one_step = [&]() -> int {
         for (size_t t = 0; t < E.terms.size(); ++t) {
             Term& T = E.terms[t];
@@ -947,7 +950,9 @@ int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta
     // kernels per step) 69 vs 62 us per iteration, cfg2 401 vs 390 us: the loop is bound by the dependent kernels' own latencies, not by
     // host launch cost, and the graph's kernel nodes do not start any closer together than stream launches do.
     const bool want_graph = std::getenv("PINN_GRAPH") != nullptr;       // (read per call: the tests switch it)
-    if (want_graph && nsteps >= 8 && K <= 256 && adam_steps_graph(E, nsteps, lr, beta1, beta2, eps, term_w) == 0) {
+    const int graph_rc = (want_graph && nsteps >= 8 && K <= 256) ? adam_steps_graph(E, nsteps, lr, beta1, beta2, eps, term_w) : -1;
+    if (graph_rc > 0) return g_err.empty() ? fail("pinn_adam_steps: a step of the graph path failed") : 1;      // state may have advanced: no re-run
+    if (graph_rc == 0) {
         E.opt_t += nsteps;
         for (auto& T : E.terms) if (T.sampler != 0) T.draws += (unsigned)nsteps;
     } else {

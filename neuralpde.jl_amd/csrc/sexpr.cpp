@@ -38,9 +38,13 @@ struct Parser {
     const std::string& s;
     size_t i = 0;
     std::string err;
+    int depth = 0;
+    static constexpr int MAX_DEPTH = 200;            // nesting of the reference's expression trees is a few dozen at most
     explicit Parser(const std::string& src) : s(src) {}
     void skip() { while (i < s.size() && std::isspace((unsigned char)s[i])) ++i; }
     bool parse(Node& out) {
+        struct Guard { int& d; explicit Guard(int& x) : d(x) { ++d; } ~Guard() { --d; } } guard(depth);
+        if (depth > MAX_DEPTH) { err = "expression nested deeper than " + std::to_string(MAX_DEPTH) + " levels"; return false; }
         skip();
         if (i >= s.size()) { err = "unexpected end of expression"; return false; }
         if (s[i] == ')') { err = "unexpected ')'"; return false; }
@@ -71,23 +75,39 @@ struct Parser {
     }
 };
 
+// A decimal literal and nothing else: [+-] digits [. digits] [e|E|f [+-] digits] (Julia prints Float32 exponents with `f`).  strtod alone
+// would also take "inf", "nan", "infinity" and hex floats, i.e. silently fold a variable or parameter of such a name into a constant.
+static bool decimal_literal(const std::string& t, double& v) {
+    size_t i = 0, nd = 0;
+    if (i < t.size() && (t[i] == '+' || t[i] == '-')) ++i;
+    while (i < t.size() && std::isdigit((unsigned char)t[i])) { ++i; ++nd; }
+    if (i < t.size() && t[i] == '.') { ++i; while (i < t.size() && std::isdigit((unsigned char)t[i])) { ++i; ++nd; } }
+    if (nd == 0) return false;
+    std::string u = t;
+    if (i < t.size() && (t[i] == 'e' || t[i] == 'E' || t[i] == 'f')) {
+        u[i] = 'e';
+        ++i;
+        if (i < t.size() && (t[i] == '+' || t[i] == '-')) ++i;
+        size_t ne = 0;
+        while (i < t.size() && std::isdigit((unsigned char)t[i])) { ++i; ++ne; }
+        if (ne == 0) return false;
+    }
+    if (i != t.size()) return false;
+    char* e = nullptr;
+    v = std::strtod(u.c_str(), &e);
+    return e && *e == 0 && std::isfinite(v);
+}
 bool as_number(const Node& n, double& v) {
     if (!n.atom) return false;
     if (n.text == "pi" || n.text == "π") { v = 3.14159265358979323846; return true; }
     if (n.text == "ℯ") { v = 2.71828182845904523536; return true; }
-    const char* b = n.text.c_str();
-    char* e = nullptr;
-    v = std::strtod(b, &e);
-    if (e == b || *e != 0) {
-        // Julia rationals print as a//b
-        const size_t p = n.text.find("//");
-        if (p == std::string::npos) return false;
-        char *e1 = nullptr, *e2 = nullptr;
-        const std::string num = n.text.substr(0, p), den = n.text.substr(p + 2);
-        const double a = std::strtod(num.c_str(), &e1), d = std::strtod(den.c_str(), &e2);
-        if (*e1 != 0 || *e2 != 0 || num.empty() || den.empty() || d == 0.0) return false;
-        v = a / d;
-    }
+    if (decimal_literal(n.text, v)) return true;
+    // Julia rationals print as a//b
+    const size_t p = n.text.find("//");
+    if (p == std::string::npos) return false;
+    double a = 0.0, d = 0.0;
+    if (!decimal_literal(n.text.substr(0, p), a) || !decimal_literal(n.text.substr(p + 2), d) || d == 0.0) return false;
+    v = a / d;
     return true;
 }
 bool is_pi(const Node& n) { return n.atom && (n.text == "pi" || n.text == "π"); }
@@ -145,9 +165,11 @@ struct Lowering {
         const Node* cur = &n;
         while (!cur->atom && cur->text == "D") {
             if (cur->args.size() != 3 || !cur->args[0].atom || !cur->args[1].atom) return fail_("malformed (D variable order expr)");
-            const int ord = std::atoi(cur->args[1].text.c_str());
-            if (ord < 1) return fail_("derivative order must be a positive integer");
-            by.push_back({cur->args[0].text, ord});
+            char* oe = nullptr;
+            const long ord = std::strtol(cur->args[1].text.c_str(), &oe, 10);
+            if (cur->args[1].text.empty() || *oe != 0 || ord < 1 || ord > MAX_DERIV_ORDER)
+                return fail_("derivative order must be an integer 1.." + std::to_string(MAX_DERIV_ORDER) + ", got '" + cur->args[1].text + "'");
+            by.push_back({cur->args[0].text, (int)ord});
             cur = &cur->args[2];
         }
         const int net = cur->atom ? -1 : depvar_of(cur->text);

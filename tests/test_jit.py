@@ -66,9 +66,39 @@ def test_jit_failures_are_loud(npde, use_emu):
             "sysm, _ = tp.poisson2d(m)\n"
             "odd = m.Chain(m.Dense(2, 200, 'tanh'), m.Dense(200, 200, 'tanh'), m.Dense(200, 1))\n"
             "try:\n    m.symbolic_discretize(sysm, m.PhysicsInformedNN(odd, m.GridTraining(0.5)))\nexcept m.EngineError as e:\n    print('ENGINEERROR', e)\n"
-            % (root, os.path.join(root, "tests"), os.path.join(root, "oracle"), os.path.join(root, "tests", "emu", "libpinn_emu.so")))
+            % (root, os.path.join(root, "tests"), os.path.join(root, "oracle"), npde._lib.default_library().path))     # the library UNDER TEST
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PINN_NO_JIT="1"), capture_output=True, text=True, timeout=300)
     assert "ENGINEERROR" in r.stdout and "no compiled kernel" in r.stdout, r.stdout + r.stderr
+
+
+def test_jit_needs_no_source_tree(npde, use_emu, tmp_path):
+    """an installed library: no kernel source tree ($PINN_SRC_DIR points nowhere), a fresh cache directory — the kernel headers embedded in
+    the library are unpacked next to the cache and a shape outside the ahead-of-time table (3 hidden layers of 24, 1 input, third
+    derivative) is specialised, loaded and evaluated; the second process finds the object in the cache"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, sympy as sp\n"
+            "import pinn_import; m = pinn_import.load(); m._lib.set_library(m.Library(%r))\n"
+            "(x,) = m.parameters('x'); (u,) = m.variables('u')\n"
+            "eq = m.Eq((m.Differential(x) ** 3)(u(x)) + u(x), sp.cos(sp.pi * x))\n"
+            "sysm = m.PDESystem([eq], [m.Eq(u(0.0), 0.0)], [m.In(x, m.Interval(0.0, 1.0))], [x], [u(x)])\n"
+            "ch = m.Chain(m.Dense(1, 24, 'tanh'), m.Dense(24, 24, 'tanh'), m.Dense(24, 24, 'tanh'), m.Dense(24, 24, 'tanh'), m.Dense(24, 1))\n"
+            "th0 = np.sin(np.arange(ch.nparams) * 0.37) * 0.3\n"
+            "t0 = time.time(); rep = m.symbolic_discretize(sysm, m.PhysicsInformedNN(ch, m.GridTraining(0.1), init_params=th0)); dt = time.time() - t0\n"
+            "l, g = rep.engine.loss_grad(rep.flat_init_params)\n"
+            "print('JITOK', float(l[0]), float(np.abs(g).max()), 'create_s', round(dt, 2))\n"
+            % (root, os.path.join(root, "tests"), os.path.join(root, "oracle"), npde._lib.default_library().path))
+    env = dict(os.environ, PINN_JIT_DIR=str(tmp_path / "cache"), PINN_SRC_DIR=str(tmp_path / "nowhere"))
+    env.pop("PINN_NO_JIT", None)
+    outs = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        assert "JITOK" in r.stdout, r.stdout + r.stderr
+        outs.append(r.stdout.split("JITOK")[1].split())
+    assert outs[0][:2] == outs[1][:2]                                   # same numbers from the cached object
+    assert float(outs[1][3]) < float(outs[0][3]) or float(outs[1][3]) < 2.0, outs     # the second create does not compile
+    srcs = list((tmp_path / "cache").rglob("spec_registry.hpp"))
+    assert len(srcs) == 1 and (srcs[0].parent / ".complete").exists()
 
 
 def test_general_multi_index_derivatives(npde, use_emu):

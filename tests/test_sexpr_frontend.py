@@ -90,6 +90,18 @@ def test_julia_style_spellings_and_errors(npde, use_emu):
                      ("(+ (u x y) w)", "neither an independent variable"), ("(+ (u x y)", "missing '\\)'"), ("(sin x)", "does not contain a dependent variable")]:
         with pytest.raises(Exception, match=msg):
             _engine(npde, lhs, "0")
+    # numeric literals are decimal literals only: a symbol that strtod would read as a number ("inf", "nan", hex) stays a symbol, so a
+    # parameter of that name is a parameter and an unknown one is an error — never silently a constant; derivative orders are integers
+    a = resid("(+ (u x y) nan)", "0", params=("nan",))
+    b = resid("(+ (u x y) q)", "0", params=("q",))
+    np.testing.assert_array_equal(a, b)
+    assert np.all(np.isfinite(a))
+    np.testing.assert_allclose(resid("(+ (u x y) 1.5f0)", "2e-1"), resid("(+ (u x y) 1.3)", "0"), rtol=0, atol=1e-6)      # Julia Float32 spelling
+    for lhs, msg in [("(+ (u x y) inf)", "neither an independent variable"), ("(+ (u x y) 0x10)", "neither an independent variable"),
+                     ("(D x 2.5 (u x y))", "derivative order must be an integer"), ("(D x 1e1 (u x y))", "derivative order must be an integer"),
+                     ("(+ 1 " * 300 + "(u x y)" + ")" * 300, "nested deeper")]:
+        with pytest.raises(Exception, match=msg):
+            _engine(npde, lhs, "0")
 
 
 @pytest.mark.parametrize("cfg", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
