@@ -43,7 +43,7 @@ import NeuralPDE: AbstractTrainingStrategy, PINNRepresentation, GridTraining, St
 import QuasiMonteCarlo
 import Optimization
 
-export HIPStrategy, hip_discretize, descriptor, sexpr, HIPEngine, HIPEngineError
+export HIPStrategy, hip_discretize, descriptor, sexpr, HIPEngine, HIPEngineError, state_of
 
 # ------------------------------------------------------------------------------------------------
 # library + error convention (include/pinn_hip.h: every function returns 0 or sets pinn_last_error)
@@ -94,13 +94,17 @@ function set_points!(e::HIPEngine, k::Integer, pts::AbstractMatrix; n_norm::Inte
     return nothing
 end
 
-"`(term_losses::Vector{Float64}, grad::Vector{Float64})` of `Σ_k w[k] * mean(abs2, residual_k)` — one fused device evaluation."
+"""
+`(term_losses::Vector{Float64}, grad::Vector{Float64})` of `Σ_k w[k] * mean(abs2, residual_k)` — one fused device evaluation.
+`want_grad = false` is the engine's LOSS-ONLY evaluation (`grad = NULL` at the ABI: forward pass + residuals + sums of squares, no reverse
+sweep, about 2.6x cheaper): the same term losses, `grad` comes back empty.
+"""
 function loss_grad(e::HIPEngine, θ::AbstractVector{<:Real}, w::AbstractVector{<:Real}; want_grad::Bool = true)
     θ64 = Vector{Float64}(θ); w64 = Vector{Float64}(w)
     length(θ64) == e.P || throw(DimensionMismatch("θ has $(length(θ64)) entries, the engine expects $(e.P)"))
     length(w64) == e.K || throw(DimensionMismatch("need one weight per loss term ($(e.K))"))
     losses = zeros(Float64, e.K)
-    grad = zeros(Float64, e.P)
+    grad = zeros(Float64, want_grad ? e.P : 0)
     GC.@preserve θ64 w64 losses grad check(ccall(sym(:pinn_loss_grad_f64), Cint,
         (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
         e.h, θ64, e.P, w64, losses, want_grad ? pointer(grad) : Ptr{Float64}(C_NULL)), "pinn_loss_grad_f64")
@@ -318,9 +322,13 @@ mutable struct HIPState
     resample::Union{Nothing, Function}           # () -> Vector{Matrix}: fresh sets (resampling strategies), called once per new θ
     key::UInt64
     losses::Vector{Float64}
-    grad::Vector{Float64}                        # of Σ w_k L_k under `weights`
+    grad::Vector{Float64}                        # of Σ w_k L_k under `weights`; empty after a loss-only evaluation
     weights::Vector{Float64}
     tgrads::Union{Nothing, Matrix{Float32}}      # P × K per-term gradients (filled on the first per-term pullback at this θ)
+    eager_grad::Bool                             # true (hip_discretize): a plain call of a term closure already runs the fused loss + gradient
+                                                 # evaluation that the optimiser's `grad!` of the same iterate will ask for
+    lock::ReentrantLock                          # the closures of one discretisation share this state; BPINN calls them from
+                                                 # Threads.@threads (ext/bpinn/PDE_BPINN.jl:548)
 end
 
 function current_weights(st::HIPState)
@@ -332,21 +340,31 @@ function current_weights(st::HIPState)
     return w
 end
 
-function evaluate!(st::HIPState, θ)
+"""
+One device evaluation per (θ, weights), shared by every closure of the discretisation.  `want_grad = false`: only the term losses are
+needed (a callback, an adaptive-weight rule, a plain call of a term closure outside AD — the reference's closures are value-only unless
+differentiated, src/training_strategies.jl:215-221) — the engine's loss-only evaluation; a later request for the gradient at the same θ
+upgrades the memo with one fused evaluation.  Returns `(losses, grad, weights)` copied out under the lock.
+"""
+function evaluate!(st::HIPState, θ; want_grad::Bool = true)
     flat = collect(Float64, ComponentArrays.getdata(θ))
-    w = current_weights(st)
-    key = hash(flat, hash(w))
-    if key != st.key
-        if st.resample !== nothing                              # fresh sets on every new θ (src/training_strategies.jl:277-281, 375-381)
+    lock(st.lock) do
+        w = current_weights(st)
+        key = hash(flat, hash(w))
+        fresh = key != st.key
+        if fresh && st.resample !== nothing                         # fresh sets on every new θ (src/training_strategies.jl:277-281, 375-381)
             st.sets = st.resample()
             for (k, s) in enumerate(st.sets)
                 set_points!(st.engine, k, s)
             end
         end
-        st.losses, st.grad = loss_grad(st.engine, flat, w)
-        st.weights, st.key, st.tgrads = w, key, nothing
+        if fresh || (want_grad && isempty(st.grad))
+            st.losses, st.grad = loss_grad(st.engine, flat, w; want_grad = want_grad || st.eager_grad)
+            st.weights, st.key = w, key
+            fresh && (st.tgrads = nothing)
+        end
+        return (copy(st.losses), st.grad, st.weights)
     end
-    return st
 end
 
 "`θ -> mean(abs2, residual_k(set_k, θ))` (src/training_strategies.jl:220, 280, 380) served by the engine."
@@ -354,16 +372,20 @@ struct HIPTermLoss <: Function
     st::HIPState
     k::Int
 end
-(f::HIPTermLoss)(θ) = evaluate!(f.st, θ).losses[f.k]
+(f::HIPTermLoss)(θ) = evaluate!(f.st, θ; want_grad = false)[1][f.k]
 
 function ChainRulesCore.rrule(f::HIPTermLoss, θ)
-    st = evaluate!(f.st, θ)
-    y = st.losses[f.k]
+    st = f.st
+    y = evaluate!(st, θ; want_grad = false)[1][f.k]
+    flat = collect(Float64, ComponentArrays.getdata(θ))
     function term_pullback(ȳ)
-        if st.tgrads === nothing
-            _, st.tgrads = term_grads(st.engine, collect(Float64, ComponentArrays.getdata(θ)))
+        tg = lock(st.lock) do
+            if st.tgrads === nothing || st.key != hash(flat, hash(st.weights))
+                _, st.tgrads = term_grads(st.engine, flat)
+            end
+            Float64.(view(st.tgrads, :, f.k))
         end
-        g = Float64.(view(st.tgrads, :, f.k)) .* ChainRulesCore.unthunk(ȳ)
+        g = tg .* ChainRulesCore.unthunk(ȳ)
         return NoTangent(), θ isa ComponentArray ? ComponentArray(g, ComponentArrays.getaxes(θ)) : g
     end
     return y, term_pullback
@@ -402,15 +424,22 @@ function build_state(pinnrep::PINNRepresentation, inner)
         set_points!(engine, k, s)
     end
     n_pde = pinnrep.eqs isa AbstractArray ? length(pinnrep.eqs) : 1
-    return HIPState(engine, pinnrep, n_pde, sets, resample, UInt64(0), Float64[], Float64[], Float64[], nothing)
+    return HIPState(engine, pinnrep, n_pde, sets, resample, UInt64(0), Float64[], Float64[], Float64[], nothing, false, ReentrantLock())
 end
 
-const STATES = IdDict{Any, HIPState}()            # pinnrep -> state, so hip_discretize can reach the engine behind the closures
+# The state (and with it the engine and its HBM) lives exactly as long as the closures that `merge_strategy_with_loss_function` returns:
+# they end up in `pinnrep.loss_functions.pde_loss_functions` / `.bc_loss_functions` (src/discretize.jl:760-764), from where
+# `state_of` reads it back — no global table that would keep every engine of the session alive.
+function state_of(pinnrep::PINNRepresentation)
+    fs = vcat(collect(pinnrep.loss_functions.pde_loss_functions), collect(pinnrep.loss_functions.bc_loss_functions))
+    i = findfirst(f -> f isa HIPTermLoss, fs)
+    i === nothing && throw(HIPEngineError("this PINNRepresentation was not built with a HIPStrategy"))
+    return fs[i].st
+end
 
 function NeuralPDE.merge_strategy_with_loss_function(pinnrep::PINNRepresentation, strategy::HIPStrategy,
                                                     datafree_pde_loss_function, datafree_bc_loss_function)
     st = build_state(pinnrep, strategy.inner)
-    STATES[pinnrep] = st
     n_pde, n_bc = length(datafree_pde_loss_function), length(datafree_bc_loss_function)
     n_pde + n_bc == st.engine.K || throw(HIPEngineError("engine has $(st.engine.K) terms, the discretisation $(n_pde + n_bc)"))
     return [HIPTermLoss(st, k) for k in 1:n_pde], [HIPTermLoss(st, n_pde + j) for j in 1:n_bc]
@@ -431,16 +460,15 @@ function hip_discretize(pde_system, discretization::PhysicsInformedNN)
     strat = discretization.strategy isa HIPStrategy ? discretization.strategy : HIPStrategy(discretization.strategy)
     disc = discretization.strategy isa HIPStrategy ? discretization : rebuild(discretization, strat)
     pinnrep = SciMLBase.symbolic_discretize(pde_system, disc)
-    st = STATES[pinnrep]
+    st = state_of(pinnrep)
+    st.eager_grad = true                 # value and gradient of one iterate share ONE fused evaluation, whichever the optimiser asks for first
     full = pinnrep.loss_functions.full_loss_function
     function grad!(G, θ, p)
-        evaluate!(st, θ)
-        w = current_weights(st)
-        g = w == st.weights ? st.grad : last(loss_grad(st.engine, collect(Float64, ComponentArrays.getdata(θ)), w))
+        _, g, _ = evaluate!(st, θ; want_grad = true)      # memoised on (θ, current weights): the reweighting of this iterate has already run
         G .= g
         if pinnrep.additional_loss !== nothing
             wa = pinnrep.adaloss.additional_loss_weights[1]
-            ga = first(Optimization.Zygote.gradient(θ) do t
+            ga = first(NeuralPDE.Zygote.gradient(θ) do t      # (NeuralPDE imports Zygote, src/NeuralPDE.jl:36; Optimization.jl does not export it)
                 (t_, p_) = pinnrep.param_estim ? (t.depvar, t.p) : (t, nothing)
                 pinnrep.additional_loss(pinnrep.phi, t_, p_)
             end)
