@@ -60,13 +60,21 @@ int ensure_points(pinn_engine& E) {
     return 0;
 }
 
+// the weights every network's kernels read in this evaluation: the network's slice of theta itself where the kernels' image is theta's own
+// layout (NetPlan::direct; needs a 16-byte aligned address), otherwise the packed image rebuilt by k_pack
 void pack_all(pinn_engine& E, const float* d_theta = nullptr, bool packed_fresh = false) {
     const float* th = d_theta ? d_theta : E.d_theta;
-    for (size_t n = 0; n < E.nets.size() && !packed_fresh; ++n) {      // (fresh: the optimiser's update kernel already wrote the images)
+    for (size_t n = 0; n < E.nets.size(); ++n) {
         NetPlan& NP = E.netplans[n];
-        if (!NP.spec || NP.spec->family == 3) continue;          // DGM kernels read theta unpacked
-        aux::launch_pack(NP.d_packed, NP.d_pack_idx, th, NP.npacked, E.stream);
+        if (!NP.spec) continue;
+        if (NP.spec->family == 3) { NP.cur = th + E.nets[n].theta_off; continue; }          // DGM kernels read theta unpacked
+        const float* slice = th + E.nets[n].theta_off;
+        if (NP.direct && ((uintptr_t)slice & 15u) == 0) { NP.cur = slice; continue; }
+        NP.cur = NP.d_packed;
+        if (!packed_fresh || NP.direct)                            // (fresh: the optimiser's update kernel already wrote the images)
+            aux::launch_pack(NP.d_packed, NP.d_pack_idx, th, NP.npacked, E.stream);
     }
+    for (auto& G : E.groups) G.ga.packed = E.netplans[G.net].cur;
     aux::launch_params(E.d_params, th, E.d_defaults, E.np, E.ne, E.p_theta_off, E.stream);
 }
 
@@ -172,7 +180,6 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
         const int nent = (chained || loss_only) ? 0 : G.nent;
         G.ga.slabs = chained ? E.groups[G.chain_to].d_slabs : G.d_slabs;
         G.ga.chain = chained ? 1 : 0;
-        if (G.spec->family == 3) G.ga.packed = d_theta + E.nets[G.net].theta_off;      // DGM: weights straight from theta
         // a single-term evaluation (pinn_term_grads) of a fused group launches ONLY that term's tiles: the K per-term gradients then cost
         // about one full evaluation in total instead of K
         pk::GroupArgs ga_one;
@@ -626,7 +633,6 @@ int pinn_residual(pinn_handle h, int term, const float* theta, int64_t p, float*
     }
     Group& G = E.groups[T.group];
     pk::GroupArgs ga = G.ga;
-    if (G.spec->family == 3) ga.packed = E.d_theta + E.nets[G.net].theta_off;      // DGM: weights straight from theta
     ga.nterms = 1;
     ga.terms[0] = G.ga.terms[T.slot_in_group];
     ga.terms[0].tile0 = 0;
@@ -659,7 +665,7 @@ static int forward_jets(pinn_engine& E, int net, const pk::SpecInfo* sp, const f
     plat_h2d(E.d_phi_pts, pts, sizeof(float) * n * N.sizes[0], E.stream);
     pk::GroupArgs ga;
     std::memset(&ga, 0, sizeof ga);
-    ga.packed = E.netplans[net].d_packed;
+    ga.packed = E.netplans[net].cur;
     ga.params = E.d_params;
     ga.nterms = 1;
     ga.nterms_total = 1;
@@ -682,7 +688,6 @@ static int forward_jets(pinn_engine& E, int net, const pk::SpecInfo* sp, const f
             E.phi_scr_cap = E.d_phi_scr ? need : 0;
             if (!E.d_phi_scr) return fail("device allocation failed (phi scratch)");
         }
-        ga.packed = E.d_theta + N.theta_off;
         ga.scratch = E.d_phi_scr;
         ga.dgm_modes = N.sizes[1];
         ga.dgm_npad = ga.ntiles * 64;
@@ -1150,6 +1155,9 @@ int pinn_describe(pinn_handle h, char* buf, int64_t buflen) {
     if (!h || !buf || buflen <= 0) return fail("pinn_describe: bad argument");
     std::ostringstream os;
     os << "backend=" << plat_name() << " cus=" << h->ncu << " ntheta=" << h->ntheta << " terms=" << h->terms.size() << "\n";
+    for (size_t n = 0; n < h->netplans.size(); ++n)
+        if (h->netplans[n].spec && h->netplans[n].spec->family != 3)
+            os << "net " << n << " weights=" << (h->netplans[n].direct ? "theta itself (theta-order image, no pack kernel)" : "packed image (k_pack per evaluation)") << "\n";
     for (size_t g = 0; g < h->groups.size(); ++g) {
         const Group& G = h->groups[g];
         os << "group " << g << (G.kind == 1 ? (G.use_rec ? " [coupled fwd/gradin, records in HBM]" : " [coupled fwd/gradin]") : "") << " net=" << G.net << " kernel=" << spec_name(*G.spec) << " tiles=" << G.ga.ntiles << " blocks=" << G.blocks << " terms=";

@@ -158,6 +158,9 @@ struct NetPlan {
     const pk::SpecInfo* spec = nullptr;   // any spec with the right (HP,NHH,D): packed layout is shared
     float* d_packed = nullptr;
     int* d_pack_idx = nullptr;
+    bool direct = false;             // the kernels' weight image IS this network's slice of theta (family 2, theta-order layout, every hidden
+                                     // width equal to the padded width, 16-byte aligned offset): no pack kernel, no copy
+    const float* cur = nullptr;      // weights the kernels read in the current evaluation: theta + theta_off (direct) or d_packed
     std::vector<int> h_pack_idx;     // host copy (inverse map construction)
     int npacked = 0;
 };

@@ -69,6 +69,17 @@
 #ifndef PINN_F2_PP
 #define PINN_F2_PP 0
 #endif
+// weight image of the neuron-split kernels.  0 (product) = two pre-shuffled MFMA-fragment images per layer written by k_pack: one 16-byte
+// load per lane and fragment, every byte of a fetched line used by the wave that fetched it.  1 = theta's OWN layout with every width
+// padded to HP (per layer W[out + in HP], then the bias): a network whose hidden widths equal HP is read straight out of theta — no pack
+// kernel, no second copy of the weights; the transposed fragment is still one 16-byte load (W[16 mo + 4 g + rr][16 mi + c], rr
+// contiguous) but the forward A-operand fragment becomes four dword loads per lane (W[16 mo + c][16 mi + 4 g + rr]) that use half of every
+// 128-byte line they touch.  Measured in round 3 (profiles/r03_experiments.txt): the evaluation loses the 2.5 us pack kernel and its
+// launch, and the fused kernel gains 12 us at full size — 382.8 vs 376.9 us per evaluation on the bench workload (79.1 vs 81.7 us on
+// the 8,192-point share, where the fixed cost matters more).  Kept as a build option; the CPU test-suite exercises both layouts.
+#ifndef PINN_F2_NATURAL_W
+#define PINN_F2_NATURAL_W 0
+#endif
 #ifndef PINN_F2_GEMM_SITES
 #define PINN_F2_GEMM_SITES 7            // bit mask: 1 forward GEMM, 2 dA GEMM, 4 dW GEMM
 #endif
@@ -120,13 +131,29 @@ struct Spec2 {
     static constexpr int pair_a(int p) { return J::pair_a(p); }
     static constexpr int pair_b(int p) { return J::pair_b(p); }
     // packed parameter buffer (floats); fragment images are [layer][tile a][tile b][lane][4 k-steps]
+#if PINN_F2_NATURAL_W
+    // theta's layout of a Dense chain, widths padded to HP: [W1 (D x HP) | b1 | W2 (HP x HP, W[out + in HP]) | b2 | ... | W_out (HP) | b_out]
+    static constexpr bool NATURAL = true;
+    static constexpr int LSTR = HP_ * HP_ + HP_;
+    static constexpr int OFF_W1 = 0;
+    static constexpr int off_w(int hl) { return D_ * HP_ + HP_ + hl * LSTR; }                       // hidden -> hidden layer hl
+    static constexpr int off_b(int layer) { return layer == 0 ? D_ * HP_ : off_w(layer - 1) + HP_ * HP_; }   // bias of hidden layer `layer`
+    static constexpr int OFF_B = D_ * HP_;
+    static constexpr int OFF_WL = off_w(NHH_);
+    static constexpr int OFF_BL = OFF_WL + HP_;
+    static constexpr int OFF_WPK = off_w(0), OFF_WTPK = off_w(0);
+    static constexpr int PACKED = ((OFF_BL + 1 + 3) / 4) * 4;
+#else
+    static constexpr bool NATURAL = false;
     static constexpr int OFF_W1 = 0;
     static constexpr int OFF_B = OFF_W1 + D_ * HP_;
+    static constexpr int off_b(int layer) { return OFF_B + layer * HP_; }
     static constexpr int OFF_WL = OFF_B + LH * HP_;
     static constexpr int OFF_BL = OFF_WL + HP_;
     static constexpr int OFF_WPK = OFF_BL + 4;                       // [NHH][mo][mi][64][4]: W[16mo+(l&15)][16mi+4(l>>4)+rr]
     static constexpr int OFF_WTPK = OFF_WPK + NHH_ * HP_ * HP_;      // [NHH][mi][mo][64][4]: W[16mo+4(l>>4)+rr][16mi+(l&15)]
     static constexpr int PACKED = OFF_WTPK + NHH_ * HP_ * HP_;
+#endif
     // per-workgroup gradient slab: every entry is written by exactly one wave
     static constexpr int O_WBAR = 0;                                 // [NHH][to][ti][64][4]
     static constexpr int O_BH = NHH_ * HP_ * HP_;                    // [LH][HP]  natural neuron order
@@ -289,6 +316,25 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
     vdacc& lsum = ac.lsum;
     int& cur_term = ac.cur_term;
 
+    // weight fragments of this wave's neuron tile t: forward A operand of k-block mi, transposed A operand of output tile mo, bias
+    auto ld_wf = [&](int hl, int t, int mi) -> vfloat4 {
+#if PINN_F2_NATURAL_W
+        vfloat4 r;
+        PINN_UNROLL for (int rr = 0; rr < 4; ++rr) r[rr] = ub_load(PB, S::off_w(hl) + 16 * (w * MTW + t) + (16 * mi + rr) * HP, c + (g << 2) * HP);
+        return r;
+#else
+        return ub_load4(PB, S::OFF_WPK + ((hl * MT + w * MTW + t) * MT + mi) * 256, lane << 2);
+#endif
+    };
+    auto ld_wt = [&](int hl, int t, int mo) -> vfloat4 {
+#if PINN_F2_NATURAL_W
+        return ub_load4(PB, S::off_w(hl) + 16 * mo + 16 * (w * MTW + t) * HP, (g << 2) + c * HP);
+#else
+        return ub_load4(PB, S::OFF_WTPK + ((hl * MT + w * MTW + t) * MT + mo) * 256, lane << 2);
+#endif
+    };
+    auto ld_bias = [&](int layer, int t) -> vfloat4 { return ub_load4(PB, S::off_b(layer) + 16 * (w * MTW + t), g << 2); };
+
     vfloat4 wL[MTW];
     PINN_UNROLL for (int t = 0; t < MTW; ++t) wL[t] = ub_load4(PB, S::OFF_WL + 16 * (w * MTW + t), g << 2);
     const float bL = P[S::OFF_BL];
@@ -377,7 +423,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
         if (!RECIN) {
             PINN_UNROLL for (int t = 0; t < MTW; ++t) {                          // hidden layer 0: d -> HP on the VALU
                 const int n0 = 16 * (w * MTW + t);
-                vfloat4 b1 = ub_load4(PB, S::OFF_B + n0, g << 2);
+                vfloat4 b1 = ub_load4(PB, S::off_b(0) + n0, g << 2);
                 vfloat4 w1[D];
                 PINN_UNROLL for (int i = 0; i < D; ++i) w1[i] = ub_load4(PB, S::OFF_W1 + i * HP + n0, g << 2);
                 PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
@@ -399,15 +445,15 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 if (WPRE) {
                     PINN_UNROLL for (int mi = 0; mi < MT; ++mi)
                         PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                            wf[mi][t] = ub_load4(PB, S::OFF_WPK + ((hl * MT + w * MTW + t) * MT + mi) * 256, lane << 2);
-                    PINN_UNROLL for (int t = 0; t < MTW; ++t) bv[t] = ub_load4(PB, S::OFF_B + (hl + 1) * HP + 16 * (w * MTW + t), g << 2);
+                            wf[mi][t] = ld_wf(hl, t, mi);
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t) bv[t] = ld_bias(hl + 1, t);
                     sched_fence();
                 }
                 publish(Xin, A);
                 wg_barrier();                                                   // layer hl activations complete in Xin
                 STAMP(1)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t) {
-                    if (!WPRE) bv[t] = ub_load4(PB, S::OFF_B + (hl + 1) * HP + 16 * (w * MTW + t), g << 2);
+                    if (!WPRE) bv[t] = ld_bias(hl + 1, t);
                     PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
                         A[pg * C][t] = bv[t];
                         PINN_UNROLL for (int ch = 1; ch < C; ++ch) A[pg * C + ch][t] = vzero4();
@@ -417,7 +463,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 PINN_UNROLL for (int mi = 0; mi < MT; ++mi) {
                     if (!WPRE)
                         PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                            wf[0][t] = ub_load4(PB, S::OFF_WPK + ((hl * MT + w * MTW + t) * MT + mi) * 256, lane << 2);
+                            wf[0][t] = ld_wf(hl, t, mi);
                     vfloat4 b4[NG];                                          // all B fragments of this k-block first: their LDS latency overlaps
                     PINN_UNROLL for (int q = 0; q < NG; ++q) b4[q] = lds_load4(Xin, vint(((q * MT + mi) * 64) * 4) + (lane << 2));
                     PINN_UNROLL for (int q = 0; q < NG; ++q)
@@ -462,7 +508,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
             if (LH == 1) {
                 PINN_UNROLL for (int t = 0; t < MTW; ++t) {
                     const int n0 = 16 * (w * MTW + t);
-                    vfloat4 b1 = ub_load4(PB, S::OFF_B + n0, g << 2);
+                    vfloat4 b1 = ub_load4(PB, S::off_b(0) + n0, g << 2);
                     vfloat4 w1[D];
                     PINN_UNROLL for (int i = 0; i < D; ++i) w1[i] = ub_load4(PB, S::OFF_W1 + i * HP + n0, g << 2);
                     PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
@@ -680,7 +726,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
             if (hl == 0) {              // record of hidden layer 0: K = d, recomputed on the VALU
                 PINN_UNROLL for (int t = 0; t < MTW; ++t) {
                     const int n0 = 16 * (w * MTW + t);
-                    vfloat4 b1 = ub_load4(PB, S::OFF_B + n0, g << 2);
+                    vfloat4 b1 = ub_load4(PB, S::off_b(0) + n0, g << 2);
                     vfloat4 w1[D];
                     PINN_UNROLL for (int i = 0; i < D; ++i) w1[i] = ub_load4(PB, S::OFF_W1 + i * HP + n0, g << 2);
                     PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
@@ -742,7 +788,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
             if (WPRE) {
                 PINN_UNROLL for (int mo = 0; mo < MT; ++mo)
                     PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                        wt[mo][t] = ub_load4(PB, S::OFF_WTPK + ((hl * MT + w * MTW + t) * MT + mo) * 256, lane << 2);
+                        wt[mo][t] = ld_wt(hl, t, mo);
                 sched_fence();
             }
             vfloat4 Gn[NG][MTW];
@@ -856,7 +902,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
             PINN_UNROLL for (int mo = 0; mo < MT; ++mo) {
                 if (!WPRE)
                     PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                        wt[0][t] = ub_load4(PB, S::OFF_WTPK + ((hl * MT + w * MTW + t) * MT + mo) * 256, lane << 2);
+                        wt[0][t] = ld_wt(hl, t, mo);
                 PINN_UNROLL for (int q = 0; q < NG; ++q) {
                     vfloat4 b4 = lds_load4(X0, vint(((q * MT + mo) * 64) * 4) + (lane << 2));
                     PINN_UNROLL for (int t = 0; t < MTW; ++t)

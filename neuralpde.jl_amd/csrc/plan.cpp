@@ -552,11 +552,16 @@ static int plan_pack_maps(pinn_engine& E) {
         std::vector<int> idx(s.PACKED, -1);
         for (int i = 0; i < D; ++i)
             for (int nn = 0; nn < HP; ++nn) idx[s.OFF_W1 + i * HP + nn] = Widx(0, nn, i);
+        const int lstr = HP * HP + HP;                       // theta-order image (SpecInfo::NATURAL): W of hidden->hidden layer hl, then its bias
         for (int l = 0; l < LH; ++l)
-            for (int nn = 0; nn < HP; ++nn) idx[s.OFF_B + l * HP + nn] = bidx(l, nn);
+            for (int nn = 0; nn < HP; ++nn)
+                idx[s.NATURAL ? (l == 0 ? s.OFF_B : s.OFF_WPK + (l - 1) * lstr + HP * HP) + nn : s.OFF_B + l * HP + nn] = bidx(l, nn);
         for (int nn = 0; nn < HP; ++nn) idx[s.OFF_WL + nn] = Widx(LH, 0, nn);
         idx[s.OFF_BL] = bidx(LH, 0);
-        for (int hl = 0; hl < s.NHH && s.family == 2; ++hl)
+        for (int hl = 0; hl < s.NHH && s.family == 2 && s.NATURAL; ++hl)
+            for (int in = 0; in < HP; ++in)
+                for (int out = 0; out < HP; ++out) idx[s.OFF_WPK + hl * lstr + out + in * HP] = Widx(hl + 1, out, in);
+        for (int hl = 0; hl < s.NHH && s.family == 2 && !s.NATURAL; ++hl)
             for (int ta = 0; ta < MT; ++ta)
                 for (int tb = 0; tb < MT; ++tb)
                     for (int lane = 0; lane < 64; ++lane)
@@ -577,6 +582,10 @@ static int plan_pack_maps(pinn_engine& E) {
                             // transposed fragments: [mo=m1][rr][lane][mi=m2] = W[out=16mo+4g+rr][in=16mi+c]
                             idx[s.OFF_WTPK + hl * HP * HP + ((m1 * 4 + rr) * 64 + lane) * MT + m2] = Widx(hl + 1, 16 * m1 + 4 * g + rr, 16 * m2 + c);
                         }
+        // theta-order image of a network whose widths need no padding = the network's slice of theta itself
+        NP.direct = s.family == 2 && s.NATURAL && std::getenv("PINN_NO_DIRECT_WEIGHTS") == nullptr && N.theta_off % 4 == 0;
+        for (size_t j = 1; j + 1 < N.sizes.size(); ++j) NP.direct = NP.direct && N.sizes[j] == HP;
+        for (int q = 0; q < s.PACKED && NP.direct; ++q) NP.direct = idx[q] < 0 ? q >= s.OFF_BL + 1 : idx[q] == N.theta_off + q;
         NP.npacked = s.PACKED;
         NP.d_packed = (float*)plat_malloc(sizeof(float) * s.PACKED);
         NP.d_pack_idx = (int*)plat_malloc(sizeof(int) * s.PACKED);
@@ -592,7 +601,7 @@ static int plan_pack_maps(pinn_engine& E) {
         std::vector<std::vector<int>> inv((size_t)E.ntheta);
         for (size_t n = 0; n < E.nets.size(); ++n) {
             const NetPlan& NP = E.netplans[n];
-            if (!NP.spec || NP.spec->family == 3) continue;
+            if (!NP.spec || NP.spec->family == 3 || NP.direct) continue;      // (direct: the kernels read theta itself, nothing to scatter)
             if (NP.npacked >= (1 << 24)) { E.inv_ok = false; break; }
             for (int q = 0; q < NP.npacked; ++q)
                 if (NP.h_pack_idx[q] >= 0) inv[(size_t)NP.h_pack_idx[q]].push_back((int)((n << 24) | (unsigned)q));

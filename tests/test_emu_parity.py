@@ -831,6 +831,34 @@ def test_merged_launch_matches_chained_launches_and_oracle(npde, use_emu, monkey
     assert np.array_equal(l_again, l_m) and np.array_equal(g_again, g_m)
 
 
+def test_weights_read_straight_from_theta(npde, use_emu, monkeypatch):
+    """builds with -DPINN_F2_NATURAL_W=1 only (theta-order weight image, a measured-and-rejected option, csrc/pinn_kernels2.hpp; the whole
+    CPU suite and the GPU parity tests passed with it in round 3): neuron-split kernels whose hidden widths equal the padded width read their weights out of theta itself (no pack kernel, no
+    copy); PINN_NO_DIRECT_WEIGHTS=1 packs the same layout; a padded width (40 -> 64) always packs: same numbers"""
+    wl = _merge_cfg2(npde, 200, 70)
+    w = [1.0, 2.0, 0.5, 3.0, 1.5]
+    rep, _, sets, th = check(npde, wl.pde_system, wl.chains, wl.strategy, wl.theta, weights=w)
+    if "weights=theta itself" not in rep.engine.describe():
+        pytest.skip("this build uses the pre-shuffled fragment images (PINN_F2_NATURAL_W=0, the product default)")
+    l_d, g_d = rep.engine.loss_grad(th, w)
+    monkeypatch.setenv("PINN_NO_DIRECT_WEIGHTS", "1")              # (read when the engine is created)
+    rep2 = npde.symbolic_discretize(wl.pde_system, wl.discretization())
+    assert "weights=packed image" in rep2.engine.describe()
+    for k, sset in enumerate(sets):                                # the same point sets (the strategy draws a new design per discretisation)
+        rep2.engine.set_points(k, sset)
+    l_p, g_p = rep2.engine.loss_grad(th, w)
+    monkeypatch.delenv("PINN_NO_DIRECT_WEIGHTS")
+    assert np.array_equal(l_d, l_p) and np.array_equal(g_d, g_p)
+    # resident Adam (theta lives in the optimiser's device buffer: the kernels read THAT buffer) against the packed path
+    t1, h1 = rep.engine.adam(th, 5, 1e-3, w)
+    t2, h2 = rep2.engine.adam(th, 5, 1e-3, w)
+    assert np.array_equal(t1, t2) and np.array_equal(h1, h2)
+    from neuralpde_jl_amd import workloads
+    wl40 = workloads.cfg2_poisson2d(points=70, bcs_points=70, width=40, hidden=3)
+    rep3, _, _, _ = check(npde, wl40.pde_system, wl40.chains, wl40.strategy, wl40.theta)
+    assert "weights=packed image" in rep3.engine.describe()
+
+
 def test_ping_pong_merged_launch(npde, use_emu, monkeypatch):
     """PINN_PP=1: the merged launch as 8-wave workgroups of two wave quartets that run the tile body half a tile apart (GEMM supersteps of
     one beside element-wise supersteps of the other); odd / even tile counts, idle tile slots; against the oracle and the plain merged launch"""

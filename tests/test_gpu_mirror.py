@@ -37,7 +37,7 @@ def _cases():
 
 
 @pytest.mark.parametrize("mod,name,kw", _cases())
-def test_on_hardware(npde, hip_lib, monkeypatch, mod, name, kw):
+def test_on_hardware(npde, hip_lib, monkeypatch, tmp_path, mod, name, kw):
     monkeypatch.setattr(tp, "EXPECTED_BACKEND", "hip")
     assert npde._lib.default_library().backend == "hip", "the mirror must run on the product library"
     fn = getattr(mod, name)
@@ -49,6 +49,8 @@ def test_on_hardware(npde, hip_lib, monkeypatch, mod, name, kw):
             args[p] = None                      # the fixture only switches libraries; the default library is the HIP build here
         elif p == "monkeypatch":
             args[p] = monkeypatch
+        elif p == "tmp_path":
+            args[p] = tmp_path
         else:
             args[p] = kw[p]
     fn(**args)
