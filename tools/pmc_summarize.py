@@ -33,10 +33,10 @@ SPEC_RE = r"pk::Spec2?<(\d+), (\d+), (\d+), (\d+)u?, (\d+)(?:ull|ul|u)?, (\d+), 
 def spec_key(kernel_name):
     """k_wave2<Spec2<HP,NHH,D,D1MASK,PAIRS,NPAIR,PG,HI>,MODE,ACT> -> the name pinn_describe prints (plan.cpp: spec_name);
     k_wave2m<Spec2<..>,Spec2<..>,ACT> (merged launch, MODE_FUSED) -> "keyA+keyB" as bench.py builds it"""
-    m = re.search(r"k_wave2m<" + SPEC_RE + ", " + SPEC_RE + r", (\d+)>", kernel_name)
+    m = re.search(r"k_wave2m<" + SPEC_RE + ", " + SPEC_RE + r", (\d+)(?:, (\d+))?>", kernel_name)      # <S0, S1, ACT[, MODE]>
     if m:
         v = [int(m.group(i)) for i in range(1, 18)]
-        return _one_key(2, *v[0:8]) + "+" + _one_key(2, *v[8:16]), 0
+        return _one_key(2, *v[0:8]) + "+" + _one_key(2, *v[8:16]), int(m.group(18) or 0)
     m = re.search(r"k_wave(2?)<" + SPEC_RE + r", (\d+), (\d+)>", kernel_name)
     if not m:
         return None, None
