@@ -287,6 +287,56 @@ AUX_DEV void sample_sobol_body(int e, float* pts, int d, const float* lb, const 
 // sharded evaluations: the K per-term sums of squares cross the ranks as DOUBLES (their own all-reduce, grouped with the gradient's), so
 // that N > 1 delivers the same losses as N = 1 to double rounding; this writes them back into the float out vector [P .. P + K)
 AUX_DEV void sums_from_double_body(int k, float* out_sums, const double* raw) { out_sums[k] = (float)raw[k]; }
+// split-operand weight images of the neuron-split kernels (Spec2::BFX, v_mfma_f32_16x16x32_bf16): per hidden->hidden layer, neuron tile
+// `ta`, k-block `kb` of 32 and piece (hi / mid / lo) one 1 KB fragment [64 lanes][8 bf16]; lane (g, c), element j <-> the OTHER index
+// 16 (2 kb + (j >> 2)) + 4 g + (j & 3).  forward image: W[out = 16 ta + c][in = other]; transposed image: W[out = other][in = 16 ta + c].
+// One thread per 32-bit word (two bf16).  Widths below the padded width read zeros.
+struct PackBfArgs {
+    const float* theta;
+    unsigned* out_fwd;                   // packed + OFF_WB  (as 32-bit words)
+    unsigned* out_tr;                    // packed + OFF_WTB
+    int nhh, hp;                         // hidden->hidden layers, padded width
+    int woff[8], nout[8], nin[8];        // per hidden->hidden layer: theta offset of W (column-major: W[out + in nout]) and its real sizes
+};
+AUX_DEV unsigned bf16_rne(float x) {
+    unsigned u;
+    __builtin_memcpy(&u, &x, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+AUX_DEV float bf16_val(unsigned h) { const unsigned u = h << 16; float x; __builtin_memcpy(&x, &u, 4); return x; }
+AUX_DEV unsigned bf16_piece(float v, int piece) {
+    const unsigned h = bf16_rne(v);
+    if (piece == 0) return h;
+    const float r = v - bf16_val(h);
+    const unsigned m = bf16_rne(r);
+    if (piece == 1) return m;
+    return bf16_rne(r - bf16_val(m));
+}
+AUX_DEV void pack_bf16_body(int e, const PackBfArgs& a) {
+    const int mt = a.hp / 16, kbn = a.hp / 32;
+    const int total = a.nhh * mt * kbn * 3 * 256;        // words per image
+    if (e >= 2 * total) return;
+    const bool tr = e >= total;
+    int r = tr ? e - total : e;
+    const int j2 = r & 3; r >>= 2;
+    const int lane = r & 63; r >>= 6;
+    const int piece = r % 3; r /= 3;
+    const int kb = r % kbn; r /= kbn;
+    const int ta = r % mt; r /= mt;
+    const int hl = r;
+    const int g = lane >> 4, c = lane & 15;
+    unsigned word = 0;
+    for (int half = 0; half < 2; ++half) {
+        const int j = 2 * j2 + half;
+        const int other = 16 * (2 * kb + (j >> 2)) + 4 * g + (j & 3), mine = 16 * ta + c;
+        const int out = tr ? other : mine, in = tr ? mine : other;
+        const float v = (out < a.nout[hl] && in < a.nin[hl]) ? a.theta[a.woff[hl] + out + in * a.nout[hl]] : 0.f;
+        word |= bf16_piece(v, piece) << (16 * half);
+    }
+    (tr ? a.out_tr : a.out_fwd)[tr ? e - total : e] = word;
+}
 AUX_DEV void pack_body(int i, float* packed, const int* idx, const float* theta) {
     const int j = idx[i];
     packed[i] = (j >= 0) ? theta[j] : 0.f;
@@ -429,6 +479,10 @@ inline void launch_pack(float* packed, const int* idx, const float* theta, int n
 }
 inline void launch_params(float* params, const float* theta, const float* defaults, int np, int ne, int p_off, plat_stream) {
     for (int j = 0; j < np; ++j) params_body(j, params, theta, defaults, ne, p_off);
+}
+inline void launch_pack_bf16(const PackBfArgs& a, plat_stream) {
+    const int total = a.nhh * (a.hp / 16) * (a.hp / 32) * 3 * 256;
+    for (int e = 0; e < 2 * total; ++e) pack_bf16_body(e, a);
 }
 inline void launch_sums_from_double(float* out_sums, const double* raw, int K, plat_stream) {
     for (int k = 0; k < K; ++k) sums_from_double_body(k, out_sums, raw);
@@ -622,6 +676,11 @@ inline void launch_pack(float* packed, const int* idx, const float* theta, int n
 }
 inline void launch_params(float* params, const float* theta, const float* defaults, int np, int ne, int p_off, plat_stream st) {
     if (np > 0) hipLaunchKernelGGL(k_params, dim3(1), dim3(64), 0, st, params, theta, defaults, np, ne, p_off);
+}
+__global__ void k_pack_bf16(const PackBfArgs a) { pack_bf16_body((int)(blockIdx.x * blockDim.x + threadIdx.x), a); }
+inline void launch_pack_bf16(const PackBfArgs& a, plat_stream st) {
+    const int total = a.nhh * (a.hp / 16) * (a.hp / 32) * 3 * 256;
+    hipLaunchKernelGGL(k_pack_bf16, dim3((2 * total + 255) / 256), dim3(256), 0, st, a);
 }
 __global__ void k_sums_from_double(float* out_sums, const double* raw, int K) {
     const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);

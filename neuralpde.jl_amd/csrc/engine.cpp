@@ -73,6 +73,20 @@ void pack_all(pinn_engine& E, const float* d_theta = nullptr, bool packed_fresh 
         NP.cur = NP.d_packed;
         if (!packed_fresh || NP.direct)                            // (fresh: the optimiser's update kernel already wrote the images)
             aux::launch_pack(NP.d_packed, NP.d_pack_idx, th, NP.npacked, E.stream);
+        if (NP.spec->BFX) {                                        // split-operand GEMMs: the three bf16 pieces of every hidden->hidden weight
+            const Net& N = E.nets[n];
+            aux::PackBfArgs pa;
+            std::memset(&pa, 0, sizeof pa);
+            pa.theta = th; pa.out_fwd = (unsigned*)(NP.d_packed + NP.spec->OFF_WB); pa.out_tr = (unsigned*)(NP.d_packed + NP.spec->OFF_WTB);
+            pa.nhh = NP.spec->NHH; pa.hp = NP.spec->HP;
+            if (pa.nhh > 8) return;                                // (plan refuses such nets for this build)
+            int o = N.theta_off;
+            for (size_t j = 0; j + 1 < N.sizes.size(); ++j) {
+                if (j >= 1 && j <= (size_t)pa.nhh) { pa.woff[j - 1] = o; pa.nin[j - 1] = N.sizes[j]; pa.nout[j - 1] = N.sizes[j + 1]; }
+                o += N.sizes[j + 1] * N.sizes[j] + N.sizes[j + 1];
+            }
+            aux::launch_pack_bf16(pa, E.stream);
+        }
     }
     for (auto& G : E.groups) G.ga.packed = E.netplans[G.net].cur;
     aux::launch_params(E.d_params, th, E.d_defaults, E.np, E.ne, E.p_theta_off, E.stream);

@@ -80,6 +80,15 @@
 #ifndef PINN_F2_NATURAL_W
 #define PINN_F2_NATURAL_W 0
 #endif
+// SPLIT-OPERAND GEMMs on the bf16 matrix pipe (H = 64 kernels): an fp32 product from three bf16 pieces per operand,
+//     a b ~ ah bh + ah bm + am bh + ah bl + am bm + al bh      (a = ah + am + al to 24 bits; the dropped terms are below 2^-24 a b),
+// accumulated in fp32 by v_mfma_f32_16x16x32_bf16: 12 MFMAs of ~17 cycles for a 16x16 output tile over K = 64 instead of 16 fp32 MFMAs of
+// 32 cycles (2.56x measured, tools/micro/mfma_split_bench.hip).  1: the forward GEMMs and dA = W^T dZ (weights split once per evaluation by
+// k_pack_bf16, activations / dZ split by the publishing wave: 3 x 8-byte LDS stores instead of one 16-byte store); dW stays fp32.
+// 0: fp32 MFMAs everywhere.
+#ifndef PINN_F2_BF16X
+#define PINN_F2_BF16X 0
+#endif
 #ifndef PINN_F2_GEMM_SITES
 #define PINN_F2_GEMM_SITES 7            // bit mask: 1 forward GEMM, 2 dA GEMM, 4 dW GEMM
 #endif
@@ -142,7 +151,7 @@ struct Spec2 {
     static constexpr int OFF_WL = off_w(NHH_);
     static constexpr int OFF_BL = OFF_WL + HP_;
     static constexpr int OFF_WPK = off_w(0), OFF_WTPK = off_w(0);
-    static constexpr int PACKED = ((OFF_BL + 1 + 3) / 4) * 4;
+    static constexpr int PACKED0 = ((OFF_BL + 1 + 3) / 4) * 4;
 #else
     static constexpr bool NATURAL = false;
     static constexpr int OFF_W1 = 0;
@@ -152,8 +161,13 @@ struct Spec2 {
     static constexpr int OFF_BL = OFF_WL + HP_;
     static constexpr int OFF_WPK = OFF_BL + 4;                       // [NHH][mo][mi][64][4]: W[16mo+(l&15)][16mi+4(l>>4)+rr]
     static constexpr int OFF_WTPK = OFF_WPK + NHH_ * HP_ * HP_;      // [NHH][mi][mo][64][4]: W[16mo+4(l>>4)+rr][16mi+(l&15)]
-    static constexpr int PACKED = OFF_WTPK + NHH_ * HP_ * HP_;
+    static constexpr int PACKED0 = OFF_WTPK + NHH_ * HP_ * HP_;
 #endif
+    // split-operand images (k_pack_bf16): [NHH][out tile][k-block][piece][64 lanes][8 bf16] = 256 floats per fragment, forward then transposed
+    static constexpr int BF_LAYER = (HP_ / 16) * (HP_ / 32) * 3 * 256;
+    static constexpr int OFF_WB = PACKED0;
+    static constexpr int OFF_WTB = OFF_WB + NHH_ * BF_LAYER;
+    static constexpr int PACKED = (PINN_F2_BF16X >= 1 && HP_ == 64) ? OFF_WTB + NHH_ * BF_LAYER : PACKED0;      // (BFIMG, defined below)
     // per-workgroup gradient slab: every entry is written by exactly one wave
     static constexpr int O_WBAR = 0;                                 // [NHH][to][ti][64][4]
     static constexpr int O_BH = NHH_ * HP_ * HP_;                    // [LH][HP]  natural neuron order
@@ -168,16 +182,23 @@ struct Spec2 {
     static constexpr int REC = (LH - 1) * NG * MT * 256;
     // LDS (floats): X0 | X1 (activation / dZ exchange, A^T) | ZT (4 x private dZ^T) | output partials | coords
     static constexpr int XSZ = NG * MT * 256;
+    // split-operand GEMMs (PINN_F2_BF16X): the exchange buffers hold B operands as three bf16 pieces, [q][k-block of 32][piece][lane][8 bf16]
+    static constexpr int KB = MT / 2;                                // k-blocks of 32 per layer
+    static constexpr bool BFIMG = (PINN_F2_BF16X >= 1) && HP_ == 64;        // the weight image carries the bf16 pieces (every kernel of such a net)
+    // (NW = 4, one neuron tile per wave, weight fragments prefetched; the bigger exchange buffers must leave the un-chunked dW staging in place)
+    static constexpr bool BFX = BFIMG && (2 * NG * KB * 3 * 256 + NG * MT * 256 + (((NW + 1) * NG * 16 + 63) / 64) * 64) * 4 <= 160 * 1024;
+    static constexpr int XSZB = BFX ? NG * KB * 3 * 256 : XSZ;       // floats of one exchange buffer
     static constexpr int LDS_UP = (((NW + 1) * NG * 16 + 63) / 64) * 64;    // NW x output partials + seed broadcast (UB)
     static_assert(PG_ >= 1 && PG_ <= 4, "one tape wave per point group");
     // when X0 | X1 | ZT would not fit in 160 KiB (H = 128 with 8 jet channels) the dW operands are staged one column group
     // at a time in a double buffer carved out of X1: [A^T chunk 16 x HP | 4 x dZ^T chunk]
-    static constexpr bool CHUNKED = (3 * XSZ + LDS_UP) * 4 > 160 * 1024;
+    static constexpr bool CHUNKED = (2 * XSZB + XSZ + LDS_UP) * 4 > 160 * 1024;
     static constexpr int CH_AT = 16 * HP_;
     static constexpr int CH_ZT = MTW * 256;
     static constexpr int CHSZ = CH_AT + NW * CH_ZT;
     static_assert(!CHUNKED || 2 * CHSZ <= XSZ, "chunk double buffer must fit inside X1");
-    static constexpr int LDS_BASE = (CHUNKED ? 2 : 3) * XSZ + LDS_UP;
+    static constexpr int OFF_X1 = XSZB, OFF_ZT = 2 * XSZB, OFF_UP = 2 * XSZB + (CHUNKED ? 0 : XSZ);      // LDS offsets (floats)
+    static constexpr int LDS_BASE = OFF_UP + LDS_UP;
     // PINN_F2_OCC=3 (experiment): three workgroups per CU where the LDS allows it — the kernel is then compiled for <= 168 VGPRs
     static constexpr int WG_PER_CU = (NW == 8) ? 1 : ((PINN_F2_OCC >= 3 && (!PINN_F2_OCC3_C1 || J::C == 1) && LDS_BASE * 4 <= 53 * 1024) ? 3 : ((LDS_BASE * 4 <= 80 * 1024) ? 2 : 1));
     // the records of the stored hidden layers stay in LDS instead of the per-workgroup scratch slab in global memory — as many
@@ -193,7 +214,7 @@ struct Spec2 {
     // FORWARD-ONLY launches (MODE_FWD / FWDREC / RESID / LOSS: no reverse sweep) use the two exchange buffers and the output partials
     // only and a fraction of the registers: they are compiled for up to four waves per SIMD (the loss-only evaluation, pinn_phi,
     // pinn_residual, the forward launches of coupled equations)
-    static constexpr int LDS_FWD = 2 * XSZ + LDS_UP;
+    static constexpr int LDS_FWD = 2 * XSZB + LDS_UP;
     static constexpr int WG_FWD_LDS = (160 * 1024 - 1024) / (LDS_FWD * 4);
     static constexpr int WG_FWD = (WG_FWD_LDS * NW >= 16) ? 16 / NW : (WG_FWD_LDS < 1 ? 1 : WG_FWD_LDS);
     static constexpr int OCC_FWD = WG_FWD * NW / 4;
@@ -210,7 +231,7 @@ struct Spec2 {
     static constexpr int PP_STEPS = 6 * NHH_ + 2;
     static constexpr int PP_LAG = ((PP_STEPS / 2) & 1) ? PP_STEPS / 2 : PP_STEPS / 2 - 1;
     static constexpr bool PP_OK = (NW == 4) && (MT * MTW * 4 <= 16) && WBAR_REG && NHH_ >= 1 && ((3 * NG * MT * 256 + LDS_UP) * 4 <= 160 * 1024) &&
-                                  (2 * LDS_WG * 4 <= 160 * 1024);
+                                  (2 * LDS_WG * 4 <= 160 * 1024) && !BFX;
 };
 
 // ---- persistent gradient accumulators of this wave's neuron tiles: zero, or (chained launch group) the sums an earlier launch group of
@@ -299,9 +320,9 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
     const ubuf PB = ub_make(P, S::PACKED);
     const ubuf SB = ub_make(ga.scratch + (size_t)blk * (ga.scr_stride ? ga.scr_stride : S::SCR), S::SCR);
     float* X0 = lds;
-    float* X1 = lds + S::XSZ;
-    float* ZT = lds + 2 * S::XSZ + w * (NG * MTW * 256);      // wave-private dZ^T: [q][t][16 columns][16 neurons]
-    float* UP = lds + (BWD ? (S::CHUNKED ? 2 : 3) : 2) * S::XSZ;      // output-layer partial sums [wave][q][16] (forward-only launches: LDS_FWD)
+    float* X1 = lds + S::OFF_X1;
+    float* ZT = lds + S::OFF_ZT + w * (NG * MTW * 256);       // wave-private dZ^T: [q][t][16 columns][16 neurons]
+    float* UP = lds + (BWD ? S::OFF_UP : S::OFF_ZT);          // output-layer partial sums [wave][q][16] (forward-only launches: LDS_FWD)
     float* RL = lds + S::LDS_BASE;                            // LDS-resident record slices [(LH-2-layer)*NG + q][tile][lane][4]
     auto rec_in_lds = [](int layer, int q) { return layer >= 1 && layer <= LH - 2 && (LH - 2 - layer) * NG + q < S::NRQ; };   // (same-kernel records only)
     auto rl_off = [&](int layer, int q, int t) { return vint((((LH - 2 - layer) * NG + q) * MT + w * MTW + t) * 256) + (lane << 2); };
@@ -406,10 +427,35 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 }
         };
         // publish this wave's tiles of a [NG][MT] tensor in B-fragment order: X[q][tile][lane][4]
+        // split-operand GEMMs (S::BFX): three bf16 pieces per value in the operand order of the 16x16x32 MFMA, X[q][k-block][piece][lane][8]:
+        // k = 8 g + j of a k-block <-> neuron tile 2 kb + (j >> 2), row 4 g + (j & 3) — a lane's own four rows fill its half of the slot
         auto publish = [&](float* X, const vfloat4 (&A)[NG][MTW]) {
+            if (S::BFX) {
+                PINN_UNROLL for (int q = 0; q < NG; ++q)
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t) {
+                        const int tile = w * MTW + t;
+                        vbf4 ph, pm, pl;
+                        split3_bf16(A[q][t], ph, pm, pl);
+                        const vint at = vint(((q * S::KB + (tile >> 1)) * 3) * 256 + (tile & 1) * 2) + (lane << 2);
+                        lds_store_bf4(X, at, ph);
+                        lds_store_bf4(X, at + vint(256), pm);
+                        lds_store_bf4(X, at + vint(512), pl);
+                    }
+                return;
+            }
             PINN_UNROLL for (int q = 0; q < NG; ++q)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t)
                     lds_store4(X, vint(((q * MT + w * MTW + t) * 64) * 4) + (lane << 2), A[q][t]);
+        };
+        // six bf16 MFMAs = one fp32-accurate 16x16 (x) 16x32 product (see PINN_F2_BF16X)
+        auto mfma_split = [&](const vbf8 (&a)[3], const vbf8 (&b)[3], vfloat4 c) -> vfloat4 {
+            c = mfma16x32bf(a[0], b[0], c);
+            c = mfma16x32bf(a[0], b[1], c);
+            c = mfma16x32bf(a[1], b[0], c);
+            c = mfma16x32bf(a[0], b[2], c);
+            c = mfma16x32bf(a[1], b[1], c);
+            c = mfma16x32bf(a[2], b[0], c);
+            return c;
         };
 
         // =========================== forward ===========================
@@ -442,7 +488,15 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 // this wave's weight fragments + bias of the layer: issued before the exchange so that their L2 latency hides
                 // under publish + barrier instead of stalling the first MFMA of every k-block
                 vfloat4 wf[WPRE ? MT : 1][MTW], bv[MTW];
-                if (WPRE) {
+                vbf8 wb[S::BFX ? S::KB : 1][S::BFX ? MTW : 1][3];
+                if (S::BFX) {
+                    PINN_UNROLL for (int kb = 0; kb < S::KB; ++kb)
+                        PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                            PINN_UNROLL for (int sp = 0; sp < 3; ++sp)
+                                wb[kb][t][sp] = ub_load_bf8(PB, S::OFF_WB + (((hl * MT + w * MTW + t) * S::KB + kb) * 3 + sp) * 256, lane << 2);
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t) bv[t] = ld_bias(hl + 1, t);
+                    sched_fence();
+                } else if (WPRE) {
                     PINN_UNROLL for (int mi = 0; mi < MT; ++mi)
                         PINN_UNROLL for (int t = 0; t < MTW; ++t)
                             wf[mi][t] = ld_wf(hl, t, mi);
@@ -460,7 +514,16 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                     }
                 }
                 wave_prio_gemm(gemm_hi);
-                PINN_UNROLL for (int mi = 0; mi < MT; ++mi) {
+                if (S::BFX) {
+                    PINN_UNROLL for (int kb = 0; kb < S::KB; ++kb)
+                        PINN_UNROLL for (int q = 0; q < NG; ++q) {
+                            vbf8 bb[3];
+                            PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[sp] = lds_load_bf8(Xin, vint(((q * S::KB + kb) * 3 + sp) * 256) + (lane << 2));
+                            PINN_UNROLL for (int t = 0; t < MTW; ++t) A[q][t] = mfma_split(wb[kb][t], bb, A[q][t]);
+                        }
+                    if (PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 1)) sched_gemm_prefetch<S::KB * NG, MTW * 6, PINN_F2_GEMM_AHEAD, 3>();
+                }
+                PINN_UNROLL for (int mi = 0; mi < (S::BFX ? 0 : MT); ++mi) {
                     if (!WPRE)
                         PINN_UNROLL for (int t = 0; t < MTW; ++t)
                             wf[0][t] = ld_wf(hl, t, mi);
@@ -470,7 +533,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                         PINN_UNROLL for (int t = 0; t < MTW; ++t)
                             PINN_UNROLL for (int rr = 0; rr < 4; ++rr) A[q][t] = mfma16(wf[WPRE ? mi : 0][t][rr], b4[q][rr], A[q][t]);
                 }
-                if (WPRE && PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 1)) sched_gemm_prefetch<MT * NG, MTW * 4, PINN_F2_GEMM_AHEAD>();
+                if (!S::BFX && WPRE && PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 1)) sched_gemm_prefetch<MT * NG, MTW * 4, PINN_F2_GEMM_AHEAD>();
                 wave_prio(1);
                 STAMP(2)
                 if (PP) wg_barrier();                                           // superstep boundary: GEMM | element-wise
@@ -785,7 +848,14 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
             };
             // W^T fragments for dA: issued ahead of the dW GEMM, which hides their latency
             vfloat4 wt[WPRE ? MT : 1][MTW];
-            if (WPRE) {
+            vbf8 wtb[S::BFX ? S::KB : 1][S::BFX ? MTW : 1][3];      // split-operand W^T fragments: [k-block of 32 output neurons][own input tile][piece]
+            if (S::BFX) {
+                PINN_UNROLL for (int kb = 0; kb < S::KB; ++kb)
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                        PINN_UNROLL for (int sp = 0; sp < 3; ++sp)
+                            wtb[kb][t][sp] = ub_load_bf8(PB, S::OFF_WTB + (((hl * MT + w * MTW + t) * S::KB + kb) * 3 + sp) * 256, lane << 2);
+                sched_fence();
+            } else if (WPRE) {
                 PINN_UNROLL for (int mo = 0; mo < MT; ++mo)
                     PINN_UNROLL for (int t = 0; t < MTW; ++t)
                         wt[mo][t] = ld_wt(hl, t, mo);
@@ -843,14 +913,22 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 if (SPRE && hl - 1 >= 1) load_record(hl - 1);
                 wave_prio_gemm(gemm_hi);
                 PINN_UNROLL for (int q = 0; q < NG; ++q) {
-                    PINN_UNROLL for (int mo = 0; mo < MT; ++mo) {
-                        vfloat4 b4 = lds_load4(X0, vint(((q * MT + mo) * 64) * 4) + (lane << 2));
-                        PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                            PINN_UNROLL for (int rr = 0; rr < 4; ++rr) Gn[q][t] = mfma16(wt[mo][t][rr], b4[rr], Gn[q][t]);
+                    if (S::BFX) {
+                        PINN_UNROLL for (int kb = 0; kb < S::KB; ++kb) {
+                            vbf8 bb[3];
+                            PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[sp] = lds_load_bf8(X0, vint(((q * S::KB + kb) * 3 + sp) * 256) + (lane << 2));
+                            PINN_UNROLL for (int t = 0; t < MTW; ++t) Gn[q][t] = mfma_split(wtb[kb][t], bb, Gn[q][t]);
+                        }
+                    } else {
+                        PINN_UNROLL for (int mo = 0; mo < MT; ++mo) {
+                            vfloat4 b4 = lds_load4(X0, vint(((q * MT + mo) * 64) * 4) + (lane << 2));
+                            PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                                PINN_UNROLL for (int rr = 0; rr < 4; ++rr) Gn[q][t] = mfma16(wt[mo][t][rr], b4[rr], Gn[q][t]);
+                        }
                     }
                     stage_q(q, ZT + q * (MTW * 256), X1 + q * 16 * HP);
                 }
-                if (PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 2)) sched_gemm_prefetch<MT * NG, MTW * 4, PINN_F2_GEMM_AHEAD>();
+                if (!S::BFX && PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 2)) sched_gemm_prefetch<MT * NG, MTW * 4, PINN_F2_GEMM_AHEAD>();
                 wave_prio(1);
                 STAMP(10)
                 wg_barrier();                                               // staged operands complete; X0 free again
@@ -941,7 +1019,7 @@ DEV void acc2_store(Acc2<typename S::Shape>& ac, const GroupArgs& ga, int blk, i
     const vint g = lane >> 4;
     const vint c = lane & vint(15);
     float* slab = ga.slabs + (size_t)blk * S::SLAB;
-    float* UP = lds + (S::CHUNKED ? 2 : 3) * S::XSZ;
+    float* UP = lds + S::OFF_UP;
     if (S::WBAR_REG)
         PINN_UNROLL for (int hl = 0; hl < NHH; ++hl)
             PINN_UNROLL for (int t = 0; t < MTW; ++t)

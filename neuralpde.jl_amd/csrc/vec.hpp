@@ -149,6 +149,54 @@ inline vfloat4 mfma16(const vfloat& a, const vfloat& b, const vfloat4& c) {
     return d;
 }
 inline vfloat4 vzero4() { vfloat4 z; for (int k = 0; k < 4; ++k) z.x[k] = vfloat(0.f); return z; }
+// ---- bf16 operands of v_mfma_f32_16x16x32_bf16 (split-operand GEMMs, pinn_kernels2.hpp PINN_F2_BF16X) ----
+// bf16 = the upper 16 bits of an fp32, conversion rounds to nearest even (v_cvt_pk_bf16_f32).
+inline uint16_t bf16_bits(float x) {
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);      // NaN stays NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf16_float(uint16_t h) { const uint32_t u = (uint32_t)h << 16; float x; std::memcpy(&x, &u, 4); return x; }
+struct vbf4 { uint16_t v[4][W]; };      // 4 bf16 per lane (8 bytes)
+struct vbf8 { uint16_t v[8][W]; };      // 8 bf16 per lane (16 bytes): one A or B operand of the 16x16x32 MFMA
+// x = hi + mid + lo to 24 significant bits: three bf16 pieces of every element (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid))
+inline void split3_bf16(const vfloat4& x, vbf4& h, vbf4& m, vbf4& l) {
+    for (int k = 0; k < 4; ++k)
+        for (int q = 0; q < W; ++q) {
+            const float v = x.x[k].v[q];
+            const uint16_t hb = bf16_bits(v);
+            const float r = v - bf16_float(hb);
+            const uint16_t mb = bf16_bits(r);
+            const float r2 = r - bf16_float(mb);
+            h.v[k][q] = hb; m.v[k][q] = mb; l.v[k][q] = bf16_bits(r2);
+        }
+}
+// 8-byte LDS store / 16-byte LDS and buffer loads of bf16 operands; indices in FLOATS like every other accessor here
+inline void lds_store_bf4(float* p, const vint& i, const vbf4& x) {
+    for (int q = 0; q < W; ++q) { uint16_t t[4] = {x.v[0][q], x.v[1][q], x.v[2][q], x.v[3][q]}; std::memcpy(p + i.v[q], t, 8); }
+}
+inline vbf8 lds_load_bf8(const float* p, const vint& i) {
+    vbf8 r;
+    for (int q = 0; q < W; ++q) { uint16_t t[8]; std::memcpy(t, p + i.v[q], 16); for (int k = 0; k < 8; ++k) r.v[k][q] = t[k]; }
+    return r;
+}
+inline vbf8 ub_load_bf8(const ubuf& b, int soff, const vint& voff) { vint i; for (int q = 0; q < W; ++q) i.v[q] = soff + voff.v[q]; return lds_load_bf8(b.p, i); }
+// v_mfma_f32_16x16x32_bf16: D[i][j] += sum_{k < 32} A[i][k] B[k][j]; lane l supplies A[i = l & 15][k = 8 (l >> 4) + e] and
+// B[k = 8 (l >> 4) + e][j = l & 15], e = 0..7; D as for the 16x16x4 form.  fp32 accumulation, k-ordered here (the hardware's internal
+// order differs in the last bits).
+inline vfloat4 mfma16x32bf(const vbf8& a, const vbf8& b, const vfloat4& c) {
+    vfloat4 d;
+    for (int l = 0; l < W; ++l)
+        for (int r = 0; r < 4; ++r) {
+            const int row = (l >> 4) * 4 + r, col = l & 15;
+            float acc = c.x[r].v[l];
+            for (int k = 0; k < 32; ++k) acc = std::fmaf(bf16_float(a.v[k & 7][(k >> 3) * 16 + row]), bf16_float(b.v[k & 7][(k >> 3) * 16 + col]), acc);
+            d.x[r].v[l] = acc;
+        }
+    return d;
+}
 }  // namespace wv
 #else
 // ------------------------------------------------------------------------------------------
@@ -377,5 +425,23 @@ DEV double wave_sum_dd(vdacc a, vbool m) {
 }
 DEV vfloat4 mfma16(vfloat a, vfloat b, vfloat4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 DEV vfloat4 vzero4() { return vfloat4{0.f, 0.f, 0.f, 0.f}; }
+// ---- bf16 operands of v_mfma_f32_16x16x32_bf16 (see the emulation section) ----
+typedef __bf16 vbf4 __attribute__((ext_vector_type(4)));
+typedef __bf16 vbf8 __attribute__((ext_vector_type(8)));
+DEV void split3_bf16(vfloat4 x, vbf4& h, vbf4& m, vbf4& l) {
+    PINN_UNROLL for (int k = 0; k < 4; ++k) {
+        const __bf16 hb = (__bf16)x[k];                       // v_cvt_pk_bf16_f32: round to nearest even
+        const float r = x[k] - (float)hb;
+        const __bf16 mb = (__bf16)r;
+        const float r2 = r - (float)mb;
+        h[k] = hb; m[k] = mb; l[k] = (__bf16)r2;
+    }
+}
+DEV void lds_store_bf4(float* p, vint i, vbf4 x) { *reinterpret_cast<vbf4*>(p + i) = x; }
+DEV vbf8 lds_load_bf8(const float* p, vint i) { return *reinterpret_cast<const vbf8*>(p + i); }
+DEV vbf8 ub_load_bf8(ubuf b, int soff, vint voff) {
+    return __builtin_bit_cast(vbf8, __builtin_amdgcn_raw_buffer_load_b128(b.r, voff * 4, soff * 4, 0));
+}
+DEV vfloat4 mfma16x32bf(vbf8 a, vbf8 b, vfloat4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 }  // namespace wv
 #endif
