@@ -291,12 +291,14 @@ AUX_DEV void sums_from_double_body(int k, float* out_sums, const double* raw) { 
 // `ta`, k-block `kb` of 32 and piece (hi / mid / lo) one 1 KB fragment [64 lanes][8 bf16]; lane (g, c), element j <-> the OTHER index
 // 16 (2 kb + (j >> 2)) + 4 g + (j & 3).  forward image: W[out = 16 ta + c][in = other]; transposed image: W[out = other][in = 16 ta + c].
 // One thread per 32-bit word (two bf16).  Widths below the padded width read zeros.
+constexpr int PACK_BF_MAX_LAYERS = 16;
 struct PackBfArgs {
     const float* theta;
     unsigned* out_fwd;                   // packed + OFF_WB  (as 32-bit words)
     unsigned* out_tr;                    // packed + OFF_WTB
     int nhh, hp;                         // hidden->hidden layers, padded width
-    int woff[8], nout[8], nin[8];        // per hidden->hidden layer: theta offset of W (column-major: W[out + in nout]) and its real sizes
+    int woff[PACK_BF_MAX_LAYERS], nout[PACK_BF_MAX_LAYERS], nin[PACK_BF_MAX_LAYERS];      // per hidden->hidden layer: theta offset of W
+                                         // (column-major: W[out + in nout]) and its real sizes
 };
 AUX_DEV unsigned bf16_rne(float x) {
     unsigned u;

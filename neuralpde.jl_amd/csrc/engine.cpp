@@ -79,7 +79,7 @@ void pack_all(pinn_engine& E, const float* d_theta = nullptr, bool packed_fresh 
             std::memset(&pa, 0, sizeof pa);
             pa.theta = th; pa.out_fwd = (unsigned*)(NP.d_packed + NP.spec->OFF_WB); pa.out_tr = (unsigned*)(NP.d_packed + NP.spec->OFF_WTB);
             pa.nhh = NP.spec->NHH; pa.hp = NP.spec->HP;
-            if (pa.nhh > 8) return;                                // (plan refuses such nets for this build)
+            if (pa.nhh > aux::PACK_BF_MAX_LAYERS) return;          // (build_plan refuses such nets)
             int o = N.theta_off;
             for (size_t j = 0; j + 1 < N.sizes.size(); ++j) {
                 if (j >= 1 && j <= (size_t)pa.nhh) { pa.woff[j - 1] = o; pa.nin[j - 1] = N.sizes[j]; pa.nout[j - 1] = N.sizes[j + 1]; }
@@ -1171,7 +1171,8 @@ int pinn_describe(pinn_handle h, char* buf, int64_t buflen) {
     os << "backend=" << plat_name() << " cus=" << h->ncu << " ntheta=" << h->ntheta << " terms=" << h->terms.size() << "\n";
     for (size_t n = 0; n < h->netplans.size(); ++n)
         if (h->netplans[n].spec && h->netplans[n].spec->family != 3)
-            os << "net " << n << " weights=" << (h->netplans[n].direct ? "theta itself (theta-order image, no pack kernel)" : "packed image (k_pack per evaluation)") << "\n";
+            os << "net " << n << " weights=" << (h->netplans[n].direct ? "theta itself (theta-order image, no pack kernel)" : "packed image (k_pack per evaluation)")
+               << " gemm=" << (h->netplans[n].spec && h->netplans[n].spec->BFX ? (h->netplans[n].spec->BFX_DW ? "split-bf16(fwd,dA,dW)" : "split-bf16(fwd,dA)") : "fp32") << "\n";
     for (size_t g = 0; g < h->groups.size(); ++g) {
         const Group& G = h->groups[g];
         os << "group " << g << (G.kind == 1 ? (G.use_rec ? " [coupled fwd/gradin, records in HBM]" : " [coupled fwd/gradin]") : "") << " net=" << G.net << " kernel=" << spec_name(*G.spec) << " tiles=" << G.ga.ntiles << " blocks=" << G.blocks << " terms=";

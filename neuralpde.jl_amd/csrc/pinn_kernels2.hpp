@@ -83,11 +83,15 @@
 // SPLIT-OPERAND GEMMs on the bf16 matrix pipe (H = 64 kernels): an fp32 product from three bf16 pieces per operand,
 //     a b ~ ah bh + ah bm + am bh + ah bl + am bm + al bh      (a = ah + am + al to 24 bits; the dropped terms are below 2^-24 a b),
 // accumulated in fp32 by v_mfma_f32_16x16x32_bf16: 12 MFMAs of ~17 cycles for a 16x16 output tile over K = 64 instead of 16 fp32 MFMAs of
-// 32 cycles (2.56x measured, tools/micro/mfma_split_bench.hip).  1: the forward GEMMs and dA = W^T dZ (weights split once per evaluation by
-// k_pack_bf16, activations / dZ split by the publishing wave: 3 x 8-byte LDS stores instead of one 16-byte store); dW stays fp32.
-// 0: fp32 MFMAs everywhere.
+// 32 cycles (2.56x measured, tools/micro/mfma_split_bench.hip).
+//   1 (product): the forward GEMMs and dA = W^T dZ (weights split once per evaluation by k_pack_bf16, activations / dZ split by the
+//     publishing wave: 3 x 8-byte LDS stores instead of one 16-byte store); dW stays on the fp32 pipe.  Bench workload 378 -> 310 us per
+//     evaluation, cfg3 1268 -> 1028 us, full-size goldens unchanged at 1.7e-7 (gradient) / 4e-7 (losses), bit-reproducible.
+//   2: dW = dZ A^T as well (both operands staged transposed as bf16 pieces, K = 32 points = two column groups): correct, but the 16-bit
+//     scattered staging stores cost more than the MFMAs save — 319 vs 310 us (profiles/r03_experiments.txt).
+//   0: fp32 MFMAs everywhere (rounds 1-2).
 #ifndef PINN_F2_BF16X
-#define PINN_F2_BF16X 0
+#define PINN_F2_BF16X 1
 #endif
 #ifndef PINN_F2_GEMM_SITES
 #define PINN_F2_GEMM_SITES 7            // bit mask: 1 forward GEMM, 2 dA GEMM, 4 dW GEMM
@@ -188,16 +192,20 @@ struct Spec2 {
     // (NW = 4, one neuron tile per wave, weight fragments prefetched; the bigger exchange buffers must leave the un-chunked dW staging in place)
     static constexpr bool BFX = BFIMG && (2 * NG * KB * 3 * 256 + NG * MT * 256 + (((NW + 1) * NG * 16 + 63) / 64) * 64) * 4 <= 160 * 1024;
     static constexpr int XSZB = BFX ? NG * KB * 3 * 256 : XSZ;       // floats of one exchange buffer
+    // 2: dW = dZ A^T on the bf16 pipe as well: both operands are staged TRANSPOSED as bf16 pieces in MFMA operand order, K = 32 points = two
+    // column groups per MFMA (NG even): dZ^T fragments wave-private [pair][t][piece][64][8], A^T fragments cooperative in X1 [pair][tile][piece][64][8]
+    static constexpr bool BFX_DW = BFX && (PINN_F2_BF16X >= 2) && (NG % 2 == 0);
+    static constexpr int ZTW = BFX_DW ? (NG / 2) * (MT / NW) * 3 * 256 : NG * (MT / NW) * 256;      // floats of one wave's private dZ^T staging
     static constexpr int LDS_UP = (((NW + 1) * NG * 16 + 63) / 64) * 64;    // NW x output partials + seed broadcast (UB)
     static_assert(PG_ >= 1 && PG_ <= 4, "one tape wave per point group");
     // when X0 | X1 | ZT would not fit in 160 KiB (H = 128 with 8 jet channels) the dW operands are staged one column group
     // at a time in a double buffer carved out of X1: [A^T chunk 16 x HP | 4 x dZ^T chunk]
-    static constexpr bool CHUNKED = (2 * XSZB + XSZ + LDS_UP) * 4 > 160 * 1024;
+    static constexpr bool CHUNKED = (2 * XSZB + NW * ZTW + LDS_UP) * 4 > 160 * 1024;
     static constexpr int CH_AT = 16 * HP_;
     static constexpr int CH_ZT = MTW * 256;
     static constexpr int CHSZ = CH_AT + NW * CH_ZT;
     static_assert(!CHUNKED || 2 * CHSZ <= XSZ, "chunk double buffer must fit inside X1");
-    static constexpr int OFF_X1 = XSZB, OFF_ZT = 2 * XSZB, OFF_UP = 2 * XSZB + (CHUNKED ? 0 : XSZ);      // LDS offsets (floats)
+    static constexpr int OFF_X1 = XSZB, OFF_ZT = 2 * XSZB, OFF_UP = 2 * XSZB + (CHUNKED ? 0 : NW * ZTW);      // LDS offsets (floats)
     static constexpr int LDS_BASE = OFF_UP + LDS_UP;
     // PINN_F2_OCC=3 (experiment): three workgroups per CU where the LDS allows it — the kernel is then compiled for <= 168 VGPRs
     static constexpr int WG_PER_CU = (NW == 8) ? 1 : ((PINN_F2_OCC >= 3 && (!PINN_F2_OCC3_C1 || J::C == 1) && LDS_BASE * 4 <= 53 * 1024) ? 3 : ((LDS_BASE * 4 <= 80 * 1024) ? 2 : 1));
@@ -321,7 +329,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
     const ubuf SB = ub_make(ga.scratch + (size_t)blk * (ga.scr_stride ? ga.scr_stride : S::SCR), S::SCR);
     float* X0 = lds;
     float* X1 = lds + S::OFF_X1;
-    float* ZT = lds + S::OFF_ZT + w * (NG * MTW * 256);       // wave-private dZ^T: [q][t][16 columns][16 neurons]
+    float* ZT = lds + S::OFF_ZT + w * S::ZTW;                 // wave-private dZ^T: [q][t][16 columns][16 neurons] (BFX_DW: bf16 operand fragments)
     float* UP = lds + (BWD ? S::OFF_UP : S::OFF_ZT);          // output-layer partial sums [wave][q][16] (forward-only launches: LDS_FWD)
     float* RL = lds + S::LDS_BASE;                            // LDS-resident record slices [(LH-2-layer)*NG + q][tile][lane][4]
     auto rec_in_lds = [](int layer, int q) { return layer >= 1 && layer <= LH - 2 && (LH - 2 - layer) * NG + q < S::NRQ; };   // (same-kernel records only)
@@ -846,6 +854,38 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                     }
                 }
             };
+            // split-operand dW (S::BFX_DW): column group q's dZ (own tile) and a-jets (cooperative) as three bf16 pieces in the operand order of
+            // the 16x16x32 MFMA over K = 32 POINTS (two column groups): fragment lane (g2, c2), element j <-> neuron c2 of the tile, point
+            // 4 g2 + (j & 3) of column group 2 qp + (j >> 2).  A D-layout lane (g, c) holds neurons 4 g + r at point c: its four values go to
+            // fragment lanes (c >> 2, 4 g + r), element (q & 1) 4 + (c & 3) — 16-bit LDS stores, slots XOR-swizzled by c >> 2 against bank conflicts.
+            auto stage_q_bf = [&](int q) {
+                const int qp = q >> 1, mem = q & 1;
+                PINN_UNROLL for (int t = 0; t < MTW; ++t) {
+                    vbf4 zp[3], ap[3];
+                    split3_bf16(G[q][t], zp[0], zp[1], zp[2]);
+                    split3_bf16(ajet(Sr, q / C, q % C, t), ap[0], ap[1], ap[2]);
+                    const int tile = w * MTW + t;
+                    PINN_UNROLL for (int r = 0; r < 4; ++r) {
+                        const vint slot = ((c >> 2) << 4) + (((g << 2) + vint(r)) ^ (c >> 2));
+                        const vint h = (slot << 3) + vint(mem * 4) + (c & vint(3));                  // halfword inside the 1 KB fragment
+                        PINN_UNROLL for (int sp = 0; sp < 3; ++sp) {
+                            lds_store_bf1(ZT, h + vint(((qp * MTW + t) * 3 + sp) * 512), zp[sp], r);
+                            lds_store_bf1(X1, h + vint(((qp * MT + tile) * 3 + sp) * 512), ap[sp], r);
+                        }
+                    }
+                }
+            };
+            auto dw_pair_bf = [&](int qp) {
+                const vint slot4 = ((g << 4) + (c ^ g)) << 2;                                        // this lane's (swizzled) 16-byte slot, in floats
+                vbf8 za[MTW][3];
+                PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                    PINN_UNROLL for (int sp = 0; sp < 3; ++sp) za[t][sp] = lds_load_bf8(ZT, vint(((qp * MTW + t) * 3 + sp) * 256) + slot4);
+                PINN_UNROLL for (int ti = 0; ti < MT; ++ti) {
+                    vbf8 ab[3];
+                    PINN_UNROLL for (int sp = 0; sp < 3; ++sp) ab[sp] = lds_load_bf8(X1, vint(((qp * MT + ti) * 3 + sp) * 256) + slot4);
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t) wbar[hl][t][ti] = mfma_split(za[t], ab, wbar[hl][t][ti]);
+                }
+            };
             // W^T fragments for dA: issued ahead of the dW GEMM, which hides their latency
             vfloat4 wt[WPRE ? MT : 1][MTW];
             vbf8 wtb[S::BFX ? S::KB : 1][S::BFX ? MTW : 1][3];      // split-operand W^T fragments: [k-block of 32 output neurons][own input tile][piece]
@@ -926,7 +966,8 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                                 PINN_UNROLL for (int rr = 0; rr < 4; ++rr) Gn[q][t] = mfma16(wt[mo][t][rr], b4[rr], Gn[q][t]);
                         }
                     }
-                    stage_q(q, ZT + q * (MTW * 256), X1 + q * 16 * HP);
+                    if (S::BFX_DW) stage_q_bf(q);
+                    else stage_q(q, ZT + q * (MTW * 256), X1 + q * 16 * HP);
                 }
                 if (!S::BFX && PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 2)) sched_gemm_prefetch<MT * NG, MTW * 4, PINN_F2_GEMM_AHEAD>();
                 wave_prio(1);
@@ -934,9 +975,13 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 wg_barrier();                                               // staged operands complete; X0 free again
                 STAMP(11)
                 wave_prio_gemm(gemm_hi);
-                PINN_UNROLL for (int q = 0; q < NG; ++q) dw_q(ZT + q * (MTW * 256), X1 + q * 16 * HP);
-                if (PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 4) && MTW == 1 && MT == 4)
-                    sched_gemm_prefetch<4 * NG, 4, PINN_F2_GEMM_AHEAD, 2>();
+                if (S::BFX_DW) {
+                    PINN_UNROLL for (int qp = 0; qp < NG / 2; ++qp) dw_pair_bf(qp);
+                } else {
+                    PINN_UNROLL for (int q = 0; q < NG; ++q) dw_q(ZT + q * (MTW * 256), X1 + q * 16 * HP);
+                    if (PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 4) && MTW == 1 && MT == 4)
+                        sched_gemm_prefetch<4 * NG, 4, PINN_F2_GEMM_AHEAD, 2>();
+                }
                 wave_prio(1);
                 PINN_UNROLL for (int q = 0; q < NG; ++q)
                     PINN_UNROLL for (int t = 0; t < MTW; ++t) G[q][t] = Gn[q][t];

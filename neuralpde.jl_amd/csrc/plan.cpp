@@ -586,6 +586,7 @@ static int plan_pack_maps(pinn_engine& E) {
         NP.direct = s.family == 2 && s.NATURAL && std::getenv("PINN_NO_DIRECT_WEIGHTS") == nullptr && N.theta_off % 4 == 0;
         for (size_t j = 1; j + 1 < N.sizes.size(); ++j) NP.direct = NP.direct && N.sizes[j] == HP;
         for (int q = 0; q < s.PACKED && NP.direct; ++q) NP.direct = idx[q] < 0 ? q >= s.OFF_BL + 1 : idx[q] == N.theta_off + q;
+        if (s.BFX && s.NHH > 16) return fail("networks with more than 17 hidden layers are not supported by the 64-wide split-operand kernels");
         NP.npacked = s.PACKED;
         NP.d_packed = (float*)plat_malloc(sizeof(float) * s.PACKED);
         NP.d_pack_idx = (int*)plat_malloc(sizeof(int) * s.PACKED);
@@ -767,7 +768,9 @@ static int plan_group_buffers(pinn_engine& E) {
                 for (int in = 0; in < N.sizes[j]; ++in)
                     for (int out = 0; out < N.sizes[j + 1]; ++out) {
                         const int to = out / 16, i = out % 16, g = i / 4, r = i % 4;
-                        const int ti = (in / 64) * 4 + (in % 4), c = (in % 64) / 4;
+                        // fp32 dW GEMM: the B operand is four consecutive inputs per lane, so tile ti holds inputs 64 (ti / 4) + 4 c + ti % 4;
+                        // split-operand dW GEMM (SpecInfo::BFX_DW): plain tiles, column c of tile ti = input 16 ti + c
+                        const int ti = s.BFX_DW ? in / 16 : (in / 64) * 4 + (in % 4), c = s.BFX_DW ? in % 16 : (in % 64) / 4;
                         add_row(loff[j] + out + in * N.sizes[j + 1], s.O_WBAR + (((hl * MT + to) * MT + ti) * 64 + g * 16 + c) * 4 + r, true);
                     }
             }

@@ -36,6 +36,7 @@ struct SpecInfo {
     int ngen;                        // > 0: general multi-index channel set (jit.cpp gen_*): gen[i] = multi-index of channel i (nibble 0 = order, nibbles 1.. = axes)
     unsigned gen[MAX_GEN_CHANNELS];
     int OFF_W1, OFF_B, OFF_WL, OFF_BL, OFF_WPK, OFF_WTPK;
+    int BFX_DW;                      // family 2: dW accumulators in the natural tile order of the split-operand dW GEMM (column c of tile ti = input 16 ti + c)
     int BFX, OFF_WB, OFF_WTB;        // family 2, split-operand GEMMs (Spec2::BFIMG: the net's weight image carries them): bf16 piece images [NHH][tile][k-block][piece][64][8 bf16], forward / transposed
     int NATURAL;                     // family 2: the weight image is theta's own layout padded to HP (Spec2::NATURAL): hidden->hidden layer hl at
                                      // OFF_WPK + hl (HP HP + HP) as W[out + in HP], its bias behind it; 0: pre-shuffled fragment images
@@ -66,7 +67,7 @@ SpecInfo make_info(void (*launch)(const GroupArgs&, int, int, plat_stream), int 
     s.act1 = s.act2 = s.dgm_rows = 0;
     s.ngen = S::J::GEN ? S::C : 0;
     for (int i = 0; i < MAX_GEN_CHANNELS; ++i) s.gen[i] = (S::J::GEN && i < S::C) ? S::J::gen_channel(i) : 0u;
-    s.family = 1; s.WG_PER_CU = 1; s.WG_FWD = 1; s.NW = 4; s.NATURAL = 0; s.BFX = 0; s.OFF_WB = s.OFF_WTB = 0;
+    s.family = 1; s.WG_PER_CU = 1; s.WG_FWD = 1; s.NW = 4; s.NATURAL = 0; s.BFX = 0; s.BFX_DW = 0; s.OFF_WB = s.OFF_WTB = 0;
     s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR; s.HI = S::HI & 0xFFFFFFu; s.LAP = S::J::LAP;
     s.PG = S::PG; s.C = S::C; s.NG = S::NG; s.TP = S::TP; s.MT = S::MT; s.LH = S::LH; s.NFIRST = S::NFIRST;
     s.PACKED = S::PACKED; s.SLAB = S::SLAB; s.SCR = S::SCR; s.LDS_WG = S::LDS_WG; s.COOP = S::COOP ? 1 : 0; s.SH = S::SH; s.PW = S::PW;
@@ -87,7 +88,7 @@ SpecInfo make_info2(void (*launch)(const GroupArgs&, int, int, plat_stream), int
     s.ngen = S::J::GEN ? S::C : 0;
     for (int i = 0; i < MAX_GEN_CHANNELS; ++i) s.gen[i] = (S::J::GEN && i < S::C) ? S::J::gen_channel(i) : 0u;
     s.family = 2; s.WG_PER_CU = S::WG_PER_CU; s.WG_FWD = S::WG_FWD; s.NW = S::NW; s.NATURAL = S::NATURAL ? 1 : 0;
-    s.BFX = S::BFIMG ? 1 : 0; s.OFF_WB = S::OFF_WB; s.OFF_WTB = S::OFF_WTB;
+    s.BFX = S::BFIMG ? 1 : 0; s.OFF_WB = S::OFF_WB; s.OFF_WTB = S::OFF_WTB; s.BFX_DW = S::BFX_DW ? 1 : 0;
     s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR; s.HI = S::HI & 0xFFFFFFu; s.LAP = S::J::LAP;
     s.PG = S::PG; s.C = S::C; s.NG = S::NG; s.TP = S::TP; s.MT = S::MT; s.LH = S::LH; s.NFIRST = S::NFIRST;
     s.PACKED = S::PACKED; s.SLAB = S::SLAB; s.SCR = S::SCR; s.LDS_WG = S::LDS_WG; s.COOP = 1; s.SH = S::SLAB; s.PW = 0;

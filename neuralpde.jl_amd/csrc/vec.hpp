@@ -177,6 +177,10 @@ inline void split3_bf16(const vfloat4& x, vbf4& h, vbf4& m, vbf4& l) {
 inline void lds_store_bf4(float* p, const vint& i, const vbf4& x) {
     for (int q = 0; q < W; ++q) { uint16_t t[4] = {x.v[0][q], x.v[1][q], x.v[2][q], x.v[3][q]}; std::memcpy(p + i.v[q], t, 8); }
 }
+// one bf16 (element r of x) per lane at HALFWORD index h (ds_write_b16)
+inline void lds_store_bf1(float* p, const vint& h, const vbf4& x, int r) {
+    for (int q = 0; q < W; ++q) std::memcpy(reinterpret_cast<char*>(p) + 2 * (size_t)h.v[q], &x.v[r][q], 2);
+}
 inline vbf8 lds_load_bf8(const float* p, const vint& i) {
     vbf8 r;
     for (int q = 0; q < W; ++q) { uint16_t t[8]; std::memcpy(t, p + i.v[q], 16); for (int k = 0; k < 8; ++k) r.v[k][q] = t[k]; }
@@ -438,6 +442,7 @@ DEV void split3_bf16(vfloat4 x, vbf4& h, vbf4& m, vbf4& l) {
     }
 }
 DEV void lds_store_bf4(float* p, vint i, vbf4 x) { *reinterpret_cast<vbf4*>(p + i) = x; }
+DEV void lds_store_bf1(float* p, vint h, vbf4 x, int r) { reinterpret_cast<__bf16*>(p)[h] = x[r]; }
 DEV vbf8 lds_load_bf8(const float* p, vint i) { return *reinterpret_cast<const vbf8*>(p + i); }
 DEV vbf8 ub_load_bf8(ubuf b, int soff, vint voff) {
     return __builtin_bit_cast(vbf8, __builtin_amdgcn_raw_buffer_load_b128(b.r, voff * 4, soff * 4, 0));
