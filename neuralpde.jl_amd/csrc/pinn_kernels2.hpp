@@ -93,6 +93,14 @@
 #ifndef PINN_F2_BF16X
 #define PINN_F2_BF16X 1
 #endif
+// the 128-wide kernels (8 waves, one neuron tile each, weight fragments fetched per k-block instead of per layer) take the split-operand
+// forward / dA GEMMs as well wherever the wider exchange buffers still leave the un-chunked dW staging in LDS (NG <= 4: every 2-D set)
+#ifndef PINN_F2_BF16X_H128
+#define PINN_F2_BF16X_H128 1
+#endif
+#ifndef PINN_F2_WACC_PRELOAD
+#define PINN_F2_WACC_PRELOAD 2
+#endif
 #ifndef PINN_F2_GEMM_SITES
 #define PINN_F2_GEMM_SITES 7            // bit mask: 1 forward GEMM, 2 dA GEMM, 4 dW GEMM
 #endif
@@ -171,7 +179,8 @@ struct Spec2 {
     static constexpr int BF_LAYER = (HP_ / 16) * (HP_ / 32) * 3 * 256;
     static constexpr int OFF_WB = PACKED0;
     static constexpr int OFF_WTB = OFF_WB + NHH_ * BF_LAYER;
-    static constexpr int PACKED = (PINN_F2_BF16X >= 1 && HP_ == 64) ? OFF_WTB + NHH_ * BF_LAYER : PACKED0;      // (BFIMG, defined below)
+    static constexpr bool BFIMG = (PINN_F2_BF16X >= 1) && (HP_ == 64 || (HP_ == 128 && PINN_F2_BF16X_H128));   // the net's weight image carries the bf16 pieces
+    static constexpr int PACKED = BFIMG ? OFF_WTB + NHH_ * BF_LAYER : PACKED0;
     // per-workgroup gradient slab: every entry is written by exactly one wave
     static constexpr int O_WBAR = 0;                                 // [NHH][to][ti][64][4]
     static constexpr int O_BH = NHH_ * HP_ * HP_;                    // [LH][HP]  natural neuron order
@@ -188,8 +197,7 @@ struct Spec2 {
     static constexpr int XSZ = NG * MT * 256;
     // split-operand GEMMs (PINN_F2_BF16X): the exchange buffers hold B operands as three bf16 pieces, [q][k-block of 32][piece][lane][8 bf16]
     static constexpr int KB = MT / 2;                                // k-blocks of 32 per layer
-    static constexpr bool BFIMG = (PINN_F2_BF16X >= 1) && HP_ == 64;        // the weight image carries the bf16 pieces (every kernel of such a net)
-    // (NW = 4, one neuron tile per wave, weight fragments prefetched; the bigger exchange buffers must leave the un-chunked dW staging in place)
+    // (the bigger exchange buffers must leave the un-chunked dW staging in place)
     static constexpr bool BFX = BFIMG && (2 * NG * KB * 3 * 256 + NG * MT * 256 + (((NW + 1) * NG * 16 + 63) / 64) * 64) * 4 <= 160 * 1024;
     static constexpr int XSZB = BFX ? NG * KB * 3 * 256 : XSZ;       // floats of one exchange buffer
     // 2: dW = dZ A^T on the bf16 pipe as well: both operands are staged TRANSPOSED as bf16 pieces in MFMA operand order, K = 32 points = two
@@ -496,7 +504,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 // this wave's weight fragments + bias of the layer: issued before the exchange so that their L2 latency hides
                 // under publish + barrier instead of stalling the first MFMA of every k-block
                 vfloat4 wf[WPRE ? MT : 1][MTW], bv[MTW];
-                vbf8 wb[S::BFX ? S::KB : 1][S::BFX ? MTW : 1][3];
+                vbf8 wb[S::BFX ? S::KB : 1][S::BFX ? MTW : 1][3];      // (H = 128: 48 registers; fetched per k-block their L2 latency showed at every k-block)
                 if (S::BFX) {
                     PINN_UNROLL for (int kb = 0; kb < S::KB; ++kb)
                         PINN_UNROLL for (int t = 0; t < MTW; ++t)
@@ -515,7 +523,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 wg_barrier();                                                   // layer hl activations complete in Xin
                 STAMP(1)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t) {
-                    if (!WPRE) bv[t] = ld_bias(hl + 1, t);
+                    if (!WPRE && !S::BFX) bv[t] = ld_bias(hl + 1, t);
                     PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
                         A[pg * C][t] = bv[t];
                         PINN_UNROLL for (int ch = 1; ch < C; ++ch) A[pg * C + ch][t] = vzero4();
@@ -529,7 +537,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                             PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[sp] = lds_load_bf8(Xin, vint(((q * S::KB + kb) * 3 + sp) * 256) + (lane << 2));
                             PINN_UNROLL for (int t = 0; t < MTW; ++t) A[q][t] = mfma_split(wb[kb][t], bb, A[q][t]);
                         }
-                    if (PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 1)) sched_gemm_prefetch<S::KB * NG, MTW * 6, PINN_F2_GEMM_AHEAD, 3>();
+                    if (WPRE && PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 1)) sched_gemm_prefetch<S::KB * NG, MTW * 6, PINN_F2_GEMM_AHEAD, 3>();
                 }
                 PINN_UNROLL for (int mi = 0; mi < (S::BFX ? 0 : MT); ++mi) {
                     if (!WPRE)
@@ -833,7 +841,8 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 }
             };
             vfloat4 wacc[S::WBAR_REG ? 1 : MTW][S::WBAR_REG ? 1 : MT];
-            if (!S::WBAR_REG)
+            constexpr bool WACC_PRELOAD = !S::WBAR_REG && (S::BFX || PINN_F2_WACC_PRELOAD >= 2) && !WPRE && !S::CHUNKED && PINN_F2_WACC_PRELOAD;
+            if (!S::WBAR_REG && !WACC_PRELOAD)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t)
                     PINN_UNROLL for (int ti = 0; ti < MT; ++ti) wacc[t][ti] = vzero4();
             // dW[own rows][all inputs] += dZ A^T for one column group
@@ -997,6 +1006,16 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 STAMP(9)
                 continue;
             }
+            // split-operand kernels of this path (H = 128): dA runs FIRST, on the W^T fragments requested above (their 48 registers are
+            // dead again before the dW accumulators come alive)
+            auto da_split = [&]() {
+                PINN_UNROLL for (int kb = 0; kb < S::KB; ++kb)
+                    PINN_UNROLL for (int q = 0; q < NG; ++q) {
+                        vbf8 bb[3];
+                        PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[sp] = lds_load_bf8(X0, vint(((q * S::KB + kb) * 3 + sp) * 256) + (lane << 2));
+                        PINN_UNROLL for (int t = 0; t < MTW; ++t) Gn[q][t] = mfma_split(wtb[kb][t], bb, Gn[q][t]);
+                    }
+            };
             if (S::CHUNKED) {
                 PINN_UNROLL for (int q = 0; q < NG; ++q) {
                     float* cb = X1 + (q & 1) * S::CHSZ;
@@ -1009,6 +1028,19 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 STAMP(7)
                 wg_barrier();
                 STAMP(8)
+                if (!S::BFX && WACC_PRELOAD)
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                        PINN_UNROLL for (int ti = 0; ti < MT; ++ti)
+                            wacc[t][ti] = gload4(slab + S::O_WBAR, vint((((hl * MT + w * MTW + t) * MT + ti) * 64) * 4) + (lane << 2));
+                if (S::BFX) {
+                    // slab-resident dW: the running sums of this wave's tiles become the INITIAL accumulators of the dW GEMM — requested
+                    // as the W^T fragments' registers fall free, they arrive under the tail of the dA GEMM, and the read-add-write chain after the GEMM shrinks to plain stores
+                    da_split();
+                    if (WACC_PRELOAD)
+                        PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                            PINN_UNROLL for (int ti = 0; ti < MT; ++ti)
+                                wacc[t][ti] = gload4(slab + S::O_WBAR, vint((((hl * MT + w * MTW + t) * MT + ti) * 64) * 4) + (lane << 2));
+                }
                 PINN_UNROLL for (int q = 0; q < NG; ++q) dw_q(ZT + q * (MTW * 256), X1 + q * 16 * HP);
                 STAMP(9)
             }
@@ -1016,13 +1048,14 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 PINN_UNROLL for (int t = 0; t < MTW; ++t)
                     PINN_UNROLL for (int ti = 0; ti < MT; ++ti) {
                         const vint off = vint((((hl * MT + w * MTW + t) * MT + ti) * 64) * 4) + (lane << 2);
+                        if (WACC_PRELOAD) { gstore4(slab + S::O_WBAR, off, wacc[t][ti]); continue; }
                         vfloat4 cur = gload4(slab + S::O_WBAR, off);
                         PINN_UNROLL for (int e = 0; e < 4; ++e) cur[e] += wacc[t][ti][e];
                         gstore4(slab + S::O_WBAR, off, cur);
                     }
             if (SPRE && hl - 1 >= 1) load_record(hl - 1);                    // next iteration's record: latency hides under the dA GEMM
             // ---- dA (own input tiles) = W^T dZ ----
-            PINN_UNROLL for (int mo = 0; mo < MT; ++mo) {
+            PINN_UNROLL for (int mo = 0; mo < (S::BFX ? 0 : MT); ++mo) {
                 if (!WPRE)
                     PINN_UNROLL for (int t = 0; t < MTW; ++t)
                         wt[0][t] = ld_wt(hl, t, mo);
