@@ -98,6 +98,9 @@
 #ifndef PINN_F2_BF16X_H128
 #define PINN_F2_BF16X_H128 1
 #endif
+#ifndef PINN_F2_BF16X_TWO_STAGE
+#define PINN_F2_BF16X_TWO_STAGE 1
+#endif
 #ifndef PINN_F2_WACC_PRELOAD
 #define PINN_F2_WACC_PRELOAD 2
 #endif
@@ -197,23 +200,33 @@ struct Spec2 {
     static constexpr int XSZ = NG * MT * 256;
     // split-operand GEMMs (PINN_F2_BF16X): the exchange buffers hold B operands as three bf16 pieces, [q][k-block of 32][piece][lane][8 bf16]
     static constexpr int KB = MT / 2;                                // k-blocks of 32 per layer
-    // (the bigger exchange buffers must leave the un-chunked dW staging in place)
-    static constexpr bool BFX = BFIMG && (2 * NG * KB * 3 * 256 + NG * MT * 256 + (((NW + 1) * NG * 16 + 63) / 64) * 64) * 4 <= 160 * 1024;
-    static constexpr int XSZB = BFX ? NG * KB * 3 * 256 : XSZ;       // floats of one exchange buffer
+    // The bigger exchange buffers must leave the un-chunked dW staging in place (BF_FULL).  128-wide kernels whose staging no longer fits
+    // beside them (six column groups: the 4-D forward-Laplacian set) stage and multiply the dW operands in TWO halves of the column groups
+    // inside the second exchange buffer, which the reverse sweep does not use otherwise (NSTAGE = 2: two more barriers per layer).
+    static constexpr int XSZ_BF = NG * KB * 3 * 256;
+    static constexpr int UP_SZ = (((NW + 1) * NG * 16 + 63) / 64) * 64;
+    static constexpr bool BF_FULL = (2 * XSZ_BF + NG * MT * 256 + UP_SZ) * 4 <= 160 * 1024;
+    static constexpr bool BF_HALF = !BF_FULL && PINN_F2_BF16X_TWO_STAGE && (MT * (MT / NW) * 4 > 16) && (NG % 2 == 0) && (PINN_F2_BF16X < 2) &&
+                                    (2 * XSZ_BF + UP_SZ) * 4 <= 160 * 1024 && (NG / 2) * 16 * HP_ + (NG / 2) * MT * 256 <= XSZ_BF;
+    static constexpr bool BFX = BFIMG && (BF_FULL || BF_HALF);
+    static constexpr int NSTAGE = (BFX && BF_HALF) ? 2 : 1;          // passes of the dW staging + GEMM over the column groups
+    static constexpr int XSZB = BFX ? XSZ_BF : XSZ;                  // floats of one exchange buffer
     // 2: dW = dZ A^T on the bf16 pipe as well: both operands are staged TRANSPOSED as bf16 pieces in MFMA operand order, K = 32 points = two
     // column groups per MFMA (NG even): dZ^T fragments wave-private [pair][t][piece][64][8], A^T fragments cooperative in X1 [pair][tile][piece][64][8]
     static constexpr bool BFX_DW = BFX && (PINN_F2_BF16X >= 2) && (NG % 2 == 0);
-    static constexpr int ZTW = BFX_DW ? (NG / 2) * (MT / NW) * 3 * 256 : NG * (MT / NW) * 256;      // floats of one wave's private dZ^T staging
+    static constexpr int ZTW = BFX_DW ? (NG / 2) * (MT / NW) * 3 * 256 : (NG / NSTAGE) * (MT / NW) * 256;      // floats of one wave's private dZ^T staging
     static constexpr int LDS_UP = (((NW + 1) * NG * 16 + 63) / 64) * 64;    // NW x output partials + seed broadcast (UB)
     static_assert(PG_ >= 1 && PG_ <= 4, "one tape wave per point group");
     // when X0 | X1 | ZT would not fit in 160 KiB (H = 128 with 8 jet channels) the dW operands are staged one column group
     // at a time in a double buffer carved out of X1: [A^T chunk 16 x HP | 4 x dZ^T chunk]
-    static constexpr bool CHUNKED = (2 * XSZB + NW * ZTW + LDS_UP) * 4 > 160 * 1024;
+    static constexpr bool CHUNKED = NSTAGE == 1 && (2 * XSZB + NW * ZTW + LDS_UP) * 4 > 160 * 1024;
     static constexpr int CH_AT = 16 * HP_;
     static constexpr int CH_ZT = MTW * 256;
     static constexpr int CHSZ = CH_AT + NW * CH_ZT;
     static_assert(!CHUNKED || 2 * CHSZ <= XSZ, "chunk double buffer must fit inside X1");
-    static constexpr int OFF_X1 = XSZB, OFF_ZT = 2 * XSZB, OFF_UP = 2 * XSZB + (CHUNKED ? 0 : NW * ZTW);      // LDS offsets (floats)
+    static constexpr int OFF_X1 = XSZB;                                                                          // LDS offsets (floats)
+    static constexpr int OFF_ZT = NSTAGE == 2 ? XSZB + (NG / 2) * 16 * HP_ : 2 * XSZB;                           // (two stages: A^T half | dZ^T halves inside X1)
+    static constexpr int OFF_UP = 2 * XSZB + ((CHUNKED || NSTAGE == 2) ? 0 : NW * ZTW);
     static constexpr int LDS_BASE = OFF_UP + LDS_UP;
     // PINN_F2_OCC=3 (experiment): three workgroups per CU where the LDS allows it — the kernel is then compiled for <= 168 VGPRs
     static constexpr int WG_PER_CU = (NW == 8) ? 1 : ((PINN_F2_OCC >= 3 && (!PINN_F2_OCC3_C1 || J::C == 1) && LDS_BASE * 4 <= 53 * 1024) ? 3 : ((LDS_BASE * 4 <= 80 * 1024) ? 2 : 1));
@@ -338,7 +351,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
     float* X0 = lds;
     float* X1 = lds + S::OFF_X1;
     float* ZT = lds + S::OFF_ZT + w * S::ZTW;                 // wave-private dZ^T: [q][t][16 columns][16 neurons] (BFX_DW: bf16 operand fragments)
-    float* UP = lds + (BWD ? S::OFF_UP : S::OFF_ZT);          // output-layer partial sums [wave][q][16] (forward-only launches: LDS_FWD)
+    float* UP = lds + (BWD ? S::OFF_UP : 2 * S::XSZB);        // output-layer partial sums [wave][q][16] (forward-only launches: LDS_FWD)
     float* RL = lds + S::LDS_BASE;                            // LDS-resident record slices [(LH-2-layer)*NG + q][tile][lane][4]
     auto rec_in_lds = [](int layer, int q) { return layer >= 1 && layer <= LH - 2 && (LH - 2 - layer) * NG + q < S::NRQ; };   // (same-kernel records only)
     auto rl_off = [&](int layer, int q, int t) { return vint((((LH - 2 - layer) * NG + q) * MT + w * MTW + t) * 256) + (lane << 2); };
@@ -1024,7 +1037,8 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                     dw_q(cb + S::CH_AT + w * S::CH_ZT, cb);
                 }
             } else {
-                PINN_UNROLL for (int q = 0; q < NG; ++q) stage_q(q, ZT + q * (MTW * 256), X1 + q * 16 * HP);
+                constexpr int QH = NG / S::NSTAGE;                          // column groups per staging pass
+                PINN_UNROLL for (int q = 0; q < QH; ++q) stage_q(q, ZT + q * (MTW * 256), X1 + q * 16 * HP);
                 STAMP(7)
                 wg_barrier();
                 STAMP(8)
@@ -1041,7 +1055,13 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                             PINN_UNROLL for (int ti = 0; ti < MT; ++ti)
                                 wacc[t][ti] = gload4(slab + S::O_WBAR, vint((((hl * MT + w * MTW + t) * MT + ti) * 64) * 4) + (lane << 2));
                 }
-                PINN_UNROLL for (int q = 0; q < NG; ++q) dw_q(ZT + q * (MTW * 256), X1 + q * 16 * HP);
+                PINN_UNROLL for (int q = 0; q < QH; ++q) dw_q(ZT + q * (MTW * 256), X1 + q * 16 * HP);
+                if (S::NSTAGE == 2) {
+                    wg_barrier();                                           // first half multiplied by every wave: the staging area is free
+                    PINN_UNROLL for (int q = QH; q < NG; ++q) stage_q(q, ZT + (q - QH) * (MTW * 256), X1 + (q - QH) * 16 * HP);
+                    wg_barrier();
+                    PINN_UNROLL for (int q = QH; q < NG; ++q) dw_q(ZT + (q - QH) * (MTW * 256), X1 + (q - QH) * 16 * HP);
+                }
                 STAMP(9)
             }
             if (!S::WBAR_REG)

@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 3, GPU call 13: slab sums preloaded as dW accumulators in the fp32 128-wide path as well (cfg5); H = 128 GPU tests
+# round 3, GPU call 14: two-stage dW staging: the six-group 128-wide kernel (cfg5) on split-operand GEMMs
 set -x
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-O=gpurun_out/r03n
+O=gpurun_out/r03o
 mkdir -p $O
 export TMPDIR=/tmp
 timeout 600 python tools/golden_check.py cfg4_full cfg5_full > $O/golden_new.txt 2>&1
