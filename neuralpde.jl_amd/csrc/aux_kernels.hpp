@@ -297,6 +297,9 @@ struct PackBfArgs {
     unsigned* out_fwd;                   // packed + OFF_WB  (as 32-bit words)
     unsigned* out_tr;                    // packed + OFF_WTB
     int nhh, hp;                         // hidden->hidden layers, padded width
+    float* packed;                       // the same launch gathers the fp32 image first (threads [0, n_gather): packed[i] = theta[idx[i]]);
+    const int* idx;                      // n_gather = 0 when the optimiser's update kernel has written it already
+    int n_gather;
     int woff[PACK_BF_MAX_LAYERS], nout[PACK_BF_MAX_LAYERS], nin[PACK_BF_MAX_LAYERS];      // per hidden->hidden layer: theta offset of W
                                          // (column-major: W[out + in nout]) and its real sizes
 };
@@ -484,6 +487,7 @@ inline void launch_params(float* params, const float* theta, const float* defaul
 }
 inline void launch_pack_bf16(const PackBfArgs& a, plat_stream) {
     const int total = a.nhh * (a.hp / 16) * (a.hp / 32) * 3 * 256;
+    for (int i = 0; i < a.n_gather; ++i) pack_body(i, a.packed, a.idx, a.theta);
     for (int e = 0; e < 2 * total; ++e) pack_bf16_body(e, a);
 }
 inline void launch_sums_from_double(float* out_sums, const double* raw, int K, plat_stream) {
@@ -679,10 +683,14 @@ inline void launch_pack(float* packed, const int* idx, const float* theta, int n
 inline void launch_params(float* params, const float* theta, const float* defaults, int np, int ne, int p_off, plat_stream st) {
     if (np > 0) hipLaunchKernelGGL(k_params, dim3(1), dim3(64), 0, st, params, theta, defaults, np, ne, p_off);
 }
-__global__ void k_pack_bf16(const PackBfArgs a) { pack_bf16_body((int)(blockIdx.x * blockDim.x + threadIdx.x), a); }
+__global__ void k_pack_bf16(const PackBfArgs a) {
+    const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (e < a.n_gather) pack_body(e, a.packed, a.idx, a.theta);
+    else pack_bf16_body(e - a.n_gather, a);
+}
 inline void launch_pack_bf16(const PackBfArgs& a, plat_stream st) {
     const int total = a.nhh * (a.hp / 16) * (a.hp / 32) * 3 * 256;
-    hipLaunchKernelGGL(k_pack_bf16, dim3((2 * total + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_pack_bf16, dim3((a.n_gather + 2 * total + 255) / 256), dim3(256), 0, st, a);
 }
 __global__ void k_sums_from_double(float* out_sums, const double* raw, int K) {
     const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);

@@ -71,14 +71,16 @@ void pack_all(pinn_engine& E, const float* d_theta = nullptr, bool packed_fresh 
         const float* slice = th + E.nets[n].theta_off;
         if (NP.direct && ((uintptr_t)slice & 15u) == 0) { NP.cur = slice; continue; }
         NP.cur = NP.d_packed;
-        if (!packed_fresh || NP.direct)                            // (fresh: the optimiser's update kernel already wrote the images)
-            aux::launch_pack(NP.d_packed, NP.d_pack_idx, th, NP.npacked, E.stream);
-        if (NP.spec->BFX) {                                        // split-operand GEMMs: the three bf16 pieces of every hidden->hidden weight
+        const bool gather = !packed_fresh || NP.direct;            // (fresh: the optimiser's update kernel already wrote the fp32 image)
+        if (gather && !NP.spec->BFX) aux::launch_pack(NP.d_packed, NP.d_pack_idx, th, NP.npacked, E.stream);
+        if (NP.spec->BFX) {                                        // split-operand GEMMs: the three bf16 pieces of every hidden->hidden weight,
+                                                                   // written by the same launch as the fp32 image
             const Net& N = E.nets[n];
             aux::PackBfArgs pa;
             std::memset(&pa, 0, sizeof pa);
             pa.theta = th; pa.out_fwd = (unsigned*)(NP.d_packed + NP.spec->OFF_WB); pa.out_tr = (unsigned*)(NP.d_packed + NP.spec->OFF_WTB);
             pa.nhh = NP.spec->NHH; pa.hp = NP.spec->HP;
+            pa.packed = NP.d_packed; pa.idx = NP.d_pack_idx; pa.n_gather = gather ? NP.spec->OFF_WB : 0;      // (the fp32 part of the image ends where the bf16 pieces begin)
             if (pa.nhh > aux::PACK_BF_MAX_LAYERS) return;          // (build_plan refuses such nets)
             int o = N.theta_off;
             for (size_t j = 0; j + 1 < N.sizes.size(); ++j) {

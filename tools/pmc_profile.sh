@@ -12,6 +12,7 @@ run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" -d $REPO/$OUT/$name 
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+run mfma_bf16 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA      # split-operand GEMMs: the share of the matrix work on the bf16 pipe
 run waves SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA
 run lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS
 run l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum        # is the weight stream (packed image re-read by every workgroup) served by the L2?
