@@ -212,12 +212,27 @@ function dgm_lines(i::Int, dgm, θoff::Int, depvar::Symbol, inputs)
     return ["net $(i - 1) dgm,$a1,$a2,$L $θoff 3 $d $M 1", "netvar $(i - 1) $depvar $(length(inputs)) " * join(inputs, " ")], nparams
 end
 
-input_dim(model) = model isa NeuralPDE.DGM ? first(values(model.model.layers)).layers.in_dims : first(values(model.layers)).in_dims
+# [3P] Boltz.Layers.PeriodicEmbedding(idxs, periods) as the first layer (test/CUDA/nnpde_cuda__1d_pde_dirichlet_bc_cuda.jl:26,48), recognised
+# by name and fields so that Boltz does not become a dependency of this file: inputs `idxs` leave the input list and come back at its end
+# as their sines, then their cosines (period-scaled); the layer has no parameters, so the flat-θ layout is that of the Dense stack
+is_periodic_embedding(l) = nameof(typeof(l)) === :PeriodicEmbedding && hasproperty(l, :idxs) && hasproperty(l, :periods)
+function input_dim(model)
+    model isa NeuralPDE.DGM && return first(values(model.model.layers)).layers.in_dims
+    layers = collect(values(model.layers))
+    is_periodic_embedding(layers[1]) && return layers[2].in_dims - length(layers[1].idxs)
+    return layers[1].in_dims
+end
 
 function chain_lines(i::Int, chain, θoff::Int, depvar::Symbol, inputs)
     chain isa NeuralPDE.DGM && return dgm_lines(i, chain, θoff, depvar, inputs)
     layers = collect(values(chain.layers))
-    all(l -> l isa Lux.Dense, layers) || throw(HIPEngineError("the HIP engine runs Chains of Dense layers (got $(typeof.(layers)))"))
+    embed = nothing
+    if is_periodic_embedding(layers[1])
+        embed, layers = layers[1], layers[2:end]
+        length(embed.idxs) == length(embed.periods) || throw(HIPEngineError("PeriodicEmbedding: one period per embedded input"))
+        Lux.LuxCore.parameterlength(embed) == 0 || throw(HIPEngineError("PeriodicEmbedding with parameters is not supported"))
+    end
+    all(l -> l isa Lux.Dense, layers) || throw(HIPEngineError("the HIP engine runs Chains of Dense layers, optionally behind a PeriodicEmbedding (got $(typeof.(layers)))"))
     length(layers) >= 2 || throw(HIPEngineError("the HIP engine needs at least one hidden layer"))
     acts = [act_name(l.activation) for l in layers]
     any(isnothing, acts) && throw(HIPEngineError("unsupported activation in chain $i: $([l.activation for l in layers]) (supported: tanh, sigmoid, sin)"))
@@ -229,8 +244,13 @@ function chain_lines(i::Int, chain, θoff::Int, depvar::Symbol, inputs)
     act = all(==(hidden[1]), hidden) ? hidden[1] : join(hidden, ",")
     sizes = vcat(layers[1].in_dims, [l.out_dims for l in layers])
     nparams = sum(l.in_dims * l.out_dims + l.out_dims for l in layers)
-    lines = ["net $(i - 1) $act $θoff $(length(sizes)) " * join(sizes, " "),
-             "netvar $(i - 1) $depvar $(length(inputs)) " * join(inputs, " ")]
+    lines = ["net $(i - 1) $act $θoff $(length(sizes)) " * join(sizes, " ")]
+    if embed !== nothing              # embed <net> <n> <0-based input index> <period> ...   (csrc/descriptor.cpp: apply_embeddings)
+        sizes[1] == length(inputs) + length(embed.idxs) ||
+            throw(HIPEngineError("the first Dense layer must take $(length(inputs) + length(embed.idxs)) features (inputs + embedded inputs), got $(sizes[1])"))
+        push!(lines, "embed $(i - 1) $(length(embed.idxs)) " * join(("$(Int(ix) - 1) $(repr(Float64(p)))" for (ix, p) in zip(embed.idxs, embed.periods)), " "))
+    end
+    push!(lines, "netvar $(i - 1) $depvar $(length(inputs)) " * join(inputs, " "))
     return lines, nparams
 end
 

@@ -117,3 +117,25 @@ structural(desc) = [l for l in split(desc, '\n') if !(startswith(l, "lhs ") || s
         end
     end
 end
+
+# the reference's GPU test with a Boltz PeriodicEmbedding in front of the Dense stack
+# (test/CUDA/nnpde_cuda__1d_pde_dirichlet_bc_cuda.jl:26-48); runs when Boltz is installed
+if Base.find_package("Boltz") !== nothing
+    @eval import Boltz.Layers: PeriodicEmbedding
+    @testset "PeriodicEmbedding in front of the chain" begin
+        Random.seed!(100)
+        @parameters t x
+        @variables u(..)
+        eq = Differential(t)(u(t, x)) ~ (Differential(x)^2)(u(t, x))
+        bcs = [u(0, x) ~ cos(x), u(t, 0) ~ exp(-t), u(t, 2π) ~ exp(-t)]
+        @named sys = PDESystem(eq, bcs, [t ∈ Interval(0.0, 1.0), x ∈ Interval(0.0, 2π)], [t, x], [u(t, x)])
+        inner = 30
+        chain = Chain(PeriodicEmbedding([2], [2π]), Dense(3, inner, σ), [Dense(inner, inner, σ) for _ in 1:5]..., Dense(inner, 1))
+        strategy = QuasiRandomTraining(256; sampling_alg = SobolSample(), resampling = false, minibatch = 1)
+        disc = PhysicsInformedNN(chain, strategy)
+        ref = symbolic_discretize(sys, disc)
+        @test occursin("embed 0 1 1 ", descriptor(ref))
+        NeuralPDEHIP.build_state(ref, strategy)                                   # verify_layout: engine trial function == Lux chain incl. the embedding
+        @test NeuralPDEHIP.selftest(sys, disc; rtol = 1e-4) <= 1e-4               # residuals against the reference's generated loss functions
+    end
+end

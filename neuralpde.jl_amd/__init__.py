@@ -20,7 +20,7 @@ def ahmc_bayesian_pinn_pde(pde_system, discretization, **kw):
     return _bpinn.ahmc_bayesian_pinn_pde(_sys.modules[__name__], pde_system, discretization, **kw)
 from .adaptive import (AbstractAdaptiveLoss, GradientScaleAdaptiveLoss, MiniMaxAdaptiveLoss, ReLoBRaLoAdaptiveLoss,
                        SoftAdaptAdaptiveLoss)
-from .pinn import (DGM, DeepGalerkin, DataLoss, depvar_params, Adam, BFGS, LBFGS, OptimizationSolution, solve, Chain, Dense, LogOptions, NonAdaptiveLoss, OptimizationFunction, OptimizationProblem, Phi,
+from .pinn import (PeriodicEmbedding, DGM, DeepGalerkin, DataLoss, depvar_params, Adam, BFGS, LBFGS, OptimizationSolution, solve, Chain, Dense, LogOptions, NonAdaptiveLoss, OptimizationFunction, OptimizationProblem, Phi,
                    PhysicsInformedNN, PINNLossFunctions, PINNRepresentation, discretize, initialparameters, remake,
                    symbolic_discretize)
 from .strategies import (AbstractTrainingStrategy, QuadratureTraining, GridTraining, LatinHypercubeSample, QuasiRandomTraining,

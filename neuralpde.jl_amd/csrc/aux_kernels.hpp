@@ -342,6 +342,24 @@ AUX_DEV void pack_bf16_body(int e, const PackBfArgs& a) {
     }
     (tr ? a.out_tr : a.out_fwd)[tr ? e - total : e] = word;
 }
+// periodic-embedding rows of a point set (descriptor.cpp: apply_embeddings): point p of the installed set [n][du] -> device row
+// [x_0 .. x_du-1 | sin / cos (omega x_src) ...] of width dx; the phase is formed in double so that the rows agree with the oracle's to
+// float rounding
+struct EmbedArgs {
+    const float* upts;
+    float* pts;
+    int n, du, dx;
+    int src[4], is_cos[4];
+    double omega[4];
+};
+AUX_DEV void embed_body(int p, const EmbedArgs& a) {
+    if (p >= a.n) return;
+    for (int i = 0; i < a.du; ++i) a.pts[(size_t)p * a.dx + i] = a.upts[(size_t)p * a.du + i];
+    for (int k = 0; k < a.dx - a.du; ++k) {
+        const double ph = a.omega[k] * (double)a.upts[(size_t)p * a.du + a.src[k]];
+        a.pts[(size_t)p * a.dx + a.du + k] = (float)(a.is_cos[k] ? cos(ph) : sin(ph));
+    }
+}
 AUX_DEV void pack_body(int i, float* packed, const int* idx, const float* theta) {
     const int j = idx[i];
     packed[i] = (j >= 0) ? theta[j] : 0.f;
@@ -481,6 +499,9 @@ inline bool reduce_is_small(const Reduce1Args& a1, const Reduce2Args& a2) {
 #ifdef PINN_EMU
 inline void launch_pack(float* packed, const int* idx, const float* theta, int n, plat_stream) {
     for (int i = 0; i < n; ++i) pack_body(i, packed, idx, theta);
+}
+inline void launch_embed(const EmbedArgs& a, plat_stream) {
+    for (int p = 0; p < a.n; ++p) embed_body(p, a);
 }
 inline void launch_params(float* params, const float* theta, const float* defaults, int np, int ne, int p_off, plat_stream) {
     for (int j = 0; j < np; ++j) params_body(j, params, theta, defaults, ne, p_off);
@@ -679,6 +700,10 @@ __global__ void k_reduce2(const Reduce2Args a) {
 }
 inline void launch_pack(float* packed, const int* idx, const float* theta, int n, plat_stream st) {
     hipLaunchKernelGGL(k_pack, dim3((n + 255) / 256), dim3(256), 0, st, packed, idx, theta, n);
+}
+__global__ void k_embed(const EmbedArgs a) { embed_body((int)(blockIdx.x * blockDim.x + threadIdx.x), a); }
+inline void launch_embed(const EmbedArgs& a, plat_stream st) {
+    hipLaunchKernelGGL(k_embed, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
 }
 inline void launch_params(float* params, const float* theta, const float* defaults, int np, int ne, int p_off, plat_stream st) {
     if (np > 0) hipLaunchKernelGGL(k_params, dim3(1), dim3(64), 0, st, params, theta, defaults, np, ne, p_off);

@@ -66,9 +66,29 @@ int parse_descriptor(const char* text, pinn_engine& E) {
         E.nets[i].sizes.resize(ns);
         for (int j = 0; j < ns; ++j)
             if (!(in >> E.nets[i].sizes[j])) return fail("descriptor: net sizes");
+        {                                      // optional: embed <i> <n> <input index> <period> ... (PeriodicEmbedding in front of the chain)
+            const std::streampos pos = in.tellg();
+            std::string t2;
+            if ((in >> t2) && t2 == "embed") {
+                int eid, ne;
+                if (!(in >> eid >> ne) || eid != i || ne < 1 || ne > 4) return fail("descriptor: embed line");
+                Net& N = E.nets[i];
+                for (int k = 0; k < ne; ++k) {
+                    int ix; double per;
+                    if (!(in >> ix >> per) || !(per > 0.0)) return fail("descriptor: embed line (input index and a positive period per embedded input)");
+                    if (ix < 0 || ix >= N.sizes[0] - ne) return fail("descriptor: embed input index out of range");
+                    if (std::find(N.emb_idx.begin(), N.emb_idx.end(), ix) != N.emb_idx.end()) return fail("descriptor: embed lists an input twice");
+                    N.emb_idx.push_back(ix); N.emb_period.push_back(per);
+                }
+                if (dgm) return fail("descriptor: a periodic embedding in front of a DGM network is not supported");
+            } else {
+                in.clear();
+                in.seekg(pos);
+            }
+        }
         if (ver == 2) {                        // netvar <i> <depvar name> <#inputs> <input names...>  (dict_depvar_input, symbolic_utilities.jl:401-426)
             int vid, nin;
-            if (!expect("netvar") || !(in >> vid >> ctx.depvars[i] >> nin) || vid != i || nin != E.nets[i].sizes[0])
+            if (!expect("netvar") || !(in >> vid >> ctx.depvars[i] >> nin) || vid != i || nin != E.nets[i].n_inputs())
                 return fail("descriptor: netvar line (one per net: name and as many input names as the chain has inputs)");
             ctx.depvar_inputs[i].resize(nin);
             for (int j = 0; j < nin; ++j)
@@ -194,6 +214,199 @@ int parse_descriptor(const char* text, pinn_engine& E) {
         long long id = -1, n = 0;
         if (t2 != "hint" || !(in >> id >> n) || id < 0 || id >= nt || n < 0) return fail("descriptor: trailing text after the last term (expected `hint <term> <points>`)");
         E.terms[id].hint_n = n;
+    }
+    return apply_embeddings(E);
+}
+
+// ---------------------------------------------------------------------------------------------
+// periodic input embeddings: u(x) = N(f(x)) with features f = [x_other..., sin(w x_p)..., cos(w x_p)...]
+// ---------------------------------------------------------------------------------------------
+// The kernels know chains of Dense layers over their inputs only.  A term that references an embedded network is rewritten so that it
+// fits that model: the term's point rows grow by one sin and one cos row per embedded coordinate (filled on the device whenever the point
+// set changes), the network's inputs are mapped onto those rows, and every derivative slot of u with respect to the ORIGINAL arguments
+// becomes the chain-rule combination of derivatives of N with respect to its FEATURES:
+//     d/dx_p    =  w c d_s - w s d_c
+//     d2/dx_p2  =  w^2 (c^2 d_ss - 2 s c d_sc + s^2 d_cc - s d_s - c d_c)        (s = sin(w x_p), c = cos(w x_p), w = 2 pi / period)
+// (operators of different coordinates commute, so mixed derivatives are products of these).  The coefficient products reference
+// coordinate rows only: the planner hoists them into the per-point-set source pass like any other coordinate-only subexpression.
+namespace {
+struct ExpTerm { double k; std::vector<int> rows; std::vector<int> faxes; };      // k * prod(rows) * d^|faxes| N / d f_faxes
+}
+int apply_embeddings(pinn_engine& E) {
+    bool any = false;
+    for (auto& N : E.nets) any = any || !N.emb_idx.empty();
+    for (auto& T : E.terms) T.d_user = T.d;
+    if (!any) return 0;
+    const double TWO_PI = 6.283185307179586476925286766559;
+    for (size_t ti = 0; ti < E.terms.size(); ++ti) {
+        Term& T = E.terms[ti];
+        std::vector<int> nets;
+        for (auto& s : T.slots)
+            if (std::find(nets.begin(), nets.end(), s.net) == nets.end()) nets.push_back(s.net);
+        bool touched = false;
+        for (int n : nets) touched = touched || !E.nets[n].emb_idx.empty();
+        if (!touched) continue;
+        const int d0 = T.d, np = E.np, S0 = (int)T.slots.size();
+        // user-space input maps (explicit for every referenced network from here on: the row count of the term changes)
+        for (int n : nets) {
+            const Net& N = E.nets[n];
+            if (!T.inmap.count(n)) {
+                if (N.n_inputs() != d0)
+                    return fail("term " + std::to_string(ti) + ": network " + std::to_string(n) + " takes " + std::to_string(N.n_inputs()) +
+                                " arguments but the term binds " + std::to_string(d0) + " coordinates and the descriptor has no inmap line for it");
+                std::vector<int> id(d0);
+                for (int i = 0; i < d0; ++i) id[i] = i;
+                T.inmap[n] = id;
+            }
+            if ((int)T.inmap[n].size() != N.n_inputs())
+                return fail("term " + std::to_string(ti) + ": inmap length differs from the argument count of network " + std::to_string(n));
+        }
+        auto col_row = [&](int src, double omega, int is_cos) -> int {
+            for (size_t i = 0; i < T.emb_cols.size(); ++i)
+                if (T.emb_cols[i].src == src && T.emb_cols[i].omega == omega && T.emb_cols[i].is_cos == is_cos) return d0 + (int)i;
+            T.emb_cols.push_back({src, omega, is_cos});
+            return d0 + (int)T.emb_cols.size() - 1;
+        };
+        // feature maps: per embedded network, feature index / rows of every argument
+        struct ArgInfo { int feat = -1, fs = -1, fc = -1, rs = -1, rc = -1; double w = 0.0; };
+        std::map<int, std::vector<ArgInfo>> arg;
+        std::map<int, std::vector<int>> new_inmap;
+        for (int n : nets) {
+            const Net& N = E.nets[n];
+            if (N.emb_idx.empty()) continue;
+            const int nin = N.n_inputs(), ne = (int)N.emb_idx.size();
+            std::vector<ArgInfo> A(nin);
+            std::vector<int> m(N.sizes[0]);
+            int pass = 0;
+            for (int a = 0; a < nin; ++a) {
+                const auto it = std::find(N.emb_idx.begin(), N.emb_idx.end(), a);
+                if (it == N.emb_idx.end()) { A[a].feat = pass; m[pass] = T.inmap[n][a]; ++pass; continue; }
+                const int k = (int)(it - N.emb_idx.begin());
+                A[a].w = TWO_PI / N.emb_period[k];
+                A[a].fs = nin - ne + k; A[a].fc = nin + k;
+                A[a].rs = col_row(T.inmap[n][a], A[a].w, 0);
+                A[a].rc = col_row(T.inmap[n][a], A[a].w, 1);
+            }
+            for (int a = 0; a < nin; ++a)
+                if (A[a].feat < 0) { m[A[a].fs] = A[a].rs; m[A[a].fc] = A[a].rc; }
+            arg[n] = A;
+            new_inmap[n] = m;
+        }
+        const int dx = d0 + (int)T.emb_cols.size();
+        if (dx > 4) return fail("term " + std::to_string(ti) + ": coordinates plus periodic-embedding rows exceed 4 (" + std::to_string(dx) + ")");
+        // expansion of every slot
+        std::vector<std::vector<ExpTerm>> expn(S0);
+        std::vector<Slot> nslots;
+        auto slot_index = [&](int net, std::vector<int> fa, unsigned lap) -> int {
+            std::sort(fa.begin(), fa.end());
+            for (size_t i = 0; i < nslots.size(); ++i) {
+                const Slot& s = nslots[i];
+                if (s.net != net || s.lap != lap || s.order != (int)fa.size()) continue;
+                bool eq = true;
+                for (int a = 0; a < s.order; ++a) eq = eq && s.axes[a] == fa[a];
+                if (eq) return (int)i;
+            }
+            Slot s; s.net = net; s.lap = lap; s.order = lap ? 2 : (int)fa.size();
+            for (int a = 0; a < MAX_DERIV_ORDER; ++a) s.axes[a] = (!lap && a < (int)fa.size()) ? fa[a] : 0;
+            nslots.push_back(s);
+            return (int)nslots.size() - 1;
+        };
+        auto expand_axes = [&](int net, const std::vector<int>& axes, std::vector<ExpTerm>& out) -> int {      // product of per-argument operators
+            const auto& A = arg[net];
+            std::vector<ExpTerm> cur{{1.0, {}, {}}};
+            std::map<int, int> mult;
+            for (int a : axes) {
+                if (a < 0 || a >= (int)A.size()) return fail("descriptor: slot axis out of range");
+                ++mult[a];
+            }
+            for (auto& kv : mult) {
+                const ArgInfo& I = A[kv.first];
+                std::vector<ExpTerm> op;
+                if (I.feat >= 0) op.push_back({1.0, {}, std::vector<int>((size_t)kv.second, I.feat)});
+                else if (kv.second == 1) { op.push_back({I.w, {I.rc}, {I.fs}}); op.push_back({-I.w, {I.rs}, {I.fc}}); }
+                else if (kv.second == 2) {
+                    const double w2 = I.w * I.w;
+                    op.push_back({w2, {I.rc, I.rc}, {I.fs, I.fs}}); op.push_back({-2.0 * w2, {I.rs, I.rc}, {I.fs, I.fc}});
+                    op.push_back({w2, {I.rs, I.rs}, {I.fc, I.fc}}); op.push_back({-w2, {I.rs}, {I.fs}}); op.push_back({-w2, {I.rc}, {I.fc}});
+                } else return fail("term " + std::to_string(ti) + ": derivatives of order > 2 in a periodically embedded coordinate are not supported");
+                std::vector<ExpTerm> nxt;
+                for (auto& x : cur)
+                    for (auto& y : op) {
+                        ExpTerm z{x.k * y.k, x.rows, x.faxes};
+                        z.rows.insert(z.rows.end(), y.rows.begin(), y.rows.end());
+                        z.faxes.insert(z.faxes.end(), y.faxes.begin(), y.faxes.end());
+                        nxt.push_back(z);
+                    }
+                cur.swap(nxt);
+            }
+            out.insert(out.end(), cur.begin(), cur.end());
+            return 0;
+        };
+        for (int s = 0; s < S0; ++s) {
+            const Slot& sl = T.slots[s];
+            if (E.nets[sl.net].emb_idx.empty()) {
+                std::vector<int> fa(sl.axes, sl.axes + (sl.lap ? 0 : sl.order));
+                ExpTerm e{1.0, {}, fa};
+                expn[s].push_back(e);
+                continue;
+            }
+            if (sl.lap) {
+                for (int a = 0; a < 8; ++a)
+                    if ((sl.lap >> a) & 1u)
+                        if (expand_axes(sl.net, {a, a}, expn[s])) return 1;
+            } else if (expand_axes(sl.net, std::vector<int>(sl.axes, sl.axes + sl.order), expn[s])) return 1;
+            for (auto& e : expn[s])
+                if ((int)e.faxes.size() > MAX_DERIV_ORDER) return fail("derivative order > 6 is not supported by the HIP engine");
+        }
+        // new slot list (lap slots of plain networks keep their one-channel form)
+        std::vector<std::vector<int>> eslot(S0);
+        for (int s = 0; s < S0; ++s)
+            for (auto& e : expn[s]) {
+                const Slot& sl = T.slots[s];
+                const bool plain_lap = E.nets[sl.net].emb_idx.empty() && sl.lap;
+                eslot[s].push_back(slot_index(sl.net, e.faxes, plain_lap ? sl.lap : 0u));
+            }
+        const int S1 = (int)nslots.size();
+        const int base_ops = dx + np + S1;
+        std::vector<rp::Instr> nops;
+        auto emit = [&](int code, int a, int b, float imm) -> int {
+            rp::Instr I; I.code = code; I.a = a; I.b = b; I.imm = imm; rp::finalize(I);
+            nops.push_back(I);
+            return base_ops + (int)nops.size() - 1;
+        };
+        std::vector<int> slot_row(S0);
+        for (int s = 0; s < S0; ++s) {
+            int acc = -1;
+            for (size_t i = 0; i < expn[s].size(); ++i) {
+                const ExpTerm& e = expn[s][i];
+                int r = dx + np + eslot[s][i];
+                if (!e.rows.empty()) {
+                    int c = e.rows[0];
+                    for (size_t j = 1; j < e.rows.size(); ++j) c = emit(rp::OP_MUL, c, e.rows[j], 0.f);
+                    if (e.k != 1.0) c = emit(rp::OP_MULC, c, 0, (float)e.k);
+                    r = emit(rp::OP_MUL, c, r, 0.f);
+                } else if (e.k != 1.0) r = emit(rp::OP_MULC, r, 0, (float)e.k);
+                acc = acc < 0 ? r : emit(rp::OP_ADD, acc, r, 0.f);
+            }
+            slot_row[s] = acc;
+        }
+        const int nexp = (int)nops.size();
+        auto remap = [&](int r) -> int {
+            if (r < d0) return r;
+            if (r < d0 + np) return r - d0 + dx;
+            if (r < d0 + np + S0) return slot_row[r - d0 - np];
+            return r - (d0 + np + S0) + base_ops + nexp;
+        };
+        for (auto I : T.ops) {
+            if (!rp::is_nullary(I.code)) I.a = remap(I.a);
+            if (rp::is_binary(I.code)) I.b = remap(I.b);
+            nops.push_back(I);
+        }
+        T.out_row = remap(T.out_row);
+        T.ops.swap(nops);
+        T.slots.swap(nslots);
+        T.d = dx;
+        for (auto& kv : new_inmap) T.inmap[kv.first] = kv.second;
     }
     return 0;
 }

@@ -37,6 +37,17 @@ using namespace pe;
 namespace {
 
 // (re-)evaluate a term's coordinate-only source channels for its current point set
+// embedded terms (periodic input embedding): the installed point set lives in d_upts [n][d_user]; the device rows [n][d] = the
+// coordinates followed by their sin / cos rows are rebuilt from it whenever it changes (set_points, every sampler draw)
+inline float* user_pts(Term& T) { return T.emb_cols.empty() ? T.d_pts : T.d_upts; }
+void embed_points(pinn_engine& E, Term& T) {
+    if (T.emb_cols.empty() || !T.d_upts || T.n <= 0) return;
+    aux::EmbedArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.upts = T.d_upts; a.pts = T.d_pts; a.n = (int)T.n; a.du = T.d_user; a.dx = T.d;
+    for (size_t k = 0; k < T.emb_cols.size() && k < 4; ++k) { a.src[k] = T.emb_cols[k].src; a.is_cos[k] = T.emb_cols[k].is_cos; a.omega[k] = T.emb_cols[k].omega; }
+    aux::launch_embed(a, E.stream);
+}
 void eval_sources(pinn_engine& E, Term& T) {
     if (T.src_root.empty() || T.coupled >= 0) return;
     aux::SrcArgs a;
@@ -407,7 +418,7 @@ int pinn_destroy(pinn_handle h) {
     DeviceScope scope(E.device);
     pinn_comm_destroy(h);
     plat_sync(E.stream);
-    for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_resid); plat_free(T.d_lb); plat_free(T.d_ub); plat_free(T.d_src_prog); plat_free(T.d_src); plat_free(T.d_data); plat_free(T.d_pw); }
+    for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_upts); plat_free(T.d_resid); plat_free(T.d_lb); plat_free(T.d_ub); plat_free(T.d_src_prog); plat_free(T.d_src); plat_free(T.d_data); plat_free(T.d_pw); }
     plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist); plat_free(E.d_inv_ptr); plat_free(E.d_inv_pos); plat_free(E.d_step); plat_free(E.d_draws); plat_free(E.d_sampled); plat_free(E.d_c12);
     for (auto& G : E.groups) {
         plat_free(G.d_prog); plat_free(G.d_slabs); plat_free(G.d_losspart); plat_free(G.d_scratch); plat_free(G.d_rec);
@@ -447,15 +458,19 @@ static int set_points_impl(pinn_handle h, int term, const float* pts, int64_t n,
     if (n > T.pts_cap || !T.d_pts) {                     // grow only: a resampled set of another size reuses the buffer
         plat_sync(E.stream);                             // (an evaluation in flight may still read the old buffer)
         plat_free(T.d_pts);
+        plat_free(T.d_upts);
+        T.d_upts = nullptr;
         T.pts_cap = 0;
         T.d_pts = (float*)plat_malloc(sizeof(float) * n * T.d);
-        if (!T.d_pts) return fail("device allocation failed (points)");
+        if (!T.emb_cols.empty()) T.d_upts = (float*)plat_malloc(sizeof(float) * n * T.d_user);
+        if (!T.d_pts || (!T.emb_cols.empty() && !T.d_upts)) return fail("device allocation failed (points)");
         T.pts_cap = n;
     }
-    int rc = device ? plat_d2d(T.d_pts, pts, sizeof(float) * n * T.d, E.stream) : plat_h2d(T.d_pts, pts, sizeof(float) * n * T.d, E.stream);
+    int rc = device ? plat_d2d(user_pts(T), pts, sizeof(float) * n * T.d_user, E.stream) : plat_h2d(user_pts(T), pts, sizeof(float) * n * T.d_user, E.stream);
     if (rc) return fail(std::string("copy of points failed: ") + plat_last_error());
-    plat_sync(E.stream);
     T.n = n;
+    embed_points(E, T);
+    plat_sync(E.stream);
     T.n_norm = n_norm > 0 ? n_norm : n;
     T.data_n = 0;                                        // per-point data and weights belong to the previous set
     T.pw_n = 0;
@@ -678,6 +693,25 @@ static int forward_jets(pinn_engine& E, int net, const pk::SpecInfo* sp, const f
         E.d_phi_out = (float*)plat_malloc(sizeof(float) * E.phi_cap * E.phi_chan);
         if (!E.d_phi_pts || !E.d_phi_out) { E.phi_cap = 0; E.phi_chan = 0; return fail("device allocation failed (phi)"); }
     }
+    std::vector<float> feats;                                  // periodic embedding: [arguments] -> [features] on the host (this entry point takes host points)
+    if (!N.emb_idx.empty()) {
+        const int nin = N.n_inputs(), ne = (int)N.emb_idx.size(), F = N.sizes[0];
+        feats.resize((size_t)n * F);
+        for (int64_t q = 0; q < n; ++q) {
+            int pass = 0;
+            for (int a = 0; a < nin; ++a) {
+                const auto it = std::find(N.emb_idx.begin(), N.emb_idx.end(), a);
+                const double x = pts[q * nin + a];
+                if (it == N.emb_idx.end()) { feats[q * F + pass++] = (float)x; continue; }
+                const int k = (int)(it - N.emb_idx.begin());
+                const double ph = 6.283185307179586476925286766559 / N.emb_period[k] * x;
+                feats[q * F + nin - ne + k] = (float)std::sin(ph);
+                feats[q * F + nin + k] = (float)std::cos(ph);
+            }
+        }
+        plat_h2d(E.d_phi_pts, feats.data(), sizeof(float) * n * F, E.stream);
+        plat_sync(E.stream);                                   // (feats is a pageable temporary)
+    } else
     plat_h2d(E.d_phi_pts, pts, sizeof(float) * n * N.sizes[0], E.stream);
     pk::GroupArgs ga;
     std::memset(&ga, 0, sizeof ga);
@@ -741,6 +775,7 @@ int pinn_derivative(pinn_handle h, int net, const float* theta, int64_t p, const
     if (order < 0 || order > MAX_DERIV_ORDER || (order > 0 && !axes)) return fail("pinn_derivative: order must be 0..6 (with `order` axes)");
     const Net& N = E.nets[net];
     if (!E.netplans[net].spec) return fail("pinn_derivative: network is not used by any term");
+    if (!N.emb_idx.empty()) return fail("pinn_derivative: not available for a network behind a periodic input embedding (use pinn_residual on a term that carries the derivative)");
     Slot sl;
     sl.net = net; sl.order = order; sl.lap = 0;
     for (int a = 0; a < MAX_DERIV_ORDER; ++a) sl.axes[a] = a < order ? axes[a] : 0;
@@ -774,21 +809,22 @@ int pinn_set_sampler(pinn_handle h, int term, int kind, const float* lb, const f
     if (term < 0 || term >= (int)E.terms.size()) return fail("pinn_set_sampler: term index out of range");
     Term& T = E.terms[term];
     if (kind < 0 || kind > 3) return fail("pinn_set_sampler: kind must be 0 (fixed set), 1 (uniform), 2 (Latin hypercube) or 3 (Sobol)");
-    if (kind == 3 && T.d > 8) return fail("pinn_set_sampler: the Sobol sampler covers up to 8 axes");
+    if (kind == 3 && T.d_user > 8) return fail("pinn_set_sampler: the Sobol sampler covers up to 8 axes");
     if (kind == 0) { T.sampler = 0; return 0; }
     if (!lb || !ub || n <= 0) return fail("pinn_set_sampler: bounds and a positive point count are required");
     if (!T.d_lb) { T.d_lb = (float*)plat_malloc(sizeof(float) * 8); T.d_ub = (float*)plat_malloc(sizeof(float) * 8); }
     if (!T.d_lb || !T.d_ub) return fail("device allocation failed (sampler)");
-    plat_h2d(T.d_lb, lb, sizeof(float) * T.d, E.stream);
-    plat_h2d(T.d_ub, ub, sizeof(float) * T.d, E.stream);
+    plat_h2d(T.d_lb, lb, sizeof(float) * T.d_user, E.stream);
+    plat_h2d(T.d_ub, ub, sizeof(float) * T.d_user, E.stream);
     T.seed = (unsigned)(seed ^ (seed >> 32)) + 0x9E3779B9U * (unsigned)(term + 1);
     if (kind == 3 && seed == 0) T.seed = 0;              // un-randomised Sobol: the same design on every draw
     T.draws = 0;
     // allocate / size the term's point buffer through the normal path with a first draw
-    std::vector<float> tmp((size_t)n * T.d, 0.f);
+    std::vector<float> tmp((size_t)n * T.d_user, 0.f);
     if (set_points_impl(h, term, tmp.data(), n, 0, false)) return 1;
     T.sampler = kind;                                    // only now: every check and allocation above has succeeded
-    aux::launch_sample(kind, T.d_pts, (int)(n * T.d), T.d, T.d_lb, T.d_ub, T.seed, T.draws++, E.stream);
+    aux::launch_sample(kind, user_pts(T), (int)(n * T.d_user), T.d_user, T.d_lb, T.d_ub, T.seed, T.draws++, E.stream);
+    embed_points(E, T);
     eval_sources(E, T);
     plat_sync(E.stream);
     return 0;
@@ -857,7 +893,7 @@ int pinn_get_points(pinn_handle h, int term, float* pts, int64_t n) {
     if (term < 0 || term >= (int)E.terms.size()) return fail("pinn_get_points: term index out of range");
     Term& T = E.terms[term];
     if (!T.d_pts || n != T.n) return fail("pinn_get_points: the term holds " + std::to_string(T.n) + " points");
-    if (plat_d2h(pts, T.d_pts, sizeof(float) * (size_t)n * T.d, E.stream)) return fail("D2H copy failed");
+    if (plat_d2h(pts, user_pts(T), sizeof(float) * (size_t)n * T.d_user, E.stream)) return fail("D2H copy failed");
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
     return 0;
 }
@@ -920,7 +956,8 @@ static int adam_steps_graph(pinn_engine& E, int nsteps, float lr, float beta1, f
         for (size_t t = 0; t < E.terms.size(); ++t) {
             Term& T = E.terms[t];
             if (T.sampler != 0) {
-                aux::launch_sample_dev(T.sampler, T.d_pts, (int)(T.n * T.d), T.d, T.d_lb, T.d_ub, T.seed, E.d_draws + t, E.stream);
+                aux::launch_sample_dev(T.sampler, user_pts(T), (int)(T.n * T.d_user), T.d_user, T.d_lb, T.d_ub, T.seed, E.d_draws + t, E.stream);
+                embed_points(E, T);
                 eval_sources(E, T);
             }
         }
@@ -984,7 +1021,8 @@ int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta
             for (size_t t = 0; t < E.terms.size(); ++t) {            // resampling strategies: fresh points every evaluation, on device
                 Term& T = E.terms[t];
                 if (T.sampler != 0) {
-                    aux::launch_sample(T.sampler, T.d_pts, (int)(T.n * T.d), T.d, T.d_lb, T.d_ub, T.seed, T.draws++, E.stream);
+                    aux::launch_sample(T.sampler, user_pts(T), (int)(T.n * T.d_user), T.d_user, T.d_lb, T.d_ub, T.seed, T.draws++, E.stream);
+                    embed_points(E, T);
                     eval_sources(E, T);
                 }
             }

@@ -38,6 +38,12 @@ struct Net {
     int kind = 0;                    // 0: Chain of Dense layers; 1: the reference's DGM architecture (src/dgm.jl:97-115)
     int dgm_layers = 0;              // DGM: number of gated (LSTM-type) layers
     int act2 = 0;                    // DGM: activation of the H gate (activation2); `act` is activation1
+    // periodic input embedding in front of the chain (Boltz.Layers.PeriodicEmbedding(idxs, periods), reference test
+    // test/CUDA/nnpde_cuda__1d_pde_dirichlet_bc_cuda.jl:26,48): inputs emb_idx[k] (0-based) leave the input list and come back at its end
+    // as sin(2 pi x / period) for all k, then cos(2 pi x / period) for all k; sizes[0] counts the FEATURES the first Dense layer takes
+    std::vector<int> emb_idx;
+    std::vector<double> emb_period;
+    int n_inputs() const { return sizes[0] - (int)emb_idx.size(); }       // arguments of the dependent variable
     int nparams() const {
         if (kind == 1) { const int d = sizes[0], M = sizes[1]; return M * d + M + dgm_layers * (4 * M * d + 4 * M * M + 4 * M) + M + 1; }
         int n = 0;
@@ -51,8 +57,13 @@ struct Net {
     }
 };
 struct LinearForm { float k = 0.f; float a[pk::LIN_MAX_C] = {}; float b[pk::LIN_MAX_SRC] = {}; };
+struct EmbCol { int src; double omega; int is_cos; };      // device coordinate row = sin / cos (omega x coordinate `src`)
 struct Term {
-    int d = 0;
+    int d = 0;                       // coordinate rows of the device point set (embedded terms: d_user rows + emb_cols)
+    int d_user = 0;                  // coordinates per point at the C ABI (pinn_set_points, samplers, pinn_get_points); == d without embeddings
+    std::vector<EmbCol> emb_cols;    // rows d_user .. d-1, written by aux::k_embed whenever the point set changes (descriptor.cpp: apply_embeddings)
+    float* d_upts = nullptr;         // embedded terms: the point set as installed, [n][d_user]; otherwise unused (d_pts is the set)
+    EmbCol* d_emb_cols = nullptr;
     bool linear = false;             // the fused tape is affine in the jet channels / sources (plan.cpp: detect_linear)
     LinearForm lin;
     std::vector<Slot> slots;
@@ -236,6 +247,7 @@ struct pinn_engine {
 namespace pe {
 // descriptor.cpp
 int parse_descriptor(const char* text, pinn_engine& E);
+int apply_embeddings(pinn_engine& E);
 // sexpr.cpp: the symbolic front end ("pinnir 2"): lhs / rhs of an equation as prefix s-expressions -> jet slots + tape
 struct SexprContext {
     std::vector<std::string> params;                         // PDE parameter names, in theta.p order

@@ -63,6 +63,13 @@ class NetIR:
     sizes: Tuple[int, ...]
     act: str
     theta_off: int
+    embed: Tuple[Tuple[int, float], ...] = ()      # PeriodicEmbedding in front of the chain: (0-based input index, period) pairs
+
+    def lines(self, i: int) -> list:
+        out = [f"net {i} {self.act} {self.theta_off} {len(self.sizes)} " + " ".join(str(s) for s in self.sizes)]
+        if self.embed:
+            out.append(f"embed {i} {len(self.embed)} " + " ".join(f"{int(ix)} {float(p)!r}" for ix, p in self.embed))
+        return out
 
 
 @dataclass
@@ -94,7 +101,7 @@ class ProblemIR:
                "pnames " + " ".join(self.param_names),
                f"nets {len(self.nets)}"]
         for i, n in enumerate(self.nets):
-            out.append(f"net {i} {n.act} {n.theta_off} {len(n.sizes)} " + " ".join(str(s) for s in n.sizes))
+            out += n.lines(i)
             out.append(f"netvar {i} {self.depvar_names[i]} {len(self.depvar_inputs[i])} " + " ".join(self.depvar_inputs[i]))
         out.append(f"terms {len(self.terms)}")
         for i, t in enumerate(self.terms):
@@ -122,7 +129,7 @@ class ProblemIR:
                "defaults " + " ".join(repr(float(v)) for v in list(self.p_defaults)[: self.nparams]),
                f"nets {len(self.nets)}"]
         for i, n in enumerate(self.nets):
-            out.append(f"net {i} {n.act} {n.theta_off} {len(n.sizes)} " + " ".join(str(s) for s in n.sizes))
+            out += n.lines(i)
         out.append(f"terms {len(self.terms)}")
         for i, t in enumerate(self.terms):
             out += self._term_lines(i, t)

@@ -37,11 +37,30 @@ class Dense:
     activation: str = "identity"
 
 
-class Chain:
-    """Lux.Chain of Dense layers.  The engine supports the shape every PINN chain in the reference's PDE tests
-    has: tanh / sigmoid (per layer) or sin (all layers) on the hidden layers, identity on the last, single output."""
+@dataclass
+class PeriodicEmbedding:
+    """[3P] Boltz.Layers.PeriodicEmbedding(idxs, periods) as the FIRST layer of a Chain (reference:
+    test/CUDA/nnpde_cuda__1d_pde_dirichlet_bc_cuda.jl:26,48): inputs `idxs` (1-based, as in Julia) leave the input list and come back at
+    its end as sin(2 pi x / period) for all of them, then cos(2 pi x / period) for all of them; the other inputs pass through in order."""
+    idxs: Sequence[int]
+    periods: Sequence[float]
 
-    def __init__(self, *layers: Dense):
+
+class Chain:
+    """Lux.Chain of Dense layers, optionally behind a PeriodicEmbedding.  The engine supports the shape every PINN chain in the
+    reference's PDE tests has: tanh / sigmoid (per layer) or sin (all layers) on the hidden layers, identity on the last, single output."""
+
+    def __init__(self, *layers):
+        self.embed = ()
+        if layers and isinstance(layers[0], PeriodicEmbedding):
+            emb, layers = layers[0], layers[1:]
+            if len(emb.idxs) != len(emb.periods) or not emb.idxs:
+                raise ValueError("PeriodicEmbedding needs one period per embedded input")
+            if len(set(emb.idxs)) != len(emb.idxs) or min(emb.idxs) < 1 or any(not (p > 0) for p in emb.periods):
+                raise ValueError("PeriodicEmbedding: distinct 1-based input indices and positive periods")
+            self.embed = tuple((int(i) - 1, float(p)) for i, p in zip(emb.idxs, emb.periods))
+        if any(isinstance(l, PeriodicEmbedding) for l in layers):
+            raise ValueError("PeriodicEmbedding is supported as the first layer of a Chain only")
         if not layers:
             raise ValueError("Chain needs at least one layer")
         for a, b in zip(layers[:-1], layers[1:]):
@@ -49,6 +68,9 @@ class Chain:
                 raise ValueError("DimensionMismatch: consecutive Dense layers do not chain")
         self.layers = list(layers)
         self.sizes = tuple([layers[0].n_in] + [l.n_out for l in layers])
+        self.n_inputs = self.sizes[0] - len(self.embed)          # arguments of the dependent variable (features = sizes[0])
+        if self.embed and (self.n_inputs < len(self.embed) or max(i for i, _ in self.embed) >= self.n_inputs):
+            raise ValueError("DimensionMismatch: the first Dense layer must take (inputs + number of embedded inputs) features")
         if len(layers) < 2:
             raise ValueError("the HIP engine needs at least one hidden layer")
         if layers[-1].activation != "identity":
@@ -519,7 +541,7 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
     terms = sym_pde + sym_bc + sym_data
     ir = ProblemIR(
         ntheta=int(flat.size),
-        nets=[NetIR(tuple(ch.sizes), ch.act, off) for ch, off in zip(chains, net_offs)],
+        nets=[NetIR(tuple(ch.sizes), ch.act, off, getattr(ch, "embed", ())) for ch, off in zip(chains, net_offs)],
         terms=terms, nparams=NP, nparams_estim=NE, p_theta_off=nnet,
         p_defaults=list(default_p) if default_p is not None else [],
         param_names=[str(p) for p in eq_params], depvar_names=list(vi.depvars),
@@ -637,7 +659,7 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
         losses = losses_and_reweight(theta)
         return float(np.dot(weights_now(), losses)) + add_term(theta)[0]
 
-    phis = [Phi(engine, i, slice(net_offs[i], net_offs[i] + chains[i].nparams), chains[i].sizes[0]) for i in range(len(chains))]
+    phis = [Phi(engine, i, slice(net_offs[i], net_offs[i] + chains[i].nparams), getattr(chains[i], "n_inputs", chains[i].sizes[0])) for i in range(len(chains))]
     phi = phis if discretization.multioutput else phis[0]
     discretization.phi = phi
 

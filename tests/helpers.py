@@ -8,7 +8,7 @@ import pinn_oracle as po
 def oracle_problem(npde, pde_system, chains, param_estim=False):
     vi = npde.get_vars(pde_system.ivs, pde_system.dvs)
     sym_iv = {str(v): v for v in pde_system.ivs}
-    ochains = [po.Chain(tuple(c.sizes), c.act) for c in chains]
+    ochains = [po.Chain(tuple(c.sizes), c.act, tuple(getattr(c, "embed", ()))) for c in chains]
     depfuncs = [d.func for d in pde_system.dvs]
     net_indvars = [tuple(sym_iv[n] for n in vi.dict_depvar_input[str(f)]) for f in depfuncs]
 

@@ -44,6 +44,71 @@ def theta_for(chain, seed):
     return po.glorot_theta(po.Chain(tuple(chain.sizes), chain.act), np.random.default_rng(seed))
 
 
+def periodic_heat(npde, inner=16, hidden=2, act="sigmoid"):
+    """test/CUDA/nnpde_cuda__1d_pde_dirichlet_bc_cuda.jl:26-48: Dt(u) ~ Dxx(u) on [0, 1] x [0, 2 pi] behind
+    Chain(PeriodicEmbedding([2], [2 pi]), Dense(3, inner, sigma), ..., Dense(inner, 1))."""
+    t, x = npde.parameters("t x")
+    (u,) = npde.variables("u")
+    Dt, Dxx = npde.Differential(t), npde.Differential(x) ** 2
+    eq = npde.Eq(Dt(u(t, x)), Dxx(u(t, x)))
+    bcs = [npde.Eq(u(0, x), sp.cos(x)), npde.Eq(u(t, 0), sp.exp(-t)), npde.Eq(u(t, 2 * sp.pi), sp.exp(-t))]
+    dom = [npde.In(t, npde.Interval(0.0, 1.0)), npde.In(x, npde.Interval(0.0, 2 * np.pi))]
+    layers = [npde.PeriodicEmbedding([2], [2 * np.pi]), npde.Dense(3, inner, act)] + [npde.Dense(inner, inner, act) for _ in range(hidden - 1)] + [npde.Dense(inner, 1)]
+    return npde.PDESystem([eq], bcs, dom, [t, x], [u(t, x)]), npde.Chain(*layers)
+
+
+def test_periodic_embedding_heat_equation(npde, use_emu):
+    """PeriodicEmbedding in front of the Dense stack: the engine rewrites the term over the features (t, sin x, cos x) by the chain rule
+    (csrc/descriptor.cpp: apply_embeddings); losses, gradient, residual and phi against the oracle, which embeds inside the chain and
+    differentiates with respect to (t, x) directly."""
+    sysm, chain = periodic_heat(npde)
+    assert chain.sizes[0] == 3 and chain.n_inputs == 2 and chain.embed == ((1, 2 * np.pi),)
+    strat = npde.QuasiRandomTraining(60, bcs_points=23, sampling_alg=npde.SobolSample(seed=5), resampling=False, minibatch=1)
+    rep, prob, sets, th = check(npde, sysm, [chain], strat, theta_for(chain, 11), weights=[1.0, 2.0, 0.5, 1.5], mode="exact", tol=2e-5)
+    assert "embed 0 1 1 " in rep.ir.to_descriptor() and all(s.shape[0] == 2 for s in sets)
+    r = rep.loss_functions.datafree_pde_loss_functions[0](sets[0], th)
+    np.testing.assert_allclose(r, po.residual_values(prob, th, 0, sets[0], mode="exact"), atol=3e-5)
+    np.testing.assert_allclose(rep.phi(sets[0], th), po.phi_values(prob.chains[0], th, sets[0]), atol=2e-6)
+    # u is 2 pi - periodic in x by construction
+    pts = np.array([[0.3, 0.7], [0.4, 5.0]])
+    np.testing.assert_allclose(rep.phi(pts, th), rep.phi(pts + np.array([[0.0], [2 * np.pi]]), th), atol=2e-6)
+    # the installed point sets come back in the caller's coordinates
+    np.testing.assert_allclose(rep.engine.get_points(0, 2, sets[0].shape[1]), sets[0], atol=1e-6)
+    # the same problem through the s-expression front end (the form the Julia glue emits)
+    eng2 = npde._lib.Engine(rep.ir.to_descriptor2())
+    for k, sset in enumerate(sets):
+        eng2.set_points(k, sset)
+    l1, g1 = rep.engine.loss_grad(th)
+    l2, g2 = eng2.loss_grad(th)
+    np.testing.assert_allclose(l2, l1, rtol=1e-6)
+    np.testing.assert_allclose(g2, g1, rtol=0, atol=2e-6 * np.abs(g1).max())
+    # device samplers draw in the caller's coordinates; the embedding rows follow every draw
+    eng2.set_sampler(0, [0.0, 0.0], [1.0, 2 * np.pi], 50, seed=7, kind=1)
+    drawn = eng2.get_points(0, 2, 50)
+    assert drawn.shape == (2, 50) and drawn[1].max() <= 2 * np.pi and drawn[1].max() > 1.0
+    ls, gs = eng2.loss_grad(th)
+    ref = po.loss_and_grad(prob, th, [drawn.astype(np.float64)] + [s for s in sets[1:]], mode="exact")
+    le, e2, ei = helpers.rel_errors(ls, gs, ref)
+    assert le.max() < 2e-5 and e2 < 2e-5 and ei < 2e-5, (le, e2, ei)
+
+
+def test_periodic_embedding_reference_shape_and_limits(npde, use_emu):
+    """the reference test's own chain (6 x 30 sigmoid behind the embedding) on a handful of points; what the rewrite refuses"""
+    sysm, chain = periodic_heat(npde, inner=30, hidden=6)
+    strat = npde.QuasiRandomTraining(24, bcs_points=9, sampling_alg=npde.SobolSample(seed=2), resampling=False, minibatch=1)
+    check(npde, sysm, [chain], strat, theta_for(chain, 3), mode="exact", tol=2e-5)
+    t, x = npde.parameters("t x")
+    (u,) = npde.variables("u")
+    eq3 = npde.Eq(npde.Differential(t)(u(t, x)), (npde.Differential(x) ** 3)(u(t, x)))
+    sys3 = npde.PDESystem([eq3], sysm.bcs, sysm.domain, [t, x], [u(t, x)])
+    with pytest.raises(RuntimeError, match="order > 2 in a periodically embedded coordinate"):
+        npde.symbolic_discretize(sys3, npde.PhysicsInformedNN(chain, strat, init_params=theta_for(chain, 3)))
+    with pytest.raises(ValueError, match="first layer"):
+        npde.Chain(npde.Dense(2, 8, "tanh"), npde.PeriodicEmbedding([1], [1.0]), npde.Dense(8, 1))
+    with pytest.raises(ValueError, match="DimensionMismatch"):
+        npde.Chain(npde.PeriodicEmbedding([3], [1.0]), npde.Dense(3, 8, "tanh"), npde.Dense(8, 1))
+
+
 def test_small_poisson_tanh_and_sigmoid(npde, use_emu):
     for act, seed in (("tanh", 1), ("sigmoid", 2)):
         sysm, chain = poisson2d(npde, act)
