@@ -513,6 +513,31 @@ def test_cuda_1d_pde_neumann_bc(npde, lib):
     assert _ON_EMU or err <= 1.0
 
 
+def test_cuda_1d_pde_dirichlet_bc_periodic_embedding(npde, lib):
+    """test/CUDA/nnpde_cuda__1d_pde_dirichlet_bc_cuda.jl:26-70: u_t = u_xx on [0, 1] x [0, 2 pi], u(0, x) = cos x, u(t, 0) = u(t, 2 pi) =
+    exp(-t); Chain(PeriodicEmbedding([2], [2 pi]), Dense(3, 30, sigma), 5 x Dense(30, 30, sigma), Dense(30, 1)), StochasticTraining(1000),
+    Adam(0.01) x 1000 then Adam(0.001) x 1000; `u_predict ≈ u_real atol = 1.0` on the 0.01 grid."""
+    t, x = npde.parameters("t x")
+    (u,) = npde.variables("u")
+    eq = npde.Eq(npde.Differential(t)(u(t, x)), (npde.Differential(x) ** 2)(u(t, x)))
+    bcs = [npde.Eq(u(0, x), sp.cos(x)), npde.Eq(u(t, 0), sp.exp(-t)), npde.Eq(u(t, 2 * sp.pi), sp.exp(-t))]
+    dom = [npde.In(t, npde.Interval(0.0, 1.0)), npde.In(x, npde.Interval(0.0, 2 * math.pi))]
+    inner = 30
+    chain = npde.Chain(npde.PeriodicEmbedding([2], [2 * math.pi]), npde.Dense(3, inner, "sigmoid"),
+                       *[npde.Dense(inner, inner, "sigmoid") for _ in range(5)], npde.Dense(inner, 1))
+    theta0 = npde.initialparameters(np.random.default_rng(100), chain)
+    n, iters = (60, 100) if _ON_EMU else (1000, 1000)
+    prob = npde.discretize(npde.PDESystem([eq], bcs, dom, [t, x], [u(t, x)]),
+                           npde.PhysicsInformedNN(chain, npde.StochasticTraining(n, rng=np.random.default_rng(3)), init_params=theta0))
+    assert "HP32_NHH5_D3" in prob.pinnrep.engine.describe()             # the network runs over the three features (t, sin x, cos x)
+    theta, losses = train(npde, prob, [(0.01, iters), (0.001, iters)])
+    pts = grid2((0.0, 1.0), (0.0, 2 * math.pi), 0.01)
+    err = np.linalg.norm(prob.pinnrep.phi(pts, theta)[0] - np.exp(-pts[0]) * np.cos(pts[1]))
+    print(f"cuda 1d pde dirichlet (PeriodicEmbedding): ||u_predict - u_real||_2 = {err:.3f} over {pts.shape[1]} points (reference tolerance 1.0), "
+          f"loss {losses[0]:.3e} -> {losses[-1]:.3e}")
+    assert _ON_EMU or err <= 1.0
+
+
 def test_cuda_2d_pde(npde, lib):
     """test/CUDA/nnpde_cuda__2d_pde_cuda.jl:14-70: u_t = u_xx + u_yy on [0, 2]^3 with Dirichlet data from exp(x + y) cos(x + y + 4t),
     4 x 25 sigma network, GridTraining(0.05) (68,921 interior + 5 x 1,681 boundary points), Adam(0.01) x 2500 then Adam(0.001) x 2500;
