@@ -374,7 +374,11 @@ def main():
                          "events": f"HIP events around every fused kernel on every {every}. step of the timed region: {kern_ms.shape[0]} launches averaged",
                          "note": "frac = executed (fp32-equivalent) flops / kernel time / fp32 MFMA peak (157.3 TF/s at the 2.4 GHz peak clock; the shader clock under this "
                                  "load is ~1.9 GHz); traffic = HBM-side bytes per launch from the committed rocprofv3 --pmc passes named in traffic_source "
-                                 "(null: no profile for this kernel and size)"})
+                                 "(null: no profile for this kernel and size)" +
+                                 ("; gemm = split-bf16: the hidden-layer forward / dA products execute on the bf16 matrix pipe as 6 bf16 MFMAs per fp32 "
+                                  "product block (fp32-level results), so `frac` against the fp32 pipe's peak can exceed what that pipe alone could do — "
+                                  "frac_mixed_pipes = achieved / mixed_pipe_peak (2/3 of the flops at 2.56x the fp32 rate, 1/3 at the fp32 rate) is the "
+                                  "distance to the ceiling" if roof.get("gemm") else "")})
             line["roofline"] = roof
             line["roofline_kernels"] = per_kernel
         if world == 1 and not sharded and not args.no_cpu_baseline and args.workload == "cfg2":
