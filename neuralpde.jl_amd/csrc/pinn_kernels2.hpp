@@ -89,9 +89,17 @@
 //     evaluation, cfg3 1268 -> 1028 us, full-size goldens unchanged at 1.7e-7 (gradient) / 4e-7 (losses), bit-reproducible.
 //   2: dW = dZ A^T as well (both operands staged transposed as bf16 pieces, K = 32 points = two column groups): correct, but the 16-bit
 //     scattered staging stores cost more than the MFMAs save — 319 vs 310 us (profiles/r03_experiments.txt).
+//   3 (H = 64 kernels): dW on the bf16 pipe WITHOUT any transposed staging.  The exchange images change to "planes" — a fragment's two
+//     neuron-tile halves in separate 512-byte planes of 8-byte slots, slot(g, c) = 16 g + (c ^ 4 (g >> 1)) — so that gfx950's LDS transpose
+//     read (ds_read_b64_tr_b16: a 16-lane group turns a [4 points][16 neurons] block into per-neuron columns) delivers both operands of
+//     dW = dZ A^T in MFMA operand order (K = 32 points = two column groups) STRAIGHT OUT OF the B-operand images: dZ is already there for
+//     the dA GEMM, the a-jets are published like a forward activation.  No dZ^T / A^T staging, no ZT region (the freed LDS holds records
+//     again), 48 bf16 MFMAs instead of 64 fp32 MFMAs of twice the length per layer and tile.  The plane layout with the XOR on the
+//     point index is conflict-free for the transpose reads, the plain 8-byte reads of the forward / dA B operands and the 8-byte piece
+//     stores (tools/micro/tr_probe.hip, profiles/r03_experiments.txt).
 //   0: fp32 MFMAs everywhere (rounds 1-2).
 #ifndef PINN_F2_BF16X
-#define PINN_F2_BF16X 1
+#define PINN_F2_BF16X 3
 #endif
 // the 128-wide kernels (8 waves, one neuron tile each, weight fragments fetched per k-block instead of per layer) take the split-operand
 // forward / dA GEMMs as well wherever the wider exchange buffers still leave the un-chunked dW staging in LDS (NG <= 4: every 2-D set)
@@ -205,16 +213,23 @@ struct Spec2 {
     // inside the second exchange buffer, which the reverse sweep does not use otherwise (NSTAGE = 2: two more barriers per layer).
     static constexpr int XSZ_BF = NG * KB * 3 * 256;
     static constexpr int UP_SZ = (((NW + 1) * NG * 16 + 63) / 64) * 64;
-    static constexpr bool BF_FULL = (2 * XSZ_BF + NG * MT * 256 + UP_SZ) * 4 <= 160 * 1024;
-    static constexpr bool BF_HALF = !BF_FULL && PINN_F2_BF16X_TWO_STAGE && (MT * (MT / NW) * 4 > 16) && (NG % 2 == 0) && (PINN_F2_BF16X < 2) &&
+    // (level 3, TR_SHAPE: no staging at all — dW reads its operands out of the exchange images with the LDS transpose read)
+    static constexpr bool TR_SHAPE = (PINN_F2_BF16X >= 3) && HP_ == 64 && NW == 4 && (NHH_ * (MT / NW) * MT * 4 <= 96);
+    static constexpr bool BF_FULL = (2 * XSZ_BF + (TR_SHAPE ? 0 : NG * MT * 256) + UP_SZ) * 4 <= 160 * 1024;
+    static constexpr bool BF_HALF = !BF_FULL && PINN_F2_BF16X_TWO_STAGE && (MT * (MT / NW) * 4 > 16) && (NG % 2 == 0) && (PINN_F2_BF16X != 2) &&
                                     (2 * XSZ_BF + UP_SZ) * 4 <= 160 * 1024 && (NG / 2) * 16 * HP_ + (NG / 2) * MT * 256 <= XSZ_BF;
     static constexpr bool BFX = BFIMG && (BF_FULL || BF_HALF);
     static constexpr int NSTAGE = (BFX && BF_HALF) ? 2 : 1;          // passes of the dW staging + GEMM over the column groups
     static constexpr int XSZB = BFX ? XSZ_BF : XSZ;                  // floats of one exchange buffer
     // 2: dW = dZ A^T on the bf16 pipe as well: both operands are staged TRANSPOSED as bf16 pieces in MFMA operand order, K = 32 points = two
     // column groups per MFMA (NG even): dZ^T fragments wave-private [pair][t][piece][64][8], A^T fragments cooperative in X1 [pair][tile][piece][64][8]
-    static constexpr bool BFX_DW = BFX && (PINN_F2_BF16X >= 2) && (NG % 2 == 0);
-    static constexpr int ZTW = BFX_DW ? (NG / 2) * (MT / NW) * 3 * 256 : (NG / NSTAGE) * (MT / NW) * 256;      // floats of one wave's private dZ^T staging
+    // 3: dW operands by LDS transpose reads out of the plane-layout exchange images (H = 64 kernels: weight fragments prefetched, dW sums in
+    // registers); a shape-level decision — every member of a merged launch stores its dW tiles in the same (natural) order.  An odd number
+    // of column groups pads the last K = 32 block with zeros.
+    static constexpr bool BFX_TR = BFX && TR_SHAPE;
+    static constexpr bool BFX_DW = BFX && !BFX_TR && (PINN_F2_BF16X == 2) && (NG % 2 == 0);
+    static constexpr bool DW_NATURAL = BFX_DW || BFX_TR;             // dW tiles in natural order: column c of tile ti = input neuron 16 ti + c
+    static constexpr int ZTW = BFX_TR ? 0 : (BFX_DW ? (NG / 2) * (MT / NW) * 3 * 256 : (NG / NSTAGE) * (MT / NW) * 256);      // floats of one wave's private dZ^T staging
     static constexpr int LDS_UP = (((NW + 1) * NG * 16 + 63) / 64) * 64;    // NW x output partials + seed broadcast (UB)
     static_assert(PG_ >= 1 && PG_ <= 4, "one tape wave per point group");
     // when X0 | X1 | ZT would not fit in 160 KiB (H = 128 with 8 jet channels) the dW operands are staged one column group
@@ -340,6 +355,19 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
     const vint g = lane >> 4;
     const vint c = lane & vint(15);
     const vbool g0 = veq(g, 0);
+    // this lane's 8-byte slot in a plane of a split-operand exchange image (S::BFX_TR; floats), else its 16-byte slot
+    const vint sw = S::BFX_TR ? (((g << 4) + (c ^ ((g >> 1) << 2))) << 1) : (lane << 2);
+    // transpose-read addresses of the dW operands (S::BFX_TR): lane (g, c) of a 16-lane group reads the slot of row group c & 3 at point
+    // 8 (g & 1) + 4 jh + (c >> 2) of column group 2 qp + (g >> 1) and receives neuron c of the tile at the points k = 8 g + 4 jh + 0..3 of the
+    // K = 32 block (column group 2 qp + (k >> 4), point k & 15)
+    vint trb[2];
+    PINN_UNROLL for (int jh = 0; jh < 2; ++jh) {
+        const vint gg = c & vint(3), pc = ((g & vint(1)) << 3) + vint(4 * jh) + (c >> 2);
+        trb[jh] = (((gg << 4) + (pc ^ ((gg >> 1) << 2))) << 1);
+    }
+    vint trbq[2];                                            // ... + the offset of the pair's second column group for k >= 16
+    PINN_UNROLL for (int jh = 0; jh < 2; ++jh) trbq[jh] = trb[jh] + (g >> 1) * vint(S::KB * 3 * 256);
+    const vbool klo = vlt(g, 2);                             // lanes whose k < 16 (first column group of a pair)
     const float* P = ga.packed;
     // the activation kind is a template parameter: every kernel is straight-line code behind its GEMMs (no activation branches for the
     // optimiser to hoist); sin variants are compiled only for the specs registered with PINN_INSTANTIATE*_SIN
@@ -465,7 +493,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                         const int tile = w * MTW + t;
                         vbf4 ph, pm, pl;
                         split3_bf16(A[q][t], ph, pm, pl);
-                        const vint at = vint(((q * S::KB + (tile >> 1)) * 3) * 256 + (tile & 1) * 2) + (lane << 2);
+                        const vint at = vint(((q * S::KB + (tile >> 1)) * 3) * 256 + (tile & 1) * (S::BFX_TR ? 128 : 2)) + sw;
                         lds_store_bf4(X, at, ph);
                         lds_store_bf4(X, at + vint(256), pm);
                         lds_store_bf4(X, at + vint(512), pl);
@@ -475,6 +503,11 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
             PINN_UNROLL for (int q = 0; q < NG; ++q)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t)
                     lds_store4(X, vint(((q * MT + w * MTW + t) * 64) * 4) + (lane << 2), A[q][t]);
+        };
+        // B operand (this lane's point, k = 8 g + j) of fragment `frag` = (column group, k-block, piece) of an exchange image
+        auto ld_bfrag = [&](const float* X, int frag) -> vbf8 {
+            if (S::BFX_TR) return cat_bf8(lds_load_bf4(X, vint(frag * 256) + sw), lds_load_bf4(X, vint(frag * 256 + 128) + sw));
+            return lds_load_bf8(X, vint(frag * 256) + (lane << 2));
         };
         // six bf16 MFMAs = one fp32-accurate 16x16 (x) 16x32 product (see PINN_F2_BF16X)
         auto mfma_split = [&](const vbf8 (&a)[3], const vbf8 (&b)[3], vfloat4 c) -> vfloat4 {
@@ -532,6 +565,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                     PINN_UNROLL for (int t = 0; t < MTW; ++t) bv[t] = ld_bias(hl + 1, t);
                     sched_fence();
                 }
+                if (S::BFX_TR && BWD && hl == 0) wg_barrier();                  // the previous tile's last dW GEMM reads X0 / X1 (transpose reads)
                 publish(Xin, A);
                 wg_barrier();                                                   // layer hl activations complete in Xin
                 STAMP(1)
@@ -547,10 +581,10 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                     PINN_UNROLL for (int kb = 0; kb < S::KB; ++kb)
                         PINN_UNROLL for (int q = 0; q < NG; ++q) {
                             vbf8 bb[3];
-                            PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[sp] = lds_load_bf8(Xin, vint(((q * S::KB + kb) * 3 + sp) * 256) + (lane << 2));
+                            PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[sp] = ld_bfrag(Xin, (q * S::KB + kb) * 3 + sp);
                             PINN_UNROLL for (int t = 0; t < MTW; ++t) A[q][t] = mfma_split(wb[kb][t], bb, A[q][t]);
                         }
-                    if (WPRE && PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 1)) sched_gemm_prefetch<S::KB * NG, MTW * 6, PINN_F2_GEMM_AHEAD, 3>();
+                    if (WPRE && PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 1)) sched_gemm_prefetch<S::KB * NG, MTW * 6, PINN_F2_GEMM_AHEAD, S::BFX_TR ? 6 : 3>();
                 }
                 PINN_UNROLL for (int mi = 0; mi < (S::BFX ? 0 : MT); ++mi) {
                     if (!WPRE)
@@ -843,8 +877,27 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t)
                     PINN_UNROLL for (int r = 0; r < 4; ++r) bbar[hl + 1][t][r] += G[pg * C][t][r];
+            if (S::BFX_TR && (hl < NHH - 1 || RECIN)) wg_barrier();          // every wave's dW GEMM of the layer above (RECIN: of the previous tile) has read X0 / X1
             if (!PP || hl == NHH - 1) publish(X0, G);                        // dZ in B-fragment order for dA = W^T dZ (PP: the later layers' dZ is
                                                                              // published by the activation-adjoint superstep of the layer above)
+            if (S::BFX_TR) {
+                // the a-jets of hidden layer hl (this wave's neuron tiles) as bf16 pieces in X1, laid out like a forward activation: the
+                // transpose reads of the dW GEMM turn X0 (dZ, own tile) and X1 (every input tile) into its two operands
+                vfloat4 AJ[NG][MTW];
+                PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                        PINN_UNROLL for (int r = 0; r < 4; ++r) {
+                            vfloat zz[C], dd[ND];
+                            PINN_UNROLL for (int k = 0; k < C; ++k) zz[k] = Sr[pg * C + k][t][r];
+                            if (C > 1) {
+                                act_derivs_n<J::NORD - 1, SINACT>(act, zz[0], dd);
+                                jet_forward<J>(zz, dd);
+                            }
+                            AJ[pg * C][t][r] = act_from_record<SINACT>(Sr[pg * C][t][r]);
+                            PINN_UNROLL for (int k = 1; k < C; ++k) AJ[pg * C + k][t][r] = zz[k];
+                        }
+                publish(X1, AJ);
+            }
             // stage column group q: dZ^T (wave private, [t][column][16 neurons]) and A^T (cooperative, [column][HP]), slot-swizzled
             auto stage_q = [&](int q, float* zt, float* at) {
                 PINN_UNROLL for (int t = 0; t < MTW; ++t) {
@@ -905,6 +958,29 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 PINN_UNROLL for (int ti = 0; ti < MT; ++ti) {
                     vbf8 ab[3];
                     PINN_UNROLL for (int sp = 0; sp < 3; ++sp) ab[sp] = lds_load_bf8(X1, vint(((qp * MT + ti) * 3 + sp) * 256) + slot4);
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t) wbar[hl][t][ti] = mfma_split(za[t], ab, wbar[hl][t][ti]);
+                }
+            };
+            // dW by LDS transpose reads (S::BFX_TR): column groups 2 qp, 2 qp + 1 are the K = 32 points of one MFMA; an odd tail pair takes
+            // zeros for k >= 16 (A operand masked, B operand read from the pair's first column group: finite values)
+            auto dw_pair_tr = [&](int qp) {
+                const bool full = (2 * qp + 1 < NG);
+                auto ld_tr = [&](const float* X, int frag, int h) -> vbf8 {
+                    const int base = frag * 256 + h * 128;
+                    if (full) return cat_bf8(lds_load_tr_bf4(X, vint(base) + trbq[0]), lds_load_tr_bf4(X, vint(base) + trbq[1]));
+                    return cat_bf8(lds_load_tr_bf4(X, vint(base) + trb[0]), lds_load_tr_bf4(X, vint(base) + trb[1]));
+                };
+                vbf8 za[MTW][3];
+                PINN_UNROLL for (int t = 0; t < MTW; ++t) {
+                    const int tile = w * MTW + t;
+                    PINN_UNROLL for (int sp = 0; sp < 3; ++sp) {
+                        za[t][sp] = ld_tr(X0, (2 * qp * S::KB + (tile >> 1)) * 3 + sp, tile & 1);
+                        if (!full) za[t][sp] = bf8_select(klo, za[t][sp]);
+                    }
+                }
+                PINN_UNROLL for (int ti = 0; ti < MT; ++ti) {
+                    vbf8 ab[3];
+                    PINN_UNROLL for (int sp = 0; sp < 3; ++sp) ab[sp] = ld_tr(X1, (2 * qp * S::KB + (ti >> 1)) * 3 + sp, ti & 1);
                     PINN_UNROLL for (int t = 0; t < MTW; ++t) wbar[hl][t][ti] = mfma_split(za[t], ab, wbar[hl][t][ti]);
                 }
             };
@@ -978,7 +1054,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                     if (S::BFX) {
                         PINN_UNROLL for (int kb = 0; kb < S::KB; ++kb) {
                             vbf8 bb[3];
-                            PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[sp] = lds_load_bf8(X0, vint(((q * S::KB + kb) * 3 + sp) * 256) + (lane << 2));
+                            PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[sp] = ld_bfrag(X0, (q * S::KB + kb) * 3 + sp);
                             PINN_UNROLL for (int t = 0; t < MTW; ++t) Gn[q][t] = mfma_split(wtb[kb][t], bb, Gn[q][t]);
                         }
                     } else {
@@ -988,16 +1064,23 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                                 PINN_UNROLL for (int rr = 0; rr < 4; ++rr) Gn[q][t] = mfma16(wt[mo][t][rr], b4[rr], Gn[q][t]);
                         }
                     }
+                    if (S::BFX_TR) continue;                                // (nothing to stage: dW reads X0 / X1 as they are)
                     if (S::BFX_DW) stage_q_bf(q);
                     else stage_q(q, ZT + q * (MTW * 256), X1 + q * 16 * HP);
                 }
                 if (!S::BFX && PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 2)) sched_gemm_prefetch<MT * NG, MTW * 4, PINN_F2_GEMM_AHEAD>();
-                wave_prio(1);
-                STAMP(10)
-                wg_barrier();                                               // staged operands complete; X0 free again
-                STAMP(11)
-                wave_prio_gemm(gemm_hi);
-                if (S::BFX_DW) {
+                if (!S::BFX_TR) {
+                    wave_prio(1);
+                    STAMP(10)
+                    wg_barrier();                                           // staged operands complete; X0 free again
+                    STAMP(11)
+                    wave_prio_gemm(gemm_hi);
+                } else {
+                    STAMP(10)
+                }
+                if (S::BFX_TR) {
+                    PINN_UNROLL for (int qp = 0; qp < (NG + 1) / 2; ++qp) dw_pair_tr(qp);
+                } else if (S::BFX_DW) {
                     PINN_UNROLL for (int qp = 0; qp < NG / 2; ++qp) dw_pair_bf(qp);
                 } else {
                     PINN_UNROLL for (int q = 0; q < NG; ++q) dw_q(ZT + q * (MTW * 256), X1 + q * 16 * HP);
@@ -1025,7 +1108,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 PINN_UNROLL for (int kb = 0; kb < S::KB; ++kb)
                     PINN_UNROLL for (int q = 0; q < NG; ++q) {
                         vbf8 bb[3];
-                        PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[sp] = lds_load_bf8(X0, vint(((q * S::KB + kb) * 3 + sp) * 256) + (lane << 2));
+                        PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[sp] = ld_bfrag(X0, (q * S::KB + kb) * 3 + sp);
                         PINN_UNROLL for (int t = 0; t < MTW; ++t) Gn[q][t] = mfma_split(wtb[kb][t], bb, Gn[q][t]);
                     }
             };
@@ -1185,6 +1268,7 @@ template <class S0, class S1, int ACTK, int MODE = MODE_FUSED>
 DEV void wave_main2m(const GroupArgs& ga, int blk, int nblocks, int w, float* lds) {
     static_assert(std::is_same<typename S0::Shape, typename S1::Shape>::value, "merged launches need members of one network shape and neuron split");
     static_assert(S0::SLAB == S1::SLAB && S0::PACKED == S1::PACKED, "merged launches share the slab and the packed weight image");
+    static_assert(S0::DW_NATURAL == S1::DW_NATURAL && S0::BFX_TR == S1::BFX_TR, "merged launches: one order of the dW tiles in the slab, one exchange-image layout");
     static_assert(MODE == MODE_FUSED || MODE == MODE_LOSS, "merged launches: the fused evaluation and the loss-only evaluation");
     const int wave = blk * S0::NW + w;
     Acc2<typename S0::Shape> ac;

@@ -88,7 +88,7 @@ SpecInfo make_info2(void (*launch)(const GroupArgs&, int, int, plat_stream), int
     s.ngen = S::J::GEN ? S::C : 0;
     for (int i = 0; i < MAX_GEN_CHANNELS; ++i) s.gen[i] = (S::J::GEN && i < S::C) ? S::J::gen_channel(i) : 0u;
     s.family = 2; s.WG_PER_CU = S::WG_PER_CU; s.WG_FWD = S::WG_FWD; s.NW = S::NW; s.NATURAL = S::NATURAL ? 1 : 0;
-    s.BFX = S::BFIMG ? 1 : 0; s.OFF_WB = S::OFF_WB; s.OFF_WTB = S::OFF_WTB; s.BFX_DW = S::BFX_DW ? 1 : 0;
+    s.BFX = S::BFIMG ? 1 : 0; s.OFF_WB = S::OFF_WB; s.OFF_WTB = S::OFF_WTB; s.BFX_DW = S::DW_NATURAL ? 1 : 0;
     s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR; s.HI = S::HI & 0xFFFFFFu; s.LAP = S::J::LAP;
     s.PG = S::PG; s.C = S::C; s.NG = S::NG; s.TP = S::TP; s.MT = S::MT; s.LH = S::LH; s.NFIRST = S::NFIRST;
     s.PACKED = S::PACKED; s.SLAB = S::SLAB; s.SCR = S::SCR; s.LDS_WG = S::LDS_WG; s.COOP = 1; s.SH = S::SLAB; s.PW = 0;
