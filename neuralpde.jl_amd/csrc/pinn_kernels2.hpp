@@ -106,6 +106,9 @@
 #ifndef PINN_F2_BF16X_H128
 #define PINN_F2_BF16X_H128 1
 #endif
+#ifndef PINN_F2_TR_H128
+#define PINN_F2_TR_H128 1               // level 3 for the 128-wide 8-wave kernels as well (slab-resident dW sums as the GEMM's accumulators)
+#endif
 #ifndef PINN_F2_BF16X_TWO_STAGE
 #define PINN_F2_BF16X_TWO_STAGE 1
 #endif
@@ -214,7 +217,8 @@ struct Spec2 {
     static constexpr int XSZ_BF = NG * KB * 3 * 256;
     static constexpr int UP_SZ = (((NW + 1) * NG * 16 + 63) / 64) * 64;
     // (level 3, TR_SHAPE: no staging at all — dW reads its operands out of the exchange images with the LDS transpose read)
-    static constexpr bool TR_SHAPE = (PINN_F2_BF16X >= 3) && HP_ == 64 && NW == 4 && (NHH_ * (MT / NW) * MT * 4 <= 96);
+    static constexpr bool TR_SHAPE = (PINN_F2_BF16X >= 3) && ((HP_ == 64 && NW == 4 && (NHH_ * (MT / NW) * MT * 4 <= 96)) ||
+                                                               (HP_ == 128 && NW == 8 && PINN_F2_BF16X_H128 && PINN_F2_TR_H128));
     static constexpr bool BF_FULL = (2 * XSZ_BF + (TR_SHAPE ? 0 : NG * MT * 256) + UP_SZ) * 4 <= 160 * 1024;
     static constexpr bool BF_HALF = !BF_FULL && PINN_F2_BF16X_TWO_STAGE && (MT * (MT / NW) * 4 > 16) && (NG % 2 == 0) && (PINN_F2_BF16X != 2) &&
                                     (2 * XSZ_BF + UP_SZ) * 4 <= 160 * 1024 && (NG / 2) * 16 * HP_ + (NG / 2) * MT * 256 <= XSZ_BF;
@@ -350,6 +354,9 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
     constexpr bool RECOUT = (MODE == MODE_FWDREC), RECIN = (MODE == MODE_GRADREC);
     constexpr bool IS_FWD = (MODE == MODE_FWD || MODE == MODE_FWDREC), IS_GRADIN = (MODE == MODE_GRADIN || MODE == MODE_GRADREC);
     constexpr bool WPRE = (MT * MTW * 4 <= 16);        // prefetch a layer's weight fragments when they take <= 16 registers (H = 64)
+    // level 3 in the H = 64 schedule (dA and dW behind ONE barrier): the exchange buffers stay in use until the end of the dW GEMM, so the
+    // barrier that frees them sits in front of the next publish (the H = 128 schedule keeps its barrier behind the GEMMs)
+    constexpr bool TR_OVL = S::BFX_TR && WPRE && !S::CHUNKED;
     const int wave = blk * S::NW + w;
     const vint lane = lane_id();
     const vint g = lane >> 4;
@@ -565,7 +572,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                     PINN_UNROLL for (int t = 0; t < MTW; ++t) bv[t] = ld_bias(hl + 1, t);
                     sched_fence();
                 }
-                if (S::BFX_TR && BWD && hl == 0) wg_barrier();                  // the previous tile's last dW GEMM reads X0 / X1 (transpose reads)
+                if (TR_OVL && BWD && hl == 0) wg_barrier();                     // the previous tile's last dW GEMM reads X0 / X1 (transpose reads)
                 publish(Xin, A);
                 wg_barrier();                                                   // layer hl activations complete in Xin
                 STAMP(1)
@@ -877,7 +884,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t)
                     PINN_UNROLL for (int r = 0; r < 4; ++r) bbar[hl + 1][t][r] += G[pg * C][t][r];
-            if (S::BFX_TR && (hl < NHH - 1 || RECIN)) wg_barrier();          // every wave's dW GEMM of the layer above (RECIN: of the previous tile) has read X0 / X1
+            if (TR_OVL && (hl < NHH - 1 || RECIN)) wg_barrier();             // every wave's dW GEMM of the layer above (RECIN: of the previous tile) has read X0 / X1
             if (!PP || hl == NHH - 1) publish(X0, G);                        // dZ in B-fragment order for dA = W^T dZ (PP: the later layers' dZ is
                                                                              // published by the activation-adjoint superstep of the layer above)
             if (S::BFX_TR) {
@@ -981,7 +988,10 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 PINN_UNROLL for (int ti = 0; ti < MT; ++ti) {
                     vbf8 ab[3];
                     PINN_UNROLL for (int sp = 0; sp < 3; ++sp) ab[sp] = ld_tr(X1, (2 * qp * S::KB + (ti >> 1)) * 3 + sp, ti & 1);
-                    PINN_UNROLL for (int t = 0; t < MTW; ++t) wbar[hl][t][ti] = mfma_split(za[t], ab, wbar[hl][t][ti]);
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t) {
+                        if (S::WBAR_REG) wbar[hl][t][ti] = mfma_split(za[t], ab, wbar[hl][t][ti]);
+                        else wacc[t][ti] = mfma_split(za[t], ab, wacc[t][ti]);
+                    }
                 }
             };
             // W^T fragments for dA: issued ahead of the dW GEMM, which hides their latency
@@ -1119,6 +1129,17 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                     wg_barrier();                                           // chunk q complete; chunk q-1's buffer is free again
                     dw_q(cb + S::CH_AT + w * S::CH_ZT, cb);
                 }
+            } else if (S::BFX_TR) {
+                STAMP(7)
+                wg_barrier();                                               // dZ (X0) and the a-jets (X1) of every wave are published
+                STAMP(8)
+                da_split();
+                if (WACC_PRELOAD)
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                        PINN_UNROLL for (int ti = 0; ti < MT; ++ti)
+                            wacc[t][ti] = gload4(slab + S::O_WBAR, vint((((hl * MT + w * MTW + t) * MT + ti) * 64) * 4) + (lane << 2));
+                PINN_UNROLL for (int qp = 0; qp < (NG + 1) / 2; ++qp) dw_pair_tr(qp);
+                STAMP(9)
             } else {
                 constexpr int QH = NG / S::NSTAGE;                          // column groups per staging pass
                 PINN_UNROLL for (int q = 0; q < QH; ++q) stage_q(q, ZT + q * (MTW * 256), X1 + q * 16 * HP);
