@@ -106,6 +106,12 @@
 #ifndef PINN_F2_BF16X_H128
 #define PINN_F2_BF16X_H128 1
 #endif
+#ifndef PINN_F2_TR_FWDIMG
+#define PINN_F2_TR_FWDIMG 1             // transpose-read kernels: the forward pass's last exchange image serves as the first dW's a-jet operand
+#endif
+#ifndef PINN_F2_TR_AHEAD
+#define PINN_F2_TR_AHEAD 0              // reverse sweep of the transpose-read kernels: operand reads one group ahead of the MFMAs (vec.hpp: sched_da_dw_tr)
+#endif
 #ifndef PINN_F2_TR_H128
 #define PINN_F2_TR_H128 1               // level 3 for the 128-wide 8-wave kernels as well (slab-resident dW sums as the GEMM's accumulators)
 #endif
@@ -815,6 +821,12 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
         STAMP(5)
 
         // =========================== reverse sweep ===========================
+        // exchange buffers of the reverse sweep: XZ holds dZ (B operand of dA, A operand of dW), XA the a-jets (S::BFX_TR: B operand of dW).
+        // Transpose-read kernels choose XA = the buffer in which the FORWARD pass left the last hidden layer's input image: for hl = NHH - 1
+        // that image IS the a-jet operand, so the first layer of the sweep recomputes, splits and publishes nothing but its dZ.
+        constexpr bool FWD_IMG = S::BFX_TR && !RECIN && NHH >= 1 && PINN_F2_TR_FWDIMG;
+        float* XA = (S::BFX_TR && ((NHH - 1) & 1) == 0) ? X0 : X1;
+        float* XZ = (S::BFX_TR && ((NHH - 1) & 1) == 0) ? X1 : X0;
         auto ajet = [&](const vfloat4 (&Sr)[NG][MTW], int pg, int ch, int t) -> vfloat4 {
             vfloat4 out;
             PINN_UNROLL for (int r = 0; r < 4; ++r) {
@@ -885,11 +897,11 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 PINN_UNROLL for (int t = 0; t < MTW; ++t)
                     PINN_UNROLL for (int r = 0; r < 4; ++r) bbar[hl + 1][t][r] += G[pg * C][t][r];
             if (TR_OVL && (hl < NHH - 1 || RECIN)) wg_barrier();             // every wave's dW GEMM of the layer above (RECIN: of the previous tile) has read X0 / X1
-            if (!PP || hl == NHH - 1) publish(X0, G);                        // dZ in B-fragment order for dA = W^T dZ (PP: the later layers' dZ is
+            if (!PP || hl == NHH - 1) publish(XZ, G);                        // dZ in B-fragment order for dA = W^T dZ (PP: the later layers' dZ is
                                                                              // published by the activation-adjoint superstep of the layer above)
-            if (S::BFX_TR) {
-                // the a-jets of hidden layer hl (this wave's neuron tiles) as bf16 pieces in X1, laid out like a forward activation: the
-                // transpose reads of the dW GEMM turn X0 (dZ, own tile) and X1 (every input tile) into its two operands
+            if (S::BFX_TR && !(FWD_IMG && hl == NHH - 1)) {
+                // the a-jets of hidden layer hl (this wave's neuron tiles) as bf16 pieces in XA, laid out like a forward activation: the
+                // transpose reads of the dW GEMM turn XZ (dZ, own tile) and XA (every input tile) into its two operands
                 vfloat4 AJ[NG][MTW];
                 PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                     PINN_UNROLL for (int t = 0; t < MTW; ++t)
@@ -903,7 +915,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                             AJ[pg * C][t][r] = act_from_record<SINACT>(Sr[pg * C][t][r]);
                             PINN_UNROLL for (int k = 1; k < C; ++k) AJ[pg * C + k][t][r] = zz[k];
                         }
-                publish(X1, AJ);
+                publish(XA, AJ);
             }
             // stage column group q: dZ^T (wave private, [t][column][16 neurons]) and A^T (cooperative, [column][HP]), slot-swizzled
             auto stage_q = [&](int q, float* zt, float* at) {
@@ -981,13 +993,13 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 PINN_UNROLL for (int t = 0; t < MTW; ++t) {
                     const int tile = w * MTW + t;
                     PINN_UNROLL for (int sp = 0; sp < 3; ++sp) {
-                        za[t][sp] = ld_tr(X0, (2 * qp * S::KB + (tile >> 1)) * 3 + sp, tile & 1);
+                        za[t][sp] = ld_tr(XZ, (2 * qp * S::KB + (tile >> 1)) * 3 + sp, tile & 1);
                         if (!full) za[t][sp] = bf8_select(klo, za[t][sp]);
                     }
                 }
                 PINN_UNROLL for (int ti = 0; ti < MT; ++ti) {
                     vbf8 ab[3];
-                    PINN_UNROLL for (int sp = 0; sp < 3; ++sp) ab[sp] = ld_tr(X1, (2 * qp * S::KB + (ti >> 1)) * 3 + sp, ti & 1);
+                    PINN_UNROLL for (int sp = 0; sp < 3; ++sp) ab[sp] = ld_tr(XA, (2 * qp * S::KB + (ti >> 1)) * 3 + sp, ti & 1);
                     PINN_UNROLL for (int t = 0; t < MTW; ++t) {
                         if (S::WBAR_REG) wbar[hl][t][ti] = mfma_split(za[t], ab, wbar[hl][t][ti]);
                         else wacc[t][ti] = mfma_split(za[t], ab, wacc[t][ti]);
@@ -1064,7 +1076,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                     if (S::BFX) {
                         PINN_UNROLL for (int kb = 0; kb < S::KB; ++kb) {
                             vbf8 bb[3];
-                            PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[sp] = ld_bfrag(X0, (q * S::KB + kb) * 3 + sp);
+                            PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[sp] = ld_bfrag(XZ, (q * S::KB + kb) * 3 + sp);
                             PINN_UNROLL for (int t = 0; t < MTW; ++t) Gn[q][t] = mfma_split(wtb[kb][t], bb, Gn[q][t]);
                         }
                     } else {
@@ -1090,6 +1102,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 }
                 if (S::BFX_TR) {
                     PINN_UNROLL for (int qp = 0; qp < (NG + 1) / 2; ++qp) dw_pair_tr(qp);
+                    if (PINN_F2_TR_AHEAD > 0 && MTW == 1) sched_da_dw_tr<NG * S::KB, (NG + 1) / 2, MT>();
                 } else if (S::BFX_DW) {
                     PINN_UNROLL for (int qp = 0; qp < NG / 2; ++qp) dw_pair_bf(qp);
                 } else {
@@ -1118,7 +1131,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 PINN_UNROLL for (int kb = 0; kb < S::KB; ++kb)
                     PINN_UNROLL for (int q = 0; q < NG; ++q) {
                         vbf8 bb[3];
-                        PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[sp] = ld_bfrag(X0, (q * S::KB + kb) * 3 + sp);
+                        PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[sp] = ld_bfrag(XZ, (q * S::KB + kb) * 3 + sp);
                         PINN_UNROLL for (int t = 0; t < MTW; ++t) Gn[q][t] = mfma_split(wtb[kb][t], bb, Gn[q][t]);
                     }
             };

@@ -90,6 +90,7 @@ inline void store_pad() {}
 inline void keep_alive(const vfloat4&) {}
 inline void wave_prio(int) {}
 template <int NGROUPS, int MFMA_PER, int AHEAD, int DS_PER = 1> inline void sched_gemm_prefetch() {}
+template <int NDA, int NQP, int MT> inline void sched_da_dw_tr() {}
 inline int hw_wave_slot() { return 0; }
 inline void wave_prio_gemm(bool) {}
 inline void vsincos(const vfloat& x, vfloat& s, vfloat& c) { for (int l = 0; l < W; ++l) { s.v[l] = std::sin(x.v[l]); c.v[l] = std::cos(x.v[l]); } }
@@ -363,6 +364,25 @@ template <int NGROUPS, int MFMA_PER, int AHEAD, int DS_PER = 1> DEV void sched_g
         __builtin_amdgcn_sched_group_barrier(0x100, DS_PER, 0);
     }
     __builtin_amdgcn_sched_group_barrier(0x008, MFMA_PER * AHEAD, 0);
+}
+// The same request for the reverse sweep of the transpose-read kernels (pinn_kernels2.hpp, S::BFX_TR, one neuron tile per wave): ONE region
+// holds the dA GEMM (NDA groups of 6 operand reads + 6 MFMAs) and the dW GEMM (per column-group pair: 6 reads of the wave's dZ^T pieces,
+// then per input tile 6 reads + 6 MFMAs); every group's reads are issued in front of the PREVIOUS group's MFMAs.
+template <int NDA, int NQP, int MT> DEV void sched_da_dw_tr() {
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+    PINN_UNROLL for (int i = 0; i < NDA - 1; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+    }
+    PINN_UNROLL for (int qp = 0; qp < NQP; ++qp) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        PINN_UNROLL for (int ti = 1; ti < MT; ++ti) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        }
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
 }
 // issue priority of this wave against the other wave resident on its SIMD (s_setprio): raised around MFMA clusters
 template <int P> DEV void wave_prio_t() { __builtin_amdgcn_s_setprio(P); }
