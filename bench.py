@@ -179,6 +179,8 @@ def main():
                     "0 (default): steps // 10, i.e. at least 10 sampled launches of every kernel")
     args = ap.parse_args()
 
+    # the host driver of this pool only supports dmabuf IPC: without this RCCL's peer-buffer exchange fails with hipIpcGetMemHandle errors
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
     import torch.distributed as dist

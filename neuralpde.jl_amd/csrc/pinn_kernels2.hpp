@@ -106,6 +106,13 @@
 #ifndef PINN_F2_BF16X_H128
 #define PINN_F2_BF16X_H128 1
 #endif
+// Explicit software pipeline of the split-operand GEMMs: the B-operand (dW: both operands') LDS reads of group i + 1 are issued in front of
+// a scheduling fence, the six MFMAs of group i behind it — the compiler cannot sink the reads next to their uses (what it does when left
+// alone, and what sched_group_barrier requests did not change at 256 registers), so a wave's MFMAs no longer wait one LDS round trip per
+// group.  Bit mask: 1 forward GEMM, 2 dA GEMM, 4 dW GEMM.
+#ifndef PINN_F2_SWP
+#define PINN_F2_SWP 7
+#endif
 #ifndef PINN_F2_TR_FWDIMG
 #define PINN_F2_TR_FWDIMG 1             // transpose-read kernels: the forward pass's last exchange image serves as the first dW's a-jet operand
 #endif
@@ -533,6 +540,23 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
             return c;
         };
 
+        // C[q][t] += W[kb][t] (x) X[q][kb] over every column group and k-block, software-pipelined (PINN_F2_SWP): group i + 1's three piece
+        // fragments are requested before group i's MFMAs
+        auto gemm_swp = [&](const float* X, const vbf8 (&wfr)[S::BFX ? S::KB : 1][S::BFX ? MTW : 1][3], vfloat4 (&Cc)[NG][MTW]) {
+            constexpr int NGRP = S::KB * NG;
+            vbf8 bb[2][3];
+            PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[0][sp] = ld_bfrag(X, sp);          // group 0: kb = 0, q = 0
+            PINN_UNROLL for (int i = 0; i < NGRP; ++i) {
+                const int kb = i / NG, q = i % NG;
+                if (i + 1 < NGRP) {
+                    const int kb2 = (i + 1) / NG, q2 = (i + 1) % NG;
+                    PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[(i + 1) & 1][sp] = ld_bfrag(X, (q2 * S::KB + kb2) * 3 + sp);
+                }
+                sched_fence();
+                PINN_UNROLL for (int t = 0; t < MTW; ++t) Cc[q][t] = mfma_split(wfr[kb][t], bb[i & 1], Cc[q][t]);
+            }
+        };
+
         // =========================== forward ===========================
         vfloat4 A[NG][MTW];
         vfloat U[PG][C];
@@ -590,7 +614,9 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                     }
                 }
                 wave_prio_gemm(gemm_hi);
-                if (S::BFX) {
+                if (S::BFX && (PINN_F2_SWP & 1)) {
+                    gemm_swp(Xin, wb, A);
+                } else if (S::BFX) {
                     PINN_UNROLL for (int kb = 0; kb < S::KB; ++kb)
                         PINN_UNROLL for (int q = 0; q < NG; ++q) {
                             vbf8 bb[3];
@@ -997,6 +1023,20 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                         if (!full) za[t][sp] = bf8_select(klo, za[t][sp]);
                     }
                 }
+                if (PINN_F2_SWP & 4) {
+                    vbf8 ab[2][3];
+                    PINN_UNROLL for (int sp = 0; sp < 3; ++sp) ab[0][sp] = ld_tr(XA, (2 * qp * S::KB) * 3 + sp, 0);
+                    PINN_UNROLL for (int ti = 0; ti < MT; ++ti) {
+                        if (ti + 1 < MT)
+                            PINN_UNROLL for (int sp = 0; sp < 3; ++sp) ab[(ti + 1) & 1][sp] = ld_tr(XA, (2 * qp * S::KB + ((ti + 1) >> 1)) * 3 + sp, (ti + 1) & 1);
+                        sched_fence();
+                        PINN_UNROLL for (int t = 0; t < MTW; ++t) {
+                            if (S::WBAR_REG) wbar[hl][t][ti] = mfma_split(za[t], ab[ti & 1], wbar[hl][t][ti]);
+                            else wacc[t][ti] = mfma_split(za[t], ab[ti & 1], wacc[t][ti]);
+                        }
+                    }
+                    return;
+                }
                 PINN_UNROLL for (int ti = 0; ti < MT; ++ti) {
                     vbf8 ab[3];
                     PINN_UNROLL for (int sp = 0; sp < 3; ++sp) ab[sp] = ld_tr(XA, (2 * qp * S::KB + (ti >> 1)) * 3 + sp, ti & 1);
@@ -1072,7 +1112,8 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 STAMP(8)
                 if (SPRE && hl - 1 >= 1) load_record(hl - 1);
                 wave_prio_gemm(gemm_hi);
-                PINN_UNROLL for (int q = 0; q < NG; ++q) {
+                if (S::BFX_TR && (PINN_F2_SWP & 2)) gemm_swp(XZ, wtb, Gn);
+                PINN_UNROLL for (int q = 0; q < ((S::BFX_TR && (PINN_F2_SWP & 2)) ? 0 : NG); ++q) {
                     if (S::BFX) {
                         PINN_UNROLL for (int kb = 0; kb < S::KB; ++kb) {
                             vbf8 bb[3];
@@ -1128,6 +1169,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
             // split-operand kernels of this path (H = 128): dA runs FIRST, on the W^T fragments requested above (their 48 registers are
             // dead again before the dW accumulators come alive)
             auto da_split = [&]() {
+                if (PINN_F2_SWP & 2) { gemm_swp(XZ, wtb, Gn); return; }
                 PINN_UNROLL for (int kb = 0; kb < S::KB; ++kb)
                     PINN_UNROLL for (int q = 0; q < NG; ++q) {
                         vbf8 bb[3];

@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 3, GPU call 25: explicit software pipeline of the split GEMMs (PINN_F2_SWP) — parity + A/B per site
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+O=gpurun_out/r03zb
+mkdir -p $O
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_full_size.py tests/test_gpu_parity.py -q -m gpu -x > $O/tests_parity.log 2>&1; echo "rc=$?" >> $O/tests_parity.log
+tail -n 3 $O/tests_parity.log
+timeout 300 python tools/ab_compare.py head swp0 swp1 swp3 > $O/ab_cfg2.txt 2>&1
+timeout 300 python tools/ab_compare.py --cfg cfg3 head swp0 swp1 swp3 > $O/ab_cfg3.txt 2>&1
+timeout 300 python tools/ab_compare.py --points 8192 head swp0 > $O/ab_8192.txt 2>&1
+timeout 300 python tools/ab_compare.py --cfg cfg4 head swp0 > $O/ab_cfg4.txt 2>&1
+timeout 300 python tools/ab_compare.py --cfg cfg5 head swp0 > $O/ab_cfg5.txt 2>&1
+grep "round\|rror" $O/ab*.txt | sed 's/group1 -1000.0 us//' | cut -c1-160
