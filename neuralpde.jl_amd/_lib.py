@@ -12,6 +12,16 @@ from typing import Optional, Sequence
 
 import numpy as np
 
+# PyTorch ships its own copy of the HIP / HSA runtime (torch/lib/libamdhip64.so).  A process that maps libpinn_hip.so FIRST binds the
+# engine to the system runtime (/opt/rocm) and then initialises a SECOND runtime when torch touches the device: the later one finds "no
+# ROCm-capable device" (seen on hardware: build() followed by smoke() in one process).  With torch mapped first, the engine's HIP symbols
+# resolve to the runtime torch already carries, and the two share one device context — which the zero-copy paths (device pointers and
+# streams handed across the ABI) need anyway.  Hosts without torch (the Julia glue, the C client) use the system runtime alone.
+try:
+    import torch as _torch  # noqa: F401
+except ImportError:          # pragma: no cover
+    _torch = None
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_PATH = os.path.join(_HERE, "csrc", "libpinn_hip.so")
 
