@@ -385,14 +385,17 @@ template <int NDA, int NQP, int MT> DEV void sched_da_dw_tr() {
     __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
 }
 // issue priority of this wave against the other wave resident on its SIMD (s_setprio): raised around MFMA clusters
-template <int P> DEV void wave_prio_t() { __builtin_amdgcn_s_setprio(P); }
+#ifndef PINN_F2_NO_PRIO
+#define PINN_F2_NO_PRIO 0               // experiment: no s_setprio anywhere (every wave at priority 0)
+#endif
+template <int P> DEV void wave_prio_t() { if (!PINN_F2_NO_PRIO) __builtin_amdgcn_s_setprio(P); }
 // slot of this wave on its SIMD (HW_REG_HW_ID bits 3:0): distinguishes the two workgroups resident on a CU
 DEV int hw_wave_slot() { return (int)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 15u); }
 // issue priority inside the MFMA clusters: ASYMMETRIC between the two waves of a SIMD.  With equal priorities two workgroups that
 // enter their GEMM phases together share the matrix pipe half-half, leave them together and then sit in their non-MFMA phases
 // together (pipe idle): a convoy.  When one of them wins the pipe outright it finishes its GEMM early and runs its element-wise /
 // barrier phases while the other one has the pipe to itself: the phases fall into anti-phase.
-DEV void wave_prio_gemm(bool hi) { if (hi) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
+DEV void wave_prio_gemm(bool hi) { if (PINN_F2_NO_PRIO) return; if (hi) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
 #define wave_prio(P) wave_prio_t<P>()
 struct urec16 { int x, y, z, w; };
 DEV urec16 uload16(const void* p) {
