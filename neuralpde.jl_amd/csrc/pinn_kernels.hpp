@@ -33,6 +33,10 @@
 #include "rprog.hpp"
 #include "vec.hpp"
 
+#ifndef PINN_F1_PREFETCH
+#define PINN_F1_PREFETCH 1
+#endif
+
 namespace pk {
 using namespace wv;
 
@@ -580,38 +584,48 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                     if (SINACT) Z[pg * C][m] = av;
                 }
         };
+        // k-steps (mi, rr) of hidden layer hl's GEMM; the fragment of step ks+1 is requested before the MFMAs of step ks (software pipeline:
+        // with one wave per SIMD nothing else hides the L2 latency of a just-in-time load)
+        auto load_wf = [&](int hl, int ks, vfloat (&wf)[MT]) {
+            const int Wf = S::OFF_WPK + hl * HP * HP;
+            if (MT == 4) {
+                vfloat4 w4 = ub_load4(PB, Wf + ks * 64 * MT, lane << 2);
+                PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wf[mo] = w4[mo & 3];
+            } else {
+                PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wf[mo] = ub_load(PB, Wf + ks * 64 * MT + mo, lane * MT);
+            }
+        };
+        // PINN_F1_PREFETCH: a layer's bias and its FIRST weight fragment are requested before the activation function of the layer below
+        // runs (a lone wave per SIMD otherwise sits out one L2 round trip at the top of every layer: most of a one-tile launch's time)
+        vfloat wfirst[MT];
+        vfloat4 bvn[MT];
+        auto prefetch_layer = [&](int hl) {
+            PINN_UNROLL for (int m = 0; m < MT; ++m) bvn[m] = ub_load4(PB, S::OFF_B + (hl + 1) * HP + 16 * m, g << 2);
+            load_wf(hl, 0, wfirst);
+        };
+        if (PINN_F1_PREFETCH && NHH > 0) prefetch_layer(0);
         act_forward(A, 0);
 
         // ---- hidden -> hidden layers on the matrix cores ----
         PINN_UNROLL for (int hl = 0; hl < NHH; ++hl) {
             vfloat4 Zn[NG][MT];
+            if (!PINN_F1_PREFETCH) prefetch_layer(hl);
             PINN_UNROLL for (int m = 0; m < MT; ++m) {
-                vfloat4 bv = ub_load4(PB, S::OFF_B + (hl + 1) * HP + 16 * m, g << 2);
                 PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
-                    Zn[pg * C][m] = bv;
+                    Zn[pg * C][m] = bvn[m];
                     PINN_UNROLL for (int ch = 1; ch < C; ++ch) Zn[pg * C + ch][m] = vzero4();
                 }
             }
-            const int Wf = S::OFF_WPK + hl * HP * HP;
-            // k-steps (mi, rr); the fragment of step ks+1 is requested before the MFMAs of step ks (software pipeline:
-            // with one wave per SIMD nothing else hides the L2 latency of a just-in-time load)
-            auto load_wf = [&](int ks, vfloat (&wf)[MT]) {
-                if (MT == 4) {
-                    vfloat4 w4 = ub_load4(PB, Wf + ks * 64 * MT, lane << 2);
-                    PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wf[mo] = w4[mo & 3];
-                } else {
-                    PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wf[mo] = ub_load(PB, Wf + ks * 64 * MT + mo, lane * MT);
-                }
-            };
             vfloat wcur[MT], wnxt[MT];
-            load_wf(0, wcur);
+            PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wcur[mo] = wfirst[mo];
             PINN_UNROLL for (int ks = 0; ks < 4 * MT; ++ks) {
                 const int mi = ks >> 2, rr = ks & 3;
-                if (ks + 1 < 4 * MT) load_wf(ks + 1, wnxt);
+                if (ks + 1 < 4 * MT) load_wf(hl, ks + 1, wnxt);
                 PINN_UNROLL for (int q = 0; q < NG; ++q)
                     PINN_UNROLL for (int mo = 0; mo < MT; ++mo) Zn[q][mo] = mfma16(wcur[mo], A[q][mi][rr], Zn[q][mo]);
                 PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wcur[mo] = wnxt[mo];
             }
+            if (PINN_F1_PREFETCH && hl + 1 < NHH) prefetch_layer(hl + 1);
             act_forward(Zn, hl + 1);
             PINN_UNROLL for (int q = 0; q < NG; ++q)
                 PINN_UNROLL for (int m = 0; m < MT; ++m) A[q][m] = Zn[q][m];
@@ -771,6 +785,18 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
             vfloat4 Sr[NG][MT];
             PINN_UNROLL for (int q = 0; q < NG; ++q)
                 PINN_UNROLL for (int m = 0; m < MT; ++m) Sr[q][m] = SrN[q][m];
+            // W^T fragments of the dA GEMM below; the first one is requested here (PINN_F1_PREFETCH): its L2 round trip hides under the dW staging
+            const int Wt = S::OFF_WTPK + hl * HP * HP;
+            auto load_wt = [&](int ks, vfloat (&wf)[MT]) {
+                if (MT == 4) {
+                    vfloat4 w4 = ub_load4(PB, Wt + ks * 64 * MT, lane << 2);
+                    PINN_UNROLL for (int mi = 0; mi < MT; ++mi) wf[mi] = w4[mi & 3];
+                } else {
+                    PINN_UNROLL for (int mi = 0; mi < MT; ++mi) wf[mi] = ub_load(PB, Wt + ks * 64 * MT + mi, lane * MT);
+                }
+            };
+            vfloat tcur[MT];
+            if (PINN_F1_PREFETCH) load_wt(0, tcur);
             // ---- dW += dZ A^T through the swizzled LDS transpose, 16 columns at a time ----
             if (COOP) {
                 // Every wave publishes its (dZ^T, A^T) chunk in the workgroup-shared double buffer; after one barrier
@@ -849,17 +875,8 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
             vfloat4 Gn[NG][MT];
             PINN_UNROLL for (int q = 0; q < NG; ++q)
                 PINN_UNROLL for (int m = 0; m < MT; ++m) Gn[q][m] = vzero4();
-            const int Wt = S::OFF_WTPK + hl * HP * HP;
-            auto load_wt = [&](int ks, vfloat (&wf)[MT]) {
-                if (MT == 4) {
-                    vfloat4 w4 = ub_load4(PB, Wt + ks * 64 * MT, lane << 2);
-                    PINN_UNROLL for (int mi = 0; mi < MT; ++mi) wf[mi] = w4[mi & 3];
-                } else {
-                    PINN_UNROLL for (int mi = 0; mi < MT; ++mi) wf[mi] = ub_load(PB, Wt + ks * 64 * MT + mi, lane * MT);
-                }
-            };
-            vfloat tcur[MT], tnxt[MT];
-            load_wt(0, tcur);
+            vfloat tnxt[MT];
+            if (!PINN_F1_PREFETCH) load_wt(0, tcur);
             PINN_UNROLL for (int ks = 0; ks < 4 * MT; ++ks) {
                 const int mo = ks >> 2, rr = ks & 3;
                 if (ks + 1 < 4 * MT) load_wt(ks + 1, tnxt);
