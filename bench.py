@@ -251,7 +251,23 @@ def main():
             if comm_mode == "engine":
                 eng.comm_destroy()
             comm_mode = "torch-fallback"
-            data_group = dist.new_group(backend="nccl", device_id=torch.device("cuda", local_dev))
+            # second fallback: if torch's own RCCL group cannot be formed or fails its first collective either, the step reduces on the
+            # host through the gloo control group (slow, but the run reports a number and says which path carried it)
+            ok = True
+            try:
+                data_group = dist.new_group(backend="nccl", device_id=torch.device("cuda", local_dev))
+                probe = torch.ones(1, device="cuda")
+                dist.all_reduce(probe, group=data_group)
+                torch.cuda.synchronize()
+                ok = abs(float(probe.item()) - world) < 0.5
+            except Exception as e:
+                print(f"[bench rank {rank}] torch.distributed nccl group failed ({e}); reducing on the host over gloo", file=sys.stderr)
+                ok = False
+            oks = [None] * world
+            dist.all_gather_object(oks, ok)
+            if not all(oks):
+                data_group = None
+                comm_mode = "gloo-host-fallback"
     if args.emulate_world > 0:
         eng.comm_init_rank(1, 0, npde.comm_unique_id())           # the real RCCL entry points on a 1-rank communicator
     sharded = world > 1 or args.emulate_world > 0
@@ -359,7 +375,8 @@ def main():
                        "boundary_points_per_term": n_glob[-1], "theta": P,
                        "parallelism": f"point-shard x{world}" if world > 1 else "single",
                        "all_reduce": ({"engine": "engine-owned RCCL communicator (pinn_loss_grad_sharded_device)", "torch": f"torch.distributed ({backend})",
-                                       "torch-fallback": "torch.distributed (nccl) after the engine communicator failed"}[comm_mode] if world > 1 else None)},
+                                       "torch-fallback": "torch.distributed (nccl) after the engine communicator failed",
+                                       "gloo-host-fallback": "host reduction over gloo after both RCCL paths failed"}[comm_mode] if world > 1 else None)},
             "point_terms_per_s": sum(n_glob) * args.steps / el,
             "host_entry_ms_per_step": host_path_ms,     # pinn_loss_grad: theta host -> device, results device -> host (PCIe-inclusive)
             "loss_only_host_entry_ms": loss_only_ms,    # pinn_loss_grad(grad = NULL): the loss-only evaluation through the same entry point
