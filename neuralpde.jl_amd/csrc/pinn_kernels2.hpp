@@ -113,6 +113,9 @@
 #ifndef PINN_F2_SWP
 #define PINN_F2_SWP 7
 #endif
+#ifndef PINN_F2_ADJ_IL
+#define PINN_F2_ADJ_IL 1                // H = 64 transpose-read schedule: activation adjoint issued between the MFMA groups of the dW GEMM
+#endif
 #ifndef PINN_F2_TR_FWDIMG
 #define PINN_F2_TR_FWDIMG 1             // transpose-read kernels: the forward pass's last exchange image serves as the first dW's a-jet operand
 #endif
@@ -879,6 +882,19 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
         };
 
         vfloat4 G[NG][MTW];
+        // PINN_F2_ADJ_IL (H = 64 transpose-read schedule): the activation adjoint of a layer depends on the dA GEMM only, so its PG x 4
+        // independent (point group, row) pieces are issued BETWEEN the MFMA groups of the dW GEMM that follows — VALU work in the shadow of
+        // the wave's own MFMAs instead of a phase of its own behind them
+        constexpr bool ADJ_IL = TR_OVL && PINN_F2_ADJ_IL && MTW == 1 && (PINN_F2_SWP & 4) != 0;
+        constexpr int ADJ_NCH = PG * 4, ADJ_NGRP = ((NG + 1) / 2) * MT;
+        auto adj_piece = [&](const vfloat4 (&Sr)[NG][MTW], int j) {          // piece j = (pg, r) of act_adjoint(G, Sr)
+            const int pg = j >> 2, r = j & 3;
+            vfloat gg[C], ss[C], dd[ND];
+            PINN_UNROLL for (int k = 0; k < C; ++k) { gg[k] = G[pg * C + k][0][r]; ss[k] = Sr[pg * C + k][0][r]; }
+            act_derivs_n<J::NORD, SINACT>(act, ss[0], dd);
+            jet_adjoint<J>(gg, ss, dd);
+            PINN_UNROLL for (int k = 0; k < C; ++k) G[pg * C + k][0][r] = gg[k];
+        };
         PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {                        // output layer
             if (w == 0) bLbar += vselect(g0, ubar[pg][0], vfloat(0.f));
             PINN_UNROLL for (int ch = 0; ch < C; ++ch)
@@ -1034,6 +1050,11 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                             if (S::WBAR_REG) wbar[hl][t][ti] = mfma_split(za[t], ab[ti & 1], wbar[hl][t][ti]);
                             else wacc[t][ti] = mfma_split(za[t], ab[ti & 1], wacc[t][ti]);
                         }
+                        if (ADJ_IL) {                                       // this group's share of the activation adjoint (see adj_piece)
+                            const int gidx = qp * MT + ti;
+                            PINN_UNROLL for (int j = 0; j < ADJ_NCH; ++j)
+                                if ((j * ADJ_NGRP) / ADJ_NCH == gidx) adj_piece(Sr, j);
+                        }
                     }
                     return;
                 }
@@ -1142,6 +1163,9 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                     STAMP(10)
                 }
                 if (S::BFX_TR) {
+                    if (ADJ_IL)
+                        PINN_UNROLL for (int q = 0; q < NG; ++q)
+                            PINN_UNROLL for (int t = 0; t < MTW; ++t) G[q][t] = Gn[q][t];
                     PINN_UNROLL for (int qp = 0; qp < (NG + 1) / 2; ++qp) dw_pair_tr(qp);
                     if (PINN_F2_TR_AHEAD > 0 && MTW == 1) sched_da_dw_tr<NG * S::KB, (NG + 1) / 2, MT>();
                 } else if (S::BFX_DW) {
@@ -1152,9 +1176,11 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                         sched_gemm_prefetch<4 * NG, 4, PINN_F2_GEMM_AHEAD, 2>();
                 }
                 wave_prio(1);
-                PINN_UNROLL for (int q = 0; q < NG; ++q)
-                    PINN_UNROLL for (int t = 0; t < MTW; ++t) G[q][t] = Gn[q][t];
-                act_adjoint(G, Sr);
+                if (!ADJ_IL) {
+                    PINN_UNROLL for (int q = 0; q < NG; ++q)
+                        PINN_UNROLL for (int t = 0; t < MTW; ++t) G[q][t] = Gn[q][t];
+                    act_adjoint(G, Sr);
+                }
                 if (!S::WBAR_REG)
                     PINN_UNROLL for (int t = 0; t < MTW; ++t)
                         PINN_UNROLL for (int ti = 0; ti < MT; ++ti) {
