@@ -114,7 +114,7 @@
 #define PINN_F2_SWP 7
 #endif
 #ifndef PINN_F2_ADJ_IL
-#define PINN_F2_ADJ_IL 1                // H = 64 transpose-read schedule: activation adjoint issued between the MFMA groups of the dW GEMM
+#define PINN_F2_ADJ_IL 1                // transpose-read schedules: activation adjoint issued between the MFMA groups of the dW GEMM (1: H = 64 only, 2: H = 128 too)
 #endif
 #ifndef PINN_F2_TR_FWDIMG
 #define PINN_F2_TR_FWDIMG 1             // transpose-read kernels: the forward pass's last exchange image serves as the first dW's a-jet operand
@@ -885,7 +885,9 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
         // PINN_F2_ADJ_IL (H = 64 transpose-read schedule): the activation adjoint of a layer depends on the dA GEMM only, so its PG x 4
         // independent (point group, row) pieces are issued BETWEEN the MFMA groups of the dW GEMM that follows — VALU work in the shadow of
         // the wave's own MFMAs instead of a phase of its own behind them
-        constexpr bool ADJ_IL = TR_OVL && PINN_F2_ADJ_IL && MTW == 1 && (PINN_F2_SWP & 4) != 0;
+        // (the 8-wave H = 128 kernels gain most: both waves of a SIMD belong to one workgroup and sit in the same phase, so nothing else fills
+        // the matrix pipe's shadow)
+        constexpr bool ADJ_IL = S::BFX_TR && !S::CHUNKED && PINN_F2_ADJ_IL && MTW == 1 && (PINN_F2_SWP & 4) != 0 && (TR_OVL || PINN_F2_ADJ_IL >= 2);
         constexpr int ADJ_NCH = PG * 4, ADJ_NGRP = ((NG + 1) / 2) * MT;
         auto adj_piece = [&](const vfloat4 (&Sr)[NG][MTW], int j) {          // piece j = (pg, r) of act_adjoint(G, Sr)
             const int pg = j >> 2, r = j & 3;
@@ -1219,6 +1221,9 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                     PINN_UNROLL for (int t = 0; t < MTW; ++t)
                         PINN_UNROLL for (int ti = 0; ti < MT; ++ti)
                             wacc[t][ti] = gload4(slab + S::O_WBAR, vint((((hl * MT + w * MTW + t) * MT + ti) * 64) * 4) + (lane << 2));
+                if (ADJ_IL)
+                    PINN_UNROLL for (int q = 0; q < NG; ++q)
+                        PINN_UNROLL for (int t = 0; t < MTW; ++t) G[q][t] = Gn[q][t];
                 PINN_UNROLL for (int qp = 0; qp < (NG + 1) / 2; ++qp) dw_pair_tr(qp);
                 STAMP(9)
             } else {
@@ -1273,9 +1278,11 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
             STAMP(10)
             wg_barrier();                                                   // X0 / X1 free again
             STAMP(11)
-            PINN_UNROLL for (int q = 0; q < NG; ++q)
-                PINN_UNROLL for (int t = 0; t < MTW; ++t) G[q][t] = Gn[q][t];
-            act_adjoint(G, Sr);
+            if (!ADJ_IL) {
+                PINN_UNROLL for (int q = 0; q < NG; ++q)
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t) G[q][t] = Gn[q][t];
+                act_adjoint(G, Sr);
+            }
             STAMP(12)
         }
         // hidden layer 0: db0, dW1 in the D layout (per-lane partial sums over this lane's column)
