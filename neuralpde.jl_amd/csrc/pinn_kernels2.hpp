@@ -113,6 +113,9 @@
 #ifndef PINN_F2_SWP
 #define PINN_F2_SWP 7
 #endif
+#ifndef PINN_F2_ADJ_PIN
+#define PINN_F2_ADJ_PIN 0               // ... and pinned there (vec.hpp: pin_value)
+#endif
 #ifndef PINN_F2_ADJ_IL
 #define PINN_F2_ADJ_IL 1                // transpose-read schedules: activation adjoint issued between the MFMA groups of the dW GEMM (1: H = 64 only, 2: H = 128 too)
 #endif
@@ -896,6 +899,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
             act_derivs_n<J::NORD, SINACT>(act, ss[0], dd);
             jet_adjoint<J>(gg, ss, dd);
             PINN_UNROLL for (int k = 0; k < C; ++k) G[pg * C + k][0][r] = gg[k];
+            if (PINN_F2_ADJ_PIN) PINN_UNROLL for (int k = 0; k < C; ++k) pin_value(G[pg * C + k][0][r]);
         };
         PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {                        // output layer
             if (w == 0) bLbar += vselect(g0, ubar[pg][0], vfloat(0.f));

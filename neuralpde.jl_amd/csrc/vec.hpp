@@ -88,6 +88,7 @@ struct urec16 { int x, y, z, w; };
 inline void sched_fence() {}
 inline void store_pad() {}
 inline void keep_alive(const vfloat4&) {}
+inline void pin_value(const vfloat&) {}
 inline void wave_prio(int) {}
 template <int NGROUPS, int MFMA_PER, int AHEAD, int DS_PER = 1> inline void sched_gemm_prefetch() {}
 template <int NDA, int NQP, int MT> inline void sched_da_dw_tr() {}
@@ -351,6 +352,9 @@ DEV void store_pad() {
         else asm volatile("s_nop %0" ::"n"(PINN_STORE_PAD - 1));
     }
 }
+// an ordered use of x at this point of the instruction stream: the arithmetic that produces x cannot be deferred past the scheduling
+// fences that follow (pure VALU work is otherwise placed where the DAG scheduler likes, whatever fences surround it in the source)
+DEV void pin_value(vfloat x) { asm volatile("" ::"v"(x)); }
 DEV void keep_alive(const vfloat4& x) {
     if (PINN_STORE_PAD > 0) asm volatile("" ::"v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
 }
