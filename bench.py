@@ -18,10 +18,14 @@ blocks; one RCCL all-reduce of [gradient | per-term squared-residual sums] per s
 value = interior collocation points x steps / time  (the metric's unit: interior-point residual+grad evals/s;
 the 4x65,536 boundary-term points ride along in every step and are counted in `point_terms_per_s`).
 
-JSON extras: "roofline" (fp32 MFMA roofline of the dominant kernel = the fused residual kernel with the most device time, flops the
-kernel executes per SURVEY.md §8d's formula ÷ its mean HIP-event duration over >= 10 launches sampled inside the timed region),
-"roofline_kernels" (the same for every fused kernel of the step) and "cpu_baseline" (the float64 oracle = CPU restatement of the
-reference algorithm, timed on this box's host cores on the same full-size workload with a fixed thread count; rank 0, N=1 only).
+JSON extras: "roofline" (MFMA roofline of the dominant kernel = the fused residual kernel with the most device time, priced on the
+matrix pipe that EXECUTES its hidden-layer products: in the default "split" GEMM mode every fp32 product is six bf16 MFMAs, so
+`achieved` = executed bf16 MFMA flops / mean HIP-event duration over >= 10 launches sampled inside the timed region, `peak` = the dense
+bf16 MFMA peak, `frac` <= 1 by construction; the fp32-equivalent rate against the fp32 MFMA peak — what BASELINE.json's north star
+names — is kept as `frac_fp32_equiv`), "roofline_kernels" (the same for every fused kernel of the step) and "cpu_baseline" (the float64
+oracle = CPU restatement of the reference algorithm, timed on this box's host cores on the same full-size workload at two thread counts,
+the faster one reported; rank 0, N=1 only).  `value` keeps theta resident in HBM; `value_incl_theta_h2d` is SURVEY.md section 8d's
+definition (theta crosses PCIe every step: the C-ABI host entry point).
 """
 import argparse
 import json
@@ -33,7 +37,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md:41
-SPLIT_SPEEDUP = 2.56               # 6 bf16 16x16x32 MFMAs vs 16 fp32 16x16x4 MFMAs for the same fp32 products (tools/micro/mfma_split_bench.hip)
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # /opt/skills/guides/MI355X_MICROARCH.md:42 (dense; the 5 PF headline figure includes 2:1 sparsity)
+SPLIT_PRODUCTS = 6                 # bf16 MFMAs per fp32-accurate product block (pinn_kernels2.hpp: mfma_split)
+
+
+def split_mfma_flops(sizes, members, hp=None):
+    """bf16 MFMA flops a split-GEMM launch EXECUTES: per tile and hidden->hidden layer the forward and dA GEMMs cover NG column groups of
+    16, the dW GEMM (K = 32 points per MFMA) ceil(NG / 2) pairs of them; every fp32 product block is SPLIT_PRODUCTS bf16 MFMAs.
+    Widths are the PADDED ones the kernel multiplies (64 / 128)."""
+    hidden = sizes[1:-1]
+    hp = hp or (64 if max(hidden) <= 64 else 128)
+    nhh = len(hidden) - 1
+    total = 0
+    for h in members:
+        ng = h["channels"] * h["pg"]
+        cols = 16 * (2 * ng + 2 * ((ng + 1) // 2))
+        total += h["tiles"] * nhh * 2 * hp * hp * cols * SPLIT_PRODUCTS
+    return total
 
 
 def algorithmic_flops_per_point(sizes, C):
@@ -42,13 +62,14 @@ def algorithmic_flops_per_point(sizes, C):
     return 6 * C * S - 2 * C * sizes[0] * sizes[1]
 
 
-CPU_THREADS = 32          # fixed intra-op thread count of the CPU baseline (capped by the box's hardware threads)
+CPU_THREADS = 32          # first intra-op thread count of the CPU baseline (capped by the box's hardware threads); the second is ALL of them
 
 
-def cpu_baseline(npde, wl, sets, nevals=20, budget_s=90.0, chunk=16384):
+def cpu_baseline(npde, wl, sets, nevals=10, budget_s=45.0, chunk=16384):
     """Time the float64 oracle (stencil mode = the reference's algorithm: 6 batched forward passes per Poisson residual + reverse
     mode) on this box's host cores on the SAME workload as the GPU leg — all 65,536 interior + 4 x 65,536 boundary points, evaluated
-    in chunks of `chunk` points per term to bound memory — with a FIXED thread count; value = interior points / median eval time."""
+    in chunks of `chunk` points per term to bound memory — at two thread counts (32, the count torch's CPU GEMMs scale to on these hosts,
+    and every hardware thread of the box); value = interior points / median eval time of the FASTER setting, both are stated."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
@@ -56,8 +77,6 @@ def cpu_baseline(npde, wl, sets, nevals=20, budget_s=90.0, chunk=16384):
     import pinn_oracle as po
     import helpers
     ncpu = os.cpu_count() or 1
-    nt = min(CPU_THREADS, ncpu)
-    torch.set_num_threads(nt)
     prob = helpers.oracle_problem(npde, wl.pde_system, wl.chains)
     N = [s.shape[1] for s in sets]
     nchunks = max((n + chunk - 1) // chunk for n in N)
@@ -73,16 +92,23 @@ def cpu_baseline(npde, wl, sets, nevals=20, budget_s=90.0, chunk=16384):
             po.loss_and_grad(prob, wl.theta, part, weights=w, mode="stencil")
         return time.perf_counter() - t
 
-    one()                                   # warm-up (thread pool, allocator)
-    times, t0 = [], time.perf_counter()
-    while len(times) < nevals and (time.perf_counter() - t0 < budget_s or len(times) < 3):
-        times.append(one())
-    med = float(np.median(times))
-    return {"value": N[0] / med, "unit": "interior-point residual+grad evals/s", "cores": nt, "kind": "port",
-            "host_cpus": ncpu, "evals": len(times), "median_s": med, "min_s": float(min(times)), "max_s": float(max(times)),
-            "sample": f"median of {len(times)} evals of the float64 stencil-mode oracle (torch CPU, fixed {nt} of {ncpu} hardware threads) on the full "
-                      f"workload: {N[0]} interior + {len(N) - 1}x{N[1]} boundary points in chunks of {chunk}; Julia/NeuralPDE.jl itself is not "
-                      f"installable here (no network)"}
+    runs = []
+    for nt in sorted(set([min(CPU_THREADS, ncpu), ncpu])):
+        torch.set_num_threads(nt)
+        one()                                   # warm-up (thread pool, allocator)
+        times, t0 = [], time.perf_counter()
+        while len(times) < nevals and (time.perf_counter() - t0 < budget_s or len(times) < 3):
+            times.append(one())
+        runs.append({"threads": nt, "evals": len(times), "median_s": float(np.median(times)), "min_s": float(min(times)), "max_s": float(max(times)),
+                     "value": N[0] / float(np.median(times))})
+    best = max(runs, key=lambda r: r["value"])
+    return {"value": best["value"], "unit": "interior-point residual+grad evals/s", "cores": best["threads"], "kind": "port",
+            "host_cpus": ncpu, "evals": best["evals"], "median_s": best["median_s"], "min_s": best["min_s"], "max_s": best["max_s"],
+            "thread_counts_tried": runs,
+            "sample": f"median of {best['evals']} evals of the float64 stencil-mode oracle (torch CPU) on the full workload: {N[0]} interior + "
+                      f"{len(N) - 1}x{N[1]} boundary points in chunks of {chunk}; timed with " +
+                      " and ".join(f"{r['threads']} threads ({r['value']:.3g} pts/s)" for r in runs) + f" of {ncpu} hardware threads, the faster "
+                      f"one reported; Julia/NeuralPDE.jl itself is not installable here (no network)"}
 
 
 def pmc_traffic(kernel_key, points):
@@ -102,13 +128,37 @@ def pmc_traffic(kernel_key, points):
     return None, None
 
 
+def kernel_facts(kernel_key, points):
+    """Counter / ISA facts of a kernel from the committed profile summaries (profiles/kernel_facts.json, written by tools/pmc_summarize.py
+    and tools/isa_report.py from the rocprofv3 --pmc passes and the disassembly of the shipped objects): matrix-pipe busy fraction
+    (SQ_VALU_MFMA_BUSY_CYCLES / SIMDs / (GRBM_GUI_ACTIVE / XCDs)) and VALU instructions per interior tile.  Not measurable inside this
+    process; null when no committed profile matches this kernel and size."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "kernel_facts.json")) as f:
+            tab = json.load(f)
+    except (OSError, ValueError):
+        return {}
+    for e in tab.get("kernels", []):
+        if e.get("key") == kernel_key and e.get("points_per_launch") in (None, points):
+            return e
+    return {}
+
+
 def roofline_entries(eng, kern_ms, sizes, world):
     """One roofline entry per fused residual LAUNCH of the step.  A MERGED launch (the interior jet set and the value-only boundary set
     of one network walked by one persistent kernel, pinn_group_launched_by) is one entry covering both groups' points and flops.
-    `achieved` / `frac` count the flops the kernel EXECUTES (SURVEY.md §8d formula 6 C S - 2 C n0 n1 with C = the jet channels each
-    member carries) / its mean HIP-event duration over the sampled launches of the timed region.  The 2-D Poisson interior residual as
-    written needs C = 5 channels (u, u_x, u_y, u_xx, u_yy: 373,120 flop/point, the §8d figure); the kernel carries u_xx + u_yy as ONE
-    forward-Laplacian channel (C = 4), so the §8d "useful work" rate is reported separately as frac_algorithmic."""
+    The entry is priced on the matrix pipe that executes the launch's hidden-layer products:
+      * gemm = split-bf16 (default, 64- / 128-wide kernels): every fp32 product block is six v_mfma_f32_16x16x32_bf16, so `achieved` =
+        executed bf16 MFMA flops / mean kernel time, `peak` = the dense bf16 MFMA peak (2,500 TF/s), `frac` = their ratio (<= 1 by
+        construction: the pipe cannot execute more than its peak);
+      * gemm = fp32 (pinn_set_option / narrower nets): `achieved` = executed fp32 flops (SURVEY.md section 8d formula with the channels the
+        kernel carries) / time against the fp32 MFMA peak (157.3 TF/s).
+    `frac_fp32_equiv` is, in both cases, the fp32-equivalent executed flops (6 C S - 2 C n0 n1 per point with C = the jet channels each
+    member carries) / time / fp32 MFMA peak — the figure BASELINE.json's north star names ("% of the fp32 MFMA roofline on the layer
+    GEMMs"); with split products it may exceed what the fp32 pipe alone could do, which is why it is not `frac`.  The 2-D Poisson interior
+    residual as written needs C = 5 channels (u, u_x, u_y, u_xx, u_yy: 373,120 flop/point, the section 8d figure); the kernel carries
+    u_xx + u_yy as ONE forward-Laplacian channel (C = 4), so the section 8d "useful work" rate is reported separately as
+    frac_algorithmic."""
     import re
     import numpy as np
     groups = eng.group_timings()
@@ -134,28 +184,33 @@ def roofline_entries(eng, kern_ms, sizes, world):
         pts = sum(h["points"] for h in members)
         key = "+".join(names.get(h["group"], f"group{h['group']}") for h in members)
         traffic, tsrc = pmc_traffic(key, pts) if world == 1 else (None, None)
+        facts = kernel_facts(key, pts) if world == 1 else {}
         kind = "coupled reverse launch (forward launches not timed)" if gi in coupled else ("merged interior+boundary residual+grad" if len(members) > 1 else
                ("interior residual+grad" if g["channels"] > 1 else "boundary residual+grad"))
         tf_exec, tf_alg = f_exec / (ms * 1e-3) / 1e12, f_alg / (ms * 1e-3) / 1e12
-        per_kernel.append({
-            "bound": "mfma", "achieved": tf_exec, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf_exec / PEAK_FP32_MFMA_TFLOPS,
-            "traffic": traffic, "traffic_source": tsrc,
-            "kernel": f"{'k_wave2m' if len(members) > 1 else 'k_wave2'}<{key}, FUSED> ({kind}, neuron-split workgroups)",
-            "kernel_ms": ms, "kernel_ms_min": float(np.min(kern_ms[:, gi])), "kernel_ms_max": float(np.max(kern_ms[:, gi])),
-            "launches_sampled": int(kern_ms.shape[0]), "points_per_launch": pts,
-            "executed_channels": [h["channels"] for h in members], "executed_flops_per_launch": f_exec, "algorithmic_flops_per_launch": f_alg,
-            "achieved_algorithmic": tf_alg, "frac_algorithmic": tf_alg / PEAK_FP32_MFMA_TFLOPS,
-            "algorithmic_bytes_per_launch": 4 * sizes[0] * pts})
-        if split:
-            # hidden->hidden forward, dA and (level 3: transpose-read kernels) dW products run as 3-piece bf16 split products (6
-            # v_mfma_f32_16x16x32_bf16 per K = 32, measured 2.56x the fp32 pipe's rate for the same fp32 product); the first / last layers
-            # are VALU work.  `frac` stays what
-            # BASELINE.json's north_star names (fp32-equivalent flops / fp32 MFMA peak); frac_mixed_pipes prices the same flops against
-            # the rate the matrix pipes could deliver for this mix (all of it on the bf16 pipe at 2.56x, or 2/3 : 1/3 with dW in fp32),
-            # which is the honest "how far from the ceiling" figure.
-            share = 1.0 if "dW" in split else 2.0 / 3.0     # (fwd,dA,dW): every hidden-layer product; (fwd,dA): dW on the fp32 pipe
-            mixed_peak = 1.0 / (share / (PEAK_FP32_MFMA_TFLOPS * SPLIT_SPEEDUP) + (1 - share) / PEAK_FP32_MFMA_TFLOPS)
-            per_kernel[-1].update({"gemm": split, "mixed_pipe_peak": mixed_peak, "frac_mixed_pipes": tf_exec / mixed_peak})
+        fam2 = all(names.get(h["group"], "").startswith("F2_") for h in members)
+        hp = int(re.search(r"_HP(\d+)_", names.get(gi, "_HP0_")).group(1))
+        on_bf16 = bool(split) and fam2 and hp in (64, 128) and "dW" in split
+        entry = {"traffic": traffic, "traffic_source": tsrc,
+                 "kernel": f"{'k_wave2m' if len(members) > 1 else 'k_wave2'}<{key}, FUSED> ({kind}, neuron-split workgroups)",
+                 "kernel_ms": ms, "kernel_ms_min": float(np.min(kern_ms[:, gi])), "kernel_ms_max": float(np.max(kern_ms[:, gi])),
+                 "launches_sampled": int(kern_ms.shape[0]), "points_per_launch": pts,
+                 "executed_channels": [h["channels"] for h in members], "executed_flops_per_launch": f_exec, "algorithmic_flops_per_launch": f_alg,
+                 "achieved_fp32_equiv": tf_exec, "frac_fp32_equiv": tf_exec / PEAK_FP32_MFMA_TFLOPS,
+                 "achieved_algorithmic": tf_alg, "frac_algorithmic": tf_alg / PEAK_FP32_MFMA_TFLOPS,
+                 "algorithmic_bytes_per_launch": 4 * sizes[0] * pts,
+                 "mfma_busy": facts.get("mfma_busy"), "valu_insts_per_tile": facts.get("valu_insts_per_tile"), "facts_source": facts.get("source")}
+        if on_bf16:
+            for h in members:
+                h["pg"] = int(re.search(r"_PG(\d+)\(", names.get(h["group"], "_PG1(")).group(1))
+            f_bf = split_mfma_flops(sizes, members, hp)
+            tf_bf = f_bf / (ms * 1e-3) / 1e12
+            entry.update({"bound": "mfma-bf16(split x6)", "achieved": tf_bf, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf_bf / PEAK_BF16_MFMA_TFLOPS,
+                          "gemm": split, "executed_bf16_mfma_flops_per_launch": f_bf})
+        else:
+            entry.update({"bound": "mfma-fp32", "achieved": tf_exec, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf_exec / PEAK_FP32_MFMA_TFLOPS,
+                          "gemm": split if (split and fam2) else "fp32"})
+        per_kernel.append(entry)
     return per_kernel
 
 
@@ -171,6 +226,14 @@ def main():
                     help="scaling PROXY on one GPU: this process evaluates rank 0's contiguous 1/N share of every term's point set (n_norm = "
                          "the global N) and runs the engine's RCCL all-reduce on a 1-rank communicator, so the collective's launch cost is "
                          "inside the step; value = what N such ranks would deliver together (tools/scaling_proxy.py, profiles/r03_scaling_proxy.json)")
+    ap.add_argument("--gemm", choices=["split", "fp32"], default="split",
+                    help="GEMM arithmetic of the 64- / 128-wide kernels (pinn_set_option): split = three-piece bf16 split products (default, the "
+                         "product), fp32 = v_mfma_f32_16x16x4_f32")
+    ap.add_argument("--resident", action="store_true",
+                    help="time the RESIDENT training loop instead of the evaluation: one step = one Adam iteration with theta, moments and point "
+                         "sets in HBM (pinn_adam_steps; N > 1 / --emulate-world: evaluate -> in-stream all-reduce -> fused update on every rank, no host "
+                         "synchronisation inside the loop); the K timed steps are ONE call.  Not the headline metric (which delivers loss + "
+                         "gradient to a host optimiser every step) — the loop a training run actually executes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--events", choices=["all", "none"], default="all",
                     help="HIP events recorded inside the timed region around every fused residual kernel (sampled steps only), or none")
@@ -216,6 +279,8 @@ def main():
     rep = npde.symbolic_discretize(wl.pde_system, disc)
     eng = rep.engine
     assert eng.L.backend == "hip"
+    if args.gemm != "split":
+        eng.set_option("gemm", args.gemm)
     sets = rep.pde_train_sets + rep.bcs_train_sets
     K, P = eng.K, eng.P
     n_glob = [s.shape[1] for s in sets]
@@ -289,9 +354,18 @@ def main():
             eng.loss_grad_device(theta_d.data_ptr(), out_h.data_ptr(), tw, stream.cuda_stream)
         stream.synchronize()                 # the optimiser needs loss + gradient on the host every iteration
 
+    if args.resident:
+        assert comm_mode == "engine" or world == 1, "--resident needs the engine-owned communicator"
+        eng.adam_init(theta0)
+
+        def run_steps(n):
+            eng.adam(theta0, n, 1e-3, tw, init=False)          # pinn_adam_steps: n iterations, one host synchronisation at the end
+
     host_path_ms = None
     loss_only_ms = None
-    if world == 1 and not sharded:
+    if args.resident:
+        run_steps(30 + args.warmup)
+    elif world == 1 and not sharded:
         # (measured BEFORE the warm-up and the timed region: it doubles as the clock / cache warm-up of the device)
         # cross-check of the zero-copy delivery against a plain device-buffer evaluation + copy
         eng.set_timing(0, -1)
@@ -319,18 +393,23 @@ def main():
     else:
         for _ in range(30):                  # N > 1: the same device clock / cache settling the N = 1 leg gets from the checks above
             step()
-    for _ in range(args.warmup):
+    for _ in range(0 if args.resident else args.warmup):
         step()
     ev_level, ev_group = {"all": 1, "none": 0}[args.events], -1
+    if args.resident:
+        ev_level = 0                                          # (no per-step host turn to read events back in)
     eng.set_timing(ev_level, ev_group)
-    step()
+    if not args.resident:
+        step()
     kern_ms = []
     every = max(1, args.event_every if args.event_every > 0 else args.steps // 10)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    if args.resident:
+        run_steps(args.steps)
+    for i in range(0 if args.resident else args.steps):
         sampled = ev_level > 0 and i % every == 0
         if ev_level > 0 and every > 1:
             eng.set_timing(ev_level if sampled else 0, ev_group)
@@ -347,6 +426,9 @@ def main():
         el = float(t.item())
 
     if rank == 0:
+        if args.resident:                                     # the loss terms at the loop's final theta (outside the timed region)
+            eng.set_timing(0, -1)
+            step()
         res = out_h.numpy()
         losses = res[P:] / np.array(n_glob)
         ngroups = len(eng.group_timings())
@@ -364,12 +446,11 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32" if not any(k.get("gemm") for k in per_kernel) else
-                     ("f32 (hidden-layer forward / dA / dW GEMMs as 3-piece bf16 split products with fp32 accumulation: fp32-level results, "
-                      "golden parity 1.7e-7; first / last layer, activations, reductions in fp32)"
-                      if any("dW" in (k.get("gemm") or "") for k in per_kernel) else
-                      "f32 (hidden-layer forward / dA GEMMs as 3-piece bf16 split products with fp32 accumulation: fp32-level results, "
-                      "golden parity 1.7e-7; dW, first / last layer, activations, reductions in fp32)"),
+            "dtype": "f32" if "gemm=split" not in eng.describe() else
+                     ("f32, hidden-layer forward / dA / dW GEMMs as 3-piece bf16 split products (6 bf16 MFMAs per product block, fp32 accumulation; "
+                      "24 mantissa bits rebuilt): 2-4x the rounding error of an fp32-MFMA fmaf chain — gradient rel. L2 1.6-1.8e-7 vs the float64 "
+                      "oracle at the goldens' glorot parameters, error budget at scaled / trained parameters in DESIGN.md section 6; first / last "
+                      "layer, activations, reductions in fp32; --gemm fp32 runs the exact fp32-MFMA kernels"),
             "data": "synthetic",
             "config": {"workload": wl.name, "interior_points": n_int, "boundary_terms": K - len(rep.pde_train_sets),
                        "boundary_points_per_term": n_glob[-1], "theta": P,
@@ -378,10 +459,17 @@ def main():
                                        "torch-fallback": "torch.distributed (nccl) after the engine communicator failed",
                                        "gloo-host-fallback": "host reduction over gloo after both RCCL paths failed"}[comm_mode] if world > 1 else None)},
             "point_terms_per_s": sum(n_glob) * args.steps / el,
+            # SURVEY.md section 8d's definition of the metric has theta cross PCIe every step: the C-ABI host entry point below
+            "value_incl_theta_h2d": (n_int / (host_path_ms * 1e-3)) if host_path_ms else None,
             "host_entry_ms_per_step": host_path_ms,     # pinn_loss_grad: theta host -> device, results device -> host (PCIe-inclusive)
             "loss_only_host_entry_ms": loss_only_ms,    # pinn_loss_grad(grad = NULL): the loss-only evaluation through the same entry point
             "loss_terms": [float(v) for v in losses],
         }
+        if args.resident:
+            line["config"]["loop"] = ("resident Adam: theta / moments / point sets in HBM, " + ("evaluate -> in-stream all-reduce -> fused update on every rank, "
+                                      if sharded else "evaluate -> fused update, ") + f"{args.steps} iterations per host call (pinn_adam_steps), no per-step host synchronisation")
+            line["metric"] += " (resident training loop incl. the optimiser step)"
+            line["loss_terms_note"] = "at the loop's final theta"
         if args.emulate_world > 0:
             line["config"].update({"emulate_world": args.emulate_world, "parallelism": f"PROXY: rank 0's 1/{args.emulate_world} share on one GPU",
                                    "all_reduce": "engine-owned RCCL all-reduce on a 1-rank communicator (launch cost inside the step)"})
@@ -393,16 +481,15 @@ def main():
             all_ms = float(sum(k["kernel_ms"] for k in per_kernel))
             flops_all = sum(k["executed_flops_per_launch"] for k in per_kernel)
             roof = dict(per_kernel[dom])
-            roof.update({"all_fused_kernels_ms": all_ms, "all_fused_kernels_tflops": flops_all / (all_ms * 1e-3) / 1e12,
-                         "all_fused_kernels_frac": flops_all / (all_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            roof.update({"all_fused_kernels_ms": all_ms, "all_fused_kernels_tflops_fp32_equiv": flops_all / (all_ms * 1e-3) / 1e12,
+                         "all_fused_kernels_frac_fp32_equiv": flops_all / (all_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                          "events": f"HIP events around every fused kernel on every {every}. step of the timed region: {kern_ms.shape[0]} launches averaged",
-                         "note": "frac = executed (fp32-equivalent) flops / kernel time / fp32 MFMA peak (157.3 TF/s at the 2.4 GHz peak clock; the shader clock under this "
-                                 "load is ~1.9 GHz); traffic = HBM-side bytes per launch from the committed rocprofv3 --pmc passes named in traffic_source "
-                                 "(null: no profile for this kernel and size)" +
-                                 ("; gemm = split-bf16: the hidden-layer products execute on the bf16 matrix pipe as 6 bf16 MFMAs per fp32 "
-                                  "product block (fp32-level results), so `frac` against the fp32 pipe's peak can exceed what that pipe alone could do — "
-                                  "frac_mixed_pipes = achieved / mixed_pipe_peak (the split products at 2.56x the fp32 rate; with dW left in fp32: 2/3 of "
-                                  "the flops at 2.56x, 1/3 at the fp32 rate) is the distance to the ceiling" if roof.get("gemm") else "")})
+                         "note": ("frac = achieved / peak on the pipe named in `bound`: for split-bf16 kernels the bf16 MFMA flops the launch executes (six "
+                                  "MFMAs per fp32 product block) against the dense bf16 peak of 2,500 TF/s; frac_fp32_equiv = the fp32-equivalent executed flops "
+                                  "against the fp32 MFMA peak of 157.3 TF/s (BASELINE.json's north-star figure; not a fraction of any one pipe for split kernels); "
+                                  "peaks at the 2.4 GHz peak clock, the shader clock under this load is ~1.9-2.0 GHz; traffic = HBM-side bytes per launch from the "
+                                  "committed rocprofv3 --pmc passes named in traffic_source, mfma_busy / valu_insts_per_tile from the profile named in facts_source "
+                                  "(null: no committed profile for this kernel and size)")})
             line["roofline"] = roof
             line["roofline_kernels"] = per_kernel
         if world == 1 and not sharded and not args.no_cpu_baseline and args.workload == "cfg2":

@@ -97,6 +97,9 @@ int pinn_term_grads(pinn_handle h, const float* theta, int64_t p, double* term_l
  * its own std is the L2LossData term (ext/bpinn/PDE_BPINN.jl:148-183).  grad_theta (P floats, nullable) = d loglik / d theta by the
  * engine's reverse sweep (the reference differentiates with ForwardDiff over all P parameters, ext/bpinn/PDE_BPINN.jl:519);
  * grad_std (K doubles, nullable) = d loglik / d stds[k] = -N_k / s + SSE_k / s^3 for samplers that treat the stds as parameters.
+ * N_k is the number of points INSTALLED for term k (pinn_set_points' n), not its n_norm: with sharded point sets (n < n_norm) every
+ * returned quantity is this shard's additive part — loglik, grad_theta and grad_std summed over the ranks are the global values; a caller
+ * that passes n_norm != n for another reason (a re-normalised mean) gets the constants of n points here.
  */
 int pinn_loglik_grad(pinn_handle h, const float* theta, int64_t p, const double* stds, double* loglik, float* grad_theta, double* grad_std);
 /*
@@ -124,8 +127,30 @@ int pinn_loss_device(pinn_handle h, const float* d_theta, float* d_sums, void* s
  *   one process, G GPUs : pinn_create_on(desc, g) for g = 0..G-1; pinn_comm_init_all(handles, G) (ncclCommInitAll); per evaluation
  *                         pinn_loss_grad_sharded(handles, G, theta, ...) = pinn_loss_grad over all shards (host pointers in and out).
  * RCCL is loaded on first use; single-GPU work never needs it.
+ *   bring your own collective : pinn_comm_init_custom(h, nranks, rank, fn, ctx) makes `fn` the transport of this handle's communicator
+ *                         (one process per GPU): the engine calls  fn(ctx, buf, count, dtype, stream)  to sum `count` elements of `buf`
+ *                         (dtype 0: float, 1: double; device memory of this rank) over the ranks IN PLACE, ordered after the work already
+ *                         queued on `stream` and before whatever the engine queues next (an MPI caller synchronises the stream and calls
+ *                         MPI_Allreduce on the device pointers; a torch caller wraps them and calls dist.all_reduce).  Non-zero = failure.
+ *
+ * The RESIDENT training loop over a communicator (r04): pinn_adam_steps on a handle that belongs to a one-process-per-GPU communicator
+ * (pinn_comm_init_rank / _custom), or pinn_adam_steps_sharded over the handles of a pinn_comm_init_all communicator, runs per iteration
+ *     [redraw this rank's sampled sets] -> evaluate the local shards -> ONE in-stream all-reduce of [gradient | sums] (+ the K sums as
+ *     doubles) -> fused Adam update + weight-image scatter on EVERY rank
+ * with nothing crossing PCIe and no host synchronisation inside the loop: every rank applies the identical update to its identical copy
+ * of theta (pinn_adam_init with the same theta on every rank).  This is `solve(prob, Adam(lr); maxiters)` over full_loss_function
+ * (test/NNPDE1/nnpde__pde_ii_2d_poisson.jl:83-85, src/discretize.jl:567-598) with the K-term aggregation done across devices.
+ * Device samplers draw rank-specific points (the rank is mixed into the seed); an un-randomised Sobol design (seed 0) cannot be sharded.
  */
 #define PINN_COMM_ID_BYTES 128
+typedef int (*pinn_allreduce_fn)(void* ctx, void* buf, int64_t count, int dtype, void* stream);
+int pinn_comm_init_custom(pinn_handle h, int nranks, int rank, pinn_allreduce_fn fn, void* ctx);
+int pinn_adam_steps_sharded(pinn_handle* hs, int ndev, int nsteps, float lr, float beta1, float beta2, float eps, const float* term_w,
+                            double* loss_history);
+/* One Adam update of the resident state from a caller-supplied vector [gradient (P) | raw per-term sums (K)] in host memory: the
+ * host-optimiser form of the sharded loop (evaluate with pinn_loss_grad_sharded, apply here); *loss (nullable) = sum_k w_k sums_k / n_norm_k. */
+int pinn_adam_apply(pinn_handle h, const float* grad_and_sums, int64_t n, float lr, float beta1, float beta2, float eps, const float* term_w,
+                    double* loss);
 int pinn_comm_unique_id(void* id, int64_t nbytes);
 int pinn_comm_init_rank(pinn_handle h, int nranks, int rank, const void* id, int64_t nbytes);
 int pinn_comm_init_all(pinn_handle* hs, int ndev);
@@ -188,11 +213,27 @@ int pinn_adam_get(pinn_handle h, float* theta, int64_t p);
  * host; here inside the library so that C / Julia / Python callers share it).  theta (double, in/out) is iterated in double precision
  * on the host; every objective / gradient evaluation is one fused device evaluation in fp32.  Two-loop recursion with `history` pairs,
  * backtracking line search (Armijo), stops after `maxiters` iterations, when the gradient's max-norm falls below `gtol`, or when the line
- * search cannot decrease the objective any more (the fp32 noise floor).  loss_history (nullable): objective after every iteration,
+ * search cannot decrease the objective any more (the noise floor of the evaluation; a handle in "split" GEMM mode first switches itself to
+ * "fp32" there and goes on — the split products' floor is 2-4 x higher — and is switched back before the call returns;
+ * $PINN_LBFGS_KEEP_GEMM=1 disables that).  loss_history (nullable): objective after every iteration,
  * `maxiters` entries; *iters_done: iterations performed.  Terms with device samplers are refused (the objective must not change).
  */
 int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int history, double gtol, const float* term_w, double* loss_history,
                int* iters_done);
+
+/*
+ * Run-time options of a handle.  "gemm" = arithmetic of the hidden-layer GEMMs of the 64- / 128-wide (neuron-split) kernels:
+ *   "split" (default) — every fp32 product rebuilt from three bf16 pieces per operand on the bf16 matrix pipe (6 MFMAs, fp32 accumulation):
+ *                       2-4 x the rounding error of an fp32 fmaf chain, ~1.35 x faster (error budget: DESIGN.md section 6);
+ *   "fp32"            — v_mfma_f32_16x16x4_f32: bit-for-bit an fmaf chain per product, for callers that need the last bit (a quasi-Newton
+ *                       finisher at its noise floor: the reference's `solve(prob, BFGS())` stage, test/NNPDE1/nnpde__pde_iii_3rd_order_ode.jl:89-93,
+ *                       runs on Float64 CPU arithmetic there).
+ * Both kernel sets are in the library; switching rebuilds the handle's kernel plan in place (milliseconds) and keeps point sets, samplers,
+ * per-point data / weights and the optimiser state.  Narrower nets (one-wave-per-tile kernels) and DGM nets compute on fp32 MFMAs / the
+ * VALU in either mode.  $PINN_GEMM = split | fp32 sets the mode new handles start in.  pinn_get_option writes the current value.
+ */
+int pinn_set_option(pinn_handle h, const char* name, const char* value);
+int pinn_get_option(pinn_handle h, const char* name, char* buf, int64_t buflen);
 
 /* Timing of the last pinn_loss_grad*: HIP-event milliseconds of the fused residual kernels / of the whole device section. */
 int pinn_last_timing(pinn_handle h, float* kernel_ms, float* total_ms);

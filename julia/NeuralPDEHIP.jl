@@ -344,7 +344,9 @@ mutable struct HIPState
     losses::Vector{Float64}
     grad::Vector{Float64}                        # of Σ w_k L_k under `weights`; empty after a loss-only evaluation
     weights::Vector{Float64}
-    tgrads::Union{Nothing, Matrix{Float32}}      # P × K per-term gradients (filled on the first per-term pullback at this θ)
+    tgrads::Union{Nothing, Matrix{Float32}}      # P × K per-term gradients (filled on the first per-term pullback at a θ)
+    tgrads_key::UInt64                           # hash(θ) the per-term gradients were computed at (per-term gradients do not depend on the weights);
+                                                 # pullbacks may run out of order (nested AD, several closures / threads), so it is compared, not st.key
     eager_grad::Bool                             # true (hip_discretize): a plain call of a term closure already runs the fused loss + gradient
                                                  # evaluation that the optimiser's `grad!` of the same iterate will ask for
     lock::ReentrantLock                          # the closures of one discretisation share this state; BPINN calls them from
@@ -400,8 +402,9 @@ function ChainRulesCore.rrule(f::HIPTermLoss, θ)
     flat = collect(Float64, ComponentArrays.getdata(θ))
     function term_pullback(ȳ)
         tg = lock(st.lock) do
-            if st.tgrads === nothing || st.key != hash(flat, hash(st.weights))
+            if st.tgrads === nothing || st.tgrads_key != hash(flat)
                 _, st.tgrads = term_grads(st.engine, flat)
+                st.tgrads_key = hash(flat)
             end
             Float64.(view(st.tgrads, :, f.k))
         end
@@ -444,7 +447,7 @@ function build_state(pinnrep::PINNRepresentation, inner)
         set_points!(engine, k, s)
     end
     n_pde = pinnrep.eqs isa AbstractArray ? length(pinnrep.eqs) : 1
-    return HIPState(engine, pinnrep, n_pde, sets, resample, UInt64(0), Float64[], Float64[], Float64[], nothing, false, ReentrantLock())
+    return HIPState(engine, pinnrep, n_pde, sets, resample, UInt64(0), Float64[], Float64[], Float64[], nothing, UInt64(0), false, ReentrantLock())
 end
 
 # The state (and with it the engine and its HBM) lives exactly as long as the closures that `merge_strategy_with_loss_function` returns:

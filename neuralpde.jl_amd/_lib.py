@@ -34,6 +34,7 @@ SYMBOLS = [
     "pinn_loss_grad_sharded_device", "pinn_loss_grad_sharded",
     "pinn_set_sampler", "pinn_set_point_data", "pinn_set_point_weights", "pinn_get_points", "pinn_adam_init", "pinn_adam_steps", "pinn_adam_get", "pinn_lbfgs",
     "pinn_loss_device", "pinn_group_launched_by",
+    "pinn_set_option", "pinn_get_option", "pinn_comm_init_custom", "pinn_adam_steps_sharded", "pinn_adam_apply",
 ]
 
 
@@ -94,6 +95,12 @@ class Library:
         L.pinn_adam_steps.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, fp, dp]
         L.pinn_adam_get.argtypes = [vp, fp, C.c_int64]
         L.pinn_lbfgs.argtypes = [vp, C.POINTER(C.c_double), C.c_int64, C.c_int, C.c_int, C.c_double, fp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        self.ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_int64, C.c_int, vp)
+        L.pinn_comm_init_custom.argtypes = [vp, C.c_int, C.c_int, self.ALLREDUCE_FN, vp]
+        L.pinn_adam_steps_sharded.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, fp, dp]
+        L.pinn_adam_apply.argtypes = [vp, fp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, fp, dp]
+        L.pinn_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+        L.pinn_get_option.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int64]
         L.pinn_group_timing.argtypes = [vp, C.c_int, fp, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
 
     @property
@@ -162,6 +169,20 @@ def loss_grad_sharded(engines: Sequence["Engine"], theta, weights=None, want_gra
                                          losses.ctypes.data_as(C.POINTER(C.c_double)),
                                          grad.ctypes.data_as(C.POINTER(C.c_float)) if grad is not None else None), "pinn_loss_grad_sharded")
     return losses, grad
+
+
+def adam_steps_sharded(engines: Sequence["Engine"], nsteps: int, lr: float, weights=None, beta1=0.9, beta2=0.999, eps=1e-8):
+    """`pinn_adam_steps_sharded`: the resident Adam loop over the handles of one `comm_init_all` communicator (every handle
+    `adam_init`-ed with the same theta): per iteration evaluate the local shards, ONE all-reduce, the same update on every device.
+    Returns the loss history (rank 0's)."""
+    L = engines[0].L
+    hs = (C.c_void_p * len(engines))(*[e.h for e in engines])
+    hist = np.zeros(nsteps, dtype=np.float64)
+    w = _f32(weights) if weights is not None else None
+    L.check(L.lib.pinn_adam_steps_sharded(hs, len(engines), nsteps, lr, beta1, beta2, eps,
+                                          w.ctypes.data_as(C.POINTER(C.c_float)) if w is not None else None,
+                                          hist.ctypes.data_as(C.POINTER(C.c_double))), "pinn_adam_steps_sharded")
+    return hist
 
 
 class Engine:
@@ -361,6 +382,46 @@ class Engine:
                                            w.ctypes.data_as(C.POINTER(C.c_float)) if w is not None else None,
                                            hist.ctypes.data_as(C.POINTER(C.c_double)), C.byref(done)), "pinn_lbfgs")
         return th, hist[:done.value]
+
+    def adam_init(self, theta):
+        th = _f32(theta)
+        self.L.check(self.L.lib.pinn_adam_init(self.h, th.ctypes.data_as(C.POINTER(C.c_float)), th.size), "pinn_adam_init")
+
+    def adam_get(self) -> np.ndarray:
+        out = np.zeros(self.P, dtype=np.float32)
+        self.L.check(self.L.lib.pinn_adam_get(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), out.size), "pinn_adam_get")
+        return out
+
+    def adam_apply(self, grad_and_sums, lr: float, weights=None, beta1=0.9, beta2=0.999, eps=1e-8) -> float:
+        """`pinn_adam_apply`: one Adam update of the resident state from a host vector [gradient (P) | raw per-term sums (K)]"""
+        v = _f32(grad_and_sums)
+        w = _f32(weights) if weights is not None else None
+        loss = C.c_double(0.0)
+        self.L.check(self.L.lib.pinn_adam_apply(self.h, v.ctypes.data_as(C.POINTER(C.c_float)), v.size, lr, beta1, beta2, eps,
+                                                w.ctypes.data_as(C.POINTER(C.c_float)) if w is not None else None, C.byref(loss)), "pinn_adam_apply")
+        return loss.value
+
+    def comm_init_custom(self, nranks: int, rank: int, allreduce):
+        """`pinn_comm_init_custom`: `allreduce(buf_ptr, count, dtype, stream_ptr) -> int` (dtype 0 float / 1 double) becomes the transport of
+        this handle's communicator; the ctypes callback object is kept alive by the engine wrapper."""
+        def _cb(ctx, buf, count, dtype, stream):
+            try:
+                return int(allreduce(buf, count, dtype, stream) or 0)
+            except Exception:                                           # never unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._allreduce_cb = self.L.ALLREDUCE_FN(_cb)
+        self.L.check(self.L.lib.pinn_comm_init_custom(self.h, nranks, rank, self._allreduce_cb, None), "pinn_comm_init_custom")
+
+    def set_option(self, name: str, value: str):
+        """run-time options of the handle (include/pinn_hip.h: pinn_set_option); "gemm" = "split" | "fp32" """
+        self.L.check(self.L.lib.pinn_set_option(self.h, name.encode(), value.encode()), "pinn_set_option")
+
+    def get_option(self, name: str) -> str:
+        buf = C.create_string_buffer(64)
+        self.L.check(self.L.lib.pinn_get_option(self.h, name.encode(), buf, 64), "pinn_get_option")
+        return buf.value.decode()
 
     def group_timings(self):
         out = []

@@ -31,7 +31,8 @@ struct Reduce1Args {
     int K;
 };
 struct Reduce2Args {
-    float* out;                         // [P + K]
+    float* out;                         // [P] gradient (not touched when skip_grad)
+    float* sums;                        // [K] per-term sums of squares (normally out + P; a buffer of its own for loss-only callers)
     double* lossraw;                    // [K] (nullable)
     const int* row_ptr;                 // [P + 1]
     const int* row_grp;                 // group of every contribution
@@ -52,7 +53,8 @@ struct ReduceOneArgs {
     const float* slabs;                 // [nblocks][slab]
     int slab, nblocks, nent;            // nent: floats per slab that take part (multiple of 4)
     const int* ent_theta;               // [nent]: theta element fed by slab entry e, -1: none
-    float* out;                         // [P + K]
+    float* out;                         // [P] gradient (nent == 0: not touched)
+    float* sums;                        // [K] per-term sums of squares (normally out + P)
     double* lossraw;                    // [K] (nullable)
     int P, K;
     int nloss;                          // launches whose per-wave loss partials are summed, in this order
@@ -452,7 +454,7 @@ AUX_DEV void reduce2_body(int r, const Reduce2Args& a) {
             AUX_UNROLL8
             for (int ch = 0; ch < a.nsplit[g]; ++ch) s += t[ch];
         }
-        a.out[r] = (float)s;
+        a.sums[k] = (float)s;
         if (a.lossraw) a.lossraw[k] = s;
     }
 }
@@ -484,7 +486,7 @@ AUX_DEV void reduce_direct_body(int r, const Reduce1Args& a1, const Reduce2Args&
             AUX_UNROLL8
             for (int wv = 0; wv < nw; ++wv) s += p[(size_t)wv * a.K];
         }
-        a.out[r] = (float)s;
+        a.sums[k] = (float)s;
         if (a.lossraw) a.lossraw[k] = s;
     }
 }
@@ -583,7 +585,7 @@ inline void launch_reduce_one(const ReduceOneArgs& a, plat_stream) {
         for (int st = 128; st >= 1; st >>= 1)
             for (int t = 0; t < st; ++t) part[t] += part[t + st];
         s = part[0];
-        a.out[a.P + k] = (float)s;
+        a.sums[k] = (float)s;
         if (a.lossraw) a.lossraw[k] = s;
     }
 }
@@ -764,7 +766,7 @@ __global__ void __launch_bounds__(256) k_reduce_one(const ReduceOneArgs a) {
             __syncthreads();
         }
         if (tid == 0) {
-            a.out[a.P + k] = (float)part[0];
+            a.sums[k] = (float)part[0];
             if (a.lossraw) a.lossraw[k] = part[0];
         }
     }

@@ -111,6 +111,23 @@ int pinn_comm_init_rank(pinn_handle h, int nranks, int rank, const void* id, int
 #endif
     E.comm_size = nranks;
     E.comm_rank = rank;
+    E.comm_per_process = true;
+    return 0;
+}
+
+// bring-your-own-collective communicator (MPI, torch.distributed, ...): the engine calls `fn` where it would call ncclAllReduce
+namespace { int custom_tag; }
+int pinn_comm_init_custom(pinn_handle h, int nranks, int rank, pinn_allreduce_fn fn, void* ctx) {
+    if (!h || !fn) return fail("pinn_comm_init_custom: null handle / callback");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail("pinn_comm_init_custom: rank out of range");
+    pinn_engine& E = *h;
+    if (E.comm) return fail("pinn_comm_init_custom: the handle already belongs to a communicator (pinn_comm_destroy first)");
+    E.comm = &custom_tag;
+    E.comm_fn = fn;
+    E.comm_ctx = ctx;
+    E.comm_size = nranks;
+    E.comm_rank = rank;
+    E.comm_per_process = true;
     return 0;
 }
 
@@ -148,6 +165,13 @@ int pinn_comm_rank(pinn_handle h) { return h ? h->comm_rank : -1; }
 
 int pinn_comm_destroy(pinn_handle h) {
     if (!h || !h->comm) return 0;
+    if (h->comm_fn) {
+        DeviceScope scope(h->device);
+        plat_sync(h->stream);
+        h->comm = nullptr; h->comm_fn = nullptr; h->comm_ctx = nullptr;
+        h->comm_size = 1; h->comm_rank = 0; h->comm_per_process = false;
+        return 0;
+    }
 #ifndef PINN_EMU
     DeviceScope scope(h->device);
     plat_sync(h->stream);
@@ -161,8 +185,64 @@ int pinn_comm_destroy(pinn_handle h) {
     h->comm = nullptr;
     h->comm_size = 1;
     h->comm_rank = 0;
+    h->comm_per_process = false;
     return 0;
 }
+
+}  // extern "C"
+
+int pe::comm_all_reduce(pinn_engine** es, int ndev, float** vec, double** raw) {
+    const int64_t P = es[0]->ntheta;
+    const int K = (int)es[0]->terms.size();
+    if (ndev == 1) {
+        pinn_engine& E = *es[0];
+        if (!E.comm) return 0;
+        if (E.comm_fn) {
+            if (E.comm_fn(E.comm_ctx, vec[0], P + K, 0, (void*)E.stream)) return fail("the caller's all-reduce callback failed (gradient vector)");
+            if (E.comm_fn(E.comm_ctx, raw[0], K, 1, (void*)E.stream)) return fail("the caller's all-reduce callback failed (loss sums)");
+            return 0;
+        }
+#ifndef PINN_EMU
+        NCCL_TRY(rccl().GroupStart(), "ncclGroupStart");
+        ncclResult_t r1 = rccl().AllReduce(vec[0], vec[0], (size_t)(P + K), ncclFloat, ncclSum, (ncclComm_t)E.comm, E.stream);
+        ncclResult_t r2 = rccl().AllReduce(raw[0], raw[0], (size_t)K, ncclDouble, ncclSum, (ncclComm_t)E.comm, E.stream);
+        NCCL_TRY(rccl().GroupEnd(), "ncclGroupEnd");
+        if (r1 != ncclSuccess) return nccl_fail("ncclAllReduce", r1);
+        if (r2 != ncclSuccess) return nccl_fail("ncclAllReduce", r2);
+#else
+        if (E.comm_size != 1) return fail("the emulation build has no inter-process transport of its own (pinn_comm_init_custom supplies one)");
+#endif
+        return 0;
+    }
+#ifndef PINN_EMU
+    NCCL_TRY(rccl().GroupStart(), "ncclGroupStart");
+    for (int i = 0; i < ndev; ++i) {
+        pinn_engine& E = *es[i];
+        DeviceScope scope(E.device);
+        ncclResult_t rc = rccl().AllReduce(vec[i], vec[i], (size_t)(P + K), ncclFloat, ncclSum, (ncclComm_t)E.comm, E.stream);
+        if (rc == ncclSuccess) rc = rccl().AllReduce(raw[i], raw[i], (size_t)K, ncclDouble, ncclSum, (ncclComm_t)E.comm, E.stream);
+        if (rc != ncclSuccess) { (void)rccl().GroupEnd(); return nccl_fail("ncclAllReduce", rc); }
+    }
+    NCCL_TRY(rccl().GroupEnd(), "ncclGroupEnd");
+#else
+    {
+        std::vector<float> sum((size_t)(P + K), 0.f);
+        std::vector<double> rs((size_t)K, 0.0);
+        for (int i = 0; i < ndev; ++i) {
+            for (int64_t j = 0; j < P + K; ++j) sum[j] += vec[i][j];          // rank order: deterministic
+            for (int k = 0; k < K; ++k) rs[k] += raw[i][k];
+        }
+        for (int i = 0; i < ndev; ++i) {
+            std::memcpy(vec[i], sum.data(), sizeof(float) * (P + K));
+            std::memcpy(raw[i], rs.data(), sizeof(double) * K);
+        }
+    }
+#endif
+    return 0;
+}
+
+extern "C" {
+
 
 int pinn_loss_grad_sharded_device(pinn_handle h, const float* d_theta, const float* term_w, float* d_out, void* stream) {
     if (!h || !d_theta || !d_out) return fail("pinn_loss_grad_sharded_device: null argument");
@@ -177,16 +257,17 @@ int pinn_loss_grad_sharded_device(pinn_handle h, const float* d_theta, const flo
     E.stream = saved;
     if (rc) return rc;
     E.timing_valid = E.timing_level >= 2;
-#ifndef PINN_EMU
-    NCCL_TRY(rccl().GroupStart(), "ncclGroupStart");
-    ncclResult_t r1 = rccl().AllReduce(d_out, d_out, (size_t)(E.ntheta + (int64_t)E.terms.size()), ncclFloat, ncclSum, (ncclComm_t)E.comm, st);
-    ncclResult_t r2 = rccl().AllReduce(E.d_lossraw, E.d_lossraw, E.terms.size(), ncclDouble, ncclSum, (ncclComm_t)E.comm, st);
-    NCCL_TRY(rccl().GroupEnd(), "ncclGroupEnd");
-    if (r1 != ncclSuccess) return nccl_fail("ncclAllReduce", r1);
-    if (r2 != ncclSuccess) return nccl_fail("ncclAllReduce", r2);
-#else
-    if (E.comm_size != 1) return fail("pinn_loss_grad_sharded_device: the emulation build reduces only inside pinn_loss_grad_sharded (single process)");
-#endif
+    if (!E.comm_per_process && E.comm_size > 1)
+        return fail("pinn_loss_grad_sharded_device: the handle belongs to a single-process communicator (pinn_comm_init_all): use pinn_loss_grad_sharded");
+    {
+        pinn_engine* es[1] = {&E};
+        float* vec[1] = {d_out};
+        double* raw[1] = {E.d_lossraw};
+        E.stream = st;
+        rc = comm_all_reduce(es, 1, vec, raw);
+        E.stream = saved;
+        if (rc) return rc;
+    }
     sums_from_double(d_out + E.ntheta, E.d_lossraw, (int)E.terms.size(), st);      // the exact (double) sums replace the float-summed ones
     return 0;
 }
@@ -212,30 +293,12 @@ int pinn_loss_grad_sharded(pinn_handle* hs, int ndev, const float* theta, int64_
         if (run_loss_grad(E, E.d_theta, E.d_out, term_w, -1, false)) return 1;
     }
     // one grouped all-reduce of [gradient | sums] across the devices, each rank's call on that rank's stream
-#ifndef PINN_EMU
-    NCCL_TRY(rccl().GroupStart(), "ncclGroupStart");
-    for (int i = 0; i < ndev; ++i) {
-        pinn_engine& E = *hs[i];
-        DeviceScope scope(E.device);
-        ncclResult_t rc = rccl().AllReduce(E.d_out, E.d_out, (size_t)(P + K), ncclFloat, ncclSum, (ncclComm_t)E.comm, E.stream);
-        if (rc == ncclSuccess) rc = rccl().AllReduce(E.d_lossraw, E.d_lossraw, (size_t)K, ncclDouble, ncclSum, (ncclComm_t)E.comm, E.stream);
-        if (rc != ncclSuccess) { (void)rccl().GroupEnd(); return nccl_fail("ncclAllReduce", rc); }
-    }
-    NCCL_TRY(rccl().GroupEnd(), "ncclGroupEnd");
-#else
     {
-        std::vector<float> sum((size_t)(P + K), 0.f);
-        std::vector<double> raw((size_t)K, 0.0);
-        for (int i = 0; i < ndev; ++i) {
-            for (int64_t j = 0; j < P + K; ++j) sum[j] += hs[i]->d_out[j];          // rank order: deterministic
-            for (int k = 0; k < K; ++k) raw[k] += hs[i]->d_lossraw[k];
-        }
-        for (int i = 0; i < ndev; ++i) {
-            std::memcpy(hs[i]->d_out, sum.data(), sizeof(float) * (P + K));
-            std::memcpy(hs[i]->d_lossraw, raw.data(), sizeof(double) * K);
-        }
+        std::vector<float*> vec(ndev);
+        std::vector<double*> raw(ndev);
+        for (int i = 0; i < ndev; ++i) { vec[i] = hs[i]->d_out; raw[i] = hs[i]->d_lossraw; }
+        if (comm_all_reduce(hs, ndev, vec.data(), raw.data())) return 1;
     }
-#endif
     // the result is identical on every device; rank 0 delivers it
     pinn_engine& E0 = *hs[0];
     {

@@ -71,18 +71,15 @@ int ensure_points(pinn_engine& E) {
     return 0;
 }
 
-// the weights every network's kernels read in this evaluation: the network's slice of theta itself where the kernels' image is theta's own
-// layout (NetPlan::direct; needs a 16-byte aligned address), otherwise the packed image rebuilt by k_pack
+// the weights every network's kernels read in this evaluation: the packed image rebuilt by k_pack (DGM kernels read theta itself)
 void pack_all(pinn_engine& E, const float* d_theta = nullptr, bool packed_fresh = false) {
     const float* th = d_theta ? d_theta : E.d_theta;
     for (size_t n = 0; n < E.nets.size(); ++n) {
         NetPlan& NP = E.netplans[n];
         if (!NP.spec) continue;
         if (NP.spec->family == 3) { NP.cur = th + E.nets[n].theta_off; continue; }          // DGM kernels read theta unpacked
-        const float* slice = th + E.nets[n].theta_off;
-        if (NP.direct && ((uintptr_t)slice & 15u) == 0) { NP.cur = slice; continue; }
         NP.cur = NP.d_packed;
-        const bool gather = !packed_fresh || NP.direct;            // (fresh: the optimiser's update kernel already wrote the fp32 image)
+        const bool gather = !packed_fresh;                         // (fresh: the optimiser's update kernel already wrote the fp32 image)
         if (gather && !NP.spec->BFX) aux::launch_pack(NP.d_packed, NP.d_pack_idx, th, NP.npacked, E.stream);
         if (NP.spec->BFX) {                                        // split-operand GEMMs: the three bf16 pieces of every hidden->hidden weight,
                                                                    // written by the same launch as the fp32 image
@@ -139,7 +136,8 @@ aux::ExprArgs expr_args(pinn_engine& E, Coupled& Cp, float scale, float* resid) 
 // loss_only: MODE_LOSS launches (forward + tape + sums of squares; coupled equations: forward launches + k_expr without adjoints), only
 // the K sums are reduced and d_out[0, P) is left untouched.
 int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const float* term_w, int only_term /* -1 = all */, bool timing,
-                  double* lossraw /* K exact double sums; default: E.d_lossraw */, bool packed_fresh, bool loss_only) {
+                  double* lossraw /* K exact double sums; default: E.d_lossraw */, bool packed_fresh, bool loss_only, float* d_sums) {
+    if (!d_sums) d_sums = d_out + E.ntheta;              // the K sums follow the gradient unless the caller has a buffer of their own (loss-only)
     if (ensure_points(E)) return 1;
     const int K = (int)E.terms.size();
     const bool phase_ev = timing && E.timing_level >= 2;
@@ -223,8 +221,6 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
             ga_launch = &ga_one;
         }
         const bool merged_head = mu && (int)g == mu->head;
-        bool pp_launch = false;
-        int pp_blocks = 0;
         if (merged_head) {
             // ONE launch for this group's tiles and the tail group's: terms and tiles concatenated, the tail's after the head's
             const Group& T2 = E.groups[mu->tail];
@@ -246,12 +242,6 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
             ga_one.chain = 0;
             blocks = std::max(1, std::min(loss_only ? E.ncu * mu->pair->WG_FWD : mu->max_blocks, ga_one.ntiles));
             ga_launch = &ga_one;
-            // ping-pong scheduling (one 8-wave workgroup per CU = two wave quartets half a tile apart): PINN_PP=1
-            pp_launch = !loss_only && mu->pair->launch_pp != nullptr && std::getenv("PINN_PP") != nullptr && mu->max_blocks >= 2;
-            if (pp_launch) {
-                pp_blocks = std::max(1, std::min(mu->max_blocks / 2, (ga_one.ntiles + 1) / 2));
-                blocks = 2 * pp_blocks;                    // virtual workgroups (= gradient slabs, rows of loss partials / 4)
-            }
         }
         G.launched_blocks = blocks;
         G.launched_by = (int)g;
@@ -278,8 +268,7 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
             plat_stream_wait_event(st, E.ev_fork);
         }
         if (group_ev(g)) plat_event_record(G.ev_a, st);
-        if (merged_head && pp_launch) mu->pair->launch_pp(*ga_launch, pp_blocks, st);
-        else if (merged_head) mu->pair->launch(*ga_launch, loss_only ? pk::MODE_LOSS : pk::MODE_FUSED, blocks, st);
+        if (merged_head) mu->pair->launch(*ga_launch, loss_only ? pk::MODE_LOSS : pk::MODE_FUSED, blocks, st);
         else if (loss_only) {
             const int tiles = ga_launch->ntiles;
             const int fb = std::max(1, std::min(E.ncu * G.spec->WG_FWD, G.spec->family == 1 ? (tiles + 3) / 4 : tiles));
@@ -324,7 +313,7 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
     }
     if (phase_ev) plat_event_record(E.ev2, E.stream);
     a1.K = K;
-    a2.out = d_out; a2.lossraw = lossraw ? lossraw : E.d_lossraw; a2.row_ptr = E.d_gr_ptr; a2.row_grp = E.d_gr_grp; a2.row_ent = E.d_gr_ent;
+    a2.out = d_out; a2.sums = d_sums; a2.lossraw = lossraw ? lossraw : E.d_lossraw; a2.row_ptr = E.d_gr_ptr; a2.row_grp = E.d_gr_grp; a2.row_ent = E.d_gr_ent;
     a2.ngroups = (int)(E.groups.size() + E.coupled.size()); a2.P = (int)E.ntheta; a2.K = K;
     a2.skip_grad = loss_only ? 1 : 0;
     // one slab set carries the whole gradient (a single network whose launch groups are merged / chained): one reduction kernel
@@ -335,7 +324,7 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
         aux::ReduceOneArgs ro;
         std::memset(&ro, 0, sizeof ro);
         if (RG) { ro.slabs = RG->d_slabs; ro.slab = RG->slab_floats; ro.nblocks = a1.nblocks[slabset_group]; ro.nent = RG->nent; ro.ent_theta = RG->d_ent_theta; }
-        ro.out = d_out; ro.lossraw = a2.lossraw; ro.P = (int)E.ntheta; ro.K = K;       // (loss-only: nent = 0, only the K loss blocks run)
+        ro.out = d_out; ro.sums = d_sums; ro.lossraw = a2.lossraw; ro.P = (int)E.ntheta; ro.K = K;       // (loss-only: nent = 0, only the K loss blocks run)
         for (int g = 0; g < a2.ngroups; ++g)
             if (a1.active[g]) { ro.losspart[ro.nloss] = a1.losspart[g]; ro.nrows[ro.nloss] = a1.nblocks[g] * a1.nwpb[g]; ++ro.nloss; }
         aux::launch_reduce_one(ro, E.stream);
@@ -376,6 +365,11 @@ int pinn_create_on(const char* descriptor, int device, pinn_handle* out) {
     DeviceScope scope(dev);
     std::unique_ptr<pinn_engine> E(new pinn_engine());
     E->device = dev;
+    if (const char* gm = std::getenv("PINN_GEMM")) {             // default GEMM arithmetic of new handles (pinn_set_option switches a live one)
+        if (std::string(gm) == "fp32") E->gemm = pk::GEMM_FP32;
+        else if (std::string(gm) == "split") E->gemm = pk::GEMM_SPLIT;
+        else return fail(std::string("PINN_GEMM must be \"split\" or \"fp32\", not \"") + gm + "\"");
+    }
     if (parse_descriptor(descriptor, *E)) return 1;
     E->ncu = plat_num_cus();
     E->stream = plat_stream_create();
@@ -418,21 +412,10 @@ int pinn_destroy(pinn_handle h) {
     DeviceScope scope(E.device);
     pinn_comm_destroy(h);
     plat_sync(E.stream);
-    for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_upts); plat_free(T.d_resid); plat_free(T.d_lb); plat_free(T.d_ub); plat_free(T.d_src_prog); plat_free(T.d_src); plat_free(T.d_data); plat_free(T.d_pw); }
-    plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist); plat_free(E.d_inv_ptr); plat_free(E.d_inv_pos); plat_free(E.d_step); plat_free(E.d_draws); plat_free(E.d_sampled); plat_free(E.d_c12);
-    for (auto& G : E.groups) {
-        plat_free(G.d_prog); plat_free(G.d_slabs); plat_free(G.d_losspart); plat_free(G.d_scratch); plat_free(G.d_rec);
-        plat_free(G.d_tmp); plat_free(G.d_ent_theta);
-        plat_event_destroy(G.ev_a); plat_event_destroy(G.ev_b);
-    }
-    for (auto& M : E.merged) { plat_free(M.d_scratch); plat_free(M.d_losspart); }
-    for (auto& Cp : E.coupled) {
-        for (float* q : Cp.d_jets) plat_free(q);
-        for (float* q : Cp.d_ubar) plat_free(q);
-        plat_free(Cp.d_prog); plat_free(Cp.d_losspart); plat_free(Cp.d_pslab); plat_free(Cp.d_tmp);
-    }
-    for (auto& N : E.netplans) { plat_free(N.d_packed); plat_free(N.d_pack_idx); }
-    plat_free(E.d_theta); plat_free(E.d_params); plat_free(E.d_defaults); plat_free(E.d_lossraw); plat_free(E.d_gr_ptr); plat_free(E.d_gr_grp); plat_free(E.d_gr_ent);
+    free_plan(E);
+    for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_upts); plat_free(T.d_resid); plat_free(T.d_lb); plat_free(T.d_ub); plat_free(T.d_data); plat_free(T.d_pw); }
+    plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist); plat_free(E.d_step); plat_free(E.d_draws); plat_free(E.d_sampled); plat_free(E.d_c12);
+    plat_free(E.d_theta); plat_free(E.d_params); plat_free(E.d_defaults); plat_free(E.d_lossraw);
     plat_free(E.d_out); plat_free(E.d_phi_pts); plat_free(E.d_phi_out); plat_free(E.d_phi_scr);
     plat_host_free(E.hp_theta);
     plat_event_destroy(E.ev0); plat_event_destroy(E.ev1); plat_event_destroy(E.ev2); plat_event_destroy(E.ev3);
@@ -447,6 +430,7 @@ int pinn_destroy(pinn_handle h) {
 int pinn_num_terms(pinn_handle h) { return h ? (int)h->terms.size() : -1; }
 int64_t pinn_num_theta(pinn_handle h) { return h ? h->ntheta : -1; }
 
+static int term_installed(pinn_engine& E, int term);
 static int set_points_impl(pinn_handle h, int term, const float* pts, int64_t n, int64_t n_norm, bool device) {
     if (!h) return fail("null handle");
     pinn_engine& E = *h;
@@ -474,6 +458,14 @@ static int set_points_impl(pinn_handle h, int term, const float* pts, int64_t n,
     T.n_norm = n_norm > 0 ? n_norm : n;
     T.data_n = 0;                                        // per-point data and weights belong to the previous set
     T.pw_n = 0;
+    return term_installed(E, term);
+}
+
+// what follows the installation of a term's point set (also after a re-plan, pinn_set_option): source channels, tile tables, the buffers of
+// a coupled equation
+static int term_installed(pinn_engine& E, int term) {
+    Term& T = E.terms[term];
+    const int64_t n = T.n;
     if (T.coupled < 0) {
         if (!T.src_root.empty()) {
             if (T.src_cap < n) {
@@ -618,7 +610,7 @@ int pinn_loss_device(pinn_handle h, const float* d_theta, float* d_sums, void* s
     DeviceScope scope(E.device);
     plat_stream saved = E.stream;
     E.stream = (plat_stream)stream;
-    int rc = run_loss_grad(E, d_theta, d_sums - E.ntheta, nullptr, -1, false, nullptr, false, true);     // only [P, P + K) of the out vector is written
+    int rc = run_loss_grad(E, d_theta, nullptr, nullptr, -1, false, nullptr, false, true, d_sums);      // loss-only: no gradient vector at all
     E.stream = saved;
     if (rc && g_err.empty()) return fail("pinn_loss_device failed");
     return rc;
@@ -752,6 +744,7 @@ int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float*
     if (!h || !theta || !pts || !out) return fail("pinn_phi: null argument");
     pinn_engine& E = *h;
     DeviceScope scope(E.device);
+    GemmScope gs(E.gemm);
     if (net < 0 || net >= (int)E.nets.size()) return fail("pinn_phi: net index out of range");
     if (n <= 0) return fail("pinn_phi: n must be positive");
     const Net& N = E.nets[net];
@@ -770,6 +763,7 @@ int pinn_derivative(pinn_handle h, int net, const float* theta, int64_t p, const
     if (!h || !theta || !pts || !out) return fail("pinn_derivative: null argument");
     pinn_engine& E = *h;
     DeviceScope scope(E.device);
+    GemmScope gs(E.gemm);
     if (net < 0 || net >= (int)E.nets.size()) return fail("pinn_derivative: net index out of range");
     if (n <= 0) return fail("pinn_derivative: n must be positive");
     if (order < 0 || order > MAX_DERIV_ORDER || (order > 0 && !axes)) return fail("pinn_derivative: order must be 0..6 (with `order` axes)");
@@ -898,6 +892,52 @@ int pinn_get_points(pinn_handle h, int term, float* pts, int64_t n) {
     return 0;
 }
 
+// switch the GEMM arithmetic of a live handle: the kernel plan is rebuilt for the other mode (packed weight images, gradient-slab maps and
+// reduction tables differ), the installed point sets, samplers, per-point data / weights and the optimiser state stay
+static int replan_gemm(pinn_engine& E, int mode) {
+    if (mode == E.gemm) return 0;
+    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    const int prev = E.gemm;
+    free_plan(E);
+    E.gemm = mode;
+    int rc = build_plan(E);
+    if (rc) {                                            // e.g. the other mode's kernel of a run-time specialised shape failed to compile: go back
+        const std::string why = g_err;
+        free_plan(E);
+        E.gemm = prev;
+        if (build_plan(E)) return fail("pinn_set_option: the kernel plan could not be rebuilt (" + why + "); the handle is unusable");
+        g_err = why;
+    }
+    for (size_t t = 0; t < E.terms.size(); ++t)
+        if (E.terms[t].d_pts && E.terms[t].n > 0 && term_installed(E, (int)t)) return 1;
+    for (size_t t = 0; t < E.terms.size(); ++t) {        // per-point data feeds the source channels: re-evaluate where installed
+        Term& T = E.terms[t];
+        if (T.ndata > 0 && T.data_n == T.n && T.n > 0) eval_sources(E, T);
+    }
+    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    return rc;
+}
+
+int pinn_set_option(pinn_handle h, const char* name, const char* value) {
+    if (!h || !name || !value) return fail("pinn_set_option: null argument");
+    pinn_engine& E = *h;
+    DeviceScope scope(E.device);
+    const std::string k = name, v = value;
+    if (k == "gemm") {
+        if (v == "split") return replan_gemm(E, pk::GEMM_SPLIT);
+        if (v == "fp32") return replan_gemm(E, pk::GEMM_FP32);
+        return fail("pinn_set_option: gemm must be \"split\" or \"fp32\"");
+    }
+    return fail("pinn_set_option: unknown option \"" + k + "\" (known: gemm)");
+}
+
+int pinn_get_option(pinn_handle h, const char* name, char* buf, int64_t buflen) {
+    if (!h || !name || !buf || buflen <= 0) return fail("pinn_get_option: bad argument");
+    const std::string k = name;
+    if (k == "gemm") { std::snprintf(buf, (size_t)buflen, "%s", h->gemm == pk::GEMM_FP32 ? "fp32" : "split"); return 0; }
+    return fail("pinn_get_option: unknown option \"" + k + "\" (known: gemm)");
+}
+
 int pinn_adam_init(pinn_handle h, const float* theta, int64_t p) {
     if (!h || !theta) return fail("pinn_adam_init: null argument");
     pinn_engine& E = *h;
@@ -984,53 +1024,53 @@ static int adam_steps_graph(pinn_engine& E, int nsteps, float lr, float beta1, f
     return 0;
 }
 
-int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta2, float eps, const float* term_w, double* loss_history) {
-    if (!h) return fail("null handle");
-    pinn_engine& E = *h;
-    DeviceScope scope(E.device);
-    if (!E.d_opt_theta) return fail("pinn_adam_steps: call pinn_adam_init first");
-    if (nsteps <= 0) return fail("pinn_adam_steps: nsteps must be positive");
-    if (ensure_points(E)) return 1;
-    const int K = (int)E.terms.size(), P = (int)E.ntheta;
-    if (E.hist_cap < nsteps) {
-        plat_free(E.d_hist);
-        E.d_hist = (double*)plat_malloc(sizeof(double) * nsteps);
-        E.hist_cap = nsteps;
-        if (!E.d_hist) return fail("device allocation failed (loss history)");
-    }
-    std::vector<float> wn(K);
-    for (int k = 0; k < K; ++k) wn[k] = (term_w ? term_w[k] : 1.0f) / (float)E.terms[k].n_norm;
-    plat_h2d(E.d_w_over_n, wn.data(), sizeof(float) * K, E.stream);
-    // Default: plain launches, the step index / bias corrections / draw counters as kernel arguments.
-    // PINN_GRAPH=1 (experiment, kept for reproduction): everything that changes from step to step lives in device memory and is advanced
-    // by a kernel, so every step issues the SAME launch sequence, which is recorded once from the stream and replayed as a hipGraph.
-    // Measured on MI355X / ROCm 7.2 (tools/time_adam_loop.py): the replay is SLOWER than the plain launches — cfg1 (1,026 points, 8 small
-    // kernels per step) 69 vs 62 us per iteration, cfg2 401 vs 390 us: the loop is bound by the dependent kernels' own latencies, not by
-    // host launch cost, and the graph's kernel nodes do not start any closer together than stream launches do.
-    const bool want_graph = std::getenv("PINN_GRAPH") != nullptr;       // (read per call: the tests switch it)
-    const int graph_rc = (want_graph && nsteps >= 8 && K <= 256) ? adam_steps_graph(E, nsteps, lr, beta1, beta2, eps, term_w) : -1;
-    if (graph_rc > 0) return g_err.empty() ? fail("pinn_adam_steps: a step of the graph path failed") : 1;      // state may have advanced: no re-run
-    if (graph_rc == 0) {
-        E.opt_t += nsteps;
-        for (auto& T : E.terms) if (T.sampler != 0) T.draws += (unsigned)nsteps;
-    } else {
-        // one update kernel per step: Adam + the evaluation's total loss + the new parameters scattered into the packed weight images
-        // (PINN_NO_FUSED_ADAM=1: total_loss, adam and next step's pack as three launches)
-        const bool fused = E.inv_ok && E.d_inv_ptr && std::getenv("PINN_NO_FUSED_ADAM") == nullptr;
-        for (int s = 0; s < nsteps; ++s) {
+// seed of a term's device sampler on this rank: ranks of a communicator draw different points (their shards of one global draw)
+static unsigned sampler_seed(const pinn_engine& E, const Term& T) {
+    return E.comm_size > 1 ? T.seed + 0x85EBCA6BU * (unsigned)(E.comm_rank + 1) : T.seed;
+}
+
+// the resident loop over ndev handles: one handle (plain, or a rank of a one-process-per-GPU communicator), or the handles of one
+// pinn_comm_init_all communicator (single process, several devices).  Per iteration and device: redraw the sampled sets -> evaluate the
+// local shards; then ONE all-reduce of [gradient | sums] (+ the K double sums) over the communicator, each rank's call on its own stream;
+// then the fused update (Adam + total loss + weight-image scatter) on every device.  No host synchronisation inside the loop.
+static int adam_loop(pinn_engine** es, int ndev, int nsteps, float lr, float beta1, float beta2, float eps, const float* term_w) {
+    const int K = (int)es[0]->terms.size(), P = (int)es[0]->ntheta;
+    const bool collective = ndev > 1 || (es[0]->comm != nullptr && es[0]->comm_per_process);
+    std::vector<float*> vec(ndev);
+    std::vector<double*> raw(ndev);
+    for (int i = 0; i < ndev; ++i) { vec[i] = es[i]->d_opt_out; raw[i] = es[i]->d_lossraw; }
+    for (int s = 0; s < nsteps; ++s) {
+        for (int i = 0; i < ndev; ++i) {
+            pinn_engine& E = *es[i];
+            DeviceScope scope(E.device);
             for (size_t t = 0; t < E.terms.size(); ++t) {            // resampling strategies: fresh points every evaluation, on device
                 Term& T = E.terms[t];
                 if (T.sampler != 0) {
-                    aux::launch_sample(T.sampler, user_pts(T), (int)(T.n * T.d_user), T.d_user, T.d_lb, T.d_ub, T.seed, T.draws++, E.stream);
+                    aux::launch_sample(T.sampler, user_pts(T), (int)(T.n * T.d_user), T.d_user, T.d_lb, T.d_ub, sampler_seed(E, T), T.draws++, E.stream);
                     embed_points(E, T);
                     eval_sources(E, T);
                 }
             }
             // from the second step on the packed weight images are already those of the current theta: the update kernel below wrote them
+            const bool fused = E.inv_ok && E.d_inv_ptr && std::getenv("PINN_NO_FUSED_ADAM") == nullptr;
             if (run_loss_grad(E, E.d_opt_theta, E.d_opt_out, term_w, -1, false, nullptr, fused && s > 0)) return 1;
+        }
+        if (collective) {
+            if (comm_all_reduce(es, ndev, vec.data(), raw.data())) return 1;
+            for (int i = 0; i < ndev; ++i) {
+                DeviceScope scope(es[i]->device);
+                sums_from_double(es[i]->d_opt_out + P, es[i]->d_lossraw, K, es[i]->stream);      // the exact (double) sums replace the float-summed ones
+            }
+        }
+        for (int i = 0; i < ndev; ++i) {
+            pinn_engine& E = *es[i];
+            DeviceScope scope(E.device);
             ++E.opt_t;
             const float c1 = (float)(1.0 / (1.0 - std::pow((double)beta1, (double)E.opt_t)));
             const float c2 = (float)(1.0 / (1.0 - std::pow((double)beta2, (double)E.opt_t)));
+            // one update kernel per step: Adam + the evaluation's total loss + the new parameters scattered into the packed weight images
+            // (PINN_NO_FUSED_ADAM=1: total_loss, adam and next step's pack as three launches)
+            const bool fused = E.inv_ok && E.d_inv_ptr && std::getenv("PINN_NO_FUSED_ADAM") == nullptr;
             if (fused) {
                 aux::AdamFusedArgs fa;
                 std::memset(&fa, 0, sizeof fa);
@@ -1046,7 +1086,96 @@ int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta
             }
         }
     }
+    return 0;
+}
+
+// checks and per-call device state shared by the Adam entry points
+static int adam_prepare(pinn_engine& E, int nsteps, const float* term_w, const char* who) {
+    if (!E.d_opt_theta) return fail(std::string(who) + ": call pinn_adam_init first");
+    if (nsteps <= 0) return fail(std::string(who) + ": nsteps must be positive");
+    if (ensure_points(E)) return 1;
+    const int K = (int)E.terms.size();
+    for (auto& T : E.terms)
+        if (T.sampler == 3 && T.seed == 0 && E.comm_size > 1)
+            return fail(std::string(who) + ": an un-randomised Sobol design (seed 0) is the same on every rank and cannot be sharded; give the sampler a seed");
+    if (E.hist_cap < nsteps) {
+        plat_free(E.d_hist);
+        E.d_hist = (double*)plat_malloc(sizeof(double) * nsteps);
+        E.hist_cap = nsteps;
+        if (!E.d_hist) return fail("device allocation failed (loss history)");
+    }
+    std::vector<float> wn(K);
+    for (int k = 0; k < K; ++k) wn[k] = (term_w ? term_w[k] : 1.0f) / (float)E.terms[k].n_norm;
+    plat_h2d(E.d_w_over_n, wn.data(), sizeof(float) * K, E.stream);
+    return plat_sync(E.stream) ? fail(std::string("device error: ") + plat_last_error()) : 0;      // (wn is a pageable temporary)
+}
+
+int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta2, float eps, const float* term_w, double* loss_history) {
+    if (!h) return fail("null handle");
+    pinn_engine& E = *h;
+    DeviceScope scope(E.device);
+    if (E.comm && !E.comm_per_process && E.comm_size > 1)
+        return fail("pinn_adam_steps: the handle belongs to a single-process communicator (pinn_comm_init_all): use pinn_adam_steps_sharded");
+    if (adam_prepare(E, nsteps, term_w, "pinn_adam_steps")) return 1;
+    const int K = (int)E.terms.size();
+    // Default: plain launches, the step index / bias corrections / draw counters as kernel arguments.
+    // PINN_GRAPH=1 (experiment, kept for reproduction): everything that changes from step to step lives in device memory and is advanced
+    // by a kernel, so every step issues the SAME launch sequence, which is recorded once from the stream and replayed as a hipGraph.
+    // Measured on MI355X / ROCm 7.2 (tools/time_adam_loop.py): the replay is SLOWER than the plain launches — cfg1 (1,026 points, 8 small
+    // kernels per step) 69 vs 62 us per iteration, cfg2 401 vs 390 us: the loop is bound by the dependent kernels' own latencies, not by
+    // host launch cost, and the graph's kernel nodes do not start any closer together than stream launches do.
+    const bool want_graph = std::getenv("PINN_GRAPH") != nullptr && !E.comm;       // (read per call: the tests switch it)
+    const int graph_rc = (want_graph && nsteps >= 8 && K <= 256) ? adam_steps_graph(E, nsteps, lr, beta1, beta2, eps, term_w) : -1;
+    if (graph_rc > 0) return g_err.empty() ? fail("pinn_adam_steps: a step of the graph path failed") : 1;      // state may have advanced: no re-run
+    if (graph_rc == 0) {
+        E.opt_t += nsteps;
+        for (auto& T : E.terms) if (T.sampler != 0) T.draws += (unsigned)nsteps;
+    } else {
+        pinn_engine* es[1] = {&E};
+        if (adam_loop(es, 1, nsteps, lr, beta1, beta2, eps, term_w)) return 1;
+    }
     if (loss_history && plat_d2h(loss_history, E.d_hist, sizeof(double) * nsteps, E.stream)) return fail("D2H copy failed");
+    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    return 0;
+}
+
+int pinn_adam_steps_sharded(pinn_handle* hs, int ndev, int nsteps, float lr, float beta1, float beta2, float eps, const float* term_w,
+                            double* loss_history) {
+    if (!hs || ndev < 1) return fail("pinn_adam_steps_sharded: need at least one handle");
+    for (int i = 0; i < ndev; ++i) {
+        if (!hs[i] || !hs[i]->comm || hs[i]->comm_per_process || hs[i]->comm_size != ndev || hs[i]->comm_rank != i)
+            return fail("pinn_adam_steps_sharded: pass the handles of one pinn_comm_init_all communicator, in rank order");
+        if (hs[i]->opt_t != hs[0]->opt_t) return fail("pinn_adam_steps_sharded: the handles' optimiser states are at different steps (pinn_adam_init every handle with the same theta)");
+        DeviceScope scope(hs[i]->device);
+        if (adam_prepare(*hs[i], nsteps, term_w, "pinn_adam_steps_sharded")) return 1;
+    }
+    if (adam_loop(hs, ndev, nsteps, lr, beta1, beta2, eps, term_w)) return 1;
+    {
+        DeviceScope scope(hs[0]->device);
+        if (loss_history && plat_d2h(loss_history, hs[0]->d_hist, sizeof(double) * nsteps, hs[0]->stream)) return fail("D2H copy failed");
+    }
+    for (int i = 0; i < ndev; ++i) {
+        DeviceScope scope(hs[i]->device);
+        if (plat_sync(hs[i]->stream)) return fail(std::string("device error: ") + plat_last_error());
+    }
+    return 0;
+}
+
+int pinn_adam_apply(pinn_handle h, const float* grad_and_sums, int64_t n, float lr, float beta1, float beta2, float eps, const float* term_w,
+                    double* loss) {
+    if (!h || !grad_and_sums) return fail("pinn_adam_apply: null argument");
+    pinn_engine& E = *h;
+    DeviceScope scope(E.device);
+    const int K = (int)E.terms.size(), P = (int)E.ntheta;
+    if (n != (int64_t)P + K) return fail("pinn_adam_apply: the vector must hold P + K floats ([gradient | raw per-term sums])");
+    if (adam_prepare(E, 1, term_w, "pinn_adam_apply")) return 1;
+    if (plat_h2d(E.d_opt_out, grad_and_sums, sizeof(float) * (size_t)(P + K), E.stream)) return fail("H2D copy failed");
+    ++E.opt_t;
+    const float c1 = (float)(1.0 / (1.0 - std::pow((double)beta1, (double)E.opt_t)));
+    const float c2 = (float)(1.0 / (1.0 - std::pow((double)beta2, (double)E.opt_t)));
+    aux::launch_total_loss(E.d_hist, 0, E.d_opt_out, P, K, E.d_w_over_n, E.stream);
+    aux::launch_adam(E.d_opt_theta, E.d_opt_m, E.d_opt_v, E.d_opt_out, P, lr, beta1, beta2, eps, c1, c2, E.stream);
+    if (loss && plat_d2h(loss, E.d_hist, sizeof(double), E.stream)) return fail("D2H copy failed");
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
     return 0;
 }
@@ -1083,6 +1212,7 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
     if (eval(x, &g, f)) return 1;
     std::deque<std::vector<double>> S, Y;
     std::deque<double> RHO;
+    bool switched = false;
     int it = 0;
     for (; it < maxiters; ++it) {
         double gmax = 0.0;
@@ -1125,7 +1255,21 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
             }
             t *= 0.5;
         }
-        if (!ok) break;                                  // no decrease along a descent direction: the evaluation's noise floor
+        if (!ok) {
+            // no decrease along a descent direction: the evaluation's noise floor.  The split-operand GEMMs' floor is 2-4 x that of the
+            // fp32 MFMA kernels: switch the handle to them once and go on from the same iterate
+            if (E.gemm == pk::GEMM_SPLIT && !switched && std::getenv("PINN_LBFGS_KEEP_GEMM") == nullptr) {
+                if (replan_gemm(E, pk::GEMM_FP32)) return 1;
+                switched = E.gemm == pk::GEMM_FP32;
+                if (switched) {
+                    if (eval(x, &g, f)) return 1;
+                    S.clear(); Y.clear(); RHO.clear();   // curvature pairs carry the other arithmetic's gradient noise
+                    --it;
+                    continue;
+                }
+            }
+            break;
+        }
         std::vector<double> sv(P), yv(P);
         for (size_t j = 0; j < P; ++j) { sv[j] = xn[j] - x[j]; yv[j] = gn[j] - g[j]; }
         const double sy = dot(sv, yv);
@@ -1139,6 +1283,7 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
     if (loss_history) for (int i = it; i < maxiters; ++i) loss_history[i] = f;
     if (iters_done) *iters_done = it;
     for (size_t i = 0; i < P; ++i) theta[i] = x[i];
+    if (switched && replan_gemm(E, pk::GEMM_SPLIT)) return 1;
     return 0;
 }
 
@@ -1211,8 +1356,8 @@ int pinn_describe(pinn_handle h, char* buf, int64_t buflen) {
     os << "backend=" << plat_name() << " cus=" << h->ncu << " ntheta=" << h->ntheta << " terms=" << h->terms.size() << "\n";
     for (size_t n = 0; n < h->netplans.size(); ++n)
         if (h->netplans[n].spec && h->netplans[n].spec->family != 3)
-            os << "net " << n << " weights=" << (h->netplans[n].direct ? "theta itself (theta-order image, no pack kernel)" : "packed image (k_pack per evaluation)")
-               << " gemm=" << (h->netplans[n].spec && h->netplans[n].spec->BFX ? (h->netplans[n].spec->BFX_DW ? "split-bf16(fwd,dA,dW)" : "split-bf16(fwd,dA)") : "fp32") << "\n";
+            os << "net " << n << " weights=packed image (k_pack per evaluation)"
+               << " gemm=" << (h->netplans[n].spec->BFX ? (h->netplans[n].spec->BFX_DW ? "split-bf16(fwd,dA,dW)" : "split-bf16(fwd,dA)") : "fp32") << "\n";
     for (size_t g = 0; g < h->groups.size(); ++g) {
         const Group& G = h->groups[g];
         os << "group " << g << (G.kind == 1 ? (G.use_rec ? " [coupled fwd/gradin, records in HBM]" : " [coupled fwd/gradin]") : "") << " net=" << G.net << " kernel=" << spec_name(*G.spec) << " tiles=" << G.ga.ntiles << " blocks=" << G.blocks << " terms=";

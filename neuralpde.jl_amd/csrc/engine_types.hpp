@@ -169,9 +169,7 @@ struct NetPlan {
     const pk::SpecInfo* spec = nullptr;   // any spec with the right (HP,NHH,D): packed layout is shared
     float* d_packed = nullptr;
     int* d_pack_idx = nullptr;
-    bool direct = false;             // the kernels' weight image IS this network's slice of theta (family 2, theta-order layout, every hidden
-                                     // width equal to the padded width, 16-byte aligned offset): no pack kernel, no copy
-    const float* cur = nullptr;      // weights the kernels read in the current evaluation: theta + theta_off (direct) or d_packed
+    const float* cur = nullptr;      // weights the kernels read in the current evaluation: d_packed (DGM kernels: theta + theta_off)
     std::vector<int> h_pack_idx;     // host copy (inverse map construction)
     int npacked = 0;
 };
@@ -191,10 +189,14 @@ struct pinn_engine {
     std::vector<MergedUnit> merged;
     std::vector<NetPlan> netplans;
     int ncu = 0;
+    int gemm = pk::GEMM_SPLIT;       // GEMM arithmetic of the neuron-split kernels of this handle (pinn_set_option "gemm"; $PINN_GEMM at pinn_create)
     int device = 0;                  // the HIP device this handle lives on (pinn_create: the caller's current device; pinn_create_on)
     // engine-owned data-parallel collective (comm.cpp): communicator of this handle's rank, nullptr = single device
     void* comm = nullptr;
     int comm_size = 1, comm_rank = 0;
+    bool comm_per_process = false;   // the other ranks live in other processes (pinn_comm_init_rank / _custom): this handle's own calls carry the collective
+    pinn_allreduce_fn comm_fn = nullptr;     // caller-supplied transport (pinn_comm_init_custom) instead of RCCL
+    void* comm_ctx = nullptr;
     plat_stream stream = nullptr;
     bool own_stream = true;
     float* d_theta = nullptr;
@@ -261,9 +263,13 @@ void analyse_static(Term& T, int np);
 bool fuse_laplacian(Term& T, int np);
 // engine.cpp (shared with comm.cpp)
 int run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const float* term_w, int only_term, bool timing, double* lossraw = nullptr,
-                  bool packed_fresh = false, bool loss_only = false);
+                  bool packed_fresh = false, bool loss_only = false, float* d_sums = nullptr);
 int upload_theta(pinn_engine& E, const float* theta, int64_t p);
 void sums_from_double(float* d_out_sums, const double* d_raw, int K, plat_stream st);      // (float)raw[k] -> out_sums[k], on the stream
+// comm.cpp: sum vec[i] ([P + K] floats) and raw[i] (K doubles) of the ndev handles' ranks over their communicator, in place, each on its
+// handle's stream.  ndev == 1: a one-process-per-GPU communicator (RCCL or the caller's transport; no communicator: nothing to do);
+// ndev > 1: the handles of one pinn_comm_init_all communicator, one grouped RCCL call
+int comm_all_reduce(pinn_engine** es, int ndev, float** vec, double** raw);
 // every entry point that touches the device first makes the handle's device current (single-process multi-GPU callers)
 struct DeviceScope {
     int prev;
@@ -271,6 +277,14 @@ struct DeviceScope {
     ~DeviceScope() { if (prev >= 0) plat_set_device(prev); }
 };
 // plan.cpp
+// GEMM arithmetic the kernel look-ups of the calling thread select (family 2 kernels exist as split-operand and fp32 twins): set for the
+// duration of an entry point that may look kernels up
+int current_gemm();
+struct GemmScope {
+    int prev;
+    explicit GemmScope(int mode);
+    ~GemmScope();
+};
 int round_hp(int h);
 const pk::SpecInfo* find_spec(int HP, int NHH, int D, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs,
                               unsigned need_hi, std::vector<int>* pair_index, int need_variant = 0, int need_family = 0);
@@ -296,5 +310,6 @@ bool slot_is_general(const Slot& s);                           // not representa
 inline int variant_of(int act) { return act == pk::ACT_SIN ? 1 : (act == pk::ACT_MIXED ? 2 : 0); }
 std::string spec_name(const pk::SpecInfo& s);
 int build_plan(pinn_engine& E);
+void free_plan(pinn_engine& E);            // releases everything build_plan allocated (the terms keep their point sets)
 void retile(pinn_engine& E, int gi);
 }  // namespace pe

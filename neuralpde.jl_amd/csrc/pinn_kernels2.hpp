@@ -31,80 +31,13 @@
 #define STAMP_EXTRA 0
 #endif
 
-// waves per workgroup of the H = 128 kernels: 8 => two waves per SIMD share one workgroup's LDS tiles (each owns HALF the neuron
-// tiles a wave of a 4-wave workgroup would own, so its register state fits 256 VGPRs); 4 => one wave per SIMD with 512 registers
-#ifndef PINN_F2_WAVES128
-#define PINN_F2_WAVES128 8
-#endif
-#ifndef PINN_F2_NW8_MAXNG
-#define PINN_F2_NW8_MAXNG 6
-#endif
+// ---- build switches of this header (A/B measurements; every default is the product) ----
 #ifndef PINN_F2_REC_LDS
 #define PINN_F2_REC_LDS 1               // keep the records of the stored hidden layers in LDS as far as they fit (Spec2::NRQ)
 #endif
-#ifndef PINN_F2_SPRE_MAX
-#define PINN_F2_SPRE_MAX 24
-#endif
-#ifndef PINN_F2_OCC
-#define PINN_F2_OCC 2
-#endif
-// forward GEMM: B-fragment LDS reads issued this many MFMA groups ahead of their use (0: leave the order to the compiler)
+// fp32-MFMA GEMMs: B-fragment LDS reads issued this many MFMA groups ahead of their use (0: leave the order to the compiler)
 #ifndef PINN_F2_GEMM_AHEAD
 #define PINN_F2_GEMM_AHEAD 2
-#endif
-// asymmetric MFMA-phase issue priority between the two waves of a SIMD (vec.hpp: wave_prio_gemm)
-#ifndef PINN_F2_ASYM_PRIO
-#define PINN_F2_ASYM_PRIO 0
-#endif
-#ifndef PINN_F2_OCC3_C1
-#define PINN_F2_OCC3_C1 0              // experiment: PINN_F2_OCC=3 only for the value-only (C = 1) kernels
-#endif
-#ifndef PINN_F2_LINEAR_ONLY
-#define PINN_F2_LINEAR_ONLY 0           // experiment: compile the tape interpreter out (kernels for groups whose terms are all affine)
-#endif
-// ping-pong scheduling of the merged launch (wave_main2pp; PINN_PP=1 at run time selects it).  Measured in round 3 and NOT compiled into
-// the product: 560 vs 382 us per evaluation on the bench workload (profiles/r03_experiments.txt) — a workgroup-wide barrier after every
-// GEMM / element-wise phase makes each of the 20 supersteps of a tile as long as the slowest wave's worst latency (coordinate, weight and
-// record loads), which two free-running workgroups per CU hide from each other.  The emulation build keeps it compiled (tests).
-#ifndef PINN_F2_PP
-#define PINN_F2_PP 0
-#endif
-// weight image of the neuron-split kernels.  0 (product) = two pre-shuffled MFMA-fragment images per layer written by k_pack: one 16-byte
-// load per lane and fragment, every byte of a fetched line used by the wave that fetched it.  1 = theta's OWN layout with every width
-// padded to HP (per layer W[out + in HP], then the bias): a network whose hidden widths equal HP is read straight out of theta — no pack
-// kernel, no second copy of the weights; the transposed fragment is still one 16-byte load (W[16 mo + 4 g + rr][16 mi + c], rr
-// contiguous) but the forward A-operand fragment becomes four dword loads per lane (W[16 mo + c][16 mi + 4 g + rr]) that use half of every
-// 128-byte line they touch.  Measured in round 3 (profiles/r03_experiments.txt): the evaluation loses the 2.5 us pack kernel and its
-// launch, and the fused kernel gains 12 us at full size — 382.8 vs 376.9 us per evaluation on the bench workload (79.1 vs 81.7 us on
-// the 8,192-point share, where the fixed cost matters more).  Kept as a build option; the CPU test-suite exercises both layouts.
-#ifndef PINN_F2_NATURAL_W
-#define PINN_F2_NATURAL_W 0
-#endif
-// SPLIT-OPERAND GEMMs on the bf16 matrix pipe (H = 64 kernels): an fp32 product from three bf16 pieces per operand,
-//     a b ~ ah bh + ah bm + am bh + ah bl + am bm + al bh      (a = ah + am + al to 24 bits; the dropped terms are below 2^-24 a b),
-// accumulated in fp32 by v_mfma_f32_16x16x32_bf16: 12 MFMAs of ~17 cycles for a 16x16 output tile over K = 64 instead of 16 fp32 MFMAs of
-// 32 cycles (2.56x measured, tools/micro/mfma_split_bench.hip).
-//   1 (product): the forward GEMMs and dA = W^T dZ (weights split once per evaluation by k_pack_bf16, activations / dZ split by the
-//     publishing wave: 3 x 8-byte LDS stores instead of one 16-byte store); dW stays on the fp32 pipe.  Bench workload 378 -> 310 us per
-//     evaluation, cfg3 1268 -> 1028 us, full-size goldens unchanged at 1.7e-7 (gradient) / 4e-7 (losses), bit-reproducible.
-//   2: dW = dZ A^T as well (both operands staged transposed as bf16 pieces, K = 32 points = two column groups): correct, but the 16-bit
-//     scattered staging stores cost more than the MFMAs save — 319 vs 310 us (profiles/r03_experiments.txt).
-//   3 (H = 64 kernels): dW on the bf16 pipe WITHOUT any transposed staging.  The exchange images change to "planes" — a fragment's two
-//     neuron-tile halves in separate 512-byte planes of 8-byte slots, slot(g, c) = 16 g + (c ^ 4 (g >> 1)) — so that gfx950's LDS transpose
-//     read (ds_read_b64_tr_b16: a 16-lane group turns a [4 points][16 neurons] block into per-neuron columns) delivers both operands of
-//     dW = dZ A^T in MFMA operand order (K = 32 points = two column groups) STRAIGHT OUT OF the B-operand images: dZ is already there for
-//     the dA GEMM, the a-jets are published like a forward activation.  No dZ^T / A^T staging, no ZT region (the freed LDS holds records
-//     again), 48 bf16 MFMAs instead of 64 fp32 MFMAs of twice the length per layer and tile.  The plane layout with the XOR on the
-//     point index is conflict-free for the transpose reads, the plain 8-byte reads of the forward / dA B operands and the 8-byte piece
-//     stores (tools/micro/tr_probe.hip, profiles/r03_experiments.txt).
-//   0: fp32 MFMAs everywhere (rounds 1-2).
-#ifndef PINN_F2_BF16X
-#define PINN_F2_BF16X 3
-#endif
-// the 128-wide kernels (8 waves, one neuron tile each, weight fragments fetched per k-block instead of per layer) take the split-operand
-// forward / dA GEMMs as well wherever the wider exchange buffers still leave the un-chunked dW staging in LDS (NG <= 4: every 2-D set)
-#ifndef PINN_F2_BF16X_H128
-#define PINN_F2_BF16X_H128 1
 #endif
 // Explicit software pipeline of the split-operand GEMMs: the B-operand (dW: both operands') LDS reads of group i + 1 are issued in front of
 // a scheduling fence, the six MFMAs of group i behind it — the compiler cannot sink the reads next to their uses (what it does when left
@@ -113,32 +46,46 @@
 #ifndef PINN_F2_SWP
 #define PINN_F2_SWP 7
 #endif
-#ifndef PINN_F2_ADJ_PIN
-#define PINN_F2_ADJ_PIN 0               // ... and pinned there (vec.hpp: pin_value)
-#endif
 #ifndef PINN_F2_ADJ_IL
 #define PINN_F2_ADJ_IL 1                // transpose-read schedules: activation adjoint issued between the MFMA groups of the dW GEMM (1: H = 64 only, 2: H = 128 too)
 #endif
 #ifndef PINN_F2_TR_FWDIMG
 #define PINN_F2_TR_FWDIMG 1             // transpose-read kernels: the forward pass's last exchange image serves as the first dW's a-jet operand
 #endif
-#ifndef PINN_F2_TR_AHEAD
-#define PINN_F2_TR_AHEAD 0              // reverse sweep of the transpose-read kernels: operand reads one group ahead of the MFMAs (vec.hpp: sched_da_dw_tr)
-#endif
-#ifndef PINN_F2_TR_H128
-#define PINN_F2_TR_H128 1               // level 3 for the 128-wide 8-wave kernels as well (slab-resident dW sums as the GEMM's accumulators)
-#endif
-#ifndef PINN_F2_BF16X_TWO_STAGE
-#define PINN_F2_BF16X_TWO_STAGE 1
-#endif
 #ifndef PINN_F2_WACC_PRELOAD
-#define PINN_F2_WACC_PRELOAD 2
+#define PINN_F2_WACC_PRELOAD 2          // slab-resident dW sums (H = 128) loaded as the dW GEMM's initial accumulators (2: fp32-MFMA kernels too)
 #endif
-#ifndef PINN_F2_GEMM_SITES
-#define PINN_F2_GEMM_SITES 7            // bit mask: 1 forward GEMM, 2 dA GEMM, 4 dW GEMM
+// Which GEMM arithmetic a translation unit instantiates for its family-2 kernels (bit mask: 1 = split-operand bf16 products, 2 = fp32
+// MFMAs).  The library carries both (run-time choice per handle: pinn_set_option(h, "gemm", ...)); run-time specialised units compile
+// only the one their handle asked for.
+#ifndef PINN_F2_MODES
+#define PINN_F2_MODES 3
 #endif
 
 namespace pk {
+
+// ---- GEMM arithmetic of the hidden-layer products of a family-2 kernel (template parameter GEMM_ of Spec2; SpecInfo::gemm) ----
+//   GEMM_SPLIT (default): SPLIT-OPERAND GEMMs on the bf16 matrix pipe (64- and 128-wide kernels): an fp32 product from three bf16 pieces
+//     per operand,  a b ~ ah bh + ah bm + am bh + ah bl + am bm + al bh   (a = ah + am + al to 24 bits; the dropped terms are below
+//     2^-24 a b), accumulated in fp32 by v_mfma_f32_16x16x32_bf16: 12 MFMAs of ~17 cycles for a 16x16 output tile over K = 64 instead
+//     of 16 fp32 MFMAs of 32 cycles (2.56x measured, tools/micro/mfma_split_bench.hip).  Forward and dA = W^T dZ: weights split once per
+//     evaluation by k_pack_bf16, activations / dZ split by the publishing wave (3 x 8-byte LDS stores instead of one 16-byte store).
+//     dW = dZ A^T WITHOUT any transposed staging (Spec2::BFX_TR): the exchange images are "planes" — a fragment's two neuron-tile halves
+//     in separate 512-byte planes of 8-byte slots, slot(g, c) = 16 g + (c ^ 4 (g >> 1)) — so that gfx950's LDS transpose read
+//     (ds_read_b64_tr_b16: a 16-lane group turns a [4 points][16 neurons] block into per-neuron columns) delivers both operands in MFMA
+//     operand order (K = 32 points = two column groups) STRAIGHT OUT OF the B-operand images: dZ is already there for the dA GEMM, the
+//     a-jets are published like a forward activation.  The plane layout with the XOR on the point index is conflict-free for the transpose
+//     reads, the plain 8-byte reads of the forward / dA B operands and the 8-byte piece stores (tools/micro/tr_probe.hip).  Shapes
+//     outside BFX_TR (64-wide nets deeper than 7 hidden layers) keep dW on fp32 MFMAs with staged operands.
+//   GEMM_FP32: v_mfma_f32_16x16x4_f32 everywhere (rounds 1-2): bit-for-bit an fmaf chain per product — the exact-fp32 path for callers
+//     that need the last bit (quasi-Newton finishing); ~1.35x slower on the bench workload.
+// Error budget of the two modes against the float64 oracle: DESIGN.md section 6.
+constexpr int GEMM_FP32 = 0, GEMM_SPLIT = 1;
+// settled design parameters (measured in rounds 1-3)
+constexpr int F2_WAVES128 = 8;          // waves per workgroup of the H = 128 kernels: two waves per SIMD share one workgroup's LDS tiles
+constexpr int F2_NW8_MAXNG = 6;         // ... for up to this many column groups (beyond: 4 waves with 512 registers)
+constexpr int F2_SPRE_MAX = 24;         // records parked in the scratch slab are requested one phase early when they take <= this many registers
+
 
 // What a wave's persistent gradient accumulators depend on: the network shape and the neuron split — NOT the jet-channel set or the
 // points per tile.  Kernels of one network with different channel sets (the interior and the boundary terms of one PINN) therefore
@@ -162,18 +109,19 @@ struct Acc2 {
     STAMP_MEMBERS
 };
 
-template <int HP_, int NHH_, int D_, unsigned D1MASK_, unsigned long long PAIRS_, int NPAIR_, int PG_, unsigned HI_ = 0>
+template <int HP_, int NHH_, int D_, unsigned D1MASK_, unsigned long long PAIRS_, int NPAIR_, int PG_, unsigned HI_ = 0, int GEMM_ = GEMM_SPLIT>
 struct Spec2 {
     using J = JetSet<D1MASK_, PAIRS_, NPAIR_, HI_>;
     static constexpr unsigned HI = HI_;
     static constexpr int FAMILY = 2;
+    static constexpr int GEMM = GEMM_;
     static constexpr int HP = HP_, MT = HP_ / 16, NHH = NHH_, LH = NHH_ + 1, D = D_, NPAIR = NPAIR_, PG = PG_;
     static constexpr unsigned D1MASK = D1MASK_;
     static constexpr unsigned long long PAIRS = PAIRS_;
     // waves per workgroup: 8 where the workgroup's LDS tiles (3 x NG x MT KB) leave room for only one workgroup per CU anyway and
     // a wave's state fits 256 registers tolerably (measured: NG <= 4, cfg4 44.5 -> 39.0 ms; NG = 6, the forward-Laplacian kernel of
     // cfg5: 114 spilled registers, yet 38.8 -> 34.6 ms against the 4-wave, 512-register build — the second wave per SIMD wins)
-    static constexpr int NW = (HP_ >= 128 && J::C * PG_ <= PINN_F2_NW8_MAXNG) ? PINN_F2_WAVES128 : 4;
+    static constexpr int NW = (HP_ >= 128 && J::C * PG_ <= F2_NW8_MAXNG) ? F2_WAVES128 : 4;
     static constexpr int MTW = MT / NW;                // neuron tiles per wave
     static_assert(MT % NW == 0 && MT % 4 == 0, "family 2 needs a hidden width that is a multiple of 64 (16 x waves per workgroup)");
     static constexpr int NFIRST = J::NFIRST;
@@ -185,20 +133,6 @@ struct Spec2 {
     static constexpr int pair_a(int p) { return J::pair_a(p); }
     static constexpr int pair_b(int p) { return J::pair_b(p); }
     // packed parameter buffer (floats); fragment images are [layer][tile a][tile b][lane][4 k-steps]
-#if PINN_F2_NATURAL_W
-    // theta's layout of a Dense chain, widths padded to HP: [W1 (D x HP) | b1 | W2 (HP x HP, W[out + in HP]) | b2 | ... | W_out (HP) | b_out]
-    static constexpr bool NATURAL = true;
-    static constexpr int LSTR = HP_ * HP_ + HP_;
-    static constexpr int OFF_W1 = 0;
-    static constexpr int off_w(int hl) { return D_ * HP_ + HP_ + hl * LSTR; }                       // hidden -> hidden layer hl
-    static constexpr int off_b(int layer) { return layer == 0 ? D_ * HP_ : off_w(layer - 1) + HP_ * HP_; }   // bias of hidden layer `layer`
-    static constexpr int OFF_B = D_ * HP_;
-    static constexpr int OFF_WL = off_w(NHH_);
-    static constexpr int OFF_BL = OFF_WL + HP_;
-    static constexpr int OFF_WPK = off_w(0), OFF_WTPK = off_w(0);
-    static constexpr int PACKED0 = ((OFF_BL + 1 + 3) / 4) * 4;
-#else
-    static constexpr bool NATURAL = false;
     static constexpr int OFF_W1 = 0;
     static constexpr int OFF_B = OFF_W1 + D_ * HP_;
     static constexpr int off_b(int layer) { return OFF_B + layer * HP_; }
@@ -207,12 +141,12 @@ struct Spec2 {
     static constexpr int OFF_WPK = OFF_BL + 4;                       // [NHH][mo][mi][64][4]: W[16mo+(l&15)][16mi+4(l>>4)+rr]
     static constexpr int OFF_WTPK = OFF_WPK + NHH_ * HP_ * HP_;      // [NHH][mi][mo][64][4]: W[16mo+4(l>>4)+rr][16mi+(l&15)]
     static constexpr int PACKED0 = OFF_WTPK + NHH_ * HP_ * HP_;
-#endif
     // split-operand images (k_pack_bf16): [NHH][out tile][k-block][piece][64 lanes][8 bf16] = 256 floats per fragment, forward then transposed
     static constexpr int BF_LAYER = (HP_ / 16) * (HP_ / 32) * 3 * 256;
     static constexpr int OFF_WB = PACKED0;
     static constexpr int OFF_WTB = OFF_WB + NHH_ * BF_LAYER;
-    static constexpr bool BFIMG = (PINN_F2_BF16X >= 1) && (HP_ == 64 || (HP_ == 128 && PINN_F2_BF16X_H128));   // the net's weight image carries the bf16 pieces
+    static constexpr bool BFIMG = (GEMM_ == GEMM_SPLIT) && (HP_ == 64 || HP_ == 128);   // the net's weight image carries the bf16 pieces
+    static constexpr bool HAS_SPLIT = (HP_ == 64 || HP_ == 128);     // the shape exists in both GEMM modes (SpecInfo::twin)
     static constexpr int PACKED = BFIMG ? OFF_WTB + NHH_ * BF_LAYER : PACKED0;
     // per-workgroup gradient slab: every entry is written by exactly one wave
     static constexpr int O_WBAR = 0;                                 // [NHH][to][ti][64][4]
@@ -228,51 +162,40 @@ struct Spec2 {
     static constexpr int REC = (LH - 1) * NG * MT * 256;
     // LDS (floats): X0 | X1 (activation / dZ exchange, A^T) | ZT (4 x private dZ^T) | output partials | coords
     static constexpr int XSZ = NG * MT * 256;
-    // split-operand GEMMs (PINN_F2_BF16X): the exchange buffers hold B operands as three bf16 pieces, [q][k-block of 32][piece][lane][8 bf16]
+    // split-operand GEMMs: the exchange buffers hold B operands as three bf16 pieces, [q][k-block of 32][piece][lane][8 bf16]
     static constexpr int KB = MT / 2;                                // k-blocks of 32 per layer
-    // The bigger exchange buffers must leave the un-chunked dW staging in place (BF_FULL).  128-wide kernels whose staging no longer fits
-    // beside them (six column groups: the 4-D forward-Laplacian set) stage and multiply the dW operands in TWO halves of the column groups
-    // inside the second exchange buffer, which the reverse sweep does not use otherwise (NSTAGE = 2: two more barriers per layer).
     static constexpr int XSZ_BF = NG * KB * 3 * 256;
     static constexpr int UP_SZ = (((NW + 1) * NG * 16 + 63) / 64) * 64;
-    // (level 3, TR_SHAPE: no staging at all — dW reads its operands out of the exchange images with the LDS transpose read)
-    static constexpr bool TR_SHAPE = (PINN_F2_BF16X >= 3) && ((HP_ == 64 && NW == 4 && (NHH_ * (MT / NW) * MT * 4 <= 96)) ||
-                                                               (HP_ == 128 && NW == 8 && PINN_F2_BF16X_H128 && PINN_F2_TR_H128));
-    static constexpr bool BF_FULL = (2 * XSZ_BF + (TR_SHAPE ? 0 : NG * MT * 256) + UP_SZ) * 4 <= 160 * 1024;
-    static constexpr bool BF_HALF = !BF_FULL && PINN_F2_BF16X_TWO_STAGE && (MT * (MT / NW) * 4 > 16) && (NG % 2 == 0) && (PINN_F2_BF16X != 2) &&
-                                    (2 * XSZ_BF + UP_SZ) * 4 <= 160 * 1024 && (NG / 2) * 16 * HP_ + (NG / 2) * MT * 256 <= XSZ_BF;
-    static constexpr bool BFX = BFIMG && (BF_FULL || BF_HALF);
-    static constexpr int NSTAGE = (BFX && BF_HALF) ? 2 : 1;          // passes of the dW staging + GEMM over the column groups
+    // TR_SHAPE: no dW staging at all — dW reads its operands out of the exchange images with the LDS transpose read (H = 64: weight
+    // fragments prefetched, dW sums in registers; H = 128: 8-wave workgroups, dW sums in the slab)
+    static constexpr bool TR_SHAPE = (HP_ == 64 && NW == 4 && (NHH_ * (MT / NW) * MT * 4 <= 96)) || (HP_ == 128 && NW == 8);
+    // the bigger exchange buffers must leave the un-chunked fp32 dW staging in place where the shape still stages (BFX without BFX_TR)
+    static constexpr bool BFX = BFIMG && ((2 * XSZ_BF + (TR_SHAPE ? 0 : NG * MT * 256) + UP_SZ) * 4 <= 160 * 1024);
     static constexpr int XSZB = BFX ? XSZ_BF : XSZ;                  // floats of one exchange buffer
-    // 2: dW = dZ A^T on the bf16 pipe as well: both operands are staged TRANSPOSED as bf16 pieces in MFMA operand order, K = 32 points = two
-    // column groups per MFMA (NG even): dZ^T fragments wave-private [pair][t][piece][64][8], A^T fragments cooperative in X1 [pair][tile][piece][64][8]
-    // 3: dW operands by LDS transpose reads out of the plane-layout exchange images (H = 64 kernels: weight fragments prefetched, dW sums in
-    // registers); a shape-level decision — every member of a merged launch stores its dW tiles in the same (natural) order.  An odd number
-    // of column groups pads the last K = 32 block with zeros.
+    // dW operands by LDS transpose reads out of the plane-layout exchange images; a shape-level decision — every member of a merged launch
+    // stores its dW tiles in the same (natural) order.  An odd number of column groups pads the last K = 32 block with zeros.
     static constexpr bool BFX_TR = BFX && TR_SHAPE;
-    static constexpr bool BFX_DW = BFX && !BFX_TR && (PINN_F2_BF16X == 2) && (NG % 2 == 0);
-    static constexpr bool DW_NATURAL = BFX_DW || BFX_TR;             // dW tiles in natural order: column c of tile ti = input neuron 16 ti + c
-    static constexpr int ZTW = BFX_TR ? 0 : (BFX_DW ? (NG / 2) * (MT / NW) * 3 * 256 : (NG / NSTAGE) * (MT / NW) * 256);      // floats of one wave's private dZ^T staging
+    static constexpr bool DW_NATURAL = BFX_TR;                       // dW tiles in natural order: column c of tile ti = input neuron 16 ti + c
+    static constexpr int ZTW = BFX_TR ? 0 : NG * (MT / NW) * 256;    // floats of one wave's private dZ^T staging
     static constexpr int LDS_UP = (((NW + 1) * NG * 16 + 63) / 64) * 64;    // NW x output partials + seed broadcast (UB)
     static_assert(PG_ >= 1 && PG_ <= 4, "one tape wave per point group");
     // when X0 | X1 | ZT would not fit in 160 KiB (H = 128 with 8 jet channels) the dW operands are staged one column group
     // at a time in a double buffer carved out of X1: [A^T chunk 16 x HP | 4 x dZ^T chunk]
-    static constexpr bool CHUNKED = NSTAGE == 1 && (2 * XSZB + NW * ZTW + LDS_UP) * 4 > 160 * 1024;
+    static constexpr bool CHUNKED = (2 * XSZB + NW * ZTW + LDS_UP) * 4 > 160 * 1024;
     static constexpr int CH_AT = 16 * HP_;
     static constexpr int CH_ZT = MTW * 256;
     static constexpr int CHSZ = CH_AT + NW * CH_ZT;
     static_assert(!CHUNKED || 2 * CHSZ <= XSZ, "chunk double buffer must fit inside X1");
     static constexpr int OFF_X1 = XSZB;                                                                          // LDS offsets (floats)
-    static constexpr int OFF_ZT = NSTAGE == 2 ? XSZB + (NG / 2) * 16 * HP_ : 2 * XSZB;                           // (two stages: A^T half | dZ^T halves inside X1)
-    static constexpr int OFF_UP = 2 * XSZB + ((CHUNKED || NSTAGE == 2) ? 0 : NW * ZTW);
+    static constexpr int OFF_ZT = 2 * XSZB;
+    static constexpr int OFF_UP = 2 * XSZB + (CHUNKED ? 0 : NW * ZTW);
     static constexpr int LDS_BASE = OFF_UP + LDS_UP;
-    // PINN_F2_OCC=3 (experiment): three workgroups per CU where the LDS allows it — the kernel is then compiled for <= 168 VGPRs
-    static constexpr int WG_PER_CU = (NW == 8) ? 1 : ((PINN_F2_OCC >= 3 && (!PINN_F2_OCC3_C1 || J::C == 1) && LDS_BASE * 4 <= 53 * 1024) ? 3 : ((LDS_BASE * 4 <= 80 * 1024) ? 2 : 1));
+    static constexpr int WG_PER_CU = (NW == 8) ? 1 : ((LDS_BASE * 4 <= 80 * 1024) ? 2 : 1);
     // the records of the stored hidden layers stay in LDS instead of the per-workgroup scratch slab in global memory — as many
     // (layer, column group) slices as fit without lowering the number of resident workgroups, from layer LH-2 (needed first by the
     // reverse sweep) downwards.  Each wave writes and reads its own part of a slice only.  4x64, NG = 4: 7 of the 8 slices.
     static constexpr int RECQ = MT * 256;                            // one column group of one layer's record of a tile (floats)
-    static constexpr int LDS_CAP = (WG_PER_CU == 3 ? 53 : (WG_PER_CU == 2 ? 80 : 160)) * 256 - 64;    // floats per workgroup
+    static constexpr int LDS_CAP = (WG_PER_CU == 2 ? 80 : 160) * 256 - 64;    // floats per workgroup
     static constexpr int NRQ_ALL = (LH > 2 ? LH - 2 : 0) * NG;
     static constexpr int NRQ_FIT = (LDS_CAP - LDS_BASE) / RECQ;
     static constexpr int NRQ = PINN_F2_REC_LDS ? (NRQ_FIT < NRQ_ALL ? (NRQ_FIT > 0 ? NRQ_FIT : 0) : NRQ_ALL) : 0;
@@ -287,18 +210,8 @@ struct Spec2 {
     static constexpr int OCC_FWD = WG_FWD * NW / 4;
     // dW accumulators: resident in registers across tiles when they fit (4x64: 48 registers); for wide/deep nets they
     // are accumulated per tile into this workgroup's slab instead (read-modify-write, L2; same wave owns the same tiles)
-#ifdef PINN_F2_WBAR_SLAB
-    static constexpr bool WBAR_REG = false;      // experiment: dW always accumulated in the slab (frees 48 registers at H = 64)
-#else
     static constexpr bool WBAR_REG = (NHH_ * MTW * MT * 4 <= 96);
-#endif
     using Shape = Shape2<HP_, NHH_, D_, NW, WBAR_REG>;
-    // ping-pong scheduling (wave_tiles2<.., PP = true>): supersteps (= workgroup barriers) per tile, GEMM phases at the odd positions;
-    // the second wave quartet of a workgroup starts PP_LAG supersteps (an odd number, about half a tile) behind the first
-    static constexpr int PP_STEPS = 6 * NHH_ + 2;
-    static constexpr int PP_LAG = ((PP_STEPS / 2) & 1) ? PP_STEPS / 2 : PP_STEPS / 2 - 1;
-    static constexpr bool PP_OK = (NW == 4) && (MT * MTW * 4 <= 16) && WBAR_REG && NHH_ >= 1 && ((3 * NG * MT * 256 + LDS_UP) * 4 <= 160 * 1024) &&
-                                  (2 * LDS_WG * 4 <= 160 * 1024) && !BFX;
 };
 
 // ---- persistent gradient accumulators of this wave's neuron tiles: zero, or (chained launch group) the sums an earlier launch group of
@@ -355,15 +268,9 @@ DEV void acc2_init(Acc2<typename S::Shape>& ac, const GroupArgs& ga, int blk, in
 
 // ---- the tile loop: workgroup `blk` of `nblocks` takes the tiles tix = blk (mod nblocks) of [tile_lo, tile_hi), which belong to the terms
 // [term_lo, term_hi) of the launch (one launch group: everything; a merged launch: one call per kernel family member) ----
-// PP ("ping-pong", wave_main2pp): the tile body as a fixed sequence of S::PP_STEPS supersteps, every one closed by a workgroup barrier and
-// every one either a GEMM phase (MFMA + fragment reads only) or an element-wise phase (VALU, LDS stores, global loads) — GEMM phases at the
-// odd positions.  Two wave quartets of ONE 8-wave workgroup run this body an odd number of supersteps apart, so that on every SIMD one
-// wave is in a GEMM phase while its partner does element-wise work: the matrix pipe never serves two GEMMs at once and is never left idle
-// by two waves that sit in element-wise phases together (what two independent workgroups per CU drift into).
-template <class S, int MODE, int ACTK, bool PP = false>
+template <class S, int MODE, int ACTK>
 DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds, Acc2<typename S::Shape>& ac,
                      int term_lo, int term_hi, int tile_lo, int tile_hi) {
-    static_assert(!PP || MODE == MODE_FUSED, "ping-pong scheduling is compiled for the fused evaluation only");
     constexpr int HP = S::HP, MT = S::MT, MTW = S::MTW, NHH = S::NHH, LH = S::LH, D = S::D, C = S::C, PG = S::PG, NG = S::NG;
     constexpr int NFIRST = S::NFIRST;
     using J = typename S::J;
@@ -404,7 +311,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
     const ubuf SB = ub_make(ga.scratch + (size_t)blk * (ga.scr_stride ? ga.scr_stride : S::SCR), S::SCR);
     float* X0 = lds;
     float* X1 = lds + S::OFF_X1;
-    float* ZT = lds + S::OFF_ZT + w * S::ZTW;                 // wave-private dZ^T: [q][t][16 columns][16 neurons] (BFX_DW: bf16 operand fragments)
+    float* ZT = lds + S::OFF_ZT + w * S::ZTW;                 // wave-private dZ^T: [q][t][16 columns][16 neurons] 
     float* UP = lds + (BWD ? S::OFF_UP : 2 * S::XSZB);        // output-layer partial sums [wave][q][16] (forward-only launches: LDS_FWD)
     float* RL = lds + S::LDS_BASE;                            // LDS-resident record slices [(LH-2-layer)*NG + q][tile][lane][4]
     auto rec_in_lds = [](int layer, int q) { return layer >= 1 && layer <= LH - 2 && (LH - 2 - layer) * NG + q < S::NRQ; };   // (same-kernel records only)
@@ -422,20 +329,10 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
 
     // weight fragments of this wave's neuron tile t: forward A operand of k-block mi, transposed A operand of output tile mo, bias
     auto ld_wf = [&](int hl, int t, int mi) -> vfloat4 {
-#if PINN_F2_NATURAL_W
-        vfloat4 r;
-        PINN_UNROLL for (int rr = 0; rr < 4; ++rr) r[rr] = ub_load(PB, S::off_w(hl) + 16 * (w * MTW + t) + (16 * mi + rr) * HP, c + (g << 2) * HP);
-        return r;
-#else
         return ub_load4(PB, S::OFF_WPK + ((hl * MT + w * MTW + t) * MT + mi) * 256, lane << 2);
-#endif
     };
     auto ld_wt = [&](int hl, int t, int mo) -> vfloat4 {
-#if PINN_F2_NATURAL_W
-        return ub_load4(PB, S::off_w(hl) + 16 * mo + 16 * (w * MTW + t) * HP, (g << 2) + c * HP);
-#else
         return ub_load4(PB, S::OFF_WTPK + ((hl * MT + w * MTW + t) * MT + mo) * 256, lane << 2);
-#endif
     };
     auto ld_bias = [&](int layer, int t) -> vfloat4 { return ub_load4(PB, S::off_b(layer) + 16 * (w * MTW + t), g << 2); };
 
@@ -444,7 +341,6 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
     const float bL = P[S::OFF_BL];
 
     wave_prio(1);
-    const bool gemm_hi = PINN_F2_ASYM_PRIO ? ((hw_wave_slot() & 1) == 0) : false;        // see wave_prio_gemm
     // (no dummy tiles: every wave of a workgroup works on the same tile, so a workgroup simply stops after its last one)
     const int first = tile_lo + (((blk - tile_lo) % nblocks) + nblocks) % nblocks;
     for (int tix = first; tix < tile_hi; tix += nblocks) {
@@ -535,7 +431,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
             if (S::BFX_TR) return cat_bf8(lds_load_bf4(X, vint(frag * 256) + sw), lds_load_bf4(X, vint(frag * 256 + 128) + sw));
             return lds_load_bf8(X, vint(frag * 256) + (lane << 2));
         };
-        // six bf16 MFMAs = one fp32-accurate 16x16 (x) 16x32 product (see PINN_F2_BF16X)
+        // six bf16 MFMAs = one fp32-accurate 16x16 (x) 16x32 product (GEMM_SPLIT)
         auto mfma_split = [&](const vbf8 (&a)[3], const vbf8 (&b)[3], vfloat4 c) -> vfloat4 {
             c = mfma16x32bf(a[0], b[0], c);
             c = mfma16x32bf(a[0], b[1], c);
@@ -619,7 +515,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                         PINN_UNROLL for (int ch = 1; ch < C; ++ch) A[pg * C + ch][t] = vzero4();
                     }
                 }
-                wave_prio_gemm(gemm_hi);
+                wave_prio(0);
                 if (S::BFX && (PINN_F2_SWP & 1)) {
                     gemm_swp(Xin, wb, A);
                 } else if (S::BFX) {
@@ -629,7 +525,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                             PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[sp] = ld_bfrag(Xin, (q * S::KB + kb) * 3 + sp);
                             PINN_UNROLL for (int t = 0; t < MTW; ++t) A[q][t] = mfma_split(wb[kb][t], bb, A[q][t]);
                         }
-                    if (WPRE && PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 1)) sched_gemm_prefetch<S::KB * NG, MTW * 6, PINN_F2_GEMM_AHEAD, S::BFX_TR ? 6 : 3>();
+                    if (WPRE && PINN_F2_GEMM_AHEAD > 0) sched_gemm_prefetch<S::KB * NG, MTW * 6, PINN_F2_GEMM_AHEAD, S::BFX_TR ? 6 : 3>();
                 }
                 PINN_UNROLL for (int mi = 0; mi < (S::BFX ? 0 : MT); ++mi) {
                     if (!WPRE)
@@ -641,10 +537,9 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                         PINN_UNROLL for (int t = 0; t < MTW; ++t)
                             PINN_UNROLL for (int rr = 0; rr < 4; ++rr) A[q][t] = mfma16(wf[WPRE ? mi : 0][t][rr], b4[q][rr], A[q][t]);
                 }
-                if (!S::BFX && WPRE && PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 1)) sched_gemm_prefetch<MT * NG, MTW * 4, PINN_F2_GEMM_AHEAD>();
+                if (!S::BFX && WPRE && PINN_F2_GEMM_AHEAD > 0) sched_gemm_prefetch<MT * NG, MTW * 4, PINN_F2_GEMM_AHEAD>();
                 wave_prio(1);
                 STAMP(2)
-                if (PP) wg_barrier();                                           // superstep boundary: GEMM | element-wise
                 act_forward(A, hl + 1);
                 STAMP(3)
             }
@@ -725,7 +620,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
         // broadcasts the seeds ubar = dL/d(jet channel) to the other waves through LDS.
         // records parked in the scratch slab are requested one phase before they are needed (SPRE: when they take <= 24 registers);
         // the first request (last stored layer) goes out before the wait for the tape waves' seeds
-        constexpr bool SPRE = (NG * MTW * 4 <= PINN_F2_SPRE_MAX);
+        constexpr bool SPRE = (NG * MTW * 4 <= F2_SPRE_MAX);
         vfloat4 Snext[SPRE ? NG : 1][SPRE ? MTW : 1];
         auto load_record = [&](int hl) {                                     // record of hidden layer hl (1 <= hl <= LH-2)
             PINN_UNROLL for (int q = 0; q < NG; ++q)
@@ -755,7 +650,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                         PINN_UNROLL for (int i = 0; i < D; ++i) xin[i] = x[pg][i];
                         PINN_UNROLL for (int ch = 0; ch < C; ++ch) Uin[ch] = U[pg][ch];
                     }
-                if ((PINN_F2_LINEAR_ONLY || T.linear) && C <= LIN_MAX_C) {
+                if (T.linear && C <= LIN_MAX_C) {
                     // affine residual: no interpreter, no tape registers — a handful of FMAs and the seeds are the constant coefficients
                     vfloat r = vfloat(T.lin_k);
                     PINN_UNROLL for (int ch = 0; ch < C; ++ch) r = vfma(vfloat(T.lin_a[ch < LIN_MAX_C ? ch : 0]), Uin[ch], r);
@@ -780,7 +675,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                                 lds_store(UB, vint((w * C + ch) * 16) + c, vselect(vin, rbar * vfloat(T.lin_a[ch < LIN_MAX_C ? ch : 0]), vfloat(0.f)));
                         }
                     }
-                } else if (!PINN_F2_LINEAR_ONLY) {
+                } else {
                     const int NP = ga.nparams;
                     const int DT = T.dt;            // tape rows: [coordinates DT | params NP | jet channels C | sources | ops]
                     const int R0 = DT + NP + C + T.nsrc;
@@ -899,7 +794,6 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
             act_derivs_n<J::NORD, SINACT>(act, ss[0], dd);
             jet_adjoint<J>(gg, ss, dd);
             PINN_UNROLL for (int k = 0; k < C; ++k) G[pg * C + k][0][r] = gg[k];
-            if (PINN_F2_ADJ_PIN) PINN_UNROLL for (int k = 0; k < C; ++k) pin_value(G[pg * C + k][0][r]);
         };
         PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {                        // output layer
             if (w == 0) bLbar += vselect(g0, ubar[pg][0], vfloat(0.f));
@@ -945,8 +839,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 PINN_UNROLL for (int t = 0; t < MTW; ++t)
                     PINN_UNROLL for (int r = 0; r < 4; ++r) bbar[hl + 1][t][r] += G[pg * C][t][r];
             if (TR_OVL && (hl < NHH - 1 || RECIN)) wg_barrier();             // every wave's dW GEMM of the layer above (RECIN: of the previous tile) has read X0 / X1
-            if (!PP || hl == NHH - 1) publish(XZ, G);                        // dZ in B-fragment order for dA = W^T dZ (PP: the later layers' dZ is
-                                                                             // published by the activation-adjoint superstep of the layer above)
+            publish(XZ, G);                                                  // dZ in B-fragment order for dA = W^T dZ
             if (S::BFX_TR && !(FWD_IMG && hl == NHH - 1)) {
                 // the a-jets of hidden layer hl (this wave's neuron tiles) as bf16 pieces in XA, laid out like a forward activation: the
                 // transpose reads of the dW GEMM turn XZ (dZ, own tile) and XA (every input tile) into its two operands
@@ -994,38 +887,6 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                                 else wacc[t][hb * 4 + e] = mfma16(zf[t], a4[e], wacc[t][hb * 4 + e]);
                             }
                     }
-                }
-            };
-            // split-operand dW (S::BFX_DW): column group q's dZ (own tile) and a-jets (cooperative) as three bf16 pieces in the operand order of
-            // the 16x16x32 MFMA over K = 32 POINTS (two column groups): fragment lane (g2, c2), element j <-> neuron c2 of the tile, point
-            // 4 g2 + (j & 3) of column group 2 qp + (j >> 2).  A D-layout lane (g, c) holds neurons 4 g + r at point c: its four values go to
-            // fragment lanes (c >> 2, 4 g + r), element (q & 1) 4 + (c & 3) — 16-bit LDS stores, slots XOR-swizzled by c >> 2 against bank conflicts.
-            auto stage_q_bf = [&](int q) {
-                const int qp = q >> 1, mem = q & 1;
-                PINN_UNROLL for (int t = 0; t < MTW; ++t) {
-                    vbf4 zp[3], ap[3];
-                    split3_bf16(G[q][t], zp[0], zp[1], zp[2]);
-                    split3_bf16(ajet(Sr, q / C, q % C, t), ap[0], ap[1], ap[2]);
-                    const int tile = w * MTW + t;
-                    PINN_UNROLL for (int r = 0; r < 4; ++r) {
-                        const vint slot = ((c >> 2) << 4) + (((g << 2) + vint(r)) ^ (c >> 2));
-                        const vint h = (slot << 3) + vint(mem * 4) + (c & vint(3));                  // halfword inside the 1 KB fragment
-                        PINN_UNROLL for (int sp = 0; sp < 3; ++sp) {
-                            lds_store_bf1(ZT, h + vint(((qp * MTW + t) * 3 + sp) * 512), zp[sp], r);
-                            lds_store_bf1(X1, h + vint(((qp * MT + tile) * 3 + sp) * 512), ap[sp], r);
-                        }
-                    }
-                }
-            };
-            auto dw_pair_bf = [&](int qp) {
-                const vint slot4 = ((g << 4) + (c ^ g)) << 2;                                        // this lane's (swizzled) 16-byte slot, in floats
-                vbf8 za[MTW][3];
-                PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                    PINN_UNROLL for (int sp = 0; sp < 3; ++sp) za[t][sp] = lds_load_bf8(ZT, vint(((qp * MTW + t) * 3 + sp) * 256) + slot4);
-                PINN_UNROLL for (int ti = 0; ti < MT; ++ti) {
-                    vbf8 ab[3];
-                    PINN_UNROLL for (int sp = 0; sp < 3; ++sp) ab[sp] = lds_load_bf8(X1, vint(((qp * MT + ti) * 3 + sp) * 256) + slot4);
-                    PINN_UNROLL for (int t = 0; t < MTW; ++t) wbar[hl][t][ti] = mfma_split(za[t], ab, wbar[hl][t][ti]);
                 }
             };
             // dW by LDS transpose reads (S::BFX_TR): column groups 2 qp, 2 qp + 1 are the K = 32 points of one MFMA; an odd tail pair takes
@@ -1095,50 +956,12 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
             // the activation adjoint between those of the dW GEMM, instead of in phases of their own:
             //   publish dZ | barrier | dA(q) + stage(q) ... | barrier | dW(q) ... + act_adjoint | next layer
             constexpr bool OVL = WPRE && !S::CHUNKED;
-            if (PP) {
-                // supersteps of this layer:  [stage (+ publish of the first layer's dZ)] | dA GEMM | [activation adjoint + publish of the
-                // next layer's dZ] | dW GEMM |   — GEMM phases carry no VALU work of their own, element-wise phases no MFMA
-                static_assert(!PP || (OVL && S::WBAR_REG), "ping-pong scheduling: H = 64 kernels (weight fragments prefetched, dW in registers)");
-                PINN_UNROLL for (int q = 0; q < NG; ++q) stage_q(q, ZT + q * (MTW * 256), X1 + q * 16 * HP);
-                STAMP(7)
-                wg_barrier();                                               // staged operands + dZ of every wave visible
-                STAMP(8)
-                wave_prio_gemm(gemm_hi);
-                PINN_UNROLL for (int q = 0; q < NG; ++q)
-                    PINN_UNROLL for (int mo = 0; mo < MT; ++mo) {
-                        vfloat4 b4 = lds_load4(X0, vint(((q * MT + mo) * 64) * 4) + (lane << 2));
-                        PINN_UNROLL for (int t = 0; t < MTW; ++t)
-                            PINN_UNROLL for (int rr = 0; rr < 4; ++rr) Gn[q][t] = mfma16(wt[mo][t][rr], b4[rr], Gn[q][t]);
-                    }
-                if (PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 2)) sched_gemm_prefetch<MT * NG, MTW * 4, PINN_F2_GEMM_AHEAD>();
-                wave_prio(1);
-                STAMP(10)
-                wg_barrier();                                               // dA done: X0 free
-                STAMP(11)
-                PINN_UNROLL for (int q = 0; q < NG; ++q)
-                    PINN_UNROLL for (int t = 0; t < MTW; ++t) G[q][t] = Gn[q][t];
-                act_adjoint(G, Sr);
-                if (hl > 0) {
-                    publish(X0, G);                                         // next layer's dZ (its dW operands are staged after this layer's dW)
-                    if (SPRE && hl - 1 >= 1) load_record(hl - 1);
-                }
-                STAMP(12)
-                wg_barrier();                                               // element-wise | dW GEMM
-                wave_prio_gemm(gemm_hi);
-                PINN_UNROLL for (int q = 0; q < NG; ++q) dw_q(ZT + q * (MTW * 256), X1 + q * 16 * HP);
-                if (PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 4) && MTW == 1 && MT == 4)
-                    sched_gemm_prefetch<4 * NG, 4, PINN_F2_GEMM_AHEAD, 2>();
-                wave_prio(1);
-                STAMP(9)
-                wg_barrier();                                               // dW done: ZT / X1 free (the tile's last superstep for hl == 0)
-                continue;
-            }
             if (OVL) {
                 STAMP(7)
                 wg_barrier();                                               // dZ of every wave is in X0; the previous layer's dW reads are done
                 STAMP(8)
                 if (SPRE && hl - 1 >= 1) load_record(hl - 1);
-                wave_prio_gemm(gemm_hi);
+                wave_prio(0);
                 if (S::BFX_TR && (PINN_F2_SWP & 2)) gemm_swp(XZ, wtb, Gn);
                 PINN_UNROLL for (int q = 0; q < ((S::BFX_TR && (PINN_F2_SWP & 2)) ? 0 : NG); ++q) {
                     if (S::BFX) {
@@ -1155,16 +978,15 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                         }
                     }
                     if (S::BFX_TR) continue;                                // (nothing to stage: dW reads X0 / X1 as they are)
-                    if (S::BFX_DW) stage_q_bf(q);
-                    else stage_q(q, ZT + q * (MTW * 256), X1 + q * 16 * HP);
+                    stage_q(q, ZT + q * (MTW * 256), X1 + q * 16 * HP);
                 }
-                if (!S::BFX && PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 2)) sched_gemm_prefetch<MT * NG, MTW * 4, PINN_F2_GEMM_AHEAD>();
+                if (!S::BFX && PINN_F2_GEMM_AHEAD > 0) sched_gemm_prefetch<MT * NG, MTW * 4, PINN_F2_GEMM_AHEAD>();
                 if (!S::BFX_TR) {
                     wave_prio(1);
                     STAMP(10)
                     wg_barrier();                                           // staged operands complete; X0 free again
                     STAMP(11)
-                    wave_prio_gemm(gemm_hi);
+                    wave_prio(0);
                 } else {
                     STAMP(10)
                 }
@@ -1173,12 +995,9 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                         PINN_UNROLL for (int q = 0; q < NG; ++q)
                             PINN_UNROLL for (int t = 0; t < MTW; ++t) G[q][t] = Gn[q][t];
                     PINN_UNROLL for (int qp = 0; qp < (NG + 1) / 2; ++qp) dw_pair_tr(qp);
-                    if (PINN_F2_TR_AHEAD > 0 && MTW == 1) sched_da_dw_tr<NG * S::KB, (NG + 1) / 2, MT>();
-                } else if (S::BFX_DW) {
-                    PINN_UNROLL for (int qp = 0; qp < NG / 2; ++qp) dw_pair_bf(qp);
                 } else {
                     PINN_UNROLL for (int q = 0; q < NG; ++q) dw_q(ZT + q * (MTW * 256), X1 + q * 16 * HP);
-                    if (PINN_F2_GEMM_AHEAD > 0 && (PINN_F2_GEMM_SITES & 4) && MTW == 1 && MT == 4)
+                    if (PINN_F2_GEMM_AHEAD > 0 && MTW == 1 && MT == 4)
                         sched_gemm_prefetch<4 * NG, 4, PINN_F2_GEMM_AHEAD, 2>();
                 }
                 wave_prio(1);
@@ -1231,8 +1050,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 PINN_UNROLL for (int qp = 0; qp < (NG + 1) / 2; ++qp) dw_pair_tr(qp);
                 STAMP(9)
             } else {
-                constexpr int QH = NG / S::NSTAGE;                          // column groups per staging pass
-                PINN_UNROLL for (int q = 0; q < QH; ++q) stage_q(q, ZT + q * (MTW * 256), X1 + q * 16 * HP);
+                PINN_UNROLL for (int q = 0; q < NG; ++q) stage_q(q, ZT + q * (MTW * 256), X1 + q * 16 * HP);
                 STAMP(7)
                 wg_barrier();
                 STAMP(8)
@@ -1249,13 +1067,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                             PINN_UNROLL for (int ti = 0; ti < MT; ++ti)
                                 wacc[t][ti] = gload4(slab + S::O_WBAR, vint((((hl * MT + w * MTW + t) * MT + ti) * 64) * 4) + (lane << 2));
                 }
-                PINN_UNROLL for (int q = 0; q < QH; ++q) dw_q(ZT + q * (MTW * 256), X1 + q * 16 * HP);
-                if (S::NSTAGE == 2) {
-                    wg_barrier();                                           // first half multiplied by every wave: the staging area is free
-                    PINN_UNROLL for (int q = QH; q < NG; ++q) stage_q(q, ZT + (q - QH) * (MTW * 256), X1 + (q - QH) * 16 * HP);
-                    wg_barrier();
-                    PINN_UNROLL for (int q = QH; q < NG; ++q) dw_q(ZT + (q - QH) * (MTW * 256), X1 + (q - QH) * 16 * HP);
-                }
+                PINN_UNROLL for (int q = 0; q < NG; ++q) dw_q(ZT + q * (MTW * 256), X1 + q * 16 * HP);
                 STAMP(9)
             }
             if (!S::WBAR_REG)
@@ -1395,42 +1207,6 @@ DEV void wave_main2m(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
     if (MODE != MODE_FUSED) return;
     wg_barrier();
     acc2_store<S0, (S0::PG > S1::PG ? S0::PG : S1::PG)>(ac, ga, blk, w, lds);
-}
-
-// ---- MERGED launch with PING-PONG scheduling: one 8-wave workgroup per CU = two wave quartets, each a "virtual workgroup" of the merged
-// launch (own tile stream, own LDS half, own gradient slab: vb = 2 blk + quartet of 2 nblocks), run PP_LAG supersteps apart (see
-// wave_tiles2<.., PP>).  Every quartet passes the same number of workgroup barriers: PP_STEPS per tile slot (idle slots included), the lag
-// at the start (second quartet) or at the end (first), and the epilogue's.  Correctness never depends on how the two quartets' supersteps
-// pair up (they share no LDS) — only the overlap does. ----
-template <class S0, class S1, int ACTK>
-DEV void wave_main2pp(const GroupArgs& ga, int blk, int nblocks, int w8, float* lds) {
-    static_assert(std::is_same<typename S0::Shape, typename S1::Shape>::value, "merged launches need members of one network shape and neuron split");
-    static_assert(S0::SLAB == S1::SLAB && S0::PACKED == S1::PACKED && S0::PP_OK && S1::PP_OK, "ping-pong launches: H = 64 members of one network");
-    constexpr int LDSQ = S0::LDS_WG > S1::LDS_WG ? S0::LDS_WG : S1::LDS_WG;       // LDS floats of one quartet
-    constexpr int NB = S0::PP_STEPS, LAG = S0::PP_LAG;
-    const int quartet = w8 >> 2, w = w8 & 3;
-    const int vb = 2 * blk + quartet, nvb = 2 * nblocks;
-    float* ldsq = lds + quartet * LDSQ;
-    const int wave = vb * 4 + w;
-    Acc2<typename S0::Shape> ac;
-    acc2_init<S0>(ac, ga, vb, w, true);
-    for (int j = 0; j < ga.nterms; ++j) ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[j].term_id] = 0.0;
-    if (quartet == 1)
-        for (int i = 0; i < LAG; ++i) wg_barrier();
-    const int niter = (ga.ntiles + nvb - 1) / nvb;
-    for (int it = 0; it < niter; ++it) {
-        const int gt = it * nvb + vb;
-        if (gt < ga.sub_tiles0) wave_tiles2<S0, MODE_FUSED, ACTK, true>(ga, vb, nvb, w, ldsq, ac, 0, ga.sub_terms0, gt, gt + 1);
-        else if (gt < ga.ntiles) wave_tiles2<S1, MODE_FUSED, ACTK, true>(ga, vb, nvb, w, ldsq, ac, ga.sub_terms0, ga.nterms, gt, gt + 1);
-        else
-            for (int i = 0; i < NB; ++i) wg_barrier();                      // idle tile slot: keep in step with the other quartet
-    }
-    if (quartet == 0)
-        for (int i = 0; i < LAG; ++i) wg_barrier();
-    if (ac.cur_term >= 0)
-        ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[ac.cur_term].term_id] = wave_sum_dd(ac.lsum, veq(lane_id() >> 4, 0));
-    wg_barrier();
-    acc2_store<S0, (S0::PG > S1::PG ? S0::PG : S1::PG)>(ac, ga, vb, w, ldsq);
 }
 
 }  // namespace pk

@@ -4,6 +4,13 @@
 
 namespace pe {
 
+static thread_local int g_gemm = pk::GEMM_SPLIT;
+int current_gemm() { return g_gemm; }
+GemmScope::GemmScope(int mode) : prev(g_gemm) { g_gemm = mode; }
+GemmScope::~GemmScope() { g_gemm = prev; }
+// a family-2 kernel serves the current GEMM mode when it is compiled in that mode, or when its shape has one form only
+static bool gemm_ok(const pk::SpecInfo& s) { return s.family != 2 || !s.twin || s.gemm == g_gemm; }
+
 int round_hp(int h) {
     if (h <= 16) return 16;
     if (h <= 32) return 32;
@@ -105,7 +112,7 @@ const pk::SpecInfo* find_spec(int HP, int NHH, int D, unsigned need_first, const
     const pk::SpecInfo* best = nullptr;
     const bool want_gen = (need_hi & GEN_FLAG) != 0;
     for (const pk::SpecInfo& s : pk::registry()) {
-        if (s.family == 3 || s.HP != HP || s.NHH != NHH || s.D != D) continue;       // (family 3 = DGM networks: find_spec_dgm)
+        if (s.family == 3 || s.HP != HP || s.NHH != NHH || s.D != D || !gemm_ok(s)) continue;       // (family 3 = DGM networks: find_spec_dgm)
         if (need_variant && !(s.has_sin & need_variant)) continue;
         if (want_gen != (s.ngen > 0)) continue;
         if (want_gen) {                          // general multi-index set: every requested channel must be carried
@@ -329,7 +336,7 @@ static int plan_assign_terms(pinn_engine& E) {
         // shapes without ANY compiled kernel get the fused (fewer channels) form specialised at run time
         bool any_aot = false;
         for (const pk::SpecInfo& s : pk::registry())
-            any_aot = any_aot || (s.family != 3 && s.HP == round_hp(N.maxhidden()) && s.NHH == (int)N.sizes.size() - 3 && s.D == N.sizes[0] && s.C > 1);
+            any_aot = any_aot || (s.family != 3 && gemm_ok(s) && s.HP == round_hp(N.maxhidden()) && s.NHH == (int)N.sizes.size() - 3 && s.D == N.sizes[0] && s.C > 1);
         if (any_aot) return false;
         const std::string prev = g_err;
         const bool ok = ensure_spec(N, nf, npairs, nh) != nullptr;
@@ -552,16 +559,11 @@ static int plan_pack_maps(pinn_engine& E) {
         std::vector<int> idx(s.PACKED, -1);
         for (int i = 0; i < D; ++i)
             for (int nn = 0; nn < HP; ++nn) idx[s.OFF_W1 + i * HP + nn] = Widx(0, nn, i);
-        const int lstr = HP * HP + HP;                       // theta-order image (SpecInfo::NATURAL): W of hidden->hidden layer hl, then its bias
         for (int l = 0; l < LH; ++l)
-            for (int nn = 0; nn < HP; ++nn)
-                idx[s.NATURAL ? (l == 0 ? s.OFF_B : s.OFF_WPK + (l - 1) * lstr + HP * HP) + nn : s.OFF_B + l * HP + nn] = bidx(l, nn);
+            for (int nn = 0; nn < HP; ++nn) idx[s.OFF_B + l * HP + nn] = bidx(l, nn);
         for (int nn = 0; nn < HP; ++nn) idx[s.OFF_WL + nn] = Widx(LH, 0, nn);
         idx[s.OFF_BL] = bidx(LH, 0);
-        for (int hl = 0; hl < s.NHH && s.family == 2 && s.NATURAL; ++hl)
-            for (int in = 0; in < HP; ++in)
-                for (int out = 0; out < HP; ++out) idx[s.OFF_WPK + hl * lstr + out + in * HP] = Widx(hl + 1, out, in);
-        for (int hl = 0; hl < s.NHH && s.family == 2 && !s.NATURAL; ++hl)
+        for (int hl = 0; hl < s.NHH && s.family == 2; ++hl)
             for (int ta = 0; ta < MT; ++ta)
                 for (int tb = 0; tb < MT; ++tb)
                     for (int lane = 0; lane < 64; ++lane)
@@ -582,10 +584,6 @@ static int plan_pack_maps(pinn_engine& E) {
                             // transposed fragments: [mo=m1][rr][lane][mi=m2] = W[out=16mo+4g+rr][in=16mi+c]
                             idx[s.OFF_WTPK + hl * HP * HP + ((m1 * 4 + rr) * 64 + lane) * MT + m2] = Widx(hl + 1, 16 * m1 + 4 * g + rr, 16 * m2 + c);
                         }
-        // theta-order image of a network whose widths need no padding = the network's slice of theta itself
-        NP.direct = s.family == 2 && s.NATURAL && std::getenv("PINN_NO_DIRECT_WEIGHTS") == nullptr && N.theta_off % 4 == 0;
-        for (size_t j = 1; j + 1 < N.sizes.size(); ++j) NP.direct = NP.direct && N.sizes[j] == HP;
-        for (int q = 0; q < s.PACKED && NP.direct; ++q) NP.direct = idx[q] < 0 ? q >= s.OFF_BL + 1 : idx[q] == N.theta_off + q;
         if (s.BFX && s.NHH > 16) return fail("networks with more than 17 hidden layers are not supported by the 64-wide split-operand kernels");
         NP.npacked = s.PACKED;
         NP.d_packed = (float*)plat_malloc(sizeof(float) * s.PACKED);
@@ -602,7 +600,7 @@ static int plan_pack_maps(pinn_engine& E) {
         std::vector<std::vector<int>> inv((size_t)E.ntheta);
         for (size_t n = 0; n < E.nets.size(); ++n) {
             const NetPlan& NP = E.netplans[n];
-            if (!NP.spec || NP.spec->family == 3 || NP.direct) continue;      // (direct: the kernels read theta itself, nothing to scatter)
+            if (!NP.spec || NP.spec->family == 3) continue;
             if (NP.npacked >= (1 << 24)) { E.inv_ok = false; break; }
             for (int q = 0; q < NP.npacked; ++q)
                 if (NP.h_pack_idx[q] >= 0) inv[(size_t)NP.h_pack_idx[q]].push_back((int)((n << 24) | (unsigned)q));
@@ -769,7 +767,7 @@ static int plan_group_buffers(pinn_engine& E) {
                     for (int out = 0; out < N.sizes[j + 1]; ++out) {
                         const int to = out / 16, i = out % 16, g = i / 4, r = i % 4;
                         // fp32 dW GEMM: the B operand is four consecutive inputs per lane, so tile ti holds inputs 64 (ti / 4) + 4 c + ti % 4;
-                        // split-operand dW GEMM (SpecInfo::BFX_DW): plain tiles, column c of tile ti = input 16 ti + c
+                        // transpose-read dW GEMM (SpecInfo::BFX_DW): plain tiles, column c of tile ti = input 16 ti + c
                         const int ti = s.BFX_DW ? in / 16 : (in / 64) * 4 + (in % 4), c = s.BFX_DW ? in % 16 : (in % 64) / 4;
                         add_row(loff[j] + out + in * N.sizes[j + 1], s.O_WBAR + (((hl * MT + to) * MT + ti) * 64 + g * 16 + c) * 4 + r, true);
                     }
@@ -937,7 +935,7 @@ static int plan_chain_groups(pinn_engine& E) {
 // runs as ONE launch: the wave's weight-gradient accumulators stay in registers from the head's tiles into the tail's — no slab store
 // + reload between two chained launches, one ramp, one epilogue.  PINN_NO_MERGE=1 keeps the two chained launches (A/B measurements).
 static bool same_member(const pk::SpecInfo& x, const pk::SpecInfo& y) {
-    return x.family == 2 && y.family == 2 && x.HP == y.HP && x.NHH == y.NHH && x.D == y.D && x.D1MASK == y.D1MASK && x.PAIRS == y.PAIRS &&
+    return x.family == 2 && y.family == 2 && x.gemm == y.gemm && x.HP == y.HP && x.NHH == y.NHH && x.D == y.D && x.D1MASK == y.D1MASK && x.PAIRS == y.PAIRS &&
            x.NPAIR == y.NPAIR && x.PG == y.PG && x.HI == y.HI && x.LAP == y.LAP && x.ngen == 0 && y.ngen == 0 && x.NW == y.NW && x.SLAB == y.SLAB;
 }
 static int plan_merge_groups(pinn_engine& E) {
@@ -966,10 +964,35 @@ static int plan_merge_groups(pinn_engine& E) {
 }
 
 int build_plan(pinn_engine& E) {
+    GemmScope gs(E.gemm);
     if (plan_check_nets(E) || plan_assign_terms(E) || plan_pack_maps(E) || plan_group_buffers(E) || plan_coupled_programs(E) ||
         plan_chain_groups(E) || plan_merge_groups(E) || plan_global_reduce_map(E))
         return 1;
     return 0;
+}
+
+void free_plan(pinn_engine& E) {
+    for (auto& T : E.terms) {
+        plat_free(T.d_src_prog); T.d_src_prog = nullptr;
+        plat_free(T.d_src); T.d_src = nullptr; T.src_cap = 0;
+        T.net = T.group = T.slot_in_group = T.coupled = -1;
+    }
+    for (auto& G : E.groups) {
+        plat_free(G.d_prog); plat_free(G.d_slabs); plat_free(G.d_losspart); plat_free(G.d_scratch); plat_free(G.d_rec);
+        plat_free(G.d_tmp); plat_free(G.d_ent_theta);
+        plat_event_destroy(G.ev_a); plat_event_destroy(G.ev_b);
+    }
+    for (auto& M : E.merged) { plat_free(M.d_scratch); plat_free(M.d_losspart); }
+    for (auto& Cp : E.coupled) {
+        for (float* q : Cp.d_jets) plat_free(q);
+        for (float* q : Cp.d_ubar) plat_free(q);
+        plat_free(Cp.d_prog); plat_free(Cp.d_losspart); plat_free(Cp.d_pslab); plat_free(Cp.d_tmp);
+    }
+    for (auto& N : E.netplans) { plat_free(N.d_packed); plat_free(N.d_pack_idx); }
+    plat_free(E.d_gr_ptr); plat_free(E.d_gr_grp); plat_free(E.d_gr_ent); plat_free(E.d_inv_ptr); plat_free(E.d_inv_pos);
+    E.d_gr_ptr = E.d_gr_grp = E.d_gr_ent = E.d_inv_ptr = E.d_inv_pos = nullptr;
+    E.inv_ok = false;
+    E.groups.clear(); E.merged.clear(); E.coupled.clear(); E.netplans.clear();
 }
 
 // refresh tile tables after a point set changed

@@ -36,10 +36,10 @@ struct SpecInfo {
     int ngen;                        // > 0: general multi-index channel set (jit.cpp gen_*): gen[i] = multi-index of channel i (nibble 0 = order, nibbles 1.. = axes)
     unsigned gen[MAX_GEN_CHANNELS];
     int OFF_W1, OFF_B, OFF_WL, OFF_BL, OFF_WPK, OFF_WTPK;
-    int BFX_DW;                      // family 2: dW accumulators in the natural tile order of the split-operand dW GEMM (column c of tile ti = input 16 ti + c)
+    int BFX_DW;                      // family 2: dW accumulators in the natural tile order of the transpose-read dW GEMM (column c of tile ti = input 16 ti + c)
     int BFX, OFF_WB, OFF_WTB;        // family 2, split-operand GEMMs (Spec2::BFIMG: the net's weight image carries them): bf16 piece images [NHH][tile][k-block][piece][64][8 bf16], forward / transposed
-    int NATURAL;                     // family 2: the weight image is theta's own layout padded to HP (Spec2::NATURAL): hidden->hidden layer hl at
-                                     // OFF_WPK + hl (HP HP + HP) as W[out + in HP], its bias behind it; 0: pre-shuffled fragment images
+    int gemm;                        // family 2: GEMM arithmetic of this kernel (pk::GEMM_SPLIT / pk::GEMM_FP32); families 1, 3: GEMM_FP32
+    int twin;                        // family 2: 1 when the shape is compiled in both GEMM modes (64- and 128-wide kernels), so a handle's mode selects
     int O_WBAR, O_BFRH, O_BFR0, O_W1, O_WL, O_BL, O_P;
     void (*launch)(const GroupArgs&, int mode, int blocks, plat_stream);
 };
@@ -54,8 +54,6 @@ struct PairInfo {
     int WG_PER_CU, NW, LDS_WG, SCR;      // of the merged kernel: min / common / max / max of the members
     int WG_FWD;                          // resident workgroups per CU of the loss-only variant (min of the members)
     void (*launch)(const GroupArgs&, int mode /* MODE_FUSED | MODE_LOSS */, int blocks, plat_stream);
-    // ping-pong variant (wave_main2pp): 8-wave workgroups of two quartets, `blocks` = workgroups = half the virtual workgroups; nullptr: none
-    void (*launch_pp)(const GroupArgs&, int blocks, plat_stream);
 };
 std::deque<PairInfo>& pair_registry();
 
@@ -67,7 +65,7 @@ SpecInfo make_info(void (*launch)(const GroupArgs&, int, int, plat_stream), int 
     s.act1 = s.act2 = s.dgm_rows = 0;
     s.ngen = S::J::GEN ? S::C : 0;
     for (int i = 0; i < MAX_GEN_CHANNELS; ++i) s.gen[i] = (S::J::GEN && i < S::C) ? S::J::gen_channel(i) : 0u;
-    s.family = 1; s.WG_PER_CU = 1; s.WG_FWD = 1; s.NW = 4; s.NATURAL = 0; s.BFX = 0; s.BFX_DW = 0; s.OFF_WB = s.OFF_WTB = 0;
+    s.family = 1; s.WG_PER_CU = 1; s.WG_FWD = 1; s.NW = 4; s.gemm = GEMM_FP32; s.twin = 0; s.BFX = 0; s.BFX_DW = 0; s.OFF_WB = s.OFF_WTB = 0;
     s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR; s.HI = S::HI & 0xFFFFFFu; s.LAP = S::J::LAP;
     s.PG = S::PG; s.C = S::C; s.NG = S::NG; s.TP = S::TP; s.MT = S::MT; s.LH = S::LH; s.NFIRST = S::NFIRST;
     s.PACKED = S::PACKED; s.SLAB = S::SLAB; s.SCR = S::SCR; s.LDS_WG = S::LDS_WG; s.COOP = S::COOP ? 1 : 0; s.SH = S::SH; s.PW = S::PW;
@@ -87,7 +85,7 @@ SpecInfo make_info2(void (*launch)(const GroupArgs&, int, int, plat_stream), int
     s.act1 = s.act2 = s.dgm_rows = 0;
     s.ngen = S::J::GEN ? S::C : 0;
     for (int i = 0; i < MAX_GEN_CHANNELS; ++i) s.gen[i] = (S::J::GEN && i < S::C) ? S::J::gen_channel(i) : 0u;
-    s.family = 2; s.WG_PER_CU = S::WG_PER_CU; s.WG_FWD = S::WG_FWD; s.NW = S::NW; s.NATURAL = S::NATURAL ? 1 : 0;
+    s.family = 2; s.WG_PER_CU = S::WG_PER_CU; s.WG_FWD = S::WG_FWD; s.NW = S::NW; s.gemm = S::BFIMG ? GEMM_SPLIT : GEMM_FP32; s.twin = S::HAS_SPLIT ? 1 : 0;
     s.BFX = S::BFIMG ? 1 : 0; s.OFF_WB = S::OFF_WB; s.OFF_WTB = S::OFF_WTB; s.BFX_DW = S::DW_NATURAL ? 1 : 0;
     s.HP = S::HP; s.NHH = S::NHH; s.D = S::D; s.D1MASK = S::D1MASK; s.PAIRS = S::PAIRS; s.NPAIR = S::NPAIR; s.HI = S::HI & 0xFFFFFFu; s.LAP = S::J::LAP;
     s.PG = S::PG; s.C = S::C; s.NG = S::NG; s.TP = S::TP; s.MT = S::MT; s.LH = S::LH; s.NFIRST = S::NFIRST;
@@ -165,27 +163,8 @@ void run_emu2m(const GroupArgs& ga, int blocks) {
         for (int w = 0; w < S0::NW; ++w) th[w].join();
     }
 }
-template <class S0, class S1, int ACTK>
-void run_emu2pp(const GroupArgs& ga, int blocks) {
-    constexpr int LDSQ = S0::LDS_WG > S1::LDS_WG ? S0::LDS_WG : S1::LDS_WG;
-    std::vector<float> lds((size_t)2 * LDSQ);
-    for (int b = 0; b < blocks; ++b) {
-        for (auto& v : lds) v = std::nanf("");
-        EmuBarrier bar;
-        bar.nwaves = 8;
-        std::thread th[8];
-        for (int w = 0; w < 8; ++w)
-            th[w] = std::thread([&, w] {
-                wv::emu_barrier_hook = &EmuBarrier::wait;
-                wv::emu_barrier_ctx = &bar;
-                wave_main2pp<S0, S1, ACTK>(ga, b, blocks, w, lds.data());
-            });
-        for (int w = 0; w < 8; ++w) th[w].join();
-    }
-}
 #define PINN_LAUNCH2(S, MODE, ACTK, ga, blocks, st) run_emu2<S, MODE, ACTK>(ga, blocks)
 #define PINN_LAUNCH2M(S0, S1, ACTK, MODE, ga, blocks, st) run_emu2m<S0, S1, ACTK, MODE>(ga, blocks)
-#define PINN_LAUNCH2PP(S0, S1, ACTK, ga, blocks, st) run_emu2pp<S0, S1, ACTK>(ga, blocks)
 #define PINN_LAUNCH1(S, MODE, ACTK, ga, blocks, st) run_emu<S, MODE, ACTK>(ga, blocks)
 #else
 // One workgroup = 4 independent waves (one per SIMD); persistent grid of <= #CU workgroups.
@@ -221,14 +200,6 @@ __global__ void __launch_bounds__(64 * S0::NW, (mode_is_forward_only(MODE) ? Pai
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     wave_main2m<S0, S1, ACTK, MODE>(ga, (int)blockIdx.x, (int)gridDim.x, w, lds_all);
 }
-// ping-pong variant: one 8-wave workgroup per CU (two wave quartets = two virtual workgroups of the merged launch), 2 waves per SIMD
-template <class S0, class S1, int ACTK>
-__global__ void __launch_bounds__(512, 2) k_wave2pp(const GroupArgs ga) {
-    __shared__ __attribute__((aligned(16))) float lds_all[2 * Pair2<S0, S1>::LDS_WG];
-    const int w8 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    wave_main2pp<S0, S1, ACTK>(ga, (int)blockIdx.x, (int)gridDim.x, w8, lds_all);
-}
-#define PINN_LAUNCH2PP(S0, S1, ACTK, ga, blocks, st) hipLaunchKernelGGL((k_wave2pp<S0, S1, ACTK>), dim3(blocks), dim3(512), 0, st, ga)
 #define PINN_LAUNCH2(S, MODE, ACTK, ga, blocks, st) hipLaunchKernelGGL((k_wave2<S, MODE, ACTK>), dim3(blocks), dim3(64 * S::NW), 0, st, ga)
 #define PINN_LAUNCH2M(S0, S1, ACTK, MODE, ga, blocks, st) hipLaunchKernelGGL((k_wave2m<S0, S1, ACTK, MODE>), dim3(blocks), dim3(64 * S0::NW), 0, st, ga)
 #define PINN_LAUNCH1(S, MODE, ACTK, ga, blocks, st) hipLaunchKernelGGL((k_wave<S, MODE, ACTK>), dim3(blocks), dim3(256), 0, st, ga)
@@ -270,12 +241,6 @@ template <class S0, class S1> void launch_pair2(const GroupArgs& ga, int mode, i
         if (ga.act == ACT_TANH) PINN_LAUNCH2M(S0, S1, ACT_TANH, MODE_FUSED, ga, blocks, st); else PINN_LAUNCH2M(S0, S1, ACT_SIGMOID, MODE_FUSED, ga, blocks, st);
     }
 }
-template <class S0, class S1> void launch_pair2pp(const GroupArgs& ga, int blocks, plat_stream st) {
-    (void)st;
-    if (ga.act == ACT_TANH) PINN_LAUNCH2PP(S0, S1, ACT_TANH, ga, blocks, st); else PINN_LAUNCH2PP(S0, S1, ACT_SIGMOID, ga, blocks, st);
-}
-template <class S, bool OK> struct PairPP { template <class S0, class S1> static void (*get())(const GroupArgs&, int, plat_stream) { return nullptr; } };
-template <class S> struct PairPP<S, true> { template <class S0, class S1> static void (*get())(const GroupArgs&, int, plat_stream) { return &launch_pair2pp<S0, S1>; } };
 template <class S> void launch_spec2_sin(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
     if (ga.act == ACT_SIN) launch_modes2<S, ACT_SIN>(ga, mode, blocks, st); else launch_spec2<S>(ga, mode, blocks, st);
 }
@@ -365,12 +330,8 @@ PairInfo make_pair_info() {
     p.SCR = S0::SCR > S1::SCR ? S0::SCR : S1::SCR;
     p.WG_FWD = S0::WG_FWD < S1::WG_FWD ? S0::WG_FWD : S1::WG_FWD;
     p.launch = &launch_pair2<S0, S1>;
-    p.launch_pp = PairPP<S0, (PINN_F2_PP && S0::PP_OK && S1::PP_OK)>::template get<S0, S1>();
     return p;
 }
-struct PairRegistrar {
-    explicit PairRegistrar(const PairInfo& p) { pair_registry().push_back(p); }
-};
 
 // PAIRS encoding: pair p occupies byte p: low nibble = axis a, high nibble = axis b (a <= b)
 #define PINN_PAIR(p, a, b) (((unsigned long long)((a) | ((b) << 4))) << (8 * (p)))
@@ -379,22 +340,43 @@ struct PairRegistrar {
 #define PINN_HI(axis, order) ((unsigned)(order) << (4 * (axis)))
 // forward-Laplacian channel over the axes in `mask` (ORed into the HI argument)
 #define PINN_LAP(mask) ((unsigned)(mask) << 24)
-#define PINN_INSTANTIATE2_HI(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI)                 \
-    namespace {                                                                              \
-    using NAME##_spec2 = pk::Spec2<HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI>;                \
-    pk::Registrar NAME##_reg2(pk::make_info2<NAME##_spec2>(&pk::launch_spec2<NAME##_spec2>)); \
+// family 2: every spec is registered in the GEMM modes PINN_F2_MODES asks for (bit 0: split-operand bf16 products, bit 1: fp32 MFMAs).
+// A shape without split-operand kernels (widths other than 64 / 128) is the same fp32 kernel in both forms and is registered once.
+#if PINN_F2_MODES & 1
+#define PINN_F2_IF_SPLIT(...) __VA_ARGS__
+#else
+#define PINN_F2_IF_SPLIT(...)
+#endif
+#if PINN_F2_MODES & 2
+#define PINN_F2_IF_FP32(...) __VA_ARGS__
+#else
+#define PINN_F2_IF_FP32(...)
+#endif
+template <class S> struct Launch2Plain { static void fn(const GroupArgs& ga, int mode, int blocks, plat_stream st) { launch_spec2<S>(ga, mode, blocks, st); } };
+template <class S> struct Launch2Sin { static void fn(const GroupArgs& ga, int mode, int blocks, plat_stream st) { launch_spec2_sin<S>(ga, mode, blocks, st); } };
+template <class S, template <class> class L, bool ENABLE> struct Registrar2 {
+    explicit Registrar2(int has_sin) { registry().push_back(make_info2<S>(&L<S>::fn, has_sin)); }
+};
+template <class S, template <class> class L> struct Registrar2<S, L, false> { explicit Registrar2(int) {} };      // (no kernel is instantiated)
+template <class S0, class S1, bool ENABLE> struct PairRegistrar2 { PairRegistrar2() { pair_registry().push_back(make_pair_info<S0, S1>()); } };
+template <class S0, class S1> struct PairRegistrar2<S0, S1, false> { PairRegistrar2() {} };
+// the fp32 form of a spec is a kernel of its own only where the split form exists — or when this unit compiles the fp32 form alone
+#define PINN_F2_FP32_ENABLED(S) (S::HAS_SPLIT || !(PINN_F2_MODES & 1))
+#define PINN_INSTANTIATE2_ANY(NAME, LAUNCH, VARIANT, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI)                                   \
+    namespace {                                                                                                                  \
+    PINN_F2_IF_SPLIT(using NAME##_spec2 = pk::Spec2<HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI, pk::GEMM_SPLIT>;                    \
+                     pk::Registrar2<NAME##_spec2, pk::LAUNCH, true> NAME##_reg2(VARIANT);)                                       \
+    PINN_F2_IF_FP32(using NAME##_spec2f = pk::Spec2<HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI, pk::GEMM_FP32>;                     \
+                    pk::Registrar2<NAME##_spec2f, pk::LAUNCH, PINN_F2_FP32_ENABLED(NAME##_spec2f)> NAME##_reg2f(VARIANT);)       \
     }
+#define PINN_INSTANTIATE2_HI(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI) PINN_INSTANTIATE2_ANY(NAME, Launch2Plain, 0, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI)
 #define PINN_INSTANTIATE_HI(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI)                  \
     namespace {                                                                              \
     using NAME##_spec = pk::Spec<HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI>;                  \
     pk::Registrar NAME##_reg(pk::make_info<NAME##_spec>(&pk::launch_spec<NAME##_spec>));     \
     }
 // the same with the sin-activation kernels compiled in as well
-#define PINN_INSTANTIATE2_HI_SIN(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI)             \
-    namespace {                                                                              \
-    using NAME##_spec2 = pk::Spec2<HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI>;                \
-    pk::Registrar NAME##_reg2(pk::make_info2<NAME##_spec2>(&pk::launch_spec2_sin<NAME##_spec2>, 1)); \
-    }
+#define PINN_INSTANTIATE2_HI_SIN(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI) PINN_INSTANTIATE2_ANY(NAME, Launch2Sin, 1, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI)
 #define PINN_INSTANTIATE_HI_SIN(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI)              \
     namespace {                                                                              \
     using NAME##_spec = pk::Spec<HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI>;                  \
@@ -419,9 +401,12 @@ struct PairRegistrar {
 // tile list (normally the interior term's jet set), member B of the second (normally the value-only set of the boundary terms)
 #define PINN_INSTANTIATE2_PAIR(NAME, HP, NHH, D, D1MASK_A, PAIRS_A, NPAIR_A, PG_A, HI_A, D1MASK_B, PAIRS_B, NPAIR_B, PG_B, HI_B) \
     namespace {                                                                              \
-    using NAME##_pa = pk::Spec2<HP, NHH, D, D1MASK_A, PAIRS_A, NPAIR_A, PG_A, HI_A>;         \
-    using NAME##_pb = pk::Spec2<HP, NHH, D, D1MASK_B, PAIRS_B, NPAIR_B, PG_B, HI_B>;         \
-    pk::PairRegistrar NAME##_regp(pk::make_pair_info<NAME##_pa, NAME##_pb>());               \
+    PINN_F2_IF_SPLIT(using NAME##_pa = pk::Spec2<HP, NHH, D, D1MASK_A, PAIRS_A, NPAIR_A, PG_A, HI_A, pk::GEMM_SPLIT>;  \
+                     using NAME##_pb = pk::Spec2<HP, NHH, D, D1MASK_B, PAIRS_B, NPAIR_B, PG_B, HI_B, pk::GEMM_SPLIT>;  \
+                     pk::PairRegistrar2<NAME##_pa, NAME##_pb, true> NAME##_regp;)            \
+    PINN_F2_IF_FP32(using NAME##_paf = pk::Spec2<HP, NHH, D, D1MASK_A, PAIRS_A, NPAIR_A, PG_A, HI_A, pk::GEMM_FP32>;   \
+                    using NAME##_pbf = pk::Spec2<HP, NHH, D, D1MASK_B, PAIRS_B, NPAIR_B, PG_B, HI_B, pk::GEMM_FP32>;   \
+                    pk::PairRegistrar2<NAME##_paf, NAME##_pbf, PINN_F2_FP32_ENABLED(NAME##_paf)> NAME##_regpf;)        \
     }
 #define PINN_INSTANTIATE2(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG) PINN_INSTANTIATE2_HI(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, 0u)
 #define PINN_INSTANTIATE(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG) PINN_INSTANTIATE_HI(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, 0u)

@@ -88,12 +88,8 @@ struct urec16 { int x, y, z, w; };
 inline void sched_fence() {}
 inline void store_pad() {}
 inline void keep_alive(const vfloat4&) {}
-inline void pin_value(const vfloat&) {}
 inline void wave_prio(int) {}
 template <int NGROUPS, int MFMA_PER, int AHEAD, int DS_PER = 1> inline void sched_gemm_prefetch() {}
-template <int NDA, int NQP, int MT> inline void sched_da_dw_tr() {}
-inline int hw_wave_slot() { return 0; }
-inline void wave_prio_gemm(bool) {}
 inline void vsincos(const vfloat& x, vfloat& s, vfloat& c) { for (int l = 0; l < W; ++l) { s.v[l] = std::sin(x.v[l]); c.v[l] = std::cos(x.v[l]); } }
 inline urec16 uload16(const void* p) { urec16 r; std::memcpy(&r, p, 16); return r; }
 struct urec32 { int v[8]; };
@@ -151,7 +147,7 @@ inline vfloat4 mfma16(const vfloat& a, const vfloat& b, const vfloat4& c) {
     return d;
 }
 inline vfloat4 vzero4() { vfloat4 z; for (int k = 0; k < 4; ++k) z.x[k] = vfloat(0.f); return z; }
-// ---- bf16 operands of v_mfma_f32_16x16x32_bf16 (split-operand GEMMs, pinn_kernels2.hpp PINN_F2_BF16X) ----
+// ---- bf16 operands of v_mfma_f32_16x16x32_bf16 (split-operand GEMMs, pinn_kernels2.hpp GEMM_SPLIT) ----
 // bf16 = the upper 16 bits of an fp32, conversion rounds to nearest even (v_cvt_pk_bf16_f32).
 inline uint16_t bf16_bits(float x) {
     uint32_t u;
@@ -178,10 +174,6 @@ inline void split3_bf16(const vfloat4& x, vbf4& h, vbf4& m, vbf4& l) {
 // 8-byte LDS store / 16-byte LDS and buffer loads of bf16 operands; indices in FLOATS like every other accessor here
 inline void lds_store_bf4(float* p, const vint& i, const vbf4& x) {
     for (int q = 0; q < W; ++q) { uint16_t t[4] = {x.v[0][q], x.v[1][q], x.v[2][q], x.v[3][q]}; std::memcpy(p + i.v[q], t, 8); }
-}
-// one bf16 (element r of x) per lane at HALFWORD index h (ds_write_b16)
-inline void lds_store_bf1(float* p, const vint& h, const vbf4& x, int r) {
-    for (int q = 0; q < W; ++q) std::memcpy(reinterpret_cast<char*>(p) + 2 * (size_t)h.v[q], &x.v[r][q], 2);
 }
 inline vbf8 lds_load_bf8(const float* p, const vint& i) {
     vbf8 r;
@@ -352,9 +344,6 @@ DEV void store_pad() {
         else asm volatile("s_nop %0" ::"n"(PINN_STORE_PAD - 1));
     }
 }
-// an ordered use of x at this point of the instruction stream: the arithmetic that produces x cannot be deferred past the scheduling
-// fences that follow (pure VALU work is otherwise placed where the DAG scheduler likes, whatever fences surround it in the source)
-DEV void pin_value(vfloat x) { asm volatile("" ::"v"(x)); }
 DEV void keep_alive(const vfloat4& x) {
     if (PINN_STORE_PAD > 0) asm volatile("" ::"v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
 }
@@ -369,37 +358,10 @@ template <int NGROUPS, int MFMA_PER, int AHEAD, int DS_PER = 1> DEV void sched_g
     }
     __builtin_amdgcn_sched_group_barrier(0x008, MFMA_PER * AHEAD, 0);
 }
-// The same request for the reverse sweep of the transpose-read kernels (pinn_kernels2.hpp, S::BFX_TR, one neuron tile per wave): ONE region
-// holds the dA GEMM (NDA groups of 6 operand reads + 6 MFMAs) and the dW GEMM (per column-group pair: 6 reads of the wave's dZ^T pieces,
-// then per input tile 6 reads + 6 MFMAs); every group's reads are issued in front of the PREVIOUS group's MFMAs.
-template <int NDA, int NQP, int MT> DEV void sched_da_dw_tr() {
-    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-    PINN_UNROLL for (int i = 0; i < NDA - 1; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-    }
-    PINN_UNROLL for (int qp = 0; qp < NQP; ++qp) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-        PINN_UNROLL for (int ti = 1; ti < MT; ++ti) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-        }
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-}
-// issue priority of this wave against the other wave resident on its SIMD (s_setprio): raised around MFMA clusters
-#ifndef PINN_F2_NO_PRIO
-#define PINN_F2_NO_PRIO 0               // experiment: no s_setprio anywhere (every wave at priority 0)
-#endif
-template <int P> DEV void wave_prio_t() { if (!PINN_F2_NO_PRIO) __builtin_amdgcn_s_setprio(P); }
-// slot of this wave on its SIMD (HW_REG_HW_ID bits 3:0): distinguishes the two workgroups resident on a CU
-DEV int hw_wave_slot() { return (int)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 15u); }
-// issue priority inside the MFMA clusters: ASYMMETRIC between the two waves of a SIMD.  With equal priorities two workgroups that
-// enter their GEMM phases together share the matrix pipe half-half, leave them together and then sit in their non-MFMA phases
-// together (pipe idle): a convoy.  When one of them wins the pipe outright it finishes its GEMM early and runs its element-wise /
-// barrier phases while the other one has the pipe to itself: the phases fall into anti-phase.
-DEV void wave_prio_gemm(bool hi) { if (PINN_F2_NO_PRIO) return; if (hi) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
+// issue priority of this wave against the other wave resident on its SIMD (s_setprio): 0 inside the MFMA clusters, 1 in the element-wise
+// phases, 3 for the tape waves the rest of the workgroup waits for (asymmetric priorities between the two waves of a SIMD and no
+// priorities at all were measured in rounds 2-3: no gain)
+template <int P> DEV void wave_prio_t() { __builtin_amdgcn_s_setprio(P); }
 #define wave_prio(P) wave_prio_t<P>()
 struct urec16 { int x, y, z, w; };
 DEV urec16 uload16(const void* p) {
@@ -500,7 +462,6 @@ DEV void split3_bf16(vfloat4 x, vbf4& h, vbf4& m, vbf4& l) {
     }
 }
 DEV void lds_store_bf4(float* p, vint i, vbf4 x) { *reinterpret_cast<vbf4*>(p + i) = x; }
-DEV void lds_store_bf1(float* p, vint h, vbf4 x, int r) { reinterpret_cast<__bf16*>(p)[h] = x[r]; }
 DEV vbf8 lds_load_bf8(const float* p, vint i) { return *reinterpret_cast<const vbf8*>(p + i); }
 // 8-byte LDS read of an operand half.  PINN_F2_LDS_NOMERGE (default): a volatile access in the LDS address space, which the compiler's
 // load/store optimiser leaves alone — it would otherwise pair two such reads into one ds_read2st64_b64, which the LDS serves at HALF the

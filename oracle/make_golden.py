@@ -6,6 +6,8 @@ oracle's behaviour and give the GPU tests fixtures that do not need torch autogr
 
     python oracle/make_golden.py                 # the small cases (inputs stored in the fixture)
     python oracle/make_golden.py full [names]    # the full-size cases (inputs pinned by SHA-256, minutes of CPU time each)
+    python oracle/make_golden.py variants [names]  # the same problems at SCALED and TRAINED parameters, both oracle modes (r04: the regime
+                                                 # where the split-operand bf16 GEMMs of the 64- / 128-wide kernels have the least margin)
 """
 import os
 import sys
@@ -100,11 +102,101 @@ def make_full(out, only=None):
         print(name, "losses", losses, f"({time.time() - t0:.0f} s)", flush=True)
 
 
+# ---- parameter variants (r04) ----
+# Every loss / gradient fixture above sits at glorot-initialised parameters, where pre-activations are O(1) and nothing saturates.  The
+# variants freeze the oracle at parameters that stress the arithmetic: theta x 2 and x 4 (saturating tanh units, large higher-derivative
+# jets) and TRAINED parameters (Adam in float64 on the oracle's own exact-derivative loss over a reduced point design: gradients that are
+# small differences of large per-point terms).  Both oracle modes are stored: "stencil" = the reference's finite-difference semantics
+# (src/pinn_types.jl:445-482), "exact" = the same program with exact derivatives (what the engine computes in fp32).
+VARIANT_CASES = {
+    # name: (full-size maker, maker of the reduced problem the training runs on, scale factors, Adam iteration counts)
+    "cfg2_variants": (lambda: workloads.cfg2_poisson2d(points=65536), lambda: workloads.cfg2_poisson2d(points=2048, bcs_points=512), (2.0, 4.0), (2000, 6000)),
+    "cfg3_variants": (lambda: workloads.cfg3_burgers(points=262144), lambda: workloads.cfg3_burgers(points=2048, bcs_points=512), (2.0,), (2000,)),
+    "cfg4_variants": (lambda: workloads.cfg4_cavity(points=16384, bcs_points=4096), None, (2.0, 4.0), ()),
+    "cfg5_variants": (lambda: workloads.cfg5_heat_inverse(points=32768, bcs_points=8192), None, (2.0, 4.0), ()),
+}
+
+
+def full_theta(wl):
+    theta = np.asarray(wl.theta, dtype=np.float64)
+    if wl.param_estim:
+        theta = np.concatenate([theta, [float(wl.pde_system.defaults[p]) for p in wl.pde_system.ps]])
+    return theta
+
+
+def fixture_weights(wl, K):
+    if wl.adaptive_loss is not None:
+        return np.concatenate([wl.adaptive_loss.pde_loss_weights * np.ones(len(wl.pde_system.eqs)),
+                               wl.adaptive_loss.bc_loss_weights * np.ones(len(wl.pde_system.bcs))])
+    return np.linspace(1.0, 2.0, K)
+
+
+def adam_train(prob, theta0, sets, w, iters, lr=3e-3, decay=0.6, report=500):
+    """plain Adam (beta 0.9 / 0.999, eps 1e-8, bias-corrected) in float64 on the oracle's exact-derivative objective; the step size
+    falls by `decay` every 1000 iterations (the schedule of examples/poisson2d_train.py).  Returns theta after each count in `iters`."""
+    th = np.array(theta0, dtype=np.float64)
+    m_, v_ = np.zeros_like(th), np.zeros_like(th)
+    out = {}
+    for t in range(1, max(iters) + 1):
+        ev = po.loss_and_grad(prob, th, sets, weights=w, mode="exact")
+        g = ev.grad
+        m_ = 0.9 * m_ + 0.1 * g
+        v_ = 0.999 * v_ + 0.001 * g * g
+        step = lr * decay ** ((t - 1) // 1000)
+        th = th - step * (m_ / (1 - 0.9 ** t)) / (np.sqrt(v_ / (1 - 0.999 ** t)) + 1e-8)
+        if t % report == 0:
+            print(f"    adam {t}: objective {ev.total:.4e}", flush=True)
+        if t in iters:
+            out[t] = th.copy()
+    return out
+
+
+def make_variants(out, only=None):
+    import time
+    for name, (make, make_small, scales, adam_iters) in VARIANT_CASES.items():
+        if only and name not in only:
+            continue
+        t0 = time.time()
+        wl = make()
+        sets = point_sets(wl)
+        prob = helpers.oracle_problem(m, wl.pde_system, wl.chains, param_estim=wl.param_estim)
+        K = len(sets)
+        w = fixture_weights(wl, K)
+        theta0 = full_theta(wl)
+        nnet = len(np.asarray(wl.theta))                     # network parameters (theta.p, if any, is not scaled)
+        thetas = {}
+        for sc in scales:
+            th = theta0.copy()
+            th[:nnet] *= sc
+            thetas[f"x{sc:g}"] = th
+        if adam_iters:
+            wls = make_small()
+            probs = helpers.oracle_problem(m, wls.pde_system, wls.chains, param_estim=wls.param_estim)
+            trained = adam_train(probs, full_theta(wls), point_sets(wls), fixture_weights(wls, K), set(adam_iters))
+            for it in adam_iters:
+                thetas[f"adam{it}"] = trained[it]
+        d = {"weights": w, "nsets": np.array(K), "tags": np.array(list(thetas.keys())),
+             "set_sha256": np.array([set_digest(s) for s in sets]), "set_sizes": np.array([s.shape[1] for s in sets])}
+        for tag, th in thetas.items():
+            d["theta_" + tag] = th
+            for mode in ("stencil", "exact"):
+                losses, grad = chunked_loss_and_grad(prob, th, sets, w, mode=mode)
+                d[f"losses_{mode}_{tag}"] = losses
+                d[f"grad_{mode}_{tag}"] = grad.astype(np.float64)
+            gs, ge = d[f"grad_stencil_{tag}"], d[f"grad_exact_{tag}"]
+            print(name, tag, "losses", d[f"losses_stencil_{tag}"], "|grad|", np.linalg.norm(gs), "stencil-vs-exact grad rel L2",
+                  np.linalg.norm(gs - ge) / np.linalg.norm(ge), f"({time.time() - t0:.0f} s)", flush=True)
+        np.savez_compressed(os.path.join(out, name + ".npz"), **d)
+
+
 def main():
     out = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "full":
         make_full(out, sys.argv[2:])
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "variants":
+        make_variants(out, sys.argv[2:])
         return
     for name, make in CASES.items():
         wl = make()

@@ -42,6 +42,63 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _adam_worker(rank, world, port, q):
+    """the resident Adam loop over a one-process-per-GPU communicator whose transport is torch.distributed (gloo) through
+    pinn_comm_init_custom: per iteration evaluate the local shards -> the engine calls back for ONE all-reduce -> the same fused update
+    on every rank; no host-side optimiser, theta never leaves the "device" """
+    import ctypes
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pinn_import
+    m = pinn_import.load()
+    from neuralpde_jl_amd import workloads
+    m._lib.set_library(m.Library(os.path.join(ROOT, "tests", "emu", "libpinn_emu.so")))
+    wl = workloads.cfg2_poisson2d(points=100, bcs_points=37, width=16, hidden=2)
+    rep = m.symbolic_discretize(wl.pde_system, wl.discretization())
+    eng = rep.engine
+    sets = rep.pde_train_sets + rep.bcs_train_sets
+    w = np.array([1.0, 2.0, 0.5, 1.5, 3.0], dtype=np.float32)
+    th_single, hist_single = eng.adam(wl.theta, 6, 1e-2, w)              # the whole sets on one handle
+    for k, s in enumerate(sets):
+        n = s.shape[1]
+        lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+        eng.set_points(k, s[:, lo:hi], n_norm=n)
+
+    def allreduce(buf, count, dtype, stream):
+        ty, tt = (ctypes.c_float, torch.float32) if dtype == 0 else (ctypes.c_double, torch.float64)
+        a = np.ctypeslib.as_array(ctypes.cast(buf, ctypes.POINTER(ty)), shape=(count,))
+        t = torch.from_numpy(a)                                          # shares the engine's buffer: reduced in place
+        dist.all_reduce(t)
+        return 0
+
+    eng.comm_init_custom(world, rank, allreduce)
+    th, hist = eng.adam(wl.theta, 6, 1e-2, w)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, th)
+    if rank == 0:
+        same = all(np.array_equal(g, gathered[0]) for g in gathered)
+        q.put((same, float(np.max(np.abs(th - th_single))), float(np.max(np.abs(hist - hist_single) / hist_single))))
+    eng.comm_destroy()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_resident_adam(emu_lib):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_adam_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    same, dth, dh = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert same                                         # every rank holds the identical theta after the loop
+    assert dth < 2e-5 and dh < 1e-5, (dth, dh)          # = the single-handle loop on the whole sets to float accuracy
+
+
 def test_two_rank_sharded_equals_single(emu_lib):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -896,49 +896,61 @@ def test_merged_launch_matches_chained_launches_and_oracle(npde, use_emu, monkey
     assert np.array_equal(l_again, l_m) and np.array_equal(g_again, g_m)
 
 
-def test_weights_read_straight_from_theta(npde, use_emu, monkeypatch):
-    """builds with -DPINN_F2_NATURAL_W=1 only (theta-order weight image, a measured-and-rejected option, csrc/pinn_kernels2.hpp; the whole
-    CPU suite and the GPU parity tests passed with it in round 3): neuron-split kernels whose hidden widths equal the padded width read their weights out of theta itself (no pack kernel, no
-    copy); PINN_NO_DIRECT_WEIGHTS=1 packs the same layout; a padded width (40 -> 64) always packs: same numbers"""
+def test_gemm_mode_switch_on_a_live_handle(npde, use_emu):
+    """pinn_set_option(h, "gemm", "fp32" | "split") (include/pinn_hip.h): both kernel sets are in the library; the switch rebuilds the kernel
+    plan in place and keeps point sets and optimiser state.  fp32 mode = v_mfma_f32_16x16x4_f32 (an fmaf chain per product); split mode =
+    three bf16 pieces per operand.  Both against the oracle (`check`), the fp32 mode at least as close; switching back reproduces the first
+    result bit for bit; the merged launch exists in both modes."""
     wl = _merge_cfg2(npde, 200, 70)
     w = [1.0, 2.0, 0.5, 3.0, 1.5]
-    rep, _, sets, th = check(npde, wl.pde_system, wl.chains, wl.strategy, wl.theta, weights=w)
-    if "weights=theta itself" not in rep.engine.describe():
-        pytest.skip("this build uses the pre-shuffled fragment images (PINN_F2_NATURAL_W=0, the product default)")
-    l_d, g_d = rep.engine.loss_grad(th, w)
-    monkeypatch.setenv("PINN_NO_DIRECT_WEIGHTS", "1")              # (read when the engine is created)
-    rep2 = npde.symbolic_discretize(wl.pde_system, wl.discretization())
-    assert "weights=packed image" in rep2.engine.describe()
-    for k, sset in enumerate(sets):                                # the same point sets (the strategy draws a new design per discretisation)
-        rep2.engine.set_points(k, sset)
-    l_p, g_p = rep2.engine.loss_grad(th, w)
-    monkeypatch.delenv("PINN_NO_DIRECT_WEIGHTS")
-    assert np.array_equal(l_d, l_p) and np.array_equal(g_d, g_p)
-    # resident Adam (theta lives in the optimiser's device buffer: the kernels read THAT buffer) against the packed path
-    t1, h1 = rep.engine.adam(th, 5, 1e-3, w)
-    t2, h2 = rep2.engine.adam(th, 5, 1e-3, w)
-    assert np.array_equal(t1, t2) and np.array_equal(h1, h2)
+    rep, olosses, _, th = check(npde, wl.pde_system, wl.chains, wl.strategy, wl.theta, weights=w)
+    eng = rep.engine
+    assert eng.get_option("gemm") == "split" and "gemm=split-bf16(fwd,dA,dW)" in eng.describe()
+    l_s, g_s = eng.loss_grad(th, w)
+    eng.set_option("gemm", "fp32")
+    assert eng.get_option("gemm") == "fp32" and "gemm=fp32" in eng.describe() and "launch=merged" in eng.describe()
+    l_f, g_f = eng.loss_grad(th, w)
+    np.testing.assert_allclose(l_f, l_s, rtol=2e-6)
+    np.testing.assert_allclose(g_f, g_s, rtol=0, atol=2e-6 * np.abs(g_s).max())
+    assert not np.array_equal(g_f, g_s)                            # (different arithmetic: the two modes do not round alike)
+    tl, tg = eng.term_grads(th)                                    # per-term launches, loss-only launches, pinn_phi on the fp32 plan
+    np.testing.assert_allclose((np.array(w)[:, None] * tg).sum(axis=0), g_f, rtol=0, atol=2e-6 * np.abs(g_f).max())
+    l_lo, _ = eng.loss_grad(th, w, want_grad=False)
+    np.testing.assert_allclose(l_lo, l_f, rtol=1e-12)
+    t_f, h_f = eng.adam(th, 3, 1e-3, w)
+    eng.set_option("gemm", "split")
+    l_s2, g_s2 = eng.loss_grad(th, w)
+    assert np.array_equal(l_s2, l_s) and np.array_equal(g_s2, g_s)
+    t_s, h_s = eng.adam(th, 3, 1e-3, w)
+    np.testing.assert_allclose(t_s, t_f, rtol=0, atol=1e-6)
+    with pytest.raises(Exception):
+        eng.set_option("gemm", "bf16")
+    with pytest.raises(Exception):
+        eng.set_option("nope", "1")
+
+
+def test_gemm_mode_from_the_environment_and_128_wide(npde, use_emu, monkeypatch):
+    """$PINN_GEMM selects the mode new handles start in; the 128-wide kernels (8-wave workgroups, slab-resident dW) in both modes"""
     from neuralpde_jl_amd import workloads
-    wl40 = workloads.cfg2_poisson2d(points=70, bcs_points=70, width=40, hidden=3)
-    rep3, _, _, _ = check(npde, wl40.pde_system, wl40.chains, wl40.strategy, wl40.theta)
-    assert "weights=packed image" in rep3.engine.describe()
-
-
-def test_ping_pong_merged_launch(npde, use_emu, monkeypatch):
-    """PINN_PP=1: the merged launch as 8-wave workgroups of two wave quartets that run the tile body half a tile apart (GEMM supersteps of
-    one beside element-wise supersteps of the other); odd / even tile counts, idle tile slots; against the oracle and the plain merged launch"""
-    monkeypatch.setenv("PINN_PP", "1")
-    for pts, bpts in ((200, 70), (17, 300), (16, 65), (333, 129)):
-        wl = _merge_cfg2(npde, pts, bpts)
-        w = [1.0, 2.0, 0.5, 3.0, 1.5]
-        rep, _, _, th = check(npde, wl.pde_system, wl.chains, wl.strategy, wl.theta, weights=w)
-        assert "launch=merged" in rep.engine.describe()
-        l_pp, g_pp = rep.engine.loss_grad(th, w)
-        monkeypatch.delenv("PINN_PP")
-        l_m, g_m = rep.engine.loss_grad(th, w)
-        monkeypatch.setenv("PINN_PP", "1")
-        np.testing.assert_allclose(l_pp, l_m, rtol=1e-12)
-        np.testing.assert_allclose(g_pp, g_m, rtol=0, atol=2e-6 * np.abs(g_m).max())
+    wl = workloads.cfg2_poisson2d(points=40, bcs_points=20, width=128, hidden=2)
+    rep, _, sets, th = check(npde, wl.pde_system, wl.chains, wl.strategy, wl.theta)
+    assert "gemm=split" in rep.engine.describe()
+    l_s, g_s = rep.engine.loss_grad(th)
+    monkeypatch.setenv("PINN_GEMM", "fp32")
+    rep2 = npde.symbolic_discretize(wl.pde_system, wl.discretization())
+    monkeypatch.delenv("PINN_GEMM")
+    assert rep2.engine.get_option("gemm") == "fp32" and "gemm=fp32" in rep2.engine.describe()
+    for k, sset in enumerate(sets):
+        rep2.engine.set_points(k, sset)
+    l_f, g_f = rep2.engine.loss_grad(th)
+    np.testing.assert_allclose(l_f, l_s, rtol=2e-6)
+    np.testing.assert_allclose(g_f, g_s, rtol=0, atol=2e-6 * np.abs(g_s).max())
+    rep.engine.set_option("gemm", "fp32")
+    l_f2, g_f2 = rep.engine.loss_grad(th)
+    assert np.array_equal(l_f2, l_f) and np.array_equal(g_f2, g_f)
+    monkeypatch.setenv("PINN_GEMM", "tf32")
+    with pytest.raises(Exception):
+        npde.symbolic_discretize(wl.pde_system, wl.discretization())
 
 
 def test_merged_launch_uneven_tile_counts(npde, use_emu):

@@ -1,0 +1,78 @@
+"""Parity away from glorot-initialised parameters (r04): the benchmarked configuration and cfg3 at FULL size, cfg4 / cfg5 reduced, at
+theta x 2, theta x 4 (saturating units, large higher-derivative jets) and at TRAINED parameters (float64 Adam on the oracle's own
+objective: gradients that are small differences of large per-point terms), against committed float64-oracle outputs in BOTH oracle
+modes (tests/golden/*_variants.npz, `python oracle/make_golden.py variants`) and in BOTH GEMM modes of the engine:
+    "split" (default) — three-piece bf16 split products on the bf16 matrix pipe,
+    "fp32"            — v_mfma_f32_16x16x4_f32 (pinn_set_option(h, "gemm", "fp32")).
+Bar (north star): 1e-5 relative — per-term loss, gradient norm-wise in L2 and Linf — against the reference's semantics (stencil mode).
+The measured errors and margins of every case are printed (pytest -s) and tabulated in DESIGN.md section 6."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _digest(s):
+    return hashlib.sha256(np.ascontiguousarray(s, dtype=np.float64).tobytes()).hexdigest()
+
+
+def _makers():
+    from neuralpde_jl_amd import workloads
+    return {"cfg2_variants": lambda: workloads.cfg2_poisson2d(points=65536),
+            "cfg3_variants": lambda: workloads.cfg3_burgers(points=262144),
+            "cfg4_variants": lambda: workloads.cfg4_cavity(points=16384, bcs_points=4096),
+            "cfg5_variants": lambda: workloads.cfg5_heat_inverse(points=32768, bcs_points=8192)}
+
+
+def _errors(losses, grad, lref, gref):
+    le = np.max(np.abs(losses - lref) / np.abs(lref))
+    g2 = np.linalg.norm(grad - gref) / np.linalg.norm(gref)
+    gi = np.max(np.abs(grad - gref)) / np.max(np.abs(gref))
+    return le, g2, gi
+
+
+CASES = [("cfg2_variants", t) for t in ("x2", "x4", "adam2000", "adam6000")] + [("cfg3_variants", t) for t in ("x2", "adam2000")] + \
+        [("cfg4_variants", t) for t in ("x2", "x4")] + [("cfg5_variants", t) for t in ("x2", "x4")]
+
+
+@pytest.mark.parametrize("name,tag", CASES)
+def test_theta_variant(npde, hip_lib, name, tag):
+    path = os.path.join(GOLD, name + ".npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{name}.npz not generated (python oracle/make_golden.py variants {name})")
+    g = np.load(path)
+    if tag not in list(g["tags"]):
+        pytest.skip(f"{name}.npz holds no variant {tag}")
+    wl = _makers()[name]()
+    rep = npde.symbolic_discretize(wl.pde_system, wl.discretization())
+    eng = rep.engine
+    assert eng.L.backend == "hip"
+    sets = rep.pde_train_sets + rep.bcs_train_sets
+    assert [s.shape[1] for s in sets] == list(g["set_sizes"])
+    assert [_digest(s) for s in sets] == list(g["set_sha256"]), "regenerated point sets differ from the ones the fixture was computed on"
+    theta, w = g["theta_" + tag], g["weights"]
+    assert theta.size == eng.P
+    rows = {}
+    for mode in ("split", "fp32"):
+        eng.set_option("gemm", mode)
+        assert eng.get_option("gemm") == mode
+        losses, grad = eng.loss_grad(theta, w)
+        l2, gr2 = eng.loss_grad(theta, w)
+        assert np.array_equal(l2, losses) and np.array_equal(gr2, grad)        # bit-reproducible
+        for om in ("stencil", "exact"):
+            rows[(mode, om)] = _errors(losses, grad, g[f"losses_{om}_{tag}"], g[f"grad_{om}_{tag}"])
+    fd = _errors(g[f"losses_stencil_{tag}"], g[f"grad_stencil_{tag}"], g[f"losses_exact_{tag}"], g[f"grad_exact_{tag}"])
+    print(f"\n{name} {tag}: |grad| = {np.linalg.norm(g['grad_exact_' + tag]):.3e}; the stencil oracle against the exact oracle (the finite-difference "
+          f"error of the reference's own semantics): loss {fd[0]:.1e}, grad L2 {fd[1]:.1e}, Linf {fd[2]:.1e}")
+    for (mode, om), (le, g2, gi) in rows.items():
+        print(f"  gemm={mode:5s} vs {om:7s} oracle: loss rel {le:.2e}, grad rel L2 {g2:.2e}, Linf {gi:.2e}   margin to 1e-5: x{TOL / max(le, g2, gi):.1f}")
+    for mode in ("split", "fp32"):
+        le, g2, gi = rows[(mode, "stencil")]
+        assert le < TOL and g2 < TOL and gi < TOL, (name, tag, mode, "stencil", le, g2, gi)
+        le, g2, gi = rows[(mode, "exact")]
+        assert le < TOL and g2 < TOL and gi < TOL, (name, tag, mode, "exact", le, g2, gi)

@@ -1,6 +1,5 @@
 """A/B of the launch structure of one evaluation inside ONE process on one GPU box (the engine reads these switches at every call):
     merged     : default — interior + boundary tiles in one persistent launch, one-kernel reduction
-    pingpong   : PINN_PP=1 — the merged launch as 8-wave workgroups of two wave quartets half a tile apart (GEMM beside element-wise)
     chained    : PINN_NO_MERGE=1 — two chained launches (round 2), one-kernel reduction
     chained+2st: PINN_NO_MERGE=1 PINN_NO_REDUCE_ONE=1 — two chained launches, reduce1 + reduce2 (the round-2 launch sequence)
     merged+2st : PINN_NO_REDUCE_ONE=1
@@ -19,7 +18,7 @@ ap.add_argument("--cfg", default="cfg2")
 ap.add_argument("--points", type=int, nargs="*", default=[65536, 8192])
 ap.add_argument("--steps", type=int, default=300)
 args = ap.parse_args()
-VARIANTS = [("merged", {}), ("pingpong", {"PINN_PP": "1"}), ("chained", {"PINN_NO_MERGE": "1"}),
+VARIANTS = [("merged", {}), ("chained", {"PINN_NO_MERGE": "1"}),
             ("chained+2st", {"PINN_NO_MERGE": "1", "PINN_NO_REDUCE_ONE": "1"}), ("merged+2st", {"PINN_NO_REDUCE_ONE": "1"})]
 if os.environ.get("PINN_LIB"):                      # A/B of another build of the library (neuralpde.jl_amd/csrc/abl/libpinn_<name>.so)
     m._lib.set_library(m.Library(os.environ["PINN_LIB"]))
@@ -35,7 +34,7 @@ for pts in args.points:
     res = {}
     for rnd in range(3):
         for tag, env in VARIANTS + [("loss-only", {})]:
-            for k in ("PINN_NO_MERGE", "PINN_NO_REDUCE_ONE", "PINN_PP"):
+            for k in ("PINN_NO_MERGE", "PINN_NO_REDUCE_ONE"):
                 os.environ.pop(k, None)
             os.environ.update(env)
             ts = []
