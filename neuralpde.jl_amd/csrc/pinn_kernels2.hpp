@@ -35,16 +35,15 @@
 #ifndef PINN_F2_REC_LDS
 #define PINN_F2_REC_LDS 1               // keep the records of the stored hidden layers in LDS as far as they fit (Spec2::NRQ)
 #endif
-// fp32-MFMA GEMMs: B-fragment LDS reads issued this many MFMA groups ahead of their use (0: leave the order to the compiler)
-#ifndef PINN_F2_GEMM_AHEAD
-#define PINN_F2_GEMM_AHEAD 2
-#endif
 // Explicit software pipeline of the split-operand GEMMs: the B-operand (dW: both operands') LDS reads of group i + 1 are issued in front of
 // a scheduling fence, the six MFMAs of group i behind it — the compiler cannot sink the reads next to their uses (what it does when left
 // alone, and what sched_group_barrier requests did not change at 256 registers), so a wave's MFMAs no longer wait one LDS round trip per
 // group.  Bit mask: 1 forward GEMM, 2 dA GEMM, 4 dW GEMM.
 #ifndef PINN_F2_SWP
 #define PINN_F2_SWP 7
+#endif
+#ifndef PINN_PROBE
+#define PINN_PROBE 0                    // timing probes (tools only, wrong numbers): 1 half the MFMAs, 2 no residual pieces, 4 no workgroup barriers, 8 no weight loads, 16 a third of the operand reads
 #endif
 #ifndef PINN_F2_ADJ_IL
 #define PINN_F2_ADJ_IL 1                // transpose-read schedules: activation adjoint issued between the MFMA groups of the dW GEMM (1: H = 64 only, 2: H = 128 too)
@@ -84,6 +83,7 @@ constexpr int GEMM_FP32 = 0, GEMM_SPLIT = 1;
 // settled design parameters (measured in rounds 1-3)
 constexpr int F2_WAVES128 = 8;          // waves per workgroup of the H = 128 kernels: two waves per SIMD share one workgroup's LDS tiles
 constexpr int F2_NW8_MAXNG = 6;         // ... for up to this many column groups (beyond: 4 waves with 512 registers)
+constexpr int F2_GEMM_AHEAD = 2;       // fp32-MFMA GEMMs: B-fragment LDS reads issued this many MFMA groups ahead of their use
 constexpr int F2_SPRE_MAX = 24;         // records parked in the scratch slab are requested one phase early when they take <= this many registers
 
 
@@ -338,6 +338,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
 
     vfloat4 wL[MTW];
     PINN_UNROLL for (int t = 0; t < MTW; ++t) wL[t] = ub_load4(PB, S::OFF_WL + 16 * (w * MTW + t), g << 2);
+    const vbf8 wb_probe = ub_load_bf8(PB, S::OFF_WB, lane << 2);      // (PINN_PROBE & 8: one fragment, loaded once, stands for all)
     const float bL = P[S::OFF_BL];
 
     wave_prio(1);
@@ -414,7 +415,11 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                     PINN_UNROLL for (int t = 0; t < MTW; ++t) {
                         const int tile = w * MTW + t;
                         vbf4 ph, pm, pl;
+#if PINN_PROBE & 2
+                        split1_bf16(A[q][t], ph); pm = ph; pl = ph;      // timing probe: no residual pieces (wrong numbers)
+#else
                         split3_bf16(A[q][t], ph, pm, pl);
+#endif
                         const vint at = vint(((q * S::KB + (tile >> 1)) * 3) * 256 + (tile & 1) * (S::BFX_TR ? 128 : 2)) + sw;
                         lds_store_bf4(X, at, ph);
                         lds_store_bf4(X, at + vint(256), pm);
@@ -428,6 +433,9 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
         };
         // B operand (this lane's point, k = 8 g + j) of fragment `frag` = (column group, k-block, piece) of an exchange image
         auto ld_bfrag = [&](const float* X, int frag) -> vbf8 {
+#if PINN_PROBE & 16
+            frag = (frag / 3) * 3;                      // timing probe: one LDS read per group serves all three pieces (wrong numbers)
+#endif
             if (S::BFX_TR) return cat_bf8(lds_load_bf4(X, vint(frag * 256) + sw), lds_load_bf4(X, vint(frag * 256 + 128) + sw));
             return lds_load_bf8(X, vint(frag * 256) + (lane << 2));
         };
@@ -436,6 +444,9 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
             c = mfma16x32bf(a[0], b[0], c);
             c = mfma16x32bf(a[0], b[1], c);
             c = mfma16x32bf(a[1], b[0], c);
+#if PINN_PROBE & 1
+            return c;                                   // timing probe: half the matrix work (wrong numbers)
+#endif
             c = mfma16x32bf(a[0], b[2], c);
             c = mfma16x32bf(a[1], b[1], c);
             c = mfma16x32bf(a[2], b[0], c);
@@ -446,16 +457,21 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
         // fragments are requested before group i's MFMAs
         auto gemm_swp = [&](const float* X, const vbf8 (&wfr)[S::BFX ? S::KB : 1][S::BFX ? MTW : 1][3], vfloat4 (&Cc)[NG][MTW]) {
             constexpr int NGRP = S::KB * NG;
-            vbf8 bb[2][3];
+            constexpr int NB = 2;                                               // operand buffers in rotation (three measured in r04: no gain)
+            vbf8 bb[NB][3];
             PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[0][sp] = ld_bfrag(X, sp);          // group 0: kb = 0, q = 0
             PINN_UNROLL for (int i = 0; i < NGRP; ++i) {
                 const int kb = i / NG, q = i % NG;
                 if (i + 1 < NGRP) {
                     const int kb2 = (i + 1) / NG, q2 = (i + 1) % NG;
-                    PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[(i + 1) & 1][sp] = ld_bfrag(X, (q2 * S::KB + kb2) * 3 + sp);
+                    PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[(i + 1) % NB][sp] = ld_bfrag(X, (q2 * S::KB + kb2) * 3 + sp);
                 }
                 sched_fence();
-                PINN_UNROLL for (int t = 0; t < MTW; ++t) Cc[q][t] = mfma_split(wfr[kb][t], bb[i & 1], Cc[q][t]);
+                // every piece of this group's B operand has arrived before the first MFMA of the chain (see lds_wait): only the next group's
+                // reads may still be in flight
+                if (i + 1 < NGRP) lds_wait<S::BFX_TR ? 6 : 3>(); else lds_wait<0>();
+                PINN_UNROLL for (int t = 0; t < MTW; ++t) Cc[q][t] = mfma_split(wfr[kb][t], bb[i % NB], Cc[q][t]);
+                chain_fence();                                              // (nothing of the next group moves up into this chain)
             }
         };
 
@@ -491,11 +507,13 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 vfloat4 wf[WPRE ? MT : 1][MTW], bv[MTW];
                 vbf8 wb[S::BFX ? S::KB : 1][S::BFX ? MTW : 1][3];      // (H = 128: 48 registers; fetched per k-block their L2 latency showed at every k-block)
                 if (S::BFX) {
+                    // loads return in order: the bias (the accumulators' initial value) first, then the fragments in the order the GEMM uses them,
+                    // so the first MFMA waits for the head of the stream, not for all of it
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t) bv[t] = ld_bias(hl + 1, t);
                     PINN_UNROLL for (int kb = 0; kb < S::KB; ++kb)
                         PINN_UNROLL for (int t = 0; t < MTW; ++t)
                             PINN_UNROLL for (int sp = 0; sp < 3; ++sp)
-                                wb[kb][t][sp] = ub_load_bf8(PB, S::OFF_WB + (((hl * MT + w * MTW + t) * S::KB + kb) * 3 + sp) * 256, lane << 2);
-                    PINN_UNROLL for (int t = 0; t < MTW; ++t) bv[t] = ld_bias(hl + 1, t);
+                                wb[kb][t][sp] = (PINN_PROBE & 8) ? wb_probe : ub_load_bf8(PB, S::OFF_WB + (((hl * MT + w * MTW + t) * S::KB + kb) * 3 + sp) * 256, lane << 2);
                     sched_fence();
                 } else if (WPRE) {
                     PINN_UNROLL for (int mi = 0; mi < MT; ++mi)
@@ -525,7 +543,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                             PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[sp] = ld_bfrag(Xin, (q * S::KB + kb) * 3 + sp);
                             PINN_UNROLL for (int t = 0; t < MTW; ++t) A[q][t] = mfma_split(wb[kb][t], bb, A[q][t]);
                         }
-                    if (WPRE && PINN_F2_GEMM_AHEAD > 0) sched_gemm_prefetch<S::KB * NG, MTW * 6, PINN_F2_GEMM_AHEAD, S::BFX_TR ? 6 : 3>();
+                    if (WPRE && F2_GEMM_AHEAD > 0) sched_gemm_prefetch<S::KB * NG, MTW * 6, F2_GEMM_AHEAD, S::BFX_TR ? 6 : 3>();
                 }
                 PINN_UNROLL for (int mi = 0; mi < (S::BFX ? 0 : MT); ++mi) {
                     if (!WPRE)
@@ -537,7 +555,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                         PINN_UNROLL for (int t = 0; t < MTW; ++t)
                             PINN_UNROLL for (int rr = 0; rr < 4; ++rr) A[q][t] = mfma16(wf[WPRE ? mi : 0][t][rr], b4[q][rr], A[q][t]);
                 }
-                if (!S::BFX && WPRE && PINN_F2_GEMM_AHEAD > 0) sched_gemm_prefetch<MT * NG, MTW * 4, PINN_F2_GEMM_AHEAD>();
+                if (!S::BFX && WPRE && F2_GEMM_AHEAD > 0) sched_gemm_prefetch<MT * NG, MTW * 4, F2_GEMM_AHEAD>();
                 wave_prio(1);
                 STAMP(2)
                 act_forward(A, hl + 1);
@@ -907,16 +925,19 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                     }
                 }
                 if (PINN_F2_SWP & 4) {
-                    vbf8 ab[2][3];
+                    constexpr int NB = 2;
+                    vbf8 ab[NB][3];
                     PINN_UNROLL for (int sp = 0; sp < 3; ++sp) ab[0][sp] = ld_tr(XA, (2 * qp * S::KB) * 3 + sp, 0);
                     PINN_UNROLL for (int ti = 0; ti < MT; ++ti) {
                         if (ti + 1 < MT)
-                            PINN_UNROLL for (int sp = 0; sp < 3; ++sp) ab[(ti + 1) & 1][sp] = ld_tr(XA, (2 * qp * S::KB + ((ti + 1) >> 1)) * 3 + sp, (ti + 1) & 1);
+                            PINN_UNROLL for (int sp = 0; sp < 3; ++sp) ab[(ti + 1) % NB][sp] = ld_tr(XA, (2 * qp * S::KB + ((ti + 1) >> 1)) * 3 + sp, (ti + 1) & 1);
                         sched_fence();
+                        if (ti + 1 < MT) lds_wait<6>(); else lds_wait<0>();      // (this group's operands complete before its MFMA chain)
                         PINN_UNROLL for (int t = 0; t < MTW; ++t) {
-                            if (S::WBAR_REG) wbar[hl][t][ti] = mfma_split(za[t], ab[ti & 1], wbar[hl][t][ti]);
-                            else wacc[t][ti] = mfma_split(za[t], ab[ti & 1], wacc[t][ti]);
+                            if (S::WBAR_REG) wbar[hl][t][ti] = mfma_split(za[t], ab[ti % NB], wbar[hl][t][ti]);
+                            else wacc[t][ti] = mfma_split(za[t], ab[ti % NB], wacc[t][ti]);
                         }
+                        chain_fence();                                      // (the adjoint pieces below stay BEHIND the chain, not inside it)
                         if (ADJ_IL) {                                       // this group's share of the activation adjoint (see adj_piece)
                             const int gidx = qp * MT + ti;
                             PINN_UNROLL for (int j = 0; j < ADJ_NCH; ++j)
@@ -941,7 +962,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 PINN_UNROLL for (int kb = 0; kb < S::KB; ++kb)
                     PINN_UNROLL for (int t = 0; t < MTW; ++t)
                         PINN_UNROLL for (int sp = 0; sp < 3; ++sp)
-                            wtb[kb][t][sp] = ub_load_bf8(PB, S::OFF_WTB + (((hl * MT + w * MTW + t) * S::KB + kb) * 3 + sp) * 256, lane << 2);
+                            wtb[kb][t][sp] = (PINN_PROBE & 8) ? wb_probe : ub_load_bf8(PB, S::OFF_WTB + (((hl * MT + w * MTW + t) * S::KB + kb) * 3 + sp) * 256, lane << 2);
                 sched_fence();
             } else if (WPRE) {
                 PINN_UNROLL for (int mo = 0; mo < MT; ++mo)
@@ -980,7 +1001,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                     if (S::BFX_TR) continue;                                // (nothing to stage: dW reads X0 / X1 as they are)
                     stage_q(q, ZT + q * (MTW * 256), X1 + q * 16 * HP);
                 }
-                if (!S::BFX && PINN_F2_GEMM_AHEAD > 0) sched_gemm_prefetch<MT * NG, MTW * 4, PINN_F2_GEMM_AHEAD>();
+                if (!S::BFX && F2_GEMM_AHEAD > 0) sched_gemm_prefetch<MT * NG, MTW * 4, F2_GEMM_AHEAD>();
                 if (!S::BFX_TR) {
                     wave_prio(1);
                     STAMP(10)
@@ -997,8 +1018,8 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                     PINN_UNROLL for (int qp = 0; qp < (NG + 1) / 2; ++qp) dw_pair_tr(qp);
                 } else {
                     PINN_UNROLL for (int q = 0; q < NG; ++q) dw_q(ZT + q * (MTW * 256), X1 + q * 16 * HP);
-                    if (PINN_F2_GEMM_AHEAD > 0 && MTW == 1 && MT == 4)
-                        sched_gemm_prefetch<4 * NG, 4, PINN_F2_GEMM_AHEAD, 2>();
+                    if (F2_GEMM_AHEAD > 0 && MTW == 1 && MT == 4)
+                        sched_gemm_prefetch<4 * NG, 4, F2_GEMM_AHEAD, 2>();
                 }
                 wave_prio(1);
                 if (!ADJ_IL) {

@@ -1052,7 +1052,10 @@ void retile(pinn_engine& E, int gi) {
     }
     // coupled groups: keep the forward launch's records in HBM when they fit the budget (default 96 GB per handle, PINN_REC_GB)
     G.use_rec = false;
-    if (G.kind == 1 && s.family == 2 && s.REC > 0) {
+    // (PINN_REC_MIN_C: records only for kernels with at least this many jet channels — below, the reverse launch repeats the forward pass;
+    // with the split-operand GEMMs a 1-2 channel forward pass is cheaper than 2-4 KB of records per point through HBM and back)
+    static const int rec_min_c = [] { const char* e = std::getenv("PINN_REC_MIN_C"); return e ? std::atoi(e) : 1; }();
+    if (G.kind == 1 && s.family == 2 && s.REC > 0 && s.C >= rec_min_c) {
         static const double budget_gb = [] { const char* e = std::getenv("PINN_REC_GB"); return e ? std::atof(e) : 96.0; }();
         const size_t niter = ((size_t)tile + G.blocks - 1) / G.blocks;
         const size_t slots = niter * (size_t)G.blocks;              // dummy tiles of the last round get slots of their own

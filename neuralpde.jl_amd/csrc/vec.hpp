@@ -86,6 +86,8 @@ inline void tape_zero(vtape& t) { for (int i = 0; i < 32; ++i) t.r[i] = vfloat(0
 // 16-byte record at a wave-uniform address (device: scalar-cache load)
 struct urec16 { int x, y, z, w; };
 inline void sched_fence() {}
+template <int N> inline void lds_wait() {}
+inline void chain_fence() {}
 inline void store_pad() {}
 inline void keep_alive(const vfloat4&) {}
 inline void wave_prio(int) {}
@@ -172,6 +174,7 @@ inline void split3_bf16(const vfloat4& x, vbf4& h, vbf4& m, vbf4& l) {
         }
 }
 // 8-byte LDS store / 16-byte LDS and buffer loads of bf16 operands; indices in FLOATS like every other accessor here
+inline void split1_bf16(const vfloat4& x, vbf4& h) { vbf4 m, l; split3_bf16(x, h, m, l); }
 inline void lds_store_bf4(float* p, const vint& i, const vbf4& x) {
     for (int q = 0; q < W; ++q) { uint16_t t[4] = {x.v[0][q], x.v[1][q], x.v[2][q], x.v[3][q]}; std::memcpy(p + i.v[q], t, 8); }
 }
@@ -328,6 +331,27 @@ DEV void tape_zero(vtape& t) { PINN_UNROLL for (int i = 0; i < PINN_TAPE_ROWS; +
 // (which also drains every outstanding record store) and its fields need waterfall loops to be used as register indices.
 // the instruction scheduler may not move anything across this point (keeps a block of prefetch loads where it was written)
 DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// Wait until at most N of this wave's LDS operations are outstanding (s_waitcnt lgkmcnt(N); vmcnt / expcnt untouched).  Placed in FRONT of a
+// chain of MFMAs that accumulate into one register tuple: left alone, the compiler waits for every operand at its first use, i.e. puts
+// s_waitcnt instructions BETWEEN the dependent MFMAs of the chain — and one extra issue state between two MFMAs on the same accumulator costs
+// ~43 cycles (MI355X_MICROARCH.md, instruction constants: "a cliff, not a slope"); with the whole group's operands waited for up front the
+// chain issues back to back.  The compiler's own wait-count pass accounts for this instruction and drops the waits it makes redundant.
+#ifndef PINN_LDS_WAIT_HOIST
+#define PINN_LDS_WAIT_HOIST 1
+#endif
+// closes a chain of dependent MFMAs: the scheduler may not move later instructions (the next group's operand reads, interleaved
+// element-wise work) up between the MFMAs of the chain — same cliff as above
+#ifndef PINN_CHAIN_FENCE
+#define PINN_CHAIN_FENCE 1
+#endif
+DEV void chain_fence() { if (PINN_CHAIN_FENCE) __builtin_amdgcn_sched_barrier(0); }
+template <int N> DEV void lds_wait() {
+    static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+    if (PINN_LDS_WAIT_HOIST) {
+        __builtin_amdgcn_s_waitcnt(0xC07F | (N << 8));
+        __builtin_amdgcn_sched_barrier(0);               // (the scheduler otherwise sinks the wait behind the first MFMA of the chain)
+    }
+}
 // The data registers of a 128-bit buffer store must not be rewritten while the memory pipeline is still reading them.  The compiler
 // pads that hazard only for stores WITHOUT an SGPR offset; measured on gfx950 with an SGPR offset (8-wave workgroups, two back-to-back
 // record stores, v_pk_mul_f32 rewriting the stored registers 0-2 instructions later) the record in memory came out partly overwritten
@@ -413,7 +437,10 @@ DEV void wave_fence() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-DEV void wg_barrier() { __syncthreads(); }
+#ifndef PINN_PROBE
+#define PINN_PROBE 0
+#endif
+DEV void wg_barrier() { if (!(PINN_PROBE & 4)) __syncthreads(); }
 DEV vfloat shfl_xor(vfloat a, int m) { return __shfl_xor(a, m, 64); }
 // all-reduce sums without LDS traffic: v_add_f32_dpp row_ror within the 16-lane rows, v_permlane16/32_swap (gfx950) across rows
 template <int CTRL> DEV float dpp_mov(float v) {
@@ -461,6 +488,7 @@ DEV void split3_bf16(vfloat4 x, vbf4& h, vbf4& m, vbf4& l) {
         h[k] = hb; m[k] = mb; l[k] = (__bf16)r2;
     }
 }
+DEV void split1_bf16(vfloat4 x, vbf4& h) { PINN_UNROLL for (int k = 0; k < 4; ++k) h[k] = (__bf16)x[k]; }      // (timing probes only)
 DEV void lds_store_bf4(float* p, vint i, vbf4 x) { *reinterpret_cast<vbf4*>(p + i) = x; }
 DEV vbf8 lds_load_bf8(const float* p, vint i) { return *reinterpret_cast<const vbf8*>(p + i); }
 // 8-byte LDS read of an operand half.  PINN_F2_LDS_NOMERGE (default): a volatile access in the LDS address space, which the compiler's

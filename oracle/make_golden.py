@@ -145,7 +145,7 @@ def adam_train(prob, theta0, sets, w, iters, lr=3e-3, decay=0.6, report=500):
         step = lr * decay ** ((t - 1) // 1000)
         th = th - step * (m_ / (1 - 0.9 ** t)) / (np.sqrt(v_ / (1 - 0.999 ** t)) + 1e-8)
         if t % report == 0:
-            print(f"    adam {t}: objective {ev.total:.4e}", flush=True)
+            print(f"    adam {t}: objective {ev.loss:.4e}", flush=True)
         if t in iters:
             out[t] = th.copy()
     return out

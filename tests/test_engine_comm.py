@@ -202,6 +202,6 @@ def test_rccl_communicators_on_the_visible_devices(npde, hip_lib):
         e.adam_init(wl.theta)
     h_s = npde.adam_steps_sharded(engs2, 5, 1e-3, w)
     np.testing.assert_allclose(h_s, h_p, rtol=1e-5)
-    np.testing.assert_allclose(engs2[0].adam_get(), t_p, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(engs2[0].adam_get(), t_p, rtol=0, atol=2e-5)      # (another handle: Adam amplifies last-bit gradient differences of near-zero entries)
     for e in engs2:
         e.comm_destroy()

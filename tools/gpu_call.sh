@@ -14,6 +14,7 @@
 #   proxy            tools/scaling_proxy.py                                         -> scaling_proxy.txt / .json
 #   stamps:<lib>     tools/stamp_profile.sh with a PINN_STAMP build                 -> stamps.txt
 #   py:<script args> python <script args>                                           -> py_<n>.txt
+#   sh:<command>     bash -c "<command>" (environment variables in front of a tool)  -> sh_<n>.txt
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 TAG=${1:?tag}; shift
 O=gpurun_out/$TAG
@@ -25,7 +26,7 @@ for step in "$@"; do
     n=$((n + 1))
     echo "=== [$TAG] step $n: $step ($(date +%T))"
     case "$step" in
-        tests)      timeout 1500 python -m pytest tests -m gpu -q -x > "$O/tests.txt" 2>&1; tail -n 3 "$O/tests.txt" ;;
+        tests)      timeout 1500 python -m pytest tests -m gpu -q > "$O/tests.txt" 2>&1; tail -n 3 "$O/tests.txt" ;;
         tests:*)    timeout 1500 python -m pytest tests -m gpu -q -s -k "${step#tests:}" > "$O/tests_$n.txt" 2>&1; grep -v "^$" "$O/tests_$n.txt" | tail -n 60 ;;
         bench)      timeout 900 python bench.py > "$O/bench.json" 2> "$O/bench.err"; tail -c 1500 "$O/bench.json" ;;
         bench:*)    timeout 900 python bench.py ${step#bench:} > "$O/bench_$n.json" 2> "$O/bench_$n.err"; head -c 600 "$O/bench_$n.json"; echo ;;
@@ -38,6 +39,7 @@ for step in "$@"; do
         proxy)      timeout 1200 python tools/scaling_proxy.py --out "$O/scaling_proxy.json" > "$O/scaling_proxy.txt" 2>&1; tail -n 30 "$O/scaling_proxy.txt" ;;
         stamps:*)   timeout 600 bash tools/stamp_profile.sh "${step#stamps:}" > "$O/stamps.txt" 2>&1; tail -n 40 "$O/stamps.txt" ;;
         py:*)       timeout 1200 python ${step#py:} > "$O/py_$n.txt" 2>&1; tail -n 40 "$O/py_$n.txt" ;;
+        sh:*)       timeout 1200 bash -c "${step#sh:}" > "$O/sh_$n.txt" 2>&1; tail -n 40 "$O/sh_$n.txt" ;;
         *)          echo "unknown step $step" ;;
     esac
 done
