@@ -111,6 +111,19 @@ function loss_grad(e::HIPEngine, θ::AbstractVector{<:Real}, w::AbstractVector{<
     return losses, grad
 end
 
+"""
+    set_gemm!(e, :split | :fp32)
+
+Arithmetic of the hidden-layer GEMMs of the 64- / 128-wide kernels on a live engine (`pinn_set_option(h, "gemm", …)`): `:split` (default) =
+three bf16 pieces per operand on the bf16 matrix pipe; `:fp32` = fp32 MFMAs, an fmaf chain per product — for a quasi-Newton stage that
+runs into the split products' noise floor (the reference runs `BFGS()` in Float64, test/NNPDE1/nnpde__pde_iii_3rd_order_ode.jl:89-93).
+"""
+function set_gemm!(e::HIPEngine, mode::Symbol)
+    mode in (:split, :fp32) || throw(ArgumentError("gemm mode must be :split or :fp32"))
+    check(ccall(sym(:pinn_set_option), Cint, (Ptr{Cvoid}, Cstring, Cstring), e.h, "gemm", String(mode)), "pinn_set_option")
+    return nothing
+end
+
 "Per-term gradients `K × P` (row k = ∂ term_losses[k] / ∂θ): what GradientScaleAdaptiveLoss and the per-term rrules consume."
 function term_grads(e::HIPEngine, θ::AbstractVector{<:Real})
     θ32 = Vector{Float32}(θ)
@@ -543,6 +556,30 @@ function loss_grad(se::ShardedEngine, θ::AbstractVector{<:Real}, w::AbstractVec
         (Ptr{Ptr{Cvoid}}, Cint, Ptr{Float32}, Int64, Ptr{Float32}, Ptr{Float64}, Ptr{Float32}),
         hs, length(hs), θ32, e.P, w32, losses, grad), "pinn_loss_grad_sharded")
     return losses, Float64.(grad)
+end
+
+"""
+    adam!(se::ShardedEngine, θ0, nsteps, η; w = ones(K)) -> (θ, loss_history)
+
+`solve(prob, Adam(η); maxiters = nsteps)` resident on the devices of the communicator (`pinn_adam_steps_sharded`): per iteration every
+device evaluates its shards, ONE all-reduce sums `[gradient | per-term sums]`, every device applies the same fused Adam update — θ, the
+moments and the point sets never leave HBM and the host is not synchronised inside the loop.
+"""
+function adam!(se::ShardedEngine, θ0::AbstractVector{<:Real}, nsteps::Integer, η::Real; w::AbstractVector{<:Real} = ones(se.engines[1].K),
+               β1::Real = 0.9, β2::Real = 0.999, ϵ::Real = 1.0e-8)
+    e = se.engines[1]
+    θ32 = Vector{Float32}(θ0); w32 = Vector{Float32}(w)
+    for x in se.engines
+        GC.@preserve θ32 check(ccall(sym(:pinn_adam_init), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64), x.h, θ32, e.P), "pinn_adam_init")
+    end
+    hist = zeros(Float64, nsteps)
+    hs = [x.h for x in se.engines]
+    GC.@preserve hs w32 hist check(ccall(sym(:pinn_adam_steps_sharded), Cint,
+        (Ptr{Ptr{Cvoid}}, Cint, Cint, Cfloat, Cfloat, Cfloat, Cfloat, Ptr{Float32}, Ptr{Float64}),
+        hs, length(hs), nsteps, η, β1, β2, ϵ, w32, hist), "pinn_adam_steps_sharded")
+    out = zeros(Float32, e.P)
+    GC.@preserve out check(ccall(sym(:pinn_adam_get), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64), e.h, out, e.P), "pinn_adam_get")
+    return Float64.(out), hist
 end
 
 # ------------------------------------------------------------------------------------------------

@@ -256,11 +256,12 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
         if (a2.ent_active[g]) { ++nslabsets; slabset_group = (int)g; }
         max_n1 = std::max(max_n1, nent / 4 + K);
         max_split = std::max(max_split, nsplit_g);
-        if (G.kind == 1) {               // coupled: forward launch now, reverse launch after k_expr
+        if (G.kind == 1) {               // coupled: forward launch now, reverse launch after k_expr / the equation's tail launch
             G.spec->launch(G.ga, (G.use_rec && !loss_only) ? pk::MODE_FWDREC : pk::MODE_FWD,
                            std::max(1, std::min(E.ncu * G.spec->WG_FWD, G.spec->family == 1 ? (G.ga.ntiles + 3) / 4 : G.ga.ntiles)), E.stream);
             continue;
         }
+        if (G.kind == 2) continue;       // tail launch of a coupled equation: after the other networks' forward launches (below)
         plat_stream st = E.stream;
         const bool forked = concurrent && nforked++ > 0;       // the first fused group stays on the caller's stream
         if (forked) {
@@ -297,6 +298,23 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
         for (int gi : Cp.groups) groups_active = groups_active || E.groups[gi].active;
         if (!groups_active) continue;
         coupled_active = true;
+        if (Cp.tail >= 0) {
+            // TAIL launch: forward pass of the widest network + the equation's tape (the other networks' jets as source rows) + its reverse
+            // sweep in one kernel; it writes the other networks' seeds and carries the term's loss partials and parameter gradients
+            // itself, so the k_expr pseudo-group stays out of the reduction
+            Group& G = E.groups[Cp.groups[Cp.tail]];
+            a1.active[g] = 0; a2.active[g] = 0; a2.ent_active[g] = 0;
+            if (group_ev((size_t)Cp.groups[Cp.tail])) plat_event_record(G.ev_a, E.stream);
+            if (loss_only) {
+                const int fb = std::max(1, std::min(E.ncu * G.spec->WG_FWD, G.ga.ntiles));
+                a1.nblocks[Cp.groups[Cp.tail]] = fb;
+                G.launched_blocks = fb;
+                G.spec->launch(G.ga, pk::MODE_LOSS, fb, E.stream);
+            } else G.spec->launch(G.ga, pk::MODE_FUSED, G.blocks, E.stream);
+            if (group_ev((size_t)Cp.groups[Cp.tail])) plat_event_record(G.ev_b, E.stream);
+            G.timed = group_ev((size_t)Cp.groups[Cp.tail]);
+            continue;
+        }
         max_n1 = std::max(max_n1, nent / 4 + K);
         max_split = std::max(max_split, nsplit);
         aux::ExprArgs ea = expr_args(E, Cp, scale_of(Cp.term), nullptr);    // scale 0 => zero seeds
@@ -483,11 +501,20 @@ static int term_installed(pinn_engine& E, int term) {
     Coupled& Cp = E.coupled[T.coupled];
     const int K = (int)E.terms.size();
     if (Cp.cap < n) {
-        for (float* q : Cp.d_jets) plat_free(q);
-        for (float* q : Cp.d_ubar) plat_free(q);
+        for (size_t i = 0; i < Cp.d_jets.size(); ++i)
+            if (Cp.tail < 0 || (int)i == Cp.tail) { plat_free(Cp.d_jets[i]); plat_free(Cp.d_ubar[i]); }
+        plat_free(Cp.d_jets_all); plat_free(Cp.d_ubar_all);
+        Cp.d_jets_all = Cp.d_ubar_all = nullptr;
         Cp.d_jets.assign(Cp.nets.size(), nullptr);
         Cp.d_ubar.assign(Cp.nets.size(), nullptr);
+        Cp.cap = 0;
+        if (Cp.tail >= 0 && Cp.nsrc > 0) {               // the other networks' channels in ONE array each way: the tail launch's source rows
+            Cp.d_jets_all = (float*)plat_malloc(sizeof(float) * (size_t)Cp.nsrc * n);
+            Cp.d_ubar_all = (float*)plat_malloc(sizeof(float) * (size_t)Cp.nsrc * n);
+            if (!Cp.d_jets_all || !Cp.d_ubar_all) return fail("device allocation failed (coupled jets)");
+        }
         for (size_t i = 0; i < Cp.nets.size(); ++i) {
+            if (Cp.tail >= 0 && (int)i != Cp.tail) continue;
             const int C = E.groups[Cp.groups[i]].spec->C;
             Cp.d_jets[i] = (float*)plat_malloc(sizeof(float) * (size_t)C * n);
             Cp.d_ubar[i] = (float*)plat_malloc(sizeof(float) * (size_t)C * n);
@@ -495,6 +522,9 @@ static int term_installed(pinn_engine& E, int term) {
         }
         Cp.cap = n;
     }
+    if (Cp.tail >= 0)                                    // rows packed with stride n (the kernels address channel c at c * N)
+        for (size_t i = 0; i < Cp.nets.size(); ++i)
+            if ((int)i != Cp.tail) { Cp.d_jets[i] = Cp.d_jets_all + (size_t)Cp.src_off[i] * n; Cp.d_ubar[i] = Cp.d_ubar_all + (size_t)Cp.src_off[i] * n; }
     Cp.blocks = (int)((n + 255) / 256);
     if (Cp.cap_blocks < Cp.blocks) {
         plat_free(Cp.d_losspart); plat_free(Cp.d_pslab);
@@ -1360,7 +1390,8 @@ int pinn_describe(pinn_handle h, char* buf, int64_t buflen) {
                << " gemm=" << (h->netplans[n].spec->BFX ? (h->netplans[n].spec->BFX_DW ? "split-bf16(fwd,dA,dW)" : "split-bf16(fwd,dA)") : "fp32") << "\n";
     for (size_t g = 0; g < h->groups.size(); ++g) {
         const Group& G = h->groups[g];
-        os << "group " << g << (G.kind == 1 ? (G.use_rec ? " [coupled fwd/gradin, records in HBM]" : " [coupled fwd/gradin]") : "") << " net=" << G.net << " kernel=" << spec_name(*G.spec) << " tiles=" << G.ga.ntiles << " blocks=" << G.blocks << " terms=";
+        os << "group " << g << (G.kind == 1 ? (G.use_rec ? " [coupled fwd/gradin, records in HBM]" : " [coupled fwd/gradin]") :
+                                (G.kind == 2 ? " [coupled tail: forward + tape + reverse in one launch]" : "")) << " net=" << G.net << " kernel=" << spec_name(*G.spec) << " tiles=" << G.ga.ntiles << " blocks=" << G.blocks << " terms=";
         for (int t : G.terms) os << t << ",";
         if (G.chain_to >= 0) os << " slabs=" << (G.blocks <= h->groups[G.chain_to].blocks ? "chained onto group " : "own (more workgroups than group ") << G.chain_to << (G.blocks <= h->groups[G.chain_to].blocks ? "" : ")");
         if (G.merged >= 0 && h->merged[G.merged].tail == (int)g) os << " launch=merged into group " << h->merged[G.merged].head << "'s (one persistent kernel walks both tile lists)";

@@ -108,7 +108,8 @@ struct Term {
     unsigned seed = 0, draws = 0;
 };
 struct Group {
-    int kind = 0;                    // 0: fused (single-network terms); 1: per-network FWD/GRADIN launches of coupled terms
+    int kind = 0;                    // 0: fused (single-network terms); 1: per-network FWD/GRADIN launches of coupled terms;
+                                     // 2: TAIL network of a coupled term: forward + residual tape + reverse in one launch (Coupled::tail)
     int net = -1;
     const pk::SpecInfo* spec = nullptr;
     std::vector<int> terms;
@@ -147,6 +148,15 @@ struct Coupled {
     std::vector<int> groups;         // per network: the kind-1 group that runs it
     std::vector<int> slot_net;       // per slot: index into `nets`
     std::vector<float*> d_jets, d_ubar;   // per network: [C_n][N]
+    // TAIL launch (r04): the network with the widest channel set of the equation (family 2) runs forward + tape + reverse in ONE launch
+    // (kind-2 group, MODE_FUSED): the other networks' jets — written by their forward launches into ONE array, network after network —
+    // are its tape's source rows, and it writes their seeds.  No k_expr launch, and the tail network's records never go through HBM.
+    // -1: every network takes the forward / k_expr / reverse path (narrow nets, tapes beyond 32 rows, DATA channels, PINN_NO_TAIL_FUSE=1)
+    int tail = -1;                   // index into `nets` / `groups`
+    std::vector<int> src_off;        // per network: first source row of its kernel's channels (tail: -1)
+    int nsrc = 0;                    // source rows = sum of the other kernels' channel counts
+    float* d_jets_all = nullptr;     // [nsrc][cap]; d_jets[i] / d_ubar[i] of the other networks point into these (rows packed with stride n)
+    float* d_ubar_all = nullptr;
     int64_t cap = 0;
     rp::Instr* d_prog = nullptr;
     double* d_losspart = nullptr;    // pseudo-group for the reduction: [blocks*4][K]

@@ -210,6 +210,9 @@ struct TermDev {
     const float* in;         // MODE_GRADIN: d(loss)/d(jet) [C][N]
     const float* src;        // [nsrc][N]: coordinate-only subexpressions of the residual, evaluated when the point set was installed
     int nsrc;                // tape rows dt+NP+C .. dt+NP+C+nsrc-1
+    // tail launch of an equation that couples several networks (plan.cpp: Coupled::tail): the source rows are the OTHER networks' jet channels
+    // (written by their forward launches); the fused kernel also delivers d(loss)/d(source row) = the seeds of those networks' reverse launches
+    float* src_bar;          // [nsrc][N], nullptr: plain sources (no adjoints wanted)
     // The term binds dt coordinates (rows of its point matrix, tape rows 0..dt-1); input i of the group's network is
     // coordinate imap[i] of the term (src/discretize.jl:111-131: every depvar gets its own `cord` rows).  hetero = the map is
     // not the identity over dt == D coordinates (systems whose dependent variables take different arguments).

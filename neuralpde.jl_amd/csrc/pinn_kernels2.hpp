@@ -691,6 +691,9 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                             vfloat rbar = rm * vfloat(T.scale) * sw;
                             PINN_UNROLL for (int ch = 0; ch < C; ++ch)
                                 lds_store(UB, vint((w * C + ch) * 16) + c, vselect(vin, rbar * vfloat(T.lin_a[ch < LIN_MAX_C ? ch : 0]), vfloat(0.f)));
+                            if (T.src_bar)                                  // coupled equation: seeds of the other networks' reverse launches
+                                PINN_UNROLL for (int j = 0; j < LIN_MAX_SRC; ++j)
+                                    if (j < T.nsrc) gstore_masked(T.src_bar, vint(j * T.N + pbase + 16 * w) + c, rbar * vfloat(T.lin_b[j]), vand(vin, g0));
                         }
                     }
                 } else {
@@ -746,6 +749,9 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                         }
                         PINN_UNROLL for (int ch = 0; ch < C; ++ch)
                             lds_store(UB, vint((w * C + ch) * 16) + c, vselect(vin, rbar * tape_get(ta, DT + NP + ch), vfloat(0.f)));   // 4 row groups: same value; masked points may hold inf/NaN
+                        if (T.src_bar)                                      // coupled equation: seeds of the other networks' reverse launches
+                            for (int j = 0; j < T.nsrc; ++j)
+                                gstore_masked(T.src_bar, vint(j * T.N + pbase + 16 * w) + c, rbar * tape_get(ta, DT + NP + C + j), vand(vin, g0));
                         for (int j = 0; j < ga.nparams_estim; ++j) {
                             vfloat pj = vselect(vand(g0, vin), rbar * tape_get(ta, DT + j), vfloat(0.f));
                             PINN_UNROLL for (int jj = 0; jj < MAX_PARAMS; ++jj) if (jj == j) pbar[jj] += pj;

@@ -497,15 +497,59 @@ static int plan_assign_terms(pinn_engine& E) {
         Cp.nets = term_nets[t];
         T.chan_of_slot.assign(T.slots.size(), -1);
         Cp.slot_net.assign(T.slots.size(), -1);
+        // the kernels first: the tail decision needs every network's channel count
+        std::vector<const pk::SpecInfo*> sps(Cp.nets.size(), nullptr);
         for (size_t i = 0; i < Cp.nets.size(); ++i) {
             const int net = Cp.nets[i];
-            const pk::SpecInfo* sp = nullptr;
             if (coupled_union) {
-                if (spec_for(t, net, T.d, coupled_needs[net].first, coupled_needs[net].second, coupled_hi[net], sp)) return 1;
+                if (spec_for(t, net, T.d, coupled_needs[net].first, coupled_needs[net].second, coupled_hi[net], sps[i])) return 1;
             } else {
                 unsigned nf = 0, nh = 0;
                 std::vector<std::pair<int, int>> npairs;
-                if (needs_of(T, net, nf, npairs, nh) || spec_for(t, net, T.d, nf, npairs, nh, sp)) return 1;
+                if (needs_of(T, net, nf, npairs, nh) || spec_for(t, net, T.d, nf, npairs, nh, sps[i])) return 1;
+            }
+        }
+        // TAIL launch: the family-2 kernel with the most channels evaluates the residual tape itself, the other networks' jets as source rows
+        {
+            const bool no_tail = std::getenv("PINN_NO_TAIL_FUSE") != nullptr;      // (read per plan: the tests switch it)
+            int best = -1, nsrc_all = 0;
+            bool data_ops = false;
+            for (auto& I : T.ops) data_ops = data_ops || I.code == rp::OP_DATA;
+            for (size_t i = 0; i < Cp.nets.size(); ++i) {
+                nsrc_all += sps[i]->C;
+                if (sps[i]->family == 2 && (best < 0 || sps[i]->C > sps[best]->C)) best = (int)i;
+            }
+            if (best >= 0 && !no_tail && !data_ops && !coupled_union) {
+                const int nsrc = nsrc_all - sps[best]->C;
+                if (T.d + E.np + sps[best]->C + nsrc + (int)T.ops.size() <= rp::MAX_ROWS_FUSED) {
+                    Cp.tail = best;
+                    Cp.nsrc = nsrc;
+                    Cp.src_off.assign(Cp.nets.size(), -1);
+                    int off = 0;
+                    for (size_t i = 0; i < Cp.nets.size(); ++i)
+                        if ((int)i != best) { Cp.src_off[i] = off; off += sps[i]->C; }
+                }
+            }
+        }
+        for (size_t i = 0; i < Cp.nets.size(); ++i) {
+            const int net = Cp.nets[i];
+            const pk::SpecInfo* sp = sps[i];
+            if ((int)i == Cp.tail) {                     // a launch group of its own: one term, MODE_FUSED
+                E.groups.emplace_back();
+                Group& G = E.groups.back();
+                G.kind = 2;
+                G.net = net;
+                G.spec = sp;
+                if (!E.netplans[net].spec) E.netplans[net].spec = sp;
+                Cp.groups.push_back((int)E.groups.size() - 1);
+                G.terms.push_back((int)t);
+                for (size_t si = 0; si < T.slots.size(); ++si)
+                    if (T.slots[si].net == net) {
+                        T.chan_of_slot[si] = chan_of(*G.spec, T.slots[si]);
+                        Cp.slot_net[si] = (int)i;
+                        if (T.chan_of_slot[si] < 0) return fail("internal: slot has no channel");
+                    }
+                continue;
             }
             const auto key = std::make_pair(net, sp);
             if (coupled_group.count(key) && (int)E.groups[coupled_group[key]].terms.size() >= pk::MAX_GROUP_TERMS) coupled_group.erase(key);
@@ -693,8 +737,42 @@ static int plan_group_buffers(pinn_engine& E) {
         std::vector<rp::Instr> prog;
         for (int ti : G.terms) {
             Term& T = E.terms[ti];
-            if (G.kind == 1) {           // coupled terms: the tape runs in k_expr, not in the wave kernel
+            if (G.kind == 1) {           // coupled terms: the tape runs in k_expr (or in the equation's tail launch), not in this kernel
                 G.prog_off.push_back(0); G.prog_n.push_back(0); G.out_row.push_back(0);
+                continue;
+            }
+            if (G.kind == 2) {
+                // tail launch of a coupled equation: the WHOLE tape (nothing is hoisted), rows
+                // [coordinates d | params np | this kernel's channels C | the other kernels' channels, network after network | ops]
+                const Coupled& Cp = E.coupled[T.coupled];
+                const int S = (int)T.slots.size();
+                const int rslot0 = T.d + E.np, rop0 = rslot0 + S;
+                auto remap2 = [&](int row) -> int {
+                    if (row < rslot0) return row;
+                    if (row < rop0) {
+                        const int si = row - rslot0, i = Cp.slot_net[si];
+                        return i == Cp.tail ? T.d + E.np + T.chan_of_slot[si] : T.d + E.np + s.C + Cp.src_off[i] + T.chan_of_slot[si];
+                    }
+                    return T.d + E.np + s.C + Cp.nsrc + (row - rop0);
+                };
+                G.prog_off.push_back((int)prog.size());
+                G.prog_n.push_back((int)T.ops.size());
+                std::vector<rp::Instr> mine;
+                for (size_t q = 0; q < T.ops.size(); ++q) {
+                    rp::Instr I = T.ops[q];
+                    const int lim = rop0 + (int)q;
+                    if (!rp::is_nullary(I.code) && (I.a < 0 || I.a >= lim)) return fail("descriptor: op operand row out of range");
+                    if (rp::is_binary(I.code) && (I.b < 0 || I.b >= lim)) return fail("descriptor: op operand row out of range");
+                    I.a = rp::is_nullary(I.code) ? 0 : remap2(I.a);
+                    I.b = rp::is_binary(I.code) ? remap2(I.b) : 0;
+                    rp::finalize(I);
+                    prog.push_back(I);
+                    mine.push_back(I);
+                }
+                if (T.out_row < 0 || T.out_row >= rop0 + (int)T.ops.size()) return fail("descriptor: out row out of range");
+                T.lin = LinearForm();
+                T.linear = detect_linear(mine, T.d, E.np, s.C, Cp.nsrc, remap2(T.out_row), T.lin);
+                G.out_row.push_back(remap2(T.out_row));
                 continue;
             }
             const int S = (int)T.slots.size();
@@ -984,8 +1062,9 @@ void free_plan(pinn_engine& E) {
     }
     for (auto& M : E.merged) { plat_free(M.d_scratch); plat_free(M.d_losspart); }
     for (auto& Cp : E.coupled) {
-        for (float* q : Cp.d_jets) plat_free(q);
-        for (float* q : Cp.d_ubar) plat_free(q);
+        for (size_t i = 0; i < Cp.d_jets.size(); ++i)
+            if (Cp.tail < 0 || (int)i == Cp.tail) { plat_free(Cp.d_jets[i]); plat_free(Cp.d_ubar[i]); }      // (the others point into the *_all arrays)
+        plat_free(Cp.d_jets_all); plat_free(Cp.d_ubar_all);
         plat_free(Cp.d_prog); plat_free(Cp.d_losspart); plat_free(Cp.d_pslab); plat_free(Cp.d_tmp);
     }
     for (auto& N : E.netplans) { plat_free(N.d_packed); plat_free(N.d_pack_idx); }
@@ -1017,7 +1096,14 @@ void retile(pinn_engine& E, int gi) {
         td.pw = (T.pw_n == T.n && T.pw_n > 0) ? T.d_pw : nullptr;
         td.src = (G.kind == 0) ? T.d_src : nullptr;
         td.nsrc = (G.kind == 0) ? (int)T.src_root.size() : 0;
-        td.linear = (G.kind == 0 && T.linear) ? 1 : 0;
+        td.src_bar = nullptr;
+        td.linear = ((G.kind == 0 || G.kind == 2) && T.linear) ? 1 : 0;
+        if (G.kind == 2) {               // tail launch of a coupled equation: the other networks' jets are the source rows, their seeds come back
+            const Coupled& Cp = E.coupled[T.coupled];
+            td.src = Cp.d_jets_all;
+            td.nsrc = Cp.nsrc;
+            td.src_bar = Cp.d_ubar_all;
+        }
         td.lin_k = T.lin.k;
         for (int c = 0; c < pk::LIN_MAX_C; ++c) td.lin_a[c] = T.lin.a[c];
         for (int j = 0; j < pk::LIN_MAX_SRC; ++j) td.lin_b[j] = T.lin.b[j];
@@ -1030,7 +1116,7 @@ void retile(pinn_engine& E, int gi) {
                 if (i < (int)m.size() && m[i] != i) td.hetero = 1;
             }
         }
-        if (G.kind == 1) {               // coupled term: this network's jet / seed buffers
+        if (G.kind == 1 || G.kind == 2) {               // coupled term: this network's jet / seed buffers
             const Coupled& Cp = E.coupled[T.coupled];
             for (size_t i = 0; i < Cp.groups.size(); ++i)
                 if (Cp.groups[i] == gi && i < Cp.d_jets.size()) { td.out = Cp.d_jets[i]; td.in = Cp.d_ubar[i]; }

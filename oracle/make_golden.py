@@ -8,6 +8,7 @@ oracle's behaviour and give the GPU tests fixtures that do not need torch autogr
     python oracle/make_golden.py full [names]    # the full-size cases (inputs pinned by SHA-256, minutes of CPU time each)
     python oracle/make_golden.py variants [names]  # the same problems at SCALED and TRAINED parameters, both oracle modes (r04: the regime
                                                  # where the split-operand bf16 GEMMs of the 64- / 128-wide kernels have the least margin)
+    python oracle/make_golden.py variants-f32 [names]  # adds the float32 evaluation of the same program to the variants fixtures
 """
 import os
 import sys
@@ -112,7 +113,7 @@ VARIANT_CASES = {
     # name: (full-size maker, maker of the reduced problem the training runs on, scale factors, Adam iteration counts)
     "cfg2_variants": (lambda: workloads.cfg2_poisson2d(points=65536), lambda: workloads.cfg2_poisson2d(points=2048, bcs_points=512), (2.0, 4.0), (2000, 6000)),
     "cfg3_variants": (lambda: workloads.cfg3_burgers(points=262144), lambda: workloads.cfg3_burgers(points=2048, bcs_points=512), (2.0,), (2000,)),
-    "cfg4_variants": (lambda: workloads.cfg4_cavity(points=16384, bcs_points=4096), None, (2.0, 4.0), ()),
+    "cfg4_variants": (lambda: workloads.cfg4_cavity(points=16384, bcs_points=4096), None, (2.0,), ()),       # (P = 199,683: one variant keeps the fixture at 4.5 MB)
     "cfg5_variants": (lambda: workloads.cfg5_heat_inverse(points=32768, bcs_points=8192), None, (2.0, 4.0), ()),
 }
 
@@ -189,9 +190,40 @@ def make_variants(out, only=None):
         np.savez_compressed(os.path.join(out, name + ".npz"), **d)
 
 
+def add_f32(out, only=None):
+    """adds to every variants fixture the SAME program evaluated in float32 (torch CPU, exact-derivative mode: `losses_f32_<tag>`,
+    `grad_f32_<tag>`): what a plain fp32 implementation of the reference's mathematics returns.  At trained parameters the residual is a
+    small difference of O(1) terms and NO fp32 evaluation reaches 1e-5 relative to the float64 result; the parity tests bound the
+    engine's error there by a small multiple of this evaluation's error (tests/test_gpu_theta_variants.py)."""
+    import torch
+    for name, (make, _, _, _) in VARIANT_CASES.items():
+        path = os.path.join(out, name + ".npz")
+        if (only and name not in only) or not os.path.exists(path):
+            continue
+        d = dict(np.load(path))
+        wl = make()
+        sets = point_sets(wl)
+        assert [set_digest(s) for s in sets] == list(d["set_sha256"])
+        prob = helpers.oracle_problem(m, wl.pde_system, wl.chains, param_estim=wl.param_estim)
+        po.DT = torch.float32
+        try:
+            for tag in d["tags"]:
+                losses, grad = chunked_loss_and_grad(prob, d["theta_" + str(tag)], sets, d["weights"], mode="exact")
+                d[f"losses_f32_{tag}"], d[f"grad_f32_{tag}"] = losses, grad.astype(np.float64)
+                ge = d[f"grad_exact_{tag}"]
+                print(name, tag, "float32 evaluation vs float64: loss rel", np.max(np.abs(losses - d[f"losses_exact_{tag}"]) / np.abs(d[f"losses_exact_{tag}"])),
+                      "grad rel L2", np.linalg.norm(grad - ge) / np.linalg.norm(ge), flush=True)
+        finally:
+            po.DT = torch.float64
+        np.savez_compressed(path, **d)
+
+
 def main():
     out = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "variants-f32":
+        add_f32(out, sys.argv[2:])
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "full":
         make_full(out, sys.argv[2:])
         return
