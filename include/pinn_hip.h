@@ -231,7 +231,16 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
  * Both kernel sets are in the library; switching rebuilds the handle's kernel plan in place (milliseconds) and keeps point sets, samplers,
  * per-point data / weights and the optimiser state.  Narrower nets (one-wave-per-tile kernels) and DGM nets compute on fp32 MFMAs / the
  * VALU in either mode.  $PINN_GEMM = split | fp32 sets the mode new handles start in.  pinn_get_option writes the current value.
+ * "precision" = "f32" (default) | "f64": the FLOAT64 evaluation mode — the reference's default eltype (src/discretize.jl:432-449).  With
+ *   "f64", pinn_loss_grad_f64 evaluates natively in double (pinn_loss_grad converts at the boundary) and pinn_lbfgs iterates on the double
+ *   objective: what a quasi-Newton stage needs to take an objective below ~1e-7 (test/NNPDE1/nnpde__pde_iii_3rd_order_ode.jl:89-93) and
+ *   what parity at TRAINED parameters needs (fp32 cannot hold 1e-5 there).  One lane per point on the fp64 VALU, 10-100x
+ *   slower than the fp32 kernels: for the reference's own regime (small nets, 10^2-10^4 points) and finishing stages.  Covers equations of
+ *   up to 6 dependent variables (same argument count), Dense chains with tanh / sigmoid / sin, derivative orders <= 2 (1-D: <= 4; 4-D: first and pure second), PDE
+ *   parameters, quadrature weights; anything else fails HERE with a message and leaves the fp32 plan usable.  The Adam entry points and the
+ *   device-pointer entry points stay fp32.  pinn_set_points_f64 installs a point set in double (the fp32 kernels get its float conversion).
  */
+int pinn_set_points_f64(pinn_handle h, int term, const double* pts, int64_t n, int64_t n_norm);
 int pinn_set_option(pinn_handle h, const char* name, const char* value);
 int pinn_get_option(pinn_handle h, const char* name, char* buf, int64_t buflen);
 

@@ -124,6 +124,20 @@ function set_gemm!(e::HIPEngine, mode::Symbol)
     return nothing
 end
 
+"""
+    set_precision!(e, :f64 | :f32)
+
+FLOAT64 evaluation of a live engine (`pinn_set_option(h, "precision", …)`, DESIGN.md section 4.5): `loss_grad` and `lbfgs!` then run the
+double kernels — the reference's default eltype (src/discretize.jl:432-449) — for a `BFGS()` finisher below the fp32 noise floor or a
+digit-by-digit comparison with a Float64 CPU run.  Point sets already installed are converted; `set_points!` keeps feeding both.
+Throws (and leaves the fp32 plan untouched) for problems the mode does not cover (DGM nets, embeddings, device samplers, DATA channels).
+"""
+function set_precision!(e::HIPEngine, mode::Symbol)
+    mode in (:f64, :f32) || throw(ArgumentError("precision must be :f64 or :f32"))
+    check(ccall(sym(:pinn_set_option), Cint, (Ptr{Cvoid}, Cstring, Cstring), e.h, "precision", String(mode)), "pinn_set_option")
+    return nothing
+end
+
 "Per-term gradients `K × P` (row k = ∂ term_losses[k] / ∂θ): what GradientScaleAdaptiveLoss and the per-term rrules consume."
 function term_grads(e::HIPEngine, θ::AbstractVector{<:Real})
     θ32 = Vector{Float32}(θ)

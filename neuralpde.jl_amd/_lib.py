@@ -34,7 +34,7 @@ SYMBOLS = [
     "pinn_loss_grad_sharded_device", "pinn_loss_grad_sharded",
     "pinn_set_sampler", "pinn_set_point_data", "pinn_set_point_weights", "pinn_get_points", "pinn_adam_init", "pinn_adam_steps", "pinn_adam_get", "pinn_lbfgs",
     "pinn_loss_device", "pinn_group_launched_by",
-    "pinn_set_option", "pinn_get_option", "pinn_comm_init_custom", "pinn_adam_steps_sharded", "pinn_adam_apply",
+    "pinn_set_option", "pinn_get_option", "pinn_set_points_f64", "pinn_comm_init_custom", "pinn_adam_steps_sharded", "pinn_adam_apply",
 ]
 
 
@@ -99,6 +99,7 @@ class Library:
         L.pinn_comm_init_custom.argtypes = [vp, C.c_int, C.c_int, self.ALLREDUCE_FN, vp]
         L.pinn_adam_steps_sharded.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, fp, dp]
         L.pinn_adam_apply.argtypes = [vp, fp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, fp, dp]
+        L.pinn_set_points_f64.argtypes = [vp, C.c_int, dp, C.c_int64, C.c_int64]
         L.pinn_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
         L.pinn_get_option.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int64]
         L.pinn_group_timing.argtypes = [vp, C.c_int, fp, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -214,6 +215,12 @@ class Engine:
         flat = _f32(pts.T).reshape(-1)     # (N x d) C-order == (d x N) Fortran order
         self.L.check(self.L.lib.pinn_set_points(self.h, term, flat.ctypes.data_as(C.POINTER(C.c_float)), pts.shape[1], n_norm),
                      "pinn_set_points")
+
+    def set_points_f64(self, term: int, pts, n_norm: int = 0):
+        """`pinn_set_points_f64`: the set in double for the float64 evaluation mode (the fp32 kernels get its float conversion)"""
+        pts = np.asarray(pts, dtype=np.float64)
+        flat = np.ascontiguousarray(pts.T).reshape(-1)
+        self.L.check(self.L.lib.pinn_set_points_f64(self.h, term, flat.ctypes.data_as(C.POINTER(C.c_double)), pts.shape[1], n_norm), "pinn_set_points_f64")
 
     def set_points_device(self, term: int, dptr: int, n: int, n_norm: int = 0):
         self.L.check(self.L.lib.pinn_set_points_device(self.h, term, C.c_void_p(dptr), n, n_norm), "pinn_set_points_device")

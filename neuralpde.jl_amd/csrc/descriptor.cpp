@@ -172,10 +172,14 @@ int parse_descriptor(const char* text, pinn_engine& E) {
             std::sort(S.axes, S.axes + S.order);
         }
         T.ops.resize(no);
+        T.imm64.clear();
         for (int q = 0; q < no; ++q) {
             std::string name;
             rp::Instr& I = T.ops[q];
-            if (!expect("op") || !(in >> name >> I.a >> I.b >> I.imm)) return fail("descriptor: op line");
+            double immd = 0.0;
+            if (!expect("op") || !(in >> name >> I.a >> I.b >> immd)) return fail("descriptor: op line");
+            I.imm = (float)immd;
+            T.imm64.push_back(immd);
             I.code = -1;
             for (int c = 0; c < rp::OP_COUNT; ++c)
                 if (name == OPNAMES[c]) I.code = c;

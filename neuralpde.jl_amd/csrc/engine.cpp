@@ -389,6 +389,7 @@ int pinn_create_on(const char* descriptor, int device, pinn_handle* out) {
         else return fail(std::string("PINN_GEMM must be \"split\" or \"fp32\", not \"") + gm + "\"");
     }
     if (parse_descriptor(descriptor, *E)) return 1;
+    E->terms0 = E->terms;                              // (before the planner rewrites them: the float64 mode evaluates the terms as parsed)
     E->ncu = plat_num_cus();
     E->stream = plat_stream_create();
     const int K = (int)E->terms.size();
@@ -430,6 +431,7 @@ int pinn_destroy(pinn_handle h) {
     DeviceScope scope(E.device);
     pinn_comm_destroy(h);
     plat_sync(E.stream);
+    f64_destroy(E);
     free_plan(E);
     for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_upts); plat_free(T.d_resid); plat_free(T.d_lb); plat_free(T.d_ub); plat_free(T.d_data); plat_free(T.d_pw); }
     plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist); plat_free(E.d_step); plat_free(E.d_draws); plat_free(E.d_sampled); plat_free(E.d_c12);
@@ -476,7 +478,8 @@ static int set_points_impl(pinn_handle h, int term, const float* pts, int64_t n,
     T.n_norm = n_norm > 0 ? n_norm : n;
     T.data_n = 0;                                        // per-point data and weights belong to the previous set
     T.pw_n = 0;
-    return term_installed(E, term);
+    if (term_installed(E, term)) return 1;
+    return f64_points_changed(E, term);                  // (float64 mode: the double copy follows)
 }
 
 // what follows the installation of a term's point set (also after a re-plan, pinn_set_option): source channels, tile tables, the buffers of
@@ -541,12 +544,31 @@ static int term_installed(pinn_engine& E, int term) {
 }
 int pinn_set_points(pinn_handle h, int term, const float* pts, int64_t n, int64_t n_norm) { return set_points_impl(h, term, pts, n, n_norm, false); }
 int pinn_set_points_device(pinn_handle h, int term, const float* d_pts, int64_t n, int64_t n_norm) { return set_points_impl(h, term, d_pts, n, n_norm, true); }
+int pinn_set_points_f64(pinn_handle h, int term, const double* pts, int64_t n, int64_t n_norm) {
+    if (!h || !pts || n <= 0) return fail("pinn_set_points_f64: null argument / empty point set");
+    if (term < 0 || term >= (int)h->terms.size()) return fail("pinn_set_points_f64: term index out of range");
+    const int d = h->terms[term].d_user;
+    std::vector<float> p32((size_t)n * d);
+    for (size_t i = 0; i < p32.size(); ++i) p32[i] = (float)pts[i];
+    if (set_points_impl(h, term, p32.data(), n, n_norm, false)) return 1;       // the fp32 kernels' copy (EltypeAdaptor, src/eltype_matching.jl:8-10)
+    if (!h->f64) return 0;
+    DeviceScope scope(h->device);
+    return f64_set_points(*h, term, pts, n);                                    // the float64 mode reads the points as given
+}
 
 int pinn_loss_grad(pinn_handle h, const float* theta, int64_t p, const float* term_w, double* term_losses, float* grad) {
     if (!h || !theta) return fail("pinn_loss_grad: null argument");
     pinn_engine& E = *h;
     DeviceScope scope(E.device);
     const int K = (int)E.terms.size();
+    if (E.f64) {                                         // float64 mode: converted at the boundary, evaluated in double
+        if (p != E.ntheta) return fail("theta length " + std::to_string(p) + " != ntheta " + std::to_string(E.ntheta));
+        std::vector<double> th(theta, theta + p), w(K, 1.0), g(grad ? p : 0);
+        if (term_w) for (int k = 0; k < K; ++k) w[k] = term_w[k];
+        if (f64_eval(E, th.data(), w.data(), term_losses, grad ? g.data() : nullptr)) return 1;
+        if (grad) for (int64_t i = 0; i < p; ++i) grad[i] = (float)g[i];
+        return 0;
+    }
     if (upload_theta(E, theta, p)) return 1;
     // grad == NULL: loss-only evaluation (no records, no reverse sweep, no gradient reduction) — what a callback, an adaptive-weight
     // rule or a rejected line-search trial needs (the reference's per-term closures are value-only unless differentiated,
@@ -563,6 +585,11 @@ int pinn_loss_grad(pinn_handle h, const float* theta, int64_t p, const float* te
 int pinn_loss_grad_f64(pinn_handle h, const double* theta, int64_t p, const double* term_w, double* term_losses, double* grad) {
     if (!h || !theta) return fail("pinn_loss_grad_f64: null argument");
     const int K = (int)h->terms.size();
+    if (h->f64) {                                        // float64 mode: native
+        if (p != h->ntheta) return fail("theta length " + std::to_string(p) + " != ntheta " + std::to_string(h->ntheta));
+        DeviceScope scope(h->device);
+        return f64_eval(*h, theta, term_w, term_losses, grad);
+    }
     std::vector<float> th(p), w(K, 1.0f), g(grad ? p : 0);
     for (int64_t i = 0; i < p; ++i) th[i] = (float)theta[i];
     if (term_w)
@@ -958,14 +985,20 @@ int pinn_set_option(pinn_handle h, const char* name, const char* value) {
         if (v == "fp32") return replan_gemm(E, pk::GEMM_FP32);
         return fail("pinn_set_option: gemm must be \"split\" or \"fp32\"");
     }
-    return fail("pinn_set_option: unknown option \"" + k + "\" (known: gemm)");
+    if (k == "precision") {
+        if (v == "f64") return f64_enable(E);
+        if (v == "f32") { plat_sync(E.stream); f64_destroy(E); return 0; }
+        return fail("pinn_set_option: precision must be \"f32\" or \"f64\"");
+    }
+    return fail("pinn_set_option: unknown option \"" + k + "\" (known: gemm, precision)");
 }
 
 int pinn_get_option(pinn_handle h, const char* name, char* buf, int64_t buflen) {
     if (!h || !name || !buf || buflen <= 0) return fail("pinn_get_option: bad argument");
     const std::string k = name;
     if (k == "gemm") { std::snprintf(buf, (size_t)buflen, "%s", h->gemm == pk::GEMM_FP32 ? "fp32" : "split"); return 0; }
-    return fail("pinn_get_option: unknown option \"" + k + "\" (known: gemm)");
+    if (k == "precision") { std::snprintf(buf, (size_t)buflen, "%s", h->f64 ? "f64" : "f32"); return 0; }
+    return fail("pinn_get_option: unknown option \"" + k + "\" (known: gemm, precision)");
 }
 
 int pinn_adam_init(pinn_handle h, const float* theta, int64_t p) {
@@ -1227,6 +1260,14 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
     // one device evaluation: fused loss + gradient, or (grad == nullptr) the loss-only launch — a rejected line-search trial needs the
     // objective only, at about a third of the cost
     auto eval = [&](const std::vector<double>& at, std::vector<double>* grad, double& f) -> int {
+        if (E.f64) {                                     // float64 mode: the objective and its gradient in double, no fp32 noise floor
+            std::vector<double> w(K, 1.0), L(K);
+            if (term_w) for (int k = 0; k < K; ++k) w[k] = term_w[k];
+            if (f64_eval(E, at.data(), w.data(), L.data(), grad ? grad->data() : nullptr)) return 1;
+            f = 0.0;
+            for (int k = 0; k < K; ++k) f += w[k] * L[k];
+            return 0;
+        }
         for (size_t i = 0; i < P; ++i) th32[i] = (float)at[i];
         if (upload_theta(E, th32.data(), p)) return 1;
         if (run_loss_grad(E, E.d_theta, E.hp_out, term_w, -1, false, E.hp_raw, false, grad == nullptr)) return 1;
@@ -1288,7 +1329,7 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
         if (!ok) {
             // no decrease along a descent direction: the evaluation's noise floor.  The split-operand GEMMs' floor is 2-4 x that of the
             // fp32 MFMA kernels: switch the handle to them once and go on from the same iterate
-            if (E.gemm == pk::GEMM_SPLIT && !switched && std::getenv("PINN_LBFGS_KEEP_GEMM") == nullptr) {
+            if (!E.f64 && E.gemm == pk::GEMM_SPLIT && !switched && std::getenv("PINN_LBFGS_KEEP_GEMM") == nullptr) {
                 if (replan_gemm(E, pk::GEMM_FP32)) return 1;
                 switched = E.gemm == pk::GEMM_FP32;
                 if (switched) {
@@ -1383,7 +1424,8 @@ int pinn_group_timing(pinn_handle h, int group, float* ms, int64_t* points, int*
 int pinn_describe(pinn_handle h, char* buf, int64_t buflen) {
     if (!h || !buf || buflen <= 0) return fail("pinn_describe: bad argument");
     std::ostringstream os;
-    os << "backend=" << plat_name() << " cus=" << h->ncu << " ntheta=" << h->ntheta << " terms=" << h->terms.size() << "\n";
+    os << "backend=" << plat_name() << " cus=" << h->ncu << " ntheta=" << h->ntheta << " terms=" << h->terms.size()
+       << (h->f64 ? " precision=f64 (pinn_loss_grad*, pinn_lbfgs evaluate in double: one lane per point; the plan below serves the fp32 entry points)" : "") << "\n";
     for (size_t n = 0; n < h->netplans.size(); ++n)
         if (h->netplans[n].spec && h->netplans[n].spec->family != 3)
             os << "net " << n << " weights=packed image (k_pack per evaluation)"

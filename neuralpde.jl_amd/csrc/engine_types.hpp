@@ -68,6 +68,7 @@ struct Term {
     LinearForm lin;
     std::vector<Slot> slots;
     std::vector<rp::Instr> ops;      // descriptor row numbering
+    std::vector<double> imm64;       // the ops' immediates as the descriptor spelled them (Instr::imm is a float): the float64 evaluation mode reads these
     int out_row = 0;
     // plan
     int net = -1;
@@ -194,6 +195,8 @@ struct pinn_engine {
     std::vector<float> p_defaults;
     std::vector<Net> nets;
     std::vector<Term> terms;
+    std::vector<Term> terms0;        // the terms as parsed, before the planner's rewrites (Laplacian fusion, source hoisting): what the float64 mode evaluates
+    void* f64 = nullptr;             // pe::F64State: the float64 evaluation mode (pinn_set_option "precision"), nullptr = off
     std::vector<Group> groups;
     std::vector<Coupled> coupled;
     std::vector<MergedUnit> merged;
@@ -286,6 +289,12 @@ struct DeviceScope {
     explicit DeviceScope(int dev) : prev(plat_get_device()) { if (prev != dev) plat_set_device(dev); else prev = -1; }
     ~DeviceScope() { if (prev >= 0) plat_set_device(prev); }
 };
+// f64.cpp: the float64 evaluation mode (pinn_kernels4.hpp)
+int f64_enable(pinn_engine& E);
+void f64_destroy(pinn_engine& E);
+int f64_points_changed(pinn_engine& E, int term);
+int f64_set_points(pinn_engine& E, int term, const double* pts, int64_t n);
+int f64_eval(pinn_engine& E, const double* theta, const double* term_w, double* term_losses, double* grad);
 // plan.cpp
 // GEMM arithmetic the kernel look-ups of the calling thread select (family 2 kernels exist as split-operand and fp32 twins): set for the
 // duration of an entry point that may look kernels up

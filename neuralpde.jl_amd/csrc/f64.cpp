@@ -1,0 +1,291 @@
+// f64.cpp — host side of the float64 evaluation mode (pinn_set_option(h, "precision", "f64"); kernels: pinn_kernels4.hpp).
+//
+// The reference evaluates in Float64 by default (src/discretize.jl:432-449: `init_params` are converted to Float64 unless the chain is
+// given Float32 parameters; the EltypeAdaptor then fixes the points' eltype, src/eltype_matching.jl:8-10).  This mode is that arithmetic
+// on the device, for callers that need more than fp32 can give at trained parameters: `pinn_loss_grad_f64`
+// evaluates natively, `pinn_loss_grad` converts at the boundary, `pinn_lbfgs` iterates on the float64 objective.
+// Scope: Dense chains with tanh / sigmoid / sin, equations of one or SEVERAL dependent variables (systems: up to 6 networks per equation, all
+// with the same number of inputs), derivative orders <= 2 in 1-3 inputs (1-D: <= 4; 4-D: first and pure second derivatives), PDE parameters
+// (param_estim), quadrature weights; no periodic embeddings, no DATA channels, no device samplers, no DGM networks.  Anything else fails at pinn_set_option with a message — the fp32 plan of the handle stays usable.
+#include "engine_types.hpp"
+#include "pinn_kernels4.hpp"
+
+namespace pk {
+std::deque<F64Kernel>& f64_registry() {
+    static std::deque<F64Kernel> r;
+    return r;
+}
+}  // namespace pk
+
+namespace pe {
+
+struct F64Term {
+    const pk::F64Kernel* k = nullptr;
+    std::vector<int> nets;               // networks the equation references, increasing
+    std::vector<int> slot_net, slot_chan;      // per slot: index into `nets`, jet channel
+    rp::Instr* d_prog = nullptr;
+    double* d_imm = nullptr;
+    int nops = 0, out_row = 0, nslots = 0;
+    double* d_pts = nullptr;             // [n][d] double; converted from the float set unless pinn_set_points_f64 installed it
+    int64_t cap = 0, n = 0;
+    bool exact_pts = false;              // installed in double (not a conversion of the float set)
+};
+struct F64State {
+    std::vector<F64Term> terms;
+    double* d_theta = nullptr;
+    double* d_grad = nullptr;            // [P]
+    double* d_sumsq = nullptr;           // [K]
+    double* d_scratch = nullptr;
+    size_t scratch_cap = 0;
+    double* d_slab = nullptr;
+    size_t slab_cap = 0;
+    std::vector<double> h_out;           // host staging [P + K]
+};
+
+static void f64_free(F64State* S) {
+    if (!S) return;
+    for (auto& T : S->terms) { plat_free(T.d_prog); plat_free(T.d_imm); plat_free(T.d_pts); }
+    plat_free(S->d_theta); plat_free(S->d_grad); plat_free(S->d_sumsq); plat_free(S->d_scratch); plat_free(S->d_slab);
+    delete S;
+}
+void f64_destroy(pinn_engine& E) {
+    f64_free((F64State*)E.f64);
+    E.f64 = nullptr;
+}
+
+// the smallest float64 kernel of `D` inputs that carries every derivative slot of the term
+static const pk::F64Kernel* f64_find(int D, const std::vector<Slot>& slots, std::vector<int>& chan, std::string& why) {
+    const pk::F64Kernel* best = nullptr;
+    for (const pk::F64Kernel& k : pk::f64_registry()) {
+        if (k.D != D) continue;
+        pk::SpecInfo s;
+        std::memset(&s, 0, sizeof s);
+        s.D = D; s.D1MASK = k.D1MASK; s.PAIRS = k.PAIRS; s.NPAIR = k.NPAIR; s.HI = k.HI; s.NFIRST = k.NFIRST; s.LAP = 0; s.ngen = 0;
+        bool ok = true;
+        std::vector<int> ch;
+        for (auto& sl : slots) {
+            if (sl.lap || slot_is_general(sl)) { ok = false; break; }
+            if (sl.order == 1 && !((k.D1MASK >> sl.axes[0]) & 1)) { ok = false; break; }     // (chan_of ranks first derivatives inside the mask, it does not test membership)
+            const int c = chan_of(s, sl);
+            if (c < 0) { ok = false; break; }
+            ch.push_back(c);
+        }
+        if (ok && (!best || k.C < best->C)) { best = &k; chan = ch; }
+    }
+    if (!best) why = "no float64 kernel carries this term's derivatives (orders <= 2 in 1-3 inputs; 1-D: <= 4; 4-D: first and pure second derivatives)";
+    return best;
+}
+
+static int f64_convert_points(pinn_engine& E, F64Term& F, const Term& T) {
+    // the float set as installed -> double (exact conversion of the fp32 values the fp32 kernels read)
+    const int64_t n = T.n;
+    if (n <= 0 || !T.d_pts) { F.n = 0; return 0; }
+    std::vector<float> h((size_t)n * T.d);
+    if (plat_d2h(h.data(), T.d_pts, sizeof(float) * h.size(), E.stream) || plat_sync(E.stream)) return fail("D2H copy of points failed");
+    std::vector<double> hd(h.begin(), h.end());
+    if (F.cap < n) {
+        plat_free(F.d_pts);
+        F.d_pts = (double*)plat_malloc(sizeof(double) * hd.size());
+        if (!F.d_pts) { F.cap = 0; return fail("device allocation failed (float64 points)"); }
+        F.cap = n;
+    }
+    if (plat_h2d(F.d_pts, hd.data(), sizeof(double) * hd.size(), E.stream) || plat_sync(E.stream)) return fail("H2D copy of points failed");
+    F.n = n;
+    F.exact_pts = false;
+    return 0;
+}
+
+int f64_enable(pinn_engine& E) {
+    if (E.f64) return 0;
+    if (E.terms0.size() != E.terms.size()) return fail("precision f64: internal (no pristine copy of the terms)");
+    std::unique_ptr<F64State, void (*)(F64State*)> S(new F64State(), &f64_free);
+    S->terms.resize(E.terms0.size());
+    for (size_t t = 0; t < E.terms0.size(); ++t) {
+        const Term& T = E.terms0[t];
+        F64Term& F = S->terms[t];
+        const std::string who = "precision f64: term " + std::to_string(t) + ": ";
+        std::vector<int> nets;
+        for (auto& sl : T.slots) if (std::find(nets.begin(), nets.end(), sl.net) == nets.end()) nets.push_back(sl.net);
+        std::sort(nets.begin(), nets.end());
+        if (nets.empty()) return fail(who + "references no dependent variable");
+        if ((int)nets.size() > pk::F64_MAX_NETS) return fail(who + "references more than 6 dependent variables");
+        F.nets = nets;
+        bool any_sin = false, all_sin = true;
+        for (int net : nets) {
+            const Net& N = E.nets[net];
+            if (N.kind != 0) return fail(who + "DGM networks are not covered by the float64 mode");
+            if (!N.emb_idx.empty()) return fail(who + "periodic input embeddings are not covered by the float64 mode");
+            if (N.act != pk::ACT_TANH && N.act != pk::ACT_SIGMOID && N.act != pk::ACT_SIN) return fail(who + "per-layer activation mixes are not covered by the float64 mode");
+            if ((int)N.sizes.size() - 1 > pk::F64_MAX_LAYERS) return fail(who + "more than 16 Dense layers");
+            if (N.sizes[0] != E.nets[nets[0]].sizes[0]) return fail(who + "its dependent variables take different numbers of arguments (one jet set serves all networks of an equation in the float64 mode)");
+            any_sin = any_sin || N.act == pk::ACT_SIN;
+            all_sin = all_sin && N.act == pk::ACT_SIN;
+        }
+        if (any_sin && !all_sin) return fail(who + "mixes sin networks with tanh / sigmoid networks");
+        if (!T.emb_cols.empty()) return fail(who + "periodic input embeddings are not covered by the float64 mode");
+        if (T.d > 4 || E.nets[nets[0]].sizes[0] > 4) return fail(who + "more than 4 coordinates");
+        if (E.terms[t].sampler != 0) return fail(who + "device samplers are not covered by the float64 mode (install fixed point sets)");
+        if ((int)T.slots.size() > pk::F64_MAX_SLOTS || T.d + E.np + (int)T.slots.size() + (int)T.ops.size() > pk::F64_MAX_ROWS)
+            return fail(who + "residual expression too long for the float64 tape (96 rows)");
+        for (auto& I : T.ops) if (I.code == rp::OP_DATA) return fail(who + "per-point DATA channels are not covered by the float64 mode");
+        std::string why;
+        F.k = f64_find(E.nets[nets[0]].sizes[0], T.slots, F.slot_chan, why);
+        if (!F.k) return fail(who + why);
+        F.slot_net.clear();
+        for (auto& sl : T.slots) F.slot_net.push_back((int)(std::find(nets.begin(), nets.end(), sl.net) - nets.begin()));
+        F.nops = (int)T.ops.size(); F.out_row = T.out_row; F.nslots = (int)T.slots.size();
+        std::vector<double> imm(T.ops.size());
+        for (size_t q = 0; q < T.ops.size(); ++q) imm[q] = q < T.imm64.size() ? T.imm64[q] : (double)T.ops[q].imm;
+        F.d_prog = (rp::Instr*)plat_malloc(sizeof(rp::Instr) * std::max<size_t>(T.ops.size(), 1));
+        F.d_imm = (double*)plat_malloc(sizeof(double) * std::max<size_t>(T.ops.size(), 1));
+        if (!F.d_prog || !F.d_imm) return fail("device allocation failed (float64 programs)");
+        if (!T.ops.empty()) {
+            plat_h2d(F.d_prog, T.ops.data(), sizeof(rp::Instr) * T.ops.size(), E.stream);
+            plat_h2d(F.d_imm, imm.data(), sizeof(double) * imm.size(), E.stream);
+            if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+        }
+        if (f64_convert_points(E, F, E.terms[t])) return 1;
+    }
+    const int K = (int)E.terms.size();
+    S->d_theta = (double*)plat_malloc(sizeof(double) * E.ntheta);
+    S->d_grad = (double*)plat_malloc(sizeof(double) * E.ntheta);
+    S->d_sumsq = (double*)plat_malloc(sizeof(double) * K);
+    if (!S->d_theta || !S->d_grad || !S->d_sumsq) return fail("device allocation failed (float64 state)");
+    S->h_out.resize((size_t)E.ntheta + K);
+    E.f64 = S.release();
+    return 0;
+}
+
+// a float set was (re)installed through pinn_set_points while the mode is on: keep the double copy in step
+int f64_points_changed(pinn_engine& E, int term) {
+    if (!E.f64) return 0;
+    F64State& S = *(F64State*)E.f64;
+    return f64_convert_points(E, S.terms[term], E.terms[term]);
+}
+
+int f64_set_points(pinn_engine& E, int term, const double* pts, int64_t n) {
+    F64State& S = *(F64State*)E.f64;
+    F64Term& F = S.terms[term];
+    const Term& T = E.terms[term];
+    if (F.cap < n) {
+        plat_sync(E.stream);
+        plat_free(F.d_pts);
+        F.d_pts = (double*)plat_malloc(sizeof(double) * (size_t)n * T.d);
+        if (!F.d_pts) { F.cap = 0; return fail("device allocation failed (float64 points)"); }
+        F.cap = n;
+    }
+    if (plat_h2d(F.d_pts, pts, sizeof(double) * (size_t)n * T.d, E.stream) || plat_sync(E.stream)) return fail("H2D copy of points failed");
+    F.n = n;
+    F.exact_pts = true;
+    return 0;
+}
+
+int f64_eval(pinn_engine& E, const double* theta, const double* term_w, double* term_losses, double* grad) {
+    F64State& S = *(F64State*)E.f64;
+    const int K = (int)E.terms.size();
+    const int64_t P = E.ntheta;
+    for (int t = 0; t < K; ++t)
+        if (S.terms[t].n <= 0 || S.terms[t].n != E.terms[t].n) return fail("term " + std::to_string(t) + " has no collocation points (call pinn_set_points first)");
+    if (plat_h2d(S.d_theta, theta, sizeof(double) * P, E.stream)) return fail("H2D copy of theta failed");
+    plat_memset(S.d_grad, 0, sizeof(double) * P, E.stream);
+    plat_memset(S.d_sumsq, 0, sizeof(double) * K, E.stream);
+    for (int t = 0; t < K; ++t) {
+        const Term& T = E.terms[t];
+        const Term& T0 = E.terms0[t];
+        F64Term& F = S.terms[t];
+        pk::F64Args a;
+        std::memset(&a, 0, sizeof a);
+        a.theta = S.d_theta; a.pts = F.d_pts; a.pw = (T.pw_n == T.n && T.pw_n > 0) ? T.d_pw : nullptr;
+        a.N = (int)F.n; a.dt = T0.d;
+        a.nnets = (int)F.nets.size();
+        a.C = F.k->C;
+        for (int i = 0; i < 8; ++i) a.first_ch[i] = F.k->first_ch[i];
+        int rows = 0, ent = 0;
+        bool sin_act = false;
+        for (int ni = 0; ni < a.nnets; ++ni) {
+            const Net& N = E.nets[F.nets[ni]];
+            pk::F64Net& n = a.net[ni];
+            n.d = N.sizes[0];
+            std::vector<int> m;
+            if (T0.inmap.count(F.nets[ni])) m = T0.inmap.at(F.nets[ni]);
+            else for (int i = 0; i < n.d; ++i) m.push_back(i);
+            if ((int)m.size() != n.d) return fail("precision f64: inmap length differs from the network's input count");
+            for (int i = 0; i < 4; ++i) n.imap[i] = i < (int)m.size() ? m[i] : 0;
+            n.nl = (int)N.sizes.size() - 1;
+            int o = N.theta_off;
+            for (int l = 0; l < n.nl; ++l) {
+                n.sizes[l] = N.sizes[l];
+                n.woff[l] = o;
+                n.boff[l] = o + N.sizes[l + 1] * N.sizes[l];
+                o = n.boff[l] + N.sizes[l + 1];
+            }
+            n.sizes[n.nl] = N.sizes[n.nl];
+            n.act = N.act;
+            sin_act = sin_act || N.act == pk::ACT_SIN;
+            n.theta0 = N.theta_off; n.nparams = N.nparams(); n.ent0 = ent;
+            ent += n.nparams;
+            // scratch rows: per hidden layer record / post-activation jets / dZ, then this network's seeds
+            const int L = n.nl - 1;
+            for (int l = 0; l < L; ++l) { n.r_rec[l] = rows; rows += N.sizes[l + 1] * a.C; }
+            for (int l = 0; l < L; ++l) { n.r_post[l] = rows; rows += N.sizes[l + 1] * a.C; }
+            for (int l = 0; l < L; ++l) { n.r_dz[l] = rows; rows += N.sizes[l + 1] * a.C; }
+            n.r_ubar = rows; rows += a.C;
+        }
+        a.ent_p = ent;
+        a.nent = ent + E.ne + 1;
+        a.r_pbar = rows; rows += std::max(E.ne, 1);
+        a.r_sq = rows; rows += 1;
+        a.np = E.np; a.ne = E.ne; a.p_off = E.p_theta_off;
+        for (int j = 0; j < pk::MAX_PARAMS; ++j) a.pdef[j] = j < (int)E.p_defaults.size() ? (double)E.p_defaults[j] : 0.0;
+        a.prog = F.d_prog; a.imm = F.d_imm; a.nops = F.nops; a.out_row = F.out_row; a.nslots = F.nslots;
+        for (int s = 0; s < F.nslots; ++s) { a.slot_chan[s] = F.slot_chan[s]; a.slot_net[s] = F.slot_net[s]; }
+
+        const double w = term_w ? term_w[t] : 1.0;
+        a.scale = 2.0 * w / (double)T.n_norm;
+        a.mode = grad ? 0 : 1;
+        // chunks of points: the scratch stays below 256 MB
+        int64_t chunk = (int64_t)((256.0 * 1024 * 1024) / (8.0 * rows));
+        chunk = std::max<int64_t>(pk::F64_BLOCK, (chunk / pk::F64_BLOCK) * pk::F64_BLOCK);
+        chunk = std::min<int64_t>(chunk, ((F.n + pk::F64_BLOCK - 1) / pk::F64_BLOCK) * pk::F64_BLOCK);
+        const size_t need = (size_t)rows * (size_t)chunk;
+        if (need > S.scratch_cap) {
+            plat_sync(E.stream);
+            plat_free(S.d_scratch);
+            S.d_scratch = (double*)plat_malloc(sizeof(double) * need);
+            S.scratch_cap = S.d_scratch ? need : 0;
+            if (!S.d_scratch) return fail("device allocation failed (float64 scratch)");
+        }
+        const int nbmax = (int)(chunk / pk::F64_BLOCK);
+        const size_t sneed = (size_t)nbmax * (size_t)a.nent;
+        if (sneed > S.slab_cap) {
+            plat_sync(E.stream);
+            plat_free(S.d_slab);
+            S.d_slab = (double*)plat_malloc(sizeof(double) * sneed);
+            S.slab_cap = S.d_slab ? sneed : 0;
+            if (!S.d_slab) return fail("device allocation failed (float64 slabs)");
+        }
+        a.scratch = S.d_scratch; a.npad = (int)chunk; a.slab = S.d_slab;
+        for (int64_t p0 = 0; p0 < F.n; p0 += chunk) {
+            a.p0 = (int)p0;
+            a.npts = (int)std::min<int64_t>(chunk, F.n - p0);
+            F.k->launch_point(a, sin_act, E.stream);
+            pk::launch_f64_dw(a, E.stream);
+            pk::F64ReduceArgs r;
+            std::memset(&r, 0, sizeof r);
+            r.slab = S.d_slab; r.nblocks = (a.npts + pk::F64_BLOCK - 1) / pk::F64_BLOCK; r.nent = a.nent;
+            r.grad = S.d_grad; r.ent_p = a.ent_p; r.p_off = E.p_theta_off; r.nnets = a.nnets;
+            for (int ni = 0; ni < a.nnets; ++ni) { r.ent0[ni] = a.net[ni].ent0; r.theta0[ni] = a.net[ni].theta0; }
+            r.sumsq = S.d_sumsq + t; r.with_grad = grad ? 1 : 0;
+            pk::launch_f64_reduce(r, E.stream);
+        }
+    }
+    if (plat_d2h(S.h_out.data(), S.d_grad, sizeof(double) * P, E.stream)) return fail("D2H copy failed");
+    if (plat_d2h(S.h_out.data() + P, S.d_sumsq, sizeof(double) * K, E.stream)) return fail("D2H copy failed");
+    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    if (term_losses)
+        for (int k = 0; k < K; ++k) term_losses[k] = S.h_out[(size_t)P + k] / (double)E.terms[k].n_norm;
+    if (grad) std::memcpy(grad, S.h_out.data(), sizeof(double) * P);
+    return 0;
+}
+
+}  // namespace pe

@@ -267,78 +267,80 @@ struct GroupArgs {
 // f(z) = m s(m z) + 1 - m with s = logistic and m = 2 (tanh) or 1 (sigmoid), so the layer kind enters only through the scalar m:
 // no branch behind the GEMMs (a run-time branch there is what the unmixed kernels avoid by taking the kind as a template parameter).
 // s^(6) / (s (1 - s)) and s^(7) / (s (1 - s)) of the logistic function as polynomials in s (Horner form)
-DEV vfloat sig_poly6(vfloat s) {
-    return vfma(vfma(vfma(vfma(vfma(vfloat(-720.0f), s, vfloat(1800.0f)), s, vfloat(-1560.0f)), s, vfloat(540.0f)), s, vfloat(-62.0f)), s, vfloat(1.0f));
+// (r04) the activation / jet rules below are templates over the lane-value type V: vfloat in the wave kernels (fp32), plain double in
+// the per-point float64 kernels (pinn_kernels4.hpp) — one statement of the mathematics for both precisions
+template <class V> DEV V sig_poly6(V s) {
+    return vfma(vfma(vfma(vfma(vfma(V(-720.0f), s, V(1800.0f)), s, V(-1560.0f)), s, V(540.0f)), s, V(-62.0f)), s, V(1.0f));
 }
-DEV vfloat sig_poly7(vfloat s) {
-    return vfma(vfma(vfma(vfma(vfma(vfma(vfloat(5040.0f), s, vfloat(-15120.0f)), s, vfloat(16800.0f)), s, vfloat(-8400.0f)), s, vfloat(1806.0f)), s, vfloat(-126.0f)), s, vfloat(1.0f));
+template <class V> DEV V sig_poly7(V s) {
+    return vfma(vfma(vfma(vfma(vfma(vfma(V(5040.0f), s, V(-15120.0f)), s, V(16800.0f)), s, V(-8400.0f)), s, V(1806.0f)), s, V(-126.0f)), s, V(1.0f));
 }
-template <int NORD, bool SINACT, bool MIXED = false>
-DEV void act_derivs_n(int act, vfloat a, vfloat (&d)[ND]) {
+template <int NORD, bool SINACT, bool MIXED = false, class V = vfloat>
+DEV void act_derivs_n(int act, V a, V (&d)[ND]) {
     if (MIXED) {
         const float m = 2.0f - (float)act, im = 0.5f + 0.5f * (float)act, m2 = m * m;      // act in {ACT_TANH = 0, ACT_SIGMOID = 1}
-        const vfloat s = (a + vfloat(m - 1.0f)) * vfloat(im);                              // logistic value behind the record
-        const vfloat s1 = s * (vfloat(1.0f) - s);
-        const vfloat s2 = s1 * vfma(vfloat(-2.0f), s, vfloat(1.0f));
-        const vfloat s3 = s1 * vfma(vfloat(-6.0f), s1, vfloat(1.0f));
-        d[1] = vfloat(m2) * s1;
-        d[2] = vfloat(m2 * m) * s2;
-        d[3] = vfloat(m2 * m2) * s3;
-        if (NORD >= 4) d[4] = vfloat(m2 * m2 * m) * (s2 * vfma(vfloat(-12.0f), s1, vfloat(1.0f)));
-        if (NORD >= 5) d[5] = vfloat(m2 * m2 * m2) * vfma(s3, vfma(vfloat(-12.0f), s1, vfloat(1.0f)), vfloat(-12.0f) * s2 * s2);
-        if (NORD >= 6) d[6] = vfloat(m2 * m2 * m2 * m) * s1 * sig_poly6(s);
-        if (NORD >= 7) d[7] = vfloat(m2 * m2 * m2 * m2) * s1 * sig_poly7(s);
+        const V s = (a + V(m - 1.0f)) * V(im);                              // logistic value behind the record
+        const V s1 = s * (V(1.0f) - s);
+        const V s2 = s1 * vfma(V(-2.0f), s, V(1.0f));
+        const V s3 = s1 * vfma(V(-6.0f), s1, V(1.0f));
+        d[1] = V(m2) * s1;
+        d[2] = V(m2 * m) * s2;
+        d[3] = V(m2 * m2) * s3;
+        if (NORD >= 4) d[4] = V(m2 * m2 * m) * (s2 * vfma(V(-12.0f), s1, V(1.0f)));
+        if (NORD >= 5) d[5] = V(m2 * m2 * m2) * vfma(s3, vfma(V(-12.0f), s1, V(1.0f)), V(-12.0f) * s2 * s2);
+        if (NORD >= 6) d[6] = V(m2 * m2 * m2 * m) * s1 * sig_poly6(s);
+        if (NORD >= 7) d[7] = V(m2 * m2 * m2 * m2) * s1 * sig_poly7(s);
         return;
     }
     if (SINACT) {
-        vfloat sn, cs;
+        V sn, cs;
         vsincos(a, sn, cs);
         d[1] = cs;
-        d[2] = vfloat(0.f) - sn;
-        d[3] = vfloat(0.f) - cs;
+        d[2] = V(0.f) - sn;
+        d[3] = V(0.f) - cs;
         if (NORD >= 4) d[4] = sn;
         if (NORD >= 5) d[5] = cs;
-        if (NORD >= 6) d[6] = vfloat(0.f) - sn;
-        if (NORD >= 7) d[7] = vfloat(0.f) - cs;
+        if (NORD >= 6) d[6] = V(0.f) - sn;
+        if (NORD >= 7) d[7] = V(0.f) - cs;
     } else if (act == ACT_TANH) {
-        const vfloat a2 = a * a;
-        d[1] = vfma(-a, a, vfloat(1.0f));                           // 1 - a^2 with one rounding (the negation is an operand modifier)
-        d[2] = vfloat(-2.0f) * a * d[1];
-        d[3] = d[1] * vfma(vfloat(6.0f), a2, vfloat(-2.0f));
-        if (NORD >= 4) d[4] = d[1] * a * vfma(vfloat(-24.0f), a2, vfloat(16.0f));
-        if (NORD >= 5) d[5] = d[1] * (vfma(vfma(vfloat(120.0f), a2, vfloat(-120.0f)), a2, vfloat(16.0f)));
-        if (NORD >= 6) d[6] = d[1] * a * vfma(vfma(vfloat(-720.0f), a2, vfloat(960.0f)), a2, vfloat(-272.0f));
-        if (NORD >= 7) d[7] = d[1] * vfma(vfma(vfma(vfloat(5040.0f), a2, vfloat(-8400.0f)), a2, vfloat(3696.0f)), a2, vfloat(-272.0f));
+        const V a2 = a * a;
+        d[1] = vfma(-a, a, V(1.0f));                           // 1 - a^2 with one rounding (the negation is an operand modifier)
+        d[2] = V(-2.0f) * a * d[1];
+        d[3] = d[1] * vfma(V(6.0f), a2, V(-2.0f));
+        if (NORD >= 4) d[4] = d[1] * a * vfma(V(-24.0f), a2, V(16.0f));
+        if (NORD >= 5) d[5] = d[1] * (vfma(vfma(V(120.0f), a2, V(-120.0f)), a2, V(16.0f)));
+        if (NORD >= 6) d[6] = d[1] * a * vfma(vfma(V(-720.0f), a2, V(960.0f)), a2, V(-272.0f));
+        if (NORD >= 7) d[7] = d[1] * vfma(vfma(vfma(V(5040.0f), a2, V(-8400.0f)), a2, V(3696.0f)), a2, V(-272.0f));
     } else {
-        d[1] = a * (vfloat(1.0f) - a);
-        d[2] = d[1] * vfma(vfloat(-2.0f), a, vfloat(1.0f));
-        d[3] = d[1] * vfma(vfloat(-6.0f), d[1], vfloat(1.0f));
-        if (NORD >= 4) d[4] = d[2] * vfma(vfloat(-12.0f), d[1], vfloat(1.0f));
-        if (NORD >= 5) d[5] = vfma(d[3], vfma(vfloat(-12.0f), d[1], vfloat(1.0f)), vfloat(-12.0f) * d[2] * d[2]);
+        d[1] = a * (V(1.0f) - a);
+        d[2] = d[1] * vfma(V(-2.0f), a, V(1.0f));
+        d[3] = d[1] * vfma(V(-6.0f), d[1], V(1.0f));
+        if (NORD >= 4) d[4] = d[2] * vfma(V(-12.0f), d[1], V(1.0f));
+        if (NORD >= 5) d[5] = vfma(d[3], vfma(V(-12.0f), d[1], V(1.0f)), V(-12.0f) * d[2] * d[2]);
         if (NORD >= 6) d[6] = d[1] * sig_poly6(a);
         if (NORD >= 7) d[7] = d[1] * sig_poly7(a);
     }
 }
 // One element's jet through the activation (Faa di Bruno), in place: z[0] = a = phi(z0) on entry, z[k>0] = pre-activation
 // channels; on exit z[k] = post-activation channels.  Higher channels first: they read the lower pre-activation values.
-template <class J>
-DEV void jet_forward(vfloat (&z)[J::C], const vfloat (&d)[ND]) {
+template <class J, class V>
+DEV void jet_forward(V (&z)[J::C], const V (&d)[ND]) {
     PINN_UNROLL for (int k = 0; k < J::N4; ++k) {
         const int ax = J::hi_axis(4, k);
-        const vfloat z1 = z[J::CH_FIRST + J::first_rank(ax)], z2 = z[J::CH_PAIR + J::pair_index(ax, ax)], z3 = z[J::CH_3 + J::hi_rank(3, ax)];
-        const vfloat z11 = z1 * z1;
-        vfloat r = d[1] * z[J::CH_4 + k];
-        r = vfma(vfloat(4.0f) * d[2] * z1, z3, r);
-        r = vfma(vfloat(3.0f) * d[2] * z2, z2, r);
-        r = vfma(vfloat(6.0f) * d[3] * z11, z2, r);
+        const V z1 = z[J::CH_FIRST + J::first_rank(ax)], z2 = z[J::CH_PAIR + J::pair_index(ax, ax)], z3 = z[J::CH_3 + J::hi_rank(3, ax)];
+        const V z11 = z1 * z1;
+        V r = d[1] * z[J::CH_4 + k];
+        r = vfma(V(4.0f) * d[2] * z1, z3, r);
+        r = vfma(V(3.0f) * d[2] * z2, z2, r);
+        r = vfma(V(6.0f) * d[3] * z11, z2, r);
         r = vfma(d[4] * z11, z11, r);
         z[J::CH_4 + k] = r;
     }
     PINN_UNROLL for (int k = 0; k < J::N3; ++k) {
         const int ax = J::hi_axis(3, k);
-        const vfloat z1 = z[J::CH_FIRST + J::first_rank(ax)], z2 = z[J::CH_PAIR + J::pair_index(ax, ax)];
-        vfloat r = d[1] * z[J::CH_3 + k];
-        r = vfma(vfloat(3.0f) * d[2] * z1, z2, r);
+        const V z1 = z[J::CH_FIRST + J::first_rank(ax)], z2 = z[J::CH_PAIR + J::pair_index(ax, ax)];
+        V r = d[1] * z[J::CH_3 + k];
+        r = vfma(V(3.0f) * d[2] * z1, z2, r);
         r = vfma(d[3] * z1 * z1, z1, r);
         z[J::CH_3 + k] = r;
     }
@@ -347,7 +349,7 @@ DEV void jet_forward(vfloat (&z)[J::C], const vfloat (&d)[ND]) {
         z[J::CH_PAIR + p] = vfma(d[2] * z[ca], z[cb], d[1] * z[J::CH_PAIR + p]);
     }
     if (J::NLAP) {
-        vfloat sq = vfloat(0.f);
+        V sq = V(0.f);
         PINN_UNROLL for (int a = 0; a < 8; ++a)
             if (J::LAP & (1u << a)) sq = vfma(z[J::CH_FIRST + J::first_rank(a)], z[J::CH_FIRST + J::first_rank(a)], sq);
         z[J::CH_LAP] = vfma(d[2], sq, d[1] * z[J::CH_LAP]);
@@ -356,58 +358,58 @@ DEV void jet_forward(vfloat (&z)[J::C], const vfloat (&d)[ND]) {
 }
 // Adjoint of jet_forward for one element: g[k] = adjoint of post-activation channel k on entry, of pre-activation channel k
 // on exit; s = the record (s[0] = a, s[k>0] = pre-activation channels).
-template <class J>
-DEV void jet_adjoint(vfloat (&g)[J::C], const vfloat (&s)[J::C], const vfloat (&d)[ND]) {
+template <class J, class V>
+DEV void jet_adjoint(V (&g)[J::C], const V (&s)[J::C], const V (&d)[ND]) {
 #if !defined(PINN_EMU)
 #pragma clang fp contract(fast)      // reverse-sweep only: nothing here feeds a residual, so the compiler may fuse what it finds (vec.hpp)
 #endif
-    vfloat zv = d[1] * g[0];
-    vfloat zf[J::NFIRST > 0 ? J::NFIRST : 1], zp[J::NPAIR > 0 ? J::NPAIR : 1], z3b[J::N3 > 0 ? J::N3 : 1];
+    V zv = d[1] * g[0];
+    V zf[J::NFIRST > 0 ? J::NFIRST : 1], zp[J::NPAIR > 0 ? J::NPAIR : 1], z3b[J::N3 > 0 ? J::N3 : 1];
     PINN_UNROLL for (int kf = 0; kf < J::NFIRST; ++kf) {
-        const vfloat gk = g[J::CH_FIRST + kf];
+        const V gk = g[J::CH_FIRST + kf];
         zv = vfma(d[2] * s[J::CH_FIRST + kf], gk, zv);
         zf[kf] = d[1] * gk;
     }
     PINN_UNROLL for (int p = 0; p < J::NPAIR; ++p) {
         const int ka = J::first_rank(J::pair_a(p)), kb = J::first_rank(J::pair_b(p));
-        const vfloat za = s[J::CH_FIRST + ka], zb = s[J::CH_FIRST + kb], gp = g[J::CH_PAIR + p];
+        const V za = s[J::CH_FIRST + ka], zb = s[J::CH_FIRST + kb], gp = g[J::CH_PAIR + p];
         zv = vfma(vfma(d[3] * za, zb, d[2] * s[J::CH_PAIR + p]), gp, zv);
         zf[ka] = vfma(d[2] * zb, gp, zf[ka]);
         zf[kb] = vfma(d[2] * za, gp, zf[kb]);
         zp[p] = d[1] * gp;
     }
     if (J::NLAP) {
-        const vfloat gl = g[J::CH_LAP];
-        vfloat sq = vfloat(0.f);
+        const V gl = g[J::CH_LAP];
+        V sq = V(0.f);
         PINN_UNROLL for (int a = 0; a < 8; ++a)
             if (J::LAP & (1u << a)) {
-                const vfloat za = s[J::CH_FIRST + J::first_rank(a)];
+                const V za = s[J::CH_FIRST + J::first_rank(a)];
                 sq = vfma(za, za, sq);
-                zf[J::first_rank(a)] = vfma(vfloat(2.0f) * d[2] * za, gl, zf[J::first_rank(a)]);
+                zf[J::first_rank(a)] = vfma(V(2.0f) * d[2] * za, gl, zf[J::first_rank(a)]);
             }
         zv = vfma(vfma(d[3], sq, d[2] * s[J::CH_LAP]), gl, zv);
         g[J::CH_LAP] = d[1] * gl;
     }
     PINN_UNROLL for (int k = 0; k < J::N3; ++k) {
         const int ax = J::hi_axis(3, k), k1 = J::first_rank(ax), p2 = J::pair_index(ax, ax);
-        const vfloat z1 = s[J::CH_FIRST + k1], z2 = s[J::CH_PAIR + p2], z3 = s[J::CH_3 + k], g3 = g[J::CH_3 + k];
+        const V z1 = s[J::CH_FIRST + k1], z2 = s[J::CH_PAIR + p2], z3 = s[J::CH_3 + k], g3 = g[J::CH_3 + k];
         z3b[k] = d[1] * g3;
-        zp[p2] = vfma(vfloat(3.0f) * d[2] * z1, g3, zp[p2]);
-        zf[k1] = vfma(vfloat(3.0f) * vfma(d[3] * z1, z1, d[2] * z2), g3, zf[k1]);
-        zv = vfma(vfma(d[4] * z1 * z1, z1, vfma(vfloat(3.0f) * d[3] * z1, z2, d[2] * z3)), g3, zv);
+        zp[p2] = vfma(V(3.0f) * d[2] * z1, g3, zp[p2]);
+        zf[k1] = vfma(V(3.0f) * vfma(d[3] * z1, z1, d[2] * z2), g3, zf[k1]);
+        zv = vfma(vfma(d[4] * z1 * z1, z1, vfma(V(3.0f) * d[3] * z1, z2, d[2] * z3)), g3, zv);
     }
     PINN_UNROLL for (int k = 0; k < J::N4; ++k) {
         const int ax = J::hi_axis(4, k), k1 = J::first_rank(ax), p2 = J::pair_index(ax, ax), k3 = J::hi_rank(3, ax);
-        const vfloat z1 = s[J::CH_FIRST + k1], z2 = s[J::CH_PAIR + p2], z3 = s[J::CH_3 + k3], z4 = s[J::CH_4 + k], g4 = g[J::CH_4 + k];
-        const vfloat z11 = z1 * z1;
+        const V z1 = s[J::CH_FIRST + k1], z2 = s[J::CH_PAIR + p2], z3 = s[J::CH_3 + k3], z4 = s[J::CH_4 + k], g4 = g[J::CH_4 + k];
+        const V z11 = z1 * z1;
         g[J::CH_4 + k] = d[1] * g4;
-        z3b[k3] = vfma(vfloat(4.0f) * d[2] * z1, g4, z3b[k3]);
-        zp[p2] = vfma(vfloat(6.0f) * vfma(d[3], z11, d[2] * z2), g4, zp[p2]);
-        zf[k1] = vfma(vfloat(4.0f) * vfma(d[4] * z11, z1, vfma(vfloat(3.0f) * d[3] * z1, z2, d[2] * z3)), g4, zf[k1]);
-        vfloat t = d[2] * z4;
-        t = vfma(vfloat(4.0f) * d[3] * z1, z3, t);
-        t = vfma(vfloat(3.0f) * d[3] * z2, z2, t);
-        t = vfma(vfloat(6.0f) * d[4] * z11, z2, t);
+        z3b[k3] = vfma(V(4.0f) * d[2] * z1, g4, z3b[k3]);
+        zp[p2] = vfma(V(6.0f) * vfma(d[3], z11, d[2] * z2), g4, zp[p2]);
+        zf[k1] = vfma(V(4.0f) * vfma(d[4] * z11, z1, vfma(V(3.0f) * d[3] * z1, z2, d[2] * z3)), g4, zf[k1]);
+        V t = d[2] * z4;
+        t = vfma(V(4.0f) * d[3] * z1, z3, t);
+        t = vfma(V(3.0f) * d[3] * z2, z2, t);
+        t = vfma(V(6.0f) * d[4] * z11, z2, t);
         t = vfma(d[5] * z11, z11, t);
         zv = vfma(t, g4, zv);
     }
@@ -417,22 +419,22 @@ DEV void jet_adjoint(vfloat (&g)[J::C], const vfloat (&s)[J::C], const vfloat (&
     PINN_UNROLL for (int k = 0; k < J::N3; ++k) g[J::CH_3 + k] = z3b[k];
 }
 
-template <bool SINACT, bool MIXED = false>
-DEV vfloat act_value(int act, vfloat z) {
+template <bool SINACT, bool MIXED = false, class V = vfloat>
+DEV V act_value(int act, V z) {
     if (MIXED) {
         const float m = 2.0f - (float)act;
-        return vfma(vsigmoid_fast(vfloat(m) * z), vfloat(m), vfloat(1.0f - m));
+        return vfma(vsigmoid_fast(V(m) * z), V(m), V(1.0f - m));
     }
-    if (SINACT) { vfloat sn, cs; vsincos(z, sn, cs); return sn; }
+    if (SINACT) { V sn, cs; vsincos(z, sn, cs); return sn; }
     if (act == ACT_TANH) return vtanh_fast(z);
     return vsigmoid_fast(z);
 }
 // record value r0 of an element with pre-activation z and activation a, and the activation back from r0
-template <bool SINACT> DEV vfloat act_record(vfloat z, vfloat a) { return SINACT ? z : a; }
-template <bool SINACT>
-DEV vfloat act_from_record(vfloat r0) {
+template <bool SINACT, class V> DEV V act_record(V z, V a) { return SINACT ? z : a; }
+template <bool SINACT, class V>
+DEV V act_from_record(V r0) {
     if (!SINACT) return r0;
-    vfloat sn, cs;
+    V sn, cs;
     vsincos(r0, sn, cs);
     return sn;
 }

@@ -1,0 +1,339 @@
+// pinn_kernels4.hpp — "family 4": the FLOAT64 evaluation of the PINN loss and its gradient, one lane per collocation point.
+//
+// The reference's default parameter eltype is Float64 (src/discretize.jl:432-449) and its quasi-Newton stages rely on it
+// (test/NNPDE1/nnpde__pde_iii_3rd_order_ode.jl:89-93: objective < 1e-9).  fp32 arithmetic — whatever the GEMM — cannot follow a TRAINED
+// network below ~1e-5 relative (the residual is a small difference of O(1) terms), so the engine carries this opt-in
+// precise mode (pinn_set_option(h, "precision", "f64")): same mathematics as the fp32 kernels — exact Taylor jets through the layers
+// (the activation / jet rules of pinn_kernels.hpp instantiated with V = double), the residual tape (rprog.hpp with double immediates),
+// the hand-derived reverse sweep — but built for accuracy and generality, not for the matrix pipe:
+//   * one LANE per point, every per-point vector (records, post-activation jets, dZ) in point-major scratch rows [row][point] in
+//     HBM / L2 (coalesced; a lane only touches its own column: no LDS, no barriers), weights as wave-uniform loads straight from theta
+//     (double, ComponentArrays order — no packed image), layer widths and depth are RUN-TIME values: one kernel per (jet set, activation);
+//   * the weight gradients by a second kernel (one thread per theta entry and block of points) into per-block slabs, summed in a fixed
+//     order — deterministic, no atomics;
+//   * cost: VALU fp64 FMAs with L2-resident operands — 10-100x slower than the fp32 kernels; meant for the reference's own regime (nets of
+//     12-64 neurons, 10^2-10^4 points) and for finishing stages.
+#pragma once
+#include "pinn_kernels.hpp"
+
+namespace pk {
+
+constexpr int F64_MAX_LAYERS = 16;      // Dense layers including the output layer
+constexpr int F64_MAX_ROWS = 96;        // tape rows [coordinates | params | slots | ops]
+constexpr int F64_MAX_SLOTS = 24;
+constexpr int F64_BLOCK = 256;          // points per block of the weight-gradient kernel (= rows of the per-block slabs)
+
+constexpr int F64_MAX_NETS = 6;         // dependent variables one equation may reference (systems: test/NNPDE1/nnpde__pde_iii_3rd_order_ode.jl:70-76)
+
+struct F64Net {
+    int d;                              // inputs of the network
+    int imap[4];                        // network input i = coordinate imap[i] of the term
+    int nl;                             // Dense layers (hidden layers + the output layer)
+    int sizes[F64_MAX_LAYERS + 1];      // n_0 .. n_nl, n_nl == 1
+    int woff[F64_MAX_LAYERS], boff[F64_MAX_LAYERS];      // theta offsets of W_l (n_out x n_in, column-major) and b_l
+    int r_rec[F64_MAX_LAYERS], r_post[F64_MAX_LAYERS], r_dz[F64_MAX_LAYERS];      // scratch row bases of hidden layer l: record / post-activation
+                                                                                  // jets / dZ, H_l * C rows each (row = base + neuron * C + channel)
+    int r_ubar;                         // seeds d(loss)/d(jet channel) of this network [C]
+    int act;                            // ACT_TANH / ACT_SIGMOID / ACT_SIN
+    int theta0, nparams, ent0;          // the network's slice of theta; its first slab entry
+};
+struct F64Args {
+    const double* theta;                // the whole parameter vector
+    const double* pts;                  // [N][dt] point-major
+    const float* pw;                    // per-point factors sqrt(N w_i) of a quadrature-weighted term, nullable
+    int N, p0, npts;                    // points of the term; first point and point count of this launch (one chunk)
+    int dt;                             // coordinates per point of the term
+    int nnets;                          // networks the equation references (all with the same number of inputs: one jet set serves them)
+    F64Net net[F64_MAX_NETS];
+    int np, ne, p_off;                  // tape rows of PDE parameters; the first ne live in theta at p_off, the rest are defaults
+    double pdef[MAX_PARAMS];
+    const rp::Instr* prog;              // descriptor numbering: rows [coordinates dt | params np | slots | ops]
+    const double* imm;                  // the ops' immediates in double (Instr::imm is a float)
+    int nops, out_row, nslots;
+    int slot_net[F64_MAX_SLOTS];        // slot s reads network slot_net[s] (index into `net`) ...
+    int slot_chan[F64_MAX_SLOTS];       // ... jet channel slot_chan[s]
+    double scale;                       // 2 w_k / N_norm: the reverse sweep's seed factor
+    double* scratch;                    // rows [nrows][npad]
+    int npad;
+    int r_pbar, r_sq;                   // PDE-parameter partials [ne], squared weighted residual [1]
+    int mode;                           // 0: loss + gradient, 1: loss only, 2: residual values into `resid`
+    double* resid;
+    // weight-gradient kernel
+    int C, first_ch[8];                 // channel of d/dx_i (-1: not carried)
+    double* slab;                       // [nblocks][nent], nent = sum of the networks' parameters + ne + 1 (last entry: the block's sum of squares)
+    int nent, ent_p;                    // ent_p: first PDE-parameter entry
+};
+
+// ---- kernel A: forward jets of every network, residual tape, reverse sweep of ONE point ----
+template <class J, int ACTK /* ACT_TANH: tanh / sigmoid by run-time kind; ACT_SIN: sin */>
+DEV void f64_point(int lp, const F64Args& a) {
+    constexpr int C = J::C;
+    constexpr bool SIN = (ACTK == ACT_SIN);
+    const int p = a.p0 + lp;
+    double* S = a.scratch + lp;                                  // element `row` of this point: S[row * npad]
+    const size_t np_ = (size_t)a.npad;
+    double U[F64_MAX_NETS][C];
+    // =========================== forward ===========================
+    for (int ni = 0; ni < a.nnets; ++ni) {
+        const F64Net& n = a.net[ni];
+        const int L = n.nl - 1;                                  // hidden layers
+        double x[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = 0; i < n.d; ++i) x[i] = a.pts[(size_t)p * a.dt + n.imap[i]];
+        for (int l = 0; l < L; ++l) {
+            const int n_in = n.sizes[l], n_out = n.sizes[l + 1];
+            const double* W = a.theta + n.woff[l];
+            const double* B = a.theta + n.boff[l];
+            for (int m = 0; m < n_out; ++m) {
+                double z[C];
+                z[0] = B[m];
+                PINN_UNROLL for (int c = 1; c < C; ++c) z[c] = 0.0;
+                if (l == 0) {
+                    for (int i = 0; i < n.d; ++i) z[0] = vfma(W[m + (size_t)i * n_out], x[i], z[0]);
+                    PINN_UNROLL for (int kf = 0; kf < J::NFIRST; ++kf) z[J::CH_FIRST + kf] = W[m + (size_t)J::first_axis(kf) * n_out];
+                } else {
+                    const size_t base = (size_t)n.r_post[l - 1];
+                    for (int k = 0; k < n_in; ++k) {
+                        const double w = W[m + (size_t)k * n_out];
+                        PINN_UNROLL for (int c = 0; c < C; ++c) z[c] = vfma(w, S[(base + (size_t)k * C + c) * np_], z[c]);
+                    }
+                }
+                const double a0 = act_value<SIN>(n.act, z[0]);
+                z[0] = act_record<SIN>(z[0], a0);                // the record: a (tanh / sigmoid) or z (sin), then the pre-activation channels
+                PINN_UNROLL for (int c = 0; c < C; ++c) S[((size_t)n.r_rec[l] + (size_t)m * C + c) * np_] = z[c];
+                double dd[ND];
+                act_derivs_n<J::NORD - 1, SIN>(n.act, z[0], dd);
+                jet_forward<J>(z, dd);
+                z[0] = a0;
+                PINN_UNROLL for (int c = 0; c < C; ++c) S[((size_t)n.r_post[l] + (size_t)m * C + c) * np_] = z[c];
+            }
+        }
+        const int n_in = n.sizes[L];
+        const double* W = a.theta + n.woff[L];
+        U[ni][0] = a.theta[n.boff[L]];
+        PINN_UNROLL for (int c = 1; c < C; ++c) U[ni][c] = 0.0;
+        if (L == 0) {                                            // a single Dense layer: u = W x + b
+            for (int i = 0; i < n.d; ++i) U[ni][0] = vfma(W[i], x[i], U[ni][0]);
+            PINN_UNROLL for (int kf = 0; kf < J::NFIRST; ++kf) U[ni][J::CH_FIRST + kf] = W[J::first_axis(kf)];
+        } else {
+            const size_t base = (size_t)n.r_post[L - 1];
+            for (int k = 0; k < n_in; ++k) {
+                const double w = W[k];
+                PINN_UNROLL for (int c = 0; c < C; ++c) U[ni][c] = vfma(w, S[(base + (size_t)k * C + c) * np_], U[ni][c]);
+            }
+        }
+    }
+    // =========================== residual tape ===========================
+    double v[F64_MAX_ROWS];
+    const int R0 = a.dt + a.np + a.nslots;
+    for (int i = 0; i < a.dt; ++i) v[i] = a.pts[(size_t)p * a.dt + i];
+    for (int j = 0; j < a.np; ++j) v[a.dt + j] = j < a.ne ? a.theta[a.p_off + j] : a.pdef[j];
+    for (int s = 0; s < a.nslots; ++s) {
+        double u = 0.0;
+        for (int ni = 0; ni < a.nnets; ++ni)
+            PINN_UNROLL for (int c = 0; c < C; ++c) if (a.slot_net[s] == ni && a.slot_chan[s] == c) u = U[ni][c];
+        v[a.dt + a.np + s] = u;
+    }
+    for (int q = 0; q < a.nops; ++q) {
+        const rp::Instr ins = a.prog[q];
+        const double va = rp::is_nullary(ins.code) ? 0.0 : v[ins.a];
+        const double vb = rp::is_binary(ins.code) ? v[ins.b] : 0.0;
+        v[R0 + q] = rp::apply<double, double>(ins.code, va, vb, a.imm[q]);
+    }
+    const double r = v[a.out_row];
+    if (a.mode == 2) { a.resid[p] = r; return; }
+    const double sw = a.pw ? (double)a.pw[p] : 1.0;
+    const double rs = r * sw;
+    S[(size_t)a.r_sq * np_] = rs * rs;
+    if (a.mode == 1) return;
+    double g[F64_MAX_ROWS];
+    for (int q = 0; q < R0 + a.nops; ++q) g[q] = 0.0;
+    g[a.out_row] = 1.0;
+    for (int q = a.nops - 1; q >= 0; --q) {
+        const rp::Instr ins = a.prog[q];
+        if (rp::is_nullary(ins.code)) continue;
+        const double vb = rp::is_binary(ins.code) ? v[ins.b] : 0.0;
+        double da, db;
+        rp::adjoint<double, double>(ins.code, v[ins.a], vb, v[R0 + q], a.imm[q], g[R0 + q], da, db);
+        g[ins.a] += da;
+        if (rp::is_binary(ins.code)) g[ins.b] += db;
+    }
+    const double rbar = rs * a.scale * sw;
+    for (int j = 0; j < a.ne; ++j) S[((size_t)a.r_pbar + j) * np_] = rbar * g[a.dt + j];
+    // =========================== reverse sweep, network by network ===========================
+    for (int ni = 0; ni < a.nnets; ++ni) {
+        const F64Net& n = a.net[ni];
+        const int L = n.nl - 1;
+        double ubar[C];
+        PINN_UNROLL for (int c = 0; c < C; ++c) ubar[c] = 0.0;
+        for (int s = 0; s < a.nslots; ++s) {
+            if (a.slot_net[s] != ni) continue;
+            const double gs = rbar * g[a.dt + a.np + s];
+            PINN_UNROLL for (int c = 0; c < C; ++c) if (a.slot_chan[s] == c) ubar[c] += gs;
+        }
+        PINN_UNROLL for (int c = 0; c < C; ++c) S[((size_t)n.r_ubar + c) * np_] = ubar[c];
+        for (int l = L - 1; l >= 0; --l) {
+            const int H = n.sizes[l + 1];
+            const int n_next = n.sizes[l + 2];                   // neurons of the layer above (1 for the output layer)
+            const double* Wn = a.theta + n.woff[l + 1];          // W_{l+1}[m + k * n_next]
+            for (int k = 0; k < H; ++k) {
+                double gq[C], s[C], dd[ND];
+                if (l == L - 1) {
+                    const double w = Wn[k];
+                    PINN_UNROLL for (int c = 0; c < C; ++c) gq[c] = w * ubar[c];
+                } else {
+                    PINN_UNROLL for (int c = 0; c < C; ++c) gq[c] = 0.0;
+                    const size_t base = (size_t)n.r_dz[l + 1];
+                    for (int m = 0; m < n_next; ++m) {
+                        const double w = Wn[m + (size_t)k * n_next];
+                        PINN_UNROLL for (int c = 0; c < C; ++c) gq[c] = vfma(w, S[(base + (size_t)m * C + c) * np_], gq[c]);
+                    }
+                }
+                PINN_UNROLL for (int c = 0; c < C; ++c) s[c] = S[((size_t)n.r_rec[l] + (size_t)k * C + c) * np_];
+                act_derivs_n<J::NORD, SIN>(n.act, s[0], dd);
+                jet_adjoint<J>(gq, s, dd);
+                PINN_UNROLL for (int c = 0; c < C; ++c) S[((size_t)n.r_dz[l] + (size_t)k * C + c) * np_] = gq[c];
+            }
+        }
+    }
+}
+
+// ---- kernel B: entry e of the slab of point block b: one theta element of one of the networks (theta order), one PDE parameter, or the
+// block's sum of squared residuals; fixed order over the block's points ----
+DEV void f64_dw_entry(int e, int b, const F64Args& a) {
+    const int lo = b * F64_BLOCK, hi = (lo + F64_BLOCK < a.npts) ? lo + F64_BLOCK : a.npts;
+    const size_t np_ = (size_t)a.npad;
+    const double* S = a.scratch;
+    const int C = a.C;
+    double s = 0.0;
+    if (e == a.nent - 1) {
+        for (int p = lo; p < hi; ++p) s += S[(size_t)a.r_sq * np_ + p];
+    } else if (e >= a.ent_p) {
+        if (a.mode == 0) {
+            const int j = e - a.ent_p;
+            for (int p = lo; p < hi; ++p) s += S[((size_t)a.r_pbar + j) * np_ + p];
+        }
+    } else if (a.mode == 0) {
+        int ni = 0;
+        while (ni + 1 < a.nnets && e >= a.net[ni + 1].ent0) ++ni;
+        const F64Net& n = a.net[ni];
+        const int L = n.nl - 1;
+        // which layer does theta element t belong to?
+        const int t = n.theta0 + (e - n.ent0);
+        int l = 0;
+        while (l + 1 < n.nl && t >= n.woff[l + 1]) ++l;
+        const int n_out = n.sizes[l + 1];
+        const bool bias = t >= n.boff[l];
+        const int m = bias ? t - n.boff[l] : (t - n.woff[l]) % n_out;
+        const int k = bias ? 0 : (t - n.woff[l]) / n_out;
+        // dZ of this layer's outputs: hidden layer l's dZ rows, or (output layer) the seeds ubar
+        const size_t dz = (l == L) ? (size_t)n.r_ubar : (size_t)n.r_dz[l] + (size_t)m * C;
+        if (bias) {
+            for (int p = lo; p < hi; ++p) s += S[dz * np_ + p];
+        } else if (l == 0) {
+            // inputs of the first layer: value channel x_k, first-derivative channel of axis k = 1, everything else 0
+            const int ck = a.first_ch[k];
+            for (int p = lo; p < hi; ++p) {
+                const int gp = a.p0 + p;
+                double t2 = S[dz * np_ + p] * a.pts[(size_t)gp * a.dt + n.imap[k]];
+                if (ck >= 0) t2 += S[(dz + ck) * np_ + p];
+                s += t2;
+            }
+        } else {
+            const size_t in = (size_t)n.r_post[l - 1] + (size_t)k * C;
+            for (int p = lo; p < hi; ++p) {
+                double t2 = 0.0;
+                for (int c = 0; c < C; ++c) t2 = vfma(S[(dz + c) * np_ + p], S[(in + c) * np_ + p], t2);
+                s += t2;
+            }
+        }
+    }
+    a.slab[(size_t)b * a.nent + e] = s;
+}
+
+// ---- kernel C: sum the per-block slabs in block order onto the gradient / the term's sum of squares ----
+struct F64ReduceArgs {
+    const double* slab; int nblocks, nent, ent_p;
+    double* grad;                        // [P] (accumulated: += )
+    int nnets, ent0[F64_MAX_NETS], theta0[F64_MAX_NETS];
+    int p_off;
+    double* sumsq;                       // += the term's sum of squares
+    int with_grad;
+};
+DEV void f64_reduce_entry(int e, const F64ReduceArgs& a) {
+    if (e != a.nent - 1 && !a.with_grad) return;
+    double s = 0.0;
+    for (int b = 0; b < a.nblocks; ++b) s += a.slab[(size_t)b * a.nent + e];
+    if (e == a.nent - 1) *a.sumsq += s;
+    else if (e >= a.ent_p) a.grad[a.p_off + (e - a.ent_p)] += s;
+    else {
+        int ni = 0;
+        while (ni + 1 < a.nnets && e >= a.ent0[ni + 1]) ++ni;
+        a.grad[a.theta0[ni] + (e - a.ent0[ni])] += s;
+    }
+}
+
+// ---- the kernel table: one entry per (inputs, jet set); activations tanh / sigmoid / sin inside ----
+struct F64Kernel {
+    int D, C, NFIRST, NPAIR;
+    unsigned D1MASK, HI;
+    unsigned long long PAIRS;
+    int first_ch[8];
+    void (*launch_point)(const F64Args&, bool sin_act, plat_stream);
+};
+std::deque<F64Kernel>& f64_registry();
+
+#ifdef PINN_EMU
+template <class J, int ACT> void run_f64_point(const F64Args& a) { for (int lp = 0; lp < a.npts; ++lp) f64_point<J, ACT>(lp, a); }
+inline void launch_f64_dw(const F64Args& a, plat_stream) {
+    const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK;
+    for (int b = 0; b < nb; ++b) for (int e = 0; e < a.nent; ++e) f64_dw_entry(e, b, a);
+}
+inline void launch_f64_reduce(const F64ReduceArgs& a, plat_stream) { for (int e = 0; e < a.nent; ++e) f64_reduce_entry(e, a); }
+#define PINN_LAUNCH_F64(J, ACT, a, st) run_f64_point<J, ACT>(a)
+#else
+template <class J, int ACT> __global__ void __launch_bounds__(64) k_f64_point(const F64Args a) {
+    const int lp = (int)(blockIdx.x * 64 + threadIdx.x);
+    if (lp < a.npts) f64_point<J, ACT>(lp, a);
+}
+template <int UNUSED> __global__ void __launch_bounds__(256) k_f64_dw(const F64Args a) {
+    const int e = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (e < a.nent) f64_dw_entry(e, (int)blockIdx.y, a);
+}
+template <int UNUSED> __global__ void __launch_bounds__(256) k_f64_reduce(const F64ReduceArgs a) {
+    const int e = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (e < a.nent) f64_reduce_entry(e, a);
+}
+inline void launch_f64_dw(const F64Args& a, plat_stream st) {
+    const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK;
+    hipLaunchKernelGGL((k_f64_dw<0>), dim3((a.nent + 255) / 256, nb), dim3(256), 0, st, a);
+}
+inline void launch_f64_reduce(const F64ReduceArgs& a, plat_stream st) {
+    hipLaunchKernelGGL((k_f64_reduce<0>), dim3((a.nent + 255) / 256), dim3(256), 0, st, a);
+}
+#define PINN_LAUNCH_F64(J, ACT, a, st) hipLaunchKernelGGL((k_f64_point<J, ACT>), dim3((a.npts + 63) / 64), dim3(64), 0, st, a)
+#endif
+
+// tanh and sigmoid are a RUN-TIME kind per network here (the activation rules branch on it: no matrix pipe to keep fed); sin needs the other
+// record convention and is its own instantiation (every network of the equation then uses sin)
+template <class J> void launch_f64_point(const F64Args& a, bool sin_act, plat_stream st) {
+    (void)st;
+    if (sin_act) PINN_LAUNCH_F64(J, ACT_SIN, a, st);
+    else PINN_LAUNCH_F64(J, ACT_TANH, a, st);
+}
+template <int D, unsigned D1MASK, unsigned long long PAIRS, int NPAIR, unsigned HI> F64Kernel make_f64_kernel() {
+    using J = JetSet<D1MASK, PAIRS, NPAIR, HI>;
+    static_assert(J::NLAP == 0, "the float64 kernels carry plain derivative channels (no forward-Laplacian channel)");
+    F64Kernel k;
+    k.D = D; k.C = J::C; k.NFIRST = J::NFIRST; k.NPAIR = J::NPAIR; k.D1MASK = D1MASK; k.HI = HI; k.PAIRS = PAIRS;
+    for (int i = 0; i < 8; ++i) {
+        k.first_ch[i] = -1;
+        for (int kf = 0; kf < J::NFIRST; ++kf) if (J::first_axis(kf) == i) k.first_ch[i] = J::CH_FIRST + kf;
+    }
+    k.launch_point = &launch_f64_point<J>;
+    return k;
+}
+struct F64Registrar { explicit F64Registrar(const F64Kernel& k) { f64_registry().push_back(k); } };
+#define PINN_INSTANTIATE_F64(NAME, D, D1MASK, PAIRS, NPAIR, HI) \
+    namespace { pk::F64Registrar NAME##_regf64(pk::make_f64_kernel<D, D1MASK, PAIRS, NPAIR, HI>()); }
+
+}  // namespace pk

@@ -94,11 +94,9 @@ DEV T powi(T x, int n) {
     return neg ? vrcp(r) : r;
 }
 
-// forward value of one op
-template <class T>
-DEV T apply(int code, T va, T vb, float imm) {
-    constexpr float PI = 3.14159265358979323846f;
-    (void)PI;
+// forward value of one op (T: lane-value type — vfloat, float, or double in the float64 kernels, whose immediates I are doubles)
+template <class T, class I>
+DEV T apply(int code, T va, T vb, I imm) {
     switch (code) {
         case OP_CONST: return T(imm);
         case OP_ADD: return va + vb;
@@ -131,9 +129,9 @@ DEV T apply(int code, T va, T vb, float imm) {
 }
 
 // reverse: given inputs, output value vo and output adjoint g, return (d/da, d/db) contributions
-template <class T>
-DEV void adjoint(int code, T va, T vb, T vo, float imm, T g, T& da, T& db) {
-    constexpr float PI = 3.14159265358979323846f;
+template <class T, class I>
+DEV void adjoint(int code, T va, T vb, T vo, I imm, T g, T& da, T& db) {
+    const T PI = T(I(3.14159265358979323846));
     da = T(0.0f);
     db = T(0.0f);
     switch (code) {
@@ -147,7 +145,7 @@ DEV void adjoint(int code, T va, T vb, T vo, float imm, T g, T& da, T& db) {
         case OP_MULC: da = g * T(imm); break;
         case OP_POWI: { int n = (int)imm; da = (n == 0) ? T(0.0f) : g * T((float)n) * powi(va, n - 1); } break;
         case OP_POW: da = g * vb * vpow(va, vb - T(1.0f)); db = g * vo * vlog(va); break;
-        case OP_POWC: da = g * T(imm) * vpow(va, T(imm - 1.0f)); break;
+        case OP_POWC: da = g * T(imm) * vpow(va, T(imm - I(1))); break;
         case OP_SIN: da = g * vcos(va); break;
         case OP_COS: da = T(0.0f) - g * vsin(va); break;
         case OP_TAN: da = g * (T(1.0f) + vo * vo); break;
@@ -159,8 +157,8 @@ DEV void adjoint(int code, T va, T vb, T vo, float imm, T g, T& da, T& db) {
         case OP_SINH: da = g * vcosh(va); break;
         case OP_COSH: da = g * vsinh(va); break;
         case OP_SECH: da = T(0.0f) - g * vo * vtanh(va); break;
-        case OP_SINPI: da = g * T(PI) * vcospi(va); break;
-        case OP_COSPI: da = T(0.0f) - g * T(PI) * vsinpi(va); break;
+        case OP_SINPI: da = g * PI * vcospi(va); break;
+        case OP_COSPI: da = T(0.0f) - g * PI * vsinpi(va); break;
         case OP_MAX: { auto m = vgt(va, vb); da = vselect(m, g, T(0.0f)); db = vselect(m, T(0.0f), g); } break;
         case OP_MIN: { auto m = vgt(vb, va); da = vselect(m, g, T(0.0f)); db = vselect(m, T(0.0f), g); } break;
         default: break;

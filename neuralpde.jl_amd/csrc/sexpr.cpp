@@ -118,7 +118,7 @@ struct Lowering {
     const SexprContext& C;
     const std::vector<std::string>& indvars;
     std::vector<Slot> slots;
-    struct RawOp { int code; Ref a, b; bool has_a, has_b; float imm; };
+    struct RawOp { int code; Ref a, b; bool has_a, has_b; float imm; double imm64; };
     std::vector<RawOp> ops;
     std::map<std::string, Ref> memo;
     std::string err;
@@ -127,7 +127,7 @@ struct Lowering {
 
     Ref emit(int code, const Ref* a, const Ref* b, double imm) {
         RawOp o;
-        o.code = code; o.has_a = a != nullptr; o.has_b = b != nullptr; o.imm = (float)imm;
+        o.code = code; o.has_a = a != nullptr; o.has_b = b != nullptr; o.imm = (float)imm; o.imm64 = imm;
         o.a = a ? *a : Ref{'x', 0}; o.b = b ? *b : Ref{'x', 0};
         ops.push_back(o);
         return Ref{'o', (int)ops.size() - 1};
@@ -421,6 +421,7 @@ int lower_sexpr_term(const SexprContext& C, const std::vector<std::string>& indv
     T.d = d;
     T.slots = L.slots;
     T.ops.clear();
+    T.imm64.clear();
     for (auto& o : L.ops) {
         rp::Instr I;
         I.code = o.code;
@@ -429,6 +430,7 @@ int lower_sexpr_term(const SexprContext& C, const std::vector<std::string>& indv
         I.imm = o.imm;
         rp::finalize(I);
         T.ops.push_back(I);
+        T.imm64.push_back(o.imm64);
     }
     T.out_row = row(out);
     T.ndata = 0;

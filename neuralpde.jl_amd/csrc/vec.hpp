@@ -520,3 +520,33 @@ DEV vbf8 ub_load_bf8(ubuf b, int soff, vint voff) {
 DEV vfloat4 mfma16x32bf(vbf8 a, vbf8 b, vfloat4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 }  // namespace wv
 #endif
+
+// ------------------------------------------------------------------------------------------
+// plain DOUBLE overloads of the vocabulary (both builds): the per-point float64 kernels (pinn_kernels4.hpp) instantiate the activation /
+// jet rules (pinn_kernels.hpp) and the residual tape (rprog.hpp) with V = double — one lane, one point, IEEE double, library functions
+// ------------------------------------------------------------------------------------------
+namespace wv {
+HD double vfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+HD double vtanh(double x) { return tanh(x); }
+HD double vtanh_fast(double x) { return tanh(x); }
+HD double vsigmoid_fast(double x) { return 1.0 / (1.0 + exp(-x)); }
+HD void vsincos(double x, double& s, double& c) { s = sin(x); c = cos(x); }
+HD double vsin(double x) { return sin(x); }
+HD double vcos(double x) { return cos(x); }
+HD double vtan(double x) { return tan(x); }
+HD double vexp(double x) { return exp(x); }
+HD double vlog(double x) { return log(x); }
+HD double vsqrt(double x) { return sqrt(x); }
+HD double vabs(double x) { return fabs(x); }
+HD double vsinh(double x) { return sinh(x); }
+HD double vcosh(double x) { return cosh(x); }
+HD double vrcp(double x) { return 1.0 / x; }
+HD double vsign(double x) { return (x > 0.0) ? 1.0 : ((x < 0.0) ? -1.0 : 0.0); }
+HD double vsinpi(double x) { return sin(3.14159265358979323846 * x); }
+HD double vcospi(double x) { return cos(3.14159265358979323846 * x); }
+HD double vpow(double a, double b) { return pow(a, b); }
+HD double vmax(double a, double b) { return a > b ? a : b; }
+HD double vmin(double a, double b) { return a < b ? a : b; }
+HD bool vgt(double a, double b) { return a > b; }
+HD double vselect(bool m, double a, double b) { return m ? a : b; }
+}  // namespace wv

@@ -1,0 +1,144 @@
+"""The FLOAT64 evaluation mode (pinn_set_option(h, "precision", "f64"); csrc/pinn_kernels4.hpp, csrc/f64.cpp): the reference's default
+eltype (src/discretize.jl:432-449) on the device.  Same mathematics as the fp32 kernels — exact Taylor jets, residual tape, hand-derived
+reverse sweep — in IEEE double, one lane per point.  Against the float64 oracle's exact-derivative mode the results agree to ROUNDING
+(1e-12 and better): the engine's algorithm and the oracle's autograd are the same function.  That is also the strongest statement this
+repository can make about the fp32 kernels' mathematics: they instantiate the same jet / adjoint rules with V = float.
+(CPU: the g++ emulation; tests/test_gpu_mirror.py re-runs this module on the hardware.)"""
+import numpy as np
+import pytest
+import sympy as sp
+
+import helpers
+import pinn_oracle as po
+import test_emu_parity as tp
+
+EXACT = 1e-11
+
+
+def _engine_f64(npde, wl, param_estim=False):
+    rep = npde.symbolic_discretize(wl.pde_system, wl.discretization())
+    eng = rep.engine
+    sets = rep.pde_train_sets + rep.bcs_train_sets
+    eng.set_option("precision", "f64")
+    assert eng.get_option("precision") == "f64" and "precision=f64" in eng.describe()
+    for k, s in enumerate(sets):
+        eng.set_points_f64(k, s)
+    prob = helpers.oracle_problem(npde, wl.pde_system, wl.chains, param_estim=wl.param_estim)
+    return rep, eng, sets, prob
+
+
+def _workloads():
+    from neuralpde_jl_amd import workloads
+    return {"cfg1": lambda: workloads.cfg1_poisson1d(64),
+            "cfg2": lambda: workloads.cfg2_poisson2d(points=96, bcs_points=32),
+            "cfg3": lambda: workloads.cfg3_burgers(points=64, bcs_points=32),
+            "cfg4": lambda: workloads.cfg4_cavity(points=48, bcs_points=16, width=16, hidden=2),
+            "cfg5": lambda: workloads.cfg5_heat_inverse(points=64, bcs_points=32, width=16, hidden=2)}
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
+def test_f64_mode_equals_the_float64_oracle(npde, use_emu, name):
+    """all five BASELINE problem types (1-D / 2-D Poisson, Burgers, the three-network cavity system, the 4-D inverse heat problem with an
+    estimated parameter): losses and gradient of the float64 mode against the oracle's exact-derivative mode — equal to rounding; the same
+    handle's fp32 evaluation stays available and is 1e-7-accurate"""
+    wl = _workloads()[name]()
+    rep, eng, sets, prob = _engine_f64(npde, wl)
+    th = np.asarray(rep.flat_init_params, dtype=np.float64)
+    w = np.linspace(1.0, 2.0, eng.K)
+    ref = po.loss_and_grad(prob, th, sets, weights=w, mode="exact")
+    l64, g64 = eng.loss_grad_f64(th, w)
+    le, g2, gi = helpers.rel_errors(l64, g64, ref)
+    assert le.max() < EXACT and g2 < EXACT and gi < EXACT, (le, g2, gi)
+    l2, g2_ = eng.loss_grad_f64(th, w)
+    assert np.array_equal(l2, l64) and np.array_equal(g2_, g64)              # deterministic
+    lf, gf = eng.loss_grad(th, w)                                            # float entry point in f64 mode: converted at the boundary
+    np.testing.assert_allclose(gf, g64.astype(np.float32), rtol=0, atol=1e-7 * np.abs(g64).max())
+    eng.set_option("precision", "f32")
+    assert eng.get_option("precision") == "f32"
+    l32, g32 = eng.loss_grad_f64(th, w)
+    le, g2, gi = helpers.rel_errors(l32, g32, ref)
+    assert 1e-9 < g2 < 1e-5 and le.max() < 1e-5                              # (back on the fp32 kernels)
+
+
+def test_f64_mode_at_trained_parameters_and_lbfgs(npde, use_emu):
+    """the regime fp32 cannot follow: parameters after 6,000 float64 Adam steps (committed fixture) — the float64 mode
+    still equals the oracle to rounding where the fp32 kernels are off by 1e-4 ... 1e-2; and pinn_lbfgs iterates on the double objective,
+    far below the fp32 noise floor"""
+    import os
+    from neuralpde_jl_amd import workloads
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg2_variants.npz"))
+    wl = workloads.cfg2_poisson2d(points=256, bcs_points=64)
+    rep, eng, sets, prob = _engine_f64(npde, wl)
+    w = g["weights"]
+    th = g["theta_adam6000"]
+    ref = po.loss_and_grad(prob, th, sets, weights=w, mode="exact")
+    l64, g64 = eng.loss_grad_f64(th, w)
+    le, g2, gi = helpers.rel_errors(l64, g64, ref)
+    assert le.max() < 1e-9 and g2 < 1e-9 and gi < 1e-9, (le, g2, gi)
+    eng.set_option("precision", "f32")
+    l32, g32 = eng.loss_grad_f64(th, w)
+    assert helpers.rel_errors(l32, g32, ref)[1] > 1e-5                       # the fp32 evaluation of the same point: not 1e-5-accurate
+    eng.set_option("precision", "f64")
+    for k, s in enumerate(sets):
+        eng.set_points_f64(k, s)
+    # a small quasi-Newton run on a 1-D problem: the objective falls through the fp32 floor
+    wl1 = workloads.cfg1_poisson1d(32)
+    rep1, eng1, sets1, prob1 = _engine_f64(npde, wl1)
+    th0 = np.asarray(rep1.flat_init_params, dtype=np.float64)
+    th1, hist = eng1.lbfgs(th0, 3000, history=20, gtol=1e-14)
+    assert hist[-1] < 1e-8 and hist[-1] < 1e-9 * hist[0], (hist[0], hist[-1])     # measured 4.2e-10 (from 44.6)
+    rep32 = npde.symbolic_discretize(wl1.pde_system, wl1.discretization())
+    _, hist32 = rep32.engine.lbfgs(th0, 600, history=20, gtol=1e-14)
+    assert hist32[-1] > 50.0 * hist[-1], (hist32[-1], hist[-1])                   # the fp32 objective stalls at its noise floor (2.6e-6 measured)
+    ref1 = po.loss_and_grad(prob1, th1, sets1, mode="exact")
+    l1, g1 = eng1.loss_grad_f64(th1)
+    np.testing.assert_allclose(l1, ref1.term_losses, rtol=1e-5)      # (boundary residuals of 1e-8: eps / 1e-8 is the rounding floor)
+
+
+def test_f64_mode_derivative_orders_activations_weights(npde, use_emu):
+    """third derivative (the reference's 3rd-order ODE, sigma network), a KS-type fourth derivative in 1-D, sin activation, quadrature
+    weights; and what the mode does not cover fails at pinn_set_option with a message while the fp32 plan keeps working"""
+    from neuralpde_jl_amd import workloads
+    def run(sysm, chain, strat, seed, weights=None):
+        theta = tp.theta_for(chain, seed)
+        disc = npde.PhysicsInformedNN(chain, strat, init_params=theta)
+        rep = npde.symbolic_discretize(sysm, disc)
+        eng = rep.engine
+        sets = rep.pde_train_sets + rep.bcs_train_sets
+        eng.set_option("precision", "f64")
+        for k, s in enumerate(sets):
+            eng.set_points_f64(k, s)
+        prob = helpers.oracle_problem(npde, sysm, [chain])
+        th = np.asarray(rep.flat_init_params, dtype=np.float64)
+        ref = po.loss_and_grad(prob, th, sets, weights=weights, mode="exact")
+        l64, g64 = eng.loss_grad_f64(th, weights)
+        le, g2, gi = helpers.rel_errors(l64, g64, ref)
+        assert le.max() < EXACT and g2 < EXACT and gi < EXACT, (le, g2, gi)
+        return rep, eng, sets
+    run(tp._third_order_ode(npde), npde.Chain(npde.Dense(1, 8, "sigmoid"), npde.Dense(8, 1)), npde.GridTraining(0.05), 31)
+    (x,) = npde.parameters("x")
+    (u,) = npde.variables("u")
+    D4 = npde.Differential(x) ** 4
+    sys4 = npde.PDESystem([npde.Eq(D4(u(x)) + u(x), sp.sin(x))], [npde.Eq(u(0.0), 0.0), npde.Eq(u(1.0), 0.5)],
+                          [npde.In(x, npde.Interval(0.0, 1.0))], [x], [u(x)])
+    run(sys4, npde.Chain(npde.Dense(1, 12, "tanh"), npde.Dense(12, 12, "tanh"), npde.Dense(12, 1)), npde.GridTraining(0.05), 5)
+    sysm, chain = tp.poisson2d(npde, act="sin", width=16, hidden=2)
+    strat = npde.QuasiRandomTraining(60, bcs_points=20, sampling_alg=npde.SobolSample(seed=3), resampling=False, minibatch=1)
+    rep, eng, sets = run(sysm, chain, strat, 11, weights=[1.0, 2.0, 0.5, 1.5, 3.0])
+    # quadrature weights on the interior term
+    wq = np.random.default_rng(0).random(sets[0].shape[1]).astype(np.float32)
+    wq /= wq.sum()
+    eng.set_point_weights(0, wq)
+    th = np.asarray(rep.flat_init_params, dtype=np.float64)
+    l64, _ = eng.loss_grad_f64(th)
+    prob = helpers.oracle_problem(npde, sysm, [chain])
+    r = po.residual_values(prob, th, 0, sets[0], mode="exact").reshape(-1)
+    np.testing.assert_allclose(l64[0], float(np.sum(wq.astype(np.float64) * r * r)), rtol=1e-6)      # (the weights are stored as float sqrt(N w))
+    # not covered: device samplers; the handle's fp32 evaluation is untouched by the failed switch
+    wl = workloads.cfg2_poisson2d(points=64, bcs_points=16)
+    rep2 = npde.symbolic_discretize(wl.pde_system, wl.discretization())
+    rep2.engine.set_sampler(0, np.zeros(2, np.float32), np.ones(2, np.float32), 64, seed=3, kind=1)
+    with pytest.raises(Exception, match="device samplers"):
+        rep2.engine.set_option("precision", "f64")
+    assert rep2.engine.get_option("precision") == "f32"
+    rep2.engine.loss_grad(rep2.flat_init_params)

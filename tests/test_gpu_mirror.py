@@ -1,5 +1,5 @@
 """Hardware mirror of the CPU parity suite: every test of tests/test_emu_parity.py, tests/test_adaptive_losses.py,
-tests/test_reference_examples.py, tests/test_jit.py (kernels specialised with hipcc on the box), tests/test_sexpr_frontend.py and tests/test_dgm.py is re-run with the PRODUCT library (libpinn_hip.so on a gfx950 device) instead of the g++ lock-step
+tests/test_reference_examples.py, tests/test_jit.py (kernels specialised with hipcc on the box), tests/test_sexpr_frontend.py, tests/test_dgm.py and tests/test_f64_mode.py (the float64 evaluation mode) is re-run with the PRODUCT library (libpinn_hip.so on a gfx950 device) instead of the g++ lock-step
 emulation — same statements, same float64 oracle, same 1e-5 tolerance.  This is where the per-term gradients (pinn_term_grads), the
 BPINN physics log-likelihood, the resident-theta Adam loop (against a host Adam), the device samplers and the adaptive-weight rules
 are checked against the oracle ON THE GPU ("Next round" item 1b)."""
@@ -10,6 +10,7 @@ import pytest
 import test_adaptive_losses as ta
 import test_dgm as td
 import test_emu_parity as tp
+import test_f64_mode as tf
 import test_jit as tj
 import test_reference_examples as tr
 import test_sexpr_frontend as ts
@@ -19,7 +20,7 @@ pytestmark = pytest.mark.gpu
 
 def _cases():
     out = []
-    for mod in (tp, ta, tr, tj, ts, td):
+    for mod in (tp, ta, tr, tj, ts, td, tf):
         for name, fn in sorted(vars(mod).items()):
             if not (name.startswith("test_") and inspect.isfunction(fn) and fn.__module__ == mod.__name__):
                 continue
