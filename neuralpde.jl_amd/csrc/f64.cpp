@@ -270,6 +270,7 @@ int f64_eval(pinn_engine& E, const double* theta, const double* term_w, double* 
             a.npts = (int)std::min<int64_t>(chunk, F.n - p0);
             F.k->launch_point(a, sin_act, E.stream);
             pk::launch_f64_dw(a, E.stream);
+            pk::launch_f64_dwt(a, E.stream);
             pk::F64ReduceArgs r;
             std::memset(&r, 0, sizeof r);
             r.slab = S.d_slab; r.nblocks = (a.npts + pk::F64_BLOCK - 1) / pk::F64_BLOCK; r.nent = a.nent;

@@ -91,6 +91,8 @@ constexpr int F2_SPRE_MAX = 24;         // records parked in the scratch slab ar
 // points per tile.  Kernels of one network with different channel sets (the interior and the boundary terms of one PINN) therefore
 // share the accumulators, the gradient-slab layout and the packed weight image, which is what lets ONE launch walk both tile lists
 // (wave_main2m below).
+template <class A, class B> struct same_type { static constexpr bool value = false; };
+template <class A> struct same_type<A, A> { static constexpr bool value = true; };
 template <int HP_, int NHH_, int D_, int NW_, bool WBAR_REG_>
 struct Shape2 {
     static constexpr int HP = HP_, MT = HP_ / 16, NHH = NHH_, LH = NHH_ + 1, D = D_, NW = NW_, MTW = MT / NW_;
@@ -1218,7 +1220,7 @@ DEV void wave_main2(const GroupArgs& ga, int blk, int nblocks, int w, float* lds
 // (round-robin over the concatenated list, so the members' tile counts need not divide the grid). ----
 template <class S0, class S1, int ACTK, int MODE = MODE_FUSED>
 DEV void wave_main2m(const GroupArgs& ga, int blk, int nblocks, int w, float* lds) {
-    static_assert(std::is_same<typename S0::Shape, typename S1::Shape>::value, "merged launches need members of one network shape and neuron split");
+    static_assert(same_type<typename S0::Shape, typename S1::Shape>::value, "merged launches need members of one network shape and neuron split");
     static_assert(S0::SLAB == S1::SLAB && S0::PACKED == S1::PACKED, "merged launches share the slab and the packed weight image");
     static_assert(S0::DW_NATURAL == S1::DW_NATURAL && S0::BFX_TR == S1::BFX_TR, "merged launches: one order of the dW tiles in the slab, one exchange-image layout");
     static_assert(MODE == MODE_FUSED || MODE == MODE_LOSS, "merged launches: the fused evaluation and the loss-only evaluation");

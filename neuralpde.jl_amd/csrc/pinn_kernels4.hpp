@@ -9,10 +9,12 @@
 //   * one LANE per point, every per-point vector (records, post-activation jets, dZ) in point-major scratch rows [row][point] in
 //     HBM / L2 (coalesced; a lane only touches its own column: no LDS, no barriers), weights as wave-uniform loads straight from theta
 //     (double, ComponentArrays order — no packed image), layer widths and depth are RUN-TIME values: one kernel per (jet set, activation);
-//   * the weight gradients by a second kernel (one thread per theta entry and block of points) into per-block slabs, summed in a fixed
-//     order — deterministic, no atomics;
-//   * cost: VALU fp64 FMAs with L2-resident operands — 10-100x slower than the fp32 kernels; meant for the reference's own regime (nets of
-//     12-64 neurons, 10^2-10^4 points) and for finishing stages.
+//   * the weight gradients by two more kernels into per-block slabs, summed in a fixed order — deterministic, no atomics: the
+//     hidden-to-hidden matrices in 8 x 4 register tiles with the block's points across the lanes (k_f64_dwt), the remaining entries (first /
+//     last layer, biases, PDE parameters, the sum of squares) one thread per entry (k_f64_dw);
+//   * cost: VALU fp64 FMAs with L2-resident operands, register-blocked over 4-8 neurons (the scratch-row loads, not the FMAs, bound these
+//     kernels) — 20x (the reference's own regime: nets of 12-64 neurons, 10^2-10^4 points) to a few hundred times (10^5+ points, 128-wide
+//     nets) slower than the fp32 kernels (tools/time_f64.py): for finishing stages and digit-by-digit comparisons.
 #pragma once
 #include "pinn_kernels.hpp"
 
@@ -21,7 +23,7 @@ namespace pk {
 constexpr int F64_MAX_LAYERS = 16;      // Dense layers including the output layer
 constexpr int F64_MAX_ROWS = 96;        // tape rows [coordinates | params | slots | ops]
 constexpr int F64_MAX_SLOTS = 24;
-constexpr int F64_BLOCK = 256;          // points per block of the weight-gradient kernel (= rows of the per-block slabs)
+constexpr int F64_BLOCK = 512;          // points per block of the weight-gradient kernels (= rows of the per-block slabs)
 
 constexpr int F64_MAX_NETS = 6;         // dependent variables one equation may reference (systems: test/NNPDE1/nnpde__pde_iii_3rd_order_ode.jl:70-76)
 
@@ -69,6 +71,7 @@ template <class J, int ACTK /* ACT_TANH: tanh / sigmoid by run-time kind; ACT_SI
 DEV void f64_point(int lp, const F64Args& a) {
     constexpr int C = J::C;
     constexpr bool SIN = (ACTK == ACT_SIN);
+    constexpr int MB = (C <= 3) ? 8 : 4;                         // neurons per register block (MB * C accumulators in double)
     const int p = a.p0 + lp;
     double* S = a.scratch + lp;                                  // element `row` of this point: S[row * npad]
     const size_t np_ = (size_t)a.npad;
@@ -83,28 +86,45 @@ DEV void f64_point(int lp, const F64Args& a) {
             const int n_in = n.sizes[l], n_out = n.sizes[l + 1];
             const double* W = a.theta + n.woff[l];
             const double* B = a.theta + n.boff[l];
-            for (int m = 0; m < n_out; ++m) {
-                double z[C];
-                z[0] = B[m];
-                PINN_UNROLL for (int c = 1; c < C; ++c) z[c] = 0.0;
+            // MB output neurons at a time: every input jet loaded from the scratch rows feeds MB accumulators (the rows live in L2 / HBM: the
+            // loads, not the FMAs, bound this kernel).  Per output the sum runs over k in the same order whatever MB: blocking changes no bit.
+            for (int m0 = 0; m0 < n_out; m0 += MB) {
+                const int nb = (n_out - m0 < MB) ? n_out - m0 : MB;
+                double z[MB][C];
+                int mj[MB];
+                PINN_UNROLL for (int j = 0; j < MB; ++j) {
+                    mj[j] = (j < nb) ? m0 + j : n_out - 1;           // (tail lanes of the block repeat the last neuron; never stored)
+                    z[j][0] = B[mj[j]];
+                    PINN_UNROLL for (int c = 1; c < C; ++c) z[j][c] = 0.0;
+                }
                 if (l == 0) {
-                    for (int i = 0; i < n.d; ++i) z[0] = vfma(W[m + (size_t)i * n_out], x[i], z[0]);
-                    PINN_UNROLL for (int kf = 0; kf < J::NFIRST; ++kf) z[J::CH_FIRST + kf] = W[m + (size_t)J::first_axis(kf) * n_out];
+                    PINN_UNROLL for (int j = 0; j < MB; ++j) {
+                        for (int i = 0; i < n.d; ++i) z[j][0] = vfma(W[mj[j] + (size_t)i * n_out], x[i], z[j][0]);
+                        PINN_UNROLL for (int kf = 0; kf < J::NFIRST; ++kf) z[j][J::CH_FIRST + kf] = W[mj[j] + (size_t)J::first_axis(kf) * n_out];
+                    }
                 } else {
                     const size_t base = (size_t)n.r_post[l - 1];
                     for (int k = 0; k < n_in; ++k) {
-                        const double w = W[m + (size_t)k * n_out];
-                        PINN_UNROLL for (int c = 0; c < C; ++c) z[c] = vfma(w, S[(base + (size_t)k * C + c) * np_], z[c]);
+                        double ak[C];
+                        PINN_UNROLL for (int c = 0; c < C; ++c) ak[c] = S[(base + (size_t)k * C + c) * np_];
+                        PINN_UNROLL for (int j = 0; j < MB; ++j) {
+                            const double w = W[mj[j] + (size_t)k * n_out];
+                            PINN_UNROLL for (int c = 0; c < C; ++c) z[j][c] = vfma(w, ak[c], z[j][c]);
+                        }
                     }
                 }
-                const double a0 = act_value<SIN>(n.act, z[0]);
-                z[0] = act_record<SIN>(z[0], a0);                // the record: a (tanh / sigmoid) or z (sin), then the pre-activation channels
-                PINN_UNROLL for (int c = 0; c < C; ++c) S[((size_t)n.r_rec[l] + (size_t)m * C + c) * np_] = z[c];
-                double dd[ND];
-                act_derivs_n<J::NORD - 1, SIN>(n.act, z[0], dd);
-                jet_forward<J>(z, dd);
-                z[0] = a0;
-                PINN_UNROLL for (int c = 0; c < C; ++c) S[((size_t)n.r_post[l] + (size_t)m * C + c) * np_] = z[c];
+                PINN_UNROLL for (int j = 0; j < MB; ++j) {
+                    if (j >= nb) break;
+                    const int m = m0 + j;
+                    const double a0 = act_value<SIN>(n.act, z[j][0]);
+                    z[j][0] = act_record<SIN>(z[j][0], a0);          // the record: a (tanh / sigmoid) or z (sin), then the pre-activation channels
+                    PINN_UNROLL for (int c = 0; c < C; ++c) S[((size_t)n.r_rec[l] + (size_t)m * C + c) * np_] = z[j][c];
+                    double dd[ND];
+                    act_derivs_n<J::NORD - 1, SIN>(n.act, z[j][0], dd);
+                    jet_forward<J>(z[j], dd);
+                    z[j][0] = a0;
+                    PINN_UNROLL for (int c = 0; c < C; ++c) S[((size_t)n.r_post[l] + (size_t)m * C + c) * np_] = z[j][c];
+                }
             }
         }
         const int n_in = n.sizes[L];
@@ -175,23 +195,38 @@ DEV void f64_point(int lp, const F64Args& a) {
             const int H = n.sizes[l + 1];
             const int n_next = n.sizes[l + 2];                   // neurons of the layer above (1 for the output layer)
             const double* Wn = a.theta + n.woff[l + 1];          // W_{l+1}[m + k * n_next]
-            for (int k = 0; k < H; ++k) {
-                double gq[C], s[C], dd[ND];
+            for (int k0 = 0; k0 < H; k0 += MB) {
+                const int nb = (H - k0 < MB) ? H - k0 : MB;
+                double gq[MB][C];
+                int kj[MB];
+                PINN_UNROLL for (int j = 0; j < MB; ++j) kj[j] = (j < nb) ? k0 + j : H - 1;
                 if (l == L - 1) {
-                    const double w = Wn[k];
-                    PINN_UNROLL for (int c = 0; c < C; ++c) gq[c] = w * ubar[c];
+                    PINN_UNROLL for (int j = 0; j < MB; ++j) {
+                        const double w = Wn[kj[j]];
+                        PINN_UNROLL for (int c = 0; c < C; ++c) gq[j][c] = w * ubar[c];
+                    }
                 } else {
-                    PINN_UNROLL for (int c = 0; c < C; ++c) gq[c] = 0.0;
+                    PINN_UNROLL for (int j = 0; j < MB; ++j)
+                        PINN_UNROLL for (int c = 0; c < C; ++c) gq[j][c] = 0.0;
                     const size_t base = (size_t)n.r_dz[l + 1];
                     for (int m = 0; m < n_next; ++m) {
-                        const double w = Wn[m + (size_t)k * n_next];
-                        PINN_UNROLL for (int c = 0; c < C; ++c) gq[c] = vfma(w, S[(base + (size_t)m * C + c) * np_], gq[c]);
+                        double dzm[C];
+                        PINN_UNROLL for (int c = 0; c < C; ++c) dzm[c] = S[(base + (size_t)m * C + c) * np_];
+                        PINN_UNROLL for (int j = 0; j < MB; ++j) {
+                            const double w = Wn[m + (size_t)kj[j] * n_next];
+                            PINN_UNROLL for (int c = 0; c < C; ++c) gq[j][c] = vfma(w, dzm[c], gq[j][c]);
+                        }
                     }
                 }
-                PINN_UNROLL for (int c = 0; c < C; ++c) s[c] = S[((size_t)n.r_rec[l] + (size_t)k * C + c) * np_];
-                act_derivs_n<J::NORD, SIN>(n.act, s[0], dd);
-                jet_adjoint<J>(gq, s, dd);
-                PINN_UNROLL for (int c = 0; c < C; ++c) S[((size_t)n.r_dz[l] + (size_t)k * C + c) * np_] = gq[c];
+                PINN_UNROLL for (int j = 0; j < MB; ++j) {
+                    if (j >= nb) break;
+                    const int k = k0 + j;
+                    double s[C], dd[ND];
+                    PINN_UNROLL for (int c = 0; c < C; ++c) s[c] = S[((size_t)n.r_rec[l] + (size_t)k * C + c) * np_];
+                    act_derivs_n<J::NORD, SIN>(n.act, s[0], dd);
+                    jet_adjoint<J>(gq[j], s, dd);
+                    PINN_UNROLL for (int c = 0; c < C; ++c) S[((size_t)n.r_dz[l] + (size_t)k * C + c) * np_] = gq[j][c];
+                }
             }
         }
     }
@@ -223,6 +258,7 @@ DEV void f64_dw_entry(int e, int b, const F64Args& a) {
         while (l + 1 < n.nl && t >= n.woff[l + 1]) ++l;
         const int n_out = n.sizes[l + 1];
         const bool bias = t >= n.boff[l];
+        if (!bias && l >= 1 && l < L) return;                  // hidden-to-hidden weight matrices: the tiled kernel below writes these entries
         const int m = bias ? t - n.boff[l] : (t - n.woff[l]) % n_out;
         const int k = bias ? 0 : (t - n.woff[l]) / n_out;
         // dZ of this layer's outputs: hidden layer l's dZ rows, or (output layer) the seeds ubar
@@ -248,6 +284,60 @@ DEV void f64_dw_entry(int e, int b, const F64Args& a) {
         }
     }
     a.slab[(size_t)b * a.nent + e] = s;
+}
+
+// ---- kernel B2: the hidden-to-hidden weight matrices (all but a sliver of theta) in TILES of F64_TM outputs x F64_TK inputs: the points
+// of a block across the lanes (coalesced row reads), every loaded dZ / input jet feeds a whole row / column of the tile's accumulators
+// (12 loads per 32 FMAs; one thread per entry needs 2 per FMA and reads 64 different rows per load), lane partials summed in lane order:
+// fixed order, no atomics ----
+constexpr int F64_TM = 8, F64_TK = 4;
+HD int f64_layer_tiles(const F64Net& n, int l) { return ((n.sizes[l + 1] + F64_TM - 1) / F64_TM) * ((n.sizes[l] + F64_TK - 1) / F64_TK); }
+HD int f64_num_tiles(const F64Args& a) {
+    int t = 0;
+    for (int ni = 0; ni < a.nnets; ++ni)
+        for (int l = 1; l < a.net[ni].nl - 1; ++l) t += f64_layer_tiles(a.net[ni], l);
+    return t;
+}
+struct F64Tile { int ni, l, m0, k0; };
+HD F64Tile f64_tile_locate(const F64Args& a, int tile) {
+    F64Tile T = {0, 1, 0, 0};
+    for (int ni = 0; ni < a.nnets; ++ni)
+        for (int l = 1; l < a.net[ni].nl - 1; ++l) {
+            const int nt = f64_layer_tiles(a.net[ni], l);
+            if (tile < nt) {
+                const int kt = (a.net[ni].sizes[l] + F64_TK - 1) / F64_TK;
+                T.ni = ni; T.l = l; T.m0 = (tile / kt) * F64_TM; T.k0 = (tile % kt) * F64_TK;
+                return T;
+            }
+            tile -= nt;
+        }
+    return T;
+}
+// one lane's partial sums over its points p = lo + lane, lo + lane + 64, ... of block b
+DEV void f64_dwt_lane(const F64Tile& T, int b, int lane, const F64Args& a, double (&acc)[F64_TM * F64_TK]) {
+    const F64Net& n = a.net[T.ni];
+    const int lo = b * F64_BLOCK, hi = (lo + F64_BLOCK < a.npts) ? lo + F64_BLOCK : a.npts;
+    const size_t np_ = (size_t)a.npad;
+    const double* S = a.scratch;
+    const int C = a.C, n_out = n.sizes[T.l + 1], n_in = n.sizes[T.l];
+    size_t rz[F64_TM], ri[F64_TK];
+    PINN_UNROLL for (int j = 0; j < F64_TM; ++j) rz[j] = (size_t)n.r_dz[T.l] + (size_t)((T.m0 + j < n_out) ? T.m0 + j : n_out - 1) * C;
+    PINN_UNROLL for (int i = 0; i < F64_TK; ++i) ri[i] = (size_t)n.r_post[T.l - 1] + (size_t)((T.k0 + i < n_in) ? T.k0 + i : n_in - 1) * C;
+    PINN_UNROLL for (int e = 0; e < F64_TM * F64_TK; ++e) acc[e] = 0.0;
+    for (int p = lo + lane; p < hi; p += 64)
+        for (int c = 0; c < C; ++c) {
+            double dz[F64_TM], in[F64_TK];
+            PINN_UNROLL for (int j = 0; j < F64_TM; ++j) dz[j] = S[(rz[j] + c) * np_ + p];
+            PINN_UNROLL for (int i = 0; i < F64_TK; ++i) in[i] = S[(ri[i] + c) * np_ + p];
+            PINN_UNROLL for (int j = 0; j < F64_TM; ++j)
+                PINN_UNROLL for (int i = 0; i < F64_TK; ++i) acc[j * F64_TK + i] = vfma(dz[j], in[i], acc[j * F64_TK + i]);
+        }
+}
+DEV void f64_dwt_store(const F64Tile& T, int b, int e, double s, const F64Args& a) {
+    const F64Net& n = a.net[T.ni];
+    const int m = T.m0 + e / F64_TK, k = T.k0 + e % F64_TK, n_out = n.sizes[T.l + 1];
+    if (m >= n_out || k >= n.sizes[T.l]) return;
+    a.slab[(size_t)b * a.nent + n.ent0 + (n.woff[T.l] - n.theta0) + m + (size_t)k * n_out] = s;
 }
 
 // ---- kernel C: sum the per-block slabs in block order onto the gradient / the term's sum of squares ----
@@ -288,6 +378,25 @@ inline void launch_f64_dw(const F64Args& a, plat_stream) {
     const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK;
     for (int b = 0; b < nb; ++b) for (int e = 0; e < a.nent; ++e) f64_dw_entry(e, b, a);
 }
+inline void launch_f64_dwt(const F64Args& a, plat_stream) {
+    if (a.mode != 0) return;
+    const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK, nt = f64_num_tiles(a);
+    for (int b = 0; b < nb; ++b)
+        for (int t = 0; t < nt; ++t) {
+            const F64Tile T = f64_tile_locate(a, t);
+            double part[F64_TM * F64_TK][64];
+            for (int lane = 0; lane < 64; ++lane) {
+                double acc[F64_TM * F64_TK];
+                f64_dwt_lane(T, b, lane, a, acc);
+                for (int e = 0; e < F64_TM * F64_TK; ++e) part[e][lane] = acc[e];
+            }
+            for (int e = 0; e < F64_TM * F64_TK; ++e) {
+                double s = 0.0;
+                for (int lane = 0; lane < 64; ++lane) s += part[e][lane];
+                f64_dwt_store(T, b, e, s, a);
+            }
+        }
+}
 inline void launch_f64_reduce(const F64ReduceArgs& a, plat_stream) { for (int e = 0; e < a.nent; ++e) f64_reduce_entry(e, a); }
 #define PINN_LAUNCH_F64(J, ACT, a, st) run_f64_point<J, ACT>(a)
 #else
@@ -299,6 +408,20 @@ template <int UNUSED> __global__ void __launch_bounds__(256) k_f64_dw(const F64A
     const int e = (int)(blockIdx.x * 256 + threadIdx.x);
     if (e < a.nent) f64_dw_entry(e, (int)blockIdx.y, a);
 }
+template <int UNUSED> __global__ void __launch_bounds__(64) k_f64_dwt(const F64Args a) {
+    __shared__ double part[F64_TM * F64_TK][65];                // (65: the column sums below walk a row each, conflict-free)
+    const int lane = (int)threadIdx.x;
+    const F64Tile T = f64_tile_locate(a, (int)blockIdx.x);
+    double acc[F64_TM * F64_TK];
+    f64_dwt_lane(T, (int)blockIdx.y, lane, a, acc);
+    PINN_UNROLL for (int e = 0; e < F64_TM * F64_TK; ++e) part[e][lane] = acc[e];
+    __syncthreads();
+    if (lane < F64_TM * F64_TK) {
+        double s = 0.0;
+        for (int t = 0; t < 64; ++t) s += part[lane][t];
+        f64_dwt_store(T, (int)blockIdx.y, lane, s, a);
+    }
+}
 template <int UNUSED> __global__ void __launch_bounds__(256) k_f64_reduce(const F64ReduceArgs a) {
     const int e = (int)(blockIdx.x * 256 + threadIdx.x);
     if (e < a.nent) f64_reduce_entry(e, a);
@@ -306,6 +429,11 @@ template <int UNUSED> __global__ void __launch_bounds__(256) k_f64_reduce(const 
 inline void launch_f64_dw(const F64Args& a, plat_stream st) {
     const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK;
     hipLaunchKernelGGL((k_f64_dw<0>), dim3((a.nent + 255) / 256, nb), dim3(256), 0, st, a);
+}
+inline void launch_f64_dwt(const F64Args& a, plat_stream st) {
+    const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK, nt = f64_num_tiles(a);
+    if (a.mode != 0 || nt == 0) return;
+    hipLaunchKernelGGL((k_f64_dwt<0>), dim3(nt, nb), dim3(64), 0, st, a);
 }
 inline void launch_f64_reduce(const F64ReduceArgs& a, plat_stream st) {
     hipLaunchKernelGGL((k_f64_reduce<0>), dim3((a.nent + 255) / 256), dim3(256), 0, st, a);

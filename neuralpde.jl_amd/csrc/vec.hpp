@@ -9,10 +9,12 @@
 // *actual kernel source* on a GPU-less box against the oracle; it is never linked into
 // libpinn_hip.so and is not a product fallback.
 #pragma once
+#ifndef __HIPCC_RTC__          // (hiprtc, the in-process back end of jit.cpp, has no standard headers and needs none of them here)
 #include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <type_traits>
+#endif
 
 #ifdef PINN_EMU
 // ------------------------------------------------------------------------------------------
@@ -234,7 +236,9 @@ inline vfloat4 mfma16x32bf(const vbf8& a, const vbf8& b, const vfloat4& c) {
 // ------------------------------------------------------------------------------------------
 // gfx950 device build
 // ------------------------------------------------------------------------------------------
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 // Floating-point contraction is OFF for everything below: every multiply-add that is meant to be fused is written as vfma / fmaf.
 // With the default (-ffp-contract=fast) the compiler fuses a*b+c depending on how often a*b is used, so the SAME source expression
 // rounded differently in different instantiations of one template (MODE_LOSS vs MODE_FUSED: per-point residuals one ulp apart, found

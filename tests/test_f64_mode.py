@@ -31,7 +31,7 @@ def _workloads():
     from neuralpde_jl_amd import workloads
     return {"cfg1": lambda: workloads.cfg1_poisson1d(64),
             "cfg2": lambda: workloads.cfg2_poisson2d(points=96, bcs_points=32),
-            "cfg3": lambda: workloads.cfg3_burgers(points=64, bcs_points=32),
+            "cfg3": lambda: workloads.cfg3_burgers(points=1100, bcs_points=32),     # (three blocks of the weight-gradient kernels, the last one ragged)
             "cfg4": lambda: workloads.cfg4_cavity(points=48, bcs_points=16, width=16, hidden=2),
             "cfg5": lambda: workloads.cfg5_heat_inverse(points=64, bcs_points=32, width=16, hidden=2)}
 

@@ -27,7 +27,7 @@ def _one_key(fam, HP, NHH, D, F, PAIRS, NPAIR, PG, HI):
     return "F%d_HP%d_NHH%d_D%d_F%x_P%x_H%x_L%x_PG%d(C=%d)" % (fam, HP, NHH, D, F, PAIRS, HI & 0xFFFFFF, lap, PG, C)
 
 
-SPEC_RE = r"pk::Spec2?<(\d+), (\d+), (\d+), (\d+)u?, (\d+)(?:ull|ul|u)?, (\d+), (\d+), (\d+)u?>"
+SPEC_RE = r"pk::Spec2?<(\d+), (\d+), (\d+), (\d+)u?, (\d+)(?:ull|ul|u)?, (\d+), (\d+), (\d+)u?(?:, \d+)?>"       # (r04: family 2 carries the GEMM mode as a 9th parameter)
 
 
 def spec_key(kernel_name):
