@@ -239,15 +239,18 @@ class Engine:
             grad.ctypes.data_as(C.POINTER(C.c_float)) if grad is not None else None), "pinn_loss_grad")
         return losses, grad
 
-    def loss_grad_f64(self, theta, weights=None):
+    def loss_grad_f64(self, theta, weights=None, want_grad: bool = True):
+        """theta, weights, losses and gradient in double at the ABI.  With the handle's precision option at "f64" the evaluation itself runs
+        in double; otherwise the fp32 kernels run and the results are widened."""
         th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64))
         losses = np.zeros(self.K, dtype=np.float64)
-        grad = np.zeros(self.P, dtype=np.float64)
+        grad = np.zeros(self.P, dtype=np.float64) if want_grad else None
         w = np.ascontiguousarray(np.asarray(weights, dtype=np.float64)) if weights is not None else None
         self.L.check(self.L.lib.pinn_loss_grad_f64(
             self.h, th.ctypes.data_as(C.POINTER(C.c_double)), th.size,
             w.ctypes.data_as(C.POINTER(C.c_double)) if w is not None else None,
-            losses.ctypes.data_as(C.POINTER(C.c_double)), grad.ctypes.data_as(C.POINTER(C.c_double))), "pinn_loss_grad_f64")
+            losses.ctypes.data_as(C.POINTER(C.c_double)),
+            grad.ctypes.data_as(C.POINTER(C.c_double)) if grad is not None else None), "pinn_loss_grad_f64")
         return losses, grad
 
     def term_grads(self, theta):

@@ -192,12 +192,18 @@ class PhysicsInformedNN:
 
     def __init__(self, chain, strategy: AbstractTrainingStrategy, *, init_params=None, phi=None, derivative=None,
                  param_estim: bool = False, additional_loss: Optional[Callable] = None, adaptive_loss=None,
-                 logger=None, log_options: LogOptions = LogOptions(), iteration=None, data_loss: Sequence[DataLoss] = (), **kwargs):
+                 logger=None, log_options: LogOptions = LogOptions(), iteration=None, data_loss: Sequence[DataLoss] = (),
+                 precision: str = "f32", **kwargs):
         if phi is not None or derivative is not None:
             raise ValueError("custom `phi` / `derivative` closures are per-call Julia hooks (src/pinn_types.jl:166-167) "
                              "and cannot be fused into the HIP kernels; they are not supported by this backend")
         self.chain = list(chain) if isinstance(chain, (list, tuple)) else [chain]
         self.multioutput = isinstance(chain, (list, tuple))
+        if precision not in ("f32", "f64"):
+            raise ValueError('precision must be "f32" (the device dtype of the north star, src/eltype_matching.jl:8-10) or "f64"')
+        # "f64": the engine's float64 evaluation mode (pinn_set_option(h, "precision", "f64")) — what a Float64 `init_params` selects in the
+        # reference (src/discretize.jl:432-449): objective, gradient and the BFGS / L-BFGS stages in double, points handed over in double
+        self.precision = precision
         self.strategy = strategy
         self.init_params = init_params
         self.param_estim = param_estim
@@ -560,8 +566,14 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
         for k, s in enumerate(list(pde_sets) + list(bc_sets)):
             if s.shape[0] != terms[k].dim:
                 raise ValueError(f"point set of term {k} has {s.shape[0]} rows, the term binds {terms[k].dim} variables")
-            engine.set_points(k, s)
+            if f64:
+                engine.set_points_f64(k, s)
+            else:
+                engine.set_points(k, s)
 
+    f64 = getattr(discretization, "precision", "f32") == "f64"
+    if f64:
+        engine.set_option("precision", "f64")           # (fails with the reason for what the mode does not cover: DGM, embeddings, data terms)
     install(pde_sets, bc_sets)
     if getattr(strategy, "point_weights", None) is not None and strategy.point_weights() is not None:
         for k, w in enumerate(strategy.point_weights()):           # quadrature strategies: loss_k = sum_i w_i r_i^2
@@ -595,7 +607,7 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
             ps, bs = resample()
             state["pde_sets"], state["bc_sets"] = ps, bs
             install(ps, bs)
-        losses, grad = engine.loss_grad(th, w, want_grad=want_grad)
+        losses, grad = engine.loss_grad_f64(th, w, want_grad=want_grad) if f64 else engine.loss_grad(th, w, want_grad=want_grad)
         state["cache_theta"], state["cache"] = key, (losses, grad)
         return losses, grad
 

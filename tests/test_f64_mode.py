@@ -142,3 +142,36 @@ def test_f64_mode_derivative_orders_activations_weights(npde, use_emu):
         rep2.engine.set_option("precision", "f64")
     assert rep2.engine.get_option("precision") == "f32"
     rep2.engine.loss_grad(rep2.flat_init_params)
+
+
+def test_reference_pde_iii_system_meets_its_float64_criterion(npde, use_emu):
+    """test/NNPDE1/nnpde__pde_iii_3rd_order_ode.jl:58-137 with the reference's OWN criteria: u''' = cos(pi x) as a first-order system of five
+    dependent variables (u, Dxu, Dxxu and two slack networks; equations that reference three networks at once), Sobol design of 100 points,
+    BFGS until the objective is below 1e-9, then `u_predict ≈ u_real atol = 1e-4`.  The fp32 evaluation stops at 1.9e-7 / 1.6e-4
+    (tests/test_gpu_reference_acceptance.py::test_pde_iii_third_order_ode_system_fp32_limit); `PhysicsInformedNN(..., precision = "f64")`
+    — what a Float64 init_params selects in the reference — meets both (measured: 9.97e-10 after 2,629 iterations, 2.6e-5)."""
+    import math
+    (x,) = npde.parameters("x")
+    u, Dxu, Dxxu, O1, O2 = npde.variables("u Dxu Dxxu O1 O2")
+    Dx = npde.Differential(x)
+    eq = npde.Eq(Dx(Dxxu(x)), sp.cos(sp.pi * x))
+    ep = (np.finfo(np.float64).eps ** (1 / 3)) ** 2 / 6
+    bcs = [npde.Eq(u(0.0), 0.0), npde.Eq(u(1.0), math.cos(math.pi)), npde.Eq(Dxu(1.0), 1.0),
+           npde.Eq(Dxu(x), Dx(u(x)) + ep * O1(x)), npde.Eq(Dxxu(x), Dx(Dxu(x)) + ep * O2(x))]
+    dom = [npde.In(x, npde.Interval(0.0, 1.0))]
+    wide = lambda: npde.Chain(npde.Dense(1, 12, "tanh"), npde.Dense(12, 12, "tanh"), npde.Dense(12, 1))
+    slack = lambda: npde.Chain(npde.Dense(1, 4, "tanh"), npde.Dense(4, 1))
+    chains = [wide(), wide(), wide(), slack(), slack()]
+    rng = np.random.default_rng(100)
+    theta0 = np.concatenate([npde.initialparameters(rng, c) for c in chains])
+    strat = npde.QuasiRandomTraining(100, sampling_alg=npde.SobolSample(seed=1), resampling=False, minibatch=1)
+    prob = npde.discretize(npde.PDESystem([eq], bcs, dom, [x], [u(x), Dxu(x), Dxxu(x), O1(x), O2(x)]),
+                           npde.PhysicsInformedNN(chains, strat, init_params=theta0, precision="f64"))
+    assert prob.pinnrep.engine.get_option("precision") == "f64"
+    res = npde.solve(prob, npde.BFGS(), maxiters=5000, callback=lambda st, l: l < 1e-9)
+    xs = np.arange(0.0, 1.0 + 0.005, 0.01)[None, :]
+    real = (np.pi * xs[0] * (-xs[0] + (np.pi ** 2) * (2 * xs[0] - 3) + 1) - np.sin(np.pi * xs[0])) / (np.pi ** 3)
+    rep = prob.pinnrep
+    err = np.linalg.norm(rep.phi[0](xs, npde.depvar_params(rep, res.u, "u"))[0] - real)
+    print(f"pde_iii in float64: objective {res.objective:.3e} (reference: < 1e-9), ||u_predict - u_real||_2 = {err:.2e} (reference atol 1e-4)")
+    assert res.objective < 1e-9 and err < 1e-4

@@ -90,6 +90,35 @@ def main():
         with open(out_json, "w") as f:
             json.dump({"formula": "(2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 (gfx950 wide-read correction)", "kernels": ks}, f, indent=1)
         print("wrote", out_json, len(ks), "kernels")
+        # kernel_facts.json next to it: issue-side facts of the fused kernels that bench.py cannot measure in process
+        #   mfma_busy            = SQ_VALU_MFMA_BUSY_CYCLES / SIMDs / (GRBM_GUI_ACTIVE / XCDs)        (1,024 SIMDs, 8 XCDs on MI355X)
+        #   valu_insts_per_tile  = (SQ_INSTS_VALU - SQ_INSTS_MFMA) per tile and wave (64-row tiles, waves per tile from the kernel family)
+        #   lds_array_busy       = SQ_LDS_IDX_ACTIVE / CUs / (GRBM_GUI_ACTIVE / XCDs)
+        #   wait_inst_frac       = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES
+        facts = []
+        for kn, cs in per_kernel.items():
+            key, mode = spec_key(kn)
+            if key is None or mode != 0 or "SQ_VALU_MFMA_BUSY_CYCLES" not in cs or "GRBM_GUI_ACTIVE" not in cs:
+                continue
+            ppl = sum(points if int(c) > 1 else 4 * points for c in re.findall(r"C=(\d+)", key))
+            gui = cs["GRBM_GUI_ACTIVE"] / 8.0
+            e = {"key": key, "points_per_launch": ppl, "mfma_busy": cs["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / gui,
+                 "source": os.path.relpath(out_txt, os.path.dirname(os.path.dirname(os.path.abspath(out_json))))}
+            if "SQ_INSTS_VALU" in cs and "SQ_INSTS_MFMA" in cs:
+                # rows per tile = 64 (16 points x C channels for C = 4, 64 points x 1 channel for C = 1); HP = 64: 4 waves per tile
+                tiles = sum((points * int(c) if int(c) > 1 else 4 * points) // 64 for c in re.findall(r"C=(\d+)", key))
+                nw = 8 if "HP128" in key else 4
+                e["valu_insts_per_tile"] = (cs["SQ_INSTS_VALU"] - cs["SQ_INSTS_MFMA"]) / (tiles * nw)
+                e["mfma_insts_per_tile"] = cs["SQ_INSTS_MFMA"] / (tiles * nw)
+            if "SQ_LDS_IDX_ACTIVE" in cs:
+                e["lds_array_busy"] = cs["SQ_LDS_IDX_ACTIVE"] / 256.0 / gui
+            if "SQ_WAIT_INST_ANY" in cs and "SQ_WAVE_CYCLES" in cs:
+                e["wait_inst_frac"] = cs["SQ_WAIT_INST_ANY"] / cs["SQ_WAVE_CYCLES"]
+            facts.append(e)
+        fj = os.path.join(os.path.dirname(os.path.abspath(out_json)), "kernel_facts.json")
+        with open(fj, "w") as f:
+            json.dump({"kernels": facts}, f, indent=1)
+        print("wrote", fj, len(facts), "kernels")
 
 
 if __name__ == "__main__":
