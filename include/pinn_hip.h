@@ -239,6 +239,13 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
  *   up to 6 dependent variables (same argument count), Dense chains with tanh / sigmoid / sin, derivative orders <= 2 (1-D: <= 4; 4-D: first and pure second), PDE
  *   parameters, quadrature weights; anything else fails HERE with a message and leaves the fp32 plan usable.  The Adam entry points and the
  *   device-pointer entry points stay fp32.  pinn_set_points_f64 installs a point set in double (the fp32 kernels get its float conversion).
+ * "persistent" = "on" (default) | "off": pinn_adam_steps runs a SMALL problem — one network of the one-wave-per-tile kernel family, at most
+ *   32 workgroups (~2,000 points of a 3 x 32 net), fixed point sets, no estimated PDE parameters, no communicator — as ONE persistent launch
+ *   per call (csrc/pinn_train.hpp: evaluation, fixed-order reduction, Adam and the weight-image update of every iteration inside the kernel,
+ *   two grid barriers per iteration) instead of three launches per iteration: the reference's own test regime,
+ *   solve(prob, Adam; maxiters = 4000) on 100-1,000 points (test/NNPDE1/nnpde__pde_ii_2d_poisson.jl:83-85).  Bit-identical to the loop.
+ *   $PINN_PERSISTENT=0 switches it off for every handle.  pinn_get_option(h, "adam_path") reports what the last pinn_adam_steps call ran:
+ *   "persistent" | "loop" | "none".
  */
 int pinn_set_points_f64(pinn_handle h, int term, const double* pts, int64_t n, int64_t n_norm);
 int pinn_set_option(pinn_handle h, const char* name, const char* value);

@@ -368,8 +368,9 @@ class Engine:
                                                  ub.ctypes.data_as(C.POINTER(C.c_float)), n, seed), "pinn_set_sampler")
 
     def adam(self, theta, nsteps: int, lr: float, weights=None, beta1=0.9, beta2=0.999, eps=1e-8, init=True):
-        """`nsteps` Adam iterations with theta resident on the device; returns (theta, loss history)."""
-        th = _f32(theta)
+        """`nsteps` Adam iterations with theta resident on the device; returns (theta, loss history).  init=False continues from the
+        optimiser state on the device (theta is not read)."""
+        th = _f32(theta) if init else None
         if init:
             self.L.check(self.L.lib.pinn_adam_init(self.h, th.ctypes.data_as(C.POINTER(C.c_float)), th.size), "pinn_adam_init")
         hist = np.zeros(nsteps, dtype=np.float64)

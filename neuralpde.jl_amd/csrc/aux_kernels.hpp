@@ -11,6 +11,7 @@
 #include "aux_limits.hpp"
 #include "plat.hpp"
 #include "rprog.hpp"
+#include "update_rules.hpp"
 
 namespace aux {
 
@@ -147,15 +148,8 @@ AUX_DEV void src_point(int p, const SrcArgs& a) {
 }
 
 // ---- resident-theta training loop ----
-// Adam exactly as [3P] Optimisers.Adam: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; theta -= lr * (m/(1-b1^t)) / (sqrt(v/(1-b2^t)) + eps)
-// one Adam update ([3P] Optimisers.Adam): the multiply-adds are spelled out as fused operations, so that every kernel that performs the
-// update (plain, fused with the pack, device-counter variant) and the CPU emulation round identically — left to the compiler, two kernels
-// with the same source expression contracted it differently (1-ulp differences from the second step on)
-AUX_DEV float adam_update(float th, float& m, float& v, float g, float lr, float b1, float b2, float eps, float c1, float c2) {
-    m = __builtin_fmaf(b1, m, (1.0f - b1) * g);
-    v = __builtin_fmaf(b2, v, ((1.0f - b2) * g) * g);
-    return th - (lr * (m * c1)) / (sqrtf(v * c2) + eps);      // c1 = 1/(1-b1^t), c2 = 1/(1-b2^t)
-}
+// the Adam rule itself lives in update_rules.hpp (shared with the persistent training kernel, pinn_train.hpp)
+using ur::adam_update;
 AUX_DEV void adam_body(int i, float* theta, float* m, float* v, const float* grad, float lr, float b1, float b2, float eps, float c1, float c2) {
     float mi = m[i], vi = v[i];
     const float t = adam_update(theta[i], mi, vi, grad[i], lr, b1, b2, eps, c1, c2);

@@ -10,6 +10,8 @@
 namespace wv {
 thread_local void (*emu_barrier_hook)(void*) = nullptr;
 thread_local void* emu_barrier_ctx = nullptr;
+thread_local void (*emu_grid_hook)(void*) = nullptr;
+thread_local void* emu_grid_ctx = nullptr;
 }  // namespace wv
 #endif
 
@@ -434,7 +436,7 @@ int pinn_destroy(pinn_handle h) {
     f64_destroy(E);
     free_plan(E);
     for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_upts); plat_free(T.d_resid); plat_free(T.d_lb); plat_free(T.d_ub); plat_free(T.d_data); plat_free(T.d_pw); }
-    plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist); plat_free(E.d_step); plat_free(E.d_draws); plat_free(E.d_sampled); plat_free(E.d_c12);
+    plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist); plat_free(E.d_step); plat_free(E.d_draws); plat_free(E.d_sampled); plat_free(E.d_c12); plat_free(E.d_bar); plat_free(E.d_sums2);
     plat_free(E.d_theta); plat_free(E.d_params); plat_free(E.d_defaults); plat_free(E.d_lossraw);
     plat_free(E.d_out); plat_free(E.d_phi_pts); plat_free(E.d_phi_out); plat_free(E.d_phi_scr);
     plat_host_free(E.hp_theta);
@@ -990,7 +992,12 @@ int pinn_set_option(pinn_handle h, const char* name, const char* value) {
         if (v == "f32") { plat_sync(E.stream); f64_destroy(E); return 0; }
         return fail("pinn_set_option: precision must be \"f32\" or \"f64\"");
     }
-    return fail("pinn_set_option: unknown option \"" + k + "\" (known: gemm, precision)");
+    if (k == "persistent") {
+        if (v == "on" || v == "1") { E.persistent = true; return 0; }
+        if (v == "off" || v == "0") { E.persistent = false; return 0; }
+        return fail("pinn_set_option: persistent must be \"on\" or \"off\"");
+    }
+    return fail("pinn_set_option: unknown option \"" + k + "\" (known: gemm, precision, persistent)");
 }
 
 int pinn_get_option(pinn_handle h, const char* name, char* buf, int64_t buflen) {
@@ -998,7 +1005,9 @@ int pinn_get_option(pinn_handle h, const char* name, char* buf, int64_t buflen) 
     const std::string k = name;
     if (k == "gemm") { std::snprintf(buf, (size_t)buflen, "%s", h->gemm == pk::GEMM_FP32 ? "fp32" : "split"); return 0; }
     if (k == "precision") { std::snprintf(buf, (size_t)buflen, "%s", h->f64 ? "f64" : "f32"); return 0; }
-    return fail("pinn_get_option: unknown option \"" + k + "\" (known: gemm, precision)");
+    if (k == "persistent") { std::snprintf(buf, (size_t)buflen, "%s", h->persistent ? "on" : "off"); return 0; }
+    if (k == "adam_path") { std::snprintf(buf, (size_t)buflen, "%s", h->adam_path == 2 ? "persistent" : (h->adam_path == 1 ? "loop" : "none")); return 0; }
+    return fail("pinn_get_option: unknown option \"" + k + "\" (known: gemm, precision, persistent, adam_path)");
 }
 
 int pinn_adam_init(pinn_handle h, const float* theta, int64_t p) {
@@ -1152,6 +1161,92 @@ static int adam_loop(pinn_engine** es, int ndev, int nsteps, float lr, float bet
     return 0;
 }
 
+// ---- persistent training kernel (pinn_train.hpp): the iterations of pinn_adam_steps inside ONE launch ----
+// Eligible: ONE fused family-1 launch group of ONE network whose spec carries the kernel (tanh / sigmoid), fixed point sets, no estimated
+// PDE parameters, no communicator, float32, every workgroup resident (one per CU) and few enough for the one-stage reduction whose
+// association the kernel repeats (aux::reduce_is_small) — i.e. the small problems of the reference's own test-suite.  PINN_PERSISTENT=0
+// (read per call) keeps the stand-alone loop; results are bit-identical either way (tests/test_train_kernel.py).
+static bool train_eligible(pinn_engine& E) {
+    const char* e = std::getenv("PINN_PERSISTENT");
+    if (!E.persistent || (e && std::atoi(e) == 0)) return false;
+    if (E.comm || E.f64 || E.ne != 0 || E.groups.size() != 1 || !E.coupled.empty() || E.nets.size() != 1) return false;
+    if (!E.inv_ok || !E.d_inv_ptr) return false;
+    const Group& G = E.groups[0];
+    if (G.kind != 0 || !G.spec || G.spec->family != 1 || !G.spec->train) return false;
+    if (G.ga.act != pk::ACT_TANH && G.ga.act != pk::ACT_SIGMOID) return false;
+    for (auto& T : E.terms) if (T.sampler != 0) return false;
+    const char* lim = std::getenv("PINN_REDUCE_DIRECT_MAX");
+    const int direct_max = lim ? std::atoi(lim) : aux::REDUCE_DIRECT_MAX;
+    if (G.blocks > direct_max || G.blocks > 32 || G.blocks > E.ncu) return false;
+    return true;
+}
+// returns 0 when all nsteps ran inside the kernel, 1 on failure (g_err set)
+static int adam_steps_train(pinn_engine& E, int nsteps, float lr, float beta1, float beta2, float eps, const float* term_w) {
+    const int K = (int)E.terms.size(), P = (int)E.ntheta;
+    Group& G = E.groups[0];
+    if (!E.d_bar) {
+        E.d_bar = (unsigned*)plat_malloc(sizeof(unsigned) * 16);      // [0] arrivals, [1] time-out flag, [4..11] phase ticks of a PINN_STAMP build
+        E.d_sums2 = (float*)plat_malloc(sizeof(float) * 2 * (size_t)std::max(K, 1));
+        if (!E.d_bar || !E.d_sums2) return fail("device allocation failed (grid barrier words)");
+    }
+    if (E.c12_cap < nsteps) {
+        plat_sync(E.stream);
+        plat_free(E.d_c12);
+        E.d_c12 = (float*)plat_malloc(sizeof(float) * 2 * (size_t)nsteps);
+        E.c12_cap = E.d_c12 ? nsteps : 0;
+        if (!E.d_c12) return fail("device allocation failed (bias-correction table)");
+    }
+    std::vector<float> c12(2 * (size_t)nsteps);
+    for (int s = 0; s < nsteps; ++s) {
+        c12[2 * s] = (float)(1.0 / (1.0 - std::pow((double)beta1, (double)(E.opt_t + s + 1))));
+        c12[2 * s + 1] = (float)(1.0 / (1.0 - std::pow((double)beta2, (double)(E.opt_t + s + 1))));
+    }
+    plat_h2d(E.d_c12, c12.data(), sizeof(float) * c12.size(), E.stream);
+    plat_memset(E.d_bar, 0, sizeof(unsigned) * 16, E.stream);
+    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());       // (c12 is a pageable temporary)
+    pack_all(E, E.d_opt_theta, false);                        // the weight image of the current theta; the kernel keeps it current from here on
+    for (size_t j = 0; j < G.terms.size(); ++j) {
+        const int ti = G.terms[j];
+        G.ga.terms[j].scale = (float)(2.0 * (double)(term_w ? term_w[ti] : 1.0f) / (double)E.terms[ti].n_norm);
+    }
+    G.ga.slabs = G.d_slabs;
+    G.ga.chain = 0;
+    G.active = true;
+    G.timed = false;
+    G.launched_blocks = G.blocks;
+    G.launched_by = 0;
+    pk::TrainArgs ta;
+    std::memset(&ta, 0, sizeof ta);
+    ta.slabs = G.d_slabs; ta.losspart = G.d_losspart; ta.row_ptr = E.d_gr_ptr; ta.row_ent = E.d_gr_ent;
+    ta.slab_floats = G.slab_floats; ta.nblocks = G.blocks;
+    ta.out = E.d_opt_out; ta.lossraw = E.d_lossraw;
+    ta.theta = E.d_opt_theta; ta.m = E.d_opt_m; ta.v = E.d_opt_v;
+    ta.lr = lr; ta.b1 = beta1; ta.b2 = beta2; ta.eps = eps;
+    ta.inv_ptr = E.d_inv_ptr; ta.inv_pos = E.d_inv_pos; ta.packed = E.netplans[G.net].d_packed;
+    ta.w_over_n = E.d_w_over_n;
+    ta.P = P; ta.K = K;
+    ta.sums2 = E.d_sums2;
+    ta.cached = (G.blocks * 256 >= P + K && E.max_contrib <= pk::TRAIN_MAX_CONTRIB && E.max_inv_pos <= pk::TRAIN_MAX_POS &&
+                 std::getenv("PINN_TRAIN_NO_CACHE") == nullptr) ? 1 : 0;
+    ta.bar = E.d_bar;
+    // launches of at most TRAIN_CHUNK iterations: the barrier counter restarts with every launch
+    constexpr int TRAIN_CHUNK = 4096;
+    for (int s0 = 0; s0 < nsteps; s0 += TRAIN_CHUNK) {
+        ta.nsteps = std::min(TRAIN_CHUNK, nsteps - s0);
+        ta.c12 = E.d_c12 + 2 * (size_t)s0;
+        ta.hist = E.d_hist + s0;
+        if (s0 > 0) plat_memset(E.d_bar, 0, sizeof(unsigned), E.stream);
+        G.spec->train(G.ga, ta, G.blocks, E.stream);
+    }
+    unsigned flag[2] = {0, 0};
+    if (plat_d2h(flag, E.d_bar, sizeof flag, E.stream) || plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    E.opt_t += nsteps;
+    if (flag[1] != 0)
+        return fail("pinn_adam_steps: the grid barrier of the persistent training kernel timed out (its workgroups were not all resident); "
+                    "the optimiser state is undefined — set PINN_PERSISTENT=0 and start again from pinn_adam_init");
+    return 0;
+}
+
 // checks and per-call device state shared by the Adam entry points
 static int adam_prepare(pinn_engine& E, int nsteps, const float* term_w, const char* who) {
     if (!E.d_opt_theta) return fail(std::string(who) + ": call pinn_adam_init first");
@@ -1181,6 +1276,14 @@ int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta
         return fail("pinn_adam_steps: the handle belongs to a single-process communicator (pinn_comm_init_all): use pinn_adam_steps_sharded");
     if (adam_prepare(E, nsteps, term_w, "pinn_adam_steps")) return 1;
     const int K = (int)E.terms.size();
+    E.adam_path = 1;
+    if (train_eligible(E)) {                     // small problems: every iteration inside one persistent launch (pinn_train.hpp)
+        E.adam_path = 2;
+        if (adam_steps_train(E, nsteps, lr, beta1, beta2, eps, term_w)) return 1;
+        if (loss_history && plat_d2h(loss_history, E.d_hist, sizeof(double) * nsteps, E.stream)) return fail("D2H copy failed");
+        if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+        return 0;
+    }
     // Default: plain launches, the step index / bias corrections / draw counters as kernel arguments.
     // PINN_GRAPH=1 (experiment, kept for reproduction): everything that changes from step to step lives in device memory and is advanced
     // by a kernel, so every step issues the SAME launch sequence, which is recorded once from the stream and replayed as a hipGraph.
@@ -1390,6 +1493,14 @@ int pinn_last_timing(pinn_handle h, float* kernel_ms, float* total_ms) {
 int pinn_num_groups(pinn_handle h) { return h ? (int)h->groups.size() : -1; }
 
 #ifdef PINN_STAMP
+// profiling build only: the four phase-tick sums of the last persistent training launch (pinn_train.hpp: TRAIN_STAMP)
+int pinn_debug_train_stamps(pinn_handle h, unsigned long long* out4) {
+    if (!h || !h->d_bar || !out4) return -1;
+    plat_sync(h->stream);
+    plat_d2h(out4, h->d_bar + 4, sizeof(unsigned long long) * 4, h->stream);
+    plat_sync(h->stream);
+    return 0;
+}
 // profiling build only (tools/stamp_profile.sh): raw read-back of one workgroup's gradient slab incl. the stamp tail
 int pinn_debug_slab(pinn_handle h, int group, int blk, float* dst, int64_t n) {
     if (!h || group < 0 || group >= (int)h->groups.size()) return -1;

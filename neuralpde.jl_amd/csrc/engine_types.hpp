@@ -250,6 +250,11 @@ struct pinn_engine {
     int* d_sampled = nullptr;
     float* d_c12 = nullptr;
     int c12_cap = 0;
+    unsigned* d_bar = nullptr;       // grid-barrier words of the persistent training kernel (pinn_train.hpp)
+    float* d_sums2 = nullptr;        // its [2][K] per-step sums
+    int max_contrib = 0, max_inv_pos = 0;      // most slab entries / image positions of one theta element (plan.cpp)
+    bool persistent = true;          // pinn_set_option "persistent": small problems run pinn_adam_steps inside one launch
+    int adam_path = 0;               // what the last pinn_adam_steps call ran: 0 nothing yet, 1 the stand-alone loop, 2 the persistent kernel
     // phi scratch
     float* d_phi_pts = nullptr;
     float* d_phi_out = nullptr;

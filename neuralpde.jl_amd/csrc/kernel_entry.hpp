@@ -6,6 +6,7 @@
 #include "pinn_kernels.hpp"
 #include "pinn_kernels2.hpp"
 #include "pinn_kernels3.hpp"
+#include "pinn_train.hpp"
 #ifdef __HIPCC_RTC__
 typedef struct ihipStream_t* plat_stream;       // (= hipStream_t; only the type of SpecInfo::launch's last parameter matters here)
 #else
@@ -42,11 +43,15 @@ struct SpecInfo {
     int twin;                        // family 2: 1 when the shape is compiled in both GEMM modes (64- and 128-wide kernels), so a handle's mode selects
     int O_WBAR, O_BFRH, O_BFR0, O_W1, O_WL, O_BL, O_P;
     void (*launch)(const GroupArgs&, int mode, int blocks, plat_stream);
+    // family 1: K optimiser iterations in one launch (pinn_train.hpp: k_train, tanh / sigmoid variants); nullptr: not compiled for this spec
+    void (*train)(const GroupArgs&, const TrainArgs&, int blocks, plat_stream);
 };
 
 template <class S>
-HD SpecInfo make_info(void (*launch)(const GroupArgs&, int, int, plat_stream), int has_sin = 0) {
+HD SpecInfo make_info(void (*launch)(const GroupArgs&, int, int, plat_stream), int has_sin = 0,
+                      void (*train)(const GroupArgs&, const TrainArgs&, int, plat_stream) = nullptr) {
     SpecInfo s = {};
+    s.train = train;
     s.has_sin = has_sin;
     s.jit = 0;
     s.act1 = s.act2 = s.dgm_rows = 0;
@@ -112,6 +117,13 @@ __global__ void __launch_bounds__(256, 1) k_wave(const GroupArgs ga) {
     __shared__ __attribute__((aligned(16))) float lds_all[S::LDS_WG];
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     wave_main<S, MODE, ACTK>(ga, (int)blockIdx.x, (int)gridDim.x, w, lds_all);
+}
+// K optimiser iterations of a small problem in one launch (pinn_train.hpp); every workgroup must be resident: blocks <= #CU
+template <class S, int ACTK>
+__global__ void __launch_bounds__(256, 1) k_train(const GroupArgs ga, const TrainArgs ta) {
+    __shared__ __attribute__((aligned(16))) float lds_all[S::LDS_WG];
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    wave_train<S, ACTK>(ga, ta, (int)blockIdx.x, (int)gridDim.x, w, lds_all);
 }
 // family 2: two waves per SIMD => at most 256 VGPR+AGPR per lane: two 4-wave workgroups per CU (H = 64), or one 8-wave workgroup
 // (H = 128: LDS 100-150 KB per workgroup)

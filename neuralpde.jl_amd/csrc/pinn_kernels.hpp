@@ -36,6 +36,15 @@
 #ifndef PINN_F1_PREFETCH
 #define PINN_F1_PREFETCH 1
 #endif
+// Small nets keep their operands in REGISTERS (r04): a family-1 workgroup runs one wave per SIMD, so every lane owns the whole 512-entry
+// register file, of which a 3 x 32 network's kernel used 280.  Bit 0: every hidden->hidden weight fragment (forward and transposed), the
+// biases and the first layer are loaded ONCE per launch, in front of the tile loop — the k-steps of the GEMMs no longer wait for one L2 round
+// trip each (32 dependent round trips per tile of a 3 x 32 net; a one-tile launch is nothing but latency).  Bit 1: the records of the hidden
+// layers stay in registers between the forward and the reverse sweep instead of a store / load pair through the per-wave scratch slab.
+// Same arithmetic in the same order either way: results are bit-identical to the streaming form (PINN_F1_RESIDENT=0).
+#ifndef PINN_F1_RESIDENT
+#define PINN_F1_RESIDENT 3
+#endif
 
 namespace pk {
 using namespace wv;
@@ -194,6 +203,13 @@ struct Spec {
     static constexpr int LDS_PRIV = 4 * LDS_T + LDS_X;
     static constexpr int LDS_SHARED = COOP ? 2 * 4 * 2 * LDS_T : 0;
     static constexpr int LDS_WG = LDS_SHARED + 4 * LDS_PRIV;
+    // register-resident operands (PINN_F1_RESIDENT): registers per lane of the hidden->hidden fragments (forward + transposed), of the
+    // stored records, and of what the tile loop keeps live anyway (seven activation-sized tensors + the dW accumulators)
+    static constexpr int WREGS = 2 * NHH_ * 4 * MT * MT;
+    static constexpr int RREGS = NHH_ * NG * MT * 4;
+    static constexpr int LIVE = 7 * NG * MT * 4 + NHH_ * WT * MT * 4 + (LH + D_ + 1) * MT * 4;
+    static constexpr bool W_RESIDENT = (PINN_F1_RESIDENT & 1) && NHH_ > 0 && MT < 4 && LIVE + WREGS <= 400;
+    static constexpr bool R_RESIDENT = (PINN_F1_RESIDENT & 2) && NHH_ > 0 && LIVE + (W_RESIDENT ? WREGS : 0) + RREGS <= 400;
 };
 
 struct TermDev {
@@ -451,7 +467,9 @@ DEV vint tr_addr(vint col, vint slot) {
 // All four waves of a workgroup run the same number of tile iterations (tiles past the end are fully masked
 // dummies) because the COOP dW phase synchronises them with workgroup barriers.
 // ------------------------------------------------------------------------------------------------
-template <class S, int MODE, int ACTK>
+// WTHRU (training kernel, pinn_train.hpp): what other workgroups read inside the launch — gradient slabs, loss partials — is stored write-through,
+// and the weight image, which other workgroups rewrote, is read with agent-scope loads: no fences around the grid barriers
+template <class S, int MODE, int ACTK, bool WTHRU = false>
 DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_wg) {
     const int wave = blk * 4 + w;
     float* lds = lds_wg + S::LDS_SHARED + w * S::LDS_PRIV;     // wave-private LDS
@@ -498,16 +516,38 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
 
     const ubuf SB = ub_make(ga.scratch + (size_t)wave * S::SCR, S::SCR);      // this wave's activation scratch
     const ubuf PB = ub_make(P, S::PACKED);                                         // packed weights of this net
+    auto pld = [&](int soff, vint voff) -> vfloat { return WTHRU ? ub_load_sc1(PB, soff, voff) : ub_load(PB, soff, voff); };
+    auto pld4 = [&](int soff, vint voff) -> vfloat4 { return WTHRU ? ub_load4_sc1(PB, soff, voff) : ub_load4(PB, soff, voff); };
+    auto lp_store = [&](int term_id, double v) {                                   // this wave's loss-partial column of a term
+        double* q = ga.losspart + (size_t)wave * ga.nterms_total + term_id;
+        if (WTHRU) ustore_wt(q, v); else *q = v;
+    };
     float* xs = lds + 4 * S::LDS_T;           // coords of the tile: [pg][pt][i]
 
     // output layer weights in D layout
     vfloat4 wL[MT];
-    PINN_UNROLL for (int m = 0; m < MT; ++m) wL[m] = ub_load4(PB, S::OFF_WL + 16 * m, g << 2);
-    const float bL = P[S::OFF_BL];
+    PINN_UNROLL for (int m = 0; m < MT; ++m) wL[m] = pld4(S::OFF_WL + 16 * m, g << 2);
+    const float bL = lane0(pld(S::OFF_BL, lane & vint(0)));      // (a vector load: the training kernel rewrites the image inside the launch)
+    // register-resident weights (Spec::W_RESIDENT): [layer][k-step][tile] forward / transposed fragments, biases, first layer
+    constexpr bool WRES = S::W_RESIDENT, RRES = S::R_RESIDENT && BWD;
+    vfloat wres[WRES ? NHH : 1][WRES ? 4 * MT : 1][MT], tres[(WRES && BWD) ? NHH : 1][(WRES && BWD) ? 4 * MT : 1][MT];
+    vfloat4 bres[WRES ? LH : 1][MT], w1res[WRES ? D : 1][MT];
+    if (WRES) {
+        PINN_UNROLL for (int l = 0; l < LH; ++l)
+            PINN_UNROLL for (int m = 0; m < MT; ++m) bres[l][m] = pld4(S::OFF_B + l * HP + 16 * m, g << 2);
+        PINN_UNROLL for (int i = 0; i < D; ++i)
+            PINN_UNROLL for (int m = 0; m < MT; ++m) w1res[i][m] = pld4(S::OFF_W1 + i * HP + 16 * m, g << 2);
+        PINN_UNROLL for (int hl = 0; hl < NHH; ++hl)
+            PINN_UNROLL for (int ks = 0; ks < 4 * MT; ++ks)
+                PINN_UNROLL for (int mo = 0; mo < MT; ++mo) {
+                    wres[hl][ks][mo] = pld(S::OFF_WPK + hl * HP * HP + ks * 64 * MT + mo, lane * MT);
+                    if (BWD) tres[hl][ks][mo] = pld(S::OFF_WTPK + hl * HP * HP + ks * 64 * MT + mo, lane * MT);
+                }
+    }
 
     constexpr bool SUMS = (MODE == MODE_FUSED || MODE == MODE_LOSS);      // modes that deliver the per-term sums of squares
     if (SUMS)                    // this wave's loss columns start at zero (no host-side memset per evaluation)
-        for (int j = 0; j < ga.nterms; ++j) ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[j].term_id] = 0.0;
+        for (int j = 0; j < ga.nterms; ++j) lp_store(ga.terms[j].term_id, 0.0);
     const int niter = (ga.ntiles + 4 * nblocks - 1) / (4 * nblocks);
     for (int it = 0; it < niter; ++it) {
         const int t = (it * nblocks + blk) * 4 + w;          // >= ntiles: dummy tile of the last term, all points masked
@@ -518,7 +558,7 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
         if (k != cur_term) {
             if (cur_term >= 0) {
                 double s = wave_sum_dd(lsum, g0);
-                if (SUMS) ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[cur_term].term_id] = s;
+                if (SUMS) lp_store(ga.terms[cur_term].term_id, s);
             }
             lsum = vdacc_zero();
             cur_term = k;
@@ -542,9 +582,9 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
         vfloat4 A[NG][MT];
         // ---- layer 1: d -> HP on the VALU (K = d is tiny) ----
         PINN_UNROLL for (int m = 0; m < MT; ++m) {
-            vfloat4 b1 = ub_load4(PB, S::OFF_B + 16 * m, g << 2);
+            vfloat4 b1 = WRES ? bres[0][m] : pld4(S::OFF_B + 16 * m, g << 2);
             vfloat4 w1[D];
-            PINN_UNROLL for (int i = 0; i < D; ++i) w1[i] = ub_load4(PB, S::OFF_W1 + i * HP + 16 * m, g << 2);
+            PINN_UNROLL for (int i = 0; i < D; ++i) w1[i] = WRES ? w1res[i][m] : pld4(S::OFF_W1 + i * HP + 16 * m, g << 2);
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
                 vfloat4 z = b1;
                 PINN_UNROLL for (int i = 0; i < D; ++i)
@@ -557,6 +597,7 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
 
         // raw (a, z_i, z_ij) record of the LAST hidden layer stays in registers for the reverse sweep
         vfloat4 Rlast[NG][MT];
+        vfloat4 Rec[RRES ? NHH : 1][NG][MT];           // Spec::R_RESIDENT: the records of the hidden layers below the last, in registers
         // activation jets in place + park (a, z_i, z_ij) of the other layers in the scratch slab
         auto act_forward = [&](vfloat4 (&Z)[NG][MT], int layer /*0-based hidden layer*/) {
             const int act = act_of(layer);
@@ -571,6 +612,8 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                     if (BWD) {
                         if (layer == LH - 1) {
                             PINN_UNROLL for (int ch = 0; ch < C; ++ch) Rlast[pg * C + ch][m] = Z[pg * C + ch][m];
+                        } else if (RRES) {
+                            PINN_UNROLL for (int ch = 0; ch < C; ++ch) Rec[layer][pg * C + ch][m] = Z[pg * C + ch][m];
                         } else {
                             PINN_UNROLL for (int ch = 0; ch < C; ++ch)
                                 ub_store4(SB, (((layer * NG) + pg * C + ch) * MT + m) * 256, lane << 2, Z[pg * C + ch][m]);
@@ -594,10 +637,10 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
         auto load_wf = [&](int hl, int ks, vfloat (&wf)[MT]) {
             const int Wf = S::OFF_WPK + hl * HP * HP;
             if (MT == 4) {
-                vfloat4 w4 = ub_load4(PB, Wf + ks * 64 * MT, lane << 2);
+                vfloat4 w4 = pld4(Wf + ks * 64 * MT, lane << 2);
                 PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wf[mo] = w4[mo & 3];
             } else {
-                PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wf[mo] = ub_load(PB, Wf + ks * 64 * MT + mo, lane * MT);
+                PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wf[mo] = pld(Wf + ks * 64 * MT + mo, lane * MT);
             }
         };
         // PINN_F1_PREFETCH: a layer's bias and its FIRST weight fragment are requested before the activation function of the layer below
@@ -605,7 +648,11 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
         vfloat wfirst[MT];
         vfloat4 bvn[MT];
         auto prefetch_layer = [&](int hl) {
-            PINN_UNROLL for (int m = 0; m < MT; ++m) bvn[m] = ub_load4(PB, S::OFF_B + (hl + 1) * HP + 16 * m, g << 2);
+            if (WRES) {
+                PINN_UNROLL for (int m = 0; m < MT; ++m) bvn[m] = bres[hl + 1][m];
+                return;
+            }
+            PINN_UNROLL for (int m = 0; m < MT; ++m) bvn[m] = pld4(S::OFF_B + (hl + 1) * HP + 16 * m, g << 2);
             load_wf(hl, 0, wfirst);
         };
         if (PINN_F1_PREFETCH && NHH > 0) prefetch_layer(0);
@@ -622,13 +669,13 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
                 }
             }
             vfloat wcur[MT], wnxt[MT];
-            PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wcur[mo] = wfirst[mo];
+            if (!WRES) { PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wcur[mo] = wfirst[mo]; }
             PINN_UNROLL for (int ks = 0; ks < 4 * MT; ++ks) {
                 const int mi = ks >> 2, rr = ks & 3;
-                if (ks + 1 < 4 * MT) load_wf(hl, ks + 1, wnxt);
+                if (!WRES && ks + 1 < 4 * MT) load_wf(hl, ks + 1, wnxt);
                 PINN_UNROLL for (int q = 0; q < NG; ++q)
-                    PINN_UNROLL for (int mo = 0; mo < MT; ++mo) Zn[q][mo] = mfma16(wcur[mo], A[q][mi][rr], Zn[q][mo]);
-                PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wcur[mo] = wnxt[mo];
+                    PINN_UNROLL for (int mo = 0; mo < MT; ++mo) Zn[q][mo] = mfma16(WRES ? wres[hl][WRES ? ks : 0][mo] : wcur[mo], A[q][mi][rr], Zn[q][mo]);
+                if (!WRES) { PINN_UNROLL for (int mo = 0; mo < MT; ++mo) wcur[mo] = wnxt[mo]; }
             }
             if (PINN_F1_PREFETCH && hl + 1 < NHH) prefetch_layer(hl + 1);
             act_forward(Zn, hl + 1);
@@ -659,7 +706,7 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
         auto load_raw = [&](vfloat4 (&Sr)[NG][MT], int layer) {
             PINN_UNROLL for (int q = 0; q < NG; ++q)
                 PINN_UNROLL for (int m = 0; m < MT; ++m)
-                    Sr[q][m] = ub_load4(SB, (((layer * NG) + q) * MT + m) * 256, lane << 2);
+                    Sr[q][m] = RRES ? Rec[RRES ? layer : 0][q][m] : ub_load4(SB, (((layer * NG) + q) * MT + m) * 256, lane << 2);
         };
         // prefetch the raw record of the layer feeding the last hidden->hidden GEMM: it lands while the tape runs
         vfloat4 SrN[NG][MT];
@@ -671,6 +718,29 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
                 vint p = vint(pbase + 16 * pg) + c;
                 PINN_UNROLL for (int ch = 0; ch < C; ++ch) ubar[pg][ch] = gload_masked(T.in, vint(ch * T.N) + p, valid[pg]);
+            }
+        } else if (T.linear && C <= LIN_MAX_C) {
+            // affine residual (r04, as in the neuron-split kernels): r = k + sum_c a_c U_c + sum_j b_j src_j with constant coefficients —
+            // every Dirichlet term, lap u - f, linear PDEs with fixed coefficients (plan.cpp: detect_linear): C + nsrc FMAs and the seeds
+            // are the coefficients; no interpreter, no LDS rows
+            PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                const vint p = vint(pbase + 16 * pg) + c;
+                vfloat r = vfloat(T.lin_k);
+                PINN_UNROLL for (int ch = 0; ch < C; ++ch) r = vfma(vfloat(T.lin_a[ch < LIN_MAX_C ? ch : 0]), U[pg][ch], r);
+                PINN_UNROLL for (int j = 0; j < LIN_MAX_SRC; ++j)
+                    if (j < T.nsrc) r = vfma(vfloat(T.lin_b[j]), gload_masked(T.src, vint(j * T.N) + p, valid[pg]), r);
+                if (MODE == MODE_RESID) {
+                    gstore_masked(T.out, p, r, vand(valid[pg], g0));
+                    continue;
+                }
+                vfloat sw = vfloat(1.0f);
+                if (T.pw) sw = gload_masked(T.pw, p, valid[pg]);
+                const vfloat rm = vselect(valid[pg], r * sw, vfloat(0.f));
+                lsum = vdacc_fma(rm, vselect(g0, rm, vfloat(0.f)), lsum);
+                if (MODE == MODE_LOSS) continue;
+                const vfloat rbar = rm * vfloat(T.scale) * sw;
+                PINN_UNROLL for (int ch = 0; ch < C; ++ch)
+                    ubar[pg][ch] = vselect(valid[pg], rbar * vfloat(T.lin_a[ch < LIN_MAX_C ? ch : 0]), vfloat(0.f));
             }
         } else {
             wave_fence();
@@ -794,14 +864,14 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
             const int Wt = S::OFF_WTPK + hl * HP * HP;
             auto load_wt = [&](int ks, vfloat (&wf)[MT]) {
                 if (MT == 4) {
-                    vfloat4 w4 = ub_load4(PB, Wt + ks * 64 * MT, lane << 2);
+                    vfloat4 w4 = pld4(Wt + ks * 64 * MT, lane << 2);
                     PINN_UNROLL for (int mi = 0; mi < MT; ++mi) wf[mi] = w4[mi & 3];
                 } else {
-                    PINN_UNROLL for (int mi = 0; mi < MT; ++mi) wf[mi] = ub_load(PB, Wt + ks * 64 * MT + mi, lane * MT);
+                    PINN_UNROLL for (int mi = 0; mi < MT; ++mi) wf[mi] = pld(Wt + ks * 64 * MT + mi, lane * MT);
                 }
             };
             vfloat tcur[MT];
-            if (PINN_F1_PREFETCH) load_wt(0, tcur);
+            if (PINN_F1_PREFETCH && !WRES) load_wt(0, tcur);
             // ---- dW += dZ A^T through the swizzled LDS transpose, 16 columns at a time ----
             if (COOP) {
                 // Every wave publishes its (dZ^T, A^T) chunk in the workgroup-shared double buffer; after one barrier
@@ -881,13 +951,14 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
             PINN_UNROLL for (int q = 0; q < NG; ++q)
                 PINN_UNROLL for (int m = 0; m < MT; ++m) Gn[q][m] = vzero4();
             vfloat tnxt[MT];
-            if (!PINN_F1_PREFETCH) load_wt(0, tcur);
+            if (!PINN_F1_PREFETCH && !WRES) load_wt(0, tcur);
             PINN_UNROLL for (int ks = 0; ks < 4 * MT; ++ks) {
                 const int mo = ks >> 2, rr = ks & 3;
-                if (ks + 1 < 4 * MT) load_wt(ks + 1, tnxt);
+                if (!WRES && ks + 1 < 4 * MT) load_wt(ks + 1, tnxt);
                 PINN_UNROLL for (int q = 0; q < NG; ++q)
-                    PINN_UNROLL for (int mi = 0; mi < MT; ++mi) Gn[q][mi] = mfma16(tcur[mi], G[q][mo][rr], Gn[q][mi]);
-                PINN_UNROLL for (int mi = 0; mi < MT; ++mi) tcur[mi] = tnxt[mi];
+                    PINN_UNROLL for (int mi = 0; mi < MT; ++mi)
+                        Gn[q][mi] = mfma16((WRES && BWD) ? tres[(WRES && BWD) ? hl : 0][(WRES && BWD) ? ks : 0][mi] : tcur[mi], G[q][mo][rr], Gn[q][mi]);
+                if (!WRES) { PINN_UNROLL for (int mi = 0; mi < MT; ++mi) tcur[mi] = tnxt[mi]; }
             }
             PINN_UNROLL for (int q = 0; q < NG; ++q)
                 PINN_UNROLL for (int m = 0; m < MT; ++m) G[q][m] = Gn[q][m];
@@ -929,53 +1000,57 @@ DEV void wave_main(const GroupArgs& ga, int blk, int nblocks, int w, float* lds_
         }
     }  // tiles
 
-    if (MODE == MODE_LOSS && cur_term >= 0) ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[cur_term].term_id] = wave_sum_dd(lsum, g0);
+    if (MODE == MODE_LOSS && cur_term >= 0) lp_store(ga.terms[cur_term].term_id, wave_sum_dd(lsum, g0));
     if (!BWD) return;
 
     // =========================== epilogue: gradient slab ===========================
     if (cur_term >= 0) {
         double s = wave_sum_dd(lsum, g0);
-        ga.losspart[(size_t)wave * ga.nterms_total + ga.terms[cur_term].term_id] = s;
+        lp_store(ga.terms[cur_term].term_id, s);
     }
     // per-workgroup slab: [shared section | 4 x per-wave section]; COOP: dW / hidden-bias rows are written by their
     // owner wave into the shared section, everything else (and everything for small nets) is per wave.
     float* slab_wg = ga.slabs + (size_t)blk * S::SLAB;
     float* mine = slab_wg + S::SH + w * S::PW;
     float* big = S::COOP ? slab_wg : mine;
+    const ubuf SLW = ub_make(slab_wg, S::SLAB);
+    auto st4 = [&](float* p, vint i, const vfloat4& x) { if (WTHRU) ub_store4_wt(SLW, vint((int)(p - slab_wg)) + i, x); else gstore4(p, i, x); };
+    auto stm = [&](float* p, vint i, vfloat x, vbool m) { if (WTHRU) gstore_masked_wt(p, i, x, m); else gstore_masked(p, i, x, m); };
     PINN_UNROLL for (int hl = 0; hl < NHH; ++hl)
         PINN_UNROLL for (int to = 0; to < WT; ++to) {
             const int trow = S::COOP ? w : to;
             PINN_UNROLL for (int ti = 0; ti < MT; ++ti)
-                gstore4(big + S::O_WBAR + hl * HP * HP, vint((trow * MT + ti) * 256) + (lane << 2), wbar[hl][to][ti]);
+                st4(big + S::O_WBAR + hl * HP * HP, vint((trow * MT + ti) * 256) + (lane << 2), wbar[hl][to][ti]);
             vfloat v = bfrh[hl][to];
             v = xrow_allsum(v);
-            gstore_masked(big + S::O_BFRH, vint((hl * MT + trow) * 16) + c, v, g0);
+            stm(big + S::O_BFRH, vint((hl * MT + trow) * 16) + c, v, g0);
         }
     PINN_UNROLL for (int to = 0; to < MT; ++to) {
         vfloat v = bfr0[to];
         v = xrow_allsum(v);
-        gstore_masked(mine + S::O_BFR0, vint(to * 16) + c, v, g0);
+        stm(mine + S::O_BFR0, vint(to * 16) + c, v, g0);
     }
     PINN_UNROLL for (int i = 0; i < D; ++i)
         PINN_UNROLL for (int to = 0; to < MT; ++to) {
             vfloat v = w1fr[i][to];
             v = xrow_allsum(v);
-            gstore_masked(mine + S::O_W1, vint((i * MT + to) * 16) + c, v, g0);
+            stm(mine + S::O_W1, vint((i * MT + to) * 16) + c, v, g0);
         }
     const vbool c0 = veq(c, 0);
     PINN_UNROLL for (int m = 0; m < MT; ++m)
         PINN_UNROLL for (int r = 0; r < 4; ++r) {
             vfloat v = wLbar[m][r];
             v = row_allsum16(v);
-            gstore_masked(mine + S::O_WL, ((vint(m * 4) + g) << 2) + vint(r), v, c0);
+            stm(mine + S::O_WL, ((vint(m * 4) + g) << 2) + vint(r), v, c0);
         }
     {
         vbool all = vlt(lane, 64);
         float s = (float)wave_sum_d(bLbar, all);
-        gstore_masked(mine + S::O_BL, vint(0), vfloat(s), veq(lane, 0));
+        stm(mine + S::O_BL, vint(0), vfloat(s), veq(lane, 0));
         PINN_UNROLL for (int j = 0; j < MAX_PARAMS; ++j) {
-            float sp = (float)wave_sum_d(pbar[j], all);
-            gstore_masked(mine + S::O_P, vint(j), vfloat(sp), veq(lane, 0));
+            // (no estimated PDE parameters: the sums are zero — four 64-lane double reductions, 48 dependent cross-lane moves, off a one-tile launch)
+            float sp = ga.nparams_estim > 0 ? (float)wave_sum_d(pbar[j], all) : 0.f;
+            stm(mine + S::O_P, vint(j), vfloat(sp), veq(lane, 0));
         }
     }
 }

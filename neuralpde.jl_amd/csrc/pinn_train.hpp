@@ -1,0 +1,215 @@
+// pinn_train.hpp — K optimiser iterations of a SMALL problem in ONE launch (family 1: one wave per point tile).
+//
+// The reference's own regime — 12..32-wide networks on 100..1,000 collocation points, trained for thousands of Adam iterations
+// (test/NNPDE1/nnpde__pde_ii_2d_poisson.jl:83-85: solve(prob, Adam(0.1); maxiters = 4000) over full_loss_function,
+// src/discretize.jl:567-598) — is launch-bound on a GPU: the stand-alone loop (engine.cpp: adam_loop) pays three dependent launches per
+// iteration (residual kernel -> fixed-order reduction -> Adam + weight-image scatter), each a few microseconds of work behind a kernel
+// boundary, a grid ramp and first-touch cache misses.  Here the whole iteration is one pass of a persistent kernel whose workgroups are
+// all resident (at most REDUCE_DIRECT_MAX = 32 workgroups on 256 CUs):
+//
+//     for step = 1 .. K:
+//         wave_main<MODE_FUSED>         forward jets + residual tape + reverse sweep of this wave's tiles  -> gradient slabs, loss partials
+//         grid barrier                  (agent-scope release / acquire, vec.hpp: grid_barrier)
+//         update                        every thread of the grid owns theta elements r, r + grid, ...: the fixed-order sum of the slab
+//                                       entries over the workgroups (the association of aux::reduce_direct_body), the Adam rule
+//                                       (update_rules.hpp), the new value scattered into the packed weight image (inverse pack map);
+//                                       K more threads: the per-term sums of squares
+//         grid barrier
+//         (one lane)                    loss history of the step
+//
+// Same arithmetic, same association, same rounding as the three stand-alone kernels: K iterations in one launch equal K single steps
+// BIT FOR BIT (tests/test_train_kernel.py; GPU mirror in tests/test_gpu_mirror.py).  Not eligible (the engine takes the loop): more
+// workgroups than the one-stage reduction covers, on-device resampling, estimated PDE parameters, several networks or launch groups,
+// communicators, sin / per-layer activations, the float64 mode.
+#pragma once
+#include "pinn_kernels.hpp"
+#include "update_rules.hpp"
+
+namespace pk {
+
+struct TrainArgs {
+    // reduction inputs: the launch's gradient slabs and per-wave loss partials, the theta -> slab-entry map of the (single) launch group
+    const float* slabs;          // [nblocks][slab_floats]
+    const double* losspart;      // [nblocks * 4][K]
+    const int* row_ptr;          // [P + 1]
+    const int* row_ent;          // slab entry of every contribution
+    int slab_floats, nblocks;
+    float* out;                  // [P gradient | K raw per-term sums of squares] of the last step
+    double* lossraw;             // [K] the same sums in double
+    // Adam state, resident
+    float* theta; float* m; float* v;
+    float lr, b1, b2, eps;
+    const float* c12;            // [2 * nsteps]: 1 / (1 - b1^t), 1 / (1 - b2^t) of every step of this launch
+    const int* inv_ptr;          // theta element -> positions in the packed weight image
+    const int* inv_pos;
+    float* packed;               // the image the residual kernel reads (GroupArgs::packed)
+    double* hist;                // [nsteps] total weighted loss of every step's evaluation
+    const float* w_over_n;       // [K]
+    float* sums2;                // [2][K]: the K sums of the even / odd steps (the history entry of a step is written one update later)
+    int P, K, nsteps;
+    int cached;                  // every thread of the grid owns at most ONE element of [0, P + K) with at most TRAIN_MAX_CONTRIB slab entries and
+                                 // TRAIN_MAX_POS image positions: its maps and its (theta, m, v) stay in registers across the steps
+    unsigned* bar;               // [0] arrival counter of the grid barrier, [1] time-out flag (both zeroed by the host before the launch)
+};
+
+constexpr int TRAIN_MAX_CONTRIB = 4, TRAIN_MAX_POS = 4;
+
+// PINN_TRAIN_WT (default 1): what crosses workgroups inside the launch — gradient slabs, loss partials, the weight image, the K sums — is
+// stored WRITE-THROUGH (sc1) and read with agent-scope loads, so the two grid barriers of an iteration need no release / acquire fence
+// (vec.hpp: grid_barrier_wt; cdna_hip_programming.md Guideline 16, forms R1 / R2).  0: plain stores and loads between fenced barriers.
+#ifndef PINN_TRAIN_WT
+#define PINN_TRAIN_WT 1
+#endif
+constexpr bool TRAIN_WT = PINN_TRAIN_WT != 0;
+template <class T> DEV T train_ld(const T* p) { return TRAIN_WT ? uload_wt(p) : *p; }
+template <class T> DEV void train_st(T* p, T x) { if (TRAIN_WT) ustore_wt(p, x); else *p = x; }
+DEV void train_barrier(unsigned* bar, unsigned target) { if (TRAIN_WT) grid_barrier_wt(bar, target); else grid_barrier(bar, target); }
+
+// profiling build only (-DPINN_STAMP, tools/time_adam_loop.py --stamps): thread 0 of the launch accumulates the s_memtime ticks of the four
+// phases of an iteration — evaluation, barrier, update, barrier — into bar[4 .. 11] (64-bit sums); never defined for the product
+#if defined(PINN_STAMP) && !defined(PINN_EMU)
+#define TRAIN_STAMP_DECL unsigned long long tst_acc[4] = {0, 0, 0, 0}, tst_last = __builtin_amdgcn_s_memtime();
+#define TRAIN_STAMP(i) { const unsigned long long tst_now = __builtin_amdgcn_s_memtime(); tst_acc[i] += tst_now - tst_last; tst_last = tst_now; }
+#define TRAIN_STAMP_STORE if (first) { for (int i_ = 0; i_ < 4; ++i_) reinterpret_cast<unsigned long long*>(ta.bar + 4)[i_] = tst_acc[i_]; }
+#else
+#define TRAIN_STAMP_DECL
+#define TRAIN_STAMP(i)
+#define TRAIN_STAMP_STORE
+#endif
+
+// the K raw sums of squares of a step: column k of the per-wave loss partials in wave order, one double accumulator (aux::reduce_direct_body)
+DEV void train_sum_elem(int k, const TrainArgs& a, int step) {
+    const double* p = a.losspart + k;
+    const int nw = a.nblocks * 4;
+    double s = 0.0;
+#ifdef PINN_EMU
+    for (int wv_ = 0; wv_ < nw; ++wv_) s += train_ld(p + (size_t)wv_ * a.K);
+#else
+    // all of a chunk's loads in flight before the first add.  Every load is UNCONDITIONAL (rows past the end re-read row 0) and only the
+    // add is selected: a load under a lane-dependent condition becomes a branch with the wait for its result at the join, i.e. one full
+    // L2 round trip per load (measured on MI355X: 29 us for 68 loads per lane)
+    for (int w0 = 0; w0 < nw; w0 += 64) {
+        double q[64];
+        PINN_UNROLL for (int b = 0; b < 64; ++b) q[b] = train_ld(p + (size_t)((w0 + b < nw) ? w0 + b : 0) * a.K);
+        PINN_UNROLL for (int b = 0; b < 64; ++b) s = (w0 + b < nw) ? s + q[b] : s;
+    }
+#endif
+    a.out[a.P + k] = (float)s;
+    train_st(a.sums2 + (step & 1) * a.K + k, (float)s);
+    if (a.lossraw) a.lossraw[k] = s;
+}
+// total weighted loss of step `step` (aux::total_loss_body) from the sums its update left in sums2
+DEV void train_hist(const TrainArgs& a, int step) {
+    double s = 0.0;
+    for (int k = 0; k < a.K; ++k) s += (double)train_ld(a.sums2 + (step & 1) * a.K + k) * (double)a.w_over_n[k];
+    a.hist[step] = s;
+}
+
+// element r of [0, P + K) after a step's evaluation (general form: maps and state read from memory every step)
+DEV void train_update_elem(int r, const TrainArgs& a, int step) {
+    if (r < a.P) {
+        // the association of aux::reduce_direct_body: contributions in map order, workgroups in launch order, one double accumulator
+        double s = 0.0;
+        const int i0 = a.row_ptr[r], i1 = a.row_ptr[r + 1];
+        for (int i = i0; i < i1; ++i) {
+            const float* p = a.slabs + a.row_ent[i];
+            for (int b = 0; b < a.nblocks; ++b) s += (double)train_ld(p + (size_t)b * a.slab_floats);
+        }
+        const float g = (float)s;
+        a.out[r] = g;
+        float mi = a.m[r], vi = a.v[r];
+        const float t = ur::adam_update(a.theta[r], mi, vi, g, a.lr, a.b1, a.b2, a.eps, a.c12[2 * step], a.c12[2 * step + 1]);
+        a.m[r] = mi;
+        a.v[r] = vi;
+        a.theta[r] = t;
+        for (int q = a.inv_ptr[r]; q < a.inv_ptr[r + 1]; ++q) train_st(a.packed + (a.inv_pos[q] & 0xFFFFFF), t);
+    } else if (r < a.P + a.K) train_sum_elem(r - a.P, a, step);
+}
+
+// cached form (TrainArgs::cached): what a thread keeps across the steps for the one element it owns.  Per step only the slab entries are
+// read — every load of the step in flight at once, ONE L2 round trip — instead of three dependent index / state round trips first
+struct TrainOwn {
+    int r, n, npos;
+    int ent[TRAIN_MAX_CONTRIB], pos[TRAIN_MAX_POS];
+    float th, m, v;
+};
+DEV void train_own_init(TrainOwn& o, int r, const TrainArgs& a) {
+    o.r = r; o.n = 0; o.npos = 0; o.th = o.m = o.v = 0.f;
+    PINN_UNROLL for (int j = 0; j < TRAIN_MAX_CONTRIB; ++j) o.ent[j] = 0;
+    PINN_UNROLL for (int j = 0; j < TRAIN_MAX_POS; ++j) o.pos[j] = 0;
+    if (r < a.P) {
+        const int i0 = a.row_ptr[r], q0 = a.inv_ptr[r];
+        o.n = a.row_ptr[r + 1] - i0;
+        o.npos = a.inv_ptr[r + 1] - q0;
+        PINN_UNROLL for (int j = 0; j < TRAIN_MAX_CONTRIB; ++j) if (j < o.n) o.ent[j] = a.row_ent[i0 + j];
+        PINN_UNROLL for (int j = 0; j < TRAIN_MAX_POS; ++j) if (j < o.npos) o.pos[j] = a.inv_pos[q0 + j] & 0xFFFFFF;
+        o.th = a.theta[r]; o.m = a.m[r]; o.v = a.v[r];
+    }
+}
+DEV void train_own_step(TrainOwn& o, const TrainArgs& a, int step) {
+    const int r = o.r;
+    if (r < a.P) {
+        double s = 0.0;
+#ifdef PINN_EMU
+        for (int j = 0; j < o.n; ++j)
+            for (int b = 0; b < a.nblocks; ++b) s += (double)train_ld(a.slabs + (size_t)o.ent[j] + (size_t)b * a.slab_floats);
+#else
+        float q[TRAIN_MAX_CONTRIB][32];                       // (the launch has at most 32 workgroups)
+        PINN_UNROLL for (int j = 0; j < TRAIN_MAX_CONTRIB; ++j)          // unconditional loads (see train_sum_elem): unused slots re-read entry ent[j] of workgroup 0
+            PINN_UNROLL for (int b = 0; b < 32; ++b) q[j][b] = train_ld(a.slabs + (size_t)o.ent[j] + (size_t)((b < a.nblocks) ? b : 0) * a.slab_floats);
+        PINN_UNROLL for (int j = 0; j < TRAIN_MAX_CONTRIB; ++j)
+            PINN_UNROLL for (int b = 0; b < 32; ++b) s = (j < o.n && b < a.nblocks) ? s + (double)q[j][b] : s;
+#endif
+        const float g = (float)s;
+        a.out[r] = g;
+        const float t = ur::adam_update(o.th, o.m, o.v, g, a.lr, a.b1, a.b2, a.eps, a.c12[2 * step], a.c12[2 * step + 1]);
+        o.th = t;
+        a.m[r] = o.m;
+        a.v[r] = o.v;
+        a.theta[r] = t;
+        PINN_UNROLL for (int j = 0; j < TRAIN_MAX_POS; ++j) if (j < o.npos) train_st(a.packed + o.pos[j], t);
+    } else if (r < a.P + a.K) train_sum_elem(r - a.P, a, step);
+}
+
+// the wave program of the training kernel: workgroup `blk` of `nblocks`, wave `w` of the workgroup
+template <class S, int ACTK>
+DEV void wave_train(const GroupArgs& ga, const TrainArgs& ta, int blk, int nblocks, int w, float* lds) {
+    unsigned arrivals = 0;
+#ifdef PINN_EMU
+    const int gid0 = (blk * 4 + w) * 64;                      // first of this wave's 64 threads
+    TrainOwn own[64];
+    if (ta.cached) for (int l = 0; l < 64; ++l) train_own_init(own[l], gid0 + l, ta);
+    const bool first = (blk == 0 && w == 0);
+#else
+    const int gid0 = blk * 256 + (int)threadIdx.x;
+    TrainOwn own;
+    if (ta.cached) train_own_init(own, gid0, ta);
+    const bool first = (gid0 == 0);
+#endif
+    TRAIN_STAMP_DECL
+    for (int step = 0; step < ta.nsteps; ++step) {
+        wave_main<S, MODE_FUSED, ACTK, TRAIN_WT>(ga, blk, nblocks, w, lds);
+        TRAIN_STAMP(0)
+        arrivals += (unsigned)nblocks;
+        train_barrier(ta.bar, arrivals);                      // every workgroup's slabs and loss partials are visible
+        TRAIN_STAMP(1)
+        if (first && step > 0) train_hist(ta, step - 1);      // the previous step's loss: its K sums were written one barrier ago
+#ifdef PINN_EMU
+        for (int l = 0; l < 64; ++l) {
+            if (ta.cached) train_own_step(own[l], ta, step);
+            else for (int r = gid0 + l; r < ta.P + ta.K; r += nblocks * 256) train_update_elem(r, ta, step);
+        }
+#else
+        if (ta.cached) train_own_step(own, ta, step);
+        else for (int r = gid0; r < ta.P + ta.K; r += nblocks * 256) train_update_elem(r, ta, step);
+#endif
+        TRAIN_STAMP(2)
+        arrivals += (unsigned)nblocks;
+        train_barrier(ta.bar, arrivals);                      // the new parameters (theta, weight image) and the K sums are visible
+        TRAIN_STAMP(3)
+    }
+    if (first && ta.nsteps > 0) train_hist(ta, ta.nsteps - 1);
+    TRAIN_STAMP_STORE
+}
+
+}  // namespace pk

@@ -651,7 +651,8 @@ static int plan_pack_maps(pinn_engine& E) {
         }
         if (E.inv_ok) {
             std::vector<int> ptr{0}, pos;
-            for (auto& v : inv) { pos.insert(pos.end(), v.begin(), v.end()); ptr.push_back((int)pos.size()); }
+            E.max_inv_pos = 0;
+            for (auto& v : inv) { pos.insert(pos.end(), v.begin(), v.end()); ptr.push_back((int)pos.size()); E.max_inv_pos = std::max(E.max_inv_pos, (int)v.size()); }
             E.d_inv_ptr = (int*)plat_malloc(sizeof(int) * ptr.size());
             E.d_inv_pos = (int*)plat_malloc(sizeof(int) * std::max<size_t>(pos.size(), 1));
             if (!E.d_inv_ptr || !E.d_inv_pos) return fail("device allocation failed (inverse pack map)");
@@ -800,7 +801,7 @@ static int plan_group_buffers(pinn_engine& E) {
                 mine.push_back(I);
             }
             T.lin = LinearForm();
-            T.linear = s.family == 2 && detect_linear(mine, T.d, E.np, s.C, nsrc, remap(T.out_row), T.lin);
+            T.linear = (s.family == 2 || s.family == 1) && detect_linear(mine, T.d, E.np, s.C, nsrc, remap(T.out_row), T.lin);
             if (nsrc > 0) {
                 T.d_src_prog = (rp::Instr*)plat_malloc(sizeof(rp::Instr) * T.src_prog.size());
                 if (!T.d_src_prog) return fail("device allocation failed (source programs)");
@@ -970,7 +971,9 @@ static int plan_global_reduce_map(pinn_engine& E) {
                     contrib[Cp.row_theta[r]].push_back({(int)(E.groups.size() + c), Cp.row_off[e]});
         }
         std::vector<int> ptr{0}, grp, ent;
+        E.max_contrib = 0;
         for (auto& c : contrib) {
+            E.max_contrib = std::max(E.max_contrib, (int)c.size());
             for (auto& pr : c) { grp.push_back(pr.first); ent.push_back(pr.second); }
             ptr.push_back((int)grp.size());
         }

@@ -56,6 +56,26 @@ void run_emu(const GroupArgs& ga, int blocks) {
         for (int w = 0; w < 4; ++w) th[w].join();
     }
 }
+// the training kernel's grid barrier needs EVERY wave of the launch alive at once: blocks x 4 host threads, one barrier per workgroup
+// (wg_barrier) and one over all of them (grid_barrier)
+template <class S, int ACTK>
+void run_emu_train(const GroupArgs& ga, const TrainArgs& ta, int blocks) {
+    std::vector<std::vector<float>> lds((size_t)blocks, std::vector<float>((size_t)S::LDS_WG, 0.f));
+    std::vector<EmuBarrier> bars((size_t)blocks);
+    EmuBarrier grid;
+    grid.nwaves = 4 * blocks;
+    std::vector<std::thread> th;
+    for (int b = 0; b < blocks; ++b)
+        for (int w = 0; w < 4; ++w)
+            th.emplace_back([&, b, w] {
+                wv::emu_barrier_hook = &EmuBarrier::wait;
+                wv::emu_barrier_ctx = &bars[(size_t)b];
+                wv::emu_grid_hook = &EmuBarrier::wait;
+                wv::emu_grid_ctx = &grid;
+                wave_train<S, ACTK>(ga, ta, b, blocks, w, lds[(size_t)b].data());
+            });
+    for (auto& t : th) t.join();
+}
 template <class S, int MODE, int ACTK>
 void run_emu2(const GroupArgs& ga, int blocks) {
     std::vector<float> lds((size_t)S::LDS_WG);
@@ -93,10 +113,12 @@ void run_emu2m(const GroupArgs& ga, int blocks) {
 #define PINN_LAUNCH2(S, MODE, ACTK, ga, blocks, st) run_emu2<S, MODE, ACTK>(ga, blocks)
 #define PINN_LAUNCH2M(S0, S1, ACTK, MODE, ga, blocks, st) run_emu2m<S0, S1, ACTK, MODE>(ga, blocks)
 #define PINN_LAUNCH1(S, MODE, ACTK, ga, blocks, st) run_emu<S, MODE, ACTK>(ga, blocks)
+#define PINN_LAUNCH_TRAIN(S, ACTK, ga, ta, blocks, st) run_emu_train<S, ACTK>(ga, ta, blocks)
 #else
 #define PINN_LAUNCH2(S, MODE, ACTK, ga, blocks, st) hipLaunchKernelGGL((k_wave2<S, MODE, ACTK>), dim3(blocks), dim3(64 * S::NW), 0, st, ga)
 #define PINN_LAUNCH2M(S0, S1, ACTK, MODE, ga, blocks, st) hipLaunchKernelGGL((k_wave2m<S0, S1, ACTK, MODE>), dim3(blocks), dim3(64 * S0::NW), 0, st, ga)
 #define PINN_LAUNCH1(S, MODE, ACTK, ga, blocks, st) hipLaunchKernelGGL((k_wave<S, MODE, ACTK>), dim3(blocks), dim3(256), 0, st, ga)
+#define PINN_LAUNCH_TRAIN(S, ACTK, ga, ta, blocks, st) hipLaunchKernelGGL((k_train<S, ACTK>), dim3(blocks), dim3(256), 0, st, ga, ta)
 #endif
 
 // The activation kind is a template parameter of the kernels (ACTK): tanh and sigmoid variants for every spec; sin variants (sincos in
@@ -126,6 +148,12 @@ template <class S> void launch_spec2(const GroupArgs& ga, int mode, int blocks, 
 }
 template <class S> void launch_spec(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
     if (ga.act == ACT_TANH) launch_modes1<S, ACT_TANH>(ga, mode, blocks, st); else launch_modes1<S, ACT_SIGMOID>(ga, mode, blocks, st);
+}
+// the training kernel of a family-1 spec (tanh / sigmoid; the engine keeps the stand-alone loop for the other activations)
+template <class S> void launch_train(const GroupArgs& ga, const TrainArgs& ta, int blocks, plat_stream st) {
+    (void)st;
+    static_assert(sizeof(GroupArgs) + sizeof(TrainArgs) <= 4096, "kernel arguments of k_train");
+    if (ga.act == ACT_TANH) PINN_LAUNCH_TRAIN(S, ACT_TANH, ga, ta, blocks, st); else PINN_LAUNCH_TRAIN(S, ACT_SIGMOID, ga, ta, blocks, st);
 }
 template <class S0, class S1> void launch_pair2(const GroupArgs& ga, int mode, int blocks, plat_stream st) {
     (void)st;
@@ -225,6 +253,15 @@ PairInfo make_pair_info() {
 #else
 #define PINN_F2_IF_FP32(...)
 #endif
+// PINN_F1_TRAIN=0 leaves the training kernels out of a translation unit (A/B builds)
+#ifndef PINN_F1_TRAIN
+#define PINN_F1_TRAIN 1
+#endif
+#if PINN_F1_TRAIN
+#define PINN_TRAIN_OF(S) (&pk::launch_train<S>)
+#else
+#define PINN_TRAIN_OF(S) nullptr
+#endif
 template <class S> struct Launch2Plain { static void fn(const GroupArgs& ga, int mode, int blocks, plat_stream st) { launch_spec2<S>(ga, mode, blocks, st); } };
 template <class S> struct Launch2Sin { static void fn(const GroupArgs& ga, int mode, int blocks, plat_stream st) { launch_spec2_sin<S>(ga, mode, blocks, st); } };
 template <class S, template <class> class L, bool ENABLE> struct Registrar2 {
@@ -246,20 +283,20 @@ template <class S0, class S1> struct PairRegistrar2<S0, S1, false> { PairRegistr
 #define PINN_INSTANTIATE_HI(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI)                  \
     namespace {                                                                              \
     using NAME##_spec = pk::Spec<HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI>;                  \
-    pk::Registrar NAME##_reg(pk::make_info<NAME##_spec>(&pk::launch_spec<NAME##_spec>));     \
+    pk::Registrar NAME##_reg(pk::make_info<NAME##_spec>(&pk::launch_spec<NAME##_spec>, 0, PINN_TRAIN_OF(NAME##_spec))); \
     }
 // the same with the sin-activation kernels compiled in as well
 #define PINN_INSTANTIATE2_HI_SIN(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI) PINN_INSTANTIATE2_ANY(NAME, Launch2Sin, 1, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI)
 #define PINN_INSTANTIATE_HI_SIN(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI)              \
     namespace {                                                                              \
     using NAME##_spec = pk::Spec<HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI>;                  \
-    pk::Registrar NAME##_reg(pk::make_info<NAME##_spec>(&pk::launch_spec_sin<NAME##_spec>, 1)); \
+    pk::Registrar NAME##_reg(pk::make_info<NAME##_spec>(&pk::launch_spec_sin<NAME##_spec>, 1, PINN_TRAIN_OF(NAME##_spec))); \
     }
 // family 1 spec that also carries the per-layer tanh / sigmoid variant (small nets such as the reference's Dense(1, 8, tanh), Dense(8, 8, sigma))
 #define PINN_INSTANTIATE_HI_MIX(NAME, HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI)                  \
     namespace {                                                                              \
     using NAME##_spec = pk::Spec<HP, NHH, D, D1MASK, PAIRS, NPAIR, PG, HI>;                  \
-    pk::Registrar NAME##_reg(pk::make_info<NAME##_spec>(&pk::launch_spec_mix<NAME##_spec>, 2)); \
+    pk::Registrar NAME##_reg(pk::make_info<NAME##_spec>(&pk::launch_spec_mix<NAME##_spec>, 2, PINN_TRAIN_OF(NAME##_spec))); \
     }
 // DGM network (family 3): modes padded to MP, L gated layers, D inputs, jet set, gate activation ACT1, output-gate activation ACT2
 #define PINN_INSTANTIATE_DGM(NAME, MP, L, D, D1MASK, PAIRS, NPAIR, HI, ACT1, ACT2)           \

@@ -105,6 +105,14 @@ inline vfloat4 ub_load4(const ubuf& b, int soff, const vint& voff) { vfloat4 r; 
 inline vfloat4 ub_load4_sc1(const ubuf& b, int soff, const vint& voff) { return ub_load4(b, soff, voff); }
 inline void ub_store4(const ubuf& b, int soff, const vint& voff, const vfloat4& x) { for (int k = 0; k < 4; ++k) for (int l = 0; l < W; ++l) b.p[soff + voff.v[l] + k] = x.x[k].v[l]; }
 inline vfloat ub_load(const ubuf& b, int soff, const vint& voff) { vfloat r; for (int l = 0; l < W; ++l) r.v[l] = b.p[soff + voff.v[l]]; return r; }
+inline vfloat ub_load_sc1(const ubuf& b, int soff, const vint& voff) { return ub_load(b, soff, voff); }
+// agent-scope write-through stores / loads of data another workgroup reads inside the same launch (device: sc1)
+inline void ub_store4_wt(const ubuf& b, const vint& voff, const vfloat4& x) { for (int k = 0; k < 4; ++k) for (int l = 0; l < W; ++l) b.p[voff.v[l] + k] = x.x[k].v[l]; }
+inline void gstore_masked_wt(float* p, const vint& i, const vfloat& x, const vbool& m) { for (int l = 0; l < W; ++l) if (m.v[l]) p[i.v[l]] = x.v[l]; }
+inline void ustore_wt(double* p, double x) { *p = x; }
+inline void ustore_wt(float* p, float x) { *p = x; }
+inline float uload_wt(const float* p) { return *p; }
+inline double uload_wt(const double* p) { return *p; }
 // LDS (per-wave private region in the emulation == a plain array)
 inline vfloat lds_load(const float* p, const vint& i) { return gload(p, i); }
 inline void lds_store(float* p, const vint& i, const vfloat& x) { gstore(p, i, x); }
@@ -115,6 +123,11 @@ inline void wave_fence() {}
 extern thread_local void (*emu_barrier_hook)(void*);
 extern thread_local void* emu_barrier_ctx;
 inline void wg_barrier() { if (emu_barrier_hook) emu_barrier_hook(emu_barrier_ctx); }
+// grid barrier of the persistent training kernel (pinn_train.hpp): the emulation runs EVERY wave of the launch as a host thread
+extern thread_local void (*emu_grid_hook)(void*);
+extern thread_local void* emu_grid_ctx;
+inline void grid_barrier(unsigned*, unsigned) { if (emu_grid_hook) emu_grid_hook(emu_grid_ctx); }
+inline void grid_barrier_wt(unsigned*, unsigned) { if (emu_grid_hook) emu_grid_hook(emu_grid_ctx); }
 // cross-lane
 inline vfloat shfl_xor(const vfloat& a, int m) { vfloat r; for (int l = 0; l < W; ++l) r.v[l] = a.v[l ^ m]; return r; }
 // all-reduce sums without LDS traffic (device: DPP row rotations / gfx950 permlane swaps)
@@ -429,6 +442,22 @@ DEV void ub_store4(ubuf b, int soff, vint voff, vfloat4 x) {
 DEV vfloat ub_load(ubuf b, int soff, vint voff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, voff * 4, soff * 4, 0));
 }
+DEV vfloat ub_load_sc1(ubuf b, int soff, vint voff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, voff * 4, soff * 4, 16));
+}
+// Agent-scope WRITE-THROUGH stores (sc1) and agent-scope loads of data that another workgroup reads / wrote inside the same launch (the
+// training kernel's gradient slabs, loss partials and weight image): such data needs no release / acquire fence around the grid barrier
+// (cdna_hip_programming.md Guideline 16, forms R1 / R2) — every storing wave drains its stores (s_waitcnt vmcnt(0)) before the arrival.
+// 16-byte write-through store through a buffer view (one store: four 4-byte sc1 stores would be the slow "narrow re-issue" form of a bulk
+// publish); everything in the per-lane offset, no SGPR offset: the form whose store-data hazard the compiler pads (see store_pad above)
+DEV void ub_store4_wt(ubuf b, vint voff, vfloat4 x) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vuint4, x), b.r, voff * 4, 0, 16);
+}
+DEV void gstore_masked_wt(float* p, vint i, vfloat x, vbool m) { if (m) __hip_atomic_store(p + i, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void ustore_wt(double* p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void ustore_wt(float* p, float x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV float uload_wt(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV double uload_wt(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV vfloat lds_load(const float* p, vint i) { return p[i]; }
 DEV void lds_store(float* p, vint i, vfloat x) { p[i] = x; }
 DEV vfloat4 lds_load4(const float* p, vint i) { return *reinterpret_cast<const vfloat4*>(p + i); }
@@ -445,6 +474,48 @@ DEV void wave_fence() {
 #define PINN_PROBE 0
 #endif
 DEV void wg_barrier() { if (!(PINN_PROBE & 4)) __syncthreads(); }
+// Grid barrier of a launch whose workgroups are ALL resident (pinn_train.hpp: at most one workgroup per CU, far fewer workgroups than
+// CUs).  bar[0]: monotonic arrival counter, zeroed by the host before the launch; `target` = arrivals expected so far (workgroups x
+// barriers passed); bar[1]: time-out flag.  Protocol of cdna_hip_programming.md Guideline 16 in its counter form: every wave drains its
+// stores, the workgroup meets, ONE lane releases at agent scope (L2 write-back: the other XCDs' L2s are not coherent with this one),
+// arrives, polls the one word with relaxed agent-scope loads + s_sleep, acquires ONCE (drops this CU's stale L1 / non-local L2 lines), and
+// the workgroup meets again.  Every spin is bounded: a launch that is not fully resident sets bar[1] and runs to its end with wrong numbers
+// instead of hanging the device (the host checks the flag and fails the call).
+DEV void grid_barrier(unsigned* bar, unsigned target) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (restates the wait behind the L2 write-back where the compiler cannot drop it: Guideline 16, pitfall 12)
+            __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 21)) { __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+    __syncthreads();
+}
+// the same barrier for data exchanged with write-through stores and agent-scope loads only (gstore*_wt / ustore_wt / uload_wt / ub_load*_sc1):
+// no release, no acquire — the arrival follows the drain of every wave's stores, the loads behind it bypass this CU's L1
+DEV void grid_barrier_wt(unsigned* bar, unsigned target) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 21)) { __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+    }
+    __syncthreads();
+}
 DEV vfloat shfl_xor(vfloat a, int m) { return __shfl_xor(a, m, 64); }
 // all-reduce sums without LDS traffic: v_add_f32_dpp row_ror within the 16-lane rows, v_permlane16/32_swap (gfx950) across rows
 template <int CTRL> DEV float dpp_mov(float v) {
@@ -463,7 +534,7 @@ DEV vfloat xrow_allsum(vfloat v) {
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(s), "+v"(t));
     return s + t;
 }
-DEV float lane0(vfloat a) { return __builtin_amdgcn_readfirstlane(a); }
+DEV float lane0(vfloat a) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a))); }      // (the builtin is int -> int: a float argument would be truncated)
 DEV double wave_sum_d(vfloat a, vbool m) {
     double s = m ? (double)a : 0.0;
     PINN_UNROLL for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);

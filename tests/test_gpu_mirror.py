@@ -1,5 +1,5 @@
 """Hardware mirror of the CPU parity suite: every test of tests/test_emu_parity.py, tests/test_adaptive_losses.py,
-tests/test_reference_examples.py, tests/test_jit.py (kernels specialised with hipcc on the box), tests/test_sexpr_frontend.py, tests/test_dgm.py and tests/test_f64_mode.py (the float64 evaluation mode) is re-run with the PRODUCT library (libpinn_hip.so on a gfx950 device) instead of the g++ lock-step
+tests/test_reference_examples.py, tests/test_jit.py (kernels specialised with hipcc on the box), tests/test_sexpr_frontend.py, tests/test_dgm.py, tests/test_f64_mode.py (the float64 evaluation mode) and tests/test_train_kernel.py (the persistent training kernel against the stand-alone loop, bit for bit) is re-run with the PRODUCT library (libpinn_hip.so on a gfx950 device) instead of the g++ lock-step
 emulation — same statements, same float64 oracle, same 1e-5 tolerance.  This is where the per-term gradients (pinn_term_grads), the
 BPINN physics log-likelihood, the resident-theta Adam loop (against a host Adam), the device samplers and the adaptive-weight rules
 are checked against the oracle ON THE GPU ("Next round" item 1b)."""
@@ -14,13 +14,14 @@ import test_f64_mode as tf
 import test_jit as tj
 import test_reference_examples as tr
 import test_sexpr_frontend as ts
+import test_train_kernel as tk
 
 pytestmark = pytest.mark.gpu
 
 
 def _cases():
     out = []
-    for mod in (tp, ta, tr, tj, ts, td, tf):
+    for mod in (tp, ta, tr, tj, ts, td, tf, tk):
         for name, fn in sorted(vars(mod).items()):
             if not (name.startswith("test_") and inspect.isfunction(fn) and fn.__module__ == mod.__name__):
                 continue

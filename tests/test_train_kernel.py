@@ -1,0 +1,68 @@
+"""The persistent training kernel (csrc/pinn_train.hpp): K Adam iterations of a small problem inside ONE launch — evaluation, fixed-order
+reduction, update and weight-image scatter per iteration, two grid barriers — against the stand-alone loop (three launches per iteration).
+Same arithmetic and association: bit-identical parameters and loss histories, across a resume.  Runs the kernel SOURCES on the host
+emulation (every wave of the launch a thread); the GPU mirror is tests/test_gpu_mirror.py::test_persistent_training_kernel_*.
+Reference loop: solve(prob, Adam(..); maxiters = ...) over full_loss_function (test/NNPDE1/nnpde__pde_ii_2d_poisson.jl:83-85,
+src/discretize.jl:567-598)."""
+import numpy as np
+import pytest
+
+from test_emu_parity import poisson2d, theta_for
+
+
+def _run(npde, eng, th, w, persistent, steps=(9, 4)):
+    eng.set_option("persistent", "on" if persistent else "off")
+    t1, h1 = eng.adam(th, steps[0], 1e-2, w)
+    path = eng.get_option("adam_path")
+    t2, h2 = eng.adam(None, steps[1], 1e-2, w, init=False)      # resume: the optimiser state stays on the device
+    return t1, h1, t2, h2, path
+
+
+def _cases(npde):
+    from neuralpde_jl_amd import workloads
+    wl = workloads.cfg1_poisson1d(100)                               # 3 x 32 tanh, 100 + 1 + 1 points: ragged last tile, 3 terms in one launch group
+    yield "cfg1_3x32_tanh", wl.pde_system, wl.chains[0], wl.strategy, wl.theta, None
+    sysm, chain = poisson2d(npde, "sigmoid", width=16, hidden=2)     # 2 x 16 sigmoid, 2-D, {u, u_x, u_y, lap u}: 25 + 4 x 5 grid points
+    yield "poisson2d_2x16_sigmoid", sysm, chain, npde.GridTraining(0.25), theta_for(chain, 7), [1.0, 2.0, 1.0, 3.0, 1.0]
+
+
+def test_persistent_training_kernel_equals_the_loop_bit_for_bit(npde, use_emu):
+    for name, sysm, chain, strat, th0, w in _cases(npde):
+        disc = npde.PhysicsInformedNN(chain, strat, init_params=th0)
+        rep = npde.symbolic_discretize(sysm, disc)
+        eng = rep.engine
+        wts = None if w is None else np.asarray(w, dtype=np.float32)
+        a = _run(npde, eng, th0, wts, False)
+        b = _run(npde, eng, th0, wts, True)
+        assert a[4] == "loop" and b[4] == "persistent", (name, a[4], b[4], eng.describe())
+        for x, y, what in zip(a[:4], b[:4], ("theta", "history", "theta after resume", "history after resume")):
+            assert np.array_equal(x, y), (name, what, np.max(np.abs(np.asarray(x) - np.asarray(y))))
+        assert np.all(np.isfinite(b[1])) and np.all(np.isfinite(b[3])) and not np.array_equal(b[0], th0.astype(np.float32))
+        # the state the kernel leaves behind serves the stand-alone entry points: the packed weight image is the current theta's
+        l1, g1 = eng.loss_grad(b[2])
+        eng.set_option("persistent", "off")
+        t3, h3 = eng.adam(b[2], 1, 1e-2, wts)
+        wn = np.ones(eng.K) if wts is None else wts.astype(np.float64)
+        assert abs(h3[0] - float(np.dot(l1, wn))) <= 1e-6 * abs(h3[0])
+
+
+def test_persistent_training_kernel_is_refused_where_it_does_not_apply(npde, use_emu, monkeypatch):
+    sysm, chain = poisson2d(npde, "tanh", width=16, hidden=2)
+    th0 = theta_for(chain, 3)
+    # on-device resampling: the loop
+    disc = npde.PhysicsInformedNN(chain, npde.StochasticTraining(64, bcs_points=32, rng=np.random.default_rng(3)), init_params=th0)
+    prob = npde.discretize(sysm, disc)
+    npde.solve(prob, npde.Adam(0.01), maxiters=3)
+    assert prob.pinnrep.engine.get_option("adam_path") == "loop"
+    # fixed sets: the kernel; the environment switch: the loop again
+    disc = npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=th0)
+    prob = npde.discretize(sysm, disc)
+    r1 = npde.solve(prob, npde.Adam(0.01), maxiters=6)
+    assert prob.pinnrep.engine.get_option("adam_path") == "persistent"
+    monkeypatch.setenv("PINN_PERSISTENT", "0")
+    prob2 = npde.discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=th0))
+    r2 = npde.solve(prob2, npde.Adam(0.01), maxiters=6)
+    assert prob2.pinnrep.engine.get_option("adam_path") == "loop"
+    assert np.array_equal(r1.u, r2.u) and np.array_equal(np.asarray(r1.losses), np.asarray(r2.losses))
+    with pytest.raises(Exception):
+        prob2.pinnrep.engine.set_option("persistent", "maybe")
