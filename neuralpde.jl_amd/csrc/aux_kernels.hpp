@@ -43,6 +43,9 @@ struct Reduce2Args {
     int ent_active[MAX_GROUPS];         // 0: this group's gradient went into another group's slabs (chained launch groups)
     int ngroups, P, K;
     int skip_grad;                      // loss-only evaluation: only the K sums are produced, out[0, P) is left alone
+    const int* perm;                    // one-stage form (k_reduce_direct): thread t sums element perm[t] of [theta | K sums] (nullable: t itself).
+                                        // The engine orders the elements by their first slab entry, so that the lanes of a wave read CONSECUTIVE
+                                        // slab entries — the slabs are in MFMA-fragment order, in theta order a wave touches 64 cache lines per load
 };
 // ONE-kernel reduction for the common case that a single slab set carries the whole gradient (one network whose launch groups are
 // merged / chained, family 2 or 3: every theta element has exactly one slab entry): a block sums 32 consecutive slab entries over all
@@ -457,7 +460,9 @@ AUX_DEV void reduce2_body(int r, const Reduce2Args& a) {
 // workgroups directly, in the fixed order (map entry, workgroup); two kernels of ~6 us each for a 17-workgroup problem were a third of
 // its evaluation time
 constexpr int REDUCE_DIRECT_MAX = 32;
-AUX_DEV void reduce_direct_body(int r, const Reduce1Args& a1, const Reduce2Args& a) {
+AUX_DEV void reduce_direct_body(int t, const Reduce1Args& a1, const Reduce2Args& a) {
+    if (t >= a.P + a.K) return;
+    const int r = a.perm ? a.perm[t] : t;
     if (r < a.P) {
         if (a.skip_grad) return;
         double s = 0.0;

@@ -336,6 +336,7 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
     a2.out = d_out; a2.sums = d_sums; a2.lossraw = lossraw ? lossraw : E.d_lossraw; a2.row_ptr = E.d_gr_ptr; a2.row_grp = E.d_gr_grp; a2.row_ent = E.d_gr_ent;
     a2.ngroups = (int)(E.groups.size() + E.coupled.size()); a2.P = (int)E.ntheta; a2.K = K;
     a2.skip_grad = loss_only ? 1 : 0;
+    a2.perm = std::getenv("PINN_NO_REDUCE_PERM") ? nullptr : E.d_red_perm;
     // one slab set carries the whole gradient (a single network whose launch groups are merged / chained): one reduction kernel
     const bool no_reduce_one = std::getenv("PINN_NO_REDUCE_ONE") != nullptr;
     const Group* RG = (nslabsets == 1 && !coupled_active && !loss_only && !no_reduce_one) ? &E.groups[slabset_group] : nullptr;
@@ -436,7 +437,7 @@ int pinn_destroy(pinn_handle h) {
     f64_destroy(E);
     free_plan(E);
     for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_upts); plat_free(T.d_resid); plat_free(T.d_lb); plat_free(T.d_ub); plat_free(T.d_data); plat_free(T.d_pw); }
-    plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist); plat_free(E.d_step); plat_free(E.d_draws); plat_free(E.d_sampled); plat_free(E.d_c12); plat_free(E.d_bar); plat_free(E.d_sums2);
+    plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist); plat_free(E.d_step); plat_free(E.d_draws); plat_free(E.d_sampled); plat_free(E.d_c12); plat_free(E.d_bar); plat_free(E.d_sums2); plat_free(E.d_own_r);
     plat_free(E.d_theta); plat_free(E.d_params); plat_free(E.d_defaults); plat_free(E.d_lossraw);
     plat_free(E.d_out); plat_free(E.d_phi_pts); plat_free(E.d_phi_out); plat_free(E.d_phi_scr);
     plat_host_free(E.hp_theta);
@@ -1178,6 +1179,10 @@ static bool train_eligible(pinn_engine& E) {
     const char* lim = std::getenv("PINN_REDUCE_DIRECT_MAX");
     const int direct_max = lim ? std::atoi(lim) : aux::REDUCE_DIRECT_MAX;
     if (G.blocks > direct_max || G.blocks > 32 || G.blocks > E.ncu) return false;
+    // every thread of the launch owns at most one element of [theta | K sums] and keeps its maps and optimiser state in registers; a launch
+    // with fewer threads than parameters (a handful of points under a comparatively large net) has nothing to win from the kernel
+    const int K = (int)E.terms.size(), P = (int)E.ntheta;
+    if (G.blocks * 256 < P + K || E.max_contrib > pk::TRAIN_MAX_CONTRIB || E.max_inv_pos > pk::TRAIN_MAX_POS) return std::getenv("PINN_TRAIN_GENERAL") != nullptr;
     return true;
 }
 // returns 0 when all nsteps ran inside the kernel, 1 on failure (g_err set)
@@ -1228,6 +1233,49 @@ static int adam_steps_train(pinn_engine& E, int nsteps, float lr, float beta1, f
     ta.sums2 = E.d_sums2;
     ta.cached = (G.blocks * 256 >= P + K && E.max_contrib <= pk::TRAIN_MAX_CONTRIB && E.max_inv_pos <= pk::TRAIN_MAX_POS &&
                  std::getenv("PINN_TRAIN_NO_CACHE") == nullptr) ? 1 : 0;
+    if (ta.cached && (!E.d_own_r || E.own_blocks != G.blocks)) {
+        // thread -> element: theta element r sits at gid = its FIRST slab entry when those are distinct and leave room for the K sums at the
+        // end of the grid (lanes of a wave then read consecutive slab entries: coalesced), else at gid = r
+        const int nthr = G.blocks * 256;
+        std::vector<int> own((size_t)nthr, -1);
+        bool by_entry = true;
+        for (size_t i = 0; i < G.row_theta.size() && by_entry; ++i) {
+            const int e0 = G.row_ptr[i] < G.row_ptr[i + 1] ? G.row_off[G.row_ptr[i]] : -1;
+            if (e0 < 0 || e0 >= nthr - K || own[(size_t)e0] >= 0) by_entry = false;
+            else own[(size_t)e0] = G.row_theta[i];
+        }
+        int placed = 0;
+        for (int v : own) placed += v >= 0;
+        if (!by_entry || placed != P || std::getenv("PINN_TRAIN_NO_COALESCE")) {
+            std::fill(own.begin(), own.end(), -1);
+            for (int r = 0; r < P; ++r) own[(size_t)r] = r;
+        } else {
+            // 64-entry groups dealt round-robin over the workgroups (group g -> workgroup g % blocks, wave g / blocks): the slab reads of an
+            // update spread over every CU of the launch instead of the first ceil(PW / 256)
+            int last = 0;
+            for (int e = 0; e < nthr; ++e) if (own[(size_t)e] >= 0) last = e;
+            const int ngroups = last / 64 + 1;
+            if ((ngroups + G.blocks - 1) / G.blocks <= 4) {
+                std::vector<int> dealt((size_t)nthr, -1);
+                for (int g = 0; g < ngroups; ++g)
+                    for (int l = 0; l < 64; ++l) dealt[(size_t)((g % G.blocks) * 256 + (g / G.blocks) * 64 + l)] = own[(size_t)(g * 64 + l)];
+                own.swap(dealt);
+            }
+        }
+        for (int k = 0, gid = nthr - 1; k < K && gid >= 0; --gid)           // the K sums: threads without an element, from the end of the grid
+            if (own[(size_t)gid] < 0) own[(size_t)gid] = P + k++;
+        E.hist_gid = 0;
+        for (int gid = nthr - 1; gid >= 0; --gid) if (own[(size_t)gid] < 0) { E.hist_gid = gid; break; }
+        plat_sync(E.stream);
+        plat_free(E.d_own_r);
+        E.d_own_r = (int*)plat_malloc(sizeof(int) * (size_t)nthr);
+        if (!E.d_own_r) return fail("device allocation failed (training kernel: thread map)");
+        plat_h2d(E.d_own_r, own.data(), sizeof(int) * (size_t)nthr, E.stream);
+        if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+        E.own_blocks = G.blocks;
+    }
+    ta.own_r = E.d_own_r;
+    ta.hist_gid = ta.cached ? E.hist_gid : 0;
     ta.bar = E.d_bar;
     // launches of at most TRAIN_CHUNK iterations: the barrier counter restarts with every launch
     constexpr int TRAIN_CHUNK = 4096;

@@ -219,6 +219,7 @@ struct pinn_engine {
     int* d_gr_ptr = nullptr;         // global reduce CSR over theta: contributions (group, entry)
     int* d_gr_grp = nullptr;
     int* d_gr_ent = nullptr;
+    int* d_red_perm = nullptr;       // [P + K] thread order of the one-stage reduction (aux::Reduce2Args::perm)
     float* d_out = nullptr;          // [P grad | K raw sums]
     // pinned host block of the host entry points: [P floats theta | P + K floats out | K doubles raw sums]
     float* hp_theta = nullptr;
@@ -252,6 +253,8 @@ struct pinn_engine {
     int c12_cap = 0;
     unsigned* d_bar = nullptr;       // grid-barrier words of the persistent training kernel (pinn_train.hpp)
     float* d_sums2 = nullptr;        // its [2][K] per-step sums
+    int* d_own_r = nullptr;          // its thread -> element map (pinn_train.hpp: TrainArgs::own_r), built for own_blocks workgroups
+    int own_blocks = 0, hist_gid = 0;
     int max_contrib = 0, max_inv_pos = 0;      // most slab entries / image positions of one theta element (plan.cpp)
     bool persistent = true;          // pinn_set_option "persistent": small problems run pinn_adam_steps inside one launch
     int adam_path = 0;               // what the last pinn_adam_steps call ran: 0 nothing yet, 1 the stand-alone loop, 2 the persistent kernel

@@ -47,6 +47,11 @@ struct TrainArgs {
     const float* w_over_n;       // [K]
     float* sums2;                // [2][K]: the K sums of the even / odd steps (the history entry of a step is written one update later)
     int P, K, nsteps;
+    const int* own_r;            // cached form: [nblocks * 256] the element of [0, P + K) thread gid owns, -1: none.  The engine places theta element r
+                                 // at gid = its first slab entry, so that the lanes of a wave read CONSECUTIVE slab entries (the slabs are in MFMA
+                                 // fragment order, not theta order: with gid = r a wave's 64 lanes touch 64 cache lines per load — measured 8.9 us per
+                                 // update phase on MI355X, most of it the L1's line-by-line service of 128 such loads per lane)
+    int hist_gid;                // the thread that writes the loss history (one without an element where the grid has one)
     int cached;                  // every thread of the grid owns at most ONE element of [0, P + K) with at most TRAIN_MAX_CONTRIB slab entries and
                                  // TRAIN_MAX_POS image positions: its maps and its (theta, m, v) stay in registers across the steps
     unsigned* bar;               // [0] arrival counter of the grid barrier, [1] time-out flag (both zeroed by the host before the launch)
@@ -85,13 +90,19 @@ DEV void train_sum_elem(int k, const TrainArgs& a, int step) {
 #ifdef PINN_EMU
     for (int wv_ = 0; wv_ < nw; ++wv_) s += train_ld(p + (size_t)wv_ * a.K);
 #else
-    // all of a chunk's loads in flight before the first add.  Every load is UNCONDITIONAL (rows past the end re-read row 0) and only the
-    // add is selected: a load under a lane-dependent condition becomes a branch with the wait for its result at the join, i.e. one full
-    // L2 round trip per load (measured on MI355X: 29 us for 68 loads per lane)
-    for (int w0 = 0; w0 < nw; w0 += 64) {
-        double q[64];
-        PINN_UNROLL for (int b = 0; b < 64; ++b) q[b] = train_ld(p + (size_t)((w0 + b < nw) ? w0 + b : 0) * a.K);
-        PINN_UNROLL for (int b = 0; b < 64; ++b) s = (w0 + b < nw) ? s + q[b] : s;
+    // Every load of a chunk in flight before the first add, through a buffer view: ONE per-lane offset register (the column), the row in
+    // the scalar offset.  Every load is UNCONDITIONAL (rows past the end re-read row 0) and only the add is selected: a load under a
+    // lane-dependent condition becomes a branch with the wait for its result at the join, i.e. one full L2 round trip per load; and with
+    // plain pointers the compiler precomputes one 64-bit address per load in front of the step loop and spills them (measured on MI355X:
+    // 23-35 us per update phase either way, 836 B of scratch per lane)
+    const ubuf LPB = ub_make(reinterpret_cast<const float*>(a.losspart), (size_t)nw * a.K * 2);
+    int kcol = k, K_ = a.K, nw_ = nw;
+    opaque_v(kcol); opaque_s(K_); opaque_s(nw_);
+    constexpr int CH = 72;                                    // (one chunk = one round trip for launches of up to 18 workgroups)
+    for (int w0 = 0; w0 < nw_; w0 += CH) {
+        double q[CH];
+        PINN_UNROLL for (int b = 0; b < CH; ++b) q[b] = ub_loadd<TRAIN_WT ? 16 : 0>(LPB, ((w0 + b < nw_) ? w0 + b : 0) * K_, kcol);
+        PINN_UNROLL for (int b = 0; b < CH; ++b) s += (w0 + b < nw_) ? q[b] : 0.0;      // (+0.0 is exact here: see train_own_step)
     }
 #endif
     a.out[a.P + k] = (float)s;
@@ -134,7 +145,8 @@ struct TrainOwn {
     float th, m, v;
 };
 DEV void train_own_init(TrainOwn& o, int r, const TrainArgs& a) {
-    o.r = r; o.n = 0; o.npos = 0; o.th = o.m = o.v = 0.f;
+    o.r = r < 0 ? a.P + a.K : r;                              // (no element: past the end)
+    r = o.r; o.n = 0; o.npos = 0; o.th = o.m = o.v = 0.f;
     PINN_UNROLL for (int j = 0; j < TRAIN_MAX_CONTRIB; ++j) o.ent[j] = 0;
     PINN_UNROLL for (int j = 0; j < TRAIN_MAX_POS; ++j) o.pos[j] = 0;
     if (r < a.P) {
@@ -154,11 +166,20 @@ DEV void train_own_step(TrainOwn& o, const TrainArgs& a, int step) {
         for (int j = 0; j < o.n; ++j)
             for (int b = 0; b < a.nblocks; ++b) s += (double)train_ld(a.slabs + (size_t)o.ent[j] + (size_t)b * a.slab_floats);
 #else
-        float q[TRAIN_MAX_CONTRIB][32];                       // (the launch has at most 32 workgroups)
-        PINN_UNROLL for (int j = 0; j < TRAIN_MAX_CONTRIB; ++j)          // unconditional loads (see train_sum_elem): unused slots re-read entry ent[j] of workgroup 0
-            PINN_UNROLL for (int b = 0; b < 32; ++b) q[j][b] = train_ld(a.slabs + (size_t)o.ent[j] + (size_t)((b < a.nblocks) ? b : 0) * a.slab_floats);
+        // (see train_sum_elem) buffer view over the slabs: the slab entry in the per-lane offset, the workgroup in the scalar offset; the
+        // launch has at most 32 workgroups
+        const ubuf SLB = ub_make(a.slabs, (size_t)a.nblocks * a.slab_floats);
+        int ent[TRAIN_MAX_CONTRIB], n_ = o.n, nb_ = a.nblocks, stride_ = a.slab_floats;
+        PINN_UNROLL for (int j = 0; j < TRAIN_MAX_CONTRIB; ++j) { ent[j] = o.ent[j]; opaque_v(ent[j]); }
+        opaque_v(n_); opaque_s(nb_); opaque_s(stride_);
+        float q[TRAIN_MAX_CONTRIB][32];
         PINN_UNROLL for (int j = 0; j < TRAIN_MAX_CONTRIB; ++j)
-            PINN_UNROLL for (int b = 0; b < 32; ++b) s = (j < o.n && b < a.nblocks) ? s + (double)q[j][b] : s;
+            PINN_UNROLL for (int b = 0; b < 32; ++b) q[j][b] = ub_loadf<TRAIN_WT ? 16 : 0>(SLB, ((b < nb_) ? b : 0) * stride_, ent[j]);
+        // unused slots add +0.0, which is exact: s starts at +0.0 and a sum that started there is never -0.0 — so the accumulator chain is
+        // one v_add_f64 per slot, no select on it, and the sum equals the stand-alone kernel's bit for bit
+        // (no early exit from these loops: with one, they are not flattened and q[][] lives in scratch memory — measured)
+        PINN_UNROLL for (int j = 0; j < TRAIN_MAX_CONTRIB; ++j)
+            PINN_UNROLL for (int b = 0; b < 32; ++b) s += (double)((j < n_ && b < nb_) ? q[j][b] : 0.f);
 #endif
         const float g = (float)s;
         a.out[r] = g;
@@ -178,13 +199,13 @@ DEV void wave_train(const GroupArgs& ga, const TrainArgs& ta, int blk, int nbloc
 #ifdef PINN_EMU
     const int gid0 = (blk * 4 + w) * 64;                      // first of this wave's 64 threads
     TrainOwn own[64];
-    if (ta.cached) for (int l = 0; l < 64; ++l) train_own_init(own[l], gid0 + l, ta);
-    const bool first = (blk == 0 && w == 0);
+    if (ta.cached) for (int l = 0; l < 64; ++l) train_own_init(own[l], ta.own_r[gid0 + l], ta);
+    const bool first = (ta.hist_gid >= gid0 && ta.hist_gid < gid0 + 64);
 #else
     const int gid0 = blk * 256 + (int)threadIdx.x;
     TrainOwn own;
-    if (ta.cached) train_own_init(own, gid0, ta);
-    const bool first = (gid0 == 0);
+    if (ta.cached) train_own_init(own, ta.own_r[gid0], ta);
+    const bool first = (gid0 == ta.hist_gid);
 #endif
     TRAIN_STAMP_DECL
     for (int step = 0; step < ta.nsteps; ++step) {

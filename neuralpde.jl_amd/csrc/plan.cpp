@@ -1,5 +1,6 @@
 // plan.cpp — the kernel plan of a handle: which compiled kernel evaluates which term, launch groups, packed-weight and gradient-slab
 // index maps, the fixed-order reduction tables, tile tables (retile).
+#include <algorithm>
 #include "engine_types.hpp"
 
 namespace pe {
@@ -977,6 +978,20 @@ static int plan_global_reduce_map(pinn_engine& E) {
             for (auto& pr : c) { grp.push_back(pr.first); ent.push_back(pr.second); }
             ptr.push_back((int)grp.size());
         }
+        // order of the one-stage reduction's threads: by (group, slab entry) of an element's first contribution (aux::Reduce2Args::perm)
+        {
+            std::vector<int> perm((size_t)E.ntheta);
+            for (int r = 0; r < (int)E.ntheta; ++r) perm[(size_t)r] = r;
+            std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) {
+                const auto kx = contrib[(size_t)x].empty() ? std::make_pair(1 << 30, 0) : contrib[(size_t)x][0];
+                const auto ky = contrib[(size_t)y].empty() ? std::make_pair(1 << 30, 0) : contrib[(size_t)y][0];
+                return kx < ky;
+            });
+            for (size_t k = 0; k < E.terms.size(); ++k) perm.push_back((int)(E.ntheta + (int64_t)k));
+            E.d_red_perm = (int*)plat_malloc(sizeof(int) * perm.size());
+            if (!E.d_red_perm) return fail("device allocation failed (reduction order)");
+            plat_h2d(E.d_red_perm, perm.data(), sizeof(int) * perm.size(), E.stream);
+        }
         E.d_gr_ptr = (int*)plat_malloc(sizeof(int) * ptr.size());
         E.d_gr_grp = (int*)plat_malloc(sizeof(int) * std::max<size_t>(grp.size(), 1));
         E.d_gr_ent = (int*)plat_malloc(sizeof(int) * std::max<size_t>(ent.size(), 1));
@@ -1071,7 +1086,9 @@ void free_plan(pinn_engine& E) {
         plat_free(Cp.d_prog); plat_free(Cp.d_losspart); plat_free(Cp.d_pslab); plat_free(Cp.d_tmp);
     }
     for (auto& N : E.netplans) { plat_free(N.d_packed); plat_free(N.d_pack_idx); }
-    plat_free(E.d_gr_ptr); plat_free(E.d_gr_grp); plat_free(E.d_gr_ent); plat_free(E.d_inv_ptr); plat_free(E.d_inv_pos);
+    plat_free(E.d_gr_ptr); plat_free(E.d_gr_grp); plat_free(E.d_gr_ent); plat_free(E.d_inv_ptr); plat_free(E.d_inv_pos); plat_free(E.d_red_perm);
+    E.d_red_perm = nullptr;
+    E.own_blocks = 0;                 // (the training kernel's thread map belongs to the plan)
     E.d_gr_ptr = E.d_gr_grp = E.d_gr_ent = E.d_inv_ptr = E.d_inv_pos = nullptr;
     E.inv_ok = false;
     E.groups.clear(); E.merged.clear(); E.coupled.clear(); E.netplans.clear();

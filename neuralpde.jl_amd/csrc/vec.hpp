@@ -442,6 +442,18 @@ DEV void ub_store4(ubuf b, int soff, vint voff, vfloat4 x) {
 DEV vfloat ub_load(ubuf b, int soff, vint voff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, voff * 4, soff * 4, 0));
 }
+// one double per lane through a buffer view over doubles (offsets in doubles); AUX 16 = sc1 (agent-scope load)
+template <int AUX> DEV double ub_loadd(ubuf b, int soff, vint voff) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(b.r, voff * 8, soff * 8, AUX));
+}
+template <int AUX> DEV float ub_loadf(ubuf b, int soff, vint voff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, voff * 4, soff * 4, AUX));
+}
+// values the optimiser must treat as unknown from here on: loop-invariant address arithmetic built on them stays INSIDE the loop instead of
+// being hoisted in front of it as hundreds of precomputed (and then spilled) registers
+DEV void opaque_v(int& x) { asm volatile("" : "+v"(x)); }
+DEV void opaque_s(int& x) { asm volatile("" : "+s"(x)); }
 DEV vfloat ub_load_sc1(ubuf b, int soff, vint voff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, voff * 4, soff * 4, 16));
 }

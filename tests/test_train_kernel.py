@@ -20,13 +20,18 @@ def _run(npde, eng, th, w, persistent, steps=(9, 4)):
 
 def _cases(npde):
     from neuralpde_jl_amd import workloads
-    wl = workloads.cfg1_poisson1d(100)                               # 3 x 32 tanh, 100 + 1 + 1 points: ragged last tile, 3 terms in one launch group
-    yield "cfg1_3x32_tanh", wl.pde_system, wl.chains[0], wl.strategy, wl.theta, None
+    wl = workloads.cfg1_poisson1d(100)                               # 3 x 32 tanh, 100 + 1 + 1 points: ragged last tile, 3 terms in one launch group;
+    yield "cfg1_3x32_tanh", wl.pde_system, wl.chains[0], wl.strategy, wl.theta, None       # fewer threads than parameters: the kernel's general form
+    wl = workloads.cfg1_poisson1d()                                  # BASELINE config 1 at its size: 1,024 + 1 + 1 points (on the GPU: 17 workgroups,
+    yield "cfg1_full", wl.pde_system, wl.chains[0], wl.strategy, wl.theta, None            # every thread owns one element, placed by slab entry)
     sysm, chain = poisson2d(npde, "sigmoid", width=16, hidden=2)     # 2 x 16 sigmoid, 2-D, {u, u_x, u_y, lap u}: 25 + 4 x 5 grid points
     yield "poisson2d_2x16_sigmoid", sysm, chain, npde.GridTraining(0.25), theta_for(chain, 7), [1.0, 2.0, 1.0, 3.0, 1.0]
 
 
-def test_persistent_training_kernel_equals_the_loop_bit_for_bit(npde, use_emu):
+def test_persistent_training_kernel_equals_the_loop_bit_for_bit(npde, use_emu, monkeypatch):
+    # (the engine keeps launches with fewer threads than parameters on the loop: nothing to win there; the switch lets the kernel's general
+    # form — maps and optimiser state re-read from memory every step — be checked as well, on the emulation's two "CUs" in particular)
+    monkeypatch.setenv("PINN_TRAIN_GENERAL", "1")
     for name, sysm, chain, strat, th0, w in _cases(npde):
         disc = npde.PhysicsInformedNN(chain, strat, init_params=th0)
         rep = npde.symbolic_discretize(sysm, disc)
