@@ -240,7 +240,7 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
  *   parameters, quadrature weights; anything else fails HERE with a message and leaves the fp32 plan usable.  The Adam entry points and the
  *   device-pointer entry points stay fp32.  pinn_set_points_f64 installs a point set in double (the fp32 kernels get its float conversion).
  * "persistent" = "on" (default) | "off": pinn_adam_steps runs a SMALL problem — one network of the one-wave-per-tile kernel family, at most
- *   32 workgroups (~2,000 points of a 3 x 32 net), fixed point sets, no estimated PDE parameters, no communicator — as ONE persistent launch
+ *   32 workgroups (~2,000 points of a 3 x 32 net), fixed or device-redrawn point sets (pinn_set_sampler), no estimated PDE parameters, no communicator — as ONE persistent launch
  *   per call (csrc/pinn_train.hpp: evaluation, fixed-order reduction, Adam and the weight-image update of every iteration inside the kernel,
  *   two grid barriers per iteration) instead of three launches per iteration: the reference's own test regime,
  *   solve(prob, Adam; maxiters = 4000) on 100-1,000 points (test/NNPDE1/nnpde__pde_ii_2d_poisson.jl:83-85).  Bit-identical to the loop.

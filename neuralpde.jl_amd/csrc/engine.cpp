@@ -437,7 +437,7 @@ int pinn_destroy(pinn_handle h) {
     f64_destroy(E);
     free_plan(E);
     for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_upts); plat_free(T.d_resid); plat_free(T.d_lb); plat_free(T.d_ub); plat_free(T.d_data); plat_free(T.d_pw); }
-    plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist); plat_free(E.d_step); plat_free(E.d_draws); plat_free(E.d_sampled); plat_free(E.d_c12); plat_free(E.d_bar); plat_free(E.d_sums2); plat_free(E.d_own_r);
+    plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist); plat_free(E.d_step); plat_free(E.d_draws); plat_free(E.d_sampled); plat_free(E.d_c12); plat_free(E.d_bar); plat_free(E.d_sums2); plat_free(E.d_own_r); plat_free(E.d_train_samp);
     plat_free(E.d_theta); plat_free(E.d_params); plat_free(E.d_defaults); plat_free(E.d_lossraw);
     plat_free(E.d_out); plat_free(E.d_phi_pts); plat_free(E.d_phi_out); plat_free(E.d_phi_scr);
     plat_host_free(E.hp_theta);
@@ -1163,19 +1163,21 @@ static int adam_loop(pinn_engine** es, int ndev, int nsteps, float lr, float bet
 }
 
 // ---- persistent training kernel (pinn_train.hpp): the iterations of pinn_adam_steps inside ONE launch ----
-// Eligible: ONE fused family-1 launch group of ONE network whose spec carries the kernel (tanh / sigmoid), fixed point sets, no estimated
+// Eligible: ONE fused family-1 launch group of ONE network whose spec carries the kernel (tanh / sigmoid), fixed or plainly redrawn point sets, no estimated
 // PDE parameters, no communicator, float32, every workgroup resident (one per CU) and few enough for the one-stage reduction whose
 // association the kernel repeats (aux::reduce_is_small) — i.e. the small problems of the reference's own test-suite.  PINN_PERSISTENT=0
 // (read per call) keeps the stand-alone loop; results are bit-identical either way (tests/test_train_kernel.py).
 static bool train_eligible(pinn_engine& E) {
     const char* e = std::getenv("PINN_PERSISTENT");
     if (!E.persistent || (e && std::atoi(e) == 0)) return false;
+    if (std::getenv("PINN_GRAPH")) return false;               // (the graph-replay experiment of the loop)
     if (E.comm || E.f64 || E.ne != 0 || E.groups.size() != 1 || !E.coupled.empty() || E.nets.size() != 1) return false;
     if (!E.inv_ok || !E.d_inv_ptr) return false;
     const Group& G = E.groups[0];
     if (G.kind != 0 || !G.spec || G.spec->family != 1 || !G.spec->train) return false;
     if (G.ga.act != pk::ACT_TANH && G.ga.act != pk::ACT_SIGMOID) return false;
-    for (auto& T : E.terms) if (T.sampler != 0) return false;
+    for (auto& T : E.terms)          // redrawn point sets: drawn inside the kernel unless they carry embeddings or per-point data / weights
+        if (T.sampler != 0 && (!T.emb_cols.empty() || T.ndata > 0 || T.pw_n > 0 || T.coupled >= 0 || T.src_root.size() > (size_t)aux::SRC_MAX)) return false;
     const char* lim = std::getenv("PINN_REDUCE_DIRECT_MAX");
     const int direct_max = lim ? std::atoi(lim) : aux::REDUCE_DIRECT_MAX;
     if (G.blocks > direct_max || G.blocks > 32 || G.blocks > E.ncu) return false;
@@ -1277,6 +1279,21 @@ static int adam_steps_train(pinn_engine& E, int nsteps, float lr, float beta1, f
     ta.own_r = E.d_own_r;
     ta.hist_gid = ta.cached ? E.hist_gid : 0;
     ta.bar = E.d_bar;
+    // redrawn point sets (device samplers): the host draws the set of a launch's FIRST step with the stand-alone kernels, exactly as the
+    // loop does before every step; the kernel draws the sets of the following steps itself (pinn_train.hpp: train_resample)
+    std::vector<int> sampled;
+    for (size_t t = 0; t < E.terms.size(); ++t) if (E.terms[t].sampler != 0) sampled.push_back((int)t);
+    std::vector<pk::TrainSampler> samp(sampled.size());
+    if (!sampled.empty() && (int)sampled.size() > E.train_samp_cap) {
+        plat_sync(E.stream);
+        plat_free(E.d_train_samp);
+        E.d_train_samp = plat_malloc(sizeof(pk::TrainSampler) * sampled.size());
+        E.train_samp_cap = E.d_train_samp ? (int)sampled.size() : 0;
+        if (!E.d_train_samp) return fail("device allocation failed (training kernel: sampler table)");
+    }
+    ta.nsamp = (int)sampled.size();
+    ta.samp = (const pk::TrainSampler*)E.d_train_samp;
+    ta.fenced = sampled.empty() ? 0 : 1;
     // launches of at most TRAIN_CHUNK iterations: the barrier counter restarts with every launch
     constexpr int TRAIN_CHUNK = 4096;
     for (int s0 = 0; s0 < nsteps; s0 += TRAIN_CHUNK) {
@@ -1284,6 +1301,28 @@ static int adam_steps_train(pinn_engine& E, int nsteps, float lr, float beta1, f
         ta.c12 = E.d_c12 + 2 * (size_t)s0;
         ta.hist = E.d_hist + s0;
         if (s0 > 0) plat_memset(E.d_bar, 0, sizeof(unsigned), E.stream);
+        for (size_t i = 0; i < sampled.size(); ++i) {
+            Term& T = E.terms[(size_t)sampled[i]];
+            aux::launch_sample(T.sampler, user_pts(T), (int)(T.n * T.d_user), T.d_user, T.d_lb, T.d_ub, sampler_seed(E, T), T.draws, E.stream);
+            eval_sources(E, T);
+            pk::TrainSampler& S = samp[i];
+            std::memset(&S, 0, sizeof S);
+            S.pts = T.d_pts; S.n = (int)T.n; S.d = T.d; S.kind = T.sampler; S.lb = T.d_lb; S.ub = T.d_ub;
+            S.seed = sampler_seed(E, T); S.draw0 = T.draws;
+            S.has_src = T.src_root.empty() ? 0 : 1;
+            if (S.has_src) {
+                S.src.pts = T.d_pts; S.src.N = (int)T.n; S.src.d = T.d; S.src.prog = T.d_src_prog; S.src.nops = (int)T.src_prog.size();
+                S.src.nsrc = (int)T.src_root.size();
+                for (int j = 0; j < S.src.nsrc; ++j) S.src.root[j] = T.src_root[(size_t)j];
+                S.src.out = T.d_src; S.src.data = nullptr;
+            }
+            T.draws += (unsigned)ta.nsteps;
+        }
+        if (!sampled.empty()) {
+            if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());      // (the previous launch still reads the table)
+            plat_h2d(E.d_train_samp, samp.data(), sizeof(pk::TrainSampler) * samp.size(), E.stream);
+            if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());      // (samp is a pageable temporary)
+        }
         G.spec->train(G.ga, ta, G.blocks, E.stream);
     }
     unsigned flag[2] = {0, 0};

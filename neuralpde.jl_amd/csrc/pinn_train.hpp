@@ -19,13 +19,26 @@
 //
 // Same arithmetic, same association, same rounding as the three stand-alone kernels: K iterations in one launch equal K single steps
 // BIT FOR BIT (tests/test_train_kernel.py; GPU mirror in tests/test_gpu_mirror.py).  Not eligible (the engine takes the loop): more
-// workgroups than the one-stage reduction covers, on-device resampling, estimated PDE parameters, several networks or launch groups,
-// communicators, sin / per-layer activations, the float64 mode.
+// workgroups than the one-stage reduction covers, estimated PDE parameters, several networks or launch groups,
+// communicators, sin / per-layer activations, the float64 mode, embedded or data-carrying redrawn sets.
 #pragma once
 #include "pinn_kernels.hpp"
 #include "update_rules.hpp"
+#include "sample_rules.hpp"
 
 namespace pk {
+
+// a term whose point set is REDRAWN before every evaluation (StochasticTraining, QuasiRandomTraining(resampling = true):
+// src/training_strategies.jl:242-245, 375-381): the kernel draws the set of step s + 1 during the update phase of step s — same counter-based
+// rules as the stand-alone k_sample* kernels (sample_rules.hpp), one thread per POINT: its coordinates, then its coordinate-only source channels
+struct TrainSampler {
+    float* pts;                  // [n][d]
+    int n, d, kind;              // 1 uniform, 2 Latin hypercube, 3 Sobol'
+    const float* lb; const float* ub;
+    unsigned seed, draw0;        // draw counter of the launch's FIRST step (drawn by the host before the launch)
+    int has_src;
+    aux::SrcArgs src;
+};
 
 struct TrainArgs {
     // reduction inputs: the launch's gradient slabs and per-wave loss partials, the theta -> slab-entry map of the (single) launch group
@@ -51,6 +64,9 @@ struct TrainArgs {
                                  // at gid = its first slab entry, so that the lanes of a wave read CONSECUTIVE slab entries (the slabs are in MFMA
                                  // fragment order, not theta order: with gid = r a wave's 64 lanes touch 64 cache lines per load — measured 8.9 us per
                                  // update phase on MI355X, most of it the L1's line-by-line service of 128 such loads per lane)
+    const TrainSampler* samp;    // [nsamp] redrawn terms (device memory), nullptr: fixed point sets
+    int nsamp;
+    int fenced;                  // 1: barriers with release / acquire fences (redrawn point sets are read through the L1 by the evaluation)
     int hist_gid;                // the thread that writes the loss history (one without an element where the grid has one)
     int cached;                  // every thread of the grid owns at most ONE element of [0, P + K) with at most TRAIN_MAX_CONTRIB slab entries and
                                  // TRAIN_MAX_POS image positions: its maps and its (theta, m, v) stay in registers across the steps
@@ -68,7 +84,7 @@ constexpr int TRAIN_MAX_CONTRIB = 4, TRAIN_MAX_POS = 4;
 constexpr bool TRAIN_WT = PINN_TRAIN_WT != 0;
 template <class T> DEV T train_ld(const T* p) { return TRAIN_WT ? uload_wt(p) : *p; }
 template <class T> DEV void train_st(T* p, T x) { if (TRAIN_WT) ustore_wt(p, x); else *p = x; }
-DEV void train_barrier(unsigned* bar, unsigned target) { if (TRAIN_WT) grid_barrier_wt(bar, target); else grid_barrier(bar, target); }
+DEV void train_barrier(unsigned* bar, unsigned target, int fenced) { if (TRAIN_WT && !fenced) grid_barrier_wt(bar, target); else grid_barrier(bar, target); }
 
 // profiling build only (-DPINN_STAMP, tools/time_adam_loop.py --stamps): thread 0 of the launch accumulates the s_memtime ticks of the four
 // phases of an iteration — evaluation, barrier, update, barrier — into bar[4 .. 11] (64-bit sums); never defined for the product
@@ -192,6 +208,23 @@ DEV void train_own_step(TrainOwn& o, const TrainArgs& a, int step) {
     } else if (r < a.P + a.K) train_sum_elem(r - a.P, a, step);
 }
 
+// thread gid's share of the NEXT step's point sets: points gid, gid + nthreads, ... of every redrawn term
+DEV void train_resample(const TrainArgs& a, int gid, int nthreads, int next_step) {
+    for (int t = 0; t < a.nsamp; ++t) {
+        const TrainSampler& S = a.samp[t];
+        const unsigned draw = S.draw0 + (unsigned)next_step;
+        for (int p = gid; p < S.n; p += nthreads) {
+            for (int i = 0; i < S.d; ++i) {
+                const int e = p * S.d + i;
+                if (S.kind == 3) aux::sample_sobol_body(e, S.pts, S.d, S.lb, S.ub, S.seed, draw);
+                else if (S.kind == 2) aux::sample_lhs_body(e, S.pts, S.d, S.n, S.lb, S.ub, S.seed, draw);
+                else aux::sample_body(e, S.pts, S.d, S.lb, S.ub, S.seed, draw);
+            }
+            if (S.has_src) aux::src_point(p, S.src);          // (reads the coordinates this thread has just written)
+        }
+    }
+}
+
 // the wave program of the training kernel: workgroup `blk` of `nblocks`, wave `w` of the workgroup
 template <class S, int ACTK>
 DEV void wave_train(const GroupArgs& ga, const TrainArgs& ta, int blk, int nblocks, int w, float* lds) {
@@ -212,21 +245,23 @@ DEV void wave_train(const GroupArgs& ga, const TrainArgs& ta, int blk, int nbloc
         wave_main<S, MODE_FUSED, ACTK, TRAIN_WT>(ga, blk, nblocks, w, lds);
         TRAIN_STAMP(0)
         arrivals += (unsigned)nblocks;
-        train_barrier(ta.bar, arrivals);                      // every workgroup's slabs and loss partials are visible
+        train_barrier(ta.bar, arrivals, ta.fenced);           // every workgroup's slabs and loss partials are visible
         TRAIN_STAMP(1)
         if (first && step > 0) train_hist(ta, step - 1);      // the previous step's loss: its K sums were written one barrier ago
 #ifdef PINN_EMU
         for (int l = 0; l < 64; ++l) {
             if (ta.cached) train_own_step(own[l], ta, step);
             else for (int r = gid0 + l; r < ta.P + ta.K; r += nblocks * 256) train_update_elem(r, ta, step);
+            if (ta.nsamp > 0 && step + 1 < ta.nsteps) train_resample(ta, gid0 + l, nblocks * 256, step + 1);
         }
 #else
         if (ta.cached) train_own_step(own, ta, step);
         else for (int r = gid0; r < ta.P + ta.K; r += nblocks * 256) train_update_elem(r, ta, step);
+        if (ta.nsamp > 0 && step + 1 < ta.nsteps) train_resample(ta, gid0, nblocks * 256, step + 1);
 #endif
         TRAIN_STAMP(2)
         arrivals += (unsigned)nblocks;
-        train_barrier(ta.bar, arrivals);                      // the new parameters (theta, weight image) and the K sums are visible
+        train_barrier(ta.bar, arrivals, ta.fenced);           // the new parameters (theta, weight image) and the K sums are visible
         TRAIN_STAMP(3)
     }
     if (first && ta.nsteps > 0) train_hist(ta, ta.nsteps - 1);

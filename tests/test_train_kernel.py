@@ -51,14 +51,46 @@ def test_persistent_training_kernel_equals_the_loop_bit_for_bit(npde, use_emu, m
         assert abs(h3[0] - float(np.dot(l1, wn))) <= 1e-6 * abs(h3[0])
 
 
+def test_persistent_training_kernel_redraws_the_point_sets_like_the_loop(npde, use_emu, monkeypatch):
+    """StochasticTraining / QuasiRandomTraining(resampling = true) (src/training_strategies.jl:242-245, 375-381): the kernel draws the point
+    sets of the steps after the first inside the launch (uniform, Latin hypercube, Sobol' — the counter-based rules of the stand-alone
+    sampler kernels) and re-evaluates the coordinate-only source channels; parameters, histories AND the point sets left installed equal
+    the loop's bit for bit, across a resume (the draw counters continue)."""
+    sysm, chain = poisson2d(npde, "tanh", width=16, hidden=2)
+    th0 = theta_for(chain, 3)
+    strategies = (lambda: npde.StochasticTraining(64, bcs_points=32, rng=np.random.default_rng(3)),
+                  lambda: npde.QuasiRandomTraining(100, bcs_points=37, sampling_alg=npde.LatinHypercubeSample(seed=5)),
+                  lambda: npde.QuasiRandomTraining(80, bcs_points=16, sampling_alg=npde.SobolSample(seed=9)))
+    for make in strategies:
+        outs = []
+        for mode in ("0", "1"):
+            monkeypatch.setenv("PINN_PERSISTENT", mode)
+            prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, make(), init_params=th0))
+            rep = prob.pinnrep                               # the same device-sampler seeds in both runs (an unseeded strategy draws fresh ones)
+            rep._device_samplers = {k: (lb, ub, n, 4321 + 17 * k, kind) for k, (lb, ub, n, _, kind) in rep._device_samplers.items()}
+            r1 = npde.solve(prob, npde.Adam(0.01), maxiters=7)
+            r2 = npde.solve(npde.remake(prob, u0=r1.u), npde.Adam(0.01), maxiters=4)
+            eng = prob.pinnrep.engine
+            assert eng.get_option("adam_path") == ("persistent" if mode == "1" else "loop")
+            pts = [eng.get_points(k, 2, n) for k, (_, _, n, _, _) in sorted(prob.pinnrep._device_samplers.items())]
+            outs.append((r1.u, np.asarray(r1.losses), r2.u, np.asarray(r2.losses), pts))
+        a, b = outs
+        for x, y in zip(a[:4], b[:4]):
+            assert np.array_equal(x, y)
+        for x, y in zip(a[4], b[4]):
+            assert np.array_equal(x, y)
+        assert len(set(np.round(b[1], 12))) == 7               # a new point set every step
+
+
 def test_persistent_training_kernel_is_refused_where_it_does_not_apply(npde, use_emu, monkeypatch):
     sysm, chain = poisson2d(npde, "tanh", width=16, hidden=2)
     th0 = theta_for(chain, 3)
-    # on-device resampling: the loop
-    disc = npde.PhysicsInformedNN(chain, npde.StochasticTraining(64, bcs_points=32, rng=np.random.default_rng(3)), init_params=th0)
-    prob = npde.discretize(sysm, disc)
-    npde.solve(prob, npde.Adam(0.01), maxiters=3)
+    # the graph-replay experiment of the loop keeps the loop
+    monkeypatch.setenv("PINN_GRAPH", "1")
+    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=th0))
+    npde.solve(prob, npde.Adam(0.01), maxiters=9)
     assert prob.pinnrep.engine.get_option("adam_path") == "loop"
+    monkeypatch.delenv("PINN_GRAPH")
     # fixed sets: the kernel; the environment switch: the loop again
     disc = npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=th0)
     prob = npde.discretize(sysm, disc)

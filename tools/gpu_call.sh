@@ -26,7 +26,7 @@ for step in "$@"; do
     n=$((n + 1))
     echo "=== [$TAG] step $n: $step ($(date +%T))"
     case "$step" in
-        tests)      timeout 1500 python -m pytest tests -m gpu -q > "$O/tests.txt" 2>&1; tail -n 3 "$O/tests.txt" ;;
+        tests)      timeout 1500 python -m pytest tests -m gpu -q --durations=30 > "$O/tests.txt" 2>&1; tail -n 3 "$O/tests.txt" ;;
         tests:*)    timeout 1500 python -m pytest tests -m gpu -q -s -k "${step#tests:}" > "$O/tests_$n.txt" 2>&1; grep -v "^$" "$O/tests_$n.txt" | tail -n 60 ;;
         bench)      timeout 900 python bench.py > "$O/bench.json" 2> "$O/bench.err"; tail -c 1500 "$O/bench.json" ;;
         bench:*)    timeout 900 python bench.py ${step#bench:} > "$O/bench_$n.json" 2> "$O/bench_$n.err"; head -c 600 "$O/bench_$n.json"; echo ;;

@@ -29,8 +29,22 @@ def small2d():
     return sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.1), init_params=tp.theta_for(chain, 5))
 
 
+def small2d_stochastic():
+    import test_emu_parity as tp
+    sysm, chain = tp.poisson2d(npde, "tanh", width=16, hidden=2)
+    return sysm, npde.PhysicsInformedNN(chain, npde.StochasticTraining(128, bcs_points=32, rng=np.random.default_rng(3)), init_params=tp.theta_for(chain, 5))
+
+
+def small2d_lhs():
+    import test_emu_parity as tp
+    sysm, chain = tp.poisson2d(npde, "tanh", width=32, hidden=3)
+    return sysm, npde.PhysicsInformedNN(chain, npde.QuasiRandomTraining(1000, bcs_points=100, sampling_alg=npde.LatinHypercubeSample(seed=5)), init_params=tp.theta_for(chain, 5))
+
+
 cases = [("cfg1 3x32 1,026 pts", lambda: (workloads.cfg1_poisson1d().pde_system, workloads.cfg1_poisson1d().discretization()), 5000),
          ("poisson2d 2x16 165 pts", small2d, 5000),
+         ("2x16 Stochastic 256 pts", small2d_stochastic, 5000),          # points redrawn before every step (5 sampler + 1 source launches per loop step)
+         ("3x32 LatinHyp. 1,400 pts", small2d_lhs, 3000),
          ("cfg2 4x64 327,680 pts", lambda: (workloads.cfg2_poisson2d(points=65536).pde_system, workloads.cfg2_poisson2d(points=65536).discretization()), 1000)]
 for name, make, iters in cases:
     if ONLY and ONLY not in name:
@@ -40,6 +54,8 @@ for name, make, iters in cases:
         os.environ["PINN_PERSISTENT"] = "0" if mode == "loop" else "1"
         sysm, disc = make()
         prob = npde.discretize(sysm, disc)
+        if getattr(prob.pinnrep, "_device_samplers", None):                   # the same sampler seeds in both modes
+            prob.pinnrep._device_samplers = {k: (lb, ub, n, 4321 + 17 * k, kind) for k, (lb, ub, n, _, kind) in prob.pinnrep._device_samplers.items()}
         res = npde.solve(prob, npde.Adam(1e-3), maxiters=50)                # warm-up: kernels loaded, clocks up
         t0 = time.perf_counter()
         res = npde.solve(npde.remake(prob, u0=res.u), npde.Adam(1e-3), maxiters=iters)
