@@ -125,6 +125,46 @@ function set_gemm!(e::HIPEngine, mode::Symbol)
 end
 
 """
+    adam!(e::HIPEngine, θ0, nsteps, η; w = ones(K), init = true) -> (θ, loss_history)
+
+`solve(prob, Adam(η); maxiters = nsteps)` with θ, the moments and the point sets resident on the device (`pinn_adam_steps`).
+"""
+function adam!(e::HIPEngine, θ0::AbstractVector{<:Real}, nsteps::Integer, η::Real; w::AbstractVector{<:Real} = ones(e.K),
+               β1::Real = 0.9, β2::Real = 0.999, ϵ::Real = 1.0e-8, init::Bool = true)
+    # `solve(prob, Adam(η); maxiters = nsteps)` with θ, the moments and the point sets resident on the device (`pinn_adam_steps`): the
+    # persistent kernel where the problem is small enough, the launch-per-step loop otherwise; `init = false` continues from the device state
+    θ32 = Vector{Float32}(θ0); w32 = Vector{Float32}(w)
+    if init
+        GC.@preserve θ32 check(ccall(sym(:pinn_adam_init), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64), e.h, θ32, e.P), "pinn_adam_init")
+    end
+    hist = zeros(Float64, nsteps)
+    GC.@preserve w32 hist check(ccall(sym(:pinn_adam_steps), Cint,
+        (Ptr{Cvoid}, Cint, Cfloat, Cfloat, Cfloat, Cfloat, Ptr{Float32}, Ptr{Float64}), e.h, nsteps, η, β1, β2, ϵ, w32, hist), "pinn_adam_steps")
+    out = zeros(Float32, e.P)
+    GC.@preserve out check(ccall(sym(:pinn_adam_get), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64), e.h, out, e.P), "pinn_adam_get")
+    return Float64.(out), hist
+end
+
+"""
+    set_persistent!(e, on::Bool)
+
+`adam!` on a SMALL problem (one network of at most 32-wide layers, up to ~2,000 collocation points, fixed or device-redrawn point sets)
+runs all its iterations inside ONE persistent launch (`pinn_set_option(h, "persistent", …)`, DESIGN.md section 4.6: 2x fewer microseconds
+per iteration in the regime of the reference's own tests, `solve(prob, Adam(0.1); maxiters = 4000)`,
+test/NNPDE1/nnpde__pde_ii_2d_poisson.jl:83-85); results are bit-identical to the launch-per-step loop.  On by default; `false` keeps
+the loop.  `adam_path(e)` tells which one the last `adam!` ran (`:persistent | :loop | :none`).
+"""
+function set_persistent!(e::HIPEngine, on::Bool)
+    check(ccall(sym(:pinn_set_option), Cint, (Ptr{Cvoid}, Cstring, Cstring), e.h, "persistent", on ? "on" : "off"), "pinn_set_option")
+    return nothing
+end
+function adam_path(e::HIPEngine)
+    buf = zeros(UInt8, 64)
+    check(ccall(sym(:pinn_get_option), Cint, (Ptr{Cvoid}, Cstring, Ptr{UInt8}, Int64), e.h, "adam_path", buf, 64), "pinn_get_option")
+    return Symbol(unsafe_string(pointer(buf)))
+end
+
+"""
     set_precision!(e, :f64 | :f32)
 
 FLOAT64 evaluation of a live engine (`pinn_set_option(h, "precision", …)`, DESIGN.md section 4.5): `loss_grad` and `lbfgs!` then run the

@@ -7,7 +7,10 @@ src/discretize.jl:567-598)."""
 import numpy as np
 import pytest
 
-from test_emu_parity import poisson2d, theta_for
+import sympy as sp
+
+import helpers
+from test_emu_parity import _ks, _third_order_ode, poisson2d, theta_for
 
 
 def _run(npde, eng, th, w, persistent, steps=(9, 4)):
@@ -103,3 +106,42 @@ def test_persistent_training_kernel_is_refused_where_it_does_not_apply(npde, use
     assert np.array_equal(r1.u, r2.u) and np.array_equal(np.asarray(r1.losses), np.asarray(r2.losses))
     with pytest.raises(Exception):
         prob2.pinnrep.engine.set_option("persistent", "maybe")
+
+
+def _shape_cases(npde):
+    """(name, system, chain, strategy, weights): the kernel families / jet sets / residual forms the training kernel wraps"""
+    sob = lambda seed, n=48, b=12: npde.QuasiRandomTraining(n, bcs_points=b, sampling_alg=npde.SobolSample(seed=seed), resampling=False, minibatch=1)
+    # the reference's 3rd-order ODE net (8 wide, sigmoid): pure d3/dx3 channel, Neumann term
+    chain = npde.Chain(npde.Dense(1, 8, "sigmoid"), npde.Dense(8, 1))
+    yield "ode3_1x8", _third_order_ode(npde), chain, npde.GridTraining(0.02), None
+    # Kuramoto-Sivashinsky (12 wide padded to 16, sigmoid): d4/dx4, a NON-affine residual (u u_x): the tape interpreter inside the kernel
+    chain = npde.Chain(npde.Dense(2, 12, "sigmoid"), npde.Dense(12, 12, "sigmoid"), npde.Dense(12, 1))
+    yield "ks_2x12", _ks(npde), chain, sob(12, 60, 20), [1.0, 1.0, 2.0, 2.0, 0.5, 0.5]
+    # mixed second derivatives in 2-D / 3-D at the reference's widths (full-Hessian jet sets), 1-3 hidden layers
+    for width, hidden, d in ((16, 1, 2), (25, 2, 3), (32, 3, 2)):
+        sysm, chain = helpers.shape_problem(npde, width, hidden, d)
+        yield f"shape_{hidden}x{width}_d{d}", sysm, chain, sob(width + hidden), None
+    # quadrature-weighted terms ride along unchanged (weights are per-point factors of the residual)
+    sysm, chain = poisson2d(npde, "tanh", width=16, hidden=3)
+    yield "poisson2d_3x16", sysm, chain, npde.GridTraining(0.125), [0.5, 1.0, 2.0, 1.0, 3.0]
+
+
+def test_persistent_training_kernel_over_kernel_shapes(npde, use_emu, monkeypatch):
+    """Loop and kernel bit for bit over jet sets (value-only rows, full Hessians, pure third / fourth derivatives), widths 8-32, 1-3 hidden
+    layers, 1-3 inputs, tanh / sigmoid, affine and non-affine residuals, per-term weights — whatever launch shape the planner picks."""
+    monkeypatch.setenv("PINN_TRAIN_GENERAL", "1")
+    ran = []
+    for name, sysm, chain, strat, w in _shape_cases(npde):
+        th0 = theta_for(chain, 77)
+        rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th0))
+        eng = rep.engine
+        wts = None if w is None else np.asarray(w, dtype=np.float32)
+        a = _run(npde, eng, th0, wts, False, steps=(5, 3))
+        b = _run(npde, eng, th0, wts, True, steps=(5, 3))
+        ran.append((name, b[4]))
+        if b[4] != "persistent":                   # (several launch groups: the planner did not fold the terms into one — the loop, by design)
+            assert len([l for l in eng.describe().splitlines() if l.startswith("group")]) > 1, (name, eng.describe())
+            continue
+        for x, y, what in zip(a[:4], b[:4], ("theta", "history", "theta after resume", "history after resume")):
+            assert np.array_equal(x, y), (name, what)
+    assert sum(p == "persistent" for _, p in ran) >= 4, ran
