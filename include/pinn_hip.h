@@ -244,7 +244,8 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
  *   per call (csrc/pinn_train.hpp: evaluation, fixed-order reduction, Adam and the weight-image update of every iteration inside the kernel,
  *   two grid barriers per iteration) instead of three launches per iteration: the reference's own test regime,
  *   solve(prob, Adam; maxiters = 4000) on 100-1,000 points (test/NNPDE1/nnpde__pde_ii_2d_poisson.jl:83-85).  Bit-identical to the loop.
- *   $PINN_PERSISTENT=0 switches it off for every handle.  pinn_get_option(h, "adam_path") reports what the last pinn_adam_steps call ran:
+ *   A launch whose workgroups are not all resident (a device shared with another process) ends by its barrier's time-out: the call then
+ *   restores the optimiser state, runs the loop instead and keeps the loop for the handle.  $PINN_PERSISTENT=0 switches it off for every handle.  pinn_get_option(h, "adam_path") reports what the last pinn_adam_steps call ran:
  *   "persistent" | "loop" | "none".
  */
 int pinn_set_points_f64(pinn_handle h, int term, const double* pts, int64_t n, int64_t n_norm);

@@ -437,7 +437,7 @@ int pinn_destroy(pinn_handle h) {
     f64_destroy(E);
     free_plan(E);
     for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_upts); plat_free(T.d_resid); plat_free(T.d_lb); plat_free(T.d_ub); plat_free(T.d_data); plat_free(T.d_pw); }
-    plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist); plat_free(E.d_step); plat_free(E.d_draws); plat_free(E.d_sampled); plat_free(E.d_c12); plat_free(E.d_bar); plat_free(E.d_sums2); plat_free(E.d_own_r); plat_free(E.d_train_samp);
+    plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist); plat_free(E.d_step); plat_free(E.d_draws); plat_free(E.d_sampled); plat_free(E.d_c12); plat_free(E.d_bar); plat_free(E.d_sums2); plat_free(E.d_own_r); plat_free(E.d_train_samp); plat_free(E.d_opt_bak);
     plat_free(E.d_theta); plat_free(E.d_params); plat_free(E.d_defaults); plat_free(E.d_lossraw);
     plat_free(E.d_out); plat_free(E.d_phi_pts); plat_free(E.d_phi_out); plat_free(E.d_phi_scr);
     plat_host_free(E.hp_theta);
@@ -1187,7 +1187,8 @@ static bool train_eligible(pinn_engine& E) {
     if (G.blocks * 256 < P + K || E.max_contrib > pk::TRAIN_MAX_CONTRIB || E.max_inv_pos > pk::TRAIN_MAX_POS) return std::getenv("PINN_TRAIN_GENERAL") != nullptr;
     return true;
 }
-// returns 0 when all nsteps ran inside the kernel, 1 on failure (g_err set)
+// returns 0 when all nsteps ran inside the kernel, 1 on failure (g_err set), 2 when the kernel's grid barrier timed out: the optimiser state
+// and the draw counters are back where the call started and the caller runs the loop
 static int adam_steps_train(pinn_engine& E, int nsteps, float lr, float beta1, float beta2, float eps, const float* term_w) {
     const int K = (int)E.terms.size(), P = (int)E.ntheta;
     Group& G = E.groups[0];
@@ -1208,6 +1209,17 @@ static int adam_steps_train(pinn_engine& E, int nsteps, float lr, float beta1, f
         c12[2 * s] = (float)(1.0 / (1.0 - std::pow((double)beta1, (double)(E.opt_t + s + 1))));
         c12[2 * s + 1] = (float)(1.0 / (1.0 - std::pow((double)beta2, (double)(E.opt_t + s + 1))));
     }
+    // snapshot of the optimiser state: a launch whose workgroups were not all resident (another process filling the device) ends by its
+    // barrier time-out with wrong numbers — then the state is restored and the caller runs the stand-alone loop instead
+    if (!E.d_opt_bak) {
+        E.d_opt_bak = (float*)plat_malloc(sizeof(float) * 3 * (size_t)P);
+        if (!E.d_opt_bak) return fail("device allocation failed (optimiser snapshot)");
+    }
+    plat_d2d(E.d_opt_bak, E.d_opt_theta, sizeof(float) * (size_t)P, E.stream);
+    plat_d2d(E.d_opt_bak + P, E.d_opt_m, sizeof(float) * (size_t)P, E.stream);
+    plat_d2d(E.d_opt_bak + 2 * (size_t)P, E.d_opt_v, sizeof(float) * (size_t)P, E.stream);
+    std::vector<unsigned> draws0(E.terms.size());
+    for (size_t t = 0; t < E.terms.size(); ++t) draws0[t] = E.terms[t].draws;
     plat_h2d(E.d_c12, c12.data(), sizeof(float) * c12.size(), E.stream);
     plat_memset(E.d_bar, 0, sizeof(unsigned) * 16, E.stream);
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());       // (c12 is a pageable temporary)
@@ -1327,10 +1339,19 @@ static int adam_steps_train(pinn_engine& E, int nsteps, float lr, float beta1, f
     }
     unsigned flag[2] = {0, 0};
     if (plat_d2h(flag, E.d_bar, sizeof flag, E.stream) || plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    if (flag[1] != 0 || std::getenv("PINN_TRAIN_FORCE_TIMEOUT")) {
+        // back to the state the call started from; this handle keeps the loop from now on
+        plat_d2d(E.d_opt_theta, E.d_opt_bak, sizeof(float) * (size_t)P, E.stream);
+        plat_d2d(E.d_opt_m, E.d_opt_bak + P, sizeof(float) * (size_t)P, E.stream);
+        plat_d2d(E.d_opt_v, E.d_opt_bak + 2 * (size_t)P, sizeof(float) * (size_t)P, E.stream);
+        for (size_t t = 0; t < E.terms.size(); ++t) E.terms[t].draws = draws0[t];
+        if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+        E.persistent = false;
+        std::fprintf(stderr, "[pinn] the persistent training kernel's grid barrier timed out (its workgroups were not all resident: is the device "
+                             "shared?); optimiser state restored, this handle continues with the launch-per-step loop\n");
+        return 2;
+    }
     E.opt_t += nsteps;
-    if (flag[1] != 0)
-        return fail("pinn_adam_steps: the grid barrier of the persistent training kernel timed out (its workgroups were not all resident); "
-                    "the optimiser state is undefined — set PINN_PERSISTENT=0 and start again from pinn_adam_init");
     return 0;
 }
 
@@ -1366,10 +1387,14 @@ int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta
     E.adam_path = 1;
     if (train_eligible(E)) {                     // small problems: every iteration inside one persistent launch (pinn_train.hpp)
         E.adam_path = 2;
-        if (adam_steps_train(E, nsteps, lr, beta1, beta2, eps, term_w)) return 1;
-        if (loss_history && plat_d2h(loss_history, E.d_hist, sizeof(double) * nsteps, E.stream)) return fail("D2H copy failed");
-        if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
-        return 0;
+        const int rc = adam_steps_train(E, nsteps, lr, beta1, beta2, eps, term_w);
+        if (rc == 1) return 1;
+        if (rc == 0) {
+            if (loss_history && plat_d2h(loss_history, E.d_hist, sizeof(double) * nsteps, E.stream)) return fail("D2H copy failed");
+            if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+            return 0;
+        }
+        E.adam_path = 1;                         // (rc == 2: timed out and restored — the loop below runs the same steps)
     }
     // Default: plain launches, the step index / bias corrections / draw counters as kernel arguments.
     // PINN_GRAPH=1 (experiment, kept for reproduction): everything that changes from step to step lives in device memory and is advanced

@@ -257,6 +257,7 @@ struct pinn_engine {
     int own_blocks = 0, hist_gid = 0;
     void* d_train_samp = nullptr;    // its table of redrawn terms (pk::TrainSampler[train_samp_cap])
     int train_samp_cap = 0;
+    float* d_opt_bak = nullptr;      // [3 P] snapshot of (theta, m, v) at the start of a persistent launch (restored when its barrier times out)
     int max_contrib = 0, max_inv_pos = 0;      // most slab entries / image positions of one theta element (plan.cpp)
     bool persistent = true;          // pinn_set_option "persistent": small problems run pinn_adam_steps inside one launch
     int adam_path = 0;               // what the last pinn_adam_steps call ran: 0 nothing yet, 1 the stand-alone loop, 2 the persistent kernel

@@ -106,6 +106,15 @@ def test_persistent_training_kernel_is_refused_where_it_does_not_apply(npde, use
     assert np.array_equal(r1.u, r2.u) and np.array_equal(np.asarray(r1.losses), np.asarray(r2.losses))
     with pytest.raises(Exception):
         prob2.pinnrep.engine.set_option("persistent", "maybe")
+    # a launch whose grid barrier times out (workgroups not all resident: a shared device) — forced here — restores the optimiser state
+    # and the draw counters, runs the same steps in the loop and keeps the loop for the handle: same numbers, no error
+    monkeypatch.delenv("PINN_PERSISTENT")
+    monkeypatch.setenv("PINN_TRAIN_FORCE_TIMEOUT", "1")
+    prob3 = npde.discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=th0))
+    r3 = npde.solve(prob3, npde.Adam(0.01), maxiters=6)
+    eng3 = prob3.pinnrep.engine
+    assert eng3.get_option("adam_path") == "loop" and eng3.get_option("persistent") == "off"
+    assert np.array_equal(r1.u, r3.u) and np.array_equal(np.asarray(r1.losses), np.asarray(r3.losses))
 
 
 def _shape_cases(npde):
