@@ -419,6 +419,9 @@ inline void launch_sample(int kind, float* pts, int n_elems, int d, const float*
 inline void launch_adam_fused(const AdamFusedArgs& a, plat_stream) {
     for (int i = 0; i < (a.P > 1 ? a.P : 1); ++i) adam_fused_body(i, a);
 }
+inline void launch_resample(const ResampleTerm* samp, int nsamp, int max_n, int step, plat_stream) {
+    for (int p = 0; p < max_n; ++p) resample_point_sets(samp, nsamp, p, max_n, step);
+}
 // device-counter variants for the resident optimiser loop: the step index and the samplers' draw counters live in device memory, so one
 // step's launch sequence is the same every step and can be replayed as a graph (engine.cpp: pinn_adam_steps)
 inline void launch_adam_dev(float* theta, float* m, float* v, const float* grad, int P, float lr, float b1, float b2, float eps, const float* c12, const int* step, plat_stream st) {
@@ -524,6 +527,13 @@ inline void launch_sample(int kind, float* pts, int n_elems, int d, const float*
     if (kind == 3) hipLaunchKernelGGL(k_sample_sobol, dim3((n_elems + 255) / 256), dim3(256), 0, st, pts, n_elems, d, lb, ub, seed, draw);
     else if (kind == 2) hipLaunchKernelGGL(k_sample_lhs, dim3((n_elems + 255) / 256), dim3(256), 0, st, pts, n_elems, d, lb, ub, seed, draw);
     else hipLaunchKernelGGL(k_sample, dim3((n_elems + 255) / 256), dim3(256), 0, st, pts, n_elems, d, lb, ub, seed, draw);
+}
+// every redrawn term of a problem in ONE launch (sample_rules.hpp: ResampleTerm): one thread per point index over the largest set
+__global__ void __launch_bounds__(256) k_resample(const ResampleTerm* samp, int nsamp, int step) {
+    resample_point_sets(samp, nsamp, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x), step);
+}
+inline void launch_resample(const ResampleTerm* samp, int nsamp, int max_n, int step, plat_stream st) {
+    hipLaunchKernelGGL(k_resample, dim3((max_n + 255) / 256), dim3(256), 0, st, samp, nsamp, step);
 }
 __global__ void k_adam_fused(const AdamFusedArgs a) { adam_fused_body((int)(blockIdx.x * blockDim.x + threadIdx.x), a); }
 inline void launch_adam_fused(const AdamFusedArgs& a, plat_stream st) {

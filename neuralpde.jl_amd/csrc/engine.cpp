@@ -1102,6 +1102,42 @@ static unsigned sampler_seed(const pinn_engine& E, const Term& T) {
     return E.comm_size > 1 ? T.seed + 0x85EBCA6BU * (unsigned)(E.comm_rank + 1) : T.seed;
 }
 
+// Device-side table of a handle's redrawn terms (aux::ResampleTerm), draw counters as they stand now.  Returns the number of terms in the
+// table (0: no sampler), -1 when a redrawn term carries what the one-launch redraw does not cover (embeddings, per-point data / weights,
+// coupled equations: the per-term kernels stay), -2 on a device error (g_err set).  max_n = the largest set.
+static int upload_resample_table(pinn_engine& E, int* max_n) {
+    std::vector<pk::TrainSampler> samp;
+    *max_n = 0;
+    for (auto& T : E.terms) {
+        if (T.sampler == 0) continue;
+        if (!T.emb_cols.empty() || T.ndata > 0 || T.pw_n > 0 || T.coupled >= 0 || T.src_root.size() > (size_t)aux::SRC_MAX) return -1;
+        pk::TrainSampler S;
+        std::memset(&S, 0, sizeof S);
+        S.pts = T.d_pts; S.n = (int)T.n; S.d = T.d; S.kind = T.sampler; S.lb = T.d_lb; S.ub = T.d_ub;
+        S.seed = sampler_seed(E, T); S.draw0 = T.draws;
+        S.has_src = T.src_root.empty() ? 0 : 1;
+        if (S.has_src) {
+            S.src.pts = T.d_pts; S.src.N = (int)T.n; S.src.d = T.d; S.src.prog = T.d_src_prog; S.src.nops = (int)T.src_prog.size();
+            S.src.nsrc = (int)T.src_root.size();
+            for (int j = 0; j < S.src.nsrc; ++j) S.src.root[j] = T.src_root[(size_t)j];
+            S.src.out = T.d_src; S.src.data = nullptr;
+        }
+        *max_n = std::max(*max_n, S.n);
+        samp.push_back(S);
+    }
+    if (samp.empty()) return 0;
+    if (plat_sync(E.stream)) { fail(std::string("device error: ") + plat_last_error()); return -2; }      // (an earlier launch may still read the table)
+    if ((int)samp.size() > E.train_samp_cap) {
+        plat_free(E.d_train_samp);
+        E.d_train_samp = plat_malloc(sizeof(pk::TrainSampler) * samp.size());
+        E.train_samp_cap = E.d_train_samp ? (int)samp.size() : 0;
+        if (!E.d_train_samp) { fail("device allocation failed (table of redrawn terms)"); return -2; }
+    }
+    plat_h2d(E.d_train_samp, samp.data(), sizeof(pk::TrainSampler) * samp.size(), E.stream);
+    if (plat_sync(E.stream)) { fail(std::string("device error: ") + plat_last_error()); return -2; }      // (samp is a pageable temporary)
+    return (int)samp.size();
+}
+
 // the resident loop over ndev handles: one handle (plain, or a rank of a one-process-per-GPU communicator), or the handles of one
 // pinn_comm_init_all communicator (single process, several devices).  Per iteration and device: redraw the sampled sets -> evaluate the
 // local shards; then ONE all-reduce of [gradient | sums] (+ the K double sums) over the communicator, each rank's call on its own stream;
@@ -1112,11 +1148,23 @@ static int adam_loop(pinn_engine** es, int ndev, int nsteps, float lr, float bet
     std::vector<float*> vec(ndev);
     std::vector<double*> raw(ndev);
     for (int i = 0; i < ndev; ++i) { vec[i] = es[i]->d_opt_out; raw[i] = es[i]->d_lossraw; }
+    // redrawn point sets: ONE launch per step redraws every such term and its source channels (aux::k_resample over a device-side table);
+    // terms with embeddings / per-point data keep their own sampler / embed / source launches (PINN_NO_FUSED_RESAMPLE=1: always)
+    std::vector<int> nsamp(ndev, -1), max_n(ndev, 0);
+    for (int i = 0; i < ndev && std::getenv("PINN_NO_FUSED_RESAMPLE") == nullptr; ++i) {
+        DeviceScope scope(es[i]->device);
+        nsamp[i] = upload_resample_table(*es[i], &max_n[i]);
+        if (nsamp[i] == -2) return 1;
+    }
     for (int s = 0; s < nsteps; ++s) {
         for (int i = 0; i < ndev; ++i) {
             pinn_engine& E = *es[i];
             DeviceScope scope(E.device);
-            for (size_t t = 0; t < E.terms.size(); ++t) {            // resampling strategies: fresh points every evaluation, on device
+            if (nsamp[i] > 0) {
+                aux::launch_resample((const pk::TrainSampler*)E.d_train_samp, nsamp[i], max_n[i], s, E.stream);
+                for (auto& T : E.terms) if (T.sampler != 0) ++T.draws;
+            }
+            for (size_t t = 0; t < E.terms.size() && nsamp[i] < 0; ++t) {            // resampling strategies: fresh points every evaluation, on device
                 Term& T = E.terms[t];
                 if (T.sampler != 0) {
                     aux::launch_sample(T.sampler, user_pts(T), (int)(T.n * T.d_user), T.d_user, T.d_lb, T.d_ub, sampler_seed(E, T), T.draws++, E.stream);
@@ -1291,21 +1339,11 @@ static int adam_steps_train(pinn_engine& E, int nsteps, float lr, float beta1, f
     ta.own_r = E.d_own_r;
     ta.hist_gid = ta.cached ? E.hist_gid : 0;
     ta.bar = E.d_bar;
-    // redrawn point sets (device samplers): the host draws the set of a launch's FIRST step with the stand-alone kernels, exactly as the
-    // loop does before every step; the kernel draws the sets of the following steps itself (pinn_train.hpp: train_resample)
-    std::vector<int> sampled;
-    for (size_t t = 0; t < E.terms.size(); ++t) if (E.terms[t].sampler != 0) sampled.push_back((int)t);
-    std::vector<pk::TrainSampler> samp(sampled.size());
-    if (!sampled.empty() && (int)sampled.size() > E.train_samp_cap) {
-        plat_sync(E.stream);
-        plat_free(E.d_train_samp);
-        E.d_train_samp = plat_malloc(sizeof(pk::TrainSampler) * sampled.size());
-        E.train_samp_cap = E.d_train_samp ? (int)sampled.size() : 0;
-        if (!E.d_train_samp) return fail("device allocation failed (training kernel: sampler table)");
-    }
-    ta.nsamp = (int)sampled.size();
-    ta.samp = (const pk::TrainSampler*)E.d_train_samp;
-    ta.fenced = sampled.empty() ? 0 : 1;
+    // redrawn point sets (device samplers): the host draws the set of a launch's FIRST step, exactly as the loop does before every step;
+    // the kernel draws the sets of the following steps itself (pinn_train.hpp: train_resample)
+    bool any_sampler = false;
+    for (auto& T : E.terms) any_sampler = any_sampler || T.sampler != 0;
+    ta.fenced = any_sampler ? 1 : 0;
     // launches of at most TRAIN_CHUNK iterations: the barrier counter restarts with every launch
     constexpr int TRAIN_CHUNK = 4096;
     for (int s0 = 0; s0 < nsteps; s0 += TRAIN_CHUNK) {
@@ -1313,27 +1351,14 @@ static int adam_steps_train(pinn_engine& E, int nsteps, float lr, float beta1, f
         ta.c12 = E.d_c12 + 2 * (size_t)s0;
         ta.hist = E.d_hist + s0;
         if (s0 > 0) plat_memset(E.d_bar, 0, sizeof(unsigned), E.stream);
-        for (size_t i = 0; i < sampled.size(); ++i) {
-            Term& T = E.terms[(size_t)sampled[i]];
-            aux::launch_sample(T.sampler, user_pts(T), (int)(T.n * T.d_user), T.d_user, T.d_lb, T.d_ub, sampler_seed(E, T), T.draws, E.stream);
-            eval_sources(E, T);
-            pk::TrainSampler& S = samp[i];
-            std::memset(&S, 0, sizeof S);
-            S.pts = T.d_pts; S.n = (int)T.n; S.d = T.d; S.kind = T.sampler; S.lb = T.d_lb; S.ub = T.d_ub;
-            S.seed = sampler_seed(E, T); S.draw0 = T.draws;
-            S.has_src = T.src_root.empty() ? 0 : 1;
-            if (S.has_src) {
-                S.src.pts = T.d_pts; S.src.N = (int)T.n; S.src.d = T.d; S.src.prog = T.d_src_prog; S.src.nops = (int)T.src_prog.size();
-                S.src.nsrc = (int)T.src_root.size();
-                for (int j = 0; j < S.src.nsrc; ++j) S.src.root[j] = T.src_root[(size_t)j];
-                S.src.out = T.d_src; S.src.data = nullptr;
-            }
-            T.draws += (unsigned)ta.nsteps;
-        }
-        if (!sampled.empty()) {
-            if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());      // (the previous launch still reads the table)
-            plat_h2d(E.d_train_samp, samp.data(), sizeof(pk::TrainSampler) * samp.size(), E.stream);
-            if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());      // (samp is a pageable temporary)
+        if (any_sampler) {
+            int max_n = 0;
+            const int ns = upload_resample_table(E, &max_n);      // draw counters of this launch's first step
+            if (ns < 0) return ns == -2 ? 1 : fail("pinn_adam_steps: a redrawn term of the persistent kernel carries embeddings or per-point data");
+            aux::launch_resample((const pk::TrainSampler*)E.d_train_samp, ns, max_n, 0, E.stream);
+            for (auto& T : E.terms) if (T.sampler != 0) T.draws += (unsigned)ta.nsteps;
+            ta.nsamp = ns;
+            ta.samp = (const pk::TrainSampler*)E.d_train_samp;
         }
         G.spec->train(G.ga, ta, G.blocks, E.stream);
     }

@@ -28,17 +28,7 @@
 
 namespace pk {
 
-// a term whose point set is REDRAWN before every evaluation (StochasticTraining, QuasiRandomTraining(resampling = true):
-// src/training_strategies.jl:242-245, 375-381): the kernel draws the set of step s + 1 during the update phase of step s — same counter-based
-// rules as the stand-alone k_sample* kernels (sample_rules.hpp), one thread per POINT: its coordinates, then its coordinate-only source channels
-struct TrainSampler {
-    float* pts;                  // [n][d]
-    int n, d, kind;              // 1 uniform, 2 Latin hypercube, 3 Sobol'
-    const float* lb; const float* ub;
-    unsigned seed, draw0;        // draw counter of the launch's FIRST step (drawn by the host before the launch)
-    int has_src;
-    aux::SrcArgs src;
-};
+using TrainSampler = aux::ResampleTerm;      // a term whose point set is redrawn before every evaluation (sample_rules.hpp)
 
 struct TrainArgs {
     // reduction inputs: the launch's gradient slabs and per-wave loss partials, the theta -> slab-entry map of the (single) launch group
@@ -208,22 +198,9 @@ DEV void train_own_step(TrainOwn& o, const TrainArgs& a, int step) {
     } else if (r < a.P + a.K) train_sum_elem(r - a.P, a, step);
 }
 
-// thread gid's share of the NEXT step's point sets: points gid, gid + nthreads, ... of every redrawn term
-DEV void train_resample(const TrainArgs& a, int gid, int nthreads, int next_step) {
-    for (int t = 0; t < a.nsamp; ++t) {
-        const TrainSampler& S = a.samp[t];
-        const unsigned draw = S.draw0 + (unsigned)next_step;
-        for (int p = gid; p < S.n; p += nthreads) {
-            for (int i = 0; i < S.d; ++i) {
-                const int e = p * S.d + i;
-                if (S.kind == 3) aux::sample_sobol_body(e, S.pts, S.d, S.lb, S.ub, S.seed, draw);
-                else if (S.kind == 2) aux::sample_lhs_body(e, S.pts, S.d, S.n, S.lb, S.ub, S.seed, draw);
-                else aux::sample_body(e, S.pts, S.d, S.lb, S.ub, S.seed, draw);
-            }
-            if (S.has_src) aux::src_point(p, S.src);          // (reads the coordinates this thread has just written)
-        }
-    }
-}
+// thread gid's share of the NEXT step's point sets: points gid, gid + nthreads, ... of every redrawn term (drawn during the update phase of
+// the step before: same counter-based rules as the stand-alone kernels, one thread per POINT — its coordinates, then its source channels)
+DEV void train_resample(const TrainArgs& a, int gid, int nthreads, int next_step) { aux::resample_point_sets(a.samp, a.nsamp, gid, nthreads, next_step); }
 
 // the wave program of the training kernel: workgroup `blk` of `nblocks`, wave `w` of the workgroup
 template <class S, int ACTK>

@@ -128,4 +128,33 @@ AUX_DEV void sample_sobol_body(int e, float* pts, int d, const float* lb, const 
 }
 
 
+// A term whose point set is REDRAWN before every evaluation (StochasticTraining, QuasiRandomTraining(resampling = true):
+// src/training_strategies.jl:242-245, 375-381), as one record of a device-side table: ONE launch (k_resample, or the update phase of the
+// persistent training kernel) redraws every such term of a problem and re-evaluates its coordinate-only source channels, instead of a
+// sampler launch + a source launch per term and step.
+struct ResampleTerm {
+    float* pts;                  // [n][d]
+    int n, d, kind;              // 1 uniform, 2 Latin hypercube, 3 Sobol'
+    const float* lb; const float* ub;
+    unsigned seed, draw0;        // draw counter of step 0 of the table's lifetime
+    int has_src;
+    SrcArgs src;
+};
+// thread gid of nthreads: points gid, gid + nthreads, ... of every term, at draw counter draw0 + step
+AUX_DEV void resample_point_sets(const ResampleTerm* samp, int nsamp, int gid, int nthreads, int step) {
+    for (int t = 0; t < nsamp; ++t) {
+        const ResampleTerm& S = samp[t];
+        const unsigned draw = S.draw0 + (unsigned)step;
+        for (int p = gid; p < S.n; p += nthreads) {
+            for (int i = 0; i < S.d; ++i) {
+                const int e = p * S.d + i;
+                if (S.kind == 3) sample_sobol_body(e, S.pts, S.d, S.lb, S.ub, S.seed, draw);
+                else if (S.kind == 2) sample_lhs_body(e, S.pts, S.d, S.n, S.lb, S.ub, S.seed, draw);
+                else sample_body(e, S.pts, S.d, S.lb, S.ub, S.seed, draw);
+            }
+            if (S.has_src) src_point(p, S.src);               // (reads the coordinates this thread has just written)
+        }
+    }
+}
+
 }  // namespace aux

@@ -66,8 +66,13 @@ def test_persistent_training_kernel_redraws_the_point_sets_like_the_loop(npde, u
                   lambda: npde.QuasiRandomTraining(80, bcs_points=16, sampling_alg=npde.SobolSample(seed=9)))
     for make in strategies:
         outs = []
-        for mode in ("0", "1"):
-            monkeypatch.setenv("PINN_PERSISTENT", mode)
+        for mode in ("0 per-term sampler launches", "0", "1"):      # the loop with one sampler + one source launch per term and step, the loop with
+            monkeypatch.setenv("PINN_PERSISTENT", mode[0])            # ONE redraw launch per step (aux::k_resample), the persistent kernel
+            if len(mode) > 1:
+                monkeypatch.setenv("PINN_NO_FUSED_RESAMPLE", "1")
+            else:
+                monkeypatch.delenv("PINN_NO_FUSED_RESAMPLE", raising=False)
+            mode = mode[0]
             prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, make(), init_params=th0))
             rep = prob.pinnrep                               # the same device-sampler seeds in both runs (an unseeded strategy draws fresh ones)
             rep._device_samplers = {k: (lb, ub, n, 4321 + 17 * k, kind) for k, (lb, ub, n, _, kind) in rep._device_samplers.items()}
@@ -77,12 +82,13 @@ def test_persistent_training_kernel_redraws_the_point_sets_like_the_loop(npde, u
             assert eng.get_option("adam_path") == ("persistent" if mode == "1" else "loop")
             pts = [eng.get_points(k, 2, n) for k, (_, _, n, _, _) in sorted(prob.pinnrep._device_samplers.items())]
             outs.append((r1.u, np.asarray(r1.losses), r2.u, np.asarray(r2.losses), pts))
-        a, b = outs
-        for x, y in zip(a[:4], b[:4]):
-            assert np.array_equal(x, y)
-        for x, y in zip(a[4], b[4]):
-            assert np.array_equal(x, y)
-        assert len(set(np.round(b[1], 12))) == 7               # a new point set every step
+        a = outs[0]
+        for b in outs[1:]:
+            for x, y in zip(a[:4], b[:4]):
+                assert np.array_equal(x, y)
+            for x, y in zip(a[4], b[4]):
+                assert np.array_equal(x, y)
+        assert len(set(np.round(outs[2][1], 12))) == 7         # a new point set every step
 
 
 def test_persistent_training_kernel_is_refused_where_it_does_not_apply(npde, use_emu, monkeypatch):

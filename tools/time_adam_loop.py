@@ -41,10 +41,17 @@ def small2d_lhs():
     return sysm, npde.PhysicsInformedNN(chain, npde.QuasiRandomTraining(1000, bcs_points=100, sampling_alg=npde.LatinHypercubeSample(seed=5)), init_params=tp.theta_for(chain, 5))
 
 
+def mid2d_stochastic():
+    wl = workloads.cfg2_poisson2d(points=4096, bcs_points=1024)
+    disc = npde.PhysicsInformedNN(wl.chains[0], npde.StochasticTraining(4096, bcs_points=1024, rng=np.random.default_rng(3)), init_params=wl.theta)
+    return wl.pde_system, disc
+
+
 cases = [("cfg1 3x32 1,026 pts", lambda: (workloads.cfg1_poisson1d().pde_system, workloads.cfg1_poisson1d().discretization()), 5000),
          ("poisson2d 2x16 165 pts", small2d, 5000),
          ("2x16 Stochastic 256 pts", small2d_stochastic, 5000),          # points redrawn before every step (5 sampler + 1 source launches per loop step)
          ("3x32 LatinHyp. 1,400 pts", small2d_lhs, 3000),
+         ("4x64 Stochastic 8,192 pts", mid2d_stochastic, 2000),           # too large for the kernel: the loop, ONE redraw launch per step (PINN_NO_FUSED_RESAMPLE=1: ten)
          ("cfg2 4x64 327,680 pts", lambda: (workloads.cfg2_poisson2d(points=65536).pde_system, workloads.cfg2_poisson2d(points=65536).discretization()), 1000)]
 for name, make, iters in cases:
     if ONLY and ONLY not in name:
