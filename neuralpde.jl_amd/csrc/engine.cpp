@@ -1345,7 +1345,8 @@ static int adam_steps_train(pinn_engine& E, int nsteps, float lr, float beta1, f
     for (auto& T : E.terms) any_sampler = any_sampler || T.sampler != 0;
     ta.fenced = any_sampler ? 1 : 0;
     // launches of at most TRAIN_CHUNK iterations: the barrier counter restarts with every launch
-    constexpr int TRAIN_CHUNK = 4096;
+    const char* chunk_env = std::getenv("PINN_TRAIN_CHUNK");                        // (tests: several launches per call)
+    const int TRAIN_CHUNK = (chunk_env && std::atoi(chunk_env) > 0) ? std::atoi(chunk_env) : 4096;
     for (int s0 = 0; s0 < nsteps; s0 += TRAIN_CHUNK) {
         ta.nsteps = std::min(TRAIN_CHUNK, nsteps - s0);
         ta.c12 = E.d_c12 + 2 * (size_t)s0;

@@ -82,6 +82,17 @@ def test_persistent_training_kernel_redraws_the_point_sets_like_the_loop(npde, u
             assert eng.get_option("adam_path") == ("persistent" if mode == "1" else "loop")
             pts = [eng.get_points(k, 2, n) for k, (_, _, n, _, _) in sorted(prob.pinnrep._device_samplers.items())]
             outs.append((r1.u, np.asarray(r1.losses), r2.u, np.asarray(r2.losses), pts))
+        # the same call split over several launches of the kernel (the engine does that every 4,096 steps): the host redraws the first
+        # set of every launch, the barrier counter restarts, the history continues
+        monkeypatch.setenv("PINN_TRAIN_CHUNK", "3")
+        prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, make(), init_params=th0))
+        rep = prob.pinnrep
+        rep._device_samplers = {k: (lb, ub, n, 4321 + 17 * k, kind) for k, (lb, ub, n, _, kind) in rep._device_samplers.items()}
+        r1 = npde.solve(prob, npde.Adam(0.01), maxiters=7)
+        r2 = npde.solve(npde.remake(prob, u0=r1.u), npde.Adam(0.01), maxiters=4)
+        monkeypatch.delenv("PINN_TRAIN_CHUNK")
+        pts = [rep.engine.get_points(k, 2, n) for k, (_, _, n, _, _) in sorted(rep._device_samplers.items())]
+        outs.append((r1.u, np.asarray(r1.losses), r2.u, np.asarray(r2.losses), pts))
         a = outs[0]
         for b in outs[1:]:
             for x, y in zip(a[:4], b[:4]):
