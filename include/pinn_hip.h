@@ -246,7 +246,9 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
  *   solve(prob, Adam; maxiters = 4000) on 100-1,000 points (test/NNPDE1/nnpde__pde_ii_2d_poisson.jl:83-85).  Bit-identical to the loop.
  *   A launch whose workgroups are not all resident (a device shared with another process) ends by its barrier's time-out: the call then
  *   restores the optimiser state, runs the loop instead and keeps the loop for the handle.  $PINN_PERSISTENT=0 switches it off for every handle.  pinn_get_option(h, "adam_path") reports what the last pinn_adam_steps call ran:
- *   "persistent" | "loop" | "none".
+ *   "persistent" | "loop" | "none".  The host-entry evaluations of such a problem (pinn_loss_grad with a gradient, the objective calls of
+ *   pinn_lbfgs) take the same kernel in its evaluation-only form — residual kernel, grid barrier and fixed-order sums in ONE launch instead of
+ *   two, same numbers — unless HIP events were requested (pinn_set_timing); pinn_get_option(h, "eval_path"): "one launch" | "stand-alone kernels".
  */
 int pinn_set_points_f64(pinn_handle h, int term, const double* pts, int64_t n, int64_t n_norm);
 int pinn_set_option(pinn_handle h, const char* name, const char* value);

@@ -437,7 +437,7 @@ int pinn_destroy(pinn_handle h) {
     f64_destroy(E);
     free_plan(E);
     for (auto& T : E.terms) { plat_free(T.d_pts); plat_free(T.d_upts); plat_free(T.d_resid); plat_free(T.d_lb); plat_free(T.d_ub); plat_free(T.d_data); plat_free(T.d_pw); }
-    plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist); plat_free(E.d_step); plat_free(E.d_draws); plat_free(E.d_sampled); plat_free(E.d_c12); plat_free(E.d_bar); plat_free(E.d_sums2); plat_free(E.d_own_r); plat_free(E.d_train_samp); plat_free(E.d_opt_bak);
+    plat_free(E.d_opt_theta); plat_free(E.d_opt_m); plat_free(E.d_opt_v); plat_free(E.d_opt_out); plat_free(E.d_w_over_n); plat_free(E.d_hist); plat_free(E.d_step); plat_free(E.d_draws); plat_free(E.d_sampled); plat_free(E.d_c12); plat_free(E.d_bar); plat_free(E.d_sums2); plat_free(E.d_own_r); plat_free(E.d_train_samp); plat_free(E.d_opt_bak); plat_host_free(E.h_flag);
     plat_free(E.d_theta); plat_free(E.d_params); plat_free(E.d_defaults); plat_free(E.d_lossraw);
     plat_free(E.d_out); plat_free(E.d_phi_pts); plat_free(E.d_phi_out); plat_free(E.d_phi_scr);
     plat_host_free(E.hp_theta);
@@ -559,6 +559,23 @@ int pinn_set_points_f64(pinn_handle h, int term, const double* pts, int64_t n, i
     return f64_set_points(*h, term, pts, n);                                    // the float64 mode reads the points as given
 }
 
+static bool eval_eligible(pinn_engine& E);
+static int eval_fused(pinn_engine& E, const float* d_theta, float* d_out, const float* term_w, double* lossraw);
+static bool train_timed_out(pinn_engine& E);
+// loss + gradient for a host entry point that synchronises right after: small problems in ONE launch (eval_fused), everything else by
+// run_loss_grad; results in d_out / lossraw either way.  Synchronises.
+static int eval_and_sync(pinn_engine& E, float* d_out, const float* term_w, double* lossraw, bool timing) {
+    E.eval_path = 1;
+    if (eval_eligible(E)) {
+        if (eval_fused(E, E.d_theta, d_out, term_w, lossraw)) return 1;
+        if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+        if (!train_timed_out(E)) { E.eval_path = 2; return 0; }           // (timed out: the stand-alone kernels repeat the evaluation)
+    }
+    if (run_loss_grad(E, E.d_theta, d_out, term_w, -1, timing, lossraw, false, false)) return 1;
+    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    return 0;
+}
+
 int pinn_loss_grad(pinn_handle h, const float* theta, int64_t p, const float* term_w, double* term_losses, float* grad) {
     if (!h || !theta) return fail("pinn_loss_grad: null argument");
     pinn_engine& E = *h;
@@ -576,8 +593,12 @@ int pinn_loss_grad(pinn_handle h, const float* theta, int64_t p, const float* te
     // grad == NULL: loss-only evaluation (no records, no reverse sweep, no gradient reduction) — what a callback, an adaptive-weight
     // rule or a rejected line-search trial needs (the reference's per-term closures are value-only unless differentiated,
     // src/training_strategies.jl:215-221)
-    if (run_loss_grad(E, E.d_theta, E.hp_out, term_w, -1, true, E.hp_raw, false, grad == nullptr)) return 1;     // results land in pinned host memory
-    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    if (grad) {
+        if (eval_and_sync(E, E.hp_out, term_w, E.hp_raw, true)) return 1;                                            // results land in pinned host memory
+    } else {
+        if (run_loss_grad(E, E.d_theta, E.hp_out, term_w, -1, true, E.hp_raw, false, true)) return 1;
+        if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    }
     E.timing_valid = E.timing_level >= 2;
     if (term_losses)
         for (int k = 0; k < K; ++k) term_losses[k] = E.hp_raw[k] / (double)E.terms[k].n_norm;   // exact double sums
@@ -1007,8 +1028,9 @@ int pinn_get_option(pinn_handle h, const char* name, char* buf, int64_t buflen) 
     if (k == "gemm") { std::snprintf(buf, (size_t)buflen, "%s", h->gemm == pk::GEMM_FP32 ? "fp32" : "split"); return 0; }
     if (k == "precision") { std::snprintf(buf, (size_t)buflen, "%s", h->f64 ? "f64" : "f32"); return 0; }
     if (k == "persistent") { std::snprintf(buf, (size_t)buflen, "%s", h->persistent ? "on" : "off"); return 0; }
+    if (k == "eval_path") { std::snprintf(buf, (size_t)buflen, "%s", h->eval_path == 2 ? "one launch" : (h->eval_path == 1 ? "stand-alone kernels" : "none")); return 0; }
     if (k == "adam_path") { std::snprintf(buf, (size_t)buflen, "%s", h->adam_path == 2 ? "persistent" : (h->adam_path == 1 ? "loop" : "none")); return 0; }
-    return fail("pinn_get_option: unknown option \"" + k + "\" (known: gemm, precision, persistent, adam_path)");
+    return fail("pinn_get_option: unknown option \"" + k + "\" (known: gemm, precision, persistent, adam_path, eval_path)");
 }
 
 int pinn_adam_init(pinn_handle h, const float* theta, int64_t p) {
@@ -1235,43 +1257,21 @@ static bool train_eligible(pinn_engine& E) {
     if (G.blocks * 256 < P + K || E.max_contrib > pk::TRAIN_MAX_CONTRIB || E.max_inv_pos > pk::TRAIN_MAX_POS) return std::getenv("PINN_TRAIN_GENERAL") != nullptr;
     return true;
 }
-// returns 0 when all nsteps ran inside the kernel, 1 on failure (g_err set), 2 when the kernel's grid barrier timed out: the optimiser state
-// and the draw counters are back where the call started and the caller runs the loop
-static int adam_steps_train(pinn_engine& E, int nsteps, float lr, float beta1, float beta2, float eps, const float* term_w) {
+// what a launch of the training kernel needs besides the optimiser: barrier words, the reduction inputs of the (single) launch group, the
+// thread -> element map, the seeds of the reverse sweep.  Returns 0 / 1 (g_err set).
+static int train_common(pinn_engine& E, pk::TrainArgs& ta, const float* term_w) {
     const int K = (int)E.terms.size(), P = (int)E.ntheta;
     Group& G = E.groups[0];
     if (!E.d_bar) {
         E.d_bar = (unsigned*)plat_malloc(sizeof(unsigned) * 16);      // [0] arrivals, [1] time-out flag, [4..11] phase ticks of a PINN_STAMP build
         E.d_sums2 = (float*)plat_malloc(sizeof(float) * 2 * (size_t)std::max(K, 1));
-        if (!E.d_bar || !E.d_sums2) return fail("device allocation failed (grid barrier words)");
+        E.h_flag = (unsigned*)plat_host_alloc(sizeof(unsigned) * 4);
+        if (!E.d_bar || !E.d_sums2 || !E.h_flag) return fail("device allocation failed (grid barrier words)");
+        E.h_flag[0] = 0;
+        E.bar_arrivals = 0;
+        plat_memset(E.d_bar, 0, sizeof(unsigned) * 16, E.stream);     // (once: the arrival counter runs on from launch to launch)
+        if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
     }
-    if (E.c12_cap < nsteps) {
-        plat_sync(E.stream);
-        plat_free(E.d_c12);
-        E.d_c12 = (float*)plat_malloc(sizeof(float) * 2 * (size_t)nsteps);
-        E.c12_cap = E.d_c12 ? nsteps : 0;
-        if (!E.d_c12) return fail("device allocation failed (bias-correction table)");
-    }
-    std::vector<float> c12(2 * (size_t)nsteps);
-    for (int s = 0; s < nsteps; ++s) {
-        c12[2 * s] = (float)(1.0 / (1.0 - std::pow((double)beta1, (double)(E.opt_t + s + 1))));
-        c12[2 * s + 1] = (float)(1.0 / (1.0 - std::pow((double)beta2, (double)(E.opt_t + s + 1))));
-    }
-    // snapshot of the optimiser state: a launch whose workgroups were not all resident (another process filling the device) ends by its
-    // barrier time-out with wrong numbers — then the state is restored and the caller runs the stand-alone loop instead
-    if (!E.d_opt_bak) {
-        E.d_opt_bak = (float*)plat_malloc(sizeof(float) * 3 * (size_t)P);
-        if (!E.d_opt_bak) return fail("device allocation failed (optimiser snapshot)");
-    }
-    plat_d2d(E.d_opt_bak, E.d_opt_theta, sizeof(float) * (size_t)P, E.stream);
-    plat_d2d(E.d_opt_bak + P, E.d_opt_m, sizeof(float) * (size_t)P, E.stream);
-    plat_d2d(E.d_opt_bak + 2 * (size_t)P, E.d_opt_v, sizeof(float) * (size_t)P, E.stream);
-    std::vector<unsigned> draws0(E.terms.size());
-    for (size_t t = 0; t < E.terms.size(); ++t) draws0[t] = E.terms[t].draws;
-    plat_h2d(E.d_c12, c12.data(), sizeof(float) * c12.size(), E.stream);
-    plat_memset(E.d_bar, 0, sizeof(unsigned) * 16, E.stream);
-    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());       // (c12 is a pageable temporary)
-    pack_all(E, E.d_opt_theta, false);                        // the weight image of the current theta; the kernel keeps it current from here on
     for (size_t j = 0; j < G.terms.size(); ++j) {
         const int ti = G.terms[j];
         G.ga.terms[j].scale = (float)(2.0 * (double)(term_w ? term_w[ti] : 1.0f) / (double)E.terms[ti].n_norm);
@@ -1282,17 +1282,13 @@ static int adam_steps_train(pinn_engine& E, int nsteps, float lr, float beta1, f
     G.timed = false;
     G.launched_blocks = G.blocks;
     G.launched_by = 0;
-    pk::TrainArgs ta;
     std::memset(&ta, 0, sizeof ta);
     ta.slabs = G.d_slabs; ta.losspart = G.d_losspart; ta.row_ptr = E.d_gr_ptr; ta.row_ent = E.d_gr_ent;
     ta.slab_floats = G.slab_floats; ta.nblocks = G.blocks;
-    ta.out = E.d_opt_out; ta.lossraw = E.d_lossraw;
-    ta.theta = E.d_opt_theta; ta.m = E.d_opt_m; ta.v = E.d_opt_v;
-    ta.lr = lr; ta.b1 = beta1; ta.b2 = beta2; ta.eps = eps;
-    ta.inv_ptr = E.d_inv_ptr; ta.inv_pos = E.d_inv_pos; ta.packed = E.netplans[G.net].d_packed;
-    ta.w_over_n = E.d_w_over_n;
     ta.P = P; ta.K = K;
     ta.sums2 = E.d_sums2;
+    ta.bar = E.d_bar;
+    ta.hflag = E.h_flag;
     ta.cached = (G.blocks * 256 >= P + K && E.max_contrib <= pk::TRAIN_MAX_CONTRIB && E.max_inv_pos <= pk::TRAIN_MAX_POS &&
                  std::getenv("PINN_TRAIN_NO_CACHE") == nullptr) ? 1 : 0;
     if (ta.cached && (!E.d_own_r || E.own_blocks != G.blocks)) {
@@ -1338,20 +1334,105 @@ static int adam_steps_train(pinn_engine& E, int nsteps, float lr, float beta1, f
     }
     ta.own_r = E.d_own_r;
     ta.hist_gid = ta.cached ? E.hist_gid : 0;
-    ta.bar = E.d_bar;
+    return 0;
+}
+// after a synchronisation: did a launch of the training kernel run into its barrier's time-out?  Then the barrier words start afresh and the
+// handle keeps the stand-alone kernels from now on.
+static bool train_timed_out(pinn_engine& E) {
+    if (E.h_flag[0] == 0 && std::getenv("PINN_TRAIN_FORCE_TIMEOUT") == nullptr) return false;
+    E.h_flag[0] = 0;
+    E.bar_arrivals = 0;
+    plat_memset(E.d_bar, 0, sizeof(unsigned) * 16, E.stream);
+    plat_sync(E.stream);
+    E.persistent = false;
+    std::fprintf(stderr, "[pinn] the persistent kernel's grid barrier timed out (its workgroups were not all resident: is the device shared?); "
+                         "this handle continues with the stand-alone kernels\n");
+    return true;
+}
+
+// ONE evaluation of a small problem in one launch (pinn_train.hpp, TrainArgs::eval_only): the residual kernel, a grid barrier and the
+// fixed-order sums of aux::reduce_direct_body, thread per slab entry — instead of the residual kernel + the reduction kernel.  Only for
+// callers that synchronise right after (the host entry points): a time-out is detected there and the evaluation repeated by the
+// stand-alone kernels.  Same numbers bit for bit.  Returns 0 done, 1 failure, 2 timed out (the caller takes the normal path).
+static int eval_fused(pinn_engine& E, const float* d_theta, float* d_out, const float* term_w, double* lossraw) {
+    Group& G = E.groups[0];
+    pk::TrainArgs ta;
+    if (train_common(E, ta, term_w)) return 1;
+    pack_all(E, d_theta, false);
+    ta.out = d_out; ta.lossraw = lossraw ? lossraw : E.d_lossraw;
+    ta.eval_only = 1; ta.nsteps = 1;
+    ta.arrivals0 = E.bar_arrivals;
+    E.bar_arrivals += (unsigned)G.blocks;
+    G.spec->train(G.ga, ta, G.blocks, E.stream);
+    return 0;
+}
+
+// the same launch shape as the training kernel's, without the optimiser's needs (estimated PDE parameters are fine here); callers that
+// asked for HIP events around the kernels (pinn_set_timing) keep the stand-alone kernels those events bracket.  PINN_NO_FUSED_EVAL=1: never.
+static bool eval_eligible(pinn_engine& E) {
+    const char* e = std::getenv("PINN_PERSISTENT");
+    if (!E.persistent || (e && std::atoi(e) == 0) || std::getenv("PINN_NO_FUSED_EVAL")) return false;
+    if (E.timing_level != 0 || E.comm || E.f64 || E.groups.size() != 1 || !E.coupled.empty() || E.nets.size() != 1) return false;
+    const Group& G = E.groups[0];
+    if (G.kind != 0 || !G.spec || G.spec->family != 1 || !G.spec->train) return false;
+    if (G.ga.act != pk::ACT_TANH && G.ga.act != pk::ACT_SIGMOID) return false;
+    const char* lim = std::getenv("PINN_REDUCE_DIRECT_MAX");
+    const int direct_max = lim ? std::atoi(lim) : aux::REDUCE_DIRECT_MAX;
+    if (G.blocks > direct_max || G.blocks > 32 || G.blocks > E.ncu) return false;
+    const int K = (int)E.terms.size(), P = (int)E.ntheta;
+    return G.blocks * 256 >= P + K && E.max_contrib <= pk::TRAIN_MAX_CONTRIB;
+}
+
+// returns 0 when all nsteps ran inside the kernel, 1 on failure (g_err set), 2 when the kernel's grid barrier timed out: the optimiser state
+// and the draw counters are back where the call started and the caller runs the loop
+static int adam_steps_train(pinn_engine& E, int nsteps, float lr, float beta1, float beta2, float eps, const float* term_w) {
+    const int P = (int)E.ntheta;
+    Group& G = E.groups[0];
+    pk::TrainArgs ta;
+    if (train_common(E, ta, term_w)) return 1;
+    if (E.c12_cap < nsteps) {
+        plat_sync(E.stream);
+        plat_free(E.d_c12);
+        E.d_c12 = (float*)plat_malloc(sizeof(float) * 2 * (size_t)nsteps);
+        E.c12_cap = E.d_c12 ? nsteps : 0;
+        if (!E.d_c12) return fail("device allocation failed (bias-correction table)");
+    }
+    std::vector<float> c12(2 * (size_t)nsteps);
+    for (int s = 0; s < nsteps; ++s) {
+        c12[2 * s] = (float)(1.0 / (1.0 - std::pow((double)beta1, (double)(E.opt_t + s + 1))));
+        c12[2 * s + 1] = (float)(1.0 / (1.0 - std::pow((double)beta2, (double)(E.opt_t + s + 1))));
+    }
+    // snapshot of the optimiser state: a launch whose workgroups were not all resident (another process filling the device) ends by its
+    // barrier time-out with wrong numbers — then the state is restored and the caller runs the stand-alone loop instead
+    if (!E.d_opt_bak) {
+        E.d_opt_bak = (float*)plat_malloc(sizeof(float) * 3 * (size_t)P);
+        if (!E.d_opt_bak) return fail("device allocation failed (optimiser snapshot)");
+    }
+    plat_d2d(E.d_opt_bak, E.d_opt_theta, sizeof(float) * (size_t)P, E.stream);
+    plat_d2d(E.d_opt_bak + P, E.d_opt_m, sizeof(float) * (size_t)P, E.stream);
+    plat_d2d(E.d_opt_bak + 2 * (size_t)P, E.d_opt_v, sizeof(float) * (size_t)P, E.stream);
+    std::vector<unsigned> draws0(E.terms.size());
+    for (size_t t = 0; t < E.terms.size(); ++t) draws0[t] = E.terms[t].draws;
+    plat_h2d(E.d_c12, c12.data(), sizeof(float) * c12.size(), E.stream);
+    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());       // (c12 is a pageable temporary)
+    pack_all(E, E.d_opt_theta, false);                        // the weight image of the current theta; the kernel keeps it current from here on
+    ta.out = E.d_opt_out; ta.lossraw = E.d_lossraw;
+    ta.theta = E.d_opt_theta; ta.m = E.d_opt_m; ta.v = E.d_opt_v;
+    ta.lr = lr; ta.b1 = beta1; ta.b2 = beta2; ta.eps = eps;
+    ta.inv_ptr = E.d_inv_ptr; ta.inv_pos = E.d_inv_pos; ta.packed = E.netplans[G.net].d_packed;
+    ta.w_over_n = E.d_w_over_n;
     // redrawn point sets (device samplers): the host draws the set of a launch's FIRST step, exactly as the loop does before every step;
     // the kernel draws the sets of the following steps itself (pinn_train.hpp: train_resample)
     bool any_sampler = false;
     for (auto& T : E.terms) any_sampler = any_sampler || T.sampler != 0;
     ta.fenced = any_sampler ? 1 : 0;
-    // launches of at most TRAIN_CHUNK iterations: the barrier counter restarts with every launch
+    // launches of at most TRAIN_CHUNK iterations
     const char* chunk_env = std::getenv("PINN_TRAIN_CHUNK");                        // (tests: several launches per call)
     const int TRAIN_CHUNK = (chunk_env && std::atoi(chunk_env) > 0) ? std::atoi(chunk_env) : 4096;
     for (int s0 = 0; s0 < nsteps; s0 += TRAIN_CHUNK) {
         ta.nsteps = std::min(TRAIN_CHUNK, nsteps - s0);
         ta.c12 = E.d_c12 + 2 * (size_t)s0;
         ta.hist = E.d_hist + s0;
-        if (s0 > 0) plat_memset(E.d_bar, 0, sizeof(unsigned), E.stream);
         if (any_sampler) {
             int max_n = 0;
             const int ns = upload_resample_table(E, &max_n);      // draw counters of this launch's first step
@@ -1361,20 +1442,18 @@ static int adam_steps_train(pinn_engine& E, int nsteps, float lr, float beta1, f
             ta.nsamp = ns;
             ta.samp = (const pk::TrainSampler*)E.d_train_samp;
         }
+        ta.arrivals0 = E.bar_arrivals;
+        E.bar_arrivals += (unsigned)G.blocks * 2u * (unsigned)ta.nsteps;
         G.spec->train(G.ga, ta, G.blocks, E.stream);
     }
-    unsigned flag[2] = {0, 0};
-    if (plat_d2h(flag, E.d_bar, sizeof flag, E.stream) || plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
-    if (flag[1] != 0 || std::getenv("PINN_TRAIN_FORCE_TIMEOUT")) {
-        // back to the state the call started from; this handle keeps the loop from now on
+    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    if (train_timed_out(E)) {
+        // back to the state the call started from
         plat_d2d(E.d_opt_theta, E.d_opt_bak, sizeof(float) * (size_t)P, E.stream);
         plat_d2d(E.d_opt_m, E.d_opt_bak + P, sizeof(float) * (size_t)P, E.stream);
         plat_d2d(E.d_opt_v, E.d_opt_bak + 2 * (size_t)P, sizeof(float) * (size_t)P, E.stream);
         for (size_t t = 0; t < E.terms.size(); ++t) E.terms[t].draws = draws0[t];
         if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
-        E.persistent = false;
-        std::fprintf(stderr, "[pinn] the persistent training kernel's grid barrier timed out (its workgroups were not all resident: is the device "
-                             "shared?); optimiser state restored, this handle continues with the launch-per-step loop\n");
         return 2;
     }
     E.opt_t += nsteps;
@@ -1511,8 +1590,12 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
         }
         for (size_t i = 0; i < P; ++i) th32[i] = (float)at[i];
         if (upload_theta(E, th32.data(), p)) return 1;
-        if (run_loss_grad(E, E.d_theta, E.hp_out, term_w, -1, false, E.hp_raw, false, grad == nullptr)) return 1;
-        if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+        if (grad) {
+            if (eval_and_sync(E, E.hp_out, term_w, E.hp_raw, false)) return 1;
+        } else {
+            if (run_loss_grad(E, E.d_theta, E.hp_out, term_w, -1, false, E.hp_raw, false, true)) return 1;
+            if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+        }
         f = 0.0;
         for (int k = 0; k < K; ++k) f += (double)(term_w ? term_w[k] : 1.0f) * E.hp_raw[k] / (double)E.terms[k].n_norm;
         if (grad)

@@ -252,6 +252,8 @@ struct pinn_engine {
     float* d_c12 = nullptr;
     int c12_cap = 0;
     unsigned* d_bar = nullptr;       // grid-barrier words of the persistent training kernel (pinn_train.hpp)
+    unsigned* h_flag = nullptr;      // host-mapped: a launch's barrier timed out
+    unsigned bar_arrivals = 0;       // arrivals the barrier counter has seen so far (it is never reset between launches)
     float* d_sums2 = nullptr;        // its [2][K] per-step sums
     int* d_own_r = nullptr;          // its thread -> element map (pinn_train.hpp: TrainArgs::own_r), built for own_blocks workgroups
     int own_blocks = 0, hist_gid = 0;
@@ -260,6 +262,7 @@ struct pinn_engine {
     float* d_opt_bak = nullptr;      // [3 P] snapshot of (theta, m, v) at the start of a persistent launch (restored when its barrier times out)
     int max_contrib = 0, max_inv_pos = 0;      // most slab entries / image positions of one theta element (plan.cpp)
     bool persistent = true;          // pinn_set_option "persistent": small problems run pinn_adam_steps inside one launch
+    int eval_path = 0;               // what the last host-entry loss + gradient evaluation ran: 1 the stand-alone kernels, 2 one launch (eval_fused)
     int adam_path = 0;               // what the last pinn_adam_steps call ran: 0 nothing yet, 1 the stand-alone loop, 2 the persistent kernel
     // phi scratch
     float* d_phi_pts = nullptr;

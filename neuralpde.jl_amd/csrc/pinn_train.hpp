@@ -57,6 +57,10 @@ struct TrainArgs {
     const TrainSampler* samp;    // [nsamp] redrawn terms (device memory), nullptr: fixed point sets
     int nsamp;
     int fenced;                  // 1: barriers with release / acquire fences (redrawn point sets are read through the L1 by the evaluation)
+    int eval_only;               // 1: ONE evaluation — residual kernel, barrier, fixed-order sums into out[] — and nothing else (pinn_loss_grad on a small
+                                 // problem: one launch instead of the residual kernel + the reduction kernel); theta / m / v / hist / c12 unused
+    unsigned* hflag;             // host-mapped word: set to 1 by the launch when its barrier timed out (the host reads it after its next synchronisation)
+    unsigned arrivals0;          // value of the barrier's arrival counter when this launch starts (the counter is never reset between launches)
     int hist_gid;                // the thread that writes the loss history (one without an element where the grid has one)
     int cached;                  // every thread of the grid owns at most ONE element of [0, P + K) with at most TRAIN_MAX_CONTRIB slab entries and
                                  // TRAIN_MAX_POS image positions: its maps and its (theta, m, v) stay in registers across the steps
@@ -134,6 +138,7 @@ DEV void train_update_elem(int r, const TrainArgs& a, int step) {
         }
         const float g = (float)s;
         a.out[r] = g;
+        if (a.eval_only) return;
         float mi = a.m[r], vi = a.v[r];
         const float t = ur::adam_update(a.theta[r], mi, vi, g, a.lr, a.b1, a.b2, a.eps, a.c12[2 * step], a.c12[2 * step + 1]);
         a.m[r] = mi;
@@ -156,12 +161,15 @@ DEV void train_own_init(TrainOwn& o, int r, const TrainArgs& a) {
     PINN_UNROLL for (int j = 0; j < TRAIN_MAX_CONTRIB; ++j) o.ent[j] = 0;
     PINN_UNROLL for (int j = 0; j < TRAIN_MAX_POS; ++j) o.pos[j] = 0;
     if (r < a.P) {
-        const int i0 = a.row_ptr[r], q0 = a.inv_ptr[r];
+        const int i0 = a.row_ptr[r];
         o.n = a.row_ptr[r + 1] - i0;
-        o.npos = a.inv_ptr[r + 1] - q0;
         PINN_UNROLL for (int j = 0; j < TRAIN_MAX_CONTRIB; ++j) if (j < o.n) o.ent[j] = a.row_ent[i0 + j];
-        PINN_UNROLL for (int j = 0; j < TRAIN_MAX_POS; ++j) if (j < o.npos) o.pos[j] = a.inv_pos[q0 + j] & 0xFFFFFF;
-        o.th = a.theta[r]; o.m = a.m[r]; o.v = a.v[r];
+        if (!a.eval_only) {                                   // (an evaluation-only launch has no optimiser state and no weight image to update)
+            const int q0 = a.inv_ptr[r];
+            o.npos = a.inv_ptr[r + 1] - q0;
+            PINN_UNROLL for (int j = 0; j < TRAIN_MAX_POS; ++j) if (j < o.npos) o.pos[j] = a.inv_pos[q0 + j] & 0xFFFFFF;
+            o.th = a.theta[r]; o.m = a.m[r]; o.v = a.v[r];
+        }
     }
 }
 DEV void train_own_step(TrainOwn& o, const TrainArgs& a, int step) {
@@ -189,6 +197,7 @@ DEV void train_own_step(TrainOwn& o, const TrainArgs& a, int step) {
 #endif
         const float g = (float)s;
         a.out[r] = g;
+        if (a.eval_only) return;
         const float t = ur::adam_update(o.th, o.m, o.v, g, a.lr, a.b1, a.b2, a.eps, a.c12[2 * step], a.c12[2 * step + 1]);
         o.th = t;
         a.m[r] = o.m;
@@ -202,10 +211,17 @@ DEV void train_own_step(TrainOwn& o, const TrainArgs& a, int step) {
 // the step before: same counter-based rules as the stand-alone kernels, one thread per POINT — its coordinates, then its source channels)
 DEV void train_resample(const TrainArgs& a, int gid, int nthreads, int next_step) { aux::resample_point_sets(a.samp, a.nsamp, gid, nthreads, next_step); }
 
+// one thread reports a barrier time-out of this launch to the host
+DEV void train_report(const TrainArgs& ta, int blk, int w) {
+#ifndef PINN_EMU
+    if (blk == 0 && threadIdx.x == 0 && __hip_atomic_load(ta.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) *ta.hflag = 1u;
+#endif
+}
+
 // the wave program of the training kernel: workgroup `blk` of `nblocks`, wave `w` of the workgroup
 template <class S, int ACTK>
 DEV void wave_train(const GroupArgs& ga, const TrainArgs& ta, int blk, int nblocks, int w, float* lds) {
-    unsigned arrivals = 0;
+    unsigned arrivals = ta.arrivals0;
 #ifdef PINN_EMU
     const int gid0 = (blk * 4 + w) * 64;                      // first of this wave's 64 threads
     TrainOwn own[64];
@@ -237,11 +253,13 @@ DEV void wave_train(const GroupArgs& ga, const TrainArgs& ta, int blk, int nbloc
         if (ta.nsamp > 0 && step + 1 < ta.nsteps) train_resample(ta, gid0, nblocks * 256, step + 1);
 #endif
         TRAIN_STAMP(2)
+        if (ta.eval_only) { train_report(ta, blk, w); return; }
         arrivals += (unsigned)nblocks;
         train_barrier(ta.bar, arrivals, ta.fenced);           // the new parameters (theta, weight image) and the K sums are visible
         TRAIN_STAMP(3)
     }
     if (first && ta.nsteps > 0) train_hist(ta, ta.nsteps - 1);
+    train_report(ta, blk, w);
     TRAIN_STAMP_STORE
 }
 

@@ -171,3 +171,38 @@ def test_persistent_training_kernel_over_kernel_shapes(npde, use_emu, monkeypatc
         for x, y, what in zip(a[:4], b[:4], ("theta", "history", "theta after resume", "history after resume")):
             assert np.array_equal(x, y), (name, what)
     assert sum(p == "persistent" for _, p in ran) >= 4, ran
+
+
+def test_single_evaluation_in_one_launch_equals_the_stand_alone_kernels(npde, use_emu, monkeypatch):
+    """pinn_loss_grad / pinn_lbfgs on a small problem: residual kernel + grid barrier + fixed-order sums in ONE launch (the training kernel's
+    evaluation-only mode) instead of residual kernel + reduction kernel — term losses and gradient bit for bit, also with an estimated PDE
+    parameter in theta; a caller that asks for HIP events (set_timing) keeps the stand-alone kernels."""
+    from neuralpde_jl_amd import workloads
+    wl = workloads.cfg1_poisson1d(600)
+    cases = [("cfg1", wl.pde_system, wl.chains[0], wl.strategy, wl.theta, None)]
+    sysm, chain = poisson2d(npde, "sigmoid", width=16, hidden=2)
+    cases.append(("poisson2d", sysm, chain, npde.GridTraining(0.1), theta_for(chain, 9), [1.0, 2.0, 1.0, 3.0, 1.0]))
+    taken = []
+    for name, sysm, chain, strat, th0, w in cases:
+        rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th0))
+        eng = rep.engine
+        wts = None if w is None else np.asarray(w, dtype=np.float32)
+        monkeypatch.setenv("PINN_NO_FUSED_EVAL", "1")
+        l0, g0 = eng.loss_grad(th0, wts)
+        monkeypatch.delenv("PINN_NO_FUSED_EVAL")
+        assert eng.get_option("eval_path") == "stand-alone kernels"
+        l1, g1 = eng.loss_grad(th0, wts)
+        taken.append(eng.get_option("eval_path"))
+        l2, g2 = eng.loss_grad(th0 * 1.01, wts)                   # (the barrier counter runs on from launch to launch)
+        l3, g3 = eng.loss_grad(th0, wts)
+        assert np.array_equal(l0, l1) and np.array_equal(g0, g1), name
+        assert np.array_equal(l0, l3) and np.array_equal(g0, g3) and not np.array_equal(g0, g2), name
+        theta, hist = eng.lbfgs(th0, 5, wts)
+        monkeypatch.setenv("PINN_NO_FUSED_EVAL", "1")
+        theta_b, hist_b = eng.lbfgs(th0, 5, wts)
+        monkeypatch.delenv("PINN_NO_FUSED_EVAL")
+        assert np.array_equal(theta, theta_b) and np.array_equal(hist, hist_b), name
+    assert "one launch" in taken, taken
+    eng.set_timing(1, -1)                                  # events requested: the stand-alone kernels they bracket
+    eng.loss_grad(th0, wts)
+    assert eng.get_option("eval_path") == "stand-alone kernels"

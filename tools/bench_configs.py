@@ -37,6 +37,7 @@ for name, fn, kw in cfgs:
         al.broadcast(len(rep.pde_train_sets), len(rep.bcs_train_sets))
         w = list(al.pde_loss_weights) + list(al.bc_loss_weights)
     st = torch.cuda.current_stream()
+    eng.set_timing(1, -1)                      # HIP events around every launch group for the per-kernel column
     for _ in range(3):
         eng.loss_grad_device(th.data_ptr(), out.data_ptr(), w, st.cuda_stream)
     torch.cuda.synchronize()
