@@ -256,9 +256,10 @@ int pinn_get_option(pinn_handle h, const char* name, char* buf, int64_t buflen);
 
 /* Timing of the last pinn_loss_grad*: HIP-event milliseconds of the fused residual kernels / of the whole device section. */
 int pinn_last_timing(pinn_handle h, float* kernel_ms, float* total_ms);
-/* How many HIP events an evaluation records: level 0 none, 1 a start/stop pair around launch group `group` (-1: every
- * group), 2 (default) additionally the phase events behind pinn_last_timing.  Every recorded event costs a few us of
- * dispatch gap between kernels, so latency-critical callers (small per-rank shares) use 0 or 1. */
+/* How many HIP events an evaluation records: level 0 (default) none, 1 a start/stop pair around launch group `group` (-1: every
+ * group), 2 additionally the phase events behind pinn_last_timing.  Every recorded event costs a few us of dispatch gap between
+ * kernels — 25 us per pinn_loss_grad call at level 2, measured on the reference's 1-D Poisson test (profiles/r04_train_kernel.txt) —
+ * so events are opt-in: profiling callers switch them on, pinn_last_timing / pinn_group_timing report -1 otherwise. */
 int pinn_set_timing(pinn_handle h, int level, int group);
 /* Kernel plan: number of launch groups (terms that share one fused kernel) and the HIP-event duration of group g's
  * fused residual kernel in the last evaluation (-1 if that group was not timed, see pinn_set_timing), with the

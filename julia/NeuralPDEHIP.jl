@@ -81,9 +81,7 @@ mutable struct HIPEngine
         e = new(out[], 0, 0)
         e.K = ccall(sym(:pinn_num_terms), Cint, (Ptr{Cvoid},), e.h)
         e.P = ccall(sym(:pinn_num_theta), Int64, (Ptr{Cvoid},), e.h)
-        # no HIP events around the kernels of an evaluation (the library's default records the phase events behind pinn_last_timing on every
-        # host-entry call: ~10 µs of dispatch gaps, as much as a small problem's kernels); profiling callers switch them on with pinn_set_timing
-        ccall(sym(:pinn_set_timing), Cint, (Ptr{Cvoid}, Cint, Cint), e.h, 0, -1)
+        # (no HIP events around the kernels of an evaluation — the library's default; profiling callers switch them on with pinn_set_timing)
         finalizer(x -> (x.h != C_NULL && ccall(sym(:pinn_destroy), Cint, (Ptr{Cvoid},), x.h); x.h = C_NULL), e)
         return e
     end

@@ -197,9 +197,8 @@ class Engine:
         self.L.check(self.L.lib.pinn_create_on(descriptor.encode(), device, C.byref(self.h)), "pinn_create")
         self.K = self.L.lib.pinn_num_terms(self.h)
         self.P = int(self.L.lib.pinn_num_theta(self.h))
-        # no HIP events around the kernels of an evaluation unless a caller asks for timings (set_timing): the library's default records
-        # the phase events behind pinn_last_timing on every host-entry call, ~10 us of dispatch gaps — as much as a small problem's kernels
-        self.L.lib.pinn_set_timing(self.h, 0, -1)
+        # (no HIP events around the kernels of an evaluation unless a caller asks for timings with set_timing: the library's default since
+        # r04 — the phase events behind pinn_last_timing cost 25 us per host-entry call, as much as a small problem's kernels)
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:

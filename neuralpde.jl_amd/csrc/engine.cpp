@@ -1704,7 +1704,7 @@ int pinn_set_timing(pinn_handle h, int level, int group) {
 
 int pinn_last_timing(pinn_handle h, float* kernel_ms, float* total_ms) {
     if (!h) return fail("null handle");
-    if (!h->timing_valid) return fail("no timing available (call pinn_loss_grad first)");
+    if (!h->timing_valid) return fail("no timing available: switch the phase events on (pinn_set_timing(h, 2, -1)), then call pinn_loss_grad");
     plat_event_sync(h->ev3);
     if (kernel_ms) *kernel_ms = plat_event_ms(h->ev1, h->ev2);
     if (total_ms) *total_ms = plat_event_ms(h->ev0, h->ev3);

@@ -230,7 +230,7 @@ struct pinn_engine {
     plat_event ev_fork, ev_join[aux::MAX_GROUPS];
     float last_kernel_ms = 0.f, last_total_ms = 0.f;
     bool timing_valid = false;
-    int timing_level = 2;        // 0: no events, 1: per-launch-group kernel events, 2: + phase events (pinn_last_timing)
+    int timing_level = 0;        // 0 (default since r04): no events, 1: per-launch-group kernel events, 2: + phase events (pinn_last_timing)
     int timing_group = -1;       // level >= 1: which launch group gets events (-1: all)
     // resident-theta Adam state
     float* d_opt_theta = nullptr;
