@@ -52,6 +52,9 @@ int main(void) {
     CHECK(pinn_adam_init(h, theta, 337));
     CHECK(pinn_adam_steps(h, 300, 0.01f, 0.9f, 0.999f, 1e-8f, w, hist));
     CHECK(pinn_adam_get(h, theta, 337));
+    char path[64];
+    CHECK(pinn_get_option(h, "adam_path", path, (int64_t)sizeof path));      /* "persistent": all 300 iterations inside one launch (small problems) */
+    printf("pinn_adam_steps ran: %s\n", path);
     CHECK(pinn_loss_grad(h, theta, 337, NULL, losses, NULL));
     const double last = losses[0] + losses[1] + losses[2];
     printf("after 300 Adam iterations: %.4e %.4e %.4e (weighted objective %.4e -> %.4e)\n", losses[0], losses[1], losses[2], hist[0], hist[299]);
