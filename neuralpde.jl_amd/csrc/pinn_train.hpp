@@ -7,20 +7,23 @@
 // boundary, a grid ramp and first-touch cache misses.  Here the whole iteration is one pass of a persistent kernel whose workgroups are
 // all resident (at most REDUCE_DIRECT_MAX = 32 workgroups on 256 CUs):
 //
+//     (once)  every thread takes ONE element of [theta | K sums] (TrainArgs::own_r: placed in slab-entry order) and keeps its reduction map,
+//             its image positions and its (theta, m, v) in registers across the steps
 //     for step = 1 .. K:
-//         wave_main<MODE_FUSED>         forward jets + residual tape + reverse sweep of this wave's tiles  -> gradient slabs, loss partials
-//         grid barrier                  (agent-scope release / acquire, vec.hpp: grid_barrier)
-//         update                        every thread of the grid owns theta elements r, r + grid, ...: the fixed-order sum of the slab
-//                                       entries over the workgroups (the association of aux::reduce_direct_body), the Adam rule
-//                                       (update_rules.hpp), the new value scattered into the packed weight image (inverse pack map);
-//                                       K more threads: the per-term sums of squares
-//         grid barrier
-//         (one lane)                    loss history of the step
+//         wave_main<MODE_FUSED>         forward jets + residual + reverse sweep of this wave's tiles -> gradient slabs, loss partials
+//         grid barrier A                (write-through exchange, no fences: vec.hpp grid_barrier_wt; fenced when point sets are redrawn)
+//         update                        the fixed-order sum of the element's slab entries over the workgroups (the association of
+//                                       aux::reduce_direct_body: every load in flight at once), the Adam rule (update_rules.hpp), the new
+//                                       value scattered into the packed weight image; K threads: the per-term sums of squares; one idle
+//                                       thread: the loss history of the PREVIOUS step; every thread: its share of the NEXT step's redrawn
+//                                       point sets (sample_rules.hpp) where the strategy resamples
+//         grid barrier B
 //
 // Same arithmetic, same association, same rounding as the three stand-alone kernels: K iterations in one launch equal K single steps
-// BIT FOR BIT (tests/test_train_kernel.py; GPU mirror in tests/test_gpu_mirror.py).  Not eligible (the engine takes the loop): more
-// workgroups than the one-stage reduction covers, estimated PDE parameters, several networks or launch groups,
-// communicators, sin / per-layer activations, the float64 mode, embedded or data-carrying redrawn sets.
+// BIT FOR BIT (tests/test_train_kernel.py; GPU mirror in tests/test_gpu_mirror.py).  With TrainArgs::eval_only the same kernel is ONE
+// evaluation (residual kernel, barrier A, sums -> out) for the host entry points.  Not eligible (the engine takes the loop): more
+// workgroups than the one-stage reduction covers, fewer threads than parameters, estimated PDE parameters (training), several networks or
+// launch groups, communicators, sin / per-layer activations, the float64 mode, embedded or data-carrying redrawn sets.  DESIGN.md 4.6.
 #pragma once
 #include "pinn_kernels.hpp"
 #include "update_rules.hpp"
@@ -64,7 +67,7 @@ struct TrainArgs {
     int hist_gid;                // the thread that writes the loss history (one without an element where the grid has one)
     int cached;                  // every thread of the grid owns at most ONE element of [0, P + K) with at most TRAIN_MAX_CONTRIB slab entries and
                                  // TRAIN_MAX_POS image positions: its maps and its (theta, m, v) stay in registers across the steps
-    unsigned* bar;               // [0] arrival counter of the grid barrier, [1] time-out flag (both zeroed by the host before the launch)
+    unsigned* bar;               // [0] arrival counter of the grid barrier (zeroed once, then running on: arrivals0), [1] time-out flag
 };
 
 constexpr int TRAIN_MAX_CONTRIB = 4, TRAIN_MAX_POS = 4;
@@ -80,7 +83,7 @@ template <class T> DEV T train_ld(const T* p) { return TRAIN_WT ? uload_wt(p) : 
 template <class T> DEV void train_st(T* p, T x) { if (TRAIN_WT) ustore_wt(p, x); else *p = x; }
 DEV void train_barrier(unsigned* bar, unsigned target, int fenced) { if (TRAIN_WT && !fenced) grid_barrier_wt(bar, target); else grid_barrier(bar, target); }
 
-// profiling build only (-DPINN_STAMP, tools/time_adam_loop.py --stamps): thread 0 of the launch accumulates the s_memtime ticks of the four
+// profiling build only (-DPINN_STAMP variant, tools/time_adam_loop.py --lib <it>): the history thread of the launch accumulates the s_memtime ticks of the four
 // phases of an iteration — evaluation, barrier, update, barrier — into bar[4 .. 11] (64-bit sums); never defined for the product
 #if defined(PINN_STAMP) && !defined(PINN_EMU)
 #define TRAIN_STAMP_DECL unsigned long long tst_acc[4] = {0, 0, 0, 0}, tst_last = __builtin_amdgcn_s_memtime();

@@ -444,7 +444,6 @@ DEV vfloat ub_load(ubuf b, int soff, vint voff) {
 }
 // one double per lane through a buffer view over doubles (offsets in doubles); AUX 16 = sc1 (agent-scope load)
 template <int AUX> DEV double ub_loadd(ubuf b, int soff, vint voff) {
-    typedef unsigned u2 __attribute__((ext_vector_type(2)));
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(b.r, voff * 8, soff * 8, AUX));
 }
 template <int AUX> DEV float ub_loadf(ubuf b, int soff, vint voff) {
@@ -487,8 +486,9 @@ DEV void wave_fence() {
 #endif
 DEV void wg_barrier() { if (!(PINN_PROBE & 4)) __syncthreads(); }
 // Grid barrier of a launch whose workgroups are ALL resident (pinn_train.hpp: at most one workgroup per CU, far fewer workgroups than
-// CUs).  bar[0]: monotonic arrival counter, zeroed by the host before the launch; `target` = arrivals expected so far (workgroups x
-// barriers passed); bar[1]: time-out flag.  Protocol of cdna_hip_programming.md Guideline 16 in its counter form: every wave drains its
+// CUs).  bar[0]: monotonic arrival counter, zeroed by the host ONCE and running on from launch to launch; `target` = arrivals expected so
+// far (the launch's starting count + workgroups x barriers passed; compared as a signed difference, so the counter may wrap); bar[1]:
+// time-out flag.  Protocol of cdna_hip_programming.md Guideline 16 in its counter form: every wave drains its
 // stores, the workgroup meets, ONE lane releases at agent scope (L2 write-back: the other XCDs' L2s are not coherent with this one),
 // arrives, polls the one word with relaxed agent-scope loads + s_sleep, acquires ONCE (drops this CU's stale L1 / non-local L2 lines), and
 // the workgroup meets again.  Every spin is bounded: a launch that is not fully resident sets bar[1] and runs to its end with wrong numbers
