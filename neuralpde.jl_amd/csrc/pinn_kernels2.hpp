@@ -340,7 +340,8 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
 
     vfloat4 wL[MTW];
     PINN_UNROLL for (int t = 0; t < MTW; ++t) wL[t] = ub_load4(PB, S::OFF_WL + 16 * (w * MTW + t), g << 2);
-    const vbf8 wb_probe = ub_load_bf8(PB, S::OFF_WB, lane << 2);      // (PINN_PROBE & 8: one fragment, loaded once, stands for all)
+    // (PINN_PROBE & 8, timing probe: one fragment, loaded once, stands for all — fp32-MFMA kernels have no bf16 image: OFF_WB is the image's end)
+    const vbf8 wb_probe = ((PINN_PROBE & 8) && S::BFIMG) ? ub_load_bf8(PB, S::OFF_WB, lane << 2) : vbf8{};
     const float bL = P[S::OFF_BL];
 
     wave_prio(1);

@@ -827,7 +827,7 @@ static int plan_group_buffers(pinn_engine& E) {
         const bool coop = s.COOP != 0;
         std::vector<int> loff(LH + 1);
         int o = N.theta_off;
-        for (int j = 0; j <= LH; ++j) {
+        for (int j = 0; j <= LH && s.family != 3; ++j) {        // (Dense chains; a DGM net's `sizes` is {d, modes, 1} whatever its depth)
             loff[j] = o;
             o += N.sizes[j + 1] * N.sizes[j] + N.sizes[j + 1];
         }
@@ -872,7 +872,7 @@ static int plan_group_buffers(pinn_engine& E) {
             for (int out = 0; out < N.sizes[j + 1]; ++out)
                 add_row(loff[j] + N.sizes[j + 1] * N.sizes[j] + out, s.O_BFRH + (hl * MT + out % MT) * 16 + out / MT, coop);
         }
-        for (int in = 0; in < N.sizes[LH] && s.family == 1; ++in)                // W_out (1 x nLH)
+        for (int in = 0; s.family == 1 && in < N.sizes[LH]; ++in)                // W_out (1 x nLH)   (family first: a DGM net's `sizes` has three entries)
             add_row(loff[LH] + in, s.O_WL + ((in / 16) * 4 + (in % 16) / 4) * 4 + in % 4, false);
         if (s.family == 1) {
             add_row(loff[LH] + N.sizes[LH], s.O_BL, false);
