@@ -206,3 +206,22 @@ def test_single_evaluation_in_one_launch_equals_the_stand_alone_kernels(npde, us
     eng.set_timing(1, -1)                                  # events requested: the stand-alone kernels they bracket
     eng.loss_grad(th0, wts)
     assert eng.get_option("eval_path") == "stand-alone kernels"
+
+
+def test_hip_events_are_opt_in(npde, use_emu):
+    """pinn_set_timing: no HIP events around an evaluation's kernels unless the caller asks (they cost 25 us per host-entry call on the
+    hardware): pinn_last_timing refuses until the phase events are switched on, and a caller that switches them on gets the stand-alone
+    kernels those events bracket."""
+    sysm, chain = poisson2d(npde, "tanh", width=16, hidden=2)
+    th0 = theta_for(chain, 4)
+    eng = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.2), init_params=th0)).engine
+    eng.loss_grad(th0)
+    with pytest.raises(Exception, match="pinn_set_timing"):
+        eng.last_timing()
+    eng.set_timing(2, -1)
+    eng.loss_grad(th0)
+    k, t = eng.last_timing()
+    assert k >= 0.0 and t >= 0.0 and eng.get_option("eval_path") == "stand-alone kernels"
+    eng.set_timing(0, -1)
+    eng.loss_grad(th0)
+    assert eng.get_option("eval_path") == "one launch"
