@@ -23,7 +23,7 @@ matrix pipe that EXECUTES its hidden-layer products: in the default "split" GEMM
 `achieved` = executed bf16 MFMA flops / mean HIP-event duration over >= 10 launches sampled inside the timed region, `peak` = the dense
 bf16 MFMA peak, `frac` <= 1 by construction; the fp32-equivalent rate against the fp32 MFMA peak — what BASELINE.json's north star
 names — is kept as `frac_fp32_equiv`), "roofline_kernels" (the same for every fused kernel of the step) and "cpu_baseline" (the float64
-oracle = CPU restatement of the reference algorithm, timed on this box's host cores on the same full-size workload at two thread counts,
+oracle = CPU restatement of the reference algorithm, timed on this box's host cores on the same full-size workload at 32 / 64 / 96 / 128 threads,
 the faster one reported; rank 0, N=1 only).  `value` keeps theta resident in HBM; `value_incl_theta_h2d` is SURVEY.md section 8d's
 definition (theta crosses PCIe every step: the C-ABI host entry point).
 """
@@ -62,14 +62,15 @@ def algorithmic_flops_per_point(sizes, C):
     return 6 * C * S - 2 * C * sizes[0] * sizes[1]
 
 
-CPU_THREADS = 32          # first intra-op thread count of the CPU baseline (capped by the box's hardware threads); the second is ALL of them
+CPU_THREADS = (32, 64, 96, 128)   # intra-op thread counts of the CPU baseline (capped by the box's hardware threads): torch's CPU GEMMs stop scaling
+                                   # somewhere in this range on the 256-thread hosts and COLLAPSE at every hardware thread (r04: 43 pts/s), so "all" is not tried
 
 
-def cpu_baseline(npde, wl, sets, nevals=10, budget_s=30.0, chunk=16384):
+def cpu_baseline(npde, wl, sets, nevals=5, budget_s=9.0, chunk=16384):
     """Time the float64 oracle (stencil mode = the reference's algorithm: 6 batched forward passes per Poisson residual + reverse
     mode) on this box's host cores on the SAME workload as the GPU leg — all 65,536 interior + 4 x 65,536 boundary points, evaluated
-    in chunks of `chunk` points per term to bound memory — at two thread counts (32, the count torch's CPU GEMMs scale to on these hosts,
-    and every hardware thread of the box); value = interior points / median eval time of the FASTER setting, both are stated."""
+    in chunks of `chunk` points per term to bound memory — at 32 / 64 / 96 / 128 intra-op threads (as far as the box has them; about 10 s of
+    work per leg); value = interior points / median eval time of the FASTEST setting, every leg is stated."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
@@ -95,7 +96,7 @@ def cpu_baseline(npde, wl, sets, nevals=10, budget_s=30.0, chunk=16384):
 
     runs = []
     probe = 2048                                # points per term of the probe that decides whether a thread count gets full evaluations
-    for nt in sorted(set([min(CPU_THREADS, ncpu), ncpu])):
+    for nt in sorted(set(min(t, ncpu) for t in CPU_THREADS)):
         torch.set_num_threads(nt)
         one(probe, 1)                           # warm-up (thread pool, allocator) on the probe ...
         est = one(probe, 1) * (max(N) / probe)  # ... and an estimate of one full evaluation from it
@@ -117,7 +118,7 @@ def cpu_baseline(npde, wl, sets, nevals=10, budget_s=30.0, chunk=16384):
             "thread_counts_tried": runs,
             "sample": f"median of {best['evals']} evals of the float64 stencil-mode oracle (torch CPU) on the full workload: {N[0]} interior + "
                       f"{len(N) - 1}x{N[1]} boundary points in chunks of {chunk}; timed with " +
-                      " and ".join(f"{r['threads']} threads ({r['value']:.3g} pts/s, {r['sample']})" for r in runs) + f" of {ncpu} hardware threads, the faster "
+                      ", ".join(f"{r['threads']} threads ({r['value']:.3g} pts/s, {r['sample']})" for r in runs) + f" of {ncpu} hardware threads, the fastest "
                       f"one reported; Julia/NeuralPDE.jl itself is not installable here (no network)"}
 
 
@@ -224,6 +225,54 @@ def roofline_entries(eng, kern_ms, sizes, world):
     return per_kernel
 
 
+F64_MFMA_PEAK_TF = 78.6          # dense v_mfma_f64_16x16x4_f64 peak of MI355X (MI355X_MICROARCH.md; = the f64 vector peak)
+
+
+def bench_f64(args, eng, rep, sets, wl):
+    """One line for the FLOAT64 evaluation mode on the same workload: a step = pinn_loss_grad_f64 (theta from host memory in double, loss +
+    gradient back in double; the chunked tile / small-entry / weight-gradient / reduce kernels of csrc/pinn_kernels5.hpp + pinn_kernels4.hpp).
+    roofline: the hidden-layer GEMM flops the f64 MFMAs execute (forward + dA in the tile kernel, dW in the weight-gradient kernel: 3 x 2 x
+    H^2 per hidden-to-hidden layer, point and jet channel — the channel counts are the FLOAT64 kernels' (Poisson interior: C = 5, no
+    forward-Laplacian channel)) over the WHOLE evaluation's wall time against the dense f64 MFMA peak; the per-kernel durations are in
+    profiles/r05_f64_kernel_stats.txt."""
+    import numpy as np
+    import torch
+    eng.set_option("precision", "f64")
+    for k, s_ in enumerate(sets):
+        eng.set_points_f64(k, s_)
+    th = np.asarray(rep.flat_init_params, dtype=np.float64)
+    K = eng.K
+    w = np.ones(K)
+    for _ in range(max(2, args.warmup)):
+        l0, g0 = eng.loss_grad_f64(th, w)
+    path = eng.get_option("f64_path")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        l1, g1 = eng.loss_grad_f64(th, w)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert np.array_equal(l1, l0) and np.array_equal(g1, g0), "float64 evaluation is not reproducible"
+    ms = dt / args.steps * 1e3
+    sizes = list(wl.chains[0].sizes)
+    hh = sum(sizes[i] * sizes[i + 1] for i in range(1, len(sizes) - 2))          # hidden-to-hidden products per point and channel
+    chans = [int(c) for c in eng.describe().split("f64_channels=")[1].split()[0].split(",")] if "f64_channels=" in eng.describe() else None
+    n = [s_.shape[1] for s_ in sets]
+    if chans is None:
+        chans = [5] + [1] * (K - 1) if args.workload == "cfg2" else [1] * K
+    flops = sum(3 * 2 * hh * c * nn for c, nn in zip(chans, n))
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"metric": "collocation-point residual+grad evals/sec, 2D Poisson 4x64 MLP (float64 evaluation mode)" if args.workload == "cfg2" else f"collocation-point residual+grad evals/sec ({args.workload}, float64 evaluation mode)",
+            "value": n[0] / (ms * 1e-3), "unit": "interior-point residual+grad evals/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wl.name if hasattr(wl, "name") else args.workload, "points_per_term": n, "precision": "f64", "f64_path": path,
+                       "entry": "pinn_loss_grad_f64 (theta H2D + gradient D2H in double inside the step)"},
+            "roofline": {"bound": "mfma-f64", "achieved": ach, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / F64_MFMA_PEAK_TF, "traffic": None,
+                         "flops_per_step": flops, "channels_per_term": chans,
+                         "note": "executed f64 MFMA flops (forward + dA + dW hidden-layer GEMMs) / whole-evaluation wall time; kernel-level durations: profiles/r05_f64_kernel_stats.txt"},
+            "loss_terms": [float(x) for x in l1]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -244,6 +293,10 @@ def main():
                          "sets in HBM (pinn_adam_steps; N > 1 / --emulate-world: evaluate -> in-stream all-reduce -> fused update on every rank, no host "
                          "synchronisation inside the loop); the K timed steps are ONE call.  Not the headline metric (which delivers loss + "
                          "gradient to a host optimiser every step) — the loop a training run actually executes")
+    ap.add_argument("--precision", choices=["f32", "f64"], default="f32",
+                    help="f64: the engine's FLOAT64 evaluation mode (pinn_set_option(h, \"precision\", \"f64\"): the reference's default eltype, "
+                         "src/discretize.jl:432-449) on the same workload — its own line with a roofline entry against the f64 MFMA peak (r05: "
+                         "v_mfma_f64_16x16x4_f64 tile kernels, csrc/pinn_kernels5.hpp).  Not the headline metric (north star: fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--events", choices=["all", "none"], default="all",
                     help="HIP events recorded inside the timed region around every fused residual kernel (sampled steps only), or none")
@@ -293,6 +346,10 @@ def main():
         eng.set_option("gemm", args.gemm)
     sets = rep.pde_train_sets + rep.bcs_train_sets
     K, P = eng.K, eng.P
+    if args.precision == "f64":
+        assert world == 1 and not args.emulate_world and not args.resident, "--precision f64 is a single-GPU evaluation line"
+        print(json.dumps(bench_f64(args, eng, rep, sets, wl)))
+        return
     n_glob = [s.shape[1] for s in sets]
     theta0 = np.asarray(rep.flat_init_params, dtype=np.float32)
     tw = rep._weights_now() if hasattr(rep, "_weights_now") else None        # cfg4: bc weights 10 (NonAdaptiveLoss)

@@ -259,7 +259,9 @@ int pinn_last_timing(pinn_handle h, float* kernel_ms, float* total_ms);
 /* How many HIP events an evaluation records: level 0 (default) none, 1 a start/stop pair around launch group `group` (-1: every
  * group), 2 additionally the phase events behind pinn_last_timing.  Every recorded event costs a few us of dispatch gap between
  * kernels — 25 us per pinn_loss_grad call at level 2, measured on the reference's 1-D Poisson test (profiles/r04_train_kernel.txt) —
- * so events are opt-in: profiling callers switch them on, pinn_last_timing / pinn_group_timing report -1 otherwise. */
+ * so events are opt-in (the default changed from level 2 to level 0 in r04: callers of pinn_last_timing must call pinn_set_timing(h, 2, -1)
+ * first): with the events off pinn_last_timing FAILS (non-zero return, pinn_last_error says how to switch them on) and
+ * pinn_group_timing reports ms = -1. */
 int pinn_set_timing(pinn_handle h, int level, int group);
 /* Kernel plan: number of launch groups (terms that share one fused kernel) and the HIP-event duration of group g's
  * fused residual kernel in the last evaluation (-1 if that group was not timed, see pinn_set_timing), with the

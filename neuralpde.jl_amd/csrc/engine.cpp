@@ -566,6 +566,7 @@ static bool train_timed_out(pinn_engine& E);
 // run_loss_grad; results in d_out / lossraw either way.  Synchronises.
 static int eval_and_sync(pinn_engine& E, float* d_out, const float* term_w, double* lossraw, bool timing) {
     E.eval_path = 1;
+    if (ensure_points(E)) return 1;                  // (every path: the one-launch evaluation below does not go through run_loss_grad's check — ADVICE r04)
     if (eval_eligible(E)) {
         if (eval_fused(E, E.d_theta, d_out, term_w, lossraw)) return 1;
         if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
@@ -886,6 +887,8 @@ int pinn_set_sampler(pinn_handle h, int term, int kind, const float* lb, const f
     if (kind < 0 || kind > 3) return fail("pinn_set_sampler: kind must be 0 (fixed set), 1 (uniform), 2 (Latin hypercube) or 3 (Sobol)");
     if (kind == 3 && T.d_user > 8) return fail("pinn_set_sampler: the Sobol sampler covers up to 8 axes");
     if (kind == 0) { T.sampler = 0; return 0; }
+    if (E.f64) return fail("pinn_set_sampler: the float64 evaluation mode has no device samplers (the float32 optimiser entry points would run beside a float64 evaluation); "
+                           "switch precision back to \"f32\" first or redraw on the host");
     if (!lb || !ub || n <= 0) return fail("pinn_set_sampler: bounds and a positive point count are required");
     if (!T.d_lb) { T.d_lb = (float*)plat_malloc(sizeof(float) * 8); T.d_ub = (float*)plat_malloc(sizeof(float) * 8); }
     if (!T.d_lb || !T.d_ub) return fail("device allocation failed (sampler)");
@@ -1029,8 +1032,9 @@ int pinn_get_option(pinn_handle h, const char* name, char* buf, int64_t buflen) 
     if (k == "precision") { std::snprintf(buf, (size_t)buflen, "%s", h->f64 ? "f64" : "f32"); return 0; }
     if (k == "persistent") { std::snprintf(buf, (size_t)buflen, "%s", h->persistent ? "on" : "off"); return 0; }
     if (k == "eval_path") { std::snprintf(buf, (size_t)buflen, "%s", h->eval_path == 2 ? "one launch" : (h->eval_path == 1 ? "stand-alone kernels" : "none")); return 0; }
+    if (k == "f64_path") { std::snprintf(buf, (size_t)buflen, "%s", pe::f64_path(*h)); return 0; }
     if (k == "adam_path") { std::snprintf(buf, (size_t)buflen, "%s", h->adam_path == 2 ? "persistent" : (h->adam_path == 1 ? "loop" : "none")); return 0; }
-    return fail("pinn_get_option: unknown option \"" + k + "\" (known: gemm, precision, persistent, adam_path, eval_path)");
+    return fail("pinn_get_option: unknown option \"" + k + "\" (known: gemm, precision, persistent, adam_path, eval_path, f64_path)");
 }
 
 int pinn_adam_init(pinn_handle h, const float* theta, int64_t p) {
@@ -1608,6 +1612,13 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
     std::deque<std::vector<double>> S, Y;
     std::deque<double> RHO;
     bool switched = false;
+    // the noise-floor switch below only changes arithmetic where a launch group runs a family-2 kernel that exists as a split / fp32 twin
+    bool has_twin = false;
+    for (const NetPlan& NP : E.netplans) has_twin = has_twin || (NP.spec && NP.spec->family == 2 && NP.spec->twin);
+    struct Restore {                                     // every exit path hands the handle back in the mode it came in
+        pinn_engine& E; bool armed = false;
+        ~Restore() { if (armed && E.gemm != pk::GEMM_SPLIT) { const std::string keep = g_err; replan_gemm(E, pk::GEMM_SPLIT); if (!keep.empty()) g_err = keep; } }
+    } restore{E};
     int it = 0;
     for (; it < maxiters; ++it) {
         double gmax = 0.0;
@@ -1653,9 +1664,12 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
         if (!ok) {
             // no decrease along a descent direction: the evaluation's noise floor.  The split-operand GEMMs' floor is 2-4 x that of the
             // fp32 MFMA kernels: switch the handle to them once and go on from the same iterate
-            if (!E.f64 && E.gemm == pk::GEMM_SPLIT && !switched && std::getenv("PINN_LBFGS_KEEP_GEMM") == nullptr) {
-                if (replan_gemm(E, pk::GEMM_FP32)) return 1;
+            if (!E.f64 && E.gemm == pk::GEMM_SPLIT && !switched && has_twin && std::getenv("PINN_LBFGS_KEEP_GEMM") == nullptr) {
+                // a failed switch (the fp32 twin of a run-time specialised shape did not compile) leaves the handle in split mode — replan_gemm
+                // restored the plan: the iterate reached so far is the answer, not an error
+                if (replan_gemm(E, pk::GEMM_FP32)) { if (E.gemm != pk::GEMM_SPLIT || E.groups.empty()) return 1; g_err.clear(); break; }
                 switched = E.gemm == pk::GEMM_FP32;
+                restore.armed = switched;
                 if (switched) {
                     if (eval(x, &g, f)) return 1;
                     S.clear(); Y.clear(); RHO.clear();   // curvature pairs carry the other arithmetic's gradient noise
@@ -1678,7 +1692,7 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
     if (loss_history) for (int i = it; i < maxiters; ++i) loss_history[i] = f;
     if (iters_done) *iters_done = it;
     for (size_t i = 0; i < P; ++i) theta[i] = x[i];
-    if (switched && replan_gemm(E, pk::GEMM_SPLIT)) return 1;
+    if (switched) { restore.armed = false; if (replan_gemm(E, pk::GEMM_SPLIT)) return 1; }
     return 0;
 }
 
@@ -1757,7 +1771,7 @@ int pinn_describe(pinn_handle h, char* buf, int64_t buflen) {
     if (!h || !buf || buflen <= 0) return fail("pinn_describe: bad argument");
     std::ostringstream os;
     os << "backend=" << plat_name() << " cus=" << h->ncu << " ntheta=" << h->ntheta << " terms=" << h->terms.size()
-       << (h->f64 ? " precision=f64 (pinn_loss_grad*, pinn_lbfgs evaluate in double: one lane per point; the plan below serves the fp32 entry points)" : "") << "\n";
+       << (h->f64 ? " precision=f64 (pinn_loss_grad*, pinn_lbfgs evaluate in double — matrix-pipe tile kernels where instantiated, one lane per point elsewhere; the plan below serves the fp32 entry points)" + pe::f64_describe(*h) : std::string()) << "\n";
     for (size_t n = 0; n < h->netplans.size(); ++n)
         if (h->netplans[n].spec && h->netplans[n].spec->family != 3)
             os << "net " << n << " weights=packed image (k_pack per evaluation)"

@@ -306,6 +306,8 @@ struct DeviceScope {
 // f64.cpp: the float64 evaluation mode (pinn_kernels4.hpp)
 int f64_enable(pinn_engine& E);
 void f64_destroy(pinn_engine& E);
+std::string f64_describe(const pinn_engine& E);
+const char* f64_path(const pinn_engine& E);      // kernels of the last float64 evaluation: "mfma" | "lanes" | "mfma+lanes" | "none" | "off"
 int f64_points_changed(pinn_engine& E, int term);
 int f64_set_points(pinn_engine& E, int term, const double* pts, int64_t n);
 int f64_eval(pinn_engine& E, const double* theta, const double* term_w, double* term_losses, double* grad);

@@ -8,11 +8,15 @@
 // with the same number of inputs), derivative orders <= 2 in 1-3 inputs (1-D: <= 4; 4-D: first and pure second derivatives), PDE parameters
 // (param_estim), quadrature weights; no periodic embeddings, no DATA channels, no device samplers, no DGM networks.  Anything else fails at pinn_set_option with a message — the fp32 plan of the handle stays usable.
 #include "engine_types.hpp"
-#include "pinn_kernels4.hpp"
+#include "pinn_kernels5.hpp"
 
 namespace pk {
 std::deque<F64Kernel>& f64_registry() {
     static std::deque<F64Kernel> r;
+    return r;
+}
+std::deque<F64MKernel>& f64m_registry() {
+    static std::deque<F64MKernel> r;
     return r;
 }
 }  // namespace pk
@@ -21,6 +25,7 @@ namespace pe {
 
 struct F64Term {
     const pk::F64Kernel* k = nullptr;
+    const pk::F64MKernel* km = nullptr;  // the matrix-pipe kernels of the same jet set (family 4m), nullptr: one lane per point (family 4)
     std::vector<int> nets;               // networks the equation references, increasing
     std::vector<int> slot_net, slot_chan;      // per slot: index into `nets`, jet channel
     rp::Instr* d_prog = nullptr;
@@ -40,6 +45,7 @@ struct F64State {
     double* d_slab = nullptr;
     size_t slab_cap = 0;
     std::vector<double> h_out;           // host staging [P + K]
+    int path = 0;                        // kernels of the last evaluation: bit 0 one lane per point (family 4), bit 1 matrix pipe (family 4m)
 };
 
 static void f64_free(F64State* S) {
@@ -131,6 +137,21 @@ int f64_enable(pinn_engine& E) {
         std::string why;
         F.k = f64_find(E.nets[nets[0]].sizes[0], T.slots, F.slot_chan, why);
         if (!F.k) return fail(who + why);
+        // family 4m (v_mfma_f64_16x16x4_f64): tanh / sigmoid networks with hidden layers no wider than an instantiated 16 * HT
+        {
+            int maxh = 0;
+            bool ok = !any_sin;
+            for (int net : nets) {
+                const Net& N = E.nets[net];
+                if (N.sizes.size() < 3) ok = false;
+                for (size_t j = 1; j + 1 < N.sizes.size(); ++j) maxh = std::max(maxh, N.sizes[j]);
+            }
+            F.km = nullptr;
+            if (ok)
+                for (const pk::F64MKernel& km : pk::f64m_registry())
+                    if (km.D == F.k->D && km.D1MASK == F.k->D1MASK && km.PAIRS == F.k->PAIRS && km.NPAIR == F.k->NPAIR && km.HI == F.k->HI &&
+                        16 * km.HT >= maxh && (!F.km || km.HT < F.km->HT)) F.km = &km;
+        }
         F.slot_net.clear();
         for (auto& sl : T.slots) F.slot_net.push_back((int)(std::find(nets.begin(), nets.end(), sl.net) - nets.begin()));
         F.nops = (int)T.ops.size(); F.out_row = T.out_row; F.nslots = (int)T.slots.size();
@@ -189,6 +210,7 @@ int f64_eval(pinn_engine& E, const double* theta, const double* term_w, double* 
     if (plat_h2d(S.d_theta, theta, sizeof(double) * P, E.stream)) return fail("H2D copy of theta failed");
     plat_memset(S.d_grad, 0, sizeof(double) * P, E.stream);
     plat_memset(S.d_sumsq, 0, sizeof(double) * K, E.stream);
+    S.path = 0;
     for (int t = 0; t < K; ++t) {
         const Term& T = E.terms[t];
         const Term& T0 = E.terms0[t];
@@ -243,8 +265,13 @@ int f64_eval(pinn_engine& E, const double* theta, const double* term_w, double* 
         const double w = term_w ? term_w[t] : 1.0;
         a.scale = 2.0 * w / (double)T.n_norm;
         a.mode = grad ? 0 : 1;
-        // chunks of points: the scratch stays below 256 MB
-        int64_t chunk = (int64_t)((256.0 * 1024 * 1024) / (8.0 * rows));
+        const bool mfma = F.km && std::getenv("PINN_F64_NO_MFMA") == nullptr;
+        S.path |= mfma ? 2 : 1;
+        // chunks of points: the scratch stays below 256 MB (one lane per point) / 1 GB (matrix-pipe kernels: one wave per 16-64 points, a
+        // chunk should hold a few thousand tiles); $PINN_F64_SCRATCH_MB overrides
+        double mb = mfma ? 1024.0 : 256.0;
+        if (const char* e = std::getenv("PINN_F64_SCRATCH_MB")) mb = std::max(1.0, std::atof(e));
+        int64_t chunk = (int64_t)((mb * 1024 * 1024) / (8.0 * rows));
         chunk = std::max<int64_t>(pk::F64_BLOCK, (chunk / pk::F64_BLOCK) * pk::F64_BLOCK);
         chunk = std::min<int64_t>(chunk, ((F.n + pk::F64_BLOCK - 1) / pk::F64_BLOCK) * pk::F64_BLOCK);
         const size_t need = (size_t)rows * (size_t)chunk;
@@ -268,9 +295,11 @@ int f64_eval(pinn_engine& E, const double* theta, const double* term_w, double* 
         for (int64_t p0 = 0; p0 < F.n; p0 += chunk) {
             a.p0 = (int)p0;
             a.npts = (int)std::min<int64_t>(chunk, F.n - p0);
-            F.k->launch_point(a, sin_act, E.stream);
+            if (mfma) F.km->launch_tile(a, E.stream);
+            else F.k->launch_point(a, sin_act, E.stream);
             pk::launch_f64_dw(a, E.stream);
-            pk::launch_f64_dwt(a, E.stream);
+            if (mfma) F.km->launch_dwt(a, E.stream);
+            else pk::launch_f64_dwt(a, E.stream);
             pk::F64ReduceArgs r;
             std::memset(&r, 0, sizeof r);
             r.slab = S.d_slab; r.nblocks = (a.npts + pk::F64_BLOCK - 1) / pk::F64_BLOCK; r.nent = a.nent;
@@ -287,6 +316,25 @@ int f64_eval(pinn_engine& E, const double* theta, const double* term_w, double* 
         for (int k = 0; k < K; ++k) term_losses[k] = S.h_out[(size_t)P + k] / (double)E.terms[k].n_norm;
     if (grad) std::memcpy(grad, S.h_out.data(), sizeof(double) * P);
     return 0;
+}
+
+// " f64_channels=5,1,1,1,1 f64_kernels=mfma:HT4xPG1,mfma:HT4xPG4,..." for pinn_describe
+std::string f64_describe(const pinn_engine& E) {
+    if (!E.f64) return "";
+    const F64State& S = *(const F64State*)E.f64;
+    std::string c = " f64_channels=", k = " f64_kernels=";
+    for (size_t t = 0; t < S.terms.size(); ++t) {
+        const F64Term& F = S.terms[t];
+        c += (t ? "," : "") + std::to_string(F.k ? F.k->C : 0);
+        k += (t ? "," : "") + (F.km ? "mfma:HT" + std::to_string(F.km->HT) + "xPG" + std::to_string(F.km->PG) : std::string("lanes"));
+    }
+    return c + k;
+}
+
+const char* f64_path(const pinn_engine& E) {
+    if (!E.f64) return "off";
+    const int p = ((const F64State*)E.f64)->path;
+    return p == 2 ? "mfma" : (p == 1 ? "lanes" : (p == 3 ? "mfma+lanes" : "none"));
 }
 
 }  // namespace pe

@@ -8,6 +8,8 @@ PINN_INSTANTIATE_F64(f64_d1_h, 1, 0x1, PINN_PAIR(0, 0, 0), 1, 0u)
 PINN_INSTANTIATE_F64(f64_d1_h4, 1, 0x1, PINN_PAIR(0, 0, 0), 1, PINN_HI(0, 4))
 PINN_INSTANTIATE_F64(f64_d2_v, 2, 0x0, 0ull, 0, 0u)
 PINN_INSTANTIATE_F64(f64_d2_g, 2, 0x3, 0ull, 0, 0u)
+PINN_INSTANTIATE_F64(f64_d2_p, 2, 0x3, (PINN_PAIR(0, 0, 0) | PINN_PAIR(1, 1, 1)), 2, 0u)            // r05: {u, u_x, u_y, u_xx, u_yy} (Poisson: C = 5 instead of the Hessian set's 6)
+PINN_INSTANTIATE_F64(f64_d2_b, 2, 0x3, PINN_PAIR(0, 1, 1), 1, 0u)                                   // r05: {u, u_t, u_x, u_xx} (Burgers: C = 4)
 PINN_INSTANTIATE_F64(f64_d2_h, 2, 0x3, (PINN_PAIR(0, 0, 0) | PINN_PAIR(1, 0, 1) | PINN_PAIR(2, 1, 1)), 3, 0u)
 PINN_INSTANTIATE_F64(f64_d3_v, 3, 0x0, 0ull, 0, 0u)
 PINN_INSTANTIATE_F64(f64_d3_h, 3, 0x7, (PINN_PAIR(0, 0, 0) | PINN_PAIR(1, 0, 1) | PINN_PAIR(2, 0, 2) | PINN_PAIR(3, 1, 1) | PINN_PAIR(4, 1, 2) | PINN_PAIR(5, 2, 2)), 6, 0u)

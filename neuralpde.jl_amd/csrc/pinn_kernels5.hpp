@@ -1,0 +1,396 @@
+// pinn_kernels5.hpp — "family 4m": the FLOAT64 evaluation on the matrix pipe (v_mfma_f64_16x16x4_f64), r05.
+//
+// Family 4 (pinn_kernels4.hpp) evaluates one POINT per lane and pays for every multiply-add with scratch-row loads; the reference's default
+// eltype (Float64, src/discretize.jl:432-449) deserves the matrix cores.  Same mathematics, same scratch rows, same slab layout and the same
+// small-entry / reduction kernels as family 4 — only the two heavy kernels are replaced:
+//   * k_f64m_tile: one WAVE per tile of 16 * PG points.  The f64 MFMA's C/D layout (lane (q, j) = (lane >> 4, lane & 15) holds rows q + 4 r,
+//     column j, cdna_hip_programming.md "f64 MFMA does NOT use these maps") is SELF-FEEDING with neuron = row, point = column: D register r of
+//     output tile t is exactly the B operand (k = lane >> 4, j = lane & 15) of k-block 4 t + r of the next GEMM — activations, jets and dZ stay
+//     in the lane that produced them from the first layer to the last and back: no LDS exchange, no barriers, wave-private tiles.  A operands
+//     (W for the forward GEMM, W^T for dA) come straight from theta (double, ComponentArrays order; L2-resident), masked to the layer's
+//     true width.  All C jet channels of PG point groups travel as NCG = PG * C column groups of 16 columns that share every weight fragment.
+//     Per element the activation / jet rules are the templates of pinn_kernels.hpp with V = double, the tape is family 4's.
+//   * k_f64m_dwt: the hidden-to-hidden weight gradients dW = dZ A^T as MFMAs over the scratch rows (k = 4 consecutive points of one channel),
+//     one wave per (512-point block, layer, 16 output neurons), accumulators for every input tile in registers, written into the block's slab.
+// Records / post-activation jets / dZ go through the same point-major scratch rows as family 4's (so family 4's k_f64_dw — biases, first and
+// last layer, PDE parameters, the sum of squares — and k_f64_reduce run unchanged behind it).
+// Eligibility (f64.cpp): tanh / sigmoid networks with at least one hidden layer, hidden widths <= 16 * HT of an instantiated (jet set, HT)
+// pair; everything else keeps family 4.  PINN_F64_NO_MFMA=1 keeps family 4 everywhere (A/B, tests).
+#pragma once
+#include "pinn_kernels4.hpp"
+
+namespace pk {
+
+// ---- lane arrays: N doubles per lane.  Device: registers of the executing lane; emulation: [N][64], phases written as PINN_LANES(l) { ... } ----
+#ifdef PINN_EMU
+template <int N> struct LVd {
+    double v[N][64];
+    double& operator()(int l, int i) { return v[i][l]; }
+    const double& operator()(int l, int i) const { return v[i][l]; }
+};
+#define PINN_LANES(l) for (int l = 0; l < 64; ++l)
+// D[i][j] += sum_k A[i][k] B[k][j]: lane (k, i) supplies A[i][k], lane (k, j) supplies B[k][j], lane (q, j) receives rows q + 4 r (r = 0..3) in
+// registers c0 + r * cs
+template <int NC, int NA, int NB>
+inline void mfma_f64(LVd<NC>& C, int c0, int cs, const LVd<NA>& A, int ia, const LVd<NB>& B, int ib) {
+    double out[4][64];
+    for (int l = 0; l < 64; ++l)
+        for (int r = 0; r < 4; ++r) {
+            const int i = (l >> 4) + 4 * r, j = l & 15;
+            double acc = C(l, c0 + r * cs);
+            for (int k = 0; k < 4; ++k) acc = std::fma(A(16 * k + i, ia), B(16 * k + j, ib), acc);
+            out[r][l] = acc;
+        }
+    for (int l = 0; l < 64; ++l) for (int r = 0; r < 4; ++r) C(l, c0 + r * cs) = out[r][l];
+}
+// sum over the four lanes that share lane & 15, result in all four
+template <int N> inline void lv_qsum(LVd<N>& X, int i) {
+    for (int j = 0; j < 16; ++j) {
+        const double s = (X(j, i) + X(j + 16, i)) + (X(j + 32, i) + X(j + 48, i));
+        for (int q = 0; q < 4; ++q) X(j + 16 * q, i) = s;
+    }
+}
+#else
+template <int N> struct LVd {
+    double v[N];
+    DEV double& operator()(int, int i) { return v[i]; }
+    DEV const double& operator()(int, int i) const { return v[i]; }
+};
+#define PINN_LANES(l) for (int l = (int)(threadIdx.x & 63), once_##l = 1; once_##l; once_##l = 0)
+template <int NC, int NA, int NB>
+DEV void mfma_f64(LVd<NC>& C, int c0, int cs, const LVd<NA>& A, int ia, const LVd<NB>& B, int ib) {
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    d4 c = {C.v[c0], C.v[c0 + cs], C.v[c0 + 2 * cs], C.v[c0 + 3 * cs]};
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(A.v[ia], B.v[ib], c, 0, 0, 0);
+    C.v[c0] = c[0]; C.v[c0 + cs] = c[1]; C.v[c0 + 2 * cs] = c[2]; C.v[c0 + 3 * cs] = c[3];
+}
+template <int N> DEV void lv_qsum(LVd<N>& X, int i) {
+    const double x = X.v[i];
+    const double y = x + __shfl_xor(x, 16, 64);          // (q ^ 1)
+    X.v[i] = y + __shfl_xor(y, 32, 64);                  // same association as the emulation: (x0 + x1) + (x2 + x3)
+}
+#endif
+
+// ---- kernel A': forward jets of every network, residual tape, reverse sweep of one tile of 16 * PG points ----
+template <class J, int HT, int PG, int ACTK>
+DEV void f64m_tile(int tile, const F64Args& a) {
+    constexpr int C = J::C, NCG = PG * C, NR = HT * 4;
+    constexpr bool SIN = (ACTK == ACT_SIN);
+    const int pbase = tile * (16 * PG);
+    const size_t np_ = (size_t)a.npad;
+    double* S = a.scratch;
+    LVd<NR * NCG> X, Z;                                          // X: operand of the next GEMM (a jets / dZ); Z: its result (z jets / G)
+    LVd<F64_MAX_NETS * NCG> U;                                   // every network's output jets (forward), then their seeds (reverse)
+    // =========================== forward ===========================
+    for (int ni = 0; ni < a.nnets; ++ni) {
+        const F64Net& n = a.net[ni];
+        const int L = n.nl - 1;
+        for (int lyr = 0; lyr < L; ++lyr) {
+            const int n_in = n.sizes[lyr], n_out = n.sizes[lyr + 1];
+            const double* W = a.theta + n.woff[lyr];
+            const double* B = a.theta + n.boff[lyr];
+            if (lyr == 0) {
+                PINN_LANES(l) {
+                    const int q = l >> 4, j = l & 15;
+                    PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                        const int p = pbase + 16 * pg + j, pc = p < a.npts ? p : a.npts - 1;
+                        double x[4] = {0.0, 0.0, 0.0, 0.0};
+                        for (int i = 0; i < n.d; ++i) x[i] = a.pts[(size_t)(a.p0 + pc) * a.dt + n.imap[i]];
+                        PINN_UNROLL for (int tr = 0; tr < NR; ++tr) {
+                            const int m = 16 * (tr >> 2) + 4 * (tr & 3) + q, mc = m < n_out ? m : n_out - 1;
+                            const bool valid = m < n_out;
+                            double z0 = B[mc];
+                            for (int i = 0; i < n.d; ++i) z0 = vfma(W[mc + (size_t)i * n_out], x[i], z0);
+                            PINN_UNROLL for (int c = 0; c < C; ++c) Z(l, tr * NCG + pg * C + c) = 0.0;
+                            Z(l, tr * NCG + pg * C) = valid ? z0 : 0.0;
+                            PINN_UNROLL for (int kf = 0; kf < J::NFIRST; ++kf)
+                                Z(l, tr * NCG + pg * C + J::CH_FIRST + kf) = valid ? W[mc + (size_t)J::first_axis(kf) * n_out] : 0.0;
+                        }
+                    }
+                }
+            } else {
+                PINN_LANES(l) { PINN_UNROLL for (int e = 0; e < NR * NCG; ++e) Z(l, e) = 0.0; }
+                PINN_UNROLL for (int t = 0; t < HT; ++t) {
+                    if (16 * t >= n_out) break;
+                    PINN_UNROLL for (int kb = 0; kb < NR; ++kb) {
+                        if (4 * kb >= n_in) break;
+                        LVd<1> Af;
+                        PINN_LANES(l) {
+                            const int m = 16 * t + (l & 15), k = 4 * kb + (l >> 4);
+                            Af(l, 0) = (m < n_out && k < n_in) ? W[m + (size_t)k * n_out] : 0.0;
+                        }
+                        PINN_UNROLL for (int g = 0; g < NCG; ++g) mfma_f64(Z, (4 * t) * NCG + g, NCG, Af, 0, X, kb * NCG + g);
+                    }
+                }
+                PINN_LANES(l) {
+                    const int q = l >> 4;
+                    PINN_UNROLL for (int tr = 0; tr < NR; ++tr) {
+                        const int m = 16 * (tr >> 2) + 4 * (tr & 3) + q;
+                        const double b = m < n_out ? B[m] : 0.0;
+                        PINN_UNROLL for (int pg = 0; pg < PG; ++pg) Z(l, tr * NCG + pg * C) += b;
+                    }
+                }
+            }
+            // activation: record, jets (rows as family 4 writes them: rec / post of hidden layer lyr, row = base + neuron * C + channel)
+            PINN_LANES(l) {
+                const int q = l >> 4, j = l & 15;
+                PINN_UNROLL for (int tr = 0; tr < NR; ++tr) {
+                    const int m = 16 * (tr >> 2) + 4 * (tr & 3) + q;
+                    const bool valid = m < n_out;
+                    PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                        const int p = pbase + 16 * pg + j;
+                        const bool st = valid && p < a.npts && a.mode == 0;
+                        double z[C];
+                        PINN_UNROLL for (int c = 0; c < C; ++c) z[c] = Z(l, tr * NCG + pg * C + c);
+                        const double a0 = act_value<SIN>(n.act, z[0]);
+                        z[0] = act_record<SIN>(z[0], a0);
+                        if (st) { PINN_UNROLL for (int c = 0; c < C; ++c) S[((size_t)n.r_rec[lyr] + (size_t)m * C + c) * np_ + p] = z[c]; }
+                        double dd[ND];
+                        act_derivs_n<J::NORD - 1, SIN>(n.act, z[0], dd);
+                        jet_forward<J>(z, dd);
+                        z[0] = a0;
+                        if (st) { PINN_UNROLL for (int c = 0; c < C; ++c) S[((size_t)n.r_post[lyr] + (size_t)m * C + c) * np_ + p] = z[c]; }
+                        PINN_UNROLL for (int c = 0; c < C; ++c) X(l, tr * NCG + pg * C + c) = valid ? z[c] : 0.0;
+                    }
+                }
+            }
+        }
+        // output layer: u[g] = sum_n w_n a_n[g] (+ b on the value channel): per-lane partial over its neurons, then over the four lane groups
+        {
+            const int n_in = n.sizes[L];
+            const double* W = a.theta + n.woff[L];
+            const double bo = a.theta[n.boff[L]];
+            LVd<NCG> u;
+            PINN_LANES(l) {
+                const int q = l >> 4;
+                PINN_UNROLL for (int g = 0; g < NCG; ++g) u(l, g) = 0.0;
+                PINN_UNROLL for (int tr = 0; tr < NR; ++tr) {
+                    const int m = 16 * (tr >> 2) + 4 * (tr & 3) + q;
+                    const double w = m < n_in ? W[m] : 0.0;
+                    PINN_UNROLL for (int g = 0; g < NCG; ++g) u(l, g) = vfma(w, X(l, tr * NCG + g), u(l, g));
+                }
+            }
+            PINN_UNROLL for (int g = 0; g < NCG; ++g) lv_qsum(u, g);
+            PINN_LANES(l) {
+                PINN_UNROLL for (int g = 0; g < NCG; ++g) U(l, ni * NCG + g) = u(l, g) + ((g % C) == 0 ? bo : 0.0);
+            }
+        }
+    }
+    // =========================== residual tape (per point; the four lanes of a point run it redundantly, lane group 0 writes) ===========================
+    PINN_LANES(l) {
+        const int q = l >> 4, j = l & 15;
+        const int R0 = a.dt + a.np + a.nslots;
+        PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+            const int p = pbase + 16 * pg + j, pc = p < a.npts ? p : a.npts - 1, gp = a.p0 + pc;
+            const bool live = p < a.npts, wr = live && q == 0;
+            double v[F64_MAX_ROWS];
+            for (int i = 0; i < a.dt; ++i) v[i] = a.pts[(size_t)gp * a.dt + i];
+            for (int k = 0; k < a.np; ++k) v[a.dt + k] = k < a.ne ? a.theta[a.p_off + k] : a.pdef[k];
+            for (int s = 0; s < a.nslots; ++s) {
+                double uu = 0.0;
+                for (int ni = 0; ni < a.nnets; ++ni)
+                    PINN_UNROLL for (int c = 0; c < C; ++c) if (a.slot_net[s] == ni && a.slot_chan[s] == c) uu = U(l, ni * NCG + pg * C + c);
+                v[a.dt + a.np + s] = uu;
+            }
+            for (int o = 0; o < a.nops; ++o) {
+                const rp::Instr ins = a.prog[o];
+                const double va = rp::is_nullary(ins.code) ? 0.0 : v[ins.a];
+                const double vb = rp::is_binary(ins.code) ? v[ins.b] : 0.0;
+                v[R0 + o] = rp::apply<double, double>(ins.code, va, vb, a.imm[o]);
+            }
+            const double r = v[a.out_row];
+            if (a.mode == 2) { if (wr) a.resid[gp] = r; continue; }
+            const double sw = a.pw ? (double)a.pw[gp] : 1.0;
+            const double rs = r * sw;
+            if (wr) S[(size_t)a.r_sq * np_ + p] = rs * rs;
+            if (a.mode == 1) continue;
+            double g[F64_MAX_ROWS];
+            for (int o = 0; o < R0 + a.nops; ++o) g[o] = 0.0;
+            g[a.out_row] = 1.0;
+            for (int o = a.nops - 1; o >= 0; --o) {
+                const rp::Instr ins = a.prog[o];
+                if (rp::is_nullary(ins.code)) continue;
+                const double vb = rp::is_binary(ins.code) ? v[ins.b] : 0.0;
+                double da, db;
+                rp::adjoint<double, double>(ins.code, v[ins.a], vb, v[R0 + o], a.imm[o], g[R0 + o], da, db);
+                g[ins.a] += da;
+                if (rp::is_binary(ins.code)) g[ins.b] += db;
+            }
+            const double rbar = live ? rs * a.scale * sw : 0.0;
+            if (wr) for (int k = 0; k < a.ne; ++k) S[((size_t)a.r_pbar + k) * np_ + p] = rbar * g[a.dt + k];
+            // the seeds of every network's output jets replace its outputs in U
+            for (int ni = 0; ni < a.nnets; ++ni) {
+                double ub[C];
+                PINN_UNROLL for (int c = 0; c < C; ++c) ub[c] = 0.0;
+                for (int s = 0; s < a.nslots; ++s) {
+                    if (a.slot_net[s] != ni) continue;
+                    const double gs = rbar * g[a.dt + a.np + s];
+                    PINN_UNROLL for (int c = 0; c < C; ++c) if (a.slot_chan[s] == c) ub[c] += gs;
+                }
+                PINN_UNROLL for (int c = 0; c < C; ++c) {
+                    U(l, ni * NCG + pg * C + c) = ub[c];
+                    if (wr) S[((size_t)a.net[ni].r_ubar + c) * np_ + p] = ub[c];
+                }
+            }
+        }
+    }
+    if (a.mode != 0) return;
+    // =========================== reverse sweep, network by network ===========================
+    for (int ni = 0; ni < a.nnets; ++ni) {
+        const F64Net& n = a.net[ni];
+        const int L = n.nl - 1;
+        for (int lyr = L - 1; lyr >= 0; --lyr) {
+            const int H = n.sizes[lyr + 1];
+            const int n_next = n.sizes[lyr + 2];
+            const double* Wn = a.theta + n.woff[lyr + 1];            // W_{lyr+1}[m + k * n_next]
+            if (lyr == L - 1) {
+                PINN_LANES(l) {
+                    const int q = l >> 4;
+                    PINN_UNROLL for (int tr = 0; tr < NR; ++tr) {
+                        const int k = 16 * (tr >> 2) + 4 * (tr & 3) + q;
+                        const double w = k < H ? Wn[k] : 0.0;
+                        PINN_UNROLL for (int g = 0; g < NCG; ++g) Z(l, tr * NCG + g) = w * U(l, ni * NCG + g);
+                    }
+                }
+            } else {
+                PINN_LANES(l) { PINN_UNROLL for (int e = 0; e < NR * NCG; ++e) Z(l, e) = 0.0; }
+                PINN_UNROLL for (int t = 0; t < HT; ++t) {
+                    if (16 * t >= H) break;
+                    PINN_UNROLL for (int kb = 0; kb < NR; ++kb) {
+                        if (4 * kb >= n_next) break;
+                        LVd<1> Af;                                   // W^T: rows = this layer's neurons, k = the layer above's
+                        PINN_LANES(l) {
+                            const int k = 16 * t + (l & 15), m = 4 * kb + (l >> 4);
+                            Af(l, 0) = (k < H && m < n_next) ? Wn[m + (size_t)k * n_next] : 0.0;
+                        }
+                        PINN_UNROLL for (int g = 0; g < NCG; ++g) mfma_f64(Z, (4 * t) * NCG + g, NCG, Af, 0, X, kb * NCG + g);
+                    }
+                }
+            }
+            PINN_LANES(l) {
+                const int q = l >> 4, j = l & 15;
+                PINN_UNROLL for (int tr = 0; tr < NR; ++tr) {
+                    const int k = 16 * (tr >> 2) + 4 * (tr & 3) + q, kc = k < H ? k : H - 1;
+                    const bool valid = k < H;
+                    PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                        const int p = pbase + 16 * pg + j, pc = p < a.npts ? p : a.npts - 1;
+                        const bool st = valid && p < a.npts;
+                        double s[C], gq[C], dd[ND];
+                        PINN_UNROLL for (int c = 0; c < C; ++c) s[c] = S[((size_t)n.r_rec[lyr] + (size_t)kc * C + c) * np_ + pc];
+                        PINN_UNROLL for (int c = 0; c < C; ++c) gq[c] = Z(l, tr * NCG + pg * C + c);
+                        act_derivs_n<J::NORD, SIN>(n.act, s[0], dd);
+                        jet_adjoint<J>(gq, s, dd);
+                        if (st) { PINN_UNROLL for (int c = 0; c < C; ++c) S[((size_t)n.r_dz[lyr] + (size_t)k * C + c) * np_ + p] = gq[c]; }
+                        PINN_UNROLL for (int c = 0; c < C; ++c) X(l, tr * NCG + pg * C + c) = st ? gq[c] : 0.0;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- kernel B2': rows of 16 output neurons of the hidden-to-hidden weight gradients of one 512-point block ----
+HD int f64m_num_rows(const F64Args& a) {
+    int t = 0;
+    for (int ni = 0; ni < a.nnets; ++ni)
+        for (int l = 1; l < a.net[ni].nl - 1; ++l) t += (a.net[ni].sizes[l + 1] + 15) / 16;
+    return t;
+}
+template <int HT>
+DEV void f64m_dwt(int row, int b, const F64Args& a) {
+    int ni = 0, lyr = 1, t_out = 0;
+    {
+        bool found = false;
+        for (int i = 0; i < a.nnets && !found; ++i)
+            for (int l = 1; l < a.net[i].nl - 1 && !found; ++l) {
+                const int nt = (a.net[i].sizes[l + 1] + 15) / 16;
+                if (row < nt) { ni = i; lyr = l; t_out = row; found = true; }
+                else row -= nt;
+            }
+    }
+    const F64Net& n = a.net[ni];
+    const int n_out = n.sizes[lyr + 1], n_in = n.sizes[lyr], C = a.C;
+    const int lo = b * F64_BLOCK, hi = (lo + F64_BLOCK < a.npts) ? lo + F64_BLOCK : a.npts;
+    const size_t np_ = (size_t)a.npad;
+    const double* S = a.scratch;
+    LVd<HT * 4> acc;
+    PINN_LANES(l) { PINN_UNROLL for (int e = 0; e < HT * 4; ++e) acc(l, e) = 0.0; }
+    for (int p = lo; p < hi; p += 4)
+        for (int c = 0; c < C; ++c) {
+            LVd<1> Af;
+            LVd<HT> Bf;
+            PINN_LANES(l) {
+                const int pp = p + (l >> 4), m = 16 * t_out + (l & 15);
+                const bool pv = pp < hi;
+                Af(l, 0) = (pv && m < n_out) ? S[((size_t)n.r_dz[lyr] + (size_t)m * C + c) * np_ + pp] : 0.0;
+                PINN_UNROLL for (int t = 0; t < HT; ++t) {
+                    const int k = 16 * t + (l & 15);
+                    Bf(l, t) = (pv && k < n_in) ? S[((size_t)n.r_post[lyr - 1] + (size_t)k * C + c) * np_ + pp] : 0.0;
+                }
+            }
+            PINN_UNROLL for (int t = 0; t < HT; ++t) {
+                if (16 * t >= n_in) break;
+                mfma_f64(acc, 4 * t, 1, Af, 0, Bf, t);
+            }
+        }
+    PINN_LANES(l) {
+        PINN_UNROLL for (int t = 0; t < HT; ++t)
+            PINN_UNROLL for (int r = 0; r < 4; ++r) {
+                const int m = 16 * t_out + (l >> 4) + 4 * r, k = 16 * t + (l & 15);
+                if (m < n_out && k < n_in) a.slab[(size_t)b * a.nent + n.ent0 + (n.woff[lyr] - n.theta0) + m + (size_t)k * n_out] = acc(l, 4 * t + r);
+            }
+    }
+}
+
+// ---- the kernel table: (inputs, jet set, HT) -> launchers; matched against a term's float64 kernel in f64.cpp ----
+struct F64MKernel {
+    int D, NPAIR, HT, PG;
+    unsigned D1MASK, HI;
+    unsigned long long PAIRS;
+    void (*launch_tile)(const F64Args&, plat_stream);
+    void (*launch_dwt)(const F64Args&, plat_stream);
+};
+std::deque<F64MKernel>& f64m_registry();
+
+#ifdef PINN_EMU
+template <class J, int HT, int PG> void launch_f64m_tile(const F64Args& a, plat_stream) {
+    const int nt = (a.npts + 16 * PG - 1) / (16 * PG);
+    for (int t = 0; t < nt; ++t) f64m_tile<J, HT, PG, ACT_TANH>(t, a);
+}
+template <int HT> void launch_f64m_dwt(const F64Args& a, plat_stream) {
+    if (a.mode != 0) return;
+    const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK, nr = f64m_num_rows(a);
+    for (int b = 0; b < nb; ++b) for (int r = 0; r < nr; ++r) f64m_dwt<HT>(r, b, a);
+}
+#else
+template <class J, int HT, int PG> __global__ void __launch_bounds__(64) k_f64m_tile(const F64Args a) { f64m_tile<J, HT, PG, ACT_TANH>((int)blockIdx.x, a); }
+template <int HT> __global__ void __launch_bounds__(64) k_f64m_dwt(const F64Args a) { f64m_dwt<HT>((int)blockIdx.x, (int)blockIdx.y, a); }
+template <class J, int HT, int PG> void launch_f64m_tile(const F64Args& a, plat_stream st) {
+    const int nt = (a.npts + 16 * PG - 1) / (16 * PG);
+    hipLaunchKernelGGL((k_f64m_tile<J, HT, PG>), dim3(nt), dim3(64), 0, st, a);
+}
+template <int HT> void launch_f64m_dwt(const F64Args& a, plat_stream st) {
+    const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK, nr = f64m_num_rows(a);
+    if (a.mode != 0 || nr == 0) return;
+    hipLaunchKernelGGL((k_f64m_dwt<HT>), dim3(nr, nb), dim3(64), 0, st, a);
+}
+#endif
+
+template <int D, unsigned D1MASK, unsigned long long PAIRS, int NPAIR, unsigned HI, int HT> F64MKernel make_f64m_kernel() {
+    using J = JetSet<D1MASK, PAIRS, NPAIR, HI>;
+    static_assert(J::NLAP == 0, "the float64 kernels carry plain derivative channels (no forward-Laplacian channel)");
+    // column groups per wave: as many point groups as keep the two operand arrays (2 x HT * 4 * NCG doubles per lane) inside the register file
+    constexpr int CAP = (HT <= 4) ? 4 : 2;
+    constexpr int PG = (J::C >= CAP) ? 1 : CAP / J::C;
+    static_assert(HT * PG * J::C <= 24, "operand arrays of this (jet set, width) pair exceed the register file: keep family 4");
+    F64MKernel k;
+    k.D = D; k.NPAIR = NPAIR; k.HT = HT; k.PG = PG; k.D1MASK = D1MASK; k.HI = HI; k.PAIRS = PAIRS;
+    k.launch_tile = &launch_f64m_tile<J, HT, PG>;
+    k.launch_dwt = &launch_f64m_dwt<HT>;
+    return k;
+}
+struct F64MRegistrar { explicit F64MRegistrar(const F64MKernel& k) { f64m_registry().push_back(k); } };
+#define PINN_INSTANTIATE_F64M(NAME, D, D1MASK, PAIRS, NPAIR, HI, HT) \
+    namespace { pk::F64MRegistrar NAME##_regf64m(pk::make_f64m_kernel<D, D1MASK, PAIRS, NPAIR, HI, HT>()); }
+
+}  // namespace pk

@@ -60,7 +60,35 @@ inline vfloat vfma(const vfloat& a, const vfloat& b, const vfloat& c) {
 VFN1(vtanh, std::tanh(x)) VFN1(vsin, std::sin(x)) VFN1(vcos, std::cos(x)) VFN1(vexp, std::exp(x))
 VFN1(vlog, std::log(x)) VFN1(vsqrt, std::sqrt(x)) VFN1(vabs, std::fabs(x)) VFN1(vsinh, std::sinh(x))
 VFN1(vcosh, std::cosh(x)) VFN1(vtan, std::tan(x)) VFN1(vrcp, 1.0f / x)
+#ifndef PINN_ACT_TANH
+#define PINN_ACT_TANH 3
+#endif
+#ifndef PINN_EMU_LIBM_ACT
+// the DEVICE's arithmetic restated (v_exp_f32 / v_rcp_f32 are 1-ulp instructions; exp2f and the division here are at most as far off), so the
+// CPU suite sees the cancellation structure of the activation the hardware evaluates; -DPINN_EMU_LIBM_ACT=1: libm (A/B of the activation's share)
+inline float emu_tanh_dev(float x) {
+#if PINN_ACT_TANH == 0
+    return std::fmaf(-2.0f, 1.0f / (exp2f(x * 2.8853900817779268f) + 1.0f), 1.0f);
+#else
+#if PINN_ACT_TANH >= 3
+    const float ax = std::fabs(x);
+    const float e = exp2f(std::fmaf(ax, -2.885390043258667f, ax * -3.851926067000022e-08f));
+#else
+    const float e = exp2f(std::fabs(x) * -2.8853900817779268f);
+#endif
+    const float s = 1.0f + e;
+    float r = 1.0f / s;
+#if PINN_ACT_TANH >= 2
+    r = std::fmaf(std::fmaf(-s, r, 1.0f), r, r);
+#endif
+    return std::copysign((1.0f - e) * r, x);
+#endif
+}
+VFN1(vtanh_fast, emu_tanh_dev(x))
+VFN1(vsigmoid_fast, 1.0f / (1.0f + exp2f(x * -1.4426950408889634f)))
+#else
 VFN1(vtanh_fast, std::tanh(x)) VFN1(vsigmoid_fast, 1.0f / (1.0f + std::exp(-x)))
+#endif
 VFN1(vsign, (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f))
 VFN1(vsinpi, std::sin(3.14159265358979323846f * x)) VFN1(vcospi, std::cos(3.14159265358979323846f * x))
 #undef VFN1
@@ -304,9 +332,33 @@ DEV void vsincos(vfloat x, vfloat& s, vfloat& c) {
 #ifndef PINN_ACT_EXP2
 #define PINN_ACT_EXP2 1
 #endif
+// tanh.  PINN_ACT_TANH = 0: 1 - 2 / (e^{2x} + 1) — five instructions, but the sum e^{2x} + 1 and the reciprocal are rounded at magnitude ~1 and the
+// final subtraction turns those into ABSOLUTE errors of up to 2.4e-7 around x = 0 (libm: half an ulp of the result).  1 / 2 (r05, the default 2):
+// the odd form sign(x) (1 - e) / (1 + e), e = e^{-2|x|} in (0, 1]: 1 - e is exact for e >= 1/2 (Sterbenz) and every later rounding is RELATIVE
+// to the result, so what remains around 0 is the v_exp_f32 error alone (<= 1 ulp of e, halved by d tanh / d e); 2 adds one Newton step on the
+// 1-ulp v_rcp_f32 (two fmas) so that saturating units are within an ulp as well.  Measured against double tanh on the device:
+// tools/micro/tanh_probe.hip, profiles/r05_tanh_probe.txt; effect on the trained-parameter parity: profiles/r05_theta_variants_ab.txt.
+#ifndef PINN_ACT_TANH
+#define PINN_ACT_TANH 3
+#endif
 DEV vfloat vtanh_fast(vfloat x) {
+#if PINN_ACT_TANH == 0
     const float e = PINN_ACT_EXP2 ? __builtin_amdgcn_exp2f(x * 2.8853900817779268f) : __expf(2.0f * x);
     return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+#else
+#if PINN_ACT_TANH >= 3
+    const float ax = __builtin_fabsf(x);
+    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(ax, -2.885390043258667f, ax * -3.851926067000022e-08f));
+#else
+    const float e = __builtin_amdgcn_exp2f(__builtin_fabsf(x) * -2.8853900817779268f);
+#endif
+    const float s = 1.0f + e;
+    float r = __builtin_amdgcn_rcpf(s);
+#if PINN_ACT_TANH >= 2
+    r = __builtin_fmaf(__builtin_fmaf(-s, r, 1.0f), r, r);
+#endif
+    return __builtin_copysignf((1.0f - e) * r, x);
+#endif
 }
 DEV vfloat vsigmoid_fast(vfloat x) {
     const float e = PINN_ACT_EXP2 ? __builtin_amdgcn_exp2f(x * -1.4426950408889634f) : __expf(-x);

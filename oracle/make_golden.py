@@ -8,6 +8,7 @@ oracle's behaviour and give the GPU tests fixtures that do not need torch autogr
     python oracle/make_golden.py full [names]    # the full-size cases (inputs pinned by SHA-256, minutes of CPU time each)
     python oracle/make_golden.py variants [names]  # the same problems at SCALED and TRAINED parameters, both oracle modes (r04: the regime
                                                  # where the split-operand bf16 GEMMs of the 64- / 128-wide kernels have the least margin)
+    python oracle/make_golden.py variants-theta32 [names]  # adds the exact oracle at the float32-rounded trained parameters (r05)
     python oracle/make_golden.py variants-f32 [names]  # adds the float32 evaluation of the same program to the variants fixtures
 """
 import os
@@ -218,8 +219,38 @@ def add_f32(out, only=None):
         np.savez_compressed(path, **d)
 
 
+def add_theta32(out, only=None):
+    """adds to every variants fixture the exact-derivative float64 oracle AT THE FLOAT32-ROUNDED PARAMETERS of the trained variants
+    (`losses_exact32_<tag>`, `grad_exact32_<tag>`): an fp32 engine is handed float32(theta), so at a trained theta — where the gradient is
+    a small difference of large terms and H dtheta of the rounding alone is 4e-5 ... 1e-2 of it — this is the reference that isolates the
+    engine's ARITHMETIC error from the quantisation of its input (r05; tools/r05/theta_ab_gpu.py, tests/test_gpu_theta_variants.py)."""
+    for name, (make, _, _, _) in VARIANT_CASES.items():
+        path = os.path.join(out, name + ".npz")
+        if (only and name not in only) or not os.path.exists(path):
+            continue
+        d = dict(np.load(path))
+        tags = [str(t) for t in d["tags"] if str(t).startswith("adam")]
+        if not tags:
+            continue
+        wl = make()
+        sets = point_sets(wl)
+        assert [set_digest(s) for s in sets] == list(d["set_sha256"])
+        prob = helpers.oracle_problem(m, wl.pde_system, wl.chains, param_estim=wl.param_estim)
+        for tag in tags:
+            th32 = d["theta_" + tag].astype(np.float32).astype(np.float64)
+            losses, grad = chunked_loss_and_grad(prob, th32, sets, d["weights"], mode="exact")
+            d[f"losses_exact32_{tag}"], d[f"grad_exact32_{tag}"] = losses, grad.astype(np.float64)
+            ge = d[f"grad_exact_{tag}"]
+            print(name, tag, "oracle(theta64) vs oracle(float32(theta64)): loss rel", np.max(np.abs(losses - d[f"losses_exact_{tag}"]) / np.abs(losses)),
+                  "grad rel L2", np.linalg.norm(grad - ge) / np.linalg.norm(grad), flush=True)
+        np.savez_compressed(path, **d)
+
+
 def main():
     out = os.path.join(ROOT, "tests", "golden")
+    if len(sys.argv) > 1 and sys.argv[1] == "variants-theta32":
+        add_theta32(out, sys.argv[2:])
+        return
     os.makedirs(out, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "variants-f32":
         add_f32(out, sys.argv[2:])

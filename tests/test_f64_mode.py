@@ -51,6 +51,19 @@ def test_f64_mode_equals_the_float64_oracle(npde, use_emu, name):
     assert le.max() < EXACT and g2 < EXACT and gi < EXACT, (le, g2, gi)
     l2, g2_ = eng.loss_grad_f64(th, w)
     assert np.array_equal(l2, l64) and np.array_equal(g2_, g64)              # deterministic
+    # r05: which kernels ran — the matrix-pipe family (csrc/pinn_kernels5.hpp, v_mfma_f64_16x16x4_f64) wherever a (jet set, width) pair is
+    # instantiated, one lane per point elsewhere (4-D nets); both families agree to rounding
+    assert eng.get_option("f64_path") == {"cfg1": "mfma", "cfg2": "mfma", "cfg3": "mfma", "cfg4": "mfma", "cfg5": "lanes"}[name]
+    if name != "cfg5":
+        import os
+        os.environ["PINN_F64_NO_MFMA"] = "1"
+        try:
+            ll, gl = eng.loss_grad_f64(th, w)
+        finally:
+            del os.environ["PINN_F64_NO_MFMA"]
+        assert eng.get_option("f64_path") == "lanes"
+        np.testing.assert_allclose(ll, l64, rtol=1e-12)
+        np.testing.assert_allclose(gl, g64, rtol=0, atol=1e-12 * np.abs(g64).max())
     lf, gf = eng.loss_grad(th, w)                                            # float entry point in f64 mode: converted at the boundary
     np.testing.assert_allclose(gf, g64.astype(np.float32), rtol=0, atol=1e-7 * np.abs(g64).max())
     eng.set_option("precision", "f32")

@@ -34,6 +34,15 @@ def main():
         eng.set_option("precision", "f64")
         l64, g64 = eng.loss_grad_f64(th)
         t64 = timed(lambda: eng.loss_grad_f64(th), 5)
+        path = eng.get_option("f64_path")
+        tl = None
+        if path != "lanes":                                  # r05: the same evaluation on the one-lane-per-point kernels (family 4) for comparison
+            os.environ["PINN_F64_NO_MFMA"] = "1"
+            ll, gl = eng.loss_grad_f64(th)
+            tl = timed(lambda: eng.loss_grad_f64(th), 3)
+            del os.environ["PINN_F64_NO_MFMA"]
+            print(f"   [{name.split()[0]}] float64 kernels: {path} {t64:.3f} ms vs one lane per point {tl:.3f} ms ({tl / t64:.1f}x); the two agree to "
+                  f"{np.linalg.norm(gl - g64) / np.linalg.norm(g64):.1e} (gradient rel L2)", flush=True)
         print(f"{name}: P = {eng.P}, {npts} points\n   fp32 kernels {t32:8.3f} ms  ({npts / t32 * 1e3:.3e} evals/s)    float64 mode {t64:8.3f} ms  ({npts / t64 * 1e3:.3e} evals/s)   ratio {t64 / t32:.1f}x"
               f"\n   fp32 vs float64: loss rel {np.max(np.abs(l32 - l64) / np.abs(l64)):.2e}, gradient rel L2 {np.linalg.norm(g32 - g64) / np.linalg.norm(g64):.2e}", flush=True)
 
