@@ -34,6 +34,8 @@ struct F64Term {
     double* d_pts = nullptr;             // [n][d] double; converted from the float set unless pinn_set_points_f64 installed it
     int64_t cap = 0, n = 0;
     bool exact_pts = false;              // installed in double (not a conversion of the float set)
+    int* d_small = nullptr;              // family 4m: the slab entries its small-entry kernel owns (everything but hidden-to-hidden weights)
+    int nsmall = 0;
 };
 struct F64State {
     std::vector<F64Term> terms;
@@ -50,7 +52,7 @@ struct F64State {
 
 static void f64_free(F64State* S) {
     if (!S) return;
-    for (auto& T : S->terms) { plat_free(T.d_prog); plat_free(T.d_imm); plat_free(T.d_pts); }
+    for (auto& T : S->terms) { plat_free(T.d_prog); plat_free(T.d_imm); plat_free(T.d_pts); plat_free(T.d_small); }
     plat_free(S->d_theta); plat_free(S->d_grad); plat_free(S->d_sumsq); plat_free(S->d_scratch); plat_free(S->d_slab);
     delete S;
 }
@@ -267,9 +269,9 @@ int f64_eval(pinn_engine& E, const double* theta, const double* term_w, double* 
         a.mode = grad ? 0 : 1;
         const bool mfma = F.km && std::getenv("PINN_F64_NO_MFMA") == nullptr;
         S.path |= mfma ? 2 : 1;
-        // chunks of points: the scratch stays below 256 MB (one lane per point) / 1 GB (matrix-pipe kernels: one wave per 16-64 points, a
-        // chunk should hold a few thousand tiles); $PINN_F64_SCRATCH_MB overrides
-        double mb = mfma ? 1024.0 : 256.0;
+        // chunks of points: the scratch stays below 256 MB (one lane per point) / 4 GB (matrix-pipe kernels: one wave per 16-32 points, a chunk
+        // should hold several tiles per SIMD — the bench workload's 65,536-point terms are one chunk each: 3 kernels + a reduction per term); $PINN_F64_SCRATCH_MB overrides
+        double mb = mfma ? 4096.0 : 256.0;
         if (const char* e = std::getenv("PINN_F64_SCRATCH_MB")) mb = std::max(1.0, std::atof(e));
         int64_t chunk = (int64_t)((mb * 1024 * 1024) / (8.0 * rows));
         chunk = std::max<int64_t>(pk::F64_BLOCK, (chunk / pk::F64_BLOCK) * pk::F64_BLOCK);
@@ -292,12 +294,27 @@ int f64_eval(pinn_engine& E, const double* theta, const double* term_w, double* 
             if (!S.d_slab) return fail("device allocation failed (float64 slabs)");
         }
         a.scratch = S.d_scratch; a.npad = (int)chunk; a.slab = S.d_slab;
+        if (mfma && !F.d_small) {                        // (the entry layout depends on the networks only: built once per term)
+            std::vector<int> small;
+            pk::F64Args a0 = a;
+            a0.mode = 0;
+            for (int e = 0; e < a.nent; ++e) {
+                int ni, lyr, m, k; bool bias;
+                if (pk::f64m_dw_decode(e, a0, ni, lyr, bias, m, k)) small.push_back(e);
+            }
+            F.d_small = (int*)plat_malloc(sizeof(int) * std::max<size_t>(small.size(), 1));
+            if (!F.d_small) return fail("device allocation failed (float64 entry list)");
+            plat_h2d(F.d_small, small.data(), sizeof(int) * small.size(), E.stream);
+            if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+            F.nsmall = (int)small.size();
+        }
         for (int64_t p0 = 0; p0 < F.n; p0 += chunk) {
             a.p0 = (int)p0;
             a.npts = (int)std::min<int64_t>(chunk, F.n - p0);
             if (mfma) F.km->launch_tile(a, E.stream);
             else F.k->launch_point(a, sin_act, E.stream);
-            pk::launch_f64_dw(a, E.stream);
+            if (mfma) pk::launch_f64m_dw(a, F.d_small, F.nsmall, E.stream);
+            else pk::launch_f64_dw(a, E.stream);
             if (mfma) F.km->launch_dwt(a, E.stream);
             else pk::launch_f64_dwt(a, E.stream);
             pk::F64ReduceArgs r;

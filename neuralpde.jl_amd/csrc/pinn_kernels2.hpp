@@ -51,6 +51,16 @@
 #ifndef PINN_F2_TR_FWDIMG
 #define PINN_F2_TR_FWDIMG 1             // transpose-read kernels: the forward pass's last exchange image serves as the first dW's a-jet operand
 #endif
+// Split products: the five SMALL piece products (hm mh hl mm lh: 2^-8 ... 2^-16 of the result) in an accumulator of their own, added to the big one
+// (bias / running sum + the hh products) by one VALU add per GEMM.  v_mfma_f32_16x16x32_bf16 does not ROUND products that are small against
+// its accumulator, it truncates them towards -infinity below ~2^-31 of the accumulator: six pieces on one accumulator shift every GEMM output
+// by -0.6 ... -1.0e-8 (|z| ~ 1.6) — a coherent offset of every pre-activation, which a TRAINED theta amplifies (tools/micro/split_bias_probe.hip,
+// profiles/r05_split_bias_probe.txt: own accumulator = zero mean AND a third of the rms error).  Bit mask: 1 forward GEMM, 2 dA GEMM,
+// 4 dW GEMM with register-resident sums (H = 64), 8 dW GEMM with slab-resident sums (H = 128), 16 (with 4) the H = 64 dW GEMM forms a tile's WHOLE
+// product in fresh accumulators (dw_layer_tr2).
+#ifndef PINN_F2_SPLIT_ACC2
+#define PINN_F2_SPLIT_ACC2 23
+#endif
 #ifndef PINN_F2_WACC_PRELOAD
 #define PINN_F2_WACC_PRELOAD 2          // slab-resident dW sums (H = 128) loaded as the dW GEMM's initial accumulators (2: fp32-MFMA kernels too)
 #endif
@@ -456,10 +466,25 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
             return c;
         };
 
+        // the same with the five small piece products on an accumulator of their own (PINN_F2_SPLIT_ACC2), smallest first
+        auto mfma_split2 = [&](const vbf8 (&a)[3], const vbf8 (&b)[3], vfloat4& big, vfloat4& sm) {
+#if !(PINN_PROBE & 1)
+            sm = mfma16x32bf(a[2], b[0], sm);
+            sm = mfma16x32bf(a[1], b[1], sm);
+            sm = mfma16x32bf(a[0], b[2], sm);
+#endif
+            sm = mfma16x32bf(a[1], b[0], sm);
+            sm = mfma16x32bf(a[0], b[1], sm);
+            big = mfma16x32bf(a[0], b[0], big);
+        };
         // C[q][t] += W[kb][t] (x) X[q][kb] over every column group and k-block, software-pipelined (PINN_F2_SWP): group i + 1's three piece
         // fragments are requested before group i's MFMAs
-        auto gemm_swp = [&](const float* X, const vbf8 (&wfr)[S::BFX ? S::KB : 1][S::BFX ? MTW : 1][3], vfloat4 (&Cc)[NG][MTW]) {
+        auto gemm_swp = [&](const float* X, const vbf8 (&wfr)[S::BFX ? S::KB : 1][S::BFX ? MTW : 1][3], vfloat4 (&Cc)[NG][MTW], bool acc2) {
             constexpr int NGRP = S::KB * NG;
+            vfloat4 Cs[NG][MTW];
+            if (acc2)
+                PINN_UNROLL for (int q = 0; q < NG; ++q)
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t) Cs[q][t] = vzero4();
             constexpr int NB = 2;                                               // operand buffers in rotation (three measured in r04: no gain)
             vbf8 bb[NB][3];
             PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[0][sp] = ld_bfrag(X, sp);          // group 0: kb = 0, q = 0
@@ -473,9 +498,16 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 // every piece of this group's B operand has arrived before the first MFMA of the chain (see lds_wait): only the next group's
                 // reads may still be in flight
                 if (i + 1 < NGRP) lds_wait<S::BFX_TR ? 6 : 3>(); else lds_wait<0>();
-                PINN_UNROLL for (int t = 0; t < MTW; ++t) Cc[q][t] = mfma_split(wfr[kb][t], bb[i % NB], Cc[q][t]);
+                PINN_UNROLL for (int t = 0; t < MTW; ++t) {
+                    if (acc2) mfma_split2(wfr[kb][t], bb[i % NB], Cc[q][t], Cs[q][t]);
+                    else Cc[q][t] = mfma_split(wfr[kb][t], bb[i % NB], Cc[q][t]);
+                }
                 chain_fence();                                              // (nothing of the next group moves up into this chain)
             }
+            if (acc2)
+                PINN_UNROLL for (int q = 0; q < NG; ++q)
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                        PINN_UNROLL for (int e = 0; e < 4; ++e) Cc[q][t][e] += Cs[q][t][e];
         };
 
         // =========================== forward ===========================
@@ -538,14 +570,26 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 }
                 wave_prio(0);
                 if (S::BFX && (PINN_F2_SWP & 1)) {
-                    gemm_swp(Xin, wb, A);
+                    gemm_swp(Xin, wb, A, (PINN_F2_SPLIT_ACC2 & 1) != 0);
                 } else if (S::BFX) {
+                    constexpr bool ACC2 = (PINN_F2_SPLIT_ACC2 & 1) != 0;
+                    vfloat4 As[ACC2 ? NG : 1][ACC2 ? MTW : 1];
+                    if (ACC2)
+                        PINN_UNROLL for (int q = 0; q < NG; ++q)
+                            PINN_UNROLL for (int t = 0; t < MTW; ++t) As[q][t] = vzero4();
                     PINN_UNROLL for (int kb = 0; kb < S::KB; ++kb)
                         PINN_UNROLL for (int q = 0; q < NG; ++q) {
                             vbf8 bb[3];
                             PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[sp] = ld_bfrag(Xin, (q * S::KB + kb) * 3 + sp);
-                            PINN_UNROLL for (int t = 0; t < MTW; ++t) A[q][t] = mfma_split(wb[kb][t], bb, A[q][t]);
+                            PINN_UNROLL for (int t = 0; t < MTW; ++t) {
+                                if (ACC2) mfma_split2(wb[kb][t], bb, A[q][t], As[ACC2 ? q : 0][ACC2 ? t : 0]);
+                                else A[q][t] = mfma_split(wb[kb][t], bb, A[q][t]);
+                            }
                         }
+                    if (ACC2)
+                        PINN_UNROLL for (int q = 0; q < NG; ++q)
+                            PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                                PINN_UNROLL for (int e = 0; e < 4; ++e) A[q][t][e] += As[q][t][e];
                     if (WPRE && F2_GEMM_AHEAD > 0) sched_gemm_prefetch<S::KB * NG, MTW * 6, F2_GEMM_AHEAD, S::BFX_TR ? 6 : 3>();
                 }
                 PINN_UNROLL for (int mi = 0; mi < (S::BFX ? 0 : MT); ++mi) {
@@ -918,6 +962,20 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
             };
             // dW by LDS transpose reads (S::BFX_TR): column groups 2 qp, 2 qp + 1 are the K = 32 points of one MFMA; an odd tail pair takes
             // zeros for k >= 16 (A operand masked, B operand read from the pair's first column group: finite values)
+            constexpr bool DW_ACC2 = S::BFX_TR && ((S::WBAR_REG && (PINN_F2_SPLIT_ACC2 & 4)) || (!S::WBAR_REG && (PINN_F2_SPLIT_ACC2 & 8)));
+            vfloat4 ws[DW_ACC2 ? MTW : 1][DW_ACC2 ? MT : 1];
+            if (DW_ACC2)
+                PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                    PINN_UNROLL for (int ti = 0; ti < MT; ++ti) ws[t][ti] = vzero4();
+            auto dw_merge = [&]() {                                         // after the last pair of the layer: sums += small pieces (one rounding each)
+                if (!DW_ACC2) return;
+                PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                    PINN_UNROLL for (int ti = 0; ti < MT; ++ti)
+                        PINN_UNROLL for (int e = 0; e < 4; ++e) {
+                            if (S::WBAR_REG) wbar[hl][t][ti][e] += ws[DW_ACC2 ? t : 0][DW_ACC2 ? ti : 0][e];
+                            else wacc[t][ti][e] += ws[DW_ACC2 ? t : 0][DW_ACC2 ? ti : 0][e];
+                        }
+            };
             auto dw_pair_tr = [&](int qp) {
                 const bool full = (2 * qp + 1 < NG);
                 auto ld_tr = [&](const float* X, int frag, int h) -> vbf8 {
@@ -943,7 +1001,9 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                         sched_fence();
                         if (ti + 1 < MT) lds_wait<6>(); else lds_wait<0>();      // (this group's operands complete before its MFMA chain)
                         PINN_UNROLL for (int t = 0; t < MTW; ++t) {
-                            if (S::WBAR_REG) wbar[hl][t][ti] = mfma_split(za[t], ab[ti % NB], wbar[hl][t][ti]);
+                            if (DW_ACC2 && S::WBAR_REG) mfma_split2(za[t], ab[ti % NB], wbar[hl][t][ti], ws[DW_ACC2 ? t : 0][DW_ACC2 ? ti : 0]);
+                            else if (DW_ACC2) mfma_split2(za[t], ab[ti % NB], wacc[t][ti], ws[DW_ACC2 ? t : 0][DW_ACC2 ? ti : 0]);
+                            else if (S::WBAR_REG) wbar[hl][t][ti] = mfma_split(za[t], ab[ti % NB], wbar[hl][t][ti]);
                             else wacc[t][ti] = mfma_split(za[t], ab[ti % NB], wacc[t][ti]);
                         }
                         chain_fence();                                      // (the adjoint pieces below stay BEHIND the chain, not inside it)
@@ -959,9 +1019,52 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                     vbf8 ab[3];
                     PINN_UNROLL for (int sp = 0; sp < 3; ++sp) ab[sp] = ld_tr(XA, (2 * qp * S::KB + (ti >> 1)) * 3 + sp, ti & 1);
                     PINN_UNROLL for (int t = 0; t < MTW; ++t) {
-                        if (S::WBAR_REG) wbar[hl][t][ti] = mfma_split(za[t], ab, wbar[hl][t][ti]);
+                        if (DW_ACC2 && S::WBAR_REG) mfma_split2(za[t], ab, wbar[hl][t][ti], ws[DW_ACC2 ? t : 0][DW_ACC2 ? ti : 0]);
+                        else if (DW_ACC2) mfma_split2(za[t], ab, wacc[t][ti], ws[DW_ACC2 ? t : 0][DW_ACC2 ? ti : 0]);
+                        else if (S::WBAR_REG) wbar[hl][t][ti] = mfma_split(za[t], ab, wbar[hl][t][ti]);
                         else wacc[t][ti] = mfma_split(za[t], ab, wacc[t][ti]);
                     }
+                }
+            };
+            // (PINN_F2_SPLIT_ACC2 & 16; register-resident sums, one neuron tile per wave) the dW GEMM of a layer with the INPUT tile as the outer
+            // loop: a tile's whole product — every column-group pair, the hh pieces in one fresh accumulator, the small pieces in another —
+            // is formed in zero-initialised accumulators and added to the running sum by ONE rounded VALU add per tile, so the running sums
+            // (after 100 tiles: 100 x a tile's products) never take a product the matrix pipe would truncate
+            constexpr bool DW_TI_OUTER = DW_ACC2 && S::WBAR_REG && MTW == 1 && (PINN_F2_SWP & 4) != 0 && (PINN_F2_SPLIT_ACC2 & 16) != 0;
+            auto dw_layer_tr2 = [&]() {
+                constexpr int NPR = (NG + 1) / 2, NGRP2 = MT * NPR, NB = 2;
+                auto ld_trq = [&](const float* X, int qp, int frag, int h) -> vbf8 {
+                    const int base = frag * 256 + h * 128;
+                    if (2 * qp + 1 < NG) return cat_bf8(lds_load_tr_bf4(X, vint(base) + trbq[0]), lds_load_tr_bf4(X, vint(base) + trbq[1]));
+                    return cat_bf8(lds_load_tr_bf4(X, vint(base) + trb[0]), lds_load_tr_bf4(X, vint(base) + trb[1]));
+                };
+                vbf8 za[NPR][3];
+                const int tile = w * MTW;
+                PINN_UNROLL for (int qp = 0; qp < NPR; ++qp)
+                    PINN_UNROLL for (int sp = 0; sp < 3; ++sp) {
+                        za[qp][sp] = ld_trq(XZ, qp, (2 * qp * S::KB + (tile >> 1)) * 3 + sp, tile & 1);
+                        if (2 * qp + 1 >= NG) za[qp][sp] = bf8_select(klo, za[qp][sp]);
+                    }
+                vbf8 ab[NB][3];
+                PINN_UNROLL for (int sp = 0; sp < 3; ++sp) ab[0][sp] = ld_trq(XA, 0, 0 * 3 + sp, 0);
+                PINN_UNROLL for (int ti = 0; ti < MT; ++ti) {
+                    vfloat4 wb_ = vzero4(), ws_ = vzero4();
+                    PINN_UNROLL for (int qp = 0; qp < NPR; ++qp) {
+                        const int gi = ti * NPR + qp;
+                        if (gi + 1 < NGRP2) {
+                            const int ti2 = (gi + 1) / NPR, qp2 = (gi + 1) % NPR;
+                            PINN_UNROLL for (int sp = 0; sp < 3; ++sp) ab[(gi + 1) % NB][sp] = ld_trq(XA, qp2, (2 * qp2 * S::KB + (ti2 >> 1)) * 3 + sp, ti2 & 1);
+                        }
+                        sched_fence();
+                        if (gi + 1 < NGRP2) lds_wait<6>(); else lds_wait<0>();
+                        mfma_split2(za[qp], ab[gi % NB], wb_, ws_);
+                        chain_fence();
+                        if (ADJ_IL) {
+                            PINN_UNROLL for (int j = 0; j < ADJ_NCH; ++j)
+                                if ((j * ADJ_NGRP) / ADJ_NCH == gi) adj_piece(Sr, j);
+                        }
+                    }
+                    PINN_UNROLL for (int e = 0; e < 4; ++e) wbar[hl][0][ti][e] += wb_[e] + ws_[e];
                 }
             };
             // W^T fragments for dA: issued ahead of the dW GEMM, which hides their latency
@@ -992,14 +1095,23 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 STAMP(8)
                 if (SPRE && hl - 1 >= 1) load_record(hl - 1);
                 wave_prio(0);
-                if (S::BFX_TR && (PINN_F2_SWP & 2)) gemm_swp(XZ, wtb, Gn);
+                if (S::BFX_TR && (PINN_F2_SWP & 2)) gemm_swp(XZ, wtb, Gn, (PINN_F2_SPLIT_ACC2 & 2) != 0);
                 PINN_UNROLL for (int q = 0; q < ((S::BFX_TR && (PINN_F2_SWP & 2)) ? 0 : NG); ++q) {
                     if (S::BFX) {
+                        constexpr bool ACC2 = (PINN_F2_SPLIT_ACC2 & 2) != 0;
+                        vfloat4 Gs[MTW];
+                        PINN_UNROLL for (int t = 0; t < MTW; ++t) Gs[t] = vzero4();
                         PINN_UNROLL for (int kb = 0; kb < S::KB; ++kb) {
                             vbf8 bb[3];
                             PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[sp] = ld_bfrag(XZ, (q * S::KB + kb) * 3 + sp);
-                            PINN_UNROLL for (int t = 0; t < MTW; ++t) Gn[q][t] = mfma_split(wtb[kb][t], bb, Gn[q][t]);
+                            PINN_UNROLL for (int t = 0; t < MTW; ++t) {
+                                if (ACC2) mfma_split2(wtb[kb][t], bb, Gn[q][t], Gs[t]);
+                                else Gn[q][t] = mfma_split(wtb[kb][t], bb, Gn[q][t]);
+                            }
                         }
+                        if (ACC2)
+                            PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                                PINN_UNROLL for (int e = 0; e < 4; ++e) Gn[q][t][e] += Gs[t][e];
                     } else {
                         PINN_UNROLL for (int mo = 0; mo < MT; ++mo) {
                             vfloat4 b4 = lds_load4(X0, vint(((q * MT + mo) * 64) * 4) + (lane << 2));
@@ -1024,7 +1136,11 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                     if (ADJ_IL)
                         PINN_UNROLL for (int q = 0; q < NG; ++q)
                             PINN_UNROLL for (int t = 0; t < MTW; ++t) G[q][t] = Gn[q][t];
-                    PINN_UNROLL for (int qp = 0; qp < (NG + 1) / 2; ++qp) dw_pair_tr(qp);
+                    if (DW_TI_OUTER) dw_layer_tr2();
+                    else {
+                        PINN_UNROLL for (int qp = 0; qp < (NG + 1) / 2; ++qp) dw_pair_tr(qp);
+                        dw_merge();
+                    }
                 } else {
                     PINN_UNROLL for (int q = 0; q < NG; ++q) dw_q(ZT + q * (MTW * 256), X1 + q * 16 * HP);
                     if (F2_GEMM_AHEAD > 0 && MTW == 1 && MT == 4)
@@ -1050,13 +1166,25 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
             // split-operand kernels of this path (H = 128): dA runs FIRST, on the W^T fragments requested above (their 48 registers are
             // dead again before the dW accumulators come alive)
             auto da_split = [&]() {
-                if (PINN_F2_SWP & 2) { gemm_swp(XZ, wtb, Gn); return; }
+                if (PINN_F2_SWP & 2) { gemm_swp(XZ, wtb, Gn, (PINN_F2_SPLIT_ACC2 & 2) != 0); return; }
+                constexpr bool ACC2 = (PINN_F2_SPLIT_ACC2 & 2) != 0;
+                vfloat4 Gs[ACC2 ? NG : 1][ACC2 ? MTW : 1];
+                if (ACC2)
+                    PINN_UNROLL for (int q = 0; q < NG; ++q)
+                        PINN_UNROLL for (int t = 0; t < MTW; ++t) Gs[q][t] = vzero4();
                 PINN_UNROLL for (int kb = 0; kb < S::KB; ++kb)
                     PINN_UNROLL for (int q = 0; q < NG; ++q) {
                         vbf8 bb[3];
                         PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[sp] = ld_bfrag(XZ, (q * S::KB + kb) * 3 + sp);
-                        PINN_UNROLL for (int t = 0; t < MTW; ++t) Gn[q][t] = mfma_split(wtb[kb][t], bb, Gn[q][t]);
+                        PINN_UNROLL for (int t = 0; t < MTW; ++t) {
+                            if (ACC2) mfma_split2(wtb[kb][t], bb, Gn[q][t], Gs[ACC2 ? q : 0][ACC2 ? t : 0]);
+                            else Gn[q][t] = mfma_split(wtb[kb][t], bb, Gn[q][t]);
+                        }
                     }
+                if (ACC2)
+                    PINN_UNROLL for (int q = 0; q < NG; ++q)
+                        PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                            PINN_UNROLL for (int e = 0; e < 4; ++e) Gn[q][t][e] += Gs[q][t][e];
             };
             if (S::CHUNKED) {
                 PINN_UNROLL for (int q = 0; q < NG; ++q) {
@@ -1077,7 +1205,11 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 if (ADJ_IL)
                     PINN_UNROLL for (int q = 0; q < NG; ++q)
                         PINN_UNROLL for (int t = 0; t < MTW; ++t) G[q][t] = Gn[q][t];
-                PINN_UNROLL for (int qp = 0; qp < (NG + 1) / 2; ++qp) dw_pair_tr(qp);
+                if (DW_TI_OUTER) dw_layer_tr2();
+                    else {
+                        PINN_UNROLL for (int qp = 0; qp < (NG + 1) / 2; ++qp) dw_pair_tr(qp);
+                        dw_merge();
+                    }
                 STAMP(9)
             } else {
                 PINN_UNROLL for (int q = 0; q < NG; ++q) stage_q(q, ZT + q * (MTW * 256), X1 + q * 16 * HP);

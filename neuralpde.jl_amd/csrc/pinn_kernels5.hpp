@@ -110,16 +110,26 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                 }
             } else {
                 PINN_LANES(l) { PINN_UNROLL for (int e = 0; e < NR * NCG; ++e) Z(l, e) = 0.0; }
+                // A fragments (W rows of output tile t, k-block kb) with a ROLLING prefetch: fragment (t + 1, kb) is requested right behind the
+                // MFMAs that consumed fragment (t, kb), so an L2 round trip has a whole tile row of MFMAs (16 NCG x 64 cycles) to land
+                LVd<NR> Af;
+                PINN_LANES(l) {
+                    PINN_UNROLL for (int kb = 0; kb < NR; ++kb) {
+                        const int m = (l & 15), k = 4 * kb + (l >> 4);
+                        Af(l, kb) = (m < n_out && k < n_in) ? W[m + (size_t)k * n_out] : 0.0;
+                    }
+                }
                 PINN_UNROLL for (int t = 0; t < HT; ++t) {
                     if (16 * t >= n_out) break;
                     PINN_UNROLL for (int kb = 0; kb < NR; ++kb) {
                         if (4 * kb >= n_in) break;
-                        LVd<1> Af;
-                        PINN_LANES(l) {
-                            const int m = 16 * t + (l & 15), k = 4 * kb + (l >> 4);
-                            Af(l, 0) = (m < n_out && k < n_in) ? W[m + (size_t)k * n_out] : 0.0;
+                        PINN_UNROLL for (int g = 0; g < NCG; ++g) mfma_f64(Z, (4 * t) * NCG + g, NCG, Af, kb, X, kb * NCG + g);
+                        if (t + 1 < HT) {
+                            PINN_LANES(l) {
+                                const int m = 16 * (t + 1) + (l & 15), k = 4 * kb + (l >> 4);
+                                Af(l, kb) = (m < n_out && k < n_in) ? W[m + (size_t)k * n_out] : 0.0;
+                            }
                         }
-                        PINN_UNROLL for (int g = 0; g < NCG; ++g) mfma_f64(Z, (4 * t) * NCG + g, NCG, Af, 0, X, kb * NCG + g);
                     }
                 }
                 PINN_LANES(l) {
@@ -254,29 +264,49 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                 }
             } else {
                 PINN_LANES(l) { PINN_UNROLL for (int e = 0; e < NR * NCG; ++e) Z(l, e) = 0.0; }
+                LVd<NR> Af;                                          // W^T: rows = this layer's neurons, k = the layer above's; rolling prefetch as above
+                PINN_LANES(l) {
+                    PINN_UNROLL for (int kb = 0; kb < NR; ++kb) {
+                        const int k = (l & 15), m = 4 * kb + (l >> 4);
+                        Af(l, kb) = (k < H && m < n_next) ? Wn[m + (size_t)k * n_next] : 0.0;
+                    }
+                }
                 PINN_UNROLL for (int t = 0; t < HT; ++t) {
                     if (16 * t >= H) break;
                     PINN_UNROLL for (int kb = 0; kb < NR; ++kb) {
                         if (4 * kb >= n_next) break;
-                        LVd<1> Af;                                   // W^T: rows = this layer's neurons, k = the layer above's
-                        PINN_LANES(l) {
-                            const int k = 16 * t + (l & 15), m = 4 * kb + (l >> 4);
-                            Af(l, 0) = (k < H && m < n_next) ? Wn[m + (size_t)k * n_next] : 0.0;
+                        PINN_UNROLL for (int g = 0; g < NCG; ++g) mfma_f64(Z, (4 * t) * NCG + g, NCG, Af, kb, X, kb * NCG + g);
+                        if (t + 1 < HT) {
+                            PINN_LANES(l) {
+                                const int k = 16 * (t + 1) + (l & 15), m = 4 * kb + (l >> 4);
+                                Af(l, kb) = (k < H && m < n_next) ? Wn[m + (size_t)k * n_next] : 0.0;
+                            }
                         }
-                        PINN_UNROLL for (int g = 0; g < NCG; ++g) mfma_f64(Z, (4 * t) * NCG + g, NCG, Af, 0, X, kb * NCG + g);
+                    }
+                }
+            }
+            // this layer's records into X (dead after the GEMM above): every load in flight before the first use — behind the stores of the
+            // adjoint loop below the compiler could not hoist them (same scratch pointer), and each would expose a memory round trip
+            PINN_LANES(l) {
+                const int q = l >> 4, j = l & 15;
+                PINN_UNROLL for (int tr = 0; tr < NR; ++tr) {
+                    const int k = 16 * (tr >> 2) + 4 * (tr & 3) + q, kc = k < H ? k : H - 1;
+                    PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                        const int p = pbase + 16 * pg + j, pc = p < a.npts ? p : a.npts - 1;
+                        PINN_UNROLL for (int c = 0; c < C; ++c) X(l, tr * NCG + pg * C + c) = S[((size_t)n.r_rec[lyr] + (size_t)kc * C + c) * np_ + pc];
                     }
                 }
             }
             PINN_LANES(l) {
                 const int q = l >> 4, j = l & 15;
                 PINN_UNROLL for (int tr = 0; tr < NR; ++tr) {
-                    const int k = 16 * (tr >> 2) + 4 * (tr & 3) + q, kc = k < H ? k : H - 1;
+                    const int k = 16 * (tr >> 2) + 4 * (tr & 3) + q;
                     const bool valid = k < H;
                     PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
-                        const int p = pbase + 16 * pg + j, pc = p < a.npts ? p : a.npts - 1;
+                        const int p = pbase + 16 * pg + j;
                         const bool st = valid && p < a.npts;
                         double s[C], gq[C], dd[ND];
-                        PINN_UNROLL for (int c = 0; c < C; ++c) s[c] = S[((size_t)n.r_rec[lyr] + (size_t)kc * C + c) * np_ + pc];
+                        PINN_UNROLL for (int c = 0; c < C; ++c) s[c] = X(l, tr * NCG + pg * C + c);
                         PINN_UNROLL for (int c = 0; c < C; ++c) gq[c] = Z(l, tr * NCG + pg * C + c);
                         act_derivs_n<J::NORD, SIN>(n.act, s[0], dd);
                         jet_adjoint<J>(gq, s, dd);
@@ -289,13 +319,17 @@ DEV void f64m_tile(int tile, const F64Args& a) {
     }
 }
 
-// ---- kernel B2': rows of 16 output neurons of the hidden-to-hidden weight gradients of one 512-point block ----
+// ---- kernel B2': rows of 16 output neurons of the hidden-to-hidden weight gradients of one 512-point block.  k = 16 consecutive points of
+// one channel per group of four MFMAs: lane (q, i) loads points p + 4 q .. + 3 of its row (32 contiguous bytes: a row's 16 points are one
+// 128-byte line) and MFMA step s contracts the points {s, 4 + s, 8 + s, 12 + s} — any assignment of points to k works as long as A and B
+// agree.  The waves of a workgroup take neighbouring output rows of the same (layer, block): they read the same input-jet rows (L1 / L2). ----
 HD int f64m_num_rows(const F64Args& a) {
     int t = 0;
     for (int ni = 0; ni < a.nnets; ++ni)
         for (int l = 1; l < a.net[ni].nl - 1; ++l) t += (a.net[ni].sizes[l + 1] + 15) / 16;
     return t;
 }
+constexpr int F64M_DWT_WAVES = 4;
 template <int HT>
 DEV void f64m_dwt(int row, int b, const F64Args& a) {
     int ni = 0, lyr = 1, t_out = 0;
@@ -307,6 +341,7 @@ DEV void f64m_dwt(int row, int b, const F64Args& a) {
                 if (row < nt) { ni = i; lyr = l; t_out = row; found = true; }
                 else row -= nt;
             }
+        if (!found) return;
     }
     const F64Net& n = a.net[ni];
     const int n_out = n.sizes[lyr + 1], n_in = n.sizes[lyr], C = a.C;
@@ -315,24 +350,36 @@ DEV void f64m_dwt(int row, int b, const F64Args& a) {
     const double* S = a.scratch;
     LVd<HT * 4> acc;
     PINN_LANES(l) { PINN_UNROLL for (int e = 0; e < HT * 4; ++e) acc(l, e) = 0.0; }
-    for (int p = lo; p < hi; p += 4)
-        for (int c = 0; c < C; ++c) {
-            LVd<1> Af;
-            LVd<HT> Bf;
-            PINN_LANES(l) {
-                const int pp = p + (l >> 4), m = 16 * t_out + (l & 15);
-                const bool pv = pp < hi;
-                Af(l, 0) = (pv && m < n_out) ? S[((size_t)n.r_dz[lyr] + (size_t)m * C + c) * np_ + pp] : 0.0;
-                PINN_UNROLL for (int t = 0; t < HT; ++t) {
-                    const int k = 16 * t + (l & 15);
-                    Bf(l, t) = (pv && k < n_in) ? S[((size_t)n.r_post[lyr - 1] + (size_t)k * C + c) * np_ + pp] : 0.0;
-                }
-            }
+    // steps = (16 points, channel); the operands of step i + 1 are requested before the MFMAs of step i (two register sets in rotation)
+    LVd<4> Af[2];
+    LVd<HT * 4> Bf[2];
+    auto load_step = [&](LVd<4>& A_, LVd<HT * 4>& B_, int p, int c) {
+        PINN_LANES(l) {
+            const int pp = p + 4 * (l >> 4), m = 16 * t_out + (l & 15);
+            const double* rz = S + ((size_t)n.r_dz[lyr] + (size_t)(m < n_out ? m : 0) * C + c) * np_;
+            PINN_UNROLL for (int s4 = 0; s4 < 4; ++s4) A_(l, s4) = (m < n_out && pp + s4 < hi) ? rz[pp + s4] : 0.0;
             PINN_UNROLL for (int t = 0; t < HT; ++t) {
-                if (16 * t >= n_in) break;
-                mfma_f64(acc, 4 * t, 1, Af, 0, Bf, t);
+                const int k = 16 * t + (l & 15);
+                const double* ri = S + ((size_t)n.r_post[lyr - 1] + (size_t)(k < n_in ? k : 0) * C + c) * np_;
+                PINN_UNROLL for (int s4 = 0; s4 < 4; ++s4) B_(l, 4 * t + s4) = (k < n_in && pp + s4 < hi) ? ri[pp + s4] : 0.0;
             }
         }
+    };
+    auto mma_step = [&](const LVd<4>& A_, const LVd<HT * 4>& B_) {
+        PINN_UNROLL for (int s4 = 0; s4 < 4; ++s4)
+            PINN_UNROLL for (int t = 0; t < HT; ++t) {
+                if (16 * t >= n_in) break;
+                mfma_f64(acc, 4 * t, 1, A_, s4, B_, 4 * t + s4);
+            }
+    };
+    const int nsteps = ((hi - lo + 15) / 16) * C;
+    if (nsteps > 0) load_step(Af[0], Bf[0], lo, 0);
+    for (int i = 0; i < nsteps; i += 2) {
+        if (i + 1 < nsteps) load_step(Af[1], Bf[1], lo + 16 * ((i + 1) / C), (i + 1) % C);
+        mma_step(Af[0], Bf[0]);
+        if (i + 2 < nsteps) load_step(Af[0], Bf[0], lo + 16 * ((i + 2) / C), (i + 2) % C);
+        if (i + 1 < nsteps) mma_step(Af[1], Bf[1]);
+    }
     PINN_LANES(l) {
         PINN_UNROLL for (int t = 0; t < HT; ++t)
             PINN_UNROLL for (int r = 0; r < 4; ++r) {
@@ -340,6 +387,49 @@ DEV void f64m_dwt(int row, int b, const F64Args& a) {
                 if (m < n_out && k < n_in) a.slab[(size_t)b * a.nent + n.ent0 + (n.woff[lyr] - n.theta0) + m + (size_t)k * n_out] = acc(l, 4 * t + r);
             }
     }
+}
+
+// ---- kernel B': the remaining slab entries (biases, first / last layer, PDE parameters, the block's sum of squares: family 4's f64_dw_entry)
+// with the block's points ACROSS THE LANES (coalesced row reads), one wave per entry of the term's small-entry list, lane partials summed in a
+// fixed butterfly order.  (Family 4's k_f64_dw runs one THREAD per entry over the block's 512 points: neighbouring threads read different rows.) ----
+DEV double f64m_dw_point(int e, int p, const F64Args& a, int ni, int lyr, bool bias, int m, int k) {
+    const size_t np_ = (size_t)a.npad;
+    const double* S = a.scratch;
+    const int C = a.C;
+    if (e == a.nent - 1) return S[(size_t)a.r_sq * np_ + p];
+    if (e >= a.ent_p) return S[((size_t)a.r_pbar + (e - a.ent_p)) * np_ + p];
+    const F64Net& n = a.net[ni];
+    const int L = n.nl - 1;
+    const size_t dz = (lyr == L) ? (size_t)n.r_ubar : (size_t)n.r_dz[lyr] + (size_t)m * C;
+    if (bias) return S[dz * np_ + p];
+    if (lyr == 0) {
+        const int ck = a.first_ch[k];
+        double t2 = S[dz * np_ + p] * a.pts[(size_t)(a.p0 + p) * a.dt + n.imap[k]];
+        if (ck >= 0) t2 += S[(dz + ck) * np_ + p];
+        return t2;
+    }
+    const size_t in = (size_t)n.r_post[lyr - 1] + (size_t)k * C;
+    double t2 = 0.0;
+    for (int c = 0; c < C; ++c) t2 = vfma(S[(dz + c) * np_ + p], S[(in + c) * np_ + p], t2);
+    return t2;
+}
+// decode of entry e (wave-uniform): network, layer, bias / weight indices; returns false for entries this kernel does not own
+HD bool f64m_dw_decode(int e, const F64Args& a, int& ni, int& lyr, bool& bias, int& m, int& k) {
+    ni = 0; lyr = 0; bias = false; m = 0; k = 0;
+    if (e == a.nent - 1) return true;
+    if (e >= a.ent_p) return a.mode == 0;
+    if (a.mode != 0) return false;
+    while (ni + 1 < a.nnets && e >= a.net[ni + 1].ent0) ++ni;
+    const F64Net& n = a.net[ni];
+    const int L = n.nl - 1;
+    const int t = n.theta0 + (e - n.ent0);
+    while (lyr + 1 < n.nl && t >= n.woff[lyr + 1]) ++lyr;
+    const int n_out = n.sizes[lyr + 1];
+    bias = t >= n.boff[lyr];
+    if (!bias && lyr >= 1 && lyr < L) return false;            // hidden-to-hidden weights: k_f64m_dwt
+    m = bias ? t - n.boff[lyr] : (t - n.woff[lyr]) % n_out;
+    k = bias ? 0 : (t - n.woff[lyr]) / n_out;
+    return true;
 }
 
 // ---- the kernel table: (inputs, jet set, HT) -> launchers; matched against a term's float64 kernel in f64.cpp ----
@@ -362,9 +452,30 @@ template <int HT> void launch_f64m_dwt(const F64Args& a, plat_stream) {
     const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK, nr = f64m_num_rows(a);
     for (int b = 0; b < nb; ++b) for (int r = 0; r < nr; ++r) f64m_dwt<HT>(r, b, a);
 }
+inline void launch_f64m_dw(const F64Args& a, const int* small_ent, int nsmall, plat_stream) {
+    const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK;
+    for (int b = 0; b < nb; ++b)
+        for (int i = 0; i < nsmall; ++i) {
+            const int e = small_ent[i];
+            int ni, lyr, m, k; bool bias;
+            if (!f64m_dw_decode(e, a, ni, lyr, bias, m, k)) { if (e == a.nent - 1 || e >= a.ent_p) a.slab[(size_t)b * a.nent + e] = 0.0; continue; }
+            const int lo = b * F64_BLOCK, hi = (lo + F64_BLOCK < a.npts) ? lo + F64_BLOCK : a.npts;
+            double part[64];
+            for (int lane = 0; lane < 64; ++lane) { double s = 0.0; for (int p = lo + lane; p < hi; p += 64) s += f64m_dw_point(e, p, a, ni, lyr, bias, m, k); part[lane] = s; }
+            // (the device's xor butterfly: after step o every lane holds the sum of its 2o-lane group; association = a balanced tree)
+            double t[64];
+            for (int lane = 0; lane < 64; ++lane) t[lane] = part[lane];
+            for (int o = 32; o >= 1; o >>= 1) { double u[64]; for (int lane = 0; lane < 64; ++lane) u[lane] = t[lane] + t[lane ^ o]; for (int lane = 0; lane < 64; ++lane) t[lane] = u[lane]; }
+            a.slab[(size_t)b * a.nent + e] = t[0];
+        }
+}
 #else
-template <class J, int HT, int PG> __global__ void __launch_bounds__(64) k_f64m_tile(const F64Args a) { f64m_tile<J, HT, PG, ACT_TANH>((int)blockIdx.x, a); }
-template <int HT> __global__ void __launch_bounds__(64) k_f64m_dwt(const F64Args a) { f64m_dwt<HT>((int)blockIdx.x, (int)blockIdx.y, a); }
+template <class J, int HT, int PG> __global__ void __launch_bounds__(64, (HT * PG * J::C <= 8) ? 2 : 1) k_f64m_tile(const F64Args a) {
+    f64m_tile<J, HT, PG, ACT_TANH>((int)blockIdx.x, a);
+}
+template <int HT> __global__ void __launch_bounds__(64 * F64M_DWT_WAVES) k_f64m_dwt(const F64Args a) {
+    f64m_dwt<HT>((int)(blockIdx.x * F64M_DWT_WAVES + (threadIdx.x >> 6)), (int)blockIdx.y, a);
+}
 template <class J, int HT, int PG> void launch_f64m_tile(const F64Args& a, plat_stream st) {
     const int nt = (a.npts + 16 * PG - 1) / (16 * PG);
     hipLaunchKernelGGL((k_f64m_tile<J, HT, PG>), dim3(nt), dim3(64), 0, st, a);
@@ -372,7 +483,25 @@ template <class J, int HT, int PG> void launch_f64m_tile(const F64Args& a, plat_
 template <int HT> void launch_f64m_dwt(const F64Args& a, plat_stream st) {
     const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK, nr = f64m_num_rows(a);
     if (a.mode != 0 || nr == 0) return;
-    hipLaunchKernelGGL((k_f64m_dwt<HT>), dim3(nr, nb), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((k_f64m_dwt<HT>), dim3((nr + F64M_DWT_WAVES - 1) / F64M_DWT_WAVES, nb), dim3(64 * F64M_DWT_WAVES), 0, st, a);
+}
+constexpr int F64M_DW_SPLIT = 8;          // workgroups (of 4 waves) per block of points: wave v of 32 takes the entries v, v + 32, ... of the list
+template <int UNUSED> __global__ void __launch_bounds__(256) k_f64m_dw(const F64Args a, const int* small_ent, int nsmall) {
+    const int wv = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), b = (int)blockIdx.y, lane = (int)(threadIdx.x & 63);
+    const int lo = b * F64_BLOCK, hi = (lo + F64_BLOCK < a.npts) ? lo + F64_BLOCK : a.npts;
+    for (int i = wv; i < nsmall; i += 4 * F64M_DW_SPLIT) {
+        const int e = small_ent[i];
+        int ni, lyr, m, k; bool bias;
+        if (!f64m_dw_decode(e, a, ni, lyr, bias, m, k)) { if (lane == 0 && (e == a.nent - 1 || e >= a.ent_p)) a.slab[(size_t)b * a.nent + e] = 0.0; continue; }
+        double s = 0.0;
+        for (int p = lo + lane; p < hi; p += 64) s += f64m_dw_point(e, p, a, ni, lyr, bias, m, k);
+        PINN_UNROLL for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) a.slab[(size_t)b * a.nent + e] = s;
+    }
+}
+inline void launch_f64m_dw(const F64Args& a, const int* small_ent, int nsmall, plat_stream st) {
+    const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK;
+    hipLaunchKernelGGL((k_f64m_dw<0>), dim3(F64M_DW_SPLIT, nb), dim3(256), 0, st, a, small_ent, nsmall);
 }
 #endif
 
@@ -380,7 +509,9 @@ template <int D, unsigned D1MASK, unsigned long long PAIRS, int NPAIR, unsigned 
     using J = JetSet<D1MASK, PAIRS, NPAIR, HI>;
     static_assert(J::NLAP == 0, "the float64 kernels carry plain derivative channels (no forward-Laplacian channel)");
     // column groups per wave: as many point groups as keep the two operand arrays (2 x HT * 4 * NCG doubles per lane) inside the register file
-    constexpr int CAP = (HT <= 4) ? 4 : 2;
+    // ... and, where the channel count allows it, few enough (NCG <= 2: the operand arrays take <= 128 registers) that TWO waves fit a SIMD —
+    // one wave's element-wise float64 work (the activation alone is ~45 f64 instructions per element) then runs under the other's MFMAs
+    constexpr int CAP = 2;
     constexpr int PG = (J::C >= CAP) ? 1 : CAP / J::C;
     static_assert(HT * PG * J::C <= 24, "operand arrays of this (jet set, width) pair exceed the register file: keep family 4");
     F64MKernel k;

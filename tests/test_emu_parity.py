@@ -1001,7 +1001,10 @@ def test_scaled_parameters_both_gemm_modes(npde, use_emu, scale):
         le, g2, gi = err[(mode, "stencil")]
         for e, f in ((le.max(), fd[0].max()), (g2, fd[1]), (gi, fd[2])):
             assert e < max(TOL, 1.3 * f + 5e-6), (mode, "stencil", scale, e, f)
-    assert err[("fp32", "exact")][1] < 1.5 * err[("split", "exact")][1] + 1e-7      # (never worse; in the emulation strictly closer)
+    # (r05: with the small piece products on an accumulator of their own the split products round LESS often at full magnitude than an fmaf
+    # chain — neither mode is systematically closer any more; what the bar asks is above: both inside 1e-5)
+    e_f, e_s = err[("fp32", "exact")][1], err[("split", "exact")][1]
+    assert max(e_f, e_s) < 2.5 * min(e_f, e_s) + 1e-7
 
 
 def test_gemm_mode_from_the_environment_and_128_wide(npde, use_emu, monkeypatch):

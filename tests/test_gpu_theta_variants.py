@@ -9,11 +9,18 @@ engine implements) the bar holds as is.  Against the STENCIL oracle (the referen
 wherever the stencil's own truncation error leaves room: at saturating parameters the float64 stencil differs from the exact derivative by
 more than 1e-5 on its own (printed per case as "finite-difference error"), and there the engine must be as close to the reference as exact
 derivatives can be: within 1.3 x that error + 5e-6.
-At TRAINED parameters the residual is a small difference of O(1) terms (|r| ~ 1e-3 |u_xx|): every fp32 evaluation of it is off by
-1e-5 ... 1e-3 relative to the float64 result, whatever the GEMM arithmetic (the fixtures carry the SAME program evaluated by torch in float32:
-`*_f32_*`).  The north star prescribes fp32 compute, so there the engine is held to "no worse than a plain fp32 implementation of the
-reference's mathematics": error <= max(1e-5, 8 x the float32 evaluation's error) (measured ratios 1.1 ... 5.7, DESIGN.md section 6: the two
-evaluate the same mathematics in different operation orders, and the engine's tanh is exp2 + rcp (1e-7 absolute) where torch's is libm).
+At TRAINED parameters the residual is a small difference of O(1) terms (|r| ~ 1e-3 |u_xx|) and the gradient a small difference of large
+per-point terms: the QUANTISATION of theta to float32 alone moves loss and gradient by 2e-5 ... 1e-2 (the fixtures carry the float64 oracle at
+float32(theta): `*_exact32_*`, oracle/make_golden.py variants-theta32), and every fp32 evaluation adds its rounding to that (the fixtures
+carry the SAME program evaluated by torch in float32: `*_f32_*`).  The north star prescribes fp32 compute, so there the engine is held to
+"no worse than a plain fp32 implementation of the reference's mathematics": error <= max(1e-5, 2 x the float32 evaluation's error), against
+the oracle at theta64 AND against the oracle at float32(theta) (r05; 8 x in r04).  What made 2 x possible: r04's engine was 2.4-2.8 x
+worse than torch-f32 on the cfg2 gradients because its tanh formed e^{2x} as exp2(x * float32(2 log2 e)) — the constant's rounding error
+(-1.3e-8 relative) scaled EVERY pre-activation of the network coherently, which a trained theta amplifies like a perturbation of all weights
+in one direction (profiles/r05_theta_variants_ab.txt: tools/r05/theta_ab_gpu.py over four tanh variants); now a two-constant exponent, an
+odd formula and one Newton step on the reciprocal (csrc/vec.hpp: vtanh_fast): 0.3-1.0 x torch-f32 on the gradients.
+The FLOAT64 mode (r05: on the matrix pipe, csrc/pinn_kernels5.hpp) is held to the PLAIN 1e-5 at every trained case at full size — it meets
+it with nine orders of magnitude to spare.
 The measured errors and margins of every case are printed (pytest -s) and tabulated in DESIGN.md section 6."""
 import hashlib
 import os
@@ -84,12 +91,40 @@ def test_theta_variant(npde, hip_lib, name, tag):
     if f"grad_f32_{tag}" in g:
         f32 = _errors(g[f"losses_f32_{tag}"], g[f"grad_f32_{tag}"], g[f"losses_exact_{tag}"], g[f"grad_exact_{tag}"])
         print(f"  float32 torch evaluation of the same program vs the exact float64 oracle: loss rel {f32[0]:.2e}, grad rel L2 {f32[1]:.2e}, Linf {f32[2]:.2e}")
+    trained = tag.startswith("adam")
+    REL = 2.0                                                     # trained parameters: at most this multiple of a plain float32 evaluation's error
+    f32q = None
+    if trained and f"grad_exact32_{tag}" in g:
+        # the arithmetic alone: reference = the float64 oracle at the float32-rounded parameters the fp32 kernels are handed
+        l32, g32 = g[f"losses_exact32_{tag}"], g[f"grad_exact32_{tag}"]
+        f32q = _errors(g[f"losses_f32_{tag}"], g[f"grad_f32_{tag}"], l32, g32)
+        print(f"  against the oracle at float32(theta): torch-f32 loss rel {f32q[0]:.2e}, grad rel L2 {f32q[1]:.2e}, Linf {f32q[2]:.2e}")
     for mode in ("split", "fp32"):
         for i, e in enumerate(rows[(mode, "exact")]):
-            bound = TOL if (f32 is None or not tag.startswith("adam")) else max(TOL, 8.0 * f32[i])
+            bound = TOL if (f32 is None or not trained) else max(TOL, REL * f32[i])
             assert e < bound, (name, tag, mode, "exact", i, e, bound)
         for i, (e, f) in enumerate(zip(rows[(mode, "stencil")], fd)):
             bound = max(TOL, 1.3 * f + 5e-6)
-            if f32 is not None and tag.startswith("adam"):
-                bound = max(bound, 8.0 * f32[i] + 1.3 * f)
+            if f32 is not None and trained:
+                bound = max(bound, REL * f32[i] + 1.3 * f)
             assert e < bound, (name, tag, mode, "stencil", i, e, bound)
+        if f32q is not None:
+            eng.set_option("gemm", mode)
+            losses, grad = eng.loss_grad(theta, w)
+            eq = _errors(losses, grad, l32, g32)
+            print(f"  gemm={mode:5s} vs oracle at float32(theta): loss rel {eq[0]:.2e}, grad rel L2 {eq[1]:.2e}, Linf {eq[2]:.2e}   x torch-f32: "
+                  f"{eq[0] / f32q[0]:.2f} / {eq[1] / f32q[1]:.2f} / {eq[2] / f32q[2]:.2f}")
+            for i, e in enumerate(eq):
+                assert e < max(TOL, REL * f32q[i]), (name, tag, mode, "exact32", i, e, f32q[i])
+    if trained:
+        # the float64 mode at FULL size: the north star's tolerance as is, no relaxation
+        eng.set_option("gemm", "split")
+        eng.set_option("precision", "f64")
+        for k, s_ in enumerate(sets):
+            eng.set_points_f64(k, s_)
+        l64, g64 = eng.loss_grad_f64(theta, w)
+        e64 = _errors(l64, g64, g[f"losses_exact_{tag}"], g[f"grad_exact_{tag}"])
+        print(f"  float64 mode ({eng.get_option('f64_path')}) vs exact oracle: loss rel {e64[0]:.2e}, grad rel L2 {e64[1]:.2e}, Linf {e64[2]:.2e}   margin to 1e-5: x{TOL / max(e64):.1e}")
+        assert max(e64) < TOL, (name, tag, "f64", e64)
+        assert eng.get_option("f64_path") == "mfma"
+        eng.set_option("precision", "f32")

@@ -225,3 +225,30 @@ def test_hip_events_are_opt_in(npde, use_emu):
     eng.set_timing(0, -1)
     eng.loss_grad(th0)
     assert eng.get_option("eval_path") == "one launch"
+
+
+def test_one_launch_evaluation_checks_points_and_data(npde, use_emu):
+    """the one-launch evaluation (eval_and_sync -> eval_fused) skipped ensure_points — a handle with point sets installed for
+    SOME terms returned NaN losses and a finite gradient instead of the error the stand-alone kernels report.  Every path checks now."""
+    import os
+    sysm, chain = poisson2d(npde, "tanh", width=16, hidden=2)
+    th0 = theta_for(chain, 4)
+    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.2), init_params=th0))
+    rep.engine.loss_grad(th0)
+    assert rep.engine.get_option("eval_path") == "one launch"             # (the shape IS eligible for the one-launch evaluation)
+    desc = rep.ir.to_descriptor()
+    sets = rep.pde_train_sets + rep.bcs_train_sets
+    for env in (None, "1"):
+        if env:
+            os.environ["PINN_NO_FUSED_EVAL"] = env
+        try:
+            eng = npde.Engine(desc)
+            eng.set_points(0, sets[0])                                         # term 0 only
+            with pytest.raises(Exception, match="term 1 has no collocation points"):
+                eng.loss_grad(th0)
+            for k in range(1, eng.K):
+                eng.set_points(k, sets[k])
+            l, g = eng.loss_grad(th0)
+            assert np.all(np.isfinite(l)) and np.all(np.isfinite(g))
+        finally:
+            os.environ.pop("PINN_NO_FUSED_EVAL", None)

@@ -7,6 +7,7 @@
 #   tests:<expr>     ... -k "<expr>" -s                                             -> tests_<n>.txt
 #   bench[:args]     python bench.py [args]                                         -> bench.json / bench.err
 #   trace            rocprofv3 --kernel-trace --stats of bench.py                   -> trace/ + kernel_stats.txt
+#   trace:<args>     the same with bench.py <args> (e.g. --precision f64)                        -> trace_<n>/ + kernel_stats_<n>.txt
 #   pmc              tools/pmc_profile.sh (separate --pmc passes, kernel-trace only) -> pmc/
 #   ab:<v1,v2,..>    tools/ab_compare.py over the variant libraries csrc/abl/libpinn_<v>.so (+ "head" = the product)   -> ab_<cfg>.txt
 #   abcfg:<cfg>:<v1,v2,..>   the same on another config (cfg3, cfg4, cfg5)
@@ -32,6 +33,8 @@ for step in "$@"; do
         bench:*)    timeout 900 python bench.py ${step#bench:} > "$O/bench_$n.json" 2> "$O/bench_$n.err"; head -c 600 "$O/bench_$n.json"; echo ;;
         trace)      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$O/trace" -o t -- python "$OLDPWD/bench.py" --steps 80 --warmup 5 --no-cpu-baseline > "$OLDPWD/$O/bench_under_rocprof.json" 2> "$OLDPWD/$O/trace.err")
                     python profiles/rocpd_stats.py "$(find "$O/trace" -name '*_results.db' | head -n 1)" > "$O/kernel_stats.txt" 2>&1; head -n 12 "$O/kernel_stats.txt"; find "$O/trace" -name '*.db' -size +20M -delete ;;
+        trace:*)    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$O/trace_$n" -o t -- python "$OLDPWD/bench.py" ${step#trace:} > "$OLDPWD/$O/bench_under_rocprof_$n.json" 2> "$OLDPWD/$O/trace_$n.err")
+                    python profiles/rocpd_stats.py "$(find "$O/trace_$n" -name '*_results.db' | head -n 1)" > "$O/kernel_stats_$n.txt" 2>&1; head -n 16 "$O/kernel_stats_$n.txt"; find "$O/trace_$n" -name '*.db' -size +20M -delete ;;
         pmc)        timeout 1200 bash tools/pmc_profile.sh "$O/pmc" > "$O/pmc.log" 2>&1; tail -n 40 "$O/pmc/pmc_summary.txt" ;;
         ab:*)       timeout 900 python tools/ab_compare.py $(echo "${step#ab:}" | tr ',' ' ') > "$O/ab_cfg2.txt" 2>&1; grep -i "round\|rror\|median" "$O/ab_cfg2.txt" | cut -c1-200 ;;
         abcfg:*)    rest=${step#abcfg:}; cfg=${rest%%:*}; timeout 900 python tools/ab_compare.py --cfg "$cfg" $(echo "${rest#*:}" | tr ',' ' ') > "$O/ab_$cfg.txt" 2>&1; grep -i "round\|rror\|median" "$O/ab_$cfg.txt" | cut -c1-200 ;;

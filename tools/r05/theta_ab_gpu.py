@@ -22,6 +22,10 @@ for cfg, make, tags in CASES:
         has32 = f"grad_exact32_{tag}" in g
         print(f"{cfg} {tag} (full size): |grad| = {np.linalg.norm(gref):.3e}; torch-f32 vs exact float64 oracle: loss {ef[0]:.2e} grad L2 {ef[1]:.2e} Linf {ef[2]:.2e}", flush=True)
         if has32:
+            ef2 = err(g[f"losses_f32_{tag}"], g[f"grad_f32_{tag}"], g[f"losses_exact32_{tag}"], g[f"grad_exact32_{tag}"])
+            print(f"    torch-f32 vs oracle at float32(theta): loss {ef2[0]:.2e} grad L2 {ef2[1]:.2e} Linf {ef2[2]:.2e}  per-term loss errors " +
+                  " ".join(f"{x:.1e}" for x in np.abs(g[f"losses_f32_{tag}"] - g[f"losses_exact32_{tag}"]) / np.abs(g[f"losses_exact32_{tag}"])) +
+                  "   term losses " + " ".join(f"{x:.2e}" for x in g[f"losses_exact32_{tag}"]))
             e32 = err(lr, gref, g[f"losses_exact32_{tag}"], g[f"grad_exact32_{tag}"])
             print(f"    input quantisation alone (oracle at theta64 vs oracle at float32(theta64)): loss {e32[0]:.2e} grad L2 {e32[1]:.2e} Linf {e32[2]:.2e}")
         for name in names:
@@ -37,5 +41,6 @@ for cfg, make, tags in CASES:
                 if has32:
                     e2 = err(l, gr, g[f"losses_exact32_{tag}"], g[f"grad_exact32_{tag}"])
                     line += f"   | vs oracle at float32(theta): loss {e2[0]:.2e} grad L2 {e2[1]:.2e} Linf {e2[2]:.2e}"
+                    line += "  per-term loss errors " + " ".join(f"{x:.1e}" for x in np.abs(l - g[f"losses_exact32_{tag}"]) / np.abs(g[f"losses_exact32_{tag}"]))
                 print(line, flush=True)
             del rep, eng
