@@ -202,12 +202,17 @@ struct Spec2 {
     static constexpr int OFF_ZT = 2 * XSZB;
     static constexpr int OFF_UP = 2 * XSZB + (CHUNKED ? 0 : NW * ZTW);
     static constexpr int LDS_BASE = OFF_UP + LDS_UP;
-    static constexpr int WG_PER_CU = (NW == 8) ? 1 : ((LDS_BASE * 4 <= 80 * 1024) ? 2 : 1);
+    // (r05 experiment, -DPINN_F2_WG3=1 with -DPINN_F2_REC_LDS=0: THREE workgroups per CU — 168 registers per wave, <= 53 KB LDS per workgroup;
+    // profiles/r05_experiments.txt)
+#ifndef PINN_F2_WG3
+#define PINN_F2_WG3 0
+#endif
+    static constexpr int WG_PER_CU = (NW == 8) ? 1 : ((PINN_F2_WG3 && LDS_BASE * 4 <= 53 * 1024) ? 3 : ((LDS_BASE * 4 <= 80 * 1024) ? 2 : 1));
     // the records of the stored hidden layers stay in LDS instead of the per-workgroup scratch slab in global memory — as many
     // (layer, column group) slices as fit without lowering the number of resident workgroups, from layer LH-2 (needed first by the
     // reverse sweep) downwards.  Each wave writes and reads its own part of a slice only.  4x64, NG = 4: 7 of the 8 slices.
     static constexpr int RECQ = MT * 256;                            // one column group of one layer's record of a tile (floats)
-    static constexpr int LDS_CAP = (WG_PER_CU == 2 ? 80 : 160) * 256 - 64;    // floats per workgroup
+    static constexpr int LDS_CAP = (WG_PER_CU == 3 ? 53 : (WG_PER_CU == 2 ? 80 : 160)) * 256 - 64;    // floats per workgroup
     static constexpr int NRQ_ALL = (LH > 2 ? LH - 2 : 0) * NG;
     static constexpr int NRQ_FIT = (LDS_CAP - LDS_BASE) / RECQ;
     static constexpr int NRQ = PINN_F2_REC_LDS ? (NRQ_FIT < NRQ_ALL ? (NRQ_FIT > 0 ? NRQ_FIT : 0) : NRQ_ALL) : 0;
@@ -222,7 +227,10 @@ struct Spec2 {
     static constexpr int OCC_FWD = WG_FWD * NW / 4;
     // dW accumulators: resident in registers across tiles when they fit (4x64: 48 registers); for wide/deep nets they
     // are accumulated per tile into this workgroup's slab instead (read-modify-write, L2; same wave owns the same tiles)
-    static constexpr bool WBAR_REG = (NHH_ * MTW * MT * 4 <= 96);
+#ifndef PINN_F2_NO_WBAR_REG
+#define PINN_F2_NO_WBAR_REG 0           // (r05 experiment: the dW sums of the H = 64 kernels in the slab as well — 48 registers fewer per wave)
+#endif
+    static constexpr bool WBAR_REG = !PINN_F2_NO_WBAR_REG && (NHH_ * MTW * MT * 4 <= 96);
     using Shape = Shape2<HP_, NHH_, D_, NW, WBAR_REG>;
 };
 

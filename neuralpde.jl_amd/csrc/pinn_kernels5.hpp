@@ -10,8 +10,9 @@
 //     (W for the forward GEMM, W^T for dA) come straight from theta (double, ComponentArrays order; L2-resident), masked to the layer's
 //     true width.  All C jet channels of PG point groups travel as NCG = PG * C column groups of 16 columns that share every weight fragment.
 //     Per element the activation / jet rules are the templates of pinn_kernels.hpp with V = double, the tape is family 4's.
-//   * k_f64m_dwt: the hidden-to-hidden weight gradients dW = dZ A^T as MFMAs over the scratch rows (k = 4 consecutive points of one channel),
-//     one wave per (512-point block, layer, 16 output neurons), accumulators for every input tile in registers, written into the block's slab.
+//   * k_f64m_dwt: the hidden-to-hidden weight gradients dW = dZ A^T (and those layers' bias gradients) as MFMAs over the scratch rows
+//     (k = 16 consecutive points of one channel), one workgroup of four waves per (512-point block, layer), each wave a quarter of the block's
+//     points and every output x input tile of the layer in registers, combined through LDS in wave order, written into the block's slab.
 // Records / post-activation jets / dZ go through the same point-major scratch rows as family 4's (so family 4's k_f64_dw — biases, first and
 // last layer, PDE parameters, the sum of squares — and k_f64_reduce run unchanged behind it).
 // Eligibility (f64.cpp): tanh / sigmoid networks with at least one hidden layer, hidden widths <= 16 * HT of an instantiated (jet set, HT)
@@ -71,6 +72,17 @@ template <int N> DEV void lv_qsum(LVd<N>& X, int i) {
 }
 #endif
 
+// four consecutive doubles at a 32-byte aligned address (device: two global_load_dwordx4)
+#ifdef PINN_EMU
+inline void ld4_f64(const double* p, double (&o)[4]) { for (int i = 0; i < 4; ++i) o[i] = p[i]; }
+#else
+DEV void ld4_f64(const double* p, double (&o)[4]) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2 a = *reinterpret_cast<const d2*>(p), b = *reinterpret_cast<const d2*>(p + 2);
+    o[0] = a[0]; o[1] = a[1]; o[2] = b[0]; o[3] = b[1];
+}
+#endif
+
 // ---- kernel A': forward jets of every network, residual tape, reverse sweep of one tile of 16 * PG points ----
 template <class J, int HT, int PG, int ACTK>
 DEV void f64m_tile(int tile, const F64Args& a) {
@@ -116,7 +128,7 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                 PINN_LANES(l) {
                     PINN_UNROLL for (int kb = 0; kb < NR; ++kb) {
                         const int m = (l & 15), k = 4 * kb + (l >> 4);
-                        Af(l, kb) = (m < n_out && k < n_in) ? W[m + (size_t)k * n_out] : 0.0;
+                        { const double wv = W[(m < n_out ? m : 0) + (size_t)(k < n_in ? k : 0) * n_out]; Af(l, kb) = (m < n_out && k < n_in) ? wv : 0.0; }      // (unconditional load, masked afterwards)
                     }
                 }
                 PINN_UNROLL for (int t = 0; t < HT; ++t) {
@@ -127,7 +139,7 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                         if (t + 1 < HT) {
                             PINN_LANES(l) {
                                 const int m = 16 * (t + 1) + (l & 15), k = 4 * kb + (l >> 4);
-                                Af(l, kb) = (m < n_out && k < n_in) ? W[m + (size_t)k * n_out] : 0.0;
+                                { const double wv = W[(m < n_out ? m : 0) + (size_t)(k < n_in ? k : 0) * n_out]; Af(l, kb) = (m < n_out && k < n_in) ? wv : 0.0; }      // (unconditional load, masked afterwards)
                             }
                         }
                     }
@@ -268,7 +280,7 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                 PINN_LANES(l) {
                     PINN_UNROLL for (int kb = 0; kb < NR; ++kb) {
                         const int k = (l & 15), m = 4 * kb + (l >> 4);
-                        Af(l, kb) = (k < H && m < n_next) ? Wn[m + (size_t)k * n_next] : 0.0;
+                        { const double wv = Wn[(m < n_next ? m : 0) + (size_t)(k < H ? k : 0) * n_next]; Af(l, kb) = (k < H && m < n_next) ? wv : 0.0; }
                     }
                 }
                 PINN_UNROLL for (int t = 0; t < HT; ++t) {
@@ -279,7 +291,7 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                         if (t + 1 < HT) {
                             PINN_LANES(l) {
                                 const int k = 16 * (t + 1) + (l & 15), m = 4 * kb + (l >> 4);
-                                Af(l, kb) = (k < H && m < n_next) ? Wn[m + (size_t)k * n_next] : 0.0;
+                                { const double wv = Wn[(m < n_next ? m : 0) + (size_t)(k < H ? k : 0) * n_next]; Af(l, kb) = (k < H && m < n_next) ? wv : 0.0; }
                             }
                         }
                     }
@@ -319,74 +331,117 @@ DEV void f64m_tile(int tile, const F64Args& a) {
     }
 }
 
-// ---- kernel B2': rows of 16 output neurons of the hidden-to-hidden weight gradients of one 512-point block.  k = 16 consecutive points of
-// one channel per group of four MFMAs: lane (q, i) loads points p + 4 q .. + 3 of its row (32 contiguous bytes: a row's 16 points are one
-// 128-byte line) and MFMA step s contracts the points {s, 4 + s, 8 + s, 12 + s} — any assignment of points to k works as long as A and B
-// agree.  The waves of a workgroup take neighbouring output rows of the same (layer, block): they read the same input-jet rows (L1 / L2). ----
-HD int f64m_num_rows(const F64Args& a) {
+// ---- kernel B2': the hidden-to-hidden weight gradients dW = dZ A^T AND the bias gradients of those layers for one 512-point block: one
+// workgroup of four waves per (layer, block).  Wave w takes the 16-point steps w, w + 4, ... of the block and accumulates EVERY output tile x input
+// tile of the layer (HT^2 accumulators: each scratch datum is read exactly once, by one wave); k = 16 consecutive points of one channel per
+// group of MFMAs — lane (q, i) loads points p + 4 q .. + 3 of its row (32 contiguous bytes; a row's 16 points are one 128-byte line) and MFMA
+// step s contracts the points {s, 4 + s, 8 + s, 12 + s}: any assignment of points to k works as long as A and B agree.  The operands of step
+// i + 1 are requested before the MFMAs of step i.  The four waves' partial sums are combined through LDS in wave order (deterministic). ----
+HD int f64m_num_layers(const F64Args& a) {
     int t = 0;
-    for (int ni = 0; ni < a.nnets; ++ni)
-        for (int l = 1; l < a.net[ni].nl - 1; ++l) t += (a.net[ni].sizes[l + 1] + 15) / 16;
+    for (int ni = 0; ni < a.nnets; ++ni) t += (a.net[ni].nl - 2 > 0) ? a.net[ni].nl - 2 : 0;
     return t;
 }
 constexpr int F64M_DWT_WAVES = 4;
+template <int HT> struct F64mDwtAcc { LVd<HT * HT * 4> acc; LVd<HT> bsum; };
+// one wave's partial sums
 template <int HT>
-DEV void f64m_dwt(int row, int b, const F64Args& a) {
-    int ni = 0, lyr = 1, t_out = 0;
-    {
-        bool found = false;
-        for (int i = 0; i < a.nnets && !found; ++i)
-            for (int l = 1; l < a.net[i].nl - 1 && !found; ++l) {
-                const int nt = (a.net[i].sizes[l + 1] + 15) / 16;
-                if (row < nt) { ni = i; lyr = l; t_out = row; found = true; }
-                else row -= nt;
-            }
-        if (!found) return;
-    }
+DEV void f64m_dwt_wave(int ni, int lyr, int b, int w, const F64Args& a, F64mDwtAcc<HT>& R) {
     const F64Net& n = a.net[ni];
     const int n_out = n.sizes[lyr + 1], n_in = n.sizes[lyr], C = a.C;
     const int lo = b * F64_BLOCK, hi = (lo + F64_BLOCK < a.npts) ? lo + F64_BLOCK : a.npts;
     const size_t np_ = (size_t)a.npad;
     const double* S = a.scratch;
-    LVd<HT * 4> acc;
-    PINN_LANES(l) { PINN_UNROLL for (int e = 0; e < HT * 4; ++e) acc(l, e) = 0.0; }
-    // steps = (16 points, channel); the operands of step i + 1 are requested before the MFMAs of step i (two register sets in rotation)
-    LVd<4> Af[2];
-    LVd<HT * 4> Bf[2];
-    auto load_step = [&](LVd<4>& A_, LVd<HT * 4>& B_, int p, int c) {
+    PINN_LANES(l) {
+        PINN_UNROLL for (int e = 0; e < HT * HT * 4; ++e) R.acc(l, e) = 0.0;
+        PINN_UNROLL for (int t = 0; t < HT; ++t) R.bsum(l, t) = 0.0;
+    }
+    LVd<HT * 4> Af[2], Bf[2];
+    // UNCONDITIONAL 32-byte loads (rows clamped to a valid one, the four points always inside the scratch row: npad is a multiple of the block
+    // size), masked by selects afterwards: a predicate per element turns every load into its own exec-masked 8-byte access
+    auto load_step = [&](LVd<HT * 4>& A_, LVd<HT * 4>& B_, int p, int c) {
         PINN_LANES(l) {
-            const int pp = p + 4 * (l >> 4), m = 16 * t_out + (l & 15);
-            const double* rz = S + ((size_t)n.r_dz[lyr] + (size_t)(m < n_out ? m : 0) * C + c) * np_;
-            PINN_UNROLL for (int s4 = 0; s4 < 4; ++s4) A_(l, s4) = (m < n_out && pp + s4 < hi) ? rz[pp + s4] : 0.0;
+            const int pp = p + 4 * (l >> 4);
             PINN_UNROLL for (int t = 0; t < HT; ++t) {
-                const int k = 16 * t + (l & 15);
-                const double* ri = S + ((size_t)n.r_post[lyr - 1] + (size_t)(k < n_in ? k : 0) * C + c) * np_;
-                PINN_UNROLL for (int s4 = 0; s4 < 4; ++s4) B_(l, 4 * t + s4) = (k < n_in && pp + s4 < hi) ? ri[pp + s4] : 0.0;
+                const int m = 16 * t + (l & 15);
+                const double* rz = S + ((size_t)n.r_dz[lyr] + (size_t)(m < n_out ? m : 0) * C + c) * np_ + pp;
+                const double* ri = S + ((size_t)n.r_post[lyr - 1] + (size_t)(m < n_in ? m : 0) * C + c) * np_ + pp;
+                double za[4], ia[4];
+                ld4_f64(rz, za);
+                ld4_f64(ri, ia);
+                PINN_UNROLL for (int s4 = 0; s4 < 4; ++s4) {
+                    A_(l, 4 * t + s4) = (m < n_out && pp + s4 < hi) ? za[s4] : 0.0;
+                    B_(l, 4 * t + s4) = (m < n_in && pp + s4 < hi) ? ia[s4] : 0.0;
+                }
             }
         }
     };
-    auto mma_step = [&](const LVd<4>& A_, const LVd<HT * 4>& B_) {
+    auto mma_step = [&](const LVd<HT * 4>& A_, const LVd<HT * 4>& B_, int c) {
         PINN_UNROLL for (int s4 = 0; s4 < 4; ++s4)
-            PINN_UNROLL for (int t = 0; t < HT; ++t) {
-                if (16 * t >= n_in) break;
-                mfma_f64(acc, 4 * t, 1, A_, s4, B_, 4 * t + s4);
+            PINN_UNROLL for (int to = 0; to < HT; ++to) {
+                if (16 * to >= n_out) break;
+                PINN_UNROLL for (int t = 0; t < HT; ++t) {
+                    if (16 * t >= n_in) break;
+                    mfma_f64(R.acc, (to * HT + t) * 4, 1, A_, 4 * to + s4, B_, 4 * t + s4);
+                }
             }
+        if (c == 0) {                                           // bias gradient = sum over the points of the value channel's dZ
+            PINN_LANES(l) {
+                PINN_UNROLL for (int to = 0; to < HT; ++to)
+                    R.bsum(l, to) += (A_(l, 4 * to) + A_(l, 4 * to + 1)) + (A_(l, 4 * to + 2) + A_(l, 4 * to + 3));
+            }
+        }
     };
-    const int nsteps = ((hi - lo + 15) / 16) * C;
-    if (nsteps > 0) load_step(Af[0], Bf[0], lo, 0);
-    for (int i = 0; i < nsteps; i += 2) {
-        if (i + 1 < nsteps) load_step(Af[1], Bf[1], lo + 16 * ((i + 1) / C), (i + 1) % C);
-        mma_step(Af[0], Bf[0]);
-        if (i + 2 < nsteps) load_step(Af[0], Bf[0], lo + 16 * ((i + 2) / C), (i + 2) % C);
-        if (i + 1 < nsteps) mma_step(Af[1], Bf[1]);
+    const int nsteps = ((hi - lo + 15) / 16) * C;                // step i: points lo + 16 (i / C) .., channel i % C; this wave: i = w, w + 4, ...
+    int i = w;
+    if (i < nsteps) load_step(Af[0], Bf[0], lo + 16 * (i / C), i % C);
+    for (; i < nsteps; i += 2 * F64M_DWT_WAVES) {
+        const int i1 = i + F64M_DWT_WAVES, i2 = i + 2 * F64M_DWT_WAVES;
+        if (i1 < nsteps) load_step(Af[1], Bf[1], lo + 16 * (i1 / C), i1 % C);
+        mma_step(Af[0], Bf[0], i % C);
+        if (i2 < nsteps) load_step(Af[0], Bf[0], lo + 16 * (i2 / C), i2 % C);
+        if (i1 < nsteps) mma_step(Af[1], Bf[1], i1 % C);
     }
+}
+// wave w's turn of the fixed-order combine through `lds` ([HT * HT * 4 + HT][64] doubles): wave 0 stores, waves 1, 2 add, wave 3 adds and writes the slab
+template <int HT>
+DEV void f64m_dwt_combine(int ni, int lyr, int b, int w, const F64Args& a, F64mDwtAcc<HT>& R, double* lds) {
+    const F64Net& n = a.net[ni];
+    const int n_out = n.sizes[lyr + 1], n_in = n.sizes[lyr];
+    constexpr int NE = HT * HT * 4;
     PINN_LANES(l) {
-        PINN_UNROLL for (int t = 0; t < HT; ++t)
-            PINN_UNROLL for (int r = 0; r < 4; ++r) {
-                const int m = 16 * t_out + (l >> 4) + 4 * r, k = 16 * t + (l & 15);
-                if (m < n_out && k < n_in) a.slab[(size_t)b * a.nent + n.ent0 + (n.woff[lyr] - n.theta0) + m + (size_t)k * n_out] = acc(l, 4 * t + r);
+        PINN_UNROLL for (int e = 0; e < NE; ++e) {
+            const double v = (w == 0) ? R.acc(l, e) : lds[e * 64 + l] + R.acc(l, e);
+            if (w < F64M_DWT_WAVES - 1) lds[e * 64 + l] = v;
+            else {
+                const int to = e / (HT * 4), t = (e / 4) % HT, r = e % 4;
+                const int m = 16 * to + (l >> 4) + 4 * r, k = 16 * t + (l & 15);
+                if (m < n_out && k < n_in) a.slab[(size_t)b * a.nent + n.ent0 + (n.woff[lyr] - n.theta0) + m + (size_t)k * n_out] = v;
             }
+        }
+        PINN_UNROLL for (int to = 0; to < HT; ++to) {
+            const double v = (w == 0) ? R.bsum(l, to) : lds[(NE + to) * 64 + l] + R.bsum(l, to);
+            if (w < F64M_DWT_WAVES - 1) lds[(NE + to) * 64 + l] = v;
+            else R.bsum(l, to) = v;
+        }
     }
+    if (w == F64M_DWT_WAVES - 1) {                               // the four lane groups hold the row's points 4 q .. 4 q + 3 of every step: sum them
+        PINN_UNROLL for (int to = 0; to < HT; ++to) lv_qsum(R.bsum, to);
+        PINN_LANES(l) {
+            PINN_UNROLL for (int to = 0; to < HT; ++to) {
+                const int m = 16 * to + (l & 15);
+                if ((l >> 4) == 0 && m < n_out) a.slab[(size_t)b * a.nent + n.ent0 + (n.boff[lyr] - n.theta0) + m] = R.bsum(l, to);
+            }
+        }
+    }
+}
+HD bool f64m_dwt_locate(int idx, const F64Args& a, int& ni, int& lyr) {
+    for (int i = 0; i < a.nnets; ++i)
+        for (int l = 1; l < a.net[i].nl - 1; ++l) {
+            if (idx == 0) { ni = i; lyr = l; return true; }
+            --idx;
+        }
+    return false;
 }
 
 // ---- kernel B': the remaining slab entries (biases, first / last layer, PDE parameters, the block's sum of squares: family 4's f64_dw_entry)
@@ -426,7 +481,7 @@ HD bool f64m_dw_decode(int e, const F64Args& a, int& ni, int& lyr, bool& bias, i
     while (lyr + 1 < n.nl && t >= n.woff[lyr + 1]) ++lyr;
     const int n_out = n.sizes[lyr + 1];
     bias = t >= n.boff[lyr];
-    if (!bias && lyr >= 1 && lyr < L) return false;            // hidden-to-hidden weights: k_f64m_dwt
+    if (lyr >= 1 && lyr < L) return false;                     // hidden-to-hidden weights and the biases of their layers: k_f64m_dwt
     m = bias ? t - n.boff[lyr] : (t - n.woff[lyr]) % n_out;
     k = bias ? 0 : (t - n.woff[lyr]) / n_out;
     return true;
@@ -449,8 +504,18 @@ template <class J, int HT, int PG> void launch_f64m_tile(const F64Args& a, plat_
 }
 template <int HT> void launch_f64m_dwt(const F64Args& a, plat_stream) {
     if (a.mode != 0) return;
-    const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK, nr = f64m_num_rows(a);
-    for (int b = 0; b < nb; ++b) for (int r = 0; r < nr; ++r) f64m_dwt<HT>(r, b, a);
+    const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK, nl = f64m_num_layers(a);
+    std::vector<double> lds((size_t)(HT * HT * 4 + HT) * 64);
+    for (int b = 0; b < nb; ++b)
+        for (int li = 0; li < nl; ++li) {
+            int ni = 0, lyr = 1;
+            if (!f64m_dwt_locate(li, a, ni, lyr)) continue;
+            for (int w = 0; w < F64M_DWT_WAVES; ++w) {          // (the combine is sequential in wave order: running the waves one after another IS the device's result)
+                F64mDwtAcc<HT> R;
+                f64m_dwt_wave<HT>(ni, lyr, b, w, a, R);
+                f64m_dwt_combine<HT>(ni, lyr, b, w, a, R, lds.data());
+            }
+        }
 }
 inline void launch_f64m_dw(const F64Args& a, const int* small_ent, int nsmall, plat_stream) {
     const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK;
@@ -474,16 +539,25 @@ template <class J, int HT, int PG> __global__ void __launch_bounds__(64, (HT * P
     f64m_tile<J, HT, PG, ACT_TANH>((int)blockIdx.x, a);
 }
 template <int HT> __global__ void __launch_bounds__(64 * F64M_DWT_WAVES) k_f64m_dwt(const F64Args a) {
-    f64m_dwt<HT>((int)(blockIdx.x * F64M_DWT_WAVES + (threadIdx.x >> 6)), (int)blockIdx.y, a);
+    __shared__ double lds[(HT * HT * 4 + HT) * 64];
+    int ni = 0, lyr = 1;
+    if (!f64m_dwt_locate((int)blockIdx.x, a, ni, lyr)) return;
+    const int w = (int)(threadIdx.x >> 6), b = (int)blockIdx.y;
+    F64mDwtAcc<HT> R;
+    f64m_dwt_wave<HT>(ni, lyr, b, w, a, R);
+    for (int turn = 0; turn < F64M_DWT_WAVES; ++turn) {
+        if (w == turn) f64m_dwt_combine<HT>(ni, lyr, b, w, a, R, lds);
+        __syncthreads();
+    }
 }
 template <class J, int HT, int PG> void launch_f64m_tile(const F64Args& a, plat_stream st) {
     const int nt = (a.npts + 16 * PG - 1) / (16 * PG);
     hipLaunchKernelGGL((k_f64m_tile<J, HT, PG>), dim3(nt), dim3(64), 0, st, a);
 }
 template <int HT> void launch_f64m_dwt(const F64Args& a, plat_stream st) {
-    const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK, nr = f64m_num_rows(a);
-    if (a.mode != 0 || nr == 0) return;
-    hipLaunchKernelGGL((k_f64m_dwt<HT>), dim3((nr + F64M_DWT_WAVES - 1) / F64M_DWT_WAVES, nb), dim3(64 * F64M_DWT_WAVES), 0, st, a);
+    const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK, nl = f64m_num_layers(a);
+    if (a.mode != 0 || nl == 0) return;
+    hipLaunchKernelGGL((k_f64m_dwt<HT>), dim3(nl, nb), dim3(64 * F64M_DWT_WAVES), 0, st, a);
 }
 constexpr int F64M_DW_SPLIT = 8;          // workgroups (of 4 waves) per block of points: wave v of 32 takes the entries v, v + 32, ... of the list
 template <int UNUSED> __global__ void __launch_bounds__(256) k_f64m_dw(const F64Args a, const int* small_ent, int nsmall) {

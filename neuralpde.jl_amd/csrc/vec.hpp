@@ -61,7 +61,7 @@ VFN1(vtanh, std::tanh(x)) VFN1(vsin, std::sin(x)) VFN1(vcos, std::cos(x)) VFN1(v
 VFN1(vlog, std::log(x)) VFN1(vsqrt, std::sqrt(x)) VFN1(vabs, std::fabs(x)) VFN1(vsinh, std::sinh(x))
 VFN1(vcosh, std::cosh(x)) VFN1(vtan, std::tan(x)) VFN1(vrcp, 1.0f / x)
 #ifndef PINN_ACT_TANH
-#define PINN_ACT_TANH 3
+#define PINN_ACT_TANH 4
 #endif
 #ifndef PINN_EMU_LIBM_ACT
 // the DEVICE's arithmetic restated (v_exp_f32 / v_rcp_f32 are 1-ulp instructions; exp2f and the division here are at most as far off), so the
@@ -332,14 +332,17 @@ DEV void vsincos(vfloat x, vfloat& s, vfloat& c) {
 #ifndef PINN_ACT_EXP2
 #define PINN_ACT_EXP2 1
 #endif
-// tanh.  PINN_ACT_TANH = 0: 1 - 2 / (e^{2x} + 1) — five instructions, but the sum e^{2x} + 1 and the reciprocal are rounded at magnitude ~1 and the
-// final subtraction turns those into ABSOLUTE errors of up to 2.4e-7 around x = 0 (libm: half an ulp of the result).  1 / 2 (r05, the default 2):
-// the odd form sign(x) (1 - e) / (1 + e), e = e^{-2|x|} in (0, 1]: 1 - e is exact for e >= 1/2 (Sterbenz) and every later rounding is RELATIVE
-// to the result, so what remains around 0 is the v_exp_f32 error alone (<= 1 ulp of e, halved by d tanh / d e); 2 adds one Newton step on the
-// 1-ulp v_rcp_f32 (two fmas) so that saturating units are within an ulp as well.  Measured against double tanh on the device:
-// tools/micro/tanh_probe.hip, profiles/r05_tanh_probe.txt; effect on the trained-parameter parity: profiles/r05_theta_variants_ab.txt.
+// tanh.  PINN_ACT_TANH = 0 (r01-r04): 1 - 2 / (e^{2x} + 1) with e^{2x} = exp2(x * float32(2 log2 e)) — five instructions, and two flaws that only a
+// TRAINED network shows (profiles/r05_theta_variants_ab.txt): (a) float32(2 log2 e) is 1.33e-8 (relative) too small, which scales EVERY
+// pre-activation of the network coherently — at a trained theta that is amplified like a perturbation of all weights in one direction (the
+// engine's gradient error was 2.4-2.8 x a plain float32 evaluation's); (b) the sum e^{2x} + 1 and the reciprocal are rounded at magnitude ~1
+// and the final subtraction turns that into ABSOLUTE errors of up to 2.2e-7 around x = 0.  1: the odd form sign(x) (1 - e) / (1 + e),
+// e = e^{-2|x|} in (0, 1]: 1 - e is exact for e >= 1/2 and every later rounding is relative to the result.  2: 1 + one Newton step on the
+// 1-ulp v_rcp_f32.  3: 2 + a TWO-CONSTANT exponent fma(|x|, -c_hi, |x| * -c_lo), c_hi + c_lo = 2 log2 e to 48 bits.  4 (the product): 3
+// without the Newton step — the reciprocal's rounding is incoherent and measured irrelevant (0.3-1.2 x torch-f32 with or without), eight
+// instructions.  Accuracy against double tanh on the device: tools/micro/tanh_probe.hip, profiles/r05_tanh_probe.txt.
 #ifndef PINN_ACT_TANH
-#define PINN_ACT_TANH 3
+#define PINN_ACT_TANH 4
 #endif
 DEV vfloat vtanh_fast(vfloat x) {
 #if PINN_ACT_TANH == 0

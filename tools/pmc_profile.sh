@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes for the bench workload (each counter set in its own run, --kernel-trace only; see MI355X_MICROARCH.md
 # "rocprofv3 PMC slots"): HBM read bytes, HBM write bytes, MFMA busy / issue counters, wave-state counters.
-# Usage (on the GPU box): tools/pmc_profile.sh <outdir> [pass ...]      (no pass names: the standard set; "icache", "issue": diagnostics)
+# Usage (on the GPU box): [PMC_BENCH_ARGS="--precision f64"] tools/pmc_profile.sh <outdir> [pass ...]      (no pass names: the standard set; "icache", "issue": diagnostics)
 set -e
 OUT=${1:-gpurun_out/pmc}
 shift || true
@@ -10,7 +10,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$(pwd)
 cd /tmp
-run() { name=$1; shift; if [ "$ONLY" != "  " ] && [[ "$ONLY" != *" $name "* ]]; then return 0; fi; rocprofv3 --kernel-trace --pmc "$@" -d $REPO/$OUT/$name -o p -- python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $REPO/$OUT/$name.json 2> $REPO/$OUT/$name.err || echo "pass $name failed"; }
+run() { name=$1; shift; if [ "$ONLY" != "  " ] && [[ "$ONLY" != *" $name "* ]]; then return 0; fi; rocprofv3 --kernel-trace --pmc "$@" -d $REPO/$OUT/$name -o p -- python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline $PMC_BENCH_ARGS > $REPO/$OUT/$name.json 2> $REPO/$OUT/$name.err || echo "pass $name failed"; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
