@@ -293,7 +293,7 @@ int f64_eval(pinn_engine& E, const double* theta, const double* term_w, double* 
             S.slab_cap = S.d_slab ? sneed : 0;
             if (!S.d_slab) return fail("device allocation failed (float64 slabs)");
         }
-        a.scratch = S.d_scratch; a.npad = (int)chunk; a.slab = S.d_slab;
+        a.scratch = S.d_scratch; a.npad = (int)chunk; a.slab = S.d_slab; a.nrows = rows;
         if (mfma && !F.d_small) {                        // (the entry layout depends on the networks only: built once per term)
             std::vector<int> small;
             pk::F64Args a0 = a;

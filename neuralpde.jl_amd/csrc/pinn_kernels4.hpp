@@ -55,8 +55,9 @@ struct F64Args {
     int slot_net[F64_MAX_SLOTS];        // slot s reads network slot_net[s] (index into `net`) ...
     int slot_chan[F64_MAX_SLOTS];       // ... jet channel slot_chan[s]
     double scale;                       // 2 w_k / N_norm: the reverse sweep's seed factor
-    double* scratch;                    // rows [nrows][npad]
+    double* scratch;                    // rows [nrows][npad] (family 4); the matrix-pipe kernels (pinn_kernels5.hpp) lay the same rows out point-block-major
     int npad;
+    int nrows;                          // total scratch rows of the term (pinn_kernels5.hpp: f64m_six)
     int r_pbar, r_sq;                   // PDE-parameter partials [ne], squared weighted residual [1]
     int mode;                           // 0: loss + gradient, 1: loss only, 2: residual values into `resid`
     double* resid;

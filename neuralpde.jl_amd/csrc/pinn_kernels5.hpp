@@ -19,6 +19,9 @@
 // pair; everything else keeps family 4.  PINN_F64_NO_MFMA=1 keeps family 4 everywhere (A/B, tests).
 #pragma once
 #include "pinn_kernels4.hpp"
+#ifndef PINN_F64M_PROBE
+#define PINN_F64M_PROBE 0               // timing probes (tools only, wrong numbers): 1 no rolling reload of the weight fragments, 2 no scratch stores, 4 no activation function
+#endif
 
 namespace pk {
 
@@ -72,6 +75,11 @@ template <int N> DEV void lv_qsum(LVd<N>& X, int i) {
 }
 #endif
 
+// scratch element (row, point) of the matrix-pipe kernels: POINT-BLOCK-MAJOR [point / 16][row][point % 16] — a wave's tile (16 points x every
+// row) is one contiguous region (rows x 128 bytes), so its ~1,500 stores per layer land in a few DRAM pages instead of one 128-byte line in
+// each of 1,500 rows that lie npad x 8 bytes apart (family 4's row-major layout: 1.6 of 4.1 ms of the bench workload's float64 evaluation were
+// the tile kernels' stores, profiles/r05_f64_kernel_stats.txt), and the dW kernel's 16-point operand lines of one channel are neighbours
+HD size_t f64m_six(const F64Args& a, size_t row, int p) { return (((size_t)(p >> 4) * (size_t)a.nrows + row) << 4) + (size_t)(p & 15); }
 // four consecutive doubles at a 32-byte aligned address (device: two global_load_dwordx4)
 #ifdef PINN_EMU
 inline void ld4_f64(const double* p, double (&o)[4]) { for (int i = 0; i < 4; ++i) o[i] = p[i]; }
@@ -89,7 +97,6 @@ DEV void f64m_tile(int tile, const F64Args& a) {
     constexpr int C = J::C, NCG = PG * C, NR = HT * 4;
     constexpr bool SIN = (ACTK == ACT_SIN);
     const int pbase = tile * (16 * PG);
-    const size_t np_ = (size_t)a.npad;
     double* S = a.scratch;
     LVd<NR * NCG> X, Z;                                          // X: operand of the next GEMM (a jets / dZ); Z: its result (z jets / G)
     LVd<F64_MAX_NETS * NCG> U;                                   // every network's output jets (forward), then their seeds (reverse)
@@ -128,7 +135,7 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                 PINN_LANES(l) {
                     PINN_UNROLL for (int kb = 0; kb < NR; ++kb) {
                         const int m = (l & 15), k = 4 * kb + (l >> 4);
-                        { const double wv = W[(m < n_out ? m : 0) + (size_t)(k < n_in ? k : 0) * n_out]; Af(l, kb) = (m < n_out && k < n_in) ? wv : 0.0; }      // (unconditional load, masked afterwards)
+                        Af(l, kb) = (m < n_out && k < n_in) ? W[m + (size_t)k * n_out] : 0.0;
                     }
                 }
                 PINN_UNROLL for (int t = 0; t < HT; ++t) {
@@ -136,10 +143,10 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                     PINN_UNROLL for (int kb = 0; kb < NR; ++kb) {
                         if (4 * kb >= n_in) break;
                         PINN_UNROLL for (int g = 0; g < NCG; ++g) mfma_f64(Z, (4 * t) * NCG + g, NCG, Af, kb, X, kb * NCG + g);
-                        if (t + 1 < HT) {
+                        if (t + 1 < HT && !(PINN_F64M_PROBE & 1)) {
                             PINN_LANES(l) {
                                 const int m = 16 * (t + 1) + (l & 15), k = 4 * kb + (l >> 4);
-                                { const double wv = W[(m < n_out ? m : 0) + (size_t)(k < n_in ? k : 0) * n_out]; Af(l, kb) = (m < n_out && k < n_in) ? wv : 0.0; }      // (unconditional load, masked afterwards)
+                                Af(l, kb) = (m < n_out && k < n_in) ? W[m + (size_t)k * n_out] : 0.0;
                             }
                         }
                     }
@@ -161,17 +168,17 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                     const bool valid = m < n_out;
                     PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
                         const int p = pbase + 16 * pg + j;
-                        const bool st = valid && p < a.npts && a.mode == 0;
+                        const bool st = valid && p < a.npts && a.mode == 0 && !(PINN_F64M_PROBE & 2);
                         double z[C];
                         PINN_UNROLL for (int c = 0; c < C; ++c) z[c] = Z(l, tr * NCG + pg * C + c);
-                        const double a0 = act_value<SIN>(n.act, z[0]);
+                        const double a0 = (PINN_F64M_PROBE & 4) ? z[0] * 0.5 : act_value<SIN>(n.act, z[0]);
                         z[0] = act_record<SIN>(z[0], a0);
-                        if (st) { PINN_UNROLL for (int c = 0; c < C; ++c) S[((size_t)n.r_rec[lyr] + (size_t)m * C + c) * np_ + p] = z[c]; }
+                        if (st) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)m * C + c, p)] = z[c]; }
                         double dd[ND];
                         act_derivs_n<J::NORD - 1, SIN>(n.act, z[0], dd);
                         jet_forward<J>(z, dd);
                         z[0] = a0;
-                        if (st) { PINN_UNROLL for (int c = 0; c < C; ++c) S[((size_t)n.r_post[lyr] + (size_t)m * C + c) * np_ + p] = z[c]; }
+                        if (st) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_post[lyr] + (size_t)m * C + c, p)] = z[c]; }
                         PINN_UNROLL for (int c = 0; c < C; ++c) X(l, tr * NCG + pg * C + c) = valid ? z[c] : 0.0;
                     }
                 }
@@ -224,7 +231,7 @@ DEV void f64m_tile(int tile, const F64Args& a) {
             if (a.mode == 2) { if (wr) a.resid[gp] = r; continue; }
             const double sw = a.pw ? (double)a.pw[gp] : 1.0;
             const double rs = r * sw;
-            if (wr) S[(size_t)a.r_sq * np_ + p] = rs * rs;
+            if (wr) S[f64m_six(a, (size_t)a.r_sq, p)] = rs * rs;
             if (a.mode == 1) continue;
             double g[F64_MAX_ROWS];
             for (int o = 0; o < R0 + a.nops; ++o) g[o] = 0.0;
@@ -239,7 +246,7 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                 if (rp::is_binary(ins.code)) g[ins.b] += db;
             }
             const double rbar = live ? rs * a.scale * sw : 0.0;
-            if (wr) for (int k = 0; k < a.ne; ++k) S[((size_t)a.r_pbar + k) * np_ + p] = rbar * g[a.dt + k];
+            if (wr) for (int k = 0; k < a.ne; ++k) S[f64m_six(a, (size_t)a.r_pbar + k, p)] = rbar * g[a.dt + k];
             // the seeds of every network's output jets replace its outputs in U
             for (int ni = 0; ni < a.nnets; ++ni) {
                 double ub[C];
@@ -251,7 +258,7 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                 }
                 PINN_UNROLL for (int c = 0; c < C; ++c) {
                     U(l, ni * NCG + pg * C + c) = ub[c];
-                    if (wr) S[((size_t)a.net[ni].r_ubar + c) * np_ + p] = ub[c];
+                    if (wr) S[f64m_six(a, (size_t)a.net[ni].r_ubar + c, p)] = ub[c];
                 }
             }
         }
@@ -280,7 +287,7 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                 PINN_LANES(l) {
                     PINN_UNROLL for (int kb = 0; kb < NR; ++kb) {
                         const int k = (l & 15), m = 4 * kb + (l >> 4);
-                        { const double wv = Wn[(m < n_next ? m : 0) + (size_t)(k < H ? k : 0) * n_next]; Af(l, kb) = (k < H && m < n_next) ? wv : 0.0; }
+                        Af(l, kb) = (k < H && m < n_next) ? Wn[m + (size_t)k * n_next] : 0.0;
                     }
                 }
                 PINN_UNROLL for (int t = 0; t < HT; ++t) {
@@ -288,10 +295,10 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                     PINN_UNROLL for (int kb = 0; kb < NR; ++kb) {
                         if (4 * kb >= n_next) break;
                         PINN_UNROLL for (int g = 0; g < NCG; ++g) mfma_f64(Z, (4 * t) * NCG + g, NCG, Af, kb, X, kb * NCG + g);
-                        if (t + 1 < HT) {
+                        if (t + 1 < HT && !(PINN_F64M_PROBE & 1)) {
                             PINN_LANES(l) {
                                 const int k = 16 * (t + 1) + (l & 15), m = 4 * kb + (l >> 4);
-                                { const double wv = Wn[(m < n_next ? m : 0) + (size_t)(k < H ? k : 0) * n_next]; Af(l, kb) = (k < H && m < n_next) ? wv : 0.0; }
+                                Af(l, kb) = (k < H && m < n_next) ? Wn[m + (size_t)k * n_next] : 0.0;
                             }
                         }
                     }
@@ -305,7 +312,7 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                     const int k = 16 * (tr >> 2) + 4 * (tr & 3) + q, kc = k < H ? k : H - 1;
                     PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
                         const int p = pbase + 16 * pg + j, pc = p < a.npts ? p : a.npts - 1;
-                        PINN_UNROLL for (int c = 0; c < C; ++c) X(l, tr * NCG + pg * C + c) = S[((size_t)n.r_rec[lyr] + (size_t)kc * C + c) * np_ + pc];
+                        PINN_UNROLL for (int c = 0; c < C; ++c) X(l, tr * NCG + pg * C + c) = S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)kc * C + c, pc)];
                     }
                 }
             }
@@ -317,12 +324,13 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                     PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
                         const int p = pbase + 16 * pg + j;
                         const bool st = valid && p < a.npts;
+                        const bool st2 = st && !(PINN_F64M_PROBE & 2);
                         double s[C], gq[C], dd[ND];
                         PINN_UNROLL for (int c = 0; c < C; ++c) s[c] = X(l, tr * NCG + pg * C + c);
                         PINN_UNROLL for (int c = 0; c < C; ++c) gq[c] = Z(l, tr * NCG + pg * C + c);
                         act_derivs_n<J::NORD, SIN>(n.act, s[0], dd);
                         jet_adjoint<J>(gq, s, dd);
-                        if (st) { PINN_UNROLL for (int c = 0; c < C; ++c) S[((size_t)n.r_dz[lyr] + (size_t)k * C + c) * np_ + p] = gq[c]; }
+                        if (st2) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_dz[lyr] + (size_t)k * C + c, p)] = gq[c]; }
                         PINN_UNROLL for (int c = 0; c < C; ++c) X(l, tr * NCG + pg * C + c) = st ? gq[c] : 0.0;
                     }
                 }
@@ -350,7 +358,6 @@ DEV void f64m_dwt_wave(int ni, int lyr, int b, int w, const F64Args& a, F64mDwtA
     const F64Net& n = a.net[ni];
     const int n_out = n.sizes[lyr + 1], n_in = n.sizes[lyr], C = a.C;
     const int lo = b * F64_BLOCK, hi = (lo + F64_BLOCK < a.npts) ? lo + F64_BLOCK : a.npts;
-    const size_t np_ = (size_t)a.npad;
     const double* S = a.scratch;
     PINN_LANES(l) {
         PINN_UNROLL for (int e = 0; e < HT * HT * 4; ++e) R.acc(l, e) = 0.0;
@@ -364,8 +371,8 @@ DEV void f64m_dwt_wave(int ni, int lyr, int b, int w, const F64Args& a, F64mDwtA
             const int pp = p + 4 * (l >> 4);
             PINN_UNROLL for (int t = 0; t < HT; ++t) {
                 const int m = 16 * t + (l & 15);
-                const double* rz = S + ((size_t)n.r_dz[lyr] + (size_t)(m < n_out ? m : 0) * C + c) * np_ + pp;
-                const double* ri = S + ((size_t)n.r_post[lyr - 1] + (size_t)(m < n_in ? m : 0) * C + c) * np_ + pp;
+                const double* rz = S + f64m_six(a, (size_t)n.r_dz[lyr] + (size_t)(m < n_out ? m : 0) * C + c, pp);
+                const double* ri = S + f64m_six(a, (size_t)n.r_post[lyr - 1] + (size_t)(m < n_in ? m : 0) * C + c, pp);
                 double za[4], ia[4];
                 ld4_f64(rz, za);
                 ld4_f64(ri, ia);
@@ -448,24 +455,23 @@ HD bool f64m_dwt_locate(int idx, const F64Args& a, int& ni, int& lyr) {
 // with the block's points ACROSS THE LANES (coalesced row reads), one wave per entry of the term's small-entry list, lane partials summed in a
 // fixed butterfly order.  (Family 4's k_f64_dw runs one THREAD per entry over the block's 512 points: neighbouring threads read different rows.) ----
 DEV double f64m_dw_point(int e, int p, const F64Args& a, int ni, int lyr, bool bias, int m, int k) {
-    const size_t np_ = (size_t)a.npad;
     const double* S = a.scratch;
     const int C = a.C;
-    if (e == a.nent - 1) return S[(size_t)a.r_sq * np_ + p];
-    if (e >= a.ent_p) return S[((size_t)a.r_pbar + (e - a.ent_p)) * np_ + p];
+    if (e == a.nent - 1) return S[f64m_six(a, (size_t)a.r_sq, p)];
+    if (e >= a.ent_p) return S[f64m_six(a, (size_t)a.r_pbar + (e - a.ent_p), p)];
     const F64Net& n = a.net[ni];
     const int L = n.nl - 1;
     const size_t dz = (lyr == L) ? (size_t)n.r_ubar : (size_t)n.r_dz[lyr] + (size_t)m * C;
-    if (bias) return S[dz * np_ + p];
+    if (bias) return S[f64m_six(a, dz, p)];
     if (lyr == 0) {
         const int ck = a.first_ch[k];
-        double t2 = S[dz * np_ + p] * a.pts[(size_t)(a.p0 + p) * a.dt + n.imap[k]];
-        if (ck >= 0) t2 += S[(dz + ck) * np_ + p];
+        double t2 = S[f64m_six(a, dz, p)] * a.pts[(size_t)(a.p0 + p) * a.dt + n.imap[k]];
+        if (ck >= 0) t2 += S[f64m_six(a, dz + ck, p)];
         return t2;
     }
     const size_t in = (size_t)n.r_post[lyr - 1] + (size_t)k * C;
     double t2 = 0.0;
-    for (int c = 0; c < C; ++c) t2 = vfma(S[(dz + c) * np_ + p], S[(in + c) * np_ + p], t2);
+    for (int c = 0; c < C; ++c) t2 = vfma(S[f64m_six(a, dz + c, p)], S[f64m_six(a, in + c, p)], t2);
     return t2;
 }
 // decode of entry e (wave-uniform): network, layer, bias / weight indices; returns false for entries this kernel does not own
