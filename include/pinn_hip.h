@@ -207,6 +207,13 @@ int pinn_get_points(pinn_handle h, int term, float* pts, int64_t n);
 int pinn_adam_init(pinn_handle h, const float* theta, int64_t p);
 int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta2, float eps, const float* term_w, double* loss_history);
 int pinn_adam_get(pinn_handle h, float* theta, int64_t p);
+/* The same in double (r05).  On a handle in float64 mode (pinn_set_option(h, "precision", "f64")) the WHOLE loop runs in double on the
+ * device — parameters, moments, the redrawn point sets (the fp32 samplers' points widened on the device: StochasticTraining /
+ * QuasiRandomTraining(resampling = true) with the reference's default Float64 parameters, src/discretize.jl:432-449,
+ * src/training_strategies.jl:271-282, 365-389), residual + gradient kernels, Adam — and pinn_adam_init / pinn_adam_get convert at the
+ * boundary; in float32 mode these two narrow / widen at the boundary. */
+int pinn_adam_init_f64(pinn_handle h, const double* theta, int64_t p);
+int pinn_adam_get_f64(pinn_handle h, double* theta, int64_t p);
 /*
  * L-BFGS on the weighted objective sum_k w_k L_k over FIXED point sets (the quasi-Newton finisher of the reference's scripts,
  * `solve(prob, BFGS() / LBFGS(); maxiters)`, e.g. test/NNPDE1/nnpde__pde_ii_2d_poisson.jl:86 — there [3P] OptimizationOptimJL on the

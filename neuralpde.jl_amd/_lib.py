@@ -35,6 +35,7 @@ SYMBOLS = [
     "pinn_set_sampler", "pinn_set_point_data", "pinn_set_point_weights", "pinn_get_points", "pinn_adam_init", "pinn_adam_steps", "pinn_adam_get", "pinn_lbfgs",
     "pinn_loss_device", "pinn_group_launched_by",
     "pinn_set_option", "pinn_get_option", "pinn_set_points_f64", "pinn_comm_init_custom", "pinn_adam_steps_sharded", "pinn_adam_apply",
+    "pinn_adam_init_f64", "pinn_adam_get_f64",
 ]
 
 
@@ -94,6 +95,8 @@ class Library:
         L.pinn_adam_init.argtypes = [vp, fp, C.c_int64]
         L.pinn_adam_steps.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, fp, dp]
         L.pinn_adam_get.argtypes = [vp, fp, C.c_int64]
+        L.pinn_adam_init_f64.argtypes = [vp, dp, C.c_int64]
+        L.pinn_adam_get_f64.argtypes = [vp, dp, C.c_int64]
         L.pinn_lbfgs.argtypes = [vp, C.POINTER(C.c_double), C.c_int64, C.c_int, C.c_int, C.c_double, fp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         self.ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_int64, C.c_int, vp)
         L.pinn_comm_init_custom.argtypes = [vp, C.c_int, C.c_int, self.ALLREDUCE_FN, vp]
@@ -382,6 +385,21 @@ class Engine:
                                                 hist.ctypes.data_as(C.POINTER(C.c_double))), "pinn_adam_steps")
         out = np.zeros(self.P, dtype=np.float32)
         self.L.check(self.L.lib.pinn_adam_get(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), out.size), "pinn_adam_get")
+        return out, hist
+
+    def adam_f64(self, theta, nsteps: int, lr: float, weights=None, beta1=0.9, beta2=0.999, eps=1e-8, init=True):
+        """the same through the double entry points (pinn_adam_init_f64 / pinn_adam_get_f64): on a handle in float64 mode every kernel of the
+        loop — redraw, residual + gradient, Adam — runs in double on the device; returns (theta float64, loss history)"""
+        if init:
+            th = np.ascontiguousarray(np.asarray(theta, dtype=np.float64))
+            self.L.check(self.L.lib.pinn_adam_init_f64(self.h, th.ctypes.data_as(C.POINTER(C.c_double)), th.size), "pinn_adam_init_f64")
+        hist = np.zeros(nsteps, dtype=np.float64)
+        w = _f32(weights) if weights is not None else None
+        self.L.check(self.L.lib.pinn_adam_steps(self.h, nsteps, lr, beta1, beta2, eps,
+                                                w.ctypes.data_as(C.POINTER(C.c_float)) if w is not None else None,
+                                                hist.ctypes.data_as(C.POINTER(C.c_double))), "pinn_adam_steps")
+        out = np.zeros(self.P, dtype=np.float64)
+        self.L.check(self.L.lib.pinn_adam_get_f64(self.h, out.ctypes.data_as(C.POINTER(C.c_double)), out.size), "pinn_adam_get_f64")
         return out, hist
 
     def lbfgs(self, theta, maxiters: int, weights=None, history: int = 10, gtol: float = 1e-8):

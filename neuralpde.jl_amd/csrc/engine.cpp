@@ -661,6 +661,17 @@ int pinn_term_grads(pinn_handle h, const float* theta, int64_t p, double* term_l
     pinn_engine& E = *h;
     DeviceScope scope(E.device);
     const int K = (int)E.terms.size();
+    if (E.f64) {                                         // float64 mode: K evaluations with one-hot weights (the double kernels evaluate whole
+        if (p != E.ntheta) return fail("pinn_term_grads: theta length mismatch");      // problems; per-term statistics are not their hot path)
+        std::vector<double> th(theta, theta + p), w(K), L(K), g((size_t)p);
+        for (int k = 0; k < K; ++k) {
+            for (int j = 0; j < K; ++j) w[j] = (j == k) ? 1.0 : 0.0;
+            if (f64_eval(E, th.data(), w.data(), L.data(), g.data())) return 1;
+            for (int64_t i = 0; i < p; ++i) term_grads[(size_t)k * p + i] = (float)g[(size_t)i];
+            if (term_losses) term_losses[k] = L[k];
+        }
+        return 0;
+    }
     if (upload_theta(E, theta, p)) return 1;
     for (int k = 0; k < K; ++k) {
         if (run_loss_grad(E, E.d_theta, E.hp_out, nullptr, k, false, E.hp_raw)) return 1;
@@ -679,7 +690,8 @@ int pinn_loss_grad_device(pinn_handle h, const float* d_theta, const float* term
     plat_stream user = (plat_stream)stream;
     plat_stream saved = E.stream;
     E.stream = user;     // NULL is the (legacy) default stream — e.g. torch's current stream
-    int rc = run_loss_grad(E, d_theta, d_out, term_w, -1, true);
+    // float64 mode (r05): the double kernels between a device-side widening of theta and narrowing of [gradient | sums]
+    int rc = E.f64 ? f64_eval_from_device_f32(E, d_theta, term_w, d_out, true) : run_loss_grad(E, d_theta, d_out, term_w, -1, true);
     E.stream = saved;
     if (rc && g_err.empty()) return fail("pinn_loss_grad_device failed");
     E.timing_valid = (rc == 0) && E.timing_level >= 2;
@@ -692,7 +704,8 @@ int pinn_loss_device(pinn_handle h, const float* d_theta, float* d_sums, void* s
     DeviceScope scope(E.device);
     plat_stream saved = E.stream;
     E.stream = (plat_stream)stream;
-    int rc = run_loss_grad(E, d_theta, nullptr, nullptr, -1, false, nullptr, false, true, d_sums);      // loss-only: no gradient vector at all
+    int rc = E.f64 ? f64_eval_from_device_f32(E, d_theta, nullptr, d_sums, false)
+                   : run_loss_grad(E, d_theta, nullptr, nullptr, -1, false, nullptr, false, true, d_sums);      // loss-only: no gradient vector at all
     E.stream = saved;
     if (rc && g_err.empty()) return fail("pinn_loss_device failed");
     return rc;
@@ -887,8 +900,6 @@ int pinn_set_sampler(pinn_handle h, int term, int kind, const float* lb, const f
     if (kind < 0 || kind > 3) return fail("pinn_set_sampler: kind must be 0 (fixed set), 1 (uniform), 2 (Latin hypercube) or 3 (Sobol)");
     if (kind == 3 && T.d_user > 8) return fail("pinn_set_sampler: the Sobol sampler covers up to 8 axes");
     if (kind == 0) { T.sampler = 0; return 0; }
-    if (E.f64) return fail("pinn_set_sampler: the float64 evaluation mode has no device samplers (the float32 optimiser entry points would run beside a float64 evaluation); "
-                           "switch precision back to \"f32\" first or redraw on the host");
     if (!lb || !ub || n <= 0) return fail("pinn_set_sampler: bounds and a positive point count are required");
     if (!T.d_lb) { T.d_lb = (float*)plat_malloc(sizeof(float) * 8); T.d_ub = (float*)plat_malloc(sizeof(float) * 8); }
     if (!T.d_lb || !T.d_ub) return fail("device allocation failed (sampler)");
@@ -904,6 +915,7 @@ int pinn_set_sampler(pinn_handle h, int term, int kind, const float* lb, const f
     aux::launch_sample(kind, user_pts(T), (int)(n * T.d_user), T.d_user, T.d_lb, T.d_ub, T.seed, T.draws++, E.stream);
     embed_points(E, T);
     eval_sources(E, T);
+    if (E.f64 && f64_points_from_device(E, term)) return 1;       // float64 mode: the double copy follows every draw (r05)
     plat_sync(E.stream);
     return 0;
 }
@@ -1042,6 +1054,10 @@ int pinn_adam_init(pinn_handle h, const float* theta, int64_t p) {
     pinn_engine& E = *h;
     DeviceScope scope(E.device);
     if (p != E.ntheta) return fail("pinn_adam_init: theta length mismatch");
+    if (E.f64) {                                         // float64 mode: the optimiser state lives in double (f64.cpp)
+        std::vector<double> th(theta, theta + p);
+        return f64_adam_init(E, th.data());
+    }
     const int K = (int)E.terms.size();
     if (!E.d_opt_theta) {
         E.d_opt_theta = (float*)plat_malloc(sizeof(float) * p);
@@ -1126,6 +1142,11 @@ static int adam_steps_graph(pinn_engine& E, int nsteps, float lr, float beta1, f
 // seed of a term's device sampler on this rank: ranks of a communicator draw different points (their shards of one global draw)
 static unsigned sampler_seed(const pinn_engine& E, const Term& T) {
     return E.comm_size > 1 ? T.seed + 0x85EBCA6BU * (unsigned)(E.comm_rank + 1) : T.seed;
+}
+
+// one redraw of a sampled term's float point set (the float64 optimiser loop widens it afterwards: f64.cpp)
+static void redraw_term_f32(pinn_engine& E, Term& T) {
+    aux::launch_sample(T.sampler, user_pts(T), (int)(T.n * T.d_user), T.d_user, T.d_lb, T.d_ub, sampler_seed(E, T), T.draws++, E.stream);
 }
 
 // Device-side table of a handle's redrawn terms (aux::ResampleTerm), draw counters as they stand now.  Returns the number of terms in the
@@ -1485,10 +1506,37 @@ static int adam_prepare(pinn_engine& E, int nsteps, const float* term_w, const c
     return plat_sync(E.stream) ? fail(std::string("device error: ") + plat_last_error()) : 0;      // (wn is a pageable temporary)
 }
 
+int pinn_adam_init_f64(pinn_handle h, const double* theta, int64_t p) {
+    if (!h || !theta) return fail("pinn_adam_init_f64: null argument");
+    pinn_engine& E = *h;
+    DeviceScope scope(E.device);
+    if (p != E.ntheta) return fail("pinn_adam_init_f64: theta length mismatch");
+    if (E.f64) return f64_adam_init(E, theta);
+    std::vector<float> th(theta, theta + p);             // fp32 mode: narrowed at the boundary
+    return pinn_adam_init(h, th.data(), p);
+}
+int pinn_adam_get_f64(pinn_handle h, double* theta, int64_t p) {
+    if (!h || !theta) return fail("pinn_adam_get_f64: null argument");
+    pinn_engine& E = *h;
+    DeviceScope scope(E.device);
+    if (p != E.ntheta) return fail("pinn_adam_get_f64: theta length mismatch");
+    if (E.f64) return f64_adam_get(E, theta);
+    std::vector<float> th((size_t)p);
+    if (pinn_adam_get(h, th.data(), p)) return 1;
+    for (int64_t i = 0; i < p; ++i) theta[i] = (double)th[(size_t)i];
+    return 0;
+}
+
 int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta2, float eps, const float* term_w, double* loss_history) {
     if (!h) return fail("null handle");
     pinn_engine& E = *h;
     DeviceScope scope(E.device);
+    if (E.f64) {                                         // float64 mode: redraw -> evaluate -> Adam, all in double on the device (f64.cpp)
+        if (E.comm) return fail("pinn_adam_steps: the float64 mode has no communicator path");
+        if (nsteps <= 0) return fail("pinn_adam_steps: nsteps must be positive");
+        E.adam_path = 1;
+        return f64_adam_steps(E, nsteps, (double)lr, (double)beta1, (double)beta2, (double)eps, term_w, loss_history, &redraw_term_f32);
+    }
     if (E.comm && !E.comm_per_process && E.comm_size > 1)
         return fail("pinn_adam_steps: the handle belongs to a single-process communicator (pinn_comm_init_all): use pinn_adam_steps_sharded");
     if (adam_prepare(E, nsteps, term_w, "pinn_adam_steps")) return 1;
@@ -1700,6 +1748,13 @@ int pinn_adam_get(pinn_handle h, float* theta, int64_t p) {
     if (!h || !theta) return fail("pinn_adam_get: null argument");
     pinn_engine& E = *h;
     DeviceScope scope(E.device);
+    if (E.f64) {
+        if (p != E.ntheta) return fail("pinn_adam_get: length mismatch");
+        std::vector<double> th((size_t)p);
+        if (f64_adam_get(E, th.data())) return 1;
+        for (int64_t i = 0; i < p; ++i) theta[i] = (float)th[(size_t)i];
+        return 0;
+    }
     if (!E.d_opt_theta || p != E.ntheta) return fail("pinn_adam_get: no optimiser state / length mismatch");
     if (plat_d2h(theta, E.d_opt_theta, sizeof(float) * p, E.stream)) return fail("D2H copy failed");
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());

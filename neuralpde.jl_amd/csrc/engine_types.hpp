@@ -311,6 +311,12 @@ const char* f64_path(const pinn_engine& E);      // kernels of the last float64 
 int f64_points_changed(pinn_engine& E, int term);
 int f64_set_points(pinn_engine& E, int term, const double* pts, int64_t n);
 int f64_eval(pinn_engine& E, const double* theta, const double* term_w, double* term_losses, double* grad);
+int f64_adam_init(pinn_engine& E, const double* theta);
+int f64_adam_get(pinn_engine& E, double* theta);
+int f64_adam_steps(pinn_engine& E, int nsteps, double lr, double beta1, double beta2, double eps, const float* term_w, double* loss_history,
+                   void (*redraw)(pinn_engine&, pe::Term&));
+int f64_points_from_device(pinn_engine& E, int term);
+int f64_eval_from_device_f32(pinn_engine& E, const float* d_theta, const float* term_w, float* d_out, bool want_grad);
 // plan.cpp
 // GEMM arithmetic the kernel look-ups of the calling thread select (family 2 kernels exist as split-operand and fp32 twins): set for the
 // duration of an entry point that may look kernels up

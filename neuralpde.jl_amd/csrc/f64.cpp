@@ -47,6 +47,12 @@ struct F64State {
     double* d_slab = nullptr;
     size_t slab_cap = 0;
     std::vector<double> h_out;           // host staging [P + K]
+    double* d_m = nullptr;               // optimiser moments of the float64 Adam loop (f64_adam_*), allocated on first use
+    double* d_v = nullptr;
+    double* d_w_over_n = nullptr;        // [K] w_k / N_k of the running call
+    double* d_hist = nullptr;
+    int hist_cap = 0;
+    bool opt_ready = false;              // d_theta holds the optimiser's parameters
     int path = 0;                        // kernels of the last evaluation: bit 0 one lane per point (family 4), bit 1 matrix pipe (family 4m)
 };
 
@@ -54,6 +60,7 @@ static void f64_free(F64State* S) {
     if (!S) return;
     for (auto& T : S->terms) { plat_free(T.d_prog); plat_free(T.d_imm); plat_free(T.d_pts); plat_free(T.d_small); }
     plat_free(S->d_theta); plat_free(S->d_grad); plat_free(S->d_sumsq); plat_free(S->d_scratch); plat_free(S->d_slab);
+    plat_free(S->d_m); plat_free(S->d_v); plat_free(S->d_w_over_n); plat_free(S->d_hist);
     delete S;
 }
 void f64_destroy(pinn_engine& E) {
@@ -132,7 +139,6 @@ int f64_enable(pinn_engine& E) {
         if (any_sin && !all_sin) return fail(who + "mixes sin networks with tanh / sigmoid networks");
         if (!T.emb_cols.empty()) return fail(who + "periodic input embeddings are not covered by the float64 mode");
         if (T.d > 4 || E.nets[nets[0]].sizes[0] > 4) return fail(who + "more than 4 coordinates");
-        if (E.terms[t].sampler != 0) return fail(who + "device samplers are not covered by the float64 mode (install fixed point sets)");
         if ((int)T.slots.size() > pk::F64_MAX_SLOTS || T.d + E.np + (int)T.slots.size() + (int)T.ops.size() > pk::F64_MAX_ROWS)
             return fail(who + "residual expression too long for the float64 tape (96 rows)");
         for (auto& I : T.ops) if (I.code == rp::OP_DATA) return fail(who + "per-point DATA channels are not covered by the float64 mode");
@@ -203,13 +209,32 @@ int f64_set_points(pinn_engine& E, int term, const double* pts, int64_t n) {
     return 0;
 }
 
+static int f64_eval_device(pinn_engine& E, const double* term_w, bool want_grad);
+
 int f64_eval(pinn_engine& E, const double* theta, const double* term_w, double* term_losses, double* grad) {
     F64State& S = *(F64State*)E.f64;
     const int K = (int)E.terms.size();
     const int64_t P = E.ntheta;
+    if (plat_h2d(S.d_theta, theta, sizeof(double) * P, E.stream)) return fail("H2D copy of theta failed");
+    S.opt_ready = false;                                 // (d_theta no longer holds the optimiser's iterate)
+    if (f64_eval_device(E, term_w, grad != nullptr)) return 1;
+    if (plat_d2h(S.h_out.data(), S.d_grad, sizeof(double) * P, E.stream)) return fail("D2H copy failed");
+    if (plat_d2h(S.h_out.data() + P, S.d_sumsq, sizeof(double) * K, E.stream)) return fail("D2H copy failed");
+    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    if (term_losses)
+        for (int k = 0; k < K; ++k) term_losses[k] = S.h_out[(size_t)P + k] / (double)E.terms[k].n_norm;
+    if (grad) std::memcpy(grad, S.h_out.data(), sizeof(double) * P);
+    return 0;
+}
+
+// loss sums (S.d_sumsq) and gradient (S.d_grad) of the parameters in S.d_theta, everything on the device, nothing synchronised
+static int f64_eval_device(pinn_engine& E, const double* term_w, bool want_grad) {
+    F64State& S = *(F64State*)E.f64;
+    const int K = (int)E.terms.size();
+    const int64_t P = E.ntheta;
+    const double* grad = want_grad ? S.d_grad : nullptr;         // (non-null = evaluate the gradient)
     for (int t = 0; t < K; ++t)
         if (S.terms[t].n <= 0 || S.terms[t].n != E.terms[t].n) return fail("term " + std::to_string(t) + " has no collocation points (call pinn_set_points first)");
-    if (plat_h2d(S.d_theta, theta, sizeof(double) * P, E.stream)) return fail("H2D copy of theta failed");
     plat_memset(S.d_grad, 0, sizeof(double) * P, E.stream);
     plat_memset(S.d_sumsq, 0, sizeof(double) * K, E.stream);
     S.path = 0;
@@ -326,12 +351,98 @@ int f64_eval(pinn_engine& E, const double* theta, const double* term_w, double* 
             pk::launch_f64_reduce(r, E.stream);
         }
     }
-    if (plat_d2h(S.h_out.data(), S.d_grad, sizeof(double) * P, E.stream)) return fail("D2H copy failed");
-    if (plat_d2h(S.h_out.data() + P, S.d_sumsq, sizeof(double) * K, E.stream)) return fail("D2H copy failed");
+    return 0;
+}
+
+// ---- the resident optimiser loop in float64 (pinn_adam_* on a handle in float64 mode; r05): theta, moments, points and every kernel of the
+// iteration in double on the device — redraw (the fp32 samplers' points, converted on the device: the reference's StochasticTraining /
+// QuasiRandomTraining(resampling = true) with Float64 parameters, src/training_strategies.jl:271-282, 365-389) -> evaluate -> Adam ----
+int f64_adam_init(pinn_engine& E, const double* theta) {
+    F64State& S = *(F64State*)E.f64;
+    const int64_t P = E.ntheta;
+    const int K = (int)E.terms.size();
+    if (!S.d_m) {
+        S.d_m = (double*)plat_malloc(sizeof(double) * P);
+        S.d_v = (double*)plat_malloc(sizeof(double) * P);
+        S.d_w_over_n = (double*)plat_malloc(sizeof(double) * K);
+        if (!S.d_m || !S.d_v || !S.d_w_over_n) return fail("device allocation failed (float64 optimiser state)");
+    }
+    if (plat_h2d(S.d_theta, theta, sizeof(double) * P, E.stream)) return fail("H2D copy of theta failed");
+    plat_memset(S.d_m, 0, sizeof(double) * P, E.stream);
+    plat_memset(S.d_v, 0, sizeof(double) * P, E.stream);
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
-    if (term_losses)
-        for (int k = 0; k < K; ++k) term_losses[k] = S.h_out[(size_t)P + k] / (double)E.terms[k].n_norm;
-    if (grad) std::memcpy(grad, S.h_out.data(), sizeof(double) * P);
+    S.opt_ready = true;
+    E.opt_t = 0;
+    return 0;
+}
+int f64_adam_get(pinn_engine& E, double* theta) {
+    F64State& S = *(F64State*)E.f64;
+    if (!S.opt_ready) return fail("pinn_adam_get: no float64 optimiser state (pinn_adam_init after switching to precision f64; evaluations at other parameters reset it)");
+    if (plat_d2h(theta, S.d_theta, sizeof(double) * E.ntheta, E.stream) || plat_sync(E.stream)) return fail("D2H copy failed");
+    return 0;
+}
+// a sampled term's float points (just redrawn on the device) -> the double copy the float64 kernels read
+int f64_points_from_device(pinn_engine& E, int term) {
+    F64State& S = *(F64State*)E.f64;
+    F64Term& F = S.terms[term];
+    const Term& T = E.terms[term];
+    if (F.cap < T.n) {
+        plat_sync(E.stream);
+        plat_free(F.d_pts);
+        F.d_pts = (double*)plat_malloc(sizeof(double) * (size_t)T.n * T.d);
+        if (!F.d_pts) { F.cap = 0; return fail("device allocation failed (float64 points)"); }
+        F.cap = T.n;
+    }
+    pk::launch_f64_cvt(T.d_pts, F.d_pts, (int64_t)T.n * T.d, E.stream);
+    F.n = T.n;
+    F.exact_pts = false;
+    return 0;
+}
+int f64_adam_steps(pinn_engine& E, int nsteps, double lr, double beta1, double beta2, double eps, const float* term_w, double* loss_history, void (*redraw)(pinn_engine&, Term&)) {
+    F64State& S = *(F64State*)E.f64;
+    if (!S.opt_ready) return fail("pinn_adam_steps: call pinn_adam_init first (float64 mode keeps its own optimiser state)");
+    const int K = (int)E.terms.size();
+    const int P = (int)E.ntheta;
+    std::vector<double> w(K), won(K);
+    for (int k = 0; k < K; ++k) { w[k] = term_w ? (double)term_w[k] : 1.0; won[k] = w[k] / (double)E.terms[k].n_norm; }
+    plat_h2d(S.d_w_over_n, won.data(), sizeof(double) * K, E.stream);
+    if (S.hist_cap < nsteps) {
+        plat_sync(E.stream);
+        plat_free(S.d_hist);
+        S.d_hist = (double*)plat_malloc(sizeof(double) * nsteps);
+        S.hist_cap = S.d_hist ? nsteps : 0;
+        if (!S.d_hist) return fail("device allocation failed (loss history)");
+    }
+    for (int s = 0; s < nsteps; ++s) {
+        for (size_t t = 0; t < E.terms.size(); ++t) {
+            Term& T = E.terms[t];
+            if (T.sampler == 0) continue;
+            redraw(E, T);                                    // (engine.cpp: the fp32 sampler kernels, draw counter advanced)
+            if (f64_points_from_device(E, (int)t)) return 1;
+        }
+        if (f64_eval_device(E, w.data(), true)) return 1;
+        ++E.opt_t;
+        const double c1 = 1.0 / (1.0 - std::pow(beta1, (double)E.opt_t)), c2 = 1.0 / (1.0 - std::pow(beta2, (double)E.opt_t));
+        pk::launch_f64_total(S.d_hist, s, S.d_sumsq, S.d_w_over_n, K, E.stream);
+        pk::launch_f64_adam(S.d_theta, S.d_m, S.d_v, S.d_grad, P, lr, beta1, beta2, eps, c1, c2, E.stream);
+    }
+    if (loss_history && plat_d2h(loss_history, S.d_hist, sizeof(double) * nsteps, E.stream)) return fail("D2H copy failed");
+    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    return 0;
+}
+// float64 evaluation at DEVICE-resident float parameters (pinn_loss_grad_device / pinn_loss_device in float64 mode): theta converted on the
+// device, [gradient | term sums] converted back into the caller's float vector — the kernels in between are the double ones
+int f64_eval_from_device_f32(pinn_engine& E, const float* d_theta, const float* term_w, float* d_out, bool want_grad) {
+    F64State& S = *(F64State*)E.f64;
+    const int K = (int)E.terms.size();
+    const int64_t P = E.ntheta;
+    std::vector<double> w(K);
+    for (int k = 0; k < K; ++k) w[k] = term_w ? (double)term_w[k] : 1.0;
+    pk::launch_f64_cvt(d_theta, S.d_theta, P, E.stream);
+    S.opt_ready = false;
+    if (f64_eval_device(E, w.data(), want_grad)) return 1;
+    if (want_grad) pk::launch_f64_narrow(S.d_grad, d_out, P, E.stream);
+    pk::launch_f64_narrow(S.d_sumsq, d_out + (want_grad ? P : 0), K, E.stream);
     return 0;
 }
 

@@ -585,6 +585,51 @@ inline void launch_f64m_dw(const F64Args& a, const int* small_ent, int nsmall, p
 }
 #endif
 
+// ---- float64 optimiser loop (f64.cpp: f64_adam_steps): points redrawn by the fp32 samplers -> double, Adam in double, the step's total loss ----
+DEV void f64_cvt_elem(int i, const float* src, double* dst) { dst[i] = (double)src[i]; }
+DEV void f64_adam_elem(int i, double* theta, double* m, double* v, const double* g, double lr, double b1, double b2, double eps, double c1, double c2) {
+    const double gi = g[i];
+    const double mi = b1 * m[i] + (1.0 - b1) * gi, vi = b2 * v[i] + (1.0 - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    theta[i] -= lr * (mi * c1) / (sqrt(vi * c2) + eps);
+}
+#ifdef PINN_EMU
+inline void launch_f64_cvt(const float* src, double* dst, int64_t n, plat_stream) { for (int64_t i = 0; i < n; ++i) dst[i] = (double)src[i]; }
+inline void launch_f64_adam(double* theta, double* m, double* v, const double* g, int P, double lr, double b1, double b2, double eps, double c1, double c2, plat_stream) {
+    for (int i = 0; i < P; ++i) f64_adam_elem(i, theta, m, v, g, lr, b1, b2, eps, c1, c2);
+}
+inline void launch_f64_total(double* hist, int step, const double* sumsq, const double* w_over_n, int K, plat_stream) {
+    double s = 0.0;
+    for (int k = 0; k < K; ++k) s += w_over_n[k] * sumsq[k];
+    hist[step] = s;
+}
+inline void launch_f64_narrow(const double* src, float* dst, int64_t n, plat_stream) { for (int64_t i = 0; i < n; ++i) dst[i] = (float)src[i]; }
+#else
+template <int UNUSED> __global__ void __launch_bounds__(256) k_f64_cvt(const float* src, double* dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (double)src[i];
+}
+template <int UNUSED> __global__ void __launch_bounds__(256) k_f64_adam(double* theta, double* m, double* v, const double* g, int P, double lr, double b1, double b2, double eps, double c1, double c2) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i < P) f64_adam_elem(i, theta, m, v, g, lr, b1, b2, eps, c1, c2);
+}
+template <int UNUSED> __global__ void k_f64_total(double* hist, int step, const double* sumsq, const double* w_over_n, int K) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { double s = 0.0; for (int k = 0; k < K; ++k) s += w_over_n[k] * sumsq[k]; hist[step] = s; }
+}
+inline void launch_f64_cvt(const float* src, double* dst, int64_t n, plat_stream st) { hipLaunchKernelGGL((k_f64_cvt<0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n); }
+inline void launch_f64_adam(double* theta, double* m, double* v, const double* g, int P, double lr, double b1, double b2, double eps, double c1, double c2, plat_stream st) {
+    hipLaunchKernelGGL((k_f64_adam<0>), dim3((P + 255) / 256), dim3(256), 0, st, theta, m, v, g, P, lr, b1, b2, eps, c1, c2);
+}
+inline void launch_f64_total(double* hist, int step, const double* sumsq, const double* w_over_n, int K, plat_stream st) {
+    hipLaunchKernelGGL((k_f64_total<0>), dim3(1), dim3(64), 0, st, hist, step, sumsq, w_over_n, K);
+}
+template <int UNUSED> __global__ void __launch_bounds__(256) k_f64_narrow(const double* src, float* dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
+}
+inline void launch_f64_narrow(const double* src, float* dst, int64_t n, plat_stream st) { hipLaunchKernelGGL((k_f64_narrow<0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n); }
+#endif
+
 template <int D, unsigned D1MASK, unsigned long long PAIRS, int NPAIR, unsigned HI, int HT> F64MKernel make_f64m_kernel() {
     using J = JetSet<D1MASK, PAIRS, NPAIR, HI>;
     static_assert(J::NLAP == 0, "the float64 kernels carry plain derivative channels (no forward-Laplacian channel)");

@@ -147,14 +147,18 @@ def test_f64_mode_derivative_orders_activations_weights(npde, use_emu):
     prob = helpers.oracle_problem(npde, sysm, [chain])
     r = po.residual_values(prob, th, 0, sets[0], mode="exact").reshape(-1)
     np.testing.assert_allclose(l64[0], float(np.sum(wq.astype(np.float64) * r * r)), rtol=1e-6)      # (the weights are stored as float sqrt(N w))
-    # not covered: device samplers; the handle's fp32 evaluation is untouched by the failed switch
+    # device samplers (r05: covered — the double copy follows every draw; test_f64_mode_resident_adam_samplers_and_device_entry_points): a
+    # handle that already redraws a term switches to float64 and evaluates the drawn set in double
     wl = workloads.cfg2_poisson2d(points=64, bcs_points=16)
     rep2 = npde.symbolic_discretize(wl.pde_system, wl.discretization())
     rep2.engine.set_sampler(0, np.zeros(2, np.float32), np.ones(2, np.float32), 64, seed=3, kind=1)
-    with pytest.raises(Exception, match="device samplers"):
-        rep2.engine.set_option("precision", "f64")
-    assert rep2.engine.get_option("precision") == "f32"
-    rep2.engine.loss_grad(rep2.flat_init_params)
+    l32, g32 = rep2.engine.loss_grad_f64(np.asarray(rep2.flat_init_params, dtype=np.float64))
+    rep2.engine.set_option("precision", "f64")
+    assert rep2.engine.get_option("precision") == "f64"
+    l64s, g64s = rep2.engine.loss_grad_f64(np.asarray(rep2.flat_init_params, dtype=np.float64))
+    assert 1e-10 < np.linalg.norm(g64s - g32) / np.linalg.norm(g64s) < 1e-5
+    # still outside the mode: periodic embeddings, DATA channels, DGM networks — the switch fails with a message and the fp32 plan stays usable
+    # (tests/test_emu_parity.py::test_periodic_embedding_* carry such handles)
 
 
 def test_reference_pde_iii_system_meets_its_float64_criterion(npde, use_emu):
@@ -188,3 +192,89 @@ def test_reference_pde_iii_system_meets_its_float64_criterion(npde, use_emu):
     err = np.linalg.norm(rep.phi[0](xs, npde.depvar_params(rep, res.u, "u"))[0] - real)
     print(f"pde_iii in float64: objective {res.objective:.3e} (reference: < 1e-9), ||u_predict - u_real||_2 = {err:.2e} (reference atol 1e-4)")
     assert res.objective < 1e-9 and err < 1e-4
+
+
+def _host_adam(theta, grads, lr, b1=0.9, b2=0.999, eps=1e-8):
+    """float64 Adam over a list of gradient callbacks (one per step): the reference's `solve(prob, Adam(lr))` arithmetic"""
+    lr, b1, b2, eps = (float(np.float32(x)) for x in (lr, b1, b2, eps))       # (the C ABI takes the hyper-parameters as floats)
+    th, m, v = theta.copy(), np.zeros_like(theta), np.zeros_like(theta)
+    for t, gfun in enumerate(grads, start=1):
+        g = gfun(th)
+        m = b1 * m + (1 - b1) * g
+        v = b2 * v + (1 - b2) * g * g
+        th = th - lr * (m / (1 - b1 ** t)) / (np.sqrt(v / (1 - b2 ** t)) + eps)
+    return th
+
+
+def test_f64_mode_resident_adam_samplers_and_device_entry_points(npde, use_emu):
+    """r05: the float64 mode covers the optimiser loop and the device samplers — StochasticTraining /
+    QuasiRandomTraining(resampling = true) with the reference's default Float64 parameters (src/discretize.jl:432-449,
+    src/training_strategies.jl:271-282, 365-389) no longer falls back to fp32.  (a) pinn_adam_* on fixed sets = a float64 host Adam over the
+    mode's own gradients, to rounding; (b) with device samplers: every step's redrawn set read back, the same iterates from a second handle
+    evaluated on exactly those points; (c) pinn_loss_grad_device / pinn_loss_device / pinn_term_grads evaluate in double in this mode."""
+    from neuralpde_jl_amd import workloads
+    wl = workloads.cfg2_poisson2d(points=96, bcs_points=32, width=16, hidden=2)
+    rep, eng, sets, prob = _engine_f64(npde, wl)
+    th0 = np.asarray(rep.flat_init_params, dtype=np.float64)
+    w = np.linspace(1.0, 2.0, eng.K)
+    # (a) fixed sets
+    th_dev, hist = eng.adam_f64(th0, 12, 3e-3, w)
+    assert eng.get_option("f64_path") == "mfma"
+    th_host = _host_adam(th0, [lambda th: eng.loss_grad_f64(th, w)[1]] * 12, 3e-3)
+    np.testing.assert_allclose(th_dev, th_host, rtol=0, atol=1e-13 * np.abs(th_host).max())
+    l0, _ = eng.loss_grad_f64(th0, w)
+    assert abs(hist[0] - float(np.dot(w, l0))) < 1e-13 * abs(hist[0])
+    th_f32 = eng.adam(th0, 3, 3e-3, w)[0]                                     # the float entry points of the same loop: converted at the boundary
+    np.testing.assert_allclose(th_f32, _host_adam(th0, [lambda th: eng.loss_grad_f64(th, w)[1]] * 3, 3e-3).astype(np.float32), rtol=0, atol=2e-7)
+    # (b) device samplers in float64 mode: every step's redrawn sets read back, the update reproduced from a second handle's gradient on them
+    d = sets[0].shape[0]
+    lb, ub = [0.0] * d, [1.0] * d
+    eng.set_sampler(0, lb, ub, 80, seed=5, kind=1)
+    eng.set_sampler(1, [0.0, 0.0], [0.0, 1.0], 24, seed=6, kind=2)
+    rep2, eng2, _, _ = _engine_f64(npde, wl)
+    for k, s_ in enumerate(sets):                                              # (a second discretisation draws its own boundary sets: same sets on both handles)
+        eng2.set_points_f64(k, s_)
+    th_prev, m, v = th0.copy(), np.zeros_like(th0), np.zeros_like(th0)
+    seen = []
+    for t in range(1, 5):
+        th_dev, _ = eng.adam_f64(th0 if t == 1 else None, 1, 3e-3, w, init=(t == 1))
+        assert eng.get_option("f64_path") == "mfma"
+        for k, n in ((0, 80), (1, 24)):
+            pts = eng.get_points(k, d, n).astype(np.float64)
+            eng2.set_points_f64(k, pts)
+            if k == 0:
+                seen.append(pts.copy())
+        g = eng2.loss_grad_f64(th_prev, w)[1]
+        lr, b1, b2, eps = (float(np.float32(x)) for x in (3e-3, 0.9, 0.999, 1e-8))
+        m = b1 * m + (1 - b1) * g
+        v = b2 * v + (1 - b2) * g * g
+        th_host = th_prev - lr * (m / (1 - b1 ** t)) / (np.sqrt(v / (1 - b2 ** t)) + eps)
+        np.testing.assert_allclose(th_dev, th_host, rtol=0, atol=1e-13 * np.abs(th_host).max())
+        th_prev = th_dev
+    assert not np.array_equal(seen[0], seen[1]) and seen[0].min() >= 0.0 and seen[0].max() <= 1.0      # (fresh points every step)
+    # (c) device-pointer entry points and per-term gradients in float64 mode (emulation: "device" pointers are host pointers)
+    rep3, eng3, _, _ = _engine_f64(npde, wl)
+    l64, g64 = eng3.loss_grad_f64(th0, w)
+    th32 = th0.astype(np.float32)
+    l64b, g64b = eng3.loss_grad_f64(th32.astype(np.float64), w)
+    n_norm = np.array([s.shape[1] for s in sets], dtype=np.float64)
+    if eng3.L.backend == "hip":                                                # (the mirror of this test on the hardware: real device memory)
+        import torch
+        d_th = torch.tensor(th32, device="cuda")
+        d_out = torch.zeros(eng3.P + eng3.K, dtype=torch.float32, device="cuda")
+        d_sums = torch.zeros(eng3.K, dtype=torch.float32, device="cuda")
+        eng3.loss_grad_device(d_th.data_ptr(), d_out.data_ptr(), w)
+        eng3.loss_device(d_th.data_ptr(), d_sums.data_ptr())
+        torch.cuda.synchronize()
+        out, sums = d_out.cpu().numpy(), d_sums.cpu().numpy()
+    else:
+        out = np.zeros(eng3.P + eng3.K, dtype=np.float32)
+        sums = np.zeros(eng3.K, dtype=np.float32)
+        eng3.loss_grad_device(th32.ctypes.data, out.ctypes.data, w)
+        eng3.loss_device(th32.ctypes.data, sums.ctypes.data)
+    np.testing.assert_allclose(out[:eng3.P], g64b.astype(np.float32), rtol=0, atol=1e-7 * np.abs(g64b).max())
+    np.testing.assert_allclose(out[eng3.P:] / n_norm, l64b, rtol=2e-7)
+    np.testing.assert_allclose(sums / n_norm, l64b, rtol=2e-7)
+    tl, tg = eng3.term_grads(th32)
+    np.testing.assert_allclose(tl, l64b, rtol=1e-12)
+    np.testing.assert_allclose((tg * w[:, None]).sum(0), g64b, rtol=0, atol=2e-7 * np.abs(g64b).max())
