@@ -134,16 +134,19 @@ function adam!(e::HIPEngine, θ0::AbstractVector{<:Real}, nsteps::Integer, η::R
                β1::Real = 0.9, β2::Real = 0.999, ϵ::Real = 1.0e-8, init::Bool = true)
     # `solve(prob, Adam(η); maxiters = nsteps)` with θ, the moments and the point sets resident on the device (`pinn_adam_steps`): the
     # persistent kernel where the problem is small enough, the launch-per-step loop otherwise; `init = false` continues from the device state
-    θ32 = Vector{Float32}(θ0); w32 = Vector{Float32}(w)
+    # The parameters cross the boundary in DOUBLE (pinn_adam_init_f64 / pinn_adam_get_f64, r05): a handle in float64 mode
+    # (`set_precision!(e, :f64)`, the reference's default eltype, src/discretize.jl:432-449) keeps θ, the moments, the redrawn point sets and
+    # every kernel of the iteration in double on the device; a float32 handle narrows / widens at the boundary.
+    θ64 = Vector{Float64}(θ0); w32 = Vector{Float32}(w)
     if init
-        GC.@preserve θ32 check(ccall(sym(:pinn_adam_init), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64), e.h, θ32, e.P), "pinn_adam_init")
+        GC.@preserve θ64 check(ccall(sym(:pinn_adam_init_f64), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), e.h, θ64, e.P), "pinn_adam_init_f64")
     end
     hist = zeros(Float64, nsteps)
     GC.@preserve w32 hist check(ccall(sym(:pinn_adam_steps), Cint,
         (Ptr{Cvoid}, Cint, Cfloat, Cfloat, Cfloat, Cfloat, Ptr{Float32}, Ptr{Float64}), e.h, nsteps, η, β1, β2, ϵ, w32, hist), "pinn_adam_steps")
-    out = zeros(Float32, e.P)
-    GC.@preserve out check(ccall(sym(:pinn_adam_get), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64), e.h, out, e.P), "pinn_adam_get")
-    return Float64.(out), hist
+    out = zeros(Float64, e.P)
+    GC.@preserve out check(ccall(sym(:pinn_adam_get_f64), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), e.h, out, e.P), "pinn_adam_get_f64")
+    return out, hist
 end
 
 """

@@ -95,8 +95,11 @@ class Library:
         L.pinn_adam_init.argtypes = [vp, fp, C.c_int64]
         L.pinn_adam_steps.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, fp, dp]
         L.pinn_adam_get.argtypes = [vp, fp, C.c_int64]
-        L.pinn_adam_init_f64.argtypes = [vp, dp, C.c_int64]
-        L.pinn_adam_get_f64.argtypes = [vp, dp, C.c_int64]
+        try:                                     # (r05 entry points: A/B variant libraries built before them still load for tools/ab_compare.py)
+            L.pinn_adam_init_f64.argtypes = [vp, dp, C.c_int64]
+            L.pinn_adam_get_f64.argtypes = [vp, dp, C.c_int64]
+        except AttributeError:
+            pass
         L.pinn_lbfgs.argtypes = [vp, C.POINTER(C.c_double), C.c_int64, C.c_int, C.c_int, C.c_double, fp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         self.ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_int64, C.c_int, vp)
         L.pinn_comm_init_custom.argtypes = [vp, C.c_int, C.c_int, self.ALLREDUCE_FN, vp]

@@ -251,6 +251,7 @@ static int f64_eval_device(pinn_engine& E, const double* term_w, bool want_grad)
         for (int i = 0; i < 8; ++i) a.first_ch[i] = F.k->first_ch[i];
         int rows = 0, ent = 0;
         bool sin_act = false;
+        const bool mfma_rows = F.km && std::getenv("PINN_F64_NO_MFMA") == nullptr;
         for (int ni = 0; ni < a.nnets; ++ni) {
             const Net& N = E.nets[F.nets[ni]];
             pk::F64Net& n = a.net[ni];
@@ -276,7 +277,11 @@ static int f64_eval_device(pinn_engine& E, const double* term_w, bool want_grad)
             // scratch rows: per hidden layer record / post-activation jets / dZ, then this network's seeds
             const int L = n.nl - 1;
             for (int l = 0; l < L; ++l) { n.r_rec[l] = rows; rows += N.sizes[l + 1] * a.C; }
-            for (int l = 0; l < L; ++l) { n.r_post[l] = rows; rows += N.sizes[l + 1] * a.C; }
+            // value-only terms of tanh / sigmoid networks: the record of an element IS its post-activation value (act_record), so the
+            // matrix-pipe kernels keep ONE copy (a third of the tile kernel's stores less; 4 of the bench workload's 5 terms)
+            const bool post_is_rec = mfma_rows && a.C == 1 && N.act != pk::ACT_SIN;
+            a.post_alias = post_is_rec ? 1 : 0;
+            for (int l = 0; l < L; ++l) { if (post_is_rec) n.r_post[l] = n.r_rec[l]; else { n.r_post[l] = rows; rows += N.sizes[l + 1] * a.C; } }
             for (int l = 0; l < L; ++l) { n.r_dz[l] = rows; rows += N.sizes[l + 1] * a.C; }
             n.r_ubar = rows; rows += a.C;
         }

@@ -56,10 +56,11 @@
 // its accumulator, it truncates them towards -infinity below ~2^-31 of the accumulator: six pieces on one accumulator shift every GEMM output
 // by -0.6 ... -1.0e-8 (|z| ~ 1.6) — a coherent offset of every pre-activation, which a TRAINED theta amplifies (tools/micro/split_bias_probe.hip,
 // profiles/r05_split_bias_probe.txt: own accumulator = zero mean AND a third of the rms error).  Bit mask: 1 forward GEMM, 2 dA GEMM,
-// 4 dW GEMM with register-resident sums (H = 64), 8 dW GEMM with slab-resident sums (H = 128), 16 (with 4) the H = 64 dW GEMM forms a tile's WHOLE
-// product in fresh accumulators (dw_layer_tr2).
+// 4 dW GEMM with register-resident sums (H = 64), 8 dW GEMM with slab-resident sums (H = 128: not enabled — 32 more live registers in a kernel
+// that already spills).  (A variant that also formed the hh products of a dW tile in fresh accumulators, input tile as the outer loop, gave
+// the same parity figures to three digits and was not bit-reproducible in stand-alone launches on the hardware: removed, profiles/r05_experiments.txt.)
 #ifndef PINN_F2_SPLIT_ACC2
-#define PINN_F2_SPLIT_ACC2 23
+#define PINN_F2_SPLIT_ACC2 7
 #endif
 #ifndef PINN_F2_WACC_PRELOAD
 #define PINN_F2_WACC_PRELOAD 2          // slab-resident dW sums (H = 128) loaded as the dW GEMM's initial accumulators (2: fp32-MFMA kernels too)
@@ -1034,47 +1035,6 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                     }
                 }
             };
-            // (PINN_F2_SPLIT_ACC2 & 16; register-resident sums, one neuron tile per wave) the dW GEMM of a layer with the INPUT tile as the outer
-            // loop: a tile's whole product — every column-group pair, the hh pieces in one fresh accumulator, the small pieces in another —
-            // is formed in zero-initialised accumulators and added to the running sum by ONE rounded VALU add per tile, so the running sums
-            // (after 100 tiles: 100 x a tile's products) never take a product the matrix pipe would truncate
-            constexpr bool DW_TI_OUTER = DW_ACC2 && S::WBAR_REG && MTW == 1 && (PINN_F2_SWP & 4) != 0 && (PINN_F2_SPLIT_ACC2 & 16) != 0;
-            auto dw_layer_tr2 = [&]() {
-                constexpr int NPR = (NG + 1) / 2, NGRP2 = MT * NPR, NB = 2;
-                auto ld_trq = [&](const float* X, int qp, int frag, int h) -> vbf8 {
-                    const int base = frag * 256 + h * 128;
-                    if (2 * qp + 1 < NG) return cat_bf8(lds_load_tr_bf4(X, vint(base) + trbq[0]), lds_load_tr_bf4(X, vint(base) + trbq[1]));
-                    return cat_bf8(lds_load_tr_bf4(X, vint(base) + trb[0]), lds_load_tr_bf4(X, vint(base) + trb[1]));
-                };
-                vbf8 za[NPR][3];
-                const int tile = w * MTW;
-                PINN_UNROLL for (int qp = 0; qp < NPR; ++qp)
-                    PINN_UNROLL for (int sp = 0; sp < 3; ++sp) {
-                        za[qp][sp] = ld_trq(XZ, qp, (2 * qp * S::KB + (tile >> 1)) * 3 + sp, tile & 1);
-                        if (2 * qp + 1 >= NG) za[qp][sp] = bf8_select(klo, za[qp][sp]);
-                    }
-                vbf8 ab[NB][3];
-                PINN_UNROLL for (int sp = 0; sp < 3; ++sp) ab[0][sp] = ld_trq(XA, 0, 0 * 3 + sp, 0);
-                PINN_UNROLL for (int ti = 0; ti < MT; ++ti) {
-                    vfloat4 wb_ = vzero4(), ws_ = vzero4();
-                    PINN_UNROLL for (int qp = 0; qp < NPR; ++qp) {
-                        const int gi = ti * NPR + qp;
-                        if (gi + 1 < NGRP2) {
-                            const int ti2 = (gi + 1) / NPR, qp2 = (gi + 1) % NPR;
-                            PINN_UNROLL for (int sp = 0; sp < 3; ++sp) ab[(gi + 1) % NB][sp] = ld_trq(XA, qp2, (2 * qp2 * S::KB + (ti2 >> 1)) * 3 + sp, ti2 & 1);
-                        }
-                        sched_fence();
-                        if (gi + 1 < NGRP2) lds_wait<6>(); else lds_wait<0>();
-                        mfma_split2(za[qp], ab[gi % NB], wb_, ws_);
-                        chain_fence();
-                        if (ADJ_IL) {
-                            PINN_UNROLL for (int j = 0; j < ADJ_NCH; ++j)
-                                if ((j * ADJ_NGRP) / ADJ_NCH == gi) adj_piece(Sr, j);
-                        }
-                    }
-                    PINN_UNROLL for (int e = 0; e < 4; ++e) wbar[hl][0][ti][e] += wb_[e] + ws_[e];
-                }
-            };
             // W^T fragments for dA: issued ahead of the dW GEMM, which hides their latency
             vfloat4 wt[WPRE ? MT : 1][MTW];
             vbf8 wtb[S::BFX ? S::KB : 1][S::BFX ? MTW : 1][3];      // split-operand W^T fragments: [k-block of 32 output neurons][own input tile][piece]
@@ -1144,11 +1104,8 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                     if (ADJ_IL)
                         PINN_UNROLL for (int q = 0; q < NG; ++q)
                             PINN_UNROLL for (int t = 0; t < MTW; ++t) G[q][t] = Gn[q][t];
-                    if (DW_TI_OUTER) dw_layer_tr2();
-                    else {
-                        PINN_UNROLL for (int qp = 0; qp < (NG + 1) / 2; ++qp) dw_pair_tr(qp);
-                        dw_merge();
-                    }
+                    PINN_UNROLL for (int qp = 0; qp < (NG + 1) / 2; ++qp) dw_pair_tr(qp);
+                    dw_merge();
                 } else {
                     PINN_UNROLL for (int q = 0; q < NG; ++q) dw_q(ZT + q * (MTW * 256), X1 + q * 16 * HP);
                     if (F2_GEMM_AHEAD > 0 && MTW == 1 && MT == 4)
@@ -1213,11 +1170,8 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 if (ADJ_IL)
                     PINN_UNROLL for (int q = 0; q < NG; ++q)
                         PINN_UNROLL for (int t = 0; t < MTW; ++t) G[q][t] = Gn[q][t];
-                if (DW_TI_OUTER) dw_layer_tr2();
-                    else {
-                        PINN_UNROLL for (int qp = 0; qp < (NG + 1) / 2; ++qp) dw_pair_tr(qp);
-                        dw_merge();
-                    }
+                PINN_UNROLL for (int qp = 0; qp < (NG + 1) / 2; ++qp) dw_pair_tr(qp);
+                    dw_merge();
                 STAMP(9)
             } else {
                 PINN_UNROLL for (int q = 0; q < NG; ++q) stage_q(q, ZT + q * (MTW * 256), X1 + q * 16 * HP);

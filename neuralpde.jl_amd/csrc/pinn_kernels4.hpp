@@ -58,6 +58,7 @@ struct F64Args {
     double* scratch;                    // rows [nrows][npad] (family 4); the matrix-pipe kernels (pinn_kernels5.hpp) lay the same rows out point-block-major
     int npad;
     int nrows;                          // total scratch rows of the term (pinn_kernels5.hpp: f64m_six)
+    int post_alias;                     // matrix-pipe kernels, value-only tanh / sigmoid terms: r_post == r_rec (one copy: the record is the activation)
     int r_pbar, r_sq;                   // PDE-parameter partials [ne], squared weighted residual [1]
     int mode;                           // 0: loss + gradient, 1: loss only, 2: residual values into `resid`
     double* resid;

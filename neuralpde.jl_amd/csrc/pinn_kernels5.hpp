@@ -19,6 +19,10 @@
 // pair; everything else keeps family 4.  PINN_F64_NO_MFMA=1 keeps family 4 everywhere (A/B, tests).
 #pragma once
 #include "pinn_kernels4.hpp"
+#ifndef PINN_F64M_DWT_SINGLE
+#define PINN_F64M_DWT_SINGLE 1          // the dW kernel with ONE operand buffer: 256 registers, two workgroups per CU — 2.93 against 3.92 ms for the bench
+                                        // workload's float64 evaluation with the second buffer (334 registers, one workgroup per CU); 0 restores it (A/B)
+#endif
 #ifndef PINN_F64M_PROBE
 #define PINN_F64M_PROBE 0               // timing probes (tools only, wrong numbers): 1 no rolling reload of the weight fragments, 2 no scratch stores, 4 no activation function
 #endif
@@ -178,7 +182,7 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                         act_derivs_n<J::NORD - 1, SIN>(n.act, z[0], dd);
                         jet_forward<J>(z, dd);
                         z[0] = a0;
-                        if (st) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_post[lyr] + (size_t)m * C + c, p)] = z[c]; }
+                        if (st && !a.post_alias) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_post[lyr] + (size_t)m * C + c, p)] = z[c]; }
                         PINN_UNROLL for (int c = 0; c < C; ++c) X(l, tr * NCG + pg * C + c) = valid ? z[c] : 0.0;
                     }
                 }
@@ -401,6 +405,9 @@ DEV void f64m_dwt_wave(int ni, int lyr, int b, int w, const F64Args& a, F64mDwtA
     };
     const int nsteps = ((hi - lo + 15) / 16) * C;                // step i: points lo + 16 (i / C) .., channel i % C; this wave: i = w, w + 4, ...
     int i = w;
+#if PINN_F64M_DWT_SINGLE
+    for (; i < nsteps; i += F64M_DWT_WAVES) { load_step(Af[0], Bf[0], lo + 16 * (i / C), i % C); mma_step(Af[0], Bf[0], i % C); }
+#endif
     if (i < nsteps) load_step(Af[0], Bf[0], lo + 16 * (i / C), i % C);
     for (; i < nsteps; i += 2 * F64M_DWT_WAVES) {
         const int i1 = i + F64M_DWT_WAVES, i2 = i + 2 * F64M_DWT_WAVES;
@@ -544,7 +551,7 @@ inline void launch_f64m_dw(const F64Args& a, const int* small_ent, int nsmall, p
 template <class J, int HT, int PG> __global__ void __launch_bounds__(64, (HT * PG * J::C <= 8) ? 2 : 1) k_f64m_tile(const F64Args a) {
     f64m_tile<J, HT, PG, ACT_TANH>((int)blockIdx.x, a);
 }
-template <int HT> __global__ void __launch_bounds__(64 * F64M_DWT_WAVES) k_f64m_dwt(const F64Args a) {
+template <int HT> __global__ void __launch_bounds__(64 * F64M_DWT_WAVES, PINN_F64M_DWT_SINGLE ? 2 : 1) k_f64m_dwt(const F64Args a) {
     __shared__ double lds[(HT * HT * 4 + HT) * 64];
     int ni = 0, lyr = 1;
     if (!f64m_dwt_locate((int)blockIdx.x, a, ni, lyr)) return;
@@ -565,7 +572,7 @@ template <int HT> void launch_f64m_dwt(const F64Args& a, plat_stream st) {
     if (a.mode != 0 || nl == 0) return;
     hipLaunchKernelGGL((k_f64m_dwt<HT>), dim3(nl, nb), dim3(64 * F64M_DWT_WAVES), 0, st, a);
 }
-constexpr int F64M_DW_SPLIT = 8;          // workgroups (of 4 waves) per block of points: wave v of 32 takes the entries v, v + 32, ... of the list
+constexpr int F64M_DW_SPLIT = 32;         // workgroups (of 4 waves) per block of points: wave v of 128 takes the entries v, v + 128, ... of the list
 template <int UNUSED> __global__ void __launch_bounds__(256) k_f64m_dw(const F64Args a, const int* small_ent, int nsmall) {
     const int wv = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), b = (int)blockIdx.y, lane = (int)(threadIdx.x & 63);
     const int lo = b * F64_BLOCK, hi = (lo + F64_BLOCK < a.npts) ? lo + F64_BLOCK : a.npts;

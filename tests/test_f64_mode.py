@@ -135,6 +135,24 @@ def test_f64_mode_derivative_orders_activations_weights(npde, use_emu):
     sys4 = npde.PDESystem([npde.Eq(D4(u(x)) + u(x), sp.sin(x))], [npde.Eq(u(0.0), 0.0), npde.Eq(u(1.0), 0.5)],
                           [npde.In(x, npde.Interval(0.0, 1.0))], [x], [u(x)])
     run(sys4, npde.Chain(npde.Dense(1, 12, "tanh"), npde.Dense(12, 12, "tanh"), npde.Dense(12, 1)), npde.GridTraining(0.05), 5)
+    # r05: orders 3 and 4 and a mixed second derivative in TWO dimensions (csrc/inst_f64.hip: f64_d2_h4), and a 3-D case
+    x, y = npde.parameters("x y")
+    (u,) = npde.variables("u")
+    Dx, Dy = npde.Differential(x), npde.Differential(y)
+    sys2 = npde.PDESystem([npde.Eq((Dx ** 4)(u(x, y)) + (Dy ** 3)(u(x, y)) + 0.5 * Dx(Dy(u(x, y))) - u(x, y) * Dx(u(x, y)), sp.sin(x) * sp.cos(y))],
+                          [npde.Eq(u(0.0, y), 0.0), npde.Eq(u(x, 1.0), x)],
+                          [npde.In(x, npde.Interval(0.0, 1.0)), npde.In(y, npde.Interval(0.0, 1.0))], [x, y], [u(x, y)])
+    strat2 = npde.QuasiRandomTraining(48, bcs_points=12, sampling_alg=npde.SobolSample(seed=2), resampling=False, minibatch=1)
+    rep_h, eng_h, _ = run(sys2, npde.Chain(npde.Dense(2, 12, "tanh"), npde.Dense(12, 12, "tanh"), npde.Dense(12, 1)), strat2, 9)
+    assert "f64_channels=10" in eng_h.describe()
+    t, x3, y3 = npde.parameters("t x y")
+    U3 = u(t, x3, y3)
+    Dt, Dx3, Dy3 = npde.Differential(t), npde.Differential(x3), npde.Differential(y3)
+    sys3 = npde.PDESystem([npde.Eq(Dt(U3) + (Dx3 ** 4)(U3), (Dy3 ** 2)(U3) + 0.3 * Dx3(Dy3(U3)) + (Dy3 ** 3)(U3))],
+                          [npde.Eq(u(0.0, x3, y3), sp.sin(sp.pi * x3) * sp.sin(sp.pi * y3)), npde.Eq(u(t, 0.0, y3), 0.0)],
+                          [npde.In(v_, npde.Interval(0.0, 1.0)) for v_ in (t, x3, y3)], [t, x3, y3], [U3])
+    strat3 = npde.QuasiRandomTraining(40, bcs_points=12, sampling_alg=npde.SobolSample(seed=4), resampling=False, minibatch=1)
+    run(sys3, npde.Chain(npde.Dense(3, 10, "sigmoid"), npde.Dense(10, 10, "sigmoid"), npde.Dense(10, 1)), strat3, 13)
     sysm, chain = tp.poisson2d(npde, act="sin", width=16, hidden=2)
     strat = npde.QuasiRandomTraining(60, bcs_points=20, sampling_alg=npde.SobolSample(seed=3), resampling=False, minibatch=1)
     rep, eng, sets = run(sysm, chain, strat, 11, weights=[1.0, 2.0, 0.5, 1.5, 3.0])
