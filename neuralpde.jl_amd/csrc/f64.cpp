@@ -34,8 +34,6 @@ struct F64Term {
     double* d_pts = nullptr;             // [n][d] double; converted from the float set unless pinn_set_points_f64 installed it
     int64_t cap = 0, n = 0;
     bool exact_pts = false;              // installed in double (not a conversion of the float set)
-    int* d_small = nullptr;              // family 4m: the slab entries its small-entry kernel owns (everything but hidden-to-hidden weights)
-    int nsmall = 0;
 };
 struct F64State {
     std::vector<F64Term> terms;
@@ -58,7 +56,7 @@ struct F64State {
 
 static void f64_free(F64State* S) {
     if (!S) return;
-    for (auto& T : S->terms) { plat_free(T.d_prog); plat_free(T.d_imm); plat_free(T.d_pts); plat_free(T.d_small); }
+    for (auto& T : S->terms) { plat_free(T.d_prog); plat_free(T.d_imm); plat_free(T.d_pts); }
     plat_free(S->d_theta); plat_free(S->d_grad); plat_free(S->d_sumsq); plat_free(S->d_scratch); plat_free(S->d_slab);
     plat_free(S->d_m); plat_free(S->d_v); plat_free(S->d_w_over_n); plat_free(S->d_hist);
     delete S;
@@ -324,26 +322,12 @@ static int f64_eval_device(pinn_engine& E, const double* term_w, bool want_grad)
             if (!S.d_slab) return fail("device allocation failed (float64 slabs)");
         }
         a.scratch = S.d_scratch; a.npad = (int)chunk; a.slab = S.d_slab; a.nrows = rows;
-        if (mfma && !F.d_small) {                        // (the entry layout depends on the networks only: built once per term)
-            std::vector<int> small;
-            pk::F64Args a0 = a;
-            a0.mode = 0;
-            for (int e = 0; e < a.nent; ++e) {
-                int ni, lyr, m, k; bool bias;
-                if (pk::f64m_dw_decode(e, a0, ni, lyr, bias, m, k)) small.push_back(e);
-            }
-            F.d_small = (int*)plat_malloc(sizeof(int) * std::max<size_t>(small.size(), 1));
-            if (!F.d_small) return fail("device allocation failed (float64 entry list)");
-            plat_h2d(F.d_small, small.data(), sizeof(int) * small.size(), E.stream);
-            if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
-            F.nsmall = (int)small.size();
-        }
         for (int64_t p0 = 0; p0 < F.n; p0 += chunk) {
             a.p0 = (int)p0;
             a.npts = (int)std::min<int64_t>(chunk, F.n - p0);
             if (mfma) F.km->launch_tile(a, E.stream);
             else F.k->launch_point(a, sin_act, E.stream);
-            if (mfma) pk::launch_f64m_dw(a, F.d_small, F.nsmall, E.stream);
+            if (mfma) pk::launch_f64m_dw(a, E.stream);
             else pk::launch_f64_dw(a, E.stream);
             if (mfma) F.km->launch_dwt(a, E.stream);
             else pk::launch_f64_dwt(a, E.stream);
@@ -353,7 +337,8 @@ static int f64_eval_device(pinn_engine& E, const double* term_w, bool want_grad)
             r.grad = S.d_grad; r.ent_p = a.ent_p; r.p_off = E.p_theta_off; r.nnets = a.nnets;
             for (int ni = 0; ni < a.nnets; ++ni) { r.ent0[ni] = a.net[ni].ent0; r.theta0[ni] = a.net[ni].theta0; }
             r.sumsq = S.d_sumsq + t; r.with_grad = grad ? 1 : 0;
-            pk::launch_f64_reduce(r, E.stream);
+            if (mfma) pk::launch_f64m_reduce(r, E.stream);
+            else pk::launch_f64_reduce(r, E.stream);
         }
     }
     return 0;

@@ -133,6 +133,19 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                 }
             } else {
                 PINN_LANES(l) { PINN_UNROLL for (int e = 0; e < NR * NCG; ++e) Z(l, e) = 0.0; }
+                // the layer's biases first: requested in front of the GEMM (behind it — after the previous layer's scratch stores, which the
+                // compiler must assume to alias theta — their L2 round trip would sit between the last MFMA and the activation)
+                // (one-wave-per-SIMD kernels only: the two-wave kernels have no 32 registers to spare — measured 207 -> 244 us with the prefetch)
+                constexpr bool BPRE = (HT * NCG > 8);
+                LVd<BPRE ? NR : 1> Bv;
+                if (BPRE) {
+                    PINN_LANES(l) {
+                        PINN_UNROLL for (int tr = 0; tr < NR; ++tr) {
+                            const int m = 16 * (tr >> 2) + 4 * (tr & 3) + (l >> 4);
+                            Bv(l, BPRE ? tr : 0) = B[m < n_out ? m : n_out - 1];
+                        }
+                    }
+                }
                 // A fragments (W rows of output tile t, k-block kb) with a ROLLING prefetch: fragment (t + 1, kb) is requested right behind the
                 // MFMAs that consumed fragment (t, kb), so an L2 round trip has a whole tile row of MFMAs (16 NCG x 64 cycles) to land
                 LVd<NR> Af;
@@ -159,7 +172,7 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                     const int q = l >> 4;
                     PINN_UNROLL for (int tr = 0; tr < NR; ++tr) {
                         const int m = 16 * (tr >> 2) + 4 * (tr & 3) + q;
-                        const double b = m < n_out ? B[m] : 0.0;
+                        const double b = m < n_out ? (BPRE ? Bv(l, BPRE ? tr : 0) : B[m]) : 0.0;
                         PINN_UNROLL for (int pg = 0; pg < PG; ++pg) Z(l, tr * NCG + pg * C) += b;
                     }
                 }
@@ -172,7 +185,7 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                     const bool valid = m < n_out;
                     PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
                         const int p = pbase + 16 * pg + j;
-                        const bool st = valid && p < a.npts && a.mode == 0 && !(PINN_F64M_PROBE & 2);
+                        const bool st = valid && a.mode == 0 && !(PINN_F64M_PROBE & 2);      // (points past the chunk's end: into the rows' padding — npad is a multiple of the 512-point block, every reader masks by the point count)
                         double z[C];
                         PINN_UNROLL for (int c = 0; c < C; ++c) z[c] = Z(l, tr * NCG + pg * C + c);
                         const double a0 = (PINN_F64M_PROBE & 4) ? z[0] * 0.5 : act_value<SIN>(n.act, z[0]);
@@ -328,7 +341,7 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                     PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
                         const int p = pbase + 16 * pg + j;
                         const bool st = valid && p < a.npts;
-                        const bool st2 = st && !(PINN_F64M_PROBE & 2);
+                        const bool st2 = valid && !(PINN_F64M_PROBE & 2);
                         double s[C], gq[C], dd[ND];
                         PINN_UNROLL for (int c = 0; c < C; ++c) s[c] = X(l, tr * NCG + pg * C + c);
                         PINN_UNROLL for (int c = 0; c < C; ++c) gq[c] = Z(l, tr * NCG + pg * C + c);
@@ -458,46 +471,74 @@ HD bool f64m_dwt_locate(int idx, const F64Args& a, int& ni, int& lyr) {
     return false;
 }
 
-// ---- kernel B': the remaining slab entries (biases, first / last layer, PDE parameters, the block's sum of squares: family 4's f64_dw_entry)
-// with the block's points ACROSS THE LANES (coalesced row reads), one wave per entry of the term's small-entry list, lane partials summed in a
-// fixed butterfly order.  (Family 4's k_f64_dw runs one THREAD per entry over the block's 512 points: neighbouring threads read different rows.) ----
-DEV double f64m_dw_point(int e, int p, const F64Args& a, int ni, int lyr, bool bias, int m, int k) {
+// ---- kernel B': the remaining slab entries (first / last layer, PDE parameters, the block's sum of squares: family 4's f64_dw_entry) by UNITS, the
+// block's points across the lanes (coalesced row reads; family 4 runs one THREAD per entry over the block's 512 points: neighbouring threads read
+// different rows), lane partials summed in a fixed butterfly order: one wave per (network, first-layer neuron) — W0[m, 0..d) and b0[m] from ONE pass over the neuron's dZ rows —,
+// per (network, last-hidden-layer neuron) — W_L[k] —, per network's b_L, per PDE parameter, and the sum of squares: every dZ / activation row
+// of the block is read once (the entry-wise kernel above reads a first-layer neuron's row d + 1 times) ----
+HD int f64m_num_units(const F64Args& a) {
+    int u = 0;
+    for (int ni = 0; ni < a.nnets; ++ni) u += a.net[ni].sizes[1] + a.net[ni].sizes[a.net[ni].nl - 1] + 1;
+    return u + a.ne + 1;
+}
+constexpr int F64M_UNIT_OUT = 6;        // sums of a unit: up to 4 first-layer weights + its bias
+// lane partials of unit u over the block's points; returns the number of sums and their slab entries
+DEV int f64m_unit_lane(int u, int b, int lane, const F64Args& a, double (&s)[F64M_UNIT_OUT], int (&ent)[F64M_UNIT_OUT]) {
+    const int lo = b * F64_BLOCK, hi = (lo + F64_BLOCK < a.npts) ? lo + F64_BLOCK : a.npts;
     const double* S = a.scratch;
     const int C = a.C;
-    if (e == a.nent - 1) return S[f64m_six(a, (size_t)a.r_sq, p)];
-    if (e >= a.ent_p) return S[f64m_six(a, (size_t)a.r_pbar + (e - a.ent_p), p)];
-    const F64Net& n = a.net[ni];
-    const int L = n.nl - 1;
-    const size_t dz = (lyr == L) ? (size_t)n.r_ubar : (size_t)n.r_dz[lyr] + (size_t)m * C;
-    if (bias) return S[f64m_six(a, dz, p)];
-    if (lyr == 0) {
-        const int ck = a.first_ch[k];
-        double t2 = S[f64m_six(a, dz, p)] * a.pts[(size_t)(a.p0 + p) * a.dt + n.imap[k]];
-        if (ck >= 0) t2 += S[f64m_six(a, dz + ck, p)];
-        return t2;
+    PINN_UNROLL for (int i = 0; i < F64M_UNIT_OUT; ++i) { s[i] = 0.0; ent[i] = -1; }
+    for (int ni = 0; ni < a.nnets; ++ni) {
+        const F64Net& n = a.net[ni];
+        const int L = n.nl - 1, n1 = n.sizes[1], nL = n.sizes[L];
+        if (u < n1) {                                            // first-layer neuron m = u (L >= 1: hidden layer 0)
+            if (a.mode != 0) return 0;
+            const int m = u;
+            for (int i = 0; i < n.d; ++i) ent[i] = n.ent0 + (n.woff[0] - n.theta0) + m + i * n1;
+            ent[n.d] = n.ent0 + (n.boff[0] - n.theta0) + m;
+            const size_t dz = (size_t)n.r_dz[0] + (size_t)m * C;
+            for (int p = lo + lane; p < hi; p += 64) {
+                const double z0 = S[f64m_six(a, dz, p)];
+                s[n.d] += z0;
+                for (int i = 0; i < n.d; ++i) {
+                    const int ck = a.first_ch[i];
+                    double t2 = z0 * a.pts[(size_t)(a.p0 + p) * a.dt + n.imap[i]];
+                    if (ck >= 0) t2 += S[f64m_six(a, dz + ck, p)];
+                    s[i] += t2;
+                }
+            }
+            return n.d + 1;
+        }
+        u -= n1;
+        if (u < nL) {                                            // output-layer weight of last-hidden-layer neuron k = u
+            if (a.mode != 0) return 0;
+            const int k = u;
+            ent[0] = n.ent0 + (n.woff[L] - n.theta0) + k;
+            const size_t in = (size_t)n.r_post[L - 1] + (size_t)k * C;
+            for (int p = lo + lane; p < hi; p += 64) {
+                double t2 = 0.0;
+                for (int c = 0; c < C; ++c) t2 = vfma(S[f64m_six(a, (size_t)n.r_ubar + c, p)], S[f64m_six(a, in + c, p)], t2);
+                s[0] += t2;
+            }
+            return 1;
+        }
+        u -= nL;
+        if (u == 0) {                                            // output-layer bias
+            if (a.mode != 0) return 0;
+            ent[0] = n.ent0 + (n.boff[L] - n.theta0);
+            for (int p = lo + lane; p < hi; p += 64) s[0] += S[f64m_six(a, (size_t)n.r_ubar, p)];
+            return 1;
+        }
+        u -= 1;
     }
-    const size_t in = (size_t)n.r_post[lyr - 1] + (size_t)k * C;
-    double t2 = 0.0;
-    for (int c = 0; c < C; ++c) t2 = vfma(S[f64m_six(a, dz + c, p)], S[f64m_six(a, in + c, p)], t2);
-    return t2;
-}
-// decode of entry e (wave-uniform): network, layer, bias / weight indices; returns false for entries this kernel does not own
-HD bool f64m_dw_decode(int e, const F64Args& a, int& ni, int& lyr, bool& bias, int& m, int& k) {
-    ni = 0; lyr = 0; bias = false; m = 0; k = 0;
-    if (e == a.nent - 1) return true;
-    if (e >= a.ent_p) return a.mode == 0;
-    if (a.mode != 0) return false;
-    while (ni + 1 < a.nnets && e >= a.net[ni + 1].ent0) ++ni;
-    const F64Net& n = a.net[ni];
-    const int L = n.nl - 1;
-    const int t = n.theta0 + (e - n.ent0);
-    while (lyr + 1 < n.nl && t >= n.woff[lyr + 1]) ++lyr;
-    const int n_out = n.sizes[lyr + 1];
-    bias = t >= n.boff[lyr];
-    if (lyr >= 1 && lyr < L) return false;                     // hidden-to-hidden weights and the biases of their layers: k_f64m_dwt
-    m = bias ? t - n.boff[lyr] : (t - n.woff[lyr]) % n_out;
-    k = bias ? 0 : (t - n.woff[lyr]) / n_out;
-    return true;
+    if (u < a.ne) {
+        ent[0] = a.ent_p + u;
+        if (a.mode == 0) for (int p = lo + lane; p < hi; p += 64) s[0] += S[f64m_six(a, (size_t)a.r_pbar + u, p)];
+        return 1;
+    }
+    ent[0] = a.nent - 1;
+    for (int p = lo + lane; p < hi; p += 64) s[0] += S[f64m_six(a, (size_t)a.r_sq, p)];
+    return 1;
 }
 
 // ---- the kernel table: (inputs, jet set, HT) -> launchers; matched against a term's float64 kernel in f64.cpp ----
@@ -530,21 +571,24 @@ template <int HT> void launch_f64m_dwt(const F64Args& a, plat_stream) {
             }
         }
 }
-inline void launch_f64m_dw(const F64Args& a, const int* small_ent, int nsmall, plat_stream) {
-    const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK;
+inline void launch_f64m_dw(const F64Args& a, plat_stream) {
+    const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK, nu = f64m_num_units(a);
     for (int b = 0; b < nb; ++b)
-        for (int i = 0; i < nsmall; ++i) {
-            const int e = small_ent[i];
-            int ni, lyr, m, k; bool bias;
-            if (!f64m_dw_decode(e, a, ni, lyr, bias, m, k)) { if (e == a.nent - 1 || e >= a.ent_p) a.slab[(size_t)b * a.nent + e] = 0.0; continue; }
-            const int lo = b * F64_BLOCK, hi = (lo + F64_BLOCK < a.npts) ? lo + F64_BLOCK : a.npts;
-            double part[64];
-            for (int lane = 0; lane < 64; ++lane) { double s = 0.0; for (int p = lo + lane; p < hi; p += 64) s += f64m_dw_point(e, p, a, ni, lyr, bias, m, k); part[lane] = s; }
-            // (the device's xor butterfly: after step o every lane holds the sum of its 2o-lane group; association = a balanced tree)
-            double t[64];
-            for (int lane = 0; lane < 64; ++lane) t[lane] = part[lane];
-            for (int o = 32; o >= 1; o >>= 1) { double u[64]; for (int lane = 0; lane < 64; ++lane) u[lane] = t[lane] + t[lane ^ o]; for (int lane = 0; lane < 64; ++lane) t[lane] = u[lane]; }
-            a.slab[(size_t)b * a.nent + e] = t[0];
+        for (int u = 0; u < nu; ++u) {
+            double part[F64M_UNIT_OUT][64];
+            int ent[F64M_UNIT_OUT], nout = 0;
+            for (int lane = 0; lane < 64; ++lane) {
+                double s[F64M_UNIT_OUT];
+                nout = f64m_unit_lane(u, b, lane, a, s, ent);
+                for (int i = 0; i < F64M_UNIT_OUT; ++i) part[i][lane] = s[i];
+            }
+            for (int i = 0; i < nout; ++i) {
+                // (the device's xor butterfly: after step o every lane holds the sum of its 2o-lane group; association = a balanced tree)
+                double t[64];
+                for (int lane = 0; lane < 64; ++lane) t[lane] = part[i][lane];
+                for (int o = 32; o >= 1; o >>= 1) { double v[64]; for (int lane = 0; lane < 64; ++lane) v[lane] = t[lane] + t[lane ^ o]; for (int lane = 0; lane < 64; ++lane) t[lane] = v[lane]; }
+                if (ent[i] >= 0) a.slab[(size_t)b * a.nent + ent[i]] = t[0];
+            }
         }
 }
 #else
@@ -572,23 +616,24 @@ template <int HT> void launch_f64m_dwt(const F64Args& a, plat_stream st) {
     if (a.mode != 0 || nl == 0) return;
     hipLaunchKernelGGL((k_f64m_dwt<HT>), dim3(nl, nb), dim3(64 * F64M_DWT_WAVES), 0, st, a);
 }
-constexpr int F64M_DW_SPLIT = 32;         // workgroups (of 4 waves) per block of points: wave v of 128 takes the entries v, v + 128, ... of the list
-template <int UNUSED> __global__ void __launch_bounds__(256) k_f64m_dw(const F64Args a, const int* small_ent, int nsmall) {
+constexpr int F64M_DW_SPLIT = 32;         // workgroups (of 4 waves) per block of points: wave v of 128 takes the units v, v + 128, ...
+template <int UNUSED> __global__ void __launch_bounds__(256) k_f64m_dw(const F64Args a, int nunits) {
     const int wv = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), b = (int)blockIdx.y, lane = (int)(threadIdx.x & 63);
-    const int lo = b * F64_BLOCK, hi = (lo + F64_BLOCK < a.npts) ? lo + F64_BLOCK : a.npts;
-    for (int i = wv; i < nsmall; i += 4 * F64M_DW_SPLIT) {
-        const int e = small_ent[i];
-        int ni, lyr, m, k; bool bias;
-        if (!f64m_dw_decode(e, a, ni, lyr, bias, m, k)) { if (lane == 0 && (e == a.nent - 1 || e >= a.ent_p)) a.slab[(size_t)b * a.nent + e] = 0.0; continue; }
-        double s = 0.0;
-        for (int p = lo + lane; p < hi; p += 64) s += f64m_dw_point(e, p, a, ni, lyr, bias, m, k);
-        PINN_UNROLL for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (lane == 0) a.slab[(size_t)b * a.nent + e] = s;
+    for (int u = wv; u < nunits; u += 4 * F64M_DW_SPLIT) {
+        double s[F64M_UNIT_OUT];
+        int ent[F64M_UNIT_OUT];
+        const int nout = f64m_unit_lane(u, b, lane, a, s, ent);
+        PINN_UNROLL for (int i = 0; i < F64M_UNIT_OUT; ++i) {
+            if (i >= nout) break;
+            double v = s[i];
+            PINN_UNROLL for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0 && ent[i] >= 0) a.slab[(size_t)b * a.nent + ent[i]] = v;
+        }
     }
 }
-inline void launch_f64m_dw(const F64Args& a, const int* small_ent, int nsmall, plat_stream st) {
+inline void launch_f64m_dw(const F64Args& a, plat_stream st) {
     const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK;
-    hipLaunchKernelGGL((k_f64m_dw<0>), dim3(F64M_DW_SPLIT, nb), dim3(256), 0, st, a, small_ent, nsmall);
+    hipLaunchKernelGGL((k_f64m_dw<0>), dim3(F64M_DW_SPLIT, nb), dim3(256), 0, st, a, f64m_num_units(a));
 }
 #endif
 
@@ -635,6 +680,44 @@ template <int UNUSED> __global__ void __launch_bounds__(256) k_f64_narrow(const 
     if (i < n) dst[i] = (float)src[i];
 }
 inline void launch_f64_narrow(const double* src, float* dst, int64_t n, plat_stream st) { hipLaunchKernelGGL((k_f64_narrow<0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n); }
+#endif
+
+// ---- slab reduction of the matrix-pipe path: FOUR lanes per entry (blocks part, part + 4, ... each; (p0 + p1) + (p2 + p3)), four times the
+// threads and a quarter of the dependent adds of family 4's one-thread-per-entry kernel (38 us per term on the bench workload) ----
+DEV double f64m_reduce_part(int e, int part, const F64ReduceArgs& a) {
+    double s = 0.0;
+    for (int b = part; b < a.nblocks; b += 4) s += a.slab[(size_t)b * a.nent + e];
+    return s;
+}
+DEV void f64m_reduce_write(int e, double s, const F64ReduceArgs& a) {
+    if (e == a.nent - 1) *a.sumsq += s;
+    else if (e >= a.ent_p) a.grad[a.p_off + (e - a.ent_p)] += s;
+    else {
+        int ni = 0;
+        while (ni + 1 < a.nnets && e >= a.ent0[ni + 1]) ++ni;
+        a.grad[a.theta0[ni] + (e - a.ent0[ni])] += s;
+    }
+}
+#ifdef PINN_EMU
+inline void launch_f64m_reduce(const F64ReduceArgs& a, plat_stream) {
+    for (int e = 0; e < a.nent; ++e) {
+        if (e != a.nent - 1 && !a.with_grad) continue;
+        const double p0 = f64m_reduce_part(e, 0, a), p1 = f64m_reduce_part(e, 1, a), p2 = f64m_reduce_part(e, 2, a), p3 = f64m_reduce_part(e, 3, a);
+        f64m_reduce_write(e, (p0 + p1) + (p2 + p3), a);
+    }
+}
+#else
+template <int UNUSED> __global__ void __launch_bounds__(256) k_f64m_reduce(const F64ReduceArgs a) {
+    const int gid = (int)(blockIdx.x * 256 + threadIdx.x), e = gid >> 2, part = gid & 3;
+    const bool live = e < a.nent && (e == a.nent - 1 || a.with_grad);
+    double s = live ? f64m_reduce_part(e, part, a) : 0.0;
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (live && part == 0) f64m_reduce_write(e, s, a);
+}
+inline void launch_f64m_reduce(const F64ReduceArgs& a, plat_stream st) {
+    hipLaunchKernelGGL((k_f64m_reduce<0>), dim3((4 * a.nent + 255) / 256), dim3(256), 0, st, a);
+}
 #endif
 
 template <int D, unsigned D1MASK, unsigned long long PAIRS, int NPAIR, unsigned HI, int HT> F64MKernel make_f64m_kernel() {

@@ -22,6 +22,9 @@ def main():
              ("cfg2 2-D Poisson 4x64, 65,536 + 4x65,536 points (bench workload)", lambda: workloads.cfg2_poisson2d(points=65536)),
              ("cfg3 Burgers 4x64, 65,536 + 3x8,192 points", lambda: workloads.cfg3_burgers(points=65536, bcs_points=8192)),
              ("cfg5 inverse heat 6x128 d=4, 32,768 + 7x8,192 points", lambda: workloads.cfg5_heat_inverse(points=32768, bcs_points=8192))]
+    only = sys.argv[1:]                                           # (case prefixes, e.g. `cfg3`: that case alone in a fresh process)
+    if only:
+        cases = [c for c in cases if any(c[0].startswith(o) for o in only)]
     for name, make in cases:
         wl = make()
         rep = npde.symbolic_discretize(wl.pde_system, wl.discretization())
