@@ -515,9 +515,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if "gemm=split" not in eng.describe() else
                      ("f32, hidden-layer forward / dA / dW GEMMs as 3-piece bf16 split products (6 bf16 MFMAs per product block, fp32 accumulation; "
-                      "24 mantissa bits rebuilt): 2-4x the rounding error of an fp32-MFMA fmaf chain — gradient rel. L2 1.6-1.8e-7 vs the float64 "
-                      "oracle at the goldens' glorot parameters, error budget at scaled / trained parameters in DESIGN.md section 6; first / last "
-                      "layer, activations, reductions in fp32; --gemm fp32 runs the exact fp32-MFMA kernels"),
+                      "24 mantissa bits rebuilt; the five small piece products on an accumulator of their own: zero-mean, a third of the rms error "
+                      "of an fp32-MFMA fmaf chain per GEMM output, tools/micro/split_bias_probe.hip) — gradient rel. L2 ~3e-8 of the float64 mode at "
+                      "the goldens' glorot parameters, 0.3-1.1x a plain float32 evaluation's error at trained parameters (DESIGN.md section 6.1); "
+                      "first / last layer, activations, reductions in fp32; --gemm fp32 runs the exact fp32-MFMA kernels"),
             "data": "synthetic",
             "config": {"workload": wl.name, "interior_points": n_int, "boundary_terms": K - len(rep.pde_train_sets),
                        "boundary_points_per_term": n_glob[-1], "theta": P,
