@@ -488,13 +488,48 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
         };
         // C[q][t] += W[kb][t] (x) X[q][kb] over every column group and k-block, software-pipelined (PINN_F2_SWP): group i + 1's three piece
         // fragments are requested before group i's MFMAs
-        auto gemm_swp = [&](const float* X, const vbf8 (&wfr)[S::BFX ? S::KB : 1][S::BFX ? MTW : 1][3], vfloat4 (&Cc)[NG][MTW], bool acc2) {
+        // acc: 0 all six piece products on Cc (r03-r04); 1 the five small ones on accumulators of their own, merged at the end (PINN_F2_SPLIT_ACC2);
+        // 2 TWO PASSES over the groups on the one accumulator — every small piece product of every k-block first, the hh products last — for
+        // the kernels without 4 NG MTW registers to spare (H = 128 with >= 5 column groups: cfg5 20.0 -> 21.8 ms with mode 1, gpurun r05u); Cc must
+        // start at ZERO (the caller adds the bias afterwards), the hh pass re-reads the h piece of every group's B operand
+        auto gemm_swp = [&](const float* X, const vbf8 (&wfr)[S::BFX ? S::KB : 1][S::BFX ? MTW : 1][3], vfloat4 (&Cc)[NG][MTW], int acc) {
             constexpr int NGRP = S::KB * NG;
+            constexpr int NB = 2;                                               // operand buffers in rotation (three measured in r04: no gain)
+            constexpr int RD = S::BFX_TR ? 2 : 1;                                // LDS reads per piece fragment
+            if (acc == 2) {
+                vbf8 bb[NB][3];
+                PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[0][sp] = ld_bfrag(X, sp);
+                PINN_UNROLL for (int i = 0; i < 2 * NGRP; ++i) {
+                    const int gi = i % NGRP, kb = gi / NG, q = gi % NG;
+                    const bool small_pass = i < NGRP;
+                    if (i + 1 < 2 * NGRP) {
+                        const int g2 = (i + 1) % NGRP, kb2 = g2 / NG, q2 = g2 % NG;
+                        const int np = (i + 1 < NGRP) ? 3 : 1;                   // the hh pass needs the h piece only
+                        PINN_UNROLL for (int sp = 0; sp < 3; ++sp) if (sp < np) bb[(i + 1) % NB][sp] = ld_bfrag(X, (q2 * S::KB + kb2) * 3 + sp);
+                    }
+                    sched_fence();
+                    if (i + 1 >= 2 * NGRP) lds_wait<0>(); else if (i + 1 < NGRP) lds_wait<3 * RD>(); else lds_wait<RD>();
+                    PINN_UNROLL for (int t = 0; t < MTW; ++t) {
+                        const vbf8 (&a_)[3] = wfr[kb][t];
+                        const vbf8 (&b_)[3] = bb[i % NB];
+                        if (small_pass) {
+                            Cc[q][t] = mfma16x32bf(a_[2], b_[0], Cc[q][t]);
+                            Cc[q][t] = mfma16x32bf(a_[1], b_[1], Cc[q][t]);
+                            Cc[q][t] = mfma16x32bf(a_[0], b_[2], Cc[q][t]);
+                            Cc[q][t] = mfma16x32bf(a_[1], b_[0], Cc[q][t]);
+                            Cc[q][t] = mfma16x32bf(a_[0], b_[1], Cc[q][t]);
+                        } else {
+                            Cc[q][t] = mfma16x32bf(a_[0], b_[0], Cc[q][t]);
+                        }
+                    }
+                    chain_fence();
+                }
+                return;
+            }
             vfloat4 Cs[NG][MTW];
-            if (acc2)
+            if (acc == 1)
                 PINN_UNROLL for (int q = 0; q < NG; ++q)
                     PINN_UNROLL for (int t = 0; t < MTW; ++t) Cs[q][t] = vzero4();
-            constexpr int NB = 2;                                               // operand buffers in rotation (three measured in r04: no gain)
             vbf8 bb[NB][3];
             PINN_UNROLL for (int sp = 0; sp < 3; ++sp) bb[0][sp] = ld_bfrag(X, sp);          // group 0: kb = 0, q = 0
             PINN_UNROLL for (int i = 0; i < NGRP; ++i) {
@@ -506,18 +541,21 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 sched_fence();
                 // every piece of this group's B operand has arrived before the first MFMA of the chain (see lds_wait): only the next group's
                 // reads may still be in flight
-                if (i + 1 < NGRP) lds_wait<S::BFX_TR ? 6 : 3>(); else lds_wait<0>();
+                if (i + 1 < NGRP) lds_wait<3 * RD>(); else lds_wait<0>();
                 PINN_UNROLL for (int t = 0; t < MTW; ++t) {
-                    if (acc2) mfma_split2(wfr[kb][t], bb[i % NB], Cc[q][t], Cs[q][t]);
+                    if (acc == 1) mfma_split2(wfr[kb][t], bb[i % NB], Cc[q][t], Cs[q][t]);
                     else Cc[q][t] = mfma_split(wfr[kb][t], bb[i % NB], Cc[q][t]);
                 }
                 chain_fence();                                              // (nothing of the next group moves up into this chain)
             }
-            if (acc2)
+            if (acc == 1)
                 PINN_UNROLL for (int q = 0; q < NG; ++q)
                     PINN_UNROLL for (int t = 0; t < MTW; ++t)
                         PINN_UNROLL for (int e = 0; e < 4; ++e) Cc[q][t][e] += Cs[q][t][e];
         };
+        // which form a GEMM site takes (bit of PINN_F2_SPLIT_ACC2: 1 forward, 2 dA)
+        constexpr bool ACC_2PASS = (HP >= 128 && NG >= 5);
+        auto acc_mode = [&](int bit) -> int { return (PINN_F2_SPLIT_ACC2 & bit) ? (ACC_2PASS ? 2 : 1) : 0; };
 
         // =========================== forward ===========================
         vfloat4 A[NG][MTW];
@@ -570,16 +608,21 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 publish(Xin, A);
                 wg_barrier();                                                   // layer hl activations complete in Xin
                 STAMP(1)
+                const bool bias_after = S::BFX && (PINN_F2_SWP & 1) && acc_mode(1) == 2;      // two-pass GEMM: accumulators start at zero
                 PINN_UNROLL for (int t = 0; t < MTW; ++t) {
                     if (!WPRE && !S::BFX) bv[t] = ld_bias(hl + 1, t);
                     PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
-                        A[pg * C][t] = bv[t];
+                        A[pg * C][t] = bias_after ? vzero4() : bv[t];
                         PINN_UNROLL for (int ch = 1; ch < C; ++ch) A[pg * C + ch][t] = vzero4();
                     }
                 }
                 wave_prio(0);
                 if (S::BFX && (PINN_F2_SWP & 1)) {
-                    gemm_swp(Xin, wb, A, (PINN_F2_SPLIT_ACC2 & 1) != 0);
+                    gemm_swp(Xin, wb, A, acc_mode(1));
+                    if (bias_after)
+                        PINN_UNROLL for (int t = 0; t < MTW; ++t)
+                            PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
+                                PINN_UNROLL for (int e = 0; e < 4; ++e) A[pg * C][t][e] += bv[t][e];
                 } else if (S::BFX) {
                     constexpr bool ACC2 = (PINN_F2_SPLIT_ACC2 & 1) != 0;
                     vfloat4 As[ACC2 ? NG : 1][ACC2 ? MTW : 1];
@@ -1063,7 +1106,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                 STAMP(8)
                 if (SPRE && hl - 1 >= 1) load_record(hl - 1);
                 wave_prio(0);
-                if (S::BFX_TR && (PINN_F2_SWP & 2)) gemm_swp(XZ, wtb, Gn, (PINN_F2_SPLIT_ACC2 & 2) != 0);
+                if (S::BFX_TR && (PINN_F2_SWP & 2)) gemm_swp(XZ, wtb, Gn, acc_mode(2));
                 PINN_UNROLL for (int q = 0; q < ((S::BFX_TR && (PINN_F2_SWP & 2)) ? 0 : NG); ++q) {
                     if (S::BFX) {
                         constexpr bool ACC2 = (PINN_F2_SPLIT_ACC2 & 2) != 0;
@@ -1131,7 +1174,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
             // split-operand kernels of this path (H = 128): dA runs FIRST, on the W^T fragments requested above (their 48 registers are
             // dead again before the dW accumulators come alive)
             auto da_split = [&]() {
-                if (PINN_F2_SWP & 2) { gemm_swp(XZ, wtb, Gn, (PINN_F2_SPLIT_ACC2 & 2) != 0); return; }
+                if (PINN_F2_SWP & 2) { gemm_swp(XZ, wtb, Gn, acc_mode(2)); return; }
                 constexpr bool ACC2 = (PINN_F2_SPLIT_ACC2 & 2) != 0;
                 vfloat4 Gs[ACC2 ? NG : 1][ACC2 ? MTW : 1];
                 if (ACC2)
