@@ -554,7 +554,10 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                         PINN_UNROLL for (int e = 0; e < 4; ++e) Cc[q][t][e] += Cs[q][t][e];
         };
         // which form a GEMM site takes (bit of PINN_F2_SPLIT_ACC2: 1 forward, 2 dA)
-        constexpr bool ACC_2PASS = (HP >= 128 && NG >= 5);
+#ifndef PINN_F2_ACC_2PASS_ALL
+#define PINN_F2_ACC_2PASS_ALL 0         // (A/B: the two-pass form for every split-GEMM kernel)
+#endif
+        constexpr bool ACC_2PASS = PINN_F2_ACC_2PASS_ALL || (HP >= 128 && NG >= 5);
         auto acc_mode = [&](int bit) -> int { return (PINN_F2_SPLIT_ACC2 & bit) ? (ACC_2PASS ? 2 : 1) : 0; };
 
         // =========================== forward ===========================
