@@ -374,13 +374,17 @@ def solve(prob: OptimizationProblem, alg: Adam, maxiters: int = 1000, callback: 
     chunk = maxiters if callback is None else 50
     if ada.reweight_every > 0:                     # adaptive weights: reweight on the host between chunks of device steps
         chunk = min(chunk, ada.reweight_every)
-    th32 = theta.astype(np.float32)
+    # precision = "f64": theta crosses the ABI in double (pinn_adam_init_f64 / pinn_adam_get_f64), so a chunked run continues from the
+    # exact state; otherwise float32, the device dtype of the north star
+    f64 = eng.get_option("precision") == "f64"
+    step = eng.adam_f64 if f64 else eng.adam
+    th32 = theta.astype(np.float64 if f64 else np.float32)
     while done < maxiters:
         n = min(chunk, maxiters - done)
         if ada.reweight_every > 0:                 # end the chunk where the iteration counter hits a multiple of reweight_every
             it = rep.iteration[0] + done
             n = min(n, ada.reweight_every - (it % ada.reweight_every))
-        th32, hist = eng.adam(th32, n, alg.eta, rep._weights_now(), alg.beta[0], alg.beta[1], alg.epsilon, init=init)
+        th32, hist = step(th32, n, alg.eta, rep._weights_now(), alg.beta[0], alg.beta[1], alg.epsilon, init=init)
         init = False
         losses.append(hist)
         done += n
