@@ -195,6 +195,8 @@ int pinn_set_sampler(pinn_handle h, int term, int kind, const float* lb, const f
  * `additional_loss`, e.g. docs/src/tutorials/param_estim.md:79-95, evaluated inside the fused loss + gradient instead of on the host).
  */
 int pinn_set_point_data(pinn_handle h, int term, const float* data, int ndata, int64_t n);
+/* the same with the observations in double: the float64 evaluation mode reads them as given, the fp32 kernels their float conversion */
+int pinn_set_point_data_f64(pinn_handle h, int term, const double* data, int ndata, int64_t n);
 /*
  * Quadrature weights for the term's current point set: the term's loss becomes  sum_i w[i] * r_i^2  (with sum_i w[i] = 1: a weighted mean,
  * e.g. a tensor Gauss-Legendre rule — (1/area) * integral of r^2, the objective of the reference's QuadratureTraining,
@@ -241,11 +243,17 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
  * "precision" = "f32" (default) | "f64": the FLOAT64 evaluation mode — the reference's default eltype (src/discretize.jl:432-449).  With
  *   "f64", pinn_loss_grad_f64 evaluates natively in double (pinn_loss_grad converts at the boundary) and pinn_lbfgs iterates on the double
  *   objective: what a quasi-Newton stage needs to take an objective below ~1e-7 (test/NNPDE1/nnpde__pde_iii_3rd_order_ode.jl:89-93) and
- *   what parity at TRAINED parameters needs (fp32 cannot hold 1e-5 there).  One lane per point on the fp64 VALU, 10-100x
- *   slower than the fp32 kernels: for the reference's own regime (small nets, 10^2-10^4 points) and finishing stages.  Covers equations of
- *   up to 6 dependent variables (same argument count), Dense chains with tanh / sigmoid / sin, derivative orders <= 2 (1-D: <= 4; 4-D: first and pure second), PDE
- *   parameters, quadrature weights; anything else fails HERE with a message and leaves the fp32 plan usable.  The Adam entry points and the
- *   device-pointer entry points stay fp32.  pinn_set_points_f64 installs a point set in double (the fp32 kernels get its float conversion).
+ *   what parity at TRAINED parameters needs (fp32 cannot hold 1e-5 there).  Kernels: wave-private tiles on
+ *   v_mfma_f64_16x16x4_f64 (csrc/pinn_kernels5.hpp) for tanh / sigmoid nets with hidden layers up to 64 wide and the instantiated jet sets,
+ *   one lane per point on the fp64 VALU (csrc/pinn_kernels4.hpp) for everything else the mode covers; pinn_get_option(h, "f64_path") reports
+ *   what the last evaluation ran ("mfma" | "lanes" | "mfma+lanes").  7-8x the time of the fp32 kernels on the matrix pipe.
+ *   Covers equations of up to 6 dependent variables (same argument count), Dense chains with tanh / sigmoid / sin, derivative orders <= 2
+ *   in 1-3 inputs (1-D, and mixed / pure in 2-D and 3-D where instantiated: <= 4; 4-D: first and pure second), PDE parameters, quadrature
+ *   weights, per-point DATA channels, device samplers; anything else (DGM, periodic embeddings) fails HERE with a message and leaves the fp32
+ *   plan usable.  In this mode EVERY evaluating entry point runs the double kernels: pinn_loss_grad / pinn_loss_grad_device / pinn_loss_device
+ *   / pinn_term_grads convert at the boundary, pinn_adam_* keep theta and the moments in double on the device (pinn_adam_init_f64 /
+ *   pinn_adam_get_f64 hand them over in double), samplers redraw in float and the double copy follows.  pinn_set_points_f64 /
+ *   pinn_set_point_data_f64 install a point set / its observations in double (the fp32 kernels get the float conversion).
  * "persistent" = "on" (default) | "off": pinn_adam_steps runs a SMALL problem — one network of the one-wave-per-tile kernel family, at most
  *   32 workgroups (~2,000 points of a 3 x 32 net), fixed or device-redrawn point sets (pinn_set_sampler), no estimated PDE parameters, no communicator — as ONE persistent launch
  *   per call (csrc/pinn_train.hpp: evaluation, fixed-order reduction, Adam and the weight-image update of every iteration inside the kernel,

@@ -35,7 +35,7 @@ SYMBOLS = [
     "pinn_set_sampler", "pinn_set_point_data", "pinn_set_point_weights", "pinn_get_points", "pinn_adam_init", "pinn_adam_steps", "pinn_adam_get", "pinn_lbfgs",
     "pinn_loss_device", "pinn_group_launched_by",
     "pinn_set_option", "pinn_get_option", "pinn_set_points_f64", "pinn_comm_init_custom", "pinn_adam_steps_sharded", "pinn_adam_apply",
-    "pinn_adam_init_f64", "pinn_adam_get_f64",
+    "pinn_adam_init_f64", "pinn_adam_get_f64", "pinn_set_point_data_f64",
 ]
 
 
@@ -98,6 +98,7 @@ class Library:
         try:                                     # (r05 entry points: A/B variant libraries built before them still load for tools/ab_compare.py)
             L.pinn_adam_init_f64.argtypes = [vp, dp, C.c_int64]
             L.pinn_adam_get_f64.argtypes = [vp, dp, C.c_int64]
+            L.pinn_set_point_data_f64.argtypes = [vp, C.c_int, dp, C.c_int, C.c_int64]
         except AttributeError:
             pass
         L.pinn_lbfgs.argtypes = [vp, C.POINTER(C.c_double), C.c_int64, C.c_int, C.c_int, C.c_double, fp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -355,6 +356,12 @@ class Engine:
         data = _f32(np.atleast_2d(np.asarray(data)))
         self.L.check(self.L.lib.pinn_set_point_data(self.h, term, data.ctypes.data_as(C.POINTER(C.c_float)), data.shape[0], data.shape[1]),
                      "pinn_set_point_data")
+
+    def set_point_data_f64(self, term: int, data):
+        """`pinn_set_point_data_f64`: the observations in double for the float64 evaluation mode (the fp32 kernels get their float conversion)"""
+        data = np.ascontiguousarray(np.atleast_2d(np.asarray(data, dtype=np.float64)))
+        self.L.check(self.L.lib.pinn_set_point_data_f64(self.h, term, data.ctypes.data_as(C.POINTER(C.c_double)), data.shape[0], data.shape[1]),
+                     "pinn_set_point_data_f64")
 
     def set_point_weights(self, term: int, w):
         """quadrature weights of the term's current point set: loss_k = sum_i w_i r_i^2 (None: back to mean(abs2, r))"""

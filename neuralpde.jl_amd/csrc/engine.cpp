@@ -941,7 +941,16 @@ int pinn_set_point_data(pinn_handle h, int term, const float* data, int ndata, i
     T.data_n = n;
     eval_sources(E, T);
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
-    return 0;
+    return f64_set_point_data(E, term, nullptr);         // (float64 mode: the double rows follow)
+}
+int pinn_set_point_data_f64(pinn_handle h, int term, const double* data, int ndata, int64_t n) {
+    if (!h || !data || ndata <= 0 || n <= 0) return fail("pinn_set_point_data_f64: null argument / empty data");
+    std::vector<float> d32((size_t)ndata * (size_t)n);
+    for (size_t i = 0; i < d32.size(); ++i) d32[i] = (float)data[i];
+    if (pinn_set_point_data(h, term, d32.data(), ndata, n)) return 1;           // the fp32 kernels' rows (and every check)
+    if (!h->f64) return 0;
+    DeviceScope scope(h->device);
+    return f64_set_point_data(*h, term, data);                                  // the float64 mode reads the observations as given
 }
 
 int pinn_set_point_weights(pinn_handle h, int term, const float* w, int64_t n) {

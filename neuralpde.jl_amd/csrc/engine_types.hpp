@@ -310,6 +310,7 @@ std::string f64_describe(const pinn_engine& E);
 const char* f64_path(const pinn_engine& E);      // kernels of the last float64 evaluation: "mfma" | "lanes" | "mfma+lanes" | "none" | "off"
 int f64_points_changed(pinn_engine& E, int term);
 int f64_set_points(pinn_engine& E, int term, const double* pts, int64_t n);
+int f64_set_point_data(pinn_engine& E, int term, const double* data);      // nullptr: convert the float rows just installed
 int f64_eval(pinn_engine& E, const double* theta, const double* term_w, double* term_losses, double* grad);
 int f64_adam_init(pinn_engine& E, const double* theta);
 int f64_adam_get(pinn_engine& E, double* theta);

@@ -6,7 +6,7 @@
 // evaluates natively, `pinn_loss_grad` converts at the boundary, `pinn_lbfgs` iterates on the float64 objective.
 // Scope: Dense chains with tanh / sigmoid / sin, equations of one or SEVERAL dependent variables (systems: up to 6 networks per equation, all
 // with the same number of inputs), derivative orders <= 2 in 1-3 inputs (1-D: <= 4; 4-D: first and pure second derivatives), PDE parameters
-// (param_estim), quadrature weights; no periodic embeddings, no DATA channels, no device samplers, no DGM networks.  Anything else fails at pinn_set_option with a message — the fp32 plan of the handle stays usable.
+// (param_estim), quadrature weights, per-point DATA channels, device samplers; no periodic embeddings, no DGM networks.  Anything else fails at pinn_set_option with a message — the fp32 plan of the handle stays usable.
 #include "engine_types.hpp"
 #include "pinn_kernels5.hpp"
 
@@ -34,6 +34,9 @@ struct F64Term {
     double* d_pts = nullptr;             // [n][d] double; converted from the float set unless pinn_set_points_f64 installed it
     int64_t cap = 0, n = 0;
     bool exact_pts = false;              // installed in double (not a conversion of the float set)
+    int ndata = 0;                       // per-point DATA channels of the residual (OP_DATA), valid for the current point set only
+    double* d_data = nullptr;            // [ndata][n]; converted from the float rows unless pinn_set_point_data_f64 installed them
+    int64_t data_cap = 0, data_n = 0;
 };
 struct F64State {
     std::vector<F64Term> terms;
@@ -56,7 +59,7 @@ struct F64State {
 
 static void f64_free(F64State* S) {
     if (!S) return;
-    for (auto& T : S->terms) { plat_free(T.d_prog); plat_free(T.d_imm); plat_free(T.d_pts); }
+    for (auto& T : S->terms) { plat_free(T.d_prog); plat_free(T.d_imm); plat_free(T.d_pts); plat_free(T.d_data); }
     plat_free(S->d_theta); plat_free(S->d_grad); plat_free(S->d_sumsq); plat_free(S->d_scratch); plat_free(S->d_slab);
     plat_free(S->d_m); plat_free(S->d_v); plat_free(S->d_w_over_n); plat_free(S->d_hist);
     delete S;
@@ -92,6 +95,7 @@ static const pk::F64Kernel* f64_find(int D, const std::vector<Slot>& slots, std:
 static int f64_convert_points(pinn_engine& E, F64Term& F, const Term& T) {
     // the float set as installed -> double (exact conversion of the fp32 values the fp32 kernels read)
     const int64_t n = T.n;
+    F.data_n = 0;                                        // (per-point data belong to the previous set)
     if (n <= 0 || !T.d_pts) { F.n = 0; return 0; }
     std::vector<float> h((size_t)n * T.d);
     if (plat_d2h(h.data(), T.d_pts, sizeof(float) * h.size(), E.stream) || plat_sync(E.stream)) return fail("D2H copy of points failed");
@@ -105,6 +109,30 @@ static int f64_convert_points(pinn_engine& E, F64Term& F, const Term& T) {
     if (plat_h2d(F.d_pts, hd.data(), sizeof(double) * hd.size(), E.stream) || plat_sync(E.stream)) return fail("H2D copy of points failed");
     F.n = n;
     F.exact_pts = false;
+    return 0;
+}
+
+// the term's DATA rows in double: `src` given in double (pinn_set_point_data_f64), or the conversion of the float rows as installed
+static int f64_install_data(pinn_engine& E, F64Term& F, const Term& T, const double* src) {
+    const int64_t n = T.n;
+    if (F.ndata == 0 || n <= 0) return 0;
+    std::vector<double> hd;
+    if (!src) {
+        if (!T.d_data || T.data_n != n) { F.data_n = 0; return 0; }
+        std::vector<float> h((size_t)F.ndata * n);
+        if (plat_d2h(h.data(), T.d_data, sizeof(float) * h.size(), E.stream) || plat_sync(E.stream)) return fail("D2H copy of point data failed");
+        hd.assign(h.begin(), h.end());
+        src = hd.data();
+    }
+    if (F.data_cap < n) {
+        plat_sync(E.stream);
+        plat_free(F.d_data);
+        F.d_data = (double*)plat_malloc(sizeof(double) * (size_t)F.ndata * n);
+        if (!F.d_data) { F.data_cap = 0; return fail("device allocation failed (float64 point data)"); }
+        F.data_cap = n;
+    }
+    if (plat_h2d(F.d_data, src, sizeof(double) * (size_t)F.ndata * n, E.stream) || plat_sync(E.stream)) return fail("H2D copy of point data failed");
+    F.data_n = n;
     return 0;
 }
 
@@ -139,7 +167,7 @@ int f64_enable(pinn_engine& E) {
         if (T.d > 4 || E.nets[nets[0]].sizes[0] > 4) return fail(who + "more than 4 coordinates");
         if ((int)T.slots.size() > pk::F64_MAX_SLOTS || T.d + E.np + (int)T.slots.size() + (int)T.ops.size() > pk::F64_MAX_ROWS)
             return fail(who + "residual expression too long for the float64 tape (96 rows)");
-        for (auto& I : T.ops) if (I.code == rp::OP_DATA) return fail(who + "per-point DATA channels are not covered by the float64 mode");
+        F.ndata = E.terms[t].ndata;                      // (OP_DATA rows stay in this mode's tape: the float path hoists them into source channels)
         std::string why;
         F.k = f64_find(E.nets[nets[0]].sizes[0], T.slots, F.slot_chan, why);
         if (!F.k) return fail(who + why);
@@ -172,6 +200,7 @@ int f64_enable(pinn_engine& E) {
             if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
         }
         if (f64_convert_points(E, F, E.terms[t])) return 1;
+        if (f64_install_data(E, F, E.terms[t], nullptr)) return 1;
     }
     const int K = (int)E.terms.size();
     S->d_theta = (double*)plat_malloc(sizeof(double) * E.ntheta);
@@ -207,6 +236,13 @@ int f64_set_points(pinn_engine& E, int term, const double* pts, int64_t n) {
     return 0;
 }
 
+// pinn_set_point_data while the mode is on: the double rows follow (data == nullptr: converted from the float rows just installed)
+int f64_set_point_data(pinn_engine& E, int term, const double* data) {
+    if (!E.f64) return 0;
+    F64State& S = *(F64State*)E.f64;
+    return f64_install_data(E, S.terms[term], E.terms[term], data);
+}
+
 static int f64_eval_device(pinn_engine& E, const double* term_w, bool want_grad);
 
 int f64_eval(pinn_engine& E, const double* theta, const double* term_w, double* term_losses, double* grad) {
@@ -233,6 +269,9 @@ static int f64_eval_device(pinn_engine& E, const double* term_w, bool want_grad)
     const double* grad = want_grad ? S.d_grad : nullptr;         // (non-null = evaluate the gradient)
     for (int t = 0; t < K; ++t)
         if (S.terms[t].n <= 0 || S.terms[t].n != E.terms[t].n) return fail("term " + std::to_string(t) + " has no collocation points (call pinn_set_points first)");
+    for (int t = 0; t < K; ++t)
+        if (S.terms[t].ndata > 0 && S.terms[t].data_n != S.terms[t].n)
+            return fail("term " + std::to_string(t) + " uses per-point data channels but none are installed for its current point set (call pinn_set_point_data after pinn_set_points)");
     plat_memset(S.d_grad, 0, sizeof(double) * P, E.stream);
     plat_memset(S.d_sumsq, 0, sizeof(double) * K, E.stream);
     S.path = 0;
@@ -242,6 +281,7 @@ static int f64_eval_device(pinn_engine& E, const double* term_w, bool want_grad)
         F64Term& F = S.terms[t];
         pk::F64Args a;
         std::memset(&a, 0, sizeof a);
+        a.data = F.ndata > 0 ? F.d_data : nullptr;
         a.theta = S.d_theta; a.pts = F.d_pts; a.pw = (T.pw_n == T.n && T.pw_n > 0) ? T.d_pw : nullptr;
         a.N = (int)F.n; a.dt = T0.d;
         a.nnets = (int)F.nets.size();

@@ -43,6 +43,7 @@ struct F64Args {
     const double* theta;                // the whole parameter vector
     const double* pts;                  // [N][dt] point-major
     const float* pw;                    // per-point factors sqrt(N w_i) of a quadrature-weighted term, nullable
+    const double* data;                 // [ndata][N] user-supplied per-point channels of the term (OP_DATA: observations of a data-misfit term), nullable
     int N, p0, npts;                    // points of the term; first point and point count of this launch (one chunk)
     int dt;                             // coordinates per point of the term
     int nnets;                          // networks the equation references (all with the same number of inputs: one jet set serves them)
@@ -159,7 +160,7 @@ DEV void f64_point(int lp, const F64Args& a) {
         const rp::Instr ins = a.prog[q];
         const double va = rp::is_nullary(ins.code) ? 0.0 : v[ins.a];
         const double vb = rp::is_binary(ins.code) ? v[ins.b] : 0.0;
-        v[R0 + q] = rp::apply<double, double>(ins.code, va, vb, a.imm[q]);
+        v[R0 + q] = (ins.code == rp::OP_DATA) ? a.data[(size_t)(int)a.imm[q] * (size_t)a.N + (size_t)p] : rp::apply<double, double>(ins.code, va, vb, a.imm[q]);
     }
     const double r = v[a.out_row];
     if (a.mode == 2) { a.resid[p] = r; return; }

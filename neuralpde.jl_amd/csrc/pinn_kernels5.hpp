@@ -242,7 +242,7 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                 const rp::Instr ins = a.prog[o];
                 const double va = rp::is_nullary(ins.code) ? 0.0 : v[ins.a];
                 const double vb = rp::is_binary(ins.code) ? v[ins.b] : 0.0;
-                v[R0 + o] = rp::apply<double, double>(ins.code, va, vb, a.imm[o]);
+                v[R0 + o] = (ins.code == rp::OP_DATA) ? a.data[(size_t)(int)a.imm[o] * (size_t)a.N + (size_t)gp] : rp::apply<double, double>(ins.code, va, vb, a.imm[o]);
             }
             const double r = v[a.out_row];
             if (a.mode == 2) { if (wr) a.resid[gp] = r; continue; }

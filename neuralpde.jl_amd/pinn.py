@@ -577,7 +577,7 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
 
     f64 = getattr(discretization, "precision", "f32") == "f64"
     if f64:
-        engine.set_option("precision", "f64")           # (fails with the reason for what the mode does not cover: DGM, embeddings, data terms)
+        engine.set_option("precision", "f64")           # (fails with the reason for what the mode does not cover: DGM, embeddings)
     install(pde_sets, bc_sets)
     if getattr(strategy, "point_weights", None) is not None and strategy.point_weights() is not None:
         for k, w in enumerate(strategy.point_weights()):           # quadrature strategies: loss_k = sum_i w_i r_i^2
@@ -585,8 +585,8 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
     n_data = len(sym_data)
     data_sets = [np.asarray(dl.points, dtype=np.float64) for dl in discretization.data_loss]
     for j, dl in enumerate(discretization.data_loss):                    # fixed sets + their observations, installed once
-        engine.set_points(n_pde + n_bc + j, data_sets[j])
-        engine.set_point_data(n_pde + n_bc + j, np.asarray(dl.values, dtype=np.float64).reshape(1, -1))
+        (engine.set_points_f64 if f64 else engine.set_points)(n_pde + n_bc + j, data_sets[j])
+        (engine.set_point_data_f64 if f64 else engine.set_point_data)(n_pde + n_bc + j, np.asarray(dl.values, dtype=np.float64).reshape(1, -1))
     state = {"pde_sets": pde_sets, "bc_sets": bc_sets, "cache_theta": None, "cache": None, "resample": resample}
 
     adaloss = discretization.adaptive_loss or NonAdaptiveLoss()

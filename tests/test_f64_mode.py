@@ -321,3 +321,59 @@ def test_mirror_solve_adam_keeps_theta_in_double(npde, use_emu):
     assert whole.u.dtype == np.float64 and np.any(whole.u != whole.u.astype(np.float32))
     assert np.array_equal(whole.u, chunks.u) and np.array_equal(whole.losses, chunks.losses)
     assert whole.losses[-1] < whole.losses[0]
+
+
+def test_f64_mode_data_misfit_term_and_estimated_parameter(npde, use_emu):
+    """A Float64 inverse problem (test/NNPDE2/additional_loss__lorenz_system.jl:66-77 / docs/src/tutorials/param_estim.md:79-95 in the
+    reference's default eltype): PDE parameter in theta, observations as per-point DATA channels of a device-side misfit term
+    (pinn_set_point_data_f64).  Against (a) the oracle's network values at the observation points, (b) the same objective with the misfit
+    as a host-side float64 `additional_loss` (torch autograd) — value and gradient to 1e-11, where the fp32 mode's bar is 1e-5
+    (tests/test_reference_examples.py::test_data_misfit_terms_on_device)."""
+    import torch
+    import pinn_oracle as po
+    t, x = npde.parameters("t x")
+    (u,) = npde.variables("u")
+    (k,) = npde.parameters("k")
+    Dt, Dxx = npde.Differential(t), npde.Differential(x) ** 2
+    eq = npde.Eq(Dt(u(t, x)), k * Dxx(u(t, x)))
+    bcs = [npde.Eq(u(0, x), sp.sin(sp.pi * x)), npde.Eq(u(t, 0), 0.0)]
+    dom = [npde.In(t, npde.Interval(0.0, 1.0)), npde.In(x, npde.Interval(0.0, 1.0))]
+    chain = npde.Chain(npde.Dense(2, 16, "tanh"), npde.Dense(16, 16, "tanh"), npde.Dense(16, 1))
+    th = npde.initialparameters(np.random.default_rng(171), chain)
+    mk = lambda: npde.QuasiRandomTraining(40, bcs_points=16, sampling_alg=npde.SobolSample(seed=8), resampling=False, minibatch=1)
+    pts = np.random.default_rng(3).uniform(size=(2, 37))
+    vals = np.exp(-0.3 * np.pi ** 2 * pts[0]) * np.sin(np.pi * pts[1])
+    sysm = npde.PDESystem([eq], bcs, dom, [t, x], [u(t, x)], ps=[k], defaults={k: 0.7})
+    weights = npde.NonAdaptiveLoss(pde_loss_weights=1.0, bc_loss_weights=2.0, additional_loss_weights=0.5)
+    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, mk(), init_params=th, param_estim=True, precision="f64", adaptive_loss=weights,
+                                                        data_loss=[npde.DataLoss(u(t, x), pts, vals, weight=3.0)]))
+    rep = prob.pinnrep
+    assert rep.engine.get_option("precision") == "f64"
+    theta = rep.flat_init_params
+    oc = po.Chain(tuple(chain.sizes), chain.act)
+    u_at = po.phi_values(oc, theta[:chain.nparams], pts).reshape(-1)
+    dl = rep.loss_functions.data_loss_functions[0](theta)
+    assert abs(dl - np.mean((u_at - vals) ** 2)) < 1e-12 * dl
+
+    def additional(phi, th_net, p):
+        tt = torch.tensor(np.asarray(th_net), dtype=torch.float64, requires_grad=True)
+        out = oc(torch.tensor(pts, dtype=torch.float64), tt).reshape(-1)
+        val = 3.0 * torch.mean((out - torch.tensor(vals, dtype=torch.float64)) ** 2)
+        (gr,) = torch.autograd.grad(val, tt)
+        return float(val.detach()), np.concatenate([gr.numpy(), np.zeros(1)])
+    prob_h = npde.discretize(sysm, npde.PhysicsInformedNN(chain, mk(), init_params=th, param_estim=True, precision="f64", adaptive_loss=weights,
+                                                          additional_loss=additional))
+    v_d, g_d = prob.f.value_and_grad(theta)
+    v_h, g_h = prob_h.f.value_and_grad(theta)
+    print(f"float64 inverse problem: objective {v_d:.12e} (host misfit {v_h:.12e}), gradient rel L2 {np.linalg.norm(g_d - g_h) / np.linalg.norm(g_h):.2e}")
+    assert abs(v_d - v_h) < 1e-11 * abs(v_h)
+    assert np.linalg.norm(g_d - g_h) < 1e-11 * np.linalg.norm(g_h)
+    assert g_d[-1] != 0.0                                   # (the estimated parameter's slot)
+    # points re-installed without their observations: refused, as in the fp32 mode
+    rep.engine.set_points_f64(3, pts)
+    with pytest.raises(RuntimeError, match="per-point data"):
+        rep.engine.loss_grad_f64(theta)
+    rep.engine.set_point_data_f64(3, vals[None, :])
+    assert abs(rep.engine.loss_grad_f64(theta, want_grad=False)[0][3] - dl) < 1e-13 * dl
+    res = npde.solve(prob, npde.Adam(0.01), maxiters=30)
+    assert res.u.dtype == np.float64 and res.losses[-1] < res.losses[0]

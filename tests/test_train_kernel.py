@@ -3,7 +3,11 @@ reduction, update and weight-image scatter per iteration, two grid barriers — 
 Same arithmetic and association: bit-identical parameters and loss histories, across a resume.  Runs the kernel SOURCES on the host
 emulation (every wave of the launch a thread); the GPU mirror is tests/test_gpu_mirror.py::test_persistent_training_kernel_*.
 Reference loop: solve(prob, Adam(..); maxiters = ...) over full_loss_function (test/NNPDE1/nnpde__pde_ii_2d_poisson.jl:83-85,
-src/discretize.jl:567-598)."""
+src/discretize.jl:567-598).
+
+What this file pins is kernel == loop (the engine against itself).  The chain to the oracle runs through the loop: its evaluation against the float64
+oracle (tests/test_emu_parity.py, tests/test_gpu_parity.py) and its Adam trajectory against a host float64 Adam over oracle gradients
+(tests/test_emu_parity.py::test_resident_adam_matches_host_adam_and_sampler)."""
 import numpy as np
 import pytest
 
