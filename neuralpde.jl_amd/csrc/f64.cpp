@@ -47,6 +47,8 @@ struct F64State {
     size_t scratch_cap = 0;
     double* d_slab = nullptr;
     size_t slab_cap = 0;
+    double* d_tpart = nullptr;           // matrix-pipe kernels: per-tile partial sums of the first / last layer entries (F64Args::tpart)
+    size_t tpart_cap = 0;
     std::vector<double> h_out;           // host staging [P + K]
     double* d_m = nullptr;               // optimiser moments of the float64 Adam loop (f64_adam_*), allocated on first use
     double* d_v = nullptr;
@@ -60,7 +62,7 @@ struct F64State {
 static void f64_free(F64State* S) {
     if (!S) return;
     for (auto& T : S->terms) { plat_free(T.d_prog); plat_free(T.d_imm); plat_free(T.d_pts); plat_free(T.d_data); }
-    plat_free(S->d_theta); plat_free(S->d_grad); plat_free(S->d_sumsq); plat_free(S->d_scratch); plat_free(S->d_slab);
+    plat_free(S->d_theta); plat_free(S->d_grad); plat_free(S->d_sumsq); plat_free(S->d_scratch); plat_free(S->d_slab); plat_free(S->d_tpart);
     plat_free(S->d_m); plat_free(S->d_v); plat_free(S->d_w_over_n); plat_free(S->d_hist);
     delete S;
 }
@@ -312,6 +314,8 @@ static int f64_eval_device(pinn_engine& E, const double* term_w, bool want_grad)
             sin_act = sin_act || N.act == pk::ACT_SIN;
             n.theta0 = N.theta_off; n.nparams = N.nparams(); n.ent0 = ent;
             ent += n.nparams;
+            n.tp0 = a.tp_p;                                       // (running column count of the tile partial sums)
+            a.tp_p += (n.d + 1) * N.sizes[1] + N.sizes[n.nl - 1] + 1;
             // scratch rows: per hidden layer record / post-activation jets / dZ, then this network's seeds
             const int L = n.nl - 1;
             for (int l = 0; l < L; ++l) { n.r_rec[l] = rows; rows += N.sizes[l + 1] * a.C; }
@@ -362,13 +366,25 @@ static int f64_eval_device(pinn_engine& E, const double* term_w, bool want_grad)
             if (!S.d_slab) return fail("device allocation failed (float64 slabs)");
         }
         a.scratch = S.d_scratch; a.npad = (int)chunk; a.slab = S.d_slab; a.nrows = rows;
+        if (mfma) {
+            a.ntp = a.tp_p + E.ne + 1;
+            a.tile_pts = 16 * F.km->PG;
+            const size_t tneed = (size_t)(chunk / a.tile_pts + 1) * (size_t)a.ntp;
+            if (tneed > S.tpart_cap) {
+                plat_sync(E.stream);
+                plat_free(S.d_tpart);
+                S.d_tpart = (double*)plat_malloc(sizeof(double) * tneed);
+                S.tpart_cap = S.d_tpart ? tneed : 0;
+                if (!S.d_tpart) return fail("device allocation failed (float64 tile sums)");
+            }
+            a.tpart = S.d_tpart;
+        }
         for (int64_t p0 = 0; p0 < F.n; p0 += chunk) {
             a.p0 = (int)p0;
             a.npts = (int)std::min<int64_t>(chunk, F.n - p0);
             if (mfma) F.km->launch_tile(a, E.stream);
             else F.k->launch_point(a, sin_act, E.stream);
-            if (mfma) pk::launch_f64m_dw(a, E.stream);
-            else pk::launch_f64_dw(a, E.stream);
+            if (!mfma) pk::launch_f64_dw(a, E.stream);           // (matrix-pipe path: those entries come out of the tile kernel, summed in the dW launch)
             if (mfma) F.km->launch_dwt(a, E.stream);
             else pk::launch_f64_dwt(a, E.stream);
             pk::F64ReduceArgs r;

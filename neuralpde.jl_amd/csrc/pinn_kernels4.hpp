@@ -38,6 +38,8 @@ struct F64Net {
     int r_ubar;                         // seeds d(loss)/d(jet channel) of this network [C]
     int act;                            // ACT_TANH / ACT_SIGMOID / ACT_SIN
     int theta0, nparams, ent0;          // the network's slice of theta; its first slab entry
+    int tp0;                            // matrix-pipe kernels: first column of this network in a tile's row of partial sums (F64Args::tpart):
+                                        // [W_0: n_1 * d][b_0: n_1][W_L: n_L][b_L]
 };
 struct F64Args {
     const double* theta;                // the whole parameter vector
@@ -67,6 +69,11 @@ struct F64Args {
     int C, first_ch[8];                 // channel of d/dx_i (-1: not carried)
     double* slab;                       // [nblocks][nent], nent = sum of the networks' parameters + ne + 1 (last entry: the block's sum of squares)
     int nent, ent_p;                    // ent_p: first PDE-parameter entry
+    // matrix-pipe kernels (pinn_kernels5.hpp): the tile kernel leaves the sums of everything that is not a hidden-to-hidden weight / bias — first and
+    // last layer, PDE parameters, the squared residuals — per TILE: [tiles][ntp], columns = the networks' blocks (F64Net::tp0), then [ne] PDE
+    // parameters, then the sum of squares; f64m_tsum_entry adds a block's tiles in order into the slab
+    double* tpart;
+    int ntp, tp_p, tile_pts;            // columns per tile; first PDE-parameter column; points per tile (16 * PG)
 };
 
 // ---- kernel A: forward jets of every network, residual tape, reverse sweep of ONE point ----

@@ -13,8 +13,11 @@
 //   * k_f64m_dwt: the hidden-to-hidden weight gradients dW = dZ A^T (and those layers' bias gradients) as MFMAs over the scratch rows
 //     (k = 16 consecutive points of one channel), one workgroup of four waves per (512-point block, layer), each wave a quarter of the block's
 //     points and every output x input tile of the layer in registers, combined through LDS in wave order, written into the block's slab.
-// Records / post-activation jets / dZ go through the same point-major scratch rows as family 4's (so family 4's k_f64_dw — biases, first and
-// last layer, PDE parameters, the sum of squares — and k_f64_reduce run unchanged behind it).
+//     One more workgroup row of the same launch adds the tile kernel's per-tile sums (below) into the slab.
+// Records / post-activation jets / dZ of the hidden-to-hidden GEMMs go through scratch rows numbered as family 4's, laid out point-block-major
+// (f64m_six).  What family 4's k_f64_dw reads back from rows — first and last layer, output bias, PDE parameters, the sum of squares — the tile
+// kernel sums over its own points while the operands are in registers (F64Args::tpart: one row of partial sums per tile): the first layer's dZ
+// rows, the last hidden layer's activation rows and the seed / parameter / residual rows are never written.
 // Eligibility (f64.cpp): tanh / sigmoid networks with at least one hidden layer, hidden widths <= 16 * HT of an instantiated (jet set, HT)
 // pair; everything else keeps family 4.  PINN_F64_NO_MFMA=1 keeps family 4 everywhere (A/B, tests).
 #pragma once
@@ -58,6 +61,18 @@ template <int N> inline void lv_qsum(LVd<N>& X, int i) {
         for (int q = 0; q < 4; ++q) X(j + 16 * q, i) = s;
     }
 }
+// sum over the sixteen lanes that share lane >> 4 (the 16 points of a tile row), in every one of them: the device's four DPP row rotations
+template <int N> inline void lv_rowsum(LVd<N>& X, int i) {
+    for (int q = 0; q < 4; ++q) {
+        double t[16], u[16];
+        for (int j = 0; j < 16; ++j) t[j] = X(16 * q + j, i);
+        for (int o = 8; o >= 1; o >>= 1) {
+            for (int j = 0; j < 16; ++j) u[j] = t[j] + t[(j - o) & 15];
+            for (int j = 0; j < 16; ++j) t[j] = u[j];
+        }
+        for (int j = 0; j < 16; ++j) X(16 * q + j, i) = t[j];
+    }
+}
 #else
 template <int N> struct LVd {
     double v[N];
@@ -76,6 +91,17 @@ template <int N> DEV void lv_qsum(LVd<N>& X, int i) {
     const double x = X.v[i];
     const double y = x + __shfl_xor(x, 16, 64);          // (q ^ 1)
     X.v[i] = y + __shfl_xor(y, 32, 64);                  // same association as the emulation: (x0 + x1) + (x2 + x3)
+}
+template <int CTRL> DEV double dpp_mov_d(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xF, 0xF, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <int N> DEV void lv_rowsum(LVd<N>& X, int i) {  // row_ror 8, 4, 2, 1 (vec.hpp: row_allsum16): VALU only, no LDS crossbar
+    double v = X.v[i];
+    v += dpp_mov_d<0x128>(v); v += dpp_mov_d<0x124>(v); v += dpp_mov_d<0x122>(v); v += dpp_mov_d<0x121>(v);
+    X.v[i] = v;
 }
 #endif
 
@@ -104,6 +130,10 @@ DEV void f64m_tile(int tile, const F64Args& a) {
     double* S = a.scratch;
     LVd<NR * NCG> X, Z;                                          // X: operand of the next GEMM (a jets / dZ); Z: its result (z jets / G)
     LVd<F64_MAX_NETS * NCG> U;                                   // every network's output jets (forward), then their seeds (reverse)
+    // value-only terms of ONE tanh / sigmoid network: the last hidden layer's activations are still in X when the reverse sweep starts (the output
+    // layer and the tape read X / U only) and the record of such an element is its activation: that layer's rows never go to memory
+    const bool keep_last = a.nnets == 1 && C == 1 && a.post_alias != 0;
+    double* TP = a.tpart + (size_t)tile * (size_t)a.ntp;         // this tile's row of partial sums (F64Args::tpart)
     // =========================== forward ===========================
     for (int ni = 0; ni < a.nnets; ++ni) {
         const F64Net& n = a.net[ni];
@@ -190,12 +220,14 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                         PINN_UNROLL for (int c = 0; c < C; ++c) z[c] = Z(l, tr * NCG + pg * C + c);
                         const double a0 = (PINN_F64M_PROBE & 4) ? z[0] * 0.5 : act_value<SIN>(n.act, z[0]);
                         z[0] = act_record<SIN>(z[0], a0);
-                        if (st) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)m * C + c, p)] = z[c]; }
+                        // the LAST hidden layer's rows have one reader left, this wave's reverse sweep (its post-activation jets fed the output
+                        // weights' gradient, which the reverse sweep now forms itself): no post rows, and no record either where X keeps it
+                        if (st && !(keep_last && lyr == L - 1)) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)m * C + c, p)] = z[c]; }
                         double dd[ND];
                         act_derivs_n<J::NORD - 1, SIN>(n.act, z[0], dd);
                         jet_forward<J>(z, dd);
                         z[0] = a0;
-                        if (st && !a.post_alias) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_post[lyr] + (size_t)m * C + c, p)] = z[c]; }
+                        if (st && !a.post_alias && lyr != L - 1) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_post[lyr] + (size_t)m * C + c, p)] = z[c]; }
                         PINN_UNROLL for (int c = 0; c < C; ++c) X(l, tr * NCG + pg * C + c) = valid ? z[c] : 0.0;
                     }
                 }
@@ -223,6 +255,8 @@ DEV void f64m_tile(int tile, const F64Args& a) {
         }
     }
     // =========================== residual tape (per point; the four lanes of a point run it redundantly, lane group 0 writes) ===========================
+    LVd<1 + MAX_PARAMS> TS;                                      // lane group 0, lane j: squared weighted residual / PDE-parameter partials of its points
+    PINN_LANES(l) { PINN_UNROLL for (int e = 0; e < 1 + MAX_PARAMS; ++e) TS(l, e) = 0.0; }
     PINN_LANES(l) {
         const int q = l >> 4, j = l & 15;
         const int R0 = a.dt + a.np + a.nslots;
@@ -248,7 +282,7 @@ DEV void f64m_tile(int tile, const F64Args& a) {
             if (a.mode == 2) { if (wr) a.resid[gp] = r; continue; }
             const double sw = a.pw ? (double)a.pw[gp] : 1.0;
             const double rs = r * sw;
-            if (wr) S[f64m_six(a, (size_t)a.r_sq, p)] = rs * rs;
+            if (wr) TS(l, 0) += rs * rs;
             if (a.mode == 1) continue;
             double g[F64_MAX_ROWS];
             for (int o = 0; o < R0 + a.nops; ++o) g[o] = 0.0;
@@ -263,7 +297,7 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                 if (rp::is_binary(ins.code)) g[ins.b] += db;
             }
             const double rbar = live ? rs * a.scale * sw : 0.0;
-            if (wr) for (int k = 0; k < a.ne; ++k) S[f64m_six(a, (size_t)a.r_pbar + k, p)] = rbar * g[a.dt + k];
+            PINN_UNROLL for (int k = 0; k < MAX_PARAMS; ++k) if (wr && k < a.ne) TS(l, 1 + k) += rbar * g[a.dt + k];
             // the seeds of every network's output jets replace its outputs in U
             for (int ni = 0; ni < a.nnets; ++ni) {
                 double ub[C];
@@ -273,14 +307,32 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                     const double gs = rbar * g[a.dt + a.np + s];
                     PINN_UNROLL for (int c = 0; c < C; ++c) if (a.slot_chan[s] == c) ub[c] += gs;
                 }
-                PINN_UNROLL for (int c = 0; c < C; ++c) {
-                    U(l, ni * NCG + pg * C + c) = ub[c];
-                    if (wr) S[f64m_six(a, (size_t)a.net[ni].r_ubar + c, p)] = ub[c];
-                }
+                PINN_UNROLL for (int c = 0; c < C; ++c) U(l, ni * NCG + pg * C + c) = ub[c];
+            }
+        }
+    }
+    // the tile's sums of the per-point scalars: sum of squares, PDE-parameter partials, every network's output-bias gradient (= sum of its value seeds)
+    if (a.mode != 2) {
+        PINN_UNROLL for (int e = 0; e < 1 + MAX_PARAMS; ++e) { if (e > a.ne) break; lv_rowsum(TS, e); }
+        PINN_LANES(l) {
+            if (l == 0) {
+                TP[a.tp_p + a.ne] = TS(l, 0);
+                PINN_UNROLL for (int k = 0; k < MAX_PARAMS; ++k) if (k < a.ne && a.mode == 0) TP[a.tp_p + k] = TS(l, 1 + k);
             }
         }
     }
     if (a.mode != 0) return;
+    for (int ni = 0; ni < a.nnets; ++ni) {
+        const F64Net& n = a.net[ni];
+        LVd<1> bl;
+        PINN_LANES(l) {
+            double t = 0.0;
+            PINN_UNROLL for (int pg = 0; pg < PG; ++pg) t += U(l, ni * NCG + pg * C);
+            bl(l, 0) = (l >> 4) == 0 ? t : 0.0;                   // (the four lane groups of a point hold the same seeds)
+        }
+        lv_rowsum(bl, 0);
+        PINN_LANES(l) { if (l == 0) TP[n.tp0 + (n.d + 1) * n.sizes[1] + n.sizes[n.nl - 1]] = bl(l, 0); }
+    }
     // =========================== reverse sweep, network by network ===========================
     for (int ni = 0; ni < a.nnets; ++ni) {
         const F64Net& n = a.net[ni];
@@ -323,32 +375,86 @@ DEV void f64m_tile(int tile, const F64Args& a) {
             }
             // this layer's records into X (dead after the GEMM above): every load in flight before the first use — behind the stores of the
             // adjoint loop below the compiler could not hoist them (same scratch pointer), and each would expose a memory round trip
-            PINN_LANES(l) {
-                const int q = l >> 4, j = l & 15;
-                PINN_UNROLL for (int tr = 0; tr < NR; ++tr) {
-                    const int k = 16 * (tr >> 2) + 4 * (tr & 3) + q, kc = k < H ? k : H - 1;
-                    PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
-                        const int p = pbase + 16 * pg + j, pc = p < a.npts ? p : a.npts - 1;
-                        PINN_UNROLL for (int c = 0; c < C; ++c) X(l, tr * NCG + pg * C + c) = S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)kc * C + c, pc)];
+            if (!(keep_last && lyr == L - 1)) {
+                PINN_LANES(l) {
+                    const int q = l >> 4, j = l & 15;
+                    PINN_UNROLL for (int tr = 0; tr < NR; ++tr) {
+                        const int k = 16 * (tr >> 2) + 4 * (tr & 3) + q, kc = k < H ? k : H - 1;
+                        PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                            const int p = pbase + 16 * pg + j, pc = p < a.npts ? p : a.npts - 1;
+                            PINN_UNROLL for (int c = 0; c < C; ++c) X(l, tr * NCG + pg * C + c) = S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)kc * C + c, pc)];
+                        }
                     }
                 }
             }
-            PINN_LANES(l) {
-                const int q = l >> 4, j = l & 15;
-                PINN_UNROLL for (int tr = 0; tr < NR; ++tr) {
+            // first hidden layer: the network's inputs at this lane's points, for dW_0 = sum_p dZ_0 x^T
+            LVd<PG * 4> XI;
+            if (lyr == 0) {
+                PINN_LANES(l) {
+                    PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                        const int p = pbase + 16 * pg + (l & 15), pc = p < a.npts ? p : a.npts - 1;
+                        PINN_UNROLL for (int i = 0; i < 4; ++i) XI(l, pg * 4 + i) = i < n.d ? a.pts[(size_t)(a.p0 + pc) * a.dt + n.imap[i]] : 0.0;
+                    }
+                }
+            }
+            // one tile row (four neurons x 16 points x PG) at a time: adjoint of the activation, then — first / last hidden layer — the row's
+            // sums over the tile's points of what the input / output weights' gradients need (the rows never leave the wave: no dZ_0 rows, no
+            // re-read of the last layer's activations by another kernel)
+            PINN_UNROLL for (int tr = 0; tr < NR; ++tr) {
+                LVd<6> T6;                                           // [0, d) dW_0[m][i], [4] db_0[m], [5] dW_L[m]
+                PINN_LANES(l) {
+                    const int q = l >> 4, j = l & 15;
                     const int k = 16 * (tr >> 2) + 4 * (tr & 3) + q;
                     const bool valid = k < H;
+                    double t6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
                     PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
                         const int p = pbase + 16 * pg + j;
                         const bool st = valid && p < a.npts;
-                        const bool st2 = valid && !(PINN_F64M_PROBE & 2);
+                        const bool st2 = valid && lyr != 0 && !(PINN_F64M_PROBE & 2);
                         double s[C], gq[C], dd[ND];
                         PINN_UNROLL for (int c = 0; c < C; ++c) s[c] = X(l, tr * NCG + pg * C + c);
                         PINN_UNROLL for (int c = 0; c < C; ++c) gq[c] = Z(l, tr * NCG + pg * C + c);
                         act_derivs_n<J::NORD, SIN>(n.act, s[0], dd);
+                        if (lyr == L - 1) {                          // dW_L[k] += sum_c ubar_c * (post-activation jet c of neuron k): the forward rule on the record
+                            double pz[C];
+                            PINN_UNROLL for (int c = 0; c < C; ++c) pz[c] = s[c];
+                            jet_forward<J>(pz, dd);
+                            pz[0] = SIN ? act_value<SIN>(n.act, s[0]) : s[0];
+                            double t2 = 0.0;
+                            PINN_UNROLL for (int c = 0; c < C; ++c) t2 = vfma(U(l, ni * NCG + pg * C + c), pz[c], t2);
+                            t6[5] += st ? t2 : 0.0;
+                        }
                         jet_adjoint<J>(gq, s, dd);
                         if (st2) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_dz[lyr] + (size_t)k * C + c, p)] = gq[c]; }
                         PINN_UNROLL for (int c = 0; c < C; ++c) X(l, tr * NCG + pg * C + c) = st ? gq[c] : 0.0;
+                        if (lyr == 0) {
+                            const double z0 = st ? gq[0] : 0.0;
+                            t6[4] += z0;
+                            PINN_UNROLL for (int i = 0; i < 4; ++i) {
+                                if (i >= n.d) break;
+                                double t2 = z0 * XI(l, pg * 4 + i);
+                                const int ck = a.first_ch[i];
+                                PINN_UNROLL for (int c = 1; c < C; ++c) if (c == ck) t2 += st ? gq[c] : 0.0;
+                                t6[i] += t2;
+                            }
+                        }
+                    }
+                    PINN_UNROLL for (int i = 0; i < 6; ++i) T6(l, i) = t6[i];
+                }
+                if (lyr == 0) {
+                    PINN_UNROLL for (int i = 0; i < 4; ++i) { if (i >= n.d) break; lv_rowsum(T6, i); }
+                    lv_rowsum(T6, 4);
+                }
+                if (lyr == L - 1) lv_rowsum(T6, 5);
+                PINN_LANES(l) {
+                    const int k = 16 * (tr >> 2) + 4 * (tr & 3) + (l >> 4);
+                    if ((l & 15) == 0 && k < H) {
+                        const int n1 = n.sizes[1];
+                        if (lyr == 0) {
+                            PINN_UNROLL for (int i = 0; i < 4; ++i) if (i < n.d) TP[n.tp0 + i * n1 + k] = T6(l, i);
+                            TP[n.tp0 + n.d * n1 + k] = T6(l, 4);
+                        }
+                        if (lyr == L - 1) TP[n.tp0 + (n.d + 1) * n1 + k] = T6(l, 5);
                     }
                 }
             }
@@ -471,74 +577,34 @@ HD bool f64m_dwt_locate(int idx, const F64Args& a, int& ni, int& lyr) {
     return false;
 }
 
-// ---- kernel B': the remaining slab entries (first / last layer, PDE parameters, the block's sum of squares: family 4's f64_dw_entry) by UNITS, the
-// block's points across the lanes (coalesced row reads; family 4 runs one THREAD per entry over the block's 512 points: neighbouring threads read
-// different rows), lane partials summed in a fixed butterfly order: one wave per (network, first-layer neuron) — W0[m, 0..d) and b0[m] from ONE pass over the neuron's dZ rows —,
-// per (network, last-hidden-layer neuron) — W_L[k] —, per network's b_L, per PDE parameter, and the sum of squares: every dZ / activation row
-// of the block is read once (the entry-wise kernel above reads a first-layer neuron's row d + 1 times) ----
-HD int f64m_num_units(const F64Args& a) {
-    int u = 0;
-    for (int ni = 0; ni < a.nnets; ++ni) u += a.net[ni].sizes[1] + a.net[ni].sizes[a.net[ni].nl - 1] + 1;
-    return u + a.ne + 1;
-}
-constexpr int F64M_UNIT_OUT = 6;        // sums of a unit: up to 4 first-layer weights + its bias
-// lane partials of unit u over the block's points; returns the number of sums and their slab entries
-DEV int f64m_unit_lane(int u, int b, int lane, const F64Args& a, double (&s)[F64M_UNIT_OUT], int (&ent)[F64M_UNIT_OUT]) {
-    const int lo = b * F64_BLOCK, hi = (lo + F64_BLOCK < a.npts) ? lo + F64_BLOCK : a.npts;
-    const double* S = a.scratch;
-    const int C = a.C;
-    PINN_UNROLL for (int i = 0; i < F64M_UNIT_OUT; ++i) { s[i] = 0.0; ent[i] = -1; }
-    for (int ni = 0; ni < a.nnets; ++ni) {
-        const F64Net& n = a.net[ni];
-        const int L = n.nl - 1, n1 = n.sizes[1], nL = n.sizes[L];
-        if (u < n1) {                                            // first-layer neuron m = u (L >= 1: hidden layer 0)
-            if (a.mode != 0) return 0;
-            const int m = u;
-            for (int i = 0; i < n.d; ++i) ent[i] = n.ent0 + (n.woff[0] - n.theta0) + m + i * n1;
-            ent[n.d] = n.ent0 + (n.boff[0] - n.theta0) + m;
-            const size_t dz = (size_t)n.r_dz[0] + (size_t)m * C;
-            for (int p = lo + lane; p < hi; p += 64) {
-                const double z0 = S[f64m_six(a, dz, p)];
-                s[n.d] += z0;
-                for (int i = 0; i < n.d; ++i) {
-                    const int ck = a.first_ch[i];
-                    double t2 = z0 * a.pts[(size_t)(a.p0 + p) * a.dt + n.imap[i]];
-                    if (ck >= 0) t2 += S[f64m_six(a, dz + ck, p)];
-                    s[i] += t2;
-                }
-            }
-            return n.d + 1;
+// ---- the remaining slab entries (first / last layer, PDE parameters, the block's sum of squares): the tile kernel left them summed per TILE
+// (F64Args::tpart); column e of block b = its tiles' values added in tile order -> the block's slab.  Runs as one more workgroup row of the dW
+// kernel's launch (k_f64m_dwt, blockIdx.x == number of hidden-to-hidden layers). ----
+HD void f64m_tsum_entry(int e, int b, const F64Args& a) {
+    int ent = -1;
+    bool grad_entry = true;
+    if (e >= a.tp_p) {
+        if (e - a.tp_p < a.ne) ent = a.ent_p + (e - a.tp_p);
+        else { ent = a.nent - 1; grad_entry = false; }            // the sum of squares: needed in every mode
+    } else {
+        for (int ni = 0; ni < a.nnets; ++ni) {
+            const F64Net& n = a.net[ni];
+            const int L = n.nl - 1, n1 = n.sizes[1], nL = n.sizes[L];
+            const int r = e - n.tp0;
+            if (r < 0 || r >= (n.d + 1) * n1 + nL + 1) continue;
+            if (r < n.d * n1) ent = n.ent0 + (n.woff[0] - n.theta0) + r;                            // W_0[m + i * n_1]
+            else if (r < (n.d + 1) * n1) ent = n.ent0 + (n.boff[0] - n.theta0) + (r - n.d * n1);
+            else if (r < (n.d + 1) * n1 + nL) ent = n.ent0 + (n.woff[L] - n.theta0) + (r - (n.d + 1) * n1);
+            else ent = n.ent0 + (n.boff[L] - n.theta0);
+            break;
         }
-        u -= n1;
-        if (u < nL) {                                            // output-layer weight of last-hidden-layer neuron k = u
-            if (a.mode != 0) return 0;
-            const int k = u;
-            ent[0] = n.ent0 + (n.woff[L] - n.theta0) + k;
-            const size_t in = (size_t)n.r_post[L - 1] + (size_t)k * C;
-            for (int p = lo + lane; p < hi; p += 64) {
-                double t2 = 0.0;
-                for (int c = 0; c < C; ++c) t2 = vfma(S[f64m_six(a, (size_t)n.r_ubar + c, p)], S[f64m_six(a, in + c, p)], t2);
-                s[0] += t2;
-            }
-            return 1;
-        }
-        u -= nL;
-        if (u == 0) {                                            // output-layer bias
-            if (a.mode != 0) return 0;
-            ent[0] = n.ent0 + (n.boff[L] - n.theta0);
-            for (int p = lo + lane; p < hi; p += 64) s[0] += S[f64m_six(a, (size_t)n.r_ubar, p)];
-            return 1;
-        }
-        u -= 1;
     }
-    if (u < a.ne) {
-        ent[0] = a.ent_p + u;
-        if (a.mode == 0) for (int p = lo + lane; p < hi; p += 64) s[0] += S[f64m_six(a, (size_t)a.r_pbar + u, p)];
-        return 1;
-    }
-    ent[0] = a.nent - 1;
-    for (int p = lo + lane; p < hi; p += 64) s[0] += S[f64m_six(a, (size_t)a.r_sq, p)];
-    return 1;
+    if (ent < 0 || (grad_entry && a.mode != 0)) return;
+    const int tpb = F64_BLOCK / a.tile_pts, nt = (a.npts + a.tile_pts - 1) / a.tile_pts;
+    const int t0 = b * tpb, t1 = (t0 + tpb < nt) ? t0 + tpb : nt;
+    double sum = 0.0;
+    for (int t = t0; t < t1; ++t) sum += a.tpart[(size_t)t * (size_t)a.ntp + e];
+    a.slab[(size_t)b * a.nent + ent] = sum;
 }
 
 // ---- the kernel table: (inputs, jet set, HT) -> launchers; matched against a term's float64 kernel in f64.cpp ----
@@ -557,8 +623,10 @@ template <class J, int HT, int PG> void launch_f64m_tile(const F64Args& a, plat_
     for (int t = 0; t < nt; ++t) f64m_tile<J, HT, PG, ACT_TANH>(t, a);
 }
 template <int HT> void launch_f64m_dwt(const F64Args& a, plat_stream) {
-    if (a.mode != 0) return;
     const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK, nl = f64m_num_layers(a);
+    for (int b = 0; b < nb; ++b)
+        for (int e = 0; e < a.ntp; ++e) f64m_tsum_entry(e, b, a);
+    if (a.mode != 0) return;
     std::vector<double> lds((size_t)(HT * HT * 4 + HT) * 64);
     for (int b = 0; b < nb; ++b)
         for (int li = 0; li < nl; ++li) {
@@ -571,26 +639,6 @@ template <int HT> void launch_f64m_dwt(const F64Args& a, plat_stream) {
             }
         }
 }
-inline void launch_f64m_dw(const F64Args& a, plat_stream) {
-    const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK, nu = f64m_num_units(a);
-    for (int b = 0; b < nb; ++b)
-        for (int u = 0; u < nu; ++u) {
-            double part[F64M_UNIT_OUT][64];
-            int ent[F64M_UNIT_OUT], nout = 0;
-            for (int lane = 0; lane < 64; ++lane) {
-                double s[F64M_UNIT_OUT];
-                nout = f64m_unit_lane(u, b, lane, a, s, ent);
-                for (int i = 0; i < F64M_UNIT_OUT; ++i) part[i][lane] = s[i];
-            }
-            for (int i = 0; i < nout; ++i) {
-                // (the device's xor butterfly: after step o every lane holds the sum of its 2o-lane group; association = a balanced tree)
-                double t[64];
-                for (int lane = 0; lane < 64; ++lane) t[lane] = part[i][lane];
-                for (int o = 32; o >= 1; o >>= 1) { double v[64]; for (int lane = 0; lane < 64; ++lane) v[lane] = t[lane] + t[lane ^ o]; for (int lane = 0; lane < 64; ++lane) t[lane] = v[lane]; }
-                if (ent[i] >= 0) a.slab[(size_t)b * a.nent + ent[i]] = t[0];
-            }
-        }
-}
 #else
 template <class J, int HT, int PG> __global__ void __launch_bounds__(64, (HT * PG * J::C <= 8) ? 2 : 1) k_f64m_tile(const F64Args a) {
     f64m_tile<J, HT, PG, ACT_TANH>((int)blockIdx.x, a);
@@ -598,7 +646,11 @@ template <class J, int HT, int PG> __global__ void __launch_bounds__(64, (HT * P
 template <int HT> __global__ void __launch_bounds__(64 * F64M_DWT_WAVES, PINN_F64M_DWT_SINGLE ? 2 : 1) k_f64m_dwt(const F64Args a) {
     __shared__ double lds[(HT * HT * 4 + HT) * 64];
     int ni = 0, lyr = 1;
-    if (!f64m_dwt_locate((int)blockIdx.x, a, ni, lyr)) return;
+    if (!f64m_dwt_locate((int)blockIdx.x, a, ni, lyr)) {          // the workgroup row behind the layers: this block's sums of the tile partials
+        for (int e = (int)threadIdx.x; e < a.ntp; e += 64 * F64M_DWT_WAVES) f64m_tsum_entry(e, (int)blockIdx.y, a);
+        return;
+    }
+    if (a.mode != 0) return;
     const int w = (int)(threadIdx.x >> 6), b = (int)blockIdx.y;
     F64mDwtAcc<HT> R;
     f64m_dwt_wave<HT>(ni, lyr, b, w, a, R);
@@ -613,27 +665,7 @@ template <class J, int HT, int PG> void launch_f64m_tile(const F64Args& a, plat_
 }
 template <int HT> void launch_f64m_dwt(const F64Args& a, plat_stream st) {
     const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK, nl = f64m_num_layers(a);
-    if (a.mode != 0 || nl == 0) return;
-    hipLaunchKernelGGL((k_f64m_dwt<HT>), dim3(nl, nb), dim3(64 * F64M_DWT_WAVES), 0, st, a);
-}
-constexpr int F64M_DW_SPLIT = 32;         // workgroups (of 4 waves) per block of points: wave v of 128 takes the units v, v + 128, ...
-template <int UNUSED> __global__ void __launch_bounds__(256) k_f64m_dw(const F64Args a, int nunits) {
-    const int wv = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), b = (int)blockIdx.y, lane = (int)(threadIdx.x & 63);
-    for (int u = wv; u < nunits; u += 4 * F64M_DW_SPLIT) {
-        double s[F64M_UNIT_OUT];
-        int ent[F64M_UNIT_OUT];
-        const int nout = f64m_unit_lane(u, b, lane, a, s, ent);
-        PINN_UNROLL for (int i = 0; i < F64M_UNIT_OUT; ++i) {
-            if (i >= nout) break;
-            double v = s[i];
-            PINN_UNROLL for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (lane == 0 && ent[i] >= 0) a.slab[(size_t)b * a.nent + ent[i]] = v;
-        }
-    }
-}
-inline void launch_f64m_dw(const F64Args& a, plat_stream st) {
-    const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK;
-    hipLaunchKernelGGL((k_f64m_dw<0>), dim3(F64M_DW_SPLIT, nb), dim3(256), 0, st, a, f64m_num_units(a));
+    hipLaunchKernelGGL((k_f64m_dwt<HT>), dim3(nl + 1, nb), dim3(64 * F64M_DWT_WAVES), 0, st, a);
 }
 #endif
 
