@@ -26,8 +26,11 @@
 #define PINN_F64M_DWT_SINGLE 1          // the dW kernel with ONE operand buffer: 256 registers, two workgroups per CU — 2.93 against 3.92 ms for the bench
                                         // workload's float64 evaluation with the second buffer (334 registers, one workgroup per CU); 0 restores it (A/B)
 #endif
+#ifndef PINN_F64M_DEFER
+#define PINN_F64M_DEFER 1               // a layer's scratch stores ride inside the NEXT GEMM's MFMA stream (f64m_tile); 0: issued by the activation loop (A/B)
+#endif
 #ifndef PINN_F64M_PROBE
-#define PINN_F64M_PROBE 0               // timing probes (tools only, wrong numbers): 1 no rolling reload of the weight fragments, 2 no scratch stores, 4 no activation function
+#define PINN_F64M_PROBE 0               // timing probes (tools only, wrong numbers): 1 no rolling reload of the weight fragments, 2 no scratch stores, 4 no activation function, 8 no lane predicates on the element loops (full-width nets and full tiles only)
 #endif
 
 namespace pk {
@@ -134,6 +137,38 @@ DEV void f64m_tile(int tile, const F64Args& a) {
     // layer and the tape read X / U only) and the record of such an element is its activation: that layer's rows never go to memory
     const bool keep_last = a.nnets == 1 && C == 1 && a.post_alias != 0;
     double* TP = a.tpart + (size_t)tile * (size_t)a.ntp;         // this tile's row of partial sums (F64Args::tpart)
+    // DEFERRED STORES (PINN_F64M_DEFER).  vmcnt counts loads and stores alike and retires them in order: a burst of ~100 row stores behind an
+    // activation loop stands between the wave and the first weight fragment of the next GEMM, with one wave (or two) per SIMD nothing else to
+    // run meanwhile (timing probe without stores: -0.5 of 2.4 ms, profiles/r05_f64_kernel_stats.txt section 6).  The values stay where they are
+    // — activations / dZ in X (the next GEMM's B operand), the record's derivative channels in Z until the next GEMM's tile row overwrites
+    // them — and go out a row at a time between that GEMM's MFMAs.
+    constexpr bool DEFER = PINN_F64M_DEFER != 0;
+    static_assert(!DEFER || !SIN, "deferred stores take the record's value channel from X: tanh / sigmoid kernels only");
+    const bool stores_on = a.mode == 0 && !(PINN_F64M_PROBE & 2);
+    // row tr of X (neurons 4 tr + q of a layer `width` wide) -> scratch rows base + neuron * C + c, channels [c0, C)
+    auto store_x_row = [&](int tr, int base, int width, int c0) {
+        PINN_LANES(l) {
+            const int m = 4 * tr + (l >> 4);
+            if (m < width) {
+                PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                    const int p = pbase + 16 * pg + (l & 15);
+                    PINN_UNROLL for (int c = 0; c < C; ++c) if (c >= c0) S[f64m_six(a, (size_t)base + (size_t)m * C + c, p)] = X(l, tr * NCG + pg * C + c);
+                }
+            }
+        }
+    };
+    // the derivative channels (c >= 1) of row tr of Z -> the record rows
+    auto store_z_row = [&](int tr, int base, int width) {
+        PINN_LANES(l) {
+            const int m = 4 * tr + (l >> 4);
+            if (m < width) {
+                PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
+                    const int p = pbase + 16 * pg + (l & 15);
+                    PINN_UNROLL for (int c = 1; c < C; ++c) S[f64m_six(a, (size_t)base + (size_t)m * C + c, p)] = Z(l, tr * NCG + pg * C + c);
+                }
+            }
+        }
+    };
     // =========================== forward ===========================
     for (int ni = 0; ni < a.nnets; ++ni) {
         const F64Net& n = a.net[ni];
@@ -162,7 +197,7 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                     }
                 }
             } else {
-                PINN_LANES(l) { PINN_UNROLL for (int e = 0; e < NR * NCG; ++e) Z(l, e) = 0.0; }
+                if (!DEFER) { PINN_LANES(l) { PINN_UNROLL for (int e = 0; e < NR * NCG; ++e) Z(l, e) = 0.0; } }
                 // the layer's biases first: requested in front of the GEMM (behind it — after the previous layer's scratch stores, which the
                 // compiler must assume to alias theta — their L2 round trip would sit between the last MFMA and the activation)
                 // (one-wave-per-SIMD kernels only: the two-wave kernels have no 32 registers to spare — measured 207 -> 244 us with the prefetch)
@@ -186,14 +221,35 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                     }
                 }
                 PINN_UNROLL for (int t = 0; t < HT; ++t) {
-                    if (16 * t >= n_out) break;
-                    PINN_UNROLL for (int kb = 0; kb < NR; ++kb) {
-                        if (4 * kb >= n_in) break;
-                        PINN_UNROLL for (int g = 0; g < NCG; ++g) mfma_f64(Z, (4 * t) * NCG + g, NCG, Af, kb, X, kb * NCG + g);
-                        if (t + 1 < HT && !(PINN_F64M_PROBE & 1)) {
-                            PINN_LANES(l) {
-                                const int m = 16 * (t + 1) + (l & 15), k = 4 * kb + (l >> 4);
-                                Af(l, kb) = (m < n_out && k < n_in) ? W[m + (size_t)k * n_out] : 0.0;
+                    if (DEFER) {
+                        // tile row t of Z still holds the PREVIOUS layer's pre-activation jets: their derivative channels are that layer's record
+                        if (C > 1 && stores_on) { PINN_UNROLL for (int r = 0; r < 4; ++r) store_z_row(4 * t + r, n.r_rec[lyr - 1], n_in); }
+                        PINN_LANES(l) { PINN_UNROLL for (int e = 0; e < 4 * NCG; ++e) Z(l, 4 * t * NCG + e) = 0.0; }
+                    }
+                    if (16 * t < n_out) {
+                        PINN_UNROLL for (int kb = 0; kb < NR; ++kb) {
+                            if (4 * kb >= n_in) break;
+                            PINN_UNROLL for (int g = 0; g < NCG; ++g) mfma_f64(Z, (4 * t) * NCG + g, NCG, Af, kb, X, kb * NCG + g);
+                            if (t + 1 < HT && !(PINN_F64M_PROBE & 1)) {
+                                PINN_LANES(l) {
+                                    const int m = 16 * (t + 1) + (l & 15), k = 4 * kb + (l >> 4);
+                                    Af(l, kb) = (m < n_out && k < n_in) ? W[m + (size_t)k * n_out] : 0.0;
+                                }
+                            }
+                            // the previous layer's activations (this GEMM's B operand, row kb of X) go out behind the MFMAs that read them first:
+                            // value channel = the record's value channel (tanh / sigmoid), every channel = the post-activation jets the dW kernel reads
+                            if (DEFER && t == 0 && stores_on) {
+                                if (a.post_alias) store_x_row(kb, n.r_rec[lyr - 1], n_in, 0);
+                                else {
+                                    PINN_LANES(l) {
+                                        const int m = 4 * kb + (l >> 4);
+                                        if (m < n_in) {
+                                            PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
+                                                S[f64m_six(a, (size_t)n.r_rec[lyr - 1] + (size_t)m * C, pbase + 16 * pg + (l & 15))] = X(l, kb * NCG + pg * C);
+                                        }
+                                    }
+                                    store_x_row(kb, n.r_post[lyr - 1], n_in, 0);
+                                }
                             }
                         }
                     }
@@ -212,22 +268,23 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                 const int q = l >> 4, j = l & 15;
                 PINN_UNROLL for (int tr = 0; tr < NR; ++tr) {
                     const int m = 16 * (tr >> 2) + 4 * (tr & 3) + q;
-                    const bool valid = m < n_out;
+                    const bool valid = (PINN_F64M_PROBE & 8) ? true : m < n_out;
                     PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
                         const int p = pbase + 16 * pg + j;
-                        const bool st = valid && a.mode == 0 && !(PINN_F64M_PROBE & 2);      // (points past the chunk's end: into the rows' padding — npad is a multiple of the 512-point block, every reader masks by the point count)
+                        const bool st = (PINN_F64M_PROBE & 8) ? true : valid && a.mode == 0 && !(PINN_F64M_PROBE & 2);      // (points past the chunk's end: into the rows' padding — npad is a multiple of the 512-point block, every reader masks by the point count)
                         double z[C];
                         PINN_UNROLL for (int c = 0; c < C; ++c) z[c] = Z(l, tr * NCG + pg * C + c);
                         const double a0 = (PINN_F64M_PROBE & 4) ? z[0] * 0.5 : act_value<SIN>(n.act, z[0]);
                         z[0] = act_record<SIN>(z[0], a0);
                         // the LAST hidden layer's rows have one reader left, this wave's reverse sweep (its post-activation jets fed the output
                         // weights' gradient, which the reverse sweep now forms itself): no post rows, and no record either where X keeps it
-                        if (st && !(keep_last && lyr == L - 1)) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)m * C + c, p)] = z[c]; }
+                        // (the other layers' rows: deferred into the next GEMM, above)
+                        if (st && (!DEFER || lyr == L - 1) && !(keep_last && lyr == L - 1)) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)m * C + c, p)] = z[c]; }
                         double dd[ND];
                         act_derivs_n<J::NORD - 1, SIN>(n.act, z[0], dd);
                         jet_forward<J>(z, dd);
                         z[0] = a0;
-                        if (st && !a.post_alias && lyr != L - 1) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_post[lyr] + (size_t)m * C + c, p)] = z[c]; }
+                        if (st && !DEFER && !a.post_alias && lyr != L - 1) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_post[lyr] + (size_t)m * C + c, p)] = z[c]; }
                         PINN_UNROLL for (int c = 0; c < C; ++c) X(l, tr * NCG + pg * C + c) = valid ? z[c] : 0.0;
                     }
                 }
@@ -370,6 +427,8 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                                 Af(l, kb) = (k < H && m < n_next) ? Wn[m + (size_t)k * n_next] : 0.0;
                             }
                         }
+                        // dZ of the layer above (this GEMM's B operand, row kb of X): its rows for the dW kernel, behind the MFMAs that read it first
+                        if (DEFER && t == 0 && stores_on) store_x_row(kb, n.r_dz[lyr + 1], n_next, 0);
                     }
                 }
             }
@@ -405,12 +464,12 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                 PINN_LANES(l) {
                     const int q = l >> 4, j = l & 15;
                     const int k = 16 * (tr >> 2) + 4 * (tr & 3) + q;
-                    const bool valid = k < H;
+                    const bool valid = (PINN_F64M_PROBE & 8) ? true : k < H;
                     double t6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
                     PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
                         const int p = pbase + 16 * pg + j;
-                        const bool st = valid && p < a.npts;
-                        const bool st2 = valid && lyr != 0 && !(PINN_F64M_PROBE & 2);
+                        const bool st = (PINN_F64M_PROBE & 8) ? true : valid && p < a.npts;
+                        const bool st2 = !DEFER && ((PINN_F64M_PROBE & 8) ? lyr != 0 : valid && lyr != 0 && !(PINN_F64M_PROBE & 2));   // (deferred: out of X inside the next dA GEMM)
                         double s[C], gq[C], dd[ND];
                         PINN_UNROLL for (int c = 0; c < C; ++c) s[c] = X(l, tr * NCG + pg * C + c);
                         PINN_UNROLL for (int c = 0; c < C; ++c) gq[c] = Z(l, tr * NCG + pg * C + c);

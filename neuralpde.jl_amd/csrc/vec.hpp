@@ -694,12 +694,36 @@ HD double vexp_nonpos(double y) {
 // the float64 kernels' tanh: sign(x) (1 - e) / (1 + e), e = e^{-2|x|} — absolute error <= 1.7e-16 (ocml / libm: 0.6e-16) at a quarter of the
 // device's tanh(double) cost (776 -> 193 cycles per evaluation, tools/micro/tanh64_probe.hip, profiles/r05_tanh64_probe.txt); the relative
 // error of tiny results (2.7e-10 at |x| ~ 1e-7) is immaterial here: activations enter sums of O(1) terms
+// n / s for 1 <= s <= 2, |n| <= 1: the hardware reciprocal, two Newton steps and one residual correction (8 instructions, <= 1 ulp) instead of the
+// compiler's IEEE division sequence (scaling, fix-up of denormal / infinite operands: 12-13 instructions that these operands never need)
+#ifndef PINN_F64_DIV_RCP
+#define PINN_F64_DIV_RCP 1
+#endif
+HD double vdiv_1to2(double n, double s) {
+#if PINN_F64_DIV_RCP
+#ifdef PINN_EMU
+    double r = 1.0 / s;                                  // (v_rcp_f64's result differs from this in its last bits; the Newton steps below take both to the same place)
+#else
+    double r = __builtin_amdgcn_rcp(s);
+#endif
+    r = __builtin_fma(__builtin_fma(-s, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-s, r, 1.0), r, r);
+    const double q = n * r;
+    return __builtin_fma(__builtin_fma(-s, q, n), r, q);
+#else
+    return n / s;
+#endif
+}
 HD double vtanh_fast(double x) {
     const double ax = __builtin_fmin(__builtin_fabs(x), 40.0);
     const double e = vexp_nonpos(-2.0 * ax);
-    return __builtin_copysign((1.0 - e) / (1.0 + e), x);
+    return __builtin_copysign(vdiv_1to2(1.0 - e, 1.0 + e), x);
 }
-HD double vsigmoid_fast(double x) { return 1.0 / (1.0 + exp(-x)); }
+// sigma(x) = 1 / (1 + e^-|x|) for x >= 0, e^-|x| / (1 + e^-|x|) for x < 0: the same exponential and division (ocml's exp alone is ~4x the cost)
+HD double vsigmoid_fast(double x) {
+    const double e = vexp_nonpos(-__builtin_fmin(__builtin_fabs(x), 80.0));
+    return vdiv_1to2(x >= 0.0 ? 1.0 : e, 1.0 + e);
+}
 HD void vsincos(double x, double& s, double& c) { s = sin(x); c = cos(x); }
 HD double vsin(double x) { return sin(x); }
 HD double vcos(double x) { return cos(x); }

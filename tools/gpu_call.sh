@@ -11,6 +11,7 @@
 #   pmc              tools/pmc_profile.sh (separate --pmc passes, kernel-trace only) -> pmc/
 #   ab:<v1,v2,..>    tools/ab_compare.py over the variant libraries csrc/abl/libpinn_<v>.so (+ "head" = the product)   -> ab_<cfg>.txt
 #   abcfg:<cfg>:<v1,v2,..>   the same on another config (cfg3, cfg4, cfg5)
+#   abf64:<v1,v2,..> the same for the float64 evaluation mode of the bench workload (wall time per pinn_loss_grad_f64 call)   -> ab_f64.txt
 #   configs          tools/bench_configs.py (all BASELINE configs, HIP events on)   -> all_configs.txt
 #   proxy            tools/scaling_proxy.py                                         -> scaling_proxy.txt / .json
 #   stamps:<lib>     tools/stamp_profile.sh with a PINN_STAMP build                 -> stamps.txt
@@ -37,6 +38,7 @@ for step in "$@"; do
                     python profiles/rocpd_stats.py "$(find "$O/trace_$n" -name '*_results.db' | head -n 1)" > "$O/kernel_stats_$n.txt" 2>&1; head -n 16 "$O/kernel_stats_$n.txt"; find "$O/trace_$n" -name '*.db' -size +20M -delete ;;
         pmc)        timeout 1200 bash tools/pmc_profile.sh "$O/pmc" > "$O/pmc.log" 2>&1; tail -n 40 "$O/pmc/pmc_summary.txt" ;;
         ab:*)       timeout 900 python tools/ab_compare.py $(echo "${step#ab:}" | tr ',' ' ') > "$O/ab_cfg2.txt" 2>&1; grep -i "round\|rror\|median" "$O/ab_cfg2.txt" | cut -c1-200 ;;
+        abf64:*)    timeout 900 python tools/ab_compare.py --precision f64 $(echo "${step#abf64:}" | tr ',' ' ') > "$O/ab_f64.txt" 2>&1; grep -i "round\|rror\|median" "$O/ab_f64.txt" | cut -c1-200 ;;
         abcfg:*)    rest=${step#abcfg:}; cfg=${rest%%:*}; timeout 900 python tools/ab_compare.py --cfg "$cfg" $(echo "${rest#*:}" | tr ',' ' ') > "$O/ab_$cfg.txt" 2>&1; grep -i "round\|rror\|median" "$O/ab_$cfg.txt" | cut -c1-200 ;;
         configs)    timeout 900 python tools/bench_configs.py > "$O/all_configs.txt" 2>&1; tail -n 30 "$O/all_configs.txt" ;;
         proxy)      timeout 1200 python tools/scaling_proxy.py --out "$O/scaling_proxy.json" > "$O/scaling_proxy.txt" 2>&1; tail -n 30 "$O/scaling_proxy.txt" ;;
