@@ -251,9 +251,26 @@ def bench_f64(args, eng, rep, sets, wl):
     for _ in range(args.steps):
         l1, g1 = eng.loss_grad_f64(th, w)
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt_host = time.perf_counter() - t0
     assert np.array_equal(l1, l0) and np.array_equal(g1, g0), "float64 evaluation is not reproducible"
+    # `value`: as the fp32 line — theta and the result resident in HBM (pinn_loss_grad_device_f64, double device buffers), every step
+    # synchronised; the host-entry rate (theta H2D + gradient D2H in double inside the step) rides along as value_host_entry
+    P = eng.P
+    d_th = torch.tensor(th, dtype=torch.float64, device="cuda")
+    d_out = torch.zeros(P + K, dtype=torch.float64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(max(2, args.warmup)):
+        eng.loss_grad_device_f64(d_th.data_ptr(), d_out.data_ptr(), w, st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.loss_grad_device_f64(d_th.data_ptr(), d_out.data_ptr(), w, st)
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = d_out.cpu().numpy()
+    assert np.array_equal(out[:P], g0) and np.allclose(out[P:] / np.array([s_.shape[1] for s_ in sets]), l0, rtol=1e-15, atol=0), "device-pointer and host entry disagree"
     ms = dt / args.steps * 1e3
+    ms_host = dt_host / args.steps * 1e3
     sizes = list(wl.chains[0].sizes)
     hh = sum(sizes[i] * sizes[i + 1] for i in range(1, len(sizes) - 2))          # hidden-to-hidden products per point and channel
     chans = [int(c) for c in eng.describe().split("f64_channels=")[1].split()[0].split(",")] if "f64_channels=" in eng.describe() else None
@@ -266,7 +283,8 @@ def bench_f64(args, eng, rep, sets, wl):
             "value": n[0] / (ms * 1e-3), "unit": "interior-point residual+grad evals/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl.name if hasattr(wl, "name") else args.workload, "points_per_term": n, "precision": "f64", "f64_path": path,
-                       "entry": "pinn_loss_grad_f64 (theta H2D + gradient D2H in double inside the step)"},
+                       "entry": "pinn_loss_grad_device_f64 (theta and [gradient | sums] resident in HBM as doubles, one synchronisation per step)"},
+            "value_host_entry": n[0] / (ms_host * 1e-3), "ms_per_step_host_entry": ms_host,          # pinn_loss_grad_f64: theta H2D + gradient D2H inside the step
             "roofline": {"bound": "mfma-f64", "achieved": ach, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / F64_MFMA_PEAK_TF, "traffic": None,
                          "flops_per_step": flops, "channels_per_term": chans,
                          "note": "executed f64 MFMA flops (forward + dA + dW hidden-layer GEMMs) / whole-evaluation wall time; kernel-level durations: profiles/r05_f64_kernel_stats.txt"},

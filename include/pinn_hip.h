@@ -112,6 +112,10 @@ int pinn_loglik_grad(pinn_handle h, const float* theta, int64_t p, const double*
  * reduction kernel then delivers the result to the host without a copy command (what pinn_loss_grad does internally).
  */
 int pinn_loss_grad_device(pinn_handle h, const float* d_theta, const float* term_w, float* d_out, void* stream);
+/* The same for a handle in the float64 evaluation mode (pinn_set_option(h, "precision", "f64")) with DOUBLE device buffers: d_theta = P doubles,
+ * d_out = P + K doubles — the Float64 caller's residual + gradient without a narrowing at the boundary and without PCIe (the device-array form
+ * of src/discretize.jl:541-545 with Float64 parameters).  Fails on a handle that is not in the mode. */
+int pinn_loss_grad_device_f64(pinn_handle h, const double* d_theta, const float* term_w, double* d_out, void* stream);
 /* Loss-only counterpart: d_sums = K floats in device-accessible memory = this shard's sum of squared residuals per term
  * (divide by n_norm_k; the same numbers pinn_loss_grad_device writes to d_out[P..P+K)).  Asynchronous on `stream`. */
 int pinn_loss_device(pinn_handle h, const float* d_theta, float* d_sums, void* stream);

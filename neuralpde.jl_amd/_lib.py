@@ -35,7 +35,7 @@ SYMBOLS = [
     "pinn_set_sampler", "pinn_set_point_data", "pinn_set_point_weights", "pinn_get_points", "pinn_adam_init", "pinn_adam_steps", "pinn_adam_get", "pinn_lbfgs",
     "pinn_loss_device", "pinn_group_launched_by",
     "pinn_set_option", "pinn_get_option", "pinn_set_points_f64", "pinn_comm_init_custom", "pinn_adam_steps_sharded", "pinn_adam_apply",
-    "pinn_adam_init_f64", "pinn_adam_get_f64", "pinn_set_point_data_f64",
+    "pinn_adam_init_f64", "pinn_adam_get_f64", "pinn_set_point_data_f64", "pinn_loss_grad_device_f64",
 ]
 
 
@@ -99,6 +99,7 @@ class Library:
             L.pinn_adam_init_f64.argtypes = [vp, dp, C.c_int64]
             L.pinn_adam_get_f64.argtypes = [vp, dp, C.c_int64]
             L.pinn_set_point_data_f64.argtypes = [vp, C.c_int, dp, C.c_int, C.c_int64]
+            L.pinn_loss_grad_device_f64.argtypes = [vp, vp, fp, vp, vp]
         except AttributeError:
             pass
         L.pinn_lbfgs.argtypes = [vp, C.POINTER(C.c_double), C.c_int64, C.c_int, C.c_int, C.c_double, fp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -290,6 +291,13 @@ class Engine:
         self.L.check(self.L.lib.pinn_loss_grad_device(
             self.h, C.c_void_p(d_theta), w.ctypes.data_as(C.POINTER(C.c_float)) if w is not None else None,
             C.c_void_p(d_out), C.c_void_p(stream)), "pinn_loss_grad_device")
+
+    def loss_grad_device_f64(self, d_theta: int, d_out: int, weights=None, stream: int = 0):
+        """`pinn_loss_grad_device_f64`: a float64-mode handle on DOUBLE device buffers (d_theta: P doubles, d_out: P + K doubles)"""
+        w = _f32(weights) if weights is not None else None
+        self.L.check(self.L.lib.pinn_loss_grad_device_f64(
+            self.h, C.c_void_p(d_theta), w.ctypes.data_as(C.POINTER(C.c_float)) if w is not None else None,
+            C.c_void_p(d_out), C.c_void_p(stream)), "pinn_loss_grad_device_f64")
 
     def loss_device(self, d_theta: int, d_sums: int, stream: int = 0):
         """loss-only evaluation on device pointers: d_sums = K floats (this shard's sums of squared residuals per term)"""

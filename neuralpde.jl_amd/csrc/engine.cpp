@@ -698,6 +698,19 @@ int pinn_loss_grad_device(pinn_handle h, const float* d_theta, const float* term
     return rc;
 }
 
+int pinn_loss_grad_device_f64(pinn_handle h, const double* d_theta, const float* term_w, double* d_out, void* stream) {
+    if (!h || !d_theta || !d_out) return fail("pinn_loss_grad_device_f64: null argument");
+    pinn_engine& E = *h;
+    if (!E.f64) return fail("pinn_loss_grad_device_f64: the handle is not in the float64 evaluation mode (pinn_set_option(h, \"precision\", \"f64\"))");
+    DeviceScope scope(E.device);
+    plat_stream saved = E.stream;
+    E.stream = (plat_stream)stream;
+    const int rc = f64_eval_from_device_f64(E, d_theta, term_w, d_out);
+    E.stream = saved;
+    if (rc && g_err.empty()) return fail("pinn_loss_grad_device_f64 failed");
+    return rc;
+}
+
 int pinn_loss_device(pinn_handle h, const float* d_theta, float* d_sums, void* stream) {
     if (!h || !d_theta || !d_sums) return fail("pinn_loss_device: null argument");
     pinn_engine& E = *h;

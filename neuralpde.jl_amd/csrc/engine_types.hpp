@@ -318,6 +318,7 @@ int f64_adam_steps(pinn_engine& E, int nsteps, double lr, double beta1, double b
                    void (*redraw)(pinn_engine&, pe::Term&));
 int f64_points_from_device(pinn_engine& E, int term);
 int f64_eval_from_device_f32(pinn_engine& E, const float* d_theta, const float* term_w, float* d_out, bool want_grad);
+int f64_eval_from_device_f64(pinn_engine& E, const double* d_theta, const float* term_w, double* d_out);
 // plan.cpp
 // GEMM arithmetic the kernel look-ups of the calling thread select (family 2 kernels exist as split-operand and fp32 twins): set for the
 // duration of an entry point that may look kernels up

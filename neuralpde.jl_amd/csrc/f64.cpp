@@ -492,6 +492,20 @@ int f64_eval_from_device_f32(pinn_engine& E, const float* d_theta, const float* 
     return 0;
 }
 
+// theta and [gradient | raw sums] as DOUBLE device pointers: nothing crosses the boundary in fp32, nothing crosses PCIe
+int f64_eval_from_device_f64(pinn_engine& E, const double* d_theta, const float* term_w, double* d_out) {
+    F64State& S = *(F64State*)E.f64;
+    const int K = (int)E.terms.size();
+    const int64_t P = E.ntheta;
+    std::vector<double> w(K);
+    for (int k = 0; k < K; ++k) w[k] = term_w ? (double)term_w[k] : 1.0;
+    if (plat_d2d(S.d_theta, d_theta, sizeof(double) * P, E.stream)) return fail("device copy of theta failed");
+    S.opt_ready = false;
+    if (f64_eval_device(E, w.data(), true)) return 1;
+    if (plat_d2d(d_out, S.d_grad, sizeof(double) * P, E.stream) || plat_d2d(d_out + P, S.d_sumsq, sizeof(double) * K, E.stream)) return fail("device copy of the gradient failed");
+    return 0;
+}
+
 // " f64_channels=5,1,1,1,1 f64_kernels=mfma:HT4xPG1,mfma:HT4xPG4,..." for pinn_describe
 std::string f64_describe(const pinn_engine& E) {
     if (!E.f64) return "";

@@ -271,7 +271,7 @@ def test_f64_mode_resident_adam_samplers_and_device_entry_points(npde, use_emu):
         th_prev = th_dev
     assert not np.array_equal(seen[0], seen[1]) and seen[0].min() >= 0.0 and seen[0].max() <= 1.0      # (fresh points every step)
     # (c) device-pointer entry points and per-term gradients in float64 mode (emulation: "device" pointers are host pointers)
-    rep3, eng3, _, _ = _engine_f64(npde, wl)
+    rep3, eng3, sets3, _ = _engine_f64(npde, wl)
     l64, g64 = eng3.loss_grad_f64(th0, w)
     th32 = th0.astype(np.float32)
     l64b, g64b = eng3.loss_grad_f64(th32.astype(np.float64), w)
@@ -290,6 +290,23 @@ def test_f64_mode_resident_adam_samplers_and_device_entry_points(npde, use_emu):
         sums = np.zeros(eng3.K, dtype=np.float32)
         eng3.loss_grad_device(th32.ctypes.data, out.ctypes.data, w)
         eng3.loss_device(th32.ctypes.data, sums.ctypes.data)
+    # the double device-pointer entry (pinn_loss_grad_device_f64): the host entry's numbers bit for bit, nothing narrowed
+    if eng3.L.backend == "hip":
+        d_th64 = torch.tensor(th0, dtype=torch.float64, device="cuda")
+        d_out64 = torch.zeros(eng3.P + eng3.K, dtype=torch.float64, device="cuda")
+        eng3.loss_grad_device_f64(d_th64.data_ptr(), d_out64.data_ptr(), w)
+        torch.cuda.synchronize()
+        out64 = d_out64.cpu().numpy()
+    else:
+        out64 = np.zeros(eng3.P + eng3.K, dtype=np.float64)
+        eng3.loss_grad_device_f64(th0.ctypes.data, out64.ctypes.data, w)
+    assert np.array_equal(out64[:eng3.P], g64) and np.array_equal(out64[eng3.P:] / n_norm, l64)
+    eng3.set_option("precision", "f32")
+    with pytest.raises(RuntimeError, match="float64 evaluation mode"):
+        eng3.loss_grad_device_f64(th0.ctypes.data, out64.ctypes.data, w)
+    eng3.set_option("precision", "f64")
+    for k, s_ in enumerate(sets3):
+        eng3.set_points_f64(k, s_)
     np.testing.assert_allclose(out[:eng3.P], g64b.astype(np.float32), rtol=0, atol=1e-7 * np.abs(g64b).max())
     np.testing.assert_allclose(out[eng3.P:] / n_norm, l64b, rtol=2e-7)
     np.testing.assert_allclose(sums / n_norm, l64b, rtol=2e-7)
