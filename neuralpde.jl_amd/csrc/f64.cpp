@@ -274,8 +274,14 @@ static int f64_eval_device(pinn_engine& E, const double* term_w, bool want_grad)
     for (int t = 0; t < K; ++t)
         if (S.terms[t].ndata > 0 && S.terms[t].data_n != S.terms[t].n)
             return fail("term " + std::to_string(t) + " uses per-point data channels but none are installed for its current point set (call pinn_set_point_data after pinn_set_points)");
-    plat_memset(S.d_grad, 0, sizeof(double) * P, E.stream);
-    plat_memset(S.d_sumsq, 0, sizeof(double) * K, E.stream);
+    // the first reduction of the evaluation writes the gradient instead of adding to it when its term's entries cover all of theta (one network,
+    // or every network in the first equation); otherwise one memset.  Every term's first chunk writes its own sum of squares.
+    bool grad_started = false;
+    if (want_grad) {
+        int64_t covered = E.ne;
+        for (int ni : S.terms[0].nets) covered += E.nets[ni].nparams();
+        if (covered != P) { plat_memset(S.d_grad, 0, sizeof(double) * P, E.stream); grad_started = true; }
+    }
     S.path = 0;
     for (int t = 0; t < K; ++t) {
         const Term& T = E.terms[t];
@@ -393,6 +399,9 @@ static int f64_eval_device(pinn_engine& E, const double* term_w, bool want_grad)
             r.grad = S.d_grad; r.ent_p = a.ent_p; r.p_off = E.p_theta_off; r.nnets = a.nnets;
             for (int ni = 0; ni < a.nnets; ++ni) { r.ent0[ni] = a.net[ni].ent0; r.theta0[ni] = a.net[ni].theta0; }
             r.sumsq = S.d_sumsq + t; r.with_grad = grad ? 1 : 0;
+            r.init_sumsq = (p0 == 0) ? 1 : 0;
+            r.init_grad = (grad && !grad_started) ? 1 : 0;
+            if (grad) grad_started = true;
             if (mfma) pk::launch_f64m_reduce(r, E.stream);
             else pk::launch_f64_reduce(r, E.stream);
         }
@@ -499,11 +508,13 @@ int f64_eval_from_device_f64(pinn_engine& E, const double* d_theta, const float*
     const int64_t P = E.ntheta;
     std::vector<double> w(K);
     for (int k = 0; k < K; ++k) w[k] = term_w ? (double)term_w[k] : 1.0;
-    if (plat_d2d(S.d_theta, d_theta, sizeof(double) * P, E.stream)) return fail("device copy of theta failed");
-    S.opt_ready = false;
-    if (f64_eval_device(E, w.data(), true)) return 1;
-    if (plat_d2d(d_out, S.d_grad, sizeof(double) * P, E.stream) || plat_d2d(d_out + P, S.d_sumsq, sizeof(double) * K, E.stream)) return fail("device copy of the gradient failed");
-    return 0;
+    // the kernels read the caller's theta and write the caller's [gradient | sums] directly: no copies (the handle's own buffers — the optimiser's
+    // iterate among them — stay as they are)
+    double* const th0 = S.d_theta; double* const g0 = S.d_grad; double* const s0 = S.d_sumsq;
+    S.d_theta = const_cast<double*>(d_theta); S.d_grad = d_out; S.d_sumsq = d_out + P;
+    const int rc = f64_eval_device(E, w.data(), true);
+    S.d_theta = th0; S.d_grad = g0; S.d_sumsq = s0;
+    return rc;
 }
 
 // " f64_channels=5,1,1,1,1 f64_kernels=mfma:HT4xPG1,mfma:HT4xPG4,..." for pinn_describe

@@ -358,18 +358,25 @@ struct F64ReduceArgs {
     int p_off;
     double* sumsq;                       // += the term's sum of squares
     int with_grad;
+    int init_grad, init_sumsq;           // 1: this launch WRITES its sums (the evaluation's first reduction covering all of theta / the term's first chunk)
+                                         // instead of adding to them: no memset launches in front of an evaluation
 };
+DEV void f64_reduce_write(int e, double s, const F64ReduceArgs& a) {
+    if (e == a.nent - 1) { *a.sumsq = a.init_sumsq ? s : *a.sumsq + s; return; }
+    int i;
+    if (e >= a.ent_p) i = a.p_off + (e - a.ent_p);
+    else {
+        int ni = 0;
+        while (ni + 1 < a.nnets && e >= a.ent0[ni + 1]) ++ni;
+        i = a.theta0[ni] + (e - a.ent0[ni]);
+    }
+    a.grad[i] = a.init_grad ? s : a.grad[i] + s;
+}
 DEV void f64_reduce_entry(int e, const F64ReduceArgs& a) {
     if (e != a.nent - 1 && !a.with_grad) return;
     double s = 0.0;
     for (int b = 0; b < a.nblocks; ++b) s += a.slab[(size_t)b * a.nent + e];
-    if (e == a.nent - 1) *a.sumsq += s;
-    else if (e >= a.ent_p) a.grad[a.p_off + (e - a.ent_p)] += s;
-    else {
-        int ni = 0;
-        while (ni + 1 < a.nnets && e >= a.ent0[ni + 1]) ++ni;
-        a.grad[a.theta0[ni] + (e - a.ent0[ni])] += s;
-    }
+    f64_reduce_write(e, s, a);
 }
 
 // ---- the kernel table: one entry per (inputs, jet set); activations tanh / sigmoid / sin inside ----

@@ -775,39 +775,35 @@ inline void launch_f64_narrow(const double* src, float* dst, int64_t n, plat_str
 
 // ---- slab reduction of the matrix-pipe path: FOUR lanes per entry (blocks part, part + 4, ... each; (p0 + p1) + (p2 + p3)), four times the
 // threads and a quarter of the dependent adds of family 4's one-thread-per-entry kernel (38 us per term on the bench workload) ----
+constexpr int F64M_RED_LANES = 16;       // lanes per slab entry: lane i adds the blocks i, i + 16, ...; the lanes' sums meet in an xor butterfly (1, 2, 4, 8)
 DEV double f64m_reduce_part(int e, int part, const F64ReduceArgs& a) {
     double s = 0.0;
-    for (int b = part; b < a.nblocks; b += 4) s += a.slab[(size_t)b * a.nent + e];
+    for (int b = part; b < a.nblocks; b += F64M_RED_LANES) s += a.slab[(size_t)b * a.nent + e];
     return s;
-}
-DEV void f64m_reduce_write(int e, double s, const F64ReduceArgs& a) {
-    if (e == a.nent - 1) *a.sumsq += s;
-    else if (e >= a.ent_p) a.grad[a.p_off + (e - a.ent_p)] += s;
-    else {
-        int ni = 0;
-        while (ni + 1 < a.nnets && e >= a.ent0[ni + 1]) ++ni;
-        a.grad[a.theta0[ni] + (e - a.ent0[ni])] += s;
-    }
 }
 #ifdef PINN_EMU
 inline void launch_f64m_reduce(const F64ReduceArgs& a, plat_stream) {
     for (int e = 0; e < a.nent; ++e) {
         if (e != a.nent - 1 && !a.with_grad) continue;
-        const double p0 = f64m_reduce_part(e, 0, a), p1 = f64m_reduce_part(e, 1, a), p2 = f64m_reduce_part(e, 2, a), p3 = f64m_reduce_part(e, 3, a);
-        f64m_reduce_write(e, (p0 + p1) + (p2 + p3), a);
+        double t[F64M_RED_LANES], u[F64M_RED_LANES];
+        for (int i = 0; i < F64M_RED_LANES; ++i) t[i] = f64m_reduce_part(e, i, a);
+        for (int o = 1; o < F64M_RED_LANES; o <<= 1) {
+            for (int i = 0; i < F64M_RED_LANES; ++i) u[i] = t[i] + t[i ^ o];
+            for (int i = 0; i < F64M_RED_LANES; ++i) t[i] = u[i];
+        }
+        f64_reduce_write(e, t[0], a);
     }
 }
 #else
 template <int UNUSED> __global__ void __launch_bounds__(256) k_f64m_reduce(const F64ReduceArgs a) {
-    const int gid = (int)(blockIdx.x * 256 + threadIdx.x), e = gid >> 2, part = gid & 3;
+    const int gid = (int)(blockIdx.x * 256 + threadIdx.x), e = gid / F64M_RED_LANES, part = gid % F64M_RED_LANES;
     const bool live = e < a.nent && (e == a.nent - 1 || a.with_grad);
     double s = live ? f64m_reduce_part(e, part, a) : 0.0;
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    if (live && part == 0) f64m_reduce_write(e, s, a);
+    PINN_UNROLL for (int o = 1; o < F64M_RED_LANES; o <<= 1) s += __shfl_xor(s, o, 64);
+    if (live && part == 0) f64_reduce_write(e, s, a);
 }
 inline void launch_f64m_reduce(const F64ReduceArgs& a, plat_stream st) {
-    hipLaunchKernelGGL((k_f64m_reduce<0>), dim3((4 * a.nent + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_f64m_reduce<0>), dim3((F64M_RED_LANES * a.nent + 255) / 256), dim3(256), 0, st, a);
 }
 #endif
 
