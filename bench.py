@@ -279,13 +279,24 @@ def bench_f64(args, eng, rep, sets, wl):
         chans = [5] + [1] * (K - 1) if args.workload == "cfg2" else [1] * K
     flops = sum(3 * 2 * hh * c * nn for c, nn in zip(chans, n))
     ach = flops / (ms * 1e-3) / 1e12
+    # HBM-side bytes of one evaluation from the committed PMC passes (profiles/pmc_traffic_f64.json: this workload at 65,536 points per term)
+    traffic, tsrc, busy = None, None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic_f64.json")) as f:
+            tj = json.load(f)
+        if args.workload == "cfg2" and all(nn == 65536 for nn in n) and path == "mfma":
+            traffic, tsrc = tj["bytes_per_evaluation"], tj["source"]
+            busy = {k_["kernel"].split("(")[0].replace("void pk::", ""): round(k_["mfma_busy"], 3) for k_ in tj["kernels"] if k_["mfma_busy"] > 0}
+    except (OSError, KeyError, ValueError):
+        pass
     return {"metric": "collocation-point residual+grad evals/sec, 2D Poisson 4x64 MLP (float64 evaluation mode)" if args.workload == "cfg2" else f"collocation-point residual+grad evals/sec ({args.workload}, float64 evaluation mode)",
             "value": n[0] / (ms * 1e-3), "unit": "interior-point residual+grad evals/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl.name if hasattr(wl, "name") else args.workload, "points_per_term": n, "precision": "f64", "f64_path": path,
                        "entry": "pinn_loss_grad_device_f64 (theta and [gradient | sums] resident in HBM as doubles, one synchronisation per step)"},
             "value_host_entry": n[0] / (ms_host * 1e-3), "ms_per_step_host_entry": ms_host,          # pinn_loss_grad_f64: theta H2D + gradient D2H inside the step
-            "roofline": {"bound": "mfma-f64", "achieved": ach, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / F64_MFMA_PEAK_TF, "traffic": None,
+            "roofline": {"bound": "mfma-f64", "achieved": ach, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / F64_MFMA_PEAK_TF, "traffic": traffic,
+                         "traffic_source": tsrc, "mfma_busy_per_kernel": busy,
                          "flops_per_step": flops, "channels_per_term": chans,
                          "note": "executed f64 MFMA flops (forward + dA + dW hidden-layer GEMMs) / whole-evaluation wall time; kernel-level durations: profiles/r05_f64_kernel_stats.txt"},
             "loss_terms": [float(x) for x in l1]}
