@@ -353,6 +353,8 @@ int pe::run_loss_grad(pinn_engine& E, const float* d_theta, float* d_out, const 
         aux::launch_reduce(a1, a2, max_n1, max_split, E.stream);
     }
     if (phase_ev) plat_event_record(E.ev3, E.stream);
+    // a run-time specialised kernel whose code object could not be produced / loaded at its first launch (jit.cpp: rtc_launch) was NOT launched
+    { const std::string e = jit_take_launch_error(); if (!e.empty()) return fail(e); }
     return 0;
 }
 

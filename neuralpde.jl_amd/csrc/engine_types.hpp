@@ -323,6 +323,7 @@ int f64_eval_from_device_f64(pinn_engine& E, const double* d_theta, const float*
 // GEMM arithmetic the kernel look-ups of the calling thread select (family 2 kernels exist as split-operand and fp32 twins): set for the
 // duration of an entry point that may look kernels up
 int current_gemm();
+int current_act_hint();             // activation kind of the network being planned (-1: none): which kernels a hiprtc-specialised member compiles first
 struct GemmScope {
     int prev;
     explicit GemmScope(int mode);
@@ -338,6 +339,7 @@ const pk::SpecInfo* ensure_spec(const Net& N, unsigned need_first, const std::ve
 // jit.cpp
 int jit_round_hp(int h);
 int jit_spec(int HP, int NHH, int D, unsigned D1MASK, unsigned long long PAIRS, int NPAIR, unsigned HI, int variant);
+std::string jit_take_launch_error();          // message of a specialised kernel that could not be launched since the last call (empty: none); clears it
 // general multi-index jet sets (mixed derivatives of order >= 3, orders 5-6): closed, ordered channel list of a set of requested
 // multi-indices (nibble 0 = order, nibbles 1.. = sorted axes) and the kernel generated for it
 std::vector<unsigned> gen_close(const std::vector<unsigned>& want);

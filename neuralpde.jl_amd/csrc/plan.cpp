@@ -9,6 +9,10 @@ static thread_local int g_gemm = pk::GEMM_SPLIT;
 int current_gemm() { return g_gemm; }
 GemmScope::GemmScope(int mode) : prev(g_gemm) { g_gemm = mode; }
 GemmScope::~GemmScope() { g_gemm = prev; }
+// activation kind of the network whose kernel is being looked up (-1: none): a run-time specialised member compiles that kind's kernels first (jit.cpp: rtc_build)
+static thread_local int g_act_hint = -1;
+int current_act_hint() { return g_act_hint; }
+namespace { struct ActScope { int prev; explicit ActScope(int a) : prev(g_act_hint) { g_act_hint = a; } ~ActScope() { g_act_hint = prev; } }; }
 // a family-2 kernel serves the current GEMM mode when it is compiled in that mode, or when its shape has one form only
 static bool gemm_ok(const pk::SpecInfo& s) { return s.family != 2 || !s.twin || s.gemm == g_gemm; }
 
@@ -76,6 +80,7 @@ static const pk::SpecInfo* ensure_spec_dgm(const Net& N, unsigned need_first, st
 
 const pk::SpecInfo* ensure_spec(const Net& N, unsigned need_first, const std::vector<std::pair<int, int>>& need_pairs, unsigned need_hi, int need_family) {
     if (N.kind == 1) return ensure_spec_dgm(N, need_first, need_pairs, need_hi);
+    ActScope as((N.act >= 0 && N.act < 4) ? N.act : -1);
     const int HP = round_hp(N.maxhidden()), NHH = (int)N.sizes.size() - 3, D = N.sizes[0], variant = variant_of(N.act);
     if (need_hi & GEN_FLAG) {                    // general multi-index channel set: always generated (jit.cpp: jit_spec_gen)
         const pk::SpecInfo* g = find_spec(HP, NHH, D, 0, {}, need_hi, nullptr, variant, need_family);
