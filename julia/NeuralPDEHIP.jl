@@ -174,11 +174,38 @@ end
 FLOAT64 evaluation of a live engine (`pinn_set_option(h, "precision", …)`, DESIGN.md section 4.5): `loss_grad` and `lbfgs!` then run the
 double kernels — the reference's default eltype (src/discretize.jl:432-449) — for a `BFGS()` finisher below the fp32 noise floor or a
 digit-by-digit comparison with a Float64 CPU run.  Point sets already installed are converted; `set_points!` keeps feeding both.
-Throws (and leaves the fp32 plan untouched) for problems the mode does not cover (DGM nets, embeddings, device samplers, DATA channels).
+Throws (and leaves the fp32 plan untouched) for problems the mode does not cover (DGM nets, periodic embeddings).  Since round 5 the resident
+Adam loop, the device samplers, per-point DATA channels and the device-pointer entries evaluate in double as well.
 """
 function set_precision!(e::HIPEngine, mode::Symbol)
     mode in (:f64, :f32) || throw(ArgumentError("precision must be :f64 or :f32"))
     check(ccall(sym(:pinn_set_option), Cint, (Ptr{Cvoid}, Cstring, Cstring), e.h, "precision", String(mode)), "pinn_set_option")
+    return nothing
+end
+
+"""
+    set_point_data_f64!(e, k, data)
+
+Observations of a data-misfit term (descriptor op `DATA j`; `ndata × N`, channel-major) in double (`pinn_set_point_data_f64`): the float64
+evaluation mode reads them as given, the fp32 kernels their float conversion.
+"""
+function set_point_data_f64!(e::HIPEngine, k::Integer, data::AbstractMatrix)
+    d64 = Matrix{Float64}(permutedims(data))          # Julia column-major N × ndata == C row-major ndata × N
+    GC.@preserve d64 check(ccall(sym(:pinn_set_point_data_f64), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Cint, Int64),
+                                 e.h, k - 1, d64, size(data, 1), size(data, 2)), "pinn_set_point_data_f64")
+    return nothing
+end
+
+"""
+    loss_grad_device_f64!(e, dθ::Ptr{Float64}, dout::Ptr{Float64}, w; stream = C_NULL)
+
+The float64 evaluation on DOUBLE device buffers (`pinn_loss_grad_device_f64`; e.g. the pointers of two `ROCArray{Float64}`): `dθ` holds P
+parameters, `dout` receives `[gradient (P) | raw per-term sums of squares (K)]`; asynchronous on `stream`.  The engine must be in float64 mode.
+"""
+function loss_grad_device_f64!(e::HIPEngine, dθ::Ptr{Float64}, dout::Ptr{Float64}, w::AbstractVector{<:Real}; stream::Ptr{Cvoid} = C_NULL)
+    w32 = Vector{Float32}(w)
+    GC.@preserve w32 check(ccall(sym(:pinn_loss_grad_device_f64), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float32}, Ptr{Float64}, Ptr{Cvoid}),
+                                 e.h, dθ, w32, dout, stream), "pinn_loss_grad_device_f64")
     return nothing
 end
 
