@@ -24,7 +24,7 @@ theta0 = np.concatenate([npde.initialparameters(rng, ch) for ch in wl.chains])
 u = wl.pde_system.dvs[0]
 disc = npde.PhysicsInformedNN(wl.chains[0], wl.strategy, init_params=theta0, param_estim=True,
                               data_loss=[npde.DataLoss(u, obs_pts, obs, weight=1.0)],
-                              adaptive_loss=npde.NonAdaptiveLoss(pde_loss_weights=1.0, bc_loss_weights=10.0, additional_loss_weights=100.0))
+                              adaptive_loss=npde.NonAdaptiveLoss(pde_loss_weights=1.0, bc_loss_weights=10.0, additional_loss_weights=100.0), precision="f32")
 prob = npde.discretize(wl.pde_system, disc)
 rep = prob.pinnrep
 print(rep.engine.describe().split("\n")[0])

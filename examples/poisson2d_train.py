@@ -18,7 +18,7 @@ wl = workloads.cfg2_poisson2d(points=65536)
 rng = np.random.default_rng(0)
 theta0 = np.concatenate([npde.initialparameters(rng, ch) for ch in wl.chains])          # glorot weights, zero biases (Lux default)
 disc = npde.PhysicsInformedNN(wl.chains[0], wl.strategy, init_params=theta0,
-                              adaptive_loss=npde.NonAdaptiveLoss(pde_loss_weights=1.0, bc_loss_weights=100.0))
+                              adaptive_loss=npde.NonAdaptiveLoss(pde_loss_weights=1.0, bc_loss_weights=100.0), precision="f32")
 prob = npde.discretize(wl.pde_system, disc)
 xs = np.linspace(0.0, 1.0, 100)
 X, Y = np.meshgrid(xs, xs, indexing="ij")

@@ -13,9 +13,10 @@
  *                             [net(depvar 1): W1 (out x in, col-major) | b1 | W2 | b2 ... | net(depvar 2) ... | p]
  *                             == pinnrep.flat_init_params, src/discretize.jl:451-465
  * Every function returns 0 on success, non-zero on error; pinn_last_error() gives the message
- * (thread-local).  The engine computes in fp32 on the device with exact (Taylor-mode) derivatives;
- * it reproduces the reference's Float64 finite-difference semantics to ~1e-7 relative
- * (SURVEY.md §8c).  There is NO CPU fallback: without a gfx950 device pinn_create fails.
+ * (thread-local).  The engine computes with exact (Taylor-mode) derivatives, in fp32 on the device by default
+ * (it reproduces the reference's Float64 finite-difference semantics to ~1e-7 relative at initialisation,
+ * SURVEY.md §8c) or in float64 (pinn_set_option "precision"; every entry point has a double twin `_f64`).
+ * There is NO CPU fallback: without a gfx950 device pinn_create fails.
  *
  * One handle = one caller thread at a time (the reference's loss closures are not re-entrant
  * either: `iteration[] += 1`, src/discretize.jl:574-576).
@@ -87,6 +88,8 @@ int pinn_loss_grad_f64(pinn_handle h, const double* theta, int64_t p, const doub
  * term_grads is K x P (row k = d term_losses[k] / d theta), row-major.
  */
 int pinn_term_grads(pinn_handle h, const float* theta, int64_t p, double* term_losses, float* term_grads);
+/* The same with theta and the K x P gradients in double (r06): native on a handle in float64 mode, fp32 kernels + widening otherwise. */
+int pinn_term_grads_f64(pinn_handle h, const double* theta, int64_t p, double* term_losses, double* term_grads);
 
 /*
  * BPINN physics (+ data) log-likelihood and its gradients in one evaluation:
@@ -102,6 +105,9 @@ int pinn_term_grads(pinn_handle h, const float* theta, int64_t p, double* term_l
  * that passes n_norm != n for another reason (a re-normalised mean) gets the constants of n points here.
  */
 int pinn_loglik_grad(pinn_handle h, const float* theta, int64_t p, const double* stds, double* loglik, float* grad_theta, double* grad_std);
+/* theta and grad_theta in double (r06; the reference's BPINN samples Float64 parameters, ext/bpinn/PDE_BPINN.jl:519): native on a handle in
+ * float64 mode, fp32 kernels + widening otherwise. */
+int pinn_loglik_grad_f64(pinn_handle h, const double* theta, int64_t p, const double* stds, double* loglik, double* grad_theta, double* grad_std);
 /*
  * Device-resident variant for multi-GPU data parallelism (one process per GPU; the caller
  * all-reduces d_out with RCCL): d_theta = P floats in HBM; d_out = P + K floats in HBM:
@@ -176,6 +182,20 @@ int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float*
  * Taylor-jet kernels carry (the value the reference's central differences approximate to ~1e-8, test/Forward/forward__derivatives.jl:22-44).
  */
 int pinn_derivative(pinn_handle h, int net, const float* theta, int64_t p, const float* pts, int64_t n, int order, const int* axes, float* out);
+/*
+ * The three per-point closures in DOUBLE (r06).  The reference evaluates them in eltype(theta), Float64 by default (src/discretize.jl:432-449,
+ * src/eltype_matching.jl:8-10), and pins them at Float64 tolerances: datafree_pde_loss_functions[i](cord, theta) at rtol 1e-8
+ * (src/pinn_types.jl:435-439, test/Forward/forward__ode.jl:46-47), numeric_derivative against automatic differentiation at atol 1e-8 / 4e-5
+ * (src/pinn_types.jl:445-482, test/Forward/forward__derivatives.jl:29-44), phi(x, theta) (src/pinn_types.jl:88-90).  On a handle in float64
+ * mode (pinn_set_option(h, "precision", "f64")) theta, points and results cross the boundary in double and the double kernels evaluate them
+ * (matrix-pipe tile kernels where instantiated, one lane per point elsewhere): results equal a Float64 evaluation to rounding.  On an fp32
+ * handle they narrow / widen at the boundary (the fp32 kernels run).  pinn_derivative_f64 covers the derivatives the float64 jet sets carry
+ * (orders <= 2 in 1-3 inputs, pure orders 3-4, first + pure second in 4 inputs); anything else fails with a message.
+ * pinn_residual_f64 reads the term's set as installed: pinn_set_points_f64 for Float64 coordinates.
+ */
+int pinn_residual_f64(pinn_handle h, int term, const double* theta, int64_t p, double* r);
+int pinn_phi_f64(pinn_handle h, int net, const double* theta, int64_t p, const double* pts, int64_t n, double* out);
+int pinn_derivative_f64(pinn_handle h, int net, const double* theta, int64_t p, const double* pts, int64_t n, int order, const int* axes, double* out);
 
 /*
  * Resident-theta training loop: theta, the Adam moments and the collocation sets stay in HBM; no
@@ -254,10 +274,17 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
  *   Covers equations of up to 6 dependent variables (same argument count), Dense chains with tanh / sigmoid / sin, derivative orders <= 2
  *   in 1-3 inputs (1-D, and mixed / pure in 2-D and 3-D where instantiated: <= 4; 4-D: first and pure second), PDE parameters, quadrature
  *   weights, per-point DATA channels, device samplers; anything else (DGM, periodic embeddings) fails HERE with a message and leaves the fp32
- *   plan usable.  In this mode EVERY evaluating entry point runs the double kernels: pinn_loss_grad / pinn_loss_grad_device / pinn_loss_device
- *   / pinn_term_grads convert at the boundary, pinn_adam_* keep theta and the moments in double on the device (pinn_adam_init_f64 /
- *   pinn_adam_get_f64 hand them over in double), samplers redraw in float and the double copy follows.  pinn_set_points_f64 /
- *   pinn_set_point_data_f64 install a point set / its observations in double (the fp32 kernels get the float conversion).
+ *   plan usable.  In this mode EVERY evaluating entry point runs the double kernels (r06): pinn_loss_grad / pinn_loss_grad_device /
+ *   pinn_loss_device / pinn_term_grads / pinn_loglik_grad / pinn_residual / pinn_phi / pinn_derivative convert at the boundary, their _f64
+ *   twins hand everything over in double; pinn_adam_init / _steps / _get / _apply keep theta and the moments in double on the device, in
+ *   a buffer of their own (evaluations between two pinn_adam_steps calls — adaptive reweighting, callbacks — leave the iterate alone);
+ *   samplers redraw in float and the double copy follows.  pinn_set_points_f64 / pinn_set_point_data_f64 install a point set / its
+ *   observations in double (the fp32 kernels get the float conversion).  Not available in this mode (explicit error): the communicator paths
+ *   pinn_adam_steps_sharded and pinn_adam_steps on a handle with a communicator — shard a float64 job with pinn_loss_grad_device_f64 + the
+ *   caller's all-reduce + pinn_adam_apply; pinn_loss_grad_sharded(_device) run the fp32 kernels whatever the mode.
+ *   PRECISION POLICY of the glue (Julia: HIPStrategy / hip_discretize `precision = :auto`; Python mirror: PhysicsInformedNN(precision = "auto")):
+ *   the reference's contract compute dtype = eltype(theta) (src/eltype_matching.jl:8-10) — Float64 parameters select "f64", Float32
+ *   parameters "f32"; "f32" on Float64 parameters is the explicit fast opt-in.
  * "persistent" = "on" (default) | "off": pinn_adam_steps runs a SMALL problem — one network of the one-wave-per-tile kernel family, at most
  *   32 workgroups (~2,000 points of a 3 x 32 net), fixed or device-redrawn point sets (pinn_set_sampler), no estimated PDE parameters, no communicator — as ONE persistent launch
  *   per call (csrc/pinn_train.hpp: evaluation, fixed-order reduction, Adam and the weight-image update of every iteration inside the kernel,

@@ -75,10 +75,11 @@ mutable struct HIPEngine
     h::Ptr{Cvoid}
     K::Int          # number of loss terms (pde terms first, then bcs: src/discretize.jl:569-570)
     P::Int          # length(θ)
+    precision::Symbol   # :f32 (fp32 kernels) | :f64 (float64 evaluation mode); follows `set_precision!`
     function HIPEngine(desc::AbstractString; device::Integer = -1)
         out = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall(sym(:pinn_create_on), Cint, (Cstring, Cint, Ref{Ptr{Cvoid}}), desc, device, out), "pinn_create")
-        e = new(out[], 0, 0)
+        e = new(out[], 0, 0, :f32)
         e.K = ccall(sym(:pinn_num_terms), Cint, (Ptr{Cvoid},), e.h)
         e.P = ccall(sym(:pinn_num_theta), Int64, (Ptr{Cvoid},), e.h)
         # (no HIP events around the kernels of an evaluation — the library's default; profiling callers switch them on with pinn_set_timing)
@@ -89,9 +90,17 @@ end
 
 "Install the collocation set of term `k` (1-based): `pts` is the reference's `d × N` matrix (column-major == point-major, no transpose)."
 function set_points!(e::HIPEngine, k::Integer, pts::AbstractMatrix; n_norm::Integer = 0)
-    p32 = Matrix{Float32}(pts)                       # EltypeAdaptor of the reference (src/eltype_matching.jl:8-10): device dtype is fp32
-    GC.@preserve p32 check(ccall(sym(:pinn_set_points), Cint, (Ptr{Cvoid}, Cint, Ptr{Float32}, Int64, Int64),
-                                 e.h, k - 1, p32, size(p32, 2), n_norm), "pinn_set_points")
+    # EltypeAdaptor of the reference (src/eltype_matching.jl:8-10): the points take the compute dtype — Float64 in float64 mode
+    # (pinn_set_points_f64: the double kernels read them as given), Float32 for the fp32 kernels
+    if e.precision === :f64
+        p64 = Matrix{Float64}(pts)
+        GC.@preserve p64 check(ccall(sym(:pinn_set_points_f64), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Int64, Int64),
+                                     e.h, k - 1, p64, size(p64, 2), n_norm), "pinn_set_points_f64")
+    else
+        p32 = Matrix{Float32}(pts)
+        GC.@preserve p32 check(ccall(sym(:pinn_set_points), Cint, (Ptr{Cvoid}, Cint, Ptr{Float32}, Int64, Int64),
+                                     e.h, k - 1, p32, size(p32, 2), n_norm), "pinn_set_points")
+    end
     return nothing
 end
 
@@ -180,7 +189,24 @@ Adam loop, the device samplers, per-point DATA channels and the device-pointer e
 function set_precision!(e::HIPEngine, mode::Symbol)
     mode in (:f64, :f32) || throw(ArgumentError("precision must be :f64 or :f32"))
     check(ccall(sym(:pinn_set_option), Cint, (Ptr{Cvoid}, Cstring, Cstring), e.h, "precision", String(mode)), "pinn_set_option")
+    e.precision = mode
     return nothing
+end
+
+"""
+    resolve_precision(precision::Symbol, θ) -> :f32 | :f64
+
+The glue's PRECISION POLICY (r06) = the reference's contract, compute dtype = eltype(θ) (src/eltype_matching.jl:8-10; `init_params` are
+Float64 unless the user passes Float32 ones, src/discretize.jl:432-449):
+`:auto` (default of `HIPStrategy` / `hip_discretize`) selects the float64 kernels for `eltype(θ) == Float64` and the fp32 kernels for
+`Float32`; `:f32` is the explicit fast opt-in (fp32 kernels whatever eltype(θ), 7-8x faster on the matrix pipe, results converted at
+the boundary); `:f64` forces the float64 kernels.  A problem the float64 kernels do not cover (DGM networks, periodic embeddings) fails
+at `discretize` time under `:auto` with the library's message — never a silent narrowing; pass `precision = :f32` for it.
+"""
+function resolve_precision(precision::Symbol, θ)
+    precision in (:auto, :f32, :f64) || throw(ArgumentError("precision must be :auto, :f32 or :f64"))
+    precision === :auto || return precision
+    return eltype(ComponentArrays.getdata(θ)) === Float32 ? :f32 : :f64
 end
 
 """
@@ -209,30 +235,68 @@ function loss_grad_device_f64!(e::HIPEngine, dθ::Ptr{Float64}, dout::Ptr{Float6
     return nothing
 end
 
-"Per-term gradients `K × P` (row k = ∂ term_losses[k] / ∂θ): what GradientScaleAdaptiveLoss and the per-term rrules consume."
+# The per-point / per-term closures cross the boundary in DOUBLE (r06: pinn_*_f64).  On an engine in float64 mode the double kernels evaluate
+# them — the reference computes all of them in eltype(θ) (src/pinn_types.jl:88-90, 435-439, 445-482) — and nothing is narrowed; on an fp32 engine
+# the library narrows / widens at the boundary, so the same glue serves both.
+"Per-term gradients `P × K` (column k = ∂ term_losses[k] / ∂θ): what GradientScaleAdaptiveLoss and the per-term rrules consume."
 function term_grads(e::HIPEngine, θ::AbstractVector{<:Real})
-    θ32 = Vector{Float32}(θ)
+    θ64 = Vector{Float64}(θ)
     losses = zeros(Float64, e.K)
-    tg = zeros(Float32, e.P, e.K)                    # C row-major K × P == Julia column-major P × K
-    GC.@preserve θ32 losses tg check(ccall(sym(:pinn_term_grads), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64, Ptr{Float64}, Ptr{Float32}),
-                                           e.h, θ32, e.P, losses, tg), "pinn_term_grads")
+    tg = zeros(Float64, e.P, e.K)                    # C row-major K × P == Julia column-major P × K
+    GC.@preserve θ64 losses tg check(ccall(sym(:pinn_term_grads_f64), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}),
+                                           e.h, θ64, e.P, losses, tg), "pinn_term_grads_f64")
     return losses, tg
 end
 
 "`residual_k(set_k, θ)`: the datafree loss function of src/discretize.jl:174 on the installed set (1 × N like the reference)."
 function residual(e::HIPEngine, k::Integer, θ::AbstractVector{<:Real}, n::Integer)
-    θ32 = Vector{Float32}(θ); r = zeros(Float32, n)
-    GC.@preserve θ32 r check(ccall(sym(:pinn_residual), Cint, (Ptr{Cvoid}, Cint, Ptr{Float32}, Int64, Ptr{Float32}), e.h, k - 1, θ32, e.P, r),
-                             "pinn_residual")
-    return reshape(Float64.(r), 1, :)
+    θ64 = Vector{Float64}(θ); r = zeros(Float64, n)
+    GC.@preserve θ64 r check(ccall(sym(:pinn_residual_f64), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Int64, Ptr{Float64}), e.h, k - 1, θ64, e.P, r),
+                             "pinn_residual_f64")
+    return reshape(r, 1, :)
 end
 
 "`phi(x, θ)` of network `net` (1-based) through the engine (src/pinn_types.jl:88-90)."
 function phi(e::HIPEngine, net::Integer, θ::AbstractVector{<:Real}, x::AbstractMatrix)
-    θ32 = Vector{Float32}(θ); x32 = Matrix{Float32}(x); out = zeros(Float32, size(x32, 2))
-    GC.@preserve θ32 x32 out check(ccall(sym(:pinn_phi), Cint, (Ptr{Cvoid}, Cint, Ptr{Float32}, Int64, Ptr{Float32}, Int64, Ptr{Float32}),
-                                         e.h, net - 1, θ32, e.P, x32, size(x32, 2), out), "pinn_phi")
-    return reshape(Float64.(out), 1, :)
+    θ64 = Vector{Float64}(θ); x64 = Matrix{Float64}(x); out = zeros(Float64, size(x64, 2))
+    GC.@preserve θ64 x64 out check(ccall(sym(:pinn_phi_f64), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Float64}),
+                                         e.h, net - 1, θ64, e.P, x64, size(x64, 2), out), "pinn_phi_f64")
+    return reshape(out, 1, :)
+end
+
+"""
+    derivative(e, net, θ, x, axes) -> 1 × N
+
+`numeric_derivative(phi, u, x, εs, order, θ)` of the reference (src/pinn_types.jl:445-482) through the engine: the EXACT derivative of the trial
+function of network `net` along `axes` (1-based input axes, `length(axes)` = order) — the value the reference's central differences
+approximate to atol 1e-8 (order 1) / 4e-5 (order 2) in Float64 (test/Forward/forward__derivatives.jl:29-44), met at those tolerances by an
+engine in float64 mode (tests/test_f64_mode.py).
+"""
+function derivative(e::HIPEngine, net::Integer, θ::AbstractVector{<:Real}, x::AbstractMatrix, axes::AbstractVector{<:Integer})
+    θ64 = Vector{Float64}(θ); x64 = Matrix{Float64}(x); out = zeros(Float64, size(x64, 2))
+    ax = Cint[a - 1 for a in axes]
+    isempty(ax) && return phi(e, net, θ, x)
+    GC.@preserve θ64 x64 ax out check(ccall(sym(:pinn_derivative_f64), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Cint, Ptr{Cint}, Ptr{Float64}),
+        e.h, net - 1, θ64, e.P, x64, size(x64, 2), length(ax), ax, out), "pinn_derivative_f64")
+    return reshape(out, 1, :)
+end
+
+"""
+    loglik_grad(e, θ, stds) -> (loglik, ∇θ, ∂/∂stds)
+
+BPINN physics (+ data) log-likelihood `Σ_k logpdf(MvNormal(r_k, σ_k² I), 0)` and its gradients in ONE device evaluation
+(`pinn_loglik_grad_f64`; src/training_strategies.jl:113-127, ext/bpinn/PDE_BPINN.jl:16-26) — what an HMC leapfrog step needs instead of the
+reference's ForwardDiff sweep over all P parameters (ext/bpinn/PDE_BPINN.jl:519).
+"""
+function loglik_grad(e::HIPEngine, θ::AbstractVector{<:Real}, stds::AbstractVector{<:Real})
+    θ64 = Vector{Float64}(θ); sd = Vector{Float64}(stds)
+    length(sd) == e.K || throw(DimensionMismatch("need one std per loss term ($(e.K))"))
+    ll = Ref{Float64}(0.0); g = zeros(Float64, e.P); gs = zeros(Float64, e.K)
+    GC.@preserve θ64 sd g gs check(ccall(sym(:pinn_loglik_grad_f64), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}, Ref{Float64}, Ptr{Float64}, Ptr{Float64}),
+        e.h, θ64, e.P, sd, ll, g, gs), "pinn_loglik_grad_f64")
+    return ll[], g, gs
 end
 
 # ------------------------------------------------------------------------------------------------
@@ -421,7 +485,11 @@ end
 # 3a. plug-in point (1): training strategy
 # ------------------------------------------------------------------------------------------------
 """
-    HIPStrategy(inner)
+    HIPStrategy(inner; precision = :auto)
+
+`precision`: `:auto` (default) = compute dtype follows `eltype(θ)` as in the reference (src/eltype_matching.jl:8-10) — Float64 parameters,
+the reference's default, run the float64 kernels, Float32 `init_params` the fp32 kernels; `:f32` = the fp32 kernels whatever eltype(θ)
+(the explicit fast opt-in); `:f64` = the float64 kernels (`resolve_precision`).
 
 `inner` is the reference strategy whose POINT SETS are used (`GridTraining`, `StochasticTraining`, `QuasiRandomTraining`); the residual,
 `mean(abs2, ·)` and the gradient run on the engine.  Use it wherever a strategy goes:
@@ -429,7 +497,9 @@ end
 """
 struct HIPStrategy{S} <: AbstractTrainingStrategy
     inner::S
+    precision::Symbol        # :auto (compute dtype = eltype(θ), the reference's contract) | :f32 (explicit fast opt-in) | :f64
 end
+HIPStrategy(inner; precision::Symbol = :auto) = HIPStrategy(inner, precision)
 
 # shared state of all closures of one discretisation: one fused evaluation per θ serves every term
 mutable struct HIPState
@@ -442,7 +512,7 @@ mutable struct HIPState
     losses::Vector{Float64}
     grad::Vector{Float64}                        # of Σ w_k L_k under `weights`; empty after a loss-only evaluation
     weights::Vector{Float64}
-    tgrads::Union{Nothing, Matrix{Float32}}      # P × K per-term gradients (filled on the first per-term pullback at a θ)
+    tgrads::Union{Nothing, Matrix{Float64}}      # P × K per-term gradients (filled on the first per-term pullback at a θ)
     tgrads_key::UInt64                           # hash(θ) the per-term gradients were computed at (per-term gradients do not depend on the weights);
                                                  # pullbacks may run out of order (nested AD, several closures / threads), so it is compared, not st.key
     eager_grad::Bool                             # true (hip_discretize): a plain call of a term closure already runs the fused loss + gradient
@@ -504,7 +574,7 @@ function ChainRulesCore.rrule(f::HIPTermLoss, θ)
                 _, st.tgrads = term_grads(st.engine, flat)
                 st.tgrads_key = hash(flat)
             end
-            Float64.(view(st.tgrads, :, f.k))
+            copy(view(st.tgrads, :, f.k))
         end
         g = tg .* ChainRulesCore.unthunk(ȳ)
         return NoTangent(), θ isa ComponentArray ? ComponentArray(g, ComponentArrays.getaxes(θ)) : g
@@ -537,9 +607,11 @@ end
 point_sets(pinnrep, s) = throw(HIPEngineError("HIPStrategy wraps GridTraining, StochasticTraining or QuasiRandomTraining (got $(typeof(s))); " *
                                               "QuadratureTraining's adaptive cubature is a host algorithm"))
 
-function build_state(pinnrep::PINNRepresentation, inner)
+function build_state(pinnrep::PINNRepresentation, inner; precision::Symbol = :auto)
     sets, resample = point_sets(pinnrep, inner)
     engine = HIPEngine(descriptor(pinnrep; hints = [size(s, 2) for s in sets]))
+    # compute dtype = eltype(θ) unless the caller opted into :f32 / :f64 (resolve_precision); the float64 mode refuses what it does not cover HERE
+    resolve_precision(precision, pinnrep.flat_init_params) === :f64 && set_precision!(engine, :f64)
     verify_layout(engine, pinnrep)
     for (k, s) in enumerate(sets)
         set_points!(engine, k, s)
@@ -560,7 +632,7 @@ end
 
 function NeuralPDE.merge_strategy_with_loss_function(pinnrep::PINNRepresentation, strategy::HIPStrategy,
                                                     datafree_pde_loss_function, datafree_bc_loss_function)
-    st = build_state(pinnrep, strategy.inner)
+    st = build_state(pinnrep, strategy.inner; precision = strategy.precision)
     n_pde, n_bc = length(datafree_pde_loss_function), length(datafree_bc_loss_function)
     n_pde + n_bc == st.engine.K || throw(HIPEngineError("engine has $(st.engine.K) terms, the discretisation $(n_pde + n_bc)"))
     return [HIPTermLoss(st, k) for k in 1:n_pde], [HIPTermLoss(st, n_pde + j) for j in 1:n_bc]
@@ -570,15 +642,15 @@ end
 # 3b. plug-in point (2): the fast path — explicit gradient, one fused device call per optimiser iteration
 # ------------------------------------------------------------------------------------------------
 """
-    prob = hip_discretize(pde_system, discretization::PhysicsInformedNN)
+    prob = hip_discretize(pde_system, discretization::PhysicsInformedNN; precision = :auto)
 
 Same `OptimizationProblem` as `discretize` (src/discretize.jl:776-780: objective `full_loss_function`, `u0 = flat_init_params`), but the
 `OptimizationFunction` carries an explicit `grad`: the engine's fused `∇θ Σ_k w_k L_k` (+ the Zygote gradient of `additional_loss`, which
 stays a Julia function).  The objective itself is the reference's own `full_loss_function`, so the iteration counter, adaptive
 reweighting and logging behave as always; value and gradient of one iterate share ONE device evaluation (memoised on θ and weights).
 """
-function hip_discretize(pde_system, discretization::PhysicsInformedNN)
-    strat = discretization.strategy isa HIPStrategy ? discretization.strategy : HIPStrategy(discretization.strategy)
+function hip_discretize(pde_system, discretization::PhysicsInformedNN; precision::Symbol = :auto)
+    strat = discretization.strategy isa HIPStrategy ? discretization.strategy : HIPStrategy(discretization.strategy; precision = precision)
     disc = discretization.strategy isa HIPStrategy ? discretization : rebuild(discretization, strat)
     pinnrep = SciMLBase.symbolic_discretize(pde_system, disc)
     st = state_of(pinnrep)
@@ -681,7 +753,7 @@ difference (expected ~1e-7 for Float64 θ: the central-difference error of the r
 """
 function selftest(pde_system, discretization::PhysicsInformedNN; rtol = 1.0e-4)
     ref = SciMLBase.symbolic_discretize(pde_system, discretization)
-    st = build_state(ref, GridTraining(0.1))                  # engine built from the REFERENCE's pinnrep, on its GridTraining(0.1) sets
+    st = build_state(ref, GridTraining(0.1))                  # engine built from the REFERENCE's pinnrep, on its GridTraining(0.1) sets; precision :auto = eltype(θ)
     θ = ref.flat_init_params
     flat = collect(Float64, ComponentArrays.getdata(θ))
     dfs = vcat(ref.loss_functions.datafree_pde_loss_functions, ref.loss_functions.datafree_bc_loss_functions)

@@ -36,6 +36,7 @@ SYMBOLS = [
     "pinn_loss_device", "pinn_group_launched_by",
     "pinn_set_option", "pinn_get_option", "pinn_set_points_f64", "pinn_comm_init_custom", "pinn_adam_steps_sharded", "pinn_adam_apply",
     "pinn_adam_init_f64", "pinn_adam_get_f64", "pinn_set_point_data_f64", "pinn_loss_grad_device_f64",
+    "pinn_residual_f64", "pinn_phi_f64", "pinn_derivative_f64", "pinn_term_grads_f64", "pinn_loglik_grad_f64",
 ]
 
 
@@ -100,6 +101,11 @@ class Library:
             L.pinn_adam_get_f64.argtypes = [vp, dp, C.c_int64]
             L.pinn_set_point_data_f64.argtypes = [vp, C.c_int, dp, C.c_int, C.c_int64]
             L.pinn_loss_grad_device_f64.argtypes = [vp, vp, fp, vp, vp]
+            L.pinn_residual_f64.argtypes = [vp, C.c_int, dp, C.c_int64, dp]
+            L.pinn_phi_f64.argtypes = [vp, C.c_int, dp, C.c_int64, dp, C.c_int64, dp]
+            L.pinn_derivative_f64.argtypes = [vp, C.c_int, dp, C.c_int64, dp, C.c_int64, C.c_int, C.POINTER(C.c_int), dp]
+            L.pinn_term_grads_f64.argtypes = [vp, dp, C.c_int64, dp, dp]
+            L.pinn_loglik_grad_f64.argtypes = [vp, dp, C.c_int64, dp, dp, dp, dp]
         except AttributeError:
             pass
         L.pinn_lbfgs.argtypes = [vp, C.POINTER(C.c_double), C.c_int64, C.c_int, C.c_int, C.c_double, fp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -143,6 +149,10 @@ def set_library(lib: Optional[Library]):
 
 def _f32(a) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def _f64(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
 
 
 COMM_ID_BYTES = 128
@@ -272,6 +282,30 @@ class Engine:
                                                 tg.ctypes.data_as(C.POINTER(C.c_float))), "pinn_term_grads")
         return losses, tg
 
+    def term_grads_f64(self, theta):
+        """`pinn_term_grads_f64`: theta and the K x P per-term gradients in double (native in float64 mode)"""
+        th = _f64(theta)
+        losses = np.zeros(self.K, dtype=np.float64)
+        tg = np.zeros((self.K, self.P), dtype=np.float64)
+        self.L.check(self.L.lib.pinn_term_grads_f64(self.h, th.ctypes.data_as(C.POINTER(C.c_double)), th.size,
+                                                    losses.ctypes.data_as(C.POINTER(C.c_double)),
+                                                    tg.ctypes.data_as(C.POINTER(C.c_double))), "pinn_term_grads_f64")
+        return losses, tg
+
+    def loglik_grad_f64(self, theta, stds, want_grad: bool = True):
+        """`pinn_loglik_grad_f64`: theta and d loglik / d theta in double (native in float64 mode)"""
+        th = _f64(theta)
+        sd = _f64(stds)
+        if sd.shape != (self.K,):
+            raise ValueError(f"need one std per loss term ({self.K})")
+        ll = C.c_double()
+        g = np.zeros(self.P, dtype=np.float64) if want_grad else None
+        gs = np.zeros(self.K, dtype=np.float64)
+        self.L.check(self.L.lib.pinn_loglik_grad_f64(self.h, th.ctypes.data_as(C.POINTER(C.c_double)), th.size, sd.ctypes.data_as(C.POINTER(C.c_double)),
+                                                     C.byref(ll), g.ctypes.data_as(C.POINTER(C.c_double)) if g is not None else None,
+                                                     gs.ctypes.data_as(C.POINTER(C.c_double))), "pinn_loglik_grad_f64")
+        return ll.value, g, gs
+
     def loglik_grad(self, theta, stds, want_grad: bool = True):
         """BPINN log-likelihood sum_k logpdf(MvNormal(r_k, std_k^2 I), 0), d/dtheta and d/dstd (pinn_loglik_grad)"""
         th = _f32(theta)
@@ -328,6 +362,36 @@ class Engine:
         self.L.check(self.L.lib.pinn_residual(self.h, term, th.ctypes.data_as(C.POINTER(C.c_float)), th.size,
                                               r.ctypes.data_as(C.POINTER(C.c_float))), "pinn_residual")
         return r
+
+    def residual_f64(self, term: int, theta, n: int) -> np.ndarray:
+        """`pinn_residual_f64`: the term's residuals in double (native in float64 mode: equal to a Float64 evaluation to rounding)"""
+        th = _f64(theta)
+        r = np.zeros(n, dtype=np.float64)
+        self.L.check(self.L.lib.pinn_residual_f64(self.h, term, th.ctypes.data_as(C.POINTER(C.c_double)), th.size,
+                                                  r.ctypes.data_as(C.POINTER(C.c_double))), "pinn_residual_f64")
+        return r
+
+    def phi_f64(self, net: int, theta, pts) -> np.ndarray:
+        """`pinn_phi_f64`: the trial function at the columns of pts (d x N), everything in double"""
+        return self.derivative_f64(net, theta, pts, ())
+
+    def derivative_f64(self, net: int, theta, pts, axes: Sequence[int]) -> np.ndarray:
+        """`pinn_derivative_f64`: d^k phi_net / dx_axes in double (numeric_derivative at the reference's Float64 tolerances,
+        test/Forward/forward__derivatives.jl:29-44)"""
+        th = _f64(theta)
+        pts = np.asarray(pts, dtype=np.float64)
+        flat = np.ascontiguousarray(pts.T).reshape(-1)
+        out = np.zeros(pts.shape[1], dtype=np.float64)
+        ax = (C.c_int * max(len(axes), 1))(*[int(a) for a in axes])
+        if len(axes) == 0:
+            self.L.check(self.L.lib.pinn_phi_f64(self.h, net, th.ctypes.data_as(C.POINTER(C.c_double)), th.size,
+                                                 flat.ctypes.data_as(C.POINTER(C.c_double)), pts.shape[1],
+                                                 out.ctypes.data_as(C.POINTER(C.c_double))), "pinn_phi_f64")
+        else:
+            self.L.check(self.L.lib.pinn_derivative_f64(self.h, net, th.ctypes.data_as(C.POINTER(C.c_double)), th.size,
+                                                        flat.ctypes.data_as(C.POINTER(C.c_double)), pts.shape[1], len(axes), ax,
+                                                        out.ctypes.data_as(C.POINTER(C.c_double))), "pinn_derivative_f64")
+        return out
 
     def phi(self, net: int, theta, pts) -> np.ndarray:
         th = _f32(theta)

@@ -43,7 +43,7 @@ def loglikelihood(engine, theta, stds: Sequence[float], want_grad: bool = True):
     """The same log-likelihood through the engine's own entry point `pinn_loglik_grad`: returns (loglik, d/dtheta, d/dstds) — the stds
     as trailing sampler parameters (`allstd` of ext/bpinn/PDE_BPINN.jl:16-26 when they are not fixed).  Terms may include DataLoss
     terms: with their own std they are the L2LossData term (ext/bpinn/PDE_BPINN.jl:148-183), evaluated in the same fused call."""
-    ll, g, gs = engine.loglik_grad(theta, stds, want_grad=want_grad)
+    ll, g, gs = engine.loglik_grad_f64(theta, stds, want_grad=want_grad)      # (double at the ABI: native on a handle in float64 mode, fp32 kernels + widening otherwise)
     return ll, (None if g is None else g.astype(np.float64)), gs
 
 
@@ -185,7 +185,7 @@ def ahmc_bayesian_pinn_pde(npde, pde_system, discretization, draw_samples=1000, 
     nn = eng.P - ninv
 
     def logp_grad(th):
-        ll, g, _ = eng.loglik_grad(th, stds)
+        ll, g, _ = eng.loglik_grad_f64(th, stds)
         g = g.astype(np.float64)
         w = th[:nn]
         lp = ll - 0.5 * np.sum(((w - mu0) / sd0) ** 2) - nn * (np.log(sd0) + 0.5 * np.log(2 * np.pi))

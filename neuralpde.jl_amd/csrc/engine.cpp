@@ -628,14 +628,48 @@ int pinn_loss_grad_f64(pinn_handle h, const double* theta, int64_t p, const doub
     return 0;
 }
 
+// l = sum_k logpdf(MvNormal(r_k, sigma_k^2 I), 0) = sum_k [ -N_k/2 log(2 pi) - N_k log sigma_k - SSE_k / (2 sigma_k^2) ]
+// (src/training_strategies.jl:113-127; "SSE not MSE", src/discretize.jl:681): an affine function of the per-term sums of squares,
+// so grad_theta l = - grad_theta sum_k w_k L_k with w_k = N_k / (2 sigma_k^2): ONE weighted evaluation.  sse[k]: raw sums of squares.
+static void loglik_from_sse(const pinn_engine& E, const double* stds, const double* sse, double* loglik, double* grad_std) {
+    const int K = (int)E.terms.size();
+    double ll = 0.0;
+    for (int k = 0; k < K; ++k) {
+        // sharded point sets (n < n_norm): every quantity returned here is THIS SHARD'S additive part — the constants count the shard's
+        // own points — so that loglik, grad_theta and grad_std summed over the ranks are the global values
+        const double N = (double)E.terms[k].n, sd = stds[k];
+        ll += -0.5 * N * std::log(2.0 * 3.14159265358979323846) - N * std::log(sd) - sse[k] / (2.0 * sd * sd);
+        if (grad_std) grad_std[k] = -N / sd + sse[k] / (sd * sd * sd);
+    }
+    *loglik = ll;
+}
+// the float64-mode evaluation behind both pinn_loglik_grad entry points: grad_theta in double
+static int loglik_f64(pinn_engine& E, const double* theta, const double* stds, double* loglik, double* grad_theta, double* grad_std) {
+    const int K = (int)E.terms.size();
+    std::vector<double> w(K), L(K), g(grad_theta ? (size_t)E.ntheta : 0);
+    for (int k = 0; k < K; ++k) {
+        if (!(stds[k] > 0.0)) return fail("pinn_loglik_grad: standard deviations must be positive");
+        w[k] = (double)E.terms[k].n_norm / (2.0 * stds[k] * stds[k]);
+    }
+    if (f64_eval(E, theta, w.data(), L.data(), grad_theta ? g.data() : nullptr)) return 1;
+    for (int k = 0; k < K; ++k) L[k] *= (double)E.terms[k].n_norm;           // mean -> SSE
+    loglik_from_sse(E, stds, L.data(), loglik, grad_std);
+    if (grad_theta) for (int64_t i = 0; i < E.ntheta; ++i) grad_theta[i] = -g[(size_t)i];
+    return 0;
+}
+
 int pinn_loglik_grad(pinn_handle h, const float* theta, int64_t p, const double* stds, double* loglik, float* grad_theta, double* grad_std) {
     if (!h || !theta || !stds || !loglik) return fail("pinn_loglik_grad: null argument");
     pinn_engine& E = *h;
     DeviceScope scope(E.device);
     const int K = (int)E.terms.size();
-    // l = sum_k logpdf(MvNormal(r_k, sigma_k^2 I), 0) = sum_k [ -N_k/2 log(2 pi) - N_k log sigma_k - SSE_k / (2 sigma_k^2) ]
-    // (src/training_strategies.jl:113-127; "SSE not MSE", src/discretize.jl:681): an affine function of the per-term sums of squares,
-    // so grad_theta l = - grad_theta sum_k w_k L_k with w_k = N_k / (2 sigma_k^2): ONE weighted evaluation
+    if (E.f64) {                                         // float64 mode: converted at the boundary, evaluated in double
+        if (p != E.ntheta) return fail("pinn_loglik_grad: theta length mismatch");
+        std::vector<double> th(theta, theta + p), g(grad_theta ? (size_t)p : 0);
+        if (loglik_f64(E, th.data(), stds, loglik, grad_theta ? g.data() : nullptr, grad_std)) return 1;
+        if (grad_theta) for (int64_t i = 0; i < p; ++i) grad_theta[i] = (float)g[(size_t)i];
+        return 0;
+    }
     std::vector<float> w(K);
     for (int k = 0; k < K; ++k) {
         if (!(stds[k] > 0.0)) return fail("pinn_loglik_grad: standard deviations must be positive");
@@ -644,17 +678,38 @@ int pinn_loglik_grad(pinn_handle h, const float* theta, int64_t p, const double*
     if (upload_theta(E, theta, p)) return 1;
     if (run_loss_grad(E, E.d_theta, E.hp_out, w.data(), -1, false, E.hp_raw)) return 1;
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
-    double ll = 0.0;
-    for (int k = 0; k < K; ++k) {
-        // sharded point sets (n < n_norm): every quantity returned here is THIS SHARD'S additive part — the constants count the shard's
-        // own points — so that loglik, grad_theta and grad_std summed over the ranks are the global values
-        const double N = (double)E.terms[k].n, sse = E.hp_raw[k], sd = stds[k];
-        ll += -0.5 * N * std::log(2.0 * 3.14159265358979323846) - N * std::log(sd) - sse / (2.0 * sd * sd);
-        if (grad_std) grad_std[k] = -N / sd + sse / (sd * sd * sd);
-    }
-    *loglik = ll;
+    loglik_from_sse(E, stds, E.hp_raw, loglik, grad_std);
     if (grad_theta)
         for (int64_t i = 0; i < E.ntheta; ++i) grad_theta[i] = -E.hp_out[i];
+    return 0;
+}
+
+int pinn_loglik_grad_f64(pinn_handle h, const double* theta, int64_t p, const double* stds, double* loglik, double* grad_theta, double* grad_std) {
+    if (!h || !theta || !stds || !loglik) return fail("pinn_loglik_grad_f64: null argument");
+    pinn_engine& E = *h;
+    if (p != E.ntheta) return fail("pinn_loglik_grad_f64: theta length mismatch");
+    if (E.f64) {
+        DeviceScope scope(E.device);
+        return loglik_f64(E, theta, stds, loglik, grad_theta, grad_std);
+    }
+    std::vector<float> th((size_t)p), g(grad_theta ? (size_t)p : 0);
+    for (int64_t i = 0; i < p; ++i) th[(size_t)i] = (float)theta[i];
+    if (pinn_loglik_grad(h, th.data(), p, stds, loglik, grad_theta ? g.data() : nullptr, grad_std)) return 1;
+    if (grad_theta) for (int64_t i = 0; i < p; ++i) grad_theta[i] = (double)g[(size_t)i];
+    return 0;
+}
+
+// float64 mode: K evaluations with one-hot weights (the double kernels evaluate whole problems; per-term statistics are not their hot path);
+// row k of term_grads (K x P doubles) = d term_losses[k] / d theta
+static int term_grads_f64(pinn_engine& E, const double* theta, double* term_losses, double* term_grads) {
+    const int K = (int)E.terms.size();
+    const int64_t p = E.ntheta;
+    std::vector<double> w(K), L(K);
+    for (int k = 0; k < K; ++k) {
+        for (int j = 0; j < K; ++j) w[j] = (j == k) ? 1.0 : 0.0;
+        if (f64_eval(E, theta, w.data(), L.data(), term_grads + (size_t)k * p)) return 1;
+        if (term_losses) term_losses[k] = L[k];
+    }
     return 0;
 }
 
@@ -663,15 +718,11 @@ int pinn_term_grads(pinn_handle h, const float* theta, int64_t p, double* term_l
     pinn_engine& E = *h;
     DeviceScope scope(E.device);
     const int K = (int)E.terms.size();
-    if (E.f64) {                                         // float64 mode: K evaluations with one-hot weights (the double kernels evaluate whole
-        if (p != E.ntheta) return fail("pinn_term_grads: theta length mismatch");      // problems; per-term statistics are not their hot path)
-        std::vector<double> th(theta, theta + p), w(K), L(K), g((size_t)p);
-        for (int k = 0; k < K; ++k) {
-            for (int j = 0; j < K; ++j) w[j] = (j == k) ? 1.0 : 0.0;
-            if (f64_eval(E, th.data(), w.data(), L.data(), g.data())) return 1;
-            for (int64_t i = 0; i < p; ++i) term_grads[(size_t)k * p + i] = (float)g[(size_t)i];
-            if (term_losses) term_losses[k] = L[k];
-        }
+    if (E.f64) {                                         // float64 mode: converted at the boundary
+        if (p != E.ntheta) return fail("pinn_term_grads: theta length mismatch");
+        std::vector<double> th(theta, theta + p), g((size_t)K * p);
+        if (term_grads_f64(E, th.data(), term_losses, g.data())) return 1;
+        for (size_t i = 0; i < g.size(); ++i) term_grads[i] = (float)g[i];
         return 0;
     }
     if (upload_theta(E, theta, p)) return 1;
@@ -681,6 +732,22 @@ int pinn_term_grads(pinn_handle h, const float* theta, int64_t p, double* term_l
         std::memcpy(term_grads + (size_t)k * p, E.hp_out, sizeof(float) * p);
         if (term_losses) term_losses[k] = E.hp_raw[k] / (double)E.terms[k].n_norm;
     }
+    return 0;
+}
+
+int pinn_term_grads_f64(pinn_handle h, const double* theta, int64_t p, double* term_losses, double* term_grads) {
+    if (!h || !theta || !term_grads) return fail("pinn_term_grads_f64: null argument");
+    pinn_engine& E = *h;
+    if (p != E.ntheta) return fail("pinn_term_grads_f64: theta length mismatch");
+    const int K = (int)E.terms.size();
+    if (E.f64) {
+        DeviceScope scope(E.device);
+        return term_grads_f64(E, theta, term_losses, term_grads);
+    }
+    std::vector<float> th((size_t)p), g((size_t)K * p);
+    for (int64_t i = 0; i < p; ++i) th[(size_t)i] = (float)theta[i];
+    if (pinn_term_grads(h, th.data(), p, term_losses, g.data())) return 1;
+    for (size_t i = 0; i < g.size(); ++i) term_grads[i] = (double)g[i];
     return 0;
 }
 
@@ -738,8 +805,16 @@ int pinn_residual(pinn_handle h, int term, const float* theta, int64_t p, float*
     if (term < 0 || term >= (int)E.terms.size()) return fail("pinn_residual: term index out of range");
     Term& T = E.terms[term];
     if (!T.d_pts) return fail("pinn_residual: term has no points");
+    if (E.f64) {                                         // float64 mode: converted at the boundary, evaluated in double
+        if (p != E.ntheta) return fail("pinn_residual: theta length mismatch");
+        std::vector<double> th(theta, theta + p), rd((size_t)T.n);
+        if (f64_residual(E, term, th.data(), rd.data())) return 1;
+        for (int64_t i = 0; i < T.n; ++i) r[i] = (float)rd[(size_t)i];
+        return 0;
+    }
     if (upload_theta(E, theta, p)) return 1;
     pack_all(E);
+    jit_take_launch_error();                             // (a stale message of an earlier call must not fail this one)
     if (T.resid_cap < T.n) {
         plat_free(T.d_resid);
         T.d_resid = (float*)plat_malloc(sizeof(float) * T.n);
@@ -762,6 +837,7 @@ int pinn_residual(pinn_handle h, int term, const float* theta, int64_t p, float*
         aux::launch_expr(expr_args(E, Cp, 0.f, T.d_resid), Cp.blocks, E.stream);
         if (plat_d2h(r, T.d_resid, sizeof(float) * T.n, E.stream)) return fail("D2H copy failed");
         if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+        { const std::string le = jit_take_launch_error(); if (!le.empty()) return fail("pinn_residual: " + le); }
         return 0;
     }
     Group& G = E.groups[T.group];
@@ -775,6 +851,25 @@ int pinn_residual(pinn_handle h, int term, const float* theta, int64_t p, float*
     G.spec->launch(ga, pk::MODE_RESID, blocks, E.stream);
     if (plat_d2h(r, T.d_resid, sizeof(float) * T.n, E.stream)) return fail("D2H copy failed");
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    // a run-time specialised kernel whose (mode, activation) member could not be compiled at this, its first, launch leaves r unwritten
+    { const std::string le = jit_take_launch_error(); if (!le.empty()) return fail("pinn_residual: " + le); }
+    return 0;
+}
+
+int pinn_residual_f64(pinn_handle h, int term, const double* theta, int64_t p, double* r) {
+    if (!h || !theta || !r) return fail("pinn_residual_f64: null argument");
+    pinn_engine& E = *h;
+    if (term < 0 || term >= (int)E.terms.size()) return fail("pinn_residual_f64: term index out of range");
+    if (p != E.ntheta) return fail("pinn_residual_f64: theta length mismatch");
+    if (E.f64) {
+        DeviceScope scope(E.device);
+        return f64_residual(E, term, theta, r);
+    }
+    const int64_t n = E.terms[term].n;
+    std::vector<float> th((size_t)p), rf((size_t)std::max<int64_t>(n, 1));
+    for (int64_t i = 0; i < p; ++i) th[(size_t)i] = (float)theta[i];
+    if (pinn_residual(h, term, th.data(), p, rf.data())) return 1;
+    for (int64_t i = 0; i < n; ++i) r[i] = (double)rf[(size_t)i];
     return 0;
 }
 
@@ -786,6 +881,7 @@ static int forward_jets(pinn_engine& E, int net, const pk::SpecInfo* sp, const f
         return fail("internal: forward kernel and the network's packed weight image disagree");
     if (upload_theta(E, theta, p)) return 1;
     pack_all(E);
+    jit_take_launch_error();                             // (clear: the check behind the launch below reports THIS launch)
     if (E.phi_cap < n || E.phi_chan < sp->C) {
         plat_sync(E.stream);
         plat_free(E.d_phi_pts); plat_free(E.d_phi_out);
@@ -847,6 +943,7 @@ static int forward_jets(pinn_engine& E, int net, const pk::SpecInfo* sp, const f
     }
     const int blocks = std::max(1, std::min(E.ncu * sp->WG_FWD, sp->family == 1 ? (ga.ntiles + 3) / 4 : ga.ntiles));
     sp->launch(ga, pk::MODE_FWD, blocks, E.stream);
+    { const std::string le = jit_take_launch_error(); if (!le.empty()) return fail("forward kernel: " + le); }
     return 0;
 }
 
@@ -858,6 +955,14 @@ int pinn_phi(pinn_handle h, int net, const float* theta, int64_t p, const float*
     if (net < 0 || net >= (int)E.nets.size()) return fail("pinn_phi: net index out of range");
     if (n <= 0) return fail("pinn_phi: n must be positive");
     const Net& N = E.nets[net];
+    if (E.f64) {                                         // float64 mode: converted at the boundary, evaluated in double
+        if (p != E.ntheta) return fail("pinn_phi: theta length mismatch");
+        const size_t np_ = (size_t)n * N.sizes[0];
+        std::vector<double> th(theta, theta + p), xd(pts, pts + np_), od((size_t)n);
+        if (f64_net_eval(E, net, th.data(), xd.data(), n, 0, nullptr, od.data())) return 1;
+        for (int64_t i = 0; i < n; ++i) out[i] = (float)od[(size_t)i];
+        return 0;
+    }
     if (!E.netplans[net].spec) return fail("pinn_phi: network is not used by any term");
     const int LH = (int)N.sizes.size() - 2;
     (void)LH;
@@ -878,6 +983,14 @@ int pinn_derivative(pinn_handle h, int net, const float* theta, int64_t p, const
     if (n <= 0) return fail("pinn_derivative: n must be positive");
     if (order < 0 || order > MAX_DERIV_ORDER || (order > 0 && !axes)) return fail("pinn_derivative: order must be 0..6 (with `order` axes)");
     const Net& N = E.nets[net];
+    if (E.f64) {                                         // float64 mode: converted at the boundary, evaluated in double
+        if (p != E.ntheta) return fail("pinn_derivative: theta length mismatch");
+        const size_t np_ = (size_t)n * N.sizes[0];
+        std::vector<double> th(theta, theta + p), xd(pts, pts + np_), od((size_t)n);
+        if (f64_net_eval(E, net, th.data(), xd.data(), n, order, axes, od.data())) return 1;
+        for (int64_t i = 0; i < n; ++i) out[i] = (float)od[(size_t)i];
+        return 0;
+    }
     if (!E.netplans[net].spec) return fail("pinn_derivative: network is not used by any term");
     if (!N.emb_idx.empty()) return fail("pinn_derivative: not available for a network behind a periodic input embedding (use pinn_residual on a term that carries the derivative)");
     Slot sl;
@@ -903,6 +1016,32 @@ int pinn_derivative(pinn_handle h, int net, const float* theta, int64_t p, const
     if (forward_jets(E, net, sp, theta, p, pts, n)) return 1;
     if (plat_d2h(out, E.d_phi_out + (size_t)ch * n, sizeof(float) * n, E.stream)) return fail("D2H copy failed");
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    return 0;
+}
+
+// phi(x, theta) and numeric_derivative in double (r06): the reference's closures compute in eltype(theta) = Float64 by default
+// (src/pinn_types.jl:88-90, 445-482; src/discretize.jl:432-449).  Native on a handle in float64 mode; on an fp32 handle they narrow at the boundary.
+int pinn_phi_f64(pinn_handle h, int net, const double* theta, int64_t p, const double* pts, int64_t n, double* out) {
+    return pinn_derivative_f64(h, net, theta, p, pts, n, 0, nullptr, out);
+}
+int pinn_derivative_f64(pinn_handle h, int net, const double* theta, int64_t p, const double* pts, int64_t n, int order, const int* axes, double* out) {
+    if (!h || !theta || !pts || !out) return fail("pinn_derivative_f64: null argument");
+    pinn_engine& E = *h;
+    if (net < 0 || net >= (int)E.nets.size()) return fail("pinn_derivative_f64: net index out of range");
+    if (n <= 0) return fail("pinn_derivative_f64: n must be positive");
+    if (p != E.ntheta) return fail("pinn_derivative_f64: theta length mismatch");
+    if (order < 0 || order > MAX_DERIV_ORDER || (order > 0 && !axes)) return fail("pinn_derivative_f64: order must be 0..6 (with `order` axes)");
+    if (E.f64) {
+        DeviceScope scope(E.device);
+        return f64_net_eval(E, net, theta, pts, n, order, axes, out);
+    }
+    const size_t np_ = (size_t)n * E.nets[net].n_inputs();
+    std::vector<float> th((size_t)p), xf(np_), of((size_t)n);
+    for (int64_t i = 0; i < p; ++i) th[(size_t)i] = (float)theta[i];
+    for (size_t i = 0; i < np_; ++i) xf[i] = (float)pts[i];
+    const int rc = order == 0 ? pinn_phi(h, net, th.data(), p, xf.data(), n, of.data()) : pinn_derivative(h, net, th.data(), p, xf.data(), n, order, axes, of.data());
+    if (rc) return rc;
+    for (int64_t i = 0; i < n; ++i) out[i] = (double)of[(size_t)i];
     return 0;
 }
 
@@ -1604,6 +1743,7 @@ int pinn_adam_steps_sharded(pinn_handle* hs, int ndev, int nsteps, float lr, flo
     for (int i = 0; i < ndev; ++i) {
         if (!hs[i] || !hs[i]->comm || hs[i]->comm_per_process || hs[i]->comm_size != ndev || hs[i]->comm_rank != i)
             return fail("pinn_adam_steps_sharded: pass the handles of one pinn_comm_init_all communicator, in rank order");
+        if (hs[i]->f64) return fail("pinn_adam_steps_sharded: not available in the float64 evaluation mode (the sharded resident loop runs the fp32 kernels: pinn_set_option(h, \"precision\", \"f32\"), or drive the float64 evaluation per rank with pinn_loss_grad_device_f64 + your own all-reduce + pinn_adam_apply)");
         if (hs[i]->opt_t != hs[0]->opt_t) return fail("pinn_adam_steps_sharded: the handles' optimiser states are at different steps (pinn_adam_init every handle with the same theta)");
         DeviceScope scope(hs[i]->device);
         if (adam_prepare(*hs[i], nsteps, term_w, "pinn_adam_steps_sharded")) return 1;
@@ -1627,6 +1767,10 @@ int pinn_adam_apply(pinn_handle h, const float* grad_and_sums, int64_t n, float 
     DeviceScope scope(E.device);
     const int K = (int)E.terms.size(), P = (int)E.ntheta;
     if (n != (int64_t)P + K) return fail("pinn_adam_apply: the vector must hold P + K floats ([gradient | raw per-term sums])");
+    if (E.f64) {                                         // float64 mode: the optimiser state lives in double (f64.cpp)
+        std::vector<double> v(grad_and_sums, grad_and_sums + n);
+        return f64_adam_apply(E, v.data(), (double)lr, (double)beta1, (double)beta2, (double)eps, term_w, loss);
+    }
     if (adam_prepare(E, 1, term_w, "pinn_adam_apply")) return 1;
     if (plat_h2d(E.d_opt_out, grad_and_sums, sizeof(float) * (size_t)(P + K), E.stream)) return fail("H2D copy failed");
     ++E.opt_t;

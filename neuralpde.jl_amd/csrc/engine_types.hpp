@@ -312,6 +312,9 @@ int f64_points_changed(pinn_engine& E, int term);
 int f64_set_points(pinn_engine& E, int term, const double* pts, int64_t n);
 int f64_set_point_data(pinn_engine& E, int term, const double* data);      // nullptr: convert the float rows just installed
 int f64_eval(pinn_engine& E, const double* theta, const double* term_w, double* term_losses, double* grad);
+int f64_residual(pinn_engine& E, int term, const double* theta, double* r);      // host theta, host r[n_term]
+int f64_net_eval(pinn_engine& E, int net, const double* theta, const double* pts, int64_t n, int order, const int* axes, double* out);      // d^order phi_net / dx_axes at host points
+int f64_adam_apply(pinn_engine& E, const double* grad_and_sums, double lr, double beta1, double beta2, double eps, const float* term_w, double* loss);
 int f64_adam_init(pinn_engine& E, const double* theta);
 int f64_adam_get(pinn_engine& E, double* theta);
 int f64_adam_steps(pinn_engine& E, int nsteps, double lr, double beta1, double beta2, double eps, const float* term_w, double* loss_history,

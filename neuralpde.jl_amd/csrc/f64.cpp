@@ -40,7 +40,8 @@ struct F64Term {
 };
 struct F64State {
     std::vector<F64Term> terms;
-    double* d_theta = nullptr;
+    double* d_theta = nullptr;           // [P] parameters of the running EVALUATION (host-entry evaluations upload here; never the optimiser's iterate)
+    double* d_opt_theta = nullptr;       // [P] the Adam loop's iterate (f64_adam_*): evaluations in between — adaptive reweighting, callbacks — leave it alone
     double* d_grad = nullptr;            // [P]
     double* d_sumsq = nullptr;           // [K]
     double* d_scratch = nullptr;
@@ -55,14 +56,17 @@ struct F64State {
     double* d_w_over_n = nullptr;        // [K] w_k / N_k of the running call
     double* d_hist = nullptr;
     int hist_cap = 0;
-    bool opt_ready = false;              // d_theta holds the optimiser's parameters
+    bool opt_ready = false;              // d_opt_theta holds the optimiser's parameters
+    double* d_aux_pts = nullptr;         // caller-supplied points of pinn_phi_f64 / pinn_derivative_f64 [n][d]
+    double* d_aux_out = nullptr;         // per-point outputs (residuals, trial-function values / derivatives) [n]
+    int64_t aux_pts_cap = 0, aux_out_cap = 0;
     int path = 0;                        // kernels of the last evaluation: bit 0 one lane per point (family 4), bit 1 matrix pipe (family 4m)
 };
 
 static void f64_free(F64State* S) {
     if (!S) return;
     for (auto& T : S->terms) { plat_free(T.d_prog); plat_free(T.d_imm); plat_free(T.d_pts); plat_free(T.d_data); }
-    plat_free(S->d_theta); plat_free(S->d_grad); plat_free(S->d_sumsq); plat_free(S->d_scratch); plat_free(S->d_slab); plat_free(S->d_tpart);
+    plat_free(S->d_theta); plat_free(S->d_opt_theta); plat_free(S->d_aux_pts); plat_free(S->d_aux_out); plat_free(S->d_grad); plat_free(S->d_sumsq); plat_free(S->d_scratch); plat_free(S->d_slab); plat_free(S->d_tpart);
     plat_free(S->d_m); plat_free(S->d_v); plat_free(S->d_w_over_n); plat_free(S->d_hist);
     delete S;
 }
@@ -91,6 +95,22 @@ static const pk::F64Kernel* f64_find(int D, const std::vector<Slot>& slots, std:
         if (ok && (!best || k.C < best->C)) { best = &k; chan = ch; }
     }
     if (!best) why = "no float64 kernel carries this term's derivatives (orders <= 2 in 1-3 inputs; 1-D: <= 4; 4-D: first and pure second derivatives)";
+    return best;
+}
+
+// family 4m (v_mfma_f64_16x16x4_f64) for the jet set of `k`: tanh / sigmoid networks with at least one hidden layer, none wider than an instantiated
+// 16 * HT; nullptr: family 4 (one lane per point)
+static const pk::F64MKernel* f64_find_m(const pinn_engine& E, const pk::F64Kernel* k, const std::vector<int>& nets) {
+    int maxh = 0;
+    for (int net : nets) {
+        const Net& N = E.nets[net];
+        if (N.act == pk::ACT_SIN || N.sizes.size() < 3) return nullptr;
+        for (size_t j = 1; j + 1 < N.sizes.size(); ++j) maxh = std::max(maxh, N.sizes[j]);
+    }
+    const pk::F64MKernel* best = nullptr;
+    for (const pk::F64MKernel& km : pk::f64m_registry())
+        if (km.D == k->D && km.D1MASK == k->D1MASK && km.PAIRS == k->PAIRS && km.NPAIR == k->NPAIR && km.HI == k->HI &&
+            16 * km.HT >= maxh && (!best || km.HT < best->HT)) best = &km;
     return best;
 }
 
@@ -173,21 +193,7 @@ int f64_enable(pinn_engine& E) {
         std::string why;
         F.k = f64_find(E.nets[nets[0]].sizes[0], T.slots, F.slot_chan, why);
         if (!F.k) return fail(who + why);
-        // family 4m (v_mfma_f64_16x16x4_f64): tanh / sigmoid networks with hidden layers no wider than an instantiated 16 * HT
-        {
-            int maxh = 0;
-            bool ok = !any_sin;
-            for (int net : nets) {
-                const Net& N = E.nets[net];
-                if (N.sizes.size() < 3) ok = false;
-                for (size_t j = 1; j + 1 < N.sizes.size(); ++j) maxh = std::max(maxh, N.sizes[j]);
-            }
-            F.km = nullptr;
-            if (ok)
-                for (const pk::F64MKernel& km : pk::f64m_registry())
-                    if (km.D == F.k->D && km.D1MASK == F.k->D1MASK && km.PAIRS == F.k->PAIRS && km.NPAIR == F.k->NPAIR && km.HI == F.k->HI &&
-                        16 * km.HT >= maxh && (!F.km || km.HT < F.km->HT)) F.km = &km;
-        }
+        F.km = f64_find_m(E, F.k, nets);
         F.slot_net.clear();
         for (auto& sl : T.slots) F.slot_net.push_back((int)(std::find(nets.begin(), nets.end(), sl.net) - nets.begin()));
         F.nops = (int)T.ops.size(); F.out_row = T.out_row; F.nslots = (int)T.slots.size();
@@ -245,30 +251,117 @@ int f64_set_point_data(pinn_engine& E, int term, const double* data) {
     return f64_install_data(E, S.terms[term], E.terms[term], data);
 }
 
-static int f64_eval_device(pinn_engine& E, const double* term_w, bool want_grad);
-
-int f64_eval(pinn_engine& E, const double* theta, const double* term_w, double* term_losses, double* grad) {
-    F64State& S = *(F64State*)E.f64;
-    const int K = (int)E.terms.size();
-    const int64_t P = E.ntheta;
-    if (plat_h2d(S.d_theta, theta, sizeof(double) * P, E.stream)) return fail("H2D copy of theta failed");
-    S.opt_ready = false;                                 // (d_theta no longer holds the optimiser's iterate)
-    if (f64_eval_device(E, term_w, grad != nullptr)) return 1;
-    if (plat_d2h(S.h_out.data(), S.d_grad, sizeof(double) * P, E.stream)) return fail("D2H copy failed");
-    if (plat_d2h(S.h_out.data() + P, S.d_sumsq, sizeof(double) * K, E.stream)) return fail("D2H copy failed");
-    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
-    if (term_losses)
-        for (int k = 0; k < K; ++k) term_losses[k] = S.h_out[(size_t)P + k] / (double)E.terms[k].n_norm;
-    if (grad) std::memcpy(grad, S.h_out.data(), sizeof(double) * P);
+// ---- one term (or pseudo-term: a network's trial function / derivative at caller-supplied points) as the kernels see it ----
+struct F64Launch {
+    pk::F64Args a;
+    int rows = 0;                        // scratch rows per point
+    bool sin_act = false, mfma = false;
+};
+// everything of F64Args that does not depend on the evaluation (theta, weights, mode, chunk): networks, scratch row numbering, tape, slots
+static int f64_build(pinn_engine& E, const F64Term& F, int dt, const std::map<int, std::vector<int>>* inmap, F64Launch& L) {
+    pk::F64Args& a = L.a;
+    std::memset(&a, 0, sizeof a);
+    a.data = F.ndata > 0 ? F.d_data : nullptr;
+    a.pts = F.d_pts;
+    a.N = (int)F.n; a.dt = dt;
+    a.nnets = (int)F.nets.size();
+    a.C = F.k->C;
+    for (int i = 0; i < 8; ++i) a.first_ch[i] = F.k->first_ch[i];
+    int rows = 0, ent = 0;
+    L.sin_act = false;
+    L.mfma = F.km && std::getenv("PINN_F64_NO_MFMA") == nullptr;
+    for (int ni = 0; ni < a.nnets; ++ni) {
+        const Net& N = E.nets[F.nets[ni]];
+        pk::F64Net& n = a.net[ni];
+        n.d = N.sizes[0];
+        std::vector<int> m;
+        if (inmap && inmap->count(F.nets[ni])) m = inmap->at(F.nets[ni]);
+        else for (int i = 0; i < n.d; ++i) m.push_back(i);
+        if ((int)m.size() != n.d) return fail("precision f64: inmap length differs from the network's input count");
+        for (int i = 0; i < 4; ++i) n.imap[i] = i < (int)m.size() ? m[i] : 0;
+        n.nl = (int)N.sizes.size() - 1;
+        int o = N.theta_off;
+        for (int l = 0; l < n.nl; ++l) {
+            n.sizes[l] = N.sizes[l];
+            n.woff[l] = o;
+            n.boff[l] = o + N.sizes[l + 1] * N.sizes[l];
+            o = n.boff[l] + N.sizes[l + 1];
+        }
+        n.sizes[n.nl] = N.sizes[n.nl];
+        n.act = N.act;
+        L.sin_act = L.sin_act || N.act == pk::ACT_SIN;
+        n.theta0 = N.theta_off; n.nparams = N.nparams(); n.ent0 = ent;
+        ent += n.nparams;
+        n.tp0 = a.tp_p;                                       // (running column count of the tile partial sums)
+        a.tp_p += (n.d + 1) * N.sizes[1] + N.sizes[n.nl - 1] + 1;
+        // scratch rows: per hidden layer record / post-activation jets / dZ, then this network's seeds
+        const int LH = n.nl - 1;
+        for (int l = 0; l < LH; ++l) { n.r_rec[l] = rows; rows += N.sizes[l + 1] * a.C; }
+        // value-only terms of tanh / sigmoid networks: the record of an element IS its post-activation value (act_record), so the
+        // matrix-pipe kernels keep ONE copy (a third of the tile kernel's stores less; 4 of the bench workload's 5 terms)
+        const bool post_is_rec = L.mfma && a.C == 1 && N.act != pk::ACT_SIN;
+        a.post_alias = post_is_rec ? 1 : 0;
+        for (int l = 0; l < LH; ++l) { if (post_is_rec) n.r_post[l] = n.r_rec[l]; else { n.r_post[l] = rows; rows += N.sizes[l + 1] * a.C; } }
+        for (int l = 0; l < LH; ++l) { n.r_dz[l] = rows; rows += N.sizes[l + 1] * a.C; }
+        n.r_ubar = rows; rows += a.C;
+    }
+    a.ent_p = ent;
+    a.nent = ent + E.ne + 1;
+    a.r_pbar = rows; rows += std::max(E.ne, 1);
+    a.r_sq = rows; rows += 1;
+    a.np = E.np; a.ne = E.ne; a.p_off = E.p_theta_off;
+    for (int j = 0; j < pk::MAX_PARAMS; ++j) a.pdef[j] = j < (int)E.p_defaults.size() ? (double)E.p_defaults[j] : 0.0;
+    a.prog = F.d_prog; a.imm = F.d_imm; a.nops = F.nops; a.out_row = F.out_row; a.nslots = F.nslots;
+    for (int s = 0; s < F.nslots; ++s) { a.slot_chan[s] = F.slot_chan[s]; a.slot_net[s] = F.slot_net[s]; }
+    a.nrows = rows;
+    L.rows = rows;
+    if (L.mfma) {
+        a.ntp = a.tp_p + E.ne + 1;
+        a.tile_pts = 16 * F.km->PG;
+    }
     return 0;
 }
+static bool grow(double*& buf, size_t& cap, size_t need, plat_stream st) {
+    if (need <= cap) return true;
+    plat_sync(st);
+    plat_free(buf);
+    buf = (double*)plat_malloc(sizeof(double) * need);
+    cap = buf ? need : 0;
+    return buf != nullptr;
+}
+// points per launch and the buffers of one: scratch rows (below 256 MB with one lane per point / 4 GB with the matrix-pipe kernels — one wave per
+// 16-32 points there, a chunk should hold several tiles per SIMD: the bench workload's 65,536-point terms are one chunk each; $PINN_F64_SCRATCH_MB
+// overrides), per-block slabs, per-tile partial sums.  An allocation that fails is retried with half the chunk down to one block.
+// with_sums == false (values-only launches, a.mode == 2): no slabs / tile sums
+static int f64_buffers(pinn_engine& E, F64State& S, F64Launch& L, int64_t n, bool with_sums, int64_t& chunk_out) {
+    pk::F64Args& a = L.a;
+    double mb = L.mfma ? 4096.0 : 256.0;
+    if (const char* e = std::getenv("PINN_F64_SCRATCH_MB")) mb = std::max(1.0, std::atof(e));
+    const bool need_scratch = !(L.mfma && a.mode != 0);              // (the tile kernels keep everything in registers unless a reverse sweep / dW launch follows)
+    for (;; mb *= 0.5) {
+        int64_t chunk = (int64_t)((mb * 1024 * 1024) / (8.0 * L.rows));
+        chunk = std::max<int64_t>(pk::F64_BLOCK, (chunk / pk::F64_BLOCK) * pk::F64_BLOCK);
+        chunk = std::min<int64_t>(chunk, ((n + pk::F64_BLOCK - 1) / pk::F64_BLOCK) * pk::F64_BLOCK);
+        const bool last_try = chunk <= pk::F64_BLOCK;
+        bool ok = true;
+        if (need_scratch) ok = grow(S.d_scratch, S.scratch_cap, (size_t)L.rows * (size_t)chunk, E.stream);
+        if (ok && with_sums) ok = grow(S.d_slab, S.slab_cap, (size_t)(chunk / pk::F64_BLOCK) * (size_t)a.nent, E.stream);
+        if (ok && with_sums && L.mfma) ok = grow(S.d_tpart, S.tpart_cap, (size_t)(chunk / a.tile_pts + 1) * (size_t)a.ntp, E.stream);
+        if (ok) {
+            a.scratch = S.d_scratch; a.npad = (int)chunk; a.slab = S.d_slab; a.tpart = S.d_tpart;
+            chunk_out = chunk;
+            return 0;
+        }
+        if (last_try) return fail("device allocation failed (float64 scratch / slabs, even for one 512-point block)");
+    }
+}
 
-// loss sums (S.d_sumsq) and gradient (S.d_grad) of the parameters in S.d_theta, everything on the device, nothing synchronised
-static int f64_eval_device(pinn_engine& E, const double* term_w, bool want_grad) {
+// loss sums (`sumsq`, K doubles) and gradient (`grad`, P doubles; nullptr: loss only) at the parameters `theta` — all three device pointers —
+// everything on the device, nothing synchronised
+static int f64_eval_device(pinn_engine& E, const double* theta, double* grad, double* sumsq, const double* term_w) {
     F64State& S = *(F64State*)E.f64;
     const int K = (int)E.terms.size();
     const int64_t P = E.ntheta;
-    const double* grad = want_grad ? S.d_grad : nullptr;         // (non-null = evaluate the gradient)
     for (int t = 0; t < K; ++t)
         if (S.terms[t].n <= 0 || S.terms[t].n != E.terms[t].n) return fail("term " + std::to_string(t) + " has no collocation points (call pinn_set_points first)");
     for (int t = 0; t < K; ++t)
@@ -277,141 +370,153 @@ static int f64_eval_device(pinn_engine& E, const double* term_w, bool want_grad)
     // the first reduction of the evaluation writes the gradient instead of adding to it when its term's entries cover all of theta (one network,
     // or every network in the first equation); otherwise one memset.  Every term's first chunk writes its own sum of squares.
     bool grad_started = false;
-    if (want_grad) {
+    if (grad) {
         int64_t covered = E.ne;
         for (int ni : S.terms[0].nets) covered += E.nets[ni].nparams();
-        if (covered != P) { plat_memset(S.d_grad, 0, sizeof(double) * P, E.stream); grad_started = true; }
+        if (covered != P) { plat_memset(grad, 0, sizeof(double) * P, E.stream); grad_started = true; }
     }
     S.path = 0;
     for (int t = 0; t < K; ++t) {
         const Term& T = E.terms[t];
         const Term& T0 = E.terms0[t];
         F64Term& F = S.terms[t];
-        pk::F64Args a;
-        std::memset(&a, 0, sizeof a);
-        a.data = F.ndata > 0 ? F.d_data : nullptr;
-        a.theta = S.d_theta; a.pts = F.d_pts; a.pw = (T.pw_n == T.n && T.pw_n > 0) ? T.d_pw : nullptr;
-        a.N = (int)F.n; a.dt = T0.d;
-        a.nnets = (int)F.nets.size();
-        a.C = F.k->C;
-        for (int i = 0; i < 8; ++i) a.first_ch[i] = F.k->first_ch[i];
-        int rows = 0, ent = 0;
-        bool sin_act = false;
-        const bool mfma_rows = F.km && std::getenv("PINN_F64_NO_MFMA") == nullptr;
-        for (int ni = 0; ni < a.nnets; ++ni) {
-            const Net& N = E.nets[F.nets[ni]];
-            pk::F64Net& n = a.net[ni];
-            n.d = N.sizes[0];
-            std::vector<int> m;
-            if (T0.inmap.count(F.nets[ni])) m = T0.inmap.at(F.nets[ni]);
-            else for (int i = 0; i < n.d; ++i) m.push_back(i);
-            if ((int)m.size() != n.d) return fail("precision f64: inmap length differs from the network's input count");
-            for (int i = 0; i < 4; ++i) n.imap[i] = i < (int)m.size() ? m[i] : 0;
-            n.nl = (int)N.sizes.size() - 1;
-            int o = N.theta_off;
-            for (int l = 0; l < n.nl; ++l) {
-                n.sizes[l] = N.sizes[l];
-                n.woff[l] = o;
-                n.boff[l] = o + N.sizes[l + 1] * N.sizes[l];
-                o = n.boff[l] + N.sizes[l + 1];
-            }
-            n.sizes[n.nl] = N.sizes[n.nl];
-            n.act = N.act;
-            sin_act = sin_act || N.act == pk::ACT_SIN;
-            n.theta0 = N.theta_off; n.nparams = N.nparams(); n.ent0 = ent;
-            ent += n.nparams;
-            n.tp0 = a.tp_p;                                       // (running column count of the tile partial sums)
-            a.tp_p += (n.d + 1) * N.sizes[1] + N.sizes[n.nl - 1] + 1;
-            // scratch rows: per hidden layer record / post-activation jets / dZ, then this network's seeds
-            const int L = n.nl - 1;
-            for (int l = 0; l < L; ++l) { n.r_rec[l] = rows; rows += N.sizes[l + 1] * a.C; }
-            // value-only terms of tanh / sigmoid networks: the record of an element IS its post-activation value (act_record), so the
-            // matrix-pipe kernels keep ONE copy (a third of the tile kernel's stores less; 4 of the bench workload's 5 terms)
-            const bool post_is_rec = mfma_rows && a.C == 1 && N.act != pk::ACT_SIN;
-            a.post_alias = post_is_rec ? 1 : 0;
-            for (int l = 0; l < L; ++l) { if (post_is_rec) n.r_post[l] = n.r_rec[l]; else { n.r_post[l] = rows; rows += N.sizes[l + 1] * a.C; } }
-            for (int l = 0; l < L; ++l) { n.r_dz[l] = rows; rows += N.sizes[l + 1] * a.C; }
-            n.r_ubar = rows; rows += a.C;
-        }
-        a.ent_p = ent;
-        a.nent = ent + E.ne + 1;
-        a.r_pbar = rows; rows += std::max(E.ne, 1);
-        a.r_sq = rows; rows += 1;
-        a.np = E.np; a.ne = E.ne; a.p_off = E.p_theta_off;
-        for (int j = 0; j < pk::MAX_PARAMS; ++j) a.pdef[j] = j < (int)E.p_defaults.size() ? (double)E.p_defaults[j] : 0.0;
-        a.prog = F.d_prog; a.imm = F.d_imm; a.nops = F.nops; a.out_row = F.out_row; a.nslots = F.nslots;
-        for (int s = 0; s < F.nslots; ++s) { a.slot_chan[s] = F.slot_chan[s]; a.slot_net[s] = F.slot_net[s]; }
-
+        F64Launch L;
+        if (f64_build(E, F, T0.d, &T0.inmap, L)) return 1;
+        pk::F64Args& a = L.a;
+        a.theta = theta;
+        a.pw = (T.pw_n == T.n && T.pw_n > 0) ? T.d_pw : nullptr;
         const double w = term_w ? term_w[t] : 1.0;
         a.scale = 2.0 * w / (double)T.n_norm;
         a.mode = grad ? 0 : 1;
-        const bool mfma = F.km && std::getenv("PINN_F64_NO_MFMA") == nullptr;
-        S.path |= mfma ? 2 : 1;
-        // chunks of points: the scratch stays below 256 MB (one lane per point) / 4 GB (matrix-pipe kernels: one wave per 16-32 points, a chunk
-        // should hold several tiles per SIMD — the bench workload's 65,536-point terms are one chunk each: 3 kernels + a reduction per term); $PINN_F64_SCRATCH_MB overrides
-        double mb = mfma ? 4096.0 : 256.0;
-        if (const char* e = std::getenv("PINN_F64_SCRATCH_MB")) mb = std::max(1.0, std::atof(e));
-        int64_t chunk = (int64_t)((mb * 1024 * 1024) / (8.0 * rows));
-        chunk = std::max<int64_t>(pk::F64_BLOCK, (chunk / pk::F64_BLOCK) * pk::F64_BLOCK);
-        chunk = std::min<int64_t>(chunk, ((F.n + pk::F64_BLOCK - 1) / pk::F64_BLOCK) * pk::F64_BLOCK);
-        const size_t need = (size_t)rows * (size_t)chunk;
-        if (need > S.scratch_cap) {
-            plat_sync(E.stream);
-            plat_free(S.d_scratch);
-            S.d_scratch = (double*)plat_malloc(sizeof(double) * need);
-            S.scratch_cap = S.d_scratch ? need : 0;
-            if (!S.d_scratch) return fail("device allocation failed (float64 scratch)");
-        }
-        const int nbmax = (int)(chunk / pk::F64_BLOCK);
-        const size_t sneed = (size_t)nbmax * (size_t)a.nent;
-        if (sneed > S.slab_cap) {
-            plat_sync(E.stream);
-            plat_free(S.d_slab);
-            S.d_slab = (double*)plat_malloc(sizeof(double) * sneed);
-            S.slab_cap = S.d_slab ? sneed : 0;
-            if (!S.d_slab) return fail("device allocation failed (float64 slabs)");
-        }
-        a.scratch = S.d_scratch; a.npad = (int)chunk; a.slab = S.d_slab; a.nrows = rows;
-        if (mfma) {
-            a.ntp = a.tp_p + E.ne + 1;
-            a.tile_pts = 16 * F.km->PG;
-            const size_t tneed = (size_t)(chunk / a.tile_pts + 1) * (size_t)a.ntp;
-            if (tneed > S.tpart_cap) {
-                plat_sync(E.stream);
-                plat_free(S.d_tpart);
-                S.d_tpart = (double*)plat_malloc(sizeof(double) * tneed);
-                S.tpart_cap = S.d_tpart ? tneed : 0;
-                if (!S.d_tpart) return fail("device allocation failed (float64 tile sums)");
-            }
-            a.tpart = S.d_tpart;
-        }
+        S.path |= L.mfma ? 2 : 1;
+        int64_t chunk = 0;
+        if (f64_buffers(E, S, L, F.n, true, chunk)) return 1;
         for (int64_t p0 = 0; p0 < F.n; p0 += chunk) {
             a.p0 = (int)p0;
             a.npts = (int)std::min<int64_t>(chunk, F.n - p0);
-            if (mfma) F.km->launch_tile(a, E.stream);
-            else F.k->launch_point(a, sin_act, E.stream);
-            if (!mfma) pk::launch_f64_dw(a, E.stream);           // (matrix-pipe path: those entries come out of the tile kernel, summed in the dW launch)
-            if (mfma) F.km->launch_dwt(a, E.stream);
+            if (L.mfma) F.km->launch_tile(a, E.stream);
+            else F.k->launch_point(a, L.sin_act, E.stream);
+            if (!L.mfma) pk::launch_f64_dw(a, E.stream);         // (matrix-pipe path: those entries come out of the tile kernel, summed in the dW launch)
+            if (L.mfma) F.km->launch_dwt(a, E.stream);
             else pk::launch_f64_dwt(a, E.stream);
             pk::F64ReduceArgs r;
             std::memset(&r, 0, sizeof r);
             r.slab = S.d_slab; r.nblocks = (a.npts + pk::F64_BLOCK - 1) / pk::F64_BLOCK; r.nent = a.nent;
-            r.grad = S.d_grad; r.ent_p = a.ent_p; r.p_off = E.p_theta_off; r.nnets = a.nnets;
+            r.grad = grad; r.ent_p = a.ent_p; r.p_off = E.p_theta_off; r.nnets = a.nnets;
             for (int ni = 0; ni < a.nnets; ++ni) { r.ent0[ni] = a.net[ni].ent0; r.theta0[ni] = a.net[ni].theta0; }
-            r.sumsq = S.d_sumsq + t; r.with_grad = grad ? 1 : 0;
+            r.sumsq = sumsq + t; r.with_grad = grad ? 1 : 0;
             r.init_sumsq = (p0 == 0) ? 1 : 0;
             r.init_grad = (grad && !grad_started) ? 1 : 0;
             if (grad) grad_started = true;
-            if (mfma) pk::launch_f64m_reduce(r, E.stream);
+            if (L.mfma) pk::launch_f64m_reduce(r, E.stream);
             else pk::launch_f64_reduce(r, E.stream);
         }
     }
     return 0;
 }
 
+int f64_eval(pinn_engine& E, const double* theta, const double* term_w, double* term_losses, double* grad) {
+    F64State& S = *(F64State*)E.f64;
+    const int K = (int)E.terms.size();
+    const int64_t P = E.ntheta;
+    if (plat_h2d(S.d_theta, theta, sizeof(double) * P, E.stream)) return fail("H2D copy of theta failed");
+    if (f64_eval_device(E, S.d_theta, grad ? S.d_grad : nullptr, S.d_sumsq, term_w)) return 1;
+    if (grad && plat_d2h(S.h_out.data(), S.d_grad, sizeof(double) * P, E.stream)) return fail("D2H copy failed");
+    if (plat_d2h(S.h_out.data() + P, S.d_sumsq, sizeof(double) * K, E.stream)) return fail("D2H copy failed");
+    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    if (term_losses)
+        for (int k = 0; k < K; ++k) term_losses[k] = S.h_out[(size_t)P + k] / (double)E.terms[k].n_norm;
+    if (grad) std::memcpy(grad, S.h_out.data(), sizeof(double) * P);
+    return 0;
+}
+
+// ---- the public closures that return PER-POINT values, in double (r06): the reference evaluates them in eltype(theta) = Float64 by default —
+// datafree_pde_loss_functions[i](cord, theta) (src/pinn_types.jl:435-439, compared at rtol 1e-8 in test/Forward/forward__ode.jl:46-47),
+// phi(x, theta) (src/pinn_types.jl:88-90), numeric_derivative (src/pinn_types.jl:445-482; atol 1e-8 in test/Forward/forward__derivatives.jl:29-30) ----
+// values-only launches (F64Args::mode == 2) of `L` over n points: out[p] on the device
+static int f64_values(pinn_engine& E, F64State& S, const F64Term& F, F64Launch& L, int64_t n, double* d_out) {
+    pk::F64Args& a = L.a;
+    a.mode = 2;
+    a.resid = d_out;
+    a.scale = 0.0;
+    S.path |= L.mfma ? 2 : 1;
+    int64_t chunk = 0;
+    if (f64_buffers(E, S, L, n, false, chunk)) return 1;
+    for (int64_t p0 = 0; p0 < n; p0 += chunk) {
+        a.p0 = (int)p0;
+        a.npts = (int)std::min<int64_t>(chunk, n - p0);
+        if (L.mfma) F.km->launch_tile(a, E.stream);
+        else F.k->launch_point(a, L.sin_act, E.stream);
+    }
+    return 0;
+}
+// residual_k(set_k, theta) at every point of the installed set (pinn_residual_f64; pinn_residual in float64 mode)
+int f64_residual(pinn_engine& E, int term, const double* theta, double* r) {
+    F64State& S = *(F64State*)E.f64;
+    F64Term& F = S.terms[term];
+    if (F.n <= 0 || F.n != E.terms[term].n) return fail("pinn_residual: term has no points");
+    if (F.ndata > 0 && F.data_n != F.n) return fail("pinn_residual: the term uses per-point data channels but none are installed for its current point set");
+    if (plat_h2d(S.d_theta, theta, sizeof(double) * E.ntheta, E.stream)) return fail("H2D copy of theta failed");
+    size_t cap = (size_t)S.aux_out_cap;
+    if (!grow(S.d_aux_out, cap, (size_t)F.n, E.stream)) { S.aux_out_cap = 0; return fail("device allocation failed (float64 residuals)"); }
+    S.aux_out_cap = (int64_t)cap;
+    F64Launch L;
+    if (f64_build(E, F, E.terms0[term].d, &E.terms0[term].inmap, L)) return 1;
+    L.a.theta = S.d_theta;
+    S.path = 0;
+    if (f64_values(E, S, F, L, F.n, S.d_aux_out)) return 1;
+    if (plat_d2h(r, S.d_aux_out, sizeof(double) * (size_t)F.n, E.stream) || plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    return 0;
+}
+// d^order phi_net / dx_axes (order 0: the trial function itself) at n caller-supplied points (pinn_phi_f64, pinn_derivative_f64 and their float
+// counterparts in float64 mode): a pseudo-term of one slot and an empty tape on the jet set that carries the derivative
+int f64_net_eval(pinn_engine& E, int net, const double* theta, const double* pts, int64_t n, int order, const int* axes, double* out) {
+    F64State& S = *(F64State*)E.f64;
+    const Net& N = E.nets[net];
+    const std::string who = "float64 trial-function evaluation: ";
+    if (N.kind != 0) return fail(who + "DGM networks are not covered by the float64 mode");
+    if (!N.emb_idx.empty()) return fail(who + "periodic input embeddings are not covered by the float64 mode");
+    if (N.act != pk::ACT_TANH && N.act != pk::ACT_SIGMOID && N.act != pk::ACT_SIN) return fail(who + "per-layer activation mixes are not covered by the float64 mode");
+    if ((int)N.sizes.size() - 1 > pk::F64_MAX_LAYERS || N.sizes[0] > 4) return fail(who + "more than 16 Dense layers / more than 4 inputs");
+    const int d = N.sizes[0];
+    Slot sl;
+    sl.net = net; sl.order = order; sl.lap = 0;
+    for (int q = 0; q < MAX_DERIV_ORDER; ++q) sl.axes[q] = q < order ? axes[q] : 0;
+    std::sort(sl.axes, sl.axes + order);
+    for (int q = 0; q < order; ++q)
+        if (sl.axes[q] < 0 || sl.axes[q] >= d) return fail("pinn_derivative: axis out of range");
+    F64Term F;
+    std::string why;
+    F.k = f64_find(d, std::vector<Slot>{sl}, F.slot_chan, why);
+    if (!F.k) return fail(who + why);
+    F.nets = {net};
+    F.km = f64_find_m(E, F.k, F.nets);
+    F.slot_net = {0};
+    F.nops = 0; F.nslots = 1; F.out_row = d + E.np;
+    F.n = n;
+    size_t cp = (size_t)S.aux_pts_cap, co = (size_t)S.aux_out_cap;
+    const bool okp = grow(S.d_aux_pts, cp, (size_t)n * d, E.stream), oko = grow(S.d_aux_out, co, (size_t)n, E.stream);
+    S.aux_pts_cap = (int64_t)cp; S.aux_out_cap = (int64_t)co;
+    if (!okp || !oko) return fail("device allocation failed (float64 trial-function points)");
+    F.d_pts = S.d_aux_pts;
+    if (plat_h2d(S.d_theta, theta, sizeof(double) * E.ntheta, E.stream) || plat_h2d(S.d_aux_pts, pts, sizeof(double) * (size_t)n * d, E.stream)) {
+        F.d_pts = nullptr;
+        return fail("H2D copy failed");
+    }
+    F64Launch L;
+    int rc = f64_build(E, F, d, nullptr, L);
+    L.a.theta = S.d_theta;
+    S.path = 0;
+    if (!rc) rc = f64_values(E, S, F, L, n, S.d_aux_out);
+    if (!rc && (plat_d2h(out, S.d_aux_out, sizeof(double) * (size_t)n, E.stream) || plat_sync(E.stream))) rc = fail(std::string("device error: ") + plat_last_error());
+    F.d_pts = nullptr;                                   // (borrowed: the pseudo-term owns nothing)
+    return rc;
+}
+
 // ---- the resident optimiser loop in float64 (pinn_adam_* on a handle in float64 mode; r05): theta, moments, points and every kernel of the
 // iteration in double on the device — redraw (the fp32 samplers' points, converted on the device: the reference's StochasticTraining /
-// QuasiRandomTraining(resampling = true) with Float64 parameters, src/training_strategies.jl:271-282, 365-389) -> evaluate -> Adam ----
+// QuasiRandomTraining(resampling = true) with Float64 parameters, src/training_strategies.jl:271-282, 365-389) -> evaluate -> Adam.
+// The iterate has its OWN buffer (d_opt_theta): evaluations between two pinn_adam_steps calls (adaptive reweighting, callbacks) do not touch it ----
 int f64_adam_init(pinn_engine& E, const double* theta) {
     F64State& S = *(F64State*)E.f64;
     const int64_t P = E.ntheta;
@@ -419,10 +524,11 @@ int f64_adam_init(pinn_engine& E, const double* theta) {
     if (!S.d_m) {
         S.d_m = (double*)plat_malloc(sizeof(double) * P);
         S.d_v = (double*)plat_malloc(sizeof(double) * P);
+        S.d_opt_theta = (double*)plat_malloc(sizeof(double) * P);
         S.d_w_over_n = (double*)plat_malloc(sizeof(double) * K);
-        if (!S.d_m || !S.d_v || !S.d_w_over_n) return fail("device allocation failed (float64 optimiser state)");
+        if (!S.d_m || !S.d_v || !S.d_w_over_n || !S.d_opt_theta) return fail("device allocation failed (float64 optimiser state)");
     }
-    if (plat_h2d(S.d_theta, theta, sizeof(double) * P, E.stream)) return fail("H2D copy of theta failed");
+    if (plat_h2d(S.d_opt_theta, theta, sizeof(double) * P, E.stream)) return fail("H2D copy of theta failed");
     plat_memset(S.d_m, 0, sizeof(double) * P, E.stream);
     plat_memset(S.d_v, 0, sizeof(double) * P, E.stream);
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
@@ -432,8 +538,8 @@ int f64_adam_init(pinn_engine& E, const double* theta) {
 }
 int f64_adam_get(pinn_engine& E, double* theta) {
     F64State& S = *(F64State*)E.f64;
-    if (!S.opt_ready) return fail("pinn_adam_get: no float64 optimiser state (pinn_adam_init after switching to precision f64; evaluations at other parameters reset it)");
-    if (plat_d2h(theta, S.d_theta, sizeof(double) * E.ntheta, E.stream) || plat_sync(E.stream)) return fail("D2H copy failed");
+    if (!S.opt_ready) return fail("pinn_adam_get: no float64 optimiser state (call pinn_adam_init after switching to precision f64)");
+    if (plat_d2h(theta, S.d_opt_theta, sizeof(double) * E.ntheta, E.stream) || plat_sync(E.stream)) return fail("D2H copy failed");
     return 0;
 }
 // a sampled term's float points (just redrawn on the device) -> the double copy the float64 kernels read
@@ -451,6 +557,7 @@ int f64_points_from_device(pinn_engine& E, int term) {
     pk::launch_f64_cvt(T.d_pts, F.d_pts, (int64_t)T.n * T.d, E.stream);
     F.n = T.n;
     F.exact_pts = false;
+    F.data_n = 0;                                        // (per-point data belong to the previous set: a sampled term with DATA channels fails its next evaluation with the message — ADVICE r05)
     return 0;
 }
 int f64_adam_steps(pinn_engine& E, int nsteps, double lr, double beta1, double beta2, double eps, const float* term_w, double* loss_history, void (*redraw)(pinn_engine&, Term&)) {
@@ -475,14 +582,32 @@ int f64_adam_steps(pinn_engine& E, int nsteps, double lr, double beta1, double b
             redraw(E, T);                                    // (engine.cpp: the fp32 sampler kernels, draw counter advanced)
             if (f64_points_from_device(E, (int)t)) return 1;
         }
-        if (f64_eval_device(E, w.data(), true)) return 1;
+        if (f64_eval_device(E, S.d_opt_theta, S.d_grad, S.d_sumsq, w.data())) return 1;
         ++E.opt_t;
         const double c1 = 1.0 / (1.0 - std::pow(beta1, (double)E.opt_t)), c2 = 1.0 / (1.0 - std::pow(beta2, (double)E.opt_t));
         pk::launch_f64_total(S.d_hist, s, S.d_sumsq, S.d_w_over_n, K, E.stream);
-        pk::launch_f64_adam(S.d_theta, S.d_m, S.d_v, S.d_grad, P, lr, beta1, beta2, eps, c1, c2, E.stream);
+        pk::launch_f64_adam(S.d_opt_theta, S.d_m, S.d_v, S.d_grad, P, lr, beta1, beta2, eps, c1, c2, E.stream);
     }
     if (loss_history && plat_d2h(loss_history, S.d_hist, sizeof(double) * nsteps, E.stream)) return fail("D2H copy failed");
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    return 0;
+}
+// one Adam update of the float64 state from a caller-supplied host vector [gradient (P) | raw per-term sums (K)] (pinn_adam_apply in float64 mode)
+int f64_adam_apply(pinn_engine& E, const double* grad_and_sums, double lr, double beta1, double beta2, double eps, const float* term_w, double* loss) {
+    F64State& S = *(F64State*)E.f64;
+    if (!S.opt_ready) return fail("pinn_adam_apply: call pinn_adam_init first (float64 mode keeps its own optimiser state)");
+    const int K = (int)E.terms.size();
+    const int P = (int)E.ntheta;
+    if (plat_h2d(S.d_grad, grad_and_sums, sizeof(double) * P, E.stream)) return fail("H2D copy failed");
+    ++E.opt_t;
+    const double c1 = 1.0 / (1.0 - std::pow(beta1, (double)E.opt_t)), c2 = 1.0 / (1.0 - std::pow(beta2, (double)E.opt_t));
+    pk::launch_f64_adam(S.d_opt_theta, S.d_m, S.d_v, S.d_grad, P, lr, beta1, beta2, eps, c1, c2, E.stream);
+    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    if (loss) {
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) s += (term_w ? (double)term_w[k] : 1.0) * grad_and_sums[P + k] / (double)E.terms[k].n_norm;
+        *loss = s;
+    }
     return 0;
 }
 // float64 evaluation at DEVICE-resident float parameters (pinn_loss_grad_device / pinn_loss_device in float64 mode): theta converted on the
@@ -494,27 +619,20 @@ int f64_eval_from_device_f32(pinn_engine& E, const float* d_theta, const float* 
     std::vector<double> w(K);
     for (int k = 0; k < K; ++k) w[k] = term_w ? (double)term_w[k] : 1.0;
     pk::launch_f64_cvt(d_theta, S.d_theta, P, E.stream);
-    S.opt_ready = false;
-    if (f64_eval_device(E, w.data(), want_grad)) return 1;
+    if (f64_eval_device(E, S.d_theta, want_grad ? S.d_grad : nullptr, S.d_sumsq, w.data())) return 1;
     if (want_grad) pk::launch_f64_narrow(S.d_grad, d_out, P, E.stream);
     pk::launch_f64_narrow(S.d_sumsq, d_out + (want_grad ? P : 0), K, E.stream);
     return 0;
 }
 
-// theta and [gradient | raw sums] as DOUBLE device pointers: nothing crosses the boundary in fp32, nothing crosses PCIe
+// theta and [gradient | raw sums] as DOUBLE device pointers: nothing crosses the boundary in fp32, nothing crosses PCIe; the kernels read the
+// caller's theta and write the caller's [gradient | sums] directly: no copies
 int f64_eval_from_device_f64(pinn_engine& E, const double* d_theta, const float* term_w, double* d_out) {
-    F64State& S = *(F64State*)E.f64;
     const int K = (int)E.terms.size();
     const int64_t P = E.ntheta;
     std::vector<double> w(K);
     for (int k = 0; k < K; ++k) w[k] = term_w ? (double)term_w[k] : 1.0;
-    // the kernels read the caller's theta and write the caller's [gradient | sums] directly: no copies (the handle's own buffers — the optimiser's
-    // iterate among them — stay as they are)
-    double* const th0 = S.d_theta; double* const g0 = S.d_grad; double* const s0 = S.d_sumsq;
-    S.d_theta = const_cast<double*>(d_theta); S.d_grad = d_out; S.d_sumsq = d_out + P;
-    const int rc = f64_eval_device(E, w.data(), true);
-    S.d_theta = th0; S.d_grad = g0; S.d_sumsq = s0;
-    return rc;
+    return f64_eval_device(E, d_theta, d_out, d_out + P, w.data());
 }
 
 // " f64_channels=5,1,1,1,1 f64_kernels=mfma:HT4xPG1,mfma:HT4xPG4,..." for pinn_describe

@@ -714,14 +714,17 @@ HD double vdiv_1to2(double n, double s) {
     return n / s;
 #endif
 }
+// (the clamps are selects, not fmin: fmin(NaN, 40) = 40 would turn a NaN pre-activation into +-1 and mask a diverged run — ADVICE r05)
 HD double vtanh_fast(double x) {
-    const double ax = __builtin_fmin(__builtin_fabs(x), 40.0);
+    const double a0 = __builtin_fabs(x);
+    const double ax = (a0 > 40.0) ? 40.0 : a0;
     const double e = vexp_nonpos(-2.0 * ax);
     return __builtin_copysign(vdiv_1to2(1.0 - e, 1.0 + e), x);
 }
 // sigma(x) = 1 / (1 + e^-|x|) for x >= 0, e^-|x| / (1 + e^-|x|) for x < 0: the same exponential and division (ocml's exp alone is ~4x the cost)
 HD double vsigmoid_fast(double x) {
-    const double e = vexp_nonpos(-__builtin_fmin(__builtin_fabs(x), 80.0));
+    const double a0 = __builtin_fabs(x);
+    const double e = vexp_nonpos(-((a0 > 80.0) ? 80.0 : a0));
     return vdiv_1to2(x >= 0.0 ? 1.0 : e, 1.0 + e);
 }
 HD void vsincos(double x, double& s, double& c) { s = sin(x); c = cos(x); }

@@ -193,16 +193,24 @@ class PhysicsInformedNN:
     def __init__(self, chain, strategy: AbstractTrainingStrategy, *, init_params=None, phi=None, derivative=None,
                  param_estim: bool = False, additional_loss: Optional[Callable] = None, adaptive_loss=None,
                  logger=None, log_options: LogOptions = LogOptions(), iteration=None, data_loss: Sequence[DataLoss] = (),
-                 precision: str = "f32", **kwargs):
+                 precision: str = "auto", **kwargs):
         if phi is not None or derivative is not None:
             raise ValueError("custom `phi` / `derivative` closures are per-call Julia hooks (src/pinn_types.jl:166-167) "
                              "and cannot be fused into the HIP kernels; they are not supported by this backend")
         self.chain = list(chain) if isinstance(chain, (list, tuple)) else [chain]
         self.multioutput = isinstance(chain, (list, tuple))
-        if precision not in ("f32", "f64"):
-            raise ValueError('precision must be "f32" (the device dtype of the north star, src/eltype_matching.jl:8-10) or "f64"')
-        # "f64": the engine's float64 evaluation mode (pinn_set_option(h, "precision", "f64")) — what a Float64 `init_params` selects in the
-        # reference (src/discretize.jl:432-449): objective, gradient and the BFGS / L-BFGS stages in double, points handed over in double
+        if precision not in ("auto", "f32", "f64"):
+            raise ValueError('precision must be "auto" (compute dtype = eltype(theta), the reference\'s contract, src/eltype_matching.jl:8-10), "f32" or "f64"')
+        # PRECISION POLICY (r06) = the reference's: the compute dtype follows eltype(theta) (src/eltype_matching.jl:8-10,
+        # src/discretize.jl:432-449: Float64 unless the user passes Float32 init_params).
+        #   "auto" (default): Float64 parameters (incl. init_params = None) -> the engine's float64 evaluation mode (pinn_set_option(h,
+        #           "precision", "f64"): objective, gradient, every public closure and the BFGS / L-BFGS stages in double, points handed
+        #           over in double); Float32 parameters -> the fp32 kernels.  A problem the float64 kernels do not cover (DGM networks,
+        #           periodic embeddings, general mixed derivatives of order >= 3) FAILS at discretize time with the reason — never a
+        #           silent narrowing;
+        #   "f32":  the explicit fast opt-in — fp32 kernels (7-8x faster on the matrix pipe) whatever eltype(theta); parameters and
+        #           results are converted at the boundary;
+        #   "f64":  the float64 mode whatever eltype(theta).
         self.precision = precision
         self.strategy = strategy
         self.init_params = init_params
@@ -238,7 +246,11 @@ class Phi:
             full = np.zeros(self.engine.P, dtype=th.dtype)
             full[self.theta_slice] = th
             th = full
-        out = self.engine.phi(self.net, th, pts).astype(np.float64).reshape(1, -1)
+        # a handle in float64 mode evaluates the trial function in double end to end (pinn_phi_f64; src/pinn_types.jl:88-90 computes in eltype(theta))
+        if self.engine.get_option("precision") == "f64":
+            out = self.engine.phi_f64(self.net, th, pts).reshape(1, -1)
+        else:
+            out = self.engine.phi(self.net, th, pts).astype(np.float64).reshape(1, -1)
         return out[:, 0] if single else out
 
 
@@ -389,8 +401,9 @@ def solve(prob: OptimizationProblem, alg: Adam, maxiters: int = 1000, callback: 
         losses.append(hist)
         done += n
         if ada.reweight_every > 0:
-            tl, _ = eng.loss_grad(th32, None, want_grad=False)
-            ada.reweight(th32, tl[:n_pde], tl[n_pde:n_pde + len(rep.bcs)], rep.iteration[0] + done, term_grads=lambda: eng.term_grads(th32)[1])
+            tl, _ = (eng.loss_grad_f64 if f64 else eng.loss_grad)(th32, None, want_grad=False)
+            ada.reweight(th32, tl[:n_pde], tl[n_pde:n_pde + len(rep.bcs)], rep.iteration[0] + done,
+                         term_grads=lambda: (eng.term_grads_f64 if f64 else eng.term_grads)(th32)[1])
         if callback is not None and callback({"iter": done, "u": th32.astype(np.float64)}, float(hist[-1])):
             break
     losses = np.concatenate(losses)
@@ -575,9 +588,19 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
             else:
                 engine.set_points(k, s)
 
-    f64 = getattr(discretization, "precision", "f32") == "f64"
+    prec = getattr(discretization, "precision", "auto")
+    if prec == "auto":                                  # compute dtype = eltype(theta) (src/eltype_matching.jl:8-10)
+        prec = "f32" if dtype == np.float32 else "f64"
+    f64 = prec == "f64"
     if f64:
-        engine.set_option("precision", "f64")           # (fails with the reason for what the mode does not cover: DGM, embeddings)
+        try:
+            engine.set_option("precision", "f64")       # (fails with the reason for what the mode does not cover: DGM, embeddings)
+        except _lib.EngineError as e:
+            if getattr(discretization, "precision", "auto") != "auto":
+                raise
+            raise _lib.EngineError(f"{e}\n(the parameters are Float64, so precision = \"auto\" selected the float64 kernels — the reference's contract, "
+                                   "src/eltype_matching.jl:8-10.  Pass PhysicsInformedNN(..., precision = \"f32\") to run this problem on the fp32 kernels, "
+                                   "or Float32 init_params.)") from None
     install(pde_sets, bc_sets)
     if getattr(strategy, "point_weights", None) is not None and strategy.point_weights() is not None:
         for k, w in enumerate(strategy.point_weights()):           # quadrature strategies: loss_k = sum_i w_i r_i^2
@@ -624,9 +647,14 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
         def f(cord, theta):
             """(cord, theta) -> 1 x N residual (src/discretize.jl:174)."""
             cord = np.asarray(cord)
-            engine.set_points(k, cord)
-            r = engine.residual(k, np.asarray(theta), cord.shape[1]).astype(np.float64).reshape(1, -1)
-            engine.set_points(k, (state["pde_sets"] + state["bc_sets"])[k])
+            if f64:                                     # Float64 closure (src/pinn_types.jl:435-439; rtol 1e-8 in test/Forward/forward__ode.jl:46-47)
+                engine.set_points_f64(k, cord)
+                r = engine.residual_f64(k, np.asarray(theta), cord.shape[1]).reshape(1, -1)
+                engine.set_points_f64(k, (state["pde_sets"] + state["bc_sets"])[k])
+            else:
+                engine.set_points(k, cord)
+                r = engine.residual(k, np.asarray(theta), cord.shape[1]).astype(np.float64).reshape(1, -1)
+                engine.set_points(k, (state["pde_sets"] + state["bc_sets"])[k])
             if getattr(strategy, "point_weights", None) is not None and strategy.point_weights() is not None:
                 engine.set_point_weights(k, strategy.point_weights()[k])
             state["cache_theta"] = None
@@ -642,7 +670,7 @@ def symbolic_discretize(pde_system: PDESystem, discretization: PhysicsInformedNN
         if discretization.self_increment:
             iteration[0] += 1
         adaloss.reweight(theta, losses[:n_pde], losses[n_pde:n_pde + n_bc], iteration[0],
-                         term_grads=lambda: engine.term_grads(np.asarray(theta))[1])
+                         term_grads=lambda: (engine.term_grads_f64 if f64 else engine.term_grads)(np.asarray(theta))[1])
         return losses
 
     def add_term(theta):

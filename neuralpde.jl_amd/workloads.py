@@ -30,10 +30,13 @@ class Workload:
     param_estim: bool = False
     n_interior: int = 0
 
-    def discretization(self) -> PhysicsInformedNN:
+    def discretization(self, precision: str = "f32") -> PhysicsInformedNN:
+        """the BASELINE configurations are the north star's fp32 workloads: the benchmark harness opts into the fp32 kernels explicitly
+        (`precision = "f32"`); pass "auto" (the API default: compute dtype = eltype(theta), i.e. the float64 kernels for these Float64
+        parameter vectors) or "f64" for the reference's default eltype"""
         chain = self.chains if len(self.chains) > 1 else self.chains[0]
         return PhysicsInformedNN(chain, self.strategy, init_params=self.theta, adaptive_loss=self.adaptive_loss,
-                                 param_estim=self.param_estim)
+                                 param_estim=self.param_estim, precision=precision)
 
 
 def mlp(n_in: int, width: int, hidden_layers: int, act: str = "tanh") -> Chain:

@@ -10,7 +10,7 @@ def _setup(npde, ada, seed=61):
     sysm, chain = poisson2d(npde)
     th0 = theta_for(chain, seed)
     strat = npde.QuasiRandomTraining(48, bcs_points=20, sampling_alg=npde.SobolSample(seed=2), resampling=False, minibatch=1)
-    disc = npde.PhysicsInformedNN(chain, strat, init_params=th0, adaptive_loss=ada)
+    disc = npde.PhysicsInformedNN(chain, strat, init_params=th0, adaptive_loss=ada, precision="f32")
     prob = npde.discretize(sysm, disc)
     return sysm, chain, prob, th0
 

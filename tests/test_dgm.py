@@ -58,7 +58,7 @@ def test_deep_galerkin_constructor_trains_and_misuse(npde, use_emu):
     parameter estimation run through the same family; unsupported set-ups fail loudly."""
     sysm = _burgers(npde)
     strat = npde.QuasiRandomTraining(64, bcs_points=16, sampling_alg=npde.SobolSample(seed=5), resampling=False, minibatch=1)
-    disc = npde.DeepGalerkin(2, 1, 8, 2, "tanh", "tanh", "identity", strat)
+    disc = npde.DeepGalerkin(2, 1, 8, 2, "tanh", "tanh", "identity", strat, precision="f32")      # (DGM networks run on the fp32 kernels: the explicit opt-in; "auto" + Float64 parameters fails with the reason, below)
     prob = npde.discretize(sysm, disc)
     assert prob.u0.size == npde.DGM(2, 1, 8, 2).nparams
     res = npde.solve(prob, npde.Adam(0.01), maxiters=30)
@@ -81,4 +81,4 @@ def test_deep_galerkin_constructor_trains_and_misuse(npde, use_emu):
     sys3 = npde.PDESystem([npde.Eq(Dt(u(t, x)) + v(t, x), 0), npde.Eq(Dx(v(t, x)) - u(t, x), 0)],
                           [npde.Eq(u(0, x), 0.0), npde.Eq(v(0, x), 0.0)], list(sysm.domain), [t, x], [u(t, x), v(t, x)])
     with pytest.raises(npde.EngineError, match="single-network equations"):
-        npde.symbolic_discretize(sys3, npde.PhysicsInformedNN([npde.DGM(2, 1, 8, 1), npde.DGM(2, 1, 8, 1)], strat))
+        npde.symbolic_discretize(sys3, npde.PhysicsInformedNN([npde.DGM(2, 1, 8, 1), npde.DGM(2, 1, 8, 1)], strat, precision="f32"))

@@ -14,7 +14,7 @@ EXPECTED_BACKEND = "emu"      # tests/test_gpu_mirror.py re-runs this module's t
 
 def check(npde, sysm, chains, strat, theta, weights=None, param_estim=False, tol=TOL, mode="stencil"):
     disc = npde.PhysicsInformedNN(chains if len(chains) > 1 else chains[0], strat, init_params=theta,
-                                  param_estim=param_estim)
+                                  param_estim=param_estim, precision="f32")
     rep = npde.symbolic_discretize(sysm, disc)
     assert rep.engine.L.backend == EXPECTED_BACKEND
     sets = rep.pde_train_sets + rep.bcs_train_sets
@@ -102,7 +102,7 @@ def test_periodic_embedding_reference_shape_and_limits(npde, use_emu):
     eq3 = npde.Eq(npde.Differential(t)(u(t, x)), (npde.Differential(x) ** 3)(u(t, x)))
     sys3 = npde.PDESystem([eq3], sysm.bcs, sysm.domain, [t, x], [u(t, x)])
     with pytest.raises(RuntimeError, match="order > 2 in a periodically embedded coordinate"):
-        npde.symbolic_discretize(sys3, npde.PhysicsInformedNN(chain, strat, init_params=theta_for(chain, 3)))
+        npde.symbolic_discretize(sys3, npde.PhysicsInformedNN(chain, strat, init_params=theta_for(chain, 3), precision="f32"))
     with pytest.raises(ValueError, match="first layer"):
         npde.Chain(npde.Dense(2, 8, "tanh"), npde.PeriodicEmbedding([1], [1.0]), npde.Dense(8, 1))
     with pytest.raises(ValueError, match="DimensionMismatch"):
@@ -250,7 +250,7 @@ def test_high_level_api_and_resampling(npde, use_emu):
     sysm, chain = poisson2d(npde)
     th0 = theta_for(chain, 21)
     disc = npde.PhysicsInformedNN(chain, npde.StochasticTraining(40, bcs_points=10, rng=np.random.default_rng(1)), init_params=th0,
-                                  adaptive_loss=npde.NonAdaptiveLoss(pde_loss_weights=2.0, bc_loss_weights=[1, 2, 3, 4]))
+                                  adaptive_loss=npde.NonAdaptiveLoss(pde_loss_weights=2.0, bc_loss_weights=[1, 2, 3, 4]), precision="f32")
     prob = npde.discretize(sysm, disc)
     assert prob.u0.dtype == np.float64 and prob.u0.size == chain.nparams
     f1, f2 = prob.f(prob.u0), prob.f(prob.u0)
@@ -259,7 +259,7 @@ def test_high_level_api_and_resampling(npde, use_emu):
     assert np.isfinite(val) and g.shape == prob.u0.shape and g.dtype == np.float64
     assert disc.iteration[0] == 4                       # self-incremented by every evaluation (discretize.jl:574-576)
     # a few Adam steps on a fixed grid lower the loss (the reference's own convergence-style check, loosely)
-    disc = npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=th0)
+    disc = npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=th0, precision="f32")
     prob = npde.discretize(sysm, disc)
     th, m_, v_ = prob.u0.copy(), 0.0, 0.0
     l0 = prob.f(th)
@@ -425,7 +425,7 @@ def test_resident_adam_matches_host_adam_and_sampler(npde, use_emu):
     sysm, chain = poisson2d(npde)
     th0 = theta_for(chain, 51)
     disc = npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=th0,
-                                  adaptive_loss=npde.NonAdaptiveLoss(pde_loss_weights=1.0, bc_loss_weights=[2.0, 1.0, 3.0, 1.0]))
+                                  adaptive_loss=npde.NonAdaptiveLoss(pde_loss_weights=1.0, bc_loss_weights=[2.0, 1.0, 3.0, 1.0]), precision="f32")
     prob = npde.discretize(sysm, disc)
     res = npde.solve(prob, npde.Adam(0.01), maxiters=25)
     th, m_, v_, hist = prob.u0.astype(np.float32).copy(), 0.0, 0.0, []
@@ -447,7 +447,7 @@ def test_resident_adam_matches_host_adam_and_sampler(npde, use_emu):
     res2 = npde.solve(prob, npde.Adam(0.01), maxiters=200, callback=lambda st, l: calls.append(st["iter"]) or True)
     assert calls == [50] and len(res2.losses) == 50
     # StochasticTraining -> on-device sampler
-    disc = npde.PhysicsInformedNN(chain, npde.StochasticTraining(64, bcs_points=32, rng=np.random.default_rng(3)), init_params=th0)
+    disc = npde.PhysicsInformedNN(chain, npde.StochasticTraining(64, bcs_points=32, rng=np.random.default_rng(3)), init_params=th0, precision="f32")
     prob = npde.discretize(sysm, disc)
     res = npde.solve(prob, npde.Adam(0.01), maxiters=6)
     assert np.all(np.isfinite(res.losses)) and len(set(np.round(res.losses, 12))) == 6
@@ -460,7 +460,7 @@ def test_resident_adam_matches_host_adam_and_sampler(npde, use_emu):
     assert np.all(pts[0] == 0.0) and pts[1].min() >= 1 / 64 - 1e-6 and pts[1].max() <= 1 - 1 / 64 + 1e-6
     # QuasiRandomTraining(resampling = true) with its default LatinHypercubeSample -> on-device Latin-hypercube redraw
     disc = npde.PhysicsInformedNN(chain, npde.QuasiRandomTraining(100, bcs_points=37, sampling_alg=npde.LatinHypercubeSample(seed=5)),
-                                  init_params=th0)
+                                  init_params=th0, precision="f32")
     prob = npde.discretize(sysm, disc)
     res = npde.solve(prob, npde.Adam(0.01), maxiters=4)
     assert np.all(np.isfinite(res.losses)) and len(set(np.round(res.losses, 12))) == 4
@@ -493,7 +493,7 @@ def test_adam_loop_graph_replay_matches_plain_launches(npde, use_emu, monkeypatc
                 monkeypatch.setenv("PINN_GRAPH", "1")
             else:
                 monkeypatch.delenv("PINN_GRAPH", raising=False)
-            prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, strat(), init_params=th0))
+            prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, strat(), init_params=th0, precision="f32"))
             res = npde.solve(prob, npde.Adam(0.01), maxiters=20)
             res_b = npde.solve(npde.remake(prob, u0=res.u), npde.Adam(0.01), maxiters=12)
             out.append((np.asarray(res.losses), res.u, np.asarray(res_b.losses), res_b.u))
@@ -508,7 +508,7 @@ def test_library_lbfgs(npde, use_emu):
     and refusal when a term's points are redrawn on the device."""
     sysm, chain = poisson2d(npde, "tanh")
     th0 = theta_for(chain, 61)
-    disc = npde.PhysicsInformedNN(chain, npde.GridTraining(0.1), init_params=th0)
+    disc = npde.PhysicsInformedNN(chain, npde.GridTraining(0.1), init_params=th0, precision="f32")
     prob = npde.discretize(sysm, disc)
     rep = prob.pinnrep
     w = rep._weights_now()
@@ -523,7 +523,7 @@ def test_library_lbfgs(npde, use_emu):
     np.testing.assert_allclose(res.losses[-1], hist[-1], rtol=1e-12)
     with pytest.raises(npde.EngineError, match="history in 1..64"):
         rep.engine.lbfgs(th0, 10, w, history=0)
-    disc_s = npde.PhysicsInformedNN(chain, npde.StochasticTraining(64, bcs_points=32, rng=np.random.default_rng(3)), init_params=th0)
+    disc_s = npde.PhysicsInformedNN(chain, npde.StochasticTraining(64, bcs_points=32, rng=np.random.default_rng(3)), init_params=th0, precision="f32")
     prob_s = npde.discretize(sysm, disc_s)
     npde.solve(prob_s, npde.Adam(0.01), maxiters=2)                     # installs the device samplers
     with pytest.raises(npde.EngineError, match="fixed objective"):
@@ -538,7 +538,7 @@ def test_device_sobol_sampler_matches_reference_sequence(npde, use_emu):
     sysm, chain = poisson2d(npde)
     th0 = theta_for(chain, 52)
     strat = npde.QuasiRandomTraining(256, bcs_points=64, sampling_alg=npde.SobolSample(scramble=False))
-    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th0))
+    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th0, precision="f32"))
     res = npde.solve(prob, npde.Adam(0.01), maxiters=3)
     rep = prob.pinnrep
     assert np.all(np.isfinite(res.losses)) and rep._device_samplers[0][4] == 3 and rep._device_samplers[0][3] == 0
@@ -584,7 +584,7 @@ def test_sobol_direction_numbers_up_to_8_axes(npde, use_emu):
     chain = npde.Chain(npde.Dense(3, 16, "tanh"), npde.Dense(16, 16, "tanh"), npde.Dense(16, 1))
     th0 = theta_for(chain, 53)
     strat = npde.QuasiRandomTraining(512, bcs_points=32, sampling_alg=npde.SobolSample(scramble=False))
-    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th0))
+    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th0, precision="f32"))
     eng = prob.pinnrep.engine
     eng.set_sampler(0, [0.0] * 3, [1.0] * 3, 512, seed=0, kind=3)
     with warnings.catch_warnings():
@@ -737,7 +737,7 @@ def test_per_layer_activations(npde, use_emu):
     sysm, _ = helpers.shape_problem(npde, 64, 4, 2)
     big = npde.Chain(npde.Dense(2, 64, "tanh"), npde.Dense(64, 64, "sigmoid"), npde.Dense(64, 64, "tanh"), npde.Dense(64, 64, "tanh"), npde.Dense(64, 1))
     with pytest.raises(Exception, match="per-layer tanh/sigmoid"):
-        npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(big, npde.GridTraining(0.25), init_params=theta_for(big, 75)))
+        npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(big, npde.GridTraining(0.25), init_params=theta_for(big, 75), precision="f32"))
 
 
 def test_bpinn_physics_loglikelihood(npde, use_emu):
@@ -745,7 +745,7 @@ def test_bpinn_physics_loglikelihood(npde, use_emu):
     and its gradient from the engine's per-term sums, against the oracle's residuals."""
     sysm, chain = poisson2d(npde, "tanh")
     th = theta_for(chain, 61)
-    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.125), init_params=th))
+    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.125), init_params=th, precision="f32"))
     sets = rep.pde_train_sets + rep.bcs_train_sets
     stds = [0.7, 0.05, 0.08, 0.11, 0.2]
     sizes = [s.shape[1] for s in sets]
@@ -836,7 +836,7 @@ def test_forward_derivatives_mirror(npde, use_emu):
     xt = torch.tensor(x, dtype=po.DT)
     for seed in range(3):
         theta = po.glorot_theta(ochain, np.random.default_rng(seed), bias_amp=0.0)
-        rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=theta))
+        rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=theta, precision="f32"))
         eng = rep.engine
         tht = torch.tensor(theta, dtype=po.DT)
         assert abs(eng.derivative(0, theta, x, [])[0] - float(ochain(xt, tht))) < 2e-6             # phi([1, 2], theta)
@@ -875,7 +875,7 @@ def test_bpinn_loglikelihood_with_std_gradients_and_data_term(npde, use_emu):
     rng = np.random.default_rng(9)
     xd = rng.uniform(0.1, 0.9, size=(2, 24))
     yd = np.sin(np.pi * xd[0]) * np.sin(np.pi * xd[1]) / (2 * np.pi ** 2) + 0.01 * rng.standard_normal(24)
-    disc = npde.PhysicsInformedNN(chain, npde.GridTraining(0.125), init_params=th, data_loss=[npde.DataLoss(sysm.dvs[0], xd, yd)])
+    disc = npde.PhysicsInformedNN(chain, npde.GridTraining(0.125), init_params=th, data_loss=[npde.DataLoss(sysm.dvs[0], xd, yd)], precision="f32")
     rep = npde.symbolic_discretize(sysm, disc)
     eng = rep.engine
     sets = rep.pde_train_sets + rep.bcs_train_sets

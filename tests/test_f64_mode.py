@@ -114,7 +114,7 @@ def test_f64_mode_derivative_orders_activations_weights(npde, use_emu):
     from neuralpde_jl_amd import workloads
     def run(sysm, chain, strat, seed, weights=None):
         theta = tp.theta_for(chain, seed)
-        disc = npde.PhysicsInformedNN(chain, strat, init_params=theta)
+        disc = npde.PhysicsInformedNN(chain, strat, init_params=theta, precision="f32")
         rep = npde.symbolic_discretize(sysm, disc)
         eng = rep.engine
         sets = rep.pde_train_sets + rep.bcs_train_sets
@@ -394,3 +394,194 @@ def test_f64_mode_data_misfit_term_and_estimated_parameter(npde, use_emu):
     assert abs(rep.engine.loss_grad_f64(theta, want_grad=False)[0][3] - dl) < 1e-13 * dl
     res = npde.solve(prob, npde.Adam(0.01), maxiters=30)
     assert res.u.dtype == np.float64 and res.losses[-1] < res.losses[0]
+
+
+# ---- r06: float64 through the WHOLE boundary — every public closure of the reference in eltype(theta) = Float64 ----
+def test_forward_derivatives_pin_at_the_reference_tolerances_f64(npde, use_emu):
+    """test/Forward/forward__derivatives.jl:7-44 through the C ABI in float64 mode AT THE REFERENCE'S OWN TOLERANCES: a 2 -> 16 -> 16 -> 1
+    sigmoid chain at [1, 2]; pinn_derivative_f64 (the engine's numeric_derivative: exact Taylor jets) against Zygote's role (the oracle's
+    exact derivatives) and against the reference's central differences with its get_eps steps — first order atol 1e-8, second order
+    (xx, xy, yy) atol 4e-5 (:29-30, :40-43).  (tests/test_emu_parity.py::test_forward_derivatives_mirror is the fp32 path's version: 2e-6.)"""
+    import torch
+    sysm, _ = helpers.shape_problem(npde, 16, 2, 2)
+    chain = npde.Chain(npde.Dense(2, 16, "sigmoid"), npde.Dense(16, 16, "sigmoid"), npde.Dense(16, 1))
+    ochain = po.Chain((2, 16, 16, 1), "sigmoid")
+    u = lambda cord, th, phi: phi(cord, th).sum(dim=0, keepdim=True)      # u_ of the reference test
+    x = np.array([[1.0], [2.0]])
+    xt = torch.tensor(x, dtype=po.DT)
+    for seed in range(3):
+        theta = po.glorot_theta(ochain, np.random.default_rng(seed), bias_amp=0.0)
+        rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=theta, precision="f64"))
+        eng = rep.engine
+        assert eng.get_option("precision") == "f64"
+        tht = torch.tensor(theta, dtype=po.DT)
+        assert abs(eng.phi_f64(0, theta, x)[0] - float(ochain(xt, tht))) < 1e-14                       # phi([1, 2], theta)
+        for ax in (0, 1):
+            got = float(eng.derivative_f64(0, theta, x, [ax])[0])
+            fd = float(po.numeric_derivative(ochain, u, xt, [po.get_eps(2, ax + 1, np.float64, 1)], 1, tht))
+            ex = float(po.exact_derivative(ochain, u, xt, [ax], tht))
+            assert abs(got - ex) < 1e-14 and abs(got - fd) < 1e-8, (ax, got, ex, fd)                   # forward__derivatives.jl:29-30: atol 1e-8
+        ex_, ey_ = po.get_eps(2, 1, np.float64, 2), po.get_eps(2, 2, np.float64, 2)
+        for epss, axes in [([ex_, ex_], [0, 0]), ([ex_, ey_], [0, 1]), ([ey_, ey_], [1, 1])]:
+            got = float(eng.derivative_f64(0, theta, x, axes)[0])
+            fd = float(po.numeric_derivative(ochain, u, xt, epss, 2, tht))
+            ex = float(po.exact_derivative(ochain, u, xt, axes, tht))
+            assert abs(got - ex) < 1e-13 and abs(got - fd) < 4e-5, (axes, got, ex, fd)                 # :40-43: atol 4e-5
+        # the float entry points of a handle in float64 mode run the same double kernels and narrow at the boundary
+        assert abs(float(eng.derivative(0, theta, x, [0])[0]) - float(eng.derivative_f64(0, theta, x, [0])[0])) < 1e-7
+        assert abs(float(eng.phi(0, theta, x)[0]) - float(eng.phi_f64(0, theta, x)[0])) < 1e-7
+    pts = np.random.default_rng(5).uniform(0, 1, size=(2, 700))      # two chunks of the lanes kernels' blocks, ragged
+    for axes in ([], [0], [1], [0, 0], [0, 1], [1, 1]):
+        got = eng.derivative_f64(0, theta, pts, axes)
+        ex = po.exact_derivative(ochain, u, torch.tensor(pts, dtype=po.DT), axes, tht).detach().numpy().reshape(-1)
+        assert np.max(np.abs(got - ex)) < 1e-13 * max(1.0, np.max(np.abs(ex))), axes
+    with pytest.raises(Exception, match="no float64 kernel carries"):
+        eng.derivative_f64(0, theta, pts, [0, 0, 1])                 # mixed third derivative: fp32 generated jet sets only
+    with pytest.raises(Exception, match="axis out of range"):
+        eng.derivative_f64(0, theta, pts, [2])
+    # an fp32 handle: the double entry points narrow / widen at the boundary (fp32 kernels)
+    eng.set_option("precision", "f32")
+    got = eng.derivative_f64(0, theta, pts, [0, 0])
+    ex = po.exact_derivative(ochain, u, torch.tensor(pts, dtype=po.DT), [0, 0], tht).detach().numpy().reshape(-1)
+    assert 1e-10 < np.max(np.abs(got - ex)) < 1e-5
+
+
+def test_forward_ode_pin_at_the_reference_tolerance_f64(npde, use_emu):
+    """test/Forward/forward__ode.jl:10-47 in float64 mode: chain x -> x.^2 is not expressible as Dense layers, so the same statement on a
+    network: the datafree residual closure of `Dx(u(x)) ~ 0` on the GridTraining(0.1) set (BC argument 0.0 removed: 0.1 ... 1.0) equals
+    du/dx at rtol 1e-8 (:46-47) — through pinn_residual_f64, and through the mirror's datafree_pde_loss_functions under precision = "f64"."""
+    import torch
+    (x,) = npde.parameters("x")
+    (u,) = npde.variables("u")
+    U = u(x)
+    sysm = npde.PDESystem([npde.Eq(npde.Differential(x)(U), 0.0)], [npde.Eq(u(0.0), 0.0)], [npde.In(x, npde.Interval(0.0, 1.0))], [x], [U])
+    chain = npde.Chain(npde.Dense(1, 12, "tanh"), npde.Dense(12, 12, "tanh"), npde.Dense(12, 1))
+    ochain = po.Chain((1, 12, 12, 1), "tanh")
+    theta = po.glorot_theta(ochain, np.random.default_rng(3))
+    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.1), init_params=theta, precision="f64"))
+    train = rep.pde_train_sets[0]
+    assert train.shape[0] == 1 and train.shape[1] >= 10                             # (0.1 ... 1.0, with or without the BC's own 0.0: strategies.py keeps the v6.2.2 `dif` quirk)
+    uf = lambda cord, th, phi: phi(cord, th)
+    tht = torch.tensor(theta, dtype=po.DT)
+    exact = po.exact_derivative(ochain, uf, torch.tensor(train, dtype=po.DT), [0], tht).detach().numpy().reshape(-1)
+    r = rep.engine.residual_f64(0, theta, train.shape[1])
+    np.testing.assert_allclose(r, exact, rtol=1e-12)
+    r2 = rep.loss_functions.datafree_pde_loss_functions[0](train, theta)            # the reference's public closure (pinn_types.jl:435-439)
+    assert r2.dtype == np.float64 and r2.shape == (1, train.shape[1])
+    np.testing.assert_allclose(r2.reshape(-1), exact, rtol=1e-8)                    # forward__ode.jl:46-47
+    fd = po.numeric_derivative(ochain, uf, torch.tensor(train, dtype=po.DT), [po.get_eps(1, 1, np.float64, 1)], 1, tht).detach().numpy().reshape(-1)
+    np.testing.assert_allclose(r2.reshape(-1), fd, rtol=1e-8, atol=1e-9)            # = the reference's own stencil value to its pin
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg4", "cfg5"])
+def test_f64_per_point_and_per_term_entry_points(npde, use_emu, name):
+    """pinn_residual_f64 / pinn_term_grads_f64 / pinn_loglik_grad_f64 on a handle in float64 mode against the float64 oracle: a single-network
+    problem on the matrix-pipe kernels, the three-network system, the 4-D inverse problem (lanes kernels, estimated parameter)"""
+    wl = _workloads()[name]()
+    rep, eng, sets, prob = _engine_f64(npde, wl)
+    th = np.asarray(rep.flat_init_params, dtype=np.float64) * 1.0
+    for k in range(eng.K):
+        r = eng.residual_f64(k, th, sets[k].shape[1])
+        ref = po.residual_values(prob, th, k, sets[k], mode="exact")
+        assert np.max(np.abs(r - ref)) < 1e-12 * max(1.0, np.max(np.abs(ref))), k
+        rf = eng.residual(k, th, sets[k].shape[1])                                   # float entry point: same kernels, narrowed
+        assert rf.dtype == np.float32 and np.max(np.abs(rf - ref)) < 2e-7 * max(1.0, np.max(np.abs(ref)))
+    L, tg = eng.term_grads_f64(th)
+    assert tg.dtype == np.float64 and tg.shape == (eng.K, eng.P)
+    for k in range(eng.K):
+        w = np.zeros(eng.K)
+        w[k] = 1.0
+        ref = po.loss_and_grad(prob, th, sets, weights=w, mode="exact")
+        assert abs(L[k] - ref.term_losses[k]) < EXACT * abs(ref.term_losses[k])
+        assert np.linalg.norm(tg[k] - ref.grad) < EXACT * np.linalg.norm(ref.grad), k
+    # BPINN log-likelihood: ll = sum_k [-N/2 log 2pi - N log s - SSE/(2 s^2)], d/dtheta, d/ds
+    stds = np.linspace(0.05, 0.2, eng.K)
+    ll, g, gs = eng.loglik_grad_f64(th, stds)
+    N = np.array([s.shape[1] for s in sets], dtype=np.float64)
+    w = N / (2.0 * stds ** 2)
+    ref = po.loss_and_grad(prob, th, sets, weights=w, mode="exact")
+    sse = ref.term_losses * N
+    ll_ref = float(np.sum(-0.5 * N * np.log(2 * np.pi) - N * np.log(stds) - sse / (2 * stds ** 2)))
+    assert abs(ll - ll_ref) < 1e-12 * abs(ll_ref)
+    assert np.linalg.norm(g + ref.grad) < EXACT * np.linalg.norm(ref.grad)
+    np.testing.assert_allclose(gs, -N / stds + sse / stds ** 3, rtol=1e-11)
+    ll32, g32, _ = eng.loglik_grad(th, stds)                                         # float entry point in float64 mode: evaluated in double
+    assert abs(ll32 - ll) < 1e-6 * abs(ll) and np.linalg.norm(g32 - g) < 1e-5 * np.linalg.norm(g)      # (theta itself is narrowed to float at that boundary)
+
+
+def test_f64_adam_iterate_survives_evaluations_between_chunks(npde, use_emu):
+    """in float64 mode the Adam iterate lived in the evaluation buffer — any evaluation between two pinn_adam_steps calls
+    (adaptive reweighting, a callback that evaluates the loss) destroyed it.  The iterate has its own buffer now: a chunked run with
+    evaluations in between equals the unchunked run bit for bit, and solve() with GradientScaleAdaptiveLoss / a loss-evaluating callback runs."""
+    from neuralpde_jl_amd import workloads
+    wl = workloads.cfg1_poisson1d(48)
+    rep, eng, sets, prob = _engine_f64(npde, wl)
+    th0 = np.asarray(rep.flat_init_params, dtype=np.float64)
+    ref_th, ref_hist = eng.adam_f64(th0, 12, 1e-3)
+    th, h1 = eng.adam_f64(th0, 5, 1e-3)
+    eng.loss_grad_f64(th0 * 0.5)                           # an evaluation at OTHER parameters between the chunks
+    eng.term_grads_f64(th0 * 0.25)
+    eng.residual_f64(0, th0 * 2.0, sets[0].shape[1])
+    th, h2 = eng.adam_f64(None, 7, 1e-3, init=False)
+    assert np.array_equal(np.concatenate([h1, h2]), ref_hist) and np.array_equal(th, ref_th)
+    # pinn_adam_apply on the float64 state: one host-driven update equals the resident loop's first step
+    l0, g0 = eng.loss_grad_f64(th0)
+    eng.adam_f64(th0, 1, 1e-3)                             # reference: theta after one resident step
+    one = eng.adam_f64(th0, 1, 1e-3)[0]
+    eng.L.check(eng.L.lib.pinn_adam_init_f64(eng.h, th0.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_double)), th0.size), "init")
+    raw = l0 * np.array([s.shape[1] for s in sets], dtype=np.float64)
+    eng.adam_apply(np.concatenate([g0, raw]), 1e-3)
+    got = np.zeros(eng.P)
+    import ctypes as C
+    eng.L.check(eng.L.lib.pinn_adam_get_f64(eng.h, got.ctypes.data_as(C.POINTER(C.c_double)), got.size), "get")
+    np.testing.assert_allclose(got, one, rtol=0, atol=2e-10)                         # (the gradient crosses pinn_adam_apply's float boundary)
+    # the mirror's solve(): adaptive reweighting between chunks + a callback that evaluates the loss
+    disc = npde.PhysicsInformedNN(wl.chains[0], wl.strategy, init_params=th0, precision="f64",
+                                  adaptive_loss=npde.GradientScaleAdaptiveLoss(4))
+    prob2 = npde.discretize(wl.pde_system, disc)
+    seen = []
+    def cb(state, loss):
+        seen.append(prob2.f(state["u"]))
+        return False
+    res = npde.solve(prob2, npde.Adam(1e-3), maxiters=12, callback=cb)
+    assert len(seen) >= 3 and np.all(np.isfinite(seen)) and np.isfinite(res.objective) and res.u.dtype == np.float64
+
+
+def test_precision_policy_follows_eltype_of_theta(npde, use_emu):
+    """the glue's precision policy = the reference's contract, compute dtype = eltype(theta) (src/eltype_matching.jl:8-10,
+    src/discretize.jl:432-449): PhysicsInformedNN(...) [precision = "auto"] runs the float64 kernels for Float64 parameters (incl. the default
+    init_params = None) and the fp32 kernels for Float32 init_params; "f32" on Float64 parameters is the explicit fast opt-in; a problem the
+    float64 kernels do not cover fails at discretize time under "auto" — with the reason and the opt-in spelled out, never a silent narrowing"""
+    from neuralpde_jl_amd import workloads
+    wl = workloads.cfg2_poisson2d(points=64, bcs_points=16)
+    chain, strat = wl.chains[0], wl.strategy
+    prob = helpers.oracle_problem(npde, wl.pde_system, wl.chains)
+    for init, want in ((None, "f64"), (wl.theta.astype(np.float64), "f64"), (wl.theta.astype(np.float32), "f32")):
+        rep = npde.symbolic_discretize(wl.pde_system, npde.PhysicsInformedNN(chain, strat, init_params=init))
+        assert rep.engine.get_option("precision") == want, (None if init is None else init.dtype, want)
+        assert rep.flat_init_params.dtype == (np.float32 if want == "f32" else np.float64)
+        th = rep.flat_init_params
+        val, g = rep._value_and_grad(th)
+        assert g.dtype == th.dtype
+        ref = po.loss_and_grad(prob, np.asarray(th, dtype=np.float64), rep.pde_train_sets + rep.bcs_train_sets, mode="exact")
+        g2 = np.linalg.norm(g - ref.grad) / np.linalg.norm(ref.grad)
+        assert (g2 < 1e-11) if want == "f64" else (1e-9 < g2 < 1e-5), (want, g2)
+        # phi and the datafree residual closures compute in the same dtype
+        x = np.array([[0.3, 0.6], [0.2, 0.9]])
+        ph = rep.phi(x, th)
+        exact = po.phi_values(prob.chains[0], np.asarray(th, dtype=np.float64), x).reshape(1, -1)
+        err = np.max(np.abs(ph - exact))
+        assert (err < 1e-14) if want == "f64" else (1e-10 < err < 1e-5)
+    rep = npde.symbolic_discretize(wl.pde_system, npde.PhysicsInformedNN(chain, strat, init_params=wl.theta, precision="f32"))
+    assert rep.engine.get_option("precision") == "f32"                               # the explicit fast opt-in on Float64 parameters
+    assert wl.discretization().precision == "f32" and wl.discretization("auto").precision == "auto"      # (the benchmark workloads opt in explicitly)
+    # DGM networks have fp32 kernels only: "auto" + Float64 parameters refuses, naming the opt-in
+    t, x = npde.parameters("t x")
+    (u,) = npde.variables("u")
+    sysd = npde.PDESystem([npde.Eq(npde.Differential(t)(u(t, x)) + npde.Differential(x)(u(t, x)), 0)], [npde.Eq(u(0, x), sp.sin(x))],
+                          [npde.In(t, npde.Interval(0.0, 1.0)), npde.In(x, npde.Interval(0.0, 1.0))], [t, x], [u(t, x)])
+    with pytest.raises(npde.EngineError, match='DGM networks are not covered by the float64 mode(.|\n)*precision = "f32"'):
+        npde.discretize(sysd, npde.DeepGalerkin(2, 1, 8, 1, "tanh", "tanh", "identity", npde.GridTraining(0.25)))
+    npde.discretize(sysd, npde.DeepGalerkin(2, 1, 8, 1, "tanh", "tanh", "identity", npde.GridTraining(0.25), precision="f32"))
+    with pytest.raises(ValueError, match="precision must be"):
+        npde.PhysicsInformedNN(chain, strat, precision="f16")

@@ -70,7 +70,7 @@ sysm, _ = tp.poisson2d(npde)
 chain = npde.Chain(npde.Dense(2, 200, "tanh"), npde.Dense(200, 200, "tanh"), npde.Dense(200, 200, "tanh"), npde.Dense(200, 1))
 mk = lambda: npde.QuasiRandomTraining(24, bcs_points=70, sampling_alg=npde.SobolSample(seed=9), resampling=False, minibatch=1)     # (> 64 boundary points: their own launch)
 tc = time.time()
-prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, mk(), init_params=tp.theta_for(chain, 65)))
+prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, mk(), init_params=tp.theta_for(chain, 65), precision="f32"))
 print("  COLD_CREATE 3 x 200 chain (two members: interior forward-Laplacian set + value-only boundary set): %%.2f s" %% (time.time() - tc), flush=True)
 tl[-1] = time.time()
 tp.check(npde, sysm, [chain], mk(), tp.theta_for(chain, 65))

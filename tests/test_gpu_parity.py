@@ -138,7 +138,7 @@ def test_param_estim_4x64(npde, hip_lib):
     chain = workloads.mlp(2, 64, 4)
     theta = workloads.synthetic_theta([chain], 77)
     strat = npde.QuasiRandomTraining(3000, bcs_points=500, sampling_alg=npde.SobolSample(seed=9), resampling=False, minibatch=1)
-    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=theta, param_estim=True))
+    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=theta, param_estim=True, precision="f32"))
     th = rep.flat_init_params
     sets = rep.pde_train_sets + rep.bcs_train_sets
     losses, grad = rep.engine.loss_grad(th)
@@ -205,7 +205,7 @@ def test_training_converges_resident_adam(npde, hip_lib):
     chain = npde.Chain(npde.Dense(2, 16, "tanh"), npde.Dense(16, 16, "tanh"), npde.Dense(16, 1))
     th0 = npde.initialparameters(np.random.default_rng(0), chain)
     strat = npde.QuasiRandomTraining(2048, bcs_points=256, sampling_alg=npde.SobolSample(seed=1), resampling=False, minibatch=1)
-    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th0))
+    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th0, precision="f32"))
     res = npde.solve(prob, npde.Adam(0.01), maxiters=3000)
     xs = np.linspace(0, 1, 21)
     grid = np.array([[a, b] for a in xs for b in xs]).T
@@ -232,7 +232,7 @@ def test_device_samplers_gpu(npde, hip_lib):
     chain = npde.Chain(npde.Dense(2, 16, "tanh"), npde.Dense(16, 16, "tanh"), npde.Dense(16, 1))
     th0 = npde.initialparameters(np.random.default_rng(0), chain)
     strat = npde.QuasiRandomTraining(65536, bcs_points=1024, sampling_alg=npde.SobolSample(scramble=False))
-    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th0))
+    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th0, precision="f32"))
     eng = prob.pinnrep.engine
     assert eng.L.backend == "hip"
     n = 65536
@@ -261,7 +261,7 @@ def test_small_net_shape_grid_gpu(npde, hip_lib, width, hidden, d):
     sysm, chain = helpers.shape_problem(npde, width, hidden, d)
     strat = npde.QuasiRandomTraining(700, bcs_points=300, sampling_alg=npde.SobolSample(seed=width + hidden), resampling=False, minibatch=1)
     th = po.glorot_theta(po.Chain(tuple(chain.sizes), chain.act), np.random.default_rng(100 + width + 10 * hidden + d))
-    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th))
+    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th, precision="f32"))
     assert rep.engine.L.backend == "hip"
     sets = rep.pde_train_sets + rep.bcs_train_sets
     losses, grad = rep.engine.loss_grad(rep.flat_init_params)
@@ -303,7 +303,7 @@ def test_per_layer_activations_gpu(npde, hip_lib, d, width, acts):
     chain = npde.Chain(*layers)
     strat = npde.QuasiRandomTraining(900, bcs_points=300, sampling_alg=npde.SobolSample(seed=width), resampling=False, minibatch=1)
     th = po.glorot_theta(po.Chain(tuple(chain.sizes), chain.act), np.random.default_rng(width))
-    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th))
+    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th, precision="f32"))
     assert rep.engine.L.backend == "hip"
     sets = rep.pde_train_sets + rep.bcs_train_sets
     losses, grad = rep.engine.loss_grad(rep.flat_init_params)
@@ -330,7 +330,7 @@ def test_wide_nets_3_and_4_hidden_layers_gpu(npde, hip_lib, width, hidden, act):
     chain = npde.Chain(*layers)
     strat = npde.QuasiRandomTraining(2000, bcs_points=500, sampling_alg=npde.SobolSample(seed=hidden), resampling=False, minibatch=1)
     th = po.glorot_theta(po.Chain(tuple(chain.sizes), chain.act), np.random.default_rng(300 + hidden))
-    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th))
+    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th, precision="f32"))
     sets = rep.pde_train_sets + rep.bcs_train_sets
     losses, grad = rep.engine.loss_grad(rep.flat_init_params)
     ref = po.loss_and_grad(helpers.oracle_problem(npde, sysm, [chain]), rep.flat_init_params, sets, mode="stencil")
@@ -350,7 +350,7 @@ def test_higher_order_derivatives_gpu(npde, hip_lib):
 
     def run(sysm, chain, strat, seed, weights=None):
         th = tp.theta_for(chain, seed)
-        rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th))
+        rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th, precision="f32"))
         assert rep.engine.L.backend == "hip"
         sets = rep.pde_train_sets + rep.bcs_train_sets
         losses, grad = rep.engine.loss_grad(th, weights)
@@ -388,7 +388,7 @@ def test_heterogeneous_system_gpu(npde, hip_lib):
                           [u(x, y, z), v(y, x), h(z), p(x, z)])
     chains = [npde.Chain(npde.Dense(n, 12, "tanh"), npde.Dense(12, 12, "tanh"), npde.Dense(12, 1)) for n in (3, 2, 1, 2)]
     theta = np.concatenate([tp.theta_for(c, 50 + i) for i, c in enumerate(chains)])
-    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chains, npde.GridTraining(0.1), init_params=theta))
+    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chains, npde.GridTraining(0.1), init_params=theta, precision="f32"))
     assert rep.engine.L.backend == "hip"
     sets = rep.pde_train_sets + rep.bcs_train_sets
     w = [1.0, 2.0, 0.5, 1.5, 3.0, 1.0]
@@ -406,7 +406,7 @@ def test_sin_activation_gpu(npde, hip_lib):
     for chain, seed, s, mode in ((npde.Chain(npde.Dense(2, 64, "sin"), *[npde.Dense(64, 64, "sin") for _ in range(3)], npde.Dense(64, 1)), 82, sysm, "stencil"),
                                  (npde.Chain(npde.Dense(2, 16, "sin"), npde.Dense(16, 16, "sin"), npde.Dense(16, 1)), 83, tp._ks(npde), "exact")):
         th = tp.theta_for(chain, seed)
-        rep = npde.symbolic_discretize(s, npde.PhysicsInformedNN(chain, strat, init_params=th))
+        rep = npde.symbolic_discretize(s, npde.PhysicsInformedNN(chain, strat, init_params=th, precision="f32"))
         sets = rep.pde_train_sets + rep.bcs_train_sets
         losses, grad = rep.engine.loss_grad(th)
         ref = po.loss_and_grad(helpers.oracle_problem(npde, s, [chain]), th, sets, mode=mode)

@@ -65,7 +65,7 @@ def test_pde_ii_2d_poisson(npde, lib, strategy):
              "stochastic": lambda: npde.StochasticTraining(100, bcs_points=50, rng=np.random.default_rng(1)),
              "quasirandom": lambda: npde.QuasiRandomTraining(100, bcs_points=50, sampling_alg=npde.LatinHypercubeSample(seed=2))}[strategy]()
     theta0 = npde.initialparameters(np.random.default_rng(100), chain)
-    prob = npde.discretize(npde.PDESystem([eq], bcs, dom, [x, y], [u(x, y)]), npde.PhysicsInformedNN(chain, strat, init_params=theta0))
+    prob = npde.discretize(npde.PDESystem([eq], bcs, dom, [x, y], [u(x, y)]), npde.PhysicsInformedNN(chain, strat, init_params=theta0, precision="f32"))
     # the reference's schedule where the objective is fixed (BFGS needs that); resampling strategies: Adam only
     theta, losses = train(npde, prob, [(0.01, 1000), ("bfgs", 1000)] if strategy == "grid" else [(0.01, 1000), (0.003, 2000)])
     pts = grid2((0.0, 1.0), (0.0, 1.0), 0.01)
@@ -89,7 +89,7 @@ def test_pde_iv_system_of_pdes(npde, lib):
     chains = [npde.Chain(npde.Dense(2, 15, "tanh"), npde.Dense(15, 1)) for _ in range(2)]
     rng = np.random.default_rng(7)
     theta0 = np.concatenate([npde.initialparameters(rng, c) for c in chains])
-    disc = npde.PhysicsInformedNN(chains, npde.QuadratureTraining(), init_params=theta0)
+    disc = npde.PhysicsInformedNN(chains, npde.QuadratureTraining(), init_params=theta0, precision="f32")
     prob = npde.discretize(npde.PDESystem(eqs, bcs, dom, [x, y], [u1(x, y), u2(x, y)]), disc)
     theta, losses = train(npde, prob, [(0.01, 2000)])
     pts = grid2((0.0, 1.0), (0.0, 1.0), 0.01)
@@ -114,7 +114,7 @@ def test_pde_v_2d_wave_equation(npde, lib):
     chain = chain_of(npde, 2, 16, 2, "sigmoid")
     theta0 = npde.initialparameters(np.random.default_rng(3), chain)
     prob = npde.discretize(npde.PDESystem([eq], bcs, dom, [x, t], [u(x, t)]),
-                           npde.PhysicsInformedNN(chain, npde.QuadratureTraining(), init_params=theta0))
+                           npde.PhysicsInformedNN(chain, npde.QuadratureTraining(), init_params=theta0, precision="f32"))
     theta, losses = train(npde, prob, [(0.01, 2000), ("bfgs", 2000)])          # the reference's schedule
     pts = grid2((0.0, 1.0), (0.0, 1.0), 0.1)
     k = np.arange(1, 2001, 2)[:, None]
@@ -136,7 +136,7 @@ def test_pde_vi_mixed_derivative(npde, lib):
     chain = chain_of(npde, 2, 32, 2, "sigmoid")
     theta0 = npde.initialparameters(np.random.default_rng(100), chain)
     strat = npde.QuasiRandomTraining(2048, sampling_alg=npde.SobolSample(seed=1), resampling=False, minibatch=1)
-    prob = npde.discretize(npde.PDESystem([eq], bcs, dom, [x, y], [u(x, y)]), npde.PhysicsInformedNN(chain, strat, init_params=theta0))
+    prob = npde.discretize(npde.PDESystem([eq], bcs, dom, [x, y], [u(x, y)]), npde.PhysicsInformedNN(chain, strat, init_params=theta0, precision="f32"))
     theta, losses = train(npde, prob, [("lbfgs", 500)])                       # the reference's schedule (BFGS there; L-BFGS of the library here)
     pts = grid2((0.0, 1.0), (0.0, 1.0), 0.01)
     real = pts[0] + pts[0] * pts[1] + pts[1] ** 2 / 2
@@ -156,7 +156,7 @@ def test_direct_function_approximation_1d(npde, lib):
     chain = chain_of(npde, 1, 10, 2, "tanh")
     theta0 = npde.initialparameters(np.random.default_rng(110), chain)
     prob = npde.discretize(npde.PDESystem(eq, [npde.Eq(u(0), u(0))], dom, [x], [u(x)]),
-                           npde.PhysicsInformedNN(chain, npde.GridTraining(0.01), init_params=theta0))
+                           npde.PhysicsInformedNN(chain, npde.GridTraining(0.01), init_params=theta0, precision="f32"))
     theta, losses = train(npde, prob, [(0.05, 1000), ("bfgs", 500)])          # the reference's schedule
     xs = np.arange(0.0, 2.0 + 0.0005, 0.001)[None, :]
     real = 2 + np.abs(xs[0] - 0.5)
@@ -179,7 +179,7 @@ def test_docs_third_order_ode(npde, lib):
     chain = npde.Chain(npde.Dense(1, 8, "sigmoid"), npde.Dense(8, 1))
     theta0 = npde.initialparameters(np.random.default_rng(5), chain)
     strat = npde.QuasiRandomTraining(20, sampling_alg=npde.LatinHypercubeSample(seed=4))
-    prob = npde.discretize(npde.PDESystem([eq], bcs, dom, [x], [u(x)]), npde.PhysicsInformedNN(chain, strat, init_params=theta0))
+    prob = npde.discretize(npde.PDESystem([eq], bcs, dom, [x], [u(x)]), npde.PhysicsInformedNN(chain, strat, init_params=theta0, precision="f32"))
     theta, losses = train(npde, prob, [(0.01, 2000), (0.003, 4000)])
     xs = np.arange(0.0, 1.0 + 0.0025, 0.005)[None, :]
     real = (np.pi * xs[0] * (-xs[0] + (np.pi ** 2) * (2 * xs[0] - 3) + 1) - np.sin(np.pi * xs[0])) / (np.pi ** 3)
@@ -213,7 +213,7 @@ def test_simple_1d_ode_all_strategies(npde, lib, strategy):
              "quasirandom_resampling": lambda: npde.QuasiRandomTraining(100, bcs_points=50, sampling_alg=npde.LatinHypercubeSample(seed=13), resampling=True, minibatch=0),
              "quadrature": lambda: npde.QuadratureTraining()}[strategy]()
     theta0 = npde.initialparameters(np.random.default_rng(21), chain)
-    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=theta0))
+    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=theta0, precision="f32"))
     theta, losses = train(npde, prob, [(0.1, 1000), (0.01, 500), (0.001, 500)])
     err = np.linalg.norm(prob.pinnrep.phi(ts, theta)[0] - real)
     print(f"1-d ode {strategy}: ||u_predict - u_real||_2 = {err:.4f} over 101 points (reference tolerance 0.8), loss {losses[0]:.3e} -> {losses[-1]:.3e}")
@@ -226,7 +226,7 @@ def test_translating_from_flux(npde, lib):
     sysm, ts, real = _simple_1d_ode(npde)
     chain = npde.Chain(npde.Dense(1, 12, "sigmoid"), npde.Dense(12, 1))
     theta0 = npde.initialparameters(np.random.default_rng(22), chain)
-    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, npde.QuadratureTraining(), init_params=theta0))
+    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, npde.QuadratureTraining(), init_params=theta0, precision="f32"))
     theta, losses = train(npde, prob, [(0.1, 1000), (0.01, 500), (0.001, 500)])
     err = np.linalg.norm(prob.pinnrep.phi(ts, theta)[0] - real)
     print(f"translating from flux: ||u_predict - u_real||_2 = {err:.4f} (reference tolerance 0.1)")
@@ -254,7 +254,7 @@ def test_adaptive_loss_2d_poisson(npde, lib, scheme):
     rels = []
     for seed in (60, 61, 62):          # the reference fixes Random.seed!(60); the final iterate of 2000 Adam(0.03) steps on 256 redrawn points
         theta0 = npde.initialparameters(np.random.default_rng(seed), chain)      # is noisy, so the mirror takes the median of three seeds
-        disc = npde.PhysicsInformedNN(chain, npde.StochasticTraining(256, rng=np.random.default_rng(seed + 100)), init_params=theta0, adaptive_loss=loss())
+        disc = npde.PhysicsInformedNN(chain, npde.StochasticTraining(256, rng=np.random.default_rng(seed + 100)), init_params=theta0, adaptive_loss=loss(), precision="f32")
         prob = npde.discretize(npde.PDESystem([eq], bcs, dom, [x, y], [u(x, y)]), disc)
         res = npde.solve(prob, npde.Adam(0.03), maxiters=2000)
         pred = prob.pinnrep.phi(pts, res.u)[0]
@@ -286,7 +286,7 @@ def test_lorenz_parameter_estimation(npde, lib):
     data = [npde.DataLoss(v(t), ts[None, :], sol.y[i]) for i, v in enumerate((xv, yv, zv))]
     rng = np.random.default_rng(100)
     theta0 = np.concatenate([npde.initialparameters(rng, c) for c in chains])
-    disc = npde.PhysicsInformedNN(chains, npde.GridTraining(0.05), init_params=theta0, param_estim=True, data_loss=data)
+    disc = npde.PhysicsInformedNN(chains, npde.GridTraining(0.05), init_params=theta0, param_estim=True, data_loss=data, precision="f32")
     prob = npde.discretize(sysm, disc)
     theta, losses = train(npde, prob, [("bfgs", 4000)])
     p = theta[-3:]
@@ -308,7 +308,7 @@ def test_pde_i_heterogeneous_system(npde, lib):
     chains = [chain_of(npde, d, 12, 2, "tanh") for d in (3, 2, 1, 2)]
     rng = np.random.default_rng(9)
     theta0 = np.concatenate([npde.initialparameters(rng, c) for c in chains])
-    disc = npde.PhysicsInformedNN(chains, npde.GridTraining(0.1), init_params=theta0)
+    disc = npde.PhysicsInformedNN(chains, npde.GridTraining(0.1), init_params=theta0, precision="f32")
     prob = npde.discretize(npde.PDESystem(eqs, bcs, dom, [x, y, z], [u(x, y, z), v(y, x), h(z), p(x, z)]), disc)
     theta, losses = train(npde, prob, [("lbfgs", 2000)])
     g = np.arange(0.0, 1.0 + 0.05, 0.1)
@@ -333,7 +333,7 @@ def test_direct_function_approximation_2d(npde, lib):
     chain = chain_of(npde, 2, 25, 3, "tanh")
     theta0 = npde.initialparameters(np.random.default_rng(110), chain)
     prob = npde.discretize(npde.PDESystem([npde.Eq(u(x, y), f)], [npde.Eq(u(0, 0), u(0, 0))], dom, [x, y], [u(x, y)]),
-                           npde.PhysicsInformedNN(chain, npde.GridTraining(0.4), init_params=theta0))
+                           npde.PhysicsInformedNN(chain, npde.GridTraining(0.4), init_params=theta0, precision="f32"))
     # (L-BFGS instead of the reference's dense BFGS: 1,401 parameters make scipy's dense update the slow part of the test, not the engine)
     theta, losses = train(npde, prob, [(0.01, 500), ("lbfgs", 1000), ("lbfgs", 500)])
     pts = grid2((-10.0, 10.0), (-10.0, 10.0), 0.1)
@@ -363,7 +363,7 @@ def test_pde_iii_third_order_ode_system_fp32_limit(npde, lib):
     theta0 = np.concatenate([npde.initialparameters(rng, c) for c in chains])
     strat = npde.QuasiRandomTraining(100, sampling_alg=npde.SobolSample(seed=1), resampling=False, minibatch=1)
     prob = npde.discretize(npde.PDESystem([eq], bcs, dom, [x], [u(x), Dxu(x), Dxxu(x), O1(x), O2(x)]),
-                           npde.PhysicsInformedNN(chains, strat, init_params=theta0))
+                           npde.PhysicsInformedNN(chains, strat, init_params=theta0, precision="f32"))
     res = npde.solve(prob, npde.BFGS(), maxiters=5000, callback=lambda st, l: l < 1e-9)
     xs = np.arange(0.0, 1.0 + 0.005, 0.01)[None, :]
     real = (np.pi * xs[0] * (-xs[0] + (np.pi ** 2) * (2 * xs[0] - 3) + 1) - np.sin(np.pi * xs[0])) / (np.pi ** 3)
@@ -384,7 +384,7 @@ def test_bpinn_pde_i_1d_periodic_system(npde, lib):
     sysm = npde.PDESystem([eq], [npde.Eq(u(0.0), 0.0)], [npde.In(t, npde.Interval(0.0, 2.0))], [t], [u(t)])
     chain = npde.Chain(npde.Dense(1, 6, "tanh"), npde.Dense(6, 1))
     theta0 = npde.initialparameters(np.random.default_rng(100), chain)
-    disc = npde.PhysicsInformedNN(chain, npde.GridTraining(0.01), init_params=theta0)
+    disc = npde.PhysicsInformedNN(chain, npde.GridTraining(0.01), init_params=theta0, precision="f32")
     sol = npde.ahmc_bayesian_pinn_pde(sysm, disc, draw_samples=1500, bcstd=[0.01], phystd=[0.01], priorsNNw=(0.0, 1.0), saveats=[1 / 50.0],
                                       rng=np.random.default_rng(101))
     ts = sol.timepoints[0][0]
@@ -406,7 +406,7 @@ def test_bpinn_pde_ii_1d_ode(npde, lib):
     errs = []
     for seed in (100, 101, 102):
         theta0 = npde.initialparameters(np.random.default_rng(seed), chain)
-        sol = npde.ahmc_bayesian_pinn_pde(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.01), init_params=theta0), draw_samples=500,
+        sol = npde.ahmc_bayesian_pinn_pde(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.01), init_params=theta0, precision="f32"), draw_samples=500,
                                           bcstd=[0.1], phystd=[0.05], priorsNNw=(0.0, 10.0), saveats=[1 / 100.0], rng=np.random.default_rng(seed + 2))
         ts = sol.timepoints[0][0]
         real = np.exp(-(ts ** 2) / 2) / (1 + ts + ts ** 3) + ts ** 2
@@ -433,7 +433,7 @@ def test_bpinn_pde_inv_i_1d_periodic_system(npde, lib):
     clean = np.sin(2 * np.pi * tp) / (2 * np.pi)
     obs = clean + clean * 0.2 * rng.standard_normal(tp.size)
     theta0 = npde.initialparameters(rng, chain)                       # (theta.p is appended by the discretizer from `defaults`)
-    disc = npde.PhysicsInformedNN(chain, npde.GridTraining(0.02), init_params=theta0, param_estim=True, data_loss=[npde.DataLoss(u(t), tp[None, :], obs)])
+    disc = npde.PhysicsInformedNN(chain, npde.GridTraining(0.02), init_params=theta0, param_estim=True, data_loss=[npde.DataLoss(u(t), tp[None, :], obs)], precision="f32")
     sol = npde.ahmc_bayesian_pinn_pde(sysm, disc, draw_samples=1500, bcstd=[0.02], phystd=[0.02], l2std=[0.02], priorsNNw=(0.0, 1.0),
                                       saveats=[1 / 50.0], param=[bpinn.LogNormal(6.0, 0.5)], rng=np.random.default_rng(104))
     ts = sol.timepoints[0][0]
@@ -464,7 +464,7 @@ def test_bpinn_pde_inv_ii_lorenz_system(npde, lib):
     us = ode.y + 0.05 * rng.standard_normal(ode.y.shape) * ode.y
     theta0 = np.concatenate([npde.initialparameters(rng, c) for c in chains])
     disc = npde.PhysicsInformedNN(chains, npde.GridTraining(0.01), init_params=theta0, param_estim=True,
-                                  data_loss=[npde.DataLoss(v(t), ts[None, :], us[i]) for i, v in enumerate((xv, yv, zv))])
+                                  data_loss=[npde.DataLoss(v(t), ts[None, :], us[i]) for i, v in enumerate((xv, yv, zv))], precision="f32")
     sol = npde.ahmc_bayesian_pinn_pde(sysm, disc, draw_samples=50, bcstd=[0.3] * 3, phystd=[0.1] * 3, l2std=[1.0] * 3, priorsNNw=(0.0, 1.0),
                                       saveats=[0.01], param=[bpinn.Normal(12.0, 2.0)], rng=np.random.default_rng(105))
     pe = sol.estimated_de_params[0]
@@ -482,7 +482,7 @@ def test_cuda_1d_ode(npde, lib):
     sysm, ts, real = _simple_1d_ode(npde)
     chain = chain_of(npde, 1, 20, 5, "sigmoid")
     theta0 = npde.initialparameters(np.random.default_rng(100), chain)
-    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.1), init_params=theta0))
+    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.1), init_params=theta0, precision="f32"))
     assert "HP32_NHH4_D1" in prob.pinnrep.engine.describe()
     theta, losses = train(npde, prob, [(0.01, 2000)])
     err = np.linalg.norm(prob.pinnrep.phi(ts, theta)[0] - real)
@@ -504,7 +504,7 @@ def test_cuda_1d_pde_neumann_bc(npde, lib):
     theta0 = npde.initialparameters(np.random.default_rng(100), chain)
     n, iters = (60, 150) if _ON_EMU else (500, 2000)
     strat = npde.QuasiRandomTraining(n, sampling_alg=npde.SobolSample(seed=1), resampling=False, minibatch=30, rng=np.random.default_rng(2))
-    prob = npde.discretize(npde.PDESystem([eq], bcs, dom, [t, x], [u(t, x)]), npde.PhysicsInformedNN(chain, strat, init_params=theta0))
+    prob = npde.discretize(npde.PDESystem([eq], bcs, dom, [t, x], [u(t, x)]), npde.PhysicsInformedNN(chain, strat, init_params=theta0, precision="f32"))
     assert "HP32_NHH3_D2" in prob.pinnrep.engine.describe()
     theta, losses = train(npde, prob, [(0.1, iters), (0.01, iters)])
     pts = grid2((0.0, 1.0), (0.0, 1.0), 0.01)
@@ -528,7 +528,7 @@ def test_cuda_1d_pde_dirichlet_bc_periodic_embedding(npde, lib):
     theta0 = npde.initialparameters(np.random.default_rng(100), chain)
     n, iters = (60, 100) if _ON_EMU else (1000, 1000)
     prob = npde.discretize(npde.PDESystem([eq], bcs, dom, [t, x], [u(t, x)]),
-                           npde.PhysicsInformedNN(chain, npde.StochasticTraining(n, rng=np.random.default_rng(3)), init_params=theta0))
+                           npde.PhysicsInformedNN(chain, npde.StochasticTraining(n, rng=np.random.default_rng(3)), init_params=theta0, precision="f32"))
     assert "HP32_NHH5_D3" in prob.pinnrep.engine.describe()             # the network runs over the three features (t, sin x, cos x)
     theta, losses = train(npde, prob, [(0.01, iters), (0.001, iters)])
     pts = grid2((0.0, 1.0), (0.0, 2 * math.pi), 0.01)
@@ -553,7 +553,7 @@ def test_cuda_2d_pde(npde, lib):
     chain = chain_of(npde, 3, 25, 4, "sigmoid")
     theta0 = npde.initialparameters(np.random.default_rng(100), chain)
     dx, iters = (0.5, 100) if _ON_EMU else (0.05, 2500)
-    prob = npde.discretize(npde.PDESystem([eq], bcs, dom, [t, x, y], [u(t, x, y)]), npde.PhysicsInformedNN(chain, npde.GridTraining(dx), init_params=theta0))
+    prob = npde.discretize(npde.PDESystem([eq], bcs, dom, [t, x, y], [u(t, x, y)]), npde.PhysicsInformedNN(chain, npde.GridTraining(dx), init_params=theta0, precision="f32"))
     assert "HP32_NHH3_D3" in prob.pinnrep.engine.describe() and "L6" in prob.pinnrep.engine.describe()
     theta, losses = train(npde, prob, [(0.01, iters), (0.001, iters)])
     g = np.arange(0.0, 2.0 + 0.05, 0.1)
@@ -576,7 +576,7 @@ def test_dgm_poisson(npde, lib):
            npde.Eq(u(x, 0), 0.0), npde.Eq(u(x, 1), -sp.sin(sp.pi * x) * math.sin(math.pi * 1))]
     dom = [npde.In(x, npde.Interval(0.0, 1.0)), npde.In(y, npde.Interval(0.0, 1.0))]
     strat = npde.QuasiRandomTraining(256, sampling_alg=npde.LatinHypercubeSample(seed=7), minibatch=32)
-    disc = npde.DeepGalerkin(2, 1, 20, 3, "tanh", "tanh", "identity", strat)
+    disc = npde.DeepGalerkin(2, 1, 20, 3, "tanh", "tanh", "identity", strat, precision="f32")
     prob = npde.discretize(npde.PDESystem([eq], bcs, dom, [x, y], [u(x, y)]), disc)
     theta, losses = train(npde, prob, [(0.01, 500), (0.001, 200)])
     pts = grid2((0.0, 1.0), (0.0, 1.0), 0.01)
@@ -599,7 +599,7 @@ def test_dgm_black_scholes(npde, lib):
     bcs = [npde.Eq(g(T, xx), sp.Max(xx - K, 0.0))]
     dom = [npde.In(tt, npde.Interval(0.0, T)), npde.In(xx, npde.Interval(0.0, S * mult))]
     strat = npde.QuasiRandomTraining(128, sampling_alg=npde.LatinHypercubeSample(seed=8), minibatch=32)
-    disc = npde.DeepGalerkin(2, 1, 40, 3, "tanh", "tanh", "identity", strat)
+    disc = npde.DeepGalerkin(2, 1, 40, 3, "tanh", "tanh", "identity", strat, precision="f32")
     prob = npde.discretize(npde.PDESystem([eq], bcs, dom, [tt, xx], [g(tt, xx)]), disc)
     theta, losses = train(npde, prob, [(0.1, 100), (0.01, 500)])
     ts, xs = np.arange(0.0, T - 0.001 + 1e-9, 0.01), np.arange(0.0, S + 0.5, 1.0)

@@ -27,7 +27,7 @@ def test_dgm_burgers_against_the_reference_mol_table(npde, hip_lib):
         rng = np.random.default_rng(seed)
         strategy = npde.QuasiRandomTraining(256, minibatch=32, sampling_alg=npde.LatinHypercubeSample(seed=seed), rng=rng)
         disc = npde.DeepGalerkin(2, 1, 50, 5, "tanh", "tanh", "identity", strategy,
-                                 init_params=npde.initialparameters(rng, npde.DGM(2, 1, 50, 5, "tanh", "tanh")))
+                                 init_params=npde.initialparameters(rng, npde.DGM(2, 1, 50, 5, "tanh", "tanh")), precision="f32")
         prob = npde.discretize(sysm, disc)
         assert prob.pinnrep.engine.L.backend == "hip"
         res = npde.solve(prob, npde.Adam(0.01), maxiters=500)

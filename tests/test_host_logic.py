@@ -101,16 +101,16 @@ def test_discretizer_errors(npde, use_emu):
     chain = npde.Chain(npde.Dense(2, 16, "tanh"), npde.Dense(16, 16, "tanh"), npde.Dense(16, 1))
     with pytest.raises(TypeError):                # no boundary conditions (reference: MethodError in the solve phase)
         npde.symbolic_discretize(npde.PDESystem(sysm.eqs, [], sysm.domain, sysm.ivs, sysm.dvs),
-                                 npde.PhysicsInformedNN(chain, npde.GridTraining(0.5)))
+                                 npde.PhysicsInformedNN(chain, npde.GridTraining(0.5), precision="f32"))
     with pytest.raises(ValueError):               # trivial bc 0 ~ 0 (reference: ArgumentError at discretize)
         npde.symbolic_discretize(npde.PDESystem(sysm.eqs, [npde.Eq(0.0, 0.0)], sysm.domain, sysm.ivs, sysm.dvs),
-                                 npde.PhysicsInformedNN(chain, npde.GridTraining(0.5)))
+                                 npde.PhysicsInformedNN(chain, npde.GridTraining(0.5), precision="f32"))
     with pytest.raises(ValueError):               # chain count != dependent variable count
-        npde.symbolic_discretize(sysm, npde.PhysicsInformedNN([chain, chain], npde.GridTraining(0.5)))
+        npde.symbolic_discretize(sysm, npde.PhysicsInformedNN([chain, chain], npde.GridTraining(0.5), precision="f32"))
     # shapes outside the kernel table are specialised at create time (tests/test_jit.py); what cannot be built fails loudly, never a fallback
     odd = npde.Chain(npde.Dense(2, 200, "relu"), npde.Dense(200, 200, "relu"), npde.Dense(200, 1))
     with pytest.raises(npde.EngineError, match="unsupported activation"):
-        npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(odd, npde.GridTraining(0.5)))
+        npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(odd, npde.GridTraining(0.5), precision="f32"))
     with pytest.raises(npde.EngineError):
         npde.Engine("pinnir 2\n")
 
@@ -174,7 +174,7 @@ def test_strategy_plugin_contract(npde, use_emu):
     chain = npde.Chain(npde.Dense(2, 16, "tanh"), npde.Dense(16, 16, "tanh"), npde.Dense(16, 1))
     th = npde.initialparameters(np.random.default_rng(5), chain)
     strat = TwoRowsOfPoints()
-    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th))
+    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th, precision="f32"))
     rep = prob.pinnrep
     assert rep.pde_train_sets[0].shape == (2, 18)
     lf = rep.loss_functions
@@ -199,7 +199,7 @@ def test_dropped_call_arguments_quirk(npde, use_emu):
     sysm = npde.PDESystem([eq], bcs, dom, [t, x], [u(t, x)])
     chain = npde.Chain(npde.Dense(2, 16, "sigmoid"), npde.Dense(16, 16, "sigmoid"), npde.Dense(16, 1))
     th = npde.initialparameters(np.random.default_rng(2), chain)
-    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=th))
+    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=th, precision="f32"))
     assert np.all(rep.bcs_train_sets[3][1] == -1.0)                      # the first call's arguments define the set
     assert rep.loss_functions.bc_loss_functions[3](th) == 0.0
     assert rep.loss_functions.bc_loss_functions[1](th) > 0.0

@@ -57,7 +57,7 @@ def test_jit_failures_are_loud(npde, use_emu):
     sysm, _ = helpers.shape_problem(npde, 64, 4, 2)
     big = npde.Chain(npde.Dense(2, 64, "tanh"), npde.Dense(64, 64, "sigmoid"), npde.Dense(64, 64, "tanh"), npde.Dense(64, 64, "tanh"), npde.Dense(64, 1))
     with pytest.raises(Exception, match="per-layer tanh/sigmoid"):
-        npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(big, npde.GridTraining(0.25), init_params=tp.theta_for(big, 75)))
+        npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(big, npde.GridTraining(0.25), init_params=tp.theta_for(big, 75), precision="f32"))
     # PINN_NO_JIT: the old behaviour — fail at create time with the line to add to the table
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
@@ -65,7 +65,7 @@ def test_jit_failures_are_loud(npde, use_emu):
             "import test_emu_parity as tp\n"
             "sysm, _ = tp.poisson2d(m)\n"
             "odd = m.Chain(m.Dense(2, 200, 'tanh'), m.Dense(200, 200, 'tanh'), m.Dense(200, 1))\n"
-            "try:\n    m.symbolic_discretize(sysm, m.PhysicsInformedNN(odd, m.GridTraining(0.5)))\nexcept m.EngineError as e:\n    print('ENGINEERROR', e)\n"
+            "try:\n    m.symbolic_discretize(sysm, m.PhysicsInformedNN(odd, m.GridTraining(0.5), precision='f32'))\nexcept m.EngineError as e:\n    print('ENGINEERROR', e)\n"
             % (root, os.path.join(root, "tests"), os.path.join(root, "oracle"), npde._lib.default_library().path))     # the library UNDER TEST
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PINN_NO_JIT="1"), capture_output=True, text=True, timeout=300)
     assert "ENGINEERROR" in r.stdout and "no compiled kernel" in r.stdout, r.stdout + r.stderr
@@ -84,7 +84,7 @@ def test_jit_needs_no_source_tree(npde, use_emu, tmp_path):
             "sysm = m.PDESystem([eq], [m.Eq(u(0.0), 0.0)], [m.In(x, m.Interval(0.0, 1.0))], [x], [u(x)])\n"
             "ch = m.Chain(m.Dense(1, 24, 'tanh'), m.Dense(24, 24, 'tanh'), m.Dense(24, 24, 'tanh'), m.Dense(24, 24, 'tanh'), m.Dense(24, 1))\n"
             "th0 = np.sin(np.arange(ch.nparams) * 0.37) * 0.3\n"
-            "t0 = time.time(); rep = m.symbolic_discretize(sysm, m.PhysicsInformedNN(ch, m.GridTraining(0.1), init_params=th0)); dt = time.time() - t0\n"
+            "t0 = time.time(); rep = m.symbolic_discretize(sysm, m.PhysicsInformedNN(ch, m.GridTraining(0.1), init_params=th0, precision='f32')); dt = time.time() - t0\n"
             "l, g = rep.engine.loss_grad(rep.flat_init_params)\n"
             "print('JITOK', float(l[0]), float(np.abs(g).max()), 'create_s', round(dt, 2))\n"
             % (root, os.path.join(root, "tests"), os.path.join(root, "oracle"), npde._lib.default_library().path))

@@ -168,7 +168,7 @@ def test_system_tutorial_idioms(npde, use_emu):
     dom = [npde.In(t, npde.Interval(0.0, 1.0)), npde.In(x, npde.Interval(0.0, 1.0))]
     sysm = npde.PDESystem(eqs, bcs, dom, [t, x], [u1(t, x), u2(t, x)])
     chains = chains_for(npde, [2, 2], 15, "sigmoid")
-    disc = npde.PhysicsInformedNN(chains, npde.GridTraining(0.25), init_params=thetas(chains, 160))
+    disc = npde.PhysicsInformedNN(chains, npde.GridTraining(0.25), init_params=thetas(chains, 160), precision="f32")
     sym_prob = npde.symbolic_discretize(sysm, disc)
     prob = npde.discretize(sysm, disc)
     pde_inner, bcs_inner = sym_prob.loss_functions.pde_loss_functions, sym_prob.loss_functions.bc_loss_functions
@@ -213,7 +213,7 @@ def test_data_misfit_terms_on_device(npde, use_emu):
     sysm = npde.PDESystem([eq], bcs, dom, [t, x], [u(t, x)], ps=[k], defaults={k: 0.7})
     disc = npde.PhysicsInformedNN(chain, strat, init_params=th, param_estim=True,
                                   data_loss=[npde.DataLoss(u(t, x), pts, vals, weight=3.0)],
-                                  adaptive_loss=npde.NonAdaptiveLoss(pde_loss_weights=1.0, bc_loss_weights=2.0, additional_loss_weights=0.5))
+                                  adaptive_loss=npde.NonAdaptiveLoss(pde_loss_weights=1.0, bc_loss_weights=2.0, additional_loss_weights=0.5), precision="f32")
     prob = npde.discretize(sysm, disc)
     rep = prob.pinnrep
     theta = rep.flat_init_params
@@ -233,7 +233,7 @@ def test_data_misfit_terms_on_device(npde, use_emu):
         (gr,) = torch.autograd.grad(val, tt)
         return float(val.detach()), np.concatenate([gr.numpy(), np.zeros(1)])
     disc_h = npde.PhysicsInformedNN(chain, mk(), init_params=th, param_estim=True, additional_loss=additional,          # (a sampler object continues its sequence)
-                                    adaptive_loss=npde.NonAdaptiveLoss(pde_loss_weights=1.0, bc_loss_weights=2.0, additional_loss_weights=0.5))
+                                    adaptive_loss=npde.NonAdaptiveLoss(pde_loss_weights=1.0, bc_loss_weights=2.0, additional_loss_weights=0.5), precision="f32")
     prob_h = npde.discretize(sysm, disc_h)
     v_d, g_d = prob.f.value_and_grad(theta)
     v_h, g_h = prob_h.f.value_and_grad(theta)
@@ -251,16 +251,16 @@ def test_data_misfit_terms_on_device(npde, use_emu):
     # pre-generated designs picked at random per call (resampling = false, minibatch > 1, src/training_strategies.jl:383-387)
     strat_mb = npde.QuasiRandomTraining(40, bcs_points=16, sampling_alg=npde.SobolSample(seed=8), resampling=False, minibatch=3,
                                         rng=np.random.default_rng(1))
-    prob_mb = npde.discretize(sysm, npde.PhysicsInformedNN(chain, strat_mb, init_params=th, param_estim=True))
+    prob_mb = npde.discretize(sysm, npde.PhysicsInformedNN(chain, strat_mb, init_params=th, param_estim=True, precision="f32"))
     res_mb = npde.solve(prob_mb, npde.Adam(0.01), maxiters=12)
     assert len(res_mb.losses) == 12 and np.all(np.isfinite(res_mb.losses)) and len(set(np.round(res_mb.losses, 10))) == 12
     with pytest.raises(TypeError, match="must return"):          # a bare value cannot be differentiated by this host
         npde.solve(npde.discretize(sysm, npde.PhysicsInformedNN(chain, mk(), init_params=th, param_estim=True,
-                                                               additional_loss=lambda phi, t_, p_: 1.0)), npde.Adam(0.01), maxiters=2)
+                                                               additional_loss=lambda phi, t_, p_: 1.0, precision="f32")), npde.Adam(0.01), maxiters=2)
     # misuse
     with pytest.raises(ValueError):
         npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, mk(), init_params=th, param_estim=True,
-                                                             data_loss=[npde.DataLoss(u(t, x), pts[:1], vals)]))
+                                                             data_loss=[npde.DataLoss(u(t, x), pts[:1], vals)], precision="f32"))
 
 
 def test_quadrature_training_stand_in(npde, use_emu):
@@ -272,7 +272,7 @@ def test_quadrature_training_stand_in(npde, use_emu):
     sysm, chain = poisson2d(npde, "tanh")
     th = theta_for(chain, 181)
     strat = npde.QuadratureTraining(nodes=6)
-    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th))
+    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th, precision="f32"))
     sets = rep.pde_train_sets + rep.bcs_train_sets
     ws = strat.point_weights()
     assert sets[0].shape == (2, 36) and sets[1].shape == (2, 6) and abs(ws[0].sum() - 1) < 1e-12 and np.all(sets[1][0] == 0.0)
@@ -296,6 +296,6 @@ def test_quadrature_training_stand_in(npde, use_emu):
     l2, _ = rep.engine.loss_grad(th, wterm)
     np.testing.assert_allclose(l2, losses, rtol=1e-12)
     # more nodes -> the integral converges (the rule is exact for polynomials of degree 2n - 1)
-    fine = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, npde.QuadratureTraining(nodes=14), init_params=th))
+    fine = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, npde.QuadratureTraining(nodes=14), init_params=th, precision="f32"))
     lf, _ = fine.engine.loss_grad(th)
     assert abs(lf[0] - losses[0]) < 2e-3 * abs(lf[0])

@@ -40,7 +40,7 @@ def test_persistent_training_kernel_equals_the_loop_bit_for_bit(npde, use_emu, m
     # form — maps and optimiser state re-read from memory every step — be checked as well, on the emulation's two "CUs" in particular)
     monkeypatch.setenv("PINN_TRAIN_GENERAL", "1")
     for name, sysm, chain, strat, th0, w in _cases(npde):
-        disc = npde.PhysicsInformedNN(chain, strat, init_params=th0)
+        disc = npde.PhysicsInformedNN(chain, strat, init_params=th0, precision="f32")
         rep = npde.symbolic_discretize(sysm, disc)
         eng = rep.engine
         wts = None if w is None else np.asarray(w, dtype=np.float32)
@@ -77,7 +77,7 @@ def test_persistent_training_kernel_redraws_the_point_sets_like_the_loop(npde, u
             else:
                 monkeypatch.delenv("PINN_NO_FUSED_RESAMPLE", raising=False)
             mode = mode[0]
-            prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, make(), init_params=th0))
+            prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, make(), init_params=th0, precision="f32"))
             rep = prob.pinnrep                               # the same device-sampler seeds in both runs (an unseeded strategy draws fresh ones)
             rep._device_samplers = {k: (lb, ub, n, 4321 + 17 * k, kind) for k, (lb, ub, n, _, kind) in rep._device_samplers.items()}
             r1 = npde.solve(prob, npde.Adam(0.01), maxiters=7)
@@ -89,7 +89,7 @@ def test_persistent_training_kernel_redraws_the_point_sets_like_the_loop(npde, u
         # the same call split over several launches of the kernel (the engine does that every 4,096 steps): the host redraws the first
         # set of every launch, the barrier counter restarts, the history continues
         monkeypatch.setenv("PINN_TRAIN_CHUNK", "3")
-        prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, make(), init_params=th0))
+        prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, make(), init_params=th0, precision="f32"))
         rep = prob.pinnrep
         rep._device_samplers = {k: (lb, ub, n, 4321 + 17 * k, kind) for k, (lb, ub, n, _, kind) in rep._device_samplers.items()}
         r1 = npde.solve(prob, npde.Adam(0.01), maxiters=7)
@@ -111,17 +111,17 @@ def test_persistent_training_kernel_is_refused_where_it_does_not_apply(npde, use
     th0 = theta_for(chain, 3)
     # the graph-replay experiment of the loop keeps the loop
     monkeypatch.setenv("PINN_GRAPH", "1")
-    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=th0))
+    prob = npde.discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=th0, precision="f32"))
     npde.solve(prob, npde.Adam(0.01), maxiters=9)
     assert prob.pinnrep.engine.get_option("adam_path") == "loop"
     monkeypatch.delenv("PINN_GRAPH")
     # fixed sets: the kernel; the environment switch: the loop again
-    disc = npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=th0)
+    disc = npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=th0, precision="f32")
     prob = npde.discretize(sysm, disc)
     r1 = npde.solve(prob, npde.Adam(0.01), maxiters=6)
     assert prob.pinnrep.engine.get_option("adam_path") == "persistent"
     monkeypatch.setenv("PINN_PERSISTENT", "0")
-    prob2 = npde.discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=th0))
+    prob2 = npde.discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=th0, precision="f32"))
     r2 = npde.solve(prob2, npde.Adam(0.01), maxiters=6)
     assert prob2.pinnrep.engine.get_option("adam_path") == "loop"
     assert np.array_equal(r1.u, r2.u) and np.array_equal(np.asarray(r1.losses), np.asarray(r2.losses))
@@ -131,7 +131,7 @@ def test_persistent_training_kernel_is_refused_where_it_does_not_apply(npde, use
     # and the draw counters, runs the same steps in the loop and keeps the loop for the handle: same numbers, no error
     monkeypatch.delenv("PINN_PERSISTENT")
     monkeypatch.setenv("PINN_TRAIN_FORCE_TIMEOUT", "1")
-    prob3 = npde.discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=th0))
+    prob3 = npde.discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.25), init_params=th0, precision="f32"))
     r3 = npde.solve(prob3, npde.Adam(0.01), maxiters=6)
     eng3 = prob3.pinnrep.engine
     assert eng3.get_option("adam_path") == "loop" and eng3.get_option("persistent") == "off"
@@ -163,7 +163,7 @@ def test_persistent_training_kernel_over_kernel_shapes(npde, use_emu, monkeypatc
     ran = []
     for name, sysm, chain, strat, w in _shape_cases(npde):
         th0 = theta_for(chain, 77)
-        rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th0))
+        rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th0, precision="f32"))
         eng = rep.engine
         wts = None if w is None else np.asarray(w, dtype=np.float32)
         a = _run(npde, eng, th0, wts, False, steps=(5, 3))
@@ -188,7 +188,7 @@ def test_single_evaluation_in_one_launch_equals_the_stand_alone_kernels(npde, us
     cases.append(("poisson2d", sysm, chain, npde.GridTraining(0.1), theta_for(chain, 9), [1.0, 2.0, 1.0, 3.0, 1.0]))
     taken = []
     for name, sysm, chain, strat, th0, w in cases:
-        rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th0))
+        rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=th0, precision="f32"))
         eng = rep.engine
         wts = None if w is None else np.asarray(w, dtype=np.float32)
         monkeypatch.setenv("PINN_NO_FUSED_EVAL", "1")
@@ -218,7 +218,7 @@ def test_hip_events_are_opt_in(npde, use_emu):
     kernels those events bracket."""
     sysm, chain = poisson2d(npde, "tanh", width=16, hidden=2)
     th0 = theta_for(chain, 4)
-    eng = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.2), init_params=th0)).engine
+    eng = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.2), init_params=th0, precision="f32")).engine
     eng.loss_grad(th0)
     with pytest.raises(Exception, match="pinn_set_timing"):
         eng.last_timing()
@@ -237,7 +237,7 @@ def test_one_launch_evaluation_checks_points_and_data(npde, use_emu):
     import os
     sysm, chain = poisson2d(npde, "tanh", width=16, hidden=2)
     th0 = theta_for(chain, 4)
-    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.2), init_params=th0))
+    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.2), init_params=th0, precision="f32"))
     rep.engine.loss_grad(th0)
     assert rep.engine.get_option("eval_path") == "one launch"             # (the shape IS eligible for the one-launch evaluation)
     desc = rep.ir.to_descriptor()

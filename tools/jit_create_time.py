@@ -41,7 +41,7 @@ for name, mk, net in cases:
     out = []
     for rnd in ("cold", "warm"):
         t0 = time.perf_counter()
-        rep = npde.symbolic_discretize(mk(), npde.PhysicsInformedNN(net(), strat()))
+        rep = npde.symbolic_discretize(mk(), npde.PhysicsInformedNN(net(), strat(), precision="f32"))
         out.append(time.perf_counter() - t0)
         njit = rep.engine.describe().count("kernel=")
         del rep

@@ -26,24 +26,24 @@ if "--only" in sys.argv:
 def small2d():
     import test_emu_parity as tp
     sysm, chain = tp.poisson2d(npde, "tanh", width=16, hidden=2)
-    return sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.1), init_params=tp.theta_for(chain, 5))
+    return sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.1), init_params=tp.theta_for(chain, 5), precision="f32")
 
 
 def small2d_stochastic():
     import test_emu_parity as tp
     sysm, chain = tp.poisson2d(npde, "tanh", width=16, hidden=2)
-    return sysm, npde.PhysicsInformedNN(chain, npde.StochasticTraining(128, bcs_points=32, rng=np.random.default_rng(3)), init_params=tp.theta_for(chain, 5))
+    return sysm, npde.PhysicsInformedNN(chain, npde.StochasticTraining(128, bcs_points=32, rng=np.random.default_rng(3)), init_params=tp.theta_for(chain, 5), precision="f32")
 
 
 def small2d_lhs():
     import test_emu_parity as tp
     sysm, chain = tp.poisson2d(npde, "tanh", width=32, hidden=3)
-    return sysm, npde.PhysicsInformedNN(chain, npde.QuasiRandomTraining(1000, bcs_points=100, sampling_alg=npde.LatinHypercubeSample(seed=5)), init_params=tp.theta_for(chain, 5))
+    return sysm, npde.PhysicsInformedNN(chain, npde.QuasiRandomTraining(1000, bcs_points=100, sampling_alg=npde.LatinHypercubeSample(seed=5)), init_params=tp.theta_for(chain, 5), precision="f32")
 
 
 def mid2d_stochastic():
     wl = workloads.cfg2_poisson2d(points=4096, bcs_points=1024)
-    disc = npde.PhysicsInformedNN(wl.chains[0], npde.StochasticTraining(4096, bcs_points=1024, rng=np.random.default_rng(3)), init_params=wl.theta)
+    disc = npde.PhysicsInformedNN(wl.chains[0], npde.StochasticTraining(4096, bcs_points=1024, rng=np.random.default_rng(3)), init_params=wl.theta, precision="f32")
     return wl.pde_system, disc
 
 

@@ -19,9 +19,9 @@ def problems():
     wl = workloads.cfg1_poisson1d()
     yield "cfg1 3x32 1,026 pts", wl.pde_system, wl.discretization()
     sysm, chain = tp.poisson2d(npde, "tanh", width=16, hidden=2)
-    yield "poisson2d 2x16 165 pts", sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.1), init_params=tp.theta_for(chain, 5))
+    yield "poisson2d 2x16 165 pts", sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.1), init_params=tp.theta_for(chain, 5), precision="f32")
     sysm, chain = tp.poisson2d(npde, "tanh", width=32, hidden=3)
-    yield "poisson2d 3x32 1,400 pts", sysm, npde.PhysicsInformedNN(chain, npde.QuasiRandomTraining(1000, bcs_points=100, sampling_alg=npde.SobolSample(seed=3), resampling=False, minibatch=1), init_params=tp.theta_for(chain, 5))
+    yield "poisson2d 3x32 1,400 pts", sysm, npde.PhysicsInformedNN(chain, npde.QuasiRandomTraining(1000, bcs_points=100, sampling_alg=npde.SobolSample(seed=3), resampling=False, minibatch=1), init_params=tp.theta_for(chain, 5), precision="f32")
 
 
 for name, sysm, disc in problems():
