@@ -8,6 +8,7 @@ oracle's behaviour and give the GPU tests fixtures that do not need torch autogr
     python oracle/make_golden.py full [names]    # the full-size cases (inputs pinned by SHA-256, minutes of CPU time each)
     python oracle/make_golden.py variants [names]  # the same problems at SCALED and TRAINED parameters, both oracle modes (r04: the regime
                                                  # where the split-operand bf16 GEMMs of the 64- / 128-wide kernels have the least margin)
+    python oracle/make_golden.py variants-trained [names]  # appends the trained variants an existing variants fixture lacks (r06: cfg4 / cfg5)
     python oracle/make_golden.py variants-theta32 [names]  # adds the exact oracle at the float32-rounded trained parameters (r05)
     python oracle/make_golden.py variants-f32 [names]  # adds the float32 evaluation of the same program to the variants fixtures
 """
@@ -114,8 +115,10 @@ VARIANT_CASES = {
     # name: (full-size maker, maker of the reduced problem the training runs on, scale factors, Adam iteration counts)
     "cfg2_variants": (lambda: workloads.cfg2_poisson2d(points=65536), lambda: workloads.cfg2_poisson2d(points=2048, bcs_points=512), (2.0, 4.0), (2000, 6000)),
     "cfg3_variants": (lambda: workloads.cfg3_burgers(points=262144), lambda: workloads.cfg3_burgers(points=2048, bcs_points=512), (2.0,), (2000,)),
-    "cfg4_variants": (lambda: workloads.cfg4_cavity(points=16384, bcs_points=4096), None, (2.0,), ()),       # (P = 199,683: one variant keeps the fixture at 4.5 MB)
-    "cfg5_variants": (lambda: workloads.cfg5_heat_inverse(points=32768, bcs_points=8192), None, (2.0, 4.0), ()),
+    # r06: trained parameters for the 128-wide configurations too (the two-pass split GEMM of H = 128 where its bias matters); the training runs
+    # on a small design (`variants-trained` appends the tags to an existing fixture without recomputing the scaled ones)
+    "cfg4_variants": (lambda: workloads.cfg4_cavity(points=16384, bcs_points=4096), lambda: workloads.cfg4_cavity(points=1024, bcs_points=256), (2.0,), (400,)),
+    "cfg5_variants": (lambda: workloads.cfg5_heat_inverse(points=32768, bcs_points=8192), lambda: workloads.cfg5_heat_inverse(points=2048, bcs_points=512), (2.0, 4.0), (600,)),
 }
 
 
@@ -191,6 +194,43 @@ def make_variants(out, only=None):
         np.savez_compressed(os.path.join(out, name + ".npz"), **d)
 
 
+def add_trained(out, only=None):
+    """appends the TRAINED variants of VARIANT_CASES that an existing fixture lacks (both oracle modes); run `variants-f32` and
+    `variants-theta32` afterwards for the float32 evaluation / the oracle at float32(theta) of the new tags"""
+    import time
+    for name, (make, make_small, scales, adam_iters) in VARIANT_CASES.items():
+        path = os.path.join(out, name + ".npz")
+        if (only and name not in only) or not os.path.exists(path) or not adam_iters:
+            continue
+        d = dict(np.load(path))
+        have = [str(t) for t in d["tags"]]
+        todo = [it for it in adam_iters if f"adam{it}" not in have]
+        if not todo:
+            continue
+        t0 = time.time()
+        wl = make()
+        sets = point_sets(wl)
+        assert [set_digest(s) for s in sets] == list(d["set_sha256"])
+        prob = helpers.oracle_problem(m, wl.pde_system, wl.chains, param_estim=wl.param_estim)
+        K = len(sets)
+        w = d["weights"]
+        wls = make_small()
+        probs = helpers.oracle_problem(m, wls.pde_system, wls.chains, param_estim=wls.param_estim)
+        trained = adam_train(probs, full_theta(wls), point_sets(wls), fixture_weights(wls, K), set(todo), report=100)
+        for it in todo:
+            tag, th = f"adam{it}", trained[it]
+            d["theta_" + tag] = th
+            for mode in ("stencil", "exact"):
+                losses, grad = chunked_loss_and_grad(prob, th, sets, w, mode=mode)
+                d[f"losses_{mode}_{tag}"], d[f"grad_{mode}_{tag}"] = losses, grad.astype(np.float64)
+            gs, ge = d[f"grad_stencil_{tag}"], d[f"grad_exact_{tag}"]
+            print(name, tag, "losses", d[f"losses_stencil_{tag}"], "|grad|", np.linalg.norm(gs), "stencil-vs-exact grad rel L2",
+                  np.linalg.norm(gs - ge) / np.linalg.norm(ge), f"({time.time() - t0:.0f} s)", flush=True)
+            have.append(tag)
+        d["tags"] = np.array(have)
+        np.savez_compressed(path, **d)
+
+
 def add_f32(out, only=None):
     """adds to every variants fixture the SAME program evaluated in float32 (torch CPU, exact-derivative mode: `losses_f32_<tag>`,
     `grad_f32_<tag>`): what a plain fp32 implementation of the reference's mathematics returns.  At trained parameters the residual is a
@@ -209,6 +249,8 @@ def add_f32(out, only=None):
         po.DT = torch.float32
         try:
             for tag in d["tags"]:
+                if f"grad_f32_{tag}" in d:
+                    continue                                 # (already there: `variants-trained` appends tags)
                 losses, grad = chunked_loss_and_grad(prob, d["theta_" + str(tag)], sets, d["weights"], mode="exact")
                 d[f"losses_f32_{tag}"], d[f"grad_f32_{tag}"] = losses, grad.astype(np.float64)
                 ge = d[f"grad_exact_{tag}"]
@@ -229,7 +271,7 @@ def add_theta32(out, only=None):
         if (only and name not in only) or not os.path.exists(path):
             continue
         d = dict(np.load(path))
-        tags = [str(t) for t in d["tags"] if str(t).startswith("adam")]
+        tags = [str(t) for t in d["tags"] if str(t).startswith("adam") and f"grad_exact32_{t}" not in d]
         if not tags:
             continue
         wl = make()
@@ -257,6 +299,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "full":
         make_full(out, sys.argv[2:])
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "variants-trained":
+        add_trained(out, sys.argv[2:])
         return
     if len(sys.argv) > 1 and sys.argv[1] == "variants":
         make_variants(out, sys.argv[2:])

@@ -53,7 +53,9 @@ def _errors(losses, grad, lref, gref):
 
 
 CASES = [("cfg2_variants", t) for t in ("x2", "x4", "adam2000", "adam6000")] + [("cfg3_variants", t) for t in ("x2", "adam2000")] + \
-        [("cfg4_variants", t) for t in ("x2",)] + [("cfg5_variants", t) for t in ("x2", "x4")]
+        [("cfg4_variants", t) for t in ("x2", "adam400")] + [("cfg5_variants", t) for t in ("x2", "x4", "adam600")]
+# (r06: trained parameters for the 128-wide configurations too — 400 / 600 float64 Adam steps of the oracle on a reduced design,
+# `python oracle/make_golden.py variants-trained`: the two-pass split GEMM of H = 128 where the bias it removes matters)
 
 
 @pytest.mark.parametrize("name,tag", CASES)
@@ -138,5 +140,5 @@ def test_theta_variant(npde, hip_lib, name, tag):
         e64 = _errors(l64, g64, g[f"losses_exact_{tag}"], g[f"grad_exact_{tag}"])
         print(f"  float64 mode ({eng.get_option('f64_path')}) vs exact oracle: loss rel {e64[0]:.2e}, grad rel L2 {e64[1]:.2e}, Linf {e64[2]:.2e}   margin to 1e-5: x{TOL / max(e64):.1e}")
         assert max(e64) < TOL, (name, tag, "f64", e64)
-        assert eng.get_option("f64_path") == "mfma"
+        assert "mfma" in eng.get_option("f64_path"), eng.get_option("f64_path")      # (r06: 128-wide and 4-D sets on the sliced matrix-pipe kernels as well)
         eng.set_option("precision", "f32")
