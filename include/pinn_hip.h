@@ -285,6 +285,16 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
  *   PRECISION POLICY of the glue (Julia: HIPStrategy / hip_discretize `precision = :auto`; Python mirror: PhysicsInformedNN(precision = "auto")):
  *   the reference's contract compute dtype = eltype(theta) (src/eltype_matching.jl:8-10) — Float64 parameters select "f64", Float32
  *   parameters "f32"; "f32" on Float64 parameters is the explicit fast opt-in.
+ * "derivative" = "exact" (default) | "stencil" (r06; float64 mode only): a VALIDATION mode, not a performance path.  "stencil" evaluates every
+ *   derivative slot as the reference's central differences — numeric_derivative (src/pinn_types.jl:445-482: the order-1..4 formulas, the
+ *   recursion for mixed derivatives and orders > 4) with the steps of get_eps (src/symbolic_utilities.jl:98-103: eps(Float64)^(1/(2+order)),
+ *   the TOTAL order's step on every axis, :185), in the reference's order of operations — as value-only forward passes at shifted copies of the
+ *   point set, the difference formulas as tape ops, and a reverse sweep through the same combination (one seeded launch per shifted set;
+ *   csrc/f64.cpp: f64_stencil_term).  pinn_loss_grad*, pinn_term_grads*, pinn_loglik_grad*, pinn_residual* then return the reference's
+ *   finite-difference numbers instead of exact derivatives: for digit-by-digit comparisons with the reference's generated loss functions
+ *   (julia: NeuralPDEHIP.selftest) and with the stencil oracle.  How close two correct implementations of these formulas can be is bounded by the
+ *   formulas themselves: u(x +- eps) carries ~1e-16 relative rounding and 1 / eps^2 ~ 7e7 multiplies it — 1e-8 at initialisation, 1e-5 ... 1e-4
+ *   of the gradient at trained parameters (tests/test_f64_mode.py measures it as the stencil oracle against itself with permuted neurons).
  * "persistent" = "on" (default) | "off": pinn_adam_steps runs a SMALL problem — one network of the one-wave-per-tile kernel family, at most
  *   32 workgroups (~2,000 points of a 3 x 32 net), fixed or device-redrawn point sets (pinn_set_sampler), no estimated PDE parameters, no communicator — as ONE persistent launch
  *   per call (csrc/pinn_train.hpp: evaluation, fixed-order reduction, Adam and the weight-image update of every iteration inside the kernel,

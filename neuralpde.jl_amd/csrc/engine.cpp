@@ -1197,7 +1197,12 @@ int pinn_set_option(pinn_handle h, const char* name, const char* value) {
         if (v == "off" || v == "0") { E.persistent = false; return 0; }
         return fail("pinn_set_option: persistent must be \"on\" or \"off\"");
     }
-    return fail("pinn_set_option: unknown option \"" + k + "\" (known: gemm, precision, persistent)");
+    if (k == "derivative") {
+        if (v == "stencil") return f64_stencil_enable(E, true);
+        if (v == "exact") return E.f64 ? f64_stencil_enable(E, false) : 0;
+        return fail("pinn_set_option: derivative must be \"exact\" or \"stencil\"");
+    }
+    return fail("pinn_set_option: unknown option \"" + k + "\" (known: gemm, precision, persistent, derivative)");
 }
 
 int pinn_get_option(pinn_handle h, const char* name, char* buf, int64_t buflen) {
@@ -1206,10 +1211,11 @@ int pinn_get_option(pinn_handle h, const char* name, char* buf, int64_t buflen) 
     if (k == "gemm") { std::snprintf(buf, (size_t)buflen, "%s", h->gemm == pk::GEMM_FP32 ? "fp32" : "split"); return 0; }
     if (k == "precision") { std::snprintf(buf, (size_t)buflen, "%s", h->f64 ? "f64" : "f32"); return 0; }
     if (k == "persistent") { std::snprintf(buf, (size_t)buflen, "%s", h->persistent ? "on" : "off"); return 0; }
+    if (k == "derivative") { std::snprintf(buf, (size_t)buflen, "%s", pe::f64_stencil_on(*h) ? "stencil" : "exact"); return 0; }
     if (k == "eval_path") { std::snprintf(buf, (size_t)buflen, "%s", h->eval_path == 2 ? "one launch" : (h->eval_path == 1 ? "stand-alone kernels" : "none")); return 0; }
     if (k == "f64_path") { std::snprintf(buf, (size_t)buflen, "%s", pe::f64_path(*h)); return 0; }
     if (k == "adam_path") { std::snprintf(buf, (size_t)buflen, "%s", h->adam_path == 2 ? "persistent" : (h->adam_path == 1 ? "loop" : "none")); return 0; }
-    return fail("pinn_get_option: unknown option \"" + k + "\" (known: gemm, precision, persistent, adam_path, eval_path, f64_path)");
+    return fail("pinn_get_option: unknown option \"" + k + "\" (known: gemm, precision, persistent, derivative, adam_path, eval_path, f64_path)");
 }
 
 int pinn_adam_init(pinn_handle h, const float* theta, int64_t p) {

@@ -315,6 +315,8 @@ int f64_eval(pinn_engine& E, const double* theta, const double* term_w, double* 
 int f64_residual(pinn_engine& E, int term, const double* theta, double* r);      // host theta, host r[n_term]
 int f64_net_eval(pinn_engine& E, int net, const double* theta, const double* pts, int64_t n, int order, const int* axes, double* out);      // d^order phi_net / dx_axes at host points
 int f64_adam_apply(pinn_engine& E, const double* grad_and_sums, double lr, double beta1, double beta2, double eps, const float* term_w, double* loss);
+int f64_stencil_enable(pinn_engine& E, bool on);      // pinn_set_option "derivative" = "stencil" | "exact"
+bool f64_stencil_on(const pinn_engine& E);
 int f64_adam_init(pinn_engine& E, const double* theta);
 int f64_adam_get(pinn_engine& E, double* theta);
 int f64_adam_steps(pinn_engine& E, int nsteps, double lr, double beta1, double beta2, double eps, const float* term_w, double* loss_history,

@@ -38,8 +38,24 @@ struct F64Term {
     double* d_data = nullptr;            // [ndata][n]; converted from the float rows unless pinn_set_point_data_f64 installed them
     int64_t data_cap = 0, data_n = 0;
 };
+// one (network, shift sequence) of a term's finite-difference stencils: the trial function of `net` at the term's points moved by the shifts in order
+struct F64VNet { int net; std::vector<std::pair<int, double>> shifts; };
+// the reference-semantics evaluation of one term (pinn_set_option(h, "derivative", "stencil"); pinn_kernels4.hpp: k_f64_stape)
+struct F64Stencil {
+    bool active = false;                 // the term has derivative slots (value-only terms evaluate as always: nothing to difference)
+    std::vector<F64VNet> vnets;
+    rp::Instr* d_prog = nullptr;         // stencil tape: the difference formulas, then the term's ops; rows [coordinates | params | vnets | ops]
+    double* d_imm = nullptr;
+    int nops = 0, out_row = 0;
+};
 struct F64State {
     std::vector<F64Term> terms;
+    bool stencil = false;                // derivative slots by the reference's central differences instead of exact jets
+    std::vector<F64Stencil> sten;
+    double* d_uv = nullptr;              // [nv][n] values of the virtual networks
+    double* d_seeds = nullptr;           // [nv][n][2 + ne]
+    double* d_spts = nullptr;            // [nv][n][d] their shifted point sets
+    size_t uv_cap = 0, seeds_cap = 0, spts_cap = 0;
     double* d_theta = nullptr;           // [P] parameters of the running EVALUATION (host-entry evaluations upload here; never the optimiser's iterate)
     double* d_opt_theta = nullptr;       // [P] the Adam loop's iterate (f64_adam_*): evaluations in between — adaptive reweighting, callbacks — leave it alone
     double* d_grad = nullptr;            // [P]
@@ -66,6 +82,8 @@ struct F64State {
 static void f64_free(F64State* S) {
     if (!S) return;
     for (auto& T : S->terms) { plat_free(T.d_prog); plat_free(T.d_imm); plat_free(T.d_pts); plat_free(T.d_data); }
+    for (auto& X : S->sten) { plat_free(X.d_prog); plat_free(X.d_imm); }
+    plat_free(S->d_uv); plat_free(S->d_seeds); plat_free(S->d_spts);
     plat_free(S->d_theta); plat_free(S->d_opt_theta); plat_free(S->d_aux_pts); plat_free(S->d_aux_out); plat_free(S->d_grad); plat_free(S->d_sumsq); plat_free(S->d_scratch); plat_free(S->d_slab); plat_free(S->d_tpart);
     plat_free(S->d_m); plat_free(S->d_v); plat_free(S->d_w_over_n); plat_free(S->d_hist);
     delete S;
@@ -356,6 +374,226 @@ static int f64_buffers(pinn_engine& E, F64State& S, F64Launch& L, int64_t n, boo
     }
 }
 
+// ---- the reference-semantics ("stencil") validation mode ----
+// get_eps (src/symbolic_utilities.jl:98-103): eps(Float64)^(1 / (2 + order)), the TOTAL order of the derivative on every axis (:185)
+static double stencil_eps(int order) { return std::pow(2.220446049250313e-16, 1.0 / (2.0 + (double)order)); }
+namespace {
+struct StOperand { int kind, idx; };     // 0: virtual network idx, 1: stencil op idx, 2: an original row below the slots (coordinate / parameter)
+struct StBuilder {
+    std::vector<F64VNet> vnets;
+    struct Op { int code; StOperand a, b; double imm; };
+    std::vector<Op> ops;
+    int vnet(int net, const std::vector<std::pair<int, double>>& sh) {
+        for (size_t i = 0; i < vnets.size(); ++i) if (vnets[i].net == net && vnets[i].shifts == sh) return (int)i;
+        vnets.push_back({net, sh});
+        return (int)vnets.size() - 1;
+    }
+    StOperand op(int code, StOperand a, StOperand b, double imm) { ops.push_back({code, a, b, imm}); return {1, (int)ops.size() - 1}; }
+    StOperand mulc(StOperand a, double c) { return op(rp::OP_MULC, a, {2, 0}, c); }
+    StOperand u(int net, std::vector<std::pair<int, double>> sh, int axis, double delta) {
+        sh.push_back({axis, delta});
+        return {0, vnet(net, sh)};
+    }
+    // numeric_derivative(phi, u, x, eps_s, order, theta) (src/pinn_types.jl:445-482) at the points shifted by `sh`: axes[0 .. k) = the derivative
+    // variables, eps = the step (one magnitude for all axes: the total order's); the formulas in the reference's own order of operations
+    StOperand deriv(int net, const int* axes, int k, double eps, const std::vector<std::pair<int, double>>& sh) {
+        if (k == 0) return {0, vnet(net, sh)};
+        const double inv = 1.0 / eps;                    // _epsilon = inv(first(eps[eps .!= 0]))
+        const int ax = axes[k - 1];                      // eps = eps_s[order]
+        bool same = true;
+        for (int i = 1; i < k; ++i) same = same && axes[i] == axes[0];
+        if (k > 4 || !same) {                            // :454-460
+            auto up = sh, dn = sh;
+            up.push_back({ax, eps}); dn.push_back({ax, -eps});
+            const StOperand a = deriv(net, axes, k - 1, eps, up), b = deriv(net, axes, k - 1, eps, dn);
+            return mulc(mulc(op(rp::OP_SUB, a, b, 0.0), inv), 0.5);
+        }
+        if (k == 4) {                                    // :461-468: (u(x+2e) - 4u(x+e) + 6u(x) - 4u(x-e) + u(x-2e)) * _epsilon^4
+            StOperand t = op(rp::OP_SUB, u(net, sh, ax, 2.0 * eps), mulc(u(net, sh, ax, eps), 4.0), 0.0);
+            t = op(rp::OP_ADD, t, mulc({0, vnet(net, sh)}, 6.0), 0.0);
+            t = op(rp::OP_SUB, t, mulc(u(net, sh, ax, -eps), 4.0), 0.0);
+            t = op(rp::OP_ADD, t, u(net, sh, ax, -2.0 * eps), 0.0);
+            return mulc(t, (inv * inv) * (inv * inv));
+        }
+        if (k == 3) {                                    // :469-474: (u(x+2e) - 2u(x+e) + 2u(x-e) - u(x-2e)) * _epsilon^3 / 2
+            StOperand t = op(rp::OP_SUB, u(net, sh, ax, 2.0 * eps), mulc(u(net, sh, ax, eps), 2.0), 0.0);
+            t = op(rp::OP_ADD, t, mulc(u(net, sh, ax, -eps), 2.0), 0.0);
+            t = op(rp::OP_SUB, t, u(net, sh, ax, -2.0 * eps), 0.0);
+            return mulc(mulc(t, inv * inv * inv), 0.5);
+        }
+        if (k == 2) {                                    // :475-476: (u(x+e) + u(x-e) - 2u(x)) * _epsilon^2
+            StOperand t = op(rp::OP_ADD, u(net, sh, ax, eps), u(net, sh, ax, -eps), 0.0);
+            t = op(rp::OP_SUB, t, mulc({0, vnet(net, sh)}, 2.0), 0.0);
+            return mulc(t, inv * inv);
+        }
+        return mulc(mulc(op(rp::OP_SUB, u(net, sh, ax, eps), u(net, sh, ax, -eps), 0.0), inv), 0.5);      // :477-478
+    }
+};
+}  // namespace
+
+// build every term's stencil tape (pinn_set_option(h, "derivative", "stencil"); the float64 mode must be on)
+int f64_stencil_enable(pinn_engine& E, bool on) {
+    if (!E.f64) return fail("pinn_set_option: \"derivative\" = \"stencil\" is a validation mode of the float64 evaluation (set \"precision\" to \"f64\" first)");
+    F64State& S = *(F64State*)E.f64;
+    if (!on) { S.stencil = false; return 0; }
+    if (!S.sten.empty()) { S.stencil = true; return 0; }
+    std::vector<F64Stencil> sten(E.terms0.size());
+    for (size_t t = 0; t < E.terms0.size(); ++t) {
+        const Term& T = E.terms0[t];
+        F64Stencil& X = sten[t];
+        const std::string who = "derivative = stencil: term " + std::to_string(t) + ": ";
+        for (auto& sl : T.slots) X.active = X.active || sl.order > 0 || sl.lap != 0;
+        if (!X.active) continue;
+        StBuilder B;
+        std::vector<StOperand> slot_val;
+        for (auto& sl : T.slots) {
+            if (sl.lap) return fail(who + "internal (a fused Laplacian slot in the pristine term)");
+            slot_val.push_back(B.deriv(sl.net, sl.axes, sl.order, stencil_eps(sl.order), {}));
+        }
+        const int dt = T.d, np = E.np, nv = (int)B.vnets.size(), nold = (int)T.slots.size(), npre = (int)B.ops.size();
+        if (nv > pk::F64_MAX_SLOTS || dt + np + nv + npre + (int)T.ops.size() > pk::F64_MAX_ROWS)
+            return fail(who + "the stencil tape needs " + std::to_string(dt + np + nv + npre + (int)T.ops.size()) + " rows / " + std::to_string(nv) + " shifted evaluations (limits: 96 / 24)");
+        for (auto& vn : B.vnets)
+            if (vn.shifts.size() > 8) return fail(who + "derivative order above 8");
+        auto row = [&](StOperand o) { return o.kind == 0 ? dt + np + o.idx : (o.kind == 1 ? dt + np + nv + o.idx : o.idx); };
+        std::vector<rp::Instr> prog;
+        std::vector<double> imm;
+        for (auto& o : B.ops) {
+            rp::Instr I;
+            std::memset(&I, 0, sizeof I);
+            I.code = o.code; I.a = row(o.a); I.b = rp::is_binary(o.code) ? row(o.b) : 0; I.imm = (float)o.imm;
+            rp::finalize(I);
+            prog.push_back(I); imm.push_back(o.imm);
+        }
+        auto remap = [&](int r) {                        // a row of the term's own numbering [coordinates | params | slots | ops]
+            if (r < dt + np) return r;
+            if (r < dt + np + nold) return row(slot_val[r - dt - np]);
+            return dt + np + nv + npre + (r - dt - np - nold);
+        };
+        for (size_t q = 0; q < T.ops.size(); ++q) {
+            rp::Instr I = T.ops[q];
+            if (!rp::is_nullary(I.code)) I.a = remap(I.a);
+            if (rp::is_binary(I.code)) I.b = remap(I.b);
+            prog.push_back(I);
+            imm.push_back(q < T.imm64.size() ? T.imm64[q] : (double)T.ops[q].imm);
+        }
+        X.vnets = B.vnets;
+        X.nops = (int)prog.size();
+        X.out_row = remap(T.out_row);
+        X.d_prog = (rp::Instr*)plat_malloc(sizeof(rp::Instr) * std::max<size_t>(prog.size(), 1));
+        X.d_imm = (double*)plat_malloc(sizeof(double) * std::max<size_t>(prog.size(), 1));
+        if (!X.d_prog || !X.d_imm) return fail("device allocation failed (stencil tape)");
+        plat_h2d(X.d_prog, prog.data(), sizeof(rp::Instr) * prog.size(), E.stream);
+        plat_h2d(X.d_imm, imm.data(), sizeof(double) * imm.size(), E.stream);
+        if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    }
+    S.sten.swap(sten);
+    S.stencil = true;
+    return 0;
+}
+bool f64_stencil_on(const pinn_engine& E) { return E.f64 && ((const F64State*)E.f64)->stencil; }
+
+static int f64_values(pinn_engine& E, F64State& S, const F64Term& F, F64Launch& L, int64_t n, double* d_out);
+// the value-only pseudo-term of virtual network `vn` of term t on its shifted set
+static int stencil_vnet_term(pinn_engine& E, F64State& S, const F64VNet& vn, double* d_pts, int64_t n, F64Term& F) {
+    const Net& N = E.nets[vn.net];
+    std::string why;
+    Slot sl;
+    sl.net = vn.net; sl.order = 0; sl.lap = 0;
+    for (int q = 0; q < MAX_DERIV_ORDER; ++q) sl.axes[q] = 0;
+    F.k = f64_find(N.sizes[0], std::vector<Slot>{sl}, F.slot_chan, why);
+    if (!F.k) return fail("derivative = stencil: " + why);
+    F.km = nullptr;                                      // (one lane per point: a validation mode)
+    F.nets = {vn.net};
+    F.slot_net = {0};
+    F.nops = 0; F.nslots = 1; F.out_row = N.sizes[0] + E.np;
+    F.n = n;
+    F.d_pts = d_pts;
+    return 0;
+}
+// one term in stencil mode.  mode 0: loss + gradient (accumulated into `grad`, which the caller has zeroed), 1: loss only, 2: residuals into d_resid
+static int f64_stencil_term(pinn_engine& E, int t, const double* theta, double* grad, double* sumsq_t, double w, int mode, double* d_resid) {
+    F64State& S = *(F64State*)E.f64;
+    const F64Stencil& X = S.sten[t];
+    const F64Term& F0 = S.terms[t];
+    const Term& T = E.terms[t];
+    const Term& T0 = E.terms0[t];
+    const int64_t n = F0.n;
+    const int nv = (int)X.vnets.size(), stride = 2 + E.ne;
+    int dmax = 1;
+    for (auto& vn : X.vnets) dmax = std::max(dmax, E.nets[vn.net].sizes[0]);
+    if (!grow(S.d_uv, S.uv_cap, (size_t)nv * n, E.stream) || !grow(S.d_seeds, S.seeds_cap, (size_t)nv * n * stride, E.stream) ||
+        !grow(S.d_spts, S.spts_cap, (size_t)nv * n * dmax, E.stream)) return fail("device allocation failed (stencil evaluation)");
+    // 1. shifted sets and the virtual networks' values
+    for (int v = 0; v < nv; ++v) {
+        const F64VNet& vn = X.vnets[v];
+        const Net& N = E.nets[vn.net];
+        pk::F64ShiftArgs sa;
+        std::memset(&sa, 0, sizeof sa);
+        sa.pts = F0.d_pts; sa.dt = T0.d; sa.out = S.d_spts + (size_t)v * n * dmax; sa.d = N.sizes[0]; sa.n = (int)n;
+        std::vector<int> m;
+        if (T0.inmap.count(vn.net)) m = T0.inmap.at(vn.net);
+        else for (int i = 0; i < sa.d; ++i) m.push_back(i);
+        for (int i = 0; i < 4; ++i) sa.imap[i] = i < (int)m.size() ? m[i] : 0;
+        sa.nshift = (int)vn.shifts.size();
+        for (int q = 0; q < sa.nshift; ++q) { sa.axis[q] = vn.shifts[q].first; sa.delta[q] = vn.shifts[q].second; }
+        pk::launch_f64_shift(sa, E.stream);
+        F64Term F;
+        if (stencil_vnet_term(E, S, vn, sa.out, n, F)) return 1;
+        F64Launch L;
+        int rc = f64_build(E, F, sa.d, nullptr, L);
+        L.a.theta = theta;
+        if (!rc) rc = f64_values(E, S, F, L, n, S.d_uv + (size_t)v * n);
+        F.d_pts = nullptr;
+        if (rc) return rc;
+    }
+    // 2. the stencil tape: residuals / squared residuals / seeds
+    pk::F64StapeArgs ta;
+    std::memset(&ta, 0, sizeof ta);
+    ta.pts = F0.d_pts; ta.dt = T0.d; ta.n = (int)n; ta.theta = theta;
+    ta.np = E.np; ta.ne = E.ne; ta.p_off = E.p_theta_off;
+    for (int j = 0; j < pk::MAX_PARAMS; ++j) ta.pdef[j] = j < (int)E.p_defaults.size() ? (double)E.p_defaults[j] : 0.0;
+    ta.pw = (T.pw_n == T.n && T.pw_n > 0) ? T.d_pw : nullptr;
+    ta.data = F0.ndata > 0 ? F0.d_data : nullptr;
+    ta.uv = S.d_uv; ta.nv = nv;
+    ta.prog = X.d_prog; ta.imm = X.d_imm; ta.nops = X.nops; ta.out_row = X.out_row;
+    ta.scale = 2.0 * w / (double)T.n_norm;
+    ta.mode = mode; ta.resid = d_resid; ta.seeds = S.d_seeds; ta.seed_stride = stride;
+    pk::launch_f64_stape(ta, E.stream);
+    if (mode == 2) return 0;
+    // 3. seeded launches: the squared residuals ride in virtual network 0's records; loss only: that launch alone
+    for (int v = 0; v < (mode == 1 ? 1 : nv); ++v) {
+        const F64VNet& vn = X.vnets[v];
+        F64Term F;
+        if (stencil_vnet_term(E, S, vn, S.d_spts + (size_t)v * n * dmax, n, F)) return 1;
+        F64Launch L;
+        if (f64_build(E, F, E.nets[vn.net].sizes[0], nullptr, L)) { F.d_pts = nullptr; return 1; }
+        pk::F64Args& a = L.a;
+        a.theta = theta; a.mode = mode; a.scale = 0.0;
+        a.seed = S.d_seeds + (size_t)v * n * stride; a.seed_stride = stride;
+        int64_t chunk = 0;
+        if (f64_buffers(E, S, L, n, true, chunk)) { F.d_pts = nullptr; return 1; }
+        for (int64_t p0 = 0; p0 < n; p0 += chunk) {
+            a.p0 = (int)p0;
+            a.npts = (int)std::min<int64_t>(chunk, n - p0);
+            F.k->launch_point(a, L.sin_act, E.stream);
+            pk::launch_f64_dw(a, E.stream);
+            pk::launch_f64_dwt(a, E.stream);
+            pk::F64ReduceArgs r;
+            std::memset(&r, 0, sizeof r);
+            r.slab = S.d_slab; r.nblocks = (a.npts + pk::F64_BLOCK - 1) / pk::F64_BLOCK; r.nent = a.nent;
+            r.grad = grad; r.ent_p = a.ent_p; r.p_off = E.p_theta_off; r.nnets = 1;
+            r.ent0[0] = a.net[0].ent0; r.theta0[0] = a.net[0].theta0;
+            r.sumsq = sumsq_t; r.with_grad = mode == 0 ? 1 : 0;
+            r.init_sumsq = (v == 0 && p0 == 0) ? 1 : 0;
+            r.init_grad = 0;
+            pk::launch_f64_reduce(r, E.stream);
+        }
+        F.d_pts = nullptr;
+    }
+    return 0;
+}
+
 // loss sums (`sumsq`, K doubles) and gradient (`grad`, P doubles; nullptr: loss only) at the parameters `theta` — all three device pointers —
 // everything on the device, nothing synchronised
 static int f64_eval_device(pinn_engine& E, const double* theta, double* grad, double* sumsq, const double* term_w) {
@@ -373,13 +611,18 @@ static int f64_eval_device(pinn_engine& E, const double* theta, double* grad, do
     if (grad) {
         int64_t covered = E.ne;
         for (int ni : S.terms[0].nets) covered += E.nets[ni].nparams();
-        if (covered != P) { plat_memset(grad, 0, sizeof(double) * P, E.stream); grad_started = true; }
+        if (covered != P || S.stencil) { plat_memset(grad, 0, sizeof(double) * P, E.stream); grad_started = true; }
     }
     S.path = 0;
     for (int t = 0; t < K; ++t) {
         const Term& T = E.terms[t];
         const Term& T0 = E.terms0[t];
         F64Term& F = S.terms[t];
+        if (S.stencil && S.sten[t].active) {             // reference semantics: central differences (a validation mode, one lane per point)
+            S.path |= 1;
+            if (f64_stencil_term(E, t, theta, grad, sumsq + t, term_w ? term_w[t] : 1.0, grad ? 0 : 1, nullptr)) return 1;
+            continue;
+        }
         F64Launch L;
         if (f64_build(E, F, T0.d, &T0.inmap, L)) return 1;
         pk::F64Args& a = L.a;
@@ -460,11 +703,16 @@ int f64_residual(pinn_engine& E, int term, const double* theta, double* r) {
     size_t cap = (size_t)S.aux_out_cap;
     if (!grow(S.d_aux_out, cap, (size_t)F.n, E.stream)) { S.aux_out_cap = 0; return fail("device allocation failed (float64 residuals)"); }
     S.aux_out_cap = (int64_t)cap;
-    F64Launch L;
-    if (f64_build(E, F, E.terms0[term].d, &E.terms0[term].inmap, L)) return 1;
-    L.a.theta = S.d_theta;
     S.path = 0;
-    if (f64_values(E, S, F, L, F.n, S.d_aux_out)) return 1;
+    if (S.stencil && S.sten[term].active) {
+        S.path = 1;
+        if (f64_stencil_term(E, term, S.d_theta, nullptr, nullptr, 1.0, 2, S.d_aux_out)) return 1;
+    } else {
+        F64Launch L;
+        if (f64_build(E, F, E.terms0[term].d, &E.terms0[term].inmap, L)) return 1;
+        L.a.theta = S.d_theta;
+        if (f64_values(E, S, F, L, F.n, S.d_aux_out)) return 1;
+    }
     if (plat_d2h(r, S.d_aux_out, sizeof(double) * (size_t)F.n, E.stream) || plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
     return 0;
 }

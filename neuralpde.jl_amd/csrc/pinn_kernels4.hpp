@@ -65,6 +65,11 @@ struct F64Args {
     int r_pbar, r_sq;                   // PDE-parameter partials [ne], squared weighted residual [1]
     int mode;                           // 0: loss + gradient, 1: loss only, 2: residual values into `resid`
     double* resid;
+    // SEEDED launches (the reference-semantics "stencil" validation mode, f64.cpp: f64_stencil_*): the term is one network's value at (shifted)
+    // points and the reverse sweep starts from a per-point seed computed elsewhere (the stencil tape, k_f64_stape) instead of from this launch's
+    // own tape: record [seed_stride] per point = { d loss / d u(point), squared weighted residual, PDE-parameter partials [ne] }; nullptr: off
+    const double* seed;
+    int seed_stride;
     // weight-gradient kernel
     int C, first_ch[8];                 // channel of d/dx_i (-1: not carried)
     double* slab;                       // [nblocks][nent], nent = sum of the networks' parameters + ne + 1 (last entry: the block's sum of squares)
@@ -85,6 +90,8 @@ DEV void f64_point(int lp, const F64Args& a) {
     const int p = a.p0 + lp;
     double* S = a.scratch + lp;                                  // element `row` of this point: S[row * npad]
     const size_t np_ = (size_t)a.npad;
+    const double* sd = a.seed ? a.seed + (size_t)p * (size_t)a.seed_stride : nullptr;
+    if (sd && a.mode == 1) { S[(size_t)a.r_sq * np_] = sd[1]; return; }      // seeded loss-only launch: the squared residual is the seed record's
     double U[F64_MAX_NETS][C];
     // =========================== forward ===========================
     for (int ni = 0; ni < a.nnets; ++ni) {
@@ -154,6 +161,9 @@ DEV void f64_point(int lp, const F64Args& a) {
     }
     // =========================== residual tape ===========================
     double v[F64_MAX_ROWS];
+    double g[F64_MAX_ROWS];
+    double rbar = 0.0;
+    if (!sd) {
     const int R0 = a.dt + a.np + a.nslots;
     for (int i = 0; i < a.dt; ++i) v[i] = a.pts[(size_t)p * a.dt + i];
     for (int j = 0; j < a.np; ++j) v[a.dt + j] = j < a.ne ? a.theta[a.p_off + j] : a.pdef[j];
@@ -175,7 +185,6 @@ DEV void f64_point(int lp, const F64Args& a) {
     const double rs = r * sw;
     S[(size_t)a.r_sq * np_] = rs * rs;
     if (a.mode == 1) return;
-    double g[F64_MAX_ROWS];
     for (int q = 0; q < R0 + a.nops; ++q) g[q] = 0.0;
     g[a.out_row] = 1.0;
     for (int q = a.nops - 1; q >= 0; --q) {
@@ -187,8 +196,17 @@ DEV void f64_point(int lp, const F64Args& a) {
         g[ins.a] += da;
         if (rp::is_binary(ins.code)) g[ins.b] += db;
     }
-    const double rbar = rs * a.scale * sw;
+    rbar = rs * a.scale * sw;
     for (int j = 0; j < a.ne; ++j) S[((size_t)a.r_pbar + j) * np_] = rbar * g[a.dt + j];
+    } else {
+        // seeded: d loss / d (slot s) = the record's seed for slot 0 (one network, value channel), nothing for any other row
+        if (a.mode == 2) { a.resid[p] = U[0][0]; return; }
+        S[(size_t)a.r_sq * np_] = sd[1];
+        for (int j = 0; j < a.ne; ++j) S[((size_t)a.r_pbar + j) * np_] = sd[2 + j];
+        for (int s = 0; s < a.nslots; ++s) g[a.dt + a.np + s] = 0.0;
+        g[a.dt + a.np] = 1.0;
+        rbar = sd[0];
+    }
     // =========================== reverse sweep, network by network ===========================
     for (int ni = 0; ni < a.nnets; ++ni) {
         const F64Net& n = a.net[ni];
@@ -378,6 +396,101 @@ DEV void f64_reduce_entry(int e, const F64ReduceArgs& a) {
     for (int b = 0; b < a.nblocks; ++b) s += a.slab[(size_t)b * a.nent + e];
     f64_reduce_write(e, s, a);
 }
+
+// ---- the reference-semantics ("stencil") validation mode: derivative slots as the reference's CENTRAL DIFFERENCES (numeric_derivative,
+// src/pinn_types.jl:445-482, steps from get_eps, src/symbolic_utilities.jl:98-103) instead of exact Taylor jets.  Not a performance path: it
+// exists so that the engine can be compared digit by digit with the reference's generated loss functions (NeuralPDEHIP.selftest) and with the
+// stencil oracle at TRAINED parameters, where exact and finite-difference derivatives differ by 1e-3 in the gradient.  Every derivative is a
+// linear combination of VALUES of the trial function at shifted points, so an evaluation is (f64.cpp: f64_stencil_term)
+//   1. one value-only launch (k_f64_point, mode 2) per distinct (network, shift sequence) — a "virtual network" — on its shifted copy of the set,
+//   2. k_f64_stape: per point the STENCIL TAPE — the reference's difference formulas as tape ops in the reference's order of operations over the
+//      virtual networks' values, then the term's own tape — forward and reverse: residual, squared residual, and d loss / d (value of virtual
+//      network v at this point) = the seed of
+//   3. one SEEDED loss + gradient launch per virtual network (F64Args::seed): forward again, reverse sweep from the seed, the usual
+//      weight-gradient kernels and slab reduction, accumulated into the gradient. ----
+struct F64ShiftArgs {
+    const double* pts; int dt;          // the term's set [n][dt]
+    double* out; int d;                 // the virtual network's set [n][d]: out[p][i] = pts[p][imap[i]], then the shifts in order (one rounding each,
+    int imap[4];                        // like the reference's x .+ eps, then .+ the inner level's eps, ...)
+    int nshift, axis[8];
+    double delta[8];
+    int n;
+};
+DEV void f64_shift_point(int p, const F64ShiftArgs& a) {
+    double x[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < a.d; ++i) x[i] = a.pts[(size_t)p * a.dt + a.imap[i]];
+    for (int s = 0; s < a.nshift; ++s)
+        for (int i = 0; i < a.d; ++i) if (i == a.axis[s]) x[i] = x[i] + a.delta[s];
+    for (int i = 0; i < a.d; ++i) a.out[(size_t)p * a.d + i] = x[i];
+}
+struct F64StapeArgs {
+    const double* pts; int dt, n;       // the term's set
+    const double* theta;                // PDE parameters theta.p
+    int np, ne, p_off;
+    double pdef[MAX_PARAMS];
+    const float* pw;                    // quadrature factors sqrt(N w_i), nullable
+    const double* data;                 // [ndata][n], nullable
+    const double* uv; int nv;           // values of the virtual networks [nv][n]: tape rows dt + np + v
+    const rp::Instr* prog; const double* imm; int nops, out_row;      // stencil tape: difference formulas, then the term's own ops
+    double scale;                       // 2 w_k / N_norm
+    int mode;                           // 0: seeds for a loss + gradient evaluation, 1: squared residuals only, 2: residuals into `resid`
+    double* resid;
+    double* seeds; int seed_stride;     // [nv][n][seed_stride]: { d loss / d uv[v][p], (v == 0: squared weighted residual, parameter partials; else 0) }
+};
+DEV void f64_stape_point(int p, const F64StapeArgs& a) {
+    double v[F64_MAX_ROWS];
+    const int R0 = a.dt + a.np + a.nv;
+    for (int i = 0; i < a.dt; ++i) v[i] = a.pts[(size_t)p * a.dt + i];
+    for (int j = 0; j < a.np; ++j) v[a.dt + j] = j < a.ne ? a.theta[a.p_off + j] : a.pdef[j];
+    for (int s = 0; s < a.nv; ++s) v[a.dt + a.np + s] = a.uv[(size_t)s * a.n + p];
+    for (int q = 0; q < a.nops; ++q) {
+        const rp::Instr ins = a.prog[q];
+        const double va = rp::is_nullary(ins.code) ? 0.0 : v[ins.a];
+        const double vb = rp::is_binary(ins.code) ? v[ins.b] : 0.0;
+        v[R0 + q] = (ins.code == rp::OP_DATA) ? a.data[(size_t)(int)a.imm[q] * (size_t)a.n + (size_t)p] : rp::apply<double, double>(ins.code, va, vb, a.imm[q]);
+    }
+    const double r = v[a.out_row];
+    if (a.mode == 2) { a.resid[p] = r; return; }
+    const double sw = a.pw ? (double)a.pw[p] : 1.0;
+    const double rs = r * sw;
+    double* sd0 = a.seeds + (size_t)p * a.seed_stride;
+    sd0[1] = rs * rs;
+    if (a.mode == 1) return;
+    double g[F64_MAX_ROWS];
+    for (int q = 0; q < R0 + a.nops; ++q) g[q] = 0.0;
+    g[a.out_row] = 1.0;
+    for (int q = a.nops - 1; q >= 0; --q) {
+        const rp::Instr ins = a.prog[q];
+        if (rp::is_nullary(ins.code)) continue;
+        const double vb = rp::is_binary(ins.code) ? v[ins.b] : 0.0;
+        double da, db;
+        rp::adjoint<double, double>(ins.code, v[ins.a], vb, v[R0 + q], a.imm[q], g[R0 + q], da, db);
+        g[ins.a] += da;
+        if (rp::is_binary(ins.code)) g[ins.b] += db;
+    }
+    const double rbar = rs * a.scale * sw;
+    for (int j = 0; j < a.ne; ++j) sd0[2 + j] = rbar * g[a.dt + j];
+    for (int s = 0; s < a.nv; ++s) {
+        double* sd = a.seeds + ((size_t)s * a.n + p) * a.seed_stride;
+        sd[0] = rbar * g[a.dt + a.np + s];
+        if (s > 0) { sd[1] = 0.0; for (int j = 0; j < a.ne; ++j) sd[2 + j] = 0.0; }
+    }
+}
+#ifdef PINN_EMU
+inline void launch_f64_shift(const F64ShiftArgs& a, plat_stream) { for (int p = 0; p < a.n; ++p) f64_shift_point(p, a); }
+inline void launch_f64_stape(const F64StapeArgs& a, plat_stream) { for (int p = 0; p < a.n; ++p) f64_stape_point(p, a); }
+#else
+template <int UNUSED> __global__ void __launch_bounds__(256) k_f64_shift(const F64ShiftArgs a) {
+    const int p = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (p < a.n) f64_shift_point(p, a);
+}
+template <int UNUSED> __global__ void __launch_bounds__(64) k_f64_stape(const F64StapeArgs a) {
+    const int p = (int)(blockIdx.x * 64 + threadIdx.x);
+    if (p < a.n) f64_stape_point(p, a);
+}
+inline void launch_f64_shift(const F64ShiftArgs& a, plat_stream st) { hipLaunchKernelGGL((k_f64_shift<0>), dim3((a.n + 255) / 256), dim3(256), 0, st, a); }
+inline void launch_f64_stape(const F64StapeArgs& a, plat_stream st) { hipLaunchKernelGGL((k_f64_stape<0>), dim3((a.n + 63) / 64), dim3(64), 0, st, a); }
+#endif
 
 // ---- the kernel table: one entry per (inputs, jet set); activations tanh / sigmoid / sin inside ----
 struct F64Kernel {

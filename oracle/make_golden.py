@@ -9,6 +9,7 @@ oracle's behaviour and give the GPU tests fixtures that do not need torch autogr
     python oracle/make_golden.py variants [names]  # the same problems at SCALED and TRAINED parameters, both oracle modes (r04: the regime
                                                  # where the split-operand bf16 GEMMs of the 64- / 128-wide kernels have the least margin)
     python oracle/make_golden.py variants-trained [names]  # appends the trained variants an existing variants fixture lacks (r06: cfg4 / cfg5)
+    python oracle/make_golden.py variants-noise [names]  # adds the stencil oracle's own reproducibility (permuted neurons) at the trained variants (r06)
     python oracle/make_golden.py variants-theta32 [names]  # adds the exact oracle at the float32-rounded trained parameters (r05)
     python oracle/make_golden.py variants-f32 [names]  # adds the float32 evaluation of the same program to the variants fixtures
 """
@@ -288,8 +289,59 @@ def add_theta32(out, only=None):
         np.savez_compressed(path, **d)
 
 
+def hidden_permutation(chain, nparams_total, rng):
+    """index vector idx: theta[idx] is the SAME network function with the neurons of every hidden layer permuted (another summation order
+    in every layer); its gradient is grad[idx]"""
+    ix = np.arange(nparams_total)
+    sizes, out, o, perm_in = chain.sizes, [], 0, None
+    for l in range(len(sizes) - 1):
+        n_in, n_out = sizes[l], sizes[l + 1]
+        W = ix[o:o + n_in * n_out].reshape(n_in, n_out).T.copy()
+        b = ix[o + n_in * n_out:o + n_in * n_out + n_out].copy()
+        o += n_in * n_out + n_out
+        if perm_in is not None:
+            W = W[:, perm_in]
+        perm_out = rng.permutation(n_out) if l < len(sizes) - 2 else np.arange(n_out)
+        W, b = W[perm_out], b[perm_out]
+        out += [W.T.reshape(-1), b]
+        perm_in = perm_out
+    return np.concatenate(out + [ix[o:]])
+
+
+def add_stencil_noise(out, only=None):
+    """adds `noise_stencil_<tag>` = (loss rel, grad rel L2, grad rel Linf) of the STENCIL oracle against itself on the same function with
+    permuted hidden neurons (first network), for the trained variants (r06): how reproducible the reference's finite-difference numbers are
+    across summation orders — u(x +- eps) carries ~1e-16 relative rounding and the difference formulas multiply it by 1 / eps^2 ~ 7e7; at a
+    trained theta, where the gradient is a small difference of large per-point terms, that is 1e-5 ... 1e-4 of the gradient.  The bound the
+    engine's stencil mode is held to (tests/test_gpu_theta_variants.py)."""
+    for name, (make, _, _, _) in VARIANT_CASES.items():
+        path = os.path.join(out, name + ".npz")
+        if (only and name not in only) or not os.path.exists(path):
+            continue
+        d = dict(np.load(path))
+        tags = [str(t) for t in d["tags"] if str(t).startswith("adam") and f"noise_stencil_{t}" not in d]
+        if not tags:
+            continue
+        wl = make()
+        sets = point_sets(wl)
+        assert [set_digest(s) for s in sets] == list(d["set_sha256"])
+        prob = helpers.oracle_problem(m, wl.pde_system, wl.chains, param_estim=wl.param_estim)
+        for tag in tags:
+            th = d["theta_" + tag]
+            idx = hidden_permutation(prob.chains[0], len(th), np.random.default_rng(7))
+            losses, grad = chunked_loss_and_grad(prob, th[idx], sets, d["weights"], mode="stencil")
+            l0, g0 = d[f"losses_stencil_{tag}"], d[f"grad_stencil_{tag}"][idx]
+            noise = np.array([np.max(np.abs(losses - l0) / np.abs(l0)), np.linalg.norm(grad - g0) / np.linalg.norm(g0), np.max(np.abs(grad - g0)) / np.max(np.abs(g0))])
+            d[f"noise_stencil_{tag}"] = noise
+            print(name, tag, "stencil oracle against its permuted self: loss rel, grad rel L2, Linf =", noise, flush=True)
+        np.savez_compressed(path, **d)
+
+
 def main():
     out = os.path.join(ROOT, "tests", "golden")
+    if len(sys.argv) > 1 and sys.argv[1] == "variants-noise":
+        add_stencil_noise(out, sys.argv[2:])
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "variants-theta32":
         add_theta32(out, sys.argv[2:])
         return

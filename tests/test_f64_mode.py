@@ -585,3 +585,132 @@ def test_precision_policy_follows_eltype_of_theta(npde, use_emu):
     npde.discretize(sysd, npde.DeepGalerkin(2, 1, 8, 1, "tanh", "tanh", "identity", npde.GridTraining(0.25), precision="f32"))
     with pytest.raises(ValueError, match="precision must be"):
         npde.PhysicsInformedNN(chain, strat, precision="f16")
+
+
+# ---- r06: the reference-semantics validation mode, pinn_set_option(h, "derivative", "stencil") ----
+def _permutation(chain, nparams_total, rng):
+    """index vector `idx` of the same network with the neurons of every hidden layer permuted: theta[idx] parametrises the identical function
+    (another summation order in every layer), and its gradient is grad[idx]"""
+    ix = np.arange(nparams_total)
+    sizes, out, o, perm_in = chain.sizes, [], 0, None
+    for l in range(len(sizes) - 1):
+        n_in, n_out = sizes[l], sizes[l + 1]
+        W = ix[o:o + n_in * n_out].reshape(n_in, n_out).T.copy()       # (out x in) from the column-major flat block
+        b = ix[o + n_in * n_out:o + n_in * n_out + n_out].copy()
+        o += n_in * n_out + n_out
+        if perm_in is not None:
+            W = W[:, perm_in]
+        perm_out = rng.permutation(n_out) if l < len(sizes) - 2 else np.arange(n_out)
+        W, b = W[perm_out], b[perm_out]
+        out += [W.T.reshape(-1), b]
+        perm_in = perm_out
+    return np.concatenate(out + [ix[o:]])
+
+
+def _stencil_noise(prob, th, sets, w, st, seeds=(11, 12)):
+    """the stencil oracle against ITSELF on the same function with permuted hidden neurons (first network): the reproducibility of the
+    reference's finite-difference numbers across summation orders, as (loss rel, grad rel L2, grad rel Linf) maxima over the seeds"""
+    worst = np.zeros(3)
+    for seed in seeds:
+        idx = _permutation(prob.chains[0], len(th), np.random.default_rng(seed))
+        stp = po.loss_and_grad(prob, th[idx], sets, weights=w, mode="stencil")
+        gp = st.grad[idx]
+        worst = np.maximum(worst, [np.max(np.abs(stp.term_losses - st.term_losses) / np.abs(st.term_losses)),
+                                   np.linalg.norm(stp.grad - gp) / np.linalg.norm(gp), np.max(np.abs(stp.grad - gp)) / np.max(np.abs(gp))])
+    return worst
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
+def test_stencil_mode_reproduces_the_reference_finite_differences(npde, use_emu, name):
+    """derivative = "stencil": every derivative slot evaluated as the reference's central differences (numeric_derivative,
+    src/pinn_types.jl:445-482, steps get_eps = eps(Float64)^(1/(2+order)), src/symbolic_utilities.jl:98-103, in the reference's order of
+    operations) — losses, gradient and the datafree residuals against the STENCIL oracle.  The yardstick is the stencil's own noise floor:
+    u(x +- eps) carries ~1e-16 relative rounding error and the difference formulas multiply it by 1 / eps^2 ~ 7e7, so ANY two correct
+    implementations differ by ~1e-8 in a second derivative — measured here as the stencil oracle against ITSELF on the same network with its
+    hidden neurons permuted (the identical function, another summation order: `_stencil_noise`).  The engine must sit within 4 x that."""
+    wl = _workloads()[name]()
+    rep, eng, sets, prob = _engine_f64(npde, wl)
+    th = np.asarray(rep.flat_init_params, dtype=np.float64)
+    w = np.linspace(1.0, 2.0, eng.K)
+    st = po.loss_and_grad(prob, th, sets, weights=w, mode="stencil")
+    noise = _stencil_noise(prob, th, sets, w, st)          # the stencil oracle's own reproducibility (systems: the first network's neurons permuted)
+    eng.set_option("derivative", "stencil")
+    assert eng.get_option("derivative") == "stencil"
+    l, g = eng.loss_grad_f64(th, w)
+    le, g2, gi = helpers.rel_errors(l, g, st)
+    ex = po.loss_and_grad(prob, th, sets, weights=w, mode="exact")
+    fd = helpers.rel_errors(st.term_losses, st.grad, ex)
+    print(f"\n{name}: engine(stencil) vs stencil oracle: loss {le.max():.1e} grad L2 {g2:.1e} Linf {gi:.1e}; the oracle against its permuted self: loss {noise[0]:.1e} "
+          f"grad L2 {noise[1]:.1e} Linf {noise[2]:.1e}; stencil vs exact oracle: loss {fd[0].max():.1e} grad {fd[1]:.1e}")
+    assert le.max() < 4 * max(noise[0], 2e-9) and g2 < 4 * max(noise[1], 2e-9) and gi < 4 * max(noise[2], 2e-9), (le, g2, gi, noise)
+    lo, _ = eng.loss_grad_f64(th, w, want_grad=False)
+    assert np.array_equal(lo, l)                                               # loss-only evaluation: the same sums
+    l2, g2_ = eng.loss_grad_f64(th, w)
+    assert np.array_equal(l2, l) and np.array_equal(g2_, g)                    # deterministic
+    for k in range(eng.K):
+        r = eng.residual_f64(k, th, sets[k].shape[1])
+        rr = po.residual_values(prob, th, k, sets[k], mode="stencil")
+        assert np.max(np.abs(r - rr)) < 2e-6 * max(1.0, np.max(np.abs(rr))), k   # (per-point noise: ~1e-16 |u| / eps^2)
+    eng.set_option("derivative", "exact")
+    l3, g3 = eng.loss_grad_f64(th, w)
+    assert max(helpers.rel_errors(l3, g3, ex)[1:]) < EXACT
+
+
+def test_stencil_mode_at_trained_parameters_and_higher_orders(npde, use_emu):
+    """at TRAINED parameters the reference's finite differences and exact derivatives give gradients ~1e-3 apart (cfg2 after 6,000 Adam steps:
+    8e-4 at full size) — the stencil mode is held to the reproducibility of the reference's own numbers there; third / fourth order formulas
+    and a mixed derivative (the recursion of :454-460) against the stencil oracle; the mode needs the float64 evaluation and says so"""
+    import os
+    from neuralpde_jl_amd import workloads
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg2_variants.npz"))
+    wl = workloads.cfg2_poisson2d(points=768, bcs_points=64)
+    rep, eng, sets, prob = _engine_f64(npde, wl)
+    th, w = g["theta_adam6000"], g["weights"]
+    st = po.loss_and_grad(prob, th, sets, weights=w, mode="stencil")
+    ex = po.loss_and_grad(prob, th, sets, weights=w, mode="exact")
+    fd = helpers.rel_errors(st.term_losses, st.grad, ex)
+    l, gr = eng.loss_grad_f64(th, w)
+    e_exact = helpers.rel_errors(l, gr, st)                                    # the exact-derivative kernels against the REFERENCE's semantics
+    eng.set_option("derivative", "stencil")
+    l, gr = eng.loss_grad_f64(th, w)
+    e_sten = helpers.rel_errors(l, gr, st)
+    noise = _stencil_noise(prob, th, sets, w, st, seeds=(1, 2, 3))
+    print(f"\ncfg2 adam6000 (768 + 4 x 64 points): stencil vs exact oracle grad L2 {fd[1]:.1e}; engine exact mode vs stencil oracle {e_exact[1]:.1e}; engine stencil mode vs "
+          f"stencil oracle: loss {e_sten[0].max():.1e} grad L2 {e_sten[1]:.1e} Linf {e_sten[2]:.1e}; the stencil oracle against its permuted self: loss {noise[0]:.1e} grad L2 {noise[1]:.1e} Linf {noise[2]:.1e}")
+    # FINDING (r06): at trained parameters the reference's finite-difference gradient is itself reproducible only to ~1e-4 relative — the
+    # oracle against the SAME function with permuted neurons moves by as much as the engine's stencil mode differs from it; most of the
+    # "8e-4 finite-difference error" of such a point is this rounding noise (1e-16 |u| / eps^2 per point against a gradient that is a small
+    # difference of large terms), not truncation error.  The engine's stencil mode is held to that floor (x 4); the losses — sums of squares,
+    # where the per-point noise averages out — agree to ~1e-6
+    assert e_sten[0].max() < 4 * max(noise[0], 1e-8) and e_sten[1] < 4 * noise[1] and e_sten[2] < 4 * noise[2], (e_sten, noise)
+    # orders 3 and 4 in 1-D (test/NNPDE1/nnpde__pde_iii_3rd_order_ode.jl; a KS-type fourth derivative), a mixed second derivative in 2-D
+    def run(sysm, chain, strat, seed):
+        theta = tp.theta_for(chain, seed)
+        rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=theta, precision="f64"))
+        e = rep.engine
+        e.set_option("derivative", "stencil")
+        sets_ = rep.pde_train_sets + rep.bcs_train_sets
+        pr = helpers.oracle_problem(npde, sysm, [chain])
+        th_ = np.asarray(rep.flat_init_params, dtype=np.float64)
+        ref = po.loss_and_grad(pr, th_, sets_, mode="stencil")
+        l_, g_ = e.loss_grad_f64(th_)
+        le, g2, gi = helpers.rel_errors(l_, g_, ref)
+        exr = po.loss_and_grad(pr, th_, sets_, mode="exact")
+        return le.max(), g2, helpers.rel_errors(ref.term_losses, ref.grad, exr)[1]
+    le, g2, fd3 = run(tp._third_order_ode(npde), npde.Chain(npde.Dense(1, 8, "sigmoid"), npde.Dense(8, 1)), npde.GridTraining(0.05), 31)
+    assert le < 1e-4 * max(1.0, fd3 / 1e-6) and g2 < 1e-3, (le, g2, fd3)       # (order 3: eps = 7.4e-4, noise 1e-16 / eps^3 ~ 2.5e-7 per point)
+    (x,) = npde.parameters("x")
+    (u,) = npde.variables("u")
+    D4 = npde.Differential(x) ** 4
+    sys4 = npde.PDESystem([npde.Eq(D4(u(x)) + u(x), sp.sin(x))], [npde.Eq(u(0.0), 0.0), npde.Eq(u(1.0), 0.5)],
+                          [npde.In(x, npde.Interval(0.0, 1.0))], [x], [u(x)])
+    le, g2, fd4 = run(sys4, npde.Chain(npde.Dense(1, 10, "tanh"), npde.Dense(10, 10, "tanh"), npde.Dense(10, 1)), npde.GridTraining(0.05), 32)
+    assert le < 1e-3 and g2 < 1e-3, (le, g2, fd4)                              # (order 4: eps = 2.5e-3, noise 1e-16 / eps^4 ~ 2.7e-6 per point)
+    sysm, chain = helpers.shape_problem(npde, 16, 2, 2)                        # u_xx + u_yy + 0.5 u_xy - u u_x: the mixed derivative takes the recursion
+    le, g2, fdm = run(sysm, chain, npde.GridTraining(0.25), 33)
+    assert le < 1e-6 and g2 < 1e-6, (le, g2, fdm)
+    # an fp32 handle refuses the option with the reason
+    rep32 = npde.symbolic_discretize(wl.pde_system, wl.discretization("f32"))
+    with pytest.raises(npde.EngineError, match="validation mode of the float64 evaluation"):
+        rep32.engine.set_option("derivative", "stencil")
+    assert rep32.engine.get_option("derivative") == "exact"

@@ -142,4 +142,19 @@ def test_theta_variant(npde, hip_lib, name, tag):
         assert max(e64) < TOL, (name, tag, "f64", e64)
         if name in ("cfg2_variants", "cfg3_variants"):
             assert eng.get_option("f64_path") == "mfma"
+        # r06: the reference-semantics validation mode (pinn_set_option "derivative" = "stencil": the reference's central differences with its
+        # get_eps steps) at FULL size against the STENCIL oracle.  The bound is the reproducibility of the reference's own finite-difference
+        # numbers: the stencil oracle against itself on the same function with permuted hidden neurons (`noise_stencil_<tag>`,
+        # oracle/make_golden.py variants-noise) — 1e-16 |u| / eps^2 of rounding per point against a gradient that is a small difference of large terms
+        if f"noise_stencil_{tag}" in g:
+            noise = g[f"noise_stencil_{tag}"]
+            eng.set_option("derivative", "stencil")
+            ls, gs = eng.loss_grad_f64(theta, w)
+            es = _errors(ls, gs, g[f"losses_stencil_{tag}"], g[f"grad_stencil_{tag}"])
+            ee = _errors(l64, g64, g[f"losses_stencil_{tag}"], g[f"grad_stencil_{tag}"])
+            print(f"  stencil mode vs STENCIL oracle: loss rel {es[0]:.2e}, grad rel L2 {es[1]:.2e}, Linf {es[2]:.2e}   (exact-derivative float64 kernels vs the stencil oracle: "
+                  f"{ee[0]:.2e} / {ee[1]:.2e} / {ee[2]:.2e}; the stencil oracle against its permuted self: {noise[0]:.2e} / {noise[1]:.2e} / {noise[2]:.2e})")
+            for i in range(3):
+                assert es[i] < 4.0 * max(noise[i], 2e-9), (name, tag, "stencil mode", i, es[i], noise[i])
+            eng.set_option("derivative", "exact")
         eng.set_option("precision", "f32")
