@@ -125,10 +125,14 @@ static const pk::F64MKernel* f64_find_m(const pinn_engine& E, const pk::F64Kerne
         if (N.act == pk::ACT_SIN || N.sizes.size() < 3) return nullptr;
         for (size_t j = 1; j + 1 < N.sizes.size(); ++j) maxh = std::max(maxh, N.sizes[j]);
     }
+    // a register-resident kernel (family 4m) before a channel-sliced one (family 4s: every layer through the scratch rows); the narrowest that covers the width
+    const bool no_sliced = std::getenv("PINN_F64_NO_SLICED") != nullptr;
     const pk::F64MKernel* best = nullptr;
-    for (const pk::F64MKernel& km : pk::f64m_registry())
-        if (km.D == k->D && km.D1MASK == k->D1MASK && km.PAIRS == k->PAIRS && km.NPAIR == k->NPAIR && km.HI == k->HI &&
-            16 * km.HT >= maxh && (!best || km.HT < best->HT)) best = &km;
+    for (const pk::F64MKernel& km : pk::f64m_registry()) {
+        if (!(km.D == k->D && km.D1MASK == k->D1MASK && km.PAIRS == k->PAIRS && km.NPAIR == k->NPAIR && km.HI == k->HI && 16 * km.HT >= maxh)) continue;
+        if (km.sliced && no_sliced) continue;
+        if (!best || (km.sliced < best->sliced) || (km.sliced == best->sliced && km.HT < best->HT)) best = &km;
+    }
     return best;
 }
 
@@ -274,6 +278,7 @@ struct F64Launch {
     pk::F64Args a;
     int rows = 0;                        // scratch rows per point
     bool sin_act = false, mfma = false;
+    bool sliced = false;                 // family 4s: the tile kernel passes every layer through the scratch rows (needed in every mode)
 };
 // everything of F64Args that does not depend on the evaluation (theta, weights, mode, chunk): networks, scratch row numbering, tape, slots
 static int f64_build(pinn_engine& E, const F64Term& F, int dt, const std::map<int, std::vector<int>>* inmap, F64Launch& L) {
@@ -288,6 +293,7 @@ static int f64_build(pinn_engine& E, const F64Term& F, int dt, const std::map<in
     int rows = 0, ent = 0;
     L.sin_act = false;
     L.mfma = F.km && std::getenv("PINN_F64_NO_MFMA") == nullptr;
+    L.sliced = L.mfma && F.km->sliced != 0;
     for (int ni = 0; ni < a.nnets; ++ni) {
         const Net& N = E.nets[F.nets[ni]];
         pk::F64Net& n = a.net[ni];
@@ -355,7 +361,7 @@ static int f64_buffers(pinn_engine& E, F64State& S, F64Launch& L, int64_t n, boo
     pk::F64Args& a = L.a;
     double mb = L.mfma ? 4096.0 : 256.0;
     if (const char* e = std::getenv("PINN_F64_SCRATCH_MB")) mb = std::max(1.0, std::atof(e));
-    const bool need_scratch = !(L.mfma && a.mode != 0);              // (the tile kernels keep everything in registers unless a reverse sweep / dW launch follows)
+    const bool need_scratch = !(L.mfma && a.mode != 0) || L.sliced;              // (the tile kernels keep everything in registers unless a reverse sweep / dW launch follows)
     for (;; mb *= 0.5) {
         int64_t chunk = (int64_t)((mb * 1024 * 1024) / (8.0 * L.rows));
         chunk = std::max<int64_t>(pk::F64_BLOCK, (chunk / pk::F64_BLOCK) * pk::F64_BLOCK);
@@ -891,7 +897,7 @@ std::string f64_describe(const pinn_engine& E) {
     for (size_t t = 0; t < S.terms.size(); ++t) {
         const F64Term& F = S.terms[t];
         c += (t ? "," : "") + std::to_string(F.k ? F.k->C : 0);
-        k += (t ? "," : "") + (F.km ? "mfma:HT" + std::to_string(F.km->HT) + "xPG" + std::to_string(F.km->PG) : std::string("lanes"));
+        k += (t ? "," : "") + (F.km ? std::string(F.km->sliced ? "mfma-sliced:HT" : "mfma:HT") + std::to_string(F.km->HT) + "xPG" + std::to_string(F.km->PG) : std::string("lanes"));
     }
     return c + k;
 }

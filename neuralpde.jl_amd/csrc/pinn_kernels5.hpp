@@ -668,6 +668,7 @@ HD void f64m_tsum_entry(int e, int b, const F64Args& a) {
 
 // ---- the kernel table: (inputs, jet set, HT) -> launchers; matched against a term's float64 kernel in f64.cpp ----
 struct F64MKernel {
+    int sliced = 0;                     // 1: family 4s (pinn_kernels6.hpp): channel-sliced GEMM passes through the scratch rows — needs the scratch in every mode
     int D, NPAIR, HT, PG;
     unsigned D1MASK, HI;
     unsigned long long PAIRS;

@@ -21,6 +21,7 @@ def main():
     cases = [("cfg1 1-D Poisson, 3x32... as in BASELINE.json, 4,096 points", lambda: workloads.cfg1_poisson1d(4096)),
              ("cfg2 2-D Poisson 4x64, 65,536 + 4x65,536 points (bench workload)", lambda: workloads.cfg2_poisson2d(points=65536)),
              ("cfg3 Burgers 4x64, 65,536 + 3x8,192 points", lambda: workloads.cfg3_burgers(points=65536, bcs_points=8192)),
+             ("cfg4 cavity 3 x (5x128), 16,384 + 8x4,096 points", lambda: workloads.cfg4_cavity(points=16384, bcs_points=4096)),
              ("cfg5 inverse heat 6x128 d=4, 32,768 + 7x8,192 points", lambda: workloads.cfg5_heat_inverse(points=32768, bcs_points=8192))]
     only = sys.argv[1:]                                           # (case prefixes, e.g. `cfg3`: that case alone in a fresh process)
     if only:
