@@ -8,7 +8,7 @@
 // with the same number of inputs), derivative orders <= 2 in 1-3 inputs (1-D: <= 4; 4-D: first and pure second derivatives), PDE parameters
 // (param_estim), quadrature weights, per-point DATA channels, device samplers; no periodic embeddings, no DGM networks.  Anything else fails at pinn_set_option with a message — the fp32 plan of the handle stays usable.
 #include "engine_types.hpp"
-#include "pinn_kernels5.hpp"
+#include "pinn_kernels6.hpp"
 
 namespace pk {
 std::deque<F64Kernel>& f64_registry() {
@@ -233,7 +233,9 @@ int f64_enable(pinn_engine& E) {
         if (f64_install_data(E, F, E.terms[t], nullptr)) return 1;
     }
     const int K = (int)E.terms.size();
-    S->d_theta = (double*)plat_malloc(sizeof(double) * E.ntheta);
+    // (+ F64S_PAD_THETA zeroed doubles behind theta: the sliced matrix-pipe kernels read full 16 HT-wide fragments of a narrower layer's matrix)
+    S->d_theta = (double*)plat_malloc(sizeof(double) * (E.ntheta + pk::F64S_PAD_THETA));
+    if (S->d_theta) plat_memset(S->d_theta, 0, sizeof(double) * (E.ntheta + pk::F64S_PAD_THETA), E.stream);
     S->d_grad = (double*)plat_malloc(sizeof(double) * E.ntheta);
     S->d_sumsq = (double*)plat_malloc(sizeof(double) * K);
     if (!S->d_theta || !S->d_grad || !S->d_sumsq) return fail("device allocation failed (float64 state)");
@@ -368,7 +370,7 @@ static int f64_buffers(pinn_engine& E, F64State& S, F64Launch& L, int64_t n, boo
         chunk = std::min<int64_t>(chunk, ((n + pk::F64_BLOCK - 1) / pk::F64_BLOCK) * pk::F64_BLOCK);
         const bool last_try = chunk <= pk::F64_BLOCK;
         bool ok = true;
-        if (need_scratch) ok = grow(S.d_scratch, S.scratch_cap, (size_t)L.rows * (size_t)chunk, E.stream);
+        if (need_scratch) ok = grow(S.d_scratch, S.scratch_cap, (size_t)L.rows * (size_t)chunk + pk::F64S_PAD_SCRATCH, E.stream);
         if (ok && with_sums) ok = grow(S.d_slab, S.slab_cap, (size_t)(chunk / pk::F64_BLOCK) * (size_t)a.nent, E.stream);
         if (ok && with_sums && L.mfma) ok = grow(S.d_tpart, S.tpart_cap, (size_t)(chunk / a.tile_pts + 1) * (size_t)a.ntp, E.stream);
         if (ok) {
@@ -606,6 +608,16 @@ static int f64_eval_device(pinn_engine& E, const double* theta, double* grad, do
     F64State& S = *(F64State*)E.f64;
     const int K = (int)E.terms.size();
     const int64_t P = E.ntheta;
+    if (theta != S.d_theta && theta != S.d_opt_theta) {
+        // a CALLER's device buffer (pinn_loss_grad_device_f64): the sliced kernels read up to F64S_PAD_THETA doubles past a narrow layer's matrix —
+        // evaluate from the handle's padded copy (P doubles device to device: microseconds)
+        bool sliced = false;
+        for (auto& F : S.terms) sliced = sliced || (F.km && F.km->sliced);
+        if (sliced) {
+            if (plat_d2d(S.d_theta, theta, sizeof(double) * P, E.stream)) return fail("device copy of theta failed");
+            theta = S.d_theta;
+        }
+    }
     for (int t = 0; t < K; ++t)
         if (S.terms[t].n <= 0 || S.terms[t].n != E.terms[t].n) return fail("term " + std::to_string(t) + " has no collocation points (call pinn_set_points first)");
     for (int t = 0; t < K; ++t)
@@ -778,7 +790,8 @@ int f64_adam_init(pinn_engine& E, const double* theta) {
     if (!S.d_m) {
         S.d_m = (double*)plat_malloc(sizeof(double) * P);
         S.d_v = (double*)plat_malloc(sizeof(double) * P);
-        S.d_opt_theta = (double*)plat_malloc(sizeof(double) * P);
+        S.d_opt_theta = (double*)plat_malloc(sizeof(double) * (P + pk::F64S_PAD_THETA));
+        if (S.d_opt_theta) plat_memset(S.d_opt_theta, 0, sizeof(double) * (P + pk::F64S_PAD_THETA), E.stream);
         S.d_w_over_n = (double*)plat_malloc(sizeof(double) * K);
         if (!S.d_m || !S.d_v || !S.d_w_over_n || !S.d_opt_theta) return fail("device allocation failed (float64 optimiser state)");
     }

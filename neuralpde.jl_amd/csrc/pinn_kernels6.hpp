@@ -22,16 +22,25 @@
 // every wave walks all points of the 512-point block, no LDS combine.
 #pragma once
 #include "pinn_kernels5.hpp"
-#ifndef PINN_F64S_WAVES
-#define PINN_F64S_WAVES 2               // waves per SIMD the sliced tile kernel is compiled for (register cap 512 / waves); 1: no spills, no latency cover (A/B)
+#ifndef PINN_F64S_ZMAX
+#define PINN_F64S_ZMAX 24               // channel group size CG = ZMAX / HT: the GEMM accumulators are 4 HT x CG = 4 ZMAX doubles per lane (A/B)
 #endif
+#ifndef PINN_F64S_WAVES
+#define PINN_F64S_WAVES 1               // waves per SIMD the sliced tile kernel is compiled for (register cap 512 / waves): at 1 the GEMM loop is operand loads and MFMAs only; at 2 (256 registers, 192 of them accumulators) it spills inside the loop (A/B: profiles/r06_f64_sliced.txt)
+#endif
+namespace pk {
+// what the sliced kernels may read past a layer's weight matrix (theta) / past a layer's scratch rows when the layer is narrower than 16 HT: in doubles
+constexpr size_t F64S_PAD_THETA = 128 * 128;
+constexpr size_t F64S_PAD_SCRATCH = (size_t)128 * 24 * 16;
+}
 
 namespace pk {
 
 // ---- kernel A'': one tile of 16 points through every network of the term, sliced over channel groups ----
 template <class J, int HT, int CG, int ACTK>
 DEV void f64s_tile(int tile, const F64Args& a, double* ulds /* [F64_MAX_NETS][C][16] */) {
-    constexpr int C = J::C, NR = HT * 4, NG = (C + CG - 1) / CG;
+    constexpr int C = J::C, NR = HT * 4;
+    constexpr int TB = (C <= 2) ? 8 : ((C <= 6) ? 4 : 2);       // tile rows per batch of the element-wise passes (loads in flight: TB x C, reverse: 2 TB x C)
     constexpr bool SIN = (ACTK == ACT_SIN);
     const int pbase = tile * 16;
     double* S = a.scratch;
@@ -39,35 +48,40 @@ DEV void f64s_tile(int tile, const F64Args& a, double* ulds /* [F64_MAX_NETS][C]
     const bool rev = a.mode == 0;
     // one GEMM pass: Z[rows of the layer `n_out` wide][group g0 .. g0 + CG) = A (n_out x n_in, element (m, k) at Aw[m * sm + k * sk]) x B rows
     // `brow` (n_in neurons x C channels), (+ bias on channel 0), stored to rows `zrow`
-    auto gemm = [&](const double* Aw, size_t sm, size_t sk, int n_out, int n_in, int brow, int zrow, const double* bias) {
+    auto gemm = [&](const double* Aw, int sm, int sk, int n_out, int n_in, int brow, int zrow, const double* bias) {
         for (int g0 = 0; g0 < C; g0 += CG) {
             LVd<NR * CG> Z;
             PINN_LANES(l) { PINN_UNROLL for (int e = 0; e < NR * CG; ++e) Z(l, e) = 0.0; }
-            LVd<HT> Af[2];
-            LVd<CG> Bf[2];
+            // operand ring: the fragments of k-block kb + PD are requested before the MFMAs of k-block kb (HT x CG MFMAs of 64 cycles each: one
+            // k-block ahead covers an L2 round trip at CG = 3; value-only terms — 8 MFMAs per k-block — look three ahead)
+            constexpr int PD = (CG >= 3) ? 1 : ((CG == 2) ? 2 : 3);
+            LVd<HT> Af[PD + 1];
+            LVd<CG> Bf[PD + 1];
+            // UNCONDITIONAL, AFFINE loads: per-lane base + (compile-time multiples of) uniform strides.  Nothing is clamped or predicated — a clamp per
+            // element makes every address its own value (the compiler then precomputes all 256 of a GEMM, spills them, and waits for memory in front
+            // of each load: measured) — so a layer narrower than the kernel's 16 HT reads past its matrix / its scratch rows: theta and the scratch are
+            // allocated with that margin (f64.cpp: F64S_PAD), what is read there meets B rows that a select has zeroed (k >= n_in) or lands in rows of
+            // Z that are never stored (m >= n_out)
             auto load = [&](int kb, LVd<HT>& A_, LVd<CG>& B_) {
                 PINN_LANES(l) {
-                    const int k = 4 * kb + (l >> 4);
-                    PINN_UNROLL for (int t = 0; t < HT; ++t) {
-                        const int m = 16 * t + (l & 15);
-                        A_(l, t) = (m < n_out && k < n_in) ? Aw[(size_t)m * sm + (size_t)k * sk] : 0.0;
-                    }
-                    const int kc = k < n_in ? k : 0;
+                    const double* pa = Aw + ((l & 15) * sm + (l >> 4) * sk);
+                    PINN_UNROLL for (int t = 0; t < HT; ++t) A_(l, t) = pa[16 * t * sm + 4 * kb * sk];
+                    const bool kin = 4 * kb + (l >> 4) < n_in;
+                    const double* pb = S + f64m_six(a, (size_t)brow + (size_t)((l >> 4) * C + g0), pbase + (l & 15));
                     PINN_UNROLL for (int g = 0; g < CG; ++g) {
-                        const int c = g0 + g, cc = c < C ? c : 0;
-                        const double v = S[f64m_six(a, (size_t)brow + (size_t)kc * C + cc, pbase + (l & 15))];
-                        B_(l, g) = (k < n_in && c < C) ? v : 0.0;
+                        const double v = pb[(4 * kb * C + g) * 16];
+                        B_(l, g) = (kin && g0 + g < C) ? v : 0.0;
                     }
                 }
             };
-            load(0, Af[0], Bf[0]);
+            // (no early exits on the layer's true width: operands beyond it are loaded as zeros — with run-time `break`s the compiler keeps the
+            // k-block loop rolled and the accumulators / operand rings, indexed by a run-time counter then, go to private memory: measured)
+            PINN_UNROLL for (int kb = 0; kb < PD; ++kb) load(kb, Af[kb], Bf[kb]);
             PINN_UNROLL for (int kb = 0; kb < NR; ++kb) {
-                if (4 * kb >= n_in) break;
-                if (kb + 1 < NR && 4 * (kb + 1) < n_in) load(kb + 1, Af[(kb + 1) & 1], Bf[(kb + 1) & 1]);
-                PINN_UNROLL for (int t = 0; t < HT; ++t) {
-                    if (16 * t >= n_out) break;
-                    PINN_UNROLL for (int g = 0; g < CG; ++g) mfma_f64(Z, (4 * t) * CG + g, CG, Af[kb & 1], t, Bf[kb & 1], g);
-                }
+                if (kb + PD < NR) load(kb + PD, Af[(kb + PD) % (PD + 1)], Bf[(kb + PD) % (PD + 1)]);
+                PINN_UNROLL for (int t = 0; t < HT; ++t)
+                    PINN_UNROLL for (int g = 0; g < CG; ++g) mfma_f64(Z, (4 * t) * CG + g, CG, Af[kb % (PD + 1)], t, Bf[kb % (PD + 1)], g);
+                sched_fence();                                   // (keeps the operand requests where they are: unfenced, the scheduler hoists the loads of all 32 k-blocks to the front and spills)
             }
             PINN_LANES(l) {
                 PINN_UNROLL for (int tr = 0; tr < NR; ++tr) {
@@ -93,42 +107,50 @@ DEV void f64s_tile(int tile, const F64Args& a, double* ulds /* [F64_MAX_NETS][C]
             const int n_in = n.sizes[lyr], n_out = n.sizes[lyr + 1];
             const double* W = a.theta + n.woff[lyr];
             const double* B = a.theta + n.boff[lyr];
-            if (lyr > 0) gemm(W, 1, (size_t)n_out, n_out, n_in, n.r_post[lyr - 1], n.r_rec[lyr], B);
-            // element-wise pass: pre-activation jets (layer 0: formed here) -> record, post-activation jets (last hidden layer: straight into the output sums)
+            if (lyr > 0) gemm(W, 1, n_out, n_out, n_in, n.r_post[lyr - 1], n.r_rec[lyr], B);
+            // element-wise pass: pre-activation jets (layer 0: formed here) -> record, post-activation jets (last hidden layer: straight into the output sums).
+            // TB tile rows at a time with every load of the batch in flight before the first use: one element per iteration would expose a full
+            // memory round trip per element (2 waves per SIMD cover nothing) — the first version of this kernel spent 14 x its MFMA time here
             PINN_LANES(l) {
                 const int q = l >> 4, j = l & 15;
                 const int p = pbase + j, pc = p < a.npts ? p : a.npts - 1;
                 double x[4] = {0.0, 0.0, 0.0, 0.0};
                 if (lyr == 0) { for (int i = 0; i < n.d; ++i) x[i] = a.pts[(size_t)(a.p0 + pc) * a.dt + n.imap[i]]; }
-                for (int tr = 0; tr < NR; ++tr) {
-                    const int m = 16 * (tr >> 2) + 4 * (tr & 3) + q;
-                    if (m >= n_out) continue;
-                    double z[C];
-                    if (lyr == 0) {
-                        double z0 = B[m];
-                        for (int i = 0; i < n.d; ++i) z0 = vfma(W[m + (size_t)i * n_out], x[i], z0);
-                        PINN_UNROLL for (int c = 0; c < C; ++c) z[c] = 0.0;
-                        z[0] = z0;
-                        PINN_UNROLL for (int kf = 0; kf < J::NFIRST; ++kf) z[J::CH_FIRST + kf] = W[m + (size_t)J::first_axis(kf) * n_out];
-                    } else {
-                        PINN_UNROLL for (int c = 0; c < C; ++c) z[c] = S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)m * C + c, p)];
+                for (int tr0 = 0; tr0 < NR; tr0 += TB) {
+                    if (16 * (tr0 >> 2) >= n_out) break;
+                    double z[TB][C], wl[TB];
+                    PINN_UNROLL for (int b = 0; b < TB; ++b) {
+                        const int tr = tr0 + b, m = 16 * (tr >> 2) + 4 * (tr & 3) + q, mc = m < n_out ? m : n_out - 1;
+                        if (lyr == 0) {
+                            double z0 = B[mc];
+                            for (int i = 0; i < n.d; ++i) z0 = vfma(W[mc + (size_t)i * n_out], x[i], z0);
+                            PINN_UNROLL for (int c = 0; c < C; ++c) z[b][c] = 0.0;
+                            z[b][0] = z0;
+                            PINN_UNROLL for (int kf = 0; kf < J::NFIRST; ++kf) z[b][J::CH_FIRST + kf] = W[mc + (size_t)J::first_axis(kf) * n_out];
+                        } else {
+                            PINN_UNROLL for (int c = 0; c < C; ++c) z[b][c] = S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)mc * C + c, p)];
+                        }
+                        wl[b] = (lyr == L - 1 && m < n_out) ? WL[mc] : 0.0;
                     }
-                    const double a0 = act_value<SIN>(n.act, z[0]);
-                    z[0] = act_record<SIN>(z[0], a0);
-                    if (rev) {
-                        if (lyr == 0) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)m * C + c, p)] = z[c]; }
-                        else if (!SIN) S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)m * C, p)] = z[0];
-                    }
-                    double dd[ND];
-                    act_derivs_n<J::NORD - 1, SIN>(n.act, z[0], dd);
-                    jet_forward<J>(z, dd);
-                    z[0] = a0;
-                    if (lyr < L - 1) {
-                        // (value-only tanh / sigmoid terms: r_post == r_rec, the activation IS the record — the store above already wrote it when rev)
-                        if (!(a.post_alias && rev)) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_post[lyr] + (size_t)m * C + c, p)] = z[c]; }
-                    } else {
-                        const double w = WL[m];
-                        PINN_UNROLL for (int c = 0; c < C; ++c) u(l, c) = vfma(w, z[c], u(l, c));
+                    PINN_UNROLL for (int b = 0; b < TB; ++b) {
+                        const int tr = tr0 + b, m = 16 * (tr >> 2) + 4 * (tr & 3) + q;
+                        const bool valid = m < n_out;
+                        const double a0 = act_value<SIN>(n.act, z[b][0]);
+                        z[b][0] = act_record<SIN>(z[b][0], a0);
+                        if (rev && valid) {
+                            if (lyr == 0) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)m * C + c, p)] = z[b][c]; }
+                            else if (!SIN) S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)m * C, p)] = z[b][0];
+                        }
+                        double dd[ND];
+                        act_derivs_n<J::NORD - 1, SIN>(n.act, z[b][0], dd);
+                        jet_forward<J>(z[b], dd);
+                        z[b][0] = a0;
+                        if (lyr < L - 1) {
+                            // (value-only tanh / sigmoid terms: r_post == r_rec, the activation IS the record — the store above already wrote it when rev)
+                            if (valid && !(a.post_alias && rev)) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_post[lyr] + (size_t)m * C + c, p)] = z[b][c]; }
+                        } else {
+                            PINN_UNROLL for (int c = 0; c < C; ++c) u(l, c) = vfma(wl[b], z[b][c], u(l, c));
+                        }
                     }
                 }
             }
@@ -220,63 +242,74 @@ DEV void f64s_tile(int tile, const F64Args& a, double* ulds /* [F64_MAX_NETS][C]
             const int n_next = n.sizes[lyr + 2];
             const double* Wn = a.theta + n.woff[lyr + 1];            // W_{lyr+1}[m + k * n_next]
             // G = W_{lyr+1}^T dZ_{lyr+1} into this layer's dZ rows (the output layer's row vector: formed per element below)
-            if (lyr < L - 1) gemm(Wn, (size_t)n_next, 1, H, n_next, n.r_dz[lyr + 1], n.r_dz[lyr], nullptr);
-            for (int tr = 0; tr < NR; ++tr) {
-                LVd<6> T6;                                           // [0, d) dW_0[m][i], [4] db_0[m], [5] dW_L[m]
+            if (lyr < L - 1) gemm(Wn, n_next, 1, H, n_next, n.r_dz[lyr + 1], n.r_dz[lyr], nullptr);
+            for (int tr0 = 0; tr0 < NR; tr0 += TB) {
+                if (16 * (tr0 >> 2) >= H) break;
+                LVd<6 * TB> T6;                                      // per row of the batch: [0, d) dW_0[m][i], [4] db_0[m], [5] dW_L[m]
                 PINN_LANES(l) {
                     const int q = l >> 4, j = l & 15;
-                    const int k = 16 * (tr >> 2) + 4 * (tr & 3) + q;
                     const int p = pbase + j, pc = p < a.npts ? p : a.npts - 1;
-                    const bool valid = k < H, st = valid && p < a.npts;
-                    const int kc = valid ? k : H - 1;
-                    double t6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-                    double s[C], gq[C], dd[ND], ub[C];
-                    PINN_UNROLL for (int c = 0; c < C; ++c) s[c] = S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)kc * C + c, p)];
-                    if (lyr == L - 1) {
-                        const double w = valid ? Wn[kc] : 0.0;
-                        PINN_UNROLL for (int c = 0; c < C; ++c) { ub[c] = ulds[(ni * C + c) * 16 + j]; gq[c] = w * ub[c]; }
-                    } else {
-                        PINN_UNROLL for (int c = 0; c < C; ++c) gq[c] = S[f64m_six(a, (size_t)n.r_dz[lyr] + (size_t)kc * C + c, p)];
-                    }
-                    act_derivs_n<J::NORD, SIN>(n.act, s[0], dd);
-                    if (lyr == L - 1) {                              // dW_L[k] += sum_c ubar_c * (post-activation jet c of neuron k): the forward rule on the record
-                        double pz[C];
-                        PINN_UNROLL for (int c = 0; c < C; ++c) pz[c] = s[c];
-                        jet_forward<J>(pz, dd);
-                        pz[0] = SIN ? act_value<SIN>(n.act, s[0]) : s[0];
-                        double t2 = 0.0;
-                        PINN_UNROLL for (int c = 0; c < C; ++c) t2 = vfma(ub[c], pz[c], t2);
-                        t6[5] = st ? t2 : 0.0;
-                    }
-                    jet_adjoint<J>(gq, s, dd);
-                    if (valid && lyr > 0) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_dz[lyr] + (size_t)k * C + c, p)] = st ? gq[c] : 0.0; }
-                    if (lyr == 0) {
-                        const double z0 = st ? gq[0] : 0.0;
-                        t6[4] = z0;
-                        PINN_UNROLL for (int i = 0; i < 4; ++i) {
-                            if (i >= n.d) break;
-                            double t2 = z0 * a.pts[(size_t)(a.p0 + pc) * a.dt + n.imap[i]];
-                            const int ck = a.first_ch[i];
-                            PINN_UNROLL for (int c = 1; c < C; ++c) if (c == ck) t2 += st ? gq[c] : 0.0;
-                            t6[i] = t2;
+                    double s[TB][C], gq[TB][C], ub[C], xin[4] = {0.0, 0.0, 0.0, 0.0};
+                    if (lyr == 0) { for (int i = 0; i < n.d; ++i) xin[i] = a.pts[(size_t)(a.p0 + pc) * a.dt + n.imap[i]]; }
+                    if (lyr == L - 1) { PINN_UNROLL for (int c = 0; c < C; ++c) ub[c] = ulds[(ni * C + c) * 16 + j]; }
+                    PINN_UNROLL for (int b = 0; b < TB; ++b) {
+                        const int tr = tr0 + b, k = 16 * (tr >> 2) + 4 * (tr & 3) + q, kc = k < H ? k : H - 1;
+                        PINN_UNROLL for (int c = 0; c < C; ++c) s[b][c] = S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)kc * C + c, p)];
+                        if (lyr == L - 1) {
+                            const double w = k < H ? Wn[kc] : 0.0;
+                            PINN_UNROLL for (int c = 0; c < C; ++c) gq[b][c] = w * ub[c];
+                        } else {
+                            PINN_UNROLL for (int c = 0; c < C; ++c) gq[b][c] = S[f64m_six(a, (size_t)n.r_dz[lyr] + (size_t)kc * C + c, p)];
                         }
                     }
-                    PINN_UNROLL for (int i = 0; i < 6; ++i) T6(l, i) = t6[i];
-                }
-                if (lyr == 0) {
-                    PINN_UNROLL for (int i = 0; i < 4; ++i) { if (i >= n.d) break; lv_rowsum(T6, i); }
-                    lv_rowsum(T6, 4);
-                }
-                if (lyr == L - 1) lv_rowsum(T6, 5);
-                PINN_LANES(l) {
-                    const int k = 16 * (tr >> 2) + 4 * (tr & 3) + (l >> 4);
-                    if ((l & 15) == 0 && k < H) {
-                        const int n1 = n.sizes[1];
+                    PINN_UNROLL for (int b = 0; b < TB; ++b) {
+                        const int tr = tr0 + b, k = 16 * (tr >> 2) + 4 * (tr & 3) + q;
+                        const bool valid = k < H, st = valid && p < a.npts;
+                        double t6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, dd[ND];
+                        act_derivs_n<J::NORD, SIN>(n.act, s[b][0], dd);
+                        if (lyr == L - 1) {                          // dW_L[k] += sum_c ubar_c * (post-activation jet c of neuron k): the forward rule on the record
+                            double pz[C];
+                            PINN_UNROLL for (int c = 0; c < C; ++c) pz[c] = s[b][c];
+                            jet_forward<J>(pz, dd);
+                            pz[0] = SIN ? act_value<SIN>(n.act, s[b][0]) : s[b][0];
+                            double t2 = 0.0;
+                            PINN_UNROLL for (int c = 0; c < C; ++c) t2 = vfma(ub[c], pz[c], t2);
+                            t6[5] = st ? t2 : 0.0;
+                        }
+                        jet_adjoint<J>(gq[b], s[b], dd);
+                        if (valid && lyr > 0) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_dz[lyr] + (size_t)k * C + c, p)] = st ? gq[b][c] : 0.0; }
                         if (lyr == 0) {
-                            PINN_UNROLL for (int i = 0; i < 4; ++i) if (i < n.d) TP[n.tp0 + i * n1 + k] = T6(l, i);
-                            TP[n.tp0 + n.d * n1 + k] = T6(l, 4);
+                            const double z0 = st ? gq[b][0] : 0.0;
+                            t6[4] = z0;
+                            PINN_UNROLL for (int i = 0; i < 4; ++i) {
+                                if (i >= n.d) break;
+                                double t2 = z0 * xin[i];
+                                const int ck = a.first_ch[i];
+                                PINN_UNROLL for (int c = 1; c < C; ++c) if (c == ck) t2 += st ? gq[b][c] : 0.0;
+                                t6[i] = t2;
+                            }
                         }
-                        if (lyr == L - 1) TP[n.tp0 + (n.d + 1) * n1 + k] = T6(l, 5);
+                        PINN_UNROLL for (int i = 0; i < 6; ++i) T6(l, 6 * b + i) = t6[i];
+                    }
+                }
+                PINN_UNROLL for (int b = 0; b < TB; ++b) {
+                    if (lyr == 0) {
+                        PINN_UNROLL for (int i = 0; i < 4; ++i) { if (i >= n.d) break; lv_rowsum(T6, 6 * b + i); }
+                        lv_rowsum(T6, 6 * b + 4);
+                    }
+                    if (lyr == L - 1) lv_rowsum(T6, 6 * b + 5);
+                }
+                PINN_LANES(l) {
+                    PINN_UNROLL for (int b = 0; b < TB; ++b) {
+                        const int tr = tr0 + b, k = 16 * (tr >> 2) + 4 * (tr & 3) + (l >> 4);
+                        if ((l & 15) == 0 && k < H) {
+                            const int n1 = n.sizes[1];
+                            if (lyr == 0) {
+                                PINN_UNROLL for (int i = 0; i < 4; ++i) if (i < n.d) TP[n.tp0 + i * n1 + k] = T6(l, 6 * b + i);
+                                TP[n.tp0 + n.d * n1 + k] = T6(l, 6 * b + 4);
+                            }
+                            if (lyr == L - 1) TP[n.tp0 + (n.d + 1) * n1 + k] = T6(l, 6 * b + 5);
+                        }
                     }
                 }
             }
@@ -403,7 +436,7 @@ template <int HT> void launch_f64s_dwt_any(const F64Args& a, plat_stream st) {
 template <int D, unsigned D1MASK, unsigned long long PAIRS, int NPAIR, unsigned HI, int HT> F64MKernel make_f64s_kernel() {
     using J = JetSet<D1MASK, PAIRS, NPAIR, HI>;
     static_assert(J::NLAP == 0, "the float64 kernels carry plain derivative channels (no forward-Laplacian channel)");
-    constexpr int CGMAX = 24 / HT;                               // accumulators 4 HT x CG <= 96 doubles per lane
+    constexpr int CGMAX = PINN_F64S_ZMAX / HT;                   // accumulators 4 HT x CG <= 4 ZMAX doubles per lane (96 by default)
     constexpr int CG = (J::C < CGMAX) ? J::C : CGMAX;
     static_assert(CG >= 1, "layer too wide for the sliced float64 kernels");
     F64MKernel k;

@@ -53,8 +53,9 @@ def test_f64_mode_equals_the_float64_oracle(npde, use_emu, name):
     assert np.array_equal(l2, l64) and np.array_equal(g2_, g64)              # deterministic
     # r05: which kernels ran — the matrix-pipe family (csrc/pinn_kernels5.hpp, v_mfma_f64_16x16x4_f64) wherever a (jet set, width) pair is
     # instantiated, one lane per point elsewhere (4-D nets); both families agree to rounding
-    assert eng.get_option("f64_path") == {"cfg1": "mfma", "cfg2": "mfma", "cfg3": "mfma", "cfg4": "mfma", "cfg5": "lanes"}[name]
-    if name != "cfg5":
+    # (r06: the 4-D jet set as well — channel-sliced kernels, csrc/pinn_kernels6.hpp)
+    assert eng.get_option("f64_path") == "mfma"
+    if True:
         import os
         os.environ["PINN_F64_NO_MFMA"] = "1"
         try:
@@ -714,3 +715,60 @@ def test_stencil_mode_at_trained_parameters_and_higher_orders(npde, use_emu):
     with pytest.raises(npde.EngineError, match="validation mode of the float64 evaluation"):
         rep32.engine.set_option("derivative", "stencil")
     assert rep32.engine.get_option("derivative") == "exact"
+
+
+# ---- r06: family 4s — the channel-sliced matrix-pipe kernels (csrc/pinn_kernels6.hpp) for 128-wide nets and the 3-D / 4-D jet sets ----
+@pytest.mark.parametrize("name", ["cfg4_128", "cfg4_100", "cfg5_128", "cfg5_64", "hess3d_64", "poisson1d_128", "poisson2d_128"])
+def test_sliced_matrix_pipe_kernels_equal_the_oracle(npde, use_emu, name):
+    """BASELINE configs 4 and 5 at their true width (three 128-wide nets; the 4-D set {u, u_t, u_x, u_y, u_z, u_xx, u_yy, u_zz} on a 128-wide
+    net), a width that is not a multiple of 16, the 3-D Hessian set, 1-D and 2-D 128-wide nets: losses, gradient, loss-only evaluation and the
+    datafree residuals of the float64 mode on the sliced v_mfma_f64 kernels against the float64 oracle — to rounding — and against the
+    lane-per-point family on the same handle; point counts that leave ragged tiles and (hess3d) several 512-point blocks"""
+    import dataclasses
+    import os
+    from neuralpde_jl_amd import workloads
+    if name.startswith("cfg4"):
+        wl = workloads.cfg4_cavity(points=40, bcs_points=20, width=int(name.split("_")[1]), hidden=3 if name.endswith("128") else 2)
+    elif name.startswith("cfg5"):
+        wl = workloads.cfg5_heat_inverse(points=50, bcs_points=24, width=int(name.split("_")[1]), hidden=2 if name.endswith("128") else 3)
+    elif name == "hess3d_64":
+        sysm, chain = helpers.shape_problem(npde, 64, 2, 3)
+        strat = npde.QuasiRandomTraining(1100, bcs_points=40, sampling_alg=npde.SobolSample(seed=3), resampling=False, minibatch=1)
+        wl = workloads.Workload("hess3d", sysm, [chain], strat, tp.theta_for(chain, 77))
+    elif name == "poisson1d_128":
+        wl = workloads.cfg1_poisson1d(70)
+        ch = workloads.mlp(1, 128, 2)
+        wl = dataclasses.replace(wl, chains=[ch], theta=workloads.synthetic_theta([ch], 5))
+    else:
+        wl = workloads.cfg2_poisson2d(points=90, bcs_points=20)
+        ch = workloads.mlp(2, 128, 2)
+        wl = dataclasses.replace(wl, chains=[ch], theta=workloads.synthetic_theta([ch], 6))
+    rep, eng, sets, prob = _engine_f64(npde, wl)
+    assert "mfma-sliced" in eng.describe()
+    th = np.asarray(rep.flat_init_params, dtype=np.float64)
+    w = np.linspace(1.0, 2.0, eng.K)
+    ref = po.loss_and_grad(prob, th, sets, weights=w, mode="exact")
+    l64, g64 = eng.loss_grad_f64(th, w)
+    assert eng.get_option("f64_path") == "mfma"
+    le, g2, gi = helpers.rel_errors(l64, g64, ref)
+    assert le.max() < EXACT and g2 < EXACT and gi < EXACT, (le, g2, gi)
+    l2, g2_ = eng.loss_grad_f64(th, w)
+    assert np.array_equal(l2, l64) and np.array_equal(g2_, g64)              # deterministic
+    lo, _ = eng.loss_grad_f64(th, w, want_grad=False)
+    np.testing.assert_allclose(lo, l64, rtol=1e-13)
+    for k in (0, eng.K - 1):
+        r = eng.residual_f64(k, th, sets[k].shape[1])
+        rr = po.residual_values(prob, th, k, sets[k], mode="exact")
+        assert np.max(np.abs(r - rr)) < 1e-12 * max(1.0, np.max(np.abs(rr)))
+    os.environ["PINN_F64_NO_SLICED"] = "1"                                   # the same handle's terms on the lane-per-point family
+    try:
+        eng.set_option("precision", "f32")
+        eng.set_option("precision", "f64")
+        for k, s in enumerate(sets):
+            eng.set_points_f64(k, s)
+        assert "mfma-sliced" not in eng.describe()
+        ll, gl = eng.loss_grad_f64(th, w)
+    finally:
+        del os.environ["PINN_F64_NO_SLICED"]
+    np.testing.assert_allclose(ll, l64, rtol=1e-12)
+    np.testing.assert_allclose(gl, g64, rtol=0, atol=1e-12 * np.abs(g64).max())

@@ -10,7 +10,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$(pwd)
 cd /tmp
-run() { name=$1; shift; if [ "$ONLY" != "  " ] && [[ "$ONLY" != *" $name "* ]]; then return 0; fi; rocprofv3 --kernel-trace --pmc "$@" -d $REPO/$OUT/$name -o p -- python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline $PMC_BENCH_ARGS > $REPO/$OUT/$name.json 2> $REPO/$OUT/$name.err || echo "pass $name failed"; }
+run() { name=$1; shift; if [ "$ONLY" != "  " ] && [[ "$ONLY" != *" $name "* ]]; then return 0; fi; rocprofv3 --kernel-trace --pmc "$@" -d $REPO/$OUT/$name -o p -- python $REPO/bench.py --steps ${PMC_STEPS:-6} --warmup ${PMC_WARMUP:-2} --no-cpu-baseline $PMC_BENCH_ARGS > $REPO/$OUT/$name.json 2> $REPO/$OUT/$name.err || echo "pass $name failed"; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
@@ -26,3 +26,5 @@ fi
 ls -R $REPO/$OUT | head -30
 # text summary per pass + profiles/pmc_traffic.json (HBM-side bytes per launch of the fused kernels; read by bench.py's roofline.traffic)
 python $REPO/tools/pmc_summarize.py $REPO/$OUT $REPO/$OUT/pmc_summary.txt $REPO/$OUT/pmc_traffic.json
+# (the per-pass databases of a long workload exceed what gpurun merges back: the text summary is what is kept)
+if [ -n "$PMC_DROP_DB" ]; then find $REPO/$OUT -name '*.db' -delete; fi
