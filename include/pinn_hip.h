@@ -261,6 +261,15 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
  *   "fp32"            — v_mfma_f32_16x16x4_f32: bit-for-bit an fmaf chain per product, for callers that need the last bit (a quasi-Newton
  *                       finisher at its noise floor: the reference's `solve(prob, BFGS())` stage, test/NNPDE1/nnpde__pde_iii_3rd_order_ode.jl:89-93,
  *                       runs on Float64 CPU arithmetic there).
+ *   "auto" (r06)      — the engine chooses between the two by MEASUREMENT: at the current parameters the gradient is evaluated with both arithmetics,
+ *                       delta = |grad(split) - grad(fp32)|_2 / |grad(fp32)|_2  (the split products' arithmetic error at this iterate); "split" runs
+ *                       while delta <= 1e-5 (the north star's tolerance), "fp32" above, back under 3e-6.  ~2e-7 at initialisation, 1e-5 / 4e-3 at the
+ *                       trained fixtures (cfg2 after 2,000 / 6,000 Adam steps).  Checked at the end of a pinn_adam_steps call (loop path) and inside
+ *                       pinn_loss_grad with a gradient, at most once per 1,000 optimiser steps / evaluations (two evaluations + at most two re-plans
+ *                       per check), never inside a resident loop.  pinn_get_option(h, "gemm") reports "auto(split)" / "auto(fp32)",
+ *                       "gemm_delta" the last delta, "grad_health" rho = |grad|_2 / sqrt(sum_k w_k L_k) of the last measured evaluation: rho against
+ *                       its value at initialisation is the cancellation factor of the gradient sum — once it has fallen by ~1e3 no fp32 evaluation holds
+ *                       1e-3 any more and "precision" = "f64" is the remedy (the glue's precision policy puts Float64 parameters there from the start).
  * Both kernel sets are in the library; switching rebuilds the handle's kernel plan in place (milliseconds) and keeps point sets, samplers,
  * per-point data / weights and the optimiser state.  Narrower nets (one-wave-per-tile kernels) and DGM nets compute on fp32 MFMAs / the
  * VALU in either mode.  $PINN_GEMM = split | fp32 sets the mode new handles start in.  pinn_get_option writes the current value.

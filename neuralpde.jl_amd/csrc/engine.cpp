@@ -561,6 +561,8 @@ int pinn_set_points_f64(pinn_handle h, int term, const double* pts, int64_t n, i
     return f64_set_points(*h, term, pts, n);                                    // the float64 mode reads the points as given
 }
 
+static void measure_grad_health(pinn_engine& E, const float* grad_and_sums, const float* term_w);
+static int gemm_auto_check(pinn_engine& E, const float* d_theta, const float* term_w, long long now);
 static bool eval_eligible(pinn_engine& E);
 static int eval_fused(pinn_engine& E, const float* d_theta, float* d_out, const float* term_w, double* lossraw);
 static bool train_timed_out(pinn_engine& E);
@@ -606,6 +608,13 @@ int pinn_loss_grad(pinn_handle h, const float* theta, int64_t p, const float* te
     if (term_losses)
         for (int k = 0; k < K; ++k) term_losses[k] = E.hp_raw[k] / (double)E.terms[k].n_norm;   // exact double sums
     if (grad) std::memcpy(grad, E.hp_out, sizeof(float) * E.ntheta);
+    if (grad && E.gemm_auto) {                           // "gemm" = "auto": this evaluation's gradient health decides the NEXT evaluation's GEMM mode
+        std::vector<float> gs((size_t)E.ntheta + K);
+        std::memcpy(gs.data(), E.hp_out, sizeof(float) * E.ntheta);
+        for (int k = 0; k < K; ++k) gs[(size_t)E.ntheta + k] = (float)E.hp_raw[k];
+        measure_grad_health(E, gs.data(), term_w);
+        if (gemm_auto_check(E, E.d_theta, term_w, ++E.eval_count)) return 1;
+    }
     return 0;
 }
 
@@ -1177,15 +1186,66 @@ static int replan_gemm(pinn_engine& E, int mode) {
     return rc;
 }
 
+// ---- "gemm" = "auto": WHEN to leave the split-bf16 products ----
+// The rule is a MEASUREMENT, not a heuristic: at the current parameters the gradient is evaluated with both GEMM arithmetics of the handle
+// (the split-bf16 products and their fp32-MFMA twin: an fmaf chain per product) and compared,
+//     delta = |grad(split) - grad(fp32)|_2 / |grad(fp32)|_2 ,
+// which IS the split products' arithmetic error at this iterate up to the twin's own (2 - 7 x smaller, profiles/r05_theta_variants_ab.txt
+// section F).  "split" is kept while delta <= 1e-5 (the north star's tolerance), "fp32" runs above; an fp32 handle goes back when delta has
+// fallen under 3e-6.  At initialisation delta ~ 2e-7; on the trained fixtures (cfg2 after 2,000 / 6,000 Adam steps) 1e-5 / 4e-3: the policy leaves
+// the fast products exactly where parity starts to depend on them.  Cost: two evaluations and at most two re-plans (milliseconds) per check; checks
+// run at the end of a pinn_adam_steps call (loop path) and inside pinn_loss_grad with a gradient, at most once per GEMM_CHECK_EVERY optimiser
+// steps / evaluations, never inside a resident loop.  Also reported: rho = |grad|_2 / sqrt(L) ("grad_health"): |grad| <= 2 sqrt(L) J_rms, so rho
+// against its value at initialisation is the cancellation factor of the gradient sum — when it has fallen by ~1e3 no fp32 arithmetic holds 1e-3
+// any more and "precision" = "f64" is the remedy (the glue's precision policy puts Float64 parameters there from the start).
+constexpr double GEMM_DELTA_UP = 1e-5, GEMM_DELTA_DOWN = 3e-6;
+constexpr long long GEMM_CHECK_EVERY = 1000;
+static void measure_grad_health(pinn_engine& E, const float* grad_and_sums, const float* term_w) {
+    const int K = (int)E.terms.size();
+    const int64_t P = E.ntheta;
+    double g2 = 0.0, L = 0.0;
+    for (int64_t i = 0; i < P; ++i) g2 += (double)grad_and_sums[i] * (double)grad_and_sums[i];
+    for (int k = 0; k < K; ++k) L += (term_w ? (double)term_w[k] : 1.0) * (double)grad_and_sums[P + k] / (double)E.terms[k].n_norm;
+    E.grad_health = L > 0.0 ? std::sqrt(g2) / std::sqrt(L) : -1.0;
+}
+static int replan_gemm(pinn_engine& E, int mode);
+// the policy's check at the device-resident parameters d_theta (clock: `now` optimiser steps / evaluations)
+static int gemm_auto_check(pinn_engine& E, const float* d_theta, const float* term_w, long long now) {
+    if (!E.gemm_auto || E.f64 || E.comm) return 0;
+    if (E.gemm_check_t >= 0 && now - E.gemm_check_t < GEMM_CHECK_EVERY && now >= E.gemm_check_t) return 0;
+    bool has_twin = false;
+    for (const NetPlan& NP : E.netplans) has_twin = has_twin || (NP.spec && NP.spec->family == 2 && NP.spec->twin);
+    if (!has_twin) return 0;
+    const int64_t P = E.ntheta;
+    const int start = E.gemm;
+    std::vector<float> ga((size_t)P), gb((size_t)P);
+    if (run_loss_grad(E, d_theta, E.d_out, term_w, -1, false)) return 1;
+    if (plat_d2h(ga.data(), E.d_out, sizeof(float) * P, E.stream) || plat_sync(E.stream)) return fail("D2H copy failed");
+    if (replan_gemm(E, start == pk::GEMM_SPLIT ? pk::GEMM_FP32 : pk::GEMM_SPLIT)) return 1;
+    if (E.gemm == start) return 0;                       // (the twin could not be built: the handle stays where it was)
+    if (run_loss_grad(E, d_theta, E.d_out, term_w, -1, false)) return 1;
+    if (plat_d2h(gb.data(), E.d_out, sizeof(float) * P, E.stream) || plat_sync(E.stream)) return fail("D2H copy failed");
+    const std::vector<float>& gs = start == pk::GEMM_SPLIT ? ga : gb;      // split / fp32 gradients
+    const std::vector<float>& gf = start == pk::GEMM_SPLIT ? gb : ga;
+    double d2 = 0.0, n2 = 0.0;
+    for (int64_t i = 0; i < P; ++i) { const double d = (double)gs[(size_t)i] - (double)gf[(size_t)i]; d2 += d * d; n2 += (double)gf[(size_t)i] * (double)gf[(size_t)i]; }
+    E.gemm_delta = n2 > 0.0 ? std::sqrt(d2 / n2) : 0.0;
+    E.gemm_check_t = now;
+    const int want = (start == pk::GEMM_SPLIT) ? (E.gemm_delta > GEMM_DELTA_UP ? pk::GEMM_FP32 : pk::GEMM_SPLIT)
+                                               : (E.gemm_delta < GEMM_DELTA_DOWN ? pk::GEMM_SPLIT : pk::GEMM_FP32);
+    return replan_gemm(E, want);
+}
+
 int pinn_set_option(pinn_handle h, const char* name, const char* value) {
     if (!h || !name || !value) return fail("pinn_set_option: null argument");
     pinn_engine& E = *h;
     DeviceScope scope(E.device);
     const std::string k = name, v = value;
     if (k == "gemm") {
-        if (v == "split") return replan_gemm(E, pk::GEMM_SPLIT);
-        if (v == "fp32") return replan_gemm(E, pk::GEMM_FP32);
-        return fail("pinn_set_option: gemm must be \"split\" or \"fp32\"");
+        if (v == "split") { E.gemm_auto = false; return replan_gemm(E, pk::GEMM_SPLIT); }
+        if (v == "fp32") { E.gemm_auto = false; return replan_gemm(E, pk::GEMM_FP32); }
+        if (v == "auto") { E.gemm_auto = true; E.gemm_check_t = -1; return 0; }
+        return fail("pinn_set_option: gemm must be \"split\", \"fp32\" or \"auto\"");
     }
     if (k == "precision") {
         if (v == "f64") return f64_enable(E);
@@ -1208,14 +1268,16 @@ int pinn_set_option(pinn_handle h, const char* name, const char* value) {
 int pinn_get_option(pinn_handle h, const char* name, char* buf, int64_t buflen) {
     if (!h || !name || !buf || buflen <= 0) return fail("pinn_get_option: bad argument");
     const std::string k = name;
-    if (k == "gemm") { std::snprintf(buf, (size_t)buflen, "%s", h->gemm == pk::GEMM_FP32 ? "fp32" : "split"); return 0; }
+    if (k == "gemm") { std::snprintf(buf, (size_t)buflen, h->gemm_auto ? "auto(%s)" : "%s", h->gemm == pk::GEMM_FP32 ? "fp32" : "split"); return 0; }
+    if (k == "grad_health") { std::snprintf(buf, (size_t)buflen, "%.9g", h->grad_health); return 0; }
+    if (k == "gemm_delta") { std::snprintf(buf, (size_t)buflen, "%.9g", h->gemm_delta); return 0; }
     if (k == "precision") { std::snprintf(buf, (size_t)buflen, "%s", h->f64 ? "f64" : "f32"); return 0; }
     if (k == "persistent") { std::snprintf(buf, (size_t)buflen, "%s", h->persistent ? "on" : "off"); return 0; }
     if (k == "derivative") { std::snprintf(buf, (size_t)buflen, "%s", pe::f64_stencil_on(*h) ? "stencil" : "exact"); return 0; }
     if (k == "eval_path") { std::snprintf(buf, (size_t)buflen, "%s", h->eval_path == 2 ? "one launch" : (h->eval_path == 1 ? "stand-alone kernels" : "none")); return 0; }
     if (k == "f64_path") { std::snprintf(buf, (size_t)buflen, "%s", pe::f64_path(*h)); return 0; }
     if (k == "adam_path") { std::snprintf(buf, (size_t)buflen, "%s", h->adam_path == 2 ? "persistent" : (h->adam_path == 1 ? "loop" : "none")); return 0; }
-    return fail("pinn_get_option: unknown option \"" + k + "\" (known: gemm, precision, persistent, derivative, adam_path, eval_path, f64_path)");
+    return fail("pinn_get_option: unknown option \"" + k + "\" (known: gemm, precision, persistent, derivative, grad_health, gemm_delta, adam_path, eval_path, f64_path)");
 }
 
 int pinn_adam_init(pinn_handle h, const float* theta, int64_t p) {
@@ -1739,7 +1801,16 @@ int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta
         if (adam_loop(es, 1, nsteps, lr, beta1, beta2, eps, term_w)) return 1;
     }
     if (loss_history && plat_d2h(loss_history, E.d_hist, sizeof(double) * nsteps, E.stream)) return fail("D2H copy failed");
+    std::vector<float> gs;
+    if (E.gemm_auto && !E.comm) {                        // "gemm" = "auto": the last step's [gradient | raw sums] (one small copy per CALL)
+        gs.resize((size_t)E.ntheta + K);
+        if (plat_d2h(gs.data(), E.d_opt_out, sizeof(float) * gs.size(), E.stream)) return fail("D2H copy failed");
+    }
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    if (!gs.empty()) {
+        measure_grad_health(E, gs.data(), term_w);
+        if (gemm_auto_check(E, E.d_opt_theta, term_w, E.opt_t)) return 1;      // (the optimiser state survives a re-plan: replan_gemm)
+    }
     return 0;
 }
 

@@ -203,6 +203,11 @@ struct pinn_engine {
     std::vector<NetPlan> netplans;
     int ncu = 0;
     int gemm = pk::GEMM_SPLIT;       // GEMM arithmetic of the neuron-split kernels of this handle (pinn_set_option "gemm"; $PINN_GEMM at pinn_create)
+    bool gemm_auto = false;          // pinn_set_option(h, "gemm", "auto"): the engine picks split / fp32 from the gradient-health figure below
+    double grad_health = -1.0;       // rho = |grad sum_k w_k L_k|_2 / sqrt(sum_k w_k L_k) of the last evaluation that measured it (-1: none yet)
+    double gemm_delta = -1.0;        // last measured |grad(split) - grad(fp32)|_2 / |grad(fp32)|_2 at one theta (-1: none yet)
+    long long gemm_check_t = -1;     // optimiser step / evaluation count of the last such comparison
+    long long eval_count = 0;        // host-entry evaluations with a gradient (the "clock" of the policy outside the resident loop)
     int device = 0;                  // the HIP device this handle lives on (pinn_create: the caller's current device; pinn_create_on)
     // engine-owned data-parallel collective (comm.cpp): communicator of this handle's rank, nullptr = single device
     void* comm = nullptr;

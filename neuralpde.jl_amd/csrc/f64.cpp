@@ -296,6 +296,7 @@ static int f64_build(pinn_engine& E, const F64Term& F, int dt, const std::map<in
     L.sin_act = false;
     L.mfma = F.km && std::getenv("PINN_F64_NO_MFMA") == nullptr;
     L.sliced = L.mfma && F.km->sliced != 0;
+    a.use_ceff = L.sliced ? 1 : 0;
     for (int ni = 0; ni < a.nnets; ++ni) {
         const Net& N = E.nets[F.nets[ni]];
         pk::F64Net& n = a.net[ni];
@@ -315,6 +316,9 @@ static int f64_build(pinn_engine& E, const F64Term& F, int dt, const std::map<in
         }
         n.sizes[n.nl] = N.sizes[n.nl];
         n.act = N.act;
+        n.ceff = 1;
+        for (int sl = 0; sl < F.nslots; ++sl) if (F.slot_net[sl] == ni) n.ceff = std::max(n.ceff, F.slot_chan[sl] + 1);
+        if (std::getenv("PINN_F64_FULL_CHANNELS")) n.ceff = a.C;              // (A/B, tests)
         L.sin_act = L.sin_act || N.act == pk::ACT_SIN;
         n.theta0 = N.theta_off; n.nparams = N.nparams(); n.ent0 = ent;
         ent += n.nparams;

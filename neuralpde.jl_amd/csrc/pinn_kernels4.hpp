@@ -40,6 +40,9 @@ struct F64Net {
     int theta0, nparams, ent0;          // the network's slice of theta; its first slab entry
     int tp0;                            // matrix-pipe kernels: first column of this network in a tile's row of partial sums (F64Args::tpart):
                                         // [W_0: n_1 * d][b_0: n_1][W_L: n_L][b_L]
+    int ceff;                           // channel PREFIX this term reads from the network (1 + its highest referenced jet channel; a channel only depends on
+                                        // lower ones): the sliced kernels (pinn_kernels6.hpp) carry channels [0, ceff) of this network and leave the rest zero —
+                                        // an equation that couples several networks needs the full set from one of them only (cfg4: u 5, v 1, p 2 of C = 5)
 };
 struct F64Args {
     const double* theta;                // the whole parameter vector
@@ -70,6 +73,7 @@ struct F64Args {
     // own tape: record [seed_stride] per point = { d loss / d u(point), squared weighted residual, PDE-parameter partials [ne] }; nullptr: off
     const double* seed;
     int seed_stride;
+    int use_ceff;                       // 1: the scratch rows hold channels [0, F64Net::ceff) of every network only (written by a sliced tile kernel): the dW kernels stop there
     // weight-gradient kernel
     int C, first_ch[8];                 // channel of d/dx_i (-1: not carried)
     double* slab;                       // [nblocks][nent], nent = sum of the networks' parameters + ne + 1 (last entry: the block's sum of squares)

@@ -581,18 +581,19 @@ DEV void f64m_dwt_wave(int ni, int lyr, int b, int w, const F64Args& a, F64mDwtA
             }
         }
     };
-    const int nsteps = ((hi - lo + 15) / 16) * C;                // step i: points lo + 16 (i / C) .., channel i % C; this wave: i = w, w + 4, ...
+    const int CE = a.use_ceff ? n.ceff : C;                      // (behind a sliced tile kernel only the channel prefix of the network was written)
+    const int nsteps = ((hi - lo + 15) / 16) * CE;               // step i: points lo + 16 (i / CE) .., channel i % CE; this wave: i = w, w + 4, ...
     int i = w;
 #if PINN_F64M_DWT_SINGLE
-    for (; i < nsteps; i += F64M_DWT_WAVES) { load_step(Af[0], Bf[0], lo + 16 * (i / C), i % C); mma_step(Af[0], Bf[0], i % C); }
+    for (; i < nsteps; i += F64M_DWT_WAVES) { load_step(Af[0], Bf[0], lo + 16 * (i / CE), i % CE); mma_step(Af[0], Bf[0], i % CE); }
 #endif
-    if (i < nsteps) load_step(Af[0], Bf[0], lo + 16 * (i / C), i % C);
+    if (i < nsteps) load_step(Af[0], Bf[0], lo + 16 * (i / CE), i % CE);
     for (; i < nsteps; i += 2 * F64M_DWT_WAVES) {
         const int i1 = i + F64M_DWT_WAVES, i2 = i + 2 * F64M_DWT_WAVES;
-        if (i1 < nsteps) load_step(Af[1], Bf[1], lo + 16 * (i1 / C), i1 % C);
-        mma_step(Af[0], Bf[0], i % C);
-        if (i2 < nsteps) load_step(Af[0], Bf[0], lo + 16 * (i2 / C), i2 % C);
-        if (i1 < nsteps) mma_step(Af[1], Bf[1], i1 % C);
+        if (i1 < nsteps) load_step(Af[1], Bf[1], lo + 16 * (i1 / CE), i1 % CE);
+        mma_step(Af[0], Bf[0], i % CE);
+        if (i2 < nsteps) load_step(Af[0], Bf[0], lo + 16 * (i2 / CE), i2 % CE);
+        if (i1 < nsteps) mma_step(Af[1], Bf[1], i1 % CE);
     }
 }
 // wave w's turn of the fixed-order combine through `lds` ([HT * HT * 4 + HT][64] doubles): wave 0 stores, waves 1, 2 add, wave 3 adds and writes the slab

@@ -48,8 +48,8 @@ DEV void f64s_tile(int tile, const F64Args& a, double* ulds /* [F64_MAX_NETS][C]
     const bool rev = a.mode == 0;
     // one GEMM pass: Z[rows of the layer `n_out` wide][group g0 .. g0 + CG) = A (n_out x n_in, element (m, k) at Aw[m * sm + k * sk]) x B rows
     // `brow` (n_in neurons x C channels), (+ bias on channel 0), stored to rows `zrow`
-    auto gemm = [&](const double* Aw, int sm, int sk, int n_out, int n_in, int brow, int zrow, const double* bias) {
-        for (int g0 = 0; g0 < C; g0 += CG) {
+    auto gemm = [&](const double* Aw, int sm, int sk, int n_out, int n_in, int brow, int zrow, const double* bias, int ce) {
+        for (int g0 = 0; g0 < ce; g0 += CG) {
             LVd<NR * CG> Z;
             PINN_LANES(l) { PINN_UNROLL for (int e = 0; e < NR * CG; ++e) Z(l, e) = 0.0; }
             // operand ring: the fragments of k-block kb + PD are requested before the MFMAs of k-block kb (HT x CG MFMAs of 64 cycles each: one
@@ -70,7 +70,7 @@ DEV void f64s_tile(int tile, const F64Args& a, double* ulds /* [F64_MAX_NETS][C]
                     const double* pb = S + f64m_six(a, (size_t)brow + (size_t)((l >> 4) * C + g0), pbase + (l & 15));
                     PINN_UNROLL for (int g = 0; g < CG; ++g) {
                         const double v = pb[(4 * kb * C + g) * 16];
-                        B_(l, g) = (kin && g0 + g < C) ? v : 0.0;
+                        B_(l, g) = (kin && g0 + g < ce) ? v : 0.0;
                     }
                 }
             };
@@ -89,7 +89,7 @@ DEV void f64s_tile(int tile, const F64Args& a, double* ulds /* [F64_MAX_NETS][C]
                     if (m < n_out) {
                         PINN_UNROLL for (int g = 0; g < CG; ++g) {
                             const int c = g0 + g;
-                            if (c < C) S[f64m_six(a, (size_t)zrow + (size_t)m * C + c, pbase + (l & 15))] = Z(l, tr * CG + g) + ((bias && c == 0) ? bias[m] : 0.0);
+                            if (c < ce) S[f64m_six(a, (size_t)zrow + (size_t)m * C + c, pbase + (l & 15))] = Z(l, tr * CG + g) + ((bias && c == 0) ? bias[m] : 0.0);
                         }
                     }
                 }
@@ -100,6 +100,7 @@ DEV void f64s_tile(int tile, const F64Args& a, double* ulds /* [F64_MAX_NETS][C]
     for (int ni = 0; ni < a.nnets; ++ni) {
         const F64Net& n = a.net[ni];
         const int L = n.nl - 1;
+        const int ce = n.ceff;                                   // channels [0, ce) of this network are carried (F64Net::ceff), the rest stay zero
         LVd<C> u;                                                // this lane's partial sums of the output layer over its neurons
         PINN_LANES(l) { PINN_UNROLL for (int c = 0; c < C; ++c) u(l, c) = 0.0; }
         const double* WL = a.theta + n.woff[L];
@@ -107,7 +108,7 @@ DEV void f64s_tile(int tile, const F64Args& a, double* ulds /* [F64_MAX_NETS][C]
             const int n_in = n.sizes[lyr], n_out = n.sizes[lyr + 1];
             const double* W = a.theta + n.woff[lyr];
             const double* B = a.theta + n.boff[lyr];
-            if (lyr > 0) gemm(W, 1, n_out, n_out, n_in, n.r_post[lyr - 1], n.r_rec[lyr], B);
+            if (lyr > 0) gemm(W, 1, n_out, n_out, n_in, n.r_post[lyr - 1], n.r_rec[lyr], B, ce);
             // element-wise pass: pre-activation jets (layer 0: formed here) -> record, post-activation jets (last hidden layer: straight into the output sums).
             // TB tile rows at a time with every load of the batch in flight before the first use: one element per iteration would expose a full
             // memory round trip per element (2 waves per SIMD cover nothing) — the first version of this kernel spent 14 x its MFMA time here
@@ -126,9 +127,9 @@ DEV void f64s_tile(int tile, const F64Args& a, double* ulds /* [F64_MAX_NETS][C]
                             for (int i = 0; i < n.d; ++i) z0 = vfma(W[mc + (size_t)i * n_out], x[i], z0);
                             PINN_UNROLL for (int c = 0; c < C; ++c) z[b][c] = 0.0;
                             z[b][0] = z0;
-                            PINN_UNROLL for (int kf = 0; kf < J::NFIRST; ++kf) z[b][J::CH_FIRST + kf] = W[mc + (size_t)J::first_axis(kf) * n_out];
+                            PINN_UNROLL for (int kf = 0; kf < J::NFIRST; ++kf) z[b][J::CH_FIRST + kf] = (J::CH_FIRST + kf < ce) ? W[mc + (size_t)J::first_axis(kf) * n_out] : 0.0;
                         } else {
-                            PINN_UNROLL for (int c = 0; c < C; ++c) z[b][c] = S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)mc * C + c, p)];
+                            PINN_UNROLL for (int c = 0; c < C; ++c) z[b][c] = (c < ce) ? S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)mc * C + c, p)] : 0.0;
                         }
                         wl[b] = (lyr == L - 1 && m < n_out) ? WL[mc] : 0.0;
                     }
@@ -138,7 +139,7 @@ DEV void f64s_tile(int tile, const F64Args& a, double* ulds /* [F64_MAX_NETS][C]
                         const double a0 = act_value<SIN>(n.act, z[b][0]);
                         z[b][0] = act_record<SIN>(z[b][0], a0);
                         if (rev && valid) {
-                            if (lyr == 0) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)m * C + c, p)] = z[b][c]; }
+                            if (lyr == 0) { PINN_UNROLL for (int c = 0; c < C; ++c) if (c < ce) S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)m * C + c, p)] = z[b][c]; }
                             else if (!SIN) S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)m * C, p)] = z[b][0];
                         }
                         double dd[ND];
@@ -147,7 +148,7 @@ DEV void f64s_tile(int tile, const F64Args& a, double* ulds /* [F64_MAX_NETS][C]
                         z[b][0] = a0;
                         if (lyr < L - 1) {
                             // (value-only tanh / sigmoid terms: r_post == r_rec, the activation IS the record — the store above already wrote it when rev)
-                            if (valid && !(a.post_alias && rev)) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_post[lyr] + (size_t)m * C + c, p)] = z[b][c]; }
+                            if (valid && !(a.post_alias && rev)) { PINN_UNROLL for (int c = 0; c < C; ++c) if (c < ce) S[f64m_six(a, (size_t)n.r_post[lyr] + (size_t)m * C + c, p)] = z[b][c]; }
                         } else {
                             PINN_UNROLL for (int c = 0; c < C; ++c) u(l, c) = vfma(wl[b], z[b][c], u(l, c));
                         }
@@ -231,6 +232,7 @@ DEV void f64s_tile(int tile, const F64Args& a, double* ulds /* [F64_MAX_NETS][C]
     for (int ni = 0; ni < a.nnets; ++ni) {
         const F64Net& n = a.net[ni];
         const int L = n.nl - 1;
+        const int ce = n.ceff;
         {                                                        // output-bias gradient: the tile's sum of the value seeds
             LVd<1> bl;
             PINN_LANES(l) { bl(l, 0) = (l >> 4) == 0 ? ulds[(ni * C) * 16 + (l & 15)] : 0.0; }
@@ -242,7 +244,7 @@ DEV void f64s_tile(int tile, const F64Args& a, double* ulds /* [F64_MAX_NETS][C]
             const int n_next = n.sizes[lyr + 2];
             const double* Wn = a.theta + n.woff[lyr + 1];            // W_{lyr+1}[m + k * n_next]
             // G = W_{lyr+1}^T dZ_{lyr+1} into this layer's dZ rows (the output layer's row vector: formed per element below)
-            if (lyr < L - 1) gemm(Wn, n_next, 1, H, n_next, n.r_dz[lyr + 1], n.r_dz[lyr], nullptr);
+            if (lyr < L - 1) gemm(Wn, n_next, 1, H, n_next, n.r_dz[lyr + 1], n.r_dz[lyr], nullptr, ce);
             for (int tr0 = 0; tr0 < NR; tr0 += TB) {
                 if (16 * (tr0 >> 2) >= H) break;
                 LVd<6 * TB> T6;                                      // per row of the batch: [0, d) dW_0[m][i], [4] db_0[m], [5] dW_L[m]
@@ -254,12 +256,12 @@ DEV void f64s_tile(int tile, const F64Args& a, double* ulds /* [F64_MAX_NETS][C]
                     if (lyr == L - 1) { PINN_UNROLL for (int c = 0; c < C; ++c) ub[c] = ulds[(ni * C + c) * 16 + j]; }
                     PINN_UNROLL for (int b = 0; b < TB; ++b) {
                         const int tr = tr0 + b, k = 16 * (tr >> 2) + 4 * (tr & 3) + q, kc = k < H ? k : H - 1;
-                        PINN_UNROLL for (int c = 0; c < C; ++c) s[b][c] = S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)kc * C + c, p)];
+                        PINN_UNROLL for (int c = 0; c < C; ++c) s[b][c] = (c < ce) ? S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)kc * C + c, p)] : 0.0;
                         if (lyr == L - 1) {
                             const double w = k < H ? Wn[kc] : 0.0;
                             PINN_UNROLL for (int c = 0; c < C; ++c) gq[b][c] = w * ub[c];
                         } else {
-                            PINN_UNROLL for (int c = 0; c < C; ++c) gq[b][c] = S[f64m_six(a, (size_t)n.r_dz[lyr] + (size_t)kc * C + c, p)];
+                            PINN_UNROLL for (int c = 0; c < C; ++c) gq[b][c] = (c < ce) ? S[f64m_six(a, (size_t)n.r_dz[lyr] + (size_t)kc * C + c, p)] : 0.0;
                         }
                     }
                     PINN_UNROLL for (int b = 0; b < TB; ++b) {
@@ -277,7 +279,7 @@ DEV void f64s_tile(int tile, const F64Args& a, double* ulds /* [F64_MAX_NETS][C]
                             t6[5] = st ? t2 : 0.0;
                         }
                         jet_adjoint<J>(gq[b], s[b], dd);
-                        if (valid && lyr > 0) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_dz[lyr] + (size_t)k * C + c, p)] = st ? gq[b][c] : 0.0; }
+                        if (valid && lyr > 0) { PINN_UNROLL for (int c = 0; c < C; ++c) if (c < ce) S[f64m_six(a, (size_t)n.r_dz[lyr] + (size_t)k * C + c, p)] = st ? gq[b][c] : 0.0; }
                         if (lyr == 0) {
                             const double z0 = st ? gq[b][0] : 0.0;
                             t6[4] = z0;
@@ -325,7 +327,7 @@ DEV void f64s_dwt_wave(int ni, int lyr, int b, int w, const F64Args& a) {
     constexpr int OW = HT / F64M_DWT_WAVES;                      // output tiles per wave
     static_assert(OW >= 1 && OW * F64M_DWT_WAVES == HT, "the split dW kernel needs HT a multiple of the wave count");
     const F64Net& n = a.net[ni];
-    const int n_out = n.sizes[lyr + 1], n_in = n.sizes[lyr], C = a.C;
+    const int n_out = n.sizes[lyr + 1], n_in = n.sizes[lyr], C = a.C, CE = n.ceff;      // rows of channels >= CE are never written (F64Net::ceff)
     const int lo = b * F64_BLOCK, hi = (lo + F64_BLOCK < a.npts) ? lo + F64_BLOCK : a.npts;
     const double* S = a.scratch;
     LVd<OW * HT * 4> acc;
@@ -334,9 +336,9 @@ DEV void f64s_dwt_wave(int ni, int lyr, int b, int w, const F64Args& a) {
         PINN_UNROLL for (int e = 0; e < OW * HT * 4; ++e) acc(l, e) = 0.0;
         PINN_UNROLL for (int t = 0; t < OW; ++t) bsum(l, t) = 0.0;
     }
-    const int nsteps = ((hi - lo + 15) / 16) * C;
+    const int nsteps = ((hi - lo + 15) / 16) * CE;
     for (int i = 0; i < nsteps; ++i) {
-        const int p = lo + 16 * (i / C), c = i % C;
+        const int p = lo + 16 * (i / CE), c = i % CE;
         LVd<OW * 4> A_;
         LVd<HT * 4> B_;
         PINN_LANES(l) {
