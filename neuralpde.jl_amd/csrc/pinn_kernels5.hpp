@@ -29,6 +29,12 @@
 #ifndef PINN_F64M_DEFER
 #define PINN_F64M_DEFER 1               // a layer's scratch stores ride inside the NEXT GEMM's MFMA stream (f64m_tile); 0: issued by the activation loop (A/B)
 #endif
+#ifndef PINN_F64M_CAP
+#define PINN_F64M_CAP 2                 // column groups per wave of the small-jet-set kernels (value-only terms: PG = CAP point groups per tile); A/B
+#endif
+#ifndef PINN_F64M_WAVES_SMALL
+#define PINN_F64M_WAVES_SMALL 2         // waves per SIMD the kernels with HT x PG x C <= 8 are compiled for (A/B: 4 with CAP = 1)
+#endif
 #ifndef PINN_F64M_PROBE
 #define PINN_F64M_PROBE 0               // timing probes (tools only, wrong numbers): 1 no rolling reload of the weight fragments, 2 no scratch stores, 4 no activation function, 8 no lane predicates on the element loops (full-width nets and full tiles only)
 #endif
@@ -701,7 +707,7 @@ template <int HT> void launch_f64m_dwt(const F64Args& a, plat_stream) {
         }
 }
 #else
-template <class J, int HT, int PG> __global__ void __launch_bounds__(64, (HT * PG * J::C <= 8) ? 2 : 1) k_f64m_tile(const F64Args a) {
+template <class J, int HT, int PG> __global__ void __launch_bounds__(64, (HT * PG * J::C <= 8) ? ((HT * PG * J::C <= 4) ? PINN_F64M_WAVES_SMALL : 2) : 1) k_f64m_tile(const F64Args a) {
     f64m_tile<J, HT, PG, ACT_TANH>((int)blockIdx.x, a);
 }
 template <int HT> __global__ void __launch_bounds__(64 * F64M_DWT_WAVES, PINN_F64M_DWT_SINGLE ? 2 : 1) k_f64m_dwt(const F64Args a) {
@@ -815,7 +821,7 @@ template <int D, unsigned D1MASK, unsigned long long PAIRS, int NPAIR, unsigned 
     // column groups per wave: as many point groups as keep the two operand arrays (2 x HT * 4 * NCG doubles per lane) inside the register file
     // ... and, where the channel count allows it, few enough (NCG <= 2: the operand arrays take <= 128 registers) that TWO waves fit a SIMD —
     // one wave's element-wise float64 work (the activation alone is ~45 f64 instructions per element) then runs under the other's MFMAs
-    constexpr int CAP = 2;
+    constexpr int CAP = PINN_F64M_CAP;
     constexpr int PG = (J::C >= CAP) ? 1 : CAP / J::C;
     static_assert(HT * PG * J::C <= 24, "operand arrays of this (jet set, width) pair exceed the register file: keep family 4");
     F64MKernel k;

@@ -70,7 +70,7 @@ DEV void f64s_tile(int tile, const F64Args& a, double* ulds /* [F64_MAX_NETS][C]
                     const double* pb = S + f64m_six(a, (size_t)brow + (size_t)((l >> 4) * C + g0), pbase + (l & 15));
                     PINN_UNROLL for (int g = 0; g < CG; ++g) {
                         const double v = pb[(4 * kb * C + g) * 16];
-                        B_(l, g) = (kin && g0 + g < ce) ? v : 0.0;
+                        B_(l, g) = kin ? v : 0.0;            // (a column group past the channel prefix multiplies whatever lies there: its Z columns are never stored)
                     }
                 }
             };
@@ -115,6 +115,7 @@ DEV void f64s_tile(int tile, const F64Args& a, double* ulds /* [F64_MAX_NETS][C]
             PINN_LANES(l) {
                 const int q = l >> 4, j = l & 15;
                 const int p = pbase + j, pc = p < a.npts ? p : a.npts - 1;
+                const int ce_v = opaque_lane(ce);                    // (selects, not uniform branches, around the loads below)
                 double x[4] = {0.0, 0.0, 0.0, 0.0};
                 if (lyr == 0) { for (int i = 0; i < n.d; ++i) x[i] = a.pts[(size_t)(a.p0 + pc) * a.dt + n.imap[i]]; }
                 for (int tr0 = 0; tr0 < NR; tr0 += TB) {
@@ -127,9 +128,9 @@ DEV void f64s_tile(int tile, const F64Args& a, double* ulds /* [F64_MAX_NETS][C]
                             for (int i = 0; i < n.d; ++i) z0 = vfma(W[mc + (size_t)i * n_out], x[i], z0);
                             PINN_UNROLL for (int c = 0; c < C; ++c) z[b][c] = 0.0;
                             z[b][0] = z0;
-                            PINN_UNROLL for (int kf = 0; kf < J::NFIRST; ++kf) z[b][J::CH_FIRST + kf] = (J::CH_FIRST + kf < ce) ? W[mc + (size_t)J::first_axis(kf) * n_out] : 0.0;
+                            PINN_UNROLL for (int kf = 0; kf < J::NFIRST; ++kf) { const double wv = W[mc + (size_t)J::first_axis(kf) * n_out]; z[b][J::CH_FIRST + kf] = (J::CH_FIRST + kf < ce_v) ? wv : 0.0; }
                         } else {
-                            PINN_UNROLL for (int c = 0; c < C; ++c) z[b][c] = (c < ce) ? S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)mc * C + c, p)] : 0.0;
+                            PINN_UNROLL for (int c = 0; c < C; ++c) { const double v = S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)mc * C + c, p)]; z[b][c] = (c < ce_v) ? v : 0.0; }
                         }
                         wl[b] = (lyr == L - 1 && m < n_out) ? WL[mc] : 0.0;
                     }
@@ -251,17 +252,18 @@ DEV void f64s_tile(int tile, const F64Args& a, double* ulds /* [F64_MAX_NETS][C]
                 PINN_LANES(l) {
                     const int q = l >> 4, j = l & 15;
                     const int p = pbase + j, pc = p < a.npts ? p : a.npts - 1;
+                    const int ce_v = opaque_lane(ce);
                     double s[TB][C], gq[TB][C], ub[C], xin[4] = {0.0, 0.0, 0.0, 0.0};
                     if (lyr == 0) { for (int i = 0; i < n.d; ++i) xin[i] = a.pts[(size_t)(a.p0 + pc) * a.dt + n.imap[i]]; }
                     if (lyr == L - 1) { PINN_UNROLL for (int c = 0; c < C; ++c) ub[c] = ulds[(ni * C + c) * 16 + j]; }
                     PINN_UNROLL for (int b = 0; b < TB; ++b) {
                         const int tr = tr0 + b, k = 16 * (tr >> 2) + 4 * (tr & 3) + q, kc = k < H ? k : H - 1;
-                        PINN_UNROLL for (int c = 0; c < C; ++c) s[b][c] = (c < ce) ? S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)kc * C + c, p)] : 0.0;
+                        PINN_UNROLL for (int c = 0; c < C; ++c) { const double v = S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)kc * C + c, p)]; s[b][c] = (c < ce_v) ? v : 0.0; }
                         if (lyr == L - 1) {
                             const double w = k < H ? Wn[kc] : 0.0;
                             PINN_UNROLL for (int c = 0; c < C; ++c) gq[b][c] = w * ub[c];
                         } else {
-                            PINN_UNROLL for (int c = 0; c < C; ++c) gq[b][c] = (c < ce) ? S[f64m_six(a, (size_t)n.r_dz[lyr] + (size_t)kc * C + c, p)] : 0.0;
+                            PINN_UNROLL for (int c = 0; c < C; ++c) { const double v = S[f64m_six(a, (size_t)n.r_dz[lyr] + (size_t)kc * C + c, p)]; gq[b][c] = (c < ce_v) ? v : 0.0; }
                         }
                     }
                     PINN_UNROLL for (int b = 0; b < TB; ++b) {

@@ -116,6 +116,7 @@ inline void tape_zero(vtape& t) { for (int i = 0; i < 32; ++i) t.r[i] = vfloat(0
 // 16-byte record at a wave-uniform address (device: scalar-cache load)
 struct urec16 { int x, y, z, w; };
 inline void sched_fence() {}
+inline int opaque_lane(int x) { return x; }
 template <int N> inline void lds_wait() {}
 inline void chain_fence() {}
 inline void store_pad() {}
@@ -403,6 +404,9 @@ DEV void tape_zero(vtape& t) { PINN_UNROLL for (int i = 0; i < PINN_TAPE_ROWS; +
 // (which also drains every outstanding record store) and its fields need waterfall loops to be used as register indices.
 // the instruction scheduler may not move anything across this point (keeps a block of prefetch loads where it was written)
 DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// a value the compiler must treat as per-lane (divergent): conditions on it become selects (v_cndmask) instead of uniform branches — around a load a
+// uniform branch costs the load its place in the batch of loads in flight (pinn_kernels6.hpp)
+DEV int opaque_lane(int x) { asm volatile("" : "+v"(x)); return x; }
 // Wait until at most N of this wave's LDS operations are outstanding (s_waitcnt lgkmcnt(N); vmcnt / expcnt untouched).  Placed in FRONT of a
 // chain of MFMAs that accumulate into one register tuple: left alone, the compiler waits for every operand at its first use, i.e. puts
 // s_waitcnt instructions BETWEEN the dependent MFMAs of the chain — and one extra issue state between two MFMAs on the same accumulator costs
