@@ -613,10 +613,10 @@ static int f64_eval_device(pinn_engine& E, const double* theta, double* grad, do
     const int K = (int)E.terms.size();
     const int64_t P = E.ntheta;
     if (theta != S.d_theta && theta != S.d_opt_theta) {
-        // a CALLER's device buffer (pinn_loss_grad_device_f64): the sliced kernels read up to F64S_PAD_THETA doubles past a narrow layer's matrix —
+        // a CALLER's device buffer (pinn_loss_grad_device_f64): the matrix-pipe kernels read up to F64S_PAD_THETA doubles past a narrow layer's matrix —
         // evaluate from the handle's padded copy (P doubles device to device: microseconds)
-        bool sliced = false;
-        for (auto& F : S.terms) sliced = sliced || (F.km && F.km->sliced);
+        bool sliced = false;                             // (r06: family 4m reads unclamped weight fragments as well)
+        for (auto& F : S.terms) sliced = sliced || F.km != nullptr;
         if (sliced) {
             if (plat_d2d(S.d_theta, theta, sizeof(double) * P, E.stream)) return fail("device copy of theta failed");
             theta = S.d_theta;

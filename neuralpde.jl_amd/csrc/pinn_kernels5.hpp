@@ -218,12 +218,15 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                     }
                 }
                 // A fragments (W rows of output tile t, k-block kb) with a ROLLING prefetch: fragment (t + 1, kb) is requested right behind the
-                // MFMAs that consumed fragment (t, kb), so an L2 round trip has a whole tile row of MFMAs (16 NCG x 64 cycles) to land
+                // MFMAs that consumed fragment (t, kb), so an L2 round trip has a whole tile row of MFMAs (16 NCG x 64 cycles) to land.
+                // r06: the loads are UNCONDITIONAL (a predicate per element made every load its own exec-masked branch in the MFMA stream,
+                // profiles/r06_f64_kernel_stats.txt): what a narrow layer reads past its matrix (theta carries a zeroed margin, f64.cpp) meets
+                // rows of X that are zero (k >= n_in) or lands in rows of Z that the element loops mask (m >= n_out)
                 LVd<NR> Af;
                 PINN_LANES(l) {
                     PINN_UNROLL for (int kb = 0; kb < NR; ++kb) {
                         const int m = (l & 15), k = 4 * kb + (l >> 4);
-                        Af(l, kb) = (m < n_out && k < n_in) ? W[m + (size_t)k * n_out] : 0.0;
+                        Af(l, kb) = W[m + k * n_out];
                     }
                 }
                 PINN_UNROLL for (int t = 0; t < HT; ++t) {
@@ -239,7 +242,7 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                             if (t + 1 < HT && !(PINN_F64M_PROBE & 1)) {
                                 PINN_LANES(l) {
                                     const int m = 16 * (t + 1) + (l & 15), k = 4 * kb + (l >> 4);
-                                    Af(l, kb) = (m < n_out && k < n_in) ? W[m + (size_t)k * n_out] : 0.0;
+                                    Af(l, kb) = W[m + k * n_out];
                                 }
                             }
                             // the previous layer's activations (this GEMM's B operand, row kb of X) go out behind the MFMAs that read them first:
@@ -419,7 +422,7 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                 PINN_LANES(l) {
                     PINN_UNROLL for (int kb = 0; kb < NR; ++kb) {
                         const int k = (l & 15), m = 4 * kb + (l >> 4);
-                        Af(l, kb) = (k < H && m < n_next) ? Wn[m + (size_t)k * n_next] : 0.0;
+                        Af(l, kb) = Wn[m + k * n_next];
                     }
                 }
                 PINN_UNROLL for (int t = 0; t < HT; ++t) {
@@ -430,7 +433,7 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                         if (t + 1 < HT && !(PINN_F64M_PROBE & 1)) {
                             PINN_LANES(l) {
                                 const int k = 16 * (t + 1) + (l & 15), m = 4 * kb + (l >> 4);
-                                Af(l, kb) = (k < H && m < n_next) ? Wn[m + (size_t)k * n_next] : 0.0;
+                                Af(l, kb) = Wn[m + k * n_next];
                             }
                         }
                         // dZ of the layer above (this GEMM's B operand, row kb of X): its rows for the dW kernel, behind the MFMAs that read it first
@@ -443,11 +446,13 @@ DEV void f64m_tile(int tile, const F64Args& a) {
             if (!(keep_last && lyr == L - 1)) {
                 PINN_LANES(l) {
                     const int q = l >> 4, j = l & 15;
+                    // (unclamped, affine addresses: rows beyond the layer's width / points beyond the chunk's end read the scratch margin or the rows'
+                    // padding — whatever comes back is discarded by the selects of the adjoint loop below)
                     PINN_UNROLL for (int tr = 0; tr < NR; ++tr) {
-                        const int k = 16 * (tr >> 2) + 4 * (tr & 3) + q, kc = k < H ? k : H - 1;
+                        const int k = 16 * (tr >> 2) + 4 * (tr & 3) + q;
                         PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
-                            const int p = pbase + 16 * pg + j, pc = p < a.npts ? p : a.npts - 1;
-                            PINN_UNROLL for (int c = 0; c < C; ++c) X(l, tr * NCG + pg * C + c) = S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)kc * C + c, pc)];
+                            const int p = pbase + 16 * pg + j;
+                            PINN_UNROLL for (int c = 0; c < C; ++c) X(l, tr * NCG + pg * C + c) = S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)k * C + c, p)];
                         }
                     }
                 }
