@@ -122,14 +122,16 @@ function loss_grad(e::HIPEngine, θ::AbstractVector{<:Real}, w::AbstractVector{<
 end
 
 """
-    set_gemm!(e, :split | :fp32)
+    set_gemm!(e, :split | :fp32 | :auto)
 
 Arithmetic of the hidden-layer GEMMs of the 64- / 128-wide kernels on a live engine (`pinn_set_option(h, "gemm", …)`): `:split` (default) =
 three bf16 pieces per operand on the bf16 matrix pipe; `:fp32` = fp32 MFMAs, an fmaf chain per product — for a quasi-Newton stage that
 runs into the split products' noise floor (the reference runs `BFGS()` in Float64, test/NNPDE1/nnpde__pde_iii_3rd_order_ode.jl:89-93).
 """
 function set_gemm!(e::HIPEngine, mode::Symbol)
-    mode in (:split, :fp32) || throw(ArgumentError("gemm mode must be :split or :fp32"))
+    # :auto (r06): the engine MEASURES when to leave the split products — at the current iterate the gradient is evaluated with both arithmetics,
+    # δ = ‖g_split − g_fp32‖ / ‖g_fp32‖; split while δ ≤ 1e-5, fp32 above (include/pinn_hip.h, "gemm")
+    mode in (:split, :fp32, :auto) || throw(ArgumentError("gemm mode must be :split, :fp32 or :auto"))
     check(ccall(sym(:pinn_set_option), Cint, (Ptr{Cvoid}, Cstring, Cstring), e.h, "gemm", String(mode)), "pinn_set_option")
     return nothing
 end
