@@ -25,6 +25,9 @@
 #ifndef PINN_F64S_ZMAX
 #define PINN_F64S_ZMAX 24               // channel group size CG = ZMAX / HT: the GEMM accumulators are 4 HT x CG = 4 ZMAX doubles per lane (A/B)
 #endif
+#ifndef PINN_F64S_DWT_SYNC
+#define PINN_F64S_DWT_SYNC 0            // 1: workgroup barrier per step of the output-split dW kernel (keeps the four waves on the same input rows) — measured SLOWER (cfg5 26.0 -> 27.0 ms, cfg4 17.4 -> 18.2 ms): off
+#endif
 #ifndef PINN_F64S_WAVES
 #define PINN_F64S_WAVES 1               // waves per SIMD the sliced tile kernel is compiled for (register cap 512 / waves): at 1 the GEMM loop is operand loads and MFMAs only; at 2 (256 registers, 192 of them accumulators) it spills inside the loop (A/B: profiles/r06_f64_sliced.txt)
 #endif
@@ -341,6 +344,10 @@ DEV void f64s_dwt_wave(int ni, int lyr, int b, int w, const F64Args& a) {
     const int nsteps = ((hi - lo + 15) / 16) * CE;
     for (int i = 0; i < nsteps; ++i) {
         const int p = lo + 16 * (i / CE), c = i % CE;
+#if PINN_F64S_DWT_SYNC && !defined(PINN_EMU)
+        // (experiment: the four waves read the SAME input rows of a step; kept in step, three of the four reads could be cache hits — the barrier costs more)
+        __syncthreads();
+#endif
         LVd<OW * 4> A_;
         LVd<HT * 4> B_;
         PINN_LANES(l) {
