@@ -200,7 +200,8 @@ int f64_enable(pinn_engine& E) {
             const Net& N = E.nets[net];
             if (N.kind != 0) return fail(who + "DGM networks are not covered by the float64 mode");
             if (!N.emb_idx.empty()) return fail(who + "periodic input embeddings are not covered by the float64 mode");
-            if (N.act != pk::ACT_TANH && N.act != pk::ACT_SIGMOID && N.act != pk::ACT_SIN) return fail(who + "per-layer activation mixes are not covered by the float64 mode");
+            if (N.act != pk::ACT_TANH && N.act != pk::ACT_SIGMOID && N.act != pk::ACT_SIN && N.act != pk::ACT_MIXED) return fail(who + "this activation is not covered by the float64 mode");
+            if (N.act == pk::ACT_MIXED && (int)N.sizes.size() - 2 > 8) return fail(who + "per-layer tanh / sigmoid mixes of more than 8 hidden layers are not covered by the float64 mode");
             if ((int)N.sizes.size() - 1 > pk::F64_MAX_LAYERS) return fail(who + "more than 16 Dense layers");
             if (N.sizes[0] != E.nets[nets[0]].sizes[0]) return fail(who + "its dependent variables take different numbers of arguments (one jet set serves all networks of an equation in the float64 mode)");
             any_sin = any_sin || N.act == pk::ACT_SIN;
@@ -316,6 +317,7 @@ static int f64_build(pinn_engine& E, const F64Term& F, int dt, const std::map<in
         }
         n.sizes[n.nl] = N.sizes[n.nl];
         n.act = N.act;
+        n.act_layers = N.act_layers;
         n.ceff = 1;
         for (int sl = 0; sl < F.nslots; ++sl) if (F.slot_net[sl] == ni) n.ceff = std::max(n.ceff, F.slot_chan[sl] + 1);
         if (std::getenv("PINN_F64_FULL_CHANNELS")) n.ceff = a.C;              // (A/B, tests)
@@ -746,7 +748,7 @@ int f64_net_eval(pinn_engine& E, int net, const double* theta, const double* pts
     const std::string who = "float64 trial-function evaluation: ";
     if (N.kind != 0) return fail(who + "DGM networks are not covered by the float64 mode");
     if (!N.emb_idx.empty()) return fail(who + "periodic input embeddings are not covered by the float64 mode");
-    if (N.act != pk::ACT_TANH && N.act != pk::ACT_SIGMOID && N.act != pk::ACT_SIN) return fail(who + "per-layer activation mixes are not covered by the float64 mode");
+    if (N.act != pk::ACT_TANH && N.act != pk::ACT_SIGMOID && N.act != pk::ACT_SIN && N.act != pk::ACT_MIXED) return fail(who + "this activation is not covered by the float64 mode");
     if ((int)N.sizes.size() - 1 > pk::F64_MAX_LAYERS || N.sizes[0] > 4) return fail(who + "more than 16 Dense layers / more than 4 inputs");
     const int d = N.sizes[0];
     Slot sl;

@@ -36,7 +36,8 @@ struct F64Net {
     int r_rec[F64_MAX_LAYERS], r_post[F64_MAX_LAYERS], r_dz[F64_MAX_LAYERS];      // scratch row bases of hidden layer l: record / post-activation
                                                                                   // jets / dZ, H_l * C rows each (row = base + neuron * C + channel)
     int r_ubar;                         // seeds d(loss)/d(jet channel) of this network [C]
-    int act;                            // ACT_TANH / ACT_SIGMOID / ACT_SIN
+    int act_layers;                     // act == ACT_MIXED: kind (tanh / sigmoid) of hidden layer l in bits 4l .. 4l+3 (<= 8 hidden layers), as GroupArgs::act_layers
+    int act;                            // ACT_TANH / ACT_SIGMOID / ACT_SIN on every hidden layer, or ACT_MIXED
     int theta0, nparams, ent0;          // the network's slice of theta; its first slab entry
     int tp0;                            // matrix-pipe kernels: first column of this network in a tile's row of partial sums (F64Args::tpart):
                                         // [W_0: n_1 * d][b_0: n_1][W_L: n_L][b_L]
@@ -84,6 +85,10 @@ struct F64Args {
     double* tpart;
     int ntp, tp_p, tile_pts;            // columns per tile; first PDE-parameter column; points per tile (16 * PG)
 };
+
+// activation kind of hidden layer l: tanh and sigmoid are a RUN-TIME kind in the float64 kernels, so per-layer mixes (Lux chains like
+// Dense(.., sigma) -> Dense(.., tanh), test/NNPDE2/additional_loss__lorenz_system.jl) cost nothing extra
+HD int f64_act(const F64Net& n, int l) { return n.act == ACT_MIXED ? ((n.act_layers >> (4 * l)) & 15) : n.act; }
 
 // ---- kernel A: forward jets of every network, residual tape, reverse sweep of ONE point ----
 template <class J, int ACTK /* ACT_TANH: tanh / sigmoid by run-time kind; ACT_SIN: sin */>
@@ -137,11 +142,11 @@ DEV void f64_point(int lp, const F64Args& a) {
                 PINN_UNROLL for (int j = 0; j < MB; ++j) {
                     if (j >= nb) break;
                     const int m = m0 + j;
-                    const double a0 = act_value<SIN>(n.act, z[j][0]);
+                    const double a0 = act_value<SIN>(f64_act(n, l), z[j][0]);
                     z[j][0] = act_record<SIN>(z[j][0], a0);          // the record: a (tanh / sigmoid) or z (sin), then the pre-activation channels
                     PINN_UNROLL for (int c = 0; c < C; ++c) S[((size_t)n.r_rec[l] + (size_t)m * C + c) * np_] = z[j][c];
                     double dd[ND];
-                    act_derivs_n<J::NORD - 1, SIN>(n.act, z[j][0], dd);
+                    act_derivs_n<J::NORD - 1, SIN>(f64_act(n, l), z[j][0], dd);
                     jet_forward<J>(z[j], dd);
                     z[j][0] = a0;
                     PINN_UNROLL for (int c = 0; c < C; ++c) S[((size_t)n.r_post[l] + (size_t)m * C + c) * np_] = z[j][c];
@@ -255,7 +260,7 @@ DEV void f64_point(int lp, const F64Args& a) {
                     const int k = k0 + j;
                     double s[C], dd[ND];
                     PINN_UNROLL for (int c = 0; c < C; ++c) s[c] = S[((size_t)n.r_rec[l] + (size_t)k * C + c) * np_];
-                    act_derivs_n<J::NORD, SIN>(n.act, s[0], dd);
+                    act_derivs_n<J::NORD, SIN>(f64_act(n, l), s[0], dd);
                     jet_adjoint<J>(gq[j], s, dd);
                     PINN_UNROLL for (int c = 0; c < C; ++c) S[((size_t)n.r_dz[l] + (size_t)k * C + c) * np_] = gq[j][c];
                 }

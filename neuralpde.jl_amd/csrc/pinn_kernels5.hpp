@@ -283,14 +283,14 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                         const bool st = (PINN_F64M_PROBE & 8) ? true : valid && a.mode == 0 && !(PINN_F64M_PROBE & 2);      // (points past the chunk's end: into the rows' padding — npad is a multiple of the 512-point block, every reader masks by the point count)
                         double z[C];
                         PINN_UNROLL for (int c = 0; c < C; ++c) z[c] = Z(l, tr * NCG + pg * C + c);
-                        const double a0 = (PINN_F64M_PROBE & 4) ? z[0] * 0.5 : act_value<SIN>(n.act, z[0]);
+                        const double a0 = (PINN_F64M_PROBE & 4) ? z[0] * 0.5 : act_value<SIN>(f64_act(n, lyr), z[0]);
                         z[0] = act_record<SIN>(z[0], a0);
                         // the LAST hidden layer's rows have one reader left, this wave's reverse sweep (its post-activation jets fed the output
                         // weights' gradient, which the reverse sweep now forms itself): no post rows, and no record either where X keeps it
                         // (the other layers' rows: deferred into the next GEMM, above)
                         if (st && (!DEFER || lyr == L - 1) && !(keep_last && lyr == L - 1)) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)m * C + c, p)] = z[c]; }
                         double dd[ND];
-                        act_derivs_n<J::NORD - 1, SIN>(n.act, z[0], dd);
+                        act_derivs_n<J::NORD - 1, SIN>(f64_act(n, lyr), z[0], dd);
                         jet_forward<J>(z, dd);
                         z[0] = a0;
                         if (st && !DEFER && !a.post_alias && lyr != L - 1) { PINN_UNROLL for (int c = 0; c < C; ++c) S[f64m_six(a, (size_t)n.r_post[lyr] + (size_t)m * C + c, p)] = z[c]; }
@@ -484,12 +484,12 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                         double s[C], gq[C], dd[ND];
                         PINN_UNROLL for (int c = 0; c < C; ++c) s[c] = X(l, tr * NCG + pg * C + c);
                         PINN_UNROLL for (int c = 0; c < C; ++c) gq[c] = Z(l, tr * NCG + pg * C + c);
-                        act_derivs_n<J::NORD, SIN>(n.act, s[0], dd);
+                        act_derivs_n<J::NORD, SIN>(f64_act(n, lyr), s[0], dd);
                         if (lyr == L - 1) {                          // dW_L[k] += sum_c ubar_c * (post-activation jet c of neuron k): the forward rule on the record
                             double pz[C];
                             PINN_UNROLL for (int c = 0; c < C; ++c) pz[c] = s[c];
                             jet_forward<J>(pz, dd);
-                            pz[0] = SIN ? act_value<SIN>(n.act, s[0]) : s[0];
+                            pz[0] = SIN ? act_value<SIN>(f64_act(n, lyr), s[0]) : s[0];
                             double t2 = 0.0;
                             PINN_UNROLL for (int c = 0; c < C; ++c) t2 = vfma(U(l, ni * NCG + pg * C + c), pz[c], t2);
                             t6[5] += st ? t2 : 0.0;

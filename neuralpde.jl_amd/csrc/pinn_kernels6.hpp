@@ -140,14 +140,14 @@ DEV void f64s_tile(int tile, const F64Args& a, double* ulds /* [F64_MAX_NETS][C]
                     PINN_UNROLL for (int b = 0; b < TB; ++b) {
                         const int tr = tr0 + b, m = 16 * (tr >> 2) + 4 * (tr & 3) + q;
                         const bool valid = m < n_out;
-                        const double a0 = act_value<SIN>(n.act, z[b][0]);
+                        const double a0 = act_value<SIN>(f64_act(n, lyr), z[b][0]);
                         z[b][0] = act_record<SIN>(z[b][0], a0);
                         if (rev && valid) {
                             if (lyr == 0) { PINN_UNROLL for (int c = 0; c < C; ++c) if (c < ce) S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)m * C + c, p)] = z[b][c]; }
                             else if (!SIN) S[f64m_six(a, (size_t)n.r_rec[lyr] + (size_t)m * C, p)] = z[b][0];
                         }
                         double dd[ND];
-                        act_derivs_n<J::NORD - 1, SIN>(n.act, z[b][0], dd);
+                        act_derivs_n<J::NORD - 1, SIN>(f64_act(n, lyr), z[b][0], dd);
                         jet_forward<J>(z[b], dd);
                         z[b][0] = a0;
                         if (lyr < L - 1) {
@@ -273,12 +273,12 @@ DEV void f64s_tile(int tile, const F64Args& a, double* ulds /* [F64_MAX_NETS][C]
                         const int tr = tr0 + b, k = 16 * (tr >> 2) + 4 * (tr & 3) + q;
                         const bool valid = k < H, st = valid && p < a.npts;
                         double t6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, dd[ND];
-                        act_derivs_n<J::NORD, SIN>(n.act, s[b][0], dd);
+                        act_derivs_n<J::NORD, SIN>(f64_act(n, lyr), s[b][0], dd);
                         if (lyr == L - 1) {                          // dW_L[k] += sum_c ubar_c * (post-activation jet c of neuron k): the forward rule on the record
                             double pz[C];
                             PINN_UNROLL for (int c = 0; c < C; ++c) pz[c] = s[b][c];
                             jet_forward<J>(pz, dd);
-                            pz[0] = SIN ? act_value<SIN>(n.act, s[b][0]) : s[b][0];
+                            pz[0] = SIN ? act_value<SIN>(f64_act(n, lyr), s[b][0]) : s[b][0];
                             double t2 = 0.0;
                             PINN_UNROLL for (int c = 0; c < C; ++c) t2 = vfma(ub[c], pz[c], t2);
                             t6[5] = st ? t2 : 0.0;

@@ -772,3 +772,34 @@ def test_sliced_matrix_pipe_kernels_equal_the_oracle(npde, use_emu, name):
         del os.environ["PINN_F64_NO_SLICED"]
     np.testing.assert_allclose(ll, l64, rtol=1e-12)
     np.testing.assert_allclose(gl, g64, rtol=0, atol=1e-12 * np.abs(g64).max())
+
+
+def test_f64_per_layer_activation_mixes(npde, use_emu):
+    """tanh and sigmoid mixed inside one chain (the reference's Lorenz chains, test/NNPDE2/additional_loss__lorenz_system.jl:46-50) in float64 mode
+    (r06): the activation kind is a run-time value per hidden layer in every float64 kernel family — losses, gradient, trial function against the
+    float64 oracle to rounding, on the matrix-pipe kernels and on the lane-per-point family"""
+    import os
+    for d, width, acts, seed in ((2, 12, ("tanh", "sigmoid"), 71), (2, 16, ("sigmoid", "tanh", "sigmoid"), 72), (1, 10, ("sigmoid", "sigmoid", "tanh"), 74)):
+        sysm, _ = helpers.shape_problem(npde, width, len(acts), d)
+        layers = [npde.Dense(d, width, acts[0])] + [npde.Dense(width, width, a) for a in acts[1:]] + [npde.Dense(width, 1)]
+        chain = npde.Chain(*layers)
+        strat = npde.QuasiRandomTraining(50, bcs_points=30, sampling_alg=npde.SobolSample(seed=seed), resampling=False, minibatch=1)
+        theta = tp.theta_for(chain, seed)
+        rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=theta))          # Float64 parameters: float64 kernels by default
+        eng = rep.engine
+        assert eng.get_option("precision") == "f64"
+        sets = rep.pde_train_sets + rep.bcs_train_sets
+        prob = helpers.oracle_problem(npde, sysm, [chain])
+        th = np.asarray(rep.flat_init_params, dtype=np.float64)
+        ref = po.loss_and_grad(prob, th, sets, mode="exact")
+        for nomfma in (False, True):
+            if nomfma:
+                os.environ["PINN_F64_NO_MFMA"] = "1"
+            try:
+                l64, g64 = eng.loss_grad_f64(th)
+            finally:
+                os.environ.pop("PINN_F64_NO_MFMA", None)
+            le, g2, gi = helpers.rel_errors(l64, g64, ref)
+            assert le.max() < EXACT and g2 < EXACT and gi < EXACT, (acts, nomfma, le, g2, gi)
+        pts = np.array([[0.3, 0.7], [0.6, 0.2]])[:d]
+        np.testing.assert_allclose(rep.phi(pts, th)[0], po.phi_values(prob.chains[0], th, pts)[0], rtol=1e-13, atol=1e-14)

@@ -1,0 +1,81 @@
+"""The reference's own END-TO-END acceptance tests under the DEFAULT precision policy (r06): the same statements as
+tests/test_gpu_reference_acceptance.py — same PDE systems, networks, point designs, schedules, known answers and tolerances — but with
+`PhysicsInformedNN(...)` as a user of the reference writes it, i.e. WITHOUT the explicit `precision = "f32"` opt-in: the parameters are
+Float64 (the reference's default, src/discretize.jl:432-449), so `precision = "auto"` puts the engine into its float64 evaluation mode
+(compute dtype = eltype(theta), src/eltype_matching.jl:8-10) — resident Adam, device samplers, quadrature weights, adaptive losses, BFGS /
+L-BFGS over the double objective, `phi` in double.  The third-order ODE system, which the fp32 kernels cannot take below their noise
+floor, meets the reference's own thresholds here (objective < 1e-9, atol 1e-4)."""
+import numpy as np
+import pytest
+
+import test_gpu_reference_acceptance as ta
+
+pytestmark = pytest.mark.gpu
+
+
+class _DefaultPrecision:
+    """the package with PhysicsInformedNN's `precision` left at its default ("auto") whatever the wrapped test passes"""
+
+    def __init__(self, m):
+        self._m = m
+        self.engines = []
+
+    def __getattr__(self, k):
+        return getattr(self._m, k)
+
+    def PhysicsInformedNN(self, *a, **kw):
+        kw.pop("precision", None)
+        return self._m.PhysicsInformedNN(*a, **kw)
+
+    def discretize(self, sysm, disc):
+        prob = self._m.discretize(sysm, disc)
+        assert prob.pinnrep.engine.get_option("precision") == "f64", "Float64 parameters must select the float64 kernels"
+        assert prob.u0.dtype == np.float64
+        self.engines.append(prob.pinnrep.engine)
+        return prob
+
+
+CASES = [("test_pde_ii_2d_poisson", {"strategy": "grid"}), ("test_pde_ii_2d_poisson", {"strategy": "stochastic"}),
+         ("test_pde_ii_2d_poisson", {"strategy": "quasirandom"}), ("test_pde_iv_system_of_pdes", {}), ("test_pde_v_2d_wave_equation", {}),
+         ("test_pde_vi_mixed_derivative", {}), ("test_direct_function_approximation_1d", {}), ("test_docs_third_order_ode", {}),
+         ("test_simple_1d_ode_all_strategies", {"strategy": "grid"}), ("test_simple_1d_ode_all_strategies", {"strategy": "stochastic"}),
+         ("test_simple_1d_ode_all_strategies", {"strategy": "quadrature"}), ("test_adaptive_loss_2d_poisson", {"scheme": "gradientscale"}),
+         ("test_adaptive_loss_2d_poisson", {"scheme": "minimax"}), ("test_lorenz_parameter_estimation", {}),
+         ("test_direct_function_approximation_2d", {}), ("test_cuda_2d_pde", {})]
+
+
+@pytest.mark.parametrize("name,kw", CASES, ids=[n + ("[" + "-".join(map(str, k.values())) + "]" if k else "") for n, k in CASES])
+def test_reference_acceptance_in_default_float64(npde, hip_lib, name, kw):
+    wrapped = _DefaultPrecision(npde)
+    getattr(ta, name)(wrapped, hip_lib, **kw)
+    assert wrapped.engines, "the wrapped test built no discretisation"
+
+
+def test_pde_iii_third_order_ode_system_meets_the_reference_thresholds_in_float64(npde, hip_lib):
+    """test/NNPDE1/nnpde__pde_iii_3rd_order_ode.jl:58-137 with the reference's OWN criteria: BFGS until the objective is below 1e-9, then
+    `u_predict ≈ u_real atol = 1e-4` — five networks, Sobol design of 100 points, Float64 parameters => float64 kernels by default
+    (tests/test_gpu_reference_acceptance.py holds the fp32 kernels to one order of magnitude above both thresholds: their noise floor)."""
+    import math
+    import sympy as sp
+    (x,) = npde.parameters("x")
+    u, Dxu, Dxxu, O1, O2 = npde.variables("u Dxu Dxxu O1 O2")
+    Dx = npde.Differential(x)
+    eq = npde.Eq(Dx(Dxxu(x)), sp.cos(sp.pi * x))
+    ep = (np.finfo(np.float64).eps ** (1 / 3)) ** 2 / 6
+    bcs = [npde.Eq(u(0.0), 0.0), npde.Eq(u(1.0), math.cos(math.pi)), npde.Eq(Dxu(1.0), 1.0),
+           npde.Eq(Dxu(x), Dx(u(x)) + ep * O1(x)), npde.Eq(Dxxu(x), Dx(Dxu(x)) + ep * O2(x))]
+    dom = [npde.In(x, npde.Interval(0.0, 1.0))]
+    chains = [ta.chain_of(npde, 1, 12, 2, "tanh") for _ in range(3)] + [ta.chain_of(npde, 1, 4, 1, "tanh") for _ in range(2)]
+    rng = np.random.default_rng(100)
+    theta0 = np.concatenate([npde.initialparameters(rng, c) for c in chains])
+    strat = npde.QuasiRandomTraining(100, sampling_alg=npde.SobolSample(seed=1), resampling=False, minibatch=1)
+    prob = npde.discretize(npde.PDESystem([eq], bcs, dom, [x], [u(x), Dxu(x), Dxxu(x), O1(x), O2(x)]),
+                           npde.PhysicsInformedNN(chains, strat, init_params=theta0))
+    assert prob.pinnrep.engine.get_option("precision") == "f64"
+    res = npde.solve(prob, npde.BFGS(), maxiters=5000, callback=lambda st, l: l < 1e-9)
+    xs = np.arange(0.0, 1.0 + 0.005, 0.01)[None, :]
+    real = (np.pi * xs[0] * (-xs[0] + (np.pi ** 2) * (2 * xs[0] - 3) + 1) - np.sin(np.pi * xs[0])) / (np.pi ** 3)
+    rep = prob.pinnrep
+    err = np.linalg.norm(rep.phi[0](xs, npde.depvar_params(rep, res.u, "u"))[0] - real)
+    print(f"pde_iii (float64 by default): objective {res.objective:.3e} (reference: < 1e-9), ||u_predict - u_real||_2 = {err:.2e} (reference atol 1e-4)")
+    assert res.objective < 1e-9 and err < 1e-4
