@@ -452,6 +452,10 @@ int f64_stencil_enable(pinn_engine& E, bool on) {
     if (!on) { S.stencil = false; return 0; }
     if (!S.sten.empty()) { S.stencil = true; return 0; }
     std::vector<F64Stencil> sten(E.terms0.size());
+    struct Guard {                                       // (a failure below must not leak the tapes already uploaded)
+        std::vector<F64Stencil>& v; bool armed = true;
+        ~Guard() { if (armed) for (auto& X : v) { plat_free(X.d_prog); plat_free(X.d_imm); } }
+    } guard{sten};
     for (size_t t = 0; t < E.terms0.size(); ++t) {
         const Term& T = E.terms0[t];
         F64Stencil& X = sten[t];
@@ -501,6 +505,7 @@ int f64_stencil_enable(pinn_engine& E, bool on) {
         plat_h2d(X.d_imm, imm.data(), sizeof(double) * imm.size(), E.stream);
         if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
     }
+    guard.armed = false;
     S.sten.swap(sten);
     S.stencil = true;
     return 0;
