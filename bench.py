@@ -225,10 +225,77 @@ def roofline_entries(eng, kern_ms, sizes, world):
     return per_kernel
 
 
+def bench_f64_sharded(args, eng, rep, sets, wl, npde, world, rank):
+    """--precision f64 with --gpus N > 1 (or --emulate-world N: rank 0's share of an N-rank job over a 1-rank RCCL communicator): every
+    rank evaluates its contiguous shard of every set with the double kernels, then the ENGINE's communicator all-reduces [P + K] doubles
+    (pinn_loss_grad_sharded_device_f64, ncclDouble on the evaluation's stream); [gradient | sums] copied to pinned host memory every step
+    as in the fp32 line.  Strong scaling: the global sets are fixed."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    eworld = args.emulate_world if args.emulate_world > 0 else world
+    erank = 0 if args.emulate_world > 0 else rank
+    n_glob = [s_.shape[1] for s_ in sets]
+    for k, s_ in enumerate(sets):
+        n = s_.shape[1]
+        lo, hi = (n * erank) // eworld, (n * (erank + 1)) // eworld
+        eng.set_points_f64(k, np.asarray(s_, dtype=np.float64)[:, lo:hi], n_norm=n)
+    if world > 1:
+        uid = [npde.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        eng.comm_init_rank(world, rank, uid[0])
+    else:
+        eng.comm_init_rank(1, 0, npde.comm_unique_id())
+    K, P = eng.K, eng.P
+    th = np.asarray(rep.flat_init_params, dtype=np.float64)
+    d_th = torch.tensor(th, dtype=torch.float64, device="cuda")
+    d_out = torch.zeros(P + K, dtype=torch.float64, device="cuda")
+    h_out = torch.zeros(P + K, dtype=torch.float64).pin_memory()
+    stream = torch.cuda.current_stream()
+
+    def step():
+        eng.loss_grad_sharded_device_f64(d_th.data_ptr(), d_out.data_ptr(), None, stream.cuda_stream)
+        h_out.copy_(d_out, non_blocking=True)
+        stream.synchronize()
+
+    for _ in range(max(2, args.warmup)):
+        step()
+    first = h_out.clone()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.equal(first, h_out), "float64 sharded evaluation is not reproducible"
+    ms = dt / args.steps * 1e3
+    path = eng.get_option("f64_path")
+    eng.comm_destroy()
+    return {"metric": "collocation-point residual+grad evals/sec, 2D Poisson 4x64 MLP (float64 evaluation mode)" if args.workload == "cfg2" else f"collocation-point residual+grad evals/sec ({args.workload}, float64 evaluation mode)",
+            "value": n_glob[0] / (ms * 1e-3), "unit": "interior-point residual+grad evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wl.name if hasattr(wl, "name") else args.workload, "points_per_term_global": n_glob, "precision": "f64", "f64_path": path,
+                       "emulate_world": args.emulate_world or None,
+                       "parallelism": (f"PROXY: rank 0's 1/{args.emulate_world} share on one GPU, 1-rank RCCL communicator (projected whole-job rate, no xGMI hop measured)"
+                                       if args.emulate_world > 0 else f"dp{world}: contiguous shards of every set, one ncclDouble all-reduce per step"),
+                       "entry": "pinn_loss_grad_sharded_device_f64 (shard evaluation in double + the engine's ncclDouble all-reduce of [P + K]) + D2H to pinned memory, one synchronisation per step"},
+            "proxy": args.emulate_world > 0,
+            "loss": float((h_out[P:].numpy() / np.array(n_glob)).sum()) if args.emulate_world == 0 else None}
+
+
 F64_MFMA_PEAK_TF = 78.6          # dense v_mfma_f64_16x16x4_f64 peak of MI355X (MI355X_MICROARCH.md; = the f64 vector peak)
 
 
-def bench_f64(args, eng, rep, sets, wl):
+def bench_f64(args, eng, rep, sets, wl, npde=None, world=1, rank=0):
     """One line for the FLOAT64 evaluation mode on the same workload: a step = pinn_loss_grad_f64 (theta from host memory in double, loss +
     gradient back in double; the chunked tile / small-entry / weight-gradient / reduce kernels of csrc/pinn_kernels5.hpp + pinn_kernels4.hpp).
     roofline: the hidden-layer GEMM flops the f64 MFMAs execute (forward + dA in the tile kernel, dW in the weight-gradient kernel: 3 x 2 x
@@ -238,6 +305,8 @@ def bench_f64(args, eng, rep, sets, wl):
     import numpy as np
     import torch
     eng.set_option("precision", "f64")
+    if world > 1 or args.emulate_world > 0:
+        return bench_f64_sharded(args, eng, rep, sets, wl, npde, world, rank)
     for k, s_ in enumerate(sets):
         eng.set_points_f64(k, s_)
     th = np.asarray(rep.flat_init_params, dtype=np.float64)
@@ -376,8 +445,12 @@ def main():
     sets = rep.pde_train_sets + rep.bcs_train_sets
     K, P = eng.K, eng.P
     if args.precision == "f64":
-        assert world == 1 and not args.emulate_world and not args.resident, "--precision f64 is a single-GPU evaluation line"
-        print(json.dumps(bench_f64(args, eng, rep, sets, wl)))
+        assert not args.resident, "--precision f64: the evaluation line (the resident double loop is timed by tools/time_f64.py)"
+        line = bench_f64(args, eng, rep, sets, wl, npde, world, rank)
+        if rank == 0:
+            print(json.dumps(line))
+        if world > 1:
+            dist.destroy_process_group()
         return
     n_glob = [s.shape[1] for s in sets]
     theta0 = np.asarray(rep.flat_init_params, dtype=np.float32)

@@ -170,6 +170,12 @@ int pinn_comm_destroy(pinn_handle h);
 int pinn_loss_grad_sharded_device(pinn_handle h, const float* d_theta, const float* term_w, float* d_out, void* stream);
 int pinn_loss_grad_sharded(pinn_handle* hs, int ndev, const float* theta, int64_t p, const float* term_w,
                            double* term_losses, float* grad);
+/* The same over handles / buffers in the FLOAT64 evaluation mode (r06): this rank's shards by the double kernels, ONE all-reduce of [P + K] doubles
+ * (ncclDouble; a caller's transport is called with dtype 1).  pinn_adam_steps on a float64-mode handle with a one-process-per-GPU communicator and
+ * pinn_adam_steps_sharded over float64-mode handles run the resident double loop with that all-reduce inside every iteration. */
+int pinn_loss_grad_sharded_device_f64(pinn_handle h, const double* d_theta, const float* term_w, double* d_out, void* stream);
+int pinn_loss_grad_sharded_f64(pinn_handle* hs, int ndev, const double* theta, int64_t p, const double* term_w,
+                               double* term_losses, double* grad);
 
 /* residual_k(set_k, theta): the datafree loss function of src/discretize.jl:174 on the installed set; r has n_k floats. */
 int pinn_residual(pinn_handle h, int term, const float* theta, int64_t p, float* r);
@@ -288,9 +294,9 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
  *   twins hand everything over in double; pinn_adam_init / _steps / _get / _apply keep theta and the moments in double on the device, in
  *   a buffer of their own (evaluations between two pinn_adam_steps calls — adaptive reweighting, callbacks — leave the iterate alone);
  *   samplers redraw in float and the double copy follows.  pinn_set_points_f64 / pinn_set_point_data_f64 install a point set / its
- *   observations in double (the fp32 kernels get the float conversion).  Not available in this mode (explicit error): the communicator paths
- *   pinn_adam_steps_sharded and pinn_adam_steps on a handle with a communicator — shard a float64 job with pinn_loss_grad_device_f64 + the
- *   caller's all-reduce + pinn_adam_apply; pinn_loss_grad_sharded(_device) run the fp32 kernels whatever the mode.
+ *   observations in double (the fp32 kernels get the float conversion).  Communicators (r06): pinn_loss_grad_sharded_device_f64 /
+ *   pinn_loss_grad_sharded_f64 and the resident loops (pinn_adam_steps over a one-process-per-GPU communicator, pinn_adam_steps_sharded) all-reduce
+ *   [P + K] DOUBLES; the float entry points pinn_loss_grad_sharded(_device) run the fp32 kernels whatever the mode.
  *   PRECISION POLICY of the glue (Julia: HIPStrategy / hip_discretize `precision = :auto`; Python mirror: PhysicsInformedNN(precision = "auto")):
  *   the reference's contract compute dtype = eltype(theta) (src/eltype_matching.jl:8-10) — Float64 parameters select "f64", Float32
  *   parameters "f32"; "f32" on Float64 parameters is the explicit fast opt-in.

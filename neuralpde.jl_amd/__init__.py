@@ -8,7 +8,7 @@ Python host mirror of the reference's discretizer API over the C ABI of libpinn_
 See DESIGN.md for the kernel design and INTEGRATION.md for the Julia `ccall` binding.
 """
 from . import _lib
-from ._lib import Engine, EngineError, Library, adam_steps_sharded, comm_init_all, comm_unique_id, loss_grad_sharded
+from ._lib import Engine, EngineError, Library, adam_steps_sharded, comm_init_all, comm_unique_id, loss_grad_sharded, loss_grad_sharded_f64
 from .ir import Instr, NetIR, ProblemIR, Slot, TermIR
 from .bpinn import BPINNsolution, loglikelihood, physics_loglikelihood
 from . import bpinn as _bpinn

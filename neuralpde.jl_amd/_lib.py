@@ -37,6 +37,7 @@ SYMBOLS = [
     "pinn_set_option", "pinn_get_option", "pinn_set_points_f64", "pinn_comm_init_custom", "pinn_adam_steps_sharded", "pinn_adam_apply",
     "pinn_adam_init_f64", "pinn_adam_get_f64", "pinn_set_point_data_f64", "pinn_loss_grad_device_f64",
     "pinn_residual_f64", "pinn_phi_f64", "pinn_derivative_f64", "pinn_term_grads_f64", "pinn_loglik_grad_f64",
+    "pinn_loss_grad_sharded_device_f64", "pinn_loss_grad_sharded_f64",
 ]
 
 
@@ -106,6 +107,8 @@ class Library:
             L.pinn_derivative_f64.argtypes = [vp, C.c_int, dp, C.c_int64, dp, C.c_int64, C.c_int, C.POINTER(C.c_int), dp]
             L.pinn_term_grads_f64.argtypes = [vp, dp, C.c_int64, dp, dp]
             L.pinn_loglik_grad_f64.argtypes = [vp, dp, C.c_int64, dp, dp, dp, dp]
+            L.pinn_loss_grad_sharded_device_f64.argtypes = [vp, vp, fp, vp, vp]
+            L.pinn_loss_grad_sharded_f64.argtypes = [C.POINTER(vp), C.c_int, dp, C.c_int64, dp, dp, dp]
         except AttributeError:
             pass
         L.pinn_lbfgs.argtypes = [vp, C.POINTER(C.c_double), C.c_int64, C.c_int, C.c_int, C.c_double, fp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -187,6 +190,22 @@ def loss_grad_sharded(engines: Sequence["Engine"], theta, weights=None, want_gra
                                          w.ctypes.data_as(C.POINTER(C.c_float)) if w is not None else None,
                                          losses.ctypes.data_as(C.POINTER(C.c_double)),
                                          grad.ctypes.data_as(C.POINTER(C.c_float)) if grad is not None else None), "pinn_loss_grad_sharded")
+    return losses, grad
+
+
+def loss_grad_sharded_f64(engines: Sequence["Engine"], theta, weights=None, want_grad: bool = True):
+    """`pinn_loss_grad_sharded_f64`: the same over handles in float64 mode — theta, losses and gradient in double, one all-reduce of [P + K] doubles"""
+    e0 = engines[0]
+    L = e0.L
+    hs = (C.c_void_p * len(engines))(*[e.h for e in engines])
+    th = _f64(theta)
+    losses = np.zeros(e0.K, dtype=np.float64)
+    grad = np.zeros(e0.P, dtype=np.float64) if want_grad else None
+    w = _f64(weights) if weights is not None else None
+    L.check(L.lib.pinn_loss_grad_sharded_f64(hs, len(engines), th.ctypes.data_as(C.POINTER(C.c_double)), th.size,
+                                             w.ctypes.data_as(C.POINTER(C.c_double)) if w is not None else None,
+                                             losses.ctypes.data_as(C.POINTER(C.c_double)),
+                                             grad.ctypes.data_as(C.POINTER(C.c_double)) if grad is not None else None), "pinn_loss_grad_sharded_f64")
     return losses, grad
 
 
@@ -349,6 +368,13 @@ class Engine:
     def comm_destroy(self):
         self.L.check(self.L.lib.pinn_comm_destroy(self.h), "pinn_comm_destroy")
 
+    def loss_grad_sharded_device_f64(self, d_theta: int, d_out: int, weights=None, stream: int = 0):
+        """`pinn_loss_grad_sharded_device_f64`: float64 mode, DOUBLE device buffers, the engine's all-reduce of [P + K] doubles on `stream`"""
+        w = _f32(weights) if weights is not None else None
+        self.L.check(self.L.lib.pinn_loss_grad_sharded_device_f64(
+            self.h, C.c_void_p(d_theta), w.ctypes.data_as(C.POINTER(C.c_float)) if w is not None else None,
+            C.c_void_p(d_out), C.c_void_p(stream)), "pinn_loss_grad_sharded_device_f64")
+
     def loss_grad_sharded_device(self, d_theta: int, d_out: int, weights=None, stream: int = 0):
         """pinn_loss_grad_device on this rank's shards + the engine's all-reduce of d_out ([P + K] floats, device memory) on `stream`"""
         w = _f32(weights) if weights is not None else None
@@ -495,6 +521,15 @@ class Engine:
                                            w.ctypes.data_as(C.POINTER(C.c_float)) if w is not None else None,
                                            hist.ctypes.data_as(C.POINTER(C.c_double)), C.byref(done)), "pinn_lbfgs")
         return th, hist[:done.value]
+
+    def adam_init_f64(self, theta):
+        th = _f64(theta)
+        self.L.check(self.L.lib.pinn_adam_init_f64(self.h, th.ctypes.data_as(C.POINTER(C.c_double)), th.size), "pinn_adam_init_f64")
+
+    def adam_get_f64(self) -> np.ndarray:
+        out = np.zeros(self.P, dtype=np.float64)
+        self.L.check(self.L.lib.pinn_adam_get_f64(self.h, out.ctypes.data_as(C.POINTER(C.c_double)), out.size), "pinn_adam_get_f64")
+        return out
 
     def adam_init(self, theta):
         th = _f32(theta)

@@ -241,8 +241,99 @@ int pe::comm_all_reduce(pinn_engine** es, int ndev, float** vec, double** raw) {
     return 0;
 }
 
+// the same for `count` DOUBLES per rank (the float64 evaluation mode: [gradient | sums] in double, r06)
+int pe::comm_all_reduce_f64(pinn_engine** es, int ndev, double** vec, int64_t count) {
+    if (ndev == 1) {
+        pinn_engine& E = *es[0];
+        if (!E.comm) return 0;
+        if (E.comm_fn) {
+            if (E.comm_fn(E.comm_ctx, vec[0], count, 1, (void*)E.stream)) return fail("the caller's all-reduce callback failed (float64 gradient vector)");
+            return 0;
+        }
+#ifndef PINN_EMU
+        const ncclResult_t r1 = rccl().AllReduce(vec[0], vec[0], (size_t)count, ncclDouble, ncclSum, (ncclComm_t)E.comm, E.stream);
+        if (r1 != ncclSuccess) return nccl_fail("ncclAllReduce", r1);
+#else
+        if (E.comm_size != 1) return fail("the emulation build has no inter-process transport of its own (pinn_comm_init_custom supplies one)");
+#endif
+        return 0;
+    }
+#ifndef PINN_EMU
+    NCCL_TRY(rccl().GroupStart(), "ncclGroupStart");
+    for (int i = 0; i < ndev; ++i) {
+        pinn_engine& E = *es[i];
+        DeviceScope scope(E.device);
+        const ncclResult_t rc = rccl().AllReduce(vec[i], vec[i], (size_t)count, ncclDouble, ncclSum, (ncclComm_t)E.comm, E.stream);
+        if (rc != ncclSuccess) { (void)rccl().GroupEnd(); return nccl_fail("ncclAllReduce", rc); }
+    }
+    NCCL_TRY(rccl().GroupEnd(), "ncclGroupEnd");
+#else
+    {
+        std::vector<double> sum((size_t)count, 0.0);
+        for (int i = 0; i < ndev; ++i)
+            for (int64_t j = 0; j < count; ++j) sum[(size_t)j] += vec[i][j];          // rank order: deterministic
+        for (int i = 0; i < ndev; ++i) std::memcpy(vec[i], sum.data(), sizeof(double) * (size_t)count);
+    }
+#endif
+    return 0;
+}
+
 extern "C" {
 
+// float64 mode over a communicator (r06): this rank's shards evaluated by the double kernels, then ONE all-reduce of [P + K] doubles in place
+int pinn_loss_grad_sharded_device_f64(pinn_handle h, const double* d_theta, const float* term_w, double* d_out, void* stream) {
+    if (!h || !d_theta || !d_out) return fail("pinn_loss_grad_sharded_device_f64: null argument");
+    pinn_engine& E = *h;
+    if (!E.f64) return fail("pinn_loss_grad_sharded_device_f64: the handle is not in the float64 evaluation mode (pinn_set_option(h, \"precision\", \"f64\"))");
+    if (!E.comm) return fail("pinn_loss_grad_sharded_device_f64: the handle has no communicator (pinn_comm_init_rank / pinn_comm_init_custom)");
+    if (!E.comm_per_process && E.comm_size > 1)
+        return fail("pinn_loss_grad_sharded_device_f64: the handle belongs to a single-process communicator (pinn_comm_init_all): use pinn_loss_grad_sharded_f64");
+    DeviceScope scope(E.device);
+    if (check_shards(E)) return 1;
+    plat_stream saved = E.stream;
+    E.stream = (plat_stream)stream;
+    int rc = f64_eval_from_device_f64(E, d_theta, term_w, d_out);
+    if (!rc) {
+        pinn_engine* es[1] = {&E};
+        double* vec[1] = {d_out};
+        rc = comm_all_reduce_f64(es, 1, vec, E.ntheta + (int64_t)E.terms.size());
+    }
+    E.stream = saved;
+    return rc;
+}
+
+int pinn_loss_grad_sharded_f64(pinn_handle* hs, int ndev, const double* theta, int64_t p, const double* term_w, double* term_losses, double* grad) {
+    if (!hs || ndev < 1 || !theta) return fail("pinn_loss_grad_sharded_f64: null argument");
+    for (int i = 0; i < ndev; ++i) {
+        if (!hs[i] || !hs[i]->comm || hs[i]->comm_size != ndev || hs[i]->comm_rank != i)
+            return fail("pinn_loss_grad_sharded_f64: pass the handles of one pinn_comm_init_all communicator, in rank order");
+        if (!hs[i]->f64) return fail("pinn_loss_grad_sharded_f64: every handle must be in the float64 evaluation mode");
+        if (p != hs[i]->ntheta) return fail("pinn_loss_grad_sharded_f64: theta length mismatch");
+    }
+    const int64_t P = hs[0]->ntheta;
+    const int K = (int)hs[0]->terms.size();
+    std::vector<double*> vec(ndev);
+    for (int i = 0; i < ndev; ++i) {
+        pinn_engine& E = *hs[i];
+        DeviceScope scope(E.device);
+        if (check_shards(E)) return 1;
+        if (f64_eval_sharded_local(E, theta, term_w, &vec[i])) return 1;          // [gradient | sums] of this device's shards, left on the device
+    }
+    if (comm_all_reduce_f64(hs, ndev, vec.data(), P + K)) return 1;
+    std::vector<double> out((size_t)(P + K));
+    {
+        pinn_engine& E0 = *hs[0];
+        DeviceScope scope(E0.device);
+        if (plat_d2h(out.data(), vec[0], sizeof(double) * (size_t)(P + K), E0.stream)) return fail("D2H copy failed");
+    }
+    for (int i = 0; i < ndev; ++i) {
+        DeviceScope scope(hs[i]->device);
+        if (plat_sync(hs[i]->stream)) return fail(std::string("device error: ") + plat_last_error());
+    }
+    if (term_losses) for (int k = 0; k < K; ++k) term_losses[k] = out[(size_t)P + k] / (double)hs[0]->terms[k].n_norm;
+    if (grad) std::memcpy(grad, out.data(), sizeof(double) * (size_t)P);
+    return 0;
+}
 
 int pinn_loss_grad_sharded_device(pinn_handle h, const float* d_theta, const float* term_w, float* d_out, void* stream) {
     if (!h || !d_theta || !d_out) return fail("pinn_loss_grad_sharded_device: null argument");

@@ -1763,7 +1763,8 @@ int pinn_adam_steps(pinn_handle h, int nsteps, float lr, float beta1, float beta
     pinn_engine& E = *h;
     DeviceScope scope(E.device);
     if (E.f64) {                                         // float64 mode: redraw -> evaluate -> Adam, all in double on the device (f64.cpp)
-        if (E.comm) return fail("pinn_adam_steps: the float64 mode has no communicator path");
+        if (E.comm && !E.comm_per_process && E.comm_size > 1)
+            return fail("pinn_adam_steps: the handle belongs to a single-process communicator (pinn_comm_init_all): use pinn_adam_steps_sharded");
         if (nsteps <= 0) return fail("pinn_adam_steps: nsteps must be positive");
         E.adam_path = 1;
         return f64_adam_steps(E, nsteps, (double)lr, (double)beta1, (double)beta2, (double)eps, term_w, loss_history, &redraw_term_f32);
@@ -1820,10 +1821,15 @@ int pinn_adam_steps_sharded(pinn_handle* hs, int ndev, int nsteps, float lr, flo
     for (int i = 0; i < ndev; ++i) {
         if (!hs[i] || !hs[i]->comm || hs[i]->comm_per_process || hs[i]->comm_size != ndev || hs[i]->comm_rank != i)
             return fail("pinn_adam_steps_sharded: pass the handles of one pinn_comm_init_all communicator, in rank order");
-        if (hs[i]->f64) return fail("pinn_adam_steps_sharded: not available in the float64 evaluation mode (the sharded resident loop runs the fp32 kernels: pinn_set_option(h, \"precision\", \"f32\"), or drive the float64 evaluation per rank with pinn_loss_grad_device_f64 + your own all-reduce + pinn_adam_apply)");
+        if ((hs[i]->f64 != nullptr) != (hs[0]->f64 != nullptr)) return fail("pinn_adam_steps_sharded: the handles are in different precision modes");
         if (hs[i]->opt_t != hs[0]->opt_t) return fail("pinn_adam_steps_sharded: the handles' optimiser states are at different steps (pinn_adam_init every handle with the same theta)");
+        if (hs[i]->f64) continue;
         DeviceScope scope(hs[i]->device);
         if (adam_prepare(*hs[i], nsteps, term_w, "pinn_adam_steps_sharded")) return 1;
+    }
+    if (hs[0]->f64) {                                    // float64 mode (r06): the double kernels, one all-reduce of [P + K] doubles per iteration
+        if (nsteps <= 0) return fail("pinn_adam_steps_sharded: nsteps must be positive");
+        return f64_adam_steps_comm(hs, ndev, nsteps, (double)lr, (double)beta1, (double)beta2, (double)eps, term_w, loss_history, &redraw_term_f32);
     }
     if (adam_loop(hs, ndev, nsteps, lr, beta1, beta2, eps, term_w)) return 1;
     {

@@ -302,6 +302,7 @@ void sums_from_double(float* d_out_sums, const double* d_raw, int K, plat_stream
 // handle's stream.  ndev == 1: a one-process-per-GPU communicator (RCCL or the caller's transport; no communicator: nothing to do);
 // ndev > 1: the handles of one pinn_comm_init_all communicator, one grouped RCCL call
 int comm_all_reduce(pinn_engine** es, int ndev, float** vec, double** raw);
+int comm_all_reduce_f64(pinn_engine** es, int ndev, double** vec, int64_t count);       // `count` doubles per rank, in place (float64 mode)
 // every entry point that touches the device first makes the handle's device current (single-process multi-GPU callers)
 struct DeviceScope {
     int prev;
@@ -329,6 +330,9 @@ int f64_adam_steps(pinn_engine& E, int nsteps, double lr, double beta1, double b
 int f64_points_from_device(pinn_engine& E, int term);
 int f64_eval_from_device_f32(pinn_engine& E, const float* d_theta, const float* term_w, float* d_out, bool want_grad);
 int f64_eval_from_device_f64(pinn_engine& E, const double* d_theta, const float* term_w, double* d_out);
+int f64_eval_sharded_local(pinn_engine& E, const double* theta, const double* term_w, double** d_out);      // host theta -> this device's [gradient | sums] (P + K doubles, device)
+int f64_adam_steps_comm(pinn_engine** es, int ndev, int nsteps, double lr, double beta1, double beta2, double eps, const float* term_w, double* loss_history,
+                        void (*redraw)(pinn_engine&, pe::Term&));
 // plan.cpp
 // GEMM arithmetic the kernel look-ups of the calling thread select (family 2 kernels exist as split-operand and fp32 twins): set for the
 // duration of an entry point that may look kernels up

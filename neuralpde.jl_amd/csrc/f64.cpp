@@ -84,7 +84,7 @@ static void f64_free(F64State* S) {
     for (auto& T : S->terms) { plat_free(T.d_prog); plat_free(T.d_imm); plat_free(T.d_pts); plat_free(T.d_data); }
     for (auto& X : S->sten) { plat_free(X.d_prog); plat_free(X.d_imm); }
     plat_free(S->d_uv); plat_free(S->d_seeds); plat_free(S->d_spts);
-    plat_free(S->d_theta); plat_free(S->d_opt_theta); plat_free(S->d_aux_pts); plat_free(S->d_aux_out); plat_free(S->d_grad); plat_free(S->d_sumsq); plat_free(S->d_scratch); plat_free(S->d_slab); plat_free(S->d_tpart);
+    plat_free(S->d_theta); plat_free(S->d_opt_theta); plat_free(S->d_aux_pts); plat_free(S->d_aux_out); plat_free(S->d_grad); plat_free(S->d_scratch); plat_free(S->d_slab); plat_free(S->d_tpart);
     plat_free(S->d_m); plat_free(S->d_v); plat_free(S->d_w_over_n); plat_free(S->d_hist);
     delete S;
 }
@@ -237,9 +237,9 @@ int f64_enable(pinn_engine& E) {
     // (+ F64S_PAD_THETA zeroed doubles behind theta: the sliced matrix-pipe kernels read full 16 HT-wide fragments of a narrower layer's matrix)
     S->d_theta = (double*)plat_malloc(sizeof(double) * (E.ntheta + pk::F64S_PAD_THETA));
     if (S->d_theta) plat_memset(S->d_theta, 0, sizeof(double) * (E.ntheta + pk::F64S_PAD_THETA), E.stream);
-    S->d_grad = (double*)plat_malloc(sizeof(double) * E.ntheta);
-    S->d_sumsq = (double*)plat_malloc(sizeof(double) * K);
-    if (!S->d_theta || !S->d_grad || !S->d_sumsq) return fail("device allocation failed (float64 state)");
+    S->d_grad = (double*)plat_malloc(sizeof(double) * (E.ntheta + K));      // [gradient (P) | sums (K)] contiguous: one all-reduce over a communicator
+    S->d_sumsq = S->d_grad ? S->d_grad + E.ntheta : nullptr;
+    if (!S->d_theta || !S->d_grad) return fail("device allocation failed (float64 state)");
     S->h_out.resize((size_t)E.ntheta + K);
     E.f64 = S.release();
     return 0;
@@ -839,35 +839,76 @@ int f64_points_from_device(pinn_engine& E, int term) {
     return 0;
 }
 int f64_adam_steps(pinn_engine& E, int nsteps, double lr, double beta1, double beta2, double eps, const float* term_w, double* loss_history, void (*redraw)(pinn_engine&, Term&)) {
+    pinn_engine* es[1] = {&E};
+    return f64_adam_steps_comm(es, 1, nsteps, lr, beta1, beta2, eps, term_w, loss_history, redraw);
+}
+// this device's part of a single-process multi-device evaluation (pinn_loss_grad_sharded_f64): theta from the host, [gradient | sums] stay on the device
+int f64_eval_sharded_local(pinn_engine& E, const double* theta, const double* term_w, double** d_out) {
     F64State& S = *(F64State*)E.f64;
-    if (!S.opt_ready) return fail("pinn_adam_steps: call pinn_adam_init first (float64 mode keeps its own optimiser state)");
-    const int K = (int)E.terms.size();
-    const int P = (int)E.ntheta;
+    if (plat_h2d(S.d_theta, theta, sizeof(double) * E.ntheta, E.stream)) return fail("H2D copy of theta failed");
+    if (f64_eval_device(E, S.d_theta, S.d_grad, S.d_sumsq, term_w)) return 1;
+    *d_out = S.d_grad;
+    return 0;
+}
+// the resident float64 Adam loop over a communicator (r06): per iteration every rank / device evaluates its shards, ONE all-reduce of [P + K] doubles,
+// the identical update on every rank.  ndev == 1: a one-process-per-GPU communicator (or none); ndev > 1: the handles of a pinn_comm_init_all communicator
+int f64_adam_steps_comm(pinn_engine** es, int ndev, int nsteps, double lr, double beta1, double beta2, double eps, const float* term_w, double* loss_history,
+                        void (*redraw)(pinn_engine&, Term&)) {
+    const int K = (int)es[0]->terms.size();
+    const int P = (int)es[0]->ntheta;
     std::vector<double> w(K), won(K);
-    for (int k = 0; k < K; ++k) { w[k] = term_w ? (double)term_w[k] : 1.0; won[k] = w[k] / (double)E.terms[k].n_norm; }
-    plat_h2d(S.d_w_over_n, won.data(), sizeof(double) * K, E.stream);
-    if (S.hist_cap < nsteps) {
-        plat_sync(E.stream);
-        plat_free(S.d_hist);
-        S.d_hist = (double*)plat_malloc(sizeof(double) * nsteps);
-        S.hist_cap = S.d_hist ? nsteps : 0;
-        if (!S.d_hist) return fail("device allocation failed (loss history)");
-    }
-    for (int s = 0; s < nsteps; ++s) {
-        for (size_t t = 0; t < E.terms.size(); ++t) {
-            Term& T = E.terms[t];
-            if (T.sampler == 0) continue;
-            redraw(E, T);                                    // (engine.cpp: the fp32 sampler kernels, draw counter advanced)
-            if (f64_points_from_device(E, (int)t)) return 1;
+    for (int k = 0; k < K; ++k) { w[k] = term_w ? (double)term_w[k] : 1.0; won[k] = w[k] / (double)es[0]->terms[k].n_norm; }
+    std::vector<double*> vec(ndev);
+    for (int i = 0; i < ndev; ++i) {
+        pinn_engine& E = *es[i];
+        DeviceScope scope(E.device);
+        F64State& S = *(F64State*)E.f64;
+        if (!S.opt_ready) return fail("pinn_adam_steps: call pinn_adam_init first (float64 mode keeps its own optimiser state)");
+        plat_h2d(S.d_w_over_n, won.data(), sizeof(double) * K, E.stream);
+        if (S.hist_cap < nsteps) {
+            plat_sync(E.stream);
+            plat_free(S.d_hist);
+            S.d_hist = (double*)plat_malloc(sizeof(double) * nsteps);
+            S.hist_cap = S.d_hist ? nsteps : 0;
+            if (!S.d_hist) return fail("device allocation failed (loss history)");
         }
-        if (f64_eval_device(E, S.d_opt_theta, S.d_grad, S.d_sumsq, w.data())) return 1;
-        ++E.opt_t;
-        const double c1 = 1.0 / (1.0 - std::pow(beta1, (double)E.opt_t)), c2 = 1.0 / (1.0 - std::pow(beta2, (double)E.opt_t));
-        pk::launch_f64_total(S.d_hist, s, S.d_sumsq, S.d_w_over_n, K, E.stream);
-        pk::launch_f64_adam(S.d_opt_theta, S.d_m, S.d_v, S.d_grad, P, lr, beta1, beta2, eps, c1, c2, E.stream);
+        vec[i] = S.d_grad;
     }
-    if (loss_history && plat_d2h(loss_history, S.d_hist, sizeof(double) * nsteps, E.stream)) return fail("D2H copy failed");
-    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
+    const bool collective = ndev > 1 || es[0]->comm != nullptr;
+    for (int s = 0; s < nsteps; ++s) {
+        for (int i = 0; i < ndev; ++i) {
+            pinn_engine& E = *es[i];
+            DeviceScope scope(E.device);
+            F64State& S = *(F64State*)E.f64;
+            for (size_t t = 0; t < E.terms.size(); ++t) {
+                Term& T = E.terms[t];
+                if (T.sampler == 0) continue;
+                redraw(E, T);                                    // (engine.cpp: the fp32 sampler kernels, rank-specific seeds, draw counter advanced)
+                if (f64_points_from_device(E, (int)t)) return 1;
+            }
+            if (f64_eval_device(E, S.d_opt_theta, S.d_grad, S.d_sumsq, w.data())) return 1;
+        }
+        if (collective && comm_all_reduce_f64(es, ndev, vec.data(), (int64_t)P + K)) return 1;
+        for (int i = 0; i < ndev; ++i) {
+            pinn_engine& E = *es[i];
+            DeviceScope scope(E.device);
+            F64State& S = *(F64State*)E.f64;
+            ++E.opt_t;
+            const double c1 = 1.0 / (1.0 - std::pow(beta1, (double)E.opt_t)), c2 = 1.0 / (1.0 - std::pow(beta2, (double)E.opt_t));
+            pk::launch_f64_total(S.d_hist, s, S.d_sumsq, S.d_w_over_n, K, E.stream);
+            pk::launch_f64_adam(S.d_opt_theta, S.d_m, S.d_v, S.d_grad, P, lr, beta1, beta2, eps, c1, c2, E.stream);
+        }
+    }
+    {
+        pinn_engine& E0 = *es[0];
+        DeviceScope scope(E0.device);
+        F64State& S0 = *(F64State*)E0.f64;
+        if (loss_history && plat_d2h(loss_history, S0.d_hist, sizeof(double) * nsteps, E0.stream)) return fail("D2H copy failed");
+    }
+    for (int i = 0; i < ndev; ++i) {
+        DeviceScope scope(es[i]->device);
+        if (plat_sync(es[i]->stream)) return fail(std::string("device error: ") + plat_last_error());
+    }
     return 0;
 }
 // one Adam update of the float64 state from a caller-supplied host vector [gradient (P) | raw per-term sums (K)] (pinn_adam_apply in float64 mode)

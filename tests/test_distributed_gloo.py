@@ -111,3 +111,68 @@ def test_two_rank_sharded_equals_single(emu_lib):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert le < 1e-6 and ge < 1e-6, (le, ge)
+
+
+def _f64_worker(rank, world, port, q):
+    """r06: the same two ranks in the FLOAT64 evaluation mode — pinn_loss_grad_sharded_device_f64 and the resident double Adam loop, the
+    transport (gloo) called once per evaluation with [P + K] doubles"""
+    import ctypes
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pinn_import
+    m = pinn_import.load()
+    from neuralpde_jl_amd import workloads
+    m._lib.set_library(m.Library(os.path.join(ROOT, "tests", "emu", "libpinn_emu.so")))
+    wl = workloads.cfg2_poisson2d(points=100, bcs_points=37, width=16, hidden=2)
+    rep = m.symbolic_discretize(wl.pde_system, wl.discretization(precision="f64"))
+    eng = rep.engine
+    sets = [np.asarray(s, dtype=np.float64) for s in rep.pde_train_sets + rep.bcs_train_sets]
+    w = np.array([1.0, 2.0, 0.5, 1.5, 3.0])
+    th0 = np.asarray(wl.theta, dtype=np.float64) + 1e-9
+    full_losses, full_grad = eng.loss_grad_f64(th0, w)
+    th_single, hist_single = eng.adam_f64(th0, 6, 1e-2, w)
+    for k, s in enumerate(sets):
+        n = s.shape[1]
+        lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+        eng.set_points_f64(k, s[:, lo:hi], n_norm=n)
+    dtypes = []
+
+    def allreduce(buf, count, dtype, stream):
+        dtypes.append(dtype)
+        ty = ctypes.c_float if dtype == 0 else ctypes.c_double
+        a = np.ctypeslib.as_array(ctypes.cast(buf, ctypes.POINTER(ty)), shape=(count,))
+        dist.all_reduce(torch.from_numpy(a))
+        return 0
+
+    eng.comm_init_custom(world, rank, allreduce)
+    out = np.zeros(eng.P + eng.K)
+    eng.loss_grad_sharded_device_f64(th0.ctypes.data, out.ctypes.data, w, 0)
+    losses = out[eng.P:] / np.array([s.shape[1] for s in sets])
+    le = float(np.max(np.abs(losses - full_losses) / full_losses))
+    ge = float(np.linalg.norm(out[:eng.P] - full_grad) / np.linalg.norm(full_grad))
+    th, hist = eng.adam_f64(th0, 6, 1e-2, w)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, th)
+    if rank == 0:
+        same = all(np.array_equal(g, gathered[0]) for g in gathered)
+        q.put((same, le, ge, float(np.max(np.abs(th - th_single))), float(np.max(np.abs(hist - hist_single) / hist_single)), set(dtypes)))
+    eng.comm_destroy()
+    dist.destroy_process_group()
+
+
+def test_two_rank_float64_mode(emu_lib):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_f64_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    same, le, ge, dth, dh, dtypes = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert same and dtypes == {1}                       # identical theta on both ranks; only doubles crossed the transport
+    assert le < 1e-13 and ge < 1e-13, (le, ge)          # = the single-handle float64 evaluation to double rounding
+    assert dth < 2e-9 and dh < 1e-7, (dth, dh)

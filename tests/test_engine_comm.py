@@ -205,3 +205,140 @@ def test_rccl_communicators_on_the_visible_devices(npde, hip_lib):
     np.testing.assert_allclose(engs2[0].adam_get(), t_p, rtol=0, atol=2e-5)      # (another handle: Adam amplifies last-bit gradient differences of near-zero entries)
     for e in engs2:
         e.comm_destroy()
+
+
+def _engines_f64(npde, wl, ndev, devices=None):
+    rep = npde.symbolic_discretize(wl.pde_system, wl.discretization(precision="f64"))
+    sets = rep.pde_train_sets + rep.bcs_train_sets
+    desc = rep.engine.descriptor
+    engs = [npde.Engine(desc, device=(devices[g] if devices else g)) for g in range(ndev)]
+    for g, e in enumerate(engs):
+        e.set_option("precision", "f64")
+        for k, s in enumerate(sets):
+            n = s.shape[1]
+            lo, hi = (n * g) // ndev, (n * (g + 1)) // ndev
+            e.set_points_f64(k, np.asarray(s, dtype=np.float64)[:, lo:hi], n_norm=n)
+    return rep, engs
+
+
+@pytest.mark.parametrize("ndev", [2, 3])
+def test_float64_mode_sharded_equals_single_handle(npde, use_emu, ndev):
+    """r06: the communicator paths in the float64 evaluation mode — pinn_loss_grad_sharded_f64 (one all-reduce of [P + K] DOUBLES) returns the
+    single-handle float64 losses and gradient to double rounding; pinn_adam_steps_sharded over float64-mode handles equals the single-handle
+    resident double loop on the union of the shards"""
+    from neuralpde_jl_amd import workloads
+    wl = workloads.cfg2_poisson2d(points=100, bcs_points=37, width=16, hidden=2)
+    rep, engs = _engines_f64(npde, wl, ndev)
+    w = np.array([1.0, 2.0, 0.5, 1.5, 3.0])
+    th0 = np.asarray(wl.theta, dtype=np.float64) + 1e-9                # (not representable in float: a float leg anywhere would show)
+    L0, G0 = rep.engine.loss_grad_f64(th0, w)
+    assert rep.engine.get_option("precision") == "f64"
+    npde.comm_init_all(engs)
+    L, G = npde.loss_grad_sharded_f64(engs, th0, w)
+    np.testing.assert_allclose(L, L0, rtol=1e-13)
+    assert np.linalg.norm(G - G0) / np.linalg.norm(G0) < 1e-13
+    L2, G2 = npde.loss_grad_sharded_f64(engs, th0, w)
+    assert np.array_equal(L, L2) and np.array_equal(G, G2)
+    # a float-mode handle in the list is refused
+    engs[1].set_option("precision", "f32")
+    with pytest.raises(Exception, match="float64 evaluation mode"):
+        npde.loss_grad_sharded_f64(engs, th0, w)
+    engs[1].set_option("precision", "f64")
+    # the resident loop
+    for e in engs:
+        e.adam_init_f64(th0)
+    hist = npde.adam_steps_sharded(engs, 6, 1e-2, w)
+    thetas = [e.adam_get_f64() for e in engs]
+    for t in thetas[1:]:
+        assert np.array_equal(t, thetas[0])
+    th_single, hist_single = rep.engine.adam_f64(th0, 6, 1e-2, w)
+    np.testing.assert_allclose(thetas[0], th_single, rtol=0, atol=2e-9)      # (Adam amplifies last-bit gradient differences of near-zero entries)
+    np.testing.assert_allclose(hist, hist_single, rtol=1e-7)
+    assert np.abs(thetas[0] - thetas[0].astype(np.float32)).max() > 1e-10   # the iterate stayed in double
+    for e in engs:
+        e.comm_destroy()
+
+
+def test_float64_mode_custom_transport(npde, use_emu):
+    """one-process-per-GPU communicator in float64 mode: pinn_loss_grad_sharded_device_f64 hands the caller's transport ONE buffer of
+    [P + K] doubles (dtype 1); pinn_adam_steps over it runs the double loop with that all-reduce inside every iteration"""
+    import ctypes
+    from neuralpde_jl_amd import workloads
+    wl = workloads.cfg2_poisson2d(points=64, bcs_points=16, width=16, hidden=2)
+    rep = npde.symbolic_discretize(wl.pde_system, wl.discretization(precision="f64"))
+    eng = rep.engine
+    calls = []
+
+    def allreduce(buf, count, dtype, stream):
+        ty = ctypes.c_float if dtype == 0 else ctypes.c_double
+        a = np.ctypeslib.as_array(ctypes.cast(buf, ctypes.POINTER(ty)), shape=(count,))
+        a *= 2
+        calls.append((count, dtype))
+        return 0
+
+    th0 = np.asarray(wl.theta, dtype=np.float64) + 1e-9
+    out = np.zeros(eng.P + eng.K)
+    with pytest.raises(Exception, match="no communicator"):
+        eng.loss_grad_sharded_device_f64(th0.ctypes.data, out.ctypes.data, None, 0)
+    L0, G0 = eng.loss_grad_f64(th0)
+    eng.comm_init_custom(2, 1, allreduce)
+    eng.loss_grad_sharded_device_f64(th0.ctypes.data, out.ctypes.data, None, 0)
+    assert calls == [(eng.P + eng.K, 1)]
+    np.testing.assert_array_equal(out[:eng.P], 2 * G0)
+    n = np.array([s.shape[1] for s in rep.pde_train_sets + rep.bcs_train_sets])
+    np.testing.assert_allclose(out[eng.P:] / n, 2 * L0, rtol=1e-14)
+    t_c, h_c = eng.adam_f64(th0, 4, 1e-2)
+    assert calls[1:] == [(eng.P + eng.K, 1)] * 4
+    eng.comm_destroy()
+    t_p, h_p = eng.adam_f64(th0, 4, 1e-2)
+    np.testing.assert_allclose(t_c, t_p, rtol=0, atol=1e-5)             # Adam on 2g = Adam on g up to eps
+    np.testing.assert_allclose(h_c, 2 * h_p, rtol=1e-4)
+    # a float-mode handle is refused by the double entry point
+    eng.set_option("precision", "f32")
+    eng.comm_init_custom(2, 1, allreduce)
+    with pytest.raises(Exception, match="float64 evaluation mode"):
+        eng.loss_grad_sharded_device_f64(th0.ctypes.data, out.ctypes.data, None, 0)
+    eng.comm_destroy()
+
+
+@pytest.mark.gpu
+def test_rccl_float64_mode_on_the_visible_devices(npde, hip_lib):
+    """real RCCL with ncclDouble: the float64-mode communicator paths on the visible device(s) — single-process form, one-process-per-GPU
+    form on a caller stream, and the resident double Adam loop with the in-stream all-reduce"""
+    import torch
+    from neuralpde_jl_amd import workloads
+    ndev = torch.cuda.device_count()
+    wl = workloads.cfg2_poisson2d(points=4096, bcs_points=1024)
+    rep, engs = _engines_f64(npde, wl, ndev)
+    assert engs[0].L.backend == "hip"
+    w = np.array([1.0, 2.0, 0.5, 1.5, 3.0])
+    th0 = np.asarray(wl.theta, dtype=np.float64) + 1e-9
+    L0, G0 = rep.engine.loss_grad_f64(th0, w)
+    assert rep.engine.get_option("f64_path") == "mfma"
+    npde.comm_init_all(engs)
+    L, G = npde.loss_grad_sharded_f64(engs, th0, w)
+    np.testing.assert_allclose(L, L0, rtol=1e-13)
+    assert np.linalg.norm(G - G0) / np.linalg.norm(G0) < 1e-13
+    for e in engs:
+        e.adam_init_f64(th0)
+    h_s = npde.adam_steps_sharded(engs, 5, 1e-3, w)
+    t_s = engs[0].adam_get_f64()
+    for e in engs:
+        e.comm_destroy()
+    eng = rep.engine
+    t_p, h_p = eng.adam_f64(th0, 5, 1e-3, w)
+    np.testing.assert_allclose(h_s, h_p, rtol=1e-9)
+    np.testing.assert_allclose(t_s, t_p, rtol=0, atol=1e-9)
+    eng.comm_init_rank(1, 0, npde.comm_unique_id())
+    th = torch.tensor(th0, dtype=torch.float64, device="cuda")
+    out = torch.zeros(eng.P + eng.K, dtype=torch.float64, device="cuda")
+    st = torch.cuda.current_stream()
+    eng.loss_grad_sharded_device_f64(th.data_ptr(), out.data_ptr(), w, st.cuda_stream)
+    st.synchronize()
+    n = np.array([s.shape[1] for s in rep.pde_train_sets + rep.bcs_train_sets])
+    np.testing.assert_allclose(out[eng.P:].cpu().numpy() / n, L0, rtol=1e-14)
+    np.testing.assert_array_equal(out[:eng.P].cpu().numpy(), G0)
+    t_c, h_c = eng.adam_f64(th0, 5, 1e-3, w)
+    eng.comm_destroy()
+    assert np.array_equal(t_c, t_p)
+    np.testing.assert_allclose(h_c, h_p, rtol=1e-14)
