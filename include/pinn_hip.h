@@ -288,7 +288,7 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
  *   what the last evaluation ran ("mfma" | "lanes" | "mfma+lanes").  7-8x the time of the fp32 kernels on the matrix pipe.
  *   Covers equations of up to 6 dependent variables (same argument count), Dense chains with tanh / sigmoid / sin, derivative orders <= 2
  *   in 1-3 inputs (1-D, and mixed / pure in 2-D and 3-D where instantiated: <= 4; 4-D: first and pure second), PDE parameters, quadrature
- *   weights, per-point DATA channels, device samplers; anything else (DGM, periodic embeddings) fails HERE with a message and leaves the fp32
+ *   weights, per-point DATA channels, device samplers, periodic input embeddings (r06); anything else (DGM) fails HERE with a message and leaves the fp32
  *   plan usable.  In this mode EVERY evaluating entry point runs the double kernels (r06): pinn_loss_grad / pinn_loss_grad_device /
  *   pinn_loss_device / pinn_term_grads / pinn_loglik_grad / pinn_residual / pinn_phi / pinn_derivative convert at the boundary, their _f64
  *   twins hand everything over in double; pinn_adam_init / _steps / _get / _apply keep theta and the moments in double on the device, in

@@ -185,7 +185,7 @@ end
 FLOAT64 evaluation of a live engine (`pinn_set_option(h, "precision", …)`, DESIGN.md section 4.5): `loss_grad` and `lbfgs!` then run the
 double kernels — the reference's default eltype (src/discretize.jl:432-449) — for a `BFGS()` finisher below the fp32 noise floor or a
 digit-by-digit comparison with a Float64 CPU run.  Point sets already installed are converted; `set_points!` keeps feeding both.
-Throws (and leaves the fp32 plan untouched) for problems the mode does not cover (DGM nets, periodic embeddings).  Since round 5 the resident
+Throws (and leaves the fp32 plan untouched) for problems the mode does not cover (DGM nets; periodic input embeddings are covered since round 6).  Since round 5 the resident
 Adam loop, the device samplers, per-point DATA channels and the device-pointer entries evaluate in double as well.
 """
 function set_precision!(e::HIPEngine, mode::Symbol)
@@ -216,7 +216,7 @@ The glue's PRECISION POLICY (r06) = the reference's contract, compute dtype = el
 Float64 unless the user passes Float32 ones, src/discretize.jl:432-449):
 `:auto` (default of `HIPStrategy` / `hip_discretize`) selects the float64 kernels for `eltype(θ) == Float64` and the fp32 kernels for
 `Float32`; `:f32` is the explicit fast opt-in (fp32 kernels whatever eltype(θ), 7-8x faster on the matrix pipe, results converted at
-the boundary); `:f64` forces the float64 kernels.  A problem the float64 kernels do not cover (DGM networks, periodic embeddings) fails
+the boundary); `:f64` forces the float64 kernels.  A problem the float64 kernels do not cover (DGM networks) fails
 at `discretize` time under `:auto` with the library's message — never a silent narrowing; pass `precision = :f32` for it.
 """
 function resolve_precision(precision::Symbol, θ)
@@ -708,9 +708,13 @@ communicator (`pinn_comm_init_all`); `loss_grad(se, θ, w)` = `pinn_loss_grad_sh
 struct ShardedEngine
     engines::Vector{HIPEngine}
 end
-function ShardedEngine(desc::AbstractString, sets::Vector{<:AbstractMatrix}; devices = 0:0)
+function ShardedEngine(desc::AbstractString, sets::Vector{<:AbstractMatrix}; devices = 0:0, precision::Symbol = :auto)
     engines = [HIPEngine(desc; device = d) for d in devices]
     G = length(engines)
+    # precision as everywhere else: the sets' eltype decides (Float64 sets -> the float64 evaluation mode on every device, the communicator
+    # then carries [P + K] doubles: pinn_loss_grad_sharded_f64 / the double resident loop, r06)
+    prec = precision === :auto ? (eltype(first(sets)) === Float64 ? :f64 : :f32) : precision
+    prec === :f64 && foreach(e -> set_precision!(e, :f64), engines)
     for (g, e) in enumerate(engines), (k, s) in enumerate(sets)
         n = size(s, 2)
         lo, hi = (n * (g - 1)) ÷ G + 1, (n * g) ÷ G
@@ -722,6 +726,15 @@ function ShardedEngine(desc::AbstractString, sets::Vector{<:AbstractMatrix}; dev
 end
 function loss_grad(se::ShardedEngine, θ::AbstractVector{<:Real}, w::AbstractVector{<:Real})
     e = se.engines[1]
+    if e.precision === :f64
+        θ64 = Vector{Float64}(θ); w64 = Vector{Float64}(w)
+        losses = zeros(Float64, e.K); grad = zeros(Float64, e.P)
+        hs = [x.h for x in se.engines]
+        GC.@preserve hs θ64 w64 losses grad check(ccall(sym(:pinn_loss_grad_sharded_f64), Cint,
+            (Ptr{Ptr{Cvoid}}, Cint, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+            hs, length(hs), θ64, e.P, w64, losses, grad), "pinn_loss_grad_sharded_f64")
+        return losses, grad
+    end
     θ32 = Vector{Float32}(θ); w32 = Vector{Float32}(w)
     losses = zeros(Float64, e.K); grad = zeros(Float32, e.P)
     hs = [x.h for x in se.engines]
@@ -742,14 +755,25 @@ function adam!(se::ShardedEngine, θ0::AbstractVector{<:Real}, nsteps::Integer, 
                β1::Real = 0.9, β2::Real = 0.999, ϵ::Real = 1.0e-8)
     e = se.engines[1]
     θ32 = Vector{Float32}(θ0); w32 = Vector{Float32}(w)
+    f64 = e.precision === :f64
+    θ64 = Vector{Float64}(θ0)
     for x in se.engines
-        GC.@preserve θ32 check(ccall(sym(:pinn_adam_init), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64), x.h, θ32, e.P), "pinn_adam_init")
+        if f64
+            GC.@preserve θ64 check(ccall(sym(:pinn_adam_init_f64), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), x.h, θ64, e.P), "pinn_adam_init_f64")
+        else
+            GC.@preserve θ32 check(ccall(sym(:pinn_adam_init), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64), x.h, θ32, e.P), "pinn_adam_init")
+        end
     end
     hist = zeros(Float64, nsteps)
     hs = [x.h for x in se.engines]
     GC.@preserve hs w32 hist check(ccall(sym(:pinn_adam_steps_sharded), Cint,
         (Ptr{Ptr{Cvoid}}, Cint, Cint, Cfloat, Cfloat, Cfloat, Cfloat, Ptr{Float32}, Ptr{Float64}),
         hs, length(hs), nsteps, η, β1, β2, ϵ, w32, hist), "pinn_adam_steps_sharded")
+    if f64
+        out64 = zeros(Float64, e.P)
+        GC.@preserve out64 check(ccall(sym(:pinn_adam_get_f64), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), e.h, out64, e.P), "pinn_adam_get_f64")
+        return out64, hist
+    end
     out = zeros(Float32, e.P)
     GC.@preserve out check(ccall(sym(:pinn_adam_get), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64), e.h, out, e.P), "pinn_adam_get")
     return Float64.(out), hist

@@ -1378,6 +1378,7 @@ static unsigned sampler_seed(const pinn_engine& E, const Term& T) {
 // one redraw of a sampled term's float point set (the float64 optimiser loop widens it afterwards: f64.cpp)
 static void redraw_term_f32(pinn_engine& E, Term& T) {
     aux::launch_sample(T.sampler, user_pts(T), (int)(T.n * T.d_user), T.d_user, T.d_lb, T.d_ub, sampler_seed(E, T), T.draws++, E.stream);
+    embed_points(E, T);                                  // (the float feature rows of an embedded term stay in step with the draw: a later switch back to fp32 reads them)
 }
 
 // Device-side table of a handle's redrawn terms (aux::ResampleTerm), draw counters as they stand now.  Returns the number of terms in the

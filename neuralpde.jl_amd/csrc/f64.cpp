@@ -6,7 +6,7 @@
 // evaluates natively, `pinn_loss_grad` converts at the boundary, `pinn_lbfgs` iterates on the float64 objective.
 // Scope: Dense chains with tanh / sigmoid / sin, equations of one or SEVERAL dependent variables (systems: up to 6 networks per equation, all
 // with the same number of inputs), derivative orders <= 2 in 1-3 inputs (1-D: <= 4; 4-D: first and pure second derivatives), PDE parameters
-// (param_estim), quadrature weights, per-point DATA channels, device samplers; no periodic embeddings, no DGM networks.  Anything else fails at pinn_set_option with a message — the fp32 plan of the handle stays usable.
+// (param_estim), quadrature weights, per-point DATA channels, device samplers, periodic input embeddings (r06: feature rows in double); no DGM networks.  Anything else fails at pinn_set_option with a message — the fp32 plan of the handle stays usable.
 #include "engine_types.hpp"
 #include "pinn_kernels6.hpp"
 
@@ -136,6 +136,14 @@ static const pk::F64MKernel* f64_find_m(const pinn_engine& E, const pk::F64Kerne
     return best;
 }
 
+// feature rows of an embedded term, in double: row d_user + k = sin / cos (omega_k x coordinate src_k) of every point of the [n][T.d] host image
+static void f64_embed_host(const Term& T, std::vector<double>& pts, int64_t n) {
+    for (int64_t i = 0; i < n; ++i)
+        for (size_t k = 0; k < T.emb_cols.size(); ++k) {
+            const double ph = T.emb_cols[k].omega * pts[(size_t)i * T.d + T.emb_cols[k].src];
+            pts[(size_t)i * T.d + T.d_user + k] = T.emb_cols[k].is_cos ? std::cos(ph) : std::sin(ph);
+        }
+}
 static int f64_convert_points(pinn_engine& E, F64Term& F, const Term& T) {
     // the float set as installed -> double (exact conversion of the fp32 values the fp32 kernels read)
     const int64_t n = T.n;
@@ -144,6 +152,7 @@ static int f64_convert_points(pinn_engine& E, F64Term& F, const Term& T) {
     std::vector<float> h((size_t)n * T.d);
     if (plat_d2h(h.data(), T.d_pts, sizeof(float) * h.size(), E.stream) || plat_sync(E.stream)) return fail("D2H copy of points failed");
     std::vector<double> hd(h.begin(), h.end());
+    if (!T.emb_cols.empty()) f64_embed_host(T, hd, n);    // (the float rows hold float-rounded sin / cos: recomputed from the coordinates in double)
     if (F.cap < n) {
         plat_free(F.d_pts);
         F.d_pts = (double*)plat_malloc(sizeof(double) * hd.size());
@@ -199,7 +208,6 @@ int f64_enable(pinn_engine& E) {
         for (int net : nets) {
             const Net& N = E.nets[net];
             if (N.kind != 0) return fail(who + "DGM networks are not covered by the float64 mode");
-            if (!N.emb_idx.empty()) return fail(who + "periodic input embeddings are not covered by the float64 mode");
             if (N.act != pk::ACT_TANH && N.act != pk::ACT_SIGMOID && N.act != pk::ACT_SIN && N.act != pk::ACT_MIXED) return fail(who + "this activation is not covered by the float64 mode");
             if (N.act == pk::ACT_MIXED && (int)N.sizes.size() - 2 > 8) return fail(who + "per-layer tanh / sigmoid mixes of more than 8 hidden layers are not covered by the float64 mode");
             if ((int)N.sizes.size() - 1 > pk::F64_MAX_LAYERS) return fail(who + "more than 16 Dense layers");
@@ -208,7 +216,9 @@ int f64_enable(pinn_engine& E) {
             all_sin = all_sin && N.act == pk::ACT_SIN;
         }
         if (any_sin && !all_sin) return fail(who + "mixes sin networks with tanh / sigmoid networks");
-        if (!T.emb_cols.empty()) return fail(who + "periodic input embeddings are not covered by the float64 mode");
+        // (periodic input embeddings, r06: the descriptor has rewritten the term already — sin / cos feature rows behind the user's coordinates, the
+        // network mapped onto them, derivative slots as chain-rule combinations (descriptor.cpp: apply_embeddings); this mode fills the feature rows in DOUBLE)
+        if (T.emb_cols.size() > 4) return fail(who + "more than 4 embedded feature rows");
         if (T.d > 4 || E.nets[nets[0]].sizes[0] > 4) return fail(who + "more than 4 coordinates");
         if ((int)T.slots.size() > pk::F64_MAX_SLOTS || T.d + E.np + (int)T.slots.size() + (int)T.ops.size() > pk::F64_MAX_ROWS)
             return fail(who + "residual expression too long for the float64 tape (96 rows)");
@@ -263,7 +273,15 @@ int f64_set_points(pinn_engine& E, int term, const double* pts, int64_t n) {
         if (!F.d_pts) { F.cap = 0; return fail("device allocation failed (float64 points)"); }
         F.cap = n;
     }
-    if (plat_h2d(F.d_pts, pts, sizeof(double) * (size_t)n * T.d, E.stream) || plat_sync(E.stream)) return fail("H2D copy of points failed");
+    if (T.emb_cols.empty()) {
+        if (plat_h2d(F.d_pts, pts, sizeof(double) * (size_t)n * T.d, E.stream) || plat_sync(E.stream)) return fail("H2D copy of points failed");
+    } else {                                             // the caller's [n][d_user] coordinates + the feature rows
+        std::vector<double> hd((size_t)n * T.d);
+        for (int64_t i = 0; i < n; ++i)
+            for (int j = 0; j < T.d_user; ++j) hd[(size_t)i * T.d + j] = pts[(size_t)i * T.d_user + j];
+        f64_embed_host(T, hd, n);
+        if (plat_h2d(F.d_pts, hd.data(), sizeof(double) * hd.size(), E.stream) || plat_sync(E.stream)) return fail("H2D copy of points failed");
+    }
     F.n = n;
     F.exact_pts = true;
     return 0;
@@ -462,6 +480,7 @@ int f64_stencil_enable(pinn_engine& E, bool on) {
         const std::string who = "derivative = stencil: term " + std::to_string(t) + ": ";
         for (auto& sl : T.slots) X.active = X.active || sl.order > 0 || sl.lap != 0;
         if (!X.active) continue;
+        if (!T.emb_cols.empty()) return fail(who + "the term reads a network behind a periodic input embedding: its derivative slots are derivatives with respect to the sin / cos FEATURES (descriptor rewrite), central differences of which are not the reference's differences in the coordinates");
         StBuilder B;
         std::vector<StOperand> slot_val;
         for (auto& sl : T.slots) {
@@ -752,10 +771,30 @@ int f64_net_eval(pinn_engine& E, int net, const double* theta, const double* pts
     const Net& N = E.nets[net];
     const std::string who = "float64 trial-function evaluation: ";
     if (N.kind != 0) return fail(who + "DGM networks are not covered by the float64 mode");
-    if (!N.emb_idx.empty()) return fail(who + "periodic input embeddings are not covered by the float64 mode");
     if (N.act != pk::ACT_TANH && N.act != pk::ACT_SIGMOID && N.act != pk::ACT_SIN && N.act != pk::ACT_MIXED) return fail(who + "this activation is not covered by the float64 mode");
     if ((int)N.sizes.size() - 1 > pk::F64_MAX_LAYERS || N.sizes[0] > 4) return fail(who + "more than 16 Dense layers / more than 4 inputs");
     const int d = N.sizes[0];
+    // a network behind a periodic input embedding (r06): the caller's points are the dependent variable's ARGUMENTS [n][n_inputs]; the Dense chain takes
+    // the features (pass-through arguments, then sin, then cos of the embedded ones — engine_types.hpp: Net::emb_idx), formed here in double
+    std::vector<double> feats;
+    if (!N.emb_idx.empty()) {
+        if (order > 0) return fail("pinn_derivative: not available for a network behind a periodic input embedding (use pinn_residual on a term that carries the derivative)");
+        const int nin = N.n_inputs(), ne = (int)N.emb_idx.size();
+        feats.resize((size_t)n * d);
+        for (int64_t q = 0; q < n; ++q) {
+            int pass = 0;
+            for (int a = 0; a < nin; ++a) {
+                const double x = pts[(size_t)q * nin + a];
+                const auto it = std::find(N.emb_idx.begin(), N.emb_idx.end(), a);
+                if (it == N.emb_idx.end()) { feats[(size_t)q * d + pass++] = x; continue; }
+                const int k = (int)(it - N.emb_idx.begin());
+                const double ph = 6.283185307179586476925286766559 / N.emb_period[k] * x;
+                feats[(size_t)q * d + nin - ne + k] = std::sin(ph);
+                feats[(size_t)q * d + nin + k] = std::cos(ph);
+            }
+        }
+        pts = feats.data();
+    }
     Slot sl;
     sl.net = net; sl.order = order; sl.lap = 0;
     for (int q = 0; q < MAX_DERIV_ORDER; ++q) sl.axes[q] = q < order ? axes[q] : 0;
@@ -832,7 +871,13 @@ int f64_points_from_device(pinn_engine& E, int term) {
         if (!F.d_pts) { F.cap = 0; return fail("device allocation failed (float64 points)"); }
         F.cap = T.n;
     }
-    pk::launch_f64_cvt(T.d_pts, F.d_pts, (int64_t)T.n * T.d, E.stream);
+    if (T.emb_cols.empty()) pk::launch_f64_cvt(T.d_pts, F.d_pts, (int64_t)T.n * T.d, E.stream);
+    else {                                               // the draw lives in d_upts [n][d_user] (the float feature rows are not refreshed by this loop): widened, features in double
+        pk::F64EmbedArgs ea;
+        ea.pts = F.d_pts; ea.upts = T.d_upts; ea.n = (int)T.n; ea.d = T.d; ea.du = T.d_user; ea.ncols = (int)T.emb_cols.size();
+        for (int k = 0; k < ea.ncols; ++k) { ea.src[k] = T.emb_cols[k].src; ea.is_cos[k] = T.emb_cols[k].is_cos; ea.omega[k] = T.emb_cols[k].omega; }
+        pk::launch_f64_embed(ea, E.stream);
+    }
     F.n = T.n;
     F.exact_pts = false;
     F.data_n = 0;                                        // (per-point data belong to the previous set: a sampled term with DATA channels fails its next evaluation with the message — ADVICE r05)

@@ -445,6 +445,14 @@ DEV V act_value(int act, V z) {
     if (act == ACT_TANH) return vtanh_fast(z);
     return vsigmoid_fast(z);
 }
+// the four elements of an accumulator fragment at once (tanh: the pairwise form, vec.hpp vtanh_fast4 — same bits)
+template <bool SINACT>
+DEV vfloat4 act_value4(int act, vfloat4 z) {
+    if (!SINACT && act == ACT_TANH) return vtanh_fast4(z);
+    vfloat4 a;
+    PINN_UNROLL for (int r = 0; r < 4; ++r) a[r] = act_value<SINACT>(act, z[r]);
+    return a;
+}
 // record value r0 of an element with pre-activation z and activation a, and the activation back from r0
 template <bool SINACT, class V> DEV V act_record(V z, V a) { return SINACT ? z : a; }
 template <bool SINACT, class V>

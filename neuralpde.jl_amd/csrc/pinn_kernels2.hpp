@@ -59,8 +59,12 @@
 // 4 dW GEMM with register-resident sums (H = 64), 8 dW GEMM with slab-resident sums (H = 128: not enabled — 32 more live registers in a kernel
 // that already spills).  (A variant that also formed the hh products of a dW tile in fresh accumulators, input tile as the outer loop, gave
 // the same parity figures to three digits and was not bit-reproducible in stand-alone launches on the hardware: removed, profiles/r05_experiments.txt.)
+// r06: FORWARD ONLY (1).  Measured on MI355X at the trained fixtures (tools/r05/theta_ab_gpu.py, profiles/r06_experiments.txt section 1): masks 1, 3, 5 and 7
+// give the same errors to three digits (cfg2 adam2000 / adam6000 / cfg3 adam2000 gradient against the oracle at float32(theta): 1.34e-5 / 4.06e-3 /
+// 4.83e-6; mask 0: 1.75e-5 / 5.27e-3 / 5.66e-6) — the coherent offset matters where it feeds the activations' cancellation, i.e. in the
+// pre-activations; the reverse GEMMs' outputs are summed over thousands of points with mixed signs.  10 fewer spilled registers, -1.5 %.
 #ifndef PINN_F2_SPLIT_ACC2
-#define PINN_F2_SPLIT_ACC2 7
+#define PINN_F2_SPLIT_ACC2 1
 #endif
 #ifndef PINN_F2_WACC_PRELOAD
 #define PINN_F2_WACC_PRELOAD 2          // slab-resident dW sums (H = 128) loaded as the dW GEMM's initial accumulators (2: fp32-MFMA kernels too)
@@ -395,11 +399,8 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
             PINN_UNROLL for (int pg = 0; pg < PG; ++pg)
                 PINN_UNROLL for (int t = 0; t < MTW; ++t) {
                     vfloat4 av;                                       // sin: activation values; Z[pg*C] holds the RECORD value z meanwhile
-                    PINN_UNROLL for (int r = 0; r < 4; ++r) {
-                        const vfloat z0 = Z[pg * C][t][r];
-                        av[r] = act_value<SINACT>(act, z0);
-                        Z[pg * C][t][r] = SINACT ? z0 : av[r];
-                    }
+                    av = act_value4<SINACT>(act, Z[pg * C][t]);
+                    if (!SINACT) Z[pg * C][t] = av;
                     if (RECOUT && layer > 0)
                         PINN_UNROLL for (int ch = 0; ch < C; ++ch)
                             ub_store4(RB, (((layer - 1) * NG + pg * C + ch) * MT + w * MTW + t) * 256, lane << 2, Z[pg * C + ch][t]);
@@ -701,7 +702,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                         vfloat4 z = b1;
                         PINN_UNROLL for (int i = 0; i < D; ++i)
                             PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = vfma(w1[i][r], x[pg][i], z[r]);
-                        PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = act_record<SINACT>(z[r], act_value<SINACT>(act, z[r]));
+                        if (!SINACT) z = act_value4<SINACT>(act, z);
                         Rlast[pg * C][t] = z;
                         PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) Rlast[pg * C + 1 + kf][t] = w1[S::first_axis(kf)];
                         PINN_UNROLL for (int ch = 1 + NFIRST; ch < C; ++ch) Rlast[pg * C + ch][t] = vzero4();
@@ -946,7 +947,7 @@ DEV void wave_tiles2(const GroupArgs& ga, int blk, int nblocks, int w, float* ld
                         vfloat4 z = b1;
                         PINN_UNROLL for (int i = 0; i < D; ++i)
                             PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = vfma(w1[i][r], x[pg][i], z[r]);
-                        PINN_UNROLL for (int r = 0; r < 4; ++r) z[r] = act_record<SINACT>(z[r], act_value<SINACT>(act, z[r]));
+                        if (!SINACT) z = act_value4<SINACT>(act, z);
                         Sr[pg * C][t] = z;
                         PINN_UNROLL for (int kf = 0; kf < NFIRST; ++kf) Sr[pg * C + 1 + kf][t] = w1[S::first_axis(kf)];
                         PINN_UNROLL for (int ch = 1 + NFIRST; ch < C; ++ch) Sr[pg * C + ch][t] = vzero4();

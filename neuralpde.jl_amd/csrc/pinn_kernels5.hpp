@@ -743,6 +743,15 @@ template <int HT> void launch_f64m_dwt(const F64Args& a, plat_stream st) {
 
 // ---- float64 optimiser loop (f64.cpp: f64_adam_steps): points redrawn by the fp32 samplers -> double, Adam in double, the step's total loss ----
 DEV void f64_cvt_elem(int i, const float* src, double* dst) { dst[i] = (double)src[i]; }
+// redrawn set of a term behind a periodic input embedding (f64.cpp): the float coordinates widened, feature row du + k = sin / cos (omega_k x_src_k) in double
+struct F64EmbedArgs { double* pts; const float* upts; int n, d, du, ncols; int src[4], is_cos[4]; double omega[4]; };      // upts: the drawn coordinates [n][du]
+HD void f64_embed_point(int p, const F64EmbedArgs& a) {
+    for (int j = 0; j < a.du; ++j) a.pts[(size_t)p * a.d + j] = (double)a.upts[(size_t)p * a.du + j];
+    for (int k = 0; k < a.ncols; ++k) {
+        const double ph = a.omega[k] * a.pts[(size_t)p * a.d + a.src[k]];
+        a.pts[(size_t)p * a.d + a.du + k] = a.is_cos[k] ? cos(ph) : sin(ph);
+    }
+}
 DEV void f64_adam_elem(int i, double* theta, double* m, double* v, const double* g, double lr, double b1, double b2, double eps, double c1, double c2) {
     const double gi = g[i];
     const double mi = b1 * m[i] + (1.0 - b1) * gi, vi = b2 * v[i] + (1.0 - b2) * gi * gi;
@@ -751,6 +760,7 @@ DEV void f64_adam_elem(int i, double* theta, double* m, double* v, const double*
 }
 #ifdef PINN_EMU
 inline void launch_f64_cvt(const float* src, double* dst, int64_t n, plat_stream) { for (int64_t i = 0; i < n; ++i) dst[i] = (double)src[i]; }
+inline void launch_f64_embed(const F64EmbedArgs& a, plat_stream) { for (int p = 0; p < a.n; ++p) f64_embed_point(p, a); }
 inline void launch_f64_adam(double* theta, double* m, double* v, const double* g, int P, double lr, double b1, double b2, double eps, double c1, double c2, plat_stream) {
     for (int i = 0; i < P; ++i) f64_adam_elem(i, theta, m, v, g, lr, b1, b2, eps, c1, c2);
 }
@@ -772,6 +782,11 @@ template <int UNUSED> __global__ void __launch_bounds__(256) k_f64_adam(double* 
 template <int UNUSED> __global__ void k_f64_total(double* hist, int step, const double* sumsq, const double* w_over_n, int K) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { double s = 0.0; for (int k = 0; k < K; ++k) s += w_over_n[k] * sumsq[k]; hist[step] = s; }
 }
+template <int UNUSED> __global__ void __launch_bounds__(256) k_f64_embed(const F64EmbedArgs a) {
+    const int p = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (p < a.n) f64_embed_point(p, a);
+}
+inline void launch_f64_embed(const F64EmbedArgs& a, plat_stream st) { hipLaunchKernelGGL((k_f64_embed<0>), dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, st, a); }
 inline void launch_f64_cvt(const float* src, double* dst, int64_t n, plat_stream st) { hipLaunchKernelGGL((k_f64_cvt<0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n); }
 inline void launch_f64_adam(double* theta, double* m, double* v, const double* g, int P, double lr, double b1, double b2, double eps, double c1, double c2, plat_stream st) {
     hipLaunchKernelGGL((k_f64_adam<0>), dim3((P + 255) / 256), dim3(256), 0, st, theta, m, v, g, P, lr, b1, b2, eps, c1, c2);

@@ -89,6 +89,7 @@ VFN1(vsigmoid_fast, 1.0f / (1.0f + exp2f(x * -1.4426950408889634f)))
 #else
 VFN1(vtanh_fast, std::tanh(x)) VFN1(vsigmoid_fast, 1.0f / (1.0f + std::exp(-x)))
 #endif
+inline vfloat4 vtanh_fast4(const vfloat4& x) { vfloat4 t; for (int r = 0; r < 4; ++r) t[r] = vtanh_fast(x[r]); return t; }
 VFN1(vsign, (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f))
 VFN1(vsinpi, std::sin(3.14159265358979323846f * x)) VFN1(vcospi, std::cos(3.14159265358979323846f * x))
 #undef VFN1
@@ -362,6 +363,34 @@ DEV vfloat vtanh_fast(vfloat x) {
     r = __builtin_fmaf(__builtin_fmaf(-s, r, 1.0f), r, r);
 #endif
     return __builtin_copysignf((1.0f - e) * r, x);
+#endif
+}
+// the four activations of one accumulator fragment (r06).  PINN_ACT_TANH_PK = 1: the SAME arithmetic as vtanh_fast (variant 4), bit for bit, written on
+// register pairs so that the exponent argument (v_pk_mul_f32 + v_pk_fma_f32 on x itself, |.| and the sign moved into v_exp_f32's source modifiers:
+// fma(|x|, -c_hi, |x| * -c_lo) = -|fma(x, c_hi, x * c_lo)| exactly), 1 + e, 1 - e and the final product take one instruction per PAIR: 5.5 VALU
+// instructions per activation instead of 7
+#ifndef PINN_ACT_TANH_PK
+#define PINN_ACT_TANH_PK 1
+#endif
+typedef float vfloat2_ __attribute__((ext_vector_type(2)));
+DEV vfloat4 vtanh_fast4(vfloat4 x) {
+#if PINN_ACT_TANH == 4 && PINN_ACT_TANH_PK
+    vfloat4 t;
+    PINN_UNROLL for (int h = 0; h < 2; ++h) {
+        const vfloat2_ xx = {x[2 * h], x[2 * h + 1]};
+        const vfloat2_ y = __builtin_elementwise_fma(xx, vfloat2_{2.885390043258667f, 2.885390043258667f}, xx * 3.851926067000022e-08f);
+        const vfloat2_ e = {__builtin_amdgcn_exp2f(-__builtin_fabsf(y[0])), __builtin_amdgcn_exp2f(-__builtin_fabsf(y[1]))};
+        const vfloat2_ s = e + 1.0f;
+        const vfloat2_ r = {__builtin_amdgcn_rcpf(s[0]), __builtin_amdgcn_rcpf(s[1])};
+        const vfloat2_ q = (1.0f - e) * r;
+        t[2 * h] = __builtin_copysignf(q[0], xx[0]);
+        t[2 * h + 1] = __builtin_copysignf(q[1], xx[1]);
+    }
+    return t;
+#else
+    vfloat4 t;
+    PINN_UNROLL for (int r = 0; r < 4; ++r) t[r] = vtanh_fast(x[r]);
+    return t;
 #endif
 }
 DEV vfloat vsigmoid_fast(vfloat x) {

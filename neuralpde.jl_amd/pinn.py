@@ -206,7 +206,7 @@ class PhysicsInformedNN:
         #   "auto" (default): Float64 parameters (incl. init_params = None) -> the engine's float64 evaluation mode (pinn_set_option(h,
         #           "precision", "f64"): objective, gradient, every public closure and the BFGS / L-BFGS stages in double, points handed
         #           over in double); Float32 parameters -> the fp32 kernels.  A problem the float64 kernels do not cover (DGM networks,
-        #           periodic embeddings, general mixed derivatives of order >= 3) FAILS at discretize time with the reason — never a
+        #           general mixed derivatives of order >= 3; periodic embeddings are covered since r06) FAILS at discretize time with the reason — never a
         #           silent narrowing;
         #   "f32":  the explicit fast opt-in — fp32 kernels (7-8x faster on the matrix pipe) whatever eltype(theta); parameters and
         #           results are converted at the boundary;

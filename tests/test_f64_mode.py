@@ -176,8 +176,8 @@ def test_f64_mode_derivative_orders_activations_weights(npde, use_emu):
     assert rep2.engine.get_option("precision") == "f64"
     l64s, g64s = rep2.engine.loss_grad_f64(np.asarray(rep2.flat_init_params, dtype=np.float64))
     assert 1e-10 < np.linalg.norm(g64s - g32) / np.linalg.norm(g64s) < 1e-5
-    # still outside the mode: periodic embeddings, DATA channels, DGM networks — the switch fails with a message and the fp32 plan stays usable
-    # (tests/test_emu_parity.py::test_periodic_embedding_* carry such handles)
+    # still outside the mode: DGM networks — the switch fails with a message and the fp32 plan stays usable (periodic embeddings: covered since r06,
+    # test_f64_periodic_embedding)
 
 
 def test_reference_pde_iii_system_meets_its_float64_criterion(npde, use_emu):
@@ -803,3 +803,60 @@ def test_f64_per_layer_activation_mixes(npde, use_emu):
             assert le.max() < EXACT and g2 < EXACT and gi < EXACT, (acts, nomfma, le, g2, gi)
         pts = np.array([[0.3, 0.7], [0.6, 0.2]])[:d]
         np.testing.assert_allclose(rep.phi(pts, th)[0], po.phi_values(prob.chains[0], th, pts)[0], rtol=1e-13, atol=1e-14)
+
+
+def test_f64_periodic_embedding(npde, use_emu):
+    """r06: a network behind a periodic input embedding (test/CUDA/nnpde_cuda__1d_pde_dirichlet_bc_cuda.jl:26-48) in the float64 mode — what a
+    Float64 init_params selects by default.  The term is the descriptor's rewrite over the features (t, sin x, cos x); the feature rows of the
+    double point sets are formed in DOUBLE (host sets, pinn_set_points_f64, redrawn sets).  Losses, gradient, residuals and the trial function
+    against the float64 oracle (which embeds inside the chain and differentiates in (t, x)) to rounding; on the matrix pipe and lane per point."""
+    import os
+    sysm, chain = tp.periodic_heat(npde)
+    strat = npde.QuasiRandomTraining(60, bcs_points=23, sampling_alg=npde.SobolSample(seed=5), resampling=False, minibatch=1)
+    theta = tp.theta_for(chain, 11)
+    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, strat, init_params=theta))
+    eng = rep.engine
+    assert eng.get_option("precision") == "f64"
+    sets = rep.pde_train_sets + rep.bcs_train_sets
+    prob = helpers.oracle_problem(npde, sysm, [chain])
+    th = np.asarray(rep.flat_init_params, dtype=np.float64) + 1e-9
+    w = [1.0, 2.0, 0.5, 1.5]
+    ref = po.loss_and_grad(prob, th, sets, weights=w, mode="exact")
+    for nomfma in (False, True):
+        if nomfma:
+            os.environ["PINN_F64_NO_MFMA"] = "1"
+        try:
+            l64, g64 = eng.loss_grad_f64(th, w)
+            path = eng.get_option("f64_path")
+        finally:
+            os.environ.pop("PINN_F64_NO_MFMA", None)
+        assert path == ("lanes" if nomfma else "mfma")
+        le, g2, gi = helpers.rel_errors(l64, g64, ref)
+        assert le.max() < EXACT and g2 < EXACT and gi < EXACT, (nomfma, le, g2, gi)
+    r = eng.residual_f64(0, th, sets[0].shape[1])
+    np.testing.assert_allclose(r, po.residual_values(prob, th, 0, sets[0], mode="exact").reshape(-1), rtol=0, atol=1e-11)
+    pts = np.array([[0.3, 0.7], [0.4, 5.0]])
+    np.testing.assert_allclose(eng.phi_f64(0, th, pts), po.phi_values(prob.chains[0], th, pts).reshape(-1), rtol=0, atol=1e-13)
+    np.testing.assert_allclose(eng.phi_f64(0, th, pts), eng.phi_f64(0, th, pts + np.array([[0.0], [2 * np.pi]])), rtol=0, atol=1e-13)
+    with pytest.raises(Exception, match="periodic input embedding"):
+        eng.derivative_f64(0, th, pts, [1])
+    # the float entry point of the same handle: converted at the boundary
+    l32, g32 = eng.loss_grad(th.astype(np.float32), np.asarray(w, dtype=np.float32))
+    assert np.linalg.norm(g32 - ref.grad) / np.linalg.norm(ref.grad) < 1e-5
+    # a set installed in float is converted and its feature rows recomputed in double
+    eng.set_points(0, sets[0].astype(np.float32))
+    s32 = sets[0].astype(np.float32).astype(np.float64)
+    ref32 = po.loss_and_grad(prob, th, [s32] + sets[1:], weights=w, mode="exact")
+    l, g = eng.loss_grad_f64(th, w)
+    le, g2, gi = helpers.rel_errors(l, g, ref32)
+    assert le.max() < EXACT and g2 < EXACT, (le, g2)
+    # device samplers: drawn in the caller's coordinates (float), feature rows in double on the device
+    eng.set_sampler(0, [0.0, 0.0], [1.0, 2 * np.pi], 50, seed=7, kind=1)
+    th1, hist = eng.adam_f64(th, 1, 1e-3, w)
+    drawn = eng.get_points(0, 2, 50).astype(np.float64)
+    refd = po.loss_and_grad(prob, th, [drawn] + sets[1:], weights=w, mode="exact")
+    assert abs(hist[0] - float(np.dot(w, refd.term_losses))) < 1e-11 * abs(hist[0])
+    # the reference-semantics validation mode differentiates in the coordinates: refused for an embedded term, the exact mode stays
+    with pytest.raises(Exception, match="periodic input embedding"):
+        eng.set_option("derivative", "stencil")
+    assert eng.get_option("derivative") == "exact"

@@ -41,7 +41,8 @@ CASES = [("test_pde_ii_2d_poisson", {"strategy": "grid"}), ("test_pde_ii_2d_pois
          ("test_simple_1d_ode_all_strategies", {"strategy": "grid"}), ("test_simple_1d_ode_all_strategies", {"strategy": "stochastic"}),
          ("test_simple_1d_ode_all_strategies", {"strategy": "quadrature"}), ("test_adaptive_loss_2d_poisson", {"scheme": "gradientscale"}),
          ("test_adaptive_loss_2d_poisson", {"scheme": "minimax"}), ("test_lorenz_parameter_estimation", {}),
-         ("test_direct_function_approximation_2d", {}), ("test_cuda_2d_pde", {})]
+         ("test_direct_function_approximation_2d", {}), ("test_cuda_2d_pde", {}),
+         ("test_cuda_1d_pde_dirichlet_bc_periodic_embedding", {})]                # (r06: periodic input embeddings in the float64 mode)
 
 
 @pytest.mark.parametrize("name,kw", CASES, ids=[n + ("[" + "-".join(map(str, k.values())) + "]" if k else "") for n, k in CASES])
