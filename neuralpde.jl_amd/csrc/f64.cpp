@@ -77,6 +77,12 @@ struct F64State {
     double* d_aux_out = nullptr;         // per-point outputs (residuals, trial-function values / derivatives) [n]
     int64_t aux_pts_cap = 0, aux_out_cap = 0;
     int path = 0;                        // kernels of the last evaluation: bit 0 one lane per point (family 4), bit 1 matrix pipe (family 4m)
+    // MERGED launches of small problems (r06, f64_make_groups): terms that share networks, input binding and an instantiated jet set in ONE tile / dW /
+    // reduction launch sequence; rebuilt when a term's point count changes
+    struct Group { std::vector<int> terms; const pk::F64Kernel* k = nullptr; const pk::F64MKernel* km = nullptr; std::vector<std::vector<int>> slot_chan; };
+    std::vector<Group> groups;
+    std::vector<int64_t> groups_sig;     // the point counts the grouping was made for (empty: not made yet)
+    int merged_launches = 0;             // of the last evaluation (pinn_get_option "f64_merged")
 };
 
 static void f64_free(F64State* S) {
@@ -622,7 +628,7 @@ static int f64_stencil_term(pinn_engine& E, int t, const double* theta, double* 
             r.slab = S.d_slab; r.nblocks = (a.npts + pk::F64_BLOCK - 1) / pk::F64_BLOCK; r.nent = a.nent;
             r.grad = grad; r.ent_p = a.ent_p; r.p_off = E.p_theta_off; r.nnets = 1;
             r.ent0[0] = a.net[0].ent0; r.theta0[0] = a.net[0].theta0;
-            r.sumsq = sumsq_t; r.with_grad = mode == 0 ? 1 : 0;
+            r.sumsq = sumsq_t; r.nsq = 1; r.sq_off[0] = 0; r.with_grad = mode == 0 ? 1 : 0;
             r.init_sumsq = (v == 0 && p0 == 0) ? 1 : 0;
             r.init_grad = 0;
             pk::launch_f64_reduce(r, E.stream);
@@ -630,6 +636,73 @@ static int f64_stencil_term(pinn_engine& E, int t, const double* theta, double* 
         F.d_pts = nullptr;
     }
     return 0;
+}
+
+// the matrix-pipe tile kernel reads the per-term fields through F64Args::sub (pinn_kernels4.hpp: F64Sub): a plain launch mirrors its own fields into entry 0
+static void f64_launch_tile(const pk::F64MKernel* km, pk::F64Args& a, plat_stream st) {
+    if (a.nsub == 0) {
+        pk::F64Sub& u = a.sub[0];
+        u.pts = a.pts; u.pw = a.pw; u.data = a.data; u.prog = a.prog; u.imm = a.imm; u.scale = a.scale;
+        u.N = a.N; u.nops = a.nops; u.out_row = a.out_row; u.nslots = a.nslots;
+        for (int q = 0; q < pk::F64_MAX_SLOTS; ++q) { u.slot_net[q] = (unsigned char)a.slot_net[q]; u.slot_chan[q] = (unsigned char)a.slot_chan[q]; }
+    }
+    km->launch_tile(a, st);
+}
+
+// Which terms ride in one launch (see F64State::Group).  Small problems only: a merged launch evaluates every member on the UNION jet set (a value-only
+// boundary term carries the interior term's derivative channels), which costs nothing while every tile of the problem is resident at once and the
+// evaluation is bound by the latency of one tile per launch — and would multiply the boundary terms' work on a large problem.
+constexpr int64_t F64_MERGE_MAX_POINTS = 8192;
+static void f64_make_groups(pinn_engine& E, F64State& S) {
+    const int K = (int)S.terms.size();
+    std::vector<int64_t> sig(K);
+    for (int t = 0; t < K; ++t) sig[t] = S.terms[t].n;
+    if (sig == S.groups_sig) return;
+    S.groups_sig = sig;
+    S.groups.clear();
+    if (std::getenv("PINN_F64_NO_MERGE") || std::getenv("PINN_F64_NO_MFMA")) return;
+    std::vector<char> used(K, 0);
+    for (int t = 0; t < K; ++t) {
+        if (used[t]) continue;
+        const Term& T0 = E.terms0[t];
+        const F64Term& F = S.terms[t];
+        if (!F.km || F.km->sliced || F.n <= 0) continue;
+        F64State::Group G;
+        std::vector<Slot> slots = T0.slots;
+        int64_t pts = F.n;
+        G.terms.push_back(t);
+        for (int u = t + 1; u < K && (int)G.terms.size() < pk::F64_MAX_SUB; ++u) {
+            const Term& U0 = E.terms0[u];
+            const F64Term& Fu = S.terms[u];
+            if (used[u] || !Fu.km || Fu.km->sliced || Fu.n <= 0) continue;
+            if (Fu.nets != F.nets || U0.d != T0.d || U0.inmap != T0.inmap) continue;
+            if (pts + Fu.n > F64_MERGE_MAX_POINTS) continue;
+            std::vector<Slot> trial = slots;
+            trial.insert(trial.end(), U0.slots.begin(), U0.slots.end());
+            std::vector<int> ch;
+            std::string why;
+            const pk::F64Kernel* k = f64_find(E.nets[F.nets[0]].sizes[0], trial, ch, why);
+            const pk::F64MKernel* km = k ? f64_find_m(E, k, F.nets) : nullptr;
+            if (!km || km->sliced) continue;
+            slots.swap(trial);
+            pts += Fu.n;
+            G.terms.push_back(u);
+        }
+        if (G.terms.size() < 2 || pts > F64_MERGE_MAX_POINTS) continue;
+        std::vector<int> ch;
+        std::string why;
+        G.k = f64_find(E.nets[F.nets[0]].sizes[0], slots, ch, why);
+        G.km = G.k ? f64_find_m(E, G.k, F.nets) : nullptr;
+        if (!G.km || G.km->sliced) continue;
+        size_t o = 0;
+        for (int u : G.terms) {
+            const size_t ns = E.terms0[u].slots.size();
+            G.slot_chan.emplace_back(ch.begin() + o, ch.begin() + o + ns);
+            o += ns;
+            used[u] = 1;
+        }
+        S.groups.push_back(std::move(G));
+    }
 }
 
 // loss sums (`sumsq`, K doubles) and gradient (`grad`, P doubles; nullptr: loss only) at the parameters `theta` — all three device pointers —
@@ -656,13 +729,79 @@ static int f64_eval_device(pinn_engine& E, const double* theta, double* grad, do
     // the first reduction of the evaluation writes the gradient instead of adding to it when its term's entries cover all of theta (one network,
     // or every network in the first equation); otherwise one memset.  Every term's first chunk writes its own sum of squares.
     bool grad_started = false;
-    if (grad) {
+    if (grad && S.stencil) { plat_memset(grad, 0, sizeof(double) * P, E.stream); grad_started = true; }
+    // (called in front of the evaluation's FIRST reduction: 1 = that launch writes the gradient, 0 = the gradient was just zeroed and it adds)
+    auto first_reduction_writes = [&](const std::vector<int>& nets) -> int {
+        if (!grad || grad_started) return 0;
+        grad_started = true;
         int64_t covered = E.ne;
-        for (int ni : S.terms[0].nets) covered += E.nets[ni].nparams();
-        if (covered != P || S.stencil) { plat_memset(grad, 0, sizeof(double) * P, E.stream); grad_started = true; }
-    }
+        for (int ni : nets) covered += E.nets[ni].nparams();
+        if (covered == P) return 1;
+        plat_memset(grad, 0, sizeof(double) * P, E.stream);
+        return 0;
+    };
     S.path = 0;
+    S.merged_launches = 0;
+    std::vector<char> done(K, 0);
+    if (!S.stencil) {
+        f64_make_groups(E, S);
+        for (const F64State::Group& G : S.groups) {
+            // a pseudo-term on the union jet set; its networks, rows and slab entries are the members' (same networks)
+            const int m = (int)G.terms.size(), t0 = G.terms[0];
+            const Term& T0 = E.terms0[t0];
+            F64Term Fg;
+            Fg.k = G.k; Fg.km = G.km; Fg.nets = S.terms[t0].nets;
+            Fg.nops = 0; Fg.nslots = 0; Fg.out_row = 0; Fg.ndata = 0;
+            F64Launch L;
+            if (f64_build(E, Fg, T0.d, &T0.inmap, L)) return 1;
+            if (!L.mfma || L.sliced) continue;
+            pk::F64Args& a = L.a;
+            const int tp = a.tile_pts;
+            int tiles = 0;
+            a.nsub = m;
+            for (int q = 0; q < m; ++q) {
+                const int t = G.terms[q];
+                const Term& T = E.terms[t];
+                const F64Term& F = S.terms[t];
+                pk::F64Sub& u = a.sub[q];
+                a.sub_tile0[q] = tiles;
+                tiles += (int)((F.n + tp - 1) / tp);
+                u.pts = F.d_pts; u.pw = (T.pw_n == T.n && T.pw_n > 0) ? T.d_pw : nullptr; u.data = F.ndata > 0 ? F.d_data : nullptr;
+                u.prog = F.d_prog; u.imm = F.d_imm;
+                u.scale = 2.0 * (term_w ? term_w[t] : 1.0) / (double)T.n_norm;
+                u.N = (int)F.n; u.nops = F.nops; u.out_row = F.out_row; u.nslots = F.nslots;
+                for (int sl = 0; sl < F.nslots; ++sl) { u.slot_net[sl] = (unsigned char)F.slot_net[sl]; u.slot_chan[sl] = (unsigned char)G.slot_chan[q][sl]; }
+            }
+            a.sub_tile0[m] = tiles;
+            for (int q = m + 1; q <= pk::F64_MAX_SUB; ++q) a.sub_tile0[q] = tiles;
+            a.nent += m - 1;                             // (the slab row ends in one sum of squares per member)
+            a.theta = theta;
+            a.mode = grad ? 0 : 1;
+            a.p0 = 0;
+            a.npts = tiles * tp;
+            int64_t chunk = 0;
+            if (f64_buffers(E, S, L, a.npts, true, chunk)) return 1;
+            if (chunk < a.npts) continue;                // (does not fit one launch: the members go one by one below)
+            S.path |= 2;
+            ++S.merged_launches;
+            f64_launch_tile(G.km, a, E.stream);
+            G.km->launch_dwt(a, E.stream);
+            pk::F64ReduceArgs r;
+            std::memset(&r, 0, sizeof r);
+            r.slab = S.d_slab; r.nblocks = (a.npts + pk::F64_BLOCK - 1) / pk::F64_BLOCK; r.nent = a.nent;
+            r.grad = grad; r.ent_p = a.ent_p; r.p_off = E.p_theta_off; r.nnets = a.nnets;
+            for (int ni = 0; ni < a.nnets; ++ni) { r.ent0[ni] = a.net[ni].ent0; r.theta0[ni] = a.net[ni].theta0; }
+            r.sumsq = sumsq; r.nsq = m;
+            for (int q = 0; q < m; ++q) r.sq_off[q] = G.terms[q];
+            r.with_grad = grad ? 1 : 0;
+            r.init_sumsq = 1;
+            r.init_grad = first_reduction_writes(Fg.nets);
+            pk::launch_f64m_reduce(r, E.stream);
+            for (int t : G.terms) done[t] = 1;
+        }
+    }
     for (int t = 0; t < K; ++t) {
+        if (done[t]) continue;
         const Term& T = E.terms[t];
         const Term& T0 = E.terms0[t];
         F64Term& F = S.terms[t];
@@ -685,7 +824,7 @@ static int f64_eval_device(pinn_engine& E, const double* theta, double* grad, do
         for (int64_t p0 = 0; p0 < F.n; p0 += chunk) {
             a.p0 = (int)p0;
             a.npts = (int)std::min<int64_t>(chunk, F.n - p0);
-            if (L.mfma) F.km->launch_tile(a, E.stream);
+            if (L.mfma) f64_launch_tile(F.km, a, E.stream);
             else F.k->launch_point(a, L.sin_act, E.stream);
             if (!L.mfma) pk::launch_f64_dw(a, E.stream);         // (matrix-pipe path: those entries come out of the tile kernel, summed in the dW launch)
             if (L.mfma) F.km->launch_dwt(a, E.stream);
@@ -695,10 +834,9 @@ static int f64_eval_device(pinn_engine& E, const double* theta, double* grad, do
             r.slab = S.d_slab; r.nblocks = (a.npts + pk::F64_BLOCK - 1) / pk::F64_BLOCK; r.nent = a.nent;
             r.grad = grad; r.ent_p = a.ent_p; r.p_off = E.p_theta_off; r.nnets = a.nnets;
             for (int ni = 0; ni < a.nnets; ++ni) { r.ent0[ni] = a.net[ni].ent0; r.theta0[ni] = a.net[ni].theta0; }
-            r.sumsq = sumsq + t; r.with_grad = grad ? 1 : 0;
+            r.sumsq = sumsq + t; r.nsq = 1; r.sq_off[0] = 0; r.with_grad = grad ? 1 : 0;
             r.init_sumsq = (p0 == 0) ? 1 : 0;
-            r.init_grad = (grad && !grad_started) ? 1 : 0;
-            if (grad) grad_started = true;
+            r.init_grad = first_reduction_writes(F.nets);
             if (L.mfma) pk::launch_f64m_reduce(r, E.stream);
             else pk::launch_f64_reduce(r, E.stream);
         }
@@ -736,7 +874,7 @@ static int f64_values(pinn_engine& E, F64State& S, const F64Term& F, F64Launch& 
     for (int64_t p0 = 0; p0 < n; p0 += chunk) {
         a.p0 = (int)p0;
         a.npts = (int)std::min<int64_t>(chunk, n - p0);
-        if (L.mfma) F.km->launch_tile(a, E.stream);
+        if (L.mfma) f64_launch_tile(F.km, a, E.stream);
         else F.k->launch_point(a, L.sin_act, E.stream);
     }
     return 0;
@@ -1012,6 +1150,7 @@ std::string f64_describe(const pinn_engine& E) {
     return c + k;
 }
 
+int f64_merged(const pinn_engine& E) { return E.f64 ? ((const F64State*)E.f64)->merged_launches : 0; }
 const char* f64_path(const pinn_engine& E) {
     if (!E.f64) return "off";
     const int p = ((const F64State*)E.f64)->path;

@@ -45,6 +45,18 @@ struct F64Net {
                                         // lower ones): the sliced kernels (pinn_kernels6.hpp) carry channels [0, ceff) of this network and leave the rest zero —
                                         // an equation that couples several networks needs the full set from one of them only (cfg4: u 5, v 1, p 2 of C = 5)
 };
+// What differs between the terms of a MERGED launch of the matrix-pipe tile kernel (r06; f64.cpp: f64_eval_device): small problems — the reference's own
+// regime, a few hundred points per term — are bound by the latency of one tile per launch, so every term that shares the networks, the input
+// binding and an instantiated jet set rides in ONE launch (its tiles back to back, the tile's term looked up from sub_tile0).  A plain launch
+// reads entry 0.
+constexpr int F64_MAX_SUB = 6;
+struct F64Sub {
+    const double* pts; const float* pw; const double* data;
+    const rp::Instr* prog; const double* imm;
+    double scale;
+    int N, nops, out_row, nslots;
+    unsigned char slot_net[F64_MAX_SLOTS], slot_chan[F64_MAX_SLOTS];
+};
 struct F64Args {
     const double* theta;                // the whole parameter vector
     const double* pts;                  // [N][dt] point-major
@@ -84,7 +96,15 @@ struct F64Args {
     // parameters, then the sum of squares; f64m_tsum_entry adds a block's tiles in order into the slab
     double* tpart;
     int ntp, tp_p, tile_pts;            // columns per tile; first PDE-parameter column; points per tile (16 * PG)
+    // the tile kernel's per-term view (F64Sub above): nsub == 0: a plain launch, sub[0] repeats this struct's own fields; nsub >= 1: a merged launch —
+    // sub-term s owns tiles [sub_tile0[s], sub_tile0[s + 1]), its points are 0 .. sub[s].N - 1 of its own set, and the slab ends in nsub sums of squares
+    int nsub;
+    int sub_tile0[F64_MAX_SUB + 1];
+    F64Sub sub[F64_MAX_SUB];
 };
+static_assert(sizeof(F64Args) <= 4096, "F64Args is a by-value kernel argument (4 KB)");
+// number of sum-of-squares entries at the end of a block's slab row
+HD int f64_nsq(const F64Args& a) { return a.nsub > 0 ? a.nsub : 1; }
 
 // activation kind of hidden layer l: tanh and sigmoid are a RUN-TIME kind in the float64 kernels, so per-layer mixes (Lux chains like
 // Dense(.., sigma) -> Dense(.., tanh), test/NNPDE2/additional_loss__lorenz_system.jl) cost nothing extra
@@ -384,12 +404,13 @@ struct F64ReduceArgs {
     int nnets, ent0[F64_MAX_NETS], theta0[F64_MAX_NETS];
     int p_off;
     double* sumsq;                       // += the term's sum of squares
+    int nsq, sq_off[F64_MAX_SUB];        // merged launches: the slab row ends in nsq sums; entry k goes to sumsq[sq_off[k]] (plain: nsq = 1, sq_off[0] = 0)
     int with_grad;
     int init_grad, init_sumsq;           // 1: this launch WRITES its sums (the evaluation's first reduction covering all of theta / the term's first chunk)
                                          // instead of adding to them: no memset launches in front of an evaluation
 };
 DEV void f64_reduce_write(int e, double s, const F64ReduceArgs& a) {
-    if (e == a.nent - 1) { *a.sumsq = a.init_sumsq ? s : *a.sumsq + s; return; }
+    if (e >= a.nent - a.nsq) { double* q = a.sumsq + a.sq_off[e - (a.nent - a.nsq)]; *q = a.init_sumsq ? s : *q + s; return; }
     int i;
     if (e >= a.ent_p) i = a.p_off + (e - a.ent_p);
     else {
@@ -400,7 +421,7 @@ DEV void f64_reduce_write(int e, double s, const F64ReduceArgs& a) {
     a.grad[i] = a.init_grad ? s : a.grad[i] + s;
 }
 DEV void f64_reduce_entry(int e, const F64ReduceArgs& a) {
-    if (e != a.nent - 1 && !a.with_grad) return;
+    if (e < a.nent - a.nsq && !a.with_grad) return;
     double s = 0.0;
     for (int b = 0; b < a.nblocks; ++b) s += a.slab[(size_t)b * a.nent + e];
     f64_reduce_write(e, s, a);

@@ -136,6 +136,12 @@ DEV void f64m_tile(int tile, const F64Args& a) {
     constexpr int C = J::C, NCG = PG * C, NR = HT * 4;
     constexpr bool SIN = (ACTK == ACT_SIN);
     const int pbase = tile * (16 * PG);
+    // this tile's term (F64Sub): its own point set, weights, data rows, tape, slots and seed factor; T_p0 + (launch point index) = index into its set
+    int sidx = 0;
+    for (int s_ = 1; s_ < a.nsub; ++s_) sidx += tile >= a.sub_tile0[s_] ? 1 : 0;
+    const F64Sub& T = a.sub[sidx];
+    const int T_p0 = a.nsub > 0 ? -a.sub_tile0[sidx] * (16 * PG) : a.p0;
+    const int T_npts = a.nsub > 0 ? a.sub_tile0[sidx] * (16 * PG) + T.N : a.npts;          // launch point indices below this one are points of the term
     double* S = a.scratch;
     LVd<NR * NCG> X, Z;                                          // X: operand of the next GEMM (a jets / dZ); Z: its result (z jets / G)
     LVd<F64_MAX_NETS * NCG> U;                                   // every network's output jets (forward), then their seeds (reverse)
@@ -187,9 +193,9 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                 PINN_LANES(l) {
                     const int q = l >> 4, j = l & 15;
                     PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
-                        const int p = pbase + 16 * pg + j, pc = p < a.npts ? p : a.npts - 1;
+                        const int p = pbase + 16 * pg + j, pc = p < T_npts ? p : T_npts - 1;
                         double x[4] = {0.0, 0.0, 0.0, 0.0};
-                        for (int i = 0; i < n.d; ++i) x[i] = a.pts[(size_t)(a.p0 + pc) * a.dt + n.imap[i]];
+                        for (int i = 0; i < n.d; ++i) x[i] = T.pts[(size_t)(T_p0 + pc) * a.dt + n.imap[i]];
                         PINN_UNROLL for (int tr = 0; tr < NR; ++tr) {
                             const int m = 16 * (tr >> 2) + 4 * (tr & 3) + q, mc = m < n_out ? m : n_out - 1;
                             const bool valid = m < n_out;
@@ -325,53 +331,53 @@ DEV void f64m_tile(int tile, const F64Args& a) {
     PINN_LANES(l) { PINN_UNROLL for (int e = 0; e < 1 + MAX_PARAMS; ++e) TS(l, e) = 0.0; }
     PINN_LANES(l) {
         const int q = l >> 4, j = l & 15;
-        const int R0 = a.dt + a.np + a.nslots;
+        const int R0 = a.dt + a.np + T.nslots;
         PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
-            const int p = pbase + 16 * pg + j, pc = p < a.npts ? p : a.npts - 1, gp = a.p0 + pc;
-            const bool live = p < a.npts, wr = live && q == 0;
+            const int p = pbase + 16 * pg + j, pc = p < T_npts ? p : T_npts - 1, gp = T_p0 + pc;
+            const bool live = p < T_npts, wr = live && q == 0;
             double v[F64_MAX_ROWS];
-            for (int i = 0; i < a.dt; ++i) v[i] = a.pts[(size_t)gp * a.dt + i];
+            for (int i = 0; i < a.dt; ++i) v[i] = T.pts[(size_t)gp * a.dt + i];
             for (int k = 0; k < a.np; ++k) v[a.dt + k] = k < a.ne ? a.theta[a.p_off + k] : a.pdef[k];
-            for (int s = 0; s < a.nslots; ++s) {
+            for (int s = 0; s < T.nslots; ++s) {
                 double uu = 0.0;
                 for (int ni = 0; ni < a.nnets; ++ni)
-                    PINN_UNROLL for (int c = 0; c < C; ++c) if (a.slot_net[s] == ni && a.slot_chan[s] == c) uu = U(l, ni * NCG + pg * C + c);
+                    PINN_UNROLL for (int c = 0; c < C; ++c) if (T.slot_net[s] == ni && T.slot_chan[s] == c) uu = U(l, ni * NCG + pg * C + c);
                 v[a.dt + a.np + s] = uu;
             }
-            for (int o = 0; o < a.nops; ++o) {
-                const rp::Instr ins = a.prog[o];
+            for (int o = 0; o < T.nops; ++o) {
+                const rp::Instr ins = T.prog[o];
                 const double va = rp::is_nullary(ins.code) ? 0.0 : v[ins.a];
                 const double vb = rp::is_binary(ins.code) ? v[ins.b] : 0.0;
-                v[R0 + o] = (ins.code == rp::OP_DATA) ? a.data[(size_t)(int)a.imm[o] * (size_t)a.N + (size_t)gp] : rp::apply<double, double>(ins.code, va, vb, a.imm[o]);
+                v[R0 + o] = (ins.code == rp::OP_DATA) ? T.data[(size_t)(int)T.imm[o] * (size_t)T.N + (size_t)gp] : rp::apply<double, double>(ins.code, va, vb, T.imm[o]);
             }
-            const double r = v[a.out_row];
+            const double r = v[T.out_row];
             if (a.mode == 2) { if (wr) a.resid[gp] = r; continue; }
-            const double sw = a.pw ? (double)a.pw[gp] : 1.0;
+            const double sw = T.pw ? (double)T.pw[gp] : 1.0;
             const double rs = r * sw;
             if (wr) TS(l, 0) += rs * rs;
             if (a.mode == 1) continue;
             double g[F64_MAX_ROWS];
-            for (int o = 0; o < R0 + a.nops; ++o) g[o] = 0.0;
-            g[a.out_row] = 1.0;
-            for (int o = a.nops - 1; o >= 0; --o) {
-                const rp::Instr ins = a.prog[o];
+            for (int o = 0; o < R0 + T.nops; ++o) g[o] = 0.0;
+            g[T.out_row] = 1.0;
+            for (int o = T.nops - 1; o >= 0; --o) {
+                const rp::Instr ins = T.prog[o];
                 if (rp::is_nullary(ins.code)) continue;
                 const double vb = rp::is_binary(ins.code) ? v[ins.b] : 0.0;
                 double da, db;
-                rp::adjoint<double, double>(ins.code, v[ins.a], vb, v[R0 + o], a.imm[o], g[R0 + o], da, db);
+                rp::adjoint<double, double>(ins.code, v[ins.a], vb, v[R0 + o], T.imm[o], g[R0 + o], da, db);
                 g[ins.a] += da;
                 if (rp::is_binary(ins.code)) g[ins.b] += db;
             }
-            const double rbar = live ? rs * a.scale * sw : 0.0;
+            const double rbar = live ? rs * T.scale * sw : 0.0;
             PINN_UNROLL for (int k = 0; k < MAX_PARAMS; ++k) if (wr && k < a.ne) TS(l, 1 + k) += rbar * g[a.dt + k];
             // the seeds of every network's output jets replace its outputs in U
             for (int ni = 0; ni < a.nnets; ++ni) {
                 double ub[C];
                 PINN_UNROLL for (int c = 0; c < C; ++c) ub[c] = 0.0;
-                for (int s = 0; s < a.nslots; ++s) {
-                    if (a.slot_net[s] != ni) continue;
+                for (int s = 0; s < T.nslots; ++s) {
+                    if (T.slot_net[s] != ni) continue;
                     const double gs = rbar * g[a.dt + a.np + s];
-                    PINN_UNROLL for (int c = 0; c < C; ++c) if (a.slot_chan[s] == c) ub[c] += gs;
+                    PINN_UNROLL for (int c = 0; c < C; ++c) if (T.slot_chan[s] == c) ub[c] += gs;
                 }
                 PINN_UNROLL for (int c = 0; c < C; ++c) U(l, ni * NCG + pg * C + c) = ub[c];
             }
@@ -462,8 +468,8 @@ DEV void f64m_tile(int tile, const F64Args& a) {
             if (lyr == 0) {
                 PINN_LANES(l) {
                     PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
-                        const int p = pbase + 16 * pg + (l & 15), pc = p < a.npts ? p : a.npts - 1;
-                        PINN_UNROLL for (int i = 0; i < 4; ++i) XI(l, pg * 4 + i) = i < n.d ? a.pts[(size_t)(a.p0 + pc) * a.dt + n.imap[i]] : 0.0;
+                        const int p = pbase + 16 * pg + (l & 15), pc = p < T_npts ? p : T_npts - 1;
+                        PINN_UNROLL for (int i = 0; i < 4; ++i) XI(l, pg * 4 + i) = i < n.d ? T.pts[(size_t)(T_p0 + pc) * a.dt + n.imap[i]] : 0.0;
                     }
                 }
             }
@@ -479,7 +485,7 @@ DEV void f64m_tile(int tile, const F64Args& a) {
                     double t6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
                     PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
                         const int p = pbase + 16 * pg + j;
-                        const bool st = (PINN_F64M_PROBE & 8) ? true : valid && p < a.npts;
+                        const bool st = (PINN_F64M_PROBE & 8) ? true : valid && p < T_npts;
                         const bool st2 = !DEFER && ((PINN_F64M_PROBE & 8) ? lyr != 0 : valid && lyr != 0 && !(PINN_F64M_PROBE & 2));   // (deferred: out of X inside the next dA GEMM)
                         double s[C], gq[C], dd[ND];
                         PINN_UNROLL for (int c = 0; c < C; ++c) s[c] = X(l, tr * NCG + pg * C + c);
@@ -673,6 +679,15 @@ HD void f64m_tsum_entry(int e, int b, const F64Args& a) {
     if (ent < 0 || (grad_entry && a.mode != 0)) return;
     const int tpb = F64_BLOCK / a.tile_pts, nt = (a.npts + a.tile_pts - 1) / a.tile_pts;
     const int t0 = b * tpb, t1 = (t0 + tpb < nt) ? t0 + tpb : nt;
+    if (!grad_entry && a.nsub > 0) {                              // merged launch: one sum of squares per sub-term (a tile belongs to exactly one)
+        for (int s = 0; s < a.nsub; ++s) {
+            const int u0 = t0 > a.sub_tile0[s] ? t0 : a.sub_tile0[s], u1 = t1 < a.sub_tile0[s + 1] ? t1 : a.sub_tile0[s + 1];
+            double sum = 0.0;
+            for (int t = u0; t < u1; ++t) sum += a.tpart[(size_t)t * (size_t)a.ntp + e];
+            a.slab[(size_t)b * a.nent + (a.nent - a.nsub + s)] = sum;
+        }
+        return;
+    }
     double sum = 0.0;
     for (int t = t0; t < t1; ++t) sum += a.tpart[(size_t)t * (size_t)a.ntp + e];
     a.slab[(size_t)b * a.nent + ent] = sum;
@@ -812,7 +827,7 @@ DEV double f64m_reduce_part(int e, int part, const F64ReduceArgs& a) {
 #ifdef PINN_EMU
 inline void launch_f64m_reduce(const F64ReduceArgs& a, plat_stream) {
     for (int e = 0; e < a.nent; ++e) {
-        if (e != a.nent - 1 && !a.with_grad) continue;
+        if (e < a.nent - a.nsq && !a.with_grad) continue;
         double t[F64M_RED_LANES], u[F64M_RED_LANES];
         for (int i = 0; i < F64M_RED_LANES; ++i) t[i] = f64m_reduce_part(e, i, a);
         for (int o = 1; o < F64M_RED_LANES; o <<= 1) {
@@ -825,7 +840,7 @@ inline void launch_f64m_reduce(const F64ReduceArgs& a, plat_stream) {
 #else
 template <int UNUSED> __global__ void __launch_bounds__(256) k_f64m_reduce(const F64ReduceArgs a) {
     const int gid = (int)(blockIdx.x * 256 + threadIdx.x), e = gid / F64M_RED_LANES, part = gid % F64M_RED_LANES;
-    const bool live = e < a.nent && (e == a.nent - 1 || a.with_grad);
+    const bool live = e < a.nent && (e >= a.nent - a.nsq || a.with_grad);
     double s = live ? f64m_reduce_part(e, part, a) : 0.0;
     PINN_UNROLL for (int o = 1; o < F64M_RED_LANES; o <<= 1) s += __shfl_xor(s, o, 64);
     if (live && part == 0) f64_reduce_write(e, s, a);

@@ -654,7 +654,27 @@ DEV vfloat4 vzero4() { return vfloat4{0.f, 0.f, 0.f, 0.f}; }
 // ---- bf16 operands of v_mfma_f32_16x16x32_bf16 (see the emulation section) ----
 typedef __bf16 vbf4 __attribute__((ext_vector_type(4)));
 typedef __bf16 vbf8 __attribute__((ext_vector_type(8)));
+// PINN_SPLIT_PK = 1 (r06): the same conversions and subtractions written on register PAIRS — one v_cvt_pk_bf16_f32 per two elements and piece, the
+// remainders as v_pk_add_f32 (element by element the compiler paired only part of them: 184 of its 568 conversions in the bench kernel converted ONE
+// element and were repeated pairwise for the packed store)
+#ifndef PINN_SPLIT_PK
+#define PINN_SPLIT_PK 1
+#endif
+typedef __bf16 vbf2_ __attribute__((ext_vector_type(2)));
 DEV void split3_bf16(vfloat4 x, vbf4& h, vbf4& m, vbf4& l) {
+#if PINN_SPLIT_PK
+    PINN_UNROLL for (int q = 0; q < 2; ++q) {
+        const vfloat2_ xx = {x[2 * q], x[2 * q + 1]};
+        const vbf2_ hb = __builtin_convertvector(xx, vbf2_);                 // v_cvt_pk_bf16_f32: round to nearest even
+        const vfloat2_ r = xx - __builtin_convertvector(hb, vfloat2_);
+        const vbf2_ mb = __builtin_convertvector(r, vbf2_);
+        const vfloat2_ r2 = r - __builtin_convertvector(mb, vfloat2_);
+        const vbf2_ lb = __builtin_convertvector(r2, vbf2_);
+        h[2 * q] = hb[0]; h[2 * q + 1] = hb[1];
+        m[2 * q] = mb[0]; m[2 * q + 1] = mb[1];
+        l[2 * q] = lb[0]; l[2 * q + 1] = lb[1];
+    }
+#else
     PINN_UNROLL for (int k = 0; k < 4; ++k) {
         const __bf16 hb = (__bf16)x[k];                       // v_cvt_pk_bf16_f32: round to nearest even
         const float r = x[k] - (float)hb;
@@ -662,6 +682,7 @@ DEV void split3_bf16(vfloat4 x, vbf4& h, vbf4& m, vbf4& l) {
         const float r2 = r - (float)mb;
         h[k] = hb; m[k] = mb; l[k] = (__bf16)r2;
     }
+#endif
 }
 DEV void split1_bf16(vfloat4 x, vbf4& h) { PINN_UNROLL for (int k = 0; k < 4; ++k) h[k] = (__bf16)x[k]; }      // (timing probes only)
 DEV void lds_store_bf4(float* p, vint i, vbf4 x) { *reinterpret_cast<vbf4*>(p + i) = x; }

@@ -860,3 +860,67 @@ def test_f64_periodic_embedding(npde, use_emu):
     with pytest.raises(Exception, match="periodic input embedding"):
         eng.set_option("derivative", "stencil")
     assert eng.get_option("derivative") == "exact"
+
+
+def test_f64_merged_launches_of_small_problems(npde, use_emu):
+    """r06: small problems (the reference's own regime) are bound by one tile's latency per launch, so the terms that share networks, input binding and
+    an instantiated jet set ride in ONE tile / dW / reduction launch sequence on the union jet set (csrc/f64.cpp: f64_make_groups; F64Sub in
+    pinn_kernels4.hpp).  Merged = term by term (PINN_F64_NO_MERGE=1) = the float64 oracle to rounding: per-term losses, weighted gradient, loss-only
+    evaluations, quadrature weights, more members than one launch takes, the resident Adam loop."""
+    import os
+
+    def both(sysm, chains, strat, seed, weights, expect_merged):
+        th0 = np.concatenate([tp.theta_for(c, seed + i) for i, c in enumerate(chains)])
+        out = []
+        for merge in (True, False):
+            if not merge:
+                os.environ["PINN_F64_NO_MERGE"] = "1"
+            try:
+                rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chains if len(chains) > 1 else chains[0], strat(), init_params=th0))      # (a fresh strategy: same design)
+                eng = rep.engine
+                th = np.asarray(rep.flat_init_params, dtype=np.float64) + 1e-9
+                l, g = eng.loss_grad_f64(th, weights)
+                nm = int(eng.get_option("f64_merged"))
+                l1, _ = eng.loss_grad_f64(th, weights, want_grad=False)
+                tha, hist = eng.adam_f64(th, 3, 1e-3, weights)
+            finally:
+                os.environ.pop("PINN_F64_NO_MERGE", None)
+            assert eng.get_option("f64_path") == "mfma"
+            assert nm == (expect_merged if merge else 0), (merge, nm)
+            np.testing.assert_array_equal(l1, l)
+            out.append((l, g, tha, hist))
+        sets = rep.pde_train_sets + rep.bcs_train_sets
+        prob = helpers.oracle_problem(npde, sysm, chains)
+        ref = po.loss_and_grad(prob, th, sets, weights=weights, mode="exact")
+        for l, g, _, _ in out:
+            le, g2, gi = helpers.rel_errors(l, g, ref)
+            assert le.max() < EXACT and g2 < EXACT and gi < EXACT, (le, g2, gi)
+        np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-14)
+        assert np.linalg.norm(out[0][1] - out[1][1]) / np.linalg.norm(out[1][1]) < 1e-14
+        np.testing.assert_allclose(out[0][2], out[1][2], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(out[0][3], out[1][3], rtol=1e-12)
+        return rep
+
+    # 2-D Poisson, 16-wide (HT = 1 kernels) and 40-wide (HT = 4): interior + four boundary terms -> one launch sequence
+    for width, hidden in ((16, 2), (40, 2)):
+        sysm, chain = tp.poisson2d(npde, "tanh", width=width, hidden=hidden)
+        both(sysm, [chain], lambda: npde.GridTraining(0.1), 5, [1.0, 2.0, 0.5, 1.5, 3.0], 1)
+    # a quasi-random design on a sigmoid network
+    sysm, chain = tp.poisson2d(npde, "sigmoid", width=12, hidden=2)
+    both(sysm, [chain], lambda: npde.QuasiRandomTraining(70, bcs_points=9, sampling_alg=npde.SobolSample(seed=4), resampling=False, minibatch=1), 9, None, 1)
+    # 3-D heat equation: one interior + five boundary / initial terms = six members; a seventh term would start a second sequence
+    t, x, y = npde.parameters("t x y")
+    (u,) = npde.variables("u")
+    Dt, Dxx, Dyy = npde.Differential(t), npde.Differential(x) ** 2, npde.Differential(y) ** 2
+    eq = npde.Eq(Dt(u(t, x, y)), Dxx(u(t, x, y)) + Dyy(u(t, x, y)))
+    bcs = [npde.Eq(u(0.0, x, y), sp.sin(x) * sp.cos(y)), npde.Eq(u(t, 0.0, y), 0.0), npde.Eq(u(t, 1.0, y), sp.exp(-2 * t) * sp.sin(1.0) * sp.cos(y)),
+           npde.Eq(u(t, x, 0.0), sp.exp(-2 * t) * sp.sin(x)), npde.Eq(u(t, x, 1.0), sp.exp(-2 * t) * sp.sin(x) * sp.cos(1.0)), npde.Eq(u(1.0, x, y), sp.exp(-2.0) * sp.sin(x) * sp.cos(y))]
+    dom = [npde.In(v, npde.Interval(0.0, 1.0)) for v in (t, x, y)]
+    chain = npde.Chain(npde.Dense(3, 20, "tanh"), npde.Dense(20, 20, "tanh"), npde.Dense(20, 1))
+    both(npde.PDESystem([eq], bcs, dom, [t, x, y], [u(t, x, y)]), [chain], lambda: npde.GridTraining(0.25), 21, [1.0, 0.5, 2.0, 1.5, 1.0, 3.0, 0.7], 1)
+    # a large set is not merged (the union jet set would multiply the boundary terms' work)
+    sysm, chain = tp.poisson2d(npde, "tanh", width=16, hidden=2)
+    rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, npde.QuasiRandomTraining(9000, bcs_points=64, sampling_alg=npde.SobolSample(seed=1), resampling=False, minibatch=1),
+                                                              init_params=tp.theta_for(chain, 3)))
+    rep.engine.loss_grad_f64(np.asarray(rep.flat_init_params, dtype=np.float64))
+    assert int(rep.engine.get_option("f64_merged")) == 1        # the four boundary terms together; the 9,000-point interior term on its own
