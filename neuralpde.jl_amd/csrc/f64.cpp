@@ -79,7 +79,7 @@ struct F64State {
     int path = 0;                        // kernels of the last evaluation: bit 0 one lane per point (family 4), bit 1 matrix pipe (family 4m)
     // MERGED launches of small problems (r06, f64_make_groups): terms that share networks, input binding and an instantiated jet set in ONE tile / dW /
     // reduction launch sequence; rebuilt when a term's point count changes
-    struct Group { std::vector<int> terms; const pk::F64Kernel* k = nullptr; const pk::F64MKernel* km = nullptr; std::vector<std::vector<int>> slot_chan; };
+    struct Group { std::vector<int> terms, nets; std::map<int, std::vector<int>> inmap; const pk::F64Kernel* k = nullptr; const pk::F64MKernel* km = nullptr; std::vector<std::vector<int>> slot_chan; };
     std::vector<Group> groups;
     std::vector<int64_t> groups_sig;     // the point counts the grouping was made for (empty: not made yet)
     int merged_launches = 0;             // of the last evaluation (pinn_get_option "f64_merged")
@@ -671,28 +671,48 @@ static void f64_make_groups(pinn_engine& E, F64State& S) {
         std::vector<Slot> slots = T0.slots;
         int64_t pts = F.n;
         G.terms.push_back(t);
+        G.nets = F.nets;
+        G.inmap = T0.inmap;
+        const int d = E.nets[F.nets[0]].sizes[0];
         for (int u = t + 1; u < K && (int)G.terms.size() < pk::F64_MAX_SUB; ++u) {
             const Term& U0 = E.terms0[u];
             const F64Term& Fu = S.terms[u];
             if (used[u] || !Fu.km || Fu.km->sliced || Fu.n <= 0) continue;
-            if (Fu.nets != F.nets || U0.d != T0.d || U0.inmap != T0.inmap) continue;
+            if (U0.d != T0.d || E.nets[Fu.nets[0]].sizes[0] != d) continue;
             if (pts + Fu.n > F64_MERGE_MAX_POINTS) continue;
+            // the launch evaluates the UNION of the members' networks for every tile (a network a member does not read gets zero seeds from it):
+            // systems of equations over different subsets of the dependent variables (the reference's Lorenz test) still ride in one sequence
+            std::vector<int> nets = G.nets;
+            for (int ni : Fu.nets) if (std::find(nets.begin(), nets.end(), ni) == nets.end()) nets.push_back(ni);
+            std::sort(nets.begin(), nets.end());
+            if ((int)nets.size() > pk::F64_MAX_NETS) continue;
+            std::map<int, std::vector<int>> inmap = G.inmap;
+            bool clash = false;
+            for (int ni : nets) {                        // one input binding per network: explicit maps must agree, an identity binding must be one for both
+                const bool a_has = G.inmap.count(ni) != 0, b_has = U0.inmap.count(ni) != 0;
+                const bool a_uses = std::find(G.nets.begin(), G.nets.end(), ni) != G.nets.end(), b_uses = std::find(Fu.nets.begin(), Fu.nets.end(), ni) != Fu.nets.end();
+                if (a_uses && b_uses && (a_has != b_has || (a_has && G.inmap.at(ni) != U0.inmap.at(ni)))) { clash = true; break; }
+                if (b_uses && b_has) inmap[ni] = U0.inmap.at(ni);
+            }
+            if (clash) continue;
             std::vector<Slot> trial = slots;
             trial.insert(trial.end(), U0.slots.begin(), U0.slots.end());
             std::vector<int> ch;
             std::string why;
-            const pk::F64Kernel* k = f64_find(E.nets[F.nets[0]].sizes[0], trial, ch, why);
-            const pk::F64MKernel* km = k ? f64_find_m(E, k, F.nets) : nullptr;
+            const pk::F64Kernel* k = f64_find(d, trial, ch, why);
+            const pk::F64MKernel* km = k ? f64_find_m(E, k, nets) : nullptr;
             if (!km || km->sliced) continue;
             slots.swap(trial);
             pts += Fu.n;
             G.terms.push_back(u);
+            G.nets.swap(nets);
+            G.inmap.swap(inmap);
         }
         if (G.terms.size() < 2 || pts > F64_MERGE_MAX_POINTS) continue;
         std::vector<int> ch;
         std::string why;
-        G.k = f64_find(E.nets[F.nets[0]].sizes[0], slots, ch, why);
-        G.km = G.k ? f64_find_m(E, G.k, F.nets) : nullptr;
+        G.k = f64_find(d, slots, ch, why);
+        G.km = G.k ? f64_find_m(E, G.k, G.nets) : nullptr;
         if (!G.km || G.km->sliced) continue;
         size_t o = 0;
         for (int u : G.terms) {
@@ -750,10 +770,10 @@ static int f64_eval_device(pinn_engine& E, const double* theta, double* grad, do
             const int m = (int)G.terms.size(), t0 = G.terms[0];
             const Term& T0 = E.terms0[t0];
             F64Term Fg;
-            Fg.k = G.k; Fg.km = G.km; Fg.nets = S.terms[t0].nets;
+            Fg.k = G.k; Fg.km = G.km; Fg.nets = G.nets;
             Fg.nops = 0; Fg.nslots = 0; Fg.out_row = 0; Fg.ndata = 0;
             F64Launch L;
-            if (f64_build(E, Fg, T0.d, &T0.inmap, L)) return 1;
+            if (f64_build(E, Fg, T0.d, &G.inmap, L)) return 1;
             if (!L.mfma || L.sliced) continue;
             pk::F64Args& a = L.a;
             const int tp = a.tile_pts;
@@ -770,7 +790,10 @@ static int f64_eval_device(pinn_engine& E, const double* theta, double* grad, do
                 u.prog = F.d_prog; u.imm = F.d_imm;
                 u.scale = 2.0 * (term_w ? term_w[t] : 1.0) / (double)T.n_norm;
                 u.N = (int)F.n; u.nops = F.nops; u.out_row = F.out_row; u.nslots = F.nslots;
-                for (int sl = 0; sl < F.nslots; ++sl) { u.slot_net[sl] = (unsigned char)F.slot_net[sl]; u.slot_chan[sl] = (unsigned char)G.slot_chan[q][sl]; }
+                for (int sl = 0; sl < F.nslots; ++sl) {          // (slot_net: position of the slot's network in the launch's — the union's — list)
+                    u.slot_net[sl] = (unsigned char)(std::find(G.nets.begin(), G.nets.end(), F.nets[F.slot_net[sl]]) - G.nets.begin());
+                    u.slot_chan[sl] = (unsigned char)G.slot_chan[q][sl];
+                }
             }
             a.sub_tile0[m] = tiles;
             for (int q = m + 1; q <= pk::F64_MAX_SUB; ++q) a.sub_tile0[q] = tiles;

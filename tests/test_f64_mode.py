@@ -918,6 +918,35 @@ def test_f64_merged_launches_of_small_problems(npde, use_emu):
     dom = [npde.In(v, npde.Interval(0.0, 1.0)) for v in (t, x, y)]
     chain = npde.Chain(npde.Dense(3, 20, "tanh"), npde.Dense(20, 20, "tanh"), npde.Dense(20, 1))
     both(npde.PDESystem([eq], bcs, dom, [t, x, y], [u(t, x, y)]), [chain], lambda: npde.GridTraining(0.25), 21, [1.0, 0.5, 2.0, 1.5, 1.0, 3.0, 0.7], 1)
+    # a system whose equations read different subsets of the dependent variables (the reference's Lorenz test, test/NNPDE2/additional_loss__lorenz_system.jl:
+    # three networks, estimated parameters): the launch evaluates the union of the members' networks, six terms in one sequence
+    (tt,) = npde.parameters("t")
+    sg, rho, beta = npde.parameters("sigma_ rho beta")
+    xv, yv, zv = npde.variables("x y z")
+    D = npde.Differential(tt)
+    eqs = [npde.Eq(D(xv(tt)), sg * (yv(tt) - xv(tt))), npde.Eq(D(yv(tt)), xv(tt) * (rho - zv(tt)) - yv(tt)), npde.Eq(D(zv(tt)), xv(tt) * yv(tt) - beta * zv(tt))]
+    ics = [npde.Eq(xv(0), 1.0), npde.Eq(yv(0), 0.0), npde.Eq(zv(0), 0.0)]
+    lsys = npde.PDESystem(eqs, ics, [npde.In(tt, npde.Interval(0.0, 1.0))], [tt], [xv(tt), yv(tt), zv(tt)], ps=[sg, rho, beta], defaults={sg: 1.0, rho: 1.0, beta: 1.0})
+    chains = [npde.Chain(npde.Dense(1, 12, "tanh"), npde.Dense(12, 12, "sigmoid"), npde.Dense(12, 1)) for _ in range(3)]
+    th0 = np.concatenate([tp.theta_for(c, 40 + i) for i, c in enumerate(chains)])
+    res = []
+    for merge in (True, False):
+        if not merge:
+            os.environ["PINN_F64_NO_MERGE"] = "1"
+        try:
+            rep = npde.symbolic_discretize(lsys, npde.PhysicsInformedNN(chains, npde.GridTraining(0.05), init_params=th0, param_estim=True))
+            th = np.asarray(rep.flat_init_params, dtype=np.float64) + 1e-9
+            w = [1.0, 2.0, 0.5, 1.5, 3.0, 0.7]
+            l, g = rep.engine.loss_grad_f64(th, w)
+            res.append((l, g, int(rep.engine.get_option("f64_merged"))))
+        finally:
+            os.environ.pop("PINN_F64_NO_MERGE", None)
+    assert res[0][2] == 1 and res[1][2] == 0
+    prob = helpers.oracle_problem(npde, lsys, chains, param_estim=True)
+    ref = po.loss_and_grad(prob, th, rep.pde_train_sets + rep.bcs_train_sets, weights=w, mode="exact")
+    for l, g, _ in res:
+        le, g2, gi = helpers.rel_errors(l, g, ref)
+        assert le.max() < EXACT and g2 < EXACT and gi < EXACT, (le, g2, gi)
     # a large set is not merged (the union jet set would multiply the boundary terms' work)
     sysm, chain = tp.poisson2d(npde, "tanh", width=16, hidden=2)
     rep = npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, npde.QuasiRandomTraining(9000, bcs_points=64, sampling_alg=npde.SobolSample(seed=1), resampling=False, minibatch=1),
