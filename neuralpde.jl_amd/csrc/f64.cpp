@@ -66,7 +66,7 @@ struct F64State {
     size_t slab_cap = 0;
     double* d_tpart = nullptr;           // matrix-pipe kernels: per-tile partial sums of the first / last layer entries (F64Args::tpart)
     size_t tpart_cap = 0;
-    std::vector<double> h_out;           // host staging [P + K]
+    double* h_pin = nullptr;             // pinned host staging: [P] theta on its way in | [P + K] gradient and sums on their way out (one copy each way)
     double* d_m = nullptr;               // optimiser moments of the float64 Adam loop (f64_adam_*), allocated on first use
     double* d_v = nullptr;
     double* d_w_over_n = nullptr;        // [K] w_k / N_k of the running call
@@ -92,6 +92,7 @@ static void f64_free(F64State* S) {
     plat_free(S->d_uv); plat_free(S->d_seeds); plat_free(S->d_spts);
     plat_free(S->d_theta); plat_free(S->d_opt_theta); plat_free(S->d_aux_pts); plat_free(S->d_aux_out); plat_free(S->d_grad); plat_free(S->d_scratch); plat_free(S->d_slab); plat_free(S->d_tpart);
     plat_free(S->d_m); plat_free(S->d_v); plat_free(S->d_w_over_n); plat_free(S->d_hist);
+    plat_host_free(S->h_pin);
     delete S;
 }
 void f64_destroy(pinn_engine& E) {
@@ -256,7 +257,8 @@ int f64_enable(pinn_engine& E) {
     S->d_grad = (double*)plat_malloc(sizeof(double) * (E.ntheta + K));      // [gradient (P) | sums (K)] contiguous: one all-reduce over a communicator
     S->d_sumsq = S->d_grad ? S->d_grad + E.ntheta : nullptr;
     if (!S->d_theta || !S->d_grad) return fail("device allocation failed (float64 state)");
-    S->h_out.resize((size_t)E.ntheta + K);
+    S->h_pin = (double*)plat_host_alloc(sizeof(double) * (2 * (size_t)E.ntheta + K));
+    if (!S->h_pin) return fail("pinned host allocation failed (float64 staging)");
     E.f64 = S.release();
     return 0;
 }
@@ -871,14 +873,17 @@ int f64_eval(pinn_engine& E, const double* theta, const double* term_w, double* 
     F64State& S = *(F64State*)E.f64;
     const int K = (int)E.terms.size();
     const int64_t P = E.ntheta;
-    if (plat_h2d(S.d_theta, theta, sizeof(double) * P, E.stream)) return fail("H2D copy of theta failed");
+    // (pinned staging both ways: a pageable source / destination makes every copy a synchronous, internally staged one — the host entry of a small problem
+    // is mostly those copies; gradient and sums are one device vector, so one copy brings both)
+    std::memcpy(S.h_pin, theta, sizeof(double) * P);
+    if (plat_h2d(S.d_theta, S.h_pin, sizeof(double) * P, E.stream)) return fail("H2D copy of theta failed");
     if (f64_eval_device(E, S.d_theta, grad ? S.d_grad : nullptr, S.d_sumsq, term_w)) return 1;
-    if (grad && plat_d2h(S.h_out.data(), S.d_grad, sizeof(double) * P, E.stream)) return fail("D2H copy failed");
-    if (plat_d2h(S.h_out.data() + P, S.d_sumsq, sizeof(double) * K, E.stream)) return fail("D2H copy failed");
+    double* out = S.h_pin + P;
+    if (grad ? plat_d2h(out, S.d_grad, sizeof(double) * (P + K), E.stream) : plat_d2h(out + P, S.d_sumsq, sizeof(double) * K, E.stream)) return fail("D2H copy failed");
     if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
     if (term_losses)
-        for (int k = 0; k < K; ++k) term_losses[k] = S.h_out[(size_t)P + k] / (double)E.terms[k].n_norm;
-    if (grad) std::memcpy(grad, S.h_out.data(), sizeof(double) * P);
+        for (int k = 0; k < K; ++k) term_losses[k] = out[(size_t)P + k] / (double)E.terms[k].n_norm;
+    if (grad) std::memcpy(grad, out, sizeof(double) * P);
     return 0;
 }
 
@@ -1101,8 +1106,7 @@ int f64_adam_steps_comm(pinn_engine** es, int ndev, int nsteps, double lr, doubl
             F64State& S = *(F64State*)E.f64;
             ++E.opt_t;
             const double c1 = 1.0 / (1.0 - std::pow(beta1, (double)E.opt_t)), c2 = 1.0 / (1.0 - std::pow(beta2, (double)E.opt_t));
-            pk::launch_f64_total(S.d_hist, s, S.d_sumsq, S.d_w_over_n, K, E.stream);
-            pk::launch_f64_adam(S.d_opt_theta, S.d_m, S.d_v, S.d_grad, P, lr, beta1, beta2, eps, c1, c2, E.stream);
+            pk::launch_f64_adam_total(S.d_opt_theta, S.d_m, S.d_v, S.d_grad, P, lr, beta1, beta2, eps, c1, c2, S.d_hist, s, S.d_sumsq, S.d_w_over_n, K, E.stream);
         }
     }
     {

@@ -784,6 +784,12 @@ inline void launch_f64_total(double* hist, int step, const double* sumsq, const 
     for (int k = 0; k < K; ++k) s += w_over_n[k] * sumsq[k];
     hist[step] = s;
 }
+// the resident loop's update: Adam on every element + (one thread) the step's total weighted loss — one launch instead of two
+inline void launch_f64_adam_total(double* theta, double* m, double* v, const double* g, int P, double lr, double b1, double b2, double eps, double c1, double c2,
+                                  double* hist, int step, const double* sumsq, const double* w_over_n, int K, plat_stream st) {
+    launch_f64_total(hist, step, sumsq, w_over_n, K, st);
+    launch_f64_adam(theta, m, v, g, P, lr, b1, b2, eps, c1, c2, st);
+}
 inline void launch_f64_narrow(const double* src, float* dst, int64_t n, plat_stream) { for (int64_t i = 0; i < n; ++i) dst[i] = (float)src[i]; }
 #else
 template <int UNUSED> __global__ void __launch_bounds__(256) k_f64_cvt(const float* src, double* dst, int64_t n) {
@@ -802,6 +808,16 @@ template <int UNUSED> __global__ void __launch_bounds__(256) k_f64_embed(const F
     if (p < a.n) f64_embed_point(p, a);
 }
 inline void launch_f64_embed(const F64EmbedArgs& a, plat_stream st) { hipLaunchKernelGGL((k_f64_embed<0>), dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, st, a); }
+template <int UNUSED> __global__ void __launch_bounds__(256) k_f64_adam_total(double* theta, double* m, double* v, const double* g, int P, double lr, double b1, double b2, double eps, double c1, double c2,
+                                                                              double* hist, int step, const double* sumsq, const double* w_over_n, int K) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i < P) f64_adam_elem(i, theta, m, v, g, lr, b1, b2, eps, c1, c2);
+    if (i == P) { double s = 0.0; for (int k = 0; k < K; ++k) s += w_over_n[k] * sumsq[k]; hist[step] = s; }      // (same association as k_f64_total)
+}
+inline void launch_f64_adam_total(double* theta, double* m, double* v, const double* g, int P, double lr, double b1, double b2, double eps, double c1, double c2,
+                                  double* hist, int step, const double* sumsq, const double* w_over_n, int K, plat_stream st) {
+    hipLaunchKernelGGL((k_f64_adam_total<0>), dim3((P + 1 + 255) / 256), dim3(256), 0, st, theta, m, v, g, P, lr, b1, b2, eps, c1, c2, hist, step, sumsq, w_over_n, K);
+}
 inline void launch_f64_cvt(const float* src, double* dst, int64_t n, plat_stream st) { hipLaunchKernelGGL((k_f64_cvt<0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n); }
 inline void launch_f64_adam(double* theta, double* m, double* v, const double* g, int P, double lr, double b1, double b2, double eps, double c1, double c2, plat_stream st) {
     hipLaunchKernelGGL((k_f64_adam<0>), dim3((P + 255) / 256), dim3(256), 0, st, theta, m, v, g, P, lr, b1, b2, eps, c1, c2);
