@@ -676,12 +676,12 @@ static void f64_make_groups(pinn_engine& E, F64State& S) {
         G.nets = F.nets;
         G.inmap = T0.inmap;
         const int d = E.nets[F.nets[0]].sizes[0];
+        bool free_merge = true;                          // every member so far runs its OWN kernel on its own networks
         for (int u = t + 1; u < K && (int)G.terms.size() < pk::F64_MAX_SUB; ++u) {
             const Term& U0 = E.terms0[u];
             const F64Term& Fu = S.terms[u];
             if (used[u] || !Fu.km || Fu.km->sliced || Fu.n <= 0) continue;
             if (U0.d != T0.d || E.nets[Fu.nets[0]].sizes[0] != d) continue;
-            if (pts + Fu.n > F64_MERGE_MAX_POINTS) continue;
             // the launch evaluates the UNION of the members' networks for every tile (a network a member does not read gets zero seeds from it):
             // systems of equations over different subsets of the dependent variables (the reference's Lorenz test) still ride in one sequence
             std::vector<int> nets = G.nets;
@@ -704,13 +704,18 @@ static void f64_make_groups(pinn_engine& E, F64State& S) {
             const pk::F64Kernel* k = f64_find(d, trial, ch, why);
             const pk::F64MKernel* km = k ? f64_find_m(E, k, nets) : nullptr;
             if (!km || km->sliced) continue;
+            // beyond the small-problem size a member joins only where it costs nothing: the same kernel and the same networks as every other member
+            // (the four boundary terms of a 2-D problem: one dW / reduction launch instead of four)
+            const bool same = free_merge && k == F.k && k == Fu.k && nets == F.nets && nets == Fu.nets;
+            if (pts + Fu.n > F64_MERGE_MAX_POINTS && !same) continue;
+            free_merge = same;
             slots.swap(trial);
             pts += Fu.n;
             G.terms.push_back(u);
             G.nets.swap(nets);
             G.inmap.swap(inmap);
         }
-        if (G.terms.size() < 2 || pts > F64_MERGE_MAX_POINTS) continue;
+        if (G.terms.size() < 2 || (pts > F64_MERGE_MAX_POINTS && !free_merge)) continue;
         std::vector<int> ch;
         std::string why;
         G.k = f64_find(d, slots, ch, why);
