@@ -300,7 +300,9 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
  *   Small problems (r06: the reference's own regime, a few hundred points per term): row-tile counts of 1 / 2 for 16- / 32-wide nets, and the terms
  *   that share an input binding and an instantiated jet set are evaluated by ONE launch sequence (<= 6 members, <= 8,192 points together) —
  *   same results to rounding; pinn_get_option(h, "f64_merged") = the number of such sequences in the last evaluation, $PINN_F64_NO_MERGE=1
- *   switches them off (A/B, tests).
+ *   switches them off (A/B, tests).  Terms whose residual is affine in the trial function(s) with constant coefficients (boundary conditions, linear
+ *   PDEs with forcing terms) skip the tape interpreter in the tile kernel: the coordinate-only part is evaluated once per point set
+ *   (pinn_get_option(h, "f64_affine") = the number of such terms; $PINN_F64_NO_LIN=1: off).
  *   PRECISION POLICY of the glue (Julia: HIPStrategy / hip_discretize `precision = :auto`; Python mirror: PhysicsInformedNN(precision = "auto")):
  *   the reference's contract compute dtype = eltype(theta) (src/eltype_matching.jl:8-10) — Float64 parameters select "f64", Float32
  *   parameters "f32"; "f32" on Float64 parameters is the explicit fast opt-in.

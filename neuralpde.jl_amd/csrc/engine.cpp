@@ -1276,9 +1276,10 @@ int pinn_get_option(pinn_handle h, const char* name, char* buf, int64_t buflen) 
     if (k == "derivative") { std::snprintf(buf, (size_t)buflen, "%s", pe::f64_stencil_on(*h) ? "stencil" : "exact"); return 0; }
     if (k == "eval_path") { std::snprintf(buf, (size_t)buflen, "%s", h->eval_path == 2 ? "one launch" : (h->eval_path == 1 ? "stand-alone kernels" : "none")); return 0; }
     if (k == "f64_path") { std::snprintf(buf, (size_t)buflen, "%s", pe::f64_path(*h)); return 0; }
+    if (k == "f64_affine") { std::snprintf(buf, (size_t)buflen, "%d", pe::f64_affine_terms(*h)); return 0; }       // terms on the affine-residual fast path
     if (k == "f64_merged") { std::snprintf(buf, (size_t)buflen, "%d", pe::f64_merged(*h)); return 0; }          // merged launches of the last float64 evaluation
     if (k == "adam_path") { std::snprintf(buf, (size_t)buflen, "%s", h->adam_path == 2 ? "persistent" : (h->adam_path == 1 ? "loop" : "none")); return 0; }
-    return fail("pinn_get_option: unknown option \"" + k + "\" (known: gemm, precision, persistent, derivative, grad_health, gemm_delta, adam_path, eval_path, f64_path, f64_merged)");
+    return fail("pinn_get_option: unknown option \"" + k + "\" (known: gemm, precision, persistent, derivative, grad_health, gemm_delta, adam_path, eval_path, f64_path, f64_merged, f64_affine)");
 }
 
 int pinn_adam_init(pinn_handle h, const float* theta, int64_t p) {

@@ -313,6 +313,7 @@ struct DeviceScope {
 int f64_enable(pinn_engine& E);
 void f64_destroy(pinn_engine& E);
 std::string f64_describe(const pinn_engine& E);
+int f64_affine_terms(const pinn_engine& E);      // terms whose residual the matrix-pipe tile kernel evaluates in affine form, without the tape interpreter
 int f64_merged(const pinn_engine& E);            // merged launch sequences of the last float64 evaluation (small problems: f64.cpp f64_make_groups)
 const char* f64_path(const pinn_engine& E);      // kernels of the last float64 evaluation: "mfma" | "lanes" | "mfma+lanes" | "none" | "off"
 int f64_points_changed(pinn_engine& E, int term);

@@ -37,6 +37,13 @@ struct F64Term {
     int ndata = 0;                       // per-point DATA channels of the residual (OP_DATA), valid for the current point set only
     double* d_data = nullptr;            // [ndata][n]; converted from the float rows unless pinn_set_point_data_f64 installed them
     int64_t data_cap = 0, data_n = 0;
+    // affine residual (r06, f64_affine): r = S(point) + sum_s a_s u_s — the matrix-pipe tile kernel then skips the tape interpreter (F64Sub::lin)
+    bool lin = false;
+    std::vector<double> lin_a;                           // [nslots]
+    std::vector<std::pair<double, int>> lin_terms;       // S = lin_k + sum coef * (tape row that depends on coordinates / constants only)
+    double lin_k = 0.0;
+    double* d_lin = nullptr;             // [nslots | n]: coefficients, then S at the points of the current set
+    int64_t lin_cap = 0, lin_n = 0;      // lin_n == n: S is valid for the installed set
 };
 // one (network, shift sequence) of a term's finite-difference stencils: the trial function of `net` at the term's points moved by the shifts in order
 struct F64VNet { int net; std::vector<std::pair<int, double>> shifts; };
@@ -87,7 +94,7 @@ struct F64State {
 
 static void f64_free(F64State* S) {
     if (!S) return;
-    for (auto& T : S->terms) { plat_free(T.d_prog); plat_free(T.d_imm); plat_free(T.d_pts); plat_free(T.d_data); }
+    for (auto& T : S->terms) { plat_free(T.d_prog); plat_free(T.d_imm); plat_free(T.d_pts); plat_free(T.d_data); plat_free(T.d_lin); }
     for (auto& X : S->sten) { plat_free(X.d_prog); plat_free(X.d_imm); }
     plat_free(S->d_uv); plat_free(S->d_seeds); plat_free(S->d_spts);
     plat_free(S->d_theta); plat_free(S->d_opt_theta); plat_free(S->d_aux_pts); plat_free(S->d_aux_out); plat_free(S->d_grad); plat_free(S->d_scratch); plat_free(S->d_slab); plat_free(S->d_tpart);
@@ -143,6 +150,104 @@ static const pk::F64MKernel* f64_find_m(const pinn_engine& E, const pk::F64Kerne
     return best;
 }
 
+// ---- affine residuals: r = S(point) + sum_s a_s u_s ----
+// Symbolic pass over the term's tape (descriptor rows [coordinates | parameters | slots | ops]): every row is either a constant-coefficient affine
+// form in the slots plus coordinate-only rows, or the term is not affine (nonlinear in u, point-dependent coefficients, estimated parameters, DATA
+// rows) and keeps the interpreter.  Boundary conditions, linear PDEs with forcing terms (Poisson, heat, wave) qualify; Burgers does not.
+static void f64_affine(const pinn_engine& E, const Term& T, F64Term& F) {
+    F.lin = false;
+    if (std::getenv("PINN_F64_NO_LIN") || F.ndata > 0) return;
+    struct Form { bool ok = true; std::vector<double> a; std::vector<std::pair<double, int>> t; double k = 0.0; };
+    const int dt = T.d, np = E.np, ns = (int)T.slots.size(), R0 = dt + np + ns;
+    std::vector<Form> row((size_t)R0 + T.ops.size());
+    for (auto& f : row) f.a.assign((size_t)ns, 0.0);
+    for (int i = 0; i < dt; ++i) row[i].t.push_back({1.0, i});
+    for (int k = 0; k < np; ++k) { if (k < E.ne) row[dt + k].ok = false; else row[dt + k].k = k < (int)E.p_defaults.size() ? (double)E.p_defaults[k] : 0.0; }
+    for (int q = 0; q < ns; ++q) row[dt + np + q].a[q] = 1.0;
+    auto has_u = [&](const Form& f) { for (double x : f.a) if (x != 0.0) return true; return false; };
+    auto is_const = [&](const Form& f) { return f.ok && !has_u(f) && f.t.empty(); };
+    auto scaled = [&](const Form& f, double c) { Form g = f; for (double& x : g.a) x *= c; for (auto& y : g.t) y.first *= c; g.k *= c; return g; };
+    auto add = [&](const Form& x, const Form& y, double sy) {
+        Form g = x;
+        for (int q = 0; q < ns; ++q) g.a[q] += sy * y.a[q];
+        for (auto& z : y.t) g.t.push_back({sy * z.first, z.second});
+        g.k += sy * y.k;
+        return g;
+    };
+    for (size_t o = 0; o < T.ops.size(); ++o) {
+        const rp::Instr& I = T.ops[o];
+        const double imm = o < T.imm64.size() ? T.imm64[o] : (double)I.imm;
+        Form& f = row[(size_t)R0 + o];
+        const Form* A = rp::is_nullary(I.code) ? nullptr : &row[(size_t)I.a];
+        const Form* B = rp::is_binary(I.code) ? &row[(size_t)I.b] : nullptr;
+        if ((A && !A->ok) || (B && !B->ok) || I.code == rp::OP_DATA) { f.ok = false; continue; }
+        const bool u_dep = (A && has_u(*A)) || (B && has_u(*B));
+        auto self = [&]() { Form g; g.a.assign((size_t)ns, 0.0); g.t.push_back({1.0, R0 + (int)o}); return g; };     // a coordinate-only row, evaluated by the source pass
+        switch (I.code) {
+            case rp::OP_CONST: f.k = imm; break;
+            case rp::OP_ADD: f = add(*A, *B, 1.0); break;
+            case rp::OP_SUB: f = add(*A, *B, -1.0); break;
+            case rp::OP_NEG: f = scaled(*A, -1.0); break;
+            case rp::OP_ADDC: f = *A; f.k += imm; break;
+            case rp::OP_MULC: f = scaled(*A, imm); break;
+            case rp::OP_MUL:
+                if (is_const(*A)) f = scaled(*B, A->k);
+                else if (is_const(*B)) f = scaled(*A, B->k);
+                else if (!u_dep) f = self();
+                else f.ok = false;
+                break;
+            case rp::OP_DIV:
+                if (is_const(*B) && B->k != 0.0) f = scaled(*A, 1.0 / B->k);
+                else if (!u_dep) f = self();
+                else f.ok = false;
+                break;
+            default:
+                if (!u_dep) f = self(); else f.ok = false;
+                break;
+        }
+        if (f.ok && f.a.size() != (size_t)ns) f.a.assign((size_t)ns, 0.0);
+    }
+    const Form& out = row[(size_t)T.out_row];
+    if (!out.ok) return;
+    // (a MULC / DIV by a constant is not bit-identical to the tape's order of operations: the results agree to rounding, which is the mode's contract)
+    std::vector<std::pair<double, int>> terms;
+    for (auto& z : out.t) {
+        bool merged = false;
+        for (auto& y : terms) if (y.second == z.second) { y.first += z.first; merged = true; break; }
+        if (!merged) terms.push_back(z);
+    }
+    if ((int)terms.size() > pk::F64_LIN_MAX_TERMS) return;
+    F.lin = true; F.lin_a = out.a; F.lin_terms = terms; F.lin_k = out.k;
+}
+// S at the points of the installed set (device pass over F.d_pts), behind the coefficients in d_lin
+static int f64_lin_install(pinn_engine& E, F64Term& F, const Term& T0) {
+    F.lin_n = 0;
+    if (!F.lin || F.n <= 0 || !F.d_pts) return 0;
+    const int ns = F.nslots;
+    if (F.lin_cap < F.n) {
+        plat_sync(E.stream);
+        plat_free(F.d_lin);
+        F.d_lin = (double*)plat_malloc(sizeof(double) * ((size_t)ns + (size_t)F.n));
+        F.lin_cap = F.d_lin ? F.n : 0;
+        if (!F.d_lin) return fail("device allocation failed (float64 affine residual)");
+    }
+    if (ns > 0 && plat_h2d(F.d_lin, F.lin_a.data(), sizeof(double) * ns, E.stream)) return fail("H2D copy failed (float64 affine residual)");
+    pk::F64LinSrcArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.pts = F.d_pts; a.N = (int)F.n; a.dt = T0.d; a.np = E.np; a.nslots = ns; a.nops = F.nops;
+    for (int j = 0; j < pk::MAX_PARAMS; ++j) a.pdef[j] = j < (int)E.p_defaults.size() ? (double)E.p_defaults[j] : 0.0;
+    a.prog = F.d_prog; a.imm = F.d_imm;
+    a.nterms = (int)F.lin_terms.size();
+    for (int j = 0; j < a.nterms; ++j) { a.coef[j] = F.lin_terms[j].first; a.row[j] = F.lin_terms[j].second; }
+    a.k = F.lin_k;
+    a.out = F.d_lin + ns;
+    pk::launch_f64_lin_src(a, E.stream);
+    if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());      // (lin_a is a host vector; installs are rare)
+    F.lin_n = F.n;
+    return 0;
+}
+static const double* f64_lin_ptr(const F64Term& F) { return (F.lin && F.lin_n == F.n && F.n > 0) ? F.d_lin : nullptr; }
+
 // feature rows of an embedded term, in double: row d_user + k = sin / cos (omega_k x coordinate src_k) of every point of the [n][T.d] host image
 static void f64_embed_host(const Term& T, std::vector<double>& pts, int64_t n) {
     for (int64_t i = 0; i < n; ++i)
@@ -169,7 +274,7 @@ static int f64_convert_points(pinn_engine& E, F64Term& F, const Term& T) {
     if (plat_h2d(F.d_pts, hd.data(), sizeof(double) * hd.size(), E.stream) || plat_sync(E.stream)) return fail("H2D copy of points failed");
     F.n = n;
     F.exact_pts = false;
-    return 0;
+    return f64_lin_install(E, F, T);
 }
 
 // the term's DATA rows in double: `src` given in double (pinn_set_point_data_f64), or the conversion of the float rows as installed
@@ -247,6 +352,7 @@ int f64_enable(pinn_engine& E) {
             plat_h2d(F.d_imm, imm.data(), sizeof(double) * imm.size(), E.stream);
             if (plat_sync(E.stream)) return fail(std::string("device error: ") + plat_last_error());
         }
+        f64_affine(E, T, F);
         if (f64_convert_points(E, F, E.terms[t])) return 1;
         if (f64_install_data(E, F, E.terms[t], nullptr)) return 1;
     }
@@ -292,7 +398,7 @@ int f64_set_points(pinn_engine& E, int term, const double* pts, int64_t n) {
     }
     F.n = n;
     F.exact_pts = true;
-    return 0;
+    return f64_lin_install(E, F, T);
 }
 
 // pinn_set_point_data while the mode is on: the double rows follow (data == nullptr: converted from the float rows just installed)
@@ -314,6 +420,7 @@ static int f64_build(pinn_engine& E, const F64Term& F, int dt, const std::map<in
     pk::F64Args& a = L.a;
     std::memset(&a, 0, sizeof a);
     a.data = F.ndata > 0 ? F.d_data : nullptr;
+    a.lin = f64_lin_ptr(F);
     a.pts = F.d_pts;
     a.N = (int)F.n; a.dt = dt;
     a.nnets = (int)F.nets.size();
@@ -644,7 +751,7 @@ static int f64_stencil_term(pinn_engine& E, int t, const double* theta, double* 
 static void f64_launch_tile(const pk::F64MKernel* km, pk::F64Args& a, plat_stream st) {
     if (a.nsub == 0) {
         pk::F64Sub& u = a.sub[0];
-        u.pts = a.pts; u.pw = a.pw; u.data = a.data; u.prog = a.prog; u.imm = a.imm; u.scale = a.scale;
+        u.pts = a.pts; u.pw = a.pw; u.data = a.data; u.prog = a.prog; u.imm = a.imm; u.lin = a.lin; u.scale = a.scale;
         u.N = a.N; u.nops = a.nops; u.out_row = a.out_row; u.nslots = a.nslots;
         for (int q = 0; q < pk::F64_MAX_SLOTS; ++q) { u.slot_net[q] = (unsigned char)a.slot_net[q]; u.slot_chan[q] = (unsigned char)a.slot_chan[q]; }
     }
@@ -794,7 +901,7 @@ static int f64_eval_device(pinn_engine& E, const double* theta, double* grad, do
                 a.sub_tile0[q] = tiles;
                 tiles += (int)((F.n + tp - 1) / tp);
                 u.pts = F.d_pts; u.pw = (T.pw_n == T.n && T.pw_n > 0) ? T.d_pw : nullptr; u.data = F.ndata > 0 ? F.d_data : nullptr;
-                u.prog = F.d_prog; u.imm = F.d_imm;
+                u.prog = F.d_prog; u.imm = F.d_imm; u.lin = f64_lin_ptr(F);
                 u.scale = 2.0 * (term_w ? term_w[t] : 1.0) / (double)T.n_norm;
                 u.N = (int)F.n; u.nops = F.nops; u.out_row = F.out_row; u.nslots = F.nslots;
                 for (int sl = 0; sl < F.nslots; ++sl) {          // (slot_net: position of the slot's network in the launch's — the union's — list)
@@ -1051,6 +1158,7 @@ int f64_points_from_device(pinn_engine& E, int term) {
     }
     F.n = T.n;
     F.exact_pts = false;
+    F.lin_n = 0;                                         // (a redrawn set: the affine fast path's per-point part is not recomputed inside the loop — the tape runs)
     F.data_n = 0;                                        // (per-point data belong to the previous set: a sampled term with DATA channels fails its next evaluation with the message — ADVICE r05)
     return 0;
 }
@@ -1183,6 +1291,12 @@ std::string f64_describe(const pinn_engine& E) {
 }
 
 int f64_merged(const pinn_engine& E) { return E.f64 ? ((const F64State*)E.f64)->merged_launches : 0; }
+int f64_affine_terms(const pinn_engine& E) {
+    if (!E.f64) return 0;
+    int n = 0;
+    for (auto& F : ((const F64State*)E.f64)->terms) n += f64_lin_ptr(F) != nullptr && F.km != nullptr;
+    return n;
+}
 const char* f64_path(const pinn_engine& E) {
     if (!E.f64) return "off";
     const int p = ((const F64State*)E.f64)->path;

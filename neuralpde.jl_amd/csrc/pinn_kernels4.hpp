@@ -53,6 +53,7 @@ constexpr int F64_MAX_SUB = 6;
 struct F64Sub {
     const double* pts; const float* pw; const double* data;
     const rp::Instr* prog; const double* imm;
+    const double* lin;                  // affine residual (tile kernel fast path): [nslots coefficients a_s | N values of the coordinate-only part]; nullptr: run the tape
     double scale;
     int N, nops, out_row, nslots;
     unsigned char slot_net[F64_MAX_SLOTS], slot_chan[F64_MAX_SLOTS];
@@ -62,6 +63,7 @@ struct F64Args {
     const double* pts;                  // [N][dt] point-major
     const float* pw;                    // per-point factors sqrt(N w_i) of a quadrature-weighted term, nullable
     const double* data;                 // [ndata][N] user-supplied per-point channels of the term (OP_DATA: observations of a data-misfit term), nullable
+    const double* lin;                  // matrix-pipe tile kernel: the term's affine form (F64Sub::lin), nullable
     int N, p0, npts;                    // points of the term; first point and point count of this launch (one chunk)
     int dt;                             // coordinates per point of the term
     int nnets;                          // networks the equation references (all with the same number of inputs: one jet set serves them)

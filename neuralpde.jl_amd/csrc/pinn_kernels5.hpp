@@ -335,48 +335,64 @@ DEV void f64m_tile(int tile, const F64Args& a) {
         PINN_UNROLL for (int pg = 0; pg < PG; ++pg) {
             const int p = pbase + 16 * pg + j, pc = p < T_npts ? p : T_npts - 1, gp = T_p0 + pc;
             const bool live = p < T_npts, wr = live && q == 0;
-            double v[F64_MAX_ROWS];
-            for (int i = 0; i < a.dt; ++i) v[i] = T.pts[(size_t)gp * a.dt + i];
-            for (int k = 0; k < a.np; ++k) v[a.dt + k] = k < a.ne ? a.theta[a.p_off + k] : a.pdef[k];
-            for (int s = 0; s < T.nslots; ++s) {
-                double uu = 0.0;
-                for (int ni = 0; ni < a.nnets; ++ni)
-                    PINN_UNROLL for (int c = 0; c < C; ++c) if (T.slot_net[s] == ni && T.slot_chan[s] == c) uu = U(l, ni * NCG + pg * C + c);
-                v[a.dt + a.np + s] = uu;
+            // AFFINE residuals (r06; F64Sub::lin, f64.cpp: f64_affine): r = S(point) + sum_s a_s u_s with constant a_s and a coordinate-only part S that the
+            // host evaluated once per point set — no interpreter, no private v[] / g[] arrays (their scratch-memory round trips are a third of a small
+            // problem's tile latency); everything else runs the tape
+            const double* LIN = T.lin;
+            double v[F64_MAX_ROWS], g[F64_MAX_ROWS];
+            double r;
+            if (LIN) {
+                r = LIN[T.nslots + gp];
+                for (int s = 0; s < T.nslots; ++s) {
+                    double uu = 0.0;
+                    for (int ni = 0; ni < a.nnets; ++ni)
+                        PINN_UNROLL for (int c = 0; c < C; ++c) if (T.slot_net[s] == ni && T.slot_chan[s] == c) uu = U(l, ni * NCG + pg * C + c);
+                    r = vfma(LIN[s], uu, r);
+                }
+            } else {
+                for (int i = 0; i < a.dt; ++i) v[i] = T.pts[(size_t)gp * a.dt + i];
+                for (int k = 0; k < a.np; ++k) v[a.dt + k] = k < a.ne ? a.theta[a.p_off + k] : a.pdef[k];
+                for (int s = 0; s < T.nslots; ++s) {
+                    double uu = 0.0;
+                    for (int ni = 0; ni < a.nnets; ++ni)
+                        PINN_UNROLL for (int c = 0; c < C; ++c) if (T.slot_net[s] == ni && T.slot_chan[s] == c) uu = U(l, ni * NCG + pg * C + c);
+                    v[a.dt + a.np + s] = uu;
+                }
+                for (int o = 0; o < T.nops; ++o) {
+                    const rp::Instr ins = T.prog[o];
+                    const double va = rp::is_nullary(ins.code) ? 0.0 : v[ins.a];
+                    const double vb = rp::is_binary(ins.code) ? v[ins.b] : 0.0;
+                    v[R0 + o] = (ins.code == rp::OP_DATA) ? T.data[(size_t)(int)T.imm[o] * (size_t)T.N + (size_t)gp] : rp::apply<double, double>(ins.code, va, vb, T.imm[o]);
+                }
+                r = v[T.out_row];
             }
-            for (int o = 0; o < T.nops; ++o) {
-                const rp::Instr ins = T.prog[o];
-                const double va = rp::is_nullary(ins.code) ? 0.0 : v[ins.a];
-                const double vb = rp::is_binary(ins.code) ? v[ins.b] : 0.0;
-                v[R0 + o] = (ins.code == rp::OP_DATA) ? T.data[(size_t)(int)T.imm[o] * (size_t)T.N + (size_t)gp] : rp::apply<double, double>(ins.code, va, vb, T.imm[o]);
-            }
-            const double r = v[T.out_row];
             if (a.mode == 2) { if (wr) a.resid[gp] = r; continue; }
             const double sw = T.pw ? (double)T.pw[gp] : 1.0;
             const double rs = r * sw;
             if (wr) TS(l, 0) += rs * rs;
             if (a.mode == 1) continue;
-            double g[F64_MAX_ROWS];
-            for (int o = 0; o < R0 + T.nops; ++o) g[o] = 0.0;
-            g[T.out_row] = 1.0;
-            for (int o = T.nops - 1; o >= 0; --o) {
-                const rp::Instr ins = T.prog[o];
-                if (rp::is_nullary(ins.code)) continue;
-                const double vb = rp::is_binary(ins.code) ? v[ins.b] : 0.0;
-                double da, db;
-                rp::adjoint<double, double>(ins.code, v[ins.a], vb, v[R0 + o], T.imm[o], g[R0 + o], da, db);
-                g[ins.a] += da;
-                if (rp::is_binary(ins.code)) g[ins.b] += db;
+            if (!LIN) {
+                for (int o = 0; o < R0 + T.nops; ++o) g[o] = 0.0;
+                g[T.out_row] = 1.0;
+                for (int o = T.nops - 1; o >= 0; --o) {
+                    const rp::Instr ins = T.prog[o];
+                    if (rp::is_nullary(ins.code)) continue;
+                    const double vb = rp::is_binary(ins.code) ? v[ins.b] : 0.0;
+                    double da, db;
+                    rp::adjoint<double, double>(ins.code, v[ins.a], vb, v[R0 + o], T.imm[o], g[R0 + o], da, db);
+                    g[ins.a] += da;
+                    if (rp::is_binary(ins.code)) g[ins.b] += db;
+                }
             }
             const double rbar = live ? rs * T.scale * sw : 0.0;
-            PINN_UNROLL for (int k = 0; k < MAX_PARAMS; ++k) if (wr && k < a.ne) TS(l, 1 + k) += rbar * g[a.dt + k];
+            PINN_UNROLL for (int k = 0; k < MAX_PARAMS; ++k) if (wr && k < a.ne && !LIN) TS(l, 1 + k) += rbar * g[a.dt + k];      // (an affine residual reads no estimated parameter)
             // the seeds of every network's output jets replace its outputs in U
             for (int ni = 0; ni < a.nnets; ++ni) {
                 double ub[C];
                 PINN_UNROLL for (int c = 0; c < C; ++c) ub[c] = 0.0;
                 for (int s = 0; s < T.nslots; ++s) {
                     if (T.slot_net[s] != ni) continue;
-                    const double gs = rbar * g[a.dt + a.np + s];
+                    const double gs = rbar * (LIN ? LIN[s] : g[a.dt + a.np + s]);
                     PINN_UNROLL for (int c = 0; c < C; ++c) if (T.slot_chan[s] == c) ub[c] += gs;
                 }
                 PINN_UNROLL for (int c = 0; c < C; ++c) U(l, ni * NCG + pg * C + c) = ub[c];
@@ -758,6 +774,33 @@ template <int HT> void launch_f64m_dwt(const F64Args& a, plat_stream st) {
 
 // ---- float64 optimiser loop (f64.cpp: f64_adam_steps): points redrawn by the fp32 samplers -> double, Adam in double, the step's total loss ----
 DEV void f64_cvt_elem(int i, const float* src, double* dst) { dst[i] = (double)src[i]; }
+// the coordinate-only part S of an affine residual (F64Sub::lin), once per point set: the term's tape run at point p with the slots at zero,
+// S = k + sum_j coef_j * row_j (rows that depend on coordinates, constants and default parameters only — f64.cpp: f64_affine)
+constexpr int F64_LIN_MAX_TERMS = 8;
+struct F64LinSrcArgs {
+    const double* pts; int N, dt, np, nslots, nops;
+    double pdef[MAX_PARAMS];
+    const rp::Instr* prog; const double* imm;
+    int nterms, row[F64_LIN_MAX_TERMS];
+    double coef[F64_LIN_MAX_TERMS], k;
+    double* out;                         // [N]
+};
+DEV void f64_lin_src_point(int p, const F64LinSrcArgs& a) {
+    double v[F64_MAX_ROWS];
+    for (int i = 0; i < a.dt; ++i) v[i] = a.pts[(size_t)p * a.dt + i];
+    for (int k = 0; k < a.np; ++k) v[a.dt + k] = a.pdef[k];
+    for (int s = 0; s < a.nslots; ++s) v[a.dt + a.np + s] = 0.0;
+    const int R0 = a.dt + a.np + a.nslots;
+    for (int o = 0; o < a.nops; ++o) {
+        const rp::Instr ins = a.prog[o];
+        const double va = rp::is_nullary(ins.code) ? 0.0 : v[ins.a];
+        const double vb = rp::is_binary(ins.code) ? v[ins.b] : 0.0;
+        v[R0 + o] = (ins.code == rp::OP_DATA) ? 0.0 : rp::apply<double, double>(ins.code, va, vb, a.imm[o]);
+    }
+    double s = a.k;
+    for (int j = 0; j < a.nterms; ++j) s = vfma(a.coef[j], v[a.row[j]], s);
+    a.out[p] = s;
+}
 // redrawn set of a term behind a periodic input embedding (f64.cpp): the float coordinates widened, feature row du + k = sin / cos (omega_k x_src_k) in double
 struct F64EmbedArgs { double* pts; const float* upts; int n, d, du, ncols; int src[4], is_cos[4]; double omega[4]; };      // upts: the drawn coordinates [n][du]
 HD void f64_embed_point(int p, const F64EmbedArgs& a) {
@@ -776,6 +819,7 @@ DEV void f64_adam_elem(int i, double* theta, double* m, double* v, const double*
 #ifdef PINN_EMU
 inline void launch_f64_cvt(const float* src, double* dst, int64_t n, plat_stream) { for (int64_t i = 0; i < n; ++i) dst[i] = (double)src[i]; }
 inline void launch_f64_embed(const F64EmbedArgs& a, plat_stream) { for (int p = 0; p < a.n; ++p) f64_embed_point(p, a); }
+inline void launch_f64_lin_src(const F64LinSrcArgs& a, plat_stream) { for (int p = 0; p < a.N; ++p) f64_lin_src_point(p, a); }
 inline void launch_f64_adam(double* theta, double* m, double* v, const double* g, int P, double lr, double b1, double b2, double eps, double c1, double c2, plat_stream) {
     for (int i = 0; i < P; ++i) f64_adam_elem(i, theta, m, v, g, lr, b1, b2, eps, c1, c2);
 }
@@ -807,6 +851,11 @@ template <int UNUSED> __global__ void __launch_bounds__(256) k_f64_embed(const F
     const int p = (int)(blockIdx.x * 256 + threadIdx.x);
     if (p < a.n) f64_embed_point(p, a);
 }
+template <int UNUSED> __global__ void __launch_bounds__(256) k_f64_lin_src(const F64LinSrcArgs a) {
+    const int p = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (p < a.N) f64_lin_src_point(p, a);
+}
+inline void launch_f64_lin_src(const F64LinSrcArgs& a, plat_stream st) { hipLaunchKernelGGL((k_f64_lin_src<0>), dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, st, a); }
 inline void launch_f64_embed(const F64EmbedArgs& a, plat_stream st) { hipLaunchKernelGGL((k_f64_embed<0>), dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, st, a); }
 template <int UNUSED> __global__ void __launch_bounds__(256) k_f64_adam_total(double* theta, double* m, double* v, const double* g, int P, double lr, double b1, double b2, double eps, double c1, double c2,
                                                                               double* hist, int step, const double* sumsq, const double* w_over_n, int K) {

@@ -953,3 +953,54 @@ def test_f64_merged_launches_of_small_problems(npde, use_emu):
                                                               init_params=tp.theta_for(chain, 3)))
     rep.engine.loss_grad_f64(np.asarray(rep.flat_init_params, dtype=np.float64))
     assert int(rep.engine.get_option("f64_merged")) == 1        # the four boundary terms together; the 9,000-point interior term on its own
+
+
+def test_f64_affine_residual_fast_path(npde, use_emu):
+    """r06: residuals that are affine in the trial functions with constant coefficients (boundary conditions, Poisson / heat with forcing terms) skip the
+    tape interpreter in the matrix-pipe tile kernel — r = S(point) + sum a_s u_s, S evaluated once per point set on the device (csrc/f64.cpp:
+    f64_affine).  Same numbers as the tape (PINN_F64_NO_LIN=1) to rounding, = the oracle; nonlinear terms, estimated parameters and redrawn sets
+    keep the interpreter."""
+    import os
+    from neuralpde_jl_amd import workloads
+
+    def run(make, expect):
+        res = []
+        for lin in (True, False):
+            if not lin:
+                os.environ["PINN_F64_NO_LIN"] = "1"
+            try:
+                rep, w = make()
+                eng = rep.engine
+                th = np.asarray(rep.flat_init_params, dtype=np.float64) + 1e-9
+                l, g = eng.loss_grad_f64(th, w)
+                n_aff = int(eng.get_option("f64_affine"))
+                r0 = eng.residual_f64(0, th, rep.pde_train_sets[0].shape[1])
+            finally:
+                os.environ.pop("PINN_F64_NO_LIN", None)
+            assert n_aff == (expect if lin else 0), (lin, n_aff)
+            res.append((l, g, r0))
+        np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-13)
+        assert np.linalg.norm(res[0][1] - res[1][1]) / np.linalg.norm(res[1][1]) < 1e-13
+        np.testing.assert_allclose(res[0][2], res[1][2], rtol=0, atol=1e-13 * max(1.0, np.abs(res[1][2]).max()))
+        return rep, th, w, res[0]
+
+    def poisson():
+        sysm, chain = tp.poisson2d(npde, "tanh", width=16, hidden=2)
+        return npde.symbolic_discretize(sysm, npde.PhysicsInformedNN(chain, npde.GridTraining(0.1), init_params=tp.theta_for(chain, 5))), [1.0, 2.0, 0.5, 1.5, 3.0]
+    rep, th, w, (l, g, _) = run(poisson, 5)                      # -sin(pi x) sin(pi y) forcing: coordinate-only; all five terms affine
+    sysm, chain = tp.poisson2d(npde, "tanh", width=16, hidden=2)
+    ref = po.loss_and_grad(helpers.oracle_problem(npde, sysm, [chain]), th, rep.pde_train_sets + rep.bcs_train_sets, weights=w, mode="exact")
+    le, g2, gi = helpers.rel_errors(l, g, ref)
+    assert le.max() < EXACT and g2 < EXACT and gi < EXACT, (le, g2, gi)
+
+    def burgers():
+        wl = workloads.cfg3_burgers(points=200, bcs_points=40)
+        return npde.symbolic_discretize(wl.pde_system, wl.discretization(precision="f64")), None
+    rep, th, w, (l, g, _) = run(burgers, 3)                      # u_t + u u_x - nu u_xx is nonlinear: tape; the three initial / boundary terms: affine
+    # a redrawn set falls back to the tape (the per-point part is not recomputed inside the loop)
+    rep, _ = poisson()
+    eng = rep.engine
+    assert int(eng.get_option("f64_affine")) == 5
+    eng.set_sampler(0, [0.0, 0.0], [1.0, 1.0], 64, seed=3, kind=1)
+    eng.adam_f64(np.asarray(rep.flat_init_params, dtype=np.float64), 2, 1e-3)
+    assert int(eng.get_option("f64_affine")) == 4
