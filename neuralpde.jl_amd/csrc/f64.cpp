@@ -521,6 +521,22 @@ static int f64_buffers(pinn_engine& E, F64State& S, F64Launch& L, int64_t n, boo
     }
 }
 
+// Small launches of the register-resident matrix-pipe kernels: SHORT blocks for the dW kernel.  One 512-point block = one workgroup per layer, whose four
+// waves walk the block's 16-point groups x channels one dependent load + MFMA step after the other: 15 us for 176 points x 5 channels.  With 64-point
+// blocks the same steps spread over many workgroups (the slab gets one row per block, the reduction adds a few more rows).  Returns the block count.
+constexpr int F64_SMALL_BLOCK = 64, F64_SMALL_MAX_POINTS = 4096;
+static int f64_short_blocks(pinn_engine& E, F64State& S, F64Launch& L) {
+    pk::F64Args& a = L.a;
+    a.block_pts = 0;
+    if (!L.mfma || L.sliced || a.npts > F64_SMALL_MAX_POINTS || a.tile_pts <= 0 || F64_SMALL_BLOCK % a.tile_pts != 0 || std::getenv("PINN_F64_NO_SHORT_BLOCKS"))
+        return (a.npts + pk::F64_BLOCK - 1) / pk::F64_BLOCK;
+    const int nb = (a.npts + F64_SMALL_BLOCK - 1) / F64_SMALL_BLOCK;
+    if (!grow(S.d_slab, S.slab_cap, (size_t)nb * (size_t)a.nent, E.stream)) return (a.npts + pk::F64_BLOCK - 1) / pk::F64_BLOCK;
+    a.slab = S.d_slab;
+    a.block_pts = F64_SMALL_BLOCK;
+    return nb;
+}
+
 // ---- the reference-semantics ("stencil") validation mode ----
 // get_eps (src/symbolic_utilities.jl:98-103): eps(Float64)^(1 / (2 + order)), the TOTAL order of the derivative on every axis (:185)
 static double stencil_eps(int order) { return std::pow(2.220446049250313e-16, 1.0 / (2.0 + (double)order)); }
@@ -921,11 +937,12 @@ static int f64_eval_device(pinn_engine& E, const double* theta, double* grad, do
             if (chunk < a.npts) continue;                // (does not fit one launch: the members go one by one below)
             S.path |= 2;
             ++S.merged_launches;
+            const int nblocks = f64_short_blocks(E, S, L);
             f64_launch_tile(G.km, a, E.stream);
             G.km->launch_dwt(a, E.stream);
             pk::F64ReduceArgs r;
             std::memset(&r, 0, sizeof r);
-            r.slab = S.d_slab; r.nblocks = (a.npts + pk::F64_BLOCK - 1) / pk::F64_BLOCK; r.nent = a.nent;
+            r.slab = S.d_slab; r.nblocks = nblocks; r.nent = a.nent;
             r.grad = grad; r.ent_p = a.ent_p; r.p_off = E.p_theta_off; r.nnets = a.nnets;
             for (int ni = 0; ni < a.nnets; ++ni) { r.ent0[ni] = a.net[ni].ent0; r.theta0[ni] = a.net[ni].theta0; }
             r.sumsq = sumsq; r.nsq = m;
@@ -961,6 +978,7 @@ static int f64_eval_device(pinn_engine& E, const double* theta, double* grad, do
         for (int64_t p0 = 0; p0 < F.n; p0 += chunk) {
             a.p0 = (int)p0;
             a.npts = (int)std::min<int64_t>(chunk, F.n - p0);
+            const int nblocks = f64_short_blocks(E, S, L);
             if (L.mfma) f64_launch_tile(F.km, a, E.stream);
             else F.k->launch_point(a, L.sin_act, E.stream);
             if (!L.mfma) pk::launch_f64_dw(a, E.stream);         // (matrix-pipe path: those entries come out of the tile kernel, summed in the dW launch)
@@ -968,7 +986,7 @@ static int f64_eval_device(pinn_engine& E, const double* theta, double* grad, do
             else pk::launch_f64_dwt(a, E.stream);
             pk::F64ReduceArgs r;
             std::memset(&r, 0, sizeof r);
-            r.slab = S.d_slab; r.nblocks = (a.npts + pk::F64_BLOCK - 1) / pk::F64_BLOCK; r.nent = a.nent;
+            r.slab = S.d_slab; r.nblocks = nblocks; r.nent = a.nent;
             r.grad = grad; r.ent_p = a.ent_p; r.p_off = E.p_theta_off; r.nnets = a.nnets;
             for (int ni = 0; ni < a.nnets; ++ni) { r.ent0[ni] = a.net[ni].ent0; r.theta0[ni] = a.net[ni].theta0; }
             r.sumsq = sumsq + t; r.nsq = 1; r.sq_off[0] = 0; r.with_grad = grad ? 1 : 0;

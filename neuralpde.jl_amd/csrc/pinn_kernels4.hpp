@@ -101,10 +101,13 @@ struct F64Args {
     // the tile kernel's per-term view (F64Sub above): nsub == 0: a plain launch, sub[0] repeats this struct's own fields; nsub >= 1: a merged launch —
     // sub-term s owns tiles [sub_tile0[s], sub_tile0[s + 1]), its points are 0 .. sub[s].N - 1 of its own set, and the slab ends in nsub sums of squares
     int nsub;
+    int block_pts;                      // matrix-pipe dW kernel: points per block (= slab row); 0: F64_BLOCK.  Small launches use short blocks so that the
+                                        // few hundred points of a small problem spread over many workgroups instead of one (f64.cpp)
     int sub_tile0[F64_MAX_SUB + 1];
     F64Sub sub[F64_MAX_SUB];
 };
 static_assert(sizeof(F64Args) <= 4096, "F64Args is a by-value kernel argument (4 KB)");
+HD int f64m_block(const F64Args& a) { return a.block_pts > 0 ? a.block_pts : F64_BLOCK; }
 // number of sum-of-squares entries at the end of a block's slab row
 HD int f64_nsq(const F64Args& a) { return a.nsub > 0 ? a.nsub : 1; }
 

@@ -572,7 +572,8 @@ template <int HT>
 DEV void f64m_dwt_wave(int ni, int lyr, int b, int w, const F64Args& a, F64mDwtAcc<HT>& R) {
     const F64Net& n = a.net[ni];
     const int n_out = n.sizes[lyr + 1], n_in = n.sizes[lyr], C = a.C;
-    const int lo = b * F64_BLOCK, hi = (lo + F64_BLOCK < a.npts) ? lo + F64_BLOCK : a.npts;
+    const int BP = f64m_block(a);
+    const int lo = b * BP, hi = (lo + BP < a.npts) ? lo + BP : a.npts;
     const double* S = a.scratch;
     PINN_LANES(l) {
         PINN_UNROLL for (int e = 0; e < HT * HT * 4; ++e) R.acc(l, e) = 0.0;
@@ -693,7 +694,7 @@ HD void f64m_tsum_entry(int e, int b, const F64Args& a) {
         }
     }
     if (ent < 0 || (grad_entry && a.mode != 0)) return;
-    const int tpb = F64_BLOCK / a.tile_pts, nt = (a.npts + a.tile_pts - 1) / a.tile_pts;
+    const int tpb = f64m_block(a) / a.tile_pts, nt = (a.npts + a.tile_pts - 1) / a.tile_pts;
     const int t0 = b * tpb, t1 = (t0 + tpb < nt) ? t0 + tpb : nt;
     if (!grad_entry && a.nsub > 0) {                              // merged launch: one sum of squares per sub-term (a tile belongs to exactly one)
         for (int s = 0; s < a.nsub; ++s) {
@@ -726,7 +727,7 @@ template <class J, int HT, int PG> void launch_f64m_tile(const F64Args& a, plat_
     for (int t = 0; t < nt; ++t) f64m_tile<J, HT, PG, ACT_TANH>(t, a);
 }
 template <int HT> void launch_f64m_dwt(const F64Args& a, plat_stream) {
-    const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK, nl = f64m_num_layers(a);
+    const int nb = (a.npts + f64m_block(a) - 1) / f64m_block(a), nl = f64m_num_layers(a);
     for (int b = 0; b < nb; ++b)
         for (int e = 0; e < a.ntp; ++e) f64m_tsum_entry(e, b, a);
     if (a.mode != 0) return;
@@ -767,7 +768,7 @@ template <class J, int HT, int PG> void launch_f64m_tile(const F64Args& a, plat_
     hipLaunchKernelGGL((k_f64m_tile<J, HT, PG>), dim3(nt), dim3(64), 0, st, a);
 }
 template <int HT> void launch_f64m_dwt(const F64Args& a, plat_stream st) {
-    const int nb = (a.npts + F64_BLOCK - 1) / F64_BLOCK, nl = f64m_num_layers(a);
+    const int nb = (a.npts + f64m_block(a) - 1) / f64m_block(a), nl = f64m_num_layers(a);
     hipLaunchKernelGGL((k_f64m_dwt<HT>), dim3(nl + 1, nb), dim3(64 * F64M_DWT_WAVES), 0, st, a);
 }
 #endif
