@@ -522,18 +522,24 @@ static int f64_buffers(pinn_engine& E, F64State& S, F64Launch& L, int64_t n, boo
 }
 
 // Small launches of the register-resident matrix-pipe kernels: SHORT blocks for the dW kernel.  One 512-point block = one workgroup per layer, whose four
-// waves walk the block's 16-point groups x channels one dependent load + MFMA step after the other: 15 us for 176 points x 5 channels.  With 64-point
+// waves walk the block's 16-point groups x channels one dependent load + MFMA step after the other: 15 us for 176 points x 5 channels.  With short
 // blocks the same steps spread over many workgroups (the slab gets one row per block, the reduction adds a few more rows).  Returns the block count.
-constexpr int F64_SMALL_BLOCK = 64, F64_SMALL_MAX_POINTS = 4096;
+constexpr int F64_SMALL_BLOCK = 64;
 static int f64_short_blocks(pinn_engine& E, F64State& S, F64Launch& L) {
     pk::F64Args& a = L.a;
     a.block_pts = 0;
-    if (!L.mfma || L.sliced || a.npts > F64_SMALL_MAX_POINTS || a.tile_pts <= 0 || F64_SMALL_BLOCK % a.tile_pts != 0 || std::getenv("PINN_F64_NO_SHORT_BLOCKS"))
-        return (a.npts + pk::F64_BLOCK - 1) / pk::F64_BLOCK;
-    const int nb = (a.npts + F64_SMALL_BLOCK - 1) / F64_SMALL_BLOCK;
-    if (!grow(S.d_slab, S.slab_cap, (size_t)nb * (size_t)a.nent, E.stream)) return (a.npts + pk::F64_BLOCK - 1) / pk::F64_BLOCK;
+    const int full = (a.npts + pk::F64_BLOCK - 1) / pk::F64_BLOCK;
+    if (!L.mfma || L.sliced || a.tile_pts <= 0 || F64_SMALL_BLOCK % a.tile_pts != 0 || std::getenv("PINN_F64_NO_SHORT_BLOCKS")) return full;
+    // the shortest power-of-two block (>= 64 points) that still gives the launch ~512 workgroups: blocks x (hidden-to-hidden layers + 1)
+    int rows = 1;
+    for (int ni = 0; ni < a.nnets; ++ni) rows += std::max(0, a.net[ni].nl - 2);
+    int bp = pk::F64_BLOCK;
+    while (bp > F64_SMALL_BLOCK && (int64_t)((a.npts + bp - 1) / bp) * rows < 512) bp >>= 1;
+    if (bp == pk::F64_BLOCK) return full;
+    const int nb = (a.npts + bp - 1) / bp;
+    if (!grow(S.d_slab, S.slab_cap, (size_t)nb * (size_t)a.nent, E.stream)) return full;
     a.slab = S.d_slab;
-    a.block_pts = F64_SMALL_BLOCK;
+    a.block_pts = bp;
     return nb;
 }
 
