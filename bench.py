@@ -371,6 +371,19 @@ def bench_f64(args, eng, rep, sets, wl, npde=None, world=1, rank=0):
             "loss_terms": [float(x) for x in l1]}
 
 
+
+def emit(line):
+    """the ONE JSON line, as the LAST line of stdout: native libraries (RCCL prints a version banner through C stdio when a communicator is made) keep
+    their text in C buffers that would otherwise be flushed at exit, i.e. behind the JSON"""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -448,7 +461,7 @@ def main():
         assert not args.resident, "--precision f64: the evaluation line (the resident double loop is timed by tools/time_f64.py)"
         line = bench_f64(args, eng, rep, sets, wl, npde, world, rank)
         if rank == 0:
-            print(json.dumps(line))
+            emit(line)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -664,7 +677,7 @@ def main():
             line["roofline_kernels"] = per_kernel
         if world == 1 and not sharded and not args.no_cpu_baseline and args.workload == "cfg2":
             line["cpu_baseline"] = cpu_baseline(npde, wl, sets)
-        print(json.dumps(line))
+        emit(line)
     if world > 1:
         dist.destroy_process_group()
 
