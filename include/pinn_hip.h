@@ -302,7 +302,8 @@ int pinn_lbfgs(pinn_handle h, double* theta, int64_t p, int maxiters, int histor
  *   same results to rounding; pinn_get_option(h, "f64_merged") = the number of such sequences in the last evaluation, $PINN_F64_NO_MERGE=1
  *   switches them off (A/B, tests).  Terms whose residual is affine in the trial function(s) with constant coefficients (boundary conditions, linear
  *   PDEs with forcing terms) skip the tape interpreter in the tile kernel: the coordinate-only part is evaluated once per point set
- *   (pinn_get_option(h, "f64_affine") = the number of such terms; $PINN_F64_NO_LIN=1: off).
+ *   (pinn_get_option(h, "f64_affine") = the number of such terms; $PINN_F64_NO_LIN=1: off).  The weight-gradient kernel of a small launch works on
+ *   short point blocks (64 ... 256 instead of 512 points per workgroup row, chosen so that the launch has ~512 workgroups; $PINN_F64_NO_SHORT_BLOCKS=1: off).
  *   PRECISION POLICY of the glue (Julia: HIPStrategy / hip_discretize `precision = :auto`; Python mirror: PhysicsInformedNN(precision = "auto")):
  *   the reference's contract compute dtype = eltype(theta) (src/eltype_matching.jl:8-10) — Float64 parameters select "f64", Float32
  *   parameters "f32"; "f32" on Float64 parameters is the explicit fast opt-in.
