@@ -534,7 +534,8 @@ static int f64_short_blocks(pinn_engine& E, F64State& S, F64Launch& L) {
     int rows = 1;
     for (int ni = 0; ni < a.nnets; ++ni) rows += std::max(0, a.net[ni].nl - 2);
     int bp = pk::F64_BLOCK;
-    while (bp > F64_SMALL_BLOCK && (int64_t)((a.npts + bp - 1) / bp) * rows < 512) bp >>= 1;
+    static const int target = std::getenv("PINN_F64_DWT_WGS") ? std::max(1, std::atoi(std::getenv("PINN_F64_DWT_WGS"))) : 512;      // (A/B knob)
+    while (bp > F64_SMALL_BLOCK && (int64_t)((a.npts + bp - 1) / bp) * rows < target) bp >>= 1;
     if (bp == pk::F64_BLOCK) return full;
     const int nb = (a.npts + bp - 1) / bp;
     if (!grow(S.d_slab, S.slab_cap, (size_t)nb * (size_t)a.nent, E.stream)) return full;
