@@ -1,6 +1,6 @@
 """Probe for an intermittent slowdown seen in tools/time_f64.py (profiles/r06_f64_anomaly.txt): does a handle with multi-GB float64 scratch (the bench
 workload), created — and destroyed or kept — earlier in the process, slow the next handle's float64 evaluation down?  (Measured: no, 10 of 10 runs clean.)
-usage: python tools/r06/f64_alloc_anomaly.py keep|free     (keep: the first handle stays alive while the second is timed)"""
+usage: python tools/r06/f64_alloc_anomaly.py keep|free|lanes     (keep: the first handle stays alive while the second is timed; lanes: the first handle also runs the lane-per-point kernels)"""
 import gc, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -28,6 +28,11 @@ def timed(rep, th, n=8):
 mode = sys.argv[1] if len(sys.argv) > 1 else "free"
 first, th1 = make(workloads.cfg2_poisson2d(points=65536))
 t_first = timed(first, th1)
+if mode == "lanes":                                  # the lane-per-point leg of tools/time_f64.py on the first handle
+    os.environ["PINN_F64_NO_MFMA"] = "1"
+    for _ in range(4):
+        first.engine.loss_grad_f64(th1)
+    del os.environ["PINN_F64_NO_MFMA"]
 if mode == "free":
     first.engine.close()
     del first
